@@ -1,0 +1,375 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ by running the REAL reference.
+
+Runs ONLY in the build container: it imports ``phc.*`` from /root/reference
+(read-only) with the stand-ins in tests/golden/_standins/ for the three
+third-party packages this image lacks, feeds seeded inputs through the
+reference's own functions/modules, and stores inputs + outputs as .npz.
+The committed .npz files are data; no reference source travels.
+
+    python tests/golden/make_golden.py          # rewrites tests/golden/*.npz
+
+Every parameter is set explicitly from a seeded generator — never through
+``reset_parameters`` — because the reference leaves ``b[out/n]`` uninitialised
+(phc/hypercomplex/layers.py:276-278).
+"""
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REPO = os.path.dirname(os.path.dirname(HERE))
+REF = "/root/reference"
+if not os.path.isdir(REF):
+    sys.exit("make_golden.py needs the reference checkout at /root/reference (build container only)")
+sys.path.insert(0, os.path.join(HERE, "_standins"))
+sys.path.insert(0, REF)
+sys.path.insert(1, REPO)          # for phc_gnn_amd.synth only; `phc` resolves to the reference
+
+import numpy as np  # noqa: E402
+import torch  # noqa: E402
+
+import phc  # noqa: E402
+assert phc.__path__[0].startswith(REF), phc.__path__
+
+from phc.hypercomplex.kronecker import (kronecker_product, kronecker_product_single,  # noqa: E402
+                                        kronecker_product_einsum_batched)
+from phc.hypercomplex.layers import PHMLinear, matvec_product_new, phm_dropout  # noqa: E402
+from phc.hypercomplex.utils import get_multiplication_matrices  # noqa: E402
+from phc.hypercomplex.norm import PHMNorm  # noqa: E402
+from phc.hypercomplex.pooling import PHMGlobalSumPooling, PHMSoftAttentionPooling  # noqa: E402
+from phc.hypercomplex.downstream import PHMDownstreamNet  # noqa: E402
+from phc.hypercomplex.undirectional.messagepassing import PHMMessagePassing  # noqa: E402
+from phc.hypercomplex.undirectional.models import PHMSkipConnectAdd  # noqa: E402
+from phc.quaternion.qr import RealP  # noqa: E402
+from torch_geometric.data import Batch  # noqa: E402
+
+from phc_gnn_amd import synth  # noqa: E402
+
+torch.set_num_threads(4)
+
+
+def npy(t):
+    return t.detach().cpu().numpy()
+
+
+def save(name, **arrays):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **{k: (npy(v) if torch.is_tensor(v) else np.asarray(v)) for k, v in arrays.items()})
+    print(f"{name}.npz  {os.path.getsize(path) / 1024:.0f} KiB  ({len(arrays)} arrays)")
+
+
+def fill_module(module, gen):
+    """Deterministic, well-conditioned values for every parameter and buffer."""
+    for name, p in module.named_parameters():
+        leaf = name.rsplit(".", 1)[-1]
+        if leaf == "phm_rule":
+            n = p.shape[0]
+            base = torch.stack(get_multiplication_matrices(n, type="standard"), 0)
+            p.data = base + 0.05 * torch.randn(p.shape, generator=gen)
+        elif leaf == "W":
+            p.data = torch.randn(p.shape, generator=gen) / np.sqrt(p.shape[0] * p.shape[1])
+        elif leaf == "b":
+            p.data = 0.1 * torch.randn(p.shape, generator=gen)
+        elif leaf == "weight" and p.dim() == 1:            # batch-norm scale
+            p.data = 0.5 + torch.rand(p.shape, generator=gen)
+        elif leaf == "bias":
+            p.data = 0.1 * torch.randn(p.shape, generator=gen)
+        elif leaf == "beta":
+            p.data = torch.tensor(1.0 + 0.25 * float(torch.randn((), generator=gen)))
+        else:                                               # embeddings, nn.Linear weights
+            p.data = torch.randn(p.shape, generator=gen) / np.sqrt(max(p.shape[-1], 1))
+    for name, buf in module.named_buffers():
+        leaf = name.rsplit(".", 1)[-1]
+        if leaf == "running_mean":
+            buf.copy_(0.1 * torch.randn(buf.shape, generator=gen))
+        elif leaf == "running_var":
+            buf.copy_(0.5 + torch.rand(buf.shape, generator=gen))
+
+
+def state_arrays(module, prefix="sd::"):
+    return {prefix + k: v for k, v in module.state_dict().items()}
+
+
+# ---------------------------------------------------------------------------
+def g1_phm_linear():
+    """G1: matvec_product_new forward + autograd backward."""
+    gen = torch.Generator().manual_seed(101)
+    cases = [  # (n, in, out, N, bias)
+        (4, 128, 128, 721, True), (4, 128, 128, 1, True), (4, 128, 128, 7, False),
+        (2, 64, 32, 37, True), (3, 48, 96, 37, True), (5, 200, 200, 64, True),
+        (8, 256, 256, 130, True), (8, 64, 128, 7, True), (4, 128, 256, 33, True),
+        (4, 256, 256, 65, True), (1, 16, 24, 9, True), (4, 8, 4, 5, True),
+    ]
+    out = {"num_cases": len(cases)}
+    for ci, (n, fin, fout, N, bias) in enumerate(cases):
+        A = torch.randn(n, n, n, generator=gen).requires_grad_()
+        W = (torch.randn(n, fin // n, fout // n, generator=gen) / np.sqrt(fin)).requires_grad_()
+        b = (0.1 * torch.randn(fout, generator=gen)).requires_grad_() if bias else None
+        x = torch.randn(N, fin, generator=gen).requires_grad_()
+        y = matvec_product_new(W=W, x=x, bias=b, phm_rule=A)
+        dy = torch.randn(N, fout, generator=gen)
+        grads = torch.autograd.grad(y, [x, W, A] + ([b] if bias else []), dy)
+        d = dict(x=x, A=A, W=W, y=y, dy=dy, dx=grads[0], dW=grads[1], dA=grads[2])
+        if bias:
+            d.update(b=b, db=grads[3])
+        d["meta"] = np.array([n, fin, fout, N, int(bias)])
+        out.update({f"c{ci}::{k}": v for k, v in d.items()})
+    save("g1_phm_linear", **out)
+
+
+def g2_g3_g4_kronecker_rules():
+    """G2 H builder (incl. the shapes of test_kronecker_product.py:13-19), G3
+    standard rules, G4 quaternion known answer (test_realrepr_sumkronecker.py)."""
+    gen = torch.Generator().manual_seed(202)
+    out = {}
+    A = torch.randn(4, 4, 4, generator=gen)
+    B = torch.randn(4, 16, 8, generator=gen)
+    ke = kronecker_product_einsum_batched(A, B)
+    ks = torch.stack([kronecker_product_single(a, b) for a, b in zip(A, B)], 0)
+    kb = kronecker_product(A, B)
+    assert torch.allclose(ks, kb) and torch.allclose(ks, ke)      # the reference's own test
+    out.update({"k0::A": A, "k0::B": B, "k0::kron": ke, "k0::H": ke.sum(0)})
+    for ci, (n, kin, kout) in enumerate([(2, 5, 3), (3, 4, 4), (5, 8, 6), (8, 6, 4)], start=1):
+        A = torch.randn(n, n, n, generator=gen)
+        B = torch.randn(n, kin, kout, generator=gen)
+        ke = kronecker_product_einsum_batched(A, B)
+        out.update({f"k{ci}::A": A, f"k{ci}::B": B, f"k{ci}::kron": ke, f"k{ci}::H": ke.sum(0)})
+    out["num_kron"] = 5
+    for n in (1, 2, 3, 4, 5, 8):
+        out[f"rule::{n}"] = torch.stack(get_multiplication_matrices(n, type="standard"), 0)
+    Q = [torch.randn(16, 8, generator=gen) for _ in range(4)]
+    rule = torch.stack(get_multiplication_matrices(4, type="standard"), 0)
+    realp = RealP(*Q)
+    ksum = kronecker_product(rule, torch.stack(Q, 0)).sum(0)
+    assert torch.allclose(realp, ksum)                            # the reference's own test
+    out.update({"quat::Q": torch.stack(Q, 0), "quat::RealP": realp})
+    # corollary: PHMLinear(c_init=standard, n=4) has H == RealP(W_0..W_3)
+    lin = PHMLinear(32, 64, phm_dim=4, c_init="standard")
+    W = torch.randn(4, 8, 16, generator=gen)
+    H = kronecker_product_einsum_batched(lin.phm_rule.data, W).sum(0)
+    assert torch.allclose(H, RealP(W[0], W[1], W[2], W[3]))
+    out.update({"quat::W": W, "quat::H": H})
+    save("g2_kronecker_rules", **out)
+
+
+def _to_batch(gb):
+    return Batch(x=torch.from_numpy(gb.x), edge_index=torch.from_numpy(gb.edge_index),
+                 edge_attr=torch.from_numpy(gb.edge_attr), batch=torch.from_numpy(gb.batch),
+                 y=torch.from_numpy(gb.y), num_graphs=gb.num_graphs)
+
+
+def g5_convs():
+    """G5: PHMConv / PHMGINEConv (aggr add) forward + backward."""
+    gen = torch.Generator().manual_seed(505)
+    mol = synth.molecule_batch(6, seed=5, isolated_frac=0.1)
+    ei_mol = torch.from_numpy(mol.edge_index)
+    n_mol = mol.num_nodes
+    ei_rag = torch.from_numpy(synth.ragged_edges(96, seed=6, hub_degree=150))
+    cases = [  # (graph, n, h, mlp, same_dim, self_loops, msg_encoder, norm)
+        ("mol", 4, 64, False, True, True, "identity", None),
+        ("mol", 4, 64, False, False, True, "identity", None),
+        ("mol", 4, 64, False, True, False, "relu", None),
+        ("mol", 4, 64, True, True, True, "identity", "naive-batch-norm"),
+        ("mol", 4, 64, True, True, False, "relu", "naive-batch-norm"),
+        ("mol", 4, 64, True, True, True, "swish", None),
+        ("rag", 4, 32, False, True, True, "identity", None),
+        ("rag", 8, 64, True, True, True, "lrelu", "naive-batch-norm"),
+        ("rag", 5, 40, False, False, True, "elu", None),
+        ("mol", 2, 24, True, True, True, "identity", "naive-batch-norm"),
+    ]
+    out = {"num_cases": len(cases)}
+    for ci, (g, n, h, mlp, same_dim, loops, enc, norm) in enumerate(cases):
+        ei, N = (ei_mol, n_mol) if g == "mol" else (ei_rag, 96)
+        conv = PHMMessagePassing(h, h, phm_dim=n, phm_rule=None, learn_phm=True, bias=True,
+                                 add_self_loops=loops, norm=norm, activation="relu", w_init="phm",
+                                 c_init="standard", aggr="add", mlp=mlp, same_dim=same_dim, msg_encoder=enc)
+        fill_module(conv, gen)
+        conv.train()
+        sd_before = {k: v.clone() for k, v in conv.state_dict().items()}
+        x = torch.randn(N, h, generator=gen).requires_grad_()
+        ea = torch.randn(ei.shape[1], h, generator=gen).requires_grad_()
+        y = conv(x, ei, ea)
+        dy = torch.randn(N, h, generator=gen)
+        params = [p for p in conv.parameters()]
+        grads = torch.autograd.grad(y, [x, ea] + params, dy)
+        d = dict(edge_index=ei, x=x, edge_attr=ea, y=y, dy=dy, dx=grads[0], dea=grads[1])
+        d.update({"sd::" + k: v for k, v in sd_before.items()})
+        d.update({"sd_after::" + k: v for k, v in conv.state_dict().items() if "running" in k})
+        d.update({"grad::" + k: gv for (k, _), gv in zip(conv.named_parameters(), grads[2:])})
+        d["meta"] = np.array([n, h, int(mlp), int(same_dim), int(loops), int(norm is not None)])
+        d["msg_encoder"] = np.array(enc)
+        out.update({f"c{ci}::{k}": v for k, v in d.items()})
+    save("g5_convs", **out)
+
+
+def g5b_softmax():
+    """softmax aggregation variants (N2 row)."""
+    gen = torch.Generator().manual_seed(515)
+    ei = torch.from_numpy(synth.ragged_edges(64, seed=7, hub_degree=70))
+    out = {}
+    cases = [(4, 32, True, "identity"), (4, 32, False, "relu")]
+    for ci, (n, h, mlp, enc) in enumerate(cases):
+        conv = PHMMessagePassing(h, h, phm_dim=n, phm_rule=None, norm="naive-batch-norm" if mlp else None,
+                                 aggr="softmax", mlp=mlp, msg_encoder=enc, initial_beta=1.0, learn_beta=True)
+        fill_module(conv, gen)
+        conv.train()
+        sd_before = {k: v.clone() for k, v in conv.state_dict().items()}
+        x = torch.randn(64, h, generator=gen).requires_grad_()
+        ea = torch.randn(ei.shape[1], h, generator=gen).requires_grad_()
+        y = conv(x, ei, ea)
+        dy = torch.randn(64, h, generator=gen)
+        grads = torch.autograd.grad(y, [x, ea] + list(conv.parameters()), dy)
+        d = dict(edge_index=ei, x=x, edge_attr=ea, y=y, dy=dy, dx=grads[0], dea=grads[1])
+        d.update({"sd::" + k: v for k, v in sd_before.items()})
+        d.update({"grad::" + k: gv for (k, _), gv in zip(conv.named_parameters(), grads[2:])})
+        d["meta"] = np.array([n, h, int(mlp)])
+        d["msg_encoder"] = np.array(enc)
+        out.update({f"c{ci}::{k}": v for k, v in d.items()})
+    out["num_cases"] = len(cases)
+    save("g5b_softmax_convs", **out)
+
+
+def g6_norm():
+    gen = torch.Generator().manual_seed(606)
+    out = {}
+    for ci, (n, h, N) in enumerate([(4, 64, 50), (8, 64, 33), (3, 30, 17)]):
+        norm = PHMNorm(num_features=h, phm_dim=n, type="naive-batch-norm")
+        fill_module(norm, gen)
+        sd = {k: v.clone() for k, v in norm.state_dict().items()}
+        x = torch.randn(N, h, generator=gen).requires_grad_()
+        norm.train()
+        y = norm(x)
+        dy = torch.randn(N, h, generator=gen)
+        grads = torch.autograd.grad(y, [x] + list(norm.parameters()), dy)
+        sd_after = {k: v.clone() for k, v in norm.state_dict().items()}
+        norm.eval()
+        y_eval = norm(x)
+        d = dict(x=x, y_train=y, dy=dy, dx=grads[0], y_eval=y_eval, meta=np.array([n, h, N]))
+        d.update({"sd::" + k: v for k, v in sd.items()})
+        d.update({"sd_after::" + k: v for k, v in sd_after.items()})
+        d.update({"grad::" + k: gv for (k, _), gv in zip(norm.named_parameters(), grads[1:])})
+        out.update({f"c{ci}::{k}": v for k, v in d.items()})
+    out["num_cases"] = 3
+    save("g6_norm", **out)
+
+
+def g7_heads():
+    gen = torch.Generator().manual_seed(707)
+    mol = synth.molecule_batch(9, seed=9)
+    batch = torch.from_numpy(mol.batch)
+    N = mol.num_nodes
+    out = {"batch": batch}
+    n, h = 4, 64
+    x = torch.randn(N, h, generator=gen).requires_grad_()
+    pool = PHMSoftAttentionPooling(embed_dim=h, phm_dim=n, phm_rule=None)
+    fill_module(pool, gen)
+    y = pool(x, batch)
+    dy = torch.randn(y.shape, generator=gen)
+    grads = torch.autograd.grad(y, [x] + list(pool.parameters()), dy)
+    out.update({"pool::x": x, "pool::y": y, "pool::dy": dy, "pool::dx": grads[0]})
+    out.update({"pool::sd::" + k: v for k, v in pool.state_dict().items()})
+    out.update({"pool::grad::" + k: gv for (k, _), gv in zip(pool.named_parameters(), grads[1:])})
+    out["sumpool::y"] = PHMGlobalSumPooling(phm_dim=n)(x.detach(), batch)
+    dn = PHMDownstreamNet(in_features=h, phm_dim=n, phm_rule=None, hidden_layers=[32, 16], out_features=3,
+                          activation="relu", bias=True, norm="naive-batch-norm", w_init="phm",
+                          c_init="standard", dropout=[0.0, 0.0])
+    fill_module(dn, gen)
+    dn.train()
+    sd = {k: v.clone() for k, v in dn.state_dict().items()}
+    xin = torch.randn(9, h, generator=gen).requires_grad_()
+    yd = dn(xin)
+    dyd = torch.randn(yd.shape, generator=gen)
+    grads = torch.autograd.grad(yd, [xin] + list(dn.parameters()), dyd)
+    out.update({"dn::x": xin, "dn::y": yd, "dn::dy": dyd, "dn::dx": grads[0]})
+    out.update({"dn::sd::" + k: v for k, v in sd.items()})
+    out.update({"dn::grad::" + k: gv for (k, _), gv in zip(dn.named_parameters(), grads[1:])})
+    save("g7_heads", **out)
+
+
+def _model_fixture(name, gb, seed, **kw):
+    gen = torch.Generator().manual_seed(seed)
+    model = PHMSkipConnectAdd(**kw)
+    fill_module(model, gen)
+    data = _to_batch(gb)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model.eval()
+    with torch.no_grad():
+        logits_eval = model(data)
+    model.train()
+    logits = model(data)
+    y = data.y.to(torch.float)
+    if kw.get("_regression"):
+        loss = torch.nn.functional.l1_loss(logits, y)
+    else:
+        mask = ~torch.isnan(y)
+        loss = torch.nn.functional.binary_cross_entropy_with_logits(logits[mask], y[mask])
+    loss.backward()
+    out = dict(x=data.x, edge_index=data.edge_index, edge_attr=data.edge_attr, batch=data.batch, y=data.y,
+               logits_eval=logits_eval, logits_train=logits, loss=loss)
+    out.update({"sd::" + k: v for k, v in sd.items()})
+    out.update({"sd_after::" + k: v for k, v in model.state_dict().items() if "running" in k})
+    out.update({"grad::" + k: p.grad for k, p in model.named_parameters() if p.grad is not None})
+    out["num_params"] = model.get_number_of_params_()
+    save(name, **out)
+
+
+def g8_models():
+    """G8: full PHMSkipConnectAdd — BASELINE config 1 (B=32) and two small variants."""
+    common = dict(norm_mp="naive-batch-norm", norm_dn="naive-batch-norm", msg_aggr="sum",
+                  pooling="softattention", activation="relu", real_trafo="linear", w_init="phm",
+                  c_init="standard", learn_phm=True)
+    _model_fixture("g8_model_cfg1", synth.molecule_batch(32, seed=0), 808,
+                   phm_dim=4, atom_encoded_dim=128, mp_layers=[128] * 4, dropout_mpnn=[0.0] * 4, mlp=True,
+                   downstream_layers=[128, 32], dropout_dn=[0.0, 0.0], target_dim=1, sc_type="first", **common)
+    _model_fixture("g8_model_conv_small", synth.molecule_batch(8, seed=1, num_tasks=5, nan_frac=0.4), 818,
+                   phm_dim=4, atom_encoded_dim=32, mp_layers=[32] * 2, dropout_mpnn=[0.0] * 2, mlp=False,
+                   downstream_layers=[32, 16], dropout_dn=[0.0, 0.0], target_dim=5, sc_type="first", **common)
+    gz = synth.molecule_batch(8, seed=2, dataset="zinc", regression=True)
+    m = PHMSkipConnectAdd  # noqa: F841
+    kw = dict(phm_dim=8, atom_input_dims=synth.ZINC_ATOM_DIMS, bond_input_dims=synth.ZINC_BOND_DIMS,
+              atom_encoded_dim=64, mp_layers=[64] * 3, dropout_mpnn=[0.0] * 3, mlp=True,
+              downstream_layers=[64, 32], dropout_dn=[0.0, 0.0], target_dim=1, sc_type="last", **common)
+    # l1 loss for the ZINC-like regression variant
+    gen = torch.Generator().manual_seed(828)
+    model = PHMSkipConnectAdd(**kw)
+    fill_module(model, gen)
+    data = _to_batch(gz)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model.eval()
+    with torch.no_grad():
+        logits_eval = model(data)
+    model.train()
+    logits = model(data)
+    loss = torch.nn.functional.l1_loss(logits, data.y)
+    loss.backward()
+    out = dict(x=data.x, edge_index=data.edge_index, edge_attr=data.edge_attr, batch=data.batch, y=data.y,
+               logits_eval=logits_eval, logits_train=logits, loss=loss)
+    out.update({"sd::" + k: v for k, v in sd.items()})
+    out.update({"sd_after::" + k: v for k, v in model.state_dict().items() if "running" in k})
+    out.update({"grad::" + k: p.grad for k, p in model.named_parameters() if p.grad is not None})
+    out["num_params"] = model.get_number_of_params_()
+    save("g8_model_zinc_small", **out)
+
+
+def g9_dropout():
+    """G9: phm_dropout(same=True) mask structure (test_ops_equal_quaternion.py:64-103)."""
+    torch.manual_seed(909)
+    n, k, N, p = 4, 16, 40, 0.3
+    x = torch.randn(N, n * k) + 3.0
+    y = phm_dropout(x, phm_dim=n, p=p, training=True, same=True)
+    kept = (y != 0).reshape(N, n, k)
+    assert bool((kept == kept[:, :1]).all())
+    ratio = (y[y != 0] / x[y != 0])
+    assert torch.allclose(ratio, torch.full_like(ratio, 1 / (1 - p)))
+    save("g9_dropout", x=x, y=y, meta=np.array([n, k, N]), p=np.array(p))
+
+
+if __name__ == "__main__":
+    g1_phm_linear()
+    g2_g3_g4_kronecker_rules()
+    g5_convs()
+    g5b_softmax()
+    g6_norm()
+    g7_heads()
+    g8_models()
+    g9_dropout()
