@@ -1,0 +1,152 @@
+/*
+ * phc_hip.h — C ABI of libphc_hip.so, the MI355X (gfx950) engine behind the
+ * PHC-GNN message-passing path.
+ *
+ * The reference (bayer-science-for-a-better-life/phc-gnn) has no FFI layer: its
+ * hot path drops from Python straight into third-party ATen / torch-scatter
+ * kernels.  Each entry point below replaces one such group of
+ * call sites; the reference location is cited per function
+ * (paths relative to the reference checkout).  INTEGRATION.md shows the ctypes
+ * stub a maintainer of the reference would add.
+ *
+ * Conventions (all entry points):
+ *   - every pointer is a DEVICE pointer (HBM) unless a comment says "host";
+ *   - matrices are dense row-major fp32; index arrays are int32 unless the
+ *     parameter is named *_i64 (the reference's edge_index / batch are int64);
+ *   - `stream` is a hipStream_t passed as void*; NULL = the default stream.
+ *     Work is only enqueued: no call synchronises, allocates or frees device
+ *     memory, so every call is legal under hipGraph stream capture;
+ *   - the caller owns every buffer, workspaces included (query *_ws_bytes);
+ *   - return value: 0 = PHC_OK, negative = error (see phc_error_string); no
+ *     C++ exception crosses the boundary; phc_last_error() returns a
+ *     thread-local detail message for the last failing call on this thread;
+ *   - thread-safe for calls on distinct streams; the only process-global state
+ *     is the opt-in launch profiler (phc_prof_*).
+ *
+ * Feature layout is the reference's component-major one: column c*k + kappa
+ * is hypercomplex component c, channel kappa (models.py:225, norm.py:32).
+ */
+#ifndef PHC_HIP_H
+#define PHC_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define PHC_ABI_VERSION 1
+
+#define PHC_OK 0
+#define PHC_ERR_INVALID_ARG (-1)   /* null pointer, negative size, bad enum        */
+#define PHC_ERR_UNSUPPORTED (-2)   /* shape outside what the kernels implement      */
+#define PHC_ERR_WORKSPACE (-3)     /* workspace pointer null or too small           */
+#define PHC_ERR_LAUNCH (-4)        /* HIP runtime reported an error at launch       */
+#define PHC_ERR_NO_DEVICE (-5)     /* no gfx950 device visible to this process      */
+
+/* message activation  phi  (phc/quaternion/activations.py:134-147) */
+#define PHC_ACT_IDENTITY 0
+#define PHC_ACT_RELU 1
+#define PHC_ACT_LRELU 2            /* nn.LeakyReLU(), slope 0.01                    */
+#define PHC_ACT_ELU 3              /* nn.ELU(), alpha 1                             */
+#define PHC_ACT_SWISH 4            /* x * sigmoid(x), activations.py:13-35          */
+#define PHC_ACT_SELU 5
+
+int phc_version(void);                       /* PHC_ABI_VERSION of the loaded library */
+const char *phc_error_string(int code);      /* host, static storage                  */
+const char *phc_last_error(void);            /* host, thread-local storage            */
+int phc_device_info(int *num_cu, int *lds_bytes_per_cu, char *arch, int arch_len);   /* host out-params */
+
+/* ------------------------------------------------------------------------- *
+ * PHM linear transform
+ * ------------------------------------------------------------------------- */
+
+/* H[a*kin+kap, c*kout+pi] = sum_i A[i,a,c] * W[i,kap,pi]     ([n*kin, n*kout])
+ * Replaces kronecker_product_einsum_batched(...).sum(0)
+ * (phc/hypercomplex/kronecker.py:35-48 + layers.py:214).  The forward/backward
+ * kernels below never need this buffer (they assemble H tiles in LDS); it is
+ * exported for inspection, tests and regularisers. */
+int phc_phm_build_H(const float *A, const float *W, int n, int kin, int kout, float *H, void *stream);
+
+/* y[N, n*kout] = x[N, n*kin] . H(A, W)  (+ b[n*kout])  (+ residual[N, n*kout])
+ * Replaces matvec_product_new (phc/hypercomplex/layers.py:198-219); the optional
+ * residual is PHMConv's `transform(agg) + x` (messagepassing.py:62-65).
+ * A is staged in LDS, H tiles are assembled in LDS from W, fp32 MFMA.
+ * b, residual may be NULL.  y must not alias x. */
+int phc_phm_linear_fwd(const float *x, const float *A, const float *W, const float *b, const float *residual,
+                       int64_t N, int n, int kin, int kout, float *y, void *stream);
+
+/* Gradients of phc_phm_linear_fwd w.r.t. x, W, A, b given dy[N, n*kout]
+ * (what autograd derives from layers.py:214-217; formulas in SURVEY.md §8 a4):
+ *   dx = dy . H^T ; dH = x^T . dy ; dW[i] = sum_{a,c} A[i,a,c] dH[a,:,c,:] ;
+ *   dA[i,a,c] = sum W[i] * dH[a,:,c,:] ; db = sum_N dy.
+ * dx, dA, db may be NULL (not computed); dW may be NULL only if dA and db are.
+ * Deterministic (fixed-order split-K slabs, no atomics). */
+size_t phc_phm_linear_bwd_ws_bytes(int64_t N, int n, int kin, int kout);
+int phc_phm_linear_bwd(const float *x, const float *A, const float *W, const float *dy,
+                       int64_t N, int n, int kin, int kout,
+                       float *dx, float *dW, float *dA, float *db,
+                       void *ws, size_t ws_bytes, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * Graph structure: destination-sorted (CSR) or source-sorted (CSC) edge lists
+ * ------------------------------------------------------------------------- */
+
+/* Stable counting sort of E items by key_i64[e] in [0, num_keys):
+ *   rowptr[num_keys+1], perm[E] = item ids grouped by key, ascending id inside
+ *   a group (so every later reduction has ONE fixed summation order),
+ *   col[E] = other_i64[perm[e]] narrowed to int32 (col = perm if other is NULL).
+ * CSR for the forward pass: key = edge_index[1] (targets), other = edge_index[0].
+ * CSC for the backward pass: key = edge_index[0], other = edge_index[1].
+ * Pooling segments: key = batch, other = NULL.
+ * Replaces the index plumbing inside PyG 1.6.1 MessagePassing.propagate /
+ * torch_scatter.scatter (call sites messagepassing.py:60,136; pooling.py:14).
+ * Keys outside [0, num_keys) are a caller error (not detected on device). */
+size_t phc_csr_ws_bytes(int64_t E, int64_t num_keys);
+int phc_csr_build(const int64_t *key_i64, const int64_t *other_i64, int64_t E, int64_t num_keys,
+                  int32_t *rowptr, int32_t *col, int32_t *perm, void *ws, size_t ws_bytes, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * Neighbour aggregation (sum)
+ * ------------------------------------------------------------------------- */
+
+/* out[d, :] = sum_{e in CSR row d} phi( x[col[e], :] + ea[perm[e], :] )  (+ x[d, :] if add_self)
+ * for d < n_dst; x has at least max(col)+1 rows (n_dst rows suffice for a
+ * square graph), ea[E, h] is in ORIGINAL edge order and may be NULL.
+ * Replaces index_select + message + scatter(reduce='add') + the self-loop add
+ * (messagepassing.py:57-60,72-74 / :133-138,144-146).  One wavefront per
+ * destination row, coalesced 16-byte-per-lane row gathers, no atomics. */
+int phc_aggregate_fwd(const float *x, const float *ea, const int32_t *rowptr, const int32_t *col,
+                      const int32_t *perm, int64_t n_dst, int h, int act, int add_self,
+                      float *out, void *stream);
+
+/* Backward of phc_aggregate_fwd, walking the SOURCE-sorted structure
+ * (rowptr_t[n_src+1], col_t[e] = destination of the e-th out-edge, perm_t[e] =
+ * its original edge id):
+ *   g_e = phi'(x[s]+ea[e]) * dout[dst(e)] ;  dea[e] = g_e ;
+ *   dx[s] = sum_{e out of s} g_e  (+ dout[s] if add_self and s < n_dst).
+ * x and ea are only read when act != identity; dea may be NULL. */
+int phc_aggregate_bwd(const float *dout, const float *x, const float *ea, const int32_t *rowptr_t,
+                      const int32_t *col_t, const int32_t *perm_t, int64_t n_src, int64_t n_dst, int h,
+                      int act, int add_self, float *dx, float *dea, void *stream);
+
+/* out[r, :] = src[idx[r], :]   (row gather; backward of a segment sum, e.g.
+ * global_add_pool's gradient dx[i] = dout[batch[i]], pooling.py:14) */
+int phc_gather_rows_i64(const float *src, const int64_t *idx_i64, int64_t n_rows, int h, float *out, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * Opt-in launch profiler (process-global).  When enabled every kernel launch
+ * made through this library is bracketed by two hipEvents on ITS stream;
+ * phc_prof_read synchronises those events and returns per-kernel totals.
+ * bench.py uses it for the "roofline" object; leave it off otherwise.
+ * ------------------------------------------------------------------------- */
+int phc_prof_enable(int on);
+int phc_prof_reset(void);
+int phc_prof_num_kernels(void);
+int phc_prof_read(int kernel_id, const char **name, uint64_t *launches, double *total_ms);   /* host out-params */
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* PHC_HIP_H */

@@ -1,0 +1,210 @@
+// Destination-/source-sorted edge lists (CSR / CSC) built on the device.
+//
+// The reference hands PyG an unsorted int64 edge_index [2, E] and lets
+// torch-scatter's atomics sort it out on every call (messagepassing.py:60,136).
+// This engine groups the edges once per batch — stable counting sort by key:
+//   histogram -> exclusive scan -> slot assignment -> per-row canonical order
+// so that every later reduction walks contiguous segments in ONE fixed order
+// (ascending original edge id).  All kernels are enqueue-only (graph-capturable).
+#include "phc_common.h"
+
+namespace phc {
+
+constexpr int SCAN_THREADS = 256;
+constexpr int SCAN_ITEMS = 8;
+constexpr int SCAN_ELEMS = SCAN_THREADS * SCAN_ITEMS;      // elements per workgroup
+
+__global__ void csr_hist_kernel(const long long *__restrict__ key, long long E, int *__restrict__ counts) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (long long)gridDim.x * blockDim.x)
+        atomicAdd(&counts[key[e]], 1);
+}
+
+// In-place exclusive scan of SCAN_ELEMS-element blocks; block totals go to sums[blockIdx.x].
+__global__ __launch_bounds__(SCAN_THREADS) void scan_block_kernel(int *__restrict__ data, int *__restrict__ sums, long long n) {
+    __shared__ int wave_tot[SCAN_THREADS / 64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const long long base = (long long)blockIdx.x * SCAN_ELEMS + (long long)tid * SCAN_ITEMS;
+    int v[SCAN_ITEMS];
+    int tot = 0;
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        v[i] = (base + i < n) ? data[base + i] : 0;
+        tot += v[i];
+    }
+    int incl = tot;                                      // inclusive scan of thread totals inside the wavefront
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        int t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int wave_off = 0;
+    for (int w = 0; w < wave; ++w) wave_off += wave_tot[w];
+    int run = wave_off + incl - tot;                     // exclusive prefix of this thread
+#pragma unroll
+    for (int i = 0; i < SCAN_ITEMS; ++i) {
+        if (base + i < n) data[base + i] = run;
+        run += v[i];
+    }
+    if (tid == SCAN_THREADS - 1 && sums) sums[blockIdx.x] = run;
+}
+
+__global__ void scan_add_kernel(int *__restrict__ data, const int *__restrict__ sums, long long n) {
+    const long long i = (long long)blockIdx.x * SCAN_ELEMS + threadIdx.x;
+    const int off = sums[blockIdx.x];
+#pragma unroll
+    for (int k = 0; k < SCAN_ITEMS; ++k) {
+        const long long j = i + (long long)k * SCAN_THREADS;
+        if (j < n) data[j] += off;
+    }
+}
+
+// slot = rowptr[key] + (arrival order); arrival order is arbitrary, csr_canon fixes it.
+__global__ void csr_fill_kernel(const long long *__restrict__ key, long long E, const int *__restrict__ rowptr,
+                                int *__restrict__ cursor, int *__restrict__ tmp_perm) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (long long)gridDim.x * blockDim.x) {
+        const long long k = key[e];
+        const int pos = rowptr[k] + atomicAdd(&cursor[k], 1);
+        tmp_perm[pos] = (int)e;
+    }
+}
+
+// Rank sort of every row's item ids (unique => ranks are a permutation), out of place.
+// SUB lanes cooperate on one row; rows with degree outside (lo, hi] are left to the other launch.
+template <int SUB>
+__global__ __launch_bounds__(256) void csr_canon_kernel(const int *__restrict__ rowptr, const int *__restrict__ tmp_perm,
+                                                       const long long *__restrict__ other, long long num_keys, int lo, int hi,
+                                                       int *__restrict__ perm, int *__restrict__ col) {
+    const int li = threadIdx.x & (SUB - 1);
+    const long long grp = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / SUB;
+    const long long n_grp = ((long long)gridDim.x * blockDim.x) / SUB;
+    for (long long k = grp; k < num_keys; k += n_grp) {
+        const int b = rowptr[k], deg = rowptr[k + 1] - b;
+        if (deg <= lo || deg > hi) continue;
+        for (int t = li; t < deg; t += SUB) {
+            const int v = tmp_perm[b + t];
+            int rank = 0;
+            for (int j = 0; j < deg; ++j) rank += (tmp_perm[b + j] < v) ? 1 : 0;
+            perm[b + rank] = v;
+            col[b + rank] = other ? (int)other[v] : v;
+        }
+    }
+}
+
+struct ScanLevels {
+    int levels;
+    long long n[6];
+    long long blocks[6];
+    size_t total_sum_ints;
+};
+
+static ScanLevels scan_levels(long long n) {
+    ScanLevels L;
+    L.levels = 0;
+    L.total_sum_ints = 0;
+    long long cur = n;
+    while (true) {
+        const long long b = (cur + SCAN_ELEMS - 1) / SCAN_ELEMS;
+        L.n[L.levels] = cur;
+        L.blocks[L.levels] = b;
+        L.levels++;
+        if (b <= 1) break;
+        L.total_sum_ints += (size_t)b;
+        cur = b;
+    }
+    return L;
+}
+
+static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
+
+}  // namespace phc
+
+using namespace phc;
+
+extern "C" {
+
+size_t phc_csr_ws_bytes(int64_t E, int64_t num_keys) {
+    if (E < 0 || num_keys < 0) return 0;
+    ScanLevels L = scan_levels(num_keys + 1);
+    // cursor[num_keys] | scan block sums | tmp_perm[E]
+    return align_up(sizeof(int) * (size_t)(num_keys + 1), 256) + align_up(sizeof(int) * (L.total_sum_ints + 1), 256) +
+           align_up(sizeof(int) * (size_t)(E + 1), 256);
+}
+
+int phc_csr_build(const int64_t *key_i64, const int64_t *other_i64, int64_t E, int64_t num_keys, int32_t *rowptr,
+                  int32_t *col, int32_t *perm, void *ws, size_t ws_bytes, void *stream) {
+    PHC_REQUIRE(E >= 0 && num_keys >= 0, PHC_ERR_INVALID_ARG, "phc_csr_build: E=%lld num_keys=%lld", (long long)E,
+                (long long)num_keys);
+    PHC_REQUIRE(E < (1LL << 31) - 1 && num_keys < (1LL << 31) - 1, PHC_ERR_UNSUPPORTED,
+                "phc_csr_build: int32 index space exceeded (E=%lld, keys=%lld)", (long long)E, (long long)num_keys);
+    PHC_REQUIRE(rowptr && (E == 0 || (key_i64 && col && perm)), PHC_ERR_INVALID_ARG, "phc_csr_build: null pointer");
+    const size_t need = phc_csr_ws_bytes(E, num_keys);
+    PHC_REQUIRE(ws && ws_bytes >= need, PHC_ERR_WORKSPACE, "phc_csr_build: workspace %zu B < required %zu B", ws_bytes, need);
+    hipStream_t s = (hipStream_t)stream;
+
+    ScanLevels L = scan_levels(num_keys + 1);
+    char *p = static_cast<char *>(ws);
+    int *cursor = reinterpret_cast<int *>(p);
+    p += align_up(sizeof(int) * (size_t)(num_keys + 1), 256);
+    int *sums = reinterpret_cast<int *>(p);
+    p += align_up(sizeof(int) * (L.total_sum_ints + 1), 256);
+    int *tmp_perm = reinterpret_cast<int *>(p);
+
+    hipMemsetAsync(rowptr, 0, sizeof(int) * (size_t)(num_keys + 1), s);
+    hipMemsetAsync(cursor, 0, sizeof(int) * (size_t)(num_keys + 1), s);
+    const unsigned egrid = (unsigned)((E + 255) / 256 > 8192 ? 8192 : (E + 255) / 256);
+    if (E > 0) {
+        ProfScope prof(K_CSR_HIST, s);
+        hipLaunchKernelGGL(csr_hist_kernel, dim3(egrid), dim3(256), 0, s, reinterpret_cast<const long long *>(key_i64),
+                           (long long)E, rowptr);
+        int rc = check_launch("csr_hist");
+        if (rc) return rc;
+    }
+    {   // exclusive scan of rowptr[0 .. num_keys] (num_keys + 1 entries, the last count is 0)
+        ProfScope prof(K_CSR_SCAN, s);
+        int *level_data[6];
+        int *level_sums[6];
+        level_data[0] = rowptr;
+        int *sp = sums;
+        for (int l = 0; l < L.levels; ++l) {
+            level_sums[l] = (L.blocks[l] > 1) ? sp : nullptr;
+            if (L.blocks[l] > 1) {
+                level_data[l + 1] = sp;
+                sp += L.blocks[l];
+            }
+        }
+        for (int l = 0; l < L.levels; ++l)
+            hipLaunchKernelGGL(scan_block_kernel, dim3((unsigned)L.blocks[l]), dim3(SCAN_THREADS), 0, s, level_data[l],
+                               level_sums[l], L.n[l]);
+        for (int l = L.levels - 2; l >= 0; --l)
+            hipLaunchKernelGGL(scan_add_kernel, dim3((unsigned)L.blocks[l]), dim3(SCAN_THREADS), 0, s, level_data[l],
+                               level_sums[l], L.n[l]);
+        int rc = check_launch("csr_scan");
+        if (rc) return rc;
+    }
+    if (E == 0) return PHC_OK;
+    {
+        ProfScope prof(K_CSR_FILL, s);
+        hipLaunchKernelGGL(csr_fill_kernel, dim3(egrid), dim3(256), 0, s, reinterpret_cast<const long long *>(key_i64),
+                           (long long)E, rowptr, cursor, tmp_perm);
+        int rc = check_launch("csr_fill");
+        if (rc) return rc;
+    }
+    {
+        ProfScope prof(K_CSR_CANON, s);
+        const long long groups8 = (num_keys + 31) / 32;        // 256 threads = 32 rows of 8 lanes
+        unsigned g8 = (unsigned)(groups8 > 16384 ? 16384 : (groups8 < 1 ? 1 : groups8));
+        hipLaunchKernelGGL((csr_canon_kernel<8>), dim3(g8), dim3(256), 0, s, rowptr, tmp_perm,
+                           reinterpret_cast<const long long *>(other_i64), (long long)num_keys, 0, 64, perm, col);
+        const long long groups64 = (num_keys + 3) / 4;
+        unsigned g64 = (unsigned)(groups64 > 8192 ? 8192 : (groups64 < 1 ? 1 : groups64));
+        hipLaunchKernelGGL((csr_canon_kernel<64>), dim3(g64), dim3(256), 0, s, rowptr, tmp_perm,
+                           reinterpret_cast<const long long *>(other_i64), (long long)num_keys, 64, 0x7fffffff, perm, col);
+        int rc = check_launch("csr_canon");
+        if (rc) return rc;
+    }
+    return PHC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,95 @@
+// Internal helpers shared by the gfx950 kernels of libphc_hip.so.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+
+#include "phc_hip.h"
+
+namespace phc {
+
+// ---- error plumbing --------------------------------------------------------
+void set_last_error(const char *fmt, ...);
+
+#define PHC_REQUIRE(cond, code, ...)         \
+    do {                                     \
+        if (!(cond)) {                       \
+            phc::set_last_error(__VA_ARGS__); \
+            return (code);                   \
+        }                                    \
+    } while (0)
+
+// ---- launch profiler ---------------------------------------------------------
+// Kernel ids are stable indices into the name table in api.hip.
+enum KernelId : int {
+    K_PHM_BUILD_H = 0,
+    K_PHM_GEMM_FWD,
+    K_PHM_GEMM_DX,
+    K_PHM_DH_PARTIAL,
+    K_PHM_DH_REDUCE,
+    K_PHM_CONTRACT,
+    K_AGG_FWD,
+    K_AGG_BWD,
+    K_GATHER_ROWS,
+    K_CSR_HIST,
+    K_CSR_SCAN,
+    K_CSR_FILL,
+    K_CSR_CANON,
+    K_NUM_KERNELS
+};
+
+extern bool g_prof_on;
+void prof_begin(int kid, hipStream_t s, int *slot);
+void prof_end(int slot, hipStream_t s);
+
+struct ProfScope {
+    int slot = -1;
+    hipStream_t s;
+    ProfScope(int kid, hipStream_t stream) : s(stream) {
+        if (g_prof_on) prof_begin(kid, s, &slot);
+    }
+    ~ProfScope() {
+        if (slot >= 0) prof_end(slot, s);
+    }
+};
+
+inline int check_launch(const char *what) {
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) {
+        set_last_error("%s: %s", what, hipGetErrorString(e));
+        return PHC_ERR_LAUNCH;
+    }
+    return PHC_OK;
+}
+
+// ---- device helpers ------------------------------------------------------------
+constexpr int WAVE = 64;
+
+template <int ACT>
+__device__ __forceinline__ float act_fwd(float v) {
+    if constexpr (ACT == PHC_ACT_RELU) return v > 0.f ? v : 0.f;
+    if constexpr (ACT == PHC_ACT_LRELU) return v > 0.f ? v : 0.01f * v;
+    if constexpr (ACT == PHC_ACT_ELU) return v > 0.f ? v : expm1f(v);
+    if constexpr (ACT == PHC_ACT_SWISH) return v / (1.f + __expf(-v));
+    if constexpr (ACT == PHC_ACT_SELU)
+        return 1.0507009873554804934193349852946f * (v > 0.f ? v : 1.6732632423543772848170429916717f * expm1f(v));
+    return v;
+}
+
+// d phi / d v evaluated at the pre-activation v
+template <int ACT>
+__device__ __forceinline__ float act_grad(float v) {
+    if constexpr (ACT == PHC_ACT_RELU) return v > 0.f ? 1.f : 0.f;
+    if constexpr (ACT == PHC_ACT_LRELU) return v > 0.f ? 1.f : 0.01f;
+    if constexpr (ACT == PHC_ACT_ELU) return v > 0.f ? 1.f : __expf(v);
+    if constexpr (ACT == PHC_ACT_SWISH) {
+        float s = 1.f / (1.f + __expf(-v));
+        return s * (1.f + v * (1.f - s));
+    }
+    if constexpr (ACT == PHC_ACT_SELU)
+        return 1.0507009873554804934193349852946f * (v > 0.f ? 1.f : 1.6732632423543772848170429916717f * __expf(v));
+    return 1.f;
+}
+
+}  // namespace phc

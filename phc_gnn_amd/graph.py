@@ -1,0 +1,128 @@
+"""Device-resident sorted edge lists for one ``edge_index`` (built by
+``phc_csr_build``), shared by every layer and by forward and backward.
+
+The reference re-derives the scatter pattern from the raw int64 ``edge_index``
+on every ``propagate`` call (PyG 1.6.1, call sites
+phc/hypercomplex/undirectional/messagepassing.py:60,136).  Here the
+destination-sorted view (forward) and the source-sorted view (backward) are
+built once per batch and cached by tensor identity.
+"""
+from __future__ import annotations
+
+from collections import OrderedDict
+from typing import Optional, Tuple
+
+import torch
+
+from . import lib as L
+
+_CACHE_SIZE = 16
+_cache: "OrderedDict[tuple, EdgeStructure]" = OrderedDict()
+
+
+def _build_sorted(key: torch.Tensor, other: Optional[torch.Tensor], num_keys: int):
+    """(rowptr[num_keys+1], col[E], perm[E]) int32 on key.device."""
+    lib = L.load()
+    dev = L.require_device(key, other)
+    E = key.numel()
+    rowptr = torch.empty(num_keys + 1, dtype=torch.int32, device=dev)
+    col = torch.empty(E, dtype=torch.int32, device=dev)
+    perm = torch.empty(E, dtype=torch.int32, device=dev)
+    ws_bytes = lib.phc_csr_ws_bytes(E, num_keys)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    L.check(lib.phc_csr_build(L.ptr(key), L.ptr(other), E, num_keys, L.ptr(rowptr), L.ptr(col), L.ptr(perm),
+                              L.ptr(ws), ws_bytes, L.stream_ptr(dev)), "phc_csr_build")
+    return rowptr, col, perm
+
+
+class EdgeStructure:
+    """CSR (by target) and CSC (by source) of a directed edge list.
+
+    ``num_src`` rows exist on the source side, ``num_dst`` on the target side
+    (equal for an ordinary graph; for a destination-range shard the targets are
+    the owned nodes and the sources are owned + halo rows)."""
+
+    def __init__(self, edge_index: torch.Tensor, num_src: int, num_dst: Optional[int] = None):
+        if edge_index.dim() != 2 or edge_index.shape[0] != 2:
+            raise L.PhcError(f"edge_index must be [2, E], got {tuple(edge_index.shape)}")
+        if edge_index.dtype != torch.int64:
+            edge_index = edge_index.to(torch.int64)
+        L.require_device(edge_index)
+        self.edge_index = edge_index            # keeps the storage alive while cached
+        self.num_src = int(num_src)
+        self.num_dst = int(num_src if num_dst is None else num_dst)
+        self.num_edges = int(edge_index.shape[1])
+        self._src = edge_index[0].contiguous()
+        self._dst = edge_index[1].contiguous()
+        self._csr: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None
+        self._csc: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None
+
+    @property
+    def csr(self):
+        """rowptr[num_dst+1], col = source of each in-edge, perm = original edge id."""
+        if self._csr is None:
+            self._csr = _build_sorted(self._dst, self._src, self.num_dst)
+        return self._csr
+
+    @property
+    def csc(self):
+        """rowptr_t[num_src+1], col_t = target of each out-edge, perm_t = original edge id."""
+        if self._csc is None:
+            self._csc = _build_sorted(self._src, self._dst, self.num_src)
+        return self._csc
+
+
+class SegmentStructure:
+    """Rows grouped by an int64 segment id (``batch`` -> graphs), for read-out."""
+
+    def __init__(self, batch: torch.Tensor, num_segments: int):
+        L.require_device(batch)
+        self.batch = batch if batch.dtype == torch.int64 else batch.to(torch.int64)
+        self.batch = self.batch.contiguous()
+        self.num_segments = int(num_segments)
+        self._csr = None
+
+    @property
+    def csr(self):
+        if self._csr is None:
+            self._csr = _build_sorted(self.batch, None, self.num_segments)
+        return self._csr
+
+
+def _key(t: torch.Tensor, *extra):
+    return (t.data_ptr(), t._version, tuple(t.shape), t.dtype, t.device, *extra)
+
+
+def edge_structure(edge_index: torch.Tensor, num_src: int, num_dst: Optional[int] = None) -> EdgeStructure:
+    k = _key(edge_index, "edge", num_src, num_dst)
+    st = _cache.get(k)
+    if st is None:
+        st = EdgeStructure(edge_index, num_src, num_dst)
+        _cache[k] = st
+        st._pin = edge_index                    # the key's data_ptr stays valid while the entry lives
+        while len(_cache) > _CACHE_SIZE:
+            _cache.popitem(last=False)
+    else:
+        _cache.move_to_end(k)
+    return st
+
+
+def segment_structure(batch: torch.Tensor, num_segments: Optional[int] = None) -> SegmentStructure:
+    if num_segments is None:
+        # same host sync the reference pays in global_add_pool (batch.max() + 1)
+        num_segments = int(batch.max().item()) + 1 if batch.numel() else 0
+    k = _key(batch, "seg", num_segments)
+    st = _cache.get(k)
+    if st is None:
+        st = SegmentStructure(batch, num_segments)
+        _cache[k] = st
+        st._pin = batch
+        while len(_cache) > _CACHE_SIZE:
+            _cache.popitem(last=False)
+    else:
+        _cache.move_to_end(k)
+    return st
+
+
+def clear_structure_cache() -> None:
+    _cache.clear()

@@ -1,0 +1,138 @@
+"""ctypes binding of libphc_hip.so (the C ABI declared in include/phc_hip.h).
+
+There is deliberately no fallback here: if the library is missing or a call
+fails, a ``PhcError`` is raised.  Tensors are passed as raw device pointers and
+the caller's current HIP stream; PyTorch only provides memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_PKG_DIR = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG_DIR, "libphc_hip.so")
+
+ACT_IDS = {"identity": 0, "relu": 1, "lrelu": 2, "elu": 3, "swish": 4, "selu": 5}
+
+
+class PhcError(RuntimeError):
+    pass
+
+
+# name -> (restype, argtypes); mirrors include/phc_hip.h one to one
+_P = C.c_void_p
+_I = C.c_int
+_L = C.c_int64
+_S = C.c_size_t
+SIGNATURES = {
+    "phc_version": (_I, []),
+    "phc_error_string": (C.c_char_p, [_I]),
+    "phc_last_error": (C.c_char_p, []),
+    "phc_device_info": (_I, [C.POINTER(_I), C.POINTER(_I), C.c_char_p, _I]),
+    "phc_phm_build_H": (_I, [_P, _P, _I, _I, _I, _P, _P]),
+    "phc_phm_linear_fwd": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P]),
+    "phc_phm_linear_bwd_ws_bytes": (_S, [_L, _I, _I, _I]),
+    "phc_phm_linear_bwd": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _S, _P]),
+    "phc_csr_ws_bytes": (_S, [_L, _L]),
+    "phc_csr_build": (_I, [_P, _P, _L, _L, _P, _P, _P, _P, _S, _P]),
+    "phc_aggregate_fwd": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P]),
+    "phc_aggregate_bwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _L, _I, _I, _I, _P, _P, _P]),
+    "phc_gather_rows_i64": (_I, [_P, _P, _L, _I, _P, _P]),
+    "phc_prof_enable": (_I, [_I]),
+    "phc_prof_reset": (_I, []),
+    "phc_prof_num_kernels": (_I, []),
+    "phc_prof_read": (_I, [_I, C.POINTER(C.c_char_p), C.POINTER(C.c_uint64), C.POINTER(C.c_double)]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def load() -> C.CDLL:
+    """Load libphc_hip.so (once).  Raises PhcError when it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise PhcError(
+            f"{LIB_PATH} not found: the HIP engine is not built (run `python -m phc_gnn_amd.build`). "
+            "phc_gnn_amd has no CPU or PyTorch fallback.")
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as exc:  # pragma: no cover
+        raise PhcError(f"cannot load {LIB_PATH}: {exc}") from exc
+    for name, (res, args) in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as exc:
+            raise PhcError(f"{LIB_PATH} does not export {name}; rebuild it") from exc
+        fn.restype = res
+        fn.argtypes = args
+    if lib.phc_version() != 1:
+        raise PhcError(f"ABI version mismatch: library {lib.phc_version()}, binding 1")
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        lib = load()
+        raise PhcError(f"{what} failed: {lib.phc_error_string(rc).decode()} ({rc}): {lib.phc_last_error().decode()}")
+
+
+def require_device(*tensors: Optional[torch.Tensor]) -> torch.device:
+    """All tensors must live on one ROCm device; anything else is a hard error."""
+    dev = None
+    for t in tensors:
+        if t is None:
+            continue
+        if not t.is_cuda:
+            raise PhcError("phc_gnn_amd runs on MI355X only: got a tensor on "
+                           f"'{t.device}'. Move the module and its inputs to a ROCm device "
+                           "(there is no CPU fallback).")
+        if dev is None:
+            dev = t.device
+        elif t.device != dev:
+            raise PhcError(f"tensors on different devices: {dev} vs {t.device}")
+    if dev is None:
+        raise PhcError("no tensor given")
+    return dev
+
+
+def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr(device: torch.device) -> int:
+    return torch.cuda.current_stream(device).cuda_stream
+
+
+def f32c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
+    """Contiguous fp32 view/copy (the ABI is dense row-major fp32)."""
+    if t is None:
+        return None
+    if t.dtype != torch.float32:
+        raise PhcError(f"fp32 expected, got {t.dtype}")
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# ---- profiler helpers (used by bench.py) -------------------------------------
+def prof_enable(on: bool) -> None:
+    check(load().phc_prof_enable(1 if on else 0), "phc_prof_enable")
+
+
+def prof_reset() -> None:
+    check(load().phc_prof_reset(), "phc_prof_reset")
+
+
+def prof_read() -> dict:
+    lib = load()
+    out = {}
+    for k in range(lib.phc_prof_num_kernels()):
+        name, n, ms = C.c_char_p(), C.c_uint64(), C.c_double()
+        check(lib.phc_prof_read(k, C.byref(name), C.byref(n), C.byref(ms)), "phc_prof_read")
+        if n.value:
+            out[name.value.decode()] = {"launches": int(n.value), "total_ms": float(ms.value)}
+    return out
