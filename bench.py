@@ -1,0 +1,211 @@
+#!/usr/bin/env python3
+"""Headline benchmark: graphs/sec of the PHC-GNN PHM-4 training step on
+ogbg-molhiv-shaped batches (BASELINE.json metric, configs[1]: hidden 128,
+4 layers, batch 512 per GPU), on N MI355X of one node.
+
+    python bench.py --gpus 1 --steps 50 --warmup 10
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path over one pre-collated, HBM-resident
+synthetic batch, reproducing the reference loop body
+(benchmarks/train_hiv.py:175-201): zero_grad, forward, NaN-masked BCE, backward,
+(N>1: one flat-bucket RCCL all-reduce of the gradients), clip_grad_norm_(2.0),
+Adam step.  Weak scaling: every rank processes its own 512-graph batches.
+
+Rank 0 prints ONE JSON line.  Besides the contract fields it carries
+  "roofline":     the dominant engine kernel of the step, algorithmic work per
+                  launch / its measured launch duration (HIP events recorded by
+                  libphc_hip's launch profiler on the launching stream),
+  "cpu_baseline": the CPU oracle (oracle/phc_oracle.py, a port of the reference's
+                  op sequence) timed on this host for a bounded sample.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+
+PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s HBM3E
+PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
+MFMA_KERNELS = ("phm_gemm_fwd", "phm_gemm_dx", "phm_dH_partial")
+
+
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--workload", default="molhiv_b512")
+    ap.add_argument("--num-batches", type=int, default=8, help="distinct resident batches cycled through")
+    ap.add_argument("--fwd-bwd-only", action="store_true", help="leave grad clipping + Adam out of the step")
+    ap.add_argument("--cpu-steps", type=int, default=30, help="timed CPU-oracle steps (0 = skip the CPU baseline)")
+    ap.add_argument("--cpu-threads", type=int, default=6, help="reference setting: torch.set_num_threads(6)")
+    ap.add_argument("--profile-steps", type=int, default=10)
+    return ap.parse_args()
+
+
+def make_grad_sync(model, world):
+    import torch.distributed as dist
+    params = [p for p in model.parameters() if p.requires_grad]
+
+    def sync(_model):
+        grads = [p.grad for p in params if p.grad is not None]
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        dist.all_reduce(flat, op=dist.ReduceOp.SUM)          # RCCL: one latency-bound bucket (~0.3 MB)
+        flat.div_(world)
+        torch._foreach_copy_(grads, [c.view_as(g) for c, g in zip(flat.split([g.numel() for g in grads]), grads)])
+    return sync
+
+
+def cpu_baseline(args, workload, model, gb):
+    """Time the CPU oracle on the same batch shape: same step contents."""
+    from oracle import phc_oracle as O
+    from phc_gnn_amd import harness
+    w = harness.WORKLOADS[workload]
+    torch.set_num_threads(args.cpu_threads)
+    sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
+    names = [k for k, _ in model.named_parameters()]
+    for k in names:
+        sd[k].requires_grad_()
+    params = [sd[k] for k in names]
+    opt = torch.optim.Adam(params, lr=1e-3)
+    x, ei, ea, batch = (torch.from_numpy(a) for a in (gb.x, gb.edge_index, gb.edge_attr, gb.batch))
+    y = torch.from_numpy(gb.y)
+    kw = dict(phm_dim=w["phm_dim"], num_layers=w["layers"], num_atom_feats=x.shape[1], num_bond_feats=ea.shape[1],
+              num_dn_hidden=len(w["d_units"]), mlp=True, sc_type=w["sc_type"], training=True, num_graphs=gb.num_graphs)
+
+    def step():
+        opt.zero_grad(set_to_none=True)
+        logits = O.skip_connect_add_forward(sd, x, ei, ea, batch, **kw)
+        loss = torch.nn.functional.l1_loss(logits, y) if w.get("regression") else O.bce_loss_masked(logits, y)
+        loss.backward()
+        if not args.fwd_bwd_only:
+            torch.nn.utils.clip_grad_norm_(params, max_norm=2.0)
+            opt.step()
+
+    for _ in range(3):
+        step()
+    t0 = time.perf_counter()
+    for _ in range(args.cpu_steps):
+        step()
+    dt = time.perf_counter() - t0
+    return {"value": round(gb.num_graphs * args.cpu_steps / dt, 1), "unit": "graphs/s", "cores": args.cpu_threads,
+            "kind": "port",
+            "sample": f"{args.cpu_steps} steps of one {gb.num_graphs}-graph batch (N={gb.num_nodes}, E={gb.num_edges}), "
+                      f"same step contents, {dt:.1f} s, oracle/phc_oracle.py on torch CPU"}
+
+
+def main():
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs an MI355X (no CPU fallback exists)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    from phc_gnn_amd import harness, lib
+    lib.load()
+    w = harness.WORKLOADS[args.workload]
+    model = harness.build_model(args.workload, dev, seed=0)           # same init on every rank
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)   # train_hiv.py:285 (Adam, weight_decay 0)
+    cfg = harness.StepConfig(regression=bool(w.get("regression")), grad_clip=2.0, optimizer=not args.fwd_bwd_only)
+    host_batches = [harness.make_batch(args.workload, seed=1000 * rank + i) for i in range(args.num_batches)]
+    batches = [harness.to_device(gb, dev) for gb in host_batches]
+    for b in batches:
+        b.all_labeled = bool(b.y_mask.all().item())                   # decided once, outside the timed region
+    grad_sync = make_grad_sync(model, world) if world > 1 else None
+
+    def run(n, offset=0):
+        for i in range(n):
+            harness.train_step(model, batches[(offset + i) % len(batches)], opt, cfg, grad_sync)
+
+    def barrier():
+        if world > 1:
+            import torch.distributed as dist
+            dist.barrier()
+
+    run(args.warmup)
+    barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run(args.steps, offset=args.warmup)
+    torch.cuda.synchronize()
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        import torch.distributed as dist
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    graphs = world * w["batch_size"] * args.steps
+    result = {
+        "metric": "graphs/sec (fwd+bwd) PHC-GNN PHM-4 on ogbg-molhiv",
+        "value": round(graphs / dt, 1), "unit": "graphs/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
+        "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": f"{args.workload}: ogbg-molhiv-shaped synthetic molecules, PHM-{w['phm_dim']}, hidden "
+                               f"{w['hidden']}, {w['layers']} PHMGINEConv layers, sum aggregation, soft-attention "
+                               f"pooling, batch {w['batch_size']}/GPU (BASELINE configs[1])",
+                   "nodes_per_batch": int(sum(b.num_nodes for b in host_batches) / len(host_batches)),
+                   "edges_per_batch": int(sum(b.num_edges for b in host_batches) / len(host_batches)),
+                   "step": "zero_grad+fwd+bce+bwd" + ("" if args.fwd_bwd_only else "+clip+adam")
+                           + ("+grad_allreduce" if world > 1 else ""),
+                   "parallelism": f"dp{world}" if world > 1 else "single"},
+    }
+
+    if rank == 0:
+        # ---- roofline of the dominant engine kernel: instrumented pass over the same steps ----
+        lib.prof_reset()
+        lib.prof_enable(True)
+        run(args.profile_steps, offset=args.warmup)
+        torch.cuda.synchronize()
+        lib.prof_enable(False)
+        times = lib.prof_read()
+        work = dict(lib.WORK)
+        if times:
+            name = max(times, key=lambda k: times[k]["total_ms"])
+            t_ms, n_launch = times[name]["total_ms"], times[name]["launches"]
+            wk = work.get(name, {"flops": 0.0, "bytes": 0.0})
+            if name in MFMA_KERNELS:
+                achieved = wk["flops"] / (t_ms * 1e-3) / 1e12
+                roof = {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
+                        "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4)}
+            else:
+                achieved = wk["bytes"] / (t_ms * 1e-3) / 1e9
+                roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": round(achieved / PEAK_HBM_GBS, 4)}
+            roof.update({"traffic": None, "kernel": name, "launches": n_launch,
+                         "avg_launch_us": round(1e3 * t_ms / max(n_launch, 1), 3),
+                         "engine_kernels_us_per_step": {k: round(1e3 * v["total_ms"] / args.profile_steps, 2)
+                                                        for k, v in sorted(times.items())}})
+            result["roofline"] = roof
+        if world == 1 and args.cpu_steps > 0:
+            result["cpu_baseline"] = cpu_baseline(args, args.workload, model, host_batches[0])
+        print(json.dumps(result), flush=True)
+
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

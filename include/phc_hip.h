@@ -136,6 +136,49 @@ int phc_aggregate_bwd(const float *dout, const float *x, const float *ea, const 
 int phc_gather_rows_i64(const float *src, const int64_t *idx_i64, int64_t n_rows, int h, float *out, void *stream);
 
 /* ------------------------------------------------------------------------- *
+ * Integer-feature encoders (atom / bond embeddings), read in place
+ *
+ * Reference: PHMEncoder = phm_dim independent IntegerEncoders, each the sum of
+ * one nn.Embedding lookup per categorical feature
+ * (phc/hypercomplex/encoder.py:31-34, phc/quaternion/encoder.py:43-51); the
+ * model flattens the result to component-major rows (models.py:223-225,238-240).
+ * `tables` is a DEVICE array of n*F device pointers, entry c*F+f -> table
+ * T_{c,f} [vocab[f], k] row-major (the reference's separate Parameters, used
+ * where they are); `vocab` is a HOST array of the F vocabulary sizes.
+ * Gradients of all n*F tables are written to ONE flat buffer laid out
+ * [c][f][vocab[f]][k]; the caller hands out per-table views of it.
+ * ------------------------------------------------------------------------- */
+#define PHC_MAX_ENC_FEATS 16
+
+/* out[i, c*k + kap] = sum_f T_{c,f}[ idx[i,f] ][kap]        idx_i64 [N, F] */
+int phc_encode_fwd(const int64_t *idx_i64, const float *const *tables, int64_t N, int F, int n, int k, float *out,
+                   void *stream);
+
+/* dT_{c,f}[v][kap] = sum_{i: idx[i,f]=v} dout[i, c*k+kap]    (replaces F*n embedding_dense_backward sorts) */
+size_t phc_encode_bwd_ws_bytes(int64_t N, int F, const int32_t *vocab, int n, int k);
+int phc_encode_bwd(const float *dout, const int64_t *idx_i64, int64_t N, int F, const int32_t *vocab, int n, int k,
+                   float *dtables_flat, void *ws, size_t ws_bytes, void *stream);
+
+/* Aggregation with the edge features looked up from LDS-staged tables; the [E, h]
+ * edge embedding of models.py:238-240 is never materialised:
+ *   out[d] = sum_{e in CSR row d} phi( x[col[e]] + sum_f T_f[bond[perm[e], f]] ) (+ x[d])
+ * bond_i64 [E, F] is in ORIGINAL edge order.  Needs k % 4 == 0 and
+ * sum(vocab) * n * k * 4 <= 48 KiB (else PHC_ERR_UNSUPPORTED: use phc_encode_fwd +
+ * phc_aggregate_fwd). */
+int phc_aggregate_enc_fwd(const float *x, const int64_t *bond_i64, const float *const *tables, const int32_t *vocab,
+                          const int32_t *rowptr, const int32_t *col, const int32_t *perm, int64_t n_dst, int F, int n, int k,
+                          int act, int add_self, float *out, void *stream);
+
+/* Backward of phc_aggregate_enc_fwd: dx (source-sorted walk, may be NULL) and the
+ * flat table gradient (destination-sorted walk, may be NULL). */
+size_t phc_aggregate_enc_bwd_ws_bytes(int64_t n_dst, int F, const int32_t *vocab, int n, int k);
+int phc_aggregate_enc_bwd(const float *dout, const float *x, const int64_t *bond_i64, const float *const *tables,
+                          const int32_t *vocab, const int32_t *rowptr, const int32_t *col, const int32_t *perm,
+                          const int32_t *rowptr_t, const int32_t *col_t, const int32_t *perm_t, int64_t n_src, int64_t n_dst,
+                          int F, int n, int k, int act, int add_self, float *dx, float *dtables_flat, void *ws,
+                          size_t ws_bytes, void *stream);
+
+/* ------------------------------------------------------------------------- *
  * Opt-in launch profiler (process-global).  When enabled every kernel launch
  * made through this library is bracketed by two hipEvents on ITS stream;
  * phc_prof_read synchronises those events and returns per-kernel totals.

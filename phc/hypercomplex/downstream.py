@@ -1,0 +1,79 @@
+"""Downstream prediction head (reference: phc/hypercomplex/downstream.py):
+PHMLinear -> norm -> activation -> dropout stack on the pooled [B, h] graph
+embeddings, a final PHMLinear to phm_dim*out_features and a RealTransformer."""
+from typing import Union
+
+import torch
+import torch.nn as nn
+
+from phc.hypercomplex.layers import PHMLinear, RealTransformer, phm_dropout
+from phc.hypercomplex.norm import PHMNorm
+from phc.quaternion.activations import get_module_activation
+
+
+class PHMDownstreamNet(nn.Module):
+    def __init__(self, in_features: int, phm_dim: int, phm_rule, hidden_layers: list, out_features: int,
+                 activation: str, bias: bool, norm: str, w_init: str, c_init: str, dropout: Union[float, list],
+                 learn_phm: bool = True, same_dropout: bool = False, real_trafo: str = "linear") -> None:
+        super().__init__()
+        self.in_features = in_features
+        self.out_features = out_features
+        self.learn_phm = learn_phm
+        self.phm_rule = phm_rule
+        self.phm_dim = phm_dim
+        self.hidden_layers = hidden_layers
+        self.activation_str = activation
+        self.activation_func = get_module_activation(activation)
+        self.w_init = w_init
+        self.c_init = c_init
+        self.bias = bias
+        self.dropout = [dropout] * len(hidden_layers) if isinstance(dropout, float) else dropout
+        assert len(self.dropout) == len(self.hidden_layers), "dropout list must be of the same size " \
+                                                             "as number of hidden layer"
+        self.norm_type = norm
+        self.same_dropout = same_dropout
+
+        widths = [in_features] + list(hidden_layers) + [phm_dim * out_features]
+        self.affine = nn.ModuleList([
+            PHMLinear(in_features=widths[i], out_features=widths[i + 1], phm_dim=phm_dim, phm_rule=phm_rule,
+                      learn_phm=learn_phm, bias=bias, w_init=w_init, c_init=c_init)
+            for i in range(len(widths) - 1)])
+        self.real_trafo_type = real_trafo
+        self.real_trafo = RealTransformer(type=real_trafo, in_features=phm_dim * out_features, phm_dim=phm_dim, bias=True)
+        self.norm_flag = bool(self.norm_type)
+        if self.norm_flag:
+            self.norm = nn.ModuleList([PHMNorm(num_features=d, phm_dim=phm_dim, type=self.norm_type)
+                                       for d in hidden_layers])
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        for module in self.affine:
+            module.reset_parameters()
+        if self.norm_flag:
+            for module in self.norm:
+                module.reset_parameters()
+        self.real_trafo.reset_parameters()
+
+    def forward(self, x: torch.Tensor, verbose=False, **kwargs) -> torch.Tensor:
+        last = len(self.affine) - 1
+        for i, layer in enumerate(self.affine):
+            x = layer(x)
+            if verbose:
+                print(f"layer {i}: {layer} -> {tuple(x.shape)}")
+            if i == last:
+                break
+            if self.norm_flag:
+                x = self.norm[i](x, **kwargs)
+            x = self.activation_func(x)
+            if self.training and self.dropout[i] > 0.0:
+                x = phm_dropout(x, p=self.dropout[i], phm_dim=self.phm_dim, training=self.training,
+                                same=self.same_dropout)
+        return self.real_trafo(x)
+
+    def __repr__(self):
+        return "{}(in_features={}, phm_dim={}, phm_rule={}, hidden_layers={}, out_features={}, activation='{}', " \
+               "bias={}, norm='{}', w_init='{}', c_init='{}', dropout={}, learn_phm={}, same_dropout={}, " \
+               "real_trafo='{}')".format(self.__class__.__name__, self.in_features, self.phm_dim, self.phm_rule,
+                                         self.hidden_layers, self.out_features, self.activation_str, self.bias,
+                                         self.norm_type, self.w_init, self.c_init, self.dropout, self.learn_phm,
+                                         self.same_dropout, self.real_trafo_type)

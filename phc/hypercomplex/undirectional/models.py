@@ -1,0 +1,196 @@
+"""Graph-property models (reference: phc/hypercomplex/undirectional/models.py).
+
+``PHMSkipConnectAdd`` is the harness BASELINE.json's metric is measured
+through: encoders -> L x [conv -> norm -> activation -> dropout -> + skip] ->
+pooling -> downstream head.  Sub-module names (``atomencoder``,
+``bondencoders``, ``convs``, ``norms``, ``pooling``, ``downstream``) are read by
+the training scripts (benchmarks/train_hiv.py:266-282) and are preserved."""
+from typing import Optional, Union
+
+import torch
+import torch.nn as nn
+
+from phc.hypercomplex.downstream import PHMDownstreamNet
+from phc.hypercomplex.encoder import NaivePHMEncoder, PHMEncoder
+from phc.hypercomplex.layers import phm_dropout
+from phc.hypercomplex.norm import PHMNorm
+from phc.hypercomplex.pooling import PHMGlobalSumPooling, PHMSoftAttentionPooling
+from phc.hypercomplex.undirectional.messagepassing import PHMMessagePassing
+from phc.hypercomplex.utils import get_multiplication_matrices
+from phc.quaternion.activations import get_module_activation
+
+# ogb 1.2.4 feature vocabularies (ogb.utils.features.get_{atom,bond}_feature_dims);
+# the reference imports them from ogb at module import time (ref :18-21).
+ATOM_FEAT_DIMS = [119, 4, 12, 12, 10, 6, 6, 2, 2]
+BOND_FEAT_DIMS = [5, 6, 2]
+
+
+class PHMSkipConnectAdd(nn.Module):
+    """Undirectional message-passing network with additive skip connections."""
+
+    def __init__(self, phm_dim: int = 4, learn_phm: bool = True, phm_rule=None,
+                 atom_input_dims: Union[int, list] = ATOM_FEAT_DIMS, atom_encoded_dim: int = 196,
+                 bond_input_dims: Union[int, list] = BOND_FEAT_DIMS, naive_encoder: bool = False,
+                 w_init: str = "phm", c_init: str = "standard", same_dropout: bool = False,
+                 mp_layers: list = [196, 196, 196], bias: bool = True, dropout_mpnn: list = [0.0, 0.0, 0.0],
+                 norm_mp: Optional[str] = "naive-batch-norm", add_self_loops: bool = True, msg_aggr: str = "add",
+                 node_aggr: str = "sum", mlp: bool = False, pooling: str = "softattention",
+                 activation: str = "relu", real_trafo: str = "linear", downstream_layers: list = [256, 128],
+                 target_dim: int = 1, dropout_dn: Union[list, float] = [0.2, 0.1],
+                 norm_dn: Optional[str] = "naive-batch-norm", msg_encoder: str = "identity",
+                 sc_type: str = "first", **kwargs) -> None:
+        super().__init__()
+        assert all(x == atom_encoded_dim == mp_layers[0] for x in mp_layers), "dimensionalities need to match for model"
+        assert activation.lower() in ["relu", "lrelu", "elu", "selu", "swish"]
+        assert len(dropout_mpnn) == len(mp_layers)
+        assert pooling in ["globalsum", "softattention"], f"pooling variable '{pooling}' wrong."
+        assert norm_mp in [None, "naive-batch-norm", "None", "naive-naive-batch-norm"]
+        assert norm_dn in [None, "naive-batch-norm", "None", "naive-naive-batch-norm"]
+        assert w_init in ["phm", "glorot_uniform", "glorot_normal"], f"w_init variable '{w_init}' wrong."
+        assert c_init in ["standard", "random"], f"c_init variable '{c_init}' wrong."
+        assert sc_type in ["first", "last"], f"sc_type variable '{sc_type}' wrong."
+
+        if msg_aggr == "sum":
+            msg_aggr = "add"
+        self.msg_encoder_str = msg_encoder
+        self.phm_rule = phm_rule
+        self.variable_phm = phm_rule is None
+        self.phm_dim = phm_dim
+        self.learn_phm = learn_phm
+        self.atom_input_dims = atom_input_dims
+        self.bond_input_dims = bond_input_dims
+        self.atom_encoded_dim = atom_encoded_dim // phm_dim          # per component, as in the reference (:72)
+        self.naive_encoder = naive_encoder
+        self.w_init = w_init
+        self.c_init = c_init
+        self.same_dropout = same_dropout
+        self.mp_layers = mp_layers
+        self.bias = bias
+        self.dropout_mpnn = dropout_mpnn
+        self.norm_mp = None if norm_mp == "None" else norm_mp
+        self.add_self_loops = add_self_loops
+        self.msg_aggr_type = msg_aggr
+        self.node_aggr_type = node_aggr
+        self.mlp_mp = mlp
+        self.pooling_type = pooling
+        self.activation_str = activation
+        self.real_trafo_type = real_trafo
+        self.downstream_layers = downstream_layers
+        self.target_dim = target_dim
+        self.dropout_dn = dropout_dn
+        self.norm_dn_type = None if norm_dn == "None" else norm_dn
+        self.input_dim = atom_encoded_dim
+        self.f_act = get_module_activation(self.activation_str)
+        self.sc_type = sc_type
+        # registration order follows the reference (convs, norms, encoders, pooling, downstream)
+        # so that parameters() / state_dict() enumerate identically
+        self.convs = nn.ModuleList()
+        self.norms = nn.ModuleList()
+
+        Encoder = NaivePHMEncoder if naive_encoder else PHMEncoder
+        self.atomencoder = Encoder(out_dim=self.atom_encoded_dim, input_dims=atom_input_dims, phm_dim=phm_dim,
+                                   combine="sum")
+        self.bondencoders = nn.ModuleList([Encoder(out_dim=d // phm_dim, input_dims=bond_input_dims,
+                                                   phm_dim=phm_dim, combine="sum") for d in mp_layers])
+        for i, out_dim in enumerate(mp_layers):
+            in_dim = self.input_dim if i == 0 else mp_layers[i - 1]
+            self.convs.append(PHMMessagePassing(in_features=in_dim, out_features=out_dim, bias=bias, phm_dim=phm_dim,
+                                           learn_phm=learn_phm, phm_rule=self.phm_rule, norm=self.norm_mp,
+                                           activation=activation, w_init=w_init, c_init=c_init, aggr=msg_aggr,
+                                           mlp=mlp, add_self_loops=add_self_loops, same_dim=True,
+                                           msg_encoder=msg_encoder, **kwargs))
+            self.norms.append(PHMNorm(num_features=out_dim, phm_dim=phm_dim, type=norm_mp) if self.norm_mp else None)
+
+        if pooling == "globalsum":
+            self.pooling = PHMGlobalSumPooling(phm_dim=phm_dim)
+        else:
+            self.pooling = PHMSoftAttentionPooling(embed_dim=mp_layers[-1], phm_dim=phm_dim, learn_phm=learn_phm,
+                                                   phm_rule=self.phm_rule, w_init=w_init, c_init=c_init, bias=bias,
+                                                   real_trafo=real_trafo)
+        self.downstream = PHMDownstreamNet(in_features=mp_layers[-1], hidden_layers=downstream_layers,
+                                           out_features=target_dim, phm_rule=self.phm_rule, phm_dim=phm_dim,
+                                           learn_phm=learn_phm, activation=activation, bias=bias,
+                                           norm=self.norm_dn_type, w_init=w_init, c_init=c_init, dropout=dropout_dn,
+                                           same_dropout=same_dropout, real_trafo=real_trafo)
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        if not self.variable_phm:
+            for i, init in enumerate(get_multiplication_matrices(phm_dim=self.phm_dim)):
+                self.phm_rule[i].data = init
+        self.atomencoder.reset_parameters()
+        for enc in self.bondencoders:
+            enc.reset_parameters()
+        for conv, norm in zip(self.convs, self.norms):
+            conv.reset_parameters()
+            if norm is not None:
+                norm.reset_parameters()
+        self.pooling.reset_parameters()
+        self.downstream.reset_parameters()
+
+    def get_number_of_params_(self) -> int:
+        return sum(p.numel() for p in self.parameters() if p.requires_grad)
+
+    def compute_hidden_layer_embedding(self, conv, norm, x, edge_index, edge_attr, dropout_mpnn: float,
+                                       size=None, edge_encoder=None) -> torch.Tensor:
+        """x = [input of the conv, skip tensor]   (ref :200-217).  With ``edge_encoder`` given,
+        ``edge_attr`` holds the raw integer bond features and the embedding is evaluated
+        inside the aggregation kernel."""
+        if edge_encoder is not None:
+            h = conv.forward_encoded(x[0], edge_index, edge_attr, edge_encoder, size)
+        else:
+            h = conv(x=x[0], edge_index=edge_index, edge_attr=edge_attr, size=size)
+        if norm is not None:
+            h = norm(h)
+        h = self.f_act(h)
+        h = phm_dropout(x=h, p=dropout_mpnn, phm_dim=self.phm_dim, training=self.training, same=self.same_dropout)
+        return h + x[1]
+
+    def forward(self, data, size=None) -> torch.Tensor:
+        x, edge_index, edge_attr, batch = data.x, data.edge_index, data.edge_attr, data.batch
+        if isinstance(self.bond_input_dims, list):
+            edge_attr = edge_attr.to(torch.long)
+        atom = self.atomencoder(x)
+        atom = atom.reshape(atom.size(0), self.phm_dim * self.atom_encoded_dim)     # component-major [N, h]
+        h = atom
+        for i in range(len(self.mp_layers)):
+            skip = atom if (i == 0 or self.sc_type == "first") else h
+            enc = self.bondencoders[i]
+            if getattr(enc, "engine_tables", None) is not None:
+                # integer bond features: embedding fused into the aggregation (no [E, h] tensor)
+                h = self.compute_hidden_layer_embedding(conv=self.convs[i], norm=self.norms[i], x=[h, skip],
+                                                        edge_index=edge_index, edge_attr=edge_attr,
+                                                        dropout_mpnn=self.dropout_mpnn[i], size=size, edge_encoder=enc)
+                continue
+            e = enc(edge_attr)
+            e = e.reshape(e.size(0), self.mp_layers[i])
+            h = self.compute_hidden_layer_embedding(conv=self.convs[i], norm=self.norms[i], x=[h, skip],
+                                                    edge_index=edge_index, edge_attr=e,
+                                                    dropout_mpnn=self.dropout_mpnn[i], size=size)
+        num_graphs = getattr(data, "num_graphs", None)
+        out = self.pooling(x=h, batch=batch, num_graphs=num_graphs)
+        return self.downstream(out)
+
+    def __repr__(self):
+        return "{}(phm_dim={}, learn_phm={}, phm_rule={}, atom_input_dim={}, atom_encoded_dim={}, " \
+               "bond_input_dims={}, naive_encoder={}, w_init='{}', c_init='{}', same_dropout={}, mp_layers={}, " \
+               "bias={}, dropout_mpnn={}, norm_mp='{}', add_self_loops={}, msg_aggr='{}', node_aggr={}, mlp={}, " \
+               "pooling='{}', activation='{}', real_trafo='{}', downstream_layers={}, target_dim={}, " \
+               "dropout_dn={}, norm_dn={})".format(
+                   self.__class__.__name__, self.phm_dim, self.learn_phm, self.phm_rule, self.atom_input_dims,
+                   self.atom_encoded_dim, self.bond_input_dims, self.naive_encoder, self.w_init, self.c_init,
+                   self.same_dropout, self.mp_layers, self.bias, self.dropout_mpnn, self.norm_mp,
+                   self.add_self_loops, self.msg_aggr_type, self.node_aggr_type, self.mlp_mp, self.pooling_type,
+                   self.activation_str, self.real_trafo_type, self.downstream_layers, self.target_dim,
+                   self.dropout_dn, self.norm_dn_type)
+
+
+class PHMSkipConnectConcat(nn.Module):
+    """Import-compatibility stub (benchmarks/train_hiv.py:32-33 imports the name):
+    the concatenating variant uses the same kernels at different widths and is
+    not part of BASELINE.json's configs."""
+
+    def __init__(self, *args, **kwargs):
+        super().__init__()
+        raise NotImplementedError("PHMSkipConnectConcat is not provided by phc_gnn_amd yet; "
+                                  "use PHMSkipConnectAdd (--type undirectional-phm-sc-add)")

@@ -1,0 +1,511 @@
+// Integer-feature encoders fused into the message-passing path.
+//
+// Reference: PHMEncoder = phm_dim independent IntegerEncoders, each a sum of
+// nn.Embedding lookups (phc/hypercomplex/encoder.py:31-34,
+// phc/quaternion/encoder.py:43-51); the model materialises the [E, h] bond
+// embedding of every layer (models.py:238-240) and autograd runs one
+// embedding_dense_backward (a device sort!) per table — 84 of them per step.
+//
+// Here the n*F tiny tables are read in place through a device pointer array:
+//   * encode_fwd           : out[i] = sum_f T_f[idx[i,f]]            (atoms)
+//   * aggregate_enc_fwd    : the aggregation kernel with edge features looked up
+//                            from LDS-staged tables — the [E, h] tensor never exists
+//   * table_grad + reduce  : dT[r] = sum of the gradient rows that used table row r,
+//                            accumulated in LDS by column-owning threads (no atomics
+//                            between threads, fixed order => reproducible), then a
+//                            fixed-order slab reduction into ONE flat gradient buffer
+//                            laid out [c][f][V_f][k] (the per-table grads are views).
+#include "phc_common.h"
+
+namespace phc {
+
+constexpr int ENC_MAX_F = PHC_MAX_ENC_FEATS;
+constexpr int ENC_THREADS = 256;
+
+struct EncMeta {
+    int F;
+    int R;                       // total table rows = sum_f V_f
+    int off[ENC_MAX_F + 1];      // row offset of feature f in the packed row space
+};
+
+__device__ __forceinline__ float4 ld4(const float *p) { return *reinterpret_cast<const float4 *>(p); }
+__device__ __forceinline__ void acc4(float4 &a, const float4 b) { a.x += b.x; a.y += b.y; a.z += b.z; a.w += b.w; }
+
+// ---- atoms: out[i, c*k+kap] = sum_f T_{c,f}[idx[i,f]][kap] --------------------------------
+// LPR lanes cover one output row with float4 columns; 64/LPR nodes per wavefront.
+template <int LPR>
+__global__ __launch_bounds__(ENC_THREADS) void encode_fwd_kernel(const long long *__restrict__ idx,
+                                                                const float *const *__restrict__ tables, long long N,
+                                                                int F, int n, int k, float *__restrict__ out) {
+    constexpr int G = WAVE / LPR;
+    const int lane = threadIdx.x & 63;
+    const int grp = lane / LPR, li = lane - grp * LPR;
+    const long long wave_id = ((long long)blockIdx.x * ENC_THREADS + threadIdx.x) >> 6;
+    const long long n_waves = ((long long)gridDim.x * ENC_THREADS) >> 6;
+    const int h = n * k, h4 = h >> 2;
+    for (long long base = wave_id * G; base < N; base += n_waves * G) {
+        const long long i = base + grp;
+        if (i >= N) continue;
+        for (int c4 = li; c4 < h4; c4 += LPR) {
+            const int col = c4 << 2;
+            const int c = col / k, kap = col - c * k;
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int f = 0; f < F; ++f) {
+                const long long v = idx[i * F + f];
+                acc4(acc, ld4(tables[c * F + f] + v * k + kap));
+            }
+            reinterpret_cast<float4 *>(out + (size_t)i * h)[c4] = acc;
+        }
+    }
+}
+
+__global__ __launch_bounds__(ENC_THREADS) void encode_fwd_scalar_kernel(const long long *__restrict__ idx,
+                                                                       const float *const *__restrict__ tables,
+                                                                       long long N, int F, int n, int k,
+                                                                       float *__restrict__ out) {
+    const int h = n * k;
+    const long long total = N * h;
+    for (long long e = (long long)blockIdx.x * ENC_THREADS + threadIdx.x; e < total; e += (long long)gridDim.x * ENC_THREADS) {
+        const long long i = e / h;
+        const int col = (int)(e - i * h);
+        const int c = col / k, kap = col - c * k;
+        float acc = 0.f;
+        for (int f = 0; f < F; ++f) acc += tables[c * F + f][idx[i * F + f] * k + kap];
+        out[e] = acc;
+    }
+}
+
+// ---- fused aggregation with table-encoded edge features -------------------------------------
+// out[d] = sum_{e in row d} phi( x[col[e]] + sum_f T_f[bond[perm[e], f]] ) (+ x[d])
+template <int LPR, int ACT>
+__global__ __launch_bounds__(ENC_THREADS) void aggregate_enc_fwd_kernel(
+    const float *__restrict__ x, const long long *__restrict__ bond, const float *const *__restrict__ tables, EncMeta m,
+    const int *__restrict__ rowptr, const int *__restrict__ col, const int *__restrict__ perm, long long n_dst, int n, int k,
+    int add_self, float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float tbl[];      // [R][h], component-major columns
+    const int h = n * k, h4 = h >> 2;
+    for (int e = threadIdx.x; e < m.R * h; e += ENC_THREADS) {
+        const int r = e / h, cidx = e - r * h;
+        const int c = cidx / k, kap = cidx - c * k;
+        int f = 0;
+        while (f + 1 < m.F && r >= m.off[f + 1]) ++f;
+        tbl[e] = tables[c * m.F + f][(size_t)(r - m.off[f]) * k + kap];
+    }
+    __syncthreads();
+
+    constexpr int G = WAVE / LPR;
+    const int lane = threadIdx.x & 63;
+    const int grp = lane / LPR, li = lane - grp * LPR;
+    const long long wave_id = ((long long)blockIdx.x * ENC_THREADS + threadIdx.x) >> 6;
+    const long long n_waves = ((long long)gridDim.x * ENC_THREADS) >> 6;
+    const int F = m.F;
+
+    for (long long d = wave_id; d < n_dst; d += n_waves) {
+        const int e_begin = rowptr[d], e_end = rowptr[d + 1];
+        for (int c4 = li; c4 < h4; c4 += LPR) {
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int e = e_begin + grp; e < e_end; e += G) {
+                const int s = col[e];
+                const long long p = perm[e];
+                float4 v = reinterpret_cast<const float4 *>(x + (size_t)s * h)[c4];
+                for (int f = 0; f < F; ++f) {
+                    const int r = m.off[f] + (int)bond[p * F + f];
+                    acc4(v, reinterpret_cast<const float4 *>(tbl + r * h)[c4]);
+                }
+                acc.x += act_fwd<ACT>(v.x); acc.y += act_fwd<ACT>(v.y);
+                acc.z += act_fwd<ACT>(v.z); acc.w += act_fwd<ACT>(v.w);
+            }
+#pragma unroll
+            for (int off = LPR; off < WAVE; off <<= 1) {
+                acc.x += __shfl_xor(acc.x, off, WAVE); acc.y += __shfl_xor(acc.y, off, WAVE);
+                acc.z += __shfl_xor(acc.z, off, WAVE); acc.w += __shfl_xor(acc.w, off, WAVE);
+            }
+            if (grp == 0) {
+                if (add_self) acc4(acc, reinterpret_cast<const float4 *>(x + (size_t)d * h)[c4]);
+                reinterpret_cast<float4 *>(out + (size_t)d * h)[c4] = acc;
+            }
+        }
+    }
+}
+
+// dx of the fused aggregation (source-sorted walk): dx[s] = sum_{e out of s} phi'(x[s] + enc_e) * dout[dst_e] (+ dout[s])
+template <int LPR, int ACT>
+__global__ __launch_bounds__(ENC_THREADS) void aggregate_enc_dx_kernel(
+    const float *__restrict__ dout, const float *__restrict__ x, const long long *__restrict__ bond,
+    const float *const *__restrict__ tables, EncMeta m, const int *__restrict__ rowptr_t, const int *__restrict__ col_t,
+    const int *__restrict__ perm_t, long long n_src, long long n_dst, int n, int k, int add_self, float *__restrict__ dx) {
+    extern __shared__ __attribute__((aligned(16))) float tbl[];
+    const int h = n * k, h4 = h >> 2;
+    if (ACT != PHC_ACT_IDENTITY) {
+        for (int e = threadIdx.x; e < m.R * h; e += ENC_THREADS) {
+            const int r = e / h, cidx = e - r * h;
+            const int c = cidx / k, kap = cidx - c * k;
+            int f = 0;
+            while (f + 1 < m.F && r >= m.off[f + 1]) ++f;
+            tbl[e] = tables[c * m.F + f][(size_t)(r - m.off[f]) * k + kap];
+        }
+        __syncthreads();
+    }
+    constexpr int G = WAVE / LPR;
+    const int lane = threadIdx.x & 63;
+    const int grp = lane / LPR, li = lane - grp * LPR;
+    const long long wave_id = ((long long)blockIdx.x * ENC_THREADS + threadIdx.x) >> 6;
+    const long long n_waves = ((long long)gridDim.x * ENC_THREADS) >> 6;
+    const int F = m.F;
+    for (long long s = wave_id; s < n_src; s += n_waves) {
+        const int e_begin = rowptr_t[s], e_end = rowptr_t[s + 1];
+        for (int c4 = li; c4 < h4; c4 += LPR) {
+            float4 xs = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (ACT != PHC_ACT_IDENTITY) xs = reinterpret_cast<const float4 *>(x + (size_t)s * h)[c4];
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int e = e_begin + grp; e < e_end; e += G) {
+                float4 g = reinterpret_cast<const float4 *>(dout + (size_t)col_t[e] * h)[c4];
+                if (ACT != PHC_ACT_IDENTITY) {
+                    const long long p = perm_t[e];
+                    float4 pre = xs;
+                    for (int f = 0; f < F; ++f)
+                        acc4(pre, reinterpret_cast<const float4 *>(tbl + (m.off[f] + (int)bond[p * F + f]) * h)[c4]);
+                    g.x *= act_grad<ACT>(pre.x); g.y *= act_grad<ACT>(pre.y);
+                    g.z *= act_grad<ACT>(pre.z); g.w *= act_grad<ACT>(pre.w);
+                }
+                acc4(acc, g);
+            }
+#pragma unroll
+            for (int off = LPR; off < WAVE; off <<= 1) {
+                acc.x += __shfl_xor(acc.x, off, WAVE); acc.y += __shfl_xor(acc.y, off, WAVE);
+                acc.z += __shfl_xor(acc.z, off, WAVE); acc.w += __shfl_xor(acc.w, off, WAVE);
+            }
+            if (grp == 0) {
+                if (add_self && s < n_dst) acc4(acc, reinterpret_cast<const float4 *>(dout + (size_t)s * h)[c4]);
+                reinterpret_cast<float4 *>(dx + (size_t)s * h)[c4] = acc;
+            }
+        }
+    }
+}
+
+// ---- table gradients ---------------------------------------------------------------------------
+// Every thread owns one column j (and row-lane q); it walks its rows in order and adds the
+// gradient value into its own LDS cell tbl[q][r][j] — no two threads ever touch the same cell.
+//   MODE 0 (atoms): row i contributes dout[i] to rows off_f + idx[i,f], f < F.
+//   MODE 1 (bonds): destination d contributes, for each in-edge e, g_e = phi'(..) * dout[d]
+//                   to rows off_f + bond[perm[e], f].
+// grid.x = slabs (row ranges), grid.y = table-row tiles; slab[b][r][j] partial tables.
+template <int MODE, int ACT>
+__global__ __launch_bounds__(ENC_THREADS) void table_grad_kernel(
+    const float *__restrict__ dout, const long long *__restrict__ idx, EncMeta m, long long n_rows, long long rows_per_block,
+    int h, int r_tile, const int *__restrict__ rowptr, const int *__restrict__ col, const int *__restrict__ perm,
+    const float *__restrict__ x, const float *const *__restrict__ tables, int n, int k, float *__restrict__ slabs) {
+    extern __shared__ __attribute__((aligned(16))) float tbl[];      // [Q][r_tile][h]
+    const int tid = threadIdx.x;
+    const int Q = h >= ENC_THREADS ? 1 : ENC_THREADS / h;
+    const int q = h >= ENC_THREADS ? 0 : tid / h;
+    const int j0 = h >= ENC_THREADS ? tid : tid - q * h;
+    const int jstep = h >= ENC_THREADS ? ENC_THREADS : h;
+    const bool active = q < Q;
+    const int r_lo = blockIdx.y * r_tile;
+    const int r_hi = min(m.R, r_lo + r_tile);
+    const int F = m.F;
+    for (int e = tid; e < Q * r_tile * h; e += ENC_THREADS) tbl[e] = 0.f;
+    __syncthreads();
+
+    const long long i_begin = blockIdx.x * rows_per_block;
+    const long long i_end = min(n_rows, i_begin + rows_per_block);
+    if (active) {
+        float *mytbl = tbl + (size_t)q * r_tile * h;
+        for (long long i = i_begin + q; i < i_end; i += Q) {
+            if (MODE == 0) {
+                for (int j = j0; j < h; j += jstep) {
+                    const float g = dout[(size_t)i * h + j];
+                    for (int f = 0; f < F; ++f) {
+                        const int r = m.off[f] + (int)idx[i * F + f];
+                        if (r >= r_lo && r < r_hi) mytbl[(r - r_lo) * h + j] += g;
+                    }
+                }
+            } else {
+                const int e_begin = rowptr[i], e_end = rowptr[i + 1];
+                for (int j = j0; j < h; j += jstep) {
+                    const float gd = dout[(size_t)i * h + j];
+                    const int c = j / k, kap = j - c * k;
+                    for (int e = e_begin; e < e_end; ++e) {
+                        const long long p = perm[e];
+                        float g = gd;
+                        if (ACT != PHC_ACT_IDENTITY) {
+                            float pre = x[(size_t)col[e] * h + j];
+                            for (int f = 0; f < F; ++f) pre += tables[c * F + f][(size_t)idx[p * F + f] * k + kap];
+                            g *= act_grad<ACT>(pre);
+                        }
+                        for (int f = 0; f < F; ++f) {
+                            const int r = m.off[f] + (int)idx[p * F + f];
+                            if (r >= r_lo && r < r_hi) mytbl[(r - r_lo) * h + j] += g;
+                        }
+                    }
+                }
+            }
+        }
+    }
+    __syncthreads();
+    float *slab = slabs + ((size_t)blockIdx.x * m.R + r_lo) * h;
+    const int rows = r_hi - r_lo;
+    for (int e = tid; e < rows * h; e += ENC_THREADS) {
+        float s = 0.f;
+        for (int qq = 0; qq < Q; ++qq) s += tbl[(size_t)qq * r_tile * h + e];
+        slab[e] = s;
+    }
+}
+
+// flat[c][r][kap] = sum_b slab[b][r][c*k+kap]    (flat is [c][f][V_f][k] because r = off_f + v)
+__global__ void table_grad_reduce_kernel(const float *__restrict__ slabs, int num_slabs, int R, int n, int k,
+                                         float *__restrict__ flat) {
+    const int h = n * k;
+    const int e = blockIdx.x * blockDim.x + threadIdx.x;
+    if (e >= R * h) return;
+    float s = 0.f;
+    for (int b = 0; b < num_slabs; ++b) s += slabs[(size_t)b * R * h + e];
+    const int r = e / h, j = e - r * h;
+    const int c = j / k, kap = j - c * k;
+    flat[((size_t)c * R + r) * k + kap] = s;
+}
+
+// ---- host helpers ---------------------------------------------------------------------------------
+static int make_meta(const char *who, int F, const int32_t *vocab, EncMeta *m) {
+    PHC_REQUIRE(F >= 1 && F <= ENC_MAX_F, PHC_ERR_UNSUPPORTED, "%s: %d features (max %d)", who, F, ENC_MAX_F);
+    PHC_REQUIRE(vocab, PHC_ERR_INVALID_ARG, "%s: vocab is null", who);
+    m->F = F;
+    m->off[0] = 0;
+    for (int f = 0; f < F; ++f) {
+        PHC_REQUIRE(vocab[f] >= 1, PHC_ERR_INVALID_ARG, "%s: vocab[%d] = %d", who, f, vocab[f]);
+        m->off[f + 1] = m->off[f] + vocab[f];
+    }
+    m->R = m->off[F];
+    return PHC_OK;
+}
+
+struct TgPlan {
+    int r_tile, r_tiles, num_slabs, Q;
+    long long rows_per_block;
+    size_t lds_bytes, slab_floats;
+};
+
+static TgPlan tg_plan(long long n_rows, int R, int h) {
+    TgPlan p;
+    p.Q = h >= ENC_THREADS ? 1 : ENC_THREADS / h;
+    const size_t lds_budget = 64 * 1024;
+    int r_tile = (int)(lds_budget / (sizeof(float) * (size_t)p.Q * h));
+    if (r_tile < 1) r_tile = 1;
+    if (r_tile > R) r_tile = R;
+    p.r_tile = r_tile;
+    p.r_tiles = (R + r_tile - 1) / r_tile;
+    p.lds_bytes = sizeof(float) * (size_t)p.Q * r_tile * h;
+    // slabs: as many row ranges as keep the partial tables around 4 MB, at least 64 rows each
+    long long slabs = (long long)((4u << 20) / (sizeof(float) * (size_t)R * h));
+    if (slabs > 256) slabs = 256;
+    if (slabs < 8) slabs = 8;
+    long long rpb = (n_rows + slabs - 1) / slabs;
+    if (rpb < 64) rpb = 64;
+    p.rows_per_block = rpb;
+    p.num_slabs = (int)((n_rows + rpb - 1) / rpb);
+    if (p.num_slabs < 1) p.num_slabs = 1;
+    p.slab_floats = (size_t)p.num_slabs * R * h;
+    return p;
+}
+
+static inline bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+static inline int lpr_for(int h4) { return h4 <= 8 ? 8 : h4 <= 16 ? 16 : h4 <= 32 ? 32 : 64; }
+
+template <int MODE>
+static int launch_table_grad(const float *dout, const long long *idx, const EncMeta &m, long long n_rows, int h, int n, int k,
+                             int act, const int *rowptr, const int *col, const int *perm, const float *x,
+                             const float *const *tables, float *flat, void *ws, size_t ws_bytes, hipStream_t s,
+                             const char *who) {
+    TgPlan p = tg_plan(n_rows, m.R, h);
+    PHC_REQUIRE(ws && ws_bytes >= sizeof(float) * p.slab_floats, PHC_ERR_WORKSPACE, "%s: workspace %zu B < required %zu B",
+                who, ws_bytes, sizeof(float) * p.slab_floats);
+    float *slabs = static_cast<float *>(ws);
+    dim3 grid(p.num_slabs, p.r_tiles);
+#define PHC_TG_LAUNCH(ACTC)                                                                                             \
+    hipLaunchKernelGGL((table_grad_kernel<MODE, ACTC>), grid, dim3(ENC_THREADS), p.lds_bytes, s, dout, idx, m, n_rows,    \
+                       p.rows_per_block, h, p.r_tile, rowptr, col, perm, x, tables, n, k, slabs)
+    {
+        ProfScope prof(K_TABLE_GRAD, s);
+        if (MODE == 0 || act == PHC_ACT_IDENTITY) {
+            PHC_TG_LAUNCH(PHC_ACT_IDENTITY);
+        } else {
+            switch (act) {
+                case PHC_ACT_RELU: PHC_TG_LAUNCH(PHC_ACT_RELU); break;
+                case PHC_ACT_LRELU: PHC_TG_LAUNCH(PHC_ACT_LRELU); break;
+                case PHC_ACT_ELU: PHC_TG_LAUNCH(PHC_ACT_ELU); break;
+                case PHC_ACT_SWISH: PHC_TG_LAUNCH(PHC_ACT_SWISH); break;
+                default: PHC_TG_LAUNCH(PHC_ACT_SELU); break;
+            }
+        }
+        int rc = check_launch(who);
+        if (rc) return rc;
+    }
+#undef PHC_TG_LAUNCH
+    ProfScope prof(K_TABLE_GRAD_REDUCE, s);
+    hipLaunchKernelGGL(table_grad_reduce_kernel, dim3((m.R * h + 255) / 256), dim3(256), 0, s, slabs, p.num_slabs, m.R, n, k,
+                       flat);
+    return check_launch(who);
+}
+
+}  // namespace phc
+
+using namespace phc;
+
+extern "C" {
+
+int phc_encode_fwd(const int64_t *idx_i64, const float *const *tables, int64_t N, int F, int n, int k, float *out,
+                   void *stream) {
+    PHC_REQUIRE(N >= 0 && F >= 1 && n >= 1 && k >= 1, PHC_ERR_INVALID_ARG, "phc_encode_fwd: N=%lld F=%d n=%d k=%d", (long long)N,
+                F, n, k);
+    if (N == 0) return PHC_OK;
+    PHC_REQUIRE(idx_i64 && tables && out, PHC_ERR_INVALID_ARG, "phc_encode_fwd: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    const int h = n * k;
+    ProfScope prof(K_ENCODE_FWD, s);
+    if (k % 4 == 0 && al16(out)) {
+        const int lpr = lpr_for(h >> 2);
+        const int G = 64 / lpr;
+        long long blocks = (N + 4 * G - 1) / (4 * G);
+        if (blocks > 4096) blocks = 4096;
+        const long long *idx = reinterpret_cast<const long long *>(idx_i64);
+        switch (lpr) {
+            case 8: hipLaunchKernelGGL((encode_fwd_kernel<8>), dim3((unsigned)blocks), dim3(ENC_THREADS), 0, s, idx, tables, (long long)N, F, n, k, out); break;
+            case 16: hipLaunchKernelGGL((encode_fwd_kernel<16>), dim3((unsigned)blocks), dim3(ENC_THREADS), 0, s, idx, tables, (long long)N, F, n, k, out); break;
+            case 32: hipLaunchKernelGGL((encode_fwd_kernel<32>), dim3((unsigned)blocks), dim3(ENC_THREADS), 0, s, idx, tables, (long long)N, F, n, k, out); break;
+            default: hipLaunchKernelGGL((encode_fwd_kernel<64>), dim3((unsigned)blocks), dim3(ENC_THREADS), 0, s, idx, tables, (long long)N, F, n, k, out); break;
+        }
+    } else {
+        long long blocks = (N * h + ENC_THREADS - 1) / ENC_THREADS;
+        if (blocks > 4096) blocks = 4096;
+        hipLaunchKernelGGL(encode_fwd_scalar_kernel, dim3((unsigned)blocks), dim3(ENC_THREADS), 0, s,
+                           reinterpret_cast<const long long *>(idx_i64), tables, (long long)N, F, n, k, out);
+    }
+    return check_launch("encode_fwd");
+}
+
+size_t phc_encode_bwd_ws_bytes(int64_t N, int F, const int32_t *vocab, int n, int k) {
+    EncMeta m;
+    if (N < 0 || n < 1 || k < 1 || make_meta("phc_encode_bwd_ws_bytes", F, vocab, &m)) return 0;
+    return sizeof(float) * tg_plan(N, m.R, n * k).slab_floats;
+}
+
+int phc_encode_bwd(const float *dout, const int64_t *idx_i64, int64_t N, int F, const int32_t *vocab, int n, int k,
+                   float *dtables_flat, void *ws, size_t ws_bytes, void *stream) {
+    EncMeta m;
+    int rc = make_meta("phc_encode_bwd", F, vocab, &m);
+    if (rc) return rc;
+    PHC_REQUIRE(N >= 0 && n >= 1 && k >= 1, PHC_ERR_INVALID_ARG, "phc_encode_bwd: N=%lld n=%d k=%d", (long long)N, n, k);
+    PHC_REQUIRE(dtables_flat && (N == 0 || (dout && idx_i64)), PHC_ERR_INVALID_ARG, "phc_encode_bwd: null pointer");
+    return launch_table_grad<0>(dout, reinterpret_cast<const long long *>(idx_i64), m, N, n * k, n, k, PHC_ACT_IDENTITY, nullptr,
+                                nullptr, nullptr, nullptr, nullptr, dtables_flat, ws, ws_bytes, (hipStream_t)stream,
+                                "phc_encode_bwd");
+}
+
+int phc_aggregate_enc_fwd(const float *x, const int64_t *bond_i64, const float *const *tables, const int32_t *vocab,
+                          const int32_t *rowptr, const int32_t *col, const int32_t *perm, int64_t n_dst, int F, int n, int k,
+                          int act, int add_self, float *out, void *stream) {
+    EncMeta m;
+    int rc = make_meta("phc_aggregate_enc_fwd", F, vocab, &m);
+    if (rc) return rc;
+    PHC_REQUIRE(n_dst >= 0 && n >= 1 && k >= 1, PHC_ERR_INVALID_ARG, "phc_aggregate_enc_fwd: bad sizes");
+    PHC_REQUIRE(act >= PHC_ACT_IDENTITY && act <= PHC_ACT_SELU, PHC_ERR_INVALID_ARG, "phc_aggregate_enc_fwd: unknown activation %d", act);
+    if (n_dst == 0) return PHC_OK;
+    PHC_REQUIRE(x && bond_i64 && tables && rowptr && col && perm && out, PHC_ERR_INVALID_ARG, "phc_aggregate_enc_fwd: null pointer");
+    const int h = n * k;
+    const size_t lds = sizeof(float) * (size_t)m.R * h;
+    PHC_REQUIRE(k % 4 == 0 && al16(x) && al16(out), PHC_ERR_UNSUPPORTED, "phc_aggregate_enc_fwd: needs k %% 4 == 0 and 16-byte aligned rows");
+    PHC_REQUIRE(lds <= 48 * 1024, PHC_ERR_UNSUPPORTED, "phc_aggregate_enc_fwd: tables (%zu B) exceed the LDS budget", lds);
+    hipStream_t s = (hipStream_t)stream;
+    long long blocks = (n_dst + 3) / 4;
+    if (blocks > 1024) blocks = 1024;                       // persistent-ish: amortise the LDS table fill
+    const long long *bond = reinterpret_cast<const long long *>(bond_i64);
+    const int lpr = lpr_for(h >> 2);
+    ProfScope prof(K_AGG_ENC_FWD, s);
+#define PHC_AE_LAUNCH(LPRC, ACTC)                                                                                          \
+    hipLaunchKernelGGL((aggregate_enc_fwd_kernel<LPRC, ACTC>), dim3((unsigned)blocks), dim3(ENC_THREADS), lds, s, x, bond,      \
+                       tables, m, rowptr, col, perm, (long long)n_dst, n, k, add_self, out)
+#define PHC_AE_ACT(LPRC)                                            \
+    switch (act) {                                                  \
+        case PHC_ACT_IDENTITY: PHC_AE_LAUNCH(LPRC, PHC_ACT_IDENTITY); break; \
+        case PHC_ACT_RELU: PHC_AE_LAUNCH(LPRC, PHC_ACT_RELU); break;         \
+        case PHC_ACT_LRELU: PHC_AE_LAUNCH(LPRC, PHC_ACT_LRELU); break;       \
+        case PHC_ACT_ELU: PHC_AE_LAUNCH(LPRC, PHC_ACT_ELU); break;           \
+        case PHC_ACT_SWISH: PHC_AE_LAUNCH(LPRC, PHC_ACT_SWISH); break;       \
+        default: PHC_AE_LAUNCH(LPRC, PHC_ACT_SELU); break;                   \
+    }
+    switch (lpr) {
+        case 8: PHC_AE_ACT(8); break;
+        case 16: PHC_AE_ACT(16); break;
+        case 32: PHC_AE_ACT(32); break;
+        default: PHC_AE_ACT(64); break;
+    }
+#undef PHC_AE_ACT
+#undef PHC_AE_LAUNCH
+    return check_launch("aggregate_enc_fwd");
+}
+
+size_t phc_aggregate_enc_bwd_ws_bytes(int64_t n_dst, int F, const int32_t *vocab, int n, int k) {
+    EncMeta m;
+    if (n_dst < 0 || n < 1 || k < 1 || make_meta("phc_aggregate_enc_bwd_ws_bytes", F, vocab, &m)) return 0;
+    return sizeof(float) * tg_plan(n_dst, m.R, n * k).slab_floats;
+}
+
+int phc_aggregate_enc_bwd(const float *dout, const float *x, const int64_t *bond_i64, const float *const *tables,
+                          const int32_t *vocab, const int32_t *rowptr, const int32_t *col, const int32_t *perm,
+                          const int32_t *rowptr_t, const int32_t *col_t, const int32_t *perm_t, int64_t n_src, int64_t n_dst,
+                          int F, int n, int k, int act, int add_self, float *dx, float *dtables_flat, void *ws, size_t ws_bytes,
+                          void *stream) {
+    EncMeta m;
+    int rc = make_meta("phc_aggregate_enc_bwd", F, vocab, &m);
+    if (rc) return rc;
+    PHC_REQUIRE(n_src >= 0 && n_dst >= 0 && n >= 1 && k >= 1, PHC_ERR_INVALID_ARG, "phc_aggregate_enc_bwd: bad sizes");
+    PHC_REQUIRE(act >= PHC_ACT_IDENTITY && act <= PHC_ACT_SELU, PHC_ERR_INVALID_ARG, "phc_aggregate_enc_bwd: unknown activation %d", act);
+    PHC_REQUIRE(dout && bond_i64 && tables, PHC_ERR_INVALID_ARG, "phc_aggregate_enc_bwd: null pointer");
+    PHC_REQUIRE(act == PHC_ACT_IDENTITY || x, PHC_ERR_INVALID_ARG, "phc_aggregate_enc_bwd: x is required when act != identity");
+    const int h = n * k;
+    hipStream_t s = (hipStream_t)stream;
+    const long long *bond = reinterpret_cast<const long long *>(bond_i64);
+    if (dx && n_src > 0) {
+        PHC_REQUIRE(rowptr_t && col_t && perm_t, PHC_ERR_INVALID_ARG, "phc_aggregate_enc_bwd: source-sorted structure missing");
+        PHC_REQUIRE(k % 4 == 0 && al16(dout) && al16(dx) && (!x || al16(x)), PHC_ERR_UNSUPPORTED,
+                    "phc_aggregate_enc_bwd: needs k %% 4 == 0 and 16-byte aligned rows");
+        const size_t lds = act == PHC_ACT_IDENTITY ? 0 : sizeof(float) * (size_t)m.R * h;
+        PHC_REQUIRE(lds <= 48 * 1024, PHC_ERR_UNSUPPORTED, "phc_aggregate_enc_bwd: tables exceed the LDS budget");
+        long long blocks = (n_src + 3) / 4;
+        const long long cap = act == PHC_ACT_IDENTITY ? 8192 : 1024;
+        if (blocks > cap) blocks = cap;
+        const int lpr = lpr_for(h >> 2);
+        ProfScope prof(K_AGG_ENC_DX, s);
+#define PHC_AD_LAUNCH(LPRC, ACTC)                                                                                         \
+    hipLaunchKernelGGL((aggregate_enc_dx_kernel<LPRC, ACTC>), dim3((unsigned)blocks), dim3(ENC_THREADS), lds, s, dout, x, bond, \
+                       tables, m, rowptr_t, col_t, perm_t, (long long)n_src, (long long)n_dst, n, k, add_self, dx)
+#define PHC_AD_ACT(LPRC)                                            \
+    switch (act) {                                                  \
+        case PHC_ACT_IDENTITY: PHC_AD_LAUNCH(LPRC, PHC_ACT_IDENTITY); break; \
+        case PHC_ACT_RELU: PHC_AD_LAUNCH(LPRC, PHC_ACT_RELU); break;         \
+        case PHC_ACT_LRELU: PHC_AD_LAUNCH(LPRC, PHC_ACT_LRELU); break;       \
+        case PHC_ACT_ELU: PHC_AD_LAUNCH(LPRC, PHC_ACT_ELU); break;           \
+        case PHC_ACT_SWISH: PHC_AD_LAUNCH(LPRC, PHC_ACT_SWISH); break;       \
+        default: PHC_AD_LAUNCH(LPRC, PHC_ACT_SELU); break;                   \
+    }
+        switch (lpr) {
+            case 8: PHC_AD_ACT(8); break;
+            case 16: PHC_AD_ACT(16); break;
+            case 32: PHC_AD_ACT(32); break;
+            default: PHC_AD_ACT(64); break;
+        }
+#undef PHC_AD_ACT
+#undef PHC_AD_LAUNCH
+        rc = check_launch("aggregate_enc_dx");
+        if (rc) return rc;
+    }
+    if (dtables_flat) {
+        PHC_REQUIRE(rowptr && col && perm, PHC_ERR_INVALID_ARG, "phc_aggregate_enc_bwd: destination-sorted structure missing");
+        return launch_table_grad<1>(dout, bond, m, n_dst, h, n, k, act, rowptr, col, perm, x, tables, dtables_flat, ws, ws_bytes,
+                                    s, "phc_aggregate_enc_bwd");
+    }
+    return PHC_OK;
+}
+
+}  // extern "C"

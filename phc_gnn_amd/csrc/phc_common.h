@@ -36,6 +36,11 @@ enum KernelId : int {
     K_CSR_SCAN,
     K_CSR_FILL,
     K_CSR_CANON,
+    K_ENCODE_FWD,
+    K_AGG_ENC_FWD,
+    K_AGG_ENC_DX,
+    K_TABLE_GRAD,
+    K_TABLE_GRAD_REDUCE,
     K_NUM_KERNELS
 };
 

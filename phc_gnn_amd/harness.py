@@ -1,0 +1,109 @@
+"""Training-step harness reproducing the reference's ``train()`` inner loop
+(benchmarks/train_hiv.py:165-218) on pre-collated, device-resident synthetic
+batches: zero_grad -> forward -> NaN-masked BCE -> backward -> grad clip -> Adam.
+Shared by bench.py, __graft_entry__.smoke() and the tests."""
+from __future__ import annotations
+
+import types
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn.functional as F
+
+from . import synth
+
+# BASELINE.json configs -> PHMSkipConnectAdd arguments (SURVEY.md §8d "Model settings")
+WORKLOADS: Dict[str, dict] = {
+    # configs[0]: the reference's own CPU-runnable case
+    "molhiv_b32": dict(dataset="molhiv", batch_size=32, phm_dim=4, hidden=128, layers=4, d_units=[128, 32],
+                       target_dim=1, sc_type="first"),
+    # configs[1]: the configuration the metric is quoted on
+    "molhiv_b512": dict(dataset="molhiv", batch_size=512, phm_dim=4, hidden=128, layers=4, d_units=[128, 32],
+                        target_dim=1, sc_type="first"),
+    # configs[2]
+    "zinc_b1024": dict(dataset="zinc", batch_size=1024, phm_dim=8, hidden=256, layers=5, d_units=[256, 128],
+                       target_dim=1, sc_type="last", regression=True),
+    # configs[3] (per-GPU share of the 2048 batch)
+    "molpcba_b1024": dict(dataset="molpcba", batch_size=1024, phm_dim=4, hidden=256, layers=5, d_units=[768, 256],
+                          target_dim=128, sc_type="first", nan_frac=0.6),
+}
+
+
+def model_kwargs(w: dict) -> dict:
+    kw = dict(phm_dim=w["phm_dim"], learn_phm=True, atom_encoded_dim=w["hidden"], mp_layers=[w["hidden"]] * w["layers"],
+              dropout_mpnn=[0.0] * w["layers"], mlp=True, msg_aggr="sum", norm_mp="naive-batch-norm",
+              norm_dn="naive-batch-norm", pooling="softattention", activation="relu", real_trafo="linear",
+              w_init="phm", c_init="standard", downstream_layers=list(w["d_units"]),
+              dropout_dn=[0.0] * len(w["d_units"]), target_dim=w["target_dim"], sc_type=w["sc_type"],
+              msg_encoder="identity")
+    if w["dataset"] == "zinc":
+        kw.update(atom_input_dims=synth.ZINC_ATOM_DIMS, bond_input_dims=synth.ZINC_BOND_DIMS)
+    return kw
+
+
+def build_model(workload: str, device, seed: int = 0):
+    from phc.hypercomplex.undirectional.models import PHMSkipConnectAdd
+    import numpy as np
+    w = WORKLOADS[workload]
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    model = PHMSkipConnectAdd(**model_kwargs(w))
+    return model.to(device)
+
+
+def make_batch(workload: str, seed: int) -> synth.GraphBatch:
+    w = WORKLOADS[workload]
+    return synth.molecule_batch(w["batch_size"], seed=seed, dataset=w["dataset"], num_tasks=w["target_dim"],
+                                nan_frac=w.get("nan_frac", 0.0), regression=w.get("regression", False))
+
+
+def to_device(gb: synth.GraphBatch, device) -> types.SimpleNamespace:
+    """The object handed to ``model(data)``: same fields PyG's Batch exposes to
+    PHMSkipConnectAdd.forward (models.py:220)."""
+    y = torch.from_numpy(gb.y).to(device)
+    return types.SimpleNamespace(
+        x=torch.from_numpy(gb.x).to(device), edge_index=torch.from_numpy(gb.edge_index).to(device),
+        edge_attr=torch.from_numpy(gb.edge_attr).to(device), batch=torch.from_numpy(gb.batch).to(device),
+        y=y, y_mask=~torch.isnan(y), num_graphs=gb.num_graphs, num_nodes=gb.num_nodes, num_edges=gb.num_edges)
+
+
+def loss_fn(logits: torch.Tensor, data, regression: bool = False) -> torch.Tensor:
+    if regression:
+        return F.l1_loss(logits, data.y)                       # benchmarks/train_zinc.py uses L1
+    mask = data.y_mask                                          # train_hiv.py:174: mask = ~isnan(y)
+    if bool(getattr(data, "all_labeled", False)):
+        return F.binary_cross_entropy_with_logits(logits, data.y)
+    # mean over the labeled entries == BCE(logits[mask], y[mask]) without the host-synchronising
+    # boolean gather of the reference
+    per = F.binary_cross_entropy_with_logits(logits, torch.where(mask, data.y, torch.zeros_like(data.y)),
+                                             reduction="none")
+    return (per * mask).sum() / mask.sum()
+
+
+@dataclass
+class StepConfig:
+    regression: bool = False
+    grad_clip: float = 2.0              # --grad_clipping default, train_hiv.py
+    optimizer: bool = True
+
+
+def train_step(model, data, optimizer: Optional[torch.optim.Optimizer], cfg: StepConfig,
+               grad_sync=None) -> torch.Tensor:
+    """One iteration of the reference loop body (train_hiv.py:175-201) without the
+    host-synchronising ``loss.item()``."""
+    if optimizer is not None:
+        optimizer.zero_grad(set_to_none=True)
+    else:
+        for p in model.parameters():
+            p.grad = None
+    logits = model(data)
+    loss = loss_fn(logits, data, cfg.regression)
+    loss.backward()
+    if grad_sync is not None:
+        grad_sync(model)
+    if optimizer is not None and cfg.optimizer:
+        if cfg.grad_clip > 0:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=cfg.grad_clip, norm_type=2)
+        optimizer.step()
+    return loss

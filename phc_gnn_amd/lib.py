@@ -41,6 +41,13 @@ SIGNATURES = {
     "phc_aggregate_fwd": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P]),
     "phc_aggregate_bwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _L, _I, _I, _I, _P, _P, _P]),
     "phc_gather_rows_i64": (_I, [_P, _P, _L, _I, _P, _P]),
+    "phc_encode_fwd": (_I, [_P, _P, _L, _I, _I, _I, _P, _P]),
+    "phc_encode_bwd_ws_bytes": (_S, [_L, _I, _P, _I, _I]),
+    "phc_encode_bwd": (_I, [_P, _P, _L, _I, _P, _I, _I, _P, _P, _S, _P]),
+    "phc_aggregate_enc_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P, _P]),
+    "phc_aggregate_enc_bwd_ws_bytes": (_S, [_L, _I, _P, _I, _I]),
+    "phc_aggregate_enc_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _I, _I, _I, _I, _P, _P, _P,
+                                   _S, _P]),
     "phc_prof_enable": (_I, [_I]),
     "phc_prof_reset": (_I, []),
     "phc_prof_num_kernels": (_I, []),
@@ -119,12 +126,30 @@ def f32c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:
 
 
 # ---- profiler helpers (used by bench.py) -------------------------------------
+# While the launch profiler is on, the operators also book the ALGORITHMIC work of
+# each launch (flops / bytes from the formulas in DESIGN.md §4) under the kernel's
+# name, so that achieved = booked work / measured time can be formed per kernel.
+PROF_ON = False
+WORK: dict = {}
+
+
+def account(kernel: str, flops: float = 0.0, nbytes: float = 0.0) -> None:
+    if PROF_ON:
+        w = WORK.setdefault(kernel, {"flops": 0.0, "bytes": 0.0, "calls": 0})
+        w["flops"] += flops
+        w["bytes"] += nbytes
+        w["calls"] += 1
+
+
 def prof_enable(on: bool) -> None:
+    global PROF_ON
     check(load().phc_prof_enable(1 if on else 0), "phc_prof_enable")
+    PROF_ON = bool(on)
 
 
 def prof_reset() -> None:
     check(load().phc_prof_reset(), "phc_prof_reset")
+    WORK.clear()
 
 
 def prof_read() -> dict:

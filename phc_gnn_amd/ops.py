@@ -45,6 +45,9 @@ class _PHMLinearFn(torch.autograd.Function):
         y = torch.empty((N, n * kout), dtype=torch.float32, device=dev)
         L.check(lib.phc_phm_linear_fwd(L.ptr(x2), L.ptr(A_), L.ptr(W_), L.ptr(b_), L.ptr(res2), N, n, kin, kout,
                                        L.ptr(y), L.stream_ptr(dev)), "phc_phm_linear_fwd")
+        if L.PROF_ON:
+            L.account("phm_gemm_fwd", 2.0 * N * n * kin * n * kout,
+                      4.0 * (N * n * (kin + kout) + n * kin * kout + n ** 3 + n * kout))
         ctx.save_for_backward(x2, A_, W_)
         ctx.has_bias = b is not None
         ctx.has_res = residual is not None
@@ -72,6 +75,13 @@ class _PHMLinearFn(torch.autograd.Function):
         L.check(lib.phc_phm_linear_bwd(L.ptr(x2), L.ptr(A), L.ptr(W), L.ptr(dy2), N, n, kin, kout, L.ptr(dx), L.ptr(dW),
                                        L.ptr(dA), L.ptr(db), L.ptr(ws), ws_bytes, L.stream_ptr(dev)),
                 "phc_phm_linear_bwd")
+        if L.PROF_ON:
+            gemm = 2.0 * N * n * kin * n * kout
+            io = 4.0 * N * n * (kin + kout)
+            if need_x:
+                L.account("phm_gemm_dx", gemm, io + 4.0 * (n * kin * kout + n ** 3))
+            if need_param:
+                L.account("phm_dH_partial", gemm, io + 4.0 * n * kin * n * kout)
         return (dx.reshape(ctx.x_shape) if need_x else None, dA, dW if need_W else None, db,
                 dy.reshape(ctx.res_shape) if (need_res and ctx.has_res) else None)
 
@@ -112,6 +122,10 @@ class _AggregateFn(torch.autograd.Function):
         out = torch.empty((st.num_dst, h), dtype=torch.float32, device=dev)
         L.check(lib.phc_aggregate_fwd(L.ptr(x_), L.ptr(ea_), L.ptr(rowptr), L.ptr(col), L.ptr(perm), st.num_dst, h, act,
                                       1 if add_self else 0, L.ptr(out), L.stream_ptr(dev)), "phc_aggregate_fwd")
+        if L.PROF_ON:
+            E, N = st.num_edges, st.num_dst
+            L.account("aggregate_fwd", 2.0 * E * h,
+                      E * (4.0 * h * (2 if ea is not None else 1) + 4) + N * 4.0 * h * (2 if add_self else 1) + 4.0 * (N + 1))
         ctx.st, ctx.act, ctx.add_self, ctx.has_ea = st, act, add_self, ea is not None
         if act != 0:
             ctx.save_for_backward(x_, ea_) if ea is not None else ctx.save_for_backward(x_)
@@ -139,6 +153,12 @@ class _AggregateFn(torch.autograd.Function):
         L.check(lib.phc_aggregate_bwd(L.ptr(dout_), L.ptr(x_), L.ptr(ea_), L.ptr(rowptr_t), L.ptr(col_t), L.ptr(perm_t),
                                       st.num_src, st.num_dst, h, ctx.act, 1 if ctx.add_self else 0, L.ptr(dx), L.ptr(dea),
                                       L.stream_ptr(dev)), "phc_aggregate_bwd")
+        if L.PROF_ON:
+            E, Ns = st.num_edges, st.num_src
+            extra = (E * 4.0 * h * (1 if ctx.has_ea else 0) + Ns * 4.0 * h) if ctx.act != 0 else 0.0
+            L.account("aggregate_bwd", 1.0 * E * h,
+                      E * (4.0 * h * (2 if need_ea else 1) + 4) + Ns * 4.0 * h * (2 if ctx.add_self else 1)
+                      + 4.0 * (Ns + 1) + extra)
         return (dx if need_x else None), dea, None, None, None
 
 
@@ -166,6 +186,9 @@ class _SegmentSumFn(torch.autograd.Function):
         out = torch.empty((st.num_segments, h), dtype=torch.float32, device=dev)
         L.check(lib.phc_aggregate_fwd(L.ptr(x_), None, L.ptr(rowptr), L.ptr(col), None, st.num_segments, h, 0, 0,
                                       L.ptr(out), L.stream_ptr(dev)), "phc_aggregate_fwd(segment sum)")
+        if L.PROF_ON:
+            L.account("aggregate_fwd", 1.0 * x_.shape[0] * h,
+                      x_.shape[0] * (4.0 * h + 4) + st.num_segments * 4.0 * h + 4.0 * (st.num_segments + 1))
         ctx.st = st
         ctx.n_rows = x_.shape[0]
         return out
@@ -180,6 +203,8 @@ class _SegmentSumFn(torch.autograd.Function):
         dx = torch.empty((ctx.n_rows, h), dtype=torch.float32, device=dev)
         L.check(lib.phc_gather_rows_i64(L.ptr(dout_), L.ptr(st.batch), ctx.n_rows, h, L.ptr(dx), L.stream_ptr(dev)),
                 "phc_gather_rows_i64")
+        if L.PROF_ON:
+            L.account("gather_rows", 0.0, ctx.n_rows * (8.0 * h + 8))
         return dx, None
 
 
@@ -187,3 +212,204 @@ def global_add_pool(x: torch.Tensor, batch, num_graphs: Optional[int] = None) ->
     """out[g] = Σ_{i: batch[i]=g} x[i]  (torch_geometric.nn.global_add_pool semantics)."""
     st = batch if isinstance(batch, SegmentStructure) else segment_structure(batch, num_graphs)
     return _SegmentSumFn.apply(x, st)
+
+
+# ---------------------------------------------------------------------------
+# integer-feature encoders (atom / bond embeddings) read in place
+# ---------------------------------------------------------------------------
+import ctypes as _C   # noqa: E402
+import weakref as _weakref  # noqa: E402
+
+
+class TableSet:
+    """The n*F embedding tables of one PHM encoder as the engine sees them: a device
+    array of table pointers (entry c*F+f) plus the host-side vocabulary sizes.
+
+    The tables stay the reference's separate ``nn.Embedding`` weights; the pointer
+    array is rebuilt only when a weight has moved (``.to()``, ``load_state_dict``
+    with assign)."""
+
+    def __init__(self, tables):
+        self.refresh(tables)
+
+    def refresh(self, tables):
+        self.n = len(tables)
+        self.F = len(tables[0])
+        self.k = int(tables[0][0].shape[1])
+        self.vocab = [int(t.shape[0]) for t in tables[0]]
+        self.R = sum(self.vocab)
+        self.vocab_c = (_C.c_int32 * self.F)(*self.vocab)
+        flat = [t for comp in tables for t in comp]
+        for t in flat:
+            if t.dtype != torch.float32 or not t.is_contiguous() or t.shape[1] != self.k:
+                raise L.PhcError("embedding tables must be contiguous fp32 [V_f, k]")
+        self.dev = L.require_device(*flat)
+        self.key = tuple(t.data_ptr() for t in flat)
+        self.ptrs = torch.tensor(self.key, dtype=torch.int64, device=self.dev)
+        offs = [0]
+        for v in self.vocab:
+            offs.append(offs[-1] + v)
+        self.offsets = offs
+
+    def current(self, tables) -> "TableSet":
+        flat = [t for comp in tables for t in comp]
+        if tuple(t.data_ptr() for t in flat) != self.key:
+            self.refresh(tables)
+        return self
+
+    def grad_views(self, flat_grad: torch.Tensor):
+        """Per-table [V_f, k] views of the flat [c][f][V_f][k] gradient buffer."""
+        out = []
+        for c in range(self.n):
+            for f in range(self.F):
+                b = (c * self.R + self.offsets[f]) * self.k
+                out.append(flat_grad[b:b + self.vocab[f] * self.k].view(self.vocab[f], self.k))
+        return out
+
+    @property
+    def fusable_into_aggregate(self) -> bool:
+        return self.k % 4 == 0 and self.R * self.n * self.k * 4 <= 48 * 1024 and self.F <= 16
+
+
+_TABLESETS: "_weakref.WeakKeyDictionary" = _weakref.WeakKeyDictionary()
+
+
+def tableset_for(owner, tables) -> TableSet:
+    """TableSet cached per owning module (weakly: nothing is stored on the module, so
+    whole-module pickling keeps working)."""
+    ts = _TABLESETS.get(owner)
+    if ts is None:
+        ts = TableSet(tables)
+        _TABLESETS[owner] = ts
+        return ts
+    return ts.current(tables)
+
+
+def _idx64(idx: torch.Tensor) -> torch.Tensor:
+    if idx.dim() == 1:
+        idx = idx.unsqueeze(1)
+    if idx.dtype != torch.int64:
+        idx = idx.to(torch.int64)
+    return idx.contiguous()
+
+
+class _EncodeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, idx, ts: TableSet, *tables):
+        lib = L.load()
+        dev = L.require_device(idx)
+        idx_ = _idx64(idx)
+        N = idx_.shape[0]
+        if idx_.shape[1] != ts.F:
+            raise L.PhcError(f"index tensor has {idx_.shape[1]} features, encoder has {ts.F}")
+        out = torch.empty((N, ts.n * ts.k), dtype=torch.float32, device=dev)
+        L.check(lib.phc_encode_fwd(L.ptr(idx_), L.ptr(ts.ptrs), N, ts.F, ts.n, ts.k, L.ptr(out), L.stream_ptr(dev)),
+                "phc_encode_fwd")
+        if L.PROF_ON:
+            L.account("encode_fwd", 0.0, N * (8.0 * ts.F + 4.0 * ts.n * ts.k) + 4.0 * ts.R * ts.n * ts.k)
+        ctx.ts = ts
+        ctx.save_for_backward(idx_)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = L.load()
+        ts: TableSet = ctx.ts
+        (idx_,) = ctx.saved_tensors
+        dout_ = L.f32c(dout)
+        dev = dout_.device
+        N = idx_.shape[0]
+        flat = torch.empty(ts.n * ts.R * ts.k, dtype=torch.float32, device=dev)
+        ws_bytes = lib.phc_encode_bwd_ws_bytes(N, ts.F, ts.vocab_c, ts.n, ts.k)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        L.check(lib.phc_encode_bwd(L.ptr(dout_), L.ptr(idx_), N, ts.F, ts.vocab_c, ts.n, ts.k, L.ptr(flat), L.ptr(ws),
+                                   ws_bytes, L.stream_ptr(dev)), "phc_encode_bwd")
+        if L.PROF_ON:
+            L.account("table_grad", 1.0 * N * ts.F * ts.n * ts.k, N * (8.0 * ts.F + 4.0 * ts.n * ts.k))
+        return (None, None, *ts.grad_views(flat))
+
+
+def encode(idx: torch.Tensor, ts: TableSet, tables) -> torch.Tensor:
+    """out[i, c*k+κ] = Σ_f tables[c][f][idx[i, f], κ]   ->  [N, n*k] component-major."""
+    return _EncodeFn.apply(idx, ts, *[t for comp in tables for t in comp])
+
+
+class _AggregateEncFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, bond_idx, st: EdgeStructure, act: int, add_self: bool, ts: TableSet, *tables):
+        lib = L.load()
+        dev = L.require_device(x, bond_idx)
+        x_ = L.f32c(x)
+        bond_ = _idx64(bond_idx)
+        h = x_.shape[1]
+        if h != ts.n * ts.k:
+            raise L.PhcError(f"x has {h} features, bond encoder produces {ts.n * ts.k}")
+        if tuple(bond_.shape) != (st.num_edges, ts.F):
+            raise L.PhcError(f"edge_attr indices must be [{st.num_edges}, {ts.F}], got {tuple(bond_.shape)}")
+        if x_.shape[0] < st.num_src:
+            raise L.PhcError(f"x has {x_.shape[0]} rows, edge structure expects {st.num_src} source rows")
+        rowptr, col, perm = st.csr
+        out = torch.empty((st.num_dst, h), dtype=torch.float32, device=dev)
+        L.check(lib.phc_aggregate_enc_fwd(L.ptr(x_), L.ptr(bond_), L.ptr(ts.ptrs), ts.vocab_c, L.ptr(rowptr), L.ptr(col),
+                                          L.ptr(perm), st.num_dst, ts.F, ts.n, ts.k, act, 1 if add_self else 0, L.ptr(out),
+                                          L.stream_ptr(dev)), "phc_aggregate_enc_fwd")
+        if L.PROF_ON:
+            E, N = st.num_edges, st.num_dst
+            L.account("aggregate_enc_fwd", 2.0 * E * h,
+                      E * (4.0 * h + 4 + 4 + 8.0 * ts.F) + N * 4.0 * h * (2 if add_self else 1) + 4.0 * (N + 1))
+        ctx.st, ctx.act, ctx.add_self, ctx.ts = st, act, add_self, ts
+        ctx.x_rows = x_.shape[0]
+        ctx.save_for_backward(x_, bond_)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = L.load()
+        st: EdgeStructure = ctx.st
+        ts: TableSet = ctx.ts
+        x_, bond_ = ctx.saved_tensors
+        dout_ = L.f32c(dout)
+        dev = dout_.device
+        h = dout_.shape[1]
+        need_x = ctx.needs_input_grad[0]
+        need_t = any(ctx.needs_input_grad[6:])
+        rowptr, col, perm = st.csr
+        rowptr_t = col_t = perm_t = None
+        dx = None
+        if need_x:
+            rowptr_t, col_t, perm_t = st.csc
+            dx = torch.empty((ctx.x_rows, h), dtype=torch.float32, device=dev)
+            if ctx.x_rows > st.num_src:
+                dx[st.num_src:].zero_()
+        flat = ws = None
+        ws_bytes = 0
+        if need_t:
+            flat = torch.empty(ts.n * ts.R * ts.k, dtype=torch.float32, device=dev)
+            ws_bytes = lib.phc_aggregate_enc_bwd_ws_bytes(st.num_dst, ts.F, ts.vocab_c, ts.n, ts.k)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        L.check(lib.phc_aggregate_enc_bwd(L.ptr(dout_), L.ptr(x_), L.ptr(bond_), L.ptr(ts.ptrs), ts.vocab_c, L.ptr(rowptr),
+                                          L.ptr(col), L.ptr(perm), L.ptr(rowptr_t), L.ptr(col_t), L.ptr(perm_t), st.num_src,
+                                          st.num_dst, ts.F, ts.n, ts.k, ctx.act, 1 if ctx.add_self else 0, L.ptr(dx),
+                                          L.ptr(flat), L.ptr(ws), ws_bytes, L.stream_ptr(dev)), "phc_aggregate_enc_bwd")
+        if L.PROF_ON:
+            E, Ns, Nd = st.num_edges, st.num_src, st.num_dst
+            if need_x:
+                L.account("aggregate_enc_dx", 1.0 * E * h, E * (4.0 * h + 4) + Ns * 4.0 * h * (2 if ctx.add_self else 1)
+                          + 4.0 * (Ns + 1))
+            if need_t:
+                L.account("table_grad", 1.0 * E * ts.F * h, Nd * 4.0 * h + E * (4.0 + 8.0 * ts.F) + 4.0 * (Nd + 1))
+        grads = ts.grad_views(flat) if need_t else [None] * (ts.n * ts.F)
+        return (dx, None, None, None, None, None, *grads)
+
+
+def aggregate_sum_encoded(x: torch.Tensor, edge_index, bond_idx: torch.Tensor, ts: TableSet, tables,
+                          msg_encoder: str = "identity", add_self_loops: bool = False,
+                          num_dst: Optional[int] = None) -> torch.Tensor:
+    """aggregate_sum with edge_attr[e] = Σ_f tables[c][f][bond_idx[e, f]] looked up inside the
+    kernel (the [E, h] bond embedding is never written)."""
+    st = edge_index if isinstance(edge_index, EdgeStructure) else edge_structure(edge_index, x.shape[0], num_dst)
+    flat_tables = [t for comp in tables for t in comp]
+    if not ts.fusable_into_aggregate:
+        ea = _EncodeFn.apply(bond_idx, ts, *flat_tables)
+        return _AggregateFn.apply(x, ea, st, _act_id(msg_encoder), bool(add_self_loops))
+    return _AggregateEncFn.apply(x, bond_idx, st, _act_id(msg_encoder), bool(add_self_loops), ts, *flat_tables)

@@ -1,0 +1,4 @@
+set -x
+python -m pytest tests -m gpu -x -q 2>&1 | tail -15
+python -c "import __graft_entry__ as g; g.smoke()" 2>&1 | tail -3
+python bench.py --steps 50 --warmup 10 2>&1 | tail -2

@@ -188,3 +188,87 @@ def test_cpu_tensors_are_rejected(ops):
     from phc_gnn_amd.lib import PhcError
     with pytest.raises(PhcError):
         ops.phm_linear(torch.randn(4, 8), torch.randn(2, 2, 2), torch.randn(2, 4, 4), None)
+
+
+# ---- fused integer encoders --------------------------------------------------
+def _make_tables(n, vocab, k, gen):
+    return [[torch.randn(v, k, generator=gen) for v in vocab] for _ in range(n)]
+
+
+def _oracle_encode(idx, tables):
+    from oracle import phc_oracle as O
+    n = len(tables)
+    p = {f"encoders.{c}.embeddings.{f}.weight": t for c, comp in enumerate(tables) for f, t in enumerate(comp)}
+    return O.phm_encoder(idx, p, "", n, len(tables[0])).reshape(idx.shape[0], -1)
+
+
+@pytest.mark.parametrize("n,k,vocab", [(4, 32, [119, 4, 12, 12, 10, 6, 6, 2, 2]), (8, 32, [28]), (2, 6, [5, 3]),
+                                       (4, 128, [119, 4, 12, 12, 10, 6, 6, 2, 2])])
+def test_encode_fwd_bwd(ops, n, k, vocab):
+    g = torch.Generator().manual_seed(n * 100 + k)
+    N = 3000
+    idx = torch.stack([torch.randint(0, v, (N,), generator=g) for v in vocab], 1)
+    tables = _make_tables(n, vocab, k, g)
+    ref_t = [[t.clone().requires_grad_() for t in comp] for comp in tables]
+    ref = _oracle_encode(idx, ref_t)
+    dy = torch.randn(N, n * k, generator=g)
+    ref_g = torch.autograd.grad(ref, [t for comp in ref_t for t in comp], dy)
+    dev_t = [[t.to(DEV).requires_grad_() for t in comp] for comp in tables]
+    ts = ops.TableSet(dev_t)
+    out = ops.encode(idx.to(DEV), ts, dev_t)
+    assert_close(out, ref, TOL, "encode fwd")
+    got = torch.autograd.grad(out, [t for comp in dev_t for t in comp], dy.to(DEV))
+    for a, b in zip(got, ref_g):
+        assert_close(a, b, TOL, "table grad")
+    got2 = torch.autograd.grad(ops.encode(idx.to(DEV), ts, dev_t), [t for comp in dev_t for t in comp], dy.to(DEV))
+    assert all(torch.equal(a, b) for a, b in zip(got, got2)), "table gradients must be bitwise reproducible"
+
+
+@pytest.mark.parametrize("act", ["identity", "relu", "swish"])
+@pytest.mark.parametrize("n,k,vocab", [(4, 32, [5, 6, 2]), (8, 32, [4]), (4, 64, [5, 6, 2])])
+def test_aggregate_encoded_matches_oracle(ops, act, n, k, vocab):
+    from oracle import phc_oracle as O
+    from phc_gnn_amd import synth
+    g = torch.Generator().manual_seed(17)
+    b = synth.molecule_batch(48, seed=21, isolated_frac=0.05)
+    ei, N = torch.from_numpy(b.edge_index), b.num_nodes
+    E, h = ei.shape[1], n * k
+    bond = torch.stack([torch.randint(0, v, (E,), generator=g) for v in vocab], 1)
+    tables = _make_tables(n, vocab, k, g)
+    x = torch.randn(N, h, generator=g)
+    dy = torch.randn(N, h, generator=g)
+    for add_self in (True, False):
+        ref_t = [[t.clone().requires_grad_() for t in comp] for comp in tables]
+        xr = x.clone().requires_grad_()
+        ref = O.propagate_add(xr, ei, _oracle_encode(bond, ref_t), act)
+        if add_self:
+            ref = ref + xr
+        rg = torch.autograd.grad(ref, [xr] + [t for comp in ref_t for t in comp], dy)
+        dev_t = [[t.to(DEV).requires_grad_() for t in comp] for comp in tables]
+        xd = x.to(DEV).requires_grad_()
+        ts = ops.TableSet(dev_t)
+        assert ts.fusable_into_aggregate
+        out = ops.aggregate_sum_encoded(xd, ei.to(DEV), bond.to(DEV), ts, dev_t, act, add_self)
+        assert_close(out, ref, TOL, f"fused fwd {act}")
+        gg = torch.autograd.grad(out, [xd] + [t for comp in dev_t for t in comp], dy.to(DEV))
+        assert_close(gg[0], rg[0], TOL, f"fused dx {act}")
+        for a, r in zip(gg[1:], rg[1:]):
+            assert_close(a, r, 2e-5, f"fused table grad {act}")
+
+
+def test_aggregate_encoded_falls_back_when_tables_exceed_lds(ops):
+    from oracle import phc_oracle as O
+    from phc_gnn_amd import synth
+    g = torch.Generator().manual_seed(5)
+    n, k, vocab = 4, 64, [40, 30]            # 70 rows * 256 cols * 4 B = 70 KiB > 48 KiB
+    ei = torch.from_numpy(synth.ragged_edges(200, seed=3, hub_degree=100))
+    E = ei.shape[1]
+    bond = torch.stack([torch.randint(0, v, (E,), generator=g) for v in vocab], 1)
+    tables = _make_tables(n, vocab, k, g)
+    x = torch.randn(200, n * k, generator=g)
+    dev_t = [[t.to(DEV) for t in comp] for comp in tables]
+    ts = ops.TableSet(dev_t)
+    assert not ts.fusable_into_aggregate
+    out = ops.aggregate_sum_encoded(x.to(DEV), ei.to(DEV), bond.to(DEV), ts, dev_t, "relu", True)
+    ref = O.propagate_add(x, ei, _oracle_encode(bond, tables), "relu") + x
+    assert_close(out, ref, TOL)
