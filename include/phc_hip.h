@@ -170,13 +170,46 @@ int phc_aggregate_enc_fwd(const float *x, const int64_t *bond_i64, const float *
                           int act, int add_self, float *out, void *stream);
 
 /* Backward of phc_aggregate_enc_fwd: dx (source-sorted walk, may be NULL) and the
- * flat table gradient (destination-sorted walk, may be NULL). */
-size_t phc_aggregate_enc_bwd_ws_bytes(int64_t n_dst, int F, const int32_t *vocab, int n, int k);
+ * flat table gradient (may be NULL).  The table gradient is a one-hot GEMM on the
+ * matrix cores over the edges in ORIGINAL order, so it takes the raw int64 edge
+ * list (edge_src_i64 / edge_dst_i64 = rows 0 / 1 of edge_index). */
+size_t phc_aggregate_enc_bwd_ws_bytes(int64_t E, int F, const int32_t *vocab, int n, int k);
 int phc_aggregate_enc_bwd(const float *dout, const float *x, const int64_t *bond_i64, const float *const *tables,
-                          const int32_t *vocab, const int32_t *rowptr, const int32_t *col, const int32_t *perm,
+                          const int32_t *vocab, const int64_t *edge_src_i64, const int64_t *edge_dst_i64, int64_t E,
                           const int32_t *rowptr_t, const int32_t *col_t, const int32_t *perm_t, int64_t n_src, int64_t n_dst,
                           int F, int n, int k, int act, int add_self, float *dx, float *dtables_flat, void *ws,
                           size_t ws_bytes, void *stream);
+
+/* ------------------------------------------------------------------------- *
+ * Batch normalisation of component-major activations, fused with the
+ * activation and the skip add that follow it
+ *
+ * Reference: NaivePHMNorm = n_comp BatchNorm1d(h/n_comp) modules applied to a
+ * reshaped copy (phc/hypercomplex/norm.py:30-35), followed in the model by
+ * activation, dropout and "+ skip" (models.py:208-215) and in PHMMLP by the
+ * activation (layers.py:351-353).  Per-column statistics make this one pass
+ * over [N, h]:   z = (x - mean) * invstd * weight + bias ;  out = act(z) (+ residual)
+ * training != 0: batch statistics (biased variance for z, unbiased for the
+ *   running estimate), running = (1-momentum)*running + momentum*batch,
+ *   num_batches_tracked += 1;  training == 0: running statistics.
+ * weight / bias / running_mean / running_var / num_batches_tracked are HOST
+ * arrays of n_comp DEVICE pointers (each [h/n_comp]; the reference's separate
+ * tensors, used in place); any of the arrays may be NULL.
+ * n_valid_dev: optional DEVICE int32 scalar; rows >= *n_valid_dev are padding of a
+ *   fixed-shape batch: excluded from the statistics, written as 0, zero gradient.
+ * save_mean / save_invstd [h]: written by the forward, consumed by the backward.
+ * dwb_flat [2h]: dweight (component-major) followed by dbias.
+ * ------------------------------------------------------------------------- */
+#define PHC_MAX_COMPONENTS 16
+
+size_t phc_bn_ws_bytes(int64_t N, int h);
+int phc_bn_fwd(const float *x, const float *const *weight, const float *const *bias, float *const *running_mean,
+               float *const *running_var, int64_t *const *num_batches_tracked, int n_comp, const int32_t *n_valid_dev,
+               int64_t N, int h, int training, float momentum, float eps, int act, const float *residual, float *out,
+               float *save_mean, float *save_invstd, void *ws, size_t ws_bytes, void *stream);
+int phc_bn_bwd(const float *dy, const float *x, const float *const *weight, const float *const *bias,
+               const float *save_mean, const float *save_invstd, int n_comp, const int32_t *n_valid_dev, int64_t N, int h,
+               int training, int act, float *dx, float *dwb_flat, void *ws, size_t ws_bytes, void *stream);
 
 /* ------------------------------------------------------------------------- *
  * Opt-in launch profiler (process-global).  When enabled every kernel launch

@@ -63,8 +63,9 @@ class PHMDownstreamNet(nn.Module):
             if i == last:
                 break
             if self.norm_flag:
-                x = self.norm[i](x, **kwargs)
-            x = self.activation_func(x)
+                x = self.norm[i].forward_fused(x, activation=self.activation_str)
+            else:
+                x = self.activation_func(x)
             if self.training and self.dropout[i] > 0.0:
                 x = phm_dropout(x, p=self.dropout[i], phm_dim=self.phm_dim, training=self.training,
                                 same=self.same_dropout)

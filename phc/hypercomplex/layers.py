@@ -149,8 +149,10 @@ class PHMMLP(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         x = self.linear1(x)
         if self.norm_flag:
-            x = self.norm(x)
-        return self.linear2(self.activation(x))
+            x = self.norm.forward_fused(x, activation=self.activation_str)      # norm + activation in one pass
+        else:
+            x = self.activation(x)
+        return self.linear2(x)
 
     def __repr__(self):
         return '{}(in_features={}, out_features={}, phm_dim={}, phm_rule={}, bias={}, learn_phm={}, ' \

@@ -10,6 +10,10 @@ import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
+from phc_gnn_amd import ops as _engine
+
+_FUSABLE_ACTS = ("identity", "relu", "lrelu", "elu", "swish", "selu")
+
 
 class NaivePHMNorm(nn.Module):
     def __init__(self, num_features: int, phm_dim: int, momentum: float = 0.1, eps: float = 1e-5,
@@ -30,28 +34,41 @@ class NaivePHMNorm(nn.Module):
             module.reset_parameters()
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
-        # x: [N, phm_dim * k], component-major
-        weight = bias = None
-        if self.affine:
-            weight = torch.cat([m.weight for m in self.bn])
-            bias = torch.cat([m.bias for m in self.bn])
-        use_batch_stats = self.training or not self.track_running_stats
-        if not self.track_running_stats:
-            return F.batch_norm(x, None, None, weight, bias, True, self.momentum, self.eps)
-        mean = torch.cat([m.running_mean for m in self.bn])
-        var = torch.cat([m.running_var for m in self.bn])
-        out = F.batch_norm(x, mean, var, weight, bias, use_batch_stats, self.momentum, self.eps)
-        if self.training:
-            k = self.num_features
-            with torch.no_grad():
-                torch._foreach_copy_([m.running_mean for m in self.bn], list(mean.split(k)))
-                torch._foreach_copy_([m.running_var for m in self.bn], list(var.split(k)))
-                torch._foreach_add_([m.num_batches_tracked for m in self.bn], 1)
-        return out
+        return self.forward_fused(x)
+
+    def forward_fused(self, x: torch.Tensor, activation: str = "identity", residual=None, n_valid=None) -> torch.Tensor:
+        """act(norm(x)) (+ residual) in one engine pass (``phc_bn_fwd``): the activation and the
+        skip add that follow the norm in the model (models.py:208-215) and in PHMMLP
+        (layers.py:351-353) ride in the normalisation kernel.  x: [N, phm_dim * k]."""
+        mods = list(self.bn)
+        track = self.track_running_stats
+        use_batch_stats = self.training or not track
+        if not track:
+            # no running statistics: batch statistics in both modes, nothing to update
+            return _engine.batch_norm_act(x, [m.weight for m in mods] if self.affine else None,
+                                          [m.bias for m in mods] if self.affine else None, None, None, None, True,
+                                          0.0, self.eps, activation, residual, n_valid) if self.affine else \
+                self._plain(x, activation, residual)
+        momentum = self.momentum if self.momentum is not None else 0.1
+        return _engine.batch_norm_act(
+            x, [m.weight for m in mods] if self.affine else None, [m.bias for m in mods] if self.affine else None,
+            [m.running_mean for m in mods], [m.running_var for m in mods],
+            [m.num_batches_tracked for m in mods] if self.training else None, use_batch_stats, momentum, self.eps,
+            activation, residual, n_valid)
+
+    def _plain(self, x, activation, residual):
+        out = F.batch_norm(x, None, None, None, None, True, 0.0, self.eps)
+        out = _engine_act(out, activation)
+        return out if residual is None else out + residual
 
     def __repr__(self):
         return "{num_features}, phm_dim={phm_dim}, eps={eps}, momentum={momentum}, affine={affine}, " \
                "track_running_stats={track_running_stats})".format(**self.__dict__)
+
+
+def _engine_act(x, activation):
+    from phc.quaternion.activations import get_module_activation
+    return get_module_activation(activation)(x)
 
 
 class PHMNorm(nn.Module):
@@ -76,6 +93,13 @@ class PHMNorm(nn.Module):
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return self.bn(x)
+
+    def forward_fused(self, x: torch.Tensor, activation: str = "identity", residual=None, n_valid=None) -> torch.Tensor:
+        """act(norm(x)) (+ residual); one engine pass for the naive-batch-norm flavour."""
+        if isinstance(self.bn, NaivePHMNorm) and activation.lower() in _FUSABLE_ACTS:
+            return self.bn.forward_fused(x, activation, residual, n_valid)
+        out = _engine_act(self.bn(x), activation)
+        return out if residual is None else out + residual
 
     def __repr__(self):
         return f"{self.__class__.__name__}:(num_features={self.num_features}, phm_dim={self.phm_dim} type={self.type})"

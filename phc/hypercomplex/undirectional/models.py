@@ -140,9 +140,14 @@ class PHMSkipConnectAdd(nn.Module):
             h = conv.forward_encoded(x[0], edge_index, edge_attr, edge_encoder, size)
         else:
             h = conv(x=x[0], edge_index=edge_index, edge_attr=edge_attr, size=size)
+        dropout_active = self.training and dropout_mpnn > 0.0
+        if norm is not None and not dropout_active:
+            # norm -> activation -> (+ skip) ride in one engine pass
+            return norm.forward_fused(h, activation=self.activation_str, residual=x[1])
         if norm is not None:
-            h = norm(h)
-        h = self.f_act(h)
+            h = norm.forward_fused(h, activation=self.activation_str)
+        else:
+            h = self.f_act(h)
         h = phm_dropout(x=h, p=dropout_mpnn, phm_dim=self.phm_dim, training=self.training, same=self.same_dropout)
         return h + x[1]
 

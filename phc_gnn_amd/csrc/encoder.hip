@@ -10,11 +10,10 @@
 //   * encode_fwd           : out[i] = sum_f T_f[idx[i,f]]            (atoms)
 //   * aggregate_enc_fwd    : the aggregation kernel with edge features looked up
 //                            from LDS-staged tables — the [E, h] tensor never exists
-//   * table_grad + reduce  : dT[r] = sum of the gradient rows that used table row r,
-//                            accumulated in LDS by column-owning threads (no atomics
-//                            between threads, fixed order => reproducible), then a
-//                            fixed-order slab reduction into ONE flat gradient buffer
-//                            laid out [c][f][V_f][k] (the per-table grads are views).
+//   * table_grad + reduce  : dT = onehot^T . g as a GEMM on the matrix cores (one-hot tiles
+//                            generated in LDS), fixed-order split slabs, then a slab sum
+//                            into ONE flat gradient buffer laid out [c][f][V_f][k]
+//                            (the per-table grads are views).  No atomics, reproducible.
 #include "phc_common.h"
 
 namespace phc {
@@ -183,87 +182,132 @@ __global__ __launch_bounds__(ENC_THREADS) void aggregate_enc_dx_kernel(
     }
 }
 
-// ---- table gradients ---------------------------------------------------------------------------
-// Every thread owns one column j (and row-lane q); it walks its rows in order and adds the
-// gradient value into its own LDS cell tbl[q][r][j] — no two threads ever touch the same cell.
-//   MODE 0 (atoms): row i contributes dout[i] to rows off_f + idx[i,f], f < F.
-//   MODE 1 (bonds): destination d contributes, for each in-edge e, g_e = phi'(..) * dout[d]
-//                   to rows off_f + bond[perm[e], f].
-// grid.x = slabs (row ranges), grid.y = table-row tiles; slab[b][r][j] partial tables.
-template <int MODE, int ACT>
-__global__ __launch_bounds__(ENC_THREADS) void table_grad_kernel(
-    const float *__restrict__ dout, const long long *__restrict__ idx, EncMeta m, long long n_rows, long long rows_per_block,
-    int h, int r_tile, const int *__restrict__ rowptr, const int *__restrict__ col, const int *__restrict__ perm,
-    const float *__restrict__ x, const float *const *__restrict__ tables, int n, int k, float *__restrict__ slabs) {
-    extern __shared__ __attribute__((aligned(16))) float tbl[];      // [Q][r_tile][h]
-    const int tid = threadIdx.x;
-    const int Q = h >= ENC_THREADS ? 1 : ENC_THREADS / h;
-    const int q = h >= ENC_THREADS ? 0 : tid / h;
-    const int j0 = h >= ENC_THREADS ? tid : tid - q * h;
-    const int jstep = h >= ENC_THREADS ? ENC_THREADS : h;
-    const bool active = q < Q;
-    const int r_lo = blockIdx.y * r_tile;
-    const int r_hi = min(m.R, r_lo + r_tile);
-    const int F = m.F;
-    for (int e = tid; e < Q * r_tile * h; e += ENC_THREADS) tbl[e] = 0.f;
-    __syncthreads();
+// ---- table gradients on the matrix cores -------------------------------------------------------
+// dT[r][j] = sum over items t of onehot[t][r] * g[t][j]  ==  (onehot^T . g), a GEMM whose K dimension is
+// the item index (nodes for the atom encoder, edges for the bond encoders).  The one-hot operand is never
+// stored: each 64-item step scatters F ones per item into an LDS tile; g rows are gathered into a second
+// tile; v_mfma_f32_32x32x2_f32 accumulates the 64 x 64 (table rows x columns) tile.  Split over item
+// ranges into fixed-order slabs => no atomics, bitwise reproducible (the reference runs one
+// embedding_dense_backward — a device sort — per table).
+//   MODE 0: item = node i,  rows off_f + idx[i,f],     g = dout[i]
+//   MODE 1: item = edge e,  rows off_f + bond[e,f],    g = phi'(x[src_e] + enc_e) * dout[dst_e]
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+constexpr int TG_T = 64;          // tile edge (table rows x feature columns)
+constexpr int TG_IB = 64;         // items per step
 
-    const long long i_begin = blockIdx.x * rows_per_block;
-    const long long i_end = min(n_rows, i_begin + rows_per_block);
-    if (active) {
-        float *mytbl = tbl + (size_t)q * r_tile * h;
-        for (long long i = i_begin + q; i < i_end; i += Q) {
-            if (MODE == 0) {
-                for (int j = j0; j < h; j += jstep) {
-                    const float g = dout[(size_t)i * h + j];
-                    for (int f = 0; f < F; ++f) {
-                        const int r = m.off[f] + (int)idx[i * F + f];
-                        if (r >= r_lo && r < r_hi) mytbl[(r - r_lo) * h + j] += g;
+template <int MODE, int ACT>
+__global__ __launch_bounds__(ENC_THREADS) void table_grad_mfma_kernel(
+    const float *__restrict__ dout, const long long *__restrict__ idx, EncMeta m, long long n_items, long long items_per_split,
+    int h, int tiles_j, const long long *__restrict__ src, const long long *__restrict__ dst, const float *__restrict__ x,
+    const float *const *__restrict__ tables, int n, int k, int vec4, float *__restrict__ slabs) {
+    __shared__ __attribute__((aligned(16))) float oh[TG_IB * TG_T];     // one-hot tile  [item][table row]
+    __shared__ __attribute__((aligned(16))) float gs[TG_IB * TG_T];     // gradient tile [item][column]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int r = lane & 31, hh = lane >> 5;
+    const int ti = blockIdx.x / tiles_j, tj = blockIdx.x - ti * tiles_j;
+    const int r0 = ti * TG_T, j0 = tj * TG_T;
+    const long long split = blockIdx.y;
+    const long long t_begin = split * items_per_split;
+    const long long t_end = min(n_items, t_begin + items_per_split);
+    const int F = m.F;
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+    for (long long tb = t_begin; tb < t_end; tb += TG_IB) {
+        __syncthreads();
+        // zero the one-hot tile (16-byte stores)
+        for (int e = tid; e < TG_IB * TG_T / 4; e += ENC_THREADS) reinterpret_cast<float4 *>(oh)[e] = make_float4(0.f, 0.f, 0.f, 0.f);
+        // gather the gradient rows: thread -> (item = e / 16, 4 columns)
+        if (!vec4) {                                         // widths that are not a multiple of 4 floats
+            for (int e = tid; e < TG_IB * TG_T; e += ENC_THREADS) {
+                const int item = e / TG_T, cc = e - item * TG_T;
+                const long long t = tb + item;
+                const int col = j0 + cc;
+                float g = 0.f;
+                if (t < t_end && col < h) {
+                    g = dout[(size_t)(MODE == 0 ? t : dst[t]) * h + col];
+                    if (MODE == 1 && ACT != PHC_ACT_IDENTITY) {
+                        float pre = x[(size_t)src[t] * h + col];
+                        const int c = col / k, kap = col - c * k;
+                        for (int f = 0; f < F; ++f) pre += tables[c * F + f][(size_t)idx[t * F + f] * k + kap];
+                        g *= act_grad<ACT>(pre);
                     }
                 }
-            } else {
-                const int e_begin = rowptr[i], e_end = rowptr[i + 1];
-                for (int j = j0; j < h; j += jstep) {
-                    const float gd = dout[(size_t)i * h + j];
-                    const int c = j / k, kap = j - c * k;
-                    for (int e = e_begin; e < e_end; ++e) {
-                        const long long p = perm[e];
-                        float g = gd;
-                        if (ACT != PHC_ACT_IDENTITY) {
-                            float pre = x[(size_t)col[e] * h + j];
-                            for (int f = 0; f < F; ++f) pre += tables[c * F + f][(size_t)idx[p * F + f] * k + kap];
-                            g *= act_grad<ACT>(pre);
-                        }
-                        for (int f = 0; f < F; ++f) {
-                            const int r = m.off[f] + (int)idx[p * F + f];
-                            if (r >= r_lo && r < r_hi) mytbl[(r - r_lo) * h + j] += g;
-                        }
+                gs[e] = g;
+            }
+        } else
+        for (int e = tid; e < TG_IB * (TG_T / 4); e += ENC_THREADS) {
+            const int item = e / (TG_T / 4), c4 = e - item * (TG_T / 4);
+            const long long t = tb + item;
+            float4 g = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int col = j0 + c4 * 4;
+            if (t < t_end && col < h) {
+                const long long row = MODE == 0 ? t : dst[t];
+                g = *reinterpret_cast<const float4 *>(dout + (size_t)row * h + col);
+                if (MODE == 1 && ACT != PHC_ACT_IDENTITY) {
+                    float4 pre = *reinterpret_cast<const float4 *>(x + (size_t)src[t] * h + col);
+                    const int c = col / k, kap = col - c * k;
+                    for (int f = 0; f < F; ++f) {
+                        const float4 tv = *reinterpret_cast<const float4 *>(tables[c * F + f] + (size_t)idx[t * F + f] * k + kap);
+                        pre.x += tv.x; pre.y += tv.y; pre.z += tv.z; pre.w += tv.w;
                     }
+                    g.x *= act_grad<ACT>(pre.x); g.y *= act_grad<ACT>(pre.y);
+                    g.z *= act_grad<ACT>(pre.z); g.w *= act_grad<ACT>(pre.w);
                 }
             }
+            *reinterpret_cast<float4 *>(gs + item * TG_T + c4 * 4) = g;
         }
+        __syncthreads();
+        // scatter the ones: thread -> (item, feature); the F rows of one item are distinct
+        for (int e = tid; e < TG_IB * F; e += ENC_THREADS) {
+            const int item = e / F, f = e - item * F;
+            const long long t = tb + item;
+            if (t < t_end) {
+                const int rr = m.off[f] + (int)idx[t * F + f] - r0;
+                if (rr >= 0 && rr < TG_T) oh[item * TG_T + rr] = 1.f;
+            }
+        }
+        __syncthreads();
+        const float *pa = oh + hh * TG_T + wi * 32 + r;
+        const float *pb = gs + hh * TG_T + wj * 32 + r;
+#pragma unroll 8
+        for (int it = 0; it < TG_IB; it += 2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[it * TG_T], pb[it * TG_T], acc, 0, 0, 0);
     }
-    __syncthreads();
-    float *slab = slabs + ((size_t)blockIdx.x * m.R + r_lo) * h;
-    const int rows = r_hi - r_lo;
-    for (int e = tid; e < rows * h; e += ENC_THREADS) {
-        float s = 0.f;
-        for (int qq = 0; qq < Q; ++qq) s += tbl[(size_t)qq * r_tile * h + e];
-        slab[e] = s;
+    float *slab = slabs + (size_t)split * m.R * h;
+    const int col = j0 + wj * 32 + r;
+    if (col < h) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = r0 + wi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+            if (row < m.R) slab[(size_t)row * h + col] = acc[reg];
+        }
     }
 }
 
 // flat[c][r][kap] = sum_b slab[b][r][c*k+kap]    (flat is [c][f][V_f][k] because r = off_f + v)
-__global__ void table_grad_reduce_kernel(const float *__restrict__ slabs, int num_slabs, int R, int n, int k,
-                                         float *__restrict__ flat) {
+// 64 elements x 4 slab lanes per workgroup, fixed summation tree.
+__global__ __launch_bounds__(256) void table_grad_reduce_kernel(const float *__restrict__ slabs, int num_slabs, int R, int n, int k,
+                                                               float *__restrict__ flat) {
+    __shared__ float part[4][64];
     const int h = n * k;
-    const int e = blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= R * h) return;
+    const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const int e = blockIdx.x * 64 + el;
     float s = 0.f;
-    for (int b = 0; b < num_slabs; ++b) s += slabs[(size_t)b * R * h + e];
-    const int r = e / h, j = e - r * h;
-    const int c = j / k, kap = j - c * k;
-    flat[((size_t)c * R + r) * k + kap] = s;
+    if (e < R * h) {
+#pragma unroll 4
+        for (int b = sl; b < num_slabs; b += 4) s += slabs[(size_t)b * R * h + e];
+    }
+    part[sl][el] = s;
+    __syncthreads();
+    if (sl == 0 && e < R * h) {
+        const int r = e / h, j = e - r * h;
+        const int c = j / k, kap = j - c * k;
+        flat[((size_t)c * R + r) * k + kap] = ((part[0][el] + part[1][el]) + part[2][el]) + part[3][el];
+    }
 }
 
 // ---- host helpers ---------------------------------------------------------------------------------
@@ -281,29 +325,25 @@ static int make_meta(const char *who, int F, const int32_t *vocab, EncMeta *m) {
 }
 
 struct TgPlan {
-    int r_tile, r_tiles, num_slabs, Q;
-    long long rows_per_block;
-    size_t lds_bytes, slab_floats;
+    int tiles_i, tiles_j, num_slabs;
+    long long items_per_split;
+    size_t slab_floats;
 };
 
-static TgPlan tg_plan(long long n_rows, int R, int h) {
+static TgPlan tg_plan(long long n_items, int R, int h) {
     TgPlan p;
-    p.Q = h >= ENC_THREADS ? 1 : ENC_THREADS / h;
-    const size_t lds_budget = 64 * 1024;
-    int r_tile = (int)(lds_budget / (sizeof(float) * (size_t)p.Q * h));
-    if (r_tile < 1) r_tile = 1;
-    if (r_tile > R) r_tile = R;
-    p.r_tile = r_tile;
-    p.r_tiles = (R + r_tile - 1) / r_tile;
-    p.lds_bytes = sizeof(float) * (size_t)p.Q * r_tile * h;
-    // slabs: as many row ranges as keep the partial tables around 4 MB, at least 64 rows each
-    long long slabs = (long long)((4u << 20) / (sizeof(float) * (size_t)R * h));
-    if (slabs > 256) slabs = 256;
-    if (slabs < 8) slabs = 8;
-    long long rpb = (n_rows + slabs - 1) / slabs;
-    if (rpb < 64) rpb = 64;
-    p.rows_per_block = rpb;
-    p.num_slabs = (int)((n_rows + rpb - 1) / rpb);
+    p.tiles_i = (R + TG_T - 1) / TG_T;
+    p.tiles_j = (h + TG_T - 1) / TG_T;
+    const int tiles = p.tiles_i * p.tiles_j;
+    long long splits = (512 + tiles - 1) / tiles;                       // ~2 workgroups per CU
+    const long long cap = (long long)((4u << 20) / (sizeof(float) * (size_t)R * h));   // keep the slabs around 4 MB
+    if (splits > cap) splits = cap;
+    if (splits < 1) splits = 1;
+    long long ips = (n_items + splits - 1) / splits;
+    ips = (ips + TG_IB - 1) / TG_IB * TG_IB;
+    if (ips < TG_IB) ips = TG_IB;
+    p.items_per_split = ips;
+    p.num_slabs = (int)((n_items + ips - 1) / ips);
     if (p.num_slabs < 1) p.num_slabs = 1;
     p.slab_floats = (size_t)p.num_slabs * R * h;
     return p;
@@ -313,18 +353,18 @@ static inline bool al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) 
 static inline int lpr_for(int h4) { return h4 <= 8 ? 8 : h4 <= 16 ? 16 : h4 <= 32 ? 32 : 64; }
 
 template <int MODE>
-static int launch_table_grad(const float *dout, const long long *idx, const EncMeta &m, long long n_rows, int h, int n, int k,
-                             int act, const int *rowptr, const int *col, const int *perm, const float *x,
-                             const float *const *tables, float *flat, void *ws, size_t ws_bytes, hipStream_t s,
-                             const char *who) {
-    TgPlan p = tg_plan(n_rows, m.R, h);
+static int launch_table_grad(const float *dout, const long long *idx, const EncMeta &m, long long n_items, int h, int n, int k,
+                             int act, const long long *src, const long long *dst, const float *x, const float *const *tables,
+                             float *flat, void *ws, size_t ws_bytes, hipStream_t s, const char *who) {
+    const int vec4 = (k % 4 == 0) && al16(dout) && (!x || al16(x));
+    TgPlan p = tg_plan(n_items, m.R, h);
     PHC_REQUIRE(ws && ws_bytes >= sizeof(float) * p.slab_floats, PHC_ERR_WORKSPACE, "%s: workspace %zu B < required %zu B",
                 who, ws_bytes, sizeof(float) * p.slab_floats);
     float *slabs = static_cast<float *>(ws);
-    dim3 grid(p.num_slabs, p.r_tiles);
-#define PHC_TG_LAUNCH(ACTC)                                                                                             \
-    hipLaunchKernelGGL((table_grad_kernel<MODE, ACTC>), grid, dim3(ENC_THREADS), p.lds_bytes, s, dout, idx, m, n_rows,    \
-                       p.rows_per_block, h, p.r_tile, rowptr, col, perm, x, tables, n, k, slabs)
+    dim3 grid(p.tiles_i * p.tiles_j, p.num_slabs);
+#define PHC_TG_LAUNCH(ACTC)                                                                                               \
+    hipLaunchKernelGGL((table_grad_mfma_kernel<MODE, ACTC>), grid, dim3(ENC_THREADS), 0, s, dout, idx, m, n_items,          \
+                       p.items_per_split, h, p.tiles_j, src, dst, x, tables, n, k, vec4, slabs)
     {
         ProfScope prof(K_TABLE_GRAD, s);
         if (MODE == 0 || act == PHC_ACT_IDENTITY) {
@@ -343,7 +383,7 @@ static int launch_table_grad(const float *dout, const long long *idx, const EncM
     }
 #undef PHC_TG_LAUNCH
     ProfScope prof(K_TABLE_GRAD_REDUCE, s);
-    hipLaunchKernelGGL(table_grad_reduce_kernel, dim3((m.R * h + 255) / 256), dim3(256), 0, s, slabs, p.num_slabs, m.R, n, k,
+    hipLaunchKernelGGL(table_grad_reduce_kernel, dim3((m.R * h + 63) / 64), dim3(256), 0, s, slabs, p.num_slabs, m.R, n, k,
                        flat);
     return check_launch(who);
 }
@@ -398,8 +438,7 @@ int phc_encode_bwd(const float *dout, const int64_t *idx_i64, int64_t N, int F, 
     PHC_REQUIRE(N >= 0 && n >= 1 && k >= 1, PHC_ERR_INVALID_ARG, "phc_encode_bwd: N=%lld n=%d k=%d", (long long)N, n, k);
     PHC_REQUIRE(dtables_flat && (N == 0 || (dout && idx_i64)), PHC_ERR_INVALID_ARG, "phc_encode_bwd: null pointer");
     return launch_table_grad<0>(dout, reinterpret_cast<const long long *>(idx_i64), m, N, n * k, n, k, PHC_ACT_IDENTITY, nullptr,
-                                nullptr, nullptr, nullptr, nullptr, dtables_flat, ws, ws_bytes, (hipStream_t)stream,
-                                "phc_encode_bwd");
+                                nullptr, nullptr, nullptr, dtables_flat, ws, ws_bytes, (hipStream_t)stream, "phc_encode_bwd");
 }
 
 int phc_aggregate_enc_fwd(const float *x, const int64_t *bond_i64, const float *const *tables, const int32_t *vocab,
@@ -445,14 +484,14 @@ int phc_aggregate_enc_fwd(const float *x, const int64_t *bond_i64, const float *
     return check_launch("aggregate_enc_fwd");
 }
 
-size_t phc_aggregate_enc_bwd_ws_bytes(int64_t n_dst, int F, const int32_t *vocab, int n, int k) {
+size_t phc_aggregate_enc_bwd_ws_bytes(int64_t E, int F, const int32_t *vocab, int n, int k) {
     EncMeta m;
-    if (n_dst < 0 || n < 1 || k < 1 || make_meta("phc_aggregate_enc_bwd_ws_bytes", F, vocab, &m)) return 0;
-    return sizeof(float) * tg_plan(n_dst, m.R, n * k).slab_floats;
+    if (E < 0 || n < 1 || k < 1 || make_meta("phc_aggregate_enc_bwd_ws_bytes", F, vocab, &m)) return 0;
+    return sizeof(float) * tg_plan(E, m.R, n * k).slab_floats;
 }
 
 int phc_aggregate_enc_bwd(const float *dout, const float *x, const int64_t *bond_i64, const float *const *tables,
-                          const int32_t *vocab, const int32_t *rowptr, const int32_t *col, const int32_t *perm,
+                          const int32_t *vocab, const int64_t *edge_src_i64, const int64_t *edge_dst_i64, int64_t E,
                           const int32_t *rowptr_t, const int32_t *col_t, const int32_t *perm_t, int64_t n_src, int64_t n_dst,
                           int F, int n, int k, int act, int add_self, float *dx, float *dtables_flat, void *ws, size_t ws_bytes,
                           void *stream) {
@@ -501,9 +540,10 @@ int phc_aggregate_enc_bwd(const float *dout, const float *x, const int64_t *bond
         if (rc) return rc;
     }
     if (dtables_flat) {
-        PHC_REQUIRE(rowptr && col && perm, PHC_ERR_INVALID_ARG, "phc_aggregate_enc_bwd: destination-sorted structure missing");
-        return launch_table_grad<1>(dout, bond, m, n_dst, h, n, k, act, rowptr, col, perm, x, tables, dtables_flat, ws, ws_bytes,
-                                    s, "phc_aggregate_enc_bwd");
+        PHC_REQUIRE(E >= 0 && (E == 0 || (edge_src_i64 && edge_dst_i64)), PHC_ERR_INVALID_ARG, "phc_aggregate_enc_bwd: edge list missing");
+        return launch_table_grad<1>(dout, bond, m, E, h, n, k, act, reinterpret_cast<const long long *>(edge_src_i64),
+                                    reinterpret_cast<const long long *>(edge_dst_i64), x, tables, dtables_flat, ws, ws_bytes, s,
+                                    "phc_aggregate_enc_bwd");
     }
     return PHC_OK;
 }

@@ -1,0 +1,568 @@
+// Per-column batch normalisation of component-major [N, h] activations, fused with the
+// activation and skip add that follow it.
+//
+// Reference: NaivePHMNorm runs one BatchNorm1d(k) per hypercomplex component on a
+// reshaped/permuted copy and concatenates (phc/hypercomplex/norm.py:30-35); the model then
+// applies ReLU, dropout and the skip add as separate ops (models.py:208-215), PHMMLP applies
+// norm -> activation (layers.py:351-353).  Batch-norm is per column, so the n component norms
+// are ONE pass over the [N, h] matrix; the n separate weight/bias/running-stat tensors are
+// addressed through by-value pointer tables (they stay the reference's Parameters/buffers).
+//
+//   forward : bn_stats_partial  (shifted sum / sum of squares per column, row ranges)
+//             bn_apply          (fixed-order finalise, z = x_hat*w + b, out = act(z) + residual,
+//                                running-stat update by workgroup 0)
+//   backward: bn_bwd_partial    (sum g, sum g*x_hat per column, g = dy * act'(z))
+//             bn_bwd_apply      (dx = w*invstd*(g - mean(g) - x_hat*mean(g*x_hat)), dweight, dbias)
+// Rows >= *n_valid (device scalar, optional) are padding: excluded from the statistics,
+// written as 0 and given zero gradient.  No atomics; fixed summation order.
+#include "phc_common.h"
+
+namespace phc {
+
+constexpr int BN_THREADS = 256;
+constexpr int BN_MAX_COMP = PHC_MAX_COMPONENTS;
+constexpr int BN_MAX_PARTIALS = 256;
+
+struct BnParams {
+    const float *weight[BN_MAX_COMP];
+    const float *bias[BN_MAX_COMP];
+    float *running_mean[BN_MAX_COMP];
+    float *running_var[BN_MAX_COMP];
+    long long *num_batches_tracked[BN_MAX_COMP];
+    int n_comp;
+    int k;              // columns per component
+    int has_weight, has_bias, has_running, has_nbt;
+};
+
+__device__ __forceinline__ float bn_w(const BnParams &p, int col) { return p.has_weight ? p.weight[col / p.k][col % p.k] : 1.f; }
+__device__ __forceinline__ float bn_b(const BnParams &p, int col) { return p.has_bias ? p.bias[col / p.k][col % p.k] : 0.f; }
+
+template <int ACT>
+__device__ __forceinline__ float bn_act(float z) { return act_fwd<ACT>(z); }
+
+// ---- pass 1 (forward): per-column shifted sums over a row range --------------------------------
+// thread -> (vector column c = tid % cols, row lane rl = tid / cols), VEC columns per thread;
+// partial[b][0..h) = sum(x - pilot), partial[b][h..2h) = sum((x - pilot)^2), pilot = x[0][col]
+template <int VEC>
+__device__ __forceinline__ void ldv(const float *p, float (&v)[VEC]) {
+    if constexpr (VEC == 4) {
+        const float4 t = *reinterpret_cast<const float4 *>(p);
+        v[0] = t.x; v[1] = t.y; v[2] = t.z; v[3] = t.w;
+    } else {
+        v[0] = *p;
+    }
+}
+
+// Block-local two-pass: partial[b][0..h) = sum_b(x), partial[b][h..2h) = M2_b = sum_b (x - mean_b)^2.
+// (the finaliser merges blocks with Chan's formula: exact in the same sense as Welford, no E[x^2]-E[x]^2
+// cancellation even when a few hub rows dominate a column)
+template <int VEC>
+__global__ __launch_bounds__(BN_THREADS) void bn_stats_partial_kernel(const float *__restrict__ x, const int *__restrict__ n_valid,
+                                                                    long long N, int h, long long rows_per_block,
+                                                                    float *__restrict__ partial) {
+    __shared__ float red[VEC * BN_THREADS];
+    __shared__ float bmean[VEC * BN_THREADS];
+    const long long count = n_valid ? min((long long)*n_valid, N) : N;
+    const int tid = threadIdx.x;
+    const long long r0 = blockIdx.x * rows_per_block;
+    const long long r1 = min(count, r0 + rows_per_block);
+    const float nb = (float)max(r1 - r0, 1LL);
+    const int hv = h / VEC;
+    for (int cbase = 0; cbase < hv; cbase += BN_THREADS) {
+        const int cols = min(BN_THREADS, hv - cbase);
+        const int lanes = BN_THREADS / cols;                 // row lanes sharing this column block
+        const int c = tid % cols, rl = tid / cols;
+        const int col = (cbase + c) * VEC;
+        float acc[VEC];
+        // ---- pass A: column sums of this block's rows
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+        if (rl < lanes) {
+#pragma unroll 4
+            for (long long r = r0 + rl; r < r1; r += lanes) {
+                float xv[VEC];
+                ldv<VEC>(x + (size_t)r * h + col, xv);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) acc[v] += xv[v];
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) red[v * BN_THREADS + tid] = acc[v];
+        __syncthreads();
+        for (int e = tid; e < cols * VEC; e += BN_THREADS) {
+            const int cc = e / VEC, v = e - cc * VEC;
+            float a = 0.f;
+            for (int l = 0; l < lanes; ++l) a += red[v * BN_THREADS + l * cols + cc];      // fixed order
+            partial[(size_t)blockIdx.x * 2 * h + (cbase + cc) * VEC + v] = a;
+            bmean[v * BN_THREADS + cc] = a / nb;
+        }
+        __syncthreads();
+        // ---- pass B: squared deviations from the block mean (rows are L1/L2 hot)
+        float m[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            m[v] = bmean[v * BN_THREADS + c];
+            acc[v] = 0.f;
+        }
+        if (rl < lanes) {
+#pragma unroll 4
+            for (long long r = r0 + rl; r < r1; r += lanes) {
+                float xv[VEC];
+                ldv<VEC>(x + (size_t)r * h + col, xv);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    const float d = xv[v] - m[v];
+                    acc[v] = fmaf(d, d, acc[v]);
+                }
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) red[v * BN_THREADS + tid] = acc[v];
+        __syncthreads();
+        for (int e = tid; e < cols * VEC; e += BN_THREADS) {
+            const int cc = e / VEC, v = e - cc * VEC;
+            float a = 0.f;
+            for (int l = 0; l < lanes; ++l) a += red[v * BN_THREADS + l * cols + cc];
+            partial[(size_t)blockIdx.x * 2 * h + h + (cbase + cc) * VEC + v] = a;
+        }
+        __syncthreads();
+    }
+}
+
+// Merge the per-block (sum, M2) pairs: 8 columns per workgroup, 32 partial lanes each, fixed order.
+// Writes stat[0..h) = mean, stat[h..2h) = invstd, stat[2h..3h) = scale = invstd*w, stat[3h..4h) = shift;
+// updates the running statistics (training).
+__global__ __launch_bounds__(BN_THREADS) void bn_finalize_kernel(BnParams p, const int *__restrict__ n_valid, long long N, int h,
+                                                               int training, float momentum, float eps,
+                                                               const float *__restrict__ partial, int num_partials,
+                                                               long long rows_per_block, float *__restrict__ stat,
+                                                               float *__restrict__ save_mean, float *__restrict__ save_invstd) {
+    __shared__ float r_sum[32][8], r_m2[32][8];
+    const long long count = n_valid ? min((long long)*n_valid, N) : N;
+    const int tid = threadIdx.x;
+    const int ci = tid & 7, pl = tid >> 3;
+    const int c = blockIdx.x * 8 + ci;
+    const float cnt = (float)max(count, 1LL);
+    float mean = 0.f, invstd = 1.f;
+    if (training) {
+        float s = 0.f;
+        if (c < h)
+            for (int b = pl; b < num_partials; b += 32) s += partial[(size_t)b * 2 * h + c];
+        r_sum[pl][ci] = s;
+        __syncthreads();
+        float tot = 0.f;
+        for (int l = 0; l < 32; ++l) tot += r_sum[l][ci];
+        mean = tot / cnt;
+        float m2 = 0.f;
+        if (c < h)
+            for (int b = pl; b < num_partials; b += 32) {
+                const long long nb_i = min(rows_per_block, max(count - (long long)b * rows_per_block, 0LL));
+                if (nb_i > 0) {
+                    const float nb = (float)nb_i;
+                    const float d = partial[(size_t)b * 2 * h + c] / nb - mean;
+                    m2 += partial[(size_t)b * 2 * h + h + c] + nb * d * d;
+                }
+            }
+        r_m2[pl][ci] = m2;
+        __syncthreads();
+        if (pl == 0 && c < h) {
+            float M2 = 0.f;
+            for (int l = 0; l < 32; ++l) M2 += r_m2[l][ci];
+            const float var = fmaxf(M2 / cnt, 0.f);
+            invstd = 1.f / sqrtf(var + eps);
+            if (p.has_running) {
+                const int comp = c / p.k, kk = c % p.k;
+                const float unbiased = count > 1 ? M2 / (cnt - 1.f) : var;
+                float *rm = p.running_mean[comp] + kk, *rv = p.running_var[comp] + kk;
+                *rm = (1.f - momentum) * (*rm) + momentum * mean;
+                *rv = (1.f - momentum) * (*rv) + momentum * unbiased;
+            }
+        }
+        if (blockIdx.x == 0 && p.has_nbt && tid < p.n_comp) *p.num_batches_tracked[tid] += 1;
+    } else if (pl == 0 && c < h) {
+        const int comp = c / p.k, kk = c % p.k;
+        mean = p.running_mean[comp][kk];
+        invstd = 1.f / sqrtf(p.running_var[comp][kk] + eps);
+    }
+    if (pl == 0 && c < h) {
+        const float w = bn_w(p, c);
+        stat[c] = mean;
+        stat[h + c] = invstd;
+        if (save_mean) save_mean[c] = mean;
+        if (save_invstd) save_invstd[c] = invstd;
+        stat[2 * h + c] = invstd * w;
+        stat[3 * h + c] = bn_b(p, c) - mean * invstd * w;
+    }
+}
+
+// ---- pass 3 (forward): out = act(x * scale + shift) (+ residual) ----------------------------------
+template <int ACT>
+__global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const float *__restrict__ x, const int *__restrict__ n_valid, long long N,
+                                                            int h, const float *__restrict__ residual,
+                                                            const float *__restrict__ stat, float *__restrict__ out) {
+    extern __shared__ float sm[];                            // scale[h], shift[h]
+    float *scale = sm, *shift = sm + h;
+    const long long count = n_valid ? min((long long)*n_valid, N) : N;
+    const int tid = threadIdx.x;
+    for (int c = tid; c < h; c += BN_THREADS) {
+        scale[c] = stat[2 * h + c];
+        shift[c] = stat[3 * h + c];
+    }
+    __syncthreads();
+    if ((h & 3) == 0) {
+        const int h4 = h >> 2;
+        const long long total4 = N * (long long)h4;
+        for (long long e = (long long)blockIdx.x * BN_THREADS + tid; e < total4; e += (long long)gridDim.x * BN_THREADS) {
+            const long long r = e / h4;
+            const int c = (int)(e - r * h4) << 2;
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < count) {
+                const float4 v = reinterpret_cast<const float4 *>(x)[e];
+                o.x = bn_act<ACT>(fmaf(v.x, scale[c], shift[c]));
+                o.y = bn_act<ACT>(fmaf(v.y, scale[c + 1], shift[c + 1]));
+                o.z = bn_act<ACT>(fmaf(v.z, scale[c + 2], shift[c + 2]));
+                o.w = bn_act<ACT>(fmaf(v.w, scale[c + 3], shift[c + 3]));
+                if (residual) {
+                    const float4 rr = reinterpret_cast<const float4 *>(residual)[e];
+                    o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+                }
+            }
+            reinterpret_cast<float4 *>(out)[e] = o;
+        }
+    } else {
+        const long long total = N * (long long)h;
+        for (long long e = (long long)blockIdx.x * BN_THREADS + tid; e < total; e += (long long)gridDim.x * BN_THREADS) {
+            const long long r = e / h;
+            const int c = (int)(e - r * h);
+            float o = 0.f;
+            if (r < count) {
+                o = bn_act<ACT>(fmaf(x[e], scale[c], shift[c]));
+                if (residual) o += residual[e];
+            }
+            out[e] = o;
+        }
+    }
+}
+
+// ---- pass 1 (backward): sum g and sum g*x_hat per column ------------------------------------------
+template <int ACT, int VEC>
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_partial_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+                                                                  BnParams p, const float *__restrict__ save_mean,
+                                                                  const float *__restrict__ save_invstd,
+                                                                  const int *__restrict__ n_valid, long long N, int h,
+                                                                  long long rows_per_block, float *__restrict__ partial) {
+    __shared__ float red[2 * VEC * BN_THREADS];
+    const long long count = n_valid ? min((long long)*n_valid, N) : N;
+    const int tid = threadIdx.x;
+    const long long r0 = blockIdx.x * rows_per_block;
+    const long long r1 = min(count, r0 + rows_per_block);
+    const int hv = h / VEC;
+    for (int cbase = 0; cbase < hv; cbase += BN_THREADS) {
+        const int cols = min(BN_THREADS, hv - cbase);
+        const int lanes = BN_THREADS / cols;
+        const int c = tid % cols, rl = tid / cols;
+        float sg[VEC], sgx[VEC];
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) sg[v] = sgx[v] = 0.f;
+        if (rl < lanes) {
+            const int col = (cbase + c) * VEC;
+            float mean[VEC], inv[VEC], w[VEC], b[VEC];
+#pragma unroll
+            for (int v = 0; v < VEC; ++v) {
+                mean[v] = save_mean[col + v];
+                inv[v] = save_invstd[col + v];
+                w[v] = bn_w(p, col + v);
+                b[v] = bn_b(p, col + v);
+            }
+#pragma unroll 4
+            for (long long r = r0 + rl; r < r1; r += lanes) {
+                float xv[VEC], gv[VEC];
+                ldv<VEC>(x + (size_t)r * h + col, xv);
+                ldv<VEC>(dy + (size_t)r * h + col, gv);
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) {
+                    const float xh = (xv[v] - mean[v]) * inv[v];
+                    float g = gv[v];
+                    if (ACT != PHC_ACT_IDENTITY) g *= act_grad<ACT>(fmaf(xh, w[v], b[v]));
+                    sg[v] += g;
+                    sgx[v] = fmaf(g, xh, sgx[v]);
+                }
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) {
+            red[v * BN_THREADS + tid] = sg[v];
+            red[(VEC + v) * BN_THREADS + tid] = sgx[v];
+        }
+        __syncthreads();
+        for (int e = tid; e < cols * VEC; e += BN_THREADS) {
+            const int cc = e / VEC, v = e - cc * VEC;
+            float a = 0.f, bsum = 0.f;
+            for (int l = 0; l < lanes; ++l) {
+                a += red[v * BN_THREADS + l * cols + cc];
+                bsum += red[(VEC + v) * BN_THREADS + l * cols + cc];
+            }
+            partial[(size_t)blockIdx.x * 2 * h + (cbase + cc) * VEC + v] = a;
+            partial[(size_t)blockIdx.x * 2 * h + h + (cbase + cc) * VEC + v] = bsum;
+        }
+        __syncthreads();
+    }
+}
+
+// ---- pass 2 (backward): merge partial sums; dwb = [dweight | dbias]; bstat = [mean(g) | mean(g*x_hat)] ------
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_finalize_kernel(const int *__restrict__ n_valid, long long N, int h, int training,
+                                                                   const float *__restrict__ partial, int num_partials,
+                                                                   float *__restrict__ dwb, float *__restrict__ bstat) {
+    __shared__ float r_a[32][8], r_b[32][8];
+    const long long count = n_valid ? min((long long)*n_valid, N) : N;
+    const int tid = threadIdx.x;
+    const int ci = tid & 7, pl = tid >> 3;
+    const int c = blockIdx.x * 8 + ci;
+    float sg = 0.f, sgx = 0.f;
+    if (c < h)
+        for (int b = pl; b < num_partials; b += 32) {
+            sg += partial[(size_t)b * 2 * h + c];
+            sgx += partial[(size_t)b * 2 * h + h + c];
+        }
+    r_a[pl][ci] = sg;
+    r_b[pl][ci] = sgx;
+    __syncthreads();
+    if (pl == 0 && c < h) {
+        float a = 0.f, b = 0.f;
+        for (int l = 0; l < 32; ++l) {
+            a += r_a[l][ci];
+            b += r_b[l][ci];
+        }
+        if (dwb) {
+            dwb[c] = b;                                      // dweight = sum g * x_hat
+            dwb[h + c] = a;                                  // dbias   = sum g
+        }
+        const float cnt = (float)max(count, 1LL);
+        bstat[c] = training ? a / cnt : 0.f;
+        bstat[h + c] = training ? b / cnt : 0.f;
+    }
+}
+
+// ---- pass 3 (backward): dx = w*invstd*(g - mean(g) - x_hat*mean(g*x_hat)) ---------------------------
+template <int ACT>
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const float *__restrict__ dy, const float *__restrict__ x, BnParams p,
+                                                                const float *__restrict__ save_mean,
+                                                                const float *__restrict__ save_invstd,
+                                                                const int *__restrict__ n_valid, long long N, int h,
+                                                                const float *__restrict__ bstat, float *__restrict__ dx) {
+    extern __shared__ float sm[];                            // mean, invstd, w, b, mg, mgx : 6 * h
+    float *s_mean = sm, *s_inv = sm + h, *s_w = sm + 2 * h, *s_b = sm + 3 * h, *s_mg = sm + 4 * h, *s_mgx = sm + 5 * h;
+    const long long count = n_valid ? min((long long)*n_valid, N) : N;
+    const int tid = threadIdx.x;
+    for (int c = tid; c < h; c += BN_THREADS) {
+        s_mean[c] = save_mean[c];
+        s_inv[c] = save_invstd[c];
+        s_w[c] = bn_w(p, c);
+        s_b[c] = bn_b(p, c);
+        s_mg[c] = bstat[c];
+        s_mgx[c] = bstat[h + c];
+    }
+    __syncthreads();
+    auto one = [&](float xv, float gv, int c) -> float {
+        const float xh = (xv - s_mean[c]) * s_inv[c];
+        float g = gv;
+        if (ACT != PHC_ACT_IDENTITY) g *= act_grad<ACT>(fmaf(xh, s_w[c], s_b[c]));
+        return s_w[c] * s_inv[c] * (g - s_mg[c] - xh * s_mgx[c]);
+    };
+    if ((h & 3) == 0) {
+        const int h4 = h >> 2;
+        const long long total4 = N * (long long)h4;
+        for (long long e = (long long)blockIdx.x * BN_THREADS + tid; e < total4; e += (long long)gridDim.x * BN_THREADS) {
+            const long long r = e / h4;
+            const int c = (int)(e - r * h4) << 2;
+            float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (r < count) {
+                const float4 xv = reinterpret_cast<const float4 *>(x)[e];
+                const float4 gv = reinterpret_cast<const float4 *>(dy)[e];
+                o.x = one(xv.x, gv.x, c); o.y = one(xv.y, gv.y, c + 1);
+                o.z = one(xv.z, gv.z, c + 2); o.w = one(xv.w, gv.w, c + 3);
+            }
+            reinterpret_cast<float4 *>(dx)[e] = o;
+        }
+    } else {
+        const long long total = N * (long long)h;
+        for (long long e = (long long)blockIdx.x * BN_THREADS + tid; e < total; e += (long long)gridDim.x * BN_THREADS) {
+            const long long r = e / h;
+            const int c = (int)(e - r * h);
+            dx[e] = r < count ? one(x[e], dy[e], c) : 0.f;
+        }
+    }
+}
+
+// ---- host ---------------------------------------------------------------------------------------------
+struct BnPlan {
+    int num_partials;
+    long long rows_per_block;
+};
+
+static BnPlan bn_plan(long long N) {
+    BnPlan p;
+    long long parts = (N + 63) / 64;                        // >= 64 rows per workgroup
+    if (parts > BN_MAX_PARTIALS) parts = BN_MAX_PARTIALS;
+    if (parts < 1) parts = 1;
+    p.rows_per_block = (N + parts - 1) / parts;
+    if (p.rows_per_block < 1) p.rows_per_block = 1;
+    p.num_partials = (int)((N + p.rows_per_block - 1) / p.rows_per_block);
+    if (p.num_partials < 1) p.num_partials = 1;
+    return p;
+}
+
+static int fill_params(const char *who, BnParams *p, const float *const *weight, const float *const *bias,
+                       float *const *running_mean, float *const *running_var, int64_t *const *nbt, int n_comp, int h) {
+    PHC_REQUIRE(n_comp >= 1 && n_comp <= BN_MAX_COMP, PHC_ERR_UNSUPPORTED, "%s: %d components (max %d)", who, n_comp, BN_MAX_COMP);
+    PHC_REQUIRE(h >= 1 && h % n_comp == 0, PHC_ERR_INVALID_ARG, "%s: h=%d not divisible by n_comp=%d", who, h, n_comp);
+    p->n_comp = n_comp;
+    p->k = h / n_comp;
+    p->has_weight = weight != nullptr;
+    p->has_bias = bias != nullptr;
+    p->has_running = running_mean != nullptr && running_var != nullptr;
+    p->has_nbt = nbt != nullptr;
+    for (int c = 0; c < n_comp; ++c) {
+        p->weight[c] = weight ? weight[c] : nullptr;
+        p->bias[c] = bias ? bias[c] : nullptr;
+        p->running_mean[c] = running_mean ? running_mean[c] : nullptr;
+        p->running_var[c] = running_var ? running_var[c] : nullptr;
+        p->num_batches_tracked[c] = nbt ? reinterpret_cast<long long *>(nbt[c]) : nullptr;
+        PHC_REQUIRE((!weight || weight[c]) && (!bias || bias[c]) && (!p->has_running || (running_mean[c] && running_var[c])),
+                    PHC_ERR_INVALID_ARG, "%s: null parameter pointer for component %d", who, c);
+    }
+    return PHC_OK;
+}
+
+static inline unsigned apply_grid(long long N, int h) {
+    long long blocks = (N * (long long)h / 4 + BN_THREADS * 4 - 1) / (BN_THREADS * 4);
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    return (unsigned)blocks;
+}
+
+#define PHC_BN_ACT_SWITCH(act, MACRO)                 \
+    switch (act) {                                    \
+        case PHC_ACT_IDENTITY: MACRO(PHC_ACT_IDENTITY); break; \
+        case PHC_ACT_RELU: MACRO(PHC_ACT_RELU); break;         \
+        case PHC_ACT_LRELU: MACRO(PHC_ACT_LRELU); break;       \
+        case PHC_ACT_ELU: MACRO(PHC_ACT_ELU); break;           \
+        case PHC_ACT_SWISH: MACRO(PHC_ACT_SWISH); break;       \
+        default: MACRO(PHC_ACT_SELU); break;                   \
+    }
+
+}  // namespace phc
+
+using namespace phc;
+
+extern "C" {
+
+size_t phc_bn_ws_bytes(int64_t N, int h) {
+    if (N < 0 || h < 1) return 0;
+    return sizeof(float) * (size_t)h * (2 * BN_MAX_PARTIALS + 4);    // partials + [mean|invstd|scale|shift]
+}
+
+int phc_bn_fwd(const float *x, const float *const *weight, const float *const *bias, float *const *running_mean,
+               float *const *running_var, int64_t *const *num_batches_tracked, int n_comp, const int32_t *n_valid_dev, int64_t N,
+               int h, int training, float momentum, float eps, int act, const float *residual, float *out, float *save_mean,
+               float *save_invstd, void *ws, size_t ws_bytes, void *stream) {
+    BnParams p;
+    int rc = fill_params("phc_bn_fwd", &p, weight, bias, running_mean, running_var, num_batches_tracked, n_comp, h);
+    if (rc) return rc;
+    PHC_REQUIRE(N >= 0, PHC_ERR_INVALID_ARG, "phc_bn_fwd: N < 0");
+    PHC_REQUIRE(act >= PHC_ACT_IDENTITY && act <= PHC_ACT_SELU, PHC_ERR_INVALID_ARG, "phc_bn_fwd: unknown activation %d", act);
+    PHC_REQUIRE(training || p.has_running, PHC_ERR_INVALID_ARG, "phc_bn_fwd: eval mode needs running statistics");
+    if (N == 0) return PHC_OK;
+    PHC_REQUIRE(x && out, PHC_ERR_INVALID_ARG, "phc_bn_fwd: null pointer");
+    PHC_REQUIRE(h <= 8192, PHC_ERR_UNSUPPORTED, "phc_bn_fwd: h=%d too wide", h);
+    hipStream_t s = (hipStream_t)stream;
+    BnPlan plan = bn_plan(N);
+    float *partial = static_cast<float *>(ws);
+    const bool vec4 = (h % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0) &&
+                      (!residual || (reinterpret_cast<uintptr_t>(residual) & 15) == 0);
+    PHC_REQUIRE(vec4 || h % 4 != 0, PHC_ERR_UNSUPPORTED, "phc_bn_fwd: rows must be 16-byte aligned when h %% 4 == 0");
+    PHC_REQUIRE(ws && ws_bytes >= phc_bn_ws_bytes(N, h), PHC_ERR_WORKSPACE, "phc_bn_fwd: workspace too small");
+    float *stat = partial + 2 * (size_t)h * BN_MAX_PARTIALS;
+    if (training) {
+        ProfScope prof(K_BN_STATS, s);
+        if (vec4)
+            hipLaunchKernelGGL((bn_stats_partial_kernel<4>), dim3(plan.num_partials), dim3(BN_THREADS), 0, s, x, n_valid_dev,
+                               (long long)N, h, plan.rows_per_block, partial);
+        else
+            hipLaunchKernelGGL((bn_stats_partial_kernel<1>), dim3(plan.num_partials), dim3(BN_THREADS), 0, s, x, n_valid_dev,
+                               (long long)N, h, plan.rows_per_block, partial);
+        rc = check_launch("bn_stats_partial");
+        if (rc) return rc;
+    }
+    {
+        ProfScope prof(K_BN_FINALIZE, s);
+        hipLaunchKernelGGL(bn_finalize_kernel, dim3((h + 7) / 8), dim3(BN_THREADS), 0, s, p, n_valid_dev, (long long)N, h, training,
+                           momentum, eps, partial, plan.num_partials, plan.rows_per_block, stat, save_mean, save_invstd);
+        rc = check_launch("bn_finalize");
+        if (rc) return rc;
+    }
+    const size_t lds = sizeof(float) * 2 * (size_t)h;
+    ProfScope prof(K_BN_APPLY, s);
+#define PHC_BN_FWD(ACTC)                                                                                                      \
+    hipLaunchKernelGGL((bn_apply_kernel<ACTC>), dim3(apply_grid(N, h)), dim3(BN_THREADS), lds, s, x, n_valid_dev, (long long)N, h,   \
+                       residual, stat, out)
+    PHC_BN_ACT_SWITCH(act, PHC_BN_FWD)
+#undef PHC_BN_FWD
+    return check_launch("bn_apply");
+}
+
+int phc_bn_bwd(const float *dy, const float *x, const float *const *weight, const float *const *bias, const float *save_mean,
+               const float *save_invstd, int n_comp, const int32_t *n_valid_dev, int64_t N, int h, int training, int act, float *dx,
+               float *dwb_flat, void *ws, size_t ws_bytes, void *stream) {
+    BnParams p;
+    int rc = fill_params("phc_bn_bwd", &p, weight, bias, nullptr, nullptr, nullptr, n_comp, h);
+    if (rc) return rc;
+    PHC_REQUIRE(N >= 0, PHC_ERR_INVALID_ARG, "phc_bn_bwd: N < 0");
+    PHC_REQUIRE(act >= PHC_ACT_IDENTITY && act <= PHC_ACT_SELU, PHC_ERR_INVALID_ARG, "phc_bn_bwd: unknown activation %d", act);
+    PHC_REQUIRE(h <= 8192, PHC_ERR_UNSUPPORTED, "phc_bn_bwd: h=%d too wide", h);
+    hipStream_t s = (hipStream_t)stream;
+    if (N == 0) {
+        if (dwb_flat) hipMemsetAsync(dwb_flat, 0, sizeof(float) * 2 * (size_t)h, s);
+        return PHC_OK;
+    }
+    PHC_REQUIRE(dy && x && save_mean && save_invstd, PHC_ERR_INVALID_ARG, "phc_bn_bwd: null pointer");
+    PHC_REQUIRE(ws && ws_bytes >= phc_bn_ws_bytes(N, h), PHC_ERR_WORKSPACE, "phc_bn_bwd: workspace too small");
+    BnPlan plan = bn_plan(N);
+    float *partial = static_cast<float *>(ws);
+    const bool vec4 = (h % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((reinterpret_cast<uintptr_t>(dy) & 15) == 0) &&
+                      (!dx || (reinterpret_cast<uintptr_t>(dx) & 15) == 0);
+    PHC_REQUIRE(vec4 || h % 4 != 0, PHC_ERR_UNSUPPORTED, "phc_bn_bwd: rows must be 16-byte aligned when h %% 4 == 0");
+    {
+        ProfScope prof(K_BN_BWD_PARTIAL, s);
+#define PHC_BN_BP(ACTC)                                                                                                      \
+    if (vec4)                                                                                                                \
+        hipLaunchKernelGGL((bn_bwd_partial_kernel<ACTC, 4>), dim3(plan.num_partials), dim3(BN_THREADS), 0, s, dy, x, p, save_mean,  \
+                           save_invstd, n_valid_dev, (long long)N, h, plan.rows_per_block, partial);                         \
+    else                                                                                                                     \
+        hipLaunchKernelGGL((bn_bwd_partial_kernel<ACTC, 1>), dim3(plan.num_partials), dim3(BN_THREADS), 0, s, dy, x, p, save_mean,  \
+                           save_invstd, n_valid_dev, (long long)N, h, plan.rows_per_block, partial)
+        PHC_BN_ACT_SWITCH(act, PHC_BN_BP)
+#undef PHC_BN_BP
+        rc = check_launch("bn_bwd_partial");
+        if (rc) return rc;
+    }
+    float *bstat = partial + 2 * (size_t)h * BN_MAX_PARTIALS;
+    {
+        ProfScope prof(K_BN_BWD_FINALIZE, s);
+        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((h + 7) / 8), dim3(BN_THREADS), 0, s, n_valid_dev, (long long)N, h, training,
+                           partial, plan.num_partials, dwb_flat, bstat);
+        rc = check_launch("bn_bwd_finalize");
+        if (rc) return rc;
+    }
+    if (!dx) return PHC_OK;
+    const size_t lds = sizeof(float) * 6 * (size_t)h;
+    ProfScope prof(K_BN_BWD_APPLY, s);
+#define PHC_BN_BA(ACTC)                                                                                                      \
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<ACTC>), dim3(apply_grid(N, h)), dim3(BN_THREADS), lds, s, dy, x, p, save_mean,          \
+                       save_invstd, n_valid_dev, (long long)N, h, bstat, dx)
+    PHC_BN_ACT_SWITCH(act, PHC_BN_BA)
+#undef PHC_BN_BA
+    return check_launch("bn_bwd_apply");
+}
+
+}  // extern "C"

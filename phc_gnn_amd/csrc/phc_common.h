@@ -41,6 +41,12 @@ enum KernelId : int {
     K_AGG_ENC_DX,
     K_TABLE_GRAD,
     K_TABLE_GRAD_REDUCE,
+    K_BN_STATS,
+    K_BN_FINALIZE,
+    K_BN_APPLY,
+    K_BN_BWD_PARTIAL,
+    K_BN_BWD_FINALIZE,
+    K_BN_BWD_APPLY,
     K_NUM_KERNELS
 };
 

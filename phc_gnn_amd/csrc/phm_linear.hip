@@ -5,10 +5,10 @@
 //
 // Forward / dX kernel (phm_gemm_kernel):
 //   * the n*n*n contribution tensor A is staged in LDS once per workgroup;
-//   * the [K x 64] panel of H (or H^T for dX) a workgroup needs is ASSEMBLED IN
+//   * the [K x 128] panel of H (or H^T for dX) a workgroup needs is ASSEMBLED IN
 //     LDS from W (n*kin*kout floats, L2 resident) — H never exists in HBM;
 //   * x tiles [64 x K-chunk] are staged through LDS with 16-byte loads and fed
-//     to v_mfma_f32_32x32x2_f32 (exact fp32, 4 waves = 2x2 tiles of 32x32).
+//     to v_mfma_f32_32x32x2_f32 (exact fp32; 4 waves as 2x2, each 32 rows x 64 cols).
 //   When K <= 128 the H panel is built once and the workgroup streams M tiles
 //   under it.
 // Backward w.r.t. parameters:
@@ -21,17 +21,27 @@ namespace phc {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
 
-constexpr int GEMM_BM = 64;        // rows of x per tile
-constexpr int GEMM_BN = 64;        // output columns per workgroup
 constexpr int GEMM_BK = 128;       // K chunk held in LDS
 constexpr int XS_STRIDE = GEMM_BK + 4;   // floats; +4 keeps ds_read_b128 conflict-free (16-lane groups hit 16 distinct 4-bank slots)
-constexpr int HS_STRIDE = GEMM_BN + 1;   // floats; odd stride: conflict-free for both fill orders and for the b32 operand reads
-constexpr int GEMM_THREADS = 256;
 constexpr int MAX_PHM_DIM = 16;
+constexpr int HB = 8;              // W-load batch of the panel builder (HB * n loads in flight per thread)
+
+// Two tile configurations of the same kernel (chosen by the row count on the host):
+//   latency    : 64 x 64 tile, 256 threads, 2 workgroups per CU  — molecule batches (a few hundred tiles in all)
+//   throughput : 128 x 128 tile, 512 threads (2 waves per SIMD), x streamed once per 128 outputs — large graphs
+template <int BM, int BN>
+struct GemmCfg {
+    static constexpr int CT = BN / 64;                       // 32-column MFMA tiles per wave (waves are 32 rows x CT*32 cols)
+    static constexpr int WAVES_M = BM / 32, WAVES_N = 2;
+    static constexpr int THREADS = 64 * WAVES_M * WAVES_N;
+    static constexpr int HS_STRIDE = BN + 1;                 // odd: conflict-free for both fill orders and the b32 operand reads
+    static constexpr int X_REGS = BM * GEMM_BK / 4 / THREADS;
+    static constexpr size_t lds_floats(int n) { return (size_t)BM * XS_STRIDE + (size_t)GEMM_BK * HS_STRIDE + (size_t)n * n * n; }
+};
 
 __host__ __device__ inline int round_up(int v, int m) { return (v + m - 1) / m * m; }
 
-// Element (k, j) of the GEMM's right operand.
+// Element (k, j) of the GEMM's right operand (used by the exported H builder).
 //   TRANS = 0: operand is H    : k = a*kin + kap (input feature), j = c*kout + pi (output feature)
 //   TRANS = 1: operand is H^T  : k = c*kout + pi,                 j = a*kin + kap
 template <int TRANS>
@@ -55,116 +65,218 @@ __device__ __forceinline__ float h_element(const float *__restrict__ As, const f
     return h;
 }
 
+// Assemble rows [k0, k0+kc) x columns [j0, j0+BN) of the operand in LDS (hs[kk * HS_STRIDE + jj]).
+// W-stationary: each work item loads the n values W[0..n)[kap][pi] ONCE (contiguous in pi across
+// lanes) and emits every operand element that uses them (one per a for H, one per c for H^T), mixing
+// with the contribution tensor held in LDS.  Items are processed HB at a time so that HB*n global
+// loads are in flight per thread.  NPHM > 0 fixes n at compile time.
+template <int TRANS, int NPHM, int BN, int THREADS>
+__device__ __forceinline__ void build_h_chunk(const float *__restrict__ As, const float *__restrict__ W, float *__restrict__ hs,
+                                              int n_rt, int kin, int kout, int k0, int kc, int kc8, int j0, int Nout, int tid) {
+    constexpr int HS_STRIDE = BN + 1;
+    const int n = NPHM ? NPHM : n_rt;
+    constexpr int NN = NPHM ? NPHM : MAX_PHM_DIM;
+    const int wstride = kin * kout;
+    const int astride = n * n;
+    // rows kc..kc8 are MFMA padding
+    for (int e = tid; e < (kc8 - kc) * BN; e += THREADS) hs[(kc + e / BN) * HS_STRIDE + (e % BN)] = 0.f;
+    if (TRANS == 0) {
+        constexpr int STEP = THREADS / BN;
+        const int jj = tid & (BN - 1);
+        const int j = j0 + jj;
+        const bool jvalid = j < Nout;
+        const int c = jvalid ? j / kout : 0;
+        const int pi = jvalid ? j - c * kout : 0;
+        const float *wbase = W + pi;
+        const float *abase = As + c;
+        for (int kap0 = tid / BN; kap0 < kin; kap0 += HB * STEP) {
+            float w[HB][NN];
+#pragma unroll
+            for (int b = 0; b < HB; ++b) {
+                const int kap = kap0 + b * STEP;
+#pragma unroll
+                for (int i = 0; i < NN; ++i) w[b][i] = (i < n && jvalid && kap < kin) ? wbase[(size_t)i * wstride + kap * kout] : 0.f;
+            }
+#pragma unroll
+            for (int b = 0; b < HB; ++b) {
+                const int kap = kap0 + b * STEP;
+                if (kap >= kin) break;
+                int a = k0 > kap ? (k0 - kap + kin - 1) / kin : 0;
+                for (; a < n; ++a) {
+                    const int kk = a * kin + kap - k0;
+                    if (kk >= kc) break;
+                    float hsum = 0.f;
+#pragma unroll
+                    for (int i = 0; i < NN; ++i)
+                        if (i < n) hsum = fmaf(abase[i * astride + a * n], w[b][i], hsum);
+                    hs[kk * HS_STRIDE + jj] = hsum;
+                }
+            }
+        }
+    } else {
+        const int items = BN * kout;
+        for (int it0 = tid; it0 < items; it0 += HB * THREADS) {
+            float w[HB][NN];
+            int jjv[HB], piv[HB], av[HB];
+#pragma unroll
+            for (int b = 0; b < HB; ++b) {
+                const int it = it0 + b * THREADS;
+                const int jj = it / kout;
+                const int pi = it - jj * kout;
+                const int j = j0 + jj;
+                const bool valid = it < items && j < Nout;
+                const int a = valid ? j / kin : 0;
+                const int kap = valid ? j - a * kin : 0;
+                jjv[b] = jj; piv[b] = pi; av[b] = a;
+                const float *wbase = W + (size_t)kap * kout + pi;
+#pragma unroll
+                for (int i = 0; i < NN; ++i) w[b][i] = (i < n && valid) ? wbase[(size_t)i * wstride] : 0.f;
+            }
+#pragma unroll
+            for (int b = 0; b < HB; ++b) {
+                if (it0 + b * THREADS >= items) break;
+                const int pi = piv[b], a = av[b];
+                int c = k0 > pi ? (k0 - pi + kout - 1) / kout : 0;
+                for (; c < n; ++c) {
+                    const int kk = c * kout + pi - k0;
+                    if (kk >= kc) break;
+                    float hsum = 0.f;
+#pragma unroll
+                    for (int i = 0; i < NN; ++i)
+                        if (i < n) hsum = fmaf(As[i * astride + a * n + c], w[b][i], hsum);
+                    hs[kk * HS_STRIDE + jjv[b]] = hsum;
+                }
+            }
+        }
+    }
+}
+
 // out[M, Nout] = X[M, K] . Op(K, Nout) (+ bias[Nout]) (+ residual[M, Nout])
-// grid.x = number of 64-wide output panels, grid.y = workgroups striding over M tiles.
-template <int TRANS>
-__global__ __launch_bounds__(GEMM_THREADS) void phm_gemm_kernel(
+// grid.x = number of BN-wide output panels, grid.y = workgroups striding over M tiles.
+// Per (M tile, K chunk): x chunk -> registers (issued first / prefetched under the previous MFMA loop),
+// operand panel assembled in LDS (once per workgroup when K fits one chunk), registers -> LDS, MFMA.
+template <int TRANS, int NPHM, int BM, int BN>
+__global__ __launch_bounds__((GemmCfg<BM, BN>::THREADS)) void phm_gemm_kernel(
     const float *__restrict__ X, const float *__restrict__ A, const float *__restrict__ W,
     const float *__restrict__ bias, const float *__restrict__ residual, float *__restrict__ out,
     long long M, int K, int Nout, int n, int kin, int kout, int vec4) {
+    using Cfg = GemmCfg<BM, BN>;
+    constexpr int THREADS = Cfg::THREADS, HS_STRIDE = Cfg::HS_STRIDE, X_REGS = Cfg::X_REGS, CT = Cfg::CT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *xs = smem;                                   // [GEMM_BM][XS_STRIDE]
-    float *hs = xs + GEMM_BM * XS_STRIDE;               // [GEMM_BK][HS_STRIDE]
+    float *xs = smem;                                   // [BM][XS_STRIDE]
+    float *hs = xs + BM * XS_STRIDE;                    // [GEMM_BK][HS_STRIDE]
     float *As = hs + GEMM_BK * HS_STRIDE;               // [n*n*n]
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int wave = tid >> 6;
-    const int wm = wave >> 1, wn = wave & 1;            // 2 x 2 waves of 32 x 32
+    const int wm = wave >> 1, wn = wave & 1;            // WAVES_M x 2 waves, each 32 rows x (CT*32) columns
     const int r = lane & 31, hh = lane >> 5;
-    const int j0 = blockIdx.x * GEMM_BN;
+    const int j0 = blockIdx.x * BN;
 
-    for (int i = tid; i < n * n * n; i += GEMM_THREADS) As[i] = A[i];
+    for (int i = tid; i < n * n * n; i += THREADS) As[i] = A[i];
 
     const int num_chunks = (K + GEMM_BK - 1) / GEMM_BK;
-    const long long num_mtiles = (M + GEMM_BM - 1) / GEMM_BM;
+    const long long num_mtiles = (M + BM - 1) / BM;
+    const long long my_tiles = blockIdx.y < num_mtiles ? (num_mtiles - blockIdx.y + gridDim.y - 1) / gridDim.y : 0;
+    const long long total_iters = my_tiles * num_chunks;
     bool h_ready = false;                               // panel resident across M tiles when K fits one chunk
 
-    for (long long mt = blockIdx.y; mt < num_mtiles; mt += gridDim.y) {
-        const long long m0 = mt * GEMM_BM;
-        f32x16 acc;
+    float4 xr[X_REGS];
+    auto load_x = [&](long long it) {                   // global -> registers for iteration `it`
+        const long long mt = blockIdx.y + (it / num_chunks) * gridDim.y;
+        const int ch = (int)(it % num_chunks);
+        const long long m0 = mt * BM;
+        const int k0 = ch * GEMM_BK;
+        const int kc = min(GEMM_BK, K - k0);
+        const int c4n = round_up(kc, 8) >> 2;
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+        for (int t = 0; t < X_REGS; ++t) {
+            const int e = tid + t * THREADS;
+            const int row = e / c4n, c4 = e - row * c4n;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (row < BM && m0 + row < M && c4 * 4 < kc)
+                v = *reinterpret_cast<const float4 *>(X + (size_t)(m0 + row) * K + k0 + c4 * 4);
+            xr[t] = v;
+        }
+    };
 
-        for (int ch = 0; ch < num_chunks; ++ch) {
-            const int k0 = ch * GEMM_BK;
-            const int kc = min(GEMM_BK, K - k0);        // valid k in this chunk
-            const int kc8 = round_up(kc, 8);            // MFMA consumes k in groups of 8
-            __syncthreads();                            // previous chunk's readers are done (also orders the As fill)
+    if (vec4 && total_iters > 0) load_x(0);
+    f32x16 acc[CT];
+    for (long long it = 0; it < total_iters; ++it) {
+        const long long mt = blockIdx.y + (it / num_chunks) * gridDim.y;
+        const int ch = (int)(it % num_chunks);
+        const long long m0 = mt * BM;
+        const int k0 = ch * GEMM_BK;
+        const int kc = min(GEMM_BK, K - k0);            // valid k in this chunk
+        const int kc8 = round_up(kc, 8);                // MFMA consumes k in groups of 8
+        if (ch == 0) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[ct][i] = 0.f;
+        }
+        __syncthreads();                                // previous MFMA loop has finished reading xs / hs (and As is filled)
 
-            // ---- assemble the H panel chunk in LDS -----------------------------------
-            if (!h_ready) {
-                if (TRANS == 0) {                       // lanes run along j: W reads are contiguous in pi
-                    const int jj = tid & (GEMM_BN - 1);
-                    const int j = j0 + jj;
-                    for (int kk = tid / GEMM_BN; kk < kc8; kk += GEMM_THREADS / GEMM_BN) {
-                        float v = 0.f;
-                        if (kk < kc && j < Nout) v = h_element<0>(As, W, n, kin, kout, k0 + kk, j);
-                        hs[kk * HS_STRIDE + jj] = v;
-                    }
-                } else {                                // lanes run along k: W reads are contiguous in pi
-                    for (int e = tid; e < kc8 * GEMM_BN; e += GEMM_THREADS) {
-                        const int jj = e / kc8;
-                        const int kk = e - jj * kc8;
-                        const int j = j0 + jj;
-                        float v = 0.f;
-                        if (kk < kc && j < Nout) v = h_element<1>(As, W, n, kin, kout, k0 + kk, j);
-                        hs[kk * HS_STRIDE + jj] = v;
-                    }
-                }
-                if (num_chunks == 1) h_ready = true;
+        if (!h_ready) {
+            build_h_chunk<TRANS, NPHM, BN, THREADS>(As, W, hs, n, kin, kout, k0, kc, kc8, j0, Nout, tid);
+            if (num_chunks == 1) h_ready = true;
+        }
+        if (vec4) {
+            const int c4n = kc8 >> 2;
+#pragma unroll
+            for (int t = 0; t < X_REGS; ++t) {
+                const int e = tid + t * THREADS;
+                const int row = e / c4n, c4 = e - row * c4n;
+                if (row < BM) *reinterpret_cast<float4 *>(xs + row * XS_STRIDE + c4 * 4) = xr[t];
             }
-
-            // ---- stage the x tile chunk ----------------------------------------------
-            if (vec4) {
-                const int c4n = kc8 >> 2;               // float4 per row (kc is a multiple of 4 here)
-                for (int e = tid; e < GEMM_BM * c4n; e += GEMM_THREADS) {
-                    const int row = e / c4n;
-                    const int c4 = e - row * c4n;
-                    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                    if (m0 + row < M && c4 * 4 < kc)
-                        v = *reinterpret_cast<const float4 *>(X + (size_t)(m0 + row) * K + k0 + c4 * 4);
-                    *reinterpret_cast<float4 *>(xs + row * XS_STRIDE + c4 * 4) = v;
-                }
-            } else {
-                for (int e = tid; e < GEMM_BM * kc8; e += GEMM_THREADS) {
-                    const int row = e / kc8;
-                    const int kk = e - row * kc8;
-                    float v = 0.f;
-                    if (m0 + row < M && kk < kc) v = X[(size_t)(m0 + row) * K + k0 + kk];
-                    xs[row * XS_STRIDE + kk] = v;
-                }
-            }
-            __syncthreads();
-
-            // ---- MFMA over the chunk ----------------------------------------------------
-            // lane (r, hh) supplies A[row r][k] and B[k][col r] for k = kg*8 + 4*hh + q, q = 0..3
-            const float *xrow = xs + (wm * 32 + r) * XS_STRIDE + 4 * hh;
-            const float *hcol = hs + (4 * hh) * HS_STRIDE + wn * 32 + r;
-            for (int kg = 0; kg < kc8; kg += 8) {
-                const float4 av = *reinterpret_cast<const float4 *>(xrow + kg);
-                const float b0 = hcol[(kg + 0) * HS_STRIDE];
-                const float b1 = hcol[(kg + 1) * HS_STRIDE];
-                const float b2 = hcol[(kg + 2) * HS_STRIDE];
-                const float b3 = hcol[(kg + 3) * HS_STRIDE];
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.x, b0, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.y, b1, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.z, b2, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av.w, b3, acc, 0, 0, 0);
+        } else {
+            for (int e = tid; e < BM * kc8; e += THREADS) {
+                const int row = e / kc8;
+                const int kk = e - row * kc8;
+                float v = 0.f;
+                if (m0 + row < M && kk < kc) v = X[(size_t)(m0 + row) * K + k0 + kk];
+                xs[row * XS_STRIDE + kk] = v;
             }
         }
+        __syncthreads();
+        if (vec4 && it + 1 < total_iters) load_x(it + 1);      // in flight under the MFMA loop
 
-        // ---- epilogue: bias, residual, store ---------------------------------------------
-        const int col = j0 + wn * 32 + r;
-        if (col < Nout) {
-            const float bv = bias ? bias[col] : 0.f;
+        // lane (r, hh) supplies A[row r][k] and B[k][col r] for k = kg*8 + 4*hh + q, q = 0..3
+        const float *xrow = xs + (wm * 32 + r) * XS_STRIDE + 4 * hh;
+        const float *hcol = hs + (4 * hh) * HS_STRIDE + wn * (CT * 32) + r;
+#pragma unroll 2
+        for (int kg = 0; kg < kc8; kg += 8) {
+            const float4 av = *reinterpret_cast<const float4 *>(xrow + kg);
+            const float a4[4] = {av.x, av.y, av.z, av.w};
+            const float *hb = hcol + kg * HS_STRIDE;
+            float bq[4][CT];
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const long long row = m0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
-                if (row < M) {
-                    float v = acc[reg] + bv;
-                    if (residual) v += residual[(size_t)row * Nout + col];
-                    out[(size_t)row * Nout + col] = v;
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) bq[q][ct] = hb[q * HS_STRIDE + ct * 32];
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct)
+                    acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q], bq[q][ct], acc[ct], 0, 0, 0);
+        }
+
+        if (ch == num_chunks - 1) {                     // epilogue: bias, residual, store
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                const int col = j0 + wn * (CT * 32) + ct * 32 + r;
+                if (col < Nout) {
+                    const float bv = bias ? bias[col] : 0.f;
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const long long row = m0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+                        if (row < M) {
+                            float v = acc[ct][reg] + bv;
+                            if (residual) v += residual[(size_t)row * Nout + col];
+                            out[(size_t)row * Nout + col] = v;
+                        }
+                    }
                 }
             }
         }
@@ -265,13 +377,21 @@ __global__ __launch_bounds__(256) void phm_dH_partial_kernel(const float *__rest
     if (ti == 0 && tid < DH_T && j0 + tid < out) slab[(size_t)in * out + j0 + tid] = colsum;
 }
 
-// dH[idx] (and the db tail) = sum over splits, in split order.
-__global__ void phm_dH_reduce_kernel(const float *__restrict__ slabs, float *__restrict__ dH, size_t slab_elems, int splits) {
-    const size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= slab_elems) return;
+// dH[idx] (and the db tail) = sum over splits.  64 elements x 4 split lanes per workgroup; every lane
+// walks its splits in order and the 4 lane sums are added in order: one fixed summation tree.
+__global__ __launch_bounds__(256) void phm_dH_reduce_kernel(const float *__restrict__ slabs, float *__restrict__ dH, size_t slab_elems,
+                                                           int splits) {
+    __shared__ float part[4][64];
+    const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const size_t idx = (size_t)blockIdx.x * 64 + e;
     float s = 0.f;
-    for (int k = 0; k < splits; ++k) s += slabs[(size_t)k * slab_elems + idx];
-    dH[idx] = s;
+    if (idx < slab_elems) {
+#pragma unroll 4
+        for (int k = sl; k < splits; k += 4) s += slabs[(size_t)k * slab_elems + idx];
+    }
+    part[sl][e] = s;
+    __syncthreads();
+    if (sl == 0 && idx < slab_elems) dH[idx] = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
 }
 
 // blocks [0, n^3): dA[i,a,c] = sum_{kap,pi} W[i,kap,pi] * dH[a*kin+kap, c*kout+pi]
@@ -329,10 +449,6 @@ static int num_cu() {
     return g_num_cu;
 }
 
-static size_t gemm_lds_bytes(int n) {
-    return sizeof(float) * ((size_t)GEMM_BM * XS_STRIDE + (size_t)GEMM_BK * HS_STRIDE + (size_t)n * n * n);
-}
-
 static int check_phm_dims(const char *who, int64_t N, int n, int kin, int kout) {
     PHC_REQUIRE(N >= 0, PHC_ERR_INVALID_ARG, "%s: N = %lld < 0", who, (long long)N);
     PHC_REQUIRE(n >= 1 && kin >= 1 && kout >= 1, PHC_ERR_INVALID_ARG, "%s: n, kin, kout must be >= 1 (got %d, %d, %d)", who,
@@ -343,27 +459,49 @@ static int check_phm_dims(const char *who, int64_t N, int n, int kin, int kout) 
     return PHC_OK;
 }
 
+template <int TRANS, int NPHM, int BM, int BN>
+static int launch_gemm_cfg(const float *X, const float *A, const float *W, const float *bias, const float *residual,
+                           float *out, int64_t M, int K, int Nout, int n, int kin, int kout, int wg_per_cu, hipStream_t s) {
+    using Cfg = GemmCfg<BM, BN>;
+    const int panels = (Nout + BN - 1) / BN;
+    const int64_t mtiles = (M + BM - 1) / BM;
+    int64_t gy = ((int64_t)wg_per_cu * num_cu() + panels - 1) / panels;   // fill the chip; further M tiles are strided in-kernel
+    if (gy > mtiles) gy = mtiles;
+    if (gy < 1) gy = 1;
+    const int vec4 = (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+    const size_t lds = sizeof(float) * Cfg::lds_floats(n);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&phm_gemm_kernel<TRANS, NPHM, BM, BN>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((phm_gemm_kernel<TRANS, NPHM, BM, BN>), dim3(panels, (unsigned)gy), dim3(Cfg::THREADS), lds, s, X, A, W,
+                       bias, residual, out, (long long)M, K, Nout, n, kin, kout, vec4);
+    return PHC_OK;
+}
+
+// rows at which the 128 x 128 throughput tile takes over from the 64 x 64 latency tile
+constexpr int64_t GEMM_BIG_M = 64 * 1024;
+
 template <int TRANS>
 static int launch_gemm(const float *X, const float *A, const float *W, const float *bias, const float *residual,
                        float *out, int64_t M, int K, int Nout, int n, int kin, int kout, hipStream_t s) {
     if (M == 0) return PHC_OK;
-    const int panels = (Nout + GEMM_BN - 1) / GEMM_BN;
-    const int64_t mtiles = (M + GEMM_BM - 1) / GEMM_BM;
-    // enough workgroups to fill the chip twice over; the rest is strided inside the kernel
-    int64_t gy = (2 * (int64_t)num_cu() + panels - 1) / panels;
-    if (gy > mtiles) gy = mtiles;
-    if (gy < 1) gy = 1;
-    const int vec4 = (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
-    const size_t lds = gemm_lds_bytes(n);
-    static bool attr_set[2] = {false, false};
-    if (!attr_set[TRANS]) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&phm_gemm_kernel<TRANS>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
-        attr_set[TRANS] = true;
-    }
     ProfScope prof(TRANS ? K_PHM_GEMM_DX : K_PHM_GEMM_FWD, s);
-    hipLaunchKernelGGL(phm_gemm_kernel<TRANS>, dim3(panels, (unsigned)gy), dim3(GEMM_THREADS), lds, s, X, A, W, bias,
-                       residual, out, (long long)M, K, Nout, n, kin, kout, vec4);
+    const bool big = M >= GEMM_BIG_M && Nout > 64;
+#define PHC_GEMM_LAUNCH(NP)                                                                                              \
+    if (big)                                                                                                             \
+        launch_gemm_cfg<TRANS, NP, 128, 128>(X, A, W, bias, residual, out, M, K, Nout, n, kin, kout, 1, s);               \
+    else                                                                                                                 \
+        launch_gemm_cfg<TRANS, NP, 64, 64>(X, A, W, bias, residual, out, M, K, Nout, n, kin, kout, 2, s)
+    switch (n) {
+        case 2: PHC_GEMM_LAUNCH(2); break;
+        case 4: PHC_GEMM_LAUNCH(4); break;
+        case 8: PHC_GEMM_LAUNCH(8); break;
+        default: PHC_GEMM_LAUNCH(0); break;
+    }
+#undef PHC_GEMM_LAUNCH
     return check_launch(TRANS ? "phm_gemm_dx" : "phm_gemm_fwd");
 }
 
@@ -459,7 +597,7 @@ int phc_phm_linear_bwd(const float *x, const float *A, const float *W, const flo
         }
         {
             ProfScope prof(K_PHM_DH_REDUCE, s);
-            hipLaunchKernelGGL(phm_dH_reduce_kernel, dim3((unsigned)((p.slab_elems + 255) / 256)), dim3(256), 0, s, slabs,
+            hipLaunchKernelGGL(phm_dH_reduce_kernel, dim3((unsigned)((p.slab_elems + 63) / 64)), dim3(256), 0, s, slabs,
                                dH, p.slab_elems, p.splits);
             rc = check_launch("phm_dH_reduce");
             if (rc) return rc;

@@ -46,8 +46,11 @@ SIGNATURES = {
     "phc_encode_bwd": (_I, [_P, _P, _L, _I, _P, _I, _I, _P, _P, _S, _P]),
     "phc_aggregate_enc_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P, _P]),
     "phc_aggregate_enc_bwd_ws_bytes": (_S, [_L, _I, _P, _I, _I]),
-    "phc_aggregate_enc_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _L, _I, _I, _I, _I, _I, _P, _P, _P,
+    "phc_aggregate_enc_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _L, _L, _I, _I, _I, _I, _I, _P, _P, _P,
                                    _S, _P]),
+    "phc_bn_ws_bytes": (_S, [_L, _I]),
+    "phc_bn_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _L, _I, _I, C.c_float, C.c_float, _I, _P, _P, _P, _P, _P, _S, _P]),
+    "phc_bn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _L, _I, _I, _I, _P, _P, _P, _S, _P]),
     "phc_prof_enable": (_I, [_I]),
     "phc_prof_reset": (_I, []),
     "phc_prof_num_kernels": (_I, []),

@@ -373,7 +373,6 @@ class _AggregateEncFn(torch.autograd.Function):
         h = dout_.shape[1]
         need_x = ctx.needs_input_grad[0]
         need_t = any(ctx.needs_input_grad[6:])
-        rowptr, col, perm = st.csr
         rowptr_t = col_t = perm_t = None
         dx = None
         if need_x:
@@ -385,10 +384,10 @@ class _AggregateEncFn(torch.autograd.Function):
         ws_bytes = 0
         if need_t:
             flat = torch.empty(ts.n * ts.R * ts.k, dtype=torch.float32, device=dev)
-            ws_bytes = lib.phc_aggregate_enc_bwd_ws_bytes(st.num_dst, ts.F, ts.vocab_c, ts.n, ts.k)
+            ws_bytes = lib.phc_aggregate_enc_bwd_ws_bytes(st.num_edges, ts.F, ts.vocab_c, ts.n, ts.k)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        L.check(lib.phc_aggregate_enc_bwd(L.ptr(dout_), L.ptr(x_), L.ptr(bond_), L.ptr(ts.ptrs), ts.vocab_c, L.ptr(rowptr),
-                                          L.ptr(col), L.ptr(perm), L.ptr(rowptr_t), L.ptr(col_t), L.ptr(perm_t), st.num_src,
+        L.check(lib.phc_aggregate_enc_bwd(L.ptr(dout_), L.ptr(x_), L.ptr(bond_), L.ptr(ts.ptrs), ts.vocab_c, L.ptr(st._src),
+                                          L.ptr(st._dst), st.num_edges, L.ptr(rowptr_t), L.ptr(col_t), L.ptr(perm_t), st.num_src,
                                           st.num_dst, ts.F, ts.n, ts.k, ctx.act, 1 if ctx.add_self else 0, L.ptr(dx),
                                           L.ptr(flat), L.ptr(ws), ws_bytes, L.stream_ptr(dev)), "phc_aggregate_enc_bwd")
         if L.PROF_ON:
@@ -413,3 +412,96 @@ def aggregate_sum_encoded(x: torch.Tensor, edge_index, bond_idx: torch.Tensor, t
         ea = _EncodeFn.apply(bond_idx, ts, *flat_tables)
         return _AggregateFn.apply(x, ea, st, _act_id(msg_encoder), bool(add_self_loops))
     return _AggregateEncFn.apply(x, bond_idx, st, _act_id(msg_encoder), bool(add_self_loops), ts, *flat_tables)
+
+
+# ---------------------------------------------------------------------------
+# batch-norm over component-major rows, fused with activation + residual
+# ---------------------------------------------------------------------------
+def _ptr_array(tensors):
+    """ctypes array of device pointers (host memory, consumed at call time)."""
+    return (_C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
+
+
+class _BatchNormActFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, residual, n_valid, running_mean, running_var, nbt, training, momentum, eps, act, n_comp,
+                *affine):
+        lib = L.load()
+        dev = L.require_device(x, residual)
+        x_ = L.f32c(x)
+        res_ = L.f32c(residual)
+        N, h = x_.shape
+        weights = list(affine[:n_comp]) if affine else None
+        biases = list(affine[n_comp:]) if affine else None
+        w_arr = _ptr_array(weights) if weights else None
+        b_arr = _ptr_array(biases) if biases else None
+        rm_arr = _ptr_array(running_mean) if running_mean else None
+        rv_arr = _ptr_array(running_var) if running_var else None
+        nbt_arr = _ptr_array(nbt) if nbt else None
+        out = torch.empty_like(x_)
+        save_mean = torch.empty(h, dtype=torch.float32, device=dev)
+        save_invstd = torch.empty(h, dtype=torch.float32, device=dev)
+        ws_bytes = lib.phc_bn_ws_bytes(N, h)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        L.check(lib.phc_bn_fwd(L.ptr(x_), w_arr, b_arr, rm_arr, rv_arr, nbt_arr, n_comp, L.ptr(n_valid), N, h,
+                               1 if training else 0, float(momentum), float(eps), act, L.ptr(res_), L.ptr(out),
+                               L.ptr(save_mean), L.ptr(save_invstd), L.ptr(ws), ws_bytes, L.stream_ptr(dev)),
+                "phc_bn_fwd")
+        if L.PROF_ON:
+            if training:
+                L.account("bn_stats_partial", 3.0 * N * h, 4.0 * N * h)
+            L.account("bn_apply", 2.0 * N * h, 4.0 * N * h * (3 if residual is not None else 2))
+        ctx.save_for_backward(x_, save_mean, save_invstd, *(weights or []), *(biases or []))
+        ctx.meta = (n_comp, bool(training), act, bool(affine), residual is not None, n_valid)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = L.load()
+        n_comp, training, act, has_affine, has_res, n_valid = ctx.meta
+        saved = ctx.saved_tensors
+        x_, save_mean, save_invstd = saved[:3]
+        weights = list(saved[3:3 + n_comp]) if has_affine else None
+        biases = list(saved[3 + n_comp:3 + 2 * n_comp]) if has_affine else None
+        dout_ = L.f32c(dout)
+        dev = dout_.device
+        N, h = x_.shape
+        need_x = ctx.needs_input_grad[0]
+        need_aff = has_affine and any(ctx.needs_input_grad[11:])
+        dx = torch.empty_like(x_) if need_x else None
+        dwb = torch.empty(2 * h, dtype=torch.float32, device=dev) if need_aff else None
+        ws_bytes = lib.phc_bn_ws_bytes(N, h)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        L.check(lib.phc_bn_bwd(L.ptr(dout_), L.ptr(x_), _ptr_array(weights) if weights else None,
+                               _ptr_array(biases) if biases else None, L.ptr(save_mean), L.ptr(save_invstd), n_comp,
+                               L.ptr(n_valid), N, h, 1 if training else 0, act, L.ptr(dx), L.ptr(dwb), L.ptr(ws), ws_bytes,
+                               L.stream_ptr(dev)), "phc_bn_bwd")
+        if L.PROF_ON:
+            L.account("bn_bwd_partial", 6.0 * N * h, 8.0 * N * h)
+            L.account("bn_bwd_apply", 8.0 * N * h, 12.0 * N * h)
+        k = h // n_comp
+        aff_grads = []
+        if has_affine:
+            if need_aff:
+                aff_grads = [dwb[c * k:(c + 1) * k] for c in range(n_comp)] + \
+                            [dwb[h + c * k:h + (c + 1) * k] for c in range(n_comp)]
+            else:
+                aff_grads = [None] * (2 * n_comp)
+        dres = dout if (has_res and ctx.needs_input_grad[1]) else None
+        return (dx, dres, None, None, None, None, None, None, None, None, None, *aff_grads)
+
+
+def batch_norm_act(x: torch.Tensor, weights, biases, running_mean, running_var, num_batches_tracked, training: bool,
+                   momentum: float, eps: float, activation: str = "identity", residual: Optional[torch.Tensor] = None,
+                   n_valid: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = act(batch_norm(x)) (+ residual) over the rows of component-major x [N, h].
+
+    ``weights`` / ``biases`` / running statistics are lists with one [h/n] tensor per hypercomplex
+    component (the reference's separate BatchNorm1d modules, norm.py:20); ``n_valid`` is an optional
+    device int32 scalar marking the padding rows of a fixed-shape batch."""
+    n_comp = len(running_mean) if running_mean else len(weights)
+    affine = (list(weights) + list(biases)) if weights else []
+    return _BatchNormActFn.apply(x, residual, n_valid, list(running_mean) if running_mean else None,
+                                 list(running_var) if running_var else None,
+                                 list(num_batches_tracked) if num_batches_tracked else None, training, momentum, eps,
+                                 _act_id(activation), n_comp, *affine)

@@ -272,3 +272,76 @@ def test_aggregate_encoded_falls_back_when_tables_exceed_lds(ops):
     out = ops.aggregate_sum_encoded(x.to(DEV), ei.to(DEV), bond.to(DEV), ts, dev_t, "relu", True)
     ref = O.propagate_add(x, ei, _oracle_encode(bond, tables), "relu") + x
     assert_close(out, ref, TOL)
+
+
+# ---- fused batch-norm -----------------------------------------------------------
+@pytest.mark.parametrize("n,h,N", [(4, 128, 3000), (8, 256, 777), (3, 30, 50), (4, 64, 1), (5, 200, 129)])
+@pytest.mark.parametrize("act", ["identity", "relu", "swish"])
+def test_batch_norm_act_matches_oracle(ops, n, h, N, act):
+    from oracle import phc_oracle as O
+    if N == 1:
+        pytest.skip("BatchNorm1d refuses a single row in training mode (so does the reference)")
+    g = torch.Generator().manual_seed(n * h + N)
+    k = h // n
+    x = torch.randn(N, h, generator=g) * 2 + 0.5
+    res = torch.randn(N, h, generator=g)
+    dy = torch.randn(N, h, generator=g)
+    w = [torch.rand(k, generator=g) + 0.5 for _ in range(n)]
+    b = [torch.randn(k, generator=g) * 0.1 for _ in range(n)]
+    rm = [torch.randn(k, generator=g) * 0.1 for _ in range(n)]
+    rv = [torch.rand(k, generator=g) + 0.5 for _ in range(n)]
+    # oracle
+    xr, rr = x.clone().requires_grad_(), res.clone().requires_grad_()
+    wr, br = [t.clone().requires_grad_() for t in w], [t.clone().requires_grad_() for t in b]
+    rm_r, rv_r = [t.clone() for t in rm], [t.clone() for t in rv]
+    ref = O.activation(act, O.batch_norm_naive(xr, n, wr, br, rm_r, rv_r, True)) + rr
+    rg = torch.autograd.grad(ref, [xr, rr] + wr + br, dy)
+    # engine
+    xd, rd = x.to(DEV).requires_grad_(), res.to(DEV).requires_grad_()
+    wd, bd = [t.to(DEV).requires_grad_() for t in w], [t.to(DEV).requires_grad_() for t in b]
+    rm_d, rv_d = [t.to(DEV) for t in rm], [t.to(DEV) for t in rv]
+    nbt = [torch.zeros((), dtype=torch.int64, device=DEV) for _ in range(n)]
+    out = ops.batch_norm_act(xd, wd, bd, rm_d, rv_d, nbt, True, 0.1, 1e-5, act, rd)
+    assert_close(out, ref, TOL, "bn fwd")
+    gg = torch.autograd.grad(out, [xd, rd] + wd + bd, dy.to(DEV))
+    assert_close(gg[0], rg[0], 2e-5, "bn dx")
+    assert torch.equal(gg[1].cpu(), dy)
+    for a, r in zip(gg[2:], rg[2:]):
+        assert_close(a, r, 3e-5, "bn dw/db")
+    for a, r in zip(rm_d + rv_d, rm_r + rv_r):
+        assert_close(a, r, TOL, "running stats")
+    assert all(int(t) == 1 for t in nbt)
+    # eval mode uses the running statistics
+    ev = ops.batch_norm_act(x.to(DEV), wd, bd, rm_d, rv_d, None, False, 0.1, 1e-5, act, None)
+    ref_ev = O.activation(act, O.batch_norm_naive(x, n, w, b, rm_r, rv_r, False))
+    assert_close(ev, ref_ev, TOL, "bn eval")
+
+
+def test_batch_norm_padding_rows_are_inert(ops):
+    """rows >= n_valid: outside the statistics, zero output, zero gradient."""
+    from oracle import phc_oracle as O
+    g = torch.Generator().manual_seed(9)
+    n, h, N, valid = 4, 128, 1000, 730
+    k = h // n
+    x = torch.randn(N, h, generator=g)
+    dy = torch.randn(N, h, generator=g)
+    w = [torch.rand(k, generator=g) + 0.5 for _ in range(n)]
+    b = [torch.randn(k, generator=g) * 0.1 for _ in range(n)]
+    rm = [torch.zeros(k) for _ in range(n)]
+    rv = [torch.ones(k) for _ in range(n)]
+    xr = x[:valid].clone().requires_grad_()
+    wr, br = [t.clone().requires_grad_() for t in w], [t.clone().requires_grad_() for t in b]
+    ref = torch.relu(O.batch_norm_naive(xr, n, wr, br, [t.clone() for t in rm], [t.clone() for t in rv], True))
+    rg = torch.autograd.grad(ref, [xr] + wr + br, dy[:valid])
+    xd = x.to(DEV).requires_grad_()
+    wd, bd = [t.to(DEV).requires_grad_() for t in w], [t.to(DEV).requires_grad_() for t in b]
+    nv = torch.tensor(valid, dtype=torch.int32, device=DEV)
+    out = ops.batch_norm_act(xd, wd, bd, [t.to(DEV) for t in rm], [t.to(DEV) for t in rv], None, True, 0.1, 1e-5, "relu",
+                             None, nv)
+    assert_close(out[:valid], ref, TOL)
+    assert float(out[valid:].abs().max()) == 0.0
+    gg = torch.autograd.grad(out, [xd] + wd + bd, dy.to(DEV))
+    assert_close(gg[0][:valid], rg[0], 2e-5)
+    assert float(gg[0][valid:].abs().max()) == 0.0
+    for a, r in zip(gg[1:], rg[1:]):
+        assert_close(a, r, 3e-5)
