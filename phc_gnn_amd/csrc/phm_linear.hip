@@ -15,11 +15,14 @@
 //   dH = x^T . dy as fixed-order split-K slabs (phm_dH_partial_kernel), a slab
 //   reduction, then the two small contractions dW = <A, dH>, dA = <W, dH>.
 //   No atomics anywhere: results are bitwise reproducible.
+#include <stdlib.h>
+
 #include "phc_common.h"
 
 namespace phc {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int GEMM_BK = 128;       // K chunk held in LDS
 constexpr int XS_STRIDE = GEMM_BK + 4;   // floats; +4 keeps ds_read_b128 conflict-free (16-lane groups hit 16 distinct 4-bank slots)
@@ -85,17 +88,18 @@ __device__ __forceinline__ void build_h_chunk(const float *__restrict__ As, cons
         const int jj = tid & (BN - 1);
         const int j = j0 + jj;
         const bool jvalid = j < Nout;
-        const int c = jvalid ? j / kout : 0;
-        const int pi = jvalid ? j - c * kout : 0;
+        const int jc = min(j, Nout - 1);                     // clamped: loads are unconditional (no wait at a branch join)
+        const int c = jc / kout;
+        const int pi = jc - c * kout;
         const float *wbase = W + pi;
         const float *abase = As + c;
         for (int kap0 = tid / BN; kap0 < kin; kap0 += HB * STEP) {
             float w[HB][NN];
 #pragma unroll
             for (int b = 0; b < HB; ++b) {
-                const int kap = kap0 + b * STEP;
+                const int kap = min(kap0 + b * STEP, kin - 1);
 #pragma unroll
-                for (int i = 0; i < NN; ++i) w[b][i] = (i < n && jvalid && kap < kin) ? wbase[(size_t)i * wstride + kap * kout] : 0.f;
+                for (int i = 0; i < NN; ++i) w[b][i] = wbase[(size_t)min(i, n - 1) * wstride + kap * kout];
             }
 #pragma unroll
             for (int b = 0; b < HB; ++b) {
@@ -109,7 +113,7 @@ __device__ __forceinline__ void build_h_chunk(const float *__restrict__ As, cons
 #pragma unroll
                     for (int i = 0; i < NN; ++i)
                         if (i < n) hsum = fmaf(abase[i * astride + a * n], w[b][i], hsum);
-                    hs[kk * HS_STRIDE + jj] = hsum;
+                    hs[kk * HS_STRIDE + jj] = jvalid ? hsum : 0.f;
                 }
             }
         }
@@ -118,19 +122,20 @@ __device__ __forceinline__ void build_h_chunk(const float *__restrict__ As, cons
         for (int it0 = tid; it0 < items; it0 += HB * THREADS) {
             float w[HB][NN];
             int jjv[HB], piv[HB], av[HB];
+            bool okv[HB];
 #pragma unroll
             for (int b = 0; b < HB; ++b) {
-                const int it = it0 + b * THREADS;
+                const int it = min(it0 + b * THREADS, items - 1);
                 const int jj = it / kout;
                 const int pi = it - jj * kout;
                 const int j = j0 + jj;
-                const bool valid = it < items && j < Nout;
-                const int a = valid ? j / kin : 0;
-                const int kap = valid ? j - a * kin : 0;
-                jjv[b] = jj; piv[b] = pi; av[b] = a;
+                const int jc = min(j, Nout - 1);             // clamped: unconditional loads
+                const int a = jc / kin;
+                const int kap = jc - a * kin;
+                jjv[b] = jj; piv[b] = pi; av[b] = a; okv[b] = j < Nout;
                 const float *wbase = W + (size_t)kap * kout + pi;
 #pragma unroll
-                for (int i = 0; i < NN; ++i) w[b][i] = (i < n && valid) ? wbase[(size_t)i * wstride] : 0.f;
+                for (int i = 0; i < NN; ++i) w[b][i] = wbase[(size_t)min(i, n - 1) * wstride];
             }
 #pragma unroll
             for (int b = 0; b < HB; ++b) {
@@ -144,7 +149,7 @@ __device__ __forceinline__ void build_h_chunk(const float *__restrict__ As, cons
 #pragma unroll
                     for (int i = 0; i < NN; ++i)
                         if (i < n) hsum = fmaf(As[i * astride + a * n + c], w[b][i], hsum);
-                    hs[kk * HS_STRIDE + jjv[b]] = hsum;
+                    hs[kk * HS_STRIDE + jjv[b]] = okv[b] ? hsum : 0.f;
                 }
             }
         }
@@ -194,10 +199,10 @@ __global__ __launch_bounds__((GemmCfg<BM, BN>::THREADS)) void phm_gemm_kernel(
         for (int t = 0; t < X_REGS; ++t) {
             const int e = tid + t * THREADS;
             const int row = e / c4n, c4 = e - row * c4n;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (row < BM && m0 + row < M && c4 * 4 < kc)
-                v = *reinterpret_cast<const float4 *>(X + (size_t)(m0 + row) * K + k0 + c4 * 4);
-            xr[t] = v;
+            // clamped, unconditional: nothing consumes the registers until the LDS write one iteration later
+            const long long rr = min(m0 + row, M - 1);
+            const int cc = min(c4 * 4, kc - 4);
+            xr[t] = *reinterpret_cast<const float4 *>(X + (size_t)rr * K + k0 + cc);
         }
     };
 
@@ -219,7 +224,9 @@ __global__ __launch_bounds__((GemmCfg<BM, BN>::THREADS)) void phm_gemm_kernel(
         __syncthreads();                                // previous MFMA loop has finished reading xs / hs (and As is filled)
 
         if (!h_ready) {
+#ifndef PHC_EXP_NO_HBUILD
             build_h_chunk<TRANS, NPHM, BN, THREADS>(As, W, hs, n, kin, kout, k0, kc, kc8, j0, Nout, tid);
+#endif
             if (num_chunks == 1) h_ready = true;
         }
         if (vec4) {
@@ -228,7 +235,9 @@ __global__ __launch_bounds__((GemmCfg<BM, BN>::THREADS)) void phm_gemm_kernel(
             for (int t = 0; t < X_REGS; ++t) {
                 const int e = tid + t * THREADS;
                 const int row = e / c4n, c4 = e - row * c4n;
-                if (row < BM) *reinterpret_cast<float4 *>(xs + row * XS_STRIDE + c4 * 4) = xr[t];
+                const bool ok = m0 + row < M && c4 * 4 < kc;                     // tail rows / k padding read as zero
+                const float4 v = ok ? xr[t] : make_float4(0.f, 0.f, 0.f, 0.f);
+                if (row < BM) *reinterpret_cast<float4 *>(xs + row * XS_STRIDE + c4 * 4) = v;
             }
         } else {
             for (int e = tid; e < BM * kc8; e += THREADS) {
@@ -245,6 +254,9 @@ __global__ __launch_bounds__((GemmCfg<BM, BN>::THREADS)) void phm_gemm_kernel(
         // lane (r, hh) supplies A[row r][k] and B[k][col r] for k = kg*8 + 4*hh + q, q = 0..3
         const float *xrow = xs + (wm * 32 + r) * XS_STRIDE + 4 * hh;
         const float *hcol = hs + (4 * hh) * HS_STRIDE + wn * (CT * 32) + r;
+#ifdef PHC_EXP_NO_MFMA
+        if (tid == 100000)
+#endif
 #pragma unroll 2
         for (int kg = 0; kg < kc8; kg += 8) {
             const float4 av = *reinterpret_cast<const float4 *>(xrow + kg);
@@ -262,20 +274,179 @@ __global__ __launch_bounds__((GemmCfg<BM, BN>::THREADS)) void phm_gemm_kernel(
                     acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q], bq[q][ct], acc[ct], 0, 0, 0);
         }
 
+#ifdef PHC_EXP_NO_EPI
+        if (ch == num_chunks - 1 && acc[0][0] == 123.456f) {
+#else
         if (ch == num_chunks - 1) {                     // epilogue: bias, residual, store
+#endif
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) {
                 const int col = j0 + wn * (CT * 32) + ct * 32 + r;
-                if (col < Nout) {
-                    const float bv = bias ? bias[col] : 0.f;
+                const int colc = min(col, Nout - 1);
+                const float bv = bias ? bias[colc] : 0.f;
+                float rv[16];
 #pragma unroll
-                    for (int reg = 0; reg < 16; ++reg) {
-                        const long long row = m0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
-                        if (row < M) {
-                            float v = acc[ct][reg] + bv;
-                            if (residual) v += residual[(size_t)row * Nout + col];
-                            out[(size_t)row * Nout + col] = v;
+                for (int reg = 0; reg < 16; ++reg) {   // residual rows: clamped, unconditional, all 16 loads in flight
+                    const long long row = min(m0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh, M - 1);
+                    rv[reg] = residual ? residual[(size_t)row * Nout + colc] : 0.f;
+                }
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const long long row = m0 + wm * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+                    if (row < M && col < Nout) out[(size_t)row * Nout + col] = acc[ct][reg] + bv + rv[reg];
+                }
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Streaming kernel for K <= 128 (every PHM layer of hidden width <= 128): wave-decoupled.
+//   * the whole [K x BN] operand panel is assembled in LDS once per workgroup (one barrier);
+//   * after that every WAVEFRONT is on its own: it owns 32-row slabs of x, stages them through a
+//     private LDS buffer (no workgroup barrier), runs the MFMAs against the shared panel, transposes
+//     its 32x32 result tiles through the same buffer and stores 16 bytes per lane.
+//   Waves of one SIMD drift apart, so one wave's loads/stores overlap another's MFMAs.
+// ------------------------------------------------------------------------------------------
+constexpr int ST_KH = 64;                       // k columns staged per step
+constexpr int ST_STRIDE = ST_KH + 4;            // floats; conflict-free ds_read_b128 of the A operand
+constexpr int ST_FLOATS = 32 * ST_STRIDE;       // private staging floats per wave (8.5 KiB); also holds a 32x36 output tile
+
+template <int TRANS, int NPHM, int BN, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
+    const float *__restrict__ X, const float *__restrict__ A, const float *__restrict__ W,
+    const float *__restrict__ bias, const float *__restrict__ residual, float *__restrict__ out,
+    long long M, int K, int Nout, int n, int kin, int kout, int out_vec4) {
+    constexpr int THREADS = 64 * WAVES, HS_STRIDE = BN + 1, CT = BN / 32;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float *hs = smem;                                          // [128][HS_STRIDE]
+    float *stage_all = hs + 128 * HS_STRIDE;                   // [WAVES][ST_FLOATS]
+    float *As = stage_all + WAVES * ST_FLOATS;                 // [n*n*n]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane & 31, hh = lane >> 5;
+    const int j0 = blockIdx.x * BN;
+    float *stage = stage_all + wave * ST_FLOATS;
+
+    const long long num_slabs = (M + 31) / 32;
+    long long slab = (long long)blockIdx.y * WAVES + wave;
+    const long long slab_step = (long long)gridDim.y * WAVES;
+    const int halves = (K + ST_KH - 1) / ST_KH;
+    const int lrow = lane >> 4, lc4 = lane & 15;               // staging: lane -> (row lrow + 4t, float4 column lc4)
+
+    // x staging registers (plain loads: hipcc drains them before the MFMA loop, so the overlap comes from the
+    // other waves of the SIMD; an inline-asm variant that hid them from hipcc made it copy the still-pending
+    // registers — cdna guide §5.7 item 1 — and was dropped)
+    f32x4 xr[8];
+    auto load_half = [&](long long sl, int half) {
+        const int k0 = half * ST_KH;
+        const int cc = min(lc4 * 4, K - k0 - 4);               // clamped: unconditional loads
+#pragma unroll
+        for (int t = 0; t < 8; ++t) {
+            const long long row = min(sl * 32 + lrow + 4 * t, M - 1);
+            xr[t] = *reinterpret_cast<const f32x4 *>(X + (size_t)row * K + k0 + cc);
+        }
+    };
+    if (slab < num_slabs) load_half(slab, 0);
+
+    // bias columns this lane will store (fixed across slabs): col = j0 + ct*32 + (lane & 7)*4
+    float4 bias4[CT];
+#pragma unroll
+    for (int ct = 0; ct < CT; ++ct) {
+        const int col = min(j0 + ct * 32 + (lane & 7) * 4, max(Nout - 4, 0));
+        bias4[ct] = (bias && out_vec4) ? *reinterpret_cast<const float4 *>(bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+
+    for (int i = tid; i < n * n * n; i += THREADS) As[i] = A[i];
+    __syncthreads();
+    build_h_chunk<TRANS, NPHM, BN, THREADS>(As, W, hs, n, kin, kout, 0, K, round_up(K, 8), j0, Nout, tid);
+    __syncthreads();
+
+    for (; slab < num_slabs; slab += slab_step) {
+        f32x16 acc[CT];
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[ct][i] = 0.f;
+
+        for (int half = 0; half < halves; ++half) {
+            const int k0 = half * ST_KH;
+            const int kc = min(ST_KH, K - k0);
+            const int kc8 = round_up(kc, 8);
+            // registers -> private LDS (k padding and the clamped column read as zero)
+            const bool colok = lc4 * 4 < kc;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) {
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                *reinterpret_cast<f32x4 *>(stage + (lrow + 4 * t) * ST_STRIDE + lc4 * 4) = colok ? xr[t] : z;
+            }
+            // next half (or the next slab's first half) goes in flight under the MFMAs
+#ifndef PHC_EXP_NO_XLOAD
+            if (half + 1 < halves) load_half(slab, half + 1);
+            else if (slab + slab_step < num_slabs) load_half(slab + slab_step, 0);
+#endif
+
+            const float *xrow = stage + r * ST_STRIDE + 4 * hh;
+            const float *hcol = hs + (k0 + 4 * hh) * HS_STRIDE + r;
+#ifdef PHC_EXP_NO_MFMA
+            if (tid == 100000)
+#endif
+#pragma unroll 2
+            for (int kg = 0; kg < kc8; kg += 8) {
+                const float4 av = *reinterpret_cast<const float4 *>(xrow + kg);
+                const float a4[4] = {av.x, av.y, av.z, av.w};
+                const float *hb = hcol + kg * HS_STRIDE;
+                float bq[4][CT];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct) bq[q][ct] = hb[q * HS_STRIDE + ct * 32];
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int ct = 0; ct < CT; ++ct)
+                        acc[ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(a4[q], bq[q][ct], acc[ct], 0, 0, 0);
+            }
+        }
+
+        // epilogue: transpose each 32x32 tile through the private buffer, 16-byte stores
+        const long long row_base = slab * 32;
+#ifdef PHC_EXP_NO_EPI
+        if (acc[0][0] == 123.456f)
+#endif
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int col0 = j0 + ct * 32;
+            if (out_vec4) {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg)
+                    stage[((reg & 3) + 8 * (reg >> 2) + 4 * hh) * 36 + r] = acc[ct][reg];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int idx = lane + 64 * t;
+                    const int row = idx >> 3, c4 = idx & 7;
+                    const int col = col0 + c4 * 4;
+                    const long long grow = row_base + row;
+                    float4 v = *reinterpret_cast<const float4 *>(stage + row * 36 + c4 * 4);
+                    if (grow < M && col < Nout) {
+                        v.x += bias4[ct].x; v.y += bias4[ct].y; v.z += bias4[ct].z; v.w += bias4[ct].w;
+                        if (residual) {
+                            const float4 r4 = *reinterpret_cast<const float4 *>(residual + (size_t)grow * Nout + col);
+                            v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
                         }
+                        *reinterpret_cast<float4 *>(out + (size_t)grow * Nout + col) = v;
+                    }
+                }
+            } else {
+                const int col = col0 + r;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const long long grow = row_base + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+                    if (grow < M && col < Nout) {
+                        float v = acc[ct][reg];
+                        if (bias) v += bias[col];
+                        if (residual) v += residual[(size_t)grow * Nout + col];
+                        out[(size_t)grow * Nout + col] = v;
                     }
                 }
             }
@@ -481,7 +652,32 @@ static int launch_gemm_cfg(const float *X, const float *A, const float *W, const
     return PHC_OK;
 }
 
-// rows at which the 128 x 128 throughput tile takes over from the 64 x 64 latency tile
+
+template <int TRANS, int NPHM, int BN, int WAVES>
+static int launch_stream_cfg(const float *X, const float *A, const float *W, const float *bias, const float *residual,
+                             float *out, int64_t M, int K, int Nout, int n, int kin, int kout, int wg_per_cu, hipStream_t s) {
+    const int panels = (Nout + BN - 1) / BN;
+    const int64_t slabs = (M + 31) / 32;
+    int64_t gy = ((int64_t)wg_per_cu * num_cu() + panels - 1) / panels;
+    const int64_t max_gy = (slabs + WAVES - 1) / WAVES;
+    if (gy > max_gy) gy = max_gy;
+    if (gy < 1) gy = 1;
+    const size_t lds = sizeof(float) * ((size_t)128 * (BN + 1) + (size_t)WAVES * ST_FLOATS + (size_t)n * n * n);
+    const int out_vec4 = (Nout % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0) &&
+                         (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0) &&
+                         (!residual || (reinterpret_cast<uintptr_t>(residual) & 15) == 0);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&phm_stream_kernel<TRANS, NPHM, BN, WAVES>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_set = true;
+    }
+    hipLaunchKernelGGL((phm_stream_kernel<TRANS, NPHM, BN, WAVES>), dim3(panels, (unsigned)gy), dim3(64 * WAVES), lds, s, X, A, W,
+                       bias, residual, out, (long long)M, K, Nout, n, kin, kout, out_vec4);
+    return PHC_OK;
+}
+
+// rows at which the 128-column / 8-wave streaming configuration takes over from the 64-column / 4-wave one
 constexpr int64_t GEMM_BIG_M = 64 * 1024;
 
 template <int TRANS>
@@ -489,9 +685,15 @@ static int launch_gemm(const float *X, const float *A, const float *W, const flo
                        float *out, int64_t M, int K, int Nout, int n, int kin, int kout, hipStream_t s) {
     if (M == 0) return PHC_OK;
     ProfScope prof(TRANS ? K_PHM_GEMM_DX : K_PHM_GEMM_FWD, s);
+    const bool vec4 = (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
+    const bool stream = vec4 && K <= 128 && !getenv("PHC_GEMM_TILED");
     const bool big = M >= GEMM_BIG_M && Nout > 64;
 #define PHC_GEMM_LAUNCH(NP)                                                                                              \
-    if (big)                                                                                                             \
+    if (stream && big)                                                                                                   \
+        launch_stream_cfg<TRANS, NP, 128, 8>(X, A, W, bias, residual, out, M, K, Nout, n, kin, kout, 1, s);               \
+    else if (stream)                                                                                                     \
+        launch_stream_cfg<TRANS, NP, 64, 4>(X, A, W, bias, residual, out, M, K, Nout, n, kin, kout, 2, s);                \
+    else if (big)                                                                                                        \
         launch_gemm_cfg<TRANS, NP, 128, 128>(X, A, W, bias, residual, out, M, K, Nout, n, kin, kout, 1, s);               \
     else                                                                                                                 \
         launch_gemm_cfg<TRANS, NP, 64, 64>(X, A, W, bias, residual, out, M, K, Nout, n, kin, kout, 2, s)
