@@ -47,6 +47,9 @@ def parse_args():
     ap.add_argument("--workload", default="molhiv_b512")
     ap.add_argument("--num-batches", type=int, default=8, help="distinct resident batches cycled through")
     ap.add_argument("--fwd-bwd-only", action="store_true", help="leave grad clipping + Adam out of the step")
+    ap.add_argument("--mode", choices=["graph", "eager"], default="graph",
+                    help="graph: whole step captured once into a hipGraph over bucket-padded batches, replayed per "
+                         "batch (phc_gnn_amd/graphed.py); eager: one launch per kernel from Python")
     ap.add_argument("--cpu-steps", type=int, default=30, help="timed CPU-oracle steps (0 = skip the CPU baseline)")
     ap.add_argument("--cpu-threads", type=int, default=6, help="reference setting: torch.set_num_threads(6)")
     ap.add_argument("--profile-steps", type=int, default=10)
@@ -124,7 +127,7 @@ def main():
     w = harness.WORKLOADS[args.workload]
     model = harness.build_model(args.workload, dev, seed=0)           # same init on every rank
     model.train()
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True)   # train_hiv.py:285 (Adam, weight_decay 0)
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True, capturable=True)   # train_hiv.py:285 (Adam, wd 0)
     cfg = harness.StepConfig(regression=bool(w.get("regression")), grad_clip=2.0, optimizer=not args.fwd_bwd_only)
     host_batches = [harness.make_batch(args.workload, seed=1000 * rank + i) for i in range(args.num_batches)]
     batches = [harness.to_device(gb, dev) for gb in host_batches]
@@ -132,9 +135,38 @@ def main():
         b.all_labeled = bool(b.y_mask.all().item())                   # decided once, outside the timed region
     grad_sync = make_grad_sync(model, world) if world > 1 else None
 
-    def run(n, offset=0):
+    graph_step = None
+    prof = None
+    if rank == 0 and args.profile_steps > 0:
+        # ---- roofline of the dominant engine kernel: instrumented EAGER pass over the same steps, taken before
+        # the hipGraph is captured (HIP events cannot be recorded inside a replayed graph) ----
+        for i in range(3):
+            harness.train_step(model, batches[i % len(batches)], opt, cfg, grad_sync)
+        torch.cuda.synchronize()
+        lib.prof_reset()
+        lib.prof_enable(True)
+        for i in range(args.profile_steps):
+            harness.train_step(model, batches[i % len(batches)], opt, cfg, grad_sync)
+        torch.cuda.synchronize()
+        lib.prof_enable(False)
+        prof = (lib.prof_read(), dict(lib.WORK))
+    if world > 1:
+        import torch.distributed as dist
+        dist.barrier()
+    graph_step = None
+    if args.mode == "graph":
+        from phc_gnn_amd import graphed
+        n_max, e_max = graphed.bucket_shape(host_batches)
+        padded = [graphed.padded_to_device(graphed.pad_batch(gb, n_max, e_max), dev) for gb in host_batches]
+        graph_step = graphed.GraphedTrainStep(model, opt, cfg, padded[0], grad_sync=grad_sync)
+
+    def run(n, offset=0, eager=False):
         for i in range(n):
-            harness.train_step(model, batches[(offset + i) % len(batches)], opt, cfg, grad_sync)
+            j = (offset + i) % len(batches)
+            if graph_step is not None and not eager:
+                graph_step.step(padded[j])                      # D2D copy into the static buffers + one graph launch
+            else:
+                harness.train_step(model, batches[j], opt, cfg, grad_sync)
 
     def barrier():
         if world > 1:
@@ -168,18 +200,14 @@ def main():
                    "edges_per_batch": int(sum(b.num_edges for b in host_batches) / len(host_batches)),
                    "step": "zero_grad+fwd+bce+bwd" + ("" if args.fwd_bwd_only else "+clip+adam")
                            + ("+grad_allreduce" if world > 1 else ""),
+                   "launch": ("hipGraph replay of the whole step on batches padded to one bucket shape "
+                              f"({n_max} nodes, {e_max} edges) + per-step D2D batch copy") if graph_step is not None
+                             else "eager (one launch per kernel)",
                    "parallelism": f"dp{world}" if world > 1 else "single"},
     }
 
     if rank == 0:
-        # ---- roofline of the dominant engine kernel: instrumented pass over the same steps ----
-        lib.prof_reset()
-        lib.prof_enable(True)
-        run(args.profile_steps, offset=args.warmup)
-        torch.cuda.synchronize()
-        lib.prof_enable(False)
-        times = lib.prof_read()
-        work = dict(lib.WORK)
+        times, work = prof if prof is not None else ({}, {})
         if times:
             name = max(times, key=lambda k: times[k]["total_ms"])
             t_ms, n_launch = times[name]["total_ms"], times[name]["launches"]

@@ -54,7 +54,7 @@ class PHMDownstreamNet(nn.Module):
                 module.reset_parameters()
         self.real_trafo.reset_parameters()
 
-    def forward(self, x: torch.Tensor, verbose=False, **kwargs) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, verbose=False, n_valid=None, **kwargs) -> torch.Tensor:
         last = len(self.affine) - 1
         for i, layer in enumerate(self.affine):
             x = layer(x)
@@ -63,7 +63,7 @@ class PHMDownstreamNet(nn.Module):
             if i == last:
                 break
             if self.norm_flag:
-                x = self.norm[i].forward_fused(x, activation=self.activation_str)
+                x = self.norm[i].forward_fused(x, activation=self.activation_str, n_valid=n_valid)
             else:
                 x = self.activation_func(x)
             if self.training and self.dropout[i] > 0.0:

@@ -146,10 +146,12 @@ class PHMMLP(nn.Module):
         if self.norm_flag:
             self.norm.reset_parameters()
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, n_valid=None) -> torch.Tensor:
+        """``n_valid`` (engine extension): device int32 scalar; rows past it are padding of a
+        fixed-shape batch and stay out of the batch-norm statistics."""
         x = self.linear1(x)
         if self.norm_flag:
-            x = self.norm.forward_fused(x, activation=self.activation_str)      # norm + activation in one pass
+            x = self.norm.forward_fused(x, activation=self.activation_str, n_valid=n_valid)   # norm + activation in one pass
         else:
             x = self.activation(x)
         return self.linear2(x)

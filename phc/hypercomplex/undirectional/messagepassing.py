@@ -102,7 +102,8 @@ class PHMConv(_SumConvBase):
         agg = self.propagate(edge_index, x=x, edge_attr=edge_attr, size=size, add_self=self.add_self_loops)
         return self.transform(agg)
 
-    def forward_encoded(self, x: torch.Tensor, edge_index: Adj, edge_idx: torch.Tensor, encoder, size: Size = None):
+    def forward_encoded(self, x: torch.Tensor, edge_index: Adj, edge_idx: torch.Tensor, encoder, size: Size = None,
+                        n_valid=None):
         """forward() with edge_attr given as integer bond features + their PHMEncoder."""
         if self.same_dim:
             agg = self.propagate_encoded(edge_index, x, edge_idx, encoder, size, add_self=False)
@@ -148,14 +149,16 @@ class PHMGINEConv(_SumConvBase):
     def reset_parameters(self):
         self.transform.reset_parameters()
 
-    def forward(self, x: torch.Tensor, edge_index: Adj, edge_attr: torch.Tensor, size: Size = None) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, edge_index: Adj, edge_attr: torch.Tensor, size: Size = None,
+                n_valid=None) -> torch.Tensor:
         agg = self.propagate(edge_index, x=x, edge_attr=edge_attr, size=size, add_self=self.add_self_loops)
-        return self.transform(agg)
+        return self.transform(agg, n_valid=n_valid)
 
-    def forward_encoded(self, x: torch.Tensor, edge_index: Adj, edge_idx: torch.Tensor, encoder, size: Size = None):
+    def forward_encoded(self, x: torch.Tensor, edge_index: Adj, edge_idx: torch.Tensor, encoder, size: Size = None,
+                        n_valid=None):
         """forward() with edge_attr given as integer bond features + their PHMEncoder."""
         agg = self.propagate_encoded(edge_index, x, edge_idx, encoder, size, add_self=self.add_self_loops)
-        return self.transform(agg)
+        return self.transform(agg, n_valid=n_valid)
 
     def __repr__(self):
         return "{}(in_features={}, out_features={}, phm_dim={}, phm_rule={}, learn_phm={}, bias={}, " \
@@ -211,7 +214,9 @@ class PHMMessagePassing(nn.Module):
     def forward(self, x: torch.Tensor, edge_index: Adj, edge_attr: torch.Tensor, size: Size = None) -> torch.Tensor:
         return self.transform(x, edge_index, edge_attr, size)
 
-    def forward_encoded(self, x: torch.Tensor, edge_index: Adj, edge_idx: torch.Tensor, encoder, size: Size = None):
+    def forward_encoded(self, x: torch.Tensor, edge_index: Adj, edge_idx: torch.Tensor, encoder, size: Size = None,
+                        n_valid=None):
         """Engine extension: like forward(), but takes the raw integer edge features and the
-        PHMEncoder that embeds them, so the embedding is fused into the aggregation."""
-        return self.transform.forward_encoded(x, edge_index, edge_idx, encoder, size)
+        PHMEncoder that embeds them, so the embedding is fused into the aggregation.  ``n_valid``
+        marks the padding rows of a fixed-shape batch (device int32 scalar)."""
+        return self.transform.forward_encoded(x, edge_index, edge_idx, encoder, size, n_valid=n_valid)

@@ -132,20 +132,22 @@ class PHMSkipConnectAdd(nn.Module):
         return sum(p.numel() for p in self.parameters() if p.requires_grad)
 
     def compute_hidden_layer_embedding(self, conv, norm, x, edge_index, edge_attr, dropout_mpnn: float,
-                                       size=None, edge_encoder=None) -> torch.Tensor:
+                                       size=None, edge_encoder=None, n_valid=None) -> torch.Tensor:
         """x = [input of the conv, skip tensor]   (ref :200-217).  With ``edge_encoder`` given,
         ``edge_attr`` holds the raw integer bond features and the embedding is evaluated
         inside the aggregation kernel."""
         if edge_encoder is not None:
-            h = conv.forward_encoded(x[0], edge_index, edge_attr, edge_encoder, size)
+            h = conv.forward_encoded(x[0], edge_index, edge_attr, edge_encoder, size, n_valid=n_valid)
+        elif n_valid is not None and self.mlp_mp:
+            h = conv.transform(x[0], edge_index, edge_attr, size, n_valid=n_valid)
         else:
             h = conv(x=x[0], edge_index=edge_index, edge_attr=edge_attr, size=size)
         dropout_active = self.training and dropout_mpnn > 0.0
         if norm is not None and not dropout_active:
             # norm -> activation -> (+ skip) ride in one engine pass
-            return norm.forward_fused(h, activation=self.activation_str, residual=x[1])
+            return norm.forward_fused(h, activation=self.activation_str, residual=x[1], n_valid=n_valid)
         if norm is not None:
-            h = norm.forward_fused(h, activation=self.activation_str)
+            h = norm.forward_fused(h, activation=self.activation_str, n_valid=n_valid)
         else:
             h = self.f_act(h)
         h = phm_dropout(x=h, p=dropout_mpnn, phm_dim=self.phm_dim, training=self.training, same=self.same_dropout)
@@ -155,6 +157,9 @@ class PHMSkipConnectAdd(nn.Module):
         x, edge_index, edge_attr, batch = data.x, data.edge_index, data.edge_attr, data.batch
         if isinstance(self.bond_input_dims, list):
             edge_attr = edge_attr.to(torch.long)
+        # fixed-shape (padded) batches carry device-side valid counts (engine extension, see phc_gnn_amd/graphed.py)
+        n_valid = getattr(data, "n_valid_nodes", None)
+        n_valid_graphs = getattr(data, "n_valid_graphs", None)
         atom = self.atomencoder(x)
         atom = atom.reshape(atom.size(0), self.phm_dim * self.atom_encoded_dim)     # component-major [N, h]
         h = atom
@@ -165,15 +170,18 @@ class PHMSkipConnectAdd(nn.Module):
                 # integer bond features: embedding fused into the aggregation (no [E, h] tensor)
                 h = self.compute_hidden_layer_embedding(conv=self.convs[i], norm=self.norms[i], x=[h, skip],
                                                         edge_index=edge_index, edge_attr=edge_attr,
-                                                        dropout_mpnn=self.dropout_mpnn[i], size=size, edge_encoder=enc)
+                                                        dropout_mpnn=self.dropout_mpnn[i], size=size, edge_encoder=enc,
+                                                        n_valid=n_valid)
                 continue
             e = enc(edge_attr)
             e = e.reshape(e.size(0), self.mp_layers[i])
             h = self.compute_hidden_layer_embedding(conv=self.convs[i], norm=self.norms[i], x=[h, skip],
                                                     edge_index=edge_index, edge_attr=e,
-                                                    dropout_mpnn=self.dropout_mpnn[i], size=size)
+                                                    dropout_mpnn=self.dropout_mpnn[i], size=size, n_valid=n_valid)
         num_graphs = getattr(data, "num_graphs", None)
         out = self.pooling(x=h, batch=batch, num_graphs=num_graphs)
+        if n_valid_graphs is not None:
+            return self.downstream(out, n_valid=n_valid_graphs)
         return self.downstream(out)
 
     def __repr__(self):

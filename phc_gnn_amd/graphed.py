@@ -1,0 +1,134 @@
+"""hipGraph-replayed training step on fixed-shape (padded) batches.
+
+The molecule-scale step is launch-bound (≈200 kernels of a few µs each), so the whole step —
+CSR/CSC build, forward, loss, backward, gradient all-reduce, clipping, Adam — is captured ONCE
+into a hipGraph and replayed per batch.  Batches differ in size, so they are padded to one
+bucket shape:
+
+  * nodes  N..N_max-1  are padding nodes with feature indices 0, owned by an extra graph id B;
+  * edges  E..E_max-1  connect padding nodes to themselves, spread over the padding nodes;
+  * the extra graph B has NaN labels (masked out of the loss exactly like an unlabeled task);
+  * ``n_valid_nodes`` / ``n_valid_graphs`` are DEVICE int32 scalars read by the batch-norm kernels:
+    padding rows stay out of the statistics, are written as 0 and receive zero gradient, so no
+    padding row ever reaches a parameter gradient (tests/test_gpu_model.py::test_graphed_step_*).
+
+Per step: one device-to-device copy of the padded batch into the static buffers + one graph launch.
+(Reference loop being reproduced: benchmarks/train_hiv.py:165-218.)
+"""
+from __future__ import annotations
+
+import gc
+import types
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import synth
+from .graph import clear_structure_cache
+from .harness import StepConfig, loss_fn
+
+
+def bucket_shape(batches: List[synth.GraphBatch], slack: float = 0.02, multiple: int = 128):
+    """(N_max, E_max) covering every batch with a little slack, plus room for padding nodes."""
+    n = max(b.num_nodes for b in batches)
+    e = max(b.num_edges for b in batches)
+    n_max = int(np.ceil(n * (1 + slack) / multiple) * multiple) + multiple
+    e_max = int(np.ceil(e * (1 + slack) / multiple) * multiple)
+    return n_max, e_max
+
+
+def pad_batch(gb: synth.GraphBatch, n_max: int, e_max: int) -> dict:
+    """Host-side padding of one collated batch to the bucket shape (part of collation)."""
+    N, E, B = gb.num_nodes, gb.num_edges, gb.num_graphs
+    if N >= n_max or E > e_max:
+        raise ValueError(f"batch ({N} nodes, {E} edges) does not fit the bucket ({n_max}, {e_max})")
+    n_pad = n_max - N
+    x = np.zeros((n_max, gb.x.shape[1]), dtype=np.int64)
+    x[:N] = gb.x
+    ei = np.empty((2, e_max), dtype=np.int64)
+    ei[:, :E] = gb.edge_index
+    pad_nodes = N + (np.arange(e_max - E, dtype=np.int64) % n_pad)
+    ei[0, E:] = pad_nodes
+    ei[1, E:] = pad_nodes
+    ea = np.zeros((e_max, gb.edge_attr.shape[1]), dtype=np.int64)
+    ea[:E] = gb.edge_attr
+    batch = np.full(n_max, B, dtype=np.int64)
+    batch[:N] = gb.batch
+    y = np.full((B + 1, gb.y.shape[1]), np.nan, dtype=np.float32)
+    y[:B] = gb.y
+    return dict(x=x, edge_index=ei, edge_attr=ea, batch=batch, y=y, n_valid_nodes=np.array(N, dtype=np.int32),
+                num_graphs=B, num_nodes=N, num_edges=E)
+
+
+def padded_to_device(p: dict, device) -> dict:
+    return {k: (torch.from_numpy(np.ascontiguousarray(v)).to(device) if isinstance(v, np.ndarray) else v)
+            for k, v in p.items()}
+
+
+class GraphedTrainStep:
+    """Static buffers + one captured hipGraph for the whole training step."""
+
+    TENSORS = ("x", "edge_index", "edge_attr", "batch", "y", "n_valid_nodes")
+
+    def __init__(self, model, optimizer, cfg: StepConfig, example: dict, grad_sync=None, warmup: int = 3):
+        self.model, self.optimizer, self.cfg, self.grad_sync = model, optimizer, cfg, grad_sync
+        dev = example["x"].device
+        self.static = {k: example[k].clone() for k in self.TENSORS}
+        B = int(example["num_graphs"])
+        self.data = types.SimpleNamespace(
+            x=self.static["x"], edge_index=self.static["edge_index"], edge_attr=self.static["edge_attr"],
+            batch=self.static["batch"], y=self.static["y"], num_graphs=B + 1,
+            n_valid_nodes=self.static["n_valid_nodes"],
+            n_valid_graphs=torch.tensor(B, dtype=torch.int32, device=dev), all_labeled=False)
+        self.loss = None
+        self.graph = torch.cuda.CUDAGraph()
+        # Warm-up (allocator pools, lazy library initialisation, pointer tables) and capture run on ONE
+        # dedicated stream, so that autograd's per-parameter AccumulateGrad nodes, the optimizer state and
+        # the captured kernels all agree on the stream (no cross-stream edges inside the graph).
+        self.stream = torch.cuda.Stream(device=dev)
+        self.stream.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(self.stream):
+            for _ in range(warmup):
+                self._body()
+        self.stream.synchronize()
+        gc.collect()                       # drop the warm-up autograd graphs before capturing
+        clear_structure_cache()            # the CSR/CSC build must be captured, not served from the cache
+        self.optimizer.zero_grad(set_to_none=True)
+        with torch.cuda.graph(self.graph, stream=self.stream):
+            self.loss = self._body()
+        clear_structure_cache()
+        # Drop the captured autograd graph (its AccumulateGrad nodes are bound to the capture stream; a later
+        # eager backward of the same model would otherwise enqueue work on that stream).  The loss buffer
+        # itself stays: it is the graph's output.
+        self.loss = self.loss.detach()
+        gc.collect()
+        # NOTE: only a device-wide synchronize here.  Making the default stream wait on the capture stream
+        # (Stream.wait_stream -> an event recorded on the just-captured stream) left the graph in a state where
+        # later eager allocations made its replays fault on ROCm 7.2 (scripts/debug_graph2.py reproduces it).
+        torch.cuda.synchronize(dev)
+
+    def _body(self):
+        self.data.y_mask = ~torch.isnan(self.data.y)
+        self.optimizer.zero_grad(set_to_none=True)
+        logits = self.model(self.data)
+        loss = loss_fn(logits, self.data, self.cfg.regression)
+        loss.backward()
+        if self.grad_sync is not None:
+            self.grad_sync(self.model)
+        if self.cfg.optimizer:
+            if self.cfg.grad_clip > 0:
+                torch.nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=self.cfg.grad_clip, norm_type=2)
+            self.optimizer.step()
+        return loss
+
+    def load(self, padded: dict) -> None:
+        """Device-to-device copy of one padded, HBM-resident batch into the static buffers."""
+        for k in self.TENSORS:
+            self.static[k].copy_(padded[k], non_blocking=True)
+
+    def step(self, padded: Optional[dict] = None) -> torch.Tensor:
+        if padded is not None:
+            self.load(padded)
+        self.graph.replay()
+        return self.loss

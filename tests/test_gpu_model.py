@@ -157,3 +157,78 @@ def test_g8_full_model(name):
     sd = model.state_dict()
     for k, v in sub(z, "sd_after::").items():
         assert_close(sd[k], v, TOL, k)
+
+
+def _fresh(workload, seed=0):
+    from phc_gnn_amd import harness
+    model = harness.build_model(workload, DEV, seed=seed)
+    model.train()
+    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True, capturable=True)
+    return model, opt
+
+
+def _reset_adam_in_place(opt):
+    for st in opt.state.values():
+        for v in st.values():
+            if torch.is_tensor(v):
+                v.zero_()
+
+
+def test_graphed_step_matches_eager_step_on_unpadded_batch():
+    """hipGraph replay over a PADDED batch == eager step over the original batch: padding rows/edges/graph
+    must not leak into the loss, the batch-norm statistics or any parameter update."""
+    from phc_gnn_amd import graphed, harness
+    wl = "molhiv_b32"
+    cfg = harness.StepConfig()
+    gbs = [harness.make_batch(wl, seed=s) for s in (3, 4, 5)]
+    n_max, e_max = graphed.bucket_shape(gbs)
+    padded = [graphed.padded_to_device(graphed.pad_batch(g, n_max, e_max), DEV) for g in gbs]
+
+    m_e, o_e = _fresh(wl)
+    m_g, o_g = _fresh(wl)
+    m_g.load_state_dict(m_e.state_dict())
+    step = graphed.GraphedTrainStep(m_g, o_g, cfg, padded[0], warmup=2)
+    # the capture + warm-up already advanced m_g and its Adam state: restart both from one state, IN PLACE
+    # (the graph holds the addresses of the parameter and optimizer-state tensors)
+    m_g.load_state_dict(m_e.state_dict())
+    _reset_adam_in_place(o_g)
+    for i, gb in enumerate(gbs):
+        d = harness.to_device(gb, DEV)
+        d.all_labeled = False
+        le = harness.train_step(m_e, d, o_e, cfg)
+        lg = step.step(padded[i])
+        assert_close(lg, le, 2e-5, f"loss step {i}")
+    sd_e, sd_g = m_e.state_dict(), m_g.state_dict()
+    worst, checked = 0.0, 0
+    for k, v in sd_e.items():
+        if not v.is_floating_point():
+            continue
+        # a bias in front of a batch-norm has an exactly-zero gradient; Adam turns its round-off noise into
+        # +-lr steps of random sign, so those tensors carry no information (and no influence on the loss)
+        if k.endswith(".b") and not (k == "pooling.linear.b" or k == "downstream.affine.2.b"):
+            continue
+        e = relerr(sd_g[k], v)
+        if e > worst:
+            worst, worst_key = e, k
+        checked += 1
+    assert checked > 100
+    assert worst < 5e-4, (worst, worst_key)                  # three Adam steps apart: fp32 order-of-summation noise only
+
+
+def test_graphed_step_is_reproducible():
+    from phc_gnn_amd import graphed, harness
+    wl = "molhiv_b32"
+    gbs = [harness.make_batch(wl, seed=s) for s in (7, 8)]
+    n_max, e_max = graphed.bucket_shape(gbs)
+    padded = [graphed.padded_to_device(graphed.pad_batch(g, n_max, e_max), DEV) for g in gbs]
+    outs = []
+    for _ in range(2):
+        m, o = _fresh(wl, seed=1)
+        step = graphed.GraphedTrainStep(m, o, harness.StepConfig(), padded[0], warmup=1)
+        base = _fresh(wl, seed=1)[0].state_dict()
+        m.load_state_dict(base)
+        _reset_adam_in_place(o)
+        losses = [float(step.step(p)) for p in padded]
+        outs.append((losses, {k: v.clone() for k, v in m.state_dict().items()}))
+    assert outs[0][0] == outs[1][0]
+    assert all(torch.equal(outs[0][1][k], outs[1][1][k]) for k in outs[0][1])
