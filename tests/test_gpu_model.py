@@ -207,6 +207,8 @@ def test_graphed_step_matches_eager_step_on_unpadded_batch():
         # +-lr steps of random sign, so those tensors carry no information (and no influence on the loss)
         if k.endswith(".b") and not (k == "pooling.linear.b" or k == "downstream.affine.2.b"):
             continue
+        if k.endswith("running_mean"):          # tracks the mean of x.H + b, i.e. inherits that bias noise
+            continue
         e = relerr(sd_g[k], v)
         if e > worst:
             worst, worst_key = e, k
