@@ -57,16 +57,9 @@ def parse_args():
 
 
 def make_grad_sync(model, world):
-    import torch.distributed as dist
-    params = [p for p in model.parameters() if p.requires_grad]
-
-    def sync(_model):
-        grads = [p.grad for p in params if p.grad is not None]
-        flat = torch.cat([g.reshape(-1) for g in grads])
-        dist.all_reduce(flat, op=dist.ReduceOp.SUM)          # RCCL: one latency-bound bucket (~0.3 MB)
-        flat.div_(world)
-        torch._foreach_copy_(grads, [c.view_as(g) for c, g in zip(flat.split([g.numel() for g in grads]), grads)])
-    return sync
+    """One flat-bucket RCCL all-reduce (mean) of the ~0.3 MB gradient per step (phc_gnn_amd/dist.py)."""
+    from phc_gnn_amd.dist import FlatGradSync
+    return FlatGradSync(list(model.parameters()))
 
 
 def cpu_baseline(args, workload, model, gb):
@@ -140,20 +133,25 @@ def main():
     if rank == 0 and args.profile_steps > 0:
         # ---- roofline of the dominant engine kernel: instrumented EAGER pass over the same steps, taken before
         # the hipGraph is captured (HIP events cannot be recorded inside a replayed graph) ----
+        # (rank 0 only, so no collective in here: grad_sync=None)
         for i in range(3):
-            harness.train_step(model, batches[i % len(batches)], opt, cfg, grad_sync)
+            harness.train_step(model, batches[i % len(batches)], opt, cfg, None)
         torch.cuda.synchronize()
         lib.prof_reset()
         lib.prof_enable(True)
         for i in range(args.profile_steps):
-            harness.train_step(model, batches[i % len(batches)], opt, cfg, grad_sync)
+            harness.train_step(model, batches[i % len(batches)], opt, cfg, None)
         torch.cuda.synchronize()
         lib.prof_enable(False)
         prof = (lib.prof_read(), dict(lib.WORK))
     if world > 1:
         import torch.distributed as dist
+        # rank 0 trained a few extra steps in the profiling pass: put every replica back on the same weights
+        for t in list(model.state_dict().values()):
+            dist.broadcast(t, src=0)
         dist.barrier()
     graph_step = None
+    n_max = e_max = 0
     if args.mode == "graph":
         from phc_gnn_amd import graphed
         n_max, e_max = graphed.bucket_shape(host_batches)

@@ -72,6 +72,9 @@ class GraphedTrainStep:
     TENSORS = ("x", "edge_index", "edge_attr", "batch", "y", "n_valid_nodes")
 
     def __init__(self, model, optimizer, cfg: StepConfig, example: dict, grad_sync=None, warmup: int = 3):
+        """``grad_sync``: optional ``phc_gnn_amd.dist.FlatGradSync`` (data-parallel ranks).  The step is then
+        captured as TWO graphs — [forward, loss, backward, pack gradients into the flat bucket] and
+        [unpack, clip, Adam] — with the RCCL all-reduce of the bucket issued eagerly between them."""
         self.model, self.optimizer, self.cfg, self.grad_sync = model, optimizer, cfg, grad_sync
         dev = example["x"].device
         self.static = {k: example[k].clone() for k in self.TENSORS}
@@ -95,8 +98,18 @@ class GraphedTrainStep:
         gc.collect()                       # drop the warm-up autograd graphs before capturing
         clear_structure_cache()            # the CSR/CSC build must be captured, not served from the cache
         self.optimizer.zero_grad(set_to_none=True)
-        with torch.cuda.graph(self.graph, stream=self.stream):
-            self.loss = self._body()
+        self.graph2 = None
+        if self.grad_sync is None:
+            with torch.cuda.graph(self.graph, stream=self.stream):
+                self.loss = self._body()
+        else:
+            with torch.cuda.graph(self.graph, stream=self.stream):
+                self.loss = self._front()
+            # second half on its own stream (the first capture stream is never touched again), same memory pool
+            self.stream2 = torch.cuda.Stream(device=dev)
+            self.graph2 = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(self.graph2, pool=self.graph.pool(), stream=self.stream2):
+                self._back()
         clear_structure_cache()
         # Drop the captured autograd graph (its AccumulateGrad nodes are bound to the capture stream; a later
         # eager backward of the same model would otherwise enqueue work on that stream).  The loss buffer
@@ -108,18 +121,31 @@ class GraphedTrainStep:
         # later eager allocations made its replays fault on ROCm 7.2 (scripts/debug_graph2.py reproduces it).
         torch.cuda.synchronize(dev)
 
-    def _body(self):
+    def _front(self):
+        """zero_grad, forward, loss, backward (+ pack the gradients into the flat all-reduce bucket)."""
         self.data.y_mask = ~torch.isnan(self.data.y)
         self.optimizer.zero_grad(set_to_none=True)
         logits = self.model(self.data)
         loss = loss_fn(logits, self.data, self.cfg.regression)
         loss.backward()
         if self.grad_sync is not None:
-            self.grad_sync(self.model)
+            self.grad_sync.pack()
+        return loss
+
+    def _back(self):
+        """(unpack the reduced bucket,) clip, Adam."""
+        if self.grad_sync is not None:
+            self.grad_sync.unpack()
         if self.cfg.optimizer:
             if self.cfg.grad_clip > 0:
                 torch.nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=self.cfg.grad_clip, norm_type=2)
             self.optimizer.step()
+
+    def _body(self):
+        loss = self._front()
+        if self.grad_sync is not None:
+            self.grad_sync.reduce()
+        self._back()
         return loss
 
     def load(self, padded: dict) -> None:
@@ -131,4 +157,7 @@ class GraphedTrainStep:
         if padded is not None:
             self.load(padded)
         self.graph.replay()
+        if self.graph2 is not None:
+            self.grad_sync.reduce()            # eager RCCL all-reduce of the flat bucket (stream-ordered)
+            self.graph2.replay()
         return self.loss

@@ -162,6 +162,37 @@ class _AggregateFn(torch.autograd.Function):
         return (dx if need_x else None), dea, None, None, None
 
 
+def aggregate_fwd_raw(x: torch.Tensor, ea: Optional[torch.Tensor], st: EdgeStructure, msg_encoder, add_self: bool) -> torch.Tensor:
+    """Non-differentiable forward launch (used by phc_gnn_amd.dist to compose the sharded operator)."""
+    lib = L.load()
+    dev = L.require_device(x, ea)
+    act = msg_encoder if isinstance(msg_encoder, int) else _act_id(msg_encoder)
+    x_, ea_ = L.f32c(x), L.f32c(ea)
+    h = x_.shape[1]
+    rowptr, col, perm = st.csr
+    out = torch.empty((st.num_dst, h), dtype=torch.float32, device=dev)
+    L.check(lib.phc_aggregate_fwd(L.ptr(x_), L.ptr(ea_), L.ptr(rowptr), L.ptr(col), L.ptr(perm), st.num_dst, h, act,
+                                  1 if add_self else 0, L.ptr(out), L.stream_ptr(dev)), "phc_aggregate_fwd")
+    return out
+
+
+def aggregate_bwd_raw(dout: torch.Tensor, x: Optional[torch.Tensor], ea: Optional[torch.Tensor], st: EdgeStructure,
+                      msg_encoder, add_self: bool, need_dea: bool):
+    """Non-differentiable backward launch: returns (dx [num_src, h], dea [E, h] or None)."""
+    lib = L.load()
+    dev = L.require_device(dout, x, ea)
+    act = msg_encoder if isinstance(msg_encoder, int) else _act_id(msg_encoder)
+    dout_, x_, ea_ = L.f32c(dout), L.f32c(x), L.f32c(ea)
+    h = dout_.shape[1]
+    rowptr_t, col_t, perm_t = st.csc
+    dx = torch.empty((st.num_src, h), dtype=torch.float32, device=dev)
+    dea = torch.empty((st.num_edges, h), dtype=torch.float32, device=dev) if need_dea else None
+    L.check(lib.phc_aggregate_bwd(L.ptr(dout_), L.ptr(x_) if act != 0 else None, L.ptr(ea_) if act != 0 else None,
+                                  L.ptr(rowptr_t), L.ptr(col_t), L.ptr(perm_t), st.num_src, st.num_dst, h, act,
+                                  1 if add_self else 0, L.ptr(dx), L.ptr(dea), L.stream_ptr(dev)), "phc_aggregate_bwd")
+    return dx, dea
+
+
 def aggregate_sum(x: torch.Tensor, edge_index, edge_attr: Optional[torch.Tensor], msg_encoder: str = "identity",
                   add_self_loops: bool = False, num_dst: Optional[int] = None) -> torch.Tensor:
     """out[i] = Σ_{e: edge_index[1,e]=i} φ(x[edge_index[0,e]] + edge_attr[e])  (+ x[i]).

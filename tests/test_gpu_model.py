@@ -234,3 +234,69 @@ def test_graphed_step_is_reproducible():
         outs.append((losses, {k: v.clone() for k, v in m.state_dict().items()}))
     assert outs[0][0] == outs[1][0]
     assert all(torch.equal(outs[0][1][k], outs[1][1][k]) for k in outs[0][1])
+
+
+# ---- multi-GPU paths exercised on ONE GPU with a single-rank RCCL group ---------------------------
+@pytest.fixture(scope="module")
+def rccl_single_rank():
+    import os
+    import socket
+    import torch.distributed as dist
+    if dist.is_initialized():
+        yield
+        return
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device(DEV))
+    yield
+    dist.destroy_process_group()
+
+
+def test_sharded_aggregate_engine_backend_single_rank(rccl_single_rank):
+    from oracle import phc_oracle as O
+    from phc_gnn_amd import synth
+    from phc_gnn_amd.dist import ShardedAggregate, build_halo_plan
+    N, E, h = 5000, 30000, 128
+    ei = torch.from_numpy(synth.random_edges(N, E, seed=9))
+    g = torch.Generator().manual_seed(3)
+    x, ea, dy = torch.randn(N, h, generator=g), torch.randn(E, h, generator=g), torch.randn(N, h, generator=g)
+    plan = build_halo_plan(ei.to(DEV), N)
+    assert plan.n_halo == 0 and plan.n_own == N
+    agg = ShardedAggregate(plan)
+    xd = x.to(DEV).requires_grad_()
+    el, eh = agg.split_edge_attr(ea.to(DEV))
+    el = el.requires_grad_()
+    out = agg(xd, el, eh, "relu", True)
+    xr, er = x.clone().requires_grad_(), ea.clone().requires_grad_()
+    ref = O.propagate_add(xr, ei, er, "relu") + xr
+    assert_close(out, ref, TOL)
+    gx, ge = torch.autograd.grad(out, [xd, el], dy.to(DEV))
+    rgx, rge = torch.autograd.grad(ref, [xr, er], dy)
+    assert_close(gx, rgx, TOL)
+    assert_close(ge, rge.index_select(0, plan.loc_edge_ids.cpu()), TOL)
+
+
+def test_graphed_data_parallel_step_single_rank(rccl_single_rank):
+    """The two-graph + eager all-reduce step used for N>1 GPUs, run with a 1-rank RCCL group: must equal the
+    single-graph step."""
+    from phc_gnn_amd import graphed, harness
+    from phc_gnn_amd.dist import FlatGradSync
+    wl = "molhiv_b32"
+    gbs = [harness.make_batch(wl, seed=s) for s in (11, 12)]
+    n_max, e_max = graphed.bucket_shape(gbs)
+    padded = [graphed.padded_to_device(graphed.pad_batch(g, n_max, e_max), DEV) for g in gbs]
+    results = []
+    for use_sync in (False, True):
+        m, o = _fresh(wl, seed=2)
+        sync = FlatGradSync(list(m.parameters())) if use_sync else None
+        step = graphed.GraphedTrainStep(m, o, harness.StepConfig(), padded[0], grad_sync=sync, warmup=2)
+        m.load_state_dict(_fresh(wl, seed=2)[0].state_dict())
+        _reset_adam_in_place(o)
+        losses = [float(step.step(p)) for p in padded + padded]
+        results.append((losses, {k: v.clone() for k, v in m.state_dict().items()}))
+    assert results[0][0] == pytest.approx(results[1][0], rel=1e-6)
+    for k, v in results[0][1].items():
+        if v.is_floating_point():
+            assert_close(results[1][1][k], v, 1e-5, k)
