@@ -107,6 +107,12 @@ size_t phc_csr_ws_bytes(int64_t E, int64_t num_keys);
 int phc_csr_build(const int64_t *key_i64, const int64_t *other_i64, int64_t E, int64_t num_keys,
                   int32_t *rowptr, int32_t *col, int32_t *perm, void *ws, size_t ws_bytes, void *stream);
 
+/* rowptr[num_keys+1] for keys that are already NON-DECREASING (PyG's collated `batch`
+ * vector: graph id per node): rowptr[s] = first position with key >= s.  Segment members are
+ * then simply positions rowptr[s] .. rowptr[s+1]-1 (identity order).  Undefined result for
+ * unsorted keys — use phc_csr_build for those. */
+int phc_segment_ptr_sorted(const int64_t *key_i64, int64_t n, int64_t num_keys, int32_t *rowptr, void *stream);
+
 /* ------------------------------------------------------------------------- *
  * Neighbour aggregation (sum)
  * ------------------------------------------------------------------------- */

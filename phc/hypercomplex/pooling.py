@@ -16,9 +16,9 @@ class PHMGlobalSumPooling(nn.Module):
         self.phm_dim = phm_dim
         self.module = _engine.global_add_pool
 
-    def __call__(self, x: torch.Tensor, batch, num_graphs: Optional[int] = None) -> torch.Tensor:
+    def __call__(self, x: torch.Tensor, batch, num_graphs: Optional[int] = None, is_sorted: bool = False) -> torch.Tensor:
         # x: [num_nodes, phm_dim * feats];  batch: int64 graph id per node
-        return self.module(x, batch, num_graphs)
+        return self.module(x, batch, num_graphs, is_sorted)
 
     def reset_parameters(self):
         pass
@@ -54,11 +54,11 @@ class PHMSoftAttentionPooling(nn.Module):
         self.real_trafo.reset_parameters()
         self.linear.reset_parameters()
 
-    def forward(self, x: torch.Tensor, batch, num_graphs: Optional[int] = None) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, batch, num_graphs: Optional[int] = None, is_sorted: bool = False) -> torch.Tensor:
         gate = self.sigmoid(self.real_trafo(self.linear(x)))                   # [N, embed_dim / phm_dim]
         k = self.embed_dim // self.phm_dim
         gated = (x.view(x.size(0), self.phm_dim, k) * gate.unsqueeze(1)).view(x.size(0), self.embed_dim)
-        return self.sum_pooling(gated, batch=batch, num_graphs=num_graphs)
+        return self.sum_pooling(gated, batch=batch, num_graphs=num_graphs, is_sorted=is_sorted)
 
     def __repr__(self):
         return "{}(embed_dim={}, phm_dim={}, phm_rule={}, learn_phm={}, bias={}, w_init='{}', c_init='{}', " \

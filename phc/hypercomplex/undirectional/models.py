@@ -179,7 +179,8 @@ class PHMSkipConnectAdd(nn.Module):
                                                     edge_index=edge_index, edge_attr=e,
                                                     dropout_mpnn=self.dropout_mpnn[i], size=size, n_valid=n_valid)
         num_graphs = getattr(data, "num_graphs", None)
-        out = self.pooling(x=h, batch=batch, num_graphs=num_graphs)
+        # `batch` of a collated mini-batch is non-decreasing (PyG); batches that say otherwise take the sorting path
+        out = self.pooling(x=h, batch=batch, num_graphs=num_graphs, is_sorted=bool(getattr(data, "batch_is_sorted", True)))
         if n_valid_graphs is not None:
             return self.downstream(out, n_valid=n_valid_graphs)
         return self.downstream(out)

@@ -92,6 +92,19 @@ __global__ __launch_bounds__(256) void csr_canon_kernel(const int *__restrict__ 
     }
 }
 
+// rowptr[s] = first position whose key is >= s, for NON-DECREASING keys (PyG's collated `batch` vector):
+// one thread per boundary, binary search.  No histogram, no atomics, no sort.
+__global__ void sorted_segment_ptr_kernel(const long long *__restrict__ key, long long n, long long num_keys, int *__restrict__ rowptr) {
+    const long long s = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (s > num_keys) return;
+    long long lo = 0, hi = n;
+    while (lo < hi) {
+        const long long mid = (lo + hi) >> 1;
+        if (key[mid] < s) lo = mid + 1; else hi = mid;
+    }
+    rowptr[s] = (int)lo;
+}
+
 struct ScanLevels {
     int levels;
     long long n[6];
@@ -130,6 +143,17 @@ size_t phc_csr_ws_bytes(int64_t E, int64_t num_keys) {
     // cursor[num_keys] | scan block sums | tmp_perm[E]
     return align_up(sizeof(int) * (size_t)(num_keys + 1), 256) + align_up(sizeof(int) * (L.total_sum_ints + 1), 256) +
            align_up(sizeof(int) * (size_t)(E + 1), 256);
+}
+
+int phc_segment_ptr_sorted(const int64_t *key_i64, int64_t n, int64_t num_keys, int32_t *rowptr, void *stream) {
+    PHC_REQUIRE(n >= 0 && num_keys >= 0 && n < (1LL << 31) - 1, PHC_ERR_INVALID_ARG, "phc_segment_ptr_sorted: n=%lld num_keys=%lld",
+                (long long)n, (long long)num_keys);
+    PHC_REQUIRE(rowptr && (n == 0 || key_i64), PHC_ERR_INVALID_ARG, "phc_segment_ptr_sorted: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(K_CSR_SCAN, s);
+    hipLaunchKernelGGL(sorted_segment_ptr_kernel, dim3((unsigned)((num_keys + 1 + 255) / 256)), dim3(256), 0, s,
+                       reinterpret_cast<const long long *>(key_i64), (long long)n, (long long)num_keys, rowptr);
+    return check_launch("sorted_segment_ptr");
 }
 
 int phc_csr_build(const int64_t *key_i64, const int64_t *other_i64, int64_t E, int64_t num_keys, int32_t *rowptr,

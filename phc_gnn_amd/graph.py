@@ -72,20 +72,45 @@ class EdgeStructure:
         return self._csc
 
 
-class SegmentStructure:
-    """Rows grouped by an int64 segment id (``batch`` -> graphs), for read-out."""
+_IOTA: dict = {}
 
-    def __init__(self, batch: torch.Tensor, num_segments: int):
+
+def _iota(n: int, dev) -> torch.Tensor:
+    """arange(n) int32 on dev, grown on demand (identity member list of sorted segments)."""
+    t = _IOTA.get(dev)
+    if t is None or t.numel() < n:
+        t = torch.arange(max(n, 1024), dtype=torch.int32, device=dev)
+        _IOTA[dev] = t
+    return t
+
+
+class SegmentStructure:
+    """Rows grouped by an int64 segment id (``batch`` -> graphs), for read-out.
+
+    ``is_sorted=True`` (the collated ``batch`` vector of a PyG mini-batch is non-decreasing by
+    construction) takes the cheap path: segment boundaries by binary search, members in place."""
+
+    def __init__(self, batch: torch.Tensor, num_segments: int, is_sorted: bool = False):
         L.require_device(batch)
         self.batch = batch if batch.dtype == torch.int64 else batch.to(torch.int64)
         self.batch = self.batch.contiguous()
         self.num_segments = int(num_segments)
+        self.is_sorted = bool(is_sorted)
         self._csr = None
 
     @property
     def csr(self):
         if self._csr is None:
-            self._csr = _build_sorted(self.batch, None, self.num_segments)
+            if self.is_sorted:
+                lib = L.load()
+                dev = self.batch.device
+                n = self.batch.numel()
+                rowptr = torch.empty(self.num_segments + 1, dtype=torch.int32, device=dev)
+                L.check(lib.phc_segment_ptr_sorted(L.ptr(self.batch), n, self.num_segments, L.ptr(rowptr),
+                                                   L.stream_ptr(dev)), "phc_segment_ptr_sorted")
+                self._csr = (rowptr, _iota(n, dev), None)
+            else:
+                self._csr = _build_sorted(self.batch, None, self.num_segments)
         return self._csr
 
 
@@ -107,14 +132,14 @@ def edge_structure(edge_index: torch.Tensor, num_src: int, num_dst: Optional[int
     return st
 
 
-def segment_structure(batch: torch.Tensor, num_segments: Optional[int] = None) -> SegmentStructure:
+def segment_structure(batch: torch.Tensor, num_segments: Optional[int] = None, is_sorted: bool = False) -> SegmentStructure:
     if num_segments is None:
         # same host sync the reference pays in global_add_pool (batch.max() + 1)
         num_segments = int(batch.max().item()) + 1 if batch.numel() else 0
-    k = _key(batch, "seg", num_segments)
+    k = _key(batch, "seg", num_segments, is_sorted)
     st = _cache.get(k)
     if st is None:
-        st = SegmentStructure(batch, num_segments)
+        st = SegmentStructure(batch, num_segments, is_sorted)
         _cache[k] = st
         st._pin = batch
         while len(_cache) > _CACHE_SIZE:

@@ -5,9 +5,10 @@ CSR/CSC build, forward, loss, backward, gradient all-reduce, clipping, Adam — 
 into a hipGraph and replayed per batch.  Batches differ in size, so they are padded to one
 bucket shape:
 
-  * nodes  N..N_max-1  are padding nodes with feature indices 0, owned by an extra graph id B;
+  * nodes  N..N_max-1  are padding nodes with feature indices 0, owned by PAD_GRAPHS extra graph ids
+    B..B+PAD_GRAPHS-1 in round-robin blocks (no single long read-out segment);
   * edges  E..E_max-1  connect padding nodes to themselves, spread over the padding nodes;
-  * the extra graph B has NaN labels (masked out of the loss exactly like an unlabeled task);
+  * the extra graphs have NaN labels (masked out of the loss exactly like unlabeled tasks);
   * ``n_valid_nodes`` / ``n_valid_graphs`` are DEVICE int32 scalars read by the batch-norm kernels:
     padding rows stay out of the statistics, are written as 0 and receive zero gradient, so no
     padding row ever reaches a parameter gradient (tests/test_gpu_model.py::test_graphed_step_*).
@@ -38,6 +39,9 @@ def bucket_shape(batches: List[synth.GraphBatch], slack: float = 0.02, multiple:
     return n_max, e_max
 
 
+PAD_GRAPHS = 32
+
+
 def pad_batch(gb: synth.GraphBatch, n_max: int, e_max: int) -> dict:
     """Host-side padding of one collated batch to the bucket shape (part of collation)."""
     N, E, B = gb.num_nodes, gb.num_edges, gb.num_graphs
@@ -53,9 +57,11 @@ def pad_batch(gb: synth.GraphBatch, n_max: int, e_max: int) -> dict:
     ei[1, E:] = pad_nodes
     ea = np.zeros((e_max, gb.edge_attr.shape[1]), dtype=np.int64)
     ea[:E] = gb.edge_attr
-    batch = np.full(n_max, B, dtype=np.int64)
+    batch = np.empty(n_max, dtype=np.int64)
     batch[:N] = gb.batch
-    y = np.full((B + 1, gb.y.shape[1]), np.nan, dtype=np.float32)
+    per = -(-n_pad // PAD_GRAPHS)                                      # contiguous blocks keep `batch` sorted
+    batch[N:] = B + np.minimum(np.arange(n_pad, dtype=np.int64) // per, PAD_GRAPHS - 1)
+    y = np.full((B + PAD_GRAPHS, gb.y.shape[1]), np.nan, dtype=np.float32)
     y[:B] = gb.y
     return dict(x=x, edge_index=ei, edge_attr=ea, batch=batch, y=y, n_valid_nodes=np.array(N, dtype=np.int32),
                 num_graphs=B, num_nodes=N, num_edges=E)
@@ -81,7 +87,7 @@ class GraphedTrainStep:
         B = int(example["num_graphs"])
         self.data = types.SimpleNamespace(
             x=self.static["x"], edge_index=self.static["edge_index"], edge_attr=self.static["edge_attr"],
-            batch=self.static["batch"], y=self.static["y"], num_graphs=B + 1,
+            batch=self.static["batch"], y=self.static["y"], num_graphs=B + PAD_GRAPHS,
             n_valid_nodes=self.static["n_valid_nodes"],
             n_valid_graphs=torch.tensor(B, dtype=torch.int32, device=dev), all_labeled=False)
         self.loss = None

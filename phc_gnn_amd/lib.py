@@ -38,6 +38,7 @@ SIGNATURES = {
     "phc_phm_linear_bwd": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _S, _P]),
     "phc_csr_ws_bytes": (_S, [_L, _L]),
     "phc_csr_build": (_I, [_P, _P, _L, _L, _P, _P, _P, _P, _S, _P]),
+    "phc_segment_ptr_sorted": (_I, [_P, _L, _L, _P, _P]),
     "phc_aggregate_fwd": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P]),
     "phc_aggregate_bwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _L, _I, _I, _I, _P, _P, _P]),
     "phc_gather_rows_i64": (_I, [_P, _P, _L, _I, _P, _P]),

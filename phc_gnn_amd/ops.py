@@ -92,6 +92,21 @@ def phm_linear(x: torch.Tensor, phm_rule: torch.Tensor, W: torch.Tensor, bias: O
     return _PHMLinearFn.apply(x, phm_rule, W, bias, residual)
 
 
+_ONES: dict = {}
+
+
+def dense_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = x · weightᵀ + bias for an ``nn.Linear`` weight [out, in], on the PHM kernels: a dense map is the
+    phm_dim = 1 case (A = [[[1]]], W = weightᵀ).  Used for the hypercomplex→real head
+    (phc/hypercomplex/layers.py:386-414), whose K = N gradient GEMM is a poor fit for the BLAS heuristics."""
+    dev = L.require_device(x, weight)
+    one = _ONES.get(dev)
+    if one is None:
+        one = torch.ones(1, 1, 1, dtype=torch.float32, device=dev)
+        _ONES[dev] = one
+    return _PHMLinearFn.apply(x, one, weight.t().unsqueeze(0), bias, None)
+
+
 def phm_build_H(phm_rule: torch.Tensor, W: torch.Tensor) -> torch.Tensor:
     """Materialise H = Σ_i A_i ⊗ W_i  [n*kin, n*kout] (inspection / tests; not differentiable)."""
     lib = L.load()
@@ -239,9 +254,10 @@ class _SegmentSumFn(torch.autograd.Function):
         return dx, None
 
 
-def global_add_pool(x: torch.Tensor, batch, num_graphs: Optional[int] = None) -> torch.Tensor:
-    """out[g] = Σ_{i: batch[i]=g} x[i]  (torch_geometric.nn.global_add_pool semantics)."""
-    st = batch if isinstance(batch, SegmentStructure) else segment_structure(batch, num_graphs)
+def global_add_pool(x: torch.Tensor, batch, num_graphs: Optional[int] = None, is_sorted: bool = False) -> torch.Tensor:
+    """out[g] = Σ_{i: batch[i]=g} x[i]  (torch_geometric.nn.global_add_pool semantics).
+    ``is_sorted=True`` promises a non-decreasing ``batch`` (PyG collation) and skips the grouping sort."""
+    st = batch if isinstance(batch, SegmentStructure) else segment_structure(batch, num_graphs, is_sorted)
     return _SegmentSumFn.apply(x, st)
 
 

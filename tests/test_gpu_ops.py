@@ -345,3 +345,37 @@ def test_batch_norm_padding_rows_are_inert(ops):
     assert float(gg[0][valid:].abs().max()) == 0.0
     for a, r in zip(gg[1:], rg[1:]):
         assert_close(a, r, 3e-5)
+
+
+def test_sorted_segment_fast_path_equals_sorting_path(ops):
+    from phc_gnn_amd import synth
+    b = synth.molecule_batch(70, seed=13)
+    batch = torch.from_numpy(b.batch).to(DEV)
+    g = torch.Generator().manual_seed(4)
+    x = torch.randn(b.num_nodes, 128, generator=g).to(DEV).requires_grad_()
+    dy = torch.randn(72, 128, generator=g).to(DEV)                       # two trailing empty graphs
+    a = ops.global_add_pool(x, batch, 72, is_sorted=True)
+    c = ops.global_add_pool(x, batch.clone(), 72, is_sorted=False)
+    assert torch.equal(a, c)
+    assert float(a[70:].abs().max()) == 0.0
+    ga, = torch.autograd.grad(a, [x], dy)
+    gc_, = torch.autograd.grad(c, [x], dy)
+    assert torch.equal(ga, gc_)
+
+
+def test_dense_linear_on_phm_kernels(ops):
+    g = torch.Generator().manual_seed(6)
+    lin = torch.nn.Linear(128, 32)
+    x = torch.randn(3001, 128, generator=g)
+    dy = torch.randn(3001, 32, generator=g)
+    xr = x.clone().requires_grad_()
+    ref = lin(xr)
+    rg = torch.autograd.grad(ref, [xr, lin.weight, lin.bias], dy)
+    lind = torch.nn.Linear(128, 32).to(DEV)
+    lind.load_state_dict(lin.state_dict())
+    xd = x.to(DEV).requires_grad_()
+    out = ops.dense_linear(xd, lind.weight, lind.bias)
+    assert_close(out, ref, TOL)
+    gg = torch.autograd.grad(out, [xd, lind.weight, lind.bias], dy.to(DEV))
+    for a, r in zip(gg, rg):
+        assert_close(a, r, TOL)
