@@ -175,6 +175,15 @@ int phc_aggregate_enc_fwd(const float *x, const int64_t *bond_i64, const float *
                           const int32_t *rowptr, const int32_t *col, const int32_t *perm, int64_t n_dst, int F, int n, int k,
                           int act, int add_self, float *out, void *stream);
 
+/* Packed variant (F <= 4 and sum(vocab) <= 256 — every molecule bond vocabulary): the F table rows of an
+ * edge are packed one byte each into codes[e] (uint32, SORTED edge order; perm may be NULL = identity) once
+ * per batch, and the aggregation reads 4 bytes per edge next to col[e]. */
+int phc_pack_edge_codes(const int64_t *bond_i64, const int32_t *perm, const int32_t *vocab, int64_t E, int F,
+                        uint32_t *codes, void *stream);
+int phc_aggregate_encp_fwd(const float *x, const uint32_t *codes, const float *const *tables, const int32_t *vocab,
+                           const int32_t *rowptr, const int32_t *col, int64_t n_dst, int F, int n, int k, int act,
+                           int add_self, float *out, void *stream);
+
 /* Backward of phc_aggregate_enc_fwd: dx (source-sorted walk, may be NULL) and the
  * flat table gradient (may be NULL).  The table gradient is a one-hot GEMM on the
  * matrix cores over the edges in ORIGINAL order, so it takes the raw int64 edge

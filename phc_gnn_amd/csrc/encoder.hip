@@ -127,6 +127,90 @@ __global__ __launch_bounds__(ENC_THREADS) void aggregate_enc_fwd_kernel(
     }
 }
 
+// ---- packed edge codes --------------------------------------------------------------------------
+// codes[e] = table rows (off_f + bond[perm[e], f]) of the e-th edge of a SORTED edge list, one byte per feature
+// (F <= 4, sum(vocab) <= 256).  Built once per (edge structure, bond tensor); the aggregation then reads
+// 4 bytes per edge next to col[e] instead of chasing perm[e] -> F int64 loads.
+__global__ void pack_edge_codes_kernel(const long long *__restrict__ bond, const int *__restrict__ perm, EncMeta m, long long E,
+                                       unsigned *__restrict__ codes) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (long long)gridDim.x * blockDim.x) {
+        const long long p = perm ? perm[e] : e;
+        unsigned c = 0;
+        for (int f = 0; f < m.F; ++f) c |= (unsigned)(m.off[f] + (int)bond[p * m.F + f]) << (8 * f);
+        codes[e] = c;
+    }
+}
+
+template <int F>
+__device__ __forceinline__ void add_code_rows(float4 &v, const float *__restrict__ tbl, unsigned code, int h, int c4) {
+#pragma unroll
+    for (int f = 0; f < F; ++f) acc4(v, reinterpret_cast<const float4 *>(tbl + ((code >> (8 * f)) & 255u) * h)[c4]);
+}
+
+// out[d] = sum_{e in row d} phi( x[col[e]] + sum_f tbl[code_f(e)] ) (+ x[d]);  two edges per lane group in flight
+template <int LPR, int ACT, int F>
+__global__ __launch_bounds__(ENC_THREADS) void aggregate_encp_fwd_kernel(
+    const float *__restrict__ x, const unsigned *__restrict__ codes, const float *const *__restrict__ tables, EncMeta m,
+    const int *__restrict__ rowptr, const int *__restrict__ col, long long n_dst, int n, int k, int add_self,
+    float *__restrict__ out) {
+    extern __shared__ __attribute__((aligned(16))) float tbl[];      // [R][h], component-major columns
+    __shared__ const float *tptr[PHC_MAX_COMPONENTS * 4];             // table base pointers (n * F <= 64)
+    const int h = n * k, h4 = h >> 2;
+    if ((int)threadIdx.x < n * m.F) tptr[threadIdx.x] = tables[threadIdx.x];
+    __syncthreads();
+    // stage the tables: k/4 float4 per (row, component); loads are independent => batched 8 deep
+    {
+        const int k4 = k >> 2, per_row = n * k4, total = m.R * per_row;
+#pragma unroll 8
+        for (int e = threadIdx.x; e < total; e += ENC_THREADS) {
+            const int r = e / per_row, q = e - r * per_row;
+            const int c = q / k4, kk = q - c * k4;
+            int f = 0;
+            while (f + 1 < m.F && r >= m.off[f + 1]) ++f;
+            reinterpret_cast<float4 *>(tbl + r * h + c * k)[kk] =
+                reinterpret_cast<const float4 *>(tptr[c * m.F + f] + (size_t)(r - m.off[f]) * k)[kk];
+        }
+    }
+    __syncthreads();
+    constexpr int G = WAVE / LPR;
+    const int lane = threadIdx.x & 63;
+    const int grp = lane / LPR, li = lane - grp * LPR;
+    const long long wave_id = ((long long)blockIdx.x * ENC_THREADS + threadIdx.x) >> 6;
+    const long long n_waves = ((long long)gridDim.x * ENC_THREADS) >> 6;
+    for (long long d = wave_id; d < n_dst; d += n_waves) {
+        const int e_begin = rowptr[d], e_end = rowptr[d + 1];
+        for (int c4 = li; c4 < h4; c4 += LPR) {
+            float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
+            int e = e_begin + grp;
+            for (; e + G < e_end; e += 2 * G) {
+                const int s0 = col[e], s1 = col[e + G];
+                const unsigned k0 = codes[e], k1 = codes[e + G];
+                float4 v0 = reinterpret_cast<const float4 *>(x + (size_t)s0 * h)[c4];
+                float4 v1 = reinterpret_cast<const float4 *>(x + (size_t)s1 * h)[c4];
+                add_code_rows<F>(v0, tbl, k0, h, c4);
+                add_code_rows<F>(v1, tbl, k1, h, c4);
+                acc0.x += act_fwd<ACT>(v0.x); acc0.y += act_fwd<ACT>(v0.y); acc0.z += act_fwd<ACT>(v0.z); acc0.w += act_fwd<ACT>(v0.w);
+                acc1.x += act_fwd<ACT>(v1.x); acc1.y += act_fwd<ACT>(v1.y); acc1.z += act_fwd<ACT>(v1.z); acc1.w += act_fwd<ACT>(v1.w);
+            }
+            if (e < e_end) {
+                float4 v0 = reinterpret_cast<const float4 *>(x + (size_t)col[e] * h)[c4];
+                add_code_rows<F>(v0, tbl, codes[e], h, c4);
+                acc0.x += act_fwd<ACT>(v0.x); acc0.y += act_fwd<ACT>(v0.y); acc0.z += act_fwd<ACT>(v0.z); acc0.w += act_fwd<ACT>(v0.w);
+            }
+            float4 acc = make_float4(acc0.x + acc1.x, acc0.y + acc1.y, acc0.z + acc1.z, acc0.w + acc1.w);
+#pragma unroll
+            for (int off = LPR; off < WAVE; off <<= 1) {
+                acc.x += __shfl_xor(acc.x, off, WAVE); acc.y += __shfl_xor(acc.y, off, WAVE);
+                acc.z += __shfl_xor(acc.z, off, WAVE); acc.w += __shfl_xor(acc.w, off, WAVE);
+            }
+            if (grp == 0) {
+                if (add_self) acc4(acc, reinterpret_cast<const float4 *>(x + (size_t)d * h)[c4]);
+                reinterpret_cast<float4 *>(out + (size_t)d * h)[c4] = acc;
+            }
+        }
+    }
+}
+
 // dx of the fused aggregation (source-sorted walk): dx[s] = sum_{e out of s} phi'(x[s] + enc_e) * dout[dst_e] (+ dout[s])
 template <int LPR, int ACT>
 __global__ __launch_bounds__(ENC_THREADS) void aggregate_enc_dx_kernel(
@@ -482,6 +566,75 @@ int phc_aggregate_enc_fwd(const float *x, const int64_t *bond_i64, const float *
 #undef PHC_AE_ACT
 #undef PHC_AE_LAUNCH
     return check_launch("aggregate_enc_fwd");
+}
+
+int phc_pack_edge_codes(const int64_t *bond_i64, const int32_t *perm, const int32_t *vocab, int64_t E, int F, uint32_t *codes,
+                        void *stream) {
+    EncMeta m;
+    int rc = make_meta("phc_pack_edge_codes", F, vocab, &m);
+    if (rc) return rc;
+    PHC_REQUIRE(F <= 4 && m.R <= 256, PHC_ERR_UNSUPPORTED, "phc_pack_edge_codes: needs F <= 4 and sum(vocab) <= 256 (got %d, %d)", F, m.R);
+    PHC_REQUIRE(E >= 0 && (E == 0 || (bond_i64 && codes)), PHC_ERR_INVALID_ARG, "phc_pack_edge_codes: bad arguments");
+    if (E == 0) return PHC_OK;
+    hipStream_t s = (hipStream_t)stream;
+    long long blocks = (E + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    ProfScope prof(K_PACK_CODES, s);
+    hipLaunchKernelGGL(pack_edge_codes_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const long long *>(bond_i64),
+                       perm, m, (long long)E, codes);
+    return check_launch("pack_edge_codes");
+}
+
+int phc_aggregate_encp_fwd(const float *x, const uint32_t *codes, const float *const *tables, const int32_t *vocab,
+                           const int32_t *rowptr, const int32_t *col, int64_t n_dst, int F, int n, int k, int act, int add_self,
+                           float *out, void *stream) {
+    EncMeta m;
+    int rc = make_meta("phc_aggregate_encp_fwd", F, vocab, &m);
+    if (rc) return rc;
+    PHC_REQUIRE(n_dst >= 0 && n >= 1 && k >= 1, PHC_ERR_INVALID_ARG, "phc_aggregate_encp_fwd: bad sizes");
+    PHC_REQUIRE(act >= PHC_ACT_IDENTITY && act <= PHC_ACT_SELU, PHC_ERR_INVALID_ARG, "phc_aggregate_encp_fwd: unknown activation %d", act);
+    if (n_dst == 0) return PHC_OK;
+    PHC_REQUIRE(x && codes && tables && rowptr && col && out, PHC_ERR_INVALID_ARG, "phc_aggregate_encp_fwd: null pointer");
+    const int h = n * k;
+    const size_t lds = sizeof(float) * (size_t)m.R * h;
+    PHC_REQUIRE(F <= 4 && m.R <= 256 && n * F <= PHC_MAX_COMPONENTS * 4, PHC_ERR_UNSUPPORTED,
+                "phc_aggregate_encp_fwd: needs F <= 4, sum(vocab) <= 256, n*F <= 64");
+    PHC_REQUIRE(k % 4 == 0 && al16(x) && al16(out), PHC_ERR_UNSUPPORTED, "phc_aggregate_encp_fwd: needs k %% 4 == 0 and 16-byte aligned rows");
+    PHC_REQUIRE(lds <= 48 * 1024, PHC_ERR_UNSUPPORTED, "phc_aggregate_encp_fwd: tables (%zu B) exceed the LDS budget", lds);
+    hipStream_t s = (hipStream_t)stream;
+    long long blocks = (n_dst + 3) / 4;
+    if (blocks > 2048) blocks = 2048;                       // persistent-ish: amortise the LDS table fill
+    const int lpr = lpr_for(h >> 2);
+    ProfScope prof(K_AGG_ENC_FWD, s);
+#define PHC_AP_LAUNCH(LPRC, ACTC, FC)                                                                                     \
+    hipLaunchKernelGGL((aggregate_encp_fwd_kernel<LPRC, ACTC, FC>), dim3((unsigned)blocks), dim3(ENC_THREADS), lds, s, x, codes, \
+                       tables, m, rowptr, col, (long long)n_dst, n, k, add_self, out)
+#define PHC_AP_F(LPRC, ACTC)                                    \
+    switch (F) {                                                \
+        case 1: PHC_AP_LAUNCH(LPRC, ACTC, 1); break;            \
+        case 2: PHC_AP_LAUNCH(LPRC, ACTC, 2); break;            \
+        case 3: PHC_AP_LAUNCH(LPRC, ACTC, 3); break;            \
+        default: PHC_AP_LAUNCH(LPRC, ACTC, 4); break;           \
+    }
+#define PHC_AP_ACT(LPRC)                                            \
+    switch (act) {                                                  \
+        case PHC_ACT_IDENTITY: PHC_AP_F(LPRC, PHC_ACT_IDENTITY); break; \
+        case PHC_ACT_RELU: PHC_AP_F(LPRC, PHC_ACT_RELU); break;         \
+        case PHC_ACT_LRELU: PHC_AP_F(LPRC, PHC_ACT_LRELU); break;       \
+        case PHC_ACT_ELU: PHC_AP_F(LPRC, PHC_ACT_ELU); break;           \
+        case PHC_ACT_SWISH: PHC_AP_F(LPRC, PHC_ACT_SWISH); break;       \
+        default: PHC_AP_F(LPRC, PHC_ACT_SELU); break;                   \
+    }
+    switch (lpr) {
+        case 8: PHC_AP_ACT(8); break;
+        case 16: PHC_AP_ACT(16); break;
+        case 32: PHC_AP_ACT(32); break;
+        default: PHC_AP_ACT(64); break;
+    }
+#undef PHC_AP_ACT
+#undef PHC_AP_F
+#undef PHC_AP_LAUNCH
+    return check_launch("aggregate_encp_fwd");
 }
 
 size_t phc_aggregate_enc_bwd_ws_bytes(int64_t E, int F, const int32_t *vocab, int n, int k) {

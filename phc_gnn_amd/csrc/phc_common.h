@@ -47,6 +47,7 @@ enum KernelId : int {
     K_BN_BWD_PARTIAL,
     K_BN_BWD_FINALIZE,
     K_BN_BWD_APPLY,
+    K_PACK_CODES,
     K_NUM_KERNELS
 };
 

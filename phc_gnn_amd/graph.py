@@ -56,6 +56,21 @@ class EdgeStructure:
         self._dst = edge_index[1].contiguous()
         self._csr: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None
         self._csc: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None
+        self._codes: dict = {}
+
+    def packed_codes(self, bond_idx: torch.Tensor, vocab_c, F: int) -> torch.Tensor:
+        """uint32 per edge in destination-sorted order: the F table rows of the edge's integer features, one
+        byte each (built once per bond tensor, shared by all layers)."""
+        key = (bond_idx.data_ptr(), bond_idx._version, tuple(vocab_c))
+        codes = self._codes.get(key)
+        if codes is None:
+            lib = L.load()
+            _, _, perm = self.csr
+            codes = torch.empty(self.num_edges, dtype=torch.int32, device=bond_idx.device)
+            L.check(lib.phc_pack_edge_codes(L.ptr(bond_idx), L.ptr(perm), vocab_c, self.num_edges, F, L.ptr(codes),
+                                            L.stream_ptr(bond_idx.device)), "phc_pack_edge_codes")
+            self._codes = {key: codes}
+        return codes
 
     @property
     def csr(self):

@@ -397,9 +397,15 @@ class _AggregateEncFn(torch.autograd.Function):
             raise L.PhcError(f"x has {x_.shape[0]} rows, edge structure expects {st.num_src} source rows")
         rowptr, col, perm = st.csr
         out = torch.empty((st.num_dst, h), dtype=torch.float32, device=dev)
-        L.check(lib.phc_aggregate_enc_fwd(L.ptr(x_), L.ptr(bond_), L.ptr(ts.ptrs), ts.vocab_c, L.ptr(rowptr), L.ptr(col),
-                                          L.ptr(perm), st.num_dst, ts.F, ts.n, ts.k, act, 1 if add_self else 0, L.ptr(out),
-                                          L.stream_ptr(dev)), "phc_aggregate_enc_fwd")
+        if ts.F <= 4 and ts.R <= 256:
+            codes = st.packed_codes(bond_, ts.vocab_c, ts.F)        # 4 bytes per edge, in sorted order, built once per batch
+            L.check(lib.phc_aggregate_encp_fwd(L.ptr(x_), L.ptr(codes), L.ptr(ts.ptrs), ts.vocab_c, L.ptr(rowptr), L.ptr(col),
+                                               st.num_dst, ts.F, ts.n, ts.k, act, 1 if add_self else 0, L.ptr(out),
+                                               L.stream_ptr(dev)), "phc_aggregate_encp_fwd")
+        else:
+            L.check(lib.phc_aggregate_enc_fwd(L.ptr(x_), L.ptr(bond_), L.ptr(ts.ptrs), ts.vocab_c, L.ptr(rowptr), L.ptr(col),
+                                              L.ptr(perm), st.num_dst, ts.F, ts.n, ts.k, act, 1 if add_self else 0, L.ptr(out),
+                                              L.stream_ptr(dev)), "phc_aggregate_enc_fwd")
         if L.PROF_ON:
             E, N = st.num_edges, st.num_dst
             L.account("aggregate_enc_fwd", 2.0 * E * h,

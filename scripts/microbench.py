@@ -97,6 +97,8 @@ def run(tag, N, E, h=128, n=4, mol=False):
     report("encode_bwd (atoms)", timeit(lambda: l.phc_encode_bwd(dy.data_ptr(), xa.data_ptr(), N, 9, tsa.vocab_c, n, k, fl.data_ptr(), ws2.data_ptr(), wsb2, sp)), 0, N * (72.0 + 4 * h))
     enc_bytes = E * (4.0 * h + 8 + 24) + N * 8.0 * h + 4.0 * (N + 1)
     report("aggregate_enc_fwd", timeit(lambda: l.phc_aggregate_enc_fwd(x.data_ptr(), xb.data_ptr(), tsb.ptrs.data_ptr(), tsb.vocab_c, rowptr.data_ptr(), col.data_ptr(), perm.data_ptr(), N, 3, n, k, 0, 1, out.data_ptr(), sp)), 0, enc_bytes)
+    codes = st.packed_codes(xb, tsb.vocab_c, 3)
+    report("aggregate_encp_fwd (packed codes)", timeit(lambda: l.phc_aggregate_encp_fwd(x.data_ptr(), codes.data_ptr(), tsb.ptrs.data_ptr(), tsb.vocab_c, rowptr.data_ptr(), col.data_ptr(), N, 3, n, k, 0, 1, out.data_ptr(), sp)), 0, E * (4.0 * h + 8) + N * 8.0 * h + 4.0 * (N + 1))
     flb = torch.empty(n * tsb.R * k, device=dev)
     wsb3 = l.phc_aggregate_enc_bwd_ws_bytes(E, 3, tsb.vocab_c, n, k); ws3 = torch.empty(wsb3, dtype=torch.uint8, device=dev)
     report("aggregate_enc_bwd (dx only)", timeit(lambda: l.phc_aggregate_enc_bwd(dy.data_ptr(), x.data_ptr(), xb.data_ptr(), tsb.ptrs.data_ptr(), tsb.vocab_c, st._src.data_ptr(), st._dst.data_ptr(), E, rt.data_ptr(), ct.data_ptr(), pt.data_ptr(), N, N, 3, n, k, 0, 1, dx.data_ptr(), None, None, 0, sp)), 0, E * (4.0 * h + 4) + N * 8.0 * h)
