@@ -137,6 +137,25 @@ int phc_aggregate_bwd(const float *dout, const float *x, const float *ea, const 
                       const int32_t *col_t, const int32_t *perm_t, int64_t n_src, int64_t n_dst, int h,
                       int act, int add_self, float *dx, float *dea, void *stream);
 
+/* ------------------------------------------------------------------------- *
+ * Softmax neighbour aggregation (the reference's default molhiv setting)
+ *   m_e = phi(x[col[e]] + ea[perm[e]]);  per destination d and per column:
+ *   out[d] = sum_e softmax_e(beta * m_e) * m_e        (empty rows: 0)
+ * Replaces scatter_softmax + scatter_sum in PHMConvSoftmax / PHMGINEConvSoftmax.aggregate
+ * (messagepassing.py:211-214, 297-300; torch-scatter 2.0.5: max-shifted, eps 1e-12 in the
+ * denominator).  beta_dev is a DEVICE scalar (the learnable nn.Parameter).  lse[n_dst, h]
+ * (max + log(sum + eps)) is written for the backward.
+ * Backward (source-sorted walk): dx[n_src, h], dea[E, h] (may be NULL) and
+ * phc_softmax_bwd_num_partials(n_src) partial sums of d/d beta (caller adds them up).
+ * ------------------------------------------------------------------------- */
+int phc_aggregate_softmax_fwd(const float *x, const float *ea, const int32_t *rowptr, const int32_t *col,
+                              const int32_t *perm, const float *beta_dev, int64_t n_dst, int h, int act, float *out,
+                              float *lse, void *stream);
+int phc_softmax_bwd_num_partials(int64_t n_src);
+int phc_aggregate_softmax_bwd(const float *dout, const float *out, const float *lse, const float *x, const float *ea,
+                              const float *beta_dev, const int32_t *rowptr_t, const int32_t *col_t, const int32_t *perm_t,
+                              int64_t n_src, int h, int act, float *dx, float *dea, float *dbeta_partial, void *stream);
+
 /* out[r, :] = src[idx[r], :]   (row gather; backward of a segment sum, e.g.
  * global_add_pool's gradient dx[i] = dout[batch[i]], pooling.py:14) */
 int phc_gather_rows_i64(const float *src, const int64_t *idx_i64, int64_t n_rows, int h, float *out, void *stream);

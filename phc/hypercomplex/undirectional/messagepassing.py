@@ -168,6 +168,70 @@ class PHMGINEConv(_SumConvBase):
                    self.c_init, self.aggr)
 
 
+class _SoftmaxMixin:
+    """beta handling + softmax aggregate shared by the two softmax operators   (ref :194-214, 280-300)."""
+
+    def _setup_beta(self, kwargs) -> None:
+        self.initial_beta = kwargs.get("initial_beta")
+        self.learn_beta = kwargs.get("learn_beta")
+        if self.initial_beta is None:
+            self.initial_beta = 1.0
+        self.beta = nn.Parameter(torch.tensor(float(self.initial_beta)), requires_grad=bool(self.learn_beta))
+
+    def propagate(self, edge_index: Adj, x: torch.Tensor, edge_attr: torch.Tensor, size: Size = None,
+                  add_self: bool = False) -> torch.Tensor:
+        assert x.size(-1) == edge_attr.size(-1)
+        num_dst = size[1] if size is not None and size[1] is not None else None
+        out = _engine.aggregate_softmax(x, edge_index, edge_attr, self.beta, self.msg_encoder_str, num_dst)
+        return out + x if add_self else out
+
+    def propagate_encoded(self, edge_index, x, edge_idx, encoder, size=None, add_self=False):
+        # softmax weights need the per-edge message: embed the bonds ([E, h]) and take the tensor path
+        ea = encoder(edge_idx)
+        return self.propagate(edge_index, x=x, edge_attr=ea.reshape(ea.size(0), -1), size=size, add_self=add_self)
+
+    def aggregate(self, inputs: torch.Tensor, index: torch.Tensor, dim_size: Optional[int] = None) -> torch.Tensor:
+        """API parity with the reference's override (scatter_softmax + scatter_sum on explicit messages)."""
+        n = int(index.max()) + 1 if dim_size is None else dim_size
+        ei = torch.stack([torch.arange(index.numel(), device=index.device), index])
+        zeros = torch.zeros_like(inputs)
+        return _engine.aggregate_softmax(inputs, _engine.EdgeStructure(ei, index.numel(), n), zeros, self.beta, "identity")
+
+
+class PHMConvSoftmax(_SoftmaxMixin, PHMConv):
+    """PHMConv with softmax aggregation and a learnable inverse temperature beta   (ref :164-245)."""
+
+    def __init__(self, in_features: int, out_features: int, phm_dim: int, phm_rule, learn_phm: True, bias: bool = True,
+                 add_self_loops: bool = True, w_init: str = "phm", c_init: str = "standard", aggr: str = "softmax",
+                 same_dim: bool = True, msg_encoder: str = "identity", **kwargs) -> None:
+        PHMConv.__init__(self, in_features, out_features, phm_dim, phm_rule, learn_phm, bias, add_self_loops, w_init, c_init,
+                         "add", same_dim, msg_encoder)
+        self.aggr = aggr
+        self._setup_beta(kwargs)
+
+    def reset_parameters(self):
+        self.transform.reset_parameters()
+        if hasattr(self, "beta"):
+            self.beta.data.fill_(float(self.initial_beta))
+
+
+class PHMGINEConvSoftmax(_SoftmaxMixin, PHMGINEConv):
+    """PHMGINEConv with softmax aggregation   (ref :248-327)."""
+
+    def __init__(self, in_features: int, out_features: int, phm_dim: int, phm_rule, learn_phm: bool = True, bias: bool = True,
+                 add_self_loops: bool = True, norm: Optional[str] = None, activation: str = "relu", w_init: str = "phm",
+                 c_init: str = "standard", aggr: str = "softmax", msg_encoder: str = "identity", **kwargs) -> None:
+        PHMGINEConv.__init__(self, in_features, out_features, phm_dim, phm_rule, learn_phm, bias, add_self_loops, norm,
+                             activation, w_init, c_init, "add", msg_encoder)
+        self.aggr = aggr
+        self._setup_beta(kwargs)
+
+    def reset_parameters(self):
+        self.transform.reset_parameters()
+        if hasattr(self, "beta"):
+            self.beta.data.fill_(float(self.initial_beta))
+
+
 class PHMMessagePassing(nn.Module):
     """Dispatcher over the graph-conv operators   (ref :456-518): ``mlp`` picks
     PHMGINEConv over PHMConv; ``aggr`` in {"add", "sum"} is served by the engine."""
@@ -196,8 +260,14 @@ class PHMMessagePassing(nn.Module):
         if aggr == "pna":
             raise NotImplementedError("aggr='pna' (PHMPNAConvSimple) is outside the MI355X engine's scope")
         if aggr == "softmax":
-            raise NotImplementedError("aggr='softmax' is scheduled after the sum path (SURVEY.md §8f N2)")
-        if mlp:
+            if mlp:
+                self.transform = PHMGINEConvSoftmax(in_features, out_features, phm_dim, phm_rule, learn_phm, bias,
+                                                    add_self_loops, norm, activation, w_init, c_init, aggr, msg_encoder,
+                                                    **kwargs)
+            else:
+                self.transform = PHMConvSoftmax(in_features, out_features, phm_dim, phm_rule, learn_phm, bias,
+                                                add_self_loops, w_init, c_init, aggr, same_dim, msg_encoder, **kwargs)
+        elif mlp:
             self.transform = PHMGINEConv(in_features, out_features, phm_dim, phm_rule, learn_phm, bias,
                                          add_self_loops, norm, activation, w_init, c_init, aggr, msg_encoder)
         else:

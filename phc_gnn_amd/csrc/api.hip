@@ -24,7 +24,7 @@ static const char *const kKernelNames[K_NUM_KERNELS] = {
     "aggregate_fwd",    "aggregate_bwd", "gather_rows", "csr_histogram",  "csr_scan",      "csr_fill",
     "csr_canonicalize", "encode_fwd",   "aggregate_enc_fwd", "aggregate_enc_dx", "table_grad", "table_grad_reduce",
     "bn_stats_partial", "bn_finalize", "bn_apply", "bn_bwd_partial", "bn_bwd_finalize", "bn_bwd_apply",
-    "pack_edge_codes",
+    "pack_edge_codes", "aggregate_softmax_fwd", "aggregate_softmax_bwd",
 };
 
 // ---- profiler ------------------------------------------------------------------

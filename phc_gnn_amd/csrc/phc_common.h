@@ -48,6 +48,8 @@ enum KernelId : int {
     K_BN_BWD_FINALIZE,
     K_BN_BWD_APPLY,
     K_PACK_CODES,
+    K_SOFTMAX_FWD,
+    K_SOFTMAX_BWD,
     K_NUM_KERNELS
 };
 

@@ -1,0 +1,234 @@
+// Softmax neighbour aggregation — the reference's default / paper-best molhiv setting.
+//
+// Reference: PHMConvSoftmax / PHMGINEConvSoftmax.aggregate
+// (phc/hypercomplex/undirectional/messagepassing.py:211-214, 297-300):
+//     w   = scatter_softmax(m * beta, index)          per destination AND per feature column
+//     out = scatter_sum(m * w, index)                 m = msg_encoder(x_j + edge_attr)
+// with torch-scatter 2.0.5's scatter_softmax (max-shifted, eps = 1e-12 added to the segment sum).
+// The reference runs 2 gathers + 6 scatter/elementwise passes over [E, h]; here one wavefront walks one
+// destination segment with an online (running max / running sum) softmax per column, all in registers.
+// Backward walks the source-sorted structure and rebuilds the weights from the saved log-sum-exp:
+//     w_e = exp(beta*m_e - lse[d]);  d out/d m_e = w_e * (1 + beta*(m_e - out[d]));  d out/d beta = sum_e w_e m_e (m_e - out[d])
+#include "phc_common.h"
+
+namespace phc {
+
+constexpr int SM_THREADS = 256;
+constexpr float SM_EPS = 1e-12f;
+
+struct Sm4 {            // online softmax state for 4 columns
+    float4 mx, s, w;
+};
+
+__device__ __forceinline__ void sm_update(float &mx, float &s, float &w, float m, float beta) {
+    const float sc = beta * m;
+    if (sc > mx) {
+        const float r = __expf(mx - sc);      // mx = -inf on the first edge: r = 0
+        s = s * r + 1.f;
+        w = w * r + m;
+        mx = sc;
+    } else {
+        const float p = __expf(sc - mx);
+        s += p;
+        w = fmaf(p, m, w);
+    }
+}
+
+__device__ __forceinline__ void sm_merge(float &mx, float &s, float &w, float mx2, float s2, float w2) {
+    const float M = fmaxf(mx, mx2);
+    const float a = (mx == -INFINITY) ? 0.f : __expf(mx - M);
+    const float b = (mx2 == -INFINITY) ? 0.f : __expf(mx2 - M);
+    s = s * a + s2 * b;
+    w = w * a + w2 * b;
+    mx = M;
+}
+
+template <int LPR, int ACT>
+__global__ __launch_bounds__(SM_THREADS) void softmax_agg_fwd_kernel(const float *__restrict__ x, const float *__restrict__ ea,
+                                                                  const int *__restrict__ rowptr, const int *__restrict__ col,
+                                                                  const int *__restrict__ perm, const float *__restrict__ beta_p,
+                                                                  long long n_dst, int h, float *__restrict__ out,
+                                                                  float *__restrict__ lse) {
+    constexpr int G = WAVE / LPR;
+    const int lane = threadIdx.x & 63;
+    const int grp = lane / LPR, li = lane - grp * LPR;
+    const long long wave_id = ((long long)blockIdx.x * SM_THREADS + threadIdx.x) >> 6;
+    const long long n_waves = ((long long)gridDim.x * SM_THREADS) >> 6;
+    const int h4 = h >> 2;
+    const float beta = *beta_p;
+    for (long long d = wave_id; d < n_dst; d += n_waves) {
+        const int e_begin = rowptr[d], e_end = rowptr[d + 1];
+        for (int c4 = li; c4 < h4; c4 += LPR) {
+            float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, s[4] = {0.f, 0.f, 0.f, 0.f}, w[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int e = e_begin + grp; e < e_end; e += G) {
+                float4 v = reinterpret_cast<const float4 *>(x + (size_t)col[e] * h)[c4];
+                if (ea) {
+                    const float4 a = reinterpret_cast<const float4 *>(ea + (size_t)perm[e] * h)[c4];
+                    v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+                }
+                sm_update(mx[0], s[0], w[0], act_fwd<ACT>(v.x), beta);
+                sm_update(mx[1], s[1], w[1], act_fwd<ACT>(v.y), beta);
+                sm_update(mx[2], s[2], w[2], act_fwd<ACT>(v.z), beta);
+                sm_update(mx[3], s[3], w[3], act_fwd<ACT>(v.w), beta);
+            }
+#pragma unroll
+            for (int off = LPR; off < WAVE; off <<= 1) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float m2 = __shfl_xor(mx[q], off, WAVE), s2 = __shfl_xor(s[q], off, WAVE), w2 = __shfl_xor(w[q], off, WAVE);
+                    sm_merge(mx[q], s[q], w[q], m2, s2, w2);
+                }
+            }
+            if (grp == 0) {
+                float4 o, l;
+                float *op = &o.x, *lp = &l.x;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float z = s[q] + SM_EPS;
+                    op[q] = (e_end > e_begin) ? w[q] / z : 0.f;
+                    lp[q] = (e_end > e_begin) ? mx[q] + __logf(z) : 0.f;
+                }
+                reinterpret_cast<float4 *>(out + (size_t)d * h)[c4] = o;
+                reinterpret_cast<float4 *>(lse + (size_t)d * h)[c4] = l;
+            }
+        }
+    }
+}
+
+// source-sorted walk; dbeta partial sums per workgroup (fixed order => reproducible)
+template <int LPR, int ACT>
+__global__ __launch_bounds__(SM_THREADS) void softmax_agg_bwd_kernel(
+    const float *__restrict__ dout, const float *__restrict__ out, const float *__restrict__ lse, const float *__restrict__ x,
+    const float *__restrict__ ea, const float *__restrict__ beta_p, const int *__restrict__ rowptr_t, const int *__restrict__ col_t,
+    const int *__restrict__ perm_t, long long n_src, int h, float *__restrict__ dx, float *__restrict__ dea,
+    float *__restrict__ dbeta_partial) {
+    __shared__ float red[SM_THREADS];
+    constexpr int G = WAVE / LPR;
+    const int lane = threadIdx.x & 63;
+    const int grp = lane / LPR, li = lane - grp * LPR;
+    const long long wave_id = ((long long)blockIdx.x * SM_THREADS + threadIdx.x) >> 6;
+    const long long n_waves = ((long long)gridDim.x * SM_THREADS) >> 6;
+    const int h4 = h >> 2;
+    const float beta = *beta_p;
+    float db = 0.f;
+    for (long long sidx = wave_id; sidx < n_src; sidx += n_waves) {
+        const int e_begin = rowptr_t[sidx], e_end = rowptr_t[sidx + 1];
+        for (int c4 = li; c4 < h4; c4 += LPR) {
+            const float4 xs = reinterpret_cast<const float4 *>(x + (size_t)sidx * h)[c4];
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int e = e_begin + grp; e < e_end; e += G) {
+                const size_t d = (size_t)col_t[e];
+                const size_t p = (size_t)perm_t[e];
+                float pre[4] = {xs.x, xs.y, xs.z, xs.w};
+                if (ea) {
+                    const float4 a = reinterpret_cast<const float4 *>(ea + p * h)[c4];
+                    pre[0] += a.x; pre[1] += a.y; pre[2] += a.z; pre[3] += a.w;
+                }
+                const float4 go4 = reinterpret_cast<const float4 *>(dout + d * h)[c4];
+                const float4 o4 = reinterpret_cast<const float4 *>(out + d * h)[c4];
+                const float4 l4 = reinterpret_cast<const float4 *>(lse + d * h)[c4];
+                const float go[4] = {go4.x, go4.y, go4.z, go4.w}, o[4] = {o4.x, o4.y, o4.z, o4.w}, l[4] = {l4.x, l4.y, l4.z, l4.w};
+                float g[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float m = act_fwd<ACT>(pre[q]);
+                    const float wgt = __expf(beta * m - l[q]);
+                    const float t = wgt * (m - o[q]);
+                    db = fmaf(go[q] * t, m, db);
+                    g[q] = go[q] * (wgt + beta * t) * act_grad<ACT>(pre[q]);
+                    acc[q] += g[q];
+                }
+                if (dea) reinterpret_cast<float4 *>(dea + p * h)[c4] = make_float4(g[0], g[1], g[2], g[3]);
+            }
+#pragma unroll
+            for (int off = LPR; off < WAVE; off <<= 1)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc[q] += __shfl_xor(acc[q], off, WAVE);
+            if (grp == 0) reinterpret_cast<float4 *>(dx + (size_t)sidx * h)[c4] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        }
+    }
+    red[threadIdx.x] = db;
+    __syncthreads();
+    for (int st = SM_THREADS / 2; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) dbeta_partial[blockIdx.x] = red[0];
+}
+
+static inline int sm_lpr(int h4) { return h4 <= 8 ? 8 : h4 <= 16 ? 16 : h4 <= 32 ? 32 : 64; }
+static inline unsigned sm_grid(long long rows) {
+    long long b = (rows + 3) / 4;
+    if (b > 4096) b = 4096;
+    if (b < 1) b = 1;
+    return (unsigned)b;
+}
+static inline bool sm_al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+#define PHC_SM_ACT(act, MACRO)                            \
+    switch (act) {                                        \
+        case PHC_ACT_IDENTITY: MACRO(PHC_ACT_IDENTITY); break; \
+        case PHC_ACT_RELU: MACRO(PHC_ACT_RELU); break;         \
+        case PHC_ACT_LRELU: MACRO(PHC_ACT_LRELU); break;       \
+        case PHC_ACT_ELU: MACRO(PHC_ACT_ELU); break;           \
+        case PHC_ACT_SWISH: MACRO(PHC_ACT_SWISH); break;       \
+        default: MACRO(PHC_ACT_SELU); break;                   \
+    }
+
+}  // namespace phc
+
+using namespace phc;
+
+extern "C" {
+
+int phc_softmax_bwd_num_partials(int64_t n_src) { return (int)sm_grid(n_src); }
+
+int phc_aggregate_softmax_fwd(const float *x, const float *ea, const int32_t *rowptr, const int32_t *col, const int32_t *perm,
+                              const float *beta_dev, int64_t n_dst, int h, int act, float *out, float *lse, void *stream) {
+    PHC_REQUIRE(n_dst >= 0 && h >= 1, PHC_ERR_INVALID_ARG, "phc_aggregate_softmax_fwd: bad sizes");
+    PHC_REQUIRE(act >= PHC_ACT_IDENTITY && act <= PHC_ACT_SELU, PHC_ERR_INVALID_ARG, "phc_aggregate_softmax_fwd: unknown activation %d", act);
+    if (n_dst == 0) return PHC_OK;
+    PHC_REQUIRE(x && rowptr && col && beta_dev && out && lse && (!ea || perm), PHC_ERR_INVALID_ARG, "phc_aggregate_softmax_fwd: null pointer");
+    PHC_REQUIRE(h % 4 == 0 && sm_al16(x) && sm_al16(out) && sm_al16(lse) && (!ea || sm_al16(ea)), PHC_ERR_UNSUPPORTED,
+                "phc_aggregate_softmax_fwd: needs h %% 4 == 0 and 16-byte aligned rows");
+    hipStream_t s = (hipStream_t)stream;
+    const int lpr = sm_lpr(h >> 2);
+    ProfScope prof(K_SOFTMAX_FWD, s);
+#define PHC_SM_FWD(ACTC)                                                                                                 \
+    switch (lpr) {                                                                                                       \
+        case 8: hipLaunchKernelGGL((softmax_agg_fwd_kernel<8, ACTC>), dim3(sm_grid(n_dst)), dim3(SM_THREADS), 0, s, x, ea, rowptr, col, perm, beta_dev, (long long)n_dst, h, out, lse); break;   \
+        case 16: hipLaunchKernelGGL((softmax_agg_fwd_kernel<16, ACTC>), dim3(sm_grid(n_dst)), dim3(SM_THREADS), 0, s, x, ea, rowptr, col, perm, beta_dev, (long long)n_dst, h, out, lse); break; \
+        case 32: hipLaunchKernelGGL((softmax_agg_fwd_kernel<32, ACTC>), dim3(sm_grid(n_dst)), dim3(SM_THREADS), 0, s, x, ea, rowptr, col, perm, beta_dev, (long long)n_dst, h, out, lse); break; \
+        default: hipLaunchKernelGGL((softmax_agg_fwd_kernel<64, ACTC>), dim3(sm_grid(n_dst)), dim3(SM_THREADS), 0, s, x, ea, rowptr, col, perm, beta_dev, (long long)n_dst, h, out, lse); break; \
+    }
+    PHC_SM_ACT(act, PHC_SM_FWD)
+#undef PHC_SM_FWD
+    return check_launch("aggregate_softmax_fwd");
+}
+
+int phc_aggregate_softmax_bwd(const float *dout, const float *out, const float *lse, const float *x, const float *ea,
+                              const float *beta_dev, const int32_t *rowptr_t, const int32_t *col_t, const int32_t *perm_t,
+                              int64_t n_src, int h, int act, float *dx, float *dea, float *dbeta_partial, void *stream) {
+    PHC_REQUIRE(n_src >= 0 && h >= 1, PHC_ERR_INVALID_ARG, "phc_aggregate_softmax_bwd: bad sizes");
+    PHC_REQUIRE(act >= PHC_ACT_IDENTITY && act <= PHC_ACT_SELU, PHC_ERR_INVALID_ARG, "phc_aggregate_softmax_bwd: unknown activation %d", act);
+    if (n_src == 0) return PHC_OK;
+    PHC_REQUIRE(dout && out && lse && x && beta_dev && rowptr_t && col_t && perm_t && dx && dbeta_partial, PHC_ERR_INVALID_ARG,
+                "phc_aggregate_softmax_bwd: null pointer");
+    PHC_REQUIRE(h % 4 == 0 && sm_al16(x) && sm_al16(dout) && sm_al16(dx) && (!ea || sm_al16(ea)) && (!dea || sm_al16(dea)),
+                PHC_ERR_UNSUPPORTED, "phc_aggregate_softmax_bwd: needs h %% 4 == 0 and 16-byte aligned rows");
+    hipStream_t s = (hipStream_t)stream;
+    const int lpr = sm_lpr(h >> 2);
+    ProfScope prof(K_SOFTMAX_BWD, s);
+#define PHC_SM_BWD(ACTC)                                                                                                 \
+    switch (lpr) {                                                                                                       \
+        case 8: hipLaunchKernelGGL((softmax_agg_bwd_kernel<8, ACTC>), dim3(sm_grid(n_src)), dim3(SM_THREADS), 0, s, dout, out, lse, x, ea, beta_dev, rowptr_t, col_t, perm_t, (long long)n_src, h, dx, dea, dbeta_partial); break;   \
+        case 16: hipLaunchKernelGGL((softmax_agg_bwd_kernel<16, ACTC>), dim3(sm_grid(n_src)), dim3(SM_THREADS), 0, s, dout, out, lse, x, ea, beta_dev, rowptr_t, col_t, perm_t, (long long)n_src, h, dx, dea, dbeta_partial); break; \
+        case 32: hipLaunchKernelGGL((softmax_agg_bwd_kernel<32, ACTC>), dim3(sm_grid(n_src)), dim3(SM_THREADS), 0, s, dout, out, lse, x, ea, beta_dev, rowptr_t, col_t, perm_t, (long long)n_src, h, dx, dea, dbeta_partial); break; \
+        default: hipLaunchKernelGGL((softmax_agg_bwd_kernel<64, ACTC>), dim3(sm_grid(n_src)), dim3(SM_THREADS), 0, s, dout, out, lse, x, ea, beta_dev, rowptr_t, col_t, perm_t, (long long)n_src, h, dx, dea, dbeta_partial); break; \
+    }
+    PHC_SM_ACT(act, PHC_SM_BWD)
+#undef PHC_SM_BWD
+    return check_launch("aggregate_softmax_bwd");
+}
+
+}  // extern "C"

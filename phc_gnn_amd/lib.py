@@ -42,6 +42,9 @@ SIGNATURES = {
     "phc_aggregate_fwd": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P]),
     "phc_aggregate_bwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _L, _I, _I, _I, _P, _P, _P]),
     "phc_gather_rows_i64": (_I, [_P, _P, _L, _I, _P, _P]),
+    "phc_aggregate_softmax_fwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P]),
+    "phc_softmax_bwd_num_partials": (_I, [_L]),
+    "phc_aggregate_softmax_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _P]),
     "phc_encode_fwd": (_I, [_P, _P, _L, _I, _I, _I, _P, _P]),
     "phc_encode_bwd_ws_bytes": (_S, [_L, _I, _P, _I, _I]),
     "phc_encode_bwd": (_I, [_P, _P, _L, _I, _P, _I, _I, _P, _P, _S, _P]),

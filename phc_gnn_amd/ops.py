@@ -219,6 +219,65 @@ def aggregate_sum(x: torch.Tensor, edge_index, edge_attr: Optional[torch.Tensor]
 
 
 # ---------------------------------------------------------------------------
+# softmax neighbour aggregation
+# ---------------------------------------------------------------------------
+class _AggregateSoftmaxFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, ea, beta, st: EdgeStructure, act: int):
+        lib = L.load()
+        dev = L.require_device(x, ea, beta)
+        x_, ea_ = L.f32c(x), L.f32c(ea)
+        beta_ = L.f32c(beta.reshape(1))
+        h = x_.shape[1]
+        if ea_ is not None and tuple(ea_.shape) != (st.num_edges, h):
+            raise L.PhcError(f"edge_attr must be [{st.num_edges}, {h}], got {tuple(ea_.shape)}")
+        rowptr, col, perm = st.csr
+        out = torch.empty((st.num_dst, h), dtype=torch.float32, device=dev)
+        lse = torch.empty((st.num_dst, h), dtype=torch.float32, device=dev)
+        L.check(lib.phc_aggregate_softmax_fwd(L.ptr(x_), L.ptr(ea_), L.ptr(rowptr), L.ptr(col), L.ptr(perm), L.ptr(beta_),
+                                              st.num_dst, h, act, L.ptr(out), L.ptr(lse), L.stream_ptr(dev)),
+                "phc_aggregate_softmax_fwd")
+        if L.PROF_ON:
+            E, N = st.num_edges, st.num_dst
+            L.account("aggregate_softmax_fwd", 8.0 * E * h, E * (4.0 * h * (2 if ea is not None else 1) + 8) + N * 8.0 * h)
+        ctx.st, ctx.act, ctx.has_ea = st, act, ea is not None
+        ctx.save_for_backward(x_, ea_ if ea is not None else x_.new_empty(0), beta_, out, lse)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = L.load()
+        st: EdgeStructure = ctx.st
+        x_, ea_, beta_, out, lse = ctx.saved_tensors
+        ea_ = ea_ if ctx.has_ea else None
+        dout_ = L.f32c(dout)
+        dev = dout_.device
+        h = dout_.shape[1]
+        rowptr_t, col_t, perm_t = st.csc
+        dx = torch.empty((st.num_src, h), dtype=torch.float32, device=dev)
+        need_ea = ctx.needs_input_grad[1] and ctx.has_ea
+        dea = torch.empty((st.num_edges, h), dtype=torch.float32, device=dev) if need_ea else None
+        nparts = lib.phc_softmax_bwd_num_partials(st.num_src)
+        parts = torch.empty(nparts, dtype=torch.float32, device=dev)
+        L.check(lib.phc_aggregate_softmax_bwd(L.ptr(dout_), L.ptr(out), L.ptr(lse), L.ptr(x_), L.ptr(ea_), L.ptr(beta_),
+                                              L.ptr(rowptr_t), L.ptr(col_t), L.ptr(perm_t), st.num_src, h, ctx.act, L.ptr(dx),
+                                              L.ptr(dea), L.ptr(parts), L.stream_ptr(dev)), "phc_aggregate_softmax_bwd")
+        if L.PROF_ON:
+            E, N = st.num_edges, st.num_src
+            L.account("aggregate_softmax_bwd", 12.0 * E * h, E * (4.0 * h * (5 if need_ea else 4) + 8) + N * 8.0 * h)
+        dbeta = parts.sum().reshape(()) if ctx.needs_input_grad[2] else None
+        return (dx if ctx.needs_input_grad[0] else None), dea, dbeta, None, None
+
+
+def aggregate_softmax(x: torch.Tensor, edge_index, edge_attr: Optional[torch.Tensor], beta: torch.Tensor,
+                      msg_encoder: str = "identity", num_dst: Optional[int] = None) -> torch.Tensor:
+    """out[i] = Σ_e softmax_e(β·m_e)·m_e over the in-edges of i, per feature column, m_e = φ(x[src_e] + edge_attr[e])
+    (messagepassing.py:211-214 semantics; empty neighbourhoods give 0)."""
+    st = edge_index if isinstance(edge_index, EdgeStructure) else edge_structure(edge_index, x.shape[0], num_dst)
+    return _AggregateSoftmaxFn.apply(x, edge_attr, beta, st, _act_id(msg_encoder))
+
+
+# ---------------------------------------------------------------------------
 # read-out: per-graph sum
 # ---------------------------------------------------------------------------
 class _SegmentSumFn(torch.autograd.Function):

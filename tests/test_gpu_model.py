@@ -300,3 +300,29 @@ def test_graphed_data_parallel_step_single_rank(rccl_single_rank):
     for k, v in results[0][1].items():
         if v.is_floating_point():
             assert_close(results[1][1][k], v, 1e-5, k)
+
+
+def test_g5b_softmax_conv_layers():
+    from phc.hypercomplex.undirectional.messagepassing import PHMMessagePassing
+    z = load("g5b_softmax_convs")
+    for ci in range(int(z["num_cases"])):
+        c = case(z, ci)
+        n, h, mlp = [int(v) for v in c["meta"]]
+        conv = PHMMessagePassing(h, h, phm_dim=n, phm_rule=None, norm="naive-batch-norm" if mlp else None, aggr="softmax",
+                                 mlp=bool(mlp), msg_encoder=str(c["msg_encoder"]), initial_beta=1.0, learn_beta=True)
+        _load_sd(conv, sub(c, "sd::"))
+        conv.to(DEV).train()
+        x = c["x"].to(DEV).requires_grad_()
+        ea = c["edge_attr"].to(DEV).requires_grad_()
+        y = conv(x, c["edge_index"].to(DEV), ea)
+        assert_close(y, c["y"], 2e-5, f"softmax conv {ci} y")
+        names = list(sub(c, "grad::").keys())
+        params = dict(conv.named_parameters())
+        grads = torch.autograd.grad(y, [x, ea] + [params[k] for k in names], c["dy"].to(DEV))
+        assert_close(grads[0], c["dx"], 3e-5, f"softmax conv {ci} dx")
+        assert_close(grads[1], c["dea"], 3e-5, f"softmax conv {ci} dea")
+        for k, g in zip(names, grads[2:]):
+            ref = c["grad::" + k]
+            if float(ref.abs().max()) < 1e-5:
+                continue
+            assert_close(g, ref, 1e-4, f"softmax conv {ci} grad {k}")

@@ -379,3 +379,29 @@ def test_dense_linear_on_phm_kernels(ops):
     gg = torch.autograd.grad(out, [xd, lind.weight, lind.bias], dy.to(DEV))
     for a, r in zip(gg, rg):
         assert_close(a, r, TOL)
+
+
+# ---- softmax aggregation ----------------------------------------------------------
+@pytest.mark.parametrize("act", ["identity", "relu", "swish"])
+@pytest.mark.parametrize("h", [128, 32, 200])
+def test_aggregate_softmax_matches_oracle(ops, act, h):
+    from oracle import phc_oracle as O
+    from phc_gnn_amd import synth
+    g = torch.Generator().manual_seed(h + len(act))
+    ei = torch.from_numpy(synth.ragged_edges(150, seed=4, hub_degree=200))
+    E, N = ei.shape[1], 150
+    x = torch.randn(N, h, generator=g)
+    ea = torch.randn(E, h, generator=g)
+    dy = torch.randn(N, h, generator=g)
+    for beta0 in (1.0, 0.3, 2.5):
+        xr, er, br = x.clone().requires_grad_(), ea.clone().requires_grad_(), torch.tensor(beta0, requires_grad=True)
+        ref = O.softmax_aggregate(xr, ei, er, br, act)
+        rg = torch.autograd.grad(ref, [xr, er, br], dy)
+        xd, ed = x.to(DEV).requires_grad_(), ea.to(DEV).requires_grad_()
+        bd = torch.tensor(beta0, device=DEV, requires_grad=True)
+        out = ops.aggregate_softmax(xd, ei.to(DEV), ed, bd, act)
+        assert_close(out, ref, 2e-5, f"softmax fwd {act} beta={beta0}")
+        gg = torch.autograd.grad(out, [xd, ed, bd], dy.to(DEV))
+        assert_close(gg[0], rg[0], 3e-5, "softmax dx")
+        assert_close(gg[1], rg[1], 3e-5, "softmax dea")
+        assert_close(gg[2], rg[2], 1e-4, "softmax dbeta")
