@@ -36,7 +36,30 @@ import torch  # noqa: E402
 
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s HBM3E
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
-MFMA_KERNELS = ("phm_gemm_fwd", "phm_gemm_dx", "phm_dH_partial")
+MFMA_KERNELS = ("phm_gemm_fwd", "phm_gemm_dx", "phm_dH_partial", "table_grad")
+# launch-profiler kernel name -> substring of the rocprofv3 kernel name in profiles/r01_pmc_traffic.json
+PMC_NAMES = {"phm_gemm_fwd": "phm_stream_kernel<0, 4", "phm_gemm_dx": "phm_stream_kernel<1, 4",
+             "phm_dH_partial": "phm_dH_partial_kernel", "aggregate_enc_fwd": "aggregate_enc_fwd_kernel",
+             "aggregate_enc_dx": "aggregate_enc_dx_kernel", "aggregate_fwd": "aggregate_fwd_kernel",
+             "bn_apply": "bn_apply_kernel", "bn_bwd_apply": "bn_bwd_apply_kernel", "bn_bwd_partial": "bn_bwd_partial_kernel",
+             "bn_stats_partial": "bn_stats_partial_kernel", "table_grad": "table_grad_mfma_kernel<1"}
+
+
+def pmc_traffic(kernel: str):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
+    MI355X_MICROARCH.md §HBM), or None.  Collected with scripts/rocprof_pmc.sh on the same workload."""
+    path = os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")
+    pat = PMC_NAMES.get(kernel)
+    if pat is None or not os.path.exists(path):
+        return None
+    try:
+        table = json.load(open(path))
+    except Exception:
+        return None
+    for name, rec in table.items():
+        if pat in name:
+            return rec.get("hbm_bytes_per_launch")
+    return None
 
 
 def parse_args():
@@ -218,7 +241,7 @@ def main():
                 achieved = wk["bytes"] / (t_ms * 1e-3) / 1e9
                 roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": round(achieved / PEAK_HBM_GBS, 4)}
-            roof.update({"traffic": None, "kernel": name, "launches": n_launch,
+            roof.update({"traffic": pmc_traffic(name), "kernel": name, "launches": n_launch,
                          "avg_launch_us": round(1e3 * t_ms / max(n_launch, 1), 3),
                          "engine_kernels_us_per_step": {k: round(1e3 * v["total_ms"] / args.profile_steps, 2)
                                                         for k, v in sorted(times.items())}})
