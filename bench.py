@@ -32,6 +32,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+import phc_gnn_amd  # noqa: E402,F401  (sets the HIP runtime flags it needs before HIP initialises)
 import torch  # noqa: E402
 
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s HBM3E
@@ -183,7 +184,7 @@ def main():
 
     def run(n, offset=0, eager=False):
         for i in range(n):
-            j = (offset + i) % len(batches)
+            j = (offset + i) % len(host_batches)
             if graph_step is not None and not eager:
                 graph_step.step(padded[j])                      # D2D copy into the static buffers + one graph launch
             else:
@@ -194,14 +195,17 @@ def main():
             import torch.distributed as dist
             dist.barrier()
 
-    run(args.warmup)
-    barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    run(args.steps, offset=args.warmup)
-    torch.cuda.synchronize()
-    barrier()
-    dt = time.perf_counter() - t0
+    import contextlib
+    # graph mode: the loop runs on the step's replay stream (see GraphedTrainStep.step: never the null stream)
+    with (graph_step.on_stream() if graph_step is not None else contextlib.nullcontext()):
+        run(args.warmup)
+        barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        run(args.steps, offset=args.warmup)
+        torch.cuda.synchronize()
+        barrier()
+        dt = time.perf_counter() - t0
     if world > 1:
         import torch.distributed as dist
         t = torch.tensor([dt], device=dev, dtype=torch.float64)

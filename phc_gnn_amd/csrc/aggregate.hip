@@ -253,14 +253,14 @@ int phc_aggregate_fwd(const float *x, const float *ea, const int32_t *rowptr, co
         const int lpr = pick_lpr(h >> 2);
         PHC_DISPATCH_ACT(act, PHC_DISPATCH_LPR(lpr, {
             if (ea)
-                hipLaunchKernelGGL((aggregate_fwd_kernel<LPR, ACT, true>), dim3(grid), dim3(AGG_THREADS), 0, s, x, ea, rowptr,
+                PHC_LAUNCH((aggregate_fwd_kernel<LPR, ACT, true>), dim3(grid), dim3(AGG_THREADS), 0, s, x, ea, rowptr,
                                    col, perm, (long long)n_dst, h, add_self, out);
             else
-                hipLaunchKernelGGL((aggregate_fwd_kernel<LPR, ACT, false>), dim3(grid), dim3(AGG_THREADS), 0, s, x, ea, rowptr,
+                PHC_LAUNCH((aggregate_fwd_kernel<LPR, ACT, false>), dim3(grid), dim3(AGG_THREADS), 0, s, x, ea, rowptr,
                                    col, perm, (long long)n_dst, h, add_self, out);
         }));
     } else {
-        PHC_DISPATCH_ACT(act, hipLaunchKernelGGL((aggregate_fwd_scalar_kernel<ACT>), dim3(grid), dim3(AGG_THREADS), 0, s, x, ea,
+        PHC_DISPATCH_ACT(act, PHC_LAUNCH((aggregate_fwd_scalar_kernel<ACT>), dim3(grid), dim3(AGG_THREADS), 0, s, x, ea,
                                                  rowptr, col, perm, (long long)n_dst, h, add_self, out));
     }
     return check_launch("aggregate_fwd");
@@ -284,14 +284,14 @@ int phc_aggregate_bwd(const float *dout, const float *x, const float *ea, const 
         const int lpr = pick_lpr(h >> 2);
         PHC_DISPATCH_ACT(act, PHC_DISPATCH_LPR(lpr, {
             if (ea)
-                hipLaunchKernelGGL((aggregate_bwd_kernel<LPR, ACT, true>), dim3(grid), dim3(AGG_THREADS), 0, s, dout, x, ea,
+                PHC_LAUNCH((aggregate_bwd_kernel<LPR, ACT, true>), dim3(grid), dim3(AGG_THREADS), 0, s, dout, x, ea,
                                    rowptr_t, col_t, perm_t, (long long)n_src, (long long)n_dst, h, add_self, dx, dea);
             else
-                hipLaunchKernelGGL((aggregate_bwd_kernel<LPR, ACT, false>), dim3(grid), dim3(AGG_THREADS), 0, s, dout, x, ea,
+                PHC_LAUNCH((aggregate_bwd_kernel<LPR, ACT, false>), dim3(grid), dim3(AGG_THREADS), 0, s, dout, x, ea,
                                    rowptr_t, col_t, perm_t, (long long)n_src, (long long)n_dst, h, add_self, dx, dea);
         }));
     } else {
-        PHC_DISPATCH_ACT(act, hipLaunchKernelGGL((aggregate_bwd_scalar_kernel<ACT>), dim3(grid), dim3(AGG_THREADS), 0, s, dout, x,
+        PHC_DISPATCH_ACT(act, PHC_LAUNCH((aggregate_bwd_scalar_kernel<ACT>), dim3(grid), dim3(AGG_THREADS), 0, s, dout, x,
                                                  ea, rowptr_t, col_t, perm_t, (long long)n_src, (long long)n_dst, h, add_self, dx,
                                                  dea));
     }
@@ -305,7 +305,7 @@ int phc_gather_rows_i64(const float *src, const int64_t *idx_i64, int64_t n_rows
     hipStream_t s = (hipStream_t)stream;
     const int vec4 = (h % 4 == 0) && aligned16(src) && aligned16(out);
     ProfScope prof(K_GATHER_ROWS, s);
-    hipLaunchKernelGGL(gather_rows_kernel, dim3(agg_grid(n_rows)), dim3(AGG_THREADS), 0, s, src,
+    PHC_LAUNCH(gather_rows_kernel, dim3(agg_grid(n_rows)), dim3(AGG_THREADS), 0, s, src,
                        reinterpret_cast<const long long *>(idx_i64), (long long)n_rows, h, vec4, out);
     return check_launch("gather_rows");
 }

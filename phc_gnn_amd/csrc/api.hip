@@ -7,6 +7,7 @@
 #include <vector>
 
 #include "phc_common.h"
+#include <string>
 
 namespace phc {
 
@@ -29,6 +30,29 @@ static const char *const kKernelNames[K_NUM_KERNELS] = {
 
 // ---- profiler ------------------------------------------------------------------
 bool g_prof_on = false;
+bool g_ablate[K_NUM_KERNELS] = {};
+thread_local bool tl_ablate = false;
+
+// PHC_ABLATE is read once, when the library is loaded
+static const bool g_ablate_init = [] {
+    const char *env = getenv("PHC_ABLATE");
+    if (!env) return false;
+    std::string list(env);
+    size_t pos = 0;
+    while (pos <= list.size()) {
+        size_t comma = list.find(',', pos);
+        if (comma == std::string::npos) comma = list.size();
+        const std::string name = list.substr(pos, comma - pos);
+        for (int k = 0; k < K_NUM_KERNELS; ++k)
+            if (name == kKernelNames[k]) {
+                g_ablate[k] = true;
+                fprintf(stderr, "[libphc_hip] PHC_ABLATE: launches of '%s' are DROPPED (timing experiment, results invalid)\n",
+                        kKernelNames[k]);
+            }
+        pos = comma + 1;
+    }
+    return true;
+}();
 
 struct ProfSlot {
     hipEvent_t start, stop;

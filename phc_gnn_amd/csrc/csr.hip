@@ -151,7 +151,7 @@ int phc_segment_ptr_sorted(const int64_t *key_i64, int64_t n, int64_t num_keys, 
     PHC_REQUIRE(rowptr && (n == 0 || key_i64), PHC_ERR_INVALID_ARG, "phc_segment_ptr_sorted: null pointer");
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(K_CSR_SCAN, s);
-    hipLaunchKernelGGL(sorted_segment_ptr_kernel, dim3((unsigned)((num_keys + 1 + 255) / 256)), dim3(256), 0, s,
+    PHC_LAUNCH(sorted_segment_ptr_kernel, dim3((unsigned)((num_keys + 1 + 255) / 256)), dim3(256), 0, s,
                        reinterpret_cast<const long long *>(key_i64), (long long)n, (long long)num_keys, rowptr);
     return check_launch("sorted_segment_ptr");
 }
@@ -180,7 +180,7 @@ int phc_csr_build(const int64_t *key_i64, const int64_t *other_i64, int64_t E, i
     const unsigned egrid = (unsigned)((E + 255) / 256 > 8192 ? 8192 : (E + 255) / 256);
     if (E > 0) {
         ProfScope prof(K_CSR_HIST, s);
-        hipLaunchKernelGGL(csr_hist_kernel, dim3(egrid), dim3(256), 0, s, reinterpret_cast<const long long *>(key_i64),
+        PHC_LAUNCH(csr_hist_kernel, dim3(egrid), dim3(256), 0, s, reinterpret_cast<const long long *>(key_i64),
                            (long long)E, rowptr);
         int rc = check_launch("csr_hist");
         if (rc) return rc;
@@ -199,10 +199,10 @@ int phc_csr_build(const int64_t *key_i64, const int64_t *other_i64, int64_t E, i
             }
         }
         for (int l = 0; l < L.levels; ++l)
-            hipLaunchKernelGGL(scan_block_kernel, dim3((unsigned)L.blocks[l]), dim3(SCAN_THREADS), 0, s, level_data[l],
+            PHC_LAUNCH(scan_block_kernel, dim3((unsigned)L.blocks[l]), dim3(SCAN_THREADS), 0, s, level_data[l],
                                level_sums[l], L.n[l]);
         for (int l = L.levels - 2; l >= 0; --l)
-            hipLaunchKernelGGL(scan_add_kernel, dim3((unsigned)L.blocks[l]), dim3(SCAN_THREADS), 0, s, level_data[l],
+            PHC_LAUNCH(scan_add_kernel, dim3((unsigned)L.blocks[l]), dim3(SCAN_THREADS), 0, s, level_data[l],
                                level_sums[l], L.n[l]);
         int rc = check_launch("csr_scan");
         if (rc) return rc;
@@ -210,7 +210,7 @@ int phc_csr_build(const int64_t *key_i64, const int64_t *other_i64, int64_t E, i
     if (E == 0) return PHC_OK;
     {
         ProfScope prof(K_CSR_FILL, s);
-        hipLaunchKernelGGL(csr_fill_kernel, dim3(egrid), dim3(256), 0, s, reinterpret_cast<const long long *>(key_i64),
+        PHC_LAUNCH(csr_fill_kernel, dim3(egrid), dim3(256), 0, s, reinterpret_cast<const long long *>(key_i64),
                            (long long)E, rowptr, cursor, tmp_perm);
         int rc = check_launch("csr_fill");
         if (rc) return rc;
@@ -219,11 +219,11 @@ int phc_csr_build(const int64_t *key_i64, const int64_t *other_i64, int64_t E, i
         ProfScope prof(K_CSR_CANON, s);
         const long long groups8 = (num_keys + 31) / 32;        // 256 threads = 32 rows of 8 lanes
         unsigned g8 = (unsigned)(groups8 > 16384 ? 16384 : (groups8 < 1 ? 1 : groups8));
-        hipLaunchKernelGGL((csr_canon_kernel<8>), dim3(g8), dim3(256), 0, s, rowptr, tmp_perm,
+        PHC_LAUNCH((csr_canon_kernel<8>), dim3(g8), dim3(256), 0, s, rowptr, tmp_perm,
                            reinterpret_cast<const long long *>(other_i64), (long long)num_keys, 0, 64, perm, col);
         const long long groups64 = (num_keys + 3) / 4;
         unsigned g64 = (unsigned)(groups64 > 8192 ? 8192 : (groups64 < 1 ? 1 : groups64));
-        hipLaunchKernelGGL((csr_canon_kernel<64>), dim3(g64), dim3(256), 0, s, rowptr, tmp_perm,
+        PHC_LAUNCH((csr_canon_kernel<64>), dim3(g64), dim3(256), 0, s, rowptr, tmp_perm,
                            reinterpret_cast<const long long *>(other_i64), (long long)num_keys, 64, 0x7fffffff, perm, col);
         int rc = check_launch("csr_canon");
         if (rc) return rc;

@@ -447,7 +447,7 @@ static int launch_table_grad(const float *dout, const long long *idx, const EncM
     float *slabs = static_cast<float *>(ws);
     dim3 grid(p.tiles_i * p.tiles_j, p.num_slabs);
 #define PHC_TG_LAUNCH(ACTC)                                                                                               \
-    hipLaunchKernelGGL((table_grad_mfma_kernel<MODE, ACTC>), grid, dim3(ENC_THREADS), 0, s, dout, idx, m, n_items,          \
+    PHC_LAUNCH((table_grad_mfma_kernel<MODE, ACTC>), grid, dim3(ENC_THREADS), 0, s, dout, idx, m, n_items,          \
                        p.items_per_split, h, p.tiles_j, src, dst, x, tables, n, k, vec4, slabs)
     {
         ProfScope prof(K_TABLE_GRAD, s);
@@ -467,7 +467,7 @@ static int launch_table_grad(const float *dout, const long long *idx, const EncM
     }
 #undef PHC_TG_LAUNCH
     ProfScope prof(K_TABLE_GRAD_REDUCE, s);
-    hipLaunchKernelGGL(table_grad_reduce_kernel, dim3((m.R * h + 63) / 64), dim3(256), 0, s, slabs, p.num_slabs, m.R, n, k,
+    PHC_LAUNCH(table_grad_reduce_kernel, dim3((m.R * h + 63) / 64), dim3(256), 0, s, slabs, p.num_slabs, m.R, n, k,
                        flat);
     return check_launch(who);
 }
@@ -494,15 +494,15 @@ int phc_encode_fwd(const int64_t *idx_i64, const float *const *tables, int64_t N
         if (blocks > 4096) blocks = 4096;
         const long long *idx = reinterpret_cast<const long long *>(idx_i64);
         switch (lpr) {
-            case 8: hipLaunchKernelGGL((encode_fwd_kernel<8>), dim3((unsigned)blocks), dim3(ENC_THREADS), 0, s, idx, tables, (long long)N, F, n, k, out); break;
-            case 16: hipLaunchKernelGGL((encode_fwd_kernel<16>), dim3((unsigned)blocks), dim3(ENC_THREADS), 0, s, idx, tables, (long long)N, F, n, k, out); break;
-            case 32: hipLaunchKernelGGL((encode_fwd_kernel<32>), dim3((unsigned)blocks), dim3(ENC_THREADS), 0, s, idx, tables, (long long)N, F, n, k, out); break;
-            default: hipLaunchKernelGGL((encode_fwd_kernel<64>), dim3((unsigned)blocks), dim3(ENC_THREADS), 0, s, idx, tables, (long long)N, F, n, k, out); break;
+            case 8: PHC_LAUNCH((encode_fwd_kernel<8>), dim3((unsigned)blocks), dim3(ENC_THREADS), 0, s, idx, tables, (long long)N, F, n, k, out); break;
+            case 16: PHC_LAUNCH((encode_fwd_kernel<16>), dim3((unsigned)blocks), dim3(ENC_THREADS), 0, s, idx, tables, (long long)N, F, n, k, out); break;
+            case 32: PHC_LAUNCH((encode_fwd_kernel<32>), dim3((unsigned)blocks), dim3(ENC_THREADS), 0, s, idx, tables, (long long)N, F, n, k, out); break;
+            default: PHC_LAUNCH((encode_fwd_kernel<64>), dim3((unsigned)blocks), dim3(ENC_THREADS), 0, s, idx, tables, (long long)N, F, n, k, out); break;
         }
     } else {
         long long blocks = (N * h + ENC_THREADS - 1) / ENC_THREADS;
         if (blocks > 4096) blocks = 4096;
-        hipLaunchKernelGGL(encode_fwd_scalar_kernel, dim3((unsigned)blocks), dim3(ENC_THREADS), 0, s,
+        PHC_LAUNCH(encode_fwd_scalar_kernel, dim3((unsigned)blocks), dim3(ENC_THREADS), 0, s,
                            reinterpret_cast<const long long *>(idx_i64), tables, (long long)N, F, n, k, out);
     }
     return check_launch("encode_fwd");
@@ -546,7 +546,7 @@ int phc_aggregate_enc_fwd(const float *x, const int64_t *bond_i64, const float *
     const int lpr = lpr_for(h >> 2);
     ProfScope prof(K_AGG_ENC_FWD, s);
 #define PHC_AE_LAUNCH(LPRC, ACTC)                                                                                          \
-    hipLaunchKernelGGL((aggregate_enc_fwd_kernel<LPRC, ACTC>), dim3((unsigned)blocks), dim3(ENC_THREADS), lds, s, x, bond,      \
+    PHC_LAUNCH((aggregate_enc_fwd_kernel<LPRC, ACTC>), dim3((unsigned)blocks), dim3(ENC_THREADS), lds, s, x, bond,      \
                        tables, m, rowptr, col, perm, (long long)n_dst, n, k, add_self, out)
 #define PHC_AE_ACT(LPRC)                                            \
     switch (act) {                                                  \
@@ -580,7 +580,7 @@ int phc_pack_edge_codes(const int64_t *bond_i64, const int32_t *perm, const int3
     long long blocks = (E + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     ProfScope prof(K_PACK_CODES, s);
-    hipLaunchKernelGGL(pack_edge_codes_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const long long *>(bond_i64),
+    PHC_LAUNCH(pack_edge_codes_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const long long *>(bond_i64),
                        perm, m, (long long)E, codes);
     return check_launch("pack_edge_codes");
 }
@@ -607,7 +607,7 @@ int phc_aggregate_encp_fwd(const float *x, const uint32_t *codes, const float *c
     const int lpr = lpr_for(h >> 2);
     ProfScope prof(K_AGG_ENC_FWD, s);
 #define PHC_AP_LAUNCH(LPRC, ACTC, FC)                                                                                     \
-    hipLaunchKernelGGL((aggregate_encp_fwd_kernel<LPRC, ACTC, FC>), dim3((unsigned)blocks), dim3(ENC_THREADS), lds, s, x, codes, \
+    PHC_LAUNCH((aggregate_encp_fwd_kernel<LPRC, ACTC, FC>), dim3((unsigned)blocks), dim3(ENC_THREADS), lds, s, x, codes, \
                        tables, m, rowptr, col, (long long)n_dst, n, k, add_self, out)
 #define PHC_AP_F(LPRC, ACTC)                                    \
     switch (F) {                                                \
@@ -670,7 +670,7 @@ int phc_aggregate_enc_bwd(const float *dout, const float *x, const int64_t *bond
         const int lpr = lpr_for(h >> 2);
         ProfScope prof(K_AGG_ENC_DX, s);
 #define PHC_AD_LAUNCH(LPRC, ACTC)                                                                                         \
-    hipLaunchKernelGGL((aggregate_enc_dx_kernel<LPRC, ACTC>), dim3((unsigned)blocks), dim3(ENC_THREADS), lds, s, dout, x, bond, \
+    PHC_LAUNCH((aggregate_enc_dx_kernel<LPRC, ACTC>), dim3((unsigned)blocks), dim3(ENC_THREADS), lds, s, dout, x, bond, \
                        tables, m, rowptr_t, col_t, perm_t, (long long)n_src, (long long)n_dst, n, k, add_self, dx)
 #define PHC_AD_ACT(LPRC)                                            \
     switch (act) {                                                  \

@@ -145,24 +145,37 @@ __global__ __launch_bounds__(BN_THREADS) void bn_finalize_kernel(BnParams p, con
     const float cnt = (float)max(count, 1LL);
     float mean = 0.f, invstd = 1.f;
     if (training) {
+        // every partial this lane owns is loaded before anything is consumed: one memory latency, not sixteen
+        constexpr int PER_LANE = BN_MAX_PARTIALS / 32;
+        float ps[PER_LANE], pm[PER_LANE];
+#pragma unroll
+        for (int t = 0; t < PER_LANE; ++t) {
+            const int b = pl + 32 * t;
+            const bool ok = c < h && b < num_partials;
+            const size_t off = (size_t)(ok ? b : 0) * 2 * h + (c < h ? c : 0);
+            const float a = partial[off], m2v = partial[off + h];
+            ps[t] = ok ? a : 0.f;
+            pm[t] = ok ? m2v : 0.f;
+        }
         float s = 0.f;
-        if (c < h)
-            for (int b = pl; b < num_partials; b += 32) s += partial[(size_t)b * 2 * h + c];
+#pragma unroll
+        for (int t = 0; t < PER_LANE; ++t) s += ps[t];
         r_sum[pl][ci] = s;
         __syncthreads();
         float tot = 0.f;
         for (int l = 0; l < 32; ++l) tot += r_sum[l][ci];
         mean = tot / cnt;
         float m2 = 0.f;
-        if (c < h)
-            for (int b = pl; b < num_partials; b += 32) {
-                const long long nb_i = min(rows_per_block, max(count - (long long)b * rows_per_block, 0LL));
-                if (nb_i > 0) {
-                    const float nb = (float)nb_i;
-                    const float d = partial[(size_t)b * 2 * h + c] / nb - mean;
-                    m2 += partial[(size_t)b * 2 * h + h + c] + nb * d * d;
-                }
+#pragma unroll
+        for (int t = 0; t < PER_LANE; ++t) {
+            const int b = pl + 32 * t;
+            const long long nb_i = min(rows_per_block, max(count - (long long)b * rows_per_block, 0LL));
+            if (c < h && b < num_partials && nb_i > 0) {
+                const float nb = (float)nb_i;
+                const float d = ps[t] / nb - mean;
+                m2 += pm[t] + nb * d * d;
             }
+        }
         r_m2[pl][ci] = m2;
         __syncthreads();
         if (pl == 0 && c < h) {
@@ -319,11 +332,24 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_finalize_kernel(const int *
     const int ci = tid & 7, pl = tid >> 3;
     const int c = blockIdx.x * 8 + ci;
     float sg = 0.f, sgx = 0.f;
-    if (c < h)
-        for (int b = pl; b < num_partials; b += 32) {
-            sg += partial[(size_t)b * 2 * h + c];
-            sgx += partial[(size_t)b * 2 * h + h + c];
+    {
+        constexpr int PER_LANE = BN_MAX_PARTIALS / 32;
+        float pa[PER_LANE], pb[PER_LANE];
+#pragma unroll
+        for (int t = 0; t < PER_LANE; ++t) {
+            const int b = pl + 32 * t;
+            const bool ok = c < h && b < num_partials;
+            const size_t off = (size_t)(ok ? b : 0) * 2 * h + (c < h ? c : 0);
+            const float a = partial[off], bb = partial[off + h];
+            pa[t] = ok ? a : 0.f;
+            pb[t] = ok ? bb : 0.f;
         }
+#pragma unroll
+        for (int t = 0; t < PER_LANE; ++t) {
+            sg += pa[t];
+            sgx += pb[t];
+        }
+    }
     r_a[pl][ci] = sg;
     r_b[pl][ci] = sgx;
     __syncthreads();
@@ -486,17 +512,17 @@ int phc_bn_fwd(const float *x, const float *const *weight, const float *const *b
     if (training) {
         ProfScope prof(K_BN_STATS, s);
         if (vec4)
-            hipLaunchKernelGGL((bn_stats_partial_kernel<4>), dim3(plan.num_partials), dim3(BN_THREADS), 0, s, x, n_valid_dev,
+            PHC_LAUNCH((bn_stats_partial_kernel<4>), dim3(plan.num_partials), dim3(BN_THREADS), 0, s, x, n_valid_dev,
                                (long long)N, h, plan.rows_per_block, partial);
         else
-            hipLaunchKernelGGL((bn_stats_partial_kernel<1>), dim3(plan.num_partials), dim3(BN_THREADS), 0, s, x, n_valid_dev,
+            PHC_LAUNCH((bn_stats_partial_kernel<1>), dim3(plan.num_partials), dim3(BN_THREADS), 0, s, x, n_valid_dev,
                                (long long)N, h, plan.rows_per_block, partial);
         rc = check_launch("bn_stats_partial");
         if (rc) return rc;
     }
     {
         ProfScope prof(K_BN_FINALIZE, s);
-        hipLaunchKernelGGL(bn_finalize_kernel, dim3((h + 7) / 8), dim3(BN_THREADS), 0, s, p, n_valid_dev, (long long)N, h, training,
+        PHC_LAUNCH(bn_finalize_kernel, dim3((h + 7) / 8), dim3(BN_THREADS), 0, s, p, n_valid_dev, (long long)N, h, training,
                            momentum, eps, partial, plan.num_partials, plan.rows_per_block, stat, save_mean, save_invstd);
         rc = check_launch("bn_finalize");
         if (rc) return rc;
@@ -504,7 +530,7 @@ int phc_bn_fwd(const float *x, const float *const *weight, const float *const *b
     const size_t lds = sizeof(float) * 2 * (size_t)h;
     ProfScope prof(K_BN_APPLY, s);
 #define PHC_BN_FWD(ACTC)                                                                                                      \
-    hipLaunchKernelGGL((bn_apply_kernel<ACTC>), dim3(apply_grid(N, h)), dim3(BN_THREADS), lds, s, x, n_valid_dev, (long long)N, h,   \
+    PHC_LAUNCH((bn_apply_kernel<ACTC>), dim3(apply_grid(N, h)), dim3(BN_THREADS), lds, s, x, n_valid_dev, (long long)N, h,   \
                        residual, stat, out)
     PHC_BN_ACT_SWITCH(act, PHC_BN_FWD)
 #undef PHC_BN_FWD
@@ -536,10 +562,10 @@ int phc_bn_bwd(const float *dy, const float *x, const float *const *weight, cons
         ProfScope prof(K_BN_BWD_PARTIAL, s);
 #define PHC_BN_BP(ACTC)                                                                                                      \
     if (vec4)                                                                                                                \
-        hipLaunchKernelGGL((bn_bwd_partial_kernel<ACTC, 4>), dim3(plan.num_partials), dim3(BN_THREADS), 0, s, dy, x, p, save_mean,  \
+        PHC_LAUNCH((bn_bwd_partial_kernel<ACTC, 4>), dim3(plan.num_partials), dim3(BN_THREADS), 0, s, dy, x, p, save_mean,  \
                            save_invstd, n_valid_dev, (long long)N, h, plan.rows_per_block, partial);                         \
     else                                                                                                                     \
-        hipLaunchKernelGGL((bn_bwd_partial_kernel<ACTC, 1>), dim3(plan.num_partials), dim3(BN_THREADS), 0, s, dy, x, p, save_mean,  \
+        PHC_LAUNCH((bn_bwd_partial_kernel<ACTC, 1>), dim3(plan.num_partials), dim3(BN_THREADS), 0, s, dy, x, p, save_mean,  \
                            save_invstd, n_valid_dev, (long long)N, h, plan.rows_per_block, partial)
         PHC_BN_ACT_SWITCH(act, PHC_BN_BP)
 #undef PHC_BN_BP
@@ -549,7 +575,7 @@ int phc_bn_bwd(const float *dy, const float *x, const float *const *weight, cons
     float *bstat = partial + 2 * (size_t)h * BN_MAX_PARTIALS;
     {
         ProfScope prof(K_BN_BWD_FINALIZE, s);
-        hipLaunchKernelGGL(bn_bwd_finalize_kernel, dim3((h + 7) / 8), dim3(BN_THREADS), 0, s, n_valid_dev, (long long)N, h, training,
+        PHC_LAUNCH(bn_bwd_finalize_kernel, dim3((h + 7) / 8), dim3(BN_THREADS), 0, s, n_valid_dev, (long long)N, h, training,
                            partial, plan.num_partials, dwb_flat, bstat);
         rc = check_launch("bn_bwd_finalize");
         if (rc) return rc;
@@ -558,7 +584,7 @@ int phc_bn_bwd(const float *dy, const float *x, const float *const *weight, cons
     const size_t lds = sizeof(float) * 6 * (size_t)h;
     ProfScope prof(K_BN_BWD_APPLY, s);
 #define PHC_BN_BA(ACTC)                                                                                                      \
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<ACTC>), dim3(apply_grid(N, h)), dim3(BN_THREADS), lds, s, dy, x, p, save_mean,          \
+    PHC_LAUNCH((bn_bwd_apply_kernel<ACTC>), dim3(apply_grid(N, h)), dim3(BN_THREADS), lds, s, dy, x, p, save_mean,          \
                        save_invstd, n_valid_dev, (long long)N, h, bstat, dx)
     PHC_BN_ACT_SWITCH(act, PHC_BN_BA)
 #undef PHC_BN_BA

@@ -57,16 +57,29 @@ extern bool g_prof_on;
 void prof_begin(int kid, hipStream_t s, int *slot);
 void prof_end(int slot, hipStream_t s);
 
+// Timing experiments only (results are WRONG): PHC_ABLATE=name[,name...] drops every launch of the named
+// kernels (names as in phc_prof_read), so "step time with - without" gives a kernel's real cost inside a
+// replayed hipGraph, where neither HIP events nor rocprofv3's serialised durations can be trusted.
+extern bool g_ablate[];
+extern thread_local bool tl_ablate;
+
 struct ProfScope {
     int slot = -1;
     hipStream_t s;
     ProfScope(int kid, hipStream_t stream) : s(stream) {
+        tl_ablate = g_ablate[kid];
         if (g_prof_on) prof_begin(kid, s, &slot);
     }
     ~ProfScope() {
         if (slot >= 0) prof_end(slot, s);
+        tl_ablate = false;
     }
 };
+
+#define PHC_LAUNCH(...)                                          \
+    do {                                                         \
+        if (!phc::tl_ablate) hipLaunchKernelGGL(__VA_ARGS__);    \
+    } while (0)
 
 inline int check_launch(const char *what) {
     hipError_t e = hipGetLastError();

@@ -647,7 +647,7 @@ static int launch_gemm_cfg(const float *X, const float *A, const float *W, const
                             hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((phm_gemm_kernel<TRANS, NPHM, BM, BN>), dim3(panels, (unsigned)gy), dim3(Cfg::THREADS), lds, s, X, A, W,
+    PHC_LAUNCH((phm_gemm_kernel<TRANS, NPHM, BM, BN>), dim3(panels, (unsigned)gy), dim3(Cfg::THREADS), lds, s, X, A, W,
                        bias, residual, out, (long long)M, K, Nout, n, kin, kout, vec4);
     return PHC_OK;
 }
@@ -672,7 +672,7 @@ static int launch_stream_cfg(const float *X, const float *A, const float *W, con
                             hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         attr_set = true;
     }
-    hipLaunchKernelGGL((phm_stream_kernel<TRANS, NPHM, BN, WAVES>), dim3(panels, (unsigned)gy), dim3(64 * WAVES), lds, s, X, A, W,
+    PHC_LAUNCH((phm_stream_kernel<TRANS, NPHM, BN, WAVES>), dim3(panels, (unsigned)gy), dim3(64 * WAVES), lds, s, X, A, W,
                        bias, residual, out, (long long)M, K, Nout, n, kin, kout, out_vec4);
     return PHC_OK;
 }
@@ -688,9 +688,14 @@ static int launch_gemm(const float *X, const float *A, const float *W, const flo
     const bool vec4 = (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
     const bool stream = vec4 && K <= 128 && !getenv("PHC_GEMM_TILED");
     const bool big = M >= GEMM_BIG_M && Nout > 64;
+    // molecule batches: 32-column panels give 4x the wavefronts of the 128-column config, each a quarter as long
+    // (measured on MI355X: no gain for y = x.H, slower for dx — kept as an opt-in experiment)
+    const bool small32 = M <= 24 * 1024 && Nout >= 64 && getenv("PHC_GEMM_32") != nullptr;
 #define PHC_GEMM_LAUNCH(NP)                                                                                              \
     if (stream && big)                                                                                                   \
         launch_stream_cfg<TRANS, NP, 128, 8>(X, A, W, bias, residual, out, M, K, Nout, n, kin, kout, 1, s);               \
+    else if (stream && small32)                                                                                          \
+        launch_stream_cfg<TRANS, NP, 32, 4>(X, A, W, bias, residual, out, M, K, Nout, n, kin, kout, 3, s);                \
     else if (stream)                                                                                                     \
         launch_stream_cfg<TRANS, NP, 64, 4>(X, A, W, bias, residual, out, M, K, Nout, n, kin, kout, 2, s);                \
     else if (big)                                                                                                        \
@@ -718,7 +723,8 @@ static DhPlan dh_plan(int64_t N, int in, int out) {
     p.tiles_i = (in + DH_T - 1) / DH_T;
     p.tiles_j = (out + DH_T - 1) / DH_T;
     const int tiles = p.tiles_i * p.tiles_j;
-    int64_t splits = (2 * 256 + tiles - 1) / tiles;             // ~2 workgroups per CU (fixed: plan must not depend on the device)
+    static const int target_blocks = getenv("PHC_DH_BLOCKS") ? atoi(getenv("PHC_DH_BLOCKS")) : 512;
+    int64_t splits = (target_blocks + tiles - 1) / tiles;       // ~2 workgroups per CU (fixed: plan must not depend on the device)
     const int64_t max_splits = (N + DH_RB - 1) / DH_RB;
     if (splits > max_splits) splits = max_splits;
     if (splits < 1) splits = 1;
@@ -747,7 +753,7 @@ int phc_phm_build_H(const float *A, const float *W, int n, int kin, int kout, fl
     int blocks = (int)((total + 255) / 256);
     if (blocks > 2048) blocks = 2048;
     ProfScope prof(K_PHM_BUILD_H, s);
-    hipLaunchKernelGGL(phm_build_H_kernel, dim3(blocks), dim3(256), sizeof(float) * n * n * n, s, A, W, H, n, kin, kout);
+    PHC_LAUNCH(phm_build_H_kernel, dim3(blocks), dim3(256), sizeof(float) * n * n * n, s, A, W, H, n, kin, kout);
     return check_launch("phm_build_H");
 }
 
@@ -766,6 +772,29 @@ size_t phc_phm_linear_bwd_ws_bytes(int64_t N, int n, int kin, int kout) {
     return sizeof(float) * p.slab_elems * ((size_t)p.splits + 1);
 }
 
+// Side stream + fork/join events so that the parameter-gradient chain (dH partial -> reduce -> contract) runs
+// CONCURRENTLY with the dx GEMM: at molecule scale neither fills the chip (a few hundred small workgroups each),
+// and under stream capture the fork/join becomes two parallel branches of the hipGraph.
+struct BwdOverlap {
+    hipStream_t side = nullptr;
+    hipEvent_t fork = nullptr, join = nullptr;
+    bool ok = false;
+};
+static BwdOverlap &bwd_overlap() {
+    static BwdOverlap o;
+    static bool init = false;
+    if (!init) {
+        init = true;
+        const char *env = getenv("PHC_BWD_OVERLAP");
+        if (env && env[0] == '1') {   // opt-in: on ROCm 7.2 the forked hipGraph branch costs more than the overlap saves at molecule scale
+            o.ok = hipStreamCreateWithFlags(&o.side, hipStreamNonBlocking) == hipSuccess &&
+                   hipEventCreateWithFlags(&o.fork, hipEventDisableTiming) == hipSuccess &&
+                   hipEventCreateWithFlags(&o.join, hipEventDisableTiming) == hipSuccess;
+        }
+    }
+    return o;
+}
+
 int phc_phm_linear_bwd(const float *x, const float *A, const float *W, const float *dy, int64_t N, int n, int kin, int kout,
                        float *dx, float *dW, float *dA, float *db, void *ws, size_t ws_bytes, void *stream) {
     int rc = check_phm_dims("phc_phm_linear_bwd", N, n, kin, kout);
@@ -773,44 +802,67 @@ int phc_phm_linear_bwd(const float *x, const float *A, const float *W, const flo
     PHC_REQUIRE(A && W && (N == 0 || (x && dy)), PHC_ERR_INVALID_ARG, "phc_phm_linear_bwd: null pointer");
     hipStream_t s = (hipStream_t)stream;
     const int in = n * kin, out = n * kout;
+    const bool want_params = dW || dA || db;
+    if (want_params) {
+        const size_t need = phc_phm_linear_bwd_ws_bytes(N, n, kin, kout);
+        PHC_REQUIRE(ws && ws_bytes >= need, PHC_ERR_WORKSPACE, "phc_phm_linear_bwd: workspace %zu B < required %zu B", ws_bytes,
+                    need);
+        PHC_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 15) == 0, PHC_ERR_WORKSPACE, "phc_phm_linear_bwd: workspace not 16-byte aligned");
+    }
+    // fork: the parameter-gradient chain goes to the side stream when there is a dx GEMM to overlap it with
+    BwdOverlap &ov = bwd_overlap();
+    const bool fork = ov.ok && dx && want_params && N > 0 && !g_prof_on;
+    hipStream_t sp = s;
+    if (fork) {
+        if (hipEventRecord(ov.fork, s) != hipSuccess || hipStreamWaitEvent(ov.side, ov.fork, 0) != hipSuccess) {
+            set_last_error("phc_phm_linear_bwd: fork failed");
+            return PHC_ERR_LAUNCH;
+        }
+        sp = ov.side;
+    }
+    if (want_params) {
+        DhPlan p = dh_plan(N, in, out);
+        float *slabs = static_cast<float *>(ws);
+        float *dH = slabs + p.slab_elems * (size_t)p.splits;
+        if (N == 0) {
+            hipMemsetAsync(dH, 0, sizeof(float) * p.slab_elems, sp);
+        } else {
+            const int vec4 = (in % 4 == 0) && (out % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
+                             ((reinterpret_cast<uintptr_t>(dy) & 15) == 0);
+            {
+                ProfScope prof(K_PHM_DH_PARTIAL, sp);
+                PHC_LAUNCH(phm_dH_partial_kernel, dim3(p.tiles_i * p.tiles_j, p.splits), dim3(256), 0, sp, x, dy, slabs,
+                                   (long long)N, in, out, p.tiles_j, (long long)p.rows_per_split, vec4);
+                rc = check_launch("phm_dH_partial");
+                if (rc) return rc;
+            }
+            {
+                ProfScope prof(K_PHM_DH_REDUCE, sp);
+                PHC_LAUNCH(phm_dH_reduce_kernel, dim3((unsigned)((p.slab_elems + 63) / 64)), dim3(256), 0, sp, slabs,
+                                   dH, p.slab_elems, p.splits);
+                rc = check_launch("phm_dH_reduce");
+                if (rc) return rc;
+            }
+        }
+        const int dA_blocks = n * n * n;
+        const int dW_blocks = (n * kin * kout + 255) / 256;
+        ProfScope prof(K_PHM_CONTRACT, sp);
+        PHC_LAUNCH(phm_contract_kernel, dim3(dA_blocks + dW_blocks), dim3(256), 0, sp, A, W, dH, dW, dA, db, n, kin, kout,
+                           dA_blocks);
+        rc = check_launch("phm_contract");
+        if (rc) return rc;
+    }
     if (dx) {
         rc = launch_gemm<1>(dy, A, W, nullptr, nullptr, dx, N, out, in, n, kin, kout, s);
         if (rc) return rc;
     }
-    if (!dW && !dA && !db) return PHC_OK;
-    const size_t need = phc_phm_linear_bwd_ws_bytes(N, n, kin, kout);
-    PHC_REQUIRE(ws && ws_bytes >= need, PHC_ERR_WORKSPACE, "phc_phm_linear_bwd: workspace %zu B < required %zu B", ws_bytes,
-                need);
-    PHC_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 15) == 0, PHC_ERR_WORKSPACE, "phc_phm_linear_bwd: workspace not 16-byte aligned");
-    DhPlan p = dh_plan(N, in, out);
-    float *slabs = static_cast<float *>(ws);
-    float *dH = slabs + p.slab_elems * (size_t)p.splits;
-    if (N == 0) {
-        hipMemsetAsync(dH, 0, sizeof(float) * p.slab_elems, s);
-    } else {
-        const int vec4 = (in % 4 == 0) && (out % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) &&
-                         ((reinterpret_cast<uintptr_t>(dy) & 15) == 0);
-        {
-            ProfScope prof(K_PHM_DH_PARTIAL, s);
-            hipLaunchKernelGGL(phm_dH_partial_kernel, dim3(p.tiles_i * p.tiles_j, p.splits), dim3(256), 0, s, x, dy, slabs,
-                               (long long)N, in, out, p.tiles_j, (long long)p.rows_per_split, vec4);
-            rc = check_launch("phm_dH_partial");
-            if (rc) return rc;
-        }
-        {
-            ProfScope prof(K_PHM_DH_REDUCE, s);
-            hipLaunchKernelGGL(phm_dH_reduce_kernel, dim3((unsigned)((p.slab_elems + 63) / 64)), dim3(256), 0, s, slabs,
-                               dH, p.slab_elems, p.splits);
-            rc = check_launch("phm_dH_reduce");
-            if (rc) return rc;
+    if (fork) {                                          // join: everything after this call on `s` sees dW / dA / db
+        if (hipEventRecord(ov.join, ov.side) != hipSuccess || hipStreamWaitEvent(s, ov.join, 0) != hipSuccess) {
+            set_last_error("phc_phm_linear_bwd: join failed");
+            return PHC_ERR_LAUNCH;
         }
     }
-    const int dA_blocks = n * n * n;
-    const int dW_blocks = (n * kin * kout + 255) / 256;
-    ProfScope prof(K_PHM_CONTRACT, s);
-    hipLaunchKernelGGL(phm_contract_kernel, dim3(dA_blocks + dW_blocks), dim3(256), 0, s, A, W, dH, dW, dA, db, n, kin, kout,
-                       dA_blocks);
-    return check_launch("phm_contract");
+    return PHC_OK;
 }
 
 }  // extern "C"

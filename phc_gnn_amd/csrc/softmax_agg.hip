@@ -196,10 +196,10 @@ int phc_aggregate_softmax_fwd(const float *x, const float *ea, const int32_t *ro
     ProfScope prof(K_SOFTMAX_FWD, s);
 #define PHC_SM_FWD(ACTC)                                                                                                 \
     switch (lpr) {                                                                                                       \
-        case 8: hipLaunchKernelGGL((softmax_agg_fwd_kernel<8, ACTC>), dim3(sm_grid(n_dst)), dim3(SM_THREADS), 0, s, x, ea, rowptr, col, perm, beta_dev, (long long)n_dst, h, out, lse); break;   \
-        case 16: hipLaunchKernelGGL((softmax_agg_fwd_kernel<16, ACTC>), dim3(sm_grid(n_dst)), dim3(SM_THREADS), 0, s, x, ea, rowptr, col, perm, beta_dev, (long long)n_dst, h, out, lse); break; \
-        case 32: hipLaunchKernelGGL((softmax_agg_fwd_kernel<32, ACTC>), dim3(sm_grid(n_dst)), dim3(SM_THREADS), 0, s, x, ea, rowptr, col, perm, beta_dev, (long long)n_dst, h, out, lse); break; \
-        default: hipLaunchKernelGGL((softmax_agg_fwd_kernel<64, ACTC>), dim3(sm_grid(n_dst)), dim3(SM_THREADS), 0, s, x, ea, rowptr, col, perm, beta_dev, (long long)n_dst, h, out, lse); break; \
+        case 8: PHC_LAUNCH((softmax_agg_fwd_kernel<8, ACTC>), dim3(sm_grid(n_dst)), dim3(SM_THREADS), 0, s, x, ea, rowptr, col, perm, beta_dev, (long long)n_dst, h, out, lse); break;   \
+        case 16: PHC_LAUNCH((softmax_agg_fwd_kernel<16, ACTC>), dim3(sm_grid(n_dst)), dim3(SM_THREADS), 0, s, x, ea, rowptr, col, perm, beta_dev, (long long)n_dst, h, out, lse); break; \
+        case 32: PHC_LAUNCH((softmax_agg_fwd_kernel<32, ACTC>), dim3(sm_grid(n_dst)), dim3(SM_THREADS), 0, s, x, ea, rowptr, col, perm, beta_dev, (long long)n_dst, h, out, lse); break; \
+        default: PHC_LAUNCH((softmax_agg_fwd_kernel<64, ACTC>), dim3(sm_grid(n_dst)), dim3(SM_THREADS), 0, s, x, ea, rowptr, col, perm, beta_dev, (long long)n_dst, h, out, lse); break; \
     }
     PHC_SM_ACT(act, PHC_SM_FWD)
 #undef PHC_SM_FWD
@@ -221,10 +221,10 @@ int phc_aggregate_softmax_bwd(const float *dout, const float *out, const float *
     ProfScope prof(K_SOFTMAX_BWD, s);
 #define PHC_SM_BWD(ACTC)                                                                                                 \
     switch (lpr) {                                                                                                       \
-        case 8: hipLaunchKernelGGL((softmax_agg_bwd_kernel<8, ACTC>), dim3(sm_grid(n_src)), dim3(SM_THREADS), 0, s, dout, out, lse, x, ea, beta_dev, rowptr_t, col_t, perm_t, (long long)n_src, h, dx, dea, dbeta_partial); break;   \
-        case 16: hipLaunchKernelGGL((softmax_agg_bwd_kernel<16, ACTC>), dim3(sm_grid(n_src)), dim3(SM_THREADS), 0, s, dout, out, lse, x, ea, beta_dev, rowptr_t, col_t, perm_t, (long long)n_src, h, dx, dea, dbeta_partial); break; \
-        case 32: hipLaunchKernelGGL((softmax_agg_bwd_kernel<32, ACTC>), dim3(sm_grid(n_src)), dim3(SM_THREADS), 0, s, dout, out, lse, x, ea, beta_dev, rowptr_t, col_t, perm_t, (long long)n_src, h, dx, dea, dbeta_partial); break; \
-        default: hipLaunchKernelGGL((softmax_agg_bwd_kernel<64, ACTC>), dim3(sm_grid(n_src)), dim3(SM_THREADS), 0, s, dout, out, lse, x, ea, beta_dev, rowptr_t, col_t, perm_t, (long long)n_src, h, dx, dea, dbeta_partial); break; \
+        case 8: PHC_LAUNCH((softmax_agg_bwd_kernel<8, ACTC>), dim3(sm_grid(n_src)), dim3(SM_THREADS), 0, s, dout, out, lse, x, ea, beta_dev, rowptr_t, col_t, perm_t, (long long)n_src, h, dx, dea, dbeta_partial); break;   \
+        case 16: PHC_LAUNCH((softmax_agg_bwd_kernel<16, ACTC>), dim3(sm_grid(n_src)), dim3(SM_THREADS), 0, s, dout, out, lse, x, ea, beta_dev, rowptr_t, col_t, perm_t, (long long)n_src, h, dx, dea, dbeta_partial); break; \
+        case 32: PHC_LAUNCH((softmax_agg_bwd_kernel<32, ACTC>), dim3(sm_grid(n_src)), dim3(SM_THREADS), 0, s, dout, out, lse, x, ea, beta_dev, rowptr_t, col_t, perm_t, (long long)n_src, h, dx, dea, dbeta_partial); break; \
+        default: PHC_LAUNCH((softmax_agg_bwd_kernel<64, ACTC>), dim3(sm_grid(n_src)), dim3(SM_THREADS), 0, s, dout, out, lse, x, ea, beta_dev, rowptr_t, col_t, perm_t, (long long)n_src, h, dx, dea, dbeta_partial); break; \
     }
     PHC_SM_ACT(act, PHC_SM_BWD)
 #undef PHC_SM_BWD

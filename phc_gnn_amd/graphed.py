@@ -19,7 +19,9 @@ Per step: one device-to-device copy of the padded batch into the static buffers 
 from __future__ import annotations
 
 import gc
+import os
 import types
+import warnings
 from typing import List, Optional
 
 import numpy as np
@@ -67,15 +69,47 @@ def pad_batch(gb: synth.GraphBatch, n_max: int, e_max: int) -> dict:
                 num_graphs=B, num_nodes=N, num_edges=E)
 
 
+FLAT_TENSORS = ("x", "edge_index", "edge_attr", "batch", "y", "n_valid_nodes")
+
+
+def _flat_layout(p: dict):
+    """Byte layout of the batch arrays inside one flat buffer (16-byte aligned segments)."""
+    layout, off = {}, 0
+    for k in FLAT_TENSORS:
+        a = np.asarray(p[k])
+        layout[k] = (off, a.shape, a.dtype)
+        off += -(-a.nbytes // 16) * 16
+    return layout, off
+
+
 def padded_to_device(p: dict, device) -> dict:
-    return {k: (torch.from_numpy(np.ascontiguousarray(v)).to(device) if isinstance(v, np.ndarray) else v)
-            for k, v in p.items()}
+    """One host buffer, ONE host-to-device copy; the per-array tensors are views into the flat device buffer,
+    so loading a batch into the static buffers of a captured step is a single device-to-device copy."""
+    layout, total = _flat_layout(p)
+    host = np.zeros(total, dtype=np.uint8)
+    for k, (off, shape, dt) in layout.items():
+        a = np.ascontiguousarray(p[k])
+        host[off:off + a.nbytes] = a.reshape(-1).view(np.uint8)
+    flat = torch.from_numpy(host).to(device)
+    out = {k: v for k, v in p.items() if k not in layout}
+    out.update(_flat_views(flat, layout))
+    out["_flat"], out["_layout"] = flat, layout
+    return out
+
+
+def _flat_views(flat: torch.Tensor, layout: dict) -> dict:
+    views = {}
+    for k, (off, shape, dt) in layout.items():
+        tdt = torch.from_numpy(np.empty(0, dtype=dt)).dtype
+        nbytes = int(np.prod(shape, dtype=np.int64)) * np.dtype(dt).itemsize
+        views[k] = flat[off:off + nbytes].view(tdt).view(tuple(shape))
+    return views
 
 
 class GraphedTrainStep:
     """Static buffers + one captured hipGraph for the whole training step."""
 
-    TENSORS = ("x", "edge_index", "edge_attr", "batch", "y", "n_valid_nodes")
+    TENSORS = FLAT_TENSORS
 
     def __init__(self, model, optimizer, cfg: StepConfig, example: dict, grad_sync=None, warmup: int = 3):
         """``grad_sync``: optional ``phc_gnn_amd.dist.FlatGradSync`` (data-parallel ranks).  The step is then
@@ -83,7 +117,12 @@ class GraphedTrainStep:
         [unpack, clip, Adam] — with the RCCL all-reduce of the bucket issued eagerly between them."""
         self.model, self.optimizer, self.cfg, self.grad_sync = model, optimizer, cfg, grad_sync
         dev = example["x"].device
-        self.static = {k: example[k].clone() for k in self.TENSORS}
+        if "_flat" in example:                      # batch arrays live in one flat buffer: one copy per step
+            self.static_flat, self.layout = example["_flat"].clone(), example["_layout"]
+            self.static = _flat_views(self.static_flat, self.layout)
+        else:
+            self.static_flat, self.layout = None, None
+            self.static = {k: example[k].clone() for k in self.TENSORS}
         B = int(example["num_graphs"])
         self.data = types.SimpleNamespace(
             x=self.static["x"], edge_index=self.static["edge_index"], edge_attr=self.static["edge_attr"],
@@ -91,6 +130,11 @@ class GraphedTrainStep:
             n_valid_nodes=self.static["n_valid_nodes"],
             n_valid_graphs=torch.tensor(B, dtype=torch.int32, device=dev), all_labeled=False)
         self.loss = None
+        self.device = dev
+        self.replay_stream = torch.cuda.Stream(device=dev)     # never the capture stream, never the null stream
+        if os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "1") != "0":
+            warnings.warn("DEBUG_CLR_GRAPH_PACKET_CAPTURE is not 0: on HIP 7.0 pipelined hipGraph replays race with the "
+                          "batch copies queued behind them (see phc_gnn_amd/__init__.py)", RuntimeWarning)
         self.graph = torch.cuda.CUDAGraph()
         # Warm-up (allocator pools, lazy library initialisation, pointer tables) and capture run on ONE
         # dedicated stream, so that autograd's per-parameter AccumulateGrad nodes, the optimizer state and
@@ -156,14 +200,38 @@ class GraphedTrainStep:
 
     def load(self, padded: dict) -> None:
         """Device-to-device copy of one padded, HBM-resident batch into the static buffers."""
+        if self.static_flat is not None and padded.get("_flat") is not None and \
+                padded["_flat"].numel() == self.static_flat.numel():
+            self.static_flat.copy_(padded["_flat"], non_blocking=True)
+            return
         for k in self.TENSORS:
             self.static[k].copy_(padded[k], non_blocking=True)
 
     def step(self, padded: Optional[dict] = None) -> torch.Tensor:
+        """Load one padded batch and replay.  Stream-ordered with the caller's current stream, but the copy and the
+        graph launch themselves are issued on a dedicated NON-DEFAULT stream: on ROCm 7.2 a hipGraphLaunch into the
+        legacy null stream is not ordered against the null-stream work queued behind it, so the next batch's copy
+        overwrote the static buffers of a replay still in flight (scripts/debug_bench_like.py reproduces the fault)."""
+        cur = torch.cuda.current_stream(self.device)
+        if cur != torch.cuda.default_stream(self.device):
+            self._issue(padded)                # caller already runs on a side stream (bench.py: `with step.on_stream():`)
+            return self.loss
+        rs = self.replay_stream                # default stream: hop over to the replay stream and back (two event waits)
+        rs.wait_stream(cur)
+        with torch.cuda.stream(rs):
+            self._issue(padded)
+        cur.wait_stream(rs)
+        return self.loss
+
+    def _issue(self, padded: Optional[dict]) -> None:
         if padded is not None:
             self.load(padded)
         self.graph.replay()
         if self.graph2 is not None:
             self.grad_sync.reduce()            # eager RCCL all-reduce of the flat bucket (stream-ordered)
             self.graph2.replay()
-        return self.loss
+
+    def on_stream(self):
+        """Context manager that makes the replay stream current: a training loop run inside it pays no per-step
+        cross-stream event waits (`torch.cuda.synchronize()` / `stream.synchronize()` still bracket it as usual)."""
+        return torch.cuda.stream(self.replay_stream)

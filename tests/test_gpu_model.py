@@ -236,6 +236,36 @@ def test_graphed_step_is_reproducible():
     assert all(torch.equal(outs[0][1][k], outs[1][1][k]) for k in outs[0][1])
 
 
+@pytest.mark.parametrize("where", ["default_stream", "on_stream"])
+def test_graphed_step_pipelined_replays_do_not_race_with_batch_loads(where):
+    """Back-to-back load+replay WITHOUT host synchronisation at the bench size: the next batch's copy into the
+    static buffers must wait for the replay in flight.  (On ROCm 7.2 a hipGraphLaunch into the null stream was not
+    ordered against the copies queued behind it: mixed batches -> out-of-range indices -> memory fault.)"""
+    import contextlib
+    from phc_gnn_amd import graphed, harness
+    wl = "molhiv_b512"
+    gbs = [harness.make_batch(wl, seed=s) for s in range(4)]
+    n_max, e_max = graphed.bucket_shape(gbs)
+    padded = [graphed.padded_to_device(graphed.pad_batch(g, n_max, e_max), DEV) for g in gbs]
+    m, o = _fresh(wl, seed=2)
+    step = graphed.GraphedTrainStep(m, o, harness.StepConfig(), padded[0], warmup=1)
+    base = {k: v.clone() for k, v in _fresh(wl, seed=2)[0].state_dict().items()}
+    results = []
+    for synced in (True, False):
+        m.load_state_dict(base)
+        _reset_adam_in_place(o)
+        torch.cuda.synchronize()
+        with (step.on_stream() if where == "on_stream" else contextlib.nullcontext()):
+            for i in range(24):
+                loss = step.step(padded[i % 4])
+                if synced:
+                    torch.cuda.synchronize()
+            torch.cuda.synchronize()
+        results.append((float(loss), {k: v.clone() for k, v in m.state_dict().items()}))
+    assert results[0][0] == results[1][0]
+    assert all(torch.equal(results[0][1][k], results[1][1][k]) for k in base)
+
+
 # ---- multi-GPU paths exercised on ONE GPU with a single-rank RCCL group ---------------------------
 @pytest.fixture(scope="module")
 def rccl_single_rank():
