@@ -89,6 +89,22 @@ int phc_phm_linear_bwd(const float *x, const float *A, const float *W, const flo
                        float *dx, float *dW, float *dA, float *db,
                        void *ws, size_t ws_bytes, void *stream);
 
+/* The parameter gradients (dW, dA, db) of MANY PHM linear layers in three launches.
+ * They are off the backward pass's critical path (only the optimizer reads them), and at
+ * molecule scale one layer's dH = x^T.dy cannot fill 256 CUs: a training step runs
+ * phc_phm_linear_bwd with dW = dA = db = NULL (dx only) per layer, keeps x and dy alive, and
+ * submits all layers here once the backward pass is over (phc_gnn_amd/ops.py:
+ * deferred_param_grads).  Same formulas and the same fixed-order split-K summation as
+ * phc_phm_linear_bwd; `jobs` is a HOST array consumed at call time; every job needs N > 0. */
+typedef struct phc_phm_grad_job {
+    const float *x, *dy, *A, *W;   /* device: [N, n*kin], [N, n*kout], [n,n,n], [n,kin,kout] */
+    float *dW, *dA, *db;           /* device outputs; dA / db may be NULL                     */
+    int64_t N;
+    int32_t n, kin, kout, reserved;
+} phc_phm_grad_job;
+size_t phc_phm_param_grads_ws_bytes(const phc_phm_grad_job *jobs, int num_jobs);
+int phc_phm_param_grads(const phc_phm_grad_job *jobs, int num_jobs, void *ws, size_t ws_bytes, void *stream);
+
 /* ------------------------------------------------------------------------- *
  * Graph structure: destination-sorted (CSR) or source-sorted (CSC) edge lists
  * ------------------------------------------------------------------------- */
@@ -231,7 +247,8 @@ int phc_aggregate_enc_bwd(const float *dout, const float *x, const int64_t *bond
  * tensors, used in place); any of the arrays may be NULL.
  * n_valid_dev: optional DEVICE int32 scalar; rows >= *n_valid_dev are padding of a
  *   fixed-shape batch: excluded from the statistics, written as 0, zero gradient.
- * save_mean / save_invstd [h]: written by the forward, consumed by the backward.
+ * save_stat [6h]: written by the forward, consumed by the backward:
+ *   [mean | invstd | invstd*w | b - mean*invstd*w | w | b], w/b per column (1/0 without affine).
  * dwb_flat [2h]: dweight (component-major) followed by dbias.
  * ------------------------------------------------------------------------- */
 #define PHC_MAX_COMPONENTS 16
@@ -240,9 +257,8 @@ size_t phc_bn_ws_bytes(int64_t N, int h);
 int phc_bn_fwd(const float *x, const float *const *weight, const float *const *bias, float *const *running_mean,
                float *const *running_var, int64_t *const *num_batches_tracked, int n_comp, const int32_t *n_valid_dev,
                int64_t N, int h, int training, float momentum, float eps, int act, const float *residual, float *out,
-               float *save_mean, float *save_invstd, void *ws, size_t ws_bytes, void *stream);
-int phc_bn_bwd(const float *dy, const float *x, const float *const *weight, const float *const *bias,
-               const float *save_mean, const float *save_invstd, int n_comp, const int32_t *n_valid_dev, int64_t N, int h,
+               float *save_stat, void *ws, size_t ws_bytes, void *stream);
+int phc_bn_bwd(const float *dy, const float *x, const float *save_stat, const int32_t *n_valid_dev, int64_t N, int h,
                int training, int act, float *dx, float *dwb_flat, void *ws, size_t ws_bytes, void *stream);
 
 /* ------------------------------------------------------------------------- *

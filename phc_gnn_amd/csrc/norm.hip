@@ -130,18 +130,33 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_partial_kernel(const floa
 }
 
 // Merge the per-block (sum, M2) pairs: 8 columns per workgroup, 32 partial lanes each, fixed order.
-// Writes stat[0..h) = mean, stat[h..2h) = invstd, stat[2h..3h) = scale = invstd*w, stat[3h..4h) = shift;
-// updates the running statistics (training).
+// Writes stat[0..h) = mean, [h..2h) = invstd, [2h..3h) = scale = invstd*w, [3h..4h) = shift, [4h..5h) = w, [5h..6h) = b
+// (the backward reads w / b from there: the by-value pointer tables live in the kernarg segment, and a
+// per-thread dynamic index into them costs two dependent long-latency loads); updates the running statistics.
 __global__ __launch_bounds__(BN_THREADS) void bn_finalize_kernel(BnParams p, const int *__restrict__ n_valid, long long N, int h,
                                                                int training, float momentum, float eps,
                                                                const float *__restrict__ partial, int num_partials,
-                                                               long long rows_per_block, float *__restrict__ stat,
-                                                               float *__restrict__ save_mean, float *__restrict__ save_invstd) {
+                                                               long long rows_per_block, float *__restrict__ stat) {
     __shared__ float r_sum[32][8], r_m2[32][8];
-    const long long count = n_valid ? min((long long)*n_valid, N) : N;
     const int tid = threadIdx.x;
     const int ci = tid & 7, pl = tid >> 3;
     const int c = blockIdx.x * 8 + ci;
+    const bool owner = pl == 0 && c < h;
+    // parameter / running-stat values of this column go in flight first (pointer table -> value: two hops)
+    float w = 1.f, b = 0.f, rm_old = 0.f, rv_old = 1.f;
+    float *rm = nullptr, *rv = nullptr;
+    if (owner) {
+        const int comp = c / p.k, kk = c - comp * p.k;
+        if (p.has_weight) w = p.weight[comp][kk];
+        if (p.has_bias) b = p.bias[comp][kk];
+        if (p.has_running) {
+            rm = p.running_mean[comp] + kk;
+            rv = p.running_var[comp] + kk;
+            rm_old = *rm;
+            rv_old = *rv;
+        }
+    }
+    const long long count = n_valid ? min((long long)*n_valid, N) : N;
     const float cnt = (float)max(count, 1LL);
     float mean = 0.f, invstd = 1.f;
     if (training) {
@@ -150,9 +165,9 @@ __global__ __launch_bounds__(BN_THREADS) void bn_finalize_kernel(BnParams p, con
         float ps[PER_LANE], pm[PER_LANE];
 #pragma unroll
         for (int t = 0; t < PER_LANE; ++t) {
-            const int b = pl + 32 * t;
-            const bool ok = c < h && b < num_partials;
-            const size_t off = (size_t)(ok ? b : 0) * 2 * h + (c < h ? c : 0);
+            const int bb = pl + 32 * t;
+            const bool ok = c < h && bb < num_partials;
+            const size_t off = (size_t)(ok ? bb : 0) * 2 * h + (c < h ? c : 0);
             const float a = partial[off], m2v = partial[off + h];
             ps[t] = ok ? a : 0.f;
             pm[t] = ok ? m2v : 0.f;
@@ -168,9 +183,9 @@ __global__ __launch_bounds__(BN_THREADS) void bn_finalize_kernel(BnParams p, con
         float m2 = 0.f;
 #pragma unroll
         for (int t = 0; t < PER_LANE; ++t) {
-            const int b = pl + 32 * t;
-            const long long nb_i = min(rows_per_block, max(count - (long long)b * rows_per_block, 0LL));
-            if (c < h && b < num_partials && nb_i > 0) {
+            const int bb = pl + 32 * t;
+            const long long nb_i = min(rows_per_block, max(count - (long long)bb * rows_per_block, 0LL));
+            if (c < h && bb < num_partials && nb_i > 0) {
                 const float nb = (float)nb_i;
                 const float d = ps[t] / nb - mean;
                 m2 += pm[t] + nb * d * d;
@@ -178,33 +193,29 @@ __global__ __launch_bounds__(BN_THREADS) void bn_finalize_kernel(BnParams p, con
         }
         r_m2[pl][ci] = m2;
         __syncthreads();
-        if (pl == 0 && c < h) {
+        if (owner) {
             float M2 = 0.f;
             for (int l = 0; l < 32; ++l) M2 += r_m2[l][ci];
             const float var = fmaxf(M2 / cnt, 0.f);
             invstd = 1.f / sqrtf(var + eps);
             if (p.has_running) {
-                const int comp = c / p.k, kk = c % p.k;
                 const float unbiased = count > 1 ? M2 / (cnt - 1.f) : var;
-                float *rm = p.running_mean[comp] + kk, *rv = p.running_var[comp] + kk;
-                *rm = (1.f - momentum) * (*rm) + momentum * mean;
-                *rv = (1.f - momentum) * (*rv) + momentum * unbiased;
+                *rm = (1.f - momentum) * rm_old + momentum * mean;
+                *rv = (1.f - momentum) * rv_old + momentum * unbiased;
             }
         }
         if (blockIdx.x == 0 && p.has_nbt && tid < p.n_comp) *p.num_batches_tracked[tid] += 1;
-    } else if (pl == 0 && c < h) {
-        const int comp = c / p.k, kk = c % p.k;
-        mean = p.running_mean[comp][kk];
-        invstd = 1.f / sqrtf(p.running_var[comp][kk] + eps);
+    } else if (owner) {
+        mean = rm_old;
+        invstd = 1.f / sqrtf(rv_old + eps);
     }
-    if (pl == 0 && c < h) {
-        const float w = bn_w(p, c);
+    if (owner) {
         stat[c] = mean;
         stat[h + c] = invstd;
-        if (save_mean) save_mean[c] = mean;
-        if (save_invstd) save_invstd[c] = invstd;
         stat[2 * h + c] = invstd * w;
-        stat[3 * h + c] = bn_b(p, c) - mean * invstd * w;
+        stat[3 * h + c] = b - mean * invstd * w;
+        stat[4 * h + c] = w;
+        stat[5 * h + c] = b;
     }
 }
 
@@ -260,8 +271,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const float *__res
 // ---- pass 1 (backward): sum g and sum g*x_hat per column ------------------------------------------
 template <int ACT, int VEC>
 __global__ __launch_bounds__(BN_THREADS) void bn_bwd_partial_kernel(const float *__restrict__ dy, const float *__restrict__ x,
-                                                                  BnParams p, const float *__restrict__ save_mean,
-                                                                  const float *__restrict__ save_invstd,
+                                                                  const float *__restrict__ stat,
                                                                   const int *__restrict__ n_valid, long long N, int h,
                                                                   long long rows_per_block, float *__restrict__ partial) {
     __shared__ float red[2 * VEC * BN_THREADS];
@@ -282,10 +292,10 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_partial_kernel(const float 
             float mean[VEC], inv[VEC], w[VEC], b[VEC];
 #pragma unroll
             for (int v = 0; v < VEC; ++v) {
-                mean[v] = save_mean[col + v];
-                inv[v] = save_invstd[col + v];
-                w[v] = bn_w(p, col + v);
-                b[v] = bn_b(p, col + v);
+                mean[v] = stat[col + v];
+                inv[v] = stat[h + col + v];
+                w[v] = stat[4 * h + col + v];
+                b[v] = stat[5 * h + col + v];
             }
 #pragma unroll 4
             for (long long r = r0 + rl; r < r1; r += lanes) {
@@ -371,9 +381,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_finalize_kernel(const int *
 
 // ---- pass 3 (backward): dx = w*invstd*(g - mean(g) - x_hat*mean(g*x_hat)) ---------------------------
 template <int ACT>
-__global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const float *__restrict__ dy, const float *__restrict__ x, BnParams p,
-                                                                const float *__restrict__ save_mean,
-                                                                const float *__restrict__ save_invstd,
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+                                                                const float *__restrict__ stat,
                                                                 const int *__restrict__ n_valid, long long N, int h,
                                                                 const float *__restrict__ bstat, float *__restrict__ dx) {
     extern __shared__ float sm[];                            // mean, invstd, w, b, mg, mgx : 6 * h
@@ -381,10 +390,10 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const float *_
     const long long count = n_valid ? min((long long)*n_valid, N) : N;
     const int tid = threadIdx.x;
     for (int c = tid; c < h; c += BN_THREADS) {
-        s_mean[c] = save_mean[c];
-        s_inv[c] = save_invstd[c];
-        s_w[c] = bn_w(p, c);
-        s_b[c] = bn_b(p, c);
+        s_mean[c] = stat[c];
+        s_inv[c] = stat[h + c];
+        s_w[c] = stat[4 * h + c];
+        s_b[c] = stat[5 * h + c];
         s_mg[c] = bstat[c];
         s_mgx[c] = bstat[h + c];
     }
@@ -485,13 +494,13 @@ extern "C" {
 
 size_t phc_bn_ws_bytes(int64_t N, int h) {
     if (N < 0 || h < 1) return 0;
-    return sizeof(float) * (size_t)h * (2 * BN_MAX_PARTIALS + 4);    // partials + [mean|invstd|scale|shift]
+    return sizeof(float) * (size_t)h * (2 * BN_MAX_PARTIALS + 2);    // partials + backward [mean(g) | mean(g*x_hat)]
 }
 
 int phc_bn_fwd(const float *x, const float *const *weight, const float *const *bias, float *const *running_mean,
                float *const *running_var, int64_t *const *num_batches_tracked, int n_comp, const int32_t *n_valid_dev, int64_t N,
-               int h, int training, float momentum, float eps, int act, const float *residual, float *out, float *save_mean,
-               float *save_invstd, void *ws, size_t ws_bytes, void *stream) {
+               int h, int training, float momentum, float eps, int act, const float *residual, float *out, float *save_stat,
+               void *ws, size_t ws_bytes, void *stream) {
     BnParams p;
     int rc = fill_params("phc_bn_fwd", &p, weight, bias, running_mean, running_var, num_batches_tracked, n_comp, h);
     if (rc) return rc;
@@ -499,7 +508,7 @@ int phc_bn_fwd(const float *x, const float *const *weight, const float *const *b
     PHC_REQUIRE(act >= PHC_ACT_IDENTITY && act <= PHC_ACT_SELU, PHC_ERR_INVALID_ARG, "phc_bn_fwd: unknown activation %d", act);
     PHC_REQUIRE(training || p.has_running, PHC_ERR_INVALID_ARG, "phc_bn_fwd: eval mode needs running statistics");
     if (N == 0) return PHC_OK;
-    PHC_REQUIRE(x && out, PHC_ERR_INVALID_ARG, "phc_bn_fwd: null pointer");
+    PHC_REQUIRE(x && out && save_stat, PHC_ERR_INVALID_ARG, "phc_bn_fwd: null pointer");
     PHC_REQUIRE(h <= 8192, PHC_ERR_UNSUPPORTED, "phc_bn_fwd: h=%d too wide", h);
     hipStream_t s = (hipStream_t)stream;
     BnPlan plan = bn_plan(N);
@@ -508,7 +517,7 @@ int phc_bn_fwd(const float *x, const float *const *weight, const float *const *b
                       (!residual || (reinterpret_cast<uintptr_t>(residual) & 15) == 0);
     PHC_REQUIRE(vec4 || h % 4 != 0, PHC_ERR_UNSUPPORTED, "phc_bn_fwd: rows must be 16-byte aligned when h %% 4 == 0");
     PHC_REQUIRE(ws && ws_bytes >= phc_bn_ws_bytes(N, h), PHC_ERR_WORKSPACE, "phc_bn_fwd: workspace too small");
-    float *stat = partial + 2 * (size_t)h * BN_MAX_PARTIALS;
+    float *stat = save_stat;
     if (training) {
         ProfScope prof(K_BN_STATS, s);
         if (vec4)
@@ -523,7 +532,7 @@ int phc_bn_fwd(const float *x, const float *const *weight, const float *const *b
     {
         ProfScope prof(K_BN_FINALIZE, s);
         PHC_LAUNCH(bn_finalize_kernel, dim3((h + 7) / 8), dim3(BN_THREADS), 0, s, p, n_valid_dev, (long long)N, h, training,
-                           momentum, eps, partial, plan.num_partials, plan.rows_per_block, stat, save_mean, save_invstd);
+                           momentum, eps, partial, plan.num_partials, plan.rows_per_block, stat);
         rc = check_launch("bn_finalize");
         if (rc) return rc;
     }
@@ -537,12 +546,10 @@ int phc_bn_fwd(const float *x, const float *const *weight, const float *const *b
     return check_launch("bn_apply");
 }
 
-int phc_bn_bwd(const float *dy, const float *x, const float *const *weight, const float *const *bias, const float *save_mean,
-               const float *save_invstd, int n_comp, const int32_t *n_valid_dev, int64_t N, int h, int training, int act, float *dx,
-               float *dwb_flat, void *ws, size_t ws_bytes, void *stream) {
-    BnParams p;
-    int rc = fill_params("phc_bn_bwd", &p, weight, bias, nullptr, nullptr, nullptr, n_comp, h);
-    if (rc) return rc;
+int phc_bn_bwd(const float *dy, const float *x, const float *save_stat, const int32_t *n_valid_dev, int64_t N, int h, int training,
+               int act, float *dx, float *dwb_flat, void *ws, size_t ws_bytes, void *stream) {
+    int rc = PHC_OK;
+    PHC_REQUIRE(h >= 1, PHC_ERR_INVALID_ARG, "phc_bn_bwd: h < 1");
     PHC_REQUIRE(N >= 0, PHC_ERR_INVALID_ARG, "phc_bn_bwd: N < 0");
     PHC_REQUIRE(act >= PHC_ACT_IDENTITY && act <= PHC_ACT_SELU, PHC_ERR_INVALID_ARG, "phc_bn_bwd: unknown activation %d", act);
     PHC_REQUIRE(h <= 8192, PHC_ERR_UNSUPPORTED, "phc_bn_bwd: h=%d too wide", h);
@@ -551,7 +558,7 @@ int phc_bn_bwd(const float *dy, const float *x, const float *const *weight, cons
         if (dwb_flat) hipMemsetAsync(dwb_flat, 0, sizeof(float) * 2 * (size_t)h, s);
         return PHC_OK;
     }
-    PHC_REQUIRE(dy && x && save_mean && save_invstd, PHC_ERR_INVALID_ARG, "phc_bn_bwd: null pointer");
+    PHC_REQUIRE(dy && x && save_stat, PHC_ERR_INVALID_ARG, "phc_bn_bwd: null pointer");
     PHC_REQUIRE(ws && ws_bytes >= phc_bn_ws_bytes(N, h), PHC_ERR_WORKSPACE, "phc_bn_bwd: workspace too small");
     BnPlan plan = bn_plan(N);
     float *partial = static_cast<float *>(ws);
@@ -562,11 +569,11 @@ int phc_bn_bwd(const float *dy, const float *x, const float *const *weight, cons
         ProfScope prof(K_BN_BWD_PARTIAL, s);
 #define PHC_BN_BP(ACTC)                                                                                                      \
     if (vec4)                                                                                                                \
-        PHC_LAUNCH((bn_bwd_partial_kernel<ACTC, 4>), dim3(plan.num_partials), dim3(BN_THREADS), 0, s, dy, x, p, save_mean,  \
-                           save_invstd, n_valid_dev, (long long)N, h, plan.rows_per_block, partial);                         \
+        PHC_LAUNCH((bn_bwd_partial_kernel<ACTC, 4>), dim3(plan.num_partials), dim3(BN_THREADS), 0, s, dy, x, save_stat,    \
+                           n_valid_dev, (long long)N, h, plan.rows_per_block, partial);                                      \
     else                                                                                                                     \
-        PHC_LAUNCH((bn_bwd_partial_kernel<ACTC, 1>), dim3(plan.num_partials), dim3(BN_THREADS), 0, s, dy, x, p, save_mean,  \
-                           save_invstd, n_valid_dev, (long long)N, h, plan.rows_per_block, partial)
+        PHC_LAUNCH((bn_bwd_partial_kernel<ACTC, 1>), dim3(plan.num_partials), dim3(BN_THREADS), 0, s, dy, x, save_stat,    \
+                           n_valid_dev, (long long)N, h, plan.rows_per_block, partial)
         PHC_BN_ACT_SWITCH(act, PHC_BN_BP)
 #undef PHC_BN_BP
         rc = check_launch("bn_bwd_partial");
@@ -584,8 +591,8 @@ int phc_bn_bwd(const float *dy, const float *x, const float *const *weight, cons
     const size_t lds = sizeof(float) * 6 * (size_t)h;
     ProfScope prof(K_BN_BWD_APPLY, s);
 #define PHC_BN_BA(ACTC)                                                                                                      \
-    PHC_LAUNCH((bn_bwd_apply_kernel<ACTC>), dim3(apply_grid(N, h)), dim3(BN_THREADS), lds, s, dy, x, p, save_mean,          \
-                       save_invstd, n_valid_dev, (long long)N, h, bstat, dx)
+    PHC_LAUNCH((bn_bwd_apply_kernel<ACTC>), dim3(apply_grid(N, h)), dim3(BN_THREADS), lds, s, dy, x, save_stat,             \
+                       n_valid_dev, (long long)N, h, bstat, dx)
     PHC_BN_ACT_SWITCH(act, PHC_BN_BA)
 #undef PHC_BN_BA
     return check_launch("bn_bwd_apply");

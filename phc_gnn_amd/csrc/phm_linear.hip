@@ -18,6 +18,7 @@
 #include <stdlib.h>
 
 #include "phc_common.h"
+#include <vector>
 
 namespace phc {
 
@@ -477,18 +478,17 @@ constexpr int DH_T = 64;            // tile edge
 constexpr int DH_RB = 64;           // rows staged per step
 constexpr int DH_STRIDE = DH_T;     // lanes read consecutive columns: conflict-free without padding
 
-__global__ __launch_bounds__(256) void phm_dH_partial_kernel(const float *__restrict__ X, const float *__restrict__ DY,
-                                                            float *__restrict__ slabs, long long N, int in, int out,
-                                                            int tiles_j, long long rows_per_split, int vec4) {
+__device__ __forceinline__ void dH_partial_body(const float *__restrict__ X, const float *__restrict__ DY,
+                                                float *__restrict__ slabs, long long N, int in, int out, int tiles_j,
+                                                long long rows_per_split, int vec4, int tile, long long split) {
     __shared__ __attribute__((aligned(16))) float xs[DH_RB * DH_STRIDE];
     __shared__ __attribute__((aligned(16))) float ds[DH_RB * DH_STRIDE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 1, wj = wave & 1;
     const int r = lane & 31, hh = lane >> 5;
-    const int ti = blockIdx.x / tiles_j, tj = blockIdx.x - ti * tiles_j;
+    const int ti = tile / tiles_j, tj = tile - ti * tiles_j;
     const int i0 = ti * DH_T, j0 = tj * DH_T;
-    const long long split = blockIdx.y;
     const long long r_begin = split * rows_per_split;
     const long long r_end = min(N, r_begin + rows_per_split);
     const size_t slab_elems = (size_t)in * out + out;
@@ -548,13 +548,19 @@ __global__ __launch_bounds__(256) void phm_dH_partial_kernel(const float *__rest
     if (ti == 0 && tid < DH_T && j0 + tid < out) slab[(size_t)in * out + j0 + tid] = colsum;
 }
 
+__global__ __launch_bounds__(256) void phm_dH_partial_kernel(const float *__restrict__ X, const float *__restrict__ DY,
+                                                            float *__restrict__ slabs, long long N, int in, int out,
+                                                            int tiles_j, long long rows_per_split, int vec4) {
+    dH_partial_body(X, DY, slabs, N, in, out, tiles_j, rows_per_split, vec4, blockIdx.x, blockIdx.y);
+}
+
 // dH[idx] (and the db tail) = sum over splits.  64 elements x 4 split lanes per workgroup; every lane
 // walks its splits in order and the 4 lane sums are added in order: one fixed summation tree.
-__global__ __launch_bounds__(256) void phm_dH_reduce_kernel(const float *__restrict__ slabs, float *__restrict__ dH, size_t slab_elems,
-                                                           int splits) {
+__device__ __forceinline__ void dH_reduce_body(const float *__restrict__ slabs, float *__restrict__ dH, size_t slab_elems, int splits,
+                                               unsigned blk) {
     __shared__ float part[4][64];
     const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const size_t idx = (size_t)blockIdx.x * 64 + e;
+    const size_t idx = (size_t)blk * 64 + e;
     float s = 0.f;
     if (idx < slab_elems) {
 #pragma unroll 4
@@ -565,17 +571,21 @@ __global__ __launch_bounds__(256) void phm_dH_reduce_kernel(const float *__restr
     if (sl == 0 && idx < slab_elems) dH[idx] = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
 }
 
+__global__ __launch_bounds__(256) void phm_dH_reduce_kernel(const float *__restrict__ slabs, float *__restrict__ dH, size_t slab_elems,
+                                                           int splits) {
+    dH_reduce_body(slabs, dH, slab_elems, splits, blockIdx.x);
+}
+
 // blocks [0, n^3): dA[i,a,c] = sum_{kap,pi} W[i,kap,pi] * dH[a*kin+kap, c*kout+pi]
 // blocks [n^3, ..): dW[i,kap,pi] = sum_{a,c} A[i,a,c] * dH[a*kin+kap, c*kout+pi]; the last block also copies db.
-__global__ __launch_bounds__(256) void phm_contract_kernel(const float *__restrict__ A, const float *__restrict__ W,
-                                                          const float *__restrict__ dH, float *__restrict__ dW,
-                                                          float *__restrict__ dA, float *__restrict__ db, int n, int kin,
-                                                          int kout, int dA_blocks) {
+__device__ __forceinline__ void contract_body(const float *__restrict__ A, const float *__restrict__ W,
+                                              const float *__restrict__ dH, float *__restrict__ dW, float *__restrict__ dA,
+                                              float *__restrict__ db, int n, int kin, int kout, int dA_blocks, int bx) {
     const int out = n * kout;
     const int tid = threadIdx.x;
-    if ((int)blockIdx.x < dA_blocks) {
+    if (bx < dA_blocks) {
         if (!dA) return;
-        const int iac = blockIdx.x;
+        const int iac = bx;
         const int i = iac / (n * n), a = (iac / n) % n, c = iac % n;
         float s = 0.f;
         for (int e = tid; e < kin * kout; e += 256) {
@@ -592,7 +602,7 @@ __global__ __launch_bounds__(256) void phm_contract_kernel(const float *__restri
         if (tid == 0) dA[iac] = red[0];
         return;
     }
-    const int blk = blockIdx.x - dA_blocks;
+    const int blk = bx - dA_blocks;
     const int e = blk * 256 + tid;                       // index into dW [n, kin, kout]
     if (dW && e < n * kin * kout) {
         const int i = e / (kin * kout);
@@ -606,6 +616,68 @@ __global__ __launch_bounds__(256) void phm_contract_kernel(const float *__restri
     }
     if (db && blk == 0)
         for (int j = tid; j < out; j += 256) db[j] = dH[(size_t)n * kin * out + j];
+}
+
+__global__ __launch_bounds__(256) void phm_contract_kernel(const float *__restrict__ A, const float *__restrict__ W,
+                                                          const float *__restrict__ dH, float *__restrict__ dW,
+                                                          float *__restrict__ dA, float *__restrict__ db, int n, int kin,
+                                                          int kout, int dA_blocks) {
+    contract_body(A, W, dH, dW, dA, db, n, kin, kout, dA_blocks, blockIdx.x);
+}
+
+// ------------------------------------------------------------------------------------------
+// Batched parameter gradients (phc_phm_param_grads): the dW / dA / db chains of MANY layers in
+// three launches.  Parameter gradients are off the critical path of the backward pass (only the
+// optimizer reads them), and one layer's chain cannot fill 256 CUs at molecule scale; batching
+// the layers fills the chip and needs ~30 split-K slabs per layer instead of ~130.
+// The job table travels by value in the kernarg segment; workgroup -> job by a scalar scan.
+// ------------------------------------------------------------------------------------------
+constexpr int GRAD_JOBS_PER_LAUNCH = 16;
+
+struct GradJobDev {
+    const float *x, *dy, *A, *W;
+    float *dW, *dA, *db;
+    float *slabs, *dH;
+    long long N, rows_per_split;
+    int in, out, n, kin, kout;
+    int tiles_j, tiles, splits, vec4;
+    int dA_blocks;
+    unsigned blk0_partial, blk0_reduce, blk0_contract;      // first workgroup of this job in each launch
+};
+struct GradBatch {
+    int num;
+    GradJobDev j[GRAD_JOBS_PER_LAUNCH];
+};
+
+template <int STAGE>
+__device__ __forceinline__ int grad_job_of_block(const GradBatch &b, unsigned bx) {
+    int job = 0;
+    for (int k = 1; k < b.num; ++k) {
+        const unsigned start = STAGE == 0 ? b.j[k].blk0_partial : (STAGE == 1 ? b.j[k].blk0_reduce : b.j[k].blk0_contract);
+        if (bx >= start) job = k;
+    }
+    return job;
+}
+
+__global__ __launch_bounds__(256) void phm_grads_partial_kernel(GradBatch b) {
+    const int k = grad_job_of_block<0>(b, blockIdx.x);
+    const GradJobDev &j = b.j[k];
+    const unsigned local = blockIdx.x - j.blk0_partial;
+    const int tile = local % j.tiles;
+    const long long split = local / j.tiles;
+    dH_partial_body(j.x, j.dy, j.slabs, j.N, j.in, j.out, j.tiles_j, j.rows_per_split, j.vec4, tile, split);
+}
+
+__global__ __launch_bounds__(256) void phm_grads_reduce_kernel(GradBatch b) {
+    const int k = grad_job_of_block<1>(b, blockIdx.x);
+    const GradJobDev &j = b.j[k];
+    dH_reduce_body(j.slabs, j.dH, (size_t)j.in * j.out + j.out, j.splits, blockIdx.x - j.blk0_reduce);
+}
+
+__global__ __launch_bounds__(256) void phm_grads_contract_kernel(GradBatch b) {
+    const int k = grad_job_of_block<2>(b, blockIdx.x);
+    const GradJobDev &j = b.j[k];
+    contract_body(j.A, j.W, j.dH, j.dW, j.dA, j.db, j.n, j.kin, j.kout, j.dA_blocks, (int)(blockIdx.x - j.blk0_contract));
 }
 
 // ---- host side ---------------------------------------------------------------------------
@@ -860,6 +932,132 @@ int phc_phm_linear_bwd(const float *x, const float *A, const float *W, const flo
         if (hipEventRecord(ov.join, ov.side) != hipSuccess || hipStreamWaitEvent(s, ov.join, 0) != hipSuccess) {
             set_last_error("phc_phm_linear_bwd: join failed");
             return PHC_ERR_LAUNCH;
+        }
+    }
+    return PHC_OK;
+}
+
+// ---- batched parameter gradients ------------------------------------------------------------
+struct GradPlan {
+    int tiles_i, tiles_j, splits;
+    int64_t rows_per_split;
+    size_t slab_elems;
+};
+
+// Split counts of a whole batch: about 1024 workgroups in total, shared among the jobs in proportion to
+// their row-block counts (depends on the shapes only, never on the device: fixed summation order).
+static void grad_plans(const phc_phm_grad_job *jobs, int num, GradPlan *plans) {
+    int64_t total = 0;
+    for (int k = 0; k < num; ++k) {
+        const int in = jobs[k].n * jobs[k].kin, out = jobs[k].n * jobs[k].kout;
+        plans[k].tiles_i = (in + DH_T - 1) / DH_T;
+        plans[k].tiles_j = (out + DH_T - 1) / DH_T;
+        plans[k].slab_elems = (size_t)in * out + out;
+        total += (int64_t)plans[k].tiles_i * plans[k].tiles_j * ((jobs[k].N + DH_RB - 1) / DH_RB);
+    }
+    const int64_t target = 1024;
+    for (int k = 0; k < num; ++k) {
+        const int64_t max_splits = (jobs[k].N + DH_RB - 1) / DH_RB;
+        int64_t splits = total > target ? (max_splits * target + total - 1) / total : max_splits;
+        if (splits < 1) splits = 1;
+        if (splits > max_splits && max_splits > 0) splits = max_splits;
+        int64_t rows = (jobs[k].N + splits - 1) / splits;
+        rows = (rows + DH_RB - 1) / DH_RB * DH_RB;
+        if (rows < DH_RB) rows = DH_RB;
+        plans[k].rows_per_split = rows;
+        plans[k].splits = (int)((jobs[k].N + rows - 1) / rows);
+        if (plans[k].splits < 1) plans[k].splits = 1;
+    }
+}
+
+static int check_grad_jobs(const char *who, const phc_phm_grad_job *jobs, int num_jobs) {
+    PHC_REQUIRE(num_jobs >= 0 && (num_jobs == 0 || jobs), PHC_ERR_INVALID_ARG, "%s: bad job table", who);
+    for (int k = 0; k < num_jobs; ++k) {
+        int rc = check_phm_dims(who, jobs[k].N, jobs[k].n, jobs[k].kin, jobs[k].kout);
+        if (rc) return rc;
+        PHC_REQUIRE(jobs[k].N > 0, PHC_ERR_INVALID_ARG, "%s: job %d has no rows (its gradients are zero: do not submit it)", who, k);
+    }
+    return PHC_OK;
+}
+
+static size_t grad_ws_floats(const phc_phm_grad_job *jobs, int num_jobs, size_t *offsets) {
+    size_t off = 0;
+    for (int c0 = 0; c0 < num_jobs; c0 += GRAD_JOBS_PER_LAUNCH) {
+        const int cn = num_jobs - c0 < GRAD_JOBS_PER_LAUNCH ? num_jobs - c0 : GRAD_JOBS_PER_LAUNCH;
+        GradPlan plans[GRAD_JOBS_PER_LAUNCH];
+        grad_plans(jobs + c0, cn, plans);
+        for (int k = 0; k < cn; ++k) {
+            if (offsets) offsets[c0 + k] = off;
+            off += (plans[k].slab_elems * ((size_t)plans[k].splits + 1) + 3) / 4 * 4;     // 16-byte aligned segments
+        }
+    }
+    return off;
+}
+
+size_t phc_phm_param_grads_ws_bytes(const phc_phm_grad_job *jobs, int num_jobs) {
+    if (check_grad_jobs("phc_phm_param_grads_ws_bytes", jobs, num_jobs)) return 0;
+    return sizeof(float) * grad_ws_floats(jobs, num_jobs, nullptr);
+}
+
+int phc_phm_param_grads(const phc_phm_grad_job *jobs, int num_jobs, void *ws, size_t ws_bytes, void *stream) {
+    int rc = check_grad_jobs("phc_phm_param_grads", jobs, num_jobs);
+    if (rc) return rc;
+    if (num_jobs == 0) return PHC_OK;
+    std::vector<size_t> offsets(num_jobs);
+    const size_t need = sizeof(float) * grad_ws_floats(jobs, num_jobs, offsets.data());
+    PHC_REQUIRE(ws && ws_bytes >= need, PHC_ERR_WORKSPACE, "phc_phm_param_grads: workspace %zu B < required %zu B", ws_bytes, need);
+    PHC_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 15) == 0, PHC_ERR_WORKSPACE, "phc_phm_param_grads: workspace not 16-byte aligned");
+    hipStream_t s = (hipStream_t)stream;
+    float *base = static_cast<float *>(ws);
+    for (int c0 = 0; c0 < num_jobs; c0 += GRAD_JOBS_PER_LAUNCH) {
+        const int cn = num_jobs - c0 < GRAD_JOBS_PER_LAUNCH ? num_jobs - c0 : GRAD_JOBS_PER_LAUNCH;
+        GradPlan plans[GRAD_JOBS_PER_LAUNCH];
+        grad_plans(jobs + c0, cn, plans);
+        GradBatch b;
+        b.num = cn;
+        unsigned nb_partial = 0, nb_reduce = 0, nb_contract = 0;
+        for (int k = 0; k < cn; ++k) {
+            const phc_phm_grad_job &jb = jobs[c0 + k];
+            PHC_REQUIRE(jb.x && jb.dy && jb.A && jb.W && (jb.dW || jb.dA || jb.db), PHC_ERR_INVALID_ARG,
+                        "phc_phm_param_grads: job %d: null pointer", c0 + k);
+            GradJobDev &d = b.j[k];
+            d.x = jb.x; d.dy = jb.dy; d.A = jb.A; d.W = jb.W;
+            d.dW = jb.dW; d.dA = jb.dA; d.db = jb.db;
+            d.N = jb.N; d.n = jb.n; d.kin = jb.kin; d.kout = jb.kout;
+            d.in = jb.n * jb.kin; d.out = jb.n * jb.kout;
+            d.tiles_j = plans[k].tiles_j;
+            d.tiles = plans[k].tiles_i * plans[k].tiles_j;
+            d.splits = plans[k].splits;
+            d.rows_per_split = plans[k].rows_per_split;
+            d.vec4 = (d.in % 4 == 0) && (d.out % 4 == 0) && ((reinterpret_cast<uintptr_t>(jb.x) & 15) == 0) &&
+                     ((reinterpret_cast<uintptr_t>(jb.dy) & 15) == 0);
+            d.slabs = base + offsets[c0 + k];
+            d.dH = d.slabs + plans[k].slab_elems * (size_t)plans[k].splits;
+            d.dA_blocks = jb.n * jb.n * jb.n;
+            d.blk0_partial = nb_partial;
+            d.blk0_reduce = nb_reduce;
+            d.blk0_contract = nb_contract;
+            nb_partial += (unsigned)d.tiles * (unsigned)d.splits;
+            nb_reduce += (unsigned)((plans[k].slab_elems + 63) / 64);
+            nb_contract += (unsigned)(d.dA_blocks + (jb.n * jb.kin * jb.kout + 255) / 256);
+        }
+        {
+            ProfScope prof(K_PHM_DH_PARTIAL, s);
+            PHC_LAUNCH(phm_grads_partial_kernel, dim3(nb_partial), dim3(256), 0, s, b);
+            rc = check_launch("phm_grads_partial");
+            if (rc) return rc;
+        }
+        {
+            ProfScope prof(K_PHM_DH_REDUCE, s);
+            PHC_LAUNCH(phm_grads_reduce_kernel, dim3(nb_reduce), dim3(256), 0, s, b);
+            rc = check_launch("phm_grads_reduce");
+            if (rc) return rc;
+        }
+        {
+            ProfScope prof(K_PHM_CONTRACT, s);
+            PHC_LAUNCH(phm_grads_contract_kernel, dim3(nb_contract), dim3(256), 0, s, b);
+            rc = check_launch("phm_grads_contract");
+            if (rc) return rc;
         }
     }
     return PHC_OK;

@@ -30,6 +30,7 @@ import torch
 from . import synth
 from .graph import clear_structure_cache
 from .harness import StepConfig, loss_fn
+from .ops import deferred_param_grads
 
 
 def bucket_shape(batches: List[synth.GraphBatch], slack: float = 0.02, multiple: int = 128):
@@ -175,9 +176,10 @@ class GraphedTrainStep:
         """zero_grad, forward, loss, backward (+ pack the gradients into the flat all-reduce bucket)."""
         self.data.y_mask = ~torch.isnan(self.data.y)
         self.optimizer.zero_grad(set_to_none=True)
-        logits = self.model(self.data)
-        loss = loss_fn(logits, self.data, self.cfg.regression)
-        loss.backward()
+        with deferred_param_grads():
+            logits = self.model(self.data)
+            loss = loss_fn(logits, self.data, self.cfg.regression)
+            loss.backward()
         if self.grad_sync is not None:
             self.grad_sync.pack()
         return loss

@@ -12,6 +12,7 @@ import torch
 import torch.nn.functional as F
 
 from . import synth
+from .ops import deferred_param_grads
 
 # BASELINE.json configs -> PHMSkipConnectAdd arguments (SURVEY.md §8d "Model settings")
 WORKLOADS: Dict[str, dict] = {
@@ -97,9 +98,10 @@ def train_step(model, data, optimizer: Optional[torch.optim.Optimizer], cfg: Ste
     else:
         for p in model.parameters():
             p.grad = None
-    logits = model(data)
-    loss = loss_fn(logits, data, cfg.regression)
-    loss.backward()
+    with deferred_param_grads():            # PHM dW/dA/db of all layers: three batched launches after the backward pass
+        logits = model(data)
+        loss = loss_fn(logits, data, cfg.regression)
+        loss.backward()
     if grad_sync is not None:
         grad_sync(model)
     if optimizer is not None and cfg.optimizer:

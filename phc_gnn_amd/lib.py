@@ -27,6 +27,12 @@ _P = C.c_void_p
 _I = C.c_int
 _L = C.c_int64
 _S = C.c_size_t
+class GradJob(C.Structure):
+    """phc_phm_grad_job (include/phc_hip.h)."""
+    _fields_ = [("x", _P), ("dy", _P), ("A", _P), ("W", _P), ("dW", _P), ("dA", _P), ("db", _P),
+                ("N", _L), ("n", C.c_int32), ("kin", C.c_int32), ("kout", C.c_int32), ("reserved", C.c_int32)]
+
+
 SIGNATURES = {
     "phc_version": (_I, []),
     "phc_error_string": (C.c_char_p, [_I]),
@@ -36,6 +42,8 @@ SIGNATURES = {
     "phc_phm_linear_fwd": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P]),
     "phc_phm_linear_bwd_ws_bytes": (_S, [_L, _I, _I, _I]),
     "phc_phm_linear_bwd": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _S, _P]),
+    "phc_phm_param_grads_ws_bytes": (_S, [C.POINTER(GradJob), _I]),
+    "phc_phm_param_grads": (_I, [C.POINTER(GradJob), _I, _P, _S, _P]),
     "phc_csr_ws_bytes": (_S, [_L, _L]),
     "phc_csr_build": (_I, [_P, _P, _L, _L, _P, _P, _P, _P, _S, _P]),
     "phc_segment_ptr_sorted": (_I, [_P, _L, _L, _P, _P]),
@@ -55,8 +63,8 @@ SIGNATURES = {
     "phc_aggregate_enc_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _L, _L, _I, _I, _I, _I, _I, _P, _P, _P,
                                    _S, _P]),
     "phc_bn_ws_bytes": (_S, [_L, _I]),
-    "phc_bn_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _L, _I, _I, C.c_float, C.c_float, _I, _P, _P, _P, _P, _P, _S, _P]),
-    "phc_bn_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _L, _I, _I, _I, _P, _P, _P, _S, _P]),
+    "phc_bn_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _L, _I, _I, C.c_float, C.c_float, _I, _P, _P, _P, _P, _S, _P]),
+    "phc_bn_bwd": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _S, _P]),
     "phc_prof_enable": (_I, [_I]),
     "phc_prof_reset": (_I, []),
     "phc_prof_num_kernels": (_I, []),

@@ -10,6 +10,8 @@ All inputs must be fp32 tensors on a ROCm device; there is no CPU path.
 """
 from __future__ import annotations
 
+import contextlib
+import threading
 from typing import Optional
 
 import torch
@@ -23,6 +25,91 @@ def _act_id(name: str) -> int:
         return L.ACT_IDS[name.lower()]
     except KeyError:
         raise L.PhcError(f"unknown message activation '{name}' (known: {sorted(L.ACT_IDS)})") from None
+
+
+# ---------------------------------------------------------------------------
+# Deferred parameter gradients
+# ---------------------------------------------------------------------------
+# The dW / dA / db chain of a PHM layer (dH = xᵀ·dy as split-K slabs -> reduce -> contract) is off the critical
+# path of the backward pass: nothing but the optimizer reads it.  At molecule scale one layer's chain cannot fill
+# 256 CUs, so inside ``deferred_param_grads()`` every layer's backward only runs its dx GEMM, keeps (x, dy) alive
+# and files a job; when the block exits, ALL layers' parameter gradients are produced by three batched launches
+# (phc_phm_param_grads) and written to ``param.grad`` (accumulating into an existing ``.grad``, like autograd).
+# Only leaf parameters are deferred; anything else (a weight that is itself computed, double backward, a backward
+# that runs after the block has exited) takes the per-layer path.  Tensor hooks on deferred parameters do not fire.
+class _Deferred:
+    def __init__(self):
+        self.active = False
+        self.jobs = []
+        self.lock = threading.Lock()       # the backward pass runs on autograd's device thread
+
+
+_DEFER = _Deferred()
+
+
+@contextlib.contextmanager
+def deferred_param_grads():
+    """Wrap forward + ``loss.backward()`` of a training step; parameter gradients of the PHM layers are complete
+    when the block exits."""
+    if _DEFER.active:                       # nested: the outermost block flushes
+        yield
+        return
+    _DEFER.active = True
+    _DEFER.jobs = []
+    try:
+        yield
+    except BaseException:
+        _DEFER.active = False
+        _DEFER.jobs = []
+        raise
+    _DEFER.active = False
+    jobs, _DEFER.jobs = _DEFER.jobs, []
+    if jobs:
+        _flush_param_grads(jobs)
+
+
+def _flush_param_grads(jobs) -> None:
+    lib = L.load()
+    by_dev = {}
+    for jb in jobs:
+        by_dev.setdefault(jb["x"].device, []).append(jb)
+    for dev, js in by_dev.items():
+        total = 0
+        for jb in js:
+            n, kin, kout = jb["W"].shape
+            jb["off"] = total
+            total += n * kin * kout + n * n * n + n * kout
+        with torch.cuda.device(dev):
+            flat = torch.empty(total, dtype=torch.float32, device=dev)
+            arr = (L.GradJob * len(js))()
+            outs = []
+            for i, jb in enumerate(js):
+                n, kin, kout = jb["W"].shape
+                o = jb["off"]
+                dW = flat[o:o + n * kin * kout].view(n, kin, kout)
+                dA = flat[o + n * kin * kout:o + n * kin * kout + n ** 3].view(n, n, n)
+                db = flat[o + n * kin * kout + n ** 3:o + n * kin * kout + n ** 3 + n * kout]
+                need_A, need_W, need_b = jb["need"]
+                arr[i] = L.GradJob(L.ptr(jb["x"]), L.ptr(jb["dy"]), L.ptr(jb["A"]), L.ptr(jb["W"]),
+                                   L.ptr(dW) if need_W else None, L.ptr(dA) if need_A else None,
+                                   L.ptr(db) if need_b else None, jb["x"].shape[0], n, kin, kout, 0)
+                outs.append((dA if need_A else None, dW if need_W else None, db if need_b else None))
+            ws_bytes = lib.phc_phm_param_grads_ws_bytes(arr, len(js))
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            L.check(lib.phc_phm_param_grads(arr, len(js), L.ptr(ws), ws_bytes, L.stream_ptr(dev)), "phc_phm_param_grads")
+            if L.PROF_ON:
+                for jb in js:
+                    n, kin, kout = jb["W"].shape
+                    N = jb["x"].shape[0]
+                    L.account("phm_dH_partial", 2.0 * N * n * kin * n * kout, 4.0 * N * n * (kin + kout) + 4.0 * n * kin * n * kout)
+            for jb, grads in zip(js, outs):
+                for prm, g in zip(jb["params"], grads):
+                    if prm is None or g is None:
+                        continue
+                    if prm.grad is None:
+                        prm.grad = g
+                    else:
+                        prm.grad.add_(g)
 
 
 # ---------------------------------------------------------------------------
@@ -49,6 +136,11 @@ class _PHMLinearFn(torch.autograd.Function):
             L.account("phm_gemm_fwd", 2.0 * N * n * kin * n * kout,
                       4.0 * (N * n * (kin + kout) + n * kin * kout + n ** 3 + n * kout))
         ctx.save_for_backward(x2, A_, W_)
+        # deferral is decided here: leaf fp32 parameters used in place (their .grad is written at flush time)
+        ctx.defer_params = None
+        if _DEFER.active and N > 0 and A_ is A and W_ is W and (b is None or b_ is b) and \
+                all(p is None or (p.is_leaf and p.grad_fn is None) for p in (A, W, b)):
+            ctx.defer_params = (A, W, b)
         ctx.has_bias = b is not None
         ctx.has_res = residual is not None
         ctx.x_shape = x.shape
@@ -67,6 +159,18 @@ class _PHMLinearFn(torch.autograd.Function):
         need_b = need_b and ctx.has_bias
         dx = torch.empty_like(x2) if need_x else None
         need_param = need_A or need_W or need_b
+        if need_param and ctx.defer_params is not None and _DEFER.active and not torch.is_grad_enabled():
+            # dx only; the parameter gradients of all layers are produced together when the deferral block exits
+            L.check(lib.phc_phm_linear_bwd(L.ptr(x2), L.ptr(A), L.ptr(W), L.ptr(dy2), N, n, kin, kout, L.ptr(dx), None,
+                                           None, None, None, 0, L.stream_ptr(dev)), "phc_phm_linear_bwd")
+            if L.PROF_ON and need_x:
+                L.account("phm_gemm_dx", 2.0 * N * n * kin * n * kout, 4.0 * (N * n * (kin + kout) + n * kin * kout + n ** 3))
+            pA, pW, pb = ctx.defer_params
+            with _DEFER.lock:
+                _DEFER.jobs.append(dict(x=x2, dy=dy2, A=A, W=W, need=(need_A, need_W, need_b),
+                                        params=(pA if need_A else None, pW if need_W else None, pb if need_b else None)))
+            return (dx.reshape(ctx.x_shape) if need_x else None, None, None, None,
+                    dy.reshape(ctx.res_shape) if (need_res and ctx.has_res) else None)
         dW = torch.empty_like(W) if need_param else None
         dA = torch.empty_like(A) if need_A else None
         db = torch.empty(n * kout, dtype=torch.float32, device=dev) if need_b else None
@@ -551,19 +655,18 @@ class _BatchNormActFn(torch.autograd.Function):
         rv_arr = _ptr_array(running_var) if running_var else None
         nbt_arr = _ptr_array(nbt) if nbt else None
         out = torch.empty_like(x_)
-        save_mean = torch.empty(h, dtype=torch.float32, device=dev)
-        save_invstd = torch.empty(h, dtype=torch.float32, device=dev)
+        save_stat = torch.empty(6 * h, dtype=torch.float32, device=dev)   # mean|invstd|scale|shift|w|b per column
         ws_bytes = lib.phc_bn_ws_bytes(N, h)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         L.check(lib.phc_bn_fwd(L.ptr(x_), w_arr, b_arr, rm_arr, rv_arr, nbt_arr, n_comp, L.ptr(n_valid), N, h,
                                1 if training else 0, float(momentum), float(eps), act, L.ptr(res_), L.ptr(out),
-                               L.ptr(save_mean), L.ptr(save_invstd), L.ptr(ws), ws_bytes, L.stream_ptr(dev)),
+                               L.ptr(save_stat), L.ptr(ws), ws_bytes, L.stream_ptr(dev)),
                 "phc_bn_fwd")
         if L.PROF_ON:
             if training:
                 L.account("bn_stats_partial", 3.0 * N * h, 4.0 * N * h)
             L.account("bn_apply", 2.0 * N * h, 4.0 * N * h * (3 if residual is not None else 2))
-        ctx.save_for_backward(x_, save_mean, save_invstd, *(weights or []), *(biases or []))
+        ctx.save_for_backward(x_, save_stat)
         ctx.meta = (n_comp, bool(training), act, bool(affine), residual is not None, n_valid)
         return out
 
@@ -571,10 +674,7 @@ class _BatchNormActFn(torch.autograd.Function):
     def backward(ctx, dout):
         lib = L.load()
         n_comp, training, act, has_affine, has_res, n_valid = ctx.meta
-        saved = ctx.saved_tensors
-        x_, save_mean, save_invstd = saved[:3]
-        weights = list(saved[3:3 + n_comp]) if has_affine else None
-        biases = list(saved[3 + n_comp:3 + 2 * n_comp]) if has_affine else None
+        x_, save_stat = ctx.saved_tensors
         dout_ = L.f32c(dout)
         dev = dout_.device
         N, h = x_.shape
@@ -584,10 +684,8 @@ class _BatchNormActFn(torch.autograd.Function):
         dwb = torch.empty(2 * h, dtype=torch.float32, device=dev) if need_aff else None
         ws_bytes = lib.phc_bn_ws_bytes(N, h)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        L.check(lib.phc_bn_bwd(L.ptr(dout_), L.ptr(x_), _ptr_array(weights) if weights else None,
-                               _ptr_array(biases) if biases else None, L.ptr(save_mean), L.ptr(save_invstd), n_comp,
-                               L.ptr(n_valid), N, h, 1 if training else 0, act, L.ptr(dx), L.ptr(dwb), L.ptr(ws), ws_bytes,
-                               L.stream_ptr(dev)), "phc_bn_bwd")
+        L.check(lib.phc_bn_bwd(L.ptr(dout_), L.ptr(x_), L.ptr(save_stat), L.ptr(n_valid), N, h, 1 if training else 0, act,
+                               L.ptr(dx), L.ptr(dwb), L.ptr(ws), ws_bytes, L.stream_ptr(dev)), "phc_bn_bwd")
         if L.PROF_ON:
             L.account("bn_bwd_partial", 6.0 * N * h, 8.0 * N * h)
             L.account("bn_bwd_apply", 8.0 * N * h, 12.0 * N * h)

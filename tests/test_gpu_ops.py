@@ -91,6 +91,68 @@ def test_phm_linear_is_deterministic(ops):
         assert all(torch.equal(a, b) for a, b in zip(o, outs[0]))
 
 
+def test_deferred_param_grads_match_oracle_and_per_layer_path(ops):
+    """phc_phm_param_grads (all layers' dW/dA/db in three batched launches, filed by deferred_param_grads())
+    against the oracle and against the per-layer backward: ragged shapes, n = 1, scalar (non-float4) widths,
+    a layer without bias, a frozen phm_rule, more jobs than one launch holds, a parameter shared by two layers
+    and accumulation into an existing .grad."""
+    from oracle import phc_oracle as O
+    g = torch.Generator().manual_seed(11)
+    shapes = [(4, 32, 32, 1500), (4, 32, 32, 70), (2, 16, 24, 333), (1, 40, 8, 90), (3, 5, 7, 129), (8, 16, 16, 64),
+              (4, 32, 8, 1)] + [(4, 8, 8, 40 + 3 * i) for i in range(14)]          # 21 jobs > 16 per launch
+    layers = []
+    for li, (n, kin, kout, N) in enumerate(shapes):
+        layers.append(dict(x=torch.randn(N, n * kin, generator=g), A=torch.randn(n, n, n, generator=g),
+                           W=torch.randn(n, kin, kout, generator=g) * 0.2,
+                           b=None if li == 2 else torch.randn(n * kout, generator=g),
+                           dy=torch.randn(N, n * kout, generator=g), learn_A=li != 1))
+
+    def run(deferred, shared=False):
+        prm = []
+        for l in layers:
+            A = l["A"].to(DEV).requires_grad_(l["learn_A"])
+            W = l["W"].to(DEV).requires_grad_()
+            b = l["b"].to(DEV).requires_grad_() if l["b"] is not None else None
+            prm.append((A, W, b))
+        prm[0][1].grad = torch.full_like(prm[0][1], 0.5)                         # existing .grad: accumulate
+        xs = [l["x"].to(DEV).requires_grad_() for l in layers]
+        ctx = ops.deferred_param_grads() if deferred else __import__("contextlib").nullcontext()
+        with ctx:
+            total = 0.0
+            for l, x, (A, W, b) in zip(layers, xs, prm):
+                total = total + (ops.phm_linear(x, A, W, b) * l["dy"].to(DEV)).sum()
+            if shared:                                                             # layer 0's parameters used twice
+                total = total + (ops.phm_linear(xs[0] * 2.0, *prm[0]) * layers[0]["dy"].to(DEV)).sum()
+            total.backward()
+        return prm, xs
+
+    prm_d, xs_d = run(True)
+    prm_i, xs_i = run(False)
+    for li, (l, pd, pi) in enumerate(zip(layers, prm_d, prm_i)):
+        dx, dW, dA, db = O.phm_linear_backward(l["x"], l["A"], l["W"], l["dy"])
+        assert_close(xs_d[li].grad, dx, TOL, f"layer {li} dx")
+        assert_close(pd[1].grad, dW + (0.5 if li == 0 else 0.0), TOL, f"layer {li} dW")
+        if l["learn_A"]:
+            assert_close(pd[0].grad, dA, TOL, f"layer {li} dA")
+        else:
+            assert pd[0].grad is None
+        if l["b"] is not None:
+            assert_close(pd[2].grad, db, TOL, f"layer {li} db")
+        for a, b_ in zip(pd, pi):                                                  # batched == per-layer path
+            if a is not None and a.grad is not None:
+                assert_close(a.grad, b_.grad, 2e-6, f"layer {li} batched vs per-layer")
+    prm_s, _ = run(True, shared=True)
+    dx, dW, dA, db = O.phm_linear_backward(layers[0]["x"], layers[0]["A"], layers[0]["W"], layers[0]["dy"])
+    assert_close(prm_s[0][1].grad, 3.0 * dW + 0.5, TOL, "shared layer dW")         # x and 2x: dW + 2 dW
+    assert_close(prm_s[0][2].grad, 2.0 * db, TOL, "shared layer db")
+    # outside the block nothing is deferred; a backward that runs after the block exited takes the per-layer path
+    A, W, b = (t.detach().clone().requires_grad_() for t in prm_d[0])
+    with ops.deferred_param_grads():
+        y = ops.phm_linear(layers[0]["x"].to(DEV), A, W, b)
+    y.backward(layers[0]["dy"].to(DEV))
+    assert_close(W.grad, dW, TOL, "late backward dW")
+
+
 def _ref_sorted(key, other, num_keys):
     order = np.argsort(key, kind="stable")
     rowptr = np.zeros(num_keys + 1, dtype=np.int64)
