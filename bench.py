@@ -148,8 +148,6 @@ def main():
     cfg = harness.StepConfig(regression=bool(w.get("regression")), grad_clip=2.0, optimizer=not args.fwd_bwd_only)
     host_batches = [harness.make_batch(args.workload, seed=1000 * rank + i) for i in range(args.num_batches)]
     batches = [harness.to_device(gb, dev) for gb in host_batches]
-    for b in batches:
-        b.all_labeled = bool(b.y_mask.all().item())                   # decided once, outside the timed region
     grad_sync = make_grad_sync(model, world) if world > 1 else None
 
     graph_step = None

@@ -262,6 +262,33 @@ int phc_bn_bwd(const float *dy, const float *x, const float *save_stat, const in
                int training, int act, float *dx, float *dwb_flat, void *ws, size_t ws_bytes, void *stream);
 
 /* ------------------------------------------------------------------------- *
+ * Read-out
+ * ------------------------------------------------------------------------- */
+
+/* NaN-masked BCE-with-logits, mean over the labeled entries:
+ *   mask = ~isnan(y); loss = BCEWithLogits(logits[mask], y[mask])   (benchmarks/train_hiv.py:174-178)
+ * without the host-synchronising boolean gather.  logits, y: [total] device fp32 (y = NaN where
+ * unlabeled); loss: device scalar; stat[2] = (sum of entry losses, labeled count), consumed by the
+ * backward: dlogits = *dloss * (sigmoid(logits) - y) / count on labeled entries, 0 elsewhere.
+ * Fixed-order reductions. */
+size_t phc_bce_masked_ws_bytes(int64_t total);
+int phc_bce_masked_fwd(const float *logits, const float *y, int64_t total, float *loss, float *stat, void *ws,
+                       size_t ws_bytes, void *stream);
+int phc_bce_masked_bwd(const float *logits, const float *y, const float *dloss, const float *stat, int64_t total,
+                       float *dlogits, void *stream);
+
+/* Gated per-graph sum of PHMSoftAttentionPooling (phc/hypercomplex/pooling.py:57-66):
+ *   out[g, c*k + j] = sum_{r : batch[r] = g} x[r, c*k + j] * sigmoid(gate[r, j]),   k = h / n_comp
+ * x [N, h], gate [N, k] (the pre-sigmoid gate), rows grouped by graph: seg_ptr [num_graphs + 1]
+ * (phc_segment_ptr_sorted or phc_csr_build on `batch`).  Replaces sigmoid + broadcast multiply +
+ * global_add_pool, and in the backward the row gather + two multiplies + component sum +
+ * sigmoid_backward.  dx / dgate may be NULL. */
+int phc_gated_pool_fwd(const float *x, const float *gate, const int32_t *seg_ptr, int64_t num_graphs, int h,
+                       int n_comp, float *out, void *stream);
+int phc_gated_pool_bwd(const float *dout, const float *x, const float *gate, const int32_t *seg_ptr,
+                       int64_t num_graphs, int h, int n_comp, float *dx, float *dgate, void *stream);
+
+/* ------------------------------------------------------------------------- *
  * Opt-in launch profiler (process-global).  When enabled every kernel launch
  * made through this library is bracketed by two hipEvents on ITS stream;
  * phc_prof_read synchronises those events and returns per-kernel totals.

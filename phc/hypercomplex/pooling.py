@@ -55,10 +55,9 @@ class PHMSoftAttentionPooling(nn.Module):
         self.linear.reset_parameters()
 
     def forward(self, x: torch.Tensor, batch, num_graphs: Optional[int] = None, is_sorted: bool = False) -> torch.Tensor:
-        gate = self.sigmoid(self.real_trafo(self.linear(x)))                   # [N, embed_dim / phm_dim]
-        k = self.embed_dim // self.phm_dim
-        gated = (x.view(x.size(0), self.phm_dim, k) * gate.unsqueeze(1)).view(x.size(0), self.embed_dim)
-        return self.sum_pooling(gated, batch=batch, num_graphs=num_graphs, is_sorted=is_sorted)
+        gate = self.real_trafo(self.linear(x))                                 # pre-sigmoid [N, embed_dim / phm_dim]
+        # sigmoid, broadcast over the components, multiply and per-graph sum in one engine pass
+        return _engine.gated_segment_sum(x, gate, batch, self.phm_dim, num_graphs=num_graphs, is_sorted=is_sorted)
 
     def __repr__(self):
         return "{}(embed_dim={}, phm_dim={}, phm_rule={}, learn_phm={}, bias={}, w_init='{}', c_init='{}', " \

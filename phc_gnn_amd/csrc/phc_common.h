@@ -50,6 +50,10 @@ enum KernelId : int {
     K_PACK_CODES,
     K_SOFTMAX_FWD,
     K_SOFTMAX_BWD,
+    K_BCE_FWD,
+    K_BCE_BWD,
+    K_GATED_POOL_FWD,
+    K_GATED_POOL_BWD,
     K_NUM_KERNELS
 };
 

@@ -174,7 +174,6 @@ class GraphedTrainStep:
 
     def _front(self):
         """zero_grad, forward, loss, backward (+ pack the gradients into the flat all-reduce bucket)."""
-        self.data.y_mask = ~torch.isnan(self.data.y)
         self.optimizer.zero_grad(set_to_none=True)
         with deferred_param_grads():
             logits = self.model(self.data)

@@ -12,7 +12,7 @@ import torch
 import torch.nn.functional as F
 
 from . import synth
-from .ops import deferred_param_grads
+from .ops import deferred_param_grads, masked_bce_with_logits
 
 # BASELINE.json configs -> PHMSkipConnectAdd arguments (SURVEY.md §8d "Model settings")
 WORKLOADS: Dict[str, dict] = {
@@ -72,14 +72,9 @@ def to_device(gb: synth.GraphBatch, device) -> types.SimpleNamespace:
 def loss_fn(logits: torch.Tensor, data, regression: bool = False) -> torch.Tensor:
     if regression:
         return F.l1_loss(logits, data.y)                       # benchmarks/train_zinc.py uses L1
-    mask = data.y_mask                                          # train_hiv.py:174: mask = ~isnan(y)
-    if bool(getattr(data, "all_labeled", False)):
-        return F.binary_cross_entropy_with_logits(logits, data.y)
-    # mean over the labeled entries == BCE(logits[mask], y[mask]) without the host-synchronising
+    # train_hiv.py:174-178: mask = ~isnan(y); BCE(logits[mask], y[mask]) — fused, without the host-synchronising
     # boolean gather of the reference
-    per = F.binary_cross_entropy_with_logits(logits, torch.where(mask, data.y, torch.zeros_like(data.y)),
-                                             reduction="none")
-    return (per * mask).sum() / mask.sum()
+    return masked_bce_with_logits(logits, data.y)
 
 
 @dataclass

@@ -65,6 +65,11 @@ SIGNATURES = {
     "phc_bn_ws_bytes": (_S, [_L, _I]),
     "phc_bn_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _L, _I, _I, C.c_float, C.c_float, _I, _P, _P, _P, _P, _S, _P]),
     "phc_bn_bwd": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _S, _P]),
+    "phc_bce_masked_ws_bytes": (_S, [_L]),
+    "phc_bce_masked_fwd": (_I, [_P, _P, _L, _P, _P, _P, _S, _P]),
+    "phc_bce_masked_bwd": (_I, [_P, _P, _P, _P, _L, _P, _P]),
+    "phc_gated_pool_fwd": (_I, [_P, _P, _P, _L, _I, _I, _P, _P]),
+    "phc_gated_pool_bwd": (_I, [_P, _P, _P, _P, _L, _I, _I, _P, _P, _P]),
     "phc_prof_enable": (_I, [_I]),
     "phc_prof_reset": (_I, []),
     "phc_prof_num_kernels": (_I, []),

@@ -424,6 +424,92 @@ def global_add_pool(x: torch.Tensor, batch, num_graphs: Optional[int] = None, is
     return _SegmentSumFn.apply(x, st)
 
 
+class _GatedSegmentSumFn(torch.autograd.Function):
+    """out[g, c*k+j] = Σ_{r in graph g} x[r, c*k+j]·σ(gate[r, j]) over rows that are already grouped by graph."""
+
+    @staticmethod
+    def forward(ctx, x, gate, st: SegmentStructure, n_comp: int):
+        lib = L.load()
+        dev = L.require_device(x, gate)
+        x_, g_ = L.f32c(x), L.f32c(gate)
+        N, h = x_.shape
+        if h % n_comp or tuple(g_.shape) != (N, h // n_comp):
+            raise L.PhcError(f"gate must be [{N}, {h // n_comp}] for x [{N}, {h}] with {n_comp} components")
+        seg_ptr = st.csr[0]
+        out = torch.empty((st.num_segments, h), dtype=torch.float32, device=dev)
+        L.check(lib.phc_gated_pool_fwd(L.ptr(x_), L.ptr(g_), L.ptr(seg_ptr), st.num_segments, h, n_comp, L.ptr(out),
+                                       L.stream_ptr(dev)), "phc_gated_pool_fwd")
+        if L.PROF_ON:
+            L.account("gated_pool_fwd", 2.0 * N * h, 4.0 * (N * (h + h // n_comp) + st.num_segments * h))
+        ctx.save_for_backward(x_, g_, seg_ptr)
+        ctx.meta = (st.num_segments, n_comp)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = L.load()
+        x_, g_, seg_ptr = ctx.saved_tensors
+        G, n_comp = ctx.meta
+        dout_ = L.f32c(dout)
+        dev = dout_.device
+        N, h = x_.shape
+        dx = torch.empty_like(x_) if ctx.needs_input_grad[0] else None
+        dg = torch.empty_like(g_) if ctx.needs_input_grad[1] else None
+        L.check(lib.phc_gated_pool_bwd(L.ptr(dout_), L.ptr(x_), L.ptr(g_), L.ptr(seg_ptr), G, h, n_comp, L.ptr(dx), L.ptr(dg),
+                                       L.stream_ptr(dev)), "phc_gated_pool_bwd")
+        if L.PROF_ON:
+            L.account("gated_pool_bwd", 4.0 * N * h, 4.0 * (N * (2 * h + 2 * h // n_comp) + G * h))
+        return dx, dg, None, None
+
+
+def gated_segment_sum(x: torch.Tensor, gate: torch.Tensor, batch, n_comp: int, num_graphs: Optional[int] = None,
+                      is_sorted: bool = False) -> torch.Tensor:
+    """Soft-attention read-out (phc/hypercomplex/pooling.py:57-66): per-graph sum of x scaled by σ(gate), the gate
+    [N, h/n_comp] broadcast over the n_comp components.  One kernel each way when ``batch`` is sorted (collated
+    mini-batches are); an unsorted ``batch`` takes the sigmoid / multiply / segment-sum route."""
+    st = batch if isinstance(batch, SegmentStructure) else segment_structure(batch, num_graphs, is_sorted)
+    if not st.is_sorted:
+        N, h = x.shape
+        gated = (x.view(N, n_comp, h // n_comp) * torch.sigmoid(gate).unsqueeze(1)).reshape(N, h)
+        return _SegmentSumFn.apply(gated, st)
+    return _GatedSegmentSumFn.apply(x, gate, st, n_comp)
+
+
+class _MaskedBCEFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, logits, y):
+        lib = L.load()
+        dev = L.require_device(logits, y)
+        z_, y_ = L.f32c(logits), L.f32c(y)
+        if z_.shape != y_.shape:
+            raise L.PhcError(f"logits {tuple(z_.shape)} vs labels {tuple(y_.shape)}")
+        total = z_.numel()
+        out = torch.empty(3, dtype=torch.float32, device=dev)             # loss | sum | labeled count
+        ws_bytes = lib.phc_bce_masked_ws_bytes(total)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if total > (1 << 16) else None
+        L.check(lib.phc_bce_masked_fwd(L.ptr(z_), L.ptr(y_), total, L.ptr(out), L.ptr(out) + 4, L.ptr(ws),
+                                       ws_bytes if ws is not None else 0, L.stream_ptr(dev)), "phc_bce_masked_fwd")
+        ctx.save_for_backward(z_, y_, out)
+        ctx.shape = logits.shape
+        return out[0]
+
+    @staticmethod
+    def backward(ctx, dloss):
+        lib = L.load()
+        z_, y_, out = ctx.saved_tensors
+        dl = L.f32c(dloss.reshape(1))
+        dz = torch.empty_like(z_)
+        L.check(lib.phc_bce_masked_bwd(L.ptr(z_), L.ptr(y_), L.ptr(dl), L.ptr(out) + 4, z_.numel(), L.ptr(dz),
+                                       L.stream_ptr(dz.device)), "phc_bce_masked_bwd")
+        return dz.reshape(ctx.shape), None
+
+
+def masked_bce_with_logits(logits: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """mean BCE-with-logits over the labeled entries, NaN in ``y`` = unlabeled (benchmarks/train_hiv.py:174-178:
+    ``mask = ~isnan(y); criterion(logits[mask], y[mask])``) — one kernel each way, no host synchronisation."""
+    return _MaskedBCEFn.apply(logits, y)
+
+
 # ---------------------------------------------------------------------------
 # integer-feature encoders (atom / bond embeddings) read in place
 # ---------------------------------------------------------------------------

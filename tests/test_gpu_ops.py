@@ -467,3 +467,45 @@ def test_aggregate_softmax_matches_oracle(ops, act, h):
         assert_close(gg[0], rg[0], 3e-5, "softmax dx")
         assert_close(gg[1], rg[1], 3e-5, "softmax dea")
         assert_close(gg[2], rg[2], 1e-4, "softmax dbeta")
+
+
+@pytest.mark.parametrize("shape,frac_nan", [((544, 1), 0.06), ((37, 12), 0.4), ((1100, 128), 0.7), ((5, 3), 0.0)])
+def test_masked_bce_matches_oracle(ops, shape, frac_nan):
+    """NaN-masked BCE-with-logits (train_hiv.py:174-178) fwd + bwd; (1100,128) exercises the multi-workgroup path."""
+    from oracle import phc_oracle as O
+    g = torch.Generator().manual_seed(21)
+    z = (torch.randn(shape, generator=g) * 3).requires_grad_()
+    y = (torch.rand(shape, generator=g) > 0.5).float()
+    y[torch.rand(shape, generator=g) < frac_nan] = float("nan")
+    ref = O.bce_loss_masked(z, y)
+    ref.backward()
+    zd = z.detach().to(DEV).requires_grad_()
+    loss = ops.masked_bce_with_logits(zd, y.to(DEV))
+    (loss * 1.7).backward()
+    assert_close(loss, ref, 2e-6, "loss")
+    assert_close(zd.grad, 1.7 * z.grad, TOL, "dlogits")
+    assert torch.equal(zd.grad.cpu() == 0, torch.isnan(y) | (z.grad == 0))      # unlabeled entries get exactly zero
+
+
+@pytest.mark.parametrize("n,k,is_sorted", [(4, 32, True), (2, 5, True), (1, 70, True), (4, 32, False)])
+def test_gated_segment_sum_matches_oracle(ops, n, k, is_sorted):
+    """Soft-attention read-out core (pooling.py:57-66): x * sigmoid(gate) broadcast over components, summed per
+    graph; ragged graphs incl. empty ones."""
+    g = torch.Generator().manual_seed(22)
+    sizes = [0, 3, 1, 40, 0, 17, 2, 0]
+    batch = torch.repeat_interleave(torch.arange(len(sizes)), torch.tensor(sizes))
+    N, h = batch.numel(), n * k
+    if not is_sorted:
+        batch = batch[torch.randperm(N, generator=g)]
+    x = torch.randn(N, h, generator=g).requires_grad_()
+    gate = torch.randn(N, k, generator=g).requires_grad_()
+    gated = (x.view(N, n, k) * torch.sigmoid(gate).unsqueeze(1)).reshape(N, h)
+    ref = torch.zeros(len(sizes), h).index_add(0, batch, gated)
+    dout = torch.randn(len(sizes), h, generator=g)
+    ref.backward(dout)
+    xd, gd = x.detach().to(DEV).requires_grad_(), gate.detach().to(DEV).requires_grad_()
+    out = ops.gated_segment_sum(xd, gd, batch.to(DEV), n, num_graphs=len(sizes), is_sorted=is_sorted)
+    out.backward(dout.to(DEV))
+    assert_close(out, ref, TOL, "pooled")
+    assert_close(xd.grad, x.grad, TOL, "dx")
+    assert_close(gd.grad, gate.grad, TOL, "dgate")
