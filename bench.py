@@ -40,7 +40,7 @@ PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
 MFMA_KERNELS = ("phm_gemm_fwd", "phm_gemm_dx", "phm_dH_partial", "table_grad")
 # launch-profiler kernel name -> substring of the rocprofv3 kernel name in profiles/r01_pmc_traffic.json
 PMC_NAMES = {"phm_gemm_fwd": "phm_stream_kernel<0, 4", "phm_gemm_dx": "phm_stream_kernel<1, 4",
-             "phm_dH_partial": "phm_dH_partial_kernel", "aggregate_enc_fwd": "aggregate_enc_fwd_kernel",
+             "phm_dH_partial": "phm_grads_partial_kernel", "aggregate_enc_fwd": "aggregate_enc_fwd_kernel",
              "aggregate_enc_dx": "aggregate_enc_dx_kernel", "aggregate_fwd": "aggregate_fwd_kernel",
              "bn_apply": "bn_apply_kernel", "bn_bwd_apply": "bn_bwd_apply_kernel", "bn_bwd_partial": "bn_bwd_partial_kernel",
              "bn_stats_partial": "bn_stats_partial_kernel", "table_grad": "table_grad_mfma_kernel<1"}

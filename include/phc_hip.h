@@ -290,10 +290,11 @@ int phc_bce_masked_bwd(const float *logits, const float *y, const float *dloss, 
  * x [N, h], gate [N, k] (the pre-sigmoid gate), rows grouped by graph: seg_ptr [num_graphs + 1]
  * (phc_segment_ptr_sorted or phc_csr_build on `batch`).  Replaces sigmoid + broadcast multiply +
  * global_add_pool, and in the backward the row gather + two multiplies + component sum +
- * sigmoid_backward.  dx / dgate may be NULL. */
+ * sigmoid_backward (row-parallel: the graph of a row comes from the int64 `batch` vector).
+ * dx / dgate may be NULL. */
 int phc_gated_pool_fwd(const float *x, const float *gate, const int32_t *seg_ptr, int64_t num_graphs, int h,
                        int n_comp, float *out, void *stream);
-int phc_gated_pool_bwd(const float *dout, const float *x, const float *gate, const int32_t *seg_ptr,
+int phc_gated_pool_bwd(const float *dout, const float *x, const float *gate, const int64_t *batch, int64_t N,
                        int64_t num_graphs, int h, int n_comp, float *dx, float *dgate, void *stream);
 
 /* ------------------------------------------------------------------------- *

@@ -775,6 +775,7 @@ static int launch_gemm(const float *X, const float *A, const float *W, const flo
     else                                                                                                                 \
         launch_gemm_cfg<TRANS, NP, 64, 64>(X, A, W, bias, residual, out, M, K, Nout, n, kin, kout, 2, s)
     switch (n) {
+        case 1: PHC_GEMM_LAUNCH(1); break;                  // dense maps (the hypercomplex -> real heads)
         case 2: PHC_GEMM_LAUNCH(2); break;
         case 4: PHC_GEMM_LAUNCH(4); break;
         case 8: PHC_GEMM_LAUNCH(8); break;

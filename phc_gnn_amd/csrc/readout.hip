@@ -92,51 +92,101 @@ __global__ __launch_bounds__(256) void bce_masked_bwd_kernel(const float *__rest
 
 // ---- gated per-graph sum --------------------------------------------------------------------------
 // out[g, c*k + j] = sum_{r in segment g} x[r, c*k + j] * sigmoid(gate[r, j])      (rows grouped by graph: seg_ptr)
-// one workgroup per graph; thread -> column (h <= 1024), rows walked in order: fixed summation order.
-__global__ __launch_bounds__(256) void gated_pool_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gate,
-                                                           const int *__restrict__ seg_ptr, int h, int k,
-                                                           float *__restrict__ out) {
-    const int g = blockIdx.x;
+// One workgroup per graph: thread -> (column slot, row lane); 8 row lanes walk the graph's rows and are summed in
+// lane order through LDS: fixed summation order.  h <= GP_MAX_H per pass (wider rows loop over column blocks).
+constexpr int GP_THREADS = 256;
+
+template <int VEC>
+__global__ __launch_bounds__(GP_THREADS) void gated_pool_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gate,
+                                                                  const int *__restrict__ seg_ptr, int h, int k,
+                                                                  float *__restrict__ out) {
+    __shared__ float red[VEC * GP_THREADS];
+    const int g = blockIdx.x, tid = threadIdx.x;
     const int r0 = seg_ptr[g], r1 = seg_ptr[g + 1];
-    for (int col = threadIdx.x; col < h; col += 256) {
-        const int j = col % k;
-        float acc = 0.f;
-        int r = r0;
-        for (; r + 4 <= r1; r += 4) {                        // four rows in flight
-            float xv[4], gv[4];
+    const int hv = h / VEC;
+    for (int cbase = 0; cbase < hv; cbase += GP_THREADS) {
+        const int cols = min(GP_THREADS, hv - cbase);
+        const int lanes = GP_THREADS / cols;
+        const int cs = tid % cols, rl = tid / cols;
+        const int col = (cbase + cs) * VEC;
+        const int j = col % k;                               // VEC | k: the VEC columns share one component
+        float acc[VEC];
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                xv[t] = x[(size_t)(r + t) * h + col];
-                gv[t] = gate[(size_t)(r + t) * k + j];
+        for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
+        if (rl < lanes) {
+#pragma unroll 2
+            for (int r = r0 + rl; r < r1; r += lanes) {
+                float xv[VEC], gv[VEC];
+                if constexpr (VEC == 4) {
+                    const float4 a = *reinterpret_cast<const float4 *>(x + (size_t)r * h + col);
+                    const float4 b = *reinterpret_cast<const float4 *>(gate + (size_t)r * k + j);
+                    xv[0] = a.x; xv[1] = a.y; xv[2] = a.z; xv[3] = a.w;
+                    gv[0] = b.x; gv[1] = b.y; gv[2] = b.z; gv[3] = b.w;
+                } else {
+                    xv[0] = x[(size_t)r * h + col];
+                    gv[0] = gate[(size_t)r * k + j];
+                }
+#pragma unroll
+                for (int v = 0; v < VEC; ++v) acc[v] = fmaf(xv[v], 1.f / (1.f + expf(-gv[v])), acc[v]);
             }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) acc = fmaf(xv[t], 1.f / (1.f + expf(-gv[t])), acc);
         }
-        for (; r < r1; ++r) acc = fmaf(x[(size_t)r * h + col], 1.f / (1.f + expf(-gate[(size_t)r * k + j])), acc);
-        out[(size_t)g * h + col] = acc;
+        __syncthreads();
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) red[v * GP_THREADS + tid] = acc[v];
+        __syncthreads();
+        for (int e = tid; e < cols * VEC; e += GP_THREADS) {
+            const int cc = e / VEC, v = e - cc * VEC;
+            float a = 0.f;
+            for (int l = 0; l < lanes; ++l) a += red[v * GP_THREADS + l * cols + cc];          // fixed order
+            out[(size_t)g * h + (cbase + cc) * VEC + v] = a;
+        }
     }
 }
 
 // dx[r, c*k+j] = dout[g(r), c*k+j] * s_j ;  dgate[r, j] = s_j (1 - s_j) * sum_c dout[g(r), c*k+j] * x[r, c*k+j]
-// one workgroup per graph, one wavefront per row (strided), lane -> gate column j.
+// Row-parallel: thread -> (row, VEC gate columns), graph id from the int64 `batch` vector.
+template <int VEC>
 __global__ __launch_bounds__(256) void gated_pool_bwd_kernel(const float *__restrict__ dout, const float *__restrict__ x,
-                                                           const float *__restrict__ gate, const int *__restrict__ seg_ptr,
-                                                           int h, int k, int n_comp, float *__restrict__ dx,
+                                                           const float *__restrict__ gate, const long long *__restrict__ batch,
+                                                           long long N, int h, int k, int n_comp, float *__restrict__ dx,
                                                            float *__restrict__ dgate) {
-    const int g = blockIdx.x;
-    const int r0 = seg_ptr[g], r1 = seg_ptr[g + 1];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int r = r0 + wave; r < r1; r += 4) {
-        for (int j = lane; j < k; j += 64) {
-            const float s = 1.f / (1.f + expf(-gate[(size_t)r * k + j]));
-            float dg = 0.f;
-            for (int c = 0; c < n_comp; ++c) {
-                const int col = c * k + j;
+    const int kv = k / VEC;
+    const long long total = N * kv;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long r = e / kv;
+        const int j = (int)(e - r * kv) * VEC;
+        const long long g = batch[r];
+        float s[VEC], dg[VEC];
+        if constexpr (VEC == 4) {
+            const float4 gv = *reinterpret_cast<const float4 *>(gate + (size_t)r * k + j);
+            s[0] = 1.f / (1.f + expf(-gv.x)); s[1] = 1.f / (1.f + expf(-gv.y));
+            s[2] = 1.f / (1.f + expf(-gv.z)); s[3] = 1.f / (1.f + expf(-gv.w));
+        } else {
+            s[0] = 1.f / (1.f + expf(-gate[(size_t)r * k + j]));
+        }
+#pragma unroll
+        for (int v = 0; v < VEC; ++v) dg[v] = 0.f;
+        for (int c = 0; c < n_comp; ++c) {
+            const int col = c * k + j;
+            if constexpr (VEC == 4) {
+                const float4 d = *reinterpret_cast<const float4 *>(dout + (size_t)g * h + col);
+                const float4 xv = *reinterpret_cast<const float4 *>(x + (size_t)r * h + col);
+                dg[0] = fmaf(d.x, xv.x, dg[0]); dg[1] = fmaf(d.y, xv.y, dg[1]);
+                dg[2] = fmaf(d.z, xv.z, dg[2]); dg[3] = fmaf(d.w, xv.w, dg[3]);
+                if (dx) *reinterpret_cast<float4 *>(dx + (size_t)r * h + col) = make_float4(d.x * s[0], d.y * s[1], d.z * s[2], d.w * s[3]);
+            } else {
                 const float d = dout[(size_t)g * h + col];
-                dg = fmaf(d, x[(size_t)r * h + col], dg);
-                if (dx) dx[(size_t)r * h + col] = d * s;
+                dg[0] = fmaf(d, x[(size_t)r * h + col], dg[0]);
+                if (dx) dx[(size_t)r * h + col] = d * s[0];
             }
-            if (dgate) dgate[(size_t)r * k + j] = dg * s * (1.f - s);
+        }
+        if (dgate) {
+            if constexpr (VEC == 4)
+                *reinterpret_cast<float4 *>(dgate + (size_t)r * k + j) =
+                    make_float4(dg[0] * s[0] * (1.f - s[0]), dg[1] * s[1] * (1.f - s[1]), dg[2] * s[2] * (1.f - s[2]),
+                                dg[3] * s[3] * (1.f - s[3]));
+            else
+                dgate[(size_t)r * k + j] = dg[0] * s[0] * (1.f - s[0]);
         }
     }
 }
@@ -179,26 +229,45 @@ int phc_bce_masked_bwd(const float *logits, const float *y, const float *dloss, 
     return check_launch("bce_masked_bwd");
 }
 
+static bool gp_vec4(int h, int k, const void *a, const void *b, const void *c, const void *d) {
+    return (k % 4 == 0) && (h % 4 == 0) && ((reinterpret_cast<uintptr_t>(a) & 15) == 0) && ((reinterpret_cast<uintptr_t>(b) & 15) == 0) &&
+           ((reinterpret_cast<uintptr_t>(c) & 15) == 0) && ((reinterpret_cast<uintptr_t>(d) & 15) == 0);
+}
+
 int phc_gated_pool_fwd(const float *x, const float *gate, const int32_t *seg_ptr, int64_t num_graphs, int h, int n_comp, float *out,
                        void *stream) {
     PHC_REQUIRE(num_graphs >= 0 && h >= 1 && n_comp >= 1 && h % n_comp == 0, PHC_ERR_INVALID_ARG, "phc_gated_pool_fwd: bad shape");
     if (num_graphs == 0) return PHC_OK;
     PHC_REQUIRE(x && gate && seg_ptr && out, PHC_ERR_INVALID_ARG, "phc_gated_pool_fwd: null pointer");
     hipStream_t s = (hipStream_t)stream;
+    const int k = h / n_comp;
     ProfScope prof(K_GATED_POOL_FWD, s);
-    PHC_LAUNCH(gated_pool_fwd_kernel, dim3((unsigned)num_graphs), dim3(256), 0, s, x, gate, seg_ptr, h, h / n_comp, out);
+    if (gp_vec4(h, k, x, gate, out, nullptr))
+        PHC_LAUNCH((gated_pool_fwd_kernel<4>), dim3((unsigned)num_graphs), dim3(GP_THREADS), 0, s, x, gate, seg_ptr, h, k, out);
+    else
+        PHC_LAUNCH((gated_pool_fwd_kernel<1>), dim3((unsigned)num_graphs), dim3(GP_THREADS), 0, s, x, gate, seg_ptr, h, k, out);
     return check_launch("gated_pool_fwd");
 }
 
-int phc_gated_pool_bwd(const float *dout, const float *x, const float *gate, const int32_t *seg_ptr, int64_t num_graphs, int h,
-                       int n_comp, float *dx, float *dgate, void *stream) {
-    PHC_REQUIRE(num_graphs >= 0 && h >= 1 && n_comp >= 1 && h % n_comp == 0, PHC_ERR_INVALID_ARG, "phc_gated_pool_bwd: bad shape");
-    if (num_graphs == 0 || (!dx && !dgate)) return PHC_OK;
-    PHC_REQUIRE(dout && x && gate && seg_ptr, PHC_ERR_INVALID_ARG, "phc_gated_pool_bwd: null pointer");
+int phc_gated_pool_bwd(const float *dout, const float *x, const float *gate, const int64_t *batch, int64_t N, int64_t num_graphs,
+                       int h, int n_comp, float *dx, float *dgate, void *stream) {
+    PHC_REQUIRE(N >= 0 && num_graphs >= 0 && h >= 1 && n_comp >= 1 && h % n_comp == 0, PHC_ERR_INVALID_ARG,
+                "phc_gated_pool_bwd: bad shape");
+    if (N == 0 || (!dx && !dgate)) return PHC_OK;
+    PHC_REQUIRE(dout && x && gate && batch, PHC_ERR_INVALID_ARG, "phc_gated_pool_bwd: null pointer");
     hipStream_t s = (hipStream_t)stream;
+    const int k = h / n_comp;
+    const bool v4 = gp_vec4(h, k, x, gate, dout, dx) && ((reinterpret_cast<uintptr_t>(dgate) & 15) == 0);
+    long long blocks = (N * (long long)(k / (v4 ? 4 : 1)) + 255) / 256;
+    if (blocks > 4096) blocks = 4096;
+    if (blocks < 1) blocks = 1;
     ProfScope prof(K_GATED_POOL_BWD, s);
-    PHC_LAUNCH(gated_pool_bwd_kernel, dim3((unsigned)num_graphs), dim3(256), 0, s, dout, x, gate, seg_ptr, h, h / n_comp, n_comp, dx,
-               dgate);
+    if (v4)
+        PHC_LAUNCH((gated_pool_bwd_kernel<4>), dim3((unsigned)blocks), dim3(256), 0, s, dout, x, gate,
+                   reinterpret_cast<const long long *>(batch), (long long)N, h, k, n_comp, dx, dgate);
+    else
+        PHC_LAUNCH((gated_pool_bwd_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, s, dout, x, gate,
+                   reinterpret_cast<const long long *>(batch), (long long)N, h, k, n_comp, dx, dgate);
     return check_launch("gated_pool_bwd");
 }
 

@@ -69,7 +69,7 @@ SIGNATURES = {
     "phc_bce_masked_fwd": (_I, [_P, _P, _L, _P, _P, _P, _S, _P]),
     "phc_bce_masked_bwd": (_I, [_P, _P, _P, _P, _L, _P, _P]),
     "phc_gated_pool_fwd": (_I, [_P, _P, _P, _L, _I, _I, _P, _P]),
-    "phc_gated_pool_bwd": (_I, [_P, _P, _P, _P, _L, _I, _I, _P, _P, _P]),
+    "phc_gated_pool_bwd": (_I, [_P, _P, _P, _P, _L, _L, _I, _I, _P, _P, _P]),
     "phc_prof_enable": (_I, [_I]),
     "phc_prof_reset": (_I, []),
     "phc_prof_num_kernels": (_I, []),

@@ -441,21 +441,21 @@ class _GatedSegmentSumFn(torch.autograd.Function):
                                        L.stream_ptr(dev)), "phc_gated_pool_fwd")
         if L.PROF_ON:
             L.account("gated_pool_fwd", 2.0 * N * h, 4.0 * (N * (h + h // n_comp) + st.num_segments * h))
-        ctx.save_for_backward(x_, g_, seg_ptr)
+        ctx.save_for_backward(x_, g_, st.batch)
         ctx.meta = (st.num_segments, n_comp)
         return out
 
     @staticmethod
     def backward(ctx, dout):
         lib = L.load()
-        x_, g_, seg_ptr = ctx.saved_tensors
+        x_, g_, batch = ctx.saved_tensors
         G, n_comp = ctx.meta
         dout_ = L.f32c(dout)
         dev = dout_.device
         N, h = x_.shape
         dx = torch.empty_like(x_) if ctx.needs_input_grad[0] else None
         dg = torch.empty_like(g_) if ctx.needs_input_grad[1] else None
-        L.check(lib.phc_gated_pool_bwd(L.ptr(dout_), L.ptr(x_), L.ptr(g_), L.ptr(seg_ptr), G, h, n_comp, L.ptr(dx), L.ptr(dg),
+        L.check(lib.phc_gated_pool_bwd(L.ptr(dout_), L.ptr(x_), L.ptr(g_), L.ptr(batch), N, G, h, n_comp, L.ptr(dx), L.ptr(dg),
                                        L.stream_ptr(dev)), "phc_gated_pool_bwd")
         if L.PROF_ON:
             L.account("gated_pool_bwd", 4.0 * N * h, 4.0 * (N * (2 * h + 2 * h // n_comp) + G * h))
