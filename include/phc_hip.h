@@ -89,6 +89,25 @@ int phc_phm_linear_bwd(const float *x, const float *A, const float *W, const flo
                        float *dx, float *dW, float *dA, float *db,
                        void *ws, size_t ws_bytes, void *stream);
 
+/* Operand matrices of MANY PHM layers in one launch: H = sum_i A_i (x) W_i  [n*kin, n*kout] and, when
+ * HT is not NULL, its transpose [n*kout, n*kin].  A training step builds them once, right after the
+ * weights changed, and runs every y = x.H (and dx = dy.H^T) of the step with phc_gemm_prebuilt: the
+ * GEMM then loads its operand panel with one round of coalesced reads instead of assembling it from
+ * A and W in every workgroup (3.6 us of a 13 us launch at molecule scale).  `jobs`: HOST array. */
+typedef struct phc_phm_H_job {
+    const float *A, *W;            /* device: [n,n,n], [n,kin,kout] */
+    float *H, *HT;                 /* device outputs; HT may be NULL */
+    int32_t n, kin, kout, reserved;
+} phc_phm_H_job;
+int phc_phm_build_H_batched(const phc_phm_H_job *jobs, int num_jobs, void *stream);
+
+/* y[N, Nout] = x[N, K] . M[K, Nout] (+ b[Nout]) (+ residual[N, Nout]) with a prebuilt row-major M
+ * (H for the forward, H^T for dx; is_dx only labels the launch for the profiler).  Streaming MFMA
+ * kernel; K <= 128, K % 4 == 0, x and M 16-byte aligned — otherwise PHC_ERR_UNSUPPORTED and the
+ * caller uses phc_phm_linear_fwd / _bwd. */
+int phc_gemm_prebuilt(const float *x, const float *M, const float *b, const float *residual, int64_t N, int K,
+                      int Nout, float *y, int is_dx, void *stream);
+
 /* The parameter gradients (dW, dA, db) of MANY PHM linear layers in three launches.
  * They are off the backward pass's critical path (only the optimizer reads them), and at
  * molecule scale one layer's dH = x^T.dy cannot fill 256 CUs: a training step runs

@@ -358,9 +358,33 @@ __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
         bias4[ct] = (bias && out_vec4) ? *reinterpret_cast<const float4 *>(bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
 
-    for (int i = tid; i < n * n * n; i += THREADS) As[i] = A[i];
-    __syncthreads();
-    build_h_chunk<TRANS, NPHM, BN, THREADS>(As, W, hs, n, kin, kout, 0, K, round_up(K, 8), j0, Nout, tid);
+#ifndef PHC_EXP_NO_HBUILD
+    if constexpr (NPHM < 0) {
+        // prebuilt operand (phc_phm_build_H_batched): W points at a row-major [K, Nout] matrix; the panel is one
+        // round of coalesced loads instead of the A -> W -> assemble chain (3.6 us of a 13 us launch at molecule scale)
+        const int K8 = round_up(K, 8);
+        if ((Nout & 3) == 0) {
+            constexpr int C4 = BN / 4;
+            for (int e = tid; e < K8 * C4; e += THREADS) {
+                const int k = e / C4, c4 = e - k * C4;
+                const int col = j0 + c4 * 4;
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+                if (k < K && col < Nout) v = *reinterpret_cast<const float4 *>(W + (size_t)k * Nout + col);
+                float *d = hs + k * HS_STRIDE + c4 * 4;
+                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            }
+        } else {
+            for (int e = tid; e < K8 * BN; e += THREADS) {
+                const int k = e / BN, jj = e - k * BN;
+                hs[k * HS_STRIDE + jj] = (k < K && j0 + jj < Nout) ? W[(size_t)k * Nout + j0 + jj] : 0.f;
+            }
+        }
+    } else {
+        for (int i = tid; i < n * n * n; i += THREADS) As[i] = A[i];
+        __syncthreads();
+        build_h_chunk<TRANS, (NPHM < 0 ? 0 : NPHM), BN, THREADS>(As, W, hs, n, kin, kout, 0, K, round_up(K, 8), j0, Nout, tid);
+    }
+#endif
     __syncthreads();
 
     for (; slab < num_slabs; slab += slab_step) {
@@ -467,6 +491,39 @@ __global__ void phm_build_H_kernel(const float *__restrict__ A, const float *__r
         const int k = (int)(e / out), j = (int)(e - (long long)k * out);
         H[e] = h_element<0>(As, W, n, kin, kout, k, j);
     }
+}
+
+// H and H^T of MANY layers in one launch (phc_phm_build_H_batched): the operand matrices of a whole
+// training step are assembled once, right after the weights changed, and every GEMM of the step
+// loads its panel from them.
+constexpr int H_JOBS_PER_LAUNCH = 16;
+struct HJobDev {
+    const float *A, *W;
+    float *H, *HT;
+    int n, kin, kout;
+    unsigned blk0;
+};
+struct HBatch {
+    int num;
+    HJobDev j[H_JOBS_PER_LAUNCH];
+};
+
+__global__ __launch_bounds__(256) void phm_build_H_batched_kernel(HBatch b) {
+    int job = 0;
+    for (int q = 1; q < b.num; ++q)
+        if (blockIdx.x >= b.j[q].blk0) job = q;
+    const HJobDev &jb = b.j[job];
+    const int n = jb.n, kin = jb.kin, kout = jb.kout;
+    const int in = n * kin, out = n * kout;
+    const int e = (blockIdx.x - jb.blk0) * 256 + threadIdx.x;
+    if (e >= in * out) return;
+    const int k = e / out, jc = e - k * out;
+    const int a = k / kin, kap = k - a * kin;
+    const int c = jc / kout, pi = jc - c * kout;
+    float hsum = 0.f;
+    for (int i = 0; i < n; ++i) hsum = fmaf(jb.A[(i * n + a) * n + c], jb.W[((size_t)i * kin + kap) * kout + pi], hsum);
+    jb.H[e] = hsum;
+    if (jb.HT) jb.HT[(size_t)jc * in + k] = hsum;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -936,6 +993,49 @@ int phc_phm_linear_bwd(const float *x, const float *A, const float *W, const flo
         }
     }
     return PHC_OK;
+}
+
+// ---- prebuilt operand matrices --------------------------------------------------------------
+int phc_phm_build_H_batched(const phc_phm_H_job *jobs, int num_jobs, void *stream) {
+    PHC_REQUIRE(num_jobs >= 0 && (num_jobs == 0 || jobs), PHC_ERR_INVALID_ARG, "phc_phm_build_H_batched: bad job table");
+    hipStream_t s = (hipStream_t)stream;
+    for (int c0 = 0; c0 < num_jobs; c0 += H_JOBS_PER_LAUNCH) {
+        const int cn = num_jobs - c0 < H_JOBS_PER_LAUNCH ? num_jobs - c0 : H_JOBS_PER_LAUNCH;
+        HBatch b;
+        b.num = cn;
+        unsigned blocks = 0;
+        for (int k = 0; k < cn; ++k) {
+            const phc_phm_H_job &jb = jobs[c0 + k];
+            int rc = check_phm_dims("phc_phm_build_H_batched", 1, jb.n, jb.kin, jb.kout);
+            if (rc) return rc;
+            PHC_REQUIRE(jb.A && jb.W && jb.H, PHC_ERR_INVALID_ARG, "phc_phm_build_H_batched: job %d: null pointer", c0 + k);
+            b.j[k].A = jb.A; b.j[k].W = jb.W; b.j[k].H = jb.H; b.j[k].HT = jb.HT;
+            b.j[k].n = jb.n; b.j[k].kin = jb.kin; b.j[k].kout = jb.kout;
+            b.j[k].blk0 = blocks;
+            blocks += (unsigned)(((size_t)jb.n * jb.kin * jb.n * jb.kout + 255) / 256);
+        }
+        ProfScope prof(K_PHM_BUILD_H, s);
+        PHC_LAUNCH(phm_build_H_batched_kernel, dim3(blocks), dim3(256), 0, s, b);
+        int rc = check_launch("phm_build_H_batched");
+        if (rc) return rc;
+    }
+    return PHC_OK;
+}
+
+int phc_gemm_prebuilt(const float *x, const float *M, const float *b, const float *residual, int64_t N, int K, int Nout, float *y,
+                      int is_dx, void *stream) {
+    PHC_REQUIRE(N >= 0 && K >= 1 && Nout >= 1, PHC_ERR_INVALID_ARG, "phc_gemm_prebuilt: bad shape");
+    if (N == 0) return PHC_OK;
+    PHC_REQUIRE(x && M && y, PHC_ERR_INVALID_ARG, "phc_gemm_prebuilt: null pointer");
+    PHC_REQUIRE(K <= 128 && K % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(M) & 15) == 0,
+                PHC_ERR_UNSUPPORTED, "phc_gemm_prebuilt: needs K <= 128, K %% 4 == 0 and 16-byte aligned x, M (K=%d)", K);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(is_dx ? K_PHM_GEMM_DX : K_PHM_GEMM_FWD, s);
+    if (N >= GEMM_BIG_M && Nout > 64)
+        launch_stream_cfg<0, -1, 128, 8>(x, nullptr, M, b, residual, y, N, K, Nout, 1, K, Nout, 1, s);
+    else
+        launch_stream_cfg<0, -1, 64, 4>(x, nullptr, M, b, residual, y, N, K, Nout, 1, K, Nout, 2, s);
+    return check_launch("phc_gemm_prebuilt");
 }
 
 // ---- batched parameter gradients ------------------------------------------------------------

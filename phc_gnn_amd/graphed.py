@@ -30,7 +30,7 @@ import torch
 from . import synth
 from .graph import clear_structure_cache
 from .harness import StepConfig, loss_fn
-from .ops import deferred_param_grads
+from .ops import deferred_param_grads, phm_pairs, prebuilt_H
 
 
 def bucket_shape(batches: List[synth.GraphBatch], slack: float = 0.02, multiple: int = 128):
@@ -132,6 +132,7 @@ class GraphedTrainStep:
             n_valid_graphs=torch.tensor(B, dtype=torch.int32, device=dev), all_labeled=False)
         self.loss = None
         self.device = dev
+        self._pairs = phm_pairs(model)
         self.replay_stream = torch.cuda.Stream(device=dev)     # never the capture stream, never the null stream
         if os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "1") != "0":
             warnings.warn("DEBUG_CLR_GRAPH_PACKET_CAPTURE is not 0: on HIP 7.0 pipelined hipGraph replays race with the "
@@ -175,7 +176,7 @@ class GraphedTrainStep:
     def _front(self):
         """zero_grad, forward, loss, backward (+ pack the gradients into the flat all-reduce bucket)."""
         self.optimizer.zero_grad(set_to_none=True)
-        with deferred_param_grads():
+        with prebuilt_H(self._pairs), deferred_param_grads():
             logits = self.model(self.data)
             loss = loss_fn(logits, self.data, self.cfg.regression)
             loss.backward()

@@ -12,7 +12,7 @@ import torch
 import torch.nn.functional as F
 
 from . import synth
-from .ops import deferred_param_grads, masked_bce_with_logits
+from .ops import deferred_param_grads, masked_bce_with_logits, phm_pairs, prebuilt_H
 
 # BASELINE.json configs -> PHMSkipConnectAdd arguments (SURVEY.md §8d "Model settings")
 WORKLOADS: Dict[str, dict] = {
@@ -93,7 +93,8 @@ def train_step(model, data, optimizer: Optional[torch.optim.Optimizer], cfg: Ste
     else:
         for p in model.parameters():
             p.grad = None
-    with deferred_param_grads():            # PHM dW/dA/db of all layers: three batched launches after the backward pass
+    # operand matrices of all PHM layers: one launch; dW/dA/db of all layers: three batched launches after the backward
+    with prebuilt_H(phm_pairs(model)), deferred_param_grads():
         logits = model(data)
         loss = loss_fn(logits, data, cfg.regression)
         loss.backward()

@@ -33,6 +33,12 @@ class GradJob(C.Structure):
                 ("N", _L), ("n", C.c_int32), ("kin", C.c_int32), ("kout", C.c_int32), ("reserved", C.c_int32)]
 
 
+class HJob(C.Structure):
+    """phc_phm_H_job (include/phc_hip.h)."""
+    _fields_ = [("A", _P), ("W", _P), ("H", _P), ("HT", _P),
+                ("n", C.c_int32), ("kin", C.c_int32), ("kout", C.c_int32), ("reserved", C.c_int32)]
+
+
 SIGNATURES = {
     "phc_version": (_I, []),
     "phc_error_string": (C.c_char_p, [_I]),
@@ -42,6 +48,8 @@ SIGNATURES = {
     "phc_phm_linear_fwd": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P]),
     "phc_phm_linear_bwd_ws_bytes": (_S, [_L, _I, _I, _I]),
     "phc_phm_linear_bwd": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _S, _P]),
+    "phc_phm_build_H_batched": (_I, [C.POINTER(HJob), _I, _P]),
+    "phc_gemm_prebuilt": (_I, [_P, _P, _P, _P, _L, _I, _I, _P, _I, _P]),
     "phc_phm_param_grads_ws_bytes": (_S, [C.POINTER(GradJob), _I]),
     "phc_phm_param_grads": (_I, [C.POINTER(GradJob), _I, _P, _S, _P]),
     "phc_csr_ws_bytes": (_S, [_L, _L]),
@@ -81,9 +89,11 @@ _lib: Optional[C.CDLL] = None
 
 def load() -> C.CDLL:
     """Load libphc_hip.so (once).  Raises PhcError when it has not been built."""
-    global _lib
+    global _lib, LIB_PATH
     if _lib is not None:
         return _lib
+    if os.environ.get("PHC_LIB_PATH"):                      # experiments: a differently built engine (scripts/exp)
+        LIB_PATH = os.environ["PHC_LIB_PATH"]
     if not os.path.exists(LIB_PATH):
         raise PhcError(
             f"{LIB_PATH} not found: the HIP engine is not built (run `python -m phc_gnn_amd.build`). "

@@ -113,6 +113,70 @@ def _flush_param_grads(jobs) -> None:
 
 
 # ---------------------------------------------------------------------------
+# Prebuilt operand matrices
+# ---------------------------------------------------------------------------
+# H = Σ_i A_i ⊗ W_i only changes when the optimizer steps.  Inside ``prebuilt_H(pairs)`` H and Hᵀ of every listed
+# (phm_rule, W) pair are assembled by ONE launch and each PHM layer's forward / dx GEMM loads its operand panel
+# from them (phc_gemm_prebuilt) instead of re-assembling it from A and W in every workgroup.  The block must not
+# span an in-place update of the weights (one training step: forward + backward, optimizer step after it).
+class _Prebuilt:
+    def __init__(self):
+        self.table = {}
+
+
+_PREBUILT = _Prebuilt()
+
+
+def phm_pairs(model) -> list:
+    """(phm_rule, W) of every PHM linear layer of ``model`` (modules exposing both as fp32 parameters / tensors)."""
+    pairs = []
+    for m in model.modules():
+        A, W = getattr(m, "phm_rule", None), getattr(m, "W", None)
+        if torch.is_tensor(A) and torch.is_tensor(W) and W.dim() == 3 and A.dim() == 3:
+            pairs.append((A, W))
+    return pairs
+
+
+@contextlib.contextmanager
+def prebuilt_H(pairs):
+    if _PREBUILT.table or not pairs:                       # nested (outermost wins) or nothing to do
+        yield
+        return
+    lib = L.load()
+    by_dev = {}
+    for A, W in pairs:
+        n, kin, kout = W.shape
+        if A.is_cuda and W.is_cuda and A.dtype == W.dtype == torch.float32 and A.is_contiguous() and W.is_contiguous() \
+                and (n * kout) <= 128 and (n * kin) <= 128 and (n * kin) % 4 == 0 and (n * kout) % 4 == 0:
+            by_dev.setdefault(W.device, []).append((A, W))
+    try:
+        for dev, prs in by_dev.items():
+            with torch.cuda.device(dev):
+                total = sum(2 * (W.shape[0] * W.shape[1]) * (W.shape[0] * W.shape[2]) for _, W in prs)
+                flat = torch.empty(total, dtype=torch.float32, device=dev)
+                arr = (L.HJob * len(prs))()
+                off = 0
+                for i, (A, W) in enumerate(prs):
+                    n, kin, kout = W.shape
+                    sz = (n * kin) * (n * kout)
+                    H, HT = flat[off:off + sz].view(n * kin, n * kout), flat[off + sz:off + 2 * sz].view(n * kout, n * kin)
+                    off += 2 * sz
+                    arr[i] = L.HJob(L.ptr(A), L.ptr(W), L.ptr(H), L.ptr(HT), n, kin, kout, 0)
+                    _PREBUILT.table[(A.data_ptr(), W.data_ptr())] = (H, HT, A._version, W._version)
+                L.check(lib.phc_phm_build_H_batched(arr, len(prs), L.stream_ptr(dev)), "phc_phm_build_H_batched")
+        yield
+    finally:
+        _PREBUILT.table = {}
+
+
+def _prebuilt_for(A, W):
+    ent = _PREBUILT.table.get((A.data_ptr(), W.data_ptr()))
+    if ent is None or ent[2] != A._version or ent[3] != W._version:      # weights touched since the build: not ours
+        return None
+    return ent[0], ent[1]
+
+
+# ---------------------------------------------------------------------------
 # PHM linear
 # ---------------------------------------------------------------------------
 class _PHMLinearFn(torch.autograd.Function):
@@ -130,8 +194,15 @@ class _PHMLinearFn(torch.autograd.Function):
         res2 = L.f32c(residual.reshape(-1, n * kout)) if residual is not None else None
         N = x2.shape[0]
         y = torch.empty((N, n * kout), dtype=torch.float32, device=dev)
-        L.check(lib.phc_phm_linear_fwd(L.ptr(x2), L.ptr(A_), L.ptr(W_), L.ptr(b_), L.ptr(res2), N, n, kin, kout,
-                                       L.ptr(y), L.stream_ptr(dev)), "phc_phm_linear_fwd")
+        pre = _prebuilt_for(A_, W_) if (_PREBUILT.table and x2.data_ptr() % 16 == 0) else None
+        ctx.HT = None
+        if pre is not None:
+            L.check(lib.phc_gemm_prebuilt(L.ptr(x2), L.ptr(pre[0]), L.ptr(b_), L.ptr(res2), N, n * kin, n * kout, L.ptr(y), 0,
+                                          L.stream_ptr(dev)), "phc_gemm_prebuilt")
+            ctx.HT = pre[1]                      # dx = dy . H^T from the same build (the weights do not change before it)
+        else:
+            L.check(lib.phc_phm_linear_fwd(L.ptr(x2), L.ptr(A_), L.ptr(W_), L.ptr(b_), L.ptr(res2), N, n, kin, kout,
+                                           L.ptr(y), L.stream_ptr(dev)), "phc_phm_linear_fwd")
         if L.PROF_ON:
             L.account("phm_gemm_fwd", 2.0 * N * n * kin * n * kout,
                       4.0 * (N * n * (kin + kout) + n * kin * kout + n ** 3 + n * kout))
@@ -161,8 +232,12 @@ class _PHMLinearFn(torch.autograd.Function):
         need_param = need_A or need_W or need_b
         if need_param and ctx.defer_params is not None and _DEFER.active and not torch.is_grad_enabled():
             # dx only; the parameter gradients of all layers are produced together when the deferral block exits
-            L.check(lib.phc_phm_linear_bwd(L.ptr(x2), L.ptr(A), L.ptr(W), L.ptr(dy2), N, n, kin, kout, L.ptr(dx), None,
-                                           None, None, None, 0, L.stream_ptr(dev)), "phc_phm_linear_bwd")
+            if need_x and ctx.HT is not None and dy2.data_ptr() % 16 == 0:
+                L.check(lib.phc_gemm_prebuilt(L.ptr(dy2), L.ptr(ctx.HT), None, None, N, n * kout, n * kin, L.ptr(dx), 1,
+                                              L.stream_ptr(dev)), "phc_gemm_prebuilt(dx)")
+            else:
+                L.check(lib.phc_phm_linear_bwd(L.ptr(x2), L.ptr(A), L.ptr(W), L.ptr(dy2), N, n, kin, kout, L.ptr(dx), None,
+                                               None, None, None, 0, L.stream_ptr(dev)), "phc_phm_linear_bwd")
             if L.PROF_ON and need_x:
                 L.account("phm_gemm_dx", 2.0 * N * n * kin * n * kout, 4.0 * (N * n * (kin + kout) + n * kin * kout + n ** 3))
             pA, pW, pb = ctx.defer_params

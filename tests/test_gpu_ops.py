@@ -517,3 +517,37 @@ def test_gated_segment_sum_matches_oracle(ops, n, k, is_sorted):
     assert_close(out, ref, TOL, "pooled")
     assert_close(xd.grad, x.grad, TOL, "dx")
     assert_close(gd.grad, gate.grad, TOL, "dgate")
+
+
+@pytest.mark.parametrize("n,kin,kout,N", [(4, 32, 32, 1000), (4, 32, 16, 77), (2, 16, 64, 300), (1, 128, 32, 500), (8, 16, 8, 64)])
+def test_prebuilt_operand_matrices_give_identical_results(ops, n, kin, kout, N):
+    """Inside prebuilt_H() the forward and dx GEMMs read H / H^T built once by phc_phm_build_H_batched; the
+    results must equal the in-kernel assembly bit for bit (same fma order), and H itself the golden formula."""
+    from oracle import phc_oracle as O
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(N, n * kin, generator=g).to(DEV)
+    A = torch.randn(n, n, n, generator=g).to(DEV).requires_grad_()
+    W = (torch.randn(n, kin, kout, generator=g) * 0.2).to(DEV).requires_grad_()
+    b = torch.randn(n * kout, generator=g).to(DEV).requires_grad_()
+    dy = torch.randn(N, n * kout, generator=g).to(DEV)
+
+    def run(pre):
+        xr = x.clone().requires_grad_()
+        for t in (A, W, b):
+            t.grad = None
+        ctx = ops.prebuilt_H([(A, W)]) if pre else __import__("contextlib").nullcontext()
+        with ctx, ops.deferred_param_grads():
+            y = ops.phm_linear(xr, A, W, b)
+            y.backward(dy)
+        return y.detach(), xr.grad, W.grad.clone(), A.grad.clone(), b.grad.clone()
+
+    ref, got = run(False), run(True)
+    for name, a, r in zip(("y", "dx", "dW", "dA", "db"), got, ref):
+        assert torch.equal(a, r), name
+    assert_close(got[0], O.phm_linear(x.cpu(), A.detach().cpu(), W.detach().cpu(), b.detach().cpu()), TOL, "y vs oracle")
+    # a weight update inside the block invalidates the entry (version check): the layer falls back to assembling H
+    with ops.prebuilt_H([(A, W)]):
+        with torch.no_grad():
+            W.mul_(2.0)
+        y2 = ops.phm_linear(x, A, W, b)
+    assert_close(y2, O.phm_linear(x.cpu(), A.detach().cpu(), W.detach().cpu(), b.detach().cpu()), TOL, "stale entry is not used")
