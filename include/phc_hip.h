@@ -288,6 +288,22 @@ int phc_bn_bwd(const float *dy, const float *x, const float *save_stat, const in
                int training, int act, float *dx, float *dwb_flat, int32_t *sync_words, void *ws, size_t ws_bytes,
                void *stream);
 
+/* Batch-norm statistics out of the producing GEMM (training mode): phc_gemm_prebuilt_stats is
+ * phc_gemm_prebuilt (no residual) whose workgroups also emit, per output column, the (sum, M2) of the
+ * rows they produced below *n_valid_dev — stats_partial [phc_gemm_stats_max_partials()][2*Nout],
+ * stats_counts [same] and *num_partials (host out).  phc_bn_fwd_from_partials merges them (same fixed-
+ * order Chan merge as phc_bn_fwd) and applies the normalisation: the separate pass over y that computes
+ * the statistics disappears.  Backward: phc_bn_bwd, unchanged. */
+int phc_gemm_stats_max_partials(void);
+int phc_gemm_prebuilt_stats(const float *x, const float *M, const float *b, int64_t N, int K, int Nout, float *y,
+                            const int32_t *n_valid_dev, float *stats_partial, float *stats_counts, int *num_partials,
+                            void *stream);
+int phc_bn_fwd_from_partials(const float *x, const float *stats_partial, const float *stats_counts, int num_partials,
+                             const float *const *weight, const float *const *bias, float *const *running_mean,
+                             float *const *running_var, int64_t *const *num_batches_tracked, int n_comp,
+                             const int32_t *n_valid_dev, int64_t N, int h, float momentum, float eps, int act,
+                             const float *residual, float *out, float *save_stat, void *stream);
+
 /* ------------------------------------------------------------------------- *
  * Read-out
  * ------------------------------------------------------------------------- */

@@ -8,6 +8,7 @@ import torch.nn as nn
 
 from phc.hypercomplex.layers import PHMLinear, RealTransformer, phm_dropout
 from phc.hypercomplex.norm import PHMNorm
+from phc_gnn_amd import ops as _engine
 from phc.quaternion.activations import get_module_activation
 
 
@@ -57,7 +58,8 @@ class PHMDownstreamNet(nn.Module):
     def forward(self, x: torch.Tensor, verbose=False, n_valid=None, **kwargs) -> torch.Tensor:
         last = len(self.affine) - 1
         for i, layer in enumerate(self.affine):
-            x = layer(x)
+            stats = self.norm_flag and i != last and self.training and x.is_cuda and x.dim() == 2
+            x = layer(x, bn_stats=_engine.BNStatsRequest(n_valid) if stats else None)
             if verbose:
                 print(f"layer {i}: {layer} -> {tuple(x.shape)}")
             if i == last:

@@ -100,9 +100,10 @@ class PHMLinear(nn.Module):
             # which also overwrites a rule handed to the constructor
             self.phm_rule.copy_(torch.stack(get_multiplication_matrices(n, type=self.c_init), dim=0))
 
-    def forward(self, x: torch.Tensor, phm_rule=None) -> torch.Tensor:
-        # the second argument is accepted and ignored, as in the reference (:284-286)
-        return _engine.phm_linear(x, self.phm_rule, self.W, self.b)
+    def forward(self, x: torch.Tensor, phm_rule=None, bn_stats=None) -> torch.Tensor:
+        # the second argument is accepted and ignored, as in the reference (:284-286); ``bn_stats`` (engine
+        # extension): an ops.BNStatsRequest when a batch-norm consumes this layer's output directly
+        return _engine.phm_linear(x, self.phm_rule, self.W, self.b, bn_stats=bn_stats)
 
     def __repr__(self):
         return "{}(in_features={}, out_features={}, phm_dim={}, bias={}, w_init={}, c_init={}, learn_phm={})".format(
@@ -149,12 +150,15 @@ class PHMMLP(nn.Module):
     def forward(self, x: torch.Tensor, n_valid=None) -> torch.Tensor:
         """``n_valid`` (engine extension): device int32 scalar; rows past it are padding of a
         fixed-shape batch and stay out of the batch-norm statistics."""
-        x = self.linear1(x)
+        want = self.training and x.is_cuda and x.dim() == 2
+        x = self.linear1(x, bn_stats=_engine.BNStatsRequest(n_valid) if (want and self.norm_flag) else None)
         if self.norm_flag:
             x = self.norm.forward_fused(x, activation=self.activation_str, n_valid=n_valid)   # norm + activation in one pass
         else:
             x = self.activation(x)
-        return self.linear2(x)
+        # ``out_norm_follows`` is set by the owning model when it normalises this MLP's output directly
+        return self.linear2(x, bn_stats=_engine.BNStatsRequest(n_valid) if (want and getattr(self, "out_norm_follows", False))
+                            else None)
 
     def __repr__(self):
         return '{}(in_features={}, out_features={}, phm_dim={}, phm_rule={}, bias={}, learn_phm={}, ' \

@@ -12,7 +12,7 @@ import torch.nn as nn
 
 from phc.hypercomplex.downstream import PHMDownstreamNet
 from phc.hypercomplex.encoder import NaivePHMEncoder, PHMEncoder
-from phc.hypercomplex.layers import phm_dropout
+from phc.hypercomplex.layers import PHMMLP, phm_dropout
 from phc.hypercomplex.norm import PHMNorm
 from phc.hypercomplex.pooling import PHMGlobalSumPooling, PHMSoftAttentionPooling
 from phc.hypercomplex.undirectional.messagepassing import PHMMessagePassing
@@ -100,6 +100,11 @@ class PHMSkipConnectAdd(nn.Module):
                                            mlp=mlp, add_self_loops=add_self_loops, same_dim=True,
                                            msg_encoder=msg_encoder, **kwargs))
             self.norms.append(PHMNorm(num_features=out_dim, phm_dim=phm_dim, type=norm_mp) if self.norm_mp else None)
+            if self.norm_mp:
+                # the model normalises the conv's MLP output directly: let that MLP's last GEMM emit the statistics
+                for m in self.convs[-1].modules():
+                    if isinstance(m, PHMMLP):
+                        m.out_norm_follows = True
 
         if pooling == "globalsum":
             self.pooling = PHMGlobalSumPooling(phm_dim=phm_dim)

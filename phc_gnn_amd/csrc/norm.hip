@@ -136,7 +136,8 @@ __global__ __launch_bounds__(BN_THREADS) void bn_stats_partial_kernel(const floa
 __global__ __launch_bounds__(BN_THREADS) void bn_finalize_kernel(BnParams p, const int *__restrict__ n_valid, long long N, int h,
                                                                int training, float momentum, float eps,
                                                                const float *__restrict__ partial, int num_partials,
-                                                               long long rows_per_block, float *__restrict__ stat) {
+                                                               long long rows_per_block, float *__restrict__ stat,
+                                                               const float *__restrict__ counts = nullptr) {
     __shared__ float r_sum[32][8], r_m2[32][8];
     const int tid = threadIdx.x;
     const int ci = tid & 7, pl = tid >> 3;
@@ -184,11 +185,13 @@ __global__ __launch_bounds__(BN_THREADS) void bn_finalize_kernel(BnParams p, con
 #pragma unroll
         for (int t = 0; t < PER_LANE; ++t) {
             const int bb = pl + 32 * t;
-            const long long nb_i = min(rows_per_block, max(count - (long long)bb * rows_per_block, 0LL));
-            if (c < h && bb < num_partials && nb_i > 0) {
-                const float nb = (float)nb_i;
-                const float d = ps[t] / nb - mean;
-                m2 += pm[t] + nb * d * d;
+            // rows behind partial bb: derived from the row partition, or given (partials emitted by a GEMM epilogue)
+            const bool inb = c < h && bb < num_partials;
+            const float nbf = counts ? (inb ? counts[bb] : 0.f)
+                                     : (float)min(rows_per_block, max(count - (long long)bb * rows_per_block, 0LL));
+            if (inb && nbf > 0.f) {
+                const float d = ps[t] / nbf - mean;
+                m2 += pm[t] + nbf * d * d;
             }
         }
         r_m2[pl][ci] = m2;
@@ -861,6 +864,40 @@ int phc_bn_fwd(const float *x, const float *const *weight, const float *const *b
                        residual, stat, out)
     PHC_BN_ACT_SWITCH(act, PHC_BN_FWD)
 #undef PHC_BN_FWD
+    return check_launch("bn_apply");
+}
+
+int phc_bn_fwd_from_partials(const float *x, const float *stats_partial, const float *stats_counts, int num_partials,
+                             const float *const *weight, const float *const *bias, float *const *running_mean,
+                             float *const *running_var, int64_t *const *num_batches_tracked, int n_comp, const int32_t *n_valid_dev,
+                             int64_t N, int h, float momentum, float eps, int act, const float *residual, float *out,
+                             float *save_stat, void *stream) {
+    BnParams p;
+    int rc = fill_params("phc_bn_fwd_from_partials", &p, weight, bias, running_mean, running_var, num_batches_tracked, n_comp, h);
+    if (rc) return rc;
+    PHC_REQUIRE(N >= 1 && num_partials >= 1 && num_partials <= BN_MAX_PARTIALS, PHC_ERR_INVALID_ARG,
+                "phc_bn_fwd_from_partials: N=%lld, %d partials (max %d)", (long long)N, num_partials, BN_MAX_PARTIALS);
+    PHC_REQUIRE(act >= PHC_ACT_IDENTITY && act <= PHC_ACT_SELU, PHC_ERR_INVALID_ARG, "phc_bn_fwd_from_partials: unknown activation %d", act);
+    PHC_REQUIRE(x && out && save_stat && stats_partial && stats_counts, PHC_ERR_INVALID_ARG, "phc_bn_fwd_from_partials: null pointer");
+    PHC_REQUIRE(h <= 8192, PHC_ERR_UNSUPPORTED, "phc_bn_fwd_from_partials: h=%d too wide", h);
+    const bool vec4 = (h % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0) &&
+                      (!residual || (reinterpret_cast<uintptr_t>(residual) & 15) == 0);
+    PHC_REQUIRE(vec4 || h % 4 != 0, PHC_ERR_UNSUPPORTED, "phc_bn_fwd_from_partials: rows must be 16-byte aligned when h %% 4 == 0");
+    hipStream_t s = (hipStream_t)stream;
+    {
+        ProfScope prof(K_BN_FINALIZE, s);
+        PHC_LAUNCH(bn_finalize_kernel, dim3((h + 7) / 8), dim3(BN_THREADS), 0, s, p, n_valid_dev, (long long)N, h, 1, momentum, eps,
+                   stats_partial, num_partials, 0LL, save_stat, stats_counts);
+        rc = check_launch("bn_finalize(from partials)");
+        if (rc) return rc;
+    }
+    const size_t lds = sizeof(float) * 2 * (size_t)h;
+    ProfScope prof(K_BN_APPLY, s);
+#define PHC_BN_FWDP(ACTC)                                                                                                     \
+    PHC_LAUNCH((bn_apply_kernel<ACTC>), dim3(apply_grid(N, h)), dim3(BN_THREADS), lds, s, x, n_valid_dev, (long long)N, h, residual,  \
+               save_stat, out)
+    PHC_BN_ACT_SWITCH(act, PHC_BN_FWDP)
+#undef PHC_BN_FWDP
     return check_launch("bn_apply");
 }
 

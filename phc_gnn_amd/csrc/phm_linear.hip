@@ -313,11 +313,16 @@ constexpr int ST_KH = 64;                       // k columns staged per step
 constexpr int ST_STRIDE = ST_KH + 4;            // floats; conflict-free ds_read_b128 of the A operand
 constexpr int ST_FLOATS = 32 * ST_STRIDE;       // private staging floats per wave (8.5 KiB); also holds a 32x36 output tile
 
-template <int TRANS, int NPHM, int BN, int WAVES>
+// STATS: the workgroup also emits, per output column, the (sum, M2) of the rows it produced below *n_valid —
+// the batch-norm statistics of y come out of the GEMM's registers instead of a second pass over y
+// (stats_partial[blockIdx.y][0..Nout) = sum, [Nout..2Nout) = M2 about the workgroup's own mean; stats_counts[blockIdx.y]).
+template <int TRANS, int NPHM, int BN, int WAVES, int STATS = 0>
 __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
     const float *__restrict__ X, const float *__restrict__ A, const float *__restrict__ W,
     const float *__restrict__ bias, const float *__restrict__ residual, float *__restrict__ out,
-    long long M, int K, int Nout, int n, int kin, int kout, int out_vec4) {
+    long long M, int K, int Nout, int n, int kin, int kout, int out_vec4,
+    const int *__restrict__ n_valid = nullptr, float *__restrict__ stats_partial = nullptr,
+    float *__restrict__ stats_counts = nullptr) {
     constexpr int THREADS = 64 * WAVES, HS_STRIDE = BN + 1, CT = BN / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *hs = smem;                                          // [128][HS_STRIDE]
@@ -356,6 +361,19 @@ __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
     for (int ct = 0; ct < CT; ++ct) {
         const int col = min(j0 + ct * 32 + (lane & 7) * 4, max(Nout - 4, 0));
         bias4[ct] = (bias && out_vec4) ? *reinterpret_cast<const float4 *>(bias + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    // STATS: running (count, sum, M2) of this wavefront's rows for the column this lane owns in the MFMA layout
+    float st_bias[CT], st_sum[CT], st_m2[CT];
+    float st_n = 0.f;
+    long long st_count = M;
+    if constexpr (STATS) {
+        if (n_valid) st_count = min((long long)*n_valid, M);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int col = j0 + ct * 32 + r;
+            st_bias[ct] = (bias && col < Nout) ? bias[col] : 0.f;
+            st_sum[ct] = st_m2[ct] = 0.f;
+        }
     }
 
 #ifndef PHC_EXP_NO_HBUILD
@@ -434,8 +452,43 @@ __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
             }
         }
 
-        // epilogue: transpose each 32x32 tile through the private buffer, 16-byte stores
         const long long row_base = slab * 32;
+        if constexpr (STATS) {
+            // rows of this slab that count: [row_base, min(row_base + 32, st_count))
+            const int nv = (int)max(0LL, min(32LL, st_count - row_base));
+            if (nv > 0) {                                                    // wave-uniform
+                const float cnt = (float)nv;
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    float sv = 0.f;
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int rw = (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+                        sv += rw < nv ? acc[ct][reg] + st_bias[ct] : 0.f;
+                    }
+                    sv += __shfl_xor(sv, 32);
+                    const float mean_s = sv / cnt;
+                    float m2 = 0.f;
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const int rw = (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+                        const float d = acc[ct][reg] + st_bias[ct] - mean_s;
+                        m2 = rw < nv ? fmaf(d, d, m2) : m2;
+                    }
+                    m2 += __shfl_xor(m2, 32);
+                    if (st_n == 0.f) {
+                        st_sum[ct] = sv;
+                        st_m2[ct] = m2;
+                    } else {                                                 // Chan merge of (st_n, st_sum, st_m2) and the slab
+                        const float delta = mean_s - st_sum[ct] / st_n;
+                        st_m2[ct] += m2 + delta * delta * (st_n * cnt / (st_n + cnt));
+                        st_sum[ct] += sv;
+                    }
+                }
+                st_n += cnt;
+            }
+        }
+        // epilogue: transpose each 32x32 tile through the private buffer, 16-byte stores
 #ifdef PHC_EXP_NO_EPI
         if (acc[0][0] == 123.456f)
 #endif
@@ -475,6 +528,45 @@ __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
                     }
                 }
             }
+        }
+    }
+    if constexpr (STATS) {
+        // merge the WAVES wavefronts of this workgroup in wave order (fixed) and publish one partial per column
+        __syncthreads();                                                     // every wave is done with its staging buffer
+        float *sw = stage_all + wave * ST_FLOATS;                            // [0] = n, [1 + ct*32 + r] = sum, [1 + CT*32 + ...] = M2
+        if (hh == 0) {
+            if (r == 0) sw[0] = st_n;
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct) {
+                sw[1 + ct * 32 + r] = st_sum[ct];
+                sw[1 + CT * 32 + ct * 32 + r] = st_m2[ct];
+            }
+        }
+        __syncthreads();
+        for (int cc = tid; cc < BN; cc += 64 * WAVES) {
+            float nt = 0.f, sum = 0.f, m2 = 0.f;
+            for (int w = 0; w < WAVES; ++w) {
+                const float *q = stage_all + w * ST_FLOATS;
+                const float nw = q[0];
+                if (nw > 0.f) {
+                    const float sw_ = q[1 + cc], mw = q[1 + CT * 32 + cc];
+                    if (nt == 0.f) {
+                        sum = sw_;
+                        m2 = mw;
+                    } else {
+                        const float delta = sw_ / nw - sum / nt;
+                        m2 += mw + delta * delta * (nt * nw / (nt + nw));
+                        sum += sw_;
+                    }
+                    nt += nw;
+                }
+            }
+            const int col = j0 + cc;
+            if (col < Nout) {
+                stats_partial[(size_t)blockIdx.y * 2 * Nout + col] = sum;
+                stats_partial[(size_t)blockIdx.y * 2 * Nout + Nout + col] = m2;
+            }
+            if (blockIdx.x == 0 && cc == 0) stats_counts[blockIdx.y] = nt;
         }
     }
 }
@@ -782,27 +874,33 @@ static int launch_gemm_cfg(const float *X, const float *A, const float *W, const
 }
 
 
-template <int TRANS, int NPHM, int BN, int WAVES>
+constexpr int GEMM_STATS_MAX_PARTIALS = 256;
+
+template <int TRANS, int NPHM, int BN, int WAVES, int STATS = 0>
 static int launch_stream_cfg(const float *X, const float *A, const float *W, const float *bias, const float *residual,
-                             float *out, int64_t M, int K, int Nout, int n, int kin, int kout, int wg_per_cu, hipStream_t s) {
+                             float *out, int64_t M, int K, int Nout, int n, int kin, int kout, int wg_per_cu, hipStream_t s,
+                             const int *n_valid = nullptr, float *stats_partial = nullptr, float *stats_counts = nullptr,
+                             int *num_partials = nullptr) {
     const int panels = (Nout + BN - 1) / BN;
     const int64_t slabs = (M + 31) / 32;
     int64_t gy = ((int64_t)wg_per_cu * num_cu() + panels - 1) / panels;
     const int64_t max_gy = (slabs + WAVES - 1) / WAVES;
     if (gy > max_gy) gy = max_gy;
+    if (STATS && gy > GEMM_STATS_MAX_PARTIALS) gy = GEMM_STATS_MAX_PARTIALS;      // one statistics partial per workgroup row
     if (gy < 1) gy = 1;
+    if (num_partials) *num_partials = (int)gy;
     const size_t lds = sizeof(float) * ((size_t)128 * (BN + 1) + (size_t)WAVES * ST_FLOATS + (size_t)n * n * n);
     const int out_vec4 = (Nout % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0) &&
                          (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0) &&
                          (!residual || (reinterpret_cast<uintptr_t>(residual) & 15) == 0);
     static bool attr_set = false;
     if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&phm_stream_kernel<TRANS, NPHM, BN, WAVES>),
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&phm_stream_kernel<TRANS, NPHM, BN, WAVES, STATS>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
         attr_set = true;
     }
-    PHC_LAUNCH((phm_stream_kernel<TRANS, NPHM, BN, WAVES>), dim3(panels, (unsigned)gy), dim3(64 * WAVES), lds, s, X, A, W,
-                       bias, residual, out, (long long)M, K, Nout, n, kin, kout, out_vec4);
+    PHC_LAUNCH((phm_stream_kernel<TRANS, NPHM, BN, WAVES, STATS>), dim3(panels, (unsigned)gy), dim3(64 * WAVES), lds, s, X, A, W,
+                       bias, residual, out, (long long)M, K, Nout, n, kin, kout, out_vec4, n_valid, stats_partial, stats_counts);
     return PHC_OK;
 }
 
@@ -1031,11 +1129,41 @@ int phc_gemm_prebuilt(const float *x, const float *M, const float *b, const floa
                 PHC_ERR_UNSUPPORTED, "phc_gemm_prebuilt: needs K <= 128, K %% 4 == 0 and 16-byte aligned x, M (K=%d)", K);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(is_dx ? K_PHM_GEMM_DX : K_PHM_GEMM_FWD, s);
+    // Few rows (molecule batches: about one 32-row slab per wavefront): 32-column panels give twice the wavefronts,
+    // each half as long — measured 0.8 us per launch faster than 64-column panels at N = 13.8k; above that the extra
+    // re-reads of x cost more than the occupancy gains.  PHC_GEMM_PRE_BN=64 forces the wider panel.
+    static const int small_bn = getenv("PHC_GEMM_PRE_BN") ? atoi(getenv("PHC_GEMM_PRE_BN")) : 32;
     if (N >= GEMM_BIG_M && Nout > 64)
         launch_stream_cfg<0, -1, 128, 8>(x, nullptr, M, b, residual, y, N, K, Nout, 1, K, Nout, 1, s);
+    else if (small_bn == 32 && Nout > 32 && N <= 32 * 1024)
+        launch_stream_cfg<0, -1, 32, 4>(x, nullptr, M, b, residual, y, N, K, Nout, 1, K, Nout, 3, s);
     else
         launch_stream_cfg<0, -1, 64, 4>(x, nullptr, M, b, residual, y, N, K, Nout, 1, K, Nout, 2, s);
     return check_launch("phc_gemm_prebuilt");
+}
+
+int phc_gemm_stats_max_partials(void) { return GEMM_STATS_MAX_PARTIALS; }
+
+int phc_gemm_prebuilt_stats(const float *x, const float *M, const float *b, int64_t N, int K, int Nout, float *y,
+                            const int32_t *n_valid_dev, float *stats_partial, float *stats_counts, int *num_partials, void *stream) {
+    PHC_REQUIRE(N >= 1 && K >= 1 && Nout >= 1, PHC_ERR_INVALID_ARG, "phc_gemm_prebuilt_stats: bad shape");
+    PHC_REQUIRE(x && M && y && stats_partial && stats_counts && num_partials, PHC_ERR_INVALID_ARG,
+                "phc_gemm_prebuilt_stats: null pointer");
+    PHC_REQUIRE(K <= 128 && K % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(M) & 15) == 0,
+                PHC_ERR_UNSUPPORTED, "phc_gemm_prebuilt_stats: needs K <= 128, K %% 4 == 0 and 16-byte aligned x, M (K=%d)", K);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(K_PHM_GEMM_FWD, s);
+    static const int small_bn = getenv("PHC_GEMM_PRE_BN") ? atoi(getenv("PHC_GEMM_PRE_BN")) : 32;
+    if (N >= GEMM_BIG_M && Nout > 64)
+        launch_stream_cfg<0, -1, 128, 8, 1>(x, nullptr, M, b, nullptr, y, N, K, Nout, 1, K, Nout, 1, s, n_valid_dev, stats_partial,
+                                            stats_counts, num_partials);
+    else if (small_bn == 32 && Nout > 32 && N <= 32 * 1024)
+        launch_stream_cfg<0, -1, 32, 4, 1>(x, nullptr, M, b, nullptr, y, N, K, Nout, 1, K, Nout, 3, s, n_valid_dev, stats_partial,
+                                           stats_counts, num_partials);
+    else
+        launch_stream_cfg<0, -1, 64, 4, 1>(x, nullptr, M, b, nullptr, y, N, K, Nout, 1, K, Nout, 2, s, n_valid_dev, stats_partial,
+                                           stats_counts, num_partials);
+    return check_launch("phc_gemm_prebuilt_stats");
 }
 
 // ---- batched parameter gradients ------------------------------------------------------------

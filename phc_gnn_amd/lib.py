@@ -50,6 +50,10 @@ SIGNATURES = {
     "phc_phm_linear_bwd": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _S, _P]),
     "phc_phm_build_H_batched": (_I, [C.POINTER(HJob), _I, _P]),
     "phc_gemm_prebuilt": (_I, [_P, _P, _P, _P, _L, _I, _I, _P, _I, _P]),
+    "phc_gemm_stats_max_partials": (_I, []),
+    "phc_gemm_prebuilt_stats": (_I, [_P, _P, _P, _L, _I, _I, _P, _P, _P, _P, C.POINTER(_I), _P]),
+    "phc_bn_fwd_from_partials": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _L, _I, C.c_float, C.c_float, _I, _P, _P, _P,
+                                      _P]),
     "phc_phm_param_grads_ws_bytes": (_S, [C.POINTER(GradJob), _I]),
     "phc_phm_param_grads": (_I, [C.POINTER(GradJob), _I, _P, _S, _P]),
     "phc_csr_ws_bytes": (_S, [_L, _L]),

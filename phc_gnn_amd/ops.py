@@ -181,7 +181,7 @@ def _prebuilt_for(A, W):
 # ---------------------------------------------------------------------------
 class _PHMLinearFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, A, W, b, residual):
+    def forward(ctx, x, A, W, b, residual, bn_stats=None):
         lib = L.load()
         dev = L.require_device(x, A, W, b, residual)
         n, kin, kout = W.shape
@@ -196,7 +196,17 @@ class _PHMLinearFn(torch.autograd.Function):
         y = torch.empty((N, n * kout), dtype=torch.float32, device=dev)
         pre = _prebuilt_for(A_, W_) if (_PREBUILT.table and x2.data_ptr() % 16 == 0) else None
         ctx.HT = None
-        if pre is not None:
+        if pre is not None and bn_stats is not None and res2 is None and N > 0 and x.dim() == 2:
+            P = lib.phc_gemm_stats_max_partials()
+            bn_stats.partial = torch.empty((P, 2 * n * kout), dtype=torch.float32, device=dev)
+            bn_stats.counts = torch.empty(P, dtype=torch.float32, device=dev)
+            num = _C.c_int(0)
+            L.check(lib.phc_gemm_prebuilt_stats(L.ptr(x2), L.ptr(pre[0]), L.ptr(b_), N, n * kin, n * kout, L.ptr(y),
+                                                L.ptr(bn_stats.n_valid), L.ptr(bn_stats.partial), L.ptr(bn_stats.counts),
+                                                _C.byref(num), L.stream_ptr(dev)), "phc_gemm_prebuilt_stats")
+            bn_stats.num = num.value
+            ctx.HT = pre[1]
+        elif pre is not None:
             L.check(lib.phc_gemm_prebuilt(L.ptr(x2), L.ptr(pre[0]), L.ptr(b_), L.ptr(res2), N, n * kin, n * kout, L.ptr(y), 0,
                                           L.stream_ptr(dev)), "phc_gemm_prebuilt")
             ctx.HT = pre[1]                      # dx = dy . H^T from the same build (the weights do not change before it)
@@ -226,7 +236,7 @@ class _PHMLinearFn(torch.autograd.Function):
         n, kin, kout = W.shape
         N = x2.shape[0]
         dy2 = L.f32c(dy.reshape(-1, n * kout))
-        need_x, need_A, need_W, need_b, need_res = ctx.needs_input_grad
+        need_x, need_A, need_W, need_b, need_res = ctx.needs_input_grad[:5]
         need_b = need_b and ctx.has_bias
         dx = torch.empty_like(x2) if need_x else None
         need_param = need_A or need_W or need_b
@@ -245,7 +255,7 @@ class _PHMLinearFn(torch.autograd.Function):
                 _DEFER.jobs.append(dict(x=x2, dy=dy2, A=A, W=W, need=(need_A, need_W, need_b),
                                         params=(pA if need_A else None, pW if need_W else None, pb if need_b else None)))
             return (dx.reshape(ctx.x_shape) if need_x else None, None, None, None,
-                    dy.reshape(ctx.res_shape) if (need_res and ctx.has_res) else None)
+                    dy.reshape(ctx.res_shape) if (need_res and ctx.has_res) else None, None)
         dW = torch.empty_like(W) if need_param else None
         dA = torch.empty_like(A) if need_A else None
         db = torch.empty(n * kout, dtype=torch.float32, device=dev) if need_b else None
@@ -262,13 +272,27 @@ class _PHMLinearFn(torch.autograd.Function):
             if need_param:
                 L.account("phm_dH_partial", gemm, io + 4.0 * n * kin * n * kout)
         return (dx.reshape(ctx.x_shape) if need_x else None, dA, dW if need_W else None, db,
-                dy.reshape(ctx.res_shape) if (need_res and ctx.has_res) else None)
+                dy.reshape(ctx.res_shape) if (need_res and ctx.has_res) else None, None)
+
+
+class BNStatsRequest:
+    """Ask a PHM linear layer for the batch-norm statistics of its output (training mode): when the layer runs on a
+    prebuilt operand matrix, its GEMM emits per-column (sum, M2) partials from registers and the normalisation that
+    follows (``batch_norm_act`` on the very tensor this layer returned) skips its own pass over the data."""
+
+    def __init__(self, n_valid: Optional[torch.Tensor] = None):
+        self.n_valid = n_valid
+        self.partial = self.counts = None
+        self.num = 0
 
 
 def phm_linear(x: torch.Tensor, phm_rule: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None,
-               residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+               residual: Optional[torch.Tensor] = None, bn_stats: Optional[BNStatsRequest] = None) -> torch.Tensor:
     """y = x · (Σ_i phm_rule[i] ⊗ W[i]) + bias (+ residual)."""
-    return _PHMLinearFn.apply(x, phm_rule, W, bias, residual)
+    y = _PHMLinearFn.apply(x, phm_rule, W, bias, residual, bn_stats)
+    if bn_stats is not None and bn_stats.partial is not None:
+        y._phc_bn = bn_stats                 # consumed by batch_norm_act if it is handed this very tensor
+    return y
 
 
 _ONES: dict = {}
@@ -283,7 +307,7 @@ def dense_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
     if one is None:
         one = torch.ones(1, 1, 1, dtype=torch.float32, device=dev)
         _ONES[dev] = one
-    return _PHMLinearFn.apply(x, one, weight.t().unsqueeze(0), bias, None)
+    return _PHMLinearFn.apply(x, one, weight.t().unsqueeze(0), bias, None, None)
 
 
 def phm_build_H(phm_rule: torch.Tensor, W: torch.Tensor) -> torch.Tensor:
@@ -807,7 +831,7 @@ BN_LAST_WORKGROUP_MERGE = False
 
 class _BatchNormActFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, residual, n_valid, running_mean, running_var, nbt, training, momentum, eps, act, n_comp,
+    def forward(ctx, x, residual, n_valid, running_mean, running_var, nbt, training, momentum, eps, act, n_comp, pre_stats,
                 *affine):
         lib = L.load()
         dev = L.require_device(x, residual)
@@ -823,6 +847,16 @@ class _BatchNormActFn(torch.autograd.Function):
         nbt_arr = _ptr_array(nbt) if nbt else None
         out = torch.empty_like(x_)
         save_stat = torch.empty(6 * h, dtype=torch.float32, device=dev)   # mean|invstd|scale|shift|w|b per column
+        if pre_stats is not None:               # statistics already emitted by the GEMM that produced x
+            L.check(lib.phc_bn_fwd_from_partials(L.ptr(x_), L.ptr(pre_stats.partial), L.ptr(pre_stats.counts), pre_stats.num,
+                                                 w_arr, b_arr, rm_arr, rv_arr, nbt_arr, n_comp, L.ptr(n_valid), N, h,
+                                                 float(momentum), float(eps), act, L.ptr(res_), L.ptr(out), L.ptr(save_stat),
+                                                 L.stream_ptr(dev)), "phc_bn_fwd_from_partials")
+            if L.PROF_ON:
+                L.account("bn_apply", 2.0 * N * h, 4.0 * N * h * (3 if residual is not None else 2))
+            ctx.save_for_backward(x_, save_stat)
+            ctx.meta = (n_comp, bool(training), act, bool(affine), residual is not None, n_valid)
+            return out
         ws_bytes = lib.phc_bn_ws_bytes(N, h)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         L.check(lib.phc_bn_fwd(L.ptr(x_), w_arr, b_arr, rm_arr, rv_arr, nbt_arr, n_comp, L.ptr(n_valid), N, h,
@@ -846,7 +880,7 @@ class _BatchNormActFn(torch.autograd.Function):
         dev = dout_.device
         N, h = x_.shape
         need_x = ctx.needs_input_grad[0]
-        need_aff = has_affine and any(ctx.needs_input_grad[11:])
+        need_aff = has_affine and any(ctx.needs_input_grad[12:])
         dx = torch.empty_like(x_) if need_x else None
         dwb = torch.empty(2 * h, dtype=torch.float32, device=dev) if need_aff else None
         ws_bytes = lib.phc_bn_ws_bytes(N, h)
@@ -866,7 +900,7 @@ class _BatchNormActFn(torch.autograd.Function):
             else:
                 aff_grads = [None] * (2 * n_comp)
         dres = dout if (has_res and ctx.needs_input_grad[1]) else None
-        return (dx, dres, None, None, None, None, None, None, None, None, None, *aff_grads)
+        return (dx, dres, None, None, None, None, None, None, None, None, None, None, *aff_grads)
 
 
 def batch_norm_act(x: torch.Tensor, weights, biases, running_mean, running_var, num_batches_tracked, training: bool,
@@ -879,7 +913,11 @@ def batch_norm_act(x: torch.Tensor, weights, biases, running_mean, running_var, 
     device int32 scalar marking the padding rows of a fixed-shape batch."""
     n_comp = len(running_mean) if running_mean else len(weights)
     affine = (list(weights) + list(biases)) if weights else []
+    pre = getattr(x, "_phc_bn", None)
+    if pre is not None and not (training and pre.partial is not None and pre.n_valid is n_valid and x.dim() == 2
+                                and pre.partial.shape[1] == 2 * x.shape[1] and x.is_contiguous()):
+        pre = None
     return _BatchNormActFn.apply(x, residual, n_valid, list(running_mean) if running_mean else None,
                                  list(running_var) if running_var else None,
                                  list(num_batches_tracked) if num_batches_tracked else None, training, momentum, eps,
-                                 _act_id(activation), n_comp, *affine)
+                                 _act_id(activation), n_comp, pre, *affine)

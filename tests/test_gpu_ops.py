@@ -551,3 +551,57 @@ def test_prebuilt_operand_matrices_give_identical_results(ops, n, kin, kout, N):
             W.mul_(2.0)
         y2 = ops.phm_linear(x, A, W, b)
     assert_close(y2, O.phm_linear(x.cpu(), A.detach().cpu(), W.detach().cpu(), b.detach().cpu()), TOL, "stale entry is not used")
+
+
+@pytest.mark.parametrize("n,kin,kout,N,valid", [(4, 32, 32, 13824, 12874), (4, 32, 32, 500, None), (2, 16, 48, 33, 20),
+                                               (4, 32, 16, 70000, 69000), (1, 64, 128, 3000, None)])
+def test_bn_statistics_from_the_gemm_epilogue(ops, n, kin, kout, N, valid):
+    """A PHM layer asked for batch-norm statistics (BNStatsRequest) on a prebuilt operand emits (sum, M2) partials
+    from the GEMM's registers; batch_norm_act on its output must agree with the oracle and with the two-pass path,
+    forward and backward, including padding rows (n_valid) and running statistics."""
+    from oracle import phc_oracle as O
+    g = torch.Generator().manual_seed(41)
+    h = n * kout
+    k = kout
+    x = torch.randn(N, n * kin, generator=g)
+    x[::7] *= 30.0                                                       # a few dominant rows: no E[x^2]-E[x]^2 shortcuts
+    A = torch.randn(n, n, n, generator=g)
+    W = torch.randn(n, kin, kout, generator=g) * 0.2
+    b = torch.randn(h, generator=g)
+    w = [torch.rand(k, generator=g) + 0.5 for _ in range(n)]
+    bb = [torch.randn(k, generator=g) * 0.1 for _ in range(n)]
+    dy = torch.randn(N, h, generator=g)
+    nv = N if valid is None else valid
+    n_valid = None if valid is None else torch.tensor(valid, dtype=torch.int32, device=DEV)
+
+    def run(fused):
+        xd = x.to(DEV).requires_grad_()
+        Ad, Wd, bd = (t.to(DEV).requires_grad_() for t in (A, W, b))
+        wd, bbd = [t.to(DEV).requires_grad_() for t in w], [t.to(DEV).requires_grad_() for t in bb]
+        rm, rv = [torch.zeros(k, device=DEV) for _ in range(n)], [torch.ones(k, device=DEV) for _ in range(n)]
+        with ops.prebuilt_H([(Ad, Wd)]):
+            req = ops.BNStatsRequest(n_valid) if fused else None
+            y = ops.phm_linear(xd, Ad, Wd, bd, bn_stats=req)
+            assert (getattr(y, "_phc_bn", None) is not None) == fused
+            out = ops.batch_norm_act(y, wd, bbd, rm, rv, None, True, 0.1, 1e-5, "relu", None, n_valid)
+            out.backward(dy.to(DEV))
+        return [out.detach(), xd.grad, Wd.grad, bd.grad] + [t.grad for t in wd + bbd] + rm + rv
+
+    fused, plain = run(True), run(False)
+    for i, (a, r) in enumerate(zip(fused, plain)):
+        if i == 3:        # a bias in front of a batch-norm has an exactly-zero gradient: both paths return round-off noise
+            assert float(a.abs().max()) < 1e-3 * float(fused[2].abs().max()) + 1e-4
+            continue
+        assert_close(a, r, 2e-5, f"fused vs two-pass, tensor {i}")
+    # oracle on the valid rows
+    xr, Ar, Wr, br = (t.clone().requires_grad_() for t in (x[:nv], A, W, b))
+    wr, bbr = [t.clone().requires_grad_() for t in w], [t.clone().requires_grad_() for t in bb]
+    rm_r, rv_r = [torch.zeros(k) for _ in range(n)], [torch.ones(k) for _ in range(n)]
+    ref = torch.relu(O.batch_norm_naive(O.phm_linear(xr, Ar, Wr, br), n, wr, bbr, rm_r, rv_r, True))
+    ref.backward(dy[:nv])
+    assert_close(fused[0][:nv], ref, 2e-5, "out vs oracle")
+    assert float(fused[0][nv:].abs().max()) == 0.0 if nv < N else True
+    assert_close(fused[1][:nv], xr.grad, 5e-5, "dx vs oracle")
+    assert_close(fused[2], Wr.grad, 5e-5, "dW vs oracle")
+    for a, r in zip(fused[4 + 2 * n:], rm_r + rv_r):
+        assert_close(a, r, 2e-5, "running stats vs oracle")
