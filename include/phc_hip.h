@@ -304,6 +304,21 @@ int phc_bn_fwd_from_partials(const float *x, const float *stats_partial, const f
                              const int32_t *n_valid_dev, int64_t N, int h, float momentum, float eps, int act,
                              const float *residual, float *out, float *save_stat, void *stream);
 
+/* Bond-table gradients of SEVERAL message-passing layers in two launches.  The layers of one model share
+ * the edge list and the integer bond features; only dout / x / tables differ.  Like the PHM parameter
+ * gradients they are off the backward pass's critical path: a training step runs phc_aggregate_enc_bwd
+ * with dtables_flat = NULL (dx only) per layer and submits the table gradients of all layers here at
+ * the end.  Same one-hot MFMA GEMM and fixed-order slabs as phc_aggregate_enc_bwd.  `jobs`: HOST array. */
+typedef struct phc_table_grad_job {
+    const float *dout, *x;             /* device: [n_dst, n*k], [n_src, n*k] (x may be NULL when act = identity) */
+    const float *const *tables;        /* device array of n*F table pointers                                     */
+    float *dtables_flat;               /* device out [n][R][k]                                                   */
+} phc_table_grad_job;
+size_t phc_table_grads_ws_bytes(int64_t E, int F, const int32_t *vocab, int n, int k, int num_jobs);
+int phc_table_grads_batched(const phc_table_grad_job *jobs, int num_jobs, const int64_t *bond_i64, const int32_t *vocab,
+                            const int64_t *edge_src_i64, const int64_t *edge_dst_i64, int64_t E, int F, int n, int k,
+                            int act, void *ws, size_t ws_bytes, void *stream);
+
 /* ------------------------------------------------------------------------- *
  * Read-out
  * ------------------------------------------------------------------------- */

@@ -280,18 +280,17 @@ constexpr int TG_T = 64;          // tile edge (table rows x feature columns)
 constexpr int TG_IB = 64;         // items per step
 
 template <int MODE, int ACT>
-__global__ __launch_bounds__(ENC_THREADS) void table_grad_mfma_kernel(
-    const float *__restrict__ dout, const long long *__restrict__ idx, EncMeta m, long long n_items, long long items_per_split,
+__device__ __forceinline__ void table_grad_body(
+    const float *__restrict__ dout, const long long *__restrict__ idx, const EncMeta &m, long long n_items, long long items_per_split,
     int h, int tiles_j, const long long *__restrict__ src, const long long *__restrict__ dst, const float *__restrict__ x,
-    const float *const *__restrict__ tables, int n, int k, int vec4, float *__restrict__ slabs) {
+    const float *const *__restrict__ tables, int n, int k, int vec4, float *__restrict__ slabs, int tile, long long split) {
     __shared__ __attribute__((aligned(16))) float oh[TG_IB * TG_T];     // one-hot tile  [item][table row]
     __shared__ __attribute__((aligned(16))) float gs[TG_IB * TG_T];     // gradient tile [item][column]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 1, wj = wave & 1;
     const int r = lane & 31, hh = lane >> 5;
-    const int ti = blockIdx.x / tiles_j, tj = blockIdx.x - ti * tiles_j;
+    const int ti = tile / tiles_j, tj = tile - ti * tiles_j;
     const int r0 = ti * TG_T, j0 = tj * TG_T;
-    const long long split = blockIdx.y;
     const long long t_begin = split * items_per_split;
     const long long t_end = min(n_items, t_begin + items_per_split);
     const int F = m.F;
@@ -372,14 +371,57 @@ __global__ __launch_bounds__(ENC_THREADS) void table_grad_mfma_kernel(
     }
 }
 
+template <int MODE, int ACT>
+__global__ __launch_bounds__(ENC_THREADS) void table_grad_mfma_kernel(
+    const float *__restrict__ dout, const long long *__restrict__ idx, EncMeta m, long long n_items, long long items_per_split,
+    int h, int tiles_j, const long long *__restrict__ src, const long long *__restrict__ dst, const float *__restrict__ x,
+    const float *const *__restrict__ tables, int n, int k, int vec4, float *__restrict__ slabs) {
+    table_grad_body<MODE, ACT>(dout, idx, m, n_items, items_per_split, h, tiles_j, src, dst, x, tables, n, k, vec4, slabs, blockIdx.x,
+                               blockIdx.y);
+}
+
+// Several layers' bond-table gradients in one launch (phc_table_grads_batched): the layers share the edge list and
+// the integer bond features, only dout / x / tables / output differ; blockIdx.z picks the layer.
+constexpr int TG_JOBS_PER_LAUNCH = 8;
+struct TgJobDev {
+    const float *dout, *x;
+    const float *const *tables;
+    float *slabs, *flat;
+};
+struct TgBatch {
+    TgJobDev j[TG_JOBS_PER_LAUNCH];
+};
+
+template <int ACT>
+__global__ __launch_bounds__(ENC_THREADS) void table_grad_mfma_batched_kernel(
+    TgBatch b, const long long *__restrict__ idx, EncMeta m, long long n_items, long long items_per_split, int h, int tiles_j,
+    const long long *__restrict__ src, const long long *__restrict__ dst, int n, int k, int vec4) {
+    const TgJobDev &jb = b.j[blockIdx.z];
+    table_grad_body<1, ACT>(jb.dout, idx, m, n_items, items_per_split, h, tiles_j, src, dst, jb.x, jb.tables, n, k, vec4, jb.slabs,
+                            blockIdx.x, blockIdx.y);
+}
+
+__device__ __forceinline__ void table_grad_reduce_body(const float *__restrict__ slabs, int num_slabs, int R, int n, int k,
+                                                       float *__restrict__ flat, int bx);
+
+__global__ __launch_bounds__(256) void table_grad_reduce_batched_kernel(TgBatch b, int num_slabs, int R, int n, int k) {
+    const TgJobDev &jb = b.j[blockIdx.y];
+    table_grad_reduce_body(jb.slabs, num_slabs, R, n, k, jb.flat, blockIdx.x);
+}
+
 // flat[c][r][kap] = sum_b slab[b][r][c*k+kap]    (flat is [c][f][V_f][k] because r = off_f + v)
 // 64 elements x 4 slab lanes per workgroup, fixed summation tree.
 __global__ __launch_bounds__(256) void table_grad_reduce_kernel(const float *__restrict__ slabs, int num_slabs, int R, int n, int k,
                                                                float *__restrict__ flat) {
+    table_grad_reduce_body(slabs, num_slabs, R, n, k, flat, blockIdx.x);
+}
+
+__device__ __forceinline__ void table_grad_reduce_body(const float *__restrict__ slabs, int num_slabs, int R, int n, int k,
+                                                       float *__restrict__ flat, int bx) {
     __shared__ float part[4][64];
     const int h = n * k;
     const int el = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const int e = blockIdx.x * 64 + el;
+    const int e = bx * 64 + el;
     float s = 0.f;
     if (e < R * h) {
 #pragma unroll 4
@@ -414,12 +456,13 @@ struct TgPlan {
     size_t slab_floats;
 };
 
-static TgPlan tg_plan(long long n_items, int R, int h) {
+static TgPlan tg_plan(long long n_items, int R, int h, int jobs = 1) {
     TgPlan p;
     p.tiles_i = (R + TG_T - 1) / TG_T;
     p.tiles_j = (h + TG_T - 1) / TG_T;
     const int tiles = p.tiles_i * p.tiles_j;
-    long long splits = (512 + tiles - 1) / tiles;                       // ~2 workgroups per CU
+    const int target = jobs > 1 ? 1024 : 512;                           // workgroups of the whole launch (~2-4 per CU)
+    long long splits = (target + tiles * jobs - 1) / (tiles * jobs);
     const long long cap = (long long)((4u << 20) / (sizeof(float) * (size_t)R * h));   // keep the slabs around 4 MB
     if (splits > cap) splits = cap;
     if (splits < 1) splits = 1;
@@ -697,6 +740,74 @@ int phc_aggregate_enc_bwd(const float *dout, const float *x, const int64_t *bond
         return launch_table_grad<1>(dout, bond, m, E, h, n, k, act, reinterpret_cast<const long long *>(edge_src_i64),
                                     reinterpret_cast<const long long *>(edge_dst_i64), x, tables, dtables_flat, ws, ws_bytes, s,
                                     "phc_aggregate_enc_bwd");
+    }
+    return PHC_OK;
+}
+
+size_t phc_table_grads_ws_bytes(int64_t E, int F, const int32_t *vocab, int n, int k, int num_jobs) {
+    EncMeta m;
+    if (num_jobs < 1 || make_meta("phc_table_grads_ws_bytes", F, vocab, &m)) return 0;
+    size_t total = 0;
+    for (int c0 = 0; c0 < num_jobs; c0 += TG_JOBS_PER_LAUNCH) {
+        const int cn = num_jobs - c0 < TG_JOBS_PER_LAUNCH ? num_jobs - c0 : TG_JOBS_PER_LAUNCH;
+        total += sizeof(float) * tg_plan(E, m.R, n * k, cn).slab_floats * cn;
+    }
+    return total;
+}
+
+int phc_table_grads_batched(const phc_table_grad_job *jobs, int num_jobs, const int64_t *bond_i64, const int32_t *vocab,
+                            const int64_t *edge_src_i64, const int64_t *edge_dst_i64, int64_t E, int F, int n, int k, int act,
+                            void *ws, size_t ws_bytes, void *stream) {
+    EncMeta m;
+    int rc = make_meta("phc_table_grads_batched", F, vocab, &m);
+    if (rc) return rc;
+    PHC_REQUIRE(num_jobs >= 1 && jobs && E >= 1 && n >= 1 && k >= 1, PHC_ERR_INVALID_ARG, "phc_table_grads_batched: bad arguments");
+    PHC_REQUIRE(act >= PHC_ACT_IDENTITY && act <= PHC_ACT_SELU, PHC_ERR_INVALID_ARG, "phc_table_grads_batched: unknown activation %d", act);
+    PHC_REQUIRE(bond_i64 && edge_src_i64 && edge_dst_i64, PHC_ERR_INVALID_ARG, "phc_table_grads_batched: null pointer");
+    PHC_REQUIRE(ws && ws_bytes >= phc_table_grads_ws_bytes(E, F, vocab, n, k, num_jobs), PHC_ERR_WORKSPACE,
+                "phc_table_grads_batched: workspace too small");
+    const int h = n * k;
+    hipStream_t s = (hipStream_t)stream;
+    const long long *idx = reinterpret_cast<const long long *>(bond_i64);
+    const long long *src = reinterpret_cast<const long long *>(edge_src_i64);
+    const long long *dst = reinterpret_cast<const long long *>(edge_dst_i64);
+    float *wsf = static_cast<float *>(ws);
+    for (int c0 = 0; c0 < num_jobs; c0 += TG_JOBS_PER_LAUNCH) {
+        const int cn = num_jobs - c0 < TG_JOBS_PER_LAUNCH ? num_jobs - c0 : TG_JOBS_PER_LAUNCH;
+        const TgPlan p = tg_plan(E, m.R, h, cn);
+        TgBatch b;
+        int vec4 = (k % 4 == 0);
+        for (int q = 0; q < cn; ++q) {
+            const phc_table_grad_job &jb = jobs[c0 + q];
+            PHC_REQUIRE(jb.dout && jb.tables && jb.dtables_flat && (act == PHC_ACT_IDENTITY || jb.x), PHC_ERR_INVALID_ARG,
+                        "phc_table_grads_batched: job %d: null pointer", c0 + q);
+            b.j[q].dout = jb.dout; b.j[q].x = jb.x; b.j[q].tables = jb.tables; b.j[q].flat = jb.dtables_flat;
+            b.j[q].slabs = wsf;
+            wsf += p.slab_floats;
+            vec4 = vec4 && al16(jb.dout) && (!jb.x || al16(jb.x));
+        }
+        const dim3 grid(p.tiles_i * p.tiles_j, p.num_slabs, cn);
+#define PHC_TGB_LAUNCH(ACTC)                                                                                              \
+    PHC_LAUNCH((table_grad_mfma_batched_kernel<ACTC>), grid, dim3(ENC_THREADS), 0, s, b, idx, m, (long long)E,            \
+               p.items_per_split, h, p.tiles_j, src, dst, n, k, vec4)
+        {
+            ProfScope prof(K_TABLE_GRAD, s);
+            switch (act) {
+                case PHC_ACT_IDENTITY: PHC_TGB_LAUNCH(PHC_ACT_IDENTITY); break;
+                case PHC_ACT_RELU: PHC_TGB_LAUNCH(PHC_ACT_RELU); break;
+                case PHC_ACT_LRELU: PHC_TGB_LAUNCH(PHC_ACT_LRELU); break;
+                case PHC_ACT_ELU: PHC_TGB_LAUNCH(PHC_ACT_ELU); break;
+                case PHC_ACT_SWISH: PHC_TGB_LAUNCH(PHC_ACT_SWISH); break;
+                default: PHC_TGB_LAUNCH(PHC_ACT_SELU); break;
+            }
+            rc = check_launch("table_grads_batched");
+            if (rc) return rc;
+        }
+#undef PHC_TGB_LAUNCH
+        ProfScope prof(K_TABLE_GRAD_REDUCE, s);
+        PHC_LAUNCH(table_grad_reduce_batched_kernel, dim3((m.R * h + 63) / 64, cn), dim3(256), 0, s, b, p.num_slabs, m.R, n, k);
+        rc = check_launch("table_grads_batched(reduce)");
+        if (rc) return rc;
     }
     return PHC_OK;
 }

@@ -39,6 +39,11 @@ class HJob(C.Structure):
                 ("n", C.c_int32), ("kin", C.c_int32), ("kout", C.c_int32), ("reserved", C.c_int32)]
 
 
+class TableGradJob(C.Structure):
+    """phc_table_grad_job (include/phc_hip.h)."""
+    _fields_ = [("dout", _P), ("x", _P), ("tables", _P), ("dtables_flat", _P)]
+
+
 SIGNATURES = {
     "phc_version": (_I, []),
     "phc_error_string": (C.c_char_p, [_I]),
@@ -74,6 +79,8 @@ SIGNATURES = {
     "phc_aggregate_enc_bwd_ws_bytes": (_S, [_L, _I, _P, _I, _I]),
     "phc_aggregate_enc_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _P, _P, _P, _L, _L, _I, _I, _I, _I, _I, _P, _P, _P,
                                    _S, _P]),
+    "phc_table_grads_ws_bytes": (_S, [_L, _I, _P, _I, _I, _I]),
+    "phc_table_grads_batched": (_I, [C.POINTER(TableGradJob), _I, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P, _S, _P]),
     "phc_bn_ws_bytes": (_S, [_L, _I]),
     "phc_bn_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _L, _I, _I, C.c_float, C.c_float, _I, _P, _P, _P, _P, _P, _S, _P]),
     "phc_bn_bwd": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _S, _P]),

@@ -41,6 +41,7 @@ class _Deferred:
     def __init__(self):
         self.active = False
         self.jobs = []
+        self.table_jobs = []
         self.lock = threading.Lock()       # the backward pass runs on autograd's device thread
 
 
@@ -55,17 +56,56 @@ def deferred_param_grads():
         yield
         return
     _DEFER.active = True
-    _DEFER.jobs = []
+    _DEFER.jobs, _DEFER.table_jobs = [], []
     try:
         yield
     except BaseException:
         _DEFER.active = False
-        _DEFER.jobs = []
+        _DEFER.jobs, _DEFER.table_jobs = [], []
         raise
     _DEFER.active = False
     jobs, _DEFER.jobs = _DEFER.jobs, []
+    tjobs, _DEFER.table_jobs = _DEFER.table_jobs, []
+    if tjobs:
+        _flush_table_grads(tjobs)
     if jobs:
         _flush_param_grads(jobs)
+
+
+def _flush_table_grads(jobs) -> None:
+    """Bond-table gradients of all message-passing layers that share one edge list: two launches per group."""
+    lib = L.load()
+    groups = {}
+    for jb in jobs:
+        groups.setdefault(jb["key"], []).append(jb)
+    for js in groups.values():
+        j0 = js[0]
+        ts, st, bond = j0["ts"], j0["st"], j0["bond"]
+        dev = bond.device
+        with torch.cuda.device(dev):
+            per = ts.n * ts.R * ts.k
+            flat = torch.empty(len(js) * per, dtype=torch.float32, device=dev)
+            arr = (L.TableGradJob * len(js))()
+            for i, jb in enumerate(js):
+                arr[i] = L.TableGradJob(L.ptr(jb["dout"]), L.ptr(jb["x"]), L.ptr(jb["ts"].ptrs), L.ptr(flat) + 4 * i * per)
+            ws_bytes = lib.phc_table_grads_ws_bytes(st.num_edges, ts.F, ts.vocab_c, ts.n, ts.k, len(js))
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            L.check(lib.phc_table_grads_batched(arr, len(js), L.ptr(bond), ts.vocab_c, L.ptr(st._src), L.ptr(st._dst),
+                                                st.num_edges, ts.F, ts.n, ts.k, j0["act"], L.ptr(ws), ws_bytes,
+                                                L.stream_ptr(dev)), "phc_table_grads_batched")
+            if L.PROF_ON:
+                E, Nd, h = st.num_edges, st.num_dst, ts.n * ts.k
+                for _ in js:
+                    L.account("table_grad", 1.0 * E * ts.F * h, Nd * 4.0 * h + E * (4.0 + 8.0 * ts.F) + 4.0 * (Nd + 1))
+            for i, jb in enumerate(js):
+                views = jb["ts"].grad_views(flat[i * per:(i + 1) * per])
+                for prm, g in zip(jb["params"], views):
+                    if prm is None:
+                        continue
+                    if prm.grad is None:
+                        prm.grad = g
+                    else:
+                        prm.grad.add_(g)
 
 
 def _flush_param_grads(jobs) -> None:
@@ -761,6 +801,9 @@ class _AggregateEncFn(torch.autograd.Function):
         ctx.st, ctx.act, ctx.add_self, ctx.ts = st, act, add_self, ts
         ctx.x_rows = x_.shape[0]
         ctx.save_for_backward(x_, bond_)
+        # table gradients can wait for the end of the backward pass when the tables are plain leaf parameters
+        ctx.defer_tables = tuple(tables) if (_DEFER.active and st.num_edges > 0 and
+                                             all(t.is_leaf and t.grad_fn is None for t in tables)) else None
         return out
 
     @staticmethod
@@ -783,7 +826,14 @@ class _AggregateEncFn(torch.autograd.Function):
                 dx[st.num_src:].zero_()
         flat = ws = None
         ws_bytes = 0
-        if need_t:
+        deferred = need_t and ctx.defer_tables is not None and _DEFER.active and not torch.is_grad_enabled()
+        if deferred:
+            params = [t if ng else None for t, ng in zip(ctx.defer_tables, ctx.needs_input_grad[6:])]
+            with _DEFER.lock:
+                _DEFER.table_jobs.append(dict(
+                    key=(bond_.data_ptr(), st._src.data_ptr(), st._dst.data_ptr(), st.num_edges, ts.F, ts.n, ts.k, tuple(ts.vocab),
+                         ctx.act), dout=dout_, x=x_, ts=ts, st=st, bond=bond_, act=ctx.act, params=params))
+        if need_t and not deferred:
             flat = torch.empty(ts.n * ts.R * ts.k, dtype=torch.float32, device=dev)
             ws_bytes = lib.phc_aggregate_enc_bwd_ws_bytes(st.num_edges, ts.F, ts.vocab_c, ts.n, ts.k)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
@@ -796,9 +846,9 @@ class _AggregateEncFn(torch.autograd.Function):
             if need_x:
                 L.account("aggregate_enc_dx", 1.0 * E * h, E * (4.0 * h + 4) + Ns * 4.0 * h * (2 if ctx.add_self else 1)
                           + 4.0 * (Ns + 1))
-            if need_t:
+            if need_t and not deferred:
                 L.account("table_grad", 1.0 * E * ts.F * h, Nd * 4.0 * h + E * (4.0 + 8.0 * ts.F) + 4.0 * (Nd + 1))
-        grads = ts.grad_views(flat) if need_t else [None] * (ts.n * ts.F)
+        grads = ts.grad_views(flat) if (need_t and not deferred) else [None] * (ts.n * ts.F)
         return (dx, None, None, None, None, None, *grads)
 
 

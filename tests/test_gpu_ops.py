@@ -605,3 +605,42 @@ def test_bn_statistics_from_the_gemm_epilogue(ops, n, kin, kout, N, valid):
     assert_close(fused[2], Wr.grad, 5e-5, "dW vs oracle")
     for a, r in zip(fused[4 + 2 * n:], rm_r + rv_r):
         assert_close(a, r, 2e-5, "running stats vs oracle")
+
+
+def test_deferred_bond_table_gradients_match_the_per_layer_path(ops):
+    """Inside deferred_param_grads() the bond-table gradients of several encoded aggregations over one edge list
+    are produced by phc_table_grads_batched at the end; they must equal the per-layer gradients bit for bit
+    (same one-hot GEMM, same slab order is NOT guaranteed across plans -> fp32 tolerance) and accumulate into .grad."""
+    from phc_gnn_amd import synth
+    g = torch.Generator().manual_seed(51)
+    n, k, vocab, N, E = 4, 8, [5, 6, 2], 300, 1500
+    ei = torch.from_numpy(synth.random_edges(N, E, seed=5)).to(DEV)
+    bond = torch.stack([torch.randint(0, v, (E,), generator=g) for v in vocab], dim=1).to(DEV)
+    layers = []
+    for li in range(3):
+        tabs = [[(torch.randn(v, k, generator=g) * 0.5).to(DEV).requires_grad_() for v in vocab] for _ in range(n)]
+        layers.append((tabs, torch.randn(N, n * k, generator=g).to(DEV), torch.randn(N, n * k, generator=g).to(DEV)))
+
+    def run(deferred):
+        owners = []
+        for tabs, _, _ in layers:
+            for comp in tabs:
+                for t in comp:
+                    t.grad = None
+        layers[0][0][0][0].grad = torch.full_like(layers[0][0][0][0], 0.25)
+        ctx = ops.deferred_param_grads() if deferred else __import__("contextlib").nullcontext()
+        with ctx:
+            total = 0.0
+            for tabs, x, dy in layers:
+                owner = torch.nn.Module()
+                owners.append(owner)
+                ts = ops.tableset_for(owner, tabs)
+                out = ops.aggregate_sum_encoded(x.clone().requires_grad_(), ei, bond, ts, tabs, "relu", True)
+                total = total + (out * dy).sum()
+            total.backward()
+        return [[t.grad.clone() for comp in tabs for t in comp] for tabs, _, _ in layers]
+
+    a, b = run(True), run(False)
+    for li, (ga, gb) in enumerate(zip(a, b)):
+        for ti, (x1, x2) in enumerate(zip(ga, gb)):
+            assert_close(x1, x2, 2e-6, f"layer {li} table {ti}")
