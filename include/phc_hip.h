@@ -319,6 +319,19 @@ int phc_table_grads_batched(const phc_table_grad_job *jobs, int num_jobs, const 
                             const int64_t *edge_src_i64, const int64_t *edge_dst_i64, int64_t E, int F, int n, int k,
                             int act, void *ws, size_t ws_bytes, void *stream);
 
+/* Per-batch preprocessing on the device: drop the nodes no edge touches and re-index,
+ * i.e. the reference's CustomRemoveIsolatedNodes / PyG RemoveIsolatedNodes applied to every collated
+ * batch (benchmarks/utils.py:36-46, train_hiv.py:171-172) — there on the CPU, before the batch is moved.
+ * Kept nodes keep their order.  edge_*_out [E]: relabelled edge list; x_out [N, F] / batch_out [N] /
+ * kept_index [N] (old index of every kept node): rows [0, *n_kept_dev) are written, the rest untouched
+ * (fixed-shape batches keep their padding and read *n_kept_dev as the valid count).  x / batch /
+ * kept_index outputs may be NULL.  F = number of int64 feature columns of x (0: no x). */
+size_t phc_remove_isolated_ws_bytes(int64_t N);
+int phc_remove_isolated_nodes(const int64_t *edge_src_i64, const int64_t *edge_dst_i64, int64_t E, int64_t N,
+                              const int64_t *x_i64, int F, const int64_t *batch_i64, int64_t *edge_src_out,
+                              int64_t *edge_dst_out, int64_t *x_out, int64_t *batch_out, int64_t *kept_index,
+                              int32_t *n_kept_dev, void *ws, size_t ws_bytes, void *stream);
+
 /* ------------------------------------------------------------------------- *
  * Read-out
  * ------------------------------------------------------------------------- */

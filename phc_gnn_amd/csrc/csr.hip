@@ -131,6 +131,44 @@ static ScanLevels scan_levels(long long n) {
 
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
+// ---- remove isolated nodes (benchmarks/utils.py:36-46, applied to every collated batch: train_hiv.py:171-172) ----
+// keep[i] = 1 when node i touches an edge; newid = exclusive scan of keep; edges are relabelled, node rows compacted.
+__global__ void iso_flag_kernel(const long long *__restrict__ src, const long long *__restrict__ dst, long long E,
+                                int *__restrict__ keep) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (long long)gridDim.x * blockDim.x) {
+        keep[src[e]] = 1;                                   // benign race: every writer stores the same value
+        keep[dst[e]] = 1;
+    }
+}
+
+// newid holds the exclusive scan of keep over N + 1 entries (newid[N] = number of kept nodes)
+__global__ void iso_relabel_kernel(const long long *__restrict__ src, const long long *__restrict__ dst, long long E,
+                                   const int *__restrict__ newid, long long *__restrict__ src_out, long long *__restrict__ dst_out) {
+    for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (long long)gridDim.x * blockDim.x) {
+        src_out[e] = newid[src[e]];
+        dst_out[e] = newid[dst[e]];
+    }
+}
+
+__global__ void iso_compact_kernel(const int *__restrict__ newid, long long N, const long long *__restrict__ x, int F,
+                                   const long long *__restrict__ batch, long long *__restrict__ x_out,
+                                   long long *__restrict__ batch_out, long long *__restrict__ kept_index, int *__restrict__ n_kept) {
+    const long long total = N * (long long)(F > 0 ? F : 1);
+    const int Fe = F > 0 ? F : 1;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const long long i = t / Fe;
+        const int f = (int)(t - i * Fe);
+        const int id = newid[i];
+        if (newid[i + 1] == id) continue;                   // isolated: dropped
+        if (x && x_out) x_out[(long long)id * F + f] = x[i * F + f];
+        if (f == 0) {
+            if (batch && batch_out) batch_out[id] = batch[i];
+            if (kept_index) kept_index[id] = i;
+        }
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0 && n_kept) *n_kept = newid[N];
+}
+
 }  // namespace phc
 
 using namespace phc;
@@ -229,6 +267,66 @@ int phc_csr_build(const int64_t *key_i64, const int64_t *other_i64, int64_t E, i
         if (rc) return rc;
     }
     return PHC_OK;
+}
+
+size_t phc_remove_isolated_ws_bytes(int64_t N) {
+    if (N < 0) return 0;
+    ScanLevels L = scan_levels(N + 1);
+    return align_up(sizeof(int) * (size_t)(N + 1), 256) + align_up(sizeof(int) * (L.total_sum_ints + 1), 256);
+}
+
+int phc_remove_isolated_nodes(const int64_t *edge_src_i64, const int64_t *edge_dst_i64, int64_t E, int64_t N, const int64_t *x_i64,
+                              int F, const int64_t *batch_i64, int64_t *edge_src_out, int64_t *edge_dst_out, int64_t *x_out,
+                              int64_t *batch_out, int64_t *kept_index, int32_t *n_kept_dev, void *ws, size_t ws_bytes,
+                              void *stream) {
+    PHC_REQUIRE(E >= 0 && N >= 0 && F >= 0, PHC_ERR_INVALID_ARG, "phc_remove_isolated_nodes: E=%lld N=%lld F=%d", (long long)E,
+                (long long)N, F);
+    PHC_REQUIRE(N < (1LL << 31) - 1, PHC_ERR_UNSUPPORTED, "phc_remove_isolated_nodes: int32 index space exceeded");
+    PHC_REQUIRE(E == 0 || (edge_src_i64 && edge_dst_i64 && edge_src_out && edge_dst_out), PHC_ERR_INVALID_ARG,
+                "phc_remove_isolated_nodes: null edge pointer");
+    PHC_REQUIRE(ws && ws_bytes >= phc_remove_isolated_ws_bytes(N), PHC_ERR_WORKSPACE, "phc_remove_isolated_nodes: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    ScanLevels L = scan_levels(N + 1);
+    char *p = static_cast<char *>(ws);
+    int *newid = reinterpret_cast<int *>(p);
+    p += align_up(sizeof(int) * (size_t)(N + 1), 256);
+    int *sums = reinterpret_cast<int *>(p);
+    hipMemsetAsync(newid, 0, sizeof(int) * (size_t)(N + 1), s);
+    const long long *src = reinterpret_cast<const long long *>(edge_src_i64);
+    const long long *dst = reinterpret_cast<const long long *>(edge_dst_i64);
+    const unsigned egrid = (unsigned)((E + 255) / 256 > 8192 ? 8192 : ((E + 255) / 256 < 1 ? 1 : (E + 255) / 256));
+    if (E > 0) {
+        ProfScope prof(K_CSR_HIST, s);
+        PHC_LAUNCH(iso_flag_kernel, dim3(egrid), dim3(256), 0, s, src, dst, (long long)E, newid);
+    }
+    {
+        ProfScope prof(K_CSR_SCAN, s);
+        int *level_data[6];
+        int *level_sums[6];
+        level_data[0] = newid;
+        int *sp = sums;
+        for (int l = 0; l < L.levels; ++l) {
+            level_sums[l] = (L.blocks[l] > 1) ? sp : nullptr;
+            if (L.blocks[l] > 1) {
+                level_data[l + 1] = sp;
+                sp += L.blocks[l];
+            }
+        }
+        for (int l = 0; l < L.levels; ++l)
+            PHC_LAUNCH(scan_block_kernel, dim3((unsigned)L.blocks[l]), dim3(SCAN_THREADS), 0, s, level_data[l], level_sums[l], L.n[l]);
+        for (int l = L.levels - 2; l >= 0; --l)
+            PHC_LAUNCH(scan_add_kernel, dim3((unsigned)L.blocks[l]), dim3(SCAN_THREADS), 0, s, level_data[l], level_sums[l], L.n[l]);
+    }
+    ProfScope prof(K_CSR_FILL, s);
+    if (E > 0)
+        PHC_LAUNCH(iso_relabel_kernel, dim3(egrid), dim3(256), 0, s, src, dst, (long long)E, newid,
+                   reinterpret_cast<long long *>(edge_src_out), reinterpret_cast<long long *>(edge_dst_out));
+    const long long total = N * (long long)(F > 0 ? F : 1);
+    const unsigned ngrid = (unsigned)((total + 255) / 256 > 8192 ? 8192 : ((total + 255) / 256 < 1 ? 1 : (total + 255) / 256));
+    PHC_LAUNCH(iso_compact_kernel, dim3(ngrid), dim3(256), 0, s, newid, (long long)N, reinterpret_cast<const long long *>(x_i64), F,
+               reinterpret_cast<const long long *>(batch_i64), reinterpret_cast<long long *>(x_out),
+               reinterpret_cast<long long *>(batch_out), reinterpret_cast<long long *>(kept_index), n_kept_dev);
+    return check_launch("remove_isolated_nodes");
 }
 
 }  // extern "C"

@@ -166,3 +166,39 @@ def segment_structure(batch: torch.Tensor, num_segments: Optional[int] = None, i
 
 def clear_structure_cache() -> None:
     _cache.clear()
+
+
+def remove_isolated_nodes(x: Optional[torch.Tensor], edge_index: torch.Tensor, batch: Optional[torch.Tensor] = None,
+                          num_nodes: Optional[int] = None, sync: bool = True):
+    """Drop the nodes that no edge touches and re-index the edge list — the per-batch transform of the reference's
+    training loop (benchmarks/utils.py:36-46 / PyG ``RemoveIsolatedNodes``, train_hiv.py:171-172), on the device.
+
+    x: int64 [N, F] node features (or None), edge_index: int64 [2, E], batch: int64 [N] (or None).
+    ``sync=True`` returns (x', edge_index', batch', kept_index) trimmed to the kept nodes (one host read of the count,
+    which the reference pays too — it runs this on the CPU); ``sync=False`` returns full-size buffers whose rows
+    [0, n_kept) are valid plus the device int32 count: (x', edge_index', batch', kept_index, n_kept), for
+    fixed-shape batches.  edge_attr is untouched by the transform (edges are never removed)."""
+    lib = L.load()
+    dev = L.require_device(edge_index, x, batch)
+    ei = edge_index if edge_index.dtype == torch.int64 else edge_index.to(torch.int64)
+    ei = ei.contiguous()
+    E = ei.shape[1]
+    N = int(num_nodes if num_nodes is not None else (x.shape[0] if x is not None else batch.shape[0]))
+    x_ = None if x is None else x.to(torch.int64).contiguous().reshape(N, -1)
+    F = 0 if x_ is None else x_.shape[1]
+    b_ = None if batch is None else batch.to(torch.int64).contiguous()
+    ei_out = torch.empty_like(ei)
+    x_out = None if x_ is None else torch.zeros_like(x_)
+    b_out = None if b_ is None else torch.zeros_like(b_)
+    kept = torch.zeros(N, dtype=torch.int64, device=dev)
+    n_kept = torch.zeros((), dtype=torch.int32, device=dev)
+    ws_bytes = lib.phc_remove_isolated_ws_bytes(N)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    L.check(lib.phc_remove_isolated_nodes(L.ptr(ei[0]) if E else None, L.ptr(ei[1]) if E else None, E, N, L.ptr(x_), F, L.ptr(b_),
+                                          L.ptr(ei_out[0]) if E else None, L.ptr(ei_out[1]) if E else None, L.ptr(x_out),
+                                          L.ptr(b_out), L.ptr(kept), L.ptr(n_kept), L.ptr(ws), ws_bytes, L.stream_ptr(dev)),
+            "phc_remove_isolated_nodes")
+    if not sync:
+        return x_out, ei_out, b_out, kept, n_kept
+    k = int(n_kept.item())
+    return (None if x_out is None else x_out[:k]), ei_out, (None if b_out is None else b_out[:k]), kept[:k]

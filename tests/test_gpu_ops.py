@@ -644,3 +644,29 @@ def test_deferred_bond_table_gradients_match_the_per_layer_path(ops):
     for li, (ga, gb) in enumerate(zip(a, b)):
         for ti, (x1, x2) in enumerate(zip(ga, gb)):
             assert_close(x1, x2, 2e-6, f"layer {li} table {ti}")
+
+
+@pytest.mark.parametrize("seed,iso", [(1, 0.0), (2, 0.1), (3, 0.5)])
+def test_remove_isolated_nodes_matches_the_reference_transform(seed, iso):
+    """Device version of the per-batch transform (benchmarks/utils.py:36-46): restated with numpy here — nodes that
+    appear in no edge are dropped, the rest keep their order, edges are relabelled, x / batch rows follow."""
+    from phc_gnn_amd import synth
+    from phc_gnn_amd.graph import remove_isolated_nodes
+    b = synth.molecule_batch(40, seed=seed, isolated_frac=iso)
+    N = b.num_nodes
+    keep = np.zeros(N, dtype=bool)
+    keep[b.edge_index[0]] = True
+    keep[b.edge_index[1]] = True
+    newid = np.cumsum(keep) - 1
+    x, ei, bt = (torch.from_numpy(a).to(DEV) for a in (b.x, b.edge_index, b.batch))
+    x2, ei2, b2, kept = remove_isolated_nodes(x, ei, bt)
+    assert torch.equal(x2.cpu(), torch.from_numpy(b.x[keep]))
+    assert torch.equal(b2.cpu(), torch.from_numpy(b.batch[keep]))
+    assert torch.equal(ei2.cpu(), torch.from_numpy(newid[b.edge_index]))
+    assert torch.equal(kept.cpu(), torch.from_numpy(np.nonzero(keep)[0]))
+    if iso > 0:
+        assert int(keep.sum()) < N
+    # fixed-shape form: full-size buffers + device count
+    x3, ei3, b3, kept3, n_kept = remove_isolated_nodes(x, ei, bt, sync=False)
+    k = int(n_kept)
+    assert k == int(keep.sum()) and x3.shape[0] == N and torch.equal(x3[:k], x2) and torch.equal(ei3, ei2)
