@@ -319,6 +319,15 @@ int phc_table_grads_batched(const phc_table_grad_job *jobs, int num_jobs, const 
                             const int64_t *edge_src_i64, const int64_t *edge_dst_i64, int64_t E, int F, int n, int k,
                             int act, void *ws, size_t ws_bytes, void *stream);
 
+/* Both sorted views of one edge list — destination-sorted (rowptr/col/perm, forward) and source-sorted
+ * (rowptr_t/col_t/perm_t, backward) — side by side in FIVE launches instead of 22 (a training step needs
+ * both).  Same result as two phc_csr_build calls (stable order).  At most 16383 rows per side (molecule
+ * batches); larger graphs use phc_csr_build. */
+size_t phc_csr_pair_ws_bytes(int64_t E, int64_t n_src, int64_t n_dst);
+int phc_csr_build_pair(const int64_t *edge_src_i64, const int64_t *edge_dst_i64, int64_t E, int64_t n_src, int64_t n_dst,
+                       int32_t *rowptr, int32_t *col, int32_t *perm, int32_t *rowptr_t, int32_t *col_t, int32_t *perm_t,
+                       void *ws, size_t ws_bytes, void *stream);
+
 /* Per-batch preprocessing on the device: drop the nodes no edge touches and re-index,
  * i.e. the reference's CustomRemoveIsolatedNodes / PyG RemoveIsolatedNodes applied to every collated
  * batch (benchmarks/utils.py:36-46, train_hiv.py:171-172) — there on the CPU, before the batch is moved.

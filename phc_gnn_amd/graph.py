@@ -17,6 +17,7 @@ import torch
 from . import lib as L
 
 _CACHE_SIZE = 16
+_NO_PAIR = bool(__import__('os').environ.get('PHC_NO_CSR_PAIR'))
 _cache: "OrderedDict[tuple, EdgeStructure]" = OrderedDict()
 
 
@@ -72,11 +73,35 @@ class EdgeStructure:
             self._codes = {key: codes}
         return codes
 
+    PAIR_MAX_ROWS = 16383
+
+    def _build_pair(self) -> None:
+        """Both views side by side (phc_csr_build_pair: 5 launches instead of 22)."""
+        lib = L.load()
+        dev = self._src.device
+        E = self.num_edges
+
+        def alloc(rows):
+            return (torch.empty(rows + 1, dtype=torch.int32, device=dev), torch.empty(E, dtype=torch.int32, device=dev),
+                    torch.empty(E, dtype=torch.int32, device=dev))
+        csr, csc = alloc(self.num_dst), alloc(self.num_src)
+        ws_bytes = lib.phc_csr_pair_ws_bytes(E, self.num_src, self.num_dst)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        L.check(lib.phc_csr_build_pair(L.ptr(self._src), L.ptr(self._dst), E, self.num_src, self.num_dst, L.ptr(csr[0]),
+                                       L.ptr(csr[1]), L.ptr(csr[2]), L.ptr(csc[0]), L.ptr(csc[1]), L.ptr(csc[2]), L.ptr(ws),
+                                       ws_bytes, L.stream_ptr(dev)), "phc_csr_build_pair")
+        self._csr, self._csc = csr, csc
+
     @property
     def csr(self):
         """rowptr[num_dst+1], col = source of each in-edge, perm = original edge id."""
         if self._csr is None:
-            self._csr = _build_sorted(self._dst, self._src, self.num_dst)
+            # a differentiable forward will want the source-sorted view in its backward: build both at once
+            if (torch.is_grad_enabled() and self._csc is None and self.num_edges > 0 and not _NO_PAIR
+                    and 0 < max(self.num_src, self.num_dst) <= self.PAIR_MAX_ROWS):
+                self._build_pair()
+            else:
+                self._csr = _build_sorted(self._dst, self._src, self.num_dst)
         return self._csr
 
     @property

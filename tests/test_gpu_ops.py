@@ -670,3 +670,28 @@ def test_remove_isolated_nodes_matches_the_reference_transform(seed, iso):
     x3, ei3, b3, kept3, n_kept = remove_isolated_nodes(x, ei, bt, sync=False)
     k = int(n_kept)
     assert k == int(keep.sum()) and x3.shape[0] == N and torch.equal(x3[:k], x2) and torch.equal(ei3, ei2)
+
+
+@pytest.mark.parametrize("kind", ["molecules", "hub", "ragged"])
+def test_csr_pair_build_equals_two_single_builds(kind):
+    """phc_csr_build_pair (both sorted views in five launches) == two phc_csr_build calls, bit for bit."""
+    from phc_gnn_amd import synth
+    from phc_gnn_amd.graph import EdgeStructure
+    if kind == "molecules":
+        b = synth.molecule_batch(64, seed=9, isolated_frac=0.05)
+        ei, n = b.edge_index, b.num_nodes
+    elif kind == "hub":
+        n = 300
+        rng = np.random.default_rng(3)
+        ei = np.stack([rng.integers(0, n, 2000), np.concatenate([np.full(700, 5), rng.integers(0, n, 1300)])]).astype(np.int64)
+    else:
+        ei, n = synth.ragged_edges(500, seed=4), 500
+    t = torch.from_numpy(np.ascontiguousarray(ei)).to(DEV)
+    with torch.enable_grad():
+        a = EdgeStructure(t, n)
+        csr_a, csc_a = a.csr, a.csc
+    with torch.no_grad():
+        b2 = EdgeStructure(t, n)
+        csr_b, csc_b = b2.csr, b2.csc
+    for x, y in zip(csr_a + csc_a, csr_b + csc_b):
+        assert torch.equal(x, y)
