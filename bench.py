@@ -39,7 +39,7 @@ PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s HBM3E
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
 MFMA_KERNELS = ("phm_gemm_fwd", "phm_gemm_dx", "phm_dH_partial", "table_grad")
 # launch-profiler kernel name -> substring of the rocprofv3 kernel name in profiles/r01_pmc_traffic.json
-PMC_NAMES = {"phm_gemm_fwd": "phm_stream_kernel<0, 4", "phm_gemm_dx": "phm_stream_kernel<1, 4",
+PMC_NAMES = {"phm_gemm_fwd": "phm_stream_kernel<0, -1, 32, 4, 1>", "phm_gemm_dx": "phm_stream_kernel<0, -1, 32, 4, 0>",
              "phm_dH_partial": "phm_grads_partial_kernel", "aggregate_enc_fwd": "aggregate_enc_fwd_kernel",
              "aggregate_enc_dx": "aggregate_enc_dx_kernel", "aggregate_fwd": "aggregate_fwd_kernel",
              "bn_apply": "bn_apply_kernel", "bn_bwd_apply": "bn_bwd_apply_kernel", "bn_bwd_partial": "bn_bwd_partial_kernel",
