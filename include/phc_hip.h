@@ -103,7 +103,7 @@ int phc_phm_build_H_batched(const phc_phm_H_job *jobs, int num_jobs, void *strea
 
 /* y[N, Nout] = x[N, K] . M[K, Nout] (+ b[Nout]) (+ residual[N, Nout]) with a prebuilt row-major M
  * (H for the forward, H^T for dx; is_dx only labels the launch for the profiler).  Streaming MFMA
- * kernel; K <= 128, K % 4 == 0, x and M 16-byte aligned — otherwise PHC_ERR_UNSUPPORTED and the
+ * kernel; K <= 256, K % 4 == 0, x and M 16-byte aligned — otherwise PHC_ERR_UNSUPPORTED and the
  * caller uses phc_phm_linear_fwd / _bwd. */
 int phc_gemm_prebuilt(const float *x, const float *M, const float *b, const float *residual, int64_t N, int K,
                       int Nout, float *y, int is_dx, void *stream);

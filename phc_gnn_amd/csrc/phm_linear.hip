@@ -302,7 +302,7 @@ __global__ __launch_bounds__((GemmCfg<BM, BN>::THREADS)) void phm_gemm_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
-// Streaming kernel for K <= 128 (every PHM layer of hidden width <= 128): wave-decoupled.
+// Streaming kernel for K <= 256 (every PHM layer of hidden width <= 256): wave-decoupled.
 //   * the whole [K x BN] operand panel is assembled in LDS once per workgroup (one barrier);
 //   * after that every WAVEFRONT is on its own: it owns 32-row slabs of x, stages them through a
 //     private LDS buffer (no workgroup barrier), runs the MFMAs against the shared panel, transposes
@@ -325,8 +325,8 @@ __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
     float *__restrict__ stats_counts = nullptr) {
     constexpr int THREADS = 64 * WAVES, HS_STRIDE = BN + 1, CT = BN / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float *hs = smem;                                          // [128][HS_STRIDE]
-    float *stage_all = hs + 128 * HS_STRIDE;                   // [WAVES][ST_FLOATS]
+    float *hs = smem;                                          // [round_up(K, 8)][HS_STRIDE]
+    float *stage_all = hs + round_up(K, 8) * HS_STRIDE;        // [WAVES][ST_FLOATS]
     float *As = stage_all + WAVES * ST_FLOATS;                 // [n*n*n]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -889,7 +889,7 @@ static int launch_stream_cfg(const float *X, const float *A, const float *W, con
     if (STATS && gy > GEMM_STATS_MAX_PARTIALS) gy = GEMM_STATS_MAX_PARTIALS;      // one statistics partial per workgroup row
     if (gy < 1) gy = 1;
     if (num_partials) *num_partials = (int)gy;
-    const size_t lds = sizeof(float) * ((size_t)128 * (BN + 1) + (size_t)WAVES * ST_FLOATS + (size_t)n * n * n);
+    const size_t lds = sizeof(float) * ((size_t)round_up(K, 8) * (BN + 1) + (size_t)WAVES * ST_FLOATS + (size_t)n * n * n);
     const int out_vec4 = (Nout % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0) &&
                          (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0) &&
                          (!residual || (reinterpret_cast<uintptr_t>(residual) & 15) == 0);
@@ -904,6 +904,7 @@ static int launch_stream_cfg(const float *X, const float *A, const float *W, con
     return PHC_OK;
 }
 
+constexpr int GEMM_STREAM_MAX_K = 256;
 // rows at which the 128-column / 8-wave streaming configuration takes over from the 64-column / 4-wave one
 constexpr int64_t GEMM_BIG_M = 64 * 1024;
 
@@ -913,13 +914,16 @@ static int launch_gemm(const float *X, const float *A, const float *W, const flo
     if (M == 0) return PHC_OK;
     ProfScope prof(TRANS ? K_PHM_GEMM_DX : K_PHM_GEMM_FWD, s);
     const bool vec4 = (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
-    const bool stream = vec4 && K <= 128 && !getenv("PHC_GEMM_TILED");
+    const bool stream = vec4 && K <= GEMM_STREAM_MAX_K && !getenv("PHC_GEMM_TILED");
+    const bool wide_k = K > 128;                       // the [K x 128] panel no longer fits next to 8 staging buffers
     const bool big = M >= GEMM_BIG_M && Nout > 64;
     // molecule batches: 32-column panels give 4x the wavefronts of the 128-column config, each a quarter as long
     // (measured on MI355X: no gain for y = x.H, slower for dx — kept as an opt-in experiment)
     const bool small32 = M <= 24 * 1024 && Nout >= 64 && getenv("PHC_GEMM_32") != nullptr;
 #define PHC_GEMM_LAUNCH(NP)                                                                                              \
-    if (stream && big)                                                                                                   \
+    if (stream && big && wide_k)                                                                                         \
+        launch_stream_cfg<TRANS, NP, 64, 8>(X, A, W, bias, residual, out, M, K, Nout, n, kin, kout, 1, s);                \
+    else if (stream && big)                                                                                              \
         launch_stream_cfg<TRANS, NP, 128, 8>(X, A, W, bias, residual, out, M, K, Nout, n, kin, kout, 1, s);               \
     else if (stream && small32)                                                                                          \
         launch_stream_cfg<TRANS, NP, 32, 4>(X, A, W, bias, residual, out, M, K, Nout, n, kin, kout, 3, s);                \
@@ -1125,15 +1129,18 @@ int phc_gemm_prebuilt(const float *x, const float *M, const float *b, const floa
     PHC_REQUIRE(N >= 0 && K >= 1 && Nout >= 1, PHC_ERR_INVALID_ARG, "phc_gemm_prebuilt: bad shape");
     if (N == 0) return PHC_OK;
     PHC_REQUIRE(x && M && y, PHC_ERR_INVALID_ARG, "phc_gemm_prebuilt: null pointer");
-    PHC_REQUIRE(K <= 128 && K % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(M) & 15) == 0,
-                PHC_ERR_UNSUPPORTED, "phc_gemm_prebuilt: needs K <= 128, K %% 4 == 0 and 16-byte aligned x, M (K=%d)", K);
+    PHC_REQUIRE(K <= GEMM_STREAM_MAX_K && K % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(M) & 15) == 0,
+                PHC_ERR_UNSUPPORTED, "phc_gemm_prebuilt: needs K <= 256, K %% 4 == 0 and 16-byte aligned x, M (K=%d)", K);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(is_dx ? K_PHM_GEMM_DX : K_PHM_GEMM_FWD, s);
     // Few rows (molecule batches: about one 32-row slab per wavefront): 32-column panels give twice the wavefronts,
     // each half as long — measured 0.8 us per launch faster than 64-column panels at N = 13.8k; above that the extra
     // re-reads of x cost more than the occupancy gains.  PHC_GEMM_PRE_BN=64 forces the wider panel.
     static const int small_bn = getenv("PHC_GEMM_PRE_BN") ? atoi(getenv("PHC_GEMM_PRE_BN")) : 32;
-    if (N >= GEMM_BIG_M && Nout > 64)
+    if (N >= GEMM_BIG_M && Nout > 64 && K > 128)
+        launch_stream_cfg<0, -1, 64, 8>(x, nullptr, M, b, residual, y, N, K, Nout, 1, K, Nout, 1, s);
+    else if (N >= GEMM_BIG_M && Nout > 64)
         launch_stream_cfg<0, -1, 128, 8>(x, nullptr, M, b, residual, y, N, K, Nout, 1, K, Nout, 1, s);
     else if (small_bn == 32 && Nout > 32 && N <= 32 * 1024)
         launch_stream_cfg<0, -1, 32, 4>(x, nullptr, M, b, residual, y, N, K, Nout, 1, K, Nout, 3, s);
@@ -1149,12 +1156,16 @@ int phc_gemm_prebuilt_stats(const float *x, const float *M, const float *b, int6
     PHC_REQUIRE(N >= 1 && K >= 1 && Nout >= 1, PHC_ERR_INVALID_ARG, "phc_gemm_prebuilt_stats: bad shape");
     PHC_REQUIRE(x && M && y && stats_partial && stats_counts && num_partials, PHC_ERR_INVALID_ARG,
                 "phc_gemm_prebuilt_stats: null pointer");
-    PHC_REQUIRE(K <= 128 && K % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(M) & 15) == 0,
-                PHC_ERR_UNSUPPORTED, "phc_gemm_prebuilt_stats: needs K <= 128, K %% 4 == 0 and 16-byte aligned x, M (K=%d)", K);
+    PHC_REQUIRE(K <= GEMM_STREAM_MAX_K && K % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(M) & 15) == 0,
+                PHC_ERR_UNSUPPORTED, "phc_gemm_prebuilt_stats: needs K <= 256, K %% 4 == 0 and 16-byte aligned x, M (K=%d)", K);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(K_PHM_GEMM_FWD, s);
     static const int small_bn = getenv("PHC_GEMM_PRE_BN") ? atoi(getenv("PHC_GEMM_PRE_BN")) : 32;
-    if (N >= GEMM_BIG_M && Nout > 64)
+    if (N >= GEMM_BIG_M && Nout > 64 && K > 128)
+        launch_stream_cfg<0, -1, 64, 8, 1>(x, nullptr, M, b, nullptr, y, N, K, Nout, 1, K, Nout, 1, s, n_valid_dev, stats_partial,
+                                           stats_counts, num_partials);
+    else if (N >= GEMM_BIG_M && Nout > 64)
         launch_stream_cfg<0, -1, 128, 8, 1>(x, nullptr, M, b, nullptr, y, N, K, Nout, 1, K, Nout, 1, s, n_valid_dev, stats_partial,
                                             stats_counts, num_partials);
     else if (small_bn == 32 && Nout > 32 && N <= 32 * 1024)

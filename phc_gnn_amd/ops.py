@@ -187,7 +187,7 @@ def prebuilt_H(pairs):
     for A, W in pairs:
         n, kin, kout = W.shape
         if A.is_cuda and W.is_cuda and A.dtype == W.dtype == torch.float32 and A.is_contiguous() and W.is_contiguous() \
-                and (n * kout) <= 128 and (n * kin) <= 128 and (n * kin) % 4 == 0 and (n * kout) % 4 == 0:
+                and (n * kout) <= 256 and (n * kin) <= 256 and (n * kin) % 4 == 0 and (n * kout) % 4 == 0:
             by_dev.setdefault(W.device, []).append((A, W))
     try:
         for dev, prs in by_dev.items():
