@@ -206,7 +206,7 @@ int phc_bce_masked_fwd(const float *logits, const float *y, int64_t total, float
                        void *stream) {
     PHC_REQUIRE(total > 0 && logits && y && loss && stat, PHC_ERR_INVALID_ARG, "phc_bce_masked_fwd: bad arguments");
     hipStream_t s = (hipStream_t)stream;
-    int blocks = (int)((total + (1 << 16) - 1) >> 16);          // 64k entries per workgroup
+    int blocks = (int)((total + (1 << 12) - 1) >> 12);          // 4k entries (4 per thread) per workgroup
     if (blocks > 256) blocks = 256;
     PHC_REQUIRE(blocks == 1 || (ws && ws_bytes >= phc_bce_masked_ws_bytes(total)), PHC_ERR_WORKSPACE,
                 "phc_bce_masked_fwd: workspace too small");

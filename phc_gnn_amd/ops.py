@@ -625,7 +625,7 @@ class _MaskedBCEFn(torch.autograd.Function):
         total = z_.numel()
         out = torch.empty(3, dtype=torch.float32, device=dev)             # loss | sum | labeled count
         ws_bytes = lib.phc_bce_masked_ws_bytes(total)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if total > (1 << 16) else None
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if total > (1 << 12) else None
         L.check(lib.phc_bce_masked_fwd(L.ptr(z_), L.ptr(y_), total, L.ptr(out), L.ptr(out) + 4, L.ptr(ws),
                                        ws_bytes if ws is not None else 0, L.stream_ptr(dev)), "phc_bce_masked_fwd")
         ctx.save_for_backward(z_, y_, out)
