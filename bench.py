@@ -148,7 +148,14 @@ def main():
     cfg = harness.StepConfig(regression=bool(w.get("regression")), grad_clip=2.0, optimizer=not args.fwd_bwd_only)
     host_batches = [harness.make_batch(args.workload, seed=1000 * rank + i) for i in range(args.num_batches)]
     batches = [harness.to_device(gb, dev) for gb in host_batches]
-    grad_sync = make_grad_sync(model, world) if world > 1 else None
+    # PHC_BENCH_FORCE_SYNC=1: exercise the data-parallel step (two graphs + RCCL all-reduce) on a single rank
+    force_sync = world == 1 and bool(os.environ.get("PHC_BENCH_FORCE_SYNC"))
+    if force_sync:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    grad_sync = make_grad_sync(model, world) if (world > 1 or force_sync) else None
 
     graph_step = None
     prof = None
@@ -252,7 +259,7 @@ def main():
             result["cpu_baseline"] = cpu_baseline(args, args.workload, model, host_batches[0])
         print(json.dumps(result), flush=True)
 
-    if world > 1:
+    if world > 1 or force_sync:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
