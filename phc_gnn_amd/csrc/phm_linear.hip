@@ -629,9 +629,10 @@ constexpr int DH_STRIDE = DH_T;     // lanes read consecutive columns: conflict-
 
 __device__ __forceinline__ void dH_partial_body(const float *__restrict__ X, const float *__restrict__ DY,
                                                 float *__restrict__ slabs, long long N, int in, int out, int tiles_j,
-                                                long long rows_per_split, int vec4, int tile, long long split) {
-    __shared__ __attribute__((aligned(16))) float xs[DH_RB * DH_STRIDE];
-    __shared__ __attribute__((aligned(16))) float ds[DH_RB * DH_STRIDE];
+                                                long long rows_per_split, int vec4, int tile, long long split,
+                                                float *__restrict__ smem) {
+    float *xs = smem;                                    // [DH_RB][DH_STRIDE]
+    float *ds = smem + DH_RB * DH_STRIDE;                // [DH_RB][DH_STRIDE]
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 1, wj = wave & 1;
@@ -697,10 +698,111 @@ __device__ __forceinline__ void dH_partial_body(const float *__restrict__ X, con
     if (ti == 0 && tid < DH_T && j0 + tid < out) slab[(size_t)in * out + j0 + tid] = colsum;
 }
 
+// 128 x 128 tile variant (in, out >= 128): each wavefront owns a 64 x 64 quadrant = 2 x 2 MFMA tiles, rows staged
+// 32 at a time.  Twice the MFMAs per staged byte and per LDS read of the 64 x 64 form, and when in = out = 128 the
+// tile is the whole matrix, so x and dy are read exactly once (the 64 x 64 form reads each twice: its 258 MB per
+// batched launch at config 2 made it HBM/L2-bound at 56 % of the MFMA peak).
+constexpr int DH_T2 = 128;
+constexpr int DH_RB2 = 32;
+
+__device__ __forceinline__ void dH_partial_body128(const float *__restrict__ X, const float *__restrict__ DY,
+                                                   float *__restrict__ slabs, long long N, int in, int out, int tiles_j,
+                                                   long long rows_per_split, int vec4, int tile, long long split,
+                                                   float *__restrict__ smem) {
+    float *xs = smem;                                    // [DH_RB2][DH_T2]
+    float *ds = smem + DH_RB2 * DH_T2;                   // [DH_RB2][DH_T2]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int r = lane & 31, hh = lane >> 5;
+    const int ti = tile / tiles_j, tj = tile - ti * tiles_j;
+    const int i0 = ti * DH_T2, j0 = tj * DH_T2;
+    const long long r_begin = split * rows_per_split;
+    const long long r_end = min(N, r_begin + rows_per_split);
+    const size_t slab_elems = (size_t)in * out + out;
+    float *slab = slabs + (size_t)split * slab_elems;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    float colsum = 0.f;                                  // threads 0..127 of tile_i == 0 workgroups
+
+    for (long long rb = r_begin; rb < r_end; rb += DH_RB2) {
+        __syncthreads();
+        if (vec4) {
+            // 32 rows x 32 float4 per operand = 4 float4 per thread and operand, all issued before the LDS stores
+            f32x4 xv[4], dv[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int e = tid + 256 * t;
+                const int row = e >> 5, c4 = e & 31;
+                const long long grow = min(rb + row, r_end - 1);
+                const int ci = min(i0 + c4 * 4, in - 4), cj = min(j0 + c4 * 4, out - 4);
+                xv[t] = *reinterpret_cast<const f32x4 *>(X + (size_t)grow * in + ci);
+                dv[t] = *reinterpret_cast<const f32x4 *>(DY + (size_t)grow * out + cj);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int e = tid + 256 * t;
+                const int row = e >> 5, c4 = e & 31;
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                const bool rok = rb + row < r_end;
+                *reinterpret_cast<f32x4 *>(xs + row * DH_T2 + c4 * 4) = (rok && i0 + c4 * 4 < in) ? xv[t] : z;
+                *reinterpret_cast<f32x4 *>(ds + row * DH_T2 + c4 * 4) = (rok && j0 + c4 * 4 < out) ? dv[t] : z;
+            }
+        } else {
+            for (int e = tid; e < DH_RB2 * DH_T2; e += 256) {
+                const int row = e / DH_T2, c = e - row * DH_T2;
+                float xv = 0.f, dv = 0.f;
+                if (rb + row < r_end) {
+                    if (i0 + c < in) xv = X[(size_t)(rb + row) * in + i0 + c];
+                    if (j0 + c < out) dv = DY[(size_t)(rb + row) * out + j0 + c];
+                }
+                xs[row * DH_T2 + c] = xv;
+                ds[row * DH_T2 + c] = dv;
+            }
+        }
+        __syncthreads();
+        const float *xa = xs + hh * DH_T2 + wi * 64 + r;
+        const float *db_ = ds + hh * DH_T2 + wj * 64 + r;
+#pragma unroll 4
+        for (int rr = 0; rr < DH_RB2; rr += 2) {
+            const float a0 = xa[rr * DH_T2], a1 = xa[rr * DH_T2 + 32];
+            const float b0 = db_[rr * DH_T2], b1 = db_[rr * DH_T2 + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (ti == 0 && tid < DH_T2) {
+#pragma unroll 8
+            for (int rr = 0; rr < DH_RB2; ++rr) colsum += ds[rr * DH_T2 + tid];
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int col = j0 + wj * 64 + b * 32 + r;
+            if (col < out) {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int row = i0 + wi * 64 + a * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+                    if (row < in) slab[(size_t)row * out + col] = acc[a][b][reg];
+                }
+            }
+        }
+    if (ti == 0 && tid < DH_T2 && j0 + tid < out) slab[(size_t)in * out + j0 + tid] = colsum;
+}
+
 __global__ __launch_bounds__(256) void phm_dH_partial_kernel(const float *__restrict__ X, const float *__restrict__ DY,
                                                             float *__restrict__ slabs, long long N, int in, int out,
                                                             int tiles_j, long long rows_per_split, int vec4) {
-    dH_partial_body(X, DY, slabs, N, in, out, tiles_j, rows_per_split, vec4, blockIdx.x, blockIdx.y);
+    __shared__ __attribute__((aligned(16))) float smem[2 * DH_RB * DH_STRIDE];
+    dH_partial_body(X, DY, slabs, N, in, out, tiles_j, rows_per_split, vec4, blockIdx.x, blockIdx.y, smem);
 }
 
 // dH[idx] (and the db tail) = sum over splits.  64 elements x 4 split lanes per workgroup; every lane
@@ -790,7 +892,7 @@ struct GradJobDev {
     long long N, rows_per_split;
     int in, out, n, kin, kout;
     int tiles_j, tiles, splits, vec4;
-    int dA_blocks;
+    int dA_blocks, t128;
     unsigned blk0_partial, blk0_reduce, blk0_contract;      // first workgroup of this job in each launch
 };
 struct GradBatch {
@@ -808,13 +910,23 @@ __device__ __forceinline__ int grad_job_of_block(const GradBatch &b, unsigned bx
     return job;
 }
 
+// one launch per tile shape (a job of the other shape has blk0_partial = UINT_MAX and is never selected): the two
+// bodies have very different register needs, and a merged kernel would run the 64 x 64 jobs at the 128 x 128 body's occupancy
+template <int T128>
 __global__ __launch_bounds__(256) void phm_grads_partial_kernel(GradBatch b) {
-    const int k = grad_job_of_block<0>(b, blockIdx.x);
+    int k = 0;
+    for (int q = 0; q < b.num; ++q)
+        if (b.j[q].blk0_partial != 0xffffffffu && blockIdx.x >= b.j[q].blk0_partial) k = q;
     const GradJobDev &j = b.j[k];
     const unsigned local = blockIdx.x - j.blk0_partial;
     const int tile = local % j.tiles;
     const long long split = local / j.tiles;
-    dH_partial_body(j.x, j.dy, j.slabs, j.N, j.in, j.out, j.tiles_j, j.rows_per_split, j.vec4, tile, split);
+    __shared__ __attribute__((aligned(16))) float smem[2 * DH_RB * DH_STRIDE];      // 32 KB, either tile shape
+    static_assert(2 * DH_RB * DH_STRIDE == 2 * DH_RB2 * DH_T2, "both tile shapes stage 32 KB");
+    if constexpr (T128)
+        dH_partial_body128(j.x, j.dy, j.slabs, j.N, j.in, j.out, j.tiles_j, j.rows_per_split, j.vec4, tile, split, smem);
+    else
+        dH_partial_body(j.x, j.dy, j.slabs, j.N, j.in, j.out, j.tiles_j, j.rows_per_split, j.vec4, tile, split, smem);
 }
 
 __global__ __launch_bounds__(256) void phm_grads_reduce_kernel(GradBatch b) {
@@ -1179,7 +1291,7 @@ int phc_gemm_prebuilt_stats(const float *x, const float *M, const float *b, int6
 
 // ---- batched parameter gradients ------------------------------------------------------------
 struct GradPlan {
-    int tiles_i, tiles_j, splits;
+    int tiles_i, tiles_j, splits, t128;
     int64_t rows_per_split;
     size_t slab_elems;
 };
@@ -1188,10 +1300,15 @@ struct GradPlan {
 // their row-block counts (depends on the shapes only, never on the device: fixed summation order).
 static void grad_plans(const phc_phm_grad_job *jobs, int num, GradPlan *plans) {
     int64_t total = 0;
+    static const bool no128 = getenv("PHC_DH_NO_128") != nullptr;
     for (int k = 0; k < num; ++k) {
         const int in = jobs[k].n * jobs[k].kin, out = jobs[k].n * jobs[k].kout;
-        plans[k].tiles_i = (in + DH_T - 1) / DH_T;
-        plans[k].tiles_j = (out + DH_T - 1) / DH_T;
+        // 128 x 128 tiles when that still leaves >= 4 tiles per matrix: with fewer, the launch needs so many more
+        // row splits for parallelism that the extra slab traffic outweighs the halved operand reads (measured at 128 x 128)
+        plans[k].t128 = (in >= 2 * DH_T2 && out >= 2 * DH_T2 && in % 4 == 0 && out % 4 == 0 && !no128) ? 1 : 0;
+        const int T = plans[k].t128 ? DH_T2 : DH_T;
+        plans[k].tiles_i = (in + T - 1) / T;
+        plans[k].tiles_j = (out + T - 1) / T;
         plans[k].slab_elems = (size_t)in * out + out;
         total += (int64_t)plans[k].tiles_i * plans[k].tiles_j * ((jobs[k].N + DH_RB - 1) / DH_RB);
     }
@@ -1255,7 +1372,7 @@ int phc_phm_param_grads(const phc_phm_grad_job *jobs, int num_jobs, void *ws, si
         grad_plans(jobs + c0, cn, plans);
         GradBatch b;
         b.num = cn;
-        unsigned nb_partial = 0, nb_reduce = 0, nb_contract = 0;
+        unsigned nb_partial = 0, nb_partial128 = 0, nb_reduce = 0, nb_contract = 0;
         for (int k = 0; k < cn; ++k) {
             const phc_phm_grad_job &jb = jobs[c0 + k];
             PHC_REQUIRE(jb.x && jb.dy && jb.A && jb.W && (jb.dW || jb.dA || jb.db), PHC_ERR_INVALID_ARG,
@@ -1268,22 +1385,31 @@ int phc_phm_param_grads(const phc_phm_grad_job *jobs, int num_jobs, void *ws, si
             d.tiles_j = plans[k].tiles_j;
             d.tiles = plans[k].tiles_i * plans[k].tiles_j;
             d.splits = plans[k].splits;
+            d.t128 = plans[k].t128;
             d.rows_per_split = plans[k].rows_per_split;
             d.vec4 = (d.in % 4 == 0) && (d.out % 4 == 0) && ((reinterpret_cast<uintptr_t>(jb.x) & 15) == 0) &&
                      ((reinterpret_cast<uintptr_t>(jb.dy) & 15) == 0);
             d.slabs = base + offsets[c0 + k];
             d.dH = d.slabs + plans[k].slab_elems * (size_t)plans[k].splits;
             d.dA_blocks = jb.n * jb.n * jb.n;
-            d.blk0_partial = nb_partial;
+            d.blk0_partial = d.t128 ? nb_partial128 : nb_partial;
             d.blk0_reduce = nb_reduce;
             d.blk0_contract = nb_contract;
-            nb_partial += (unsigned)d.tiles * (unsigned)d.splits;
+            (d.t128 ? nb_partial128 : nb_partial) += (unsigned)d.tiles * (unsigned)d.splits;
             nb_reduce += (unsigned)((plans[k].slab_elems + 63) / 64);
             nb_contract += (unsigned)(d.dA_blocks + (jb.n * jb.kin * jb.kout + 255) / 256);
         }
-        {
+        for (int shape = 0; shape < 2; ++shape) {
+            const unsigned nb = shape ? nb_partial128 : nb_partial;
+            if (nb == 0) continue;
+            GradBatch bs = b;                                // jobs of the other tile shape are masked out
+            for (int k = 0; k < cn; ++k)
+                if (bs.j[k].t128 != shape) bs.j[k].blk0_partial = 0xffffffffu;
             ProfScope prof(K_PHM_DH_PARTIAL, s);
-            PHC_LAUNCH(phm_grads_partial_kernel, dim3(nb_partial), dim3(256), 0, s, b);
+            if (shape)
+                PHC_LAUNCH(phm_grads_partial_kernel<1>, dim3(nb), dim3(256), 0, s, bs);
+            else
+                PHC_LAUNCH(phm_grads_partial_kernel<0>, dim3(nb), dim3(256), 0, s, bs);
             rc = check_launch("phm_grads_partial");
             if (rc) return rc;
         }

@@ -99,7 +99,8 @@ def test_deferred_param_grads_match_oracle_and_per_layer_path(ops):
     from oracle import phc_oracle as O
     g = torch.Generator().manual_seed(11)
     shapes = [(4, 32, 32, 1500), (4, 32, 32, 70), (2, 16, 24, 333), (1, 40, 8, 90), (3, 5, 7, 129), (8, 16, 16, 64),
-              (4, 32, 8, 1)] + [(4, 8, 8, 40 + 3 * i) for i in range(14)]          # 21 jobs > 16 per launch
+              (4, 32, 8, 1), (4, 64, 64, 700), (8, 32, 48, 333)] + \
+             [(4, 8, 8, 40 + 3 * i) for i in range(14)]          # 23 jobs > 16 per launch; two of them on 128 x 128 tiles
     layers = []
     for li, (n, kin, kout, N) in enumerate(shapes):
         layers.append(dict(x=torch.randn(N, n * kin, generator=g), A=torch.randn(n, n, n, generator=g),
