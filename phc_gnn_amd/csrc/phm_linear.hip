@@ -910,6 +910,13 @@ __device__ __forceinline__ int grad_job_of_block(const GradBatch &b, unsigned bx
     return job;
 }
 
+__global__ __launch_bounds__(256) void phm_dH_partial128_kernel(const float *__restrict__ X, const float *__restrict__ DY,
+                                                               float *__restrict__ slabs, long long N, int in, int out,
+                                                               int tiles_j, long long rows_per_split, int vec4) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * DH_RB2 * DH_T2];
+    dH_partial_body128(X, DY, slabs, N, in, out, tiles_j, rows_per_split, vec4, blockIdx.x, blockIdx.y, smem);
+}
+
 // one launch per tile shape (a job of the other shape has blk0_partial = UINT_MAX and is never selected): the two
 // bodies have very different register needs, and a merged kernel would run the 64 x 64 jobs at the 128 x 128 body's occupancy
 template <int T128>
@@ -1056,7 +1063,17 @@ static int launch_gemm(const float *X, const float *A, const float *W, const flo
     return check_launch(TRANS ? "phm_gemm_dx" : "phm_gemm_fwd");
 }
 
+// 128 x 128 tiles when that still leaves >= 4 tiles per matrix, or when there are so many rows that the extra row
+// splits a single big tile needs cost nothing next to the operand stream (>= 64k rows): otherwise the slab
+// traffic of those splits outweighs the halved operand reads (measured at 128 x 128, N = 13.8k)
+static inline bool dh_use_128(int64_t N, int in, int out) {
+    static const bool no128 = getenv("PHC_DH_NO_128") != nullptr;
+    if (no128 || in < DH_T2 || out < DH_T2 || in % 4 || out % 4) return false;
+    return (in >= 2 * DH_T2 && out >= 2 * DH_T2) || N >= 64 * 1024;
+}
+
 struct DhPlan {
+    int t128;
     int tiles_i, tiles_j, splits;
     int64_t rows_per_split;
     size_t slab_elems;
@@ -1064,8 +1081,10 @@ struct DhPlan {
 
 static DhPlan dh_plan(int64_t N, int in, int out) {
     DhPlan p;
-    p.tiles_i = (in + DH_T - 1) / DH_T;
-    p.tiles_j = (out + DH_T - 1) / DH_T;
+    p.t128 = dh_use_128(N, in, out) ? 1 : 0;
+    const int T = p.t128 ? DH_T2 : DH_T;
+    p.tiles_i = (in + T - 1) / T;
+    p.tiles_j = (out + T - 1) / T;
     const int tiles = p.tiles_i * p.tiles_j;
     static const int target_blocks = getenv("PHC_DH_BLOCKS") ? atoi(getenv("PHC_DH_BLOCKS")) : 512;
     int64_t splits = (target_blocks + tiles - 1) / tiles;       // ~2 workgroups per CU (fixed: plan must not depend on the device)
@@ -1175,8 +1194,12 @@ int phc_phm_linear_bwd(const float *x, const float *A, const float *W, const flo
                              ((reinterpret_cast<uintptr_t>(dy) & 15) == 0);
             {
                 ProfScope prof(K_PHM_DH_PARTIAL, sp);
-                PHC_LAUNCH(phm_dH_partial_kernel, dim3(p.tiles_i * p.tiles_j, p.splits), dim3(256), 0, sp, x, dy, slabs,
-                                   (long long)N, in, out, p.tiles_j, (long long)p.rows_per_split, vec4);
+                if (p.t128)
+                    PHC_LAUNCH(phm_dH_partial128_kernel, dim3(p.tiles_i * p.tiles_j, p.splits), dim3(256), 0, sp, x, dy, slabs,
+                               (long long)N, in, out, p.tiles_j, (long long)p.rows_per_split, vec4);
+                else
+                    PHC_LAUNCH(phm_dH_partial_kernel, dim3(p.tiles_i * p.tiles_j, p.splits), dim3(256), 0, sp, x, dy, slabs,
+                               (long long)N, in, out, p.tiles_j, (long long)p.rows_per_split, vec4);
                 rc = check_launch("phm_dH_partial");
                 if (rc) return rc;
             }
@@ -1300,12 +1323,9 @@ struct GradPlan {
 // their row-block counts (depends on the shapes only, never on the device: fixed summation order).
 static void grad_plans(const phc_phm_grad_job *jobs, int num, GradPlan *plans) {
     int64_t total = 0;
-    static const bool no128 = getenv("PHC_DH_NO_128") != nullptr;
     for (int k = 0; k < num; ++k) {
         const int in = jobs[k].n * jobs[k].kin, out = jobs[k].n * jobs[k].kout;
-        // 128 x 128 tiles when that still leaves >= 4 tiles per matrix: with fewer, the launch needs so many more
-        // row splits for parallelism that the extra slab traffic outweighs the halved operand reads (measured at 128 x 128)
-        plans[k].t128 = (in >= 2 * DH_T2 && out >= 2 * DH_T2 && in % 4 == 0 && out % 4 == 0 && !no128) ? 1 : 0;
+        plans[k].t128 = dh_use_128(jobs[k].N, in, out) ? 1 : 0;
         const int T = plans[k].t128 ? DH_T2 : DH_T;
         plans[k].tiles_i = (in + T - 1) / T;
         plans[k].tiles_j = (out + T - 1) / T;

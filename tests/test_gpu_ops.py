@@ -696,3 +696,23 @@ def test_csr_pair_build_equals_two_single_builds(kind):
         csr_b, csc_b = b2.csr, b2.csc
     for x, y in zip(csr_a + csc_a, csr_b + csc_b):
         assert torch.equal(x, y)
+
+
+def test_phm_linear_backward_large_n_uses_the_wide_tile(ops):
+    """N >= 64k rows: dH = x^T.dy runs on 128 x 128 tiles (per-layer path); results vs the oracle."""
+    from oracle import phc_oracle as O
+    g = torch.Generator().manual_seed(61)
+    n, kin, kout, N = 4, 32, 32, 70001
+    x = torch.randn(N, n * kin, generator=g)
+    A = torch.randn(n, n, n, generator=g)
+    W = torch.randn(n, kin, kout, generator=g) * 0.1
+    dy = torch.randn(N, n * kout, generator=g)
+    xd, Ad, Wd = (t.to(DEV).requires_grad_() for t in (x, A, W))
+    bd = torch.zeros(n * kout, device=DEV, requires_grad=True)
+    y = ops.phm_linear(xd, Ad, Wd, bd)
+    gx, gW, gA, gb = torch.autograd.grad(y, [xd, Wd, Ad, bd], dy.to(DEV))
+    ex = O.phm_linear_backward(x.double(), A.double(), W.double(), dy.double())
+    assert_close(gx, ex[0].float(), TOL, "dx")
+    assert_close(gW, ex[1].float(), TOL, "dW")
+    assert_close(gA, ex[2].float(), TOL, "dA")
+    assert_close(gb, ex[3].float(), TOL, "db")
