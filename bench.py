@@ -74,6 +74,9 @@ def parse_args():
     ap.add_argument("--mode", choices=["graph", "eager"], default="graph",
                     help="graph: whole step captured once into a hipGraph over bucket-padded batches, replayed per "
                          "batch (phc_gnn_amd/graphed.py); eager: one launch per kernel from Python")
+    ap.add_argument("--optimizer", choices=["engine", "torch"], default="engine",
+                    help="engine: phc_gnn_amd.optim.ClipAdam (clip + Adam in three launches); torch: clip_grad_norm_ + "
+                         "torch.optim.Adam(fused, capturable)")
     ap.add_argument("--cpu-steps", type=int, default=30, help="timed CPU-oracle steps (0 = skip the CPU baseline)")
     ap.add_argument("--cpu-threads", type=int, default=6, help="reference setting: torch.set_num_threads(6)")
     ap.add_argument("--profile-steps", type=int, default=10)
@@ -144,7 +147,12 @@ def main():
     w = harness.WORKLOADS[args.workload]
     model = harness.build_model(args.workload, dev, seed=0)           # same init on every rank
     model.train()
-    opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True, capturable=True)   # train_hiv.py:285 (Adam, wd 0)
+    if args.optimizer == "engine":
+        # train_hiv.py:198-201,285: clip_grad_norm_(2.0) + Adam(lr, weight_decay 0) — the engine's three-launch form
+        from phc_gnn_amd.optim import ClipAdam
+        opt = ClipAdam(model.parameters(), lr=1e-3)
+    else:
+        opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True, capturable=True)
     cfg = harness.StepConfig(regression=bool(w.get("regression")), grad_clip=2.0, optimizer=not args.fwd_bwd_only)
     host_batches = [harness.make_batch(args.workload, seed=1000 * rank + i) for i in range(args.num_batches)]
     batches = [harness.to_device(gb, dev) for gb in host_batches]

@@ -370,6 +370,33 @@ int phc_gated_pool_bwd(const float *dout, const float *x, const float *gate, con
                        int64_t num_graphs, int h, int n_comp, float *dx, float *dgate, void *stream);
 
 /* ------------------------------------------------------------------------- *
+ * Optimizer step of the training loop
+ * ------------------------------------------------------------------------- */
+
+/* clip_grad_norm_(parameters, max_norm, norm_type=2) + Adam(weight_decay=0).step() for ALL parameter
+ * tensors of a model in three launches (benchmarks/train_hiv.py:198-201, :285; PyTorch needs ~21
+ * multi-tensor launches for the ~230 small tensors of a PHC model).
+ *   table_dev  [num_tensors][4] u64 on the DEVICE: {param ptr, exp_avg ptr, exp_avg_sq ptr, numel}
+ *   grads      [num_tensors]   HOST array of device pointers, NULL = no gradient this step (tensor skipped);
+ *              consumed at call time (they travel by value: at most phc_clip_adam_max_tensors() per call)
+ *   chunks_dev [num_chunks][2] int32 on the DEVICE: {tensor, first element}, phc_clip_adam_chunk() elements each
+ *   step_dev   [num_tensors] device floats: update counts per tensor (torch.optim.Adam counts per parameter),
+ *              incremented for tensors that have a gradient; scal_dev[2] out: {total norm, clip coefficient}
+ *   partial_dev [total_chunks] scratch; max_norm <= 0: no clipping; write_back_clipped: also scale the
+ *   gradients in place, as clip_grad_norm_ does.
+ *   phases: 1 = sums of squares of this group's chunks into partial_dev[chunk_base ..), 2 = norm / clip
+ *   coefficient / step += 1 over all total_chunks, 4 = Adam update of this group; 7 = all three (a model
+ *   that fits one group).  Larger models: phase 1 per group, phase 2 once, phase 4 per group.
+ * Arithmetic as torch's fused Adam (fp32): m += (g-m)(1-b1); v = b2 v + (1-b2) g^2;
+ *   p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps).  Fixed-order norm reduction. */
+int phc_clip_adam_max_tensors(void);
+int phc_clip_adam_chunk(void);
+int phc_clip_adam_step(const uint64_t *table_dev, const float *const *grads, int num_tensors, const int32_t *chunks_dev,
+                       int num_chunks, int chunk_base, int total_chunks, int phases, float max_norm, float lr, float beta1,
+                       float beta2, float eps, float *step_dev, float *scal_dev, float *partial_dev,
+                       int write_back_clipped, void *stream);
+
+/* ------------------------------------------------------------------------- *
  * Opt-in launch profiler (process-global).  When enabled every kernel launch
  * made through this library is bracketed by two hipEvents on ITS stream;
  * phc_prof_read synchronises those events and returns per-kernel totals.

@@ -1,0 +1,131 @@
+// Gradient clipping + Adam for a whole model in three launches.
+//
+// Reference: benchmarks/train_hiv.py:198-201 — torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm) followed by
+// torch.optim.Adam(...).step() (Adam with weight_decay = 0, train_hiv.py:285).  PyTorch runs that as ~21 multi-tensor
+// launches over the ~230 small parameter tensors of a PHC model; at molecule scale each launch is pure latency.
+// Here: (1) per-chunk sums of squares (+ the per-tensor step counters), (2) one workgroup: total norm (fixed order), clip coefficient,
+// (3) the Adam update with the clip coefficient applied on the fly.  Same arithmetic as torch's fused Adam:
+//   m = m + (g - m)(1 - b1);  v = b2 v + (1 - b2) g g;  p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
+// with g = clip_coef * grad, clip_coef = min(1, max_norm / (||grads||_2 + 1e-6)).
+#include "phc_common.h"
+
+namespace phc {
+
+constexpr int OPT_CHUNK = 4096;                 // elements per workgroup
+constexpr int OPT_MAX_TENSORS = 448;            // gradient pointers travel by value (4 KB kernarg limit)
+
+struct OptGrads {
+    const float *g[OPT_MAX_TENSORS];
+};
+
+// table[t] = {param, exp_avg, exp_avg_sq, numel} (u64 each); chunks[c] = {tensor, first element}
+__global__ __launch_bounds__(256) void opt_sumsq_kernel(OptGrads grads, const unsigned long long *__restrict__ table,
+                                                      const int *__restrict__ chunks, float *__restrict__ partial,
+                                                      float *__restrict__ steps) {
+    __shared__ float red[256];
+    const int t = chunks[2 * blockIdx.x], off = chunks[2 * blockIdx.x + 1];
+    const float *g = grads.g[t];
+    const long long numel = (long long)table[4 * t + 3];
+    float s = 0.f;
+    if (g) {
+        const long long end = min((long long)off + OPT_CHUNK, numel);
+        for (long long e = off + threadIdx.x; e < end; e += 256) {
+            const float v = g[e];
+            s = fmaf(v, v, s);
+        }
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {                  // fixed tree
+        if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        partial[blockIdx.x] = red[0];
+        if (g && off == 0) steps[t] += 1.f;                 // torch.optim.Adam counts steps per parameter tensor
+    }
+}
+
+// scal[0] = total norm, scal[1] = clip coefficient
+__global__ __launch_bounds__(256) void opt_finalize_kernel(const float *__restrict__ partial, int num_chunks, float max_norm,
+                                                         float *__restrict__ scal) {
+    __shared__ float red[256];
+    float s = 0.f;
+    for (int c = threadIdx.x; c < num_chunks; c += 256) s += partial[c];
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float norm = sqrtf(red[0]);
+        scal[0] = norm;
+        scal[1] = max_norm > 0.f ? fminf(1.f, max_norm / (norm + 1e-6f)) : 1.f;
+    }
+}
+
+__global__ __launch_bounds__(256) void opt_adam_kernel(OptGrads grads, const unsigned long long *__restrict__ table,
+                                                     const int *__restrict__ chunks, const float *__restrict__ scal,
+                                                     const float *__restrict__ steps, float lr, float beta1, float beta2,
+                                                     float eps, int write_back) {
+    const int t = chunks[2 * blockIdx.x], off = chunks[2 * blockIdx.x + 1];
+    const float *g = grads.g[t];
+    if (!g) return;                                          // parameter without a gradient this step: untouched
+    float *p = reinterpret_cast<float *>(table[4 * t]);
+    float *m = reinterpret_cast<float *>(table[4 * t + 1]);
+    float *v = reinterpret_cast<float *>(table[4 * t + 2]);
+    const long long numel = (long long)table[4 * t + 3];
+    const float tstep = steps[t];                            // already incremented by the sums-of-squares launch
+    const float coef = scal[1], bc1 = 1.f - powf(beta1, tstep), bc2_sqrt = sqrtf(1.f - powf(beta2, tstep));
+    const float step_size = lr / bc1;
+    const long long end = min((long long)off + OPT_CHUNK, numel);
+    for (long long e = off + threadIdx.x; e < end; e += 256) {
+        const float gv = g[e] * coef;
+        float mv = m[e], vv = v[e];
+        mv = mv + (gv - mv) * (1.f - beta1);                 // lerp, as torch's fused kernel
+        vv = beta2 * vv + (1.f - beta2) * gv * gv;
+        const float denom = sqrtf(vv) / bc2_sqrt + eps;
+        p[e] -= step_size * (mv / denom);
+        m[e] = mv;
+        v[e] = vv;
+        if (write_back) const_cast<float *>(g)[e] = gv;      // clip_grad_norm_ scales the gradients in place
+    }
+}
+
+}  // namespace phc
+
+using namespace phc;
+
+extern "C" {
+
+int phc_clip_adam_max_tensors(void) { return OPT_MAX_TENSORS; }
+int phc_clip_adam_chunk(void) { return OPT_CHUNK; }
+
+int phc_clip_adam_step(const uint64_t *table_dev, const float *const *grads, int num_tensors, const int32_t *chunks_dev,
+                       int num_chunks, int chunk_base, int total_chunks, int phases, float max_norm, float lr, float beta1,
+                       float beta2, float eps, float *step_dev, float *scal_dev, float *partial_dev, int write_back_clipped,
+                       void *stream) {
+    PHC_REQUIRE(num_tensors >= 1 && num_tensors <= OPT_MAX_TENSORS, PHC_ERR_UNSUPPORTED,
+                "phc_clip_adam_step: %d tensors (1..%d per call)", num_tensors, OPT_MAX_TENSORS);
+    PHC_REQUIRE(num_chunks >= 1 && chunk_base >= 0 && total_chunks >= chunk_base + num_chunks && table_dev && grads && chunks_dev &&
+                    step_dev && scal_dev && partial_dev,
+                PHC_ERR_INVALID_ARG, "phc_clip_adam_step: bad arguments");
+    PHC_REQUIRE(lr > 0.f && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps > 0.f, PHC_ERR_INVALID_ARG,
+                "phc_clip_adam_step: bad hyper-parameters");
+    hipStream_t s = (hipStream_t)stream;
+    OptGrads g;
+    for (int t = 0; t < OPT_MAX_TENSORS; ++t) g.g[t] = t < num_tensors ? grads[t] : nullptr;
+    ProfScope prof(K_CLIP_ADAM, s);
+    if (phases & 1)
+        PHC_LAUNCH(opt_sumsq_kernel, dim3(num_chunks), dim3(256), 0, s, g, reinterpret_cast<const unsigned long long *>(table_dev),
+                   chunks_dev, partial_dev + chunk_base, step_dev);
+    if (phases & 2)
+        PHC_LAUNCH(opt_finalize_kernel, dim3(1), dim3(256), 0, s, partial_dev, total_chunks, max_norm, scal_dev);
+    if (phases & 4)
+        PHC_LAUNCH(opt_adam_kernel, dim3(num_chunks), dim3(256), 0, s, g, reinterpret_cast<const unsigned long long *>(table_dev),
+                   chunks_dev, scal_dev, step_dev, lr, beta1, beta2, eps, write_back_clipped);
+    return check_launch("clip_adam_step");
+}
+
+}  // extern "C"

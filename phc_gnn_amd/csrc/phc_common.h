@@ -54,6 +54,7 @@ enum KernelId : int {
     K_BCE_BWD,
     K_GATED_POOL_FWD,
     K_GATED_POOL_BWD,
+    K_CLIP_ADAM,
     K_NUM_KERNELS
 };
 

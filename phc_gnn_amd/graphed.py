@@ -29,7 +29,7 @@ import torch
 
 from . import synth
 from .graph import clear_structure_cache
-from .harness import StepConfig, loss_fn
+from .harness import StepConfig, loss_fn, optimizer_step
 from .ops import deferred_param_grads, phm_pairs, prebuilt_H
 
 
@@ -189,9 +189,7 @@ class GraphedTrainStep:
         if self.grad_sync is not None:
             self.grad_sync.unpack()
         if self.cfg.optimizer:
-            if self.cfg.grad_clip > 0:
-                torch.nn.utils.clip_grad_norm_(self.model.parameters(), max_norm=self.cfg.grad_clip, norm_type=2)
-            self.optimizer.step()
+            optimizer_step(self.model, self.optimizer, self.cfg)
 
     def _body(self):
         loss = self._front()

@@ -13,6 +13,7 @@ import torch.nn.functional as F
 
 from . import synth
 from .ops import deferred_param_grads, masked_bce_with_logits, phm_pairs, prebuilt_H
+from .optim import ClipAdam
 
 # BASELINE.json configs -> PHMSkipConnectAdd arguments (SURVEY.md §8d "Model settings")
 WORKLOADS: Dict[str, dict] = {
@@ -101,7 +102,16 @@ def train_step(model, data, optimizer: Optional[torch.optim.Optimizer], cfg: Ste
     if grad_sync is not None:
         grad_sync(model)
     if optimizer is not None and cfg.optimizer:
-        if cfg.grad_clip > 0:
-            torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=cfg.grad_clip, norm_type=2)
-        optimizer.step()
+        optimizer_step(model, optimizer, cfg)
     return loss
+
+
+def optimizer_step(model, optimizer, cfg: StepConfig) -> None:
+    """train_hiv.py:198-201: clip_grad_norm_(max_norm) then the Adam step — three launches with the engine's
+    ClipAdam, PyTorch's multi-tensor kernels for any other optimizer."""
+    if isinstance(optimizer, ClipAdam):
+        optimizer.step(max_norm=cfg.grad_clip)
+        return
+    if cfg.grad_clip > 0:
+        torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=cfg.grad_clip, norm_type=2)
+    optimizer.step()

@@ -266,6 +266,36 @@ def test_graphed_step_pipelined_replays_do_not_race_with_batch_loads(where):
     assert all(torch.equal(results[0][1][k], results[1][1][k]) for k in base)
 
 
+def test_graphed_step_with_the_engine_optimizer_tracks_the_torch_optimizer():
+    """Captured step with phc_gnn_amd.optim.ClipAdam (clip + Adam in three launches) vs the same step with
+    clip_grad_norm_ + torch.optim.Adam: losses over several steps and the parameters afterwards."""
+    from phc_gnn_amd import graphed, harness
+    from phc_gnn_amd.optim import ClipAdam
+    wl = "molhiv_b32"
+    gbs = [harness.make_batch(wl, seed=s) for s in (11, 12, 13, 14)]
+    n_max, e_max = graphed.bucket_shape(gbs)
+    padded = [graphed.padded_to_device(graphed.pad_batch(g, n_max, e_max), DEV) for g in gbs]
+    m_t, o_t = _fresh(wl, seed=3)
+    m_e = _fresh(wl, seed=3)[0]
+    o_e = ClipAdam(m_e.parameters(), lr=1e-3)
+    base = {k: v.clone() for k, v in m_t.state_dict().items()}
+    s_t = graphed.GraphedTrainStep(m_t, o_t, harness.StepConfig(), padded[0], warmup=1)
+    s_e = graphed.GraphedTrainStep(m_e, o_e, harness.StepConfig(), padded[0], warmup=1)
+    for m in (m_t, m_e):
+        m.load_state_dict(base)
+    _reset_adam_in_place(o_t)
+    o_e.step_count.zero_(); o_e.exp_avg_flat.zero_(); o_e.exp_avg_sq_flat.zero_()
+    for i, p in enumerate(padded):
+        assert_close(s_e.step(p), s_t.step(p), 2e-5, f"loss step {i}")
+    worst = 0.0
+    for (k, a), b in zip(m_e.state_dict().items(), m_t.state_dict().values()):
+        if not a.is_floating_point() or (k.endswith(".b") and not (k == "pooling.linear.b" or k == "downstream.affine.2.b")) \
+                or k.endswith("running_mean"):
+            continue                                   # zero-gradient biases: Adam amplifies round-off (see above)
+        worst = max(worst, relerr(a, b))
+    assert worst < 5e-4, worst
+
+
 # ---- multi-GPU paths exercised on ONE GPU with a single-rank RCCL group ---------------------------
 @pytest.fixture(scope="module")
 def rccl_single_rank():

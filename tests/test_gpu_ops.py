@@ -716,3 +716,33 @@ def test_phm_linear_backward_large_n_uses_the_wide_tile(ops):
     assert_close(gW, ex[1].float(), TOL, "dW")
     assert_close(gA, ex[2].float(), TOL, "dA")
     assert_close(gb, ex[3].float(), TOL, "db")
+
+
+@pytest.mark.parametrize("max_norm,steps", [(2.0, 6), (0.0, 3), (1e-3, 3)])
+def test_clip_adam_matches_torch_clip_grad_norm_and_adam(max_norm, steps):
+    """phc_clip_adam_step (three launches) == clip_grad_norm_ + torch.optim.Adam (train_hiv.py:198-201,285) over
+    several steps: parameters, clipped gradients and the reported norm; a parameter without gradient is skipped."""
+    from phc_gnn_amd.optim import ClipAdam
+    g = torch.Generator().manual_seed(71)
+    shapes = [(4, 32, 32), (4, 4, 4), (128,), (119, 32), (5000,), (1,), (3, 7)] + [(13,)] * 40
+    base = [torch.randn(s, generator=g) for s in shapes]
+    pa = [b.clone().to(DEV).requires_grad_() for b in base]
+    pb = [b.clone().to(DEV).requires_grad_() for b in base]
+    oa = ClipAdam(pa, lr=1e-2, max_norm=max_norm)
+    ob = torch.optim.Adam(pb, lr=1e-2)
+    for it in range(steps):
+        grads = [torch.randn(s, generator=g) * (5.0 if it % 2 else 0.05) for s in shapes]
+        for i, (x, y, gr) in enumerate(zip(pa, pb, grads)):
+            if i == 2 and it == 1:                        # no gradient for this tensor in this step
+                x.grad = y.grad = None
+                continue
+            x.grad, y.grad = gr.to(DEV), gr.to(DEV)
+        norm_a = oa.step()
+        norm_b = torch.nn.utils.clip_grad_norm_(pb, max_norm) if max_norm > 0 else \
+            torch.linalg.vector_norm(torch.stack([torch.linalg.vector_norm(p.grad) for p in pb if p.grad is not None]))
+        ob.step()
+        assert_close(norm_a, norm_b, 2e-6, f"norm step {it}")
+        for i, (x, y) in enumerate(zip(pa, pb)):
+            assert_close(x, y, 2e-6, f"param {i} step {it}")
+            if x.grad is not None:
+                assert_close(x.grad, y.grad, 2e-6, f"clipped grad {i} step {it}")
