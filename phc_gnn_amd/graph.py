@@ -92,16 +92,19 @@ class EdgeStructure:
                                        ws_bytes, L.stream_ptr(dev)), "phc_csr_build_pair")
         self._csr, self._csc = csr, csc
 
+    def prepare(self, for_backward: bool) -> "EdgeStructure":
+        """Build what a forward (and, with ``for_backward``, its backward) will walk.  A differentiable forward wants
+        the source-sorted view later: both views are then built side by side (5 launches instead of 22)."""
+        if (for_backward and self._csr is None and self._csc is None and self.num_edges > 0 and not _NO_PAIR
+                and 0 < max(self.num_src, self.num_dst) <= self.PAIR_MAX_ROWS):
+            self._build_pair()
+        return self
+
     @property
     def csr(self):
         """rowptr[num_dst+1], col = source of each in-edge, perm = original edge id."""
         if self._csr is None:
-            # a differentiable forward will want the source-sorted view in its backward: build both at once
-            if (torch.is_grad_enabled() and self._csc is None and self.num_edges > 0 and not _NO_PAIR
-                    and 0 < max(self.num_src, self.num_dst) <= self.PAIR_MAX_ROWS):
-                self._build_pair()
-            else:
-                self._csr = _build_sorted(self._dst, self._src, self.num_dst)
+            self._csr = _build_sorted(self._dst, self._src, self.num_dst)
         return self._csr
 
     @property

@@ -458,6 +458,7 @@ def aggregate_sum(x: torch.Tensor, edge_index, edge_attr: Optional[torch.Tensor]
     ``edge_index`` is the reference's int64 [2, E] tensor (row 0 = source,
     row 1 = target) or an ``EdgeStructure`` built from one."""
     st = edge_index if isinstance(edge_index, EdgeStructure) else edge_structure(edge_index, x.shape[0], num_dst)
+    st.prepare(for_backward=torch.is_grad_enabled() and x.requires_grad)
     return _AggregateFn.apply(x, edge_attr, st, _act_id(msg_encoder), bool(add_self_loops))
 
 
@@ -517,6 +518,7 @@ def aggregate_softmax(x: torch.Tensor, edge_index, edge_attr: Optional[torch.Ten
     """out[i] = Σ_e softmax_e(β·m_e)·m_e over the in-edges of i, per feature column, m_e = φ(x[src_e] + edge_attr[e])
     (messagepassing.py:211-214 semantics; empty neighbourhoods give 0)."""
     st = edge_index if isinstance(edge_index, EdgeStructure) else edge_structure(edge_index, x.shape[0], num_dst)
+    st.prepare(for_backward=torch.is_grad_enabled() and x.requires_grad)
     return _AggregateSoftmaxFn.apply(x, edge_attr, beta, st, _act_id(msg_encoder))
 
 
@@ -858,6 +860,7 @@ def aggregate_sum_encoded(x: torch.Tensor, edge_index, bond_idx: torch.Tensor, t
     """aggregate_sum with edge_attr[e] = Σ_f tables[c][f][bond_idx[e, f]] looked up inside the
     kernel (the [E, h] bond embedding is never written)."""
     st = edge_index if isinstance(edge_index, EdgeStructure) else edge_structure(edge_index, x.shape[0], num_dst)
+    st.prepare(for_backward=torch.is_grad_enabled() and x.requires_grad)
     flat_tables = [t for comp in tables for t in comp]
     if not ts.fusable_into_aggregate:
         ea = _EncodeFn.apply(bond_idx, ts, *flat_tables)

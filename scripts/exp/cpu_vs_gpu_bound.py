@@ -7,7 +7,8 @@ from phc_gnn_amd import harness, graphed
 dev = torch.device("cuda:0")
 wl = "molhiv_b512"
 m = harness.build_model(wl, dev, seed=0); m.train()
-o = torch.optim.Adam(m.parameters(), lr=1e-3, fused=True, capturable=True)
+from phc_gnn_amd.optim import ClipAdam
+o = ClipAdam(m.parameters(), lr=1e-3)
 hb = [harness.make_batch(wl, seed=i) for i in range(8)]
 n_max, e_max = graphed.bucket_shape(hb)
 padded = [graphed.padded_to_device(graphed.pad_batch(g, n_max, e_max), dev) for g in hb]

@@ -688,9 +688,8 @@ def test_csr_pair_build_equals_two_single_builds(kind):
     else:
         ei, n = synth.ragged_edges(500, seed=4), 500
     t = torch.from_numpy(np.ascontiguousarray(ei)).to(DEV)
-    with torch.enable_grad():
-        a = EdgeStructure(t, n)
-        csr_a, csc_a = a.csr, a.csc
+    a = EdgeStructure(t, n).prepare(for_backward=True)
+    csr_a, csc_a = a.csr, a.csc
     with torch.no_grad():
         b2 = EdgeStructure(t, n)
         csr_b, csc_b = b2.csr, b2.csc
