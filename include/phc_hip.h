@@ -97,7 +97,8 @@ int phc_phm_linear_bwd(const float *x, const float *A, const float *W, const flo
 typedef struct phc_phm_H_job {
     const float *A, *W;            /* device: [n,n,n], [n,kin,kout] */
     float *H, *HT;                 /* device outputs; HT may be NULL */
-    int32_t n, kin, kout, reserved;
+    int32_t n, kin, kout;
+    int32_t flags;                 /* bit 0: n == 1 and W is an nn.Linear weight [kout, kin]: H = W^T, HT unused (it is W) */
 } phc_phm_H_job;
 int phc_phm_build_H_batched(const phc_phm_H_job *jobs, int num_jobs, void *stream);
 
@@ -119,7 +120,8 @@ typedef struct phc_phm_grad_job {
     const float *x, *dy, *A, *W;   /* device: [N, n*kin], [N, n*kout], [n,n,n], [n,kin,kout] */
     float *dW, *dA, *db;           /* device outputs; dA / db may be NULL                     */
     int64_t N;
-    int32_t n, kin, kout, reserved;
+    int32_t n, kin, kout;
+    int32_t flags;                 /* bit 0: dW is written as [n][kout][kin] (an nn.Linear weight when n == 1) */
 } phc_phm_grad_job;
 size_t phc_phm_param_grads_ws_bytes(const phc_phm_grad_job *jobs, int num_jobs);
 int phc_phm_param_grads(const phc_phm_grad_job *jobs, int num_jobs, void *ws, size_t ws_bytes, void *stream);

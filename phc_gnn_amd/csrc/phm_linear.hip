@@ -593,6 +593,7 @@ struct HJobDev {
     const float *A, *W;
     float *H, *HT;
     int n, kin, kout;
+    int dense_t;                 // n == 1 and W is an nn.Linear weight [kout, kin]: H = W^T (H^T is W itself)
     unsigned blk0;
 };
 struct HBatch {
@@ -612,6 +613,10 @@ __global__ __launch_bounds__(256) void phm_build_H_batched_kernel(HBatch b) {
     const int k = e / out, jc = e - k * out;
     const int a = k / kin, kap = k - a * kin;
     const int c = jc / kout, pi = jc - c * kout;
+    if (jb.dense_t) {
+        jb.H[e] = jb.W[(size_t)jc * kin + k];
+        return;
+    }
     float hsum = 0.f;
     for (int i = 0; i < n; ++i) hsum = fmaf(jb.A[(i * n + a) * n + c], jb.W[((size_t)i * kin + kap) * kout + pi], hsum);
     jb.H[e] = hsum;
@@ -831,7 +836,8 @@ __global__ __launch_bounds__(256) void phm_dH_reduce_kernel(const float *__restr
 // blocks [n^3, ..): dW[i,kap,pi] = sum_{a,c} A[i,a,c] * dH[a*kin+kap, c*kout+pi]; the last block also copies db.
 __device__ __forceinline__ void contract_body(const float *__restrict__ A, const float *__restrict__ W,
                                               const float *__restrict__ dH, float *__restrict__ dW, float *__restrict__ dA,
-                                              float *__restrict__ db, int n, int kin, int kout, int dA_blocks, int bx) {
+                                              float *__restrict__ db, int n, int kin, int kout, int dA_blocks, int bx,
+                                              int dw_transposed = 0) {
     const int out = n * kout;
     const int tid = threadIdx.x;
     if (bx < dA_blocks) {
@@ -863,7 +869,8 @@ __device__ __forceinline__ void contract_body(const float *__restrict__ A, const
         for (int a = 0; a < n; ++a)
             for (int c = 0; c < n; ++c)
                 s = fmaf(A[(i * n + a) * n + c], dH[(size_t)(a * kin + kap) * out + c * kout + pi], s);
-        dW[e] = s;
+        // dw_transposed: the parameter is an nn.Linear weight [kout, kin] (n = 1)
+        dW[dw_transposed ? ((size_t)i * kout + pi) * kin + kap : (size_t)e] = s;
     }
     if (db && blk == 0)
         for (int j = tid; j < out; j += 256) db[j] = dH[(size_t)n * kin * out + j];
@@ -892,7 +899,7 @@ struct GradJobDev {
     long long N, rows_per_split;
     int in, out, n, kin, kout;
     int tiles_j, tiles, splits, vec4;
-    int dA_blocks, t128;
+    int dA_blocks, t128, dw_transposed;
     unsigned blk0_partial, blk0_reduce, blk0_contract;      // first workgroup of this job in each launch
 };
 struct GradBatch {
@@ -945,7 +952,8 @@ __global__ __launch_bounds__(256) void phm_grads_reduce_kernel(GradBatch b) {
 __global__ __launch_bounds__(256) void phm_grads_contract_kernel(GradBatch b) {
     const int k = grad_job_of_block<2>(b, blockIdx.x);
     const GradJobDev &j = b.j[k];
-    contract_body(j.A, j.W, j.dH, j.dW, j.dA, j.db, j.n, j.kin, j.kout, j.dA_blocks, (int)(blockIdx.x - j.blk0_contract));
+    contract_body(j.A, j.W, j.dH, j.dW, j.dA, j.db, j.n, j.kin, j.kout, j.dA_blocks, (int)(blockIdx.x - j.blk0_contract),
+                  j.dw_transposed);
 }
 
 // ---- host side ---------------------------------------------------------------------------
@@ -1245,9 +1253,11 @@ int phc_phm_build_H_batched(const phc_phm_H_job *jobs, int num_jobs, void *strea
             const phc_phm_H_job &jb = jobs[c0 + k];
             int rc = check_phm_dims("phc_phm_build_H_batched", 1, jb.n, jb.kin, jb.kout);
             if (rc) return rc;
-            PHC_REQUIRE(jb.A && jb.W && jb.H, PHC_ERR_INVALID_ARG, "phc_phm_build_H_batched: job %d: null pointer", c0 + k);
+            const int dense_t = jb.flags & 1;
+            PHC_REQUIRE((jb.A || dense_t) && jb.W && jb.H, PHC_ERR_INVALID_ARG, "phc_phm_build_H_batched: job %d: null pointer", c0 + k);
+            PHC_REQUIRE(!dense_t || jb.n == 1, PHC_ERR_INVALID_ARG, "phc_phm_build_H_batched: job %d: a dense weight needs n = 1", c0 + k);
             b.j[k].A = jb.A; b.j[k].W = jb.W; b.j[k].H = jb.H; b.j[k].HT = jb.HT;
-            b.j[k].n = jb.n; b.j[k].kin = jb.kin; b.j[k].kout = jb.kout;
+            b.j[k].n = jb.n; b.j[k].kin = jb.kin; b.j[k].kout = jb.kout; b.j[k].dense_t = dense_t;
             b.j[k].blk0 = blocks;
             blocks += (unsigned)(((size_t)jb.n * jb.kin * jb.n * jb.kout + 255) / 256);
         }
@@ -1406,6 +1416,7 @@ int phc_phm_param_grads(const phc_phm_grad_job *jobs, int num_jobs, void *ws, si
             d.tiles = plans[k].tiles_i * plans[k].tiles_j;
             d.splits = plans[k].splits;
             d.t128 = plans[k].t128;
+            d.dw_transposed = jb.flags & 1;
             d.rows_per_split = plans[k].rows_per_split;
             d.vec4 = (d.in % 4 == 0) && (d.out % 4 == 0) && ((reinterpret_cast<uintptr_t>(jb.x) & 15) == 0) &&
                      ((reinterpret_cast<uintptr_t>(jb.dy) & 15) == 0);

@@ -30,7 +30,7 @@ import torch
 from . import synth
 from .graph import clear_structure_cache
 from .harness import StepConfig, loss_fn, optimizer_step
-from .ops import deferred_param_grads, phm_pairs, prebuilt_H
+from .ops import deferred_param_grads, dense_weights, phm_pairs, prebuilt_H
 
 
 def bucket_shape(batches: List[synth.GraphBatch], slack: float = 0.02, multiple: int = 128):
@@ -133,6 +133,7 @@ class GraphedTrainStep:
         self.loss = None
         self.device = dev
         self._pairs = phm_pairs(model)
+        self._dense = dense_weights(model)
         self.replay_stream = torch.cuda.Stream(device=dev)     # never the capture stream, never the null stream
         if os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "1") != "0":
             warnings.warn("DEBUG_CLR_GRAPH_PACKET_CAPTURE is not 0: on HIP 7.0 pipelined hipGraph replays race with the "
@@ -176,7 +177,7 @@ class GraphedTrainStep:
     def _front(self):
         """zero_grad, forward, loss, backward (+ pack the gradients into the flat all-reduce bucket)."""
         self.optimizer.zero_grad(set_to_none=True)
-        with prebuilt_H(self._pairs), deferred_param_grads():
+        with prebuilt_H(self._pairs, self._dense), deferred_param_grads():
             logits = self.model(self.data)
             loss = loss_fn(logits, self.data, self.cfg.regression)
             loss.backward()

@@ -12,7 +12,7 @@ import torch
 import torch.nn.functional as F
 
 from . import synth
-from .ops import deferred_param_grads, masked_bce_with_logits, phm_pairs, prebuilt_H
+from .ops import deferred_param_grads, dense_weights, masked_bce_with_logits, phm_pairs, prebuilt_H
 from .optim import ClipAdam
 
 # BASELINE.json configs -> PHMSkipConnectAdd arguments (SURVEY.md §8d "Model settings")
@@ -95,7 +95,7 @@ def train_step(model, data, optimizer: Optional[torch.optim.Optimizer], cfg: Ste
         for p in model.parameters():
             p.grad = None
     # operand matrices of all PHM layers: one launch; dW/dA/db of all layers: three batched launches after the backward
-    with prebuilt_H(phm_pairs(model)), deferred_param_grads():
+    with prebuilt_H(phm_pairs(model), dense_weights(model)), deferred_param_grads():
         logits = model(data)
         loss = loss_fn(logits, data, cfg.regression)
         loss.backward()

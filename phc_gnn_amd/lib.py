@@ -30,13 +30,13 @@ _S = C.c_size_t
 class GradJob(C.Structure):
     """phc_phm_grad_job (include/phc_hip.h)."""
     _fields_ = [("x", _P), ("dy", _P), ("A", _P), ("W", _P), ("dW", _P), ("dA", _P), ("db", _P),
-                ("N", _L), ("n", C.c_int32), ("kin", C.c_int32), ("kout", C.c_int32), ("reserved", C.c_int32)]
+                ("N", _L), ("n", C.c_int32), ("kin", C.c_int32), ("kout", C.c_int32), ("flags", C.c_int32)]
 
 
 class HJob(C.Structure):
     """phc_phm_H_job (include/phc_hip.h)."""
     _fields_ = [("A", _P), ("W", _P), ("H", _P), ("HT", _P),
-                ("n", C.c_int32), ("kin", C.c_int32), ("kout", C.c_int32), ("reserved", C.c_int32)]
+                ("n", C.c_int32), ("kin", C.c_int32), ("kout", C.c_int32), ("flags", C.c_int32)]
 
 
 class TableGradJob(C.Structure):

@@ -108,6 +108,14 @@ def _flush_table_grads(jobs) -> None:
                         prm.grad.add_(g)
 
 
+def _job_dims(jb):
+    """(n, kin, kout) of a parameter-gradient job; a dense job carries the nn.Linear weight [out, in]."""
+    if jb.get("dense"):
+        fo, fi = jb["W"].shape
+        return 1, fi, fo
+    return tuple(jb["W"].shape)
+
+
 def _flush_param_grads(jobs) -> None:
     lib = L.load()
     by_dev = {}
@@ -116,7 +124,7 @@ def _flush_param_grads(jobs) -> None:
     for dev, js in by_dev.items():
         total = 0
         for jb in js:
-            n, kin, kout = jb["W"].shape
+            n, kin, kout = _job_dims(jb)
             jb["off"] = total
             total += n * kin * kout + n * n * n + n * kout
         with torch.cuda.device(dev):
@@ -124,22 +132,24 @@ def _flush_param_grads(jobs) -> None:
             arr = (L.GradJob * len(js))()
             outs = []
             for i, jb in enumerate(js):
-                n, kin, kout = jb["W"].shape
+                n, kin, kout = _job_dims(jb)
                 o = jb["off"]
                 dW = flat[o:o + n * kin * kout].view(n, kin, kout)
                 dA = flat[o + n * kin * kout:o + n * kin * kout + n ** 3].view(n, n, n)
                 db = flat[o + n * kin * kout + n ** 3:o + n * kin * kout + n ** 3 + n * kout]
                 need_A, need_W, need_b = jb["need"]
+                if jb.get("dense"):
+                    dW = dW.view(kout, kin)                # written transposed: the nn.Linear layout [out, in]
                 arr[i] = L.GradJob(L.ptr(jb["x"]), L.ptr(jb["dy"]), L.ptr(jb["A"]), L.ptr(jb["W"]),
                                    L.ptr(dW) if need_W else None, L.ptr(dA) if need_A else None,
-                                   L.ptr(db) if need_b else None, jb["x"].shape[0], n, kin, kout, 0)
+                                   L.ptr(db) if need_b else None, jb["x"].shape[0], n, kin, kout, 1 if jb.get("dense") else 0)
                 outs.append((dA if need_A else None, dW if need_W else None, db if need_b else None))
             ws_bytes = lib.phc_phm_param_grads_ws_bytes(arr, len(js))
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
             L.check(lib.phc_phm_param_grads(arr, len(js), L.ptr(ws), ws_bytes, L.stream_ptr(dev)), "phc_phm_param_grads")
             if L.PROF_ON:
                 for jb in js:
-                    n, kin, kout = jb["W"].shape
+                    n, kin, kout = _job_dims(jb)
                     N = jb["x"].shape[0]
                     L.account("phm_dH_partial", 2.0 * N * n * kin * n * kout, 4.0 * N * n * (kin + kout) + 4.0 * n * kin * n * kout)
             for jb, grads in zip(js, outs):
@@ -177,13 +187,35 @@ def phm_pairs(model) -> list:
     return pairs
 
 
+def dense_weights(model) -> list:
+    """``nn.Linear`` weights [out, in] that the engine's dense map (``dense_linear``) can serve from a prebuilt
+    operand: in, out multiples of 4 and <= 256 (the hypercomplex -> real heads of the read-out)."""
+    out = []
+    for m in model.modules():
+        if isinstance(m, torch.nn.Linear) and m.in_features % 4 == 0 and m.out_features % 4 == 0 \
+                and m.in_features <= 256 and m.out_features <= 256:
+            out.append(m.weight)
+    return out
+
+
+def _one(dev) -> torch.Tensor:
+    one = _ONES.get(dev)
+    if one is None:
+        one = torch.ones(1, 1, 1, dtype=torch.float32, device=dev)
+        _ONES[dev] = one
+    return one
+
+
 @contextlib.contextmanager
-def prebuilt_H(pairs):
-    if _PREBUILT.table or not pairs:                       # nested (outermost wins) or nothing to do
+def prebuilt_H(pairs, dense=()):
+    if _PREBUILT.table or not (pairs or dense):            # nested (outermost wins) or nothing to do
         yield
         return
     lib = L.load()
     by_dev = {}
+    for w in dense:
+        if w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and w.dim() == 2:
+            by_dev.setdefault(w.device, []).append((None, w))
     for A, W in pairs:
         n, kin, kout = W.shape
         if A.is_cuda and W.is_cuda and A.dtype == W.dtype == torch.float32 and A.is_contiguous() and W.is_contiguous() \
@@ -192,11 +224,19 @@ def prebuilt_H(pairs):
     try:
         for dev, prs in by_dev.items():
             with torch.cuda.device(dev):
-                total = sum(2 * (W.shape[0] * W.shape[1]) * (W.shape[0] * W.shape[2]) for _, W in prs)
+                total = sum(2 * (W.shape[0] * W.shape[1]) * (W.shape[0] * W.shape[2]) if A is not None else W.numel()
+                            for A, W in prs)
                 flat = torch.empty(total, dtype=torch.float32, device=dev)
                 arr = (L.HJob * len(prs))()
                 off = 0
                 for i, (A, W) in enumerate(prs):
+                    if A is None:                            # nn.Linear weight [out, in]: H = W^T, and W itself is H^T
+                        fo, fi = W.shape
+                        H = flat[off:off + fi * fo].view(fi, fo)
+                        off += fi * fo
+                        arr[i] = L.HJob(None, L.ptr(W), L.ptr(H), None, 1, fi, fo, 1)
+                        _PREBUILT.table[("dense", W.data_ptr())] = (H, W, W._version, W._version)
+                        continue
                     n, kin, kout = W.shape
                     sz = (n * kin) * (n * kout)
                     H, HT = flat[off:off + sz].view(n * kin, n * kout), flat[off + sz:off + 2 * sz].view(n * kout, n * kin)
@@ -210,8 +250,8 @@ def prebuilt_H(pairs):
 
 
 def _prebuilt_for(A, W):
-    ent = _PREBUILT.table.get((A.data_ptr(), W.data_ptr()))
-    if ent is None or ent[2] != A._version or ent[3] != W._version:      # weights touched since the build: not ours
+    ent = _PREBUILT.table.get((A.data_ptr(), W.data_ptr()) if A is not None else ("dense", W.data_ptr()))
+    if ent is None or ent[3] != W._version or (A is not None and ent[2] != A._version):   # touched since the build
         return None
     return ent[0], ent[1]
 
@@ -338,16 +378,65 @@ def phm_linear(x: torch.Tensor, phm_rule: torch.Tensor, W: torch.Tensor, bias: O
 _ONES: dict = {}
 
 
+class _DenseLinearFn(torch.autograd.Function):
+    """y = x·weightᵀ + b on a prebuilt operand (H = weightᵀ from the step's batched build; Hᵀ is the weight itself),
+    dweight / dbias deferred to the batched parameter-gradient launch (written transposed, i.e. as [out, in])."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, H):
+        lib = L.load()
+        dev = x.device
+        x_ = L.f32c(x)
+        N = x_.shape[0]
+        fo, fi = weight.shape
+        y = torch.empty((N, fo), dtype=torch.float32, device=dev)
+        L.check(lib.phc_gemm_prebuilt(L.ptr(x_), L.ptr(H), L.ptr(bias), None, N, fi, fo, L.ptr(y), 0, L.stream_ptr(dev)),
+                "phc_gemm_prebuilt(dense)")
+        if L.PROF_ON:
+            L.account("phm_gemm_fwd", 2.0 * N * fi * fo, 4.0 * (N * (fi + fo) + fi * fo + fo))
+        ctx.save_for_backward(x_, weight)
+        ctx.params = (weight, bias)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = L.load()
+        x_, weight = ctx.saved_tensors
+        dev = x_.device
+        N = x_.shape[0]
+        fo, fi = weight.shape
+        dy_ = L.f32c(dy)
+        need_x, need_w, need_b = ctx.needs_input_grad[:3]
+        dx = None
+        if need_x:
+            dx = torch.empty_like(x_)
+            L.check(lib.phc_gemm_prebuilt(L.ptr(dy_), L.ptr(weight), None, None, N, fo, fi, L.ptr(dx), 1, L.stream_ptr(dev)),
+                    "phc_gemm_prebuilt(dense dx)")
+            if L.PROF_ON:
+                L.account("phm_gemm_dx", 2.0 * N * fi * fo, 4.0 * (N * (fi + fo) + fi * fo))
+        pw, pb = ctx.params
+        if (need_w or need_b) and _DEFER.active and not torch.is_grad_enabled() and pw.is_leaf and (pb is None or pb.is_leaf):
+            with _DEFER.lock:                               # job in PHM form: n = 1, W = weightᵀ [1, in, out], dW transposed
+                _DEFER.jobs.append(dict(x=x_, dy=dy_, A=_one(dev), W=weight, need=(False, need_w, need_b and pb is not None),
+                                        params=(None, pw if need_w else None, pb if (need_b and pb is not None) else None),
+                                        dense=True))
+            return dx, None, None, None
+        dw = dy_.t().mm(x_) if need_w else None
+        db = dy_.sum(0) if (need_b and pb is not None) else None
+        return dx, dw, db, None
+
+
 def dense_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """y = x · weightᵀ + bias for an ``nn.Linear`` weight [out, in], on the PHM kernels: a dense map is the
     phm_dim = 1 case (A = [[[1]]], W = weightᵀ).  Used for the hypercomplex→real head
     (phc/hypercomplex/layers.py:386-414), whose K = N gradient GEMM is a poor fit for the BLAS heuristics."""
     dev = L.require_device(x, weight)
-    one = _ONES.get(dev)
-    if one is None:
-        one = torch.ones(1, 1, 1, dtype=torch.float32, device=dev)
-        _ONES[dev] = one
-    return _PHMLinearFn.apply(x, one, weight.t().unsqueeze(0), bias, None, None)
+    if _PREBUILT.table and x.dim() == 2 and weight.shape[0] % 4 == 0 and x.is_contiguous() and x.data_ptr() % 16 == 0 \
+            and (bias is None or bias.is_contiguous()):
+        pre = _prebuilt_for(None, weight)
+        if pre is not None:
+            return _DenseLinearFn.apply(x, weight, bias, pre[0])
+    return _PHMLinearFn.apply(x, _one(dev), weight.t().unsqueeze(0), bias, None, None)
 
 
 def phm_build_H(phm_rule: torch.Tensor, W: torch.Tensor) -> torch.Tensor:

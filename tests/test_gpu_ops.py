@@ -745,3 +745,26 @@ def test_clip_adam_matches_torch_clip_grad_norm_and_adam(max_norm, steps):
             assert_close(x, y, 2e-6, f"param {i} step {it}")
             if x.grad is not None:
                 assert_close(x.grad, y.grad, 2e-6, f"clipped grad {i} step {it}")
+
+
+@pytest.mark.parametrize("fi,fo,N", [(128, 32, 1000), (64, 64, 33), (256, 128, 500)])
+def test_dense_linear_on_prebuilt_operand_with_deferred_gradients(ops, fi, fo, N):
+    """nn.Linear weight [out, in] served from the step's batched operand build (H = W^T; H^T is W itself), weight and
+    bias gradients from the batched parameter-gradient launch (written in the [out, in] layout)."""
+    g = torch.Generator().manual_seed(81)
+    lin = torch.nn.Linear(fi, fo).to(DEV)
+    x = torch.randn(N, fi, generator=g).to(DEV)
+    dy = torch.randn(N, fo, generator=g).to(DEV)
+    xr = x.clone().requires_grad_()
+    ref = torch.nn.functional.linear(xr.double(), lin.weight.double(), lin.bias.double())
+    gx, gw, gb = torch.autograd.grad(ref, [xr, lin.weight, lin.bias], dy.double())
+    xd = x.clone().requires_grad_()
+    lin.weight.grad = lin.bias.grad = None
+    with ops.prebuilt_H([], [lin.weight]), ops.deferred_param_grads():
+        y = ops.dense_linear(xd, lin.weight, lin.bias)
+        assert y.grad_fn.__class__.__name__.startswith("_DenseLinearFn")
+        y.backward(dy)
+    assert_close(y, ref.float(), TOL, "y")
+    assert_close(xd.grad, gx.float(), TOL, "dx")
+    assert_close(lin.weight.grad, gw.float(), TOL, "dweight")
+    assert_close(lin.bias.grad, gb.float(), TOL, "dbias")
