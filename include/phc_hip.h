@@ -371,6 +371,15 @@ int phc_gated_pool_fwd(const float *x, const float *gate, const int32_t *seg_ptr
 int phc_gated_pool_bwd(const float *dout, const float *x, const float *gate, const int64_t *batch, int64_t N,
                        int64_t num_graphs, int h, int n_comp, float *dx, float *dgate, void *stream);
 
+/* The last dense map of the read-out (RealTransformer 'linear', layers.py:399-414: n*target -> target columns,
+ * 4 -> 1 for ogbg-molhiv) on B rows: y = x.w^T + b with in*out <= phc_small_linear_max_weights(), one launch
+ * forward and one backward (dx row-parallel; dw, db by one workgroup in a fixed order) instead of a BLAS
+ * call, two backward GEMMs, a bias reduction and a fill.  w [out, in] as nn.Linear stores it. */
+int phc_small_linear_max_weights(void);
+int phc_small_linear_fwd(const float *x, const float *w, const float *b, int64_t N, int fi, int fo, float *y, void *stream);
+int phc_small_linear_bwd(const float *dy, const float *x, const float *w, int64_t N, int fi, int fo, float *dx, float *dw,
+                         float *db, void *stream);
+
 /* ------------------------------------------------------------------------- *
  * Optimizer step of the training loop
  * ------------------------------------------------------------------------- */

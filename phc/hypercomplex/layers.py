@@ -192,6 +192,8 @@ class RealTransformer(nn.Module):
         if self.type == "linear":
             if x.is_cuda and self.in_features >= 32 and x.dim() == 2:
                 return _engine.dense_linear(x, self.affine.weight, self.affine.bias)      # phm_dim = 1 PHM kernel
+            if x.is_cuda and x.dim() == 2 and self.affine.weight.numel() <= 64:
+                return _engine.small_linear(x, self.affine.weight, self.affine.bias)      # the n*target -> target head
             return self.affine(x)
         # the reference splits the last dim into chunks of `in_features` columns (:405)
         parts = torch.stack(x.split(self.in_features, dim=-1), dim=0)

@@ -55,6 +55,7 @@ enum KernelId : int {
     K_GATED_POOL_FWD,
     K_GATED_POOL_BWD,
     K_CLIP_ADAM,
+    K_SMALL_LINEAR,
     K_NUM_KERNELS
 };
 

@@ -191,6 +191,69 @@ __global__ __launch_bounds__(256) void gated_pool_bwd_kernel(const float *__rest
     }
 }
 
+// ---- tiny dense head ------------------------------------------------------------------------------
+// y[r, o] = b[o] + sum_i x[r, i] w[o, i] for the last map of the read-out (RealTransformer 'linear' on
+// n*target -> target columns, layers.py:399-414: 4 -> 1 for ogbg-molhiv): a BLAS call plus its two backward GEMMs,
+// a bias reduction and a fill for 544 x 4 numbers.  in * out <= SL_MAX_W.
+constexpr int SL_MAX_W = 64;
+
+__global__ __launch_bounds__(256) void small_linear_fwd_kernel(const float *__restrict__ x, const float *__restrict__ w,
+                                                             const float *__restrict__ b, long long N, int fi, int fo,
+                                                             float *__restrict__ y) {
+    __shared__ float ws[SL_MAX_W], bs[SL_MAX_W];
+    for (int e = threadIdx.x; e < fi * fo; e += 256) ws[e] = w[e];
+    for (int e = threadIdx.x; e < fo; e += 256) bs[e] = b ? b[e] : 0.f;
+    __syncthreads();
+    const long long total = N * fo;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long r = e / fo;
+        const int o = (int)(e - r * fo);
+        float acc = bs[o];
+        for (int i = 0; i < fi; ++i) acc = fmaf(x[r * fi + i], ws[o * fi + i], acc);
+        y[e] = acc;
+    }
+}
+
+// blocks [0, gridDim.x - 1): dx[r, i] = sum_o dy[r, o] w[o, i];  last block: dw[o, i] = sum_r dy[r, o] x[r, i], db[o] = sum_r dy[r, o]
+// (one workgroup, rows in a fixed strided order + fixed tree: reproducible)
+__global__ __launch_bounds__(256) void small_linear_bwd_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+                                                             const float *__restrict__ w, long long N, int fi, int fo,
+                                                             float *__restrict__ dx, float *__restrict__ dw, float *__restrict__ db) {
+    __shared__ float ws[SL_MAX_W];
+    __shared__ float red[256];
+    if (blockIdx.x + 1 < gridDim.x) {
+        if (!dx) return;
+        for (int e = threadIdx.x; e < fi * fo; e += 256) ws[e] = w[e];
+        __syncthreads();
+        const long long total = N * fi;
+        for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)(gridDim.x - 1) * 256) {
+            const long long r = e / fi;
+            const int i = (int)(e - r * fi);
+            float acc = 0.f;
+            for (int o = 0; o < fo; ++o) acc = fmaf(dy[r * fo + o], ws[o * fi + i], acc);
+            dx[e] = acc;
+        }
+        return;
+    }
+    const int outs = (dw ? fi * fo : 0) + (db ? fo : 0);
+    for (int q = 0; q < fi * fo + fo; ++q) {
+        const bool is_w = q < fi * fo;
+        if ((is_w && !dw) || (!is_w && !db)) continue;
+        const int o = is_w ? q / fi : q - fi * fo, i = is_w ? q - o * fi : 0;
+        float acc = 0.f;
+        for (long long r = threadIdx.x; r < N; r += 256) acc = is_w ? fmaf(dy[r * fo + o], x[r * fi + i], acc) : acc + dy[r * fo + o];
+        red[threadIdx.x] = acc;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) (is_w ? dw[q] : db[o]) = red[0];
+        __syncthreads();
+    }
+    (void)outs;
+}
+
 }  // namespace phc
 
 using namespace phc;
@@ -269,6 +332,36 @@ int phc_gated_pool_bwd(const float *dout, const float *x, const float *gate, con
         PHC_LAUNCH((gated_pool_bwd_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, s, dout, x, gate,
                    reinterpret_cast<const long long *>(batch), (long long)N, h, k, n_comp, dx, dgate);
     return check_launch("gated_pool_bwd");
+}
+
+int phc_small_linear_max_weights(void) { return SL_MAX_W; }
+
+int phc_small_linear_fwd(const float *x, const float *w, const float *b, int64_t N, int fi, int fo, float *y, void *stream) {
+    PHC_REQUIRE(N >= 0 && fi >= 1 && fo >= 1 && fi * fo <= SL_MAX_W, PHC_ERR_UNSUPPORTED,
+                "phc_small_linear_fwd: in*out = %d (max %d)", fi * fo, SL_MAX_W);
+    if (N == 0) return PHC_OK;
+    PHC_REQUIRE(x && w && y, PHC_ERR_INVALID_ARG, "phc_small_linear_fwd: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    long long blocks = (N * fo + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    ProfScope prof(K_SMALL_LINEAR, s);
+    PHC_LAUNCH(small_linear_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, x, w, b, (long long)N, fi, fo, y);
+    return check_launch("small_linear_fwd");
+}
+
+int phc_small_linear_bwd(const float *dy, const float *x, const float *w, int64_t N, int fi, int fo, float *dx, float *dw, float *db,
+                         void *stream) {
+    PHC_REQUIRE(N >= 0 && fi >= 1 && fo >= 1 && fi * fo <= SL_MAX_W, PHC_ERR_UNSUPPORTED,
+                "phc_small_linear_bwd: in*out = %d (max %d)", fi * fo, SL_MAX_W);
+    PHC_REQUIRE(dy && x && w, PHC_ERR_INVALID_ARG, "phc_small_linear_bwd: null pointer");
+    if (!dx && !dw && !db) return PHC_OK;
+    hipStream_t s = (hipStream_t)stream;
+    long long blocks = (N * fi + 255) / 256;
+    if (blocks > 1024) blocks = 1024;
+    if (blocks < 1) blocks = 1;
+    ProfScope prof(K_SMALL_LINEAR, s);
+    PHC_LAUNCH(small_linear_bwd_kernel, dim3((unsigned)blocks + 1), dim3(256), 0, s, dy, x, w, (long long)N, fi, fo, dx, dw, db);
+    return check_launch("small_linear_bwd");
 }
 
 }  // extern "C"

@@ -93,6 +93,9 @@ SIGNATURES = {
     "phc_bce_masked_bwd": (_I, [_P, _P, _P, _P, _L, _P, _P]),
     "phc_gated_pool_fwd": (_I, [_P, _P, _P, _L, _I, _I, _P, _P]),
     "phc_gated_pool_bwd": (_I, [_P, _P, _P, _P, _L, _L, _I, _I, _P, _P, _P]),
+    "phc_small_linear_max_weights": (_I, []),
+    "phc_small_linear_fwd": (_I, [_P, _P, _P, _L, _I, _I, _P, _P]),
+    "phc_small_linear_bwd": (_I, [_P, _P, _P, _L, _I, _I, _P, _P, _P, _P]),
     "phc_clip_adam_max_tensors": (_I, []),
     "phc_clip_adam_chunk": (_I, []),
     "phc_clip_adam_step": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P, _P,

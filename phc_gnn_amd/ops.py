@@ -426,6 +426,42 @@ class _DenseLinearFn(torch.autograd.Function):
         return dx, dw, db, None
 
 
+class _SmallLinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        lib = L.load()
+        dev = L.require_device(x, weight, bias)
+        x_, w_, b_ = L.f32c(x), L.f32c(weight), L.f32c(bias)
+        N, (fo, fi) = x_.shape[0], w_.shape
+        y = torch.empty((N, fo), dtype=torch.float32, device=dev)
+        L.check(lib.phc_small_linear_fwd(L.ptr(x_), L.ptr(w_), L.ptr(b_), N, fi, fo, L.ptr(y), L.stream_ptr(dev)),
+                "phc_small_linear_fwd")
+        ctx.save_for_backward(x_, w_)
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = L.load()
+        x_, w_ = ctx.saved_tensors
+        dev = x_.device
+        N, (fo, fi) = x_.shape[0], w_.shape
+        dy_ = L.f32c(dy)
+        need_x, need_w, need_b = ctx.needs_input_grad
+        need_b = need_b and ctx.has_bias
+        dx = torch.empty_like(x_) if need_x else None
+        dw = torch.empty_like(w_) if need_w else None
+        db = torch.empty(fo, dtype=torch.float32, device=dev) if need_b else None
+        L.check(lib.phc_small_linear_bwd(L.ptr(dy_), L.ptr(x_), L.ptr(w_), N, fi, fo, L.ptr(dx), L.ptr(dw), L.ptr(db),
+                                         L.stream_ptr(dev)), "phc_small_linear_bwd")
+        return dx, dw, db
+
+
+def small_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y = x · weightᵀ + bias for a tiny ``nn.Linear`` (in·out <= 64): the last map of the read-out on B rows."""
+    return _SmallLinearFn.apply(x, weight, bias)
+
+
 def dense_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor] = None) -> torch.Tensor:
     """y = x · weightᵀ + bias for an ``nn.Linear`` weight [out, in], on the PHM kernels: a dense map is the
     phm_dim = 1 case (A = [[[1]]], W = weightᵀ).  Used for the hypercomplex→real head

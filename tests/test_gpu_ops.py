@@ -768,3 +768,24 @@ def test_dense_linear_on_prebuilt_operand_with_deferred_gradients(ops, fi, fo, N
     assert_close(xd.grad, gx.float(), TOL, "dx")
     assert_close(lin.weight.grad, gw.float(), TOL, "dweight")
     assert_close(lin.bias.grad, gb.float(), TOL, "dbias")
+
+
+@pytest.mark.parametrize("fi,fo,N,bias", [(4, 1, 544, True), (8, 2, 1, True), (3, 5, 3000, False), (16, 4, 70, True)])
+def test_small_linear_matches_torch(ops, fi, fo, N, bias):
+    """The tiny read-out head (RealTransformer 'linear', layers.py:399-414) as one kernel each way."""
+    g = torch.Generator().manual_seed(91)
+    x = torch.randn(N, fi, generator=g)
+    w = torch.randn(fo, fi, generator=g)
+    b = torch.randn(fo, generator=g) if bias else None
+    dy = torch.randn(N, fo, generator=g)
+    xr, wr = x.clone().requires_grad_(), w.clone().requires_grad_()
+    br = b.clone().requires_grad_() if bias else None
+    ref = torch.nn.functional.linear(xr, wr, br)
+    rg = torch.autograd.grad(ref, [xr, wr] + ([br] if bias else []), dy)
+    xd, wd = x.to(DEV).requires_grad_(), w.to(DEV).requires_grad_()
+    bd = b.to(DEV).requires_grad_() if bias else None
+    y = ops.small_linear(xd, wd, bd)
+    gg = torch.autograd.grad(y, [xd, wd] + ([bd] if bias else []), dy.to(DEV))
+    assert_close(y, ref, TOL, "y")
+    for name, a, r in zip(("dx", "dw", "db"), gg, rg):
+        assert_close(a, r, TOL, name)
