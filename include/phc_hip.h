@@ -371,6 +371,11 @@ int phc_gated_pool_fwd(const float *x, const float *gate, const int32_t *seg_ptr
 int phc_gated_pool_bwd(const float *dout, const float *x, const float *gate, const int64_t *batch, int64_t N,
                        int64_t num_graphs, int h, int n_comp, float *dx, float *dgate, void *stream);
 
+/* out = srcs[0] + srcs[1] + ... + srcs[n-1] (in that order), n <= 16, srcs a HOST array of device pointers:
+ * the gradient of a tensor that fans out to several consumers — the encoded atoms feed the first conv and
+ * every layer's skip connection (models.py:230-234) — in one pass instead of n-1 pairwise adds. */
+int phc_sum_n(const float *const *srcs, int n, int64_t numel, float *out, void *stream);
+
 /* The last dense map of the read-out (RealTransformer 'linear', layers.py:399-414: n*target -> target columns,
  * 4 -> 1 for ogbg-molhiv) on B rows: y = x.w^T + b with in*out <= phc_small_linear_max_weights(), one launch
  * forward and one backward (dx row-parallel; dw, db by one workgroup in a fixed order) instead of a BLAS

@@ -18,6 +18,7 @@ from phc.hypercomplex.pooling import PHMGlobalSumPooling, PHMSoftAttentionPoolin
 from phc.hypercomplex.undirectional.messagepassing import PHMMessagePassing
 from phc.hypercomplex.utils import get_multiplication_matrices
 from phc.quaternion.activations import get_module_activation
+from phc_gnn_amd import ops as _engine
 
 # ogb 1.2.4 feature vocabularies (ogb.utils.features.get_{atom,bond}_feature_dims);
 # the reference imports them from ogb at module import time (ref :18-21).
@@ -167,9 +168,21 @@ class PHMSkipConnectAdd(nn.Module):
         n_valid_graphs = getattr(data, "n_valid_graphs", None)
         atom = self.atomencoder(x)
         atom = atom.reshape(atom.size(0), self.phm_dim * self.atom_encoded_dim)     # component-major [N, h]
-        h = atom
-        for i in range(len(self.mp_layers)):
-            skip = atom if (i == 0 or self.sc_type == "first") else h
+        L_ = len(self.mp_layers)
+        # the encoded atoms feed the first conv and (sc_type "first") every layer's skip: one fan-out node, so that
+        # their gradients are summed in one pass
+        uses = _engine.fanout(atom, 1 + (L_ if self.sc_type == "first" else 1)) if atom.is_cuda else None
+        h = uses[0] if uses is not None else atom
+        for i in range(L_):
+            if uses is not None:
+                if self.sc_type == "first":
+                    skip = uses[1 + i]
+                elif i == 0:
+                    skip = uses[1]
+                else:
+                    h, skip = _engine.fanout(h, 2)         # conv input and its own skip ("last")
+            else:
+                skip = atom if (i == 0 or self.sc_type == "first") else h
             enc = self.bondencoders[i]
             if getattr(enc, "engine_tables", None) is not None:
                 # integer bond features: embedding fused into the aggregation (no [E, h] tensor)

@@ -56,6 +56,7 @@ enum KernelId : int {
     K_GATED_POOL_BWD,
     K_CLIP_ADAM,
     K_SMALL_LINEAR,
+    K_SUM_N,
     K_NUM_KERNELS
 };
 

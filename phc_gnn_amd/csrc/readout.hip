@@ -254,6 +254,32 @@ __global__ __launch_bounds__(256) void small_linear_bwd_kernel(const float *__re
     (void)outs;
 }
 
+// ---- n-ary sum ------------------------------------------------------------------------------------
+// out = src[0] + src[1] + ... in that order: the gradient of a tensor that fans out to several consumers (the
+// encoded atoms feed the first conv AND every layer's skip connection, models.py:230-234) in one pass instead of
+// n - 1 pairwise adds.
+constexpr int SUMN_MAX = 16;
+struct SumSrcs {
+    const float *p[SUMN_MAX];
+};
+
+__global__ __launch_bounds__(256) void sum_n_kernel(SumSrcs srcs, int n, long long numel4, long long numel, float *__restrict__ out) {
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < numel4; e += (long long)gridDim.x * 256) {
+        float4 acc = reinterpret_cast<const float4 *>(srcs.p[0])[e];
+        for (int k = 1; k < n; ++k) {
+            const float4 v = reinterpret_cast<const float4 *>(srcs.p[k])[e];
+            acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+        }
+        reinterpret_cast<float4 *>(out)[e] = acc;
+    }
+    if (blockIdx.x == 0)
+        for (long long e = numel4 * 4 + threadIdx.x; e < numel; e += 256) {
+            float acc = srcs.p[0][e];
+            for (int k = 1; k < n; ++k) acc += srcs.p[k][e];
+            out[e] = acc;
+        }
+}
+
 }  // namespace phc
 
 using namespace phc;
@@ -332,6 +358,27 @@ int phc_gated_pool_bwd(const float *dout, const float *x, const float *gate, con
         PHC_LAUNCH((gated_pool_bwd_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, s, dout, x, gate,
                    reinterpret_cast<const long long *>(batch), (long long)N, h, k, n_comp, dx, dgate);
     return check_launch("gated_pool_bwd");
+}
+
+int phc_sum_n(const float *const *srcs, int n, int64_t numel, float *out, void *stream) {
+    PHC_REQUIRE(n >= 1 && n <= SUMN_MAX && numel >= 0 && srcs && (numel == 0 || out), PHC_ERR_INVALID_ARG, "phc_sum_n: n=%d (1..%d)", n,
+                SUMN_MAX);
+    if (numel == 0) return PHC_OK;
+    SumSrcs ss;
+    bool al = (reinterpret_cast<uintptr_t>(out) & 15) == 0;
+    for (int k = 0; k < SUMN_MAX; ++k) {
+        ss.p[k] = k < n ? srcs[k] : nullptr;
+        PHC_REQUIRE(k >= n || srcs[k], PHC_ERR_INVALID_ARG, "phc_sum_n: source %d is null", k);
+        if (k < n) al = al && (reinterpret_cast<uintptr_t>(srcs[k]) & 15) == 0;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    const long long numel4 = al ? numel / 4 : 0;
+    long long blocks = (numel4 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    if (blocks < 1) blocks = 1;
+    ProfScope prof(K_SUM_N, s);
+    PHC_LAUNCH(sum_n_kernel, dim3((unsigned)blocks), dim3(256), 0, s, ss, n, numel4, (long long)numel, out);
+    return check_launch("sum_n");
 }
 
 int phc_small_linear_max_weights(void) { return SL_MAX_W; }

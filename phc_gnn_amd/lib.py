@@ -93,6 +93,7 @@ SIGNATURES = {
     "phc_bce_masked_bwd": (_I, [_P, _P, _P, _P, _L, _P, _P]),
     "phc_gated_pool_fwd": (_I, [_P, _P, _P, _L, _I, _I, _P, _P]),
     "phc_gated_pool_bwd": (_I, [_P, _P, _P, _P, _L, _L, _I, _I, _P, _P, _P]),
+    "phc_sum_n": (_I, [_P, _I, _L, _P, _P]),
     "phc_small_linear_max_weights": (_I, []),
     "phc_small_linear_fwd": (_I, [_P, _P, _P, _L, _I, _I, _P, _P]),
     "phc_small_linear_bwd": (_I, [_P, _P, _P, _L, _I, _I, _P, _P, _P, _P]),

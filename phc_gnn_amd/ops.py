@@ -426,6 +426,38 @@ class _DenseLinearFn(torch.autograd.Function):
         return dx, dw, db, None
 
 
+class _FanoutFn(torch.autograd.Function):
+    """n aliases of one tensor whose gradients are summed by ONE kernel (phc_sum_n) instead of n-1 pairwise adds."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.n = n
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        gs = [L.f32c(g) for g in grads if g is not None]
+        if not gs:
+            return None, None
+        if len(gs) == 1:
+            return gs[0], None
+        lib = L.load()
+        dev = L.require_device(*gs)
+        out = torch.empty_like(gs[0])
+        for c0 in range(0, len(gs), 16):                    # 16 sources per launch
+            part = gs[c0:c0 + 16] if c0 == 0 else [out] + gs[c0:c0 + 15]
+            arr = (_C.c_void_p * len(part))(*[g.data_ptr() for g in part])
+            L.check(lib.phc_sum_n(arr, len(part), out.numel(), L.ptr(out), L.stream_ptr(dev)), "phc_sum_n")
+        return out, None
+
+
+def fanout(x: torch.Tensor, n: int):
+    """``n`` aliases of ``x`` for ``n`` consumers; in the backward pass their gradients are summed in one pass."""
+    if n <= 1 or not (torch.is_grad_enabled() and x.requires_grad) or not x.is_cuda:
+        return tuple(x for _ in range(max(n, 1)))
+    return _FanoutFn.apply(x, n)
+
+
 class _SmallLinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias):

@@ -789,3 +789,16 @@ def test_small_linear_matches_torch(ops, fi, fo, N, bias):
     assert_close(y, ref, TOL, "y")
     for name, a, r in zip(("dx", "dw", "db"), gg, rg):
         assert_close(a, r, TOL, name)
+
+
+def test_fanout_sums_gradients_in_one_pass(ops):
+    g = torch.Generator().manual_seed(95)
+    x = torch.randn(1000, 128, generator=g).to(DEV).requires_grad_()
+    ws = [torch.randn(1000, 128, generator=g).to(DEV) for _ in range(5)]
+    outs = ops.fanout(x, 5)
+    total = sum((o * w).sum() for o, w in zip(outs[:4], ws))          # the fifth alias is unused: its gradient is None
+    total.backward()
+    ref = ws[0] + ws[1] + ws[2] + ws[3]
+    assert torch.equal(x.grad, ((ws[0] + ws[1]) + ws[2]) + ws[3]) or float((x.grad - ref).abs().max()) < 1e-6
+    with torch.no_grad():
+        assert ops.fanout(x, 3)[0] is x
