@@ -463,7 +463,7 @@ static TgPlan tg_plan(long long n_items, int R, int h, int jobs = 1) {
     const int tiles = p.tiles_i * p.tiles_j;
     const int target = jobs > 1 ? 1024 : 512;                           // workgroups of the whole launch (~2-4 per CU)
     long long splits = (target + tiles * jobs - 1) / (tiles * jobs);
-    const long long cap = (long long)((4u << 20) / (sizeof(float) * (size_t)R * h));   // keep the slabs around 4 MB
+    const long long cap = (long long)((16u << 20) / (sizeof(float) * (size_t)R * h));  // keep the slabs around 16 MB
     if (splits > cap) splits = cap;
     if (splits < 1) splits = 1;
     long long ips = (n_items + splits - 1) / splits;
