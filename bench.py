@@ -75,7 +75,7 @@ def parse_args():
                     help="graph: whole step captured once into a hipGraph over bucket-padded batches, replayed per "
                          "batch (phc_gnn_amd/graphed.py); eager: one launch per kernel from Python")
     ap.add_argument("--optimizer", choices=["engine", "torch"], default="engine",
-                    help="engine: phc_gnn_amd.optim.ClipAdam (clip + Adam in three launches); torch: clip_grad_norm_ + "
+                    help="engine: phc_gnn_amd.optim.ClipAdam (clip + Adam in two launches); torch: clip_grad_norm_ + "
                          "torch.optim.Adam(fused, capturable)")
     ap.add_argument("--cpu-steps", type=int, default=30, help="timed CPU-oracle steps (0 = skip the CPU baseline)")
     ap.add_argument("--cpu-threads", type=int, default=6, help="reference setting: torch.set_num_threads(6)")
@@ -148,7 +148,7 @@ def main():
     model = harness.build_model(args.workload, dev, seed=0)           # same init on every rank
     model.train()
     if args.optimizer == "engine":
-        # train_hiv.py:198-201,285: clip_grad_norm_(2.0) + Adam(lr, weight_decay 0) — the engine's three-launch form
+        # train_hiv.py:198-201,285: clip_grad_norm_(2.0) + Adam(lr, weight_decay 0) — the engine's two-launch form
         from phc_gnn_amd.optim import ClipAdam
         opt = ClipAdam(model.parameters(), lr=1e-3)
     else:

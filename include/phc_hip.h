@@ -390,7 +390,7 @@ int phc_small_linear_bwd(const float *dy, const float *x, const float *w, int64_
  * ------------------------------------------------------------------------- */
 
 /* clip_grad_norm_(parameters, max_norm, norm_type=2) + Adam(weight_decay=0).step() for ALL parameter
- * tensors of a model in three launches (benchmarks/train_hiv.py:198-201, :285; PyTorch needs ~21
+ * tensors of a model in two launches (benchmarks/train_hiv.py:198-201, :285; PyTorch needs ~21
  * multi-tensor launches for the ~230 small tensors of a PHC model).
  *   table_dev  [num_tensors][4] u64 on the DEVICE: {param ptr, exp_avg ptr, exp_avg_sq ptr, numel}
  *   grads      [num_tensors]   HOST array of device pointers, NULL = no gradient this step (tensor skipped);
@@ -400,9 +400,11 @@ int phc_small_linear_bwd(const float *dy, const float *x, const float *w, int64_
  *              incremented for tensors that have a gradient; scal_dev[2] out: {total norm, clip coefficient}
  *   partial_dev [total_chunks] scratch; max_norm <= 0: no clipping; write_back_clipped: also scale the
  *   gradients in place, as clip_grad_norm_ does.
- *   phases: 1 = sums of squares of this group's chunks into partial_dev[chunk_base ..), 2 = norm / clip
- *   coefficient / step += 1 over all total_chunks, 4 = Adam update of this group; 7 = all three (a model
- *   that fits one group).  Larger models: phase 1 per group, phase 2 once, phase 4 per group.
+ *   phases: 1 = sums of squares of this group's chunks into partial_dev[chunk_base ..) (+ the step counters),
+ *   4 = Adam update of this group — every workgroup derives the total norm / clip coefficient from all
+ *   total_chunks partials in the same fixed order, the group with chunk_base = 0 publishes them in scal_dev;
+ *   2 (without 4) = only publish norm and coefficient.  5 = a model that fits one group; larger models:
+ *   phase 1 per group, then phase 4 per group.
  * Arithmetic as torch's fused Adam (fp32): m += (g-m)(1-b1); v = b2 v + (1-b2) g^2;
  *   p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps).  Fixed-order norm reduction. */
 int phc_clip_adam_max_tensors(void);

@@ -1,4 +1,4 @@
-// Gradient clipping + Adam for a whole model in three launches.
+// Gradient clipping + Adam for a whole model in two launches.
 //
 // Reference: benchmarks/train_hiv.py:198-201 — torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm) followed by
 // torch.optim.Adam(...).step() (Adam with weight_decay = 0, train_hiv.py:285).  PyTorch runs that as ~21 multi-tensor
@@ -66,18 +66,43 @@ __global__ __launch_bounds__(256) void opt_finalize_kernel(const float *__restri
 }
 
 __global__ __launch_bounds__(256) void opt_adam_kernel(OptGrads grads, const unsigned long long *__restrict__ table,
-                                                     const int *__restrict__ chunks, const float *__restrict__ scal,
-                                                     const float *__restrict__ steps, float lr, float beta1, float beta2,
+                                                     const int *__restrict__ chunks, float *__restrict__ scal,
+                                                     const float *__restrict__ steps, const float *__restrict__ partial,
+                                                     int total_chunks, float max_norm, float lr, float beta1, float beta2,
                                                      float eps, int write_back) {
     const int t = chunks[2 * blockIdx.x], off = chunks[2 * blockIdx.x + 1];
     const float *g = grads.g[t];
-    if (!g) return;                                          // parameter without a gradient this step: untouched
+    if (!g && blockIdx.x != 0) return;                       // parameter without a gradient this step: untouched
     float *p = reinterpret_cast<float *>(table[4 * t]);
     float *m = reinterpret_cast<float *>(table[4 * t + 1]);
     float *v = reinterpret_cast<float *>(table[4 * t + 2]);
     const long long numel = (long long)table[4 * t + 3];
     const float tstep = steps[t];                            // already incremented by the sums-of-squares launch
-    const float coef = scal[1], bc1 = 1.f - powf(beta1, tstep), bc2_sqrt = sqrtf(1.f - powf(beta2, tstep));
+    // total norm from the per-chunk partials: every workgroup adds them in the same fixed order (a few hundred values),
+    // which is cheaper than a separate single-workgroup launch between the two passes
+    __shared__ float red[256];
+    __shared__ float s_coef;
+    {
+        float sacc = 0.f;
+        for (int c = threadIdx.x; c < total_chunks; c += 256) sacc += partial[c];
+        red[threadIdx.x] = sacc;
+        __syncthreads();
+        for (int st = 128; st > 0; st >>= 1) {
+            if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            const float norm = sqrtf(red[0]);
+            s_coef = max_norm > 0.f ? fminf(1.f, max_norm / (norm + 1e-6f)) : 1.f;
+            if (blockIdx.x == 0 && scal) {
+                scal[0] = norm;
+                scal[1] = s_coef;
+            }
+        }
+        __syncthreads();
+    }
+    const float coef = s_coef, bc1 = 1.f - powf(beta1, tstep), bc2_sqrt = sqrtf(1.f - powf(beta2, tstep));
+    if (!g) return;                                          // (workgroup 0 stayed to publish the norm)
     const float step_size = lr / bc1;
     const long long end = min((long long)off + OPT_CHUNK, numel);
     for (long long e = off + threadIdx.x; e < end; e += 256) {
@@ -120,11 +145,14 @@ int phc_clip_adam_step(const uint64_t *table_dev, const float *const *grads, int
     if (phases & 1)
         PHC_LAUNCH(opt_sumsq_kernel, dim3(num_chunks), dim3(256), 0, s, g, reinterpret_cast<const unsigned long long *>(table_dev),
                    chunks_dev, partial_dev + chunk_base, step_dev);
-    if (phases & 2)
+    // phase 2 (separate norm launch) is only needed when somebody wants the norm without an update; the update itself
+    // derives the norm from the partials in every workgroup
+    if ((phases & 2) && !(phases & 4))
         PHC_LAUNCH(opt_finalize_kernel, dim3(1), dim3(256), 0, s, partial_dev, total_chunks, max_norm, scal_dev);
     if (phases & 4)
         PHC_LAUNCH(opt_adam_kernel, dim3(num_chunks), dim3(256), 0, s, g, reinterpret_cast<const unsigned long long *>(table_dev),
-                   chunks_dev, scal_dev, step_dev, lr, beta1, beta2, eps, write_back_clipped);
+                   chunks_dev, chunk_base == 0 ? scal_dev : nullptr, step_dev, partial_dev, total_chunks, max_norm, lr, beta1, beta2,
+                   eps, write_back_clipped);
     return check_launch("clip_adam_step");
 }
 

@@ -107,7 +107,7 @@ def train_step(model, data, optimizer: Optional[torch.optim.Optimizer], cfg: Ste
 
 
 def optimizer_step(model, optimizer, cfg: StepConfig) -> None:
-    """train_hiv.py:198-201: clip_grad_norm_(max_norm) then the Adam step — three launches with the engine's
+    """train_hiv.py:198-201: clip_grad_norm_(max_norm) then the Adam step — two launches with the engine's
     ClipAdam, PyTorch's multi-tensor kernels for any other optimizer."""
     if isinstance(optimizer, ClipAdam):
         optimizer.step(max_norm=cfg.grad_clip)

@@ -1,10 +1,10 @@
-"""Gradient clipping + Adam for a whole model in three launches (``phc_clip_adam_step``).
+"""Gradient clipping + Adam for a whole model in two launches (``phc_clip_adam_step``).
 
 The reference's optimizer step is ``clip_grad_norm_(model.parameters(), max_norm)`` followed by
 ``torch.optim.Adam(lr, weight_decay=0).step()`` (benchmarks/train_hiv.py:198-201, :285).  PyTorch executes that
 as ~21 multi-tensor launches over the ~230 small parameter tensors of a PHC model; ``ClipAdam`` does the same
-arithmetic (fp32, torch's fused-Adam formulas) with one sums-of-squares launch, one single-workgroup launch for
-the norm / clip coefficient / step counter, and one update launch.  There is no CPU path."""
+arithmetic (fp32, torch's fused-Adam formulas) with one sums-of-squares launch and one update launch whose workgroups derive the
+norm / clip coefficient from the partial sums themselves.  There is no CPU path."""
 from __future__ import annotations
 
 import ctypes as C
@@ -104,11 +104,10 @@ class ClipAdam:
                                            L.ptr(self.partial), 1 if self.write_back_clipped else 0, stream),
                     "phc_clip_adam_step")
         if single:
-            call(calls[0][0], calls[0][1], 7)
+            call(calls[0][0], calls[0][1], 5)               # sums of squares, then the update (which derives the norm itself)
         else:
             for grp, arr in calls:
                 call(grp, arr, 1)
-            call(calls[0][0], calls[0][1], 2)
             for grp, arr in calls:
                 call(grp, arr, 4)
         return self.scalars[0]
