@@ -122,6 +122,13 @@ typedef struct phc_phm_grad_job {
     int64_t N;
     int32_t n, kin, kout;
     int32_t flags;                 /* bit 0: dW is written as [n][kout][kin] (an nn.Linear weight when n == 1) */
+    /* Optional: the layer's input was a batch-norm that phc_gemm_prebuilt_xf applied on the fly, so the
+     * normalised tensor does not exist in HBM: x holds the norm's INPUT, and the kernel evaluates
+     * act(x * scale + shift) per column (rows >= *xf_n_valid_dev read as 0) while staging the operand.
+     * xf_stat: the norm's save_stat [6 * n*kin] (NULL: x is used as is). */
+    const float *xf_stat;
+    const int32_t *xf_n_valid_dev;
+    int32_t xf_act, reserved;
 } phc_phm_grad_job;
 size_t phc_phm_param_grads_ws_bytes(const phc_phm_grad_job *jobs, int num_jobs);
 int phc_phm_param_grads(const phc_phm_grad_job *jobs, int num_jobs, void *ws, size_t ws_bytes, void *stream);
@@ -342,6 +349,22 @@ int phc_remove_isolated_nodes(const int64_t *edge_src_i64, const int64_t *edge_d
                               const int64_t *x_i64, int F, const int64_t *batch_i64, int64_t *edge_src_out,
                               int64_t *edge_dst_out, int64_t *x_out, int64_t *batch_out, int64_t *kept_index,
                               int32_t *n_kept_dev, void *ws, size_t ws_bytes, void *stream);
+
+/* Batch-norm + activation folded into the CONSUMING GEMM (linear -> norm -> act -> linear, layers.py:349-355):
+ * phc_bn_finalize_from_partials merges the statistics the first GEMM emitted (save_stat, running statistics) and
+ * phc_gemm_prebuilt_xf computes  y = act(x * scale + shift) . M + b  with the normalisation evaluated while each
+ * 32-row slab of x is staged (rows >= *n_valid_dev read as 0): the normalised activation is never written to or
+ * read from HBM.  Optionally it also emits the statistics partials of y (stats_partial != NULL), like
+ * phc_gemm_prebuilt_stats.  Backward: dx through phc_gemm_prebuilt (is_dx), then phc_bn_bwd on (d act-input, x,
+ * save_stat); the second layer's parameter gradients take x and the xf_* fields of phc_phm_grad_job. */
+int phc_bn_finalize_from_partials(const float *stats_partial, const float *stats_counts, int num_partials,
+                                  const float *const *weight, const float *const *bias, float *const *running_mean,
+                                  float *const *running_var, int64_t *const *num_batches_tracked, int n_comp,
+                                  const int32_t *n_valid_dev, int64_t N, int h, float momentum, float eps,
+                                  float *save_stat, void *stream);
+int phc_gemm_prebuilt_xf(const float *x, const float *xf_stat, int xf_act, const int32_t *n_valid_dev, const float *M,
+                         const float *b, int64_t N, int K, int Nout, float *y, float *stats_partial,
+                         float *stats_counts, int *num_partials, void *stream);
 
 /* ------------------------------------------------------------------------- *
  * Read-out

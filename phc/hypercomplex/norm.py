@@ -56,6 +56,18 @@ class NaivePHMNorm(nn.Module):
             [m.num_batches_tracked for m in mods] if self.training else None, use_batch_stats, momentum, self.eps,
             activation, residual, n_valid)
 
+    def forward_fused_linear(self, x: torch.Tensor, activation: str, n_valid, linear, out_stats=None):
+        """``linear(act(norm(x)))`` (training mode) without writing the normalised activation (engine:
+        ``bn_act_linear``); ``None`` when the engine cannot fuse here and the caller must run the two steps."""
+        if not (self.training and self.track_running_stats and x.is_cuda):
+            return None
+        mods = list(self.bn)
+        momentum = self.momentum if self.momentum is not None else 0.1
+        return _engine.bn_act_linear(
+            x, [m.weight for m in mods] if self.affine else None, [m.bias for m in mods] if self.affine else None,
+            [m.running_mean for m in mods], [m.running_var for m in mods], [m.num_batches_tracked for m in mods], momentum, self.eps,
+            activation, n_valid, linear.phm_rule, linear.W, linear.b, out_stats)
+
     def _plain(self, x, activation, residual):
         out = F.batch_norm(x, None, None, None, None, True, 0.0, self.eps)
         out = _engine_act(out, activation)
@@ -100,6 +112,11 @@ class PHMNorm(nn.Module):
             return self.bn.forward_fused(x, activation, residual, n_valid)
         out = _engine_act(self.bn(x), activation)
         return out if residual is None else out + residual
+
+    def forward_fused_linear(self, x: torch.Tensor, activation: str, n_valid, linear, out_stats=None):
+        if isinstance(self.bn, NaivePHMNorm) and activation.lower() in _FUSABLE_ACTS:
+            return self.bn.forward_fused_linear(x, activation, n_valid, linear, out_stats)
+        return None
 
     def __repr__(self):
         return f"{self.__class__.__name__}:(num_features={self.num_features}, phm_dim={self.phm_dim} type={self.type})"

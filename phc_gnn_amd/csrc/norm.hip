@@ -867,6 +867,23 @@ int phc_bn_fwd(const float *x, const float *const *weight, const float *const *b
     return check_launch("bn_apply");
 }
 
+int phc_bn_finalize_from_partials(const float *stats_partial, const float *stats_counts, int num_partials, const float *const *weight,
+                                  const float *const *bias, float *const *running_mean, float *const *running_var,
+                                  int64_t *const *num_batches_tracked, int n_comp, const int32_t *n_valid_dev, int64_t N, int h,
+                                  float momentum, float eps, float *save_stat, void *stream) {
+    BnParams p;
+    int rc = fill_params("phc_bn_finalize_from_partials", &p, weight, bias, running_mean, running_var, num_batches_tracked, n_comp, h);
+    if (rc) return rc;
+    PHC_REQUIRE(N >= 1 && num_partials >= 1 && num_partials <= BN_MAX_PARTIALS && h <= 8192, PHC_ERR_INVALID_ARG,
+                "phc_bn_finalize_from_partials: N=%lld, %d partials (max %d), h=%d", (long long)N, num_partials, BN_MAX_PARTIALS, h);
+    PHC_REQUIRE(save_stat && stats_partial && stats_counts, PHC_ERR_INVALID_ARG, "phc_bn_finalize_from_partials: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(K_BN_FINALIZE, s);
+    PHC_LAUNCH(bn_finalize_kernel, dim3((h + 7) / 8), dim3(BN_THREADS), 0, s, p, n_valid_dev, (long long)N, h, 1, momentum, eps,
+               stats_partial, num_partials, 0LL, save_stat, stats_counts);
+    return check_launch("bn_finalize(from partials)");
+}
+
 int phc_bn_fwd_from_partials(const float *x, const float *stats_partial, const float *stats_counts, int num_partials,
                              const float *const *weight, const float *const *bias, float *const *running_mean,
                              float *const *running_var, int64_t *const *num_batches_tracked, int n_comp, const int32_t *n_valid_dev,

@@ -112,6 +112,19 @@ __device__ __forceinline__ float act_fwd(float v) {
 }
 
 // d phi / d v evaluated at the pre-activation v
+// activation chosen at run time (wave-uniform switch): used where a template parameter per activation would
+// multiply the instantiations of a large kernel
+__device__ __forceinline__ float act_fwd_rt(int act, float v) {
+    switch (act) {
+        case PHC_ACT_RELU: return act_fwd<PHC_ACT_RELU>(v);
+        case PHC_ACT_LRELU: return act_fwd<PHC_ACT_LRELU>(v);
+        case PHC_ACT_ELU: return act_fwd<PHC_ACT_ELU>(v);
+        case PHC_ACT_SWISH: return act_fwd<PHC_ACT_SWISH>(v);
+        case PHC_ACT_SELU: return act_fwd<PHC_ACT_SELU>(v);
+        default: return v;
+    }
+}
+
 template <int ACT>
 __device__ __forceinline__ float act_grad(float v) {
     if constexpr (ACT == PHC_ACT_RELU) return v > 0.f ? 1.f : 0.f;

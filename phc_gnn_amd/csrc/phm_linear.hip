@@ -322,7 +322,11 @@ __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
     const float *__restrict__ bias, const float *__restrict__ residual, float *__restrict__ out,
     long long M, int K, int Nout, int n, int kin, int kout, int out_vec4,
     const int *__restrict__ n_valid = nullptr, float *__restrict__ stats_partial = nullptr,
-    float *__restrict__ stats_counts = nullptr) {
+    float *__restrict__ stats_counts = nullptr, const float *__restrict__ xf_stat = nullptr, int xf_act = 0) {
+    // STATS bit 0: emit batch-norm partials of the output; bit 1 (XF): the INPUT is a batch-norm that has not been
+    // applied yet — x := act(x * scale + shift) per column (xf_stat = the norm's [mean|invstd|scale|shift|w|b], width K),
+    // rows >= *n_valid read as 0 — evaluated while the slab is staged, so the normalised tensor never exists in HBM
+    constexpr bool ST = (STATS & 1) != 0, XF = (STATS & 2) != 0;
     constexpr int THREADS = 64 * WAVES, HS_STRIDE = BN + 1, CT = BN / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *hs = smem;                                          // [round_up(K, 8)][HS_STRIDE]
@@ -344,6 +348,7 @@ __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
     // other waves of the SIMD; an inline-asm variant that hid them from hipcc made it copy the still-pending
     // registers — cdna guide §5.7 item 1 — and was dropped)
     f32x4 xr[8];
+    f32x4 xsc = {1.f, 1.f, 1.f, 1.f}, xsh = {0.f, 0.f, 0.f, 0.f};      // XF: scale / shift of the 4 columns held in xr
     auto load_half = [&](long long sl, int half) {
         const int k0 = half * ST_KH;
         const int cc = min(lc4 * 4, K - k0 - 4);               // clamped: unconditional loads
@@ -352,7 +357,14 @@ __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
             const long long row = min(sl * 32 + lrow + 4 * t, M - 1);
             xr[t] = *reinterpret_cast<const f32x4 *>(X + (size_t)row * K + k0 + cc);
         }
+        if constexpr (XF) {
+            xsc = *reinterpret_cast<const f32x4 *>(xf_stat + 2 * (size_t)K + k0 + cc);
+            xsh = *reinterpret_cast<const f32x4 *>(xf_stat + 3 * (size_t)K + k0 + cc);
+        }
     };
+    long long xf_count = M;
+    if constexpr (XF)
+        if (n_valid) xf_count = min((long long)*n_valid, M);
     if (slab < num_slabs) load_half(slab, 0);
 
     // bias columns this lane will store (fixed across slabs): col = j0 + ct*32 + (lane & 7)*4
@@ -366,7 +378,7 @@ __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
     float st_bias[CT], st_sum[CT], st_m2[CT];
     float st_n = 0.f;
     long long st_count = M;
-    if constexpr (STATS) {
+    if constexpr (ST) {
         if (n_valid) st_count = min((long long)*n_valid, M);
 #pragma unroll
         for (int ct = 0; ct < CT; ++ct) {
@@ -421,7 +433,18 @@ __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                *reinterpret_cast<f32x4 *>(stage + (lrow + 4 * t) * ST_STRIDE + lc4 * 4) = colok ? xr[t] : z;
+                f32x4 v = xr[t];
+                if constexpr (XF) {
+                    const bool live = slab * 32 + lrow + 4 * t < xf_count;
+                    if (xf_act == PHC_ACT_RELU) {            // the common case stays branch-free: fma, max, select
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = live ? fmaxf(fmaf(v[q], xsc[q], xsh[q]), 0.f) : 0.f;
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) v[q] = live ? act_fwd_rt(xf_act, fmaf(v[q], xsc[q], xsh[q])) : 0.f;
+                    }
+                }
+                *reinterpret_cast<f32x4 *>(stage + (lrow + 4 * t) * ST_STRIDE + lc4 * 4) = colok ? v : z;
             }
             // next half (or the next slab's first half) goes in flight under the MFMAs
 #ifndef PHC_EXP_NO_XLOAD
@@ -453,7 +476,7 @@ __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
         }
 
         const long long row_base = slab * 32;
-        if constexpr (STATS) {
+        if constexpr (ST) {
             // rows of this slab that count: [row_base, min(row_base + 32, st_count))
             const int nv = (int)max(0LL, min(32LL, st_count - row_base));
             if (nv > 0) {                                                    // wave-uniform
@@ -530,7 +553,7 @@ __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
             }
         }
     }
-    if constexpr (STATS) {
+    if constexpr (ST) {
         // merge the WAVES wavefronts of this workgroup in wave order (fixed) and publish one partial per column
         __syncthreads();                                                     // every wave is done with its staging buffer
         float *sw = stage_all + wave * ST_FLOATS;                            // [0] = n, [1 + ct*32 + r] = sum, [1 + CT*32 + ...] = M2
@@ -635,7 +658,10 @@ constexpr int DH_STRIDE = DH_T;     // lanes read consecutive columns: conflict-
 __device__ __forceinline__ void dH_partial_body(const float *__restrict__ X, const float *__restrict__ DY,
                                                 float *__restrict__ slabs, long long N, int in, int out, int tiles_j,
                                                 long long rows_per_split, int vec4, int tile, long long split,
-                                                float *__restrict__ smem) {
+                                                float *__restrict__ smem, const float *__restrict__ xf_stat = nullptr,
+                                                int xf_act = 0, long long xf_count = 0) {
+    // xf_stat != NULL: the X operand is a batch-norm that was never applied in HBM (phc_gemm_prebuilt_xf):
+    // x := act(x * scale + shift) per column, rows >= xf_count read as 0, evaluated while the tile is staged
     float *xs = smem;                                    // [DH_RB][DH_STRIDE]
     float *ds = smem + DH_RB * DH_STRIDE;                // [DH_RB][DH_STRIDE]
 
@@ -653,6 +679,12 @@ __device__ __forceinline__ void dH_partial_body(const float *__restrict__ X, con
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
     float colsum = 0.f;                                  // threads 0..63 of tile_i == 0 workgroups
+    float4 xf_sc = make_float4(1.f, 1.f, 1.f, 1.f), xf_sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (xf_stat && vec4) {                               // this thread always stages float4 column (tid & 15) of the X tile
+        const int ci = min(i0 + (tid & 15) * 4, in - 4);
+        xf_sc = *reinterpret_cast<const float4 *>(xf_stat + 2 * (size_t)in + ci);
+        xf_sh = *reinterpret_cast<const float4 *>(xf_stat + 3 * (size_t)in + ci);
+    }
 
     for (long long rb = r_begin; rb < r_end; rb += DH_RB) {
         __syncthreads();
@@ -661,7 +693,24 @@ __device__ __forceinline__ void dH_partial_body(const float *__restrict__ X, con
                 const int row = e / (DH_T / 4), c4 = e - row * (DH_T / 4);
                 float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), dv = xv;
                 if (rb + row < r_end) {
-                    if (i0 + c4 * 4 < in) xv = *reinterpret_cast<const float4 *>(X + (size_t)(rb + row) * in + i0 + c4 * 4);
+                    if (i0 + c4 * 4 < in) {
+                        xv = *reinterpret_cast<const float4 *>(X + (size_t)(rb + row) * in + i0 + c4 * 4);
+                        if (xf_stat) {
+                            const float4 sc = xf_sc, sh = xf_sh;     // c4 = tid & 15 for every element of this thread
+                            const bool live = rb + row < xf_count;
+                            if (xf_act == PHC_ACT_RELU) {
+                                xv.x = live ? fmaxf(fmaf(xv.x, sc.x, sh.x), 0.f) : 0.f;
+                                xv.y = live ? fmaxf(fmaf(xv.y, sc.y, sh.y), 0.f) : 0.f;
+                                xv.z = live ? fmaxf(fmaf(xv.z, sc.z, sh.z), 0.f) : 0.f;
+                                xv.w = live ? fmaxf(fmaf(xv.w, sc.w, sh.w), 0.f) : 0.f;
+                            } else {
+                                xv.x = live ? act_fwd_rt(xf_act, fmaf(xv.x, sc.x, sh.x)) : 0.f;
+                                xv.y = live ? act_fwd_rt(xf_act, fmaf(xv.y, sc.y, sh.y)) : 0.f;
+                                xv.z = live ? act_fwd_rt(xf_act, fmaf(xv.z, sc.z, sh.z)) : 0.f;
+                                xv.w = live ? act_fwd_rt(xf_act, fmaf(xv.w, sc.w, sh.w)) : 0.f;
+                            }
+                        }
+                    }
                     if (j0 + c4 * 4 < out) dv = *reinterpret_cast<const float4 *>(DY + (size_t)(rb + row) * out + j0 + c4 * 4);
                 }
                 *reinterpret_cast<float4 *>(xs + row * DH_STRIDE + c4 * 4) = xv;
@@ -672,7 +721,13 @@ __device__ __forceinline__ void dH_partial_body(const float *__restrict__ X, con
                 const int row = e / DH_T, c = e - row * DH_T;
                 float xv = 0.f, dv = 0.f;
                 if (rb + row < r_end) {
-                    if (i0 + c < in) xv = X[(size_t)(rb + row) * in + i0 + c];
+                    if (i0 + c < in) {
+                        xv = X[(size_t)(rb + row) * in + i0 + c];
+                        if (xf_stat)
+                            xv = rb + row < xf_count
+                                     ? act_fwd_rt(xf_act, fmaf(xv, xf_stat[2 * (size_t)in + i0 + c], xf_stat[3 * (size_t)in + i0 + c]))
+                                     : 0.f;
+                    }
                     if (j0 + c < out) dv = DY[(size_t)(rb + row) * out + j0 + c];
                 }
                 xs[row * DH_STRIDE + c] = xv;
@@ -713,7 +768,8 @@ constexpr int DH_RB2 = 32;
 __device__ __forceinline__ void dH_partial_body128(const float *__restrict__ X, const float *__restrict__ DY,
                                                    float *__restrict__ slabs, long long N, int in, int out, int tiles_j,
                                                    long long rows_per_split, int vec4, int tile, long long split,
-                                                   float *__restrict__ smem) {
+                                                   float *__restrict__ smem, const float *__restrict__ xf_stat = nullptr,
+                                                   int xf_act = 0, long long xf_count = 0) {
     float *xs = smem;                                    // [DH_RB2][DH_T2]
     float *ds = smem + DH_RB2 * DH_T2;                   // [DH_RB2][DH_T2]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -734,6 +790,12 @@ __device__ __forceinline__ void dH_partial_body128(const float *__restrict__ X, 
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
     float colsum = 0.f;                                  // threads 0..127 of tile_i == 0 workgroups
+    f32x4 xf_sc = {1.f, 1.f, 1.f, 1.f}, xf_sh = {0.f, 0.f, 0.f, 0.f};
+    if (xf_stat && vec4) {
+        const int ci = min(i0 + (tid & 31) * 4, in - 4);
+        xf_sc = *reinterpret_cast<const f32x4 *>(xf_stat + 2 * (size_t)in + ci);
+        xf_sh = *reinterpret_cast<const f32x4 *>(xf_stat + 3 * (size_t)in + ci);
+    }
 
     for (long long rb = r_begin; rb < r_end; rb += DH_RB2) {
         __syncthreads();
@@ -755,6 +817,17 @@ __device__ __forceinline__ void dH_partial_body128(const float *__restrict__ X, 
                 const int row = e >> 5, c4 = e & 31;
                 const f32x4 z = {0.f, 0.f, 0.f, 0.f};
                 const bool rok = rb + row < r_end;
+                if (xf_stat) {
+                    const f32x4 sc = xf_sc, sh = xf_sh;      // c4 = tid & 31 for every element of this thread
+                    const bool live = rb + row < xf_count;
+                    if (xf_act == PHC_ACT_RELU) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) xv[t][q] = live ? fmaxf(fmaf(xv[t][q], sc[q], sh[q]), 0.f) : 0.f;
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) xv[t][q] = live ? act_fwd_rt(xf_act, fmaf(xv[t][q], sc[q], sh[q])) : 0.f;
+                    }
+                }
                 *reinterpret_cast<f32x4 *>(xs + row * DH_T2 + c4 * 4) = (rok && i0 + c4 * 4 < in) ? xv[t] : z;
                 *reinterpret_cast<f32x4 *>(ds + row * DH_T2 + c4 * 4) = (rok && j0 + c4 * 4 < out) ? dv[t] : z;
             }
@@ -763,7 +836,13 @@ __device__ __forceinline__ void dH_partial_body128(const float *__restrict__ X, 
                 const int row = e / DH_T2, c = e - row * DH_T2;
                 float xv = 0.f, dv = 0.f;
                 if (rb + row < r_end) {
-                    if (i0 + c < in) xv = X[(size_t)(rb + row) * in + i0 + c];
+                    if (i0 + c < in) {
+                        xv = X[(size_t)(rb + row) * in + i0 + c];
+                        if (xf_stat)
+                            xv = rb + row < xf_count
+                                     ? act_fwd_rt(xf_act, fmaf(xv, xf_stat[2 * (size_t)in + i0 + c], xf_stat[3 * (size_t)in + i0 + c]))
+                                     : 0.f;
+                    }
                     if (j0 + c < out) dv = DY[(size_t)(rb + row) * out + j0 + c];
                 }
                 xs[row * DH_T2 + c] = xv;
@@ -900,6 +979,9 @@ struct GradJobDev {
     int in, out, n, kin, kout;
     int tiles_j, tiles, splits, vec4;
     int dA_blocks, t128, dw_transposed;
+    const float *xf_stat;                                    // X operand = act(x * scale + shift) (see dH_partial_body)
+    const int *xf_n_valid;
+    int xf_act;
     unsigned blk0_partial, blk0_reduce, blk0_contract;      // first workgroup of this job in each launch
 };
 struct GradBatch {
@@ -937,10 +1019,13 @@ __global__ __launch_bounds__(256) void phm_grads_partial_kernel(GradBatch b) {
     const long long split = local / j.tiles;
     __shared__ __attribute__((aligned(16))) float smem[2 * DH_RB * DH_STRIDE];      // 32 KB, either tile shape
     static_assert(2 * DH_RB * DH_STRIDE == 2 * DH_RB2 * DH_T2, "both tile shapes stage 32 KB");
+    const long long xf_count = j.xf_stat ? (j.xf_n_valid ? min((long long)*j.xf_n_valid, j.N) : j.N) : 0;
     if constexpr (T128)
-        dH_partial_body128(j.x, j.dy, j.slabs, j.N, j.in, j.out, j.tiles_j, j.rows_per_split, j.vec4, tile, split, smem);
+        dH_partial_body128(j.x, j.dy, j.slabs, j.N, j.in, j.out, j.tiles_j, j.rows_per_split, j.vec4, tile, split, smem, j.xf_stat,
+                           j.xf_act, xf_count);
     else
-        dH_partial_body(j.x, j.dy, j.slabs, j.N, j.in, j.out, j.tiles_j, j.rows_per_split, j.vec4, tile, split, smem);
+        dH_partial_body(j.x, j.dy, j.slabs, j.N, j.in, j.out, j.tiles_j, j.rows_per_split, j.vec4, tile, split, smem, j.xf_stat,
+                        j.xf_act, xf_count);
 }
 
 __global__ __launch_bounds__(256) void phm_grads_reduce_kernel(GradBatch b) {
@@ -1007,13 +1092,13 @@ template <int TRANS, int NPHM, int BN, int WAVES, int STATS = 0>
 static int launch_stream_cfg(const float *X, const float *A, const float *W, const float *bias, const float *residual,
                              float *out, int64_t M, int K, int Nout, int n, int kin, int kout, int wg_per_cu, hipStream_t s,
                              const int *n_valid = nullptr, float *stats_partial = nullptr, float *stats_counts = nullptr,
-                             int *num_partials = nullptr) {
+                             int *num_partials = nullptr, const float *xf_stat = nullptr, int xf_act = 0) {
     const int panels = (Nout + BN - 1) / BN;
     const int64_t slabs = (M + 31) / 32;
     int64_t gy = ((int64_t)wg_per_cu * num_cu() + panels - 1) / panels;
     const int64_t max_gy = (slabs + WAVES - 1) / WAVES;
     if (gy > max_gy) gy = max_gy;
-    if (STATS && gy > GEMM_STATS_MAX_PARTIALS) gy = GEMM_STATS_MAX_PARTIALS;      // one statistics partial per workgroup row
+    if ((STATS & 1) && gy > GEMM_STATS_MAX_PARTIALS) gy = GEMM_STATS_MAX_PARTIALS;      // one statistics partial per workgroup row
     if (gy < 1) gy = 1;
     if (num_partials) *num_partials = (int)gy;
     const size_t lds = sizeof(float) * ((size_t)round_up(K, 8) * (BN + 1) + (size_t)WAVES * ST_FLOATS + (size_t)n * n * n);
@@ -1027,7 +1112,8 @@ static int launch_stream_cfg(const float *X, const float *A, const float *W, con
         attr_set = true;
     }
     PHC_LAUNCH((phm_stream_kernel<TRANS, NPHM, BN, WAVES, STATS>), dim3(panels, (unsigned)gy), dim3(64 * WAVES), lds, s, X, A, W,
-                       bias, residual, out, (long long)M, K, Nout, n, kin, kout, out_vec4, n_valid, stats_partial, stats_counts);
+                       bias, residual, out, (long long)M, K, Nout, n, kin, kout, out_vec4, n_valid, stats_partial, stats_counts,
+                       xf_stat, xf_act);
     return PHC_OK;
 }
 
@@ -1322,6 +1408,44 @@ int phc_gemm_prebuilt_stats(const float *x, const float *M, const float *b, int6
     return check_launch("phc_gemm_prebuilt_stats");
 }
 
+int phc_gemm_prebuilt_xf(const float *x, const float *xf_stat, int xf_act, const int32_t *n_valid_dev, const float *M,
+                         const float *b, int64_t N, int K, int Nout, float *y, float *stats_partial, float *stats_counts,
+                         int *num_partials, void *stream) {
+    PHC_REQUIRE(N >= 1 && K >= 1 && Nout >= 1, PHC_ERR_INVALID_ARG, "phc_gemm_prebuilt_xf: bad shape");
+    PHC_REQUIRE(x && xf_stat && M && y, PHC_ERR_INVALID_ARG, "phc_gemm_prebuilt_xf: null pointer");
+    PHC_REQUIRE(xf_act >= PHC_ACT_IDENTITY && xf_act <= PHC_ACT_SELU, PHC_ERR_INVALID_ARG, "phc_gemm_prebuilt_xf: unknown activation %d",
+                xf_act);
+    PHC_REQUIRE(!stats_partial || (stats_counts && num_partials), PHC_ERR_INVALID_ARG, "phc_gemm_prebuilt_xf: statistics outputs");
+    PHC_REQUIRE(K <= GEMM_STREAM_MAX_K && K % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(M) & 15) == 0 && (reinterpret_cast<uintptr_t>(xf_stat) & 15) == 0,
+                PHC_ERR_UNSUPPORTED, "phc_gemm_prebuilt_xf: needs K <= 256, K %% 4 == 0 and 16-byte aligned x, M, stat (K=%d)", K);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(K_PHM_GEMM_FWD, s);
+    static const int small_bn = getenv("PHC_GEMM_PRE_BN") ? atoi(getenv("PHC_GEMM_PRE_BN")) : 32;
+    const bool big = N >= GEMM_BIG_M && Nout > 64;
+    const bool small = small_bn == 32 && Nout > 32 && N <= 32 * 1024;
+#define PHC_XF_LAUNCH(SV)                                                                                                      \
+    if (big && K > 128)                                                                                                         \
+        launch_stream_cfg<0, -1, 64, 8, SV>(x, nullptr, M, b, nullptr, y, N, K, Nout, 1, K, Nout, 1, s, n_valid_dev, stats_partial, \
+                                            stats_counts, num_partials, xf_stat, xf_act);                                       \
+    else if (big)                                                                                                               \
+        launch_stream_cfg<0, -1, 128, 8, SV>(x, nullptr, M, b, nullptr, y, N, K, Nout, 1, K, Nout, 1, s, n_valid_dev, stats_partial, \
+                                             stats_counts, num_partials, xf_stat, xf_act);                                      \
+    else if (small)                                                                                                             \
+        launch_stream_cfg<0, -1, 32, 4, SV>(x, nullptr, M, b, nullptr, y, N, K, Nout, 1, K, Nout, 3, s, n_valid_dev, stats_partial, \
+                                            stats_counts, num_partials, xf_stat, xf_act);                                       \
+    else                                                                                                                        \
+        launch_stream_cfg<0, -1, 64, 4, SV>(x, nullptr, M, b, nullptr, y, N, K, Nout, 1, K, Nout, 2, s, n_valid_dev, stats_partial, \
+                                            stats_counts, num_partials, xf_stat, xf_act)
+    if (stats_partial) {
+        PHC_XF_LAUNCH(3);
+    } else {
+        PHC_XF_LAUNCH(2);
+    }
+#undef PHC_XF_LAUNCH
+    return check_launch("phc_gemm_prebuilt_xf");
+}
+
 // ---- batched parameter gradients ------------------------------------------------------------
 struct GradPlan {
     int tiles_i, tiles_j, splits, t128;
@@ -1417,6 +1541,11 @@ int phc_phm_param_grads(const phc_phm_grad_job *jobs, int num_jobs, void *ws, si
             d.splits = plans[k].splits;
             d.t128 = plans[k].t128;
             d.dw_transposed = jb.flags & 1;
+            d.xf_stat = jb.xf_stat;
+            d.xf_n_valid = jb.xf_n_valid_dev;
+            d.xf_act = jb.xf_act;
+            PHC_REQUIRE(!jb.xf_stat || (jb.xf_act >= PHC_ACT_IDENTITY && jb.xf_act <= PHC_ACT_SELU), PHC_ERR_INVALID_ARG,
+                        "phc_phm_param_grads: job %d: unknown activation %d", c0 + k, jb.xf_act);
             d.rows_per_split = plans[k].rows_per_split;
             d.vec4 = (d.in % 4 == 0) && (d.out % 4 == 0) && ((reinterpret_cast<uintptr_t>(jb.x) & 15) == 0) &&
                      ((reinterpret_cast<uintptr_t>(jb.dy) & 15) == 0);

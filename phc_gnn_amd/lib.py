@@ -30,7 +30,8 @@ _S = C.c_size_t
 class GradJob(C.Structure):
     """phc_phm_grad_job (include/phc_hip.h)."""
     _fields_ = [("x", _P), ("dy", _P), ("A", _P), ("W", _P), ("dW", _P), ("dA", _P), ("db", _P),
-                ("N", _L), ("n", C.c_int32), ("kin", C.c_int32), ("kout", C.c_int32), ("flags", C.c_int32)]
+                ("N", _L), ("n", C.c_int32), ("kin", C.c_int32), ("kout", C.c_int32), ("flags", C.c_int32),
+                ("xf_stat", _P), ("xf_n_valid", _P), ("xf_act", C.c_int32), ("reserved", C.c_int32)]
 
 
 class HJob(C.Structure):
@@ -59,6 +60,8 @@ SIGNATURES = {
     "phc_gemm_prebuilt_stats": (_I, [_P, _P, _P, _L, _I, _I, _P, _P, _P, _P, C.POINTER(_I), _P]),
     "phc_bn_fwd_from_partials": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _L, _I, C.c_float, C.c_float, _I, _P, _P, _P,
                                       _P]),
+    "phc_bn_finalize_from_partials": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _L, _I, C.c_float, C.c_float, _P, _P]),
+    "phc_gemm_prebuilt_xf": (_I, [_P, _P, _I, _P, _P, _P, _L, _I, _I, _P, _P, _P, C.POINTER(_I), _P]),
     "phc_phm_param_grads_ws_bytes": (_S, [C.POINTER(GradJob), _I]),
     "phc_phm_param_grads": (_I, [C.POINTER(GradJob), _I, _P, _S, _P]),
     "phc_csr_ws_bytes": (_S, [_L, _L]),

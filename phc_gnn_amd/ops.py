@@ -116,7 +116,7 @@ def _job_dims(jb):
     return tuple(jb["W"].shape)
 
 
-def _flush_param_grads(jobs) -> None:
+def _flush_param_grads(jobs, return_grads: bool = False):
     lib = L.load()
     by_dev = {}
     for jb in jobs:
@@ -140,9 +140,11 @@ def _flush_param_grads(jobs) -> None:
                 need_A, need_W, need_b = jb["need"]
                 if jb.get("dense"):
                     dW = dW.view(kout, kin)                # written transposed: the nn.Linear layout [out, in]
+                xf = jb.get("xf")
                 arr[i] = L.GradJob(L.ptr(jb["x"]), L.ptr(jb["dy"]), L.ptr(jb["A"]), L.ptr(jb["W"]),
                                    L.ptr(dW) if need_W else None, L.ptr(dA) if need_A else None,
-                                   L.ptr(db) if need_b else None, jb["x"].shape[0], n, kin, kout, 1 if jb.get("dense") else 0)
+                                   L.ptr(db) if need_b else None, jb["x"].shape[0], n, kin, kout, 1 if jb.get("dense") else 0,
+                                   L.ptr(xf[0]) if xf else None, L.ptr(xf[1]) if xf else None, xf[2] if xf else 0, 0)
                 outs.append((dA if need_A else None, dW if need_W else None, db if need_b else None))
             ws_bytes = lib.phc_phm_param_grads_ws_bytes(arr, len(js))
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
@@ -152,6 +154,8 @@ def _flush_param_grads(jobs) -> None:
                     n, kin, kout = _job_dims(jb)
                     N = jb["x"].shape[0]
                     L.account("phm_dH_partial", 2.0 * N * n * kin * n * kout, 4.0 * N * n * (kin + kout) + 4.0 * n * kin * n * kout)
+            if return_grads:
+                return outs
             for jb, grads in zip(js, outs):
                 for prm, g in zip(jb["params"], grads):
                     if prm is None or g is None:
@@ -1111,6 +1115,121 @@ class _BatchNormActFn(torch.autograd.Function):
                 aff_grads = [None] * (2 * n_comp)
         dres = dout if (has_res and ctx.needs_input_grad[1]) else None
         return (dx, dres, None, None, None, None, None, None, None, None, None, None, *aff_grads)
+
+
+class _BNActLinearFn(torch.autograd.Function):
+    """[training batch-norm -> activation -> PHM linear] with the normalised activation never written to HBM
+    (phc_bn_finalize_from_partials + phc_gemm_prebuilt_xf).  x is the norm's input — the output of a GEMM that
+    emitted its statistics partials (``pre``); the linear layer's operand matrices come from the step's batched
+    build and its parameter gradients go to the deferred batched launch (job with the xf_* fields)."""
+
+    @staticmethod
+    def forward(ctx, x, n_valid, pre, running_mean, running_var, nbt, momentum, eps, act, n_comp, A2, W2, b2, H2, HT2, out_stats,
+                *affine):
+        lib = L.load()
+        dev = x.device
+        N, h = x.shape
+        n2, kin2, kout2 = W2.shape
+        weights = list(affine[:n_comp]) if affine else None
+        biases = list(affine[n_comp:]) if affine else None
+        save_stat = torch.empty(6 * h, dtype=torch.float32, device=dev)
+        L.check(lib.phc_bn_finalize_from_partials(
+            L.ptr(pre.partial), L.ptr(pre.counts), pre.num, _ptr_array(weights) if weights else None,
+            _ptr_array(biases) if biases else None, _ptr_array(running_mean) if running_mean else None,
+            _ptr_array(running_var) if running_var else None, _ptr_array(nbt) if nbt else None, n_comp, L.ptr(n_valid), N, h,
+            float(momentum), float(eps), L.ptr(save_stat), L.stream_ptr(dev)), "phc_bn_finalize_from_partials")
+        y = torch.empty((N, n2 * kout2), dtype=torch.float32, device=dev)
+        num = _C.c_int(0)
+        sp = sc = None
+        if out_stats is not None:
+            P = lib.phc_gemm_stats_max_partials()
+            sp = out_stats.partial = torch.empty((P, 2 * n2 * kout2), dtype=torch.float32, device=dev)
+            sc = out_stats.counts = torch.empty(P, dtype=torch.float32, device=dev)
+        L.check(lib.phc_gemm_prebuilt_xf(L.ptr(x), L.ptr(save_stat), act, L.ptr(n_valid), L.ptr(H2), L.ptr(b2), N, h, n2 * kout2,
+                                         L.ptr(y), L.ptr(sp), L.ptr(sc), _C.byref(num), L.stream_ptr(dev)), "phc_gemm_prebuilt_xf")
+        if out_stats is not None:
+            out_stats.num = num.value
+        if L.PROF_ON:
+            L.account("phm_gemm_fwd", 2.0 * N * h * n2 * kout2, 4.0 * (N * (h + n2 * kout2) + h * n2 * kout2))
+        ctx.save_for_backward(x, save_stat, A2, W2)
+        ctx.HT2, ctx.params2 = HT2, (A2, W2, b2)
+        ctx.meta = (n_comp, act, bool(affine), n_valid)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        lib = L.load()
+        x, save_stat, A2, W2 = ctx.saved_tensors
+        n_comp, act, has_affine, n_valid = ctx.meta
+        dev = x.device
+        N, h = x.shape
+        n2, kin2, kout2 = W2.shape
+        dy_ = L.f32c(dy)
+        # d(normalised activation) = dy . H2^T
+        dz = torch.empty((N, h), dtype=torch.float32, device=dev)
+        L.check(lib.phc_gemm_prebuilt(L.ptr(dy_), L.ptr(ctx.HT2), None, None, N, n2 * kout2, h, L.ptr(dz), 1, L.stream_ptr(dev)),
+                "phc_gemm_prebuilt(dx)")
+        if L.PROF_ON:
+            L.account("phm_gemm_dx", 2.0 * N * h * n2 * kout2, 4.0 * (N * (h + n2 * kout2) + h * n2 * kout2))
+        # second layer's parameter gradients: x stays the norm's input, the kernel re-evaluates act(x*scale+shift)
+        pA, pW, pb = ctx.params2
+        needs = ctx.needs_input_grad
+        need_A, need_W, need_b = needs[10], needs[11], needs[12] and pb is not None
+        grads2 = (None, None, None)
+        if need_A or need_W or need_b:
+            job = dict(x=x, dy=dy_, A=A2, W=W2, need=(need_A, need_W, need_b),
+                       params=(pA if need_A else None, pW if need_W else None, pb if need_b else None),
+                       xf=(save_stat, n_valid, act))
+            if _DEFER.active and not torch.is_grad_enabled() and all(p is None or p.is_leaf for p in (pA, pW, pb)):
+                with _DEFER.lock:
+                    _DEFER.jobs.append(job)
+            else:                                            # not deferring: same batched entry point, one job, results returned
+                job["params"] = (None, None, None)
+                out = _flush_param_grads([job], return_grads=True)[0]
+                grads2 = (out[0], out[1], out[2])
+        # batch-norm backward on (dz, x, save_stat)
+        need_x = needs[0]
+        need_aff = has_affine and any(needs[16:])
+        dx = torch.empty_like(x) if need_x else None
+        dwb = torch.empty(2 * h, dtype=torch.float32, device=dev) if need_aff else None
+        ws_bytes = lib.phc_bn_ws_bytes(N, h)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        L.check(lib.phc_bn_bwd(L.ptr(dz), L.ptr(x), L.ptr(save_stat), L.ptr(n_valid), N, h, 1, act, L.ptr(dx), L.ptr(dwb), None,
+                               L.ptr(ws), ws_bytes, L.stream_ptr(dev)), "phc_bn_bwd")
+        if L.PROF_ON:
+            L.account("bn_bwd_partial", 6.0 * N * h, 8.0 * N * h)
+            L.account("bn_bwd_apply", 8.0 * N * h, 12.0 * N * h)
+        k = h // n_comp
+        aff_grads = []
+        if has_affine:
+            aff_grads = ([dwb[c * k:(c + 1) * k] for c in range(n_comp)] + [dwb[h + c * k:h + (c + 1) * k] for c in range(n_comp)]) \
+                if need_aff else [None] * (2 * n_comp)
+        return (dx, None, None, None, None, None, None, None, None, None, grads2[0], grads2[1], grads2[2], None, None, None,
+                *aff_grads)
+
+
+def bn_act_linear(x: torch.Tensor, weights, biases, running_mean, running_var, num_batches_tracked, momentum: float, eps: float,
+                  activation: str, n_valid, phm_rule: torch.Tensor, W: torch.Tensor, bias, out_stats=None):
+    """``phm_linear(act(batch_norm(x)), phm_rule, W, bias)`` in training mode without materialising the normalised
+    activation, or ``None`` when the preconditions do not hold (the caller then runs the two ops separately):
+    x must be the tensor a statistics-emitting GEMM just returned (``x._phc_bn``), inside ``prebuilt_H`` with an
+    entry for (phm_rule, W)."""
+    pre = getattr(x, "_phc_bn", None)
+    if pre is None or pre.partial is None or pre.n_valid is not n_valid or x.dim() != 2 or not x.is_contiguous() \
+            or pre.partial.shape[1] != 2 * x.shape[1] or not _PREBUILT.table or x.data_ptr() % 16:
+        return None
+    ent = _prebuilt_for(phm_rule, W)
+    if ent is None or W.shape[0] * W.shape[1] != x.shape[1] or (bias is not None and not bias.is_contiguous()):
+        return None
+    n_comp = len(running_mean) if running_mean else len(weights)
+    affine = (list(weights) + list(biases)) if weights else []
+    y = _BNActLinearFn.apply(x, n_valid, pre, list(running_mean) if running_mean else None,
+                             list(running_var) if running_var else None,
+                             list(num_batches_tracked) if num_batches_tracked else None, momentum, eps, _act_id(activation),
+                             n_comp, phm_rule, W, bias, ent[0], ent[1], out_stats, *affine)
+    if out_stats is not None and out_stats.partial is not None:
+        y._phc_bn = out_stats
+    return y
 
 
 def batch_norm_act(x: torch.Tensor, weights, biases, running_mean, running_var, num_batches_tracked, training: bool,

@@ -802,3 +802,45 @@ def test_fanout_sums_gradients_in_one_pass(ops):
     assert torch.equal(x.grad, ((ws[0] + ws[1]) + ws[2]) + ws[3]) or float((x.grad - ref).abs().max()) < 1e-6
     with torch.no_grad():
         assert ops.fanout(x, 3)[0] is x
+
+
+@pytest.mark.parametrize("n,k,N,valid,act,deferred", [(4, 32, 13824, 12874, "relu", True), (4, 32, 500, None, "swish", True),
+                                                      (2, 64, 333, 300, "relu", False), (8, 32, 700, None, "identity", True)])
+def test_bn_act_linear_without_materialising_the_normalised_activation(ops, n, k, N, valid, act, deferred):
+    """linear1 (statistics from its epilogue) -> [batch-norm -> act -> linear2 folded into linear2's operand staging]
+    against the three separate ops: output, every gradient, running statistics, padding rows."""
+    g = torch.Generator().manual_seed(101)
+    h = n * k
+    x = torch.randn(N, h, generator=g)
+    x[::11] *= 20.0
+    dy = torch.randn(N, h, generator=g)
+    base = dict(A1=torch.randn(n, n, n, generator=g), W1=torch.randn(n, k, k, generator=g) * 0.2, b1=torch.randn(h, generator=g),
+                A2=torch.randn(n, n, n, generator=g), W2=torch.randn(n, k, k, generator=g) * 0.2, b2=torch.randn(h, generator=g))
+    w = [torch.rand(k, generator=g) + 0.5 for _ in range(n)]
+    bb = [torch.randn(k, generator=g) * 0.1 for _ in range(n)]
+    n_valid = None if valid is None else torch.tensor(valid, dtype=torch.int32, device=DEV)
+
+    def run(fused):
+        P = {kk: v.to(DEV).requires_grad_() for kk, v in base.items()}
+        wd, bd = [t.to(DEV).requires_grad_() for t in w], [t.to(DEV).requires_grad_() for t in bb]
+        rm, rv = [torch.zeros(k, device=DEV) for _ in range(n)], [torch.ones(k, device=DEV) for _ in range(n)]
+        nbt = [torch.zeros((), dtype=torch.int64, device=DEV) for _ in range(n)]
+        xd = x.to(DEV).requires_grad_()
+        ctx = ops.deferred_param_grads() if deferred else __import__("contextlib").nullcontext()
+        with ops.prebuilt_H([(P["A1"], P["W1"]), (P["A2"], P["W2"])]), ctx:
+            y1 = ops.phm_linear(xd, P["A1"], P["W1"], P["b1"], bn_stats=ops.BNStatsRequest(n_valid))
+            y2 = ops.bn_act_linear(y1, wd, bd, rm, rv, nbt, 0.1, 1e-5, act, n_valid, P["A2"], P["W2"], P["b2"]) if fused else None
+            assert (y2 is not None) == fused
+            if y2 is None:
+                z = ops.batch_norm_act(y1, wd, bd, rm, rv, nbt, True, 0.1, 1e-5, act, None, n_valid)
+                y2 = ops.phm_linear(z, P["A2"], P["W2"], P["b2"])
+            y2.backward(dy.to(DEV))
+        return [y2.detach(), xd.grad] + [P[kk].grad for kk in ("W1", "A1", "W2", "A2", "b2")] + [t.grad for t in wd + bd] + rm + rv
+
+    a, b = run(True), run(False)
+    names = ["y2", "dx", "dW1", "dA1", "dW2", "dA2", "db2"] + [f"bn{i}" for i in range(4 * n)]
+    nv = N if valid is None else valid
+    for name, u, v in zip(names, a, b):
+        if name == "y2":
+            u, v = u[:nv], v[:nv]          # padding rows: both are b2-only rows, compare the valid part explicitly
+        assert_close(u, v, 3e-5, name)
