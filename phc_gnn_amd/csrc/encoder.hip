@@ -461,9 +461,15 @@ static TgPlan tg_plan(long long n_items, int R, int h, int jobs = 1) {
     p.tiles_i = (R + TG_T - 1) / TG_T;
     p.tiles_j = (h + TG_T - 1) / TG_T;
     const int tiles = p.tiles_i * p.tiles_j;
-    const int target = jobs > 1 ? 1024 : 512;                           // workgroups of the whole launch (~2-4 per CU)
+    // workgroups of the whole launch: ~2-4 per CU for molecule batches; for large inputs one workgroup per ~8k items
+    // (a fixed 512 left each workgroup with thousands of dependent gather -> MFMA rounds: 19 ms for 10 M atoms)
+    long long target = jobs > 1 ? 1024 : 512;
+    const long long by_items = (n_items / 8192) * tiles * jobs;
+    if (by_items > target) target = by_items;
     long long splits = (target + tiles * jobs - 1) / (tiles * jobs);
-    const long long cap = (long long)((16u << 20) / (sizeof(float) * (size_t)R * h));  // keep the slabs around 16 MB
+    // slabs: 16 MB for small inputs, up to 256 MB when the input itself is gigabytes
+    const size_t slab_budget = n_items > (1 << 20) ? ((size_t)256 << 20) : ((size_t)16 << 20);
+    const long long cap = (long long)(slab_budget / (sizeof(float) * (size_t)R * h * (size_t)jobs));
     if (splits > cap) splits = cap;
     if (splits < 1) splits = 1;
     long long ips = (n_items + splits - 1) / splits;
