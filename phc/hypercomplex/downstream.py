@@ -57,20 +57,33 @@ class PHMDownstreamNet(nn.Module):
 
     def forward(self, x: torch.Tensor, verbose=False, n_valid=None, **kwargs) -> torch.Tensor:
         last = len(self.affine) - 1
-        for i, layer in enumerate(self.affine):
-            stats = self.norm_flag and i != last and self.training and x.is_cuda and x.dim() == 2
-            x = layer(x, bn_stats=_engine.BNStatsRequest(n_valid) if stats else None)
+        engine = self.norm_flag and self.training and x.is_cuda and x.dim() == 2
+        i = 0
+        x = self.affine[0](x, bn_stats=_engine.BNStatsRequest(n_valid) if (engine and last > 0) else None)
+        while i < last:
             if verbose:
-                print(f"layer {i}: {layer} -> {tuple(x.shape)}")
-            if i == last:
-                break
+                print(f"layer {i}: {self.affine[i]} -> {tuple(x.shape)}")
+            nxt = self.affine[i + 1]
+            nxt_stats = _engine.BNStatsRequest(n_valid) if (engine and i + 1 != last) else None
+            no_dropout = not (self.training and self.dropout[i] > 0.0)
+            if engine and no_dropout:
+                # norm -> activation -> next layer inside the next GEMM's operand staging (no normalised tensor)
+                y = self.norm[i].forward_fused_linear(x, self.activation_str, n_valid, nxt, nxt_stats)
+                if y is not None:
+                    x = y
+                    i += 1
+                    continue
             if self.norm_flag:
                 x = self.norm[i].forward_fused(x, activation=self.activation_str, n_valid=n_valid)
             else:
                 x = self.activation_func(x)
-            if self.training and self.dropout[i] > 0.0:
+            if not no_dropout:
                 x = phm_dropout(x, p=self.dropout[i], phm_dim=self.phm_dim, training=self.training,
                                 same=self.same_dropout)
+            x = nxt(x, bn_stats=nxt_stats)
+            i += 1
+        if verbose:
+            print(f"layer {last}: {self.affine[last]} -> {tuple(x.shape)}")
         return self.real_trafo(x)
 
     def __repr__(self):
