@@ -366,6 +366,18 @@ int phc_gemm_prebuilt_xf(const float *x, const float *xf_stat, int xf_act, const
                          const float *b, int64_t N, int K, int Nout, float *y, float *stats_partial,
                          float *stats_counts, int *num_partials, void *stream);
 
+/* Backward of that pair.  phc_gemm_prebuilt_bwsums computes dz = dy . M (M = H^T of the second layer) and, from
+ * the same registers, the column sums the norm's backward needs — sum g and sum g*x_hat with
+ * g = dz * act'(x_hat*w + b), x_hat = (bn_x - mean)*invstd, over the rows below *n_valid_dev — as
+ * sums_partial [phc_gemm_stats_max_partials()][2*Nout] (*num_partials rows written).  phc_bn_bwd_from_partials
+ * merges them (fixed order) and produces dx / dwb_flat exactly like phc_bn_bwd (training mode); ws: 2*h floats. */
+int phc_gemm_prebuilt_bwsums(const float *dy, const float *M, int64_t N, int K, int Nout, float *dz, const float *bn_x,
+                             const float *bn_stat, int act, const int32_t *n_valid_dev, float *sums_partial,
+                             int *num_partials, void *stream);
+int phc_bn_bwd_from_partials(const float *dy, const float *x, const float *save_stat, const float *sums_partial,
+                             int num_partials, const int32_t *n_valid_dev, int64_t N, int h, int act, float *dx,
+                             float *dwb_flat, void *ws, size_t ws_bytes, void *stream);
+
 /* ------------------------------------------------------------------------- *
  * Read-out
  * ------------------------------------------------------------------------- */

@@ -985,4 +985,36 @@ int phc_bn_bwd(const float *dy, const float *x, const float *save_stat, const in
     return check_launch("bn_bwd_apply");
 }
 
+int phc_bn_bwd_from_partials(const float *dy, const float *x, const float *save_stat, const float *sums_partial, int num_partials,
+                             const int32_t *n_valid_dev, int64_t N, int h, int act, float *dx, float *dwb_flat, void *ws,
+                             size_t ws_bytes, void *stream) {
+    PHC_REQUIRE(N >= 1 && h >= 1 && h <= 8192 && num_partials >= 1 && num_partials <= BN_MAX_PARTIALS, PHC_ERR_INVALID_ARG,
+                "phc_bn_bwd_from_partials: N=%lld h=%d partials=%d", (long long)N, h, num_partials);
+    PHC_REQUIRE(act >= PHC_ACT_IDENTITY && act <= PHC_ACT_SELU, PHC_ERR_INVALID_ARG, "phc_bn_bwd_from_partials: unknown activation %d", act);
+    PHC_REQUIRE(dy && x && save_stat && sums_partial, PHC_ERR_INVALID_ARG, "phc_bn_bwd_from_partials: null pointer");
+    PHC_REQUIRE(ws && ws_bytes >= sizeof(float) * 2 * (size_t)h, PHC_ERR_WORKSPACE, "phc_bn_bwd_from_partials: workspace too small");
+    const bool vec4 = (h % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((reinterpret_cast<uintptr_t>(dy) & 15) == 0) &&
+                      (!dx || (reinterpret_cast<uintptr_t>(dx) & 15) == 0);
+    PHC_REQUIRE(vec4 || h % 4 != 0, PHC_ERR_UNSUPPORTED, "phc_bn_bwd_from_partials: rows must be 16-byte aligned when h %% 4 == 0");
+    hipStream_t s = (hipStream_t)stream;
+    float *bstat = static_cast<float *>(ws);
+    int rc;
+    {
+        ProfScope prof(K_BN_BWD_FINALIZE, s);
+        PHC_LAUNCH(bn_bwd_finalize_kernel, dim3((h + 7) / 8), dim3(BN_THREADS), 0, s, n_valid_dev, (long long)N, h, 1, sums_partial,
+                   num_partials, dwb_flat, bstat);
+        rc = check_launch("bn_bwd_finalize(from partials)");
+        if (rc) return rc;
+    }
+    if (!dx) return PHC_OK;
+    const size_t lds = sizeof(float) * 6 * (size_t)h;
+    ProfScope prof(K_BN_BWD_APPLY, s);
+#define PHC_BN_BAP(ACTC)                                                                                                     \
+    PHC_LAUNCH((bn_bwd_apply_kernel<ACTC>), dim3(apply_grid(N, h)), dim3(BN_THREADS), lds, s, dy, x, save_stat, n_valid_dev,  \
+               (long long)N, h, bstat, dx)
+    PHC_BN_ACT_SWITCH(act, PHC_BN_BAP)
+#undef PHC_BN_BAP
+    return check_launch("bn_bwd_apply");
+}
+
 }  // extern "C"

@@ -139,4 +139,16 @@ __device__ __forceinline__ float act_grad(float v) {
     return 1.f;
 }
 
+// derivative of the activation at pre-activation z, chosen at run time (see act_fwd_rt)
+__device__ __forceinline__ float act_grad_rt(int act, float z) {
+    switch (act) {
+        case PHC_ACT_RELU: return act_grad<PHC_ACT_RELU>(z);
+        case PHC_ACT_LRELU: return act_grad<PHC_ACT_LRELU>(z);
+        case PHC_ACT_ELU: return act_grad<PHC_ACT_ELU>(z);
+        case PHC_ACT_SWISH: return act_grad<PHC_ACT_SWISH>(z);
+        case PHC_ACT_SELU: return act_grad<PHC_ACT_SELU>(z);
+        default: return 1.f;
+    }
+}
+
 }  // namespace phc

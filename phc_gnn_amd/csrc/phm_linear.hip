@@ -322,11 +322,15 @@ __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
     const float *__restrict__ bias, const float *__restrict__ residual, float *__restrict__ out,
     long long M, int K, int Nout, int n, int kin, int kout, int out_vec4,
     const int *__restrict__ n_valid = nullptr, float *__restrict__ stats_partial = nullptr,
-    float *__restrict__ stats_counts = nullptr, const float *__restrict__ xf_stat = nullptr, int xf_act = 0) {
+    float *__restrict__ stats_counts = nullptr, const float *__restrict__ xf_stat = nullptr, int xf_act = 0,
+    const float *__restrict__ bw_x = nullptr, const float *__restrict__ bw_stat = nullptr, int bw_act = 0) {
     // STATS bit 0: emit batch-norm partials of the output; bit 1 (XF): the INPUT is a batch-norm that has not been
     // applied yet — x := act(x * scale + shift) per column (xf_stat = the norm's [mean|invstd|scale|shift|w|b], width K),
     // rows >= *n_valid read as 0 — evaluated while the slab is staged, so the normalised tensor never exists in HBM
-    constexpr bool ST = (STATS & 1) != 0, XF = (STATS & 2) != 0;
+    // STATS bit 2 (BW): this launch is dz = dy . H^T of a layer whose input was act(batch_norm(bw_x)); besides dz it emits
+    // the batch-norm backward's column sums of g = dz * act'(.) and g * x_hat over its rows (stats_partial[blockIdx.y]
+    // [0..Nout) / [Nout..2 Nout)), so that the norm's backward needs no separate pass over dz and bw_x for them
+    constexpr bool ST = (STATS & 1) != 0, XF = (STATS & 2) != 0, BW = (STATS & 4) != 0;
     constexpr int THREADS = 64 * WAVES, HS_STRIDE = BN + 1, CT = BN / 32;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *hs = smem;                                          // [round_up(K, 8)][HS_STRIDE]
@@ -365,6 +369,23 @@ __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
     long long xf_count = M;
     if constexpr (XF)
         if (n_valid) xf_count = min((long long)*n_valid, M);
+    // BW: per-column norm constants of the 4 columns this lane stores (col = j0 + ct*32 + (lane & 7)*4) and its sums
+    float4 bw_mean[CT], bw_inv[CT], bw_w[CT], bw_b[CT];
+    float bw_sg[CT][4], bw_sgx[CT][4];
+    long long bw_count = M;
+    if constexpr (BW) {
+        if (n_valid) bw_count = min((long long)*n_valid, M);
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+            const int col = min(j0 + ct * 32 + (lane & 7) * 4, max(Nout - 4, 0));
+            bw_mean[ct] = *reinterpret_cast<const float4 *>(bw_stat + col);
+            bw_inv[ct] = *reinterpret_cast<const float4 *>(bw_stat + (size_t)Nout + col);
+            bw_w[ct] = *reinterpret_cast<const float4 *>(bw_stat + 4 * (size_t)Nout + col);
+            bw_b[ct] = *reinterpret_cast<const float4 *>(bw_stat + 5 * (size_t)Nout + col);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) bw_sg[ct][q] = bw_sgx[ct][q] = 0.f;
+        }
+    }
     if (slab < num_slabs) load_half(slab, 0);
 
     // bias columns this lane will store (fixed across slabs): col = j0 + ct*32 + (lane & 7)*4
@@ -535,6 +556,25 @@ __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
                             const float4 r4 = *reinterpret_cast<const float4 *>(residual + (size_t)grow * Nout + col);
                             v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
                         }
+                        if constexpr (BW) {
+                            if (grow < bw_count) {
+                                const float4 x4 = *reinterpret_cast<const float4 *>(bw_x + (size_t)grow * Nout + col);
+                                const float xs_[4] = {x4.x, x4.y, x4.z, x4.w}, vs_[4] = {v.x, v.y, v.z, v.w};
+                                const float mm[4] = {bw_mean[ct].x, bw_mean[ct].y, bw_mean[ct].z, bw_mean[ct].w};
+                                const float ii[4] = {bw_inv[ct].x, bw_inv[ct].y, bw_inv[ct].z, bw_inv[ct].w};
+                                const float ww[4] = {bw_w[ct].x, bw_w[ct].y, bw_w[ct].z, bw_w[ct].w};
+                                const float bb[4] = {bw_b[ct].x, bw_b[ct].y, bw_b[ct].z, bw_b[ct].w};
+#pragma unroll
+                                for (int q = 0; q < 4; ++q) {
+                                    const float xh = (xs_[q] - mm[q]) * ii[q];
+                                    const float z = fmaf(xh, ww[q], bb[q]);
+                                    const float gq = bw_act == PHC_ACT_RELU ? (z > 0.f ? vs_[q] : 0.f)
+                                                                            : vs_[q] * act_grad_rt(bw_act, z);
+                                    bw_sg[ct][q] += gq;
+                                    bw_sgx[ct][q] = fmaf(gq, xh, bw_sgx[ct][q]);
+                                }
+                            }
+                        }
                         *reinterpret_cast<float4 *>(out + (size_t)grow * Nout + col) = v;
                     }
                 }
@@ -550,6 +590,46 @@ __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
                         out[(size_t)grow * Nout + col] = v;
                     }
                 }
+            }
+        }
+    }
+    if constexpr (BW) {
+        // lanes sharing (lane & 7) hold the same 4 columns for different rows: fold them, then the WAVES wavefronts in order
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                float a = bw_sg[ct][q], b2 = bw_sgx[ct][q];
+#pragma unroll
+                for (int off = 8; off < 64; off <<= 1) {
+                    a += __shfl_xor(a, off);
+                    b2 += __shfl_xor(b2, off);
+                }
+                bw_sg[ct][q] = a;
+                bw_sgx[ct][q] = b2;
+            }
+        __syncthreads();                                                     // every wave is done with its staging buffer
+        float *sw = stage_all + wave * ST_FLOATS;                            // [ct*32 + c] = sum g, [BN + ct*32 + c] = sum g*x_hat
+        if (lane < 8) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    sw[ct * 32 + lane * 4 + q] = bw_sg[ct][q];
+                    sw[BN + ct * 32 + lane * 4 + q] = bw_sgx[ct][q];
+                }
+        }
+        __syncthreads();
+        for (int cc = tid; cc < BN; cc += 64 * WAVES) {
+            float a = 0.f, b2 = 0.f;
+            for (int w = 0; w < WAVES; ++w) {
+                a += stage_all[w * ST_FLOATS + cc];
+                b2 += stage_all[w * ST_FLOATS + BN + cc];
+            }
+            const int col = j0 + cc;
+            if (col < Nout) {
+                stats_partial[(size_t)blockIdx.y * 2 * Nout + col] = a;
+                stats_partial[(size_t)blockIdx.y * 2 * Nout + Nout + col] = b2;
             }
         }
     }
@@ -1092,13 +1172,14 @@ template <int TRANS, int NPHM, int BN, int WAVES, int STATS = 0>
 static int launch_stream_cfg(const float *X, const float *A, const float *W, const float *bias, const float *residual,
                              float *out, int64_t M, int K, int Nout, int n, int kin, int kout, int wg_per_cu, hipStream_t s,
                              const int *n_valid = nullptr, float *stats_partial = nullptr, float *stats_counts = nullptr,
-                             int *num_partials = nullptr, const float *xf_stat = nullptr, int xf_act = 0) {
+                             int *num_partials = nullptr, const float *xf_stat = nullptr, int xf_act = 0,
+                             const float *bw_x = nullptr, const float *bw_stat = nullptr, int bw_act = 0) {
     const int panels = (Nout + BN - 1) / BN;
     const int64_t slabs = (M + 31) / 32;
     int64_t gy = ((int64_t)wg_per_cu * num_cu() + panels - 1) / panels;
     const int64_t max_gy = (slabs + WAVES - 1) / WAVES;
     if (gy > max_gy) gy = max_gy;
-    if ((STATS & 1) && gy > GEMM_STATS_MAX_PARTIALS) gy = GEMM_STATS_MAX_PARTIALS;      // one statistics partial per workgroup row
+    if ((STATS & 5) && gy > GEMM_STATS_MAX_PARTIALS) gy = GEMM_STATS_MAX_PARTIALS;      // one statistics partial per workgroup row
     if (gy < 1) gy = 1;
     if (num_partials) *num_partials = (int)gy;
     const size_t lds = sizeof(float) * ((size_t)round_up(K, 8) * (BN + 1) + (size_t)WAVES * ST_FLOATS + (size_t)n * n * n);
@@ -1113,7 +1194,7 @@ static int launch_stream_cfg(const float *X, const float *A, const float *W, con
     }
     PHC_LAUNCH((phm_stream_kernel<TRANS, NPHM, BN, WAVES, STATS>), dim3(panels, (unsigned)gy), dim3(64 * WAVES), lds, s, X, A, W,
                        bias, residual, out, (long long)M, K, Nout, n, kin, kout, out_vec4, n_valid, stats_partial, stats_counts,
-                       xf_stat, xf_act);
+                       xf_stat, xf_act, bw_x, bw_stat, bw_act);
     return PHC_OK;
 }
 
@@ -1444,6 +1525,35 @@ int phc_gemm_prebuilt_xf(const float *x, const float *xf_stat, int xf_act, const
     }
 #undef PHC_XF_LAUNCH
     return check_launch("phc_gemm_prebuilt_xf");
+}
+
+int phc_gemm_prebuilt_bwsums(const float *dy, const float *M, int64_t N, int K, int Nout, float *dz, const float *bn_x,
+                             const float *bn_stat, int act, const int32_t *n_valid_dev, float *sums_partial, int *num_partials,
+                             void *stream) {
+    PHC_REQUIRE(N >= 1 && K >= 1 && Nout >= 1, PHC_ERR_INVALID_ARG, "phc_gemm_prebuilt_bwsums: bad shape");
+    PHC_REQUIRE(dy && M && dz && bn_x && bn_stat && sums_partial && num_partials, PHC_ERR_INVALID_ARG,
+                "phc_gemm_prebuilt_bwsums: null pointer");
+    PHC_REQUIRE(act >= PHC_ACT_IDENTITY && act <= PHC_ACT_SELU, PHC_ERR_INVALID_ARG, "phc_gemm_prebuilt_bwsums: unknown activation %d", act);
+    PHC_REQUIRE(K <= GEMM_STREAM_MAX_K && K % 4 == 0 && Nout % 4 == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(M) & 15) == 0 && (reinterpret_cast<uintptr_t>(dz) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(bn_x) & 15) == 0 && (reinterpret_cast<uintptr_t>(bn_stat) & 15) == 0,
+                PHC_ERR_UNSUPPORTED, "phc_gemm_prebuilt_bwsums: needs K <= 256, K %% 4 == 0, Nout %% 4 == 0, 16-byte aligned operands");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(K_PHM_GEMM_DX, s);
+    static const int small_bn = getenv("PHC_GEMM_PRE_BN") ? atoi(getenv("PHC_GEMM_PRE_BN")) : 32;
+    if (N >= GEMM_BIG_M && Nout > 64 && K > 128)
+        launch_stream_cfg<0, -1, 64, 8, 4>(dy, nullptr, M, nullptr, nullptr, dz, N, K, Nout, 1, K, Nout, 1, s, n_valid_dev, sums_partial,
+                                           nullptr, num_partials, nullptr, 0, bn_x, bn_stat, act);
+    else if (N >= GEMM_BIG_M && Nout > 64)
+        launch_stream_cfg<0, -1, 128, 8, 4>(dy, nullptr, M, nullptr, nullptr, dz, N, K, Nout, 1, K, Nout, 1, s, n_valid_dev, sums_partial,
+                                            nullptr, num_partials, nullptr, 0, bn_x, bn_stat, act);
+    else if (small_bn == 32 && Nout > 32 && N <= 32 * 1024)
+        launch_stream_cfg<0, -1, 32, 4, 4>(dy, nullptr, M, nullptr, nullptr, dz, N, K, Nout, 1, K, Nout, 3, s, n_valid_dev, sums_partial,
+                                           nullptr, num_partials, nullptr, 0, bn_x, bn_stat, act);
+    else
+        launch_stream_cfg<0, -1, 64, 4, 4>(dy, nullptr, M, nullptr, nullptr, dz, N, K, Nout, 1, K, Nout, 2, s, n_valid_dev, sums_partial,
+                                           nullptr, num_partials, nullptr, 0, bn_x, bn_stat, act);
+    return check_launch("phc_gemm_prebuilt_bwsums");
 }
 
 // ---- batched parameter gradients ------------------------------------------------------------

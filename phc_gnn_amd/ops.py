@@ -1117,6 +1117,10 @@ class _BatchNormActFn(torch.autograd.Function):
         return (dx, dres, None, None, None, None, None, None, None, None, None, None, *aff_grads)
 
 
+# the norm backward's column sums come out of the dz GEMM's epilogue (False: separate bn_bwd_partial pass)
+BN_BWD_SUMS_IN_GEMM = __import__("os").environ.get("PHC_BN_BWD_SUMS_IN_GEMM", "1") != "0"
+
+
 class _BNActLinearFn(torch.autograd.Function):
     """[training batch-norm -> activation -> PHM linear] with the normalised activation never written to HBM
     (phc_bn_finalize_from_partials + phc_gemm_prebuilt_xf).  x is the norm's input — the output of a GEMM that
@@ -1165,10 +1169,19 @@ class _BNActLinearFn(torch.autograd.Function):
         N, h = x.shape
         n2, kin2, kout2 = W2.shape
         dy_ = L.f32c(dy)
-        # d(normalised activation) = dy . H2^T
+        # d(normalised activation) = dy . H2^T; the same launch emits the norm backward's column sums from its registers
         dz = torch.empty((N, h), dtype=torch.float32, device=dev)
-        L.check(lib.phc_gemm_prebuilt(L.ptr(dy_), L.ptr(ctx.HT2), None, None, N, n2 * kout2, h, L.ptr(dz), 1, L.stream_ptr(dev)),
-                "phc_gemm_prebuilt(dx)")
+        fused_sums = BN_BWD_SUMS_IN_GEMM and h % 4 == 0 and dy_.data_ptr() % 16 == 0
+        sums = None
+        num = _C.c_int(0)
+        if fused_sums:
+            sums = torch.empty((lib.phc_gemm_stats_max_partials(), 2 * h), dtype=torch.float32, device=dev)
+            L.check(lib.phc_gemm_prebuilt_bwsums(L.ptr(dy_), L.ptr(ctx.HT2), N, n2 * kout2, h, L.ptr(dz), L.ptr(x), L.ptr(save_stat),
+                                                 act, L.ptr(n_valid), L.ptr(sums), _C.byref(num), L.stream_ptr(dev)),
+                    "phc_gemm_prebuilt_bwsums")
+        else:
+            L.check(lib.phc_gemm_prebuilt(L.ptr(dy_), L.ptr(ctx.HT2), None, None, N, n2 * kout2, h, L.ptr(dz), 1, L.stream_ptr(dev)),
+                    "phc_gemm_prebuilt(dx)")
         if L.PROF_ON:
             L.account("phm_gemm_dx", 2.0 * N * h * n2 * kout2, 4.0 * (N * (h + n2 * kout2) + h * n2 * kout2))
         # second layer's parameter gradients: x stays the norm's input, the kernel re-evaluates act(x*scale+shift)
@@ -1192,12 +1205,19 @@ class _BNActLinearFn(torch.autograd.Function):
         need_aff = has_affine and any(needs[16:])
         dx = torch.empty_like(x) if need_x else None
         dwb = torch.empty(2 * h, dtype=torch.float32, device=dev) if need_aff else None
-        ws_bytes = lib.phc_bn_ws_bytes(N, h)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        L.check(lib.phc_bn_bwd(L.ptr(dz), L.ptr(x), L.ptr(save_stat), L.ptr(n_valid), N, h, 1, act, L.ptr(dx), L.ptr(dwb), None,
-                               L.ptr(ws), ws_bytes, L.stream_ptr(dev)), "phc_bn_bwd")
+        if fused_sums:
+            ws = torch.empty(2 * h, dtype=torch.float32, device=dev)
+            L.check(lib.phc_bn_bwd_from_partials(L.ptr(dz), L.ptr(x), L.ptr(save_stat), L.ptr(sums), num.value, L.ptr(n_valid), N, h,
+                                                 act, L.ptr(dx), L.ptr(dwb), L.ptr(ws), 8 * h, L.stream_ptr(dev)),
+                    "phc_bn_bwd_from_partials")
+        else:
+            ws_bytes = lib.phc_bn_ws_bytes(N, h)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            L.check(lib.phc_bn_bwd(L.ptr(dz), L.ptr(x), L.ptr(save_stat), L.ptr(n_valid), N, h, 1, act, L.ptr(dx), L.ptr(dwb), None,
+                                   L.ptr(ws), ws_bytes, L.stream_ptr(dev)), "phc_bn_bwd")
         if L.PROF_ON:
-            L.account("bn_bwd_partial", 6.0 * N * h, 8.0 * N * h)
+            if not fused_sums:
+                L.account("bn_bwd_partial", 6.0 * N * h, 8.0 * N * h)
             L.account("bn_bwd_apply", 8.0 * N * h, 12.0 * N * h)
         k = h // n_comp
         aff_grads = []

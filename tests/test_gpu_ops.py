@@ -806,9 +806,11 @@ def test_fanout_sums_gradients_in_one_pass(ops):
 
 @pytest.mark.parametrize("n,k,N,valid,act,deferred", [(4, 32, 13824, 12874, "relu", True), (4, 32, 500, None, "swish", True),
                                                       (2, 64, 333, 300, "relu", False), (8, 32, 700, None, "identity", True)])
-def test_bn_act_linear_without_materialising_the_normalised_activation(ops, n, k, N, valid, act, deferred):
+@pytest.mark.parametrize("bwd_sums", ["in_gemm", "separate_pass"])
+def test_bn_act_linear_without_materialising_the_normalised_activation(ops, n, k, N, valid, act, deferred, bwd_sums, monkeypatch):
     """linear1 (statistics from its epilogue) -> [batch-norm -> act -> linear2 folded into linear2's operand staging]
     against the three separate ops: output, every gradient, running statistics, padding rows."""
+    monkeypatch.setattr(ops, "BN_BWD_SUMS_IN_GEMM", bwd_sums == "in_gemm")
     g = torch.Generator().manual_seed(101)
     h = n * k
     x = torch.randn(N, h, generator=g)
