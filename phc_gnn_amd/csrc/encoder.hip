@@ -32,10 +32,13 @@ __device__ __forceinline__ void acc4(float4 &a, const float4 b) { a.x += b.x; a.
 
 // ---- atoms: out[i, c*k+kap] = sum_f T_{c,f}[idx[i,f]][kap] --------------------------------
 // LPR lanes cover one output row with float4 columns; 64/LPR nodes per wavefront.
-template <int LPR>
+template <int LPR, int FMAX>
 __global__ __launch_bounds__(ENC_THREADS) void encode_fwd_kernel(const long long *__restrict__ idx,
                                                                 const float *const *__restrict__ tables, long long N,
                                                                 int F, int n, int k, float *__restrict__ out) {
+    __shared__ const float *tptr[PHC_MAX_COMPONENTS * ENC_MAX_F];   // table base pointers: no pointer chase per lookup
+    for (int e = threadIdx.x; e < n * F; e += ENC_THREADS) tptr[e] = tables[e];
+    __syncthreads();
     constexpr int G = WAVE / LPR;
     const int lane = threadIdx.x & 63;
     const int grp = lane / LPR, li = lane - grp * LPR;
@@ -45,14 +48,20 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_fwd_kernel(const long long
     for (long long base = wave_id * G; base < N; base += n_waves * G) {
         const long long i = base + grp;
         if (i >= N) continue;
+        // all F indices of the row first (one round of loads), then all F table rows (a second round)
+        long long iv[FMAX];
+#pragma unroll
+        for (int f = 0; f < FMAX; ++f) iv[f] = idx[i * F + min(f, F - 1)];
         for (int c4 = li; c4 < h4; c4 += LPR) {
             const int col = c4 << 2;
             const int c = col / k, kap = col - c * k;
+            float4 rows[FMAX];
+#pragma unroll
+            for (int f = 0; f < FMAX; ++f) rows[f] = ld4(tptr[c * F + min(f, F - 1)] + iv[f] * k + kap);
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int f = 0; f < F; ++f) {
-                const long long v = idx[i * F + f];
-                acc4(acc, ld4(tables[c * F + f] + v * k + kap));
-            }
+#pragma unroll
+            for (int f = 0; f < FMAX; ++f)
+                if (f < F) acc4(acc, rows[f]);
             reinterpret_cast<float4 *>(out + (size_t)i * h)[c4] = acc;
         }
     }
@@ -540,17 +549,29 @@ int phc_encode_fwd(const int64_t *idx_i64, const float *const *tables, int64_t N
         const int lpr = lpr_for(h >> 2);
         const int G = 64 / lpr;
         long long blocks = (N + 4 * G - 1) / (4 * G);
-        if (blocks > 4096) blocks = 4096;
+        if (blocks > (N > 64 * 1024 ? 32768 : 4096)) blocks = N > 64 * 1024 ? 32768 : 4096;
         const long long *idx = reinterpret_cast<const long long *>(idx_i64);
+#define PHC_ENC_FWD(LPRC, FM)                                                                                               \
+    PHC_LAUNCH((encode_fwd_kernel<LPRC, FM>), dim3((unsigned)blocks), dim3(ENC_THREADS), 0, s, idx, tables, (long long)N, F, n, k, out)
+#define PHC_ENC_FWD_F(LPRC)             \
+    if (F <= 4) {                       \
+        PHC_ENC_FWD(LPRC, 4);           \
+    } else if (F <= 10) {               \
+        PHC_ENC_FWD(LPRC, 10);          \
+    } else {                            \
+        PHC_ENC_FWD(LPRC, ENC_MAX_F);   \
+    }
         switch (lpr) {
-            case 8: PHC_LAUNCH((encode_fwd_kernel<8>), dim3((unsigned)blocks), dim3(ENC_THREADS), 0, s, idx, tables, (long long)N, F, n, k, out); break;
-            case 16: PHC_LAUNCH((encode_fwd_kernel<16>), dim3((unsigned)blocks), dim3(ENC_THREADS), 0, s, idx, tables, (long long)N, F, n, k, out); break;
-            case 32: PHC_LAUNCH((encode_fwd_kernel<32>), dim3((unsigned)blocks), dim3(ENC_THREADS), 0, s, idx, tables, (long long)N, F, n, k, out); break;
-            default: PHC_LAUNCH((encode_fwd_kernel<64>), dim3((unsigned)blocks), dim3(ENC_THREADS), 0, s, idx, tables, (long long)N, F, n, k, out); break;
+            case 8: PHC_ENC_FWD_F(8); break;
+            case 16: PHC_ENC_FWD_F(16); break;
+            case 32: PHC_ENC_FWD_F(32); break;
+            default: PHC_ENC_FWD_F(64); break;
         }
+#undef PHC_ENC_FWD_F
+#undef PHC_ENC_FWD
     } else {
         long long blocks = (N * h + ENC_THREADS - 1) / ENC_THREADS;
-        if (blocks > 4096) blocks = 4096;
+        if (blocks > (N > 64 * 1024 ? 32768 : 4096)) blocks = N > 64 * 1024 ? 32768 : 4096;
         PHC_LAUNCH(encode_fwd_scalar_kernel, dim3((unsigned)blocks), dim3(ENC_THREADS), 0, s,
                            reinterpret_cast<const long long *>(idx_i64), tables, (long long)N, F, n, k, out);
     }
@@ -652,7 +673,10 @@ int phc_aggregate_encp_fwd(const float *x, const uint32_t *codes, const float *c
     PHC_REQUIRE(lds <= 48 * 1024, PHC_ERR_UNSUPPORTED, "phc_aggregate_encp_fwd: tables (%zu B) exceed the LDS budget", lds);
     hipStream_t s = (hipStream_t)stream;
     long long blocks = (n_dst + 3) / 4;
-    if (blocks > 2048) blocks = 2048;                       // persistent-ish: amortise the LDS table fill
+    // persistent-ish workgroups amortise the LDS table fill; large graphs take 8x more of them so that rows of very
+    // different degree balance out (10 M rows: 44.7 % -> 59.7 % of the HBM peak), molecule batches stay at one resident set
+    const long long cap = n_dst > 64 * 1024 ? 16384 : 2048;
+    if (blocks > cap) blocks = cap;
     const int lpr = lpr_for(h >> 2);
     ProfScope prof(K_AGG_ENC_FWD, s);
 #define PHC_AP_LAUNCH(LPRC, ACTC, FC)                                                                                     \
@@ -714,7 +738,7 @@ int phc_aggregate_enc_bwd(const float *dout, const float *x, const int64_t *bond
         const size_t lds = act == PHC_ACT_IDENTITY ? 0 : sizeof(float) * (size_t)m.R * h;
         PHC_REQUIRE(lds <= 48 * 1024, PHC_ERR_UNSUPPORTED, "phc_aggregate_enc_bwd: tables exceed the LDS budget");
         long long blocks = (n_src + 3) / 4;
-        const long long cap = act == PHC_ACT_IDENTITY ? 8192 : 1024;
+        const long long cap = n_src > 64 * 1024 ? 16384 : (act == PHC_ACT_IDENTITY ? 8192 : 1024);   // large graphs: see encp_fwd
         if (blocks > cap) blocks = cap;
         const int lpr = lpr_for(h >> 2);
         ProfScope prof(K_AGG_ENC_DX, s);
