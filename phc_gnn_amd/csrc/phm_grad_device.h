@@ -1,0 +1,313 @@
+// Device bodies and job tables of the PHM parameter-gradient kernels (dH = x^T.dy as fixed-order split-K slabs).
+// Shared by phm_linear.hip (phc_phm_linear_bwd, phc_phm_param_grads) and encoder.hip (phc_step_tail: the same
+// workgroup bodies launched side by side with the table-gradient workgroups).
+#pragma once
+#include "phc_common.h"
+
+namespace phc {
+
+using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4 = __attribute__((ext_vector_type(4))) float;
+
+// ------------------------------------------------------------------------------------------
+// dH = x^T . dy  as split-K slabs.  Workgroup (tile, split) accumulates the 64 x 64 tile
+// (i0.., j0..) of dH over its row range and writes it to slab[split].  Workgroups with
+// tile_i == 0 also produce the column sums of dy (db) for their rows.
+// ------------------------------------------------------------------------------------------
+constexpr int DH_T = 64;            // tile edge
+constexpr int DH_RB = 64;           // rows staged per step
+constexpr int DH_STRIDE = DH_T;     // lanes read consecutive columns: conflict-free without padding
+
+__device__ __forceinline__ void dH_partial_body(const float *__restrict__ X, const float *__restrict__ DY,
+                                                float *__restrict__ slabs, long long N, int in, int out, int tiles_j,
+                                                long long rows_per_split, int vec4, int tile, long long split,
+                                                float *__restrict__ smem, const float *__restrict__ xf_stat = nullptr,
+                                                int xf_act = 0, long long xf_count = 0) {
+    // xf_stat != NULL: the X operand is a batch-norm that was never applied in HBM (phc_gemm_prebuilt_xf):
+    // x := act(x * scale + shift) per column, rows >= xf_count read as 0, evaluated while the tile is staged
+    float *xs = smem;                                    // [DH_RB][DH_STRIDE]
+    float *ds = smem + DH_RB * DH_STRIDE;                // [DH_RB][DH_STRIDE]
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int r = lane & 31, hh = lane >> 5;
+    const int ti = tile / tiles_j, tj = tile - ti * tiles_j;
+    const int i0 = ti * DH_T, j0 = tj * DH_T;
+    const long long r_begin = split * rows_per_split;
+    const long long r_end = min(N, r_begin + rows_per_split);
+    const size_t slab_elems = (size_t)in * out + out;
+    float *slab = slabs + (size_t)split * slab_elems;
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    float colsum = 0.f;                                  // threads 0..63 of tile_i == 0 workgroups
+    float4 xf_sc = make_float4(1.f, 1.f, 1.f, 1.f), xf_sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (xf_stat && vec4) {                               // this thread always stages float4 column (tid & 15) of the X tile
+        const int ci = min(i0 + (tid & 15) * 4, in - 4);
+        xf_sc = *reinterpret_cast<const float4 *>(xf_stat + 2 * (size_t)in + ci);
+        xf_sh = *reinterpret_cast<const float4 *>(xf_stat + 3 * (size_t)in + ci);
+    }
+
+    for (long long rb = r_begin; rb < r_end; rb += DH_RB) {
+        __syncthreads();
+        if (vec4) {
+            for (int e = tid; e < DH_RB * (DH_T / 4); e += 256) {
+                const int row = e / (DH_T / 4), c4 = e - row * (DH_T / 4);
+                float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), dv = xv;
+                if (rb + row < r_end) {
+                    if (i0 + c4 * 4 < in) {
+                        xv = *reinterpret_cast<const float4 *>(X + (size_t)(rb + row) * in + i0 + c4 * 4);
+                        if (xf_stat) {
+                            const float4 sc = xf_sc, sh = xf_sh;     // c4 = tid & 15 for every element of this thread
+                            const bool live = rb + row < xf_count;
+                            if (xf_act == PHC_ACT_RELU) {
+                                xv.x = live ? fmaxf(fmaf(xv.x, sc.x, sh.x), 0.f) : 0.f;
+                                xv.y = live ? fmaxf(fmaf(xv.y, sc.y, sh.y), 0.f) : 0.f;
+                                xv.z = live ? fmaxf(fmaf(xv.z, sc.z, sh.z), 0.f) : 0.f;
+                                xv.w = live ? fmaxf(fmaf(xv.w, sc.w, sh.w), 0.f) : 0.f;
+                            } else {
+                                xv.x = live ? act_fwd_rt(xf_act, fmaf(xv.x, sc.x, sh.x)) : 0.f;
+                                xv.y = live ? act_fwd_rt(xf_act, fmaf(xv.y, sc.y, sh.y)) : 0.f;
+                                xv.z = live ? act_fwd_rt(xf_act, fmaf(xv.z, sc.z, sh.z)) : 0.f;
+                                xv.w = live ? act_fwd_rt(xf_act, fmaf(xv.w, sc.w, sh.w)) : 0.f;
+                            }
+                        }
+                    }
+                    if (j0 + c4 * 4 < out) dv = *reinterpret_cast<const float4 *>(DY + (size_t)(rb + row) * out + j0 + c4 * 4);
+                }
+                *reinterpret_cast<float4 *>(xs + row * DH_STRIDE + c4 * 4) = xv;
+                *reinterpret_cast<float4 *>(ds + row * DH_STRIDE + c4 * 4) = dv;
+            }
+        } else {
+            for (int e = tid; e < DH_RB * DH_T; e += 256) {
+                const int row = e / DH_T, c = e - row * DH_T;
+                float xv = 0.f, dv = 0.f;
+                if (rb + row < r_end) {
+                    if (i0 + c < in) {
+                        xv = X[(size_t)(rb + row) * in + i0 + c];
+                        if (xf_stat)
+                            xv = rb + row < xf_count
+                                     ? act_fwd_rt(xf_act, fmaf(xv, xf_stat[2 * (size_t)in + i0 + c], xf_stat[3 * (size_t)in + i0 + c]))
+                                     : 0.f;
+                    }
+                    if (j0 + c < out) dv = DY[(size_t)(rb + row) * out + j0 + c];
+                }
+                xs[row * DH_STRIDE + c] = xv;
+                ds[row * DH_STRIDE + c] = dv;
+            }
+        }
+        __syncthreads();
+        // A operand = x^T: lane (r, hh) supplies x[row rr+hh][i0 + wi*32 + r]; B = dy[row rr+hh][j0 + wj*32 + r]
+        const float *xa = xs + hh * DH_STRIDE + wi * 32 + r;
+        const float *db_ = ds + hh * DH_STRIDE + wj * 32 + r;
+#pragma unroll 8
+        for (int rr = 0; rr < DH_RB; rr += 2)
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[rr * DH_STRIDE], db_[rr * DH_STRIDE], acc, 0, 0, 0);
+        if (ti == 0 && tid < DH_T) {
+#pragma unroll 8
+            for (int rr = 0; rr < DH_RB; ++rr) colsum += ds[rr * DH_STRIDE + tid];
+        }
+    }
+
+    const int col = j0 + wj * 32 + r;
+    if (col < out) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = i0 + wi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+            if (row < in) slab[(size_t)row * out + col] = acc[reg];
+        }
+    }
+    if (ti == 0 && tid < DH_T && j0 + tid < out) slab[(size_t)in * out + j0 + tid] = colsum;
+}
+
+// 128 x 128 tile variant (in, out >= 128): each wavefront owns a 64 x 64 quadrant = 2 x 2 MFMA tiles, rows staged
+// 32 at a time.  Twice the MFMAs per staged byte and per LDS read of the 64 x 64 form, and when in = out = 128 the
+// tile is the whole matrix, so x and dy are read exactly once (the 64 x 64 form reads each twice: its 258 MB per
+// batched launch at config 2 made it HBM/L2-bound at 56 % of the MFMA peak).
+constexpr int DH_T2 = 128;
+constexpr int DH_RB2 = 32;
+
+__device__ __forceinline__ void dH_partial_body128(const float *__restrict__ X, const float *__restrict__ DY,
+                                                   float *__restrict__ slabs, long long N, int in, int out, int tiles_j,
+                                                   long long rows_per_split, int vec4, int tile, long long split,
+                                                   float *__restrict__ smem, const float *__restrict__ xf_stat = nullptr,
+                                                   int xf_act = 0, long long xf_count = 0) {
+    float *xs = smem;                                    // [DH_RB2][DH_T2]
+    float *ds = smem + DH_RB2 * DH_T2;                   // [DH_RB2][DH_T2]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int r = lane & 31, hh = lane >> 5;
+    const int ti = tile / tiles_j, tj = tile - ti * tiles_j;
+    const int i0 = ti * DH_T2, j0 = tj * DH_T2;
+    const long long r_begin = split * rows_per_split;
+    const long long r_end = min(N, r_begin + rows_per_split);
+    const size_t slab_elems = (size_t)in * out + out;
+    float *slab = slabs + (size_t)split * slab_elems;
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
+    float colsum = 0.f;                                  // threads 0..127 of tile_i == 0 workgroups
+    f32x4 xf_sc = {1.f, 1.f, 1.f, 1.f}, xf_sh = {0.f, 0.f, 0.f, 0.f};
+    if (xf_stat && vec4) {
+        const int ci = min(i0 + (tid & 31) * 4, in - 4);
+        xf_sc = *reinterpret_cast<const f32x4 *>(xf_stat + 2 * (size_t)in + ci);
+        xf_sh = *reinterpret_cast<const f32x4 *>(xf_stat + 3 * (size_t)in + ci);
+    }
+
+    for (long long rb = r_begin; rb < r_end; rb += DH_RB2) {
+        __syncthreads();
+        if (vec4) {
+            // 32 rows x 32 float4 per operand = 4 float4 per thread and operand, all issued before the LDS stores
+            f32x4 xv[4], dv[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int e = tid + 256 * t;
+                const int row = e >> 5, c4 = e & 31;
+                const long long grow = min(rb + row, r_end - 1);
+                const int ci = min(i0 + c4 * 4, in - 4), cj = min(j0 + c4 * 4, out - 4);
+                xv[t] = *reinterpret_cast<const f32x4 *>(X + (size_t)grow * in + ci);
+                dv[t] = *reinterpret_cast<const f32x4 *>(DY + (size_t)grow * out + cj);
+            }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int e = tid + 256 * t;
+                const int row = e >> 5, c4 = e & 31;
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                const bool rok = rb + row < r_end;
+                if (xf_stat) {
+                    const f32x4 sc = xf_sc, sh = xf_sh;      // c4 = tid & 31 for every element of this thread
+                    const bool live = rb + row < xf_count;
+                    if (xf_act == PHC_ACT_RELU) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) xv[t][q] = live ? fmaxf(fmaf(xv[t][q], sc[q], sh[q]), 0.f) : 0.f;
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) xv[t][q] = live ? act_fwd_rt(xf_act, fmaf(xv[t][q], sc[q], sh[q])) : 0.f;
+                    }
+                }
+                *reinterpret_cast<f32x4 *>(xs + row * DH_T2 + c4 * 4) = (rok && i0 + c4 * 4 < in) ? xv[t] : z;
+                *reinterpret_cast<f32x4 *>(ds + row * DH_T2 + c4 * 4) = (rok && j0 + c4 * 4 < out) ? dv[t] : z;
+            }
+        } else {
+            for (int e = tid; e < DH_RB2 * DH_T2; e += 256) {
+                const int row = e / DH_T2, c = e - row * DH_T2;
+                float xv = 0.f, dv = 0.f;
+                if (rb + row < r_end) {
+                    if (i0 + c < in) {
+                        xv = X[(size_t)(rb + row) * in + i0 + c];
+                        if (xf_stat)
+                            xv = rb + row < xf_count
+                                     ? act_fwd_rt(xf_act, fmaf(xv, xf_stat[2 * (size_t)in + i0 + c], xf_stat[3 * (size_t)in + i0 + c]))
+                                     : 0.f;
+                    }
+                    if (j0 + c < out) dv = DY[(size_t)(rb + row) * out + j0 + c];
+                }
+                xs[row * DH_T2 + c] = xv;
+                ds[row * DH_T2 + c] = dv;
+            }
+        }
+        __syncthreads();
+        const float *xa = xs + hh * DH_T2 + wi * 64 + r;
+        const float *db_ = ds + hh * DH_T2 + wj * 64 + r;
+#pragma unroll 4
+        for (int rr = 0; rr < DH_RB2; rr += 2) {
+            const float a0 = xa[rr * DH_T2], a1 = xa[rr * DH_T2 + 32];
+            const float b0 = db_[rr * DH_T2], b1 = db_[rr * DH_T2 + 32];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
+            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
+            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
+            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
+        }
+        if (ti == 0 && tid < DH_T2) {
+#pragma unroll 8
+            for (int rr = 0; rr < DH_RB2; ++rr) colsum += ds[rr * DH_T2 + tid];
+        }
+    }
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int col = j0 + wj * 64 + b * 32 + r;
+            if (col < out) {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
+                    const int row = i0 + wi * 64 + a * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+                    if (row < in) slab[(size_t)row * out + col] = acc[a][b][reg];
+                }
+            }
+        }
+    if (ti == 0 && tid < DH_T2 && j0 + tid < out) slab[(size_t)in * out + j0 + tid] = colsum;
+}
+
+// dH[idx] (and the db tail) = sum over splits.  64 elements x 4 split lanes per workgroup; every lane
+// walks its splits in order and the 4 lane sums are added in order: one fixed summation tree.
+__device__ __forceinline__ void dH_reduce_body(const float *__restrict__ slabs, float *__restrict__ dH, size_t slab_elems, int splits,
+                                               unsigned blk) {
+    __shared__ float part[4][64];
+    const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
+    const size_t idx = (size_t)blk * 64 + e;
+    float s = 0.f;
+    if (idx < slab_elems) {
+#pragma unroll 4
+        for (int k = sl; k < splits; k += 4) s += slabs[(size_t)k * slab_elems + idx];
+    }
+    part[sl][e] = s;
+    __syncthreads();
+    if (sl == 0 && idx < slab_elems) dH[idx] = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
+}
+
+// ------------------------------------------------------------------------------------------
+// Batched parameter gradients (phc_phm_param_grads): the dW / dA / db chains of MANY layers in
+// three launches.  Parameter gradients are off the critical path of the backward pass (only the
+// optimizer reads them), and one layer's chain cannot fill 256 CUs at molecule scale; batching
+// the layers fills the chip and needs ~30 split-K slabs per layer instead of ~130.
+// The job table travels by value in the kernarg segment; workgroup -> job by a scalar scan.
+// ------------------------------------------------------------------------------------------
+constexpr int GRAD_JOBS_PER_LAUNCH = 16;
+
+struct GradJobDev {
+    const float *x, *dy, *A, *W;
+    float *dW, *dA, *db;
+    float *slabs, *dH;
+    long long N, rows_per_split;
+    int in, out, n, kin, kout;
+    int tiles_j, tiles, splits, vec4;
+    int dA_blocks, t128, dw_transposed;
+    const float *xf_stat;                                    // X operand = act(x * scale + shift) (see dH_partial_body)
+    const int *xf_n_valid;
+    int xf_act;
+    unsigned blk0_partial, blk0_reduce, blk0_contract;      // first workgroup of this job in each launch
+};
+struct GradBatch {
+    int num;
+    GradJobDev j[GRAD_JOBS_PER_LAUNCH];
+};
+
+template <int STAGE>
+__device__ __forceinline__ int grad_job_of_block(const GradBatch &b, unsigned bx) {
+    int job = 0;
+    for (int k = 1; k < b.num; ++k) {
+        const unsigned start = STAGE == 0 ? b.j[k].blk0_partial : (STAGE == 1 ? b.j[k].blk0_reduce : b.j[k].blk0_contract);
+        if (bx >= start) job = k;
+    }
+    return job;
+}
+
+// Host: plans, slab placement and the by-value job table of one launch (<= GRAD_JOBS_PER_LAUNCH jobs); defined in
+// phm_linear.hip.  Returns PHC_OK or an error code (phc_last_error has the text).
+struct GradLaunch {
+    GradBatch batch;                                        // blk0_partial of 128-tile jobs is relative to nb_partial128
+    unsigned nb_partial, nb_partial128, nb_reduce, nb_contract;
+};
+size_t grad_chunk_ws_floats(const phc_phm_grad_job *jobs, int num_jobs);
+int prepare_grad_launch(const char *who, const phc_phm_grad_job *jobs, int num_jobs, float *ws_base, GradLaunch *out);
+int launch_grad_rest(const char *who, const GradLaunch &gl, bool partial64_too, hipStream_t s);
+int check_grad_jobs(const char *who, const phc_phm_grad_job *jobs, int num_jobs);
+
+}  // namespace phc

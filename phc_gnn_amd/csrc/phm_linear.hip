@@ -18,12 +18,11 @@
 #include <stdlib.h>
 
 #include "phc_common.h"
+#include "phm_grad_device.h"
 #include <vector>
 
 namespace phc {
 
-using f32x16 = __attribute__((ext_vector_type(16))) float;
-using f32x4 = __attribute__((ext_vector_type(4))) float;
 
 constexpr int GEMM_BK = 128;       // K chunk held in LDS
 constexpr int XS_STRIDE = GEMM_BK + 4;   // floats; +4 keeps ds_read_b128 conflict-free (16-lane groups hit 16 distinct 4-bank slots)
@@ -726,264 +725,11 @@ __global__ __launch_bounds__(256) void phm_build_H_batched_kernel(HBatch b) {
     if (jb.HT) jb.HT[(size_t)jc * in + k] = hsum;
 }
 
-// ------------------------------------------------------------------------------------------
-// dH = x^T . dy  as split-K slabs.  Workgroup (tile, split) accumulates the 64 x 64 tile
-// (i0.., j0..) of dH over its row range and writes it to slab[split].  Workgroups with
-// tile_i == 0 also produce the column sums of dy (db) for their rows.
-// ------------------------------------------------------------------------------------------
-constexpr int DH_T = 64;            // tile edge
-constexpr int DH_RB = 64;           // rows staged per step
-constexpr int DH_STRIDE = DH_T;     // lanes read consecutive columns: conflict-free without padding
-
-__device__ __forceinline__ void dH_partial_body(const float *__restrict__ X, const float *__restrict__ DY,
-                                                float *__restrict__ slabs, long long N, int in, int out, int tiles_j,
-                                                long long rows_per_split, int vec4, int tile, long long split,
-                                                float *__restrict__ smem, const float *__restrict__ xf_stat = nullptr,
-                                                int xf_act = 0, long long xf_count = 0) {
-    // xf_stat != NULL: the X operand is a batch-norm that was never applied in HBM (phc_gemm_prebuilt_xf):
-    // x := act(x * scale + shift) per column, rows >= xf_count read as 0, evaluated while the tile is staged
-    float *xs = smem;                                    // [DH_RB][DH_STRIDE]
-    float *ds = smem + DH_RB * DH_STRIDE;                // [DH_RB][DH_STRIDE]
-
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wi = wave >> 1, wj = wave & 1;
-    const int r = lane & 31, hh = lane >> 5;
-    const int ti = tile / tiles_j, tj = tile - ti * tiles_j;
-    const int i0 = ti * DH_T, j0 = tj * DH_T;
-    const long long r_begin = split * rows_per_split;
-    const long long r_end = min(N, r_begin + rows_per_split);
-    const size_t slab_elems = (size_t)in * out + out;
-    float *slab = slabs + (size_t)split * slab_elems;
-
-    f32x16 acc;
-#pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    float colsum = 0.f;                                  // threads 0..63 of tile_i == 0 workgroups
-    float4 xf_sc = make_float4(1.f, 1.f, 1.f, 1.f), xf_sh = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (xf_stat && vec4) {                               // this thread always stages float4 column (tid & 15) of the X tile
-        const int ci = min(i0 + (tid & 15) * 4, in - 4);
-        xf_sc = *reinterpret_cast<const float4 *>(xf_stat + 2 * (size_t)in + ci);
-        xf_sh = *reinterpret_cast<const float4 *>(xf_stat + 3 * (size_t)in + ci);
-    }
-
-    for (long long rb = r_begin; rb < r_end; rb += DH_RB) {
-        __syncthreads();
-        if (vec4) {
-            for (int e = tid; e < DH_RB * (DH_T / 4); e += 256) {
-                const int row = e / (DH_T / 4), c4 = e - row * (DH_T / 4);
-                float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), dv = xv;
-                if (rb + row < r_end) {
-                    if (i0 + c4 * 4 < in) {
-                        xv = *reinterpret_cast<const float4 *>(X + (size_t)(rb + row) * in + i0 + c4 * 4);
-                        if (xf_stat) {
-                            const float4 sc = xf_sc, sh = xf_sh;     // c4 = tid & 15 for every element of this thread
-                            const bool live = rb + row < xf_count;
-                            if (xf_act == PHC_ACT_RELU) {
-                                xv.x = live ? fmaxf(fmaf(xv.x, sc.x, sh.x), 0.f) : 0.f;
-                                xv.y = live ? fmaxf(fmaf(xv.y, sc.y, sh.y), 0.f) : 0.f;
-                                xv.z = live ? fmaxf(fmaf(xv.z, sc.z, sh.z), 0.f) : 0.f;
-                                xv.w = live ? fmaxf(fmaf(xv.w, sc.w, sh.w), 0.f) : 0.f;
-                            } else {
-                                xv.x = live ? act_fwd_rt(xf_act, fmaf(xv.x, sc.x, sh.x)) : 0.f;
-                                xv.y = live ? act_fwd_rt(xf_act, fmaf(xv.y, sc.y, sh.y)) : 0.f;
-                                xv.z = live ? act_fwd_rt(xf_act, fmaf(xv.z, sc.z, sh.z)) : 0.f;
-                                xv.w = live ? act_fwd_rt(xf_act, fmaf(xv.w, sc.w, sh.w)) : 0.f;
-                            }
-                        }
-                    }
-                    if (j0 + c4 * 4 < out) dv = *reinterpret_cast<const float4 *>(DY + (size_t)(rb + row) * out + j0 + c4 * 4);
-                }
-                *reinterpret_cast<float4 *>(xs + row * DH_STRIDE + c4 * 4) = xv;
-                *reinterpret_cast<float4 *>(ds + row * DH_STRIDE + c4 * 4) = dv;
-            }
-        } else {
-            for (int e = tid; e < DH_RB * DH_T; e += 256) {
-                const int row = e / DH_T, c = e - row * DH_T;
-                float xv = 0.f, dv = 0.f;
-                if (rb + row < r_end) {
-                    if (i0 + c < in) {
-                        xv = X[(size_t)(rb + row) * in + i0 + c];
-                        if (xf_stat)
-                            xv = rb + row < xf_count
-                                     ? act_fwd_rt(xf_act, fmaf(xv, xf_stat[2 * (size_t)in + i0 + c], xf_stat[3 * (size_t)in + i0 + c]))
-                                     : 0.f;
-                    }
-                    if (j0 + c < out) dv = DY[(size_t)(rb + row) * out + j0 + c];
-                }
-                xs[row * DH_STRIDE + c] = xv;
-                ds[row * DH_STRIDE + c] = dv;
-            }
-        }
-        __syncthreads();
-        // A operand = x^T: lane (r, hh) supplies x[row rr+hh][i0 + wi*32 + r]; B = dy[row rr+hh][j0 + wj*32 + r]
-        const float *xa = xs + hh * DH_STRIDE + wi * 32 + r;
-        const float *db_ = ds + hh * DH_STRIDE + wj * 32 + r;
-#pragma unroll 8
-        for (int rr = 0; rr < DH_RB; rr += 2)
-            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[rr * DH_STRIDE], db_[rr * DH_STRIDE], acc, 0, 0, 0);
-        if (ti == 0 && tid < DH_T) {
-#pragma unroll 8
-            for (int rr = 0; rr < DH_RB; ++rr) colsum += ds[rr * DH_STRIDE + tid];
-        }
-    }
-
-    const int col = j0 + wj * 32 + r;
-    if (col < out) {
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-            const int row = i0 + wi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
-            if (row < in) slab[(size_t)row * out + col] = acc[reg];
-        }
-    }
-    if (ti == 0 && tid < DH_T && j0 + tid < out) slab[(size_t)in * out + j0 + tid] = colsum;
-}
-
-// 128 x 128 tile variant (in, out >= 128): each wavefront owns a 64 x 64 quadrant = 2 x 2 MFMA tiles, rows staged
-// 32 at a time.  Twice the MFMAs per staged byte and per LDS read of the 64 x 64 form, and when in = out = 128 the
-// tile is the whole matrix, so x and dy are read exactly once (the 64 x 64 form reads each twice: its 258 MB per
-// batched launch at config 2 made it HBM/L2-bound at 56 % of the MFMA peak).
-constexpr int DH_T2 = 128;
-constexpr int DH_RB2 = 32;
-
-__device__ __forceinline__ void dH_partial_body128(const float *__restrict__ X, const float *__restrict__ DY,
-                                                   float *__restrict__ slabs, long long N, int in, int out, int tiles_j,
-                                                   long long rows_per_split, int vec4, int tile, long long split,
-                                                   float *__restrict__ smem, const float *__restrict__ xf_stat = nullptr,
-                                                   int xf_act = 0, long long xf_count = 0) {
-    float *xs = smem;                                    // [DH_RB2][DH_T2]
-    float *ds = smem + DH_RB2 * DH_T2;                   // [DH_RB2][DH_T2]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int wi = wave >> 1, wj = wave & 1;
-    const int r = lane & 31, hh = lane >> 5;
-    const int ti = tile / tiles_j, tj = tile - ti * tiles_j;
-    const int i0 = ti * DH_T2, j0 = tj * DH_T2;
-    const long long r_begin = split * rows_per_split;
-    const long long r_end = min(N, r_begin + rows_per_split);
-    const size_t slab_elems = (size_t)in * out + out;
-    float *slab = slabs + (size_t)split * slab_elems;
-
-    f32x16 acc[2][2];
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[a][b][i] = 0.f;
-    float colsum = 0.f;                                  // threads 0..127 of tile_i == 0 workgroups
-    f32x4 xf_sc = {1.f, 1.f, 1.f, 1.f}, xf_sh = {0.f, 0.f, 0.f, 0.f};
-    if (xf_stat && vec4) {
-        const int ci = min(i0 + (tid & 31) * 4, in - 4);
-        xf_sc = *reinterpret_cast<const f32x4 *>(xf_stat + 2 * (size_t)in + ci);
-        xf_sh = *reinterpret_cast<const f32x4 *>(xf_stat + 3 * (size_t)in + ci);
-    }
-
-    for (long long rb = r_begin; rb < r_end; rb += DH_RB2) {
-        __syncthreads();
-        if (vec4) {
-            // 32 rows x 32 float4 per operand = 4 float4 per thread and operand, all issued before the LDS stores
-            f32x4 xv[4], dv[4];
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int e = tid + 256 * t;
-                const int row = e >> 5, c4 = e & 31;
-                const long long grow = min(rb + row, r_end - 1);
-                const int ci = min(i0 + c4 * 4, in - 4), cj = min(j0 + c4 * 4, out - 4);
-                xv[t] = *reinterpret_cast<const f32x4 *>(X + (size_t)grow * in + ci);
-                dv[t] = *reinterpret_cast<const f32x4 *>(DY + (size_t)grow * out + cj);
-            }
-#pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const int e = tid + 256 * t;
-                const int row = e >> 5, c4 = e & 31;
-                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
-                const bool rok = rb + row < r_end;
-                if (xf_stat) {
-                    const f32x4 sc = xf_sc, sh = xf_sh;      // c4 = tid & 31 for every element of this thread
-                    const bool live = rb + row < xf_count;
-                    if (xf_act == PHC_ACT_RELU) {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) xv[t][q] = live ? fmaxf(fmaf(xv[t][q], sc[q], sh[q]), 0.f) : 0.f;
-                    } else {
-#pragma unroll
-                        for (int q = 0; q < 4; ++q) xv[t][q] = live ? act_fwd_rt(xf_act, fmaf(xv[t][q], sc[q], sh[q])) : 0.f;
-                    }
-                }
-                *reinterpret_cast<f32x4 *>(xs + row * DH_T2 + c4 * 4) = (rok && i0 + c4 * 4 < in) ? xv[t] : z;
-                *reinterpret_cast<f32x4 *>(ds + row * DH_T2 + c4 * 4) = (rok && j0 + c4 * 4 < out) ? dv[t] : z;
-            }
-        } else {
-            for (int e = tid; e < DH_RB2 * DH_T2; e += 256) {
-                const int row = e / DH_T2, c = e - row * DH_T2;
-                float xv = 0.f, dv = 0.f;
-                if (rb + row < r_end) {
-                    if (i0 + c < in) {
-                        xv = X[(size_t)(rb + row) * in + i0 + c];
-                        if (xf_stat)
-                            xv = rb + row < xf_count
-                                     ? act_fwd_rt(xf_act, fmaf(xv, xf_stat[2 * (size_t)in + i0 + c], xf_stat[3 * (size_t)in + i0 + c]))
-                                     : 0.f;
-                    }
-                    if (j0 + c < out) dv = DY[(size_t)(rb + row) * out + j0 + c];
-                }
-                xs[row * DH_T2 + c] = xv;
-                ds[row * DH_T2 + c] = dv;
-            }
-        }
-        __syncthreads();
-        const float *xa = xs + hh * DH_T2 + wi * 64 + r;
-        const float *db_ = ds + hh * DH_T2 + wj * 64 + r;
-#pragma unroll 4
-        for (int rr = 0; rr < DH_RB2; rr += 2) {
-            const float a0 = xa[rr * DH_T2], a1 = xa[rr * DH_T2 + 32];
-            const float b0 = db_[rr * DH_T2], b1 = db_[rr * DH_T2 + 32];
-            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b0, acc[0][0], 0, 0, 0);
-            acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0, b1, acc[0][1], 0, 0, 0);
-            acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b0, acc[1][0], 0, 0, 0);
-            acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1, b1, acc[1][1], 0, 0, 0);
-        }
-        if (ti == 0 && tid < DH_T2) {
-#pragma unroll 8
-            for (int rr = 0; rr < DH_RB2; ++rr) colsum += ds[rr * DH_T2 + tid];
-        }
-    }
-#pragma unroll
-    for (int a = 0; a < 2; ++a)
-#pragma unroll
-        for (int b = 0; b < 2; ++b) {
-            const int col = j0 + wj * 64 + b * 32 + r;
-            if (col < out) {
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int row = i0 + wi * 64 + a * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
-                    if (row < in) slab[(size_t)row * out + col] = acc[a][b][reg];
-                }
-            }
-        }
-    if (ti == 0 && tid < DH_T2 && j0 + tid < out) slab[(size_t)in * out + j0 + tid] = colsum;
-}
-
 __global__ __launch_bounds__(256) void phm_dH_partial_kernel(const float *__restrict__ X, const float *__restrict__ DY,
                                                             float *__restrict__ slabs, long long N, int in, int out,
                                                             int tiles_j, long long rows_per_split, int vec4) {
     __shared__ __attribute__((aligned(16))) float smem[2 * DH_RB * DH_STRIDE];
     dH_partial_body(X, DY, slabs, N, in, out, tiles_j, rows_per_split, vec4, blockIdx.x, blockIdx.y, smem);
-}
-
-// dH[idx] (and the db tail) = sum over splits.  64 elements x 4 split lanes per workgroup; every lane
-// walks its splits in order and the 4 lane sums are added in order: one fixed summation tree.
-__device__ __forceinline__ void dH_reduce_body(const float *__restrict__ slabs, float *__restrict__ dH, size_t slab_elems, int splits,
-                                               unsigned blk) {
-    __shared__ float part[4][64];
-    const int e = threadIdx.x & 63, sl = threadIdx.x >> 6;
-    const size_t idx = (size_t)blk * 64 + e;
-    float s = 0.f;
-    if (idx < slab_elems) {
-#pragma unroll 4
-        for (int k = sl; k < splits; k += 4) s += slabs[(size_t)k * slab_elems + idx];
-    }
-    part[sl][e] = s;
-    __syncthreads();
-    if (sl == 0 && idx < slab_elems) dH[idx] = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
 }
 
 __global__ __launch_bounds__(256) void phm_dH_reduce_kernel(const float *__restrict__ slabs, float *__restrict__ dH, size_t slab_elems,
@@ -1040,43 +786,6 @@ __global__ __launch_bounds__(256) void phm_contract_kernel(const float *__restri
                                                           float *__restrict__ dA, float *__restrict__ db, int n, int kin,
                                                           int kout, int dA_blocks) {
     contract_body(A, W, dH, dW, dA, db, n, kin, kout, dA_blocks, blockIdx.x);
-}
-
-// ------------------------------------------------------------------------------------------
-// Batched parameter gradients (phc_phm_param_grads): the dW / dA / db chains of MANY layers in
-// three launches.  Parameter gradients are off the critical path of the backward pass (only the
-// optimizer reads them), and one layer's chain cannot fill 256 CUs at molecule scale; batching
-// the layers fills the chip and needs ~30 split-K slabs per layer instead of ~130.
-// The job table travels by value in the kernarg segment; workgroup -> job by a scalar scan.
-// ------------------------------------------------------------------------------------------
-constexpr int GRAD_JOBS_PER_LAUNCH = 16;
-
-struct GradJobDev {
-    const float *x, *dy, *A, *W;
-    float *dW, *dA, *db;
-    float *slabs, *dH;
-    long long N, rows_per_split;
-    int in, out, n, kin, kout;
-    int tiles_j, tiles, splits, vec4;
-    int dA_blocks, t128, dw_transposed;
-    const float *xf_stat;                                    // X operand = act(x * scale + shift) (see dH_partial_body)
-    const int *xf_n_valid;
-    int xf_act;
-    unsigned blk0_partial, blk0_reduce, blk0_contract;      // first workgroup of this job in each launch
-};
-struct GradBatch {
-    int num;
-    GradJobDev j[GRAD_JOBS_PER_LAUNCH];
-};
-
-template <int STAGE>
-__device__ __forceinline__ int grad_job_of_block(const GradBatch &b, unsigned bx) {
-    int job = 0;
-    for (int k = 1; k < b.num; ++k) {
-        const unsigned start = STAGE == 0 ? b.j[k].blk0_partial : (STAGE == 1 ? b.j[k].blk0_reduce : b.j[k].blk0_contract);
-        if (bx >= start) job = k;
-    }
-    return job;
 }
 
 __global__ __launch_bounds__(256) void phm_dH_partial128_kernel(const float *__restrict__ X, const float *__restrict__ DY,
@@ -1274,6 +983,135 @@ static DhPlan dh_plan(int64_t N, int in, int out) {
     p.rows_per_split = rps;
     p.slab_elems = (size_t)in * out + out;
     return p;
+}
+
+struct GradPlan {
+    int tiles_i, tiles_j, splits, t128;
+    int64_t rows_per_split;
+    size_t slab_elems;
+};
+
+// Split counts of a whole batch: about 1024 workgroups in total, shared among the jobs in proportion to
+// their row-block counts (depends on the shapes only, never on the device: fixed summation order).
+static void grad_plans(const phc_phm_grad_job *jobs, int num, GradPlan *plans) {
+    int64_t total = 0;
+    for (int k = 0; k < num; ++k) {
+        const int in = jobs[k].n * jobs[k].kin, out = jobs[k].n * jobs[k].kout;
+        plans[k].t128 = dh_use_128(jobs[k].N, in, out) ? 1 : 0;
+        const int T = plans[k].t128 ? DH_T2 : DH_T;
+        plans[k].tiles_i = (in + T - 1) / T;
+        plans[k].tiles_j = (out + T - 1) / T;
+        plans[k].slab_elems = (size_t)in * out + out;
+        total += (int64_t)plans[k].tiles_i * plans[k].tiles_j * ((jobs[k].N + DH_RB - 1) / DH_RB);
+    }
+    const int64_t target = 1024;
+    for (int k = 0; k < num; ++k) {
+        const int64_t max_splits = (jobs[k].N + DH_RB - 1) / DH_RB;
+        int64_t splits = total > target ? (max_splits * target + total - 1) / total : max_splits;
+        if (splits < 1) splits = 1;
+        if (splits > max_splits && max_splits > 0) splits = max_splits;
+        int64_t rows = (jobs[k].N + splits - 1) / splits;
+        rows = (rows + DH_RB - 1) / DH_RB * DH_RB;
+        if (rows < DH_RB) rows = DH_RB;
+        plans[k].rows_per_split = rows;
+        plans[k].splits = (int)((jobs[k].N + rows - 1) / rows);
+        if (plans[k].splits < 1) plans[k].splits = 1;
+    }
+}
+
+int check_grad_jobs(const char *who, const phc_phm_grad_job *jobs, int num_jobs) {
+    PHC_REQUIRE(num_jobs >= 0 && (num_jobs == 0 || jobs), PHC_ERR_INVALID_ARG, "%s: bad job table", who);
+    for (int k = 0; k < num_jobs; ++k) {
+        int rc = check_phm_dims(who, jobs[k].N, jobs[k].n, jobs[k].kin, jobs[k].kout);
+        if (rc) return rc;
+        PHC_REQUIRE(jobs[k].N > 0, PHC_ERR_INVALID_ARG, "%s: job %d has no rows (its gradients are zero: do not submit it)", who, k);
+    }
+    return PHC_OK;
+}
+
+size_t grad_chunk_ws_floats(const phc_phm_grad_job *jobs, int num_jobs) {
+    GradPlan plans[GRAD_JOBS_PER_LAUNCH];
+    grad_plans(jobs, num_jobs, plans);
+    size_t off = 0;
+    for (int k = 0; k < num_jobs; ++k) off += (plans[k].slab_elems * ((size_t)plans[k].splits + 1) + 3) / 4 * 4;   // 16-byte segments
+    return off;
+}
+
+int prepare_grad_launch(const char *who, const phc_phm_grad_job *jobs, int cn, float *ws_base, GradLaunch *out) {
+    PHC_REQUIRE(cn >= 1 && cn <= GRAD_JOBS_PER_LAUNCH, PHC_ERR_INVALID_ARG, "%s: %d jobs in one launch (1..%d)", who, cn,
+                GRAD_JOBS_PER_LAUNCH);
+    GradPlan plans[GRAD_JOBS_PER_LAUNCH];
+    grad_plans(jobs, cn, plans);
+    GradBatch &b = out->batch;
+    b.num = cn;
+    unsigned nb_partial = 0, nb_partial128 = 0, nb_reduce = 0, nb_contract = 0;
+    size_t off = 0;
+    for (int k = 0; k < cn; ++k) {
+        const phc_phm_grad_job &jb = jobs[k];
+        PHC_REQUIRE(jb.x && jb.dy && jb.A && jb.W && (jb.dW || jb.dA || jb.db), PHC_ERR_INVALID_ARG, "%s: job %d: null pointer", who, k);
+        PHC_REQUIRE(!jb.xf_stat || (jb.xf_act >= PHC_ACT_IDENTITY && jb.xf_act <= PHC_ACT_SELU), PHC_ERR_INVALID_ARG,
+                    "%s: job %d: unknown activation %d", who, k, jb.xf_act);
+        GradJobDev &d = b.j[k];
+        d.x = jb.x; d.dy = jb.dy; d.A = jb.A; d.W = jb.W;
+        d.dW = jb.dW; d.dA = jb.dA; d.db = jb.db;
+        d.N = jb.N; d.n = jb.n; d.kin = jb.kin; d.kout = jb.kout;
+        d.in = jb.n * jb.kin; d.out = jb.n * jb.kout;
+        d.tiles_j = plans[k].tiles_j;
+        d.tiles = plans[k].tiles_i * plans[k].tiles_j;
+        d.splits = plans[k].splits;
+        d.t128 = plans[k].t128;
+        d.dw_transposed = jb.flags & 1;
+        d.xf_stat = jb.xf_stat;
+        d.xf_n_valid = jb.xf_n_valid_dev;
+        d.xf_act = jb.xf_act;
+        d.rows_per_split = plans[k].rows_per_split;
+        d.vec4 = (d.in % 4 == 0) && (d.out % 4 == 0) && ((reinterpret_cast<uintptr_t>(jb.x) & 15) == 0) &&
+                 ((reinterpret_cast<uintptr_t>(jb.dy) & 15) == 0);
+        d.slabs = ws_base + off;
+        d.dH = d.slabs + plans[k].slab_elems * (size_t)plans[k].splits;
+        off += (plans[k].slab_elems * ((size_t)plans[k].splits + 1) + 3) / 4 * 4;
+        d.dA_blocks = jb.n * jb.n * jb.n;
+        d.blk0_partial = d.t128 ? nb_partial128 : nb_partial;
+        d.blk0_reduce = nb_reduce;
+        d.blk0_contract = nb_contract;
+        (d.t128 ? nb_partial128 : nb_partial) += (unsigned)d.tiles * (unsigned)d.splits;
+        nb_reduce += (unsigned)((plans[k].slab_elems + 63) / 64);
+        nb_contract += (unsigned)(d.dA_blocks + (jb.n * jb.kin * jb.kout + 255) / 256);
+    }
+    out->nb_partial = nb_partial;
+    out->nb_partial128 = nb_partial128;
+    out->nb_reduce = nb_reduce;
+    out->nb_contract = nb_contract;
+    return PHC_OK;
+}
+
+// the 128 x 128 partial launch of a prepared batch (if it has such jobs), then reduce and contract; the 64 x 64 partial
+// launch is the caller's (phc_phm_param_grads launches it alone, phc_step_tail side by side with the table gradients)
+int launch_grad_rest(const char *who, const GradLaunch &gl, bool partial64_too, hipStream_t s) {
+    int rc;
+    for (int shape = partial64_too ? 0 : 1; shape < 2; ++shape) {
+        const unsigned nb = shape ? gl.nb_partial128 : gl.nb_partial;
+        if (nb == 0) continue;
+        GradBatch bs = gl.batch;                             // jobs of the other tile shape are masked out
+        for (int k = 0; k < bs.num; ++k)
+            if (bs.j[k].t128 != shape) bs.j[k].blk0_partial = 0xffffffffu;
+        ProfScope prof(K_PHM_DH_PARTIAL, s);
+        if (shape)
+            PHC_LAUNCH(phm_grads_partial_kernel<1>, dim3(nb), dim3(256), 0, s, bs);
+        else
+            PHC_LAUNCH(phm_grads_partial_kernel<0>, dim3(nb), dim3(256), 0, s, bs);
+        rc = check_launch(who);
+        if (rc) return rc;
+    }
+    {
+        ProfScope prof(K_PHM_DH_REDUCE, s);
+        PHC_LAUNCH(phm_grads_reduce_kernel, dim3(gl.nb_reduce), dim3(256), 0, s, gl.batch);
+        rc = check_launch(who);
+        if (rc) return rc;
+    }
+    ProfScope prof(K_PHM_CONTRACT, s);
+    PHC_LAUNCH(phm_grads_contract_kernel, dim3(gl.nb_contract), dim3(256), 0, s, gl.batch);
+    return check_launch(who);
 }
 
 }  // namespace phc
@@ -1557,144 +1395,31 @@ int phc_gemm_prebuilt_bwsums(const float *dy, const float *M, int64_t N, int K, 
 }
 
 // ---- batched parameter gradients ------------------------------------------------------------
-struct GradPlan {
-    int tiles_i, tiles_j, splits, t128;
-    int64_t rows_per_split;
-    size_t slab_elems;
-};
-
-// Split counts of a whole batch: about 1024 workgroups in total, shared among the jobs in proportion to
-// their row-block counts (depends on the shapes only, never on the device: fixed summation order).
-static void grad_plans(const phc_phm_grad_job *jobs, int num, GradPlan *plans) {
-    int64_t total = 0;
-    for (int k = 0; k < num; ++k) {
-        const int in = jobs[k].n * jobs[k].kin, out = jobs[k].n * jobs[k].kout;
-        plans[k].t128 = dh_use_128(jobs[k].N, in, out) ? 1 : 0;
-        const int T = plans[k].t128 ? DH_T2 : DH_T;
-        plans[k].tiles_i = (in + T - 1) / T;
-        plans[k].tiles_j = (out + T - 1) / T;
-        plans[k].slab_elems = (size_t)in * out + out;
-        total += (int64_t)plans[k].tiles_i * plans[k].tiles_j * ((jobs[k].N + DH_RB - 1) / DH_RB);
-    }
-    const int64_t target = 1024;
-    for (int k = 0; k < num; ++k) {
-        const int64_t max_splits = (jobs[k].N + DH_RB - 1) / DH_RB;
-        int64_t splits = total > target ? (max_splits * target + total - 1) / total : max_splits;
-        if (splits < 1) splits = 1;
-        if (splits > max_splits && max_splits > 0) splits = max_splits;
-        int64_t rows = (jobs[k].N + splits - 1) / splits;
-        rows = (rows + DH_RB - 1) / DH_RB * DH_RB;
-        if (rows < DH_RB) rows = DH_RB;
-        plans[k].rows_per_split = rows;
-        plans[k].splits = (int)((jobs[k].N + rows - 1) / rows);
-        if (plans[k].splits < 1) plans[k].splits = 1;
-    }
-}
-
-static int check_grad_jobs(const char *who, const phc_phm_grad_job *jobs, int num_jobs) {
-    PHC_REQUIRE(num_jobs >= 0 && (num_jobs == 0 || jobs), PHC_ERR_INVALID_ARG, "%s: bad job table", who);
-    for (int k = 0; k < num_jobs; ++k) {
-        int rc = check_phm_dims(who, jobs[k].N, jobs[k].n, jobs[k].kin, jobs[k].kout);
-        if (rc) return rc;
-        PHC_REQUIRE(jobs[k].N > 0, PHC_ERR_INVALID_ARG, "%s: job %d has no rows (its gradients are zero: do not submit it)", who, k);
-    }
-    return PHC_OK;
-}
-
-static size_t grad_ws_floats(const phc_phm_grad_job *jobs, int num_jobs, size_t *offsets) {
-    size_t off = 0;
-    for (int c0 = 0; c0 < num_jobs; c0 += GRAD_JOBS_PER_LAUNCH) {
-        const int cn = num_jobs - c0 < GRAD_JOBS_PER_LAUNCH ? num_jobs - c0 : GRAD_JOBS_PER_LAUNCH;
-        GradPlan plans[GRAD_JOBS_PER_LAUNCH];
-        grad_plans(jobs + c0, cn, plans);
-        for (int k = 0; k < cn; ++k) {
-            if (offsets) offsets[c0 + k] = off;
-            off += (plans[k].slab_elems * ((size_t)plans[k].splits + 1) + 3) / 4 * 4;     // 16-byte aligned segments
-        }
-    }
-    return off;
-}
-
 size_t phc_phm_param_grads_ws_bytes(const phc_phm_grad_job *jobs, int num_jobs) {
     if (check_grad_jobs("phc_phm_param_grads_ws_bytes", jobs, num_jobs)) return 0;
-    return sizeof(float) * grad_ws_floats(jobs, num_jobs, nullptr);
+    size_t total = 0;
+    for (int c0 = 0; c0 < num_jobs; c0 += GRAD_JOBS_PER_LAUNCH)
+        total += grad_chunk_ws_floats(jobs + c0, num_jobs - c0 < GRAD_JOBS_PER_LAUNCH ? num_jobs - c0 : GRAD_JOBS_PER_LAUNCH);
+    return sizeof(float) * total;
 }
 
 int phc_phm_param_grads(const phc_phm_grad_job *jobs, int num_jobs, void *ws, size_t ws_bytes, void *stream) {
     int rc = check_grad_jobs("phc_phm_param_grads", jobs, num_jobs);
     if (rc) return rc;
     if (num_jobs == 0) return PHC_OK;
-    std::vector<size_t> offsets(num_jobs);
-    const size_t need = sizeof(float) * grad_ws_floats(jobs, num_jobs, offsets.data());
+    const size_t need = phc_phm_param_grads_ws_bytes(jobs, num_jobs);
     PHC_REQUIRE(ws && ws_bytes >= need, PHC_ERR_WORKSPACE, "phc_phm_param_grads: workspace %zu B < required %zu B", ws_bytes, need);
     PHC_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 15) == 0, PHC_ERR_WORKSPACE, "phc_phm_param_grads: workspace not 16-byte aligned");
     hipStream_t s = (hipStream_t)stream;
     float *base = static_cast<float *>(ws);
     for (int c0 = 0; c0 < num_jobs; c0 += GRAD_JOBS_PER_LAUNCH) {
         const int cn = num_jobs - c0 < GRAD_JOBS_PER_LAUNCH ? num_jobs - c0 : GRAD_JOBS_PER_LAUNCH;
-        GradPlan plans[GRAD_JOBS_PER_LAUNCH];
-        grad_plans(jobs + c0, cn, plans);
-        GradBatch b;
-        b.num = cn;
-        unsigned nb_partial = 0, nb_partial128 = 0, nb_reduce = 0, nb_contract = 0;
-        for (int k = 0; k < cn; ++k) {
-            const phc_phm_grad_job &jb = jobs[c0 + k];
-            PHC_REQUIRE(jb.x && jb.dy && jb.A && jb.W && (jb.dW || jb.dA || jb.db), PHC_ERR_INVALID_ARG,
-                        "phc_phm_param_grads: job %d: null pointer", c0 + k);
-            GradJobDev &d = b.j[k];
-            d.x = jb.x; d.dy = jb.dy; d.A = jb.A; d.W = jb.W;
-            d.dW = jb.dW; d.dA = jb.dA; d.db = jb.db;
-            d.N = jb.N; d.n = jb.n; d.kin = jb.kin; d.kout = jb.kout;
-            d.in = jb.n * jb.kin; d.out = jb.n * jb.kout;
-            d.tiles_j = plans[k].tiles_j;
-            d.tiles = plans[k].tiles_i * plans[k].tiles_j;
-            d.splits = plans[k].splits;
-            d.t128 = plans[k].t128;
-            d.dw_transposed = jb.flags & 1;
-            d.xf_stat = jb.xf_stat;
-            d.xf_n_valid = jb.xf_n_valid_dev;
-            d.xf_act = jb.xf_act;
-            PHC_REQUIRE(!jb.xf_stat || (jb.xf_act >= PHC_ACT_IDENTITY && jb.xf_act <= PHC_ACT_SELU), PHC_ERR_INVALID_ARG,
-                        "phc_phm_param_grads: job %d: unknown activation %d", c0 + k, jb.xf_act);
-            d.rows_per_split = plans[k].rows_per_split;
-            d.vec4 = (d.in % 4 == 0) && (d.out % 4 == 0) && ((reinterpret_cast<uintptr_t>(jb.x) & 15) == 0) &&
-                     ((reinterpret_cast<uintptr_t>(jb.dy) & 15) == 0);
-            d.slabs = base + offsets[c0 + k];
-            d.dH = d.slabs + plans[k].slab_elems * (size_t)plans[k].splits;
-            d.dA_blocks = jb.n * jb.n * jb.n;
-            d.blk0_partial = d.t128 ? nb_partial128 : nb_partial;
-            d.blk0_reduce = nb_reduce;
-            d.blk0_contract = nb_contract;
-            (d.t128 ? nb_partial128 : nb_partial) += (unsigned)d.tiles * (unsigned)d.splits;
-            nb_reduce += (unsigned)((plans[k].slab_elems + 63) / 64);
-            nb_contract += (unsigned)(d.dA_blocks + (jb.n * jb.kin * jb.kout + 255) / 256);
-        }
-        for (int shape = 0; shape < 2; ++shape) {
-            const unsigned nb = shape ? nb_partial128 : nb_partial;
-            if (nb == 0) continue;
-            GradBatch bs = b;                                // jobs of the other tile shape are masked out
-            for (int k = 0; k < cn; ++k)
-                if (bs.j[k].t128 != shape) bs.j[k].blk0_partial = 0xffffffffu;
-            ProfScope prof(K_PHM_DH_PARTIAL, s);
-            if (shape)
-                PHC_LAUNCH(phm_grads_partial_kernel<1>, dim3(nb), dim3(256), 0, s, bs);
-            else
-                PHC_LAUNCH(phm_grads_partial_kernel<0>, dim3(nb), dim3(256), 0, s, bs);
-            rc = check_launch("phm_grads_partial");
-            if (rc) return rc;
-        }
-        {
-            ProfScope prof(K_PHM_DH_REDUCE, s);
-            PHC_LAUNCH(phm_grads_reduce_kernel, dim3(nb_reduce), dim3(256), 0, s, b);
-            rc = check_launch("phm_grads_reduce");
-            if (rc) return rc;
-        }
-        {
-            ProfScope prof(K_PHM_CONTRACT, s);
-            PHC_LAUNCH(phm_grads_contract_kernel, dim3(nb_contract), dim3(256), 0, s, b);
-            rc = check_launch("phm_grads_contract");
-            if (rc) return rc;
-        }
+        GradLaunch gl;
+        rc = prepare_grad_launch("phc_phm_param_grads", jobs + c0, cn, base, &gl);
+        if (rc) return rc;
+        base += grad_chunk_ws_floats(jobs + c0, cn);
+        rc = launch_grad_rest("phc_phm_param_grads", gl, true, s);
+        if (rc) return rc;
     }
     return PHC_OK;
 }
