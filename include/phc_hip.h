@@ -378,6 +378,22 @@ int phc_bn_bwd_from_partials(const float *dy, const float *x, const float *save_
                              int num_partials, const int32_t *n_valid_dev, int64_t N, int h, int act, float *dx,
                              float *dwb_flat, void *ws, size_t ws_bytes, void *stream);
 
+/* The step's tail in one pass: every parameter gradient of a model — PHM / dense layers (jobs, as for
+ * phc_phm_param_grads; <= 16, matrices below 256 columns), the bond tables of all message-passing layers
+ * (tjobs, as for phc_table_grads_batched; <= 8) and the atom-encoder tables (atom_*, as phc_encode_bwd; N_atoms
+ * = 0: none) — in three launches.  The first runs the latency-bound table-slab workgroups and the MFMA-bound
+ * dH-slab workgroups SIDE BY SIDE (the former dispatched first, into the slots the latter leave free), the
+ * second all slab reductions, the third the PHM contraction.  Results are identical to the separate entry
+ * points (same workgroup bodies, same fixed summation order).  PHC_ERR_UNSUPPORTED when a job needs the
+ * 128 x 128 tile path: use the separate entry points then. */
+size_t phc_step_tail_ws_bytes(const phc_phm_grad_job *jobs, int num_jobs, int num_tjobs, int64_t E, int F_b,
+                              const int32_t *vocab_b, int64_t N_atoms, int F_a, const int32_t *vocab_a, int n, int k);
+int phc_step_tail(const phc_phm_grad_job *jobs, int num_jobs, const phc_table_grad_job *tjobs, int num_tjobs,
+                  const int64_t *bond_i64, const int32_t *vocab_b, const int64_t *edge_src_i64,
+                  const int64_t *edge_dst_i64, int64_t E, int F_b, int act, const float *atom_dout,
+                  const int64_t *atom_idx_i64, int64_t N_atoms, int F_a, const int32_t *vocab_a,
+                  float *atom_dtables_flat, int n, int k, void *ws, size_t ws_bytes, void *stream);
+
 /* ------------------------------------------------------------------------- *
  * Read-out
  * ------------------------------------------------------------------------- */

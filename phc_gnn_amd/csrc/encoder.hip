@@ -15,6 +15,8 @@
 //                            into ONE flat gradient buffer laid out [c][f][V_f][k]
 //                            (the per-table grads are views).  No atomics, reproducible.
 #include "phc_common.h"
+#include <string.h>
+#include "phm_grad_device.h"
 
 namespace phc {
 
@@ -284,7 +286,6 @@ __global__ __launch_bounds__(ENC_THREADS) void aggregate_enc_dx_kernel(
 // embedding_dense_backward — a device sort — per table).
 //   MODE 0: item = node i,  rows off_f + idx[i,f],     g = dout[i]
 //   MODE 1: item = edge e,  rows off_f + bond[e,f],    g = phi'(x[src_e] + enc_e) * dout[dst_e]
-using f32x16 = __attribute__((ext_vector_type(16))) float;
 constexpr int TG_T = 64;          // tile edge (table rows x feature columns)
 constexpr int TG_IB = 64;         // items per step
 
@@ -292,9 +293,10 @@ template <int MODE, int ACT>
 __device__ __forceinline__ void table_grad_body(
     const float *__restrict__ dout, const long long *__restrict__ idx, const EncMeta &m, long long n_items, long long items_per_split,
     int h, int tiles_j, const long long *__restrict__ src, const long long *__restrict__ dst, const float *__restrict__ x,
-    const float *const *__restrict__ tables, int n, int k, int vec4, float *__restrict__ slabs, int tile, long long split) {
-    __shared__ __attribute__((aligned(16))) float oh[TG_IB * TG_T];     // one-hot tile  [item][table row]
-    __shared__ __attribute__((aligned(16))) float gs[TG_IB * TG_T];     // gradient tile [item][column]
+    const float *const *__restrict__ tables, int n, int k, int vec4, float *__restrict__ slabs, int tile, long long split,
+    float *__restrict__ smem) {
+    float *oh = smem;                                                   // one-hot tile  [item][table row]
+    float *gs = smem + TG_IB * TG_T;                                    // gradient tile [item][column]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wi = wave >> 1, wj = wave & 1;
     const int r = lane & 31, hh = lane >> 5;
@@ -385,8 +387,9 @@ __global__ __launch_bounds__(ENC_THREADS) void table_grad_mfma_kernel(
     const float *__restrict__ dout, const long long *__restrict__ idx, EncMeta m, long long n_items, long long items_per_split,
     int h, int tiles_j, const long long *__restrict__ src, const long long *__restrict__ dst, const float *__restrict__ x,
     const float *const *__restrict__ tables, int n, int k, int vec4, float *__restrict__ slabs) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * TG_IB * TG_T];
     table_grad_body<MODE, ACT>(dout, idx, m, n_items, items_per_split, h, tiles_j, src, dst, x, tables, n, k, vec4, slabs, blockIdx.x,
-                               blockIdx.y);
+                               blockIdx.y, smem);
 }
 
 // Several layers' bond-table gradients in one launch (phc_table_grads_batched): the layers share the edge list and
@@ -406,8 +409,9 @@ __global__ __launch_bounds__(ENC_THREADS) void table_grad_mfma_batched_kernel(
     TgBatch b, const long long *__restrict__ idx, EncMeta m, long long n_items, long long items_per_split, int h, int tiles_j,
     const long long *__restrict__ src, const long long *__restrict__ dst, int n, int k, int vec4) {
     const TgJobDev &jb = b.j[blockIdx.z];
+    __shared__ __attribute__((aligned(16))) float smem[2 * TG_IB * TG_T];
     table_grad_body<1, ACT>(jb.dout, idx, m, n_items, items_per_split, h, tiles_j, src, dst, jb.x, jb.tables, n, k, vec4, jb.slabs,
-                            blockIdx.x, blockIdx.y);
+                            blockIdx.x, blockIdx.y, smem);
 }
 
 __device__ __forceinline__ void table_grad_reduce_body(const float *__restrict__ slabs, int num_slabs, int R, int n, int k,
@@ -443,6 +447,82 @@ __device__ __forceinline__ void table_grad_reduce_body(const float *__restrict__
         const int c = j / k, kap = j - c * k;
         flat[((size_t)c * R + r) * k + kap] = ((part[0][el] + part[1][el]) + part[2][el]) + part[3][el];
     }
+}
+
+// ---- the step's tail in one pass ----------------------------------------------------------------------------
+// All parameter gradients of a model are due only when the optimizer runs.  phc_step_tail launches their first
+// stages SIDE BY SIDE: workgroups [0, nb_atom) build atom-table slabs, [nb_atom, nb_atom + nb_bond) the bond-table
+// slabs of every message-passing layer, the rest the PHM dH = x^T.dy slabs of every linear layer.  The table workgroups
+// are latency-bound gathers, the dH workgroups MFMA/bandwidth-bound; dispatched first, the former run in the slots the
+// latter leave free instead of owning the chip for 50 us on their own.  Second launch: all slab reductions.
+struct TailTables {
+    // bond tables (MODE 1): jobs share idx / src / dst
+    TgBatch bond;
+    EncMeta mb;
+    const long long *bond_idx, *src, *dst;
+    long long E, ips_b;
+    int tiles_j_b, tiles_b, slabs_b, jobs_b, vec4_b;
+    // atom tables (MODE 0): one job
+    const float *atom_dout;
+    const long long *atom_idx;
+    float *atom_slabs, *atom_flat;
+    EncMeta ma;
+    long long N_a, ips_a;
+    int tiles_j_a, tiles_a, slabs_a, vec4_a;
+    int n, k, h;
+    unsigned nb_atom, nb_bond;                               // workgroup counts of the first launch
+    unsigned nr_phm, nr_bond, nr_atom;                       // ... of the reduce launch
+};
+
+template <int ACT>
+__global__ __launch_bounds__(256) void tail_partial_kernel(GradBatch gb, TailTables t) {
+    __shared__ __attribute__((aligned(16))) float smem[2 * TG_IB * TG_T];
+    static_assert(2 * TG_IB * TG_T == 2 * DH_RB * DH_STRIDE, "table and dH workgroups stage the same 32 KB");
+    unsigned bx = blockIdx.x;
+    if (bx < t.nb_atom) {
+        const int tile = bx % t.tiles_a;
+        table_grad_body<0, PHC_ACT_IDENTITY>(t.atom_dout, t.atom_idx, t.ma, t.N_a, t.ips_a, t.h, t.tiles_j_a, nullptr, nullptr, nullptr,
+                                              nullptr, t.n, t.k, t.vec4_a, t.atom_slabs, tile, bx / t.tiles_a, smem);
+        return;
+    }
+    bx -= t.nb_atom;
+    if (bx < t.nb_bond) {
+        const unsigned per_job = (unsigned)t.tiles_b * (unsigned)t.slabs_b;
+        const int job = bx / per_job;
+        const unsigned local = bx - job * per_job;
+        const TgJobDev &jb = t.bond.j[job];
+        table_grad_body<1, ACT>(jb.dout, t.bond_idx, t.mb, t.E, t.ips_b, t.h, t.tiles_j_b, t.src, t.dst, jb.x, jb.tables, t.n, t.k,
+                                t.vec4_b, jb.slabs, local % t.tiles_b, local / t.tiles_b, smem);
+        return;
+    }
+    bx -= t.nb_bond;
+    int k = 0;
+    for (int q = 0; q < gb.num; ++q)
+        if (bx >= gb.j[q].blk0_partial) k = q;
+    const GradJobDev &j = gb.j[k];
+    const unsigned local = bx - j.blk0_partial;
+    const long long xf_count = j.xf_stat ? (j.xf_n_valid ? min((long long)*j.xf_n_valid, j.N) : j.N) : 0;
+    dH_partial_body(j.x, j.dy, j.slabs, j.N, j.in, j.out, j.tiles_j, j.rows_per_split, j.vec4, local % j.tiles, local / j.tiles, smem,
+                    j.xf_stat, j.xf_act, xf_count);
+}
+
+__global__ __launch_bounds__(256) void tail_reduce_kernel(GradBatch gb, TailTables t) {
+    unsigned bx = blockIdx.x;
+    if (bx < t.nr_phm) {
+        const int k = grad_job_of_block<1>(gb, bx);
+        const GradJobDev &j = gb.j[k];
+        dH_reduce_body(j.slabs, j.dH, (size_t)j.in * j.out + j.out, j.splits, bx - j.blk0_reduce);
+        return;
+    }
+    bx -= t.nr_phm;
+    if (bx < t.nr_bond) {
+        const unsigned per_job = (unsigned)((t.mb.R * t.h + 63) / 64);
+        const int job = bx / per_job;
+        table_grad_reduce_body(t.bond.j[job].slabs, t.slabs_b, t.mb.R, t.n, t.k, t.bond.j[job].flat, (int)(bx - job * per_job));
+        return;
+    }
+    bx -= t.nr_bond;
+    table_grad_reduce_body(t.atom_slabs, t.slabs_a, t.ma.R, t.n, t.k, t.atom_flat, (int)bx);
 }
 
 // ---- host helpers ---------------------------------------------------------------------------------
@@ -840,6 +920,123 @@ int phc_table_grads_batched(const phc_table_grad_job *jobs, int num_jobs, const 
         if (rc) return rc;
     }
     return PHC_OK;
+}
+
+static int tail_plan(const phc_phm_grad_job *jobs, int num_jobs, int num_tjobs, int64_t E, int F_b, const int32_t *vocab_b, int64_t N_atoms,
+                     int F_a, const int32_t *vocab_a, int n, int k, EncMeta *mb, EncMeta *ma, TgPlan *pb, TgPlan *pa, size_t *phm_floats) {
+    PHC_REQUIRE(num_jobs >= 1 && num_jobs <= GRAD_JOBS_PER_LAUNCH && num_tjobs >= 0 && num_tjobs <= TG_JOBS_PER_LAUNCH && n >= 1 && k >= 1,
+                PHC_ERR_UNSUPPORTED, "phc_step_tail: %d PHM jobs (1..%d), %d table jobs (0..%d)", num_jobs, GRAD_JOBS_PER_LAUNCH, num_tjobs,
+                TG_JOBS_PER_LAUNCH);
+    int rc = check_grad_jobs("phc_step_tail", jobs, num_jobs);
+    if (rc) return rc;
+    const int h = n * k;
+    *pb = TgPlan();
+    *pa = TgPlan();
+    if (num_tjobs > 0) {
+        rc = make_meta("phc_step_tail", F_b, vocab_b, mb);
+        if (rc) return rc;
+        PHC_REQUIRE(E >= 1, PHC_ERR_INVALID_ARG, "phc_step_tail: table jobs without edges");
+        *pb = tg_plan(E, mb->R, h, num_tjobs);
+    }
+    if (N_atoms > 0) {
+        rc = make_meta("phc_step_tail", F_a, vocab_a, ma);
+        if (rc) return rc;
+        *pa = tg_plan(N_atoms, ma->R, h);
+    }
+    *phm_floats = grad_chunk_ws_floats(jobs, num_jobs);
+    return PHC_OK;
+}
+
+size_t phc_step_tail_ws_bytes(const phc_phm_grad_job *jobs, int num_jobs, int num_tjobs, int64_t E, int F_b, const int32_t *vocab_b,
+                              int64_t N_atoms, int F_a, const int32_t *vocab_a, int n, int k) {
+    EncMeta mb, ma;
+    TgPlan pb, pa;
+    size_t phm = 0;
+    if (tail_plan(jobs, num_jobs, num_tjobs, E, F_b, vocab_b, N_atoms, F_a, vocab_a, n, k, &mb, &ma, &pb, &pa, &phm)) return 0;
+    return sizeof(float) * (phm + (num_tjobs > 0 ? pb.slab_floats * (size_t)num_tjobs : 0) + (N_atoms > 0 ? pa.slab_floats : 0));
+}
+
+int phc_step_tail(const phc_phm_grad_job *jobs, int num_jobs, const phc_table_grad_job *tjobs, int num_tjobs, const int64_t *bond_i64,
+                  const int32_t *vocab_b, const int64_t *edge_src_i64, const int64_t *edge_dst_i64, int64_t E, int F_b, int act,
+                  const float *atom_dout, const int64_t *atom_idx_i64, int64_t N_atoms, int F_a, const int32_t *vocab_a,
+                  float *atom_dtables_flat, int n, int k, void *ws, size_t ws_bytes, void *stream) {
+    EncMeta mb, ma;
+    TgPlan pb, pa;
+    size_t phm_floats = 0;
+    int rc = tail_plan(jobs, num_jobs, num_tjobs, E, F_b, vocab_b, N_atoms, F_a, vocab_a, n, k, &mb, &ma, &pb, &pa, &phm_floats);
+    if (rc) return rc;
+    PHC_REQUIRE(act >= PHC_ACT_IDENTITY && act <= PHC_ACT_SELU, PHC_ERR_INVALID_ARG, "phc_step_tail: unknown activation %d", act);
+    PHC_REQUIRE(num_tjobs == 0 || (tjobs && bond_i64 && edge_src_i64 && edge_dst_i64), PHC_ERR_INVALID_ARG, "phc_step_tail: null pointer");
+    PHC_REQUIRE(N_atoms == 0 || (atom_dout && atom_idx_i64 && atom_dtables_flat), PHC_ERR_INVALID_ARG, "phc_step_tail: null atom pointer");
+    const size_t need = phc_step_tail_ws_bytes(jobs, num_jobs, num_tjobs, E, F_b, vocab_b, N_atoms, F_a, vocab_a, n, k);
+    PHC_REQUIRE(ws && ws_bytes >= need && (reinterpret_cast<uintptr_t>(ws) & 15) == 0, PHC_ERR_WORKSPACE,
+                "phc_step_tail: workspace %zu B < required %zu B (or not 16-byte aligned)", ws_bytes, need);
+    hipStream_t s = (hipStream_t)stream;
+    const int h = n * k;
+    float *wsf = static_cast<float *>(ws);
+    GradLaunch gl;
+    rc = prepare_grad_launch("phc_step_tail", jobs, num_jobs, wsf, &gl);
+    if (rc) return rc;
+    PHC_REQUIRE(gl.nb_partial128 == 0, PHC_ERR_UNSUPPORTED, "phc_step_tail: 128 x 128 tile jobs take phc_phm_param_grads");
+    wsf += phm_floats;
+    TailTables t;
+    memset(&t, 0, sizeof(t));
+    t.n = n; t.k = k; t.h = h;
+    if (num_tjobs > 0) {
+        t.mb = mb;
+        t.bond_idx = reinterpret_cast<const long long *>(bond_i64);
+        t.src = reinterpret_cast<const long long *>(edge_src_i64);
+        t.dst = reinterpret_cast<const long long *>(edge_dst_i64);
+        t.E = E; t.ips_b = pb.items_per_split; t.tiles_j_b = pb.tiles_j; t.tiles_b = pb.tiles_i * pb.tiles_j; t.slabs_b = pb.num_slabs;
+        t.jobs_b = num_tjobs;
+        int vec4 = (k % 4 == 0);
+        for (int q = 0; q < num_tjobs; ++q) {
+            PHC_REQUIRE(tjobs[q].dout && tjobs[q].tables && tjobs[q].dtables_flat && (act == PHC_ACT_IDENTITY || tjobs[q].x),
+                        PHC_ERR_INVALID_ARG, "phc_step_tail: table job %d: null pointer", q);
+            t.bond.j[q].dout = tjobs[q].dout; t.bond.j[q].x = tjobs[q].x; t.bond.j[q].tables = tjobs[q].tables;
+            t.bond.j[q].flat = tjobs[q].dtables_flat; t.bond.j[q].slabs = wsf;
+            wsf += pb.slab_floats;
+            vec4 = vec4 && al16(tjobs[q].dout) && (!tjobs[q].x || al16(tjobs[q].x));
+        }
+        t.vec4_b = vec4;
+        t.nb_bond = (unsigned)t.tiles_b * (unsigned)t.slabs_b * (unsigned)num_tjobs;
+        t.nr_bond = (unsigned)((mb.R * h + 63) / 64) * (unsigned)num_tjobs;
+    }
+    if (N_atoms > 0) {
+        t.ma = ma;
+        t.atom_dout = atom_dout;
+        t.atom_idx = reinterpret_cast<const long long *>(atom_idx_i64);
+        t.atom_slabs = wsf; t.atom_flat = atom_dtables_flat;
+        t.N_a = N_atoms; t.ips_a = pa.items_per_split; t.tiles_j_a = pa.tiles_j; t.tiles_a = pa.tiles_i * pa.tiles_j; t.slabs_a = pa.num_slabs;
+        t.vec4_a = (k % 4 == 0) && al16(atom_dout);
+        t.nb_atom = (unsigned)t.tiles_a * (unsigned)t.slabs_a;
+        t.nr_atom = (unsigned)((ma.R * h + 63) / 64);
+    }
+    t.nr_phm = gl.nb_reduce;
+    const unsigned nb1 = t.nb_atom + t.nb_bond + gl.nb_partial, nb2 = t.nr_phm + t.nr_bond + t.nr_atom;
+    {
+        ProfScope prof(K_PHM_DH_PARTIAL, s);
+#define PHC_TAIL_LAUNCH(ACTC) PHC_LAUNCH((tail_partial_kernel<ACTC>), dim3(nb1), dim3(256), 0, s, gl.batch, t)
+        switch (act) {
+            case PHC_ACT_IDENTITY: PHC_TAIL_LAUNCH(PHC_ACT_IDENTITY); break;
+            case PHC_ACT_RELU: PHC_TAIL_LAUNCH(PHC_ACT_RELU); break;
+            case PHC_ACT_LRELU: PHC_TAIL_LAUNCH(PHC_ACT_LRELU); break;
+            case PHC_ACT_ELU: PHC_TAIL_LAUNCH(PHC_ACT_ELU); break;
+            case PHC_ACT_SWISH: PHC_TAIL_LAUNCH(PHC_ACT_SWISH); break;
+            default: PHC_TAIL_LAUNCH(PHC_ACT_SELU); break;
+        }
+#undef PHC_TAIL_LAUNCH
+        rc = check_launch("step_tail(partial)");
+        if (rc) return rc;
+    }
+    {
+        ProfScope prof(K_PHM_DH_REDUCE, s);
+        PHC_LAUNCH(tail_reduce_kernel, dim3(nb2), dim3(256), 0, s, gl.batch, t);
+        rc = check_launch("step_tail(reduce)");
+        if (rc) return rc;
+    }
+    ProfScope prof(K_PHM_CONTRACT, s);
+    return launch_grad_contract("phc_step_tail", gl, s);
 }
 
 }  // extern "C"

@@ -308,6 +308,7 @@ struct GradLaunch {
 size_t grad_chunk_ws_floats(const phc_phm_grad_job *jobs, int num_jobs);
 int prepare_grad_launch(const char *who, const phc_phm_grad_job *jobs, int num_jobs, float *ws_base, GradLaunch *out);
 int launch_grad_rest(const char *who, const GradLaunch &gl, bool partial64_too, hipStream_t s);
+int launch_grad_contract(const char *who, const GradLaunch &gl, hipStream_t s);
 int check_grad_jobs(const char *who, const phc_phm_grad_job *jobs, int num_jobs);
 
 }  // namespace phc

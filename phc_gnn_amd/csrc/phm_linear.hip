@@ -1085,6 +1085,11 @@ int prepare_grad_launch(const char *who, const phc_phm_grad_job *jobs, int cn, f
     return PHC_OK;
 }
 
+int launch_grad_contract(const char *who, const GradLaunch &gl, hipStream_t s) {
+    PHC_LAUNCH(phm_grads_contract_kernel, dim3(gl.nb_contract), dim3(256), 0, s, gl.batch);
+    return check_launch(who);
+}
+
 // the 128 x 128 partial launch of a prepared batch (if it has such jobs), then reduce and contract; the 64 x 64 partial
 // launch is the caller's (phc_phm_param_grads launches it alone, phc_step_tail side by side with the table gradients)
 int launch_grad_rest(const char *who, const GradLaunch &gl, bool partial64_too, hipStream_t s) {

@@ -42,6 +42,7 @@ class _Deferred:
         self.active = False
         self.jobs = []
         self.table_jobs = []
+        self.atom_jobs = []
         self.lock = threading.Lock()       # the backward pass runs on autograd's device thread
 
 
@@ -56,20 +57,146 @@ def deferred_param_grads():
         yield
         return
     _DEFER.active = True
-    _DEFER.jobs, _DEFER.table_jobs = [], []
+    _DEFER.jobs, _DEFER.table_jobs, _DEFER.atom_jobs = [], [], []
     try:
         yield
     except BaseException:
         _DEFER.active = False
-        _DEFER.jobs, _DEFER.table_jobs = [], []
+        _DEFER.jobs, _DEFER.table_jobs, _DEFER.atom_jobs = [], [], []
         raise
     _DEFER.active = False
     jobs, _DEFER.jobs = _DEFER.jobs, []
     tjobs, _DEFER.table_jobs = _DEFER.table_jobs, []
+    ajobs, _DEFER.atom_jobs = _DEFER.atom_jobs, []
+    if STEP_TAIL_MERGED and _flush_step_tail(jobs, tjobs, ajobs):
+        return
     if tjobs:
         _flush_table_grads(tjobs)
+    for aj in ajobs:
+        _flush_atom_grads(aj)
     if jobs:
         _flush_param_grads(jobs)
+
+
+# all deferred gradients of a step (PHM / dense layers, bond tables, atom tables) in three launches (phc_step_tail)
+STEP_TAIL_MERGED = __import__("os").environ.get("PHC_STEP_TAIL_MERGED", "1") != "0"
+
+
+def _assign_grads(params, grads) -> None:
+    for prm, g in zip(params, grads):
+        if prm is None or g is None:
+            continue
+        if prm.grad is None:
+            prm.grad = g
+        else:
+            prm.grad.add_(g)
+
+
+def _flush_atom_grads(aj) -> None:
+    """Atom-encoder table gradients on their own (phc_encode_bwd)."""
+    lib = L.load()
+    ts, idx_, dout_ = aj["ts"], aj["idx"], aj["dout"]
+    dev = dout_.device
+    N = idx_.shape[0]
+    with torch.cuda.device(dev):
+        flat = torch.empty(ts.n * ts.R * ts.k, dtype=torch.float32, device=dev)
+        ws_bytes = lib.phc_encode_bwd_ws_bytes(N, ts.F, ts.vocab_c, ts.n, ts.k)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        L.check(lib.phc_encode_bwd(L.ptr(dout_), L.ptr(idx_), N, ts.F, ts.vocab_c, ts.n, ts.k, L.ptr(flat), L.ptr(ws), ws_bytes,
+                                   L.stream_ptr(dev)), "phc_encode_bwd")
+        if L.PROF_ON:
+            L.account("table_grad", 1.0 * N * ts.F * ts.n * ts.k, N * (8.0 * ts.F + 4.0 * ts.n * ts.k))
+    _assign_grads(aj["params"], ts.grad_views(flat))
+
+
+def _flush_step_tail(jobs, tjobs, ajobs) -> bool:
+    """Everything in one phc_step_tail call when the shapes allow it; False: the caller runs the separate flushes."""
+    if not jobs or len(jobs) > 16 or len(ajobs) > 1:
+        return False
+    dev = jobs[0]["x"].device
+    if any(jb["x"].device != dev for jb in jobs):
+        return False
+    for jb in jobs:                                         # 128 x 128 tile jobs go through phc_phm_param_grads
+        n, kin, kout = _job_dims(jb)
+        if jb["x"].shape[0] >= 65536 or (n * kin >= 256 and n * kout >= 256):
+            return False
+    keys = {tj["key"] for tj in tjobs}
+    if len(keys) > 1 or len(tjobs) > 8:
+        return False
+    ts_b = tjobs[0]["ts"] if tjobs else None
+    ts_a = ajobs[0]["ts"] if ajobs else None
+    if ts_b is None and ts_a is None:
+        return False
+    n, k = (ts_b.n, ts_b.k) if ts_b is not None else (ts_a.n, ts_a.k)
+    if (ts_a is not None and (ts_a.n, ts_a.k) != (n, k)) or (tjobs and tjobs[0]["bond"].device != dev) or \
+            (ajobs and ajobs[0]["dout"].device != dev):
+        return False
+    lib = L.load()
+    with torch.cuda.device(dev):
+        # PHM / dense jobs
+        total = 0
+        for jb in jobs:
+            jn, jkin, jkout = _job_dims(jb)
+            jb["off"] = total
+            total += jn * jkin * jkout + jn ** 3 + jn * jkout
+        flat = torch.empty(total, dtype=torch.float32, device=dev)
+        arr = (L.GradJob * len(jobs))()
+        outs = []
+        for i, jb in enumerate(jobs):
+            jn, jkin, jkout = _job_dims(jb)
+            o = jb["off"]
+            dW = flat[o:o + jn * jkin * jkout].view(jn, jkin, jkout)
+            dA = flat[o + jn * jkin * jkout:o + jn * jkin * jkout + jn ** 3].view(jn, jn, jn)
+            db = flat[o + jn * jkin * jkout + jn ** 3:o + jn * jkin * jkout + jn ** 3 + jn * jkout]
+            need_A, need_W, need_b = jb["need"]
+            if jb.get("dense"):
+                dW = dW.view(jkout, jkin)
+            xf = jb.get("xf")
+            arr[i] = L.GradJob(L.ptr(jb["x"]), L.ptr(jb["dy"]), L.ptr(jb["A"]), L.ptr(jb["W"]), L.ptr(dW) if need_W else None,
+                               L.ptr(dA) if need_A else None, L.ptr(db) if need_b else None, jb["x"].shape[0], jn, jkin, jkout,
+                               1 if jb.get("dense") else 0, L.ptr(xf[0]) if xf else None, L.ptr(xf[1]) if xf else None,
+                               xf[2] if xf else 0, 0)
+            outs.append((dA if need_A else None, dW if need_W else None, db if need_b else None))
+        # bond tables
+        tarr, tflat, per = None, None, 0
+        E = F_b = act = 0
+        bond = src = dst = vocab_b = None
+        if tjobs:
+            st = tjobs[0]["st"]
+            per = ts_b.n * ts_b.R * ts_b.k
+            tflat = torch.empty(len(tjobs) * per, dtype=torch.float32, device=dev)
+            tarr = (L.TableGradJob * len(tjobs))()
+            for i, tj in enumerate(tjobs):
+                tarr[i] = L.TableGradJob(L.ptr(tj["dout"]), L.ptr(tj["x"]), L.ptr(tj["ts"].ptrs), L.ptr(tflat) + 4 * i * per)
+            E, F_b, act = st.num_edges, ts_b.F, tjobs[0]["act"]
+            bond, src, dst, vocab_b = tjobs[0]["bond"], st._src, st._dst, ts_b.vocab_c
+        # atom tables
+        aflat = None
+        N_a = F_a = 0
+        a_dout = a_idx = vocab_a = None
+        if ajobs:
+            aj = ajobs[0]
+            aflat = torch.empty(ts_a.n * ts_a.R * ts_a.k, dtype=torch.float32, device=dev)
+            N_a, F_a, a_dout, a_idx, vocab_a = aj["idx"].shape[0], ts_a.F, aj["dout"], aj["idx"], ts_a.vocab_c
+        ws_bytes = lib.phc_step_tail_ws_bytes(arr, len(jobs), len(tjobs), E, F_b, vocab_b, N_a, F_a, vocab_a, n, k)
+        if ws_bytes == 0:
+            return False
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        L.check(lib.phc_step_tail(arr, len(jobs), tarr, len(tjobs), L.ptr(bond), vocab_b, L.ptr(src), L.ptr(dst), E, F_b, act,
+                                  L.ptr(a_dout), L.ptr(a_idx), N_a, F_a, vocab_a, L.ptr(aflat), n, k, L.ptr(ws), ws_bytes,
+                                  L.stream_ptr(dev)), "phc_step_tail")
+        if L.PROF_ON:
+            for jb in jobs:
+                jn, jkin, jkout = _job_dims(jb)
+                N = jb["x"].shape[0]
+                L.account("phm_dH_partial", 2.0 * N * jn * jkin * jn * jkout, 4.0 * N * jn * (jkin + jkout) + 4.0 * jn * jkin * jn * jkout)
+    for jb, grads in zip(jobs, outs):
+        _assign_grads(jb["params"], grads)
+    for i, tj in enumerate(tjobs):
+        _assign_grads(tj["params"], tj["ts"].grad_views(tflat[i * per:(i + 1) * per]))
+    if ajobs:
+        _assign_grads(ajobs[0]["params"], ts_a.grad_views(aflat))
+    return True
 
 
 def _flush_table_grads(jobs) -> None:
@@ -907,6 +1034,7 @@ class _EncodeFn(torch.autograd.Function):
             L.account("encode_fwd", 0.0, N * (8.0 * ts.F + 4.0 * ts.n * ts.k) + 4.0 * ts.R * ts.n * ts.k)
         ctx.ts = ts
         ctx.save_for_backward(idx_)
+        ctx.defer_tables = tuple(tables) if (_DEFER.active and N > 0 and all(t.is_leaf and t.grad_fn is None for t in tables)) else None
         return out
 
     @staticmethod
@@ -917,6 +1045,12 @@ class _EncodeFn(torch.autograd.Function):
         dout_ = L.f32c(dout)
         dev = dout_.device
         N = idx_.shape[0]
+        if ctx.defer_tables is not None and _DEFER.active and not torch.is_grad_enabled():
+            # the table gradients join the step's tail (phc_step_tail / phc_encode_bwd at the end of the backward pass)
+            params = [t if ng else None for t, ng in zip(ctx.defer_tables, ctx.needs_input_grad[2:])]
+            with _DEFER.lock:
+                _DEFER.atom_jobs.append(dict(dout=dout_, idx=idx_, ts=ts, params=params))
+            return (None, None, *([None] * (ts.n * ts.F)))
         flat = torch.empty(ts.n * ts.R * ts.k, dtype=torch.float32, device=dev)
         ws_bytes = lib.phc_encode_bwd_ws_bytes(N, ts.F, ts.vocab_c, ts.n, ts.k)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)

@@ -296,6 +296,23 @@ def test_graphed_step_with_the_engine_optimizer_tracks_the_torch_optimizer():
     assert worst < 5e-4, worst
 
 
+@pytest.mark.parametrize("wl", ["molhiv_b32", "molhiv_b512"])
+def test_step_tail_in_one_pass_equals_the_separate_gradient_launches(wl, monkeypatch):
+    """phc_step_tail (PHM, bond-table and atom-table gradients side by side in one launch + one reduce) must give
+    bit-identical parameter gradients to phc_phm_param_grads + phc_table_grads_batched + phc_encode_bwd."""
+    from phc_gnn_amd import harness, ops
+    d = harness.to_device(harness.make_batch(wl, seed=21), DEV)
+    grads = []
+    for merged in (True, False):
+        monkeypatch.setattr(ops, "STEP_TAIL_MERGED", merged)
+        m, _ = _fresh(wl, seed=5)
+        harness.train_step(m, d, None, harness.StepConfig(optimizer=False))
+        grads.append({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
+    assert grads[0].keys() == grads[1].keys() and len(grads[0]) > 100
+    for k in grads[0]:
+        assert torch.equal(grads[0][k], grads[1][k]), k
+
+
 # ---- multi-GPU paths exercised on ONE GPU with a single-rank RCCL group ---------------------------
 @pytest.fixture(scope="module")
 def rccl_single_rank():
