@@ -1153,29 +1153,6 @@ size_t phc_phm_linear_bwd_ws_bytes(int64_t N, int n, int kin, int kout) {
     return sizeof(float) * p.slab_elems * ((size_t)p.splits + 1);
 }
 
-// Side stream + fork/join events so that the parameter-gradient chain (dH partial -> reduce -> contract) runs
-// CONCURRENTLY with the dx GEMM: at molecule scale neither fills the chip (a few hundred small workgroups each),
-// and under stream capture the fork/join becomes two parallel branches of the hipGraph.
-struct BwdOverlap {
-    hipStream_t side = nullptr;
-    hipEvent_t fork = nullptr, join = nullptr;
-    bool ok = false;
-};
-static BwdOverlap &bwd_overlap() {
-    static BwdOverlap o;
-    static bool init = false;
-    if (!init) {
-        init = true;
-        const char *env = getenv("PHC_BWD_OVERLAP");
-        if (env && env[0] == '1') {   // opt-in: on ROCm 7.2 the forked hipGraph branch costs more than the overlap saves at molecule scale
-            o.ok = hipStreamCreateWithFlags(&o.side, hipStreamNonBlocking) == hipSuccess &&
-                   hipEventCreateWithFlags(&o.fork, hipEventDisableTiming) == hipSuccess &&
-                   hipEventCreateWithFlags(&o.join, hipEventDisableTiming) == hipSuccess;
-        }
-    }
-    return o;
-}
-
 int phc_phm_linear_bwd(const float *x, const float *A, const float *W, const float *dy, int64_t N, int n, int kin, int kout,
                        float *dx, float *dW, float *dA, float *db, void *ws, size_t ws_bytes, void *stream) {
     int rc = check_phm_dims("phc_phm_linear_bwd", N, n, kin, kout);
@@ -1190,17 +1167,7 @@ int phc_phm_linear_bwd(const float *x, const float *A, const float *W, const flo
                     need);
         PHC_REQUIRE((reinterpret_cast<uintptr_t>(ws) & 15) == 0, PHC_ERR_WORKSPACE, "phc_phm_linear_bwd: workspace not 16-byte aligned");
     }
-    // fork: the parameter-gradient chain goes to the side stream when there is a dx GEMM to overlap it with
-    BwdOverlap &ov = bwd_overlap();
-    const bool fork = ov.ok && dx && want_params && N > 0 && !g_prof_on;
     hipStream_t sp = s;
-    if (fork) {
-        if (hipEventRecord(ov.fork, s) != hipSuccess || hipStreamWaitEvent(ov.side, ov.fork, 0) != hipSuccess) {
-            set_last_error("phc_phm_linear_bwd: fork failed");
-            return PHC_ERR_LAUNCH;
-        }
-        sp = ov.side;
-    }
     if (want_params) {
         DhPlan p = dh_plan(N, in, out);
         float *slabs = static_cast<float *>(ws);
@@ -1240,12 +1207,6 @@ int phc_phm_linear_bwd(const float *x, const float *A, const float *W, const flo
     if (dx) {
         rc = launch_gemm<1>(dy, A, W, nullptr, nullptr, dx, N, out, in, n, kin, kout, s);
         if (rc) return rc;
-    }
-    if (fork) {                                          // join: everything after this call on `s` sees dW / dA / db
-        if (hipEventRecord(ov.join, ov.side) != hipSuccess || hipStreamWaitEvent(s, ov.join, 0) != hipSuccess) {
-            set_last_error("phc_phm_linear_bwd: join failed");
-            return PHC_ERR_LAUNCH;
-        }
     }
     return PHC_OK;
 }
