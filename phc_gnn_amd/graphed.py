@@ -171,7 +171,8 @@ class GraphedTrainStep:
         gc.collect()
         # NOTE: only a device-wide synchronize here.  Making the default stream wait on the capture stream
         # (Stream.wait_stream -> an event recorded on the just-captured stream) left the graph in a state where
-        # later eager allocations made its replays fault on ROCm 7.2 (scripts/debug_graph2.py reproduces it).
+        # later eager allocations made its replays fault on ROCm 7.x (the packet-capture ordering bug, DESIGN.md §5;
+        # scripts/debug_pipelined.py reproduces the family).
         torch.cuda.synchronize(dev)
 
     def _front(self):
