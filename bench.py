@@ -104,7 +104,8 @@ def cpu_baseline(args, workload, model, gb):
     x, ei, ea, batch = (torch.from_numpy(a) for a in (gb.x, gb.edge_index, gb.edge_attr, gb.batch))
     y = torch.from_numpy(gb.y)
     kw = dict(phm_dim=w["phm_dim"], num_layers=w["layers"], num_atom_feats=x.shape[1], num_bond_feats=ea.shape[1],
-              num_dn_hidden=len(w["d_units"]), mlp=True, sc_type=w["sc_type"], training=True, num_graphs=gb.num_graphs)
+              num_dn_hidden=len(w["d_units"]), mlp=w.get("mlp", True), sc_type=w["sc_type"], training=True,
+              num_graphs=gb.num_graphs, msg_aggr=w.get("msg_aggr", "sum"))
 
     def step():
         opt.zero_grad(set_to_none=True)
@@ -226,14 +227,19 @@ def main():
         dt = float(t.item())
 
     graphs = world * w["batch_size"] * args.steps
+    dataset_name = {"molhiv": "ogbg-molhiv", "molpcba": "ogbg-molpcba", "zinc": "ZINC"}[w["dataset"]]
+    config_note = {"molhiv_b32": " (BASELINE configs[0])", "molhiv_b512": " (BASELINE configs[1])",
+                   "zinc_b1024": " (BASELINE configs[2])",
+                   "molpcba_b1024": " (BASELINE configs[3], per-GPU share)"}.get(args.workload, " (configs[1] variant)")
     result = {
         "metric": "graphs/sec (fwd+bwd) PHC-GNN PHM-4 on ogbg-molhiv",
         "value": round(graphs / dt, 1), "unit": "graphs/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4), "higher_is_better": True,
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": f"{args.workload}: ogbg-molhiv-shaped synthetic molecules, PHM-{w['phm_dim']}, hidden "
-                               f"{w['hidden']}, {w['layers']} PHMGINEConv layers, sum aggregation, soft-attention "
-                               f"pooling, batch {w['batch_size']}/GPU (BASELINE configs[1])",
+        "config": {"workload": f"{args.workload}: {dataset_name}-shaped synthetic molecules, PHM-{w['phm_dim']}, hidden "
+                               f"{w['hidden']}, {w['layers']} {'PHMGINEConv' if w.get('mlp', True) else 'PHMConv'} "
+                               f"layers, {w.get('msg_aggr', 'sum')} aggregation, soft-attention pooling, batch "
+                               f"{w['batch_size']}/GPU{config_note}",
                    "nodes_per_batch": int(sum(b.num_nodes for b in host_batches) / len(host_batches)),
                    "edges_per_batch": int(sum(b.num_edges for b in host_batches) / len(host_batches)),
                    "step": "zero_grad+fwd+bce+bwd" + ("" if args.fwd_bwd_only else "+clip+adam")

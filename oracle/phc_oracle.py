@@ -157,10 +157,18 @@ def phm_mlp(x: Tensor, p: Dict[str, Tensor], prefix: str, phm_dim: int, act: str
     return phm_linear(x, p[prefix + "linear2.phm_rule"], p[prefix + "linear2.W"], p.get(prefix + "linear2.b"))
 
 
+def _propagate(x: Tensor, edge_index: Tensor, edge_attr: Tensor, msg_encoder: str, beta: Optional[Tensor]) -> Tensor:
+    """Sum aggregation, or (``beta`` given) the *Softmax convs' aggregate, messagepassing.py:207-214 / :293-300."""
+    if beta is None:
+        return propagate_add(x, edge_index, edge_attr, msg_encoder)
+    return softmax_aggregate(x, edge_index, edge_attr, beta, msg_encoder)
+
+
 def phm_conv(x: Tensor, edge_index: Tensor, edge_attr: Tensor, A: Tensor, W: Tensor, b: Optional[Tensor],
-             add_self_loops: bool = True, same_dim: bool = True, msg_encoder: str = "identity") -> Tensor:
-    """messagepassing.py:55-70 (PHMConv.forward)."""
-    agg = propagate_add(x, edge_index, edge_attr, msg_encoder)
+             add_self_loops: bool = True, same_dim: bool = True, msg_encoder: str = "identity",
+             beta: Optional[Tensor] = None) -> Tensor:
+    """messagepassing.py:55-70 (PHMConv.forward); with ``beta``: PHMConvSoftmax.forward (:216-231), same body."""
+    agg = _propagate(x, edge_index, edge_attr, msg_encoder, beta)
     if same_dim:
         y = phm_linear(agg, A, W, b)
         return y + x if add_self_loops else y
@@ -171,9 +179,11 @@ def phm_conv(x: Tensor, edge_index: Tensor, edge_attr: Tensor, A: Tensor, W: Ten
 
 def phm_gine_conv(x: Tensor, edge_index: Tensor, edge_attr: Tensor, p: Dict[str, Tensor], prefix: str,
                   phm_dim: int, act: str = "relu", norm: bool = True, training: bool = True,
-                  add_self_loops: bool = True, msg_encoder: str = "identity") -> Tensor:
-    """messagepassing.py:132-142 (PHMGINEConv.forward): PHMMLP(agg + x)."""
-    agg = propagate_add(x, edge_index, edge_attr, msg_encoder)
+                  add_self_loops: bool = True, msg_encoder: str = "identity",
+                  beta: Optional[Tensor] = None) -> Tensor:
+    """messagepassing.py:132-142 (PHMGINEConv.forward): PHMMLP(agg + x); with ``beta``: PHMGINEConvSoftmax.forward
+    (:302-311), same body."""
+    agg = _propagate(x, edge_index, edge_attr, msg_encoder, beta)
     if add_self_loops:
         agg = agg + x
     return phm_mlp(agg, p, prefix, phm_dim, act, norm, training)
@@ -254,9 +264,12 @@ def skip_connect_add_forward(p: Dict[str, Tensor], x_idx: Tensor, edge_index: Te
                              act: str = "relu", norm_mp: bool = True, norm_dn: bool = True,
                              pooling: str = "softattention", sc_type: str = "first",
                              msg_encoder: str = "identity", add_self_loops: bool = True,
-                             training: bool = True, num_graphs: Optional[int] = None) -> Tensor:
+                             training: bool = True, num_graphs: Optional[int] = None,
+                             msg_aggr: str = "sum") -> Tensor:
     """State-dict driven restatement of PHMSkipConnectAdd.forward for
-    msg_aggr='sum', dropout 0.  ``p`` uses the reference's parameter names."""
+    msg_aggr in {'sum', 'softmax'}, dropout 0.  ``p`` uses the reference's parameter names (the softmax convs keep
+    their inverse temperature at ``convs.<l>.transform.beta``, messagepassing.py:197,283)."""
+    assert msg_aggr in ("sum", "add", "softmax")
     n_nodes = x_idx.shape[0]
     atom = phm_encoder(x_idx, p, "atomencoder.", phm_dim, num_atom_feats).reshape(n_nodes, -1)   # :223-225
     x = atom
@@ -264,13 +277,14 @@ def skip_connect_add_forward(p: Dict[str, Tensor], x_idx: Tensor, edge_index: Te
         skip = atom if (l == 0 or sc_type == "first") else x                                     # :227-236
         ea = phm_encoder(edge_attr_idx, p, f"bondencoders.{l}.", phm_dim, num_bond_feats)
         ea = ea.reshape(ea.shape[0], -1)                                                          # :238-240
+        beta = p[f"convs.{l}.transform.beta"] if msg_aggr == "softmax" else None
         if mlp:
             y = phm_gine_conv(x, edge_index, ea, p, f"convs.{l}.transform.transform.", phm_dim, act,
-                              norm_mp, training, add_self_loops, msg_encoder)
+                              norm_mp, training, add_self_loops, msg_encoder, beta)
         else:
             q = f"convs.{l}.transform.transform."
             y = phm_conv(x, edge_index, ea, p[q + "phm_rule"], p[q + "W"], p.get(q + "b"),
-                         add_self_loops, True, msg_encoder)
+                         add_self_loops, True, msg_encoder, beta)
         if norm_mp:
             y = _norm_from_state(y, p, f"norms.{l}.", phm_dim, training)                         # :208-209
         x = activation(act, y) + skip                                                             # :211-215

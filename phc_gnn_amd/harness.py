@@ -23,6 +23,12 @@ WORKLOADS: Dict[str, dict] = {
     # configs[1]: the configuration the metric is quoted on
     "molhiv_b512": dict(dataset="molhiv", batch_size=512, phm_dim=4, hidden=128, layers=4, d_units=[128, 32],
                         target_dim=1, sc_type="first"),
+    # SURVEY §8(d) variants of configs[1]: PHMConv instead of PHMGINEConv (mlp=False), and the reference's default
+    # molhiv aggregation (train_hiv.py:115-117: softmax with a learnable inverse temperature)
+    "molhiv_b512_conv": dict(dataset="molhiv", batch_size=512, phm_dim=4, hidden=128, layers=4, d_units=[128, 32],
+                             target_dim=1, sc_type="first", mlp=False),
+    "molhiv_b512_softmax": dict(dataset="molhiv", batch_size=512, phm_dim=4, hidden=128, layers=4, d_units=[128, 32],
+                                target_dim=1, sc_type="first", msg_aggr="softmax"),
     # configs[2]
     "zinc_b1024": dict(dataset="zinc", batch_size=1024, phm_dim=8, hidden=256, layers=5, d_units=[256, 128],
                        target_dim=1, sc_type="last", regression=True),
@@ -34,11 +40,14 @@ WORKLOADS: Dict[str, dict] = {
 
 def model_kwargs(w: dict) -> dict:
     kw = dict(phm_dim=w["phm_dim"], learn_phm=True, atom_encoded_dim=w["hidden"], mp_layers=[w["hidden"]] * w["layers"],
-              dropout_mpnn=[0.0] * w["layers"], mlp=True, msg_aggr="sum", norm_mp="naive-batch-norm",
+              dropout_mpnn=[0.0] * w["layers"], mlp=w.get("mlp", True), msg_aggr=w.get("msg_aggr", "sum"),
+              norm_mp="naive-batch-norm",
               norm_dn="naive-batch-norm", pooling="softattention", activation="relu", real_trafo="linear",
               w_init="phm", c_init="standard", downstream_layers=list(w["d_units"]),
               dropout_dn=[0.0] * len(w["d_units"]), target_dim=w["target_dim"], sc_type=w["sc_type"],
               msg_encoder="identity")
+    if kw["msg_aggr"] == "softmax":
+        kw.update(initial_beta=1.0, learn_beta=True)          # train_hiv.py defaults
     if w["dataset"] == "zinc":
         kw.update(atom_input_dims=synth.ZINC_ATOM_DIMS, bond_input_dims=synth.ZINC_BOND_DIMS)
     return kw

@@ -23,7 +23,9 @@ if not os.path.isdir(REF):
     sys.exit("make_golden.py needs the reference checkout at /root/reference (build container only)")
 sys.path.insert(0, os.path.join(HERE, "_standins"))
 sys.path.insert(0, REF)
-sys.path.insert(1, REPO)          # for phc_gnn_amd.synth only; `phc` resolves to the reference
+# the repo root stays OFF sys.path: the reference's ``phc`` is a namespace package (no __init__.py), so the
+# build's own regular ``phc`` package would shadow it
+sys.path[:] = [p for p in sys.path if os.path.abspath(p or os.getcwd()) != REPO]
 
 import numpy as np  # noqa: E402
 import torch  # noqa: E402
@@ -43,7 +45,11 @@ from phc.hypercomplex.undirectional.models import PHMSkipConnectAdd  # noqa: E40
 from phc.quaternion.qr import RealP  # noqa: E402
 from torch_geometric.data import Batch  # noqa: E402
 
-from phc_gnn_amd import synth  # noqa: E402
+import importlib.util  # noqa: E402
+_spec = importlib.util.spec_from_file_location("phc_synth", os.path.join(REPO, "phc_gnn_amd", "synth.py"))
+synth = importlib.util.module_from_spec(_spec)          # the seeded molecule generator only (numpy, no package import)
+sys.modules["phc_synth"] = synth
+_spec.loader.exec_module(synth)
 
 torch.set_num_threads(4)
 
@@ -351,6 +357,17 @@ def g8_models():
     save("g8_model_zinc_small", **out)
 
 
+def g8_model_softmax():
+    """G8 with the reference's default / paper-best molhiv message aggregation (train_hiv.py:115-117):
+    msg_aggr='softmax' with a learnable inverse temperature per layer."""
+    common = dict(norm_mp="naive-batch-norm", norm_dn="naive-batch-norm", msg_aggr="softmax",
+                  pooling="softattention", activation="relu", real_trafo="linear", w_init="phm",
+                  c_init="standard", learn_phm=True, initial_beta=1.0, learn_beta=True)
+    _model_fixture("g8_model_softmax_small", synth.molecule_batch(8, seed=3), 838,
+                   phm_dim=4, atom_encoded_dim=64, mp_layers=[64] * 3, dropout_mpnn=[0.0] * 3, mlp=True,
+                   downstream_layers=[64, 32], dropout_dn=[0.0, 0.0], target_dim=1, sc_type="first", **common)
+
+
 def g9_dropout():
     """G9: phm_dropout(same=True) mask structure (test_ops_equal_quaternion.py:64-103)."""
     torch.manual_seed(909)
@@ -365,11 +382,9 @@ def g9_dropout():
 
 
 if __name__ == "__main__":
-    g1_phm_linear()
-    g2_g3_g4_kronecker_rules()
-    g5_convs()
-    g5b_softmax()
-    g6_norm()
-    g7_heads()
-    g8_models()
-    g9_dropout()
+    makers = [g1_phm_linear, g2_g3_g4_kronecker_rules, g5_convs, g5b_softmax, g6_norm, g7_heads, g8_models,
+              g8_model_softmax, g9_dropout]
+    wanted = sys.argv[1:]                       # e.g. `make_golden.py g8_model_softmax` rewrites only that fixture
+    for make in makers:
+        if not wanted or make.__name__ in wanted:
+            make()

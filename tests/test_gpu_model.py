@@ -116,6 +116,10 @@ MODELS = {
     "g8_model_zinc_small": dict(phm_dim=8, atom_input_dims=[28], bond_input_dims=[4], atom_encoded_dim=64,
                                 mp_layers=[64] * 3, dropout_mpnn=[0.0] * 3, mlp=True, downstream_layers=[64, 32],
                                 dropout_dn=[0.0, 0.0], target_dim=1, sc_type="last"),
+    # the reference's default molhiv aggregation (train_hiv.py:115-117)
+    "g8_model_softmax_small": dict(phm_dim=4, atom_encoded_dim=64, mp_layers=[64] * 3, dropout_mpnn=[0.0] * 3, mlp=True,
+                                   downstream_layers=[64, 32], dropout_dn=[0.0, 0.0], target_dim=1, sc_type="first",
+                                   msg_aggr="softmax", initial_beta=1.0, learn_beta=True),
 }
 
 
@@ -123,8 +127,9 @@ MODELS = {
 def test_g8_full_model(name):
     from phc.hypercomplex.undirectional.models import PHMSkipConnectAdd
     z = tensors(load(name))
-    model = PHMSkipConnectAdd(msg_aggr="sum", norm_mp="naive-batch-norm", norm_dn="naive-batch-norm",
-                              pooling="softattention", **MODELS[name])
+    kw = dict(msg_aggr="sum", norm_mp="naive-batch-norm", norm_dn="naive-batch-norm", pooling="softattention")
+    kw.update(MODELS[name])
+    model = PHMSkipConnectAdd(**kw)
     assert model.get_number_of_params_() == int(z["num_params"])
     _load_sd(model, sub(z, "sd::"))
     model.to(DEV)

@@ -140,6 +140,8 @@ MODEL_CFGS = {
                                 mlp=False, sc_type="first"),
     "g8_model_zinc_small": dict(phm_dim=8, num_layers=3, num_atom_feats=1, num_bond_feats=1, num_dn_hidden=2,
                                 mlp=True, sc_type="last"),
+    "g8_model_softmax_small": dict(phm_dim=4, num_layers=3, num_atom_feats=9, num_bond_feats=3, num_dn_hidden=2,
+                                   mlp=True, sc_type="first", msg_aggr="softmax"),
 }
 
 
