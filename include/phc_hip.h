@@ -328,6 +328,18 @@ int phc_table_grads_batched(const phc_table_grad_job *jobs, int num_jobs, const 
                             const int64_t *edge_src_i64, const int64_t *edge_dst_i64, int64_t E, int F, int n, int k,
                             int act, void *ws, size_t ws_bytes, void *stream);
 
+/* The same gradients for an IDENTITY message function without touching the edges' feature rows: then
+ * d enc[e] = dout[dst_e] for every in-edge e, so  dT = C^T . dout  with C[d][r] = number of in-edges of d whose
+ * packed code (phc_pack_edge_codes, destination-sorted order) names table row r.  Workgroups walk 64 destination
+ * nodes at a time, rebuild their count rows from rowptr / codes in LDS and run the same MFMA tile: n_dst
+ * contiguous rows are read instead of E gathered ones.  jobs[].x and .tables are not read.  Needs F <= 4 and
+ * sum(vocab) <= 256 (the packed-code limits).  Summation order differs from phc_table_grads_batched (fp32
+ * rounding only). */
+size_t phc_table_grads_counted_ws_bytes(int64_t n_dst, int F, const int32_t *vocab, int n, int k, int num_jobs);
+int phc_table_grads_counted(const phc_table_grad_job *jobs, int num_jobs, const int32_t *rowptr, const uint32_t *codes,
+                            int64_t n_dst, const int32_t *vocab, int F, int n, int k, void *ws, size_t ws_bytes,
+                            void *stream);
+
 /* Both sorted views of one edge list — destination-sorted (rowptr/col/perm, forward) and source-sorted
  * (rowptr_t/col_t/perm_t, backward) — side by side in FIVE launches instead of 22 (a training step needs
  * both).  Same result as two phc_csr_build calls (stable order).  At most 16383 rows per side (molecule
@@ -385,12 +397,16 @@ int phc_bn_bwd_from_partials(const float *dy, const float *x, const float *save_
  * dH-slab workgroups SIDE BY SIDE (the former dispatched first, into the slots the latter leave free), the
  * second all slab reductions, the third the PHM contraction.  Results are identical to the separate entry
  * points (same workgroup bodies, same fixed summation order).  PHC_ERR_UNSUPPORTED when a job needs the
- * 128 x 128 tile path: use the separate entry points then. */
-size_t phc_step_tail_ws_bytes(const phc_phm_grad_job *jobs, int num_jobs, int num_tjobs, int64_t E, int F_b,
-                              const int32_t *vocab_b, int64_t N_atoms, int F_a, const int32_t *vocab_a, int n, int k);
+ * 128 x 128 tile path: use the separate entry points then.
+ * Bond tables: bond_n_dst > 0 selects the counted form of phc_table_grads_counted (bond_rowptr / bond_codes, act
+ * must be identity; bond_i64 / edge_* may be NULL), bond_n_dst = 0 the per-edge form of phc_table_grads_batched. */
+size_t phc_step_tail_ws_bytes(const phc_phm_grad_job *jobs, int num_jobs, int num_tjobs, int64_t E, int64_t bond_n_dst,
+                              int F_b, const int32_t *vocab_b, int64_t N_atoms, int F_a, const int32_t *vocab_a, int n,
+                              int k);
 int phc_step_tail(const phc_phm_grad_job *jobs, int num_jobs, const phc_table_grad_job *tjobs, int num_tjobs,
                   const int64_t *bond_i64, const int32_t *vocab_b, const int64_t *edge_src_i64,
-                  const int64_t *edge_dst_i64, int64_t E, int F_b, int act, const float *atom_dout,
+                  const int64_t *edge_dst_i64, int64_t E, int F_b, int act, const int32_t *bond_rowptr,
+                  const uint32_t *bond_codes, int64_t bond_n_dst, const float *atom_dout,
                   const int64_t *atom_idx_i64, int64_t N_atoms, int F_a, const int32_t *vocab_a,
                   float *atom_dtables_flat, int n, int k, void *ws, size_t ws_bytes, void *stream);
 

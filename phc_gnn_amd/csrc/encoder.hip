@@ -382,14 +382,135 @@ __device__ __forceinline__ void table_grad_body(
     }
 }
 
+// Row-contiguous forms (the gradient operand is read in place, no gather):
+//   MODE 0: item = node i, ones at rows off_f + idx[i, f], g = dout[i]                       (atom encoder)
+//   MODE 2: item = destination node d, COUNTS of the table rows among d's in-edges, g = dout[d]
+//           (bond encoders with an identity message function: d_enc[e] = dout[dst_e] for every in-edge, so
+//           dT = C^T . dout with C[d][r] = #{in-edges of d whose code has row r}; C is rebuilt per 64-node block from the
+//           destination-sorted rowptr / packed codes and never stored.  Reads n_dst rows instead of gathering E.)
+// The next block's gradient rows (and row pointers / indices) are loaded into registers before the current block's
+// MFMAs, clamped instead of branched, so one workgroup keeps its own loads in flight behind the matrix work.
+template <int MODE>
+__device__ __forceinline__ void table_grad_rows_body(
+    const float *__restrict__ dout, const long long *__restrict__ idx, const int *__restrict__ rowptr,
+    const unsigned *__restrict__ codes, const EncMeta &m, long long n_items, long long items_per_split, int h, int tiles_j, int vec4,
+    float *__restrict__ slabs, int tile, long long split, float *__restrict__ smem) {
+    static_assert(MODE == 0 || MODE == 2, "row-contiguous modes");
+    float *oh = smem;                                                   // one-hot / count tile [item][table row]
+    float *gs = smem + TG_IB * TG_T;                                    // gradient tile        [item][column]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wi = wave >> 1, wj = wave & 1;
+    const int r = lane & 31, hh = lane >> 5;
+    const int ti = tile / tiles_j, tj = tile - ti * tiles_j;
+    const int r0 = ti * TG_T, j0 = tj * TG_T;
+    const long long t_begin = split * items_per_split;
+    const long long t_end = min(n_items, t_begin + items_per_split);
+    const int F = m.F;
+
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    if (t_begin < t_end) {
+        const int c4 = tid & 15, row0 = tid >> 4;
+        const int cj = min(j0 + c4 * 4, h - 4);
+        const bool col_ok = j0 + c4 * 4 < h;
+        f32x4 gv[4];
+        int e0 = 0, e1 = 0;                                  // MODE 2: in-edge range of item (tb + tid), tid < 64
+        int rows[4] = {-1, -1, -1, -1};                      // MODE 0: table rows of (item, feature) pairs tid + 256 q
+        auto prefetch = [&](long long tb) {
+            if (vec4) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const long long t = min(tb + row0 + 16 * q, t_end - 1);
+                    gv[q] = *reinterpret_cast<const f32x4 *>(dout + (size_t)t * h + cj);
+                }
+            }
+            if (MODE == 2) {
+                const long long t = min(tb + (tid & 63), t_end - 1);
+                const int a = rowptr[t], b = rowptr[t + 1];
+                const bool live = tb + (tid & 63) < t_end;
+                e0 = a;
+                e1 = live ? b : a;
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int e = tid + ENC_THREADS * q;
+                    const int item = e / F, f = e - item * F;
+                    const bool live = e < TG_IB * F && tb + item < t_end;
+                    const long long t = min(tb + item, t_end - 1);
+                    const int v = (int)idx[t * F + (live ? f : 0)];
+                    rows[q] = live ? m.off[f] + v - r0 : -1;
+                }
+            }
+        };
+        prefetch(t_begin);
+        for (long long tb = t_begin; tb < t_end; tb += TG_IB) {
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 4; ++q) reinterpret_cast<float4 *>(oh)[tid + ENC_THREADS * q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (vec4) {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int item = row0 + 16 * q;
+                    const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                    *reinterpret_cast<f32x4 *>(gs + item * TG_T + c4 * 4) = (tb + item < t_end && col_ok) ? gv[q] : z;
+                }
+            } else {
+                for (int e = tid; e < TG_IB * TG_T; e += ENC_THREADS) {
+                    const int item = e / TG_T, cc = e - item * TG_T;
+                    gs[e] = (tb + item < t_end && j0 + cc < h) ? dout[(size_t)(tb + item) * h + j0 + cc] : 0.f;
+                }
+            }
+            __syncthreads();
+            if (MODE == 2) {
+                if (tid < TG_IB) {                           // one thread per node: its in-edges may repeat a row
+                    for (int e = e0; e < e1; ++e) {
+                        const unsigned code = codes[e];
+                        for (int f = 0; f < F; ++f) {
+                            const int rr = (int)((code >> (8 * f)) & 255u) - r0;
+                            if (rr >= 0 && rr < TG_T) oh[tid * TG_T + rr] += 1.f;
+                        }
+                    }
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {                // the F rows of one item are distinct
+                    const int e = tid + ENC_THREADS * q;
+                    if (rows[q] >= 0 && rows[q] < TG_T) oh[(e / F) * TG_T + rows[q]] = 1.f;
+                }
+            }
+            prefetch(tb + TG_IB);                            // past the end: clamped re-reads of the last row, never used
+            __syncthreads();
+            const float *pa = oh + hh * TG_T + wi * 32 + r;
+            const float *pb = gs + hh * TG_T + wj * 32 + r;
+#pragma unroll 8
+            for (int it = 0; it < TG_IB; it += 2)
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(pa[it * TG_T], pb[it * TG_T], acc, 0, 0, 0);
+        }
+    }
+    float *slab = slabs + (size_t)split * m.R * h;
+    const int col = j0 + wj * 32 + r;
+    if (col < h) {
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const int row = r0 + wi * 32 + (reg & 3) + 8 * (reg >> 2) + 4 * hh;
+            if (row < m.R) slab[(size_t)row * h + col] = acc[reg];
+        }
+    }
+}
+
 template <int MODE, int ACT>
 __global__ __launch_bounds__(ENC_THREADS) void table_grad_mfma_kernel(
     const float *__restrict__ dout, const long long *__restrict__ idx, EncMeta m, long long n_items, long long items_per_split,
     int h, int tiles_j, const long long *__restrict__ src, const long long *__restrict__ dst, const float *__restrict__ x,
     const float *const *__restrict__ tables, int n, int k, int vec4, float *__restrict__ slabs) {
     __shared__ __attribute__((aligned(16))) float smem[2 * TG_IB * TG_T];
-    table_grad_body<MODE, ACT>(dout, idx, m, n_items, items_per_split, h, tiles_j, src, dst, x, tables, n, k, vec4, slabs, blockIdx.x,
-                               blockIdx.y, smem);
+    if (MODE == 0)
+        table_grad_rows_body<0>(dout, idx, nullptr, nullptr, m, n_items, items_per_split, h, tiles_j, vec4, slabs, blockIdx.x, blockIdx.y,
+                                smem);
+    else
+        table_grad_body<MODE, ACT>(dout, idx, m, n_items, items_per_split, h, tiles_j, src, dst, x, tables, n, k, vec4, slabs, blockIdx.x,
+                                   blockIdx.y, smem);
 }
 
 // Several layers' bond-table gradients in one launch (phc_table_grads_batched): the layers share the edge list and
@@ -412,6 +533,16 @@ __global__ __launch_bounds__(ENC_THREADS) void table_grad_mfma_batched_kernel(
     __shared__ __attribute__((aligned(16))) float smem[2 * TG_IB * TG_T];
     table_grad_body<1, ACT>(jb.dout, idx, m, n_items, items_per_split, h, tiles_j, src, dst, jb.x, jb.tables, n, k, vec4, jb.slabs,
                             blockIdx.x, blockIdx.y, smem);
+}
+
+// identity message function: per destination node with in-edge row counts (MODE 2), n_items = n_dst
+__global__ __launch_bounds__(ENC_THREADS) void table_grad_counted_batched_kernel(
+    TgBatch b, const int *__restrict__ rowptr, const unsigned *__restrict__ codes, EncMeta m, long long n_items,
+    long long items_per_split, int h, int tiles_j, int vec4) {
+    const TgJobDev &jb = b.j[blockIdx.z];
+    __shared__ __attribute__((aligned(16))) float smem[2 * TG_IB * TG_T];
+    table_grad_rows_body<2>(jb.dout, nullptr, rowptr, codes, m, n_items, items_per_split, h, tiles_j, vec4, jb.slabs, blockIdx.x,
+                            blockIdx.y, smem);
 }
 
 __device__ __forceinline__ void table_grad_reduce_body(const float *__restrict__ slabs, int num_slabs, int R, int n, int k,
@@ -460,6 +591,8 @@ struct TailTables {
     TgBatch bond;
     EncMeta mb;
     const long long *bond_idx, *src, *dst;
+    const int *rowptr_b;                                     // counted form (identity message function): destination-sorted
+    const unsigned *codes_b;                                 // row pointers + packed codes, E = number of destination nodes
     long long E, ips_b;
     int tiles_j_b, tiles_b, slabs_b, jobs_b, vec4_b;
     // atom tables (MODE 0): one job
@@ -481,8 +614,8 @@ __global__ __launch_bounds__(256) void tail_partial_kernel(GradBatch gb, TailTab
     unsigned bx = blockIdx.x;
     if (bx < t.nb_atom) {
         const int tile = bx % t.tiles_a;
-        table_grad_body<0, PHC_ACT_IDENTITY>(t.atom_dout, t.atom_idx, t.ma, t.N_a, t.ips_a, t.h, t.tiles_j_a, nullptr, nullptr, nullptr,
-                                              nullptr, t.n, t.k, t.vec4_a, t.atom_slabs, tile, bx / t.tiles_a, smem);
+        table_grad_rows_body<0>(t.atom_dout, t.atom_idx, nullptr, nullptr, t.ma, t.N_a, t.ips_a, t.h, t.tiles_j_a, t.vec4_a, t.atom_slabs,
+                                tile, bx / t.tiles_a, smem);
         return;
     }
     bx -= t.nb_atom;
@@ -491,8 +624,12 @@ __global__ __launch_bounds__(256) void tail_partial_kernel(GradBatch gb, TailTab
         const int job = bx / per_job;
         const unsigned local = bx - job * per_job;
         const TgJobDev &jb = t.bond.j[job];
-        table_grad_body<1, ACT>(jb.dout, t.bond_idx, t.mb, t.E, t.ips_b, t.h, t.tiles_j_b, t.src, t.dst, jb.x, jb.tables, t.n, t.k,
-                                t.vec4_b, jb.slabs, local % t.tiles_b, local / t.tiles_b, smem);
+        if (ACT == PHC_ACT_IDENTITY && t.codes_b)
+            table_grad_rows_body<2>(jb.dout, nullptr, t.rowptr_b, t.codes_b, t.mb, t.E, t.ips_b, t.h, t.tiles_j_b, t.vec4_b, jb.slabs,
+                                    local % t.tiles_b, local / t.tiles_b, smem);
+        else
+            table_grad_body<1, ACT>(jb.dout, t.bond_idx, t.mb, t.E, t.ips_b, t.h, t.tiles_j_b, t.src, t.dst, jb.x, jb.tables, t.n, t.k,
+                                    t.vec4_b, jb.slabs, local % t.tiles_b, local / t.tiles_b, smem);
         return;
     }
     bx -= t.nb_bond;
@@ -922,8 +1059,54 @@ int phc_table_grads_batched(const phc_table_grad_job *jobs, int num_jobs, const 
     return PHC_OK;
 }
 
-static int tail_plan(const phc_phm_grad_job *jobs, int num_jobs, int num_tjobs, int64_t E, int F_b, const int32_t *vocab_b, int64_t N_atoms,
-                     int F_a, const int32_t *vocab_a, int n, int k, EncMeta *mb, EncMeta *ma, TgPlan *pb, TgPlan *pa, size_t *phm_floats) {
+size_t phc_table_grads_counted_ws_bytes(int64_t n_dst, int F, const int32_t *vocab, int n, int k, int num_jobs) {
+    return phc_table_grads_ws_bytes(n_dst, F, vocab, n, k, num_jobs);     // same plan, items = destination nodes
+}
+
+int phc_table_grads_counted(const phc_table_grad_job *jobs, int num_jobs, const int32_t *rowptr, const uint32_t *codes,
+                            int64_t n_dst, const int32_t *vocab, int F, int n, int k, void *ws, size_t ws_bytes, void *stream) {
+    EncMeta m;
+    int rc = make_meta("phc_table_grads_counted", F, vocab, &m);
+    if (rc) return rc;
+    PHC_REQUIRE(num_jobs >= 1 && jobs && n_dst >= 1 && n >= 1 && k >= 1, PHC_ERR_INVALID_ARG, "phc_table_grads_counted: bad arguments");
+    PHC_REQUIRE(rowptr && codes, PHC_ERR_INVALID_ARG, "phc_table_grads_counted: null pointer");
+    PHC_REQUIRE(F <= 4 && m.R <= 256, PHC_ERR_UNSUPPORTED, "phc_table_grads_counted: packed codes need F <= 4, sum(vocab) <= 256");
+    PHC_REQUIRE(ws && ws_bytes >= phc_table_grads_counted_ws_bytes(n_dst, F, vocab, n, k, num_jobs), PHC_ERR_WORKSPACE,
+                "phc_table_grads_counted: workspace too small");
+    const int h = n * k;
+    hipStream_t s = (hipStream_t)stream;
+    float *wsf = static_cast<float *>(ws);
+    for (int c0 = 0; c0 < num_jobs; c0 += TG_JOBS_PER_LAUNCH) {
+        const int cn = num_jobs - c0 < TG_JOBS_PER_LAUNCH ? num_jobs - c0 : TG_JOBS_PER_LAUNCH;
+        const TgPlan p = tg_plan(n_dst, m.R, h, cn);
+        TgBatch b;
+        int vec4 = (k % 4 == 0);
+        for (int q = 0; q < cn; ++q) {
+            const phc_table_grad_job &jb = jobs[c0 + q];
+            PHC_REQUIRE(jb.dout && jb.dtables_flat, PHC_ERR_INVALID_ARG, "phc_table_grads_counted: job %d: null pointer", c0 + q);
+            b.j[q].dout = jb.dout; b.j[q].x = nullptr; b.j[q].tables = nullptr; b.j[q].flat = jb.dtables_flat;
+            b.j[q].slabs = wsf;
+            wsf += p.slab_floats;
+            vec4 = vec4 && al16(jb.dout);
+        }
+        {
+            ProfScope prof(K_TABLE_GRAD, s);
+            PHC_LAUNCH(table_grad_counted_batched_kernel, dim3(p.tiles_i * p.tiles_j, p.num_slabs, cn), dim3(ENC_THREADS), 0, s, b, rowptr,
+                       codes, m, (long long)n_dst, p.items_per_split, h, p.tiles_j, vec4);
+            rc = check_launch("table_grads_counted");
+            if (rc) return rc;
+        }
+        ProfScope prof(K_TABLE_GRAD_REDUCE, s);
+        PHC_LAUNCH(table_grad_reduce_batched_kernel, dim3((m.R * h + 63) / 64, cn), dim3(256), 0, s, b, p.num_slabs, m.R, n, k);
+        rc = check_launch("table_grads_counted(reduce)");
+        if (rc) return rc;
+    }
+    return PHC_OK;
+}
+
+static int tail_plan(const phc_phm_grad_job *jobs, int num_jobs, int num_tjobs, int64_t E, int64_t bond_n_dst, int F_b,
+                     const int32_t *vocab_b, int64_t N_atoms, int F_a, const int32_t *vocab_a, int n, int k, EncMeta *mb, EncMeta *ma,
+                     TgPlan *pb, TgPlan *pa, size_t *phm_floats) {
     PHC_REQUIRE(num_jobs >= 1 && num_jobs <= GRAD_JOBS_PER_LAUNCH && num_tjobs >= 0 && num_tjobs <= TG_JOBS_PER_LAUNCH && n >= 1 && k >= 1,
                 PHC_ERR_UNSUPPORTED, "phc_step_tail: %d PHM jobs (1..%d), %d table jobs (0..%d)", num_jobs, GRAD_JOBS_PER_LAUNCH, num_tjobs,
                 TG_JOBS_PER_LAUNCH);
@@ -935,8 +1118,8 @@ static int tail_plan(const phc_phm_grad_job *jobs, int num_jobs, int num_tjobs, 
     if (num_tjobs > 0) {
         rc = make_meta("phc_step_tail", F_b, vocab_b, mb);
         if (rc) return rc;
-        PHC_REQUIRE(E >= 1, PHC_ERR_INVALID_ARG, "phc_step_tail: table jobs without edges");
-        *pb = tg_plan(E, mb->R, h, num_tjobs);
+        PHC_REQUIRE(E >= 1 && bond_n_dst >= 0, PHC_ERR_INVALID_ARG, "phc_step_tail: table jobs without edges");
+        *pb = tg_plan(bond_n_dst > 0 ? bond_n_dst : E, mb->R, h, num_tjobs);      // counted form: items = destination nodes
     }
     if (N_atoms > 0) {
         rc = make_meta("phc_step_tail", F_a, vocab_a, ma);
@@ -947,28 +1130,36 @@ static int tail_plan(const phc_phm_grad_job *jobs, int num_jobs, int num_tjobs, 
     return PHC_OK;
 }
 
-size_t phc_step_tail_ws_bytes(const phc_phm_grad_job *jobs, int num_jobs, int num_tjobs, int64_t E, int F_b, const int32_t *vocab_b,
-                              int64_t N_atoms, int F_a, const int32_t *vocab_a, int n, int k) {
+size_t phc_step_tail_ws_bytes(const phc_phm_grad_job *jobs, int num_jobs, int num_tjobs, int64_t E, int64_t bond_n_dst, int F_b,
+                              const int32_t *vocab_b, int64_t N_atoms, int F_a, const int32_t *vocab_a, int n, int k) {
     EncMeta mb, ma;
     TgPlan pb, pa;
     size_t phm = 0;
-    if (tail_plan(jobs, num_jobs, num_tjobs, E, F_b, vocab_b, N_atoms, F_a, vocab_a, n, k, &mb, &ma, &pb, &pa, &phm)) return 0;
+    if (tail_plan(jobs, num_jobs, num_tjobs, E, bond_n_dst, F_b, vocab_b, N_atoms, F_a, vocab_a, n, k, &mb, &ma, &pb, &pa, &phm)) return 0;
     return sizeof(float) * (phm + (num_tjobs > 0 ? pb.slab_floats * (size_t)num_tjobs : 0) + (N_atoms > 0 ? pa.slab_floats : 0));
 }
 
 int phc_step_tail(const phc_phm_grad_job *jobs, int num_jobs, const phc_table_grad_job *tjobs, int num_tjobs, const int64_t *bond_i64,
                   const int32_t *vocab_b, const int64_t *edge_src_i64, const int64_t *edge_dst_i64, int64_t E, int F_b, int act,
-                  const float *atom_dout, const int64_t *atom_idx_i64, int64_t N_atoms, int F_a, const int32_t *vocab_a,
-                  float *atom_dtables_flat, int n, int k, void *ws, size_t ws_bytes, void *stream) {
+                  const int32_t *bond_rowptr, const uint32_t *bond_codes, int64_t bond_n_dst, const float *atom_dout,
+                  const int64_t *atom_idx_i64, int64_t N_atoms, int F_a, const int32_t *vocab_a, float *atom_dtables_flat, int n, int k,
+                  void *ws, size_t ws_bytes, void *stream) {
     EncMeta mb, ma;
     TgPlan pb, pa;
     size_t phm_floats = 0;
-    int rc = tail_plan(jobs, num_jobs, num_tjobs, E, F_b, vocab_b, N_atoms, F_a, vocab_a, n, k, &mb, &ma, &pb, &pa, &phm_floats);
+    const bool counted = num_tjobs > 0 && bond_n_dst > 0;
+    int rc = tail_plan(jobs, num_jobs, num_tjobs, E, bond_n_dst, F_b, vocab_b, N_atoms, F_a, vocab_a, n, k, &mb, &ma, &pb, &pa, &phm_floats);
     if (rc) return rc;
     PHC_REQUIRE(act >= PHC_ACT_IDENTITY && act <= PHC_ACT_SELU, PHC_ERR_INVALID_ARG, "phc_step_tail: unknown activation %d", act);
-    PHC_REQUIRE(num_tjobs == 0 || (tjobs && bond_i64 && edge_src_i64 && edge_dst_i64), PHC_ERR_INVALID_ARG, "phc_step_tail: null pointer");
+    if (counted) {
+        PHC_REQUIRE(act == PHC_ACT_IDENTITY, PHC_ERR_INVALID_ARG, "phc_step_tail: the counted bond form needs an identity message function");
+        PHC_REQUIRE(tjobs && bond_rowptr && bond_codes, PHC_ERR_INVALID_ARG, "phc_step_tail: null pointer (counted bond form)");
+        PHC_REQUIRE(F_b <= 4 && mb.R <= 256, PHC_ERR_UNSUPPORTED, "phc_step_tail: packed codes need F <= 4, sum(vocab) <= 256");
+    } else {
+        PHC_REQUIRE(num_tjobs == 0 || (tjobs && bond_i64 && edge_src_i64 && edge_dst_i64), PHC_ERR_INVALID_ARG, "phc_step_tail: null pointer");
+    }
     PHC_REQUIRE(N_atoms == 0 || (atom_dout && atom_idx_i64 && atom_dtables_flat), PHC_ERR_INVALID_ARG, "phc_step_tail: null atom pointer");
-    const size_t need = phc_step_tail_ws_bytes(jobs, num_jobs, num_tjobs, E, F_b, vocab_b, N_atoms, F_a, vocab_a, n, k);
+    const size_t need = phc_step_tail_ws_bytes(jobs, num_jobs, num_tjobs, E, bond_n_dst, F_b, vocab_b, N_atoms, F_a, vocab_a, n, k);
     PHC_REQUIRE(ws && ws_bytes >= need && (reinterpret_cast<uintptr_t>(ws) & 15) == 0, PHC_ERR_WORKSPACE,
                 "phc_step_tail: workspace %zu B < required %zu B (or not 16-byte aligned)", ws_bytes, need);
     hipStream_t s = (hipStream_t)stream;
@@ -987,11 +1178,14 @@ int phc_step_tail(const phc_phm_grad_job *jobs, int num_jobs, const phc_table_gr
         t.bond_idx = reinterpret_cast<const long long *>(bond_i64);
         t.src = reinterpret_cast<const long long *>(edge_src_i64);
         t.dst = reinterpret_cast<const long long *>(edge_dst_i64);
-        t.E = E; t.ips_b = pb.items_per_split; t.tiles_j_b = pb.tiles_j; t.tiles_b = pb.tiles_i * pb.tiles_j; t.slabs_b = pb.num_slabs;
+        t.E = counted ? bond_n_dst : E;
+        t.rowptr_b = counted ? bond_rowptr : nullptr;
+        t.codes_b = counted ? bond_codes : nullptr;
+        t.ips_b = pb.items_per_split; t.tiles_j_b = pb.tiles_j; t.tiles_b = pb.tiles_i * pb.tiles_j; t.slabs_b = pb.num_slabs;
         t.jobs_b = num_tjobs;
         int vec4 = (k % 4 == 0);
         for (int q = 0; q < num_tjobs; ++q) {
-            PHC_REQUIRE(tjobs[q].dout && tjobs[q].tables && tjobs[q].dtables_flat && (act == PHC_ACT_IDENTITY || tjobs[q].x),
+            PHC_REQUIRE(tjobs[q].dout && (counted || tjobs[q].tables) && tjobs[q].dtables_flat && (act == PHC_ACT_IDENTITY || tjobs[q].x),
                         PHC_ERR_INVALID_ARG, "phc_step_tail: table job %d: null pointer", q);
             t.bond.j[q].dout = tjobs[q].dout; t.bond.j[q].x = tjobs[q].x; t.bond.j[q].tables = tjobs[q].tables;
             t.bond.j[q].flat = tjobs[q].dtables_flat; t.bond.j[q].slabs = wsf;

@@ -41,72 +41,89 @@ __device__ __forceinline__ void dH_partial_body(const float *__restrict__ X, con
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
-    float colsum = 0.f;                                  // threads 0..63 of tile_i == 0 workgroups
-    float4 xf_sc = make_float4(1.f, 1.f, 1.f, 1.f), xf_sh = make_float4(0.f, 0.f, 0.f, 0.f);
+    // column sums of dy (db): in tile_i == 0 workgroups wavefront q adds rows q*16 .. q*16+15 of every staged block for
+    // column (tid & 63); the four partials meet in fixed order after the loop
+    float colsum = 0.f;
+    f32x4 xf_sc = {1.f, 1.f, 1.f, 1.f}, xf_sh = {0.f, 0.f, 0.f, 0.f};
     if (xf_stat && vec4) {                               // this thread always stages float4 column (tid & 15) of the X tile
         const int ci = min(i0 + (tid & 15) * 4, in - 4);
-        xf_sc = *reinterpret_cast<const float4 *>(xf_stat + 2 * (size_t)in + ci);
-        xf_sh = *reinterpret_cast<const float4 *>(xf_stat + 3 * (size_t)in + ci);
+        xf_sc = *reinterpret_cast<const f32x4 *>(xf_stat + 2 * (size_t)in + ci);
+        xf_sh = *reinterpret_cast<const f32x4 *>(xf_stat + 3 * (size_t)in + ci);
+    }
+
+    // vec4 path: the 64 x 64 block of each operand is 4 float4 per thread; the NEXT block's eight loads are issued
+    // (clamped addresses, no branches) before the current block's MFMAs, so their latency hides behind the matrix work
+    f32x4 xv[4], dv[4];
+    const int c4 = tid & 15;
+    const int ci4 = min(i0 + c4 * 4, in - 4), cj4 = min(j0 + c4 * 4, out - 4);
+    const bool x_col_ok = i0 + c4 * 4 < in, d_col_ok = j0 + c4 * 4 < out;
+    if (vec4) {
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            const long long grow = min(r_begin + (tid >> 4) + 16 * t, r_end - 1);
+            xv[t] = *reinterpret_cast<const f32x4 *>(X + (size_t)grow * in + ci4);
+            dv[t] = *reinterpret_cast<const f32x4 *>(DY + (size_t)grow * out + cj4);
+        }
     }
 
     for (long long rb = r_begin; rb < r_end; rb += DH_RB) {
         __syncthreads();
         if (vec4) {
-            for (int e = tid; e < DH_RB * (DH_T / 4); e += 256) {
-                const int row = e / (DH_T / 4), c4 = e - row * (DH_T / 4);
-                float4 xv = make_float4(0.f, 0.f, 0.f, 0.f), dv = xv;
-                if (rb + row < r_end) {
-                    if (i0 + c4 * 4 < in) {
-                        xv = *reinterpret_cast<const float4 *>(X + (size_t)(rb + row) * in + i0 + c4 * 4);
-                        if (xf_stat) {
-                            const float4 sc = xf_sc, sh = xf_sh;     // c4 = tid & 15 for every element of this thread
-                            const bool live = rb + row < xf_count;
-                            if (xf_act == PHC_ACT_RELU) {
-                                xv.x = live ? fmaxf(fmaf(xv.x, sc.x, sh.x), 0.f) : 0.f;
-                                xv.y = live ? fmaxf(fmaf(xv.y, sc.y, sh.y), 0.f) : 0.f;
-                                xv.z = live ? fmaxf(fmaf(xv.z, sc.z, sh.z), 0.f) : 0.f;
-                                xv.w = live ? fmaxf(fmaf(xv.w, sc.w, sh.w), 0.f) : 0.f;
-                            } else {
-                                xv.x = live ? act_fwd_rt(xf_act, fmaf(xv.x, sc.x, sh.x)) : 0.f;
-                                xv.y = live ? act_fwd_rt(xf_act, fmaf(xv.y, sc.y, sh.y)) : 0.f;
-                                xv.z = live ? act_fwd_rt(xf_act, fmaf(xv.z, sc.z, sh.z)) : 0.f;
-                                xv.w = live ? act_fwd_rt(xf_act, fmaf(xv.w, sc.w, sh.w)) : 0.f;
-                            }
-                        }
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const int row = (tid >> 4) + 16 * t;
+                const f32x4 z = {0.f, 0.f, 0.f, 0.f};
+                const bool rok = rb + row < r_end;
+                if (xf_stat) {
+                    const bool live = rb + row < xf_count;
+                    if (xf_act == PHC_ACT_RELU) {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) xv[t][q] = live ? fmaxf(fmaf(xv[t][q], xf_sc[q], xf_sh[q]), 0.f) : 0.f;
+                    } else {
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) xv[t][q] = live ? act_fwd_rt(xf_act, fmaf(xv[t][q], xf_sc[q], xf_sh[q])) : 0.f;
                     }
-                    if (j0 + c4 * 4 < out) dv = *reinterpret_cast<const float4 *>(DY + (size_t)(rb + row) * out + j0 + c4 * 4);
                 }
-                *reinterpret_cast<float4 *>(xs + row * DH_STRIDE + c4 * 4) = xv;
-                *reinterpret_cast<float4 *>(ds + row * DH_STRIDE + c4 * 4) = dv;
+                *reinterpret_cast<f32x4 *>(xs + row * DH_STRIDE + c4 * 4) = (rok && x_col_ok) ? xv[t] : z;
+                *reinterpret_cast<f32x4 *>(ds + row * DH_STRIDE + c4 * 4) = (rok && d_col_ok) ? dv[t] : z;
             }
         } else {
             for (int e = tid; e < DH_RB * DH_T; e += 256) {
                 const int row = e / DH_T, c = e - row * DH_T;
-                float xv = 0.f, dv = 0.f;
+                float xe = 0.f, de = 0.f;
                 if (rb + row < r_end) {
                     if (i0 + c < in) {
-                        xv = X[(size_t)(rb + row) * in + i0 + c];
+                        xe = X[(size_t)(rb + row) * in + i0 + c];
                         if (xf_stat)
-                            xv = rb + row < xf_count
-                                     ? act_fwd_rt(xf_act, fmaf(xv, xf_stat[2 * (size_t)in + i0 + c], xf_stat[3 * (size_t)in + i0 + c]))
+                            xe = rb + row < xf_count
+                                     ? act_fwd_rt(xf_act, fmaf(xe, xf_stat[2 * (size_t)in + i0 + c], xf_stat[3 * (size_t)in + i0 + c]))
                                      : 0.f;
                     }
-                    if (j0 + c < out) dv = DY[(size_t)(rb + row) * out + j0 + c];
+                    if (j0 + c < out) de = DY[(size_t)(rb + row) * out + j0 + c];
                 }
-                xs[row * DH_STRIDE + c] = xv;
-                ds[row * DH_STRIDE + c] = dv;
+                xs[row * DH_STRIDE + c] = xe;
+                ds[row * DH_STRIDE + c] = de;
             }
         }
         __syncthreads();
+        if (vec4) {                                      // prefetch the next block (the last iteration re-reads row r_end-1)
+#pragma unroll
+            for (int t = 0; t < 4; ++t) {
+                const long long grow = min(rb + DH_RB + (tid >> 4) + 16 * t, r_end - 1);
+                xv[t] = *reinterpret_cast<const f32x4 *>(X + (size_t)grow * in + ci4);
+                dv[t] = *reinterpret_cast<const f32x4 *>(DY + (size_t)grow * out + cj4);
+            }
+        }
         // A operand = x^T: lane (r, hh) supplies x[row rr+hh][i0 + wi*32 + r]; B = dy[row rr+hh][j0 + wj*32 + r]
         const float *xa = xs + hh * DH_STRIDE + wi * 32 + r;
         const float *db_ = ds + hh * DH_STRIDE + wj * 32 + r;
 #pragma unroll 8
         for (int rr = 0; rr < DH_RB; rr += 2)
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[rr * DH_STRIDE], db_[rr * DH_STRIDE], acc, 0, 0, 0);
-        if (ti == 0 && tid < DH_T) {
-#pragma unroll 8
-            for (int rr = 0; rr < DH_RB; ++rr) colsum += ds[rr * DH_STRIDE + tid];
+        if (ti == 0) {
+            const float *dc = ds + (wave * 16) * DH_STRIDE + lane;
+#pragma unroll
+            for (int rr = 0; rr < 16; ++rr) colsum += dc[rr * DH_STRIDE];
         }
     }
 
@@ -118,7 +135,13 @@ __device__ __forceinline__ void dH_partial_body(const float *__restrict__ X, con
             if (row < in) slab[(size_t)row * out + col] = acc[reg];
         }
     }
-    if (ti == 0 && tid < DH_T && j0 + tid < out) slab[(size_t)in * out + j0 + tid] = colsum;
+    if (ti == 0) {                                       // uniform per workgroup
+        __syncthreads();
+        xs[wave * DH_T + lane] = colsum;
+        __syncthreads();
+        if (tid < DH_T && j0 + tid < out)
+            slab[(size_t)in * out + j0 + tid] = (xs[tid] + xs[DH_T + tid]) + (xs[2 * DH_T + tid] + xs[3 * DH_T + tid]);
+    }
 }
 
 // 128 x 128 tile variant (in, out >= 128): each wavefront owns a 64 x 64 quadrant = 2 x 2 MFMA tiles, rows staged

@@ -90,9 +90,11 @@ SIGNATURES = {
                                    _S, _P]),
     "phc_table_grads_ws_bytes": (_S, [_L, _I, _P, _I, _I, _I]),
     "phc_table_grads_batched": (_I, [C.POINTER(TableGradJob), _I, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P, _S, _P]),
-    "phc_step_tail_ws_bytes": (_S, [C.POINTER(GradJob), _I, _I, _L, _I, _P, _L, _I, _P, _I, _I]),
-    "phc_step_tail": (_I, [C.POINTER(GradJob), _I, C.POINTER(TableGradJob), _I, _P, _P, _P, _P, _L, _I, _I, _P, _P, _L, _I, _P, _P, _I,
-                           _I, _P, _S, _P]),
+    "phc_table_grads_counted_ws_bytes": (_S, [_L, _I, _P, _I, _I, _I]),
+    "phc_table_grads_counted": (_I, [C.POINTER(TableGradJob), _I, _P, _P, _L, _P, _I, _I, _I, _P, _S, _P]),
+    "phc_step_tail_ws_bytes": (_S, [C.POINTER(GradJob), _I, _I, _L, _L, _I, _P, _L, _I, _P, _I, _I]),
+    "phc_step_tail": (_I, [C.POINTER(GradJob), _I, C.POINTER(TableGradJob), _I, _P, _P, _P, _P, _L, _I, _I, _P, _P, _L, _P, _P, _L, _I,
+                           _P, _P, _I, _I, _P, _S, _P]),
     "phc_bn_ws_bytes": (_S, [_L, _I]),
     "phc_bn_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _L, _I, _I, C.c_float, C.c_float, _I, _P, _P, _P, _P, _P, _S, _P]),
     "phc_bn_bwd": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _S, _P]),

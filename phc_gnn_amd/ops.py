@@ -78,6 +78,9 @@ def deferred_param_grads():
         _flush_param_grads(jobs)
 
 
+# bond-table gradients of identity-message layers from per-node in-edge counts instead of per-edge gathers
+TABLE_GRADS_COUNTED = __import__("os").environ.get("PHC_TABLE_GRADS_COUNTED", "1") != "0"
+
 # all deferred gradients of a step (PHM / dense layers, bond tables, atom tables) in three launches (phc_step_tail)
 STEP_TAIL_MERGED = __import__("os").environ.get("PHC_STEP_TAIL_MERGED", "1") != "0"
 
@@ -159,8 +162,8 @@ def _flush_step_tail(jobs, tjobs, ajobs) -> bool:
             outs.append((dA if need_A else None, dW if need_W else None, db if need_b else None))
         # bond tables
         tarr, tflat, per = None, None, 0
-        E = F_b = act = 0
-        bond = src = dst = vocab_b = None
+        E = F_b = act = b_ndst = 0
+        bond = src = dst = vocab_b = b_codes = b_rowptr = None
         if tjobs:
             st = tjobs[0]["st"]
             per = ts_b.n * ts_b.R * ts_b.k
@@ -170,6 +173,8 @@ def _flush_step_tail(jobs, tjobs, ajobs) -> bool:
                 tarr[i] = L.TableGradJob(L.ptr(tj["dout"]), L.ptr(tj["x"]), L.ptr(tj["ts"].ptrs), L.ptr(tflat) + 4 * i * per)
             E, F_b, act = st.num_edges, ts_b.F, tjobs[0]["act"]
             bond, src, dst, vocab_b = tjobs[0]["bond"], st._src, st._dst, ts_b.vocab_c
+            if tjobs[0].get("codes") is not None:
+                b_codes, b_rowptr, b_ndst = tjobs[0]["codes"], st.csr[0], st.num_dst
         # atom tables
         aflat = None
         N_a = F_a = 0
@@ -178,13 +183,13 @@ def _flush_step_tail(jobs, tjobs, ajobs) -> bool:
             aj = ajobs[0]
             aflat = torch.empty(ts_a.n * ts_a.R * ts_a.k, dtype=torch.float32, device=dev)
             N_a, F_a, a_dout, a_idx, vocab_a = aj["idx"].shape[0], ts_a.F, aj["dout"], aj["idx"], ts_a.vocab_c
-        ws_bytes = lib.phc_step_tail_ws_bytes(arr, len(jobs), len(tjobs), E, F_b, vocab_b, N_a, F_a, vocab_a, n, k)
+        ws_bytes = lib.phc_step_tail_ws_bytes(arr, len(jobs), len(tjobs), E, b_ndst, F_b, vocab_b, N_a, F_a, vocab_a, n, k)
         if ws_bytes == 0:
             return False
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         L.check(lib.phc_step_tail(arr, len(jobs), tarr, len(tjobs), L.ptr(bond), vocab_b, L.ptr(src), L.ptr(dst), E, F_b, act,
-                                  L.ptr(a_dout), L.ptr(a_idx), N_a, F_a, vocab_a, L.ptr(aflat), n, k, L.ptr(ws), ws_bytes,
-                                  L.stream_ptr(dev)), "phc_step_tail")
+                                  L.ptr(b_rowptr), L.ptr(b_codes), b_ndst, L.ptr(a_dout), L.ptr(a_idx), N_a, F_a, vocab_a,
+                                  L.ptr(aflat), n, k, L.ptr(ws), ws_bytes, L.stream_ptr(dev)), "phc_step_tail")
         if L.PROF_ON:
             for jb in jobs:
                 jn, jkin, jkout = _job_dims(jb)
@@ -215,11 +220,18 @@ def _flush_table_grads(jobs) -> None:
             arr = (L.TableGradJob * len(js))()
             for i, jb in enumerate(js):
                 arr[i] = L.TableGradJob(L.ptr(jb["dout"]), L.ptr(jb["x"]), L.ptr(jb["ts"].ptrs), L.ptr(flat) + 4 * i * per)
-            ws_bytes = lib.phc_table_grads_ws_bytes(st.num_edges, ts.F, ts.vocab_c, ts.n, ts.k, len(js))
-            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-            L.check(lib.phc_table_grads_batched(arr, len(js), L.ptr(bond), ts.vocab_c, L.ptr(st._src), L.ptr(st._dst),
-                                                st.num_edges, ts.F, ts.n, ts.k, j0["act"], L.ptr(ws), ws_bytes,
-                                                L.stream_ptr(dev)), "phc_table_grads_batched")
+            if j0.get("codes") is not None:
+                ws_bytes = lib.phc_table_grads_counted_ws_bytes(st.num_dst, ts.F, ts.vocab_c, ts.n, ts.k, len(js))
+                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+                L.check(lib.phc_table_grads_counted(arr, len(js), L.ptr(st.csr[0]), L.ptr(j0["codes"]), st.num_dst, ts.vocab_c,
+                                                    ts.F, ts.n, ts.k, L.ptr(ws), ws_bytes, L.stream_ptr(dev)),
+                        "phc_table_grads_counted")
+            else:
+                ws_bytes = lib.phc_table_grads_ws_bytes(st.num_edges, ts.F, ts.vocab_c, ts.n, ts.k, len(js))
+                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+                L.check(lib.phc_table_grads_batched(arr, len(js), L.ptr(bond), ts.vocab_c, L.ptr(st._src), L.ptr(st._dst),
+                                                    st.num_edges, ts.F, ts.n, ts.k, j0["act"], L.ptr(ws), ws_bytes,
+                                                    L.stream_ptr(dev)), "phc_table_grads_batched")
             if L.PROF_ON:
                 E, Nd, h = st.num_edges, st.num_dst, ts.n * ts.k
                 for _ in js:
@@ -1082,8 +1094,10 @@ class _AggregateEncFn(torch.autograd.Function):
             raise L.PhcError(f"x has {x_.shape[0]} rows, edge structure expects {st.num_src} source rows")
         rowptr, col, perm = st.csr
         out = torch.empty((st.num_dst, h), dtype=torch.float32, device=dev)
+        ctx.codes = None
         if ts.F <= 4 and ts.R <= 256:
             codes = st.packed_codes(bond_, ts.vocab_c, ts.F)        # 4 bytes per edge, in sorted order, built once per batch
+            ctx.codes = codes
             L.check(lib.phc_aggregate_encp_fwd(L.ptr(x_), L.ptr(codes), L.ptr(ts.ptrs), ts.vocab_c, L.ptr(rowptr), L.ptr(col),
                                                st.num_dst, ts.F, ts.n, ts.k, act, 1 if add_self else 0, L.ptr(out),
                                                L.stream_ptr(dev)), "phc_aggregate_encp_fwd")
@@ -1129,7 +1143,9 @@ class _AggregateEncFn(torch.autograd.Function):
             with _DEFER.lock:
                 _DEFER.table_jobs.append(dict(
                     key=(bond_.data_ptr(), st._src.data_ptr(), st._dst.data_ptr(), st.num_edges, ts.F, ts.n, ts.k, tuple(ts.vocab),
-                         ctx.act), dout=dout_, x=x_, ts=ts, st=st, bond=bond_, act=ctx.act, params=params))
+                         ctx.act), dout=dout_, x=x_, ts=ts, st=st, bond=bond_, act=ctx.act, params=params,
+                    # identity message function: the per-node counted form (phc_table_grads_counted) reads these instead
+                    codes=ctx.codes if (ctx.act == 0 and TABLE_GRADS_COUNTED) else None))
         if need_t and not deferred:
             flat = torch.empty(ts.n * ts.R * ts.k, dtype=torch.float32, device=dev)
             ws_bytes = lib.phc_aggregate_enc_bwd_ws_bytes(st.num_edges, ts.F, ts.vocab_c, ts.n, ts.k)

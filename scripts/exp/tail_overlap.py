@@ -11,9 +11,11 @@ m = harness.build_model(wl, dev, seed=0); m.train()
 data = harness.to_device(harness.make_batch(wl, seed=0), dev)
 # capture the jobs of one backward pass
 jobs = {}
-orig_p, orig_t = ops._flush_param_grads, ops._flush_table_grads
+orig_p, orig_t, orig_a = ops._flush_param_grads, ops._flush_table_grads, ops._flush_atom_grads
+ops.STEP_TAIL_MERGED = False                       # separate launches: each family can be timed on its own
 ops._flush_param_grads = lambda js: jobs.__setitem__("p", js)
 ops._flush_table_grads = lambda js: jobs.__setitem__("t", js)
+ops._flush_atom_grads = lambda aj: jobs.__setitem__("a", aj)
 with ops.prebuilt_H(ops.phm_pairs(m), ops.dense_weights(m)), ops.deferred_param_grads():
     loss = harness.loss_fn(m(data), data)
     loss.backward()
