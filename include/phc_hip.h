@@ -330,15 +330,15 @@ int phc_table_grads_batched(const phc_table_grad_job *jobs, int num_jobs, const 
 
 /* The same gradients for an IDENTITY message function without touching the edges' feature rows: then
  * d enc[e] = dout[dst_e] for every in-edge e, so  dT = C^T . dout  with C[d][r] = number of in-edges of d whose
- * packed code (phc_pack_edge_codes, destination-sorted order) names table row r.  Workgroups walk 64 destination
- * nodes at a time, rebuild their count rows from rowptr / codes in LDS and run the same MFMA tile: n_dst
- * contiguous rows are read instead of E gathered ones.  jobs[].x and .tables are not read.  Needs F <= 4 and
+ * packed code (phc_pack_edge_codes, destination-sorted order; codes [E], rowptr [n_dst + 1]) names table row r.
+ * Workgroups walk 64 destination nodes at a time, rebuild their count rows from rowptr / codes in LDS and run the
+ * same MFMA tile: n_dst contiguous rows are read instead of E gathered ones.  jobs[].x and .tables are not read.  Needs F <= 4 and
  * sum(vocab) <= 256 (the packed-code limits).  Summation order differs from phc_table_grads_batched (fp32
  * rounding only). */
 size_t phc_table_grads_counted_ws_bytes(int64_t n_dst, int F, const int32_t *vocab, int n, int k, int num_jobs);
 int phc_table_grads_counted(const phc_table_grad_job *jobs, int num_jobs, const int32_t *rowptr, const uint32_t *codes,
-                            int64_t n_dst, const int32_t *vocab, int F, int n, int k, void *ws, size_t ws_bytes,
-                            void *stream);
+                            int64_t n_dst, int64_t E, const int32_t *vocab, int F, int n, int k, void *ws,
+                            size_t ws_bytes, void *stream);
 
 /* Both sorted views of one edge list — destination-sorted (rowptr/col/perm, forward) and source-sorted
  * (rowptr_t/col_t/perm_t, backward) — side by side in FIVE launches instead of 22 (a training step needs

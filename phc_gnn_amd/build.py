@@ -41,18 +41,20 @@ def _stale(target: str, deps) -> bool:
     return any(os.path.getmtime(d) > t for d in deps if os.path.exists(d))
 
 
-def build(force: bool = False, verbose: bool = True) -> str:
+def build(force: bool = False, verbose: bool = True, defines=(), lib_path: str = LIB_PATH, obj_dir: str = OBJ_DIR) -> str:
+    """``defines`` / ``lib_path`` / ``obj_dir``: an experiment variant next to the product library (A/B runs on one box
+    through PHC_LIB_PATH, e.g. ``python -m phc_gnn_amd.build --variant noxcd -DPHC_XCD_MAP=0``)."""
     hipcc = _hipcc()
-    os.makedirs(OBJ_DIR, exist_ok=True)
+    os.makedirs(obj_dir, exist_ok=True)
     headers = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")]
     headers.append(os.path.join(INCLUDE, "phc_hip.h"))
     sources = [s for s in SOURCES if os.path.exists(os.path.join(CSRC, s))]
 
     def compile_one(src: str) -> str:
         path = os.path.join(CSRC, src)
-        obj = os.path.join(OBJ_DIR, src.replace(".hip", ".o"))
+        obj = os.path.join(obj_dir, src.replace(".hip", ".o"))
         if force or _stale(obj, [path] + headers):
-            cmd = [hipcc, "-c", "-x", "hip", path, "-o", obj] + COMMON_FLAGS
+            cmd = [hipcc, "-c", "-x", "hip", path, "-o", obj] + COMMON_FLAGS + list(defines)
             if verbose:
                 print("[phc build]", " ".join(cmd), flush=True)
             subprocess.run(cmd, check=True)
@@ -60,13 +62,20 @@ def build(force: bool = False, verbose: bool = True) -> str:
 
     with ThreadPoolExecutor(max_workers=4) as ex:
         objs = list(ex.map(compile_one, sources))
-    if force or _stale(LIB_PATH, objs):
-        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", LIB_PATH] + objs
+    if force or _stale(lib_path, objs):
+        cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib_path] + objs
         if verbose:
             print("[phc build]", " ".join(cmd), flush=True)
         subprocess.run(cmd, check=True)
-    return LIB_PATH
+    return lib_path
 
 
 if __name__ == "__main__":
-    print(build(force="--force" in sys.argv))
+    if "--variant" in sys.argv:
+        name = sys.argv[sys.argv.index("--variant") + 1]
+        out_dir = os.path.join(REPO, "scripts", "exp", "variants")
+        os.makedirs(out_dir, exist_ok=True)
+        print(build(force=True, defines=[a for a in sys.argv if a.startswith("-D")],
+                    lib_path=os.path.join(out_dir, f"libphc_hip_{name}.so"), obj_dir=os.path.join(OBJ_DIR, "variant_" + name)))
+    else:
+        print(build(force="--force" in sys.argv))

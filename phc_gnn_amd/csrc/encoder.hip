@@ -388,14 +388,20 @@ __device__ __forceinline__ void table_grad_body(
 //           (bond encoders with an identity message function: d_enc[e] = dout[dst_e] for every in-edge, so
 //           dT = C^T . dout with C[d][r] = #{in-edges of d whose code has row r}; C is rebuilt per 64-node block from the
 //           destination-sorted rowptr / packed codes and never stored.  Reads n_dst rows instead of gathering E.)
-// The next block's gradient rows (and row pointers / indices) are loaded into registers before the current block's
-// MFMAs, clamped instead of branched, so one workgroup keeps its own loads in flight behind the matrix work.
+// The next block's operands are loaded into registers before the current block's MFMAs, clamped instead of branched, so
+// one workgroup keeps its own loads in flight behind the matrix work.  MODE 2: the in-edges of 64 consecutive nodes are
+// one contiguous span of `codes`; it is staged in LDS (first TG_CODES of it; longer spans fall back to global reads) and
+// thread (node, table row) counts its matches — plain stores, no read-modify-write, no per-node serial loop.
+constexpr int TG_CODES = 1024;
+
 template <int MODE>
 __device__ __forceinline__ void table_grad_rows_body(
     const float *__restrict__ dout, const long long *__restrict__ idx, const int *__restrict__ rowptr,
-    const unsigned *__restrict__ codes, const EncMeta &m, long long n_items, long long items_per_split, int h, int tiles_j, int vec4,
-    float *__restrict__ slabs, int tile, long long split, float *__restrict__ smem) {
+    const unsigned *__restrict__ codes, long long n_edges, const EncMeta &m, long long n_items, long long items_per_split, int h,
+    int tiles_j, int vec4, float *__restrict__ slabs, int tile, long long split, float *__restrict__ smem) {
     static_assert(MODE == 0 || MODE == 2, "row-contiguous modes");
+    __shared__ unsigned cbuf[MODE == 2 ? TG_CODES : 1];                 // packed codes of the block's in-edge span
+    __shared__ int rp[MODE == 2 ? TG_IB + 1 : 1];                       // row pointers of the block's nodes
     float *oh = smem;                                                   // one-hot / count tile [item][table row]
     float *gs = smem + TG_IB * TG_T;                                    // gradient tile        [item][column]
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -414,10 +420,12 @@ __device__ __forceinline__ void table_grad_rows_body(
         const int c4 = tid & 15, row0 = tid >> 4;
         const int cj = min(j0 + c4 * 4, h - 4);
         const bool col_ok = j0 + c4 * 4 < h;
+        const int RT = min(TG_T, m.R - r0);                  // table rows of this tile that exist
         f32x4 gv[4];
-        int e0 = 0, e1 = 0;                                  // MODE 2: in-edge range of item (tb + tid), tid < 64
+        int rpv = 0;                                         // MODE 2: rowptr[min(tb + tid, t_end)], tid <= 64
+        unsigned cv[4] = {0u, 0u, 0u, 0u};                   // MODE 2: codes[span start + tid + 256 q]
         int rows[4] = {-1, -1, -1, -1};                      // MODE 0: table rows of (item, feature) pairs tid + 256 q
-        auto prefetch = [&](long long tb) {
+        auto prefetch_rows = [&](long long tb) {
             if (vec4) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -426,11 +434,7 @@ __device__ __forceinline__ void table_grad_rows_body(
                 }
             }
             if (MODE == 2) {
-                const long long t = min(tb + (tid & 63), t_end - 1);
-                const int a = rowptr[t], b = rowptr[t + 1];
-                const bool live = tb + (tid & 63) < t_end;
-                e0 = a;
-                e1 = live ? b : a;
+                rpv = rowptr[min(tb + min(tid, TG_IB), t_end)];
             } else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -443,11 +447,25 @@ __device__ __forceinline__ void table_grad_rows_body(
                 }
             }
         };
-        prefetch(t_begin);
+        auto prefetch_codes = [&](long long span0) {         // MODE 2
+#pragma unroll
+            for (int q = 0; q < 4; ++q) cv[q] = codes[min(span0 + tid + ENC_THREADS * q, n_edges - 1)];
+        };
+        // rows of the tile beyond RT (and, MODE 0, everything) start from zero; MODE 2 rewrites [0, RT) every block
+#pragma unroll
+        for (int q = 0; q < 4; ++q) reinterpret_cast<float4 *>(oh)[tid + ENC_THREADS * q] = make_float4(0.f, 0.f, 0.f, 0.f);
+        prefetch_rows(t_begin);
+        if (MODE == 2) prefetch_codes(rowptr[t_begin]);
         for (long long tb = t_begin; tb < t_end; tb += TG_IB) {
             __syncthreads();
+            if (MODE == 0) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) reinterpret_cast<float4 *>(oh)[tid + ENC_THREADS * q] = make_float4(0.f, 0.f, 0.f, 0.f);
+                for (int q = 0; q < 4; ++q) reinterpret_cast<float4 *>(oh)[tid + ENC_THREADS * q] = make_float4(0.f, 0.f, 0.f, 0.f);
+            } else {
+#pragma unroll
+                for (int q = 0; q < 4; ++q) cbuf[tid + ENC_THREADS * q] = cv[q];
+                if (tid <= TG_IB) rp[tid] = rpv;
+            }
             if (vec4) {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -463,23 +481,32 @@ __device__ __forceinline__ void table_grad_rows_body(
             }
             __syncthreads();
             if (MODE == 2) {
-                if (tid < TG_IB) {                           // one thread per node: its in-edges may repeat a row
-                    for (int e = e0; e < e1; ++e) {
-                        const unsigned code = codes[e];
-                        for (int f = 0; f < F; ++f) {
-                            const int rr = (int)((code >> (8 * f)) & 255u) - r0;
-                            if (rr >= 0 && rr < TG_T) oh[tid * TG_T + rr] += 1.f;
-                        }
+                const int span0 = rp[0];
+                for (int p = tid; p < TG_IB * RT; p += ENC_THREADS) {
+                    const int item = p / RT, rr = p - item * RT;
+                    const unsigned row = (unsigned)(r0 + rr);
+                    int f = 0;
+                    for (int q = 1; q < F; ++q) f += (int)row >= m.off[q];
+                    const int sh = 8 * f;
+                    float cnt = 0.f;
+                    const int a = rp[item], b = rp[item + 1];
+                    for (int e = a; e < b; ++e) {
+                        const unsigned code = e - span0 < TG_CODES ? cbuf[e - span0] : codes[e];
+                        cnt += ((code >> sh) & 255u) == row ? 1.f : 0.f;
                     }
+                    oh[item * TG_T + rr] = cnt;
                 }
+                const long long next0 = rp[TG_IB];           // = rowptr[min(tb + 64, t_end)]: where the next block's span starts
+                prefetch_rows(tb + TG_IB);                   // past the end: clamped re-reads, never used
+                prefetch_codes(next0);
             } else {
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {                // the F rows of one item are distinct
                     const int e = tid + ENC_THREADS * q;
                     if (rows[q] >= 0 && rows[q] < TG_T) oh[(e / F) * TG_T + rows[q]] = 1.f;
                 }
+                prefetch_rows(tb + TG_IB);
             }
-            prefetch(tb + TG_IB);                            // past the end: clamped re-reads of the last row, never used
             __syncthreads();
             const float *pa = oh + hh * TG_T + wi * 32 + r;
             const float *pb = gs + hh * TG_T + wj * 32 + r;
@@ -506,8 +533,8 @@ __global__ __launch_bounds__(ENC_THREADS) void table_grad_mfma_kernel(
     const float *const *__restrict__ tables, int n, int k, int vec4, float *__restrict__ slabs) {
     __shared__ __attribute__((aligned(16))) float smem[2 * TG_IB * TG_T];
     if (MODE == 0)
-        table_grad_rows_body<0>(dout, idx, nullptr, nullptr, m, n_items, items_per_split, h, tiles_j, vec4, slabs, blockIdx.x, blockIdx.y,
-                                smem);
+        table_grad_rows_body<0>(dout, idx, nullptr, nullptr, 0, m, n_items, items_per_split, h, tiles_j, vec4, slabs, blockIdx.x,
+                                blockIdx.y, smem);
     else
         table_grad_body<MODE, ACT>(dout, idx, m, n_items, items_per_split, h, tiles_j, src, dst, x, tables, n, k, vec4, slabs, blockIdx.x,
                                    blockIdx.y, smem);
@@ -537,11 +564,11 @@ __global__ __launch_bounds__(ENC_THREADS) void table_grad_mfma_batched_kernel(
 
 // identity message function: per destination node with in-edge row counts (MODE 2), n_items = n_dst
 __global__ __launch_bounds__(ENC_THREADS) void table_grad_counted_batched_kernel(
-    TgBatch b, const int *__restrict__ rowptr, const unsigned *__restrict__ codes, EncMeta m, long long n_items,
+    TgBatch b, const int *__restrict__ rowptr, const unsigned *__restrict__ codes, long long n_edges, EncMeta m, long long n_items,
     long long items_per_split, int h, int tiles_j, int vec4) {
     const TgJobDev &jb = b.j[blockIdx.z];
     __shared__ __attribute__((aligned(16))) float smem[2 * TG_IB * TG_T];
-    table_grad_rows_body<2>(jb.dout, nullptr, rowptr, codes, m, n_items, items_per_split, h, tiles_j, vec4, jb.slabs, blockIdx.x,
+    table_grad_rows_body<2>(jb.dout, nullptr, rowptr, codes, n_edges, m, n_items, items_per_split, h, tiles_j, vec4, jb.slabs, blockIdx.x,
                             blockIdx.y, smem);
 }
 
@@ -593,6 +620,7 @@ struct TailTables {
     const long long *bond_idx, *src, *dst;
     const int *rowptr_b;                                     // counted form (identity message function): destination-sorted
     const unsigned *codes_b;                                 // row pointers + packed codes, E = number of destination nodes
+    long long n_edges_b;
     long long E, ips_b;
     int tiles_j_b, tiles_b, slabs_b, jobs_b, vec4_b;
     // atom tables (MODE 0): one job
@@ -614,7 +642,7 @@ __global__ __launch_bounds__(256) void tail_partial_kernel(GradBatch gb, TailTab
     unsigned bx = blockIdx.x;
     if (bx < t.nb_atom) {
         const int tile = bx % t.tiles_a;
-        table_grad_rows_body<0>(t.atom_dout, t.atom_idx, nullptr, nullptr, t.ma, t.N_a, t.ips_a, t.h, t.tiles_j_a, t.vec4_a, t.atom_slabs,
+        table_grad_rows_body<0>(t.atom_dout, t.atom_idx, nullptr, nullptr, 0, t.ma, t.N_a, t.ips_a, t.h, t.tiles_j_a, t.vec4_a, t.atom_slabs,
                                 tile, bx / t.tiles_a, smem);
         return;
     }
@@ -625,7 +653,7 @@ __global__ __launch_bounds__(256) void tail_partial_kernel(GradBatch gb, TailTab
         const unsigned local = bx - job * per_job;
         const TgJobDev &jb = t.bond.j[job];
         if (ACT == PHC_ACT_IDENTITY && t.codes_b)
-            table_grad_rows_body<2>(jb.dout, nullptr, t.rowptr_b, t.codes_b, t.mb, t.E, t.ips_b, t.h, t.tiles_j_b, t.vec4_b, jb.slabs,
+            table_grad_rows_body<2>(jb.dout, nullptr, t.rowptr_b, t.codes_b, t.n_edges_b, t.mb, t.E, t.ips_b, t.h, t.tiles_j_b, t.vec4_b, jb.slabs,
                                     local % t.tiles_b, local / t.tiles_b, smem);
         else
             table_grad_body<1, ACT>(jb.dout, t.bond_idx, t.mb, t.E, t.ips_b, t.h, t.tiles_j_b, t.src, t.dst, jb.x, jb.tables, t.n, t.k,
@@ -639,8 +667,11 @@ __global__ __launch_bounds__(256) void tail_partial_kernel(GradBatch gb, TailTab
     const GradJobDev &j = gb.j[k];
     const unsigned local = bx - j.blk0_partial;
     const long long xf_count = j.xf_stat ? (j.xf_n_valid ? min((long long)*j.xf_n_valid, j.N) : j.N) : 0;
-    dH_partial_body(j.x, j.dy, j.slabs, j.N, j.in, j.out, j.tiles_j, j.rows_per_split, j.vec4, local % j.tiles, local / j.tiles, smem,
-                    j.xf_stat, j.xf_act, xf_count);
+    int tile;
+    long long split;
+    xcd_tile_split(local, (unsigned)j.tiles, (unsigned)j.splits, tile, split);
+    dH_partial_body(j.x, j.dy, j.slabs, j.N, j.in, j.out, j.tiles_j, j.rows_per_split, j.vec4, tile, split, smem, j.xf_stat, j.xf_act,
+                    xf_count);
 }
 
 __global__ __launch_bounds__(256) void tail_reduce_kernel(GradBatch gb, TailTables t) {
@@ -1064,11 +1095,13 @@ size_t phc_table_grads_counted_ws_bytes(int64_t n_dst, int F, const int32_t *voc
 }
 
 int phc_table_grads_counted(const phc_table_grad_job *jobs, int num_jobs, const int32_t *rowptr, const uint32_t *codes,
-                            int64_t n_dst, const int32_t *vocab, int F, int n, int k, void *ws, size_t ws_bytes, void *stream) {
+                            int64_t n_dst, int64_t E, const int32_t *vocab, int F, int n, int k, void *ws, size_t ws_bytes,
+                            void *stream) {
     EncMeta m;
     int rc = make_meta("phc_table_grads_counted", F, vocab, &m);
     if (rc) return rc;
-    PHC_REQUIRE(num_jobs >= 1 && jobs && n_dst >= 1 && n >= 1 && k >= 1, PHC_ERR_INVALID_ARG, "phc_table_grads_counted: bad arguments");
+    PHC_REQUIRE(num_jobs >= 1 && jobs && n_dst >= 1 && E >= 1 && n >= 1 && k >= 1, PHC_ERR_INVALID_ARG,
+                "phc_table_grads_counted: bad arguments");
     PHC_REQUIRE(rowptr && codes, PHC_ERR_INVALID_ARG, "phc_table_grads_counted: null pointer");
     PHC_REQUIRE(F <= 4 && m.R <= 256, PHC_ERR_UNSUPPORTED, "phc_table_grads_counted: packed codes need F <= 4, sum(vocab) <= 256");
     PHC_REQUIRE(ws && ws_bytes >= phc_table_grads_counted_ws_bytes(n_dst, F, vocab, n, k, num_jobs), PHC_ERR_WORKSPACE,
@@ -1092,7 +1125,7 @@ int phc_table_grads_counted(const phc_table_grad_job *jobs, int num_jobs, const 
         {
             ProfScope prof(K_TABLE_GRAD, s);
             PHC_LAUNCH(table_grad_counted_batched_kernel, dim3(p.tiles_i * p.tiles_j, p.num_slabs, cn), dim3(ENC_THREADS), 0, s, b, rowptr,
-                       codes, m, (long long)n_dst, p.items_per_split, h, p.tiles_j, vec4);
+                       codes, (long long)E, m, (long long)n_dst, p.items_per_split, h, p.tiles_j, vec4);
             rc = check_launch("table_grads_counted");
             if (rc) return rc;
         }
@@ -1181,6 +1214,7 @@ int phc_step_tail(const phc_phm_grad_job *jobs, int num_jobs, const phc_table_gr
         t.E = counted ? bond_n_dst : E;
         t.rowptr_b = counted ? bond_rowptr : nullptr;
         t.codes_b = counted ? bond_codes : nullptr;
+        t.n_edges_b = E;
         t.ips_b = pb.items_per_split; t.tiles_j_b = pb.tiles_j; t.tiles_b = pb.tiles_i * pb.tiles_j; t.slabs_b = pb.num_slabs;
         t.jobs_b = num_tjobs;
         int vec4 = (k % 4 == 0);

@@ -7,6 +7,11 @@
 
 #include "phc_hip.h"
 
+// experiment switch (python -m phc_gnn_amd.build --variant noxcd -DPHC_XCD_MAP=0): XCD-aware block permutations
+#ifndef PHC_XCD_MAP
+#define PHC_XCD_MAP 1
+#endif
+
 namespace phc {
 
 // ---- error plumbing --------------------------------------------------------

@@ -312,6 +312,20 @@ struct GradBatch {
     GradJobDev j[GRAD_JOBS_PER_LAUNCH];
 };
 
+// XCD-aware (tile, split) of the `local`-th workgroup of a job: workgroups go to the 8 XCDs round-robin by block id, and
+// the tiles of one split read the same x / dy rows.  Inside every run of 8 * tiles ids the pairs are permuted so that the
+// tiles of one split sit 8 ids apart — on one XCD, whose L2 serves the re-reads (a trailing partial run keeps the plain order).
+__device__ __forceinline__ void xcd_tile_split(unsigned local, unsigned tiles, unsigned splits, int &tile, long long &split) {
+    const unsigned run = 8u * tiles, chunk = local / run, rem = local - chunk * run;
+    if (PHC_XCD_MAP && tiles > 1 && chunk * 8u + 8u <= splits) {
+        tile = (int)(rem >> 3);
+        split = chunk * 8u + (rem & 7u);
+    } else {
+        tile = (int)(local % tiles);
+        split = local / tiles;
+    }
+}
+
 template <int STAGE>
 __device__ __forceinline__ int grad_job_of_block(const GradBatch &b, unsigned bx) {
     int job = 0;

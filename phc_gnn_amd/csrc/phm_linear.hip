@@ -336,13 +336,25 @@ __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
     float *stage_all = hs + round_up(K, 8) * HS_STRIDE;        // [WAVES][ST_FLOATS]
     float *As = stage_all + WAVES * ST_FLOATS;                 // [n*n*n]
 
+    // XCD-aware block order: workgroups go to the 8 XCDs round-robin by linear id, and the gridDim.x column panels of one
+    // row-slab group read the same x rows.  Inside every run of 8 * gridDim.x consecutive ids the (panel, slab group) pairs
+    // are permuted so that the panels of one slab group sit 8 ids apart — on ONE XCD, whose L2 then serves the re-reads.
+    unsigned pbx = blockIdx.x, pby = blockIdx.y;
+    if (PHC_XCD_MAP && gridDim.x > 1) {
+        const unsigned lin = blockIdx.y * gridDim.x + blockIdx.x, run = 8u * gridDim.x;
+        const unsigned chunk = lin / run, rem = lin - chunk * run;
+        if (chunk * 8u + 8u <= gridDim.y) {
+            pbx = rem >> 3;
+            pby = chunk * 8u + (rem & 7u);
+        }
+    }
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int r = lane & 31, hh = lane >> 5;
-    const int j0 = blockIdx.x * BN;
+    const int j0 = pbx * BN;
     float *stage = stage_all + wave * ST_FLOATS;
 
     const long long num_slabs = (M + 31) / 32;
-    long long slab = (long long)blockIdx.y * WAVES + wave;
+    long long slab = (long long)pby * WAVES + wave;
     const long long slab_step = (long long)gridDim.y * WAVES;
     const int halves = (K + ST_KH - 1) / ST_KH;
     const int lrow = lane >> 4, lc4 = lane & 15;               // staging: lane -> (row lrow + 4t, float4 column lc4)
@@ -627,8 +639,8 @@ __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
             }
             const int col = j0 + cc;
             if (col < Nout) {
-                stats_partial[(size_t)blockIdx.y * 2 * Nout + col] = a;
-                stats_partial[(size_t)blockIdx.y * 2 * Nout + Nout + col] = b2;
+                stats_partial[(size_t)pby * 2 * Nout + col] = a;
+                stats_partial[(size_t)pby * 2 * Nout + Nout + col] = b2;
             }
         }
     }
@@ -665,10 +677,10 @@ __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
             }
             const int col = j0 + cc;
             if (col < Nout) {
-                stats_partial[(size_t)blockIdx.y * 2 * Nout + col] = sum;
-                stats_partial[(size_t)blockIdx.y * 2 * Nout + Nout + col] = m2;
+                stats_partial[(size_t)pby * 2 * Nout + col] = sum;
+                stats_partial[(size_t)pby * 2 * Nout + Nout + col] = m2;
             }
-            if (blockIdx.x == 0 && cc == 0) stats_counts[blockIdx.y] = nt;
+            if (pbx == 0 && cc == 0) stats_counts[pby] = nt;
         }
     }
 }
@@ -804,8 +816,9 @@ __global__ __launch_bounds__(256) void phm_grads_partial_kernel(GradBatch b) {
         if (b.j[q].blk0_partial != 0xffffffffu && blockIdx.x >= b.j[q].blk0_partial) k = q;
     const GradJobDev &j = b.j[k];
     const unsigned local = blockIdx.x - j.blk0_partial;
-    const int tile = local % j.tiles;
-    const long long split = local / j.tiles;
+    int tile;
+    long long split;
+    xcd_tile_split(local, (unsigned)j.tiles, (unsigned)j.splits, tile, split);
     __shared__ __attribute__((aligned(16))) float smem[2 * DH_RB * DH_STRIDE];      // 32 KB, either tile shape
     static_assert(2 * DH_RB * DH_STRIDE == 2 * DH_RB2 * DH_T2, "both tile shapes stage 32 KB");
     const long long xf_count = j.xf_stat ? (j.xf_n_valid ? min((long long)*j.xf_n_valid, j.N) : j.N) : 0;
@@ -1004,7 +1017,7 @@ static void grad_plans(const phc_phm_grad_job *jobs, int num, GradPlan *plans) {
         plans[k].slab_elems = (size_t)in * out + out;
         total += (int64_t)plans[k].tiles_i * plans[k].tiles_j * ((jobs[k].N + DH_RB - 1) / DH_RB);
     }
-    const int64_t target = 1024;
+    static const int64_t target = getenv("PHC_GRAD_TARGET") ? atoll(getenv("PHC_GRAD_TARGET")) : 1024;    // tuning knob
     for (int k = 0; k < num; ++k) {
         const int64_t max_splits = (jobs[k].N + DH_RB - 1) / DH_RB;
         int64_t splits = total > target ? (max_splits * target + total - 1) / total : max_splits;

@@ -91,7 +91,7 @@ SIGNATURES = {
     "phc_table_grads_ws_bytes": (_S, [_L, _I, _P, _I, _I, _I]),
     "phc_table_grads_batched": (_I, [C.POINTER(TableGradJob), _I, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P, _S, _P]),
     "phc_table_grads_counted_ws_bytes": (_S, [_L, _I, _P, _I, _I, _I]),
-    "phc_table_grads_counted": (_I, [C.POINTER(TableGradJob), _I, _P, _P, _L, _P, _I, _I, _I, _P, _S, _P]),
+    "phc_table_grads_counted": (_I, [C.POINTER(TableGradJob), _I, _P, _P, _L, _L, _P, _I, _I, _I, _P, _S, _P]),
     "phc_step_tail_ws_bytes": (_S, [C.POINTER(GradJob), _I, _I, _L, _L, _I, _P, _L, _I, _P, _I, _I]),
     "phc_step_tail": (_I, [C.POINTER(GradJob), _I, C.POINTER(TableGradJob), _I, _P, _P, _P, _P, _L, _I, _I, _P, _P, _L, _P, _P, _L, _I,
                            _P, _P, _I, _I, _P, _S, _P]),

@@ -223,8 +223,8 @@ def _flush_table_grads(jobs) -> None:
             if j0.get("codes") is not None:
                 ws_bytes = lib.phc_table_grads_counted_ws_bytes(st.num_dst, ts.F, ts.vocab_c, ts.n, ts.k, len(js))
                 ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-                L.check(lib.phc_table_grads_counted(arr, len(js), L.ptr(st.csr[0]), L.ptr(j0["codes"]), st.num_dst, ts.vocab_c,
-                                                    ts.F, ts.n, ts.k, L.ptr(ws), ws_bytes, L.stream_ptr(dev)),
+                L.check(lib.phc_table_grads_counted(arr, len(js), L.ptr(st.csr[0]), L.ptr(j0["codes"]), st.num_dst, st.num_edges,
+                                                    ts.vocab_c, ts.F, ts.n, ts.k, L.ptr(ws), ws_bytes, L.stream_ptr(dev)),
                         "phc_table_grads_counted")
             else:
                 ws_bytes = lib.phc_table_grads_ws_bytes(st.num_edges, ts.F, ts.vocab_c, ts.n, ts.k, len(js))

@@ -55,7 +55,7 @@ def capture(kind):
                 orig_p(jobs["p"])
                 s.wait_stream(side)
     return g, s
-for kind in ("p", "t", "seq", "fork"):
+for kind in (os.environ.get("TAIL_KINDS", "p,t,seq,fork").split(",")):
     g, s = capture(kind)
     rs = torch.cuda.Stream()
     with torch.cuda.stream(rs):

@@ -103,6 +103,9 @@ def run(tag, N, E, h=128, n=4, mol=False):
     wsb3 = l.phc_aggregate_enc_bwd_ws_bytes(E, 3, tsb.vocab_c, n, k); ws3 = torch.empty(wsb3, dtype=torch.uint8, device=dev)
     report("aggregate_enc_bwd (dx only)", timeit(lambda: l.phc_aggregate_enc_bwd(dy.data_ptr(), x.data_ptr(), xb.data_ptr(), tsb.ptrs.data_ptr(), tsb.vocab_c, st._src.data_ptr(), st._dst.data_ptr(), E, rt.data_ptr(), ct.data_ptr(), pt.data_ptr(), N, N, 3, n, k, 0, 1, dx.data_ptr(), None, None, 0, sp)), 0, E * (4.0 * h + 4) + N * 8.0 * h)
     report("aggregate_enc_bwd (tables only)", timeit(lambda: l.phc_aggregate_enc_bwd(dy.data_ptr(), x.data_ptr(), xb.data_ptr(), tsb.ptrs.data_ptr(), tsb.vocab_c, st._src.data_ptr(), st._dst.data_ptr(), E, rt.data_ptr(), ct.data_ptr(), pt.data_ptr(), N, N, 3, n, k, 0, 1, None, flb.data_ptr(), ws3.data_ptr(), wsb3, sp)), 0, N * 4.0 * h + E * 28.0)
+    tj = (lib.TableGradJob * 1)(lib.TableGradJob(dy.data_ptr(), None, None, flb.data_ptr()))
+    wsb4 = l.phc_table_grads_counted_ws_bytes(N, 3, tsb.vocab_c, n, k, 1); ws4 = torch.empty(wsb4, dtype=torch.uint8, device=dev)
+    report("table_grads_counted (bond tables, identity)", timeit(lambda: l.phc_table_grads_counted(tj, 1, rowptr.data_ptr(), codes.data_ptr(), N, E, tsb.vocab_c, 3, n, k, ws4.data_ptr(), wsb4, sp)), 0, N * 4.0 * h + E * 4.0 + 4.0 * (N + 1))
 
     # batch norm
     wl = [torch.rand(k, device=dev) + 0.5 for _ in range(n)]; bl = [torch.randn(k, device=dev) for _ in range(n)]
