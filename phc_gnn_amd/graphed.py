@@ -135,6 +135,7 @@ class GraphedTrainStep:
         self._pairs = phm_pairs(model)
         self._dense = dense_weights(model)
         self.replay_stream = torch.cuda.Stream(device=dev)     # never the capture stream, never the null stream
+        self._seed = torch.ones((), dtype=torch.float32, device=dev)    # d loss / d loss, resident (no fill node in the graph)
         if os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "1") != "0":
             warnings.warn("DEBUG_CLR_GRAPH_PACKET_CAPTURE is not 0: on HIP 7.0 pipelined hipGraph replays race with the "
                           "batch copies queued behind them (see phc_gnn_amd/__init__.py)", RuntimeWarning)
@@ -181,7 +182,7 @@ class GraphedTrainStep:
         with prebuilt_H(self._pairs, self._dense), deferred_param_grads():
             logits = self.model(self.data)
             loss = loss_fn(logits, self.data, self.cfg.regression)
-            loss.backward()
+            loss.backward(self._seed)
         if self.grad_sync is not None:
             self.grad_sync.pack()
         return loss

@@ -94,6 +94,17 @@ class StepConfig:
     optimizer: bool = True
 
 
+_ONE: Dict[torch.device, torch.Tensor] = {}
+
+
+def backward_seed(loss: torch.Tensor) -> torch.Tensor:
+    """d loss / d loss = 1 as a resident constant: ``loss.backward()`` would launch a fill kernel for it every step."""
+    one = _ONE.get(loss.device)
+    if one is None:
+        one = _ONE[loss.device] = torch.ones((), dtype=loss.dtype, device=loss.device)
+    return one
+
+
 def train_step(model, data, optimizer: Optional[torch.optim.Optimizer], cfg: StepConfig,
                grad_sync=None) -> torch.Tensor:
     """One iteration of the reference loop body (train_hiv.py:175-201) without the
@@ -107,7 +118,7 @@ def train_step(model, data, optimizer: Optional[torch.optim.Optimizer], cfg: Ste
     with prebuilt_H(phm_pairs(model), dense_weights(model)), deferred_param_grads():
         logits = model(data)
         loss = loss_fn(logits, data, cfg.regression)
-        loss.backward()
+        loss.backward(backward_seed(loss))
     if grad_sync is not None:
         grad_sync(model)
     if optimizer is not None and cfg.optimizer:
