@@ -200,7 +200,9 @@ def main():
         for i in range(n):
             j = (offset + i) % len(host_batches)
             if graph_step is not None and not eager:
-                graph_step.step(padded[j])                      # D2D copy into the static buffers + one graph launch
+                # D2D copy into the static buffers + one graph launch (PHC_GRAPH_PIPELINE=1: the batch's preprocessing graph
+                # was queued on a second stream by the previous call; this call launches the step graph and queues the next)
+                graph_step.step(padded[j], padded[(j + 1) % len(host_batches)] if graph_step.pipeline else None)
             else:
                 harness.train_step(model, batches[j], opt, cfg, grad_sync)
 
@@ -245,7 +247,9 @@ def main():
                    "step": "zero_grad+fwd+bce+bwd" + ("" if args.fwd_bwd_only else "+clip+adam")
                            + ("+grad_allreduce" if world > 1 else ""),
                    "launch": ("hipGraph replay of the whole step on batches padded to one bucket shape "
-                              f"({n_max} nodes, {e_max} edges) + per-step D2D batch copy") if graph_step is not None
+                              f"({n_max} nodes, {e_max} edges); per-step D2D batch copy + CSR/CSC build "
+                              + ("replayed one batch ahead on a second stream" if graph_step.pipeline else "inside the step graph"))
+                             if graph_step is not None
                              else "eager (one launch per kernel)",
                    "parallelism": f"dp{world}" if world > 1 else "single"},
     }

@@ -21,14 +21,17 @@ _NO_PAIR = bool(__import__('os').environ.get('PHC_NO_CSR_PAIR'))
 _cache: "OrderedDict[tuple, EdgeStructure]" = OrderedDict()
 
 
-def _build_sorted(key: torch.Tensor, other: Optional[torch.Tensor], num_keys: int):
-    """(rowptr[num_keys+1], col[E], perm[E]) int32 on key.device."""
+def _build_sorted(key: torch.Tensor, other: Optional[torch.Tensor], num_keys: int, out=None):
+    """(rowptr[num_keys+1], col[E], perm[E]) int32 on key.device; ``out``: rebuild into these three tensors."""
     lib = L.load()
     dev = L.require_device(key, other)
     E = key.numel()
-    rowptr = torch.empty(num_keys + 1, dtype=torch.int32, device=dev)
-    col = torch.empty(E, dtype=torch.int32, device=dev)
-    perm = torch.empty(E, dtype=torch.int32, device=dev)
+    if out is not None:
+        rowptr, col, perm = out
+    else:
+        rowptr = torch.empty(num_keys + 1, dtype=torch.int32, device=dev)
+        col = torch.empty(E, dtype=torch.int32, device=dev)
+        perm = torch.empty(E, dtype=torch.int32, device=dev)
     ws_bytes = lib.phc_csr_ws_bytes(E, num_keys)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     L.check(lib.phc_csr_build(L.ptr(key), L.ptr(other), E, num_keys, L.ptr(rowptr), L.ptr(col), L.ptr(perm),
@@ -58,6 +61,7 @@ class EdgeStructure:
         self._csr: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None
         self._csc: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None
         self._codes: dict = {}
+        self._codes_args = None
 
     def packed_codes(self, bond_idx: torch.Tensor, vocab_c, F: int) -> torch.Tensor:
         """uint32 per edge in destination-sorted order: the F table rows of the edge's integer features, one
@@ -65,17 +69,35 @@ class EdgeStructure:
         key = (bond_idx.data_ptr(), bond_idx._version, tuple(vocab_c))
         codes = self._codes.get(key)
         if codes is None:
-            lib = L.load()
-            _, _, perm = self.csr
             codes = torch.empty(self.num_edges, dtype=torch.int32, device=bond_idx.device)
-            L.check(lib.phc_pack_edge_codes(L.ptr(bond_idx), L.ptr(perm), vocab_c, self.num_edges, F, L.ptr(codes),
-                                            L.stream_ptr(bond_idx.device)), "phc_pack_edge_codes")
+            self._pack_codes(bond_idx, vocab_c, F, codes)
             self._codes = {key: codes}
+            self._codes_args = (bond_idx, vocab_c, F)
         return codes
+
+    def _pack_codes(self, bond_idx, vocab_c, F, codes) -> None:
+        _, _, perm = self.csr
+        L.check(L.load().phc_pack_edge_codes(L.ptr(bond_idx), L.ptr(perm), vocab_c, self.num_edges, F, L.ptr(codes),
+                                             L.stream_ptr(bond_idx.device)), "phc_pack_edge_codes")
+
+    def rebuild(self) -> None:
+        """Recompute every view that has been built — same tensors, new contents — after the edge list (and the bond
+        features behind the packed codes) changed IN PLACE: the per-batch preprocessing of a fixed-shape step whose
+        static buffers were reloaded (graphed.GraphedTrainStep captures this as its own small graph)."""
+        if self._csr is not None and self._csc is not None and self.num_edges > 0 and not _NO_PAIR and \
+                0 < max(self.num_src, self.num_dst) <= self.PAIR_MAX_ROWS:
+            self._build_pair(reuse=True)
+        else:
+            if self._csr is not None:
+                _build_sorted(self._dst, self._src, self.num_dst, out=self._csr)
+            if self._csc is not None:
+                _build_sorted(self._src, self._dst, self.num_src, out=self._csc)
+        for codes in self._codes.values():
+            self._pack_codes(*self._codes_args, codes)
 
     PAIR_MAX_ROWS = 16383
 
-    def _build_pair(self) -> None:
+    def _build_pair(self, reuse: bool = False) -> None:
         """Both views side by side (phc_csr_build_pair: 5 launches instead of 22)."""
         lib = L.load()
         dev = self._src.device
@@ -84,7 +106,7 @@ class EdgeStructure:
         def alloc(rows):
             return (torch.empty(rows + 1, dtype=torch.int32, device=dev), torch.empty(E, dtype=torch.int32, device=dev),
                     torch.empty(E, dtype=torch.int32, device=dev))
-        csr, csc = alloc(self.num_dst), alloc(self.num_src)
+        csr, csc = (self._csr, self._csc) if reuse else (alloc(self.num_dst), alloc(self.num_src))
         ws_bytes = lib.phc_csr_pair_ws_bytes(E, self.num_src, self.num_dst)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         L.check(lib.phc_csr_build_pair(L.ptr(self._src), L.ptr(self._dst), E, self.num_src, self.num_dst, L.ptr(csr[0]),
@@ -145,16 +167,28 @@ class SegmentStructure:
     def csr(self):
         if self._csr is None:
             if self.is_sorted:
-                lib = L.load()
                 dev = self.batch.device
                 n = self.batch.numel()
                 rowptr = torch.empty(self.num_segments + 1, dtype=torch.int32, device=dev)
-                L.check(lib.phc_segment_ptr_sorted(L.ptr(self.batch), n, self.num_segments, L.ptr(rowptr),
-                                                   L.stream_ptr(dev)), "phc_segment_ptr_sorted")
+                self._sorted_ptr(rowptr)
                 self._csr = (rowptr, _iota(n, dev), None)
             else:
                 self._csr = _build_sorted(self.batch, None, self.num_segments)
         return self._csr
+
+    def _sorted_ptr(self, rowptr) -> None:
+        dev = self.batch.device
+        L.check(L.load().phc_segment_ptr_sorted(L.ptr(self.batch), self.batch.numel(), self.num_segments, L.ptr(rowptr),
+                                                L.stream_ptr(dev)), "phc_segment_ptr_sorted")
+
+    def rebuild(self) -> None:
+        """Recompute the built view in place after ``batch`` changed in place (see EdgeStructure.rebuild)."""
+        if self._csr is None:
+            return
+        if self.is_sorted:
+            self._sorted_ptr(self._csr[0])
+        else:
+            _build_sorted(self.batch, None, self.num_segments, out=self._csr)
 
 
 def _key(t: torch.Tensor, *extra):
@@ -194,6 +228,12 @@ def segment_structure(batch: torch.Tensor, num_segments: Optional[int] = None, i
 
 def clear_structure_cache() -> None:
     _cache.clear()
+
+
+def cached_structures_of(*tensors) -> list:
+    """The cached structures that were built from any of these tensors (by storage address)."""
+    ptrs = {t.data_ptr() for t in tensors}
+    return [st for st in _cache.values() if st._pin.data_ptr() in ptrs]
 
 
 def remove_isolated_nodes(x: Optional[torch.Tensor], edge_index: torch.Tensor, batch: Optional[torch.Tensor] = None,

@@ -28,7 +28,7 @@ import numpy as np
 import torch
 
 from . import synth
-from .graph import clear_structure_cache
+from .graph import cached_structures_of, clear_structure_cache
 from .harness import StepConfig, loss_fn, optimizer_step
 from .ops import deferred_param_grads, dense_weights, phm_pairs, prebuilt_H
 
@@ -107,68 +107,114 @@ def _flat_views(flat: torch.Tensor, layout: dict) -> dict:
     return views
 
 
+class _BatchSet:
+    """One set of static batch buffers with everything captured over it."""
+    __slots__ = ("static_flat", "static", "data", "graph", "graph2", "loss", "prep", "structs", "ev_prep", "ev_main", "ready")
+
+
 class GraphedTrainStep:
-    """Static buffers + one captured hipGraph for the whole training step."""
+    """Static buffers + one captured hipGraph for the whole training step.
+
+    ``pipeline`` (opt-in, also ``PHC_GRAPH_PIPELINE=1``): the batch-dependent preprocessing — the copy of
+    the next batch into static buffers, the CSR/CSC build, the packed edge codes, the read-out segment pointers; 8
+    launches that depend on the batch only, not on the parameters — is captured as its OWN small graph over a second
+    set of static buffers and replayed on a second stream while the previous step still runs (``step(batch,
+    next_batch)``: a data-loader prefetch).  The step graph proper is captured once per buffer set and finds the
+    structures prebuilt.  Two events per step order the two streams.  Measured on ROCm 7.0 with the graph packet
+    capture disabled (phc_gnn_amd/__init__.py): bit-identical results, but 0.87 ms instead of 0.81 ms per molhiv step —
+    the host enqueues graph nodes one by one (~8 us each, ~780 us per step, as long as the GPU needs), so a second graph
+    launch and two events per step cost more host time than the 8 launches they take off the GPU's critical path.
+    Hence off by default; it pays once graph launches are cheap again."""
 
     TENSORS = FLAT_TENSORS
 
-    def __init__(self, model, optimizer, cfg: StepConfig, example: dict, grad_sync=None, warmup: int = 3):
+    def __init__(self, model, optimizer, cfg: StepConfig, example: dict, grad_sync=None, warmup: int = 3,
+                 pipeline: Optional[bool] = None):
         """``grad_sync``: optional ``phc_gnn_amd.dist.FlatGradSync`` (data-parallel ranks).  The step is then
         captured as TWO graphs — [forward, loss, backward, pack gradients into the flat bucket] and
         [unpack, clip, Adam] — with the RCCL all-reduce of the bucket issued eagerly between them."""
         self.model, self.optimizer, self.cfg, self.grad_sync = model, optimizer, cfg, grad_sync
+        if pipeline is None:
+            pipeline = os.environ.get("PHC_GRAPH_PIPELINE", "0") == "1"
+        self.pipeline = bool(pipeline)
         dev = example["x"].device
-        if "_flat" in example:                      # batch arrays live in one flat buffer: one copy per step
-            self.static_flat, self.layout = example["_flat"].clone(), example["_layout"]
-            self.static = _flat_views(self.static_flat, self.layout)
-        else:
-            self.static_flat, self.layout = None, None
-            self.static = {k: example[k].clone() for k in self.TENSORS}
         B = int(example["num_graphs"])
-        self.data = types.SimpleNamespace(
-            x=self.static["x"], edge_index=self.static["edge_index"], edge_attr=self.static["edge_attr"],
-            batch=self.static["batch"], y=self.static["y"], num_graphs=B + PAD_GRAPHS,
-            n_valid_nodes=self.static["n_valid_nodes"],
-            n_valid_graphs=torch.tensor(B, dtype=torch.int32, device=dev), all_labeled=False)
-        self.loss = None
+        n_valid_graphs = torch.tensor(B, dtype=torch.int32, device=dev)
+        self.sets: List[_BatchSet] = []
+        for _ in range(2 if self.pipeline else 1):
+            bs = _BatchSet()
+            if "_flat" in example:                  # batch arrays live in one flat buffer: one copy per step
+                bs.static_flat = example["_flat"].clone()
+                bs.static = _flat_views(bs.static_flat, example["_layout"])
+            else:
+                bs.static_flat = None
+                bs.static = {k: example[k].clone() for k in self.TENSORS}
+            bs.data = types.SimpleNamespace(
+                x=bs.static["x"], edge_index=bs.static["edge_index"], edge_attr=bs.static["edge_attr"],
+                batch=bs.static["batch"], y=bs.static["y"], num_graphs=B + PAD_GRAPHS,
+                n_valid_nodes=bs.static["n_valid_nodes"], n_valid_graphs=n_valid_graphs, all_labeled=False)
+            bs.graph = bs.graph2 = bs.loss = bs.prep = None
+            bs.structs = []
+            bs.ev_prep, bs.ev_main, bs.ready = torch.cuda.Event(), torch.cuda.Event(), False
+            self.sets.append(bs)
+        self.layout = example.get("_layout")
+        self._cur = 0
         self.device = dev
         self._pairs = phm_pairs(model)
         self._dense = dense_weights(model)
         self.replay_stream = torch.cuda.Stream(device=dev)     # never the capture stream, never the null stream
+        self.prep_stream = torch.cuda.Stream(device=dev) if self.pipeline else None
         self._seed = torch.ones((), dtype=torch.float32, device=dev)    # d loss / d loss, resident (no fill node in the graph)
         if os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "1") != "0":
             warnings.warn("DEBUG_CLR_GRAPH_PACKET_CAPTURE is not 0: on HIP 7.0 pipelined hipGraph replays race with the "
                           "batch copies queued behind them (see phc_gnn_amd/__init__.py)", RuntimeWarning)
-        self.graph = torch.cuda.CUDAGraph()
         # Warm-up (allocator pools, lazy library initialisation, pointer tables) and capture run on ONE
         # dedicated stream, so that autograd's per-parameter AccumulateGrad nodes, the optimizer state and
         # the captured kernels all agree on the stream (no cross-stream edges inside the graph).
         self.stream = torch.cuda.Stream(device=dev)
+        self.stream2 = torch.cuda.Stream(device=dev) if grad_sync is not None else None
         self.stream.wait_stream(torch.cuda.current_stream(dev))
         with torch.cuda.stream(self.stream):
             for _ in range(warmup):
-                self._body()
+                self._body(self.sets[0])
         self.stream.synchronize()
-        gc.collect()                       # drop the warm-up autograd graphs before capturing
-        clear_structure_cache()            # the CSR/CSC build must be captured, not served from the cache
-        self.optimizer.zero_grad(set_to_none=True)
-        self.graph2 = None
-        if self.grad_sync is None:
-            with torch.cuda.graph(self.graph, stream=self.stream):
-                self.loss = self._body()
-        else:
-            with torch.cuda.graph(self.graph, stream=self.stream):
-                self.loss = self._front()
-            # second half on its own stream (the first capture stream is never touched again), same memory pool
-            self.stream2 = torch.cuda.Stream(device=dev)
-            self.graph2 = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(self.graph2, pool=self.graph.pool(), stream=self.stream2):
-                self._back()
+        pool = None
+        for bs in self.sets:
+            gc.collect()                       # drop the warm-up autograd graphs before capturing
+            clear_structure_cache()
+            if self.pipeline:
+                # one more eager step over THIS set fills the structure cache with exactly what the step walks; the
+                # preprocessing graph recomputes those structures in place, the step graph is captured with the cache
+                # still holding them (no static buffer is written in between: the cache keys carry tensor versions)
+                with torch.cuda.stream(self.stream):
+                    self._body(bs)
+                self.stream.synchronize()
+                bs.structs = cached_structures_of(bs.data.edge_index, bs.data.batch)
+                bs.prep = torch.cuda.CUDAGraph()
+                cap = torch.cuda.Stream(device=dev)
+                with torch.cuda.graph(bs.prep, stream=cap):
+                    for st in bs.structs:
+                        st.rebuild()
+                gc.collect()
+            self.optimizer.zero_grad(set_to_none=True)
+            bs.graph = torch.cuda.CUDAGraph()
+            kw = {} if pool is None else {"pool": pool}
+            if self.grad_sync is None:
+                with torch.cuda.graph(bs.graph, stream=self.stream, **kw):
+                    bs.loss = self._body(bs)
+            else:
+                with torch.cuda.graph(bs.graph, stream=self.stream, **kw):
+                    bs.loss = self._front(bs)
+                # second half on its own stream (the first capture stream is never touched again), same memory pool
+                bs.graph2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(bs.graph2, pool=bs.graph.pool(), stream=self.stream2):
+                    self._back()
+            pool = bs.graph.pool()             # the step graphs of the two sets never run concurrently: one pool
+            # Drop the captured autograd graph (its AccumulateGrad nodes are bound to the capture stream; a later
+            # eager backward of the same model would otherwise enqueue work on that stream).  The loss buffer
+            # itself stays: it is the graph's output.
+            bs.loss = bs.loss.detach()
         clear_structure_cache()
-        # Drop the captured autograd graph (its AccumulateGrad nodes are bound to the capture stream; a later
-        # eager backward of the same model would otherwise enqueue work on that stream).  The loss buffer
-        # itself stays: it is the graph's output.
-        self.loss = self.loss.detach()
         gc.collect()
         # NOTE: only a device-wide synchronize here.  Making the default stream wait on the capture stream
         # (Stream.wait_stream -> an event recorded on the just-captured stream) left the graph in a state where
@@ -176,12 +222,37 @@ class GraphedTrainStep:
         # scripts/debug_pipelined.py reproduces the family).
         torch.cuda.synchronize(dev)
 
-    def _front(self):
+    # the single-set attributes of the non-pipelined form (tests, scripts)
+    @property
+    def static(self):
+        return self.sets[self._cur].static
+
+    @property
+    def static_flat(self):
+        return self.sets[self._cur].static_flat
+
+    @property
+    def data(self):
+        return self.sets[self._cur].data
+
+    @property
+    def loss(self):
+        return self.sets[self._cur].loss
+
+    @property
+    def graph(self):
+        return self.sets[self._cur].graph
+
+    @property
+    def graph2(self):
+        return self.sets[self._cur].graph2
+
+    def _front(self, bs: _BatchSet):
         """zero_grad, forward, loss, backward (+ pack the gradients into the flat all-reduce bucket)."""
         self.optimizer.zero_grad(set_to_none=True)
         with prebuilt_H(self._pairs, self._dense), deferred_param_grads():
-            logits = self.model(self.data)
-            loss = loss_fn(logits, self.data, self.cfg.regression)
+            logits = self.model(bs.data)
+            loss = loss_fn(logits, bs.data, self.cfg.regression)
             loss.backward(self._seed)
         if self.grad_sync is not None:
             self.grad_sync.pack()
@@ -194,45 +265,81 @@ class GraphedTrainStep:
         if self.cfg.optimizer:
             optimizer_step(self.model, self.optimizer, self.cfg)
 
-    def _body(self):
-        loss = self._front()
+    def _body(self, bs: _BatchSet):
+        loss = self._front(bs)
         if self.grad_sync is not None:
             self.grad_sync.reduce()
         self._back()
         return loss
 
-    def load(self, padded: dict) -> None:
-        """Device-to-device copy of one padded, HBM-resident batch into the static buffers."""
-        if self.static_flat is not None and padded.get("_flat") is not None and \
-                padded["_flat"].numel() == self.static_flat.numel():
-            self.static_flat.copy_(padded["_flat"], non_blocking=True)
+    def _load_into(self, bs: _BatchSet, padded: dict) -> None:
+        if bs.static_flat is not None and padded.get("_flat") is not None and \
+                padded["_flat"].numel() == bs.static_flat.numel():
+            bs.static_flat.copy_(padded["_flat"], non_blocking=True)
             return
         for k in self.TENSORS:
-            self.static[k].copy_(padded[k], non_blocking=True)
+            bs.static[k].copy_(padded[k], non_blocking=True)
 
-    def step(self, padded: Optional[dict] = None) -> torch.Tensor:
-        """Load one padded batch and replay.  Stream-ordered with the caller's current stream, but the copy and the
-        graph launch themselves are issued on a dedicated NON-DEFAULT stream: on ROCm 7.2 a hipGraphLaunch into the
-        legacy null stream is not ordered against the null-stream work queued behind it, so the next batch's copy
+    def load(self, padded: dict) -> None:
+        """Device-to-device copy of one padded, HBM-resident batch into the (current) static buffers."""
+        self._load_into(self.sets[self._cur], padded)
+
+    def step(self, padded: Optional[dict] = None, next_padded: Optional[dict] = None) -> torch.Tensor:
+        """Load one padded batch and replay; ``next_padded`` (pipelined form) is the batch of the NEXT call, whose
+        preprocessing starts now on the second stream.  Stream-ordered with the caller's current stream, but the copy
+        and the graph launch themselves are issued on a dedicated NON-DEFAULT stream: on ROCm 7.2 a hipGraphLaunch into
+        the legacy null stream is not ordered against the null-stream work queued behind it, so the next batch's copy
         overwrote the static buffers of a replay still in flight (scripts/debug_bench_like.py reproduces the fault)."""
         cur = torch.cuda.current_stream(self.device)
         if cur != torch.cuda.default_stream(self.device):
-            self._issue(padded)                # caller already runs on a side stream (bench.py: `with step.on_stream():`)
-            return self.loss
+            return self._issue(padded, next_padded)    # caller already runs on a side stream (`with step.on_stream():`)
         rs = self.replay_stream                # default stream: hop over to the replay stream and back (two event waits)
         rs.wait_stream(cur)
         with torch.cuda.stream(rs):
-            self._issue(padded)
+            loss = self._issue(padded, next_padded)
         cur.wait_stream(rs)
-        return self.loss
+        return loss
 
-    def _issue(self, padded: Optional[dict]) -> None:
-        if padded is not None:
-            self.load(padded)
-        self.graph.replay()
-        if self.graph2 is not None:
+    def _prepare(self, bs: _BatchSet, padded: dict) -> None:
+        """Queue one batch's preprocessing on the second stream: it may start as soon as the step that last read this
+        buffer set has finished."""
+        ps = self.prep_stream
+        ps.wait_event(bs.ev_main)
+        with torch.cuda.stream(ps):
+            self._load_into(bs, padded)
+            bs.prep.replay()
+            bs.ev_prep.record(ps)
+        bs.ready = padded
+
+    def _issue(self, padded: Optional[dict], next_padded: Optional[dict] = None) -> torch.Tensor:
+        main = torch.cuda.current_stream(self.device)
+        if not self.pipeline:
+            bs = self.sets[0]
+            if padded is not None:
+                self._load_into(bs, padded)
+        else:
+            if padded is not None:
+                nxt = self.sets[1 - self._cur]
+                if nxt.ready is padded:                        # prefetched by the previous call
+                    self._cur = 1 - self._cur
+                else:
+                    # no prefetch: this call's own preprocessing, still on the second stream (the buffer set that is
+                    # not being read by the step in flight)
+                    self._cur = 1 - self._cur
+                    self.prep_stream.wait_stream(main)
+                    self._prepare(self.sets[self._cur], padded)
+            bs = self.sets[self._cur]
+            if bs.ready is not False:
+                main.wait_event(bs.ev_prep)
+        bs.graph.replay()
+        if bs.graph2 is not None:
             self.grad_sync.reduce()            # eager RCCL all-reduce of the flat bucket (stream-ordered)
-            self.graph2.replay()
+            bs.graph2.replay()
+        if self.pipeline:
+            bs.ev_main.record(main)
+            if next_padded is not None:
+                self._prepare(self.sets[1 - self._cur], next_padded)
+        return bs.loss
 
     def on_stream(self):
         """Context manager that makes the replay stream current: a training loop run inside it pays no per-step

@@ -271,6 +271,36 @@ def test_graphed_step_pipelined_replays_do_not_race_with_batch_loads(where):
     assert all(torch.equal(results[0][1][k], results[1][1][k]) for k in base)
 
 
+def test_graphed_step_prefetched_preprocessing_equals_the_single_graph_step():
+    """The pipelined form (batch preprocessing one step ahead on a second stream, two buffer sets) must reproduce the
+    single-graph step bit for bit — losses of every step and the parameters afterwards — with and without prefetch."""
+    from phc_gnn_amd import graphed, harness
+    from phc_gnn_amd.optim import ClipAdam
+    wl = "molhiv_b512"
+    gbs = [harness.make_batch(wl, seed=s) for s in range(5)]
+    n_max, e_max = graphed.bucket_shape(gbs)
+    padded = [graphed.padded_to_device(graphed.pad_batch(g, n_max, e_max), DEV) for g in gbs]
+    base = {k: v.clone() for k, v in _fresh(wl, seed=4)[0].state_dict().items()}
+    results = {}
+    for mode in ("single", "pipelined", "pipelined+prefetch"):
+        m = _fresh(wl, seed=4)[0]
+        o = ClipAdam(m.parameters(), lr=1e-3)
+        step = graphed.GraphedTrainStep(m, o, harness.StepConfig(), padded[0], warmup=1, pipeline=mode != "single")
+        m.load_state_dict(base)
+        o.step_count.zero_(); o.exp_avg_flat.zero_(); o.exp_avg_sq_flat.zero_()
+        torch.cuda.synchronize()
+        losses = []
+        with step.on_stream():
+            for i in range(23):
+                nxt = padded[(i + 1) % 5] if mode.endswith("prefetch") else None
+                losses.append(step.step(padded[i % 5], nxt).clone())
+            torch.cuda.synchronize()
+        results[mode] = ([float(l) for l in losses], {k: v.clone() for k, v in m.state_dict().items()})
+    for mode in ("pipelined", "pipelined+prefetch"):
+        assert results[mode][0] == results["single"][0], mode
+        assert all(torch.equal(results[mode][1][k], results["single"][1][k]) for k in base), mode
+
+
 def test_graphed_step_with_the_engine_optimizer_tracks_the_torch_optimizer():
     """Captured step with phc_gnn_amd.optim.ClipAdam (clip + Adam in three launches) vs the same step with
     clip_grad_norm_ + torch.optim.Adam: losses over several steps and the parameters afterwards."""
