@@ -33,6 +33,8 @@ static const char *const kKernelNames[K_NUM_KERNELS] = {
 bool g_prof_on = false;
 bool g_ablate[K_NUM_KERNELS] = {};
 thread_local bool tl_ablate = false;
+thread_local hipEvent_t tl_prof_start = nullptr, tl_prof_stop = nullptr;
+static const bool g_prof_event_pair = getenv("PHC_PROF_EVENT_PAIR") != nullptr;
 
 // PHC_ABLATE is read once, when the library is loaded
 static const bool g_ablate_init = [] {
@@ -78,14 +80,23 @@ void prof_begin(int kid, hipStream_t s, int *slot) {
         }
     }
     p.kid = kid;
-    hipEventRecord(p.start, s);
+    if (g_prof_event_pair) {
+        hipEventRecord(p.start, s);
+    } else {
+        tl_prof_start = p.start;                 // PHC_LAUNCH hands them to hipExtLaunchKernelGGL
+        tl_prof_stop = p.stop;
+    }
     g_slots.push_back(p);
     *slot = (int)g_slots.size() - 1;
 }
 
 void prof_end(int slot, hipStream_t s) {
     std::lock_guard<std::mutex> lk(g_prof_mu);
-    if (slot >= 0 && slot < (int)g_slots.size()) hipEventRecord(g_slots[slot].stop, s);
+    if (g_prof_event_pair) {
+        if (slot >= 0 && slot < (int)g_slots.size()) hipEventRecord(g_slots[slot].stop, s);
+    } else {
+        tl_prof_start = tl_prof_stop = nullptr;
+    }
 }
 
 static void prof_drain_locked() {

@@ -2,7 +2,11 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
+#include <tuple>
+#include <type_traits>
+#include <utility>
 #include <stdio.h>
 
 #include "phc_hip.h"
@@ -75,6 +79,12 @@ void prof_end(int slot, hipStream_t s);
 extern bool g_ablate[];
 extern thread_local bool tl_ablate;
 
+// Launch profiler: the launch inside a profiled ProfScope goes through hipExtLaunchKernelGGL with the scope's event
+// pair, which the runtime stamps with the dispatch's own begin / end times (what rocprofv3's kernel trace reports) —
+// an event recorded before and after the launch would add the dispatch latency of two extra barrier packets
+// (measured: 16 us instead of 11-13 us for the molecule-scale GEMM).  PHC_PROF_EVENT_PAIR=1 selects that older form.
+extern thread_local hipEvent_t tl_prof_start, tl_prof_stop;
+
 struct ProfScope {
     int slot = -1;
     hipStream_t s;
@@ -88,9 +98,34 @@ struct ProfScope {
     }
 };
 
-#define PHC_LAUNCH(...)                                          \
-    do {                                                         \
-        if (!phc::tl_ablate) hipLaunchKernelGGL(__VA_ARGS__);    \
+// hipExtLaunchKernelGGL wants every kernel parameter spelled out; this form value-initialises the trailing ones a call
+// leaves to their defaults (every default parameter of this library's kernels is nullptr / 0 — keep it that way).
+template <typename... Formals, typename... Actuals, size_t... I>
+inline void ext_launch_impl(void (*kernel)(Formals...), dim3 grid, dim3 block, unsigned shmem, hipStream_t s, hipEvent_t e0,
+                            hipEvent_t e1, std::index_sequence<I...>, Actuals... actuals) {
+    static_assert(sizeof...(Actuals) <= sizeof...(Formals), "too many kernel arguments");
+    std::tuple<std::remove_cv_t<Formals>...> formals{};
+    std::tuple<Actuals...> given{actuals...};
+    ((std::get<I>(formals) = std::get<I>(given)), ...);
+    void *args[sizeof...(Formals)];
+    size_t n = 0;
+    std::apply([&](auto &...f) { ((args[n++] = (void *)&f), ...); }, formals);
+    hipExtLaunchKernel(reinterpret_cast<void *>(kernel), grid, block, args, shmem, s, e0, e1, 0);
+}
+template <typename... Formals, typename... Actuals>
+inline void ext_launch(void (*kernel)(Formals...), dim3 grid, dim3 block, unsigned shmem, hipStream_t s, hipEvent_t e0,
+                       hipEvent_t e1, Actuals... actuals) {
+    ext_launch_impl(kernel, grid, block, shmem, s, e0, e1, std::index_sequence_for<Actuals...>{}, actuals...);
+}
+
+#define PHC_LAUNCH(kernel, grid, block, shmem, stream, ...)                                                               \
+    do {                                                                                                                  \
+        if (!phc::tl_ablate) {                                                                                            \
+            if (phc::tl_prof_start)                                                                                       \
+                phc::ext_launch(kernel, grid, block, shmem, stream, phc::tl_prof_start, phc::tl_prof_stop, __VA_ARGS__);  \
+            else                                                                                                          \
+                hipLaunchKernelGGL(kernel, grid, block, shmem, stream, __VA_ARGS__);                                      \
+        }                                                                                                                 \
     } while (0)
 
 inline int check_launch(const char *what) {
