@@ -426,14 +426,27 @@ __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
         // round of coalesced loads instead of the A -> W -> assemble chain (3.6 us of a 13 us launch at molecule scale)
         const int K8 = round_up(K, 8);
         if ((Nout & 3) == 0) {
+            // four clamped (never branched) 16-byte loads per thread in flight, then the LDS writes: a conditional load
+            // is a branch with a vmcnt(0) at its join, i.e. one L2 round trip per iteration
             constexpr int C4 = BN / 4;
-            for (int e = tid; e < K8 * C4; e += THREADS) {
-                const int k = e / C4, c4 = e - k * C4;
-                const int col = j0 + c4 * 4;
-                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-                if (k < K && col < Nout) v = *reinterpret_cast<const float4 *>(W + (size_t)k * Nout + col);
-                float *d = hs + k * HS_STRIDE + c4 * 4;
-                d[0] = v.x; d[1] = v.y; d[2] = v.z; d[3] = v.w;
+            for (int e0 = 0; e0 < K8 * C4; e0 += 4 * THREADS) {
+                f32x4 v[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int e = e0 + tid + u * THREADS;
+                    const int k = e / C4, c4 = e - k * C4;
+                    v[u] = *reinterpret_cast<const f32x4 *>(W + (size_t)min(k, K - 1) * Nout + min(j0 + c4 * 4, Nout - 4));
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int e = e0 + tid + u * THREADS;
+                    const int k = e / C4, c4 = e - k * C4;
+                    if (e < K8 * C4) {
+                        const bool ok = k < K && j0 + c4 * 4 < Nout;
+                        float *d = hs + k * HS_STRIDE + c4 * 4;
+                        d[0] = ok ? v[u][0] : 0.f; d[1] = ok ? v[u][1] : 0.f; d[2] = ok ? v[u][2] : 0.f; d[3] = ok ? v[u][3] : 0.f;
+                    }
+                }
             }
         } else {
             for (int e = tid; e < K8 * BN; e += THREADS) {
