@@ -468,6 +468,19 @@ __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
         for (int ct = 0; ct < CT; ++ct)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[ct][i] = 0.f;
+        // BW: the norm-input rows the epilogue needs go in flight now (clamped, unconditional), under the MFMAs
+        f32x4 bwx[BW ? CT : 1][4];
+        if constexpr (BW) {
+#pragma unroll
+            for (int ct = 0; ct < CT; ++ct)
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    const int idx = lane + 64 * t;
+                    const long long grow = min(slab * 32 + (idx >> 3), M - 1);
+                    const int col = min(j0 + ct * 32 + (idx & 7) * 4, max(Nout - 4, 0));
+                    bwx[ct][t] = *reinterpret_cast<const f32x4 *>(bw_x + (size_t)grow * Nout + col);
+                }
+        }
 
         for (int half = 0; half < halves; ++half) {
             const int k0 = half * ST_KH;
@@ -582,8 +595,8 @@ __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
                         }
                         if constexpr (BW) {
                             if (grow < bw_count) {
-                                const float4 x4 = *reinterpret_cast<const float4 *>(bw_x + (size_t)grow * Nout + col);
-                                const float xs_[4] = {x4.x, x4.y, x4.z, x4.w}, vs_[4] = {v.x, v.y, v.z, v.w};
+                                const f32x4 x4 = bwx[ct][t];
+                                const float xs_[4] = {x4[0], x4[1], x4[2], x4[3]}, vs_[4] = {v.x, v.y, v.z, v.w};
                                 const float mm[4] = {bw_mean[ct].x, bw_mean[ct].y, bw_mean[ct].z, bw_mean[ct].w};
                                 const float ii[4] = {bw_inv[ct].x, bw_inv[ct].y, bw_inv[ct].z, bw_inv[ct].w};
                                 const float ww[4] = {bw_w[ct].x, bw_w[ct].y, bw_w[ct].z, bw_w[ct].w};
