@@ -429,7 +429,7 @@ __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
             // four clamped (never branched) 16-byte loads per thread in flight, then the LDS writes: a conditional load
             // is a branch with a vmcnt(0) at its join, i.e. one L2 round trip per iteration
             constexpr int C4 = BN / 4;
-            for (int e0 = 0; e0 < K8 * C4; e0 += 4 * THREADS) {
+            auto panel_chunk = [&](int e0) {
                 f32x4 v[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
@@ -447,7 +447,11 @@ __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
                         d[0] = ok ? v[u][0] : 0.f; d[1] = ok ? v[u][1] : 0.f; d[2] = ok ? v[u][2] : 0.f; d[3] = ok ? v[u][3] : 0.f;
                     }
                 }
-            }
+            };
+            // the first chunk (all of a K <= 128, 32-column panel) is straight-line code: at a loop header hipcc drains
+            // every load in flight (vmcnt(0)), which put the x slab's round trip in front of the panel's instead of beside it
+            panel_chunk(0);
+            for (int e0 = 4 * THREADS; e0 < K8 * C4; e0 += 4 * THREADS) panel_chunk(e0);
         } else {
             for (int e = tid; e < K8 * BN; e += THREADS) {
                 const int k = e / BN, jj = e - k * BN;
