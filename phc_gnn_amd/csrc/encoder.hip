@@ -192,7 +192,26 @@ __global__ __launch_bounds__(ENC_THREADS) void aggregate_encp_fwd_kernel(
         const int e_begin = rowptr[d], e_end = rowptr[d + 1];
         for (int c4 = li; c4 < h4; c4 += LPR) {
             float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
+            // the self row goes in flight first (pointer select, no branch): it used to be a serial round trip at the end
+            const float4 selfv = reinterpret_cast<const float4 *>(x + (add_self ? (size_t)d * h : 0))[c4];
             int e = e_begin + grp;
+            if (e_begin < e_end) {                           // wave-uniform
+                // the first two edges of every lane group with clamped indices: col / codes of both in one round trip,
+                // then both row gathers in one (molecule graphs rarely have more: in-degree 2-4)
+                const int i0 = min(e, e_end - 1), i1 = min(e + G, e_end - 1);
+                const int s0 = col[i0], s1 = col[i1];
+                const unsigned k0 = codes[i0], k1 = codes[i1];
+                float4 v0 = reinterpret_cast<const float4 *>(x + (size_t)s0 * h)[c4];
+                float4 v1 = reinterpret_cast<const float4 *>(x + (size_t)s1 * h)[c4];
+                add_code_rows<F>(v0, tbl, k0, h, c4);
+                add_code_rows<F>(v1, tbl, k1, h, c4);
+                const bool h0 = e < e_end, h1 = e + G < e_end;
+                acc0.x += h0 ? act_fwd<ACT>(v0.x) : 0.f; acc0.y += h0 ? act_fwd<ACT>(v0.y) : 0.f;
+                acc0.z += h0 ? act_fwd<ACT>(v0.z) : 0.f; acc0.w += h0 ? act_fwd<ACT>(v0.w) : 0.f;
+                acc1.x += h1 ? act_fwd<ACT>(v1.x) : 0.f; acc1.y += h1 ? act_fwd<ACT>(v1.y) : 0.f;
+                acc1.z += h1 ? act_fwd<ACT>(v1.z) : 0.f; acc1.w += h1 ? act_fwd<ACT>(v1.w) : 0.f;
+                e += 2 * G;
+            }
             for (; e + G < e_end; e += 2 * G) {
                 const int s0 = col[e], s1 = col[e + G];
                 const unsigned k0 = codes[e], k1 = codes[e + G];
@@ -215,9 +234,63 @@ __global__ __launch_bounds__(ENC_THREADS) void aggregate_encp_fwd_kernel(
                 acc.z += __shfl_xor(acc.z, off, WAVE); acc.w += __shfl_xor(acc.w, off, WAVE);
             }
             if (grp == 0) {
-                if (add_self) acc4(acc, reinterpret_cast<const float4 *>(x + (size_t)d * h)[c4]);
+                if (add_self) acc4(acc, selfv);
                 reinterpret_cast<float4 *>(out + (size_t)d * h)[c4] = acc;
             }
+        }
+    }
+}
+
+// The same aggregation for small destination counts (molecule batches): no LDS copy of the tables.  Staging them costs
+// every workgroup a pointer-table hop, a table round trip and two barriers before its first row (about half of an 11 us
+// launch when a workgroup owns only a handful of rows); here every wavefront owns ONE row and reads the F table rows of an
+// edge from L2 in the same round trip as the edge's source row: rowptr | table pointers -> col, codes -> rows -> store.
+template <int LPR, int ACT, int F>
+__global__ __launch_bounds__(ENC_THREADS) void aggregate_encp_direct_fwd_kernel(
+    const float *__restrict__ x, const unsigned *__restrict__ codes, const float *const *__restrict__ tables, EncMeta m,
+    const int *__restrict__ rowptr, const int *__restrict__ col, long long n_dst, int n, int k, int add_self,
+    float *__restrict__ out) {
+    const int h = n * k, h4 = h >> 2;
+    constexpr int G = WAVE / LPR;
+    const int lane = threadIdx.x & 63;
+    const int grp = lane / LPR, li = lane - grp * LPR;
+    const long long d = ((long long)blockIdx.x * ENC_THREADS + threadIdx.x) >> 6;
+    if (d >= n_dst) return;                                  // wave-uniform
+    const int e_begin = rowptr[d], e_end = rowptr[d + 1];
+    for (int c4 = li; c4 < h4; c4 += LPR) {
+        const int c = (c4 * 4) / k, kk = c4 * 4 - c * k;
+        const float *tp[F];                                  // this lane's slice of its component's F tables
+#pragma unroll
+        for (int f = 0; f < F; ++f) tp[f] = tables[c * F + f] + kk - (size_t)m.off[f] * k;      // codes hold off_f + value
+        const float4 selfv = reinterpret_cast<const float4 *>(x + (add_self ? (size_t)d * h : 0))[c4];
+        float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
+        auto message = [&](int s, unsigned code) {
+            float4 v = reinterpret_cast<const float4 *>(x + (size_t)s * h)[c4];
+#pragma unroll
+            for (int f = 0; f < F; ++f) acc4(v, *reinterpret_cast<const float4 *>(tp[f] + (size_t)((code >> (8 * f)) & 255u) * k));
+            v.x = act_fwd<ACT>(v.x); v.y = act_fwd<ACT>(v.y); v.z = act_fwd<ACT>(v.z); v.w = act_fwd<ACT>(v.w);
+            return v;
+        };
+        int e = e_begin + grp;
+        if (e_begin < e_end) {                               // wave-uniform: first two edges per lane group, clamped indices
+            const int i0 = min(e, e_end - 1), i1 = min(e + G, e_end - 1);
+            const int s0 = col[i0], s1 = col[i1];
+            const unsigned k0 = codes[i0], k1 = codes[i1];
+            const float4 v0 = message(s0, k0), v1 = message(s1, k1);
+            if (e < e_end) acc4(acc0, v0);
+            if (e + G < e_end) acc4(acc1, v1);
+            e += 2 * G;
+        }
+        for (; e < e_end; e += G) acc4(acc0, message(col[e], codes[e]));
+        float4 acc = make_float4(acc0.x + acc1.x, acc0.y + acc1.y, acc0.z + acc1.z, acc0.w + acc1.w);
+#pragma unroll
+        for (int off = LPR; off < WAVE; off <<= 1) {
+            acc.x += __shfl_xor(acc.x, off, WAVE); acc.y += __shfl_xor(acc.y, off, WAVE);
+            acc.z += __shfl_xor(acc.z, off, WAVE); acc.w += __shfl_xor(acc.w, off, WAVE);
+        }
+        if (grp == 0) {
+            if (add_self) acc4(acc, selfv);
+            reinterpret_cast<float4 *>(out + (size_t)d * h)[c4] = acc;
         }
     }
 }
@@ -252,7 +325,23 @@ __global__ __launch_bounds__(ENC_THREADS) void aggregate_enc_dx_kernel(
             float4 xs = make_float4(0.f, 0.f, 0.f, 0.f);
             if (ACT != PHC_ACT_IDENTITY) xs = reinterpret_cast<const float4 *>(x + (size_t)s * h)[c4];
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
-            for (int e = e_begin + grp; e < e_end; e += G) {
+            // the self row goes in flight first (pointer select, no branch) instead of a serial round trip at the end
+            const bool self_on = add_self && s < n_dst;
+            const float4 selfv = reinterpret_cast<const float4 *>(dout + (self_on ? (size_t)s * h : 0))[c4];
+            int e = e_begin + grp;
+            if (ACT == PHC_ACT_IDENTITY && e_begin < e_end) {                // wave-uniform
+                // identity message function: the first two out-edges of every lane group with clamped indices — both
+                // column indices in one round trip, both row gathers in the next
+                const int i0 = min(e, e_end - 1), i1 = min(e + G, e_end - 1);
+                const int d0 = col_t[i0], d1 = col_t[i1];
+                const float4 g0 = reinterpret_cast<const float4 *>(dout + (size_t)d0 * h)[c4];
+                const float4 g1 = reinterpret_cast<const float4 *>(dout + (size_t)d1 * h)[c4];
+                const bool h0 = e < e_end, h1 = e + G < e_end;
+                acc.x += (h0 ? g0.x : 0.f) + (h1 ? g1.x : 0.f); acc.y += (h0 ? g0.y : 0.f) + (h1 ? g1.y : 0.f);
+                acc.z += (h0 ? g0.z : 0.f) + (h1 ? g1.z : 0.f); acc.w += (h0 ? g0.w : 0.f) + (h1 ? g1.w : 0.f);
+                e += 2 * G;
+            }
+            for (; e < e_end; e += G) {
                 float4 g = reinterpret_cast<const float4 *>(dout + (size_t)col_t[e] * h)[c4];
                 if (ACT != PHC_ACT_IDENTITY) {
                     const long long p = perm_t[e];
@@ -270,7 +359,7 @@ __global__ __launch_bounds__(ENC_THREADS) void aggregate_enc_dx_kernel(
                 acc.z += __shfl_xor(acc.z, off, WAVE); acc.w += __shfl_xor(acc.w, off, WAVE);
             }
             if (grp == 0) {
-                if (add_self && s < n_dst) acc4(acc, reinterpret_cast<const float4 *>(dout + (size_t)s * h)[c4]);
+                if (self_on) acc4(acc, selfv);
                 reinterpret_cast<float4 *>(dx + (size_t)s * h)[c4] = acc;
             }
         }
@@ -926,10 +1015,18 @@ int phc_aggregate_encp_fwd(const float *x, const uint32_t *codes, const float *c
     const long long cap = n_dst > 64 * 1024 ? 16384 : 2048;
     if (blocks > cap) blocks = cap;
     const int lpr = lpr_for(h >> 2);
+    // molecule batches: one wavefront per row, tables read from L2 (no LDS staging); large graphs amortise the staging
+    static const long long direct_max = getenv("PHC_ENCP_DIRECT_MAX") ? atoll(getenv("PHC_ENCP_DIRECT_MAX")) : 32768;
+    const bool direct = n_dst <= direct_max;
+    const long long dblocks = (n_dst + 3) / 4;
     ProfScope prof(K_AGG_ENC_FWD, s);
 #define PHC_AP_LAUNCH(LPRC, ACTC, FC)                                                                                     \
-    PHC_LAUNCH((aggregate_encp_fwd_kernel<LPRC, ACTC, FC>), dim3((unsigned)blocks), dim3(ENC_THREADS), lds, s, x, codes, \
-                       tables, m, rowptr, col, (long long)n_dst, n, k, add_self, out)
+    if (direct)                                                                                                           \
+        PHC_LAUNCH((aggregate_encp_direct_fwd_kernel<LPRC, ACTC, FC>), dim3((unsigned)dblocks), dim3(ENC_THREADS), 0, s, \
+                   x, codes, tables, m, rowptr, col, (long long)n_dst, n, k, add_self, out);                              \
+    else                                                                                                                  \
+        PHC_LAUNCH((aggregate_encp_fwd_kernel<LPRC, ACTC, FC>), dim3((unsigned)blocks), dim3(ENC_THREADS), lds, s, x,    \
+                   codes, tables, m, rowptr, col, (long long)n_dst, n, k, add_self, out)
 #define PHC_AP_F(LPRC, ACTC)                                    \
     switch (F) {                                                \
         case 1: PHC_AP_LAUNCH(LPRC, ACTC, 1); break;            \

@@ -319,6 +319,25 @@ def test_aggregate_encoded_matches_oracle(ops, act, n, k, vocab):
             assert_close(a, r, 2e-5, f"fused table grad {act}")
 
 
+def test_aggregate_encoded_large_graph_takes_the_lds_table_kernel(ops):
+    """Above 32 768 destination rows phc_aggregate_encp_fwd stages the tables in LDS (persistent workgroups) instead of
+    the one-wavefront-per-row direct form the molecule-sized cases above run: same result."""
+    from oracle import phc_oracle as O
+    from phc_gnn_amd import synth
+    g = torch.Generator().manual_seed(15)
+    n, k, vocab, N, E = 4, 8, [5, 6, 2], 40000, 120000
+    ei = torch.from_numpy(synth.random_edges(N, E, seed=6))
+    bond = torch.stack([torch.randint(0, v, (E,), generator=g) for v in vocab], 1)
+    tables = _make_tables(n, vocab, k, g)
+    x = torch.randn(N, n * k, generator=g)
+    dev_t = [[t.to(DEV) for t in comp] for comp in tables]
+    ts = ops.TableSet(dev_t)
+    assert ts.fusable_into_aggregate
+    out = ops.aggregate_sum_encoded(x.to(DEV), ei.to(DEV), bond.to(DEV), ts, dev_t, "relu", True)
+    ref = O.propagate_add(x, ei, _oracle_encode(bond, tables), "relu") + x
+    assert_close(out, ref, TOL)
+
+
 def test_aggregate_encoded_falls_back_when_tables_exceed_lds(ops):
     from oracle import phc_oracle as O
     from phc_gnn_amd import synth
