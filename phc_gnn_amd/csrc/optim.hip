@@ -28,9 +28,15 @@ __global__ __launch_bounds__(256) void opt_sumsq_kernel(OptGrads grads, const un
     const long long numel = (long long)table[4 * t + 3];
     float s = 0.f;
     if (g) {
+        // the chunk's OPT_CHUNK / 256 elements of this thread in one round trip (clamped addresses, selected afterwards):
+        // a runtime-bounded loop costs a full memory latency per iteration
         const long long end = min((long long)off + OPT_CHUNK, numel);
-        for (long long e = off + threadIdx.x; e < end; e += 256) {
-            const float v = g[e];
+        float gv[OPT_CHUNK / 256];
+#pragma unroll
+        for (int q = 0; q < OPT_CHUNK / 256; ++q) gv[q] = g[min((long long)off + threadIdx.x + 256 * q, end - 1)];
+#pragma unroll
+        for (int q = 0; q < OPT_CHUNK / 256; ++q) {
+            const float v = (long long)off + threadIdx.x + 256 * q < end ? gv[q] : 0.f;
             s = fmaf(v, v, s);
         }
     }
@@ -105,16 +111,27 @@ __global__ __launch_bounds__(256) void opt_adam_kernel(OptGrads grads, const uns
     if (!g) return;                                          // (workgroup 0 stayed to publish the norm)
     const float step_size = lr / bc1;
     const long long end = min((long long)off + OPT_CHUNK, numel);
-    for (long long e = off + threadIdx.x; e < end; e += 256) {
-        const float gv = g[e] * coef;
-        float mv = m[e], vv = v[e];
-        mv = mv + (gv - mv) * (1.f - beta1);                 // lerp, as torch's fused kernel
-        vv = beta2 * vv + (1.f - beta2) * gv * gv;
-        const float denom = sqrtf(vv) / bc2_sqrt + eps;
-        p[e] -= step_size * (mv / denom);
-        m[e] = mv;
-        v[e] = vv;
-        if (write_back) const_cast<float *>(g)[e] = gv;      // clip_grad_norm_ scales the gradients in place
+    constexpr int PER = OPT_CHUNK / 256;
+    float g_[PER], m_[PER], v_[PER], p_[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {                          // all 4 * PER loads in flight together (clamped addresses)
+        const long long e = min((long long)off + threadIdx.x + 256 * q, end - 1);
+        g_[q] = g[e]; m_[q] = m[e]; v_[q] = v[e]; p_[q] = p[e];
+    }
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const long long e = (long long)off + threadIdx.x + 256 * q;
+        if (e < end) {
+            const float gv = g_[q] * coef;
+            float mv = m_[q], vv = v_[q];
+            mv = mv + (gv - mv) * (1.f - beta1);             // lerp, as torch's fused kernel
+            vv = beta2 * vv + (1.f - beta2) * gv * gv;
+            const float denom = sqrtf(vv) / bc2_sqrt + eps;
+            p[e] = p_[q] - step_size * (mv / denom);
+            m[e] = mv;
+            v[e] = vv;
+            if (write_back) const_cast<float *>(g)[e] = gv;  // clip_grad_norm_ scales the gradients in place
+        }
     }
 }
 
