@@ -684,8 +684,14 @@ __device__ __forceinline__ void table_grad_reduce_body(const float *__restrict__
     const int e = bx * 64 + el;
     float s = 0.f;
     if (e < R * h) {
-#pragma unroll 4
-        for (int b = sl; b < num_slabs; b += 4) s += slabs[(size_t)b * R * h + e];
+        // eight of this lane's slabs per round trip (clamped, selected; ascending order)
+        for (int b0 = sl; b0 < num_slabs; b0 += 32) {
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = slabs[(size_t)min(b0 + 4 * q, num_slabs - 1) * R * h + e];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s += b0 + 4 * q < num_slabs ? v[q] : 0.f;
+        }
     }
     part[sl][el] = s;
     __syncthreads();

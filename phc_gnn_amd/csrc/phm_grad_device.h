@@ -277,8 +277,14 @@ __device__ __forceinline__ void dH_reduce_body(const float *__restrict__ slabs, 
     const size_t idx = (size_t)blk * 64 + e;
     float s = 0.f;
     if (idx < slab_elems) {
-#pragma unroll 4
-        for (int k = sl; k < splits; k += 4) s += slabs[(size_t)k * slab_elems + idx];
+        // eight of this lane's slabs per round trip (clamped, selected; same ascending order as a plain loop)
+        for (int k0 = sl; k0 < splits; k0 += 32) {
+            float v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = slabs[(size_t)min(k0 + 4 * q, splits - 1) * slab_elems + idx];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) s += k0 + 4 * q < splits ? v[q] : 0.f;
+        }
     }
     part[sl][e] = s;
     __syncthreads();

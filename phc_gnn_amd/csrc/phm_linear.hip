@@ -792,9 +792,19 @@ __device__ __forceinline__ void contract_body(const float *__restrict__ A, const
         const int iac = bx;
         const int i = iac / (n * n), a = (iac / n) % n, c = iac % n;
         float s = 0.f;
-        for (int e = tid; e < kin * kout; e += 256) {
-            const int kap = e / kout, pi = e - kap * kout;
-            s = fmaf(W[(size_t)i * kin * kout + e], dH[(size_t)(a * kin + kap) * out + c * kout + pi], s);
+        // four (W, dH) pairs per thread in one round trip (clamped, selected; ascending order as the plain loop)
+        const int kk = kin * kout;
+        for (int e0 = 0; e0 < kk; e0 += 4 * 256) {
+            float wv[4], hv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int e = min(e0 + tid + 256 * q, kk - 1);
+                const int kap = e / kout, pi = e - kap * kout;
+                wv[q] = W[(size_t)i * kk + e];
+                hv[q] = dH[(size_t)(a * kin + kap) * out + c * kout + pi];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) s = e0 + tid + 256 * q < kk ? fmaf(wv[q], hv[q], s) : s;
         }
         __shared__ float red[256];
         red[tid] = s;
@@ -813,9 +823,21 @@ __device__ __forceinline__ void contract_body(const float *__restrict__ A, const
         const int rem = e - i * kin * kout;
         const int kap = rem / kout, pi = rem - kap * kout;
         float s = 0.f;
-        for (int a = 0; a < n; ++a)
-            for (int c = 0; c < n; ++c)
-                s = fmaf(A[(i * n + a) * n + c], dH[(size_t)(a * kin + kap) * out + c * kout + pi], s);
+        // the n*n (a, c) terms sixteen at a time in one round trip (clamped, selected; same ascending (a, c) order): a
+        // runtime-bounded double loop costs one memory latency per term
+        const int nn = n * n;
+        for (int t0 = 0; t0 < nn; t0 += 16) {
+            float av[16], hv[16];
+#pragma unroll
+            for (int q = 0; q < 16; ++q) {
+                const int t = min(t0 + q, nn - 1);
+                const int a = t / n, c = t - a * n;
+                av[q] = A[(i * n + a) * n + c];
+                hv[q] = dH[(size_t)(a * kin + kap) * out + c * kout + pi];
+            }
+#pragma unroll
+            for (int q = 0; q < 16; ++q) s = t0 + q < nn ? fmaf(av[q], hv[q], s) : s;
+        }
         // dw_transposed: the parameter is an nn.Linear weight [kout, kin] (n = 1)
         dW[dw_transposed ? ((size_t)i * kout + pi) * kin + kap : (size_t)e] = s;
     }

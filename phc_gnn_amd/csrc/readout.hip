@@ -113,21 +113,28 @@ __global__ __launch_bounds__(GP_THREADS) void gated_pool_fwd_kernel(const float 
         float acc[VEC];
 #pragma unroll
         for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
-        if (rl < lanes) {
-#pragma unroll 2
-            for (int r = r0 + rl; r < r1; r += lanes) {
-                float xv[VEC], gv[VEC];
-                if constexpr (VEC == 4) {
-                    const float4 a = *reinterpret_cast<const float4 *>(x + (size_t)r * h + col);
-                    const float4 b = *reinterpret_cast<const float4 *>(gate + (size_t)r * k + j);
-                    xv[0] = a.x; xv[1] = a.y; xv[2] = a.z; xv[3] = a.w;
-                    gv[0] = b.x; gv[1] = b.y; gv[2] = b.z; gv[3] = b.w;
-                } else {
-                    xv[0] = x[(size_t)r * h + col];
-                    gv[0] = gate[(size_t)r * k + j];
+        if (rl < lanes && r0 < r1) {
+            // four rows of this lane per round trip (clamped addresses, selected afterwards; same ascending row order)
+            for (int rb = r0 + rl; rb < r1; rb += 4 * lanes) {
+                float xv[4][VEC], gv[4][VEC];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const int r = min(rb + q * lanes, r1 - 1);
+                    if constexpr (VEC == 4) {
+                        const float4 a = *reinterpret_cast<const float4 *>(x + (size_t)r * h + col);
+                        const float4 b = *reinterpret_cast<const float4 *>(gate + (size_t)r * k + j);
+                        xv[q][0] = a.x; xv[q][1] = a.y; xv[q][2] = a.z; xv[q][3] = a.w;
+                        gv[q][0] = b.x; gv[q][1] = b.y; gv[q][2] = b.z; gv[q][3] = b.w;
+                    } else {
+                        xv[q][0] = x[(size_t)r * h + col];
+                        gv[q][0] = gate[(size_t)r * k + j];
+                    }
                 }
 #pragma unroll
-                for (int v = 0; v < VEC; ++v) acc[v] = fmaf(xv[v], 1.f / (1.f + expf(-gv[v])), acc[v]);
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int v = 0; v < VEC; ++v)
+                        acc[v] = rb + q * lanes < r1 ? fmaf(xv[q][v], 1.f / (1.f + expf(-gv[q][v])), acc[v]) : acc[v];
             }
         }
         __syncthreads();
