@@ -762,7 +762,17 @@ __global__ __launch_bounds__(256) void phm_build_H_batched_kernel(HBatch b) {
         return;
     }
     float hsum = 0.f;
-    for (int i = 0; i < n; ++i) hsum = fmaf(jb.A[(i * n + a) * n + c], jb.W[((size_t)i * kin + kap) * kout + pi], hsum);
+    for (int i0 = 0; i0 < n; i0 += 8) {                      // the n terms eight per round trip (clamped, selected; ascending i)
+        float av[8], wv[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int i = min(i0 + q, n - 1);
+            av[q] = jb.A[(i * n + a) * n + c];
+            wv[q] = jb.W[((size_t)i * kin + kap) * kout + pi];
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) hsum = i0 + q < n ? fmaf(av[q], wv[q], hsum) : hsum;
+    }
     jb.H[e] = hsum;
     if (jb.HT) jb.HT[(size_t)jc * in + k] = hsum;
 }
