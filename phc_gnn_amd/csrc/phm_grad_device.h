@@ -38,6 +38,13 @@ __device__ __forceinline__ void dH_partial_body(const float *__restrict__ X, con
     const size_t slab_elems = (size_t)in * out + out;
     float *slab = slabs + (size_t)split * slab_elems;
 
+#ifdef PHC_EXP_DH_STAGGER
+    {   // experiment: offset the phases of the workgroups that share a CU (they start together and otherwise stay in step)
+        const unsigned bid = blockIdx.x;
+        const unsigned q = ((bid >> 8) + (bid >> 3)) & 3u;
+        for (unsigned t = 0; t < q; ++t) __builtin_amdgcn_s_sleep(PHC_EXP_DH_STAGGER);
+    }
+#endif
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
@@ -106,6 +113,9 @@ __device__ __forceinline__ void dH_partial_body(const float *__restrict__ X, con
             }
         }
         __syncthreads();
+#ifdef PHC_EXP_DH_NO_LOAD
+        if (tid == 100000)
+#endif
         if (vec4) {                                      // prefetch the next block (the last iteration re-reads row r_end-1)
 #pragma unroll
             for (int t = 0; t < 4; ++t) {
@@ -117,6 +127,9 @@ __device__ __forceinline__ void dH_partial_body(const float *__restrict__ X, con
         // A operand = x^T: lane (r, hh) supplies x[row rr+hh][i0 + wi*32 + r]; B = dy[row rr+hh][j0 + wj*32 + r]
         const float *xa = xs + hh * DH_STRIDE + wi * 32 + r;
         const float *db_ = ds + hh * DH_STRIDE + wj * 32 + r;
+#ifdef PHC_EXP_DH_NO_MFMA
+        if (tid == 100000)
+#endif
 #pragma unroll 8
         for (int rr = 0; rr < DH_RB; rr += 2)
             acc = __builtin_amdgcn_mfma_f32_32x32x2f32(xa[rr * DH_STRIDE], db_[rr * DH_STRIDE], acc, 0, 0, 0);
