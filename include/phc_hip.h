@@ -200,6 +200,18 @@ int phc_aggregate_softmax_bwd(const float *dout, const float *out, const float *
                               const float *beta_dev, const int32_t *rowptr_t, const int32_t *col_t, const int32_t *perm_t,
                               int64_t n_src, int h, int act, float *dx, float *dea, float *dbeta_partial, void *stream);
 
+/* The same with the layer's self loop folded in (PHMConvSoftmax / PHMGINEConvSoftmax.forward add x to the aggregate,
+ * messagepassing.py:222-231, 303-309): the forward also writes out_self = out + x[d] (x has >= n_dst rows; `out`
+ * stays the plain aggregate for the backward), the backward adds dout[s] to dx[s] for s < self_n_dst.  One launch
+ * each way instead of the aggregation plus an elementwise add. */
+int phc_aggregate_softmax_fwd_self(const float *x, const float *ea, const int32_t *rowptr, const int32_t *col,
+                                   const int32_t *perm, const float *beta_dev, int64_t n_dst, int h, int act, float *out,
+                                   float *out_self, float *lse, void *stream);
+int phc_aggregate_softmax_bwd_self(const float *dout, const float *out, const float *lse, const float *x, const float *ea,
+                                   const float *beta_dev, const int32_t *rowptr_t, const int32_t *col_t,
+                                   const int32_t *perm_t, int64_t n_src, int h, int act, int64_t self_n_dst, float *dx,
+                                   float *dea, float *dbeta_partial, void *stream);
+
 /* out[r, :] = src[idx[r], :]   (row gather; backward of a segment sum, e.g.
  * global_add_pool's gradient dx[i] = dout[batch[i]], pooling.py:14) */
 int phc_gather_rows_i64(const float *src, const int64_t *idx_i64, int64_t n_rows, int h, float *out, void *stream);

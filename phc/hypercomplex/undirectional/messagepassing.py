@@ -182,8 +182,10 @@ class _SoftmaxMixin:
                   add_self: bool = False) -> torch.Tensor:
         assert x.size(-1) == edge_attr.size(-1)
         num_dst = size[1] if size is not None and size[1] is not None else None
-        out = _engine.aggregate_softmax(x, edge_index, edge_attr, self.beta, self.msg_encoder_str, num_dst)
-        return out + x if add_self else out
+        # the self loop (x_c added to the aggregate, ref :222-231 / :303-309) rides in the aggregation's own launches
+        fused_self = add_self and (num_dst is None or num_dst == x.size(0))
+        out = _engine.aggregate_softmax(x, edge_index, edge_attr, self.beta, self.msg_encoder_str, num_dst, add_self=fused_self)
+        return out + x if (add_self and not fused_self) else out
 
     def propagate_encoded(self, edge_index, x, edge_idx, encoder, size=None, add_self=False):
         # softmax weights need the per-edge message: embed the bonds ([E, h]) and take the tensor path

@@ -48,7 +48,9 @@ __global__ __launch_bounds__(SM_THREADS) void softmax_agg_fwd_kernel(const float
                                                                   const int *__restrict__ rowptr, const int *__restrict__ col,
                                                                   const int *__restrict__ perm, const float *__restrict__ beta_p,
                                                                   long long n_dst, int h, float *__restrict__ out,
-                                                                  float *__restrict__ lse) {
+                                                                  float *__restrict__ lse, float *__restrict__ out_self) {
+    // out_self != NULL: also writes out + x[d] (the layer's self loop, messagepassing.py:222-231 / :303-309); `out`
+    // stays the plain aggregate, which the backward needs
     constexpr int G = WAVE / LPR;
     const int lane = threadIdx.x & 63;
     const int grp = lane / LPR, li = lane - grp * LPR;
@@ -90,6 +92,10 @@ __global__ __launch_bounds__(SM_THREADS) void softmax_agg_fwd_kernel(const float
                 }
                 reinterpret_cast<float4 *>(out + (size_t)d * h)[c4] = o;
                 reinterpret_cast<float4 *>(lse + (size_t)d * h)[c4] = l;
+                if (out_self) {
+                    const float4 xd = reinterpret_cast<const float4 *>(x + (size_t)d * h)[c4];
+                    reinterpret_cast<float4 *>(out_self + (size_t)d * h)[c4] = make_float4(o.x + xd.x, o.y + xd.y, o.z + xd.z, o.w + xd.w);
+                }
             }
         }
     }
@@ -101,7 +107,7 @@ __global__ __launch_bounds__(SM_THREADS) void softmax_agg_bwd_kernel(
     const float *__restrict__ dout, const float *__restrict__ out, const float *__restrict__ lse, const float *__restrict__ x,
     const float *__restrict__ ea, const float *__restrict__ beta_p, const int *__restrict__ rowptr_t, const int *__restrict__ col_t,
     const int *__restrict__ perm_t, long long n_src, int h, float *__restrict__ dx, float *__restrict__ dea,
-    float *__restrict__ dbeta_partial) {
+    float *__restrict__ dbeta_partial, long long self_n_dst) {
     __shared__ float red[SM_THREADS];
     constexpr int G = WAVE / LPR;
     const int lane = threadIdx.x & 63;
@@ -144,7 +150,13 @@ __global__ __launch_bounds__(SM_THREADS) void softmax_agg_bwd_kernel(
             for (int off = LPR; off < WAVE; off <<= 1)
 #pragma unroll
                 for (int q = 0; q < 4; ++q) acc[q] += __shfl_xor(acc[q], off, WAVE);
-            if (grp == 0) reinterpret_cast<float4 *>(dx + (size_t)sidx * h)[c4] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            if (grp == 0) {
+                if (sidx < self_n_dst) {                     // the self loop's gradient: dx[s] += dout[s]
+                    const float4 gs = reinterpret_cast<const float4 *>(dout + (size_t)sidx * h)[c4];
+                    acc[0] += gs.x; acc[1] += gs.y; acc[2] += gs.z; acc[3] += gs.w;
+                }
+                reinterpret_cast<float4 *>(dx + (size_t)sidx * h)[c4] = make_float4(acc[0], acc[1], acc[2], acc[3]);
+            }
         }
     }
     red[threadIdx.x] = db;
@@ -183,8 +195,19 @@ extern "C" {
 
 int phc_softmax_bwd_num_partials(int64_t n_src) { return (int)sm_grid(n_src); }
 
+int phc_aggregate_softmax_fwd_self(const float *x, const float *ea, const int32_t *rowptr, const int32_t *col, const int32_t *perm,
+                                   const float *beta_dev, int64_t n_dst, int h, int act, float *out, float *out_self, float *lse,
+                                   void *stream);
+
 int phc_aggregate_softmax_fwd(const float *x, const float *ea, const int32_t *rowptr, const int32_t *col, const int32_t *perm,
                               const float *beta_dev, int64_t n_dst, int h, int act, float *out, float *lse, void *stream) {
+    return phc_aggregate_softmax_fwd_self(x, ea, rowptr, col, perm, beta_dev, n_dst, h, act, out, nullptr, lse, stream);
+}
+
+int phc_aggregate_softmax_fwd_self(const float *x, const float *ea, const int32_t *rowptr, const int32_t *col, const int32_t *perm,
+                                   const float *beta_dev, int64_t n_dst, int h, int act, float *out, float *out_self, float *lse,
+                                   void *stream) {
+    PHC_REQUIRE(!out_self || sm_al16(out_self), PHC_ERR_UNSUPPORTED, "phc_aggregate_softmax_fwd_self: out_self must be 16-byte aligned");
     PHC_REQUIRE(n_dst >= 0 && h >= 1, PHC_ERR_INVALID_ARG, "phc_aggregate_softmax_fwd: bad sizes");
     PHC_REQUIRE(act >= PHC_ACT_IDENTITY && act <= PHC_ACT_SELU, PHC_ERR_INVALID_ARG, "phc_aggregate_softmax_fwd: unknown activation %d", act);
     if (n_dst == 0) return PHC_OK;
@@ -196,19 +219,33 @@ int phc_aggregate_softmax_fwd(const float *x, const float *ea, const int32_t *ro
     ProfScope prof(K_SOFTMAX_FWD, s);
 #define PHC_SM_FWD(ACTC)                                                                                                 \
     switch (lpr) {                                                                                                       \
-        case 8: PHC_LAUNCH((softmax_agg_fwd_kernel<8, ACTC>), dim3(sm_grid(n_dst)), dim3(SM_THREADS), 0, s, x, ea, rowptr, col, perm, beta_dev, (long long)n_dst, h, out, lse); break;   \
-        case 16: PHC_LAUNCH((softmax_agg_fwd_kernel<16, ACTC>), dim3(sm_grid(n_dst)), dim3(SM_THREADS), 0, s, x, ea, rowptr, col, perm, beta_dev, (long long)n_dst, h, out, lse); break; \
-        case 32: PHC_LAUNCH((softmax_agg_fwd_kernel<32, ACTC>), dim3(sm_grid(n_dst)), dim3(SM_THREADS), 0, s, x, ea, rowptr, col, perm, beta_dev, (long long)n_dst, h, out, lse); break; \
-        default: PHC_LAUNCH((softmax_agg_fwd_kernel<64, ACTC>), dim3(sm_grid(n_dst)), dim3(SM_THREADS), 0, s, x, ea, rowptr, col, perm, beta_dev, (long long)n_dst, h, out, lse); break; \
+        case 8: PHC_LAUNCH((softmax_agg_fwd_kernel<8, ACTC>), dim3(sm_grid(n_dst)), dim3(SM_THREADS), 0, s, x, ea, rowptr, col, perm, beta_dev, (long long)n_dst, h, out, lse, out_self); break;   \
+        case 16: PHC_LAUNCH((softmax_agg_fwd_kernel<16, ACTC>), dim3(sm_grid(n_dst)), dim3(SM_THREADS), 0, s, x, ea, rowptr, col, perm, beta_dev, (long long)n_dst, h, out, lse, out_self); break; \
+        case 32: PHC_LAUNCH((softmax_agg_fwd_kernel<32, ACTC>), dim3(sm_grid(n_dst)), dim3(SM_THREADS), 0, s, x, ea, rowptr, col, perm, beta_dev, (long long)n_dst, h, out, lse, out_self); break; \
+        default: PHC_LAUNCH((softmax_agg_fwd_kernel<64, ACTC>), dim3(sm_grid(n_dst)), dim3(SM_THREADS), 0, s, x, ea, rowptr, col, perm, beta_dev, (long long)n_dst, h, out, lse, out_self); break; \
     }
     PHC_SM_ACT(act, PHC_SM_FWD)
 #undef PHC_SM_FWD
     return check_launch("aggregate_softmax_fwd");
 }
 
+int phc_aggregate_softmax_bwd_self(const float *dout, const float *out, const float *lse, const float *x, const float *ea,
+                                   const float *beta_dev, const int32_t *rowptr_t, const int32_t *col_t, const int32_t *perm_t,
+                                   int64_t n_src, int h, int act, int64_t self_n_dst, float *dx, float *dea, float *dbeta_partial,
+                                   void *stream);
+
 int phc_aggregate_softmax_bwd(const float *dout, const float *out, const float *lse, const float *x, const float *ea,
                               const float *beta_dev, const int32_t *rowptr_t, const int32_t *col_t, const int32_t *perm_t,
                               int64_t n_src, int h, int act, float *dx, float *dea, float *dbeta_partial, void *stream) {
+    return phc_aggregate_softmax_bwd_self(dout, out, lse, x, ea, beta_dev, rowptr_t, col_t, perm_t, n_src, h, act, 0, dx, dea,
+                                          dbeta_partial, stream);
+}
+
+int phc_aggregate_softmax_bwd_self(const float *dout, const float *out, const float *lse, const float *x, const float *ea,
+                                   const float *beta_dev, const int32_t *rowptr_t, const int32_t *col_t, const int32_t *perm_t,
+                                   int64_t n_src, int h, int act, int64_t self_n_dst, float *dx, float *dea, float *dbeta_partial,
+                                   void *stream) {
+    PHC_REQUIRE(self_n_dst >= 0, PHC_ERR_INVALID_ARG, "phc_aggregate_softmax_bwd_self: bad self_n_dst");
     PHC_REQUIRE(n_src >= 0 && h >= 1, PHC_ERR_INVALID_ARG, "phc_aggregate_softmax_bwd: bad sizes");
     PHC_REQUIRE(act >= PHC_ACT_IDENTITY && act <= PHC_ACT_SELU, PHC_ERR_INVALID_ARG, "phc_aggregate_softmax_bwd: unknown activation %d", act);
     if (n_src == 0) return PHC_OK;
@@ -221,10 +258,10 @@ int phc_aggregate_softmax_bwd(const float *dout, const float *out, const float *
     ProfScope prof(K_SOFTMAX_BWD, s);
 #define PHC_SM_BWD(ACTC)                                                                                                 \
     switch (lpr) {                                                                                                       \
-        case 8: PHC_LAUNCH((softmax_agg_bwd_kernel<8, ACTC>), dim3(sm_grid(n_src)), dim3(SM_THREADS), 0, s, dout, out, lse, x, ea, beta_dev, rowptr_t, col_t, perm_t, (long long)n_src, h, dx, dea, dbeta_partial); break;   \
-        case 16: PHC_LAUNCH((softmax_agg_bwd_kernel<16, ACTC>), dim3(sm_grid(n_src)), dim3(SM_THREADS), 0, s, dout, out, lse, x, ea, beta_dev, rowptr_t, col_t, perm_t, (long long)n_src, h, dx, dea, dbeta_partial); break; \
-        case 32: PHC_LAUNCH((softmax_agg_bwd_kernel<32, ACTC>), dim3(sm_grid(n_src)), dim3(SM_THREADS), 0, s, dout, out, lse, x, ea, beta_dev, rowptr_t, col_t, perm_t, (long long)n_src, h, dx, dea, dbeta_partial); break; \
-        default: PHC_LAUNCH((softmax_agg_bwd_kernel<64, ACTC>), dim3(sm_grid(n_src)), dim3(SM_THREADS), 0, s, dout, out, lse, x, ea, beta_dev, rowptr_t, col_t, perm_t, (long long)n_src, h, dx, dea, dbeta_partial); break; \
+        case 8: PHC_LAUNCH((softmax_agg_bwd_kernel<8, ACTC>), dim3(sm_grid(n_src)), dim3(SM_THREADS), 0, s, dout, out, lse, x, ea, beta_dev, rowptr_t, col_t, perm_t, (long long)n_src, h, dx, dea, dbeta_partial, (long long)self_n_dst); break;   \
+        case 16: PHC_LAUNCH((softmax_agg_bwd_kernel<16, ACTC>), dim3(sm_grid(n_src)), dim3(SM_THREADS), 0, s, dout, out, lse, x, ea, beta_dev, rowptr_t, col_t, perm_t, (long long)n_src, h, dx, dea, dbeta_partial, (long long)self_n_dst); break; \
+        case 32: PHC_LAUNCH((softmax_agg_bwd_kernel<32, ACTC>), dim3(sm_grid(n_src)), dim3(SM_THREADS), 0, s, dout, out, lse, x, ea, beta_dev, rowptr_t, col_t, perm_t, (long long)n_src, h, dx, dea, dbeta_partial, (long long)self_n_dst); break; \
+        default: PHC_LAUNCH((softmax_agg_bwd_kernel<64, ACTC>), dim3(sm_grid(n_src)), dim3(SM_THREADS), 0, s, dout, out, lse, x, ea, beta_dev, rowptr_t, col_t, perm_t, (long long)n_src, h, dx, dea, dbeta_partial, (long long)self_n_dst); break; \
     }
     PHC_SM_ACT(act, PHC_SM_BWD)
 #undef PHC_SM_BWD

@@ -767,7 +767,7 @@ def aggregate_sum(x: torch.Tensor, edge_index, edge_attr: Optional[torch.Tensor]
 # ---------------------------------------------------------------------------
 class _AggregateSoftmaxFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, ea, beta, st: EdgeStructure, act: int):
+    def forward(ctx, x, ea, beta, st: EdgeStructure, act: int, add_self: bool = False):
         lib = L.load()
         dev = L.require_device(x, ea, beta)
         x_, ea_ = L.f32c(x), L.f32c(ea)
@@ -778,15 +778,18 @@ class _AggregateSoftmaxFn(torch.autograd.Function):
         rowptr, col, perm = st.csr
         out = torch.empty((st.num_dst, h), dtype=torch.float32, device=dev)
         lse = torch.empty((st.num_dst, h), dtype=torch.float32, device=dev)
-        L.check(lib.phc_aggregate_softmax_fwd(L.ptr(x_), L.ptr(ea_), L.ptr(rowptr), L.ptr(col), L.ptr(perm), L.ptr(beta_),
-                                              st.num_dst, h, act, L.ptr(out), L.ptr(lse), L.stream_ptr(dev)),
-                "phc_aggregate_softmax_fwd")
+        if add_self and x_.shape[0] < st.num_dst:
+            raise L.PhcError(f"self loop: x has {x_.shape[0]} rows, {st.num_dst} destination rows")
+        out_self = torch.empty_like(out) if add_self else None          # aggregate + x: what the layer returns
+        L.check(lib.phc_aggregate_softmax_fwd_self(L.ptr(x_), L.ptr(ea_), L.ptr(rowptr), L.ptr(col), L.ptr(perm), L.ptr(beta_),
+                                                   st.num_dst, h, act, L.ptr(out), L.ptr(out_self), L.ptr(lse),
+                                                   L.stream_ptr(dev)), "phc_aggregate_softmax_fwd_self")
         if L.PROF_ON:
             E, N = st.num_edges, st.num_dst
             L.account("aggregate_softmax_fwd", 8.0 * E * h, E * (4.0 * h * (2 if ea is not None else 1) + 8) + N * 8.0 * h)
-        ctx.st, ctx.act, ctx.has_ea = st, act, ea is not None
+        ctx.st, ctx.act, ctx.has_ea, ctx.add_self = st, act, ea is not None, bool(add_self)
         ctx.save_for_backward(x_, ea_ if ea is not None else x_.new_empty(0), beta_, out, lse)
-        return out
+        return out_self if add_self else out
 
     @staticmethod
     def backward(ctx, dout):
@@ -803,23 +806,25 @@ class _AggregateSoftmaxFn(torch.autograd.Function):
         dea = torch.empty((st.num_edges, h), dtype=torch.float32, device=dev) if need_ea else None
         nparts = lib.phc_softmax_bwd_num_partials(st.num_src)
         parts = torch.empty(nparts, dtype=torch.float32, device=dev)
-        L.check(lib.phc_aggregate_softmax_bwd(L.ptr(dout_), L.ptr(out), L.ptr(lse), L.ptr(x_), L.ptr(ea_), L.ptr(beta_),
-                                              L.ptr(rowptr_t), L.ptr(col_t), L.ptr(perm_t), st.num_src, h, ctx.act, L.ptr(dx),
-                                              L.ptr(dea), L.ptr(parts), L.stream_ptr(dev)), "phc_aggregate_softmax_bwd")
+        L.check(lib.phc_aggregate_softmax_bwd_self(L.ptr(dout_), L.ptr(out), L.ptr(lse), L.ptr(x_), L.ptr(ea_), L.ptr(beta_),
+                                                   L.ptr(rowptr_t), L.ptr(col_t), L.ptr(perm_t), st.num_src, h, ctx.act,
+                                                   min(st.num_dst, st.num_src) if ctx.add_self else 0, L.ptr(dx), L.ptr(dea),
+                                                   L.ptr(parts), L.stream_ptr(dev)), "phc_aggregate_softmax_bwd_self")
         if L.PROF_ON:
             E, N = st.num_edges, st.num_src
             L.account("aggregate_softmax_bwd", 12.0 * E * h, E * (4.0 * h * (5 if need_ea else 4) + 8) + N * 8.0 * h)
         dbeta = parts.sum().reshape(()) if ctx.needs_input_grad[2] else None
-        return (dx if ctx.needs_input_grad[0] else None), dea, dbeta, None, None
+        return (dx if ctx.needs_input_grad[0] else None), dea, dbeta, None, None, None
 
 
 def aggregate_softmax(x: torch.Tensor, edge_index, edge_attr: Optional[torch.Tensor], beta: torch.Tensor,
-                      msg_encoder: str = "identity", num_dst: Optional[int] = None) -> torch.Tensor:
+                      msg_encoder: str = "identity", num_dst: Optional[int] = None, add_self: bool = False) -> torch.Tensor:
     """out[i] = Σ_e softmax_e(β·m_e)·m_e over the in-edges of i, per feature column, m_e = φ(x[src_e] + edge_attr[e])
-    (messagepassing.py:211-214 semantics; empty neighbourhoods give 0)."""
+    (messagepassing.py:211-214 semantics; empty neighbourhoods give 0).  ``add_self``: + x[i], the layer's self loop
+    (messagepassing.py:222-231), inside the same two launches."""
     st = edge_index if isinstance(edge_index, EdgeStructure) else edge_structure(edge_index, x.shape[0], num_dst)
     st.prepare(for_backward=torch.is_grad_enabled() and x.requires_grad)
-    return _AggregateSoftmaxFn.apply(x, edge_attr, beta, st, _act_id(msg_encoder))
+    return _AggregateSoftmaxFn.apply(x, edge_attr, beta, st, _act_id(msg_encoder), add_self)
 
 
 # ---------------------------------------------------------------------------

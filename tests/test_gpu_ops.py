@@ -483,13 +483,15 @@ def test_aggregate_softmax_matches_oracle(ops, act, h):
     x = torch.randn(N, h, generator=g)
     ea = torch.randn(E, h, generator=g)
     dy = torch.randn(N, h, generator=g)
-    for beta0 in (1.0, 0.3, 2.5):
+    for beta0, add_self in ((1.0, False), (0.3, True), (2.5, False), (2.5, True)):
         xr, er, br = x.clone().requires_grad_(), ea.clone().requires_grad_(), torch.tensor(beta0, requires_grad=True)
         ref = O.softmax_aggregate(xr, ei, er, br, act)
+        if add_self:                                        # the conv's self loop, fused into the same launches
+            ref = ref + xr
         rg = torch.autograd.grad(ref, [xr, er, br], dy)
         xd, ed = x.to(DEV).requires_grad_(), ea.to(DEV).requires_grad_()
         bd = torch.tensor(beta0, device=DEV, requires_grad=True)
-        out = ops.aggregate_softmax(xd, ei.to(DEV), ed, bd, act)
+        out = ops.aggregate_softmax(xd, ei.to(DEV), ed, bd, act, add_self=add_self)
         assert_close(out, ref, 2e-5, f"softmax fwd {act} beta={beta0}")
         gg = torch.autograd.grad(out, [xd, ed, bd], dy.to(DEV))
         assert_close(gg[0], rg[0], 3e-5, "softmax dx")
