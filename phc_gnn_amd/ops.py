@@ -68,6 +68,13 @@ def deferred_param_grads():
     jobs, _DEFER.jobs = _DEFER.jobs, []
     tjobs, _DEFER.table_jobs = _DEFER.table_jobs, []
     ajobs, _DEFER.atom_jobs = _DEFER.atom_jobs, []
+    if STEP_TAIL_MERGED and len(ajobs) > 1:
+        # several row-contiguous encoder jobs (a model whose bond encoders run on the [E, h] tensor path, e.g. softmax
+        # aggregation): the tail launch takes the largest, the others run on their own first
+        ajobs.sort(key=lambda aj: aj["idx"].shape[0] * aj["ts"].R)
+        for aj in ajobs[:-1]:
+            _flush_atom_grads(aj)
+        ajobs = ajobs[-1:]
     if STEP_TAIL_MERGED and _flush_step_tail(jobs, tjobs, ajobs):
         return
     if tjobs:
