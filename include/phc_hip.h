@@ -240,6 +240,15 @@ size_t phc_encode_bwd_ws_bytes(int64_t N, int F, const int32_t *vocab, int n, in
 int phc_encode_bwd(const float *dout, const int64_t *idx_i64, int64_t N, int F, const int32_t *vocab, int n, int k,
                    float *dtables_flat, void *ws, size_t ws_bytes, void *stream);
 
+/* The table gradients of SEVERAL encoders that were applied to one index tensor (e.g. the bond encoders of all
+ * message-passing layers when the bond embedding is materialised, as the softmax aggregation needs it) in two
+ * launches: jobs[q].dout [N, n*k] and jobs[q].dtables_flat [n][R][k] (x / tables are not read).  Same slabs and
+ * fixed summation order as phc_encode_bwd.  `jobs` is declared with phc_table_grads_batched below. */
+struct phc_table_grad_job;
+size_t phc_encode_bwd_batched_ws_bytes(int64_t N, int F, const int32_t *vocab, int n, int k, int num_jobs);
+int phc_encode_bwd_batched(const struct phc_table_grad_job *jobs, int num_jobs, const int64_t *idx_i64, int64_t N, int F,
+                           const int32_t *vocab, int n, int k, void *ws, size_t ws_bytes, void *stream);
+
 /* Aggregation with the edge features looked up from LDS-staged tables; the [E, h]
  * edge embedding of models.py:238-240 is never materialised:
  *   out[d] = sum_{e in CSR row d} phi( x[col[e]] + sum_f T_f[bond[perm[e], f]] ) (+ x[d])

@@ -651,6 +651,17 @@ __global__ __launch_bounds__(ENC_THREADS) void table_grad_mfma_batched_kernel(
                             blockIdx.x, blockIdx.y, smem);
 }
 
+// several integer encoders over ONE index tensor (e.g. the bond encoders of all layers on the [E, h] tensor path):
+// blockIdx.z picks the encoder's gradient rows / output; MODE 0 body
+__global__ __launch_bounds__(ENC_THREADS) void table_grad_rows_batched_kernel(
+    TgBatch b, const long long *__restrict__ idx, EncMeta m, long long n_items, long long items_per_split, int h, int tiles_j,
+    int vec4) {
+    const TgJobDev &jb = b.j[blockIdx.z];
+    __shared__ __attribute__((aligned(16))) float smem[2 * TG_IB * TG_T];
+    table_grad_rows_body<0>(jb.dout, idx, nullptr, nullptr, 0, m, n_items, items_per_split, h, tiles_j, vec4, jb.slabs, blockIdx.x,
+                            blockIdx.y, smem);
+}
+
 // identity message function: per destination node with in-edge row counts (MODE 2), n_items = n_dst
 __global__ __launch_bounds__(ENC_THREADS) void table_grad_counted_batched_kernel(
     TgBatch b, const int *__restrict__ rowptr, const unsigned *__restrict__ codes, long long n_edges, EncMeta m, long long n_items,
@@ -936,6 +947,49 @@ int phc_encode_bwd(const float *dout, const int64_t *idx_i64, int64_t N, int F, 
     PHC_REQUIRE(dtables_flat && (N == 0 || (dout && idx_i64)), PHC_ERR_INVALID_ARG, "phc_encode_bwd: null pointer");
     return launch_table_grad<0>(dout, reinterpret_cast<const long long *>(idx_i64), m, N, n * k, n, k, PHC_ACT_IDENTITY, nullptr,
                                 nullptr, nullptr, nullptr, dtables_flat, ws, ws_bytes, (hipStream_t)stream, "phc_encode_bwd");
+}
+
+size_t phc_encode_bwd_batched_ws_bytes(int64_t N, int F, const int32_t *vocab, int n, int k, int num_jobs) {
+    return phc_table_grads_ws_bytes(N, F, vocab, n, k, num_jobs);          // same plan, items = encoded rows
+}
+
+int phc_encode_bwd_batched(const phc_table_grad_job *jobs, int num_jobs, const int64_t *idx_i64, int64_t N, int F,
+                           const int32_t *vocab, int n, int k, void *ws, size_t ws_bytes, void *stream) {
+    EncMeta m;
+    int rc = make_meta("phc_encode_bwd_batched", F, vocab, &m);
+    if (rc) return rc;
+    PHC_REQUIRE(num_jobs >= 1 && jobs && N >= 1 && n >= 1 && k >= 1 && idx_i64, PHC_ERR_INVALID_ARG, "phc_encode_bwd_batched: bad arguments");
+    PHC_REQUIRE(ws && ws_bytes >= phc_encode_bwd_batched_ws_bytes(N, F, vocab, n, k, num_jobs), PHC_ERR_WORKSPACE,
+                "phc_encode_bwd_batched: workspace too small");
+    const int h = n * k;
+    hipStream_t s = (hipStream_t)stream;
+    float *wsf = static_cast<float *>(ws);
+    for (int c0 = 0; c0 < num_jobs; c0 += TG_JOBS_PER_LAUNCH) {
+        const int cn = num_jobs - c0 < TG_JOBS_PER_LAUNCH ? num_jobs - c0 : TG_JOBS_PER_LAUNCH;
+        const TgPlan p = tg_plan(N, m.R, h, cn);
+        TgBatch b;
+        int vec4 = (k % 4 == 0);
+        for (int q = 0; q < cn; ++q) {
+            const phc_table_grad_job &jb = jobs[c0 + q];
+            PHC_REQUIRE(jb.dout && jb.dtables_flat, PHC_ERR_INVALID_ARG, "phc_encode_bwd_batched: job %d: null pointer", c0 + q);
+            b.j[q].dout = jb.dout; b.j[q].x = nullptr; b.j[q].tables = nullptr; b.j[q].flat = jb.dtables_flat;
+            b.j[q].slabs = wsf;
+            wsf += p.slab_floats;
+            vec4 = vec4 && al16(jb.dout);
+        }
+        {
+            ProfScope prof(K_TABLE_GRAD, s);
+            PHC_LAUNCH(table_grad_rows_batched_kernel, dim3(p.tiles_i * p.tiles_j, p.num_slabs, cn), dim3(ENC_THREADS), 0, s, b,
+                       reinterpret_cast<const long long *>(idx_i64), m, (long long)N, p.items_per_split, h, p.tiles_j, vec4);
+            rc = check_launch("encode_bwd_batched");
+            if (rc) return rc;
+        }
+        ProfScope prof(K_TABLE_GRAD_REDUCE, s);
+        PHC_LAUNCH(table_grad_reduce_batched_kernel, dim3((m.R * h + 63) / 64, cn), dim3(256), 0, s, b, p.num_slabs, m.R, n, k);
+        rc = check_launch("encode_bwd_batched(reduce)");
+        if (rc) return rc;
+    }
+    return PHC_OK;
 }
 
 int phc_aggregate_enc_fwd(const float *x, const int64_t *bond_i64, const float *const *tables, const int32_t *vocab,

@@ -84,6 +84,8 @@ SIGNATURES = {
     "phc_encode_fwd": (_I, [_P, _P, _L, _I, _I, _I, _P, _P]),
     "phc_encode_bwd_ws_bytes": (_S, [_L, _I, _P, _I, _I]),
     "phc_encode_bwd": (_I, [_P, _P, _L, _I, _P, _I, _I, _P, _P, _S, _P]),
+    "phc_encode_bwd_batched_ws_bytes": (_S, [_L, _I, _P, _I, _I, _I]),
+    "phc_encode_bwd_batched": (_I, [C.POINTER(TableGradJob), _I, _P, _L, _I, _P, _I, _I, _P, _S, _P]),
     "phc_aggregate_enc_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P, _P]),
     "phc_pack_edge_codes": (_I, [_P, _P, _P, _L, _I, _P, _P]),
     "phc_aggregate_encp_fwd": (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _P, _P]),

@@ -72,15 +72,13 @@ def deferred_param_grads():
         # several row-contiguous encoder jobs (a model whose bond encoders run on the [E, h] tensor path, e.g. softmax
         # aggregation): the tail launch takes the largest, the others run on their own first
         ajobs.sort(key=lambda aj: aj["idx"].shape[0] * aj["ts"].R)
-        for aj in ajobs[:-1]:
-            _flush_atom_grads(aj)
+        _flush_encoder_grads(ajobs[:-1])
         ajobs = ajobs[-1:]
     if STEP_TAIL_MERGED and _flush_step_tail(jobs, tjobs, ajobs):
         return
     if tjobs:
         _flush_table_grads(tjobs)
-    for aj in ajobs:
-        _flush_atom_grads(aj)
+    _flush_encoder_grads(ajobs)
     if jobs:
         _flush_param_grads(jobs)
 
@@ -117,6 +115,38 @@ def _flush_atom_grads(aj) -> None:
         if L.PROF_ON:
             L.account("table_grad", 1.0 * N * ts.F * ts.n * ts.k, N * (8.0 * ts.F + 4.0 * ts.n * ts.k))
     _assign_grads(aj["params"], ts.grad_views(flat))
+
+
+def _flush_encoder_grads(ajobs) -> None:
+    """Table gradients of encoders on the tensor path: the encoders that read one index tensor (the bond encoders of
+    all layers) go through phc_encode_bwd_batched — two launches for the group — the rest one by one."""
+    groups = {}
+    for aj in ajobs:
+        ts = aj["ts"]
+        groups.setdefault((aj["idx"].data_ptr(), tuple(aj["idx"].shape), ts.F, ts.n, ts.k, tuple(ts.vocab), aj["dout"].device), []).append(aj)
+    lib = L.load()
+    for js in groups.values():
+        if len(js) == 1:
+            _flush_atom_grads(js[0])
+            continue
+        ts, idx_ = js[0]["ts"], js[0]["idx"]
+        dev = js[0]["dout"].device
+        N = idx_.shape[0]
+        with torch.cuda.device(dev):
+            per = ts.n * ts.R * ts.k
+            flat = torch.empty(len(js) * per, dtype=torch.float32, device=dev)
+            arr = (L.TableGradJob * len(js))()
+            for i, aj in enumerate(js):
+                arr[i] = L.TableGradJob(L.ptr(aj["dout"]), None, None, L.ptr(flat) + 4 * i * per)
+            ws_bytes = lib.phc_encode_bwd_batched_ws_bytes(N, ts.F, ts.vocab_c, ts.n, ts.k, len(js))
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+            L.check(lib.phc_encode_bwd_batched(arr, len(js), L.ptr(idx_), N, ts.F, ts.vocab_c, ts.n, ts.k, L.ptr(ws), ws_bytes,
+                                               L.stream_ptr(dev)), "phc_encode_bwd_batched")
+            if L.PROF_ON:
+                for _ in js:
+                    L.account("table_grad", 1.0 * N * ts.F * ts.n * ts.k, N * (8.0 * ts.F + 4.0 * ts.n * ts.k))
+        for i, aj in enumerate(js):
+            _assign_grads(aj["params"], aj["ts"].grad_views(flat[i * per:(i + 1) * per]))
 
 
 def _flush_step_tail(jobs, tjobs, ajobs) -> bool:

@@ -671,6 +671,41 @@ def test_deferred_bond_table_gradients_match_the_per_layer_path(ops, msg_act):
             assert_close(x1, x2, 2e-6 if msg_act == "relu" else 5e-6, f"layer {li} table {ti}")
 
 
+def test_deferred_encoder_gradients_of_several_encoders_over_one_index_tensor(ops):
+    """Inside deferred_param_grads() the table gradients of the encoders that were applied to ONE index tensor (the
+    bond encoders of all layers when the [E, h] embedding is materialised) come from phc_encode_bwd_batched, the largest
+    remaining job joins the step tail; all must equal the immediate per-encoder gradients bit for bit (same body, same
+    plan is NOT guaranteed -> fp32 tolerance) and accumulate into .grad."""
+    g = torch.Generator().manual_seed(91)
+    n, k, vocab, E = 4, 8, [5, 6, 2], 2100
+    idx = torch.stack([torch.randint(0, v, (E,), generator=g) for v in vocab], dim=1).to(DEV)
+    encs = []
+    for li in range(4):
+        tabs = [[(torch.randn(v, k, generator=g) * 0.5).to(DEV).requires_grad_() for v in vocab] for _ in range(n)]
+        encs.append((tabs, torch.randn(E, n * k, generator=g).to(DEV), torch.nn.Module()))
+    vocab_a, N = [7, 3, 4, 9], 333
+    idx_a = torch.stack([torch.randint(0, v, (N,), generator=g) for v in vocab_a], dim=1).to(DEV)
+    tabs_a = [[(torch.randn(v, k, generator=g) * 0.5).to(DEV).requires_grad_() for v in vocab_a] for _ in range(n)]
+    dy_a, owner_a = torch.randn(N, n * k, generator=g).to(DEV), torch.nn.Module()
+
+    def run(deferred):
+        every = [t for tabs, _, _ in encs for comp in tabs for t in comp] + [t for comp in tabs_a for t in comp]
+        for t in every:
+            t.grad = None
+        encs[1][0][0][0].grad = torch.full_like(encs[1][0][0][0], 0.5)
+        ctx = ops.deferred_param_grads() if deferred else __import__("contextlib").nullcontext()
+        with ctx:
+            total = (ops.encode(idx_a, ops.tableset_for(owner_a, tabs_a), tabs_a) * dy_a).sum()
+            for tabs, dy, owner in encs:
+                total = total + (ops.encode(idx, ops.tableset_for(owner, tabs), tabs) * dy).sum()
+            total.backward()
+        return [t.grad.clone() for t in every]
+
+    a, b = run(True), run(False)
+    for i, (x1, x2) in enumerate(zip(a, b)):
+        assert_close(x1, x2, 5e-6, f"table {i}")
+
+
 def test_counted_bond_table_gradients_match_the_oracle(ops):
     """phc_table_grads_counted against autograd through the CPU oracle's embedding sum + scatter (N1 row), with
     isolated destination nodes, multi-edges and a node count that is not a multiple of the 64-node block."""
