@@ -464,6 +464,11 @@ int phc_gated_pool_bwd(const float *dout, const float *x, const float *gate, con
  * every layer's skip connection (models.py:230-234) — in one pass instead of n-1 pairwise adds. */
 int phc_sum_n(const float *const *srcs, int n, int64_t numel, float *out, void *stream);
 
+/* *outs[j] = sum of srcs[j][0 .. lens[j])  for up to 16 vectors in one launch (one workgroup each, fixed order): the
+ * d/d beta partial sums of every softmax-aggregation layer of a step (phc_aggregate_softmax_bwd writes
+ * phc_softmax_bwd_num_partials values per layer).  srcs / lens / outs are HOST arrays of device pointers / lengths. */
+int phc_vec_sums(const float *const *srcs, const int32_t *lens, float *const *outs, int num, void *stream);
+
 /* The last dense map of the read-out (RealTransformer 'linear', layers.py:399-414: n*target -> target columns,
  * 4 -> 1 for ogbg-molhiv) on B rows: y = x.w^T + b with in*out <= phc_small_linear_max_weights(), one launch
  * forward and one backward (dx row-parallel; dw, db by one workgroup in a fixed order) instead of a BLAS

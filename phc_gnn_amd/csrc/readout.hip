@@ -287,11 +287,56 @@ __global__ __launch_bounds__(256) void sum_n_kernel(SumSrcs srcs, int n, long lo
         }
 }
 
+// ---- several partial-sum vectors to scalars: out[j] = sum(src[j][0 .. len[j])) ---------------------------------
+// One workgroup per vector, fixed order (lane-strided partial sums, then a fixed tree): the d/d beta partials of all
+// softmax-aggregation layers of a step in one launch instead of one framework reduction per layer.
+struct VecSums {
+    const float *p[SUMN_MAX];
+    int len[SUMN_MAX];
+    float *out[SUMN_MAX];
+};
+
+__global__ __launch_bounds__(256) void vec_sums_kernel(VecSums v) {
+    __shared__ float red[256];
+    const float *src = v.p[blockIdx.x];
+    const int n = v.len[blockIdx.x];
+    float s = 0.f;
+    for (int e0 = 0; e0 < n; e0 += 8 * 256) {                // eight loads per round trip (clamped, selected)
+        float t[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) t[q] = src[min(e0 + (int)threadIdx.x + 256 * q, n - 1)];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) s += e0 + (int)threadIdx.x + 256 * q < n ? t[q] : 0.f;
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *v.out[blockIdx.x] = red[0];
+}
+
 }  // namespace phc
 
 using namespace phc;
 
 extern "C" {
+
+int phc_vec_sums(const float *const *srcs, const int32_t *lens, float *const *outs, int num, void *stream) {
+    PHC_REQUIRE(num >= 1 && num <= SUMN_MAX && srcs && lens && outs, PHC_ERR_INVALID_ARG, "phc_vec_sums: %d vectors (1..%d)", num, SUMN_MAX);
+    VecSums v;
+    for (int j = 0; j < SUMN_MAX; ++j) {
+        v.p[j] = j < num ? srcs[j] : nullptr;
+        v.len[j] = j < num ? lens[j] : 0;
+        v.out[j] = j < num ? outs[j] : nullptr;
+        PHC_REQUIRE(j >= num || (srcs[j] && outs[j] && lens[j] >= 1), PHC_ERR_INVALID_ARG, "phc_vec_sums: vector %d: null or empty", j);
+    }
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(K_SUM_N, s);
+    PHC_LAUNCH(vec_sums_kernel, dim3((unsigned)num), dim3(256), 0, s, v);
+    return check_launch("vec_sums");
+}
 
 size_t phc_bce_masked_ws_bytes(int64_t total) {
     if (total < 0) return 0;

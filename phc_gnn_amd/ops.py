@@ -43,6 +43,7 @@ class _Deferred:
         self.jobs = []
         self.table_jobs = []
         self.atom_jobs = []
+        self.beta_jobs = []
         self.lock = threading.Lock()       # the backward pass runs on autograd's device thread
 
 
@@ -57,17 +58,20 @@ def deferred_param_grads():
         yield
         return
     _DEFER.active = True
-    _DEFER.jobs, _DEFER.table_jobs, _DEFER.atom_jobs = [], [], []
+    _DEFER.jobs, _DEFER.table_jobs, _DEFER.atom_jobs, _DEFER.beta_jobs = [], [], [], []
     try:
         yield
     except BaseException:
         _DEFER.active = False
-        _DEFER.jobs, _DEFER.table_jobs, _DEFER.atom_jobs = [], [], []
+        _DEFER.jobs, _DEFER.table_jobs, _DEFER.atom_jobs, _DEFER.beta_jobs = [], [], [], []
         raise
     _DEFER.active = False
     jobs, _DEFER.jobs = _DEFER.jobs, []
     tjobs, _DEFER.table_jobs = _DEFER.table_jobs, []
     ajobs, _DEFER.atom_jobs = _DEFER.atom_jobs, []
+    bjobs, _DEFER.beta_jobs = _DEFER.beta_jobs, []
+    if bjobs:
+        _flush_beta_grads(bjobs)
     if STEP_TAIL_MERGED and len(ajobs) > 1:
         # several row-contiguous encoder jobs (a model whose bond encoders run on the [E, h] tensor path, e.g. softmax
         # aggregation): the tail launch takes the largest, the others run on their own first
@@ -115,6 +119,21 @@ def _flush_atom_grads(aj) -> None:
         if L.PROF_ON:
             L.account("table_grad", 1.0 * N * ts.F * ts.n * ts.k, N * (8.0 * ts.F + 4.0 * ts.n * ts.k))
     _assign_grads(aj["params"], ts.grad_views(flat))
+
+
+def _flush_beta_grads(bjobs) -> None:
+    """d loss / d beta of the softmax-aggregation layers: their per-workgroup partial sums -> scalars, 16 per launch."""
+    lib = L.load()
+    for c0 in range(0, len(bjobs), 16):
+        chunk = bjobs[c0:c0 + 16]
+        dev = chunk[0][0].device
+        with torch.cuda.device(dev):
+            out = torch.empty(len(chunk), dtype=torch.float32, device=dev)
+            srcs = (_C.c_void_p * len(chunk))(*[L.ptr(p) for p, _ in chunk])
+            lens = (_C.c_int32 * len(chunk))(*[p.numel() for p, _ in chunk])
+            outs = (_C.c_void_p * len(chunk))(*[L.ptr(out) + 4 * i for i in range(len(chunk))])
+            L.check(lib.phc_vec_sums(srcs, lens, outs, len(chunk), L.stream_ptr(dev)), "phc_vec_sums")
+        _assign_grads([b for _, b in chunk], [out[i].reshape(b.shape) for i, (_, b) in enumerate(chunk)])
 
 
 def _flush_encoder_grads(ajobs) -> None:
@@ -825,6 +844,8 @@ class _AggregateSoftmaxFn(torch.autograd.Function):
             E, N = st.num_edges, st.num_dst
             L.account("aggregate_softmax_fwd", 8.0 * E * h, E * (4.0 * h * (2 if ea is not None else 1) + 8) + N * 8.0 * h)
         ctx.st, ctx.act, ctx.has_ea, ctx.add_self = st, act, ea is not None, bool(add_self)
+        # a leaf nn.Parameter beta can take its gradient at the end of the backward pass (deferred_param_grads)
+        ctx.beta_param = beta if (_DEFER.active and beta.is_leaf and beta.grad_fn is None and beta.requires_grad) else None
         ctx.save_for_backward(x_, ea_ if ea is not None else x_.new_empty(0), beta_, out, lse)
         return out_self if add_self else out
 
@@ -850,7 +871,15 @@ class _AggregateSoftmaxFn(torch.autograd.Function):
         if L.PROF_ON:
             E, N = st.num_edges, st.num_src
             L.account("aggregate_softmax_bwd", 12.0 * E * h, E * (4.0 * h * (5 if need_ea else 4) + 8) + N * 8.0 * h)
-        dbeta = parts.sum().reshape(()) if ctx.needs_input_grad[2] else None
+        dbeta = None
+        if ctx.needs_input_grad[2]:
+            beta_param = ctx.beta_param
+            if beta_param is not None and _DEFER.active and not torch.is_grad_enabled():
+                # d/d beta of all softmax layers of the step: one phc_vec_sums launch at the end of the backward pass
+                with _DEFER.lock:
+                    _DEFER.beta_jobs.append((parts, beta_param))
+            else:
+                dbeta = parts.sum().reshape(())
         return (dx if ctx.needs_input_grad[0] else None), dea, dbeta, None, None, None
 
 

@@ -348,6 +348,55 @@ def test_step_tail_in_one_pass_equals_the_separate_gradient_launches(wl, monkeyp
         assert torch.equal(grads[0][k], grads[1][k]), k
 
 
+@pytest.mark.parametrize("wl", ["molhiv_b32", "molhiv_b512_softmax", "molhiv_b512_conv"])
+def test_training_step_with_deferred_gradients_equals_plain_autograd(wl):
+    """harness.train_step (prebuilt operand matrices, every parameter gradient deferred to the end of the backward
+    pass: PHM / dense layers, atom and bond tables, the softmax layers' beta) vs the same model under plain
+    ``loss.backward()``: identical loss, all parameter gradients within fp32 summation noise."""
+    from phc_gnn_amd import harness
+    d = harness.to_device(harness.make_batch(wl, seed=33), DEV)
+    m, _ = _fresh(wl, seed=9)
+    loss_d = harness.train_step(m, d, None, harness.StepConfig(optimizer=False))
+    g_def = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
+    for p in m.parameters():
+        p.grad = None
+    loss_p = harness.loss_fn(m(d), d)
+    loss_p.backward()
+    g_plain = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+    assert_close(loss_d, loss_p, 1e-6, "loss")
+    assert g_def.keys() == g_plain.keys() and len(g_def) > 50
+    # biases in front of a batch-norm have an exactly-zero gradient (round-off only): no relative error to speak of
+    # per tensor max|diff| against max|ref|, floored at 1 % of the largest gradient of the model: sums over ~13 k rows
+    # that nearly cancel (a norm's bias in the last layer) carry the runs' last-bit differences at their own scale
+    top = max(float(v.abs().max()) for v in g_plain.values())
+    worst = max((float((g_def[k] - g_plain[k]).abs().max()) / max(float(g_plain[k].abs().max()), 0.01 * top), k)
+                for k in g_def if not k.endswith(".beta"))
+    assert worst[0] < 2e-4, worst
+    if "softmax" in wl:
+        # d/d beta at the initial beta = 1 is a sum of ~3000 partials of magnitude 1e-4 each that cancels to ~1e-4: the
+        # two runs' upstream gradients differ in the last bit (prebuilt vs in-kernel operand matrices), which moves the
+        # total by ~1e-6 — compared on that absolute scale (phc_vec_sums itself is checked against float64 below)
+        betas = [k for k in g_def if k.endswith(".beta")]
+        assert len(betas) == 4
+        for k in betas:
+            assert abs(float(g_def[k]) - float(g_plain[k])) < 2e-5, (k, float(g_def[k]), float(g_plain[k]))
+
+
+def test_vec_sums_matches_float64():
+    from phc_gnn_amd import lib as L
+    import ctypes as C
+    g = torch.Generator().manual_seed(4)
+    vecs = [torch.randn(n, generator=g).to(DEV) for n in (1, 255, 3312, 4096, 9000)]
+    out = torch.zeros(len(vecs), device=DEV)
+    srcs = (C.c_void_p * len(vecs))(*[v.data_ptr() for v in vecs])
+    lens = (C.c_int32 * len(vecs))(*[v.numel() for v in vecs])
+    outs = (C.c_void_p * len(vecs))(*[out.data_ptr() + 4 * i for i in range(len(vecs))])
+    L.check(L.load().phc_vec_sums(srcs, lens, outs, len(vecs), L.stream_ptr(torch.device(DEV))), "phc_vec_sums")
+    for i, v in enumerate(vecs):
+        ref = float(v.double().sum())
+        assert abs(float(out[i]) - ref) <= 1e-5 * float(v.double().abs().sum()), (i, float(out[i]), ref)
+
+
 # ---- multi-GPU paths exercised on ONE GPU with a single-rank RCCL group ---------------------------
 @pytest.fixture(scope="module")
 def rccl_single_rank():
