@@ -348,14 +348,23 @@ def test_step_tail_in_one_pass_equals_the_separate_gradient_launches(wl, monkeyp
         assert torch.equal(grads[0][k], grads[1][k]), k
 
 
-@pytest.mark.parametrize("wl", ["molhiv_b32", "molhiv_b512_softmax", "molhiv_b512_conv"])
-def test_training_step_with_deferred_gradients_equals_plain_autograd(wl):
+@pytest.mark.parametrize("variant", ["molhiv_b512", "molhiv_b512_softmax", "molhiv_b512_conv"])
+def test_training_step_with_deferred_gradients_equals_plain_autograd(variant, monkeypatch):
     """harness.train_step (prebuilt operand matrices, every parameter gradient deferred to the end of the backward
     pass: PHM / dense layers, atom and bond tables, the softmax layers' beta) vs the same model under plain
-    ``loss.backward()``: identical loss, all parameter gradients within fp32 summation noise."""
+    ``loss.backward()``: identical loss, all parameter gradients within fp32 summation noise.
+    Run with the smooth ``swish`` activation: with ReLU a handful of the 1.7 M pre-activations per layer sit within one
+    ulp of the kink, and which side they fall on differs between any two fp32 evaluation orders — the float32 CPU
+    oracle, the plain path and the deferred path each differ from a float64 oracle by up to 0.4 % in a few gradient
+    tensors at 512 graphs (scripts/exp/dbg_defer64.py; the first two by identical amounts), more at 32."""
+    from phc.hypercomplex.undirectional.models import PHMSkipConnectAdd
     from phc_gnn_amd import harness
+    wl = variant
     d = harness.to_device(harness.make_batch(wl, seed=33), DEV)
-    m, _ = _fresh(wl, seed=9)
+    torch.manual_seed(9)
+    __import__("numpy").random.seed(9)
+    m = PHMSkipConnectAdd(**dict(harness.model_kwargs(harness.WORKLOADS[wl]), activation="swish")).to(DEV)
+    m.train()
     loss_d = harness.train_step(m, d, None, harness.StepConfig(optimizer=False))
     g_def = {k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None}
     for p in m.parameters():
