@@ -188,8 +188,15 @@ class _SoftmaxMixin:
         return out + x if (add_self and not fused_self) else out
 
     def propagate_encoded(self, edge_index, x, edge_idx, encoder, size=None, add_self=False):
-        # softmax weights need the per-edge message: embed the bonds ([E, h]) and take the tensor path
-        ea = encoder(edge_idx)
+        """Softmax aggregation with edge_attr = encoder(edge_idx): the kernels add the F table rows of every edge
+        themselves (packed codes, tables from L2), so no [E, h] embedding is built in the forward pass."""
+        tables = encoder.engine_tables
+        ts = _engine.tableset_for(encoder, tables)
+        num_dst = size[1] if size is not None and size[1] is not None else None
+        if ts.F <= 4 and ts.R <= 256 and ts.k % 4 == 0 and (num_dst is None or num_dst == x.size(0) or not add_self):
+            return _engine.aggregate_softmax_encoded(x, edge_index, edge_idx, ts, tables, self.beta, self.msg_encoder_str,
+                                                     add_self=add_self, num_dst=num_dst)
+        ea = encoder(edge_idx)                               # wider vocabularies: embed the bonds and take the tensor path
         return self.propagate(edge_index, x=x, edge_attr=ea.reshape(ea.size(0), -1), size=size, add_self=add_self)
 
     def aggregate(self, inputs: torch.Tensor, index: torch.Tensor, dim_size: Optional[int] = None) -> torch.Tensor:

@@ -9,12 +9,32 @@
 // destination segment with an online (running max / running sum) softmax per column, all in registers.
 // Backward walks the source-sorted structure and rebuilds the weights from the saved log-sum-exp:
 //     w_e = exp(beta*m_e - lse[d]);  d out/d m_e = w_e * (1 + beta*(m_e - out[d]));  d out/d beta = sum_e w_e m_e (m_e - out[d])
+#include <string.h>
 #include "phc_common.h"
 
 namespace phc {
 
 constexpr int SM_THREADS = 256;
 constexpr float SM_EPS = 1e-12f;
+
+// Bond embedding read in place (SURVEY §8f N1 on the softmax operators): instead of an [E, h] edge tensor the kernels
+// take the packed table rows of every edge (phc_pack_edge_codes: byte f = off_f + value) and the n*F table pointers,
+// and add the F table rows to x[src] themselves (rows come from L2: a bond encoder has 13 rows).
+struct SmEnc {
+    const unsigned *codes;                   // NULL: use the edge tensor
+    const float *const *tables;              // [n * F] device pointers, table (c, f) is [V_f, k]
+    int F, k;
+    int off[4];
+};
+
+__device__ __forceinline__ float4 sm_enc_rows(const SmEnc &enc, const float *const *tp, unsigned code) {
+    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
+    for (int f = 0; f < enc.F; ++f) {
+        const float4 t = *reinterpret_cast<const float4 *>(tp[f] + (size_t)((code >> (8 * f)) & 255u) * enc.k);
+        a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+    }
+    return a;
+}
 
 struct Sm4 {            // online softmax state for 4 columns
     float4 mx, s, w;
@@ -48,7 +68,8 @@ __global__ __launch_bounds__(SM_THREADS) void softmax_agg_fwd_kernel(const float
                                                                   const int *__restrict__ rowptr, const int *__restrict__ col,
                                                                   const int *__restrict__ perm, const float *__restrict__ beta_p,
                                                                   long long n_dst, int h, float *__restrict__ out,
-                                                                  float *__restrict__ lse, float *__restrict__ out_self) {
+                                                                  float *__restrict__ lse, float *__restrict__ out_self,
+                                                                  SmEnc enc) {
     // out_self != NULL: also writes out + x[d] (the layer's self loop, messagepassing.py:222-231 / :303-309); `out`
     // stays the plain aggregate, which the backward needs
     constexpr int G = WAVE / LPR;
@@ -62,9 +83,17 @@ __global__ __launch_bounds__(SM_THREADS) void softmax_agg_fwd_kernel(const float
         const int e_begin = rowptr[d], e_end = rowptr[d + 1];
         for (int c4 = li; c4 < h4; c4 += LPR) {
             float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, s[4] = {0.f, 0.f, 0.f, 0.f}, w[4] = {0.f, 0.f, 0.f, 0.f};
+            const float *tp[4] = {nullptr, nullptr, nullptr, nullptr};
+            if (enc.codes) {                                 // this lane's slice of its component's F tables
+                const int c = (c4 * 4) / enc.k, kk = c4 * 4 - c * enc.k;
+                for (int f = 0; f < enc.F; ++f) tp[f] = enc.tables[c * enc.F + f] + kk - (size_t)enc.off[f] * enc.k;
+            }
             for (int e = e_begin + grp; e < e_end; e += G) {
                 float4 v = reinterpret_cast<const float4 *>(x + (size_t)col[e] * h)[c4];
-                if (ea) {
+                if (enc.codes) {                             // codes in destination-sorted order: indexed by e
+                    const float4 a = sm_enc_rows(enc, tp, enc.codes[e]);
+                    v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+                } else if (ea) {
                     const float4 a = reinterpret_cast<const float4 *>(ea + (size_t)perm[e] * h)[c4];
                     v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
                 }
@@ -107,7 +136,7 @@ __global__ __launch_bounds__(SM_THREADS) void softmax_agg_bwd_kernel(
     const float *__restrict__ dout, const float *__restrict__ out, const float *__restrict__ lse, const float *__restrict__ x,
     const float *__restrict__ ea, const float *__restrict__ beta_p, const int *__restrict__ rowptr_t, const int *__restrict__ col_t,
     const int *__restrict__ perm_t, long long n_src, int h, float *__restrict__ dx, float *__restrict__ dea,
-    float *__restrict__ dbeta_partial, long long self_n_dst) {
+    float *__restrict__ dbeta_partial, long long self_n_dst, SmEnc enc) {
     __shared__ float red[SM_THREADS];
     constexpr int G = WAVE / LPR;
     const int lane = threadIdx.x & 63;
@@ -122,11 +151,19 @@ __global__ __launch_bounds__(SM_THREADS) void softmax_agg_bwd_kernel(
         for (int c4 = li; c4 < h4; c4 += LPR) {
             const float4 xs = reinterpret_cast<const float4 *>(x + (size_t)sidx * h)[c4];
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
+            const float *tp[4] = {nullptr, nullptr, nullptr, nullptr};
+            if (enc.codes) {
+                const int c = (c4 * 4) / enc.k, kk = c4 * 4 - c * enc.k;
+                for (int f = 0; f < enc.F; ++f) tp[f] = enc.tables[c * enc.F + f] + kk - (size_t)enc.off[f] * enc.k;
+            }
             for (int e = e_begin + grp; e < e_end; e += G) {
                 const size_t d = (size_t)col_t[e];
                 const size_t p = (size_t)perm_t[e];
                 float pre[4] = {xs.x, xs.y, xs.z, xs.w};
-                if (ea) {
+                if (enc.codes) {                             // codes in ORIGINAL edge order: indexed by p
+                    const float4 a = sm_enc_rows(enc, tp, enc.codes[p]);
+                    pre[0] += a.x; pre[1] += a.y; pre[2] += a.z; pre[3] += a.w;
+                } else if (ea) {
                     const float4 a = reinterpret_cast<const float4 *>(ea + p * h)[c4];
                     pre[0] += a.x; pre[1] += a.y; pre[2] += a.z; pre[3] += a.w;
                 }
@@ -204,9 +241,48 @@ int phc_aggregate_softmax_fwd(const float *x, const float *ea, const int32_t *ro
     return phc_aggregate_softmax_fwd_self(x, ea, rowptr, col, perm, beta_dev, n_dst, h, act, out, nullptr, lse, stream);
 }
 
+static int sm_make_enc(const char *who, const uint32_t *codes, const float *const *tables, const int32_t *vocab, int F, int n, int k, int h,
+                       SmEnc *enc) {
+    PHC_REQUIRE(codes && tables && vocab && F >= 1 && F <= 4 && n >= 1 && k >= 1 && n * k == h && k % 4 == 0, PHC_ERR_INVALID_ARG,
+                "%s: needs codes, tables, 1 <= F <= 4, h = n*k, k %% 4 == 0", who);
+    enc->codes = codes; enc->tables = tables; enc->F = F; enc->k = k;
+    int off = 0;
+    for (int f = 0; f < 4; ++f) {
+        enc->off[f] = off;
+        if (f < F) {
+            PHC_REQUIRE(vocab[f] >= 1, PHC_ERR_INVALID_ARG, "%s: vocab[%d] = %d", who, f, vocab[f]);
+            off += vocab[f];
+        }
+    }
+    PHC_REQUIRE(off <= 256, PHC_ERR_UNSUPPORTED, "%s: packed codes need sum(vocab) <= 256", who);
+    return PHC_OK;
+}
+
+static int sm_fwd_impl(const float *x, const float *ea, const int32_t *rowptr, const int32_t *col, const int32_t *perm,
+                       const float *beta_dev, int64_t n_dst, int h, int act, float *out, float *out_self, float *lse, SmEnc enc,
+                       void *stream);
+
 int phc_aggregate_softmax_fwd_self(const float *x, const float *ea, const int32_t *rowptr, const int32_t *col, const int32_t *perm,
                                    const float *beta_dev, int64_t n_dst, int h, int act, float *out, float *out_self, float *lse,
                                    void *stream) {
+    SmEnc enc;
+    SmEnc zero = {};
+    enc = zero;
+    return sm_fwd_impl(x, ea, rowptr, col, perm, beta_dev, n_dst, h, act, out, out_self, lse, enc, stream);
+}
+
+int phc_aggregate_softmax_enc_fwd(const float *x, const uint32_t *codes_sorted, const float *const *tables, const int32_t *vocab, int F,
+                                  int n, int k, const int32_t *rowptr, const int32_t *col, const float *beta_dev, int64_t n_dst,
+                                  int act, float *out, float *out_self, float *lse, void *stream) {
+    SmEnc enc;
+    int rc = sm_make_enc("phc_aggregate_softmax_enc_fwd", codes_sorted, tables, vocab, F, n, k, n * k, &enc);
+    if (rc) return rc;
+    return sm_fwd_impl(x, nullptr, rowptr, col, nullptr, beta_dev, n_dst, n * k, act, out, out_self, lse, enc, stream);
+}
+
+static int sm_fwd_impl(const float *x, const float *ea, const int32_t *rowptr, const int32_t *col, const int32_t *perm,
+                       const float *beta_dev, int64_t n_dst, int h, int act, float *out, float *out_self, float *lse, SmEnc enc,
+                       void *stream) {
     PHC_REQUIRE(!out_self || sm_al16(out_self), PHC_ERR_UNSUPPORTED, "phc_aggregate_softmax_fwd_self: out_self must be 16-byte aligned");
     PHC_REQUIRE(n_dst >= 0 && h >= 1, PHC_ERR_INVALID_ARG, "phc_aggregate_softmax_fwd: bad sizes");
     PHC_REQUIRE(act >= PHC_ACT_IDENTITY && act <= PHC_ACT_SELU, PHC_ERR_INVALID_ARG, "phc_aggregate_softmax_fwd: unknown activation %d", act);
@@ -219,10 +295,10 @@ int phc_aggregate_softmax_fwd_self(const float *x, const float *ea, const int32_
     ProfScope prof(K_SOFTMAX_FWD, s);
 #define PHC_SM_FWD(ACTC)                                                                                                 \
     switch (lpr) {                                                                                                       \
-        case 8: PHC_LAUNCH((softmax_agg_fwd_kernel<8, ACTC>), dim3(sm_grid(n_dst)), dim3(SM_THREADS), 0, s, x, ea, rowptr, col, perm, beta_dev, (long long)n_dst, h, out, lse, out_self); break;   \
-        case 16: PHC_LAUNCH((softmax_agg_fwd_kernel<16, ACTC>), dim3(sm_grid(n_dst)), dim3(SM_THREADS), 0, s, x, ea, rowptr, col, perm, beta_dev, (long long)n_dst, h, out, lse, out_self); break; \
-        case 32: PHC_LAUNCH((softmax_agg_fwd_kernel<32, ACTC>), dim3(sm_grid(n_dst)), dim3(SM_THREADS), 0, s, x, ea, rowptr, col, perm, beta_dev, (long long)n_dst, h, out, lse, out_self); break; \
-        default: PHC_LAUNCH((softmax_agg_fwd_kernel<64, ACTC>), dim3(sm_grid(n_dst)), dim3(SM_THREADS), 0, s, x, ea, rowptr, col, perm, beta_dev, (long long)n_dst, h, out, lse, out_self); break; \
+        case 8: PHC_LAUNCH((softmax_agg_fwd_kernel<8, ACTC>), dim3(sm_grid(n_dst)), dim3(SM_THREADS), 0, s, x, ea, rowptr, col, perm, beta_dev, (long long)n_dst, h, out, lse, out_self, enc); break;   \
+        case 16: PHC_LAUNCH((softmax_agg_fwd_kernel<16, ACTC>), dim3(sm_grid(n_dst)), dim3(SM_THREADS), 0, s, x, ea, rowptr, col, perm, beta_dev, (long long)n_dst, h, out, lse, out_self, enc); break; \
+        case 32: PHC_LAUNCH((softmax_agg_fwd_kernel<32, ACTC>), dim3(sm_grid(n_dst)), dim3(SM_THREADS), 0, s, x, ea, rowptr, col, perm, beta_dev, (long long)n_dst, h, out, lse, out_self, enc); break; \
+        default: PHC_LAUNCH((softmax_agg_fwd_kernel<64, ACTC>), dim3(sm_grid(n_dst)), dim3(SM_THREADS), 0, s, x, ea, rowptr, col, perm, beta_dev, (long long)n_dst, h, out, lse, out_self, enc); break; \
     }
     PHC_SM_ACT(act, PHC_SM_FWD)
 #undef PHC_SM_FWD
@@ -241,10 +317,35 @@ int phc_aggregate_softmax_bwd(const float *dout, const float *out, const float *
                                           dbeta_partial, stream);
 }
 
+static int sm_bwd_impl(const float *dout, const float *out, const float *lse, const float *x, const float *ea, const float *beta_dev,
+                       const int32_t *rowptr_t, const int32_t *col_t, const int32_t *perm_t, int64_t n_src, int h, int act,
+                       int64_t self_n_dst, float *dx, float *dea, float *dbeta_partial, SmEnc enc, void *stream);
+
 int phc_aggregate_softmax_bwd_self(const float *dout, const float *out, const float *lse, const float *x, const float *ea,
                                    const float *beta_dev, const int32_t *rowptr_t, const int32_t *col_t, const int32_t *perm_t,
                                    int64_t n_src, int h, int act, int64_t self_n_dst, float *dx, float *dea, float *dbeta_partial,
                                    void *stream) {
+    SmEnc enc;
+    SmEnc zero = {};
+    enc = zero;
+    return sm_bwd_impl(dout, out, lse, x, ea, beta_dev, rowptr_t, col_t, perm_t, n_src, h, act, self_n_dst, dx, dea, dbeta_partial,
+                       enc, stream);
+}
+
+int phc_aggregate_softmax_enc_bwd(const float *dout, const float *out, const float *lse, const float *x, const uint32_t *codes_orig,
+                                  const float *const *tables, const int32_t *vocab, int F, int n, int k, const float *beta_dev,
+                                  const int32_t *rowptr_t, const int32_t *col_t, const int32_t *perm_t, int64_t n_src, int act,
+                                  int64_t self_n_dst, float *dx, float *dea, float *dbeta_partial, void *stream) {
+    SmEnc enc;
+    int rc = sm_make_enc("phc_aggregate_softmax_enc_bwd", codes_orig, tables, vocab, F, n, k, n * k, &enc);
+    if (rc) return rc;
+    return sm_bwd_impl(dout, out, lse, x, nullptr, beta_dev, rowptr_t, col_t, perm_t, n_src, n * k, act, self_n_dst, dx, dea,
+                       dbeta_partial, enc, stream);
+}
+
+static int sm_bwd_impl(const float *dout, const float *out, const float *lse, const float *x, const float *ea, const float *beta_dev,
+                       const int32_t *rowptr_t, const int32_t *col_t, const int32_t *perm_t, int64_t n_src, int h, int act,
+                       int64_t self_n_dst, float *dx, float *dea, float *dbeta_partial, SmEnc enc, void *stream) {
     PHC_REQUIRE(self_n_dst >= 0, PHC_ERR_INVALID_ARG, "phc_aggregate_softmax_bwd_self: bad self_n_dst");
     PHC_REQUIRE(n_src >= 0 && h >= 1, PHC_ERR_INVALID_ARG, "phc_aggregate_softmax_bwd: bad sizes");
     PHC_REQUIRE(act >= PHC_ACT_IDENTITY && act <= PHC_ACT_SELU, PHC_ERR_INVALID_ARG, "phc_aggregate_softmax_bwd: unknown activation %d", act);
@@ -258,10 +359,10 @@ int phc_aggregate_softmax_bwd_self(const float *dout, const float *out, const fl
     ProfScope prof(K_SOFTMAX_BWD, s);
 #define PHC_SM_BWD(ACTC)                                                                                                 \
     switch (lpr) {                                                                                                       \
-        case 8: PHC_LAUNCH((softmax_agg_bwd_kernel<8, ACTC>), dim3(sm_grid(n_src)), dim3(SM_THREADS), 0, s, dout, out, lse, x, ea, beta_dev, rowptr_t, col_t, perm_t, (long long)n_src, h, dx, dea, dbeta_partial, (long long)self_n_dst); break;   \
-        case 16: PHC_LAUNCH((softmax_agg_bwd_kernel<16, ACTC>), dim3(sm_grid(n_src)), dim3(SM_THREADS), 0, s, dout, out, lse, x, ea, beta_dev, rowptr_t, col_t, perm_t, (long long)n_src, h, dx, dea, dbeta_partial, (long long)self_n_dst); break; \
-        case 32: PHC_LAUNCH((softmax_agg_bwd_kernel<32, ACTC>), dim3(sm_grid(n_src)), dim3(SM_THREADS), 0, s, dout, out, lse, x, ea, beta_dev, rowptr_t, col_t, perm_t, (long long)n_src, h, dx, dea, dbeta_partial, (long long)self_n_dst); break; \
-        default: PHC_LAUNCH((softmax_agg_bwd_kernel<64, ACTC>), dim3(sm_grid(n_src)), dim3(SM_THREADS), 0, s, dout, out, lse, x, ea, beta_dev, rowptr_t, col_t, perm_t, (long long)n_src, h, dx, dea, dbeta_partial, (long long)self_n_dst); break; \
+        case 8: PHC_LAUNCH((softmax_agg_bwd_kernel<8, ACTC>), dim3(sm_grid(n_src)), dim3(SM_THREADS), 0, s, dout, out, lse, x, ea, beta_dev, rowptr_t, col_t, perm_t, (long long)n_src, h, dx, dea, dbeta_partial, (long long)self_n_dst, enc); break;   \
+        case 16: PHC_LAUNCH((softmax_agg_bwd_kernel<16, ACTC>), dim3(sm_grid(n_src)), dim3(SM_THREADS), 0, s, dout, out, lse, x, ea, beta_dev, rowptr_t, col_t, perm_t, (long long)n_src, h, dx, dea, dbeta_partial, (long long)self_n_dst, enc); break; \
+        case 32: PHC_LAUNCH((softmax_agg_bwd_kernel<32, ACTC>), dim3(sm_grid(n_src)), dim3(SM_THREADS), 0, s, dout, out, lse, x, ea, beta_dev, rowptr_t, col_t, perm_t, (long long)n_src, h, dx, dea, dbeta_partial, (long long)self_n_dst, enc); break; \
+        default: PHC_LAUNCH((softmax_agg_bwd_kernel<64, ACTC>), dim3(sm_grid(n_src)), dim3(SM_THREADS), 0, s, dout, out, lse, x, ea, beta_dev, rowptr_t, col_t, perm_t, (long long)n_src, h, dx, dea, dbeta_partial, (long long)self_n_dst, enc); break; \
     }
     PHC_SM_ACT(act, PHC_SM_BWD)
 #undef PHC_SM_BWD

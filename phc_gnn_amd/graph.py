@@ -62,6 +62,8 @@ class EdgeStructure:
         self._csc: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None
         self._codes: dict = {}
         self._codes_args = None
+        self._codes_orig: dict = {}
+        self._codes_orig_args = None
 
     def packed_codes(self, bond_idx: torch.Tensor, vocab_c, F: int) -> torch.Tensor:
         """uint32 per edge in destination-sorted order: the F table rows of the edge's integer features, one
@@ -75,10 +77,21 @@ class EdgeStructure:
             self._codes_args = (bond_idx, vocab_c, F)
         return codes
 
-    def _pack_codes(self, bond_idx, vocab_c, F, codes) -> None:
-        _, _, perm = self.csr
+    def _pack_codes(self, bond_idx, vocab_c, F, codes, sorted_order: bool = True) -> None:
+        perm = self.csr[2] if sorted_order else None
         L.check(L.load().phc_pack_edge_codes(L.ptr(bond_idx), L.ptr(perm), vocab_c, self.num_edges, F, L.ptr(codes),
                                              L.stream_ptr(bond_idx.device)), "phc_pack_edge_codes")
+
+    def packed_codes_orig(self, bond_idx: torch.Tensor, vocab_c, F: int) -> torch.Tensor:
+        """The same codes in ORIGINAL edge order (the source-sorted backward walk addresses edges by their original id)."""
+        key = (bond_idx.data_ptr(), bond_idx._version, tuple(vocab_c))
+        codes = self._codes_orig.get(key)
+        if codes is None:
+            codes = torch.empty(self.num_edges, dtype=torch.int32, device=bond_idx.device)
+            self._pack_codes(bond_idx, vocab_c, F, codes, sorted_order=False)
+            self._codes_orig = {key: codes}
+            self._codes_orig_args = (bond_idx, vocab_c, F)
+        return codes
 
     def rebuild(self) -> None:
         """Recompute every view that has been built — same tensors, new contents — after the edge list (and the bond
@@ -94,6 +107,8 @@ class EdgeStructure:
                 _build_sorted(self._src, self._dst, self.num_src, out=self._csc)
         for codes in self._codes.values():
             self._pack_codes(*self._codes_args, codes)
+        for codes in self._codes_orig.values():
+            self._pack_codes(*self._codes_orig_args, codes, sorted_order=False)
 
     PAIR_MAX_ROWS = 16383
 

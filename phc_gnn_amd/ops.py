@@ -893,6 +893,98 @@ def aggregate_softmax(x: torch.Tensor, edge_index, edge_attr: Optional[torch.Ten
     return _AggregateSoftmaxFn.apply(x, edge_attr, beta, st, _act_id(msg_encoder), add_self)
 
 
+class _AggregateSoftmaxEncFn(torch.autograd.Function):
+    """Softmax aggregation with the bond encoder read in place (packed codes + tables, no [E, h] forward tensor)."""
+
+    @staticmethod
+    def forward(ctx, x, bond_idx, beta, st: EdgeStructure, act: int, add_self: bool, ts: "TableSet", *tables):
+        lib = L.load()
+        dev = L.require_device(x, bond_idx, beta)
+        x_ = L.f32c(x)
+        bond_ = _idx64(bond_idx)
+        beta_ = L.f32c(beta.reshape(1))
+        h = x_.shape[1]
+        if h != ts.n * ts.k:
+            raise L.PhcError(f"x has {h} features, bond encoder produces {ts.n * ts.k}")
+        if tuple(bond_.shape) != (st.num_edges, ts.F):
+            raise L.PhcError(f"edge_attr indices must be [{st.num_edges}, {ts.F}], got {tuple(bond_.shape)}")
+        if add_self and x_.shape[0] < st.num_dst:
+            raise L.PhcError(f"self loop: x has {x_.shape[0]} rows, {st.num_dst} destination rows")
+        rowptr, col, _ = st.csr
+        codes = st.packed_codes(bond_, ts.vocab_c, ts.F)
+        out = torch.empty((st.num_dst, h), dtype=torch.float32, device=dev)
+        lse = torch.empty((st.num_dst, h), dtype=torch.float32, device=dev)
+        out_self = torch.empty_like(out) if add_self else None
+        L.check(lib.phc_aggregate_softmax_enc_fwd(L.ptr(x_), L.ptr(codes), L.ptr(ts.ptrs), ts.vocab_c, ts.F, ts.n, ts.k,
+                                                  L.ptr(rowptr), L.ptr(col), L.ptr(beta_), st.num_dst, act, L.ptr(out),
+                                                  L.ptr(out_self), L.ptr(lse), L.stream_ptr(dev)), "phc_aggregate_softmax_enc_fwd")
+        if L.PROF_ON:
+            E, N = st.num_edges, st.num_dst
+            L.account("aggregate_softmax_fwd", 8.0 * E * h, E * (4.0 * h + 12) + N * 8.0 * h)
+        ctx.st, ctx.act, ctx.add_self, ctx.ts = st, act, bool(add_self), ts
+        ctx.beta_param = beta if (_DEFER.active and beta.is_leaf and beta.grad_fn is None and beta.requires_grad) else None
+        ctx.defer_tables = tuple(tables) if (_DEFER.active and st.num_edges > 0 and
+                                             all(t.is_leaf and t.grad_fn is None for t in tables)) else None
+        ctx.save_for_backward(x_, bond_, beta_, out, lse)
+        return out_self if add_self else out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = L.load()
+        st: EdgeStructure = ctx.st
+        ts: TableSet = ctx.ts
+        x_, bond_, beta_, out, lse = ctx.saved_tensors
+        dout_ = L.f32c(dout)
+        dev = dout_.device
+        h = dout_.shape[1]
+        rowptr_t, col_t, perm_t = st.csc
+        codes_o = st.packed_codes_orig(bond_, ts.vocab_c, ts.F)
+        need_t = any(ctx.needs_input_grad[7:])
+        dx = torch.empty((st.num_src, h), dtype=torch.float32, device=dev)
+        dea = torch.empty((st.num_edges, h), dtype=torch.float32, device=dev) if need_t else None
+        nparts = lib.phc_softmax_bwd_num_partials(st.num_src)
+        parts = torch.empty(nparts, dtype=torch.float32, device=dev)
+        L.check(lib.phc_aggregate_softmax_enc_bwd(L.ptr(dout_), L.ptr(out), L.ptr(lse), L.ptr(x_), L.ptr(codes_o), L.ptr(ts.ptrs),
+                                                  ts.vocab_c, ts.F, ts.n, ts.k, L.ptr(beta_), L.ptr(rowptr_t), L.ptr(col_t),
+                                                  L.ptr(perm_t), st.num_src, ctx.act,
+                                                  min(st.num_dst, st.num_src) if ctx.add_self else 0, L.ptr(dx), L.ptr(dea),
+                                                  L.ptr(parts), L.stream_ptr(dev)), "phc_aggregate_softmax_enc_bwd")
+        if L.PROF_ON:
+            E, N = st.num_edges, st.num_src
+            L.account("aggregate_softmax_bwd", 12.0 * E * h, E * (4.0 * h * (4 if need_t else 3) + 12) + N * 8.0 * h)
+        dbeta = None
+        if ctx.needs_input_grad[2]:
+            if ctx.beta_param is not None and _DEFER.active and not torch.is_grad_enabled():
+                with _DEFER.lock:
+                    _DEFER.beta_jobs.append((parts, ctx.beta_param))
+            else:
+                dbeta = parts.sum().reshape(())
+        tgrads = [None] * (ts.n * ts.F)
+        if need_t:
+            if ctx.defer_tables is not None and _DEFER.active and not torch.is_grad_enabled():
+                params = [t if ng else None for t, ng in zip(ctx.defer_tables, ctx.needs_input_grad[7:])]
+                with _DEFER.lock:                            # d enc = dea: an encoder job over the edge rows
+                    _DEFER.atom_jobs.append(dict(dout=dea, idx=bond_, ts=ts, params=params))
+            else:
+                flat = torch.empty(ts.n * ts.R * ts.k, dtype=torch.float32, device=dev)
+                ws_bytes = lib.phc_encode_bwd_ws_bytes(st.num_edges, ts.F, ts.vocab_c, ts.n, ts.k)
+                ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+                L.check(lib.phc_encode_bwd(L.ptr(dea), L.ptr(bond_), st.num_edges, ts.F, ts.vocab_c, ts.n, ts.k, L.ptr(flat),
+                                           L.ptr(ws), ws_bytes, L.stream_ptr(dev)), "phc_encode_bwd")
+                tgrads = list(ts.grad_views(flat))
+        return ((dx if ctx.needs_input_grad[0] else None), None, dbeta, None, None, None, None, *tgrads)
+
+
+def aggregate_softmax_encoded(x: torch.Tensor, edge_index, bond_idx: torch.Tensor, ts: "TableSet", tables, beta: torch.Tensor,
+                              msg_encoder: str = "identity", add_self: bool = False, num_dst: Optional[int] = None) -> torch.Tensor:
+    """aggregate_softmax with ``edge_attr = bond encoder(bond_idx)`` evaluated inside the kernels (needs
+    ``ts.fusable_into_aggregate`` and F <= 4, sum(vocab) <= 256: the packed-code limits)."""
+    st = edge_index if isinstance(edge_index, EdgeStructure) else edge_structure(edge_index, x.shape[0], num_dst)
+    st.prepare(for_backward=torch.is_grad_enabled() and x.requires_grad)
+    return _AggregateSoftmaxEncFn.apply(x, bond_idx, beta, st, _act_id(msg_encoder), add_self, ts,
+                                        *[t for comp in tables for t in comp])
+
+
 # ---------------------------------------------------------------------------
 # read-out: per-graph sum
 # ---------------------------------------------------------------------------

@@ -499,6 +499,38 @@ def test_aggregate_softmax_matches_oracle(ops, act, h):
         assert_close(gg[2], rg[2], 1e-4, "softmax dbeta")
 
 
+@pytest.mark.parametrize("act,add_self", [("identity", True), ("relu", False), ("swish", True)])
+def test_aggregate_softmax_encoded_matches_oracle(ops, act, add_self):
+    """Softmax aggregation with the bond encoder read in place (packed codes + tables inside the kernels) against the
+    oracle's embedding + softmax_aggregate: output, dx, every table gradient and d/d beta; isolated nodes, a hub."""
+    from oracle import phc_oracle as O
+    from phc_gnn_amd import synth
+    g = torch.Generator().manual_seed(23)
+    n, k, vocab = 4, 16, [5, 6, 2]
+    ei = torch.from_numpy(synth.ragged_edges(180, seed=6, hub_degree=90))
+    E, N, h = ei.shape[1], 180, n * k
+    bond = torch.stack([torch.randint(0, v, (E,), generator=g) for v in vocab], 1)
+    tables = _make_tables(n, vocab, k, g)
+    x = torch.randn(N, h, generator=g)
+    dy = torch.randn(N, h, generator=g)
+    ref_t = [[t.clone().requires_grad_() for t in comp] for comp in tables]
+    xr, br = x.clone().requires_grad_(), torch.tensor(1.7, requires_grad=True)
+    ref = O.softmax_aggregate(xr, ei, _oracle_encode(bond, ref_t), br, act)
+    if add_self:
+        ref = ref + xr
+    rg = torch.autograd.grad(ref, [xr, br] + [t for comp in ref_t for t in comp], dy)
+    dev_t = [[t.to(DEV).requires_grad_() for t in comp] for comp in tables]
+    xd, bd = x.to(DEV).requires_grad_(), torch.tensor(1.7, device=DEV, requires_grad=True)
+    ts = ops.TableSet(dev_t)
+    out = ops.aggregate_softmax_encoded(xd, ei.to(DEV), bond.to(DEV), ts, dev_t, bd, act, add_self=add_self)
+    assert_close(out, ref, 2e-5, "softmax encoded fwd")
+    gg = torch.autograd.grad(out, [xd, bd] + [t for comp in dev_t for t in comp], dy.to(DEV))
+    assert_close(gg[0], rg[0], 3e-5, "dx")
+    assert_close(gg[1], rg[1], 1e-4, "dbeta")
+    for a, r in zip(gg[2:], rg[2:]):
+        assert_close(a, r, 3e-5, "table grad")
+
+
 @pytest.mark.parametrize("shape,frac_nan", [((544, 1), 0.06), ((37, 12), 0.4), ((1100, 128), 0.7), ((5, 3), 0.0)])
 def test_masked_bce_matches_oracle(ops, shape, frac_nan):
     """NaN-masked BCE-with-logits (train_hiv.py:174-178) fwd + bwd; (1100,128) exercises the multi-workgroup path."""
