@@ -460,6 +460,10 @@ int phc_step_tail(const phc_phm_grad_job *jobs, int num_jobs, const phc_table_gr
 size_t phc_bce_masked_ws_bytes(int64_t total);
 int phc_bce_masked_fwd(const float *logits, const float *y, int64_t total, float *loss, float *stat, void *ws,
                        size_t ws_bytes, void *stream);
+/* Single-workgroup form (total <= 4096, e.g. one task per graph): also writes dlogits_unit = d loss / d logits for an
+ * upstream gradient of exactly 1, so the backward of a scalar training loss is a tensor that already exists. */
+int phc_bce_masked_fwd_unit(const float *logits, const float *y, int64_t total, float *loss, float *stat,
+                            float *dlogits_unit, void *stream);
 int phc_bce_masked_bwd(const float *logits, const float *y, const float *dloss, const float *stat, int64_t total,
                        float *dlogits, void *stream);
 

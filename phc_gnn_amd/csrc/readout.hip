@@ -58,6 +58,33 @@ __global__ __launch_bounds__(RO_THREADS) void bce_masked_fwd_kernel(const float 
     }
 }
 
+// One workgroup (total <= 4096): the loss AND, from the same labeled count, d loss / d logits for an upstream gradient
+// of exactly 1 — what the backward of a scalar training loss receives — so that backward needs no launch of its own.
+__global__ __launch_bounds__(RO_THREADS) void bce_masked_fwd_unit_kernel(const float *__restrict__ logits, const float *__restrict__ y,
+                                                                       long long total, float *__restrict__ loss,
+                                                                       float *__restrict__ stat, float *__restrict__ dlogits_unit) {
+    __shared__ float red[2 * RO_THREADS];
+    float s = 0.f, c = 0.f;
+    for (long long e = threadIdx.x; e < total; e += RO_THREADS) {
+        const float yv = y[e];
+        if (yv == yv) {
+            s += bce_entry(logits[e], yv);
+            c += 1.f;
+        }
+    }
+    block_reduce2(s, c, red);
+    if (threadIdx.x == 0) {
+        stat[0] = s;
+        stat[1] = c;
+        *loss = s / c;
+    }
+    const float scale = 1.f / c;
+    for (long long e = threadIdx.x; e < total; e += RO_THREADS) {
+        const float yv = y[e];
+        dlogits_unit[e] = yv == yv ? (1.f / (1.f + expf(-logits[e])) - yv) * scale : 0.f;
+    }
+}
+
 __global__ __launch_bounds__(RO_THREADS) void bce_masked_finalize_kernel(const float *__restrict__ partial, int num_partials,
                                                                        float *__restrict__ loss, float *__restrict__ stat) {
     __shared__ float red[2 * RO_THREADS];
@@ -357,6 +384,16 @@ int phc_bce_masked_fwd(const float *logits, const float *y, int64_t total, float
     if (blocks > 1)
         PHC_LAUNCH(bce_masked_finalize_kernel, dim3(1), dim3(RO_THREADS), 0, s, static_cast<const float *>(ws), blocks, loss, stat);
     return check_launch("bce_masked_fwd");
+}
+
+int phc_bce_masked_fwd_unit(const float *logits, const float *y, int64_t total, float *loss, float *stat, float *dlogits_unit,
+                            void *stream) {
+    PHC_REQUIRE(total > 0 && total <= (1 << 12) && logits && y && loss && stat && dlogits_unit, PHC_ERR_INVALID_ARG,
+                "phc_bce_masked_fwd_unit: 1 <= total <= 4096 entries and non-null pointers");
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(K_BCE_FWD, s);
+    PHC_LAUNCH(bce_masked_fwd_unit_kernel, dim3(1), dim3(RO_THREADS), 0, s, logits, y, (long long)total, loss, stat, dlogits_unit);
+    return check_launch("bce_masked_fwd_unit");
 }
 
 int phc_bce_masked_bwd(const float *logits, const float *y, const float *dloss, const float *stat, int64_t total, float *dlogits,

@@ -164,7 +164,8 @@ class GraphedTrainStep:
         self._dense = dense_weights(model)
         self.replay_stream = torch.cuda.Stream(device=dev)     # never the capture stream, never the null stream
         self.prep_stream = torch.cuda.Stream(device=dev) if self.pipeline else None
-        self._seed = torch.ones((), dtype=torch.float32, device=dev)    # d loss / d loss, resident (no fill node in the graph)
+        from .ops import register_unit_seed
+        self._seed = register_unit_seed(torch.ones((), dtype=torch.float32, device=dev))   # d loss / d loss, resident
         if os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "1") != "0":
             warnings.warn("DEBUG_CLR_GRAPH_PACKET_CAPTURE is not 0: on HIP 7.0 pipelined hipGraph replays race with the "
                           "batch copies queued behind them (see phc_gnn_amd/__init__.py)", RuntimeWarning)
@@ -221,6 +222,13 @@ class GraphedTrainStep:
         # later eager allocations made its replays fault on ROCm 7.x (the packet-capture ordering bug, DESIGN.md §5;
         # scripts/debug_pipelined.py reproduces the family).
         torch.cuda.synchronize(dev)
+
+    def __del__(self):
+        try:
+            from .ops import unregister_unit_seed
+            unregister_unit_seed(self._seed)
+        except Exception:
+            pass
 
     # the single-set attributes of the non-pipelined form (tests, scripts)
     @property

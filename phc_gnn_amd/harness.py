@@ -101,7 +101,8 @@ def backward_seed(loss: torch.Tensor) -> torch.Tensor:
     """d loss / d loss = 1 as a resident constant: ``loss.backward()`` would launch a fill kernel for it every step."""
     one = _ONE.get(loss.device)
     if one is None:
-        one = _ONE[loss.device] = torch.ones((), dtype=loss.dtype, device=loss.device)
+        from .ops import register_unit_seed
+        one = _ONE[loss.device] = register_unit_seed(torch.ones((), dtype=loss.dtype, device=loss.device))
     return one
 
 
