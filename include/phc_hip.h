@@ -386,6 +386,14 @@ int phc_csr_build_pair(const int64_t *edge_src_i64, const int64_t *edge_dst_i64,
                        int32_t *rowptr, int32_t *col, int32_t *perm, int32_t *rowptr_t, int32_t *col_t, int32_t *perm_t,
                        void *ws, size_t ws_bytes, void *stream);
 
+/* The same, and the packed edge codes of phc_pack_edge_codes (destination-sorted order) out of the same five launches:
+ * the last one knows where every edge ends up and packs its bond features there.  codes / bond_i64 / vocab may be NULL
+ * (then this is phc_csr_build_pair).  F <= 4, sum(vocab) <= 256. */
+int phc_csr_build_pair_codes(const int64_t *edge_src_i64, const int64_t *edge_dst_i64, int64_t E, int64_t n_src,
+                             int64_t n_dst, int32_t *rowptr, int32_t *col, int32_t *perm, int32_t *rowptr_t,
+                             int32_t *col_t, int32_t *perm_t, const int64_t *bond_i64, const int32_t *vocab, int F,
+                             uint32_t *codes, void *ws, size_t ws_bytes, void *stream);
+
 /* Per-batch preprocessing on the device: drop the nodes no edge touches and re-index,
  * i.e. the reference's CustomRemoveIsolatedNodes / PyG RemoveIsolatedNodes applied to every collated
  * batch (benchmarks/utils.py:36-46, train_hiv.py:171-172) — there on the CPU, before the batch is moved.

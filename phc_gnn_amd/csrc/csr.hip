@@ -145,6 +145,11 @@ struct CsrSide {
 };
 struct CsrPair {
     CsrSide s[2];
+    // optional: the packed table rows of every edge in the order of side 0 (phc_pack_edge_codes), written by the
+    // canonicalising launch as it places each edge — one launch less per batch
+    const long long *bond;
+    unsigned *codes;
+    int F, off[4];
 };
 
 __global__ void csr_pair_zero_kernel(CsrPair p) {
@@ -239,6 +244,11 @@ __global__ __launch_bounds__(256) void csr_pair_canon_kernel(CsrPair p) {
             for (int j = 0; j < deg; ++j) rank += (sd.tmp_perm[b + j] < v) ? 1 : 0;
             sd.perm[b + rank] = v;
             sd.col[b + rank] = (int)sd.other[v];
+            if (blockIdx.y == 0 && p.codes) {
+                unsigned c = 0;
+                for (int f = 0; f < p.F; ++f) c |= (unsigned)(p.off[f] + (int)p.bond[(long long)v * p.F + f]) << (8 * f);
+                p.codes[b + rank] = c;
+            }
         }
     }
 }
@@ -390,6 +400,25 @@ size_t phc_csr_pair_ws_bytes(int64_t E, int64_t n_src, int64_t n_dst) {
 int phc_csr_build_pair(const int64_t *edge_src_i64, const int64_t *edge_dst_i64, int64_t E, int64_t n_src, int64_t n_dst,
                        int32_t *rowptr, int32_t *col, int32_t *perm, int32_t *rowptr_t, int32_t *col_t, int32_t *perm_t, void *ws,
                        size_t ws_bytes, void *stream) {
+    return phc_csr_build_pair_codes(edge_src_i64, edge_dst_i64, E, n_src, n_dst, rowptr, col, perm, rowptr_t, col_t, perm_t, nullptr,
+                                    nullptr, 0, nullptr, ws, ws_bytes, stream);
+}
+
+int phc_csr_build_pair_codes(const int64_t *edge_src_i64, const int64_t *edge_dst_i64, int64_t E, int64_t n_src, int64_t n_dst,
+                             int32_t *rowptr, int32_t *col, int32_t *perm, int32_t *rowptr_t, int32_t *col_t, int32_t *perm_t,
+                             const int64_t *bond_i64, const int32_t *vocab, int F, uint32_t *codes, void *ws, size_t ws_bytes,
+                             void *stream) {
+    int code_off[4] = {0, 0, 0, 0};
+    if (codes) {
+        PHC_REQUIRE(bond_i64 && vocab && F >= 1 && F <= 4, PHC_ERR_INVALID_ARG, "phc_csr_build_pair_codes: codes need bond, vocab, 1 <= F <= 4");
+        int acc = 0;
+        for (int f = 0; f < F; ++f) {
+            PHC_REQUIRE(vocab[f] >= 1, PHC_ERR_INVALID_ARG, "phc_csr_build_pair_codes: vocab[%d] = %d", f, vocab[f]);
+            code_off[f] = acc;
+            acc += vocab[f];
+        }
+        PHC_REQUIRE(acc <= 256, PHC_ERR_UNSUPPORTED, "phc_csr_build_pair_codes: packed codes need sum(vocab) <= 256");
+    }
     PHC_REQUIRE(E >= 1 && n_src >= 1 && n_dst >= 1, PHC_ERR_INVALID_ARG, "phc_csr_build_pair: E=%lld n_src=%lld n_dst=%lld",
                 (long long)E, (long long)n_src, (long long)n_dst);
     PHC_REQUIRE(n_src <= PAIR_MAX_KEYS && n_dst <= PAIR_MAX_KEYS && E < (1LL << 31) - 1, PHC_ERR_UNSUPPORTED,
@@ -411,6 +440,10 @@ int phc_csr_build_pair(const int64_t *edge_src_i64, const int64_t *edge_dst_i64,
     p.s[1].cursor = reinterpret_cast<int *>(q); q += align_up(sizeof(int) * (size_t)(n_src + 1), 256);
     p.s[0].tmp_perm = reinterpret_cast<int *>(q); q += align_up(sizeof(int) * (size_t)E, 256);
     p.s[1].tmp_perm = reinterpret_cast<int *>(q);
+    p.bond = reinterpret_cast<const long long *>(bond_i64);
+    p.codes = codes;
+    p.F = codes ? F : 0;
+    for (int f = 0; f < 4; ++f) p.off[f] = code_off[f];
     const long long nmax = (n_src > n_dst ? n_src : n_dst) + 1;
     const unsigned ngrid = (unsigned)((nmax + 255) / 256);
     const unsigned egrid = (unsigned)((E + 255) / 256 > 4096 ? 4096 : (E + 255) / 256);

@@ -97,23 +97,27 @@ class EdgeStructure:
         """Recompute every view that has been built — same tensors, new contents — after the edge list (and the bond
         features behind the packed codes) changed IN PLACE: the per-batch preprocessing of a fixed-shape step whose
         static buffers were reloaded (graphed.GraphedTrainStep captures this as its own small graph)."""
+        pair_rebuilt = False
         if self._csr is not None and self._csc is not None and self.num_edges > 0 and not _NO_PAIR and \
                 0 < max(self.num_src, self.num_dst) <= self.PAIR_MAX_ROWS:
             self._build_pair(reuse=True)
+            pair_rebuilt = True
         else:
             if self._csr is not None:
                 _build_sorted(self._dst, self._src, self.num_dst, out=self._csr)
             if self._csc is not None:
                 _build_sorted(self._src, self._dst, self.num_src, out=self._csc)
-        for codes in self._codes.values():
-            self._pack_codes(*self._codes_args, codes)
+        if not (pair_rebuilt and self._codes_args is not None):      # the pair launches repacked the sorted codes already
+            for codes in self._codes.values():
+                self._pack_codes(*self._codes_args, codes)
         for codes in self._codes_orig.values():
             self._pack_codes(*self._codes_orig_args, codes, sorted_order=False)
 
     PAIR_MAX_ROWS = 16383
 
-    def _build_pair(self, reuse: bool = False) -> None:
-        """Both views side by side (phc_csr_build_pair: 5 launches instead of 22)."""
+    def _build_pair(self, reuse: bool = False, codes_for=None) -> None:
+        """Both views side by side (phc_csr_build_pair: 5 launches instead of 22); ``codes_for = (bond_idx, vocab_c, F)``:
+        the packed edge codes of that bond tensor come out of the same launches."""
         lib = L.load()
         dev = self._src.device
         E = self.num_edges
@@ -124,17 +128,31 @@ class EdgeStructure:
         csr, csc = (self._csr, self._csc) if reuse else (alloc(self.num_dst), alloc(self.num_src))
         ws_bytes = lib.phc_csr_pair_ws_bytes(E, self.num_src, self.num_dst)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        L.check(lib.phc_csr_build_pair(L.ptr(self._src), L.ptr(self._dst), E, self.num_src, self.num_dst, L.ptr(csr[0]),
-                                       L.ptr(csr[1]), L.ptr(csr[2]), L.ptr(csc[0]), L.ptr(csc[1]), L.ptr(csc[2]), L.ptr(ws),
-                                       ws_bytes, L.stream_ptr(dev)), "phc_csr_build_pair")
+        codes = bond = vocab_c = None
+        F = 0
+        if reuse and self._codes and self._codes_args is not None:
+            bond, vocab_c, F = self._codes_args
+            codes = next(iter(self._codes.values()))
+        elif codes_for is not None:
+            bond, vocab_c, F = codes_for
+            codes = torch.empty(E, dtype=torch.int32, device=dev)
+        L.check(lib.phc_csr_build_pair_codes(L.ptr(self._src), L.ptr(self._dst), E, self.num_src, self.num_dst, L.ptr(csr[0]),
+                                             L.ptr(csr[1]), L.ptr(csr[2]), L.ptr(csc[0]), L.ptr(csc[1]), L.ptr(csc[2]),
+                                             L.ptr(bond), vocab_c, F, L.ptr(codes), L.ptr(ws), ws_bytes, L.stream_ptr(dev)),
+                "phc_csr_build_pair_codes")
         self._csr, self._csc = csr, csc
+        if codes is not None and not reuse:
+            self._codes = {(bond.data_ptr(), bond._version, tuple(vocab_c)): codes}
+            self._codes_args = (bond, vocab_c, F)
+        self._pair_packed = codes is not None
 
-    def prepare(self, for_backward: bool) -> "EdgeStructure":
+    def prepare(self, for_backward: bool, codes_for=None) -> "EdgeStructure":
         """Build what a forward (and, with ``for_backward``, its backward) will walk.  A differentiable forward wants
-        the source-sorted view later: both views are then built side by side (5 launches instead of 22)."""
+        the source-sorted view later: both views are then built side by side (5 launches instead of 22).  ``codes_for
+        = (int64 bond tensor, vocab_c, F)``: the caller will ask for ``packed_codes`` of it next — they ride along."""
         if (for_backward and self._csr is None and self._csc is None and self.num_edges > 0 and not _NO_PAIR
                 and 0 < max(self.num_src, self.num_dst) <= self.PAIR_MAX_ROWS):
-            self._build_pair()
+            self._build_pair(codes_for=codes_for)
         return self
 
     @property

@@ -980,7 +980,8 @@ def aggregate_softmax_encoded(x: torch.Tensor, edge_index, bond_idx: torch.Tenso
     """aggregate_softmax with ``edge_attr = bond encoder(bond_idx)`` evaluated inside the kernels (needs
     ``ts.fusable_into_aggregate`` and F <= 4, sum(vocab) <= 256: the packed-code limits)."""
     st = edge_index if isinstance(edge_index, EdgeStructure) else edge_structure(edge_index, x.shape[0], num_dst)
-    st.prepare(for_backward=torch.is_grad_enabled() and x.requires_grad)
+    bond_idx = _idx64(bond_idx)
+    st.prepare(for_backward=torch.is_grad_enabled() and x.requires_grad, codes_for=(bond_idx, ts.vocab_c, ts.F))
     return _AggregateSoftmaxEncFn.apply(x, bond_idx, beta, st, _act_id(msg_encoder), add_self, ts,
                                         *[t for comp in tables for t in comp])
 
@@ -1358,7 +1359,12 @@ def aggregate_sum_encoded(x: torch.Tensor, edge_index, bond_idx: torch.Tensor, t
     """aggregate_sum with edge_attr[e] = Σ_f tables[c][f][bond_idx[e, f]] looked up inside the
     kernel (the [E, h] bond embedding is never written)."""
     st = edge_index if isinstance(edge_index, EdgeStructure) else edge_structure(edge_index, x.shape[0], num_dst)
-    st.prepare(for_backward=torch.is_grad_enabled() and x.requires_grad)
+    packed = ts.fusable_into_aggregate and ts.F <= 4 and ts.R <= 256
+    if packed:
+        bond_idx = _idx64(bond_idx)
+    # the packed edge codes the forward will ask for ride in the launches that build the sorted views
+    st.prepare(for_backward=torch.is_grad_enabled() and x.requires_grad,
+               codes_for=(bond_idx, ts.vocab_c, ts.F) if packed else None)
     flat_tables = [t for comp in tables for t in comp]
     if not ts.fusable_into_aggregate:
         ea = _EncodeFn.apply(bond_idx, ts, *flat_tables)
