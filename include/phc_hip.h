@@ -484,6 +484,10 @@ int phc_bce_masked_bwd(const float *logits, const float *y, const float *dloss, 
  * dx / dgate may be NULL. */
 int phc_gated_pool_fwd(const float *x, const float *gate, const int32_t *seg_ptr, int64_t num_graphs, int h,
                        int n_comp, float *out, void *stream);
+/* The same straight from the SORTED int64 `batch` vector of a collated mini-batch (graph id per row, non-decreasing):
+ * every workgroup finds its graph's rows with two cooperative searches, so no segment-pointer launch is needed. */
+int phc_gated_pool_fwd_sorted(const float *x, const float *gate, const int64_t *batch_sorted_i64, int64_t N,
+                              int64_t num_graphs, int h, int n_comp, float *out, void *stream);
 int phc_gated_pool_bwd(const float *dout, const float *x, const float *gate, const int64_t *batch, int64_t N,
                        int64_t num_graphs, int h, int n_comp, float *dx, float *dgate, void *stream);
 

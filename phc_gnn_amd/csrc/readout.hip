@@ -123,13 +123,49 @@ __global__ __launch_bounds__(256) void bce_masked_bwd_kernel(const float *__rest
 // lane order through LDS: fixed summation order.  h <= GP_MAX_H per pass (wider rows loop over column blocks).
 constexpr int GP_THREADS = 256;
 
+// First index in [0, n) of the SORTED int64 vector `v` with v[i] >= key (n if none), by the whole workgroup: 256
+// probes per level (two levels cover 65 536 entries), each level one round trip — a per-thread binary search would
+// chain ~14 dependent loads.  `slot` is one int of shared memory.
+__device__ __forceinline__ int coop_lower_bound(const long long *__restrict__ v, int n, long long key, int *slot) {
+    int lo = 0, hi = n;                                       // the answer lies in [lo, hi]
+    while (hi > lo) {
+        const int len = hi - lo, stride = (len + GP_THREADS - 1) / GP_THREADS;
+        const int i = lo + (int)threadIdx.x * stride;
+        const bool ge = i < hi && v[i] >= key;
+        if (threadIdx.x == 0) *slot = GP_THREADS;
+        __syncthreads();
+        if (ge) atomicMin(slot, (int)threadIdx.x);
+        __syncthreads();
+        const int first = *slot;                              // first probe that is >= key (GP_THREADS: none)
+        __syncthreads();
+        const int probes = (len + stride - 1) / stride;       // probes that fell inside [lo, hi)
+        const int nlo = first == 0 ? lo : lo + (min(first, probes) - 1) * stride + 1;
+        const int nhi = first >= probes ? hi : lo + first * stride;
+        if (stride == 1) return first >= probes ? hi : lo + first;
+        lo = nlo;
+        hi = nhi;
+    }
+    return lo;
+}
+
 template <int VEC>
 __global__ __launch_bounds__(GP_THREADS) void gated_pool_fwd_kernel(const float *__restrict__ x, const float *__restrict__ gate,
                                                                   const int *__restrict__ seg_ptr, int h, int k,
-                                                                  float *__restrict__ out) {
+                                                                  float *__restrict__ out,
+                                                                  const long long *__restrict__ batch_sorted, int n_rows) {
     __shared__ float red[VEC * GP_THREADS];
+    __shared__ int slot;
     const int g = blockIdx.x, tid = threadIdx.x;
-    const int r0 = seg_ptr[g], r1 = seg_ptr[g + 1];
+    // rows of graph g: from the segment pointers, or (seg_ptr == NULL) found in the sorted `batch` vector itself — the
+    // separate launch that turns `batch` into pointers is then not needed
+    int r0, r1;
+    if (seg_ptr) {
+        r0 = seg_ptr[g];
+        r1 = seg_ptr[g + 1];
+    } else {
+        r0 = coop_lower_bound(batch_sorted, n_rows, (long long)g, &slot);
+        r1 = coop_lower_bound(batch_sorted, n_rows, (long long)g + 1, &slot);
+    }
     const int hv = h / VEC;
     for (int cbase = 0; cbase < hv; cbase += GP_THREADS) {
         const int cols = min(GP_THREADS, hv - cbase);
@@ -412,19 +448,33 @@ static bool gp_vec4(int h, int k, const void *a, const void *b, const void *c, c
            ((reinterpret_cast<uintptr_t>(c) & 15) == 0) && ((reinterpret_cast<uintptr_t>(d) & 15) == 0);
 }
 
-int phc_gated_pool_fwd(const float *x, const float *gate, const int32_t *seg_ptr, int64_t num_graphs, int h, int n_comp, float *out,
-                       void *stream) {
+static int gated_pool_fwd_impl(const float *x, const float *gate, const int32_t *seg_ptr, const int64_t *batch_sorted, int64_t N,
+                               int64_t num_graphs, int h, int n_comp, float *out, void *stream) {
     PHC_REQUIRE(num_graphs >= 0 && h >= 1 && n_comp >= 1 && h % n_comp == 0, PHC_ERR_INVALID_ARG, "phc_gated_pool_fwd: bad shape");
     if (num_graphs == 0) return PHC_OK;
-    PHC_REQUIRE(x && gate && seg_ptr && out, PHC_ERR_INVALID_ARG, "phc_gated_pool_fwd: null pointer");
+    PHC_REQUIRE(x && gate && (seg_ptr || batch_sorted) && out, PHC_ERR_INVALID_ARG, "phc_gated_pool_fwd: null pointer");
+    PHC_REQUIRE(seg_ptr || (N >= 0 && N < (1LL << 31)), PHC_ERR_UNSUPPORTED, "phc_gated_pool_fwd_sorted: N out of range");
     hipStream_t s = (hipStream_t)stream;
     const int k = h / n_comp;
+    const long long *b = reinterpret_cast<const long long *>(batch_sorted);
     ProfScope prof(K_GATED_POOL_FWD, s);
     if (gp_vec4(h, k, x, gate, out, nullptr))
-        PHC_LAUNCH((gated_pool_fwd_kernel<4>), dim3((unsigned)num_graphs), dim3(GP_THREADS), 0, s, x, gate, seg_ptr, h, k, out);
+        PHC_LAUNCH((gated_pool_fwd_kernel<4>), dim3((unsigned)num_graphs), dim3(GP_THREADS), 0, s, x, gate, seg_ptr, h, k, out, b, (int)N);
     else
-        PHC_LAUNCH((gated_pool_fwd_kernel<1>), dim3((unsigned)num_graphs), dim3(GP_THREADS), 0, s, x, gate, seg_ptr, h, k, out);
+        PHC_LAUNCH((gated_pool_fwd_kernel<1>), dim3((unsigned)num_graphs), dim3(GP_THREADS), 0, s, x, gate, seg_ptr, h, k, out, b, (int)N);
     return check_launch("gated_pool_fwd");
+}
+
+int phc_gated_pool_fwd(const float *x, const float *gate, const int32_t *seg_ptr, int64_t num_graphs, int h, int n_comp, float *out,
+                       void *stream) {
+    PHC_REQUIRE(num_graphs == 0 || seg_ptr, PHC_ERR_INVALID_ARG, "phc_gated_pool_fwd: null pointer");
+    return gated_pool_fwd_impl(x, gate, seg_ptr, nullptr, 0, num_graphs, h, n_comp, out, stream);
+}
+
+int phc_gated_pool_fwd_sorted(const float *x, const float *gate, const int64_t *batch_sorted_i64, int64_t N, int64_t num_graphs, int h,
+                              int n_comp, float *out, void *stream) {
+    PHC_REQUIRE(num_graphs == 0 || batch_sorted_i64, PHC_ERR_INVALID_ARG, "phc_gated_pool_fwd_sorted: null pointer");
+    return gated_pool_fwd_impl(x, gate, nullptr, batch_sorted_i64, N, num_graphs, h, n_comp, out, stream);
 }
 
 int phc_gated_pool_bwd(const float *dout, const float *x, const float *gate, const int64_t *batch, int64_t N, int64_t num_graphs,

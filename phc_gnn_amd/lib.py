@@ -110,6 +110,7 @@ SIGNATURES = {
     "phc_bce_masked_bwd": (_I, [_P, _P, _P, _P, _L, _P, _P]),
     "phc_bce_masked_fwd_unit": (_I, [_P, _P, _L, _P, _P, _P, _P]),
     "phc_gated_pool_fwd": (_I, [_P, _P, _P, _L, _I, _I, _P, _P]),
+    "phc_gated_pool_fwd_sorted": (_I, [_P, _P, _P, _L, _L, _I, _I, _P, _P]),
     "phc_gated_pool_bwd": (_I, [_P, _P, _P, _P, _L, _L, _I, _I, _P, _P, _P]),
     "phc_sum_n": (_I, [_P, _I, _L, _P, _P]),
     "phc_vec_sums": (_I, [_P, _P, _P, _I, _P]),

@@ -1029,6 +1029,9 @@ def global_add_pool(x: torch.Tensor, batch, num_graphs: Optional[int] = None, is
     return _SegmentSumFn.apply(x, st)
 
 
+_POOL_SEGPTR = bool(__import__("os").environ.get("PHC_POOL_SEGPTR"))      # A/B switch: segment pointers from their own launch
+
+
 class _GatedSegmentSumFn(torch.autograd.Function):
     """out[g, c*k+j] = Σ_{r in graph g} x[r, c*k+j]·σ(gate[r, j]) over rows that are already grouped by graph."""
 
@@ -1040,10 +1043,14 @@ class _GatedSegmentSumFn(torch.autograd.Function):
         N, h = x_.shape
         if h % n_comp or tuple(g_.shape) != (N, h // n_comp):
             raise L.PhcError(f"gate must be [{N}, {h // n_comp}] for x [{N}, {h}] with {n_comp} components")
-        seg_ptr = st.csr[0]
         out = torch.empty((st.num_segments, h), dtype=torch.float32, device=dev)
-        L.check(lib.phc_gated_pool_fwd(L.ptr(x_), L.ptr(g_), L.ptr(seg_ptr), st.num_segments, h, n_comp, L.ptr(out),
-                                       L.stream_ptr(dev)), "phc_gated_pool_fwd")
+        if st.is_sorted and st._csr is None and not _POOL_SEGPTR:
+            # collated batch: the workgroups find their rows in the sorted `batch` vector themselves (no pointer launch)
+            L.check(lib.phc_gated_pool_fwd_sorted(L.ptr(x_), L.ptr(g_), L.ptr(st.batch), N, st.num_segments, h, n_comp,
+                                                  L.ptr(out), L.stream_ptr(dev)), "phc_gated_pool_fwd_sorted")
+        else:
+            L.check(lib.phc_gated_pool_fwd(L.ptr(x_), L.ptr(g_), L.ptr(st.csr[0]), st.num_segments, h, n_comp, L.ptr(out),
+                                           L.stream_ptr(dev)), "phc_gated_pool_fwd")
         if L.PROF_ON:
             L.account("gated_pool_fwd", 2.0 * N * h, 4.0 * (N * (h + h // n_comp) + st.num_segments * h))
         ctx.save_for_backward(x_, g_, st.batch)
