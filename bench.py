@@ -38,7 +38,7 @@ import torch  # noqa: E402
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s HBM3E
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
 MFMA_KERNELS = ("phm_gemm_fwd", "phm_gemm_dx", "phm_dH_partial", "table_grad")
-# launch-profiler kernel name -> substring of the rocprofv3 kernel name in profiles/r01u_pmc_traffic.json
+# launch-profiler kernel name -> substring of the rocprofv3 kernel name in profiles/r01v_pmc_traffic.json
 PMC_NAMES = {"phm_gemm_fwd": "phm_stream_kernel<0, -1, 32, 4, 1>", "phm_gemm_dx": "phm_stream_kernel<0, -1, 32, 4, 0>",
              "phm_dH_partial": "tail_partial_kernel", "aggregate_enc_fwd": "aggregate_enc_fwd_kernel",
              "aggregate_enc_dx": "aggregate_enc_dx_kernel", "aggregate_fwd": "aggregate_fwd_kernel",
@@ -49,7 +49,7 @@ PMC_NAMES = {"phm_gemm_fwd": "phm_stream_kernel<0, -1, 32, 4, 1>", "phm_gemm_dx"
 def pmc_traffic(kernel: str):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
     MI355X_MICROARCH.md §HBM), or None.  Collected with scripts/rocprof_pmc.sh on the same workload."""
-    path = os.path.join(ROOT, "profiles", "r01u_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", "r01v_pmc_traffic.json")
     pat = PMC_NAMES.get(kernel)
     if pat is None or not os.path.exists(path):
         return None
