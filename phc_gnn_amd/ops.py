@@ -1390,7 +1390,7 @@ def _ptr_array(tensors):
 # True: two launches per direction (the last workgroup of each 32-column group merges); False: separate merge launch.
 # Measured on MI355X at molecule scale the merged variant is SLOWER (statistics 14.5 us vs 5.7 + 6.1 us for the two
 # launches: the ticketed tail serialises behind the slowest workgroup and its partials must bypass L2), so it is off.
-BN_LAST_WORKGROUP_MERGE = False
+BN_LAST_WORKGROUP_MERGE = __import__("os").environ.get("PHC_BN_LAST_WG_MERGE", "0") == "1"
 
 
 class _BatchNormActFn(torch.autograd.Function):
