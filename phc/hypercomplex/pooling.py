@@ -16,7 +16,7 @@ class PHMGlobalSumPooling(nn.Module):
         self.phm_dim = phm_dim
         self.module = _engine.global_add_pool
 
-    def __call__(self, x: torch.Tensor, batch, num_graphs: Optional[int] = None, is_sorted: bool = False) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, batch, num_graphs: Optional[int] = None, is_sorted: bool = False) -> torch.Tensor:
         # x: [num_nodes, phm_dim * feats];  batch: int64 graph id per node
         return self.module(x, batch, num_graphs, is_sorted)
 

@@ -197,8 +197,11 @@ class PHMSkipConnectAdd(nn.Module):
                                                     edge_index=edge_index, edge_attr=e,
                                                     dropout_mpnn=self.dropout_mpnn[i], size=size, n_valid=n_valid)
         num_graphs = getattr(data, "num_graphs", None)
-        # `batch` of a collated mini-batch is non-decreasing (PyG); batches that say otherwise take the sorting path
-        out = self.pooling(x=h, batch=batch, num_graphs=num_graphs, is_sorted=bool(getattr(data, "batch_is_sorted", True)))
+        # The reference's scatter-based global_add_pool does not care about the order of `batch`; the binary-search
+        # read-out does.  Only a batch object that SAYS its `batch` vector is non-decreasing (harness.to_device and the
+        # fixed-shape batches of graphed.py do; PyG collation produces such vectors) takes that path, anything else is
+        # grouped by a stable sort first.
+        out = self.pooling(x=h, batch=batch, num_graphs=num_graphs, is_sorted=bool(getattr(data, "batch_is_sorted", False)))
         if n_valid_graphs is not None:
             return self.downstream(out, n_valid=n_valid_graphs)
         return self.downstream(out)

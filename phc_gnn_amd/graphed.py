@@ -50,6 +50,8 @@ def pad_batch(gb: synth.GraphBatch, n_max: int, e_max: int) -> dict:
     N, E, B = gb.num_nodes, gb.num_edges, gb.num_graphs
     if N >= n_max or E > e_max:
         raise ValueError(f"batch ({N} nodes, {E} edges) does not fit the bucket ({n_max}, {e_max})")
+    if N > 1 and not bool((gb.batch[1:] >= gb.batch[:-1]).all()):
+        raise ValueError("pad_batch: `batch` must be non-decreasing (a collated mini-batch); sort the nodes by graph first")
     n_pad = n_max - N
     x = np.zeros((n_max, gb.x.shape[1]), dtype=np.int64)
     x[:N] = gb.x
@@ -109,7 +111,8 @@ def _flat_views(flat: torch.Tensor, layout: dict) -> dict:
 
 class _BatchSet:
     """One set of static batch buffers with everything captured over it."""
-    __slots__ = ("static_flat", "static", "data", "graph", "graph2", "loss", "prep", "structs", "ev_prep", "ev_main", "ready")
+    __slots__ = ("static_flat", "static", "data", "graph", "graph2", "loss", "logits", "prep", "structs", "ev_prep", "ev_main",
+                 "ready")
 
 
 class GraphedTrainStep:
@@ -152,8 +155,9 @@ class GraphedTrainStep:
             bs.data = types.SimpleNamespace(
                 x=bs.static["x"], edge_index=bs.static["edge_index"], edge_attr=bs.static["edge_attr"],
                 batch=bs.static["batch"], y=bs.static["y"], num_graphs=B + PAD_GRAPHS,
-                n_valid_nodes=bs.static["n_valid_nodes"], n_valid_graphs=n_valid_graphs, all_labeled=False)
-            bs.graph = bs.graph2 = bs.loss = bs.prep = None
+                n_valid_nodes=bs.static["n_valid_nodes"], n_valid_graphs=n_valid_graphs, all_labeled=False,
+                batch_is_sorted=True)                  # pad_batch keeps `batch` non-decreasing (and checks its input)
+            bs.graph = bs.graph2 = bs.loss = bs.logits = bs.prep = None
             bs.structs = []
             bs.ev_prep, bs.ev_main, bs.ready = torch.cuda.Event(), torch.cuda.Event(), False
             self.sets.append(bs)
@@ -248,6 +252,10 @@ class GraphedTrainStep:
         return self.sets[self._cur].loss
 
     @property
+    def logits(self):
+        return self.sets[self._cur].logits
+
+    @property
     def graph(self):
         return self.sets[self._cur].graph
 
@@ -262,6 +270,7 @@ class GraphedTrainStep:
             logits = self.model(bs.data)
             loss = loss_fn(logits, bs.data, self.cfg.regression)
             loss.backward(self._seed)
+        bs.logits = logits.detach()            # static output buffer of the captured step (rows of padding graphs included)
         if self.grad_sync is not None:
             self.grad_sync.pack()
         return loss

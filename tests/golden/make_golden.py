@@ -368,6 +368,135 @@ def g8_model_softmax():
                    downstream_layers=[64, 32], dropout_dn=[0.0, 0.0], target_dim=1, sc_type="first", **common)
 
 
+def _relerr(a, b):
+    a, b = a.detach().double(), b.detach().double()
+    return float((a - b).abs().max()) / max(float(b.abs().max()), 1e-30)
+
+
+def _loss_of(logits, y, regression):
+    y = y.to(logits.dtype)
+    if regression:
+        return torch.nn.functional.l1_loss(logits, y)
+    mask = ~torch.isnan(y)
+    return torch.nn.functional.binary_cross_entropy_with_logits(logits[mask], y[mask])
+
+
+def _fullwidth_fixture(name, workload_batches, seed, kw, regression=False, store_grad32=True, adam_steps=0):
+    """Full-width model fixture (BASELINE configs[1..3] widths): the reference in float32 (its own arithmetic) AND the
+    same reference modules cast to float64 on the same parameters and batch.  The float64 run is the yardstick for
+    the gradient tolerance: ``err32::<param>`` = max|ref32 - ref64| / max|ref64| is how far the REFERENCE's own fp32
+    evaluation sits from the exact result; a GPU fp32 evaluation in a different summation order cannot be asked to sit
+    closer to the reference than the reference sits to the truth.
+
+    ``adam_steps`` > 0: additionally the reference loop body (train_hiv.py:173-201 with weight_decay 0: zero_grad,
+    forward, masked BCE, backward, clip_grad_norm_(2.0), Adam(lr 1e-3) step) over the first ``adam_steps`` batches,
+    float32 and float64; stored: the parameters afterwards and the per-step losses."""
+    import copy
+    gen = torch.Generator().manual_seed(seed)
+    model = PHMSkipConnectAdd(**kw)
+    fill_module(model, gen)
+    gb = workload_batches[0]
+    data = _to_batch(gb)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    model64 = copy.deepcopy(model).double()
+
+    model.eval()
+    with torch.no_grad():
+        logits_eval = model(data)
+    model.train()
+    logits = model(data)
+    loss = _loss_of(logits, data.y, regression)
+    loss.backward()
+
+    model64.train()
+    logits64 = model64(_to_batch(gb))
+    assert logits64.dtype == torch.float64
+    loss64 = _loss_of(logits64, data.y, regression)
+    loss64.backward()
+
+    out = dict(x=data.x, edge_index=data.edge_index, edge_attr=data.edge_attr, batch=data.batch, y=data.y,
+               logits_eval=logits_eval, logits_train=logits, loss=loss,
+               logits_train64=logits64.float(), loss64=loss64.float(),
+               err32_logits=np.array(_relerr(logits, logits64)), err32_loss=np.array(_relerr(loss, loss64)))
+    out.update({"sd::" + k: v for k, v in sd.items()})
+    out.update({"sd_after::" + k: v for k, v in model.state_dict().items() if "running" in k})
+    p64 = dict(model64.named_parameters())
+    worst = (0.0, None)
+    for k, p in model.named_parameters():
+        if p.grad is None:
+            continue
+        if store_grad32:
+            out["grad::" + k] = p.grad
+        out["grad64::" + k] = p64[k].grad.float()
+        e = _relerr(p.grad, p64[k].grad)
+        out["err32::" + k] = np.array(e)
+        if float(p64[k].grad.abs().max()) > 1e-7 and e > worst[0]:
+            worst = (e, k)
+    out["num_params"] = model.get_number_of_params_()
+    print(f"  {name}: N={gb.num_nodes} E={gb.num_edges} params={out['num_params']} loss={float(loss):.6f} "
+          f"ref32-vs-ref64: logits {float(out['err32_logits']):.2e} loss {float(out['err32_loss']):.2e} "
+          f"worst grad {worst[0]:.2e} ({worst[1]})")
+
+    if adam_steps > 0:
+        finals, losses = {}, {}
+        for tag, dt in (("32", torch.float32), ("64", torch.float64)):
+            m = PHMSkipConnectAdd(**kw)
+            m.load_state_dict(sd)
+            m = m.to(dt).train()
+            opt = torch.optim.Adam(m.parameters(), lr=1e-3)
+            ls = []
+            for gbi in workload_batches[:adam_steps]:
+                d = _to_batch(gbi)
+                opt.zero_grad()
+                lo = _loss_of(m(d), d.y, regression)
+                lo.backward()
+                torch.nn.utils.clip_grad_norm_(m.parameters(), max_norm=2.0, norm_type=2)
+                opt.step()
+                ls.append(float(lo))
+            finals[tag], losses[tag] = {k: v.clone() for k, v in m.state_dict().items()}, ls
+        out["adam::steps"] = np.array(adam_steps)
+        out["adam::batch_seeds"] = np.array([int(s) for s in workload_batches[adam_steps:]] or [0])
+        out["adam::losses32"] = np.array(losses["32"], dtype=np.float64)
+        out["adam::losses64"] = np.array(losses["64"], dtype=np.float64)
+        for k, v in finals["64"].items():
+            if v.is_floating_point():
+                out["adam::sd64::" + k] = v.float()
+                out["adam::err32::" + k] = np.array(_relerr(finals["32"][k], v))
+    save(name, **out)
+
+
+def g10_fullwidth():
+    """Full-width fixtures for BASELINE configs[1], [2], [3] (model widths / depths / task counts of the configs; the
+    batch is the config's for molhiv and a small one for the two 256-wide models to keep the files small)."""
+    common = dict(norm_mp="naive-batch-norm", norm_dn="naive-batch-norm", msg_aggr="sum", pooling="softattention",
+                  activation="relu", real_trafo="linear", w_init="phm", c_init="standard", learn_phm=True)
+    # configs[1]: molhiv PHM-4, hidden 128, 4 layers, batch 512 (seeds 0, 1, 2 = the generator seeds of the Adam batches)
+    hiv = [synth.molecule_batch(512, seed=s) for s in (0, 1, 2)]
+    _fullwidth_fixture("g10_molhiv_b512", hiv, 1010,
+                       dict(phm_dim=4, atom_encoded_dim=128, mp_layers=[128] * 4, dropout_mpnn=[0.0] * 4, mlp=True,
+                            downstream_layers=[128, 32], dropout_dn=[0.0, 0.0], target_dim=1, sc_type="first", **common),
+                       adam_steps=3)
+    # the same model and batch with a smooth activation: no ReLU kink, so every fp32 evaluation order must agree with
+    # the float64 run tensor by tensor (the tight check of the full-width pipelines)
+    _fullwidth_fixture("g10_molhiv_b512_swish", hiv[:1], 1010,
+                       dict(phm_dim=4, atom_encoded_dim=128, mp_layers=[128] * 4, dropout_mpnn=[0.0] * 4, mlp=True,
+                            downstream_layers=[128, 32], dropout_dn=[0.0, 0.0], target_dim=1, sc_type="first",
+                            **dict(common, activation="swish")), store_grad32=False)
+    # configs[2]: ZINC PHM-8, hidden 256, 5 layers (batch 48)
+    zinc = [synth.molecule_batch(48, seed=20, dataset="zinc", regression=True)]
+    _fullwidth_fixture("g10_zinc_h256", zinc, 1020,
+                       dict(phm_dim=8, atom_input_dims=synth.ZINC_ATOM_DIMS, bond_input_dims=synth.ZINC_BOND_DIMS,
+                            atom_encoded_dim=256, mp_layers=[256] * 5, dropout_mpnn=[0.0] * 5, mlp=True,
+                            downstream_layers=[256, 128], dropout_dn=[0.0, 0.0], target_dim=1, sc_type="last", **common),
+                       regression=True)
+    # configs[3]: molpcba PHM-4, hidden 256, 5 layers, 128 tasks with ~60 % unlabeled entries (batch 64)
+    pcba = [synth.molecule_batch(64, seed=30, dataset="molpcba", num_tasks=128, nan_frac=0.6)]
+    _fullwidth_fixture("g10_molpcba_h256", pcba, 1030,
+                       dict(phm_dim=4, atom_encoded_dim=256, mp_layers=[256] * 5, dropout_mpnn=[0.0] * 5, mlp=True,
+                            downstream_layers=[768, 256], dropout_dn=[0.0, 0.0], target_dim=128, sc_type="first", **common),
+                       store_grad32=False)
+
+
 def g9_dropout():
     """G9: phm_dropout(same=True) mask structure (test_ops_equal_quaternion.py:64-103)."""
     torch.manual_seed(909)
@@ -383,7 +512,7 @@ def g9_dropout():
 
 if __name__ == "__main__":
     makers = [g1_phm_linear, g2_g3_g4_kronecker_rules, g5_convs, g5b_softmax, g6_norm, g7_heads, g8_models,
-              g8_model_softmax, g9_dropout]
+              g8_model_softmax, g9_dropout, g10_fullwidth]
     wanted = sys.argv[1:]                       # e.g. `make_golden.py g8_model_softmax` rewrites only that fixture
     for make in makers:
         if not wanted or make.__name__ in wanted:
