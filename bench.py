@@ -228,6 +228,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
 
+    lib.check_indices(dev)                     # sticky device error word: no kernel met an out-of-range index
     graphs = world * w["batch_size"] * args.steps
     dataset_name = {"molhiv": "ogbg-molhiv", "molpcba": "ogbg-molpcba", "zinc": "ZINC"}[w["dataset"]]
     config_note = {"molhiv_b32": " (BASELINE configs[0])", "molhiv_b512": " (BASELINE configs[1])",

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PHC_ABI_VERSION 1
+#define PHC_ABI_VERSION 2
 
 #define PHC_OK 0
 #define PHC_ERR_INVALID_ARG (-1)   /* null pointer, negative size, bad enum        */
@@ -54,6 +54,20 @@ extern "C" {
 #define PHC_ACT_SELU 5
 
 int phc_version(void);                       /* PHC_ABI_VERSION of the loaded library */
+
+/* Index validation.  The reference fails loudly on a bad index: nn.Embedding raises IndexError for a feature value
+ * outside its vocabulary (phc/quaternion/encoder.py:43-51), torch-scatter / index_select for a node id outside
+ * [0, N) (messagepassing.py:60,136).  The engine's kernels never dereference such a value: every kernel that reads a
+ * caller-supplied index maps an out-of-range value to 0 (so no out-of-bounds access can happen), and the FIRST kernel
+ * that sees it ORs one of the bits below into the int32 error word registered for the current device.  The word is
+ * sticky and read lazily by the host (the Python layer raises IndexError at its next check point, as a device-side
+ * assert would surface at the next synchronisation).  dev_word = NULL unregisters.  Opt-in handle: the only mutable
+ * library state besides the launch profiler. */
+#define PHC_IDX_ERR_EDGE 1         /* edge_index entry outside [0, num_nodes)                                  */
+#define PHC_IDX_ERR_ATOM 2         /* integer node feature outside its vocabulary (phc_encode_fwd)             */
+#define PHC_IDX_ERR_BOND 4         /* integer edge feature outside its vocabulary (packed codes / enc kernels) */
+#define PHC_IDX_ERR_SEGMENT 8      /* segment id (batch vector) outside [0, num_segments)                      */
+int phc_set_error_word(int device, int32_t *dev_word);
 const char *phc_error_string(int code);      /* host, static storage                  */
 const char *phc_last_error(void);            /* host, thread-local storage            */
 int phc_device_info(int *num_cu, int *lds_bytes_per_cu, char *arch, int arch_len);   /* host out-params */
@@ -146,9 +160,10 @@ int phc_phm_param_grads(const phc_phm_grad_job *jobs, int num_jobs, void *ws, si
  * Pooling segments: key = batch, other = NULL.
  * Replaces the index plumbing inside PyG 1.6.1 MessagePassing.propagate /
  * torch_scatter.scatter (call sites messagepassing.py:60,136; pooling.py:14).
- * Keys outside [0, num_keys) are a caller error (not detected on device). */
+ * Keys outside [0, num_keys) and `other` values outside [0, num_other) count as key / value 0 and raise
+ * PHC_IDX_ERR_EDGE (other given) or PHC_IDX_ERR_SEGMENT (other NULL) in the registered error word. */
 size_t phc_csr_ws_bytes(int64_t E, int64_t num_keys);
-int phc_csr_build(const int64_t *key_i64, const int64_t *other_i64, int64_t E, int64_t num_keys,
+int phc_csr_build(const int64_t *key_i64, const int64_t *other_i64, int64_t E, int64_t num_keys, int64_t num_other,
                   int32_t *rowptr, int32_t *col, int32_t *perm, void *ws, size_t ws_bytes, void *stream);
 
 /* rowptr[num_keys+1] for keys that are already NON-DECREASING (PyG's collated `batch`
@@ -247,9 +262,10 @@ int phc_gather_rows_i64(const float *src, const int64_t *idx_i64, int64_t n_rows
  * ------------------------------------------------------------------------- */
 #define PHC_MAX_ENC_FEATS 16
 
-/* out[i, c*k + kap] = sum_f T_{c,f}[ idx[i,f] ][kap]        idx_i64 [N, F] */
-int phc_encode_fwd(const int64_t *idx_i64, const float *const *tables, int64_t N, int F, int n, int k, float *out,
-                   void *stream);
+/* out[i, c*k + kap] = sum_f T_{c,f}[ idx[i,f] ][kap]        idx_i64 [N, F]
+ * idx[i,f] outside [0, vocab[f]) reads row 0 and raises PHC_IDX_ERR_ATOM (see phc_set_error_word). */
+int phc_encode_fwd(const int64_t *idx_i64, const float *const *tables, const int32_t *vocab, int64_t N, int F, int n, int k,
+                   float *out, void *stream);
 
 /* dT_{c,f}[v][kap] = sum_{i: idx[i,f]=v} dout[i, c*k+kap]    (replaces F*n embedding_dense_backward sorts) */
 size_t phc_encode_bwd_ws_bytes(int64_t N, int F, const int32_t *vocab, int n, int k);

@@ -20,6 +20,13 @@ void set_last_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+static int *g_err_words[64] = {};
+int *err_word() {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return nullptr;
+    return g_err_words[dev];
+}
+
 static const char *const kKernelNames[K_NUM_KERNELS] = {
     "phm_build_H",      "phm_gemm_fwd", "phm_gemm_dx", "phm_dH_partial", "phm_dH_reduce", "phm_contract_dW_dA",
     "aggregate_fwd",    "aggregate_bwd", "gather_rows", "csr_histogram",  "csr_scan",      "csr_fill",
@@ -132,6 +139,12 @@ const char *phc_error_string(int code) {
 }
 
 const char *phc_last_error(void) { return t_last_error; }
+
+int phc_set_error_word(int device, int32_t *dev_word) {
+    PHC_REQUIRE(device >= 0 && device < 64, PHC_ERR_INVALID_ARG, "phc_set_error_word: device %d", device);
+    g_err_words[device] = reinterpret_cast<int *>(dev_word);
+    return PHC_OK;
+}
 
 int phc_device_info(int *num_cu, int *lds_bytes_per_cu, char *arch, int arch_len) {
     int dev = 0;

@@ -14,9 +14,10 @@ constexpr int SCAN_THREADS = 256;
 constexpr int SCAN_ITEMS = 8;
 constexpr int SCAN_ELEMS = SCAN_THREADS * SCAN_ITEMS;      // elements per workgroup
 
-__global__ void csr_hist_kernel(const long long *__restrict__ key, long long E, int *__restrict__ counts) {
+__global__ void csr_hist_kernel(const long long *__restrict__ key, long long E, int *__restrict__ counts, long long num_keys,
+                                int *__restrict__ err, int err_bit) {
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (long long)gridDim.x * blockDim.x)
-        atomicAdd(&counts[key[e]], 1);
+        atomicAdd(&counts[checked_index(key[e], num_keys, err, err_bit)], 1);
 }
 
 // In-place exclusive scan of SCAN_ELEMS-element blocks; block totals go to sums[blockIdx.x].
@@ -62,9 +63,9 @@ __global__ void scan_add_kernel(int *__restrict__ data, const int *__restrict__ 
 
 // slot = rowptr[key] + (arrival order); arrival order is arbitrary, csr_canon fixes it.
 __global__ void csr_fill_kernel(const long long *__restrict__ key, long long E, const int *__restrict__ rowptr,
-                                int *__restrict__ cursor, int *__restrict__ tmp_perm) {
+                                int *__restrict__ cursor, int *__restrict__ tmp_perm, long long num_keys) {
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (long long)gridDim.x * blockDim.x) {
-        const long long k = key[e];
+        const long long k = safe_index(key[e], num_keys);
         const int pos = rowptr[k] + atomicAdd(&cursor[k], 1);
         tmp_perm[pos] = (int)e;
     }
@@ -75,7 +76,8 @@ __global__ void csr_fill_kernel(const long long *__restrict__ key, long long E, 
 template <int SUB>
 __global__ __launch_bounds__(256) void csr_canon_kernel(const int *__restrict__ rowptr, const int *__restrict__ tmp_perm,
                                                        const long long *__restrict__ other, long long num_keys, int lo, int hi,
-                                                       int *__restrict__ perm, int *__restrict__ col) {
+                                                       int *__restrict__ perm, int *__restrict__ col, long long num_other,
+                                                       int *__restrict__ err) {
     const int li = threadIdx.x & (SUB - 1);
     const long long grp = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / SUB;
     const long long n_grp = ((long long)gridDim.x * blockDim.x) / SUB;
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(256) void csr_canon_kernel(const int *__restrict__ 
             int rank = 0;
             for (int j = 0; j < deg; ++j) rank += (tmp_perm[b + j] < v) ? 1 : 0;
             perm[b + rank] = v;
-            col[b + rank] = other ? (int)other[v] : v;
+            col[b + rank] = other ? (int)checked_index(other[v], num_other, err, PHC_IDX_ERR_EDGE) : v;
         }
     }
 }
@@ -149,7 +151,8 @@ struct CsrPair {
     // canonicalising launch as it places each edge — one launch less per batch
     const long long *bond;
     unsigned *codes;
-    int F, off[4];
+    int F, off[4], vocab[4];
+    int *err;                          // registered error word (phc_set_error_word) or nullptr
 };
 
 __global__ void csr_pair_zero_kernel(CsrPair p) {
@@ -163,7 +166,7 @@ __global__ void csr_pair_zero_kernel(CsrPair p) {
 __global__ void csr_pair_hist_kernel(CsrPair p, long long E) {
     const CsrSide &sd = p.s[blockIdx.y];
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (long long)gridDim.x * blockDim.x)
-        atomicAdd(&sd.rowptr[sd.key[e]], 1);
+        atomicAdd(&sd.rowptr[checked_index(sd.key[e], sd.num_keys, p.err, PHC_IDX_ERR_EDGE)], 1);      // both sides: every src and dst
 }
 
 // exclusive scan of rowptr[0 .. num_keys] by ONE workgroup per side.  Global traffic is coalesced (thread t touches
@@ -223,7 +226,7 @@ __global__ __launch_bounds__(PAIR_SCAN_THREADS) void csr_pair_scan_kernel(CsrPai
 __global__ void csr_pair_fill_kernel(CsrPair p, long long E) {
     const CsrSide &sd = p.s[blockIdx.y];
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (long long)gridDim.x * blockDim.x) {
-        const long long k = sd.key[e];
+        const long long k = safe_index(sd.key[e], sd.num_keys);
         const int pos = sd.rowptr[k] + atomicAdd(&sd.cursor[k], 1);
         sd.tmp_perm[pos] = (int)e;
     }
@@ -232,6 +235,7 @@ __global__ void csr_pair_fill_kernel(CsrPair p, long long E) {
 // rank sort of every row, 8 lanes per row, any degree
 __global__ __launch_bounds__(256) void csr_pair_canon_kernel(CsrPair p) {
     const CsrSide &sd = p.s[blockIdx.y];
+    const long long num_other = p.s[1 - blockIdx.y].num_keys;
     constexpr int SUB = 8;
     const int li = threadIdx.x & (SUB - 1);
     const long long grp = ((long long)blockIdx.x * blockDim.x + threadIdx.x) / SUB;
@@ -243,10 +247,12 @@ __global__ __launch_bounds__(256) void csr_pair_canon_kernel(CsrPair p) {
             int rank = 0;
             for (int j = 0; j < deg; ++j) rank += (sd.tmp_perm[b + j] < v) ? 1 : 0;
             sd.perm[b + rank] = v;
-            sd.col[b + rank] = (int)sd.other[v];
+            sd.col[b + rank] = (int)safe_index(sd.other[v], num_other);
             if (blockIdx.y == 0 && p.codes) {
                 unsigned c = 0;
-                for (int f = 0; f < p.F; ++f) c |= (unsigned)(p.off[f] + (int)p.bond[(long long)v * p.F + f]) << (8 * f);
+                for (int f = 0; f < p.F; ++f)
+                    c |= (unsigned)(p.off[f] + (int)checked_index(p.bond[(long long)v * p.F + f], p.vocab[f], p.err, PHC_IDX_ERR_BOND))
+                         << (8 * f);
                 p.codes[b + rank] = c;
             }
         }
@@ -256,19 +262,20 @@ __global__ __launch_bounds__(256) void csr_pair_canon_kernel(CsrPair p) {
 // ---- remove isolated nodes (benchmarks/utils.py:36-46, applied to every collated batch: train_hiv.py:171-172) ----
 // keep[i] = 1 when node i touches an edge; newid = exclusive scan of keep; edges are relabelled, node rows compacted.
 __global__ void iso_flag_kernel(const long long *__restrict__ src, const long long *__restrict__ dst, long long E,
-                                int *__restrict__ keep) {
+                                int *__restrict__ keep, long long N, int *__restrict__ err) {
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (long long)gridDim.x * blockDim.x) {
-        keep[src[e]] = 1;                                   // benign race: every writer stores the same value
-        keep[dst[e]] = 1;
+        keep[checked_index(src[e], N, err, PHC_IDX_ERR_EDGE)] = 1;      // benign race: every writer stores the same value
+        keep[checked_index(dst[e], N, err, PHC_IDX_ERR_EDGE)] = 1;
     }
 }
 
 // newid holds the exclusive scan of keep over N + 1 entries (newid[N] = number of kept nodes)
 __global__ void iso_relabel_kernel(const long long *__restrict__ src, const long long *__restrict__ dst, long long E,
-                                   const int *__restrict__ newid, long long *__restrict__ src_out, long long *__restrict__ dst_out) {
+                                   const int *__restrict__ newid, long long *__restrict__ src_out, long long *__restrict__ dst_out,
+                                   long long N) {
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (long long)gridDim.x * blockDim.x) {
-        src_out[e] = newid[src[e]];
-        dst_out[e] = newid[dst[e]];
+        src_out[e] = newid[safe_index(src[e], N)];
+        dst_out[e] = newid[safe_index(dst[e], N)];
     }
 }
 
@@ -316,10 +323,15 @@ int phc_segment_ptr_sorted(const int64_t *key_i64, int64_t n, int64_t num_keys, 
     return check_launch("sorted_segment_ptr");
 }
 
-int phc_csr_build(const int64_t *key_i64, const int64_t *other_i64, int64_t E, int64_t num_keys, int32_t *rowptr,
-                  int32_t *col, int32_t *perm, void *ws, size_t ws_bytes, void *stream) {
+int phc_csr_build(const int64_t *key_i64, const int64_t *other_i64, int64_t E, int64_t num_keys, int64_t num_other,
+                  int32_t *rowptr, int32_t *col, int32_t *perm, void *ws, size_t ws_bytes, void *stream) {
     PHC_REQUIRE(E >= 0 && num_keys >= 0, PHC_ERR_INVALID_ARG, "phc_csr_build: E=%lld num_keys=%lld", (long long)E,
                 (long long)num_keys);
+    PHC_REQUIRE(E == 0 || num_keys >= 1, PHC_ERR_INVALID_ARG, "phc_csr_build: %lld items but no key range", (long long)E);
+    PHC_REQUIRE(!other_i64 || E == 0 || (num_other >= 1 && num_other < (1LL << 31) - 1), PHC_ERR_INVALID_ARG,
+                "phc_csr_build: num_other=%lld", (long long)num_other);
+    int *err = err_word();
+    const int err_bit = other_i64 ? PHC_IDX_ERR_EDGE : PHC_IDX_ERR_SEGMENT;
     PHC_REQUIRE(E < (1LL << 31) - 1 && num_keys < (1LL << 31) - 1, PHC_ERR_UNSUPPORTED,
                 "phc_csr_build: int32 index space exceeded (E=%lld, keys=%lld)", (long long)E, (long long)num_keys);
     PHC_REQUIRE(rowptr && (E == 0 || (key_i64 && col && perm)), PHC_ERR_INVALID_ARG, "phc_csr_build: null pointer");
@@ -341,7 +353,7 @@ int phc_csr_build(const int64_t *key_i64, const int64_t *other_i64, int64_t E, i
     if (E > 0) {
         ProfScope prof(K_CSR_HIST, s);
         PHC_LAUNCH(csr_hist_kernel, dim3(egrid), dim3(256), 0, s, reinterpret_cast<const long long *>(key_i64),
-                           (long long)E, rowptr);
+                           (long long)E, rowptr, (long long)num_keys, err, err_bit);
         int rc = check_launch("csr_hist");
         if (rc) return rc;
     }
@@ -371,7 +383,7 @@ int phc_csr_build(const int64_t *key_i64, const int64_t *other_i64, int64_t E, i
     {
         ProfScope prof(K_CSR_FILL, s);
         PHC_LAUNCH(csr_fill_kernel, dim3(egrid), dim3(256), 0, s, reinterpret_cast<const long long *>(key_i64),
-                           (long long)E, rowptr, cursor, tmp_perm);
+                           (long long)E, rowptr, cursor, tmp_perm, (long long)num_keys);
         int rc = check_launch("csr_fill");
         if (rc) return rc;
     }
@@ -380,11 +392,13 @@ int phc_csr_build(const int64_t *key_i64, const int64_t *other_i64, int64_t E, i
         const long long groups8 = (num_keys + 31) / 32;        // 256 threads = 32 rows of 8 lanes
         unsigned g8 = (unsigned)(groups8 > 16384 ? 16384 : (groups8 < 1 ? 1 : groups8));
         PHC_LAUNCH((csr_canon_kernel<8>), dim3(g8), dim3(256), 0, s, rowptr, tmp_perm,
-                           reinterpret_cast<const long long *>(other_i64), (long long)num_keys, 0, 64, perm, col);
+                           reinterpret_cast<const long long *>(other_i64), (long long)num_keys, 0, 64, perm, col,
+                           (long long)num_other, err);
         const long long groups64 = (num_keys + 3) / 4;
         unsigned g64 = (unsigned)(groups64 > 8192 ? 8192 : (groups64 < 1 ? 1 : groups64));
         PHC_LAUNCH((csr_canon_kernel<64>), dim3(g64), dim3(256), 0, s, rowptr, tmp_perm,
-                           reinterpret_cast<const long long *>(other_i64), (long long)num_keys, 64, 0x7fffffff, perm, col);
+                           reinterpret_cast<const long long *>(other_i64), (long long)num_keys, 64, 0x7fffffff, perm, col,
+                           (long long)num_other, err);
         int rc = check_launch("csr_canon");
         if (rc) return rc;
     }
@@ -443,7 +457,11 @@ int phc_csr_build_pair_codes(const int64_t *edge_src_i64, const int64_t *edge_ds
     p.bond = reinterpret_cast<const long long *>(bond_i64);
     p.codes = codes;
     p.F = codes ? F : 0;
-    for (int f = 0; f < 4; ++f) p.off[f] = code_off[f];
+    for (int f = 0; f < 4; ++f) {
+        p.off[f] = code_off[f];
+        p.vocab[f] = (codes && f < F) ? vocab[f] : 1;
+    }
+    p.err = err_word();
     const long long nmax = (n_src > n_dst ? n_src : n_dst) + 1;
     const unsigned ngrid = (unsigned)((nmax + 255) / 256);
     const unsigned egrid = (unsigned)((E + 255) / 256 > 4096 ? 4096 : (E + 255) / 256);
@@ -494,7 +512,7 @@ int phc_remove_isolated_nodes(const int64_t *edge_src_i64, const int64_t *edge_d
     const unsigned egrid = (unsigned)((E + 255) / 256 > 8192 ? 8192 : ((E + 255) / 256 < 1 ? 1 : (E + 255) / 256));
     if (E > 0) {
         ProfScope prof(K_CSR_HIST, s);
-        PHC_LAUNCH(iso_flag_kernel, dim3(egrid), dim3(256), 0, s, src, dst, (long long)E, newid);
+        PHC_LAUNCH(iso_flag_kernel, dim3(egrid), dim3(256), 0, s, src, dst, (long long)E, newid, (long long)N, err_word());
     }
     {
         ProfScope prof(K_CSR_SCAN, s);
@@ -517,7 +535,7 @@ int phc_remove_isolated_nodes(const int64_t *edge_src_i64, const int64_t *edge_d
     ProfScope prof(K_CSR_FILL, s);
     if (E > 0)
         PHC_LAUNCH(iso_relabel_kernel, dim3(egrid), dim3(256), 0, s, src, dst, (long long)E, newid,
-                   reinterpret_cast<long long *>(edge_src_out), reinterpret_cast<long long *>(edge_dst_out));
+                   reinterpret_cast<long long *>(edge_src_out), reinterpret_cast<long long *>(edge_dst_out), (long long)N);
     const long long total = N * (long long)(F > 0 ? F : 1);
     const unsigned ngrid = (unsigned)((total + 255) / 256 > 8192 ? 8192 : ((total + 255) / 256 < 1 ? 1 : (total + 255) / 256));
     PHC_LAUNCH(iso_compact_kernel, dim3(ngrid), dim3(256), 0, s, newid, (long long)N, reinterpret_cast<const long long *>(x_i64), F,

@@ -37,7 +37,8 @@ __device__ __forceinline__ void acc4(float4 &a, const float4 b) { a.x += b.x; a.
 template <int LPR, int FMAX>
 __global__ __launch_bounds__(ENC_THREADS) void encode_fwd_kernel(const long long *__restrict__ idx,
                                                                 const float *const *__restrict__ tables, long long N,
-                                                                int F, int n, int k, float *__restrict__ out) {
+                                                                int F, int n, int k, float *__restrict__ out, EncMeta m,
+                                                                int *__restrict__ err) {
     __shared__ const float *tptr[PHC_MAX_COMPONENTS * ENC_MAX_F];   // table base pointers: no pointer chase per lookup
     for (int e = threadIdx.x; e < n * F; e += ENC_THREADS) tptr[e] = tables[e];
     __syncthreads();
@@ -53,7 +54,10 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_fwd_kernel(const long long
         // all F indices of the row first (one round of loads), then all F table rows (a second round)
         long long iv[FMAX];
 #pragma unroll
-        for (int f = 0; f < FMAX; ++f) iv[f] = idx[i * F + min(f, F - 1)];
+        for (int f = 0; f < FMAX; ++f) {
+            const int ff = min(f, F - 1);
+            iv[f] = checked_index(idx[i * F + ff], m.off[ff + 1] - m.off[ff], err, PHC_IDX_ERR_ATOM);
+        }
         for (int c4 = li; c4 < h4; c4 += LPR) {
             const int col = c4 << 2;
             const int c = col / k, kap = col - c * k;
@@ -72,7 +76,7 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_fwd_kernel(const long long
 __global__ __launch_bounds__(ENC_THREADS) void encode_fwd_scalar_kernel(const long long *__restrict__ idx,
                                                                        const float *const *__restrict__ tables,
                                                                        long long N, int F, int n, int k,
-                                                                       float *__restrict__ out) {
+                                                                       float *__restrict__ out, EncMeta m, int *__restrict__ err) {
     const int h = n * k;
     const long long total = N * h;
     for (long long e = (long long)blockIdx.x * ENC_THREADS + threadIdx.x; e < total; e += (long long)gridDim.x * ENC_THREADS) {
@@ -80,7 +84,8 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_fwd_scalar_kernel(const lo
         const int col = (int)(e - i * h);
         const int c = col / k, kap = col - c * k;
         float acc = 0.f;
-        for (int f = 0; f < F; ++f) acc += tables[c * F + f][idx[i * F + f] * k + kap];
+        for (int f = 0; f < F; ++f)
+            acc += tables[c * F + f][checked_index(idx[i * F + f], m.off[f + 1] - m.off[f], err, PHC_IDX_ERR_ATOM) * k + kap];
         out[e] = acc;
     }
 }
@@ -91,7 +96,7 @@ template <int LPR, int ACT>
 __global__ __launch_bounds__(ENC_THREADS) void aggregate_enc_fwd_kernel(
     const float *__restrict__ x, const long long *__restrict__ bond, const float *const *__restrict__ tables, EncMeta m,
     const int *__restrict__ rowptr, const int *__restrict__ col, const int *__restrict__ perm, long long n_dst, int n, int k,
-    int add_self, float *__restrict__ out) {
+    int add_self, float *__restrict__ out, int *__restrict__ err) {
     extern __shared__ __attribute__((aligned(16))) float tbl[];      // [R][h], component-major columns
     const int h = n * k, h4 = h >> 2;
     for (int e = threadIdx.x; e < m.R * h; e += ENC_THREADS) {
@@ -119,7 +124,7 @@ __global__ __launch_bounds__(ENC_THREADS) void aggregate_enc_fwd_kernel(
                 const long long p = perm[e];
                 float4 v = reinterpret_cast<const float4 *>(x + (size_t)s * h)[c4];
                 for (int f = 0; f < F; ++f) {
-                    const int r = m.off[f] + (int)bond[p * F + f];
+                    const int r = m.off[f] + (int)checked_index(bond[p * F + f], m.off[f + 1] - m.off[f], err, PHC_IDX_ERR_BOND);
                     acc4(v, reinterpret_cast<const float4 *>(tbl + r * h)[c4]);
                 }
                 acc.x += act_fwd<ACT>(v.x); acc.y += act_fwd<ACT>(v.y);
@@ -143,11 +148,12 @@ __global__ __launch_bounds__(ENC_THREADS) void aggregate_enc_fwd_kernel(
 // (F <= 4, sum(vocab) <= 256).  Built once per (edge structure, bond tensor); the aggregation then reads
 // 4 bytes per edge next to col[e] instead of chasing perm[e] -> F int64 loads.
 __global__ void pack_edge_codes_kernel(const long long *__restrict__ bond, const int *__restrict__ perm, EncMeta m, long long E,
-                                       unsigned *__restrict__ codes) {
+                                       unsigned *__restrict__ codes, int *__restrict__ err) {
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (long long)gridDim.x * blockDim.x) {
         const long long p = perm ? perm[e] : e;
         unsigned c = 0;
-        for (int f = 0; f < m.F; ++f) c |= (unsigned)(m.off[f] + (int)bond[p * m.F + f]) << (8 * f);
+        for (int f = 0; f < m.F; ++f)
+            c |= (unsigned)(m.off[f] + (int)checked_index(bond[p * m.F + f], m.off[f + 1] - m.off[f], err, PHC_IDX_ERR_BOND)) << (8 * f);
         codes[e] = c;
     }
 }
@@ -347,7 +353,7 @@ __global__ __launch_bounds__(ENC_THREADS) void aggregate_enc_dx_kernel(
                     const long long p = perm_t[e];
                     float4 pre = xs;
                     for (int f = 0; f < F; ++f)
-                        acc4(pre, reinterpret_cast<const float4 *>(tbl + (m.off[f] + (int)bond[p * F + f]) * h)[c4]);
+                        acc4(pre, reinterpret_cast<const float4 *>(tbl + (m.off[f] + (int)safe_index(bond[p * F + f], m.off[f + 1] - m.off[f])) * h)[c4]);
                     g.x *= act_grad<ACT>(pre.x); g.y *= act_grad<ACT>(pre.y);
                     g.z *= act_grad<ACT>(pre.z); g.w *= act_grad<ACT>(pre.w);
                 }
@@ -415,7 +421,8 @@ __device__ __forceinline__ void table_grad_body(
                     if (MODE == 1 && ACT != PHC_ACT_IDENTITY) {
                         float pre = x[(size_t)src[t] * h + col];
                         const int c = col / k, kap = col - c * k;
-                        for (int f = 0; f < F; ++f) pre += tables[c * F + f][(size_t)idx[t * F + f] * k + kap];
+                        for (int f = 0; f < F; ++f)
+                            pre += tables[c * F + f][(size_t)safe_index(idx[t * F + f], m.off[f + 1] - m.off[f]) * k + kap];
                         g *= act_grad<ACT>(pre);
                     }
                 }
@@ -434,7 +441,8 @@ __device__ __forceinline__ void table_grad_body(
                     float4 pre = *reinterpret_cast<const float4 *>(x + (size_t)src[t] * h + col);
                     const int c = col / k, kap = col - c * k;
                     for (int f = 0; f < F; ++f) {
-                        const float4 tv = *reinterpret_cast<const float4 *>(tables[c * F + f] + (size_t)idx[t * F + f] * k + kap);
+                        const float4 tv = *reinterpret_cast<const float4 *>(
+                            tables[c * F + f] + (size_t)safe_index(idx[t * F + f], m.off[f + 1] - m.off[f]) * k + kap);
                         pre.x += tv.x; pre.y += tv.y; pre.z += tv.z; pre.w += tv.w;
                     }
                     g.x *= act_grad<ACT>(pre.x); g.y *= act_grad<ACT>(pre.y);
@@ -890,10 +898,16 @@ using namespace phc;
 
 extern "C" {
 
-int phc_encode_fwd(const int64_t *idx_i64, const float *const *tables, int64_t N, int F, int n, int k, float *out,
-                   void *stream) {
+int phc_encode_fwd(const int64_t *idx_i64, const float *const *tables, const int32_t *vocab, int64_t N, int F, int n, int k,
+                   float *out, void *stream) {
     PHC_REQUIRE(N >= 0 && F >= 1 && n >= 1 && k >= 1, PHC_ERR_INVALID_ARG, "phc_encode_fwd: N=%lld F=%d n=%d k=%d", (long long)N,
                 F, n, k);
+    EncMeta m;
+    {
+        int rc = make_meta("phc_encode_fwd", F, vocab, &m);
+        if (rc) return rc;
+    }
+    int *err = err_word();
     if (N == 0) return PHC_OK;
     PHC_REQUIRE(idx_i64 && tables && out, PHC_ERR_INVALID_ARG, "phc_encode_fwd: null pointer");
     hipStream_t s = (hipStream_t)stream;
@@ -906,7 +920,8 @@ int phc_encode_fwd(const int64_t *idx_i64, const float *const *tables, int64_t N
         if (blocks > (N > 64 * 1024 ? 32768 : 4096)) blocks = N > 64 * 1024 ? 32768 : 4096;
         const long long *idx = reinterpret_cast<const long long *>(idx_i64);
 #define PHC_ENC_FWD(LPRC, FM)                                                                                               \
-    PHC_LAUNCH((encode_fwd_kernel<LPRC, FM>), dim3((unsigned)blocks), dim3(ENC_THREADS), 0, s, idx, tables, (long long)N, F, n, k, out)
+    PHC_LAUNCH((encode_fwd_kernel<LPRC, FM>), dim3((unsigned)blocks), dim3(ENC_THREADS), 0, s, idx, tables, (long long)N, F, n, k, out, \
+               m, err)
 #define PHC_ENC_FWD_F(LPRC)             \
     if (F <= 4) {                       \
         PHC_ENC_FWD(LPRC, 4);           \
@@ -927,7 +942,7 @@ int phc_encode_fwd(const int64_t *idx_i64, const float *const *tables, int64_t N
         long long blocks = (N * h + ENC_THREADS - 1) / ENC_THREADS;
         if (blocks > (N > 64 * 1024 ? 32768 : 4096)) blocks = N > 64 * 1024 ? 32768 : 4096;
         PHC_LAUNCH(encode_fwd_scalar_kernel, dim3((unsigned)blocks), dim3(ENC_THREADS), 0, s,
-                           reinterpret_cast<const long long *>(idx_i64), tables, (long long)N, F, n, k, out);
+                           reinterpret_cast<const long long *>(idx_i64), tables, (long long)N, F, n, k, out, m, err);
     }
     return check_launch("encode_fwd");
 }
@@ -1014,7 +1029,7 @@ int phc_aggregate_enc_fwd(const float *x, const int64_t *bond_i64, const float *
     ProfScope prof(K_AGG_ENC_FWD, s);
 #define PHC_AE_LAUNCH(LPRC, ACTC)                                                                                          \
     PHC_LAUNCH((aggregate_enc_fwd_kernel<LPRC, ACTC>), dim3((unsigned)blocks), dim3(ENC_THREADS), lds, s, x, bond,      \
-                       tables, m, rowptr, col, perm, (long long)n_dst, n, k, add_self, out)
+                       tables, m, rowptr, col, perm, (long long)n_dst, n, k, add_self, out, err_word())
 #define PHC_AE_ACT(LPRC)                                            \
     switch (act) {                                                  \
         case PHC_ACT_IDENTITY: PHC_AE_LAUNCH(LPRC, PHC_ACT_IDENTITY); break; \
@@ -1048,7 +1063,7 @@ int phc_pack_edge_codes(const int64_t *bond_i64, const int32_t *perm, const int3
     if (blocks > 8192) blocks = 8192;
     ProfScope prof(K_PACK_CODES, s);
     PHC_LAUNCH(pack_edge_codes_kernel, dim3((unsigned)blocks), dim3(256), 0, s, reinterpret_cast<const long long *>(bond_i64),
-                       perm, m, (long long)E, codes);
+                       perm, m, (long long)E, codes, err_word());
     return check_launch("pack_edge_codes");
 }
 

@@ -29,6 +29,19 @@ void set_last_error(const char *fmt, ...);
         }                                    \
     } while (0)
 
+// ---- index validation (phc_set_error_word) --------------------------------------
+int *err_word();                       // device word registered for the current device, or nullptr
+
+// caller-supplied index -> a value that is safe to dereference; the first reader of an array also reports
+__device__ __forceinline__ long long checked_index(long long v, long long n, int *err, int bit) {
+    if ((unsigned long long)v >= (unsigned long long)n) {
+        if (err) atomicOr(err, bit);
+        return 0;
+    }
+    return v;
+}
+__device__ __forceinline__ long long safe_index(long long v, long long n) { return (unsigned long long)v < (unsigned long long)n ? v : 0; }
+
 // ---- launch profiler ---------------------------------------------------------
 // Kernel ids are stable indices into the name table in api.hip.
 enum KernelId : int {

@@ -21,8 +21,9 @@ _NO_PAIR = bool(__import__('os').environ.get('PHC_NO_CSR_PAIR'))
 _cache: "OrderedDict[tuple, EdgeStructure]" = OrderedDict()
 
 
-def _build_sorted(key: torch.Tensor, other: Optional[torch.Tensor], num_keys: int, out=None):
-    """(rowptr[num_keys+1], col[E], perm[E]) int32 on key.device; ``out``: rebuild into these three tensors."""
+def _build_sorted(key: torch.Tensor, other: Optional[torch.Tensor], num_keys: int, out=None, num_other: int = 0):
+    """(rowptr[num_keys+1], col[E], perm[E]) int32 on key.device; ``out``: rebuild into these three tensors.
+    ``num_other``: valid range of the ``other`` values (they become gather indices)."""
     lib = L.load()
     dev = L.require_device(key, other)
     E = key.numel()
@@ -34,8 +35,9 @@ def _build_sorted(key: torch.Tensor, other: Optional[torch.Tensor], num_keys: in
         perm = torch.empty(E, dtype=torch.int32, device=dev)
     ws_bytes = lib.phc_csr_ws_bytes(E, num_keys)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-    L.check(lib.phc_csr_build(L.ptr(key), L.ptr(other), E, num_keys, L.ptr(rowptr), L.ptr(col), L.ptr(perm),
+    L.check(lib.phc_csr_build(L.ptr(key), L.ptr(other), E, num_keys, num_other, L.ptr(rowptr), L.ptr(col), L.ptr(perm),
                               L.ptr(ws), ws_bytes, L.stream_ptr(dev)), "phc_csr_build")
+    L.maybe_check_indices(dev)
     return rowptr, col, perm
 
 
@@ -104,9 +106,9 @@ class EdgeStructure:
             pair_rebuilt = True
         else:
             if self._csr is not None:
-                _build_sorted(self._dst, self._src, self.num_dst, out=self._csr)
+                _build_sorted(self._dst, self._src, self.num_dst, out=self._csr, num_other=self.num_src)
             if self._csc is not None:
-                _build_sorted(self._src, self._dst, self.num_src, out=self._csc)
+                _build_sorted(self._src, self._dst, self.num_src, out=self._csc, num_other=self.num_dst)
         if not (pair_rebuilt and self._codes_args is not None):      # the pair launches repacked the sorted codes already
             for codes in self._codes.values():
                 self._pack_codes(*self._codes_args, codes)
@@ -140,6 +142,7 @@ class EdgeStructure:
                                              L.ptr(csr[1]), L.ptr(csr[2]), L.ptr(csc[0]), L.ptr(csc[1]), L.ptr(csc[2]),
                                              L.ptr(bond), vocab_c, F, L.ptr(codes), L.ptr(ws), ws_bytes, L.stream_ptr(dev)),
                 "phc_csr_build_pair_codes")
+        L.maybe_check_indices(dev)
         self._csr, self._csc = csr, csc
         if codes is not None and not reuse:
             self._codes = {(bond.data_ptr(), bond._version, tuple(vocab_c)): codes}
@@ -159,14 +162,14 @@ class EdgeStructure:
     def csr(self):
         """rowptr[num_dst+1], col = source of each in-edge, perm = original edge id."""
         if self._csr is None:
-            self._csr = _build_sorted(self._dst, self._src, self.num_dst)
+            self._csr = _build_sorted(self._dst, self._src, self.num_dst, num_other=self.num_src)
         return self._csr
 
     @property
     def csc(self):
         """rowptr_t[num_src+1], col_t = target of each out-edge, perm_t = original edge id."""
         if self._csc is None:
-            self._csc = _build_sorted(self._src, self._dst, self.num_src)
+            self._csc = _build_sorted(self._src, self._dst, self.num_src, num_other=self.num_dst)
         return self._csc
 
 

@@ -226,6 +226,14 @@ class GraphedTrainStep:
         # later eager allocations made its replays fault on ROCm 7.x (the packet-capture ordering bug, DESIGN.md §5;
         # scripts/debug_pipelined.py reproduces the family).
         torch.cuda.synchronize(dev)
+        from .lib import check_indices
+        check_indices(dev)                     # the example batch went through every index-reading kernel: bad ids raise here
+
+    def check(self) -> None:
+        """IndexError if any replay since the last check met an out-of-range node id / feature index (one 4-byte read;
+        the kernels read such entries as 0 instead of dereferencing them)."""
+        from .lib import check_indices
+        check_indices(self.device)
 
     def __del__(self):
         try:

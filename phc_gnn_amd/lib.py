@@ -15,6 +15,7 @@ import torch
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, "libphc_hip.so")
 
+ABI_VERSION = 2
 ACT_IDS = {"identity": 0, "relu": 1, "lrelu": 2, "elu": 3, "swish": 4, "selu": 5}
 
 
@@ -49,6 +50,7 @@ SIGNATURES = {
     "phc_version": (_I, []),
     "phc_error_string": (C.c_char_p, [_I]),
     "phc_last_error": (C.c_char_p, []),
+    "phc_set_error_word": (_I, [_I, _P]),
     "phc_device_info": (_I, [C.POINTER(_I), C.POINTER(_I), C.c_char_p, _I]),
     "phc_phm_build_H": (_I, [_P, _P, _I, _I, _I, _P, _P]),
     "phc_phm_linear_fwd": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _I, _P, _P]),
@@ -67,7 +69,7 @@ SIGNATURES = {
     "phc_phm_param_grads_ws_bytes": (_S, [C.POINTER(GradJob), _I]),
     "phc_phm_param_grads": (_I, [C.POINTER(GradJob), _I, _P, _S, _P]),
     "phc_csr_ws_bytes": (_S, [_L, _L]),
-    "phc_csr_build": (_I, [_P, _P, _L, _L, _P, _P, _P, _P, _S, _P]),
+    "phc_csr_build": (_I, [_P, _P, _L, _L, _L, _P, _P, _P, _P, _S, _P]),
     "phc_csr_pair_ws_bytes": (_S, [_L, _L, _L]),
     "phc_csr_build_pair": (_I, [_P, _P, _L, _L, _L, _P, _P, _P, _P, _P, _P, _P, _S, _P]),
     "phc_csr_build_pair_codes": (_I, [_P, _P, _L, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _S, _P]),
@@ -84,7 +86,7 @@ SIGNATURES = {
     "phc_aggregate_softmax_bwd_self": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _L, _I, _I, _L, _P, _P, _P, _P]),
     "phc_aggregate_softmax_enc_fwd": (_I, [_P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _L, _I, _P, _P, _P, _P]),
     "phc_aggregate_softmax_enc_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _L, _I, _L, _P, _P, _P, _P]),
-    "phc_encode_fwd": (_I, [_P, _P, _L, _I, _I, _I, _P, _P]),
+    "phc_encode_fwd": (_I, [_P, _P, _P, _L, _I, _I, _I, _P, _P]),
     "phc_encode_bwd_ws_bytes": (_S, [_L, _I, _P, _I, _I]),
     "phc_encode_bwd": (_I, [_P, _P, _L, _I, _P, _I, _I, _P, _P, _S, _P]),
     "phc_encode_bwd_batched_ws_bytes": (_S, [_L, _I, _P, _I, _I, _I]),
@@ -152,8 +154,8 @@ def load() -> C.CDLL:
             raise PhcError(f"{LIB_PATH} does not export {name}; rebuild it") from exc
         fn.restype = res
         fn.argtypes = args
-    if lib.phc_version() != 1:
-        raise PhcError(f"ABI version mismatch: library {lib.phc_version()}, binding 1")
+    if lib.phc_version() != ABI_VERSION:
+        raise PhcError(f"ABI version mismatch: library {lib.phc_version()}, binding {ABI_VERSION}")
     _lib = lib
     return lib
 
@@ -180,7 +182,45 @@ def require_device(*tensors: Optional[torch.Tensor]) -> torch.device:
             raise PhcError(f"tensors on different devices: {dev} vs {t.device}")
     if dev is None:
         raise PhcError("no tensor given")
+    if dev not in _ERR_WORDS:
+        _register_error_word(dev)
     return dev
+
+
+# ---- index validation (include/phc_hip.h: phc_set_error_word) ---------------------------------------------------
+# One sticky int32 per device.  Kernels never dereference an out-of-range index (it reads as 0) and OR a bit into the
+# word; the host looks at it at its check points: GraphedTrainStep after warm-up, bench.py / smoke at the end,
+# `phc_gnn_amd.check_indices()` whenever the caller wants (one 4-byte read = one synchronisation), or after EVERY
+# structure build / encoder call with PHC_CHECK_INDICES=1 (debugging aid: the reference's nn.Embedding / scatter raise
+# at the call, a device-side assert in their CUDA form at the next synchronisation).
+_ERR_WORDS: dict = {}
+_ERR_BITS = {1: "edge_index entry outside [0, num_nodes)", 2: "node feature index outside its embedding's vocabulary",
+             4: "edge feature index outside its embedding's vocabulary", 8: "segment id (batch vector) outside [0, num_graphs)"}
+CHECK_EAGERLY = os.environ.get("PHC_CHECK_INDICES", "0") == "1"
+
+
+def _register_error_word(dev: torch.device) -> None:
+    word = torch.zeros(1, dtype=torch.int32, device=dev)
+    check(load().phc_set_error_word(dev.index if dev.index is not None else torch.cuda.current_device(), word.data_ptr()),
+          "phc_set_error_word")
+    _ERR_WORDS[dev] = word
+
+
+def check_indices(device: Optional[torch.device] = None) -> None:
+    """Raise IndexError if any kernel since the last call met an out-of-range index (synchronises the device)."""
+    for dev, word in list(_ERR_WORDS.items()):
+        if device is not None and torch.device(device) != dev:
+            continue
+        bits = int(word.item())
+        if bits:
+            word.zero_()
+            what = "; ".join(msg for bit, msg in _ERR_BITS.items() if bits & bit)
+            raise IndexError(f"phc_gnn_amd ({dev}): index out of range in self: {what} (the offending entries were read as 0)")
+
+
+def maybe_check_indices(dev: torch.device) -> None:
+    if CHECK_EAGERLY:
+        check_indices(dev)
 
 
 def ptr(t: Optional[torch.Tensor]) -> Optional[int]:

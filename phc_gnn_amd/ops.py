@@ -1235,8 +1235,9 @@ class _EncodeFn(torch.autograd.Function):
         if idx_.shape[1] != ts.F:
             raise L.PhcError(f"index tensor has {idx_.shape[1]} features, encoder has {ts.F}")
         out = torch.empty((N, ts.n * ts.k), dtype=torch.float32, device=dev)
-        L.check(lib.phc_encode_fwd(L.ptr(idx_), L.ptr(ts.ptrs), N, ts.F, ts.n, ts.k, L.ptr(out), L.stream_ptr(dev)),
+        L.check(lib.phc_encode_fwd(L.ptr(idx_), L.ptr(ts.ptrs), ts.vocab_c, N, ts.F, ts.n, ts.k, L.ptr(out), L.stream_ptr(dev)),
                 "phc_encode_fwd")
+        L.maybe_check_indices(dev)
         if L.PROF_ON:
             L.account("encode_fwd", 0.0, N * (8.0 * ts.F + 4.0 * ts.n * ts.k) + 4.0 * ts.R * ts.n * ts.k)
         ctx.ts = ts

@@ -91,7 +91,7 @@ def run(tag, N, E, h=128, n=4, mol=False):
     xa = torch.stack([torch.randint(0, v, (N,), device=dev) for v in vocab_a], 1)
     xb = torch.stack([torch.randint(0, v, (E,), device=dev) for v in vocab_b], 1)
     tsa, tsb = ops.TableSet(ta), ops.TableSet(tb)
-    report("encode_fwd (atoms)", timeit(lambda: l.phc_encode_fwd(xa.data_ptr(), tsa.ptrs.data_ptr(), N, 9, n, k, out.data_ptr(), sp)), 0, N * (72.0 + 4 * h))
+    report("encode_fwd (atoms)", timeit(lambda: l.phc_encode_fwd(xa.data_ptr(), tsa.ptrs.data_ptr(), tsa.vocab_c, N, 9, n, k, out.data_ptr(), sp)), 0, N * (72.0 + 4 * h))
     fl = torch.empty(n * tsa.R * k, device=dev)
     wsb2 = l.phc_encode_bwd_ws_bytes(N, 9, tsa.vocab_c, n, k); ws2 = torch.empty(wsb2, dtype=torch.uint8, device=dev)
     report("encode_bwd (atoms)", timeit(lambda: l.phc_encode_bwd(dy.data_ptr(), xa.data_ptr(), N, 9, tsa.vocab_c, n, k, fl.data_ptr(), ws2.data_ptr(), wsb2, sp)), 0, N * (72.0 + 4 * h))

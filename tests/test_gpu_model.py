@@ -106,6 +106,16 @@ def test_g7_pooling_and_downstream():
     params = dict(dn.named_parameters())
     grads = torch.autograd.grad(yd, [xin] + [params[k] for k in names], z["dn::dy"].to(DEV))
     assert_close(grads[0], z["dn::dx"], 5e-5)
+    checked = 0
+    for k, g in zip(names, grads[1:]):
+        ref = z["dn::grad::" + k]
+        if float(ref.abs().max()) < 1e-5:
+            # bias in front of a batch-norm: exactly zero in exact arithmetic, round-off in the reference
+            assert float(g.abs().max()) < 1e-4, k
+            continue
+        assert_close(g, ref, 5e-5, "downstream grad " + k)          # 9 rows through two batch-norms: same bound as dx
+        checked += 1
+    assert checked >= 10, checked
 
 
 MODELS = {
