@@ -128,6 +128,146 @@ def cpu_baseline(args, workload, model, gb):
                       f"same step contents, {dt:.1f} s, oracle/phc_oracle.py on torch CPU"}
 
 
+LARGE_GRAPHS = {
+    # BASELINE configs[4]: one graph, node-range sharded over the ranks (strong scaling: the graph is fixed)
+    "synth_10m50m": dict(nodes=10_000_000, edges=50_000_000, phm_dim=4, hidden=128),
+    "synth_1m5m": dict(nodes=1_000_000, edges=5_000_000, phm_dim=4, hidden=128),        # quick look / CI-sized
+}
+
+
+def bench_large_graph(args, world, rank, dev):
+    """BASELINE configs[4] (SURVEY.md §8d "cfg 5"): ONE PHMGINEConv layer (aggregate -> + x -> linear1 -> batch-norm ->
+    relu -> linear2, layer-API form: float edge_attr [E, h]) forward + backward on a synthetic graph with iid-uniform
+    edges, destination-range sharded over the ranks (phc_gnn_amd/dist.py: halo all-to-all on its own stream, global
+    batch statistics, parameter gradients summed with one flat all-reduce).  A step = fwd + bwd (+ that all-reduce)."""
+    import torch.distributed as dist
+    from phc.hypercomplex.undirectional.messagepassing import PHMGINEConv
+    from phc_gnn_amd import lib
+    from phc_gnn_amd.dist import FlatGradSync, ShardedAggregate, ShardedPHMGINEConv, build_halo_plan
+    g = LARGE_GRAPHS[args.workload]
+    N, E, n, h = g["nodes"], g["edges"], g["phm_dim"], g["hidden"]
+    if not dist.is_initialized():                      # one rank: a group of one (the exchange code path stays the same)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29541")
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev)
+    gen = torch.Generator(device=dev).manual_seed(0)   # same edge list on every rank (same generator, same device type)
+    ei = torch.randint(0, N, (2, E), generator=gen, device=dev, dtype=torch.int64)
+    t0 = time.perf_counter()
+    plan = build_halo_plan(ei, N)
+    del ei
+    agg = ShardedAggregate(plan)
+    torch.manual_seed(0)
+    conv = PHMGINEConv(h, h, phm_dim=n, phm_rule=None, norm="naive-batch-norm", activation="relu", msg_encoder="identity").to(dev).train()
+    layer = ShardedPHMGINEConv(conv, agg, N).train()
+    _ = agg.st_loc.csr, agg.st_loc.csc, agg.st_halo.csr, agg.st_halo.csc       # sorted views: once per graph
+    torch.cuda.synchronize()
+    t_plan = time.perf_counter() - t0
+    gen2 = torch.Generator(device=dev).manual_seed(1 + rank)
+    e_loc, e_halo = plan.loc_edge_index.shape[1], plan.halo_edge_index.shape[1]
+    x_own = torch.randn(plan.n_own, h, generator=gen2, device=dev).requires_grad_()
+    ea_loc = torch.randn(e_loc, h, generator=gen2, device=dev).requires_grad_()
+    ea_halo = torch.randn(e_halo, h, generator=gen2, device=dev).requires_grad_() if e_halo else None
+    dy = torch.randn(plan.n_own, h, generator=gen2, device=dev)
+    sync = FlatGradSync(list(conv.parameters()), average=False) if world > 1 else None
+
+    def step():
+        for p in conv.parameters():
+            p.grad = None
+        x_own.grad = ea_loc.grad = None
+        if ea_halo is not None:
+            ea_halo.grad = None
+        y = layer(x_own, ea_loc, ea_halo)
+        y.backward(dy)
+        if sync is not None:
+            sync()
+
+    prof_steps = max(1, min(args.profile_steps, 3))
+    for _ in range(2):
+        step()
+    torch.cuda.synchronize()
+    lib.prof_reset(); lib.prof_enable(True)
+    for _ in range(prof_steps):
+        step()
+    torch.cuda.synchronize()
+    lib.prof_enable(False)
+    times, work = lib.prof_read(), dict(lib.WORK)
+    # exchange alone (no compute queued next to it): what the overlap has to hide
+    ex_ms = None
+    if plan.n_halo > 0:
+        from phc_gnn_amd.dist import _exchange_rows, _finish
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        dist.barrier(); torch.cuda.synchronize()
+        ev0.record()
+        for _ in range(3):
+            recv, wk = _exchange_rows(agg.backend, agg.lane, x_own.detach(), plan.send_rows, plan.n_halo, plan.recv_splits,
+                                      plan.send_splits, plan.group)
+            _finish(agg.lane, wk)
+        ev1.record(); torch.cuda.synchronize()
+        ex_ms = ev0.elapsed_time(ev1) / 3
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    lib.check_indices(dev)
+
+    def rate(name, key, scale):
+        if name not in times or name not in work:
+            return None
+        return round(work[name][key] / (times[name]["total_ms"] * 1e-3) / scale, 2)
+    per_rank = {"own_nodes": plan.n_own, "local_edges": e_loc, "halo_edges": e_halo, "halo_rows": plan.n_halo,
+                "aggregate_fwd_GBs": rate("aggregate_fwd", "bytes", 1e9), "aggregate_bwd_GBs": rate("aggregate_bwd", "bytes", 1e9),
+                "gemm_fwd_TFs": rate("phm_gemm_fwd", "flops", 1e12), "gemm_dx_TFs": rate("phm_gemm_dx", "flops", 1e12),
+                "param_grad_gemm_TFs": rate("phm_dH_partial", "flops", 1e12), "bn_apply_GBs": rate("bn_apply", "bytes", 1e9),
+                "halo_all_to_all_ms_alone": None if ex_ms is None else round(ex_ms, 3),
+                "halo_bytes_received": plan.n_halo * h * 4, "plan_and_sort_s": round(t_plan, 2),
+                "engine_kernels_ms_per_step": {k: round(v["total_ms"] / prof_steps, 3) for k, v in sorted(times.items())}}
+    gathered = [None] * world
+    if world > 1:
+        dist.all_gather_object(gathered, per_rank)
+    else:
+        gathered = [per_rank]
+    if rank == 0:
+        name = max((k for k in times if k in work), key=lambda k: times[k]["total_ms"])
+        t_ms, n_launch = times[name]["total_ms"], times[name]["launches"]
+        if name in MFMA_KERNELS:
+            ach = work[name]["flops"] / (t_ms * 1e-3) / 1e12
+            roof = {"bound": "mfma", "achieved": round(ach, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(ach / PEAK_FP32_MFMA_TFLOPS, 4)}
+        else:
+            ach = work[name]["bytes"] / (t_ms * 1e-3) / 1e9
+            roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4)}
+        roof.update({"traffic": None, "kernel": name, "launches": n_launch, "avg_launch_us": round(1e3 * t_ms / max(n_launch, 1), 1)})
+        agg_b = sum(work[k]["bytes"] for k in ("aggregate_fwd", "aggregate_bwd") if k in work)
+        agg_t = sum(times[k]["total_ms"] for k in ("aggregate_fwd", "aggregate_bwd") if k in times)
+        result = {"metric": "edges/sec (fwd+bwd) of one PHMGINEConv PHM-4 layer on a synthetic 10M-node/50M-edge graph",
+                  "value": round(E * args.steps / dt, 1), "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                  "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+                  "dtype": "f32", "data": "synthetic",
+                  "config": {"workload": f"{args.workload}: {N} nodes, {E} iid-uniform directed edges, PHM-{n}, hidden {h}, one PHMGINEConv "
+                                         f"layer (float edge_attr [E,{h}], batch-norm, relu), destination-range sharded over {world} "
+                                         f"rank(s) (BASELINE configs[4])",
+                             "step": "fwd+bwd" + ("+flat param-grad all-reduce" if world > 1 else ""), "parallelism": f"shard{world}"},
+                  "roofline": roof,
+                  "aggregate_hbm": {"achieved_GBs": round(agg_b / (agg_t * 1e-3) / 1e9, 1) if agg_t else None, "peak": PEAK_HBM_GBS,
+                                    "frac": round(agg_b / (agg_t * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if agg_t else None},
+                  "per_rank": gathered}
+        print(json.dumps(result), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -145,6 +285,8 @@ def main():
 
     from phc_gnn_amd import harness, lib
     lib.load()
+    if args.workload in LARGE_GRAPHS:
+        return bench_large_graph(args, world, rank, dev)
     w = harness.WORKLOADS[args.workload]
     model = harness.build_model(args.workload, dev, seed=0)           # same init on every rank
     model.train()

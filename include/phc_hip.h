@@ -181,7 +181,9 @@ int phc_segment_ptr_sorted(const int64_t *key_i64, int64_t n, int64_t num_keys, 
  * square graph), ea[E, h] is in ORIGINAL edge order and may be NULL.
  * Replaces index_select + message + scatter(reduce='add') + the self-loop add
  * (messagepassing.py:57-60,72-74 / :133-138,144-146).  One wavefront per
- * destination row, coalesced 16-byte-per-lane row gathers, no atomics. */
+ * destination row, coalesced 16-byte-per-lane row gathers, no atomics.
+ * add_self is a bit set: 1 = + x[d, :] (the self loop), 2 = + the previous contents of out[d, :] (accumulate: the
+ * halo edges of a destination-range shard are added onto the local edges' sums when their rows have landed). */
 int phc_aggregate_fwd(const float *x, const float *ea, const int32_t *rowptr, const int32_t *col,
                       const int32_t *perm, int64_t n_dst, int h, int act, int add_self,
                       float *out, void *stream);
@@ -349,6 +351,28 @@ int phc_bn_fwd(const float *x, const float *const *weight, const float *const *b
 int phc_bn_bwd(const float *dy, const float *x, const float *save_stat, const int32_t *n_valid_dev, int64_t N, int h,
                int training, int act, float *dx, float *dwb_flat, int32_t *sync_words, void *ws, size_t ws_bytes,
                void *stream);
+
+/* Row-sharded batch-norm (one large graph split by destination-node range over the GPUs of a node;
+ * the reference's BatchNorm1d sees ALL rows, norm.py:30-35, so the shards exchange 2h floats per norm and direction
+ * to keep the single-GPU numbers).  Four phases with the host's two collectives between them:
+ *   forward : phc_bn_moments (this rank's rows -> moments[2h] = sum | M2 around the rank's own mean, Chan-merged in a
+ *             fixed order)  ->  all-gather of the pairs  ->  phc_bn_fwd_from_moments (every rank merges the same
+ *             num_ranks pairs in rank order: identical mean / variance / running statistics on all ranks; then
+ *             normalise + activation (+ residual) over the local rows).  counts_all [num_ranks] = rows per rank as
+ *             DEVICE floats, N_total their sum.
+ *   backward: phc_bn_bwd_sums (local dwb_local[2h] = sum g*x_hat | sum g, g = dy*act'(z); these ARE this rank's
+ *             partial dweight | dbias)  ->  all-reduce(sum) of a copy  ->  phc_bn_bwd_apply (dx over the local rows
+ *             with the global means).  ws: phc_bn_ws_bytes(N, h) for _moments / _sums, 2h floats for _apply. */
+int phc_bn_moments(const float *x, int64_t N, int h, float *moments, void *ws, size_t ws_bytes, void *stream);
+int phc_bn_fwd_from_moments(const float *x, int64_t N_local, const float *moments_all, const float *counts_all,
+                            int num_ranks, int64_t N_total, const float *const *weight, const float *const *bias,
+                            float *const *running_mean, float *const *running_var, int64_t *const *num_batches_tracked,
+                            int n_comp, int h, float momentum, float eps, int act, const float *residual, float *out,
+                            float *save_stat, void *stream);
+int phc_bn_bwd_sums(const float *dy, const float *x, const float *save_stat, int64_t N, int h, int act, float *dwb_local,
+                    void *ws, size_t ws_bytes, void *stream);
+int phc_bn_bwd_apply(const float *dy, const float *x, const float *save_stat, const float *dwb_global, int64_t N_total,
+                     int64_t N_local, int h, int act, float *dx, void *ws, size_t ws_bytes, void *stream);
 
 /* Batch-norm statistics out of the producing GEMM (training mode): phc_gemm_prebuilt_stats is
  * phc_gemm_prebuilt (no residual) whose workgroups also emit, per output column, the (sum, M2) of the

@@ -84,7 +84,8 @@ __global__ __launch_bounds__(AGG_THREADS) void aggregate_fwd_kernel(
             }
             float4 acc = fold_groups<LPR>(f4_add(acc0, acc1));
             if (grp == 0) {
-                if (add_self) acc = f4_add(acc, reinterpret_cast<const float4 *>(x + (size_t)d * h)[c4]);
+                if (add_self & 1) acc = f4_add(acc, reinterpret_cast<const float4 *>(x + (size_t)d * h)[c4]);
+                if (add_self & 2) acc = f4_add(acc, reinterpret_cast<const float4 *>(out + (size_t)d * h)[c4]);   // accumulate
                 reinterpret_cast<float4 *>(out + (size_t)d * h)[c4] = acc;
             }
         }
@@ -109,7 +110,8 @@ __global__ __launch_bounds__(AGG_THREADS) void aggregate_fwd_scalar_kernel(
                 if (ea) v += ea[(size_t)perm[e] * h + c];
                 acc += act_fwd<ACT>(v);
             }
-            if (add_self) acc += x[(size_t)d * h + c];
+            if (add_self & 1) acc += x[(size_t)d * h + c];
+            if (add_self & 2) acc += out[(size_t)d * h + c];
             out[(size_t)d * h + c] = acc;
         }
     }

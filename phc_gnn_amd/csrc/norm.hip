@@ -432,6 +432,65 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const float *_
     }
 }
 
+
+// ---- row-sharded batch-norm (one logical batch split by rows over several ranks) ----------
+// Merge this rank's per-block (sum, M2) pairs into ONE pair for all its rows (Chan's formula, fixed order): the 2h floats
+// that travel in the all-gather.  Same 8-columns x 32-partial-lanes layout as bn_finalize_kernel.
+__global__ __launch_bounds__(BN_THREADS) void bn_merge_moments_kernel(long long N, int h, const float *__restrict__ partial,
+                                                                    int num_partials, long long rows_per_block,
+                                                                    float *__restrict__ moments) {
+    __shared__ float r_sum[32][8], r_m2[32][8];
+    const int tid = threadIdx.x;
+    const int ci = tid & 7, pl = tid >> 3;
+    const int c = blockIdx.x * 8 + ci;
+    constexpr int PER_LANE = BN_MAX_PARTIALS / 32;
+    float ps[PER_LANE], pm[PER_LANE];
+#pragma unroll
+    for (int t = 0; t < PER_LANE; ++t) {
+        const int bb = pl + 32 * t;
+        const bool ok = c < h && bb < num_partials;
+        const size_t off = (size_t)(ok ? bb : 0) * 2 * h + (c < h ? c : 0);
+        const float a = partial[off], m2v = partial[off + h];
+        ps[t] = ok ? a : 0.f;
+        pm[t] = ok ? m2v : 0.f;
+    }
+    float sloc = 0.f;
+#pragma unroll
+    for (int t = 0; t < PER_LANE; ++t) sloc += ps[t];
+    r_sum[pl][ci] = sloc;
+    __syncthreads();
+    float tot = 0.f;
+    for (int l = 0; l < 32; ++l) tot += r_sum[l][ci];
+    const float mean = tot / (float)max(N, 1LL);
+    float m2 = 0.f;
+#pragma unroll
+    for (int t = 0; t < PER_LANE; ++t) {
+        const int bb = pl + 32 * t;
+        const float nbf = (float)min(rows_per_block, max(N - (long long)bb * rows_per_block, 0LL));
+        if (c < h && bb < num_partials && nbf > 0.f) {
+            const float d = ps[t] / nbf - mean;
+            m2 += pm[t] + nbf * d * d;
+        }
+    }
+    r_m2[pl][ci] = m2;
+    __syncthreads();
+    if (pl == 0 && c < h) {
+        float M2 = 0.f;
+        for (int l = 0; l < 32; ++l) M2 += r_m2[l][ci];
+        moments[c] = tot;
+        moments[h + c] = M2;
+    }
+}
+
+// bstat = [sum g | sum g*x_hat] / N_total from the all-reduced dwb = [sum g*x_hat | sum g]
+__global__ void bn_bstat_from_dwb_kernel(const float *__restrict__ dwb, int h, float inv_count, float *__restrict__ bstat) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < h) {
+        bstat[c] = dwb[h + c] * inv_count;
+        bstat[h + c] = dwb[c] * inv_count;
+    }
+}
+
 // ---- host ---------------------------------------------------------------------------------------------
 struct BnPlan {
     int num_partials;
@@ -1014,6 +1073,134 @@ int phc_bn_bwd_from_partials(const float *dy, const float *x, const float *save_
                (long long)N, h, bstat, dx)
     PHC_BN_ACT_SWITCH(act, PHC_BN_BAP)
 #undef PHC_BN_BAP
+    return check_launch("bn_bwd_apply");
+}
+
+// ---- row-sharded batch-norm: the four phases between which the host places its two collectives -------------------
+int phc_bn_moments(const float *x, int64_t N, int h, float *moments, void *ws, size_t ws_bytes, void *stream) {
+    PHC_REQUIRE(N >= 0 && h >= 1 && h <= 8192, PHC_ERR_INVALID_ARG, "phc_bn_moments: N=%lld h=%d", (long long)N, h);
+    PHC_REQUIRE(moments, PHC_ERR_INVALID_ARG, "phc_bn_moments: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (N == 0) {
+        hipMemsetAsync(moments, 0, sizeof(float) * 2 * (size_t)h, s);
+        return PHC_OK;
+    }
+    PHC_REQUIRE(x, PHC_ERR_INVALID_ARG, "phc_bn_moments: null pointer");
+    PHC_REQUIRE(ws && ws_bytes >= phc_bn_ws_bytes(N, h), PHC_ERR_WORKSPACE, "phc_bn_moments: workspace too small");
+    const bool vec4 = (h % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+    PHC_REQUIRE(vec4 || h % 4 != 0, PHC_ERR_UNSUPPORTED, "phc_bn_moments: rows must be 16-byte aligned when h %% 4 == 0");
+    BnPlan plan = bn_plan(N);
+    float *partial = static_cast<float *>(ws);
+    {
+        ProfScope prof(K_BN_STATS, s);
+        if (vec4)
+            PHC_LAUNCH((bn_stats_partial_kernel<4>), dim3(plan.num_partials), dim3(BN_THREADS), 0, s, x, (const int *)nullptr,
+                       (long long)N, h, plan.rows_per_block, partial);
+        else
+            PHC_LAUNCH((bn_stats_partial_kernel<1>), dim3(plan.num_partials), dim3(BN_THREADS), 0, s, x, (const int *)nullptr,
+                       (long long)N, h, plan.rows_per_block, partial);
+    }
+    ProfScope prof(K_BN_FINALIZE, s);
+    PHC_LAUNCH(bn_merge_moments_kernel, dim3((h + 7) / 8), dim3(BN_THREADS), 0, s, (long long)N, h, partial, plan.num_partials,
+               plan.rows_per_block, moments);
+    return check_launch("bn_moments");
+}
+
+int phc_bn_fwd_from_moments(const float *x, int64_t N_local, const float *moments_all, const float *counts_all, int num_ranks,
+                            int64_t N_total, const float *const *weight, const float *const *bias, float *const *running_mean,
+                            float *const *running_var, int64_t *const *num_batches_tracked, int n_comp, int h, float momentum,
+                            float eps, int act, const float *residual, float *out, float *save_stat, void *stream) {
+    BnParams p;
+    int rc = fill_params("phc_bn_fwd_from_moments", &p, weight, bias, running_mean, running_var, num_batches_tracked, n_comp, h);
+    if (rc) return rc;
+    PHC_REQUIRE(N_local >= 0 && N_total >= 1 && N_local <= N_total && num_ranks >= 1 && num_ranks <= BN_MAX_PARTIALS && h <= 8192,
+                PHC_ERR_INVALID_ARG, "phc_bn_fwd_from_moments: N_local=%lld N_total=%lld ranks=%d h=%d", (long long)N_local,
+                (long long)N_total, num_ranks, h);
+    PHC_REQUIRE(act >= PHC_ACT_IDENTITY && act <= PHC_ACT_SELU, PHC_ERR_INVALID_ARG, "phc_bn_fwd_from_moments: unknown activation %d", act);
+    PHC_REQUIRE(save_stat && moments_all && counts_all && (N_local == 0 || (x && out)), PHC_ERR_INVALID_ARG,
+                "phc_bn_fwd_from_moments: null pointer");
+    const bool vec4 = (h % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0) &&
+                      (!residual || (reinterpret_cast<uintptr_t>(residual) & 15) == 0);
+    PHC_REQUIRE(vec4 || h % 4 != 0, PHC_ERR_UNSUPPORTED, "phc_bn_fwd_from_moments: rows must be 16-byte aligned when h %% 4 == 0");
+    hipStream_t s = (hipStream_t)stream;
+    {
+        // every rank merges the same num_ranks pairs in the same order: identical statistics (and running-stat updates) everywhere
+        ProfScope prof(K_BN_FINALIZE, s);
+        PHC_LAUNCH(bn_finalize_kernel, dim3((h + 7) / 8), dim3(BN_THREADS), 0, s, p, (const int *)nullptr, (long long)N_total, h, 1,
+                   momentum, eps, moments_all, num_ranks, 0LL, save_stat, counts_all);
+        rc = check_launch("bn_finalize(from moments)");
+        if (rc) return rc;
+    }
+    if (N_local == 0) return PHC_OK;
+    const size_t lds = sizeof(float) * 2 * (size_t)h;
+    ProfScope prof(K_BN_APPLY, s);
+#define PHC_BN_FWDM(ACTC)                                                                                                      \
+    PHC_LAUNCH((bn_apply_kernel<ACTC>), dim3(apply_grid(N_local, h)), dim3(BN_THREADS), lds, s, x, (const int *)nullptr,        \
+               (long long)N_local, h, residual, save_stat, out)
+    PHC_BN_ACT_SWITCH(act, PHC_BN_FWDM)
+#undef PHC_BN_FWDM
+    return check_launch("bn_apply");
+}
+
+int phc_bn_bwd_sums(const float *dy, const float *x, const float *save_stat, int64_t N, int h, int act, float *dwb_local, void *ws,
+                    size_t ws_bytes, void *stream) {
+    PHC_REQUIRE(N >= 0 && h >= 1 && h <= 8192, PHC_ERR_INVALID_ARG, "phc_bn_bwd_sums: N=%lld h=%d", (long long)N, h);
+    PHC_REQUIRE(act >= PHC_ACT_IDENTITY && act <= PHC_ACT_SELU, PHC_ERR_INVALID_ARG, "phc_bn_bwd_sums: unknown activation %d", act);
+    PHC_REQUIRE(dwb_local && save_stat, PHC_ERR_INVALID_ARG, "phc_bn_bwd_sums: null pointer");
+    hipStream_t s = (hipStream_t)stream;
+    if (N == 0) {
+        hipMemsetAsync(dwb_local, 0, sizeof(float) * 2 * (size_t)h, s);
+        return PHC_OK;
+    }
+    PHC_REQUIRE(dy && x, PHC_ERR_INVALID_ARG, "phc_bn_bwd_sums: null pointer");
+    PHC_REQUIRE(ws && ws_bytes >= phc_bn_ws_bytes(N, h), PHC_ERR_WORKSPACE, "phc_bn_bwd_sums: workspace too small");
+    const bool vec4 = (h % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((reinterpret_cast<uintptr_t>(dy) & 15) == 0);
+    PHC_REQUIRE(vec4 || h % 4 != 0, PHC_ERR_UNSUPPORTED, "phc_bn_bwd_sums: rows must be 16-byte aligned when h %% 4 == 0");
+    BnPlan plan = bn_plan(N);
+    float *partial = static_cast<float *>(ws);
+    float *bstat = partial + 2 * (size_t)h * BN_MAX_PARTIALS;
+    {
+        ProfScope prof(K_BN_BWD_PARTIAL, s);
+#define PHC_BN_BPS(ACTC)                                                                                                     \
+    if (vec4)                                                                                                                \
+        PHC_LAUNCH((bn_bwd_partial_kernel<ACTC, 4>), dim3(plan.num_partials), dim3(BN_THREADS), 0, s, dy, x, save_stat,     \
+                   (const int *)nullptr, (long long)N, h, plan.rows_per_block, partial);                                     \
+    else                                                                                                                     \
+        PHC_LAUNCH((bn_bwd_partial_kernel<ACTC, 1>), dim3(plan.num_partials), dim3(BN_THREADS), 0, s, dy, x, save_stat,     \
+                   (const int *)nullptr, (long long)N, h, plan.rows_per_block, partial)
+        PHC_BN_ACT_SWITCH(act, PHC_BN_BPS)
+#undef PHC_BN_BPS
+    }
+    ProfScope prof(K_BN_BWD_FINALIZE, s);
+    PHC_LAUNCH(bn_bwd_finalize_kernel, dim3((h + 7) / 8), dim3(BN_THREADS), 0, s, (const int *)nullptr, (long long)N, h, 1, partial,
+               plan.num_partials, dwb_local, bstat);
+    return check_launch("bn_bwd_sums");
+}
+
+int phc_bn_bwd_apply(const float *dy, const float *x, const float *save_stat, const float *dwb_global, int64_t N_total, int64_t N_local,
+                     int h, int act, float *dx, void *ws, size_t ws_bytes, void *stream) {
+    PHC_REQUIRE(N_local >= 0 && N_total >= 1 && h >= 1 && h <= 8192, PHC_ERR_INVALID_ARG, "phc_bn_bwd_apply: N_local=%lld N_total=%lld h=%d",
+                (long long)N_local, (long long)N_total, h);
+    PHC_REQUIRE(act >= PHC_ACT_IDENTITY && act <= PHC_ACT_SELU, PHC_ERR_INVALID_ARG, "phc_bn_bwd_apply: unknown activation %d", act);
+    if (N_local == 0) return PHC_OK;
+    PHC_REQUIRE(dy && x && save_stat && dwb_global && dx, PHC_ERR_INVALID_ARG, "phc_bn_bwd_apply: null pointer");
+    PHC_REQUIRE(ws && ws_bytes >= sizeof(float) * 2 * (size_t)h, PHC_ERR_WORKSPACE, "phc_bn_bwd_apply: workspace too small");
+    const bool vec4 = (h % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((reinterpret_cast<uintptr_t>(dy) & 15) == 0) &&
+                      ((reinterpret_cast<uintptr_t>(dx) & 15) == 0);
+    PHC_REQUIRE(vec4 || h % 4 != 0, PHC_ERR_UNSUPPORTED, "phc_bn_bwd_apply: rows must be 16-byte aligned when h %% 4 == 0");
+    hipStream_t s = (hipStream_t)stream;
+    float *bstat = static_cast<float *>(ws);
+    {
+        ProfScope prof(K_BN_BWD_FINALIZE, s);
+        PHC_LAUNCH(bn_bstat_from_dwb_kernel, dim3((h + 255) / 256), dim3(256), 0, s, dwb_global, h, 1.f / (float)N_total, bstat);
+    }
+    const size_t lds = sizeof(float) * 6 * (size_t)h;
+    ProfScope prof(K_BN_BWD_APPLY, s);
+#define PHC_BN_BAS(ACTC)                                                                                                     \
+    PHC_LAUNCH((bn_bwd_apply_kernel<ACTC>), dim3(apply_grid(N_local, h)), dim3(BN_THREADS), lds, s, dy, x, save_stat,       \
+               (const int *)nullptr, (long long)N_local, h, bstat, dx)
+    PHC_BN_ACT_SWITCH(act, PHC_BN_BAS)
+#undef PHC_BN_BAS
     return check_launch("bn_bwd_apply");
 }
 

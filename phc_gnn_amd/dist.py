@@ -35,10 +35,13 @@ import torch.distributed as dist
 class FlatGradSync:
     """All-reduce (mean) of every parameter gradient through ONE contiguous fp32 bucket."""
 
-    def __init__(self, params: Sequence[torch.nn.Parameter], group=None):
+    def __init__(self, params: Sequence[torch.nn.Parameter], group=None, average: bool = True):
+        """``average=True``: data-parallel replicas (mean of the per-replica gradients); ``average=False``: shards of
+        ONE batch (config 5: every rank holds the partial sums over its own rows; the gradient is their plain sum)."""
         self.params = [p for p in params if p.requires_grad]
         self.group = group
         self.world = dist.get_world_size(group)
+        self.average = bool(average)
         self.sizes = [p.numel() for p in self.params]
         self.flat: Optional[torch.Tensor] = None
 
@@ -59,7 +62,8 @@ class FlatGradSync:
                 if p.grad is None:
                     p.grad = torch.empty_like(p)
             torch._foreach_copy_([p.grad for p in self.params], [c.view_as(p) for p, c in zip(self.params, chunks)])
-            torch._foreach_div_([p.grad for p in self.params], float(self.world))
+            if self.average:
+                torch._foreach_div_([p.grad for p in self.params], float(self.world))
 
     def __call__(self, _model=None) -> None:
         self.pack()
@@ -125,6 +129,7 @@ def build_halo_plan(edge_index: torch.Tensor, num_nodes: int, group=None) -> Hal
     if req.numel() and (int(req.min()) < lo or int(req.max()) >= hi):
         raise RuntimeError("halo plan: received a request for a row this rank does not own")
 
+    # (host reads above: once per graph; the plan is reused by every layer and every step)
     loc_ei = torch.stack([s[loc_pos] - lo, d[loc_pos]], 0)
     halo_src = torch.searchsorted(halo_ids, s[halo_pos])
     halo_ei = torch.stack([halo_src, d[halo_pos]], 0)
@@ -132,6 +137,37 @@ def build_halo_plan(edge_index: torch.Tensor, num_nodes: int, group=None) -> Hal
                     halo_ids=halo_ids, recv_splits=need_l, send_rows=(req - lo).contiguous(), send_splits=asked_l,
                     loc_edge_index=loc_ei.contiguous(), loc_edge_ids=mine[loc_pos], halo_edge_index=halo_ei.contiguous(),
                     halo_edge_ids=mine[halo_pos], group=group)
+
+
+class _CommLane:
+    """The exchange's own HIP stream.  ``fork()`` makes it wait for everything queued on the compute stream so far and
+    returns a context in which staging kernels and the collective are issued; ``join()`` makes the compute stream wait
+    for the lane.  Work issued on the compute stream between the two overlaps the exchange.  On CPU (gloo tests) both
+    are no-ops and the collective's own async handle provides the overlap."""
+
+    def __init__(self, device: torch.device):
+        self.device = device
+        self.stream = torch.cuda.Stream(device=device) if device.type == "cuda" else None
+
+    def fork(self):
+        import contextlib
+        if self.stream is None:
+            return contextlib.nullcontext()
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))
+        return torch.cuda.stream(self.stream)
+
+    def join(self) -> None:
+        if self.stream is not None:
+            torch.cuda.current_stream(self.device).wait_stream(self.stream)
+
+    def keep(self, *tensors) -> None:
+        """Tensors allocated on the compute stream but consumed on the lane (or vice versa): tell the caching allocator."""
+        if self.stream is not None:
+            cur = torch.cuda.current_stream(self.device)
+            for t in tensors:
+                if t is not None and t.is_cuda:
+                    t.record_stream(self.stream)
+                    t.record_stream(cur)
 
 
 class EngineBackend:
@@ -145,34 +181,95 @@ class EngineBackend:
     def structure(self, edge_index, num_src, num_dst):
         return self._ES(edge_index, num_src, num_dst)
 
-    def aggregate_fwd(self, x, ea, st, act, add_self):
-        return self._ops.aggregate_fwd_raw(x, ea, st, act, add_self)
+    def segments(self, index, num_rows):
+        return self._SS(index, num_rows)
+
+    def aggregate_fwd(self, x, ea, st, act, add_self, accumulate_into=None):
+        return self._ops.aggregate_fwd_raw(x, ea, st, act, add_self, accumulate_into)
 
     def aggregate_bwd(self, dout, x, ea, st, act, add_self, need_dea):
         return self._ops.aggregate_bwd_raw(dout, x, ea, st, act, add_self, need_dea)
 
     def gather_rows(self, x, rows):
-        return x.index_select(0, rows)
+        return self._ops.gather_rows(x, rows)                   # phc_gather_rows_i64
 
-    def segment_sum(self, rows_values, rows_index, num_rows):
-        """out[r] = sum of rows_values[j] with rows_index[j] == r, fixed order."""
-        return self._ops.global_add_pool(rows_values, self._SS(rows_index, num_rows))
+    def segment_sum_into(self, rows_values, seg, into):
+        """into[r] += sum of rows_values[j] with index[j] == r, fixed order, accumulated inside the kernel."""
+        return self._ops.aggregate_fwd_raw(rows_values, None, seg_as_edges(seg), 0, False, accumulate_into=into)
+
+    # ---- PHM linear pieces (explicit forward / dx / parameter-gradient launches) ----
+    def linear_fwd(self, x, A, W, b):
+        with torch.no_grad():
+            return self._ops.phm_linear(x, A, W, b)
+
+    def linear_dx(self, dy, A, W):
+        return self._ops.phm_linear_dx_raw(dy, A, W)
+
+    def linear_param_grads(self, x, dy, A, W, has_bias):
+        return self._ops.phm_linear_param_grads_raw(x, dy, A, W, has_bias)
+
+    # ---- row-sharded batch-norm phases ----
+    def bn_moments(self, x):
+        return self._ops.bn_moments(x)
+
+    def bn_fwd_from_moments(self, x, moments_all, counts_all, n_total, norm, act):
+        mods = list(norm.bn)
+        return self._ops.bn_fwd_from_moments(
+            x, moments_all, counts_all, n_total, [m.weight for m in mods] if norm.affine else None,
+            [m.bias for m in mods] if norm.affine else None, [m.running_mean for m in mods], [m.running_var for m in mods],
+            [m.num_batches_tracked for m in mods], norm.momentum if norm.momentum is not None else 0.1, norm.eps,
+            self._ops._act_id(act))
+
+    def bn_bwd_sums(self, dy, x, save_stat, act):
+        return self._ops.bn_bwd_sums(dy, x, save_stat, self._ops._act_id(act))
+
+    def bn_bwd_apply(self, dy, x, save_stat, dwb_global, n_total, act):
+        return self._ops.bn_bwd_apply(dy, x, save_stat, dwb_global, n_total, self._ops._act_id(act))
+
+
+def seg_as_edges(seg):
+    """A SegmentStructure (rows grouped by an index) read as the CSR the aggregation kernel walks."""
+    class _View:
+        pass
+    v = _View()
+    v.csr = seg.csr
+    v.num_dst = seg.num_segments
+    v.num_edges = int(seg.batch.numel())
+    return v
+
+
+def _exchange_rows(be, lane: _CommLane, rows_src: torch.Tensor, gather_index: Optional[torch.Tensor], out_rows: int,
+                   out_splits, in_splits, group):
+    """Start one all-to-all(v) of feature rows on the comm lane: (optionally) gather the rows to send with the engine's
+    row-gather kernel, then the collective.  Returns (recv buffer, handle); ``_finish`` joins."""
+    h = rows_src.shape[1]
+    recv = torch.empty((out_rows, h), dtype=rows_src.dtype, device=rows_src.device)
+    with lane.fork():
+        send = be.gather_rows(rows_src, gather_index) if gather_index is not None else rows_src.contiguous()
+        work = dist.all_to_all_single(recv, send, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group,
+                                      async_op=True)
+        if lane.stream is not None:
+            work.wait()                                     # stream-ordered on the LANE only; the host does not block
+    lane.keep(recv, send, rows_src)
+    return recv, (work if lane.stream is None else None)
+
+
+def _finish(lane: _CommLane, work) -> None:
+    if work is not None:
+        work.wait()
+    lane.join()
 
 
 class _ShardedAggregateFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x_own, ea_loc, ea_halo, agg: "ShardedAggregate", act: str, add_self: bool):
-        plan, be = agg.plan, agg.backend
-        h = x_own.shape[1]
+        plan, be, lane = agg.plan, agg.backend, agg.lane
         x_own = x_own.contiguous()
-        send = be.gather_rows(x_own, plan.send_rows)                               # staging for the all-to-all
-        recv = torch.empty((plan.n_halo, h), dtype=x_own.dtype, device=x_own.device)
-        work = dist.all_to_all_single(recv, send, output_split_sizes=plan.recv_splits,
-                                      input_split_sizes=plan.send_splits, group=plan.group, async_op=True)
+        recv, work = _exchange_rows(be, lane, x_own, plan.send_rows, plan.n_halo, plan.recv_splits, plan.send_splits, plan.group)
         out = be.aggregate_fwd(x_own, ea_loc, agg.st_loc, act, add_self)            # overlaps the exchange
-        work.wait()
+        _finish(lane, work)
         if plan.halo_edge_index.shape[1] > 0:
-            out = out + be.aggregate_fwd(recv, ea_halo, agg.st_halo, act, False)
+            out = be.aggregate_fwd(recv, ea_halo, agg.st_halo, act, False, accumulate_into=out)   # summed inside the kernel
         ctx.agg, ctx.act, ctx.add_self = agg, act, add_self
         ctx.save_for_backward(x_own, recv, ea_loc if ea_loc is not None else x_own.new_empty(0),
                               ea_halo if ea_halo is not None else x_own.new_empty(0))
@@ -182,43 +279,188 @@ class _ShardedAggregateFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, dout):
         agg = ctx.agg
-        plan, be = agg.plan, agg.backend
         x_own, recv, ea_loc, ea_halo = ctx.saved_tensors
         ea_loc = ea_loc if ctx.has_ea[0] else None
         ea_halo = ea_halo if ctx.has_ea[1] else None
-        dout = dout.contiguous()
-        h = dout.shape[1]
         need_dea = (ctx.needs_input_grad[1] and ea_loc is not None, ctx.needs_input_grad[2] and ea_halo is not None)
-        # gradient of the halo rows first: it has to travel
-        if plan.n_halo > 0 and plan.halo_edge_index.shape[1] > 0:
-            d_halo, dea_halo = be.aggregate_bwd(dout, recv, ea_halo, agg.st_halo, ctx.act, False, need_dea[1])
-        else:
-            d_halo = dout.new_zeros((plan.n_halo, h))
-            dea_halo = dout.new_zeros((0, h)) if need_dea[1] else None
-        back = torch.empty((int(plan.send_rows.numel()), h), dtype=dout.dtype, device=dout.device)
-        work = dist.all_to_all_single(back, d_halo.contiguous(), output_split_sizes=plan.send_splits,
-                                      input_split_sizes=plan.recv_splits, group=plan.group, async_op=True)
-        d_own, dea_loc = be.aggregate_bwd(dout, x_own, ea_loc, agg.st_loc, ctx.act, ctx.add_self, need_dea[0])
-        work.wait()
-        if back.shape[0] > 0:
-            d_own = d_own + be.segment_sum(back, plan.send_rows, plan.n_own)       # fixed order: deterministic
+        d_own, dea_loc, dea_halo = agg.backward_raw(dout.contiguous(), x_own, recv, ea_loc, ea_halo, ctx.act, ctx.add_self, need_dea)
         return d_own, dea_loc, dea_halo, None, None, None
 
 
 class ShardedAggregate:
     """out[i] = sum_{j->i} phi(x[j] + e_ji) (+ x[i]) for the nodes this rank owns, with the remote x[j]
-    fetched by one all-to-all per call (reference op: messagepassing.py:57-60,72-74 on a single device)."""
+    fetched by one all-to-all per call (reference op: messagepassing.py:57-60,72-74 on a single device).
+
+    The exchange runs on its own HIP stream (``_CommLane``): send rows are staged there with the engine's row gather
+    (``phc_gather_rows_i64``), the local edges are aggregated meanwhile, and the halo edges are ADDED onto that result
+    inside the aggregation kernel when the rows have landed (``add_self`` bit 2 of ``phc_aggregate_fwd``).  Backward:
+    halo edges first, their gradient rows travel back while the local edges' backward (and whatever the caller queues
+    through ``overlap``) runs; returned rows are summed into the owners' rows in a fixed order inside the same kernel."""
 
     def __init__(self, plan: HaloPlan, backend=None):
         self.plan = plan
         self.backend = backend if backend is not None else EngineBackend()
+        self.lane = _CommLane(plan.loc_edge_index.device)
         self.st_loc = self.backend.structure(plan.loc_edge_index, plan.n_own, plan.n_own)
         self.st_halo = self.backend.structure(plan.halo_edge_index, max(plan.n_halo, 1), plan.n_own)
+        self.seg_back = self.backend.segments(plan.send_rows, plan.n_own) if plan.send_rows.numel() else None
 
     def split_edge_attr(self, edge_attr: torch.Tensor):
         """(rows of the local edges, rows of the halo edges) of a tensor aligned with the caller's edge list."""
         return edge_attr.index_select(0, self.plan.loc_edge_ids), edge_attr.index_select(0, self.plan.halo_edge_ids)
 
+    def forward_raw(self, x_own, ea_loc, ea_halo, act: str, add_self: bool):
+        """(out, recv) without autograd bookkeeping (the fused layer below keeps its own)."""
+        plan, be = self.plan, self.backend
+        recv, work = _exchange_rows(be, self.lane, x_own, plan.send_rows, plan.n_halo, plan.recv_splits, plan.send_splits, plan.group)
+        out = be.aggregate_fwd(x_own, ea_loc, self.st_loc, act, add_self)
+        _finish(self.lane, work)
+        if plan.halo_edge_index.shape[1] > 0:
+            out = be.aggregate_fwd(recv, ea_halo, self.st_halo, act, False, accumulate_into=out)
+        return out, recv
+
+    def backward_raw(self, dout, x_own, recv, ea_loc, ea_halo, act: str, add_self: bool, need_dea=(False, False), overlap=None):
+        """(d_own, dea_loc, dea_halo); ``overlap``: a callable queued on the compute stream while the gradient rows of
+        the halo sources travel back (the layer's parameter-gradient GEMMs)."""
+        plan, be = self.plan, self.backend
+        h = dout.shape[1]
+        if plan.n_halo > 0 and plan.halo_edge_index.shape[1] > 0:          # gradient of the halo rows first: it has to travel
+            d_halo, dea_halo = be.aggregate_bwd(dout, recv, ea_halo, self.st_halo, act, False, need_dea[1])
+        else:
+            d_halo = dout.new_zeros((plan.n_halo, h))
+            dea_halo = dout.new_zeros((0, h)) if need_dea[1] else None
+        back, work = _exchange_rows(be, self.lane, d_halo, None, int(plan.send_rows.numel()), plan.send_splits, plan.recv_splits,
+                                    plan.group)
+        d_own, dea_loc = be.aggregate_bwd(dout, x_own, ea_loc, self.st_loc, act, add_self, need_dea[0])
+        extra = overlap() if overlap is not None else None
+        _finish(self.lane, work)
+        if self.seg_back is not None:
+            d_own = be.segment_sum_into(back, self.seg_back, d_own)         # fixed order: deterministic
+        return (d_own, dea_loc, dea_halo) if overlap is None else (d_own, dea_loc, dea_halo, extra)
+
     def __call__(self, x_own: torch.Tensor, ea_loc: Optional[torch.Tensor], ea_halo: Optional[torch.Tensor],
                  msg_encoder: str = "identity", add_self_loops: bool = True) -> torch.Tensor:
         return _ShardedAggregateFn.apply(x_own, ea_loc, ea_halo, self, msg_encoder, add_self_loops)
+
+
+# ---------------------------------------------------------------------------------------------
+# 3. the sharded message-passing LAYER: aggregate -> + x -> linear1 -> norm (global statistics) -> act -> linear2
+# ---------------------------------------------------------------------------------------------
+class _ShardedGINEFn(torch.autograd.Function):
+    """PHMGINEConv.forward (messagepassing.py:132-146) + PHMMLP.forward (layers.py:349-355) on one destination-range
+    shard, forward and backward written out so that every exchange has compute queued next to it:
+
+      forward : halo rows travel            || aggregation over the local edges
+                moments all-gather (2h+0)      (tiny, between linear1 and the normalisation)
+      backward: sums all-reduce (2h)           (tiny, between the two dx GEMMs)
+                halo gradient rows travel   || local edges' backward + BOTH parameter-gradient GEMMs (dH1, dH2)
+
+    Parameter gradients come out as this rank's partial sums over its own rows (``FlatGradSync(average=False)`` adds
+    them up); batch statistics, running statistics and dx are those of the unsharded layer."""
+
+    @staticmethod
+    def forward(ctx, layer: "ShardedPHMGINEConv", x_own, ea_loc, ea_halo, A1, W1, b1, A2, W2, b2, *affine):
+        agg, be, plan = layer.agg, layer.agg.backend, layer.agg.plan
+        mlp = layer.conv.transform
+        act_msg, act = layer.msg_encoder, mlp.activation_str
+        x_own = x_own.contiguous()
+        s, recv = agg.forward_raw(x_own, ea_loc, ea_halo, act_msg, layer.conv.add_self_loops)
+        z = be.linear_fwd(s, A1, W1, b1)
+        if mlp.norm_flag:
+            norm = mlp.norm.bn
+            mom = be.bn_moments(z)
+            mom_flat = torch.empty(plan.world * mom.numel(), dtype=mom.dtype, device=mom.device)
+            dist.all_gather_into_tensor(mom_flat, mom, group=plan.group)      # 2h floats per rank
+            mom_all = mom_flat.view(plan.world, mom.numel())
+            a, save_stat = be.bn_fwd_from_moments(z, mom_all, layer.counts_all, layer.n_total, norm, act)
+        else:
+            save_stat = z.new_empty(0)
+            a = layer.act_fn(z)
+        y = be.linear_fwd(a, A2, W2, b2)
+        ctx.layer = layer
+        ctx.has_ea = (ea_loc is not None, ea_halo is not None)
+        ctx.has_bias = (b1 is not None, b2 is not None)
+        ctx.n_affine = len(affine)
+        e0 = x_own.new_empty(0)
+        ctx.save_for_backward(x_own, recv, ea_loc if ea_loc is not None else e0, ea_halo if ea_halo is not None else e0,
+                              s, z, a, save_stat, A1, W1, A2, W2)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        layer = ctx.layer
+        agg, be, plan = layer.agg, layer.agg.backend, layer.agg.plan
+        mlp = layer.conv.transform
+        act_msg, act = layer.msg_encoder, mlp.activation_str
+        x_own, recv, ea_loc, ea_halo, s, z, a, save_stat, A1, W1, A2, W2 = ctx.saved_tensors
+        ea_loc = ea_loc if ctx.has_ea[0] else None
+        ea_halo = ea_halo if ctx.has_ea[1] else None
+        dy = dy.contiguous()
+        da = be.linear_dx(dy, A2, W2)
+        if mlp.norm_flag:
+            dwb = be.bn_bwd_sums(da, z, save_stat, act)                       # this rank's partial dweight | dbias
+            dwb_all = dwb.clone()
+            dist.all_reduce(dwb_all, op=dist.ReduceOp.SUM, group=plan.group)
+            dz = be.bn_bwd_apply(da, z, save_stat, dwb_all, layer.n_total, act)
+        else:
+            dwb = None
+            dz = layer.act_bwd(z, da)
+        ds = be.linear_dx(dz, A1, W1)
+        need_dea = (ctx.needs_input_grad[2] and ea_loc is not None, ctx.needs_input_grad[3] and ea_halo is not None)
+
+        def param_grads():                                                    # queued while the halo gradients travel
+            g2 = be.linear_param_grads(a, dy, A2, W2, ctx.has_bias[1])
+            g1 = be.linear_param_grads(s, dz, A1, W1, ctx.has_bias[0])
+            return g1, g2
+
+        d_own, dea_loc, dea_halo, (g1, g2) = agg.backward_raw(ds, x_own, recv, ea_loc, ea_halo, act_msg,
+                                                              layer.conv.add_self_loops, need_dea, overlap=param_grads)
+        aff = []
+        if ctx.n_affine:
+            n = ctx.n_affine // 2
+            k = z.shape[1] // n
+            aff = [dwb[c * k:(c + 1) * k] for c in range(n)] + [dwb[n * k + c * k:n * k + (c + 1) * k] for c in range(n)]
+        return (None, d_own if ctx.needs_input_grad[1] else None, dea_loc, dea_halo, g1[0], g1[1], g1[2], g2[0], g2[1], g2[2], *aff)
+
+
+class ShardedPHMGINEConv(torch.nn.Module):
+    """One ``PHMGINEConv`` (phc/hypercomplex/undirectional/messagepassing.py:91-161) evaluated on a destination-range
+    shard of one large graph (BASELINE config 5).  Wraps an ordinary conv module — same parameters, same state_dict —
+    and a ``ShardedAggregate`` built from the graph's ``HaloPlan``; every rank holds a replica of the parameters.
+
+        y_own = layer(x_own, ea_loc, ea_halo)        # rows [plan.lo, plan.hi) of the unsharded layer's output
+    """
+
+    def __init__(self, conv, agg: ShardedAggregate, num_nodes: int):
+        super().__init__()
+        from phc.quaternion.activations import get_module_activation
+        self.conv = conv
+        self.agg = agg
+        plan = agg.plan
+        self.msg_encoder = getattr(conv, "msg_encoder_str", "identity")
+        self.n_total = int(num_nodes)
+        bounds = partition_bounds(self.n_total, plan.world)
+        dev = plan.loc_edge_index.device
+        self.counts_all = torch.tensor([float(bounds[r + 1] - bounds[r]) for r in range(plan.world)], dtype=torch.float32, device=dev)
+        self.act_fn = get_module_activation(conv.transform.activation_str)
+
+    def act_bwd(self, z, da):
+        with torch.enable_grad():
+            zr = z.detach().requires_grad_()
+            out = self.act_fn(zr)
+        return torch.autograd.grad(out, zr, da)[0]
+
+    def forward(self, x_own: torch.Tensor, ea_loc: Optional[torch.Tensor], ea_halo: Optional[torch.Tensor]) -> torch.Tensor:
+        mlp = self.conv.transform
+        if not self.training:
+            raise NotImplementedError("ShardedPHMGINEConv: training-mode statistics only (eval uses the running statistics of "
+                                      "the wrapped conv on any single rank)")
+        affine = []
+        if mlp.norm_flag:
+            nb = mlp.norm.bn
+            if not hasattr(nb, "bn") or not nb.track_running_stats:
+                raise NotImplementedError("ShardedPHMGINEConv needs the naive-batch-norm flavour with running statistics")
+            if nb.affine:
+                affine = [m.weight for m in nb.bn] + [m.bias for m in nb.bn]
+        l1, l2 = mlp.linear1, mlp.linear2
+        return _ShardedGINEFn.apply(self, x_own, ea_loc, ea_halo, l1.phm_rule, l1.W, l1.b, l2.phm_rule, l2.W, l2.b, *affine)

@@ -68,6 +68,10 @@ SIGNATURES = {
     "phc_bn_bwd_from_partials": (_I, [_P, _P, _P, _P, _I, _P, _L, _I, _I, _P, _P, _P, _S, _P]),
     "phc_phm_param_grads_ws_bytes": (_S, [C.POINTER(GradJob), _I]),
     "phc_phm_param_grads": (_I, [C.POINTER(GradJob), _I, _P, _S, _P]),
+    "phc_bn_moments": (_I, [_P, _L, _I, _P, _P, _S, _P]),
+    "phc_bn_fwd_from_moments": (_I, [_P, _L, _P, _P, _I, _L, _P, _P, _P, _P, _P, _I, _I, C.c_float, C.c_float, _I, _P, _P, _P, _P]),
+    "phc_bn_bwd_sums": (_I, [_P, _P, _P, _L, _I, _I, _P, _P, _S, _P]),
+    "phc_bn_bwd_apply": (_I, [_P, _P, _P, _P, _L, _L, _I, _I, _P, _P, _S, _P]),
     "phc_csr_ws_bytes": (_S, [_L, _L]),
     "phc_csr_build": (_I, [_P, _P, _L, _L, _L, _P, _P, _P, _P, _S, _P]),
     "phc_csr_pair_ws_bytes": (_S, [_L, _L, _L]),

@@ -554,6 +554,42 @@ class _PHMLinearFn(torch.autograd.Function):
                 dy.reshape(ctx.res_shape) if (need_res and ctx.has_res) else None, None)
 
 
+def phm_linear_dx_raw(dy: torch.Tensor, A: torch.Tensor, W: torch.Tensor) -> torch.Tensor:
+    """dx = dy . H^T (one launch, no autograd bookkeeping): the backward-data GEMM of a PHM linear layer."""
+    lib = L.load()
+    dev = L.require_device(dy, A, W)
+    n, kin, kout = W.shape
+    dy2, A_, W_ = L.f32c(dy), L.f32c(A.detach()), L.f32c(W.detach())
+    N = dy2.shape[0]
+    dx = torch.empty((N, n * kin), dtype=torch.float32, device=dev)
+    if N:
+        # (x is only read for the parameter gradients; the entry point wants a non-null pointer)
+        L.check(lib.phc_phm_linear_bwd(L.ptr(dy2), L.ptr(A_), L.ptr(W_), L.ptr(dy2), N, n, kin, kout, L.ptr(dx), None, None, None,
+                                       None, 0, L.stream_ptr(dev)), "phc_phm_linear_bwd(dx)")
+        if L.PROF_ON:
+            L.account("phm_gemm_dx", 2.0 * N * n * kin * n * kout, 4.0 * (N * n * (kin + kout) + n * kin * kout + n ** 3))
+    return dx
+
+
+def phm_linear_param_grads_raw(x: torch.Tensor, dy: torch.Tensor, A: torch.Tensor, W: torch.Tensor, has_bias: bool):
+    """(dA, dW, db | None) of y = x.H(A, W) + b from x and dy alone (no dx): dH = x^T.dy as fixed-order split-K slabs,
+    then the two contractions with A and W."""
+    lib = L.load()
+    dev = L.require_device(x, dy, A, W)
+    n, kin, kout = W.shape
+    x2, dy2, A_, W_ = L.f32c(x), L.f32c(dy), L.f32c(A.detach()), L.f32c(W.detach())
+    N = x2.shape[0]
+    dW, dA = torch.empty_like(W_), torch.empty_like(A_)
+    db = torch.empty(n * kout, dtype=torch.float32, device=dev) if has_bias else None
+    ws_bytes = lib.phc_phm_linear_bwd_ws_bytes(N, n, kin, kout)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    L.check(lib.phc_phm_linear_bwd(L.ptr(x2), L.ptr(A_), L.ptr(W_), L.ptr(dy2), N, n, kin, kout, None, L.ptr(dW), L.ptr(dA),
+                                   L.ptr(db), L.ptr(ws), ws_bytes, L.stream_ptr(dev)), "phc_phm_linear_bwd(params)")
+    if L.PROF_ON:
+        L.account("phm_dH_partial", 2.0 * N * n * kin * n * kout, 4.0 * N * n * (kin + kout) + 4.0 * n * kin * n * kout)
+    return dA, dW, db
+
+
 class BNStatsRequest:
     """Ask a PHM linear layer for the batch-norm statistics of its output (training mode): when the layer runs on a
     prebuilt operand matrix, its GEMM emits per-column (sum, M2) partials from registers and the normalisation that
@@ -776,17 +812,30 @@ class _AggregateFn(torch.autograd.Function):
         return (dx if need_x else None), dea, None, None, None
 
 
-def aggregate_fwd_raw(x: torch.Tensor, ea: Optional[torch.Tensor], st: EdgeStructure, msg_encoder, add_self: bool) -> torch.Tensor:
-    """Non-differentiable forward launch (used by phc_gnn_amd.dist to compose the sharded operator)."""
+def aggregate_fwd_raw(x: torch.Tensor, ea: Optional[torch.Tensor], st: EdgeStructure, msg_encoder, add_self: bool,
+                      accumulate_into: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Non-differentiable forward launch (used by phc_gnn_amd.dist to compose the sharded operator).
+    ``accumulate_into`` [num_dst, h]: the sums are ADDED onto this tensor inside the kernel (and it is returned)."""
     lib = L.load()
-    dev = L.require_device(x, ea)
+    dev = L.require_device(x, ea, accumulate_into)
     act = msg_encoder if isinstance(msg_encoder, int) else _act_id(msg_encoder)
     x_, ea_ = L.f32c(x), L.f32c(ea)
     h = x_.shape[1]
     rowptr, col, perm = st.csr
-    out = torch.empty((st.num_dst, h), dtype=torch.float32, device=dev)
+    if accumulate_into is not None:
+        out = accumulate_into
+        if out.dtype != torch.float32 or not out.is_contiguous() or tuple(out.shape) != (st.num_dst, h):
+            raise L.PhcError("accumulate_into must be contiguous fp32 [num_dst, h]")
+    else:
+        out = torch.empty((st.num_dst, h), dtype=torch.float32, device=dev)
     L.check(lib.phc_aggregate_fwd(L.ptr(x_), L.ptr(ea_), L.ptr(rowptr), L.ptr(col), L.ptr(perm), st.num_dst, h, act,
-                                  1 if add_self else 0, L.ptr(out), L.stream_ptr(dev)), "phc_aggregate_fwd")
+                                  (1 if add_self else 0) | (2 if accumulate_into is not None else 0), L.ptr(out),
+                                  L.stream_ptr(dev)), "phc_aggregate_fwd")
+    if L.PROF_ON:
+        E, N = st.num_edges, st.num_dst
+        L.account("aggregate_fwd", 2.0 * E * h,
+                  E * (4.0 * h * (2 if ea is not None else 1) + 4) + N * 4.0 * h * (1 + (1 if add_self else 0)
+                  + (1 if accumulate_into is not None else 0)) + 4.0 * (N + 1))
     return out
 
 
@@ -804,7 +853,97 @@ def aggregate_bwd_raw(dout: torch.Tensor, x: Optional[torch.Tensor], ea: Optiona
     L.check(lib.phc_aggregate_bwd(L.ptr(dout_), L.ptr(x_) if act != 0 else None, L.ptr(ea_) if act != 0 else None,
                                   L.ptr(rowptr_t), L.ptr(col_t), L.ptr(perm_t), st.num_src, st.num_dst, h, act,
                                   1 if add_self else 0, L.ptr(dx), L.ptr(dea), L.stream_ptr(dev)), "phc_aggregate_bwd")
+    if L.PROF_ON:
+        E, Ns = st.num_edges, st.num_src
+        extra = (E * 4.0 * h * (1 if ea is not None else 0) + Ns * 4.0 * h) if act != 0 else 0.0
+        L.account("aggregate_bwd", 1.0 * E * h,
+                  E * (4.0 * h * (2 if need_dea else 1) + 4) + Ns * 4.0 * h * (2 if add_self else 1) + 4.0 * (Ns + 1) + extra)
     return dx, dea
+
+
+def gather_rows(x: torch.Tensor, rows_i64: torch.Tensor) -> torch.Tensor:
+    """out[r] = x[rows[r]] (engine kernel; staging of the halo exchange's send buffer)."""
+    lib = L.load()
+    dev = L.require_device(x, rows_i64)
+    x_ = L.f32c(x)
+    rows = rows_i64 if rows_i64.dtype == torch.int64 else rows_i64.to(torch.int64)
+    rows = rows.contiguous()
+    out = torch.empty((rows.numel(), x_.shape[1]), dtype=torch.float32, device=dev)
+    if rows.numel():
+        L.check(lib.phc_gather_rows_i64(L.ptr(x_), L.ptr(rows), rows.numel(), x_.shape[1], L.ptr(out), L.stream_ptr(dev)),
+                "phc_gather_rows_i64")
+        if L.PROF_ON:
+            L.account("gather_rows", 0.0, rows.numel() * (8.0 * x_.shape[1] + 8))
+    return out
+
+
+# ---------------------------------------------------------------------------
+# row-sharded batch-norm: the engine phases between the host's collectives (phc_gnn_amd.dist.ShardedNorm)
+# ---------------------------------------------------------------------------
+def bn_moments(x: torch.Tensor) -> torch.Tensor:
+    """[2h] = column sums | M2 (around this shard's own column means) of the rows of x."""
+    lib = L.load()
+    dev = L.require_device(x)
+    x_ = L.f32c(x)
+    N, h = x_.shape
+    moments = torch.empty(2 * h, dtype=torch.float32, device=dev)
+    ws_bytes = lib.phc_bn_ws_bytes(N, h)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    L.check(lib.phc_bn_moments(L.ptr(x_), N, h, L.ptr(moments), L.ptr(ws), ws_bytes, L.stream_ptr(dev)), "phc_bn_moments")
+    if L.PROF_ON:
+        L.account("bn_stats_partial", 3.0 * N * h, 4.0 * N * h)
+    return moments
+
+
+def bn_fwd_from_moments(x, moments_all, counts_all, n_total, weights, biases, running_mean, running_var, nbt, momentum, eps,
+                        act: int, residual=None):
+    """(out, save_stat): normalise the local rows with the statistics merged from every shard's moments."""
+    lib = L.load()
+    dev = L.require_device(x, moments_all, counts_all, residual)
+    x_, res_ = L.f32c(x), L.f32c(residual)
+    N, h = x_.shape
+    n_comp = len(running_mean) if running_mean else len(weights)
+    out = torch.empty_like(x_)
+    save_stat = torch.empty(6 * h, dtype=torch.float32, device=dev)
+    L.check(lib.phc_bn_fwd_from_moments(
+        L.ptr(x_), N, L.ptr(moments_all), L.ptr(counts_all), int(counts_all.numel()), int(n_total),
+        _ptr_array(weights) if weights else None, _ptr_array(biases) if biases else None,
+        _ptr_array(running_mean) if running_mean else None, _ptr_array(running_var) if running_var else None,
+        _ptr_array(nbt) if nbt else None, n_comp, h, float(momentum), float(eps), act, L.ptr(res_), L.ptr(out),
+        L.ptr(save_stat), L.stream_ptr(dev)), "phc_bn_fwd_from_moments")
+    if L.PROF_ON:
+        L.account("bn_apply", 2.0 * N * h, 4.0 * N * h * (3 if residual is not None else 2))
+    return out, save_stat
+
+
+def bn_bwd_sums(dy, x, save_stat, act: int) -> torch.Tensor:
+    """[2h] = this shard's partial dweight | dbias (= sum g*x_hat | sum g over its rows)."""
+    lib = L.load()
+    dev = L.require_device(dy, x)
+    dy_, x_ = L.f32c(dy), L.f32c(x)
+    N, h = x_.shape
+    dwb = torch.empty(2 * h, dtype=torch.float32, device=dev)
+    ws_bytes = lib.phc_bn_ws_bytes(N, h)
+    ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+    L.check(lib.phc_bn_bwd_sums(L.ptr(dy_), L.ptr(x_), L.ptr(save_stat), N, h, act, L.ptr(dwb), L.ptr(ws), ws_bytes,
+                                L.stream_ptr(dev)), "phc_bn_bwd_sums")
+    if L.PROF_ON:
+        L.account("bn_bwd_partial", 6.0 * N * h, 8.0 * N * h)
+    return dwb
+
+
+def bn_bwd_apply(dy, x, save_stat, dwb_global, n_total: int, act: int) -> torch.Tensor:
+    lib = L.load()
+    dev = L.require_device(dy, x, dwb_global)
+    dy_, x_ = L.f32c(dy), L.f32c(x)
+    N, h = x_.shape
+    dx = torch.empty_like(x_)
+    ws = torch.empty(2 * h, dtype=torch.float32, device=dev)
+    L.check(lib.phc_bn_bwd_apply(L.ptr(dy_), L.ptr(x_), L.ptr(save_stat), L.ptr(dwb_global), int(n_total), N, h, act, L.ptr(dx),
+                                 L.ptr(ws), 8 * h, L.stream_ptr(dev)), "phc_bn_bwd_apply")
+    if L.PROF_ON:
+        L.account("bn_bwd_apply", 8.0 * N * h, 12.0 * N * h)
+    return dx
 
 
 def aggregate_sum(x: torch.Tensor, edge_index, edge_attr: Optional[torch.Tensor], msg_encoder: str = "identity",

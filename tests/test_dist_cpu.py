@@ -14,7 +14,7 @@ import torch.multiprocessing as mp
 
 from oracle import phc_oracle as O
 from phc_gnn_amd import synth
-from phc_gnn_amd.dist import FlatGradSync, ShardedAggregate, build_halo_plan, partition_bounds
+from phc_gnn_amd.dist import FlatGradSync, ShardedAggregate, ShardedPHMGINEConv, build_halo_plan, partition_bounds
 
 
 def _free_port():
@@ -33,12 +33,16 @@ class OracleBackend:
     def structure(self, edge_index, num_src, num_dst):
         return self.St(edge_index, num_src, num_dst)
 
-    def aggregate_fwd(self, x, ea, st, act, add_self):
+    def segments(self, index, num_rows):
+        return (index, num_rows)
+
+    def aggregate_fwd(self, x, ea, st, act, add_self, accumulate_into=None):
         msg = x.index_select(0, st.ei[0])
         if ea is not None:
             msg = msg + ea
         out = O.scatter_sum_rows(O.activation(act, msg), st.ei[1], st.num_dst)
-        return out + x[:st.num_dst] if add_self else out
+        out = out + x[:st.num_dst] if add_self else out
+        return out if accumulate_into is None else accumulate_into + out
 
     def aggregate_bwd(self, dout, x, ea, st, act, add_self, need_dea):
         with torch.enable_grad():
@@ -52,8 +56,70 @@ class OracleBackend:
     def gather_rows(self, x, rows):
         return x.index_select(0, rows)
 
-    def segment_sum(self, vals, idx, n):
-        return O.scatter_sum_rows(vals, idx, n)
+    def segment_sum_into(self, vals, seg, into):
+        return into + O.scatter_sum_rows(vals, seg[0], seg[1])
+
+    # ---- PHM linear pieces ----
+    def linear_fwd(self, x, A, W, b):
+        with torch.no_grad():
+            return O.phm_linear(x, A, W, b)
+
+    def linear_dx(self, dy, A, W):
+        with torch.no_grad():
+            return dy @ O.kron_sum_H(A, W).t()
+
+    def linear_param_grads(self, x, dy, A, W, has_bias):
+        with torch.enable_grad():
+            Ar, Wr = A.detach().clone().requires_grad_(), W.detach().clone().requires_grad_()
+            br = torch.zeros(W.shape[0] * W.shape[2], requires_grad=True) if has_bias else None
+            y = O.phm_linear(x.detach(), Ar, Wr, br)
+            g = torch.autograd.grad(y, [Ar, Wr] + ([br] if has_bias else []), dy)
+        return g[0], g[1], (g[2] if has_bias else None)
+
+    # ---- row-sharded batch-norm phases (restated from the formulas in include/phc_hip.h) ----
+    def bn_moments(self, x):
+        mean = x.mean(0) if x.shape[0] else torch.zeros(x.shape[1])
+        return torch.cat([x.sum(0), ((x - mean) ** 2).sum(0)])
+
+    def bn_fwd_from_moments(self, x, moments_all, counts_all, n_total, norm, act):
+        h = x.shape[1]
+        sums, m2s = moments_all[:, :h], moments_all[:, h:]
+        mean = sums.sum(0) / n_total
+        M2 = torch.zeros(h)
+        for r in range(moments_all.shape[0]):
+            nr = float(counts_all[r])
+            if nr > 0:
+                M2 = M2 + m2s[r] + nr * (sums[r] / nr - mean) ** 2
+        var = M2 / n_total
+        invstd = 1.0 / torch.sqrt(var + norm.eps)
+        k = h // len(norm.bn)
+        w = torch.cat([m.weight.detach() for m in norm.bn]) if norm.affine else torch.ones(h)
+        b = torch.cat([m.bias.detach() for m in norm.bn]) if norm.affine else torch.zeros(h)
+        with torch.no_grad():
+            for c, m in enumerate(norm.bn):
+                m.running_mean.mul_(1 - norm.momentum).add_(norm.momentum * mean[c * k:(c + 1) * k])
+                m.running_var.mul_(1 - norm.momentum).add_(norm.momentum * (M2 / (n_total - 1))[c * k:(c + 1) * k])
+                m.num_batches_tracked += 1
+        zhat = (x - mean) * invstd
+        return O.activation(act, zhat * w + b), torch.cat([mean, invstd, w, b])
+
+    def _g(self, dy, x, save, act):
+        mean, invstd, w, b = save.view(4, -1)
+        xhat = (x - mean) * invstd
+        with torch.enable_grad():
+            pre = (xhat * w + b).detach().requires_grad_()
+            out = O.activation(act, pre)
+        return torch.autograd.grad(out, pre, dy)[0], xhat
+
+    def bn_bwd_sums(self, dy, x, save, act):
+        g, xhat = self._g(dy, x, save, act)
+        return torch.cat([(g * xhat).sum(0), g.sum(0)])
+
+    def bn_bwd_apply(self, dy, x, save, dwb_global, n_total, act):
+        g, xhat = self._g(dy, x, save, act)
+        h = x.shape[1]
+        _, invstd, w, _ = save.view(4, -1)
+        return w * invstd * (g - dwb_global[h:] / n_total - xhat * dwb_global[:h] / n_total)
 
 
 def _worker_sharded(rank, world, port, act, tmp):
@@ -143,3 +209,104 @@ def test_partition_bounds_cover_everything():
         assert b[0] == 0 and b[-1] == n and len(b) == w + 1
         sizes = np.diff(b)
         assert sizes.min() >= 0 and sizes.max() - sizes.min() <= 1
+
+
+# ---- the sharded message-passing LAYER (aggregate -> +x -> linear1 -> norm with global statistics -> act -> linear2) ----
+LAYER_CASES = {"relu_norm": dict(norm="naive-batch-norm", msg="relu", act="relu"),
+               "identity_norm": dict(norm="naive-batch-norm", msg="identity", act="swish"),
+               "no_norm": dict(norm=None, msg="identity", act="relu")}
+
+
+def _make_conv(case, n, h, seed):
+    from phc.hypercomplex.undirectional.messagepassing import PHMGINEConv
+    c = LAYER_CASES[case]
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    conv = PHMGINEConv(h, h, phm_dim=n, phm_rule=None, norm=c["norm"], activation=c["act"], msg_encoder=c["msg"])
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in conv.named_parameters():
+            if name.endswith("phm_rule"):
+                p.add_(0.05 * torch.randn(p.shape, generator=g))
+            elif p.dim() == 1:
+                p.copy_(0.5 + torch.rand(p.shape, generator=g) if name.endswith("weight") else 0.1 * torch.randn(p.shape, generator=g))
+    return conv.train()
+
+
+def _layer_problem():
+    N, E, n, h = 157, 1100, 4, 16
+    ei = torch.from_numpy(synth.random_edges(N, E, seed=13))
+    g = torch.Generator().manual_seed(15)
+    return N, E, n, h, ei, torch.randn(N, h, generator=g), torch.randn(E, h, generator=g), torch.randn(N, h, generator=g)
+
+
+def _worker_layer(rank, world, port, case, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        N, E, n, h, ei, x, ea, dy = _layer_problem()
+        conv = _make_conv(case, n, h, seed=21)                         # replicated parameters
+        plan = build_halo_plan(ei, N)
+        agg = ShardedAggregate(plan, backend=OracleBackend())
+        layer = ShardedPHMGINEConv(conv, agg, N).train()
+        x_own = x[plan.lo:plan.hi].clone().requires_grad_()
+        ea_loc, ea_halo = agg.split_edge_attr(ea)
+        ea_loc, ea_halo = ea_loc.requires_grad_(), ea_halo.requires_grad_()
+        y = layer(x_own, ea_loc, ea_halo)
+        y.backward(dy[plan.lo:plan.hi])
+        local = {k: p.grad.clone() for k, p in conv.named_parameters()}
+        sync = FlatGradSync(list(conv.parameters()), average=False)      # partial sums over own rows -> the gradient
+        sync()
+        torch.save(dict(y=y.detach(), gx=x_own.grad, gl=ea_loc.grad, gh=ea_halo.grad, loc_ids=plan.loc_edge_ids,
+                        halo_ids=plan.halo_edge_ids, lo=plan.lo, hi=plan.hi, local=local,
+                        grads={k: p.grad.clone() for k, p in conv.named_parameters()},
+                        buffers={k: b.clone() for k, b in conv.named_buffers()}), os.path.join(tmp, f"l{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("case", list(LAYER_CASES))
+def test_sharded_gine_layer_equals_single_process(tmp_path, case):
+    """Two shards of one graph through ShardedPHMGINEConv == the unsharded layer (oracle restatement of
+    messagepassing.py:132-146 + layers.py:349-355): output rows, dx, d edge_attr, every parameter gradient after the
+    flat SUM all-reduce, and the batch-norm running statistics (identical on both ranks: global batch statistics)."""
+    world = 2
+    mp.spawn(_worker_layer, args=(world, _free_port(), case, str(tmp_path)), nprocs=world, join=True)
+    N, E, n, h, ei, x, ea, dy = _layer_problem()
+    c = LAYER_CASES[case]
+    conv = _make_conv(case, n, h, seed=21)
+    p = {"q." + k: v.detach().clone() for k, v in conv.state_dict().items()}
+    names = ["q." + k for k, _ in conv.named_parameters()]
+    for k in names:
+        p[k].requires_grad_()
+    xr, er = x.clone().requires_grad_(), ea.clone().requires_grad_()
+    ref = O.phm_gine_conv(xr, ei, er, p, "q.transform.", n, c["act"], c["norm"] is not None, True, True, c["msg"], None)
+    grads = torch.autograd.grad(ref, [xr, er] + [p[k] for k in names], dy, allow_unused=True)
+    ref_param = {k[2:]: g for k, g in zip(names, grads[2:])}
+    shards = [torch.load(os.path.join(tmp_path, f"l{r}.pt")) for r in range(world)]
+    y, gx, ge = torch.zeros(N, h), torch.zeros(N, h), torch.zeros(E, h)
+    for d in shards:
+        y[d["lo"]:d["hi"]] = d["y"]
+        gx[d["lo"]:d["hi"]] = d["gx"]
+        ge[d["loc_ids"]] = d["gl"]
+        ge[d["halo_ids"]] = d["gh"]
+
+    def close(a, b, what, tol=2e-5):
+        err = float((a - b).abs().max()) / max(float(b.abs().max()), 1e-30)
+        assert err <= tol, (what, err)
+    close(y, ref, "y")
+    close(gx, grads[0], "dx")
+    close(ge, grads[1], "d edge_attr")
+    for k, g in ref_param.items():
+        if g is None or float(g.abs().max()) < 1e-5:           # bias in front of the norm: zero gradient up to round-off
+            continue
+        close(shards[0]["grads"][k], g, "grad " + k)
+        assert torch.equal(shards[0]["grads"][k], shards[1]["grads"][k]), k
+        # each rank really held a PARTIAL sum before the all-reduce
+        close(shards[0]["local"][k] + shards[1]["local"][k], g, "partial sums " + k)
+    for k, b in shards[0]["buffers"].items():
+        assert torch.equal(b, shards[1]["buffers"][k]), k          # same global statistics on every rank
+        if b.is_floating_point():
+            close(b, p["q." + k], "buffer " + k)
+        else:
+            assert int(b) == 1, k                                  # num_batches_tracked: one training step

@@ -506,3 +506,92 @@ def test_g5b_softmax_conv_layers():
             if float(ref.abs().max()) < 1e-5:
                 continue
             assert_close(g, ref, 1e-4, f"softmax conv {ci} grad {k}")
+
+
+# ---- config-5 path on ONE GPU: the sharded layer with the engine backend, RCCL group of one rank ---------------------
+def _loopback_plan(ei, N, frac=0.5):
+    """A HaloPlan for world_size 1 that still has halo edges: sources in the upper part of the node range are treated
+    as remote rows — fetched through the (self) all-to-all, aggregated by the accumulate-into kernel, their gradients
+    sent back and summed into the owners' rows — so every exchange code path runs on a single GPU."""
+    from phc_gnn_amd.dist import HaloPlan
+    cut = int(N * frac)
+    src, dst = ei[0], ei[1]
+    remote = src >= cut
+    loc_pos, halo_pos = (~remote).nonzero().flatten(), remote.nonzero().flatten()
+    halo_ids = torch.unique(src[halo_pos])
+    halo_src = torch.searchsorted(halo_ids, src[halo_pos])
+    k = int(halo_ids.numel())
+    return HaloPlan(rank=0, world=1, lo=0, hi=N, n_own=N, n_halo=k, halo_ids=halo_ids, recv_splits=[k],
+                    send_rows=halo_ids.clone(), send_splits=[k], loc_edge_index=torch.stack([src[loc_pos], dst[loc_pos]], 0).contiguous(),
+                    loc_edge_ids=loc_pos, halo_edge_index=torch.stack([halo_src, dst[halo_pos]], 0).contiguous(),
+                    halo_edge_ids=halo_pos, group=None)
+
+
+@pytest.mark.parametrize("N,E,msg,loopback", [(20_000, 110_000, "relu", True), (20_000, 110_000, "identity", False),
+                                              (1_000_000, 5_000_000, "identity", True)])
+def test_sharded_gine_layer_engine_backend_single_rank(rccl_single_rank, N, E, msg, loopback):
+    """ShardedPHMGINEConv (halo exchange on its own stream, in-kernel accumulation, moments all-gather, sums
+    all-reduce, parameter-gradient GEMMs queued behind the reverse exchange) against the CPU oracle's unsharded layer,
+    up to 1 M nodes / 5 M edges (BASELINE config 5 is 10 M / 50 M: same code, ten times the rows)."""
+    from oracle import phc_oracle as O
+    from phc.hypercomplex.undirectional.messagepassing import PHMGINEConv
+    from phc_gnn_amd import synth
+    from phc_gnn_amd.dist import ShardedAggregate, ShardedPHMGINEConv, build_halo_plan
+    n, h = 4, 128
+    ei = torch.from_numpy(synth.random_edges(N, E, seed=11))
+    g = torch.Generator().manual_seed(12)
+    x, dy = torch.randn(N, h, generator=g), torch.randn(N, h, generator=g)
+    ea = torch.randn(E, h, generator=g) if N <= 100_000 else None          # the large case: no [E, h] edge tensor on the CPU side
+    torch.manual_seed(3)
+    conv = PHMGINEConv(h, h, phm_dim=n, phm_rule=None, norm="naive-batch-norm", activation="relu", msg_encoder=msg)
+    with torch.no_grad():
+        for name, p in conv.named_parameters():
+            if p.dim() == 1 and name.endswith("weight"):
+                p.copy_(0.5 + torch.rand(p.shape, generator=g))
+    sd = {k: v.detach().clone() for k, v in conv.state_dict().items()}
+    conv.to(DEV).train()
+    eid = ei.to(DEV)
+    plan = _loopback_plan(eid, N) if loopback else build_halo_plan(eid, N)
+    assert (plan.n_halo > 0) == loopback
+    agg = ShardedAggregate(plan)
+    layer = ShardedPHMGINEConv(conv, agg, N).train()
+    xd = x.to(DEV).requires_grad_()
+    if ea is not None:
+        el, eh = agg.split_edge_attr(ea.to(DEV))
+        el, eh = el.requires_grad_(), eh.requires_grad_()
+    else:
+        el = eh = None
+    y = layer(xd, el, eh)
+    y.backward(dy.to(DEV))
+    torch.cuda.synchronize()
+
+    p = {"q." + k: v.clone() for k, v in sd.items()}
+    names = ["q." + k for k, _ in conv.named_parameters()]
+    for k in names:
+        p[k].requires_grad_()
+    xr = x.clone().requires_grad_()
+    er = ea.clone().requires_grad_() if ea is not None else None
+    if er is None:
+        # oracle without edge features: messagepassing.py:144-146 with edge_attr = 0 (phi(x_j + 0))
+        agg_ref = O.scatter_sum_rows(O.activation(msg, xr.index_select(0, ei[0])), ei[1], N) + xr
+        ref = O.phm_mlp(agg_ref, p, "q.transform.", n, "relu", True, True)
+    else:
+        ref = O.phm_gine_conv(xr, ei, er, p, "q.transform.", n, "relu", True, True, True, msg, None)
+    grads = torch.autograd.grad(ref, [xr] + ([er] if er is not None else []) + [p[k] for k in names], dy, allow_unused=True)
+    tol = 2e-5 if N <= 100_000 else 1e-4            # sums over 1 M rows in a different order
+    assert_close(y, ref, tol, "y")
+    assert_close(xd.grad, grads[0], tol, "dx")
+    off = 1
+    if er is not None:
+        ge = torch.zeros(E, h)
+        ge[plan.loc_edge_ids.cpu()] = el.grad.cpu()
+        ge[plan.halo_edge_ids.cpu()] = eh.grad.cpu()
+        assert_close(ge, grads[1], tol, "d edge_attr")
+        off = 2
+    for (k, q), gref in zip(conv.named_parameters(), grads[off:]):
+        if gref is None or float(gref.abs().max()) < 1e-5 * max(1.0, N / 20_000):
+            continue
+        assert_close(q.grad, gref, 5 * tol, "grad " + k)
+    for k, b in conv.named_buffers():
+        if b.is_floating_point():
+            assert_close(b, p["q." + k], tol, k)
