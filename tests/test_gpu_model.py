@@ -543,7 +543,10 @@ def test_sharded_gine_layer_engine_backend_single_rank(rccl_single_rank, N, E, m
     x, dy = torch.randn(N, h, generator=g), torch.randn(N, h, generator=g)
     ea = torch.randn(E, h, generator=g) if N <= 100_000 else None          # the large case: no [E, h] edge tensor on the CPU side
     torch.manual_seed(3)
-    conv = PHMGINEConv(h, h, phm_dim=n, phm_rule=None, norm="naive-batch-norm", activation="relu", msg_encoder=msg)
+    # the large case runs the MLP with a smooth activation: among 128 M pre-activations some sit within an ulp of the ReLU
+    # kink, and one flipped gate changes that node's whole dx row (see tests/test_gpu_fullwidth.py)
+    mlp_act = "relu" if N <= 100_000 else "swish"
+    conv = PHMGINEConv(h, h, phm_dim=n, phm_rule=None, norm="naive-batch-norm", activation=mlp_act, msg_encoder=msg)
     with torch.no_grad():
         for name, p in conv.named_parameters():
             if p.dim() == 1 and name.endswith("weight"):
@@ -574,9 +577,9 @@ def test_sharded_gine_layer_engine_backend_single_rank(rccl_single_rank, N, E, m
     if er is None:
         # oracle without edge features: messagepassing.py:144-146 with edge_attr = 0 (phi(x_j + 0))
         agg_ref = O.scatter_sum_rows(O.activation(msg, xr.index_select(0, ei[0])), ei[1], N) + xr
-        ref = O.phm_mlp(agg_ref, p, "q.transform.", n, "relu", True, True)
+        ref = O.phm_mlp(agg_ref, p, "q.transform.", n, mlp_act, True, True)
     else:
-        ref = O.phm_gine_conv(xr, ei, er, p, "q.transform.", n, "relu", True, True, True, msg, None)
+        ref = O.phm_gine_conv(xr, ei, er, p, "q.transform.", n, mlp_act, True, True, True, msg, None)
     grads = torch.autograd.grad(ref, [xr] + ([er] if er is not None else []) + [p[k] for k in names], dy, allow_unused=True)
     tol = 2e-5 if N <= 100_000 else 1e-4            # sums over 1 M rows in a different order
     assert_close(y, ref, tol, "y")
@@ -589,7 +592,8 @@ def test_sharded_gine_layer_engine_backend_single_rank(rccl_single_rank, N, E, m
         assert_close(ge, grads[1], tol, "d edge_attr")
         off = 2
     for (k, q), gref in zip(conv.named_parameters(), grads[off:]):
-        if gref is None or float(gref.abs().max()) < 1e-5 * max(1.0, N / 20_000):
+        if gref is None or k == "transform.linear1.b":       # bias in front of the batch-norm: zero gradient up to round-off
+            assert k != "transform.linear1.b" or float(q.grad.abs().max()) < 1e-3 * float(grads[off + 1].abs().max())
             continue
         assert_close(q.grad, gref, 5 * tol, "grad " + k)
     for k, b in conv.named_buffers():
