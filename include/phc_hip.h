@@ -515,6 +515,51 @@ int phc_bce_masked_fwd_unit(const float *logits, const float *y, int64_t total, 
 int phc_bce_masked_bwd(const float *logits, const float *y, const float *dloss, const float *stat, int64_t total,
                        float *dlogits, void *stream);
 
+/* ------------------------------------------------------------------------- *
+ * The downstream head in one launch each way
+ *
+ * PHMDownstreamNet.forward with two hidden layers (phc/hypercomplex/downstream.py:90-120) + RealTransformer 'linear'
+ * (layers.py:399-414), training mode, dropout 0:
+ *   z1 = x.H1 + b1;  a1 = act(norm1(z1));  z2 = a1.H2 + b2;  a2 = act(norm2(z2));  z3 = a2.H3 + b3;  logits = z3.Wr^T + br
+ * on B rows (one per graph).  A workgroup keeps 32 rows on chip for the whole chain; the batch statistics of the two norms
+ * (over ALL rows, as BatchNorm1d) are exchanged between the workgroups inside the launch (csrc/downstream.hip).
+ * H* = prebuilt operand matrices [K][N], H*T = their transposes [N][K] (phc_phm_build_H_batched); Wr [T][d3] is the dense
+ * nn.Linear weight, used in place.  Widths d0, d1, d2 in {32, 64, 128}, d3 <= 32, T <= 8, B <= 2048
+ * (phc_downstream_supported; otherwise PHC_ERR_UNSUPPORTED and the caller stays on the per-layer entry points).
+ * norm*: per-component pointer tables as in phc_bn_fwd (running statistics required; they are updated by the forward).
+ * The forward writes z1 [B,d1], z2 [B,d2], z3 [B,d3], stat1 [6*d1], stat2 [6*d2] (phc_bn_fwd's save_stat layout) and
+ * logits [B,T]; the backward reads them plus dlogits and writes dx [B,d0] (may be NULL), dz1, dz2, dz3 (= the dy of the
+ * three PHM layers: their parameter gradients go through phc_phm_param_grads / phc_step_tail with x, (z1, stat1), (z2, stat2)
+ * as inputs), dwb1 [2*d1], dwb2 [2*d2] (dweight | dbias of the norms) and dWr [T*d3 + T] (d Wr, then d br).
+ * partial: phc_downstream_partial_floats(B) floats and sync: 4 uint32, both ZERO before the first use and never touched
+ * by the caller afterwards (one pair of buffers per direction, per stream and per ceil(B / 32): sync[0] is a launch
+ * generation, partial holds 8-byte {value, generation tag} granules the workgroups exchange inside the launch).
+ * n_valid_dev: optional device int32 — rows >= *n_valid_dev are padding graphs of a fixed-shape batch.
+ * ------------------------------------------------------------------------- */
+typedef struct phc_downstream_norm {
+    const float *const *weight, *const *bias;            /* host arrays of n_comp device pointers (NULL: no affine) */
+    float *const *running_mean, *const *running_var;
+    int64_t *const *num_batches_tracked;                  /* may be NULL */
+    int n_comp;
+    float momentum, eps;
+} phc_downstream_norm;
+typedef struct phc_downstream_desc {
+    int64_t B;
+    int d0, d1, d2, d3, T, act;
+    const int32_t *n_valid_dev;
+    const float *x, *H1, *b1, *H2, *b2, *H3, *b3, *H1T, *H2T, *H3T, *Wr, *br;
+    phc_downstream_norm norm1, norm2;
+    float *z1, *z2, *z3, *logits, *stat1, *stat2;
+    const float *dlogits;
+    float *dx, *dz1, *dz2, *dz3, *dwb1, *dwb2, *dWr;
+    float *partial;
+    uint32_t *sync;
+} phc_downstream_desc;
+int phc_downstream_supported(int64_t B, int d0, int d1, int d2, int d3, int T);
+size_t phc_downstream_partial_floats(int64_t B);
+int phc_downstream_fwd(const phc_downstream_desc *desc, void *stream);
+int phc_downstream_bwd(const phc_downstream_desc *desc, void *stream);
+
 /* Gated per-graph sum of PHMSoftAttentionPooling (phc/hypercomplex/pooling.py:57-66):
  *   out[g, c*k + j] = sum_{r : batch[r] = g} x[r, c*k + j] * sigmoid(gate[r, j]),   k = h / n_comp
  * x [N, h], gate [N, k] (the pre-sigmoid gate), rows grouped by graph: seg_ptr [num_graphs + 1]

@@ -58,6 +58,13 @@ class PHMDownstreamNet(nn.Module):
     def forward(self, x: torch.Tensor, verbose=False, n_valid=None, **kwargs) -> torch.Tensor:
         last = len(self.affine) - 1
         engine = self.norm_flag and self.training and x.is_cuda and x.dim() == 2
+        if engine and last == 2 and self.real_trafo_type == "linear" and not any(p > 0.0 for p in self.dropout) and \
+                all(hasattr(nm.bn, "bn") for nm in self.norm) and not verbose:
+            # the whole head (three PHM layers, two norms, the dense map to the targets) in ONE engine launch each way
+            y = _engine.downstream_head(x, n_valid, list(self.affine), [nm.bn for nm in self.norm], self.real_trafo.affine,
+                                        self.activation_str)
+            if y is not None:
+                return y
         i = 0
         x = self.affine[0](x, bn_stats=_engine.BNStatsRequest(n_valid) if (engine and last > 0) else None)
         while i < last:

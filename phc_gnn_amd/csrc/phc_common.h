@@ -79,6 +79,8 @@ enum KernelId : int {
     K_CLIP_ADAM,
     K_SMALL_LINEAR,
     K_SUM_N,
+    K_DOWNSTREAM_FWD,
+    K_DOWNSTREAM_BWD,
     K_NUM_KERNELS
 };
 

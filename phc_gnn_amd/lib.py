@@ -41,6 +41,25 @@ class HJob(C.Structure):
                 ("n", C.c_int32), ("kin", C.c_int32), ("kout", C.c_int32), ("flags", C.c_int32)]
 
 
+class DownstreamNorm(C.Structure):
+    """phc_downstream_norm (include/phc_hip.h)."""
+    _fields_ = [("weight", _P), ("bias", _P), ("running_mean", _P), ("running_var", _P), ("num_batches_tracked", _P),
+                ("n_comp", C.c_int), ("momentum", C.c_float), ("eps", C.c_float)]
+
+
+class DownstreamDesc(C.Structure):
+    """phc_downstream_desc (include/phc_hip.h)."""
+    _fields_ = [("B", _L), ("d0", C.c_int), ("d1", C.c_int), ("d2", C.c_int), ("d3", C.c_int), ("T", C.c_int), ("act", C.c_int),
+                ("n_valid_dev", _P),
+                ("x", _P), ("H1", _P), ("b1", _P), ("H2", _P), ("b2", _P), ("H3", _P), ("b3", _P), ("H1T", _P), ("H2T", _P),
+                ("H3T", _P), ("Wr", _P), ("br", _P),
+                ("norm1", DownstreamNorm), ("norm2", DownstreamNorm),
+                ("z1", _P), ("z2", _P), ("z3", _P), ("logits", _P), ("stat1", _P), ("stat2", _P),
+                ("dlogits", _P),
+                ("dx", _P), ("dz1", _P), ("dz2", _P), ("dz3", _P), ("dwb1", _P), ("dwb2", _P), ("dWr", _P),
+                ("partial", _P), ("sync", _P)]
+
+
 class TableGradJob(C.Structure):
     """phc_table_grad_job (include/phc_hip.h)."""
     _fields_ = [("dout", _P), ("x", _P), ("tables", _P), ("dtables_flat", _P)]
@@ -72,6 +91,10 @@ SIGNATURES = {
     "phc_bn_fwd_from_moments": (_I, [_P, _L, _P, _P, _I, _L, _P, _P, _P, _P, _P, _I, _I, C.c_float, C.c_float, _I, _P, _P, _P, _P]),
     "phc_bn_bwd_sums": (_I, [_P, _P, _P, _L, _I, _I, _P, _P, _S, _P]),
     "phc_bn_bwd_apply": (_I, [_P, _P, _P, _P, _L, _L, _I, _I, _P, _P, _S, _P]),
+    "phc_downstream_supported": (_I, [_L, _I, _I, _I, _I, _I]),
+    "phc_downstream_partial_floats": (_S, [_L]),
+    "phc_downstream_fwd": (_I, [C.POINTER(DownstreamDesc), _P]),
+    "phc_downstream_bwd": (_I, [C.POINTER(DownstreamDesc), _P]),
     "phc_csr_ws_bytes": (_S, [_L, _L]),
     "phc_csr_build": (_I, [_P, _P, _L, _L, _L, _P, _P, _P, _P, _S, _P]),
     "phc_csr_pair_ws_bytes": (_S, [_L, _L, _L]),

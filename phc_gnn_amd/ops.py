@@ -1760,3 +1760,186 @@ def batch_norm_act(x: torch.Tensor, weights, biases, running_mean, running_var, 
                                  list(running_var) if running_var else None,
                                  list(num_batches_tracked) if num_batches_tracked else None, training, momentum, eps,
                                  _act_id(activation), n_comp, pre, *affine)
+
+
+# ---------------------------------------------------------------------------
+# the downstream head in one launch each way (csrc/downstream.hip)
+# ---------------------------------------------------------------------------
+DOWNSTREAM_FUSED = __import__("os").environ.get("PHC_DOWNSTREAM_FUSED", "1") != "0"
+_DN_BUFFERS: dict = {}
+
+
+def _dn_buffers(dev, which: str, B: int):
+    """(sync words, partial buffer) of the fused head, per device, stream and direction: the three sync words must start
+    at zero and are owned by the kernels from then on (generation / arrival counters, never reset)."""
+    lib = L.load()
+    # ... and per number of workgroups ceil(B / 32): a launch waits for (generation + 1) * G arrivals, so one set of words
+    # serves one G only
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream, which, (B + 31) // 32)
+    need = lib.phc_downstream_partial_floats(B)
+    ent = _DN_BUFFERS.get(key)
+    if ent is None or ent[1].numel() < need:
+        sync = ent[0] if ent is not None else torch.zeros(4, dtype=torch.int32, device=dev)
+        ent = (sync, torch.zeros(max(need, 1), dtype=torch.float32, device=dev))     # tag 0 never matches a launch's tag (>= 1)
+        _DN_BUFFERS[key] = ent
+    return ent
+
+
+def _dn_norm(norm_tensors, n_comp, momentum, eps, keep):
+    """phc_downstream_norm of one NaivePHMNorm: (weights, biases, running_mean, running_var, nbt) lists of n_comp tensors."""
+    w, b, rm, rv, nbt = norm_tensors
+    arrs = [_ptr_array(t) if t else None for t in (w, b, rm, rv, nbt)]
+    keep.extend(arrs)
+    cast = lambda a: _C.cast(a, _C.c_void_p) if a is not None else None
+    return L.DownstreamNorm(cast(arrs[0]), cast(arrs[1]), cast(arrs[2]), cast(arrs[3]), cast(arrs[4]), n_comp, float(momentum), float(eps))
+
+
+class _DownstreamFn(torch.autograd.Function):
+    """logits = RealTransformer(PHMDownstreamNet(x)) for two hidden layers, training mode (downstream.py:90-120,
+    layers.py:399-414): ONE engine launch forward, ONE backward (``phc_downstream_fwd`` / ``_bwd``).  The PHM layers'
+    parameter gradients leave as three jobs of the deferred / batched gradient machinery (x, dz1), ((z1, stat1), dz2),
+    ((z2, stat2), dz3); the norms' affine gradients and the dense head's come straight out of the backward launch."""
+
+    @staticmethod
+    def forward(ctx, x, n_valid, meta, A1, W1, b1, A2, W2, b2, A3, W3, b3, Wr, br, *affine):
+        lib = L.load()
+        dev = L.require_device(x, Wr)
+        act, norms, pre = meta["act"], meta["norms"], meta["pre"]
+        x_ = L.f32c(x)
+        B, d0 = x_.shape
+        d1, d2, d3 = W1.shape[0] * W1.shape[2], W2.shape[0] * W2.shape[2], W3.shape[0] * W3.shape[2]
+        T = Wr.shape[0]
+        z1 = torch.empty((B, d1), dtype=torch.float32, device=dev)
+        z2 = torch.empty((B, d2), dtype=torch.float32, device=dev)
+        z3 = torch.empty((B, d3), dtype=torch.float32, device=dev)
+        logits = torch.empty((B, T), dtype=torch.float32, device=dev)
+        stat1 = torch.empty(6 * d1, dtype=torch.float32, device=dev)
+        stat2 = torch.empty(6 * d2, dtype=torch.float32, device=dev)
+        sync, partial = _dn_buffers(dev, "fwd", B)
+        keep = []
+        d = L.DownstreamDesc()
+        d.B, d.d0, d.d1, d.d2, d.d3, d.T, d.act = B, d0, d1, d2, d3, T, act
+        d.n_valid_dev = L.ptr(n_valid)
+        d.x, d.H1, d.b1, d.H2, d.b2, d.H3, d.b3 = L.ptr(x_), L.ptr(pre[0][0]), L.ptr(b1), L.ptr(pre[1][0]), L.ptr(b2), L.ptr(pre[2][0]), L.ptr(b3)
+        d.Wr, d.br = L.ptr(Wr), L.ptr(br)
+        d.norm1 = _dn_norm(norms[0]["tensors"], norms[0]["n_comp"], norms[0]["momentum"], norms[0]["eps"], keep)
+        d.norm2 = _dn_norm(norms[1]["tensors"], norms[1]["n_comp"], norms[1]["momentum"], norms[1]["eps"], keep)
+        d.z1, d.z2, d.z3, d.logits, d.stat1, d.stat2 = L.ptr(z1), L.ptr(z2), L.ptr(z3), L.ptr(logits), L.ptr(stat1), L.ptr(stat2)
+        d.partial, d.sync = L.ptr(partial), L.ptr(sync)
+        L.check(lib.phc_downstream_fwd(_C.byref(d), L.stream_ptr(dev)), "phc_downstream_fwd")
+        if L.PROF_ON:
+            L.account("downstream_fwd", 2.0 * B * (d0 * d1 + d1 * d2 + d2 * d3 + d3 * T), 4.0 * (B * (d0 + d1 + d2 + d3 + T) + d0 * d1 + d1 * d2))
+        ctx.save_for_backward(x_, z1, z2, z3, stat1, stat2, Wr)
+        ctx.meta = meta
+        ctx.n_valid = n_valid
+        ctx.phm = ((A1, W1, b1), (A2, W2, b2), (A3, W3, b3))
+        ctx.n_affine = len(affine)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        lib = L.load()
+        x_, z1, z2, z3, stat1, stat2, Wr = ctx.saved_tensors
+        meta, n_valid = ctx.meta, ctx.n_valid
+        act, norms, pre = meta["act"], meta["norms"], meta["pre"]
+        dev = x_.device
+        B, d0 = x_.shape
+        d1, d2, d3, T = z1.shape[1], z2.shape[1], z3.shape[1], Wr.shape[0]
+        dl = L.f32c(dlogits)
+        need_x = ctx.needs_input_grad[0]
+        dx = torch.empty_like(x_) if need_x else None
+        dz1, dz2, dz3 = torch.empty_like(z1), torch.empty_like(z2), torch.empty_like(z3)
+        dwb1 = torch.empty(2 * d1, dtype=torch.float32, device=dev)
+        dwb2 = torch.empty(2 * d2, dtype=torch.float32, device=dev)
+        dWr = torch.empty(T * d3 + T, dtype=torch.float32, device=dev)
+        sync, partial = _dn_buffers(dev, "bwd", B)
+        d = L.DownstreamDesc()
+        d.B, d.d0, d.d1, d.d2, d.d3, d.T, d.act = B, d0, d1, d2, d3, T, act
+        d.n_valid_dev = L.ptr(n_valid)
+        d.H1T, d.H2T, d.H3T, d.Wr = L.ptr(pre[0][1]), L.ptr(pre[1][1]), L.ptr(pre[2][1]), L.ptr(Wr)
+        d.z1, d.z2, d.z3, d.stat1, d.stat2 = L.ptr(z1), L.ptr(z2), L.ptr(z3), L.ptr(stat1), L.ptr(stat2)
+        d.dlogits = L.ptr(dl)
+        d.dx, d.dz1, d.dz2, d.dz3, d.dwb1, d.dwb2, d.dWr = L.ptr(dx), L.ptr(dz1), L.ptr(dz2), L.ptr(dz3), L.ptr(dwb1), L.ptr(dwb2), L.ptr(dWr)
+        d.partial, d.sync = L.ptr(partial), L.ptr(sync)
+        L.check(lib.phc_downstream_bwd(_C.byref(d), L.stream_ptr(dev)), "phc_downstream_bwd")
+        if L.PROF_ON:
+            L.account("downstream_bwd", 2.0 * B * (d0 * d1 + d1 * d2 + 2 * d2 * d3 + 2 * d3 * T), 4.0 * (B * (d0 + 2 * d1 + 2 * d2 + 2 * d3 + T) + d0 * d1 + d1 * d2))
+        # the three PHM layers' parameter gradients: jobs for the batched gradient launches
+        needs = ctx.needs_input_grad
+        xs = ((x_, None), (z1, (stat1, n_valid, act)), (z2, (stat2, n_valid, act)))
+        dys = (dz1, dz2, dz3)
+        jobs, grads = [], []
+        for i, (A, W, b) in enumerate(ctx.phm):
+            nA, nW, nb = needs[3 + 3 * i], needs[4 + 3 * i], needs[5 + 3 * i] and b is not None
+            if not (nA or nW or nb):
+                grads.append((None, None, None))
+                continue
+            job = dict(x=xs[i][0], dy=dys[i], A=A, W=W, need=(nA, nW, nb), params=(A if nA else None, W if nW else None, b if nb else None))
+            if xs[i][1] is not None:
+                job["xf"] = xs[i][1]
+            jobs.append((i, job))
+            grads.append(None)
+        if jobs:
+            deferred = _DEFER.active and not torch.is_grad_enabled() and \
+                all(p is None or p.is_leaf for _, jb in jobs for p in jb["params"])
+            if deferred:
+                with _DEFER.lock:
+                    _DEFER.jobs.extend(jb for _, jb in jobs)
+                for i, _ in jobs:
+                    grads[i] = (None, None, None)
+            else:
+                for _, jb in jobs:
+                    jb["params"] = (None, None, None)
+                outs = _flush_param_grads([jb for _, jb in jobs], return_grads=True)
+                for (i, _), o in zip(jobs, outs):
+                    grads[i] = o
+        flat = []
+        for gA, gW, gb in grads:
+            flat.extend([gA, gW, gb])
+        aff = []
+        if ctx.n_affine:
+            for dwb, nm, width in ((dwb1, norms[0], d1), (dwb2, norms[1], d2)):
+                if not nm["affine"]:
+                    continue
+                n, k = nm["n_comp"], width // nm["n_comp"]
+                aff.extend([dwb[c * k:(c + 1) * k] for c in range(n)])
+                aff.extend([dwb[width + c * k:width + (c + 1) * k] for c in range(n)])
+        return (dx, None, None, *flat, dWr[:T * d3].view(T, d3), dWr[T * d3:], *aff)
+
+
+def downstream_head(x, n_valid, affine_layers, norm_modules, real_affine, activation: str):
+    """The fused head, or ``None`` when its preconditions do not hold (the caller then runs layer by layer): three PHM
+    layers with prebuilt operand matrices (inside ``prebuilt_H``), two naive batch-norms with running statistics, a dense
+    nn.Linear head, widths the kernel supports (``phc_downstream_supported``)."""
+    if not (DOWNSTREAM_FUSED and _PREBUILT.table and x.is_cuda and x.dim() == 2 and len(affine_layers) == 3 and len(norm_modules) == 2):
+        return None
+    lib = L.load()
+    pre = []
+    for lin in affine_layers:
+        ent = _prebuilt_for(lin.phm_rule, lin.W)
+        if ent is None or ent[1] is None:
+            return None
+        pre.append(ent)
+    W1, W2, W3 = (lin.W for lin in affine_layers)
+    d0, d1, d2, d3 = W1.shape[0] * W1.shape[1], W1.shape[0] * W1.shape[2], W2.shape[0] * W2.shape[2], W3.shape[0] * W3.shape[2]
+    Wr, br = real_affine.weight, real_affine.bias
+    T = Wr.shape[0]
+    if x.shape[1] != d0 or W2.shape[0] * W2.shape[1] != d1 or W3.shape[0] * W3.shape[1] != d2 or Wr.shape[1] != d3 or \
+            not lib.phc_downstream_supported(x.shape[0], d0, d1, d2, d3, T) or x.dtype != torch.float32 or not Wr.is_contiguous():
+        return None
+    norms, affine = [], []
+    for nm in norm_modules:
+        mods = list(nm.bn)
+        if not nm.track_running_stats or nm.momentum is None:
+            return None
+        w = [m.weight for m in mods] if nm.affine else None
+        b = [m.bias for m in mods] if nm.affine else None
+        norms.append(dict(tensors=(w, b, [m.running_mean for m in mods], [m.running_var for m in mods],
+                                   [m.num_batches_tracked for m in mods]), n_comp=len(mods), momentum=nm.momentum, eps=nm.eps,
+                          affine=bool(nm.affine)))
+        if nm.affine:
+            affine.extend(w + b)
+    meta = dict(act=_act_id(activation), norms=norms, pre=pre)
+    l1, l2, l3 = affine_layers
+    return _DownstreamFn.apply(x, n_valid, meta, l1.phm_rule, l1.W, l1.b, l2.phm_rule, l2.W, l2.b, l3.phm_rule, l3.W, l3.b, Wr, br, *affine)
+
