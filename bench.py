@@ -46,10 +46,13 @@ PMC_NAMES = {"phm_gemm_fwd": "phm_stream_kernel<0, -1, 32, 4, 1>", "phm_gemm_dx"
              "bn_stats_partial": "bn_stats_partial_kernel", "table_grad": "table_grad_mfma_kernel<1"}
 
 
+PMC_FILE = "r01v_pmc_traffic.json"
+
+
 def pmc_traffic(kernel: str):
     """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
     MI355X_MICROARCH.md §HBM), or None.  Collected with scripts/rocprof_pmc.sh on the same workload."""
-    path = os.path.join(ROOT, "profiles", "r01v_pmc_traffic.json")
+    path = os.path.join(ROOT, "profiles", PMC_FILE)
     pat = PMC_NAMES.get(kernel)
     if pat is None or not os.path.exists(path):
         return None
@@ -77,7 +80,7 @@ def parse_args():
     ap.add_argument("--optimizer", choices=["engine", "torch"], default="engine",
                     help="engine: phc_gnn_amd.optim.ClipAdam (clip + Adam in two launches); torch: clip_grad_norm_ + "
                          "torch.optim.Adam(fused, capturable)")
-    ap.add_argument("--cpu-steps", type=int, default=30, help="timed CPU-oracle steps (0 = skip the CPU baseline)")
+    ap.add_argument("--cpu-steps", type=int, default=20, help="timed CPU-oracle steps (0 = skip the CPU baseline)")
     ap.add_argument("--cpu-threads", type=int, default=6, help="reference setting: torch.set_num_threads(6)")
     ap.add_argument("--profile-steps", type=int, default=10)
     ap.add_argument("--min-time", type=float, default=0.5,
@@ -92,12 +95,14 @@ def make_grad_sync(model, world):
     return FlatGradSync(list(model.parameters()))
 
 
-def cpu_baseline(args, workload, model, gb):
+def cpu_baseline(args, workload, model, gb, threads=None, steps=None):
     """Time the CPU oracle on the same batch shape: same step contents."""
     from oracle import phc_oracle as O
     from phc_gnn_amd import harness
     w = harness.WORKLOADS[workload]
-    torch.set_num_threads(args.cpu_threads)
+    threads = threads or args.cpu_threads
+    steps = steps or args.cpu_steps
+    torch.set_num_threads(threads)
     sd = {k: v.detach().cpu().clone() for k, v in model.state_dict().items()}
     names = [k for k, _ in model.named_parameters()]
     for k in names:
@@ -122,13 +127,14 @@ def cpu_baseline(args, workload, model, gb):
     for _ in range(3):
         step()
     t0 = time.perf_counter()
-    for _ in range(args.cpu_steps):
+    for _ in range(steps):
         step()
     dt = time.perf_counter() - t0
-    return {"value": round(gb.num_graphs * args.cpu_steps / dt, 1), "unit": "graphs/s", "cores": args.cpu_threads,
+    return {"value": round(gb.num_graphs * steps / dt, 1), "unit": "graphs/s", "cores": threads,
             "kind": "port",
-            "sample": f"{args.cpu_steps} steps of one {gb.num_graphs}-graph batch (N={gb.num_nodes}, E={gb.num_edges}), "
-                      f"same step contents, {dt:.1f} s, oracle/phc_oracle.py on torch CPU"}
+            "sample": f"{steps} steps of one {gb.num_graphs}-graph batch (N={gb.num_nodes}, E={gb.num_edges}), "
+                      f"same step contents, {dt:.1f} s, oracle/phc_oracle.py on torch CPU (7-8 % slower than the reference itself at "
+                      f"equal threads: BASELINE.md 3a)"}
 
 
 LARGE_GRAPHS = {
@@ -293,12 +299,13 @@ def main():
     w = harness.WORKLOADS[args.workload]
     model = harness.build_model(args.workload, dev, seed=0)           # same init on every rank
     model.train()
-    if args.optimizer == "engine":
-        # train_hiv.py:198-201,285: clip_grad_norm_(2.0) + Adam(lr, weight_decay 0) — the engine's two-launch form
-        from phc_gnn_amd.optim import ClipAdam
-        opt = ClipAdam(model.parameters(), lr=1e-3)
-    else:
-        opt = torch.optim.Adam(model.parameters(), lr=1e-3, fused=True, capturable=True)
+    def make_optimizer():
+        if args.optimizer == "engine":
+            # train_hiv.py:198-201,285: clip_grad_norm_(2.0) + Adam(lr, weight_decay 0) — the engine's two-launch form
+            from phc_gnn_amd.optim import ClipAdam
+            return ClipAdam(model.parameters(), lr=1e-3)
+        return torch.optim.Adam(model.parameters(), lr=1e-3, fused=True, capturable=True)
+    opt = make_optimizer()
     cfg = harness.StepConfig(regression=bool(w.get("regression")), grad_clip=2.0, optimizer=not args.fwd_bwd_only)
     host_batches = [harness.make_batch(args.workload, seed=1000 * rank + i) for i in range(args.num_batches)]
     batches = [harness.to_device(gb, dev) for gb in host_batches]
@@ -316,7 +323,9 @@ def main():
     if rank == 0 and args.profile_steps > 0:
         # ---- roofline of the dominant engine kernel: instrumented EAGER pass over the same steps, taken before
         # the hipGraph is captured (HIP events cannot be recorded inside a replayed graph) ----
-        # (rank 0 only, so no collective in here: grad_sync=None)
+        # (rank 0 only, so no collective in here: grad_sync=None; the pass trains a few real steps, so the weights and
+        # the optimizer are put back afterwards: every rank enters the timed run from the same state)
+        init_state = {k: v.detach().clone() for k, v in model.state_dict().items()}
         for i in range(3):
             harness.train_step(model, batches[i % len(batches)], opt, cfg, None)
         torch.cuda.synchronize()
@@ -327,9 +336,10 @@ def main():
         torch.cuda.synchronize()
         lib.prof_enable(False)
         prof = (lib.prof_read(), dict(lib.WORK))
+        model.load_state_dict(init_state)
+        opt = make_optimizer()                     # fresh Adam moments / step counts, as on the other ranks
     if world > 1:
         import torch.distributed as dist
-        # rank 0 trained a few extra steps in the profiling pass: put every replica back on the same weights
         for t in list(model.state_dict().values()):
             dist.broadcast(t, src=0)
         dist.barrier()
@@ -389,6 +399,17 @@ def main():
     dt = windows[len(windows) // 2]
 
     lib.check_indices(dev)                     # sticky device error word: no kernel met an out-of-range index
+    if world > 1:
+        # the data-parallel contract: identical replicas after any number of steps (same averaged gradient, same optimizer state)
+        import torch.distributed as dist
+        worst = torch.zeros((), device=dev)
+        for prm in model.parameters():
+            ref_p = prm.detach().clone()
+            dist.broadcast(ref_p, src=0)
+            worst = torch.maximum(worst, (prm.detach() - ref_p).abs().max())
+        dist.all_reduce(worst, op=dist.ReduceOp.MAX)
+        if float(worst) != 0.0:
+            raise SystemExit(f"data-parallel replicas diverged: max |param - rank0's| = {float(worst):.3e}")
     graphs = world * w["batch_size"] * args.steps
     dataset_name = {"molhiv": "ogbg-molhiv", "molpcba": "ogbg-molpcba", "zinc": "ZINC"}[w["dataset"]]
     config_note = {"molhiv_b32": " (BASELINE configs[0])", "molhiv_b512": " (BASELINE configs[1])",
@@ -432,13 +453,36 @@ def main():
                 achieved = wk["bytes"] / (t_ms * 1e-3) / 1e9
                 roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
                         "frac": round(achieved / PEAK_HBM_GBS, 4)}
-            roof.update({"traffic": pmc_traffic(name), "kernel": name, "launches": n_launch,
+            # both rooflines SURVEY 8(d) asks for, side by side: the PHM GEMM against the fp32 MFMA peak and the
+            # scatter-aggregate against HBM (each: algorithmic work booked by ops.py / launch durations of the instrumented pass)
+            def frac_of(kname):
+                if kname not in times or kname not in work:
+                    return None
+                tms = times[kname]["total_ms"]
+                if kname in MFMA_KERNELS:
+                    a_ = work[kname]["flops"] / (tms * 1e-3) / 1e12
+                    return {"kernel": kname, "bound": "mfma", "achieved": round(a_, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                            "frac": round(a_ / PEAK_FP32_MFMA_TFLOPS, 4), "avg_launch_us": round(1e3 * tms / times[kname]["launches"], 2)}
+                a_ = work[kname]["bytes"] / (tms * 1e-3) / 1e9
+                return {"kernel": kname, "bound": "hbm", "achieved": round(a_, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                        "frac": round(a_ / PEAK_HBM_GBS, 4), "avg_launch_us": round(1e3 * tms / times[kname]["launches"], 2),
+                        "traffic": pmc_traffic(kname)}
+            result["roofline_phm_gemm"] = frac_of("phm_gemm_fwd")
+            result["roofline_aggregate"] = frac_of("aggregate_enc_fwd") or frac_of("aggregate_fwd")
+            roof.update({"traffic": pmc_traffic(name), "traffic_source": "profiles/" + PMC_FILE + " (rocprofv3 --pmc passes of this "
+                         "command: FETCH_SIZE x2 + WRITE_SIZE per launch, MI355X_MICROARCH.md HBM section; regenerate when kernels change)",
+                         "kernel": name, "launches": n_launch,
                          "avg_launch_us": round(1e3 * t_ms / max(n_launch, 1), 3),
                          "engine_kernels_us_per_step": {k: round(1e3 * v["total_ms"] / args.profile_steps, 2)
                                                         for k, v in sorted(times.items())}})
             result["roofline"] = roof
         if world == 1 and args.cpu_steps > 0:
             result["cpu_baseline"] = cpu_baseline(args, args.workload, model, host_batches[0])
+            all_cores = os.cpu_count() or args.cpu_threads
+            if all_cores != args.cpu_threads:
+                # the secondary denominator, every core of the GPU host (count stated)
+                result["cpu_baseline_all_cores"] = cpu_baseline(args, args.workload, model, host_batches[0], threads=all_cores,
+                                                                steps=max(5, args.cpu_steps // 2))
         print(json.dumps(result), flush=True)
 
     if world > 1 or force_sync:

@@ -333,23 +333,16 @@ int phc_aggregate_enc_bwd(const float *dout, const float *x, const int64_t *bond
  * save_stat [6h]: written by the forward, consumed by the backward:
  *   [mean | invstd | invstd*w | b - mean*invstd*w | w | b], w/b per column (1/0 without affine).
  * dwb_flat [2h]: dweight (component-major) followed by dbias.
- * sync_words: optional PHC_BN_SYNC_WORDS device int32, ZERO before the first use and left zero by every
- *   call; with them the per-column merge runs in the tail of the statistics / backward-sum kernel (an
- *   atomic ticket per 32-column group picks the last workgroup) and each direction is two launches
- *   instead of three.  Calls that may run concurrently (different streams) must not share them.
- *   NULL: separate merge launch, no atomics anywhere.  Results are identical either way (the merge
- *   order is fixed; the ticket only decides WHO merges).
  * ------------------------------------------------------------------------- */
 #define PHC_MAX_COMPONENTS 16
-#define PHC_BN_SYNC_WORDS 256
 
 size_t phc_bn_ws_bytes(int64_t N, int h);
 int phc_bn_fwd(const float *x, const float *const *weight, const float *const *bias, float *const *running_mean,
                float *const *running_var, int64_t *const *num_batches_tracked, int n_comp, const int32_t *n_valid_dev,
                int64_t N, int h, int training, float momentum, float eps, int act, const float *residual, float *out,
-               float *save_stat, int32_t *sync_words, void *ws, size_t ws_bytes, void *stream);
+               float *save_stat, void *ws, size_t ws_bytes, void *stream);
 int phc_bn_bwd(const float *dy, const float *x, const float *save_stat, const int32_t *n_valid_dev, int64_t N, int h,
-               int training, int act, float *dx, float *dwb_flat, int32_t *sync_words, void *ws, size_t ws_bytes,
+               int training, int act, float *dx, float *dwb_flat, void *ws, size_t ws_bytes,
                void *stream);
 
 /* Row-sharded batch-norm (one large graph split by destination-node range over the GPUs of a node;

@@ -36,6 +36,14 @@ class NaivePHMNorm(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return self.forward_fused(x)
 
+    def _momentum(self) -> float:
+        if self.momentum is None:
+            # BatchNorm1d(momentum=None) = cumulative moving average with factor 1 / num_batches_tracked (a device
+            # counter): the engine's kernels take the factor as a launch argument, so this mode is refused rather than
+            # silently run with 0.1.  The reference never uses it (norm.py:10: momentum = 0.1).
+            raise NotImplementedError("NaivePHMNorm(momentum=None) (cumulative average) is not supported by phc_gnn_amd")
+        return float(self.momentum)
+
     def forward_fused(self, x: torch.Tensor, activation: str = "identity", residual=None, n_valid=None) -> torch.Tensor:
         """act(norm(x)) (+ residual) in one engine pass (``phc_bn_fwd``): the activation and the
         skip add that follow the norm in the model (models.py:208-215) and in PHMMLP
@@ -49,7 +57,7 @@ class NaivePHMNorm(nn.Module):
                                           [m.bias for m in mods] if self.affine else None, None, None, None, True,
                                           0.0, self.eps, activation, residual, n_valid) if self.affine else \
                 self._plain(x, activation, residual)
-        momentum = self.momentum if self.momentum is not None else 0.1
+        momentum = self._momentum()
         return _engine.batch_norm_act(
             x, [m.weight for m in mods] if self.affine else None, [m.bias for m in mods] if self.affine else None,
             [m.running_mean for m in mods], [m.running_var for m in mods],
@@ -62,7 +70,7 @@ class NaivePHMNorm(nn.Module):
         if not (self.training and self.track_running_stats and x.is_cuda):
             return None
         mods = list(self.bn)
-        momentum = self.momentum if self.momentum is not None else 0.1
+        momentum = self._momentum()
         return _engine.bn_act_linear(
             x, [m.weight for m in mods] if self.affine else None, [m.bias for m in mods] if self.affine else None,
             [m.running_mean for m in mods], [m.running_var for m in mods], [m.num_batches_tracked for m in mods], momentum, self.eps,

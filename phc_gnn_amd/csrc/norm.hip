@@ -538,312 +538,6 @@ static inline unsigned apply_grid(long long N, int h) {
     return (unsigned)blocks;
 }
 
-// ==================================================================================================
-// Two-launch variants (used when the caller passes sync words): the statistics / backward-sum
-// kernels are partitioned into column groups of 32; the LAST workgroup of a group to finish (an
-// atomic ticket per group) merges that group's partials in the same fixed order as the separate
-// finalize kernels would and resets the ticket, so the finalize launch disappears.
-//   grid = (column groups, row parts); workgroup = 32 columns x one row range.
-// The tickets ("sync words") are device int32, zero before the first use, left zero by every call; calls
-// that can run concurrently (different streams) must not share them.
-// ==================================================================================================
-constexpr int BN_CPG = 32;                                  // columns per group
-constexpr int BN_FL = BN_THREADS / BN_CPG;                  // partial lanes per column in the merge (8)
-constexpr int BN_FPL = BN_MAX_PARTIALS / BN_FL;             // partials per lane (32)
-
-// true in exactly one workgroup per column group: the last one to get here (all threads agree)
-// Cross-workgroup hand-over WITHOUT __threadfence(): on a multi-XCD part an agent-scope fence writes back and
-// invalidates the whole L2 (measured: +12 us per launch).  Instead the partials are stored and loaded with
-// agent-scope relaxed atomics (write-through / L2-bypassing accesses: pstore / pload below), every wave waits for
-// its own stores to be acknowledged (workgroup-scope release = s_waitcnt), and only then is the ticket taken.
-__device__ __forceinline__ void pstore(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ float pload(const float *p) {
-    return __hip_atomic_load(const_cast<float *>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ bool bn_last_of_group(int *sync, int g, int parts) {
-    __shared__ int s_last;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");  // this wave's partial stores are acknowledged
-    __syncthreads();
-    if (threadIdx.x == 0)
-        s_last = __hip_atomic_fetch_add(&sync[g], 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == parts - 1;
-    __syncthreads();
-    return s_last != 0;
-}
-
-// per-thread walk over the rows of one part: thread -> (column slot tc, row lane rl)
-template <int VEC, typename F>
-__device__ __forceinline__ void bn_walk_rows(long long r0, long long r1, int rl, int row_lanes, F &&f) {
-#pragma unroll 4
-    for (long long r = r0 + rl; r < r1; r += row_lanes) f(r);
-}
-
-template <int VEC>
-__global__ __launch_bounds__(BN_THREADS) void bn_stats_fused_kernel(const float *__restrict__ x, BnParams p,
-                                                                  const int *__restrict__ n_valid, long long N, int h,
-                                                                  long long rows_per_block, float momentum, float eps,
-                                                                  float *__restrict__ partial, float *__restrict__ stat,
-                                                                  int *__restrict__ sync) {
-    constexpr int TPR = BN_CPG / VEC;                       // threads per row segment: 8 (float4) or 32
-    constexpr int RL = BN_THREADS / TPR;                    // row lanes: 32 or 8
-    __shared__ float red[VEC * BN_THREADS];
-    __shared__ float bmean[BN_CPG];
-    const int tid = threadIdx.x;
-    const int g = blockIdx.x, pb = blockIdx.y, parts = gridDim.y;
-    const int tc = tid % TPR, rl = tid / TPR;
-    const int col = g * BN_CPG + tc * VEC;
-    const bool colok = col < h;
-    const long long count = n_valid ? min((long long)*n_valid, N) : N;
-    const long long r0 = pb * rows_per_block;
-    const long long r1 = min(count, r0 + rows_per_block);
-    const float nb = (float)max(r1 - r0, 1LL);
-
-    // ---- pass A: column sums of this part
-    float acc[VEC];
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) acc[v] = 0.f;
-    if (colok)
-        bn_walk_rows<VEC>(r0, r1, rl, RL, [&](long long r) {
-            float xv[VEC];
-            ldv<VEC>(x + (size_t)r * h + col, xv);
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) acc[v] += xv[v];
-        });
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) red[(v * RL + rl) * TPR + tc] = acc[v];
-    __syncthreads();
-    float my_sum = 0.f;
-    if (tid < BN_CPG) {
-        const int tcc = tid / VEC, v = tid % VEC;
-        for (int l = 0; l < RL; ++l) my_sum += red[(v * RL + l) * TPR + tcc];          // fixed order
-        bmean[tid] = my_sum / nb;
-    }
-    __syncthreads();
-    // ---- pass B: squared deviations from the part mean (rows are cache-hot)
-    float m[VEC];
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-        m[v] = bmean[tc * VEC + v];
-        acc[v] = 0.f;
-    }
-    if (colok)
-        bn_walk_rows<VEC>(r0, r1, rl, RL, [&](long long r) {
-            float xv[VEC];
-            ldv<VEC>(x + (size_t)r * h + col, xv);
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) {
-                const float d = xv[v] - m[v];
-                acc[v] = fmaf(d, d, acc[v]);
-            }
-        });
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) red[(v * RL + rl) * TPR + tc] = acc[v];
-    __syncthreads();
-    if (tid < BN_CPG) {
-        const int tcc = tid / VEC, v = tid % VEC;
-        float m2 = 0.f;
-        for (int l = 0; l < RL; ++l) m2 += red[(v * RL + l) * TPR + tcc];
-        const int c = g * BN_CPG + tid;
-        if (c < h) {
-            pstore(partial + (size_t)pb * 2 * h + c, my_sum);
-            pstore(partial + (size_t)pb * 2 * h + h + c, m2);
-        }
-    }
-    if (!bn_last_of_group(sync, g, parts)) return;
-
-    // ---- merge (Chan) of this group's parts: thread -> (column ci, partial lane pl)
-    __shared__ float r_sum[BN_FL][BN_CPG], r_m2[BN_FL][BN_CPG];
-    const int ci = tid & (BN_CPG - 1), pl = tid / BN_CPG;
-    const int c = g * BN_CPG + ci;
-    const bool owner = pl == 0 && c < h;
-    float w = 1.f, b = 0.f, rm_old = 0.f, rv_old = 1.f;
-    float *rm = nullptr, *rv = nullptr;
-    if (owner) {
-        const int comp = c / p.k, kk = c - comp * p.k;
-        if (p.has_weight) w = p.weight[comp][kk];
-        if (p.has_bias) b = p.bias[comp][kk];
-        if (p.has_running) {
-            rm = p.running_mean[comp] + kk;
-            rv = p.running_var[comp] + kk;
-            rm_old = *rm;
-            rv_old = *rv;
-        }
-    }
-    const float cnt = (float)max(count, 1LL);
-    float ps[BN_FPL], pm[BN_FPL];
-#pragma unroll
-    for (int t = 0; t < BN_FPL; ++t) {
-        ps[t] = pm[t] = 0.f;
-        if (BN_FL * t < parts) {                             // wave-uniform: no loads past the last part
-            const int bb = pl + BN_FL * t;
-            const bool ok = c < h && bb < parts;
-            const size_t off = (size_t)(ok ? bb : 0) * 2 * h + (c < h ? c : 0);
-            const float a = pload(partial + off), m2v = pload(partial + off + h);
-            ps[t] = ok ? a : 0.f;
-            pm[t] = ok ? m2v : 0.f;
-        }
-    }
-    float ssum = 0.f;
-#pragma unroll
-    for (int t = 0; t < BN_FPL; ++t) ssum += ps[t];
-    r_sum[pl][ci] = ssum;
-    __syncthreads();
-    float tot = 0.f;
-    for (int l = 0; l < BN_FL; ++l) tot += r_sum[l][ci];
-    const float mean = tot / cnt;
-    float m2 = 0.f;
-#pragma unroll
-    for (int t = 0; t < BN_FPL; ++t) {
-        const int bb = pl + BN_FL * t;
-        const long long nb_i = min(rows_per_block, max(count - (long long)bb * rows_per_block, 0LL));
-        if (c < h && bb < parts && nb_i > 0) {
-            const float nbf = (float)nb_i;
-            const float d = ps[t] / nbf - mean;
-            m2 += pm[t] + nbf * d * d;
-        }
-    }
-    r_m2[pl][ci] = m2;
-    __syncthreads();
-    if (owner) {
-        float M2 = 0.f;
-        for (int l = 0; l < BN_FL; ++l) M2 += r_m2[l][ci];
-        const float var = fmaxf(M2 / cnt, 0.f);
-        const float invstd = 1.f / sqrtf(var + eps);
-        if (p.has_running) {
-            const float unbiased = count > 1 ? M2 / (cnt - 1.f) : var;
-            *rm = (1.f - momentum) * rm_old + momentum * mean;
-            *rv = (1.f - momentum) * rv_old + momentum * unbiased;
-        }
-        stat[c] = mean;
-        stat[h + c] = invstd;
-        stat[2 * h + c] = invstd * w;
-        stat[3 * h + c] = b - mean * invstd * w;
-        stat[4 * h + c] = w;
-        stat[5 * h + c] = b;
-    }
-    if (g == 0 && p.has_nbt && tid < p.n_comp) *p.num_batches_tracked[tid] += 1;
-    if (tid == 0) __hip_atomic_store(&sync[g], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);   // ticket back to zero
-}
-
-template <int ACT, int VEC>
-__global__ __launch_bounds__(BN_THREADS) void bn_bwd_partial_fused_kernel(const float *__restrict__ dy, const float *__restrict__ x,
-                                                                        const float *__restrict__ stat,
-                                                                        const int *__restrict__ n_valid, long long N, int h,
-                                                                        long long rows_per_block, int training,
-                                                                        float *__restrict__ partial, float *__restrict__ dwb,
-                                                                        float *__restrict__ bstat, int *__restrict__ sync) {
-    constexpr int TPR = BN_CPG / VEC;
-    constexpr int RL = BN_THREADS / TPR;
-    __shared__ float red[2 * VEC * BN_THREADS];
-    const int tid = threadIdx.x;
-    const int g = blockIdx.x, pb = blockIdx.y, parts = gridDim.y;
-    const int tc = tid % TPR, rl = tid / TPR;
-    const int col = g * BN_CPG + tc * VEC;
-    const bool colok = col < h;
-    const long long count = n_valid ? min((long long)*n_valid, N) : N;
-    const long long r0 = pb * rows_per_block;
-    const long long r1 = min(count, r0 + rows_per_block);
-    float sg[VEC], sgx[VEC];
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) sg[v] = sgx[v] = 0.f;
-    if (colok) {
-        float mean[VEC], inv[VEC], w[VEC], b[VEC];
-#pragma unroll
-        for (int v = 0; v < VEC; ++v) {
-            mean[v] = stat[col + v];
-            inv[v] = stat[h + col + v];
-            w[v] = stat[4 * h + col + v];
-            b[v] = stat[5 * h + col + v];
-        }
-        bn_walk_rows<VEC>(r0, r1, rl, RL, [&](long long r) {
-            float xv[VEC], gv[VEC];
-            ldv<VEC>(x + (size_t)r * h + col, xv);
-            ldv<VEC>(dy + (size_t)r * h + col, gv);
-#pragma unroll
-            for (int v = 0; v < VEC; ++v) {
-                const float xh = (xv[v] - mean[v]) * inv[v];
-                float gg = gv[v];
-                if (ACT != PHC_ACT_IDENTITY) gg *= act_grad<ACT>(fmaf(xh, w[v], b[v]));
-                sg[v] += gg;
-                sgx[v] = fmaf(gg, xh, sgx[v]);
-            }
-        });
-    }
-#pragma unroll
-    for (int v = 0; v < VEC; ++v) {
-        red[(v * RL + rl) * TPR + tc] = sg[v];
-        red[VEC * BN_THREADS + (v * RL + rl) * TPR + tc] = sgx[v];
-    }
-    __syncthreads();
-    if (tid < BN_CPG) {
-        const int tcc = tid / VEC, v = tid % VEC;
-        float a = 0.f, bsum = 0.f;
-        for (int l = 0; l < RL; ++l) {                       // fixed order
-            a += red[(v * RL + l) * TPR + tcc];
-            bsum += red[VEC * BN_THREADS + (v * RL + l) * TPR + tcc];
-        }
-        const int c = g * BN_CPG + tid;
-        if (c < h) {
-            pstore(partial + (size_t)pb * 2 * h + c, a);
-            pstore(partial + (size_t)pb * 2 * h + h + c, bsum);
-        }
-    }
-    if (!bn_last_of_group(sync, g, parts)) return;
-
-    __shared__ float r_a[BN_FL][BN_CPG], r_b[BN_FL][BN_CPG];
-    const int ci = tid & (BN_CPG - 1), pl = tid / BN_CPG;
-    const int c = g * BN_CPG + ci;
-    float pa[BN_FPL], pbv[BN_FPL];
-#pragma unroll
-    for (int t = 0; t < BN_FPL; ++t) {
-        pa[t] = pbv[t] = 0.f;
-        if (BN_FL * t < parts) {
-            const int bb = pl + BN_FL * t;
-            const bool ok = c < h && bb < parts;
-            const size_t off = (size_t)(ok ? bb : 0) * 2 * h + (c < h ? c : 0);
-            const float a = pload(partial + off), b2 = pload(partial + off + h);
-            pa[t] = ok ? a : 0.f;
-            pbv[t] = ok ? b2 : 0.f;
-        }
-    }
-    float a = 0.f, b2 = 0.f;
-#pragma unroll
-    for (int t = 0; t < BN_FPL; ++t) {
-        a += pa[t];
-        b2 += pbv[t];
-    }
-    r_a[pl][ci] = a;
-    r_b[pl][ci] = b2;
-    __syncthreads();
-    if (pl == 0 && c < h) {
-        float ta = 0.f, tb = 0.f;
-        for (int l = 0; l < BN_FL; ++l) {
-            ta += r_a[l][ci];
-            tb += r_b[l][ci];
-        }
-        if (dwb) {
-            dwb[c] = tb;                                     // dweight = sum g * x_hat
-            dwb[h + c] = ta;                                 // dbias   = sum g
-        }
-        const float cnt = (float)max(count, 1LL);
-        bstat[c] = training ? ta / cnt : 0.f;
-        bstat[h + c] = training ? tb / cnt : 0.f;
-    }
-    if (tid == 0) __hip_atomic_store(&sync[g], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
-// rows per part / number of parts of the two-launch variants (shape-only: fixed summation order)
-static BnPlan bn_plan_fused(long long N) {
-    BnPlan p;
-    long long parts = (N + 255) / 256;                      // >= 256 rows per workgroup
-    if (parts > BN_MAX_PARTIALS) parts = BN_MAX_PARTIALS;
-    if (parts < 1) parts = 1;
-    p.rows_per_block = (N + parts - 1) / parts;
-    if (p.rows_per_block < 1) p.rows_per_block = 1;
-    p.num_partials = (int)((N + p.rows_per_block - 1) / p.rows_per_block);
-    if (p.num_partials < 1) p.num_partials = 1;
-    return p;
-}
-
 #define PHC_BN_ACT_SWITCH(act, MACRO)                 \
     switch (act) {                                    \
         case PHC_ACT_IDENTITY: MACRO(PHC_ACT_IDENTITY); break; \
@@ -868,7 +562,7 @@ size_t phc_bn_ws_bytes(int64_t N, int h) {
 int phc_bn_fwd(const float *x, const float *const *weight, const float *const *bias, float *const *running_mean,
                float *const *running_var, int64_t *const *num_batches_tracked, int n_comp, const int32_t *n_valid_dev, int64_t N,
                int h, int training, float momentum, float eps, int act, const float *residual, float *out, float *save_stat,
-               int32_t *sync_words, void *ws, size_t ws_bytes, void *stream) {
+               void *ws, size_t ws_bytes, void *stream) {
     BnParams p;
     int rc = fill_params("phc_bn_fwd", &p, weight, bias, running_mean, running_var, num_batches_tracked, n_comp, h);
     if (rc) return rc;
@@ -886,19 +580,7 @@ int phc_bn_fwd(const float *x, const float *const *weight, const float *const *b
     PHC_REQUIRE(vec4 || h % 4 != 0, PHC_ERR_UNSUPPORTED, "phc_bn_fwd: rows must be 16-byte aligned when h %% 4 == 0");
     PHC_REQUIRE(ws && ws_bytes >= phc_bn_ws_bytes(N, h), PHC_ERR_WORKSPACE, "phc_bn_fwd: workspace too small");
     float *stat = save_stat;
-    if (training && sync_words) {                           // statistics + merge in one launch
-        const BnPlan fp = bn_plan_fused(N);
-        const dim3 grid((h + BN_CPG - 1) / BN_CPG, fp.num_partials);
-        ProfScope prof(K_BN_STATS, s);
-        if (vec4)
-            PHC_LAUNCH((bn_stats_fused_kernel<4>), grid, dim3(BN_THREADS), 0, s, x, p, n_valid_dev, (long long)N, h,
-                       fp.rows_per_block, momentum, eps, partial, stat, sync_words);
-        else
-            PHC_LAUNCH((bn_stats_fused_kernel<1>), grid, dim3(BN_THREADS), 0, s, x, p, n_valid_dev, (long long)N, h,
-                       fp.rows_per_block, momentum, eps, partial, stat, sync_words);
-        rc = check_launch("bn_stats_fused");
-        if (rc) return rc;
-    } else if (training) {
+    if (training) {
         ProfScope prof(K_BN_STATS, s);
         if (vec4)
             PHC_LAUNCH((bn_stats_partial_kernel<4>), dim3(plan.num_partials), dim3(BN_THREADS), 0, s, x, n_valid_dev,
@@ -909,7 +591,7 @@ int phc_bn_fwd(const float *x, const float *const *weight, const float *const *b
         rc = check_launch("bn_stats_partial");
         if (rc) return rc;
     }
-    if (!(training && sync_words)) {
+    {
         ProfScope prof(K_BN_FINALIZE, s);
         PHC_LAUNCH(bn_finalize_kernel, dim3((h + 7) / 8), dim3(BN_THREADS), 0, s, p, n_valid_dev, (long long)N, h, training,
                            momentum, eps, partial, plan.num_partials, plan.rows_per_block, stat);
@@ -978,7 +660,7 @@ int phc_bn_fwd_from_partials(const float *x, const float *stats_partial, const f
 }
 
 int phc_bn_bwd(const float *dy, const float *x, const float *save_stat, const int32_t *n_valid_dev, int64_t N, int h, int training,
-               int act, float *dx, float *dwb_flat, int32_t *sync_words, void *ws, size_t ws_bytes, void *stream) {
+               int act, float *dx, float *dwb_flat, void *ws, size_t ws_bytes, void *stream) {
     int rc = PHC_OK;
     PHC_REQUIRE(h >= 1, PHC_ERR_INVALID_ARG, "phc_bn_bwd: h < 1");
     PHC_REQUIRE(N >= 0, PHC_ERR_INVALID_ARG, "phc_bn_bwd: N < 0");
@@ -997,22 +679,7 @@ int phc_bn_bwd(const float *dy, const float *x, const float *save_stat, const in
                       (!dx || (reinterpret_cast<uintptr_t>(dx) & 15) == 0);
     PHC_REQUIRE(vec4 || h % 4 != 0, PHC_ERR_UNSUPPORTED, "phc_bn_bwd: rows must be 16-byte aligned when h %% 4 == 0");
     float *bstat = partial + 2 * (size_t)h * BN_MAX_PARTIALS;
-    if (sync_words) {                                       // column sums + merge in one launch
-        const BnPlan fp = bn_plan_fused(N);
-        const dim3 grid((h + BN_CPG - 1) / BN_CPG, fp.num_partials);
-        ProfScope prof(K_BN_BWD_PARTIAL, s);
-#define PHC_BN_BPF(ACTC)                                                                                                     \
-    if (vec4)                                                                                                                \
-        PHC_LAUNCH((bn_bwd_partial_fused_kernel<ACTC, 4>), grid, dim3(BN_THREADS), 0, s, dy, x, save_stat, n_valid_dev,      \
-                   (long long)N, h, fp.rows_per_block, training, partial, dwb_flat, bstat, sync_words);                      \
-    else                                                                                                                     \
-        PHC_LAUNCH((bn_bwd_partial_fused_kernel<ACTC, 1>), grid, dim3(BN_THREADS), 0, s, dy, x, save_stat, n_valid_dev,      \
-                   (long long)N, h, fp.rows_per_block, training, partial, dwb_flat, bstat, sync_words)
-        PHC_BN_ACT_SWITCH(act, PHC_BN_BPF)
-#undef PHC_BN_BPF
-        rc = check_launch("bn_bwd_partial_fused");
-        if (rc) return rc;
-    } else {
+    {
         ProfScope prof(K_BN_BWD_PARTIAL, s);
 #define PHC_BN_BP(ACTC)                                                                                                      \
     if (vec4)                                                                                                                \
@@ -1026,7 +693,7 @@ int phc_bn_bwd(const float *dy, const float *x, const float *save_stat, const in
         rc = check_launch("bn_bwd_partial");
         if (rc) return rc;
     }
-    if (!sync_words) {
+    {
         ProfScope prof(K_BN_BWD_FINALIZE, s);
         PHC_LAUNCH(bn_bwd_finalize_kernel, dim3((h + 7) / 8), dim3(BN_THREADS), 0, s, n_valid_dev, (long long)N, h, training,
                            partial, plan.num_partials, dwb_flat, bstat);

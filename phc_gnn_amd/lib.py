@@ -132,8 +132,8 @@ SIGNATURES = {
     "phc_step_tail": (_I, [C.POINTER(GradJob), _I, C.POINTER(TableGradJob), _I, _P, _P, _P, _P, _L, _I, _I, _P, _P, _L, _P, _P, _L, _I,
                            _P, _P, _I, _I, _P, _S, _P]),
     "phc_bn_ws_bytes": (_S, [_L, _I]),
-    "phc_bn_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _L, _I, _I, C.c_float, C.c_float, _I, _P, _P, _P, _P, _P, _S, _P]),
-    "phc_bn_bwd": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _S, _P]),
+    "phc_bn_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _L, _I, _I, C.c_float, C.c_float, _I, _P, _P, _P, _P, _S, _P]),
+    "phc_bn_bwd": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _S, _P]),
     "phc_bce_masked_ws_bytes": (_S, [_L]),
     "phc_bce_masked_fwd": (_I, [_P, _P, _L, _P, _P, _P, _S, _P]),
     "phc_bce_masked_bwd": (_I, [_P, _P, _P, _P, _L, _P, _P]),
@@ -256,21 +256,6 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
 
 def stream_ptr(device: torch.device) -> int:
     return torch.cuda.current_stream(device).cuda_stream
-
-
-_SYNC_WORDS: dict = {}
-
-
-def sync_words(device: torch.device) -> torch.Tensor:
-    """Zero-initialised, self-resetting int32 tickets for kernels that finish with a last-workgroup merge
-    (include/phc_hip.h: PHC_BN_SYNC_WORDS): one buffer per (device, stream) — launches on one stream are
-    serialised, so they can share it; different streams never do."""
-    key = (device, torch.cuda.current_stream(device).cuda_stream)
-    t = _SYNC_WORDS.get(key)
-    if t is None:
-        t = torch.zeros(256, dtype=torch.int32, device=device)
-        _SYNC_WORDS[key] = t
-    return t
 
 
 def f32c(t: Optional[torch.Tensor]) -> Optional[torch.Tensor]:

@@ -1527,11 +1527,6 @@ def _ptr_array(tensors):
     return (_C.c_void_p * len(tensors))(*[t.data_ptr() for t in tensors])
 
 
-# True: two launches per direction (the last workgroup of each 32-column group merges); False: separate merge launch.
-# Measured on MI355X at molecule scale the merged variant is SLOWER (statistics 14.5 us vs 5.7 + 6.1 us for the two
-# launches: the ticketed tail serialises behind the slowest workgroup and its partials must bypass L2), so it is off.
-BN_LAST_WORKGROUP_MERGE = __import__("os").environ.get("PHC_BN_LAST_WG_MERGE", "0") == "1"
-
 
 class _BatchNormActFn(torch.autograd.Function):
     @staticmethod
@@ -1565,7 +1560,7 @@ class _BatchNormActFn(torch.autograd.Function):
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         L.check(lib.phc_bn_fwd(L.ptr(x_), w_arr, b_arr, rm_arr, rv_arr, nbt_arr, n_comp, L.ptr(n_valid), N, h,
                                1 if training else 0, float(momentum), float(eps), act, L.ptr(res_), L.ptr(out),
-                               L.ptr(save_stat), L.ptr(L.sync_words(dev) if BN_LAST_WORKGROUP_MERGE else None), L.ptr(ws), ws_bytes, L.stream_ptr(dev)),
+                               L.ptr(save_stat), L.ptr(ws), ws_bytes, L.stream_ptr(dev)),
                 "phc_bn_fwd")
         if L.PROF_ON:
             if training:
@@ -1590,7 +1585,7 @@ class _BatchNormActFn(torch.autograd.Function):
         ws_bytes = lib.phc_bn_ws_bytes(N, h)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         L.check(lib.phc_bn_bwd(L.ptr(dout_), L.ptr(x_), L.ptr(save_stat), L.ptr(n_valid), N, h, 1 if training else 0, act,
-                               L.ptr(dx), L.ptr(dwb), L.ptr(L.sync_words(dev) if BN_LAST_WORKGROUP_MERGE else None), L.ptr(ws), ws_bytes, L.stream_ptr(dev)),
+                               L.ptr(dx), L.ptr(dwb), L.ptr(ws), ws_bytes, L.stream_ptr(dev)),
                 "phc_bn_bwd")
         if L.PROF_ON:
             L.account("bn_bwd_partial", 6.0 * N * h, 8.0 * N * h)
@@ -1703,7 +1698,7 @@ class _BNActLinearFn(torch.autograd.Function):
         else:
             ws_bytes = lib.phc_bn_ws_bytes(N, h)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-            L.check(lib.phc_bn_bwd(L.ptr(dz), L.ptr(x), L.ptr(save_stat), L.ptr(n_valid), N, h, 1, act, L.ptr(dx), L.ptr(dwb), None,
+            L.check(lib.phc_bn_bwd(L.ptr(dz), L.ptr(x), L.ptr(save_stat), L.ptr(n_valid), N, h, 1, act, L.ptr(dx), L.ptr(dwb),
                                    L.ptr(ws), ws_bytes, L.stream_ptr(dev)), "phc_bn_bwd")
         if L.PROF_ON:
             if not fused_sums:
