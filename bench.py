@@ -83,6 +83,9 @@ def parse_args():
     ap.add_argument("--cpu-steps", type=int, default=20, help="timed CPU-oracle steps (0 = skip the CPU baseline)")
     ap.add_argument("--cpu-threads", type=int, default=6, help="reference setting: torch.set_num_threads(6)")
     ap.add_argument("--profile-steps", type=int, default=10)
+    ap.add_argument("--weight-decay", type=float, default=0.001,
+                    help="explicit weight regulariser of the reference loop body (train_hiv.py:181-196, --weightdecay default "
+                         "0.001, p = 2): one more launch per step; 0 leaves it out")
     ap.add_argument("--min-time", type=float, default=0.5,
                     help="keep timing --steps-step windows until this many seconds (and >= 5 windows) are covered; the "
                          "median window is reported (0: a single window)")
@@ -119,6 +122,8 @@ def cpu_baseline(args, workload, model, gb, threads=None, steps=None):
         opt.zero_grad(set_to_none=True)
         logits = O.skip_connect_add_forward(sd, x, ei, ea, batch, **kw)
         loss = torch.nn.functional.l1_loss(logits, y) if w.get("regression") else O.bce_loss_masked(logits, y)
+        if args.weight_decay > 0:                              # same step contents as the GPU side (train_hiv.py:181-196)
+            loss = loss + 1e-3 * args.weight_decay * O.phm_weight_regularization([sd[k] for k in names if k.endswith(".W")], p=2)
         loss.backward()
         if not args.fwd_bwd_only:
             torch.nn.utils.clip_grad_norm_(params, max_norm=2.0)
@@ -306,7 +311,8 @@ def main():
             return ClipAdam(model.parameters(), lr=1e-3)
         return torch.optim.Adam(model.parameters(), lr=1e-3, fused=True, capturable=True)
     opt = make_optimizer()
-    cfg = harness.StepConfig(regression=bool(w.get("regression")), grad_clip=2.0, optimizer=not args.fwd_bwd_only)
+    cfg = harness.StepConfig(regression=bool(w.get("regression")), grad_clip=2.0, optimizer=not args.fwd_bwd_only,
+                             weight_decay=args.weight_decay, reg_p=2, lr=1e-3)
     host_batches = [harness.make_batch(args.workload, seed=1000 * rank + i) for i in range(args.num_batches)]
     batches = [harness.to_device(gb, dev) for gb in host_batches]
     # PHC_BENCH_FORCE_SYNC=1: exercise the data-parallel step (two graphs + RCCL all-reduce) on a single rank
@@ -429,7 +435,8 @@ def main():
                                f"{w['batch_size']}/GPU{config_note}",
                    "nodes_per_batch": int(sum(b.num_nodes for b in host_batches) / len(host_batches)),
                    "edges_per_batch": int(sum(b.num_edges for b in host_batches) / len(host_batches)),
-                   "step": "zero_grad+fwd+bce+bwd" + ("" if args.fwd_bwd_only else "+clip+adam")
+                   "step": "zero_grad+fwd+bce" + ("+weight_regulariser(lr*wd*mean||W||_2)" if args.weight_decay > 0 else "") + "+bwd"
+                           + ("" if args.fwd_bwd_only else "+clip+adam")
                            + ("+grad_allreduce" if world > 1 else ""),
                    "launch": ("hipGraph replay of the whole step on batches padded to one bucket shape "
                               f"({n_max} nodes, {e_max} edges); per-step D2D batch copy + CSR/CSC build "

@@ -617,6 +617,20 @@ int phc_clip_adam_step(const uint64_t *table_dev, const float *const *grads, int
                        float beta2, float eps, float *step_dev, float *scal_dev, float *partial_dev,
                        int write_back_clipped, void *stream);
 
+/* The explicit weight regulariser of the training scripts (phc/hypercomplex/regularization.py:15-23, added to the loss at
+ * benchmarks/train_hiv.py:181-196 with coef = lr * weight_decay; --weightdecay defaults to 0.001, --regularization to 2):
+ *   reg = coef * sum_layers mean_{kappa,pi} || W_layer[:, kappa, pi] ||_p ,   p in {1, 2}
+ * for up to phc_phm_weight_reg_max_jobs() PHM weights in ONE launch: W[j] is [n[j]][cells[j]] (cells = kin*kout);
+ * d reg / d W is ADDED into dW[j] (may be NULL: value only), the value is written to *reg_out and, if loss_inout is given,
+ * added to *loss_inout (the reference's `loss += reg_loss`).  W / dW / n / cells are HOST arrays.  n[j] <= 16.
+ * ws: phc_phm_weight_reg_ws_bytes() bytes, ZERO before the first use and owned by the kernel from then on (the
+ * workgroups' shares of the value meet there as tagged granules; one buffer per stream). */
+int phc_phm_weight_reg_max_jobs(void);
+size_t phc_phm_weight_reg_ws_bytes(void);
+int phc_phm_weight_reg(const float *const *W, float *const *dW, const int32_t *n, const int32_t *cells, int num_jobs, float coef,
+                       int p, float *reg_out, float *loss_inout, void *ws, size_t ws_bytes, void *stream);
+
+
 /* ------------------------------------------------------------------------- *
  * Opt-in launch profiler (process-global).  When enabled every kernel launch
  * made through this library is bracketed by two hipEvents on ITS stream;

@@ -335,3 +335,15 @@ def quaternion_real_repr(Wr: Tensor, Wi: Tensor, Wj: Tensor, Wk: Tensor) -> Tens
         torch.cat([Wi, Wr, -Wk, Wj], 1),
         torch.cat([Wj, Wk, Wr, -Wi], 1),
         torch.cat([Wk, -Wj, Wi, Wr], 1)], 0)
+
+
+# ----------------------------------------------------------------------------
+# explicit weight regulariser of the training scripts
+# ----------------------------------------------------------------------------
+def phm_weight_regularization(weights: Sequence[Tensor], p: int = 2) -> Tensor:
+    """phc/hypercomplex/regularization.py:15-23 — sum over the PHM weights W [n, k_in, k_out] of
+    ``W.norm(p, dim=0).mean()`` (added to the loss as lr * weight_decay * this, benchmarks/train_hiv.py:181-196)."""
+    reg = torch.zeros((), dtype=weights[0].dtype)
+    for w in weights:
+        reg = reg + w.norm(p=p, dim=0).mean()
+    return reg

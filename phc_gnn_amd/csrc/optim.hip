@@ -135,6 +135,88 @@ __global__ __launch_bounds__(256) void opt_adam_kernel(OptGrads grads, const uns
     }
 }
 
+
+// ---- explicit weight regulariser of the training scripts (phm_weight_regularization) --------------------------------
+// reg = coef * sum over PHM layers of mean_{kappa,pi} || W[:, kappa, pi] ||_p   (regularization.py:15-23: weight.norm(p, dim=0)
+// .mean(); coef = lr * weight_decay, train_hiv.py:181-196).  ONE launch: a workgroup owns 256 (kappa, pi) cells of one layer,
+// adds d reg / d W into that layer's gradient tensor and publishes its share of the value as a {value, tag} granule
+// (write-through store, csrc/downstream.hip); workgroup 0 collects all shares in block order (fixed summation order) and
+// writes the value / adds it to the loss.  The tag is a generation word bumped by workgroup 0 at the end of every launch.
+constexpr int REG_MAX_JOBS = 48;
+constexpr int REG_MAX_BLOCKS = 1024;
+constexpr int REG_MAX_N = 16;
+struct RegJobs {
+    const float *W[REG_MAX_JOBS];
+    float *dW[REG_MAX_JOBS];
+    int n[REG_MAX_JOBS], cells[REG_MAX_JOBS], first_block[REG_MAX_JOBS + 1];      // W is [n][cells], cells = kin * kout
+    int num;
+};
+
+__global__ __launch_bounds__(256) void phm_weight_reg_kernel(RegJobs jobs, float coef, int p, float *__restrict__ reg_out,
+                                                             float *__restrict__ loss_inout, unsigned long long *__restrict__ gran,
+                                                             unsigned *__restrict__ gen_word) {
+    __shared__ float red[4];
+    const int tid = threadIdx.x, b = blockIdx.x;
+    const unsigned tag = __hip_atomic_load(gen_word, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    int j = 0;
+    for (int q = 1; q < jobs.num; ++q) j = b >= jobs.first_block[q] ? q : j;       // uniform scan of the by-value table
+    const float *W = nullptr;
+    float *dW = nullptr;
+    int n = 1, cells = 1;
+    for (int q = 0; q < jobs.num; ++q)
+        if (q == j) { W = jobs.W[q]; dW = jobs.dW[q]; n = jobs.n[q]; cells = jobs.cells[q]; }
+    const int c = (b - jobs.first_block[j]) * 256 + tid;
+    const bool live = c < cells;
+    const int cc = live ? c : 0;
+    float w[REG_MAX_N];
+#pragma unroll
+    for (int i = 0; i < REG_MAX_N; ++i) w[i] = W[(size_t)min(i, n - 1) * cells + cc];     // one round of unconditional loads
+    float nrm = 0.f;
+#pragma unroll
+    for (int i = 0; i < REG_MAX_N; ++i)
+        if (i < n) nrm += p == 1 ? fabsf(w[i]) : w[i] * w[i];
+    if (p != 1) nrm = sqrtf(nrm);
+    if (dW && live) {
+        const float scale = coef / (float)cells;
+#pragma unroll
+        for (int i = 0; i < REG_MAX_N; ++i)
+            if (i < n) {
+                // d ||v||_1 / dv = sign(v);  d ||v||_2 / dv = v / ||v||  (0 at the origin, as torch's norm backward)
+                const float gq = p == 1 ? (w[i] > 0.f ? 1.f : (w[i] < 0.f ? -1.f : 0.f)) : (nrm > 0.f ? w[i] / nrm : 0.f);
+                dW[(size_t)i * cells + c] += scale * gq;
+            }
+    }
+    float v = live ? nrm * (coef / (float)cells) : 0.f;            // this cell's share of coef * mean
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((tid & 63) == 0) red[tid >> 6] = v;
+    __syncthreads();
+    if (tid == 0) {
+        const float part = (red[0] + red[1]) + (red[2] + red[3]);
+        __hip_atomic_store(gran + b, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(part), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (b != 0) return;
+    // workgroup 0: all shares, block order
+    const int nb = gridDim.x;
+    float total = 0.f;
+    __shared__ float shares[REG_MAX_BLOCKS];
+    for (int q = tid; q < nb; q += 256) {
+        unsigned long long g;
+        do {
+            g = __hip_atomic_load(gran + q, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        } while ((unsigned)(g >> 32) != tag);
+        shares[q] = __uint_as_float((unsigned)g);
+    }
+    __syncthreads();
+    if (tid == 0) {
+        for (int q = 0; q < nb; ++q) total += shares[q];
+        *reg_out = total;
+        if (loss_inout) *loss_inout += total;
+        __hip_atomic_fetch_add(gen_word, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
 }  // namespace phc
 
 using namespace phc;
@@ -171,6 +253,38 @@ int phc_clip_adam_step(const uint64_t *table_dev, const float *const *grads, int
                    chunks_dev, chunk_base == 0 ? scal_dev : nullptr, step_dev, partial_dev, total_chunks, max_norm, lr, beta1, beta2,
                    eps, write_back_clipped);
     return check_launch("clip_adam_step");
+}
+
+int phc_phm_weight_reg_max_jobs(void) { return REG_MAX_JOBS; }
+size_t phc_phm_weight_reg_ws_bytes(void) { return sizeof(unsigned long long) * REG_MAX_BLOCKS + 16; }
+
+int phc_phm_weight_reg(const float *const *W, float *const *dW, const int32_t *n, const int32_t *cells, int num_jobs, float coef, int p,
+                       float *reg_out, float *loss_inout, void *ws, size_t ws_bytes, void *stream) {
+    PHC_REQUIRE(num_jobs >= 1 && num_jobs <= REG_MAX_JOBS && W && n && cells && reg_out, PHC_ERR_INVALID_ARG,
+                "phc_phm_weight_reg: %d jobs (1..%d)", num_jobs, REG_MAX_JOBS);
+    PHC_REQUIRE(p == 1 || p == 2, PHC_ERR_UNSUPPORTED, "phc_phm_weight_reg: p = %d (1 or 2)", p);
+    PHC_REQUIRE(ws && ws_bytes >= phc_phm_weight_reg_ws_bytes() && (reinterpret_cast<uintptr_t>(ws) & 7) == 0, PHC_ERR_WORKSPACE,
+                "phc_phm_weight_reg: workspace missing (phc_phm_weight_reg_ws_bytes, zero before the first use)");
+    RegJobs jobs;
+    jobs.num = num_jobs;
+    int blocks = 0;
+    for (int j = 0; j < num_jobs; ++j) {
+        PHC_REQUIRE(W[j] && n[j] >= 1 && n[j] <= REG_MAX_N && cells[j] >= 1, PHC_ERR_INVALID_ARG, "phc_phm_weight_reg: job %d (n <= %d)", j, REG_MAX_N);
+        jobs.W[j] = W[j];
+        jobs.dW[j] = dW ? dW[j] : nullptr;
+        jobs.n[j] = n[j];
+        jobs.cells[j] = cells[j];
+        jobs.first_block[j] = blocks;
+        blocks += (cells[j] + 255) / 256;
+    }
+    jobs.first_block[num_jobs] = blocks;
+    PHC_REQUIRE(blocks <= REG_MAX_BLOCKS, PHC_ERR_UNSUPPORTED, "phc_phm_weight_reg: %d workgroups (max %d)", blocks, REG_MAX_BLOCKS);
+    hipStream_t s = (hipStream_t)stream;
+    unsigned long long *gran = static_cast<unsigned long long *>(ws);
+    unsigned *gen = reinterpret_cast<unsigned *>(gran + REG_MAX_BLOCKS);
+    ProfScope prof(K_CLIP_ADAM, s);
+    PHC_LAUNCH(phm_weight_reg_kernel, dim3(blocks), dim3(256), 0, s, jobs, coef, p, reg_out, loss_inout, gran, gen);
+    return check_launch("phm_weight_reg");
 }
 
 }  // extern "C"

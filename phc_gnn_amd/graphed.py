@@ -29,7 +29,7 @@ import torch
 
 from . import synth
 from .graph import cached_structures_of, clear_structure_cache
-from .harness import StepConfig, loss_fn, optimizer_step
+from .harness import StepConfig, apply_weight_regulariser, loss_fn, optimizer_step
 from .ops import deferred_param_grads, dense_weights, phm_pairs, prebuilt_H
 
 
@@ -278,6 +278,7 @@ class GraphedTrainStep:
             logits = self.model(bs.data)
             loss = loss_fn(logits, bs.data, self.cfg.regression)
             loss.backward(self._seed)
+        apply_weight_regulariser(self.model, loss, self.cfg)
         bs.logits = logits.detach()            # static output buffer of the captured step (rows of padding graphs included)
         if self.grad_sync is not None:
             self.grad_sync.pack()

@@ -12,7 +12,8 @@ import torch
 import torch.nn.functional as F
 
 from . import synth
-from .ops import deferred_param_grads, dense_weights, masked_bce_with_logits, phm_pairs, prebuilt_H
+from .ops import (deferred_param_grads, dense_weights, masked_bce_with_logits, phm_pairs, phm_weight_regularization_,
+                  prebuilt_H)
 from .optim import ClipAdam
 
 # BASELINE.json configs -> PHMSkipConnectAdd arguments (SURVEY.md §8d "Model settings")
@@ -97,6 +98,11 @@ class StepConfig:
     regression: bool = False
     grad_clip: float = 2.0              # --grad_clipping default, train_hiv.py
     optimizer: bool = True
+    # the explicit weight regulariser of train(): loss += lr * weight_decay * phm_weight_regularization(model, p)
+    # (train_hiv.py:181-196; --weightdecay defaults to 0.001, --regularization to 2, --lr to 0.001).  0 = off.
+    weight_decay: float = 0.0
+    reg_p: int = 2
+    lr: float = 1e-3
 
 
 _ONE: Dict[torch.device, torch.Tensor] = {}
@@ -125,11 +131,19 @@ def train_step(model, data, optimizer: Optional[torch.optim.Optimizer], cfg: Ste
         logits = model(data)
         loss = loss_fn(logits, data, cfg.regression)
         loss.backward(backward_seed(loss))
+    apply_weight_regulariser(model, loss, cfg)
     if grad_sync is not None:
         grad_sync(model)
     if optimizer is not None and cfg.optimizer:
         optimizer_step(model, optimizer, cfg)
     return loss
+
+
+def apply_weight_regulariser(model, loss: torch.Tensor, cfg: StepConfig) -> None:
+    """train_hiv.py:181-196 as ONE engine launch after the backward pass: d reg / d W added into the W gradients, the value
+    into ``loss`` (what the reference logs).  No-op for weight_decay 0."""
+    if cfg.weight_decay > 0.0:
+        phm_weight_regularization_(model, cfg.lr * cfg.weight_decay, cfg.reg_p, loss=loss.detach())
 
 
 def optimizer_step(model, optimizer, cfg: StepConfig) -> None:

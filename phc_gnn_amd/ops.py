@@ -1938,3 +1938,49 @@ def downstream_head(x, n_valid, affine_layers, norm_modules, real_affine, activa
     l1, l2, l3 = affine_layers
     return _DownstreamFn.apply(x, n_valid, meta, l1.phm_rule, l1.W, l1.b, l2.phm_rule, l2.W, l2.b, l3.phm_rule, l3.W, l3.b, Wr, br, *affine)
 
+
+
+# ---------------------------------------------------------------------------
+# explicit weight regulariser (regularization.py:15-23, train_hiv.py:181-196) as one launch
+# ---------------------------------------------------------------------------
+def phm_weight_regularization_(model, coef: float, p: int = 2, loss: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """``coef * phm_weight_regularization(model, p)`` of the reference, evaluated AFTER the backward pass: the value comes
+    back as a device scalar (and is added to ``loss`` in place when given, the reference's ``loss += reg_loss``), its
+    gradient is added into the ``.grad`` of every ``W`` — what autograd would have accumulated had the term been part of
+    the loss.  Modules are found like the reference finds them: any sub-module with a non-None attribute ``W``."""
+    lib = L.load()
+    Ws = [m.W for _, m in model.named_modules() if getattr(m, "W", None) is not None]
+    if not Ws:
+        raise L.PhcError("phm_weight_regularization_: the model has no module with a `W` attribute")
+    dev = L.require_device(*Ws)
+    if p not in (1, 2) or len(Ws) > lib.phc_phm_weight_reg_max_jobs() or any(w.shape[0] > 16 for w in Ws):
+        # outside the kernel's range: the reference's own expression through autograd
+        reg = coef * sum(w.norm(p=p, dim=0).mean() for w in Ws)
+        grads = torch.autograd.grad(reg, Ws)
+        for w, g in zip(Ws, grads):
+            w.grad = g if w.grad is None else w.grad + g
+        if loss is not None:
+            loss.data.add_(reg.detach())
+        return reg.detach()
+    for w in Ws:
+        if w.dtype != torch.float32 or not w.is_contiguous() or w.dim() != 3:
+            raise L.PhcError("phm_weight_regularization_: W must be contiguous fp32 [n, k_in, k_out]")
+        if w.grad is None:
+            w.grad = torch.zeros_like(w)
+    k = len(Ws)
+    W_arr = (_C.c_void_p * k)(*[w.data_ptr() for w in Ws])
+    dW_arr = (_C.c_void_p * k)(*[w.grad.data_ptr() for w in Ws])
+    n_arr = (_C.c_int32 * k)(*[w.shape[0] for w in Ws])
+    c_arr = (_C.c_int32 * k)(*[w.shape[1] * w.shape[2] for w in Ws])
+    reg = torch.empty((), dtype=torch.float32, device=dev)
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    ws = _REG_WS.get(key)
+    if ws is None:
+        ws = _REG_WS[key] = torch.zeros(lib.phc_phm_weight_reg_ws_bytes(), dtype=torch.uint8, device=dev)
+    L.check(lib.phc_phm_weight_reg(W_arr, dW_arr, n_arr, c_arr, k, float(coef), int(p), L.ptr(reg),
+                                   L.ptr(loss) if loss is not None else None, L.ptr(ws), ws.numel(), L.stream_ptr(dev)),
+            "phc_phm_weight_reg")
+    return reg
+
+
+_REG_WS: dict = {}

@@ -497,6 +497,59 @@ def g10_fullwidth():
                        store_grad32=False)
 
 
+def g11_regulariser():
+    """phm_weight_regularization (regularization.py:15-23) value and gradients for p = 1, 2 on a stack of PHM layers, plus
+    the regularised loop body of train() (train_hiv.py:173-201 with the script's defaults lr 1e-3, weightdecay 1e-3, p 2):
+    total loss and the W gradients of the cfg-1 model on its 32-graph batch."""
+    from phc.hypercomplex.regularization import phm_weight_regularization
+    gen = torch.Generator().manual_seed(1111)
+    out = {}
+
+    class Stack(torch.nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.layers = torch.nn.ModuleList([PHMLinear(128, 128, phm_dim=4), PHMLinear(128, 32, phm_dim=4), PHMLinear(64, 64, phm_dim=8),
+                                               PHMLinear(30, 45, phm_dim=3), PHMLinear(32, 4, phm_dim=4)])
+    st = Stack()
+    fill_module(st, gen)
+    with torch.no_grad():
+        st.layers[3].W[:, 2, 5] = 0.0                              # a zero column: the p = 2 subgradient there is 0
+    for i, l in enumerate(st.layers):
+        out[f"stack::W{i}"] = l.W.detach().clone()
+    for p in (1, 2):
+        for l in st.layers:
+            l.W.grad = None
+        reg = phm_weight_regularization(st, p=p)
+        reg.backward()
+        out[f"stack::reg_p{p}"] = reg.detach()
+        for i, l in enumerate(st.layers):
+            out[f"stack::dW{i}_p{p}"] = l.W.grad.clone()
+    out["stack::num"] = np.array(len(st.layers))
+    # the regularised training loss of the cfg-1 model
+    z = np.load(os.path.join(HERE, "g8_model_cfg1.npz"))
+    common = dict(norm_mp="naive-batch-norm", norm_dn="naive-batch-norm", msg_aggr="sum", pooling="softattention", activation="relu",
+                  real_trafo="linear", w_init="phm", c_init="standard", learn_phm=True)
+    model = PHMSkipConnectAdd(phm_dim=4, atom_encoded_dim=128, mp_layers=[128] * 4, dropout_mpnn=[0.0] * 4, mlp=True,
+                              downstream_layers=[128, 32], dropout_dn=[0.0, 0.0], target_dim=1, sc_type="first", **common)
+    model.load_state_dict({k[4:]: torch.from_numpy(z[k]) for k in z.files if k.startswith("sd::")})
+    model.train()
+    data = Batch(x=torch.from_numpy(z["x"]), edge_index=torch.from_numpy(z["edge_index"]), edge_attr=torch.from_numpy(z["edge_attr"]),
+                 batch=torch.from_numpy(z["batch"]), y=torch.from_numpy(z["y"]), num_graphs=int(z["y"].shape[0]))
+    logits = model(data)
+    y = data.y.to(torch.float)
+    mask = ~torch.isnan(y)
+    loss = torch.nn.functional.binary_cross_entropy_with_logits(logits[mask], y[mask])
+    reg_loss = 1e-3 * 1e-3 * phm_weight_regularization(model, p=2)
+    loss = loss + reg_loss
+    loss.backward()
+    out["model::loss"] = loss.detach()
+    out["model::reg"] = reg_loss.detach()
+    for k, prm in model.named_parameters():
+        if k.endswith(".W"):
+            out["model::grad::" + k] = prm.grad.clone()
+    save("g11_regulariser", **out)
+
+
 def g9_dropout():
     """G9: phm_dropout(same=True) mask structure (test_ops_equal_quaternion.py:64-103)."""
     torch.manual_seed(909)
@@ -512,7 +565,7 @@ def g9_dropout():
 
 if __name__ == "__main__":
     makers = [g1_phm_linear, g2_g3_g4_kronecker_rules, g5_convs, g5b_softmax, g6_norm, g7_heads, g8_models,
-              g8_model_softmax, g9_dropout, g10_fullwidth]
+              g8_model_softmax, g9_dropout, g10_fullwidth, g11_regulariser]
     wanted = sys.argv[1:]                       # e.g. `make_golden.py g8_model_softmax` rewrites only that fixture
     for make in makers:
         if not wanted or make.__name__ in wanted:

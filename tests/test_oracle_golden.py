@@ -216,3 +216,15 @@ def test_g10_fullwidth_models(name, dtype):
             continue
         allow = 1e-6 if exact else max(1e-5, 3.0 * worst32)
         assert_close(g, ref, allow, f"{name} {dtype} grad {k}")
+
+
+def test_g11_weight_regulariser():
+    z = tensors(load("g11_regulariser"))
+    k = int(z["stack::num"])
+    for p in (1, 2):
+        ws = [z[f"stack::W{i}"].clone().requires_grad_() for i in range(k)]
+        reg = O.phm_weight_regularization(ws, p=p)
+        assert_close(reg, z[f"stack::reg_p{p}"], TOL_ORACLE, f"reg p={p}")
+        grads = torch.autograd.grad(reg, ws)
+        for i, g in enumerate(grads):
+            assert_close(g, z[f"stack::dW{i}_p{p}"], TOL_ORACLE, f"dW{i} p={p}")
