@@ -340,10 +340,21 @@ size_t phc_bn_ws_bytes(int64_t N, int h);
 int phc_bn_fwd(const float *x, const float *const *weight, const float *const *bias, float *const *running_mean,
                float *const *running_var, int64_t *const *num_batches_tracked, int n_comp, const int32_t *n_valid_dev,
                int64_t N, int h, int training, float momentum, float eps, int act, const float *residual, float *out,
-               float *save_stat, void *ws, size_t ws_bytes, void *stream);
+               float *save_stat, void *ws, size_t ws_bytes, float drop_p, int drop_same_k, int drop_site,
+               const uint64_t *rng_state, void *stream);
 int phc_bn_bwd(const float *dy, const float *x, const float *save_stat, const int32_t *n_valid_dev, int64_t N, int h,
-               int training, int act, float *dx, float *dwb_flat, void *ws, size_t ws_bytes,
-               void *stream);
+               int training, int act, float *dx, float *dwb_flat, void *ws, size_t ws_bytes, float drop_p, int drop_same_k,
+               int drop_site, const uint64_t *rng_state, void *stream);
+
+/* Dropout behind the activation, inside the same pass (models.py:211-213: act -> phm_dropout -> + skip;
+ * downstream.py:108-111).  phm_dropout (phc/hypercomplex/layers.py:31-55): an entry is dropped with probability drop_p,
+ * kept entries are scaled by 1 / (1 - drop_p); drop_same_k > 0 = `same=True`: ONE mask per (row, channel) shared by the
+ * h / drop_same_k hypercomplex components (drop_same_k = columns per component), 0 = independent entries.  The mask is a
+ * pure function of (rng_state[0] = seed, rng_state[1] = step, drop_site, row, channel) — Philox4x32-10 — so phc_bn_bwd
+ * regenerates it (same arguments) instead of reading a stored one.  rng_state is a DEVICE uint64[2]; phc_rng_advance
+ * bumps the step (one tiny launch per training step, graph-capturable: every replay draws a new mask).  drop_p = 0 or
+ * eval mode: off.  Needs h % 4 == 0 (and drop_same_k % 4 == 0). */
+int phc_rng_advance(uint64_t *rng_state, void *stream);
 
 /* Row-sharded batch-norm (one large graph split by destination-node range over the GPUs of a node;
  * the reference's BatchNorm1d sees ALL rows, norm.py:30-35, so the shards exchange 2h floats per norm and direction
@@ -381,7 +392,8 @@ int phc_bn_fwd_from_partials(const float *x, const float *stats_partial, const f
                              const float *const *weight, const float *const *bias, float *const *running_mean,
                              float *const *running_var, int64_t *const *num_batches_tracked, int n_comp,
                              const int32_t *n_valid_dev, int64_t N, int h, float momentum, float eps, int act,
-                             const float *residual, float *out, float *save_stat, void *stream);
+                             const float *residual, float *out, float *save_stat, float drop_p, int drop_same_k,
+                             int drop_site, const uint64_t *rng_state, void *stream);
 
 /* Bond-table gradients of SEVERAL message-passing layers in two launches.  The layers of one model share
  * the edge list and the integer bond features; only dout / x / tables differ.  Like the PHM parameter

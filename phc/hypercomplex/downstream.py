@@ -80,13 +80,18 @@ class PHMDownstreamNet(nn.Module):
                     x = y
                     i += 1
                     continue
-            if self.norm_flag:
-                x = self.norm[i].forward_fused(x, activation=self.activation_str, n_valid=n_valid)
+            if self.norm_flag and not no_dropout and x.is_cuda:
+                # norm -> activation -> dropout in one engine pass (mask regenerated in the backward; sites 64 + i)
+                x = self.norm[i].forward_fused(x, activation=self.activation_str, n_valid=n_valid,
+                                               dropout=(self.dropout[i], self.same_dropout, 64 + i))
             else:
-                x = self.activation_func(x)
-            if not no_dropout:
-                x = phm_dropout(x, p=self.dropout[i], phm_dim=self.phm_dim, training=self.training,
-                                same=self.same_dropout)
+                if self.norm_flag:
+                    x = self.norm[i].forward_fused(x, activation=self.activation_str, n_valid=n_valid)
+                else:
+                    x = self.activation_func(x)
+                if not no_dropout:
+                    x = phm_dropout(x, p=self.dropout[i], phm_dim=self.phm_dim, training=self.training,
+                                    same=self.same_dropout)
             x = nxt(x, bn_stats=nxt_stats)
             i += 1
         if verbose:

@@ -44,8 +44,9 @@ class NaivePHMNorm(nn.Module):
             raise NotImplementedError("NaivePHMNorm(momentum=None) (cumulative average) is not supported by phc_gnn_amd")
         return float(self.momentum)
 
-    def forward_fused(self, x: torch.Tensor, activation: str = "identity", residual=None, n_valid=None) -> torch.Tensor:
-        """act(norm(x)) (+ residual) in one engine pass (``phc_bn_fwd``): the activation and the
+    def forward_fused(self, x: torch.Tensor, activation: str = "identity", residual=None, n_valid=None, dropout=None) -> torch.Tensor:
+        """``dropout`` = (p, same, site): phm_dropout behind the activation inside the same pass (engine extension).
+        act(norm(x)) (+ residual) in one engine pass (``phc_bn_fwd``): the activation and the
         skip add that follow the norm in the model (models.py:208-215) and in PHMMLP
         (layers.py:351-353) ride in the normalisation kernel.  x: [N, phm_dim * k]."""
         mods = list(self.bn)
@@ -62,7 +63,7 @@ class NaivePHMNorm(nn.Module):
             x, [m.weight for m in mods] if self.affine else None, [m.bias for m in mods] if self.affine else None,
             [m.running_mean for m in mods], [m.running_var for m in mods],
             [m.num_batches_tracked for m in mods] if self.training else None, use_batch_stats, momentum, self.eps,
-            activation, residual, n_valid)
+            activation, residual, n_valid, dropout if self.training else None)
 
     def forward_fused_linear(self, x: torch.Tensor, activation: str, n_valid, linear, out_stats=None):
         """``linear(act(norm(x)))`` (training mode) without writing the normalised activation (engine:
@@ -114,11 +115,15 @@ class PHMNorm(nn.Module):
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return self.bn(x)
 
-    def forward_fused(self, x: torch.Tensor, activation: str = "identity", residual=None, n_valid=None) -> torch.Tensor:
-        """act(norm(x)) (+ residual); one engine pass for the naive-batch-norm flavour."""
-        if isinstance(self.bn, NaivePHMNorm) and activation.lower() in _FUSABLE_ACTS:
-            return self.bn.forward_fused(x, activation, residual, n_valid)
+    def forward_fused(self, x: torch.Tensor, activation: str = "identity", residual=None, n_valid=None, dropout=None) -> torch.Tensor:
+        """act(norm(x)) (+ dropout) (+ residual); one engine pass for the naive-batch-norm flavour."""
+        if isinstance(self.bn, NaivePHMNorm) and activation.lower() in _FUSABLE_ACTS and self.bn.track_running_stats and \
+                (dropout is None or (x.shape[-1] % 4 == 0 and (x.shape[-1] // self.phm_dim) % 4 == 0)):
+            return self.bn.forward_fused(x, activation, residual, n_valid, dropout)
         out = _engine_act(self.bn(x), activation)
+        if dropout is not None and self.training and dropout[0] > 0.0:
+            from phc.hypercomplex.layers import phm_dropout
+            out = phm_dropout(out, phm_dim=self.phm_dim, p=dropout[0], training=True, same=bool(dropout[1]))
         return out if residual is None else out + residual
 
     def forward_fused_linear(self, x: torch.Tensor, activation: str, n_valid, linear, out_stats=None):

@@ -149,9 +149,12 @@ class PHMSkipConnectAdd(nn.Module):
         else:
             h = conv(x=x[0], edge_index=edge_index, edge_attr=edge_attr, size=size)
         dropout_active = self.training and dropout_mpnn > 0.0
-        if norm is not None and not dropout_active:
-            # norm -> activation -> (+ skip) ride in one engine pass
-            return norm.forward_fused(h, activation=self.activation_str, residual=x[1], n_valid=n_valid)
+        if norm is not None and (not dropout_active or h.is_cuda):
+            # norm -> activation -> (dropout ->) (+ skip) ride in one engine pass; the dropout mask is regenerated in the
+            # backward from (seed, step, site) — site = the layer's position in self.norms
+            site = next((i for i, nm in enumerate(self.norms) if nm is norm), 0)
+            return norm.forward_fused(h, activation=self.activation_str, residual=x[1], n_valid=n_valid,
+                                      dropout=(dropout_mpnn, self.same_dropout, site) if dropout_active else None)
         if norm is not None:
             h = norm.forward_fused(h, activation=self.activation_str, n_valid=n_valid)
         else:

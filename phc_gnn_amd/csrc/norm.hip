@@ -40,6 +40,43 @@ __device__ __forceinline__ float bn_b(const BnParams &p, int col) { return p.has
 template <int ACT>
 __device__ __forceinline__ float bn_act(float z) { return act_fwd<ACT>(z); }
 
+// ---- dropout fused behind the activation (models.py:211-213, downstream.py:108-111: act -> phm_dropout -> (+ skip)) ----
+// phm_dropout (layers.py:31-55): p = drop rate, kept entries scaled by 1 / (1 - p); same = one mask per (row, channel)
+// shared by the n hypercomplex components.  The mask is a pure function of (seed, step, site, row, channel): Philox4x32-10
+// with key = seed, counter = (element group, site, step), so the backward kernels regenerate it instead of reading a
+// stored mask, and a replayed hipGraph draws a fresh mask every step (step is a device counter, phc_rng_advance).
+struct BnDrop {
+    float p;                        // 0: off
+    int same, k, site;              // k = columns per component
+    const unsigned long long *state;   // device: {seed, step}
+};
+
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 key) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = make_uint4(hi1 ^ c.y ^ key.x, lo1, hi0 ^ c.w ^ key.y, lo0);
+        key.x += 0x9E3779B9u;
+        key.y += 0xBB67AE85u;
+    }
+    return c;
+}
+
+// keep-and-scale factors of the 4 consecutive columns starting at col (col % 4 == 0, k % 4 == 0) of row r
+__device__ __forceinline__ float4 drop_factors(const BnDrop &d, unsigned long long seed, unsigned long long step, long long r, int col,
+                                               int h) {
+    const int chan = d.same ? col % d.k : col;                       // same: the mask ignores the component
+    const int width = d.same ? d.k : h;
+    const unsigned long long g = (unsigned long long)r * (unsigned long long)(width >> 2) + (unsigned long long)(chan >> 2);
+    const uint4 rnd = philox4x32_10(make_uint4((unsigned)g, (unsigned)(g >> 32), (unsigned)d.site, (unsigned)step),
+                                    make_uint2((unsigned)seed, (unsigned)(seed >> 32) ^ (unsigned)(step >> 32)));
+    const float inv = 1.f / (1.f - d.p);
+    const float u0 = rnd.x * 2.3283064365386963e-10f, u1 = rnd.y * 2.3283064365386963e-10f, u2 = rnd.z * 2.3283064365386963e-10f,
+                u3 = rnd.w * 2.3283064365386963e-10f;
+    return make_float4(u0 >= d.p ? inv : 0.f, u1 >= d.p ? inv : 0.f, u2 >= d.p ? inv : 0.f, u3 >= d.p ? inv : 0.f);
+}
+
 // ---- pass 1 (forward): per-column shifted sums over a row range --------------------------------
 // thread -> (vector column c = tid % cols, row lane rl = tid / cols), VEC columns per thread;
 // partial[b][0..h) = sum(x - pilot), partial[b][h..2h) = sum((x - pilot)^2), pilot = x[0][col]
@@ -226,11 +263,13 @@ __global__ __launch_bounds__(BN_THREADS) void bn_finalize_kernel(BnParams p, con
 template <int ACT>
 __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const float *__restrict__ x, const int *__restrict__ n_valid, long long N,
                                                             int h, const float *__restrict__ residual,
-                                                            const float *__restrict__ stat, float *__restrict__ out) {
+                                                            const float *__restrict__ stat, float *__restrict__ out, BnDrop drop = BnDrop{}) {
     extern __shared__ float sm[];                            // scale[h], shift[h]
     float *scale = sm, *shift = sm + h;
     const long long count = n_valid ? min((long long)*n_valid, N) : N;
     const int tid = threadIdx.x;
+    const bool dropping = drop.p > 0.f;
+    const unsigned long long seed = dropping ? drop.state[0] : 0ull, step = dropping ? drop.state[1] : 0ull;
     for (int c = tid; c < h; c += BN_THREADS) {
         scale[c] = stat[2 * h + c];
         shift[c] = stat[3 * h + c];
@@ -249,6 +288,10 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const float *__res
                 o.y = bn_act<ACT>(fmaf(v.y, scale[c + 1], shift[c + 1]));
                 o.z = bn_act<ACT>(fmaf(v.z, scale[c + 2], shift[c + 2]));
                 o.w = bn_act<ACT>(fmaf(v.w, scale[c + 3], shift[c + 3]));
+                if (dropping) {
+                    const float4 f = drop_factors(drop, seed, step, r, c, h);
+                    o.x *= f.x; o.y *= f.y; o.z *= f.z; o.w *= f.w;
+                }
                 if (residual) {
                     const float4 rr = reinterpret_cast<const float4 *>(residual)[e];
                     o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
@@ -276,9 +319,11 @@ template <int ACT, int VEC>
 __global__ __launch_bounds__(BN_THREADS) void bn_bwd_partial_kernel(const float *__restrict__ dy, const float *__restrict__ x,
                                                                   const float *__restrict__ stat,
                                                                   const int *__restrict__ n_valid, long long N, int h,
-                                                                  long long rows_per_block, float *__restrict__ partial) {
+                                                                  long long rows_per_block, float *__restrict__ partial, BnDrop drop = BnDrop{}) {
     __shared__ float red[2 * VEC * BN_THREADS];
     const long long count = n_valid ? min((long long)*n_valid, N) : N;
+    const bool dropping = VEC == 4 && drop.p > 0.f;
+    const unsigned long long seed = dropping ? drop.state[0] : 0ull, step = dropping ? drop.state[1] : 0ull;
     const int tid = threadIdx.x;
     const long long r0 = blockIdx.x * rows_per_block;
     const long long r1 = min(count, r0 + rows_per_block);
@@ -305,6 +350,12 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_partial_kernel(const float 
                 float xv[VEC], gv[VEC];
                 ldv<VEC>(x + (size_t)r * h + col, xv);
                 ldv<VEC>(dy + (size_t)r * h + col, gv);
+                if constexpr (VEC == 4) {
+                    if (dropping) {
+                        const float4 f = drop_factors(drop, seed, step, r, col, h);
+                        gv[0] *= f.x; gv[1] *= f.y; gv[2] *= f.z; gv[3] *= f.w;
+                    }
+                }
 #pragma unroll
                 for (int v = 0; v < VEC; ++v) {
                     const float xh = (xv[v] - mean[v]) * inv[v];
@@ -387,7 +438,9 @@ template <int ACT>
 __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const float *__restrict__ dy, const float *__restrict__ x,
                                                                 const float *__restrict__ stat,
                                                                 const int *__restrict__ n_valid, long long N, int h,
-                                                                const float *__restrict__ bstat, float *__restrict__ dx) {
+                                                                const float *__restrict__ bstat, float *__restrict__ dx, BnDrop drop = BnDrop{}) {
+    const bool dropping = drop.p > 0.f;
+    const unsigned long long seed = dropping ? drop.state[0] : 0ull, step = dropping ? drop.state[1] : 0ull;
     extern __shared__ float sm[];                            // mean, invstd, w, b, mg, mgx : 6 * h
     float *s_mean = sm, *s_inv = sm + h, *s_w = sm + 2 * h, *s_b = sm + 3 * h, *s_mg = sm + 4 * h, *s_mgx = sm + 5 * h;
     const long long count = n_valid ? min((long long)*n_valid, N) : N;
@@ -416,7 +469,11 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const float *_
             float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
             if (r < count) {
                 const float4 xv = reinterpret_cast<const float4 *>(x)[e];
-                const float4 gv = reinterpret_cast<const float4 *>(dy)[e];
+                float4 gv = reinterpret_cast<const float4 *>(dy)[e];
+                if (dropping) {
+                    const float4 f = drop_factors(drop, seed, step, r, c, h);
+                    gv.x *= f.x; gv.y *= f.y; gv.z *= f.z; gv.w *= f.w;
+                }
                 o.x = one(xv.x, gv.x, c); o.y = one(xv.y, gv.y, c + 1);
                 o.z = one(xv.z, gv.z, c + 2); o.w = one(xv.w, gv.w, c + 3);
             }
@@ -538,6 +595,21 @@ static inline unsigned apply_grid(long long N, int h) {
     return (unsigned)blocks;
 }
 
+static int make_drop(const char *who, BnDrop *d, float p, int same_k, int site, const uint64_t *state, int h) {
+    d->p = 0.f; d->same = 0; d->k = h; d->site = site; d->state = nullptr;
+    if (p <= 0.f) return PHC_OK;
+    PHC_REQUIRE(p < 1.f && state, PHC_ERR_INVALID_ARG, "%s: dropout p=%g needs 0 <= p < 1 and an rng state", who, (double)p);
+    PHC_REQUIRE(h % 4 == 0 && (same_k == 0 || (same_k % 4 == 0 && h % same_k == 0)), PHC_ERR_UNSUPPORTED,
+                "%s: fused dropout needs h %% 4 == 0 (and k %% 4 == 0 for the shared mask)", who);
+    d->p = p;
+    d->same = same_k > 0;
+    d->k = same_k > 0 ? same_k : h;
+    d->state = reinterpret_cast<const unsigned long long *>(state);
+    return PHC_OK;
+}
+
+__global__ void rng_advance_kernel(unsigned long long *state) { state[1] += 1ull; }
+
 #define PHC_BN_ACT_SWITCH(act, MACRO)                 \
     switch (act) {                                    \
         case PHC_ACT_IDENTITY: MACRO(PHC_ACT_IDENTITY); break; \
@@ -562,9 +634,12 @@ size_t phc_bn_ws_bytes(int64_t N, int h) {
 int phc_bn_fwd(const float *x, const float *const *weight, const float *const *bias, float *const *running_mean,
                float *const *running_var, int64_t *const *num_batches_tracked, int n_comp, const int32_t *n_valid_dev, int64_t N,
                int h, int training, float momentum, float eps, int act, const float *residual, float *out, float *save_stat,
-               void *ws, size_t ws_bytes, void *stream) {
+               void *ws, size_t ws_bytes, float drop_p, int drop_same_k, int drop_site, const uint64_t *rng_state, void *stream) {
     BnParams p;
-    int rc = fill_params("phc_bn_fwd", &p, weight, bias, running_mean, running_var, num_batches_tracked, n_comp, h);
+    BnDrop drop;
+    int rc = make_drop("phc_bn_fwd", &drop, training ? drop_p : 0.f, drop_same_k, drop_site, rng_state, h);
+    if (rc) return rc;
+    rc = fill_params("phc_bn_fwd", &p, weight, bias, running_mean, running_var, num_batches_tracked, n_comp, h);
     if (rc) return rc;
     PHC_REQUIRE(N >= 0, PHC_ERR_INVALID_ARG, "phc_bn_fwd: N < 0");
     PHC_REQUIRE(act >= PHC_ACT_IDENTITY && act <= PHC_ACT_SELU, PHC_ERR_INVALID_ARG, "phc_bn_fwd: unknown activation %d", act);
@@ -602,7 +677,7 @@ int phc_bn_fwd(const float *x, const float *const *weight, const float *const *b
     ProfScope prof(K_BN_APPLY, s);
 #define PHC_BN_FWD(ACTC)                                                                                                      \
     PHC_LAUNCH((bn_apply_kernel<ACTC>), dim3(apply_grid(N, h)), dim3(BN_THREADS), lds, s, x, n_valid_dev, (long long)N, h,   \
-                       residual, stat, out)
+                       residual, stat, out, drop)
     PHC_BN_ACT_SWITCH(act, PHC_BN_FWD)
 #undef PHC_BN_FWD
     return check_launch("bn_apply");
@@ -629,9 +704,12 @@ int phc_bn_fwd_from_partials(const float *x, const float *stats_partial, const f
                              const float *const *weight, const float *const *bias, float *const *running_mean,
                              float *const *running_var, int64_t *const *num_batches_tracked, int n_comp, const int32_t *n_valid_dev,
                              int64_t N, int h, float momentum, float eps, int act, const float *residual, float *out,
-                             float *save_stat, void *stream) {
+                             float *save_stat, float drop_p, int drop_same_k, int drop_site, const uint64_t *rng_state, void *stream) {
     BnParams p;
-    int rc = fill_params("phc_bn_fwd_from_partials", &p, weight, bias, running_mean, running_var, num_batches_tracked, n_comp, h);
+    BnDrop drop;
+    int rc = make_drop("phc_bn_fwd_from_partials", &drop, drop_p, drop_same_k, drop_site, rng_state, h);
+    if (rc) return rc;
+    rc = fill_params("phc_bn_fwd_from_partials", &p, weight, bias, running_mean, running_var, num_batches_tracked, n_comp, h);
     if (rc) return rc;
     PHC_REQUIRE(N >= 1 && num_partials >= 1 && num_partials <= BN_MAX_PARTIALS, PHC_ERR_INVALID_ARG,
                 "phc_bn_fwd_from_partials: N=%lld, %d partials (max %d)", (long long)N, num_partials, BN_MAX_PARTIALS);
@@ -653,15 +731,18 @@ int phc_bn_fwd_from_partials(const float *x, const float *stats_partial, const f
     ProfScope prof(K_BN_APPLY, s);
 #define PHC_BN_FWDP(ACTC)                                                                                                     \
     PHC_LAUNCH((bn_apply_kernel<ACTC>), dim3(apply_grid(N, h)), dim3(BN_THREADS), lds, s, x, n_valid_dev, (long long)N, h, residual,  \
-               save_stat, out)
+               save_stat, out, drop)
     PHC_BN_ACT_SWITCH(act, PHC_BN_FWDP)
 #undef PHC_BN_FWDP
     return check_launch("bn_apply");
 }
 
 int phc_bn_bwd(const float *dy, const float *x, const float *save_stat, const int32_t *n_valid_dev, int64_t N, int h, int training,
-               int act, float *dx, float *dwb_flat, void *ws, size_t ws_bytes, void *stream) {
-    int rc = PHC_OK;
+               int act, float *dx, float *dwb_flat, void *ws, size_t ws_bytes, float drop_p, int drop_same_k, int drop_site,
+               const uint64_t *rng_state, void *stream) {
+    BnDrop drop;
+    int rc = make_drop("phc_bn_bwd", &drop, training ? drop_p : 0.f, drop_same_k, drop_site, rng_state, h);
+    if (rc) return rc;
     PHC_REQUIRE(h >= 1, PHC_ERR_INVALID_ARG, "phc_bn_bwd: h < 1");
     PHC_REQUIRE(N >= 0, PHC_ERR_INVALID_ARG, "phc_bn_bwd: N < 0");
     PHC_REQUIRE(act >= PHC_ACT_IDENTITY && act <= PHC_ACT_SELU, PHC_ERR_INVALID_ARG, "phc_bn_bwd: unknown activation %d", act);
@@ -684,10 +765,10 @@ int phc_bn_bwd(const float *dy, const float *x, const float *save_stat, const in
 #define PHC_BN_BP(ACTC)                                                                                                      \
     if (vec4)                                                                                                                \
         PHC_LAUNCH((bn_bwd_partial_kernel<ACTC, 4>), dim3(plan.num_partials), dim3(BN_THREADS), 0, s, dy, x, save_stat,    \
-                           n_valid_dev, (long long)N, h, plan.rows_per_block, partial);                                      \
+                           n_valid_dev, (long long)N, h, plan.rows_per_block, partial, drop);                                \
     else                                                                                                                     \
         PHC_LAUNCH((bn_bwd_partial_kernel<ACTC, 1>), dim3(plan.num_partials), dim3(BN_THREADS), 0, s, dy, x, save_stat,    \
-                           n_valid_dev, (long long)N, h, plan.rows_per_block, partial)
+                           n_valid_dev, (long long)N, h, plan.rows_per_block, partial, drop)
         PHC_BN_ACT_SWITCH(act, PHC_BN_BP)
 #undef PHC_BN_BP
         rc = check_launch("bn_bwd_partial");
@@ -705,7 +786,7 @@ int phc_bn_bwd(const float *dy, const float *x, const float *save_stat, const in
     ProfScope prof(K_BN_BWD_APPLY, s);
 #define PHC_BN_BA(ACTC)                                                                                                      \
     PHC_LAUNCH((bn_bwd_apply_kernel<ACTC>), dim3(apply_grid(N, h)), dim3(BN_THREADS), lds, s, dy, x, save_stat,             \
-                       n_valid_dev, (long long)N, h, bstat, dx)
+                       n_valid_dev, (long long)N, h, bstat, dx, drop)
     PHC_BN_ACT_SWITCH(act, PHC_BN_BA)
 #undef PHC_BN_BA
     return check_launch("bn_bwd_apply");
@@ -741,6 +822,13 @@ int phc_bn_bwd_from_partials(const float *dy, const float *x, const float *save_
     PHC_BN_ACT_SWITCH(act, PHC_BN_BAP)
 #undef PHC_BN_BAP
     return check_launch("bn_bwd_apply");
+}
+
+int phc_rng_advance(uint64_t *rng_state, void *stream) {
+    PHC_REQUIRE(rng_state, PHC_ERR_INVALID_ARG, "phc_rng_advance: null state");
+    hipStream_t s = (hipStream_t)stream;
+    PHC_LAUNCH(rng_advance_kernel, dim3(1), dim3(1), 0, s, reinterpret_cast<unsigned long long *>(rng_state));
+    return check_launch("rng_advance");
 }
 
 // ---- row-sharded batch-norm: the four phases between which the host places its two collectives -------------------

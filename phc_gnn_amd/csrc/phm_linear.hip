@@ -308,6 +308,18 @@ __global__ __launch_bounds__((GemmCfg<BM, BN>::THREADS)) void phm_gemm_kernel(
 //     its 32x32 result tiles through the same buffer and stores 16 bytes per lane.
 //   Waves of one SIMD drift apart, so one wave's loads/stores overlap another's MFMAs.
 // ------------------------------------------------------------------------------------------
+#ifdef PHC_KTIMING
+// experiment build only: wave 0 of the first and the last workgroup stamp the phases of the launch (100 MHz wall clock)
+__device__ unsigned long long g_st_ts[64];
+#define ST_STAMP(i)                                                                                              \
+    do {                                                                                                         \
+        if (threadIdx.x == 0 && ((blockIdx.x == 0 && blockIdx.y == 0) || (blockIdx.x == gridDim.x - 1 && blockIdx.y == gridDim.y - 1))) \
+            g_st_ts[(blockIdx.y == 0 ? 0 : 32) + (i)] = wall_clock64();                                          \
+    } while (0)
+#else
+#define ST_STAMP(i)
+#endif
+
 constexpr int ST_KH = 64;                       // k columns staged per step
 constexpr int ST_STRIDE = ST_KH + 4;            // floats; conflict-free ds_read_b128 of the A operand
 constexpr int ST_FLOATS = 32 * ST_STRIDE;       // private staging floats per wave (8.5 KiB); also holds a 32x36 output tile
@@ -352,6 +364,7 @@ __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
     const int r = lane & 31, hh = lane >> 5;
     const int j0 = pbx * BN;
     float *stage = stage_all + wave * ST_FLOATS;
+    ST_STAMP(0);
 
     const long long num_slabs = (M + 31) / 32;
     long long slab = (long long)pby * WAVES + wave;
@@ -465,6 +478,7 @@ __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
     }
 #endif
     __syncthreads();
+    ST_STAMP(1);
 
     for (; slab < num_slabs; slab += slab_step) {
         f32x16 acc[CT];
@@ -514,6 +528,7 @@ __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
             else if (slab + slab_step < num_slabs) load_half(slab + slab_step, 0);
 #endif
 
+            ST_STAMP(2 + 2 * half);
             const float *xrow = stage + r * ST_STRIDE + 4 * hh;
             const float *hcol = hs + (k0 + 4 * hh) * HS_STRIDE + r;
 #ifdef PHC_EXP_NO_MFMA
@@ -537,6 +552,7 @@ __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
             }
         }
 
+        ST_STAMP(6);
         const long long row_base = slab * 32;
         if constexpr (ST) {
             // rows of this slab that count: [row_base, min(row_base + 32, st_count))
@@ -634,6 +650,7 @@ __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
             }
         }
     }
+    ST_STAMP(7);
     if constexpr (BW) {
         // lanes sharing (lane & 7) hold the same 4 columns for different rows: fold them, then the WAVES wavefronts in order
 #pragma unroll
@@ -713,6 +730,7 @@ __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
             if (pbx == 0 && cc == 0) stats_counts[pby] = nt;
         }
     }
+    ST_STAMP(8);
 }
 
 // H[k, j] for the whole matrix (exported helper; the hot kernels do not use it).
@@ -1199,6 +1217,12 @@ int launch_grad_rest(const char *who, const GradLaunch &gl, bool partial64_too, 
 using namespace phc;
 
 extern "C" {
+
+#ifdef PHC_KTIMING
+int phc_debug_stream_timestamps(unsigned long long *out64) {
+    return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_st_ts), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;
+}
+#endif
 
 int phc_phm_build_H(const float *A, const float *W, int n, int kin, int kout, float *H, void *stream) {
     int rc = check_phm_dims("phc_phm_build_H", 0, n, kin, kout);

@@ -29,7 +29,7 @@ import torch
 
 from . import synth
 from .graph import cached_structures_of, clear_structure_cache
-from .harness import StepConfig, apply_weight_regulariser, loss_fn, optimizer_step
+from .harness import StepConfig, advance_dropout_rng, apply_weight_regulariser, loss_fn, optimizer_step
 from .ops import deferred_param_grads, dense_weights, phm_pairs, prebuilt_H
 
 
@@ -274,6 +274,7 @@ class GraphedTrainStep:
     def _front(self, bs: _BatchSet):
         """zero_grad, forward, loss, backward (+ pack the gradients into the flat all-reduce bucket)."""
         self.optimizer.zero_grad(set_to_none=True)
+        advance_dropout_rng(self.model, bs.data)
         with prebuilt_H(self._pairs, self._dense), deferred_param_grads():
             logits = self.model(bs.data)
             loss = loss_fn(logits, bs.data, self.cfg.regression)

@@ -126,6 +126,7 @@ def train_step(model, data, optimizer: Optional[torch.optim.Optimizer], cfg: Ste
     else:
         for p in model.parameters():
             p.grad = None
+    advance_dropout_rng(model, data)
     # operand matrices of all PHM layers: one launch; dW/dA/db of all layers: three batched launches after the backward
     with prebuilt_H(phm_pairs(model), dense_weights(model)), deferred_param_grads():
         logits = model(data)
@@ -137,6 +138,14 @@ def train_step(model, data, optimizer: Optional[torch.optim.Optimizer], cfg: Ste
     if optimizer is not None and cfg.optimizer:
         optimizer_step(model, optimizer, cfg)
     return loss
+
+
+def advance_dropout_rng(model, data) -> None:
+    """New dropout masks for this step (one tiny launch, only for models that drop anything: the reference's defaults do,
+    --dropout_mpnn 0.3,0.1 / --dropout_dn 0.3,0.1; the BASELINE configs do not)."""
+    from .ops import model_uses_dropout, rng_advance
+    if model_uses_dropout(model):
+        rng_advance(data.x.device)
 
 
 def apply_weight_regulariser(model, loss: torch.Tensor, cfg: StepConfig) -> None:

@@ -80,7 +80,7 @@ SIGNATURES = {
     "phc_gemm_stats_max_partials": (_I, []),
     "phc_gemm_prebuilt_stats": (_I, [_P, _P, _P, _L, _I, _I, _P, _P, _P, _P, C.POINTER(_I), _P]),
     "phc_bn_fwd_from_partials": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _L, _I, C.c_float, C.c_float, _I, _P, _P, _P,
-                                      _P]),
+                                      C.c_float, _I, _I, _P, _P]),
     "phc_bn_finalize_from_partials": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _L, _I, C.c_float, C.c_float, _P, _P]),
     "phc_gemm_prebuilt_xf": (_I, [_P, _P, _I, _P, _P, _P, _L, _I, _I, _P, _P, _P, C.POINTER(_I), _P]),
     "phc_gemm_prebuilt_bwsums": (_I, [_P, _P, _L, _I, _I, _P, _P, _P, _I, _P, _P, C.POINTER(_I), _P]),
@@ -135,8 +135,10 @@ SIGNATURES = {
     "phc_step_tail": (_I, [C.POINTER(GradJob), _I, C.POINTER(TableGradJob), _I, _P, _P, _P, _P, _L, _I, _I, _P, _P, _L, _P, _P, _L, _I,
                            _P, _P, _I, _I, _P, _S, _P]),
     "phc_bn_ws_bytes": (_S, [_L, _I]),
-    "phc_bn_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _L, _I, _I, C.c_float, C.c_float, _I, _P, _P, _P, _P, _S, _P]),
-    "phc_bn_bwd": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _S, _P]),
+    "phc_bn_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _L, _I, _I, C.c_float, C.c_float, _I, _P, _P, _P, _P, _S, C.c_float, _I, _I,
+                        _P, _P]),
+    "phc_bn_bwd": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _S, C.c_float, _I, _I, _P, _P]),
+    "phc_rng_advance": (_I, [_P, _P]),
     "phc_bce_masked_ws_bytes": (_S, [_L]),
     "phc_bce_masked_fwd": (_I, [_P, _P, _L, _P, _P, _P, _S, _P]),
     "phc_bce_masked_bwd": (_I, [_P, _P, _P, _P, _L, _P, _P]),

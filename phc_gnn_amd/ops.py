@@ -1528,10 +1528,36 @@ def _ptr_array(tensors):
 
 
 
+# ---- dropout fused behind the norm's activation (include/phc_hip.h: phc_bn_fwd / phc_rng_advance) ----
+_RNG_STATE: dict = {}
+
+
+def rng_state(dev) -> torch.Tensor:
+    """Device int64 [2] = {seed, step} behind the engine's fused dropout masks (seeded from torch's generator at first use)."""
+    st = _RNG_STATE.get(dev)
+    if st is None:
+        st = _RNG_STATE[dev] = torch.tensor([torch.initial_seed() & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64, device=dev)
+    return st
+
+
+def rng_seed(dev, seed: int) -> None:
+    rng_state(dev).copy_(torch.tensor([int(seed) & 0x7FFFFFFFFFFFFFFF, 0], dtype=torch.int64))
+
+
+def rng_advance(dev) -> None:
+    """One tiny launch per training step: the next forward / backward pair draws new dropout masks (capturable)."""
+    L.check(L.load().phc_rng_advance(L.ptr(rng_state(dev)), L.stream_ptr(dev)), "phc_rng_advance")
+
+
+def model_uses_dropout(model) -> bool:
+    return bool(model.training and (any(p > 0.0 for p in getattr(model, "dropout_mpnn", []) or [])
+                                    or any(p > 0.0 for p in (getattr(getattr(model, "downstream", None), "dropout", None) or []))))
+
+
 class _BatchNormActFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, residual, n_valid, running_mean, running_var, nbt, training, momentum, eps, act, n_comp, pre_stats,
-                *affine):
+                dropout, *affine):
         lib = L.load()
         dev = L.require_device(x, residual)
         x_ = L.f32c(x)
@@ -1546,11 +1572,17 @@ class _BatchNormActFn(torch.autograd.Function):
         nbt_arr = _ptr_array(nbt) if nbt else None
         out = torch.empty_like(x_)
         save_stat = torch.empty(6 * h, dtype=torch.float32, device=dev)   # mean|invstd|scale|shift|w|b per column
+        # dropout = (p, same, site) or None: phm_dropout behind the activation, mask regenerated in the backward
+        drop = (0.0, 0, 0, None)
+        if dropout is not None and training and dropout[0] > 0.0:
+            drop = (float(dropout[0]), (h // n_comp) if dropout[1] else 0, int(dropout[2]), rng_state(dev))
+        ctx.drop = drop
         if pre_stats is not None:               # statistics already emitted by the GEMM that produced x
             L.check(lib.phc_bn_fwd_from_partials(L.ptr(x_), L.ptr(pre_stats.partial), L.ptr(pre_stats.counts), pre_stats.num,
                                                  w_arr, b_arr, rm_arr, rv_arr, nbt_arr, n_comp, L.ptr(n_valid), N, h,
                                                  float(momentum), float(eps), act, L.ptr(res_), L.ptr(out), L.ptr(save_stat),
-                                                 L.stream_ptr(dev)), "phc_bn_fwd_from_partials")
+                                                 drop[0], drop[1], drop[2], L.ptr(drop[3]), L.stream_ptr(dev)),
+                    "phc_bn_fwd_from_partials")
             if L.PROF_ON:
                 L.account("bn_apply", 2.0 * N * h, 4.0 * N * h * (3 if residual is not None else 2))
             ctx.save_for_backward(x_, save_stat)
@@ -1560,7 +1592,7 @@ class _BatchNormActFn(torch.autograd.Function):
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         L.check(lib.phc_bn_fwd(L.ptr(x_), w_arr, b_arr, rm_arr, rv_arr, nbt_arr, n_comp, L.ptr(n_valid), N, h,
                                1 if training else 0, float(momentum), float(eps), act, L.ptr(res_), L.ptr(out),
-                               L.ptr(save_stat), L.ptr(ws), ws_bytes, L.stream_ptr(dev)),
+                               L.ptr(save_stat), L.ptr(ws), ws_bytes, drop[0], drop[1], drop[2], L.ptr(drop[3]), L.stream_ptr(dev)),
                 "phc_bn_fwd")
         if L.PROF_ON:
             if training:
@@ -1579,13 +1611,14 @@ class _BatchNormActFn(torch.autograd.Function):
         dev = dout_.device
         N, h = x_.shape
         need_x = ctx.needs_input_grad[0]
-        need_aff = has_affine and any(ctx.needs_input_grad[12:])
+        need_aff = has_affine and any(ctx.needs_input_grad[13:])
+        drop = ctx.drop
         dx = torch.empty_like(x_) if need_x else None
         dwb = torch.empty(2 * h, dtype=torch.float32, device=dev) if need_aff else None
         ws_bytes = lib.phc_bn_ws_bytes(N, h)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         L.check(lib.phc_bn_bwd(L.ptr(dout_), L.ptr(x_), L.ptr(save_stat), L.ptr(n_valid), N, h, 1 if training else 0, act,
-                               L.ptr(dx), L.ptr(dwb), L.ptr(ws), ws_bytes, L.stream_ptr(dev)),
+                               L.ptr(dx), L.ptr(dwb), L.ptr(ws), ws_bytes, drop[0], drop[1], drop[2], L.ptr(drop[3]), L.stream_ptr(dev)),
                 "phc_bn_bwd")
         if L.PROF_ON:
             L.account("bn_bwd_partial", 6.0 * N * h, 8.0 * N * h)
@@ -1599,7 +1632,7 @@ class _BatchNormActFn(torch.autograd.Function):
             else:
                 aff_grads = [None] * (2 * n_comp)
         dres = dout if (has_res and ctx.needs_input_grad[1]) else None
-        return (dx, dres, None, None, None, None, None, None, None, None, None, None, *aff_grads)
+        return (dx, dres, None, None, None, None, None, None, None, None, None, None, None, *aff_grads)
 
 
 # the norm backward's column sums come out of the dz GEMM's epilogue (False: separate bn_bwd_partial pass)
@@ -1699,7 +1732,7 @@ class _BNActLinearFn(torch.autograd.Function):
             ws_bytes = lib.phc_bn_ws_bytes(N, h)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
             L.check(lib.phc_bn_bwd(L.ptr(dz), L.ptr(x), L.ptr(save_stat), L.ptr(n_valid), N, h, 1, act, L.ptr(dx), L.ptr(dwb),
-                                   L.ptr(ws), ws_bytes, L.stream_ptr(dev)), "phc_bn_bwd")
+                                   L.ptr(ws), ws_bytes, 0.0, 0, 0, None, L.stream_ptr(dev)), "phc_bn_bwd")
         if L.PROF_ON:
             if not fused_sums:
                 L.account("bn_bwd_partial", 6.0 * N * h, 8.0 * N * h)
@@ -1739,7 +1772,7 @@ def bn_act_linear(x: torch.Tensor, weights, biases, running_mean, running_var, n
 
 def batch_norm_act(x: torch.Tensor, weights, biases, running_mean, running_var, num_batches_tracked, training: bool,
                    momentum: float, eps: float, activation: str = "identity", residual: Optional[torch.Tensor] = None,
-                   n_valid: Optional[torch.Tensor] = None) -> torch.Tensor:
+                   n_valid: Optional[torch.Tensor] = None, dropout=None) -> torch.Tensor:
     """out = act(batch_norm(x)) (+ residual) over the rows of component-major x [N, h].
 
     ``weights`` / ``biases`` / running statistics are lists with one [h/n] tensor per hypercomplex
@@ -1754,7 +1787,7 @@ def batch_norm_act(x: torch.Tensor, weights, biases, running_mean, running_var, 
     return _BatchNormActFn.apply(x, residual, n_valid, list(running_mean) if running_mean else None,
                                  list(running_var) if running_var else None,
                                  list(num_batches_tracked) if num_batches_tracked else None, training, momentum, eps,
-                                 _act_id(activation), n_comp, pre, *affine)
+                                 _act_id(activation), n_comp, pre, dropout, *affine)
 
 
 # ---------------------------------------------------------------------------

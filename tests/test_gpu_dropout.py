@@ -1,0 +1,105 @@
+"""Dropout behind the norm's activation inside the engine pass (phc_bn_fwd / phc_bn_bwd with a Philox mask regenerated in
+the backward): the structure the reference's phm_dropout guarantees (layers.py:31-55, its own test
+test_ops_equal_quaternion.py:64-103: entries are 0 or x / (1 - p); `same=True` shares the mask between the hypercomplex
+components), exact gradients for the mask that was drawn, a fresh mask per step under hipGraph replay."""
+import pytest
+import torch
+
+from tests._util import TOL, assert_close
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda:0"
+
+
+def _setup(n, h, N, seed):
+    g = torch.Generator().manual_seed(seed)
+    k = h // n
+    x = torch.randn(N, h, generator=g) * 1.5 + 0.3
+    res = torch.randn(N, h, generator=g)
+    dy = torch.randn(N, h, generator=g)
+    w = [torch.rand(k, generator=g) + 0.5 for _ in range(n)]
+    b = [torch.randn(k, generator=g) * 0.1 for _ in range(n)]
+    return x, res, dy, w, b, k
+
+
+@pytest.mark.parametrize("same", [False, True])
+@pytest.mark.parametrize("act", ["swish", "relu"])
+def test_fused_dropout_structure_and_gradients(same, act):
+    from oracle import phc_oracle as O
+    from phc_gnn_amd import ops
+    n, h, N, p = 4, 128, 1031, 0.3
+    x, res, dy, w, b, k = _setup(n, h, N, 5)
+    dev = torch.device(DEV)
+    ops.rng_seed(dev, 1234)
+
+    def run(dropout, act=act):
+        xd, rd = x.to(DEV).requires_grad_(), res.to(DEV).requires_grad_()
+        wd, bd = [t.to(DEV).requires_grad_() for t in w], [t.to(DEV).requires_grad_() for t in b]
+        rm, rv = [torch.zeros(k, device=DEV) for _ in range(n)], [torch.ones(k, device=DEV) for _ in range(n)]
+        out = ops.batch_norm_act(xd, wd, bd, rm, rv, None, True, 0.1, 1e-5, act, rd, None, dropout)
+        grads = torch.autograd.grad(out, [xd, rd] + wd + bd, dy.to(DEV))
+        return out.detach().cpu(), [g_.cpu() for g_ in grads]
+    plain, _ = run(None)
+    out, grads = run((p, same, 3))
+    # the mask is a function of (seed, step, site, row, channel) only: read it off a run with the identity activation, where
+    # the un-dropped value is non-zero everywhere
+    probe, _ = run((p, same, 3), act="identity")
+    dropped = (probe - res).abs() <= 1e-9
+    mask = (~dropped).float()
+    frac = float(dropped.sum()) / dropped.numel()
+    assert abs(frac - p) < 0.01, frac
+    y0 = plain - res                                   # act(norm(x))
+    y1 = out - res                                     # the same after dropout
+    assert_close(y1, y0 * mask / (1 - p), TOL, "every entry is either dropped or scaled by 1 / (1 - p)")
+    if same:
+        m3 = dropped.view(N, n, k)
+        assert bool((m3 == m3[:, :1]).all()), "same=True: one mask per (row, channel), shared by the components"
+    else:
+        m3 = dropped.view(N, n, k)
+        assert not bool((m3 == m3[:, :1]).all())
+    # gradients for exactly this mask, through the oracle's norm
+    xr, rr = x.clone().requires_grad_(), res.clone().requires_grad_()
+    wr, br = [t.clone().requires_grad_() for t in w], [t.clone().requires_grad_() for t in b]
+    rm, rv = [torch.zeros(k) for _ in range(n)], [torch.ones(k) for _ in range(n)]
+    y = O.activation(act, O.batch_norm_naive(xr, n, wr, br, rm, rv, True)) * (mask / (1 - p)) + rr
+    ref_g = torch.autograd.grad(y, [xr, rr] + wr + br, dy)
+    assert_close(grads[0], ref_g[0], 3e-5, "dx")
+    assert torch.equal(grads[1], dy)
+    for a_, r_ in zip(grads[2:], ref_g[2:]):
+        assert_close(a_, r_, 5e-5, "dw / db")
+    # same (seed, step, site) -> same mask; another site or the next step -> another mask
+    again, _ = run((p, same, 3))
+    assert torch.equal(again, out)
+    other, _ = run((p, same, 4))
+    assert not torch.equal(other, out)
+    ops.rng_advance(dev)
+    nxt, _ = run((p, same, 3))
+    assert not torch.equal(nxt, out)
+
+
+def test_training_step_with_the_reference_default_dropout_under_graph_replay():
+    """--dropout_mpnn 0.3,0.1,... / --dropout_dn 0.3,0.1 (train_hiv.py:99,110) through the captured step: finite losses, a
+    different mask every replay (same batch, frozen weights => different losses), eval mode unaffected."""
+    from phc.hypercomplex.undirectional.models import PHMSkipConnectAdd
+    from phc_gnn_amd import graphed, harness
+    from phc_gnn_amd.optim import ClipAdam
+    w = dict(harness.WORKLOADS["molhiv_b32"])
+    kw = harness.model_kwargs(w)
+    kw.update(dropout_mpnn=[0.3, 0.1, 0.1, 0.1], dropout_dn=[0.3, 0.1], same_dropout=True)
+    torch.manual_seed(0)
+    model = PHMSkipConnectAdd(**kw).to(DEV).train()
+    gb = harness.make_batch("molhiv_b32", seed=3)
+    n_max, e_max = graphed.bucket_shape([gb])
+    padded = graphed.padded_to_device(graphed.pad_batch(gb, n_max, e_max), DEV)
+    cfg = harness.StepConfig(optimizer=False)
+    step = graphed.GraphedTrainStep(model, ClipAdam(model.parameters(), lr=1e-3), cfg, padded, warmup=2)
+    losses = [float(step.step(padded)) for _ in range(6)]
+    assert all(l == l and abs(l) < 1e3 for l in losses), losses
+    assert len(set(losses)) == len(losses), losses                     # a new mask every replay
+    grads = [p.grad for p in model.parameters() if p.grad is not None]
+    assert len(grads) > 100 and all(bool(torch.isfinite(g_).all()) for g_ in grads)
+    model.eval()
+    with torch.no_grad():
+        a = model(step.data)
+        b = model(step.data)
+    assert torch.equal(a, b)
