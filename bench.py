@@ -305,9 +305,11 @@ def bench_large_graph(args, world, rank, dev):
                   "aggregate_hbm": {"achieved_GBs": round(agg_b / (agg_t * 1e-3) / 1e9, 1) if agg_t else None, "peak": PEAK_HBM_GBS,
                                     "frac": round(agg_b / (agg_t * 1e-3) / 1e9 / PEAK_HBM_GBS, 4) if agg_t else None},
                   "verified_rank0": verified, "per_rank": gathered}
-        print(json.dumps(result), flush=True)
     dist.barrier()
     dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        print(json.dumps(result), flush=True)          # after RCCL's own shutdown banner: the JSON line is the LAST line of stdout
 
 
 def main():
@@ -518,12 +520,13 @@ def main():
                 # the secondary denominator, every core of the GPU host (count stated)
                 result["cpu_baseline_all_cores"] = cpu_baseline(args, args.workload, model, host_batches[0], threads=all_cores,
                                                                 steps=max(5, args.cpu_steps // 2))
-        print(json.dumps(result), flush=True)
-
     if world > 1 or force_sync:
         import torch.distributed as dist
         dist.barrier()
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        print(json.dumps(result), flush=True)          # after RCCL's own shutdown banner: the JSON line is the LAST line of stdout
 
 
 if __name__ == "__main__":
