@@ -314,6 +314,124 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const float *__res
     }
 }
 
+// ---- forward, ONE launch: the statistics merge in the prologue of the normalisation (partials emitted by a GEMM) -------
+// The separate merge launch (bn_finalize_kernel: 16 workgroups, two dependent rounds of loads) costs 7.7 us of a replayed step
+// (profiles/r01v_ablation_in_graph_costs.txt) for a few hundred KB.  Here a workgroup owns 32 COLUMNS x a row range: its 256
+// threads (32 columns x 8 partial lanes) merge the <= 256 (sum, M2) pairs of those 32 columns — all loads of a lane in flight
+// together, Chan's formula, fixed order — and then normalise their rows; the first row range also writes save_stat and the
+// running statistics.  27 KB of partials per workgroup instead of a launch boundary.
+constexpr int BNM_COLS = 32;
+constexpr int BNM_LANES = BN_THREADS / BNM_COLS;            // 8
+// PL = partials per lane: 16 serves <= 128 partials (the molecule-scale GEMM emits 108) with half the loads in flight
+template <int ACT, int PL>
+__global__ __launch_bounds__(BN_THREADS) void bn_apply_merged_kernel(const float *__restrict__ x, BnParams p, const int *__restrict__ n_valid,
+                                                                   long long N, int h, float momentum, float eps,
+                                                                   const float *__restrict__ partial, const float *__restrict__ counts,
+                                                                   int num_partials, long long rows_per_group,
+                                                                   const float *__restrict__ residual, float *__restrict__ stat,
+                                                                   float *__restrict__ out, BnDrop drop = BnDrop{}) {
+    __shared__ float r_a[BNM_LANES][BNM_COLS], r_b[BNM_LANES][BNM_COLS], s_scale[BNM_COLS], s_shift[BNM_COLS];
+    const int tid = threadIdx.x;
+    const int ci = tid & (BNM_COLS - 1), pl = tid / BNM_COLS;
+    const int c = blockIdx.x * BNM_COLS + ci;                 // h % 32 == 0
+    const long long count = n_valid ? min((long long)*n_valid, N) : N;
+    const bool dropping = drop.p > 0.f;
+    const unsigned long long seed = dropping ? drop.state[0] : 0ull, step = dropping ? drop.state[1] : 0ull;
+    // this thread's partials: b = pl + 8 u
+    float ps[PL], pm[PL], pn[PL];
+#pragma unroll
+    for (int u = 0; u < PL; ++u) {
+        const int b = min(pl + BNM_LANES * u, num_partials - 1);
+        ps[u] = partial[(size_t)b * 2 * h + c];
+        pm[u] = partial[(size_t)b * 2 * h + h + c];
+        pn[u] = counts[b];
+    }
+    // affine parameters / running statistics of the owner threads go in flight too (uniform walk of the pointer tables)
+    const int comp = c / p.k, kk = c - comp * p.k;
+    float w = 1.f, bq = 0.f, rm_old = 0.f, rv_old = 1.f;
+    if (pl == 0) {
+        for (int q = 0; q < p.n_comp; ++q)
+            if (q == comp) {
+                if (p.has_weight) w = p.weight[q][kk];
+                if (p.has_bias) bq = p.bias[q][kk];
+                if (p.has_running && blockIdx.y == 0) { rm_old = p.running_mean[q][kk]; rv_old = p.running_var[q][kk]; }
+            }
+    }
+    float sl = 0.f;
+#pragma unroll
+    for (int u = 0; u < PL; ++u) sl += (pl + BNM_LANES * u < num_partials) ? ps[u] : 0.f;
+    r_a[pl][ci] = sl;
+    __syncthreads();
+    float tot = 0.f;
+#pragma unroll
+    for (int l = 0; l < BNM_LANES; ++l) tot += r_a[l][ci];
+    const float cnt = (float)max(count, 1LL);
+    const float mean = tot / cnt;
+    float m2 = 0.f;
+#pragma unroll
+    for (int u = 0; u < PL; ++u) {
+        const bool in = pl + BNM_LANES * u < num_partials;
+        if (in && pn[u] > 0.f) {
+            const float d = ps[u] / pn[u] - mean;
+            m2 += pm[u] + pn[u] * d * d;
+        }
+    }
+    r_b[pl][ci] = m2;
+    __syncthreads();
+    if (pl == 0) {
+        float M2 = 0.f;
+#pragma unroll
+        for (int l = 0; l < BNM_LANES; ++l) M2 += r_b[l][ci];
+        const float var = fmaxf(M2 / cnt, 0.f);
+        const float invstd = 1.f / sqrtf(var + eps);
+        s_scale[ci] = invstd * w;
+        s_shift[ci] = bq - mean * invstd * w;
+        if (blockIdx.y == 0) {
+            stat[c] = mean;
+            stat[h + c] = invstd;
+            stat[2 * h + c] = invstd * w;
+            stat[3 * h + c] = bq - mean * invstd * w;
+            stat[4 * h + c] = w;
+            stat[5 * h + c] = bq;
+            if (p.has_running) {
+                const float unbiased = count > 1 ? M2 / (cnt - 1.f) : var;
+                for (int q = 0; q < p.n_comp; ++q)
+                    if (q == comp) {
+                        p.running_mean[q][kk] = (1.f - momentum) * rm_old + momentum * mean;
+                        p.running_var[q][kk] = (1.f - momentum) * rv_old + momentum * unbiased;
+                    }
+            }
+        }
+    }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && p.has_nbt && tid < p.n_comp)
+        for (int q = 0; q < p.n_comp; ++q)
+            if (q == tid) *p.num_batches_tracked[q] += 1;
+    __syncthreads();
+    // rows of this group: thread -> (row lane = tid / 8, float4 column = tid % 8)
+    const int c4 = tid & 7, rl = tid >> 3;
+    const int col = blockIdx.x * BNM_COLS + c4 * 4;
+    const float4 sc4 = *reinterpret_cast<const float4 *>(s_scale + c4 * 4), sh4 = *reinterpret_cast<const float4 *>(s_shift + c4 * 4);
+    const long long r0 = (long long)blockIdx.y * rows_per_group, r1 = min(N, r0 + rows_per_group);
+    for (long long r = r0 + rl; r < r1; r += BN_THREADS / 8) {
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        const size_t e = (size_t)r * h + col;
+        if (r < count) {
+            const float4 v = *reinterpret_cast<const float4 *>(x + e);
+            o.x = bn_act<ACT>(fmaf(v.x, sc4.x, sh4.x)); o.y = bn_act<ACT>(fmaf(v.y, sc4.y, sh4.y));
+            o.z = bn_act<ACT>(fmaf(v.z, sc4.z, sh4.z)); o.w = bn_act<ACT>(fmaf(v.w, sc4.w, sh4.w));
+            if (dropping) {
+                const float4 f = drop_factors(drop, seed, step, r, col, h);
+                o.x *= f.x; o.y *= f.y; o.z *= f.z; o.w *= f.w;
+            }
+            if (residual) {
+                const float4 rr = *reinterpret_cast<const float4 *>(residual + e);
+                o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+            }
+        }
+        *reinterpret_cast<float4 *>(out + e) = o;
+    }
+}
+
 // ---- pass 1 (backward): sum g and sum g*x_hat per column ------------------------------------------
 template <int ACT, int VEC>
 __global__ __launch_bounds__(BN_THREADS) void bn_bwd_partial_kernel(const float *__restrict__ dy, const float *__restrict__ x,
@@ -720,6 +838,30 @@ int phc_bn_fwd_from_partials(const float *x, const float *stats_partial, const f
                       (!residual || (reinterpret_cast<uintptr_t>(residual) & 15) == 0);
     PHC_REQUIRE(vec4 || h % 4 != 0, PHC_ERR_UNSUPPORTED, "phc_bn_fwd_from_partials: rows must be 16-byte aligned when h %% 4 == 0");
     hipStream_t s = (hipStream_t)stream;
+    const char *env_merged = getenv("PHC_BN_APPLY_MERGED");               // A/B switch (read per call: cheap next to a launch)
+    const bool no_merged = env_merged && atoi(env_merged) == 0;
+    if (vec4 && h % BNM_COLS == 0 && !no_merged) {
+        // one launch: the merge of the partials rides in the prologue of the normalisation
+        long long groups = (N + 127) / 128;                      // >= 128 rows per workgroup
+        const long long cap = (8LL * 256) / (h / BNM_COLS);      // ~8 workgroups per CU at most
+        if (groups > cap) groups = cap;
+        if (groups < 1) groups = 1;
+        const long long rows_per_group = (N + groups - 1) / groups;
+        groups = (N + rows_per_group - 1) / rows_per_group;
+        ProfScope prof(K_BN_APPLY, s);
+#define PHC_BN_FWDM2(ACTC)                                                                                                     \
+    if (num_partials <= 16 * BNM_LANES)                                                                                        \
+        PHC_LAUNCH((bn_apply_merged_kernel<ACTC, 16>), dim3(h / BNM_COLS, (unsigned)groups), dim3(BN_THREADS), 0, s, x, p, n_valid_dev, \
+                   (long long)N, h, momentum, eps, stats_partial, stats_counts, num_partials, rows_per_group, residual, save_stat, out, \
+                   drop);                                                                                                       \
+    else                                                                                                                       \
+        PHC_LAUNCH((bn_apply_merged_kernel<ACTC, 32>), dim3(h / BNM_COLS, (unsigned)groups), dim3(BN_THREADS), 0, s, x, p, n_valid_dev, \
+                   (long long)N, h, momentum, eps, stats_partial, stats_counts, num_partials, rows_per_group, residual, save_stat, out, \
+                   drop)
+        PHC_BN_ACT_SWITCH(act, PHC_BN_FWDM2)
+#undef PHC_BN_FWDM2
+        return check_launch("bn_apply_merged");
+    }
     {
         ProfScope prof(K_BN_FINALIZE, s);
         PHC_LAUNCH(bn_finalize_kernel, dim3((h + 7) / 8), dim3(BN_THREADS), 0, s, p, n_valid_dev, (long long)N, h, 1, momentum, eps,

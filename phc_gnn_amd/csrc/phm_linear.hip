@@ -982,6 +982,11 @@ static int launch_stream_cfg(const float *X, const float *A, const float *W, con
     const int64_t max_gy = (slabs + WAVES - 1) / WAVES;
     if (gy > max_gy) gy = max_gy;
     if ((STATS & 5) && gy > GEMM_STATS_MAX_PARTIALS) gy = GEMM_STATS_MAX_PARTIALS;      // one statistics partial per workgroup row
+    {
+        // experiment: fewer, longer workgroup rows for the statistics-emitting launches (fewer partials to merge downstream)
+        static const int cap = getenv("PHC_GEMM_STATS_GY") ? atoi(getenv("PHC_GEMM_STATS_GY")) : 0;
+        if ((STATS & 1) && cap > 0 && gy > cap) gy = cap;
+    }
     if (gy < 1) gy = 1;
     if (num_partials) *num_partials = (int)gy;
     const size_t lds = sizeof(float) * ((size_t)round_up(K, 8) * (BN + 1) + (size_t)WAVES * ST_FLOATS + (size_t)n * n * n);

@@ -924,7 +924,10 @@ def test_fanout_sums_gradients_in_one_pass(ops):
 
 @pytest.mark.parametrize("n,k,N,valid,act,deferred", [(4, 32, 13824, 12874, "relu", True), (4, 32, 500, None, "swish", True),
                                                       (2, 64, 333, 300, "relu", False), (8, 32, 700, None, "identity", True),
-                                                      (4, 32, 70001, 69000, "relu", True),        # 128-column / 8-wave configs
+                                                      # 128-column / 8-wave configs; a smooth activation: at 9 M pre-activations
+                                                      # some sit within an ulp of the ReLU kink and the two fp32 paths gate them
+                                                      # differently (one flipped gate = one dx row off by 1e-1)
+                                                      (4, 32, 70001, 69000, "swish", True),
                                                       (4, 64, 66000, None, "elu", True)])         # K = 256, 64-column / 8-wave
 @pytest.mark.parametrize("bwd_sums", ["in_gemm", "separate_pass"])
 def test_bn_act_linear_without_materialising_the_normalised_activation(ops, n, k, N, valid, act, deferred, bwd_sums, monkeypatch):
