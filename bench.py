@@ -38,15 +38,15 @@ import torch  # noqa: E402
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s HBM3E
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
 MFMA_KERNELS = ("phm_gemm_fwd", "phm_gemm_dx", "phm_dH_partial", "table_grad")
-# launch-profiler kernel name -> substring of the rocprofv3 kernel name in profiles/r01v_pmc_traffic.json
+# launch-profiler kernel name -> substring of the rocprofv3 kernel name in profiles/<PMC_FILE>
 PMC_NAMES = {"phm_gemm_fwd": "phm_stream_kernel<0, -1, 32, 4, 1>", "phm_gemm_dx": "phm_stream_kernel<0, -1, 32, 4, 0>",
-             "phm_dH_partial": "tail_partial_kernel", "aggregate_enc_fwd": "aggregate_enc_fwd_kernel",
+             "phm_dH_partial": "tail_partial_kernel", "aggregate_enc_fwd": "aggregate_encp_direct_fwd_kernel",
              "aggregate_enc_dx": "aggregate_enc_dx_kernel", "aggregate_fwd": "aggregate_fwd_kernel",
-             "bn_apply": "bn_apply_kernel", "bn_bwd_apply": "bn_bwd_apply_kernel", "bn_bwd_partial": "bn_bwd_partial_kernel",
+             "bn_apply": "bn_apply_merged_kernel", "bn_bwd_apply": "bn_bwd_apply_kernel", "bn_bwd_partial": "bn_bwd_partial_kernel",
              "bn_stats_partial": "bn_stats_partial_kernel", "table_grad": "table_grad_mfma_kernel<1"}
 
 
-PMC_FILE = "r01v_pmc_traffic.json"
+PMC_FILE = "r02_pmc_traffic.json"
 
 
 def pmc_traffic(kernel: str):
