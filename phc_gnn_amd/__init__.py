@@ -4,7 +4,7 @@ import os as _os
 # HIP 7.0 / ROCm 7.2: the "graph packet capture" fast path of hipGraphLaunch loses the ordering between a replay
 # in flight and work queued behind it as soon as an event is recorded on the launch stream (every RCCL collective
 # and every Stream.wait_stream does that) or the launch goes to the null stream: the next batch's copy then
-# overwrites the static buffers of the running step (scripts/debug_pipelined.py reproduces the memory fault).
+# overwrites the static buffers of the running step (scripts/dbg/debug_pipelined.py reproduces the memory fault).
 # The regular enqueue path is correct and, for this step, equally fast (measured 1.43 ms/step either way).
 # The flag is read when the HIP runtime initialises, i.e. at the first torch.cuda call — import this package first.
 _os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")

@@ -224,7 +224,7 @@ class GraphedTrainStep:
         # NOTE: only a device-wide synchronize here.  Making the default stream wait on the capture stream
         # (Stream.wait_stream -> an event recorded on the just-captured stream) left the graph in a state where
         # later eager allocations made its replays fault on ROCm 7.x (the packet-capture ordering bug, DESIGN.md §5;
-        # scripts/debug_pipelined.py reproduces the family).
+        # scripts/dbg/debug_pipelined.py reproduces the family).
         torch.cuda.synchronize(dev)
         from .lib import check_indices
         check_indices(dev)                     # the example batch went through every index-reading kernel: bad ids raise here
@@ -316,7 +316,7 @@ class GraphedTrainStep:
         preprocessing starts now on the second stream.  Stream-ordered with the caller's current stream, but the copy
         and the graph launch themselves are issued on a dedicated NON-DEFAULT stream: on ROCm 7.2 a hipGraphLaunch into
         the legacy null stream is not ordered against the null-stream work queued behind it, so the next batch's copy
-        overwrote the static buffers of a replay still in flight (scripts/debug_bench_like.py reproduces the fault)."""
+        overwrote the static buffers of a replay still in flight (scripts/dbg/debug_bench_like.py reproduces the fault)."""
         cur = torch.cuda.current_stream(self.device)
         if cur != torch.cuda.default_stream(self.device):
             return self._issue(padded, next_padded)    # caller already runs on a side stream (`with step.on_stream():`)
