@@ -166,6 +166,14 @@ size_t phc_csr_ws_bytes(int64_t E, int64_t num_keys);
 int phc_csr_build(const int64_t *key_i64, const int64_t *other_i64, int64_t E, int64_t num_keys, int64_t num_other,
                   int32_t *rowptr, int32_t *col, int32_t *perm, void *ws, size_t ws_bytes, void *stream);
 
+/* The same result as phc_csr_build for LARGE key spaces (BASELINE config 5: 10 M keys, 50 M items), as a two-level
+ * counting sort: items are partitioned by key >> shift into <= 16384 buckets of consecutive keys (per-chunk LDS histograms,
+ * one global atomic per non-empty (chunk, bucket)), then one workgroup per bucket sorts its items with LDS counters and makes
+ * every row ascending in item id.  Needs E >= 1 and num_keys <= 16384 * 4096; ws: phc_csr_bucketed_ws_bytes. */
+size_t phc_csr_bucketed_ws_bytes(int64_t E, int64_t num_keys);
+int phc_csr_build_bucketed(const int64_t *key_i64, const int64_t *other_i64, int64_t E, int64_t num_keys, int64_t num_other,
+                           int32_t *rowptr, int32_t *col, int32_t *perm, void *ws, size_t ws_bytes, void *stream);
+
 /* rowptr[num_keys+1] for keys that are already NON-DECREASING (PyG's collated `batch`
  * vector: graph id per node): rowptr[s] = first position with key >= s.  Segment members are
  * then simply positions rowptr[s] .. rowptr[s+1]-1 (identity order).  Undefined result for

@@ -107,6 +107,152 @@ __global__ void sorted_segment_ptr_kernel(const long long *__restrict__ key, lon
     rowptr[s] = (int)lo;
 }
 
+// ---- large graphs: two-level counting sort ---------------------------------------------------------------------------
+// phc_csr_build's histogram / fill passes are 2 E random 4-byte atomics over num_keys counters and its canonicalising pass
+// gathers through them again: at 10 M keys / 50 M items every access is its own DRAM sector (12.5 ms for both views,
+// 2.8 % of HBM, profiles/r01_microbench_config5_1gpu.txt).  Here the items are first PARTITIONED by key >> shift into
+// <= 16384 buckets of 2^shift consecutive keys (LDS histograms per 64 K-item chunk, one global atomic per non-empty
+// (chunk, bucket) instead of one per item; the partition order inside a bucket is arbitrary), then ONE workgroup per bucket
+// runs the same histogram -> scan -> fill -> per-row rank sort on its ~5 K items with LDS counters, streaming the bucket's
+// (key, id) pairs from L2.  The result is identical to phc_csr_build's (the rank sort makes every row ascending in item id
+// whatever the arrival order was).
+constexpr int BK_MAX_BUCKETS = 16384;
+constexpr int BK_CHUNK = 65536;                              // items per partition workgroup
+constexpr int BK_THREADS = 256;
+constexpr int BK_MAX_KEYS_PER_BUCKET = 4096;                 // LDS counters of the per-bucket sort (2 x 16 KB)
+
+__global__ __launch_bounds__(BK_THREADS) void bk_count_kernel(const long long *__restrict__ key, long long E, long long num_keys, int shift,
+                                                             int nb, int *__restrict__ bucket_count, int *__restrict__ err, int err_bit) {
+    extern __shared__ int hist[];                            // [nb]
+    for (int b = threadIdx.x; b < nb; b += BK_THREADS) hist[b] = 0;
+    __syncthreads();
+    const long long e0 = (long long)blockIdx.x * BK_CHUNK, e1 = min(E, e0 + BK_CHUNK);
+    for (long long e = e0 + threadIdx.x; e < e1; e += BK_THREADS)
+        atomicAdd(&hist[(int)(checked_index(key[e], num_keys, err, err_bit) >> shift)], 1);
+    __syncthreads();
+    for (int b = threadIdx.x; b < nb; b += BK_THREADS) {
+        const int c = hist[b];
+        if (c) atomicAdd(&bucket_count[b], c);
+    }
+}
+
+// exclusive scan of bucket_count[0 .. nb] (nb <= 16384) by one workgroup; also zeroes the scatter cursors
+__global__ __launch_bounds__(1024) void bk_scan_kernel(int *__restrict__ bucket_count, int *__restrict__ bucket_cursor, int nb) {
+    __shared__ int wave_tot[16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    constexpr int ITEMS = (BK_MAX_BUCKETS + 1024) / 1024;     // 17 consecutive entries per thread
+    int v[ITEMS], tot = 0;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const int idx = tid * ITEMS + i;
+        v[i] = idx < nb ? bucket_count[idx] : 0;
+        tot += v[i];
+    }
+    int incl = tot;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int run = incl - tot;
+    for (int w = 0; w < wave; ++w) run += wave_tot[w];
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const int idx = tid * ITEMS + i;
+        if (idx <= nb) bucket_count[idx] = run;              // entry nb = total
+        if (idx < nb) bucket_cursor[idx] = 0;
+        run += v[i];
+    }
+}
+
+__global__ __launch_bounds__(BK_THREADS) void bk_scatter_kernel(const long long *__restrict__ key, long long E, long long num_keys, int shift,
+                                                               int nb, const int *__restrict__ bucket_start, int *__restrict__ bucket_cursor,
+                                                               uint2 *__restrict__ pairs) {
+    extern __shared__ int hist[];                            // [nb]: count, then next free slot of (this chunk, bucket)
+    for (int b = threadIdx.x; b < nb; b += BK_THREADS) hist[b] = 0;
+    __syncthreads();
+    const long long e0 = (long long)blockIdx.x * BK_CHUNK, e1 = min(E, e0 + BK_CHUNK);
+    for (long long e = e0 + threadIdx.x; e < e1; e += BK_THREADS) atomicAdd(&hist[(int)(safe_index(key[e], num_keys) >> shift)], 1);
+    __syncthreads();
+    for (int b = threadIdx.x; b < nb; b += BK_THREADS) {
+        const int c = hist[b];
+        if (c) hist[b] = bucket_start[b] + atomicAdd(&bucket_cursor[b], c);     // ONE global atomic per non-empty (chunk, bucket)
+    }
+    __syncthreads();
+    const unsigned mask = (1u << shift) - 1u;
+    for (long long e = e0 + threadIdx.x; e < e1; e += BK_THREADS) {
+        const long long k = safe_index(key[e], num_keys);
+        const int pos = atomicAdd(&hist[(int)(k >> shift)], 1);
+        pairs[pos] = make_uint2((unsigned)k & mask, (unsigned)e);
+    }
+}
+
+// one workgroup per bucket: counting sort of its items by local key, rows made ascending in item id (rank sort, 8 lanes per row)
+__global__ __launch_bounds__(BK_THREADS) void bk_sort_kernel(const int *__restrict__ bucket_start, const uint2 *__restrict__ pairs,
+                                                            const long long *__restrict__ other, long long num_keys, long long num_other,
+                                                            int shift, int nb, int *__restrict__ tmp_perm, int *__restrict__ rowptr,
+                                                            int *__restrict__ col, int *__restrict__ perm, int *__restrict__ err) {
+    __shared__ int cnt[BK_MAX_KEYS_PER_BUCKET + 1], cur[BK_MAX_KEYS_PER_BUCKET];
+    __shared__ int wave_tot[BK_THREADS / 64];
+    const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int keys_here = (int)min((long long)(1 << shift), num_keys - ((long long)b << shift));
+    const int s0 = bucket_start[b], s1 = bucket_start[b + 1];
+    for (int k = tid; k <= keys_here; k += BK_THREADS) cnt[k] = 0;
+    __syncthreads();
+    for (int i = s0 + tid; i < s1; i += BK_THREADS) atomicAdd(&cnt[pairs[i].x], 1);
+    __syncthreads();
+    // exclusive scan of cnt[0 .. keys_here] (<= 4097 entries): 17 consecutive entries per thread
+    constexpr int ITEMS = (BK_MAX_KEYS_PER_BUCKET + BK_THREADS) / BK_THREADS;
+    int v[ITEMS], tot = 0;
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const int idx = tid * ITEMS + i;
+        v[i] = idx < keys_here ? cnt[idx] : 0;
+        tot += v[i];
+    }
+    int incl = tot;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        const int t = __shfl_up(incl, off, 64);
+        if (lane >= off) incl += t;
+    }
+    if (lane == 63) wave_tot[wave] = incl;
+    __syncthreads();
+    int run = incl - tot;
+    for (int w = 0; w < wave; ++w) run += wave_tot[w];
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < ITEMS; ++i) {
+        const int idx = tid * ITEMS + i;
+        if (idx <= keys_here) cnt[idx] = run;
+        if (idx < keys_here) cur[idx] = run;
+        run += v[i];
+    }
+    __syncthreads();
+    const long long key0 = (long long)b << shift;
+    for (int k = tid; k < keys_here; k += BK_THREADS) rowptr[key0 + k] = s0 + cnt[k];
+    if (b == nb - 1 && tid == 0) rowptr[num_keys] = s1;
+    for (int i = s0 + tid; i < s1; i += BK_THREADS) {
+        const uint2 pr = pairs[i];
+        tmp_perm[s0 + atomicAdd(&cur[pr.x], 1)] = (int)pr.y;
+    }
+    __syncthreads();
+    constexpr int SUB = 8;
+    const int li = tid & (SUB - 1);
+    for (int k = tid / SUB; k < keys_here; k += BK_THREADS / SUB) {
+        const int rb = s0 + cnt[k], deg = cnt[k + 1] - cnt[k];
+        for (int t = li; t < deg; t += SUB) {
+            const int vv = tmp_perm[rb + t];
+            int rank = 0;
+            for (int j = 0; j < deg; ++j) rank += (tmp_perm[rb + j] < vv) ? 1 : 0;
+            perm[rb + rank] = vv;
+            col[rb + rank] = other ? (int)checked_index(other[vv], num_other, err, PHC_IDX_ERR_EDGE) : vv;
+        }
+    }
+}
+
 struct ScanLevels {
     int levels;
     long long n[6];
@@ -403,6 +549,65 @@ int phc_csr_build(const int64_t *key_i64, const int64_t *other_i64, int64_t E, i
         if (rc) return rc;
     }
     return PHC_OK;
+}
+
+static int bk_shift(int64_t num_keys) {
+    int shift = 0;
+    while (((num_keys + (1LL << shift) - 1) >> shift) > BK_MAX_BUCKETS) ++shift;
+    if (shift < 10) shift = 10;                              // ~1 K keys per bucket at least: the per-bucket pass stays worthwhile
+    return shift;
+}
+
+size_t phc_csr_bucketed_ws_bytes(int64_t E, int64_t num_keys) {
+    if (E < 0 || num_keys < 0) return 0;
+    return align_up(sizeof(int) * 2 * (size_t)(BK_MAX_BUCKETS + 2), 256) + align_up(sizeof(uint2) * (size_t)(E + 1), 256) +
+           align_up(sizeof(int) * (size_t)(E + 1), 256);
+}
+
+int phc_csr_build_bucketed(const int64_t *key_i64, const int64_t *other_i64, int64_t E, int64_t num_keys, int64_t num_other,
+                           int32_t *rowptr, int32_t *col, int32_t *perm, void *ws, size_t ws_bytes, void *stream) {
+    PHC_REQUIRE(E >= 1 && num_keys >= 1 && E < (1LL << 31) - 1 && num_keys < (1LL << 31) - 1, PHC_ERR_INVALID_ARG,
+                "phc_csr_build_bucketed: E=%lld num_keys=%lld", (long long)E, (long long)num_keys);
+    const int shift = bk_shift(num_keys);
+    PHC_REQUIRE((1 << shift) <= BK_MAX_KEYS_PER_BUCKET, PHC_ERR_UNSUPPORTED, "phc_csr_build_bucketed: %lld keys exceed %d buckets x %d keys",
+                (long long)num_keys, BK_MAX_BUCKETS, BK_MAX_KEYS_PER_BUCKET);
+    PHC_REQUIRE(key_i64 && rowptr && col && perm, PHC_ERR_INVALID_ARG, "phc_csr_build_bucketed: null pointer");
+    PHC_REQUIRE(!other_i64 || (num_other >= 1 && num_other < (1LL << 31) - 1), PHC_ERR_INVALID_ARG, "phc_csr_build_bucketed: num_other=%lld",
+                (long long)num_other);
+    PHC_REQUIRE(ws && ws_bytes >= phc_csr_bucketed_ws_bytes(E, num_keys), PHC_ERR_WORKSPACE, "phc_csr_build_bucketed: workspace too small");
+    hipStream_t s = (hipStream_t)stream;
+    const int nb = (int)((num_keys + (1LL << shift) - 1) >> shift);
+    char *q = static_cast<char *>(ws);
+    int *bucket_count = reinterpret_cast<int *>(q);
+    int *bucket_cursor = bucket_count + BK_MAX_BUCKETS + 2;
+    q += align_up(sizeof(int) * 2 * (size_t)(BK_MAX_BUCKETS + 2), 256);
+    uint2 *pairs = reinterpret_cast<uint2 *>(q);
+    q += align_up(sizeof(uint2) * (size_t)(E + 1), 256);
+    int *tmp_perm = reinterpret_cast<int *>(q);
+    int *err = err_word();
+    const int err_bit = other_i64 ? PHC_IDX_ERR_EDGE : PHC_IDX_ERR_SEGMENT;
+    const long long *key = reinterpret_cast<const long long *>(key_i64);
+    const unsigned chunks = (unsigned)((E + BK_CHUNK - 1) / BK_CHUNK);
+    const size_t lds = sizeof(int) * (size_t)nb;
+    hipMemsetAsync(bucket_count, 0, sizeof(int) * (size_t)(nb + 1), s);
+    {
+        ProfScope prof(K_CSR_HIST, s);
+        PHC_LAUNCH(bk_count_kernel, dim3(chunks), dim3(BK_THREADS), lds, s, key, (long long)E, (long long)num_keys, shift, nb, bucket_count,
+                   err, err_bit);
+    }
+    {
+        ProfScope prof(K_CSR_SCAN, s);
+        PHC_LAUNCH(bk_scan_kernel, dim3(1), dim3(1024), 0, s, bucket_count, bucket_cursor, nb);
+    }
+    {
+        ProfScope prof(K_CSR_FILL, s);
+        PHC_LAUNCH(bk_scatter_kernel, dim3(chunks), dim3(BK_THREADS), lds, s, key, (long long)E, (long long)num_keys, shift, nb, bucket_count,
+                   bucket_cursor, pairs);
+    }
+    ProfScope prof(K_CSR_CANON, s);
+    PHC_LAUNCH(bk_sort_kernel, dim3(nb), dim3(BK_THREADS), 0, s, bucket_count, pairs, reinterpret_cast<const long long *>(other_i64),
+               (long long)num_keys, (long long)num_other, shift, nb, tmp_perm, rowptr, col, perm, err);
+    return check_launch("csr_build_bucketed");
 }
 
 size_t phc_csr_pair_ws_bytes(int64_t E, int64_t n_src, int64_t n_dst) {

@@ -18,6 +18,8 @@ from . import lib as L
 
 _CACHE_SIZE = 16
 _NO_PAIR = bool(__import__('os').environ.get('PHC_NO_CSR_PAIR'))
+_NO_BUCKETED = bool(__import__('os').environ.get('PHC_NO_CSR_BUCKETED'))
+BUCKETED_MIN_ITEMS, BUCKETED_MIN_KEYS = 1 << 20, 1 << 16
 _cache: "OrderedDict[tuple, EdgeStructure]" = OrderedDict()
 
 
@@ -33,6 +35,14 @@ def _build_sorted(key: torch.Tensor, other: Optional[torch.Tensor], num_keys: in
         rowptr = torch.empty(num_keys + 1, dtype=torch.int32, device=dev)
         col = torch.empty(E, dtype=torch.int32, device=dev)
         perm = torch.empty(E, dtype=torch.int32, device=dev)
+    if E >= BUCKETED_MIN_ITEMS and num_keys >= BUCKETED_MIN_KEYS and num_keys <= 16384 * 4096 and not _NO_BUCKETED:
+        # large graphs: partition by key range first, then sort bucket by bucket in LDS (same result, ~4x faster at 10 M / 50 M)
+        ws_bytes = lib.phc_csr_bucketed_ws_bytes(E, num_keys)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        L.check(lib.phc_csr_build_bucketed(L.ptr(key), L.ptr(other), E, num_keys, num_other, L.ptr(rowptr), L.ptr(col), L.ptr(perm),
+                                           L.ptr(ws), ws_bytes, L.stream_ptr(dev)), "phc_csr_build_bucketed")
+        L.maybe_check_indices(dev)
+        return rowptr, col, perm
     ws_bytes = lib.phc_csr_ws_bytes(E, num_keys)
     ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
     L.check(lib.phc_csr_build(L.ptr(key), L.ptr(other), E, num_keys, num_other, L.ptr(rowptr), L.ptr(col), L.ptr(perm),

@@ -98,6 +98,8 @@ SIGNATURES = {
     "phc_phm_weight_reg_max_jobs": (_I, []),
     "phc_phm_weight_reg_ws_bytes": (_S, []),
     "phc_phm_weight_reg": (_I, [_P, _P, _P, _P, _I, C.c_float, _I, _P, _P, _P, _S, _P]),
+    "phc_csr_bucketed_ws_bytes": (_S, [_L, _L]),
+    "phc_csr_build_bucketed": (_I, [_P, _P, _L, _L, _L, _P, _P, _P, _P, _S, _P]),
     "phc_csr_ws_bytes": (_S, [_L, _L]),
     "phc_csr_build": (_I, [_P, _P, _L, _L, _L, _P, _P, _P, _P, _S, _P]),
     "phc_csr_pair_ws_bytes": (_S, [_L, _L, _L]),

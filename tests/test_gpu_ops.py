@@ -161,7 +161,7 @@ def _ref_sorted(key, other, num_keys):
     return np.cumsum(rowptr), (other[order] if other is not None else order), order
 
 
-@pytest.mark.parametrize("kind", ["mol", "ragged", "random_big", "empty"])
+@pytest.mark.parametrize("kind", ["mol", "ragged", "random_big", "empty", "random_huge", "skewed_huge"])
 def test_csr_build_is_the_stable_sort(kind):
     from phc_gnn_amd import synth
     from phc_gnn_amd.graph import EdgeStructure
@@ -172,6 +172,15 @@ def test_csr_build_is_the_stable_sort(kind):
         ei, n = synth.ragged_edges(500, seed=1, hub_degree=700), 500
     elif kind == "random_big":
         ei, n = synth.random_edges(200_000, 1_000_000, seed=2), 200_000
+    elif kind == "random_huge":                       # the two-level (bucketed) build: >= 64 K keys and >= 1 M items
+        ei, n = synth.random_edges(300_000, 2_000_000, seed=5), 300_000
+    elif kind == "skewed_huge":                       # one key range 500 x denser than the rest, a 40 K-item hub row, empty tail rows
+        n = 400_123
+        rng = np.random.default_rng(6)
+        dst = np.concatenate([rng.integers(0, 1000, 600_000), rng.integers(0, 300_000, 900_000), np.full(40_000, 77)])
+        src = rng.integers(0, n, dst.shape[0])
+        p = rng.permutation(dst.shape[0])
+        ei = np.stack([src[p], dst[p]]).astype(np.int64)
     else:
         ei, n = np.zeros((2, 0), dtype=np.int64), 17
     st = EdgeStructure(torch.from_numpy(ei).to(DEV), n)
