@@ -86,6 +86,9 @@ def parse_args():
     ap.add_argument("--weight-decay", type=float, default=0.001,
                     help="explicit weight regulariser of the reference loop body (train_hiv.py:181-196, --weightdecay default "
                          "0.001, p = 2): one more launch per step; 0 leaves it out")
+    ap.add_argument("--layers", type=int, default=1,
+                    help="synth_* workloads: 1 = one PHMGINEConv layer (SURVEY 8d); L > 1 = L stacked layers with the model-level "
+                         "norm + relu + skip between them (ShardedGINEStack)")
     ap.add_argument("--min-time", type=float, default=0.5,
                     help="keep timing --steps-step windows until this many seconds (and >= 5 windows) are covered; the "
                          "median window is reported (0: a single window)")
@@ -157,7 +160,8 @@ def bench_large_graph(args, world, rank, dev):
     import torch.distributed as dist
     from phc.hypercomplex.undirectional.messagepassing import PHMGINEConv
     from phc_gnn_amd import lib
-    from phc_gnn_amd.dist import FlatGradSync, ShardedAggregate, ShardedPHMGINEConv, build_halo_plan
+    from phc.hypercomplex.norm import PHMNorm
+    from phc_gnn_amd.dist import FlatGradSync, ShardedAggregate, ShardedGINEStack, ShardedPHMGINEConv, build_halo_plan
     g = LARGE_GRAPHS[args.workload]
     N, E, n, h = g["nodes"], g["edges"], g["phm_dim"], g["hidden"]
     if not dist.is_initialized():                      # one rank: a group of one (the exchange code path stays the same)
@@ -169,10 +173,20 @@ def bench_large_graph(args, world, rank, dev):
     t0 = time.perf_counter()
     plan = build_halo_plan(ei, N)
     del ei
-    agg = ShardedAggregate(plan)
     torch.manual_seed(0)
-    conv = PHMGINEConv(h, h, phm_dim=n, phm_rule=None, norm="naive-batch-norm", activation="relu", msg_encoder="identity").to(dev).train()
-    layer = ShardedPHMGINEConv(conv, agg, N).train()
+    n_layers = max(1, args.layers)
+    convs = [PHMGINEConv(h, h, phm_dim=n, phm_rule=None, norm="naive-batch-norm", activation="relu", msg_encoder="identity").to(dev).train()
+             for _ in range(n_layers)]
+    conv = convs[0]
+    if n_layers == 1:
+        agg = ShardedAggregate(plan)
+        layer = ShardedPHMGINEConv(conv, agg, N).train()
+        trainable = list(conv.parameters())
+    else:
+        norms = [PHMNorm(num_features=h, phm_dim=n, type="naive-batch-norm").to(dev).train() for _ in range(n_layers)]
+        layer = ShardedGINEStack(convs, norms, plan, N, activation="relu").train()
+        agg = layer.agg
+        trainable = [p for m in convs + norms for p in m.parameters()]
     _ = agg.st_loc.csr, agg.st_loc.csc, agg.st_halo.csr, agg.st_halo.csc       # sorted views: once per graph
     torch.cuda.synchronize()
     t_plan = time.perf_counter() - t0
@@ -182,10 +196,10 @@ def bench_large_graph(args, world, rank, dev):
     ea_loc = torch.randn(e_loc, h, generator=gen2, device=dev).requires_grad_()
     ea_halo = torch.randn(e_halo, h, generator=gen2, device=dev).requires_grad_() if e_halo else None
     dy = torch.randn(plan.n_own, h, generator=gen2, device=dev)
-    sync = FlatGradSync(list(conv.parameters()), average=False) if world > 1 else None
+    sync = FlatGradSync(trainable, average=False) if world > 1 else None
 
     def step():
-        for p in conv.parameters():
+        for p in trainable:
             p.grad = None
         x_own.grad = ea_loc.grad = None
         if ea_halo is not None:
@@ -294,12 +308,14 @@ def bench_large_graph(args, world, rank, dev):
         agg_b = sum(work[k]["bytes"] for k in ("aggregate_fwd", "aggregate_bwd") if k in work)
         agg_t = sum(times[k]["total_ms"] for k in ("aggregate_fwd", "aggregate_bwd") if k in times)
         result = {"metric": "edges/sec (fwd+bwd) of one PHMGINEConv PHM-4 layer on a synthetic 10M-node/50M-edge graph",
-                  "value": round(E * args.steps / dt, 1), "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+                  "value": round(E * n_layers * args.steps / dt, 1), "unit": "edges/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
                   "ms_per_step": round(1e3 * dt / args.steps, 3), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
                   "dtype": "f32", "data": "synthetic",
-                  "config": {"workload": f"{args.workload}: {N} nodes, {E} iid-uniform directed edges, PHM-{n}, hidden {h}, one PHMGINEConv "
-                                         f"layer (float edge_attr [E,{h}], batch-norm, relu), destination-range sharded over {world} "
-                                         f"rank(s) (BASELINE configs[4])",
+                  "config": {"workload": f"{args.workload}: {N} nodes, {E} iid-uniform directed edges, PHM-{n}, hidden {h}, "
+                                         + ("one PHMGINEConv layer" if n_layers == 1 else
+                                            f"{n_layers} stacked PHMGINEConv layers with norm + relu + skip between them")
+                                         + f" (float edge_attr [E,{h}], batch-norm, relu), destination-range sharded over {world} "
+                                         f"rank(s) (BASELINE configs[4])", "layers": n_layers,
                              "step": "fwd+bwd" + ("+flat param-grad all-reduce" if world > 1 else ""), "parallelism": f"shard{world}"},
                   "roofline": roof,
                   "aggregate_hbm": {"achieved_GBs": round(agg_b / (agg_t * 1e-3) / 1e9, 1) if agg_t else None, "peak": PEAK_HBM_GBS,

@@ -212,13 +212,13 @@ class EngineBackend:
     def bn_moments(self, x):
         return self._ops.bn_moments(x)
 
-    def bn_fwd_from_moments(self, x, moments_all, counts_all, n_total, norm, act):
+    def bn_fwd_from_moments(self, x, moments_all, counts_all, n_total, norm, act, residual=None):
         mods = list(norm.bn)
         return self._ops.bn_fwd_from_moments(
             x, moments_all, counts_all, n_total, [m.weight for m in mods] if norm.affine else None,
             [m.bias for m in mods] if norm.affine else None, [m.running_mean for m in mods], [m.running_var for m in mods],
             [m.num_batches_tracked for m in mods], norm.momentum if norm.momentum is not None else 0.1, norm.eps,
-            self._ops._act_id(act))
+            self._ops._act_id(act), residual)
 
     def bn_bwd_sums(self, dy, x, save_stat, act):
         return self._ops.bn_bwd_sums(dy, x, save_stat, self._ops._act_id(act))
@@ -464,3 +464,87 @@ class ShardedPHMGINEConv(torch.nn.Module):
                 affine = [m.weight for m in nb.bn] + [m.bias for m in nb.bn]
         l1, l2 = mlp.linear1, mlp.linear2
         return _ShardedGINEFn.apply(self, x_own, ea_loc, ea_halo, l1.phm_rule, l1.W, l1.b, l2.phm_rule, l2.W, l2.b, *affine)
+
+
+# ---------------------------------------------------------------------------------------------
+# 4. the model-level norm of a sharded stack: act(norm(x)) (+ skip) with the batch statistics of ALL rows
+# ---------------------------------------------------------------------------------------------
+class _ShardedNormActFn(torch.autograd.Function):
+    """``act(batch_norm(x)) + residual`` on the rows a rank owns, statistics over the rows of every rank (models.py:208-215
+    on a destination-range shard): moments -> all-gather -> normalise; backward: sums -> all-reduce -> apply.  The affine
+    gradients come out as this rank's partial sums, like every other parameter gradient of the sharded path."""
+
+    @staticmethod
+    def forward(ctx, x, residual, mod: "ShardedPHMNorm", *affine):
+        be, plan, norm = mod.backend, mod.plan, mod.norm.bn
+        x = x.contiguous()
+        mom = be.bn_moments(x)
+        mom_flat = torch.empty(plan.world * mom.numel(), dtype=mom.dtype, device=mom.device)
+        dist.all_gather_into_tensor(mom_flat, mom, group=plan.group)
+        out, save_stat = be.bn_fwd_from_moments(x, mom_flat.view(plan.world, mom.numel()), mod.counts_all, mod.n_total, norm,
+                                                mod.activation, residual)
+        ctx.mod = mod
+        ctx.has_res = residual is not None
+        ctx.n_affine = len(affine)
+        ctx.save_for_backward(x, save_stat)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        mod = ctx.mod
+        be, plan = mod.backend, mod.plan
+        x, save_stat = ctx.saved_tensors
+        dout = dout.contiguous()
+        dwb = be.bn_bwd_sums(dout, x, save_stat, mod.activation)
+        dwb_all = dwb.clone()
+        dist.all_reduce(dwb_all, op=dist.ReduceOp.SUM, group=plan.group)
+        dx = be.bn_bwd_apply(dout, x, save_stat, dwb_all, mod.n_total, mod.activation)
+        aff = []
+        if ctx.n_affine:
+            n = ctx.n_affine // 2
+            h = x.shape[1]
+            k = h // n
+            aff = [dwb[c * k:(c + 1) * k] for c in range(n)] + [dwb[h + c * k:h + (c + 1) * k] for c in range(n)]
+        return (dx, dout if ctx.has_res else None, None, *aff)
+
+
+class ShardedPHMNorm(torch.nn.Module):
+    """A ``PHMNorm`` ("naive-batch-norm") evaluated on a shard with global batch statistics, activation and skip add fused
+    (what PHMSkipConnectAdd.compute_hidden_layer_embedding does after every conv, models.py:208-215)."""
+
+    def __init__(self, norm, plan: HaloPlan, num_nodes: int, activation: str = "relu", backend=None):
+        super().__init__()
+        self.norm = norm
+        self.plan = plan
+        self.backend = backend if backend is not None else EngineBackend()
+        self.activation = activation
+        self.n_total = int(num_nodes)
+        bounds = partition_bounds(self.n_total, plan.world)
+        dev = plan.loc_edge_index.device
+        self.counts_all = torch.tensor([float(bounds[r + 1] - bounds[r]) for r in range(plan.world)], dtype=torch.float32, device=dev)
+
+    def forward(self, x_own: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+        nb = self.norm.bn
+        if not self.training or not hasattr(nb, "bn") or not nb.track_running_stats:
+            raise NotImplementedError("ShardedPHMNorm: training-mode naive-batch-norm with running statistics only")
+        affine = ([m.weight for m in nb.bn] + [m.bias for m in nb.bn]) if nb.affine else []
+        return _ShardedNormActFn.apply(x_own, residual, self, *affine)
+
+
+class ShardedGINEStack(torch.nn.Module):
+    """L message-passing layers of PHMSkipConnectAdd on one sharded graph: x <- act(norm(conv(x, edges))) + skip per layer
+    (models.py:200-217 with sc_type "last"), every conv a ShardedPHMGINEConv and every norm a ShardedPHMNorm over ONE halo plan
+    (built once per graph, shared by all layers and steps).  ``convs`` / ``norms``: the ordinary modules (replicated)."""
+
+    def __init__(self, convs, norms, plan: HaloPlan, num_nodes: int, activation: str = "relu", backend=None):
+        super().__init__()
+        agg = ShardedAggregate(plan, backend=backend)
+        self.agg = agg
+        self.layers = torch.nn.ModuleList([ShardedPHMGINEConv(c, agg, num_nodes) for c in convs])
+        self.norms = torch.nn.ModuleList([ShardedPHMNorm(nm, plan, num_nodes, activation, backend=agg.backend) for nm in norms])
+
+    def forward(self, x_own, ea_loc, ea_halo):
+        h = x_own
+        for layer, norm in zip(self.layers, self.norms):
+            h = norm(layer(h, ea_loc, ea_halo), residual=h)
+        return h

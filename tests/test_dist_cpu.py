@@ -14,7 +14,8 @@ import torch.multiprocessing as mp
 
 from oracle import phc_oracle as O
 from phc_gnn_amd import synth
-from phc_gnn_amd.dist import FlatGradSync, ShardedAggregate, ShardedPHMGINEConv, build_halo_plan, partition_bounds
+from phc_gnn_amd.dist import (FlatGradSync, ShardedAggregate, ShardedGINEStack, ShardedPHMGINEConv, build_halo_plan,
+                              partition_bounds)
 
 
 def _free_port():
@@ -81,7 +82,7 @@ class OracleBackend:
         mean = x.mean(0) if x.shape[0] else torch.zeros(x.shape[1])
         return torch.cat([x.sum(0), ((x - mean) ** 2).sum(0)])
 
-    def bn_fwd_from_moments(self, x, moments_all, counts_all, n_total, norm, act):
+    def bn_fwd_from_moments(self, x, moments_all, counts_all, n_total, norm, act, residual=None):
         h = x.shape[1]
         sums, m2s = moments_all[:, :h], moments_all[:, h:]
         mean = sums.sum(0) / n_total
@@ -101,7 +102,8 @@ class OracleBackend:
                 m.running_var.mul_(1 - norm.momentum).add_(norm.momentum * (M2 / (n_total - 1))[c * k:(c + 1) * k])
                 m.num_batches_tracked += 1
         zhat = (x - mean) * invstd
-        return O.activation(act, zhat * w + b), torch.cat([mean, invstd, w, b])
+        out = O.activation(act, zhat * w + b)
+        return (out if residual is None else out + residual), torch.cat([mean, invstd, w, b])
 
     def _g(self, dy, x, save, act):
         mean, invstd, w, b = save.view(4, -1)
@@ -310,3 +312,80 @@ def test_sharded_gine_layer_equals_single_process(tmp_path, case):
             close(b, p["q." + k], "buffer " + k)
         else:
             assert int(b) == 1, k                                  # num_batches_tracked: one training step
+
+
+# ---- two stacked layers with the model-level norm + skip between them (ShardedGINEStack) -------------------------------
+def _make_stack(n, h, seed):
+    from phc.hypercomplex.norm import PHMNorm
+    convs = [_make_conv("relu_norm", n, h, seed + i) for i in range(2)]
+    g = torch.Generator().manual_seed(seed + 50)
+    norms = []
+    for i in range(2):
+        nm = PHMNorm(num_features=h, phm_dim=n, type="naive-batch-norm")
+        with torch.no_grad():
+            for name, p in nm.named_parameters():
+                p.copy_(0.5 + torch.rand(p.shape, generator=g) if name.endswith("weight") else 0.1 * torch.randn(p.shape, generator=g))
+        norms.append(nm.train())
+    return convs, norms
+
+
+def _worker_stack(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        N, E, n, h, ei, x, ea, dy = _layer_problem()
+        convs, norms = _make_stack(n, h, seed=31)
+        plan = build_halo_plan(ei, N)
+        stack = ShardedGINEStack(convs, norms, plan, N, activation="relu", backend=OracleBackend()).train()
+        x_own = x[plan.lo:plan.hi].clone().requires_grad_()
+        ea_loc, ea_halo = stack.agg.split_edge_attr(ea)
+        y = stack(x_own, ea_loc, ea_halo)
+        y.backward(dy[plan.lo:plan.hi])
+        params = [p for m in convs + norms for p in m.parameters()]
+        FlatGradSync(params, average=False)()
+        torch.save(dict(y=y.detach(), gx=x_own.grad, lo=plan.lo, hi=plan.hi, grads=[p.grad.clone() for p in params],
+                        buffers=[b.clone() for m in convs + norms for b in m.buffers()]), os.path.join(tmp, f"s{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_sharded_stack_with_model_level_norm_equals_single_process(tmp_path):
+    """conv -> norm(global statistics) -> relu -> + skip, twice, on two shards == the oracle on the whole graph: outputs, dx,
+    every parameter gradient (convs and norms), running statistics."""
+    world = 2
+    mp.spawn(_worker_stack, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    N, E, n, h, ei, x, ea, dy = _layer_problem()
+    convs, norms = _make_stack(n, h, seed=31)
+    p = {}
+    for i, (c, nm) in enumerate(zip(convs, norms)):
+        p.update({f"c{i}." + k: v.detach().clone() for k, v in c.state_dict().items()})
+        p.update({f"n{i}." + k: v.detach().clone() for k, v in nm.state_dict().items()})
+    names = [f"c{i}." + k for i, c in enumerate(convs) for k, _ in c.named_parameters()] + \
+            [f"n{i}." + k for i, nm in enumerate(norms) for k, _ in nm.named_parameters()]
+    order = [f"c{i}." + k for i, c in enumerate(convs) for k, _ in c.named_parameters()]
+    order += [f"n{i}." + k for i, nm in enumerate(norms) for k, _ in nm.named_parameters()]
+    for k in names:
+        p[k].requires_grad_()
+    xr = x.clone().requires_grad_()
+    hcur = xr
+    for i in range(2):
+        y = O.phm_gine_conv(hcur, ei, ea, p, f"c{i}.transform.", n, "relu", True, True, True, "relu", None)
+        hcur = O.activation("relu", O._norm_from_state(y, p, f"n{i}.", n, True)) + hcur
+    grads = torch.autograd.grad(hcur, [xr] + [p[k] for k in order], dy, allow_unused=True)
+    shards = [torch.load(os.path.join(tmp_path, f"s{r}.pt")) for r in range(world)]
+    yy, gx = torch.zeros(N, h), torch.zeros(N, h)
+    for d in shards:
+        yy[d["lo"]:d["hi"]] = d["y"]
+        gx[d["lo"]:d["hi"]] = d["gx"]
+
+    def close(a, b, what, tol=3e-5):
+        err = float((a - b).abs().max()) / max(float(b.abs().max()), 1e-30)
+        assert err <= tol, (what, err)
+    close(yy, hcur.detach(), "y")
+    close(gx, grads[0], "dx")
+    for k, got, ref in zip(order, shards[0]["grads"], grads[1:]):
+        if ref is None or k.endswith("linear1.b") or k.endswith("linear2.b"):     # biases in front of a norm: zero up to round-off
+            continue
+        close(got, ref, "grad " + k)
+    for a, b in zip(shards[0]["buffers"], shards[1]["buffers"]):
+        assert torch.equal(a, b)
