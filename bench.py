@@ -66,6 +66,17 @@ def pmc_traffic(kernel: str):
     return None
 
 
+def _flush_c_stdio():
+    """RCCL prints its version banner through C stdio, which is only flushed at exit — after Python's own prints.  Flush it
+    now so that the JSON line printed next is the LAST line of stdout."""
+    import ctypes
+    sys.stdout.flush()
+    try:
+        ctypes.CDLL(None).fflush(None)
+    except Exception:
+        pass
+
+
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -324,7 +335,7 @@ def bench_large_graph(args, world, rank, dev):
     dist.barrier()
     dist.destroy_process_group()
     if rank == 0:
-        sys.stdout.flush()
+        _flush_c_stdio()
         print(json.dumps(result), flush=True)          # after RCCL's own shutdown banner: the JSON line is the LAST line of stdout
 
 
@@ -544,7 +555,7 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0:
-        sys.stdout.flush()
+        _flush_c_stdio()
         print(json.dumps(result), flush=True)          # after RCCL's own shutdown banner: the JSON line is the LAST line of stdout
 
 
