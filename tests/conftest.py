@@ -12,6 +12,13 @@ import phc_gnn_amd  # noqa: E402,F401  (HIP runtime flags must be in the environ
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    try:
+        # the CPU oracle runs on small tensors: on a many-core GPU host torch's default intra-op pool (one thread per core)
+        # is hundreds of times slower than a handful of threads (measured: 91 s instead of 0.5 s per 512-graph step at 256)
+        import torch
+        torch.set_num_threads(max(1, min(8, os.cpu_count() or 1)))
+    except Exception:  # pragma: no cover
+        pass
 
 
 def pytest_collection_modifyitems(config, items):
