@@ -1008,6 +1008,14 @@ static int launch_stream_cfg(const float *X, const float *A, const float *W, con
 constexpr int GEMM_STREAM_MAX_K = 256;
 // rows at which the 128-column / 8-wave streaming configuration takes over from the 64-column / 4-wave one
 constexpr int64_t GEMM_BIG_M = 64 * 1024;
+// K > 128 (hidden 256): rows from which the 64-column / 8-wave configuration (one panel per CU shared by 8 wavefronts, x
+// read 4x) takes over from the 32-column / 4-wave one (two workgroups per CU, x read 8x).  PHC_GEMM_WIDE_K_M overrides.
+static inline int64_t gemm_wide_k_m() {
+    // measured (bench.py, one MI355X): zinc_b1024 (23.6 k rows, PHM-8 hidden 256) 2.75 -> 2.58 ms, molpcba_b1024 (27.2 k rows)
+    // 3.42 -> 3.19 ms per training step with the 8-wave configuration instead of 2 x (32 columns, 4 waves) per CU
+    static const int64_t v = getenv("PHC_GEMM_WIDE_K_M") ? atoll(getenv("PHC_GEMM_WIDE_K_M")) : 16 * 1024;
+    return v;
+}
 
 template <int TRANS>
 static int launch_gemm(const float *X, const float *A, const float *W, const float *bias, const float *residual,
@@ -1358,7 +1366,7 @@ int phc_gemm_prebuilt(const float *x, const float *M, const float *b, const floa
     // each half as long — measured 0.8 us per launch faster than 64-column panels at N = 13.8k; above that the extra
     // re-reads of x cost more than the occupancy gains.  PHC_GEMM_PRE_BN=64 forces the wider panel.
     static const int small_bn = getenv("PHC_GEMM_PRE_BN") ? atoi(getenv("PHC_GEMM_PRE_BN")) : 32;
-    if (N >= GEMM_BIG_M && Nout > 64 && K > 128)
+    if (N >= gemm_wide_k_m() && Nout > 64 && K > 128)
         launch_stream_cfg<0, -1, 64, 8>(x, nullptr, M, b, residual, y, N, K, Nout, 1, K, Nout, 1, s);
     else if (N >= GEMM_BIG_M && Nout > 64)
         launch_stream_cfg<0, -1, 128, 8>(x, nullptr, M, b, residual, y, N, K, Nout, 1, K, Nout, 1, s);
@@ -1382,7 +1390,7 @@ int phc_gemm_prebuilt_stats(const float *x, const float *M, const float *b, int6
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(K_PHM_GEMM_FWD, s);
     static const int small_bn = getenv("PHC_GEMM_PRE_BN") ? atoi(getenv("PHC_GEMM_PRE_BN")) : 32;
-    if (N >= GEMM_BIG_M && Nout > 64 && K > 128)
+    if (N >= gemm_wide_k_m() && Nout > 64 && K > 128)
         launch_stream_cfg<0, -1, 64, 8, 1>(x, nullptr, M, b, nullptr, y, N, K, Nout, 1, K, Nout, 1, s, n_valid_dev, stats_partial,
                                            stats_counts, num_partials);
     else if (N >= GEMM_BIG_M && Nout > 64)
@@ -1414,7 +1422,7 @@ int phc_gemm_prebuilt_xf(const float *x, const float *xf_stat, int xf_act, const
     const bool big = N >= GEMM_BIG_M && Nout > 64;
     const bool small = small_bn == 32 && Nout > 32 && N <= 32 * 1024;
 #define PHC_XF_LAUNCH(SV)                                                                                                      \
-    if (big && K > 128)                                                                                                         \
+    if (N >= gemm_wide_k_m() && Nout > 64 && K > 128)                                                                          \
         launch_stream_cfg<0, -1, 64, 8, SV>(x, nullptr, M, b, nullptr, y, N, K, Nout, 1, K, Nout, 1, s, n_valid_dev, stats_partial, \
                                             stats_counts, num_partials, xf_stat, xf_act);                                       \
     else if (big)                                                                                                               \
@@ -1449,7 +1457,7 @@ int phc_gemm_prebuilt_bwsums(const float *dy, const float *M, int64_t N, int K, 
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(K_PHM_GEMM_DX, s);
     static const int small_bn = getenv("PHC_GEMM_PRE_BN") ? atoi(getenv("PHC_GEMM_PRE_BN")) : 32;
-    if (N >= GEMM_BIG_M && Nout > 64 && K > 128)
+    if (N >= gemm_wide_k_m() && Nout > 64 && K > 128)
         launch_stream_cfg<0, -1, 64, 8, 4>(dy, nullptr, M, nullptr, nullptr, dz, N, K, Nout, 1, K, Nout, 1, s, n_valid_dev, sums_partial,
                                            nullptr, num_partials, nullptr, 0, bn_x, bn_stat, act);
     else if (N >= GEMM_BIG_M && Nout > 64)
