@@ -32,6 +32,26 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
+
+
+def _packet_capture_choice(argv, env) -> str:
+    """`--packet-capture 0|1` has to act before the HIP runtime initialises, i.e. before the imports below.  With 1 the
+    single-process hipGraph bench uses hipGraphLaunch's packet-capture fast path; GraphedTrainStep then alternates two static
+    input sets, so the next batch's copy never targets buffers of the replay in flight.  Default 0: measured
+    A/B on one MI355X the fast path is worth 0 +- 10 us per step now that the step is bound by its dependent chain on the GPU."""
+    choice = env.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+    for i, a in enumerate(argv):
+        if a == "--packet-capture" and i + 1 < len(argv):
+            choice = argv[i + 1]
+        elif a.startswith("--packet-capture="):
+            choice = a.split("=", 1)[1]
+    if int(env.get("WORLD_SIZE", "1")) > 1:
+        choice = "0"                     # a collective queued behind a replay is not protected by double buffering
+    return "1" if choice == "1" else "0"
+
+
+os.environ["DEBUG_CLR_GRAPH_PACKET_CAPTURE"] = _packet_capture_choice(sys.argv[1:], os.environ)
+
 import phc_gnn_amd  # noqa: E402,F401  (sets the HIP runtime flags it needs before HIP initialises)
 import torch  # noqa: E402
 
@@ -96,6 +116,8 @@ def parse_args():
     ap.add_argument("--cpu-all-cores-max", type=int, default=32,
                     help="run the all-cores CPU baseline only on hosts with at most this many logical CPUs")
     ap.add_argument("--profile-steps", type=int, default=10)
+    ap.add_argument("--packet-capture", choices=["0", "1"], default="0",
+                    help="hipGraphLaunch's packet-capture fast path (read before HIP initialises, see _packet_capture_choice)")
     ap.add_argument("--weight-decay", type=float, default=0.001,
                     help="explicit weight regulariser of the reference loop body (train_hiv.py:181-196, --weightdecay default "
                          "0.001, p = 2): one more launch per step; 0 leaves it out")
@@ -504,6 +526,9 @@ def main():
                               + ("replayed one batch ahead on a second stream" if graph_step.pipeline else "inside the step graph"))
                              if graph_step is not None
                              else "eager (one launch per kernel)",
+                   "graph_packet_capture": (os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "1")
+                                           + 0 if graph_step is not None else None,
+                   "static_input_sets": len(graph_step.sets) if graph_step is not None else None,
                    "parallelism": f"dp{world}" if world > 1 else "single",
                    "replicas_max_param_diff": replicas_max_diff},
     }

@@ -132,7 +132,7 @@ class GraphedTrainStep:
     TENSORS = FLAT_TENSORS
 
     def __init__(self, model, optimizer, cfg: StepConfig, example: dict, grad_sync=None, warmup: int = 3,
-                 pipeline: Optional[bool] = None):
+                 pipeline: Optional[bool] = None, double_buffer: Optional[bool] = None):
         """``grad_sync``: optional ``phc_gnn_amd.dist.FlatGradSync`` (data-parallel ranks).  The step is then
         captured as TWO graphs — [forward, loss, backward, pack gradients into the flat bucket] and
         [unpack, clip, Adam] — with the RCCL all-reduce of the bucket issued eagerly between them."""
@@ -140,11 +140,23 @@ class GraphedTrainStep:
         if pipeline is None:
             pipeline = os.environ.get("PHC_GRAPH_PIPELINE", "0") == "1"
         self.pipeline = bool(pipeline)
+        # ``double_buffer``: TWO sets of static batch buffers, each with its own captured step, used alternately.  The next
+        # batch's copy then never targets buffers a replay in flight may still read — which is the only thing the "graph
+        # packet capture" fast path of HIP 7.0 fails to order (module docstring of phc_gnn_amd/__init__.py).  Default: on
+        # exactly when that fast path is on (DEBUG_CLR_GRAPH_PACKET_CAPTURE != 0); single-process runs only — a collective
+        # queued behind a replay is not protected by this.
+        packet_capture = os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "1") != "0"
+        if double_buffer is None:
+            double_buffer = packet_capture and not self.pipeline
+        self.double_buffer = bool(double_buffer) and not self.pipeline
+        if packet_capture and grad_sync is not None:
+            raise RuntimeError("GraphedTrainStep: the graph packet capture fast path (DEBUG_CLR_GRAPH_PACKET_CAPTURE != 0) does not "
+                               "order a replay against the collective queued behind it; keep it off for data-parallel runs")
         dev = example["x"].device
         B = int(example["num_graphs"])
         n_valid_graphs = torch.tensor(B, dtype=torch.int32, device=dev)
         self.sets: List[_BatchSet] = []
-        for _ in range(2 if self.pipeline else 1):
+        for _ in range(2 if (self.pipeline or self.double_buffer) else 1):
             bs = _BatchSet()
             if "_flat" in example:                  # batch arrays live in one flat buffer: one copy per step
                 bs.static_flat = example["_flat"].clone()
@@ -170,7 +182,7 @@ class GraphedTrainStep:
         self.prep_stream = torch.cuda.Stream(device=dev) if self.pipeline else None
         from .ops import register_unit_seed
         self._seed = register_unit_seed(torch.ones((), dtype=torch.float32, device=dev))   # d loss / d loss, resident
-        if os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "1") != "0":
+        if packet_capture and not self.double_buffer:
             warnings.warn("DEBUG_CLR_GRAPH_PACKET_CAPTURE is not 0: on HIP 7.0 pipelined hipGraph replays race with the "
                           "batch copies queued behind them (see phc_gnn_amd/__init__.py)", RuntimeWarning)
         # Warm-up (allocator pools, lazy library initialisation, pointer tables) and capture run on ONE
@@ -340,7 +352,12 @@ class GraphedTrainStep:
 
     def _issue(self, padded: Optional[dict], next_padded: Optional[dict] = None) -> torch.Tensor:
         main = torch.cuda.current_stream(self.device)
-        if not self.pipeline:
+        if self.double_buffer:
+            if padded is not None:
+                self._cur = 1 - self._cur                      # the other set: nothing in flight reads it
+                self._load_into(self.sets[self._cur], padded)
+            bs = self.sets[self._cur]
+        elif not self.pipeline:
             bs = self.sets[0]
             if padded is not None:
                 self._load_into(bs, padded)
