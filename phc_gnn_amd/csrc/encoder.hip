@@ -834,7 +834,8 @@ static TgPlan tg_plan(long long n_items, int R, int h, int jobs = 1) {
     const int tiles = p.tiles_i * p.tiles_j;
     // workgroups of the whole launch: ~2-4 per CU for molecule batches; for large inputs one workgroup per ~8k items
     // (a fixed 512 left each workgroup with thousands of dependent gather -> MFMA rounds: 19 ms for 10 M atoms)
-    long long target = jobs > 1 ? 1024 : 512;
+    static const long long knob = getenv("PHC_TG_TARGET") ? atoll(getenv("PHC_TG_TARGET")) : 0;      // tuning knob
+    long long target = knob > 0 ? knob : (jobs > 1 ? 1024 : 512);
     const long long by_items = (n_items / 8192) * tiles * jobs;
     if (by_items > target) target = by_items;
     long long splits = (target + tiles * jobs - 1) / (tiles * jobs);
@@ -1413,10 +1414,23 @@ int phc_step_tail(const phc_phm_grad_job *jobs, int num_jobs, const phc_table_gr
         t.nr_atom = (unsigned)((ma.R * h + 63) / 64);
     }
     t.nr_phm = gl.nb_reduce;
+#ifdef PHC_EXP_TAIL_SKIP
+    {   // experiment build: leave one family of workgroups out of the first launch (results are wrong, timing only)
+        const char *skip = getenv("PHC_EXP_TAIL_SKIP");
+        if (skip && strstr(skip, "atom")) t.nb_atom = 0;
+        if (skip && strstr(skip, "bond")) t.nb_bond = 0;
+        if (skip && strstr(skip, "dh")) gl.nb_partial = 0;
+    }
+#endif
     const unsigned nb1 = t.nb_atom + t.nb_bond + gl.nb_partial, nb2 = t.nr_phm + t.nr_bond + t.nr_atom;
-    {
+    rc = launch_grad_direct("step_tail(direct)", gl, s);     // the 128-multiple layers: register-resident tiles, their own launch
+    if (rc) return rc;
+    if (nb1 > 0) {
         ProfScope prof(K_PHM_DH_PARTIAL, s);
-#define PHC_TAIL_LAUNCH(ACTC) PHC_LAUNCH((tail_partial_kernel<ACTC>), dim3(nb1), dim3(256), 0, s, gl.batch, t)
+        GradBatch b64 = gl.batch;                            // this launch takes the 64 x 64 tile jobs only
+        for (int q = 0; q < b64.num; ++q)
+            if (b64.j[q].t128 != 0) b64.j[q].blk0_partial = 0xffffffffu;
+#define PHC_TAIL_LAUNCH(ACTC) PHC_LAUNCH((tail_partial_kernel<ACTC>), dim3(nb1), dim3(256), 0, s, b64, t)
         switch (act) {
             case PHC_ACT_IDENTITY: PHC_TAIL_LAUNCH(PHC_ACT_IDENTITY); break;
             case PHC_ACT_RELU: PHC_TAIL_LAUNCH(PHC_ACT_RELU); break;
@@ -1429,6 +1443,7 @@ int phc_step_tail(const phc_phm_grad_job *jobs, int num_jobs, const phc_table_gr
         rc = check_launch("step_tail(partial)");
         if (rc) return rc;
     }
+
     {
         ProfScope prof(K_PHM_DH_REDUCE, s);
         PHC_LAUNCH(tail_reduce_kernel, dim3(nb2), dim3(256), 0, s, gl.batch, t);

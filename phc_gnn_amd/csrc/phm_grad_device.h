@@ -281,6 +281,234 @@ __device__ __forceinline__ void dH_partial_body128(const float *__restrict__ X, 
     if (ti == 0 && tid < DH_T2 && j0 + tid < out) slab[(size_t)in * out + j0 + tid] = colsum;
 }
 
+// ------------------------------------------------------------------------------------------
+// Register-resident form (in, out multiples of 128, 16-byte aligned operands): every WAVEFRONT owns a whole 128 x 128
+// tile of dH for its own row range and feeds the MFMAs straight from global memory — no LDS staging, no barrier in the
+// main loop.  It works because the contraction index of dH = x^T . dy is the ROW: in v_mfma_f32_32x32x2 lane (r, hh)
+// supplies A[m = r][k = hh] and B[k = hh][n = r], so with row pair (rr, rr+1) <-> k = (0, 1) the half-wave hh reads row
+// rr + hh, and lane r reads the float4 x[row][4r..4r+3] / dy[row][4r..4r+3] (one fully coalesced 512-byte row per half-wave
+// and operand).  Component q of the x load is the A operand of "M block q" = columns {4m + q}, component p of the dy load
+// the B operand of "N block p" = columns {4n + p}: 16 MFMAs per row pair from two 16-byte loads per lane, and
+// acc[q][p][reg] = dH[i0 + 4m + q][j0 + 4r + p] with m = (reg & 3) + 8 (reg >> 2) + 4 hh — the four p of one (q, reg) are
+// one float4 of the slab.  256 accumulator registers per lane (one wavefront per SIMD, 512-register budget); the loads of
+// the next DH_PF row pairs are in flight while the current ones are consumed.
+// A workgroup = 4 wavefronts on 4 consecutive row quarters of one split; they meet once, at the end, through LDS (fixed
+// summation order 0, 1, 2, 3) and write one slab per WORKGROUP.
+// ------------------------------------------------------------------------------------------
+constexpr int DH_D = 128;                               // tile edge of the register-resident form
+#ifndef PHC_DH_PF
+#define PHC_DH_PF 4
+#endif
+constexpr int DH_PF = PHC_DH_PF;                        // row pairs per load batch (two batches alternate)
+constexpr int DH_DIRECT_LDS_BYTES = 4 * 16 * 64 * 16;   // exchange slots: [wave][reg][lane] float4 = 64 KB
+
+// One batch of DH_PF row pairs.  The x operand is always x := max(x * scale + shift, floor) per column: a plain operand is
+// (1, 0, -inf) — exact —, an unapplied batch-norm its (scale, shift) with floor -inf / 0 for identity / relu (the other
+// activations stay on the LDS forms).  MASKED = false: every row of the batch is a live row of the wavefront's range — no
+// selects; MASKED = true: rows at or past `lim` contribute zero.
+// (fp32 MFMAs run on the vector ALU's own multipliers: every VALU instruction between them costs its full issue time, nothing
+// hides in their shadow — measured 36.6 ns per MFMA with 2 VALU instructions per MFMA against 30 with none — so the interior
+// loop carries only the operand transform and the column sums.)
+template <bool MASKED>
+__device__ __forceinline__ void dH_direct_pairs(f32x16 (&acc)[4][4], f32x4 &colsum, const f32x4 (&XV)[DH_PF], const f32x4 (&DV)[DH_PF],
+                                                long long row0, long long lim, int hh, const f32x4 &xf_sc, const f32x4 &xf_sh,
+                                                float floor_) {
+#pragma unroll
+    for (int t = 0; t < DH_PF; ++t) {
+        f32x4 xv = XV[t], dv = DV[t];
+        bool live = true;
+        if constexpr (MASKED) live = row0 + 2 * t + hh < lim;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const float a = fmaxf(fmaf(xv[q], xf_sc[q], xf_sh[q]), floor_);
+            xv[q] = MASKED ? (live ? a : 0.f) : a;
+        }
+        if constexpr (MASKED) {
+#pragma unroll
+            for (int q = 0; q < 4; ++q) dv[q] = live ? dv[q] : 0.f;
+        }
+        colsum += dv;
+#ifdef PHC_EXP_DIRECT_NO_MFMA
+        colsum += xv;
+#else
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int p2 = 0; p2 < 4; ++p2) acc[q][p2] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[q], dv[p2], acc[q][p2], 0, 0, 0);
+#endif
+    }
+}
+
+// Loads of one batch.  EXACT = false: the pair base (wave-uniform: scalar registers) is clamped to the last whole pair of the
+// range, the lane part is a constant byte offset — no per-load vector arithmetic; a pair past the range reads a neighbour pair,
+// which is fine for prefetches whose data is discarded.  EXACT = true: every lane's own row clamped to `last_row` (the masked tail).
+template <bool EXACT>
+__device__ __forceinline__ void dH_direct_load(f32x4 (&XV)[DH_PF], f32x4 (&DV)[DH_PF], const float *__restrict__ X,
+                                               const float *__restrict__ DY, int in, int out, unsigned xoff, unsigned doff,
+                                               unsigned xrow, unsigned drow, long long row0, long long last_row) {
+#pragma unroll
+    for (int t = 0; t < DH_PF; ++t) {
+#ifdef PHC_EXP_DIRECT_NO_LOAD
+        const long long g = 2 * t;                        // experiment: the same few (cached) rows every time
+#else
+        const long long g = row0 + 2 * t;
+#endif
+        if constexpr (EXACT) {
+            const long long gc = min(g, last_row);
+            const bool up = g < last_row;                // the upper half-wave's row exists (else it re-reads row gc: masked)
+            XV[t] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(X + (size_t)gc * in) + (xoff + (up ? xrow : 0u)));
+            DV[t] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(DY + (size_t)gc * out) + (doff + (up ? drow : 0u)));
+        } else {
+            // X / DY point at the wavefront's first row here and row0 counts from it: 32-bit scalar byte offsets (the planner
+            // keeps a wavefront's rows below 2^31 bytes), clamped to the last whole pair of the range
+            const unsigned pr = min((unsigned)g, (unsigned)last_row - 1u);
+            XV[t] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(X) + (pr * ((unsigned)in * 4u) + (xoff + xrow)));
+            DV[t] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(DY) + (pr * ((unsigned)out * 4u) + (doff + drow)));
+        }
+    }
+}
+
+// Rows [w_begin, w_end) of one wavefront; rows at or past xf_count are padding of the x operand (read as zero).
+//   1. the LAST 4 * DH_PF-row iteration of the live rows, masked, straight-line, FIRST (it only initialises the accumulators:
+//      placed after the loop, or as a second body inside it, it made the register allocator shuffle or spill accumulators);
+//   2. the interior iterations, select-free: two register sets alternate, the set being loaded is consumed one half-iteration
+//      later.  The scheduling fences keep each batch of loads where it is written — issued BEFORE the MFMAs of the other set
+//      (left alone, the scheduler sinks every load to just in front of its first use and the wavefront, the only one on its
+//      SIMD, waits out the full memory latency once per row pair);
+//   3. padding rows: only the column sums of dy.
+__device__ __forceinline__ void dH_direct_rows(f32x16 (&acc)[4][4], f32x4 &colsum, const float *__restrict__ X,
+                                               const float *__restrict__ DY, int in, int out, unsigned xoff, unsigned doff,
+                                               unsigned xrow, unsigned drow, long long w_begin, long long w_end, long long last,
+                                               int hh, const f32x4 &xf_sc, const f32x4 &xf_sh, float floor_, long long xf_count) {
+    constexpr long long IT = 4 * DH_PF;
+    f32x4 xa[DH_PF], da[DH_PF], xb[DH_PF], db[DH_PF];
+    const long long lim = max(min(w_end, xf_count), w_begin);
+    const long long n_it = (lim - w_begin + IT - 1) / IT;
+    const long long tail0 = w_begin + (n_it > 0 ? n_it - 1 : 0) * IT;
+    dH_direct_load<true>(xa, da, X, DY, in, out, xoff, doff, xrow, drow, tail0, last);
+    dH_direct_load<true>(xb, db, X, DY, in, out, xoff, doff, xrow, drow, tail0 + 2 * DH_PF, last);
+    __builtin_amdgcn_sched_barrier(0);
+    dH_direct_pairs<true>(acc, colsum, xa, da, tail0, lim, hh, xf_sc, xf_sh, floor_);
+    dH_direct_pairs<true>(acc, colsum, xb, db, tail0 + 2 * DH_PF, lim, hh, xf_sc, xf_sh, floor_);
+    __builtin_amdgcn_sched_barrier(0);
+    if (tail0 > w_begin) {
+        // interior: addresses relative to the wavefront's first row (32-bit arithmetic, scalar)
+        const float *Xw = X + (size_t)w_begin * in, *DYw = DY + (size_t)w_begin * out;
+        const long long lastw = last - w_begin;          // >= 1: the interior exists only when the range has > 4 * DH_PF rows
+        const int n_rows = (int)(tail0 - w_begin);
+        dH_direct_load<false>(xa, da, Xw, DYw, in, out, xoff, doff, xrow, drow, 0, lastw);
+        for (int row = 0; row < n_rows; row += (int)IT) {
+            dH_direct_load<false>(xb, db, Xw, DYw, in, out, xoff, doff, xrow, drow, row + 2 * DH_PF, lastw);
+            __builtin_amdgcn_sched_barrier(0);
+            dH_direct_pairs<false>(acc, colsum, xa, da, row, lim, hh, xf_sc, xf_sh, floor_);
+            __builtin_amdgcn_sched_barrier(0);
+            dH_direct_load<false>(xa, da, Xw, DYw, in, out, xoff, doff, xrow, drow, row + (int)IT, lastw);
+            __builtin_amdgcn_sched_barrier(0);
+            dH_direct_pairs<false>(acc, colsum, xb, db, row + 2 * DH_PF, lim, hh, xf_sc, xf_sh, floor_);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    for (long long g = lim + hh; g < w_end; g += 2)
+        colsum += *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(DY + (size_t)g * out) + doff);
+}
+
+#ifdef PHC_KTIMING
+// experiment build only: wave 0 of the first and the last workgroup stamp the phases of the launch (100 MHz wall clock)
+static __device__ unsigned long long g_dh_ts[64];
+#define DH_STAMP(i)                                                                                    \
+    do {                                                                                               \
+        if (threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))                      \
+            g_dh_ts[(blockIdx.x == 0 ? 0 : 32) + (i)] = wall_clock64();                                \
+    } while (0)
+#else
+#define DH_STAMP(i) do { } while (0)
+#endif
+
+__device__ __forceinline__ void dH_direct_body(const float *__restrict__ X, const float *__restrict__ DY, float *__restrict__ slabs,
+                                               long long N, int in, int out, int tiles_j, long long rows_per_split, int tile,
+                                               long long split, float *__restrict__ smem, const float *__restrict__ xf_stat,
+                                               int xf_act, long long xf_count) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // scalar: the row range of the wavefront is uniform
+    const int r = lane & 31, hh = lane >> 5;
+    const int ti = tile / tiles_j, tj = tile - ti * tiles_j;
+    const int i0 = ti * DH_D, j0 = tj * DH_D;
+    const long long r_begin = split * rows_per_split;
+    const long long r_end = min(N, r_begin + rows_per_split);
+    const long long rq = rows_per_split >> 2;           // rows_per_split % 8 == 0: every quarter starts on an even row
+    const long long w_begin = min(r_begin + wave * rq, r_end), w_end = min(w_begin + rq, r_end);
+    const size_t slab_elems = (size_t)in * out + out;
+    float *slab = slabs + (size_t)split * slab_elems;
+
+    DH_STAMP(0);
+    f32x16 acc[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int p2 = 0; p2 < 4; ++p2)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[q][p2][i] = 0.f;
+    f32x4 colsum = {0.f, 0.f, 0.f, 0.f};
+    f32x4 xf_sc = {1.f, 1.f, 1.f, 1.f}, xf_sh = {0.f, 0.f, 0.f, 0.f};
+    float floor_ = -__builtin_inff();
+    if (xf_stat) {
+        xf_sc = *reinterpret_cast<const f32x4 *>(xf_stat + 2 * (size_t)in + i0 + 4 * r);
+        xf_sh = *reinterpret_cast<const f32x4 *>(xf_stat + 3 * (size_t)in + i0 + 4 * r);
+        if (xf_act == PHC_ACT_RELU) floor_ = 0.f;
+    } else {
+        xf_count = N;                                    // a plain operand has no padding rows of its own
+    }
+    // lane part of every address: this lane's four columns; the upper half-wave reads the odd row of each pair
+    const unsigned xoff = (unsigned)(i0 + 4 * r) * 4u, doff = (unsigned)(j0 + 4 * r) * 4u;
+    const unsigned xrow = hh ? (unsigned)in * 4u : 0u, drow = hh ? (unsigned)out * 4u : 0u;
+    const long long last = max(r_end - 1, 0LL);          // clamped rows: reads past the range stay in bounds
+
+    DH_STAMP(1);
+    if (w_begin < w_end)
+        dH_direct_rows(acc, colsum, X, DY, in, out, xoff, doff, xrow, drow, w_begin, w_end, last, hh, xf_sc, xf_sh, floor_, xf_count);
+
+    DH_STAMP(2);
+    // ---- the four wavefronts meet.  One phase per "M block" q: every wavefront parks the block in LDS ([wave][reg][lane] float4 =
+    // 64 KB, which leaves room for other kernels' workgroups on the CU), then wavefront w sums registers 4w .. 4w+3 of all four
+    // wavefronts in the fixed order 0, 1, 2, 3 and writes those rows of the slab.  Nothing here indexes the accumulators by the
+    // wavefront number (a rotation that did cost 10 us of selects and spills).
+    f32x4 *slots = reinterpret_cast<f32x4 *>(smem);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        if (q) __syncthreads();
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const f32x4 v = {acc[q][0][reg], acc[q][1][reg], acc[q][2][reg], acc[q][3][reg]};
+            slots[(wave * 16 + reg) * 64 + lane] = v;
+        }
+        __syncthreads();
+        f32x4 part[4][4];
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) part[w2][e] = slots[(w2 * 16 + 4 * wave + e) * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const f32x4 v = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
+            const int m = e + 8 * wave + 4 * hh;         // reg = 4 wave + e: (reg & 3) + 8 (reg >> 2) + 4 hh
+            *reinterpret_cast<f32x4 *>(slab + (size_t)(i0 + 4 * m + q) * out + j0 + 4 * r) = v;
+        }
+    }
+    DH_STAMP(3);
+    if (ti == 0) {                                       // db: column sums of dy over the split (uniform per workgroup)
+        __syncthreads();
+        slots[tid] = colsum;                             // [wave][hh][r]
+        __syncthreads();
+        if (tid < 32) {
+            f32x4 v = slots[tid];
+#pragma unroll
+            for (int e = 1; e < 8; ++e) v += slots[e * 32 + tid];           // fixed order: (wave 0: hh 0, hh 1), wave 1, ...
+            *reinterpret_cast<f32x4 *>(slab + (size_t)in * out + j0 + 4 * tid) = v;
+        }
+    }
+    DH_STAMP(4);
+}
+
 // dH[idx] (and the db tail) = sum over splits.  64 elements x 4 split lanes per workgroup; every lane
 // walks its splits in order and the 4 lane sums are added in order: one fixed summation tree.
 __device__ __forceinline__ void dH_reduce_body(const float *__restrict__ slabs, float *__restrict__ dH, size_t slab_elems, int splits,
@@ -320,7 +548,7 @@ struct GradJobDev {
     long long N, rows_per_split;
     int in, out, n, kin, kout;
     int tiles_j, tiles, splits, vec4;
-    int dA_blocks, t128, dw_transposed;
+    int dA_blocks, t128, dw_transposed;                      // t128: tile form 0 = 64 x 64 (LDS), 1 = 128 x 128 (LDS), 2 = register-resident
     const float *xf_stat;                                    // X operand = act(x * scale + shift) (see dH_partial_body)
     const int *xf_n_valid;
     int xf_act;
@@ -358,13 +586,15 @@ __device__ __forceinline__ int grad_job_of_block(const GradBatch &b, unsigned bx
 // Host: plans, slab placement and the by-value job table of one launch (<= GRAD_JOBS_PER_LAUNCH jobs); defined in
 // phm_linear.hip.  Returns PHC_OK or an error code (phc_last_error has the text).
 struct GradLaunch {
-    GradBatch batch;                                        // blk0_partial of 128-tile jobs is relative to nb_partial128
-    unsigned nb_partial, nb_partial128, nb_reduce, nb_contract;
+    GradBatch batch;                                        // blk0_partial counts inside the job's own tile form
+    unsigned nb_partial, nb_partial128, nb_direct, nb_reduce, nb_contract;
 };
 size_t grad_chunk_ws_floats(const phc_phm_grad_job *jobs, int num_jobs);
 int prepare_grad_launch(const char *who, const phc_phm_grad_job *jobs, int num_jobs, float *ws_base, GradLaunch *out);
 int launch_grad_rest(const char *who, const GradLaunch &gl, bool partial64_too, hipStream_t s);
 int launch_grad_contract(const char *who, const GradLaunch &gl, hipStream_t s);
+// the register-resident jobs' partial launch (if any); profile = false: the caller already holds a launch-profiler scope
+int launch_grad_direct(const char *who, const GradLaunch &gl, hipStream_t s, bool profile = true);
 int check_grad_jobs(const char *who, const phc_phm_grad_job *jobs, int num_jobs);
 
 }  // namespace phc

