@@ -152,7 +152,7 @@ class PHMMLP(nn.Module):
         fixed-shape batch and stay out of the batch-norm statistics."""
         want = self.training and x.is_cuda and x.dim() == 2
         x = self.linear1(x, bn_stats=_engine.BNStatsRequest(n_valid) if (want and self.norm_flag) else None)
-        out_req = _engine.BNStatsRequest(n_valid) if (want and getattr(self, "out_norm_follows", False)) else None
+        out_req = _engine.BNStatsRequest(n_valid, "apply") if (want and getattr(self, "out_norm_follows", False)) else None
         if self.norm_flag and want:
             # norm -> activation -> linear2 in the second GEMM's operand staging: the normalised activation never exists
             y = self.norm.forward_fused_linear(x, self.activation_str, n_valid, self.linear2, out_req)
@@ -163,7 +163,7 @@ class PHMMLP(nn.Module):
         else:
             x = self.activation(x)
         # ``out_norm_follows`` is set by the owning model when it normalises this MLP's output directly
-        return self.linear2(x, bn_stats=_engine.BNStatsRequest(n_valid) if (want and getattr(self, "out_norm_follows", False))
+        return self.linear2(x, bn_stats=_engine.BNStatsRequest(n_valid, "apply") if (want and getattr(self, "out_norm_follows", False))
                             else None)
 
     def __repr__(self):

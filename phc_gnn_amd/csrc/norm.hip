@@ -432,12 +432,103 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_merged_kernel(const float
     }
 }
 
+// ---- forward, ONE launch, statistics from an ACCUMULATOR (phc_common.h): the producing GEMM added every workgroup's (sum, sum of
+// squares) into 64-bit fixed-point words; a workgroup here reads the totals of its 32 columns (4 replicas x 4 words), derives
+// mean / invstd in double and normalises its rows.  No merge launch, no per-workgroup partial rows.
+template <int ACT>
+__global__ __launch_bounds__(BN_THREADS) void bn_apply_acc_kernel(const float *__restrict__ x, BnParams p, const int *__restrict__ n_valid,
+                                                                long long N, int h, float momentum, float eps,
+                                                                const unsigned long long *__restrict__ acc, long long rows_per_group,
+                                                                const float *__restrict__ residual, float *__restrict__ stat,
+                                                                float *__restrict__ out, BnDrop drop = BnDrop{}) {
+    __shared__ double r_d[BNM_LANES][BNM_COLS];
+    __shared__ float s_scale[BNM_COLS], s_shift[BNM_COLS];
+    static_assert(BNM_LANES == 2 * STAT_ACC_REP, "one (quantity, replica) pair per partial lane");
+    const int tid = threadIdx.x;
+    const int ci = tid & (BNM_COLS - 1), pl = tid / BNM_COLS;
+    const int c = blockIdx.x * BNM_COLS + ci;                 // h % 32 == 0
+    const long long count = n_valid ? min((long long)*n_valid, N) : N;
+    const bool dropping = drop.p > 0.f;
+    const unsigned long long seed = dropping ? drop.state[0] : 0ull, step = dropping ? drop.state[1] : 0ull;
+    r_d[pl][ci] = stat_acc_part(acc, h, pl & (STAT_ACC_REP - 1), pl / STAT_ACC_REP, c);
+    const int comp = c / p.k, kk = c - comp * p.k;
+    float w = 1.f, bq = 0.f, rm_old = 0.f, rv_old = 1.f;
+    if (pl == 0) {
+        for (int q = 0; q < p.n_comp; ++q)
+            if (q == comp) {
+                if (p.has_weight) w = p.weight[q][kk];
+                if (p.has_bias) bq = p.bias[q][kk];
+                if (p.has_running && blockIdx.y == 0) { rm_old = p.running_mean[q][kk]; rv_old = p.running_var[q][kk]; }
+            }
+    }
+    __syncthreads();
+    if (pl == 0) {
+        double S = 0.0, Q = 0.0;
+#pragma unroll
+        for (int rp = 0; rp < STAT_ACC_REP; ++rp) {
+            S += r_d[rp][ci];
+            Q += r_d[STAT_ACC_REP + rp][ci];
+        }
+        const double cntd = (double)max(count, 1LL);
+        const double meand = S / cntd;
+        const double vard = fmax(Q / cntd - meand * meand, 0.0);
+        const float mean = (float)meand, var = (float)vard;
+        const float invstd = 1.f / sqrtf(var + eps);
+        s_scale[ci] = invstd * w;
+        s_shift[ci] = bq - mean * invstd * w;
+        if (blockIdx.y == 0) {
+            stat[c] = mean;
+            stat[h + c] = invstd;
+            stat[2 * h + c] = invstd * w;
+            stat[3 * h + c] = bq - mean * invstd * w;
+            stat[4 * h + c] = w;
+            stat[5 * h + c] = bq;
+            if (p.has_running) {
+                const float unbiased = count > 1 ? (float)(vard * cntd / (cntd - 1.0)) : var;
+                for (int q = 0; q < p.n_comp; ++q)
+                    if (q == comp) {
+                        p.running_mean[q][kk] = (1.f - momentum) * rm_old + momentum * mean;
+                        p.running_var[q][kk] = (1.f - momentum) * rv_old + momentum * unbiased;
+                    }
+            }
+        }
+    }
+    if (blockIdx.x == 0 && blockIdx.y == 0 && p.has_nbt && tid < p.n_comp)
+        for (int q = 0; q < p.n_comp; ++q)
+            if (q == tid) *p.num_batches_tracked[q] += 1;
+    __syncthreads();
+    const int c4 = tid & 7, rl = tid >> 3;
+    const int col = blockIdx.x * BNM_COLS + c4 * 4;
+    const float4 sc4 = *reinterpret_cast<const float4 *>(s_scale + c4 * 4), sh4 = *reinterpret_cast<const float4 *>(s_shift + c4 * 4);
+    const long long r0 = (long long)blockIdx.y * rows_per_group, r1 = min(N, r0 + rows_per_group);
+    for (long long r = r0 + rl; r < r1; r += BN_THREADS / 8) {
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        const size_t e = (size_t)r * h + col;
+        if (r < count) {
+            const float4 v = *reinterpret_cast<const float4 *>(x + e);
+            o.x = bn_act<ACT>(fmaf(v.x, sc4.x, sh4.x)); o.y = bn_act<ACT>(fmaf(v.y, sc4.y, sh4.y));
+            o.z = bn_act<ACT>(fmaf(v.z, sc4.z, sh4.z)); o.w = bn_act<ACT>(fmaf(v.w, sc4.w, sh4.w));
+            if (dropping) {
+                const float4 f = drop_factors(drop, seed, step, r, col, h);
+                o.x *= f.x; o.y *= f.y; o.z *= f.z; o.w *= f.w;
+            }
+            if (residual) {
+                const float4 rr = *reinterpret_cast<const float4 *>(residual + e);
+                o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
+            }
+        }
+        *reinterpret_cast<float4 *>(out + e) = o;
+    }
+}
+
 // ---- pass 1 (backward): sum g and sum g*x_hat per column ------------------------------------------
 template <int ACT, int VEC>
 __global__ __launch_bounds__(BN_THREADS) void bn_bwd_partial_kernel(const float *__restrict__ dy, const float *__restrict__ x,
                                                                   const float *__restrict__ stat,
                                                                   const int *__restrict__ n_valid, long long N, int h,
-                                                                  long long rows_per_block, float *__restrict__ partial, BnDrop drop = BnDrop{}) {
+                                                                  long long rows_per_block, float *__restrict__ partial, BnDrop drop = BnDrop{},
+                                                                  int acc_mode = 0) {
+    // acc_mode: `partial` is a statistics accumulator (phc_common.h) — the sums of this row block are ADDED into it
     __shared__ float red[2 * VEC * BN_THREADS];
     const long long count = n_valid ? min((long long)*n_valid, N) : N;
     const bool dropping = VEC == 4 && drop.p > 0.f;
@@ -497,8 +588,14 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_partial_kernel(const float 
                 a += red[v * BN_THREADS + l * cols + cc];
                 bsum += red[(VEC + v) * BN_THREADS + l * cols + cc];
             }
-            partial[(size_t)blockIdx.x * 2 * h + (cbase + cc) * VEC + v] = a;
-            partial[(size_t)blockIdx.x * 2 * h + h + (cbase + cc) * VEC + v] = bsum;
+            if (acc_mode) {
+                unsigned long long *acc64 = reinterpret_cast<unsigned long long *>(partial);
+                stat_acc_add(acc64, h, (int)(blockIdx.x % STAT_ACC_REP), 0, (cbase + cc) * VEC + v, (double)a);
+                stat_acc_add(acc64, h, (int)(blockIdx.x % STAT_ACC_REP), 1, (cbase + cc) * VEC + v, (double)bsum);
+            } else {
+                partial[(size_t)blockIdx.x * 2 * h + (cbase + cc) * VEC + v] = a;
+                partial[(size_t)blockIdx.x * 2 * h + h + (cbase + cc) * VEC + v] = bsum;
+            }
         }
         __syncthreads();
     }
@@ -551,12 +648,25 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_finalize_kernel(const int *
     }
 }
 
+// accumulator form without a dx request: only dwb = [dweight | dbias] from the totals
+__global__ void bn_bwd_acc_dwb_kernel(int h, const unsigned long long *__restrict__ acc, float *__restrict__ dwb) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c < h && dwb) {
+        dwb[c] = (float)stat_acc_total(acc, h, 1, c);
+        dwb[h + c] = (float)stat_acc_total(acc, h, 0, c);
+    }
+}
+
 // ---- pass 3 (backward): dx = w*invstd*(g - mean(g) - x_hat*mean(g*x_hat)) ---------------------------
 template <int ACT>
 __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const float *__restrict__ dy, const float *__restrict__ x,
                                                                 const float *__restrict__ stat,
                                                                 const int *__restrict__ n_valid, long long N, int h,
-                                                                const float *__restrict__ bstat, float *__restrict__ dx, BnDrop drop = BnDrop{}) {
+                                                                const float *__restrict__ bstat, float *__restrict__ dx, BnDrop drop = BnDrop{},
+                                                                const unsigned long long *__restrict__ acc = nullptr,
+                                                                float *__restrict__ dwb = nullptr, int training = 1) {
+    // acc != NULL: the column sums (sum g, sum g * x_hat) come as accumulator totals (phc_common.h) instead of bstat; the first
+    // workgroup also writes dwb = [dweight | dbias] from them (what bn_bwd_finalize_kernel does on the partial-row path)
     const bool dropping = drop.p > 0.f;
     const unsigned long long seed = dropping ? drop.state[0] : 0ull, step = dropping ? drop.state[1] : 0ull;
     extern __shared__ float sm[];                            // mean, invstd, w, b, mg, mgx : 6 * h
@@ -568,8 +678,19 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const float *_
         s_inv[c] = stat[h + c];
         s_w[c] = stat[4 * h + c];
         s_b[c] = stat[5 * h + c];
-        s_mg[c] = bstat[c];
-        s_mgx[c] = bstat[h + c];
+        if (acc) {
+            const float a = (float)stat_acc_total(acc, h, 0, c), b = (float)stat_acc_total(acc, h, 1, c);
+            const float cnt = (float)max(count, 1LL);
+            s_mg[c] = training ? a / cnt : 0.f;
+            s_mgx[c] = training ? b / cnt : 0.f;
+            if (dwb && blockIdx.x == 0) {
+                dwb[c] = b;                                  // dweight = sum g * x_hat
+                dwb[h + c] = a;                              // dbias   = sum g
+            }
+        } else {
+            s_mg[c] = bstat[c];
+            s_mgx[c] = bstat[h + c];
+        }
     }
     __syncthreads();
     auto one = [&](float xv, float gv, int c) -> float {
@@ -829,15 +950,34 @@ int phc_bn_fwd_from_partials(const float *x, const float *stats_partial, const f
     if (rc) return rc;
     rc = fill_params("phc_bn_fwd_from_partials", &p, weight, bias, running_mean, running_var, num_batches_tracked, n_comp, h);
     if (rc) return rc;
-    PHC_REQUIRE(N >= 1 && num_partials >= 1 && num_partials <= BN_MAX_PARTIALS, PHC_ERR_INVALID_ARG,
+    const bool acc_mode = stats_counts == nullptr;           // accumulator form: stats_partial holds totals, nothing to merge
+    PHC_REQUIRE(N >= 1 && (acc_mode || (num_partials >= 1 && num_partials <= BN_MAX_PARTIALS)), PHC_ERR_INVALID_ARG,
                 "phc_bn_fwd_from_partials: N=%lld, %d partials (max %d)", (long long)N, num_partials, BN_MAX_PARTIALS);
     PHC_REQUIRE(act >= PHC_ACT_IDENTITY && act <= PHC_ACT_SELU, PHC_ERR_INVALID_ARG, "phc_bn_fwd_from_partials: unknown activation %d", act);
-    PHC_REQUIRE(x && out && save_stat && stats_partial && stats_counts, PHC_ERR_INVALID_ARG, "phc_bn_fwd_from_partials: null pointer");
+    PHC_REQUIRE(x && out && save_stat && stats_partial, PHC_ERR_INVALID_ARG, "phc_bn_fwd_from_partials: null pointer");
     PHC_REQUIRE(h <= 8192, PHC_ERR_UNSUPPORTED, "phc_bn_fwd_from_partials: h=%d too wide", h);
     const bool vec4 = (h % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0) &&
                       (!residual || (reinterpret_cast<uintptr_t>(residual) & 15) == 0);
     PHC_REQUIRE(vec4 || h % 4 != 0, PHC_ERR_UNSUPPORTED, "phc_bn_fwd_from_partials: rows must be 16-byte aligned when h %% 4 == 0");
     hipStream_t s = (hipStream_t)stream;
+    if (acc_mode) {
+        PHC_REQUIRE(vec4 && h % BNM_COLS == 0 && (reinterpret_cast<uintptr_t>(stats_partial) & 7) == 0, PHC_ERR_UNSUPPORTED,
+                    "phc_bn_fwd_from_partials: the accumulator form needs h %% 32 == 0 and aligned rows (h=%d)", h);
+        long long groups = (N + 127) / 128;
+        const long long cap = (8LL * 256) / (h / BNM_COLS);
+        if (groups > cap) groups = cap;
+        if (groups < 1) groups = 1;
+        const long long rows_per_group = (N + groups - 1) / groups;
+        groups = (N + rows_per_group - 1) / rows_per_group;
+        const unsigned long long *acc = reinterpret_cast<const unsigned long long *>(stats_partial);
+        ProfScope prof(K_BN_APPLY, s);
+#define PHC_BN_FWDA(ACTC)                                                                                                      \
+    PHC_LAUNCH((bn_apply_acc_kernel<ACTC>), dim3(h / BNM_COLS, (unsigned)groups), dim3(BN_THREADS), 0, s, x, p, n_valid_dev,     \
+               (long long)N, h, momentum, eps, acc, rows_per_group, residual, save_stat, out, drop)
+        PHC_BN_ACT_SWITCH(act, PHC_BN_FWDA)
+#undef PHC_BN_FWDA
+        return check_launch("bn_apply_acc");
+    }
     const char *env_merged = getenv("PHC_BN_APPLY_MERGED");               // A/B switch (read per call: cheap next to a launch)
     const bool no_merged = env_merged && atoi(env_merged) == 0;
     if (vec4 && h % BNM_COLS == 0 && !no_merged) {
@@ -895,7 +1035,9 @@ int phc_bn_bwd(const float *dy, const float *x, const float *save_stat, const in
         return PHC_OK;
     }
     PHC_REQUIRE(dy && x && save_stat, PHC_ERR_INVALID_ARG, "phc_bn_bwd: null pointer");
-    PHC_REQUIRE(ws && ws_bytes >= phc_bn_ws_bytes(N, h), PHC_ERR_WORKSPACE, "phc_bn_bwd: workspace too small");
+    const bool acc_mode = ws && ws_bytes == 0;               // accumulator form: ws is a zeroed statistics accumulator
+    PHC_REQUIRE(ws && (acc_mode || ws_bytes >= phc_bn_ws_bytes(N, h)), PHC_ERR_WORKSPACE, "phc_bn_bwd: workspace too small");
+    PHC_REQUIRE(!acc_mode || (reinterpret_cast<uintptr_t>(ws) & 7) == 0, PHC_ERR_INVALID_ARG, "phc_bn_bwd: the accumulator must be 8-byte aligned");
     BnPlan plan = bn_plan(N);
     float *partial = static_cast<float *>(ws);
     const bool vec4 = (h % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((reinterpret_cast<uintptr_t>(dy) & 15) == 0) &&
@@ -907,19 +1049,23 @@ int phc_bn_bwd(const float *dy, const float *x, const float *save_stat, const in
 #define PHC_BN_BP(ACTC)                                                                                                      \
     if (vec4)                                                                                                                \
         PHC_LAUNCH((bn_bwd_partial_kernel<ACTC, 4>), dim3(plan.num_partials), dim3(BN_THREADS), 0, s, dy, x, save_stat,    \
-                           n_valid_dev, (long long)N, h, plan.rows_per_block, partial, drop);                                \
+                           n_valid_dev, (long long)N, h, plan.rows_per_block, partial, drop, acc_mode ? 1 : 0);              \
     else                                                                                                                     \
         PHC_LAUNCH((bn_bwd_partial_kernel<ACTC, 1>), dim3(plan.num_partials), dim3(BN_THREADS), 0, s, dy, x, save_stat,    \
-                           n_valid_dev, (long long)N, h, plan.rows_per_block, partial, drop)
+                           n_valid_dev, (long long)N, h, plan.rows_per_block, partial, drop, acc_mode ? 1 : 0)
         PHC_BN_ACT_SWITCH(act, PHC_BN_BP)
 #undef PHC_BN_BP
         rc = check_launch("bn_bwd_partial");
         if (rc) return rc;
     }
-    {
+    const unsigned long long *acc = acc_mode ? static_cast<const unsigned long long *>(ws) : nullptr;
+    if (!acc_mode || !dx) {                                  // (accumulator form without dx: the finaliser still owes dwb)
         ProfScope prof(K_BN_BWD_FINALIZE, s);
-        PHC_LAUNCH(bn_bwd_finalize_kernel, dim3((h + 7) / 8), dim3(BN_THREADS), 0, s, n_valid_dev, (long long)N, h, training,
-                           partial, plan.num_partials, dwb_flat, bstat);
+        if (acc_mode)
+            PHC_LAUNCH(bn_bwd_acc_dwb_kernel, dim3((h + BN_THREADS - 1) / BN_THREADS), dim3(BN_THREADS), 0, s, h, acc, dwb_flat);
+        else
+            PHC_LAUNCH(bn_bwd_finalize_kernel, dim3((h + 7) / 8), dim3(BN_THREADS), 0, s, n_valid_dev, (long long)N, h, training,
+                       partial, plan.num_partials, dwb_flat, bstat);
         rc = check_launch("bn_bwd_finalize");
         if (rc) return rc;
     }
@@ -928,7 +1074,7 @@ int phc_bn_bwd(const float *dy, const float *x, const float *save_stat, const in
     ProfScope prof(K_BN_BWD_APPLY, s);
 #define PHC_BN_BA(ACTC)                                                                                                      \
     PHC_LAUNCH((bn_bwd_apply_kernel<ACTC>), dim3(apply_grid(N, h)), dim3(BN_THREADS), lds, s, dy, x, save_stat,             \
-                       n_valid_dev, (long long)N, h, bstat, dx, drop)
+                       n_valid_dev, (long long)N, h, bstat, dx, drop, acc, dwb_flat, training)
     PHC_BN_ACT_SWITCH(act, PHC_BN_BA)
 #undef PHC_BN_BA
     return check_launch("bn_bwd_apply");
@@ -937,21 +1083,29 @@ int phc_bn_bwd(const float *dy, const float *x, const float *save_stat, const in
 int phc_bn_bwd_from_partials(const float *dy, const float *x, const float *save_stat, const float *sums_partial, int num_partials,
                              const int32_t *n_valid_dev, int64_t N, int h, int act, float *dx, float *dwb_flat, void *ws,
                              size_t ws_bytes, void *stream) {
-    PHC_REQUIRE(N >= 1 && h >= 1 && h <= 8192 && num_partials >= 1 && num_partials <= BN_MAX_PARTIALS, PHC_ERR_INVALID_ARG,
+    const bool acc_mode = num_partials == 0;                 // accumulator form: sums_partial holds totals (no workspace needed)
+    PHC_REQUIRE(N >= 1 && h >= 1 && h <= 8192 && num_partials >= 0 && num_partials <= BN_MAX_PARTIALS, PHC_ERR_INVALID_ARG,
                 "phc_bn_bwd_from_partials: N=%lld h=%d partials=%d", (long long)N, h, num_partials);
     PHC_REQUIRE(act >= PHC_ACT_IDENTITY && act <= PHC_ACT_SELU, PHC_ERR_INVALID_ARG, "phc_bn_bwd_from_partials: unknown activation %d", act);
     PHC_REQUIRE(dy && x && save_stat && sums_partial, PHC_ERR_INVALID_ARG, "phc_bn_bwd_from_partials: null pointer");
-    PHC_REQUIRE(ws && ws_bytes >= sizeof(float) * 2 * (size_t)h, PHC_ERR_WORKSPACE, "phc_bn_bwd_from_partials: workspace too small");
+    PHC_REQUIRE(acc_mode || (ws && ws_bytes >= sizeof(float) * 2 * (size_t)h), PHC_ERR_WORKSPACE,
+                "phc_bn_bwd_from_partials: workspace too small");
+    PHC_REQUIRE(!acc_mode || (reinterpret_cast<uintptr_t>(sums_partial) & 7) == 0, PHC_ERR_INVALID_ARG,
+                "phc_bn_bwd_from_partials: the accumulator must be 8-byte aligned");
     const bool vec4 = (h % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0) && ((reinterpret_cast<uintptr_t>(dy) & 15) == 0) &&
                       (!dx || (reinterpret_cast<uintptr_t>(dx) & 15) == 0);
     PHC_REQUIRE(vec4 || h % 4 != 0, PHC_ERR_UNSUPPORTED, "phc_bn_bwd_from_partials: rows must be 16-byte aligned when h %% 4 == 0");
     hipStream_t s = (hipStream_t)stream;
     float *bstat = static_cast<float *>(ws);
+    const unsigned long long *acc = acc_mode ? reinterpret_cast<const unsigned long long *>(sums_partial) : nullptr;
     int rc;
-    {
+    if (!acc_mode || !dx) {
         ProfScope prof(K_BN_BWD_FINALIZE, s);
-        PHC_LAUNCH(bn_bwd_finalize_kernel, dim3((h + 7) / 8), dim3(BN_THREADS), 0, s, n_valid_dev, (long long)N, h, 1, sums_partial,
-                   num_partials, dwb_flat, bstat);
+        if (acc_mode)
+            PHC_LAUNCH(bn_bwd_acc_dwb_kernel, dim3((h + BN_THREADS - 1) / BN_THREADS), dim3(BN_THREADS), 0, s, h, acc, dwb_flat);
+        else
+            PHC_LAUNCH(bn_bwd_finalize_kernel, dim3((h + 7) / 8), dim3(BN_THREADS), 0, s, n_valid_dev, (long long)N, h, 1, sums_partial,
+                       num_partials, dwb_flat, bstat);
         rc = check_launch("bn_bwd_finalize(from partials)");
         if (rc) return rc;
     }
@@ -960,7 +1114,7 @@ int phc_bn_bwd_from_partials(const float *dy, const float *x, const float *save_
     ProfScope prof(K_BN_BWD_APPLY, s);
 #define PHC_BN_BAP(ACTC)                                                                                                     \
     PHC_LAUNCH((bn_bwd_apply_kernel<ACTC>), dim3(apply_grid(N, h)), dim3(BN_THREADS), lds, s, dy, x, save_stat, n_valid_dev,  \
-               (long long)N, h, bstat, dx)
+               (long long)N, h, bstat, dx, BnDrop{}, acc, dwb_flat, 1)
     PHC_BN_ACT_SWITCH(act, PHC_BN_BAP)
 #undef PHC_BN_BAP
     return check_launch("bn_bwd_apply");

@@ -143,6 +143,39 @@ inline void ext_launch(void (*kernel)(Formals...), dim3 grid, dim3 block, unsign
         }                                                                                                                 \
     } while (0)
 
+// ---- statistics accumulators --------------------------------------------------------------------------------------
+// Column sums that many workgroups of one launch contribute to, WITHOUT a merge launch behind it: every workgroup adds its
+// partial with 64-bit INTEGER atomics (integer adds commute: the total does not depend on the arrival order, results stay
+// bit-reproducible) and the next launch reads the totals in its prologue.  A value d is split into two fixed-point words,
+// hi = rint(d * 2^12) and lo = rint((d - hi * 2^-12) * 2^62): resolution 2^-62 up to |total| < 2^51 — partials beyond that
+// saturate, by then the fp32 activations themselves have long overflowed.  Layout (caller-zeroed, 8-byte words):
+// [STAT_ACC_REP replicas][2 quantities][hi | lo][h columns]; a workgroup adds into replica (its row-group index % REP),
+// which spreads the same-address traffic (108 adders per address cost +2 us per launch, 27 per address +1).
+constexpr int STAT_ACC_REP = 4;
+__device__ __forceinline__ void stat_acc_add(unsigned long long *__restrict__ acc, int h, int rep, int qty, int col, double d) {
+    const long long hi = __double2ll_rn(d * 4096.0);
+    const long long lo = __double2ll_rn((d - (double)hi * (1.0 / 4096.0)) * 4611686018427387904.0);
+    unsigned long long *p = acc + ((size_t)(rep * 2 + qty) * 2) * h + col;
+    atomicAdd(p, (unsigned long long)hi);
+    atomicAdd(p + h, (unsigned long long)lo);
+}
+// one replica's words of (qty, col) as a double (the caller adds the replicas in a fixed order)
+__device__ __forceinline__ double stat_acc_part(const unsigned long long *__restrict__ acc, int h, int rep, int qty, int col) {
+    const unsigned long long *p = acc + ((size_t)(rep * 2 + qty) * 2) * h + col;
+    const long long hi = (long long)p[0], lo = (long long)p[h];
+    return (double)hi * (1.0 / 4096.0) + (double)lo * (1.0 / 4611686018427387904.0);
+}
+__device__ __forceinline__ double stat_acc_total(const unsigned long long *__restrict__ acc, int h, int qty, int col) {
+    long long hi = 0, lo = 0;
+#pragma unroll
+    for (int rep = 0; rep < STAT_ACC_REP; ++rep) {
+        const unsigned long long *p = acc + ((size_t)(rep * 2 + qty) * 2) * h + col;
+        hi += (long long)p[0];
+        lo += (long long)p[h];
+    }
+    return (double)hi * (1.0 / 4096.0) + (double)lo * (1.0 / 4611686018427387904.0);
+}
+
 inline int check_launch(const char *what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

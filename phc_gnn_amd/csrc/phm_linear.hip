@@ -334,7 +334,9 @@ __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
     long long M, int K, int Nout, int n, int kin, int kout, int out_vec4,
     const int *__restrict__ n_valid = nullptr, float *__restrict__ stats_partial = nullptr,
     float *__restrict__ stats_counts = nullptr, const float *__restrict__ xf_stat = nullptr, int xf_act = 0,
-    const float *__restrict__ bw_x = nullptr, const float *__restrict__ bw_stat = nullptr, int bw_act = 0) {
+    const float *__restrict__ bw_x = nullptr, const float *__restrict__ bw_stat = nullptr, int bw_act = 0, int stats_acc = 0) {
+    // stats_acc != 0: stats_partial is a statistics accumulator (phc_common.h: 64-bit fixed-point words added with integer
+    // atomics, no merge launch behind this one) instead of one [2 * Nout] partial row per workgroup row
     // STATS bit 0: emit batch-norm partials of the output; bit 1 (XF): the INPUT is a batch-norm that has not been
     // applied yet — x := act(x * scale + shift) per column (xf_stat = the norm's [mean|invstd|scale|shift|w|b], width K),
     // rows >= *n_valid read as 0 — evaluated while the slab is staged, so the normalised tensor never exists in HBM
@@ -686,8 +688,14 @@ __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
             }
             const int col = j0 + cc;
             if (col < Nout) {
-                stats_partial[(size_t)pby * 2 * Nout + col] = a;
-                stats_partial[(size_t)pby * 2 * Nout + Nout + col] = b2;
+                if (stats_acc) {
+                    unsigned long long *acc64 = reinterpret_cast<unsigned long long *>(stats_partial);
+                    stat_acc_add(acc64, Nout, (int)(pby % STAT_ACC_REP), 0, col, (double)a);
+                    stat_acc_add(acc64, Nout, (int)(pby % STAT_ACC_REP), 1, col, (double)b2);
+                } else {
+                    stats_partial[(size_t)pby * 2 * Nout + col] = a;
+                    stats_partial[(size_t)pby * 2 * Nout + Nout + col] = b2;
+                }
             }
         }
     }
@@ -724,10 +732,18 @@ __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
             }
             const int col = j0 + cc;
             if (col < Nout) {
-                stats_partial[(size_t)pby * 2 * Nout + col] = sum;
-                stats_partial[(size_t)pby * 2 * Nout + Nout + col] = m2;
+                if (stats_acc) {
+                    // additive form of the workgroup's (sum, M2 about its own mean): sum and sum of squares, in double
+                    unsigned long long *acc64 = reinterpret_cast<unsigned long long *>(stats_partial);
+                    const double sd = (double)sum, qd = (double)m2 + (nt > 0.f ? sd * sd / (double)nt : 0.0);
+                    stat_acc_add(acc64, Nout, (int)(pby % STAT_ACC_REP), 0, col, sd);
+                    stat_acc_add(acc64, Nout, (int)(pby % STAT_ACC_REP), 1, col, qd);
+                } else {
+                    stats_partial[(size_t)pby * 2 * Nout + col] = sum;
+                    stats_partial[(size_t)pby * 2 * Nout + Nout + col] = m2;
+                }
             }
-            if (pbx == 0 && cc == 0) stats_counts[pby] = nt;
+            if (!stats_acc && pbx == 0 && cc == 0) stats_counts[pby] = nt;
         }
     }
     ST_STAMP(8);
@@ -991,7 +1007,7 @@ static int launch_stream_cfg(const float *X, const float *A, const float *W, con
                              float *out, int64_t M, int K, int Nout, int n, int kin, int kout, int wg_per_cu, hipStream_t s,
                              const int *n_valid = nullptr, float *stats_partial = nullptr, float *stats_counts = nullptr,
                              int *num_partials = nullptr, const float *xf_stat = nullptr, int xf_act = 0,
-                             const float *bw_x = nullptr, const float *bw_stat = nullptr, int bw_act = 0) {
+                             const float *bw_x = nullptr, const float *bw_stat = nullptr, int bw_act = 0, int stats_acc = 0) {
     const int panels = (Nout + BN - 1) / BN;
     const int64_t slabs = (M + 31) / 32;
     int64_t gy = ((int64_t)wg_per_cu * num_cu() + panels - 1) / panels;
@@ -1017,7 +1033,7 @@ static int launch_stream_cfg(const float *X, const float *A, const float *W, con
     }
     PHC_LAUNCH((phm_stream_kernel<TRANS, NPHM, BN, WAVES, STATS>), dim3(panels, (unsigned)gy), dim3(64 * WAVES), lds, s, X, A, W,
                        bias, residual, out, (long long)M, K, Nout, n, kin, kout, out_vec4, n_valid, stats_partial, stats_counts,
-                       xf_stat, xf_act, bw_x, bw_stat, bw_act);
+                       xf_stat, xf_act, bw_x, bw_stat, bw_act, stats_acc);
     return PHC_OK;
 }
 
@@ -1505,8 +1521,10 @@ int phc_gemm_stats_max_partials(void) { return GEMM_STATS_MAX_PARTIALS; }
 int phc_gemm_prebuilt_stats(const float *x, const float *M, const float *b, int64_t N, int K, int Nout, float *y,
                             const int32_t *n_valid_dev, float *stats_partial, float *stats_counts, int *num_partials, void *stream) {
     PHC_REQUIRE(N >= 1 && K >= 1 && Nout >= 1, PHC_ERR_INVALID_ARG, "phc_gemm_prebuilt_stats: bad shape");
-    PHC_REQUIRE(x && M && y && stats_partial && stats_counts && num_partials, PHC_ERR_INVALID_ARG,
-                "phc_gemm_prebuilt_stats: null pointer");
+    const int acc = stats_counts ? 0 : 1;                    // accumulator form: stats_partial is a statistics accumulator
+    PHC_REQUIRE(x && M && y && stats_partial && (acc || num_partials), PHC_ERR_INVALID_ARG, "phc_gemm_prebuilt_stats: null pointer");
+    PHC_REQUIRE(!acc || (reinterpret_cast<uintptr_t>(stats_partial) & 7) == 0, PHC_ERR_INVALID_ARG,
+                "phc_gemm_prebuilt_stats: the accumulator must be 8-byte aligned");
     PHC_REQUIRE(K <= GEMM_STREAM_MAX_K && K % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
                     (reinterpret_cast<uintptr_t>(M) & 15) == 0,
                 PHC_ERR_UNSUPPORTED, "phc_gemm_prebuilt_stats: needs K <= 256, K %% 4 == 0 and 16-byte aligned x, M (K=%d)", K);
@@ -1515,16 +1533,16 @@ int phc_gemm_prebuilt_stats(const float *x, const float *M, const float *b, int6
     static const int small_bn = getenv("PHC_GEMM_PRE_BN") ? atoi(getenv("PHC_GEMM_PRE_BN")) : 32;
     if (N >= gemm_wide_k_m() && Nout > 64 && K > 128)
         launch_stream_cfg<0, -1, 64, 8, 1>(x, nullptr, M, b, nullptr, y, N, K, Nout, 1, K, Nout, 1, s, n_valid_dev, stats_partial,
-                                           stats_counts, num_partials);
+                                           stats_counts, num_partials, nullptr, 0, nullptr, nullptr, 0, acc);
     else if (N >= GEMM_BIG_M && Nout > 64)
         launch_stream_cfg<0, -1, 128, 8, 1>(x, nullptr, M, b, nullptr, y, N, K, Nout, 1, K, Nout, 1, s, n_valid_dev, stats_partial,
-                                            stats_counts, num_partials);
+                                            stats_counts, num_partials, nullptr, 0, nullptr, nullptr, 0, acc);
     else if (small_bn == 32 && Nout > 32 && N <= 32 * 1024)
         launch_stream_cfg<0, -1, 32, 4, 1>(x, nullptr, M, b, nullptr, y, N, K, Nout, 1, K, Nout, 3, s, n_valid_dev, stats_partial,
-                                           stats_counts, num_partials);
+                                           stats_counts, num_partials, nullptr, 0, nullptr, nullptr, 0, acc);
     else
         launch_stream_cfg<0, -1, 64, 4, 1>(x, nullptr, M, b, nullptr, y, N, K, Nout, 1, K, Nout, 2, s, n_valid_dev, stats_partial,
-                                           stats_counts, num_partials);
+                                           stats_counts, num_partials, nullptr, 0, nullptr, nullptr, 0, acc);
     return check_launch("phc_gemm_prebuilt_stats");
 }
 
@@ -1535,7 +1553,10 @@ int phc_gemm_prebuilt_xf(const float *x, const float *xf_stat, int xf_act, const
     PHC_REQUIRE(x && xf_stat && M && y, PHC_ERR_INVALID_ARG, "phc_gemm_prebuilt_xf: null pointer");
     PHC_REQUIRE(xf_act >= PHC_ACT_IDENTITY && xf_act <= PHC_ACT_SELU, PHC_ERR_INVALID_ARG, "phc_gemm_prebuilt_xf: unknown activation %d",
                 xf_act);
-    PHC_REQUIRE(!stats_partial || (stats_counts && num_partials), PHC_ERR_INVALID_ARG, "phc_gemm_prebuilt_xf: statistics outputs");
+    const int acc = (stats_partial && !stats_counts) ? 1 : 0;        // accumulator form of the statistics output
+    PHC_REQUIRE(!stats_partial || acc || num_partials, PHC_ERR_INVALID_ARG, "phc_gemm_prebuilt_xf: statistics outputs");
+    PHC_REQUIRE(!acc || (reinterpret_cast<uintptr_t>(stats_partial) & 7) == 0, PHC_ERR_INVALID_ARG,
+                "phc_gemm_prebuilt_xf: the accumulator must be 8-byte aligned");
     PHC_REQUIRE(K <= GEMM_STREAM_MAX_K && K % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
                     (reinterpret_cast<uintptr_t>(M) & 15) == 0 && (reinterpret_cast<uintptr_t>(xf_stat) & 15) == 0,
                 PHC_ERR_UNSUPPORTED, "phc_gemm_prebuilt_xf: needs K <= 256, K %% 4 == 0 and 16-byte aligned x, M, stat (K=%d)", K);
@@ -1547,16 +1568,16 @@ int phc_gemm_prebuilt_xf(const float *x, const float *xf_stat, int xf_act, const
 #define PHC_XF_LAUNCH(SV)                                                                                                      \
     if (N >= gemm_wide_k_m() && Nout > 64 && K > 128)                                                                          \
         launch_stream_cfg<0, -1, 64, 8, SV>(x, nullptr, M, b, nullptr, y, N, K, Nout, 1, K, Nout, 1, s, n_valid_dev, stats_partial, \
-                                            stats_counts, num_partials, xf_stat, xf_act);                                       \
+                                            stats_counts, num_partials, xf_stat, xf_act, nullptr, nullptr, 0, acc);                  \
     else if (big)                                                                                                               \
         launch_stream_cfg<0, -1, 128, 8, SV>(x, nullptr, M, b, nullptr, y, N, K, Nout, 1, K, Nout, 1, s, n_valid_dev, stats_partial, \
-                                             stats_counts, num_partials, xf_stat, xf_act);                                      \
+                                             stats_counts, num_partials, xf_stat, xf_act, nullptr, nullptr, 0, acc);                 \
     else if (small)                                                                                                             \
         launch_stream_cfg<0, -1, 32, 4, SV>(x, nullptr, M, b, nullptr, y, N, K, Nout, 1, K, Nout, 3, s, n_valid_dev, stats_partial, \
-                                            stats_counts, num_partials, xf_stat, xf_act);                                       \
+                                            stats_counts, num_partials, xf_stat, xf_act, nullptr, nullptr, 0, acc);                  \
     else                                                                                                                        \
         launch_stream_cfg<0, -1, 64, 4, SV>(x, nullptr, M, b, nullptr, y, N, K, Nout, 1, K, Nout, 2, s, n_valid_dev, stats_partial, \
-                                            stats_counts, num_partials, xf_stat, xf_act)
+                                            stats_counts, num_partials, xf_stat, xf_act, nullptr, nullptr, 0, acc)
     if (stats_partial) {
         PHC_XF_LAUNCH(3);
     } else {
@@ -1570,8 +1591,10 @@ int phc_gemm_prebuilt_bwsums(const float *dy, const float *M, int64_t N, int K, 
                              const float *bn_stat, int act, const int32_t *n_valid_dev, float *sums_partial, int *num_partials,
                              void *stream) {
     PHC_REQUIRE(N >= 1 && K >= 1 && Nout >= 1, PHC_ERR_INVALID_ARG, "phc_gemm_prebuilt_bwsums: bad shape");
-    PHC_REQUIRE(dy && M && dz && bn_x && bn_stat && sums_partial && num_partials, PHC_ERR_INVALID_ARG,
-                "phc_gemm_prebuilt_bwsums: null pointer");
+    const int acc = num_partials ? 0 : 1;                    // accumulator form: sums_partial is a statistics accumulator
+    PHC_REQUIRE(dy && M && dz && bn_x && bn_stat && sums_partial, PHC_ERR_INVALID_ARG, "phc_gemm_prebuilt_bwsums: null pointer");
+    PHC_REQUIRE(!acc || (reinterpret_cast<uintptr_t>(sums_partial) & 7) == 0, PHC_ERR_INVALID_ARG,
+                "phc_gemm_prebuilt_bwsums: the accumulator must be 8-byte aligned");
     PHC_REQUIRE(act >= PHC_ACT_IDENTITY && act <= PHC_ACT_SELU, PHC_ERR_INVALID_ARG, "phc_gemm_prebuilt_bwsums: unknown activation %d", act);
     PHC_REQUIRE(K <= GEMM_STREAM_MAX_K && K % 4 == 0 && Nout % 4 == 0 && (reinterpret_cast<uintptr_t>(dy) & 15) == 0 &&
                     (reinterpret_cast<uintptr_t>(M) & 15) == 0 && (reinterpret_cast<uintptr_t>(dz) & 15) == 0 &&
@@ -1582,16 +1605,16 @@ int phc_gemm_prebuilt_bwsums(const float *dy, const float *M, int64_t N, int K, 
     static const int small_bn = getenv("PHC_GEMM_PRE_BN") ? atoi(getenv("PHC_GEMM_PRE_BN")) : 32;
     if (N >= gemm_wide_k_m() && Nout > 64 && K > 128)
         launch_stream_cfg<0, -1, 64, 8, 4>(dy, nullptr, M, nullptr, nullptr, dz, N, K, Nout, 1, K, Nout, 1, s, n_valid_dev, sums_partial,
-                                           nullptr, num_partials, nullptr, 0, bn_x, bn_stat, act);
+                                           nullptr, num_partials, nullptr, 0, bn_x, bn_stat, act, acc);
     else if (N >= GEMM_BIG_M && Nout > 64)
         launch_stream_cfg<0, -1, 128, 8, 4>(dy, nullptr, M, nullptr, nullptr, dz, N, K, Nout, 1, K, Nout, 1, s, n_valid_dev, sums_partial,
-                                            nullptr, num_partials, nullptr, 0, bn_x, bn_stat, act);
+                                            nullptr, num_partials, nullptr, 0, bn_x, bn_stat, act, acc);
     else if (small_bn == 32 && Nout > 32 && N <= 32 * 1024)
         launch_stream_cfg<0, -1, 32, 4, 4>(dy, nullptr, M, nullptr, nullptr, dz, N, K, Nout, 1, K, Nout, 3, s, n_valid_dev, sums_partial,
-                                           nullptr, num_partials, nullptr, 0, bn_x, bn_stat, act);
+                                           nullptr, num_partials, nullptr, 0, bn_x, bn_stat, act, acc);
     else
         launch_stream_cfg<0, -1, 64, 4, 4>(dy, nullptr, M, nullptr, nullptr, dz, N, K, Nout, 1, K, Nout, 2, s, n_valid_dev, sums_partial,
-                                           nullptr, num_partials, nullptr, 0, bn_x, bn_stat, act);
+                                           nullptr, num_partials, nullptr, 0, bn_x, bn_stat, act, acc);
     return check_launch("phc_gemm_prebuilt_bwsums");
 }
 

@@ -13,7 +13,7 @@ import torch.nn.functional as F
 
 from . import synth
 from .ops import (deferred_param_grads, dense_weights, masked_bce_with_logits, phm_pairs, phm_weight_regularization_,
-                  prebuilt_H)
+                  prebuilt_H, stat_accumulators)
 from .optim import ClipAdam
 
 # BASELINE.json configs -> PHMSkipConnectAdd arguments (SURVEY.md §8d "Model settings")
@@ -128,7 +128,8 @@ def train_step(model, data, optimizer: Optional[torch.optim.Optimizer], cfg: Ste
             p.grad = None
     advance_dropout_rng(model, data)
     # operand matrices of all PHM layers: one launch; dW/dA/db of all layers: three batched launches after the backward
-    with prebuilt_H(phm_pairs(model), dense_weights(model)), deferred_param_grads():
+    # (stat_accumulators: the batch-norm statistics of the step travel through zeroed accumulator slots, no merge launches)
+    with prebuilt_H(phm_pairs(model), dense_weights(model)), deferred_param_grads(), stat_accumulators(data.x.device):
         logits = model(data)
         loss = loss_fn(logits, data, cfg.regression)
         loss.backward(backward_seed(loss))

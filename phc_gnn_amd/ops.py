@@ -476,13 +476,11 @@ class _PHMLinearFn(torch.autograd.Function):
         pre = _prebuilt_for(A_, W_) if (_PREBUILT.table and x2.data_ptr() % 16 == 0) else None
         ctx.HT = None
         if pre is not None and bn_stats is not None and res2 is None and N > 0 and x.dim() == 2:
-            P = lib.phc_gemm_stats_max_partials()
-            bn_stats.partial = torch.empty((P, 2 * n * kout), dtype=torch.float32, device=dev)
-            bn_stats.counts = torch.empty(P, dtype=torch.float32, device=dev)
+            sp, sc, want_num = bn_stats.allocate(dev, n * kout, lib.phc_gemm_stats_max_partials())
             num = _C.c_int(0)
             L.check(lib.phc_gemm_prebuilt_stats(L.ptr(x2), L.ptr(pre[0]), L.ptr(b_), N, n * kin, n * kout, L.ptr(y),
-                                                L.ptr(bn_stats.n_valid), L.ptr(bn_stats.partial), L.ptr(bn_stats.counts),
-                                                _C.byref(num), L.stream_ptr(dev)), "phc_gemm_prebuilt_stats")
+                                                L.ptr(bn_stats.n_valid), L.ptr(sp), L.ptr(sc),
+                                                _C.byref(num) if want_num else None, L.stream_ptr(dev)), "phc_gemm_prebuilt_stats")
             bn_stats.num = num.value
             ctx.HT = pre[1]
         elif pre is not None:
@@ -590,15 +588,94 @@ def phm_linear_param_grads_raw(x: torch.Tensor, dy: torch.Tensor, A: torch.Tenso
     return dA, dW, db
 
 
+# ---------------------------------------------------------------------------
+# statistics accumulators (csrc/phc_common.h): column sums that the workgroups of one launch ADD into 64-bit fixed-point
+# words with integer atomics, read as totals by the next launch — no merge launch in between.  They must be zero when the
+# producing launch starts: a per-device arena hands out slots inside ``with stat_accumulators(dev):`` (one training step:
+# harness.train_step / GraphedTrainStep) and zeroes what the previous step used with ONE memset on entry.
+# ---------------------------------------------------------------------------
+STAT_ACC = __import__("os").environ.get("PHC_STAT_ACC", "1") != "0"
+STAT_ACC_REP = 4                       # csrc/phc_common.h STAT_ACC_REP
+_STAT_ARENAS: dict = {}
+
+
+class _StatArena:
+    WORDS = 1 << 18                    # 2 MB of int64 words per device: ~128 norms of width 128 per step
+
+    def __init__(self, dev):
+        self.buf = torch.zeros(self.WORDS, dtype=torch.int64, device=dev)
+        self.used = 0                  # words handed out since the last reset
+        self.dirty = 0                 # words that may be non-zero
+        self.active = False
+
+    def slot(self, h: int):
+        words = STAT_ACC_REP * 4 * h
+        if not self.active or self.used + words > self.WORDS:
+            return None
+        t = self.buf[self.used:self.used + words].view(STAT_ACC_REP * 2, 2 * h)
+        self.used += words
+        self.dirty = max(self.dirty, self.used)
+        return t
+
+
+class stat_accumulators:
+    """Context of one training step on ``dev``: statistics-emitting launches inside it use accumulator slots."""
+
+    def __init__(self, dev):
+        self.dev = torch.device(dev)
+
+    def __enter__(self):
+        if not STAT_ACC or self.dev.type != "cuda":
+            self.arena = None
+            return self
+        key = (self.dev.type, self.dev.index if self.dev.index is not None else torch.cuda.current_device())
+        arena = _STAT_ARENAS.get(key)
+        if arena is None:
+            arena = _STAT_ARENAS[key] = _StatArena(self.dev)
+        if arena.dirty:
+            arena.buf[:arena.dirty].zero_()                    # one memset: everything the previous step added into
+        arena.used = 0
+        arena.active = True
+        self.arena = arena
+        return self
+
+    def __exit__(self, *exc):
+        if self.arena is not None:
+            self.arena.active = False
+        return False
+
+
+def stat_acc_slot(dev, h: int):
+    """A zeroed accumulator [2 * STAT_ACC_REP, 2 h] (int64) of the running step, or None outside ``stat_accumulators``."""
+    if h % 32:
+        return None
+    dev = torch.device(dev)
+    arena = _STAT_ARENAS.get((dev.type, dev.index if dev.index is not None else torch.cuda.current_device()))
+    return arena.slot(h) if arena is not None else None
+
+
 class BNStatsRequest:
     """Ask a PHM linear layer for the batch-norm statistics of its output (training mode): when the layer runs on a
     prebuilt operand matrix, its GEMM emits per-column (sum, M2) partials from registers and the normalisation that
-    follows (``batch_norm_act`` on the very tensor this layer returned) skips its own pass over the data."""
+    follows (``batch_norm_act`` on the very tensor this layer returned) skips its own pass over the data.
+    ``consumer``: "apply" (``batch_norm_act``: may take the statistics through an accumulator, ``counts`` stays None)
+    or "linear" (``bn_act_linear``: partial rows)."""
 
-    def __init__(self, n_valid: Optional[torch.Tensor] = None):
+    def __init__(self, n_valid: Optional[torch.Tensor] = None, consumer: str = "linear"):
         self.n_valid = n_valid
+        self.consumer = consumer
         self.partial = self.counts = None
         self.num = 0
+
+    def allocate(self, dev, h: int, max_partials: int):
+        """Output buffers of the producing launch: (partial, counts, want_num)."""
+        acc = stat_acc_slot(dev, h) if self.consumer == "apply" else None
+        if acc is not None:
+            self.partial, self.counts = acc, None
+            return acc, None, False
+        self.partial = torch.empty((max_partials, 2 * h), dtype=torch.float32, device=dev)
+        self.counts = torch.empty(max_partials, dtype=torch.float32, device=dev)
+        return self.partial, self.counts, True
 
 
 def phm_linear(x: torch.Tensor, phm_rule: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None,
@@ -1615,8 +1692,11 @@ class _BatchNormActFn(torch.autograd.Function):
         drop = ctx.drop
         dx = torch.empty_like(x_) if need_x else None
         dwb = torch.empty(2 * h, dtype=torch.float32, device=dev) if need_aff else None
-        ws_bytes = lib.phc_bn_ws_bytes(N, h)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        ws = stat_acc_slot(dev, h) if N > 0 else None        # accumulator form: no merge launch between the two passes
+        ws_bytes = 0
+        if ws is None:
+            ws_bytes = lib.phc_bn_ws_bytes(N, h)
+            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         L.check(lib.phc_bn_bwd(L.ptr(dout_), L.ptr(x_), L.ptr(save_stat), L.ptr(n_valid), N, h, 1 if training else 0, act,
                                L.ptr(dx), L.ptr(dwb), L.ptr(ws), ws_bytes, drop[0], drop[1], drop[2], L.ptr(drop[3]), L.stream_ptr(dev)),
                 "phc_bn_bwd")
@@ -1663,12 +1743,12 @@ class _BNActLinearFn(torch.autograd.Function):
         y = torch.empty((N, n2 * kout2), dtype=torch.float32, device=dev)
         num = _C.c_int(0)
         sp = sc = None
+        want_num = True
         if out_stats is not None:
-            P = lib.phc_gemm_stats_max_partials()
-            sp = out_stats.partial = torch.empty((P, 2 * n2 * kout2), dtype=torch.float32, device=dev)
-            sc = out_stats.counts = torch.empty(P, dtype=torch.float32, device=dev)
+            sp, sc, want_num = out_stats.allocate(dev, n2 * kout2, lib.phc_gemm_stats_max_partials())
         L.check(lib.phc_gemm_prebuilt_xf(L.ptr(x), L.ptr(save_stat), act, L.ptr(n_valid), L.ptr(H2), L.ptr(b2), N, h, n2 * kout2,
-                                         L.ptr(y), L.ptr(sp), L.ptr(sc), _C.byref(num), L.stream_ptr(dev)), "phc_gemm_prebuilt_xf")
+                                         L.ptr(y), L.ptr(sp), L.ptr(sc), _C.byref(num) if want_num else None, L.stream_ptr(dev)),
+                "phc_gemm_prebuilt_xf")
         if out_stats is not None:
             out_stats.num = num.value
         if L.PROF_ON:
@@ -1692,10 +1772,15 @@ class _BNActLinearFn(torch.autograd.Function):
         fused_sums = BN_BWD_SUMS_IN_GEMM and h % 4 == 0 and dy_.data_ptr() % 16 == 0
         sums = None
         num = _C.c_int(0)
+        sums_acc = False
         if fused_sums:
-            sums = torch.empty((lib.phc_gemm_stats_max_partials(), 2 * h), dtype=torch.float32, device=dev)
+            sums = stat_acc_slot(dev, h)
+            sums_acc = sums is not None
+            if not sums_acc:
+                sums = torch.empty((lib.phc_gemm_stats_max_partials(), 2 * h), dtype=torch.float32, device=dev)
             L.check(lib.phc_gemm_prebuilt_bwsums(L.ptr(dy_), L.ptr(ctx.HT2), N, n2 * kout2, h, L.ptr(dz), L.ptr(x), L.ptr(save_stat),
-                                                 act, L.ptr(n_valid), L.ptr(sums), _C.byref(num), L.stream_ptr(dev)),
+                                                 act, L.ptr(n_valid), L.ptr(sums), None if sums_acc else _C.byref(num),
+                                                 L.stream_ptr(dev)),
                     "phc_gemm_prebuilt_bwsums")
         else:
             L.check(lib.phc_gemm_prebuilt(L.ptr(dy_), L.ptr(ctx.HT2), None, None, N, n2 * kout2, h, L.ptr(dz), 1, L.stream_ptr(dev)),
@@ -1724,9 +1809,10 @@ class _BNActLinearFn(torch.autograd.Function):
         dx = torch.empty_like(x) if need_x else None
         dwb = torch.empty(2 * h, dtype=torch.float32, device=dev) if need_aff else None
         if fused_sums:
-            ws = torch.empty(2 * h, dtype=torch.float32, device=dev)
-            L.check(lib.phc_bn_bwd_from_partials(L.ptr(dz), L.ptr(x), L.ptr(save_stat), L.ptr(sums), num.value, L.ptr(n_valid), N, h,
-                                                 act, L.ptr(dx), L.ptr(dwb), L.ptr(ws), 8 * h, L.stream_ptr(dev)),
+            ws = None if sums_acc else torch.empty(2 * h, dtype=torch.float32, device=dev)
+            L.check(lib.phc_bn_bwd_from_partials(L.ptr(dz), L.ptr(x), L.ptr(save_stat), L.ptr(sums), 0 if sums_acc else num.value,
+                                                 L.ptr(n_valid), N, h, act, L.ptr(dx), L.ptr(dwb), L.ptr(ws), 0 if sums_acc else 8 * h,
+                                                 L.stream_ptr(dev)),
                     "phc_bn_bwd_from_partials")
         else:
             ws_bytes = lib.phc_bn_ws_bytes(N, h)
@@ -1753,9 +1839,9 @@ def bn_act_linear(x: torch.Tensor, weights, biases, running_mean, running_var, n
     x must be the tensor a statistics-emitting GEMM just returned (``x._phc_bn``), inside ``prebuilt_H`` with an
     entry for (phm_rule, W)."""
     pre = getattr(x, "_phc_bn", None)
-    if pre is None or pre.partial is None or pre.n_valid is not n_valid or x.dim() != 2 or not x.is_contiguous() \
-            or pre.partial.shape[1] != 2 * x.shape[1] or not _PREBUILT.table or x.data_ptr() % 16:
-        return None
+    if pre is None or pre.partial is None or pre.counts is None or pre.n_valid is not n_valid or x.dim() != 2 \
+            or not x.is_contiguous() or pre.partial.shape[1] != 2 * x.shape[1] or not _PREBUILT.table or x.data_ptr() % 16:
+        return None                              # (counts is None: the statistics went to an accumulator, batch_norm_act reads it)
     ent = _prebuilt_for(phm_rule, W)
     if ent is None or W.shape[0] * W.shape[1] != x.shape[1] or (bias is not None and not bias.is_contiguous()):
         return None
