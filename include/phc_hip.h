@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PHC_ABI_VERSION 2
+#define PHC_ABI_VERSION 3
 
 #define PHC_OK 0
 #define PHC_ERR_INVALID_ARG (-1)   /* null pointer, negative size, bad enum        */
@@ -391,8 +391,23 @@ int phc_bn_bwd_apply(const float *dy, const float *x, const float *save_stat, co
  * rows they produced below *n_valid_dev — stats_partial [phc_gemm_stats_max_partials()][2*Nout],
  * stats_counts [same] and *num_partials (host out).  phc_bn_fwd_from_partials merges them (same fixed-
  * order Chan merge as phc_bn_fwd) and applies the normalisation: the separate pass over y that computes
- * the statistics disappears.  Backward: phc_bn_bwd, unchanged. */
+ * the statistics disappears.  Backward: phc_bn_bwd, unchanged.
+ *
+ * ACCUMULATOR FORM (ABI 3).  Every statistics hand-over of this header also exists without partial rows and without a
+ * merge launch: the producing launch ADDS each workgroup's column sums into a caller-zeroed accumulator of
+ * phc_stat_acc_words(h) 64-bit words (8-byte aligned) with integer atomics — two fixed-point words per value, so the
+ * totals do not depend on the order of arrival and results stay bit-reproducible — and the consuming launch reads the
+ * totals in its prologue.  It is selected by the arguments that have no meaning without partial rows:
+ *   phc_gemm_prebuilt_stats    stats_counts = NULL (num_partials may be NULL): stats_partial is the accumulator
+ *   phc_gemm_prebuilt_xf       stats_partial != NULL, stats_counts = NULL
+ *   phc_bn_fwd_from_partials   stats_counts = NULL (num_partials ignored); needs h % 32 == 0
+ *   phc_gemm_prebuilt_bwsums   num_partials = NULL: sums_partial is the accumulator
+ *   phc_bn_bwd_from_partials   num_partials = 0: sums_partial is the accumulator (ws unused)
+ *   phc_bn_bwd                 ws_bytes = 0: ws is the accumulator (one launch less: no merge between the two passes)
+ * phc_bn_finalize_from_partials (the hand-over into phc_gemm_prebuilt_xf's operand) has no accumulator form. */
 int phc_gemm_stats_max_partials(void);
+size_t phc_stat_acc_words(int h);             /* 64-bit words of one statistics accumulator of width h */
+int phc_stat_acc_replicas(void);              /* rows of its [2 * replicas][2 * h] word layout (ops.py views it that way) */
 int phc_gemm_prebuilt_stats(const float *x, const float *M, const float *b, int64_t N, int K, int Nout, float *y,
                             const int32_t *n_valid_dev, float *stats_partial, float *stats_counts, int *num_partials,
                             void *stream);

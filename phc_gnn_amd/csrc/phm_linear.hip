@@ -1517,6 +1517,8 @@ int phc_gemm_prebuilt(const float *x, const float *M, const float *b, const floa
 }
 
 int phc_gemm_stats_max_partials(void) { return GEMM_STATS_MAX_PARTIALS; }
+size_t phc_stat_acc_words(int h) { return h > 0 ? (size_t)STAT_ACC_REP * 4 * (size_t)h : 0; }
+int phc_stat_acc_replicas(void) { return STAT_ACC_REP; }
 
 int phc_gemm_prebuilt_stats(const float *x, const float *M, const float *b, int64_t N, int K, int Nout, float *y,
                             const int32_t *n_valid_dev, float *stats_partial, float *stats_counts, int *num_partials, void *stream) {

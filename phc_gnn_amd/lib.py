@@ -15,7 +15,7 @@ import torch
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, "libphc_hip.so")
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 ACT_IDS = {"identity": 0, "relu": 1, "lrelu": 2, "elu": 3, "swish": 4, "selu": 5}
 
 
@@ -78,6 +78,8 @@ SIGNATURES = {
     "phc_phm_build_H_batched": (_I, [C.POINTER(HJob), _I, _P]),
     "phc_gemm_prebuilt": (_I, [_P, _P, _P, _P, _L, _I, _I, _P, _I, _P]),
     "phc_gemm_stats_max_partials": (_I, []),
+    "phc_stat_acc_words": (_S, [_I]),
+    "phc_stat_acc_replicas": (_I, []),
     "phc_gemm_prebuilt_stats": (_I, [_P, _P, _P, _L, _I, _I, _P, _P, _P, _P, C.POINTER(_I), _P]),
     "phc_bn_fwd_from_partials": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _L, _I, C.c_float, C.c_float, _I, _P, _P, _P,
                                       C.c_float, _I, _I, _P, _P]),

@@ -595,7 +595,6 @@ def phm_linear_param_grads_raw(x: torch.Tensor, dy: torch.Tensor, A: torch.Tenso
 # harness.train_step / GraphedTrainStep) and zeroes what the previous step used with ONE memset on entry.
 # ---------------------------------------------------------------------------
 STAT_ACC = __import__("os").environ.get("PHC_STAT_ACC", "1") != "0"
-STAT_ACC_REP = 4                       # csrc/phc_common.h STAT_ACC_REP
 _STAT_ARENAS: dict = {}
 
 
@@ -609,10 +608,11 @@ class _StatArena:
         self.active = False
 
     def slot(self, h: int):
-        words = STAT_ACC_REP * 4 * h
+        lib = L.load()
+        words = lib.phc_stat_acc_words(h)
         if not self.active or self.used + words > self.WORDS:
             return None
-        t = self.buf[self.used:self.used + words].view(STAT_ACC_REP * 2, 2 * h)
+        t = self.buf[self.used:self.used + words].view(2 * lib.phc_stat_acc_replicas(), 2 * h)
         self.used += words
         self.dirty = max(self.dirty, self.used)
         return t
@@ -646,7 +646,7 @@ class stat_accumulators:
 
 
 def stat_acc_slot(dev, h: int):
-    """A zeroed accumulator [2 * STAT_ACC_REP, 2 h] (int64) of the running step, or None outside ``stat_accumulators``."""
+    """A zeroed accumulator [2 * replicas, 2 h] (int64) of the running step, or None outside ``stat_accumulators``."""
     if h % 32:
         return None
     dev = torch.device(dev)
