@@ -750,9 +750,11 @@ struct TailTables {
 };
 
 template <int ACT>
-__global__ __launch_bounds__(256) void tail_partial_kernel(GradBatch gb, TailTables t) {
+__global__ __launch_bounds__(256, 2) void tail_partial_kernel(GradBatch gb, TailTables t) {
     __shared__ __attribute__((aligned(16))) float smem[2 * TG_IB * TG_T];
     static_assert(2 * TG_IB * TG_T == 2 * DH_RB * DH_STRIDE, "table and dH workgroups stage the same 32 KB");
+    // (Dispatch order was tried three ways — table families first, interleaved in proportion, the long dH workgroups first: within
+    // noise of each other, the interleaved one 15 us slower because the last dH workgroups start late.  Family order is kept.)
     unsigned bx = blockIdx.x;
     if (bx < t.nb_atom) {
         const int tile = bx % t.tiles_a;
@@ -784,8 +786,12 @@ __global__ __launch_bounds__(256) void tail_partial_kernel(GradBatch gb, TailTab
     int tile;
     long long split;
     xcd_tile_split(local, (unsigned)j.tiles, (unsigned)j.splits, tile, split);
-    dH_partial_body(j.x, j.dy, j.slabs, j.N, j.in, j.out, j.tiles_j, j.rows_per_split, j.vec4, tile, split, smem, j.xf_stat, j.xf_act,
-                    xf_count);
+    if (j.t128 == 3)
+        dH_direct_body<2>(j.x, j.dy, j.slabs, j.N, j.in, j.out, j.tiles_j, j.rows_per_split, tile, split, smem, j.xf_stat, j.xf_act,
+                          xf_count);
+    else
+        dH_partial_body(j.x, j.dy, j.slabs, j.N, j.in, j.out, j.tiles_j, j.rows_per_split, j.vec4, tile, split, smem, j.xf_stat, j.xf_act,
+                        xf_count);
 }
 
 __global__ __launch_bounds__(256) void tail_reduce_kernel(GradBatch gb, TailTables t) {
@@ -1310,6 +1316,15 @@ int phc_table_grads_counted(const phc_table_grad_job *jobs, int num_jobs, const 
     return PHC_OK;
 }
 
+// With table-gradient workgroups in the launch, the 128-multiple layers take the 128 x 64 register-resident tiles INSIDE it (two
+// wavefronts per SIMD: the latency-bound table gathers run beside the MFMA-bound dH wavefronts); without them the 128 x 128
+// tiles in their own launch.
+static int tail_direct_form(int num_tjobs, int64_t N_atoms) {
+    static const int forced = getenv("PHC_TAIL_DIRECT_FORM") ? atoi(getenv("PHC_TAIL_DIRECT_FORM")) : 0;
+    if (forced == 2 || forced == 3) return forced;
+    return (num_tjobs > 0 || N_atoms > 0) ? 3 : 2;
+}
+
 static int tail_plan(const phc_phm_grad_job *jobs, int num_jobs, int num_tjobs, int64_t E, int64_t bond_n_dst, int F_b,
                      const int32_t *vocab_b, int64_t N_atoms, int F_a, const int32_t *vocab_a, int n, int k, EncMeta *mb, EncMeta *ma,
                      TgPlan *pb, TgPlan *pa, size_t *phm_floats) {
@@ -1332,7 +1347,7 @@ static int tail_plan(const phc_phm_grad_job *jobs, int num_jobs, int num_tjobs, 
         if (rc) return rc;
         *pa = tg_plan(N_atoms, ma->R, h);
     }
-    *phm_floats = grad_chunk_ws_floats(jobs, num_jobs);
+    *phm_floats = grad_chunk_ws_floats(jobs, num_jobs, tail_direct_form(num_tjobs, N_atoms));
     return PHC_OK;
 }
 
@@ -1372,7 +1387,7 @@ int phc_step_tail(const phc_phm_grad_job *jobs, int num_jobs, const phc_table_gr
     const int h = n * k;
     float *wsf = static_cast<float *>(ws);
     GradLaunch gl;
-    rc = prepare_grad_launch("phc_step_tail", jobs, num_jobs, wsf, &gl);
+    rc = prepare_grad_launch("phc_step_tail", jobs, num_jobs, wsf, &gl, tail_direct_form(num_tjobs, N_atoms));
     if (rc) return rc;
     PHC_REQUIRE(gl.nb_partial128 == 0, PHC_ERR_UNSUPPORTED, "phc_step_tail: 128 x 128 tile jobs take phc_phm_param_grads");
     wsf += phm_floats;
@@ -1429,7 +1444,7 @@ int phc_step_tail(const phc_phm_grad_job *jobs, int num_jobs, const phc_table_gr
         ProfScope prof(K_PHM_DH_PARTIAL, s);
         GradBatch b64 = gl.batch;                            // this launch takes the 64 x 64 tile jobs only
         for (int q = 0; q < b64.num; ++q)
-            if (b64.j[q].t128 != 0) b64.j[q].blk0_partial = 0xffffffffu;
+            if (b64.j[q].t128 != 0 && b64.j[q].t128 != 3) b64.j[q].blk0_partial = 0xffffffffu;
 #define PHC_TAIL_LAUNCH(ACTC) PHC_LAUNCH((tail_partial_kernel<ACTC>), dim3(nb1), dim3(256), 0, s, b64, t)
         switch (act) {
             case PHC_ACT_IDENTITY: PHC_TAIL_LAUNCH(PHC_ACT_IDENTITY); break;

@@ -302,6 +302,12 @@ constexpr int DH_D = 128;                               // tile edge of the regi
 constexpr int DH_PF = PHC_DH_PF;                        // row pairs per load batch (two batches alternate)
 constexpr int DH_DIRECT_LDS_BYTES = 4 * 16 * 64 * 16;   // exchange slots: [wave][reg][lane] float4 = 64 KB
 
+using f32x2 = __attribute__((ext_vector_type(2))) float;
+// NP = "N blocks" of a register-resident tile: 4 -> 128 columns of dy per wavefront (float4 per lane), 2 -> 64 (float2)
+template <int NP> struct DhVec;
+template <> struct DhVec<4> { using T = f32x4; };
+template <> struct DhVec<2> { using T = f32x2; };
+
 // One batch of DH_PF row pairs.  The x operand is always x := max(x * scale + shift, floor) per column: a plain operand is
 // (1, 0, -inf) — exact —, an unapplied batch-norm its (scale, shift) with floor -inf / 0 for identity / relu (the other
 // activations stay on the LDS forms).  MASKED = false: every row of the batch is a live row of the wavefront's range — no
@@ -309,13 +315,15 @@ constexpr int DH_DIRECT_LDS_BYTES = 4 * 16 * 64 * 16;   // exchange slots: [wave
 // (fp32 MFMAs run on the vector ALU's own multipliers: every VALU instruction between them costs its full issue time, nothing
 // hides in their shadow — measured 36.6 ns per MFMA with 2 VALU instructions per MFMA against 30 with none — so the interior
 // loop carries only the operand transform and the column sums.)
-template <bool MASKED>
-__device__ __forceinline__ void dH_direct_pairs(f32x16 (&acc)[4][4], f32x4 &colsum, const f32x4 (&XV)[DH_PF], const f32x4 (&DV)[DH_PF],
+template <bool MASKED, int NP>
+__device__ __forceinline__ void dH_direct_pairs(f32x16 (&acc)[4][NP], typename DhVec<NP>::T &colsum, const f32x4 (&XV)[DH_PF],
+                                                const typename DhVec<NP>::T (&DV)[DH_PF],
                                                 long long row0, long long lim, int hh, const f32x4 &xf_sc, const f32x4 &xf_sh,
                                                 float floor_) {
 #pragma unroll
     for (int t = 0; t < DH_PF; ++t) {
-        f32x4 xv = XV[t], dv = DV[t];
+        f32x4 xv = XV[t];
+        typename DhVec<NP>::T dv = DV[t];
         bool live = true;
         if constexpr (MASKED) live = row0 + 2 * t + hh < lim;
 #pragma unroll
@@ -325,16 +333,16 @@ __device__ __forceinline__ void dH_direct_pairs(f32x16 (&acc)[4][4], f32x4 &cols
         }
         if constexpr (MASKED) {
 #pragma unroll
-            for (int q = 0; q < 4; ++q) dv[q] = live ? dv[q] : 0.f;
+            for (int q = 0; q < NP; ++q) dv[q] = live ? dv[q] : 0.f;
         }
         colsum += dv;
 #ifdef PHC_EXP_DIRECT_NO_MFMA
-        colsum += xv;
+        colsum[0] += xv[0] + xv[1] + xv[2] + xv[3];
 #else
 #pragma unroll
         for (int q = 0; q < 4; ++q)
 #pragma unroll
-            for (int p2 = 0; p2 < 4; ++p2) acc[q][p2] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[q], dv[p2], acc[q][p2], 0, 0, 0);
+            for (int p2 = 0; p2 < NP; ++p2) acc[q][p2] = __builtin_amdgcn_mfma_f32_32x32x2f32(xv[q], dv[p2], acc[q][p2], 0, 0, 0);
 #endif
     }
 }
@@ -342,8 +350,8 @@ __device__ __forceinline__ void dH_direct_pairs(f32x16 (&acc)[4][4], f32x4 &cols
 // Loads of one batch.  EXACT = false: the pair base (wave-uniform: scalar registers) is clamped to the last whole pair of the
 // range, the lane part is a constant byte offset — no per-load vector arithmetic; a pair past the range reads a neighbour pair,
 // which is fine for prefetches whose data is discarded.  EXACT = true: every lane's own row clamped to `last_row` (the masked tail).
-template <bool EXACT>
-__device__ __forceinline__ void dH_direct_load(f32x4 (&XV)[DH_PF], f32x4 (&DV)[DH_PF], const float *__restrict__ X,
+template <bool EXACT, int NP>
+__device__ __forceinline__ void dH_direct_load(f32x4 (&XV)[DH_PF], typename DhVec<NP>::T (&DV)[DH_PF], const float *__restrict__ X,
                                                const float *__restrict__ DY, int in, int out, unsigned xoff, unsigned doff,
                                                unsigned xrow, unsigned drow, long long row0, long long last_row) {
 #pragma unroll
@@ -357,13 +365,13 @@ __device__ __forceinline__ void dH_direct_load(f32x4 (&XV)[DH_PF], f32x4 (&DV)[D
             const long long gc = min(g, last_row);
             const bool up = g < last_row;                // the upper half-wave's row exists (else it re-reads row gc: masked)
             XV[t] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(X + (size_t)gc * in) + (xoff + (up ? xrow : 0u)));
-            DV[t] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(DY + (size_t)gc * out) + (doff + (up ? drow : 0u)));
+            DV[t] = *reinterpret_cast<const typename DhVec<NP>::T *>(reinterpret_cast<const char *>(DY + (size_t)gc * out) + (doff + (up ? drow : 0u)));
         } else {
             // X / DY point at the wavefront's first row here and row0 counts from it: 32-bit scalar byte offsets (the planner
             // keeps a wavefront's rows below 2^31 bytes), clamped to the last whole pair of the range
             const unsigned pr = min((unsigned)g, (unsigned)last_row - 1u);
             XV[t] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(X) + (pr * ((unsigned)in * 4u) + (xoff + xrow)));
-            DV[t] = *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(DY) + (pr * ((unsigned)out * 4u) + (doff + drow)));
+            DV[t] = *reinterpret_cast<const typename DhVec<NP>::T *>(reinterpret_cast<const char *>(DY) + (pr * ((unsigned)out * 4u) + (doff + drow)));
         }
     }
 }
@@ -376,40 +384,42 @@ __device__ __forceinline__ void dH_direct_load(f32x4 (&XV)[DH_PF], f32x4 (&DV)[D
 //      (left alone, the scheduler sinks every load to just in front of its first use and the wavefront, the only one on its
 //      SIMD, waits out the full memory latency once per row pair);
 //   3. padding rows: only the column sums of dy.
-__device__ __forceinline__ void dH_direct_rows(f32x16 (&acc)[4][4], f32x4 &colsum, const float *__restrict__ X,
+template <int NP>
+__device__ __forceinline__ void dH_direct_rows(f32x16 (&acc)[4][NP], typename DhVec<NP>::T &colsum, const float *__restrict__ X,
                                                const float *__restrict__ DY, int in, int out, unsigned xoff, unsigned doff,
                                                unsigned xrow, unsigned drow, long long w_begin, long long w_end, long long last,
                                                int hh, const f32x4 &xf_sc, const f32x4 &xf_sh, float floor_, long long xf_count) {
     constexpr long long IT = 4 * DH_PF;
-    f32x4 xa[DH_PF], da[DH_PF], xb[DH_PF], db[DH_PF];
+    f32x4 xa[DH_PF], xb[DH_PF];
+    typename DhVec<NP>::T da[DH_PF], db[DH_PF];
     const long long lim = max(min(w_end, xf_count), w_begin);
     const long long n_it = (lim - w_begin + IT - 1) / IT;
     const long long tail0 = w_begin + (n_it > 0 ? n_it - 1 : 0) * IT;
-    dH_direct_load<true>(xa, da, X, DY, in, out, xoff, doff, xrow, drow, tail0, last);
-    dH_direct_load<true>(xb, db, X, DY, in, out, xoff, doff, xrow, drow, tail0 + 2 * DH_PF, last);
+    dH_direct_load<true, NP>(xa, da, X, DY, in, out, xoff, doff, xrow, drow, tail0, last);
+    dH_direct_load<true, NP>(xb, db, X, DY, in, out, xoff, doff, xrow, drow, tail0 + 2 * DH_PF, last);
     __builtin_amdgcn_sched_barrier(0);
-    dH_direct_pairs<true>(acc, colsum, xa, da, tail0, lim, hh, xf_sc, xf_sh, floor_);
-    dH_direct_pairs<true>(acc, colsum, xb, db, tail0 + 2 * DH_PF, lim, hh, xf_sc, xf_sh, floor_);
+    dH_direct_pairs<true, NP>(acc, colsum, xa, da, tail0, lim, hh, xf_sc, xf_sh, floor_);
+    dH_direct_pairs<true, NP>(acc, colsum, xb, db, tail0 + 2 * DH_PF, lim, hh, xf_sc, xf_sh, floor_);
     __builtin_amdgcn_sched_barrier(0);
     if (tail0 > w_begin) {
         // interior: addresses relative to the wavefront's first row (32-bit arithmetic, scalar)
         const float *Xw = X + (size_t)w_begin * in, *DYw = DY + (size_t)w_begin * out;
         const long long lastw = last - w_begin;          // >= 1: the interior exists only when the range has > 4 * DH_PF rows
         const int n_rows = (int)(tail0 - w_begin);
-        dH_direct_load<false>(xa, da, Xw, DYw, in, out, xoff, doff, xrow, drow, 0, lastw);
+        dH_direct_load<false, NP>(xa, da, Xw, DYw, in, out, xoff, doff, xrow, drow, 0, lastw);
         for (int row = 0; row < n_rows; row += (int)IT) {
-            dH_direct_load<false>(xb, db, Xw, DYw, in, out, xoff, doff, xrow, drow, row + 2 * DH_PF, lastw);
+            dH_direct_load<false, NP>(xb, db, Xw, DYw, in, out, xoff, doff, xrow, drow, row + 2 * DH_PF, lastw);
             __builtin_amdgcn_sched_barrier(0);
-            dH_direct_pairs<false>(acc, colsum, xa, da, row, lim, hh, xf_sc, xf_sh, floor_);
+            dH_direct_pairs<false, NP>(acc, colsum, xa, da, row, lim, hh, xf_sc, xf_sh, floor_);
             __builtin_amdgcn_sched_barrier(0);
-            dH_direct_load<false>(xa, da, Xw, DYw, in, out, xoff, doff, xrow, drow, row + (int)IT, lastw);
+            dH_direct_load<false, NP>(xa, da, Xw, DYw, in, out, xoff, doff, xrow, drow, row + (int)IT, lastw);
             __builtin_amdgcn_sched_barrier(0);
-            dH_direct_pairs<false>(acc, colsum, xb, db, row + 2 * DH_PF, lim, hh, xf_sc, xf_sh, floor_);
+            dH_direct_pairs<false, NP>(acc, colsum, xb, db, row + 2 * DH_PF, lim, hh, xf_sc, xf_sh, floor_);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
     for (long long g = lim + hh; g < w_end; g += 2)
-        colsum += *reinterpret_cast<const f32x4 *>(reinterpret_cast<const char *>(DY + (size_t)g * out) + doff);
+        colsum += *reinterpret_cast<const typename DhVec<NP>::T *>(reinterpret_cast<const char *>(DY + (size_t)g * out) + doff);
 }
 
 #ifdef PHC_KTIMING
@@ -424,6 +434,7 @@ static __device__ unsigned long long g_dh_ts[64];
 #define DH_STAMP(i) do { } while (0)
 #endif
 
+template <int NP>
 __device__ __forceinline__ void dH_direct_body(const float *__restrict__ X, const float *__restrict__ DY, float *__restrict__ slabs,
                                                long long N, int in, int out, int tiles_j, long long rows_per_split, int tile,
                                                long long split, float *__restrict__ smem, const float *__restrict__ xf_stat,
@@ -432,7 +443,8 @@ __device__ __forceinline__ void dH_direct_body(const float *__restrict__ X, cons
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);          // scalar: the row range of the wavefront is uniform
     const int r = lane & 31, hh = lane >> 5;
     const int ti = tile / tiles_j, tj = tile - ti * tiles_j;
-    const int i0 = ti * DH_D, j0 = tj * DH_D;
+    const int i0 = ti * DH_D, j0 = tj * (32 * NP);
+    using DVT = typename DhVec<NP>::T;
     const long long r_begin = split * rows_per_split;
     const long long r_end = min(N, r_begin + rows_per_split);
     const long long rq = rows_per_split >> 2;           // rows_per_split % 8 == 0: every quarter starts on an even row
@@ -441,14 +453,16 @@ __device__ __forceinline__ void dH_direct_body(const float *__restrict__ X, cons
     float *slab = slabs + (size_t)split * slab_elems;
 
     DH_STAMP(0);
-    f32x16 acc[4][4];
+    f32x16 acc[4][NP];
 #pragma unroll
     for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int p2 = 0; p2 < 4; ++p2)
+        for (int p2 = 0; p2 < NP; ++p2)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[q][p2][i] = 0.f;
-    f32x4 colsum = {0.f, 0.f, 0.f, 0.f};
+    DVT colsum;
+#pragma unroll
+    for (int p2 = 0; p2 < NP; ++p2) colsum[p2] = 0.f;
     f32x4 xf_sc = {1.f, 1.f, 1.f, 1.f}, xf_sh = {0.f, 0.f, 0.f, 0.f};
     float floor_ = -__builtin_inff();
     if (xf_stat) {
@@ -459,39 +473,41 @@ __device__ __forceinline__ void dH_direct_body(const float *__restrict__ X, cons
         xf_count = N;                                    // a plain operand has no padding rows of its own
     }
     // lane part of every address: this lane's four columns; the upper half-wave reads the odd row of each pair
-    const unsigned xoff = (unsigned)(i0 + 4 * r) * 4u, doff = (unsigned)(j0 + 4 * r) * 4u;
+    const unsigned xoff = (unsigned)(i0 + 4 * r) * 4u, doff = (unsigned)(j0 + NP * r) * 4u;
     const unsigned xrow = hh ? (unsigned)in * 4u : 0u, drow = hh ? (unsigned)out * 4u : 0u;
     const long long last = max(r_end - 1, 0LL);          // clamped rows: reads past the range stay in bounds
 
     DH_STAMP(1);
     if (w_begin < w_end)
-        dH_direct_rows(acc, colsum, X, DY, in, out, xoff, doff, xrow, drow, w_begin, w_end, last, hh, xf_sc, xf_sh, floor_, xf_count);
+        dH_direct_rows<NP>(acc, colsum, X, DY, in, out, xoff, doff, xrow, drow, w_begin, w_end, last, hh, xf_sc, xf_sh, floor_, xf_count);
 
     DH_STAMP(2);
     // ---- the four wavefronts meet.  One phase per "M block" q: every wavefront parks the block in LDS ([wave][reg][lane] float4 =
     // 64 KB, which leaves room for other kernels' workgroups on the CU), then wavefront w sums registers 4w .. 4w+3 of all four
     // wavefronts in the fixed order 0, 1, 2, 3 and writes those rows of the slab.  Nothing here indexes the accumulators by the
     // wavefront number (a rotation that did cost 10 us of selects and spills).
-    f32x4 *slots = reinterpret_cast<f32x4 *>(smem);
+    DVT *slots = reinterpret_cast<DVT *>(smem);          // [wave][reg][lane] of NP floats: 16 KB * NP
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         if (q) __syncthreads();
 #pragma unroll
         for (int reg = 0; reg < 16; ++reg) {
-            const f32x4 v = {acc[q][0][reg], acc[q][1][reg], acc[q][2][reg], acc[q][3][reg]};
+            DVT v;
+#pragma unroll
+            for (int p2 = 0; p2 < NP; ++p2) v[p2] = acc[q][p2][reg];
             slots[(wave * 16 + reg) * 64 + lane] = v;
         }
         __syncthreads();
-        f32x4 part[4][4];
+        DVT part[4][4];
 #pragma unroll
         for (int w2 = 0; w2 < 4; ++w2)
 #pragma unroll
             for (int e = 0; e < 4; ++e) part[w2][e] = slots[(w2 * 16 + 4 * wave + e) * 64 + lane];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-            const f32x4 v = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
+            const DVT v = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
             const int m = e + 8 * wave + 4 * hh;         // reg = 4 wave + e: (reg & 3) + 8 (reg >> 2) + 4 hh
-            *reinterpret_cast<f32x4 *>(slab + (size_t)(i0 + 4 * m + q) * out + j0 + 4 * r) = v;
+            *reinterpret_cast<DVT *>(slab + (size_t)(i0 + 4 * m + q) * out + j0 + NP * r) = v;
         }
     }
     DH_STAMP(3);
@@ -500,10 +516,10 @@ __device__ __forceinline__ void dH_direct_body(const float *__restrict__ X, cons
         slots[tid] = colsum;                             // [wave][hh][r]
         __syncthreads();
         if (tid < 32) {
-            f32x4 v = slots[tid];
+            DVT v = slots[tid];
 #pragma unroll
             for (int e = 1; e < 8; ++e) v += slots[e * 32 + tid];           // fixed order: (wave 0: hh 0, hh 1), wave 1, ...
-            *reinterpret_cast<f32x4 *>(slab + (size_t)in * out + j0 + 4 * tid) = v;
+            *reinterpret_cast<DVT *>(slab + (size_t)in * out + j0 + NP * tid) = v;
         }
     }
     DH_STAMP(4);
@@ -548,7 +564,8 @@ struct GradJobDev {
     long long N, rows_per_split;
     int in, out, n, kin, kout;
     int tiles_j, tiles, splits, vec4;
-    int dA_blocks, t128, dw_transposed;                      // t128: tile form 0 = 64 x 64 (LDS), 1 = 128 x 128 (LDS), 2 = register-resident
+    int dA_blocks, t128, dw_transposed;                      // t128: tile form 0 = 64 x 64 (LDS), 1 = 128 x 128 (LDS), 2 / 3 = register-resident
+                                                             // 128 x 128 (own launch) / 128 x 64 (shares the 64 x 64 form's launch)
     const float *xf_stat;                                    // X operand = act(x * scale + shift) (see dH_partial_body)
     const int *xf_n_valid;
     int xf_act;
@@ -589,8 +606,8 @@ struct GradLaunch {
     GradBatch batch;                                        // blk0_partial counts inside the job's own tile form
     unsigned nb_partial, nb_partial128, nb_direct, nb_reduce, nb_contract;
 };
-size_t grad_chunk_ws_floats(const phc_phm_grad_job *jobs, int num_jobs);
-int prepare_grad_launch(const char *who, const phc_phm_grad_job *jobs, int num_jobs, float *ws_base, GradLaunch *out);
+size_t grad_chunk_ws_floats(const phc_phm_grad_job *jobs, int num_jobs, int direct_form = 2);
+int prepare_grad_launch(const char *who, const phc_phm_grad_job *jobs, int num_jobs, float *ws_base, GradLaunch *out, int direct_form = 2);
 int launch_grad_rest(const char *who, const GradLaunch &gl, bool partial64_too, hipStream_t s);
 int launch_grad_contract(const char *who, const GradLaunch &gl, hipStream_t s);
 // the register-resident jobs' partial launch (if any); profile = false: the caller already holds a launch-profiler scope

@@ -938,7 +938,7 @@ __global__ __launch_bounds__(256) void phm_grads_direct_kernel(GradBatch b) {
     long long split;
     xcd_tile_split(local, (unsigned)j.tiles, (unsigned)j.splits, tile, split);
     const long long xf_count = j.xf_stat ? (j.xf_n_valid ? min((long long)*j.xf_n_valid, j.N) : j.N) : 0;
-    dH_direct_body(j.x, j.dy, j.slabs, j.N, j.in, j.out, j.tiles_j, j.rows_per_split, tile, split, direct_smem, j.xf_stat, j.xf_act,
+    dH_direct_body<4>(j.x, j.dy, j.slabs, j.N, j.in, j.out, j.tiles_j, j.rows_per_split, tile, split, direct_smem, j.xf_stat, j.xf_act,
                    xf_count);
 }
 
@@ -1165,16 +1165,19 @@ static inline bool dh_use_direct(const phc_phm_grad_job &jb) {
 
 // Split counts of a whole batch: about 1024 workgroups in total, shared among the jobs in proportion to
 // their row-block counts (depends on the shapes only, never on the device: fixed summation order).
-static void grad_plans(const phc_phm_grad_job *jobs, int num, GradPlan *plans) {
+// direct_form: 2 = 128 x 128 tiles per wavefront in their own launch (512 registers, one wavefront per SIMD); 3 = 128 x 64 tiles
+// (256 registers, two per SIMD) for a launch SHARED with other workgroup families (phc_step_tail: the table-gradient workgroups
+// are latency-bound gathers and run in the slots beside the MFMA-bound dH wavefronts)
+static void grad_plans(const phc_phm_grad_job *jobs, int num, GradPlan *plans, int direct_form = 2) {
     int64_t total = 0, direct_rows = 0;
     for (int k = 0; k < num; ++k) {
         const int in = jobs[k].n * jobs[k].kin, out = jobs[k].n * jobs[k].kout;
-        plans[k].t128 = dh_use_direct(jobs[k]) ? 2 : (dh_use_128(jobs[k].N, in, out) ? 1 : 0);
+        plans[k].t128 = dh_use_direct(jobs[k]) ? direct_form : (dh_use_128(jobs[k].N, in, out) ? 1 : 0);
         const int T = plans[k].t128 ? DH_T2 : DH_T;
         plans[k].tiles_i = (in + T - 1) / T;
-        plans[k].tiles_j = (out + T - 1) / T;
+        plans[k].tiles_j = plans[k].t128 == 3 ? out / 64 : (out + T - 1) / T;
         plans[k].slab_elems = (size_t)in * out + out;
-        if (plans[k].t128 == 2)
+        if (plans[k].t128 >= 2)
             direct_rows += (int64_t)plans[k].tiles_i * plans[k].tiles_j * jobs[k].N;
         else
             total += (int64_t)plans[k].tiles_i * plans[k].tiles_j * ((jobs[k].N + DH_RB - 1) / DH_RB);
@@ -1182,18 +1185,20 @@ static void grad_plans(const phc_phm_grad_job *jobs, int num, GradPlan *plans) {
     if (direct_rows > 0) {
         // register-resident jobs: one workgroup per CU of a 256-CU part in ONE round (a workgroup owns its CU: 512 registers per
         // lane), every workgroup the same number of rows: the smallest multiple of 8 whose workgroup count fits the target
-        static const int64_t dtarget = getenv("PHC_DH_DIRECT_TARGET") ? atoll(getenv("PHC_DH_DIRECT_TARGET")) : 256;
+        static const int64_t dtarget2 = getenv("PHC_DH_DIRECT_TARGET") ? atoll(getenv("PHC_DH_DIRECT_TARGET")) : 256;
+        static const int64_t dtarget3 = getenv("PHC_DH_DIRECT64_TARGET") ? atoll(getenv("PHC_DH_DIRECT64_TARGET")) : 512;
+        const int64_t dtarget = direct_form == 3 ? dtarget3 : dtarget2;       // form 3: two workgroups per CU
         // multiples of 64 rows: each of the four wavefronts then runs whole 16-row iterations of the unmasked loop
         int64_t rps = (direct_rows / dtarget + 63) / 64 * 64;
         if (rps < 64) rps = 64;
         for (;; rps += 64) {
             int64_t wgs = 0;
             for (int k = 0; k < num; ++k)
-                if (plans[k].t128 == 2) wgs += (int64_t)plans[k].tiles_i * plans[k].tiles_j * ((jobs[k].N + rps - 1) / rps);
+                if (plans[k].t128 >= 2) wgs += (int64_t)plans[k].tiles_i * plans[k].tiles_j * ((jobs[k].N + rps - 1) / rps);
             if (wgs <= dtarget || rps >= direct_rows) break;
         }
         for (int k = 0; k < num; ++k)
-            if (plans[k].t128 == 2) {
+            if (plans[k].t128 >= 2) {
                 plans[k].rows_per_split = rps;
                 plans[k].splits = (int)((jobs[k].N + rps - 1) / rps);
             }
@@ -1204,9 +1209,9 @@ static void grad_plans(const phc_phm_grad_job *jobs, int num, GradPlan *plans) {
         for (int k = 0; k < num; ++k)
             fprintf(stderr, "[phc plan] job %d: N=%lld in=%d out=%d form=%d xf=%d splits=%d rows_per_split=%lld\n", k, (long long)jobs[k].N,
                     jobs[k].n * jobs[k].kin, jobs[k].n * jobs[k].kout, plans[k].t128, jobs[k].xf_stat ? jobs[k].xf_act : -1,
-                    plans[k].t128 == 2 ? plans[k].splits : -1, plans[k].t128 == 2 ? (long long)plans[k].rows_per_split : -1LL);
+                    plans[k].t128 >= 2 ? plans[k].splits : -1, plans[k].t128 >= 2 ? (long long)plans[k].rows_per_split : -1LL);
     for (int k = 0; k < num; ++k) {
-        if (plans[k].t128 == 2) continue;
+        if (plans[k].t128 >= 2) continue;
         const int64_t max_splits = (jobs[k].N + DH_RB - 1) / DH_RB;
         int64_t splits = total > target ? (max_splits * target + total - 1) / total : max_splits;
         if (splits < 1) splits = 1;
@@ -1230,19 +1235,19 @@ int check_grad_jobs(const char *who, const phc_phm_grad_job *jobs, int num_jobs)
     return PHC_OK;
 }
 
-size_t grad_chunk_ws_floats(const phc_phm_grad_job *jobs, int num_jobs) {
+size_t grad_chunk_ws_floats(const phc_phm_grad_job *jobs, int num_jobs, int direct_form) {
     GradPlan plans[GRAD_JOBS_PER_LAUNCH];
-    grad_plans(jobs, num_jobs, plans);
+    grad_plans(jobs, num_jobs, plans, direct_form);
     size_t off = 0;
     for (int k = 0; k < num_jobs; ++k) off += (plans[k].slab_elems * ((size_t)plans[k].splits + 1) + 3) / 4 * 4;   // 16-byte segments
     return off;
 }
 
-int prepare_grad_launch(const char *who, const phc_phm_grad_job *jobs, int cn, float *ws_base, GradLaunch *out) {
+int prepare_grad_launch(const char *who, const phc_phm_grad_job *jobs, int cn, float *ws_base, GradLaunch *out, int direct_form) {
     PHC_REQUIRE(cn >= 1 && cn <= GRAD_JOBS_PER_LAUNCH, PHC_ERR_INVALID_ARG, "%s: %d jobs in one launch (1..%d)", who, cn,
                 GRAD_JOBS_PER_LAUNCH);
     GradPlan plans[GRAD_JOBS_PER_LAUNCH];
-    grad_plans(jobs, cn, plans);
+    grad_plans(jobs, cn, plans, direct_form);
     GradBatch &b = out->batch;
     b.num = cn;
     unsigned nb_partial = 0, nb_partial128 = 0, nb_direct = 0, nb_reduce = 0, nb_contract = 0;
@@ -1272,7 +1277,7 @@ int prepare_grad_launch(const char *who, const phc_phm_grad_job *jobs, int cn, f
         d.dH = d.slabs + plans[k].slab_elems * (size_t)plans[k].splits;
         off += (plans[k].slab_elems * ((size_t)plans[k].splits + 1) + 3) / 4 * 4;
         d.dA_blocks = jb.n * jb.n * jb.n;
-        unsigned &nb_mine = d.t128 == 2 ? nb_direct : (d.t128 ? nb_partial128 : nb_partial);
+        unsigned &nb_mine = d.t128 == 2 ? nb_direct : (d.t128 == 1 ? nb_partial128 : nb_partial);     // forms 0 and 3 share a launch
         d.blk0_partial = nb_mine;
         d.blk0_reduce = nb_reduce;
         d.blk0_contract = nb_contract;
