@@ -62,7 +62,7 @@ MFMA_KERNELS = ("phm_gemm_fwd", "phm_gemm_dx", "phm_dH_partial", "table_grad")
 PMC_NAMES = {"phm_gemm_fwd": "phm_stream_kernel<0, -1, 32, 4, 1>", "phm_gemm_dx": "phm_stream_kernel<0, -1, 32, 4, 0>",
              "phm_dH_partial": "tail_partial_kernel", "aggregate_enc_fwd": "aggregate_encp_direct_fwd_kernel",
              "aggregate_enc_dx": "aggregate_enc_dx_kernel", "aggregate_fwd": "aggregate_fwd_kernel",
-             "bn_apply": "bn_apply_merged_kernel", "bn_bwd_apply": "bn_bwd_apply_kernel", "bn_bwd_partial": "bn_bwd_partial_kernel",
+             "bn_apply": "bn_apply_acc_kernel", "bn_bwd_apply": "bn_bwd_apply_kernel", "bn_bwd_partial": "bn_bwd_partial_kernel",
              "bn_stats_partial": "bn_stats_partial_kernel", "table_grad": "table_grad_mfma_kernel<1"}
 
 

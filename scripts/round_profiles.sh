@@ -1,0 +1,18 @@
+# Round-end evidence in one call: kernel stats + launch sequence + PMC traffic of the headline bench, the other workloads' lines.
+#   scripts/gpu.sh --timeout 2400 -- 'bash scripts/round_profiles.sh r02'
+R=${1:-rXX}
+bash scripts/rocprof_bench.sh ${R} > gpurun_out/${R}_rocprof_bench.log 2>&1
+bash scripts/rocprof_trace.sh ${R}b 1800 > gpurun_out/${R}_rocprof_trace.log 2>&1
+bash scripts/rocprof_pmc.sh ${R} > gpurun_out/${R}_rocprof_pmc.log 2>&1
+F=$(find gpurun_out/pmc_${R}_FETCH_SIZE -name "*counter_collection.csv" | head -1)
+W=$(find gpurun_out/pmc_${R}_WRITE_SIZE -name "*counter_collection.csv" | head -1)
+python3 scripts/summarize_pmc.py $F $W gpurun_out/${R}_pmc_traffic.json > gpurun_out/${R}_pmc_traffic.txt 2>&1
+find gpurun_out/pmc_${R}_FETCH_SIZE gpurun_out/pmc_${R}_WRITE_SIZE -name "*.csv" -size +5M -delete
+for wl in zinc_b1024 molpcba_b1024 molhiv_b512_softmax; do
+  python bench.py --workload $wl --cpu-steps 0 2>&1 | tail -1 > gpurun_out/${R}_bench_$wl.json
+done
+python bench.py --workload synth_10m50m --steps 10 --warmup 2 2>&1 | tail -1 > gpurun_out/${R}_bench_synth_10m50m_1gpu.json
+python bench.py --workload synth_10m50m --layers 4 --steps 5 --warmup 2 2>&1 | tail -1 > gpurun_out/${R}_bench_synth_10m50m_4layers_1gpu.json
+timeout 900 python scripts/microbench.py huge > gpurun_out/${R}_microbench_config5_1gpu.txt 2>&1
+python bench.py 2>&1 | tail -1 > gpurun_out/${R}_bench_default.json
+ls -la gpurun_out/${R}_* | head -30
