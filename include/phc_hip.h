@@ -456,11 +456,15 @@ int phc_csr_build_pair(const int64_t *edge_src_i64, const int64_t *edge_dst_i64,
 
 /* The same, and the packed edge codes of phc_pack_edge_codes (destination-sorted order) out of the same five launches:
  * the last one knows where every edge ends up and packs its bond features there.  codes / bond_i64 / vocab may be NULL
- * (then this is phc_csr_build_pair).  F <= 4, sum(vocab) <= 256. */
+ * (then this is phc_csr_build_pair).  F <= 4, sum(vocab) <= 256.
+ * code_counts (optional, needs codes and sum(vocab) <= 32): [n_dst][CR] floats, CR = 16 when sum(vocab) <= 16 else 32 —
+ * code_counts[d][t] = number of in-edges of node d whose code names table row t (columns >= sum(vocab) are 0): the bond
+ * encoders' one-hot operand summed per destination, which phc_step_tail multiplies with each layer's dout on the matrix
+ * cores.  Written by the same last launch. */
 int phc_csr_build_pair_codes(const int64_t *edge_src_i64, const int64_t *edge_dst_i64, int64_t E, int64_t n_src,
                              int64_t n_dst, int32_t *rowptr, int32_t *col, int32_t *perm, int32_t *rowptr_t,
                              int32_t *col_t, int32_t *perm_t, const int64_t *bond_i64, const int32_t *vocab, int F,
-                             uint32_t *codes, void *ws, size_t ws_bytes, void *stream);
+                             uint32_t *codes, float *code_counts, void *ws, size_t ws_bytes, void *stream);
 
 /* Per-batch preprocessing on the device: drop the nodes no edge touches and re-index,
  * i.e. the reference's CustomRemoveIsolatedNodes / PyG RemoveIsolatedNodes applied to every collated
@@ -512,14 +516,17 @@ int phc_bn_bwd_from_partials(const float *dy, const float *x, const float *save_
  * points (same workgroup bodies, same fixed summation order).  PHC_ERR_UNSUPPORTED when a job needs the
  * 128 x 128 tile path: use the separate entry points then.
  * Bond tables: bond_n_dst > 0 selects the counted form of phc_table_grads_counted (bond_rowptr / bond_codes, act
- * must be identity; bond_i64 / edge_* may be NULL), bond_n_dst = 0 the per-edge form of phc_table_grads_batched. */
+ * must be identity; bond_i64 / edge_* may be NULL), bond_n_dst = 0 the per-edge form of phc_table_grads_batched.
+ * bond_counts (optional, counted form only): the code_counts of phc_csr_build_pair_codes — the bond tables then take
+ * the register-resident form (dT = counts^T . dout straight from global memory, all layers of a group sharing the
+ * counts operand); the atom tables take theirs whenever h % 64 == 0. */
 size_t phc_step_tail_ws_bytes(const phc_phm_grad_job *jobs, int num_jobs, int num_tjobs, int64_t E, int64_t bond_n_dst,
                               int F_b, const int32_t *vocab_b, int64_t N_atoms, int F_a, const int32_t *vocab_a, int n,
                               int k);
 int phc_step_tail(const phc_phm_grad_job *jobs, int num_jobs, const phc_table_grad_job *tjobs, int num_tjobs,
                   const int64_t *bond_i64, const int32_t *vocab_b, const int64_t *edge_src_i64,
                   const int64_t *edge_dst_i64, int64_t E, int F_b, int act, const int32_t *bond_rowptr,
-                  const uint32_t *bond_codes, int64_t bond_n_dst, const float *atom_dout,
+                  const uint32_t *bond_codes, const float *bond_counts, int64_t bond_n_dst, const float *atom_dout,
                   const int64_t *atom_idx_i64, int64_t N_atoms, int F_a, const int32_t *vocab_a,
                   float *atom_dtables_flat, int n, int k, void *ws, size_t ws_bytes, void *stream);
 

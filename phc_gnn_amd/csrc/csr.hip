@@ -299,6 +299,10 @@ struct CsrPair {
     unsigned *codes;
     int F, off[4], vocab[4];
     int *err;                          // registered error word (phc_set_error_word) or nullptr
+    // optional: per destination row, how many of its in-edges name each table row — counts[row][CR], CR = 16 or 32 columns
+    // (the A operand of the register-resident bond-table gradient, phc_step_tail); R = sum(vocab) <= CR
+    float *counts;
+    int CR, R;
 };
 
 __global__ void csr_pair_zero_kernel(CsrPair p) {
@@ -400,6 +404,21 @@ __global__ __launch_bounds__(256) void csr_pair_canon_kernel(CsrPair p) {
                     c |= (unsigned)(p.off[f] + (int)checked_index(p.bond[(long long)v * p.F + f], p.vocab[f], p.err, PHC_IDX_ERR_BOND))
                          << (8 * f);
                 p.codes[b + rank] = c;
+            }
+        }
+        if (blockIdx.y == 0 && p.counts) {
+            // the 8 lanes of the row's group share the table rows; each walks the row's edges for its own rows (read from the
+            // bond features, not from the codes the other lanes are writing right now)
+            for (int tp = li; tp < p.CR; tp += SUB) {
+                int f = 0;
+                for (int u = 1; u < p.F; ++u) f += tp >= p.off[u];
+                int cnt = 0;
+                if (tp < p.R)
+                    for (int j = 0; j < deg; ++j) {
+                        const long long v = sd.tmp_perm[b + j];
+                        cnt += p.off[f] + (int)safe_index(p.bond[v * p.F + f], p.vocab[f]) == tp ? 1 : 0;
+                    }
+                p.counts[(size_t)k * p.CR + tp] = (float)cnt;
             }
         }
     }
@@ -620,14 +639,15 @@ int phc_csr_build_pair(const int64_t *edge_src_i64, const int64_t *edge_dst_i64,
                        int32_t *rowptr, int32_t *col, int32_t *perm, int32_t *rowptr_t, int32_t *col_t, int32_t *perm_t, void *ws,
                        size_t ws_bytes, void *stream) {
     return phc_csr_build_pair_codes(edge_src_i64, edge_dst_i64, E, n_src, n_dst, rowptr, col, perm, rowptr_t, col_t, perm_t, nullptr,
-                                    nullptr, 0, nullptr, ws, ws_bytes, stream);
+                                    nullptr, 0, nullptr, nullptr, ws, ws_bytes, stream);
 }
 
 int phc_csr_build_pair_codes(const int64_t *edge_src_i64, const int64_t *edge_dst_i64, int64_t E, int64_t n_src, int64_t n_dst,
                              int32_t *rowptr, int32_t *col, int32_t *perm, int32_t *rowptr_t, int32_t *col_t, int32_t *perm_t,
-                             const int64_t *bond_i64, const int32_t *vocab, int F, uint32_t *codes, void *ws, size_t ws_bytes,
-                             void *stream) {
+                             const int64_t *bond_i64, const int32_t *vocab, int F, uint32_t *codes, float *code_counts, void *ws,
+                             size_t ws_bytes, void *stream) {
     int code_off[4] = {0, 0, 0, 0};
+    int code_rows = 0;
     if (codes) {
         PHC_REQUIRE(bond_i64 && vocab && F >= 1 && F <= 4, PHC_ERR_INVALID_ARG, "phc_csr_build_pair_codes: codes need bond, vocab, 1 <= F <= 4");
         int acc = 0;
@@ -637,7 +657,10 @@ int phc_csr_build_pair_codes(const int64_t *edge_src_i64, const int64_t *edge_ds
             acc += vocab[f];
         }
         PHC_REQUIRE(acc <= 256, PHC_ERR_UNSUPPORTED, "phc_csr_build_pair_codes: packed codes need sum(vocab) <= 256");
+        code_rows = acc;
     }
+    PHC_REQUIRE(!code_counts || (codes && code_rows <= 32), PHC_ERR_INVALID_ARG,
+                "phc_csr_build_pair_codes: code_counts need codes and sum(vocab) <= 32");
     PHC_REQUIRE(E >= 1 && n_src >= 1 && n_dst >= 1, PHC_ERR_INVALID_ARG, "phc_csr_build_pair: E=%lld n_src=%lld n_dst=%lld",
                 (long long)E, (long long)n_src, (long long)n_dst);
     PHC_REQUIRE(n_src <= PAIR_MAX_KEYS && n_dst <= PAIR_MAX_KEYS && E < (1LL << 31) - 1, PHC_ERR_UNSUPPORTED,
@@ -661,6 +684,9 @@ int phc_csr_build_pair_codes(const int64_t *edge_src_i64, const int64_t *edge_ds
     p.s[1].tmp_perm = reinterpret_cast<int *>(q);
     p.bond = reinterpret_cast<const long long *>(bond_i64);
     p.codes = codes;
+    p.counts = code_counts;
+    p.R = code_rows;
+    p.CR = code_rows <= 16 ? 16 : 32;
     p.F = codes ? F : 0;
     for (int f = 0; f < 4; ++f) {
         p.off[f] = code_off[f];

@@ -623,6 +623,117 @@ __device__ __forceinline__ void table_grad_rows_body(
     }
 }
 
+// ---- atom-table gradients, register-resident (the form of dH_direct_body, phm_grad_device.h) ---------------------------------
+// dT = O^T . g with O[i][t] = 1 iff table row t = off_f + idx[i, f] for the feature f that owns row t: the contraction index is
+// the node, so v_mfma_f32_32x32x2_f32 takes both operands straight from global memory — half-wave hh handles node i + hh, lane r
+// holds g[i + hh][j0 + 2r, 2r + 1] (one coalesced 256-byte row per half-wave) and, per 32-row M block q, the ONE index
+// idx[i + hh, f(t)] of the feature that owns its table row t = r0 + 32 q + r (a 4-byte load, same cache line for the whole
+// half-wave): A = (index == t - off_f) ? 1 : 0.  No LDS tile, no barrier per 64 items (the LDS form spends four), nothing scattered.
+// A workgroup = 4 wavefronts on 4 node quarters of one (M group of TD_MB blocks, 64-column tile, split); they meet once through LDS.
+constexpr int TD_MB = 3;                                 // M blocks per tile: 96 table rows
+constexpr int TD_PF = 4;                                 // node pairs per load batch
+
+__device__ __forceinline__ void atom_direct_body(const float *__restrict__ dout, const long long *__restrict__ idx, const EncMeta &m,
+                                                 long long n_items, long long items_per_split, int h, int tiles_j, float *__restrict__ slabs,
+                                                 int tile, long long split, float *__restrict__ smem) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int mg = tile / tiles_j, tj = tile - mg * tiles_j;
+    const int r0 = mg * 32 * TD_MB, j0 = tj * 64;
+    const int F = m.F;
+    const long long t_begin = split * items_per_split, t_end = min(n_items, t_begin + items_per_split);
+    const long long rq = items_per_split >> 2;           // items_per_split % 8 == 0: quarters start on even nodes
+    const long long w_begin = min(t_begin + wave * rq, t_end), w_end = min(w_begin + rq, t_end);
+    // the feature that owns this lane's table row in each M block, as a byte offset into an index row, and the value to match
+    unsigned foff[TD_MB];
+    int val[TD_MB];
+#pragma unroll
+    for (int q = 0; q < TD_MB; ++q) {
+        const int t = r0 + 32 * q + r;
+        int f = 0;
+        for (int u = 1; u < F; ++u) f += t >= m.off[u];
+        int base = 0;
+        for (int u = 0; u < F; ++u) base = u == f ? m.off[u] : base;            // uniform walk of the by-value table
+        foff[q] = (unsigned)f * 8u;
+        val[q] = t < m.R ? t - base : -1;                // rows past the tables match nothing (indices are >= 0)
+    }
+    f32x16 acc[TD_MB][2];
+#pragma unroll
+    for (int q = 0; q < TD_MB; ++q)
+#pragma unroll
+        for (int p2 = 0; p2 < 2; ++p2)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[q][p2][i] = 0.f;
+    const long long last = max(t_end - 1, 0LL);
+    const unsigned goff = (unsigned)(j0 + 2 * r) * 4u;
+    f32x2 ga[TD_PF], gb[TD_PF];
+    int ia[TD_PF][TD_MB], ib[TD_PF][TD_MB];
+    auto load = [&](f32x2 (&G)[TD_PF], int (&I)[TD_PF][TD_MB], long long row0) {
+#pragma unroll
+        for (int t = 0; t < TD_PF; ++t) {
+            const long long g = min(row0 + 2 * t + hh, last);               // clamped: nodes past the range are read and masked
+            G[t] = *reinterpret_cast<const f32x2 *>(reinterpret_cast<const char *>(dout + (size_t)g * h) + goff);
+            const char *irow = reinterpret_cast<const char *>(idx + (size_t)g * F);
+#pragma unroll
+            for (int q = 0; q < TD_MB; ++q) I[t][q] = *reinterpret_cast<const int *>(irow + foff[q]);
+        }
+    };
+    auto pairs = [&](const f32x2 (&G)[TD_PF], const int (&I)[TD_PF][TD_MB], long long row0) {
+#pragma unroll
+        for (int t = 0; t < TD_PF; ++t) {
+            const bool live = row0 + 2 * t + hh < w_end;
+            f32x2 gv = G[t];
+            gv[0] = live ? gv[0] : 0.f;
+            gv[1] = live ? gv[1] : 0.f;
+#pragma unroll
+            for (int q = 0; q < TD_MB; ++q) {
+                const float a = I[t][q] == val[q] ? 1.f : 0.f;
+                acc[q][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, gv[0], acc[q][0], 0, 0, 0);
+                acc[q][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, gv[1], acc[q][1], 0, 0, 0);
+            }
+        }
+    };
+    if (w_begin < w_end) {
+        load(ga, ia, w_begin);
+        for (long long row = w_begin; row < w_end; row += 4 * TD_PF) {
+            load(gb, ib, row + 2 * TD_PF);
+            __builtin_amdgcn_sched_barrier(0);
+            pairs(ga, ia, row);
+            __builtin_amdgcn_sched_barrier(0);
+            load(ga, ia, row + 4 * TD_PF);
+            __builtin_amdgcn_sched_barrier(0);
+            pairs(gb, ib, row + 2 * TD_PF);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    // the four wavefronts meet: per M block, every wavefront parks it in LDS ([wave][reg][lane] float2 = 32 KB), then wavefront
+    // w sums registers 4w .. 4w+3 of all four in the fixed order 0, 1, 2, 3 and writes those table rows of the slab
+    float *slab = slabs + (size_t)split * m.R * h;
+    f32x2 *slots = reinterpret_cast<f32x2 *>(smem);
+#pragma unroll
+    for (int q = 0; q < TD_MB; ++q) {
+        if (q) __syncthreads();
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const f32x2 v = {acc[q][0][reg], acc[q][1][reg]};
+            slots[(wave * 16 + reg) * 64 + lane] = v;
+        }
+        __syncthreads();
+        f32x2 part[4][4];
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) part[w2][e] = slots[(w2 * 16 + 4 * wave + e) * 64 + lane];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const f32x2 v = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
+            const int row = r0 + 32 * q + e + 8 * wave + 4 * hh;            // reg = 4 wave + e
+            if (row < m.R) *reinterpret_cast<f32x2 *>(slab + (size_t)row * h + j0 + 2 * r) = v;
+        }
+    }
+}
+
 template <int MODE, int ACT>
 __global__ __launch_bounds__(ENC_THREADS) void table_grad_mfma_kernel(
     const float *__restrict__ dout, const long long *__restrict__ idx, EncMeta m, long long n_items, long long items_per_split,
@@ -721,6 +832,100 @@ __device__ __forceinline__ void table_grad_reduce_body(const float *__restrict__
     }
 }
 
+// ---- bond-table gradients (identity message function), register-resident ------------------------------------------------------
+// dT_l = C^T . dout_l for every message-passing layer l, C[d][t] = number of in-edges of node d whose code names table row t
+// (code_counts of phc_csr_build_pair_codes: built once per batch by the structure build, [n_dst][CR]).  One M block (<= 32 table
+// rows); the layers of a group of TD_JG share the A operand: per node pair one 4-byte load of C and one 8-byte load of every
+// layer's dout feed 2 * TD_JG MFMAs.  Rows past the range are masked in A only (a zero row of C annihilates whatever dout holds).
+constexpr int TD_JG = 4;                                 // layers per tile
+
+__device__ __forceinline__ void bond_direct_body(const TgBatch &jobs, int job0, int njobs, const float *__restrict__ counts, int CR, int R,
+                                                 long long n_items, long long items_per_split, int h, int tj, long long split,
+                                                 float *__restrict__ smem) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int j0 = tj * 64;
+    const long long t_begin = split * items_per_split, t_end = min(n_items, t_begin + items_per_split);
+    const long long rq = items_per_split >> 2;
+    const long long w_begin = min(t_begin + wave * rq, t_end), w_end = min(w_begin + rq, t_end);
+    const float *dptr[TD_JG];
+#pragma unroll
+    for (int u = 0; u < TD_JG; ++u) dptr[u] = jobs.j[min(job0 + u, job0 + njobs - 1)].dout;       // (a short group re-reads its last layer)
+    f32x16 acc[TD_JG][2];
+#pragma unroll
+    for (int u = 0; u < TD_JG; ++u)
+#pragma unroll
+        for (int p2 = 0; p2 < 2; ++p2)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[u][p2][i] = 0.f;
+    const long long last = max(t_end - 1, 0LL);
+    const unsigned goff = (unsigned)(j0 + 2 * r) * 4u;
+    const bool ccol = r < CR;
+    const int cr = ccol ? r : 0;
+    float ca[TD_PF], cb[TD_PF];
+    f32x2 ga[TD_PF][TD_JG], gb[TD_PF][TD_JG];
+    auto load = [&](float (&Cv)[TD_PF], f32x2 (&G)[TD_PF][TD_JG], long long row0) {
+#pragma unroll
+        for (int t = 0; t < TD_PF; ++t) {
+            const long long g = min(row0 + 2 * t + hh, last);
+            Cv[t] = counts[(size_t)g * CR + cr];
+#pragma unroll
+            for (int u = 0; u < TD_JG; ++u)
+                G[t][u] = *reinterpret_cast<const f32x2 *>(reinterpret_cast<const char *>(dptr[u] + (size_t)g * h) + goff);
+        }
+    };
+    auto pairs = [&](const float (&Cv)[TD_PF], const f32x2 (&G)[TD_PF][TD_JG], long long row0) {
+#pragma unroll
+        for (int t = 0; t < TD_PF; ++t) {
+            const float a = (ccol && row0 + 2 * t + hh < w_end) ? Cv[t] : 0.f;
+#pragma unroll
+            for (int u = 0; u < TD_JG; ++u) {
+                acc[u][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, G[t][u][0], acc[u][0], 0, 0, 0);
+                acc[u][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, G[t][u][1], acc[u][1], 0, 0, 0);
+            }
+        }
+    };
+    if (w_begin < w_end) {
+        load(ca, ga, w_begin);
+        for (long long row = w_begin; row < w_end; row += 4 * TD_PF) {
+            load(cb, gb, row + 2 * TD_PF);
+            __builtin_amdgcn_sched_barrier(0);
+            pairs(ca, ga, row);
+            __builtin_amdgcn_sched_barrier(0);
+            load(ca, ga, row + 4 * TD_PF);
+            __builtin_amdgcn_sched_barrier(0);
+            pairs(cb, gb, row + 2 * TD_PF);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    f32x2 *slots = reinterpret_cast<f32x2 *>(smem);
+#pragma unroll
+    for (int u = 0; u < TD_JG; ++u) {
+        if (u) __syncthreads();
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const f32x2 v = {acc[u][0][reg], acc[u][1][reg]};
+            slots[(wave * 16 + reg) * 64 + lane] = v;
+        }
+        __syncthreads();
+        f32x2 part[4][4];
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) part[w2][e] = slots[(w2 * 16 + 4 * wave + e) * 64 + lane];
+        if (u < njobs) {                                 // uniform
+            float *slab = jobs.j[job0 + u].slabs + (size_t)split * R * h;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const f32x2 v = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
+                const int row = e + 8 * wave + 4 * hh;
+                if (row < R) *reinterpret_cast<f32x2 *>(slab + (size_t)row * h + j0 + 2 * r) = v;
+            }
+        }
+    }
+}
+
 // ---- the step's tail in one pass ----------------------------------------------------------------------------
 // All parameter gradients of a model are due only when the optimizer runs.  phc_step_tail launches their first
 // stages SIDE BY SIDE: workgroups [0, nb_atom) build atom-table slabs, [nb_atom, nb_atom + nb_bond) the bond-table
@@ -745,6 +950,10 @@ struct TailTables {
     long long N_a, ips_a;
     int tiles_j_a, tiles_a, slabs_a, vec4_a;
     int n, k, h;
+    int dh_first;                                            // block order: the dH family before the table families
+    int atom_direct;                                         // atom tables in the register-resident form (atom_direct_body)
+    const float *counts_b;                                   // != NULL: bond tables in the register-resident form (bond_direct_body)
+    int cr_b;                                                // columns of counts_b (16 | 32)
     unsigned nb_atom, nb_bond;                               // workgroup counts of the first launch
     unsigned nr_phm, nr_bond, nr_atom;                       // ... of the reduce launch
 };
@@ -753,16 +962,34 @@ template <int ACT>
 __global__ __launch_bounds__(256, 2) void tail_partial_kernel(GradBatch gb, TailTables t) {
     __shared__ __attribute__((aligned(16))) float smem[2 * TG_IB * TG_T];
     static_assert(2 * TG_IB * TG_T == 2 * DH_RB * DH_STRIDE, "table and dH workgroups stage the same 32 KB");
-    // (Dispatch order was tried three ways — table families first, interleaved in proportion, the long dH workgroups first: within
-    // noise of each other, the interleaved one 15 us slower because the last dH workgroups start late.  Family order is kept.)
+    // Dispatch order: workgroups start in block order, two per CU: table families, then the dH family.  The long dH workgroups
+    // first (t.dh_first, PHC_TAIL_DH_FIRST=1) measured within noise of it; interleaving the families in proportion cost 15 us.
     unsigned bx = blockIdx.x;
+    if (t.dh_first) {
+        const unsigned nT = t.nb_atom + t.nb_bond, nD = gridDim.x - nT;
+        bx = bx < nD ? nT + bx : bx - nD;
+    }
     if (bx < t.nb_atom) {
         const int tile = bx % t.tiles_a;
+        if (t.atom_direct) {
+            atom_direct_body(t.atom_dout, t.atom_idx, t.ma, t.N_a, t.ips_a, t.h, t.tiles_j_a, t.atom_slabs, tile, bx / t.tiles_a, smem);
+            return;
+        }
         table_grad_rows_body<0>(t.atom_dout, t.atom_idx, nullptr, nullptr, 0, t.ma, t.N_a, t.ips_a, t.h, t.tiles_j_a, t.vec4_a, t.atom_slabs,
                                 tile, bx / t.tiles_a, smem);
         return;
     }
     bx -= t.nb_atom;
+    if (bx < t.nb_bond && t.counts_b) {
+        // register-resident form: (layer group, 64-column tile, split)
+        const unsigned per_group = (unsigned)t.tiles_b * (unsigned)t.slabs_b;
+        const int jg = bx / per_group;
+        const unsigned local = bx - jg * per_group;
+        const int job0 = jg * TD_JG;
+        bond_direct_body(t.bond, job0, min(TD_JG, t.jobs_b - job0), t.counts_b, t.cr_b, t.mb.R, t.E, t.ips_b, t.h, local % t.tiles_b,
+                         local / t.tiles_b, smem);
+        return;
+    }
     if (bx < t.nb_bond) {
         const unsigned per_job = (unsigned)t.tiles_b * (unsigned)t.slabs_b;
         const int job = bx / per_job;
@@ -786,8 +1013,11 @@ __global__ __launch_bounds__(256, 2) void tail_partial_kernel(GradBatch gb, Tail
     int tile;
     long long split;
     xcd_tile_split(local, (unsigned)j.tiles, (unsigned)j.splits, tile, split);
-    if (j.t128 == 3)
+    if (j.t128 == 3 && j.out % 64 == 0)
         dH_direct_body<2>(j.x, j.dy, j.slabs, j.N, j.in, j.out, j.tiles_j, j.rows_per_split, tile, split, smem, j.xf_stat, j.xf_act,
+                          xf_count);
+    else if (j.t128 == 3)                                    // out an odd multiple of 32: 128 x 32 tiles
+        dH_direct_body<1>(j.x, j.dy, j.slabs, j.N, j.in, j.out, j.tiles_j, j.rows_per_split, tile, split, smem, j.xf_stat, j.xf_act,
                           xf_count);
     else
         dH_partial_body(j.x, j.dy, j.slabs, j.N, j.in, j.out, j.tiles_j, j.rows_per_split, j.vec4, tile, split, smem, j.xf_stat, j.xf_act,
@@ -832,6 +1062,45 @@ struct TgPlan {
     long long items_per_split;
     size_t slab_floats;
 };
+
+// register-resident atom form: tiles = (M groups of 96 table rows) x (64-column tiles), one workgroup per (tile, split), about 256
+// workgroups, every split the same number of nodes (a multiple of 8: four wavefront quarters starting on even nodes)
+static bool tg_direct_shape_ok(long long n_items, int h) {
+    static const bool off = getenv("PHC_TG_NO_DIRECT") != nullptr;
+    return !off && h % 64 == 0 && n_items >= 8;
+}
+static TgPlan tg_plan_direct(long long n_items, int R, int h) {
+    TgPlan p;
+    p.tiles_i = (R + 32 * TD_MB - 1) / (32 * TD_MB);
+    p.tiles_j = h / 64;
+    const long long tiles = (long long)p.tiles_i * p.tiles_j;
+    static const long long target = getenv("PHC_TG_DIRECT_TARGET") ? atoll(getenv("PHC_TG_DIRECT_TARGET")) : 256;
+    long long ips = ((n_items * tiles + target - 1) / target + 7) / 8 * 8;
+    if (ips < 8) ips = 8;
+    const size_t cap_slabs = ((size_t)16 << 20) / (sizeof(float) * (size_t)R * h);       // <= 16 MB of slabs
+    if ((size_t)((n_items + ips - 1) / ips) > cap_slabs && cap_slabs > 0) ips = ((n_items + (long long)cap_slabs - 1) / (long long)cap_slabs + 7) / 8 * 8;
+    p.items_per_split = ips;
+    p.num_slabs = (int)((n_items + ips - 1) / ips);
+    if (p.num_slabs < 1) p.num_slabs = 1;
+    p.slab_floats = (size_t)p.num_slabs * R * h;
+    return p;
+}
+
+// register-resident bond form: tiles = (layer groups of TD_JG) x (64-column tiles); slab_floats is PER JOB
+static TgPlan tg_plan_direct_bond(long long n_items, int R, int h, int jobs) {
+    TgPlan p;
+    p.tiles_i = (jobs + TD_JG - 1) / TD_JG;                  // layer groups
+    p.tiles_j = h / 64;
+    const long long tiles = (long long)p.tiles_i * p.tiles_j;
+    static const long long target = getenv("PHC_TG_DIRECT_TARGET") ? atoll(getenv("PHC_TG_DIRECT_TARGET")) : 256;
+    long long ips = ((n_items * tiles + target - 1) / target + 7) / 8 * 8;
+    if (ips < 8) ips = 8;
+    p.items_per_split = ips;
+    p.num_slabs = (int)((n_items + ips - 1) / ips);
+    if (p.num_slabs < 1) p.num_slabs = 1;
+    p.slab_floats = (size_t)p.num_slabs * R * h;
+    return p;
+}
 
 static TgPlan tg_plan(long long n_items, int R, int h, int jobs = 1) {
     TgPlan p;
@@ -1341,11 +1610,19 @@ static int tail_plan(const phc_phm_grad_job *jobs, int num_jobs, int num_tjobs, 
         if (rc) return rc;
         PHC_REQUIRE(E >= 1 && bond_n_dst >= 0, PHC_ERR_INVALID_ARG, "phc_step_tail: table jobs without edges");
         *pb = tg_plan(bond_n_dst > 0 ? bond_n_dst : E, mb->R, h, num_tjobs);      // counted form: items = destination nodes
+        if (bond_n_dst > 0 && mb->R <= 32 && tg_direct_shape_ok(bond_n_dst, h)) {   // either form may run: room for the larger slab set
+            const TgPlan d = tg_plan_direct_bond(bond_n_dst, mb->R, h, num_tjobs);
+            if (d.slab_floats > pb->slab_floats) pb->slab_floats = d.slab_floats;
+        }
     }
     if (N_atoms > 0) {
         rc = make_meta("phc_step_tail", F_a, vocab_a, ma);
         if (rc) return rc;
         *pa = tg_plan(N_atoms, ma->R, h);
+        if (tg_direct_shape_ok(N_atoms, h)) {                // either form may run (the register-resident one needs an aligned dout):
+            const TgPlan d = tg_plan_direct(N_atoms, ma->R, h);                   // the workspace holds the larger slab set
+            if (d.slab_floats > pa->slab_floats) pa->slab_floats = d.slab_floats;
+        }
     }
     *phm_floats = grad_chunk_ws_floats(jobs, num_jobs, tail_direct_form(num_tjobs, N_atoms));
     return PHC_OK;
@@ -1362,7 +1639,7 @@ size_t phc_step_tail_ws_bytes(const phc_phm_grad_job *jobs, int num_jobs, int nu
 
 int phc_step_tail(const phc_phm_grad_job *jobs, int num_jobs, const phc_table_grad_job *tjobs, int num_tjobs, const int64_t *bond_i64,
                   const int32_t *vocab_b, const int64_t *edge_src_i64, const int64_t *edge_dst_i64, int64_t E, int F_b, int act,
-                  const int32_t *bond_rowptr, const uint32_t *bond_codes, int64_t bond_n_dst, const float *atom_dout,
+                  const int32_t *bond_rowptr, const uint32_t *bond_codes, const float *bond_counts, int64_t bond_n_dst, const float *atom_dout,
                   const int64_t *atom_idx_i64, int64_t N_atoms, int F_a, const int32_t *vocab_a, float *atom_dtables_flat, int n, int k,
                   void *ws, size_t ws_bytes, void *stream) {
     EncMeta mb, ma;
@@ -1403,6 +1680,14 @@ int phc_step_tail(const phc_phm_grad_job *jobs, int num_jobs, const phc_table_gr
         t.rowptr_b = counted ? bond_rowptr : nullptr;
         t.codes_b = counted ? bond_codes : nullptr;
         t.n_edges_b = E;
+        bool bond_direct = counted && bond_counts && mb.R <= 32 && tg_direct_shape_ok(bond_n_dst, h);
+        for (int q = 0; q < num_tjobs && bond_direct; ++q) bond_direct = tjobs[q].dout && (reinterpret_cast<uintptr_t>(tjobs[q].dout) & 7) == 0;
+        if (bond_direct) {                                   // register-resident form: its own split plan, the same slab stride
+            const TgPlan d = tg_plan_direct_bond(bond_n_dst, mb.R, h, num_tjobs);
+            pb.items_per_split = d.items_per_split; pb.tiles_i = d.tiles_i; pb.tiles_j = d.tiles_j; pb.num_slabs = d.num_slabs;
+            t.counts_b = bond_counts;
+            t.cr_b = mb.R <= 16 ? 16 : 32;
+        }
         t.ips_b = pb.items_per_split; t.tiles_j_b = pb.tiles_j; t.tiles_b = pb.tiles_i * pb.tiles_j; t.slabs_b = pb.num_slabs;
         t.jobs_b = num_tjobs;
         int vec4 = (k % 4 == 0);
@@ -1415,7 +1700,12 @@ int phc_step_tail(const phc_phm_grad_job *jobs, int num_jobs, const phc_table_gr
             vec4 = vec4 && al16(tjobs[q].dout) && (!tjobs[q].x || al16(tjobs[q].x));
         }
         t.vec4_b = vec4;
-        t.nb_bond = (unsigned)t.tiles_b * (unsigned)t.slabs_b * (unsigned)num_tjobs;
+        if (bond_direct) {
+            t.tiles_b = pb.tiles_j;                          // 64-column tiles; the layer groups are the outer index
+            t.nb_bond = (unsigned)pb.tiles_i * (unsigned)pb.tiles_j * (unsigned)t.slabs_b;
+        } else {
+            t.nb_bond = (unsigned)t.tiles_b * (unsigned)t.slabs_b * (unsigned)num_tjobs;
+        }
         t.nr_bond = (unsigned)((mb.R * h + 63) / 64) * (unsigned)num_tjobs;
     }
     if (N_atoms > 0) {
@@ -1423,6 +1713,8 @@ int phc_step_tail(const phc_phm_grad_job *jobs, int num_jobs, const phc_table_gr
         t.atom_dout = atom_dout;
         t.atom_idx = reinterpret_cast<const long long *>(atom_idx_i64);
         t.atom_slabs = wsf; t.atom_flat = atom_dtables_flat;
+        t.atom_direct = tg_direct_shape_ok(N_atoms, h) && (reinterpret_cast<uintptr_t>(atom_dout) & 7) == 0;
+        if (t.atom_direct) pa = tg_plan_direct(N_atoms, ma.R, h);
         t.N_a = N_atoms; t.ips_a = pa.items_per_split; t.tiles_j_a = pa.tiles_j; t.tiles_a = pa.tiles_i * pa.tiles_j; t.slabs_a = pa.num_slabs;
         t.vec4_a = (k % 4 == 0) && al16(atom_dout);
         t.nb_atom = (unsigned)t.tiles_a * (unsigned)t.slabs_a;
@@ -1437,6 +1729,10 @@ int phc_step_tail(const phc_phm_grad_job *jobs, int num_jobs, const phc_table_gr
         if (skip && strstr(skip, "dh")) gl.nb_partial = 0;
     }
 #endif
+    {
+        static const int knob = getenv("PHC_TAIL_DH_FIRST") ? atoi(getenv("PHC_TAIL_DH_FIRST")) : -1;
+        t.dh_first = knob > 0 ? 1 : 0;                       // measured within noise of the family order: off
+    }
     const unsigned nb1 = t.nb_atom + t.nb_bond + gl.nb_partial, nb2 = t.nr_phm + t.nr_bond + t.nr_atom;
     rc = launch_grad_direct("step_tail(direct)", gl, s);     // the 128-multiple layers: register-resident tiles, their own launch
     if (rc) return rc;

@@ -303,10 +303,12 @@ constexpr int DH_PF = PHC_DH_PF;                        // row pairs per load ba
 constexpr int DH_DIRECT_LDS_BYTES = 4 * 16 * 64 * 16;   // exchange slots: [wave][reg][lane] float4 = 64 KB
 
 using f32x2 = __attribute__((ext_vector_type(2))) float;
-// NP = "N blocks" of a register-resident tile: 4 -> 128 columns of dy per wavefront (float4 per lane), 2 -> 64 (float2)
+// NP = "N blocks" of a register-resident tile: 4 -> 128 columns of dy per wavefront (float4 per lane), 2 -> 64 (float2), 1 -> 32
 template <int NP> struct DhVec;
 template <> struct DhVec<4> { using T = f32x4; };
 template <> struct DhVec<2> { using T = f32x2; };
+using f32x1 = __attribute__((ext_vector_type(1))) float;
+template <> struct DhVec<1> { using T = f32x1; };
 
 // One batch of DH_PF row pairs.  The x operand is always x := max(x * scale + shift, floor) per column: a plain operand is
 // (1, 0, -inf) — exact —, an unapplied batch-norm its (scale, shift) with floor -inf / 0 for identity / relu (the other

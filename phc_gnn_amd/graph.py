@@ -73,6 +73,7 @@ class EdgeStructure:
         self._csr: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None
         self._csc: Optional[Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None
         self._codes: dict = {}
+        self._code_counts = None          # (codes tensor, [num_dst, 16 | 32] per-destination table-row counts) from the pair build
         self._codes_args = None
         self._codes_orig: dict = {}
         self._codes_orig_args = None
@@ -120,6 +121,7 @@ class EdgeStructure:
             if self._csc is not None:
                 _build_sorted(self._src, self._dst, self.num_src, out=self._csc, num_other=self.num_dst)
         if not (pair_rebuilt and self._codes_args is not None):      # the pair launches repacked the sorted codes already
+            self._code_counts = None                                  # (and the counts that go with them; stale otherwise)
             for codes in self._codes.values():
                 self._pack_codes(*self._codes_args, codes)
         for codes in self._codes_orig.values():
@@ -140,18 +142,25 @@ class EdgeStructure:
         csr, csc = (self._csr, self._csc) if reuse else (alloc(self.num_dst), alloc(self.num_src))
         ws_bytes = lib.phc_csr_pair_ws_bytes(E, self.num_src, self.num_dst)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        codes = bond = vocab_c = None
+        codes = bond = vocab_c = counts = None
         F = 0
         if reuse and self._codes and self._codes_args is not None:
             bond, vocab_c, F = self._codes_args
             codes = next(iter(self._codes.values()))
+            cc = getattr(self, "_code_counts", None)
+            counts = cc[1] if (cc is not None and cc[0] is codes) else None
         elif codes_for is not None:
             bond, vocab_c, F = codes_for
             codes = torch.empty(E, dtype=torch.int32, device=dev)
+            rows = sum(int(v) for v in list(vocab_c)[:F])
+            if rows <= 32:                                   # per-destination table-row counts (phc_step_tail's bond operand)
+                counts = torch.empty((self.num_dst, 16 if rows <= 16 else 32), dtype=torch.float32, device=dev)
         L.check(lib.phc_csr_build_pair_codes(L.ptr(self._src), L.ptr(self._dst), E, self.num_src, self.num_dst, L.ptr(csr[0]),
                                              L.ptr(csr[1]), L.ptr(csr[2]), L.ptr(csc[0]), L.ptr(csc[1]), L.ptr(csc[2]),
-                                             L.ptr(bond), vocab_c, F, L.ptr(codes), L.ptr(ws), ws_bytes, L.stream_ptr(dev)),
+                                             L.ptr(bond), vocab_c, F, L.ptr(codes), L.ptr(counts), L.ptr(ws), ws_bytes,
+                                             L.stream_ptr(dev)),
                 "phc_csr_build_pair_codes")
+        self._code_counts = (codes, counts) if counts is not None else None
         L.maybe_check_indices(dev)
         self._csr, self._csc = csr, csc
         if codes is not None and not reuse:

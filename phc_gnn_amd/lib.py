@@ -106,7 +106,7 @@ SIGNATURES = {
     "phc_csr_build": (_I, [_P, _P, _L, _L, _L, _P, _P, _P, _P, _S, _P]),
     "phc_csr_pair_ws_bytes": (_S, [_L, _L, _L]),
     "phc_csr_build_pair": (_I, [_P, _P, _L, _L, _L, _P, _P, _P, _P, _P, _P, _P, _S, _P]),
-    "phc_csr_build_pair_codes": (_I, [_P, _P, _L, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _S, _P]),
+    "phc_csr_build_pair_codes": (_I, [_P, _P, _L, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _S, _P]),
     "phc_remove_isolated_ws_bytes": (_S, [_L]),
     "phc_remove_isolated_nodes": (_I, [_P, _P, _L, _L, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _S, _P]),
     "phc_segment_ptr_sorted": (_I, [_P, _L, _L, _P, _P]),
@@ -136,7 +136,7 @@ SIGNATURES = {
     "phc_table_grads_counted_ws_bytes": (_S, [_L, _I, _P, _I, _I, _I]),
     "phc_table_grads_counted": (_I, [C.POINTER(TableGradJob), _I, _P, _P, _L, _L, _P, _I, _I, _I, _P, _S, _P]),
     "phc_step_tail_ws_bytes": (_S, [C.POINTER(GradJob), _I, _I, _L, _L, _I, _P, _L, _I, _P, _I, _I]),
-    "phc_step_tail": (_I, [C.POINTER(GradJob), _I, C.POINTER(TableGradJob), _I, _P, _P, _P, _P, _L, _I, _I, _P, _P, _L, _P, _P, _L, _I,
+    "phc_step_tail": (_I, [C.POINTER(GradJob), _I, C.POINTER(TableGradJob), _I, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _L, _P, _P, _L, _I,
                            _P, _P, _I, _I, _P, _S, _P]),
     "phc_bn_ws_bytes": (_S, [_L, _I]),
     "phc_bn_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _L, _I, _I, C.c_float, C.c_float, _I, _P, _P, _P, _P, _S, C.c_float, _I, _I,

@@ -219,7 +219,7 @@ def _flush_step_tail(jobs, tjobs, ajobs) -> bool:
         # bond tables
         tarr, tflat, per = None, None, 0
         E = F_b = act = b_ndst = 0
-        bond = src = dst = vocab_b = b_codes = b_rowptr = None
+        bond = src = dst = vocab_b = b_codes = b_rowptr = b_counts = None
         if tjobs:
             st = tjobs[0]["st"]
             per = ts_b.n * ts_b.R * ts_b.k
@@ -231,6 +231,9 @@ def _flush_step_tail(jobs, tjobs, ajobs) -> bool:
             bond, src, dst, vocab_b = tjobs[0]["bond"], st._src, st._dst, ts_b.vocab_c
             if tjobs[0].get("codes") is not None:
                 b_codes, b_rowptr, b_ndst = tjobs[0]["codes"], st.csr[0], st.num_dst
+                cc = getattr(st, "_code_counts", None)       # per-destination table-row counts out of the pair build
+                if cc is not None and cc[0] is b_codes:
+                    b_counts = cc[1]
         # atom tables
         aflat = None
         N_a = F_a = 0
@@ -244,7 +247,7 @@ def _flush_step_tail(jobs, tjobs, ajobs) -> bool:
             return False
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         L.check(lib.phc_step_tail(arr, len(jobs), tarr, len(tjobs), L.ptr(bond), vocab_b, L.ptr(src), L.ptr(dst), E, F_b, act,
-                                  L.ptr(b_rowptr), L.ptr(b_codes), b_ndst, L.ptr(a_dout), L.ptr(a_idx), N_a, F_a, vocab_a,
+                                  L.ptr(b_rowptr), L.ptr(b_codes), L.ptr(b_counts), b_ndst, L.ptr(a_dout), L.ptr(a_idx), N_a, F_a, vocab_a,
                                   L.ptr(aflat), n, k, L.ptr(ws), ws_bytes, L.stream_ptr(dev)), "phc_step_tail")
         if L.PROF_ON:
             for jb in jobs:

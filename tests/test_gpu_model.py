@@ -347,8 +347,11 @@ def test_graphed_step_with_the_engine_optimizer_tracks_the_torch_optimizer():
 
 @pytest.mark.parametrize("wl", ["molhiv_b32", "molhiv_b512"])
 def test_step_tail_in_one_pass_equals_the_separate_gradient_launches(wl, monkeypatch):
-    """phc_step_tail (PHM, bond-table and atom-table gradients side by side in one launch + one reduce) must give
-    bit-identical parameter gradients to phc_phm_param_grads + phc_table_grads_batched + phc_encode_bwd."""
+    """phc_step_tail (PHM, bond-table and atom-table gradients side by side in one launch + one reduce) against the separate
+    entry points phc_phm_param_grads + phc_table_grads_* + phc_encode_bwd: the same gradients to fp32 round-off.  (The tail
+    uses the register-resident forms — 128 x 64 / 128 x 32 dH tiles, count / one-hot operands generated in registers — where the
+    separate launches use 128 x 128 tiles or LDS tiles: different, but each fixed, summation orders; bit-reproducibility of
+    the step itself is test_graphed_step_is_reproducible's and test_accumulator_steps_are_bit_reproducible's business.)"""
     from phc_gnn_amd import harness, ops
     d = harness.to_device(harness.make_batch(wl, seed=21), DEV)
     grads = []
@@ -358,8 +361,14 @@ def test_step_tail_in_one_pass_equals_the_separate_gradient_launches(wl, monkeyp
         harness.train_step(m, d, None, harness.StepConfig(optimizer=False))
         grads.append({k: p.grad.clone() for k, p in m.named_parameters() if p.grad is not None})
     assert grads[0].keys() == grads[1].keys() and len(grads[0]) > 100
+    n_enc = 0
     for k in grads[0]:
-        assert torch.equal(grads[0][k], grads[1][k]), k
+        n_enc += "encoder" in k
+        if k.endswith(".b") and k not in ("pooling.linear.b", "downstream.affine.2.b"):
+            continue                                         # a bias in front of a batch-norm: its gradient is exactly 0 + round-off
+        if float(grads[1][k].abs().max()) > 0:
+            assert_close(grads[0][k], grads[1][k], 5e-6, k)
+    assert n_enc >= 2                                        # atom and bond encoders
 
 
 @pytest.mark.parametrize("variant", ["molhiv_b512", "molhiv_b512_softmax", "molhiv_b512_conv"])
