@@ -4,8 +4,8 @@ R=${1:-rXX}
 bash scripts/rocprof_bench.sh ${R} > gpurun_out/${R}_rocprof_bench.log 2>&1
 bash scripts/rocprof_trace.sh ${R}b 1800 > gpurun_out/${R}_rocprof_trace.log 2>&1
 bash scripts/rocprof_pmc.sh ${R} > gpurun_out/${R}_rocprof_pmc.log 2>&1
-F=$(find gpurun_out/pmc_${R}_FETCH_SIZE -name "*counter_collection.csv" | head -1)
-W=$(find gpurun_out/pmc_${R}_WRITE_SIZE -name "*counter_collection.csv" | head -1)
+F=$(ls -t gpurun_out/pmc_${R}_FETCH_SIZE/*/*counter_collection.csv | head -1)
+W=$(ls -t gpurun_out/pmc_${R}_WRITE_SIZE/*/*counter_collection.csv | head -1)
 python3 scripts/summarize_pmc.py $F $W gpurun_out/${R}_pmc_traffic.json > gpurun_out/${R}_pmc_traffic.txt 2>&1
 find gpurun_out/pmc_${R}_FETCH_SIZE gpurun_out/pmc_${R}_WRITE_SIZE -name "*.csv" -size +5M -delete
 for wl in zinc_b1024 molpcba_b1024 molhiv_b512_softmax; do
