@@ -631,7 +631,15 @@ __device__ __forceinline__ void table_grad_rows_body(
 // half-wave): A = (index == t - off_f) ? 1 : 0.  No LDS tile, no barrier per 64 items (the LDS form spends four), nothing scattered.
 // A workgroup = 4 wavefronts on 4 node quarters of one (M group of TD_MB blocks, 64-column tile, split); they meet once through LDS.
 constexpr int TD_MB = 3;                                 // M blocks per tile: 96 table rows
-constexpr int TD_PF = 4;                                 // node pairs per load batch
+// node pairs per load batch (two batches alternate).  Deeper batches (8 for atoms, 6 for bonds, so that a batch's MFMAs outlast a
+// memory round trip) cost registers (228 -> 256) and made the launch 8 us slower at molecule scale: 4 and 4.
+#ifndef PHC_TD_PFA
+#define PHC_TD_PFA 4
+#endif
+#ifndef PHC_TD_PFB
+#define PHC_TD_PFB 4
+#endif
+constexpr int TD_PFA = PHC_TD_PFA, TD_PFB = PHC_TD_PFB;
 
 __device__ __forceinline__ void atom_direct_body(const float *__restrict__ dout, const long long *__restrict__ idx, const EncMeta &m,
                                                  long long n_items, long long items_per_split, int h, int tiles_j, float *__restrict__ slabs,
@@ -667,11 +675,11 @@ __device__ __forceinline__ void atom_direct_body(const float *__restrict__ dout,
             for (int i = 0; i < 16; ++i) acc[q][p2][i] = 0.f;
     const long long last = max(t_end - 1, 0LL);
     const unsigned goff = (unsigned)(j0 + 2 * r) * 4u;
-    f32x2 ga[TD_PF], gb[TD_PF];
-    int ia[TD_PF][TD_MB], ib[TD_PF][TD_MB];
-    auto load = [&](f32x2 (&G)[TD_PF], int (&I)[TD_PF][TD_MB], long long row0) {
+    f32x2 ga[TD_PFA], gb[TD_PFA];
+    int ia[TD_PFA][TD_MB], ib[TD_PFA][TD_MB];
+    auto load = [&](f32x2 (&G)[TD_PFA], int (&I)[TD_PFA][TD_MB], long long row0) {
 #pragma unroll
-        for (int t = 0; t < TD_PF; ++t) {
+        for (int t = 0; t < TD_PFA; ++t) {
             const long long g = min(row0 + 2 * t + hh, last);               // clamped: nodes past the range are read and masked
             G[t] = *reinterpret_cast<const f32x2 *>(reinterpret_cast<const char *>(dout + (size_t)g * h) + goff);
             const char *irow = reinterpret_cast<const char *>(idx + (size_t)g * F);
@@ -679,9 +687,9 @@ __device__ __forceinline__ void atom_direct_body(const float *__restrict__ dout,
             for (int q = 0; q < TD_MB; ++q) I[t][q] = *reinterpret_cast<const int *>(irow + foff[q]);
         }
     };
-    auto pairs = [&](const f32x2 (&G)[TD_PF], const int (&I)[TD_PF][TD_MB], long long row0) {
+    auto pairs = [&](const f32x2 (&G)[TD_PFA], const int (&I)[TD_PFA][TD_MB], long long row0) {
 #pragma unroll
-        for (int t = 0; t < TD_PF; ++t) {
+        for (int t = 0; t < TD_PFA; ++t) {
             const bool live = row0 + 2 * t + hh < w_end;
             f32x2 gv = G[t];
             gv[0] = live ? gv[0] : 0.f;
@@ -696,14 +704,14 @@ __device__ __forceinline__ void atom_direct_body(const float *__restrict__ dout,
     };
     if (w_begin < w_end) {
         load(ga, ia, w_begin);
-        for (long long row = w_begin; row < w_end; row += 4 * TD_PF) {
-            load(gb, ib, row + 2 * TD_PF);
+        for (long long row = w_begin; row < w_end; row += 4 * TD_PFA) {
+            load(gb, ib, row + 2 * TD_PFA);
             __builtin_amdgcn_sched_barrier(0);
             pairs(ga, ia, row);
             __builtin_amdgcn_sched_barrier(0);
-            load(ga, ia, row + 4 * TD_PF);
+            load(ga, ia, row + 4 * TD_PFA);
             __builtin_amdgcn_sched_barrier(0);
-            pairs(gb, ib, row + 2 * TD_PF);
+            pairs(gb, ib, row + 2 * TD_PFA);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
@@ -863,11 +871,11 @@ __device__ __forceinline__ void bond_direct_body(const TgBatch &jobs, int job0, 
     const unsigned goff = (unsigned)(j0 + 2 * r) * 4u;
     const bool ccol = r < CR;
     const int cr = ccol ? r : 0;
-    float ca[TD_PF], cb[TD_PF];
-    f32x2 ga[TD_PF][TD_JG], gb[TD_PF][TD_JG];
-    auto load = [&](float (&Cv)[TD_PF], f32x2 (&G)[TD_PF][TD_JG], long long row0) {
+    float ca[TD_PFB], cb[TD_PFB];
+    f32x2 ga[TD_PFB][TD_JG], gb[TD_PFB][TD_JG];
+    auto load = [&](float (&Cv)[TD_PFB], f32x2 (&G)[TD_PFB][TD_JG], long long row0) {
 #pragma unroll
-        for (int t = 0; t < TD_PF; ++t) {
+        for (int t = 0; t < TD_PFB; ++t) {
             const long long g = min(row0 + 2 * t + hh, last);
             Cv[t] = counts[(size_t)g * CR + cr];
 #pragma unroll
@@ -875,9 +883,9 @@ __device__ __forceinline__ void bond_direct_body(const TgBatch &jobs, int job0, 
                 G[t][u] = *reinterpret_cast<const f32x2 *>(reinterpret_cast<const char *>(dptr[u] + (size_t)g * h) + goff);
         }
     };
-    auto pairs = [&](const float (&Cv)[TD_PF], const f32x2 (&G)[TD_PF][TD_JG], long long row0) {
+    auto pairs = [&](const float (&Cv)[TD_PFB], const f32x2 (&G)[TD_PFB][TD_JG], long long row0) {
 #pragma unroll
-        for (int t = 0; t < TD_PF; ++t) {
+        for (int t = 0; t < TD_PFB; ++t) {
             const float a = (ccol && row0 + 2 * t + hh < w_end) ? Cv[t] : 0.f;
 #pragma unroll
             for (int u = 0; u < TD_JG; ++u) {
@@ -888,14 +896,14 @@ __device__ __forceinline__ void bond_direct_body(const TgBatch &jobs, int job0, 
     };
     if (w_begin < w_end) {
         load(ca, ga, w_begin);
-        for (long long row = w_begin; row < w_end; row += 4 * TD_PF) {
-            load(cb, gb, row + 2 * TD_PF);
+        for (long long row = w_begin; row < w_end; row += 4 * TD_PFB) {
+            load(cb, gb, row + 2 * TD_PFB);
             __builtin_amdgcn_sched_barrier(0);
             pairs(ca, ga, row);
             __builtin_amdgcn_sched_barrier(0);
-            load(ca, ga, row + 4 * TD_PF);
+            load(ca, ga, row + 4 * TD_PFB);
             __builtin_amdgcn_sched_barrier(0);
-            pairs(cb, gb, row + 2 * TD_PF);
+            pairs(cb, gb, row + 2 * TD_PFB);
             __builtin_amdgcn_sched_barrier(0);
         }
     }
