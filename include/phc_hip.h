@@ -404,7 +404,7 @@ int phc_bn_bwd_apply(const float *dy, const float *x, const float *save_stat, co
  *   phc_gemm_prebuilt_bwsums   num_partials = NULL: sums_partial is the accumulator
  *   phc_bn_bwd_from_partials   num_partials = 0: sums_partial is the accumulator (ws unused)
  *   phc_bn_bwd                 ws_bytes = 0: ws is the accumulator (one launch less: no merge between the two passes)
- * phc_bn_finalize_from_partials (the hand-over into phc_gemm_prebuilt_xf's operand) has no accumulator form. */
+ * phc_bn_finalize_from_partials + phc_gemm_prebuilt_xf: phc_gemm_prebuilt_xf_acc reads the accumulator itself. */
 int phc_gemm_stats_max_partials(void);
 size_t phc_stat_acc_words(int h);             /* 64-bit words of one statistics accumulator of width h */
 int phc_stat_acc_replicas(void);              /* rows of its [2 * replicas][2 * h] word layout (ops.py views it that way) */
@@ -494,6 +494,14 @@ int phc_bn_finalize_from_partials(const float *stats_partial, const float *stats
 int phc_gemm_prebuilt_xf(const float *x, const float *xf_stat, int xf_act, const int32_t *n_valid_dev, const float *M,
                          const float *b, int64_t N, int K, int Nout, float *y, float *stats_partial,
                          float *stats_counts, int *num_partials, void *stream);
+/* The same with the input norm's statistics still in an ACCUMULATOR (xf_acc, width K, filled by phc_gemm_prebuilt_stats' accumulator
+ * form): the launch derives scale / shift in its prologue — beside its operand panel load — writes save_stat [6 K] and updates the
+ * running statistics: phc_bn_finalize_from_partials and its launch are not needed. */
+int phc_gemm_prebuilt_xf_acc(const float *x, const uint64_t *xf_acc, const float *const *weight, const float *const *bias,
+                             float *const *running_mean, float *const *running_var, int64_t *const *num_batches_tracked,
+                             int n_comp, float momentum, float eps, float *save_stat, int xf_act, const int32_t *n_valid_dev,
+                             const float *M, const float *b, int64_t N, int K, int Nout, float *y, float *stats_partial,
+                             float *stats_counts, int *num_partials, void *stream);
 
 /* Backward of that pair.  phc_gemm_prebuilt_bwsums computes dz = dy . M (M = H^T of the second layer) and, from
  * the same registers, the column sums the norm's backward needs — sum g and sum g*x_hat with

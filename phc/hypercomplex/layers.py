@@ -151,7 +151,7 @@ class PHMMLP(nn.Module):
         """``n_valid`` (engine extension): device int32 scalar; rows past it are padding of a
         fixed-shape batch and stay out of the batch-norm statistics."""
         want = self.training and x.is_cuda and x.dim() == 2
-        x = self.linear1(x, bn_stats=_engine.BNStatsRequest(n_valid) if (want and self.norm_flag) else None)
+        x = self.linear1(x, bn_stats=_engine.BNStatsRequest(n_valid, "apply") if (want and self.norm_flag) else None)
         out_req = _engine.BNStatsRequest(n_valid, "apply") if (want and getattr(self, "out_norm_follows", False)) else None
         if self.norm_flag and want:
             # norm -> activation -> linear2 in the second GEMM's operand staging: the normalised activation never exists

@@ -143,6 +143,41 @@ inline void ext_launch(void (*kernel)(Formals...), dim3 grid, dim3 block, unsign
         }                                                                                                                 \
     } while (0)
 
+// ---- batch-norm parameter tables (one BatchNorm1d per hypercomplex component, norm.py:20), by value in the kernarg segment ----
+constexpr int BN_MAX_COMP = PHC_MAX_COMPONENTS;
+struct BnParams {
+    const float *weight[BN_MAX_COMP];
+    const float *bias[BN_MAX_COMP];
+    float *running_mean[BN_MAX_COMP];
+    float *running_var[BN_MAX_COMP];
+    long long *num_batches_tracked[BN_MAX_COMP];
+    int n_comp;
+    int k;              // columns per component
+    int has_weight, has_bias, has_running, has_nbt;
+};
+inline int fill_params(const char *who, BnParams *p, const float *const *weight, const float *const *bias,
+                       float *const *running_mean, float *const *running_var, int64_t *const *nbt, int n_comp, int h) {
+    PHC_REQUIRE(n_comp >= 1 && n_comp <= BN_MAX_COMP, PHC_ERR_UNSUPPORTED, "%s: %d components (max %d)", who, n_comp, BN_MAX_COMP);
+    PHC_REQUIRE(h >= 1 && h % n_comp == 0, PHC_ERR_INVALID_ARG, "%s: h=%d not divisible by n_comp=%d", who, h, n_comp);
+    p->n_comp = n_comp;
+    p->k = h / n_comp;
+    p->has_weight = weight != nullptr;
+    p->has_bias = bias != nullptr;
+    p->has_running = running_mean != nullptr && running_var != nullptr;
+    p->has_nbt = nbt != nullptr;
+    for (int c = 0; c < n_comp; ++c) {
+        p->weight[c] = weight ? weight[c] : nullptr;
+        p->bias[c] = bias ? bias[c] : nullptr;
+        p->running_mean[c] = running_mean ? running_mean[c] : nullptr;
+        p->running_var[c] = running_var ? running_var[c] : nullptr;
+        p->num_batches_tracked[c] = nbt ? reinterpret_cast<long long *>(nbt[c]) : nullptr;
+        PHC_REQUIRE((!weight || weight[c]) && (!bias || bias[c]) && (!p->has_running || (running_mean[c] && running_var[c])),
+                    PHC_ERR_INVALID_ARG, "%s: null parameter pointer for component %d", who, c);
+    }
+    return PHC_OK;
+}
+
+
 // ---- statistics accumulators --------------------------------------------------------------------------------------
 // Column sums that many workgroups of one launch contribute to, WITHOUT a merge launch behind it: every workgroup adds its
 // partial with 64-bit INTEGER atomics (integer adds commute: the total does not depend on the arrival order, results stay

@@ -327,6 +327,15 @@ constexpr int ST_FLOATS = 32 * ST_STRIDE;       // private staging floats per wa
 // STATS: the workgroup also emits, per output column, the (sum, M2) of the rows it produced below *n_valid —
 // the batch-norm statistics of y come out of the GEMM's registers instead of a second pass over y
 // (stats_partial[blockIdx.y][0..Nout) = sum, [Nout..2Nout) = M2 about the workgroup's own mean; stats_counts[blockIdx.y]).
+// XF operand whose batch statistics are still in an ACCUMULATOR (phc_common.h): the launch derives scale / shift itself, in its
+// prologue, beside the operand panel load — no merge launch in front of it.  acc == NULL: xf_stat holds them (merged elsewhere).
+struct XfAcc {
+    const unsigned long long *acc = nullptr;
+    BnParams p = {};
+    float momentum = 0.f, eps = 0.f;
+    float *stat_out = nullptr;                               // [6 K] mean | invstd | scale | shift | w | b, written by workgroup (0, 0)
+};
+
 template <int TRANS, int NPHM, int BN, int WAVES, int STATS = 0>
 __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
     const float *__restrict__ X, const float *__restrict__ A, const float *__restrict__ W,
@@ -334,7 +343,8 @@ __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
     long long M, int K, int Nout, int n, int kin, int kout, int out_vec4,
     const int *__restrict__ n_valid = nullptr, float *__restrict__ stats_partial = nullptr,
     float *__restrict__ stats_counts = nullptr, const float *__restrict__ xf_stat = nullptr, int xf_act = 0,
-    const float *__restrict__ bw_x = nullptr, const float *__restrict__ bw_stat = nullptr, int bw_act = 0, int stats_acc = 0) {
+    const float *__restrict__ bw_x = nullptr, const float *__restrict__ bw_stat = nullptr, int bw_act = 0, int stats_acc = 0,
+    XfAcc xa = XfAcc{}) {
     // stats_acc != 0: stats_partial is a statistics accumulator (phc_common.h: 64-bit fixed-point words added with integer
     // atomics, no merge launch behind this one) instead of one [2 * Nout] partial row per workgroup row
     // STATS bit 0: emit batch-norm partials of the output; bit 1 (XF): the INPUT is a batch-norm that has not been
@@ -349,6 +359,7 @@ __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
     float *hs = smem;                                          // [round_up(K, 8)][HS_STRIDE]
     float *stage_all = hs + round_up(K, 8) * HS_STRIDE;        // [WAVES][ST_FLOATS]
     float *As = stage_all + WAVES * ST_FLOATS;                 // [n*n*n]
+    float *xf_lds = As + round_up(n * n * n, 4);               // XF from an accumulator: scale[K] | shift[K] (16-byte aligned)
 
     // XCD-aware block order: workgroups go to the 8 XCDs round-robin by linear id, and the gridDim.x column panels of one
     // row-slab group read the same x rows.  Inside every run of 8 * gridDim.x consecutive ids the (panel, slab group) pairs
@@ -379,6 +390,7 @@ __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
     // registers — cdna guide §5.7 item 1 — and was dropped)
     f32x4 xr[8];
     f32x4 xsc = {1.f, 1.f, 1.f, 1.f}, xsh = {0.f, 0.f, 0.f, 0.f};      // XF: scale / shift of the 4 columns held in xr
+    int xf_k = 0;                                                      // first of those 4 columns
     auto load_half = [&](long long sl, int half) {
         const int k0 = half * ST_KH;
         const int cc = min(lc4 * 4, K - k0 - 4);               // clamped: unconditional loads
@@ -388,13 +400,55 @@ __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
             xr[t] = *reinterpret_cast<const f32x4 *>(X + (size_t)row * K + k0 + cc);
         }
         if constexpr (XF) {
-            xsc = *reinterpret_cast<const f32x4 *>(xf_stat + 2 * (size_t)K + k0 + cc);
-            xsh = *reinterpret_cast<const f32x4 *>(xf_stat + 3 * (size_t)K + k0 + cc);
+            if (!xa.acc) {
+                xsc = *reinterpret_cast<const f32x4 *>(xf_stat + 2 * (size_t)K + k0 + cc);
+                xsh = *reinterpret_cast<const f32x4 *>(xf_stat + 3 * (size_t)K + k0 + cc);
+            }
         }
+        xf_k = k0 + cc;                                        // (accumulator form: scale / shift come from LDS at staging time)
     };
     long long xf_count = M;
-    if constexpr (XF)
+    if constexpr (XF) {
         if (n_valid) xf_count = min((long long)*n_valid, M);
+        if (xa.acc) {
+            // statistics of the K operand columns from the accumulator totals (double), then scale / shift into LDS; it is read
+            // after the operand panel's barrier.  Workgroup (0, 0) also leaves save_stat and the running statistics behind.
+            const bool owner = pbx == 0 && pby == 0;
+            for (int c = tid; c < K; c += THREADS) {
+                const double S = stat_acc_total(xa.acc, K, 0, c), Q = stat_acc_total(xa.acc, K, 1, c);
+                const double cntd = (double)max(xf_count, 1LL);
+                const double meand = S / cntd, vard = fmax(Q / cntd - meand * meand, 0.0);
+                const int comp = c / xa.p.k, kk = c - comp * xa.p.k;
+                float w = 1.f, bq = 0.f;
+                for (int q = 0; q < xa.p.n_comp; ++q)
+                    if (q == comp) {
+                        if (xa.p.has_weight) w = xa.p.weight[q][kk];
+                        if (xa.p.has_bias) bq = xa.p.bias[q][kk];
+                    }
+                const float mean = (float)meand, var = (float)vard;
+                const float invstd = 1.f / sqrtf(var + xa.eps);
+                xf_lds[c] = invstd * w;
+                xf_lds[K + c] = bq - mean * invstd * w;
+                if (owner) {
+                    float *st = xa.stat_out;
+                    st[c] = mean; st[K + c] = invstd; st[2 * K + c] = invstd * w; st[3 * K + c] = bq - mean * invstd * w;
+                    st[4 * K + c] = w; st[5 * K + c] = bq;
+                    if (xa.p.has_running) {
+                        const float unbiased = xf_count > 1 ? (float)(vard * cntd / (cntd - 1.0)) : var;
+                        for (int q = 0; q < xa.p.n_comp; ++q)
+                            if (q == comp) {
+                                float *rm = xa.p.running_mean[q] + kk, *rv = xa.p.running_var[q] + kk;
+                                *rm = (1.f - xa.momentum) * *rm + xa.momentum * mean;
+                                *rv = (1.f - xa.momentum) * *rv + xa.momentum * unbiased;
+                            }
+                    }
+                }
+            }
+            if (owner && xa.p.has_nbt && tid < xa.p.n_comp)
+                for (int q = 0; q < xa.p.n_comp; ++q)
+                    if (q == tid) *xa.p.num_batches_tracked[q] += 1;
+        }
+    }
     // BW: per-column norm constants of the 4 columns this lane stores (col = j0 + ct*32 + (lane & 7)*4) and its sums
     float4 bw_mean[CT], bw_inv[CT], bw_w[CT], bw_b[CT];
     float bw_sg[CT][4], bw_sgx[CT][4];
@@ -508,6 +562,12 @@ __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
             const int kc8 = round_up(kc, 8);
             // registers -> private LDS (k padding and the clamped column read as zero)
             const bool colok = lc4 * 4 < kc;
+            if constexpr (XF) {
+                if (xa.acc) {                                  // written in the prologue, in front of the panel's barrier
+                    xsc = *reinterpret_cast<const f32x4 *>(xf_lds + xf_k);
+                    xsh = *reinterpret_cast<const f32x4 *>(xf_lds + K + xf_k);
+                }
+            }
 #pragma unroll
             for (int t = 0; t < 8; ++t) {
                 const f32x4 z = {0.f, 0.f, 0.f, 0.f};
@@ -1007,7 +1067,8 @@ static int launch_stream_cfg(const float *X, const float *A, const float *W, con
                              float *out, int64_t M, int K, int Nout, int n, int kin, int kout, int wg_per_cu, hipStream_t s,
                              const int *n_valid = nullptr, float *stats_partial = nullptr, float *stats_counts = nullptr,
                              int *num_partials = nullptr, const float *xf_stat = nullptr, int xf_act = 0,
-                             const float *bw_x = nullptr, const float *bw_stat = nullptr, int bw_act = 0, int stats_acc = 0) {
+                             const float *bw_x = nullptr, const float *bw_stat = nullptr, int bw_act = 0, int stats_acc = 0,
+                             const XfAcc &xa = XfAcc{}) {
     const int panels = (Nout + BN - 1) / BN;
     const int64_t slabs = (M + 31) / 32;
     int64_t gy = ((int64_t)wg_per_cu * num_cu() + panels - 1) / panels;
@@ -1021,7 +1082,8 @@ static int launch_stream_cfg(const float *X, const float *A, const float *W, con
     }
     if (gy < 1) gy = 1;
     if (num_partials) *num_partials = (int)gy;
-    const size_t lds = sizeof(float) * ((size_t)round_up(K, 8) * (BN + 1) + (size_t)WAVES * ST_FLOATS + (size_t)n * n * n);
+    const size_t lds = sizeof(float) * ((size_t)round_up(K, 8) * (BN + 1) + (size_t)WAVES * ST_FLOATS + (size_t)round_up(n * n * n, 4) +
+                                        ((STATS & 2) ? 2 * (size_t)K : 0));
     const int out_vec4 = (Nout % 4 == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0) &&
                          (!bias || (reinterpret_cast<uintptr_t>(bias) & 15) == 0) &&
                          (!residual || (reinterpret_cast<uintptr_t>(residual) & 15) == 0);
@@ -1033,7 +1095,7 @@ static int launch_stream_cfg(const float *X, const float *A, const float *W, con
     }
     PHC_LAUNCH((phm_stream_kernel<TRANS, NPHM, BN, WAVES, STATS>), dim3(panels, (unsigned)gy), dim3(64 * WAVES), lds, s, X, A, W,
                        bias, residual, out, (long long)M, K, Nout, n, kin, kout, out_vec4, n_valid, stats_partial, stats_counts,
-                       xf_stat, xf_act, bw_x, bw_stat, bw_act, stats_acc);
+                       xf_stat, xf_act, bw_x, bw_stat, bw_act, stats_acc, xa);
     return PHC_OK;
 }
 
@@ -1554,9 +1616,38 @@ int phc_gemm_prebuilt_stats(const float *x, const float *M, const float *b, int6
     return check_launch("phc_gemm_prebuilt_stats");
 }
 
+static int gemm_prebuilt_xf_impl(const float *x, const float *xf_stat, int xf_act, const int32_t *n_valid_dev, const float *M,
+                                 const float *b, int64_t N, int K, int Nout, float *y, float *stats_partial, float *stats_counts,
+                                 int *num_partials, void *stream, const XfAcc &xa);
+
 int phc_gemm_prebuilt_xf(const float *x, const float *xf_stat, int xf_act, const int32_t *n_valid_dev, const float *M,
                          const float *b, int64_t N, int K, int Nout, float *y, float *stats_partial, float *stats_counts,
                          int *num_partials, void *stream) {
+    return gemm_prebuilt_xf_impl(x, xf_stat, xf_act, n_valid_dev, M, b, N, K, Nout, y, stats_partial, stats_counts, num_partials, stream,
+                                 XfAcc{});
+}
+
+int phc_gemm_prebuilt_xf_acc(const float *x, const uint64_t *xf_acc, const float *const *weight, const float *const *bias,
+                             float *const *running_mean, float *const *running_var, int64_t *const *num_batches_tracked, int n_comp,
+                             float momentum, float eps, float *save_stat, int xf_act, const int32_t *n_valid_dev, const float *M,
+                             const float *b, int64_t N, int K, int Nout, float *y, float *stats_partial, float *stats_counts,
+                             int *num_partials, void *stream) {
+    PHC_REQUIRE(xf_acc && save_stat && (reinterpret_cast<uintptr_t>(xf_acc) & 7) == 0, PHC_ERR_INVALID_ARG,
+                "phc_gemm_prebuilt_xf_acc: accumulator / save_stat pointer");
+    XfAcc xa;
+    xa.acc = reinterpret_cast<const unsigned long long *>(xf_acc);
+    int rc = fill_params("phc_gemm_prebuilt_xf_acc", &xa.p, weight, bias, running_mean, running_var, num_batches_tracked, n_comp, K);
+    if (rc) return rc;
+    xa.momentum = momentum;
+    xa.eps = eps;
+    xa.stat_out = save_stat;
+    return gemm_prebuilt_xf_impl(x, save_stat, xf_act, n_valid_dev, M, b, N, K, Nout, y, stats_partial, stats_counts, num_partials, stream,
+                                 xa);
+}
+
+static int gemm_prebuilt_xf_impl(const float *x, const float *xf_stat, int xf_act, const int32_t *n_valid_dev, const float *M,
+                                 const float *b, int64_t N, int K, int Nout, float *y, float *stats_partial, float *stats_counts,
+                                 int *num_partials, void *stream, const XfAcc &xa) {
     PHC_REQUIRE(N >= 1 && K >= 1 && Nout >= 1, PHC_ERR_INVALID_ARG, "phc_gemm_prebuilt_xf: bad shape");
     PHC_REQUIRE(x && xf_stat && M && y, PHC_ERR_INVALID_ARG, "phc_gemm_prebuilt_xf: null pointer");
     PHC_REQUIRE(xf_act >= PHC_ACT_IDENTITY && xf_act <= PHC_ACT_SELU, PHC_ERR_INVALID_ARG, "phc_gemm_prebuilt_xf: unknown activation %d",
@@ -1576,16 +1667,16 @@ int phc_gemm_prebuilt_xf(const float *x, const float *xf_stat, int xf_act, const
 #define PHC_XF_LAUNCH(SV)                                                                                                      \
     if (N >= gemm_wide_k_m() && Nout > 64 && K > 128)                                                                          \
         launch_stream_cfg<0, -1, 64, 8, SV>(x, nullptr, M, b, nullptr, y, N, K, Nout, 1, K, Nout, 1, s, n_valid_dev, stats_partial, \
-                                            stats_counts, num_partials, xf_stat, xf_act, nullptr, nullptr, 0, acc);                  \
+                                            stats_counts, num_partials, xf_stat, xf_act, nullptr, nullptr, 0, acc, xa);              \
     else if (big)                                                                                                               \
         launch_stream_cfg<0, -1, 128, 8, SV>(x, nullptr, M, b, nullptr, y, N, K, Nout, 1, K, Nout, 1, s, n_valid_dev, stats_partial, \
-                                             stats_counts, num_partials, xf_stat, xf_act, nullptr, nullptr, 0, acc);                 \
+                                             stats_counts, num_partials, xf_stat, xf_act, nullptr, nullptr, 0, acc, xa);             \
     else if (small)                                                                                                             \
         launch_stream_cfg<0, -1, 32, 4, SV>(x, nullptr, M, b, nullptr, y, N, K, Nout, 1, K, Nout, 3, s, n_valid_dev, stats_partial, \
-                                            stats_counts, num_partials, xf_stat, xf_act, nullptr, nullptr, 0, acc);                  \
+                                            stats_counts, num_partials, xf_stat, xf_act, nullptr, nullptr, 0, acc, xa);              \
     else                                                                                                                        \
         launch_stream_cfg<0, -1, 64, 4, SV>(x, nullptr, M, b, nullptr, y, N, K, Nout, 1, K, Nout, 2, s, n_valid_dev, stats_partial, \
-                                            stats_counts, num_partials, xf_stat, xf_act, nullptr, nullptr, 0, acc)
+                                            stats_counts, num_partials, xf_stat, xf_act, nullptr, nullptr, 0, acc, xa)
     if (stats_partial) {
         PHC_XF_LAUNCH(3);
     } else {

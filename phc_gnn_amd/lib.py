@@ -85,6 +85,8 @@ SIGNATURES = {
                                       C.c_float, _I, _I, _P, _P]),
     "phc_bn_finalize_from_partials": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _L, _I, C.c_float, C.c_float, _P, _P]),
     "phc_gemm_prebuilt_xf": (_I, [_P, _P, _I, _P, _P, _P, _L, _I, _I, _P, _P, _P, C.POINTER(_I), _P]),
+    "phc_gemm_prebuilt_xf_acc": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, C.c_float, C.c_float, _P, _I, _P, _P, _P, _L, _I, _I, _P, _P, _P,
+                                      C.POINTER(_I), _P]),
     "phc_gemm_prebuilt_bwsums": (_I, [_P, _P, _L, _I, _I, _P, _P, _P, _I, _P, _P, C.POINTER(_I), _P]),
     "phc_bn_bwd_from_partials": (_I, [_P, _P, _P, _P, _I, _P, _L, _I, _I, _P, _P, _P, _S, _P]),
     "phc_phm_param_grads_ws_bytes": (_S, [C.POINTER(GradJob), _I]),

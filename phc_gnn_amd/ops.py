@@ -661,8 +661,8 @@ class BNStatsRequest:
     """Ask a PHM linear layer for the batch-norm statistics of its output (training mode): when the layer runs on a
     prebuilt operand matrix, its GEMM emits per-column (sum, M2) partials from registers and the normalisation that
     follows (``batch_norm_act`` on the very tensor this layer returned) skips its own pass over the data.
-    ``consumer``: "apply" (``batch_norm_act``: may take the statistics through an accumulator, ``counts`` stays None)
-    or "linear" (``bn_act_linear``: partial rows)."""
+    ``consumer``: "apply" (``batch_norm_act`` or ``bn_act_linear`` follows: the statistics may travel through an accumulator,
+    ``counts`` stays None) or "linear" (partial rows in any case)."""
 
     def __init__(self, n_valid: Optional[torch.Tensor] = None, consumer: str = "linear"):
         self.n_valid = n_valid
@@ -1738,20 +1738,30 @@ class _BNActLinearFn(torch.autograd.Function):
         weights = list(affine[:n_comp]) if affine else None
         biases = list(affine[n_comp:]) if affine else None
         save_stat = torch.empty(6 * h, dtype=torch.float32, device=dev)
-        L.check(lib.phc_bn_finalize_from_partials(
-            L.ptr(pre.partial), L.ptr(pre.counts), pre.num, _ptr_array(weights) if weights else None,
-            _ptr_array(biases) if biases else None, _ptr_array(running_mean) if running_mean else None,
-            _ptr_array(running_var) if running_var else None, _ptr_array(nbt) if nbt else None, n_comp, L.ptr(n_valid), N, h,
-            float(momentum), float(eps), L.ptr(save_stat), L.stream_ptr(dev)), "phc_bn_finalize_from_partials")
+        from_acc = pre.counts is None                   # the statistics are accumulator totals: the GEMM below derives scale / shift
+        if not from_acc:
+            L.check(lib.phc_bn_finalize_from_partials(
+                L.ptr(pre.partial), L.ptr(pre.counts), pre.num, _ptr_array(weights) if weights else None,
+                _ptr_array(biases) if biases else None, _ptr_array(running_mean) if running_mean else None,
+                _ptr_array(running_var) if running_var else None, _ptr_array(nbt) if nbt else None, n_comp, L.ptr(n_valid), N, h,
+                float(momentum), float(eps), L.ptr(save_stat), L.stream_ptr(dev)), "phc_bn_finalize_from_partials")
         y = torch.empty((N, n2 * kout2), dtype=torch.float32, device=dev)
         num = _C.c_int(0)
         sp = sc = None
         want_num = True
         if out_stats is not None:
             sp, sc, want_num = out_stats.allocate(dev, n2 * kout2, lib.phc_gemm_stats_max_partials())
-        L.check(lib.phc_gemm_prebuilt_xf(L.ptr(x), L.ptr(save_stat), act, L.ptr(n_valid), L.ptr(H2), L.ptr(b2), N, h, n2 * kout2,
-                                         L.ptr(y), L.ptr(sp), L.ptr(sc), _C.byref(num) if want_num else None, L.stream_ptr(dev)),
-                "phc_gemm_prebuilt_xf")
+        if from_acc:
+            L.check(lib.phc_gemm_prebuilt_xf_acc(
+                L.ptr(x), L.ptr(pre.partial), _ptr_array(weights) if weights else None, _ptr_array(biases) if biases else None,
+                _ptr_array(running_mean) if running_mean else None, _ptr_array(running_var) if running_var else None,
+                _ptr_array(nbt) if nbt else None, n_comp, float(momentum), float(eps), L.ptr(save_stat), act, L.ptr(n_valid),
+                L.ptr(H2), L.ptr(b2), N, h, n2 * kout2, L.ptr(y), L.ptr(sp), L.ptr(sc), _C.byref(num) if want_num else None,
+                L.stream_ptr(dev)), "phc_gemm_prebuilt_xf_acc")
+        else:
+            L.check(lib.phc_gemm_prebuilt_xf(L.ptr(x), L.ptr(save_stat), act, L.ptr(n_valid), L.ptr(H2), L.ptr(b2), N, h, n2 * kout2,
+                                             L.ptr(y), L.ptr(sp), L.ptr(sc), _C.byref(num) if want_num else None, L.stream_ptr(dev)),
+                    "phc_gemm_prebuilt_xf")
         if out_stats is not None:
             out_stats.num = num.value
         if L.PROF_ON:
@@ -1842,9 +1852,9 @@ def bn_act_linear(x: torch.Tensor, weights, biases, running_mean, running_var, n
     x must be the tensor a statistics-emitting GEMM just returned (``x._phc_bn``), inside ``prebuilt_H`` with an
     entry for (phm_rule, W)."""
     pre = getattr(x, "_phc_bn", None)
-    if pre is None or pre.partial is None or pre.counts is None or pre.n_valid is not n_valid or x.dim() != 2 \
+    if pre is None or pre.partial is None or pre.n_valid is not n_valid or x.dim() != 2 \
             or not x.is_contiguous() or pre.partial.shape[1] != 2 * x.shape[1] or not _PREBUILT.table or x.data_ptr() % 16:
-        return None                              # (counts is None: the statistics went to an accumulator, batch_norm_act reads it)
+        return None
     ent = _prebuilt_for(phm_rule, W)
     if ent is None or W.shape[0] * W.shape[1] != x.shape[1] or (bias is not None and not bias.is_contiguous()):
         return None

@@ -1,5 +1,3 @@
-# A/B of the statistics accumulators (PHC_STAT_ACC=0: partial rows + merge launches)
-for wl in molhiv_b512; do
-for cfg in "PHC_STAT_ACC=1" "PHC_STAT_ACC=0" "PHC_STAT_ACC=1" "PHC_STAT_ACC=0"; do
-  env $cfg python bench.py --cpu-steps 0 --workload $wl 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$wl $cfg', d['ms_per_step'], d['timing']['ms_per_step_min'], d['timing']['ms_per_step_max'])"
-done; done
+for cfg in "PHC_STAT_ACC=1" "PHC_STAT_ACC=0" "PHC_STAT_ACC=1" "PHC_STAT_ACC=0" "PHC_STAT_ACC=1" "PHC_STAT_ACC=0"; do
+  env $cfg python bench.py --cpu-steps 0 2>&1 | tail -1 | python -c "import sys,json; d=json.loads(sys.stdin.read()); print('$cfg', d['ms_per_step'], d['timing']['ms_per_step_min'], d['timing']['ms_per_step_max'])"
+done
