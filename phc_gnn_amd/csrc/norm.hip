@@ -717,6 +717,91 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_kernel(const float *_
 }
 
 
+// ---- pass 3 (backward) with the column sums in an ACCUMULATOR: a workgroup owns 32 COLUMNS x a row range (the layout of
+// bn_apply_acc_kernel), reads only those columns' totals (4 KB instead of every column's 16 KB) — and issues the loads of its first
+// rows BEFORE that prologue, whose L2 miss (the totals were added at the memory side a moment ago) then costs nothing extra.
+constexpr int BNB_PRE = 4;                                   // row rounds whose (dy, x) loads are in flight during the prologue
+template <int ACT>
+__global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_acc_kernel(const float *__restrict__ dy, const float *__restrict__ x,
+                                                                    const float *__restrict__ stat, const int *__restrict__ n_valid,
+                                                                    long long N, int h, const unsigned long long *__restrict__ acc,
+                                                                    long long rows_per_group, float *__restrict__ dx,
+                                                                    float *__restrict__ dwb, int training, BnDrop drop = BnDrop{}) {
+    __shared__ double r_d[BNM_LANES][BNM_COLS];
+    __shared__ float s_c[6][BNM_COLS];                       // mean, invstd, w, b, mean g, mean g x_hat
+    static_assert(BNM_LANES == 2 * STAT_ACC_REP, "one (quantity, replica) pair per partial lane");
+    const int tid = threadIdx.x;
+    const int ci = tid & (BNM_COLS - 1), pl = tid / BNM_COLS;
+    const int c = blockIdx.x * BNM_COLS + ci;
+    const long long count = n_valid ? min((long long)*n_valid, N) : N;
+    const bool dropping = drop.p > 0.f;
+    const unsigned long long seed = dropping ? drop.state[0] : 0ull, step = dropping ? drop.state[1] : 0ull;
+    const int c4 = tid & 7, rl = tid >> 3;
+    const int col = blockIdx.x * BNM_COLS + c4 * 4;
+    const long long r0 = (long long)blockIdx.y * rows_per_group, r1 = min(N, r0 + rows_per_group);
+    // first rounds of this thread's rows go in flight (clamped addresses; rows past the range are never stored)
+    float4 gpre[BNB_PRE], xpre[BNB_PRE];
+#pragma unroll
+    for (int u = 0; u < BNB_PRE; ++u) {
+        const long long r = min(r0 + rl + (long long)u * (BN_THREADS / 8), N - 1);
+        gpre[u] = *reinterpret_cast<const float4 *>(dy + (size_t)r * h + col);
+        xpre[u] = *reinterpret_cast<const float4 *>(x + (size_t)r * h + col);
+    }
+    r_d[pl][ci] = stat_acc_part(acc, h, pl & (STAT_ACC_REP - 1), pl / STAT_ACC_REP, c);
+    __syncthreads();
+    if (pl == 0) {
+        double a = 0.0, b = 0.0;
+#pragma unroll
+        for (int rp = 0; rp < STAT_ACC_REP; ++rp) {
+            a += r_d[rp][ci];
+            b += r_d[STAT_ACC_REP + rp][ci];
+        }
+        const float af = (float)a, bf = (float)b;
+        const float cnt = (float)max(count, 1LL);
+        s_c[0][ci] = stat[c];
+        s_c[1][ci] = stat[h + c];
+        s_c[2][ci] = stat[4 * h + c];
+        s_c[3][ci] = stat[5 * h + c];
+        s_c[4][ci] = training ? af / cnt : 0.f;
+        s_c[5][ci] = training ? bf / cnt : 0.f;
+        if (dwb && blockIdx.y == 0) {
+            dwb[c] = bf;                                     // dweight = sum g * x_hat
+            dwb[h + c] = af;                                 // dbias   = sum g
+        }
+    }
+    __syncthreads();
+    float mean[4], inv[4], w[4], bb[4], mg[4], mgx[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        mean[q] = s_c[0][c4 * 4 + q]; inv[q] = s_c[1][c4 * 4 + q]; w[q] = s_c[2][c4 * 4 + q];
+        bb[q] = s_c[3][c4 * 4 + q]; mg[q] = s_c[4][c4 * 4 + q]; mgx[q] = s_c[5][c4 * 4 + q];
+    }
+    auto one = [&](float xv, float gv, int q) -> float {
+        const float xh = (xv - mean[q]) * inv[q];
+        float g = gv;
+        if (ACT != PHC_ACT_IDENTITY) g *= act_grad<ACT>(fmaf(xh, w[q], bb[q]));
+        return w[q] * inv[q] * (g - mg[q] - xh * mgx[q]);
+    };
+    auto row = [&](long long r, float4 gv, float4 xv) {
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (r < count) {
+            if (dropping) {
+                const float4 f = drop_factors(drop, seed, step, r, col, h);
+                gv.x *= f.x; gv.y *= f.y; gv.z *= f.z; gv.w *= f.w;
+            }
+            o.x = one(xv.x, gv.x, 0); o.y = one(xv.y, gv.y, 1); o.z = one(xv.z, gv.z, 2); o.w = one(xv.w, gv.w, 3);
+        }
+        *reinterpret_cast<float4 *>(dx + (size_t)r * h + col) = o;
+    };
+#pragma unroll
+    for (int u = 0; u < BNB_PRE; ++u) {
+        const long long r = r0 + rl + (long long)u * (BN_THREADS / 8);
+        if (r < r1) row(r, gpre[u], xpre[u]);
+    }
+    for (long long r = r0 + rl + (long long)BNB_PRE * (BN_THREADS / 8); r < r1; r += BN_THREADS / 8)
+        row(r, *reinterpret_cast<const float4 *>(dy + (size_t)r * h + col), *reinterpret_cast<const float4 *>(x + (size_t)r * h + col));
+}
+
 // ---- row-sharded batch-norm (one logical batch split by rows over several ranks) ----------
 // Merge this rank's per-block (sum, M2) pairs into ONE pair for all its rows (Chan's formula, fixed order): the 2h floats
 // that travel in the all-gather.  Same 8-columns x 32-partial-lanes layout as bn_finalize_kernel.
@@ -985,6 +1070,24 @@ int phc_bn_fwd_from_partials(const float *x, const float *stats_partial, const f
     return check_launch("bn_apply");
 }
 
+static int launch_bwd_apply_acc(const float *dy, const float *x, const float *save_stat, const int32_t *n_valid_dev, int64_t N, int h,
+                                int act, const unsigned long long *acc, float *dx, float *dwb_flat, int training, const BnDrop &drop,
+                                hipStream_t s) {
+    long long groups = (N + 127) / 128;
+    const long long cap = (8LL * 256) / (h / BNM_COLS);
+    if (groups > cap) groups = cap;
+    if (groups < 1) groups = 1;
+    const long long rows_per_group = (N + groups - 1) / groups;
+    groups = (N + rows_per_group - 1) / rows_per_group;
+    ProfScope prof(K_BN_BWD_APPLY, s);
+#define PHC_BN_BAA(ACTC)                                                                                                     \
+    PHC_LAUNCH((bn_bwd_apply_acc_kernel<ACTC>), dim3(h / BNM_COLS, (unsigned)groups), dim3(BN_THREADS), 0, s, dy, x, save_stat,    \
+               n_valid_dev, (long long)N, h, acc, rows_per_group, dx, dwb_flat, training, drop)
+    PHC_BN_ACT_SWITCH(act, PHC_BN_BAA)
+#undef PHC_BN_BAA
+    return check_launch("bn_bwd_apply_acc");
+}
+
 int phc_bn_bwd(const float *dy, const float *x, const float *save_stat, const int32_t *n_valid_dev, int64_t N, int h, int training,
                int act, float *dx, float *dwb_flat, void *ws, size_t ws_bytes, float drop_p, int drop_same_k, int drop_site,
                const uint64_t *rng_state, void *stream) {
@@ -1036,6 +1139,7 @@ int phc_bn_bwd(const float *dy, const float *x, const float *save_stat, const in
         if (rc) return rc;
     }
     if (!dx) return PHC_OK;
+    if (acc_mode && vec4 && h % BNM_COLS == 0 && !getenv("PHC_BN_BWD_APPLY_FLAT")) return launch_bwd_apply_acc(dy, x, save_stat, n_valid_dev, N, h, act, acc, dx, dwb_flat, training, drop, s);
     const size_t lds = sizeof(float) * 6 * (size_t)h;
     ProfScope prof(K_BN_BWD_APPLY, s);
 #define PHC_BN_BA(ACTC)                                                                                                      \
@@ -1076,6 +1180,8 @@ int phc_bn_bwd_from_partials(const float *dy, const float *x, const float *save_
         if (rc) return rc;
     }
     if (!dx) return PHC_OK;
+    if (acc_mode && vec4 && h % BNM_COLS == 0 && !getenv("PHC_BN_BWD_APPLY_FLAT"))
+        return launch_bwd_apply_acc(dy, x, save_stat, n_valid_dev, N, h, act, acc, dx, dwb_flat, 1, BnDrop{0.f, 0, h, 0, nullptr}, s);
     const size_t lds = sizeof(float) * 6 * (size_t)h;
     ProfScope prof(K_BN_BWD_APPLY, s);
 #define PHC_BN_BAP(ACTC)                                                                                                     \
