@@ -438,6 +438,19 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_acc_kernel(const float *_
     const long long count = n_valid ? min((long long)*n_valid, N) : N;
     const bool dropping = drop.p > 0.f;
     const unsigned long long seed = dropping ? drop.state[0] : 0ull, step = dropping ? drop.state[1] : 0ull;
+    // the first rounds of this thread's rows go in flight BEFORE the totals prologue (clamped addresses): its L2 miss — the totals
+    // were added at the memory side a moment ago — then overlaps with them
+    const int c4 = tid & 7, rl = tid >> 3;
+    const int col = blockIdx.x * BNM_COLS + c4 * 4;
+    const long long r0 = (long long)blockIdx.y * rows_per_group, r1 = min(N, r0 + rows_per_group);
+    constexpr int PRE = 4;
+    float4 xpre[PRE], rpre[PRE];
+#pragma unroll
+    for (int u = 0; u < PRE; ++u) {
+        const long long r = min(r0 + rl + (long long)u * (BN_THREADS / 8), N - 1);
+        xpre[u] = *reinterpret_cast<const float4 *>(x + (size_t)r * h + col);
+        rpre[u] = residual ? *reinterpret_cast<const float4 *>(residual + (size_t)r * h + col) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
     r_d[pl][ci] = stat_acc_part(acc, h, pl & (STAT_ACC_REP - 1), pl / STAT_ACC_REP, c);
     const int comp = c / p.k, kk = c - comp * p.k;
     float w = 1.f, bq = 0.f, rm_old = 0.f, rv_old = 1.f;
@@ -485,27 +498,29 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_acc_kernel(const float *_
         for (int q = 0; q < p.n_comp; ++q)
             if (q == tid) *p.num_batches_tracked[q] += 1;
     __syncthreads();
-    const int c4 = tid & 7, rl = tid >> 3;
-    const int col = blockIdx.x * BNM_COLS + c4 * 4;
     const float4 sc4 = *reinterpret_cast<const float4 *>(s_scale + c4 * 4), sh4 = *reinterpret_cast<const float4 *>(s_shift + c4 * 4);
-    const long long r0 = (long long)blockIdx.y * rows_per_group, r1 = min(N, r0 + rows_per_group);
-    for (long long r = r0 + rl; r < r1; r += BN_THREADS / 8) {
+    auto row = [&](long long r, const float4 v, const float4 rr) {
         float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
-        const size_t e = (size_t)r * h + col;
         if (r < count) {
-            const float4 v = *reinterpret_cast<const float4 *>(x + e);
             o.x = bn_act<ACT>(fmaf(v.x, sc4.x, sh4.x)); o.y = bn_act<ACT>(fmaf(v.y, sc4.y, sh4.y));
             o.z = bn_act<ACT>(fmaf(v.z, sc4.z, sh4.z)); o.w = bn_act<ACT>(fmaf(v.w, sc4.w, sh4.w));
             if (dropping) {
                 const float4 f = drop_factors(drop, seed, step, r, col, h);
                 o.x *= f.x; o.y *= f.y; o.z *= f.z; o.w *= f.w;
             }
-            if (residual) {
-                const float4 rr = *reinterpret_cast<const float4 *>(residual + e);
-                o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;
-            }
+            o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w;          // (zeros without a residual)
         }
-        *reinterpret_cast<float4 *>(out + e) = o;
+        *reinterpret_cast<float4 *>(out + (size_t)r * h + col) = o;
+    };
+#pragma unroll
+    for (int u = 0; u < PRE; ++u) {
+        const long long r = r0 + rl + (long long)u * (BN_THREADS / 8);
+        if (r < r1) row(r, xpre[u], rpre[u]);
+    }
+    for (long long r = r0 + rl + (long long)PRE * (BN_THREADS / 8); r < r1; r += BN_THREADS / 8) {
+        const size_t e = (size_t)r * h + col;
+        row(r, *reinterpret_cast<const float4 *>(x + e),
+            residual ? *reinterpret_cast<const float4 *>(residual + e) : make_float4(0.f, 0.f, 0.f, 0.f));
     }
 }
 
