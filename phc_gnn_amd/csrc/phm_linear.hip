@@ -410,44 +410,6 @@ __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
     long long xf_count = M;
     if constexpr (XF) {
         if (n_valid) xf_count = min((long long)*n_valid, M);
-        if (xa.acc) {
-            // statistics of the K operand columns from the accumulator totals (double), then scale / shift into LDS; it is read
-            // after the operand panel's barrier.  Workgroup (0, 0) also leaves save_stat and the running statistics behind.
-            const bool owner = pbx == 0 && pby == 0;
-            for (int c = tid; c < K; c += THREADS) {
-                const double S = stat_acc_total(xa.acc, K, 0, c), Q = stat_acc_total(xa.acc, K, 1, c);
-                const double cntd = (double)max(xf_count, 1LL);
-                const double meand = S / cntd, vard = fmax(Q / cntd - meand * meand, 0.0);
-                const int comp = c / xa.p.k, kk = c - comp * xa.p.k;
-                float w = 1.f, bq = 0.f;
-                for (int q = 0; q < xa.p.n_comp; ++q)
-                    if (q == comp) {
-                        if (xa.p.has_weight) w = xa.p.weight[q][kk];
-                        if (xa.p.has_bias) bq = xa.p.bias[q][kk];
-                    }
-                const float mean = (float)meand, var = (float)vard;
-                const float invstd = 1.f / sqrtf(var + xa.eps);
-                xf_lds[c] = invstd * w;
-                xf_lds[K + c] = bq - mean * invstd * w;
-                if (owner) {
-                    float *st = xa.stat_out;
-                    st[c] = mean; st[K + c] = invstd; st[2 * K + c] = invstd * w; st[3 * K + c] = bq - mean * invstd * w;
-                    st[4 * K + c] = w; st[5 * K + c] = bq;
-                    if (xa.p.has_running) {
-                        const float unbiased = xf_count > 1 ? (float)(vard * cntd / (cntd - 1.0)) : var;
-                        for (int q = 0; q < xa.p.n_comp; ++q)
-                            if (q == comp) {
-                                float *rm = xa.p.running_mean[q] + kk, *rv = xa.p.running_var[q] + kk;
-                                *rm = (1.f - xa.momentum) * *rm + xa.momentum * mean;
-                                *rv = (1.f - xa.momentum) * *rv + xa.momentum * unbiased;
-                            }
-                    }
-                }
-            }
-            if (owner && xa.p.has_nbt && tid < xa.p.n_comp)
-                for (int q = 0; q < xa.p.n_comp; ++q)
-                    if (q == tid) *xa.p.num_batches_tracked[q] += 1;
-        }
     }
     // BW: per-column norm constants of the 4 columns this lane stores (col = j0 + ct*32 + (lane & 7)*4) and its sums
     float4 bw_mean[CT], bw_inv[CT], bw_w[CT], bw_b[CT];
@@ -467,6 +429,22 @@ __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
         }
     }
     if (slab < num_slabs) load_half(slab, 0);
+    // XF from an accumulator, part 1: the totals and the affine parameters of column `tid` go in flight right behind the x slab
+    // (K <= 256 <= THREADS: one column per thread); they are consumed after the operand panel has been issued too
+    double xa_S = 0.0, xa_Q = 0.0;
+    float xa_w = 1.f, xa_b = 0.f;
+    if constexpr (XF) {
+        if (xa.acc && tid < K) {
+            xa_S = stat_acc_total(xa.acc, K, 0, tid);
+            xa_Q = stat_acc_total(xa.acc, K, 1, tid);
+            const int comp = tid / xa.p.k, kk = tid - comp * xa.p.k;
+            for (int q = 0; q < xa.p.n_comp; ++q)
+                if (q == comp) {
+                    if (xa.p.has_weight) xa_w = xa.p.weight[q][kk];
+                    if (xa.p.has_bias) xa_b = xa.p.bias[q][kk];
+                }
+        }
+    }
 
     // bias columns this lane will store (fixed across slabs): col = j0 + ct*32 + (lane & 7)*4
     float4 bias4[CT];
@@ -533,6 +511,41 @@ __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
         build_h_chunk<TRANS, (NPHM < 0 ? 0 : NPHM), BN, THREADS>(As, W, hs, n, kin, kout, 0, K, round_up(K, 8), j0, Nout, tid);
     }
 #endif
+    if constexpr (XF) {
+        if (xa.acc) {
+            // part 2: scale / shift of the K operand columns into LDS (read after the barrier below); workgroup (0, 0) also leaves
+            // save_stat and the running statistics behind
+            const bool owner = pbx == 0 && pby == 0;
+            const int c = tid;
+            if (c < K) {
+                const double cntd = (double)max(xf_count, 1LL);
+                const double meand = xa_S / cntd, vard = fmax(xa_Q / cntd - meand * meand, 0.0);
+                const float w = xa_w, bq = xa_b;
+                const float mean = (float)meand, var = (float)vard;
+                const float invstd = 1.f / sqrtf(var + xa.eps);
+                xf_lds[c] = invstd * w;
+                xf_lds[K + c] = bq - mean * invstd * w;
+                if (owner) {
+                    float *st = xa.stat_out;
+                    st[c] = mean; st[K + c] = invstd; st[2 * K + c] = invstd * w; st[3 * K + c] = bq - mean * invstd * w;
+                    st[4 * K + c] = w; st[5 * K + c] = bq;
+                    if (xa.p.has_running) {
+                        const float unbiased = xf_count > 1 ? (float)(vard * cntd / (cntd - 1.0)) : var;
+                        const int comp = c / xa.p.k, kk = c - comp * xa.p.k;
+                        for (int q = 0; q < xa.p.n_comp; ++q)
+                            if (q == comp) {
+                                float *rm = xa.p.running_mean[q] + kk, *rv = xa.p.running_var[q] + kk;
+                                *rm = (1.f - xa.momentum) * *rm + xa.momentum * mean;
+                                *rv = (1.f - xa.momentum) * *rv + xa.momentum * unbiased;
+                            }
+                    }
+                }
+            }
+            if (owner && xa.p.has_nbt && tid < xa.p.n_comp)
+                for (int q = 0; q < xa.p.n_comp; ++q)
+                    if (q == tid) *xa.p.num_batches_tracked[q] += 1;
+        }
+    }
     __syncthreads();
     ST_STAMP(1);
 
