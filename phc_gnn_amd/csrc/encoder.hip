@@ -1741,6 +1741,9 @@ int phc_step_tail(const phc_phm_grad_job *jobs, int num_jobs, const phc_table_gr
         static const int knob = getenv("PHC_TAIL_DH_FIRST") ? atoi(getenv("PHC_TAIL_DH_FIRST")) : -1;
         t.dh_first = knob > 0 ? 1 : 0;                       // measured within noise of the family order: off
     }
+    if (getenv("PHC_DEBUG_PLANS"))
+        fprintf(stderr, "[phc tail] atoms: %lld nodes direct=%d wgs=%u | bonds: %d jobs direct=%d wgs=%u | dH wgs=%u (own launch %u)\n",
+                (long long)N_atoms, t.atom_direct, t.nb_atom, num_tjobs, t.counts_b ? 1 : 0, t.nb_bond, gl.nb_partial, gl.nb_direct);
     const unsigned nb1 = t.nb_atom + t.nb_bond + gl.nb_partial, nb2 = t.nr_phm + t.nr_bond + t.nr_atom;
     rc = launch_grad_direct("step_tail(direct)", gl, s);     // the 128-multiple layers: register-resident tiles, their own launch
     if (rc) return rc;

@@ -978,3 +978,49 @@ def test_bn_act_linear_without_materialising_the_normalised_activation(ops, n, k
         if name == "y2":
             u, v = u[:nv], v[:nv]          # padding rows: both are b2-only rows, compare the valid part explicitly
         assert_close(u, v, 3e-5, name)
+
+
+@pytest.mark.parametrize("N,k,vocab_b,n_layers", [(777, 16, [12, 9, 7], 5), (1203, 32, [5, 6, 2], 2), (64, 16, [3], 1)])
+def test_step_tail_register_resident_table_gradients(ops, N, k, vocab_b, n_layers):
+    """phc_step_tail with the encoder tables in their register-resident forms (atom_direct_body / bond_direct_body): widths of 64
+    and 128 columns, 28 bond-table rows (32-column count operand) and 13 (16 columns), five layers (a full group of four and a
+    short one), 180 atom-table rows (two M groups), node counts that are no multiple of anything — against the immediate
+    per-layer gradients (LDS tiles)."""
+    from phc_gnn_amd import synth
+    g = torch.Generator().manual_seed(N)
+    n = 4
+    h = n * k
+    E = 3 * N
+    ei = torch.from_numpy(synth.random_edges(N - N // 7, E, seed=N)).to(DEV)          # the last nodes receive nothing
+    bond = torch.stack([torch.randint(0, v, (E,), generator=g) for v in vocab_b], dim=1).to(DEV)
+    vocab_a = [40, 50, 60, 30]
+    idx_a = torch.stack([torch.randint(0, v, (N,), generator=g) for v in vocab_a], dim=1).to(DEV)
+    tabs_a = [[(torch.randn(v, k, generator=g) * 0.5).to(DEV).requires_grad_() for v in vocab_a] for _ in range(n)]
+    layers = []
+    for li in range(n_layers):
+        tabs = [[(torch.randn(v, k, generator=g) * 0.5).to(DEV).requires_grad_() for v in vocab_b] for _ in range(n)]
+        layers.append((tabs, torch.randn(N, h, generator=g).to(DEV)))
+    A = torch.randn(n, n, n, generator=g).to(DEV).requires_grad_()
+    W = (torch.randn(n, k, k, generator=g) * 0.2).to(DEV).requires_grad_()
+    dy_lin = torch.randn(N, h, generator=g).to(DEV)
+    owners = [torch.nn.Module() for _ in range(n_layers + 1)]
+
+    def run(deferred):
+        every = [t for comp in tabs_a for t in comp] + [t for tabs, _ in layers for comp in tabs for t in comp] + [A, W]
+        for t in every:
+            t.grad = None
+        ctx = ops.deferred_param_grads() if deferred else __import__("contextlib").nullcontext()
+        with ctx:
+            x0 = ops.encode(idx_a, ops.tableset_for(owners[-1], tabs_a), tabs_a)
+            total = (ops.phm_linear(x0, A, W, None) * dy_lin).sum()                # a PHM job: the tail has something to batch
+            x = x0
+            for (tabs, dy), owner in zip(layers, owners):
+                out = ops.aggregate_sum_encoded(x, ei, bond, ops.tableset_for(owner, tabs), tabs, "identity", True)
+                total = total + (out * dy).sum()
+            total.backward()
+        return [t.grad.clone() for t in every]
+
+    a, b = run(True), run(False)
+    assert len(a) == len(b) and len(a) > 2
+    for i, (x1, x2) in enumerate(zip(a, b)):
+        assert_close(x1, x2, 5e-6, f"gradient {i}")
