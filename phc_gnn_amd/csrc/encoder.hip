@@ -934,6 +934,111 @@ __device__ __forceinline__ void bond_direct_body(const TgBatch &jobs, int job0, 
     }
 }
 
+// ---- several encoders over ONE index tensor (phc_encode_bwd_batched), <= 32 table rows, register-resident ----------------------
+// dT_j = O^T . dout_j for every encoder j of a group of TD_JG: O[i][t] = 1 iff t = off_f + idx[i, f] for the feature f owning row t
+// (generated per item from ONE 4-byte index load, as in atom_direct_body); the group shares it (bond_direct_body's B side).
+__device__ __forceinline__ void enc_direct_body(const TgBatch &jobs, int job0, int njobs, const long long *__restrict__ idx, const EncMeta &m,
+                                                long long n_items, long long items_per_split, int h, int tj, long long split,
+                                                float *__restrict__ smem) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, hh = lane >> 5;
+    const int j0 = tj * 64, F = m.F, R = m.R;
+    const long long t_begin = split * items_per_split, t_end = min(n_items, t_begin + items_per_split);
+    const long long rq = items_per_split >> 2;
+    const long long w_begin = min(t_begin + wave * rq, t_end), w_end = min(w_begin + rq, t_end);
+    int f = 0;
+    for (int u = 1; u < F; ++u) f += r >= m.off[u];
+    int base = 0;
+    for (int u = 0; u < F; ++u) base = u == f ? m.off[u] : base;
+    const unsigned foff = (unsigned)f * 8u;
+    const int val = r < R ? r - base : -1;
+    const float *dptr[TD_JG];
+#pragma unroll
+    for (int u = 0; u < TD_JG; ++u) dptr[u] = jobs.j[min(job0 + u, job0 + njobs - 1)].dout;
+    f32x16 acc[TD_JG][2];
+#pragma unroll
+    for (int u = 0; u < TD_JG; ++u)
+#pragma unroll
+        for (int p2 = 0; p2 < 2; ++p2)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[u][p2][i] = 0.f;
+    const long long last = max(t_end - 1, 0LL);
+    const unsigned goff = (unsigned)(j0 + 2 * r) * 4u;
+    int ia[TD_PFB], ib[TD_PFB];
+    f32x2 ga[TD_PFB][TD_JG], gb[TD_PFB][TD_JG];
+    auto load = [&](int (&I)[TD_PFB], f32x2 (&G)[TD_PFB][TD_JG], long long row0) {
+#pragma unroll
+        for (int t = 0; t < TD_PFB; ++t) {
+            const long long g = min(row0 + 2 * t + hh, last);
+            I[t] = *reinterpret_cast<const int *>(reinterpret_cast<const char *>(idx + (size_t)g * F) + foff);
+#pragma unroll
+            for (int u = 0; u < TD_JG; ++u)
+                G[t][u] = *reinterpret_cast<const f32x2 *>(reinterpret_cast<const char *>(dptr[u] + (size_t)g * h) + goff);
+        }
+    };
+    auto pairs = [&](const int (&I)[TD_PFB], const f32x2 (&G)[TD_PFB][TD_JG], long long row0) {
+#pragma unroll
+        for (int t = 0; t < TD_PFB; ++t) {
+            const float a = (I[t] == val && row0 + 2 * t + hh < w_end) ? 1.f : 0.f;
+#pragma unroll
+            for (int u = 0; u < TD_JG; ++u) {
+                acc[u][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, G[t][u][0], acc[u][0], 0, 0, 0);
+                acc[u][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, G[t][u][1], acc[u][1], 0, 0, 0);
+            }
+        }
+    };
+    if (w_begin < w_end) {
+        load(ia, ga, w_begin);
+        for (long long row = w_begin; row < w_end; row += 4 * TD_PFB) {
+            load(ib, gb, row + 2 * TD_PFB);
+            __builtin_amdgcn_sched_barrier(0);
+            pairs(ia, ga, row);
+            __builtin_amdgcn_sched_barrier(0);
+            load(ia, ga, row + 4 * TD_PFB);
+            __builtin_amdgcn_sched_barrier(0);
+            pairs(ib, gb, row + 2 * TD_PFB);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+    }
+    f32x2 *slots = reinterpret_cast<f32x2 *>(smem);
+#pragma unroll
+    for (int u = 0; u < TD_JG; ++u) {
+        if (u) __syncthreads();
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+            const f32x2 v = {acc[u][0][reg], acc[u][1][reg]};
+            slots[(wave * 16 + reg) * 64 + lane] = v;
+        }
+        __syncthreads();
+        f32x2 part[4][4];
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) part[w2][e] = slots[(w2 * 16 + 4 * wave + e) * 64 + lane];
+        if (u < njobs) {                                 // uniform
+            float *slab = jobs.j[job0 + u].slabs + (size_t)split * R * h;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const f32x2 v = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
+                const int row = e + 8 * wave + 4 * hh;
+                if (row < R) *reinterpret_cast<f32x2 *>(slab + (size_t)row * h + j0 + 2 * r) = v;
+            }
+        }
+    }
+}
+
+__global__ __launch_bounds__(ENC_THREADS) void enc_direct_batched_kernel(TgBatch b, int num_jobs, const long long *__restrict__ idx, EncMeta m,
+                                                                        long long n_items, long long items_per_split, int h,
+                                                                        int tiles_j, int num_slabs) {
+    __shared__ __attribute__((aligned(16))) float smem[4 * 16 * 64 * 2];           // exchange slots, 32 KB
+    const unsigned per_group = (unsigned)tiles_j * (unsigned)num_slabs;
+    const int jg = blockIdx.x / per_group;
+    const unsigned local = blockIdx.x - jg * per_group;
+    const int job0 = jg * TD_JG;
+    enc_direct_body(b, job0, min(TD_JG, num_jobs - job0), idx, m, n_items, items_per_split, h, local % tiles_j, local / tiles_j, smem);
+}
+
 // ---- the step's tail in one pass ----------------------------------------------------------------------------
 // All parameter gradients of a model are due only when the optimizer runs.  phc_step_tail launches their first
 // stages SIDE BY SIDE: workgroups [0, nb_atom) build atom-table slabs, [nb_atom, nb_atom + nb_bond) the bond-table
@@ -1248,8 +1353,20 @@ int phc_encode_bwd(const float *dout, const int64_t *idx_i64, int64_t N, int F, 
                                 nullptr, nullptr, nullptr, dtables_flat, ws, ws_bytes, (hipStream_t)stream, "phc_encode_bwd");
 }
 
+static bool enc_direct_batched_ok(const EncMeta &m, int64_t N, int h) { return m.R <= 32 && tg_direct_shape_ok(N, h); }
+
 size_t phc_encode_bwd_batched_ws_bytes(int64_t N, int F, const int32_t *vocab, int n, int k, int num_jobs) {
-    return phc_table_grads_ws_bytes(N, F, vocab, n, k, num_jobs);          // same plan, items = encoded rows
+    size_t need = phc_table_grads_ws_bytes(N, F, vocab, n, k, num_jobs);          // same plan, items = encoded rows
+    EncMeta m;
+    if (num_jobs >= 1 && !make_meta("phc_encode_bwd_batched_ws_bytes", F, vocab, &m) && enc_direct_batched_ok(m, N, n * k)) {
+        size_t direct = 0;                                                     // the register-resident form's slabs (either may run)
+        for (int c0 = 0; c0 < num_jobs; c0 += TG_JOBS_PER_LAUNCH) {
+            const int cn = num_jobs - c0 < TG_JOBS_PER_LAUNCH ? num_jobs - c0 : TG_JOBS_PER_LAUNCH;
+            direct += sizeof(float) * tg_plan_direct_bond(N, m.R, n * k, cn).slab_floats * cn;
+        }
+        if (direct > need) need = direct;
+    }
+    return need;
 }
 
 int phc_encode_bwd_batched(const phc_table_grad_job *jobs, int num_jobs, const int64_t *idx_i64, int64_t N, int F,
@@ -1265,7 +1382,9 @@ int phc_encode_bwd_batched(const phc_table_grad_job *jobs, int num_jobs, const i
     float *wsf = static_cast<float *>(ws);
     for (int c0 = 0; c0 < num_jobs; c0 += TG_JOBS_PER_LAUNCH) {
         const int cn = num_jobs - c0 < TG_JOBS_PER_LAUNCH ? num_jobs - c0 : TG_JOBS_PER_LAUNCH;
-        const TgPlan p = tg_plan(N, m.R, h, cn);
+        bool direct = enc_direct_batched_ok(m, N, h);
+        for (int q = 0; q < cn && direct; ++q) direct = jobs[c0 + q].dout && (reinterpret_cast<uintptr_t>(jobs[c0 + q].dout) & 7) == 0;
+        const TgPlan p = direct ? tg_plan_direct_bond(N, m.R, h, cn) : tg_plan(N, m.R, h, cn);
         TgBatch b;
         int vec4 = (k % 4 == 0);
         for (int q = 0; q < cn; ++q) {
@@ -1276,7 +1395,14 @@ int phc_encode_bwd_batched(const phc_table_grad_job *jobs, int num_jobs, const i
             wsf += p.slab_floats;
             vec4 = vec4 && al16(jb.dout);
         }
-        {
+        if (direct) {
+            // register-resident form: (encoder group, 64-column tile, split) workgroups
+            ProfScope prof(K_TABLE_GRAD, s);
+            PHC_LAUNCH(enc_direct_batched_kernel, dim3((unsigned)(p.tiles_i * p.tiles_j * p.num_slabs)), dim3(ENC_THREADS), 0, s, b, cn,
+                       reinterpret_cast<const long long *>(idx_i64), m, (long long)N, p.items_per_split, h, p.tiles_j, p.num_slabs);
+            rc = check_launch("encode_bwd_batched(direct)");
+            if (rc) return rc;
+        } else {
             ProfScope prof(K_TABLE_GRAD, s);
             PHC_LAUNCH(table_grad_rows_batched_kernel, dim3(p.tiles_i * p.tiles_j, p.num_slabs, cn), dim3(ENC_THREADS), 0, s, b,
                        reinterpret_cast<const long long *>(idx_i64), m, (long long)N, p.items_per_split, h, p.tiles_j, vec4);

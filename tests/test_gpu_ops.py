@@ -713,13 +713,15 @@ def test_deferred_bond_table_gradients_match_the_per_layer_path(ops, msg_act):
             assert_close(x1, x2, 2e-6 if msg_act == "relu" else 5e-6, f"layer {li} table {ti}")
 
 
-def test_deferred_encoder_gradients_of_several_encoders_over_one_index_tensor(ops):
+@pytest.mark.parametrize("k", [8, 16, 32])
+def test_deferred_encoder_gradients_of_several_encoders_over_one_index_tensor(ops, k):
     """Inside deferred_param_grads() the table gradients of the encoders that were applied to ONE index tensor (the
     bond encoders of all layers when the [E, h] embedding is materialised) come from phc_encode_bwd_batched, the largest
     remaining job joins the step tail; all must equal the immediate per-encoder gradients bit for bit (same body, same
-    plan is NOT guaranteed -> fp32 tolerance) and accumulate into .grad."""
+    plan is NOT guaranteed -> fp32 tolerance) and accumulate into .grad.  k = 16 / 32: widths of 64 / 128 columns, where the
+    batched launch takes the register-resident form (enc_direct_batched_kernel)."""
     g = torch.Generator().manual_seed(91)
-    n, k, vocab, E = 4, 8, [5, 6, 2], 2100
+    n, vocab, E = 4, [5, 6, 2], 2100
     idx = torch.stack([torch.randint(0, v, (E,), generator=g) for v in vocab], dim=1).to(DEV)
     encs = []
     for li in range(4):
