@@ -37,13 +37,16 @@ WORKLOADS: Dict[str, dict] = {
     "molpcba_b1024": dict(dataset="molpcba", batch_size=1024, phm_dim=4, hidden=256, layers=5, d_units=[768, 256],
                           target_dim=128, sc_type="first", nan_frac=0.6),
 }
+# smooth-activation twins (parity runs: without the ReLU kink every gradient tensor is comparable to ~1e-5)
+for _k in ("zinc_b1024", "molpcba_b1024", "molhiv_b512_softmax"):
+    WORKLOADS[_k + "_swish"] = dict(WORKLOADS[_k], activation="swish")
 
 
 def model_kwargs(w: dict) -> dict:
     kw = dict(phm_dim=w["phm_dim"], learn_phm=True, atom_encoded_dim=w["hidden"], mp_layers=[w["hidden"]] * w["layers"],
               dropout_mpnn=[0.0] * w["layers"], mlp=w.get("mlp", True), msg_aggr=w.get("msg_aggr", "sum"),
               norm_mp="naive-batch-norm",
-              norm_dn="naive-batch-norm", pooling="softattention", activation="relu", real_trafo="linear",
+              norm_dn="naive-batch-norm", pooling="softattention", activation=w.get("activation", "relu"), real_trafo="linear",
               w_init="phm", c_init="standard", downstream_layers=list(w["d_units"]),
               dropout_dn=[0.0] * len(w["d_units"]), target_dim=w["target_dim"], sc_type=w["sc_type"],
               msg_encoder="identity")

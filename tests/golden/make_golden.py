@@ -497,6 +497,25 @@ def g10_fullwidth():
                        store_grad32=False)
 
 
+def g10_fullwidth_swish256():
+    """Smooth-activation twins of the two 256-wide fixtures (same seeds, parameters and batches as g10_zinc_h256 /
+    g10_molpcba_h256, activation swish): no ReLU kink, so every gradient tensor of PHM-8 / k = 32 / hidden 256 and of
+    PHM-4 / k = 64 / 128 NaN-masked tasks must agree with the float64 run to ~1e-5 on every execution path."""
+    common = dict(norm_mp="naive-batch-norm", norm_dn="naive-batch-norm", msg_aggr="sum", pooling="softattention",
+                  activation="swish", real_trafo="linear", w_init="phm", c_init="standard", learn_phm=True)
+    zinc = [synth.molecule_batch(48, seed=20, dataset="zinc", regression=True)]
+    _fullwidth_fixture("g10_zinc_h256_swish", zinc, 1020,
+                       dict(phm_dim=8, atom_input_dims=synth.ZINC_ATOM_DIMS, bond_input_dims=synth.ZINC_BOND_DIMS,
+                            atom_encoded_dim=256, mp_layers=[256] * 5, dropout_mpnn=[0.0] * 5, mlp=True,
+                            downstream_layers=[256, 128], dropout_dn=[0.0, 0.0], target_dim=1, sc_type="last", **common),
+                       regression=True, store_grad32=False)
+    pcba = [synth.molecule_batch(64, seed=30, dataset="molpcba", num_tasks=128, nan_frac=0.6)]
+    _fullwidth_fixture("g10_molpcba_h256_swish", pcba, 1030,
+                       dict(phm_dim=4, atom_encoded_dim=256, mp_layers=[256] * 5, dropout_mpnn=[0.0] * 5, mlp=True,
+                            downstream_layers=[768, 256], dropout_dn=[0.0, 0.0], target_dim=128, sc_type="first", **common),
+                       store_grad32=False)
+
+
 def g11_regulariser():
     """phm_weight_regularization (regularization.py:15-23) value and gradients for p = 1, 2 on a stack of PHM layers, plus
     the regularised loop body of train() (train_hiv.py:173-201 with the script's defaults lr 1e-3, weightdecay 1e-3, p 2):
@@ -565,7 +584,7 @@ def g9_dropout():
 
 if __name__ == "__main__":
     makers = [g1_phm_linear, g2_g3_g4_kronecker_rules, g5_convs, g5b_softmax, g6_norm, g7_heads, g8_models,
-              g8_model_softmax, g9_dropout, g10_fullwidth, g11_regulariser]
+              g8_model_softmax, g9_dropout, g10_fullwidth, g10_fullwidth_swish256, g11_regulariser]
     wanted = sys.argv[1:]                       # e.g. `make_golden.py g8_model_softmax` rewrites only that fixture
     for make in makers:
         if not wanted or make.__name__ in wanted:

@@ -45,6 +45,14 @@ FULL = {
                            dropout_dn=[0.0, 0.0], target_dim=1, sc_type="last"), True),
     "g10_molpcba_h256": (dict(phm_dim=4, atom_encoded_dim=256, mp_layers=[256] * 5, dropout_mpnn=[0.0] * 5, mlp=True,
                               downstream_layers=[768, 256], dropout_dn=[0.0, 0.0], target_dim=128, sc_type="first"), False),
+    # smooth twins of the two 256-wide models (PHM-8 / k = 32 and PHM-4 / k = 64 with 128 NaN-masked tasks): W ~ 5e-6 / 9e-6,
+    # so every gradient tensor is held to <= 3e-5 on all three paths
+    "g10_zinc_h256_swish": (dict(phm_dim=8, atom_input_dims=[28], bond_input_dims=[4], atom_encoded_dim=256,
+                                 mp_layers=[256] * 5, dropout_mpnn=[0.0] * 5, mlp=True, downstream_layers=[256, 128],
+                                 dropout_dn=[0.0, 0.0], target_dim=1, sc_type="last", activation="swish"), True),
+    "g10_molpcba_h256_swish": (dict(phm_dim=4, atom_encoded_dim=256, mp_layers=[256] * 5, dropout_mpnn=[0.0] * 5, mlp=True,
+                                    downstream_layers=[768, 256], dropout_dn=[0.0, 0.0], target_dim=128, sc_type="first",
+                                    activation="swish"), False),
 }
 
 
@@ -240,6 +248,9 @@ FULL_SIZE = {
     "molhiv_b512_softmax": dict(phm_dim=4, num_layers=4, num_atom_feats=9, num_bond_feats=3, num_dn_hidden=2, mlp=True,
                                 sc_type="first", msg_aggr="softmax"),
 }
+# the same three with the smooth activation (no ReLU kink): every gradient tensor within 3e-5 of the float64 oracle
+FULL_SIZE.update({k + "_swish": dict(v, act="swish") for k, v in list(FULL_SIZE.items())})
+SMOOTH_GRAD_TOL = 3e-5
 
 
 _ORACLE_CACHE: dict = {}                      # the CPU oracle in float32 + float64 is the expensive part: once per workload
@@ -288,9 +299,9 @@ def test_full_size_config_against_the_oracle(workload, path):
         loss = step.step(padded)
         logits = step.logits[:gb.num_graphs]
     torch.cuda.synchronize()
-    assert_close(loss, ref["32"][1], 2e-5, f"{workload} {path}: loss vs the float32 oracle")
+    assert_close(loss, ref["32"][1], TOL, f"{workload} {path}: loss vs the float32 oracle")
     if logits is not None:
-        assert_close(logits, ref["32"][0], 2e-5, f"{workload} {path}: logits vs the float32 oracle")
+        assert_close(logits, ref["32"][0], TOL, f"{workload} {path}: logits vs the float32 oracle")
     g32, g64 = ref["32"][2], ref["64"][2]
     live = [k for k in names if g64[k] is not None and float(g64[k].abs().max()) >= 1e-7]
     worst32 = max(relerr(g32[k], g64[k]) for k in live)
@@ -298,5 +309,8 @@ def test_full_size_config_against_the_oracle(workload, path):
     rows = sorted(((relerr(params[k].grad, g64[k]), k) for k in live), reverse=True)
     print(f"[{workload} {path}] N={gb.num_nodes} E={gb.num_edges}: {len(rows)} gradient tensors vs the float64 oracle: median "
           f"{rows[len(rows) // 2][0]:.1e}, worst {rows[0][0]:.1e} ({rows[0][1]}); the float32 oracle's own worst {worst32:.1e}")
-    bad = [(e, k) for e, k in rows if e > max(TOL, GRAD_SLACK * worst32)]
+    allow = max(TOL, GRAD_SLACK * worst32)
+    if workload.endswith("_swish"):
+        allow = min(allow, SMOOTH_GRAD_TOL)
+    bad = [(e, k) for e, k in rows if e > allow]
     assert not bad, bad[:6]

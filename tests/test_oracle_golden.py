@@ -181,6 +181,10 @@ FULLWIDTH_CFGS = {
                           sc_type="last"),
     "g10_molpcba_h256": dict(phm_dim=4, num_layers=5, num_atom_feats=9, num_bond_feats=3, num_dn_hidden=2, mlp=True,
                              sc_type="first"),
+    "g10_zinc_h256_swish": dict(phm_dim=8, num_layers=5, num_atom_feats=1, num_bond_feats=1, num_dn_hidden=2, mlp=True,
+                                sc_type="last", act="swish"),
+    "g10_molpcba_h256_swish": dict(phm_dim=4, num_layers=5, num_atom_feats=9, num_bond_feats=3, num_dn_hidden=2, mlp=True,
+                                   sc_type="first", act="swish"),
 }
 
 
@@ -199,7 +203,7 @@ def test_g10_fullwidth_models(name, dtype):
     lt = O.skip_connect_add_forward(p, z["x"], z["edge_index"], z["edge_attr"], z["batch"], training=True, **cfg)
     assert lt.dtype == dtype
     y = z["y"].to(dtype)
-    loss = torch.nn.functional.l1_loss(lt, y) if name == "g10_zinc_h256" else O.bce_loss_masked(lt, y)
+    loss = torch.nn.functional.l1_loss(lt, y) if name.startswith("g10_zinc_h256") else O.bce_loss_masked(lt, y)
     grads = torch.autograd.grad(loss, [p[k] for k in gnames])
     exact = dtype == torch.float64
     # gradient yardstick: the largest float32-vs-float64 distance of any of the reference's own gradient tensors (the
