@@ -67,6 +67,8 @@ int phc_version(void);                       /* PHC_ABI_VERSION of the loaded li
 #define PHC_IDX_ERR_ATOM 2         /* integer node feature outside its vocabulary (phc_encode_fwd)             */
 #define PHC_IDX_ERR_BOND 4         /* integer edge feature outside its vocabulary (packed codes / enc kernels) */
 #define PHC_IDX_ERR_SEGMENT 8      /* segment id (batch vector) outside [0, num_segments)                      */
+#define PHC_ERR_RENDEZVOUS 16      /* a fused launch's grid-wide exchange timed out (workgroups not co-resident):
+                                    * its outputs are invalid (phc_downstream_fwd / _bwd poll loops are bounded)        */
 int phc_set_error_word(int device, int32_t *dev_word);
 const char *phc_error_string(int code);      /* host, static storage                  */
 const char *phc_last_error(void);            /* host, thread-local storage            */
@@ -672,10 +674,12 @@ int phc_clip_adam_step(const uint64_t *table_dev, const float *const *grads, int
  *   reg = coef * sum_layers mean_{kappa,pi} || W_layer[:, kappa, pi] ||_p ,   p in {1, 2}
  * for up to phc_phm_weight_reg_max_jobs() PHM weights in ONE launch: W[j] is [n[j]][cells[j]] (cells = kin*kout);
  * d reg / d W is ADDED into dW[j] (may be NULL: value only), the value is written to *reg_out and, if loss_inout is given,
- * added to *loss_inout (the reference's `loss += reg_loss`).  W / dW / n / cells are HOST arrays.  n[j] <= 16.
+ * added to *loss_inout (the reference's `loss += reg_loss`).  W / dW / n / cells are HOST arrays.  n[j] <= 16, and
+ * sum_j ceil(cells[j] / 256) <= phc_phm_weight_reg_max_blocks() (one workgroup per 256 cells; PHC_ERR_UNSUPPORTED beyond).
  * ws: phc_phm_weight_reg_ws_bytes() bytes, ZERO before the first use and owned by the kernel from then on (the
  * workgroups' shares of the value meet there as tagged granules; one buffer per stream). */
 int phc_phm_weight_reg_max_jobs(void);
+int phc_phm_weight_reg_max_blocks(void);
 size_t phc_phm_weight_reg_ws_bytes(void);
 int phc_phm_weight_reg(const float *const *W, float *const *dW, const int32_t *n, const int32_t *cells, int num_jobs, float coef,
                        int p, float *reg_out, float *loss_inout, void *ws, size_t ws_bytes, void *stream);

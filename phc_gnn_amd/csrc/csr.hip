@@ -94,6 +94,85 @@ __global__ __launch_bounds__(256) void csr_canon_kernel(const int *__restrict__ 
     }
 }
 
+// Rows too long for the rank sorts above (O(deg^2 / lanes): a 1e5-degree hub of a power-law graph would keep one lane group
+// busy for seconds): one WORKGROUP per heavy row sorts the row's item ids with a bitonic network whose comparators all point
+// the same way (the "flip" formulation), so a length that is not a power of two needs no padding — a partner index past the
+// end is +infinity and never moves.  Rows of up to CSR_HEAVY_LDS items are sorted in LDS, longer ones in place in the scratch
+// segment (tmp_perm) through L2.  O(deg log^2 deg / 256) per row.  Every workgroup scans its share of the row pointers and
+// queues the heavy rows it finds (no host round trip, no extra buffer).
+constexpr int CSR_HEAVY_MIN = 2048;                            // rows longer than this are left to csr_heavy_rows_kernel
+constexpr int CSR_HEAVY_LDS = 8192;                            // items sorted in LDS (32 KB)
+constexpr int CSR_HEAVY_GRID = 1024;
+
+template <typename Arr>
+__device__ __forceinline__ void bitonic_flip_sort(Arr a, int n, int tid, int nthreads) {
+    int P = 1;
+    while (P < n) P <<= 1;
+    for (int k = 2; k <= P; k <<= 1) {
+        for (int i = tid; i < n; i += nthreads) {              // flip: i <-> i ^ (k - 1)
+            const int j = i ^ (k - 1);
+            if (j > i && j < n) {
+                const int x = a[i], y = a[j];
+                if (x > y) { a[i] = y; a[j] = x; }
+            }
+        }
+        __syncthreads();
+        for (int st = k >> 2; st > 0; st >>= 1) {
+            for (int i = tid; i < n; i += nthreads) {
+                const int j = i ^ st;
+                if (j > i && j < n) {
+                    const int x = a[i], y = a[j];
+                    if (x > y) { a[i] = y; a[j] = x; }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void csr_heavy_rows_kernel(const int *__restrict__ rowptr, int *__restrict__ tmp_perm,
+                                                            const long long *__restrict__ other, long long num_keys,
+                                                            long long num_other, int *__restrict__ perm, int *__restrict__ col,
+                                                            int *__restrict__ err) {
+    __shared__ int items[CSR_HEAVY_LDS];
+    __shared__ int queue[256];
+    __shared__ int qn;
+    const int tid = threadIdx.x;
+    for (long long base = (long long)blockIdx.x * 256; base < num_keys; base += (long long)gridDim.x * 256) {
+        if (tid == 0) qn = 0;
+        __syncthreads();
+        const long long k = base + tid;
+        if (k < num_keys && rowptr[k + 1] - rowptr[k] > CSR_HEAVY_MIN) queue[atomicAdd(&qn, 1)] = tid;
+        __syncthreads();
+        const int nq = qn;
+        for (int qi = 0; qi < nq; ++qi) {
+            // (queue order is arbitrary; each row's result does not depend on it)
+            const long long row = base + queue[qi];
+            const int b = rowptr[row], deg = rowptr[row + 1] - b;
+            if (deg <= CSR_HEAVY_LDS) {
+                for (int t = tid; t < deg; t += 256) items[t] = tmp_perm[b + t];
+                __syncthreads();
+                bitonic_flip_sort(items, deg, tid, 256);
+                for (int t = tid; t < deg; t += 256) {
+                    const int v = items[t];
+                    perm[b + t] = v;
+                    col[b + t] = other ? (int)checked_index(other[v], num_other, err, PHC_IDX_ERR_EDGE) : v;
+                }
+            } else {
+                __syncthreads();
+                bitonic_flip_sort(tmp_perm + b, deg, tid, 256);
+                for (int t = tid; t < deg; t += 256) {
+                    const int v = tmp_perm[b + t];
+                    perm[b + t] = v;
+                    col[b + t] = other ? (int)checked_index(other[v], num_other, err, PHC_IDX_ERR_EDGE) : v;
+                }
+            }
+            __syncthreads();
+        }
+        __syncthreads();
+    }
+}
+
 // rowptr[s] = first position whose key is >= s, for NON-DECREASING keys (PyG's collated `batch` vector):
 // one thread per boundary, binary search.  No histogram, no atomics, no sort.
 __global__ void sorted_segment_ptr_kernel(const long long *__restrict__ key, long long n, long long num_keys, int *__restrict__ rowptr) {
@@ -243,6 +322,7 @@ __global__ __launch_bounds__(BK_THREADS) void bk_sort_kernel(const int *__restri
     const int li = tid & (SUB - 1);
     for (int k = tid / SUB; k < keys_here; k += BK_THREADS / SUB) {
         const int rb = s0 + cnt[k], deg = cnt[k + 1] - cnt[k];
+        if (deg > CSR_HEAVY_MIN) continue;                    // csr_heavy_rows_kernel (next launch)
         for (int t = li; t < deg; t += SUB) {
             const int vv = tmp_perm[rb + t];
             int rank = 0;
@@ -562,8 +642,11 @@ int phc_csr_build(const int64_t *key_i64, const int64_t *other_i64, int64_t E, i
         const long long groups64 = (num_keys + 3) / 4;
         unsigned g64 = (unsigned)(groups64 > 8192 ? 8192 : (groups64 < 1 ? 1 : groups64));
         PHC_LAUNCH((csr_canon_kernel<64>), dim3(g64), dim3(256), 0, s, rowptr, tmp_perm,
-                           reinterpret_cast<const long long *>(other_i64), (long long)num_keys, 64, 0x7fffffff, perm, col,
+                           reinterpret_cast<const long long *>(other_i64), (long long)num_keys, 64, CSR_HEAVY_MIN, perm, col,
                            (long long)num_other, err);
+        const long long hg = (num_keys + 255) / 256;
+        PHC_LAUNCH(csr_heavy_rows_kernel, dim3((unsigned)(hg > CSR_HEAVY_GRID ? CSR_HEAVY_GRID : hg)), dim3(256), 0, s, rowptr, tmp_perm,
+                   reinterpret_cast<const long long *>(other_i64), (long long)num_keys, (long long)num_other, perm, col, err);
         int rc = check_launch("csr_canon");
         if (rc) return rc;
     }
@@ -626,6 +709,11 @@ int phc_csr_build_bucketed(const int64_t *key_i64, const int64_t *other_i64, int
     ProfScope prof(K_CSR_CANON, s);
     PHC_LAUNCH(bk_sort_kernel, dim3(nb), dim3(BK_THREADS), 0, s, bucket_count, pairs, reinterpret_cast<const long long *>(other_i64),
                (long long)num_keys, (long long)num_other, shift, nb, tmp_perm, rowptr, col, perm, err);
+    {
+        const long long hg = (num_keys + 255) / 256;
+        PHC_LAUNCH(csr_heavy_rows_kernel, dim3((unsigned)(hg > CSR_HEAVY_GRID ? CSR_HEAVY_GRID : hg)), dim3(256), 0, s, rowptr, tmp_perm,
+                   reinterpret_cast<const long long *>(other_i64), (long long)num_keys, (long long)num_other, perm, col, err);
+    }
     return check_launch("csr_build_bucketed");
 }
 

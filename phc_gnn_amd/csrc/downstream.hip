@@ -9,8 +9,11 @@
 //   * batch-norm needs statistics over ALL rows: every workgroup publishes its (sum, M2) pair per column with write-through
 //     (sc1) stores, arrives at a device-scope counter and, once all have arrived, merges the G pairs in workgroup order
 //     (Chan's formula; the same order on every workgroup => identical statistics, bitwise reproducible).  Two such
-//     exchanges per direction.  The workgroups are co-resident by construction (G = ceil(B / 32) <= 64 on 256 CUs), so
-//     the wait cannot deadlock.  The hand-off is MI355X_MICROARCH.md's data-tagged granule: every value travels as ONE
+//     exchanges per direction.  The G = ceil(B / 32) <= 64 workgroups must be co-resident: the host checks the device's real
+//     capacity (occupancy for this launch's LDS size x the CU count of the — possibly partitioned — device; a CU mask in the
+//     environment disqualifies) in phc_downstream_supported / every launch and answers PHC_ERR_UNSUPPORTED otherwise, and the
+//     poll loops are bounded (DN_SPIN_MAX -> PHC_ERR_RENDEZVOUS in the device error word) so that even an unforeseen
+//     scheduling stall ends the launch instead of hanging the GPU.  The hand-off is MI355X_MICROARCH.md's data-tagged granule: every value travels as ONE
 //     naturally aligned 8-byte {value, tag} written by one sc1 (write-through) store and read by sc1 loads that are
 //     repeated until every tag equals this launch's; no flag, no counter, no fence, no L2 write-back — one memory round
 //     trip after the last producer's store has landed (a counter + payload hand-off measured 4.2 + 3.5 us per exchange
@@ -19,6 +22,8 @@
 //     their start, and workgroup 0 cannot get to the bump before every other one has published, i.e. has read it).
 // Padding rows of a fixed-shape batch (rows >= *n_valid) stay out of the statistics, read as 0 after each norm and get zero
 // gradient, as in norm.hip.
+#include <stdlib.h>
+
 #include "phc_common.h"
 
 namespace phc {
@@ -55,7 +60,14 @@ struct DnArgs {
     float *dx, *dz1, *dz2, *dz3, *dwb1, *dwb2, *dWr, *dbr;    // backward outputs
     unsigned long long *partial;                              // [2][G][DN_PSTRIDE] {value, tag} granules
     unsigned *sync;                                           // generation word
+    int *err;                                                 // device error word (phc_set_error_word) or NULL
 };
+
+// A rendezvous that never completes (a producer workgroup that is not resident: CU mask, another stream owning the CUs, a
+// partitioned device the capacity query did not see) must not hang the GPU: every poll loop gives up after DN_SPIN_MAX
+// rounds, raises PHC_ERR_RENDEZVOUS in the device error word and lets the launch run to its end (its outputs are then
+// garbage; the host raises at its next check point).  2^21 rounds of >= 1 us each: seconds, never reached by a live exchange.
+constexpr int DN_SPIN_MAX = 1 << 21;
 
 #ifdef PHC_DN_TIMING
 // experiment build only: workgroup 0 / G-1 stamp the phases of the forward launch (100 MHz wall clock)
@@ -82,8 +94,9 @@ constexpr int DN_MERGE = 32;                                 // granule pairs in
 // Collect column `col` of partial vectors A (offset 0) and Bv (offset DN_MAXW) of workgroups g0 .. g0+DN_MERGE-1 (clamped to
 // G-1): all loads of a round in flight together, repeated until every tag matches.
 __device__ __forceinline__ void collect_pairs(const unsigned long long *part, int G, int g0, int col, unsigned tag, float (&va)[DN_MERGE],
-                                              float (&vb)[DN_MERGE]) {
+                                              float (&vb)[DN_MERGE], int *err) {
     bool ok;
+    int spins = 0;
     do {
         ok = true;
 #pragma unroll
@@ -95,7 +108,13 @@ __device__ __forceinline__ void collect_pairs(const unsigned long long *part, in
             vb[u] = __uint_as_float((unsigned)qb);
             ok = ok && (unsigned)(qa >> 32) == tag && (unsigned)(qb >> 32) == tag;
         }
-        if (!ok) __builtin_amdgcn_s_sleep(1);
+        if (!ok) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > DN_SPIN_MAX) {
+                if (err) atomicOr(err, PHC_ERR_RENDEZVOUS);
+                break;
+            }
+        }
     } while (!ok);
 }
 
@@ -262,7 +281,7 @@ __device__ __forceinline__ void fwd_norm(const DnArgs &a, const DnNorm &bn, cons
         float n = 0.f, mean = 0.f, M2 = 0.f;
         for (int g0 = 0; g0 < a.G; g0 += DN_MERGE) {
             float ps[DN_MERGE], pm[DN_MERGE];
-            collect_pairs(part, a.G, g0, tid, tag, ps, pm);
+            collect_pairs(part, a.G, g0, tid, tag, ps, pm, a.err);
 #pragma unroll
             for (int u = 0; u < DN_MERGE; ++u) {
                 const float ng = g0 + u < a.G ? (float)rows_counted(nvalid, g0 + u) : 0.f;
@@ -412,7 +431,7 @@ __device__ __forceinline__ void bwd_norm(const DnArgs &a, float *Gm, const float
         float SG = 0.f, SGX = 0.f;
         for (int g0 = 0; g0 < a.G; g0 += DN_MERGE) {
             float pa[DN_MERGE], pb[DN_MERGE];
-            collect_pairs(part, a.G, g0, tid, tag, pa, pb);
+            collect_pairs(part, a.G, g0, tid, tag, pa, pb, a.err);
 #pragma unroll
             for (int u = 0; u < DN_MERGE; ++u)
                 if (g0 + u < a.G) {
@@ -433,8 +452,13 @@ __device__ __forceinline__ void bwd_norm(const DnArgs &a, float *Gm, const float
             float s = 0.f;
             for (int gg = 0; gg < a.G; ++gg) {
                 unsigned long long q;
+                int spins = 0;
                 do {
                     q = get_granule(part + (size_t)gg * DN_PSTRIDE + 2 * DN_MAXW + j);
+                    if (++spins > DN_SPIN_MAX) {
+                        if (a.err) atomicOr(a.err, PHC_ERR_RENDEZVOUS);
+                        break;
+                    }
                 } while ((unsigned)(q >> 32) != tag);
                 s += __uint_as_float((unsigned)q);
             }
@@ -596,6 +620,44 @@ static bool dn_shape_ok(int B, int d0, int d1, int d2, int d3, int T) {
     return sizeof(float) * dn_lds_floats(d0, d1, d2, d3, T, false) <= 150 * 1024 && sizeof(float) * dn_lds_floats(d0, d1, d2, d3, T, true) <= 150 * 1024;
 }
 
+// How many workgroups of a fused-head launch the CURRENT device can hold at the same time (the rendezvous needs all G of
+// them resident): occupancy per CU for the launch's real LDS size x the CU count the runtime reports for this (possibly
+// partitioned: CPX = 32 CUs) device.  0 when a CU mask is in the environment (the runtime reports the unmasked count) or
+// when any query fails — the caller then takes the per-layer path.  Cached per (device, direction, LDS size).
+static int dn_resident_capacity(bool bwd, size_t lds_bytes) {
+    static const bool masked = getenv("HSA_CU_MASK") || getenv("ROC_GLOBAL_CU_MASK") || getenv("HSA_CU_MASK_SKIP_INIT");
+    if (masked) return 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    struct Slot { size_t lds; int cap; };
+    static Slot cache[64][2] = {};
+    Slot &sl = cache[dev][bwd ? 1 : 0];
+    if (sl.lds == lds_bytes && sl.cap > 0) return sl.cap;
+    const void *fn = bwd ? reinterpret_cast<const void *>(&downstream_bwd_kernel) : reinterpret_cast<const void *>(&downstream_fwd_kernel);
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024) != hipSuccess) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    int per_cu = 0;
+    hipError_t e = bwd ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, downstream_bwd_kernel, DN_THREADS, lds_bytes)
+                       : hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, downstream_fwd_kernel, DN_THREADS, lds_bytes);
+    hipDeviceProp_t prop;
+    if (e != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess || per_cu < 1 || prop.multiProcessorCount < 1) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    sl.lds = lds_bytes;
+    sl.cap = per_cu * prop.multiProcessorCount;
+    return sl.cap;
+}
+
+// all G workgroups of BOTH launches must be able to be resident at once on this device
+static bool dn_device_ok(int B, int d0, int d1, int d2, int d3, int T) {
+    const int G = (B + DN_ROWS - 1) / DN_ROWS;
+    return dn_resident_capacity(false, sizeof(float) * dn_lds_floats(d0, d1, d2, d3, T, false)) >= G &&
+           dn_resident_capacity(true, sizeof(float) * dn_lds_floats(d0, d1, d2, d3, T, true)) >= G;
+}
+
 static int fill_norm(const char *who, DnNorm *o, const phc_downstream_norm &n, int width) {
     PHC_REQUIRE(n.n_comp >= 1 && n.n_comp <= PHC_MAX_COMPONENTS && width % n.n_comp == 0, PHC_ERR_INVALID_ARG, "%s: norm with %d components on width %d",
                 who, n.n_comp, width);
@@ -622,12 +684,16 @@ static int dn_common(const char *who, const phc_downstream_desc *d, DnArgs *a) {
                 "%s: B=%lld widths %d-%d-%d-%d-%d outside the fused head's range (use the per-layer path)", who, (long long)d->B, d->d0, d->d1,
                 d->d2, d->d3, d->T);
     PHC_REQUIRE(d->act >= PHC_ACT_IDENTITY && d->act <= PHC_ACT_SELU, PHC_ERR_INVALID_ARG, "%s: unknown activation %d", who, d->act);
+    PHC_REQUIRE(dn_device_ok((int)d->B, d->d0, d->d1, d->d2, d->d3, d->T), PHC_ERR_UNSUPPORTED,
+                "%s: the %lld workgroups of the fused head cannot all be resident on this device (partitioned device or CU mask): use "
+                "the per-layer path", who, (long long)((d->B + DN_ROWS - 1) / DN_ROWS));
     PHC_REQUIRE(d->partial && d->sync, PHC_ERR_WORKSPACE, "%s: partial / sync buffers missing", who);
     a->B = (int)d->B; a->d0 = d->d0; a->d1 = d->d1; a->d2 = d->d2; a->d3 = d->d3; a->T = d->T; a->act = d->act;
     a->G = (a->B + DN_ROWS - 1) / DN_ROWS;
     a->n_valid = d->n_valid_dev;
     a->partial = reinterpret_cast<unsigned long long *>(d->partial);
     a->sync = reinterpret_cast<unsigned *>(d->sync);
+    a->err = err_word();
     a->Wr = d->Wr; a->br = d->br;
     a->z1 = d->z1; a->z2 = d->z2; a->z3 = d->z3; a->stat1 = d->stat1; a->stat2 = d->stat2;
     PHC_REQUIRE(a->Wr && a->z1 && a->z2 && a->z3 && a->stat1 && a->stat2, PHC_ERR_INVALID_ARG, "%s: null pointer", who);
@@ -646,7 +712,10 @@ int phc_debug_dn_timestamps(unsigned long long *out64) {
 }
 #endif
 
-int phc_downstream_supported(int64_t B, int d0, int d1, int d2, int d3, int T) { return dn_shape_ok((int)(B > (1LL << 30) ? 1 << 30 : B), d0, d1, d2, d3, T) ? 1 : 0; }
+int phc_downstream_supported(int64_t B, int d0, int d1, int d2, int d3, int T) {
+    const int Bc = (int)(B > (1LL << 30) ? 1 << 30 : B);
+    return (dn_shape_ok(Bc, d0, d1, d2, d3, T) && dn_device_ok(Bc, d0, d1, d2, d3, T)) ? 1 : 0;
+}
 
 size_t phc_downstream_partial_floats(int64_t B) {
     if (B < 1) return 0;
@@ -668,11 +737,7 @@ int phc_downstream_fwd(const phc_downstream_desc *d, void *stream) {
                 PHC_ERR_UNSUPPORTED, "phc_downstream_fwd: 16-byte aligned rows required");
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = sizeof(float) * dn_lds_floats(a.d0, a.d1, a.d2, a.d3, a.T, false);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&downstream_fwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        attr_set = true;
-    }
+    // (hipFuncAttributeMaxDynamicSharedMemorySize was set, per device and checked, by dn_device_ok's capacity query)
     ProfScope prof(K_DOWNSTREAM_FWD, s);
     PHC_LAUNCH(downstream_fwd_kernel, dim3(a.G), dim3(DN_THREADS), lds, s, a);
     return check_launch("downstream_fwd");
@@ -690,11 +755,6 @@ int phc_downstream_bwd(const phc_downstream_desc *d, void *stream) {
                 PHC_ERR_UNSUPPORTED, "phc_downstream_bwd: 16-byte aligned rows required");
     hipStream_t s = (hipStream_t)stream;
     const size_t lds = sizeof(float) * dn_lds_floats(a.d0, a.d1, a.d2, a.d3, a.T, true);
-    static bool attr_set = false;
-    if (!attr_set) {
-        hipFuncSetAttribute(reinterpret_cast<const void *>(&downstream_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
-        attr_set = true;
-    }
     ProfScope prof(K_DOWNSTREAM_BWD, s);
     PHC_LAUNCH(downstream_bwd_kernel, dim3(a.G), dim3(DN_THREADS), lds, s, a);
     return check_launch("downstream_bwd");

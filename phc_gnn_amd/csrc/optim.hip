@@ -256,6 +256,7 @@ int phc_clip_adam_step(const uint64_t *table_dev, const float *const *grads, int
 }
 
 int phc_phm_weight_reg_max_jobs(void) { return REG_MAX_JOBS; }
+int phc_phm_weight_reg_max_blocks(void) { return REG_MAX_BLOCKS; }
 size_t phc_phm_weight_reg_ws_bytes(void) { return sizeof(unsigned long long) * REG_MAX_BLOCKS + 16; }
 
 int phc_phm_weight_reg(const float *const *W, float *const *dW, const int32_t *n, const int32_t *cells, int num_jobs, float coef, int p,

@@ -217,7 +217,7 @@ class EngineBackend:
         return self._ops.bn_fwd_from_moments(
             x, moments_all, counts_all, n_total, [m.weight for m in mods] if norm.affine else None,
             [m.bias for m in mods] if norm.affine else None, [m.running_mean for m in mods], [m.running_var for m in mods],
-            [m.num_batches_tracked for m in mods], norm.momentum if norm.momentum is not None else 0.1, norm.eps,
+            [m.num_batches_tracked for m in mods], norm._momentum(), norm.eps,       # momentum=None is refused, as on one device
             self._ops._act_id(act), residual)
 
     def bn_bwd_sums(self, dy, x, save_stat, act):

@@ -36,7 +36,8 @@ def _build_sorted(key: torch.Tensor, other: Optional[torch.Tensor], num_keys: in
         col = torch.empty(E, dtype=torch.int32, device=dev)
         perm = torch.empty(E, dtype=torch.int32, device=dev)
     if E >= BUCKETED_MIN_ITEMS and num_keys >= BUCKETED_MIN_KEYS and num_keys <= 16384 * 4096 and not _NO_BUCKETED:
-        # large graphs: partition by key range first, then sort bucket by bucket in LDS (same result, ~4x faster at 10 M / 50 M)
+        # large graphs: partition by key range first, then sort bucket by bucket in LDS (same result, ~2x faster at 10 M / 50 M;
+        # rows longer than 2048 items — a hub of a power-law graph — are sorted by a workgroup-wide bitonic network in both paths)
         ws_bytes = lib.phc_csr_bucketed_ws_bytes(E, num_keys)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
         L.check(lib.phc_csr_build_bucketed(L.ptr(key), L.ptr(other), E, num_keys, num_other, L.ptr(rowptr), L.ptr(col), L.ptr(perm),

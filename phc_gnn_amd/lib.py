@@ -100,6 +100,7 @@ SIGNATURES = {
     "phc_downstream_fwd": (_I, [C.POINTER(DownstreamDesc), _P]),
     "phc_downstream_bwd": (_I, [C.POINTER(DownstreamDesc), _P]),
     "phc_phm_weight_reg_max_jobs": (_I, []),
+    "phc_phm_weight_reg_max_blocks": (_I, []),
     "phc_phm_weight_reg_ws_bytes": (_S, []),
     "phc_phm_weight_reg": (_I, [_P, _P, _P, _P, _I, C.c_float, _I, _P, _P, _P, _S, _P]),
     "phc_csr_bucketed_ws_bytes": (_S, [_L, _L]),
@@ -234,6 +235,7 @@ def require_device(*tensors: Optional[torch.Tensor]) -> torch.device:
 _ERR_WORDS: dict = {}
 _ERR_BITS = {1: "edge_index entry outside [0, num_nodes)", 2: "node feature index outside its embedding's vocabulary",
              4: "edge feature index outside its embedding's vocabulary", 8: "segment id (batch vector) outside [0, num_graphs)"}
+ERR_RENDEZVOUS = 16                # PHC_ERR_RENDEZVOUS (include/phc_hip.h)
 CHECK_EAGERLY = os.environ.get("PHC_CHECK_INDICES", "0") == "1"
 
 
@@ -250,6 +252,11 @@ def check_indices(device: Optional[torch.device] = None) -> None:
         if device is not None and torch.device(device) != dev:
             continue
         bits = int(word.item())
+        if bits & ERR_RENDEZVOUS:
+            word.zero_()
+            raise PhcError(f"phc_gnn_amd ({dev}): the grid-wide exchange of a fused launch (phc_downstream_fwd / _bwd) timed out — its "
+                           "workgroups were not co-resident (CU mask / partitioned device / CUs owned by another stream); the step's "
+                           "results are invalid")
         if bits:
             word.zero_()
             what = "; ".join(msg for bit, msg in _ERR_BITS.items() if bits & bit)

@@ -2085,7 +2085,9 @@ def phm_weight_regularization_(model, coef: float, p: int = 2, loss: Optional[to
     if not Ws:
         raise L.PhcError("phm_weight_regularization_: the model has no module with a `W` attribute")
     dev = L.require_device(*Ws)
-    if p not in (1, 2) or len(Ws) > lib.phc_phm_weight_reg_max_jobs() or any(w.shape[0] > 16 for w in Ws):
+    blocks = sum((w.shape[1] * w.shape[2] + 255) // 256 for w in Ws if w.dim() == 3)       # the kernel's workgroup count
+    if p not in (1, 2) or len(Ws) > lib.phc_phm_weight_reg_max_jobs() or any(w.shape[0] > 16 for w in Ws) or \
+            blocks > lib.phc_phm_weight_reg_max_blocks():
         # outside the kernel's range: the reference's own expression through autograd
         reg = coef * sum(w.norm(p=p, dim=0).mean() for w in Ws)
         grads = torch.autograd.grad(reg, Ws)

@@ -161,7 +161,7 @@ def _ref_sorted(key, other, num_keys):
     return np.cumsum(rowptr), (other[order] if other is not None else order), order
 
 
-@pytest.mark.parametrize("kind", ["mol", "ragged", "random_big", "empty", "random_huge", "skewed_huge"])
+@pytest.mark.parametrize("kind", ["mol", "ragged", "random_big", "empty", "random_huge", "skewed_huge", "hubs_big", "hubs_huge"])
 def test_csr_build_is_the_stable_sort(kind):
     from phc_gnn_amd import synth
     from phc_gnn_amd.graph import EdgeStructure
@@ -179,6 +179,18 @@ def test_csr_build_is_the_stable_sort(kind):
         rng = np.random.default_rng(6)
         dst = np.concatenate([rng.integers(0, 1000, 600_000), rng.integers(0, 300_000, 900_000), np.full(40_000, 77)])
         src = rng.integers(0, n, dst.shape[0])
+        p = rng.permutation(dst.shape[0])
+        ei = np.stack([src[p], dst[p]]).astype(np.int64)
+    elif kind in ("hubs_big", "hubs_huge"):
+        # power-law-like rows: hubs of 3 000 / 8 192 / 8 193 / 20 000 (/ 150 000) items next to short rows — the workgroup-wide
+        # bitonic sort of rows longer than 2 048 items (LDS up to 8 192, in place through L2 beyond), in the plain build
+        # ("hubs_big": < 1 M items) and in the two-level one ("hubs_huge")
+        n = 50_021 if kind == "hubs_big" else 300_017
+        rng = np.random.default_rng(8)
+        hubs = [(11, 3000), (n - 1, 8192), (n // 2, 8193), (4097, 20_000)] + ([(123_456, 150_000)] if kind == "hubs_huge" else [])
+        dst = np.concatenate([rng.integers(0, n, 400_000 if kind == "hubs_big" else 1_200_000)] + [np.full(d, k) for k, d in hubs])
+        src = rng.integers(0, n, dst.shape[0])
+        src[-1000:] = 7                                    # and a hub on the source side of the backward view
         p = rng.permutation(dst.shape[0])
         ei = np.stack([src[p], dst[p]]).astype(np.int64)
     else:
