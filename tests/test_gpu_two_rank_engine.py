@@ -98,16 +98,25 @@ def test_two_rank_engine_stack_equals_single_process_and_oracle(tmp_path, activa
         href = O.activation(activation, O._norm_from_state(yl, p, f"m{C.LAYERS + l}.", n, True)) + href
     gref = torch.autograd.grad(href, [xr, er] + [p[k] for k in order], dy, allow_unused=True)
 
-    # relu: a pre-activation within an ulp of the kink may fall on either side depending on the summation order, which
-    # moves that row of dx by O(1) of its size (tests/test_gpu_fullwidth.py); swish is the tight comparison
+    # swish is the tight comparison (every tensor within 3e-5).  relu: a pre-activation within an ulp of the kink falls on
+    # either side depending on the summation order, and one flipped gate changes that node's gradient row by O(1) of its size
+    # (and, through the aggregation's backward, the rows of its neighbours): row-wise tensors are compared row by row — all but
+    # a handful of rows within 3e-5 — and the parameter gradients (sums over all rows) within 2e-3 (tests/test_gpu_fullwidth.py)
     tight = activation == "swish"
     tol_y, tol_g = 2e-5, (3e-5 if tight else 2e-3)
+
+    def rows_close(got, ref, what):
+        if tight:
+            return assert_close(got, ref, 3e-5, what)
+        scale = float(ref.abs().max())
+        bad = ((got - ref).abs().amax(dim=1) > 3e-5 * scale)
+        assert int(bad.sum()) <= max(8, got.shape[0] // 500), f"{what}: {int(bad.sum())} of {got.shape[0]} rows differ"
     assert_close(y2, href.detach(), tol_y, "2 ranks vs oracle: y")
     assert_close(y2, hcur.detach().cpu(), tol_y, "2 ranks vs 1 process: y")
-    assert_close(gx2, gref[0], tol_g, "2 ranks vs oracle: dx")
-    assert_close(gx2, xd.grad.cpu(), tol_g, "2 ranks vs 1 process: dx")
-    assert_close(ge2, gref[1], tol_g, "2 ranks vs oracle: d edge_attr")
-    assert_close(ge2, ead.grad.cpu(), tol_g, "2 ranks vs 1 process: d edge_attr")
+    rows_close(gx2, gref[0], "2 ranks vs oracle: dx")
+    rows_close(gx2, xd.grad.cpu(), "2 ranks vs 1 process: dx")
+    rows_close(ge2, gref[1], "2 ranks vs oracle: d edge_attr")
+    rows_close(ge2, ead.grad.cpu(), "2 ranks vs 1 process: d edge_attr")
     checked = 0
     for i, (k, g_or) in enumerate(zip(names, gref[2:])):
         g2 = shards[0]["grads"][i]
