@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PHC_ABI_VERSION 3
+#define PHC_ABI_VERSION 4
 
 #define PHC_OK 0
 #define PHC_ERR_INVALID_ARG (-1)   /* null pointer, negative size, bad enum        */
@@ -115,14 +115,22 @@ typedef struct phc_phm_H_job {
     float *H, *HT;                 /* device outputs; HT may be NULL */
     int32_t n, kin, kout;
     int32_t flags;                 /* bit 0: n == 1 and W is an nn.Linear weight [kout, kin]: H = W^T, HT unused (it is W) */
+    /* Optional (ABI 4): the same matrices in "k4" form for the H-stationary GEMM — a [Kd, Nd] operand stored as
+     * [Kd / 4][Nd] float4, slot (k / 4) * Nd + j = rows 4 (k / 4) .. +3 of column j (Kd % 4 == 0; PHM jobs only).  A lane of
+     * v_mfma_f32_16x16x4_f32 then fetches its operands of four consecutive k-steps with ONE 16-byte access. */
+    float *Hk4, *HTk4;
 } phc_phm_H_job;
 int phc_phm_build_H_batched(const phc_phm_H_job *jobs, int num_jobs, void *stream);
 
 /* y[N, Nout] = x[N, K] . M[K, Nout] (+ b[Nout]) (+ residual[N, Nout]) with a prebuilt row-major M
  * (H for the forward, H^T for dx; is_dx only labels the launch for the profiler).  Streaming MFMA
  * kernel; K <= 256, K % 4 == 0, x and M 16-byte aligned — otherwise PHC_ERR_UNSUPPORTED and the
- * caller uses phc_phm_linear_fwd / _bwd. */
-int phc_gemm_prebuilt(const float *x, const float *M, const float *b, const float *residual, int64_t N, int K,
+ * caller uses phc_phm_linear_fwd / _bwd.
+ * Mk4 (ABI 4, may be NULL): the same operand in k4 form (phc_phm_H_job.Hk4 / HTk4).  With it, K in {128, 256} and Nout in
+ * {128, 256} run on the H-stationary kernel (csrc/gemm_hs_device.h): operand columns resident in registers, x streamed through
+ * an LDS ring by LDS-DMA, statistics / operand-transform variants in their accumulator forms.  Same results up to the fp32
+ * summation order; every phc_gemm_prebuilt* entry point takes the pair (M, Mk4) the same way. */
+int phc_gemm_prebuilt(const float *x, const float *M, const float *Mk4, const float *b, const float *residual, int64_t N, int K,
                       int Nout, float *y, int is_dx, void *stream);
 
 /* The parameter gradients (dW, dA, db) of MANY PHM linear layers in three launches.
@@ -410,7 +418,7 @@ int phc_bn_bwd_apply(const float *dy, const float *x, const float *save_stat, co
 int phc_gemm_stats_max_partials(void);
 size_t phc_stat_acc_words(int h);             /* 64-bit words of one statistics accumulator of width h */
 int phc_stat_acc_replicas(void);              /* rows of its [2 * replicas][2 * h] word layout (ops.py views it that way) */
-int phc_gemm_prebuilt_stats(const float *x, const float *M, const float *b, int64_t N, int K, int Nout, float *y,
+int phc_gemm_prebuilt_stats(const float *x, const float *M, const float *Mk4, const float *b, int64_t N, int K, int Nout, float *y,
                             const int32_t *n_valid_dev, float *stats_partial, float *stats_counts, int *num_partials,
                             void *stream);
 int phc_bn_fwd_from_partials(const float *x, const float *stats_partial, const float *stats_counts, int num_partials,
@@ -494,7 +502,7 @@ int phc_bn_finalize_from_partials(const float *stats_partial, const float *stats
                                   const int32_t *n_valid_dev, int64_t N, int h, float momentum, float eps,
                                   float *save_stat, void *stream);
 int phc_gemm_prebuilt_xf(const float *x, const float *xf_stat, int xf_act, const int32_t *n_valid_dev, const float *M,
-                         const float *b, int64_t N, int K, int Nout, float *y, float *stats_partial,
+                         const float *Mk4, const float *b, int64_t N, int K, int Nout, float *y, float *stats_partial,
                          float *stats_counts, int *num_partials, void *stream);
 /* The same with the input norm's statistics still in an ACCUMULATOR (xf_acc, width K, filled by phc_gemm_prebuilt_stats' accumulator
  * form): the launch derives scale / shift in its prologue — beside its operand panel load — writes save_stat [6 K] and updates the
@@ -502,15 +510,15 @@ int phc_gemm_prebuilt_xf(const float *x, const float *xf_stat, int xf_act, const
 int phc_gemm_prebuilt_xf_acc(const float *x, const uint64_t *xf_acc, const float *const *weight, const float *const *bias,
                              float *const *running_mean, float *const *running_var, int64_t *const *num_batches_tracked,
                              int n_comp, float momentum, float eps, float *save_stat, int xf_act, const int32_t *n_valid_dev,
-                             const float *M, const float *b, int64_t N, int K, int Nout, float *y, float *stats_partial,
-                             float *stats_counts, int *num_partials, void *stream);
+                             const float *M, const float *Mk4, const float *b, int64_t N, int K, int Nout, float *y,
+                             float *stats_partial, float *stats_counts, int *num_partials, void *stream);
 
 /* Backward of that pair.  phc_gemm_prebuilt_bwsums computes dz = dy . M (M = H^T of the second layer) and, from
  * the same registers, the column sums the norm's backward needs — sum g and sum g*x_hat with
  * g = dz * act'(x_hat*w + b), x_hat = (bn_x - mean)*invstd, over the rows below *n_valid_dev — as
  * sums_partial [phc_gemm_stats_max_partials()][2*Nout] (*num_partials rows written).  phc_bn_bwd_from_partials
  * merges them (fixed order) and produces dx / dwb_flat exactly like phc_bn_bwd (training mode); ws: 2*h floats. */
-int phc_gemm_prebuilt_bwsums(const float *dy, const float *M, int64_t N, int K, int Nout, float *dz, const float *bn_x,
+int phc_gemm_prebuilt_bwsums(const float *dy, const float *M, const float *Mk4, int64_t N, int K, int Nout, float *dz, const float *bn_x,
                              const float *bn_stat, int act, const int32_t *n_valid_dev, float *sums_partial,
                              int *num_partials, void *stream);
 int phc_bn_bwd_from_partials(const float *dy, const float *x, const float *save_stat, const float *sums_partial,

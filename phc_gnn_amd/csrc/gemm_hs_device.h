@@ -1,0 +1,423 @@
+// H-stationary streaming GEMM of the PHM layers on gfx950:  y = x . H (+ b) (+ residual),  dx = dy . H^T
+// (the matmul of matvec_product_new, phc/hypercomplex/layers.py:198-219, on an operand matrix prebuilt once per step).
+//
+// The OPERAND MATRIX lives in registers, x streams through LDS:
+//   * v_mfma_f32_16x16x4_f32 takes from lane (c = lane % 16, kq = lane / 16) ONE element of each operand.  The sum over k may
+//     run in any order, so the k of MFMA step (g, q) on lane group kq is chosen as k = 16 g + 4 kq + q: a lane's operands of
+//     four consecutive steps are then 16 contiguous bytes of one row of x, and — with the operand matrix stored "k4-interleaved"
+//     (float4 slot (k / 4) * Nout + j = H[4 (k / 4) .. +3][j], written by phc_phm_build_H_batched) — 16 contiguous bytes of H.
+//   * every wavefront of a workgroup keeps its own 16 TPW columns of H for the WHOLE contraction in registers (K / 16 float4 per
+//     tile and lane, loaded once per launch in 256-byte runs);
+//   * the workgroup streams x in steps of RS = 16 RB rows: a step's rows are brought into a ring of LDS slots by LDS-DMA
+//     (global_load_lds_dwordx4: whole 1-KiB lines, no VGPR round trip, issued once per WORKGROUP — all wavefronts read the same
+//     rows), and each wavefront reads its fragments x[row c][16 g + 4 kq .. +3] with ONE ds_read_b128 per k-group for all of
+//     its tiles;
+//   * with the MFMA operand roles swapped (A := H, B := x) the result tile comes out transposed: lane (c, kq) holds
+//     y[row c][col0 + 4 kq .. +3] — one 16-byte store per tile, bias / residual as float4, and per-column statistics of the
+//     output are per-lane running sums that live across the whole launch (a wavefront owns its columns for every row).
+// Against an LDS-resident operand panel (the previous design: 128 KB panel fill before the first MFMA, x re-read once per
+// column panel through per-wavefront staging): x is read once, in full lines; no panel fill; a quarter of the LDS reads per MFMA.
+//
+// LDS image of a slot: one DMA instruction = 1 KiB = RPI = 256 / K rows; instruction stride 1 KiB + 32 B (the pad makes the
+// fragment reads conflict-free: each ds_read_b128 lane group then covers 16 distinct 16-byte bank groups); for K = 128 the odd
+// row of a pair is stored with its 16-byte chunks XOR 1 (applied on the SOURCE address: the DMA's LDS side is lane-linear).
+// Ring protocol (one raw s_barrier per step): counted vmcnt wait for the own DMA pieces of step i (younger DMAs and stores
+// stay in flight) -> [operand transform of the own pieces, in place] -> barrier -> issue the DMA of step i + R - 1 into the slot
+// step i - 1 was read from -> MFMAs of step i -> epilogue.
+//
+// FLAGS: HS_ST  emit the batch-norm statistics (sum, sum of squares over the rows below *n_valid) of the OUTPUT columns into a
+//               statistics accumulator (phc_common.h; 64-bit integer atomics, one add per column and workgroup);
+//        HS_XF  the INPUT is a batch-norm that has not been applied: x := act(x * scale + shift), rows >= *n_valid := 0,
+//               evaluated in LDS by the wavefront that fetched the rows (scale / shift from save_stat, or derived in the
+//               prologue from an accumulator: XfAcc);
+//        HS_BW  dz = dy . H^T of a layer whose input was act(batch_norm(bw_x)): besides dz the launch adds the norm backward's
+//               column sums of g = dz * act'(.) and g * x_hat into a statistics accumulator.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "phc_common.h"
+
+namespace phc {
+
+using f32x4_t = __attribute__((ext_vector_type(4))) float;
+
+constexpr int HS_ST = 1, HS_XF = 2, HS_BW = 4;
+
+// XF operand whose batch statistics are still in an ACCUMULATOR: the launch derives scale / shift itself, in its prologue
+// (acc == NULL: xf_stat holds them, merged elsewhere).
+struct XfAcc {
+    const unsigned long long *acc = nullptr;
+    BnParams p = {};
+    float momentum = 0.f, eps = 0.f;
+    float *stat_out = nullptr;                               // [6 K] mean | invstd | scale | shift | w | b, written by workgroup 0
+};
+
+struct GemmHsArgs {
+    const float *x;            // [M, K]
+    const float *hk4;          // k4 form of the operand, [K / 4][Nout] float4
+    const float *bias;         // [Nout] or null
+    const float *residual;     // [M, Nout] or null
+    float *y;                  // [M, Nout]
+    long long M;
+    int Nout;                  // = 16 * TPW * WAVES * panels
+    int panels;
+    int groups;                // workgroups per panel (gridDim.x = panels * groups)
+    const int *n_valid;        // device scalar or null (ST / XF / BW)
+    unsigned long long *stat_acc;   // ST: accumulator of width Nout;  BW: accumulator of width Nout (sum g | sum g x_hat)
+    const float *xf_stat;      // XF: [6 K] mean | invstd | scale | shift | w | b
+    int xf_act;
+    const float *bw_x;         // BW: the norm's input [M, Nout]
+    const float *bw_stat;      // BW: [6 Nout]
+    int bw_act;
+    unsigned long long *stamps;     // diagnostics only (null in the product)
+};
+
+template <int N>
+__device__ __forceinline__ void hs_wait_vm() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+typedef __attribute__((address_space(3))) void hs_lds_void;
+
+// One LDS-DMA instruction: every lane's 16 bytes at `gsrc` land at LDS byte address lds_dst + 16 * lane (lds_dst wave-uniform).
+// Inline asm on purpose: hipcc orders a __builtin_amdgcn_global_load_lds against every later ds_read with s_waitcnt vmcnt(0),
+// which would drain the prefetch ring at each step; the ring's own counted waits (hs_wait_vm) are the ordering here.  An asm
+// VMEM operation only makes hipcc's waits for its own loads stricter (more operations outstanding), never too weak.  M0 is the
+// DMA's LDS base; it is saved and restored inside the statement.
+__device__ __forceinline__ void hs_dma16(const void *gsrc, unsigned lds_dst) {
+    unsigned keep;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep)
+                 : "v"(gsrc), "s"(lds_dst)
+                 : "memory");
+}
+
+// sum over the 16 lanes that share kq (lanes kq * 16 .. + 15): xor offsets 1, 2, 4, 8 stay inside the group
+__device__ __forceinline__ double hs_sum16(double v) {
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+constexpr int HS_ISTRIDE = 66;                                    // float4 slots per DMA instruction (64 + 2 pad)
+
+template <int K, int RB>
+constexpr size_t hs_slot_bytes() {
+    return (size_t)(16 * RB / (256 / K)) * HS_ISTRIDE * 16;
+}
+
+template <int K, int TPW, int WAVES, int RB, int R, int FLAGS>
+__global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfAcc xa) {
+    static_assert(K == 128 || K == 256, "K = 128 or 256 (one DMA instruction = 1 KiB = 256 / K rows)");
+    constexpr bool ST = (FLAGS & HS_ST) != 0, XF = (FLAGS & HS_XF) != 0, BW = (FLAGS & HS_BW) != 0;
+    constexpr int G = K / 16, RS = 16 * RB, RPI = 256 / K, INSTR = RS / RPI, IPW = INSTR / WAVES;
+    static_assert(INSTR % WAVES == 0 && IPW >= 1, "the DMA instructions of a step divide among the wavefronts");
+    constexpr int ISTRIDE = HS_ISTRIDE;
+    constexpr int SLOT_F4 = INSTR * ISTRIDE;
+    constexpr int THREADS = 64 * WAVES;
+    static_assert(R >= 3 && R <= 8, "ring depth");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    f32x4_t *ring = reinterpret_cast<f32x4_t *>(smem);            // [R][SLOT_F4]
+    float *xf_lds = smem + (size_t)R * SLOT_F4 * 4;               // XF from an accumulator: scale[K] | shift[K]
+    const unsigned ring_lds = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(hs_lds_void *)smem);   // LDS byte address
+
+    unsigned long long st_t[3] = {0, 0, 0}, st_r[3] = {0, 0, 0};
+    if (a.stamps) { st_t[0] = __builtin_amdgcn_s_memtime(); st_r[0] = __builtin_amdgcn_s_memrealtime(); }
+    const unsigned panel = blockIdx.x % (unsigned)a.panels, group = blockIdx.x / (unsigned)a.panels;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, kq = lane >> 4;
+    const int Nout = a.Nout;
+    const int col0 = ((int)panel * WAVES + wave) * 16 * TPW;      // this wavefront's first column (< Nout by construction)
+
+    const long long num_steps = (a.M + RS - 1) / RS;
+    const long long my_steps = group < num_steps ? (num_steps - group + a.groups - 1) / a.groups : 0;
+    if (my_steps == 0) return;                                    // whole workgroup: uniform
+    long long n_valid = a.M;
+    if constexpr (ST || XF || BW) {
+        if (a.n_valid) n_valid = min((long long)*a.n_valid, a.M);
+    }
+
+    // ---- DMA of one step: instruction ii = wave + WAVES * u covers rows ii * RPI .. of the step ----
+    const int dsub = RPI == 1 ? 0 : (lane >> 5);                  // row of the pair (K = 128)
+    const int dchunk = (RPI == 1 ? lane : (lane & 31)) ^ dsub;    // the 16-byte chunk of its row this lane fetches
+    auto issue_step = [&](long long step_local, int slot) {
+        const long long step = group + min(step_local, my_steps - 1) * a.groups;       // clamped: the tail re-loads valid rows
+#pragma unroll
+        for (int u = 0; u < IPW; ++u) {
+            const int ii = wave + WAVES * u;
+            const long long row = min(step * RS + ii * RPI + dsub, a.M - 1);
+            hs_dma16(a.x + (size_t)row * K + 4 * dchunk, ring_lds + 16u * (unsigned)(slot * SLOT_F4 + ii * ISTRIDE));
+        }
+    };
+#pragma unroll
+    for (int s = 0; s < R - 1; ++s) issue_step(s, s);
+
+    // ---- operand slice -> registers (once per launch) ----
+    f32x4_t hreg[TPW][G];
+    {
+        const f32x4_t *src = reinterpret_cast<const f32x4_t *>(a.hk4);
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) hreg[t][g] = src[(size_t)(4 * g + kq) * Nout + col0 + c + 16 * t];
+    }
+    // fragment base of this lane per row block (float4 slots): row = rb * 16 + c
+    int fbase[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const int row = rb * 16 + c;
+        fbase[rb] = (row / RPI) * ISTRIDE + (row % RPI) * (K / 4) + (kq ^ (row % RPI));
+    }
+    const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+    f32x4_t bias4[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) bias4[t] = a.bias ? *reinterpret_cast<const f32x4_t *>(a.bias + col0 + 16 * t + 4 * kq) : zero4;
+
+    // ---- XF: scale / shift of the 4 operand columns this lane fetches (fixed for the launch) ----
+    f32x4_t xsc = {1.f, 1.f, 1.f, 1.f}, xsh = zero4;
+    if constexpr (XF) {
+        if (xa.acc) {
+            // statistics still in an accumulator: column `tid` -> scale / shift in LDS (K <= THREADS or strided), workgroup 0
+            // also leaves save_stat and the running statistics behind (the merge launch this replaces)
+            const bool owner = blockIdx.x == 0;
+            for (int col = tid; col < K; col += THREADS) {
+                const double S = stat_acc_total(xa.acc, K, 0, col), Q = stat_acc_total(xa.acc, K, 1, col);
+                const int comp = col / xa.p.k, kk = col - comp * xa.p.k;
+                float w = 1.f, bq = 0.f;
+                for (int q = 0; q < xa.p.n_comp; ++q)
+                    if (q == comp) {
+                        if (xa.p.has_weight) w = xa.p.weight[q][kk];
+                        if (xa.p.has_bias) bq = xa.p.bias[q][kk];
+                    }
+                const double cntd = (double)max(n_valid, 1LL);
+                const double meand = S / cntd, vard = fmax(Q / cntd - meand * meand, 0.0);
+                const float mean = (float)meand, var = (float)vard;
+                const float invstd = 1.f / sqrtf(var + xa.eps);
+                xf_lds[col] = invstd * w;
+                xf_lds[K + col] = bq - mean * invstd * w;
+                if (owner) {
+                    float *st = xa.stat_out;
+                    st[col] = mean; st[K + col] = invstd; st[2 * K + col] = invstd * w; st[3 * K + col] = bq - mean * invstd * w;
+                    st[4 * K + col] = w; st[5 * K + col] = bq;
+                    if (xa.p.has_running) {
+                        const float unbiased = n_valid > 1 ? (float)(vard * cntd / (cntd - 1.0)) : var;
+                        for (int q = 0; q < xa.p.n_comp; ++q)
+                            if (q == comp) {
+                                float *rm = xa.p.running_mean[q] + kk, *rv = xa.p.running_var[q] + kk;
+                                *rm = (1.f - xa.momentum) * *rm + xa.momentum * mean;
+                                *rv = (1.f - xa.momentum) * *rv + xa.momentum * unbiased;
+                            }
+                    }
+                }
+            }
+            if (owner && xa.p.has_nbt && tid < xa.p.n_comp)
+                for (int q = 0; q < xa.p.n_comp; ++q)
+                    if (q == tid) *xa.p.num_batches_tracked[q] += 1;
+            __syncthreads();
+            xsc = *reinterpret_cast<const f32x4_t *>(xf_lds + 4 * dchunk);
+            xsh = *reinterpret_cast<const f32x4_t *>(xf_lds + K + 4 * dchunk);
+        } else {
+            xsc = *reinterpret_cast<const f32x4_t *>(a.xf_stat + 2 * (size_t)K + 4 * dchunk);
+            xsh = *reinterpret_cast<const f32x4_t *>(a.xf_stat + 3 * (size_t)K + 4 * dchunk);
+        }
+    }
+    // ---- BW: norm constants of the 4 columns this lane owns per tile, running sums ----
+    f32x4_t bw_mean[BW ? TPW : 1], bw_inv[BW ? TPW : 1], bw_w[BW ? TPW : 1], bw_b[BW ? TPW : 1];
+    f32x4_t bw_sg[BW ? TPW : 1], bw_sgx[BW ? TPW : 1];
+    if constexpr (BW) {
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            const int col = col0 + 16 * t + 4 * kq;
+            bw_mean[t] = *reinterpret_cast<const f32x4_t *>(a.bw_stat + col);
+            bw_inv[t] = *reinterpret_cast<const f32x4_t *>(a.bw_stat + (size_t)Nout + col);
+            bw_w[t] = *reinterpret_cast<const f32x4_t *>(a.bw_stat + 4 * (size_t)Nout + col);
+            bw_b[t] = *reinterpret_cast<const f32x4_t *>(a.bw_stat + 5 * (size_t)Nout + col);
+            bw_sg[t] = zero4;
+            bw_sgx[t] = zero4;
+        }
+    }
+    // ---- ST: per lane, per owned column: pivot (the lane's first counted value), sum and sum of squares of (v - pivot) ----
+    f32x4_t st_p[ST ? TPW : 1], st_s1[ST ? TPW : 1], st_s2[ST ? TPW : 1];
+    float st_n = 0.f;
+    if constexpr (ST) {
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) st_p[t] = st_s1[t] = st_s2[t] = zero4;
+    }
+
+    // The operand slice and the per-column constants must be COMPLETE in hipcc's own bookkeeping before the loop: a load it
+    // still counts as pending at the loop header is waited for with vmcnt(0) at its first use in EVERY iteration — which would
+    // also drain the DMA ring.  An empty asm that reads the registers makes hipcc place that wait here, once.
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+#pragma unroll
+        for (int g = 0; g < G; g += 8)
+            asm volatile("" ::"v"(hreg[t][g]), "v"(hreg[t][g + 1]), "v"(hreg[t][g + 2]), "v"(hreg[t][g + 3]), "v"(hreg[t][g + 4]),
+                         "v"(hreg[t][g + 5]), "v"(hreg[t][g + 6]), "v"(hreg[t][g + 7]));
+        asm volatile("" ::"v"(bias4[t]));
+        if constexpr (BW) asm volatile("" ::"v"(bw_mean[t]), "v"(bw_inv[t]), "v"(bw_w[t]), "v"(bw_b[t]));
+    }
+    if constexpr (XF) asm volatile("" ::"v"(xsc), "v"(xsh));
+    if (a.stamps) { st_t[1] = __builtin_amdgcn_s_memtime(); st_r[1] = __builtin_amdgcn_s_memrealtime(); }
+
+    // Counted wait for DMA(i): the (R - 2) * IPW DMA instructions of steps i + 1 .. i + R - 2 are younger than it in every
+    // iteration (the tail re-issues clamped steps), so "at most that many operations outstanding" implies DMA(i) has landed
+    // whatever number of stores / epilogue loads was issued in between (they share the counter and only make the wait stricter).
+    constexpr int VM_KEEP = (R - 2) * IPW;
+    int slot = 0;
+    for (long long i = 0; i < my_steps; ++i) {
+        const long long step = group + i * a.groups;
+        hs_wait_vm<VM_KEEP>();
+        if constexpr (XF) {
+            // this wavefront's own rows of the step, in place: act(x * scale + shift); rows past n_valid read as zero
+#pragma unroll
+            for (int u = 0; u < IPW; ++u) {
+                const int ii = wave + WAVES * u;
+                const long long row = step * RS + ii * RPI + dsub;
+                f32x4_t *p = ring + (size_t)slot * SLOT_F4 + ii * ISTRIDE + lane;
+                f32x4_t v = *p;
+                const bool live = row < n_valid;
+                if (a.xf_act == PHC_ACT_RELU) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = live ? fmaxf(fmaf(v[q], xsc[q], xsh[q]), 0.f) : 0.f;
+                } else {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = live ? act_fwd_rt(a.xf_act, fmaf(v[q], xsc[q], xsh[q])) : 0.f;
+                }
+                *p = v;
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the in-place writes are done before the barrier releases readers
+        }
+        // after the barrier: every wavefront's pieces of step i are in place, the slot of step i - 1 is free
+        __builtin_amdgcn_s_barrier();
+        {
+            int nslot = slot + R - 1;
+            nslot = nslot >= R ? nslot - R : nslot;
+            issue_step(i + R - 1, nslot);
+        }
+        // BW: the norm-input rows the epilogue needs go in flight now, under the MFMAs (clamped, unconditional)
+        f32x4_t bwx[BW ? RB : 1][BW ? TPW : 1];
+        if constexpr (BW) {
+#pragma unroll
+            for (int rb = 0; rb < RB; ++rb) {
+                const long long rowc = min(step * RS + rb * 16 + c, a.M - 1);
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) bwx[rb][t] = *reinterpret_cast<const f32x4_t *>(a.bw_x + (size_t)rowc * Nout + col0 + 16 * t + 4 * kq);
+            }
+        }
+        const f32x4_t *sl = ring + (size_t)slot * SLOT_F4;
+        f32x4_t acc[RB][TPW];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) acc[rb][t] = bias4[t];
+        f32x4_t fr[2][RB];
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) fr[0][rb] = sl[fbase[rb]];
+#pragma unroll
+        for (int g = 0; g < G; ++g) {
+            if (g + 1 < G) {
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) fr[(g + 1) & 1][rb] = sl[fbase[rb] + 4 * (g + 1)];
+            }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                    for (int t = 0; t < TPW; ++t)
+                        acc[rb][t] = __builtin_amdgcn_mfma_f32_16x16x4f32(hreg[t][g][q], fr[g & 1][rb][q], acc[rb][t], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        // ---- epilogue: lane (c, kq) holds y[row][col0 + 16 t + 4 kq .. +3] ----
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            const long long row = step * RS + rb * 16 + c;
+            if constexpr (ST) {
+                if (row < n_valid) {
+                    if (st_n == 0.f) {
+#pragma unroll
+                        for (int t = 0; t < TPW; ++t) st_p[t] = acc[rb][t];
+                    } else {
+#pragma unroll
+                        for (int t = 0; t < TPW; ++t) {
+                            const f32x4_t d = acc[rb][t] - st_p[t];
+                            st_s1[t] += d;
+                            st_s2[t] += d * d;
+                        }
+                    }
+                    st_n += 1.f;
+                }
+            }
+            if constexpr (BW) {
+                if (row < n_valid) {
+#pragma unroll
+                    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+                        for (int q = 0; q < 4; ++q) {
+                            const float xh = (bwx[rb][t][q] - bw_mean[t][q]) * bw_inv[t][q];
+                            const float z = fmaf(xh, bw_w[t][q], bw_b[t][q]);
+                            const float v = acc[rb][t][q];
+                            const float gq = a.bw_act == PHC_ACT_RELU ? (z > 0.f ? v : 0.f) : v * act_grad_rt(a.bw_act, z);
+                            bw_sg[t][q] += gq;
+                            bw_sgx[t][q] = fmaf(gq, xh, bw_sgx[t][q]);
+                        }
+                }
+            }
+            if (row < a.M) {
+                float *yr = a.y + (size_t)row * Nout + col0 + 4 * kq;
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) {
+                    f32x4_t v = acc[rb][t];
+                    if (a.residual) v += *reinterpret_cast<const f32x4_t *>(a.residual + (size_t)row * Nout + col0 + 4 * kq + 16 * t);
+                    *reinterpret_cast<f32x4_t *>(yr + 16 * t) = v;
+                }
+            }
+        }
+        slot = slot + 1 == R ? 0 : slot + 1;
+    }
+    hs_wait_vm<0>();                                              // the clamped tail DMAs must not outlive the workgroup's LDS
+
+    // ---- statistics: the 16 row lanes of a column group meet (fixed order), one integer-atomic add per column ----
+    if constexpr (ST) {
+        const int rep = (int)(group % STAT_ACC_REP);
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                // about zero, in double: sum = n p + s1 ; sum of squares = n p^2 + 2 p s1 + s2
+                const double n = (double)st_n, p = (double)st_p[t][q], s1 = (double)st_s1[t][q], s2 = (double)st_s2[t][q];
+                const double S = hs_sum16(n * p + s1), Q = hs_sum16(n * p * p + 2.0 * p * s1 + s2);
+                if (c == 0) {
+                    const int col = col0 + 16 * t + 4 * kq + q;
+                    stat_acc_add(a.stat_acc, Nout, rep, 0, col, S);
+                    stat_acc_add(a.stat_acc, Nout, rep, 1, col, Q);
+                }
+            }
+    }
+    if constexpr (BW) {
+        const int rep = (int)(group % STAT_ACC_REP);
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double sg = hs_sum16((double)bw_sg[t][q]), sgx = hs_sum16((double)bw_sgx[t][q]);
+                if (c == 0) {
+                    const int col = col0 + 16 * t + 4 * kq + q;
+                    stat_acc_add(a.stat_acc, Nout, rep, 0, col, sg);
+                    stat_acc_add(a.stat_acc, Nout, rep, 1, col, sgx);
+                }
+            }
+    }
+    if (a.stamps) {
+        st_t[2] = __builtin_amdgcn_s_memtime(); st_r[2] = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) {
+            unsigned long long *o = a.stamps + ((size_t)blockIdx.x * WAVES + wave) * 6;
+#pragma unroll
+            for (int i = 0; i < 3; ++i) { o[i] = st_t[i]; o[3 + i] = st_r[i]; }
+        }
+    }
+}
+
+}  // namespace phc

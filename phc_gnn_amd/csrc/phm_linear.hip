@@ -19,6 +19,7 @@
 
 #include "phc_common.h"
 #include "phm_grad_device.h"
+#include "gemm_hs_device.h"
 #include <vector>
 
 namespace phc {
@@ -327,15 +328,7 @@ constexpr int ST_FLOATS = 32 * ST_STRIDE;       // private staging floats per wa
 // STATS: the workgroup also emits, per output column, the (sum, M2) of the rows it produced below *n_valid —
 // the batch-norm statistics of y come out of the GEMM's registers instead of a second pass over y
 // (stats_partial[blockIdx.y][0..Nout) = sum, [Nout..2Nout) = M2 about the workgroup's own mean; stats_counts[blockIdx.y]).
-// XF operand whose batch statistics are still in an ACCUMULATOR (phc_common.h): the launch derives scale / shift itself, in its
-// prologue, beside the operand panel load — no merge launch in front of it.  acc == NULL: xf_stat holds them (merged elsewhere).
-struct XfAcc {
-    const unsigned long long *acc = nullptr;
-    BnParams p = {};
-    float momentum = 0.f, eps = 0.f;
-    float *stat_out = nullptr;                               // [6 K] mean | invstd | scale | shift | w | b, written by workgroup (0, 0)
-};
-
+// (XfAcc — an XF operand whose batch statistics are still in an accumulator — is declared in gemm_hs_device.h)
 template <int TRANS, int NPHM, int BN, int WAVES, int STATS = 0>
 __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
     const float *__restrict__ X, const float *__restrict__ A, const float *__restrict__ W,
@@ -843,6 +836,7 @@ constexpr int H_JOBS_PER_LAUNCH = 16;
 struct HJobDev {
     const float *A, *W;
     float *H, *HT;
+    float *Hk4, *HTk4;           // k4-interleaved copies for the H-stationary GEMM (gemm_hs_device.h), or NULL
     int n, kin, kout;
     int dense_t;                 // n == 1 and W is an nn.Linear weight [kout, kin]: H = W^T (H^T is W itself)
     unsigned blk0;
@@ -882,6 +876,9 @@ __global__ __launch_bounds__(256) void phm_build_H_batched_kernel(HBatch b) {
     }
     jb.H[e] = hsum;
     if (jb.HT) jb.HT[(size_t)jc * in + k] = hsum;
+    // k4 form of a [Kd, Nd] operand: float4 slot (kd / 4) * Nd + jd holds rows 4 (kd / 4) .. +3 of column jd
+    if (jb.Hk4) jb.Hk4[((size_t)(k >> 2) * out + jc) * 4 + (k & 3)] = hsum;
+    if (jb.HTk4) jb.HTk4[((size_t)(jc >> 2) * in + k) * 4 + (jc & 3)] = hsum;
 }
 
 __global__ __launch_bounds__(256) void phm_dH_partial_kernel(const float *__restrict__ X, const float *__restrict__ DY,
@@ -1110,6 +1107,63 @@ static int launch_stream_cfg(const float *X, const float *A, const float *W, con
                        bias, residual, out, (long long)M, K, Nout, n, kin, kout, out_vec4, n_valid, stats_partial, stats_counts,
                        xf_stat, xf_act, bw_x, bw_stat, bw_act, stats_acc, xa);
     return PHC_OK;
+}
+
+
+// ---- H-stationary streaming GEMM (gemm_hs_device.h): launcher ----------------------------------------------------------
+// Shapes it serves: K in {128, 256}, Nout in {128, 256} (every hidden-width PHM layer of the BASELINE configs), 16-byte aligned
+// dense rows, operand available in k4 form; statistics only in the accumulator form.  Everything else stays on phm_stream_kernel.
+constexpr int HS_RING = 4;
+static inline bool hs_enabled() {
+    static const bool off = getenv("PHC_GEMM_NO_HS") != nullptr;
+    return !off;
+}
+// Where it is the faster kernel (A/B inside the replayed training steps, one MI355X): hidden 256 at 23-27 k rows -19..-20 % per
+// launch (zinc_b1024 2.46 -> 2.31 ms, molpcba_b1024 3.00 -> 2.87 ms per step), 1 M rows x 256: 1205 -> 992 us (132 TFLOP/s);
+// at K = Nout = 128 and 12.9 k rows the 32-column staged kernel is 0.2-0.4 us per launch ahead (805 sixteen-row steps on 256
+// CUs: 4 rounds for 3.1 rounds of work), from 32 k rows on the H-stationary one again.  PHC_GEMM_HS_ALL=1: every served shape.
+static bool hs_shape_ok(const float *x, const float *Mk4, int64_t N, int K, int Nout) {
+    static const bool all = getenv("PHC_GEMM_HS_ALL") != nullptr;
+    return hs_enabled() && Mk4 && N >= 1 && (K == 128 || K == 256) && (Nout == 128 || Nout == 256) &&
+           (all || K == 256 || Nout == 256 || N >= 32 * 1024) &&
+           ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(Mk4)) & 15) == 0;
+}
+
+template <int K, int TPW, int WAVES, int FLAGS>
+static int launch_hs_cfg(GemmHsArgs a, const XfAcc &xa, hipStream_t s) {
+    constexpr int RB = 1, R = HS_RING;
+    a.panels = a.Nout / (16 * TPW * WAVES);
+    const long long steps = (a.M + 16 * RB - 1) / (16 * RB);
+    static const int per_cu = getenv("PHC_HS_GROUPS_PER_CU") ? atoi(getenv("PHC_HS_GROUPS_PER_CU")) : 1;
+    long long groups = (long long)(per_cu > 0 ? per_cu : 1) * num_cu() / a.panels;
+    if (groups > steps) groups = steps;
+    if (groups < 1) groups = 1;
+    a.groups = (int)groups;
+    const size_t lds = (size_t)R * hs_slot_bytes<K, RB>() + ((FLAGS & HS_XF) ? 2 * (size_t)K * sizeof(float) : 0);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_hs16_kernel<K, TPW, WAVES, RB, R, FLAGS>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, 150 * 1024);
+        attr_set = true;
+    }
+    PHC_LAUNCH((gemm_hs16_kernel<K, TPW, WAVES, RB, R, FLAGS>), dim3((unsigned)(a.panels * a.groups)), dim3(64 * WAVES), lds, s, a, xa);
+    return PHC_OK;
+}
+
+template <int FLAGS>
+static int launch_hs(const GemmHsArgs &a, int K, const XfAcc &xa, hipStream_t s) {
+    // Nout = 256: 8 wavefronts x 2 tiles; Nout = 128: 4 wavefronts x 2 tiles (two independent accumulators per wavefront keep
+    // the 16x16x4 MFMA's 40-cycle dependent latency off the issue path)
+    if (K == 256 && a.Nout == 256) return launch_hs_cfg<256, 2, 8, FLAGS>(a, xa, s);
+    if (K == 256 && a.Nout == 128) return launch_hs_cfg<256, 2, 4, FLAGS>(a, xa, s);
+    if (K == 128 && a.Nout == 256) return launch_hs_cfg<128, 2, 8, FLAGS>(a, xa, s);
+    return launch_hs_cfg<128, 2, 4, FLAGS>(a, xa, s);
+}
+
+static GemmHsArgs hs_args(const float *x, const float *Mk4, const float *b, const float *residual, float *y, int64_t N, int Nout) {
+    GemmHsArgs a = {};
+    a.x = x; a.hk4 = Mk4; a.bias = b; a.residual = residual; a.y = y; a.M = N; a.Nout = Nout;
+    return a;
 }
 
 constexpr int GEMM_STREAM_MAX_K = 256;
@@ -1560,6 +1614,10 @@ int phc_phm_build_H_batched(const phc_phm_H_job *jobs, int num_jobs, void *strea
             PHC_REQUIRE((jb.A || dense_t) && jb.W && jb.H, PHC_ERR_INVALID_ARG, "phc_phm_build_H_batched: job %d: null pointer", c0 + k);
             PHC_REQUIRE(!dense_t || jb.n == 1, PHC_ERR_INVALID_ARG, "phc_phm_build_H_batched: job %d: a dense weight needs n = 1", c0 + k);
             b.j[k].A = jb.A; b.j[k].W = jb.W; b.j[k].H = jb.H; b.j[k].HT = jb.HT;
+            const int in_ = jb.n * jb.kin, out_ = jb.n * jb.kout;
+            PHC_REQUIRE((!jb.Hk4 || in_ % 4 == 0) && (!jb.HTk4 || out_ % 4 == 0) && (!dense_t || (!jb.Hk4 && !jb.HTk4)), PHC_ERR_INVALID_ARG,
+                        "phc_phm_build_H_batched: job %d: the k4 form needs a contraction width that is a multiple of 4 (PHM jobs only)", c0 + k);
+            b.j[k].Hk4 = jb.Hk4; b.j[k].HTk4 = jb.HTk4;
             b.j[k].n = jb.n; b.j[k].kin = jb.kin; b.j[k].kout = jb.kout; b.j[k].dense_t = dense_t;
             b.j[k].blk0 = blocks;
             blocks += (unsigned)(((size_t)jb.n * jb.kin * jb.n * jb.kout + 255) / 256);
@@ -1572,11 +1630,17 @@ int phc_phm_build_H_batched(const phc_phm_H_job *jobs, int num_jobs, void *strea
     return PHC_OK;
 }
 
-int phc_gemm_prebuilt(const float *x, const float *M, const float *b, const float *residual, int64_t N, int K, int Nout, float *y,
-                      int is_dx, void *stream) {
+int phc_gemm_prebuilt(const float *x, const float *M, const float *Mk4, const float *b, const float *residual, int64_t N, int K, int Nout,
+                      float *y, int is_dx, void *stream) {
     PHC_REQUIRE(N >= 0 && K >= 1 && Nout >= 1, PHC_ERR_INVALID_ARG, "phc_gemm_prebuilt: bad shape");
     if (N == 0) return PHC_OK;
     PHC_REQUIRE(x && M && y, PHC_ERR_INVALID_ARG, "phc_gemm_prebuilt: null pointer");
+    if (hs_shape_ok(x, Mk4, N, K, Nout) && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(residual)) & 15) == 0) {
+        hipStream_t hs = (hipStream_t)stream;
+        ProfScope prof(is_dx ? K_PHM_GEMM_DX : K_PHM_GEMM_FWD, hs);
+        launch_hs<0>(hs_args(x, Mk4, b, residual, y, N, Nout), K, XfAcc{}, hs);
+        return check_launch("phc_gemm_prebuilt(hs)");
+    }
     PHC_REQUIRE(K <= GEMM_STREAM_MAX_K && K % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
                     (reinterpret_cast<uintptr_t>(M) & 15) == 0,
                 PHC_ERR_UNSUPPORTED, "phc_gemm_prebuilt: needs K <= 256, K %% 4 == 0 and 16-byte aligned x, M (K=%d)", K);
@@ -1601,7 +1665,7 @@ int phc_gemm_stats_max_partials(void) { return GEMM_STATS_MAX_PARTIALS; }
 size_t phc_stat_acc_words(int h) { return h > 0 ? (size_t)STAT_ACC_REP * 4 * (size_t)h : 0; }
 int phc_stat_acc_replicas(void) { return STAT_ACC_REP; }
 
-int phc_gemm_prebuilt_stats(const float *x, const float *M, const float *b, int64_t N, int K, int Nout, float *y,
+int phc_gemm_prebuilt_stats(const float *x, const float *M, const float *Mk4, const float *b, int64_t N, int K, int Nout, float *y,
                             const int32_t *n_valid_dev, float *stats_partial, float *stats_counts, int *num_partials, void *stream) {
     PHC_REQUIRE(N >= 1 && K >= 1 && Nout >= 1, PHC_ERR_INVALID_ARG, "phc_gemm_prebuilt_stats: bad shape");
     const int acc = stats_counts ? 0 : 1;                    // accumulator form: stats_partial is a statistics accumulator
@@ -1613,6 +1677,13 @@ int phc_gemm_prebuilt_stats(const float *x, const float *M, const float *b, int6
                 PHC_ERR_UNSUPPORTED, "phc_gemm_prebuilt_stats: needs K <= 256, K %% 4 == 0 and 16-byte aligned x, M (K=%d)", K);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(K_PHM_GEMM_FWD, s);
+    if (acc && hs_shape_ok(x, Mk4, N, K, Nout) && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(b)) & 15) == 0) {
+        GemmHsArgs a = hs_args(x, Mk4, b, nullptr, y, N, Nout);
+        a.n_valid = n_valid_dev;
+        a.stat_acc = reinterpret_cast<unsigned long long *>(stats_partial);
+        launch_hs<HS_ST>(a, K, XfAcc{}, s);
+        return check_launch("phc_gemm_prebuilt_stats(hs)");
+    }
     static const int small_bn = getenv("PHC_GEMM_PRE_BN") ? atoi(getenv("PHC_GEMM_PRE_BN")) : 32;
     if (N >= gemm_wide_k_m() && Nout > 64 && K > 128)
         launch_stream_cfg<0, -1, 64, 8, 1>(x, nullptr, M, b, nullptr, y, N, K, Nout, 1, K, Nout, 1, s, n_valid_dev, stats_partial,
@@ -1630,21 +1701,21 @@ int phc_gemm_prebuilt_stats(const float *x, const float *M, const float *b, int6
 }
 
 static int gemm_prebuilt_xf_impl(const float *x, const float *xf_stat, int xf_act, const int32_t *n_valid_dev, const float *M,
-                                 const float *b, int64_t N, int K, int Nout, float *y, float *stats_partial, float *stats_counts,
-                                 int *num_partials, void *stream, const XfAcc &xa);
+                                 const float *Mk4, const float *b, int64_t N, int K, int Nout, float *y, float *stats_partial,
+                                 float *stats_counts, int *num_partials, void *stream, const XfAcc &xa);
 
-int phc_gemm_prebuilt_xf(const float *x, const float *xf_stat, int xf_act, const int32_t *n_valid_dev, const float *M,
+int phc_gemm_prebuilt_xf(const float *x, const float *xf_stat, int xf_act, const int32_t *n_valid_dev, const float *M, const float *Mk4,
                          const float *b, int64_t N, int K, int Nout, float *y, float *stats_partial, float *stats_counts,
                          int *num_partials, void *stream) {
-    return gemm_prebuilt_xf_impl(x, xf_stat, xf_act, n_valid_dev, M, b, N, K, Nout, y, stats_partial, stats_counts, num_partials, stream,
-                                 XfAcc{});
+    return gemm_prebuilt_xf_impl(x, xf_stat, xf_act, n_valid_dev, M, Mk4, b, N, K, Nout, y, stats_partial, stats_counts, num_partials,
+                                 stream, XfAcc{});
 }
 
 int phc_gemm_prebuilt_xf_acc(const float *x, const uint64_t *xf_acc, const float *const *weight, const float *const *bias,
                              float *const *running_mean, float *const *running_var, int64_t *const *num_batches_tracked, int n_comp,
                              float momentum, float eps, float *save_stat, int xf_act, const int32_t *n_valid_dev, const float *M,
-                             const float *b, int64_t N, int K, int Nout, float *y, float *stats_partial, float *stats_counts,
-                             int *num_partials, void *stream) {
+                             const float *Mk4, const float *b, int64_t N, int K, int Nout, float *y, float *stats_partial,
+                             float *stats_counts, int *num_partials, void *stream) {
     PHC_REQUIRE(xf_acc && save_stat && (reinterpret_cast<uintptr_t>(xf_acc) & 7) == 0, PHC_ERR_INVALID_ARG,
                 "phc_gemm_prebuilt_xf_acc: accumulator / save_stat pointer");
     XfAcc xa;
@@ -1654,13 +1725,13 @@ int phc_gemm_prebuilt_xf_acc(const float *x, const uint64_t *xf_acc, const float
     xa.momentum = momentum;
     xa.eps = eps;
     xa.stat_out = save_stat;
-    return gemm_prebuilt_xf_impl(x, save_stat, xf_act, n_valid_dev, M, b, N, K, Nout, y, stats_partial, stats_counts, num_partials, stream,
-                                 xa);
+    return gemm_prebuilt_xf_impl(x, save_stat, xf_act, n_valid_dev, M, Mk4, b, N, K, Nout, y, stats_partial, stats_counts, num_partials,
+                                 stream, xa);
 }
 
 static int gemm_prebuilt_xf_impl(const float *x, const float *xf_stat, int xf_act, const int32_t *n_valid_dev, const float *M,
-                                 const float *b, int64_t N, int K, int Nout, float *y, float *stats_partial, float *stats_counts,
-                                 int *num_partials, void *stream, const XfAcc &xa) {
+                                 const float *Mk4, const float *b, int64_t N, int K, int Nout, float *y, float *stats_partial,
+                                 float *stats_counts, int *num_partials, void *stream, const XfAcc &xa) {
     PHC_REQUIRE(N >= 1 && K >= 1 && Nout >= 1, PHC_ERR_INVALID_ARG, "phc_gemm_prebuilt_xf: bad shape");
     PHC_REQUIRE(x && xf_stat && M && y, PHC_ERR_INVALID_ARG, "phc_gemm_prebuilt_xf: null pointer");
     PHC_REQUIRE(xf_act >= PHC_ACT_IDENTITY && xf_act <= PHC_ACT_SELU, PHC_ERR_INVALID_ARG, "phc_gemm_prebuilt_xf: unknown activation %d",
@@ -1674,6 +1745,19 @@ static int gemm_prebuilt_xf_impl(const float *x, const float *xf_stat, int xf_ac
                 PHC_ERR_UNSUPPORTED, "phc_gemm_prebuilt_xf: needs K <= 256, K %% 4 == 0 and 16-byte aligned x, M, stat (K=%d)", K);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(K_PHM_GEMM_FWD, s);
+    if ((!stats_partial || acc) && hs_shape_ok(x, Mk4, N, K, Nout) &&
+        ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(xf_stat)) & 15) == 0) {
+        GemmHsArgs a = hs_args(x, Mk4, b, nullptr, y, N, Nout);
+        a.n_valid = n_valid_dev;
+        a.xf_stat = xf_stat;
+        a.xf_act = xf_act;
+        a.stat_acc = reinterpret_cast<unsigned long long *>(stats_partial);
+        if (stats_partial)
+            launch_hs<HS_XF | HS_ST>(a, K, xa, s);
+        else
+            launch_hs<HS_XF>(a, K, xa, s);
+        return check_launch("phc_gemm_prebuilt_xf(hs)");
+    }
     static const int small_bn = getenv("PHC_GEMM_PRE_BN") ? atoi(getenv("PHC_GEMM_PRE_BN")) : 32;
     const bool big = N >= GEMM_BIG_M && Nout > 64;
     const bool small = small_bn == 32 && Nout > 32 && N <= 32 * 1024;
@@ -1699,7 +1783,7 @@ static int gemm_prebuilt_xf_impl(const float *x, const float *xf_stat, int xf_ac
     return check_launch("phc_gemm_prebuilt_xf");
 }
 
-int phc_gemm_prebuilt_bwsums(const float *dy, const float *M, int64_t N, int K, int Nout, float *dz, const float *bn_x,
+int phc_gemm_prebuilt_bwsums(const float *dy, const float *M, const float *Mk4, int64_t N, int K, int Nout, float *dz, const float *bn_x,
                              const float *bn_stat, int act, const int32_t *n_valid_dev, float *sums_partial, int *num_partials,
                              void *stream) {
     PHC_REQUIRE(N >= 1 && K >= 1 && Nout >= 1, PHC_ERR_INVALID_ARG, "phc_gemm_prebuilt_bwsums: bad shape");
@@ -1714,6 +1798,16 @@ int phc_gemm_prebuilt_bwsums(const float *dy, const float *M, int64_t N, int K, 
                 PHC_ERR_UNSUPPORTED, "phc_gemm_prebuilt_bwsums: needs K <= 256, K %% 4 == 0, Nout %% 4 == 0, 16-byte aligned operands");
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(K_PHM_GEMM_DX, s);
+    if (acc && hs_shape_ok(dy, Mk4, N, K, Nout)) {
+        GemmHsArgs a = hs_args(dy, Mk4, nullptr, nullptr, dz, N, Nout);
+        a.n_valid = n_valid_dev;
+        a.stat_acc = reinterpret_cast<unsigned long long *>(sums_partial);
+        a.bw_x = bn_x;
+        a.bw_stat = bn_stat;
+        a.bw_act = act;
+        launch_hs<HS_BW>(a, K, XfAcc{}, s);
+        return check_launch("phc_gemm_prebuilt_bwsums(hs)");
+    }
     static const int small_bn = getenv("PHC_GEMM_PRE_BN") ? atoi(getenv("PHC_GEMM_PRE_BN")) : 32;
     if (N >= gemm_wide_k_m() && Nout > 64 && K > 128)
         launch_stream_cfg<0, -1, 64, 8, 4>(dy, nullptr, M, nullptr, nullptr, dz, N, K, Nout, 1, K, Nout, 1, s, n_valid_dev, sums_partial,

@@ -101,6 +101,7 @@ class HaloPlan:
     halo_edge_index: torch.Tensor     # [2, E_halo] src in halo-local numbering, dst in own-local numbering
     halo_edge_ids: torch.Tensor       # [E_halo]
     group: Optional[object] = None
+    max_pair_rows: int = 0            # largest row count any PAIR of ranks exchanges (same value on every rank; 0 = unknown)
 
 
 def build_halo_plan(edge_index: torch.Tensor, num_nodes: int, group=None) -> HaloPlan:
@@ -130,13 +131,15 @@ def build_halo_plan(edge_index: torch.Tensor, num_nodes: int, group=None) -> Hal
         raise RuntimeError("halo plan: received a request for a row this rank does not own")
 
     # (host reads above: once per graph; the plan is reused by every layer and every step)
+    biggest = torch.tensor([max(need_l + asked_l + [0])], dtype=torch.int64, device=dev)
+    dist.all_reduce(biggest, op=dist.ReduceOp.MAX, group=group)         # every rank must cut its exchanges alike (_exchange_rows)
     loc_ei = torch.stack([s[loc_pos] - lo, d[loc_pos]], 0)
     halo_src = torch.searchsorted(halo_ids, s[halo_pos])
     halo_ei = torch.stack([halo_src, d[halo_pos]], 0)
     return HaloPlan(rank=rank, world=world, lo=lo, hi=hi, n_own=hi - lo, n_halo=int(halo_ids.numel()),
                     halo_ids=halo_ids, recv_splits=need_l, send_rows=(req - lo).contiguous(), send_splits=asked_l,
                     loc_edge_index=loc_ei.contiguous(), loc_edge_ids=mine[loc_pos], halo_edge_index=halo_ei.contiguous(),
-                    halo_edge_ids=mine[halo_pos], group=group)
+                    halo_edge_ids=mine[halo_pos], group=group, max_pair_rows=int(biggest.item()))
 
 
 class _CommLane:
@@ -238,18 +241,62 @@ def seg_as_edges(seg):
     return v
 
 
+# One message between a pair of ranks stays below this: a single 2.5 GB self-exchange came back corrupted from RCCL 2.26 /
+# ROCm 7 (found by tests/test_gpu_config5_fullsize.py: 4.97 M rows x 512 B in ONE all-to-all on one rank), so larger exchanges
+# are cut into row chunks.  At BASELINE config 5 on 8 ranks a pair exchanges ~0.3 GB: one call, as before.
+MAX_PAIR_BYTES = 1 << 30
+
+
+def _chunk_bounds(n: int, chunks: int):
+    return [(n * k) // chunks for k in range(chunks + 1)]
+
+
 def _exchange_rows(be, lane: _CommLane, rows_src: torch.Tensor, gather_index: Optional[torch.Tensor], out_rows: int,
-                   out_splits, in_splits, group):
+                   out_splits, in_splits, group, max_pair_rows: int = 0):
     """Start one all-to-all(v) of feature rows on the comm lane: (optionally) gather the rows to send with the engine's
-    row-gather kernel, then the collective.  Returns (recv buffer, handle); ``_finish`` joins."""
+    row-gather kernel, then the collective.  Returns (recv buffer, handle); ``_finish`` joins.
+    ``max_pair_rows``: the plan's global pair maximum (HaloPlan.max_pair_rows) — decides, identically on every rank, into how
+    many row chunks the exchange is cut (0: this rank's own splits decide; only valid for a group of one)."""
     h = rows_src.shape[1]
     recv = torch.empty((out_rows, h), dtype=rows_src.dtype, device=rows_src.device)
+    biggest = max_pair_rows if max_pair_rows > 0 else max(list(out_splits) + list(in_splits) + [0])
+    chunks = max(1, -(-(biggest * h * rows_src.element_size()) // MAX_PAIR_BYTES))
     with lane.fork():
-        send = be.gather_rows(rows_src, gather_index) if gather_index is not None else rows_src.contiguous()
-        work = dist.all_to_all_single(recv, send, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group,
-                                      async_op=True)
-        if lane.stream is not None:
-            work.wait()                                     # stream-ordered on the LANE only; the host does not block
+        if chunks == 1:
+            send = be.gather_rows(rows_src, gather_index) if gather_index is not None else rows_src.contiguous()
+            work = dist.all_to_all_single(recv, send, output_split_sizes=out_splits, input_split_sizes=in_splits, group=group,
+                                          async_op=True)
+            if lane.stream is not None:
+                work.wait()                                     # stream-ordered on the LANE only; the host does not block
+        else:
+            # chunk k carries rows [b[k], b[k+1]) of EVERY pair's segment (same cut on both sides of a pair)
+            in_off = [0]
+            for n in in_splits:
+                in_off.append(in_off[-1] + n)
+            out_off = [0]
+            for n in out_splits:
+                out_off.append(out_off[-1] + n)
+            in_b = [_chunk_bounds(n, chunks) for n in in_splits]
+            out_b = [_chunk_bounds(n, chunks) for n in out_splits]
+            src_all = rows_src if gather_index is not None else rows_src.contiguous()
+            send = src_all
+            work = None
+            for k in range(chunks):
+                isz = [b[k + 1] - b[k] for b in in_b]
+                osz = [b[k + 1] - b[k] for b in out_b]
+                if gather_index is not None:
+                    idx = torch.cat([gather_index[in_off[r] + in_b[r][k]:in_off[r] + in_b[r][k + 1]] for r in range(len(isz))])
+                    part = be.gather_rows(rows_src, idx)
+                else:
+                    part = torch.cat([src_all[in_off[r] + in_b[r][k]:in_off[r] + in_b[r][k + 1]] for r in range(len(isz))])
+                got = torch.empty((sum(osz), h), dtype=rows_src.dtype, device=rows_src.device)
+                wk = dist.all_to_all_single(got, part, output_split_sizes=osz, input_split_sizes=isz, group=group, async_op=True)
+                wk.wait()                                       # stream-ordered on a lane; blocking only under gloo (CPU tests)
+                o = 0
+                for r, n in enumerate(osz):
+                    recv[out_off[r] + out_b[r][k]:out_off[r] + out_b[r][k] + n].copy_(got[o:o + n])
+                    o += n
+                lane.keep(part, got)
     lane.keep(recv, send, rows_src)
     return recv, (work if lane.stream is None else None)
 
@@ -265,7 +312,8 @@ class _ShardedAggregateFn(torch.autograd.Function):
     def forward(ctx, x_own, ea_loc, ea_halo, agg: "ShardedAggregate", act: str, add_self: bool):
         plan, be, lane = agg.plan, agg.backend, agg.lane
         x_own = x_own.contiguous()
-        recv, work = _exchange_rows(be, lane, x_own, plan.send_rows, plan.n_halo, plan.recv_splits, plan.send_splits, plan.group)
+        recv, work = _exchange_rows(be, lane, x_own, plan.send_rows, plan.n_halo, plan.recv_splits, plan.send_splits, plan.group,
+                                    plan.max_pair_rows)
         out = be.aggregate_fwd(x_own, ea_loc, agg.st_loc, act, add_self)            # overlaps the exchange
         _finish(lane, work)
         if plan.halo_edge_index.shape[1] > 0:
@@ -312,7 +360,8 @@ class ShardedAggregate:
     def forward_raw(self, x_own, ea_loc, ea_halo, act: str, add_self: bool):
         """(out, recv) without autograd bookkeeping (the fused layer below keeps its own)."""
         plan, be = self.plan, self.backend
-        recv, work = _exchange_rows(be, self.lane, x_own, plan.send_rows, plan.n_halo, plan.recv_splits, plan.send_splits, plan.group)
+        recv, work = _exchange_rows(be, self.lane, x_own, plan.send_rows, plan.n_halo, plan.recv_splits, plan.send_splits, plan.group,
+                                    plan.max_pair_rows)
         out = be.aggregate_fwd(x_own, ea_loc, self.st_loc, act, add_self)
         _finish(self.lane, work)
         if plan.halo_edge_index.shape[1] > 0:
@@ -330,7 +379,7 @@ class ShardedAggregate:
             d_halo = dout.new_zeros((plan.n_halo, h))
             dea_halo = dout.new_zeros((0, h)) if need_dea[1] else None
         back, work = _exchange_rows(be, self.lane, d_halo, None, int(plan.send_rows.numel()), plan.send_splits, plan.recv_splits,
-                                    plan.group)
+                                    plan.group, plan.max_pair_rows)
         d_own, dea_loc = be.aggregate_bwd(dout, x_own, ea_loc, self.st_loc, act, add_self, need_dea[0])
         extra = overlap() if overlap is not None else None
         _finish(self.lane, work)

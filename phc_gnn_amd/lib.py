@@ -15,7 +15,7 @@ import torch
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, "libphc_hip.so")
 
-ABI_VERSION = 3
+ABI_VERSION = 4
 ACT_IDS = {"identity": 0, "relu": 1, "lrelu": 2, "elu": 3, "swish": 4, "selu": 5}
 
 
@@ -38,7 +38,8 @@ class GradJob(C.Structure):
 class HJob(C.Structure):
     """phc_phm_H_job (include/phc_hip.h)."""
     _fields_ = [("A", _P), ("W", _P), ("H", _P), ("HT", _P),
-                ("n", C.c_int32), ("kin", C.c_int32), ("kout", C.c_int32), ("flags", C.c_int32)]
+                ("n", C.c_int32), ("kin", C.c_int32), ("kout", C.c_int32), ("flags", C.c_int32),
+                ("Hk4", _P), ("HTk4", _P)]
 
 
 class DownstreamNorm(C.Structure):
@@ -76,18 +77,18 @@ SIGNATURES = {
     "phc_phm_linear_bwd_ws_bytes": (_S, [_L, _I, _I, _I]),
     "phc_phm_linear_bwd": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _S, _P]),
     "phc_phm_build_H_batched": (_I, [C.POINTER(HJob), _I, _P]),
-    "phc_gemm_prebuilt": (_I, [_P, _P, _P, _P, _L, _I, _I, _P, _I, _P]),
+    "phc_gemm_prebuilt": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _P, _I, _P]),
     "phc_gemm_stats_max_partials": (_I, []),
     "phc_stat_acc_words": (_S, [_I]),
     "phc_stat_acc_replicas": (_I, []),
-    "phc_gemm_prebuilt_stats": (_I, [_P, _P, _P, _L, _I, _I, _P, _P, _P, _P, C.POINTER(_I), _P]),
+    "phc_gemm_prebuilt_stats": (_I, [_P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _P, C.POINTER(_I), _P]),
     "phc_bn_fwd_from_partials": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _L, _I, C.c_float, C.c_float, _I, _P, _P, _P,
                                       C.c_float, _I, _I, _P, _P]),
     "phc_bn_finalize_from_partials": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _L, _I, C.c_float, C.c_float, _P, _P]),
-    "phc_gemm_prebuilt_xf": (_I, [_P, _P, _I, _P, _P, _P, _L, _I, _I, _P, _P, _P, C.POINTER(_I), _P]),
-    "phc_gemm_prebuilt_xf_acc": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, C.c_float, C.c_float, _P, _I, _P, _P, _P, _L, _I, _I, _P, _P, _P,
+    "phc_gemm_prebuilt_xf": (_I, [_P, _P, _I, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P, C.POINTER(_I), _P]),
+    "phc_gemm_prebuilt_xf_acc": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, C.c_float, C.c_float, _P, _I, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P,
                                       C.POINTER(_I), _P]),
-    "phc_gemm_prebuilt_bwsums": (_I, [_P, _P, _L, _I, _I, _P, _P, _P, _I, _P, _P, C.POINTER(_I), _P]),
+    "phc_gemm_prebuilt_bwsums": (_I, [_P, _P, _P, _L, _I, _I, _P, _P, _P, _I, _P, _P, C.POINTER(_I), _P]),
     "phc_bn_bwd_from_partials": (_I, [_P, _P, _P, _P, _I, _P, _L, _I, _I, _P, _P, _P, _S, _P]),
     "phc_phm_param_grads_ws_bytes": (_S, [C.POINTER(GradJob), _I]),
     "phc_phm_param_grads": (_I, [C.POINTER(GradJob), _I, _P, _S, _P]),

@@ -426,7 +426,8 @@ def prebuilt_H(pairs, dense=()):
     try:
         for dev, prs in by_dev.items():
             with torch.cuda.device(dev):
-                total = sum(2 * (W.shape[0] * W.shape[1]) * (W.shape[0] * W.shape[2]) if A is not None else W.numel()
+                # per PHM pair: H, H^T and their k4-interleaved copies (the H-stationary GEMM's operand form)
+                total = sum(4 * (W.shape[0] * W.shape[1]) * (W.shape[0] * W.shape[2]) if A is not None else W.numel()
                             for A, W in prs)
                 flat = torch.empty(total, dtype=torch.float32, device=dev)
                 arr = (L.HJob * len(prs))()
@@ -436,15 +437,16 @@ def prebuilt_H(pairs, dense=()):
                         fo, fi = W.shape
                         H = flat[off:off + fi * fo].view(fi, fo)
                         off += fi * fo
-                        arr[i] = L.HJob(None, L.ptr(W), L.ptr(H), None, 1, fi, fo, 1)
-                        _PREBUILT.table[("dense", W.data_ptr())] = (H, W, W._version, W._version)
+                        arr[i] = L.HJob(None, L.ptr(W), L.ptr(H), None, 1, fi, fo, 1, None, None)
+                        _PREBUILT.table[("dense", W.data_ptr())] = (H, W, W._version, W._version, None, None)
                         continue
                     n, kin, kout = W.shape
                     sz = (n * kin) * (n * kout)
                     H, HT = flat[off:off + sz].view(n * kin, n * kout), flat[off + sz:off + 2 * sz].view(n * kout, n * kin)
-                    off += 2 * sz
-                    arr[i] = L.HJob(L.ptr(A), L.ptr(W), L.ptr(H), L.ptr(HT), n, kin, kout, 0)
-                    _PREBUILT.table[(A.data_ptr(), W.data_ptr())] = (H, HT, A._version, W._version)
+                    Hk4, HTk4 = flat[off + 2 * sz:off + 3 * sz], flat[off + 3 * sz:off + 4 * sz]
+                    off += 4 * sz
+                    arr[i] = L.HJob(L.ptr(A), L.ptr(W), L.ptr(H), L.ptr(HT), n, kin, kout, 0, L.ptr(Hk4), L.ptr(HTk4))
+                    _PREBUILT.table[(A.data_ptr(), W.data_ptr())] = (H, HT, A._version, W._version, Hk4, HTk4)
                 L.check(lib.phc_phm_build_H_batched(arr, len(prs), L.stream_ptr(dev)), "phc_phm_build_H_batched")
         yield
     finally:
@@ -455,7 +457,7 @@ def _prebuilt_for(A, W):
     ent = _PREBUILT.table.get((A.data_ptr(), W.data_ptr()) if A is not None else ("dense", W.data_ptr()))
     if ent is None or ent[3] != W._version or (A is not None and ent[2] != A._version):   # touched since the build
         return None
-    return ent[0], ent[1]
+    return ent[0], ent[1], ent[4], ent[5]            # H, H^T, and their k4 forms (None for a dense weight)
 
 
 # ---------------------------------------------------------------------------
@@ -477,19 +479,19 @@ class _PHMLinearFn(torch.autograd.Function):
         N = x2.shape[0]
         y = torch.empty((N, n * kout), dtype=torch.float32, device=dev)
         pre = _prebuilt_for(A_, W_) if (_PREBUILT.table and x2.data_ptr() % 16 == 0) else None
-        ctx.HT = None
+        ctx.HT = ctx.HTk4 = None
         if pre is not None and bn_stats is not None and res2 is None and N > 0 and x.dim() == 2:
             sp, sc, want_num = bn_stats.allocate(dev, n * kout, lib.phc_gemm_stats_max_partials())
             num = _C.c_int(0)
-            L.check(lib.phc_gemm_prebuilt_stats(L.ptr(x2), L.ptr(pre[0]), L.ptr(b_), N, n * kin, n * kout, L.ptr(y),
+            L.check(lib.phc_gemm_prebuilt_stats(L.ptr(x2), L.ptr(pre[0]), L.ptr(pre[2]), L.ptr(b_), N, n * kin, n * kout, L.ptr(y),
                                                 L.ptr(bn_stats.n_valid), L.ptr(sp), L.ptr(sc),
                                                 _C.byref(num) if want_num else None, L.stream_ptr(dev)), "phc_gemm_prebuilt_stats")
             bn_stats.num = num.value
-            ctx.HT = pre[1]
+            ctx.HT, ctx.HTk4 = pre[1], pre[3]
         elif pre is not None:
-            L.check(lib.phc_gemm_prebuilt(L.ptr(x2), L.ptr(pre[0]), L.ptr(b_), L.ptr(res2), N, n * kin, n * kout, L.ptr(y), 0,
+            L.check(lib.phc_gemm_prebuilt(L.ptr(x2), L.ptr(pre[0]), L.ptr(pre[2]), L.ptr(b_), L.ptr(res2), N, n * kin, n * kout, L.ptr(y), 0,
                                           L.stream_ptr(dev)), "phc_gemm_prebuilt")
-            ctx.HT = pre[1]                      # dx = dy . H^T from the same build (the weights do not change before it)
+            ctx.HT, ctx.HTk4 = pre[1], pre[3]    # dx = dy . H^T from the same build (the weights do not change before it)
         else:
             L.check(lib.phc_phm_linear_fwd(L.ptr(x2), L.ptr(A_), L.ptr(W_), L.ptr(b_), L.ptr(res2), N, n, kin, kout,
                                            L.ptr(y), L.stream_ptr(dev)), "phc_phm_linear_fwd")
@@ -523,7 +525,7 @@ class _PHMLinearFn(torch.autograd.Function):
         if need_param and ctx.defer_params is not None and _DEFER.active and not torch.is_grad_enabled():
             # dx only; the parameter gradients of all layers are produced together when the deferral block exits
             if need_x and ctx.HT is not None and dy2.data_ptr() % 16 == 0:
-                L.check(lib.phc_gemm_prebuilt(L.ptr(dy2), L.ptr(ctx.HT), None, None, N, n * kout, n * kin, L.ptr(dx), 1,
+                L.check(lib.phc_gemm_prebuilt(L.ptr(dy2), L.ptr(ctx.HT), L.ptr(ctx.HTk4), None, None, N, n * kout, n * kin, L.ptr(dx), 1,
                                               L.stream_ptr(dev)), "phc_gemm_prebuilt(dx)")
             else:
                 L.check(lib.phc_phm_linear_bwd(L.ptr(x2), L.ptr(A), L.ptr(W), L.ptr(dy2), N, n, kin, kout, L.ptr(dx), None,
@@ -705,7 +707,7 @@ class _DenseLinearFn(torch.autograd.Function):
         N = x_.shape[0]
         fo, fi = weight.shape
         y = torch.empty((N, fo), dtype=torch.float32, device=dev)
-        L.check(lib.phc_gemm_prebuilt(L.ptr(x_), L.ptr(H), L.ptr(bias), None, N, fi, fo, L.ptr(y), 0, L.stream_ptr(dev)),
+        L.check(lib.phc_gemm_prebuilt(L.ptr(x_), L.ptr(H), None, L.ptr(bias), None, N, fi, fo, L.ptr(y), 0, L.stream_ptr(dev)),
                 "phc_gemm_prebuilt(dense)")
         if L.PROF_ON:
             L.account("phm_gemm_fwd", 2.0 * N * fi * fo, 4.0 * (N * (fi + fo) + fi * fo + fo))
@@ -725,7 +727,7 @@ class _DenseLinearFn(torch.autograd.Function):
         dx = None
         if need_x:
             dx = torch.empty_like(x_)
-            L.check(lib.phc_gemm_prebuilt(L.ptr(dy_), L.ptr(weight), None, None, N, fo, fi, L.ptr(dx), 1, L.stream_ptr(dev)),
+            L.check(lib.phc_gemm_prebuilt(L.ptr(dy_), L.ptr(weight), None, None, None, N, fo, fi, L.ptr(dx), 1, L.stream_ptr(dev)),
                     "phc_gemm_prebuilt(dense dx)")
             if L.PROF_ON:
                 L.account("phm_gemm_dx", 2.0 * N * fi * fo, 4.0 * (N * (fi + fo) + fi * fo))
@@ -1730,7 +1732,7 @@ class _BNActLinearFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, n_valid, pre, running_mean, running_var, nbt, momentum, eps, act, n_comp, A2, W2, b2, H2, HT2, out_stats,
-                *affine):
+                k4, *affine):
         lib = L.load()
         dev = x.device
         N, h = x.shape
@@ -1756,18 +1758,19 @@ class _BNActLinearFn(torch.autograd.Function):
                 L.ptr(x), L.ptr(pre.partial), _ptr_array(weights) if weights else None, _ptr_array(biases) if biases else None,
                 _ptr_array(running_mean) if running_mean else None, _ptr_array(running_var) if running_var else None,
                 _ptr_array(nbt) if nbt else None, n_comp, float(momentum), float(eps), L.ptr(save_stat), act, L.ptr(n_valid),
-                L.ptr(H2), L.ptr(b2), N, h, n2 * kout2, L.ptr(y), L.ptr(sp), L.ptr(sc), _C.byref(num) if want_num else None,
+                L.ptr(H2), L.ptr(k4[0]), L.ptr(b2), N, h, n2 * kout2, L.ptr(y), L.ptr(sp), L.ptr(sc), _C.byref(num) if want_num else None,
                 L.stream_ptr(dev)), "phc_gemm_prebuilt_xf_acc")
         else:
-            L.check(lib.phc_gemm_prebuilt_xf(L.ptr(x), L.ptr(save_stat), act, L.ptr(n_valid), L.ptr(H2), L.ptr(b2), N, h, n2 * kout2,
-                                             L.ptr(y), L.ptr(sp), L.ptr(sc), _C.byref(num) if want_num else None, L.stream_ptr(dev)),
+            L.check(lib.phc_gemm_prebuilt_xf(L.ptr(x), L.ptr(save_stat), act, L.ptr(n_valid), L.ptr(H2), L.ptr(k4[0]), L.ptr(b2), N, h,
+                                             n2 * kout2, L.ptr(y), L.ptr(sp), L.ptr(sc), _C.byref(num) if want_num else None,
+                                             L.stream_ptr(dev)),
                     "phc_gemm_prebuilt_xf")
         if out_stats is not None:
             out_stats.num = num.value
         if L.PROF_ON:
             L.account("phm_gemm_fwd", 2.0 * N * h * n2 * kout2, 4.0 * (N * (h + n2 * kout2) + h * n2 * kout2))
         ctx.save_for_backward(x, save_stat, A2, W2)
-        ctx.HT2, ctx.params2 = HT2, (A2, W2, b2)
+        ctx.HT2, ctx.HT2k4, ctx.params2 = HT2, k4[1], (A2, W2, b2)
         ctx.meta = (n_comp, act, bool(affine), n_valid)
         return y
 
@@ -1791,13 +1794,13 @@ class _BNActLinearFn(torch.autograd.Function):
             sums_acc = sums is not None
             if not sums_acc:
                 sums = torch.empty((lib.phc_gemm_stats_max_partials(), 2 * h), dtype=torch.float32, device=dev)
-            L.check(lib.phc_gemm_prebuilt_bwsums(L.ptr(dy_), L.ptr(ctx.HT2), N, n2 * kout2, h, L.ptr(dz), L.ptr(x), L.ptr(save_stat),
+            L.check(lib.phc_gemm_prebuilt_bwsums(L.ptr(dy_), L.ptr(ctx.HT2), L.ptr(ctx.HT2k4), N, n2 * kout2, h, L.ptr(dz), L.ptr(x), L.ptr(save_stat),
                                                  act, L.ptr(n_valid), L.ptr(sums), None if sums_acc else _C.byref(num),
                                                  L.stream_ptr(dev)),
                     "phc_gemm_prebuilt_bwsums")
         else:
-            L.check(lib.phc_gemm_prebuilt(L.ptr(dy_), L.ptr(ctx.HT2), None, None, N, n2 * kout2, h, L.ptr(dz), 1, L.stream_ptr(dev)),
-                    "phc_gemm_prebuilt(dx)")
+            L.check(lib.phc_gemm_prebuilt(L.ptr(dy_), L.ptr(ctx.HT2), L.ptr(ctx.HT2k4), None, None, N, n2 * kout2, h, L.ptr(dz), 1,
+                                          L.stream_ptr(dev)), "phc_gemm_prebuilt(dx)")
         if L.PROF_ON:
             L.account("phm_gemm_dx", 2.0 * N * h * n2 * kout2, 4.0 * (N * (h + n2 * kout2) + h * n2 * kout2))
         # second layer's parameter gradients: x stays the norm's input, the kernel re-evaluates act(x*scale+shift)
@@ -1818,7 +1821,7 @@ class _BNActLinearFn(torch.autograd.Function):
                 grads2 = (out[0], out[1], out[2])
         # batch-norm backward on (dz, x, save_stat)
         need_x = needs[0]
-        need_aff = has_affine and any(needs[16:])
+        need_aff = has_affine and any(needs[17:])
         dx = torch.empty_like(x) if need_x else None
         dwb = torch.empty(2 * h, dtype=torch.float32, device=dev) if need_aff else None
         if fused_sums:
@@ -1841,7 +1844,7 @@ class _BNActLinearFn(torch.autograd.Function):
         if has_affine:
             aff_grads = ([dwb[c * k:(c + 1) * k] for c in range(n_comp)] + [dwb[h + c * k:h + (c + 1) * k] for c in range(n_comp)]) \
                 if need_aff else [None] * (2 * n_comp)
-        return (dx, None, None, None, None, None, None, None, None, None, grads2[0], grads2[1], grads2[2], None, None, None,
+        return (dx, None, None, None, None, None, None, None, None, None, grads2[0], grads2[1], grads2[2], None, None, None, None,
                 *aff_grads)
 
 
@@ -1863,7 +1866,7 @@ def bn_act_linear(x: torch.Tensor, weights, biases, running_mean, running_var, n
     y = _BNActLinearFn.apply(x, n_valid, pre, list(running_mean) if running_mean else None,
                              list(running_var) if running_var else None,
                              list(num_batches_tracked) if num_batches_tracked else None, momentum, eps, _act_id(activation),
-                             n_comp, phm_rule, W, bias, ent[0], ent[1], out_stats, *affine)
+                             n_comp, phm_rule, W, bias, ent[0], ent[1], out_stats, (ent[2], ent[3]), *affine)
     if out_stats is not None and out_stats.partial is not None:
         y._phc_bn = out_stats
     return y

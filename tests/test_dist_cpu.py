@@ -124,10 +124,13 @@ class OracleBackend:
         return w * invstd * (g - dwb_global[h:] / n_total - xhat * dwb_global[:h] / n_total)
 
 
-def _worker_sharded(rank, world, port, act, tmp):
+def _worker_sharded(rank, world, port, act, tmp, max_pair_bytes=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
+        if max_pair_bytes is not None:                          # force the chunked exchange (several all-to-alls per halo pull)
+            import phc_gnn_amd.dist as D
+            D.MAX_PAIR_BYTES = max_pair_bytes
         N, E, h = 203, 1500, 16
         ei = torch.from_numpy(synth.random_edges(N, E, seed=3))
         g = torch.Generator().manual_seed(5)
@@ -156,10 +159,12 @@ def _worker_sharded(rank, world, port, act, tmp):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("act", ["identity", "relu"])
-def test_sharded_aggregate_equals_single_process(tmp_path, act):
+@pytest.mark.parametrize("act,max_pair_bytes", [("identity", None), ("relu", None), ("relu", 5000)])
+def test_sharded_aggregate_equals_single_process(tmp_path, act, max_pair_bytes):
+    """``max_pair_bytes`` = 5000: every exchange of ~100 rows x 64 B per pair is cut into row chunks (dist.MAX_PAIR_BYTES, the
+    guard against > 1 GiB messages), forward and reverse, with the plan's global pair maximum deciding the cut on both ranks."""
     world = 2
-    mp.spawn(_worker_sharded, args=(world, _free_port(), act, str(tmp_path)), nprocs=world, join=True)
+    mp.spawn(_worker_sharded, args=(world, _free_port(), act, str(tmp_path), max_pair_bytes), nprocs=world, join=True)
     N, E, h = 203, 1500, 16
     ei = torch.from_numpy(synth.random_edges(N, E, seed=3))
     g = torch.Generator().manual_seed(5)

@@ -595,10 +595,12 @@ def test_gated_segment_sum_matches_oracle(ops, n, k, is_sorted):
     assert_close(gd.grad, gate.grad, TOL, "dgate")
 
 
-@pytest.mark.parametrize("n,kin,kout,N", [(4, 32, 32, 1000), (4, 32, 16, 77), (2, 16, 64, 300), (1, 128, 32, 500), (8, 16, 8, 64)])
+@pytest.mark.parametrize("n,kin,kout,N", [(4, 32, 32, 1000), (4, 32, 16, 77), (2, 16, 64, 300), (1, 128, 32, 500), (8, 16, 8, 64),
+                                          (4, 64, 64, 1000), (8, 32, 32, 40000)])
 def test_prebuilt_operand_matrices_give_identical_results(ops, n, kin, kout, N):
     """Inside prebuilt_H() the forward and dx GEMMs read H / H^T built once by phc_phm_build_H_batched; the
-    results must equal the in-kernel assembly bit for bit (same fma order), and H itself the golden formula."""
+    results must equal the in-kernel assembly bit for bit (same fma order) where both run the LDS-staged kernel, and to
+    2e-6 where the prebuilt path takes the H-stationary kernel (hidden 256: another summation order); H itself the golden formula."""
     from oracle import phc_oracle as O
     g = torch.Generator().manual_seed(31)
     x = torch.randn(N, n * kin, generator=g).to(DEV)
@@ -618,8 +620,12 @@ def test_prebuilt_operand_matrices_give_identical_results(ops, n, kin, kout, N):
         return y.detach(), xr.grad, W.grad.clone(), A.grad.clone(), b.grad.clone()
 
     ref, got = run(False), run(True)
+    hs = n * kin == 256 or n * kout == 256                    # csrc/phm_linear.hip: hs_shape_ok
     for name, a, r in zip(("y", "dx", "dW", "dA", "db"), got, ref):
-        assert torch.equal(a, r), name
+        if hs and name in ("y", "dx"):
+            assert_close(a, r, 2e-6, name)
+        else:
+            assert torch.equal(a, r), name
     assert_close(got[0], O.phm_linear(x.cpu(), A.detach().cpu(), W.detach().cpu(), b.detach().cpu()), TOL, "y vs oracle")
     # a weight update inside the block invalidates the entry (version check): the layer falls back to assembling H
     with ops.prebuilt_H([(A, W)]):

@@ -71,7 +71,7 @@ def test_statistics_gemm_into_an_accumulator_matches_float64(N, h, scale):
     y = torch.empty(N, h, device=DEV)
     acc = torch.zeros(lib.phc_stat_acc_words(h), dtype=torch.int64, device=DEV)
     sp = L.stream_ptr(torch.device(DEV))
-    L.check(lib.phc_gemm_prebuilt_stats(L.ptr(xd), L.ptr(Md), L.ptr(bd), N, h, h, L.ptr(y), None, L.ptr(acc), None, None, sp), "gemm")
+    L.check(lib.phc_gemm_prebuilt_stats(L.ptr(xd), L.ptr(Md), None, L.ptr(bd), N, h, h, L.ptr(y), None, L.ptr(acc), None, None, sp), "gemm")
     out = torch.empty_like(y)
     stat = torch.empty(6 * h, device=DEV)
     L.check(lib.phc_bn_fwd_from_partials(L.ptr(y), L.ptr(acc), None, 0, None, None, None, None, None, 4, None, N, h, 0.1, 1e-5, 0,

@@ -97,13 +97,31 @@ def test_two_rank_engine_stack_equals_single_process_and_oracle(tmp_path, activa
         yl = O.phm_gine_conv(href, ei, er, p, f"m{l}.transform.", n, activation, True, True, True, "identity", None)
         href = O.activation(activation, O._norm_from_state(yl, p, f"m{C.LAYERS + l}.", n, True)) + href
     gref = torch.autograd.grad(href, [xr, er] + [p[k] for k in order], dy, allow_unused=True)
+    # relu: the same oracle in float64 is the yardstick for the parameter gradients (tests/test_gpu_fullwidth.py): W = how far
+    # the float32 oracle's own gradients sit from it (gate flips at the ReLU kink move whole tensors by 1e-3 .. 1e-2)
+    param_allow = 3e-5
+    if activation == "relu":
+        p64 = {k: (v.detach().double() if v.is_floating_point() else v.clone()) for k, v in
+               {f"m{i}." + k: v for i, sd in enumerate(sd0) for k, v in sd.items()}.items()}
+        for k in order:
+            p64[k].requires_grad_()
+        h64 = x.double()
+        for l in range(C.LAYERS):
+            yl = O.phm_gine_conv(h64, ei, ea.double(), p64, f"m{l}.transform.", n, activation, True, True, True, "identity", None)
+            h64 = O.activation(activation, O._norm_from_state(yl, p64, f"m{C.LAYERS + l}.", n, True)) + h64
+        g64 = torch.autograd.grad(h64, [p64[k] for k in order], dy.double(), allow_unused=True)
+        worst32 = max(float((a.double() - b).abs().max() / b.abs().max()) for a, b in zip(gref[2:], g64)
+                      if b is not None and float(b.abs().max()) > 1e-7)
+        param_allow = max(1e-5, 3.0 * worst32)
+        print(f"[two ranks, relu] float32 oracle vs float64 oracle, worst parameter gradient: {worst32:.2e} -> allowance {param_allow:.2e}")
 
     # swish is the tight comparison (every tensor within 3e-5).  relu: a pre-activation within an ulp of the kink falls on
     # either side depending on the summation order, and one flipped gate changes that node's gradient row by O(1) of its size
     # (and, through the aggregation's backward, the rows of its neighbours): row-wise tensors are compared row by row — all but
-    # a handful of rows within 3e-5 — and the parameter gradients (sums over all rows) within 2e-3 (tests/test_gpu_fullwidth.py)
+    # a handful of rows within 3e-5 — and the parameter gradients (sums over all rows) within 3 x the float32 oracle's own
+    # distance from the float64 oracle
     tight = activation == "swish"
-    tol_y, tol_g = 2e-5, (3e-5 if tight else 2e-3)
+    tol_y = 2e-5
 
     def rows_close(got, ref, what):
         if tight:
@@ -124,8 +142,8 @@ def test_two_rank_engine_stack_equals_single_process_and_oracle(tmp_path, activa
         if g_or is None or k.endswith("linear1.b") or k.endswith("linear2.b"):
             # a bias in front of a batch-norm: exactly zero in exact arithmetic, round-off noise in fp32
             continue
-        assert_close(g2, g_or, 5 * tol_g, f"2 ranks vs oracle: grad {k}")
-        assert_close(g2, params1[i].grad.cpu(), 5 * tol_g, f"2 ranks vs 1 process: grad {k}")
+        assert_close(g2, g_or, param_allow, f"2 ranks vs oracle: grad {k}")
+        assert_close(g2, params1[i].grad.cpu(), param_allow, f"2 ranks vs 1 process: grad {k}")
         # each rank really contributed a PARTIAL sum (and neither part is the whole)
         part = shards[0]["local"][i] + shards[1]["local"][i]
         assert_close(part, g2, 1e-6, f"partial sums {k}")
