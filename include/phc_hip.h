@@ -521,6 +521,41 @@ int phc_gemm_prebuilt_xf_acc(const float *x, const uint64_t *xf_acc, const float
 int phc_gemm_prebuilt_bwsums(const float *dy, const float *M, const float *Mk4, int64_t N, int K, int Nout, float *dz, const float *bn_x,
                              const float *bn_stat, int act, const int32_t *n_valid_dev, float *sums_partial,
                              int *num_partials, void *stream);
+/* The norm backward's ELEMENT-WISE pass folded into the dx GEMM behind it (ABI 4).  For  out = act(batch_norm(x)) (+ residual)
+ * with the backward's column sums (sum g | sum g x_hat over the valid rows, g = dout * act'(.)) already in a statistics
+ * accumulator (phc_bn_bwd_partial_acc, or the HS_BW epilogue of the GEMM in front), ONE launch computes
+ *     dz = w invstd (g - mean g - x_hat mean(g x_hat))        (what phc_bn_bwd writes as dx; rows >= *n_valid_dev := 0)
+ *     y  = dz . M                                             (M = H^T of the layer in front of the norm, k4 form)
+ * with dz evaluated in LDS while the rows of dout and bn_x stream in, written out once (dz: the layer's parameter-gradient GEMM
+ * reads it) and never re-read; dwb (dweight | dbias, [2 K]) is left behind by the first workgroup.  Optional second stage
+ * (bw_sums_acc != NULL): y is itself the gradient of act(batch_norm(bw_x)) — the launch also adds THAT norm's column sums
+ * into bw_sums_acc (the epilogue of phc_gemm_prebuilt_bwsums), so that the next phc_gemm_bwd_apply can follow directly.
+ * One PHMGINEConv + model norm backward = phc_bn_bwd_partial_acc -> phc_gemm_bwd_apply (two stages) -> phc_gemm_bwd_apply:
+ * 3 launches instead of 6.  K, Nout in {128, 256} (phc_gemm_bwd_apply_supported); otherwise PHC_ERR_UNSUPPORTED.
+ * Reference ops: phc/hypercomplex/norm.py:30-35 (backward), layers.py:198-219, 349-355. */
+typedef struct phc_gemm_ba_desc {
+    const float *dout;             /* [N, K] upstream gradient                                        */
+    const float *bn_x;             /* [N, K] the norm's input                                         */
+    const float *bn_stat;          /* [6 K] its save_stat (mean | invstd | scale | shift | w | b)     */
+    const uint64_t *sums_acc;      /* accumulator of width K: sum g | sum g x_hat                     */
+    const int32_t *n_valid_dev;    /* device scalar or NULL                                           */
+    float *dz;                     /* [N, K] out                                                      */
+    float *dwb;                    /* [2 K] out or NULL                                               */
+    const float *Mk4;              /* [K, Nout] operand in k4 form                                    */
+    float *y;                      /* [N, Nout] out                                                   */
+    int64_t N;
+    int32_t K, Nout, act;
+    int32_t bw_act;
+    const float *bw_x;             /* second stage: [N, Nout] input of the norm in front, or NULL     */
+    const float *bw_stat;          /* [6 Nout]                                                        */
+    uint64_t *bw_sums_acc;         /* accumulator of width Nout (zeroed by the caller), or NULL       */
+} phc_gemm_ba_desc;
+int phc_gemm_bwd_apply_supported(int K, int Nout);
+int phc_gemm_bwd_apply(const phc_gemm_ba_desc *d, void *stream);
+/* The sums pass alone: adds sum g | sum g x_hat of (dy, x, save_stat) over the rows below *n_valid_dev into `acc` (width h,
+ * zeroed by the caller; h %% 32 == 0, 16-byte aligned rows) — phc_bn_bwd's first launch without its second. */
+int phc_bn_bwd_partial_acc(const float *dy, const float *x, const float *save_stat, const int32_t *n_valid_dev, int64_t N, int h,
+                           int act, uint64_t *acc, void *stream);
 int phc_bn_bwd_from_partials(const float *dy, const float *x, const float *save_stat, const float *sums_partial,
                              int num_partials, const int32_t *n_valid_dev, int64_t N, int h, int act, float *dx,
                              float *dwb_flat, void *ws, size_t ws_bytes, void *stream);

@@ -142,13 +142,26 @@ class PHMSkipConnectAdd(nn.Module):
         """x = [input of the conv, skip tensor]   (ref :200-217).  With ``edge_encoder`` given,
         ``edge_attr`` holds the raw integer bond features and the embedding is evaluated
         inside the aggregation kernel."""
-        if edge_encoder is not None:
+        dropout_active = self.training and dropout_mpnn > 0.0
+        tr = getattr(conv, "transform", None)
+        if self.training and norm is not None and not dropout_active and self.mlp_mp and x[0].is_cuda and \
+                hasattr(tr, "propagate_encoded") and hasattr(getattr(tr, "transform", None), "linear2"):
+            # PHMGINEConv + model norm, training mode: aggregation, then the MLP and the norm as ONE autograd node whose
+            # backward folds both batch-norm backwards into the dx GEMMs (engine: mlp_norm_fused); None = not applicable
+            if edge_encoder is not None:
+                agg = tr.propagate_encoded(edge_index, x[0], edge_attr, edge_encoder, size, add_self=tr.add_self_loops)
+            else:
+                agg = tr.propagate(edge_index, x=x[0], edge_attr=edge_attr, size=size, add_self=tr.add_self_loops)
+            fused = _engine.mlp_norm_fused(agg, x[1], n_valid, tr.transform, norm, self.activation_str)
+            if fused is not None:
+                return fused
+            h = tr.transform(agg, n_valid=n_valid)
+        elif edge_encoder is not None:
             h = conv.forward_encoded(x[0], edge_index, edge_attr, edge_encoder, size, n_valid=n_valid)
         elif n_valid is not None and self.mlp_mp:
             h = conv.transform(x[0], edge_index, edge_attr, size, n_valid=n_valid)
         else:
             h = conv(x=x[0], edge_index=edge_index, edge_attr=edge_attr, size=size)
-        dropout_active = self.training and dropout_mpnn > 0.0
         if norm is not None and (not dropout_active or h.is_cuda):
             # norm -> activation -> (dropout ->) (+ skip) ride in one engine pass; the dropout mask is regenerated in the
             # backward from (seed, step, site) — site = the layer's position in self.norms

@@ -32,6 +32,12 @@
 //               prologue from an accumulator: XfAcc);
 //        HS_BW  dz = dy . H^T of a layer whose input was act(batch_norm(bw_x)): besides dz the launch adds the norm backward's
 //               column sums of g = dz * act'(.) and g * x_hat into a statistics accumulator.
+//        HS_BA  the operand is a batch-norm BACKWARD that has not been applied: the rows of the upstream gradient (x) and of
+//               the norm's input (ba_x) arrive side by side in the ring, and the wavefront that fetched them evaluates
+//                   dz = w invstd (g - mean g - x_hat mean(g x_hat)),   g = dout * act'(x_hat w + b),   rows >= *n_valid := 0
+//               in LDS (norm.py:30-35 backward; the per-column means come from the sums accumulator of the pass in front),
+//               feeds it to the MFMAs and also writes it out (the parameter-gradient GEMM of the layer reads it later):
+//               the norm backward's element-wise pass and its launch disappear into the dx GEMM behind it.
 #pragma once
 #include <hip/hip_runtime.h>
 
@@ -41,7 +47,7 @@ namespace phc {
 
 using f32x4_t = __attribute__((ext_vector_type(4))) float;
 
-constexpr int HS_ST = 1, HS_XF = 2, HS_BW = 4;
+constexpr int HS_ST = 1, HS_XF = 2, HS_BW = 4, HS_BA = 8;
 
 // XF operand whose batch statistics are still in an ACCUMULATOR: the launch derives scale / shift itself, in its prologue
 // (acc == NULL: xf_stat holds them, merged elsewhere).
@@ -69,6 +75,12 @@ struct GemmHsArgs {
     const float *bw_x;         // BW: the norm's input [M, Nout]
     const float *bw_stat;      // BW: [6 Nout]
     int bw_act;
+    const float *ba_x;         // BA: the norm's input [M, K] (x holds the upstream gradient)
+    const float *ba_stat;      // BA: [6 K] save_stat of that norm
+    const unsigned long long *ba_acc;   // BA: accumulator of width K: sum g | sum g x_hat over the valid rows
+    int ba_act;
+    float *ba_dz;              // BA: [M, K] out
+    float *ba_dwb;             // BA: [2 K] out or null: dweight = sum g x_hat | dbias = sum g   (written by workgroup 0)
     unsigned long long *stamps;     // diagnostics only (null in the product)
 };
 
@@ -102,23 +114,31 @@ __device__ __forceinline__ double hs_sum16(double v) {
 constexpr int HS_ISTRIDE = 66;                                    // float4 slots per DMA instruction (64 + 2 pad)
 
 template <int K, int RB>
-constexpr size_t hs_slot_bytes() {
+constexpr size_t hs_slot_bytes() {                                // one operand image of a ring slot (BA: two images per slot)
     return (size_t)(16 * RB / (256 / K)) * HS_ISTRIDE * 16;
+}
+template <int K, int RB, int R, int FLAGS>
+constexpr size_t hs_lds_bytes() {
+    return (size_t)R * hs_slot_bytes<K, RB>() * ((FLAGS & HS_BA) ? 2 : 1) + ((FLAGS & HS_XF) ? 2 * (size_t)K * sizeof(float) : 0) +
+           ((FLAGS & HS_BA) ? 6 * (size_t)K * sizeof(float) : 0);
 }
 
 template <int K, int TPW, int WAVES, int RB, int R, int FLAGS>
 __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfAcc xa) {
     static_assert(K == 128 || K == 256, "K = 128 or 256 (one DMA instruction = 1 KiB = 256 / K rows)");
-    constexpr bool ST = (FLAGS & HS_ST) != 0, XF = (FLAGS & HS_XF) != 0, BW = (FLAGS & HS_BW) != 0;
+    constexpr bool ST = (FLAGS & HS_ST) != 0, XF = (FLAGS & HS_XF) != 0, BW = (FLAGS & HS_BW) != 0, BA = (FLAGS & HS_BA) != 0;
+    static_assert(!(BA && XF), "one operand transform per launch");
     constexpr int G = K / 16, RS = 16 * RB, RPI = 256 / K, INSTR = RS / RPI, IPW = INSTR / WAVES;
     static_assert(INSTR % WAVES == 0 && IPW >= 1, "the DMA instructions of a step divide among the wavefronts");
     constexpr int ISTRIDE = HS_ISTRIDE;
-    constexpr int SLOT_F4 = INSTR * ISTRIDE;
+    constexpr int IMG_F4 = INSTR * ISTRIDE;                        // one operand image
+    constexpr int SLOT_F4 = IMG_F4 * (BA ? 2 : 1);                 // BA: [upstream gradient | norm input]
     constexpr int THREADS = 64 * WAVES;
     static_assert(R >= 3 && R <= 8, "ring depth");
     extern __shared__ __attribute__((aligned(16))) float smem[];
     f32x4_t *ring = reinterpret_cast<f32x4_t *>(smem);            // [R][SLOT_F4]
     float *xf_lds = smem + (size_t)R * SLOT_F4 * 4;               // XF from an accumulator: scale[K] | shift[K]
+    float *ba_lds = xf_lds;                                       // BA: mean | invstd | w | b | mean g | mean g x_hat   [6][K]
     const unsigned ring_lds = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(hs_lds_void *)smem);   // LDS byte address
 
     unsigned long long st_t[3] = {0, 0, 0}, st_r[3] = {0, 0, 0};
@@ -134,7 +154,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
     const long long my_steps = group < num_steps ? (num_steps - group + a.groups - 1) / a.groups : 0;
     if (my_steps == 0) return;                                    // whole workgroup: uniform
     long long n_valid = a.M;
-    if constexpr (ST || XF || BW) {
+    if constexpr (ST || XF || BW || BA) {
         if (a.n_valid) n_valid = min((long long)*a.n_valid, a.M);
     }
 
@@ -148,8 +168,30 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
             const int ii = wave + WAVES * u;
             const long long row = min(step * RS + ii * RPI + dsub, a.M - 1);
             hs_dma16(a.x + (size_t)row * K + 4 * dchunk, ring_lds + 16u * (unsigned)(slot * SLOT_F4 + ii * ISTRIDE));
+            if constexpr (BA)
+                hs_dma16(a.ba_x + (size_t)row * K + 4 * dchunk, ring_lds + 16u * (unsigned)(slot * SLOT_F4 + IMG_F4 + ii * ISTRIDE));
         }
     };
+    // BA: the accumulator words and norm constants of column `tid` go in flight FIRST (their consumer below waits for every
+    // older operation: behind the DMAs they would wait for the whole first ring fill and the operand slice too)
+    unsigned long long ba_raw[BA ? 2 : 1][BA ? STAT_ACC_REP : 1][2];
+    float ba_cst[4] = {0.f, 1.f, 1.f, 0.f};
+    if constexpr (BA) {
+        static_assert(K <= THREADS, "one column per thread in the BA prologue");
+        const int col = min(tid, K - 1);
+#pragma unroll
+        for (int qty = 0; qty < 2; ++qty)
+#pragma unroll
+            for (int rep = 0; rep < STAT_ACC_REP; ++rep) {
+                const unsigned long long *p = a.ba_acc + ((size_t)(rep * 2 + qty) * 2) * K + col;
+                ba_raw[qty][rep][0] = p[0];
+                ba_raw[qty][rep][1] = p[K];
+            }
+        ba_cst[0] = a.ba_stat[col];
+        ba_cst[1] = a.ba_stat[K + col];
+        ba_cst[2] = a.ba_stat[4 * K + col];
+        ba_cst[3] = a.ba_stat[5 * K + col];
+    }
 #pragma unroll
     for (int s = 0; s < R - 1; ++s) issue_step(s, s);
 
@@ -222,6 +264,35 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
             xsh = *reinterpret_cast<const f32x4_t *>(a.xf_stat + 3 * (size_t)K + 4 * dchunk);
         }
     }
+    // ---- BA: per-column constants of the un-applied norm backward -> LDS (workgroup 0 also leaves dweight | dbias behind) ----
+    if constexpr (BA) {
+        if (tid < K) {
+            const int col = tid;
+            double tot[2];
+#pragma unroll
+            for (int qty = 0; qty < 2; ++qty) {
+                long long hi = 0, lo = 0;
+#pragma unroll
+                for (int rep = 0; rep < STAT_ACC_REP; ++rep) {
+                    hi += (long long)ba_raw[qty][rep][0];
+                    lo += (long long)ba_raw[qty][rep][1];
+                }
+                tot[qty] = (double)hi * (1.0 / 4096.0) + (double)lo * (1.0 / 4611686018427387904.0);
+            }
+            const float cnt = (float)max(n_valid, 1LL);
+            ba_lds[col] = ba_cst[0];
+            ba_lds[K + col] = ba_cst[1];
+            ba_lds[2 * K + col] = ba_cst[2];
+            ba_lds[3 * K + col] = ba_cst[3];
+            ba_lds[4 * K + col] = (float)tot[0] / cnt;
+            ba_lds[5 * K + col] = (float)tot[1] / cnt;
+            if (blockIdx.x == 0 && a.ba_dwb) {
+                a.ba_dwb[col] = (float)tot[1];
+                a.ba_dwb[K + col] = (float)tot[0];
+            }
+        }
+        __syncthreads();
+    }
     // ---- BW: norm constants of the 4 columns this lane owns per tile, running sums ----
     f32x4_t bw_mean[BW ? TPW : 1], bw_inv[BW ? TPW : 1], bw_w[BW ? TPW : 1], bw_b[BW ? TPW : 1];
     f32x4_t bw_sg[BW ? TPW : 1], bw_sgx[BW ? TPW : 1];
@@ -260,21 +331,23 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
     if constexpr (XF) asm volatile("" ::"v"(xsc), "v"(xsh));
     if (a.stamps) { st_t[1] = __builtin_amdgcn_s_memtime(); st_r[1] = __builtin_amdgcn_s_memrealtime(); }
 
-    // Counted wait for DMA(i): the (R - 2) * IPW DMA instructions of steps i + 1 .. i + R - 2 are younger than it in every
-    // iteration (the tail re-issues clamped steps), so "at most that many operations outstanding" implies DMA(i) has landed
+    // Counted wait for DMA(j): the (R - 2) * IPW DMA instructions of the R - 2 steps behind it are younger than it at every
+    // wait below (the tail re-issues clamped steps), so "at most that many operations outstanding" implies DMA(j) has landed
     // whatever number of stores / epilogue loads was issued in between (they share the counter and only make the wait stricter).
-    constexpr int VM_KEEP = (R - 2) * IPW;
-    int slot = 0;
-    for (long long i = 0; i < my_steps; ++i) {
-        const long long step = group + i * a.groups;
-        hs_wait_vm<VM_KEEP>();
+    constexpr int VM_KEEP = (R - 2) * IPW * (BA ? 2 : 1);
+
+    // Operand transform of THIS wavefront's own pieces of step `sl_step` (local index), in place in ring slot `tslot`
+    // (XF: act(x * scale + shift); BA: the norm backward, also written out).  It runs one step AHEAD of the MFMAs: the pieces
+    // of step i + 1 are transformed in front of the MFMAs of step i, so that their LDS round trip and the barrier that
+    // publishes them never sit between two steps' matrix work.
+    auto transform = [&](long long sl_step, int tslot) {
+        const long long step = group + sl_step * a.groups;
         if constexpr (XF) {
-            // this wavefront's own rows of the step, in place: act(x * scale + shift); rows past n_valid read as zero
 #pragma unroll
             for (int u = 0; u < IPW; ++u) {
                 const int ii = wave + WAVES * u;
                 const long long row = step * RS + ii * RPI + dsub;
-                f32x4_t *p = ring + (size_t)slot * SLOT_F4 + ii * ISTRIDE + lane;
+                f32x4_t *p = ring + (size_t)tslot * SLOT_F4 + ii * ISTRIDE + lane;
                 f32x4_t v = *p;
                 const bool live = row < n_valid;
                 if (a.xf_act == PHC_ACT_RELU) {
@@ -286,14 +359,58 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
                 }
                 *p = v;
             }
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the in-place writes are done before the barrier releases readers
         }
+        if constexpr (BA) {
+            const f32x4_t cm = *reinterpret_cast<const f32x4_t *>(ba_lds + 4 * dchunk), ci = *reinterpret_cast<const f32x4_t *>(ba_lds + K + 4 * dchunk);
+            const f32x4_t cw = *reinterpret_cast<const f32x4_t *>(ba_lds + 2 * K + 4 * dchunk), cb = *reinterpret_cast<const f32x4_t *>(ba_lds + 3 * K + 4 * dchunk);
+            const f32x4_t cg = *reinterpret_cast<const f32x4_t *>(ba_lds + 4 * K + 4 * dchunk), cgx = *reinterpret_cast<const f32x4_t *>(ba_lds + 5 * K + 4 * dchunk);
+#pragma unroll
+            for (int u = 0; u < IPW; ++u) {
+                const int ii = wave + WAVES * u;
+                const long long row = step * RS + ii * RPI + dsub;
+                f32x4_t *p = ring + (size_t)tslot * SLOT_F4 + ii * ISTRIDE + lane;
+                const f32x4_t gv = *p, xv = p[IMG_F4];
+                f32x4_t o = zero4;
+                if (row < n_valid) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float xh = (xv[q] - cm[q]) * ci[q];
+                        float g = gv[q];
+                        if (a.ba_act == PHC_ACT_RELU)
+                            g = fmaf(xh, cw[q], cb[q]) > 0.f ? g : 0.f;
+                        else if (a.ba_act != PHC_ACT_IDENTITY)
+                            g *= act_grad_rt(a.ba_act, fmaf(xh, cw[q], cb[q]));
+                        o[q] = cw[q] * ci[q] * (g - cg[q] - xh * cgx[q]);
+                    }
+                }
+                *p = o;
+                if (row < a.M) *reinterpret_cast<f32x4_t *>(a.ba_dz + (size_t)row * K + 4 * dchunk) = o;
+            }
+        }
+    };
+    if constexpr (XF || BA) {
+        hs_wait_vm<VM_KEEP>();                                    // DMA(0)
+        transform(0, 0);
+    }
+    int slot = 0;
+    for (long long i = 0; i < my_steps; ++i) {
+        const long long step = group + i * a.groups;
+        if constexpr (XF || BA)
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the in-place writes of step i are done before the barrier releases readers
+        else
+            hs_wait_vm<VM_KEEP>();                                // own DMA pieces of step i
         // after the barrier: every wavefront's pieces of step i are in place, the slot of step i - 1 is free
         __builtin_amdgcn_s_barrier();
         {
             int nslot = slot + R - 1;
             nslot = nslot >= R ? nslot - R : nslot;
             issue_step(i + R - 1, nslot);
+        }
+        if constexpr (XF || BA) {
+            if (i + 1 < my_steps) {
+                hs_wait_vm<VM_KEEP>();                            // DMA(i + 1): R - 2 younger steps in flight behind it
+                transform(i + 1, slot + 1 == R ? 0 : slot + 1);
+            }
         }
         // BW: the norm-input rows the epilogue needs go in flight now, under the MFMAs (clamped, unconditional)
         f32x4_t bwx[BW ? RB : 1][BW ? TPW : 1];

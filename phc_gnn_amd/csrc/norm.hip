@@ -1103,6 +1103,25 @@ static int launch_bwd_apply_acc(const float *dy, const float *x, const float *sa
     return check_launch("bn_bwd_apply_acc");
 }
 
+int phc_bn_bwd_partial_acc(const float *dy, const float *x, const float *save_stat, const int32_t *n_valid_dev, int64_t N, int h,
+                           int act, uint64_t *acc, void *stream) {
+    PHC_REQUIRE(N >= 1 && h >= 4 && h % 4 == 0 && h <= 8192, PHC_ERR_INVALID_ARG, "phc_bn_bwd_partial_acc: N=%lld h=%d", (long long)N, h);
+    PHC_REQUIRE(act >= PHC_ACT_IDENTITY && act <= PHC_ACT_SELU, PHC_ERR_INVALID_ARG, "phc_bn_bwd_partial_acc: unknown activation %d", act);
+    PHC_REQUIRE(dy && x && save_stat && acc, PHC_ERR_INVALID_ARG, "phc_bn_bwd_partial_acc: null pointer");
+    PHC_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0 && (reinterpret_cast<uintptr_t>(acc) & 7) == 0,
+                PHC_ERR_UNSUPPORTED, "phc_bn_bwd_partial_acc: 16-byte aligned rows, 8-byte aligned accumulator");
+    hipStream_t s = (hipStream_t)stream;
+    BnPlan plan = bn_plan(N);
+    BnDrop drop = {};
+    ProfScope prof(K_BN_BWD_PARTIAL, s);
+#define PHC_BN_BPA(ACTC)                                                                                                     \
+    PHC_LAUNCH((bn_bwd_partial_kernel<ACTC, 4>), dim3(plan.num_partials), dim3(BN_THREADS), 0, s, dy, x, save_stat, n_valid_dev,     \
+               (long long)N, h, plan.rows_per_block, reinterpret_cast<float *>(acc), drop, 1)
+    PHC_BN_ACT_SWITCH(act, PHC_BN_BPA)
+#undef PHC_BN_BPA
+    return check_launch("bn_bwd_partial_acc");
+}
+
 int phc_bn_bwd(const float *dy, const float *x, const float *save_stat, const int32_t *n_valid_dev, int64_t N, int h, int training,
                int act, float *dx, float *dwb_flat, void *ws, size_t ws_bytes, float drop_p, int drop_same_k, int drop_site,
                const uint64_t *rng_state, void *stream) {

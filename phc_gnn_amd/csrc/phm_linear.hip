@@ -1139,7 +1139,7 @@ static int launch_hs_cfg(GemmHsArgs a, const XfAcc &xa, hipStream_t s) {
     if (groups > steps) groups = steps;
     if (groups < 1) groups = 1;
     a.groups = (int)groups;
-    const size_t lds = (size_t)R * hs_slot_bytes<K, RB>() + ((FLAGS & HS_XF) ? 2 * (size_t)K * sizeof(float) : 0);
+    const size_t lds = hs_lds_bytes<K, RB, R, FLAGS>();
     static bool attr_set = false;
     if (!attr_set) {
         hipFuncSetAttribute(reinterpret_cast<const void *>(&gemm_hs16_kernel<K, TPW, WAVES, RB, R, FLAGS>),
@@ -1822,6 +1822,48 @@ int phc_gemm_prebuilt_bwsums(const float *dy, const float *M, const float *Mk4, 
         launch_stream_cfg<0, -1, 64, 4, 4>(dy, nullptr, M, nullptr, nullptr, dz, N, K, Nout, 1, K, Nout, 2, s, n_valid_dev, sums_partial,
                                            nullptr, num_partials, nullptr, 0, bn_x, bn_stat, act, acc);
     return check_launch("phc_gemm_prebuilt_bwsums");
+}
+
+// The norm backward's element-wise pass folded into the dx GEMM behind it (HS_BA), optionally with the sums epilogue of the
+// norm in front of that GEMM (HS_BW): see include/phc_hip.h.
+int phc_gemm_bwd_apply_supported(int K, int Nout) {
+    return (hs_enabled() && (K == 128 || K == 256) && (Nout == 128 || Nout == 256)) ? 1 : 0;
+}
+
+int phc_gemm_bwd_apply(const phc_gemm_ba_desc *d, void *stream) {
+    PHC_REQUIRE(d, PHC_ERR_INVALID_ARG, "phc_gemm_bwd_apply: null descriptor");
+    PHC_REQUIRE(d->N >= 1 && phc_gemm_bwd_apply_supported(d->K, d->Nout), PHC_ERR_UNSUPPORTED,
+                "phc_gemm_bwd_apply: N=%lld K=%d Nout=%d outside the fused form's range (K, Nout in {128, 256})", (long long)d->N, d->K, d->Nout);
+    PHC_REQUIRE(d->dout && d->bn_x && d->bn_stat && d->sums_acc && d->dz && d->Mk4 && d->y, PHC_ERR_INVALID_ARG, "phc_gemm_bwd_apply: null pointer");
+    PHC_REQUIRE(d->act >= PHC_ACT_IDENTITY && d->act <= PHC_ACT_SELU, PHC_ERR_INVALID_ARG, "phc_gemm_bwd_apply: unknown activation %d", d->act);
+    const bool bw = d->bw_sums_acc != nullptr;
+    PHC_REQUIRE(!bw || (d->bw_x && d->bw_stat && d->bw_act >= PHC_ACT_IDENTITY && d->bw_act <= PHC_ACT_SELU), PHC_ERR_INVALID_ARG,
+                "phc_gemm_bwd_apply: second-stage sums need bw_x, bw_stat and an activation");
+    PHC_REQUIRE(((reinterpret_cast<uintptr_t>(d->dout) | reinterpret_cast<uintptr_t>(d->bn_x) | reinterpret_cast<uintptr_t>(d->bn_stat) |
+                  reinterpret_cast<uintptr_t>(d->dz) | reinterpret_cast<uintptr_t>(d->Mk4) | reinterpret_cast<uintptr_t>(d->y) |
+                  reinterpret_cast<uintptr_t>(d->bw_x) | reinterpret_cast<uintptr_t>(d->bw_stat)) & 15) == 0 &&
+                    ((reinterpret_cast<uintptr_t>(d->sums_acc) | reinterpret_cast<uintptr_t>(d->bw_sums_acc)) & 7) == 0,
+                PHC_ERR_UNSUPPORTED, "phc_gemm_bwd_apply: 16-byte aligned rows / 8-byte aligned accumulators required");
+    hipStream_t s = (hipStream_t)stream;
+    GemmHsArgs a = hs_args(d->dout, d->Mk4, nullptr, nullptr, d->y, d->N, d->Nout);
+    a.n_valid = d->n_valid_dev;
+    a.ba_x = d->bn_x;
+    a.ba_stat = d->bn_stat;
+    a.ba_acc = reinterpret_cast<const unsigned long long *>(d->sums_acc);
+    a.ba_act = d->act;
+    a.ba_dz = d->dz;
+    a.ba_dwb = d->dwb;
+    ProfScope prof(K_PHM_GEMM_DX, s);
+    if (bw) {
+        a.stat_acc = reinterpret_cast<unsigned long long *>(d->bw_sums_acc);
+        a.bw_x = d->bw_x;
+        a.bw_stat = d->bw_stat;
+        a.bw_act = d->bw_act;
+        launch_hs<HS_BA | HS_BW>(a, d->K, XfAcc{}, s);
+    } else {
+        launch_hs<HS_BA>(a, d->K, XfAcc{}, s);
+    }
+    return check_launch("phc_gemm_bwd_apply");
 }
 
 // ---- batched parameter gradients ------------------------------------------------------------

@@ -61,6 +61,13 @@ class DownstreamDesc(C.Structure):
                 ("partial", _P), ("sync", _P)]
 
 
+class GemmBaDesc(C.Structure):
+    """phc_gemm_ba_desc (include/phc_hip.h)."""
+    _fields_ = [("dout", _P), ("bn_x", _P), ("bn_stat", _P), ("sums_acc", _P), ("n_valid_dev", _P), ("dz", _P), ("dwb", _P),
+                ("Mk4", _P), ("y", _P), ("N", _L), ("K", C.c_int32), ("Nout", C.c_int32), ("act", C.c_int32), ("bw_act", C.c_int32),
+                ("bw_x", _P), ("bw_stat", _P), ("bw_sums_acc", _P)]
+
+
 class TableGradJob(C.Structure):
     """phc_table_grad_job (include/phc_hip.h)."""
     _fields_ = [("dout", _P), ("x", _P), ("tables", _P), ("dtables_flat", _P)]
@@ -89,6 +96,9 @@ SIGNATURES = {
     "phc_gemm_prebuilt_xf_acc": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, C.c_float, C.c_float, _P, _I, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P,
                                       C.POINTER(_I), _P]),
     "phc_gemm_prebuilt_bwsums": (_I, [_P, _P, _P, _L, _I, _I, _P, _P, _P, _I, _P, _P, C.POINTER(_I), _P]),
+    "phc_gemm_bwd_apply_supported": (_I, [_I, _I]),
+    "phc_gemm_bwd_apply": (_I, [C.POINTER(GemmBaDesc), _P]),
+    "phc_bn_bwd_partial_acc": (_I, [_P, _P, _P, _P, _L, _I, _I, _P, _P]),
     "phc_bn_bwd_from_partials": (_I, [_P, _P, _P, _P, _I, _P, _L, _I, _I, _P, _P, _P, _S, _P]),
     "phc_phm_param_grads_ws_bytes": (_S, [C.POINTER(GradJob), _I]),
     "phc_phm_param_grads": (_I, [C.POINTER(GradJob), _I, _P, _S, _P]),

@@ -1893,6 +1893,184 @@ def batch_norm_act(x: torch.Tensor, weights, biases, running_mean, running_var, 
 
 
 # ---------------------------------------------------------------------------
+# PHMMLP + model-level norm of one message-passing layer as ONE autograd node
+# ---------------------------------------------------------------------------
+# x_next = act(norm_o(linear2(act(norm_i(linear1(s)))))) + skip      (layers.py:349-355 inside messagepassing.py:132-146, then
+# models.py:208-215).  Forward: the three launches the separate nodes would issue (GEMM + statistics, GEMM with the inner norm
+# as operand transform + statistics, normalise + activation + skip).  Backward: the two batch-norm backwards' element-wise
+# passes ride in the dx GEMMs behind them (phc_gemm_bwd_apply) — sums of the outer norm, GEMM (outer apply, inner sums), GEMM
+# (inner apply): 3 launches instead of 6, and one [N, h] write + two reads per norm less.
+MLP_NORM_FUSED = __import__("os").environ.get("PHC_MLP_NORM_FUSED", "1") != "0"
+# Where the fused node is the faster one (A/B inside the replayed steps): hidden 256 at 23-27 k rows (zinc_b1024 2.315 -> 2.247 ms,
+# molpcba_b1024 2.885 -> 2.807 ms).  At hidden 128 and 12.9 k rows the two folded GEMMs cost 5.7 us more each than the GEMMs they
+# replace — more than the two element-wise launches they save (0.707 -> 0.743 ms) — so narrower / shorter problems keep the
+# separate nodes.  PHC_MLP_NORM_FUSED_MIN_WORK overrides the rows x width threshold.
+MLP_NORM_FUSED_MIN_WORK = int(__import__("os").environ.get("PHC_MLP_NORM_FUSED_MIN_WORK", str(16384 * 256)))
+
+
+def _zero_acc(dev, h: int):
+    """A zeroed statistics accumulator of width h: a slot of the step's arena, or (outside ``stat_accumulators`` / arena
+    exhausted) a fresh zero tensor."""
+    slot = stat_acc_slot(dev, h)
+    if slot is not None:
+        return slot
+    lib = L.load()
+    return torch.zeros(lib.phc_stat_acc_words(h), dtype=torch.int64, device=dev)
+
+
+class _MLPNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, s, skip, n_valid, meta, A1, W1, b1, A2, W2, b2, *affine):
+        lib = L.load()
+        dev = s.device
+        N, h = s.shape
+        pre1, pre2, inner, outer = meta["pre1"], meta["pre2"], meta["inner"], meta["outer"]
+        act_i, act_o = meta["act_inner"], meta["act_outer"]
+        ni, no = inner["n_comp"], outer["n_comp"]
+        aff_i = affine[:2 * ni] if inner["affine"] else ()
+        aff_o = affine[len(aff_i):] if outer["affine"] else ()
+        sp = L.stream_ptr(dev)
+        z1 = torch.empty((N, h), dtype=torch.float32, device=dev)
+        y2 = torch.empty((N, h), dtype=torch.float32, device=dev)
+        out = torch.empty((N, h), dtype=torch.float32, device=dev)
+        save_i = torch.empty(6 * h, dtype=torch.float32, device=dev)
+        save_o = torch.empty(6 * h, dtype=torch.float32, device=dev)
+        acc1, acc2 = _zero_acc(dev, h), _zero_acc(dev, h)
+        L.check(lib.phc_gemm_prebuilt_stats(L.ptr(s), L.ptr(pre1[0]), L.ptr(pre1[2]), L.ptr(b1), N, h, h, L.ptr(z1), L.ptr(n_valid),
+                                            L.ptr(acc1), None, None, sp), "phc_gemm_prebuilt_stats")
+        L.check(lib.phc_gemm_prebuilt_xf_acc(
+            L.ptr(z1), L.ptr(acc1), _ptr_array(aff_i[:ni]) if aff_i else None, _ptr_array(aff_i[ni:]) if aff_i else None,
+            _ptr_array(inner["running_mean"]), _ptr_array(inner["running_var"]), _ptr_array(inner["nbt"]), ni,
+            float(inner["momentum"]), float(inner["eps"]), L.ptr(save_i), act_i, L.ptr(n_valid), L.ptr(pre2[0]), L.ptr(pre2[2]),
+            L.ptr(b2), N, h, h, L.ptr(y2), L.ptr(acc2), None, None, sp), "phc_gemm_prebuilt_xf_acc")
+        L.check(lib.phc_bn_fwd_from_partials(
+            L.ptr(y2), L.ptr(acc2), None, 0, _ptr_array(aff_o[:no]) if aff_o else None, _ptr_array(aff_o[no:]) if aff_o else None,
+            _ptr_array(outer["running_mean"]), _ptr_array(outer["running_var"]), _ptr_array(outer["nbt"]), no, L.ptr(n_valid), N, h,
+            float(outer["momentum"]), float(outer["eps"]), act_o, L.ptr(skip), L.ptr(out), L.ptr(save_o), 0.0, 0, 0, None, sp),
+            "phc_bn_fwd_from_partials")
+        if L.PROF_ON:
+            L.account("phm_gemm_fwd", 2.0 * N * h * h, 4.0 * (2 * N * h + h * h + h))
+            L.account("phm_gemm_fwd", 2.0 * N * h * h, 4.0 * (2 * N * h + h * h + h))
+            L.account("bn_apply", 2.0 * N * h, 4.0 * N * h * (3 if skip is not None else 2))
+        ctx.save_for_backward(s, z1, y2, save_i, save_o, A1, W1, A2, W2)
+        ctx.meta, ctx.n_valid = meta, n_valid
+        ctx.params = ((A1, W1, b1), (A2, W2, b2))
+        ctx.has_skip = skip is not None
+        ctx.n_aff = (len(aff_i), len(aff_o))
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        lib = L.load()
+        s, z1, y2, save_i, save_o, A1, W1, A2, W2 = ctx.saved_tensors
+        meta, n_valid = ctx.meta, ctx.n_valid
+        pre1, pre2, inner, outer = meta["pre1"], meta["pre2"], meta["inner"], meta["outer"]
+        act_i, act_o = meta["act_inner"], meta["act_outer"]
+        dev = s.device
+        N, h = s.shape
+        sp = L.stream_ptr(dev)
+        dout_ = L.f32c(dout)
+        needs = ctx.needs_input_grad
+        acc_o, acc_i = _zero_acc(dev, h), _zero_acc(dev, h)
+        dy2 = torch.empty((N, h), dtype=torch.float32, device=dev)       # d loss / d y2 (the outer norm's dx)
+        da = torch.empty((N, h), dtype=torch.float32, device=dev)        # d loss / d act(norm_i(z1))
+        dz1 = torch.empty((N, h), dtype=torch.float32, device=dev)       # d loss / d z1 (the inner norm's dx)
+        ds = torch.empty((N, h), dtype=torch.float32, device=dev)
+        dwb_o = torch.empty(2 * h, dtype=torch.float32, device=dev)
+        dwb_i = torch.empty(2 * h, dtype=torch.float32, device=dev)
+        L.check(lib.phc_bn_bwd_partial_acc(L.ptr(dout_), L.ptr(y2), L.ptr(save_o), L.ptr(n_valid), N, h, act_o, L.ptr(acc_o), sp),
+                "phc_bn_bwd_partial_acc")
+        d = L.GemmBaDesc()
+        d.dout, d.bn_x, d.bn_stat, d.sums_acc, d.n_valid_dev = L.ptr(dout_), L.ptr(y2), L.ptr(save_o), L.ptr(acc_o), L.ptr(n_valid)
+        d.dz, d.dwb, d.Mk4, d.y = L.ptr(dy2), L.ptr(dwb_o), L.ptr(pre2[3]), L.ptr(da)
+        d.N, d.K, d.Nout, d.act = N, h, h, act_o
+        d.bw_act, d.bw_x, d.bw_stat, d.bw_sums_acc = act_i, L.ptr(z1), L.ptr(save_i), L.ptr(acc_i)
+        L.check(lib.phc_gemm_bwd_apply(_C.byref(d), sp), "phc_gemm_bwd_apply(outer)")
+        d2 = L.GemmBaDesc()
+        d2.dout, d2.bn_x, d2.bn_stat, d2.sums_acc, d2.n_valid_dev = L.ptr(da), L.ptr(z1), L.ptr(save_i), L.ptr(acc_i), L.ptr(n_valid)
+        d2.dz, d2.dwb, d2.Mk4, d2.y = L.ptr(dz1), L.ptr(dwb_i), L.ptr(pre1[3]), L.ptr(ds)
+        d2.N, d2.K, d2.Nout, d2.act = N, h, h, act_i
+        d2.bw_act, d2.bw_x, d2.bw_stat, d2.bw_sums_acc = 0, None, None, None
+        L.check(lib.phc_gemm_bwd_apply(_C.byref(d2), sp), "phc_gemm_bwd_apply(inner)")
+        if L.PROF_ON:
+            L.account("bn_bwd_partial", 6.0 * N * h, 8.0 * N * h)
+            L.account("phm_gemm_dx", 2.0 * N * h * h, 4.0 * (4 * N * h + h * h))
+            L.account("phm_gemm_dx", 2.0 * N * h * h, 4.0 * (4 * N * h + h * h))
+        # parameter gradients: (z1 through the inner norm, dy2) for linear2, (s, dz1) for linear1
+        (pA1, pW1, pb1), (pA2, pW2, pb2) = ctx.params
+        grads = [None] * 6
+        jobs = []
+        for li, (x_in, dy_in, A, W, b, xf, base) in enumerate(((s, dz1, pA1, pW1, pb1, None, 4), (z1, dy2, pA2, pW2, pb2, (save_i, n_valid, act_i), 7))):
+            nA, nW, nb = needs[base], needs[base + 1], needs[base + 2] and b is not None
+            if not (nA or nW or nb):
+                continue
+            job = dict(x=x_in, dy=dy_in, A=A, W=W, need=(nA, nW, nb), params=(A if nA else None, W if nW else None, b if nb else None))
+            if xf is not None:
+                job["xf"] = xf
+            jobs.append((li, job))
+        if jobs:
+            deferred = _DEFER.active and not torch.is_grad_enabled() and all(p is None or p.is_leaf for _, jb in jobs for p in jb["params"])
+            if deferred:
+                with _DEFER.lock:
+                    _DEFER.jobs.extend(jb for _, jb in jobs)
+            else:
+                for _, jb in jobs:
+                    jb["params"] = (None, None, None)
+                outs = _flush_param_grads([jb for _, jb in jobs], return_grads=True)
+                for (li, _), o in zip(jobs, outs):
+                    grads[3 * li:3 * li + 3] = list(o)
+        aff = []
+        for dwb, nm, cnt in ((dwb_i, inner, ctx.n_aff[0]), (dwb_o, outer, ctx.n_aff[1])):
+            if cnt:
+                n, k = nm["n_comp"], h // nm["n_comp"]
+                aff.extend([dwb[c * k:(c + 1) * k] for c in range(n)])
+                aff.extend([dwb[h + c * k:h + (c + 1) * k] for c in range(n)])
+        return (ds if needs[0] else None, dout if (ctx.has_skip and needs[1]) else None, None, None, *grads, *aff)
+
+
+def _norm_meta(nm):
+    """What the fused kernels need of a NaivePHMNorm (training mode, running statistics, fixed momentum), or None."""
+    mods = list(getattr(nm, "bn", []))
+    if not mods or not getattr(nm, "track_running_stats", False) or nm.momentum is None:
+        return None
+    return dict(n_comp=len(mods), momentum=nm.momentum, eps=nm.eps, affine=bool(nm.affine),
+                running_mean=[m.running_mean for m in mods], running_var=[m.running_var for m in mods],
+                nbt=[m.num_batches_tracked for m in mods],
+                weights=[m.weight for m in mods] if nm.affine else [], biases=[m.bias for m in mods] if nm.affine else [])
+
+
+def mlp_norm_fused(s, skip, n_valid, mlp, outer_norm, activation: str):
+    """``act(outer_norm(mlp(s))) + skip`` for a PHMMLP with an inner naive batch-norm, as one autograd node (training mode),
+    or ``None`` when the preconditions do not hold: both linears square of width 128 or 256 with prebuilt k4 operands (inside
+    ``prebuilt_H``), both norms naive batch-norms with running statistics, fusable activations, 16-byte aligned dense rows."""
+    if not (MLP_NORM_FUSED and _PREBUILT.table and s.is_cuda and s.dim() == 2 and s.dtype == torch.float32 and s.is_contiguous()
+            and s.data_ptr() % 16 == 0 and getattr(mlp, "norm_flag", False) and torch.is_grad_enabled()):
+        return None
+    l1, l2 = mlp.linear1, mlp.linear2
+    N, h = s.shape
+    lib = L.load()
+    if N < 1 or N * h < MLP_NORM_FUSED_MIN_WORK or tuple(l1.W.shape) != tuple(l2.W.shape) or l1.W.shape[0] * l1.W.shape[1] != h \
+            or l1.W.shape[0] * l1.W.shape[2] != h or not lib.phc_gemm_bwd_apply_supported(h, h):
+        return None
+    try:
+        act_i, act_o = L.ACT_IDS[mlp.activation_str.lower()], L.ACT_IDS[activation.lower()]
+    except KeyError:
+        return None
+    inner = _norm_meta(getattr(mlp.norm, "bn", None))
+    outer = _norm_meta(getattr(outer_norm, "bn", None))
+    pre1, pre2 = _prebuilt_for(l1.phm_rule, l1.W), _prebuilt_for(l2.phm_rule, l2.W)
+    if inner is None or outer is None or pre1 is None or pre2 is None or pre1[2] is None or pre2[2] is None:
+        return None
+    if skip is not None and not (skip.is_contiguous() and skip.shape == s.shape and skip.data_ptr() % 16 == 0):
+        return None
+    if any(b is not None and not b.is_contiguous() for b in (l1.b, l2.b)):
+        return None
+    meta = dict(pre1=pre1, pre2=pre2, inner=inner, outer=outer, act_inner=act_i, act_outer=act_o)
+    affine = inner["weights"] + inner["biases"] + outer["weights"] + outer["biases"]
+    return _MLPNormFn.apply(s, skip, n_valid, meta, l1.phm_rule, l1.W, l1.b, l2.phm_rule, l2.W, l2.b, *affine)
+
+
+# ---------------------------------------------------------------------------
 # the downstream head in one launch each way (csrc/downstream.hip)
 # ---------------------------------------------------------------------------
 DOWNSTREAM_FUSED = __import__("os").environ.get("PHC_DOWNSTREAM_FUSED", "1") != "0"
