@@ -551,6 +551,9 @@ typedef struct phc_gemm_ba_desc {
     uint64_t *bw_sums_acc;         /* accumulator of width Nout (zeroed by the caller), or NULL       */
 } phc_gemm_ba_desc;
 int phc_gemm_bwd_apply_supported(int K, int Nout);
+/* Diagnostics only: when set (device buffer, 12 x 8 bytes per wavefront of the largest launch), every H-stationary GEMM launch
+ * stamps its wavefronts' phase clocks there (scripts/dbg/hs_phases.py); NULL (the default) switches it off. */
+int phc_debug_hs_stamps(unsigned long long *dev_words);
 int phc_gemm_bwd_apply(const phc_gemm_ba_desc *d, void *stream);
 /* The sums pass alone: adds sum g | sum g x_hat of (dy, x, save_stat) over the rows below *n_valid_dev into `acc` (width h,
  * zeroed by the caller; h %% 32 == 0, 16-byte aligned rows) — phc_bn_bwd's first launch without its second. */

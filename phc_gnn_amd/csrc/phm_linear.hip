@@ -1129,9 +1129,12 @@ static bool hs_shape_ok(const float *x, const float *Mk4, int64_t N, int K, int 
            ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(Mk4)) & 15) == 0;
 }
 
+static unsigned long long *g_hs_stamps = nullptr;             // diagnostics (phc_debug_hs_stamps): per-wavefront phase clocks
+
 template <int K, int TPW, int WAVES, int FLAGS>
 static int launch_hs_cfg(GemmHsArgs a, const XfAcc &xa, hipStream_t s) {
     constexpr int RB = 1, R = HS_RING;
+    a.stamps = g_hs_stamps;
     a.panels = a.Nout / (16 * TPW * WAVES);
     const long long steps = (a.M + 16 * RB - 1) / (16 * RB);
     static const int per_cu = getenv("PHC_HS_GROUPS_PER_CU") ? atoi(getenv("PHC_HS_GROUPS_PER_CU")) : 1;
@@ -1826,6 +1829,11 @@ int phc_gemm_prebuilt_bwsums(const float *dy, const float *M, const float *Mk4, 
 
 // The norm backward's element-wise pass folded into the dx GEMM behind it (HS_BA), optionally with the sums epilogue of the
 // norm in front of that GEMM (HS_BW): see include/phc_hip.h.
+int phc_debug_hs_stamps(unsigned long long *dev_words) {
+    g_hs_stamps = dev_words;
+    return PHC_OK;
+}
+
 int phc_gemm_bwd_apply_supported(int K, int Nout) {
     return (hs_enabled() && (K == 128 || K == 256) && (Nout == 128 || Nout == 256)) ? 1 : 0;
 }

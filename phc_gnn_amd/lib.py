@@ -97,6 +97,7 @@ SIGNATURES = {
                                       C.POINTER(_I), _P]),
     "phc_gemm_prebuilt_bwsums": (_I, [_P, _P, _P, _L, _I, _I, _P, _P, _P, _I, _P, _P, C.POINTER(_I), _P]),
     "phc_gemm_bwd_apply_supported": (_I, [_I, _I]),
+    "phc_debug_hs_stamps": (_I, [_P]),
     "phc_gemm_bwd_apply": (_I, [C.POINTER(GemmBaDesc), _P]),
     "phc_bn_bwd_partial_acc": (_I, [_P, _P, _P, _P, _L, _I, _I, _P, _P]),
     "phc_bn_bwd_from_partials": (_I, [_P, _P, _P, _P, _I, _P, _L, _I, _I, _P, _P, _P, _S, _P]),
