@@ -715,6 +715,13 @@ int phc_clip_adam_step(const uint64_t *table_dev, const float *const *grads, int
                        float beta2, float eps, float *step_dev, float *scal_dev, float *partial_dev,
                        int write_back_clipped, void *stream);
 
+/* Data-parallel gradient bucket (ABI 4): every gradient tensor of the model -> ONE flat fp32 buffer in ONE launch, scaled by
+ * `scale` (1 / world: the mean of the replicas' gradients folded in in front of the SUM all-reduce).  Tables as phc_clip_adam_step
+ * (the flat offset of tensor t is the offset of its first-moment view from `moments_base`); a NULL gradient packs zeros.  The
+ * optimizer then reads the reduced gradients in place (views of the bucket): no unpack pass. */
+int phc_pack_grads(const uint64_t *table_dev, const float *const *grads, int num_tensors, const int32_t *chunks_dev, int num_chunks,
+                   const float *moments_base, float *out_flat, float scale, void *stream);
+
 /* The explicit weight regulariser of the training scripts (phc/hypercomplex/regularization.py:15-23, added to the loss at
  * benchmarks/train_hiv.py:181-196 with coef = lr * weight_decay; --weightdecay defaults to 0.001, --regularization to 2):
  *   reg = coef * sum_layers mean_{kappa,pi} || W_layer[:, kappa, pi] ||_p ,   p in {1, 2}

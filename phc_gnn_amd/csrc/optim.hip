@@ -136,6 +136,30 @@ __global__ __launch_bounds__(256) void opt_adam_kernel(OptGrads grads, const uns
 }
 
 
+// All gradient tensors of a model -> ONE flat buffer (laid out like the optimizer's flat moment buffers), scaled on the way:
+// the send buffer of the data-parallel all-reduce in one launch, mean folded in (sum_r g_r / W = sum_r (g_r / W)).  A parameter
+// without a gradient contributes zeros.  The flat offset of tensor t is the offset of its first-moment view in exp_avg_flat.
+__global__ __launch_bounds__(256) void opt_pack_kernel(OptGrads grads, const unsigned long long *__restrict__ table,
+                                                     const int *__restrict__ chunks, const float *__restrict__ m_base,
+                                                     float *__restrict__ out, float scale) {
+    const int t = chunks[2 * blockIdx.x], off = chunks[2 * blockIdx.x + 1];
+    const float *g = grads.g[t];
+    const float *m = reinterpret_cast<const float *>(table[4 * t + 1]);
+    const long long numel = (long long)table[4 * t + 3];
+    float *dst = out + (m - m_base);
+    const long long end = min((long long)off + OPT_CHUNK, numel);
+    constexpr int PER = OPT_CHUNK / 256;
+    float gv[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) gv[q] = g ? g[min((long long)off + threadIdx.x + 256 * q, end - 1)] : 0.f;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const long long e = (long long)off + threadIdx.x + 256 * q;
+        if (e < end) dst[e] = gv[q] * scale;
+    }
+}
+
+
 // ---- explicit weight regulariser of the training scripts (phm_weight_regularization) --------------------------------
 // reg = coef * sum over PHM layers of mean_{kappa,pi} || W[:, kappa, pi] ||_p   (regularization.py:15-23: weight.norm(p, dim=0)
 // .mean(); coef = lr * weight_decay, train_hiv.py:181-196).  ONE launch: a workgroup owns 256 (kappa, pi) cells of one layer,
@@ -253,6 +277,21 @@ int phc_clip_adam_step(const uint64_t *table_dev, const float *const *grads, int
                    chunks_dev, chunk_base == 0 ? scal_dev : nullptr, step_dev, partial_dev, total_chunks, max_norm, lr, beta1, beta2,
                    eps, write_back_clipped);
     return check_launch("clip_adam_step");
+}
+
+int phc_pack_grads(const uint64_t *table_dev, const float *const *grads, int num_tensors, const int32_t *chunks_dev, int num_chunks,
+                   const float *moments_base, float *out_flat, float scale, void *stream) {
+    PHC_REQUIRE(num_tensors >= 1 && num_tensors <= OPT_MAX_TENSORS, PHC_ERR_INVALID_ARG, "phc_pack_grads: %d tensors (max %d per call)",
+                num_tensors, OPT_MAX_TENSORS);
+    PHC_REQUIRE(table_dev && grads && chunks_dev && num_chunks >= 1 && moments_base && out_flat, PHC_ERR_INVALID_ARG,
+                "phc_pack_grads: null pointer");
+    OptGrads g;
+    for (int t = 0; t < num_tensors; ++t) g.g[t] = grads[t];
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(K_CLIP_ADAM, s);
+    PHC_LAUNCH(opt_pack_kernel, dim3(num_chunks), dim3(256), 0, s, g, reinterpret_cast<const unsigned long long *>(table_dev), chunks_dev,
+               moments_base, out_flat, scale);
+    return check_launch("opt_pack");
 }
 
 int phc_phm_weight_reg_max_jobs(void) { return REG_MAX_JOBS; }

@@ -33,9 +33,15 @@ import torch.distributed as dist
 # 1. data-parallel graph batches: one flat gradient bucket
 # ---------------------------------------------------------------------------------------------
 class FlatGradSync:
-    """All-reduce (mean) of every parameter gradient through ONE contiguous fp32 bucket."""
+    """All-reduce (mean) of every parameter gradient through ONE contiguous fp32 bucket.
 
-    def __init__(self, params: Sequence[torch.nn.Parameter], group=None, average: bool = True):
+    With the engine's optimizer (``optimizer=ClipAdam`` over the same parameters, on the GPU) the bucket is the optimizer's own
+    flat gradient buffer: ONE engine launch packs every ``.grad`` into it with the 1 / world of the mean folded in
+    (``phc_pack_grads``), the all-reduce runs in place, and the parameters' ``.grad`` become views of the bucket — the
+    clip + Adam launches read the reduced values where the collective left them: no unpack pass, no separate division.
+    Without it (CPU tensors under gloo, ``torch.optim`` optimizers): ``torch.cat`` / ``_foreach_copy_`` / ``_foreach_div_``."""
+
+    def __init__(self, params: Sequence[torch.nn.Parameter], group=None, average: bool = True, optimizer=None):
         """``average=True``: data-parallel replicas (mean of the per-replica gradients); ``average=False``: shards of
         ONE batch (config 5: every rank holds the partial sums over its own rows; the gradient is their plain sum)."""
         self.params = [p for p in params if p.requires_grad]
@@ -44,8 +50,15 @@ class FlatGradSync:
         self.average = bool(average)
         self.sizes = [p.numel() for p in self.params]
         self.flat: Optional[torch.Tensor] = None
+        self.opt = None
+        if optimizer is not None and hasattr(optimizer, "pack_grads") and all(p.is_cuda for p in self.params) and \
+                len(optimizer.params) == len(self.params) and all(a is b for a, b in zip(optimizer.params, self.params)):
+            self.opt = optimizer
 
     def pack(self) -> torch.Tensor:
+        if self.opt is not None:
+            self.flat = self.opt.pack_grads(1.0 / self.world if self.average else 1.0)
+            return self.flat
         grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in self.params]
         if self.flat is None:
             self.flat = torch.empty(sum(self.sizes), dtype=torch.float32, device=grads[0].device)
@@ -56,6 +69,9 @@ class FlatGradSync:
         dist.all_reduce(self.flat, op=dist.ReduceOp.SUM, group=self.group)
 
     def unpack(self) -> None:
+        if self.opt is not None:
+            self.opt.adopt_bucket_grads()                       # views of the bucket: nothing to launch
+            return
         chunks = self.flat.split(self.sizes)
         with torch.no_grad():
             for p, c in zip(self.params, chunks):

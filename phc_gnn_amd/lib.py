@@ -111,6 +111,7 @@ SIGNATURES = {
     "phc_downstream_partial_floats": (_S, [_L]),
     "phc_downstream_fwd": (_I, [C.POINTER(DownstreamDesc), _P]),
     "phc_downstream_bwd": (_I, [C.POINTER(DownstreamDesc), _P]),
+    "phc_pack_grads": (_I, [_P, _P, _I, _P, _I, _P, _P, C.c_float, _P]),
     "phc_phm_weight_reg_max_jobs": (_I, []),
     "phc_phm_weight_reg_max_blocks": (_I, []),
     "phc_phm_weight_reg_ws_bytes": (_S, []),

@@ -112,6 +112,42 @@ class ClipAdam:
                 call(grp, arr, 4)
         return self.scalars[0]
 
+    # -- data-parallel gradient bucket (phc_gnn_amd.dist.FlatGradSync) ---------------------------------
+    def grad_bucket(self) -> torch.Tensor:
+        """The flat fp32 buffer (same layout as the moment buffers) the gradients are packed into / reduced in / read from."""
+        if getattr(self, "_grad_flat", None) is None:
+            self._grad_flat = torch.zeros_like(self.exp_avg_flat)
+            self._grad_views, off = [], 0
+            for p in self.params:
+                self._grad_views.append(self._grad_flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+        return self._grad_flat
+
+    @torch.no_grad()
+    def pack_grads(self, scale: float = 1.0) -> torch.Tensor:
+        """All ``.grad`` tensors -> the bucket, times ``scale``, one launch per parameter group (a missing gradient packs zeros)."""
+        lib = L.load()
+        self._check_tables()
+        flat = self.grad_bucket()
+        stream = L.stream_ptr(self.device)
+        for grp in self.groups:
+            arr = (C.c_void_p * len(grp["idx"]))()
+            for t, i in enumerate(grp["idx"]):
+                g = self.params[i].grad
+                if g is not None and not g.is_contiguous():
+                    g = g.contiguous()
+                    self.params[i].grad = g
+                arr[t] = g.data_ptr() if g is not None else None
+            L.check(lib.phc_pack_grads(L.ptr(grp["table"]), arr, len(grp["idx"]), L.ptr(grp["chunks"]), grp["num_chunks"],
+                                       L.ptr(self.exp_avg_flat), L.ptr(flat), float(scale), stream), "phc_pack_grads")
+        return flat
+
+    def adopt_bucket_grads(self) -> None:
+        """``p.grad`` := the parameter's view of the bucket (no copy, no launch): the optimizer step reads the reduced values in place."""
+        self.grad_bucket()
+        for p, v in zip(self.params, self._grad_views):
+            p.grad = v
+
     def state_dict(self) -> dict:
         return dict(step=self.step_count.clone(), exp_avg=self.exp_avg_flat.clone(), exp_avg_sq=self.exp_avg_sq_flat.clone(),
                     lr=self.lr, betas=self.betas, eps=self.eps, max_norm=self.max_norm)

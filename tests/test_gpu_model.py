@@ -483,7 +483,7 @@ def test_graphed_data_parallel_step_single_rank(rccl_single_rank):
     results = []
     for use_sync in (False, True):
         m, o = _fresh(wl, seed=2)
-        sync = FlatGradSync(list(m.parameters())) if use_sync else None
+        sync = FlatGradSync(list(m.parameters()), optimizer=o) if use_sync else None
         step = graphed.GraphedTrainStep(m, o, harness.StepConfig(), padded[0], grad_sync=sync, warmup=2)
         m.load_state_dict(_fresh(wl, seed=2)[0].state_dict())
         _reset_adam_in_place(o)
@@ -493,6 +493,40 @@ def test_graphed_data_parallel_step_single_rank(rccl_single_rank):
     for k, v in results[0][1].items():
         if v.is_floating_point():
             assert_close(results[1][1][k], v, 1e-5, k)
+
+
+def test_graphed_data_parallel_step_with_the_engine_gradient_bucket(rccl_single_rank):
+    """The data-parallel step with the engine optimizer: gradients packed into ClipAdam's flat bucket by ONE launch
+    (phc_pack_grads, mean folded in), all-reduced in place, read by clip + Adam as views of the bucket (no unpack) — on a
+    1-rank RCCL group it must reproduce the single-graph step: losses over 4 steps, parameters, Adam moments."""
+    from phc_gnn_amd import graphed, harness
+    from phc_gnn_amd.dist import FlatGradSync
+    from phc_gnn_amd.optim import ClipAdam
+    wl = "molhiv_b32"
+    gbs = [harness.make_batch(wl, seed=s) for s in (11, 12)]
+    n_max, e_max = graphed.bucket_shape(gbs)
+    padded = [graphed.padded_to_device(graphed.pad_batch(g, n_max, e_max), DEV) for g in gbs]
+    results = []
+    for use_sync in (False, True):
+        m = _fresh(wl, seed=2)[0]
+        o = ClipAdam(m.parameters(), lr=1e-3)
+        sync = FlatGradSync(list(m.parameters()), optimizer=o) if use_sync else None
+        assert sync is None or sync.opt is o                     # the engine path, not torch.cat / _foreach_copy_
+        step = graphed.GraphedTrainStep(m, o, harness.StepConfig(weight_decay=1e-3), padded[0], grad_sync=sync, warmup=2)
+        m.load_state_dict(_fresh(wl, seed=2)[0].state_dict())
+        o.step_count.zero_(); o.exp_avg_flat.zero_(); o.exp_avg_sq_flat.zero_()
+        losses = [float(step.step(p)) for p in padded + padded]
+        torch.cuda.synchronize()
+        if use_sync:                                             # the parameters' .grad ARE the bucket
+            flat = o.grad_bucket()
+            assert all(p.grad.data_ptr() >= flat.data_ptr() and p.grad.data_ptr() < flat.data_ptr() + 4 * flat.numel() for p in m.parameters())
+        results.append((losses, {k: v.clone() for k, v in m.state_dict().items()}, o.exp_avg_flat.clone(), o.exp_avg_sq_flat.clone()))
+    assert results[0][0] == pytest.approx(results[1][0], rel=1e-6)
+    for k, v in results[0][1].items():
+        if v.is_floating_point():
+            assert_close(results[1][1][k], v, 1e-5, k)
+    assert_close(results[1][2], results[0][2], 1e-5, "first moments")
+    assert_close(results[1][3], results[0][3], 1e-5, "second moments")
 
 
 def test_g5b_softmax_conv_layers():
