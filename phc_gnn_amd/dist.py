@@ -224,6 +224,18 @@ class EngineBackend:
     def linear_dx(self, dy, A, W):
         return self._ops.phm_linear_dx_raw(dy, A, W)
 
+    # operand matrices built once per layer call (one launch for both linears): the H-stationary GEMM's k4 forms included
+    def build_operands(self, pairs):
+        ok = all((W.shape[0] * W.shape[1]) % 4 == 0 and (W.shape[0] * W.shape[2]) % 4 == 0 and W.shape[0] * W.shape[1] <= 256
+                 and W.shape[0] * W.shape[2] <= 256 for _, W in pairs)
+        return self._ops.phm_build_operands(pairs) if ok else None
+
+    def linear_fwd_pre(self, x, pre, b):
+        return self._ops.phm_linear_pre(x, pre, b)
+
+    def linear_dx_pre(self, dy, pre):
+        return self._ops.phm_linear_pre(dy, pre, None, dx=True)
+
     def linear_param_grads(self, x, dy, A, W, has_bias):
         return self._ops.phm_linear_param_grads_raw(x, dy, A, W, has_bias)
 
@@ -430,7 +442,10 @@ class _ShardedGINEFn(torch.autograd.Function):
         act_msg, act = layer.msg_encoder, mlp.activation_str
         x_own = x_own.contiguous()
         s, recv = agg.forward_raw(x_own, ea_loc, ea_halo, act_msg, layer.conv.add_self_loops)
-        z = be.linear_fwd(s, A1, W1, b1)
+        build = getattr(be, "build_operands", None)
+        pre = build([(A1, W1), (A2, W2)]) if build is not None else None      # engine: H, H^T (+ k4 forms) of both linears
+        ctx.pre = pre
+        z = be.linear_fwd_pre(s, pre[0], b1) if pre is not None else be.linear_fwd(s, A1, W1, b1)
         if mlp.norm_flag:
             norm = mlp.norm.bn
             mom = be.bn_moments(z)
@@ -441,7 +456,7 @@ class _ShardedGINEFn(torch.autograd.Function):
         else:
             save_stat = z.new_empty(0)
             a = layer.act_fn(z)
-        y = be.linear_fwd(a, A2, W2, b2)
+        y = be.linear_fwd_pre(a, pre[1], b2) if pre is not None else be.linear_fwd(a, A2, W2, b2)
         ctx.layer = layer
         ctx.has_ea = (ea_loc is not None, ea_halo is not None)
         ctx.has_bias = (b1 is not None, b2 is not None)
@@ -461,7 +476,8 @@ class _ShardedGINEFn(torch.autograd.Function):
         ea_loc = ea_loc if ctx.has_ea[0] else None
         ea_halo = ea_halo if ctx.has_ea[1] else None
         dy = dy.contiguous()
-        da = be.linear_dx(dy, A2, W2)
+        pre = ctx.pre
+        da = be.linear_dx_pre(dy, pre[1]) if pre is not None else be.linear_dx(dy, A2, W2)
         if mlp.norm_flag:
             dwb = be.bn_bwd_sums(da, z, save_stat, act)                       # this rank's partial dweight | dbias
             dwb_all = dwb.clone()
@@ -470,7 +486,7 @@ class _ShardedGINEFn(torch.autograd.Function):
         else:
             dwb = None
             dz = layer.act_bwd(z, da)
-        ds = be.linear_dx(dz, A1, W1)
+        ds = be.linear_dx_pre(dz, pre[0]) if pre is not None else be.linear_dx(dz, A1, W1)
         need_dea = (ctx.needs_input_grad[2] and ea_loc is not None, ctx.needs_input_grad[3] and ea_halo is not None)
 
         def param_grads():                                                    # queued while the halo gradients travel

@@ -824,6 +824,47 @@ def dense_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
     return _PHMLinearFn.apply(x, _one(dev), weight.t().unsqueeze(0), bias, None, None)
 
 
+def phm_build_operands(pairs):
+    """[(H, H^T, Hk4, H^Tk4)] of the listed (phm_rule, W) pairs, assembled by ONE launch (phc_phm_build_H_batched) — the
+    operand forms of ``phm_linear_pre`` / ``phm_linear_dx_pre`` (no autograd; the sharded layer of dist.py keeps its own)."""
+    lib = L.load()
+    if not pairs:
+        return []
+    dev = L.require_device(*[t for pr in pairs for t in pr])
+    total = sum(4 * (W.shape[0] * W.shape[1]) * (W.shape[0] * W.shape[2]) for _, W in pairs)
+    flat = torch.empty(total, dtype=torch.float32, device=dev)
+    arr = (L.HJob * len(pairs))()
+    out, off = [], 0
+    for i, (A, W) in enumerate(pairs):
+        n, kin, kout = W.shape
+        if (n * kin) % 4 or (n * kout) % 4:
+            raise L.PhcError("phm_build_operands: widths must be multiples of 4")
+        sz = (n * kin) * (n * kout)
+        H, HT = flat[off:off + sz].view(n * kin, n * kout), flat[off + sz:off + 2 * sz].view(n * kout, n * kin)
+        Hk4, HTk4 = flat[off + 2 * sz:off + 3 * sz], flat[off + 3 * sz:off + 4 * sz]
+        off += 4 * sz
+        arr[i] = L.HJob(L.ptr(L.f32c(A.detach())), L.ptr(L.f32c(W.detach())), L.ptr(H), L.ptr(HT), n, kin, kout, 0, L.ptr(Hk4), L.ptr(HTk4))
+        out.append((H, HT, Hk4, HTk4))
+    L.check(lib.phc_phm_build_H_batched(arr, len(pairs), L.stream_ptr(dev)), "phc_phm_build_H_batched")
+    return out
+
+
+def phm_linear_pre(x: torch.Tensor, pre, bias: Optional[torch.Tensor], dx: bool = False) -> torch.Tensor:
+    """y = x . H + bias (``dx=False``) or dx = x . H^T (``dx=True``, bias ignored) on prebuilt operands (``phm_build_operands``):
+    the H-stationary GEMM where it serves the shape, the LDS-staged one otherwise.  No autograd bookkeeping."""
+    lib = L.load()
+    dev = L.require_device(x)
+    x_ = L.f32c(x)
+    M, Mk4 = (pre[1], pre[3]) if dx else (pre[0], pre[2])
+    K, Nout = M.shape
+    y = torch.empty((x_.shape[0], Nout), dtype=torch.float32, device=dev)
+    L.check(lib.phc_gemm_prebuilt(L.ptr(x_), L.ptr(M), L.ptr(Mk4), None if (dx or bias is None) else L.ptr(L.f32c(bias)), None, x_.shape[0], K, Nout, L.ptr(y),
+                                  1 if dx else 0, L.stream_ptr(dev)), "phc_gemm_prebuilt")
+    if L.PROF_ON:
+        L.account("phm_gemm_dx" if dx else "phm_gemm_fwd", 2.0 * x_.shape[0] * K * Nout, 4.0 * (x_.shape[0] * (K + Nout) + K * Nout))
+    return y
+
+
 def phm_build_H(phm_rule: torch.Tensor, W: torch.Tensor) -> torch.Tensor:
     """Materialise H = Σ_i A_i ⊗ W_i  [n*kin, n*kout] (inspection / tests; not differentiable)."""
     lib = L.load()
