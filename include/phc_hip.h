@@ -250,7 +250,7 @@ int phc_aggregate_softmax_bwd_self(const float *dout, const float *out, const fl
 /* The softmax aggregation with the bond embedding read in place (N1 on the N2 operators): instead of an [E, h] edge
  * tensor the kernels take the packed table rows of every edge (phc_pack_edge_codes) and the n*F table pointers, as
  * phc_aggregate_encp_fwd does for the sum.  Forward: codes_sorted in destination-sorted order (perm = the CSR's perm).
- * Backward: codes_orig in ORIGINAL edge order (phc_pack_edge_codes with perm = NULL); dea [E, n*k] (original order,
+ * Backward: codes_src in SOURCE-sorted order (phc_pack_edge_codes with perm = perm_t); dea [E, n*k] (original order,
  * may be NULL) is the gradient of the embedded edge features, from which phc_encode_bwd[_batched] makes the table
  * gradients.  out_self / self_n_dst as in the *_self forms.  Needs F <= 4, sum(vocab) <= 256, k % 4 == 0. */
 int phc_aggregate_softmax_enc_fwd(const float *x, const uint32_t *codes_sorted, const float *const *tables,
@@ -258,7 +258,7 @@ int phc_aggregate_softmax_enc_fwd(const float *x, const uint32_t *codes_sorted, 
                                   const float *beta_dev, int64_t n_dst, int act, float *out, float *out_self, float *lse,
                                   void *stream);
 int phc_aggregate_softmax_enc_bwd(const float *dout, const float *out, const float *lse, const float *x,
-                                  const uint32_t *codes_orig, const float *const *tables, const int32_t *vocab, int F,
+                                  const uint32_t *codes_src, const float *const *tables, const int32_t *vocab, int F,
                                   int n, int k, const float *beta_dev, const int32_t *rowptr_t, const int32_t *col_t,
                                   const int32_t *perm_t, int64_t n_src, int act, int64_t self_n_dst, float *dx,
                                   float *dea, float *dbeta_partial, void *stream);

@@ -251,6 +251,12 @@ __global__ __launch_bounds__(ENC_THREADS) void aggregate_encp_fwd_kernel(
 // every workgroup a pointer-table hop, a table round trip and two barriers before its first row (about half of an 11 us
 // launch when a workgroup owns only a handful of rows); here every wavefront owns ONE row and reads the F table rows of an
 // edge from L2 in the same round trip as the edge's source row: rowptr | table pointers -> col, codes -> rows -> store.
+// Work split: a wavefront holds G = 64/LPR lane groups and every lane group owns a row of its own (at a molecule's degree of
+// two a row split over the groups is one edge per group, a cross-group sum, and twice the wavefronts — two resident sets
+// instead of one).  A row with more than AGG_HEAVY edges is left to the whole wavefront afterwards, its edges dealt over the
+// groups (a hub walked by one group alone would hold its wavefront for as long as the rest of the launch takes).
+constexpr int AGG_HEAVY = 16;
+
 template <int LPR, int ACT, int F>
 __global__ __launch_bounds__(ENC_THREADS) void aggregate_encp_direct_fwd_kernel(
     const float *__restrict__ x, const unsigned *__restrict__ codes, const float *const *__restrict__ tables, EncMeta m,
@@ -260,43 +266,119 @@ __global__ __launch_bounds__(ENC_THREADS) void aggregate_encp_direct_fwd_kernel(
     constexpr int G = WAVE / LPR;
     const int lane = threadIdx.x & 63;
     const int grp = lane / LPR, li = lane - grp * LPR;
-    const long long d = ((long long)blockIdx.x * ENC_THREADS + threadIdx.x) >> 6;
-    if (d >= n_dst) return;                                  // wave-uniform
-    const int e_begin = rowptr[d], e_end = rowptr[d + 1];
-    for (int c4 = li; c4 < h4; c4 += LPR) {
-        const int c = (c4 * 4) / k, kk = c4 * 4 - c * k;
-        const float *tp[F];                                  // this lane's slice of its component's F tables
+    const long long d0 = (((long long)xcd_contiguous_block(blockIdx.x, gridDim.x) * ENC_THREADS + threadIdx.x) >> 6) * G;
+    if (d0 >= n_dst) return;                                 // wave-uniform
+    // one row: edges e0 + first, e0 + first + step, ... of [e0, e1); coop = the groups of the wavefront share the row
+    auto row = [&](long long d, int e0, int e1, int first, int step, bool coop) {
+        for (int c4 = li; c4 < h4; c4 += LPR) {
+            const int c = (c4 * 4) / k, kk = c4 * 4 - c * k;
+            const float *tp[F];                              // this lane's slice of its component's F tables
 #pragma unroll
-        for (int f = 0; f < F; ++f) tp[f] = tables[c * F + f] + kk - (size_t)m.off[f] * k;      // codes hold off_f + value
-        const float4 selfv = reinterpret_cast<const float4 *>(x + (add_self ? (size_t)d * h : 0))[c4];
-        float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
-        auto message = [&](int s, unsigned code) {
-            float4 v = reinterpret_cast<const float4 *>(x + (size_t)s * h)[c4];
+            for (int f = 0; f < F; ++f) tp[f] = tables[c * F + f] + kk - (size_t)m.off[f] * k;  // codes hold off_f + value
+            const float4 selfv = reinterpret_cast<const float4 *>(x + (add_self ? (size_t)d * h : 0))[c4];
+            float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
+            auto message = [&](int s, unsigned code) {
+                float4 v = reinterpret_cast<const float4 *>(x + (size_t)s * h)[c4];
 #pragma unroll
-            for (int f = 0; f < F; ++f) acc4(v, *reinterpret_cast<const float4 *>(tp[f] + (size_t)((code >> (8 * f)) & 255u) * k));
-            v.x = act_fwd<ACT>(v.x); v.y = act_fwd<ACT>(v.y); v.z = act_fwd<ACT>(v.z); v.w = act_fwd<ACT>(v.w);
-            return v;
-        };
-        int e = e_begin + grp;
-        if (e_begin < e_end) {                               // wave-uniform: first two edges per lane group, clamped indices
-            const int i0 = min(e, e_end - 1), i1 = min(e + G, e_end - 1);
-            const int s0 = col[i0], s1 = col[i1];
-            const unsigned k0 = codes[i0], k1 = codes[i1];
-            const float4 v0 = message(s0, k0), v1 = message(s1, k1);
-            if (e < e_end) acc4(acc0, v0);
-            if (e + G < e_end) acc4(acc1, v1);
-            e += 2 * G;
+                for (int f = 0; f < F; ++f) acc4(v, *reinterpret_cast<const float4 *>(tp[f] + (size_t)((code >> (8 * f)) & 255u) * k));
+                v.x = act_fwd<ACT>(v.x); v.y = act_fwd<ACT>(v.y); v.z = act_fwd<ACT>(v.z); v.w = act_fwd<ACT>(v.w);
+                return v;
+            };
+            int e = e0 + first;
+            if (e0 < e1) {                                   // the first two edges travel together (clamped indices)
+                const int i0 = min(e, e1 - 1), i1 = min(e + step, e1 - 1);
+                const int s0 = col[i0], s1 = col[i1];
+                const unsigned k0 = codes[i0], k1 = codes[i1];
+                const float4 v0 = message(s0, k0), v1 = message(s1, k1);
+                if (e < e1) acc4(acc0, v0);
+                if (e + step < e1) acc4(acc1, v1);
+                e += 2 * step;
+            }
+            for (; e < e1; e += step) acc4(acc0, message(col[e], codes[e]));
+            float4 acc = make_float4(acc0.x + acc1.x, acc0.y + acc1.y, acc0.z + acc1.z, acc0.w + acc1.w);
+            if (coop) {
+#pragma unroll
+                for (int off = LPR; off < WAVE; off <<= 1) {
+                    acc.x += __shfl_xor(acc.x, off, WAVE); acc.y += __shfl_xor(acc.y, off, WAVE);
+                    acc.z += __shfl_xor(acc.z, off, WAVE); acc.w += __shfl_xor(acc.w, off, WAVE);
+                }
+            }
+            if (!coop || grp == 0) {
+                if (add_self) acc4(acc, selfv);
+                reinterpret_cast<float4 *>(out + (size_t)d * h)[c4] = acc;
+            }
         }
-        for (; e < e_end; e += G) acc4(acc0, message(col[e], codes[e]));
-        float4 acc = make_float4(acc0.x + acc1.x, acc0.y + acc1.y, acc0.z + acc1.z, acc0.w + acc1.w);
-#pragma unroll
-        for (int off = LPR; off < WAVE; off <<= 1) {
-            acc.x += __shfl_xor(acc.x, off, WAVE); acc.y += __shfl_xor(acc.y, off, WAVE);
-            acc.z += __shfl_xor(acc.z, off, WAVE); acc.w += __shfl_xor(acc.w, off, WAVE);
+    };
+    const long long d = d0 + grp;
+    const bool valid = d < n_dst;
+    const int e_begin = valid ? rowptr[d] : 0, e_end = valid ? rowptr[d + 1] : 0;
+    const bool heavy = G > 1 && e_end - e_begin > AGG_HEAVY;
+    if (valid && !heavy) row(d, e_begin, e_end, 0, 1, false);
+    if (G > 1) {
+        const unsigned long long hb = __ballot(heavy);
+        if (hb) {
+            for (int g = 0; g < G; ++g) {
+                const int eb = __shfl(e_begin, g * LPR, WAVE), ee = __shfl(e_end, g * LPR, WAVE);
+                if ((hb >> (g * LPR)) & 1ull) row(d0 + g, eb, ee, grp, G, true);
+            }
         }
-        if (grp == 0) {
-            if (add_self) acc4(acc, selfv);
-            reinterpret_cast<float4 *>(out + (size_t)d * h)[c4] = acc;
+    }
+}
+
+// dx of the same aggregation for an identity message function on a molecule batch (dx[s] = sum of dout over the out-edges
+// of s, + dout[s] for the self loop): one source row per lane group as above, no tables, no x.
+template <int LPR>
+__global__ __launch_bounds__(ENC_THREADS) void aggregate_dx_rows_kernel(
+    const float *__restrict__ dout, const int *__restrict__ rowptr_t, const int *__restrict__ col_t, long long n_src,
+    long long n_dst, int h, int add_self, float *__restrict__ dx) {
+    const int h4 = h >> 2;
+    constexpr int G = WAVE / LPR;
+    const int lane = threadIdx.x & 63;
+    const int grp = lane / LPR, li = lane - grp * LPR;
+    const long long s0 = (((long long)xcd_contiguous_block(blockIdx.x, gridDim.x) * ENC_THREADS + threadIdx.x) >> 6) * G;
+    if (s0 >= n_src) return;                                 // wave-uniform
+    auto row = [&](long long s, int e0, int e1, int first, int step, bool coop) {
+        for (int c4 = li; c4 < h4; c4 += LPR) {
+            const bool self_on = add_self && s < n_dst;      // the self row goes in flight first (pointer select, no branch)
+            const float4 selfv = reinterpret_cast<const float4 *>(dout + (self_on ? (size_t)s * h : 0))[c4];
+            float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+            int e = e0 + first;
+            if (e0 < e1) {                                   // both column indices in one round trip, both rows in the next
+                const int i0 = min(e, e1 - 1), i1 = min(e + step, e1 - 1);
+                const int t0 = col_t[i0], t1 = col_t[i1];
+                const float4 g0 = reinterpret_cast<const float4 *>(dout + (size_t)t0 * h)[c4];
+                const float4 g1 = reinterpret_cast<const float4 *>(dout + (size_t)t1 * h)[c4];
+                const bool h0 = e < e1, h1 = e + step < e1;
+                acc.x += (h0 ? g0.x : 0.f) + (h1 ? g1.x : 0.f); acc.y += (h0 ? g0.y : 0.f) + (h1 ? g1.y : 0.f);
+                acc.z += (h0 ? g0.z : 0.f) + (h1 ? g1.z : 0.f); acc.w += (h0 ? g0.w : 0.f) + (h1 ? g1.w : 0.f);
+                e += 2 * step;
+            }
+            for (; e < e1; e += step) acc4(acc, reinterpret_cast<const float4 *>(dout + (size_t)col_t[e] * h)[c4]);
+            if (coop) {
+#pragma unroll
+                for (int off = LPR; off < WAVE; off <<= 1) {
+                    acc.x += __shfl_xor(acc.x, off, WAVE); acc.y += __shfl_xor(acc.y, off, WAVE);
+                    acc.z += __shfl_xor(acc.z, off, WAVE); acc.w += __shfl_xor(acc.w, off, WAVE);
+                }
+            }
+            if (!coop || grp == 0) {
+                if (self_on) acc4(acc, selfv);
+                reinterpret_cast<float4 *>(dx + (size_t)s * h)[c4] = acc;
+            }
+        }
+    };
+    const long long s = s0 + grp;
+    const bool valid = s < n_src;
+    const int e_begin = valid ? rowptr_t[s] : 0, e_end = valid ? rowptr_t[s + 1] : 0;
+    const bool heavy = G > 1 && e_end - e_begin > AGG_HEAVY;
+    if (valid && !heavy) row(s, e_begin, e_end, 0, 1, false);
+    if (G > 1) {
+        const unsigned long long hb = __ballot(heavy);
+        if (hb) {
+            for (int g = 0; g < G; ++g) {
+                const int eb = __shfl(e_begin, g * LPR, WAVE), ee = __shfl(e_end, g * LPR, WAVE);
+                if ((hb >> (g * LPR)) & 1ull) row(s0 + g, eb, ee, grp, G, true);
+            }
         }
     }
 }
@@ -322,7 +404,7 @@ __global__ __launch_bounds__(ENC_THREADS) void aggregate_enc_dx_kernel(
     constexpr int G = WAVE / LPR;
     const int lane = threadIdx.x & 63;
     const int grp = lane / LPR, li = lane - grp * LPR;
-    const long long wave_id = ((long long)blockIdx.x * ENC_THREADS + threadIdx.x) >> 6;
+    const long long wave_id = ((long long)xcd_contiguous_block(blockIdx.x, gridDim.x) * ENC_THREADS + threadIdx.x) >> 6;
     const long long n_waves = ((long long)gridDim.x * ENC_THREADS) >> 6;
     const int F = m.F;
     for (long long s = wave_id; s < n_src; s += n_waves) {
@@ -1500,10 +1582,11 @@ int phc_aggregate_encp_fwd(const float *x, const uint32_t *codes, const float *c
     const long long cap = n_dst > 64 * 1024 ? 16384 : 2048;
     if (blocks > cap) blocks = cap;
     const int lpr = lpr_for(h >> 2);
+    const int rows_per_wg = 4 * (WAVE / lpr);                 // direct form: one row per lane group
+    const long long dblocks = xcd_grid((n_dst + rows_per_wg - 1) / rows_per_wg);      // a multiple of 8: one contiguous row range per XCD
     // molecule batches: one wavefront per row, tables read from L2 (no LDS staging); large graphs amortise the staging
     static const long long direct_max = getenv("PHC_ENCP_DIRECT_MAX") ? atoll(getenv("PHC_ENCP_DIRECT_MAX")) : 32768;
     const bool direct = n_dst <= direct_max;
-    const long long dblocks = (n_dst + 3) / 4;
     ProfScope prof(K_AGG_ENC_FWD, s);
 #define PHC_AP_LAUNCH(LPRC, ACTC, FC)                                                                                     \
     if (direct)                                                                                                           \
@@ -1570,8 +1653,20 @@ int phc_aggregate_enc_bwd(const float *dout, const float *x, const int64_t *bond
         long long blocks = (n_src + 3) / 4;
         const long long cap = n_src > 64 * 1024 ? 16384 : (act == PHC_ACT_IDENTITY ? 8192 : 1024);   // large graphs: see encp_fwd
         if (blocks > cap) blocks = cap;
+        blocks = xcd_grid(blocks);
         const int lpr = lpr_for(h >> 2);
         ProfScope prof(K_AGG_ENC_DX, s);
+        static const long long rows_max = getenv("PHC_ENCP_DIRECT_MAX") ? atoll(getenv("PHC_ENCP_DIRECT_MAX")) : 32768;
+        if (act == PHC_ACT_IDENTITY && n_src <= rows_max) {                   // molecule batches: one source row per lane group
+            const int rows_per_wg = 4 * (WAVE / lpr);
+            const unsigned rb = (unsigned)xcd_grid((n_src + rows_per_wg - 1) / rows_per_wg);
+            switch (lpr) {
+                case 8: PHC_LAUNCH((aggregate_dx_rows_kernel<8>), dim3(rb), dim3(ENC_THREADS), 0, s, dout, rowptr_t, col_t, (long long)n_src, (long long)n_dst, h, add_self, dx); break;
+                case 16: PHC_LAUNCH((aggregate_dx_rows_kernel<16>), dim3(rb), dim3(ENC_THREADS), 0, s, dout, rowptr_t, col_t, (long long)n_src, (long long)n_dst, h, add_self, dx); break;
+                case 32: PHC_LAUNCH((aggregate_dx_rows_kernel<32>), dim3(rb), dim3(ENC_THREADS), 0, s, dout, rowptr_t, col_t, (long long)n_src, (long long)n_dst, h, add_self, dx); break;
+                default: PHC_LAUNCH((aggregate_dx_rows_kernel<64>), dim3(rb), dim3(ENC_THREADS), 0, s, dout, rowptr_t, col_t, (long long)n_src, (long long)n_dst, h, add_self, dx); break;
+            }
+        } else {
 #define PHC_AD_LAUNCH(LPRC, ACTC)                                                                                         \
     PHC_LAUNCH((aggregate_enc_dx_kernel<LPRC, ACTC>), dim3((unsigned)blocks), dim3(ENC_THREADS), lds, s, dout, x, bond, \
                        tables, m, rowptr_t, col_t, perm_t, (long long)n_src, (long long)n_dst, n, k, add_self, dx)
@@ -1592,6 +1687,7 @@ int phc_aggregate_enc_bwd(const float *dout, const float *x, const int64_t *bond
         }
 #undef PHC_AD_ACT
 #undef PHC_AD_LAUNCH
+        }
         rc = check_launch("aggregate_enc_dx");
         if (rc) return rc;
     }

@@ -16,7 +16,21 @@
 #define PHC_XCD_MAP 1
 #endif
 
+// A/B switch for the row walkers' contiguous-rows-per-XCD order alone (-DPHC_XCD_ROWS=0)
+#ifndef PHC_XCD_ROWS
+#define PHC_XCD_ROWS PHC_XCD_MAP
+#endif
+
 namespace phc {
+
+// Workgroups go to the 8 XCDs round-robin by block id.  A row-walking kernel whose neighbouring rows gather the same rows
+// (a molecule's atoms are consecutive rows and its bonds stay inside it) gives every XCD one CONTIGUOUS range of rows: a row
+// that two neighbours gather comes from the Infinity Cache once and from that XCD's L2 afterwards.  The grid must be a
+// multiple of 8 (xcd_grid); the permuted id stays below it, rows are bound-checked by the callers as before.
+__device__ __forceinline__ unsigned xcd_contiguous_block(unsigned b, unsigned nb) {
+    return PHC_XCD_ROWS ? (b & 7u) * (nb >> 3) + (b >> 3) : b;
+}
+static inline long long xcd_grid(long long blocks) { return (blocks + 7) / 8 * 8; }
 
 // ---- error plumbing --------------------------------------------------------
 void set_last_error(const char *fmt, ...);

@@ -27,13 +27,32 @@ struct SmEnc {
     int off[4];
 };
 
+// the F <= 4 table rows of one edge: all four loads go out together (a feature the encoder does not have re-reads
+// feature 0's row and is masked out of the sum) — a runtime-F loop would wait for each row before asking for the next
 __device__ __forceinline__ float4 sm_enc_rows(const SmEnc &enc, const float *const *tp, unsigned code) {
-    float4 a = make_float4(0.f, 0.f, 0.f, 0.f);
-    for (int f = 0; f < enc.F; ++f) {
-        const float4 t = *reinterpret_cast<const float4 *>(tp[f] + (size_t)((code >> (8 * f)) & 255u) * enc.k);
-        a.x += t.x; a.y += t.y; a.z += t.z; a.w += t.w;
+    float4 t[4];
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const int sh = f < enc.F ? 8 * f : 0;            // tp[f] of a missing feature is feature 0's pointer (sm_table_ptrs)
+        t[f] = *reinterpret_cast<const float4 *>(tp[f] + (size_t)((code >> sh) & 255u) * enc.k);
+    }
+    float4 a = t[0];
+#pragma unroll
+    for (int f = 1; f < 4; ++f) {
+        const float on = f < enc.F ? 1.f : 0.f;
+        a.x = fmaf(on, t[f].x, a.x); a.y = fmaf(on, t[f].y, a.y); a.z = fmaf(on, t[f].z, a.z); a.w = fmaf(on, t[f].w, a.w);
     }
     return a;
+}
+
+// this lane's slice (column group c4) of its component's F tables; slots past F repeat feature 0
+__device__ __forceinline__ void sm_table_ptrs(const SmEnc &enc, int c4, const float *(&tp)[4]) {
+    const int c = (c4 * 4) / enc.k, kk = c4 * 4 - c * enc.k;
+#pragma unroll
+    for (int f = 0; f < 4; ++f) {
+        const int ff = f < enc.F ? f : 0;
+        tp[f] = enc.tables[c * enc.F + ff] + kk - (size_t)enc.off[ff] * enc.k;
+    }
 }
 
 struct Sm4 {            // online softmax state for 4 columns
@@ -63,6 +82,14 @@ __device__ __forceinline__ void sm_merge(float &mx, float &s, float &w, float mx
     mx = M;
 }
 
+// Work split.  With h/4 <= 32 a wavefront holds G = 64/LPR lane groups, and every lane group owns a ROW of its own: it
+// walks that row's edges itself, the first two in one round trip (clamped indices), with the row's own reads (the self row,
+// dout) in flight from the start.  At a molecule's average degree of two that is half (a quarter, an eighth) the wavefronts
+// of one row per wavefront — one resident set instead of two or three — and no cross-group merge.  A row with more than
+// SM_HEAVY edges is left to the whole wavefront afterwards: its edges are dealt over the G groups and the partial states
+// merged by shuffles (hubs of a general graph; a group walking 10^4 edges alone would hold its wavefront for milliseconds).
+constexpr int SM_HEAVY = 16;
+
 template <int LPR, int ACT>
 __global__ __launch_bounds__(SM_THREADS) void softmax_agg_fwd_kernel(const float *__restrict__ x, const float *__restrict__ ea,
                                                                   const int *__restrict__ rowptr, const int *__restrict__ col,
@@ -75,102 +102,133 @@ __global__ __launch_bounds__(SM_THREADS) void softmax_agg_fwd_kernel(const float
     constexpr int G = WAVE / LPR;
     const int lane = threadIdx.x & 63;
     const int grp = lane / LPR, li = lane - grp * LPR;
-    const long long wave_id = ((long long)blockIdx.x * SM_THREADS + threadIdx.x) >> 6;
+    const long long wave_id = ((long long)xcd_contiguous_block(blockIdx.x, gridDim.x) * SM_THREADS + threadIdx.x) >> 6;
     const long long n_waves = ((long long)gridDim.x * SM_THREADS) >> 6;
     const int h4 = h >> 2;
     const float beta = *beta_p;
-    for (long long d = wave_id; d < n_dst; d += n_waves) {
-        const int e_begin = rowptr[d], e_end = rowptr[d + 1];
+    // one row: edges e0 + first, e0 + first + step, ... of [e0, e1); coop = the groups of the wavefront share the row
+    auto row = [&](long long d, int e0, int e1, int first, int step, bool coop) {
         for (int c4 = li; c4 < h4; c4 += LPR) {
+            float4 xd = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (out_self) xd = reinterpret_cast<const float4 *>(x + (size_t)d * h)[c4];
             float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, s[4] = {0.f, 0.f, 0.f, 0.f}, w[4] = {0.f, 0.f, 0.f, 0.f};
             const float *tp[4] = {nullptr, nullptr, nullptr, nullptr};
-            if (enc.codes) {                                 // this lane's slice of its component's F tables
-                const int c = (c4 * 4) / enc.k, kk = c4 * 4 - c * enc.k;
-                for (int f = 0; f < enc.F; ++f) tp[f] = enc.tables[c * enc.F + f] + kk - (size_t)enc.off[f] * enc.k;
-            }
-            for (int e = e_begin + grp; e < e_end; e += G) {
+            if (enc.codes) sm_table_ptrs(enc, c4, tp);
+            auto message = [&](int e) {                      // codes in destination-sorted order: indexed by e
                 float4 v = reinterpret_cast<const float4 *>(x + (size_t)col[e] * h)[c4];
-                if (enc.codes) {                             // codes in destination-sorted order: indexed by e
+                if (enc.codes) {
                     const float4 a = sm_enc_rows(enc, tp, enc.codes[e]);
                     v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
                 } else if (ea) {
                     const float4 a = reinterpret_cast<const float4 *>(ea + (size_t)perm[e] * h)[c4];
                     v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
                 }
-                sm_update(mx[0], s[0], w[0], act_fwd<ACT>(v.x), beta);
-                sm_update(mx[1], s[1], w[1], act_fwd<ACT>(v.y), beta);
-                sm_update(mx[2], s[2], w[2], act_fwd<ACT>(v.z), beta);
-                sm_update(mx[3], s[3], w[3], act_fwd<ACT>(v.w), beta);
+                return make_float4(act_fwd<ACT>(v.x), act_fwd<ACT>(v.y), act_fwd<ACT>(v.z), act_fwd<ACT>(v.w));
+            };
+            auto update = [&](const float4 &m) {
+                sm_update(mx[0], s[0], w[0], m.x, beta);
+                sm_update(mx[1], s[1], w[1], m.y, beta);
+                sm_update(mx[2], s[2], w[2], m.z, beta);
+                sm_update(mx[3], s[3], w[3], m.w, beta);
+            };
+            int e = e0 + first;
+            if (e0 < e1) {                                   // the first two edges travel together (clamped indices)
+                const float4 m0 = message(min(e, e1 - 1)), m1 = message(min(e + step, e1 - 1));
+                if (e < e1) update(m0);
+                if (e + step < e1) update(m1);
+                e += 2 * step;
             }
+            for (; e < e1; e += step) update(message(e));
+            if (coop) {
 #pragma unroll
-            for (int off = LPR; off < WAVE; off <<= 1) {
+                for (int off = LPR; off < WAVE; off <<= 1) {
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    const float m2 = __shfl_xor(mx[q], off, WAVE), s2 = __shfl_xor(s[q], off, WAVE), w2 = __shfl_xor(w[q], off, WAVE);
-                    sm_merge(mx[q], s[q], w[q], m2, s2, w2);
+                    for (int q = 0; q < 4; ++q) {
+                        const float m2 = __shfl_xor(mx[q], off, WAVE), s2 = __shfl_xor(s[q], off, WAVE), w2 = __shfl_xor(w[q], off, WAVE);
+                        sm_merge(mx[q], s[q], w[q], m2, s2, w2);
+                    }
                 }
             }
-            if (grp == 0) {
+            if (!coop || grp == 0) {
                 float4 o, l;
                 float *op = &o.x, *lp = &l.x;
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
                     const float z = s[q] + SM_EPS;
-                    op[q] = (e_end > e_begin) ? w[q] / z : 0.f;
-                    lp[q] = (e_end > e_begin) ? mx[q] + __logf(z) : 0.f;
+                    op[q] = (e1 > e0) ? w[q] / z : 0.f;
+                    lp[q] = (e1 > e0) ? mx[q] + __logf(z) : 0.f;
                 }
                 reinterpret_cast<float4 *>(out + (size_t)d * h)[c4] = o;
                 reinterpret_cast<float4 *>(lse + (size_t)d * h)[c4] = l;
-                if (out_self) {
-                    const float4 xd = reinterpret_cast<const float4 *>(x + (size_t)d * h)[c4];
+                if (out_self)
                     reinterpret_cast<float4 *>(out_self + (size_t)d * h)[c4] = make_float4(o.x + xd.x, o.y + xd.y, o.z + xd.z, o.w + xd.w);
+            }
+        }
+    };
+    for (long long d0 = wave_id * G; d0 < n_dst; d0 += n_waves * G) {           // wave-uniform bounds
+        const long long d = d0 + grp;
+        const bool valid = d < n_dst;
+        const int e_begin = valid ? rowptr[d] : 0, e_end = valid ? rowptr[d + 1] : 0;
+        const bool heavy = G > 1 && e_end - e_begin > SM_HEAVY;
+        if (valid && !heavy) row(d, e_begin, e_end, 0, 1, false);
+        if (G > 1) {
+            const unsigned long long hb = __ballot(heavy);
+            if (hb) {
+                for (int g = 0; g < G; ++g) {
+                    const int eb = __shfl(e_begin, g * LPR, WAVE), ee = __shfl(e_end, g * LPR, WAVE);
+                    if ((hb >> (g * LPR)) & 1ull) row(d0 + g, eb, ee, grp, G, true);
                 }
             }
         }
     }
 }
 
-// source-sorted walk; dbeta partial sums per workgroup (fixed order => reproducible)
+// source-sorted walk; dbeta partial sums per workgroup (fixed order => reproducible).  dbeta_partial has n_partials slots
+// (phc_softmax_bwd_num_partials: the one-row-per-wavefront bound); the grid may be smaller and zeroes the rest.
 template <int LPR, int ACT>
 __global__ __launch_bounds__(SM_THREADS) void softmax_agg_bwd_kernel(
     const float *__restrict__ dout, const float *__restrict__ out, const float *__restrict__ lse, const float *__restrict__ x,
     const float *__restrict__ ea, const float *__restrict__ beta_p, const int *__restrict__ rowptr_t, const int *__restrict__ col_t,
     const int *__restrict__ perm_t, long long n_src, int h, float *__restrict__ dx, float *__restrict__ dea,
-    float *__restrict__ dbeta_partial, long long self_n_dst, SmEnc enc) {
+    float *__restrict__ dbeta_partial, int n_partials, long long self_n_dst, SmEnc enc) {
     __shared__ float red[SM_THREADS];
     constexpr int G = WAVE / LPR;
     const int lane = threadIdx.x & 63;
     const int grp = lane / LPR, li = lane - grp * LPR;
-    const long long wave_id = ((long long)blockIdx.x * SM_THREADS + threadIdx.x) >> 6;
+    const long long wave_id = ((long long)xcd_contiguous_block(blockIdx.x, gridDim.x) * SM_THREADS + threadIdx.x) >> 6;
     const long long n_waves = ((long long)gridDim.x * SM_THREADS) >> 6;
     const int h4 = h >> 2;
     const float beta = *beta_p;
     float db = 0.f;
-    for (long long sidx = wave_id; sidx < n_src; sidx += n_waves) {
-        const int e_begin = rowptr_t[sidx], e_end = rowptr_t[sidx + 1];
+    auto row = [&](long long sidx, int e0, int e1, int first, int step, bool coop) {
         for (int c4 = li; c4 < h4; c4 += LPR) {
             const float4 xs = reinterpret_cast<const float4 *>(x + (size_t)sidx * h)[c4];
+            float4 gs = make_float4(0.f, 0.f, 0.f, 0.f);    // the self loop's gradient: dx[s] += dout[s]
+            if (sidx < self_n_dst) gs = reinterpret_cast<const float4 *>(dout + (size_t)sidx * h)[c4];
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
             const float *tp[4] = {nullptr, nullptr, nullptr, nullptr};
-            if (enc.codes) {
-                const int c = (c4 * 4) / enc.k, kk = c4 * 4 - c * enc.k;
-                for (int f = 0; f < enc.F; ++f) tp[f] = enc.tables[c * enc.F + f] + kk - (size_t)enc.off[f] * enc.k;
-            }
-            for (int e = e_begin + grp; e < e_end; e += G) {
+            if (enc.codes) sm_table_ptrs(enc, c4, tp);
+            struct EdgeRows { float4 pre, go, o, l; size_t p; };
+            auto fetch = [&](int e) {                        // every row of one out-edge, all loads in flight together
+                EdgeRows r;
                 const size_t d = (size_t)col_t[e];
-                const size_t p = (size_t)perm_t[e];
-                float pre[4] = {xs.x, xs.y, xs.z, xs.w};
-                if (enc.codes) {                             // codes in ORIGINAL edge order: indexed by p
-                    const float4 a = sm_enc_rows(enc, tp, enc.codes[p]);
-                    pre[0] += a.x; pre[1] += a.y; pre[2] += a.z; pre[3] += a.w;
+                r.p = (size_t)perm_t[e];
+                r.pre = xs;
+                if (enc.codes) {                             // codes in SOURCE-sorted order: indexed by e
+                    const float4 a = sm_enc_rows(enc, tp, enc.codes[e]);
+                    r.pre.x += a.x; r.pre.y += a.y; r.pre.z += a.z; r.pre.w += a.w;
                 } else if (ea) {
-                    const float4 a = reinterpret_cast<const float4 *>(ea + p * h)[c4];
-                    pre[0] += a.x; pre[1] += a.y; pre[2] += a.z; pre[3] += a.w;
+                    const float4 a = reinterpret_cast<const float4 *>(ea + r.p * h)[c4];
+                    r.pre.x += a.x; r.pre.y += a.y; r.pre.z += a.z; r.pre.w += a.w;
                 }
-                const float4 go4 = reinterpret_cast<const float4 *>(dout + d * h)[c4];
-                const float4 o4 = reinterpret_cast<const float4 *>(out + d * h)[c4];
-                const float4 l4 = reinterpret_cast<const float4 *>(lse + d * h)[c4];
-                const float go[4] = {go4.x, go4.y, go4.z, go4.w}, o[4] = {o4.x, o4.y, o4.z, o4.w}, l[4] = {l4.x, l4.y, l4.z, l4.w};
+                r.go = reinterpret_cast<const float4 *>(dout + d * h)[c4];
+                r.o = reinterpret_cast<const float4 *>(out + d * h)[c4];
+                r.l = reinterpret_cast<const float4 *>(lse + d * h)[c4];
+                return r;
+            };
+            auto apply = [&](const EdgeRows &r) {
+                const float pre[4] = {r.pre.x, r.pre.y, r.pre.z, r.pre.w};
+                const float go[4] = {r.go.x, r.go.y, r.go.z, r.go.w}, o[4] = {r.o.x, r.o.y, r.o.z, r.o.w}, l[4] = {r.l.x, r.l.y, r.l.z, r.l.w};
                 float g[4];
 #pragma unroll
                 for (int q = 0; q < 4; ++q) {
@@ -181,18 +239,39 @@ __global__ __launch_bounds__(SM_THREADS) void softmax_agg_bwd_kernel(
                     g[q] = go[q] * (wgt + beta * t) * act_grad<ACT>(pre[q]);
                     acc[q] += g[q];
                 }
-                if (dea) reinterpret_cast<float4 *>(dea + p * h)[c4] = make_float4(g[0], g[1], g[2], g[3]);
+                if (dea) reinterpret_cast<float4 *>(dea + r.p * h)[c4] = make_float4(g[0], g[1], g[2], g[3]);
+            };
+            int e = e0 + first;
+            if (e0 < e1) {                                   // the first two out-edges travel together (clamped indices)
+                const EdgeRows r0 = fetch(min(e, e1 - 1)), r1 = fetch(min(e + step, e1 - 1));
+                if (e < e1) apply(r0);
+                if (e + step < e1) apply(r1);
+                e += 2 * step;
             }
+            for (; e < e1; e += step) apply(fetch(e));
+            if (coop) {
 #pragma unroll
-            for (int off = LPR; off < WAVE; off <<= 1)
+                for (int off = LPR; off < WAVE; off <<= 1)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) acc[q] += __shfl_xor(acc[q], off, WAVE);
-            if (grp == 0) {
-                if (sidx < self_n_dst) {                     // the self loop's gradient: dx[s] += dout[s]
-                    const float4 gs = reinterpret_cast<const float4 *>(dout + (size_t)sidx * h)[c4];
-                    acc[0] += gs.x; acc[1] += gs.y; acc[2] += gs.z; acc[3] += gs.w;
+                    for (int q = 0; q < 4; ++q) acc[q] += __shfl_xor(acc[q], off, WAVE);
+            }
+            if (!coop || grp == 0)
+                reinterpret_cast<float4 *>(dx + (size_t)sidx * h)[c4] = make_float4(acc[0] + gs.x, acc[1] + gs.y, acc[2] + gs.z, acc[3] + gs.w);
+        }
+    };
+    for (long long s0 = wave_id * G; s0 < n_src; s0 += n_waves * G) {           // wave-uniform bounds
+        const long long sidx = s0 + grp;
+        const bool valid = sidx < n_src;
+        const int e_begin = valid ? rowptr_t[sidx] : 0, e_end = valid ? rowptr_t[sidx + 1] : 0;
+        const bool heavy = G > 1 && e_end - e_begin > SM_HEAVY;
+        if (valid && !heavy) row(sidx, e_begin, e_end, 0, 1, false);
+        if (G > 1) {
+            const unsigned long long hb = __ballot(heavy);
+            if (hb) {
+                for (int g = 0; g < G; ++g) {
+                    const int eb = __shfl(e_begin, g * LPR, WAVE), ee = __shfl(e_end, g * LPR, WAVE);
+                    if ((hb >> (g * LPR)) & 1ull) row(s0 + g, eb, ee, grp, G, true);
                 }
-                reinterpret_cast<float4 *>(dx + (size_t)sidx * h)[c4] = make_float4(acc[0], acc[1], acc[2], acc[3]);
             }
         }
     }
@@ -202,15 +281,18 @@ __global__ __launch_bounds__(SM_THREADS) void softmax_agg_bwd_kernel(
         if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
         __syncthreads();
     }
-    if (threadIdx.x == 0) dbeta_partial[blockIdx.x] = red[0];
+    if (threadIdx.x == 0) {
+        dbeta_partial[blockIdx.x] = red[0];
+        for (int i = (int)(gridDim.x + blockIdx.x); i < n_partials; i += (int)gridDim.x) dbeta_partial[i] = 0.f;
+    }
 }
 
 static inline int sm_lpr(int h4) { return h4 <= 8 ? 8 : h4 <= 16 ? 16 : h4 <= 32 ? 32 : 64; }
-static inline unsigned sm_grid(long long rows) {
-    long long b = (rows + 3) / 4;
+static inline unsigned sm_grid(long long rows, int rows_per_wave = 1) {
+    long long b = (rows + 4 * rows_per_wave - 1) / (4 * rows_per_wave);
     if (b > 4096) b = 4096;
     if (b < 1) b = 1;
-    return (unsigned)b;
+    return (unsigned)xcd_grid(b);                 // a multiple of 8: xcd_contiguous_block
 }
 static inline bool sm_al16(const void *p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -295,10 +377,10 @@ static int sm_fwd_impl(const float *x, const float *ea, const int32_t *rowptr, c
     ProfScope prof(K_SOFTMAX_FWD, s);
 #define PHC_SM_FWD(ACTC)                                                                                                 \
     switch (lpr) {                                                                                                       \
-        case 8: PHC_LAUNCH((softmax_agg_fwd_kernel<8, ACTC>), dim3(sm_grid(n_dst)), dim3(SM_THREADS), 0, s, x, ea, rowptr, col, perm, beta_dev, (long long)n_dst, h, out, lse, out_self, enc); break;   \
-        case 16: PHC_LAUNCH((softmax_agg_fwd_kernel<16, ACTC>), dim3(sm_grid(n_dst)), dim3(SM_THREADS), 0, s, x, ea, rowptr, col, perm, beta_dev, (long long)n_dst, h, out, lse, out_self, enc); break; \
-        case 32: PHC_LAUNCH((softmax_agg_fwd_kernel<32, ACTC>), dim3(sm_grid(n_dst)), dim3(SM_THREADS), 0, s, x, ea, rowptr, col, perm, beta_dev, (long long)n_dst, h, out, lse, out_self, enc); break; \
-        default: PHC_LAUNCH((softmax_agg_fwd_kernel<64, ACTC>), dim3(sm_grid(n_dst)), dim3(SM_THREADS), 0, s, x, ea, rowptr, col, perm, beta_dev, (long long)n_dst, h, out, lse, out_self, enc); break; \
+        case 8: PHC_LAUNCH((softmax_agg_fwd_kernel<8, ACTC>), dim3(sm_grid(n_dst, 64 / lpr)), dim3(SM_THREADS), 0, s, x, ea, rowptr, col, perm, beta_dev, (long long)n_dst, h, out, lse, out_self, enc); break;   \
+        case 16: PHC_LAUNCH((softmax_agg_fwd_kernel<16, ACTC>), dim3(sm_grid(n_dst, 64 / lpr)), dim3(SM_THREADS), 0, s, x, ea, rowptr, col, perm, beta_dev, (long long)n_dst, h, out, lse, out_self, enc); break; \
+        case 32: PHC_LAUNCH((softmax_agg_fwd_kernel<32, ACTC>), dim3(sm_grid(n_dst, 64 / lpr)), dim3(SM_THREADS), 0, s, x, ea, rowptr, col, perm, beta_dev, (long long)n_dst, h, out, lse, out_self, enc); break; \
+        default: PHC_LAUNCH((softmax_agg_fwd_kernel<64, ACTC>), dim3(sm_grid(n_dst, 64 / lpr)), dim3(SM_THREADS), 0, s, x, ea, rowptr, col, perm, beta_dev, (long long)n_dst, h, out, lse, out_self, enc); break; \
     }
     PHC_SM_ACT(act, PHC_SM_FWD)
 #undef PHC_SM_FWD
@@ -332,12 +414,12 @@ int phc_aggregate_softmax_bwd_self(const float *dout, const float *out, const fl
                        enc, stream);
 }
 
-int phc_aggregate_softmax_enc_bwd(const float *dout, const float *out, const float *lse, const float *x, const uint32_t *codes_orig,
+int phc_aggregate_softmax_enc_bwd(const float *dout, const float *out, const float *lse, const float *x, const uint32_t *codes_src,
                                   const float *const *tables, const int32_t *vocab, int F, int n, int k, const float *beta_dev,
                                   const int32_t *rowptr_t, const int32_t *col_t, const int32_t *perm_t, int64_t n_src, int act,
                                   int64_t self_n_dst, float *dx, float *dea, float *dbeta_partial, void *stream) {
     SmEnc enc;
-    int rc = sm_make_enc("phc_aggregate_softmax_enc_bwd", codes_orig, tables, vocab, F, n, k, n * k, &enc);
+    int rc = sm_make_enc("phc_aggregate_softmax_enc_bwd", codes_src, tables, vocab, F, n, k, n * k, &enc);
     if (rc) return rc;
     return sm_bwd_impl(dout, out, lse, x, nullptr, beta_dev, rowptr_t, col_t, perm_t, n_src, n * k, act, self_n_dst, dx, dea,
                        dbeta_partial, enc, stream);
@@ -359,10 +441,10 @@ static int sm_bwd_impl(const float *dout, const float *out, const float *lse, co
     ProfScope prof(K_SOFTMAX_BWD, s);
 #define PHC_SM_BWD(ACTC)                                                                                                 \
     switch (lpr) {                                                                                                       \
-        case 8: PHC_LAUNCH((softmax_agg_bwd_kernel<8, ACTC>), dim3(sm_grid(n_src)), dim3(SM_THREADS), 0, s, dout, out, lse, x, ea, beta_dev, rowptr_t, col_t, perm_t, (long long)n_src, h, dx, dea, dbeta_partial, (long long)self_n_dst, enc); break;   \
-        case 16: PHC_LAUNCH((softmax_agg_bwd_kernel<16, ACTC>), dim3(sm_grid(n_src)), dim3(SM_THREADS), 0, s, dout, out, lse, x, ea, beta_dev, rowptr_t, col_t, perm_t, (long long)n_src, h, dx, dea, dbeta_partial, (long long)self_n_dst, enc); break; \
-        case 32: PHC_LAUNCH((softmax_agg_bwd_kernel<32, ACTC>), dim3(sm_grid(n_src)), dim3(SM_THREADS), 0, s, dout, out, lse, x, ea, beta_dev, rowptr_t, col_t, perm_t, (long long)n_src, h, dx, dea, dbeta_partial, (long long)self_n_dst, enc); break; \
-        default: PHC_LAUNCH((softmax_agg_bwd_kernel<64, ACTC>), dim3(sm_grid(n_src)), dim3(SM_THREADS), 0, s, dout, out, lse, x, ea, beta_dev, rowptr_t, col_t, perm_t, (long long)n_src, h, dx, dea, dbeta_partial, (long long)self_n_dst, enc); break; \
+        case 8: PHC_LAUNCH((softmax_agg_bwd_kernel<8, ACTC>), dim3(sm_grid(n_src, 64 / lpr)), dim3(SM_THREADS), 0, s, dout, out, lse, x, ea, beta_dev, rowptr_t, col_t, perm_t, (long long)n_src, h, dx, dea, dbeta_partial, (int)sm_grid(n_src), (long long)self_n_dst, enc); break;   \
+        case 16: PHC_LAUNCH((softmax_agg_bwd_kernel<16, ACTC>), dim3(sm_grid(n_src, 64 / lpr)), dim3(SM_THREADS), 0, s, dout, out, lse, x, ea, beta_dev, rowptr_t, col_t, perm_t, (long long)n_src, h, dx, dea, dbeta_partial, (int)sm_grid(n_src), (long long)self_n_dst, enc); break; \
+        case 32: PHC_LAUNCH((softmax_agg_bwd_kernel<32, ACTC>), dim3(sm_grid(n_src, 64 / lpr)), dim3(SM_THREADS), 0, s, dout, out, lse, x, ea, beta_dev, rowptr_t, col_t, perm_t, (long long)n_src, h, dx, dea, dbeta_partial, (int)sm_grid(n_src), (long long)self_n_dst, enc); break; \
+        default: PHC_LAUNCH((softmax_agg_bwd_kernel<64, ACTC>), dim3(sm_grid(n_src, 64 / lpr)), dim3(SM_THREADS), 0, s, dout, out, lse, x, ea, beta_dev, rowptr_t, col_t, perm_t, (long long)n_src, h, dx, dea, dbeta_partial, (int)sm_grid(n_src), (long long)self_n_dst, enc); break; \
     }
     PHC_SM_ACT(act, PHC_SM_BWD)
 #undef PHC_SM_BWD

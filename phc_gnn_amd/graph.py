@@ -78,6 +78,8 @@ class EdgeStructure:
         self._codes_args = None
         self._codes_orig: dict = {}
         self._codes_orig_args = None
+        self._codes_src: dict = {}
+        self._codes_src_args = None
 
     def packed_codes(self, bond_idx: torch.Tensor, vocab_c, F: int) -> torch.Tensor:
         """uint32 per edge in destination-sorted order: the F table rows of the edge's integer features, one
@@ -91,8 +93,8 @@ class EdgeStructure:
             self._codes_args = (bond_idx, vocab_c, F)
         return codes
 
-    def _pack_codes(self, bond_idx, vocab_c, F, codes, sorted_order: bool = True) -> None:
-        perm = self.csr[2] if sorted_order else None
+    def _pack_codes(self, bond_idx, vocab_c, F, codes, sorted_order: bool = True, by_source: bool = False) -> None:
+        perm = self.csc[2] if by_source else (self.csr[2] if sorted_order else None)
         L.check(L.load().phc_pack_edge_codes(L.ptr(bond_idx), L.ptr(perm), vocab_c, self.num_edges, F, L.ptr(codes),
                                              L.stream_ptr(bond_idx.device)), "phc_pack_edge_codes")
 
@@ -105,6 +107,18 @@ class EdgeStructure:
             self._pack_codes(bond_idx, vocab_c, F, codes, sorted_order=False)
             self._codes_orig = {key: codes}
             self._codes_orig_args = (bond_idx, vocab_c, F)
+        return codes
+
+    def packed_codes_src(self, bond_idx: torch.Tensor, vocab_c, F: int) -> torch.Tensor:
+        """The same codes in SOURCE-sorted order (the softmax backward walks the out-edges of a source and wants an edge's
+        code in the same round trip as its target index, not one hop later through the original edge id)."""
+        key = (bond_idx.data_ptr(), bond_idx._version, tuple(vocab_c))
+        codes = self._codes_src.get(key)
+        if codes is None:
+            codes = torch.empty(self.num_edges, dtype=torch.int32, device=bond_idx.device)
+            self._pack_codes(bond_idx, vocab_c, F, codes, by_source=True)
+            self._codes_src = {key: codes}
+            self._codes_src_args = (bond_idx, vocab_c, F)
         return codes
 
     def rebuild(self) -> None:
@@ -127,6 +141,8 @@ class EdgeStructure:
                 self._pack_codes(*self._codes_args, codes)
         for codes in self._codes_orig.values():
             self._pack_codes(*self._codes_orig_args, codes, sorted_order=False)
+        for codes in self._codes_src.values():
+            self._pack_codes(*self._codes_src_args, codes, by_source=True)
 
     PAIR_MAX_ROWS = 16383
 

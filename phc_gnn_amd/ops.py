@@ -1200,7 +1200,7 @@ class _AggregateSoftmaxEncFn(torch.autograd.Function):
         dev = dout_.device
         h = dout_.shape[1]
         rowptr_t, col_t, perm_t = st.csc
-        codes_o = st.packed_codes_orig(bond_, ts.vocab_c, ts.F)
+        codes_o = st.packed_codes_src(bond_, ts.vocab_c, ts.F)
         need_t = any(ctx.needs_input_grad[7:])
         dx = torch.empty((st.num_src, h), dtype=torch.float32, device=dev)
         dea = torch.empty((st.num_edges, h), dtype=torch.float32, device=dev) if need_t else None

@@ -1,0 +1,17 @@
+#!/bin/bash
+cd "$GRAFT_REPO_ROOT" || exit 1
+export TMPDIR=/tmp
+O=gpurun_out/r03s; mkdir -p $O
+timeout 1800 python -m pytest tests/test_gpu_ops.py tests/test_gpu_model.py tests/test_gpu_fullwidth.py -m gpu -q -x > $O/tests.log 2>&1
+echo "tests rc=$?"; tail -3 $O/tests.log
+bash scripts/ab.sh norows 3 --workload molhiv_b512
+bash scripts/ab.sh norows 2 --workload molhiv_b512_softmax
+bash scripts/ab.sh norows 2 --workload zinc_b1024
+for wl in molhiv_b512; do
+  OUT=$GRAFT_REPO_ROOT/$O/prof_$wl
+  rm -rf $OUT && mkdir -p $OUT
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 bench.py --workload $wl --steps 50 --warmup 10 --cpu-steps 0 --min-time 0 --profile-steps 0 > $OUT/bench.log 2>&1
+  python3 scripts/summarize_rocprof.py $(ls -t $OUT/*/*kernel_stats.csv | head -1) 60 70 > $OUT/summary.txt
+  grep -E "softmax_agg|aggregate_|enc_direct" $OUT/summary.txt | cut -c1-200
+  find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*.db" -delete
+done
