@@ -511,9 +511,12 @@ def main():
     dataset_name = {"molhiv": "ogbg-molhiv", "molpcba": "ogbg-molpcba", "zinc": "ZINC"}[w["dataset"]]
     config_note = {"molhiv_b32": " (BASELINE configs[0])", "molhiv_b512": " (BASELINE configs[1])",
                    "zinc_b1024": " (BASELINE configs[2])",
-                   "molpcba_b1024": " (BASELINE configs[3], per-GPU share)"}.get(args.workload, " (configs[1] variant)")
+                   "molpcba_b1024": " (BASELINE configs[3], per-GPU share)"}.get(
+        args.workload, " (the reference's published model shape, benchmarks/README.md:45-91)" if "_pub_" in args.workload
+        else " (configs[1] variant)")
+    drop_note = "".join(f", {k} {w[k]}" for k in ("dropout_mpnn", "dropout_dn") if any(w.get(k, [])))
     result = {
-        "metric": "graphs/sec (fwd+bwd) PHC-GNN PHM-4 on ogbg-molhiv",
+        "metric": f"graphs/sec (fwd+bwd) PHC-GNN PHM-{w['phm_dim']} on {dataset_name}",
         "value": round(graphs / dt, 1), "unit": "graphs/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(1e3 * dt / args.steps, 4),
         "timing": {"windows": len(windows), "steps_per_window": args.steps, "reported": "median window",
@@ -522,7 +525,7 @@ def main():
         "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
         "config": {"workload": f"{args.workload}: {dataset_name}-shaped synthetic molecules, PHM-{w['phm_dim']}, hidden "
                                f"{w['hidden']}, {w['layers']} {'PHMGINEConv' if w.get('mlp', True) else 'PHMConv'} "
-                               f"layers, {w.get('msg_aggr', 'sum')} aggregation, soft-attention pooling, batch "
+                               f"layers, {w.get('msg_aggr', 'sum')} aggregation, soft-attention pooling{drop_note}, batch "
                                f"{w['batch_size']}/GPU{config_note}",
                    "nodes_per_batch": int(sum(b.num_nodes for b in host_batches) / len(host_batches)),
                    "edges_per_batch": int(sum(b.num_edges for b in host_batches) / len(host_batches)),

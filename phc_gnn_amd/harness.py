@@ -37,6 +37,24 @@ WORKLOADS: Dict[str, dict] = {
     "molpcba_b1024": dict(dataset="molpcba", batch_size=1024, phm_dim=4, hidden=256, layers=5, d_units=[768, 256],
                           target_dim=128, sc_type="first", nan_frac=0.6),
 }
+# The reference's PUBLISHED model shapes (benchmarks/README.md:45-91, benchmarks/run_script_zinc_phm4.sh:4-5) at the BASELINE
+# batch sizes, dropout as published: per-component sizes 50 / 40 / 45 (not multiples of four), GEMM depths 200 / 180.
+# ``*_pub_nodrop``: the same models without dropout (what the oracle parity tests run; dropout parity: test_gpu_dropout.py).
+WORKLOADS.update({
+    # ogbg-molhiv paper model: PHC-4, 2 x 200, softmax aggregation with a learnable inverse temperature
+    "molhiv_pub_phc4_2x200": dict(dataset="molhiv", batch_size=512, phm_dim=4, hidden=200, layers=2, d_units=[128, 32],
+                                  target_dim=1, sc_type="first", msg_aggr="softmax", dropout_mpnn=[0.2, 0.2], dropout_dn=[0.3, 0.1]),
+    # ZINC 100 K model: PHC-5, 4 x 200.  The README's --input_embed_dim 180 / --d_units 200,128 do not construct
+    # (models.py:46 wants one width, layers.py:231 wants 128 % 5 == 0): 200 everywhere, head 200, 130
+    "zinc_pub_phc5_4x200": dict(dataset="zinc", batch_size=1024, phm_dim=5, hidden=200, layers=4, d_units=[200, 130],
+                                target_dim=1, sc_type="last", regression=True, dropout_dn=[0.2, 0.1]),
+    # run_script_zinc_phm4.sh: PHC-4, embed 180, 4 x 180, head 180, 80
+    "zinc_pub_phc4_4x180": dict(dataset="zinc", batch_size=1024, phm_dim=4, hidden=180, layers=4, d_units=[180, 80],
+                                target_dim=1, sc_type="last", regression=True, dropout_dn=[0.2, 0.1]),
+})
+for _k in ("molhiv_pub_phc4_2x200", "zinc_pub_phc5_4x200", "zinc_pub_phc4_4x180"):
+    WORKLOADS[_k + "_nodrop"] = {k: v for k, v in WORKLOADS[_k].items() if not k.startswith("dropout")}
+    WORKLOADS[_k + "_nodrop_swish"] = dict(WORKLOADS[_k + "_nodrop"], activation="swish")
 # smooth-activation twins (parity runs: without the ReLU kink every gradient tensor is comparable to ~1e-5)
 for _k in ("zinc_b1024", "molpcba_b1024", "molhiv_b512_softmax"):
     WORKLOADS[_k + "_swish"] = dict(WORKLOADS[_k], activation="swish")
@@ -44,11 +62,11 @@ for _k in ("zinc_b1024", "molpcba_b1024", "molhiv_b512_softmax"):
 
 def model_kwargs(w: dict) -> dict:
     kw = dict(phm_dim=w["phm_dim"], learn_phm=True, atom_encoded_dim=w["hidden"], mp_layers=[w["hidden"]] * w["layers"],
-              dropout_mpnn=[0.0] * w["layers"], mlp=w.get("mlp", True), msg_aggr=w.get("msg_aggr", "sum"),
+              dropout_mpnn=list(w.get("dropout_mpnn", [0.0] * w["layers"])), mlp=w.get("mlp", True), msg_aggr=w.get("msg_aggr", "sum"),
               norm_mp="naive-batch-norm",
               norm_dn="naive-batch-norm", pooling="softattention", activation=w.get("activation", "relu"), real_trafo="linear",
               w_init="phm", c_init="standard", downstream_layers=list(w["d_units"]),
-              dropout_dn=[0.0] * len(w["d_units"]), target_dim=w["target_dim"], sc_type=w["sc_type"],
+              dropout_dn=list(w.get("dropout_dn", [0.0] * len(w["d_units"]))), target_dim=w["target_dim"], sc_type=w["sc_type"],
               msg_encoder="identity")
     if kw["msg_aggr"] == "softmax":
         kw.update(initial_beta=1.0, learn_beta=True)          # train_hiv.py defaults

@@ -516,6 +516,39 @@ def g10_fullwidth_swish256():
                        store_grad32=False)
 
 
+def g12_published():
+    """The reference's PUBLISHED model shapes (benchmarks/README.md:45-91, benchmarks/run_script_zinc_phm4.sh:4-5), dropout 0
+    (dropout has its own fixture, g9): widths whose per-component size is not a multiple of four and GEMM depths of 180 / 200.
+
+      g12_hiv_phc4_2x200      ogbg-molhiv paper model: PHC-4, embed 200, 2 x 200 (k = 50), softmax aggregation with a learnable
+                              inverse temperature, head 128, 32
+      g12_zinc_phc5_4x200     ZINC 100 K model: PHC-5, 4 x 200 (k = 40), head 200, 130.  The README's command line does not construct:
+                              --input_embed_dim 180 trips PHMSkipConnectAdd's width assertion (models.py:46) and --d_units
+                              200,128 PHMLinear's divisibility assertion (layers.py:231); nearest shapes that do: 200, 130
+      g12_zinc_phc4_4x180     run_script_zinc_phm4.sh: PHC-4, embed 180, 4 x 180 (k = 45), head 180, 80
+    and a smooth-activation twin of each (no ReLU kink: the tight gradient check)."""
+    common = dict(norm_mp="naive-batch-norm", norm_dn="naive-batch-norm", pooling="softattention", real_trafo="linear",
+                  w_init="phm", c_init="standard", learn_phm=True)
+    hiv = [synth.molecule_batch(64, seed=40)]
+    zinc = [synth.molecule_batch(48, seed=41, dataset="zinc", regression=True)]
+    zkw = dict(atom_input_dims=synth.ZINC_ATOM_DIMS, bond_input_dims=synth.ZINC_BOND_DIMS)
+    for act in ("relu", "swish"):
+        sfx = "" if act == "relu" else "_swish"
+        _fullwidth_fixture("g12_hiv_phc4_2x200" + sfx, hiv, 1210,
+                           dict(phm_dim=4, atom_encoded_dim=200, mp_layers=[200, 200], dropout_mpnn=[0.0, 0.0], mlp=True,
+                                msg_aggr="softmax", initial_beta=1.0, learn_beta=True, downstream_layers=[128, 32],
+                                dropout_dn=[0.0, 0.0], target_dim=1, sc_type="first", activation=act, **common),
+                           store_grad32=False)
+        _fullwidth_fixture("g12_zinc_phc5_4x200" + sfx, zinc, 1220,
+                           dict(phm_dim=5, atom_encoded_dim=200, mp_layers=[200] * 4, dropout_mpnn=[0.0] * 4, mlp=True,
+                                msg_aggr="sum", downstream_layers=[200, 130], dropout_dn=[0.0, 0.0], target_dim=1,
+                                sc_type="last", activation=act, **common, **zkw), regression=True, store_grad32=False)
+        _fullwidth_fixture("g12_zinc_phc4_4x180" + sfx, zinc, 1230,
+                           dict(phm_dim=4, atom_encoded_dim=180, mp_layers=[180] * 4, dropout_mpnn=[0.0] * 4, mlp=True,
+                                msg_aggr="sum", downstream_layers=[180, 80], dropout_dn=[0.0, 0.0], target_dim=1,
+                                sc_type="last", activation=act, **common, **zkw), regression=True, store_grad32=False)
+
+
 def g11_regulariser():
     """phm_weight_regularization (regularization.py:15-23) value and gradients for p = 1, 2 on a stack of PHM layers, plus
     the regularised loop body of train() (train_hiv.py:173-201 with the script's defaults lr 1e-3, weightdecay 1e-3, p 2):
@@ -584,7 +617,7 @@ def g9_dropout():
 
 if __name__ == "__main__":
     makers = [g1_phm_linear, g2_g3_g4_kronecker_rules, g5_convs, g5b_softmax, g6_norm, g7_heads, g8_models,
-              g8_model_softmax, g9_dropout, g10_fullwidth, g10_fullwidth_swish256, g11_regulariser]
+              g8_model_softmax, g9_dropout, g10_fullwidth, g10_fullwidth_swish256, g11_regulariser, g12_published]
     wanted = sys.argv[1:]                       # e.g. `make_golden.py g8_model_softmax` rewrites only that fixture
     for make in makers:
         if not wanted or make.__name__ in wanted:

@@ -55,6 +55,18 @@ FULL = {
                                     activation="swish"), False),
 }
 
+# the reference's published shapes (make_golden.py::g12_published): k = 50 / 40 / 45 per component, GEMM depths 200 / 180
+for _sfx, _act in (("", "relu"), ("_swish", "swish")):
+    FULL["g12_hiv_phc4_2x200" + _sfx] = (dict(phm_dim=4, atom_encoded_dim=200, mp_layers=[200, 200], dropout_mpnn=[0.0, 0.0], mlp=True,
+                                              msg_aggr="softmax", initial_beta=1.0, learn_beta=True, downstream_layers=[128, 32],
+                                              dropout_dn=[0.0, 0.0], target_dim=1, sc_type="first", activation=_act), False)
+    FULL["g12_zinc_phc5_4x200" + _sfx] = (dict(phm_dim=5, atom_input_dims=[28], bond_input_dims=[4], atom_encoded_dim=200,
+                                               mp_layers=[200] * 4, dropout_mpnn=[0.0] * 4, mlp=True, downstream_layers=[200, 130],
+                                               dropout_dn=[0.0, 0.0], target_dim=1, sc_type="last", activation=_act), True)
+    FULL["g12_zinc_phc4_4x180" + _sfx] = (dict(phm_dim=4, atom_input_dims=[28], bond_input_dims=[4], atom_encoded_dim=180,
+                                               mp_layers=[180] * 4, dropout_mpnn=[0.0] * 4, mlp=True, downstream_layers=[180, 80],
+                                               dropout_dn=[0.0, 0.0], target_dim=1, sc_type="last", activation=_act), True)
+
 
 def _model(name, z):
     from phc.hypercomplex.undirectional.models import PHMSkipConnectAdd
@@ -71,10 +83,30 @@ def _host_batch(z):
                             batch=z["batch"].numpy(), y=z["y"].numpy().astype(np.float32), num_graphs=int(z["y"].shape[0]))
 
 
+def _worst32(z):
+    return max(float(z[k]) for k in z if k.startswith("err32::") and float(z["grad64::" + k[7:]].abs().max()) >= 1e-7)
+
+
+_KINK_W = []
+
+
+def _with_kink_yardstick(name, z):
+    """The g12 ReLU fixtures are small batches (1.1-1.5 k nodes) on which the reference's own float32 run happened to flip no
+    ReLU mask bit against its float64 run (W ~ 3e-6), while another fp32 summation order can (one flip: 3e-3 on the tensors
+    behind it, the logits unmoved; the swish twins of the same shapes hold 3e-5 on every path).  Their yardstick is the
+    model-wide W of the reference's own arithmetic with ReLU, as measured on the full 512-graph batch (g10_molhiv_b512)."""
+    if name.startswith("g12_") and not name.endswith("_swish"):
+        if not _KINK_W:
+            _KINK_W.append(_worst32(tensors(load("g10_molhiv_b512"))))
+        z = dict(z)
+        z["kink_w"] = torch.tensor(_KINK_W[0])
+    return z
+
+
 def _grad_rows(named_grads, z):
     """(worst ratio, table): per tensor, error against the float64 reference gradient vs the allowance."""
     rows = []
-    worst32 = max(float(z[k]) for k in z if k.startswith("err32::") and float(z["grad64::" + k[7:]].abs().max()) >= 1e-7)
+    worst32 = max(_worst32(z), float(z.get("kink_w", 0.0)))
     for k, g in named_grads:
         ref64 = z.get("grad64::" + k)
         if ref64 is None:
@@ -104,7 +136,7 @@ def _check_grads(named_grads, z, what):
     if "grad::" + rows[0][3] in z:
         # where the fixture also holds the reference's float32 gradients: the direct comparison (one more W of allowance:
         # that is how far those values themselves are from exact)
-        worst32 = max(r[2] for r in rows)
+        worst32 = max(max(r[2] for r in rows), float(z.get("kink_w", 0.0)))
         for _, _, _, k in rows:
             g = dict(named_grads)[k]
             assert relerr(g, z["grad::" + k]) <= max(TOL, (GRAD_SLACK + 1.0) * worst32), k
@@ -127,7 +159,7 @@ def _check_running_stats(model, z, what):
 
 @pytest.mark.parametrize("name", list(FULL))
 def test_fullwidth_plain_module_path(name):
-    z = tensors(load(name))
+    z = _with_kink_yardstick(name, tensors(load(name)))
     model = _model(name, z)
     regression = FULL[name][1]
     data = types.SimpleNamespace(x=z["x"].to(DEV), edge_index=z["edge_index"].to(DEV), edge_attr=z["edge_attr"].to(DEV),
@@ -154,7 +186,7 @@ def test_fullwidth_deferred_gradient_path(name):
     """harness.train_step without the optimizer: prebuilt H, deferred parameter gradients, the merged step tail and
     the engine's fused NaN-masked BCE."""
     from phc_gnn_amd import harness
-    z = tensors(load(name))
+    z = _with_kink_yardstick(name, tensors(load(name)))
     model = _model(name, z)
     regression = FULL[name][1]
     data = harness.to_device(_host_batch(z), DEV)
@@ -174,7 +206,7 @@ def test_fullwidth_graphed_replay_on_padded_batch(name):
     out so that the gradients can be read."""
     from phc_gnn_amd import graphed, harness
     from phc_gnn_amd.optim import ClipAdam
-    z = tensors(load(name))
+    z = _with_kink_yardstick(name, tensors(load(name)))
     model = _model(name, z)
     regression = FULL[name][1]
     gb = _host_batch(z)
@@ -248,6 +280,15 @@ FULL_SIZE = {
     "molhiv_b512_softmax": dict(phm_dim=4, num_layers=4, num_atom_feats=9, num_bond_feats=3, num_dn_hidden=2, mlp=True,
                                 sc_type="first", msg_aggr="softmax"),
 }
+# the reference's published shapes at the BASELINE batch sizes (harness.WORKLOADS *_pub_*_nodrop): k = 50 / 40 / 45
+FULL_SIZE.update({
+    "molhiv_pub_phc4_2x200_nodrop": dict(phm_dim=4, num_layers=2, num_atom_feats=9, num_bond_feats=3, num_dn_hidden=2, mlp=True,
+                                         sc_type="first", msg_aggr="softmax"),
+    "zinc_pub_phc5_4x200_nodrop": dict(phm_dim=5, num_layers=4, num_atom_feats=1, num_bond_feats=1, num_dn_hidden=2, mlp=True,
+                                       sc_type="last"),
+    "zinc_pub_phc4_4x180_nodrop": dict(phm_dim=4, num_layers=4, num_atom_feats=1, num_bond_feats=1, num_dn_hidden=2, mlp=True,
+                                       sc_type="last"),
+})
 # the same three with the smooth activation (no ReLU kink): every gradient tensor within 3e-5 of the float64 oracle
 FULL_SIZE.update({k + "_swish": dict(v, act="swish") for k, v in list(FULL_SIZE.items())})
 SMOOTH_GRAD_TOL = 3e-5

@@ -186,6 +186,16 @@ FULLWIDTH_CFGS = {
     "g10_molpcba_h256_swish": dict(phm_dim=4, num_layers=5, num_atom_feats=9, num_bond_feats=3, num_dn_hidden=2, mlp=True,
                                    sc_type="first", act="swish"),
 }
+# the reference's published shapes (benchmarks/README.md:45-91, run_script_zinc_phm4.sh:4-5; make_golden.py::g12_published):
+# component sizes 50 / 40 / 45, GEMM depths 200 / 180, the softmax aggregation of the molhiv paper model
+for _sfx, _act in (("", "relu"), ("_swish", "swish")):
+    FULLWIDTH_CFGS["g12_hiv_phc4_2x200" + _sfx] = dict(phm_dim=4, num_layers=2, num_atom_feats=9, num_bond_feats=3, num_dn_hidden=2,
+                                                      mlp=True, sc_type="first", msg_aggr="softmax", act=_act)
+    FULLWIDTH_CFGS["g12_zinc_phc5_4x200" + _sfx] = dict(phm_dim=5, num_layers=4, num_atom_feats=1, num_bond_feats=1, num_dn_hidden=2,
+                                                       mlp=True, sc_type="last", act=_act)
+    FULLWIDTH_CFGS["g12_zinc_phc4_4x180" + _sfx] = dict(phm_dim=4, num_layers=4, num_atom_feats=1, num_bond_feats=1, num_dn_hidden=2,
+                                                       mlp=True, sc_type="last", act=_act)
+L1_FIXTURES = ("g10_zinc_h256", "g12_zinc")
 
 
 @pytest.mark.parametrize("name", list(FULLWIDTH_CFGS))
@@ -203,7 +213,7 @@ def test_g10_fullwidth_models(name, dtype):
     lt = O.skip_connect_add_forward(p, z["x"], z["edge_index"], z["edge_attr"], z["batch"], training=True, **cfg)
     assert lt.dtype == dtype
     y = z["y"].to(dtype)
-    loss = torch.nn.functional.l1_loss(lt, y) if name.startswith("g10_zinc_h256") else O.bce_loss_masked(lt, y)
+    loss = torch.nn.functional.l1_loss(lt, y) if name.startswith(L1_FIXTURES) else O.bce_loss_masked(lt, y)
     grads = torch.autograd.grad(loss, [p[k] for k in gnames])
     exact = dtype == torch.float64
     # gradient yardstick: the largest float32-vs-float64 distance of any of the reference's own gradient tensors (the
