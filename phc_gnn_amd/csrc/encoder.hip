@@ -1208,7 +1208,7 @@ __global__ __launch_bounds__(256, 2) void tail_partial_kernel(GradBatch gb, Tail
     int tile;
     long long split;
     xcd_tile_split(local, (unsigned)j.tiles, (unsigned)j.splits, tile, split);
-    if (j.t128 == 3 && j.out % 64 == 0)
+    if (j.t128 == 3 && dh3_np(j.out) == 2)
         dH_direct_body<2>(j.x, j.dy, j.slabs, j.N, j.in, j.out, j.tiles_j, j.rows_per_split, tile, split, smem, j.xf_stat, j.xf_act,
                           xf_count);
     else if (j.t128 == 3)                                    // out an odd multiple of 32: 128 x 32 tiles

@@ -296,6 +296,9 @@ __device__ __forceinline__ void dH_partial_body128(const float *__restrict__ X, 
 // summation order 0, 1, 2, 3) and write one slab per WORKGROUP.
 // ------------------------------------------------------------------------------------------
 constexpr int DH_D = 128;                               // tile edge of the register-resident form
+// columns per lane of the 256-register form (t128 == 3) for an output width: 128 x 64 tiles, or 128 x 32 ones when out is an
+// odd multiple of 32; any other width (a multiple of 4) takes 128 x 64 tiles with a partial last one
+__host__ __device__ inline int dh3_np(int out) { return out % 64 == 0 ? 2 : (out % 32 == 0 ? 1 : 2); }
 #ifndef PHC_DH_PF
 #define PHC_DH_PF 4
 #endif
@@ -467,15 +470,19 @@ __device__ __forceinline__ void dH_direct_body(const float *__restrict__ X, cons
     for (int p2 = 0; p2 < NP; ++p2) colsum[p2] = 0.f;
     f32x4 xf_sc = {1.f, 1.f, 1.f, 1.f}, xf_sh = {0.f, 0.f, 0.f, 0.f};
     float floor_ = -__builtin_inff();
+    // partial edge tiles (in / out not multiples of the tile: the published 180- and 200-wide models): a lane whose columns lie
+    // past the matrix reads the tile's first columns instead (in bounds) — its accumulator rows / columns are never stored
+    const bool x_live = i0 + 4 * r < in, d_live = j0 + NP * r < out;
+    const int xc = x_live ? i0 + 4 * r : i0, dc = d_live ? j0 + NP * r : j0;
     if (xf_stat) {
-        xf_sc = *reinterpret_cast<const f32x4 *>(xf_stat + 2 * (size_t)in + i0 + 4 * r);
-        xf_sh = *reinterpret_cast<const f32x4 *>(xf_stat + 3 * (size_t)in + i0 + 4 * r);
+        xf_sc = *reinterpret_cast<const f32x4 *>(xf_stat + 2 * (size_t)in + xc);
+        xf_sh = *reinterpret_cast<const f32x4 *>(xf_stat + 3 * (size_t)in + xc);
         if (xf_act == PHC_ACT_RELU) floor_ = 0.f;
     } else {
         xf_count = N;                                    // a plain operand has no padding rows of its own
     }
     // lane part of every address: this lane's four columns; the upper half-wave reads the odd row of each pair
-    const unsigned xoff = (unsigned)(i0 + 4 * r) * 4u, doff = (unsigned)(j0 + NP * r) * 4u;
+    const unsigned xoff = (unsigned)xc * 4u, doff = (unsigned)dc * 4u;
     const unsigned xrow = hh ? (unsigned)in * 4u : 0u, drow = hh ? (unsigned)out * 4u : 0u;
     const long long last = max(r_end - 1, 0LL);          // clamped rows: reads past the range stay in bounds
 
@@ -509,7 +516,7 @@ __device__ __forceinline__ void dH_direct_body(const float *__restrict__ X, cons
         for (int e = 0; e < 4; ++e) {
             const DVT v = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
             const int m = e + 8 * wave + 4 * hh;         // reg = 4 wave + e: (reg & 3) + 8 (reg >> 2) + 4 hh
-            *reinterpret_cast<DVT *>(slab + (size_t)(i0 + 4 * m + q) * out + j0 + NP * r) = v;
+            if (d_live && i0 + 4 * m + q < in) *reinterpret_cast<DVT *>(slab + (size_t)(i0 + 4 * m + q) * out + j0 + NP * r) = v;
         }
     }
     DH_STAMP(3);
@@ -521,7 +528,7 @@ __device__ __forceinline__ void dH_direct_body(const float *__restrict__ X, cons
             DVT v = slots[tid];
 #pragma unroll
             for (int e = 1; e < 8; ++e) v += slots[e * 32 + tid];           // fixed order: (wave 0: hh 0, hh 1), wave 1, ...
-            *reinterpret_cast<DVT *>(slab + (size_t)in * out + j0 + NP * tid) = v;
+            if (j0 + NP * tid < out) *reinterpret_cast<DVT *>(slab + (size_t)in * out + j0 + NP * tid) = v;
         }
     }
     DH_STAMP(4);

@@ -1260,13 +1260,13 @@ static DhPlan dh_plan(int64_t N, int in, int out) {
 static bool dh_direct_shape_ok(int64_t N, int in, int out) {
     static const bool off = getenv("PHC_DH_NO_DIRECT") != nullptr;
     if ((int64_t)(in > out ? in : out) * 4 * (N / 256 + 128) >= ((int64_t)1 << 31)) return false;       // 32-bit offsets per wavefront
-    return !off && in % DH_D == 0 && out % DH_D == 0 && N >= 8;
+    return !off && in % 4 == 0 && out % 4 == 0 && in >= 96 && out >= 32 && N >= 8;             // partial edge tiles: dH_direct_body
 }
 static DhPlan dh_plan_direct(int64_t N, int in, int out) {
     DhPlan p;
     p.t128 = 2;
-    p.tiles_i = in / DH_D;
-    p.tiles_j = out / DH_D;
+    p.tiles_i = (in + DH_D - 1) / DH_D;
+    p.tiles_j = (out + DH_D - 1) / DH_D;
     const int64_t tiles = (int64_t)p.tiles_i * p.tiles_j;
     static const int64_t dtarget = getenv("PHC_DH_DIRECT_TARGET") ? atoll(getenv("PHC_DH_DIRECT_TARGET")) : 256;
     int64_t rps = (tiles * N / dtarget + 63) / 64 * 64;
@@ -1284,13 +1284,13 @@ struct GradPlan {
     size_t slab_elems;
 };
 
-// register-resident tile form (dH_direct_body): whole 128 x 128 tiles and float4-addressable operands
-// out_mult: 128 for the 128 x 128 tiles (form 2), 32 for form 3 (128 x 64 tiles, or 128 x 32 ones when out is an odd multiple of 32)
-static inline bool dh_use_direct(const phc_phm_grad_job &jb, int out_mult = DH_D) {
+// register-resident tile form (dH_direct_body): float4-addressable operands; widths that are not multiples of the tile end in a
+// partial tile (form 2: 128 x 128 tiles; form 3: 128 x 64, or 128 x 32 when out is an odd multiple of 32 — dh3_np)
+static inline bool dh_use_direct(const phc_phm_grad_job &jb) {
     static const bool off = getenv("PHC_DH_NO_DIRECT") != nullptr;
     const int in = jb.n * jb.kin, out = jb.n * jb.kout;
     if ((int64_t)(in > out ? in : out) * 4 * (jb.N / 256 + 128) >= ((int64_t)1 << 31)) return false;    // 32-bit offsets per wavefront
-    return !off && in % DH_D == 0 && out % out_mult == 0 && jb.N >= 8 && (reinterpret_cast<uintptr_t>(jb.x) & 15) == 0 &&
+    return !off && in % 4 == 0 && out % 4 == 0 && in >= 96 && out >= 32 && jb.N >= 8 && (reinterpret_cast<uintptr_t>(jb.x) & 15) == 0 &&
            (reinterpret_cast<uintptr_t>(jb.dy) & 15) == 0 &&
            (!jb.xf_stat || ((reinterpret_cast<uintptr_t>(jb.xf_stat) & 15) == 0 &&
                             (jb.xf_act == PHC_ACT_IDENTITY || jb.xf_act == PHC_ACT_RELU)));
@@ -1305,10 +1305,10 @@ static void grad_plans(const phc_phm_grad_job *jobs, int num, GradPlan *plans, i
     int64_t total = 0, direct_rows = 0;
     for (int k = 0; k < num; ++k) {
         const int in = jobs[k].n * jobs[k].kin, out = jobs[k].n * jobs[k].kout;
-        plans[k].t128 = dh_use_direct(jobs[k], direct_form == 3 ? 32 : DH_D) ? direct_form : (dh_use_128(jobs[k].N, in, out) ? 1 : 0);
+        plans[k].t128 = dh_use_direct(jobs[k]) ? direct_form : (dh_use_128(jobs[k].N, in, out) ? 1 : 0);
         const int T = plans[k].t128 ? DH_T2 : DH_T;
         plans[k].tiles_i = (in + T - 1) / T;
-        plans[k].tiles_j = plans[k].t128 == 3 ? (out % 64 == 0 ? out / 64 : out / 32) : (out + T - 1) / T;
+        plans[k].tiles_j = plans[k].t128 == 3 ? (out + 32 * dh3_np(out) - 1) / (32 * dh3_np(out)) : (out + T - 1) / T;
         plans[k].slab_elems = (size_t)in * out + out;
         if (plans[k].t128 >= 2)
             direct_rows += (int64_t)plans[k].tiles_i * plans[k].tiles_j * jobs[k].N;

@@ -154,6 +154,33 @@ def test_deferred_param_grads_match_oracle_and_per_layer_path(ops):
     assert_close(W.grad, dW, TOL, "late backward dW")
 
 
+@pytest.mark.parametrize("n,kin,kout,N", [(4, 50, 50, 3000), (4, 45, 45, 1200), (5, 40, 40, 2500), (4, 45, 20, 900), (5, 40, 26, 700),
+                                          (4, 50, 32, 1100), (4, 32, 50, 640)])
+def test_param_grads_on_partial_register_tiles(ops, n, kin, kout, N):
+    """Widths of the reference's published models (200 = 4 x 50 = 5 x 40, 180 = 4 x 45, heads 80 / 130 / 128): dH = x^T dy on the
+    register-resident tiles whose last tile is partial, per-layer (phc_phm_linear_bwd) and batched (phc_phm_param_grads) — dW, dA,
+    db and dx against the oracle."""
+    from oracle import phc_oracle as O
+    g = torch.Generator().manual_seed(n * 1000 + kin + kout)
+    x = torch.randn(N, n * kin, generator=g)
+    A = torch.randn(n, n, n, generator=g)
+    W = torch.randn(n, kin, kout, generator=g) * 0.2
+    b = torch.randn(n * kout, generator=g)
+    dy = torch.randn(N, n * kout, generator=g)
+    dx, dW, dA, db = O.phm_linear_backward(x, A, W, dy)
+    for deferred in (False, True):
+        xd = x.to(DEV).requires_grad_()
+        Ad, Wd, bd = (t.to(DEV).requires_grad_() for t in (A, W, b))
+        ctx = ops.deferred_param_grads() if deferred else __import__("contextlib").nullcontext()
+        with ctx:
+            (ops.phm_linear(xd, Ad, Wd, bd) * dy.to(DEV)).sum().backward()
+        what = "batched" if deferred else "per-layer"
+        assert_close(xd.grad, dx, TOL, f"{what} dx")
+        assert_close(Wd.grad, dW, TOL, f"{what} dW")
+        assert_close(Ad.grad, dA, TOL, f"{what} dA")
+        assert_close(bd.grad, db, TOL, f"{what} db")
+
+
 def _ref_sorted(key, other, num_keys):
     order = np.argsort(key, kind="stable")
     rowptr = np.zeros(num_keys + 1, dtype=np.int64)
