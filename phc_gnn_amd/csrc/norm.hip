@@ -310,6 +310,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_kernel(const float *__res
 // running statistics.  27 KB of partials per workgroup instead of a launch boundary.
 constexpr int BNM_COLS = 32;
 constexpr int BNM_LANES = BN_THREADS / BNM_COLS;            // 8
+static inline int bn_col_blocks(int h) { return (h + BNM_COLS - 1) / BNM_COLS; }     // the last block may be partial (h % 4 == 0)
 // PL = partials per lane: 16 serves <= 128 partials (the molecule-scale GEMM emits 108) with half the loads in flight
 template <int ACT, int PL>
 __global__ __launch_bounds__(BN_THREADS) void bn_apply_merged_kernel(const float *__restrict__ x, BnParams p, const int *__restrict__ n_valid,
@@ -321,7 +322,9 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_merged_kernel(const float
     __shared__ float r_a[BNM_LANES][BNM_COLS], r_b[BNM_LANES][BNM_COLS], s_scale[BNM_COLS], s_shift[BNM_COLS];
     const int tid = threadIdx.x;
     const int ci = tid & (BNM_COLS - 1), pl = tid / BNM_COLS;
-    const int c = blockIdx.x * BNM_COLS + ci;                 // h % 32 == 0
+    // the last column block may be partial (h % 4 == 0 only): its spare threads work on the last column again and store nothing
+    const bool c_ok = blockIdx.x * BNM_COLS + ci < h;
+    const int c = c_ok ? blockIdx.x * BNM_COLS + ci : h - 1;
     const long long count = n_valid ? min((long long)*n_valid, N) : N;
     const bool dropping = drop.p > 0.f;
     const unsigned long long seed = dropping ? drop.state[0] : 0ull, step = dropping ? drop.state[1] : 0ull;
@@ -374,7 +377,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_merged_kernel(const float
         const float invstd = 1.f / sqrtf(var + eps);
         s_scale[ci] = invstd * w;
         s_shift[ci] = bq - mean * invstd * w;
-        if (blockIdx.y == 0) {
+        if (blockIdx.y == 0 && c_ok) {
             stat[c] = mean;
             stat[h + c] = invstd;
             stat[2 * h + c] = invstd * w;
@@ -398,6 +401,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_merged_kernel(const float
     // rows of this group: thread -> (row lane = tid / 8, float4 column = tid % 8)
     const int c4 = tid & 7, rl = tid >> 3;
     const int col = blockIdx.x * BNM_COLS + c4 * 4;
+    if (col >= h) return;                                     // partial last column block
     const float4 sc4 = *reinterpret_cast<const float4 *>(s_scale + c4 * 4), sh4 = *reinterpret_cast<const float4 *>(s_shift + c4 * 4);
     const long long r0 = (long long)blockIdx.y * rows_per_group, r1 = min(N, r0 + rows_per_group);
     for (long long r = r0 + rl; r < r1; r += BN_THREADS / 8) {
@@ -434,14 +438,17 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_acc_kernel(const float *_
     static_assert(BNM_LANES == 2 * STAT_ACC_REP, "one (quantity, replica) pair per partial lane");
     const int tid = threadIdx.x;
     const int ci = tid & (BNM_COLS - 1), pl = tid / BNM_COLS;
-    const int c = blockIdx.x * BNM_COLS + ci;                 // h % 32 == 0
+    // the last column block may be partial (h % 4 == 0 only): its spare threads work on the last columns again and store nothing
+    const bool c_ok = blockIdx.x * BNM_COLS + ci < h;
+    const int c = c_ok ? blockIdx.x * BNM_COLS + ci : h - 1;
     const long long count = n_valid ? min((long long)*n_valid, N) : N;
     const bool dropping = drop.p > 0.f;
     const unsigned long long seed = dropping ? drop.state[0] : 0ull, step = dropping ? drop.state[1] : 0ull;
     // the first rounds of this thread's rows go in flight BEFORE the totals prologue (clamped addresses): its L2 miss — the totals
     // were added at the memory side a moment ago — then overlaps with them
     const int c4 = tid & 7, rl = tid >> 3;
-    const int col = blockIdx.x * BNM_COLS + c4 * 4;
+    const bool col_ok = blockIdx.x * BNM_COLS + c4 * 4 < h;
+    const int col = col_ok ? blockIdx.x * BNM_COLS + c4 * 4 : h - 4;
     const long long r0 = (long long)blockIdx.y * rows_per_group, r1 = min(N, r0 + rows_per_group);
     constexpr int PRE = 4;
     float4 xpre[PRE], rpre[PRE];
@@ -477,7 +484,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_acc_kernel(const float *_
         const float invstd = 1.f / sqrtf(var + eps);
         s_scale[ci] = invstd * w;
         s_shift[ci] = bq - mean * invstd * w;
-        if (blockIdx.y == 0) {
+        if (blockIdx.y == 0 && c_ok) {
             stat[c] = mean;
             stat[h + c] = invstd;
             stat[2 * h + c] = invstd * w;
@@ -512,6 +519,7 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_acc_kernel(const float *_
         }
         *reinterpret_cast<float4 *>(out + (size_t)r * h + col) = o;
     };
+    if (!col_ok) return;
 #pragma unroll
     for (int u = 0; u < PRE; ++u) {
         const long long r = r0 + rl + (long long)u * (BN_THREADS / 8);
@@ -747,12 +755,15 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_acc_kernel(const floa
     static_assert(BNM_LANES == 2 * STAT_ACC_REP, "one (quantity, replica) pair per partial lane");
     const int tid = threadIdx.x;
     const int ci = tid & (BNM_COLS - 1), pl = tid / BNM_COLS;
-    const int c = blockIdx.x * BNM_COLS + ci;
+    // the last column block may be partial (h % 4 == 0 only): its spare threads work on the last columns again and store nothing
+    const bool c_ok = blockIdx.x * BNM_COLS + ci < h;
+    const int c = c_ok ? blockIdx.x * BNM_COLS + ci : h - 1;
     const long long count = n_valid ? min((long long)*n_valid, N) : N;
     const bool dropping = drop.p > 0.f;
     const unsigned long long seed = dropping ? drop.state[0] : 0ull, step = dropping ? drop.state[1] : 0ull;
     const int c4 = tid & 7, rl = tid >> 3;
-    const int col = blockIdx.x * BNM_COLS + c4 * 4;
+    const bool col_ok = blockIdx.x * BNM_COLS + c4 * 4 < h;
+    const int col = col_ok ? blockIdx.x * BNM_COLS + c4 * 4 : h - 4;
     const long long r0 = (long long)blockIdx.y * rows_per_group, r1 = min(N, r0 + rows_per_group);
     // first rounds of this thread's rows go in flight (clamped addresses; rows past the range are never stored)
     float4 gpre[BNB_PRE], xpre[BNB_PRE];
@@ -779,12 +790,13 @@ __global__ __launch_bounds__(BN_THREADS) void bn_bwd_apply_acc_kernel(const floa
         s_c[3][ci] = stat[5 * h + c];
         s_c[4][ci] = training ? af / cnt : 0.f;
         s_c[5][ci] = training ? bf / cnt : 0.f;
-        if (dwb && blockIdx.y == 0) {
+        if (dwb && blockIdx.y == 0 && c_ok) {
             dwb[c] = bf;                                     // dweight = sum g * x_hat
             dwb[h + c] = af;                                 // dbias   = sum g
         }
     }
     __syncthreads();
+    if (!col_ok) return;
     float mean[4], inv[4], w[4], bb[4], mg[4], mgx[4];
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
@@ -1027,10 +1039,10 @@ int phc_bn_fwd_from_partials(const float *x, const float *stats_partial, const f
     PHC_REQUIRE(vec4 || h % 4 != 0, PHC_ERR_UNSUPPORTED, "phc_bn_fwd_from_partials: rows must be 16-byte aligned when h %% 4 == 0");
     hipStream_t s = (hipStream_t)stream;
     if (acc_mode) {
-        PHC_REQUIRE(vec4 && h % BNM_COLS == 0 && (reinterpret_cast<uintptr_t>(stats_partial) & 7) == 0, PHC_ERR_UNSUPPORTED,
-                    "phc_bn_fwd_from_partials: the accumulator form needs h %% 32 == 0 and aligned rows (h=%d)", h);
+        PHC_REQUIRE(vec4 && (reinterpret_cast<uintptr_t>(stats_partial) & 7) == 0, PHC_ERR_UNSUPPORTED,
+                    "phc_bn_fwd_from_partials: the accumulator form needs h %% 4 == 0 and aligned rows (h=%d)", h);
         long long groups = (N + 127) / 128;
-        const long long cap = (8LL * 256) / (h / BNM_COLS);
+        const long long cap = (8LL * 256) / bn_col_blocks(h);
         if (groups > cap) groups = cap;
         if (groups < 1) groups = 1;
         const long long rows_per_group = (N + groups - 1) / groups;
@@ -1038,7 +1050,7 @@ int phc_bn_fwd_from_partials(const float *x, const float *stats_partial, const f
         const unsigned long long *acc = reinterpret_cast<const unsigned long long *>(stats_partial);
         ProfScope prof(K_BN_APPLY, s);
 #define PHC_BN_FWDA(ACTC)                                                                                                      \
-    PHC_LAUNCH((bn_apply_acc_kernel<ACTC>), dim3(h / BNM_COLS, (unsigned)groups), dim3(BN_THREADS), 0, s, x, p, n_valid_dev,     \
+    PHC_LAUNCH((bn_apply_acc_kernel<ACTC>), dim3(bn_col_blocks(h), (unsigned)groups), dim3(BN_THREADS), 0, s, x, p, n_valid_dev,     \
                (long long)N, h, momentum, eps, acc, rows_per_group, residual, save_stat, out, drop)
         PHC_BN_ACT_SWITCH(act, PHC_BN_FWDA)
 #undef PHC_BN_FWDA
@@ -1046,10 +1058,10 @@ int phc_bn_fwd_from_partials(const float *x, const float *stats_partial, const f
     }
     const char *env_merged = getenv("PHC_BN_APPLY_MERGED");               // A/B switch (read per call: cheap next to a launch)
     const bool no_merged = env_merged && atoi(env_merged) == 0;
-    if (vec4 && h % BNM_COLS == 0 && !no_merged) {
+    if (vec4 && !no_merged) {
         // one launch: the merge of the partials rides in the prologue of the normalisation
         long long groups = (N + 127) / 128;                      // >= 128 rows per workgroup
-        const long long cap = (8LL * 256) / (h / BNM_COLS);      // ~8 workgroups per CU at most
+        const long long cap = (8LL * 256) / bn_col_blocks(h);    // ~8 workgroups per CU at most
         if (groups > cap) groups = cap;
         if (groups < 1) groups = 1;
         const long long rows_per_group = (N + groups - 1) / groups;
@@ -1057,11 +1069,11 @@ int phc_bn_fwd_from_partials(const float *x, const float *stats_partial, const f
         ProfScope prof(K_BN_APPLY, s);
 #define PHC_BN_FWDM2(ACTC)                                                                                                     \
     if (num_partials <= 16 * BNM_LANES)                                                                                        \
-        PHC_LAUNCH((bn_apply_merged_kernel<ACTC, 16>), dim3(h / BNM_COLS, (unsigned)groups), dim3(BN_THREADS), 0, s, x, p, n_valid_dev, \
+        PHC_LAUNCH((bn_apply_merged_kernel<ACTC, 16>), dim3(bn_col_blocks(h), (unsigned)groups), dim3(BN_THREADS), 0, s, x, p, n_valid_dev, \
                    (long long)N, h, momentum, eps, stats_partial, stats_counts, num_partials, rows_per_group, residual, save_stat, out, \
                    drop);                                                                                                       \
     else                                                                                                                       \
-        PHC_LAUNCH((bn_apply_merged_kernel<ACTC, 32>), dim3(h / BNM_COLS, (unsigned)groups), dim3(BN_THREADS), 0, s, x, p, n_valid_dev, \
+        PHC_LAUNCH((bn_apply_merged_kernel<ACTC, 32>), dim3(bn_col_blocks(h), (unsigned)groups), dim3(BN_THREADS), 0, s, x, p, n_valid_dev, \
                    (long long)N, h, momentum, eps, stats_partial, stats_counts, num_partials, rows_per_group, residual, save_stat, out, \
                    drop)
         PHC_BN_ACT_SWITCH(act, PHC_BN_FWDM2)
@@ -1089,14 +1101,14 @@ static int launch_bwd_apply_acc(const float *dy, const float *x, const float *sa
                                 int act, const unsigned long long *acc, float *dx, float *dwb_flat, int training, const BnDrop &drop,
                                 hipStream_t s) {
     long long groups = (N + 127) / 128;
-    const long long cap = (8LL * 256) / (h / BNM_COLS);
+    const long long cap = (8LL * 256) / bn_col_blocks(h);
     if (groups > cap) groups = cap;
     if (groups < 1) groups = 1;
     const long long rows_per_group = (N + groups - 1) / groups;
     groups = (N + rows_per_group - 1) / rows_per_group;
     ProfScope prof(K_BN_BWD_APPLY, s);
 #define PHC_BN_BAA(ACTC)                                                                                                     \
-    PHC_LAUNCH((bn_bwd_apply_acc_kernel<ACTC>), dim3(h / BNM_COLS, (unsigned)groups), dim3(BN_THREADS), 0, s, dy, x, save_stat,    \
+    PHC_LAUNCH((bn_bwd_apply_acc_kernel<ACTC>), dim3(bn_col_blocks(h), (unsigned)groups), dim3(BN_THREADS), 0, s, dy, x, save_stat,    \
                n_valid_dev, (long long)N, h, acc, rows_per_group, dx, dwb_flat, training, drop)
     PHC_BN_ACT_SWITCH(act, PHC_BN_BAA)
 #undef PHC_BN_BAA
@@ -1173,7 +1185,7 @@ int phc_bn_bwd(const float *dy, const float *x, const float *save_stat, const in
         if (rc) return rc;
     }
     if (!dx) return PHC_OK;
-    if (acc_mode && vec4 && h % BNM_COLS == 0 && !getenv("PHC_BN_BWD_APPLY_FLAT")) return launch_bwd_apply_acc(dy, x, save_stat, n_valid_dev, N, h, act, acc, dx, dwb_flat, training, drop, s);
+    if (acc_mode && vec4 && !getenv("PHC_BN_BWD_APPLY_FLAT")) return launch_bwd_apply_acc(dy, x, save_stat, n_valid_dev, N, h, act, acc, dx, dwb_flat, training, drop, s);
     const size_t lds = sizeof(float) * 6 * (size_t)h;
     ProfScope prof(K_BN_BWD_APPLY, s);
 #define PHC_BN_BA(ACTC)                                                                                                      \
@@ -1214,7 +1226,7 @@ int phc_bn_bwd_from_partials(const float *dy, const float *x, const float *save_
         if (rc) return rc;
     }
     if (!dx) return PHC_OK;
-    if (acc_mode && vec4 && h % BNM_COLS == 0 && !getenv("PHC_BN_BWD_APPLY_FLAT"))
+    if (acc_mode && vec4 && !getenv("PHC_BN_BWD_APPLY_FLAT"))
         return launch_bwd_apply_acc(dy, x, save_stat, n_valid_dev, N, h, act, acc, dx, dwb_flat, 1, BnDrop{0.f, 0, h, 0, nullptr}, s);
     const size_t lds = sizeof(float) * 6 * (size_t)h;
     ProfScope prof(K_BN_BWD_APPLY, s);

@@ -56,7 +56,7 @@ for _k in ("molhiv_pub_phc4_2x200", "zinc_pub_phc5_4x200", "zinc_pub_phc4_4x180"
     WORKLOADS[_k + "_nodrop"] = {k: v for k, v in WORKLOADS[_k].items() if not k.startswith("dropout")}
     WORKLOADS[_k + "_nodrop_swish"] = dict(WORKLOADS[_k + "_nodrop"], activation="swish")
 # smooth-activation twins (parity runs: without the ReLU kink every gradient tensor is comparable to ~1e-5)
-for _k in ("zinc_b1024", "molpcba_b1024", "molhiv_b512_softmax"):
+for _k in ("molhiv_b32", "molhiv_b512", "zinc_b1024", "molpcba_b1024", "molhiv_b512_softmax"):
     WORKLOADS[_k + "_swish"] = dict(WORKLOADS[_k], activation="swish")
 
 

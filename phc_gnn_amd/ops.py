@@ -652,7 +652,7 @@ class stat_accumulators:
 
 def stat_acc_slot(dev, h: int):
     """A zeroed accumulator [2 * replicas, 2 h] (int64) of the running step, or None outside ``stat_accumulators``."""
-    if h % 32:
+    if h % 4:                              # the accumulator kernels address float4 column groups (a partial last 32-column block is fine)
         return None
     dev = torch.device(dev)
     arena = _STAT_ARENAS.get((dev.type, dev.index if dev.index is not None else torch.cuda.current_device()))

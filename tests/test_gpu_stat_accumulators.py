@@ -28,7 +28,8 @@ def _step_grads(wl, use_acc, seed=5):
     return float(loss), grads, stats
 
 
-@pytest.mark.parametrize("wl", ["molhiv_b32", "molhiv_b512"])
+@pytest.mark.parametrize("wl", ["molhiv_b32", "molhiv_b512", "molhiv_b32_swish", "molhiv_b512_swish", "zinc_pub_phc5_4x200_nodrop_swish",
+                                "zinc_pub_phc4_4x180_nodrop_swish", "molhiv_pub_phc4_2x200_nodrop_swish"])
 def test_training_step_with_accumulators_equals_the_partial_row_path(wl):
     """Same loss, gradients and running statistics with and without the accumulators (only the summation order of the
     statistics differs: fp32 per workgroup, then exact integer totals instead of a fixed-order Chan merge)."""
@@ -40,8 +41,9 @@ def test_training_step_with_accumulators_equals_the_partial_row_path(wl):
     keep = [k for k in g0 if not (k.endswith(".b") and k not in ("pooling.linear.b", "downstream.affine.2.b"))
             and float(g0[k].abs().max()) > 0]
     worst, worst_key = max((relerr(g1[k], g0[k]), k) for k in keep)
-    # fp32 noise through 12 batch-norms and ReLU kinks (a pre-activation within 1e-7 of zero may flip): a wrong statistic shows as 1e-1
-    assert worst < 5e-4, (worst, worst_key)
+    # fp32 noise through 12 batch-norms; with ReLU a pre-activation within 1e-7 of zero may flip (one flip: 3e-3 .. 1e-2 on the
+    # tensors behind it; a wrong statistic shows as 1e-1) — the smooth twins are the tight check of the same pipelines
+    assert worst < (5e-5 if wl.endswith("_swish") else 3e-2), (worst, worst_key)
     for k in s0:
         assert_close(s1[k], s0[k], 1e-5, k)
 
@@ -55,7 +57,8 @@ def test_accumulator_steps_are_bit_reproducible():
     assert all(torch.equal(a[2][k], b[2][k]) for k in a[2])
 
 
-@pytest.mark.parametrize("N,h,scale", [(1000, 128, 1.0), (12874, 128, 30.0), (70001, 256, 1e-3), (33, 32, 1.0)])
+@pytest.mark.parametrize("N,h,scale", [(1000, 128, 1.0), (12874, 128, 30.0), (70001, 256, 1e-3), (33, 32, 1.0),
+                                       (2500, 200, 1.0), (900, 180, 3.0), (640, 72, 1.0)])      # partial last 32-column block
 def test_statistics_gemm_into_an_accumulator_matches_float64(N, h, scale):
     """phc_gemm_prebuilt_stats (accumulator form) -> phc_bn_fwd_from_partials (accumulator form): the normalised output and the
     saved statistics against float64, incl. a column with a large mean (cancellation in E[x^2] - E[x]^2 is done in double)."""
