@@ -114,7 +114,9 @@ typedef struct phc_phm_H_job {
     const float *A, *W;            /* device: [n,n,n], [n,kin,kout] */
     float *H, *HT;                 /* device outputs; HT may be NULL */
     int32_t n, kin, kout;
-    int32_t flags;                 /* bit 0: n == 1 and W is an nn.Linear weight [kout, kin]: H = W^T, HT unused (it is W) */
+    int32_t flags;                 /* bit 0: n == 1 and W is an nn.Linear weight [kout, kin]: H = W^T, HT unused (it is W);
+                                    * flags == 2: zero fill — H[0 .. kin * kout) = 0, n = 1, everything else NULL (the step's
+                                    * statistics accumulators are cleared by the launch that opens the step) */
     /* Optional (ABI 4): the same matrices in "k4" form for the H-stationary GEMM — a [Kd, Nd] operand stored as
      * [Kd / 4][Nd] float4, slot (k / 4) * Nd + j = rows 4 (k / 4) .. +3 of column j (Kd % 4 == 0; PHM jobs only).  A lane of
      * v_mfma_f32_16x16x4_f32 then fetches its operands of four consecutive k-steps with ONE 16-byte access. */

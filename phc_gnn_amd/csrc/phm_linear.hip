@@ -832,7 +832,7 @@ __global__ void phm_build_H_kernel(const float *__restrict__ A, const float *__r
 // H and H^T of MANY layers in one launch (phc_phm_build_H_batched): the operand matrices of a whole
 // training step are assembled once, right after the weights changed, and every GEMM of the step
 // loads its panel from them.
-constexpr int H_JOBS_PER_LAUNCH = 16;
+constexpr int H_JOBS_PER_LAUNCH = 32;
 struct HJobDev {
     const float *A, *W;
     float *H, *HT;
@@ -858,6 +858,10 @@ __global__ __launch_bounds__(256) void phm_build_H_batched_kernel(HBatch b) {
     const int k = e / out, jc = e - k * out;
     const int a = k / kin, kap = k - a * kin;
     const int c = jc / kout, pi = jc - c * kout;
+    if (jb.dense_t == 2) {                                   // zero-fill job
+        jb.H[e] = 0.f;
+        return;
+    }
     if (jb.dense_t) {
         jb.H[e] = jb.W[(size_t)jc * kin + k];
         return;
@@ -1133,6 +1137,8 @@ static unsigned long long *g_hs_stamps = nullptr;             // diagnostics (ph
 
 template <int K, int TPW, int WAVES, int FLAGS>
 static int launch_hs_cfg(GemmHsArgs a, const XfAcc &xa, hipStream_t s) {
+    // 16-row steps (RB = 1).  32-row steps (RB = 2) were measured inside the replayed zinc_b1024 step: plain 28.3 -> 33.6 us,
+    // with statistics 41.9 -> 46.9 us per launch (5.8 -> 2.9 steps per workgroup: the last round is half empty)
     constexpr int RB = 1, R = HS_RING;
     a.stamps = g_hs_stamps;
     a.panels = a.Nout / (16 * TPW * WAVES);
@@ -1613,6 +1619,15 @@ int phc_phm_build_H_batched(const phc_phm_H_job *jobs, int num_jobs, void *strea
             const phc_phm_H_job &jb = jobs[c0 + k];
             int rc = check_phm_dims("phc_phm_build_H_batched", 1, jb.n, jb.kin, jb.kout);
             if (rc) return rc;
+            if (jb.flags == 2) {                                 // zero fill: H[0 .. kin * kout) = 0 (n = 1; the step's statistics arena)
+                PHC_REQUIRE(jb.H && jb.n == 1 && !jb.HT && !jb.Hk4 && !jb.HTk4, PHC_ERR_INVALID_ARG,
+                            "phc_phm_build_H_batched: job %d: a zero-fill job takes H, n = 1 and nothing else", c0 + k);
+                b.j[k] = HJobDev{};
+                b.j[k].H = jb.H; b.j[k].n = 1; b.j[k].kin = jb.kin; b.j[k].kout = jb.kout; b.j[k].dense_t = 2;
+                b.j[k].blk0 = blocks;
+                blocks += (unsigned)(((size_t)jb.kin * jb.kout + 255) / 256);
+                continue;
+            }
             const int dense_t = jb.flags & 1;
             PHC_REQUIRE((jb.A || dense_t) && jb.W && jb.H, PHC_ERR_INVALID_ARG, "phc_phm_build_H_batched: job %d: null pointer", c0 + k);
             PHC_REQUIRE(!dense_t || jb.n == 1, PHC_ERR_INVALID_ARG, "phc_phm_build_H_batched: job %d: a dense weight needs n = 1", c0 + k);

@@ -287,7 +287,7 @@ class GraphedTrainStep:
         """zero_grad, forward, loss, backward (+ pack the gradients into the flat all-reduce bucket)."""
         self.optimizer.zero_grad(set_to_none=True)
         advance_dropout_rng(self.model, bs.data)
-        with prebuilt_H(self._pairs, self._dense), deferred_param_grads(), stat_accumulators(self.device):
+        with stat_accumulators(self.device), prebuilt_H(self._pairs, self._dense), deferred_param_grads():
             logits = self.model(bs.data)
             loss = loss_fn(logits, bs.data, self.cfg.regression)
             loss.backward(self._seed)

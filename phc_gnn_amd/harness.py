@@ -150,7 +150,7 @@ def train_step(model, data, optimizer: Optional[torch.optim.Optimizer], cfg: Ste
     advance_dropout_rng(model, data)
     # operand matrices of all PHM layers: one launch; dW/dA/db of all layers: three batched launches after the backward
     # (stat_accumulators: the batch-norm statistics of the step travel through zeroed accumulator slots, no merge launches)
-    with prebuilt_H(phm_pairs(model), dense_weights(model)), deferred_param_grads(), stat_accumulators(data.x.device):
+    with stat_accumulators(data.x.device), prebuilt_H(phm_pairs(model), dense_weights(model)), deferred_param_grads():
         logits = model(data)
         loss = loss_fn(logits, data, cfg.regression)
         loss.backward(backward_seed(loss))

@@ -430,7 +430,12 @@ def prebuilt_H(pairs, dense=()):
                 total = sum(4 * (W.shape[0] * W.shape[1]) * (W.shape[0] * W.shape[2]) if A is not None else W.numel()
                             for A, W in prs)
                 flat = torch.empty(total, dtype=torch.float32, device=dev)
-                arr = (L.HJob * len(prs))()
+                # the step's statistics accumulators are cleared by this launch too (stat_accumulators entered just before)
+                arena = _STAT_ARENAS.get((dev.type, dev.index if dev.index is not None else torch.cuda.current_device()))
+                zero = arena.take_pending_zero() if (arena is not None and arena.active) else None
+                arr = (L.HJob * (len(prs) + (1 if zero else 0)))()
+                if zero:
+                    arr[len(prs)] = L.HJob(None, None, L.ptr(zero[0]), None, 1, zero[1] // 256, 256, 2, None, None)
                 off = 0
                 for i, (A, W) in enumerate(prs):
                     if A is None:                            # nn.Linear weight [out, in]: H = W^T, and W itself is H^T
@@ -447,7 +452,7 @@ def prebuilt_H(pairs, dense=()):
                     off += 4 * sz
                     arr[i] = L.HJob(L.ptr(A), L.ptr(W), L.ptr(H), L.ptr(HT), n, kin, kout, 0, L.ptr(Hk4), L.ptr(HTk4))
                     _PREBUILT.table[(A.data_ptr(), W.data_ptr())] = (H, HT, A._version, W._version, Hk4, HTk4)
-                L.check(lib.phc_phm_build_H_batched(arr, len(prs), L.stream_ptr(dev)), "phc_phm_build_H_batched")
+                L.check(lib.phc_phm_build_H_batched(arr, len(arr), L.stream_ptr(dev)), "phc_phm_build_H_batched")
         yield
     finally:
         _PREBUILT.table = {}
@@ -610,13 +615,28 @@ class _StatArena:
         self.buf = torch.zeros(self.WORDS, dtype=torch.int64, device=dev)
         self.used = 0                  # words handed out since the last reset
         self.dirty = 0                 # words that may be non-zero
+        self.pending_zero = 0          # words of the previous step still to be cleared (stat_accumulators.__enter__)
         self.active = False
+
+    def take_pending_zero(self):
+        """(tensor, float count) of the region a zero-fill job must clear (rounded up to whole 256-float blocks), or None."""
+        if not self.pending_zero:
+            return None
+        floats = min((2 * self.pending_zero + 255) // 256 * 256, 2 * self.WORDS)
+        self.pending_zero = 0
+        return self.buf, floats
+
+    def flush_pending_zero(self):
+        if self.pending_zero:
+            self.buf[:self.pending_zero].zero_()
+            self.pending_zero = 0
 
     def slot(self, h: int):
         lib = L.load()
         words = lib.phc_stat_acc_words(h)
         if not self.active or self.used + words > self.WORDS:
             return None
+        self.flush_pending_zero()
         t = self.buf[self.used:self.used + words].view(2 * lib.phc_stat_acc_replicas(), 2 * h)
         self.used += words
         self.dirty = max(self.dirty, self.used)
@@ -637,8 +657,10 @@ class stat_accumulators:
         arena = _STAT_ARENAS.get(key)
         if arena is None:
             arena = _STAT_ARENAS[key] = _StatArena(self.dev)
-        if arena.dirty:
-            arena.buf[:arena.dirty].zero_()                    # one memset: everything the previous step added into
+        # everything the previous step added into is cleared before this step's first accumulator user: by the operand-build
+        # launch that opens a training step (prebuilt_H, entered right after this context: a zero-fill job in its table) or, when
+        # no build follows, by one memset at the first slot()
+        arena.pending_zero = arena.dirty
         arena.used = 0
         arena.active = True
         self.arena = arena
