@@ -36,6 +36,7 @@ def phm_dropout(x: torch.Tensor, phm_dim: int, p: float = 0.2, training: bool = 
     assert 0.0 <= p <= 1.0, f"dropout rate must be in [0.0 ; 1.0]. {p} was inserted!"
     if not (training and p > 0.0):
         return x
+    _engine.warn_slow_path("phm-dropout", "phm_dropout as a stand-alone op")
     if not same:
         return F.dropout(input=x, p=p, training=training)
     k = x.size(-1) // phm_dim

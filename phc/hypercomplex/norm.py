@@ -78,6 +78,7 @@ class NaivePHMNorm(nn.Module):
             activation, n_valid, linear.phm_rule, linear.W, linear.b, out_stats)
 
     def _plain(self, x, activation, residual):
+        _engine.warn_slow_path("norm-plain", "NaivePHMNorm without running statistics")
         out = F.batch_norm(x, None, None, None, None, True, 0.0, self.eps)
         out = _engine_act(out, activation)
         return out if residual is None else out + residual
@@ -120,6 +121,8 @@ class PHMNorm(nn.Module):
         if isinstance(self.bn, NaivePHMNorm) and activation.lower() in _FUSABLE_ACTS and self.bn.track_running_stats and \
                 (dropout is None or (x.shape[-1] % 4 == 0 and (x.shape[-1] // self.phm_dim) % 4 == 0)):
             return self.bn.forward_fused(x, activation, residual, n_valid, dropout)
+        _engine.warn_slow_path("norm-act-dropout", f"norm + activation '{activation}'" + (" + dropout" if dropout is not None else "")
+                               + f" at width {x.shape[-1]} / phm_dim {self.phm_dim}")
         out = _engine_act(self.bn(x), activation)
         if dropout is not None and self.training and dropout[0] > 0.0:
             from phc.hypercomplex.layers import phm_dropout

@@ -19,6 +19,17 @@ import torch
 from . import lib as L
 from .graph import EdgeStructure, SegmentStructure, edge_structure, segment_structure
 
+_SLOW_PATHS_SEEN: set = set()
+
+
+def warn_slow_path(tag: str, what: str) -> None:
+    """One RuntimeWarning per process and tag: a module of the ``phc`` mirror is about to run on plain PyTorch ops because the
+    engine has no kernel for that case (the results are the reference's; only the speed differs)."""
+    if tag not in _SLOW_PATHS_SEEN:
+        _SLOW_PATHS_SEEN.add(tag)
+        import warnings
+        warnings.warn(f"phc: {what} runs on PyTorch ops, not on the HIP engine", RuntimeWarning, stacklevel=3)
+
 
 def _act_id(name: str) -> int:
     try:

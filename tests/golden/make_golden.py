@@ -516,6 +516,56 @@ def g10_fullwidth_swish256():
                        store_grad32=False)
 
 
+def g8_yardsticks():
+    """Float64 yardsticks for the four G8 model fixtures (the G10 tests' allowance, tests/test_gpu_fullwidth.py): the SAME models
+    (same seeds as g8_models / g8_model_softmax: the parameters are checked against the committed fixtures) run in float64 on the
+    same batch; stored per fixture: grad64::<param> and err32::<param> = how far the reference's own float32 gradient sits from it."""
+    import copy
+    common = dict(norm_mp="naive-batch-norm", norm_dn="naive-batch-norm", msg_aggr="sum", pooling="softattention", activation="relu",
+                  real_trafo="linear", w_init="phm", c_init="standard", learn_phm=True)
+    cases = [
+        ("g8_model_cfg1", synth.molecule_batch(32, seed=0), 808, False,
+         dict(phm_dim=4, atom_encoded_dim=128, mp_layers=[128] * 4, dropout_mpnn=[0.0] * 4, mlp=True, downstream_layers=[128, 32],
+              dropout_dn=[0.0, 0.0], target_dim=1, sc_type="first", **common)),
+        ("g8_model_conv_small", synth.molecule_batch(8, seed=1, num_tasks=5, nan_frac=0.4), 818, False,
+         dict(phm_dim=4, atom_encoded_dim=32, mp_layers=[32] * 2, dropout_mpnn=[0.0] * 2, mlp=False, downstream_layers=[32, 16],
+              dropout_dn=[0.0, 0.0], target_dim=5, sc_type="first", **common)),
+        ("g8_model_zinc_small", synth.molecule_batch(8, seed=2, dataset="zinc", regression=True), 828, True,
+         dict(phm_dim=8, atom_input_dims=synth.ZINC_ATOM_DIMS, bond_input_dims=synth.ZINC_BOND_DIMS, atom_encoded_dim=64,
+              mp_layers=[64] * 3, dropout_mpnn=[0.0] * 3, mlp=True, downstream_layers=[64, 32], dropout_dn=[0.0, 0.0], target_dim=1,
+              sc_type="last", **common)),
+        ("g8_model_softmax_small", synth.molecule_batch(8, seed=3), 838, False,
+         dict(phm_dim=4, atom_encoded_dim=64, mp_layers=[64] * 3, dropout_mpnn=[0.0] * 3, mlp=True, downstream_layers=[64, 32],
+              dropout_dn=[0.0, 0.0], target_dim=1, sc_type="first",
+              **dict(common, msg_aggr="softmax", initial_beta=1.0, learn_beta=True))),
+    ]
+    for name, gb, seed, regression, kw in cases:
+        gen = torch.Generator().manual_seed(seed)
+        model = PHMSkipConnectAdd(**kw)
+        fill_module(model, gen)
+        have = np.load(os.path.join(HERE, name + ".npz"))
+        for k, v in model.state_dict().items():
+            assert np.array_equal(npy(v), have["sd::" + k]), (name, k)          # the very model of the committed fixture
+        model64 = copy.deepcopy(model).double()
+        out = {}
+        grads = {}
+        for tag, m in (("32", model), ("64", model64)):
+            m.train()
+            data = _to_batch(gb)
+            logits = m(data)
+            _loss_of(logits, data.y, regression).backward()
+            grads[tag] = {k: p.grad for k, p in m.named_parameters() if p.grad is not None}
+        worst = 0.0
+        for k, g64 in grads["64"].items():
+            out["grad64::" + k] = g64.float()
+            e = _relerr(grads["32"][k], g64)
+            out["err32::" + k] = np.array(e)
+            if float(g64.abs().max()) >= 1e-7:
+                worst = max(worst, e)
+        print(f"  {name}: reference float32 vs float64 gradients: worst {worst:.2e}")
+        save("g8y_" + name[3:], **out)
+
+
 def g12_published():
     """The reference's PUBLISHED model shapes (benchmarks/README.md:45-91, benchmarks/run_script_zinc_phm4.sh:4-5), dropout 0
     (dropout has its own fixture, g9): widths whose per-component size is not a multiple of four and GEMM depths of 180 / 200.
@@ -617,7 +667,7 @@ def g9_dropout():
 
 if __name__ == "__main__":
     makers = [g1_phm_linear, g2_g3_g4_kronecker_rules, g5_convs, g5b_softmax, g6_norm, g7_heads, g8_models,
-              g8_model_softmax, g9_dropout, g10_fullwidth, g10_fullwidth_swish256, g11_regulariser, g12_published]
+              g8_model_softmax, g9_dropout, g10_fullwidth, g10_fullwidth_swish256, g11_regulariser, g12_published, g8_yardsticks]
     wanted = sys.argv[1:]                       # e.g. `make_golden.py g8_model_softmax` rewrites only that fixture
     for make in makers:
         if not wanted or make.__name__ in wanted:

@@ -160,15 +160,16 @@ def test_g8_full_model(name):
         loss = torch.nn.functional.binary_cross_entropy_with_logits(logits[mask], y[mask])
     assert_close(loss, z["loss"], TOL, "loss")
     loss.backward()
-    worst = 0.0
-    for k, p in model.named_parameters():
-        ref = z.get("grad::" + k)
-        if ref is None or float(ref.abs().max()) < 1e-7:
-            continue
-        worst = max(worst, relerr(p.grad, ref))
-    # the CPU oracle itself differs from the reference by up to ~1e-4 on these gradients (fp32
-    # summation order through 4-13 batch-norms), see tests/test_oracle_golden.py
-    assert worst < 5e-4, worst
+    # gradients against the reference's FLOAT64 run of the same model and batch (tests/golden/g8y_*.npz), every tensor within
+    # max(1e-5, 3 W) of its largest entry, W = the largest distance of any of the reference's own float32 gradient tensors from
+    # that float64 run (the yardstick of tests/test_gpu_fullwidth.py; 3e-6 .. 8e-6 on these small batches)
+    zy = tensors(load("g8y_" + name[3:]))
+    live = [k for k, _ in model.named_parameters() if "grad64::" + k in zy and float(zy["grad64::" + k].abs().max()) >= 1e-7]
+    assert len(live) > 20
+    W = max(float(zy["err32::" + k]) for k in live)
+    grads = dict((k, p.grad) for k, p in model.named_parameters())
+    bad = [(relerr(grads[k], zy["grad64::" + k]), k) for k in live if relerr(grads[k], zy["grad64::" + k]) > max(TOL, 3.0 * W)]
+    assert not bad, (W, sorted(bad, reverse=True)[:5])
     sd = model.state_dict()
     for k, v in sub(z, "sd_after::").items():
         assert_close(sd[k], v, TOL, k)
