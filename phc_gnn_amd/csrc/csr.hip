@@ -360,6 +360,9 @@ static ScanLevels scan_levels(long long n) {
 static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; }
 
 // ---- both sorted views in five launches (molecule batches) --------------------------------------------------
+// (Tried: count + scan + fill of a side by ONE 1024-thread workgroup with the histogram, the scan and the fill cursors in LDS
+// and the thread's 29 edge keys in registers — 2 launches instead of 5.  Its serial phases take 13.4 us with no edges at all and
+// 22.5 us at 27.6 k edges, against 21.6 us for the four launch-floor-bound launches it replaces: no gain, removed.)
 // A training step needs the destination-sorted view (forward) AND the source-sorted one (backward).  Building
 // them side by side (blockIdx.y picks the side) with a one-workgroup scan takes 5 launches instead of 22.
 constexpr int PAIR_SCAN_THREADS = 1024;
@@ -451,80 +454,6 @@ __global__ __launch_bounds__(PAIR_SCAN_THREADS) void csr_pair_scan_kernel(CsrPai
         const int e = i * PAIR_SCAN_THREADS + tid;
         if (e < n) sd.rowptr[e] = buf[e];
     }
-}
-
-// Count, scan and fill of one side by ONE workgroup, everything between the edge list and tmp_perm in LDS: the row counts are
-// LDS atomics (a molecule batch has ~30 k edges: 29 per thread), the exclusive scan runs in place, rowptr goes to memory once, and
-// the same LDS words then serve as the rows' fill cursors.  Replaces the zero / histogram / scan / fill launches (4 x ~5 us of
-// launch floor inside a replayed training step) for edge lists of at most PAIR_FRONT_MAX_E; the order inside a row is settled by
-// the canonicalising launch as before, so the result is the same stable sort.
-constexpr long long PAIR_FRONT_MAX_E = 1 << 18;
-constexpr int PAIR_FRONT_REG = 32;                          // edges per thread held in registers: 32 k edges per side
-__global__ __launch_bounds__(PAIR_SCAN_THREADS) void csr_pair_front_kernel(CsrPair p, long long E) {
-    __shared__ int buf[PAIR_SCAN_THREADS * PAIR_SCAN_ITEMS];
-    __shared__ int wave_tot[PAIR_SCAN_THREADS / 64];
-    const CsrSide &sd = p.s[blockIdx.x];
-    const int n = (int)(sd.num_keys + 1);
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-#pragma unroll
-    for (int i = 0; i < PAIR_SCAN_ITEMS; ++i) buf[i * PAIR_SCAN_THREADS + tid] = 0;
-    __syncthreads();
-    // the keys of this thread's edges stay in registers for both passes (up to PAIR_FRONT_REG edges per thread; all loads of a
-    // pass in flight together — a plain loop is one dependent round trip per edge: 29 of them at molecule scale)
-    int kreg[PAIR_FRONT_REG];
-#pragma unroll
-    for (int u = 0; u < PAIR_FRONT_REG; ++u) {
-        const long long e = (long long)u * PAIR_SCAN_THREADS + tid;
-        kreg[u] = (int)checked_index(sd.key[min(e, E - 1)], sd.num_keys, p.err, PHC_IDX_ERR_EDGE);
-    }
-#pragma unroll
-    for (int u = 0; u < PAIR_FRONT_REG; ++u)
-        if ((long long)u * PAIR_SCAN_THREADS + tid < E) atomicAdd(&buf[kreg[u]], 1);
-    for (long long e = (long long)PAIR_FRONT_REG * PAIR_SCAN_THREADS + tid; e < E; e += PAIR_SCAN_THREADS)
-        atomicAdd(&buf[checked_index(sd.key[e], sd.num_keys, p.err, PHC_IDX_ERR_EDGE)], 1);
-    __syncthreads();
-    const int base = tid * PAIR_SCAN_ITEMS;
-    int v[PAIR_SCAN_ITEMS];
-    int tot = 0;
-#pragma unroll
-    for (int i = 0; i < PAIR_SCAN_ITEMS; ++i) {
-        v[i] = buf[base + ((i + tid) & (PAIR_SCAN_ITEMS - 1))];          // rotated start: no 16-way bank conflict
-        tot += v[i];
-    }
-    int incl = tot;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) {
-        const int t = __shfl_up(incl, off, 64);
-        if (lane >= off) incl += t;
-    }
-    if (lane == 63) wave_tot[wave] = incl;
-    __syncthreads();
-    int wave_off = 0;
-    for (int w = 0; w < wave; ++w) wave_off += wave_tot[w];
-    int run = wave_off + incl - tot;
-#pragma unroll
-    for (int j = 0; j < PAIR_SCAN_ITEMS; ++j) {                          // item j = (i + tid) & 15 sits in v[i]
-        const int i = (j - tid) & (PAIR_SCAN_ITEMS - 1);
-        int val = 0;
-#pragma unroll
-        for (int q = 0; q < PAIR_SCAN_ITEMS; ++q) val = (q == i) ? v[q] : val;       // register select, no dynamic indexing
-        buf[base + j] = run;
-        run += val;
-    }
-    __syncthreads();
-#pragma unroll
-    for (int i = 0; i < PAIR_SCAN_ITEMS; ++i) {
-        const int e = i * PAIR_SCAN_THREADS + tid;
-        if (e < n) sd.rowptr[e] = buf[e];
-    }
-    __syncthreads();                                                     // buf[k] = start of row k: from here on its fill cursor
-#pragma unroll
-    for (int u = 0; u < PAIR_FRONT_REG; ++u) {
-        const long long e = (long long)u * PAIR_SCAN_THREADS + tid;
-        if (e < E) sd.tmp_perm[atomicAdd(&buf[kreg[u]], 1)] = (int)e;
-    }
-    for (long long e = (long long)PAIR_FRONT_REG * PAIR_SCAN_THREADS + tid; e < E; e += PAIR_SCAN_THREADS)
-        sd.tmp_perm[atomicAdd(&buf[safe_index(sd.key[e], sd.num_keys)], 1)] = (int)e;
 }
 
 __global__ void csr_pair_fill_kernel(CsrPair p, long long E) {
@@ -858,24 +787,18 @@ int phc_csr_build_pair_codes(const int64_t *edge_src_i64, const int64_t *edge_ds
     const long long nmax = (n_src > n_dst ? n_src : n_dst) + 1;
     const unsigned ngrid = (unsigned)((nmax + 255) / 256);
     const unsigned egrid = (unsigned)((E + 255) / 256 > 4096 ? 4096 : (E + 255) / 256);
-    static const bool no_front = getenv("PHC_CSR_PAIR_NO_FRONT") != nullptr;        // A/B switch
-    if (E <= PAIR_FRONT_MAX_E && !no_front) {
+    {
         ProfScope prof(K_CSR_HIST, s);
-        PHC_LAUNCH(csr_pair_front_kernel, dim3(2), dim3(PAIR_SCAN_THREADS), 0, s, p, (long long)E);
-    } else {
-        {
-            ProfScope prof(K_CSR_HIST, s);
-            PHC_LAUNCH(csr_pair_zero_kernel, dim3(ngrid, 2), dim3(256), 0, s, p);
-            PHC_LAUNCH(csr_pair_hist_kernel, dim3(egrid, 2), dim3(256), 0, s, p, (long long)E);
-        }
-        {
-            ProfScope prof(K_CSR_SCAN, s);
-            PHC_LAUNCH(csr_pair_scan_kernel, dim3(2), dim3(PAIR_SCAN_THREADS), 0, s, p);
-        }
-        {
-            ProfScope prof(K_CSR_FILL, s);
-            PHC_LAUNCH(csr_pair_fill_kernel, dim3(egrid, 2), dim3(256), 0, s, p, (long long)E);
-        }
+        PHC_LAUNCH(csr_pair_zero_kernel, dim3(ngrid, 2), dim3(256), 0, s, p);
+        PHC_LAUNCH(csr_pair_hist_kernel, dim3(egrid, 2), dim3(256), 0, s, p, (long long)E);
+    }
+    {
+        ProfScope prof(K_CSR_SCAN, s);
+        PHC_LAUNCH(csr_pair_scan_kernel, dim3(2), dim3(PAIR_SCAN_THREADS), 0, s, p);
+    }
+    {
+        ProfScope prof(K_CSR_FILL, s);
+        PHC_LAUNCH(csr_pair_fill_kernel, dim3(egrid, 2), dim3(256), 0, s, p, (long long)E);
     }
     ProfScope prof(K_CSR_CANON, s);
     const long long groups = (nmax + 31) / 32;
