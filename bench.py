@@ -66,7 +66,7 @@ PMC_NAMES = {"phm_gemm_fwd": "phm_stream_kernel<0, -1, 32, 4, 1>", "phm_gemm_dx"
              "bn_stats_partial": "bn_stats_partial_kernel", "table_grad": "table_grad_mfma_kernel<1"}
 
 
-PMC_FILE = "r02_pmc_traffic.json"
+PMC_FILE = "r03_pmc_traffic.json"
 
 
 def pmc_traffic(kernel: str):

@@ -8,8 +8,17 @@ F=$(ls -t gpurun_out/pmc_${R}_FETCH_SIZE/*/*counter_collection.csv | head -1)
 W=$(ls -t gpurun_out/pmc_${R}_WRITE_SIZE/*/*counter_collection.csv | head -1)
 python3 scripts/summarize_pmc.py $F $W gpurun_out/${R}_pmc_traffic.json > gpurun_out/${R}_pmc_traffic.txt 2>&1
 find gpurun_out/pmc_${R}_FETCH_SIZE gpurun_out/pmc_${R}_WRITE_SIZE -name "*.csv" -size +5M -delete
-for wl in zinc_b1024 molpcba_b1024 molhiv_b512_softmax; do
-  python bench.py --workload $wl --cpu-steps 0 2>&1 | tail -1 > gpurun_out/${R}_bench_$wl.json
+for wl in zinc_b1024 molpcba_b1024 molhiv_b512_softmax molhiv_pub_phc4_2x200 zinc_pub_phc5_4x200 zinc_pub_phc4_4x180; do
+  python bench.py --workload $wl --cpu-steps 0 2>&1 | grep '^{"metric"' | tail -1 > gpurun_out/${R}_bench_$wl.json
+done
+# kernel stats of the wide configurations and of config-5 at its full size (one GPU)
+for wl in zinc_b1024 molpcba_b1024 synth_10m50m; do
+  OUT=$GRAFT_REPO_ROOT/gpurun_out/prof_${R}_$wl
+  rm -rf $OUT && mkdir -p $OUT
+  if [ $wl = synth_10m50m ]; then ST=8; WU=2; else ST=50; WU=10; fi
+  rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 bench.py --workload $wl --steps $ST --warmup $WU --cpu-steps 0 --min-time 0 --profile-steps 0 > $OUT/bench.log 2>&1
+  python3 scripts/summarize_rocprof.py $(ls -t $OUT/*/*kernel_stats.csv | head -1) $((ST + WU)) 60 > gpurun_out/${R}_bench_${wl}_kernel_stats_summary.txt
+  find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*.db" -delete
 done
 python bench.py --workload synth_10m50m --steps 10 --warmup 2 2>&1 | tail -1 > gpurun_out/${R}_bench_synth_10m50m_1gpu.json
 python bench.py --workload synth_10m50m --layers 4 --steps 5 --warmup 2 2>&1 | tail -1 > gpurun_out/${R}_bench_synth_10m50m_4layers_1gpu.json
