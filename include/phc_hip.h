@@ -669,6 +669,24 @@ int phc_gated_pool_fwd_sorted(const float *x, const float *gate, const int64_t *
 int phc_gated_pool_bwd(const float *dout, const float *x, const float *gate, const int64_t *batch, int64_t N,
                        int64_t num_graphs, int h, int n_comp, float *dx, float *dgate, void *stream);
 
+/* Many small strided 2-D copies in one launch: dst[r * dst_stride + c] = src[r * src_stride + c], r < rows, c < cols, with
+ * src = (job.src ? job.src : src_base) + job.src_off and dst likewise (element offsets).  `jobs_dev` is a DEVICE array, built once
+ * (the pointers of a model's tables do not move; per-call buffers come in through the two base pointers); max_elems = the largest
+ * rows * cols of any job.
+ * Use: an encoder whose component size k is not a multiple of four (the reference's published 180- / 200-wide models, k = 45,
+ * 50) keeps a flat [sum_f V_f, n*k] image of its n*F tables [V_f, k] — image[off_f + r, c*k + j] = table(c, f)[r, j] — that the
+ * vector kernels read as the tables of a ONE-component encoder of width n*k (16-byte aligned rows whatever k is); a second job
+ * table turns the image's gradient into the per-table gradients (encoder.py:30-75). */
+typedef struct phc_copy2d_job {
+    const float *src;              /* NULL: src_base */
+    float *dst;                    /* NULL: dst_base */
+    int64_t src_off, dst_off;      /* elements */
+    int64_t src_stride, dst_stride;
+    int32_t rows, cols;
+} phc_copy2d_job;
+int phc_copy2d_batched(const phc_copy2d_job *jobs_dev, int num_jobs, int64_t max_elems, const float *src_base, float *dst_base,
+                       void *stream);
+
 /* out = srcs[0] + srcs[1] + ... + srcs[n-1] (in that order), n <= 16, srcs a HOST array of device pointers:
  * the gradient of a tensor that fans out to several consumers — the encoded atoms feed the first conv and
  * every layer's skip connection (models.py:230-234) — in one pass instead of n-1 pairwise adds. */

@@ -191,7 +191,7 @@ class _SoftmaxMixin:
         """Softmax aggregation with edge_attr = encoder(edge_idx): the kernels add the F table rows of every edge
         themselves (packed codes, tables from L2), so no [E, h] embedding is built in the forward pass."""
         tables = encoder.engine_tables
-        ts = _engine.tableset_for(encoder, tables)
+        ts = _engine.tableset_for(encoder, tables).vector_form(tables)     # (k % 4 != 0: the flat one-component image)
         num_dst = size[1] if size is not None and size[1] is not None else None
         if ts.F <= 4 and ts.R <= 256 and ts.k % 4 == 0 and (num_dst is None or num_dst == x.size(0) or not add_self):
             return _engine.aggregate_softmax_encoded(x, edge_index, edge_idx, ts, tables, self.beta, self.msg_encoder_str,

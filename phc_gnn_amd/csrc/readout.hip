@@ -499,6 +499,32 @@ int phc_gated_pool_bwd(const float *dout, const float *x, const float *gate, con
     return check_launch("gated_pool_bwd");
 }
 
+// ---- batched strided 2-D copies (phc_copy2d_batched): the flat [R, h] image of an encoder's [V_f, k] tables and back ----
+__global__ __launch_bounds__(256) void copy2d_batched_kernel(const phc_copy2d_job *__restrict__ jobs, const float *__restrict__ src_base,
+                                                            float *__restrict__ dst_base) {
+    const phc_copy2d_job j = jobs[blockIdx.y];
+    const float *src = (j.src ? j.src : src_base) + j.src_off;
+    float *dst = (j.dst ? j.dst : dst_base) + j.dst_off;
+    const long long total = (long long)j.rows * j.cols;
+    for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+        const long long r = e / j.cols;
+        const int cc = (int)(e - r * j.cols);
+        dst[r * j.dst_stride + cc] = src[r * j.src_stride + cc];
+    }
+}
+
+int phc_copy2d_batched(const phc_copy2d_job *jobs_dev, int num_jobs, int64_t max_elems, const float *src_base, float *dst_base,
+                       void *stream) {
+    PHC_REQUIRE(num_jobs >= 0 && max_elems >= 0 && (num_jobs == 0 || jobs_dev), PHC_ERR_INVALID_ARG, "phc_copy2d_batched: bad arguments");
+    if (num_jobs == 0 || max_elems == 0) return PHC_OK;
+    PHC_REQUIRE(num_jobs <= 65535, PHC_ERR_UNSUPPORTED, "phc_copy2d_batched: at most 65535 jobs per call");
+    long long bx = (max_elems + 255) / 256;
+    if (bx > 64) bx = 64;
+    hipStream_t s = (hipStream_t)stream;
+    PHC_LAUNCH(copy2d_batched_kernel, dim3((unsigned)bx, (unsigned)num_jobs), dim3(256), 0, s, jobs_dev, src_base, dst_base);
+    return check_launch("copy2d_batched");
+}
+
 int phc_sum_n(const float *const *srcs, int n, int64_t numel, float *out, void *stream) {
     PHC_REQUIRE(n >= 1 && n <= SUMN_MAX && numel >= 0 && srcs && (numel == 0 || out), PHC_ERR_INVALID_ARG, "phc_sum_n: n=%d (1..%d)", n,
                 SUMN_MAX);

@@ -68,6 +68,12 @@ class GemmBaDesc(C.Structure):
                 ("bw_x", _P), ("bw_stat", _P), ("bw_sums_acc", _P)]
 
 
+class Copy2dJob(C.Structure):
+    """phc_copy2d_job (include/phc_hip.h)."""
+    _fields_ = [("src", _P), ("dst", _P), ("src_off", C.c_int64), ("dst_off", C.c_int64), ("src_stride", C.c_int64),
+                ("dst_stride", C.c_int64), ("rows", C.c_int32), ("cols", C.c_int32)]
+
+
 class TableGradJob(C.Structure):
     """phc_table_grad_job (include/phc_hip.h)."""
     _fields_ = [("dout", _P), ("x", _P), ("tables", _P), ("dtables_flat", _P)]
@@ -167,6 +173,7 @@ SIGNATURES = {
     "phc_gated_pool_fwd_sorted": (_I, [_P, _P, _P, _L, _L, _I, _I, _P, _P]),
     "phc_gated_pool_bwd": (_I, [_P, _P, _P, _P, _L, _L, _I, _I, _P, _P, _P]),
     "phc_sum_n": (_I, [_P, _I, _L, _P, _P]),
+    "phc_copy2d_batched": (_I, [_P, _I, _L, _P, _P, _P]),
     "phc_vec_sums": (_I, [_P, _P, _P, _I, _P]),
     "phc_small_linear_max_weights": (_I, []),
     "phc_small_linear_fwd": (_I, [_P, _P, _P, _L, _I, _I, _P, _P]),

@@ -424,6 +424,10 @@ def prebuilt_H(pairs, dense=()):
     if _PREBUILT.table or not (pairs or dense):            # nested (outermost wins) or nothing to do
         yield
         return
+    outer_step = getattr(_FLAT_STEP, "packed", None) is None
+    if outer_step:
+        _FLAT_STEP.packed = set()                          # flat table images (FlatTableSet) are refreshed once inside this block
+        FlatTableSet.refresh_all()                         # ... all the live ones by one launch per device, right here
     lib = L.load()
     by_dev = {}
     for w in dense:
@@ -467,6 +471,8 @@ def prebuilt_H(pairs, dense=()):
         yield
     finally:
         _PREBUILT.table = {}
+        if outer_step:
+            _FLAT_STEP.packed = None
 
 
 def _prebuilt_for(A, W):
@@ -1254,7 +1260,7 @@ class _AggregateSoftmaxEncFn(torch.autograd.Function):
                     _DEFER.beta_jobs.append((parts, ctx.beta_param))
             else:
                 dbeta = parts.sum().reshape(())
-        tgrads = [None] * (ts.n * ts.F)
+        tgrads = [None] * ts.num_tables
         if need_t:
             if ctx.defer_tables is not None and _DEFER.active and not torch.is_grad_enabled():
                 params = [t if ng else None for t, ng in zip(ctx.defer_tables, ctx.needs_input_grad[7:])]
@@ -1275,6 +1281,7 @@ def aggregate_softmax_encoded(x: torch.Tensor, edge_index, bond_idx: torch.Tenso
     """aggregate_softmax with ``edge_attr = bond encoder(bond_idx)`` evaluated inside the kernels (needs
     ``ts.fusable_into_aggregate`` and F <= 4, sum(vocab) <= 256: the packed-code limits)."""
     st = edge_index if isinstance(edge_index, EdgeStructure) else edge_structure(edge_index, x.shape[0], num_dst)
+    ts = ts.vector_form(tables)
     bond_idx = _idx64(bond_idx)
     st.prepare(for_backward=torch.is_grad_enabled() and x.requires_grad, codes_for=(bond_idx, ts.vocab_c, ts.F))
     return _AggregateSoftmaxEncFn.apply(x, bond_idx, beta, st, _act_id(msg_encoder), add_self, ts,
@@ -1497,6 +1504,122 @@ class TableSet:
     def fusable_into_aggregate(self) -> bool:
         return self.k % 4 == 0 and self.R * self.n * self.k * 4 <= 48 * 1024 and self.F <= 16
 
+    @property
+    def num_tables(self) -> int:
+        """Number of nn.Embedding weights behind this set (= gradients an autograd node returns for it)."""
+        return self.n * self.F
+
+    def vector_form(self, tables) -> "TableSet":
+        """The table set the vector kernels can read: this one when k % 4 == 0 (or when no float4 form exists: (n*k) % 4 != 0);
+        otherwise its flat ONE-component image (``FlatTableSet``), refreshed from the tables' current values."""
+        if self.k % 4 == 0 or (self.n * self.k) % 4 != 0 or not FLAT_TABLES:
+            return self
+        flat = getattr(self, "_flat_form", None)
+        if flat is None or flat.parent_key != self.key:
+            flat = self._flat_form = FlatTableSet(self)
+        flat.refresh_image()
+        return flat
+
+
+FLAT_TABLES = __import__("os").environ.get("PHC_FLAT_TABLES", "1") != "0"      # A/B switch
+_FLAT_STEP = threading.local()           # .packed: ids of the images refreshed in the running step (prebuilt_H context)
+
+
+class FlatTableSet(TableSet):
+    """One-component image of an encoder whose component size is not a multiple of four (the reference's published 180- /
+    200-wide models: k = 45, 50): ``image[off_f + r, c*k + j] = table(c, f)[r, j]``, a ``[R, n*k]`` buffer whose rows are 16-byte
+    aligned whatever k is.  To the kernels it is an encoder with n = 1, k = n*k and F tables ``image[off_f : off_f + V_f]`` — every
+    vector path (float4 encoders, the aggregation with the bond embedding read in place, the MFMA / register-resident table
+    gradients) applies unchanged.  Costs: one small launch to refresh the image when the tables have changed (once per training
+    step inside ``prebuilt_H``; before every use outside) and one to turn the image's gradient into the per-table gradients."""
+
+    def __init__(self, parent: TableSet):
+        self.parent = parent
+        self.parent_key = parent.key
+        self.n, self.F, self.k = 1, parent.F, parent.n * parent.k
+        self.vocab, self.R, self.vocab_c, self.offsets, self.dev = parent.vocab, parent.R, parent.vocab_c, parent.offsets, parent.dev
+        h, pk = self.k, parent.k
+        self.image = torch.zeros((self.R, h), dtype=torch.float32, device=self.dev)
+        self.key = tuple(self.image.data_ptr() + 4 * parent.offsets[f] * h for f in range(self.F))
+        self.ptrs = torch.tensor(self.key, dtype=torch.int64, device=self.dev)
+        pack = (L.Copy2dJob * (parent.n * parent.F))()
+        unpack = (L.Copy2dJob * (parent.n * parent.F))()
+        for c in range(parent.n):
+            for f in range(parent.F):
+                i = c * parent.F + f
+                V, off = parent.vocab[f], parent.offsets[f]
+                # image <- table(c, f);  per-table gradient block [c][f] of the [n][R][k] buffer <- image gradient
+                pack[i] = L.Copy2dJob(parent.key[i], None, 0, off * h + c * pk, pk, h, V, pk)
+                unpack[i] = L.Copy2dJob(None, None, off * h + c * pk, (c * parent.R + off) * pk, h, pk, V, pk)
+        self.max_elems = max(parent.vocab) * pk
+        self._pack_jobs = torch.frombuffer(bytearray(bytes(pack)), dtype=torch.uint8).to(self.dev)
+        self._unpack_jobs = torch.frombuffer(bytearray(bytes(unpack)), dtype=torch.uint8).to(self.dev)
+        self.num_jobs = parent.n * parent.F
+        if FlatTableSet._LIVE is None:
+            FlatTableSet._LIVE = _weakref.WeakSet()
+        FlatTableSet._LIVE.add(self)
+        FlatTableSet._SERIAL += 1
+        self.serial = FlatTableSet._SERIAL                   # (ids of dead objects are reused; serial numbers are not)
+
+    @property
+    def num_tables(self) -> int:
+        return self.parent.n * self.parent.F
+
+    _LIVE: "_weakref.WeakSet" = None        # every image alive (refresh_all)
+    _SERIAL = 0
+    _ALL_JOBS: dict = {}                    # device -> (ids, concatenated job table, count, max_elems)
+
+    @classmethod
+    def refresh_all(cls) -> None:
+        """One pack launch per device for every live image (the start of a training step: prebuilt_H)."""
+        live = [f for f in (cls._LIVE or ()) if f.parent_key == f.parent.key]
+        by_dev = {}
+        for f in live:
+            by_dev.setdefault(f.dev, []).append(f)
+        for dev, fs in by_dev.items():
+            fs.sort(key=lambda f: f.serial)
+            ids = tuple(f.serial for f in fs)
+            ent = cls._ALL_JOBS.get(dev)
+            if (ent is None or ent[0] != ids) and torch.cuda.is_current_stream_capturing():
+                continue                                     # no uploads inside a capture: every image refreshes itself at first use
+            if ent is None or ent[0] != ids:
+                jobs = []
+                for f in fs:                                 # absolute destinations: the images sit in different buffers
+                    h = f.k
+                    for c in range(f.parent.n):
+                        for fe in range(f.parent.F):
+                            off = f.parent.offsets[fe]
+                            jobs.append(L.Copy2dJob(f.parent.key[c * f.parent.F + fe], f.image.data_ptr(), 0, off * h + c * f.parent.k,
+                                                    f.parent.k, h, f.parent.vocab[fe], f.parent.k))
+                arr = (L.Copy2dJob * len(jobs))(*jobs)
+                ent = cls._ALL_JOBS[dev] = (ids, torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev), len(jobs),
+                                            max(f.max_elems for f in fs))
+            L.check(L.load().phc_copy2d_batched(L.ptr(ent[1]), ent[2], ent[3], None, None, L.stream_ptr(dev)),
+                    "phc_copy2d_batched(pack all tables)")
+            packed = getattr(_FLAT_STEP, "packed", None)
+            if packed is not None:
+                packed.update(id(f) for f in fs)
+
+    def refresh(self, tables):              # (TableSet.current: the image has no tables of its own to follow)
+        raise L.PhcError("FlatTableSet is derived from its parent TableSet")
+
+    def refresh_image(self) -> None:
+        packed = getattr(_FLAT_STEP, "packed", None)
+        if packed is not None:
+            if id(self) in packed:
+                return                      # already refreshed in this training step (the tables change only at its end)
+            packed.add(id(self))
+        L.check(L.load().phc_copy2d_batched(L.ptr(self._pack_jobs), self.num_jobs, self.max_elems, None, L.ptr(self.image),
+                                            L.stream_ptr(self.dev)), "phc_copy2d_batched(pack tables)")
+
+    def grad_views(self, flat_grad: torch.Tensor):
+        """Per-table [V_f, k] gradients of the PARENT's tables from the image's gradient ``[R, n*k]`` (one launch)."""
+        p = self.parent
+        real = torch.empty(p.n * p.R * p.k, dtype=torch.float32, device=flat_grad.device)
+        L.check(L.load().phc_copy2d_batched(L.ptr(self._unpack_jobs), self.num_jobs, self.max_elems, L.ptr(flat_grad), L.ptr(real),
+                                            L.stream_ptr(flat_grad.device)), "phc_copy2d_batched(unpack table gradients)")
+        return p.grad_views(real)
+
 
 _TABLESETS: "_weakref.WeakKeyDictionary" = _weakref.WeakKeyDictionary()
 
@@ -1553,7 +1676,7 @@ class _EncodeFn(torch.autograd.Function):
             params = [t if ng else None for t, ng in zip(ctx.defer_tables, ctx.needs_input_grad[2:])]
             with _DEFER.lock:
                 _DEFER.atom_jobs.append(dict(dout=dout_, idx=idx_, ts=ts, params=params))
-            return (None, None, *([None] * (ts.n * ts.F)))
+            return (None, None, *([None] * ts.num_tables))
         flat = torch.empty(ts.n * ts.R * ts.k, dtype=torch.float32, device=dev)
         ws_bytes = lib.phc_encode_bwd_ws_bytes(N, ts.F, ts.vocab_c, ts.n, ts.k)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
@@ -1566,7 +1689,7 @@ class _EncodeFn(torch.autograd.Function):
 
 def encode(idx: torch.Tensor, ts: TableSet, tables) -> torch.Tensor:
     """out[i, c*k+κ] = Σ_f tables[c][f][idx[i, f], κ]   ->  [N, n*k] component-major."""
-    return _EncodeFn.apply(idx, ts, *[t for comp in tables for t in comp])
+    return _EncodeFn.apply(idx, ts.vector_form(tables), *[t for comp in tables for t in comp])
 
 
 class _AggregateEncFn(torch.autograd.Function):
@@ -1652,7 +1775,7 @@ class _AggregateEncFn(torch.autograd.Function):
                           + 4.0 * (Ns + 1))
             if need_t and not deferred:
                 L.account("table_grad", 1.0 * E * ts.F * h, Nd * 4.0 * h + E * (4.0 + 8.0 * ts.F) + 4.0 * (Nd + 1))
-        grads = ts.grad_views(flat) if (need_t and not deferred) else [None] * (ts.n * ts.F)
+        grads = ts.grad_views(flat) if (need_t and not deferred) else [None] * ts.num_tables
         return (dx, None, None, None, None, None, *grads)
 
 
@@ -1662,6 +1785,7 @@ def aggregate_sum_encoded(x: torch.Tensor, edge_index, bond_idx: torch.Tensor, t
     """aggregate_sum with edge_attr[e] = Σ_f tables[c][f][bond_idx[e, f]] looked up inside the
     kernel (the [E, h] bond embedding is never written)."""
     st = edge_index if isinstance(edge_index, EdgeStructure) else edge_structure(edge_index, x.shape[0], num_dst)
+    ts = ts.vector_form(tables)
     packed = ts.fusable_into_aggregate and ts.F <= 4 and ts.R <= 256
     if packed:
         bond_idx = _idx64(bond_idx)

@@ -313,6 +313,62 @@ def _oracle_encode(idx, tables):
     return O.phm_encoder(idx, p, "", n, len(tables[0])).reshape(idx.shape[0], -1)
 
 
+@pytest.mark.parametrize("n,k,vocab_a,vocab_b", [(4, 50, [119, 4, 12, 12, 10, 6, 6, 2, 2], [5, 6, 2]), (4, 45, [28], [4]), (5, 26, [28], [4])])
+@pytest.mark.parametrize("flat", [True, False])
+def test_encoders_with_component_size_not_a_multiple_of_four(ops, n, k, vocab_a, vocab_b, flat):
+    """The reference's published widths (200 = 4 x 50, 180 = 4 x 45; a 130-wide head layer = 5 x 26): the encoders run on the flat
+    one-component image of their tables (ops.FlatTableSet: float4 rows whatever k is) — atom encoder, sum aggregation and softmax
+    aggregation with the bond embedding read in place, outputs and EVERY table gradient against the oracle; ``flat=False``: the same
+    through the scalar fall-back kernels."""
+    from oracle import phc_oracle as O
+    from phc_gnn_amd import synth
+    g = torch.Generator().manual_seed(n * 100 + k)
+    old = ops.FLAT_TABLES
+    ops.FLAT_TABLES = flat
+    try:
+        N, h = 700, n * k
+        ei = torch.from_numpy(synth.ragged_edges(N, seed=9, hub_degree=60))
+        E = ei.shape[1]
+        idx = torch.stack([torch.randint(0, v, (N,), generator=g) for v in vocab_a], 1)
+        bond = torch.stack([torch.randint(0, v, (E,), generator=g) for v in vocab_b], 1)
+        ta, tb = _make_tables(n, vocab_a, k, g), _make_tables(n, vocab_b, k, g)
+        dy = torch.randn(N, h, generator=g)
+        # oracle
+        ra = [[t.clone().requires_grad_() for t in comp] for comp in ta]
+        rb = [[t.clone().requires_grad_() for t in comp] for comp in tb]
+        beta_r = torch.tensor(1.3, requires_grad=True)
+        x_r = _oracle_encode(idx, ra)
+        ea_r = _oracle_encode(bond, rb)
+        s_r = O.propagate_add(x_r, ei, ea_r, "identity") + x_r
+        m_r = O.softmax_aggregate(x_r, ei, ea_r, beta_r, "identity")
+        flat_r = [t for comp in ra for t in comp] + [t for comp in rb for t in comp]
+        # engine
+        da = [[t.to(DEV).requires_grad_() for t in comp] for comp in ta]
+        db = [[t.to(DEV).requires_grad_() for t in comp] for comp in tb]
+        beta_d = torch.tensor(1.3, device=DEV, requires_grad=True)
+        tsa, tsb = ops.TableSet(da), ops.TableSet(db)
+        x_d = ops.encode(idx.to(DEV), tsa, da)
+        assert_close(x_d, x_r, TOL, "encode")
+        m_d = ops.aggregate_softmax_encoded(x_d, ei.to(DEV), bond.to(DEV), tsb, db, beta_d, "identity") if ((flat and h % 4 == 0) or k % 4 == 0) else None
+        outs_d, outs_r = [], []
+        if s_r is not None:
+            s_d = ops.aggregate_sum_encoded(x_d, ei.to(DEV), bond.to(DEV), tsb, db, "identity", add_self_loops=True)
+            assert_close(s_d, s_r, 2e-5, "sum aggregation")
+            outs_d.append(s_d); outs_r.append(s_r)
+        if m_d is not None:
+            assert_close(m_d, m_r, 2e-5, "softmax aggregation")
+            outs_d.append(m_d); outs_r.append(m_r)
+        loss_d = sum((o * dy.to(DEV)).sum() for o in outs_d)
+        loss_r = sum((o * dy).sum() for o in outs_r)
+        flat_d = [t for comp in da for t in comp] + [t for comp in db for t in comp]
+        gd = torch.autograd.grad(loss_d, flat_d + ([beta_d] if m_d is not None else []))
+        gr = torch.autograd.grad(loss_r, flat_r + ([beta_r] if m_d is not None else []))
+        for i, (a, r) in enumerate(zip(gd, gr)):
+            assert_close(a, r, 3e-5, f"gradient {i}")
+    finally:
+        ops.FLAT_TABLES = old
+
+
 @pytest.mark.parametrize("n,k,vocab", [(4, 32, [119, 4, 12, 12, 10, 6, 6, 2, 2]), (8, 32, [28]), (2, 6, [5, 3]),
                                        (4, 128, [119, 4, 12, 12, 10, 6, 6, 2, 2])])
 def test_encode_fwd_bwd(ops, n, k, vocab):
