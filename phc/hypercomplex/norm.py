@@ -119,7 +119,7 @@ class PHMNorm(nn.Module):
     def forward_fused(self, x: torch.Tensor, activation: str = "identity", residual=None, n_valid=None, dropout=None) -> torch.Tensor:
         """act(norm(x)) (+ dropout) (+ residual); one engine pass for the naive-batch-norm flavour."""
         if isinstance(self.bn, NaivePHMNorm) and activation.lower() in _FUSABLE_ACTS and self.bn.track_running_stats and \
-                (dropout is None or (x.shape[-1] % 4 == 0 and (x.shape[-1] // self.phm_dim) % 4 == 0)):
+                (dropout is None or (x.shape[-1] % 4 == 0 and (not dropout[1] or (x.shape[-1] // self.phm_dim) % 4 == 0))):
             return self.bn.forward_fused(x, activation, residual, n_valid, dropout)
         _engine.warn_slow_path("norm-act-dropout", f"norm + activation '{activation}'" + (" + dropout" if dropout is not None else "")
                                + f" at width {x.shape[-1]} / phm_dim {self.phm_dim}")
