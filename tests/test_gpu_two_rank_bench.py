@@ -1,0 +1,59 @@
+"""``bench.py --gpus 2`` — the data-parallel training step as the driver's scaling run launches it — as a REAL two-process run
+on the box's single GPU (collectives through gloo, staged via host memory by tests/helpers/two_rank_bench_child.py; RCCL
+refuses two ranks on one device).  Checks the line rank 0 prints: two ranks, the aggregate over both, the gradient exchange
+in the step, and replicas that end bit-identical (reference loop being replicated: benchmarks/train_hiv.py:165-218)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _two_ranks(args):
+    port = str(_free_port())
+    child = os.path.join(HERE, "helpers", "two_rank_bench_child.py")
+    procs = [subprocess.Popen([sys.executable, child, str(r), "2", port] + args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                              text=True) for r in range(2)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=900)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out)
+    for r, (p, out) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and "TWO_RANK_BENCH_CHILD_OK" in out, f"rank {r}:\n{out[-4000:]}"
+    lines = [ln for ln in outs[0].splitlines() if ln.startswith('{"metric"')]
+    assert len(lines) == 1 and not any(ln.startswith('{"metric"') for ln in outs[1].splitlines())
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("mode", ["graph", "eager"])
+def test_bench_two_ranks_data_parallel(mode):
+    d = _two_ranks(["--gpus", "2", "--workload", "molhiv_b32", "--steps", "6", "--warmup", "3", "--min-time", "0", "--cpu-steps", "0",
+                    "--profile-steps", "2", "--num-batches", "3", "--mode", mode])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["steps"] == 6
+    assert d["config"]["parallelism"] == "dp2" and "grad_allreduce" in d["config"]["step"]
+    assert d["config"]["replicas_max_param_diff"] == 0.0
+    assert abs(d["value"] - 2 * 32 * 6 / (d["ms_per_step"] * 6e-3)) <= 1e-3 * d["value"]      # whole-job aggregate over both ranks
+
+
+def test_bench_two_ranks_one_large_graph():
+    """``bench.py --workload synth_1m5m --gpus 2``: the destination-range sharded layer (halo all-to-all, global batch-norm
+    moments, summed partial parameter gradients) through bench.py's own multi-rank flow, incl. its sampled-row check."""
+    d = _two_ranks(["--gpus", "2", "--workload", "synth_1m5m", "--steps", "2", "--warmup", "1"])
+    assert d["n_gpus"] == 2 and d["scaling"] == "strong" and d["config"]["parallelism"] == "shard2"
+    assert d["value"] > 0
