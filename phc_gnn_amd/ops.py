@@ -1568,6 +1568,7 @@ class FlatTableSet(TableSet):
     _LIVE: "_weakref.WeakSet" = None        # every image alive (refresh_all)
     _SERIAL = 0
     _ALL_JOBS: dict = {}                    # device -> (ids, concatenated job table, count, max_elems)
+    _KEEP: list = []                        # every job table ever launched (a few KB each)
 
     @classmethod
     def refresh_all(cls) -> None:
@@ -1594,6 +1595,7 @@ class FlatTableSet(TableSet):
                 arr = (L.Copy2dJob * len(jobs))(*jobs)
                 ent = cls._ALL_JOBS[dev] = (ids, torch.frombuffer(bytearray(bytes(arr)), dtype=torch.uint8).to(dev), len(jobs),
                                             max(f.max_elems for f in fs))
+                cls._KEEP.append(ent[1])                     # a captured step may still hold the address of an older table
             L.check(L.load().phc_copy2d_batched(L.ptr(ent[1]), ent[2], ent[3], None, None, L.stream_ptr(dev)),
                     "phc_copy2d_batched(pack all tables)")
             packed = getattr(_FLAT_STEP, "packed", None)
