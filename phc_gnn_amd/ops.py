@@ -2101,11 +2101,11 @@ def batch_norm_act(x: torch.Tensor, weights, biases, running_mean, running_var, 
 # passes ride in the dx GEMMs behind them (phc_gemm_bwd_apply) — sums of the outer norm, GEMM (outer apply, inner sums), GEMM
 # (inner apply): 3 launches instead of 6, and one [N, h] write + two reads per norm less.
 MLP_NORM_FUSED = __import__("os").environ.get("PHC_MLP_NORM_FUSED", "1") != "0"
-# Where the fused node is the faster one (A/B inside the replayed steps): hidden 256 at 23-27 k rows (zinc_b1024 2.315 -> 2.247 ms,
-# molpcba_b1024 2.885 -> 2.807 ms).  At hidden 128 and 12.9 k rows the two folded GEMMs cost 5.7 us more each than the GEMMs they
-# replace — more than the two element-wise launches they save (0.707 -> 0.743 ms) — so narrower / shorter problems keep the
-# separate nodes.  PHC_MLP_NORM_FUSED_MIN_WORK overrides the rows x width threshold.
-MLP_NORM_FUSED_MIN_WORK = int(__import__("os").environ.get("PHC_MLP_NORM_FUSED_MIN_WORK", str(16384 * 256)))
+# A/B inside the replayed steps: hidden 256 at 23-27 k rows zinc_b1024 2.315 -> 2.247 ms, molpcba_b1024 2.885 -> 2.807 ms; at hidden
+# 128 and 12.9 k rows the two folded GEMMs cost what the GEMMs + element-wise launches they replace cost (0.7168 vs 0.7172 ms,
+# three alternating runs) with 8 launches per step fewer (65 -> 57), and at 32 graphs per batch the step is launch-bound: 0.492 ->
+# 0.462 ms.  On everywhere the kernels serve; PHC_MLP_NORM_FUSED_MIN_WORK sets a rows x width threshold for A/B runs.
+MLP_NORM_FUSED_MIN_WORK = int(__import__("os").environ.get("PHC_MLP_NORM_FUSED_MIN_WORK", "0"))
 
 
 def _zero_acc(dev, h: int):
