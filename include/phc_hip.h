@@ -477,6 +477,14 @@ int phc_csr_build_pair_codes(const int64_t *edge_src_i64, const int64_t *edge_ds
                              int64_t n_dst, int32_t *rowptr, int32_t *col, int32_t *perm, int32_t *rowptr_t,
                              int32_t *col_t, int32_t *perm_t, const int64_t *bond_i64, const int32_t *vocab, int F,
                              uint32_t *codes, float *code_counts, void *ws, size_t ws_bytes, void *stream);
+/* The same with a RESIDENT workspace: the caller zero-fills `ws_zeroed_once` ONCE (phc_csr_pair_ws_bytes bytes) and hands the same
+ * buffer to every later call for this graph size; each call leaves the counter arrays zeroed again (the scan clears the counts it
+ * has read, the canonicalising launch clears the fill cursors), so the per-call zero launch disappears — 4 launches instead of 5
+ * in the per-batch preprocessing of a replayed training step.  A call that fails mid-way leaves the buffer undefined: zero it again. */
+int phc_csr_build_pair_codes_resident(const int64_t *edge_src_i64, const int64_t *edge_dst_i64, int64_t E, int64_t n_src,
+                                      int64_t n_dst, int32_t *rowptr, int32_t *col, int32_t *perm, int32_t *rowptr_t, int32_t *col_t,
+                                      int32_t *perm_t, const int64_t *bond_i64, const int32_t *vocab, int F, uint32_t *codes,
+                                      float *code_counts, void *ws_zeroed_once, size_t ws_bytes, void *stream);
 
 /* Per-batch preprocessing on the device: drop the nodes no edge touches and re-index,
  * i.e. the reference's CustomRemoveIsolatedNodes / PyG RemoveIsolatedNodes applied to every collated

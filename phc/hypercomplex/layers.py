@@ -101,10 +101,10 @@ class PHMLinear(nn.Module):
             # which also overwrites a rule handed to the constructor
             self.phm_rule.copy_(torch.stack(get_multiplication_matrices(n, type=self.c_init), dim=0))
 
-    def forward(self, x: torch.Tensor, phm_rule=None, bn_stats=None) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, phm_rule=None, bn_stats=None, dx_handoff=None) -> torch.Tensor:
         # the second argument is accepted and ignored, as in the reference (:284-286); ``bn_stats`` (engine
         # extension): an ops.BNStatsRequest when a batch-norm consumes this layer's output directly
-        return _engine.phm_linear(x, self.phm_rule, self.W, self.b, bn_stats=bn_stats)
+        return _engine.phm_linear(x, self.phm_rule, self.W, self.b, bn_stats=bn_stats, dx_handoff=dx_handoff)
 
     def __repr__(self):
         return "{}(in_features={}, out_features={}, phm_dim={}, bias={}, w_init={}, c_init={}, learn_phm={})".format(

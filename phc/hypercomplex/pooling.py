@@ -55,9 +55,14 @@ class PHMSoftAttentionPooling(nn.Module):
         self.linear.reset_parameters()
 
     def forward(self, x: torch.Tensor, batch, num_graphs: Optional[int] = None, is_sorted: bool = False) -> torch.Tensor:
-        gate = self.real_trafo(self.linear(x))                                 # pre-sigmoid [N, embed_dim / phm_dim]
+        # x has two consumers (the gate's PHM layer and the gated sum): the sum's share of dx rides into the layer's dx GEMM
+        # instead of meeting it in an autograd add (engine: DxHandoff; sorted batches, i.e. the one-kernel read-out)
+        handoff = _engine.DxHandoff() if (is_sorted and x.is_cuda and x.dim() == 2 and torch.is_grad_enabled() and x.requires_grad) \
+            else None
+        gate = self.real_trafo(self.linear(x, dx_handoff=handoff))             # pre-sigmoid [N, embed_dim / phm_dim]
         # sigmoid, broadcast over the components, multiply and per-graph sum in one engine pass
-        return _engine.gated_segment_sum(x, gate, batch, self.phm_dim, num_graphs=num_graphs, is_sorted=is_sorted)
+        return _engine.gated_segment_sum(x, gate, batch, self.phm_dim, num_graphs=num_graphs, is_sorted=is_sorted,
+                                         dx_handoff=handoff)
 
     def __repr__(self):
         return "{}(embed_dim={}, phm_dim={}, phm_rule={}, learn_phm={}, bias={}, w_init='{}', c_init='{}', " \

@@ -386,6 +386,7 @@ struct CsrPair {
     // (the A operand of the register-resident bond-table gradient, phc_step_tail); R = sum(vocab) <= CR
     float *counts;
     int CR, R;
+    int resident;                      // the counter arrays of the workspace are zero on entry and are left zero (no zero launch)
 };
 
 __global__ void csr_pair_zero_kernel(CsrPair p) {
@@ -396,10 +397,12 @@ __global__ void csr_pair_zero_kernel(CsrPair p) {
     }
 }
 
+// resident workspace (phc_csr_build_pair_resident): the counts go into `cursor`, which every build leaves zeroed — no zero launch
 __global__ void csr_pair_hist_kernel(CsrPair p, long long E) {
     const CsrSide &sd = p.s[blockIdx.y];
+    int *cnt = p.resident ? sd.cursor : sd.rowptr;
     for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < E; e += (long long)gridDim.x * blockDim.x)
-        atomicAdd(&sd.rowptr[checked_index(sd.key[e], sd.num_keys, p.err, PHC_IDX_ERR_EDGE)], 1);      // both sides: every src and dst
+        atomicAdd(&cnt[checked_index(sd.key[e], sd.num_keys, p.err, PHC_IDX_ERR_EDGE)], 1);      // both sides: every src and dst
 }
 
 // exclusive scan of rowptr[0 .. num_keys] by ONE workgroup per side.  Global traffic is coalesced (thread t touches
@@ -411,11 +414,19 @@ __global__ __launch_bounds__(PAIR_SCAN_THREADS) void csr_pair_scan_kernel(CsrPai
     const CsrSide &sd = p.s[blockIdx.x];
     const int n = (int)(sd.num_keys + 1);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int *cnt = p.resident ? sd.cursor : sd.rowptr;
 #pragma unroll
     for (int i = 0; i < PAIR_SCAN_ITEMS; ++i) {
         const int e = i * PAIR_SCAN_THREADS + tid;
-        const int v = sd.rowptr[min(e, n - 1)];
+        const int v = cnt[min(e, n - 1)];
         buf[e] = e < n ? v : 0;
+    }
+    if (p.resident) {                                   // the counts are in registers / LDS now: the fill starts its cursors from zero
+#pragma unroll
+        for (int i = 0; i < PAIR_SCAN_ITEMS; ++i) {
+            const int e = i * PAIR_SCAN_THREADS + tid;
+            if (e < n) sd.cursor[e] = 0;
+        }
     }
     __syncthreads();
     const int base = tid * PAIR_SCAN_ITEMS;
@@ -475,6 +486,7 @@ __global__ __launch_bounds__(256) void csr_pair_canon_kernel(CsrPair p) {
     const long long n_grp = ((long long)gridDim.x * blockDim.x) / SUB;
     for (long long k = grp; k < sd.num_keys; k += n_grp) {
         const int b = sd.rowptr[k], deg = sd.rowptr[k + 1] - b;
+        if (p.resident && li == 0) sd.cursor[k] = 0;      // leave the workspace as the next build expects it
         for (int t = li; t < deg; t += SUB) {
             const int v = sd.tmp_perm[b + t];
             int rank = 0;
@@ -733,10 +745,31 @@ int phc_csr_build_pair(const int64_t *edge_src_i64, const int64_t *edge_dst_i64,
                                     nullptr, 0, nullptr, nullptr, ws, ws_bytes, stream);
 }
 
+static int csr_build_pair_impl(const int64_t *edge_src_i64, const int64_t *edge_dst_i64, int64_t E, int64_t n_src, int64_t n_dst,
+                               int32_t *rowptr, int32_t *col, int32_t *perm, int32_t *rowptr_t, int32_t *col_t, int32_t *perm_t,
+                               const int64_t *bond_i64, const int32_t *vocab, int F, uint32_t *codes, float *code_counts, void *ws,
+                               size_t ws_bytes, void *stream, int resident);
+
 int phc_csr_build_pair_codes(const int64_t *edge_src_i64, const int64_t *edge_dst_i64, int64_t E, int64_t n_src, int64_t n_dst,
                              int32_t *rowptr, int32_t *col, int32_t *perm, int32_t *rowptr_t, int32_t *col_t, int32_t *perm_t,
                              const int64_t *bond_i64, const int32_t *vocab, int F, uint32_t *codes, float *code_counts, void *ws,
                              size_t ws_bytes, void *stream) {
+    return csr_build_pair_impl(edge_src_i64, edge_dst_i64, E, n_src, n_dst, rowptr, col, perm, rowptr_t, col_t, perm_t, bond_i64, vocab, F,
+                               codes, code_counts, ws, ws_bytes, stream, 0);
+}
+
+int phc_csr_build_pair_codes_resident(const int64_t *edge_src_i64, const int64_t *edge_dst_i64, int64_t E, int64_t n_src,
+                                      int64_t n_dst, int32_t *rowptr, int32_t *col, int32_t *perm, int32_t *rowptr_t, int32_t *col_t,
+                                      int32_t *perm_t, const int64_t *bond_i64, const int32_t *vocab, int F, uint32_t *codes,
+                                      float *code_counts, void *ws_zeroed_once, size_t ws_bytes, void *stream) {
+    return csr_build_pair_impl(edge_src_i64, edge_dst_i64, E, n_src, n_dst, rowptr, col, perm, rowptr_t, col_t, perm_t, bond_i64, vocab, F,
+                               codes, code_counts, ws_zeroed_once, ws_bytes, stream, 1);
+}
+
+static int csr_build_pair_impl(const int64_t *edge_src_i64, const int64_t *edge_dst_i64, int64_t E, int64_t n_src, int64_t n_dst,
+                               int32_t *rowptr, int32_t *col, int32_t *perm, int32_t *rowptr_t, int32_t *col_t, int32_t *perm_t,
+                               const int64_t *bond_i64, const int32_t *vocab, int F, uint32_t *codes, float *code_counts, void *ws,
+                               size_t ws_bytes, void *stream, int resident) {
     int code_off[4] = {0, 0, 0, 0};
     int code_rows = 0;
     if (codes) {
@@ -784,12 +817,13 @@ int phc_csr_build_pair_codes(const int64_t *edge_src_i64, const int64_t *edge_ds
         p.vocab[f] = (codes && f < F) ? vocab[f] : 1;
     }
     p.err = err_word();
+    p.resident = resident;
     const long long nmax = (n_src > n_dst ? n_src : n_dst) + 1;
     const unsigned ngrid = (unsigned)((nmax + 255) / 256);
     const unsigned egrid = (unsigned)((E + 255) / 256 > 4096 ? 4096 : (E + 255) / 256);
     {
         ProfScope prof(K_CSR_HIST, s);
-        PHC_LAUNCH(csr_pair_zero_kernel, dim3(ngrid, 2), dim3(256), 0, s, p);
+        if (!resident) PHC_LAUNCH(csr_pair_zero_kernel, dim3(ngrid, 2), dim3(256), 0, s, p);
         PHC_LAUNCH(csr_pair_hist_kernel, dim3(egrid, 2), dim3(256), 0, s, p, (long long)E);
     }
     {

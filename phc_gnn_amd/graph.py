@@ -158,7 +158,10 @@ class EdgeStructure:
                     torch.empty(E, dtype=torch.int32, device=dev))
         csr, csc = (self._csr, self._csc) if reuse else (alloc(self.num_dst), alloc(self.num_src))
         ws_bytes = lib.phc_csr_pair_ws_bytes(E, self.num_src, self.num_dst)
-        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
+        # resident workspace: zeroed once; every build leaves its counter arrays zeroed again (one launch less per rebuild)
+        ws = getattr(self, "_pair_ws", None)
+        if ws is None or ws.numel() != ws_bytes:
+            ws = self._pair_ws = torch.zeros(ws_bytes, dtype=torch.uint8, device=dev)
         codes = bond = vocab_c = counts = None
         F = 0
         if reuse and self._codes and self._codes_args is not None:
@@ -172,11 +175,11 @@ class EdgeStructure:
             rows = sum(int(v) for v in list(vocab_c)[:F])
             if rows <= 32:                                   # per-destination table-row counts (phc_step_tail's bond operand)
                 counts = torch.empty((self.num_dst, 16 if rows <= 16 else 32), dtype=torch.float32, device=dev)
-        L.check(lib.phc_csr_build_pair_codes(L.ptr(self._src), L.ptr(self._dst), E, self.num_src, self.num_dst, L.ptr(csr[0]),
+        L.check(lib.phc_csr_build_pair_codes_resident(L.ptr(self._src), L.ptr(self._dst), E, self.num_src, self.num_dst, L.ptr(csr[0]),
                                              L.ptr(csr[1]), L.ptr(csr[2]), L.ptr(csc[0]), L.ptr(csc[1]), L.ptr(csc[2]),
                                              L.ptr(bond), vocab_c, F, L.ptr(codes), L.ptr(counts), L.ptr(ws), ws_bytes,
                                              L.stream_ptr(dev)),
-                "phc_csr_build_pair_codes")
+                "phc_csr_build_pair_codes_resident")
         self._code_counts = (codes, counts) if counts is not None else None
         L.maybe_check_indices(dev)
         self._csr, self._csc = csr, csc

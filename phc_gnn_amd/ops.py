@@ -487,8 +487,9 @@ def _prebuilt_for(A, W):
 # ---------------------------------------------------------------------------
 class _PHMLinearFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, A, W, b, residual, bn_stats=None):
+    def forward(ctx, x, A, W, b, residual, bn_stats=None, dx_handoff=None):
         lib = L.load()
+        ctx.dx_handoff = dx_handoff
         dev = L.require_device(x, A, W, b, residual)
         n, kin, kout = W.shape
         if tuple(A.shape) != (n, n, n):
@@ -543,15 +544,22 @@ class _PHMLinearFn(torch.autograd.Function):
         need_x, need_A, need_W, need_b, need_res = ctx.needs_input_grad[:5]
         need_b = need_b and ctx.has_bias
         dx = torch.empty_like(x2) if need_x else None
+        # the other consumer's share of dx (DxHandoff): added inside the dx GEMM where that path runs, by one add otherwise
+        extra = ctx.dx_handoff.take() if ctx.dx_handoff is not None else None
+        if extra is not None and (not need_x or tuple(extra.shape) != tuple(x2.shape)):
+            raise L.PhcError("DxHandoff: a parked gradient needs a consumer that computes dx of the same shape")
         need_param = need_A or need_W or need_b
         if need_param and ctx.defer_params is not None and _DEFER.active and not torch.is_grad_enabled():
             # dx only; the parameter gradients of all layers are produced together when the deferral block exits
-            if need_x and ctx.HT is not None and dy2.data_ptr() % 16 == 0:
-                L.check(lib.phc_gemm_prebuilt(L.ptr(dy2), L.ptr(ctx.HT), L.ptr(ctx.HTk4), None, None, N, n * kout, n * kin, L.ptr(dx), 1,
+            if need_x and ctx.HT is not None and dy2.data_ptr() % 16 == 0 and (extra is None or extra.data_ptr() % 16 == 0):
+                L.check(lib.phc_gemm_prebuilt(L.ptr(dy2), L.ptr(ctx.HT), L.ptr(ctx.HTk4), None, L.ptr(extra), N, n * kout, n * kin, L.ptr(dx), 1,
                                               L.stream_ptr(dev)), "phc_gemm_prebuilt(dx)")
+                extra = None
             else:
                 L.check(lib.phc_phm_linear_bwd(L.ptr(x2), L.ptr(A), L.ptr(W), L.ptr(dy2), N, n, kin, kout, L.ptr(dx), None,
                                                None, None, None, 0, L.stream_ptr(dev)), "phc_phm_linear_bwd")
+            if extra is not None:
+                dx += extra
             if L.PROF_ON and need_x:
                 L.account("phm_gemm_dx", 2.0 * N * n * kin * n * kout, 4.0 * (N * n * (kin + kout) + n * kin * kout + n ** 3))
             pA, pW, pb = ctx.defer_params
@@ -559,7 +567,7 @@ class _PHMLinearFn(torch.autograd.Function):
                 _DEFER.jobs.append(dict(x=x2, dy=dy2, A=A, W=W, need=(need_A, need_W, need_b),
                                         params=(pA if need_A else None, pW if need_W else None, pb if need_b else None)))
             return (dx.reshape(ctx.x_shape) if need_x else None, None, None, None,
-                    dy.reshape(ctx.res_shape) if (need_res and ctx.has_res) else None, None)
+                    dy.reshape(ctx.res_shape) if (need_res and ctx.has_res) else None, None, None)
         dW = torch.empty_like(W) if need_param else None
         dA = torch.empty_like(A) if need_A else None
         db = torch.empty(n * kout, dtype=torch.float32, device=dev) if need_b else None
@@ -575,8 +583,10 @@ class _PHMLinearFn(torch.autograd.Function):
                 L.account("phm_gemm_dx", gemm, io + 4.0 * (n * kin * kout + n ** 3))
             if need_param:
                 L.account("phm_dH_partial", gemm, io + 4.0 * n * kin * n * kout)
+        if extra is not None:
+            dx += extra
         return (dx.reshape(ctx.x_shape) if need_x else None, dA, dW if need_W else None, db,
-                dy.reshape(ctx.res_shape) if (need_res and ctx.has_res) else None, None)
+                dy.reshape(ctx.res_shape) if (need_res and ctx.has_res) else None, None, None)
 
 
 def phm_linear_dx_raw(dy: torch.Tensor, A: torch.Tensor, W: torch.Tensor) -> torch.Tensor:
@@ -722,10 +732,24 @@ class BNStatsRequest:
         return self.partial, self.counts, True
 
 
+class DxHandoff:
+    """Gradient hand-over between two consumers of ONE tensor x (the soft-attention read-out: x feeds the gate's PHM layer and
+    the gated sum).  The consumer whose backward runs first parks its dx here instead of returning it; the PHM layer's backward
+    adds it inside its dx GEMM (the GEMM's residual operand) — autograd then sees one gradient for x and launches no add."""
+
+    def __init__(self):
+        self.tensor = None
+
+    def take(self):
+        t, self.tensor = self.tensor, None
+        return t
+
+
 def phm_linear(x: torch.Tensor, phm_rule: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None,
-               residual: Optional[torch.Tensor] = None, bn_stats: Optional[BNStatsRequest] = None) -> torch.Tensor:
+               residual: Optional[torch.Tensor] = None, bn_stats: Optional[BNStatsRequest] = None,
+               dx_handoff: Optional[DxHandoff] = None) -> torch.Tensor:
     """y = x · (Σ_i phm_rule[i] ⊗ W[i]) + bias (+ residual)."""
-    y = _PHMLinearFn.apply(x, phm_rule, W, bias, residual, bn_stats)
+    y = _PHMLinearFn.apply(x, phm_rule, W, bias, residual, bn_stats, dx_handoff)
     if bn_stats is not None and bn_stats.partial is not None:
         y._phc_bn = bn_stats                 # consumed by batch_norm_act if it is handed this very tensor
     return y
@@ -1338,8 +1362,9 @@ class _GatedSegmentSumFn(torch.autograd.Function):
     """out[g, c*k+j] = Σ_{r in graph g} x[r, c*k+j]·σ(gate[r, j]) over rows that are already grouped by graph."""
 
     @staticmethod
-    def forward(ctx, x, gate, st: SegmentStructure, n_comp: int):
+    def forward(ctx, x, gate, st: SegmentStructure, n_comp: int, dx_handoff=None):
         lib = L.load()
+        ctx.dx_handoff = dx_handoff
         dev = L.require_device(x, gate)
         x_, g_ = L.f32c(x), L.f32c(gate)
         N, h = x_.shape
@@ -1373,11 +1398,14 @@ class _GatedSegmentSumFn(torch.autograd.Function):
                                        L.stream_ptr(dev)), "phc_gated_pool_bwd")
         if L.PROF_ON:
             L.account("gated_pool_bwd", 4.0 * N * h, 4.0 * (N * (2 * h + 2 * h // n_comp) + G * h))
-        return dx, dg, None, None
+        if ctx.dx_handoff is not None and dx is not None:
+            ctx.dx_handoff.tensor = dx                      # added inside the gate layer's dx GEMM (DxHandoff)
+            dx = None
+        return dx, dg, None, None, None
 
 
 def gated_segment_sum(x: torch.Tensor, gate: torch.Tensor, batch, n_comp: int, num_graphs: Optional[int] = None,
-                      is_sorted: bool = False) -> torch.Tensor:
+                      is_sorted: bool = False, dx_handoff=None) -> torch.Tensor:
     """Soft-attention read-out (phc/hypercomplex/pooling.py:57-66): per-graph sum of x scaled by σ(gate), the gate
     [N, h/n_comp] broadcast over the n_comp components.  One kernel each way when ``batch`` is sorted (collated
     mini-batches are); an unsorted ``batch`` takes the sigmoid / multiply / segment-sum route."""
@@ -1386,7 +1414,7 @@ def gated_segment_sum(x: torch.Tensor, gate: torch.Tensor, batch, n_comp: int, n
         N, h = x.shape
         gated = (x.view(N, n_comp, h // n_comp) * torch.sigmoid(gate).unsqueeze(1)).reshape(N, h)
         return _SegmentSumFn.apply(gated, st)
-    return _GatedSegmentSumFn.apply(x, gate, st, n_comp)
+    return _GatedSegmentSumFn.apply(x, gate, st, n_comp, dx_handoff)
 
 
 # Tensors known to hold exactly 1.0 for their whole life (harness.backward_seed, GraphedTrainStep's seed): a backward

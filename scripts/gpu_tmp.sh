@@ -1,5 +1,10 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-timeout 2700 python -m pytest tests -m gpu -q > gpurun_out/r03_gpu_suite2.log 2>&1
-echo "suite rc=$?"; grep -E "passed|failed" gpurun_out/r03_gpu_suite2.log | tail -3
+timeout 2700 python -m pytest tests -m gpu -q -x > gpurun_out/r03_gpu_suite3.log 2>&1
+echo "suite rc=$?"; grep -E "passed|failed|^E  " gpurun_out/r03_gpu_suite3.log | tail -5 | cut -c1-250
+for i in 1 2 3; do
+  timeout 600 python bench.py --workload molhiv_b512 --cpu-steps 0 --profile-steps 0 2>&1 | grep '^{"metric"' | python3 -c "
+import json,sys
+d=json.loads(sys.stdin.read()); print('molhiv_b512', d['ms_per_step'])"
+done
