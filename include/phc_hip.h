@@ -615,6 +615,14 @@ int phc_bce_masked_fwd_unit(const float *logits, const float *y, int64_t total, 
                             float *dlogits_unit, void *stream);
 int phc_bce_masked_bwd(const float *logits, const float *y, const float *dloss, const float *stat, int64_t total,
                        float *dlogits, void *stream);
+/* The same three for the mean L1 loss over the labeled entries (benchmarks/train_zinc.py: torch.nn.L1Loss on the regression target;
+ * d|d|/dd = sign(d) with sign(0) = 0 as in torch).  A NaN target (a padding graph of a fixed-shape batch) stays out of the mean. */
+int phc_l1_masked_fwd(const float *pred, const float *y, int64_t total, float *loss, float *stat, void *ws, size_t ws_bytes,
+                      void *stream);
+int phc_l1_masked_fwd_unit(const float *pred, const float *y, int64_t total, float *loss, float *stat, float *dpred_unit,
+                           void *stream);
+int phc_l1_masked_bwd(const float *pred, const float *y, const float *dloss, const float *stat, int64_t total, float *dpred,
+                      void *stream);
 
 /* ------------------------------------------------------------------------- *
  * The downstream head in one launch each way

@@ -33,6 +33,20 @@ __device__ __forceinline__ void block_reduce2(float &a, float &b, float *red) {
     b = red[RO_THREADS];
 }
 
+// KIND 0: BCE with logits (train_hiv.py:174-178); KIND 1: L1 (train_zinc.py: torch.nn.L1Loss) — both as the mean over the labeled
+// (non-NaN) entries
+template <int KIND>
+__device__ __forceinline__ float loss_entry(float z, float yv) {
+    return KIND == 0 ? bce_entry(z, yv) : fabsf(z - yv);
+}
+template <int KIND>
+__device__ __forceinline__ float loss_grad(float z, float yv) {
+    if (KIND == 0) return 1.f / (1.f + expf(-z)) - yv;
+    const float d = z - yv;
+    return d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);              // torch's sign(0) = 0
+}
+
+template <int KIND>
 __global__ __launch_bounds__(RO_THREADS) void bce_masked_fwd_kernel(const float *__restrict__ logits, const float *__restrict__ y,
                                                                   long long total, float *__restrict__ partial,
                                                                   float *__restrict__ loss, float *__restrict__ stat) {
@@ -41,7 +55,7 @@ __global__ __launch_bounds__(RO_THREADS) void bce_masked_fwd_kernel(const float 
     for (long long e = (long long)blockIdx.x * RO_THREADS + threadIdx.x; e < total; e += (long long)gridDim.x * RO_THREADS) {
         const float yv = y[e];
         if (yv == yv) {                                       // labeled (not NaN)
-            s += bce_entry(logits[e], yv);
+            s += loss_entry<KIND>(logits[e], yv);
             c += 1.f;
         }
     }
@@ -60,6 +74,7 @@ __global__ __launch_bounds__(RO_THREADS) void bce_masked_fwd_kernel(const float 
 
 // One workgroup (total <= 4096): the loss AND, from the same labeled count, d loss / d logits for an upstream gradient
 // of exactly 1 — what the backward of a scalar training loss receives — so that backward needs no launch of its own.
+template <int KIND>
 __global__ __launch_bounds__(RO_THREADS) void bce_masked_fwd_unit_kernel(const float *__restrict__ logits, const float *__restrict__ y,
                                                                        long long total, float *__restrict__ loss,
                                                                        float *__restrict__ stat, float *__restrict__ dlogits_unit) {
@@ -68,7 +83,7 @@ __global__ __launch_bounds__(RO_THREADS) void bce_masked_fwd_unit_kernel(const f
     for (long long e = threadIdx.x; e < total; e += RO_THREADS) {
         const float yv = y[e];
         if (yv == yv) {
-            s += bce_entry(logits[e], yv);
+            s += loss_entry<KIND>(logits[e], yv);
             c += 1.f;
         }
     }
@@ -81,7 +96,7 @@ __global__ __launch_bounds__(RO_THREADS) void bce_masked_fwd_unit_kernel(const f
     const float scale = 1.f / c;
     for (long long e = threadIdx.x; e < total; e += RO_THREADS) {
         const float yv = y[e];
-        dlogits_unit[e] = yv == yv ? (1.f / (1.f + expf(-logits[e])) - yv) * scale : 0.f;
+        dlogits_unit[e] = yv == yv ? loss_grad<KIND>(logits[e], yv) * scale : 0.f;
     }
 }
 
@@ -101,7 +116,8 @@ __global__ __launch_bounds__(RO_THREADS) void bce_masked_finalize_kernel(const f
     }
 }
 
-// dlogits = dloss * (sigmoid(z) - y) / count on labeled entries, 0 elsewhere
+// dlogits = dloss * (sigmoid(z) - y) / count on labeled entries, 0 elsewhere (L1: sign(z - y) in place of the difference)
+template <int KIND>
 __global__ __launch_bounds__(256) void bce_masked_bwd_kernel(const float *__restrict__ logits, const float *__restrict__ y,
                                                            const float *__restrict__ dloss, const float *__restrict__ stat,
                                                            long long total, float *__restrict__ dlogits) {
@@ -110,8 +126,7 @@ __global__ __launch_bounds__(256) void bce_masked_bwd_kernel(const float *__rest
         const float yv = y[e];
         float g = 0.f;
         if (yv == yv) {
-            const float z = logits[e];
-            g = (1.f / (1.f + expf(-z)) - yv) * scale;
+            g = loss_grad<KIND>(logits[e], yv) * scale;
         }
         dlogits[e] = g;
     }
@@ -406,41 +421,73 @@ size_t phc_bce_masked_ws_bytes(int64_t total) {
     return sizeof(float) * 2 * 256;
 }
 
-int phc_bce_masked_fwd(const float *logits, const float *y, int64_t total, float *loss, float *stat, void *ws, size_t ws_bytes,
-                       void *stream) {
-    PHC_REQUIRE(total > 0 && logits && y && loss && stat, PHC_ERR_INVALID_ARG, "phc_bce_masked_fwd: bad arguments");
+static int masked_loss_fwd(const char *who, int kind, const float *logits, const float *y, int64_t total, float *loss, float *stat, void *ws,
+                           size_t ws_bytes, void *stream) {
+    PHC_REQUIRE(total > 0 && logits && y && loss && stat, PHC_ERR_INVALID_ARG, "%s: bad arguments", who);
     hipStream_t s = (hipStream_t)stream;
     int blocks = (int)((total + (1 << 12) - 1) >> 12);          // 4k entries (4 per thread) per workgroup
     if (blocks > 256) blocks = 256;
-    PHC_REQUIRE(blocks == 1 || (ws && ws_bytes >= phc_bce_masked_ws_bytes(total)), PHC_ERR_WORKSPACE,
-                "phc_bce_masked_fwd: workspace too small");
+    PHC_REQUIRE(blocks == 1 || (ws && ws_bytes >= phc_bce_masked_ws_bytes(total)), PHC_ERR_WORKSPACE, "%s: workspace too small", who);
     ProfScope prof(K_BCE_FWD, s);
-    PHC_LAUNCH(bce_masked_fwd_kernel, dim3(blocks), dim3(RO_THREADS), 0, s, logits, y, (long long)total, static_cast<float *>(ws),
-               loss, stat);
+    if (kind == 0)
+        PHC_LAUNCH(bce_masked_fwd_kernel<0>, dim3(blocks), dim3(RO_THREADS), 0, s, logits, y, (long long)total, static_cast<float *>(ws), loss, stat);
+    else
+        PHC_LAUNCH(bce_masked_fwd_kernel<1>, dim3(blocks), dim3(RO_THREADS), 0, s, logits, y, (long long)total, static_cast<float *>(ws), loss, stat);
     if (blocks > 1)
         PHC_LAUNCH(bce_masked_finalize_kernel, dim3(1), dim3(RO_THREADS), 0, s, static_cast<const float *>(ws), blocks, loss, stat);
-    return check_launch("bce_masked_fwd");
+    return check_launch(who);
 }
 
-int phc_bce_masked_fwd_unit(const float *logits, const float *y, int64_t total, float *loss, float *stat, float *dlogits_unit,
-                            void *stream) {
+static int masked_loss_fwd_unit(const char *who, int kind, const float *logits, const float *y, int64_t total, float *loss, float *stat,
+                                float *dlogits_unit, void *stream) {
     PHC_REQUIRE(total > 0 && total <= (1 << 12) && logits && y && loss && stat && dlogits_unit, PHC_ERR_INVALID_ARG,
-                "phc_bce_masked_fwd_unit: 1 <= total <= 4096 entries and non-null pointers");
+                "%s: 1 <= total <= 4096 entries and non-null pointers", who);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(K_BCE_FWD, s);
-    PHC_LAUNCH(bce_masked_fwd_unit_kernel, dim3(1), dim3(RO_THREADS), 0, s, logits, y, (long long)total, loss, stat, dlogits_unit);
-    return check_launch("bce_masked_fwd_unit");
+    if (kind == 0)
+        PHC_LAUNCH(bce_masked_fwd_unit_kernel<0>, dim3(1), dim3(RO_THREADS), 0, s, logits, y, (long long)total, loss, stat, dlogits_unit);
+    else
+        PHC_LAUNCH(bce_masked_fwd_unit_kernel<1>, dim3(1), dim3(RO_THREADS), 0, s, logits, y, (long long)total, loss, stat, dlogits_unit);
+    return check_launch(who);
 }
 
-int phc_bce_masked_bwd(const float *logits, const float *y, const float *dloss, const float *stat, int64_t total, float *dlogits,
-                       void *stream) {
-    PHC_REQUIRE(total > 0 && logits && y && dloss && stat && dlogits, PHC_ERR_INVALID_ARG, "phc_bce_masked_bwd: bad arguments");
+static int masked_loss_bwd(const char *who, int kind, const float *logits, const float *y, const float *dloss, const float *stat,
+                           int64_t total, float *dlogits, void *stream) {
+    PHC_REQUIRE(total > 0 && logits && y && dloss && stat && dlogits, PHC_ERR_INVALID_ARG, "%s: bad arguments", who);
     hipStream_t s = (hipStream_t)stream;
     long long blocks = (total + 1023) / 1024;
     if (blocks > 1024) blocks = 1024;
     ProfScope prof(K_BCE_BWD, s);
-    PHC_LAUNCH(bce_masked_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, s, logits, y, dloss, stat, (long long)total, dlogits);
-    return check_launch("bce_masked_bwd");
+    if (kind == 0)
+        PHC_LAUNCH(bce_masked_bwd_kernel<0>, dim3((unsigned)blocks), dim3(256), 0, s, logits, y, dloss, stat, (long long)total, dlogits);
+    else
+        PHC_LAUNCH(bce_masked_bwd_kernel<1>, dim3((unsigned)blocks), dim3(256), 0, s, logits, y, dloss, stat, (long long)total, dlogits);
+    return check_launch(who);
+}
+
+int phc_bce_masked_fwd(const float *logits, const float *y, int64_t total, float *loss, float *stat, void *ws, size_t ws_bytes,
+                       void *stream) {
+    return masked_loss_fwd("phc_bce_masked_fwd", 0, logits, y, total, loss, stat, ws, ws_bytes, stream);
+}
+int phc_bce_masked_fwd_unit(const float *logits, const float *y, int64_t total, float *loss, float *stat, float *dlogits_unit,
+                            void *stream) {
+    return masked_loss_fwd_unit("phc_bce_masked_fwd_unit", 0, logits, y, total, loss, stat, dlogits_unit, stream);
+}
+int phc_bce_masked_bwd(const float *logits, const float *y, const float *dloss, const float *stat, int64_t total, float *dlogits,
+                       void *stream) {
+    return masked_loss_bwd("phc_bce_masked_bwd", 0, logits, y, dloss, stat, total, dlogits, stream);
+}
+// the same three for the L1 loss of the regression models (benchmarks/train_zinc.py: torch.nn.L1Loss), NaN labels left out
+int phc_l1_masked_fwd(const float *pred, const float *y, int64_t total, float *loss, float *stat, void *ws, size_t ws_bytes,
+                      void *stream) {
+    return masked_loss_fwd("phc_l1_masked_fwd", 1, pred, y, total, loss, stat, ws, ws_bytes, stream);
+}
+int phc_l1_masked_fwd_unit(const float *pred, const float *y, int64_t total, float *loss, float *stat, float *dpred_unit, void *stream) {
+    return masked_loss_fwd_unit("phc_l1_masked_fwd_unit", 1, pred, y, total, loss, stat, dpred_unit, stream);
+}
+int phc_l1_masked_bwd(const float *pred, const float *y, const float *dloss, const float *stat, int64_t total, float *dpred,
+                      void *stream) {
+    return masked_loss_bwd("phc_l1_masked_bwd", 1, pred, y, dloss, stat, total, dpred, stream);
 }
 
 static bool gp_vec4(int h, int k, const void *a, const void *b, const void *c, const void *d) {

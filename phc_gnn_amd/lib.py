@@ -169,6 +169,9 @@ SIGNATURES = {
     "phc_bce_masked_ws_bytes": (_S, [_L]),
     "phc_bce_masked_fwd": (_I, [_P, _P, _L, _P, _P, _P, _S, _P]),
     "phc_bce_masked_bwd": (_I, [_P, _P, _P, _P, _L, _P, _P]),
+    "phc_l1_masked_fwd": (_I, [_P, _P, _L, _P, _P, _P, _S, _P]),
+    "phc_l1_masked_fwd_unit": (_I, [_P, _P, _L, _P, _P, _P, _P]),
+    "phc_l1_masked_bwd": (_I, [_P, _P, _P, _P, _L, _P, _P]),
     "phc_bce_masked_fwd_unit": (_I, [_P, _P, _L, _P, _P, _P, _P]),
     "phc_gated_pool_fwd": (_I, [_P, _P, _P, _L, _I, _I, _P, _P]),
     "phc_gated_pool_fwd_sorted": (_I, [_P, _P, _P, _L, _L, _I, _I, _P, _P]),

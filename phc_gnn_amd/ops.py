@@ -1432,42 +1432,68 @@ def unregister_unit_seed(t: torch.Tensor) -> None:
     _UNIT_SEEDS.discard((t.data_ptr(), t.device))
 
 
+def _masked_loss_forward(kind, ctx, logits, y):
+    """Shared forward of the NaN-masked mean losses; ``kind``: entry-point family phc_<kind>_masked_{fwd, fwd_unit, bwd}."""
+    lib = L.load()
+    dev = L.require_device(logits, y)
+    z_, y_ = L.f32c(logits), L.f32c(y)
+    if z_.shape != y_.shape:
+        raise L.PhcError(f"logits {tuple(z_.shape)} vs labels {tuple(y_.shape)}")
+    total = z_.numel()
+    out = torch.empty(3, dtype=torch.float32, device=dev)             # loss | sum | labeled count
+    ctx.dz_unit = None
+    ctx.kind = kind
+    if total <= (1 << 12) and ctx.needs_input_grad[0]:
+        # one workgroup: loss and d loss / d logits (for an upstream gradient of 1) in the same launch
+        ctx.dz_unit = torch.empty_like(z_)
+        L.check(getattr(lib, f"phc_{kind}_masked_fwd_unit")(L.ptr(z_), L.ptr(y_), total, L.ptr(out), L.ptr(out) + 4, L.ptr(ctx.dz_unit),
+                                                           L.stream_ptr(dev)), f"phc_{kind}_masked_fwd_unit")
+    else:
+        ws_bytes = lib.phc_bce_masked_ws_bytes(total)
+        ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if total > (1 << 12) else None
+        L.check(getattr(lib, f"phc_{kind}_masked_fwd")(L.ptr(z_), L.ptr(y_), total, L.ptr(out), L.ptr(out) + 4, L.ptr(ws),
+                                                      ws_bytes if ws is not None else 0, L.stream_ptr(dev)), f"phc_{kind}_masked_fwd")
+    ctx.save_for_backward(z_, y_, out)
+    ctx.shape = logits.shape
+    return out[0]
+
+
+def _masked_loss_backward(ctx, dloss):
+    lib = L.load()
+    z_, y_, out = ctx.saved_tensors
+    if ctx.dz_unit is not None and dloss.numel() == 1 and (dloss.data_ptr(), dloss.device) in _UNIT_SEEDS:
+        return ctx.dz_unit.reshape(ctx.shape), None              # upstream gradient is the resident 1: nothing to launch
+    dl = L.f32c(dloss.reshape(1))
+    dz = torch.empty_like(z_)
+    L.check(getattr(lib, f"phc_{ctx.kind}_masked_bwd")(L.ptr(z_), L.ptr(y_), L.ptr(dl), L.ptr(out) + 4, z_.numel(), L.ptr(dz),
+                                                      L.stream_ptr(dz.device)), f"phc_{ctx.kind}_masked_bwd")
+    return dz.reshape(ctx.shape), None
+
+
 class _MaskedBCEFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, logits, y):
-        lib = L.load()
-        dev = L.require_device(logits, y)
-        z_, y_ = L.f32c(logits), L.f32c(y)
-        if z_.shape != y_.shape:
-            raise L.PhcError(f"logits {tuple(z_.shape)} vs labels {tuple(y_.shape)}")
-        total = z_.numel()
-        out = torch.empty(3, dtype=torch.float32, device=dev)             # loss | sum | labeled count
-        ctx.dz_unit = None
-        if total <= (1 << 12) and ctx.needs_input_grad[0]:
-            # one workgroup: loss and d loss / d logits (for an upstream gradient of 1) in the same launch
-            ctx.dz_unit = torch.empty_like(z_)
-            L.check(lib.phc_bce_masked_fwd_unit(L.ptr(z_), L.ptr(y_), total, L.ptr(out), L.ptr(out) + 4, L.ptr(ctx.dz_unit),
-                                                L.stream_ptr(dev)), "phc_bce_masked_fwd_unit")
-        else:
-            ws_bytes = lib.phc_bce_masked_ws_bytes(total)
-            ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev) if total > (1 << 12) else None
-            L.check(lib.phc_bce_masked_fwd(L.ptr(z_), L.ptr(y_), total, L.ptr(out), L.ptr(out) + 4, L.ptr(ws),
-                                           ws_bytes if ws is not None else 0, L.stream_ptr(dev)), "phc_bce_masked_fwd")
-        ctx.save_for_backward(z_, y_, out)
-        ctx.shape = logits.shape
-        return out[0]
+        return _masked_loss_forward("bce", ctx, logits, y)
 
     @staticmethod
     def backward(ctx, dloss):
-        lib = L.load()
-        z_, y_, out = ctx.saved_tensors
-        if ctx.dz_unit is not None and dloss.numel() == 1 and (dloss.data_ptr(), dloss.device) in _UNIT_SEEDS:
-            return ctx.dz_unit.reshape(ctx.shape), None              # upstream gradient is the resident 1: nothing to launch
-        dl = L.f32c(dloss.reshape(1))
-        dz = torch.empty_like(z_)
-        L.check(lib.phc_bce_masked_bwd(L.ptr(z_), L.ptr(y_), L.ptr(dl), L.ptr(out) + 4, z_.numel(), L.ptr(dz),
-                                       L.stream_ptr(dz.device)), "phc_bce_masked_bwd")
-        return dz.reshape(ctx.shape), None
+        return _masked_loss_backward(ctx, dloss)
+
+
+class _MaskedL1Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, y):
+        return _masked_loss_forward("l1", ctx, pred, y)
+
+    @staticmethod
+    def backward(ctx, dloss):
+        return _masked_loss_backward(ctx, dloss)
+
+
+def masked_l1(pred: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+    """mean |pred - y| over the entries whose target is not NaN (benchmarks/train_zinc.py: torch.nn.L1Loss; the padding graphs
+    of a fixed-shape batch carry NaN targets) — one kernel each way instead of a dozen element-wise launches."""
+    return _MaskedL1Fn.apply(pred, y)
 
 
 def masked_bce_with_logits(logits: torch.Tensor, y: torch.Tensor) -> torch.Tensor:

@@ -1,8 +1,10 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
-for i in 1 2 3; do for v in 0 1; do
-  if [ $v = 1 ]; then export PHC_GEMM_HS_ALL=1; else unset PHC_GEMM_HS_ALL; fi
-  timeout 600 python bench.py --workload molhiv_b512 --cpu-steps 0 --profile-steps 0 2>&1 | grep '^{"metric"' | python3 -c "
+export TMPDIR=/tmp
+timeout 2400 python -m pytest tests/test_gpu_ops.py tests/test_gpu_fullwidth.py tests/test_gpu_model.py -m gpu -q -k "l1 or bce or zinc or g10 or g12 or g8" > gpurun_out/r03_l1.log 2>&1
+echo "rc=$?"; grep -E "passed|failed|^E  " gpurun_out/r03_l1.log | tail -5 | cut -c1-250
+for wl in zinc_b1024 zinc_pub_phc5_4x200 zinc_pub_phc4_4x180; do
+  timeout 600 python bench.py --workload $wl --cpu-steps 0 --profile-steps 0 2>&1 | grep '^{"metric"' | python3 -c "
 import json,sys
-d=json.loads(sys.stdin.read()); print('hs_all=$v', d['ms_per_step'])"
-done; done
+d=json.loads(sys.stdin.read()); print('$wl', d['ms_per_step'])"
+done

@@ -629,6 +629,30 @@ def test_aggregate_softmax_encoded_matches_oracle(ops, act, add_self):
         assert_close(a, r, 3e-5, "table grad")
 
 
+@pytest.mark.parametrize("shape,frac_nan", [((1088, 1), 0.06), ((37, 12), 0.4), ((1100, 128), 0.7), ((5, 3), 0.0)])
+def test_masked_l1_matches_torch(ops, shape, frac_nan):
+    """NaN-masked mean L1 (benchmarks/train_zinc.py: torch.nn.L1Loss; padding graphs of a fixed-shape batch carry NaN targets) fwd +
+    bwd against ``F.l1_loss(pred[mask], y[mask])``, incl. exact ties (gradient 0, torch's sign(0)) and the multi-workgroup path."""
+    g = torch.Generator().manual_seed(31)
+    z = (torch.randn(shape, generator=g) * 3)
+    y = torch.randn(shape, generator=g)
+    y[torch.rand(shape, generator=g) < frac_nan] = float("nan")
+    z.view(-1)[:3] = torch.nan_to_num(y.view(-1)[:3])                 # ties where the target is labeled
+    z.requires_grad_()
+    mask = ~torch.isnan(y)
+    ref = torch.nn.functional.l1_loss(z[mask], y[mask])
+    ref.backward()
+    zd = z.detach().to(DEV).requires_grad_()
+    loss = ops.masked_l1(zd, y.to(DEV))
+    loss.backward()
+    assert_close(loss, ref, TOL, "masked L1")
+    assert_close(zd.grad, z.grad, TOL, "d masked L1")
+    w = torch.tensor(0.37, device=DEV)                                # a non-unit upstream gradient takes the backward launch
+    zd2 = z.detach().to(DEV).requires_grad_()
+    (ops.masked_l1(zd2, y.to(DEV)) * w).backward()
+    assert_close(zd2.grad, z.grad * 0.37, TOL, "d masked L1, scaled")
+
+
 @pytest.mark.parametrize("shape,frac_nan", [((544, 1), 0.06), ((37, 12), 0.4), ((1100, 128), 0.7), ((5, 3), 0.0)])
 def test_masked_bce_matches_oracle(ops, shape, frac_nan):
     """NaN-masked BCE-with-logits (train_hiv.py:174-178) fwd + bwd; (1100,128) exercises the multi-workgroup path."""
