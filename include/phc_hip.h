@@ -459,7 +459,7 @@ int phc_table_grads_counted(const phc_table_grad_job *jobs, int num_jobs, const 
 
 /* Both sorted views of one edge list — destination-sorted (rowptr/col/perm, forward) and source-sorted
  * (rowptr_t/col_t/perm_t, backward) — side by side in FIVE launches instead of 22 (a training step needs
- * both).  Same result as two phc_csr_build calls (stable order).  At most 16383 rows per side (molecule
+ * both).  Same result as two phc_csr_build calls (stable order).  At most 32767 rows per side (molecule
  * batches); larger graphs use phc_csr_build. */
 size_t phc_csr_pair_ws_bytes(int64_t E, int64_t n_src, int64_t n_dst);
 int phc_csr_build_pair(const int64_t *edge_src_i64, const int64_t *edge_dst_i64, int64_t E, int64_t n_src, int64_t n_dst,

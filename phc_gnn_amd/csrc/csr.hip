@@ -366,7 +366,7 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 // A training step needs the destination-sorted view (forward) AND the source-sorted one (backward).  Building
 // them side by side (blockIdx.y picks the side) with a one-workgroup scan takes 5 launches instead of 22.
 constexpr int PAIR_SCAN_THREADS = 1024;
-constexpr int PAIR_SCAN_ITEMS = 16;
+constexpr int PAIR_SCAN_ITEMS = 32;
 constexpr int PAIR_MAX_KEYS = PAIR_SCAN_THREADS * PAIR_SCAN_ITEMS - 1;      // rowptr has num_keys + 1 entries
 
 struct CsrSide {
@@ -405,38 +405,36 @@ __global__ void csr_pair_hist_kernel(CsrPair p, long long E) {
         atomicAdd(&cnt[checked_index(sd.key[e], sd.num_keys, p.err, PHC_IDX_ERR_EDGE)], 1);      // both sides: every src and dst
 }
 
-// exclusive scan of rowptr[0 .. num_keys] by ONE workgroup per side.  Global traffic is coalesced (thread t touches
-// elements t, t + 1024, ...) and staged through LDS; each thread then scans its own 16 consecutive LDS entries
-// (a 16-int stride per lane in global memory made every load / store instruction touch 64 cache lines: 13 us).
+// exclusive scan of the row counts [0 .. num_keys] by ONE workgroup per side.  Global traffic is coalesced (thread t touches
+// elements t, t + 1024, ...) and staged through LDS; each thread then scans its own 32 consecutive LDS entries.  The LDS image is
+// padded by one word per 32 (entry e sits at e + e / 32), so that the 64 lanes of a wavefront, 32 entries apart, hit 64 different
+// banks.  32 767 rows per side: the 1024-graph batches of the 256-wide configurations (23-27 k nodes) take this path too.
+__device__ __forceinline__ int pair_pad(int e) { return e + (e >> 5); }
 __global__ __launch_bounds__(PAIR_SCAN_THREADS) void csr_pair_scan_kernel(CsrPair p) {
-    __shared__ int buf[PAIR_SCAN_THREADS * PAIR_SCAN_ITEMS];
+    __shared__ int buf[PAIR_SCAN_THREADS * (PAIR_SCAN_ITEMS + 1)];
     __shared__ int wave_tot[PAIR_SCAN_THREADS / 64];
     const CsrSide &sd = p.s[blockIdx.x];
     const int n = (int)(sd.num_keys + 1);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int *cnt = p.resident ? sd.cursor : sd.rowptr;
-#pragma unroll
+#pragma unroll 8
     for (int i = 0; i < PAIR_SCAN_ITEMS; ++i) {
         const int e = i * PAIR_SCAN_THREADS + tid;
         const int v = cnt[min(e, n - 1)];
-        buf[e] = e < n ? v : 0;
+        buf[pair_pad(e)] = e < n ? v : 0;
     }
-    if (p.resident) {                                   // the counts are in registers / LDS now: the fill starts its cursors from zero
-#pragma unroll
+    if (p.resident) {                                   // the counts are in LDS now: the fill starts its cursors from zero
+#pragma unroll 8
         for (int i = 0; i < PAIR_SCAN_ITEMS; ++i) {
             const int e = i * PAIR_SCAN_THREADS + tid;
             if (e < n) sd.cursor[e] = 0;
         }
     }
     __syncthreads();
-    const int base = tid * PAIR_SCAN_ITEMS;
-    int v[PAIR_SCAN_ITEMS];
+    const int base = tid * PAIR_SCAN_ITEMS;             // pair_pad(base + j) = tid * 33 + j
     int tot = 0;
-#pragma unroll
-    for (int i = 0; i < PAIR_SCAN_ITEMS; ++i) {
-        v[i] = buf[base + ((i + tid) & (PAIR_SCAN_ITEMS - 1))];          // rotated start: no 16-way bank conflict
-        tot += v[i];
-    }
+#pragma unroll 8
+    for (int j = 0; j < PAIR_SCAN_ITEMS; ++j) tot += buf[pair_pad(base + j)];
     int incl = tot;
 #pragma unroll
     for (int off = 1; off < 64; off <<= 1) {
@@ -445,25 +443,19 @@ __global__ __launch_bounds__(PAIR_SCAN_THREADS) void csr_pair_scan_kernel(CsrPai
     }
     if (lane == 63) wave_tot[wave] = incl;
     __syncthreads();
-    int wave_off = 0;
-    for (int w = 0; w < wave; ++w) wave_off += wave_tot[w];
-    const int start = wave_off + incl - tot;
-    // v[] holds the items in rotated order: item j = (i + tid) & 15 sits in v[i]; walk the items in order
-    int run = start;
-#pragma unroll
+    int run = incl - tot;
+    for (int w = 0; w < wave; ++w) run += wave_tot[w];
+#pragma unroll 8
     for (int j = 0; j < PAIR_SCAN_ITEMS; ++j) {
-        const int i = (j - tid) & (PAIR_SCAN_ITEMS - 1);
-        int val = 0;
-#pragma unroll
-        for (int q = 0; q < PAIR_SCAN_ITEMS; ++q) val = (q == i) ? v[q] : val;       // register select, no dynamic indexing
-        buf[base + j] = run;
-        run += val;
+        const int v = buf[pair_pad(base + j)];
+        buf[pair_pad(base + j)] = run;
+        run += v;
     }
     __syncthreads();
-#pragma unroll
+#pragma unroll 8
     for (int i = 0; i < PAIR_SCAN_ITEMS; ++i) {
         const int e = i * PAIR_SCAN_THREADS + tid;
-        if (e < n) sd.rowptr[e] = buf[e];
+        if (e < n) sd.rowptr[e] = buf[pair_pad(e)];
     }
 }
 

@@ -144,7 +144,7 @@ class EdgeStructure:
         for codes in self._codes_src.values():
             self._pack_codes(*self._codes_src_args, codes, by_source=True)
 
-    PAIR_MAX_ROWS = 16383
+    PAIR_MAX_ROWS = 32767
 
     def _build_pair(self, reuse: bool = False, codes_for=None) -> None:
         """Both views side by side (phc_csr_build_pair: 5 launches instead of 22); ``codes_for = (bond_idx, vocab_c, F)``:

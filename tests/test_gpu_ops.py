@@ -927,14 +927,24 @@ def test_remove_isolated_nodes_matches_the_reference_transform(seed, iso):
     assert k == int(keep.sum()) and x3.shape[0] == N and torch.equal(x3[:k], x2) and torch.equal(ei3, ei2)
 
 
-@pytest.mark.parametrize("kind", ["molecules", "hub", "ragged"])
+@pytest.mark.parametrize("kind", ["molecules", "molecules_1024", "rows_32767", "hub", "ragged"])
 def test_csr_pair_build_equals_two_single_builds(kind):
-    """phc_csr_build_pair (both sorted views in five launches) == two phc_csr_build calls, bit for bit."""
+    """phc_csr_build_pair (both sorted views in four launches on a resident workspace) == two phc_csr_build calls, bit for bit;
+    rebuilt in place twice (the workspace must come back clean); up to 32 767 rows per side (the 1024-graph batches of the
+    256-wide configurations: 23-27 k nodes)."""
     from phc_gnn_amd import synth
     from phc_gnn_amd.graph import EdgeStructure
     if kind == "molecules":
         b = synth.molecule_batch(64, seed=9, isolated_frac=0.05)
         ei, n = b.edge_index, b.num_nodes
+    elif kind == "molecules_1024":
+        b = synth.molecule_batch(1024, seed=10, dataset="zinc")
+        ei, n = b.edge_index, b.num_nodes
+        assert 16384 < n <= 32767
+    elif kind == "rows_32767":
+        n = 32767
+        ei = synth.random_edges(n, 90_000, seed=12)
+        ei[1, :200] = n - 1                                  # the last row is a small hub, row 0 may be empty
     elif kind == "hub":
         n = 300
         rng = np.random.default_rng(3)
@@ -949,6 +959,13 @@ def test_csr_pair_build_equals_two_single_builds(kind):
         csr_b, csc_b = b2.csr, b2.csc
     for x, y in zip(csr_a + csc_a, csr_b + csc_b):
         assert torch.equal(x, y)
+    assert a._pair_ws is not None
+    for _ in range(2):                                       # in-place rebuilds on the same (resident) workspace
+        for v in csr_a + csc_a:
+            v.fill_(-7)
+        a.rebuild()
+        for x, y in zip(a.csr + a.csc, csr_b + csc_b):
+            assert torch.equal(x, y)
 
 
 def test_phm_linear_backward_large_n_uses_the_wide_tile(ops):
