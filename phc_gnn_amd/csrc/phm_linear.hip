@@ -1176,6 +1176,10 @@ static GemmHsArgs hs_args(const float *x, const float *Mk4, const float *b, cons
 }
 
 constexpr int GEMM_STREAM_MAX_K = 256;
+// plain and statistics launches on a PREBUILT operand also take deeper contractions (the 768-wide head of the molpcba
+// configuration, run_script_pcba_phm4.sh: --d_units 768,256): the [K x 32] panel of a 32-column workgroup still fits the LDS
+// (768 x 33 floats = 99 KB + 4 x 8.5 KB staging).  Operand transforms and backward sums keep the 256 limit (one column per thread).
+constexpr int GEMM_PREBUILT_MAX_K = 768;
 // rows at which the 128-column / 8-wave streaming configuration takes over from the 64-column / 4-wave one
 constexpr int64_t GEMM_BIG_M = 64 * 1024;
 // K > 128 (hidden 256): rows from which the 64-column / 8-wave configuration (one panel per CU shared by 8 wavefronts, x
@@ -1659,11 +1663,15 @@ int phc_gemm_prebuilt(const float *x, const float *M, const float *Mk4, const fl
         launch_hs<0>(hs_args(x, Mk4, b, residual, y, N, Nout), K, XfAcc{}, hs);
         return check_launch("phc_gemm_prebuilt(hs)");
     }
-    PHC_REQUIRE(K <= GEMM_STREAM_MAX_K && K % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+    PHC_REQUIRE(K <= GEMM_PREBUILT_MAX_K && K % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
                     (reinterpret_cast<uintptr_t>(M) & 15) == 0,
-                PHC_ERR_UNSUPPORTED, "phc_gemm_prebuilt: needs K <= 256, K %% 4 == 0 and 16-byte aligned x, M (K=%d)", K);
+                PHC_ERR_UNSUPPORTED, "phc_gemm_prebuilt: needs K <= 768, K %% 4 == 0 and 16-byte aligned x, M (K=%d)", K);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(is_dx ? K_PHM_GEMM_DX : K_PHM_GEMM_FWD, s);
+    if (K > GEMM_STREAM_MAX_K) {                             // deep contraction: 32-column panels, one workgroup per CU
+        launch_stream_cfg<0, -1, 32, 4>(x, nullptr, M, b, residual, y, N, K, Nout, 1, K, Nout, 1, s);
+        return check_launch("phc_gemm_prebuilt(deep)");
+    }
     // Few rows (molecule batches: about one 32-row slab per wavefront): 32-column panels give twice the wavefronts,
     // each half as long — measured 0.8 us per launch faster than 64-column panels at N = 13.8k; above that the extra
     // re-reads of x cost more than the occupancy gains.  PHC_GEMM_PRE_BN=64 forces the wider panel.
@@ -1690,9 +1698,9 @@ int phc_gemm_prebuilt_stats(const float *x, const float *M, const float *Mk4, co
     PHC_REQUIRE(x && M && y && stats_partial && (acc || num_partials), PHC_ERR_INVALID_ARG, "phc_gemm_prebuilt_stats: null pointer");
     PHC_REQUIRE(!acc || (reinterpret_cast<uintptr_t>(stats_partial) & 7) == 0, PHC_ERR_INVALID_ARG,
                 "phc_gemm_prebuilt_stats: the accumulator must be 8-byte aligned");
-    PHC_REQUIRE(K <= GEMM_STREAM_MAX_K && K % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
+    PHC_REQUIRE(K <= GEMM_PREBUILT_MAX_K && K % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
                     (reinterpret_cast<uintptr_t>(M) & 15) == 0,
-                PHC_ERR_UNSUPPORTED, "phc_gemm_prebuilt_stats: needs K <= 256, K %% 4 == 0 and 16-byte aligned x, M (K=%d)", K);
+                PHC_ERR_UNSUPPORTED, "phc_gemm_prebuilt_stats: needs K <= 768, K %% 4 == 0 and 16-byte aligned x, M (K=%d)", K);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(K_PHM_GEMM_FWD, s);
     if (acc && hs_shape_ok(x, Mk4, N, K, Nout) && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(b)) & 15) == 0) {
@@ -1703,7 +1711,10 @@ int phc_gemm_prebuilt_stats(const float *x, const float *M, const float *Mk4, co
         return check_launch("phc_gemm_prebuilt_stats(hs)");
     }
     static const int small_bn = getenv("PHC_GEMM_PRE_BN") ? atoi(getenv("PHC_GEMM_PRE_BN")) : 32;
-    if (N >= gemm_wide_k_m() && Nout > 64 && K > 128)
+    if (K > GEMM_STREAM_MAX_K)                               // deep contraction: 32-column panels, one workgroup per CU
+        launch_stream_cfg<0, -1, 32, 4, 1>(x, nullptr, M, b, nullptr, y, N, K, Nout, 1, K, Nout, 1, s, n_valid_dev, stats_partial,
+                                           stats_counts, num_partials, nullptr, 0, nullptr, nullptr, 0, acc);
+    else if (N >= gemm_wide_k_m() && Nout > 64 && K > 128)
         launch_stream_cfg<0, -1, 64, 8, 1>(x, nullptr, M, b, nullptr, y, N, K, Nout, 1, K, Nout, 1, s, n_valid_dev, stats_partial,
                                            stats_counts, num_partials, nullptr, 0, nullptr, nullptr, 0, acc);
     else if (N >= GEMM_BIG_M && Nout > 64)

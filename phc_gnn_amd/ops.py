@@ -402,11 +402,11 @@ def phm_pairs(model) -> list:
 
 def dense_weights(model) -> list:
     """``nn.Linear`` weights [out, in] that the engine's dense map (``dense_linear``) can serve from a prebuilt
-    operand: in, out multiples of 4 and <= 256 (the hypercomplex -> real heads of the read-out)."""
+    operand: in, out multiples of 4 and <= 768 (the hypercomplex -> real heads of the read-out; molpcba: 512 -> 128)."""
     out = []
     for m in model.modules():
         if isinstance(m, torch.nn.Linear) and m.in_features % 4 == 0 and m.out_features % 4 == 0 \
-                and m.in_features <= 256 and m.out_features <= 256:
+                and m.in_features <= PREBUILT_MAX_WIDTH and m.out_features <= PREBUILT_MAX_WIDTH:
             out.append(m.weight)
     return out
 
@@ -417,6 +417,12 @@ def _one(dev) -> torch.Tensor:
         one = torch.ones(1, 1, 1, dtype=torch.float32, device=dev)
         _ONES[dev] = one
     return one
+
+
+# widest layer side whose operand matrices are prebuilt (phc_gemm_prebuilt[_stats] take K <= 768: the 768-wide head of the
+# molpcba configuration); the fused variants (operand transform, backward sums, the H-stationary kernel) stop at 256
+PREBUILT_MAX_WIDTH = 768
+FUSED_MAX_WIDTH = 256
 
 
 @contextlib.contextmanager
@@ -436,7 +442,7 @@ def prebuilt_H(pairs, dense=()):
     for A, W in pairs:
         n, kin, kout = W.shape
         if A.is_cuda and W.is_cuda and A.dtype == W.dtype == torch.float32 and A.is_contiguous() and W.is_contiguous() \
-                and (n * kout) <= 256 and (n * kin) <= 256 and (n * kin) % 4 == 0 and (n * kout) % 4 == 0:
+                and (n * kout) <= PREBUILT_MAX_WIDTH and (n * kin) <= PREBUILT_MAX_WIDTH and (n * kin) % 4 == 0 and (n * kout) % 4 == 0:
             by_dev.setdefault(W.device, []).append((A, W))
     try:
         for dev, prs in by_dev.items():
@@ -463,7 +469,9 @@ def prebuilt_H(pairs, dense=()):
                     n, kin, kout = W.shape
                     sz = (n * kin) * (n * kout)
                     H, HT = flat[off:off + sz].view(n * kin, n * kout), flat[off + sz:off + 2 * sz].view(n * kout, n * kin)
-                    Hk4, HTk4 = flat[off + 2 * sz:off + 3 * sz], flat[off + 3 * sz:off + 4 * sz]
+                    Hk4 = HTk4 = None
+                    if max(n * kin, n * kout) <= FUSED_MAX_WIDTH:      # the k4 forms feed the H-stationary kernel only
+                        Hk4, HTk4 = flat[off + 2 * sz:off + 3 * sz], flat[off + 3 * sz:off + 4 * sz]
                     off += 4 * sz
                     arr[i] = L.HJob(L.ptr(A), L.ptr(W), L.ptr(H), L.ptr(HT), n, kin, kout, 0, L.ptr(Hk4), L.ptr(HTk4))
                     _PREBUILT.table[(A.data_ptr(), W.data_ptr())] = (H, HT, A._version, W._version, Hk4, HTk4)
@@ -2113,7 +2121,8 @@ def bn_act_linear(x: torch.Tensor, weights, biases, running_mean, running_var, n
             or not x.is_contiguous() or pre.partial.shape[1] != 2 * x.shape[1] or not _PREBUILT.table or x.data_ptr() % 16:
         return None
     ent = _prebuilt_for(phm_rule, W)
-    if ent is None or W.shape[0] * W.shape[1] != x.shape[1] or (bias is not None and not bias.is_contiguous()):
+    if ent is None or W.shape[0] * W.shape[1] != x.shape[1] or (bias is not None and not bias.is_contiguous()) \
+            or max(x.shape[1], W.shape[0] * W.shape[2]) > FUSED_MAX_WIDTH:      # (the operand transform handles one column per thread)
         return None
     n_comp = len(running_mean) if running_mean else len(weights)
     affine = (list(weights) + list(biases)) if weights else []
