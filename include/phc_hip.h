@@ -332,6 +332,12 @@ int phc_aggregate_enc_bwd(const float *dout, const float *x, const int64_t *bond
                           const int32_t *rowptr_t, const int32_t *col_t, const int32_t *perm_t, int64_t n_src, int64_t n_dst,
                           int F, int n, int k, int act, int add_self, float *dx, float *dtables_flat, void *ws,
                           size_t ws_bytes, void *stream);
+/* dx of the sum aggregation for an IDENTITY message function, one source row per lane group (molecule batches; any size works, the
+ * walk is latency-bound): dx[s] = sum over the out-edges of s of dout[dst] (+ dout[s] with add_self, s < n_dst) (+ residual[s]).
+ * `residual` (may be NULL): another gradient of the same rows — the additive skip connection's share of d x (models.py:208-215) —
+ * added on the way out instead of by a separate element-wise launch.  h % 4 == 0, 16-byte aligned rows. */
+int phc_aggregate_dx_rows(const float *dout, const int32_t *rowptr_t, const int32_t *col_t, int64_t n_src, int64_t n_dst, int h,
+                          int add_self, const float *residual, float *dx, void *stream);
 
 /* ------------------------------------------------------------------------- *
  * Batch normalisation of component-major activations, fused with the

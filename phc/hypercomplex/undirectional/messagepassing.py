@@ -50,13 +50,14 @@ class _SumConvBase(nn.Module):
         return _engine.aggregate_sum(x, edge_index, edge_attr, self.msg_encoder_str, add_self, num_dst)
 
     def propagate_encoded(self, edge_index: Adj, x: torch.Tensor, edge_idx: torch.Tensor, encoder, size: Size = None,
-                          add_self: bool = False) -> torch.Tensor:
+                          add_self: bool = False, dx_handoff=None) -> torch.Tensor:
         """Same as ``propagate`` with edge_attr = encoder(edge_idx), evaluated inside the
-        aggregation kernel from LDS-staged embedding tables (no [E, h] tensor)."""
+        aggregation kernel from LDS-staged embedding tables (no [E, h] tensor).  ``dx_handoff`` (engine: DxHandoff): another
+        consumer of ``x`` may park its gradient there; this op's backward then adds it inside its own dx kernel."""
         tables = encoder.engine_tables
         num_dst = size[1] if size is not None and size[1] is not None else None
         return _engine.aggregate_sum_encoded(x, edge_index, edge_idx, _engine.tableset_for(encoder, tables), tables,
-                                             self.msg_encoder_str, add_self, num_dst)
+                                             self.msg_encoder_str, add_self, num_dst, dx_handoff=dx_handoff)
 
     def message(self, x_j: torch.Tensor, edge_attr: torch.Tensor) -> torch.Tensor:
         """Per-edge message (API parity; the engine fuses this into the aggregation)."""
@@ -187,7 +188,8 @@ class _SoftmaxMixin:
         out = _engine.aggregate_softmax(x, edge_index, edge_attr, self.beta, self.msg_encoder_str, num_dst, add_self=fused_self)
         return out + x if (add_self and not fused_self) else out
 
-    def propagate_encoded(self, edge_index, x, edge_idx, encoder, size=None, add_self=False):
+    def propagate_encoded(self, edge_index, x, edge_idx, encoder, size=None, add_self=False, dx_handoff=None):
+        # (dx_handoff is never accepted here: the softmax backward has no residual input, so nobody parks a gradient in it)
         """Softmax aggregation with edge_attr = encoder(edge_idx): the kernels add the F table rows of every edge
         themselves (packed codes, tables from L2), so no [E, h] embedding is built in the forward pass."""
         tables = encoder.engine_tables

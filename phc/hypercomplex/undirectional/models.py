@@ -148,11 +148,15 @@ class PHMSkipConnectAdd(nn.Module):
                 hasattr(tr, "propagate_encoded") and hasattr(getattr(tr, "transform", None), "linear2"):
             # PHMGINEConv + model norm, training mode: aggregation, then the MLP and the norm as ONE autograd node whose
             # backward folds both batch-norm backwards into the dx GEMMs (engine: mlp_norm_fused); None = not applicable
+            # the conv's input is also the layer's skip tensor (sc_type "last"): the skip's share of dx is handed to the
+            # aggregation's backward, which adds it inside its dx kernel — x then has ONE gradient and autograd launches no add
+            handoff = _engine.DxHandoff() if (x[0] is x[1] and edge_encoder is not None and x[0].requires_grad) else None
             if edge_encoder is not None:
-                agg = tr.propagate_encoded(edge_index, x[0], edge_attr, edge_encoder, size, add_self=tr.add_self_loops)
+                agg = tr.propagate_encoded(edge_index, x[0], edge_attr, edge_encoder, size, add_self=tr.add_self_loops,
+                                           dx_handoff=handoff)
             else:
                 agg = tr.propagate(edge_index, x=x[0], edge_attr=edge_attr, size=size, add_self=tr.add_self_loops)
-            fused = _engine.mlp_norm_fused(agg, x[1], n_valid, tr.transform, norm, self.activation_str)
+            fused = _engine.mlp_norm_fused(agg, x[1], n_valid, tr.transform, norm, self.activation_str, skip_handoff=handoff)
             if fused is not None:
                 return fused
             h = tr.transform(agg, n_valid=n_valid)
@@ -187,16 +191,12 @@ class PHMSkipConnectAdd(nn.Module):
         L_ = len(self.mp_layers)
         # the encoded atoms feed the first conv and (sc_type "first") every layer's skip: one fan-out node, so that
         # their gradients are summed in one pass
-        uses = _engine.fanout(atom, 1 + (L_ if self.sc_type == "first" else 1)) if atom.is_cuda else None
+        # ("last": the conv input IS the skip tensor — one tensor object, see compute_hidden_layer_embedding's hand-off)
+        uses = _engine.fanout(atom, 1 + L_) if (atom.is_cuda and self.sc_type == "first") else None
         h = uses[0] if uses is not None else atom
         for i in range(L_):
             if uses is not None:
-                if self.sc_type == "first":
-                    skip = uses[1 + i]
-                elif i == 0:
-                    skip = uses[1]
-                else:
-                    h, skip = _engine.fanout(h, 2)         # conv input and its own skip ("last")
+                skip = uses[1 + i]
             else:
                 skip = atom if (i == 0 or self.sc_type == "first") else h
             enc = self.bondencoders[i]

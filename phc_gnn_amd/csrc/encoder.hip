@@ -330,7 +330,7 @@ __global__ __launch_bounds__(ENC_THREADS) void aggregate_encp_direct_fwd_kernel(
 template <int LPR>
 __global__ __launch_bounds__(ENC_THREADS) void aggregate_dx_rows_kernel(
     const float *__restrict__ dout, const int *__restrict__ rowptr_t, const int *__restrict__ col_t, long long n_src,
-    long long n_dst, int h, int add_self, float *__restrict__ dx) {
+    long long n_dst, int h, int add_self, float *__restrict__ dx, const float *__restrict__ residual = nullptr) {
     const int h4 = h >> 2;
     constexpr int G = WAVE / LPR;
     const int lane = threadIdx.x & 63;
@@ -341,6 +341,8 @@ __global__ __launch_bounds__(ENC_THREADS) void aggregate_dx_rows_kernel(
         for (int c4 = li; c4 < h4; c4 += LPR) {
             const bool self_on = add_self && s < n_dst;      // the self row goes in flight first (pointer select, no branch)
             const float4 selfv = reinterpret_cast<const float4 *>(dout + (self_on ? (size_t)s * h : 0))[c4];
+            // residual: another gradient of the same rows (the skip connection's share of dx) added on the way out
+            const float4 resv = reinterpret_cast<const float4 *>(residual ? residual + (size_t)s * h : dout)[c4];
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
             int e = e0 + first;
             if (e0 < e1) {                                   // both column indices in one round trip, both rows in the next
@@ -363,6 +365,7 @@ __global__ __launch_bounds__(ENC_THREADS) void aggregate_dx_rows_kernel(
             }
             if (!coop || grp == 0) {
                 if (self_on) acc4(acc, selfv);
+                if (residual) acc4(acc, resv);
                 reinterpret_cast<float4 *>(dx + (size_t)s * h)[c4] = acc;
             }
         }
@@ -1623,6 +1626,26 @@ int phc_aggregate_encp_fwd(const float *x, const uint32_t *codes, const float *c
     return check_launch("aggregate_encp_fwd");
 }
 
+int phc_aggregate_dx_rows(const float *dout, const int32_t *rowptr_t, const int32_t *col_t, int64_t n_src, int64_t n_dst, int h,
+                          int add_self, const float *residual, float *dx, void *stream) {
+    PHC_REQUIRE(n_src >= 0 && n_dst >= 0 && h >= 4 && h % 4 == 0, PHC_ERR_INVALID_ARG, "phc_aggregate_dx_rows: bad sizes (h %% 4 == 0)");
+    if (n_src == 0) return PHC_OK;
+    PHC_REQUIRE(dout && rowptr_t && col_t && dx, PHC_ERR_INVALID_ARG, "phc_aggregate_dx_rows: null pointer");
+    PHC_REQUIRE(al16(dout) && al16(dx) && (!residual || al16(residual)), PHC_ERR_UNSUPPORTED, "phc_aggregate_dx_rows: 16-byte aligned rows");
+    hipStream_t s = (hipStream_t)stream;
+    const int lpr = lpr_for(h >> 2);
+    const int rows_per_wg = 4 * (WAVE / lpr);
+    const unsigned rb = (unsigned)xcd_grid((n_src + rows_per_wg - 1) / rows_per_wg);
+    ProfScope prof(K_AGG_ENC_DX, s);
+    switch (lpr) {
+        case 8: PHC_LAUNCH((aggregate_dx_rows_kernel<8>), dim3(rb), dim3(ENC_THREADS), 0, s, dout, rowptr_t, col_t, (long long)n_src, (long long)n_dst, h, add_self, dx, residual); break;
+        case 16: PHC_LAUNCH((aggregate_dx_rows_kernel<16>), dim3(rb), dim3(ENC_THREADS), 0, s, dout, rowptr_t, col_t, (long long)n_src, (long long)n_dst, h, add_self, dx, residual); break;
+        case 32: PHC_LAUNCH((aggregate_dx_rows_kernel<32>), dim3(rb), dim3(ENC_THREADS), 0, s, dout, rowptr_t, col_t, (long long)n_src, (long long)n_dst, h, add_self, dx, residual); break;
+        default: PHC_LAUNCH((aggregate_dx_rows_kernel<64>), dim3(rb), dim3(ENC_THREADS), 0, s, dout, rowptr_t, col_t, (long long)n_src, (long long)n_dst, h, add_self, dx, residual); break;
+    }
+    return check_launch("aggregate_dx_rows");
+}
+
 size_t phc_aggregate_enc_bwd_ws_bytes(int64_t E, int F, const int32_t *vocab, int n, int k) {
     EncMeta m;
     if (E < 0 || n < 1 || k < 1 || make_meta("phc_aggregate_enc_bwd_ws_bytes", F, vocab, &m)) return 0;
@@ -1661,10 +1684,10 @@ int phc_aggregate_enc_bwd(const float *dout, const float *x, const int64_t *bond
             const int rows_per_wg = 4 * (WAVE / lpr);
             const unsigned rb = (unsigned)xcd_grid((n_src + rows_per_wg - 1) / rows_per_wg);
             switch (lpr) {
-                case 8: PHC_LAUNCH((aggregate_dx_rows_kernel<8>), dim3(rb), dim3(ENC_THREADS), 0, s, dout, rowptr_t, col_t, (long long)n_src, (long long)n_dst, h, add_self, dx); break;
-                case 16: PHC_LAUNCH((aggregate_dx_rows_kernel<16>), dim3(rb), dim3(ENC_THREADS), 0, s, dout, rowptr_t, col_t, (long long)n_src, (long long)n_dst, h, add_self, dx); break;
-                case 32: PHC_LAUNCH((aggregate_dx_rows_kernel<32>), dim3(rb), dim3(ENC_THREADS), 0, s, dout, rowptr_t, col_t, (long long)n_src, (long long)n_dst, h, add_self, dx); break;
-                default: PHC_LAUNCH((aggregate_dx_rows_kernel<64>), dim3(rb), dim3(ENC_THREADS), 0, s, dout, rowptr_t, col_t, (long long)n_src, (long long)n_dst, h, add_self, dx); break;
+                case 8: PHC_LAUNCH((aggregate_dx_rows_kernel<8>), dim3(rb), dim3(ENC_THREADS), 0, s, dout, rowptr_t, col_t, (long long)n_src, (long long)n_dst, h, add_self, dx, (const float *)nullptr); break;
+                case 16: PHC_LAUNCH((aggregate_dx_rows_kernel<16>), dim3(rb), dim3(ENC_THREADS), 0, s, dout, rowptr_t, col_t, (long long)n_src, (long long)n_dst, h, add_self, dx, (const float *)nullptr); break;
+                case 32: PHC_LAUNCH((aggregate_dx_rows_kernel<32>), dim3(rb), dim3(ENC_THREADS), 0, s, dout, rowptr_t, col_t, (long long)n_src, (long long)n_dst, h, add_self, dx, (const float *)nullptr); break;
+                default: PHC_LAUNCH((aggregate_dx_rows_kernel<64>), dim3(rb), dim3(ENC_THREADS), 0, s, dout, rowptr_t, col_t, (long long)n_src, (long long)n_dst, h, add_self, dx, (const float *)nullptr); break;
             }
         } else {
 #define PHC_AD_LAUNCH(LPRC, ACTC)                                                                                         \

@@ -498,6 +498,8 @@ class _PHMLinearFn(torch.autograd.Function):
     def forward(ctx, x, A, W, b, residual, bn_stats=None, dx_handoff=None):
         lib = L.load()
         ctx.dx_handoff = dx_handoff
+        if dx_handoff is not None:
+            dx_handoff.accepted = True
         dev = L.require_device(x, A, W, b, residual)
         n, kin, kout = W.shape
         if tuple(A.shape) != (n, n, n):
@@ -747,6 +749,7 @@ class DxHandoff:
 
     def __init__(self):
         self.tensor = None
+        self.accepted = False      # set by the consumer that will add the parked gradient (its forward ran): nobody parks before
 
     def take(self):
         t, self.tensor = self.tensor, None
@@ -1406,7 +1409,7 @@ class _GatedSegmentSumFn(torch.autograd.Function):
                                        L.stream_ptr(dev)), "phc_gated_pool_bwd")
         if L.PROF_ON:
             L.account("gated_pool_bwd", 4.0 * N * h, 4.0 * (N * (2 * h + 2 * h // n_comp) + G * h))
-        if ctx.dx_handoff is not None and dx is not None:
+        if ctx.dx_handoff is not None and ctx.dx_handoff.accepted and dx is not None:
             ctx.dx_handoff.tensor = dx                      # added inside the gate layer's dx GEMM (DxHandoff)
             dx = None
         return dx, dg, None, None, None
@@ -1758,8 +1761,11 @@ def encode(idx: torch.Tensor, ts: TableSet, tables) -> torch.Tensor:
 
 class _AggregateEncFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, bond_idx, st: EdgeStructure, act: int, add_self: bool, ts: TableSet, *tables):
+    def forward(ctx, x, bond_idx, st: EdgeStructure, act: int, add_self: bool, ts: TableSet, dx_handoff, *tables):
         lib = L.load()
+        ctx.dx_handoff = dx_handoff
+        if dx_handoff is not None:
+            dx_handoff.accepted = True
         dev = L.require_device(x, bond_idx)
         x_ = L.f32c(x)
         bond_ = _idx64(bond_idx)
@@ -1805,7 +1811,11 @@ class _AggregateEncFn(torch.autograd.Function):
         dev = dout_.device
         h = dout_.shape[1]
         need_x = ctx.needs_input_grad[0]
-        need_t = any(ctx.needs_input_grad[6:])
+        need_t = any(ctx.needs_input_grad[7:])
+        # the skip connection's share of dx (DxHandoff, parked by the layer's fused MLP + norm node)
+        extra = ctx.dx_handoff.take() if ctx.dx_handoff is not None else None
+        if extra is not None and (not need_x or tuple(extra.shape) != (ctx.x_rows, h)):
+            raise L.PhcError("DxHandoff: a parked gradient needs a consumer that computes dx of the same shape")
         rowptr_t = col_t = perm_t = None
         dx = None
         if need_x:
@@ -1813,11 +1823,19 @@ class _AggregateEncFn(torch.autograd.Function):
             dx = torch.empty((ctx.x_rows, h), dtype=torch.float32, device=dev)
             if ctx.x_rows > st.num_src:
                 dx[st.num_src:].zero_()
+        dx_done = False
+        if need_x and extra is not None and ctx.act == 0 and ctx.x_rows == st.num_src and h % 4 == 0 and extra.data_ptr() % 16 == 0 \
+                and dout_.data_ptr() % 16 == 0:
+            # identity message function: dx by the row walker, the parked gradient added on the way out (no add launch)
+            L.check(lib.phc_aggregate_dx_rows(L.ptr(dout_), L.ptr(rowptr_t), L.ptr(col_t), st.num_src, st.num_dst, h,
+                                              1 if ctx.add_self else 0, L.ptr(extra), L.ptr(dx), L.stream_ptr(dev)),
+                    "phc_aggregate_dx_rows")
+            dx_done, extra = True, None
         flat = ws = None
         ws_bytes = 0
         deferred = need_t and ctx.defer_tables is not None and _DEFER.active and not torch.is_grad_enabled()
         if deferred:
-            params = [t if ng else None for t, ng in zip(ctx.defer_tables, ctx.needs_input_grad[6:])]
+            params = [t if ng else None for t, ng in zip(ctx.defer_tables, ctx.needs_input_grad[7:])]
             with _DEFER.lock:
                 _DEFER.table_jobs.append(dict(
                     key=(bond_.data_ptr(), st._src.data_ptr(), st._dst.data_ptr(), st.num_edges, ts.F, ts.n, ts.k, tuple(ts.vocab),
@@ -1828,10 +1846,14 @@ class _AggregateEncFn(torch.autograd.Function):
             flat = torch.empty(ts.n * ts.R * ts.k, dtype=torch.float32, device=dev)
             ws_bytes = lib.phc_aggregate_enc_bwd_ws_bytes(st.num_edges, ts.F, ts.vocab_c, ts.n, ts.k)
             ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        L.check(lib.phc_aggregate_enc_bwd(L.ptr(dout_), L.ptr(x_), L.ptr(bond_), L.ptr(ts.ptrs), ts.vocab_c, L.ptr(st._src),
-                                          L.ptr(st._dst), st.num_edges, L.ptr(rowptr_t), L.ptr(col_t), L.ptr(perm_t), st.num_src,
-                                          st.num_dst, ts.F, ts.n, ts.k, ctx.act, 1 if ctx.add_self else 0, L.ptr(dx),
-                                          L.ptr(flat), L.ptr(ws), ws_bytes, L.stream_ptr(dev)), "phc_aggregate_enc_bwd")
+        if not dx_done or flat is not None:
+            L.check(lib.phc_aggregate_enc_bwd(L.ptr(dout_), L.ptr(x_), L.ptr(bond_), L.ptr(ts.ptrs), ts.vocab_c, L.ptr(st._src),
+                                              L.ptr(st._dst), st.num_edges, L.ptr(rowptr_t), L.ptr(col_t), L.ptr(perm_t), st.num_src,
+                                              st.num_dst, ts.F, ts.n, ts.k, ctx.act, 1 if ctx.add_self else 0,
+                                              None if dx_done else L.ptr(dx), L.ptr(flat), L.ptr(ws), ws_bytes, L.stream_ptr(dev)),
+                    "phc_aggregate_enc_bwd")
+        if extra is not None:
+            dx += extra
         if L.PROF_ON:
             E, Ns, Nd = st.num_edges, st.num_src, st.num_dst
             if need_x:
@@ -1840,12 +1862,12 @@ class _AggregateEncFn(torch.autograd.Function):
             if need_t and not deferred:
                 L.account("table_grad", 1.0 * E * ts.F * h, Nd * 4.0 * h + E * (4.0 + 8.0 * ts.F) + 4.0 * (Nd + 1))
         grads = ts.grad_views(flat) if (need_t and not deferred) else [None] * ts.num_tables
-        return (dx, None, None, None, None, None, *grads)
+        return (dx, None, None, None, None, None, None, *grads)
 
 
 def aggregate_sum_encoded(x: torch.Tensor, edge_index, bond_idx: torch.Tensor, ts: TableSet, tables,
                           msg_encoder: str = "identity", add_self_loops: bool = False,
-                          num_dst: Optional[int] = None) -> torch.Tensor:
+                          num_dst: Optional[int] = None, dx_handoff=None) -> torch.Tensor:
     """aggregate_sum with edge_attr[e] = Σ_f tables[c][f][bond_idx[e, f]] looked up inside the
     kernel (the [E, h] bond embedding is never written)."""
     st = edge_index if isinstance(edge_index, EdgeStructure) else edge_structure(edge_index, x.shape[0], num_dst)
@@ -1860,7 +1882,7 @@ def aggregate_sum_encoded(x: torch.Tensor, edge_index, bond_idx: torch.Tensor, t
     if not ts.fusable_into_aggregate:
         ea = _EncodeFn.apply(bond_idx, ts, *flat_tables)
         return _AggregateFn.apply(x, ea, st, _act_id(msg_encoder), bool(add_self_loops))
-    return _AggregateEncFn.apply(x, bond_idx, st, _act_id(msg_encoder), bool(add_self_loops), ts, *flat_tables)
+    return _AggregateEncFn.apply(x, bond_idx, st, _act_id(msg_encoder), bool(add_self_loops), ts, dx_handoff, *flat_tables)
 
 
 # ---------------------------------------------------------------------------
@@ -2288,7 +2310,12 @@ class _MLPNormFn(torch.autograd.Function):
                 n, k = nm["n_comp"], h // nm["n_comp"]
                 aff.extend([dwb[c * k:(c + 1) * k] for c in range(n)])
                 aff.extend([dwb[h + c * k:h + (c + 1) * k] for c in range(n)])
-        return (ds if needs[0] else None, dout if (ctx.has_skip and needs[1]) else None, None, None, *grads, *aff)
+        dskip = dout if (ctx.has_skip and needs[1]) else None
+        hd = meta.get("skip_handoff")
+        if hd is not None and hd.accepted and dskip is not None:
+            hd.tensor = dout_                                 # the skip's share of dx: added inside the aggregation's dx kernel
+            dskip = None
+        return (ds if needs[0] else None, dskip, None, None, *grads, *aff)
 
 
 def _norm_meta(nm):
@@ -2302,7 +2329,7 @@ def _norm_meta(nm):
                 weights=[m.weight for m in mods] if nm.affine else [], biases=[m.bias for m in mods] if nm.affine else [])
 
 
-def mlp_norm_fused(s, skip, n_valid, mlp, outer_norm, activation: str):
+def mlp_norm_fused(s, skip, n_valid, mlp, outer_norm, activation: str, skip_handoff=None):
     """``act(outer_norm(mlp(s))) + skip`` for a PHMMLP with an inner naive batch-norm, as one autograd node (training mode),
     or ``None`` when the preconditions do not hold: both linears square of width 128 or 256 with prebuilt k4 operands (inside
     ``prebuilt_H``), both norms naive batch-norms with running statistics, fusable activations, 16-byte aligned dense rows."""
@@ -2328,7 +2355,7 @@ def mlp_norm_fused(s, skip, n_valid, mlp, outer_norm, activation: str):
         return None
     if any(b is not None and not b.is_contiguous() for b in (l1.b, l2.b)):
         return None
-    meta = dict(pre1=pre1, pre2=pre2, inner=inner, outer=outer, act_inner=act_i, act_outer=act_o)
+    meta = dict(pre1=pre1, pre2=pre2, inner=inner, outer=outer, act_inner=act_i, act_outer=act_o, skip_handoff=skip_handoff)
     affine = inner["weights"] + inner["biases"] + outer["weights"] + outer["biases"]
     return _MLPNormFn.apply(s, skip, n_valid, meta, l1.phm_rule, l1.W, l1.b, l2.phm_rule, l2.W, l2.b, *affine)
 
