@@ -158,10 +158,21 @@ class EdgeStructure:
                     torch.empty(E, dtype=torch.int32, device=dev))
         csr, csc = (self._csr, self._csc) if reuse else (alloc(self.num_dst), alloc(self.num_src))
         ws_bytes = lib.phc_csr_pair_ws_bytes(E, self.num_src, self.num_dst)
-        # resident workspace: zeroed once; every build leaves its counter arrays zeroed again (one launch less per rebuild)
-        ws = getattr(self, "_pair_ws", None)
-        if ws is None or ws.numel() != ws_bytes:
-            ws = self._pair_ws = torch.zeros(ws_bytes, dtype=torch.uint8, device=dev)
+        # resident workspace: zeroed ONCE per (device, stream, E, rows) and shared by every structure of those sizes — each build leaves
+        # its counter arrays zeroed again, so neither a zero launch nor a fill is part of a (captured) per-batch build
+        # (keyed by the sizes, not the byte count: the zeroed counter arrays sit at size-dependent offsets, the rest is scratch)
+        key = (dev, torch.cuda.current_stream(dev).cuda_stream, int(E), int(self.num_src), int(self.num_dst))
+        ws = _PAIR_WS.get(key)
+        if ws is None:
+            if torch.cuda.is_current_stream_capturing():
+                ws = torch.zeros(ws_bytes, dtype=torch.uint8, device=dev)        # (first seen inside a capture: a captured fill)
+            else:
+                ws = _PAIR_WS[key] = torch.zeros(ws_bytes, dtype=torch.uint8, device=dev)
+                while len(_PAIR_WS) > _PAIR_WS_MAX:           # eager training over many batch shapes: keep the recent ones
+                    _PAIR_WS.pop(next(iter(_PAIR_WS)))
+        else:
+            _PAIR_WS[key] = _PAIR_WS.pop(key)                 # most recently used last
+        self._pair_ws = ws
         codes = bond = vocab_c = counts = None
         F = 0
         if reuse and self._codes and self._codes_args is not None:
@@ -213,6 +224,8 @@ class EdgeStructure:
 
 
 _IOTA: dict = {}
+_PAIR_WS_MAX = 16
+_PAIR_WS: dict = {}          # (device, stream, E, n_src, n_dst) -> zeroed workspace of the pair build (EdgeStructure._build_pair)
 
 
 def _iota(n: int, dev) -> torch.Tensor:

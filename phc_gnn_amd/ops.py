@@ -722,8 +722,8 @@ class BNStatsRequest:
     """Ask a PHM linear layer for the batch-norm statistics of its output (training mode): when the layer runs on a
     prebuilt operand matrix, its GEMM emits per-column (sum, M2) partials from registers and the normalisation that
     follows (``batch_norm_act`` on the very tensor this layer returned) skips its own pass over the data.
-    ``consumer``: "apply" (``batch_norm_act`` or ``bn_act_linear`` follows: the statistics may travel through an accumulator,
-    ``counts`` stays None) or "linear" (partial rows in any case)."""
+    ``consumer``: "apply" / "linear" — which op follows (``batch_norm_act`` or ``bn_act_linear``); inside ``stat_accumulators`` the
+    statistics travel through an accumulator either way (``counts`` stays None), outside as partial rows."""
 
     def __init__(self, n_valid: Optional[torch.Tensor] = None, consumer: str = "linear"):
         self.n_valid = n_valid
@@ -733,7 +733,7 @@ class BNStatsRequest:
 
     def allocate(self, dev, h: int, max_partials: int):
         """Output buffers of the producing launch: (partial, counts, want_num)."""
-        acc = stat_acc_slot(dev, h) if self.consumer == "apply" else None
+        acc = stat_acc_slot(dev, h)        # (either consumer reads accumulator totals: bn_apply_acc / the operand transform's prologue)
         if acc is not None:
             self.partial, self.counts = acc, None
             return acc, None, False

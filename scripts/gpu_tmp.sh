@@ -1,9 +1,9 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-timeout 2700 python -m pytest tests -m gpu -q -x > gpurun_out/r03_gpu_suite6.log 2>&1
-echo "suite rc=$?"; grep -E "passed|failed|^E  " gpurun_out/r03_gpu_suite6.log | tail -5 | cut -c1-250
-for wl in zinc_b1024 zinc_pub_phc5_4x200 zinc_pub_phc4_4x180 molhiv_b512; do
+timeout 2700 python -m pytest tests -m gpu -q -x > gpurun_out/r03_gpu_suite7.log 2>&1
+echo "suite rc=$?"; grep -E "passed|failed|^E  " gpurun_out/r03_gpu_suite7.log | tail -5 | cut -c1-250
+for wl in zinc_b1024 molpcba_b1024 molhiv_b512 molhiv_b512_softmax; do
   timeout 600 python bench.py --workload $wl --cpu-steps 0 --profile-steps 0 2>&1 | grep '^{"metric"' | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read()); print('$wl', d['ms_per_step'])"
