@@ -162,7 +162,11 @@ class EdgeStructure:
         # its counter arrays zeroed again, so neither a zero launch nor a fill is part of a (captured) per-batch build
         # (keyed by the sizes, not the byte count: the zeroed counter arrays sit at size-dependent offsets, the rest is scratch)
         key = (dev, torch.cuda.current_stream(dev).cuda_stream, int(E), int(self.num_src), int(self.num_dst))
-        ws = _PAIR_WS.get(key)
+        ws = _PAIR_WS_PINNED.get(key)
+        if ws is None:
+            ws = _PAIR_WS.get(key)
+            if ws is not None and torch.cuda.is_current_stream_capturing():
+                _PAIR_WS_PINNED[key] = ws                     # a captured step holds this address from now on: never evicted
         if ws is None:
             if torch.cuda.is_current_stream_capturing():
                 ws = torch.zeros(ws_bytes, dtype=torch.uint8, device=dev)        # (first seen inside a capture: a captured fill)
@@ -170,7 +174,7 @@ class EdgeStructure:
                 ws = _PAIR_WS[key] = torch.zeros(ws_bytes, dtype=torch.uint8, device=dev)
                 while len(_PAIR_WS) > _PAIR_WS_MAX:           # eager training over many batch shapes: keep the recent ones
                     _PAIR_WS.pop(next(iter(_PAIR_WS)))
-        else:
+        elif key in _PAIR_WS:
             _PAIR_WS[key] = _PAIR_WS.pop(key)                 # most recently used last
         self._pair_ws = ws
         codes = bond = vocab_c = counts = None
@@ -225,6 +229,7 @@ class EdgeStructure:
 
 _IOTA: dict = {}
 _PAIR_WS_MAX = 16
+_PAIR_WS_PINNED: dict = {}   # entries a captured hipGraph refers to
 _PAIR_WS: dict = {}          # (device, stream, E, n_src, n_dst) -> zeroed workspace of the pair build (EdgeStructure._build_pair)
 
 
