@@ -1,10 +1,8 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT" || exit 1
 export TMPDIR=/tmp
-timeout 2700 python -m pytest tests -m gpu -q -x > gpurun_out/r03_gpu_suite7.log 2>&1
-echo "suite rc=$?"; grep -E "passed|failed|^E  " gpurun_out/r03_gpu_suite7.log | tail -5 | cut -c1-250
-for wl in zinc_b1024 molpcba_b1024 molhiv_b512 molhiv_b512_softmax; do
-  timeout 600 python bench.py --workload $wl --cpu-steps 0 --profile-steps 0 2>&1 | grep '^{"metric"' | python3 -c "
-import json,sys
-d=json.loads(sys.stdin.read()); print('$wl', d['ms_per_step'])"
-done
+mkdir -p gpurun_out
+timeout 2700 python -m pytest tests -m gpu -q > gpurun_out/r03_gpu_suite_final.log 2>&1
+echo "suite rc=$?"; grep -E "passed|failed" gpurun_out/r03_gpu_suite_final.log | tail -2
+bash scripts/round_profiles.sh r03 > gpurun_out/r03_round_profiles.log 2>&1
+ls gpurun_out/r03_* | wc -l
