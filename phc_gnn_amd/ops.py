@@ -402,11 +402,12 @@ def phm_pairs(model) -> list:
 
 def dense_weights(model) -> list:
     """``nn.Linear`` weights [out, in] that the engine's dense map (``dense_linear``) can serve from a prebuilt
-    operand: in, out multiples of 4 and <= 768 (the hypercomplex -> real heads of the read-out; molpcba: 512 -> 128)."""
+    operand: in a multiple of 4, in and out <= 768 (the hypercomplex -> real heads of the read-out; molpcba: 512 -> 128; the
+    published 200-wide models: 200 -> 50)."""
     out = []
     for m in model.modules():
-        if isinstance(m, torch.nn.Linear) and m.in_features % 4 == 0 and m.out_features % 4 == 0 \
-                and m.in_features <= PREBUILT_MAX_WIDTH and m.out_features <= PREBUILT_MAX_WIDTH:
+        if isinstance(m, torch.nn.Linear) and m.in_features % 4 == 0 and m.in_features <= PREBUILT_MAX_WIDTH \
+                and m.out_features <= PREBUILT_MAX_WIDTH:
             out.append(m.weight)
     return out
 
@@ -787,6 +788,7 @@ class _DenseLinearFn(torch.autograd.Function):
             L.account("phm_gemm_fwd", 2.0 * N * fi * fo, 4.0 * (N * (fi + fo) + fi * fo + fo))
         ctx.save_for_backward(x_, weight)
         ctx.params = (weight, bias)
+        ctx.H = H
         return y
 
     @staticmethod
@@ -801,8 +803,14 @@ class _DenseLinearFn(torch.autograd.Function):
         dx = None
         if need_x:
             dx = torch.empty_like(x_)
-            L.check(lib.phc_gemm_prebuilt(L.ptr(dy_), L.ptr(weight), None, None, None, N, fo, fi, L.ptr(dx), 1, L.stream_ptr(dev)),
-                    "phc_gemm_prebuilt(dense dx)")
+            if fo % 4 == 0 and dy_.data_ptr() % 16 == 0:
+                L.check(lib.phc_gemm_prebuilt(L.ptr(dy_), L.ptr(weight), None, None, None, N, fo, fi, L.ptr(dx), 1, L.stream_ptr(dev)),
+                        "phc_gemm_prebuilt(dense dx)")
+            else:
+                # an output width that is not a multiple of four (the 50-wide gate of the published 200-wide model) cannot be the
+                # contraction of the streaming kernel: dx through the tiled kernel, on the prebuilt H = weight^T as the n = 1 weight
+                L.check(lib.phc_phm_linear_bwd(L.ptr(x_), L.ptr(_one(dev)), L.ptr(ctx.H), L.ptr(dy_), N, 1, fi, fo, L.ptr(dx), None,
+                                               None, None, None, 0, L.stream_ptr(dev)), "phc_phm_linear_bwd(dense dx)")
             if L.PROF_ON:
                 L.account("phm_gemm_dx", 2.0 * N * fi * fo, 4.0 * (N * (fi + fo) + fi * fo))
         pw, pb = ctx.params
@@ -890,8 +898,7 @@ def dense_linear(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Ten
     phm_dim = 1 case (A = [[[1]]], W = weightᵀ).  Used for the hypercomplex→real head
     (phc/hypercomplex/layers.py:386-414), whose K = N gradient GEMM is a poor fit for the BLAS heuristics."""
     dev = L.require_device(x, weight)
-    if _PREBUILT.table and x.dim() == 2 and weight.shape[0] % 4 == 0 and x.is_contiguous() and x.data_ptr() % 16 == 0 \
-            and (bias is None or bias.is_contiguous()):
+    if _PREBUILT.table and x.dim() == 2 and x.is_contiguous() and x.data_ptr() % 16 == 0 and (bias is None or bias.is_contiguous()):
         pre = _prebuilt_for(None, weight)
         if pre is not None:
             return _DenseLinearFn.apply(x, weight, bias, pre[0])
