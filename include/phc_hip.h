@@ -426,6 +426,11 @@ int phc_bn_bwd_apply(const float *dy, const float *x, const float *save_stat, co
 int phc_gemm_stats_max_partials(void);
 size_t phc_stat_acc_words(int h);             /* 64-bit words of one statistics accumulator of width h */
 int phc_stat_acc_replicas(void);              /* rows of its [2 * replicas][2 * h] word layout (ops.py views it that way) */
+/* An accumulator read back as floats (one tiny launch) — the bridge to host-side collectives of a row-sharded norm (dist.py):
+ * count == 0: out[2h] = total of quantity 0 | total of quantity 1 (e.g. sum g | sum g x_hat of phc_bn_bwd_partial_acc);
+ * count  > 0: the accumulator of a statistics epilogue (sum y | sum y^2) over `count` rows -> out[2h] = sum | M2 about the rows' own
+ * mean, the pair phc_bn_moments produces (and phc_bn_fwd_from_moments merges across ranks). */
+int phc_stat_acc_read(const uint64_t *acc, int h, int64_t count, float *out, void *stream);
 int phc_gemm_prebuilt_stats(const float *x, const float *M, const float *Mk4, const float *b, int64_t N, int K, int Nout, float *y,
                             const int32_t *n_valid_dev, float *stats_partial, float *stats_counts, int *num_partials,
                             void *stream);
@@ -565,6 +570,9 @@ typedef struct phc_gemm_ba_desc {
     const float *bw_x;             /* second stage: [N, Nout] input of the norm in front, or NULL     */
     const float *bw_stat;          /* [6 Nout]                                                        */
     uint64_t *bw_sums_acc;         /* accumulator of width Nout (zeroed by the caller), or NULL       */
+    int64_t count;                 /* rows sums_acc was taken over when that is MORE than this launch's rows: a row-sharded norm
+                                      whose accumulators were all-reduced (integer sum: exact) divides by the total of all ranks;
+                                      0 = the valid rows of this launch                                */
 } phc_gemm_ba_desc;
 int phc_gemm_bwd_apply_supported(int K, int Nout);
 /* Diagnostics only: when set (device buffer, 12 x 8 bytes per wavefront of the largest launch), every H-stationary GEMM launch

@@ -80,6 +80,7 @@ struct GemmHsArgs {
     const float *ba_x;         // BA: the norm's input [M, K] (x holds the upstream gradient)
     const float *ba_stat;      // BA: [6 K] save_stat of that norm
     const unsigned long long *ba_acc;   // BA: accumulator of width K: sum g | sum g x_hat over the valid rows
+    long long ba_count;        // BA: rows those sums were taken over when that is not this launch's valid rows (a row shard); 0 = n_valid
     int ba_act;
     float *ba_dz;              // BA: [M, K] out
     float *ba_dwb;             // BA: [2 K] out or null: dweight = sum g x_hat | dbias = sum g   (written by workgroup 0)
@@ -337,7 +338,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
                 }
                 tot[qty] = (double)hi * (1.0 / 4096.0) + (double)lo * (1.0 / 4611686018427387904.0);
             }
-            const float cnt = (float)max(n_valid, 1LL);
+            const float cnt = (float)max(a.ba_count > 0 ? a.ba_count : n_valid, 1LL);
             ba_lds[col] = ba_cst[1];
             ba_lds[K + col] = ba_cst[0];
             ba_lds[2 * K + col] = ba_cst[2];

@@ -1275,6 +1275,27 @@ int phc_bn_moments(const float *x, int64_t N, int h, float *moments, void *ws, s
     return check_launch("bn_moments");
 }
 
+// A statistics accumulator read back as floats: the bridge from the GEMM epilogues (integer totals) to the row-sharded norm's
+// host-side collectives.  count == 0: out = total of quantity 0 | total of quantity 1.  count > 0: the accumulator holds a
+// statistics epilogue's (sum y | sum y^2 about zero) over `count` rows and out = sum | M2 about their own mean, what
+// phc_bn_moments produces with its two passes over y (the subtraction in double: the totals are exact to 2^-62).
+__global__ __launch_bounds__(256) void stat_acc_read_kernel(const unsigned long long *__restrict__ acc, int h, long long count,
+                                                            float *__restrict__ out) {
+    const int col = blockIdx.x * 256 + threadIdx.x;
+    if (col >= h) return;
+    const double S = stat_acc_total(acc, h, 0, col), Q = stat_acc_total(acc, h, 1, col);
+    out[col] = (float)S;
+    out[h + col] = count > 0 ? (float)fmax(Q - S * S / (double)count, 0.0) : (float)Q;
+}
+
+int phc_stat_acc_read(const uint64_t *acc, int h, int64_t count, float *out, void *stream) {
+    PHC_REQUIRE(acc && out && h >= 1 && h <= 8192 && count >= 0, PHC_ERR_INVALID_ARG, "phc_stat_acc_read: h=%d count=%lld", h, (long long)count);
+    PHC_REQUIRE((reinterpret_cast<uintptr_t>(acc) & 7) == 0, PHC_ERR_UNSUPPORTED, "phc_stat_acc_read: 8-byte aligned accumulator required");
+    PHC_LAUNCH(stat_acc_read_kernel, dim3((h + 255) / 256), dim3(256), 0, (hipStream_t)stream,
+               reinterpret_cast<const unsigned long long *>(acc), h, (long long)count, out);
+    return check_launch("stat_acc_read");
+}
+
 int phc_bn_fwd_from_moments(const float *x, int64_t N_local, const float *moments_all, const float *counts_all, int num_ranks,
                             int64_t N_total, const float *const *weight, const float *const *bias, float *const *running_mean,
                             float *const *running_var, int64_t *const *num_batches_tracked, int n_comp, int h, float momentum,

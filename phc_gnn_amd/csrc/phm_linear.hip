@@ -1143,8 +1143,12 @@ static int launch_hs_cfg(GemmHsArgs a, const XfAcc &xa, hipStream_t s) {
     a.stamps = g_hs_stamps;
     a.panels = a.Nout / (16 * TPW * WAVES);
     const long long steps = (a.M + 16 * RB - 1) / (16 * RB);
-    static const int per_cu = getenv("PHC_HS_GROUPS_PER_CU") ? atoi(getenv("PHC_HS_GROUPS_PER_CU")) : 1;
-    long long groups = (long long)(per_cu > 0 ? per_cu : 1) * num_cu() / a.panels;
+    // workgroups per CU: one (8 wavefronts = two per SIMD at Nout = 256).  The 4-wavefront configurations (Nout = 128) leave a
+    // SIMD with one wavefront; a second workgroup per CU is worth +3-4 % from 16 steps per workgroup on (64 k rows: 27.9 -> 27.1 us,
+    // 10 M rows: 3.07 -> 2.95 ms) and nothing below (scripts/dbg/gemm_hs_vs_panel.py with PHC_HS_GROUPS_PER_CU = 1 / 2 / 3)
+    static const int per_cu_env = getenv("PHC_HS_GROUPS_PER_CU") ? atoi(getenv("PHC_HS_GROUPS_PER_CU")) : 0;
+    const int per_cu = per_cu_env > 0 ? per_cu_env : (WAVES == 4 && steps >= 16LL * num_cu() ? 2 : 1);
+    long long groups = (long long)per_cu * num_cu() / a.panels;
     if (groups > steps) groups = steps;
     if (groups < 1) groups = 1;
     a.groups = (int)groups;
@@ -1870,6 +1874,7 @@ int phc_gemm_bwd_apply(const phc_gemm_ba_desc *d, void *stream) {
                 "phc_gemm_bwd_apply: N=%lld K=%d Nout=%d outside the fused form's range (K, Nout in {128, 256})", (long long)d->N, d->K, d->Nout);
     PHC_REQUIRE(d->dout && d->bn_x && d->bn_stat && d->sums_acc && d->dz && d->Mk4 && d->y, PHC_ERR_INVALID_ARG, "phc_gemm_bwd_apply: null pointer");
     PHC_REQUIRE(d->act >= PHC_ACT_IDENTITY && d->act <= PHC_ACT_SELU, PHC_ERR_INVALID_ARG, "phc_gemm_bwd_apply: unknown activation %d", d->act);
+    PHC_REQUIRE(d->count == 0 || d->count >= d->N, PHC_ERR_INVALID_ARG, "phc_gemm_bwd_apply: count=%lld < N=%lld", (long long)d->count, (long long)d->N);
     const bool bw = d->bw_sums_acc != nullptr;
     PHC_REQUIRE(!bw || (d->bw_x && d->bw_stat && d->bw_act >= PHC_ACT_IDENTITY && d->bw_act <= PHC_ACT_SELU), PHC_ERR_INVALID_ARG,
                 "phc_gemm_bwd_apply: second-stage sums need bw_x, bw_stat and an activation");
@@ -1887,6 +1892,7 @@ int phc_gemm_bwd_apply(const phc_gemm_ba_desc *d, void *stream) {
     a.ba_act = d->act;
     a.ba_dz = d->dz;
     a.ba_dwb = d->dwb;
+    a.ba_count = d->count;
     ProfScope prof(K_PHM_GEMM_DX, s);
     if (bw) {
         a.stat_acc = reinterpret_cast<unsigned long long *>(d->bw_sums_acc);

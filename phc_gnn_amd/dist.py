@@ -257,6 +257,43 @@ class EngineBackend:
     def bn_bwd_apply(self, dy, x, save_stat, dwb_global, n_total, act):
         return self._ops.bn_bwd_apply(dy, x, save_stat, dwb_global, n_total, self._ops._act_id(act))
 
+    # ---- the same norm folded into the GEMMs around it (engine only; the layer asks `norm_fusable` first) ----
+    FUSED_NORM = __import__("os").environ.get("PHC_SHARDED_NORM_FUSED", "1") != "0"
+
+    def norm_fusable(self, pre):
+        """linear1 [in -> h], norm over h, linear2 [h -> out]: the folded forms need in and h in the H-stationary GEMM's range."""
+        if not self.FUSED_NORM or pre is None:
+            return False
+        k_in, h = pre[0][0].shape
+        return self._ops.sharded_norm_fusable(h, k_in) and pre[1][0].shape[0] == h
+
+    def linear_fwd_stats(self, x, pre, b):
+        """(z, moments [2h]): the GEMM's statistics epilogue instead of a pass over z."""
+        z, acc = self._ops.gemm_pre_stats(x, pre, b)
+        return z, self._ops.stat_acc_read(acc, z.shape[1], max(z.shape[0], 1))
+
+    def bn_finalize_from_moments(self, moments_all, counts_all, n_total, norm, h):
+        mods = list(norm.bn)
+        return self._ops.bn_finalize_from_moments(
+            moments_all, counts_all, n_total, [m.weight for m in mods] if norm.affine else None,
+            [m.bias for m in mods] if norm.affine else None, [m.running_mean for m in mods], [m.running_var for m in mods],
+            [m.num_batches_tracked for m in mods], norm._momentum(), norm.eps, h)
+
+    def linear_fwd_xf(self, z, save_stat, act, pre, b):
+        return self._ops.gemm_pre_xf(z, save_stat, self._ops._act_id(act), pre, b)
+
+    def bn_bwd_sums_acc(self, dy, x, save_stat, act):
+        return self._ops.bn_bwd_sums_acc(dy, x, save_stat, self._ops._act_id(act))
+
+    def acc_totals(self, acc, h):
+        return self._ops.stat_acc_read(acc, h, 0)
+
+    def linear_dx_bwd_apply(self, dy, x, save_stat, sums_acc, n_total, act, pre):
+        return self._ops.gemm_pre_bwd_apply(dy, x, save_stat, sums_acc, n_total, self._ops._act_id(act), pre)
+
+    def linear_param_grads_xf(self, x, save_stat, act, dy, A, W, has_bias):
+        return self._ops.phm_param_grads_xf(x, save_stat, self._ops._act_id(act), dy, A, W, has_bias)
+
 
 def seg_as_edges(seg):
     """A SegmentStructure (rows grouped by an index) read as the CSR the aggregation kernel walks."""
@@ -445,18 +482,30 @@ class _ShardedGINEFn(torch.autograd.Function):
         build = getattr(be, "build_operands", None)
         pre = build([(A1, W1), (A2, W2)]) if build is not None else None      # engine: H, H^T (+ k4 forms) of both linears
         ctx.pre = pre
-        z = be.linear_fwd_pre(s, pre[0], b1) if pre is not None else be.linear_fwd(s, A1, W1, b1)
-        if mlp.norm_flag:
+        # the norm's passes inside the GEMMs around it: every rank decides alike (width and row counts are global knowledge)
+        fused = bool(mlp.norm_flag and getattr(be, "norm_fusable", None) is not None and be.norm_fusable(pre) and layer.min_count >= 1)
+        ctx.fused = fused
+        if fused:
             norm = mlp.norm.bn
-            mom = be.bn_moments(z)
+            z, mom = be.linear_fwd_stats(s, pre[0], b1)                       # statistics: the GEMM's epilogue
             mom_flat = torch.empty(plan.world * mom.numel(), dtype=mom.dtype, device=mom.device)
             dist.all_gather_into_tensor(mom_flat, mom, group=plan.group)      # 2h floats per rank
-            mom_all = mom_flat.view(plan.world, mom.numel())
-            a, save_stat = be.bn_fwd_from_moments(z, mom_all, layer.counts_all, layer.n_total, norm, act)
+            save_stat = be.bn_finalize_from_moments(mom_flat.view(plan.world, mom.numel()), layer.counts_all, layer.n_total, norm, z.shape[1])
+            y = be.linear_fwd_xf(z, save_stat, act, pre[1], b2)               # act(norm(z)) exists only in the GEMM's LDS
+            a = z.new_empty(0)
         else:
-            save_stat = z.new_empty(0)
-            a = layer.act_fn(z)
-        y = be.linear_fwd_pre(a, pre[1], b2) if pre is not None else be.linear_fwd(a, A2, W2, b2)
+            z = be.linear_fwd_pre(s, pre[0], b1) if pre is not None else be.linear_fwd(s, A1, W1, b1)
+            if mlp.norm_flag:
+                norm = mlp.norm.bn
+                mom = be.bn_moments(z)
+                mom_flat = torch.empty(plan.world * mom.numel(), dtype=mom.dtype, device=mom.device)
+                dist.all_gather_into_tensor(mom_flat, mom, group=plan.group)  # 2h floats per rank
+                mom_all = mom_flat.view(plan.world, mom.numel())
+                a, save_stat = be.bn_fwd_from_moments(z, mom_all, layer.counts_all, layer.n_total, norm, act)
+            else:
+                save_stat = z.new_empty(0)
+                a = layer.act_fn(z)
+            y = be.linear_fwd_pre(a, pre[1], b2) if pre is not None else be.linear_fwd(a, A2, W2, b2)
         ctx.layer = layer
         ctx.has_ea = (ea_loc is not None, ea_halo is not None)
         ctx.has_bias = (b1 is not None, b2 is not None)
@@ -478,7 +527,16 @@ class _ShardedGINEFn(torch.autograd.Function):
         dy = dy.contiguous()
         pre = ctx.pre
         da = be.linear_dx_pre(dy, pre[1]) if pre is not None else be.linear_dx(dy, A2, W2)
-        if mlp.norm_flag:
+        if ctx.fused:
+            h = z.shape[1]
+            acc = be.bn_bwd_sums_acc(da, z, save_stat, act)                   # this rank's sum g | sum g x_hat, integer totals
+            dwb = None
+            if ctx.n_affine:
+                tot = be.acc_totals(acc, h)                                   # (before the all-reduce: the partial of this rank)
+                dwb = torch.cat([tot[h:], tot[:h]])                           # dweight | dbias
+            dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=plan.group)      # integer words: the same totals on every rank
+            dz, ds = be.linear_dx_bwd_apply(da, z, save_stat, acc, layer.n_total, act, pre[0])
+        elif mlp.norm_flag:
             dwb = be.bn_bwd_sums(da, z, save_stat, act)                       # this rank's partial dweight | dbias
             dwb_all = dwb.clone()
             dist.all_reduce(dwb_all, op=dist.ReduceOp.SUM, group=plan.group)
@@ -486,11 +544,13 @@ class _ShardedGINEFn(torch.autograd.Function):
         else:
             dwb = None
             dz = layer.act_bwd(z, da)
-        ds = be.linear_dx_pre(dz, pre[0]) if pre is not None else be.linear_dx(dz, A1, W1)
+        if not ctx.fused:
+            ds = be.linear_dx_pre(dz, pre[0]) if pre is not None else be.linear_dx(dz, A1, W1)
         need_dea = (ctx.needs_input_grad[2] and ea_loc is not None, ctx.needs_input_grad[3] and ea_halo is not None)
 
         def param_grads():                                                    # queued while the halo gradients travel
-            g2 = be.linear_param_grads(a, dy, A2, W2, ctx.has_bias[1])
+            g2 = (be.linear_param_grads_xf(z, save_stat, act, dy, A2, W2, ctx.has_bias[1]) if ctx.fused
+                  else be.linear_param_grads(a, dy, A2, W2, ctx.has_bias[1]))
             g1 = be.linear_param_grads(s, dz, A1, W1, ctx.has_bias[0])
             return g1, g2
 
@@ -523,6 +583,7 @@ class ShardedPHMGINEConv(torch.nn.Module):
         bounds = partition_bounds(self.n_total, plan.world)
         dev = plan.loc_edge_index.device
         self.counts_all = torch.tensor([float(bounds[r + 1] - bounds[r]) for r in range(plan.world)], dtype=torch.float32, device=dev)
+        self.min_count = min(bounds[r + 1] - bounds[r] for r in range(plan.world))
         self.act_fn = get_module_activation(conv.transform.activation_str)
 
     def act_bwd(self, z, da):

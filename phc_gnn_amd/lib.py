@@ -65,7 +65,7 @@ class GemmBaDesc(C.Structure):
     """phc_gemm_ba_desc (include/phc_hip.h)."""
     _fields_ = [("dout", _P), ("bn_x", _P), ("bn_stat", _P), ("sums_acc", _P), ("n_valid_dev", _P), ("dz", _P), ("dwb", _P),
                 ("Mk4", _P), ("y", _P), ("N", _L), ("K", C.c_int32), ("Nout", C.c_int32), ("act", C.c_int32), ("bw_act", C.c_int32),
-                ("bw_x", _P), ("bw_stat", _P), ("bw_sums_acc", _P)]
+                ("bw_x", _P), ("bw_stat", _P), ("bw_sums_acc", _P), ("count", _L)]
 
 
 class Copy2dJob(C.Structure):
@@ -103,6 +103,7 @@ SIGNATURES = {
                                       C.POINTER(_I), _P]),
     "phc_gemm_prebuilt_bwsums": (_I, [_P, _P, _P, _L, _I, _I, _P, _P, _P, _I, _P, _P, C.POINTER(_I), _P]),
     "phc_gemm_bwd_apply_supported": (_I, [_I, _I]),
+    "phc_stat_acc_read": (_I, [_P, _I, _L, _P, _P]),
     "phc_debug_hs_stamps": (_I, [_P]),
     "phc_gemm_bwd_apply": (_I, [C.POINTER(GemmBaDesc), _P]),
     "phc_bn_bwd_partial_acc": (_I, [_P, _P, _P, _P, _L, _I, _I, _P, _P]),

@@ -1150,6 +1150,124 @@ def bn_bwd_apply(dy, x, save_stat, dwb_global, n_total: int, act: int) -> torch.
     return dx
 
 
+# ---- the same norm with its four passes folded into the GEMMs on either side (dist._ShardedGINEFn, engine backend) ----
+# linear1 -> norm -> act -> linear2 on a row shard: the statistics leave linear1's GEMM as integer totals (read back as this rank's
+# moments for the all-gather), linear2's GEMM normalises its operand while it streams in, and in the backward the element-wise norm
+# backward runs inside linear1's dx GEMM on the all-reduced (integer: exact) column sums.  What remains a pass of its own is the
+# backward's column sums (phc_bn_bwd_partial_acc): as a GEMM epilogue they cost more than the pass at 10 M rows
+# (scripts/dbg/gemm_variants_at_scale.py).
+def sharded_norm_fusable(h: int, k_in: int) -> bool:
+    """Whether the folded forms serve a norm of width h behind a linear [k_in -> h] (both in {128, 256}: the H-stationary GEMM's range)."""
+    return bool(L.load().phc_gemm_bwd_apply_supported(int(h), int(k_in)))
+
+
+def new_stat_acc(h: int, dev) -> torch.Tensor:
+    """A zeroed statistics accumulator of width h outside the per-step arena (the sharded layer keeps it across collectives)."""
+    return torch.zeros(int(L.load().phc_stat_acc_words(int(h))), dtype=torch.int64, device=dev)
+
+
+def stat_acc_read(acc: torch.Tensor, h: int, count: int = 0) -> torch.Tensor:
+    """[2h] floats of an accumulator: its two totals (count = 0) or sum | M2 of a statistics epilogue over ``count`` rows."""
+    lib = L.load()
+    out = torch.empty(2 * h, dtype=torch.float32, device=acc.device)
+    L.check(lib.phc_stat_acc_read(L.ptr(acc), int(h), int(count), L.ptr(out), L.stream_ptr(acc.device)), "phc_stat_acc_read")
+    return out
+
+
+def gemm_pre_stats(x: torch.Tensor, pre, bias: Optional[torch.Tensor]):
+    """(y, acc): y = x . H + bias on prebuilt operands with the statistics epilogue (sum y | sum y^2 per column) in a fresh accumulator."""
+    lib = L.load()
+    dev = L.require_device(x)
+    x_ = L.f32c(x)
+    M, Mk4 = pre[0], pre[2]
+    K, Nout = M.shape
+    N = x_.shape[0]
+    y = torch.empty((N, Nout), dtype=torch.float32, device=dev)
+    acc = new_stat_acc(Nout, dev)
+    L.check(lib.phc_gemm_prebuilt_stats(L.ptr(x_), L.ptr(M), L.ptr(Mk4), None if bias is None else L.ptr(L.f32c(bias)), N, K, Nout, L.ptr(y), None,
+                                        L.ptr(acc), None, None, L.stream_ptr(dev)), "phc_gemm_prebuilt_stats")
+    if L.PROF_ON:
+        L.account("phm_gemm_fwd", 2.0 * N * K * Nout, 4.0 * (N * (K + Nout) + K * Nout))
+    return y, acc
+
+
+def bn_finalize_from_moments(moments_all, counts_all, n_total, weights, biases, running_mean, running_var, nbt, momentum, eps, h: int):
+    """save_stat [6h] of the statistics merged from every shard's moments (running statistics updated) — ``bn_fwd_from_moments``
+    without its element-wise pass."""
+    lib = L.load()
+    dev = L.require_device(moments_all, counts_all)
+    n_comp = len(running_mean) if running_mean else len(weights)
+    save_stat = torch.empty(6 * h, dtype=torch.float32, device=dev)
+    L.check(lib.phc_bn_fwd_from_moments(
+        None, 0, L.ptr(moments_all), L.ptr(counts_all), int(counts_all.numel()), int(n_total),
+        _ptr_array(weights) if weights else None, _ptr_array(biases) if biases else None,
+        _ptr_array(running_mean) if running_mean else None, _ptr_array(running_var) if running_var else None,
+        _ptr_array(nbt) if nbt else None, n_comp, h, float(momentum), float(eps), 0, None, None,
+        L.ptr(save_stat), L.stream_ptr(dev)), "phc_bn_fwd_from_moments(finalize)")
+    return save_stat
+
+
+def gemm_pre_xf(x: torch.Tensor, save_stat: torch.Tensor, act: int, pre, bias: Optional[torch.Tensor]) -> torch.Tensor:
+    """y = act(batch_norm(x)) . H + bias with the norm (save_stat) applied to the operand as it streams in."""
+    lib = L.load()
+    dev = L.require_device(x, save_stat)
+    x_ = L.f32c(x)
+    M, Mk4 = pre[0], pre[2]
+    K, Nout = M.shape
+    N = x_.shape[0]
+    y = torch.empty((N, Nout), dtype=torch.float32, device=dev)
+    L.check(lib.phc_gemm_prebuilt_xf(L.ptr(x_), L.ptr(save_stat), int(act), None, L.ptr(M), L.ptr(Mk4), None if bias is None else L.ptr(L.f32c(bias)),
+                                     N, K, Nout, L.ptr(y), None, None, None, L.stream_ptr(dev)), "phc_gemm_prebuilt_xf")
+    if L.PROF_ON:
+        L.account("phm_gemm_fwd", 2.0 * N * K * Nout, 4.0 * (N * (K + Nout) + K * Nout))
+    return y
+
+
+def bn_bwd_sums_acc(dy: torch.Tensor, x: torch.Tensor, save_stat: torch.Tensor, act: int) -> torch.Tensor:
+    """This shard's sum g | sum g x_hat as a fresh accumulator (``bn_bwd_sums`` in the form that all-reduces exactly)."""
+    lib = L.load()
+    dev = L.require_device(dy, x)
+    dy_, x_ = L.f32c(dy), L.f32c(x)
+    N, h = x_.shape
+    acc = new_stat_acc(h, dev)
+    L.check(lib.phc_bn_bwd_partial_acc(L.ptr(dy_), L.ptr(x_), L.ptr(save_stat), None, N, h, int(act), L.ptr(acc), L.stream_ptr(dev)),
+            "phc_bn_bwd_partial_acc")
+    if L.PROF_ON:
+        L.account("bn_bwd_partial", 6.0 * N * h, 8.0 * N * h)
+    return acc
+
+
+def gemm_pre_bwd_apply(dy: torch.Tensor, x: torch.Tensor, save_stat: torch.Tensor, sums_acc: torch.Tensor, count: int, act: int, pre):
+    """(dz, ds): dz = the norm backward of (dy, x) on the column sums in ``sums_acc`` (taken over ``count`` rows: every shard's),
+    ds = dz . H^T — one launch (phc_gemm_bwd_apply)."""
+    lib = L.load()
+    dev = L.require_device(dy, x, sums_acc)
+    dy_, x_ = L.f32c(dy), L.f32c(x)
+    N, K = x_.shape
+    MT = pre[1]
+    Nout = MT.shape[1]
+    dz = torch.empty_like(x_)
+    ds = torch.empty((N, Nout), dtype=torch.float32, device=dev)
+    d = L.GemmBaDesc()
+    d.dout, d.bn_x, d.bn_stat, d.sums_acc, d.n_valid_dev = L.ptr(dy_), L.ptr(x_), L.ptr(save_stat), L.ptr(sums_acc), None
+    d.dz, d.dwb, d.Mk4, d.y = L.ptr(dz), None, L.ptr(pre[3]), L.ptr(ds)
+    d.N, d.K, d.Nout, d.act = N, K, Nout, int(act)
+    d.bw_act, d.bw_x, d.bw_stat, d.bw_sums_acc = 0, None, None, None
+    d.count = int(count)
+    L.check(lib.phc_gemm_bwd_apply(_C.byref(d), L.stream_ptr(dev)), "phc_gemm_bwd_apply")
+    if L.PROF_ON:
+        L.account("phm_gemm_dx", 2.0 * N * K * Nout, 4.0 * (4 * N * K + K * Nout))
+    return dz, ds
+
+
+def phm_param_grads_xf(x: torch.Tensor, save_stat: torch.Tensor, act: int, dy: torch.Tensor, A: torch.Tensor, W: torch.Tensor, has_bias: bool):
+    """(dA, dW, db | None) of y = act(batch_norm(x)) . H(A, W) + b: the normalised operand is rebuilt from x inside the launch."""
+    job = dict(x=L.f32c(x), dy=L.f32c(dy), A=L.f32c(A.detach()), W=L.f32c(W.detach()), need=(True, True, bool(has_bias)),
+               params=(None, None, None), xf=(save_stat, None, int(act)))
+    (dA, dW, db), = _flush_param_grads([job], return_grads=True)
+    return dA, dW, db
+
+
 def aggregate_sum(x: torch.Tensor, edge_index, edge_attr: Optional[torch.Tensor], msg_encoder: str = "identity",
                   add_self_loops: bool = False, num_dst: Optional[int] = None) -> torch.Tensor:
     """out[i] = Σ_{e: edge_index[1,e]=i} φ(x[edge_index[0,e]] + edge_attr[e])  (+ x[i]).

@@ -6,7 +6,7 @@ import torch
 from phc_gnn_amd import ops
 dev = torch.device("cuda:0")
 g = torch.Generator(device=dev).manual_seed(0)
-for K in (128, 256):
+for K in ([int(a) for a in sys.argv[1:]] or (128, 256)):
     n, k = 4, K // 4
     A = torch.randn(n, n, n, device=dev, generator=g)
     W = torch.randn(n, k, k, device=dev, generator=g) * 0.1

@@ -2,6 +2,8 @@
 by the real reference (tests/golden/make_golden.py)."""
 import types
 
+import numpy as np
+
 import pytest
 import torch
 
@@ -575,9 +577,54 @@ def _loopback_plan(ei, N, frac=0.5):
                     halo_edge_ids=halo_pos, group=None)
 
 
-@pytest.mark.parametrize("N,E,msg,loopback", [(20_000, 110_000, "relu", True), (20_000, 110_000, "identity", False),
-                                              (1_000_000, 5_000_000, "identity", True)])
-def test_sharded_gine_layer_engine_backend_single_rank(rccl_single_rank, N, E, msg, loopback):
+def test_sharded_gine_layer_norm_folded_into_gemms_equals_separate_passes(rccl_single_rank):
+    """The sharded layer's norm inside its GEMMs (statistics epilogue -> moments, normalising operand, norm backward in the dx
+    GEMM on all-reduced integer sums) against the same layer with the four norm passes as launches of their own
+    (EngineBackend.FUSED_NORM off): outputs, dx, d edge_attr, every parameter gradient, running statistics."""
+    from phc.hypercomplex.undirectional.messagepassing import PHMGINEConv
+    from phc_gnn_amd import synth
+    from phc_gnn_amd.dist import EngineBackend, ShardedAggregate, ShardedPHMGINEConv
+    n, h, N, E = 4, 128, 30_001, 150_000
+    ei = torch.from_numpy(synth.random_edges(N, E, seed=21)).to(DEV)
+    g = torch.Generator().manual_seed(22)
+    x, dy, ea = torch.randn(N, h, generator=g), torch.randn(N, h, generator=g), torch.randn(E, h, generator=g)
+    res = []
+    for fused in (True, False):
+        torch.manual_seed(5)
+        np.random.seed(5)                                  # (the "phm" weight initialisation draws from numpy / scipy)
+        conv = PHMGINEConv(h, h, phm_dim=n, phm_rule=None, norm="naive-batch-norm", activation="swish", msg_encoder="identity")
+        with torch.no_grad():
+            for name, p in conv.named_parameters():
+                if p.dim() == 1 and name.endswith("weight"):
+                    p.copy_(0.5 + torch.rand(p.shape, generator=torch.Generator().manual_seed(23)))
+        conv.to(DEV).train()
+        old = EngineBackend.FUSED_NORM
+        EngineBackend.FUSED_NORM = fused
+        try:
+            plan = _loopback_plan(ei, N)
+            agg = ShardedAggregate(plan)
+            layer = ShardedPHMGINEConv(conv, agg, N).train()
+            xd = x.to(DEV).requires_grad_()
+            el, eh = agg.split_edge_attr(ea.to(DEV))
+            el, eh = el.requires_grad_(), eh.requires_grad_()
+            y = layer(xd, el, eh)
+            y.backward(dy.to(DEV))
+            torch.cuda.synchronize()
+        finally:
+            EngineBackend.FUSED_NORM = old
+        res.append(dict(y=y.detach().cpu(), dx=xd.grad.cpu(), dl=el.grad.cpu(), dh=eh.grad.cpu(),
+                        **{"g." + k: q.grad.cpu() for k, q in conv.named_parameters()},
+                        **{"b." + k: b.cpu().float() for k, b in conv.named_buffers()}))
+    for k in res[0]:
+        if k == "g.transform.linear1.b":                 # bias in front of the batch-norm: zero up to round-off on both sides
+            continue
+        assert_close(res[0][k], res[1][k], 2e-5, k)
+
+
+@pytest.mark.parametrize("N,E,msg,loopback,mlp_act", [(20_000, 110_000, "relu", True, "swish"), (20_000, 110_000, "identity", False, "swish"),
+                                                      (20_000, 110_000, "identity", True, "relu"),
+                                                      (1_000_000, 5_000_000, "identity", True, "swish")])
+def test_sharded_gine_layer_engine_backend_single_rank(rccl_single_rank, N, E, msg, loopback, mlp_act):
     """ShardedPHMGINEConv (halo exchange on its own stream, in-kernel accumulation, moments all-gather, sums
     all-reduce, parameter-gradient GEMMs queued behind the reverse exchange) against the CPU oracle's unsharded layer,
     up to 1 M nodes / 5 M edges (BASELINE config 5 is 10 M / 50 M: same code, ten times the rows)."""
@@ -591,9 +638,10 @@ def test_sharded_gine_layer_engine_backend_single_rank(rccl_single_rank, N, E, m
     x, dy = torch.randn(N, h, generator=g), torch.randn(N, h, generator=g)
     ea = torch.randn(E, h, generator=g) if N <= 100_000 else None          # the large case: no [E, h] edge tensor on the CPU side
     torch.manual_seed(3)
-    # the large case runs the MLP with a smooth activation: among 128 M pre-activations some sit within an ulp of the ReLU
-    # kink, and one flipped gate changes that node's whole dx row (see tests/test_gpu_fullwidth.py)
-    mlp_act = "relu" if N <= 100_000 else "swish"
+    # The tight comparisons run the MLP with a smooth activation: among N x 128 pre-activations some sit within an ulp of the
+    # ReLU kink, the batch statistics of two implementations differ in the last bit (here: one pass inside the GEMM's epilogue
+    # against the oracle's two passes), and one flipped gate changes that node's whole dx row (see tests/test_gpu_fullwidth.py).
+    # The ReLU case keeps the forward tolerance and bounds the gradients by the kink floor used there.
     conv = PHMGINEConv(h, h, phm_dim=n, phm_rule=None, norm="naive-batch-norm", activation=mlp_act, msg_encoder=msg)
     with torch.no_grad():
         for name, p in conv.named_parameters():
@@ -631,6 +679,10 @@ def test_sharded_gine_layer_engine_backend_single_rank(rccl_single_rank, N, E, m
     grads = torch.autograd.grad(ref, [xr] + ([er] if er is not None else []) + [p[k] for k in names], dy, allow_unused=True)
     tol = 2e-5 if N <= 100_000 else 1e-4            # sums over 1 M rows in a different order
     assert_close(y, ref, tol, "y")
+    if mlp_act == "relu":
+        tol = 1e-2                                  # RELU_KINK_FLOOR of tests/test_gpu_fullwidth.py
+        bad = ((xd.grad.cpu() - grads[0]).abs().amax(1) > 2e-5 * float(grads[0].abs().max())).float().mean()
+        assert float(bad) < 1e-3, f"dx: {float(bad):.2e} of the rows differ — more than a handful of flipped gates"
     assert_close(xd.grad, grads[0], tol, "dx")
     off = 1
     if er is not None:
