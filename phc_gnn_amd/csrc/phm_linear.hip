@@ -1124,12 +1124,14 @@ static inline bool hs_enabled() {
 }
 // Where it is the faster kernel (A/B inside the replayed training steps, one MI355X): hidden 256 at 23-27 k rows -19..-20 % per
 // launch (zinc_b1024 2.46 -> 2.31 ms, molpcba_b1024 3.00 -> 2.87 ms per step), 1 M rows x 256: 1205 -> 992 us (132 TFLOP/s);
-// at K = Nout = 128 and 12.9 k rows the 32-column staged kernel is 0.2-0.4 us per launch ahead (805 sixteen-row steps on 256
-// CUs: 4 rounds for 3.1 rounds of work), from 32 k rows on the H-stationary one again.  PHC_GEMM_HS_ALL=1: every served shape.
+// at K = Nout = 128 with ONE workgroup per CU the 32-column staged kernel was 0.2-0.4 us per launch ahead at 12.9 k rows (805
+// sixteen-row steps on 256 CUs: 4 rounds for 3.1 rounds of work); with two workgroups per CU (launch_hs_cfg) the H-stationary
+// kernel wins there too: molhiv_b512 0.694 / 0.692 / 0.697 -> 0.680 / 0.688 / 0.676 ms, molhiv_b32 (1 152 rows) 0.457 -> 0.425 ms,
+// the softmax step 0.801 -> 0.796 ms (alternating runs on one box).  PHC_GEMM_HS_MIN_ROWS_128=<rows> restores a threshold.
 static bool hs_shape_ok(const float *x, const float *Mk4, int64_t N, int K, int Nout) {
-    static const bool all = getenv("PHC_GEMM_HS_ALL") != nullptr;
+    static const long long min128 = getenv("PHC_GEMM_HS_MIN_ROWS_128") ? atoll(getenv("PHC_GEMM_HS_MIN_ROWS_128")) : 0;
     return hs_enabled() && Mk4 && N >= 1 && (K == 128 || K == 256) && (Nout == 128 || Nout == 256) &&
-           (all || K == 256 || Nout == 256 || N >= 32 * 1024) &&
+           (K == 256 || Nout == 256 || N >= min128) &&
            ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(Mk4)) & 15) == 0;
 }
 
@@ -1143,11 +1145,13 @@ static int launch_hs_cfg(GemmHsArgs a, const XfAcc &xa, hipStream_t s) {
     a.stamps = g_hs_stamps;
     a.panels = a.Nout / (16 * TPW * WAVES);
     const long long steps = (a.M + 16 * RB - 1) / (16 * RB);
-    // workgroups per CU: one (8 wavefronts = two per SIMD at Nout = 256).  The 4-wavefront configurations (Nout = 128) leave a
-    // SIMD with one wavefront; a second workgroup per CU is worth +3-4 % from 16 steps per workgroup on (64 k rows: 27.9 -> 27.1 us,
-    // 10 M rows: 3.07 -> 2.95 ms) and nothing below (scripts/dbg/gemm_hs_vs_panel.py with PHC_HS_GROUPS_PER_CU = 1 / 2 / 3)
+    // workgroups per CU: one for the 8-wavefront configurations (two wavefronts per SIMD; a second workgroup made the zinc_b1024
+    // step 2.10 -> 2.23 ms).  The 128 x 128 configuration (4 wavefronts, 64 operand registers, 33 KB of ring) leaves a SIMD with
+    // one wavefront: two workgroups per CU are worth 3-4 % at scale (10 M rows: 3.07 -> 2.95 ms, scripts/dbg/gemm_hs_vs_panel.py)
+    // and 2 % of the molhiv_b512 step, whose folded-norm dx GEMMs then run 1.7 instead of 3.4 steps per workgroup
+    // (0.706 / 0.711 / 0.714 -> 0.695 / 0.692 / 0.698 ms, alternating runs on one box with PHC_HS_GROUPS_PER_CU = 1 / 2)
     static const int per_cu_env = getenv("PHC_HS_GROUPS_PER_CU") ? atoi(getenv("PHC_HS_GROUPS_PER_CU")) : 0;
-    const int per_cu = per_cu_env > 0 ? per_cu_env : (WAVES == 4 && steps >= 16LL * num_cu() ? 2 : 1);
+    const int per_cu = per_cu_env > 0 ? per_cu_env : (WAVES == 4 && K == 128 ? 2 : 1);
     long long groups = (long long)per_cu * num_cu() / a.panels;
     if (groups > steps) groups = steps;
     if (groups < 1) groups = 1;
@@ -1167,6 +1171,8 @@ template <int FLAGS>
 static int launch_hs(const GemmHsArgs &a, int K, const XfAcc &xa, hipStream_t s) {
     // Nout = 256: 8 wavefronts x 2 tiles; Nout = 128: 4 wavefronts x 2 tiles (two independent accumulators per wavefront keep
     // the 16x16x4 MFMA's 40-cycle dependent latency off the issue path)
+    // (Nout = 256 as two 128-column workgroups of 4 wavefronts, two per CU: zinc_b1024 2.11 -> 3.98 ms — the doubled ring of the
+    // folded-norm variants leaves room for one workgroup per CU only)
     if (K == 256 && a.Nout == 256) return launch_hs_cfg<256, 2, 8, FLAGS>(a, xa, s);
     if (K == 256 && a.Nout == 128) return launch_hs_cfg<256, 2, 4, FLAGS>(a, xa, s);
     if (K == 128 && a.Nout == 256) return launch_hs_cfg<128, 2, 8, FLAGS>(a, xa, s);
