@@ -555,21 +555,35 @@ __global__ __launch_bounds__(DN_THREADS) void downstream_bwd_kernel(DnArgs a) {
     }
     __syncthreads();
     // g2 = da2 * act'(z_hat2 * w + b) -> A0, x_hat2 -> A1 (over z2)
-    for (int e = tid; e < DN_ROWS * d2; e += DN_THREADS) {
-        const int row = e >> lg2, c = e & (d2 - 1);
-        float da = 0.f;
-        for (int j = 0; j < d3; ++j) da = fmaf(dz3s[row * d3 + j], Hs3T[j * d2 + c], da);
-        const float xh = (A1[row * lda + c] - st2[c]) * st2[DN_MAXW + c];
-        const float pre = fmaf(xh, st2[2 * DN_MAXW + c], st2[3 * DN_MAXW + c]);
-        A0[row * lda + c] = rb + row < nvalid ? da * act_grad_rt(a.act, pre) : 0.f;
-        A1[row * lda + c] = xh;
-    }
+    // (the ReLU test sits outside the element loops here and below: inside, the run-time activation switch became a chain of
+    // scalar branches per element)
+    const bool relu = a.act == PHC_ACT_RELU;
+    auto g2_rows = [&](auto is_relu) {
+        for (int e = tid; e < DN_ROWS * d2; e += DN_THREADS) {
+            const int row = e >> lg2, c = e & (d2 - 1);
+            float da = 0.f;
+            for (int j = 0; j < d3; ++j) da = fmaf(dz3s[row * d3 + j], Hs3T[j * d2 + c], da);
+            const float xh = (A1[row * lda + c] - st2[c]) * st2[DN_MAXW + c];
+            const float pre = fmaf(xh, st2[2 * DN_MAXW + c], st2[3 * DN_MAXW + c]);
+            float g;
+            if constexpr (decltype(is_relu)::value)
+                g = pre > 0.f ? da : 0.f;
+            else
+                g = da * act_grad_rt(a.act, pre);
+            A0[row * lda + c] = rb + row < nvalid ? g : 0.f;
+            A1[row * lda + c] = xh;
+        }
+    };
+    if (relu)
+        g2_rows(std::true_type{});
+    else
+        g2_rows(std::false_type{});
     __syncthreads();
     bwd_norm(a, A0, A1, lda, d2, lg2, nvalid, rb, part1, tag, st2, a.dwb2, sc, T * d3 + T, a.dWr);
     store_rows(A0, lda, a.B, rb, d2, a.dz2);
     // da1 = dz2 . H2^T -> A1 (the GEMM's output slab); then g1 -> A0, x_hat1 -> A1 (z1 comes out of the registers)
     wg_gemm(A0, lda, Hs2T, d1 + 4, d2, d1, nullptr, red, A1, lda);
-    {
+    auto g1_rows = [&](auto is_relu) {
         const int w4 = d1 >> 2;
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
@@ -582,12 +596,22 @@ __global__ __launch_bounds__(DN_THREADS) void downstream_bwd_kernel(DnArgs a) {
                     const int c = c0 + q;
                     const float xh = row < rows_here ? (zq[q] - st1[c]) * st1[DN_MAXW + c] : 0.f;
                     const float pre = fmaf(xh, st1[2 * DN_MAXW + c], st1[3 * DN_MAXW + c]);
-                    A0[row * lda + c] = rb + row < nvalid ? A1[row * lda + c] * act_grad_rt(a.act, pre) : 0.f;
+                    const float da = A1[row * lda + c];
+                    float g;
+                    if constexpr (decltype(is_relu)::value)
+                        g = pre > 0.f ? da : 0.f;
+                    else
+                        g = da * act_grad_rt(a.act, pre);
+                    A0[row * lda + c] = rb + row < nvalid ? g : 0.f;
                     A1[row * lda + c] = xh;
                 }
             }
         }
-    }
+    };
+    if (relu)
+        g1_rows(std::true_type{});
+    else
+        g1_rows(std::false_type{});
     __syncthreads();
     bwd_norm(a, A0, A1, lda, d1, lg1, nvalid, rb, part2, tag, st1, a.dwb1, sc, 0, nullptr);
     store_rows(A0, lda, a.B, rb, d1, a.dz1);

@@ -440,31 +440,42 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
             const f32x4_t cw = *reinterpret_cast<const f32x4_t *>(ba_lds + 2 * K + 4 * dchunk), cb = *reinterpret_cast<const f32x4_t *>(ba_lds + 3 * K + 4 * dchunk);
             const f32x4_t cngx = *reinterpret_cast<const f32x4_t *>(ba_lds + 4 * K + 4 * dchunk), cng = *reinterpret_cast<const f32x4_t *>(ba_lds + 5 * K + 4 * dchunk);
             const f32x4_t c1 = *reinterpret_cast<const f32x4_t *>(ba_lds + 6 * K + 4 * dchunk);
+            // The activation switch stays OUTSIDE the element loops (one straight-line body per kind): as a per-element select
+            // chain hipcc turned it into ~20 scalar branches per element, 0.3-0.4 us of a 16-row step.
+            auto rows = [&](auto kind) {
+                constexpr int KIND = decltype(kind)::value;           // 0 identity, 1 relu, 2 any other (runtime switch per element)
 #pragma unroll
-            for (int u = 0; u < IPW; ++u) {
-                const int ii = wave + WAVES * u;
-                const long long row = step * RS + ii * RPI + dsub;
-                f32x4_t *p = ring + (size_t)tslot * SLOT_F4 + ii * ISTRIDE + lane;
-                const f32x4_t gv = *p, xv = p[IMG_F4];
-                f32x4_t o = zero4;
-                if (row < n_valid) {
+                for (int u = 0; u < IPW; ++u) {
+                    const int ii = wave + WAVES * u;
+                    const long long row = step * RS + ii * RPI + dsub;
+                    f32x4_t *p = ring + (size_t)tslot * SLOT_F4 + ii * ISTRIDE + lane;
+                    const f32x4_t gv = *p, xv = p[IMG_F4];
+                    f32x4_t o = zero4;
+                    if (row < n_valid) {
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        // dz = w invstd (g - mean g - x_hat mean(g x_hat)); x_hat and the pre-activation exactly as the separate
-                        // norm backward (and the reference) round them — (x - mean) invstd, then fma — so that an element
-                        // on the ReLU kink falls on the same side in every implementation of this pass
-                        const float xh = (xv[q] - cnm[q]) * ci[q];
-                        float g = gv[q];
-                        if (a.ba_act == PHC_ACT_RELU)
-                            g = fmaf(xh, cw[q], cb[q]) > 0.f ? g : 0.f;
-                        else if (a.ba_act != PHC_ACT_IDENTITY)
-                            g *= act_grad_rt(a.ba_act, fmaf(xh, cw[q], cb[q]));
-                        o[q] = c1[q] * (g + fmaf(xh, cngx[q], cng[q]));
+                        for (int q = 0; q < 4; ++q) {
+                            // dz = w invstd (g - mean g - x_hat mean(g x_hat)); x_hat and the pre-activation exactly as the separate
+                            // norm backward (and the reference) round them — (x - mean) invstd, then fma — so that an element
+                            // on the ReLU kink falls on the same side in every implementation of this pass
+                            const float xh = (xv[q] - cnm[q]) * ci[q];
+                            float g = gv[q];
+                            if constexpr (KIND == 1)
+                                g = fmaf(xh, cw[q], cb[q]) > 0.f ? g : 0.f;
+                            else if constexpr (KIND == 2)
+                                g *= act_grad_rt(a.ba_act, fmaf(xh, cw[q], cb[q]));
+                            o[q] = c1[q] * (g + fmaf(xh, cngx[q], cng[q]));
+                        }
                     }
+                    *p = o;
+                    if (row < a.M) *reinterpret_cast<f32x4_t *>(a.ba_dz + (size_t)row * K + 4 * dchunk) = o;
                 }
-                *p = o;
-                if (row < a.M) *reinterpret_cast<f32x4_t *>(a.ba_dz + (size_t)row * K + 4 * dchunk) = o;
-            }
+            };
+            if (a.ba_act == PHC_ACT_RELU)
+                rows(std::integral_constant<int, 1>{});
+            else if (a.ba_act == PHC_ACT_IDENTITY)
+                rows(std::integral_constant<int, 0>{});
+            else
+                rows(std::integral_constant<int, 2>{});
         }
     };
     if constexpr (XF || BA) {
@@ -559,17 +570,32 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
             }
             if constexpr (BW) {
                 if (row < n_valid) {
+                    auto sums = [&](auto kind) {                  // (the activation switch outside the element loops, as in `transform`)
+                        constexpr int KIND = decltype(kind)::value;
 #pragma unroll
-                    for (int t = 0; t < TPW; ++t)
+                        for (int t = 0; t < TPW; ++t)
 #pragma unroll
-                        for (int q = 0; q < 4; ++q) {
-                            const float xh = (bwx[rb][t][q] - bw_mean[t][q]) * bw_inv[t][q];
-                            const float z = fmaf(xh, bw_w[t][q], bw_b[t][q]);
-                            const float v = acc[rb][t][q];
-                            const float gq = a.bw_act == PHC_ACT_RELU ? (z > 0.f ? v : 0.f) : v * act_grad_rt(a.bw_act, z);
-                            bw_sg[t][q] += gq;
-                            bw_sgx[t][q] = fmaf(gq, xh, bw_sgx[t][q]);
-                        }
+                            for (int q = 0; q < 4; ++q) {
+                                const float xh = (bwx[rb][t][q] - bw_mean[t][q]) * bw_inv[t][q];
+                                const float z = fmaf(xh, bw_w[t][q], bw_b[t][q]);
+                                const float v = acc[rb][t][q];
+                                float gq;
+                                if constexpr (KIND == 1)
+                                    gq = z > 0.f ? v : 0.f;
+                                else if constexpr (KIND == 0)
+                                    gq = v;
+                                else
+                                    gq = v * act_grad_rt(a.bw_act, z);
+                                bw_sg[t][q] += gq;
+                                bw_sgx[t][q] = fmaf(gq, xh, bw_sgx[t][q]);
+                            }
+                    };
+                    if (a.bw_act == PHC_ACT_RELU)
+                        sums(std::integral_constant<int, 1>{});
+                    else if (a.bw_act == PHC_ACT_IDENTITY)
+                        sums(std::integral_constant<int, 0>{});
+                    else
+                        sums(std::integral_constant<int, 2>{});
                 }
             }
             if (row < a.M) {

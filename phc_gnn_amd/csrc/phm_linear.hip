@@ -689,14 +689,24 @@ __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
                                 const float ii[4] = {bw_inv[ct].x, bw_inv[ct].y, bw_inv[ct].z, bw_inv[ct].w};
                                 const float ww[4] = {bw_w[ct].x, bw_w[ct].y, bw_w[ct].z, bw_w[ct].w};
                                 const float bb[4] = {bw_b[ct].x, bw_b[ct].y, bw_b[ct].z, bw_b[ct].w};
+                                // (the ReLU test outside the element loop: inside, the run-time activation switch became a
+                                // chain of scalar branches per element)
+                                if (bw_act == PHC_ACT_RELU) {
 #pragma unroll
-                                for (int q = 0; q < 4; ++q) {
-                                    const float xh = (xs_[q] - mm[q]) * ii[q];
-                                    const float z = fmaf(xh, ww[q], bb[q]);
-                                    const float gq = bw_act == PHC_ACT_RELU ? (z > 0.f ? vs_[q] : 0.f)
-                                                                            : vs_[q] * act_grad_rt(bw_act, z);
-                                    bw_sg[ct][q] += gq;
-                                    bw_sgx[ct][q] = fmaf(gq, xh, bw_sgx[ct][q]);
+                                    for (int q = 0; q < 4; ++q) {
+                                        const float xh = (xs_[q] - mm[q]) * ii[q];
+                                        const float gq = fmaf(xh, ww[q], bb[q]) > 0.f ? vs_[q] : 0.f;
+                                        bw_sg[ct][q] += gq;
+                                        bw_sgx[ct][q] = fmaf(gq, xh, bw_sgx[ct][q]);
+                                    }
+                                } else {
+#pragma unroll
+                                    for (int q = 0; q < 4; ++q) {
+                                        const float xh = (xs_[q] - mm[q]) * ii[q];
+                                        const float gq = vs_[q] * act_grad_rt(bw_act, fmaf(xh, ww[q], bb[q]));
+                                        bw_sg[ct][q] += gq;
+                                        bw_sgx[ct][q] = fmaf(gq, xh, bw_sgx[ct][q]);
+                                    }
                                 }
                             }
                         }
