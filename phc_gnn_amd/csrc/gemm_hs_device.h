@@ -108,6 +108,18 @@ __device__ __forceinline__ void hs_dma16(const void *gsrc, unsigned lds_dst) {
                  : "memory");
 }
 
+// Loads that hipcc's wait-count insertion does not see (the caller waits with a counted s_waitcnt and ties the registers to it).
+__device__ __forceinline__ unsigned long long hs_ld64(const unsigned long long *p) {
+    unsigned long long v;
+    asm volatile("global_load_dwordx2 %0, %1, off" : "=&v"(v) : "v"(p) : "memory");
+    return v;
+}
+__device__ __forceinline__ float hs_ld32(const float *p) {
+    float v;
+    asm volatile("global_load_dword %0, %1, off" : "=&v"(v) : "v"(p) : "memory");
+    return v;
+}
+
 // sum over the 16 lanes that share kq (lanes kq * 16 .. + 15): xor offsets 1, 2, 4, 8 stay inside the group
 __device__ __forceinline__ double hs_sum16(double v) {
 #pragma unroll
@@ -163,7 +175,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
     float *ba_lds = xf_lds;                                       // BA: invstd | mean | w | b | -mean(g x_hat) | -mean g | w invstd   [7][K]
     const unsigned ring_lds = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(hs_lds_void *)smem);   // LDS byte address
 
-    unsigned long long st_t[3] = {0, 0, 0}, st_r[3] = {0, 0, 0};
+    unsigned long long st_t[3] = {0, 0, 0}, st_r[3] = {0, 0, 0}, dbg_t[3] = {0, 0, 0};
     if (a.stamps) { st_t[0] = __builtin_amdgcn_s_memtime(); st_r[0] = __builtin_amdgcn_s_memrealtime(); }
     const unsigned panel = blockIdx.x % (unsigned)a.panels, group = blockIdx.x / (unsigned)a.panels;
     const int tid = threadIdx.x, lane = tid & 63;
@@ -194,79 +206,70 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
                 hs_dma16(a.ba_x + (size_t)row * K + 4 * dchunk, ring_lds + 16u * (unsigned)(slot * SLOT_F4 + IMG_F4 + ii * ISTRIDE));
         }
     };
-    // BA: the accumulator words and norm constants of column `tid` go in flight FIRST (their consumer below waits for every
-    // older operation: behind the DMAs they would wait for the whole first ring fill and the operand slice too)
+    // BA / XF from an accumulator: the totals' words and the norm constants of column `tid` go in flight FIRST, as ASM loads with
+    // a counted wait of their own (ACC_YOUNGER below).  As ordinary loads hipcc waited for them with a count that leaves the
+    // ring's first fill out (it does not see the asm DMAs): the constants — and with them the first transform — came 5 us after
+    // entry instead of one memory round trip (scripts/dbg/hs_phases.py, prologue detail).  Only the K / 64 wavefronts that own
+    // a column load.
     unsigned long long ba_raw[(BA || XF) ? 2 : 1][(BA || XF) ? STAT_ACC_REP : 1][2];
     float ba_cst[4] = {0.f, 1.f, 1.f, 0.f};
     float xf_w = 1.f, xf_b = 0.f;
-    if constexpr (XF) {                                           // the same for an operand norm whose statistics are still totals
-        static_assert(K <= THREADS, "one column per thread in the XF prologue");
-        if (xa.acc) {
-            const int col = min(tid, K - 1);
-#pragma unroll
-            for (int qty = 0; qty < 2; ++qty)
-#pragma unroll
-                for (int rep = 0; rep < STAT_ACC_REP; ++rep) {
-                    const unsigned long long *p = xa.acc + ((size_t)(rep * 2 + qty) * 2) * K + col;
-                    ba_raw[qty][rep][0] = p[0];
-                    ba_raw[qty][rep][1] = p[K];
-                }
-            const int comp = col / xa.p.k, kk = col - comp * xa.p.k;
-            for (int q = 0; q < xa.p.n_comp; ++q)
-                if (q == comp) {
-                    if (xa.p.has_weight) xf_w = xa.p.weight[q][kk];
-                    if (xa.p.has_bias) xf_b = xa.p.bias[q][kk];
-                }
-        }
-    }
-    if constexpr (BA) {
-        static_assert(K <= THREADS, "one column per thread in the BA prologue");
-        const int col = min(tid, K - 1);
+    auto acc_loads = [&](const unsigned long long *acc) {
+        const unsigned long long *p0 = acc + tid;
 #pragma unroll
         for (int qty = 0; qty < 2; ++qty)
 #pragma unroll
             for (int rep = 0; rep < STAT_ACC_REP; ++rep) {
-                const unsigned long long *p = a.ba_acc + ((size_t)(rep * 2 + qty) * 2) * K + col;
-                ba_raw[qty][rep][0] = p[0];
-                ba_raw[qty][rep][1] = p[K];
+                const unsigned long long *p = p0 + ((size_t)(rep * 2 + qty) * 2) * K;
+                ba_raw[qty][rep][0] = hs_ld64(p);
+                ba_raw[qty][rep][1] = hs_ld64(p + K);
             }
-        ba_cst[0] = a.ba_stat[col];
-        ba_cst[1] = a.ba_stat[K + col];
-        ba_cst[2] = a.ba_stat[4 * K + col];
-        ba_cst[3] = a.ba_stat[5 * K + col];
+    };
+    if constexpr (XF) {                                           // an operand norm whose statistics are still totals
+        static_assert(K <= THREADS && K % 64 == 0, "one column per thread in the XF prologue");
+        if (xa.acc && tid < K) {
+            acc_loads(xa.acc);
+            const int comp = tid / xa.p.k, kk = tid - comp * xa.p.k;
+            // (always two loads — the counted wait below relies on it; without affine parameters they read accumulator words)
+            const float *pw = reinterpret_cast<const float *>(xa.acc), *pb = pw;
+            for (int q = 0; q < xa.p.n_comp; ++q)
+                if (q == comp) {
+                    if (xa.p.has_weight) pw = xa.p.weight[q] + kk;
+                    if (xa.p.has_bias) pb = xa.p.bias[q] + kk;
+                }
+            xf_w = hs_ld32(pw);
+            xf_b = hs_ld32(pb);
+        }
     }
+    if constexpr (BA) {
+        static_assert(K <= THREADS && K % 64 == 0, "one column per thread in the BA prologue");
+        if (tid < K) {
+            acc_loads(a.ba_acc);
+            ba_cst[0] = hs_ld32(a.ba_stat + tid);
+            ba_cst[1] = hs_ld32(a.ba_stat + K + tid);
+            ba_cst[2] = hs_ld32(a.ba_stat + 4 * K + tid);
+            ba_cst[3] = hs_ld32(a.ba_stat + 5 * K + tid);
+        }
+    }
+    // what a wavefront issues between those loads and their first use: the ring's first fill (bias and operand slice follow
+    // the constants)
+    constexpr int ACC_YOUNGER = (R - 1) * IPW * (BA ? 2 : 1);
+    static_assert(ACC_YOUNGER <= 63, "vmcnt is a 6-bit counter");
+    auto acc_arrived = [&]() {                                    // counted wait + the registers tied behind it
+        asm volatile("s_waitcnt vmcnt(%8)"
+                     : "+v"(ba_raw[0][0][0]), "+v"(ba_raw[0][0][1]), "+v"(ba_raw[0][1][0]), "+v"(ba_raw[0][1][1]), "+v"(ba_raw[0][2][0]),
+                       "+v"(ba_raw[0][2][1]), "+v"(ba_raw[0][3][0]), "+v"(ba_raw[0][3][1])
+                     : "n"(ACC_YOUNGER)
+                     : "memory");
+        asm volatile("" : "+v"(ba_raw[1][0][0]), "+v"(ba_raw[1][0][1]), "+v"(ba_raw[1][1][0]), "+v"(ba_raw[1][1][1]), "+v"(ba_raw[1][2][0]),
+                          "+v"(ba_raw[1][2][1]), "+v"(ba_raw[1][3][0]), "+v"(ba_raw[1][3][1]));
+        asm volatile("" : "+v"(ba_cst[0]), "+v"(ba_cst[1]), "+v"(ba_cst[2]), "+v"(ba_cst[3]), "+v"(xf_w), "+v"(xf_b));
+    };
+    static_assert(STAT_ACC_REP == 4, "acc_arrived lists the accumulator's registers by name");
 #pragma unroll
     for (int s = 0; s < R - 1; ++s) issue_step(s, s);
 
-    // (the accumulators start from the bias: its loads go in front of the operand slice's, or the first MFMA would wait for
-    // the youngest load of the prologue and with it for all of them)
     const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
-    f32x4_t bias4[TPW];
-#pragma unroll
-    for (int t = 0; t < TPW; ++t) {
-        // unconditional load (a null bias reads operand words and selects zero): the number of prologue loads is a constant
-        // of the kernel — the first step's counted wait relies on it (PRO_LOADS below)
-        const f32x4_t v = *reinterpret_cast<const f32x4_t *>((a.bias ? a.bias : a.hk4) + col0 + 16 * t + 4 * kq);
-        bias4[t] = a.bias ? v : zero4;
-    }
-    __builtin_amdgcn_sched_barrier(0);                            // (hipcc would otherwise issue these loads last)
-    // ---- operand slice -> registers (once per launch), k-group major: the first step consumes it in this order ----
-    f32x4_t hreg[TPW][G];
-    {
-        const f32x4_t *src = reinterpret_cast<const f32x4_t *>(a.hk4);
-#pragma unroll
-        for (int g = 0; g < G; ++g)
-#pragma unroll
-            for (int t = 0; t < TPW; ++t) hreg[t][g] = src[(size_t)(4 * g + kq) * Nout + col0 + c + 16 * t];
-    }
-    // fragment base of this lane per row block (float4 slots): row = rb * 16 + c
-    int fbase[RB];
-#pragma unroll
-    for (int rb = 0; rb < RB; ++rb) {
-        const int row = rb * 16 + c;
-        fbase[rb] = (row / RPI) * ISTRIDE + (row % RPI) * (K / 4) + (kq ^ (row % RPI));
-    }
-
     // ---- XF: scale / shift of the 4 operand columns this lane fetches (fixed for the launch) ----
     f32x4_t xsc = {1.f, 1.f, 1.f, 1.f}, xsh = zero4;
     if constexpr (XF) {
@@ -276,6 +279,9 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
             const bool owner = blockIdx.x == 0;
             if (tid < K) {
                 const int col = tid;
+                acc_arrived();
+                if (!xa.p.has_weight) xf_w = 1.f;
+                if (!xa.p.has_bias) xf_b = 0.f;
                 double tq[2];
 #pragma unroll
                 for (int qty = 0; qty < 2; ++qty) {
@@ -327,6 +333,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
     if constexpr (BA) {
         if (tid < K) {
             const int col = tid;
+            acc_arrived();
             double tot[2];
 #pragma unroll
             for (int qty = 0; qty < 2; ++qty) {
@@ -338,6 +345,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
                 }
                 tot[qty] = (double)hi * (1.0 / 4096.0) + (double)lo * (1.0 / 4611686018427387904.0);
             }
+            if (a.stamps) { asm volatile("" ::"v"(tot[0]), "v"(tot[1])); dbg_t[0] = __builtin_amdgcn_s_memrealtime(); }
             const float cnt = (float)max(a.ba_count > 0 ? a.ba_count : n_valid, 1LL);
             ba_lds[col] = ba_cst[1];
             ba_lds[K + col] = ba_cst[0];
@@ -354,7 +362,40 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
         // (a raw barrier: __syncthreads() would also wait for the operand slice and the ring's first fill)
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
+        if (a.stamps) dbg_t[1] = __builtin_amdgcn_s_memrealtime();
     }
+    // ---- bias and operand slice: issued BEHIND the XF / BA constants (when there are any).  In front of them their 256 KB per
+    // workgroup (every workgroup of the chip at once: the L2's bandwidth for 2-3 us) stood between the accumulator words and
+    // their consumer: the constants' barrier came 7.5 us after entry (scripts/dbg/hs_phases.py, prologue detail) ----
+    __builtin_amdgcn_sched_barrier(0);
+    // (the accumulators start from the bias: its loads go in front of the operand slice's, or the first MFMA would wait for
+    // the youngest load of the prologue and with it for all of them)
+    f32x4_t bias4[TPW];
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) {
+        // unconditional load (a null bias reads operand words and selects zero): the number of prologue loads is a constant
+        // of the kernel — the first step's counted wait relies on it (PRO_LOADS below)
+        const f32x4_t v = *reinterpret_cast<const f32x4_t *>((a.bias ? a.bias : a.hk4) + col0 + 16 * t + 4 * kq);
+        bias4[t] = a.bias ? v : zero4;
+    }
+    __builtin_amdgcn_sched_barrier(0);                            // (hipcc would otherwise issue these loads last)
+    // ---- operand slice -> registers (once per launch), k-group major: the first step consumes it in this order ----
+    f32x4_t hreg[TPW][G];
+    {
+        const f32x4_t *src = reinterpret_cast<const f32x4_t *>(a.hk4);
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) hreg[t][g] = src[(size_t)(4 * g + kq) * Nout + col0 + c + 16 * t];
+    }
+    // fragment base of this lane per row block (float4 slots): row = rb * 16 + c
+    int fbase[RB];
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb) {
+        const int row = rb * 16 + c;
+        fbase[rb] = (row / RPI) * ISTRIDE + (row % RPI) * (K / 4) + (kq ^ (row % RPI));
+    }
+
     // ---- BW: norm constants of the 4 columns this lane owns per tile, running sums ----
     f32x4_t bw_mean[BW ? TPW : 1], bw_inv[BW ? TPW : 1], bw_w[BW ? TPW : 1], bw_b[BW ? TPW : 1];
     f32x4_t bw_sg[BW ? TPW : 1], bw_sgx[BW ? TPW : 1];
@@ -480,6 +521,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
     };
     if constexpr (XF || BA) {
         hs_wait_vm<VM_KEEP + PRO_LOADS>();                        // DMA(0)
+        if (a.stamps) dbg_t[2] = __builtin_amdgcn_s_memrealtime();
         transform(0, 0);
     }
     int slot = 0;
@@ -660,6 +702,9 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
 #pragma unroll
             for (int i = 0; i < 4; ++i) o[6 + i] = ph[i];
             o[10] = (unsigned long long)my_steps;
+            // [11] prologue detail (BA): ticks from entry until the accumulator words arrived (bits 0-19), the constants' barrier
+            // (20-39), the first DMA image (40-59)
+            o[11] = ((dbg_t[0] - st_r[0]) & 0xfffff) | (((dbg_t[1] - st_r[0]) & 0xfffff) << 20) | (((dbg_t[2] - st_r[0]) & 0xfffff) << 40);
         }
     }
 }

@@ -91,6 +91,10 @@ for name, fn in (("plain", plain), ("ST", st), ("XF", xf), ("XF|ST", xf_st), ("B
         continue
     span = (w[:, 5].max() - w[:, 3].min()) * 0.01
     clk = ((w[:, 2] - w[:, 1]) / (w[:, 5] - w[:, 4]).clamp_min(1) * 0.1).median()
+    d11 = w[:, 11].long()
+    pd = [((d11 >> sh) & 0xfffff).double() * 0.01 for sh in (0, 20, 40)]
+    if name.startswith("BA"):
+        print(f"       prologue detail: accumulator words arrived med {pd[0][pd[0] > 0].median():5.2f} | constants in LDS + barrier {pd[1].median():5.2f} | first DMA image {pd[2].median():5.2f} us after entry")
     print(f"{name:6s} N={N} K={K} Nout={Nout}: {us:7.2f} us/launch | in-kernel span {span:6.2f} | prologue med {pro.median():5.2f} max {pro.max():5.2f} | loop med "
           f"{loop.median():6.2f} max {loop.max():6.2f} | per step: wait+barrier {ph[:, 0].median():5.2f}  issue+transform {ph[:, 1].median():5.2f}  "
           f"MFMA {ph[:, 2].median():5.2f}  epilogue {ph[:, 3].median():5.2f} | steps {int(steps.median())} | clock {clk:4.2f} GHz")
