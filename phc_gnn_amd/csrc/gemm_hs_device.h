@@ -211,9 +211,10 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
     // ring's first fill out (it does not see the asm DMAs): the constants — and with them the first transform — came 5 us after
     // entry instead of one memory round trip (scripts/dbg/hs_phases.py, prologue detail).  Only the K / 64 wavefronts that own
     // a column load.
+    // (the asm loads' destinations are never initialised, copied or merged with another value before `acc_arrived` has tied
+    // them to the counted wait: a register copy hipcc placed in between would read them before the data is there)
     unsigned long long ba_raw[(BA || XF) ? 2 : 1][(BA || XF) ? STAT_ACC_REP : 1][2];
-    float ba_cst[4] = {0.f, 1.f, 1.f, 0.f};
-    float xf_w = 1.f, xf_b = 0.f;
+    float cst_raw[4], xfw_raw, xfb_raw;
     auto acc_loads = [&](const unsigned long long *acc) {
         const unsigned long long *p0 = acc + tid;
 #pragma unroll
@@ -237,18 +238,18 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
                     if (xa.p.has_weight) pw = xa.p.weight[q] + kk;
                     if (xa.p.has_bias) pb = xa.p.bias[q] + kk;
                 }
-            xf_w = hs_ld32(pw);
-            xf_b = hs_ld32(pb);
+            xfw_raw = hs_ld32(pw);
+            xfb_raw = hs_ld32(pb);
         }
     }
     if constexpr (BA) {
         static_assert(K <= THREADS && K % 64 == 0, "one column per thread in the BA prologue");
         if (tid < K) {
             acc_loads(a.ba_acc);
-            ba_cst[0] = hs_ld32(a.ba_stat + tid);
-            ba_cst[1] = hs_ld32(a.ba_stat + K + tid);
-            ba_cst[2] = hs_ld32(a.ba_stat + 4 * K + tid);
-            ba_cst[3] = hs_ld32(a.ba_stat + 5 * K + tid);
+            cst_raw[0] = hs_ld32(a.ba_stat + tid);
+            cst_raw[1] = hs_ld32(a.ba_stat + K + tid);
+            cst_raw[2] = hs_ld32(a.ba_stat + 4 * K + tid);
+            cst_raw[3] = hs_ld32(a.ba_stat + 5 * K + tid);
         }
     }
     // what a wavefront issues between those loads and their first use: the ring's first fill (bias and operand slice follow
@@ -263,7 +264,8 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
                      : "memory");
         asm volatile("" : "+v"(ba_raw[1][0][0]), "+v"(ba_raw[1][0][1]), "+v"(ba_raw[1][1][0]), "+v"(ba_raw[1][1][1]), "+v"(ba_raw[1][2][0]),
                           "+v"(ba_raw[1][2][1]), "+v"(ba_raw[1][3][0]), "+v"(ba_raw[1][3][1]));
-        asm volatile("" : "+v"(ba_cst[0]), "+v"(ba_cst[1]), "+v"(ba_cst[2]), "+v"(ba_cst[3]), "+v"(xf_w), "+v"(xf_b));
+        if constexpr (BA) asm volatile("" : "+v"(cst_raw[0]), "+v"(cst_raw[1]), "+v"(cst_raw[2]), "+v"(cst_raw[3]));
+        if constexpr (XF) asm volatile("" : "+v"(xfw_raw), "+v"(xfb_raw));
     };
     static_assert(STAT_ACC_REP == 4, "acc_arrived lists the accumulator's registers by name");
 #pragma unroll
@@ -280,8 +282,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
             if (tid < K) {
                 const int col = tid;
                 acc_arrived();
-                if (!xa.p.has_weight) xf_w = 1.f;
-                if (!xa.p.has_bias) xf_b = 0.f;
+                const float xf_w = xa.p.has_weight ? xfw_raw : 1.f, xf_b = xa.p.has_bias ? xfb_raw : 0.f;
                 double tq[2];
 #pragma unroll
                 for (int qty = 0; qty < 2; ++qty) {
@@ -334,6 +335,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
         if (tid < K) {
             const int col = tid;
             acc_arrived();
+            const float ba_cst[4] = {cst_raw[0], cst_raw[1], cst_raw[2], cst_raw[3]};
             double tot[2];
 #pragma unroll
             for (int qty = 0; qty < 2; ++qty) {
