@@ -282,6 +282,11 @@ class EngineBackend:
     def linear_fwd_xf(self, z, save_stat, act, pre, b):
         return self._ops.gemm_pre_xf(z, save_stat, self._ops._act_id(act), pre, b)
 
+    def linear_fwd_xf_stats(self, z, save_stat, act, pre, b):
+        """(y, moments [2h] of y): the normalising GEMM with the statistics epilogue for the norm behind the layer."""
+        y, acc = self._ops.gemm_pre_xf(z, save_stat, self._ops._act_id(act), pre, b, want_stats=True)
+        return y, self._ops.stat_acc_read(acc, y.shape[1], max(y.shape[0], 1))
+
     def bn_bwd_sums_acc(self, dy, x, save_stat, act):
         return self._ops.bn_bwd_sums_acc(dy, x, save_stat, self._ops._act_id(act))
 
@@ -460,6 +465,20 @@ class ShardedAggregate:
 # ---------------------------------------------------------------------------------------------
 # 3. the sharded message-passing LAYER: aggregate -> + x -> linear1 -> norm (global statistics) -> act -> linear2
 # ---------------------------------------------------------------------------------------------
+class NormLink:
+    """Hand-over between a sharded conv and the model-level norm directly behind it (``ShardedGINEStack``), engine backend with
+    the folded norm forms only.  Forward: the conv's second GEMM leaves the column statistics of its output here (``moments``:
+    the norm skips its pass over y).  Backward: the norm takes its column sums, all-reduces them and PARKS (dout, y, save_stat,
+    sums, activation) instead of applying them; the conv's backward runs the element-wise part inside its first dx GEMM
+    (``phc_gemm_bwd_apply``).  The conv's output must feed that norm and nothing else."""
+    __slots__ = ("fused", "moments", "parked")
+
+    def __init__(self):
+        self.fused = False
+        self.moments = None
+        self.parked = None
+
+
 class _ShardedGINEFn(torch.autograd.Function):
     """PHMGINEConv.forward (messagepassing.py:132-146) + PHMMLP.forward (layers.py:349-355) on one destination-range
     shard, forward and backward written out so that every exchange has compute queued next to it:
@@ -473,7 +492,7 @@ class _ShardedGINEFn(torch.autograd.Function):
     them up); batch statistics, running statistics and dx are those of the unsharded layer."""
 
     @staticmethod
-    def forward(ctx, layer: "ShardedPHMGINEConv", x_own, ea_loc, ea_halo, A1, W1, b1, A2, W2, b2, *affine):
+    def forward(ctx, layer: "ShardedPHMGINEConv", link: Optional[NormLink], x_own, ea_loc, ea_halo, A1, W1, b1, A2, W2, b2, *affine):
         agg, be, plan = layer.agg, layer.agg.backend, layer.agg.plan
         mlp = layer.conv.transform
         act_msg, act = layer.msg_encoder, mlp.activation_str
@@ -491,7 +510,10 @@ class _ShardedGINEFn(torch.autograd.Function):
             mom_flat = torch.empty(plan.world * mom.numel(), dtype=mom.dtype, device=mom.device)
             dist.all_gather_into_tensor(mom_flat, mom, group=plan.group)      # 2h floats per rank
             save_stat = be.bn_finalize_from_moments(mom_flat.view(plan.world, mom.numel()), layer.counts_all, layer.n_total, norm, z.shape[1])
-            y = be.linear_fwd_xf(z, save_stat, act, pre[1], b2)               # act(norm(z)) exists only in the GEMM's LDS
+            if link is not None:                                              # + the statistics of y for the model's norm behind
+                y, link.moments = be.linear_fwd_xf_stats(z, save_stat, act, pre[1], b2)
+            else:
+                y = be.linear_fwd_xf(z, save_stat, act, pre[1], b2)           # act(norm(z)) exists only in the GEMM's LDS
             a = z.new_empty(0)
         else:
             z = be.linear_fwd_pre(s, pre[0], b1) if pre is not None else be.linear_fwd(s, A1, W1, b1)
@@ -507,6 +529,9 @@ class _ShardedGINEFn(torch.autograd.Function):
                 a = layer.act_fn(z)
             y = be.linear_fwd_pre(a, pre[1], b2) if pre is not None else be.linear_fwd(a, A2, W2, b2)
         ctx.layer = layer
+        ctx.link = link if (link is not None and fused) else None
+        if link is not None:
+            link.fused = fused
         ctx.has_ea = (ea_loc is not None, ea_halo is not None)
         ctx.has_bias = (b1 is not None, b2 is not None)
         ctx.n_affine = len(affine)
@@ -524,9 +549,18 @@ class _ShardedGINEFn(torch.autograd.Function):
         x_own, recv, ea_loc, ea_halo, s, z, a, save_stat, A1, W1, A2, W2 = ctx.saved_tensors
         ea_loc = ea_loc if ctx.has_ea[0] else None
         ea_halo = ea_halo if ctx.has_ea[1] else None
-        dy = dy.contiguous()
         pre = ctx.pre
-        da = be.linear_dx_pre(dy, pre[1]) if pre is not None else be.linear_dx(dy, A2, W2)
+        link = ctx.link
+        if link is not None and link.parked is not None:
+            # the model's norm behind this conv left its backward un-applied: dy (its dx) is evaluated inside the dx GEMM
+            dout, y_in, stat_o, acc_o, act_o = link.parked
+            link.parked = None
+            if dy.data_ptr() != dout.data_ptr():
+                raise RuntimeError("NormLink: the conv's output was consumed by something besides its norm")
+            dy, da = be.linear_dx_bwd_apply(dout, y_in, stat_o, acc_o, layer.n_total, act_o, pre[1])
+        else:
+            dy = dy.contiguous()
+            da = be.linear_dx_pre(dy, pre[1]) if pre is not None else be.linear_dx(dy, A2, W2)
         if ctx.fused:
             h = z.shape[1]
             acc = be.bn_bwd_sums_acc(da, z, save_stat, act)                   # this rank's sum g | sum g x_hat, integer totals
@@ -546,7 +580,7 @@ class _ShardedGINEFn(torch.autograd.Function):
             dz = layer.act_bwd(z, da)
         if not ctx.fused:
             ds = be.linear_dx_pre(dz, pre[0]) if pre is not None else be.linear_dx(dz, A1, W1)
-        need_dea = (ctx.needs_input_grad[2] and ea_loc is not None, ctx.needs_input_grad[3] and ea_halo is not None)
+        need_dea = (ctx.needs_input_grad[3] and ea_loc is not None, ctx.needs_input_grad[4] and ea_halo is not None)
 
         def param_grads():                                                    # queued while the halo gradients travel
             g2 = (be.linear_param_grads_xf(z, save_stat, act, dy, A2, W2, ctx.has_bias[1]) if ctx.fused
@@ -561,7 +595,7 @@ class _ShardedGINEFn(torch.autograd.Function):
             n = ctx.n_affine // 2
             k = z.shape[1] // n
             aff = [dwb[c * k:(c + 1) * k] for c in range(n)] + [dwb[n * k + c * k:n * k + (c + 1) * k] for c in range(n)]
-        return (None, d_own if ctx.needs_input_grad[1] else None, dea_loc, dea_halo, g1[0], g1[1], g1[2], g2[0], g2[1], g2[2], *aff)
+        return (None, None, d_own if ctx.needs_input_grad[2] else None, dea_loc, dea_halo, g1[0], g1[1], g1[2], g2[0], g2[1], g2[2], *aff)
 
 
 class ShardedPHMGINEConv(torch.nn.Module):
@@ -592,7 +626,8 @@ class ShardedPHMGINEConv(torch.nn.Module):
             out = self.act_fn(zr)
         return torch.autograd.grad(out, zr, da)[0]
 
-    def forward(self, x_own: torch.Tensor, ea_loc: Optional[torch.Tensor], ea_halo: Optional[torch.Tensor]) -> torch.Tensor:
+    def forward(self, x_own: torch.Tensor, ea_loc: Optional[torch.Tensor], ea_halo: Optional[torch.Tensor],
+                link: Optional[NormLink] = None) -> torch.Tensor:
         mlp = self.conv.transform
         if not self.training:
             raise NotImplementedError("ShardedPHMGINEConv: training-mode statistics only (eval uses the running statistics of "
@@ -605,7 +640,7 @@ class ShardedPHMGINEConv(torch.nn.Module):
             if nb.affine:
                 affine = [m.weight for m in nb.bn] + [m.bias for m in nb.bn]
         l1, l2 = mlp.linear1, mlp.linear2
-        return _ShardedGINEFn.apply(self, x_own, ea_loc, ea_halo, l1.phm_rule, l1.W, l1.b, l2.phm_rule, l2.W, l2.b, *affine)
+        return _ShardedGINEFn.apply(self, link, x_own, ea_loc, ea_halo, l1.phm_rule, l1.W, l1.b, l2.phm_rule, l2.W, l2.b, *affine)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -617,15 +652,19 @@ class _ShardedNormActFn(torch.autograd.Function):
     gradients come out as this rank's partial sums, like every other parameter gradient of the sharded path."""
 
     @staticmethod
-    def forward(ctx, x, residual, mod: "ShardedPHMNorm", *affine):
+    def forward(ctx, x, residual, mod: "ShardedPHMNorm", link: Optional[NormLink], *affine):
         be, plan, norm = mod.backend, mod.plan, mod.norm.bn
         x = x.contiguous()
-        mom = be.bn_moments(x)
+        linked = link is not None and link.fused and link.moments is not None
+        mom = link.moments if linked else be.bn_moments(x)        # linked: the producing GEMM's epilogue already has them
+        if linked:
+            link.moments = None
         mom_flat = torch.empty(plan.world * mom.numel(), dtype=mom.dtype, device=mom.device)
         dist.all_gather_into_tensor(mom_flat, mom, group=plan.group)
         out, save_stat = be.bn_fwd_from_moments(x, mom_flat.view(plan.world, mom.numel()), mod.counts_all, mod.n_total, norm,
                                                 mod.activation, residual)
         ctx.mod = mod
+        ctx.link = link if linked else None
         ctx.has_res = residual is not None
         ctx.n_affine = len(affine)
         ctx.save_for_backward(x, save_stat)
@@ -637,17 +676,29 @@ class _ShardedNormActFn(torch.autograd.Function):
         be, plan = mod.backend, mod.plan
         x, save_stat = ctx.saved_tensors
         dout = dout.contiguous()
-        dwb = be.bn_bwd_sums(dout, x, save_stat, mod.activation)
-        dwb_all = dwb.clone()
-        dist.all_reduce(dwb_all, op=dist.ReduceOp.SUM, group=plan.group)
-        dx = be.bn_bwd_apply(dout, x, save_stat, dwb_all, mod.n_total, mod.activation)
+        if ctx.link is not None:
+            # column sums as integer totals, all-reduced exactly; the element-wise part runs inside the conv's dx GEMM (NormLink)
+            h = x.shape[1]
+            acc = be.bn_bwd_sums_acc(dout, x, save_stat, mod.activation)
+            dwb = None
+            if ctx.n_affine:
+                tot = be.acc_totals(acc, h)
+                dwb = torch.cat([tot[h:], tot[:h]])                           # dweight | dbias, this rank's partial
+            dist.all_reduce(acc, op=dist.ReduceOp.SUM, group=plan.group)
+            ctx.link.parked = (dout, x, save_stat, acc, mod.activation)
+            dx = dout                                                         # placeholder: the conv's backward takes the parked operands
+        else:
+            dwb = be.bn_bwd_sums(dout, x, save_stat, mod.activation)
+            dwb_all = dwb.clone()
+            dist.all_reduce(dwb_all, op=dist.ReduceOp.SUM, group=plan.group)
+            dx = be.bn_bwd_apply(dout, x, save_stat, dwb_all, mod.n_total, mod.activation)
         aff = []
         if ctx.n_affine:
             n = ctx.n_affine // 2
             h = x.shape[1]
             k = h // n
             aff = [dwb[c * k:(c + 1) * k] for c in range(n)] + [dwb[h + c * k:h + (c + 1) * k] for c in range(n)]
-        return (dx, dout if ctx.has_res else None, None, *aff)
+        return (dx, dout if ctx.has_res else None, None, None, *aff)
 
 
 class ShardedPHMNorm(torch.nn.Module):
@@ -665,12 +716,12 @@ class ShardedPHMNorm(torch.nn.Module):
         dev = plan.loc_edge_index.device
         self.counts_all = torch.tensor([float(bounds[r + 1] - bounds[r]) for r in range(plan.world)], dtype=torch.float32, device=dev)
 
-    def forward(self, x_own: torch.Tensor, residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    def forward(self, x_own: torch.Tensor, residual: Optional[torch.Tensor] = None, link: Optional[NormLink] = None) -> torch.Tensor:
         nb = self.norm.bn
         if not self.training or not hasattr(nb, "bn") or not nb.track_running_stats:
             raise NotImplementedError("ShardedPHMNorm: training-mode naive-batch-norm with running statistics only")
         affine = ([m.weight for m in nb.bn] + [m.bias for m in nb.bn]) if nb.affine else []
-        return _ShardedNormActFn.apply(x_own, residual, self, *affine)
+        return _ShardedNormActFn.apply(x_own, residual, self, link, *affine)
 
 
 class ShardedGINEStack(torch.nn.Module):
@@ -688,5 +739,6 @@ class ShardedGINEStack(torch.nn.Module):
     def forward(self, x_own, ea_loc, ea_halo):
         h = x_own
         for layer, norm in zip(self.layers, self.norms):
-            h = norm(layer(h, ea_loc, ea_halo), residual=h)
+            link = NormLink()                   # (does nothing unless the engine's folded norm forms serve the layer)
+            h = norm(layer(h, ea_loc, ea_halo, link=link), residual=h, link=link)
         return h

@@ -1207,8 +1207,9 @@ def bn_finalize_from_moments(moments_all, counts_all, n_total, weights, biases, 
     return save_stat
 
 
-def gemm_pre_xf(x: torch.Tensor, save_stat: torch.Tensor, act: int, pre, bias: Optional[torch.Tensor]) -> torch.Tensor:
-    """y = act(batch_norm(x)) . H + bias with the norm (save_stat) applied to the operand as it streams in."""
+def gemm_pre_xf(x: torch.Tensor, save_stat: torch.Tensor, act: int, pre, bias: Optional[torch.Tensor], want_stats: bool = False):
+    """y = act(batch_norm(x)) . H + bias with the norm (save_stat) applied to the operand as it streams in; ``want_stats``:
+    (y, acc) with the column statistics of y (sum | sum of squares) in a fresh accumulator."""
     lib = L.load()
     dev = L.require_device(x, save_stat)
     x_ = L.f32c(x)
@@ -1216,11 +1217,12 @@ def gemm_pre_xf(x: torch.Tensor, save_stat: torch.Tensor, act: int, pre, bias: O
     K, Nout = M.shape
     N = x_.shape[0]
     y = torch.empty((N, Nout), dtype=torch.float32, device=dev)
+    acc = new_stat_acc(Nout, dev) if want_stats else None
     L.check(lib.phc_gemm_prebuilt_xf(L.ptr(x_), L.ptr(save_stat), int(act), None, L.ptr(M), L.ptr(Mk4), None if bias is None else L.ptr(L.f32c(bias)),
-                                     N, K, Nout, L.ptr(y), None, None, None, L.stream_ptr(dev)), "phc_gemm_prebuilt_xf")
+                                     N, K, Nout, L.ptr(y), L.ptr(acc), None, None, L.stream_ptr(dev)), "phc_gemm_prebuilt_xf")
     if L.PROF_ON:
         L.account("phm_gemm_fwd", 2.0 * N * K * Nout, 4.0 * (N * (K + Nout) + K * Nout))
-    return y
+    return (y, acc) if want_stats else y
 
 
 def bn_bwd_sums_acc(dy: torch.Tensor, x: torch.Tensor, save_stat: torch.Tensor, act: int) -> torch.Tensor:

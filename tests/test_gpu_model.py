@@ -577,6 +577,57 @@ def _loopback_plan(ei, N, frac=0.5):
                     halo_edge_ids=halo_pos, group=None)
 
 
+def test_sharded_stack_norm_link_equals_unlinked_stack(rccl_single_rank):
+    """ShardedGINEStack with the model-level norms LINKED to their convs (statistics of y out of the conv's second GEMM, the norm's
+    backward applied inside the conv's first dx GEMM: dist.NormLink) against the same stack with every norm pass a launch of its
+    own (EngineBackend.FUSED_NORM off): outputs, dx, d edge_attr, every parameter gradient, running statistics; swish (smooth)."""
+    from phc.hypercomplex.norm import PHMNorm
+    from phc.hypercomplex.undirectional.messagepassing import PHMGINEConv
+    from phc_gnn_amd import synth
+    from phc_gnn_amd.dist import EngineBackend, ShardedGINEStack
+    n, h, N, E, LAYERS = 4, 128, 20_001, 90_000, 3
+    ei = torch.from_numpy(synth.random_edges(N, E, seed=31)).to(DEV)
+    g = torch.Generator().manual_seed(32)
+    x, dy, ea = torch.randn(N, h, generator=g), torch.randn(N, h, generator=g), torch.randn(E, h, generator=g)
+    res = []
+    for fused in (True, False):
+        torch.manual_seed(6)
+        np.random.seed(6)
+        convs = [PHMGINEConv(h, h, phm_dim=n, phm_rule=None, norm="naive-batch-norm", activation="swish", msg_encoder="identity")
+                 for _ in range(LAYERS)]
+        norms = [PHMNorm(num_features=h, phm_dim=n, type="naive-batch-norm") for _ in range(LAYERS)]
+        gw = torch.Generator().manual_seed(33)
+        with torch.no_grad():
+            for mod in convs + norms:
+                for name, p in mod.named_parameters():
+                    if p.dim() == 1:
+                        p.copy_(0.5 + torch.rand(p.shape, generator=gw) if name.endswith("weight") else 0.1 * torch.randn(p.shape, generator=gw))
+        for m in convs + norms:
+            m.to(DEV).train()
+        old = EngineBackend.FUSED_NORM
+        EngineBackend.FUSED_NORM = fused
+        try:
+            plan = _loopback_plan(ei, N)
+            stack = ShardedGINEStack(convs, norms, plan, N, activation="swish").train()
+            xd = x.to(DEV).requires_grad_()
+            el, eh = stack.agg.split_edge_attr(ea.to(DEV))
+            el, eh = el.requires_grad_(), eh.requires_grad_()
+            y = stack(xd, el, eh)
+            y.backward(dy.to(DEV))
+            torch.cuda.synchronize()
+        finally:
+            EngineBackend.FUSED_NORM = old
+        out = dict(y=y.detach().cpu(), dx=xd.grad.cpu(), dl=el.grad.cpu(), dh=eh.grad.cpu())
+        for i, m in enumerate(convs + norms):
+            out.update({f"g{i}." + k: q.grad.cpu() for k, q in m.named_parameters()})
+            out.update({f"b{i}." + k: b.cpu().float() for k, b in m.named_buffers()})
+        res.append(out)
+    for k in res[0]:
+        if k.endswith("linear1.b") or k.endswith("linear2.b"):      # a bias in front of a batch-norm: zero up to round-off on both sides
+            continue
+        assert_close(res[0][k], res[1][k], 3e-5, k)
+
+
 def test_sharded_gine_layer_norm_folded_into_gemms_equals_separate_passes(rccl_single_rank):
     """The sharded layer's norm inside its GEMMs (statistics epilogue -> moments, normalising operand, norm backward in the dx
     GEMM on all-reduced integer sums) against the same layer with the four norm passes as launches of their own

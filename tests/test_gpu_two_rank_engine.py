@@ -128,7 +128,12 @@ def test_two_rank_engine_stack_equals_single_process_and_oracle(tmp_path, activa
             return assert_close(got, ref, 3e-5, what)
         scale = float(ref.abs().max())
         bad = ((got - ref).abs().amax(dim=1) > 3e-5 * scale)
-        assert int(bad.sum()) <= max(8, got.shape[0] // 500), f"{what}: {int(bad.sum())} of {got.shape[0]} rows differ"
+        # one flipped gate in the top layer reaches (1 + E / N) ** LAYERS rows of dx through the aggregations' backward (42 here);
+        # with 10 M pre-activations per step and statistics that differ in the last bit between a GEMM epilogue's one pass and
+        # the oracle's two, a handful of flips is the expectation: room for four
+        per_flip = (1.0 + C.N_EDGES / C.N_NODES) ** C.LAYERS
+        allowed = max(8, got.shape[0] // 500, int(4 * per_flip))
+        assert int(bad.sum()) <= allowed, f"{what}: {int(bad.sum())} of {got.shape[0]} rows differ (allowed {allowed})"
     assert_close(y2, href.detach(), tol_y, "2 ranks vs oracle: y")
     assert_close(y2, hcur.detach().cpu(), tol_y, "2 ranks vs 1 process: y")
     rows_close(gx2, gref[0], "2 ranks vs oracle: dx")
