@@ -89,3 +89,54 @@ def test_statistics_gemm_into_an_accumulator_matches_float64(N, h, scale):
     # tolerance: y itself is fp32 — a column with |mean| / std ~ 300 keeps only ~4.5 digits of its deviations
     assert_close(out[:, 1:], ref[:, 1:].float(), 2e-5, "normalised output")
     assert_close(out[:, 0], ref[:, 0].float(), 5e-3, "normalised output, offset column")
+
+
+@pytest.mark.parametrize("N,h", [(20001, 128), (70001, 256), (513, 128)])
+def test_accumulator_read_back_and_row_sharded_norm_backward(N, h):
+    """The two entry points the row-sharded norm adds to the accumulator protocol (dist._ShardedGINEFn), through the C ABI:
+    phc_stat_acc_read turns a statistics epilogue's totals into the (sum, M2) pair phc_bn_moments produces (float64 reference),
+    and phc_gemm_bwd_apply with phc_gemm_ba_desc.count = rows of ALL shards, run shard by shard on accumulators that were added
+    as integers (what the all-reduce does), gives the rows of ONE launch over all rows — dz and dz . H^T to fp32 round-off."""
+    from phc_gnn_amd import ops
+    g = torch.Generator().manual_seed(N + h)
+    n, k = 4, h // 4
+    A = torch.randn(n, n, n, generator=g).to(DEV)
+    W = (torch.randn(n, k, k, generator=g) * 0.1).to(DEV)
+    b = torch.randn(h, generator=g).to(DEV)
+    pre = ops.phm_build_operands([(A, W)])[0]
+    x = torch.randn(N, h, generator=g).to(DEV)
+    # forward statistics: epilogue totals -> (sum, M2)
+    y, acc = ops.gemm_pre_stats(x, pre, b)
+    mom = ops.stat_acc_read(acc, h, N).cpu().double()
+    y64 = y.cpu().double()
+    assert_close(mom[:h], y64.sum(0), 2e-6, "sum")
+    assert_close(mom[h:], ((y64 - y64.mean(0)) ** 2).sum(0), 2e-5, "M2")
+    tot = ops.stat_acc_read(acc, h, 0).cpu().double()
+    assert_close(tot[h:], (y64 ** 2).sum(0), 2e-5, "sum of squares (count = 0: raw totals)")
+    # backward: one launch over all rows against two "ranks" with added accumulators and count = N
+    dy = torch.randn(N, h, generator=g).to(DEV)
+    mean, var = y64.mean(0), y64.var(0, unbiased=False)
+    w = (0.5 + torch.rand(h, generator=g)).double()
+    bb = (0.1 * torch.randn(h, generator=g)).double()
+    invstd = 1.0 / torch.sqrt(var + 1e-5)
+    stat = torch.cat([mean, invstd, invstd * w, bb - mean * invstd * w, w, bb]).float().to(DEV)
+    for act in (1, 4):                                           # relu, swish (include/phc_hip.h PHC_ACT_*)
+        acc_all = ops.bn_bwd_sums_acc(dy, y, stat, act)
+        dz_all, ds_all = ops.gemm_pre_bwd_apply(dy, y, stat, acc_all, 0, act, pre)
+        cut = N // 2 + 1
+        parts = [(0, cut), (cut, N)]
+        accs = [ops.bn_bwd_sums_acc(dy[lo:hi], y[lo:hi], stat, act) for lo, hi in parts]
+        # integer words: exactly what an all-reduce(SUM) leaves on every rank, in any reduction order (the shards' own fp32
+        # partial sums differ from the single launch's, so the totals agree to fp32 round-off, not bit for bit)
+        summed = accs[0] + accs[1]
+        assert torch.equal(summed, accs[1] + accs[0])
+        assert_close(ops.stat_acc_read(summed, h, 0), ops.stat_acc_read(acc_all, h, 0), 2e-6, f"summed totals act {act}")
+        for lo, hi in parts:
+            dz, ds = ops.gemm_pre_bwd_apply(dy[lo:hi].contiguous(), y[lo:hi].contiguous(), stat, summed, N, act, pre)
+            assert_close(dz, dz_all[lo:hi], 2e-6, f"dz rows {lo}:{hi} act {act}")
+            assert_close(ds, ds_all[lo:hi], 2e-6, f"ds rows {lo}:{hi} act {act}")
+        # and against the stand-alone passes (phc_bn_bwd_sums / phc_bn_bwd_apply) + plain dx GEMM
+        dwb = ops.bn_bwd_sums(dy, y, stat, act)
+        dz_ref = ops.bn_bwd_apply(dy, y, stat, dwb, N, act)
+        assert_close(dz_all, dz_ref, 2e-5, f"dz vs stand-alone passes act {act}")
+        assert_close(ds_all, ops.phm_linear_pre(dz_ref, pre, None, dx=True), 2e-5, f"ds vs stand-alone passes act {act}")
