@@ -1204,6 +1204,9 @@ constexpr int GEMM_PREBUILT_MAX_K = 768;
 constexpr int64_t GEMM_BIG_M = 64 * 1024;
 // K > 128 (hidden 256): rows from which the 64-column / 8-wave configuration (one panel per CU shared by 8 wavefronts, x
 // read 4x) takes over from the 32-column / 4-wave one (two workgroups per CU, x read 8x).  PHC_GEMM_WIDE_K_M overrides.
+// ... and the contraction depth from which it does: the published 180-wide model (run_script_zinc_phm4.sh) runs 1.756 -> 1.622 ms per
+// step on the 32-column configuration, the 200-wide one 1.940 -> 1.972 ms (alternating runs, PHC_GEMM_WIDE_K_M = 16384 / 1000000)
+constexpr int GEMM_WIDE_K_MIN = 192;
 static inline int64_t gemm_wide_k_m() {
     // measured (bench.py, one MI355X): zinc_b1024 (23.6 k rows, PHM-8 hidden 256) 2.75 -> 2.58 ms, molpcba_b1024 (27.2 k rows)
     // 3.42 -> 3.19 ms per training step with the 8-wave configuration instead of 2 x (32 columns, 4 waves) per CU
@@ -1696,7 +1699,7 @@ int phc_gemm_prebuilt(const float *x, const float *M, const float *Mk4, const fl
     // each half as long — measured 0.8 us per launch faster than 64-column panels at N = 13.8k; above that the extra
     // re-reads of x cost more than the occupancy gains.  PHC_GEMM_PRE_BN=64 forces the wider panel.
     static const int small_bn = getenv("PHC_GEMM_PRE_BN") ? atoi(getenv("PHC_GEMM_PRE_BN")) : 32;
-    if (N >= gemm_wide_k_m() && Nout > 64 && K > 128)
+    if (N >= gemm_wide_k_m() && Nout > 64 && K > GEMM_WIDE_K_MIN)
         launch_stream_cfg<0, -1, 64, 8>(x, nullptr, M, b, residual, y, N, K, Nout, 1, K, Nout, 1, s);
     else if (N >= GEMM_BIG_M && Nout > 64)
         launch_stream_cfg<0, -1, 128, 8>(x, nullptr, M, b, residual, y, N, K, Nout, 1, K, Nout, 1, s);
@@ -1734,7 +1737,7 @@ int phc_gemm_prebuilt_stats(const float *x, const float *M, const float *Mk4, co
     if (K > GEMM_STREAM_MAX_K)                               // deep contraction: 32-column panels, one workgroup per CU
         launch_stream_cfg<0, -1, 32, 4, 1>(x, nullptr, M, b, nullptr, y, N, K, Nout, 1, K, Nout, 1, s, n_valid_dev, stats_partial,
                                            stats_counts, num_partials, nullptr, 0, nullptr, nullptr, 0, acc);
-    else if (N >= gemm_wide_k_m() && Nout > 64 && K > 128)
+    else if (N >= gemm_wide_k_m() && Nout > 64 && K > GEMM_WIDE_K_MIN)
         launch_stream_cfg<0, -1, 64, 8, 1>(x, nullptr, M, b, nullptr, y, N, K, Nout, 1, K, Nout, 1, s, n_valid_dev, stats_partial,
                                            stats_counts, num_partials, nullptr, 0, nullptr, nullptr, 0, acc);
     else if (N >= GEMM_BIG_M && Nout > 64)
@@ -1811,7 +1814,7 @@ static int gemm_prebuilt_xf_impl(const float *x, const float *xf_stat, int xf_ac
     const bool big = N >= GEMM_BIG_M && Nout > 64;
     const bool small = small_bn == 32 && Nout > 32 && N <= 32 * 1024;
 #define PHC_XF_LAUNCH(SV)                                                                                                      \
-    if (N >= gemm_wide_k_m() && Nout > 64 && K > 128)                                                                          \
+    if (N >= gemm_wide_k_m() && Nout > 64 && K > GEMM_WIDE_K_MIN)                                                                          \
         launch_stream_cfg<0, -1, 64, 8, SV>(x, nullptr, M, b, nullptr, y, N, K, Nout, 1, K, Nout, 1, s, n_valid_dev, stats_partial, \
                                             stats_counts, num_partials, xf_stat, xf_act, nullptr, nullptr, 0, acc, xa);              \
     else if (big)                                                                                                               \
@@ -1858,7 +1861,7 @@ int phc_gemm_prebuilt_bwsums(const float *dy, const float *M, const float *Mk4, 
         return check_launch("phc_gemm_prebuilt_bwsums(hs)");
     }
     static const int small_bn = getenv("PHC_GEMM_PRE_BN") ? atoi(getenv("PHC_GEMM_PRE_BN")) : 32;
-    if (N >= gemm_wide_k_m() && Nout > 64 && K > 128)
+    if (N >= gemm_wide_k_m() && Nout > 64 && K > GEMM_WIDE_K_MIN)
         launch_stream_cfg<0, -1, 64, 8, 4>(dy, nullptr, M, nullptr, nullptr, dz, N, K, Nout, 1, K, Nout, 1, s, n_valid_dev, sums_partial,
                                            nullptr, num_partials, nullptr, 0, bn_x, bn_stat, act, acc);
     else if (N >= GEMM_BIG_M && Nout > 64)
