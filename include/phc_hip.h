@@ -121,8 +121,21 @@ typedef struct phc_phm_H_job {
      * [Kd / 4][Nd] float4, slot (k / 4) * Nd + j = rows 4 (k / 4) .. +3 of column j (Kd % 4 == 0; PHM jobs only).  A lane of
      * v_mfma_f32_16x16x4_f32 then fetches its operands of four consecutive k-steps with ONE 16-byte access. */
     float *Hk4, *HTk4;
+    /* flags == 3 (ABI 4): the read-out's gate as ONE linear map.  pooling.py:57-66 computes Linear_{h -> kg}(PHMLinear_{in -> h}(x))
+     * with nothing between the two maps: x . M + c with M = H(A, W) . gate_w^T [in, kg] and c = phm_b . gate_w^T + gate_b is the
+     * same function (fp32 round-off apart) with one small operand.  The job writes H := M, HT := M^T (may be NULL) and gate_c;
+     * Hk4 / HTk4 must be NULL.  gate_w [kg, h] is the nn.Linear weight, gate_b [kg] / phm_b [h] may be NULL. */
+    const float *gate_w, *gate_b, *phm_b;
+    float *gate_c;
+    int32_t gate_k;
 } phc_phm_H_job;
 int phc_phm_build_H_batched(const phc_phm_H_job *jobs, int num_jobs, void *stream);
+/* Parameter gradients of that gate map from dM^T = dg^T . x [kg, in] and dbg = sum dg [kg] (what a dense parameter-gradient job
+ * with x and dg leaves behind): dH = dM . gate_w is re-evaluated where needed (never stored), dA / dW its contractions with W / A,
+ * dWg = dM^T . H + dbg (x) phm_b, db = dbg . gate_w.  H [in, h] is the PHM layer's operand matrix (phc_phm_build_H*).  Outputs may be
+ * NULL.  One launch, fixed summation order. */
+int phc_gate_param_grads(const float *dMT, const float *dbg, const float *H, const float *gate_w, const float *phm_b, const float *A,
+                         const float *W, int n, int kin, int kout, int kg, float *dA, float *dW, float *db, float *dWg, void *stream);
 
 /* y[N, Nout] = x[N, K] . M[K, Nout] (+ b[Nout]) (+ residual[N, Nout]) with a prebuilt row-major M
  * (H for the forward, H^T for dx; is_dx only labels the launch for the profiler).  Streaming MFMA

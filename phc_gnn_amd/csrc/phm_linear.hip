@@ -848,13 +848,70 @@ struct HJobDev {
     float *H, *HT;
     float *Hk4, *HTk4;           // k4-interleaved copies for the H-stationary GEMM (gemm_hs_device.h), or NULL
     int n, kin, kout;
-    int dense_t;                 // n == 1 and W is an nn.Linear weight [kout, kin]: H = W^T (H^T is W itself)
+    int dense_t;                 // n == 1 and W is an nn.Linear weight [kout, kin]: H = W^T (H^T is W itself); 2: zero fill; 3: gate map
     unsigned blk0;
+    // dense_t == 3 (the read-out's gate as ONE linear map, pooling.py:57-66): H := M = H(A, W) . gate_w^T [in, kg], HT := M^T,
+    // gate_c[j] = sum_col phm_b[col] gate_w[j, col] + gate_b[j]
+    const float *gate_w, *gate_b, *phm_b;
+    float *gate_c;
+    int kg;
 };
 struct HBatch {
     int num;
     HJobDev j[H_JOBS_PER_LAUNCH];
 };
+
+// Gate-map job, one workgroup per row r of M (r == in: the bias row): the row of H(A, W) goes through LDS, then every wavefront
+// takes gate columns j = wave, wave + 4, ... and sums over the row in a fixed order (lane-strided partials, xor tree).
+__device__ __forceinline__ void gate_compose_block(const HJobDev &jb, int r) {
+    __shared__ float hrow[1024];
+    const int n = jb.n, kin = jb.kin, kout = jb.kout, in = n * kin, out = n * kout, kg = jb.kg;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int a = r / kin, kap = r - a * kin;
+    for (int col = tid; col < out; col += 256) {
+        float v;
+        if (r == in) {
+            v = jb.phm_b ? jb.phm_b[col] : 0.f;
+        } else {
+            const int c = col / kout, pi = col - c * kout;
+            v = 0.f;
+            for (int i = 0; i < n; ++i) v = fmaf(jb.A[(i * n + a) * n + c], jb.W[((size_t)i * kin + kap) * kout + pi], v);
+        }
+        hrow[col] = v;
+    }
+    __syncthreads();
+    // eight gate columns of this wavefront per round, their gate_w words all in flight before the first is used (one at a time, a
+    // round trip per column stood in the launch's critical path)
+    constexpr int JR = 8;
+    for (int j0 = wave; j0 < kg; j0 += 4 * JR) {
+        float p[JR];
+#pragma unroll
+        for (int q = 0; q < JR; ++q) p[q] = 0.f;
+        for (int col = lane; col < out; col += 64) {
+            float gw[JR];
+#pragma unroll
+            for (int q = 0; q < JR; ++q) gw[q] = jb.gate_w[(size_t)min(j0 + 4 * q, kg - 1) * out + col];
+            const float hv = hrow[col];
+#pragma unroll
+            for (int q = 0; q < JR; ++q) p[q] = fmaf(hv, gw[q], p[q]);
+        }
+#pragma unroll
+        for (int q = 0; q < JR; ++q) {
+            float v = p[q];
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+            const int j = j0 + 4 * q;
+            if (lane == 0 && j < kg) {
+                if (r == in) {
+                    jb.gate_c[j] = v + (jb.gate_b ? jb.gate_b[j] : 0.f);
+                } else {
+                    jb.H[(size_t)r * kg + j] = v;
+                    if (jb.HT) jb.HT[(size_t)j * in + r] = v;
+                }
+            }
+        }
+    }
+}
 
 __global__ __launch_bounds__(256) void phm_build_H_batched_kernel(HBatch b) {
     int job = 0;
@@ -863,6 +920,10 @@ __global__ __launch_bounds__(256) void phm_build_H_batched_kernel(HBatch b) {
     const HJobDev &jb = b.j[job];
     const int n = jb.n, kin = jb.kin, kout = jb.kout;
     const int in = n * kin, out = n * kout;
+    if (jb.dense_t == 3) {                                    // (block-uniform)
+        gate_compose_block(jb, (int)(blockIdx.x - jb.blk0));
+        return;
+    }
     const int e = (blockIdx.x - jb.blk0) * 256 + threadIdx.x;
     if (e >= in * out) return;
     const int k = e / out, jc = e - k * out;
@@ -1037,6 +1098,129 @@ __global__ __launch_bounds__(256) void phm_grads_contract_kernel(GradBatch b) {
     const GradJobDev &j = b.j[k];
     contract_body(j.A, j.W, j.dH, j.dW, j.dA, j.db, j.n, j.kin, j.kout, j.dA_blocks, (int)(blockIdx.x - j.blk0_contract),
                   j.dw_transposed);
+}
+
+// ---- the gate map's parameter gradients (pooling.py:57-66 as ONE linear map M = H(A, W) . gate_w^T) ----
+// From dM^T = dg^T . x [kg, in] and dbg = sum dg [kg] (a dense parameter-gradient job's outputs):
+//   dH[r, col]  = sum_j dM^T[j, r] gate_w[j, col]                 (never stored: re-evaluated where it is needed, kg MACs)
+//   dA[i, a, c] = sum_{kap, pi} W[i, kap, pi] dH[a kin + kap, c kout + pi]          blocks [0, n^3)
+//   dW[i, kap, pi] = sum_{a, c} A[i, a, c] dH[a kin + kap, c kout + pi]             blocks [n^3, n^3 + ceil(n kin kout / 256))
+//   dWg[j, col] = sum_r dM^T[j, r] H[r, col] + dbg[j] b[col]                        then ceil(kg out / 256) blocks
+//   db[col]     = sum_j dbg[j] gate_w[j, col]                                       last block
+// every sum in a fixed order (thread-strided partials, LDS tree): bit-reproducible.
+struct GateGradArgs {
+    const float *dMT, *dbg, *H, *gate_w, *phm_b, *A, *W;
+    float *dA, *dW, *db, *dWg;
+    int n, k, kg;                 // kin == kout == k
+    int blk_rows, blk_dWg, blk_db;
+};
+
+// Operands staged in LDS (dynamic): tile blocks kg * k * 2 + k * (k + 1) floats, row blocks kg * (n k) + kg * n + n^3 floats.
+// Every phase issues its global loads together and sums in a fixed order; none of the sums depends on the grid's shape.
+__global__ __launch_bounds__(256) void gate_param_grads_kernel(GateGradArgs g) {
+    extern __shared__ float gsm[];
+    __shared__ float red[4][256];
+    const int n = g.n, k = g.k, kg = g.kg, h = n * k;
+    const int tid = threadIdx.x, bx = blockIdx.x;
+    if (bx < g.blk_rows) {
+        // ---- tile (a, c): dH[a k .. , c k ..] = dM[a-rows, :] . gate_w[:, c-cols] in LDS, then dA[i, a, c] for every i ----
+        const int a = bx / n, c = bx - a * n;
+        float *sM = gsm, *sG = gsm + kg * k, *tile = gsm + 2 * kg * k;          // [kg][k], [kg][k], [k][k + 1]
+        for (int e = tid; e < kg * k; e += 256) {
+            const int j = e / k, t = e - j * k;
+            sM[e] = g.dMT[(size_t)j * h + a * k + t];
+            sG[e] = g.gate_w[(size_t)j * h + c * k + t];
+        }
+        __syncthreads();
+        for (int e = tid; e < k * k; e += 256) {
+            const int kap = e / k, pi = e - kap * k;
+            float v = 0.f;
+#pragma unroll 8
+            for (int j = 0; j < kg; ++j) v = fmaf(sM[j * k + kap], sG[j * k + pi], v);
+            tile[kap * (k + 1) + pi] = v;
+        }
+        __syncthreads();
+        if (!g.dA) return;
+        for (int i0 = 0; i0 < n; i0 += 4) {                                       // four i per round: one reduction tree for the four
+            float p[4] = {0.f, 0.f, 0.f, 0.f};
+            for (int e = tid; e < k * k; e += 256) {
+                const int kap = e / k, pi = e - kap * k;
+                float wv[4];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) wv[q] = g.W[((size_t)min(i0 + q, n - 1) * k + kap) * k + pi];
+                const float tv = tile[kap * (k + 1) + pi];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) p[q] = fmaf(wv[q], tv, p[q]);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q) red[q][tid] = p[q];
+            __syncthreads();
+            for (int st = 128; st >= 1; st >>= 1) {
+                if (tid < st) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) red[q][tid] += red[q][tid + st];
+                }
+                __syncthreads();
+            }
+            if (tid < 4 && i0 + tid < n) g.dA[((i0 + tid) * n + a) * n + c] = red[tid][0];
+            __syncthreads();
+        }
+        return;
+    }
+    if (bx < g.blk_dWg) {
+        // ---- row kap of every tile: dW[i, kap, pi] = sum_{a, c} A[i, a, c] dH[a k + kap, c k + pi], gate_w whole in LDS ----
+        if (!g.dW) return;
+        const int kap = bx - g.blk_rows;
+        float *sG = gsm, *sMk = gsm + kg * h, *sA = sMk + kg * n;                 // [kg][h], [kg][n], [n][n][n]
+        for (int e = tid; e < kg * h; e += 256) sG[e] = g.gate_w[e];
+        for (int e = tid; e < kg * n; e += 256) {
+            const int j = e / n, a = e - j * n;
+            sMk[e] = g.dMT[(size_t)j * h + a * k + kap];
+        }
+        for (int e = tid; e < n * n * n; e += 256) sA[e] = g.A[e];
+        __syncthreads();
+        for (int o = tid; o < h; o += 256) {                                      // o = (i, pi)
+            const int i = o / k, pi = o - i * k;
+            float acc = 0.f;
+            for (int a = 0; a < n; ++a)
+                for (int c = 0; c < n; ++c) {
+                    // (the LDS reads of eight j go out together: one at a time the chain waited a round trip per term — 25 us)
+                    float v = 0.f;
+#pragma unroll 8
+                    for (int j = 0; j < kg; ++j) v = fmaf(sMk[j * n + a], sG[j * h + c * k + pi], v);
+                    acc = fmaf(sA[(i * n + a) * n + c], v, acc);
+                }
+            g.dW[((size_t)i * k + kap) * k + pi] = acc;
+        }
+        return;
+    }
+    if (bx < g.blk_db) {
+        // ---- dWg[j, col] = sum_r dM^T[j, r] H[r, col] + dbg[j] b[col]: one j and 32 columns per workgroup, r dealt over 8 thread rows ----
+        if (!g.dWg) return;
+        const int cb = h / 32 + (h % 32 ? 1 : 0);
+        const int w = bx - g.blk_dWg, j = w / cb, col = (w - j * cb) * 32 + (tid & 31), part = tid >> 5;
+        float p = 0.f;
+        if (col < h) {
+#pragma unroll 8
+            for (int r = part; r < h; r += 8) p = fmaf(g.dMT[(size_t)j * h + r], g.H[(size_t)r * h + col], p);
+        }
+        red[0][tid] = p;
+        __syncthreads();
+        if (part == 0 && col < h) {
+            float v = 0.f;
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v += red[0][q * 32 + (tid & 31)];
+            if (g.phm_b) v = fmaf(g.dbg[j], g.phm_b[col], v);
+            g.dWg[(size_t)j * h + col] = v;
+        }
+        return;
+    }
+    if (g.db)                                                 // db[col] = sum_j dbg[j] gate_w[j, col]
+        for (int col = tid; col < h; col += 256) {
+            float p = 0.f;
+            for (int j = 0; j < kg; ++j) p = fmaf(g.dbg[j], g.gate_w[(size_t)j * h + col], p);
+            g.db[col] = p;
+        }
 }
 
 // ---- host side ---------------------------------------------------------------------------
@@ -1655,9 +1839,23 @@ int phc_phm_build_H_batched(const phc_phm_H_job *jobs, int num_jobs, void *strea
                 blocks += (unsigned)(((size_t)jb.kin * jb.kout + 255) / 256);
                 continue;
             }
+            if (jb.flags == 3) {                                 // gate map: M = H(A, W) . gate_w^T, M^T, composed bias
+                const int in_ = jb.n * jb.kin, out_ = jb.n * jb.kout;
+                PHC_REQUIRE(jb.A && jb.W && jb.H && jb.gate_w && jb.gate_c && jb.gate_k >= 1 && out_ <= 1024 && !jb.Hk4 && !jb.HTk4,
+                            PHC_ERR_INVALID_ARG, "phc_phm_build_H_batched: job %d: a gate job takes A, W, H (= M), gate_w, gate_c, "
+                            "gate_k >= 1 and an inner width <= 1024 (got %d)", c0 + k, out_);
+                b.j[k] = HJobDev{};
+                b.j[k].A = jb.A; b.j[k].W = jb.W; b.j[k].H = jb.H; b.j[k].HT = jb.HT;
+                b.j[k].n = jb.n; b.j[k].kin = jb.kin; b.j[k].kout = jb.kout; b.j[k].dense_t = 3;
+                b.j[k].gate_w = jb.gate_w; b.j[k].gate_b = jb.gate_b; b.j[k].phm_b = jb.phm_b; b.j[k].gate_c = jb.gate_c; b.j[k].kg = jb.gate_k;
+                b.j[k].blk0 = blocks;
+                blocks += (unsigned)(in_ + 1);
+                continue;
+            }
             const int dense_t = jb.flags & 1;
             PHC_REQUIRE((jb.A || dense_t) && jb.W && jb.H, PHC_ERR_INVALID_ARG, "phc_phm_build_H_batched: job %d: null pointer", c0 + k);
             PHC_REQUIRE(!dense_t || jb.n == 1, PHC_ERR_INVALID_ARG, "phc_phm_build_H_batched: job %d: a dense weight needs n = 1", c0 + k);
+            b.j[k] = HJobDev{};
             b.j[k].A = jb.A; b.j[k].W = jb.W; b.j[k].H = jb.H; b.j[k].HT = jb.HT;
             const int in_ = jb.n * jb.kin, out_ = jb.n * jb.kout;
             PHC_REQUIRE((!jb.Hk4 || in_ % 4 == 0) && (!jb.HTk4 || out_ % 4 == 0) && (!dense_t || (!jb.Hk4 && !jb.HTk4)), PHC_ERR_INVALID_ARG,
@@ -1673,6 +1871,35 @@ int phc_phm_build_H_batched(const phc_phm_H_job *jobs, int num_jobs, void *strea
         if (rc) return rc;
     }
     return PHC_OK;
+}
+
+int phc_gate_param_grads(const float *dMT, const float *dbg, const float *H, const float *gate_w, const float *phm_b, const float *A,
+                         const float *W, int n, int kin, int kout, int kg, float *dA, float *dW, float *db, float *dWg, void *stream) {
+    int rc = check_phm_dims("phc_gate_param_grads", 1, n, kin, kout);
+    if (rc) return rc;
+    PHC_REQUIRE(dMT && dbg && H && gate_w && A && W && kg >= 1, PHC_ERR_INVALID_ARG, "phc_gate_param_grads: null pointer / kg = %d", kg);
+    PHC_REQUIRE(!db || phm_b, PHC_ERR_INVALID_ARG, "phc_gate_param_grads: db without a PHM bias");
+    PHC_REQUIRE(kin == kout, PHC_ERR_UNSUPPORTED, "phc_gate_param_grads: a square PHM layer (kin == kout), got %d x %d", kin, kout);
+    const int k = kin, h = n * k;
+    const int lds_tile = 2 * kg * k + k * (k + 1), lds_row = kg * h + kg * n + n * n * n;
+    const size_t lds = sizeof(float) * (size_t)(lds_tile > lds_row ? lds_tile : lds_row);
+    PHC_REQUIRE(lds <= 128 * 1024, PHC_ERR_UNSUPPORTED, "phc_gate_param_grads: gate_w [%d x %d] does not fit the LDS staging", kg, h);
+    GateGradArgs g;
+    g.dMT = dMT; g.dbg = dbg; g.H = H; g.gate_w = gate_w; g.phm_b = phm_b; g.A = A; g.W = W;
+    g.dA = dA; g.dW = dW; g.db = db; g.dWg = dWg;
+    g.n = n; g.k = k; g.kg = kg;
+    g.blk_rows = n * n;
+    g.blk_dWg = g.blk_rows + k;
+    g.blk_db = g.blk_dWg + kg * ((h + 31) / 32);
+    static bool attr_set = false;
+    if (!attr_set) {
+        hipFuncSetAttribute(reinterpret_cast<const void *>(&gate_param_grads_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        attr_set = true;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(K_PHM_CONTRACT, s);
+    PHC_LAUNCH(gate_param_grads_kernel, dim3((unsigned)(g.blk_db + 1)), dim3(256), lds, s, g);
+    return check_launch("gate_param_grads");
 }
 
 int phc_gemm_prebuilt(const float *x, const float *M, const float *Mk4, const float *b, const float *residual, int64_t N, int K, int Nout,

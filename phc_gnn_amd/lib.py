@@ -39,7 +39,7 @@ class HJob(C.Structure):
     """phc_phm_H_job (include/phc_hip.h)."""
     _fields_ = [("A", _P), ("W", _P), ("H", _P), ("HT", _P),
                 ("n", C.c_int32), ("kin", C.c_int32), ("kout", C.c_int32), ("flags", C.c_int32),
-                ("Hk4", _P), ("HTk4", _P)]
+                ("Hk4", _P), ("HTk4", _P), ("gate_w", _P), ("gate_b", _P), ("phm_b", _P), ("gate_c", _P), ("gate_k", C.c_int32)]
 
 
 class DownstreamNorm(C.Structure):
@@ -104,6 +104,7 @@ SIGNATURES = {
     "phc_gemm_prebuilt_bwsums": (_I, [_P, _P, _P, _L, _I, _I, _P, _P, _P, _I, _P, _P, C.POINTER(_I), _P]),
     "phc_gemm_bwd_apply_supported": (_I, [_I, _I]),
     "phc_stat_acc_read": (_I, [_P, _I, _L, _P, _P]),
+    "phc_gate_param_grads": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "phc_debug_hs_stamps": (_I, [_P]),
     "phc_gemm_bwd_apply": (_I, [C.POINTER(GemmBaDesc), _P]),
     "phc_bn_bwd_partial_acc": (_I, [_P, _P, _P, _P, _L, _I, _I, _P, _P]),

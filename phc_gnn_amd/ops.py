@@ -267,6 +267,8 @@ def _flush_step_tail(jobs, tjobs, ajobs) -> bool:
                 L.account("phm_dH_partial", 2.0 * N * jn * jkin * jn * jkout, 4.0 * N * jn * (jkin + jkout) + 4.0 * jn * jkin * jn * jkout)
     for jb, grads in zip(jobs, outs):
         _assign_grads(jb["params"], grads)
+        if jb.get("post") is not None:
+            jb["post"](grads)
     for i, tj in enumerate(tjobs):
         _assign_grads(tj["params"], tj["ts"].grad_views(tflat[i * per:(i + 1) * per]))
     if ajobs:
@@ -366,6 +368,8 @@ def _flush_param_grads(jobs, return_grads: bool = False):
             if return_grads:
                 return outs
             for jb, grads in zip(js, outs):
+                if jb.get("post") is not None:
+                    jb["post"](grads)
                 for prm, g in zip(jb["params"], grads):
                     if prm is None or g is None:
                         continue
@@ -412,6 +416,19 @@ def dense_weights(model) -> list:
     return out
 
 
+def gate_specs(model) -> list:
+    """(phm_rule, W, b, gate_weight, gate_bias) of every soft-attention read-out of ``model`` whose gate
+    ``Linear(PHMLinear(x))`` the engine evaluates as ONE linear map (``gate_linear``; pooling.py:57-66)."""
+    out = []
+    for m in model.modules():
+        lin, rt = getattr(m, "linear", None), getattr(m, "real_trafo", None)
+        aff = getattr(rt, "affine", None)
+        if lin is not None and isinstance(aff, torch.nn.Linear) and torch.is_tensor(getattr(lin, "W", None)) \
+                and torch.is_tensor(getattr(lin, "phm_rule", None)) and gate_composable(lin.W, aff.weight):
+            out.append((lin.phm_rule, lin.W, getattr(lin, "b", None), aff.weight, aff.bias))
+    return out
+
+
 def _one(dev) -> torch.Tensor:
     one = _ONES.get(dev)
     if one is None:
@@ -427,8 +444,8 @@ FUSED_MAX_WIDTH = 256
 
 
 @contextlib.contextmanager
-def prebuilt_H(pairs, dense=()):
-    if _PREBUILT.table or not (pairs or dense):            # nested (outermost wins) or nothing to do
+def prebuilt_H(pairs, dense=(), gates=()):
+    if _PREBUILT.table or not (pairs or dense or gates):   # nested (outermost wins) or nothing to do
         yield
         return
     outer_step = getattr(_FLAT_STEP, "packed", None) is None
@@ -445,26 +462,48 @@ def prebuilt_H(pairs, dense=()):
         if A.is_cuda and W.is_cuda and A.dtype == W.dtype == torch.float32 and A.is_contiguous() and W.is_contiguous() \
                 and (n * kout) <= PREBUILT_MAX_WIDTH and (n * kin) <= PREBUILT_MAX_WIDTH and (n * kin) % 4 == 0 and (n * kout) % 4 == 0:
             by_dev.setdefault(W.device, []).append((A, W))
+    gates_by_dev = {}
+    if GATE_COMPOSED:
+        for gs in gates:
+            A, W, Wg = gs[0], gs[1], gs[3]
+            if A.is_cuda and all(t is None or (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()) for t in gs) \
+                    and gate_composable(W, Wg):
+                gates_by_dev.setdefault(W.device, []).append(gs)
+                by_dev.setdefault(W.device, [])
     try:
         for dev, prs in by_dev.items():
             with torch.cuda.device(dev):
+                gts = gates_by_dev.get(dev, [])
                 # per PHM pair: H, H^T and their k4-interleaved copies (the H-stationary GEMM's operand form)
                 total = sum(4 * (W.shape[0] * W.shape[1]) * (W.shape[0] * W.shape[2]) if A is not None else W.numel()
                             for A, W in prs)
+                # per gate map: M [in, kg], M^T and the composed bias [kg]
+                total += sum(2 * (g[1].shape[0] * g[1].shape[1]) * g[3].shape[0] + g[3].shape[0] + 4 for g in gts)
                 flat = torch.empty(total, dtype=torch.float32, device=dev)
                 # the step's statistics accumulators are cleared by this launch too (stat_accumulators entered just before)
                 arena = _STAT_ARENAS.get((dev.type, dev.index if dev.index is not None else torch.cuda.current_device()))
                 zero = arena.take_pending_zero() if (arena is not None and arena.active) else None
-                arr = (L.HJob * (len(prs) + (1 if zero else 0)))()
+                arr = (L.HJob * (len(prs) + len(gts) + (1 if zero else 0)))()
                 if zero:
-                    arr[len(prs)] = L.HJob(None, None, L.ptr(zero[0]), None, 1, zero[1] // 256, 256, 2, None, None)
+                    arr[len(prs) + len(gts)] = L.HJob(None, None, L.ptr(zero[0]), None, 1, zero[1] // 256, 256, 2, None, None)
                 off = 0
+                for i, (A, W, b, Wg, bg) in enumerate(gts):
+                    n, kin, kout = W.shape
+                    kg, inw = Wg.shape[0], n * kin
+                    M, MT = flat[off:off + inw * kg].view(inw, kg), flat[off + inw * kg:off + 2 * inw * kg].view(kg, inw)
+                    c = flat[off + 2 * inw * kg:off + 2 * inw * kg + kg]
+                    off += 2 * inw * kg + kg
+                    off = (off + 3) // 4 * 4                  # 16-byte aligned segments
+                    arr[i] = L.HJob(L.ptr(A), L.ptr(W), L.ptr(M), L.ptr(MT), n, kin, kout, 3, None, None, L.ptr(Wg), L.ptr(bg),
+                                    L.ptr(b), L.ptr(c), kg)            # (first in the launch: two dependent phases per workgroup)
+                    _PREBUILT.table[("gate", A.data_ptr(), W.data_ptr(), Wg.data_ptr())] = (
+                        M, MT, c, tuple(t._version if t is not None else -1 for t in (A, W, b, Wg, bg)))
                 for i, (A, W) in enumerate(prs):
                     if A is None:                            # nn.Linear weight [out, in]: H = W^T, and W itself is H^T
                         fo, fi = W.shape
                         H = flat[off:off + fi * fo].view(fi, fo)
                         off += fi * fo
-                        arr[i] = L.HJob(None, L.ptr(W), L.ptr(H), None, 1, fi, fo, 1, None, None)
+                        arr[len(gts) + i] = L.HJob(None, L.ptr(W), L.ptr(H), None, 1, fi, fo, 1, None, None)
                         _PREBUILT.table[("dense", W.data_ptr())] = (H, W, W._version, W._version, None, None)
                         continue
                     n, kin, kout = W.shape
@@ -474,7 +513,7 @@ def prebuilt_H(pairs, dense=()):
                     if max(n * kin, n * kout) <= FUSED_MAX_WIDTH:      # the k4 forms feed the H-stationary kernel only
                         Hk4, HTk4 = flat[off + 2 * sz:off + 3 * sz], flat[off + 3 * sz:off + 4 * sz]
                     off += 4 * sz
-                    arr[i] = L.HJob(L.ptr(A), L.ptr(W), L.ptr(H), L.ptr(HT), n, kin, kout, 0, L.ptr(Hk4), L.ptr(HTk4))
+                    arr[len(gts) + i] = L.HJob(L.ptr(A), L.ptr(W), L.ptr(H), L.ptr(HT), n, kin, kout, 0, L.ptr(Hk4), L.ptr(HTk4))
                     _PREBUILT.table[(A.data_ptr(), W.data_ptr())] = (H, HT, A._version, W._version, Hk4, HTk4)
                 L.check(lib.phc_phm_build_H_batched(arr, len(arr), L.stream_ptr(dev)), "phc_phm_build_H_batched")
         yield
@@ -1553,6 +1592,140 @@ def gated_segment_sum(x: torch.Tensor, gate: torch.Tensor, batch, n_comp: int, n
         gated = (x.view(N, n_comp, h // n_comp) * torch.sigmoid(gate).unsqueeze(1)).reshape(N, h)
         return _SegmentSumFn.apply(gated, st)
     return _GatedSegmentSumFn.apply(x, gate, st, n_comp, dx_handoff)
+
+
+# ---------------------------------------------------------------------------
+# The read-out's gate as ONE linear map (pooling.py:57-66: Linear_{h->kg}(PHMLinear_{in->h}(x)), nothing between the two maps):
+#   gate = x . M + c,   M = H(A, W) . Wg^T [in, kg],   c = b . Wg^T + bg
+# M, M^T and c are assembled by the step's operand-build launch (phc_phm_H_job.flags == 3); forward one GEMM instead of two and no
+# [N, h] intermediate; backward dx = dg . M^T (K = kg); parameter gradients from dM^T = dg^T . x (a dense job of the step tail) and one
+# small launch behind it (phc_gate_param_grads: dH = dM . Wg re-evaluated inside the contractions, dWg = dM^T . H + dbg (x) b).
+# Same function as the two-map form up to fp32 round-off.  PHC_GATE_COMPOSED=0 restores the two GEMMs.
+# ---------------------------------------------------------------------------
+GATE_COMPOSED = __import__("os").environ.get("PHC_GATE_COMPOSED", "1") != "0"
+
+
+def gate_composable(W: torch.Tensor, gate_weight: torch.Tensor) -> bool:
+    """Shapes the composed form serves: a square PHM layer [h -> h] (h % 4 == 0, h <= 256) in front of Linear [h -> kg], kg % 4 == 0,
+    gate_weight small enough for the LDS staging of phc_gate_param_grads."""
+    if W.dim() != 3 or gate_weight.dim() != 2:
+        return False
+    n, kin, kout = W.shape
+    h, kg = n * kout, gate_weight.shape[0]
+    return kin == kout and gate_weight.shape[1] == h and h % 4 == 0 and kg % 4 == 0 and h <= FUSED_MAX_WIDTH and kg * (h + n) <= 30000
+
+
+def _gate_operands(A, W, b, Wg, bg):
+    """(M [in, kg], M^T [kg, in], c [kg]): from the step's operand table when it is current, else built now (one launch)."""
+    ent = _PREBUILT.table.get(("gate", A.data_ptr(), W.data_ptr(), Wg.data_ptr())) if _PREBUILT.table else None
+    if ent is not None and ent[3] == tuple(t._version if t is not None else -1 for t in (A, W, b, Wg, bg)):
+        return ent[0], ent[1], ent[2]
+    lib = L.load()
+    dev = W.device
+    n, kin, kout = W.shape
+    kg, inw = Wg.shape[0], n * kin
+    M = torch.empty((inw, kg), dtype=torch.float32, device=dev)
+    MT = torch.empty((kg, inw), dtype=torch.float32, device=dev)
+    c = torch.empty(kg, dtype=torch.float32, device=dev)
+    arr = (L.HJob * 1)()
+    arr[0] = L.HJob(L.ptr(A), L.ptr(W), L.ptr(M), L.ptr(MT), n, kin, kout, 3, None, None, L.ptr(Wg), L.ptr(bg), L.ptr(b), L.ptr(c), kg)
+    L.check(lib.phc_phm_build_H_batched(arr, 1, L.stream_ptr(dev)), "phc_phm_build_H_batched(gate)")
+    return M, MT, c
+
+
+class _GateLinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, A, W, b, Wg, bg, dx_handoff=None):
+        lib = L.load()
+        dev = L.require_device(x, A, W, b, Wg, bg)
+        n, kin, kout = W.shape
+        inw, kg = n * kin, Wg.shape[0]
+        x_ = L.f32c(x)
+        A_, W_, b_, Wg_, bg_ = (L.f32c(t.detach()) if t is not None else None for t in (A, W, b, Wg, bg))
+        N = x_.shape[0]
+        M, MT, c = _gate_operands(A_, W_, b_, Wg_, bg_)
+        gate = torch.empty((N, kg), dtype=torch.float32, device=dev)
+        if N:
+            L.check(lib.phc_gemm_prebuilt(L.ptr(x_), L.ptr(M), None, L.ptr(c), None, N, inw, kg, L.ptr(gate), 0, L.stream_ptr(dev)),
+                    "phc_gemm_prebuilt(gate)")
+            if L.PROF_ON:
+                L.account("phm_gemm_fwd", 2.0 * N * inw * kg, 4.0 * (N * (inw + kg) + inw * kg))
+        ctx.dx_handoff = dx_handoff
+        if dx_handoff is not None:
+            dx_handoff.accepted = True
+        pre = _prebuilt_for(A_, W_) if _PREBUILT.table else None
+        ctx.H = pre[0] if pre is not None else None          # the PHM layer's own operand matrix, for dWg = dM^T . H
+        ctx.MT = MT
+        ctx.params = (A, W, b, Wg, bg)
+        ctx.save_for_backward(x_, A_, W_, Wg_)
+        ctx.b_ = b_
+        return gate
+
+    @staticmethod
+    def backward(ctx, dg):
+        lib = L.load()
+        x_, A_, W_, Wg_ = ctx.saved_tensors
+        b_ = ctx.b_
+        A, W, b, Wg, bg = ctx.params
+        dev = x_.device
+        n, kin, kout = W_.shape
+        inw, kg = n * kin, Wg_.shape[0]
+        N = x_.shape[0]
+        dg_ = L.f32c(dg)
+        sp = L.stream_ptr(dev)
+        dx = None
+        extra = ctx.dx_handoff.take() if ctx.dx_handoff is not None else None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty((N, inw), dtype=torch.float32, device=dev)
+            if N:
+                L.check(lib.phc_gemm_prebuilt(L.ptr(dg_), L.ptr(ctx.MT), None, None, L.ptr(L.f32c(extra)) if extra is not None else None, N, kg,
+                                              inw, L.ptr(dx), 1, sp), "phc_gemm_prebuilt(gate dx)")
+                if L.PROF_ON:
+                    L.account("phm_gemm_dx", 2.0 * N * inw * kg, 4.0 * (N * (inw + kg) + inw * kg))
+            elif extra is not None:
+                dx = extra
+        elif extra is not None:
+            raise L.PhcError("gate_linear: a parked dx share without a dx to add it to")
+        need = ctx.needs_input_grad
+        nA, nW, nb, nWg, nbg = need[1], need[2], need[3] and b is not None, need[4], need[5] and bg is not None
+        if not (nA or nW or nb or nWg or nbg) or N == 0:
+            return dx, None, None, None, None, None, None
+        H = ctx.H
+        results = {}
+
+        def post(grads):
+            # grads = (None, dM^T [kg, in] in the nn.Linear layout, dbg [kg]) of the dense job (x, dg)
+            _, dMT, dbg = grads
+            Hm = H if H is not None else phm_build_operands([(A_, W_)])[0][0]
+            dA = torch.empty_like(A_) if nA else None
+            dW = torch.empty_like(W_) if nW else None
+            db = torch.empty(n * kout, dtype=torch.float32, device=dev) if nb else None
+            dWg = torch.empty_like(Wg_) if nWg else None
+            L.check(lib.phc_gate_param_grads(L.ptr(dMT), L.ptr(dbg), L.ptr(Hm), L.ptr(Wg_), L.ptr(b_), L.ptr(A_), L.ptr(W_), n, kin, kout, kg,
+                                             L.ptr(dA), L.ptr(dW), L.ptr(db), L.ptr(dWg), L.stream_ptr(dev)), "phc_gate_param_grads")
+            results["g"] = (dA, dW, db, dWg, dbg if nbg else None)
+
+        job = dict(x=x_, dy=dg_, A=_one(dev), W=Wg_, need=(False, True, True), params=(None, None, None), dense=True, post=post)
+        deferred = _DEFER.active and not torch.is_grad_enabled() and all(p is None or p.is_leaf for p in (A, W, b, Wg, bg))
+        if deferred:
+            def post_assign(grads):
+                post(grads)
+                _assign_grads((A if nA else None, W if nW else None, b if nb else None, Wg if nWg else None, bg if nbg else None),
+                              results["g"])
+            job["post"] = post_assign
+            with _DEFER.lock:
+                _DEFER.jobs.append(job)
+            return dx, None, None, None, None, None, None
+        job["post"] = None
+        (grads,) = _flush_param_grads([job], return_grads=True)
+        post(grads)
+        dA, dW, db, dWg, dbg = results["g"]
+        return dx, dA, dW, db, dWg, dbg, None
+
+
+def gate_linear(x: torch.Tensor, phm_rule, W, b, gate_weight, gate_bias, dx_handoff=None) -> torch.Tensor:
+    """Pre-sigmoid gate of the soft-attention read-out, ``Linear(PHMLinear(x))`` as one linear map (see above)."""
+    return _GateLinearFn.apply(x, phm_rule, W, b, gate_weight, gate_bias, dx_handoff)
 
 
 # Tensors known to hold exactly 1.0 for their whole life (harness.backward_seed, GraphedTrainStep's seed): a backward

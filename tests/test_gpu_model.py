@@ -314,12 +314,15 @@ def test_graphed_step_prefetched_preprocessing_equals_the_single_graph_step():
         assert all(torch.equal(results[mode][1][k], results["single"][1][k]) for k in base), mode
 
 
-def test_graphed_step_with_the_engine_optimizer_tracks_the_torch_optimizer():
+@pytest.mark.parametrize("wl,bound", [("molhiv_b32_swish", 5e-4), ("molhiv_b32", 5e-3)])
+def test_graphed_step_with_the_engine_optimizer_tracks_the_torch_optimizer(wl, bound):
     """Captured step with phc_gnn_amd.optim.ClipAdam (clip + Adam in three launches) vs the same step with
-    clip_grad_norm_ + torch.optim.Adam: losses over several steps and the parameters afterwards."""
+    clip_grad_norm_ + torch.optim.Adam: losses over several steps and the parameters afterwards.  The smooth twin is the tight
+    comparison; with ReLU the two optimizers' last-bit differences after one step can flip a gate in the next (parameters agree to
+    1e-7 after step 0 and the norm biases of every layer move apart by 5 % of lr after step 1, scripts/dbg/gate_track_dbg.py): ten
+    times the bound."""
     from phc_gnn_amd import graphed, harness
     from phc_gnn_amd.optim import ClipAdam
-    wl = "molhiv_b32"
     gbs = [harness.make_batch(wl, seed=s) for s in (11, 12, 13, 14)]
     n_max, e_max = graphed.bucket_shape(gbs)
     padded = [graphed.padded_to_device(graphed.pad_batch(g, n_max, e_max), DEV) for g in gbs]
@@ -345,7 +348,7 @@ def test_graphed_step_with_the_engine_optimizer_tracks_the_torch_optimizer():
         # decide the sign of an lr-sized step, so a tensor also passes when it differs by < 5 % of the 4 * lr it can have moved
         if e > worst and float((a - b).abs().max()) > 0.05 * 4 * 1e-3:
             worst, worst_key = e, k
-    assert worst < 5e-4, (worst, worst_key)
+    assert worst < bound, (worst, worst_key)
 
 
 @pytest.mark.parametrize("wl", ["molhiv_b32", "molhiv_b512"])

@@ -1168,3 +1168,62 @@ def test_step_tail_register_resident_table_gradients(ops, N, k, vocab_b, n_layer
     assert len(a) == len(b) and len(a) > 2
     for i, (x1, x2) in enumerate(zip(a, b)):
         assert_close(x1, x2, 5e-6, f"gradient {i}")
+
+
+@pytest.mark.parametrize("n,k,N,bias", [(4, 32, 13824, True), (8, 32, 2001, True), (4, 64, 777, False), (5, 40, 501, True)])
+def test_gate_as_one_linear_map_equals_the_two_maps(ops, n, k, N, bias):
+    """ops.gate_linear (the read-out's Linear(PHMLinear(x)) as x . (H . Wg^T) + (b . Wg^T + bg), pooling.py:57-66) against the two
+    maps applied one after the other in float64: the gate, dx (with a parked share of dx added inside the GEMM) and the gradients of
+    all five parameters — on the plain path, inside prebuilt_H (operands from the step's build launch) and with deferred gradients."""
+    h = n * k
+    g = torch.Generator().manual_seed(n * 1000 + k)
+    x = torch.randn(N, h, generator=g)
+    A = torch.randn(n, n, n, generator=g)
+    W = torch.randn(n, k, k, generator=g) * 0.2
+    b = torch.randn(h, generator=g) if bias else None
+    Wg = torch.randn(k, h, generator=g) * 0.1
+    bg = torch.randn(k, generator=g) if bias else None
+    dg = torch.randn(N, k, generator=g)
+    extra = torch.randn(N, h, generator=g)
+    assert ops.gate_composable(W, Wg)
+    # float64 reference: the two maps
+    xr, Ar, Wr, Wgr = (t.double().requires_grad_() for t in (x, A, W, Wg))
+    br = b.double().requires_grad_() if bias else None
+    bgr = bg.double().requires_grad_() if bias else None
+    H = torch.einsum("iac,ikp->akcp", Ar, Wr).reshape(h, h)
+    y1 = xr @ H + (br if bias else 0.0)
+    ref = y1 @ Wgr.t() + (bgr if bias else 0.0)
+    ins = [xr, Ar, Wr, Wgr] + ([br, bgr] if bias else [])
+    gr = torch.autograd.grad(ref, ins, dg.double())
+
+    def run(mode):
+        xd = x.to(DEV).requires_grad_()
+        ps = [t.to(DEV).requires_grad_() if t is not None else None for t in (A, W, b, Wg, bg)]
+        hand = ops.DxHandoff()
+        ctxs = []
+        if mode != "plain":
+            ctxs.append(ops.prebuilt_H([(ps[0], ps[1])], gates=[tuple(ps)]))
+        if mode == "deferred":
+            ctxs.append(ops.deferred_param_grads())
+        import contextlib
+        with contextlib.ExitStack() as st:
+            for c in ctxs:
+                st.enter_context(c)
+            gate = ops.gate_linear(xd, *ps, dx_handoff=hand)
+            assert hand.accepted
+            hand.tensor = extra.to(DEV)
+            gate.backward(dg.to(DEV))
+        torch.cuda.synchronize()
+        return gate.detach(), xd.grad, [p.grad if p is not None else None for p in ps]
+
+    for mode in ("plain", "prebuilt", "deferred"):
+        gate, dx, pg = run(mode)
+        assert_close(gate, ref.detach().float(), 2e-6, f"{mode}: gate")
+        assert_close(dx, (gr[0] + extra.double()).float(), 2e-6, f"{mode}: dx + parked share")
+        names = ["dA", "dW", "db", "dWg", "dbg"]
+        refs = [gr[1], gr[2], gr[4] if bias else None, gr[3], gr[5] if bias else None]
+        for nm, got, want in zip(names, pg, refs):
+            if want is None:
+                assert got is None, (mode, nm)
+                continue
+            assert_close(got, want.float(), 1e-5, f"{mode}: {nm}")
