@@ -1115,7 +1115,7 @@ struct GateGradArgs {
     int blk_rows, blk_dWg, blk_db;
 };
 
-// Operands staged in LDS (dynamic): tile blocks kg * k * 2 + k * (k + 1) floats, row blocks kg * (n k) + kg * n + n^3 floats.
+// Operands staged in LDS (dynamic): tile blocks kg * k * 2 + k * (k + 1) floats, row blocks kg * (n k) + kg * n + n^3 + n * (n k) floats.
 // Every phase issues its global loads together and sums in a fixed order; none of the sums depends on the grid's shape.
 __global__ __launch_bounds__(256) void gate_param_grads_kernel(GateGradArgs g) {
     extern __shared__ float gsm[];
@@ -1178,18 +1178,32 @@ __global__ __launch_bounds__(256) void gate_param_grads_kernel(GateGradArgs g) {
             sMk[e] = g.dMT[(size_t)j * h + a * k + kap];
         }
         for (int e = tid; e < n * n * n; e += 256) sA[e] = g.A[e];
+        float *sD = sA + n * n * n;                                               // [n][h]: dH[a k + kap, col] of this row
         __syncthreads();
+        // stage 1: one column per thread, its n values in one pass over gate_w's column (each word read once, n FMAs on it; the
+        // LDS reads of eight j go out together — one at a time the chain waited a round trip per term)
+        for (int col = tid; col < h; col += 256) {
+            for (int a0 = 0; a0 < n; a0 += 4) {
+                float v[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 8
+                for (int j = 0; j < kg; ++j) {
+                    const float gw = sG[j * h + col];
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) v[q] = fmaf(sMk[j * n + min(a0 + q, n - 1)], gw, v[q]);
+                }
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+                    if (a0 + q < n) sD[(a0 + q) * h + col] = v[q];
+            }
+        }
+        __syncthreads();
+        // stage 2: dW[i, kap, pi] = sum_{a, c} A[i, a, c] dH[a k + kap, c k + pi]
         for (int o = tid; o < h; o += 256) {                                      // o = (i, pi)
             const int i = o / k, pi = o - i * k;
             float acc = 0.f;
             for (int a = 0; a < n; ++a)
-                for (int c = 0; c < n; ++c) {
-                    // (the LDS reads of eight j go out together: one at a time the chain waited a round trip per term — 25 us)
-                    float v = 0.f;
-#pragma unroll 8
-                    for (int j = 0; j < kg; ++j) v = fmaf(sMk[j * n + a], sG[j * h + c * k + pi], v);
-                    acc = fmaf(sA[(i * n + a) * n + c], v, acc);
-                }
+#pragma unroll 4
+                for (int c = 0; c < n; ++c) acc = fmaf(sA[(i * n + a) * n + c], sD[a * h + c * k + pi], acc);
             g.dW[((size_t)i * k + kap) * k + pi] = acc;
         }
         return;
@@ -1881,7 +1895,7 @@ int phc_gate_param_grads(const float *dMT, const float *dbg, const float *H, con
     PHC_REQUIRE(!db || phm_b, PHC_ERR_INVALID_ARG, "phc_gate_param_grads: db without a PHM bias");
     PHC_REQUIRE(kin == kout, PHC_ERR_UNSUPPORTED, "phc_gate_param_grads: a square PHM layer (kin == kout), got %d x %d", kin, kout);
     const int k = kin, h = n * k;
-    const int lds_tile = 2 * kg * k + k * (k + 1), lds_row = kg * h + kg * n + n * n * n;
+    const int lds_tile = 2 * kg * k + k * (k + 1), lds_row = kg * h + kg * n + n * n * n + n * h;
     const size_t lds = sizeof(float) * (size_t)(lds_tile > lds_row ? lds_tile : lds_row);
     PHC_REQUIRE(lds <= 128 * 1024, PHC_ERR_UNSUPPORTED, "phc_gate_param_grads: gate_w [%d x %d] does not fit the LDS staging", kg, h);
     GateGradArgs g;

@@ -1612,7 +1612,7 @@ def gate_composable(W: torch.Tensor, gate_weight: torch.Tensor) -> bool:
         return False
     n, kin, kout = W.shape
     h, kg = n * kout, gate_weight.shape[0]
-    return kin == kout and gate_weight.shape[1] == h and h % 4 == 0 and kg % 4 == 0 and h <= FUSED_MAX_WIDTH and kg * (h + n) <= 30000
+    return kin == kout and gate_weight.shape[1] == h and h % 4 == 0 and kg % 4 == 0 and h <= FUSED_MAX_WIDTH and (kg + n) * (h + n) + n ** 3 <= 30000
 
 
 def _gate_operands(A, W, b, Wg, bg):
