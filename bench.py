@@ -58,32 +58,46 @@ import torch  # noqa: E402
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s HBM3E
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
 MFMA_KERNELS = ("phm_gemm_fwd", "phm_gemm_dx", "phm_dH_partial", "table_grad")
-# launch-profiler kernel name -> substring of the rocprofv3 kernel name in profiles/<PMC_FILE>
-PMC_NAMES = {"phm_gemm_fwd": "phm_stream_kernel<0, -1, 32, 4, 1>", "phm_gemm_dx": "phm_stream_kernel<0, -1, 32, 4, 0>",
-             "phm_dH_partial": "tail_partial_kernel", "aggregate_enc_fwd": "aggregate_encp_direct_fwd_kernel",
-             "aggregate_enc_dx": "aggregate_enc_dx_kernel", "aggregate_fwd": "aggregate_fwd_kernel",
-             "bn_apply": "bn_apply_acc_kernel", "bn_bwd_apply": "bn_bwd_apply_kernel", "bn_bwd_partial": "bn_bwd_partial_kernel",
-             "bn_stats_partial": "bn_stats_partial_kernel", "table_grad": "table_grad_mfma_kernel<1"}
+# launch-profiler kernel name -> substrings of the rocprofv3 kernel names of that FAMILY in profiles/<PMC_FILE>
+# (a family = every instantiation the launch profiler books under one name; traffic = launch-weighted mean over them)
+PMC_NAMES = {"phm_gemm_fwd": ("gemm_hs16_kernel<128, 2, 4, 1, 4, 1>", "gemm_hs16_kernel<128, 2, 4, 1, 4, 3>",
+                              "gemm_hs16_kernel<256, 2, 8, 1, 4, 1>", "gemm_hs16_kernel<256, 2, 8, 1, 4, 3>",
+                              "gemm_hs16_kernel<256, 2, 8, 1, 4, 0>", "gemm_hs16_kernel<128, 2, 4, 1, 4, 0>"),
+             "phm_gemm_dx": ("gemm_hs16_kernel<128, 2, 4, 1, 4, 8>", "gemm_hs16_kernel<128, 2, 4, 1, 4, 12>",
+                             "gemm_hs16_kernel<256, 2, 8, 1, 4, 8>", "gemm_hs16_kernel<256, 2, 8, 1, 4, 12>"),
+             "phm_dH_partial": ("tail_partial_kernel",), "aggregate_enc_fwd": ("aggregate_encp_direct_fwd_kernel", "aggregate_norm_fwd_kernel"),
+             "aggregate_enc_dx": ("aggregate_dx_rows_kernel",), "aggregate_fwd": ("aggregate_fwd_kernel",),
+             "bn_apply": ("bn_apply_acc_kernel",), "bn_bwd_apply": ("bn_bwd_apply_acc_kernel",), "bn_bwd_partial": ("bn_bwd_partial_kernel",),
+             "bn_stats_partial": ("bn_stats_partial_kernel",), "table_grad": ("table_grad_mfma_kernel<1",)}
 
 
-PMC_FILE = "r03_pmc_traffic.json"
+PMC_FILE = "r04_pmc_traffic.json"
+# below this footprint a row walker's rows are served by the L2s / the 256 MiB Infinity Cache, not by HBM
+# (MI355X_MICROARCH.md: 38 MB table of random rows 8.6 TB/s, 151 MB 7.4-7.9 TB/s, HBM sweep 6.0-6.1 TB/s)
+INFINITY_CACHE_BYTES = 256 * 1024 * 1024
+PEAK_INFINITY_CACHE_GBS = 8600.0
 
 
-def pmc_traffic(kernel: str):
-    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (FETCH_SIZE x2 + WRITE_SIZE,
-    MI355X_MICROARCH.md §HBM), or None.  Collected with scripts/rocprof_pmc.sh on the same workload."""
+def pmc_traffic(kernel: str, workload: str = "molhiv_b512"):
+    """HBM bytes per launch of the kernel family `kernel` in `workload` from the committed rocprofv3 PMC passes
+    (FETCH_SIZE x2 + WRITE_SIZE, MI355X_MICROARCH.md §HBM; scripts/rocprof_pmc.sh <round> <workload>), or None.  The file
+    is keyed by workload: a workload without its own passes reports None rather than another workload's bytes."""
     path = os.path.join(ROOT, "profiles", PMC_FILE)
-    pat = PMC_NAMES.get(kernel)
-    if pat is None or not os.path.exists(path):
+    pats = PMC_NAMES.get(kernel)
+    if pats is None or not os.path.exists(path):
         return None
     try:
-        table = json.load(open(path))
+        table = json.load(open(path)).get(workload)
     except Exception:
         return None
+    if not table:
+        return None
+    tot = n = 0.0
     for name, rec in table.items():
-        if pat in name:
-            return rec.get("hbm_bytes_per_launch")
-    return None
+        if any(p in name for p in pats):
+            tot += rec.get("hbm_bytes_per_launch", 0.0) * rec.get("launches", 1)
+            n += rec.get("launches", 1)
+    return round(tot / n) if n else None
 
 
 def _flush_c_stdio():
@@ -126,7 +140,7 @@ def parse_args():
     ap.add_argument("--layers", type=int, default=1,
                     help="synth_* workloads: 1 = one PHMGINEConv layer (SURVEY 8d); L > 1 = L stacked layers with the model-level "
                          "norm + relu + skip between them (ShardedGINEStack)")
-    ap.add_argument("--min-time", type=float, default=2.0,
+    ap.add_argument("--min-time", type=float, default=6.0,
                     help="keep timing --steps-step windows until this many seconds (and >= 5 windows) are covered; the "
                          "median window is reported (0: a single window)")
     return ap.parse_args()
@@ -303,6 +317,30 @@ def bench_large_graph(args, world, rank, dev):
             _finish(agg.lane, wk)
         ev1.record(); torch.cuda.synchronize()
         ex_ms = ev0.elapsed_time(ev1) / 3
+    # the overlap the layer's forward relies on, measured per rank so that ONE multi-GPU run yields it: the local-edge aggregate
+    # alone, and the span of {exchange on the comm lane || local aggregate on the compute stream} as ShardedAggregate issues them
+    loc_ms = span_ms = None
+    with torch.no_grad():
+        xo, el = x_own.detach(), ea_loc.detach()
+        eh = ea_halo.detach() if ea_halo is not None else None
+        e0, e1, e2, e3 = (torch.cuda.Event(enable_timing=True) for _ in range(4))
+        dist.barrier(); torch.cuda.synchronize()
+        e0.record()
+        for _ in range(3):
+            agg.backend.aggregate_fwd(xo, el, agg.st_loc, "identity", True)
+        e1.record(); torch.cuda.synchronize()
+        loc_ms = e0.elapsed_time(e1) / 3
+        if plan.n_halo > 0:
+            from phc_gnn_amd.dist import _exchange_rows, _finish
+            dist.barrier(); torch.cuda.synchronize()
+            e2.record()
+            for _ in range(3):
+                recv, wk = _exchange_rows(agg.backend, agg.lane, xo, plan.send_rows, plan.n_halo, plan.recv_splits, plan.send_splits,
+                                          plan.group, plan.max_pair_rows)
+                agg.backend.aggregate_fwd(xo, el, agg.st_loc, "identity", True)
+                _finish(agg.lane, wk)
+            e3.record(); torch.cuda.synchronize()
+            span_ms = e2.elapsed_time(e3) / 3
     for _ in range(args.warmup):
         step()
     if world > 1:
@@ -330,6 +368,11 @@ def bench_large_graph(args, world, rank, dev):
                 "gemm_fwd_TFs": rate("phm_gemm_fwd", "flops", 1e12), "gemm_dx_TFs": rate("phm_gemm_dx", "flops", 1e12),
                 "param_grad_gemm_TFs": rate("phm_dH_partial", "flops", 1e12), "bn_apply_GBs": rate("bn_apply", "bytes", 1e9),
                 "halo_all_to_all_ms_alone": None if ex_ms is None else round(ex_ms, 3),
+                "local_aggregate_ms_alone": None if loc_ms is None else round(loc_ms, 3),
+                "exchange_and_local_aggregate_overlapped_ms": None if span_ms is None else round(span_ms, 3),
+                # 1 = the shorter of the two is hidden completely behind the longer one, 0 = they run back to back
+                "overlap_efficiency": None if (span_ms is None or ex_ms is None or min(ex_ms, loc_ms) <= 0) else
+                round((ex_ms + loc_ms - span_ms) / min(ex_ms, loc_ms), 3),
                 "halo_bytes_received": plan.n_halo * h * 4, "plan_and_sort_s": round(t_plan, 2),
                 "engine_kernels_ms_per_step": {k: round(v["total_ms"] / prof_steps, 3) for k, v in sorted(times.items())}}
     gathered = [None] * world
@@ -529,7 +572,7 @@ def main():
                                f"{w['batch_size']}/GPU{config_note}",
                    "nodes_per_batch": int(sum(b.num_nodes for b in host_batches) / len(host_batches)),
                    "edges_per_batch": int(sum(b.num_edges for b in host_batches) / len(host_batches)),
-                   "step": "zero_grad+fwd+bce" + ("+weight_regulariser(lr*wd*mean||W||_2)" if args.weight_decay > 0 else "") + "+bwd"
+                   "step": "zero_grad+fwd+" + ("masked_l1" if w.get("regression") else "bce") + ("+weight_regulariser(lr*wd*mean||W||_2)" if args.weight_decay > 0 else "") + "+bwd"
                            + ("" if args.fwd_bwd_only else "+clip+adam")
                            + ("+grad_allreduce" if world > 1 else ""),
                    "launch": ("hipGraph replay of the whole step on batches padded to one bucket shape "
@@ -548,36 +591,41 @@ def main():
         times, work = prof if prof is not None else ({}, {})
         if times:
             name = max(times, key=lambda k: times[k]["total_ms"])
-            t_ms, n_launch = times[name]["total_ms"], times[name]["launches"]
-            wk = work.get(name, {"flops": 0.0, "bytes": 0.0})
-            if name in MFMA_KERNELS:
-                achieved = wk["flops"] / (t_ms * 1e-3) / 1e12
-                roof = {"bound": "mfma", "achieved": round(achieved, 3), "peak": PEAK_FP32_MFMA_TFLOPS,
-                        "unit": "TFLOP/s", "frac": round(achieved / PEAK_FP32_MFMA_TFLOPS, 4)}
-            else:
-                achieved = wk["bytes"] / (t_ms * 1e-3) / 1e9
-                roof = {"bound": "hbm", "achieved": round(achieved, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": round(achieved / PEAK_HBM_GBS, 4)}
-            # both rooflines SURVEY 8(d) asks for, side by side: the PHM GEMM against the fp32 MFMA peak and the
-            # scatter-aggregate against HBM (each: algorithmic work booked by ops.py / launch durations of the instrumented pass)
+            rows = int(sum(b.num_nodes for b in host_batches) / len(host_batches))
+
+            # One roofline object per engine kernel FAMILY (every instantiation the launch profiler books under one name):
+            # algorithmic work booked by ops.py / launch durations of the instrumented pass.  `rows`, `flops_per_launch` /
+            # `bytes_per_launch` and `avg_launch_us` let a reader recompute `frac` from the line alone.  A row walker whose
+            # whole footprint fits the 256 MiB Infinity Cache is NOT priced against HBM: the activations the previous launch
+            # wrote are served by the L2s / Infinity Cache (`cache_resident`, roof = the guide's random-row figure there).
             def frac_of(kname):
-                if kname not in times or kname not in work:
+                if kname not in times:
                     return None
-                tms = times[kname]["total_ms"]
+                tms, n_l = times[kname]["total_ms"], max(times[kname]["launches"], 1)
+                wk_ = work.get(kname, {"flops": 0.0, "bytes": 0.0})
+                out = {"kernel": kname, "launches": n_l, "avg_launch_us": round(1e3 * tms / n_l, 3), "rows": rows}
                 if kname in MFMA_KERNELS:
-                    a_ = work[kname]["flops"] / (tms * 1e-3) / 1e12
-                    return {"kernel": kname, "bound": "mfma", "achieved": round(a_, 2), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
-                            "frac": round(a_ / PEAK_FP32_MFMA_TFLOPS, 4), "avg_launch_us": round(1e3 * tms / times[kname]["launches"], 2)}
-                a_ = work[kname]["bytes"] / (tms * 1e-3) / 1e9
-                return {"kernel": kname, "bound": "hbm", "achieved": round(a_, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s",
-                        "frac": round(a_ / PEAK_HBM_GBS, 4), "avg_launch_us": round(1e3 * tms / times[kname]["launches"], 2),
-                        "traffic": pmc_traffic(kname)}
+                    a_ = wk_["flops"] / (tms * 1e-3) / 1e12
+                    out.update({"bound": "mfma", "achieved": round(a_, 3), "peak": PEAK_FP32_MFMA_TFLOPS, "unit": "TFLOP/s",
+                                "frac": round(a_ / PEAK_FP32_MFMA_TFLOPS, 4), "flops_per_launch": round(wk_["flops"] / n_l)})
+                else:
+                    a_ = wk_["bytes"] / (tms * 1e-3) / 1e9
+                    per_launch = wk_["bytes"] / n_l
+                    resident = per_launch < INFINITY_CACHE_BYTES
+                    peak = PEAK_INFINITY_CACHE_GBS if resident else PEAK_HBM_GBS
+                    out.update({"bound": "hbm", "achieved": round(a_, 1), "peak": peak, "unit": "GB/s", "frac": round(a_ / peak, 4),
+                                "bytes_per_launch": round(per_launch), "cache_resident": resident})
+                    if resident:
+                        out["peak_note"] = ("footprint below the 256 MiB Infinity Cache: priced against the guide's random-row rate "
+                                            "out of it (8.6 TB/s), not against HBM (8 TB/s)")
+                out["traffic"] = pmc_traffic(kname, args.workload)
+                return out
             result["roofline_phm_gemm"] = frac_of("phm_gemm_fwd")
             result["roofline_aggregate"] = frac_of("aggregate_enc_fwd") or frac_of("aggregate_fwd")
-            roof.update({"traffic": pmc_traffic(name), "traffic_source": "profiles/" + PMC_FILE + " (rocprofv3 --pmc passes of this "
-                         "command: FETCH_SIZE x2 + WRITE_SIZE per launch, MI355X_MICROARCH.md HBM section; regenerate when kernels change)",
-                         "kernel": name, "launches": n_launch,
-                         "avg_launch_us": round(1e3 * t_ms / max(n_launch, 1), 3),
+            roof = frac_of(name)
+            roof.update({"traffic_source": "profiles/" + PMC_FILE + " (rocprofv3 --pmc passes of this workload: FETCH_SIZE x2 + "
+                         "WRITE_SIZE per launch, MI355X_MICROARCH.md HBM section, launch-weighted over the family's instantiations; "
+                         "null = no passes committed for this workload)",
                          "engine_kernels_us_per_step": {k: round(1e3 * v["total_ms"] / args.profile_steps, 2)
                                                         for k, v in sorted(times.items())}})
             result["roofline"] = roof

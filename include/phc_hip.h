@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PHC_ABI_VERSION 4
+#define PHC_ABI_VERSION 5
 
 #define PHC_OK 0
 #define PHC_ERR_INVALID_ARG (-1)   /* null pointer, negative size, bad enum        */
@@ -431,7 +431,7 @@ int phc_bn_bwd_apply(const float *dy, const float *x, const float *save_stat, co
  * totals in its prologue.  It is selected by the arguments that have no meaning without partial rows:
  *   phc_gemm_prebuilt_stats    stats_counts = NULL (num_partials may be NULL): stats_partial is the accumulator
  *   phc_gemm_prebuilt_xf       stats_partial != NULL, stats_counts = NULL
- *   phc_bn_fwd_from_partials   stats_counts = NULL (num_partials ignored); needs h % 32 == 0
+ *   phc_bn_fwd_from_partials   stats_counts = NULL (num_partials ignored); needs h % 4 == 0 and 16-byte aligned rows
  *   phc_gemm_prebuilt_bwsums   num_partials = NULL: sums_partial is the accumulator
  *   phc_bn_bwd_from_partials   num_partials = 0: sums_partial is the accumulator (ws unused)
  *   phc_bn_bwd                 ws_bytes = 0: ws is the accumulator (one launch less: no merge between the two passes)
@@ -591,9 +591,16 @@ int phc_gemm_bwd_apply_supported(int K, int Nout);
 /* Diagnostics only: when set (device buffer, 12 x 8 bytes per wavefront of the largest launch), every H-stationary GEMM launch
  * stamps its wavefronts' phase clocks there (scripts/dbg/hs_phases.py); NULL (the default) switches it off. */
 int phc_debug_hs_stamps(unsigned long long *dev_words);
+/* Run-time switch of the H-stationary kernel (ABI 5; host, process-wide): 0 = every phc_gemm_prebuilt* call takes the LDS-panel
+ * kernel and phc_gemm_bwd_apply_supported answers 0 (the environment variable PHC_GEMM_NO_HS is the initial value).  The kernel's
+ * correctness rests on inline-asm loads with hand-counted waits that hipcc cannot check (csrc/gemm_hs_device.h); the Python layer
+ * compares it with the LDS-panel kernel once per process and device (phc_gnn_amd/selfcheck.py) and turns it off on a mismatch.
+ * phc_gemm_hs_set_enabled returns the previous setting. */
+int phc_gemm_hs_enabled(void);
+int phc_gemm_hs_set_enabled(int on);
 int phc_gemm_bwd_apply(const phc_gemm_ba_desc *d, void *stream);
 /* The sums pass alone: adds sum g | sum g x_hat of (dy, x, save_stat) over the rows below *n_valid_dev into `acc` (width h,
- * zeroed by the caller; h %% 32 == 0, 16-byte aligned rows) — phc_bn_bwd's first launch without its second. */
+ * zeroed by the caller; h % 4 == 0, h <= 8192, 16-byte aligned rows) — phc_bn_bwd's first launch without its second. */
 int phc_bn_bwd_partial_acc(const float *dy, const float *x, const float *save_stat, const int32_t *n_valid_dev, int64_t N, int h,
                            int act, uint64_t *acc, void *stream);
 int phc_bn_bwd_from_partials(const float *dy, const float *x, const float *save_stat, const float *sums_partial,

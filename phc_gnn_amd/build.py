@@ -60,8 +60,38 @@ def build(force: bool = False, verbose: bool = True, defines=(), lib_path: str =
             subprocess.run(cmd, check=True)
         return obj
 
+    # The H-stationary GEMM's inline-asm contract (gemm_hs_device.h) is audited in the generated code whenever its translation
+    # unit is recompiled (scripts/audit_hs_asm_loads.py: prologue loads untouched until their counted wait, DMA instruction
+    # counts and counted waits of the ring as the source derives them); a violation FAILS the build.  Runs beside the compiles.
+    hs_obj = os.path.join(obj_dir, "phm_linear.o")
+    hs_deps = [os.path.join(CSRC, "phm_linear.hip")] + headers
+    stamp = os.path.join(obj_dir, "hs_asm_audit.ok")
+    need_audit = not defines and (force or _stale(hs_obj, hs_deps) or _stale(stamp, hs_deps)) and os.environ.get("PHC_SKIP_ASM_AUDIT") != "1"
+
+    def audit_hs() -> str:
+        import importlib.util
+        import tempfile
+        spec = importlib.util.spec_from_file_location("audit_hs_asm_loads", os.path.join(REPO, "scripts", "audit_hs_asm_loads.py"))
+        mod = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(mod)
+        with tempfile.TemporaryDirectory() as d:
+            asm = os.path.join(d, "phm_linear.s")
+            mod.compile_asm(asm)
+            text = open(asm).read()
+        loads, ring = mod.audit(text), mod.audit_ring(text)
+        bad = [f"{name}: {b}" for name, _, _, bl in loads for b in bl] + [f"{name}: {pr}" for name, prs in ring for pr in prs]
+        if bad or not loads or not ring:
+            raise RuntimeError("H-stationary GEMM asm audit failed (hipcc " + _hipcc() + "):\n  " + "\n  ".join(bad[:12] or ["no variants found"]))
+        return f"{len(loads)} variants with asm loads, {len(ring)} instantiations: ok"
+
     with ThreadPoolExecutor(max_workers=4) as ex:
+        audit_future = ex.submit(audit_hs) if need_audit else None
         objs = list(ex.map(compile_one, sources))
+        if audit_future is not None:
+            msg = audit_future.result()
+            open(stamp, "w").write(msg + "\n")
+            if verbose:
+                print("[phc build] asm audit:", msg, flush=True)
     if force or _stale(lib_path, objs):
         cmd = [hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", lib_path] + objs
         if verbose:

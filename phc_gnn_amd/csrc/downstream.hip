@@ -112,6 +112,10 @@ __device__ __forceinline__ void collect_pairs(const unsigned long long *part, in
             __builtin_amdgcn_s_sleep(1);
             if (++spins > DN_SPIN_MAX) {
                 if (err) atomicOr(err, PHC_ERR_RENDEZVOUS);
+                // a launch whose exchange timed out must not look like a result: the statistics become NaN, and with them the
+                // logits / gradients of every row (the loss turns NaN at once); the running statistics are left alone (fwd_norm)
+#pragma unroll
+                for (int u = 0; u < DN_MERGE; ++u) va[u] = vb[u] = __int_as_float(0x7fc00000);
                 break;
             }
         }
@@ -299,7 +303,7 @@ __device__ __forceinline__ void fwd_norm(const DnArgs &a, const DnNorm &bn, cons
         const float invstd = 1.f / sqrtf(var + bn.eps);
         sc[tid] = invstd * w;
         sc[KM + tid] = b - mean * invstd * w;
-        if (g == 0) {
+        if (g == 0 && mean == mean && M2 == M2) {                // (NaN: the exchange timed out — nothing persistent is touched)
             stat[tid] = mean;
             stat[N + tid] = invstd;
             stat[2 * N + tid] = invstd * w;
@@ -460,7 +464,7 @@ __device__ __forceinline__ void bwd_norm(const DnArgs &a, float *Gm, const float
                         break;
                     }
                 } while ((unsigned)(q >> 32) != tag);
-                s += __uint_as_float((unsigned)q);
+                s += (unsigned)(q >> 32) == tag ? __uint_as_float((unsigned)q) : __int_as_float(0x7fc00000);
             }
             extra_out[j] = s;
         }

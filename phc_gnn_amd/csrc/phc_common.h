@@ -225,6 +225,27 @@ __device__ __forceinline__ double stat_acc_total(const unsigned long long *__res
     return (double)hi * (1.0 / 4096.0) + (double)lo * (1.0 / 4611686018427387904.0);
 }
 
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute: one bit per device ordinal and kernel instantiation
+// (the static lives in the template instantiation), set on first use on that device and checked.  false = the runtime refused
+// (the caller takes its fallback path or reports PHC_ERR_LAUNCH).
+template <typename K>
+inline bool ensure_dynamic_lds(K kernel, size_t bytes) {
+    static unsigned long long done[4] = {0, 0, 0, 0};           // device ordinals 0..255
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 256) {
+        (void)hipGetLastError();
+        return false;
+    }
+    const unsigned long long bit = 1ull << (dev & 63);
+    if (__atomic_load_n(&done[dev >> 6], __ATOMIC_ACQUIRE) & bit) return true;
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    __atomic_fetch_or(&done[dev >> 6], bit, __ATOMIC_RELEASE);
+    return true;
+}
+
 inline int check_launch(const char *what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

@@ -321,13 +321,63 @@ def _chunk_bounds(n: int, chunks: int):
     return [(n * k) // chunks for k in range(chunks + 1)]
 
 
+# ---- start-up check of the exchange ------------------------------------------------------------------------------------
+# The first exchange of every (lane, split pattern, width) is preceded by ONE exchange of the same shape whose payload every
+# receiver can predict: row j of the segment rank s sends to rank d holds (s * A + d * B + 97 j + column) mod 65521 — exact in
+# fp32.  It travels the very path the real rows take (same splits, same chunk cut, same backend), so a transport that delivers
+# wrong rows at this size — as one > 2 GiB RCCL all-to-all did — fails LOUDLY at start-up on every rank (the mismatch count is
+# all-reduced, so no rank is left waiting in a collective) instead of training on silently corrupted halo rows.
+# PHC_EXCHANGE_SELFCHECK=0 skips it.
+EXCHANGE_SELFCHECK = __import__("os").environ.get("PHC_EXCHANGE_SELFCHECK", "1") != "0"
+_PAT_A, _PAT_B, _PAT_M = 1315423911, 2654435761, 65521
+
+
+def _pattern_rows(splits, h: int, me: int, me_is_sender: bool, device, dtype) -> torch.Tensor:
+    """Rows of the check payload, grouped by peer like the splits: what `me` sends (me_is_sender) or must receive."""
+    parts = []
+    col = torch.arange(h, dtype=torch.int32, device=device)
+    for peer, n in enumerate(splits):
+        if n == 0:
+            continue
+        s, d = (me, peer) if me_is_sender else (peer, me)
+        base = (s * _PAT_A + d * _PAT_B) % _PAT_M               # (host integers; everything on the device stays below 2^31)
+        j = torch.arange(n, dtype=torch.int32, device=device) % _PAT_M
+        parts.append((((97 * j) % _PAT_M + base)[:, None] + col[None, :]) % _PAT_M)
+    if not parts:
+        return torch.zeros((0, h), dtype=dtype, device=device)
+    return torch.cat(parts).to(dtype)
+
+
+def _verify_exchange(be, lane: "_CommLane", h: int, dtype, device, out_splits, in_splits, group, max_pair_rows: int) -> None:
+    me = dist.get_rank(group)
+    send = _pattern_rows(in_splits, h, me, True, device, dtype)
+    want = _pattern_rows(out_splits, h, me, False, device, dtype)
+    got, work = _exchange_rows(be, lane, send, None, int(sum(out_splits)), out_splits, in_splits, group, max_pair_rows, _check=False)
+    _finish(lane, work)
+    bad = (got != want).any(dim=1).sum().to(torch.int64).reshape(1) if want.numel() else torch.zeros(1, dtype=torch.int64, device=device)
+    first = int((got != want).any(dim=1).nonzero()[0]) if int(bad) else -1
+    total = bad.clone()
+    dist.all_reduce(total, op=dist.ReduceOp.SUM, group=group)
+    if int(total):
+        raise RuntimeError(f"halo exchange self check failed: rank {me} received {int(bad)} wrong rows of {int(sum(out_splits))} "
+                           f"(first at row {first}; {int(total)} wrong rows over all ranks; splits in={list(in_splits)} "
+                           f"out={list(out_splits)}, {h} columns, MAX_PAIR_BYTES={MAX_PAIR_BYTES}): the collective backend "
+                           "delivers corrupted data at this message size")
+
+
 def _exchange_rows(be, lane: _CommLane, rows_src: torch.Tensor, gather_index: Optional[torch.Tensor], out_rows: int,
-                   out_splits, in_splits, group, max_pair_rows: int = 0):
+                   out_splits, in_splits, group, max_pair_rows: int = 0, _check: bool = True):
     """Start one all-to-all(v) of feature rows on the comm lane: (optionally) gather the rows to send with the engine's
     row-gather kernel, then the collective.  Returns (recv buffer, handle); ``_finish`` joins.
     ``max_pair_rows``: the plan's global pair maximum (HaloPlan.max_pair_rows) — decides, identically on every rank, into how
     many row chunks the exchange is cut (0: this rank's own splits decide; only valid for a group of one)."""
     h = rows_src.shape[1]
+    if _check and EXCHANGE_SELFCHECK and dist.is_initialized():
+        key = (tuple(out_splits), tuple(in_splits), h, rows_src.dtype, MAX_PAIR_BYTES)
+        seen = lane.__dict__.setdefault("_verified", set())
+        if key not in seen:                                     # (same key on both sides of every pair: collective by construction)
+            seen.add(key)
+            _verify_exchange(be, lane, h, rows_src.dtype, rows_src.device, out_splits, in_splits, group, max_pair_rows)
     recv = torch.empty((out_rows, h), dtype=rows_src.dtype, device=rows_src.device)
     biggest = max_pair_rows if max_pair_rows > 0 else max(list(out_splits) + list(in_splits) + [0])
     chunks = max(1, -(-(biggest * h * rows_src.element_size()) // MAX_PAIR_BYTES))

@@ -15,7 +15,7 @@ import torch
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, "libphc_hip.so")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 ACT_IDS = {"identity": 0, "relu": 1, "lrelu": 2, "elu": 3, "swish": 4, "selu": 5}
 
 
@@ -106,6 +106,8 @@ SIGNATURES = {
     "phc_stat_acc_read": (_I, [_P, _I, _L, _P, _P]),
     "phc_gate_param_grads": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _P, _P, _P, _P, _P]),
     "phc_debug_hs_stamps": (_I, [_P]),
+    "phc_gemm_hs_enabled": (_I, []),
+    "phc_gemm_hs_set_enabled": (_I, [_I]),
     "phc_gemm_bwd_apply": (_I, [C.POINTER(GemmBaDesc), _P]),
     "phc_bn_bwd_partial_acc": (_I, [_P, _P, _P, _P, _L, _I, _I, _P, _P]),
     "phc_bn_bwd_from_partials": (_I, [_P, _P, _P, _P, _I, _P, _L, _I, _I, _P, _P, _P, _S, _P]),
@@ -250,6 +252,12 @@ def require_device(*tensors: Optional[torch.Tensor]) -> torch.device:
         raise PhcError("no tensor given")
     if dev not in _ERR_WORDS:
         _register_error_word(dev)
+    if dev not in _SELF_CHECKED:
+        # first engine op on this device: the H-stationary GEMM is compared with the LDS-panel kernel once (selfcheck.py)
+        from . import selfcheck
+        if not torch.cuda.is_current_stream_capturing():
+            _SELF_CHECKED.add(dev)
+            selfcheck.hs_self_check(dev)
     return dev
 
 
@@ -260,6 +268,7 @@ def require_device(*tensors: Optional[torch.Tensor]) -> torch.device:
 # structure build / encoder call with PHC_CHECK_INDICES=1 (debugging aid: the reference's nn.Embedding / scatter raise
 # at the call, a device-side assert in their CUDA form at the next synchronisation).
 _ERR_WORDS: dict = {}
+_SELF_CHECKED: set = set()
 _ERR_BITS = {1: "edge_index entry outside [0, num_nodes)", 2: "node feature index outside its embedding's vocabulary",
              4: "edge feature index outside its embedding's vocabulary", 8: "segment id (batch vector) outside [0, num_graphs)"}
 ERR_RENDEZVOUS = 16                # PHC_ERR_RENDEZVOUS (include/phc_hip.h)

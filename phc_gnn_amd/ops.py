@@ -451,8 +451,17 @@ def prebuilt_H(pairs, dense=(), gates=()):
     outer_step = getattr(_FLAT_STEP, "packed", None) is None
     if outer_step:
         _FLAT_STEP.packed = set()                          # flat table images (FlatTableSet) are refreshed once inside this block
-        FlatTableSet.refresh_all()                         # ... all the live ones by one launch per device, right here
-    lib = L.load()
+        try:
+            FlatTableSet.refresh_all()                     # ... all the live ones by one launch per device, right here
+        except BaseException:
+            _FLAT_STEP.packed = None                       # (a failed refresh must not leave the thread "inside a step")
+            raise
+    try:
+        lib = L.load()
+    except BaseException:
+        if outer_step:
+            _FLAT_STEP.packed = None
+        raise
     by_dev = {}
     for w in dense:
         if w.is_cuda and w.dtype == torch.float32 and w.is_contiguous() and w.dim() == 2:
@@ -472,6 +481,7 @@ def prebuilt_H(pairs, dense=(), gates=()):
                 by_dev.setdefault(W.device, [])
     try:
         for dev, prs in by_dev.items():
+            L.require_device(torch.empty(0, device=dev))   # (first engine op on a device: error word, load-time self check)
             with torch.cuda.device(dev):
                 gts = gates_by_dev.get(dev, [])
                 # per PHM pair: H, H^T and their k4-interleaved copies (the H-stationary GEMM's operand form)

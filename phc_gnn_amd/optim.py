@@ -74,27 +74,32 @@ class ClipAdam:
             raise L.PhcError("ClipAdam: a parameter's storage moved (module.to(), load_state_dict(assign=True)); "
                              "construct the optimizer after the model is on its device")
 
+    def _grad_pointers(self, grp):
+        """Device pointers of a group's ``.grad`` tensors (None = no gradient), validated: the kernels read them as dense fp32
+        of the parameter's shape, anything else raises instead of being read as garbage (``step`` and ``pack_grads`` alike)."""
+        arr = (C.c_void_p * len(grp["idx"]))()
+        for t, i in enumerate(grp["idx"]):
+            p = self.params[i]
+            g = p.grad
+            if g is None:
+                arr[t] = None
+                continue
+            if g.dtype != torch.float32 or g.shape != p.shape or g.device != p.device:
+                raise L.PhcError(f"ClipAdam: gradient of parameter {i} is {g.dtype} {tuple(g.shape)} on {g.device}, expected "
+                                 f"torch.float32 {tuple(p.shape)} on {p.device}")
+            if not g.is_contiguous():
+                g = g.contiguous()
+                p.grad = g
+            arr[t] = g.data_ptr()
+        return arr
+
     @torch.no_grad()
     def step(self, max_norm: Optional[float] = None) -> torch.Tensor:
         lib = L.load()
         self._check_tables()
         mn = self.max_norm if max_norm is None else float(max_norm)
         stream = L.stream_ptr(self.device)
-        calls = []
-        for grp in self.groups:
-            arr = (C.c_void_p * len(grp["idx"]))()
-            for t, i in enumerate(grp["idx"]):
-                g = self.params[i].grad
-                if g is None:
-                    arr[t] = None
-                    continue
-                if g.dtype != torch.float32 or g.shape != self.params[i].shape:
-                    raise L.PhcError("ClipAdam: gradient dtype/shape mismatch")
-                if not g.is_contiguous():
-                    g = g.contiguous()
-                    self.params[i].grad = g
-                arr[t] = g.data_ptr()
-            calls.append((grp, arr))
+        calls = [(grp, self._grad_pointers(grp)) for grp in self.groups]
         single = len(calls) == 1
 
         def call(grp, arr, phases):
@@ -131,13 +136,7 @@ class ClipAdam:
         flat = self.grad_bucket()
         stream = L.stream_ptr(self.device)
         for grp in self.groups:
-            arr = (C.c_void_p * len(grp["idx"]))()
-            for t, i in enumerate(grp["idx"]):
-                g = self.params[i].grad
-                if g is not None and not g.is_contiguous():
-                    g = g.contiguous()
-                    self.params[i].grad = g
-                arr[t] = g.data_ptr() if g is not None else None
+            arr = self._grad_pointers(grp)
             L.check(lib.phc_pack_grads(L.ptr(grp["table"]), arr, len(grp["idx"]), L.ptr(grp["chunks"]), grp["num_chunks"],
                                        L.ptr(self.exp_avg_flat), L.ptr(flat), float(scale), stream), "phc_pack_grads")
         return flat

@@ -1,8 +1,9 @@
 """The H-stationary GEMM's prologue loads its accumulator words and norm constants with inline-asm loads that hipcc's wait-count
 insertion does not see, and waits for them with its own `s_waitcnt vmcnt(N)` (csrc/gemm_hs_device.h: hs_ld64 / hs_ld32 /
 acc_arrived).  That is only correct while NO instruction reads or copies those registers between the loads and the counted wait.
-This script compiles phm_linear.hip to gfx950 assembly and checks exactly that for every instantiated variant; it is also what
-tests/test_hs_asm_contract.py runs.   python scripts/audit_hs_asm_loads.py [existing.s]"""
+This script compiles phm_linear.hip to gfx950 assembly and checks exactly that for every instantiated variant, plus the ring's
+own counted waits and DMA instruction counts (audit_ring); phc_gnn_amd.build runs it whenever the file is recompiled and fails the
+build on a violation, and tests/test_hs_asm_contract.py runs it too.   python scripts/audit_hs_asm_loads.py [existing.s]"""
 import os
 import re
 import subprocess
@@ -62,6 +63,71 @@ def audit(asm_text: str):
     return results
 
 
+def audit_ring(asm_text: str):
+    """The LDS-DMA ring of every gemm_hs16_kernel instantiation: [(kernel, problems)].  What the generated code must still say
+    for the hand-counted waits of csrc/gemm_hs_device.h to mean what they were written to mean:
+      * the number of global_load_lds_dwordx4 instructions = (R - 1 + 2) * IPW * images — the ring's first fill plus ONE refill
+        per step body (the peeled first step and the loop body): a compiler that duplicated or dropped a DMA would shift what
+        `vmcnt(N)` counts;
+      * the counted waits present are exactly the ones the source derives from (R, IPW, images, prologue loads);
+      * plain / ST / BW variants: between a step's counted wait and its `s_barrier` no LDS read is issued (the wait covers only
+        the wavefront's OWN pieces; the other wavefronts' pieces are valid behind the barrier only)."""
+    out = []
+    for m in re.finditer(r"^(_ZN3phc16gemm_hs16_kernelILi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)ELi(\d+)E\w+):", asm_text, re.M):
+        name = m.group(1)
+        K, TPW, WAVES, RB, R, FLAGS = (int(m.group(i)) for i in range(2, 8))
+        end = asm_text.index(".Lfunc_end", m.end())
+        lines = [ln.strip() for ln in asm_text[m.end():end].split("\n")]
+        XF, BW, BA = bool(FLAGS & 2), bool(FLAGS & 4), bool(FLAGS & 8)
+        rpi = 256 // K if K in (128, 256) else 1
+        ipw = (16 * RB // rpi) // WAVES
+        imgs = 2 if BA else 1
+        G = K // 16
+        pro = TPW + TPW * G + (4 * TPW if BW else 0)
+        vm_keep = (R - 2) * ipw * imgs
+        vm_mid = (R - 2 - (1 if BW else 0)) * ipw * imgs
+        acc_younger = (R - 1) * ipw * imgs
+        problems = []
+        n_dma = sum(1 for t in lines if t.startswith("global_load_lds_dwordx4"))
+        if n_dma != (R - 1 + 2) * ipw * imgs:
+            problems.append(f"{n_dma} LDS-DMA instructions, expected {(R - 1 + 2) * ipw * imgs}")
+        in_asm, waits = False, []
+        for n, t in enumerate(lines):
+            if t.startswith(";;#ASMSTART"):
+                in_asm = True
+            elif t.startswith(";;#ASMEND"):
+                in_asm = False
+            elif in_asm:
+                w = re.match(r"s_waitcnt vmcnt\((\d+)\)", t)
+                if w:
+                    waits.append((n, int(w.group(1))))
+        have = {v for _, v in waits}
+        allowed = {0, vm_keep + pro}
+        need = {vm_keep + pro}
+        if XF or BA:
+            allowed |= {vm_mid, acc_younger}
+            need |= {vm_mid}
+        else:
+            allowed |= {vm_keep}
+            need |= {vm_keep}
+        if have - allowed:
+            problems.append(f"unexpected counted waits {sorted(have - allowed)} (allowed {sorted(allowed)})")
+        if need - have:
+            problems.append(f"missing counted waits {sorted(need - have)}")
+        if not (XF or BA):
+            for n, v in waits:
+                if v not in (vm_keep, vm_keep + pro):
+                    continue
+                for t in lines[n + 1:]:
+                    if t.startswith("s_barrier"):
+                        break
+                    if t.startswith("ds_read") or t.startswith("ds_load"):
+                        problems.append(f"LDS read between the step's vmcnt({v}) wait and its barrier: {t}")
+                        break
+        out.append((name, problems))
+    return out
+
+
 def main():
     if len(sys.argv) > 1:
         text = open(sys.argv[1]).read()
@@ -78,7 +144,14 @@ def main():
             print("      ", b)
         worst += len(bad)
     print(f"{len(res)} variants with asm loads, {worst} offending instructions")
-    return 1 if worst or not res else 0
+    ring = audit_ring(text)
+    ring_bad = 0
+    for name, problems in ring:
+        for pr in problems:
+            print(f"{name[:70]:70s} RING: {pr}")
+            ring_bad += 1
+    print(f"{len(ring)} instantiations, {ring_bad} ring problems")
+    return 1 if worst or not res or ring_bad or not ring else 0
 
 
 if __name__ == "__main__":

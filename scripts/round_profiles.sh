@@ -3,12 +3,15 @@
 R=${1:-rXX}
 bash scripts/rocprof_bench.sh ${R} > gpurun_out/${R}_rocprof_bench.log 2>&1
 bash scripts/rocprof_trace.sh ${R}b 1800 > gpurun_out/${R}_rocprof_trace.log 2>&1
-bash scripts/rocprof_pmc.sh ${R} > gpurun_out/${R}_rocprof_pmc.log 2>&1
-F=$(ls -t gpurun_out/pmc_${R}_FETCH_SIZE/*/*counter_collection.csv | head -1)
-W=$(ls -t gpurun_out/pmc_${R}_WRITE_SIZE/*/*counter_collection.csv | head -1)
-python3 scripts/summarize_pmc.py $F $W gpurun_out/${R}_pmc_traffic.json > gpurun_out/${R}_pmc_traffic.txt 2>&1
-find gpurun_out/pmc_${R}_FETCH_SIZE gpurun_out/pmc_${R}_WRITE_SIZE -name "*.csv" -size +5M -delete
-for wl in zinc_b1024 molpcba_b1024 molhiv_b512_softmax molhiv_pub_phc4_2x200 zinc_pub_phc5_4x200 zinc_pub_phc4_4x180; do
+rm -f gpurun_out/${R}_pmc_traffic.json gpurun_out/${R}_pmc_traffic.txt
+for wl in molhiv_b512 zinc_b1024 molpcba_b1024; do
+  bash scripts/rocprof_pmc.sh ${R} $wl > gpurun_out/${R}_rocprof_pmc_$wl.log 2>&1
+  F=$(ls -t gpurun_out/pmc_${R}_${wl}_FETCH_SIZE/*/*counter_collection.csv | head -1)
+  W=$(ls -t gpurun_out/pmc_${R}_${wl}_WRITE_SIZE/*/*counter_collection.csv | head -1)
+  python3 scripts/summarize_pmc.py $F $W gpurun_out/${R}_pmc_traffic.json $wl >> gpurun_out/${R}_pmc_traffic.txt 2>&1
+  find gpurun_out/pmc_${R}_${wl}_FETCH_SIZE gpurun_out/pmc_${R}_${wl}_WRITE_SIZE -name "*.csv" -size +5M -delete
+done
+for wl in zinc_b1024 molpcba_b1024 molhiv_b512_softmax molhiv_b512_conv molhiv_b32 molhiv_pub_phc4_2x200 zinc_pub_phc5_4x200 zinc_pub_phc4_4x180; do
   python bench.py --workload $wl --cpu-steps 0 2>&1 | grep '^{"metric"' | tail -1 > gpurun_out/${R}_bench_$wl.json
 done
 # kernel stats of the wide configurations and of config-5 at its full size (one GPU)

@@ -124,20 +124,47 @@ class OracleBackend:
         return w * invstd * (g - dwb_global[h:] / n_total - xhat * dwb_global[:h] / n_total)
 
 
-def _worker_sharded(rank, world, port, act, tmp, max_pair_bytes=None):
+def _graph(N, E, world, kind, seed):
+    """Edge list [2, E'] of the multi-rank tests.  kind "uniform": iid edges.  kind "holes" (what an 8-rank run meets on real
+    partitions and a uniform toy graph never shows): the LAST rank's nodes have local in-edges only (a rank with no halo at
+    all), ranks 0 and 1 exchange nothing in either direction (empty peer segments inside the all-to-all), and from 4 ranks up
+    rank 2's nodes have no in-edge whatsoever (empty local AND halo structures; it still serves rows to the others)."""
+    ei = torch.from_numpy(synth.random_edges(N, E, seed=seed))
+    if kind == "uniform":
+        return ei
+    b = torch.tensor(partition_bounds(N, world)[1:])
+    own_s, own_d = torch.bucketize(ei[0], b, right=True), torch.bucketize(ei[1], b, right=True)
+    drop = (own_d == world - 1) & (own_s != world - 1)
+    drop |= ((own_s == 0) & (own_d == 1)) | ((own_s == 1) & (own_d == 0))
+    if world >= 4:
+        drop |= own_d == 2
+    return ei[:, ~drop].contiguous()
+
+
+def _worker_sharded(rank, world, port, act, tmp, max_pair_bytes=None, kind="uniform"):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
         if max_pair_bytes is not None:                          # force the chunked exchange (several all-to-alls per halo pull)
             import phc_gnn_amd.dist as D
             D.MAX_PAIR_BYTES = max_pair_bytes
-        N, E, h = 203, 1500, 16
-        ei = torch.from_numpy(synth.random_edges(N, E, seed=3))
+        N, h = 203, 16
+        ei = _graph(N, 1500, world, kind, seed=3)
+        E = ei.shape[1]
         g = torch.Generator().manual_seed(5)
         x = torch.randn(N, h, generator=g)
         ea = torch.randn(E, h, generator=g)
         dy = torch.randn(N, h, generator=g)
         plan = build_halo_plan(ei, N)
+        if kind == "holes":
+            assert (plan.n_halo == 0) == (rank == world - 1 or (world >= 4 and rank == 2)), (rank, plan.n_halo)
+            if rank in (0, 1):
+                assert plan.recv_splits[1 - rank] == 0 and plan.send_splits[1 - rank] == 0
+            if world >= 4 and rank == 2:
+                assert plan.loc_edge_index.shape[1] == 0 and plan.halo_edge_index.shape[1] == 0 and sum(plan.send_splits) > 0
+        if max_pair_bytes is not None:
+            chunks = -(-(plan.max_pair_rows * h * 4) // max_pair_bytes)
+            assert chunks > 1, (plan.max_pair_rows, max_pair_bytes)           # the case really cuts its exchanges
         bounds = partition_bounds(N, world)
         assert (plan.lo, plan.hi) == (bounds[rank], bounds[rank + 1])
         # plan sanity: halo ids are exactly the remote sources of my in-edges
@@ -159,14 +186,20 @@ def _worker_sharded(rank, world, port, act, tmp, max_pair_bytes=None):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("act,max_pair_bytes", [("identity", None), ("relu", None), ("relu", 5000)])
-def test_sharded_aggregate_equals_single_process(tmp_path, act, max_pair_bytes):
-    """``max_pair_bytes`` = 5000: every exchange of ~100 rows x 64 B per pair is cut into row chunks (dist.MAX_PAIR_BYTES, the
-    guard against > 1 GiB messages), forward and reverse, with the plan's global pair maximum deciding the cut on both ranks."""
-    world = 2
-    mp.spawn(_worker_sharded, args=(world, _free_port(), act, str(tmp_path), max_pair_bytes), nprocs=world, join=True)
-    N, E, h = 203, 1500, 16
-    ei = torch.from_numpy(synth.random_edges(N, E, seed=3))
+@pytest.mark.parametrize("world,act,max_pair_bytes,kind", [
+    (2, "identity", None, "uniform"), (2, "relu", None, "uniform"), (2, "relu", 5000, "uniform"),
+    (3, "relu", 700, "uniform"),            # odd world, three chunks per exchange
+    (4, "identity", None, "holes"),
+    (8, "relu", 300, "holes"),              # the driver's 8-rank shape: chunked, empty peer segments, ranks without halo / edges
+])
+def test_sharded_aggregate_equals_single_process(tmp_path, world, act, max_pair_bytes, kind):
+    """``max_pair_bytes``: every exchange is cut into row chunks (dist.MAX_PAIR_BYTES, the guard against > 1 GiB messages),
+    forward and reverse, with the plan's global pair maximum deciding the cut on all ranks alike.  Every first exchange of a
+    shape also runs the start-up pattern check (dist._verify_exchange)."""
+    mp.spawn(_worker_sharded, args=(world, _free_port(), act, str(tmp_path), max_pair_bytes, kind), nprocs=world, join=True)
+    N, h = 203, 16
+    ei = _graph(N, 1500, world, kind, seed=3)
+    E = ei.shape[1]
     g = torch.Generator().manual_seed(5)
     x = torch.randn(N, h, generator=g).requires_grad_()
     ea = torch.randn(E, h, generator=g).requires_grad_()
@@ -334,11 +367,22 @@ def _make_stack(n, h, seed):
     return convs, norms
 
 
-def _worker_stack(rank, world, port, tmp):
+def _stack_problem(world, kind):
+    N, E, n, h, ei, x, ea, dy = _layer_problem()
+    if kind != "uniform":
+        ei = _graph(N, E, world, kind, seed=13)
+        ea = ea[:ei.shape[1]].contiguous()
+    return N, ei.shape[1], n, h, ei, x, ea, dy
+
+
+def _worker_stack(rank, world, port, tmp, kind="uniform", max_pair_bytes=None):
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
     dist.init_process_group("gloo", rank=rank, world_size=world)
     try:
-        N, E, n, h, ei, x, ea, dy = _layer_problem()
+        if max_pair_bytes is not None:
+            import phc_gnn_amd.dist as D
+            D.MAX_PAIR_BYTES = max_pair_bytes
+        N, E, n, h, ei, x, ea, dy = _stack_problem(world, kind)
         convs, norms = _make_stack(n, h, seed=31)
         plan = build_halo_plan(ei, N)
         stack = ShardedGINEStack(convs, norms, plan, N, activation="relu", backend=OracleBackend()).train()
@@ -354,12 +398,13 @@ def _worker_stack(rank, world, port, tmp):
         dist.destroy_process_group()
 
 
-def test_sharded_stack_with_model_level_norm_equals_single_process(tmp_path):
-    """conv -> norm(global statistics) -> relu -> + skip, twice, on two shards == the oracle on the whole graph: outputs, dx,
-    every parameter gradient (convs and norms), running statistics."""
-    world = 2
-    mp.spawn(_worker_stack, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
-    N, E, n, h, ei, x, ea, dy = _layer_problem()
+@pytest.mark.parametrize("world,kind,max_pair_bytes", [(2, "uniform", None), (3, "uniform", 900), (4, "holes", None), (8, "holes", 400)])
+def test_sharded_stack_with_model_level_norm_equals_single_process(tmp_path, world, kind, max_pair_bytes):
+    """conv -> norm(global statistics) -> relu -> + skip, twice, on 2 / 3 / 4 / 8 shards == the oracle on the whole graph:
+    outputs, dx, every parameter gradient (convs and norms), running statistics — incl. shards without halo rows, without any
+    edge, empty peer segments and chunked exchanges ("holes", max_pair_bytes)."""
+    mp.spawn(_worker_stack, args=(world, _free_port(), str(tmp_path), kind, max_pair_bytes), nprocs=world, join=True)
+    N, E, n, h, ei, x, ea, dy = _stack_problem(world, kind)
     convs, norms = _make_stack(n, h, seed=31)
     p = {}
     for i, (c, nm) in enumerate(zip(convs, norms)):
@@ -392,5 +437,49 @@ def test_sharded_stack_with_model_level_norm_equals_single_process(tmp_path):
         if ref is None or k.endswith("linear1.b") or k.endswith("linear2.b"):     # biases in front of a norm: zero up to round-off
             continue
         close(got, ref, "grad " + k)
-    for a, b in zip(shards[0]["buffers"], shards[1]["buffers"]):
-        assert torch.equal(a, b)
+    for other in shards[1:]:
+        for a, b in zip(shards[0]["buffers"], other["buffers"]):
+            assert torch.equal(a, b)
+        for a, b in zip(shards[0]["grads"], other["grads"]):
+            assert torch.equal(a, b)                                  # one summed gradient on every rank
+
+
+# ---- the exchange's start-up check: a transport that delivers a wrong row fails loudly, on every rank -----------------------
+def _worker_corrupt(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        import phc_gnn_amd.dist as D
+        real = dist.all_to_all_single
+
+        def flaky(output, input, *a, **kw):                      # noqa: A002 (torch's own parameter names)
+            w = real(output, input, *a, **kw)
+            if w is not None:
+                w.wait()
+            if rank == 1 and output.dim() == 2 and output.is_floating_point() and output.shape[0] > 3:
+                output[3, 0] += 1.0                              # one wrong value in one received row, on one rank
+            return None
+        N, h = 203, 16
+        ei = _graph(N, 1500, world, "uniform", seed=3)
+        plan = build_halo_plan(ei, N)
+        agg = ShardedAggregate(plan, backend=OracleBackend())
+        D.dist.all_to_all_single = flaky
+        x = torch.randn(N, h, generator=torch.Generator().manual_seed(5))
+        msg = "no error"
+        try:
+            agg(x[plan.lo:plan.hi].clone(), None, None, "identity", True)
+        except RuntimeError as exc:
+            msg = str(exc)
+        finally:
+            D.dist.all_to_all_single = real
+        open(os.path.join(tmp, f"c{rank}.txt"), "w").write(msg)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_exchange_self_check_catches_a_corrupted_row_on_every_rank(tmp_path):
+    world = 2
+    mp.spawn(_worker_corrupt, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    msgs = [open(os.path.join(tmp_path, f"c{r}.txt")).read() for r in range(world)]
+    assert all("halo exchange self check failed" in m for m in msgs), msgs
+    assert "rank 1 received 1 wrong rows" in msgs[1] and "rank 0 received 0 wrong rows" in msgs[0], msgs
