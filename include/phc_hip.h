@@ -675,7 +675,7 @@ int phc_l1_masked_bwd(const float *pred, const float *y, const float *dloss, con
  * three PHM layers: their parameter gradients go through phc_phm_param_grads / phc_step_tail with x, (z1, stat1), (z2, stat2)
  * as inputs), dwb1 [2*d1], dwb2 [2*d2] (dweight | dbias of the norms) and dWr [T*d3 + T] (d Wr, then d br).
  * partial: phc_downstream_partial_floats(B) floats and sync: 4 uint32, both ZERO before the first use and never touched
- * by the caller afterwards (one pair of buffers per direction, per stream and per ceil(B / 32): sync[0] is a launch
+ * by the caller afterwards (one pair of buffers per direction, per stream and per B: sync[0] is a launch
  * generation, partial holds 8-byte {value, generation tag} granules the workgroups exchange inside the launch).
  * n_valid_dev: optional device int32 — rows >= *n_valid_dev are padding graphs of a fixed-shape batch.
  * ------------------------------------------------------------------------- */
@@ -697,8 +697,15 @@ typedef struct phc_downstream_desc {
     float *dx, *dz1, *dz2, *dz3, *dwb1, *dwb2, *dWr;
     float *partial;
     uint32_t *sync;
+    /* ABI 5 (may all be NULL): the k4 forms of H1, H2 and of their transposes (phc_phm_H_job.Hk4 / HTk4).  With them the call runs
+     * on the 16-row kernels (csrc/downstream.hip, v2): 16 rows per workgroup (32 above 1024 rows), the three wide GEMMs on
+     * v_mfma_f32_16x16x4_f32 with the operand loaded straight into registers — no LDS staging pass in front of the first MFMA —
+     * and d0, d1, d2 any multiple of 4 in [16, 256] (the 256-wide heads of configs[2], the reference's 180 -> 180 -> 80 head),
+     * B <= 2048 (phc_downstream_supported_k4).  Same results up to the fp32 summation order; same partial / sync protocol. */
+    const float *H1k4, *H2k4, *H1Tk4, *H2Tk4;
 } phc_downstream_desc;
 int phc_downstream_supported(int64_t B, int d0, int d1, int d2, int d3, int T);
+int phc_downstream_supported_k4(int64_t B, int d0, int d1, int d2, int d3, int T);
 size_t phc_downstream_partial_floats(int64_t B);
 int phc_downstream_fwd(const phc_downstream_desc *desc, void *stream);
 int phc_downstream_bwd(const phc_downstream_desc *desc, void *stream);

@@ -29,6 +29,7 @@
 namespace phc {
 
 using f32x16 = __attribute__((ext_vector_type(16))) float;
+using f32x4_t = __attribute__((ext_vector_type(4))) float;
 
 constexpr int DN_THREADS = 256;
 constexpr int DN_ROWS = 32;
@@ -54,6 +55,7 @@ struct DnArgs {
     const int *n_valid;
     // forward operands: H* row-major [K][N]; backward operands: H*T row-major [N][K] (= H^T)
     const float *x, *H1, *b1, *H2, *b2, *H3, *b3, *H1T, *H2T, *H3T, *Wr, *br;
+    const float *H1k4, *H2k4, *H1Tk4, *H2Tk4;                 // v2: k4 forms of H1, H2 (forward) and of their transposes (backward)
     DnNorm bn1, bn2;
     float *z1, *z2, *z3, *logits, *stat1, *stat2;             // forward outputs (z*, stat* are what the backward reads)
     const float *dlogits;
@@ -627,6 +629,747 @@ __global__ __launch_bounds__(DN_THREADS) void downstream_bwd_kernel(DnArgs a) {
     if (g == 0 && tid == 0) __hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// =====================================================================================================================
+// v2 of the fused head (round 4): the same chain and the same exchange protocol with
+//   * 16 rows per workgroup (32 above 1024 rows) and 512 threads: twice the workgroups, each GEMM half as long — the launch is a
+//     chain of latency-bound phases, so the phases are what must shrink;
+//   * the three big GEMMs on v_mfma_f32_16x16x4_f32 with the operand matrix taken straight from memory in its k4 form
+//     (phc_phm_H_job.Hk4 / HTk4: one 16-byte load = four consecutive k of one column) into REGISTERS — all of a wavefront's
+//     loads in flight at once, issued at kernel entry (first GEMM) or behind a publish (the next GEMM's operand arrives while
+//     the statistics travel) — no 64 KB LDS staging pass in front of the first MFMA (6 us of the 32 us v1 launch);
+//   * widths that are any multiple of 4 up to 256 (zero-padded k-groups / column tiles): the 256-wide ZINC / molpcba-style
+//     heads and the reference's 180 -> 180 -> 80 head run fused too.
+// MFMA roles as in gemm_hs_device.h: A := operand slice (A[i][k] = H[k][col0 + i]), B := activations (B[k][j] = a[row j][k]),
+// lane (c = lane % 16, kq = lane / 16) ends with y[row c][col0 + 4 kq .. + 3].  Activations live in LDS as [rows][ld] with
+// ld = width rounded up to 16, + 4 (one 16-byte pad: the 16 lanes of a kq group read 16 different bank groups).
+// =====================================================================================================================
+constexpr int D2_THREADS = 512, D2_WAVES = 8;
+constexpr int D2_MAXW = 256;                           // widest layer (d0, d1, d2)
+constexpr int D2_EXTRA = DN_MAXT * DN_MAXD3 + DN_MAXT;
+constexpr int D2_PSTRIDE = 2 * D2_MAXW + D2_EXTRA;     // granules per workgroup per exchange
+constexpr int D2_MAX_WG = 128;
+constexpr int D2_MERGE = 16;                           // granule pairs in flight per thread while collecting
+
+__host__ __device__ __forceinline__ int r16(int v) { return (v + 15) & ~15; }
+
+// one wavefront's share of a GEMM  out[R, N] = A[R, K] . H[K, N]:  tiles of 16 columns; with fewer than 8 tiles the
+// contraction is split over the wavefronts that share a tile (partials meet in LDS)
+struct D2Plan {
+    int tiles, tp2, ks_n, tile0, tpw, kg0, kgn;
+};
+__device__ __forceinline__ D2Plan d2_plan(int K, int N, int wave) {
+    D2Plan p;
+    const int kg = (K + 15) >> 4;
+    p.tiles = (N + 15) >> 4;
+    if (p.tiles > 4) {
+        p.tp2 = 8; p.ks_n = 1; p.tile0 = wave; p.tpw = (p.tiles + 7) >> 3; p.kg0 = 0; p.kgn = kg;
+    } else {
+        p.tp2 = p.tiles <= 1 ? 1 : (p.tiles <= 2 ? 2 : 4);
+        p.ks_n = 8 / p.tp2;
+        p.tile0 = wave % p.tp2;
+        const int ks = wave / p.tp2;
+        p.tpw = 1;
+        p.kg0 = ks * kg / p.ks_n;
+        p.kgn = (ks + 1) * kg / p.ks_n - p.kg0;
+    }
+    // (every field is the same for all lanes of a wavefront: tell the compiler, so that the branches on them are scalar)
+    p.tile0 = __builtin_amdgcn_readfirstlane(p.tile0); p.kg0 = __builtin_amdgcn_readfirstlane(p.kg0);
+    p.kgn = __builtin_amdgcn_readfirstlane(p.kgn); p.tpw = __builtin_amdgcn_readfirstlane(p.tpw);
+    p.tiles = __builtin_amdgcn_readfirstlane(p.tiles); p.ks_n = __builtin_amdgcn_readfirstlane(p.ks_n);
+    p.tp2 = __builtin_amdgcn_readfirstlane(p.tp2);
+    return p;
+}
+
+// A barrier that orders LDS traffic only: __syncthreads() also waits for every global load / store in flight (s_waitcnt
+// vmcnt(0)) — here that would put the next GEMM's operand loads (issued early on purpose) and the slab's write-back in
+// front of every phase boundary (measured: 4.2 us for a 0.3 us element-wise phase).
+__device__ __forceinline__ void d2_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
+struct D2Regs {
+    f32x4_t v[2][16];                                   // [tile of this wavefront][k-group of this wavefront]
+};
+
+// every operand load of the wavefront in flight together.  Whole blocks of four k-groups (and the second tile) are skipped by
+// WAVE-UNIFORM branches — d2_gemm_t skips the same blocks, so their registers are never read; a CU's address unit needs 16
+// cycles per 16-byte wave-load: with all 32 slots loaded (24 of them dummies at 128 x 128) the eight wavefronts of a workgroup
+// spent 1.9 us just issuing.  Inside a block the loads are unconditional (clamped address, selected value): a per-lane
+// conditional load is a branch with a full wait at its join.
+__device__ __forceinline__ void d2_load_operand(const float *__restrict__ Hk4, int K, int N, const D2Plan &p, int lane, D2Regs &h) {
+    const int c = lane & 15, kq = lane >> 4;
+    const f32x4_t *src = reinterpret_cast<const f32x4_t *>(Hk4);
+    const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int g4 = 0; g4 < 4; ++g4) {
+            if (t < p.tpw && 4 * g4 < p.kgn) {
+#pragma unroll
+                for (int gq = 0; gq < 4; ++gq) {
+                    const int gi = 4 * g4 + gq;
+                    const int tile = p.tile0 + 8 * t, col = 16 * tile + c, srow = 4 * (p.kg0 + gi) + kq;
+                    const bool ok = gi < p.kgn && tile < p.tiles && col < N && srow < (K >> 2);
+                    const f32x4_t v = src[ok ? (size_t)srow * N + col : 0];
+                    h.v[t][gi] = ok ? v : zero;
+                }
+            }
+        }
+}
+
+// out[r][col] = sum_k A[r][k] H[k][col] (+ bias[col]); A in LDS [16 RB][lda] (columns K .. r16(K) zero), out in LDS [16 RB][ldo]
+// (columns N .. r16(N) come out as 0), red: LDS scratch of 8 * 16 RB * 20 floats.  Ends with a barrier.
+template <int RB, int TPW>
+__device__ __forceinline__ void d2_gemm_t(const float *A, int lda, const D2Regs &h, const D2Plan &p, int N, const float *__restrict__ bias,
+                                          float *red, float *out, int ldo) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, kq = lane >> 4;
+    const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+    f32x4_t acc[RB][TPW][2];                              // [row block][tile][chain]: two independent accumulator chains per tile
+#pragma unroll
+    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) acc[rb][t][0] = acc[rb][t][1] = zero;
+#pragma unroll
+    for (int g4 = 0; g4 < 4; ++g4) {
+        if (4 * g4 < p.kgn) {                            // wave-uniform: whole groups of four k-groups are skipped
+#pragma unroll
+            for (int gq = 0; gq < 4; ++gq) {
+                const int gi = 4 * g4 + gq;
+                const int g = p.kg0 + min(gi, p.kgn - 1);     // (beyond kgn the operand registers are zero)
+                f32x4_t fr[RB];
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb) fr[rb] = *reinterpret_cast<const f32x4_t *>(A + (rb * 16 + c) * lda + 16 * g + 4 * kq);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int rb = 0; rb < RB; ++rb)
+#pragma unroll
+                        for (int t = 0; t < TPW; ++t)
+                            acc[rb][t][q & 1] = __builtin_amdgcn_mfma_f32_16x16x4f32(h.v[t][gi][q], fr[rb][q], acc[rb][t][q & 1], 0, 0, 0);
+            }
+        }
+    }
+    if (p.ks_n == 1) {
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            const int tile = p.tile0 + 8 * t;
+            if (tile < p.tiles) {
+                const int col = 16 * tile + 4 * kq;
+                f32x4_t b4 = zero;
+                if (bias) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) b4[q] = col + q < N ? bias[col + q] : 0.f;
+                }
+#pragma unroll
+                for (int rb = 0; rb < RB; ++rb)
+                    *reinterpret_cast<f32x4_t *>(out + (rb * 16 + c) * ldo + col) = acc[rb][t][0] + acc[rb][t][1] + b4;
+            }
+        }
+        d2_lds_barrier();
+        return;
+    }
+    // split contraction: partial tiles -> red[wave][16 RB][20], then one output element per thread and round
+    {
+        float *mine = red + (size_t)wave * (16 * RB * 20);
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) *reinterpret_cast<f32x4_t *>(mine + (rb * 16 + c) * 20 + 4 * kq) = acc[rb][0][0] + acc[rb][0][1];
+    }
+    d2_lds_barrier();
+    const int Np = 16 * p.tiles;
+    for (int e = tid; e < 16 * RB * Np; e += D2_THREADS) {
+        const int row = e / Np, col = e - row * Np;
+        const int tile = col >> 4, cc = col & 15;
+        float v = (bias && col < N) ? bias[col] : 0.f;
+        for (int ks = 0; ks < p.ks_n; ++ks) v += red[(size_t)(ks * p.tp2 + tile) * (16 * RB * 20) + row * 20 + cc];
+        out[row * ldo + col] = v;
+    }
+    d2_lds_barrier();
+}
+
+template <int RB>
+__device__ __forceinline__ void d2_gemm(const float *A, int lda, const D2Regs &h, const D2Plan &p, int N, const float *__restrict__ bias,
+                                        float *red, float *out, int ldo) {
+    if (p.tpw > 1)                                       // (uniform over the workgroup: every wavefront's plan has the same tpw)
+        d2_gemm_t<RB, 2>(A, lda, h, p, N, bias, red, out, ldo);
+    else
+        d2_gemm_t<RB, 1>(A, lda, h, p, N, bias, red, out, ldo);
+}
+
+template <int RB>
+__device__ __forceinline__ int d2_rows_counted(int nvalid, int g) { return max(0, min(16 * RB, nvalid - g * 16 * RB)); }
+
+// A column's two values travel as ONE 16-byte pair of granules {a, tag, b, tag} (words 2 col, 2 col + 1 of the workgroup's
+// record): written by two 8-byte write-through stores, read by one 16-byte sc1 load — each half carries its own tag, so a pair
+// torn between the halves is simply "not there yet".  (Half the load instructions of the collect, and 16-byte sc1 loads run at
+// 1.4-1.8x the 8-byte rate: the collect's time is its bytes per CU, MI355X_MICROARCH.md 'allgather'.)
+using u32x4_t = __attribute__((ext_vector_type(4))) unsigned;
+__device__ __forceinline__ void d2_put_pair(unsigned long long *rec, int col, float va, float vb, unsigned tag) {
+    put_granule(rec + 2 * col, va, tag);
+    put_granule(rec + 2 * col + 1, vb, tag);
+}
+// collect column `col` of workgroups g0 .. g0 + D2_MERGE - 1 (clamped to G - 1)
+__device__ __forceinline__ void d2_collect(const unsigned long long *part, int G, int g0, int col, unsigned tag, float (&va)[D2_MERGE],
+                                           float (&vb)[D2_MERGE], int *err) {
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc((void *)part, 0, 0x7ffffff0, 0x00020000);
+    bool ok;
+    int spins = 0;
+    do {
+        ok = true;
+#pragma unroll
+        for (int u = 0; u < D2_MERGE; ++u) {
+            const int gg = min(g0 + u, G - 1);
+            const u32x4_t q = __builtin_amdgcn_raw_buffer_load_b128(rsrc, (int)(((size_t)gg * D2_PSTRIDE + 2 * col) * 8), 0, 16);   // aux 16 = sc1
+            va[u] = __uint_as_float(q[0]);
+            vb[u] = __uint_as_float(q[2]);
+            ok = ok && q[1] == tag && q[3] == tag;
+        }
+        if (!ok) {
+            __builtin_amdgcn_s_sleep(1);
+            if (++spins > DN_SPIN_MAX) {
+                if (err) atomicOr(err, PHC_ERR_RENDEZVOUS);
+#pragma unroll
+                for (int u = 0; u < D2_MERGE; ++u) va[u] = vb[u] = __int_as_float(0x7fc00000);      // poisoned, see collect_pairs
+                break;
+            }
+        }
+    } while (!ok);
+}
+
+// rows [rb, rb + 16 RB) of a [B, w] matrix <-> LDS [16 RB][ld]; rows >= B read as 0, columns w .. r16(w) are written 0
+template <int RB>
+__device__ __forceinline__ void d2_rows_to_lds(const float *__restrict__ src, int B, int rb, int w, float *dst, int ld) {
+    // (all loads of the slab in flight together, the LDS writes in a second pass: a "load, store" loop pays one memory round
+    // trip per iteration — hipcc drains the loads at the loop header)
+    constexpr int U = 2 * RB;                            // 16 RB rows x up to 64 float4 over 512 threads
+    const int w4 = r16(w) >> 2;
+    float4 v[U];
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int e = threadIdx.x + u * D2_THREADS;
+        const int row = e / w4, c4 = e - row * w4;
+        const bool ok = e < 16 * RB * w4 && rb + row < B && 4 * c4 < w;
+        v[u] = *reinterpret_cast<const float4 *>(src + (ok ? (size_t)(rb + row) * w + 4 * c4 : 0));
+        if (!ok) v[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int u = 0; u < U; ++u) {
+        const int e = threadIdx.x + u * D2_THREADS;
+        const int row = e / w4, c4 = e - row * w4;
+        if (e < 16 * RB * w4) *reinterpret_cast<float4 *>(dst + row * ld + 4 * c4) = v[u];
+    }
+}
+template <int RB>
+__device__ __forceinline__ void d2_store_rows(const float *src, int ld, int B, int rb, int w, float *__restrict__ dst) {
+    const int w4 = w >> 2;
+    for (int e = threadIdx.x; e < 16 * RB * w4; e += D2_THREADS) {
+        const int row = e / w4, c4 = e - row * w4;
+        if (rb + row < B)
+            *reinterpret_cast<float4 *>(dst + (size_t)(rb + row) * w + 4 * c4) = *reinterpret_cast<const float4 *>(src + row * ld + 4 * c4);
+    }
+}
+
+// How the collect of one exchange is dealt over the 512 threads: column = tid % nc, part = tid / nc; part p merges the
+// workgroups [p gp, (p + 1) gp) in ascending order, the column's part-0 thread then merges the parts in ascending order (a
+// fixed order: bit-reproducible).  One round = 16 granule pairs in flight per thread; at 34 workgroups and 128 columns every
+// thread has 9: ONE round trip instead of three (the rounds were the exchange's cost: ~3 us each).
+struct D2Deal {
+    int nc, parts, gp;
+};
+__device__ __forceinline__ D2Deal d2_deal(int N, int G) {
+    D2Deal d;
+    d.nc = (N + 31) & ~31;
+    d.parts = min(min(D2_THREADS / d.nc, 4), G);              // (at most four: the column's last merge walks the parts one by one)
+    d.gp = (G + d.parts - 1) / d.parts;
+    return d;
+}
+
+// What workgroup 0 leaves behind of a forward norm (save_stat, running statistics): kept in registers and written at the END
+// of the launch — written in place, the stores sat in front of the next barrier of the one workgroup every other one waits for.
+struct D2Keep {
+    float mean, invstd, w, b, unbiased, rm_old, rv_old;
+    int valid;
+};
+__device__ __forceinline__ void d2_write_norm_state(const DnNorm &bn, const D2Keep &k, float *stat, int N) {
+    const int tid = threadIdx.x;
+    if (tid < N && k.valid) {
+        stat[tid] = k.mean;
+        stat[N + tid] = k.invstd;
+        stat[2 * N + tid] = k.invstd * k.w;
+        stat[3 * N + tid] = k.b - k.mean * k.invstd * k.w;
+        stat[4 * N + tid] = k.w;
+        stat[5 * N + tid] = k.b;
+        const int comp = tid / bn.k, kk = tid - comp * bn.k;
+        for (int q = 0; q < bn.n_comp; ++q) {                    // uniform index into the kernarg pointer tables
+            if (q == comp) {
+                bn.rmean[q][kk] = (1.f - bn.momentum) * k.rm_old + bn.momentum * k.mean;
+                bn.rvar[q][kk] = (1.f - bn.momentum) * k.rv_old + bn.momentum * k.unbiased;
+            }
+            if (q == tid && bn.nbt[q]) *bn.nbt[q] += 1;
+        }
+    }
+}
+
+// forward norm over all rows (as fwd_norm): Z = this workgroup's slab [16 RB][ld]; scale / shift -> sc[0 .. N) / sc[D2_MAXW ..);
+// scratch: 3 x 512 floats of LDS (the parts' partial merges)
+template <int RB>
+__device__ __forceinline__ void d2_fwd_norm(const DnArgs &a, const DnNorm &bn, const float *Z, int ld, int N, int nvalid,
+                                            unsigned long long *part, unsigned tag, float *sc, float *scratch, float w, float b,
+                                            float rm_old, float rv_old, D2Keep &keep, int stamp) {
+    const int tid = threadIdx.x, g = blockIdx.x;
+    if (tid < N) {
+        const int nv = d2_rows_counted<RB>(nvalid, g);
+        float s = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16 * RB; ++r) s += r < nv ? Z[r * ld + tid] : 0.f;
+        const float mean_l = nv > 0 ? s / (float)nv : 0.f;
+        float m2 = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16 * RB; ++r) {
+            const float d = Z[r * ld + tid] - mean_l;
+            m2 = r < nv ? fmaf(d, d, m2) : m2;
+        }
+        d2_put_pair(part + (size_t)g * D2_PSTRIDE, tid, s, m2, tag);
+    }
+    DN_STAMP(stamp);
+    const D2Deal dl = d2_deal(N, a.G);
+    const int col = tid % dl.nc, pt = tid / dl.nc;
+    const bool active = pt < dl.parts && col < N;
+    float n = 0.f, mean = 0.f, M2 = 0.f;
+    if (active) {
+        const int gbeg = pt * dl.gp, gend = min(gbeg + dl.gp, a.G);
+        for (int g0 = gbeg; g0 < gend; g0 += D2_MERGE) {
+            float ps[D2_MERGE], pm[D2_MERGE];
+            d2_collect(part, gend, g0, col, tag, ps, pm, a.err);
+#pragma unroll
+            for (int u = 0; u < D2_MERGE; ++u) {
+                const float ng = g0 + u < gend ? (float)d2_rows_counted<RB>(nvalid, g0 + u) : 0.f;
+                if (ng > 0.f) {
+                    const float delta = ps[u] / ng - mean, tot = n + ng;
+                    mean += delta * (ng / tot);
+                    M2 += pm[u] + delta * delta * (n * ng / tot);
+                    n = tot;
+                }
+            }
+        }
+        scratch[pt * dl.nc + col] = n;
+        scratch[512 + pt * dl.nc + col] = mean;
+        scratch[1024 + pt * dl.nc + col] = M2;
+    }
+    d2_lds_barrier();
+    DN_STAMP(stamp + 1);
+    if (tid < N) {
+        for (int q = 1; q < dl.parts; ++q) {                     // part 0 is this thread's own (n, mean, M2)
+            const float nq = scratch[q * dl.nc + tid], mq = scratch[512 + q * dl.nc + tid], Mq = scratch[1024 + q * dl.nc + tid];
+            if (nq > 0.f) {
+                const float delta = mq - mean, tot = n + nq;
+                mean += delta * (nq / tot);
+                M2 += Mq + delta * delta * (n * nq / tot);
+                n = tot;
+            }
+        }
+        const float cnt = fmaxf(n, 1.f);
+        const float var = fmaxf(M2 / cnt, 0.f);
+        const float invstd = 1.f / sqrtf(var + bn.eps);
+        sc[tid] = invstd * w;
+        sc[D2_MAXW + tid] = b - mean * invstd * w;
+        keep.mean = mean; keep.invstd = invstd; keep.w = w; keep.b = b; keep.rm_old = rm_old; keep.rv_old = rv_old;
+        keep.unbiased = n > 1.f ? M2 / (n - 1.f) : var;
+        keep.valid = (mean == mean && M2 == M2) ? 1 : 0;         // (NaN: the exchange timed out — nothing persistent is touched)
+    }
+    d2_lds_barrier();
+}
+
+// Aout = act(Z * scale + shift) on the slab (rows >= n_valid: 0; columns N .. r16(N): 0)
+template <int RB>
+__device__ __forceinline__ void d2_apply_norm_act(const float *Z, int ldz, float *Aout, int lda, int N, const float *sc, int act, int rb,
+                                                  int nvalid) {
+    const int n4 = r16(N) >> 2;
+    const bool relu = act == PHC_ACT_RELU;
+    for (int e = threadIdx.x; e < 16 * RB * n4; e += D2_THREADS) {
+        const int row = e / n4, c = (e - row * n4) << 2;
+        float4 o = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < N && rb + row < nvalid) {
+            const float4 z = *reinterpret_cast<const float4 *>(Z + row * ldz + c);
+            const float4 s4 = *reinterpret_cast<const float4 *>(sc + c), h4 = *reinterpret_cast<const float4 *>(sc + D2_MAXW + c);
+            if (relu) {
+                o.x = fmaxf(fmaf(z.x, s4.x, h4.x), 0.f); o.y = fmaxf(fmaf(z.y, s4.y, h4.y), 0.f);
+                o.z = fmaxf(fmaf(z.z, s4.z, h4.z), 0.f); o.w = fmaxf(fmaf(z.w, s4.w, h4.w), 0.f);
+            } else {
+                o.x = act_fwd_rt(act, fmaf(z.x, s4.x, h4.x)); o.y = act_fwd_rt(act, fmaf(z.y, s4.y, h4.y));
+                o.z = act_fwd_rt(act, fmaf(z.z, s4.z, h4.z)); o.w = act_fwd_rt(act, fmaf(z.w, s4.w, h4.w));
+            }
+        }
+        *reinterpret_cast<float4 *>(Aout + row * lda + c) = o;
+    }
+    d2_lds_barrier();
+}
+
+// LDS carve-up shared by host and device (floats)
+struct D2Lds {
+    int ldx, ld1, ld2, off_a, off_b, off_red, off_sc, off_small, total;
+};
+__host__ __device__ inline D2Lds d2_lds(int RB, int d0, int d1, int d2, int d3, int T) {
+    D2Lds l;
+    l.ldx = r16(d0) + 4; l.ld1 = r16(d1) + 4; l.ld2 = r16(d2) + 4;
+    const int ldm = (l.ldx > l.ld1 ? (l.ldx > l.ld2 ? l.ldx : l.ld2) : (l.ld1 > l.ld2 ? l.ld1 : l.ld2));
+    const int R = 16 * RB;
+    l.off_a = 0;                                         // buffer A  [R][ldm]
+    l.off_b = l.off_a + R * ldm;                         // buffer B  [R][ldm]
+    l.off_red = l.off_b + R * ldm;                       // split-contraction partials [8][R][20]
+    l.off_sc = l.off_red + 8 * R * 20;                   // scale | shift (forward), mean g | mean g x_hat (backward): 2 x D2_MAXW
+    l.off_small = l.off_sc + 2 * D2_MAXW;                // H3 / H3T, Wr, br, biases, z3 slab, statistics rows, ...
+    // forward: H3 [d2 d3] + Wr [T d3 + T] + z3s [R d3] + biases 3 x D2_MAXW
+    // backward: H3T [d3 d2] + Wr [T d3] + dls [R T] + z3s, dz3s [R d3] x 2 + st1, st2 [4 D2_MAXW] x 2 + third slab [R][ldm]
+    const int fwd = r4(d2 * d3) + r4(T * d3 + T) + r4(R * d3) + 3 * D2_MAXW;
+    const int bwd = r4(d3 * d2) + r4(T * d3) + r4(R * T) + 2 * r4(R * d3) + 8 * D2_MAXW + R * ldm;
+    l.total = l.off_small + (fwd > bwd ? fwd : bwd) + 16;
+    return l;
+}
+
+template <int RB>
+__global__ __launch_bounds__(D2_THREADS) void downstream2_fwd_kernel(DnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int R = 16 * RB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = blockIdx.x, rb = g * R;
+    const int d0 = a.d0, d1 = a.d1, d2 = a.d2, d3 = a.d3, T = a.T;
+    const D2Lds L = d2_lds(RB, d0, d1, d2, d3, T);
+    float *bufA = sm + L.off_a, *bufB = sm + L.off_b, *red = sm + L.off_red, *sc = sm + L.off_sc;
+    float *Hs3 = sm + L.off_small, *wr = Hs3 + r4(d2 * d3), *z3s = wr + r4(T * d3 + T), *bs = z3s + r4(R * d3);     // bs: b1 | b2 | b3
+    const unsigned tag = __hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    const int nvalid = a.n_valid ? min(*a.n_valid, a.B) : a.B;
+
+    // ---- everything this launch reads from memory goes in flight now: the first GEMM's operand slice into registers, the
+    // x slab and the small operands into LDS ----
+    DN_STAMP(0);
+    const D2Plan p1 = d2_plan(d0, d1, wave), p2 = d2_plan(d1, d2, wave);
+    D2Regs h;
+    d2_load_operand(a.H1k4, d0, d1, p1, lane, h);
+    DN_STAMP(12);
+    // the norms' per-component parameter pointers -> LDS (uniform kernarg reads), each column thread fetches its own four values
+    // behind the staging barrier: they arrive under the first GEMM (as run-time loops over the components with the loads inside,
+    // hipcc drained the loads once per component: 3.3 us in front of the staging barrier)
+    unsigned long long *ptab = reinterpret_cast<unsigned long long *>(sc);       // [2 norms][4 arrays][16 components]; sc is free until the first norm
+    if (tid == 0) {
+        for (int q = 0; q < a.bn1.n_comp; ++q) {
+            ptab[0 * 16 + q] = (unsigned long long)a.bn1.weight[q]; ptab[1 * 16 + q] = (unsigned long long)a.bn1.bias[q];
+            ptab[2 * 16 + q] = (unsigned long long)a.bn1.rmean[q]; ptab[3 * 16 + q] = (unsigned long long)a.bn1.rvar[q];
+        }
+        for (int q = 0; q < a.bn2.n_comp; ++q) {
+            ptab[4 * 16 + q] = (unsigned long long)a.bn2.weight[q]; ptab[5 * 16 + q] = (unsigned long long)a.bn2.bias[q];
+            ptab[6 * 16 + q] = (unsigned long long)a.bn2.rmean[q]; ptab[7 * 16 + q] = (unsigned long long)a.bn2.rvar[q];
+        }
+    }
+    DN_STAMP(13);
+    d2_rows_to_lds<RB>(a.x, a.B, rb, d0, bufA, L.ldx);
+    DN_STAMP(14);
+    for (int e = tid; e < d2 * d3; e += D2_THREADS) Hs3[e] = a.H3[e];
+    for (int e = tid; e < T * d3; e += D2_THREADS) wr[e] = a.Wr[e];
+    if (tid < T) wr[T * d3 + tid] = a.br ? a.br[tid] : 0.f;
+    if (tid < d1) bs[tid] = a.b1 ? a.b1[tid] : 0.f;
+    if (tid < d2) bs[D2_MAXW + tid] = a.b2 ? a.b2[tid] : 0.f;
+    if (tid < d3) bs[2 * D2_MAXW + tid] = a.b3 ? a.b3[tid] : 0.f;
+    __syncthreads();
+    DN_STAMP(1);
+    float w1 = 1.f, bb1 = 0.f, rm1 = 0.f, rv1 = 1.f, w2 = 1.f, bb2 = 0.f, rm2 = 0.f, rv2 = 1.f;
+    {
+        const int c1 = min(tid, d1 - 1), c2 = min(tid, d2 - 1);
+        const int q1 = c1 / a.bn1.k, k1 = c1 - q1 * a.bn1.k, q2 = c2 / a.bn2.k, k2 = c2 - q2 * a.bn2.k;
+        const float *pw1 = reinterpret_cast<const float *>(ptab[0 * 16 + q1]), *pb1 = reinterpret_cast<const float *>(ptab[1 * 16 + q1]);
+        const float *pm1 = reinterpret_cast<const float *>(ptab[2 * 16 + q1]), *pv1 = reinterpret_cast<const float *>(ptab[3 * 16 + q1]);
+        const float *pw2 = reinterpret_cast<const float *>(ptab[4 * 16 + q2]), *pb2 = reinterpret_cast<const float *>(ptab[5 * 16 + q2]);
+        const float *pm2 = reinterpret_cast<const float *>(ptab[6 * 16 + q2]), *pv2 = reinterpret_cast<const float *>(ptab[7 * 16 + q2]);
+        // (unconditional loads: without affine parameters the weight / bias slots are read from the running mean's address)
+        const float lw1 = (a.bn1.affine ? pw1 : pm1)[k1], lb1 = (a.bn1.affine ? pb1 : pm1)[k1], lw2 = (a.bn2.affine ? pw2 : pm2)[k2],
+                    lb2 = (a.bn2.affine ? pb2 : pm2)[k2];
+        rm1 = pm1[k1]; rv1 = pv1[k1]; rm2 = pm2[k2]; rv2 = pv2[k2];
+        if (a.bn1.affine) { w1 = lw1; bb1 = lb1; }
+        if (a.bn2.affine) { w2 = lw2; bb2 = lb2; }
+    }
+    d2_lds_barrier();                                            // (the pointer table sits in `sc`: every read is done before the first norm writes it)
+
+    // layer 1: z1 = x . H1 + b1 -> norm -> act
+    d2_gemm<RB>(bufA, L.ldx, h, p1, d1, bs, red, bufB, L.ld1);
+    DN_STAMP(2);
+    d2_store_rows<RB>(bufB, L.ld1, a.B, rb, d1, a.z1);
+    D2Keep k1 = {}, k2 = {};
+    d2_fwd_norm<RB>(a, a.bn1, bufB, L.ld1, d1, nvalid, a.partial, tag, sc, red, w1, bb1, rm1, rv1, k1, 3);
+    // the second GEMM's operand: issued BEHIND the exchange (its lines would compete with the granule sweep for the CU's few
+    // outstanding misses: the collect took 6.5 us with the operand in flight beside it, 2.6 us without), it arrives under the
+    // element-wise pass
+    d2_load_operand(a.H2k4, d1, d2, p2, lane, h);
+    DN_STAMP(5);
+    d2_apply_norm_act<RB>(bufB, L.ld1, bufA, L.ld1, d1, sc, a.act, rb, nvalid);
+    // layer 2
+    DN_STAMP(6);
+    d2_gemm<RB>(bufA, L.ld1, h, p2, d2, bs + D2_MAXW, red, bufB, L.ld2);
+    DN_STAMP(7);
+    d2_store_rows<RB>(bufB, L.ld2, a.B, rb, d2, a.z2);
+    d2_fwd_norm<RB>(a, a.bn2, bufB, L.ld2, d2, nvalid, a.partial + (size_t)a.G * D2_PSTRIDE, tag, sc, red, w2, bb2, rm2, rv2, k2, 8);
+    DN_STAMP(10);
+    d2_apply_norm_act<RB>(bufB, L.ld2, bufA, L.ld2, d2, sc, a.act, rb, nvalid);
+    // layer 3 (d2 -> d3 = n * target, a handful of columns) and the real head (d3 -> T): plain FMAs
+    // (eight lanes per output element, each a strided eighth of the contraction, fixed-order butterfly: one thread per element
+    // walked d2 dependent LDS reads — 1.6 us for 64 outputs)
+    for (int e0 = 0; e0 < R * d3; e0 += D2_THREADS / 8) {
+        const int e = e0 + (tid >> 3), part = tid & 7;
+        const int row = min(e, R * d3 - 1) / d3, j = min(e, R * d3 - 1) - row * d3;
+        float v = 0.f;
+        for (int k = part; k < d2; k += 8) v = fmaf(bufA[row * L.ld2 + k], Hs3[k * d3 + j], v);
+        v += __shfl_xor(v, 1, 64);
+        v += __shfl_xor(v, 2, 64);
+        v += __shfl_xor(v, 4, 64);
+        v += bs[2 * D2_MAXW + j];
+        if (part == 0 && e < R * d3) {
+            z3s[row * d3 + j] = v;
+            if (rb + row < a.B) a.z3[(size_t)(rb + row) * d3 + j] = v;
+        }
+    }
+    d2_lds_barrier();
+    for (int e = tid; e < R * T; e += D2_THREADS) {
+        const int row = e / T, t = e - row * T;
+        float v = wr[T * d3 + t];
+        for (int j = 0; j < d3; ++j) v = fmaf(z3s[row * d3 + j], wr[t * d3 + j], v);
+        if (rb + row < a.B) a.logits[(size_t)(rb + row) * T + t] = v;
+    }
+    DN_STAMP(11);
+    if (g == 0) {                                                // what the norms leave behind, off every other workgroup's path
+        d2_write_norm_state(a.bn1, k1, a.stat1, d1);
+        d2_write_norm_state(a.bn2, k2, a.stat2, d2);
+        if (tid == 0) __hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+}
+
+// backward norm (as bwd_norm): Gm = g, XH = x_hat, both [16 RB][ld] in LDS; Gm := dz in place.  keep_sg / keep_sgx: the column
+// totals (workgroup 0 writes dweight | dbias from them at the end of the launch); scratch: 2 x 512 floats of LDS
+template <int RB>
+__device__ __forceinline__ void d2_bwd_norm(const DnArgs &a, float *Gm, const float *XH, int ld, int N, int nvalid, int rb,
+                                            unsigned long long *part, unsigned tag, const float *st, float *sc, float *scratch,
+                                            float &keep_sg, float &keep_sgx, int stamp) {
+    const int tid = threadIdx.x, g = blockIdx.x;
+    if (tid < N) {
+        float sg = 0.f, sgx = 0.f;
+#pragma unroll
+        for (int r = 0; r < 16 * RB; ++r) {
+            const float gv = Gm[r * ld + tid];
+            sg += gv;
+            sgx = fmaf(gv, XH[r * ld + tid], sgx);
+        }
+        d2_put_pair(part + (size_t)g * D2_PSTRIDE, tid, sg, sgx, tag);
+    }
+    DN_STAMP(stamp);
+    const D2Deal dl = d2_deal(N, a.G);
+    const int col = tid % dl.nc, pt = tid / dl.nc;
+    float SG = 0.f, SGX = 0.f;
+    if (pt < dl.parts && col < N) {
+        const int gbeg = pt * dl.gp, gend = min(gbeg + dl.gp, a.G);
+        for (int g0 = gbeg; g0 < gend; g0 += D2_MERGE) {
+            float pa[D2_MERGE], pb[D2_MERGE];
+            d2_collect(part, gend, g0, col, tag, pa, pb, a.err);
+#pragma unroll
+            for (int u = 0; u < D2_MERGE; ++u)
+                if (g0 + u < gend) {
+                    SG += pa[u];
+                    SGX += pb[u];
+                }
+        }
+        scratch[pt * dl.nc + col] = SG;
+        scratch[512 + pt * dl.nc + col] = SGX;
+    }
+    d2_lds_barrier();
+    DN_STAMP(stamp + 1);
+    if (tid < N) {
+        for (int q = 1; q < dl.parts; ++q) {
+            SG += scratch[q * dl.nc + tid];
+            SGX += scratch[512 + q * dl.nc + tid];
+        }
+        const float cnt = (float)max(nvalid, 1);
+        sc[tid] = SG / cnt;
+        sc[D2_MAXW + tid] = SGX / cnt;
+        keep_sg = SG;
+        keep_sgx = SGX;
+    }
+    d2_lds_barrier();
+    const int n4 = r16(N) >> 2;
+    for (int e = tid; e < 16 * RB * n4; e += D2_THREADS) {
+        const int row = e / n4, c = (e - row * n4) << 2;
+        float4 gq = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (c < N && rb + row < nvalid) {
+            gq = *reinterpret_cast<const float4 *>(Gm + row * ld + c);
+            const float4 xh = *reinterpret_cast<const float4 *>(XH + row * ld + c);
+            const float4 w4 = *reinterpret_cast<const float4 *>(st + 2 * D2_MAXW + c), i4 = *reinterpret_cast<const float4 *>(st + D2_MAXW + c);
+            const float4 mg = *reinterpret_cast<const float4 *>(sc + c), mx = *reinterpret_cast<const float4 *>(sc + D2_MAXW + c);
+            gq.x = w4.x * i4.x * (gq.x - mg.x - xh.x * mx.x);
+            gq.y = w4.y * i4.y * (gq.y - mg.y - xh.y * mx.y);
+            gq.z = w4.z * i4.z * (gq.z - mg.z - xh.z * mx.z);
+            gq.w = w4.w * i4.w * (gq.w - mg.w - xh.w * mx.w);
+        }
+        *reinterpret_cast<float4 *>(Gm + row * ld + c) = gq;
+    }
+    d2_lds_barrier();
+}
+
+// The extras of the first backward exchange (dWr | dbr partials of every workgroup) summed by workgroup 0 at the END of the
+// launch: extra j by wavefront j % 8, the G <= 128 workgroups over its lanes (two per lane), eight extras in flight per round,
+// fixed-order butterfly.  (Merged in place by one wavefront, one granule at a time, this was 34 dependent round trips in front
+// of the barrier that every other workgroup's next exchange waits behind.)
+__device__ __forceinline__ void d2_merge_extras(const unsigned long long *part, int G, unsigned tag, int n_extra, float *out, int *err) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int j0 = 8 * wave; j0 < n_extra; j0 += 64) {           // this wavefront's extras j0 .. j0 + 7 (of every group of 64)
+        float v[8][2];
+        bool ok;
+        int spins = 0;
+        do {
+            ok = true;
+#pragma unroll
+            for (int u = 0; u < 8; ++u)
+#pragma unroll
+                for (int hh = 0; hh < 2; ++hh) {
+                    const int j = min(j0 + u, n_extra - 1), gg = lane + 64 * hh;
+                    const unsigned long long q = get_granule(part + (size_t)min(gg, G - 1) * D2_PSTRIDE + 2 * D2_MAXW + j);
+                    v[u][hh] = gg < G ? __uint_as_float((unsigned)q) : 0.f;
+                    ok = ok && (gg >= G || (unsigned)(q >> 32) == tag);
+                }
+            if (!ok && ++spins > DN_SPIN_MAX) {
+                if (err) atomicOr(err, PHC_ERR_RENDEZVOUS);
+#pragma unroll
+                for (int u = 0; u < 8; ++u) v[u][0] = v[u][1] = __int_as_float(0x7fc00000);
+                break;
+            }
+        } while (!ok);
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            float sum = v[u][0] + v[u][1];
+#pragma unroll
+            for (int off = 1; off < 64; off <<= 1) sum += __shfl_xor(sum, off, 64);
+            if (lane == 0 && j0 + u < n_extra) out[j0 + u] = sum;
+        }
+    }
+}
+
+// g = da * act'(x_hat w + b), x_hat = (z - mean) invstd for the slab: DA (LDS) and Z (LDS) -> Gout, XHout (may alias DA / Z)
+template <int RB>
+__device__ __forceinline__ void d2_gate_rows(const float *DA, const float *Z, int ld, int N, const float *st, int act, int rb, int nvalid,
+                                             float *Gout, float *XHout) {
+    const bool relu = act == PHC_ACT_RELU;
+    const int Np = r16(N);
+    for (int e = threadIdx.x; e < 16 * RB * Np; e += D2_THREADS) {
+        const int row = e / Np, c = e - row * Np;
+        float gv = 0.f, xh = 0.f;
+        if (c < N) {
+            xh = (Z[row * ld + c] - st[c]) * st[D2_MAXW + c];
+            const float pre = fmaf(xh, st[2 * D2_MAXW + c], st[3 * D2_MAXW + c]);
+            const float da = DA[row * ld + c];
+            gv = relu ? (pre > 0.f ? da : 0.f) : da * act_grad_rt(act, pre);
+            if (rb + row >= nvalid) gv = 0.f;
+        }
+        Gout[row * ld + c] = gv;
+        XHout[row * ld + c] = xh;
+    }
+    d2_lds_barrier();
+}
+
+template <int RB>
+__global__ __launch_bounds__(D2_THREADS) void downstream2_bwd_kernel(DnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int R = 16 * RB;
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = blockIdx.x, rb = g * R;
+    const int d0 = a.d0, d1 = a.d1, d2 = a.d2, d3 = a.d3, T = a.T;
+    const D2Lds L = d2_lds(RB, d0, d1, d2, d3, T);
+    const int ldm = max(L.ldx, max(L.ld1, L.ld2));
+    float *bufA = sm + L.off_a, *bufB = sm + L.off_b, *red = sm + L.off_red, *sc = sm + L.off_sc;
+    float *Hs3T = sm + L.off_small, *wr = Hs3T + r4(d3 * d2), *dls = wr + r4(T * d3), *z3s = dls + r4(R * T), *dz3s = z3s + r4(R * d3),
+          *st1 = dz3s + r4(R * d3), *st2 = st1 + 4 * D2_MAXW, *bufC = st2 + 4 * D2_MAXW;        // st*: mean | invstd | w | b
+    const unsigned tag = __hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    const int nvalid = a.n_valid ? min(*a.n_valid, a.B) : a.B;
+    (void)ldm;
+
+    // ---- everything in flight: the first GEMM's operand (H2^T) into registers, the slabs of z2 / z1 and the small operands into LDS ----
+    DN_STAMP(16);
+    const D2Plan pa = d2_plan(d2, d1, wave), pb = d2_plan(d1, d0, wave);
+    D2Regs h;
+    d2_load_operand(a.H2Tk4, d2, d1, pa, lane, h);
+    d2_rows_to_lds<RB>(a.z2, a.B, rb, d2, bufB, L.ld2);          // bufB: z2 slab -> x_hat2
+    d2_rows_to_lds<RB>(a.z1, a.B, rb, d1, bufC, L.ld1);          // bufC: z1 slab (kept until its turn)
+    for (int e = tid; e < d3 * d2; e += D2_THREADS) Hs3T[e] = a.H3T[e];
+    for (int e = tid; e < T * d3; e += D2_THREADS) wr[e] = a.Wr[e];
+    for (int e = tid; e < R * T; e += D2_THREADS) dls[e] = rb * T + e < a.B * T ? a.dlogits[(size_t)rb * T + e] : 0.f;
+    for (int e = tid; e < R * d3; e += D2_THREADS) z3s[e] = rb * d3 + e < a.B * d3 ? a.z3[(size_t)rb * d3 + e] : 0.f;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {                            // mean, invstd, w, b of both norms (save_stat slots 0, 1, 4, 5)
+        const int slot = q < 2 ? q : q + 2;
+        if (tid < d1) st1[q * D2_MAXW + tid] = a.stat1[slot * d1 + tid];
+        if (tid < d2) st2[q * D2_MAXW + tid] = a.stat2[slot * d2 + tid];
+    }
+    __syncthreads();
+    DN_STAMP(17);
+
+    // head and layer 3 backwards (a handful of columns): dz3 = dlogits . Wr, da2 = dz3 . H3^T; partial dWr | dbr of these rows
+    for (int e = tid; e < R * d3; e += D2_THREADS) {
+        const int row = e / d3, j = e - row * d3;
+        float v = 0.f;
+        for (int t = 0; t < T; ++t) v = fmaf(dls[row * T + t], wr[t * d3 + j], v);
+        dz3s[row * d3 + j] = v;
+        if (rb + row < a.B) a.dz3[(size_t)(rb + row) * d3 + j] = v;
+    }
+    unsigned long long *part1 = a.partial, *part2 = a.partial + (size_t)a.G * D2_PSTRIDE;
+    for (int e = tid; e < T * d3 + T; e += D2_THREADS) {
+        float s = 0.f;
+        if (e < T * d3) {
+            const int t = e / d3, j = e - t * d3;
+            for (int r = 0; r < R; ++r) s = fmaf(dls[r * T + t], z3s[r * d3 + j], s);
+        } else {
+            const int t = e - T * d3;
+            for (int r = 0; r < R; ++r) s += dls[r * T + t];
+        }
+        put_granule(part1 + (size_t)g * D2_PSTRIDE + 2 * D2_MAXW + e, s, tag);
+    }
+    d2_lds_barrier();
+    // da2 = dz3 . H3^T -> bufA; then g2 -> bufA, x_hat2 -> bufB (over z2)
+    {
+        const int Np = r16(d2);
+        for (int e = tid; e < R * Np; e += D2_THREADS) {
+            const int row = e / Np, c = e - row * Np;
+            float da = 0.f;
+            if (c < d2)
+                for (int j = 0; j < d3; ++j) da = fmaf(dz3s[row * d3 + j], Hs3T[j * d2 + c], da);
+            bufA[row * L.ld2 + c] = da;
+        }
+    }
+    d2_lds_barrier();
+    DN_STAMP(18);
+    d2_gate_rows<RB>(bufA, bufB, L.ld2, d2, st2, a.act, rb, nvalid, bufA, bufB);
+    DN_STAMP(19);
+    float sg2 = 0.f, sgx2 = 0.f, sg1 = 0.f, sgx1 = 0.f;
+    d2_bwd_norm<RB>(a, bufA, bufB, L.ld2, d2, nvalid, rb, part1, tag, st2, sc, red, sg2, sgx2, 20);
+    DN_STAMP(22);
+    d2_store_rows<RB>(bufA, L.ld2, a.B, rb, d2, a.dz2);
+    // da1 = dz2 . H2^T -> bufB; the last GEMM's operand (H1^T) goes in flight behind it
+    d2_gemm<RB>(bufA, L.ld2, h, pa, d1, nullptr, red, bufB, L.ld1);
+    DN_STAMP(23);
+    if (a.dx) d2_load_operand(a.H1Tk4, d1, d0, pb, lane, h);
+    d2_gate_rows<RB>(bufB, bufC, L.ld1, d1, st1, a.act, rb, nvalid, bufA, bufB);       // g1 -> bufA, x_hat1 -> bufB
+    DN_STAMP(24);
+    d2_bwd_norm<RB>(a, bufA, bufB, L.ld1, d1, nvalid, rb, part2, tag, st1, sc, red, sg1, sgx1, 25);
+    DN_STAMP(27);
+    d2_store_rows<RB>(bufA, L.ld1, a.B, rb, d1, a.dz1);
+    // dx = dz1 . H1^T
+    if (a.dx) {
+        d2_gemm<RB>(bufA, L.ld1, h, pb, d0, nullptr, red, bufB, L.ldx);
+        DN_STAMP(28);
+        d2_store_rows<RB>(bufB, L.ldx, a.B, rb, d0, a.dx);
+    }
+    DN_STAMP(29);
+    if (g == 0) {                                                // workgroup 0's leftovers, off every other workgroup's path
+        if (a.dwb2 && tid < d2) { a.dwb2[tid] = sgx2; a.dwb2[d2 + tid] = sg2; }
+        if (a.dwb1 && tid < d1) { a.dwb1[tid] = sgx1; a.dwb1[d1 + tid] = sg1; }
+        if (a.dWr) d2_merge_extras(part1, a.G, tag, T * d3 + T, a.dWr, a.err);
+    }
+    if (g == 0 && tid == 0) __hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+
 static size_t dn_lds_floats(int d0, int d1, int d2, int d3, int T, bool bwd) {
     const int KM = d0 > d1 ? (d0 > d2 ? d0 : d2) : (d1 > d2 ? d1 : d2);
     size_t f = 2 * (size_t)DN_ROWS * (KM + 4) + 4 * 32 * 33;
@@ -679,6 +1422,53 @@ static int dn_resident_capacity(bool bwd, size_t lds_bytes) {
     return sl.cap;
 }
 
+// ---- v2 (16-row workgroups, k4 operands) ----
+static inline bool dn2_enabled() {
+    static const bool off = getenv("PHC_DOWNSTREAM_V2") && atoi(getenv("PHC_DOWNSTREAM_V2")) == 0;
+    return !off;
+}
+// rows per workgroup: 16 (RB = 1) up to 1024 rows, 32 above (at most D2_MAX_WG workgroups).  PHC_DN2_RB=2 forces 32-row workgroups.
+static inline int dn2_rb(int B) {
+    static const int forced = getenv("PHC_DN2_RB") ? atoi(getenv("PHC_DN2_RB")) : 0;
+    return (B > 1024 || forced == 2) ? 2 : 1;
+}
+static bool dn2_shape_ok(int B, int d0, int d1, int d2, int d3, int T) {
+    auto wide = [](int d) { return d >= 16 && d <= D2_MAXW && d % 4 == 0; };
+    if (!(dn2_enabled() && B >= 1 && wide(d0) && wide(d1) && wide(d2) && d3 >= 1 && d3 <= DN_MAXD3 && T >= 1 && T <= DN_MAXT)) return false;
+    const int RB = dn2_rb(B);
+    if ((B + 16 * RB - 1) / (16 * RB) > D2_MAX_WG) return false;
+    return sizeof(float) * (size_t)d2_lds(RB, d0, d1, d2, d3, T).total <= 150 * 1024;
+}
+template <typename K>
+static int dn2_capacity_of(K kernel, int slot, size_t lds_bytes) {
+    static const bool masked = getenv("HSA_CU_MASK") || getenv("ROC_GLOBAL_CU_MASK") || getenv("HSA_CU_MASK_SKIP_INIT");
+    if (masked) return 0;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    struct Slot { size_t lds; int cap; };
+    static Slot cache[64][4] = {};
+    Slot &sl = cache[dev][slot];
+    if (sl.lds == lds_bytes && sl.cap > 0) return sl.cap;
+    if (!ensure_dynamic_lds(kernel, 150 * 1024)) return 0;
+    int per_cu = 0;
+    hipDeviceProp_t prop;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, D2_THREADS, lds_bytes) != hipSuccess ||
+        hipGetDeviceProperties(&prop, dev) != hipSuccess || per_cu < 1 || prop.multiProcessorCount < 1) {
+        (void)hipGetLastError();
+        return 0;
+    }
+    sl.lds = lds_bytes;
+    sl.cap = per_cu * prop.multiProcessorCount;
+    return sl.cap;
+}
+static bool dn2_device_ok(int B, int d0, int d1, int d2, int d3, int T) {
+    const int RB = dn2_rb(B), G = (B + 16 * RB - 1) / (16 * RB);
+    const size_t lds = sizeof(float) * (size_t)d2_lds(RB, d0, d1, d2, d3, T).total;
+    if (RB == 1)
+        return dn2_capacity_of(&downstream2_fwd_kernel<1>, 0, lds) >= G && dn2_capacity_of(&downstream2_bwd_kernel<1>, 1, lds) >= G;
+    return dn2_capacity_of(&downstream2_fwd_kernel<2>, 2, lds) >= G && dn2_capacity_of(&downstream2_bwd_kernel<2>, 3, lds) >= G;
+}
+
 // all G workgroups of BOTH launches must be able to be resident at once on this device
 static bool dn_device_ok(int B, int d0, int d1, int d2, int d3, int T) {
     const int G = (B + DN_ROWS - 1) / DN_ROWS;
@@ -706,18 +1496,27 @@ static int fill_norm(const char *who, DnNorm *o, const phc_downstream_norm &n, i
     return PHC_OK;
 }
 
-static int dn_common(const char *who, const phc_downstream_desc *d, DnArgs *a) {
+// v2 serves a call when its k4 operands are there and the shape / device allow it; *v2 says which kernels the caller launches
+static int dn_common(const char *who, const phc_downstream_desc *d, DnArgs *a, bool *v2) {
     PHC_REQUIRE(d, PHC_ERR_INVALID_ARG, "%s: null descriptor", who);
-    PHC_REQUIRE(dn_shape_ok((int)d->B, d->d0, d->d1, d->d2, d->d3, d->T), PHC_ERR_UNSUPPORTED,
-                "%s: B=%lld widths %d-%d-%d-%d-%d outside the fused head's range (use the per-layer path)", who, (long long)d->B, d->d0, d->d1,
-                d->d2, d->d3, d->T);
+    PHC_REQUIRE(d->B >= 1 && d->B <= (1 << 20), PHC_ERR_UNSUPPORTED, "%s: B=%lld", who, (long long)d->B);
     PHC_REQUIRE(d->act >= PHC_ACT_IDENTITY && d->act <= PHC_ACT_SELU, PHC_ERR_INVALID_ARG, "%s: unknown activation %d", who, d->act);
-    PHC_REQUIRE(dn_device_ok((int)d->B, d->d0, d->d1, d->d2, d->d3, d->T), PHC_ERR_UNSUPPORTED,
-                "%s: the %lld workgroups of the fused head cannot all be resident on this device (partitioned device or CU mask): use "
-                "the per-layer path", who, (long long)((d->B + DN_ROWS - 1) / DN_ROWS));
+    *v2 = d->H1k4 && d->H2k4 && d->H1Tk4 && d->H2Tk4 && dn2_shape_ok((int)d->B, d->d0, d->d1, d->d2, d->d3, d->T) &&
+          dn2_device_ok((int)d->B, d->d0, d->d1, d->d2, d->d3, d->T) &&
+          ((reinterpret_cast<uintptr_t>(d->H1k4) | reinterpret_cast<uintptr_t>(d->H2k4) | reinterpret_cast<uintptr_t>(d->H1Tk4) |
+            reinterpret_cast<uintptr_t>(d->H2Tk4)) & 15) == 0;
+    if (!*v2) {
+        PHC_REQUIRE(dn_shape_ok((int)d->B, d->d0, d->d1, d->d2, d->d3, d->T), PHC_ERR_UNSUPPORTED,
+                    "%s: B=%lld widths %d-%d-%d-%d-%d outside the fused head's range (use the per-layer path)", who, (long long)d->B, d->d0,
+                    d->d1, d->d2, d->d3, d->T);
+        PHC_REQUIRE(dn_device_ok((int)d->B, d->d0, d->d1, d->d2, d->d3, d->T), PHC_ERR_UNSUPPORTED,
+                    "%s: the %lld workgroups of the fused head cannot all be resident on this device (partitioned device or CU mask): use "
+                    "the per-layer path", who, (long long)((d->B + DN_ROWS - 1) / DN_ROWS));
+    }
     PHC_REQUIRE(d->partial && d->sync, PHC_ERR_WORKSPACE, "%s: partial / sync buffers missing", who);
     a->B = (int)d->B; a->d0 = d->d0; a->d1 = d->d1; a->d2 = d->d2; a->d3 = d->d3; a->T = d->T; a->act = d->act;
-    a->G = (a->B + DN_ROWS - 1) / DN_ROWS;
+    a->G = *v2 ? (a->B + 16 * dn2_rb(a->B) - 1) / (16 * dn2_rb(a->B)) : (a->B + DN_ROWS - 1) / DN_ROWS;
+    a->H1k4 = d->H1k4; a->H2k4 = d->H2k4; a->H1Tk4 = d->H1Tk4; a->H2Tk4 = d->H2Tk4;
     a->n_valid = d->n_valid_dev;
     a->partial = reinterpret_cast<unsigned long long *>(d->partial);
     a->sync = reinterpret_cast<unsigned *>(d->sync);
@@ -741,18 +1540,27 @@ int phc_debug_dn_timestamps(unsigned long long *out64) {
 #endif
 
 int phc_downstream_supported(int64_t B, int d0, int d1, int d2, int d3, int T) {
-    const int Bc = (int)(B > (1LL << 30) ? 1 << 30 : B);
+    const int Bc = (int)(B > (1LL << 20) ? 1 << 20 : B);
     return (dn_shape_ok(Bc, d0, d1, d2, d3, T) && dn_device_ok(Bc, d0, d1, d2, d3, T)) ? 1 : 0;
+}
+/* with the k4 operand forms at hand (phc_downstream_desc.H1k4 ...): the wider range of the 16-row kernels */
+int phc_downstream_supported_k4(int64_t B, int d0, int d1, int d2, int d3, int T) {
+    const int Bc = (int)(B > (1LL << 20) ? 1 << 20 : B);
+    if (dn2_shape_ok(Bc, d0, d1, d2, d3, T) && dn2_device_ok(Bc, d0, d1, d2, d3, T)) return 1;
+    return phc_downstream_supported(B, d0, d1, d2, d3, T);
 }
 
 size_t phc_downstream_partial_floats(int64_t B) {
     if (B < 1) return 0;
-    return 2 * 2 * (size_t)((B + DN_ROWS - 1) / DN_ROWS) * DN_PSTRIDE;      // 8-byte {value, tag} granules
+    const size_t v1 = 2 * 2 * (size_t)((B + DN_ROWS - 1) / DN_ROWS) * DN_PSTRIDE;      // 8-byte {value, tag} granules
+    const size_t v2 = 2 * 2 * (size_t)((B + 15) / 16) * D2_PSTRIDE;
+    return v1 > v2 ? v1 : v2;
 }
 
 int phc_downstream_fwd(const phc_downstream_desc *d, void *stream) {
     DnArgs a = {};
-    int rc = dn_common("phc_downstream_fwd", d, &a);
+    bool v2 = false;
+    int rc = dn_common("phc_downstream_fwd", d, &a, &v2);
     if (rc) return rc;
     rc = fill_norm("phc_downstream_fwd", &a.bn1, d->norm1, d->d1);
     if (rc) return rc;
@@ -764,16 +1572,26 @@ int phc_downstream_fwd(const phc_downstream_desc *d, void *stream) {
                   reinterpret_cast<uintptr_t>(a.z1) | reinterpret_cast<uintptr_t>(a.z2)) & 15) == 0,
                 PHC_ERR_UNSUPPORTED, "phc_downstream_fwd: 16-byte aligned rows required");
     hipStream_t s = (hipStream_t)stream;
-    const size_t lds = sizeof(float) * dn_lds_floats(a.d0, a.d1, a.d2, a.d3, a.T, false);
-    // (hipFuncAttributeMaxDynamicSharedMemorySize was set, per device and checked, by dn_device_ok's capacity query)
+    // (hipFuncAttributeMaxDynamicSharedMemorySize was set, per device and checked, by the capacity queries of dn_common)
     ProfScope prof(K_DOWNSTREAM_FWD, s);
+    if (v2) {
+        const int RB = dn2_rb(a.B);
+        const size_t lds2 = sizeof(float) * (size_t)d2_lds(RB, a.d0, a.d1, a.d2, a.d3, a.T).total;
+        if (RB == 1)
+            PHC_LAUNCH(downstream2_fwd_kernel<1>, dim3(a.G), dim3(D2_THREADS), lds2, s, a);
+        else
+            PHC_LAUNCH(downstream2_fwd_kernel<2>, dim3(a.G), dim3(D2_THREADS), lds2, s, a);
+        return check_launch("downstream2_fwd");
+    }
+    const size_t lds = sizeof(float) * dn_lds_floats(a.d0, a.d1, a.d2, a.d3, a.T, false);
     PHC_LAUNCH(downstream_fwd_kernel, dim3(a.G), dim3(DN_THREADS), lds, s, a);
     return check_launch("downstream_fwd");
 }
 
 int phc_downstream_bwd(const phc_downstream_desc *d, void *stream) {
     DnArgs a = {};
-    int rc = dn_common("phc_downstream_bwd", d, &a);
+    bool v2 = false;
+    int rc = dn_common("phc_downstream_bwd", d, &a, &v2);
     if (rc) return rc;
     a.H1T = d->H1T; a.H2T = d->H2T; a.H3T = d->H3T; a.dlogits = d->dlogits;
     a.dx = d->dx; a.dz1 = d->dz1; a.dz2 = d->dz2; a.dz3 = d->dz3; a.dwb1 = d->dwb1; a.dwb2 = d->dwb2; a.dWr = d->dWr; a.dbr = d->dWr ? d->dWr + d->T * d->d3 : nullptr;
@@ -782,8 +1600,17 @@ int phc_downstream_bwd(const phc_downstream_desc *d, void *stream) {
                   reinterpret_cast<uintptr_t>(a.dz1) | reinterpret_cast<uintptr_t>(a.dz2) | reinterpret_cast<uintptr_t>(a.dx)) & 15) == 0,
                 PHC_ERR_UNSUPPORTED, "phc_downstream_bwd: 16-byte aligned rows required");
     hipStream_t s = (hipStream_t)stream;
-    const size_t lds = sizeof(float) * dn_lds_floats(a.d0, a.d1, a.d2, a.d3, a.T, true);
     ProfScope prof(K_DOWNSTREAM_BWD, s);
+    if (v2) {
+        const int RB = dn2_rb(a.B);
+        const size_t lds2 = sizeof(float) * (size_t)d2_lds(RB, a.d0, a.d1, a.d2, a.d3, a.T).total;
+        if (RB == 1)
+            PHC_LAUNCH(downstream2_bwd_kernel<1>, dim3(a.G), dim3(D2_THREADS), lds2, s, a);
+        else
+            PHC_LAUNCH(downstream2_bwd_kernel<2>, dim3(a.G), dim3(D2_THREADS), lds2, s, a);
+        return check_launch("downstream2_bwd");
+    }
+    const size_t lds = sizeof(float) * dn_lds_floats(a.d0, a.d1, a.d2, a.d3, a.T, true);
     PHC_LAUNCH(downstream_bwd_kernel, dim3(a.G), dim3(DN_THREADS), lds, s, a);
     return check_launch("downstream_bwd");
 }

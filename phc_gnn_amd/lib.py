@@ -58,7 +58,8 @@ class DownstreamDesc(C.Structure):
                 ("z1", _P), ("z2", _P), ("z3", _P), ("logits", _P), ("stat1", _P), ("stat2", _P),
                 ("dlogits", _P),
                 ("dx", _P), ("dz1", _P), ("dz2", _P), ("dz3", _P), ("dwb1", _P), ("dwb2", _P), ("dWr", _P),
-                ("partial", _P), ("sync", _P)]
+                ("partial", _P), ("sync", _P),
+                ("H1k4", _P), ("H2k4", _P), ("H1Tk4", _P), ("H2Tk4", _P)]
 
 
 class GemmBaDesc(C.Structure):
@@ -118,6 +119,7 @@ SIGNATURES = {
     "phc_bn_bwd_sums": (_I, [_P, _P, _P, _L, _I, _I, _P, _P, _S, _P]),
     "phc_bn_bwd_apply": (_I, [_P, _P, _P, _P, _L, _L, _I, _I, _P, _P, _S, _P]),
     "phc_downstream_supported": (_I, [_L, _I, _I, _I, _I, _I]),
+    "phc_downstream_supported_k4": (_I, [_L, _I, _I, _I, _I, _I]),
     "phc_downstream_partial_floats": (_S, [_L]),
     "phc_downstream_fwd": (_I, [C.POINTER(DownstreamDesc), _P]),
     "phc_downstream_bwd": (_I, [C.POINTER(DownstreamDesc), _P]),

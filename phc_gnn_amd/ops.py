@@ -2681,9 +2681,9 @@ def _dn_buffers(dev, which: str, B: int):
     """(sync words, partial buffer) of the fused head, per device, stream and direction: the three sync words must start
     at zero and are owned by the kernels from then on (generation / arrival counters, never reset)."""
     lib = L.load()
-    # ... and per number of workgroups ceil(B / 32): a launch waits for (generation + 1) * G arrivals, so one set of words
-    # serves one G only
-    key = (dev, torch.cuda.current_stream(dev).cuda_stream, which, (B + 31) // 32)
+    # ... and per number of rows B (hence per number of workgroups: 32 rows each on the first kernels, 16 / 32 on the k4 ones): a
+    # launch's granules carry its generation tag, one set of words serves one grid shape only
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream, which, B)
     need = lib.phc_downstream_partial_floats(B)
     ent = _DN_BUFFERS.get(key)
     if ent is None or ent[1].numel() < need:
@@ -2734,6 +2734,8 @@ class _DownstreamFn(torch.autograd.Function):
         d.norm2 = _dn_norm(norms[1]["tensors"], norms[1]["n_comp"], norms[1]["momentum"], norms[1]["eps"], keep)
         d.z1, d.z2, d.z3, d.logits, d.stat1, d.stat2 = L.ptr(z1), L.ptr(z2), L.ptr(z3), L.ptr(logits), L.ptr(stat1), L.ptr(stat2)
         d.partial, d.sync = L.ptr(partial), L.ptr(sync)
+        d.H1k4, d.H2k4 = L.ptr(pre[0][2]), L.ptr(pre[1][2])                        # k4 forms (None: the 32-row kernels)
+        d.H1Tk4, d.H2Tk4 = L.ptr(pre[0][3]), L.ptr(pre[1][3])
         L.check(lib.phc_downstream_fwd(_C.byref(d), L.stream_ptr(dev)), "phc_downstream_fwd")
         if L.PROF_ON:
             L.account("downstream_fwd", 2.0 * B * (d0 * d1 + d1 * d2 + d2 * d3 + d3 * T), 4.0 * (B * (d0 + d1 + d2 + d3 + T) + d0 * d1 + d1 * d2))
@@ -2769,6 +2771,8 @@ class _DownstreamFn(torch.autograd.Function):
         d.dlogits = L.ptr(dl)
         d.dx, d.dz1, d.dz2, d.dz3, d.dwb1, d.dwb2, d.dWr = L.ptr(dx), L.ptr(dz1), L.ptr(dz2), L.ptr(dz3), L.ptr(dwb1), L.ptr(dwb2), L.ptr(dWr)
         d.partial, d.sync = L.ptr(partial), L.ptr(sync)
+        d.H1k4, d.H2k4 = L.ptr(pre[0][2]), L.ptr(pre[1][2])
+        d.H1Tk4, d.H2Tk4 = L.ptr(pre[0][3]), L.ptr(pre[1][3])
         L.check(lib.phc_downstream_bwd(_C.byref(d), L.stream_ptr(dev)), "phc_downstream_bwd")
         if L.PROF_ON:
             L.account("downstream_bwd", 2.0 * B * (d0 * d1 + d1 * d2 + 2 * d2 * d3 + 2 * d3 * T), 4.0 * (B * (d0 + 2 * d1 + 2 * d2 + 2 * d3 + T) + d0 * d1 + d1 * d2))
@@ -2832,8 +2836,10 @@ def downstream_head(x, n_valid, affine_layers, norm_modules, real_affine, activa
     d0, d1, d2, d3 = W1.shape[0] * W1.shape[1], W1.shape[0] * W1.shape[2], W2.shape[0] * W2.shape[2], W3.shape[0] * W3.shape[2]
     Wr, br = real_affine.weight, real_affine.bias
     T = Wr.shape[0]
+    has_k4 = all(pre[i][2] is not None and pre[i][3] is not None for i in (0, 1))
+    supported = lib.phc_downstream_supported_k4 if has_k4 else lib.phc_downstream_supported
     if x.shape[1] != d0 or W2.shape[0] * W2.shape[1] != d1 or W3.shape[0] * W3.shape[1] != d2 or Wr.shape[1] != d3 or \
-            not lib.phc_downstream_supported(x.shape[0], d0, d1, d2, d3, T) or x.dtype != torch.float32 or not Wr.is_contiguous():
+            not supported(x.shape[0], d0, d1, d2, d3, T) or x.dtype != torch.float32 or not Wr.is_contiguous():
         return None
     norms, affine = [], []
     for nm in norm_modules:

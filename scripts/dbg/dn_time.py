@@ -1,18 +1,26 @@
+"""In-kernel phase clocks of the fused head (variant build -DPHC_DN_TIMING: python -m phc_gnn_amd.build --variant dntime -DPHC_DN_TIMING,
+then PHC_LIB_PATH=scripts/exp/variants/libphc_hip_dntime.so python scripts/dbg/dn_time.py [B d0 d1 d2 n]).  Thread 0 of the first and
+last workgroup stamp wall_clock64() (100 MHz); printed: microseconds since kernel entry."""
 import os, sys, ctypes as C
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import phc_gnn_amd, torch
 from phc_gnn_amd import ops, lib as L
 from tests.test_gpu_downstream import _make
-dn = _make(4, 128, (128, 32), 1, "relu", seed=7).to("cuda:0")
-x = torch.randn(544, 128, device="cuda:0")
+B, d0, d1, d2, n = (int(v) for v in (sys.argv[1:6] + ["544", "128", "128", "32", "4"][len(sys.argv) - 1:]))
+dn = _make(n, d0, (d1, d2), 1, "relu", seed=7).to("cuda:0")
+x = torch.randn(B, d0, device="cuda:0").requires_grad_()
 lib = L.load()
-names = {0: "start", 1: "staged", 2: "gemm1", 3: "published1", 4: "rendezvous1", 5: "norm1 done", 6: "applied1", 7: "gemm2", 8: "published2", 9: "rendezvous2", 10: "norm2 done", 11: "end"}
+fwd = {12: "H1 issued", 13: "norm cols", 14: "x in LDS", 1: "staged", 2: "gemm1", 3: "published1", 4: "collected1", 5: "norm1 done", 6: "applied1", 7: "gemm2", 8: "published2", 9: "collected2",
+       10: "norm2 done", 11: "end"}
+bwd = {17: "staged", 18: "small", 19: "gated2", 20: "published2", 21: "collected2", 22: "dz2", 23: "gemm(dz2.H2T)", 24: "gated1", 25: "published1",
+       26: "collected1", 27: "dz1", 28: "gemm(dz1.H1T)", 29: "end"}
 with ops.prebuilt_H(ops.phm_pairs(dn), ops.dense_weights(dn)):
     for it in range(5):
         y = dn(x)
+        y.sum().backward()
         torch.cuda.synchronize()
         buf = (C.c_ulonglong * 64)()
         rc = C.CDLL(L.LIB_PATH).phc_debug_dn_timestamps(buf)  # same handle: dlopen of an already loaded path
         for base, who in ((0, "wg0"), (32, "wgLast")):
-            t0 = buf[base]
-            print(it, who, " ".join(f"{names[i]}={(buf[base + i] - t0) / 100.0:.2f}us" for i in range(1, 12)), flush=True)
+            print(it, "fwd", who, " ".join(f"{fwd[i]}={(buf[base + i] - buf[base]) / 100.0:.2f}" for i in fwd if buf[base + i]), flush=True)
+            print(it, "bwd", who, " ".join(f"{bwd[i]}={(buf[base + i] - buf[base + 16]) / 100.0:.2f}" for i in sorted(bwd) if buf[base + i]), flush=True)

@@ -52,12 +52,19 @@ def _run_fused(dn, x, dy, n_valid=None):
     return y.detach(), xd.grad
 
 
-@pytest.mark.parametrize("n,d_in,hidden,target,act,B", [(4, 128, (128, 32), 1, "relu", 544), (4, 128, (128, 32), 1, "relu", 9),
-                                                        (4, 64, (64, 32), 2, "swish", 100), (8, 128, (64, 64), 1, "lrelu", 33),
-                                                        (4, 32, (128, 128), 3, "relu", 1025)])
+@pytest.mark.parametrize("n,d_in,hidden,target,act,B", [
+    (4, 128, (128, 32), 1, "relu", 544), (4, 128, (128, 32), 1, "relu", 9),
+    (4, 64, (64, 32), 2, "swish", 100), (8, 128, (64, 64), 1, "lrelu", 33),
+    (4, 32, (128, 128), 3, "relu", 1025),
+    # the 16-row kernels' wider range (round 4): configs[2]'s head (ZINC PHM-8, d_units 256,128), a 256-wide PHM-4 head, the
+    # reference's own ZINC head (run_script_zinc_phm4.sh: 180 -> 180 -> 80: partial k-groups and column tiles), a 200-wide PHM-5
+    # head, 32-row workgroups above 1024 rows, one partial workgroup, fewer rows than one MFMA block
+    (8, 256, (256, 128), 1, "relu", 1024), (4, 256, (256, 128), 2, "swish", 777), (4, 180, (180, 80), 1, "relu", 1000),
+    (5, 200, (200, 100), 4, "relu", 513), (4, 128, (128, 32), 1, "relu", 1500), (4, 128, (256, 16), 1, "elu", 2048),
+    (4, 128, (128, 32), 1, "relu", 3), (4, 16, (16, 16), 1, "relu", 70)])
 def test_fused_head_matches_oracle(n, d_in, hidden, target, act, B):
     from phc_gnn_amd import lib
-    if not lib.load().phc_downstream_supported(B, d_in, hidden[0], hidden[1], n * target, target):
+    if not lib.load().phc_downstream_supported_k4(B, d_in, hidden[0], hidden[1], n * target, target):
         pytest.skip("shape outside the fused head")
     dn = _make(n, d_in, hidden, target, act, seed=7)
     g = torch.Generator().manual_seed(8)
@@ -84,11 +91,15 @@ def test_fused_head_matches_oracle(n, d_in, hidden, target, act, B):
             assert int(b) == 1, k
 
 
-def test_fused_head_padding_rows_are_inert_and_launches_repeat():
+@pytest.mark.parametrize("n,d_in,hidden,B,valid", [(4, 128, (128, 32), 544, 512), (8, 256, (256, 128), 1088, 1024),
+                                                   (4, 180, (180, 80), 1200, 1111), (4, 128, (128, 32), 64, 17)])
+def test_fused_head_padding_rows_are_inert_and_launches_repeat(n, d_in, hidden, B, valid):
     """Rows >= n_valid (padding graphs of a fixed-shape batch) stay out of the statistics and get zero gradient; ten
     back-to-back launches (generation / arrival counters run on) give bit-identical results."""
-    n, d_in, hidden, target, act = 4, 128, (128, 32), 1, "relu"
-    B, valid = 544, 512
+    from phc_gnn_amd import lib
+    target, act = 1, "relu"
+    if not lib.load().phc_downstream_supported_k4(B, d_in, hidden[0], hidden[1], n * target, target):
+        pytest.skip("shape outside the fused head")
     g = torch.Generator().manual_seed(18)
     x, dy = torch.randn(B, d_in, generator=g), torch.randn(B, target, generator=g)
     dy[valid:] = 0.0                                                   # NaN-label rows: the loss hands back zero
