@@ -629,6 +629,32 @@ int phc_step_tail(const phc_phm_grad_job *jobs, int num_jobs, const phc_table_gr
                   const uint32_t *bond_codes, const float *bond_counts, int64_t bond_n_dst, const float *atom_dout,
                   const int64_t *atom_idx_i64, int64_t N_atoms, int F_a, const int32_t *vocab_a,
                   float *atom_dtables_flat, int n, int k, void *ws, size_t ws_bytes, void *stream);
+/* ABI 5: the same call with two more families of workgroups riding in its last two launches (no launch of their own):
+ *   - the gate map's parameter gradients (phc_gate_param_grads): `gate_job` names the dense job (x, dg) of `jobs` — its dW may be
+ *     NULL, its db receives dbg — whose dH = x^T . dg is read where the reduce launch leaves it;
+ *   - the explicit weight regulariser (phc_phm_weight_reg; regularization.py:15-23, train_hiv.py:181-196): reg_W[q] [reg_n[q],
+ *     reg_cells[q]] are the regularised weights, reg_job[q] the job of `jobs` that writes that layer's dW (same W pointer; -2 = the
+ *     gate map).  The gradient is ADDED to the freshly written dW, the value written to reg_value and added to *reg_loss_inout
+ *     (either may be NULL).  reg_ws: phc_tail_extras_ws_floats(extras) floats, 16-byte aligned, contents irrelevant.
+ * extras == NULL: exactly phc_step_tail.  gate_job < 0 / reg_num == 0 switch the families off individually. */
+typedef struct phc_tail_extras {
+    int32_t gate_job;
+    int32_t gate_n, gate_kin, gate_kout, gate_kg;
+    const float *gate_H, *gate_w, *gate_phm_b, *gate_A, *gate_W;
+    float *gate_dA, *gate_dW, *gate_db, *gate_dWg;
+    int32_t reg_num, reg_p;
+    float reg_coef;
+    const float *const *reg_W;                /* host arrays of reg_num entries */
+    const int32_t *reg_n, *reg_cells, *reg_job;
+    float *reg_value, *reg_loss_inout, *reg_ws;
+} phc_tail_extras;
+int phc_tail_reg_max_jobs(void);
+size_t phc_tail_extras_ws_floats(const phc_tail_extras *extras);
+int phc_step_tail_ex(const phc_phm_grad_job *jobs, int num_jobs, const phc_table_grad_job *tjobs, int num_tjobs, const int64_t *bond_i64,
+                     const int32_t *vocab_b, const int64_t *edge_src_i64, const int64_t *edge_dst_i64, int64_t E, int F_b, int act,
+                     const int32_t *bond_rowptr, const uint32_t *bond_codes, const float *bond_counts, int64_t bond_n_dst,
+                     const float *atom_dout, const int64_t *atom_idx_i64, int64_t N_atoms, int F_a, const int32_t *vocab_a,
+                     float *atom_dtables_flat, int n, int k, void *ws, size_t ws_bytes, const phc_tail_extras *extras, void *stream);
 
 /* ------------------------------------------------------------------------- *
  * Read-out

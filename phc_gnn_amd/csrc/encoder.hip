@@ -1222,8 +1222,13 @@ __global__ __launch_bounds__(256, 2) void tail_partial_kernel(GradBatch gb, Tail
                         xf_count);
 }
 
-__global__ __launch_bounds__(256) void tail_reduce_kernel(GradBatch gb, TailTables t) {
+__global__ __launch_bounds__(256) void tail_reduce_kernel(GradBatch gb, TailTables t, TailReg reg) {
     unsigned bx = blockIdx.x;
+    const unsigned nr_tail = t.nr_phm + t.nr_bond + t.nr_atom;
+    if (bx >= nr_tail) {                                     // the weight regulariser's workgroups ride behind the reductions
+        tail_reg_body(reg, bx - nr_tail);
+        return;
+    }
     if (bx < t.nr_phm) {
         const int k = grad_job_of_block<1>(gb, bx);
         const GradJobDev &j = gb.j[k];
@@ -1890,11 +1895,46 @@ size_t phc_step_tail_ws_bytes(const phc_phm_grad_job *jobs, int num_jobs, int nu
     return sizeof(float) * (phm + (num_tjobs > 0 ? pb.slab_floats * (size_t)num_tjobs : 0) + (N_atoms > 0 ? pa.slab_floats : 0));
 }
 
+static int step_tail_impl(const phc_phm_grad_job *jobs, int num_jobs, const phc_table_grad_job *tjobs, int num_tjobs, const int64_t *bond_i64,
+                          const int32_t *vocab_b, const int64_t *edge_src_i64, const int64_t *edge_dst_i64, int64_t E, int F_b, int act,
+                          const int32_t *bond_rowptr, const uint32_t *bond_codes, const float *bond_counts, int64_t bond_n_dst,
+                          const float *atom_dout, const int64_t *atom_idx_i64, int64_t N_atoms, int F_a, const int32_t *vocab_a,
+                          float *atom_dtables_flat, int n, int k, void *ws, size_t ws_bytes, const phc_tail_extras *ex, void *stream);
+
 int phc_step_tail(const phc_phm_grad_job *jobs, int num_jobs, const phc_table_grad_job *tjobs, int num_tjobs, const int64_t *bond_i64,
                   const int32_t *vocab_b, const int64_t *edge_src_i64, const int64_t *edge_dst_i64, int64_t E, int F_b, int act,
                   const int32_t *bond_rowptr, const uint32_t *bond_codes, const float *bond_counts, int64_t bond_n_dst, const float *atom_dout,
                   const int64_t *atom_idx_i64, int64_t N_atoms, int F_a, const int32_t *vocab_a, float *atom_dtables_flat, int n, int k,
                   void *ws, size_t ws_bytes, void *stream) {
+    return step_tail_impl(jobs, num_jobs, tjobs, num_tjobs, bond_i64, vocab_b, edge_src_i64, edge_dst_i64, E, F_b, act, bond_rowptr,
+                          bond_codes, bond_counts, bond_n_dst, atom_dout, atom_idx_i64, N_atoms, F_a, vocab_a, atom_dtables_flat, n, k, ws,
+                          ws_bytes, nullptr, stream);
+}
+
+int phc_tail_reg_max_jobs(void) { return TAIL_REG_MAX_JOBS; }
+size_t phc_tail_extras_ws_floats(const phc_tail_extras *ex) {
+    if (!ex || ex->reg_num <= 0 || !ex->reg_n || !ex->reg_cells) return 0;
+    size_t f = 0;
+    for (int q = 0; q < ex->reg_num; ++q)
+        f += ((size_t)ex->reg_n[q] * ex->reg_cells[q] + 3) / 4 * 4 + (size_t)(ex->reg_cells[q] + 255) / 256;
+    return f + 4;
+}
+
+int phc_step_tail_ex(const phc_phm_grad_job *jobs, int num_jobs, const phc_table_grad_job *tjobs, int num_tjobs, const int64_t *bond_i64,
+                     const int32_t *vocab_b, const int64_t *edge_src_i64, const int64_t *edge_dst_i64, int64_t E, int F_b, int act,
+                     const int32_t *bond_rowptr, const uint32_t *bond_codes, const float *bond_counts, int64_t bond_n_dst,
+                     const float *atom_dout, const int64_t *atom_idx_i64, int64_t N_atoms, int F_a, const int32_t *vocab_a,
+                     float *atom_dtables_flat, int n, int k, void *ws, size_t ws_bytes, const phc_tail_extras *extras, void *stream) {
+    return step_tail_impl(jobs, num_jobs, tjobs, num_tjobs, bond_i64, vocab_b, edge_src_i64, edge_dst_i64, E, F_b, act, bond_rowptr,
+                          bond_codes, bond_counts, bond_n_dst, atom_dout, atom_idx_i64, N_atoms, F_a, vocab_a, atom_dtables_flat, n, k, ws,
+                          ws_bytes, extras, stream);
+}
+
+static int step_tail_impl(const phc_phm_grad_job *jobs, int num_jobs, const phc_table_grad_job *tjobs, int num_tjobs, const int64_t *bond_i64,
+                          const int32_t *vocab_b, const int64_t *edge_src_i64, const int64_t *edge_dst_i64, int64_t E, int F_b, int act,
+                          const int32_t *bond_rowptr, const uint32_t *bond_codes, const float *bond_counts, int64_t bond_n_dst,
+                          const float *atom_dout, const int64_t *atom_idx_i64, int64_t N_atoms, int F_a, const int32_t *vocab_a,
+                          float *atom_dtables_flat, int n, int k, void *ws, size_t ws_bytes, const phc_tail_extras *ex, void *stream) {
     EncMeta mb, ma;
     TgPlan pb, pa;
     size_t phm_floats = 0;
@@ -2011,14 +2051,63 @@ int phc_step_tail(const phc_phm_grad_job *jobs, int num_jobs, const phc_table_gr
         if (rc) return rc;
     }
 
+    // ---- extras of the last two launches: the weight regulariser (its cells ride in the reduce launch, its gradient is added
+    // where dW is written) and the gate map's parameter gradients (workgroups of the last launch) ----
+    TailReg reg;
+    memset(&reg, 0, sizeof(reg));
+    GateGradHost gate;
+    memset(&gate, 0, sizeof(gate));
+    bool has_reg = false, has_gate = false;
+    unsigned nr_reg = 0;
+    if (ex) {
+        has_gate = ex->gate_job >= 0;
+        if (has_gate) {
+            PHC_REQUIRE(ex->gate_job < num_jobs && ex->gate_H && ex->gate_w && ex->gate_A && ex->gate_W, PHC_ERR_INVALID_ARG,
+                        "phc_step_tail_ex: gate job %d / null pointer", ex->gate_job);
+            PHC_REQUIRE(!ex->gate_db || ex->gate_phm_b, PHC_ERR_INVALID_ARG, "phc_step_tail_ex: gate db without a PHM bias");
+            gate.job = ex->gate_job; gate.H = ex->gate_H; gate.gate_w = ex->gate_w; gate.phm_b = ex->gate_phm_b; gate.A = ex->gate_A;
+            gate.W = ex->gate_W; gate.n = ex->gate_n; gate.kin = ex->gate_kin; gate.kout = ex->gate_kout; gate.kg = ex->gate_kg;
+            gate.dA = ex->gate_dA; gate.dW = ex->gate_dW; gate.db = ex->gate_db; gate.dWg = ex->gate_dWg; gate.dbg = nullptr;
+        }
+        if (ex->reg_num > 0) {
+            PHC_REQUIRE(ex->reg_num <= TAIL_REG_MAX_JOBS && ex->reg_W && ex->reg_n && ex->reg_cells && ex->reg_job && ex->reg_ws &&
+                            (ex->reg_p == 1 || ex->reg_p == 2) && (reinterpret_cast<uintptr_t>(ex->reg_ws) & 15) == 0,
+                        PHC_ERR_INVALID_ARG, "phc_step_tail_ex: regulariser table (%d layers, p = %d)", ex->reg_num, ex->reg_p);
+            has_reg = true;
+            reg.num = ex->reg_num; reg.p = ex->reg_p; reg.coef = ex->reg_coef; reg.value = ex->reg_value; reg.loss_inout = ex->reg_loss_inout;
+            float *side = ex->reg_ws;
+            for (int q = 0; q < ex->reg_num; ++q) {
+                const int nq = ex->reg_n[q], cells = ex->reg_cells[q], jq = ex->reg_job[q];
+                PHC_REQUIRE(ex->reg_W[q] && nq >= 1 && nq <= TAIL_REG_MAX_N && cells >= 1, PHC_ERR_INVALID_ARG,
+                            "phc_step_tail_ex: regularised layer %d: n = %d, cells = %d", q, nq, cells);
+                reg.W[q] = ex->reg_W[q]; reg.n[q] = nq; reg.cells[q] = cells; reg.grad[q] = side;
+                reg.first_block[q] = (int)nr_reg;
+                nr_reg += (unsigned)((cells + 255) / 256);
+                // who writes this layer's dW: a PHM job of the batch (same W pointer, not transposed) or the gate map (-2)
+                if (jq == -2) {
+                    PHC_REQUIRE(has_gate && ex->gate_W == ex->reg_W[q] && ex->gate_n * ex->gate_kin * ex->gate_kout == nq * cells,
+                                PHC_ERR_INVALID_ARG, "phc_step_tail_ex: regularised layer %d names the gate map", q);
+                    gate.reg_add = side;
+                } else {
+                    PHC_REQUIRE(jq >= 0 && jq < num_jobs && gl.batch.j[jq].W == ex->reg_W[q] && !gl.batch.j[jq].dw_transposed &&
+                                    gl.batch.j[jq].dW && gl.batch.j[jq].n * gl.batch.j[jq].kin * gl.batch.j[jq].kout == nq * cells,
+                                PHC_ERR_INVALID_ARG, "phc_step_tail_ex: regularised layer %d does not match job %d", q, jq);
+                    gl.batch.j[jq].reg_add = side;
+                }
+                side += ((size_t)nq * cells + 3) / 4 * 4;
+            }
+            reg.first_block[ex->reg_num] = (int)nr_reg;
+            reg.shares = side;
+        }
+    }
     {
         ProfScope prof(K_PHM_DH_REDUCE, s);
-        PHC_LAUNCH(tail_reduce_kernel, dim3(nb2), dim3(256), 0, s, gl.batch, t);
+        PHC_LAUNCH(tail_reduce_kernel, dim3(nb2 + nr_reg), dim3(256), 0, s, gl.batch, t, reg);
         rc = check_launch("step_tail(reduce)");
         if (rc) return rc;
     }
     ProfScope prof(K_PHM_CONTRACT, s);
-    return launch_grad_contract("phc_step_tail", gl, s);
+    return launch_tail_finish("phc_step_tail", gl, has_gate ? &gate : nullptr, has_reg ? &reg : nullptr, s);
 }
 
 }  // extern "C"

@@ -579,6 +579,7 @@ struct GradJobDev {
     const int *xf_n_valid;
     int xf_act;
     unsigned blk0_partial, blk0_reduce, blk0_contract;      // first workgroup of this job in each launch
+    const float *reg_add;                                    // != NULL: added to dW as it is written (the weight regulariser's gradient)
 };
 struct GradBatch {
     int num;
@@ -597,6 +598,79 @@ __device__ __forceinline__ void xcd_tile_split(unsigned local, unsigned tiles, u
         tile = (int)(local % tiles);
         split = local / tiles;
     }
+}
+
+// ---- the explicit weight regulariser inside the step tail (regularization.py:15-23, train_hiv.py:181-196) ----
+// reg = coef * sum over PHM layers of mean_{kappa, pi} || W[:, kappa, pi] ||_p depends on the weights only.  Its workgroups ride in
+// the tail's REDUCE launch (a workgroup = 256 (kappa, pi) cells of one layer): d reg / d W goes to a side buffer, the
+// workgroup's share of the value to `shares[block]`; the tail's LAST launch adds the side buffer into dW as it writes it
+// (GradJobDev.reg_add, GateGradArgs.reg_add) and one extra workgroup sums the shares in block order — plain stores and loads
+// across a kernel boundary, no launch of its own (the stand-alone form, phc_phm_weight_reg, is one more launch per step).
+constexpr int TAIL_REG_MAX_JOBS = 24;
+constexpr int TAIL_REG_MAX_N = 16;
+struct TailReg {
+    const float *W[TAIL_REG_MAX_JOBS];
+    float *grad[TAIL_REG_MAX_JOBS];                          // side buffers [n][cells]
+    int n[TAIL_REG_MAX_JOBS], cells[TAIL_REG_MAX_JOBS], first_block[TAIL_REG_MAX_JOBS + 1];
+    int num, p;
+    float coef;
+    float *shares;                                           // [first_block[num]]
+    float *value, *loss_inout;                               // written / incremented by the last launch
+};
+
+__device__ __forceinline__ void tail_reg_body(const TailReg &r, unsigned b) {
+    __shared__ float reg_red[4];
+    const int tid = threadIdx.x;
+    int j = 0;
+    for (int q = 1; q < r.num; ++q) j = (int)b >= r.first_block[q] ? q : j;        // uniform scan of the by-value table
+    const float *W = nullptr;
+    float *G = nullptr;
+    int n = 1, cells = 1;
+    for (int q = 0; q < r.num; ++q)
+        if (q == j) { W = r.W[q]; G = r.grad[q]; n = r.n[q]; cells = r.cells[q]; }
+    const int c = ((int)b - r.first_block[j]) * 256 + tid;
+    const bool live = c < cells;
+    const int cc = live ? c : 0;
+    float w[TAIL_REG_MAX_N];
+#pragma unroll
+    for (int i = 0; i < TAIL_REG_MAX_N; ++i) w[i] = W[(size_t)min(i, n - 1) * cells + cc];      // one round of unconditional loads
+    float nrm = 0.f;
+#pragma unroll
+    for (int i = 0; i < TAIL_REG_MAX_N; ++i)
+        if (i < n) nrm += r.p == 1 ? fabsf(w[i]) : w[i] * w[i];
+    if (r.p != 1) nrm = sqrtf(nrm);
+    if (live) {
+        const float scale = r.coef / (float)cells;
+#pragma unroll
+        for (int i = 0; i < TAIL_REG_MAX_N; ++i)
+            if (i < n) {
+                // d ||v||_1 / dv = sign(v);  d ||v||_2 / dv = v / ||v||  (0 at the origin, as torch's norm backward)
+                const float gq = r.p == 1 ? (w[i] > 0.f ? 1.f : (w[i] < 0.f ? -1.f : 0.f)) : (nrm > 0.f ? w[i] / nrm : 0.f);
+                G[(size_t)i * cells + c] = scale * gq;
+            }
+    }
+    float v = live ? nrm * (r.coef / (float)cells) : 0.f;          // this cell's share of coef * mean
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off, 64);
+    if ((tid & 63) == 0) reg_red[tid >> 6] = v;
+    __syncthreads();
+    if (tid == 0) r.shares[b] = (reg_red[0] + reg_red[1]) + (reg_red[2] + reg_red[3]);
+}
+
+// the value: all shares in block order (fixed summation order), by one wavefront-sized loop of the last launch's extra workgroup
+__device__ __forceinline__ void tail_reg_finish(const TailReg &r) {
+    if (threadIdx.x != 0) return;
+    const int nb = r.first_block[r.num];
+    float total = 0.f;
+    for (int q0 = 0; q0 < nb; q0 += 16) {
+        float v[16];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) v[u] = r.shares[min(q0 + u, nb - 1)];
+#pragma unroll
+        for (int u = 0; u < 16; ++u) total += q0 + u < nb ? v[u] : 0.f;
+    }
+    if (r.value) *r.value = total;
+    if (r.loss_inout) *r.loss_inout += total;
 }
 
 template <int STAGE>
@@ -619,6 +693,15 @@ size_t grad_chunk_ws_floats(const phc_phm_grad_job *jobs, int num_jobs, int dire
 int prepare_grad_launch(const char *who, const phc_phm_grad_job *jobs, int num_jobs, float *ws_base, GradLaunch *out, int direct_form = 2);
 int launch_grad_rest(const char *who, const GradLaunch &gl, bool partial64_too, hipStream_t s);
 int launch_grad_contract(const char *who, const GradLaunch &gl, hipStream_t s);
+// the tail's last launch with the gate map's parameter gradients (gate != NULL, see GateGradHost) and the weight regulariser's
+// value (reg != NULL) riding in it as extra workgroups
+struct GateGradHost {
+    int job;                                                 // the dense job (x, dg) among the batch's jobs whose dH holds dM | dbg
+    const float *H, *gate_w, *phm_b, *A, *W, *reg_add;
+    int n, kin, kout, kg;
+    float *dA, *dW, *db, *dWg, *dbg;
+};
+int launch_tail_finish(const char *who, const GradLaunch &gl, const GateGradHost *gate, const TailReg *reg, hipStream_t s);
 // the register-resident jobs' partial launch (if any); profile = false: the caller already holds a launch-profiler scope
 int launch_grad_direct(const char *who, const GradLaunch &gl, hipStream_t s, bool profile = true);
 int check_grad_jobs(const char *who, const phc_phm_grad_job *jobs, int num_jobs);

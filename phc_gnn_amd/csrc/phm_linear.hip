@@ -973,7 +973,7 @@ __global__ __launch_bounds__(256) void phm_dH_reduce_kernel(const float *__restr
 __device__ __forceinline__ void contract_body(const float *__restrict__ A, const float *__restrict__ W,
                                               const float *__restrict__ dH, float *__restrict__ dW, float *__restrict__ dA,
                                               float *__restrict__ db, int n, int kin, int kout, int dA_blocks, int bx,
-                                              int dw_transposed = 0) {
+                                              int dw_transposed = 0, const float *__restrict__ reg_add = nullptr) {
     const int out = n * kout;
     const int tid = threadIdx.x;
     if (bx < dA_blocks) {
@@ -1027,6 +1027,7 @@ __device__ __forceinline__ void contract_body(const float *__restrict__ A, const
 #pragma unroll
             for (int q = 0; q < 16; ++q) s = t0 + q < nn ? fmaf(av[q], hv[q], s) : s;
         }
+        if (reg_add) s += reg_add[e];                    // the weight regulariser's gradient (tail_reg_body, the launch in front)
         // dw_transposed: the parameter is an nn.Linear weight [kout, kin] (n = 1)
         dW[dw_transposed ? ((size_t)i * kout + pi) * kin + kap : (size_t)e] = s;
     }
@@ -1097,7 +1098,7 @@ __global__ __launch_bounds__(256) void phm_grads_contract_kernel(GradBatch b) {
     const int k = grad_job_of_block<2>(b, blockIdx.x);
     const GradJobDev &j = b.j[k];
     contract_body(j.A, j.W, j.dH, j.dW, j.dA, j.db, j.n, j.kin, j.kout, j.dA_blocks, (int)(blockIdx.x - j.blk0_contract),
-                  j.dw_transposed);
+                  j.dw_transposed, j.reg_add);
 }
 
 // ---- the gate map's parameter gradients (pooling.py:57-66 as ONE linear map M = H(A, W) . gate_w^T) ----
@@ -1113,22 +1114,25 @@ struct GateGradArgs {
     float *dA, *dW, *db, *dWg;
     int n, k, kg;                 // kin == kout == k
     int blk_rows, blk_dWg, blk_db;
+    // dM^T[j, r] = dMT[j * sj + r * sr]: (h, 1) for the nn.Linear layout [kg, in] of the stand-alone entry point, (1, kg) when the
+    // launch reads the dense job's dH = x^T . dg [in, kg] where the reduce launch left it (dbg = its bias row)
+    int sj, sr;
+    const float *reg_add;         // added to dW as it is written (the weight regulariser's gradient), or NULL
+    float *dbg_out;               // a copy of dbg for the gate bias's gradient, or NULL
 };
 
 // Operands staged in LDS (dynamic): tile blocks kg * k * 2 + k * (k + 1) floats, row blocks kg * (n k) + kg * n + n^3 + n * (n k) floats.
 // Every phase issues its global loads together and sums in a fixed order; none of the sums depends on the grid's shape.
-__global__ __launch_bounds__(256) void gate_param_grads_kernel(GateGradArgs g) {
-    extern __shared__ float gsm[];
-    __shared__ float red[4][256];
+__device__ __forceinline__ void gate_param_grads_body(const GateGradArgs &g, float *gsm, float (*red)[256], int bx) {
     const int n = g.n, k = g.k, kg = g.kg, h = n * k;
-    const int tid = threadIdx.x, bx = blockIdx.x;
+    const int tid = threadIdx.x;
     if (bx < g.blk_rows) {
         // ---- tile (a, c): dH[a k .. , c k ..] = dM[a-rows, :] . gate_w[:, c-cols] in LDS, then dA[i, a, c] for every i ----
         const int a = bx / n, c = bx - a * n;
         float *sM = gsm, *sG = gsm + kg * k, *tile = gsm + 2 * kg * k;          // [kg][k], [kg][k], [k][k + 1]
         for (int e = tid; e < kg * k; e += 256) {
             const int j = e / k, t = e - j * k;
-            sM[e] = g.dMT[(size_t)j * h + a * k + t];
+            sM[e] = g.dMT[(size_t)j * g.sj + (size_t)(a * k + t) * g.sr];
             sG[e] = g.gate_w[(size_t)j * h + c * k + t];
         }
         __syncthreads();
@@ -1175,7 +1179,7 @@ __global__ __launch_bounds__(256) void gate_param_grads_kernel(GateGradArgs g) {
         for (int e = tid; e < kg * h; e += 256) sG[e] = g.gate_w[e];
         for (int e = tid; e < kg * n; e += 256) {
             const int j = e / n, a = e - j * n;
-            sMk[e] = g.dMT[(size_t)j * h + a * k + kap];
+            sMk[e] = g.dMT[(size_t)j * g.sj + (size_t)(a * k + kap) * g.sr];
         }
         for (int e = tid; e < n * n * n; e += 256) sA[e] = g.A[e];
         float *sD = sA + n * n * n;                                               // [n][h]: dH[a k + kap, col] of this row
@@ -1204,6 +1208,7 @@ __global__ __launch_bounds__(256) void gate_param_grads_kernel(GateGradArgs g) {
             for (int a = 0; a < n; ++a)
 #pragma unroll 4
                 for (int c = 0; c < n; ++c) acc = fmaf(sA[(i * n + a) * n + c], sD[a * h + c * k + pi], acc);
+            if (g.reg_add) acc += g.reg_add[((size_t)i * k + kap) * k + pi];
             g.dW[((size_t)i * k + kap) * k + pi] = acc;
         }
         return;
@@ -1216,7 +1221,7 @@ __global__ __launch_bounds__(256) void gate_param_grads_kernel(GateGradArgs g) {
         float p = 0.f;
         if (col < h) {
 #pragma unroll 8
-            for (int r = part; r < h; r += 8) p = fmaf(g.dMT[(size_t)j * h + r], g.H[(size_t)r * h + col], p);
+            for (int r = part; r < h; r += 8) p = fmaf(g.dMT[(size_t)j * g.sj + (size_t)r * g.sr], g.H[(size_t)r * h + col], p);
         }
         red[0][tid] = p;
         __syncthreads();
@@ -1235,6 +1240,35 @@ __global__ __launch_bounds__(256) void gate_param_grads_kernel(GateGradArgs g) {
             for (int j = 0; j < kg; ++j) p = fmaf(g.dbg[j], g.gate_w[(size_t)j * h + col], p);
             g.db[col] = p;
         }
+    if (g.dbg_out)
+        for (int j = tid; j < kg; j += 256) g.dbg_out[j] = g.dbg[j];
+}
+
+__global__ __launch_bounds__(256) void gate_param_grads_kernel(GateGradArgs g) {
+    extern __shared__ float gsm[];
+    __shared__ float red[4][256];
+    gate_param_grads_body(g, gsm, red, (int)blockIdx.x);
+}
+
+// The step tail's LAST launch: the contractions dH -> dW / dA / db of every job, the gate map's parameter gradients (reading the
+// dense job's dH in place) and the weight regulariser's value as three families of workgroups of one launch — they all depend on
+// the reduce launch only (three launches in a row before: 7 + 9.5 + 7 us).
+__global__ __launch_bounds__(256) void tail_finish_kernel(GradBatch b, GateGradArgs g, TailReg r, unsigned nb_contract, unsigned nb_gate) {
+    extern __shared__ float gsm[];
+    __shared__ float red[4][256];
+    const unsigned bx = blockIdx.x;
+    if (bx < nb_contract) {
+        const int k = grad_job_of_block<2>(b, bx);
+        const GradJobDev &j = b.j[k];
+        contract_body(j.A, j.W, j.dH, j.dW, j.dA, j.db, j.n, j.kin, j.kout, j.dA_blocks, (int)(bx - j.blk0_contract), j.dw_transposed,
+                      j.reg_add);
+        return;
+    }
+    if (bx < nb_contract + nb_gate) {
+        gate_param_grads_body(g, gsm, red, (int)(bx - nb_contract));
+        return;
+    }
+    tail_reg_finish(r);
 }
 
 // ---- host side ---------------------------------------------------------------------------
@@ -1626,6 +1660,7 @@ int prepare_grad_launch(const char *who, const phc_phm_grad_job *jobs, int cn, f
         d.splits = plans[k].splits;
         d.t128 = plans[k].t128;
         d.dw_transposed = jb.flags & 1;
+        d.reg_add = nullptr;
         d.xf_stat = jb.xf_stat;
         d.xf_n_valid = jb.xf_n_valid_dev;
         d.xf_act = jb.xf_act;
@@ -1670,6 +1705,39 @@ int launch_grad_direct(const char *who, const GradLaunch &gl, hipStream_t s, boo
 
 int launch_grad_contract(const char *who, const GradLaunch &gl, hipStream_t s) {
     PHC_LAUNCH(phm_grads_contract_kernel, dim3(gl.nb_contract), dim3(256), 0, s, gl.batch);
+    return check_launch(who);
+}
+
+int launch_tail_finish(const char *who, const GradLaunch &gl, const GateGradHost *gate, const TailReg *reg, hipStream_t s) {
+    if (!gate && !reg) return launch_grad_contract(who, gl, s);
+    GateGradArgs g = {};
+    unsigned nb_gate = 0;
+    size_t lds = 0;
+    if (gate) {
+        PHC_REQUIRE(gate->job >= 0 && gate->job < gl.batch.num && gate->kin == gate->kout && gate->kg >= 1, PHC_ERR_INVALID_ARG,
+                    "%s: gate job %d / shape", who, gate->job);
+        const GradJobDev &dj = gl.batch.j[gate->job];
+        const int k = gate->kin, h = gate->n * k;
+        PHC_REQUIRE(dj.n == 1 && dj.in == h && dj.out == gate->kg && dj.dH, PHC_ERR_INVALID_ARG,
+                    "%s: the gate's dense job is [%d x %d], expected [%d x %d]", who, dj.in, dj.out, h, gate->kg);
+        const int lds_tile = 2 * gate->kg * k + k * (k + 1), lds_row = gate->kg * h + gate->kg * gate->n + gate->n * gate->n * gate->n + gate->n * h;
+        lds = sizeof(float) * (size_t)(lds_tile > lds_row ? lds_tile : lds_row);
+        PHC_REQUIRE(lds <= 128 * 1024, PHC_ERR_UNSUPPORTED, "%s: gate_w [%d x %d] does not fit the LDS staging", who, gate->kg, h);
+        g.dMT = dj.dH; g.dbg = dj.dH + (size_t)h * gate->kg;                     // dH = x^T . dg [h, kg], then its bias row = sum dg
+        g.sj = 1; g.sr = gate->kg;
+        g.H = gate->H; g.gate_w = gate->gate_w; g.phm_b = gate->phm_b; g.A = gate->A; g.W = gate->W;
+        g.dA = gate->dA; g.dW = gate->dW; g.db = gate->db; g.dWg = gate->dWg; g.dbg_out = gate->dbg; g.reg_add = gate->reg_add;
+        g.n = gate->n; g.k = k; g.kg = gate->kg;
+        g.blk_rows = g.n * g.n;
+        g.blk_dWg = g.blk_rows + k;
+        g.blk_db = g.blk_dWg + g.kg * ((h + 31) / 32);
+        nb_gate = (unsigned)(g.blk_db + 1);
+    }
+    TailReg r = {};
+    if (reg) r = *reg;
+    PHC_REQUIRE(ensure_dynamic_lds(&tail_finish_kernel, 128 * 1024), PHC_ERR_LAUNCH, "%s: the device refused %d bytes of dynamic LDS", who,
+                128 * 1024);
+    PHC_LAUNCH(tail_finish_kernel, dim3(gl.nb_contract + nb_gate + (reg ? 1u : 0u)), dim3(256), lds, s, gl.batch, g, r, gl.nb_contract, nb_gate);
     return check_launch(who);
 }
 
@@ -1893,6 +1961,7 @@ int phc_gate_param_grads(const float *dMT, const float *dbg, const float *H, con
     g.dMT = dMT; g.dbg = dbg; g.H = H; g.gate_w = gate_w; g.phm_b = phm_b; g.A = A; g.W = W;
     g.dA = dA; g.dW = dW; g.db = db; g.dWg = dWg;
     g.n = n; g.k = k; g.kg = kg;
+    g.sj = h; g.sr = 1; g.reg_add = nullptr; g.dbg_out = nullptr;
     g.blk_rows = n * n;
     g.blk_dWg = g.blk_rows + k;
     g.blk_db = g.blk_dWg + kg * ((h + 31) / 32);

@@ -29,7 +29,7 @@ import torch
 
 from . import synth
 from .graph import cached_structures_of, clear_structure_cache
-from .harness import StepConfig, advance_dropout_rng, apply_weight_regulariser, loss_fn, optimizer_step
+from .harness import StepConfig, advance_dropout_rng, apply_weight_regulariser, loss_fn, optimizer_step, park_weight_regulariser
 from .ops import deferred_param_grads, dense_weights, gate_specs, phm_pairs, prebuilt_H, stat_accumulators
 
 
@@ -292,7 +292,9 @@ class GraphedTrainStep:
             logits = self.model(bs.data)
             loss = loss_fn(logits, bs.data, self.cfg.regression)
             loss.backward(self._seed)
-        apply_weight_regulariser(self.model, loss, self.cfg)
+            parked = park_weight_regulariser(self.model, loss, self.cfg)
+        if not parked:
+            apply_weight_regulariser(self.model, loss, self.cfg)
         bs.logits = logits.detach()            # static output buffer of the captured step (rows of padding graphs included)
         if self.grad_sync is not None:
             self.grad_sync.pack()

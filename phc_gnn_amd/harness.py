@@ -152,7 +152,9 @@ def train_step(model, data, optimizer: Optional[torch.optim.Optimizer], cfg: Ste
         logits = model(data)
         loss = loss_fn(logits, data, cfg.regression)
         loss.backward(backward_seed(loss))
-    apply_weight_regulariser(model, loss, cfg)
+        parked = park_weight_regulariser(model, loss, cfg)       # rides in the step tail's launches when it can
+    if not parked:
+        apply_weight_regulariser(model, loss, cfg)
     if grad_sync is not None:
         grad_sync(model)
     if optimizer is not None and cfg.optimizer:
@@ -166,6 +168,15 @@ def advance_dropout_rng(model, data) -> None:
     from .ops import model_uses_dropout, rng_advance
     if model_uses_dropout(model):
         rng_advance(data.x.device)
+
+
+def park_weight_regulariser(model, loss: torch.Tensor, cfg: StepConfig) -> bool:
+    """Inside the step's ``deferred_param_grads`` block, after ``backward``: hand the regulariser to the step tail (no launch of
+    its own: gradient added where dW is written, value added to ``loss``).  True = taken (or nothing to do)."""
+    if cfg.weight_decay <= 0.0:
+        return True
+    from .ops import regularised_weights, request_weight_regulariser
+    return request_weight_regulariser(regularised_weights(model), cfg.lr * cfg.weight_decay, cfg.reg_p, loss.detach())
 
 
 def apply_weight_regulariser(model, loss: torch.Tensor, cfg: StepConfig) -> None:

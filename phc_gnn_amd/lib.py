@@ -69,6 +69,16 @@ class GemmBaDesc(C.Structure):
                 ("bw_x", _P), ("bw_stat", _P), ("bw_sums_acc", _P), ("count", _L)]
 
 
+class TailExtras(C.Structure):
+    """phc_tail_extras (include/phc_hip.h)."""
+    _fields_ = [("gate_job", C.c_int32), ("gate_n", C.c_int32), ("gate_kin", C.c_int32), ("gate_kout", C.c_int32), ("gate_kg", C.c_int32),
+                ("gate_H", _P), ("gate_w", _P), ("gate_phm_b", _P), ("gate_A", _P), ("gate_W", _P),
+                ("gate_dA", _P), ("gate_dW", _P), ("gate_db", _P), ("gate_dWg", _P),
+                ("reg_num", C.c_int32), ("reg_p", C.c_int32), ("reg_coef", C.c_float),
+                ("reg_W", _P), ("reg_n", _P), ("reg_cells", _P), ("reg_job", _P),
+                ("reg_value", _P), ("reg_loss_inout", _P), ("reg_ws", _P)]
+
+
 class Copy2dJob(C.Structure):
     """phc_copy2d_job (include/phc_hip.h)."""
     _fields_ = [("src", _P), ("dst", _P), ("src_off", C.c_int64), ("dst_off", C.c_int64), ("src_stride", C.c_int64),
@@ -167,6 +177,10 @@ SIGNATURES = {
     "phc_step_tail_ws_bytes": (_S, [C.POINTER(GradJob), _I, _I, _L, _L, _I, _P, _L, _I, _P, _I, _I]),
     "phc_step_tail": (_I, [C.POINTER(GradJob), _I, C.POINTER(TableGradJob), _I, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _L, _P, _P, _L, _I,
                            _P, _P, _I, _I, _P, _S, _P]),
+    "phc_tail_reg_max_jobs": (_I, []),
+    "phc_tail_extras_ws_floats": (_S, [C.POINTER(TailExtras)]),
+    "phc_step_tail_ex": (_I, [C.POINTER(GradJob), _I, C.POINTER(TableGradJob), _I, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _L, _P, _P, _L, _I,
+                              _P, _P, _I, _I, _P, _S, C.POINTER(TailExtras), _P]),
     "phc_bn_ws_bytes": (_S, [_L, _I]),
     "phc_bn_fwd": (_I, [_P, _P, _P, _P, _P, _P, _I, _P, _L, _I, _I, C.c_float, C.c_float, _I, _P, _P, _P, _P, _S, C.c_float, _I, _I,
                         _P, _P]),

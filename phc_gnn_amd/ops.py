@@ -55,6 +55,7 @@ class _Deferred:
         self.table_jobs = []
         self.atom_jobs = []
         self.beta_jobs = []
+        self.reg = None                    # a weight regulariser waiting for the step tail (request_weight_regulariser)
         self.lock = threading.Lock()       # the backward pass runs on autograd's device thread
 
 
@@ -69,18 +70,19 @@ def deferred_param_grads():
         yield
         return
     _DEFER.active = True
-    _DEFER.jobs, _DEFER.table_jobs, _DEFER.atom_jobs, _DEFER.beta_jobs = [], [], [], []
+    _DEFER.jobs, _DEFER.table_jobs, _DEFER.atom_jobs, _DEFER.beta_jobs, _DEFER.reg = [], [], [], [], None
     try:
         yield
     except BaseException:
         _DEFER.active = False
-        _DEFER.jobs, _DEFER.table_jobs, _DEFER.atom_jobs, _DEFER.beta_jobs = [], [], [], []
+        _DEFER.jobs, _DEFER.table_jobs, _DEFER.atom_jobs, _DEFER.beta_jobs, _DEFER.reg = [], [], [], [], None
         raise
     _DEFER.active = False
     jobs, _DEFER.jobs = _DEFER.jobs, []
     tjobs, _DEFER.table_jobs = _DEFER.table_jobs, []
     ajobs, _DEFER.atom_jobs = _DEFER.atom_jobs, []
     bjobs, _DEFER.beta_jobs = _DEFER.beta_jobs, []
+    reg, _DEFER.reg = _DEFER.reg, None
     if bjobs:
         _flush_beta_grads(bjobs)
     if STEP_TAIL_MERGED and len(ajobs) > 1:
@@ -89,13 +91,29 @@ def deferred_param_grads():
         ajobs.sort(key=lambda aj: aj["idx"].shape[0] * aj["ts"].R)
         _flush_encoder_grads(ajobs[:-1])
         ajobs = ajobs[-1:]
-    if STEP_TAIL_MERGED and _flush_step_tail(jobs, tjobs, ajobs):
+    if STEP_TAIL_MERGED and _flush_step_tail(jobs, tjobs, ajobs, reg):
         return
     if tjobs:
         _flush_table_grads(tjobs)
     _flush_encoder_grads(ajobs)
     if jobs:
         _flush_param_grads(jobs)
+    if reg is not None:                                      # the regulariser could not ride in a step tail: its own launch
+        _weight_reg_launch(reg["Ws"], reg["coef"], reg["p"], reg["loss"])
+
+
+# the explicit weight regulariser and the gate map's parameter gradients inside the step tail's last two launches
+TAIL_EXTRAS = __import__("os").environ.get("PHC_TAIL_EXTRAS", "1") != "0"
+
+
+def request_weight_regulariser(Ws, coef: float, p: int, loss: Optional[torch.Tensor]) -> bool:
+    """Inside ``deferred_param_grads``: park ``coef * sum_W mean ||W[:, kappa, pi]||_p`` for the step tail — its gradient is
+    added to the dW tensors as the tail writes them, its value to ``loss`` (in place), without a launch of its own.  False: no
+    deferred block is open (or the switch is off) and the caller runs ``phm_weight_regularization_``."""
+    if not (_DEFER.active and TAIL_EXTRAS):
+        return False
+    _DEFER.reg = dict(Ws=list(Ws), coef=float(coef), p=int(p), loss=loss)
+    return True
 
 
 # bond-table gradients of identity-message layers from per-node in-edge counts instead of per-edge gathers
@@ -179,8 +197,9 @@ def _flush_encoder_grads(ajobs) -> None:
             _assign_grads(aj["params"], aj["ts"].grad_views(flat[i * per:(i + 1) * per]))
 
 
-def _flush_step_tail(jobs, tjobs, ajobs) -> bool:
-    """Everything in one phc_step_tail call when the shapes allow it; False: the caller runs the separate flushes."""
+def _flush_step_tail(jobs, tjobs, ajobs, reg=None) -> bool:
+    """Everything in one phc_step_tail call when the shapes allow it; False: the caller runs the separate flushes (``reg``, a
+    parked weight regulariser, is then still the caller's to launch)."""
     if not jobs or len(jobs) > 16 or len(ajobs) > 1:
         return False
     dev = jobs[0]["x"].device
@@ -227,6 +246,54 @@ def _flush_step_tail(jobs, tjobs, ajobs) -> bool:
                                1 if jb.get("dense") else 0, L.ptr(xf[0]) if xf else None, L.ptr(xf[1]) if xf else None,
                                xf[2] if xf else 0, 0)
             outs.append((dA if need_A else None, dW if need_W else None, db if need_b else None))
+        # ---- extras of the tail's last two launches: the gate map's parameter gradients, the weight regulariser ----
+        extras, keep, gate_i, gate_out = None, [], -1, None
+        if TAIL_EXTRAS:
+            gate_jobs = [i for i, jb in enumerate(jobs) if jb.get("gate") is not None]
+            ex = L.TailExtras()
+            ex.gate_job = -1
+            if len(gate_jobs) == 1:
+                gate_i = gate_jobs[0]
+                gt = jobs[gate_i]["gate"]
+                gn, gkin, gkout = gt["W"].shape
+                nA, nW, nb, nWg, nbg = gt["need"]
+                gdA = torch.empty_like(gt["A"]) if nA else None
+                gdW = torch.empty_like(gt["W"]) if nW else None
+                gdb = torch.empty(gn * gkout, dtype=torch.float32, device=dev) if nb else None
+                gdWg = torch.empty_like(gt["Wg"]) if nWg else None
+                dbg = outs[gate_i][2]                                  # the dense job's bias gradient = sum dg
+                arr[gate_i].dW = None                                  # dM^T is read from the job's dH in place: nobody needs it written
+                ex.gate_job, ex.gate_n, ex.gate_kin, ex.gate_kout, ex.gate_kg = gate_i, gn, gkin, gkout, gt["Wg"].shape[0]
+                ex.gate_H, ex.gate_w, ex.gate_phm_b, ex.gate_A, ex.gate_W = L.ptr(gt["H"]), L.ptr(gt["Wg"]), L.ptr(gt["b"]), L.ptr(gt["A"]), L.ptr(gt["W"])
+                ex.gate_dA, ex.gate_dW, ex.gate_db, ex.gate_dWg = L.ptr(gdA), L.ptr(gdW), L.ptr(gdb), L.ptr(gdWg)
+                gate_out = (gdA, gdW, gdb, gdWg, dbg if nbg else None)
+                extras = ex
+            if reg is not None:
+                Ws = reg["Ws"]
+                by_ptr = {jb["W"].data_ptr(): i for i, jb in enumerate(jobs) if not jb.get("dense") and jb["need"][1]}
+                where = []
+                for w in Ws:
+                    if gate_i >= 0 and w.data_ptr() == jobs[gate_i]["gate"]["W"].data_ptr() and jobs[gate_i]["gate"]["need"][1]:
+                        where.append(-2)
+                    else:
+                        where.append(by_ptr.get(w.data_ptr(), -1))
+                ok = all(j != -1 for j in where) and 0 < len(Ws) <= lib.phc_tail_reg_max_jobs() and reg["p"] in (1, 2) and \
+                    all(w.dim() == 3 and w.shape[0] <= 16 and w.dtype == torch.float32 and w.is_contiguous() and w.device == dev for w in Ws)
+                if ok:
+                    k_ = len(Ws)
+                    W_arr = (_C.c_void_p * k_)(*[w.data_ptr() for w in Ws])
+                    n_arr = (_C.c_int32 * k_)(*[w.shape[0] for w in Ws])
+                    c_arr = (_C.c_int32 * k_)(*[w.shape[1] * w.shape[2] for w in Ws])
+                    j_arr = (_C.c_int32 * k_)(*where)
+                    keep += [W_arr, n_arr, c_arr, j_arr]
+                    ex.reg_num, ex.reg_p, ex.reg_coef = k_, reg["p"], reg["coef"]
+                    ex.reg_W, ex.reg_n, ex.reg_cells, ex.reg_job = (_C.cast(a_, _C.c_void_p) for a_ in (W_arr, n_arr, c_arr, j_arr))
+                    reg_value = torch.empty((), dtype=torch.float32, device=dev)
+                    reg_ws = torch.empty(lib.phc_tail_extras_ws_floats(_C.byref(ex)), dtype=torch.float32, device=dev)
+                    keep += [reg_value, reg_ws]
+                    ex.reg_value, ex.reg_loss_inout, ex.reg_ws = L.ptr(reg_value), L.ptr(reg["loss"]), L.ptr(reg_ws)
+                    extras = ex
+                    reg = None                                         # consumed
         # bond tables
         tarr, tflat, per = None, None, 0
         E = F_b = act = b_ndst = 0
@@ -257,15 +324,19 @@ def _flush_step_tail(jobs, tjobs, ajobs) -> bool:
         if ws_bytes == 0:
             return False
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
-        L.check(lib.phc_step_tail(arr, len(jobs), tarr, len(tjobs), L.ptr(bond), vocab_b, L.ptr(src), L.ptr(dst), E, F_b, act,
-                                  L.ptr(b_rowptr), L.ptr(b_codes), L.ptr(b_counts), b_ndst, L.ptr(a_dout), L.ptr(a_idx), N_a, F_a, vocab_a,
-                                  L.ptr(aflat), n, k, L.ptr(ws), ws_bytes, L.stream_ptr(dev)), "phc_step_tail")
+        L.check(lib.phc_step_tail_ex(arr, len(jobs), tarr, len(tjobs), L.ptr(bond), vocab_b, L.ptr(src), L.ptr(dst), E, F_b, act,
+                                     L.ptr(b_rowptr), L.ptr(b_codes), L.ptr(b_counts), b_ndst, L.ptr(a_dout), L.ptr(a_idx), N_a, F_a, vocab_a,
+                                     L.ptr(aflat), n, k, L.ptr(ws), ws_bytes, _C.byref(extras) if extras is not None else None,
+                                     L.stream_ptr(dev)), "phc_step_tail_ex")
         if L.PROF_ON:
             for jb in jobs:
                 jn, jkin, jkout = _job_dims(jb)
                 N = jb["x"].shape[0]
                 L.account("phm_dH_partial", 2.0 * N * jn * jkin * jn * jkout, 4.0 * N * jn * (jkin + jkout) + 4.0 * jn * jkin * jn * jkout)
-    for jb, grads in zip(jobs, outs):
+    for i, (jb, grads) in enumerate(zip(jobs, outs)):
+        if i == gate_i:                                                # the gate map's gradients came out of the tail itself
+            _assign_grads(jb["gate"]["params"], gate_out)
+            continue
         _assign_grads(jb["params"], grads)
         if jb.get("post") is not None:
             jb["post"](grads)
@@ -273,6 +344,8 @@ def _flush_step_tail(jobs, tjobs, ajobs) -> bool:
         _assign_grads(tj["params"], tj["ts"].grad_views(tflat[i * per:(i + 1) * per]))
     if ajobs:
         _assign_grads(ajobs[0]["params"], ts_a.grad_views(aflat))
+    if reg is not None:                                                # a parked regulariser this tail could not take
+        _weight_reg_launch(reg["Ws"], reg["coef"], reg["p"], reg["loss"])
     return True
 
 
@@ -1723,6 +1796,11 @@ class _GateLinearFn(torch.autograd.Function):
                 _assign_grads((A if nA else None, W if nW else None, b if nb else None, Wg if nWg else None, bg if nbg else None),
                               results["g"])
             job["post"] = post_assign
+            if H is not None:
+                # what the step tail needs to produce these gradients inside its own last launch (phc_step_tail_ex) instead
+                job["gate"] = dict(H=H, Wg=Wg_, b=b_, A=A_, W=W_, need=(nA, nW, nb, nWg, nbg),
+                                   params=(A if nA else None, W if nW else None, b if nb else None, Wg if nWg else None,
+                                           bg if nbg else None))
             with _DEFER.lock:
                 _DEFER.jobs.append(job)
             return dx, None, None, None, None, None, None
@@ -2862,6 +2940,24 @@ def downstream_head(x, n_valid, affine_layers, norm_modules, real_affine, activa
 # ---------------------------------------------------------------------------
 # explicit weight regulariser (regularization.py:15-23, train_hiv.py:181-196) as one launch
 # ---------------------------------------------------------------------------
+def regularised_weights(model) -> list:
+    """The weights the reference's regulariser sees: any sub-module with a non-None attribute ``W`` (regularization.py:15-23)."""
+    return [m.W for _, m in model.named_modules() if getattr(m, "W", None) is not None]
+
+
+def _weight_reg_launch(Ws, coef: float, p: int, loss: Optional[torch.Tensor]):
+    class _M:                                                # (phm_weight_regularization_ walks named_modules)
+        def __init__(self, ws):
+            self._ws = ws
+
+        def named_modules(self):
+            for i, w in enumerate(self._ws):
+                holder = type("H", (), {})()
+                holder.W = w
+                yield str(i), holder
+    return phm_weight_regularization_(_M(Ws), coef, p, loss)
+
+
 def phm_weight_regularization_(model, coef: float, p: int = 2, loss: Optional[torch.Tensor] = None) -> torch.Tensor:
     """``coef * phm_weight_regularization(model, p)`` of the reference, evaluated AFTER the backward pass: the value comes
     back as a device scalar (and is added to ``loss`` in place when given, the reference's ``loss += reg_loss``), its

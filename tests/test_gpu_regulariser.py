@@ -82,3 +82,28 @@ def test_regularised_training_step_matches_the_reference(path):
         if path == "eager":
             mine = dict(model.named_parameters())[k].grad - dict(model2.named_parameters())[k].grad
             assert float((mine.cpu() - ref).abs().max()) <= 1e-4 * float(ref.abs().max()) + 1e-7 * float(z8["grad::" + k].abs().max()), k
+
+
+def test_regulariser_and_gate_gradients_inside_the_step_tail_equal_their_own_launches():
+    """phc_step_tail_ex: the regulariser's cells ride in the tail's reduce launch and its gradient is added where dW is written,
+    the gate map's parameter gradients are workgroups of the tail's last launch reading the dense job's dH in place — the same
+    arithmetic in the same order as phc_phm_weight_reg / phc_gate_param_grads behind the tail: every gradient and the loss bit for bit."""
+    from phc_gnn_amd import harness, ops, synth
+    z8 = tensors(load("g8_model_cfg1"))
+    gb = synth.GraphBatch(x=z8["x"].numpy(), edge_index=z8["edge_index"].numpy(), edge_attr=z8["edge_attr"].numpy(),
+                          batch=z8["batch"].numpy(), y=z8["y"].numpy().astype(np.float32), num_graphs=int(z8["y"].shape[0]))
+    cfg = harness.StepConfig(optimizer=False, weight_decay=1e-3, reg_p=2, lr=1e-3)
+    out = {}
+    keep = ops.TAIL_EXTRAS
+    try:
+        for mode in (False, True):
+            ops.TAIL_EXTRAS = mode
+            model = _cfg1_model(z8)
+            loss = harness.train_step(model, harness.to_device(gb, DEV), None, cfg)
+            torch.cuda.synchronize()
+            out[mode] = (loss.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters()})
+    finally:
+        ops.TAIL_EXTRAS = keep
+    assert torch.equal(out[False][0], out[True][0]), (float(out[False][0]), float(out[True][0]))
+    for k, g in out[False][1].items():
+        assert torch.equal(g, out[True][1][k]), k
