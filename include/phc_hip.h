@@ -351,6 +351,11 @@ int phc_aggregate_enc_bwd(const float *dout, const float *x, const int64_t *bond
  * added on the way out instead of by a separate element-wise launch.  h % 4 == 0, 16-byte aligned rows. */
 int phc_aggregate_dx_rows(const float *dout, const int32_t *rowptr_t, const int32_t *col_t, int64_t n_src, int64_t n_dst, int h,
                           int add_self, const float *residual, float *dx, void *stream);
+/* ABI 5: the same with up to 8 further gradients of the same rows added on the way out, in the order given (residuals: HOST array of
+ * device pointers) — the shares of a skip tensor that feeds every layer (sc_type "first", models.py:230-234) meet in the first
+ * layer's dx kernel instead of an n-way sum launch of their own. */
+int phc_aggregate_dx_rows_multi(const float *dout, const int32_t *rowptr_t, const int32_t *col_t, int64_t n_src, int64_t n_dst, int h,
+                                int add_self, const float *const *residuals, int num_residuals, float *dx, void *stream);
 
 /* ------------------------------------------------------------------------- *
  * Batch normalisation of component-major activations, fused with the

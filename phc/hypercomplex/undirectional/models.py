@@ -138,7 +138,7 @@ class PHMSkipConnectAdd(nn.Module):
         return sum(p.numel() for p in self.parameters() if p.requires_grad)
 
     def compute_hidden_layer_embedding(self, conv, norm, x, edge_index, edge_attr, dropout_mpnn: float,
-                                       size=None, edge_encoder=None, n_valid=None) -> torch.Tensor:
+                                       size=None, edge_encoder=None, n_valid=None, skip_sum=None, first_layer=False) -> torch.Tensor:
         """x = [input of the conv, skip tensor]   (ref :200-217).  With ``edge_encoder`` given,
         ``edge_attr`` holds the raw integer bond features and the embedding is evaluated
         inside the aggregation kernel."""
@@ -151,9 +151,15 @@ class PHMSkipConnectAdd(nn.Module):
             # the conv's input is also the layer's skip tensor (sc_type "last"): the skip's share of dx is handed to the
             # aggregation's backward, which adds it inside its dx kernel — x then has ONE gradient and autograd launches no add
             handoff = _engine.DxHandoff() if (x[0] is x[1] and edge_encoder is not None and x[0].requires_grad) else None
+            # sc_type "first": every layer's skip is the encoded atoms, which also feed the first conv — the skips' shares of their
+            # gradient are parked in `skip_sum` by every layer and added inside the FIRST layer's aggregation backward
+            agg_handoff = handoff
+            if handoff is None and skip_sum is not None and edge_encoder is not None and x[0].requires_grad:
+                agg_handoff = skip_sum if first_layer else None
+                handoff = skip_sum
             if edge_encoder is not None:
                 agg = tr.propagate_encoded(edge_index, x[0], edge_attr, edge_encoder, size, add_self=tr.add_self_loops,
-                                           dx_handoff=handoff)
+                                           dx_handoff=agg_handoff)
             else:
                 agg = tr.propagate(edge_index, x=x[0], edge_attr=edge_attr, size=size, add_self=tr.add_self_loops)
             fused = _engine.mlp_norm_fused(agg, x[1], n_valid, tr.transform, norm, self.activation_str, skip_handoff=handoff)
@@ -193,6 +199,10 @@ class PHMSkipConnectAdd(nn.Module):
         # their gradients are summed in one pass
         # ("last": the conv input IS the skip tensor — one tensor object, see compute_hidden_layer_embedding's hand-off)
         uses = _engine.fanout(atom, 1 + L_) if (atom.is_cuda and self.sc_type == "first") else None
+        # (their gradients meet in the first layer's aggregation backward when that layer takes the hand-off; the fan-out node then
+        # sees one gradient and launches nothing)
+        skip_sum = _engine.DxSumHandoff() if (uses is not None and atom.requires_grad and torch.is_grad_enabled()
+                                              and L_ <= _engine.DxSumHandoff.MAX and _engine.SKIP_SUM_HANDOFF) else None
         h = uses[0] if uses is not None else atom
         for i in range(L_):
             if uses is not None:
@@ -205,7 +215,7 @@ class PHMSkipConnectAdd(nn.Module):
                 h = self.compute_hidden_layer_embedding(conv=self.convs[i], norm=self.norms[i], x=[h, skip],
                                                         edge_index=edge_index, edge_attr=edge_attr,
                                                         dropout_mpnn=self.dropout_mpnn[i], size=size, edge_encoder=enc,
-                                                        n_valid=n_valid)
+                                                        n_valid=n_valid, skip_sum=skip_sum, first_layer=(i == 0))
                 continue
             e = enc(edge_attr)
             e = e.reshape(e.size(0), self.mp_layers[i])

@@ -327,10 +327,16 @@ __global__ __launch_bounds__(ENC_THREADS) void aggregate_encp_direct_fwd_kernel(
 
 // dx of the same aggregation for an identity message function on a molecule batch (dx[s] = sum of dout over the out-edges
 // of s, + dout[s] for the self loop): one source row per lane group as above, no tables, no x.
-template <int LPR>
+// NRES > 1: up to NRES further gradients of the same rows (the shares of a skip tensor that feeds every layer, sc_type "first":
+// models.py:230-234) are added on the way out — the n-way sum launch in front of the atom-table gradient disappears.
+struct DxResiduals {
+    const float *p[8];
+    int n;
+};
+template <int LPR, int NRES = 1>
 __global__ __launch_bounds__(ENC_THREADS) void aggregate_dx_rows_kernel(
     const float *__restrict__ dout, const int *__restrict__ rowptr_t, const int *__restrict__ col_t, long long n_src,
-    long long n_dst, int h, int add_self, float *__restrict__ dx, const float *__restrict__ residual = nullptr) {
+    long long n_dst, int h, int add_self, float *__restrict__ dx, const float *__restrict__ residual = nullptr, DxResiduals more = {}) {
     const int h4 = h >> 2;
     constexpr int G = WAVE / LPR;
     const int lane = threadIdx.x & 63;
@@ -343,6 +349,12 @@ __global__ __launch_bounds__(ENC_THREADS) void aggregate_dx_rows_kernel(
             const float4 selfv = reinterpret_cast<const float4 *>(dout + (self_on ? (size_t)s * h : 0))[c4];
             // residual: another gradient of the same rows (the skip connection's share of dx) added on the way out
             const float4 resv = reinterpret_cast<const float4 *>(residual ? residual + (size_t)s * h : dout)[c4];
+            float4 morev[NRES > 1 ? NRES : 1];
+            if constexpr (NRES > 1) {                        // unconditional loads (an unused slot re-reads the dout row), selected below
+#pragma unroll
+                for (int q = 0; q < NRES; ++q)
+                    morev[q] = reinterpret_cast<const float4 *>(q < more.n ? more.p[q] + (size_t)s * h : dout)[c4];
+            }
             float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
             int e = e0 + first;
             if (e0 < e1) {                                   // both column indices in one round trip, both rows in the next
@@ -366,6 +378,11 @@ __global__ __launch_bounds__(ENC_THREADS) void aggregate_dx_rows_kernel(
             if (!coop || grp == 0) {
                 if (self_on) acc4(acc, selfv);
                 if (residual) acc4(acc, resv);
+                if constexpr (NRES > 1) {
+#pragma unroll
+                    for (int q = 0; q < NRES; ++q)
+                        if (q < more.n) acc4(acc, morev[q]);     // fixed order: slot 0, 1, ...
+                }
                 reinterpret_cast<float4 *>(dx + (size_t)s * h)[c4] = acc;
             }
         }
@@ -1629,6 +1646,47 @@ int phc_aggregate_encp_fwd(const float *x, const uint32_t *codes, const float *c
 #undef PHC_AP_F
 #undef PHC_AP_LAUNCH
     return check_launch("aggregate_encp_fwd");
+}
+
+int phc_aggregate_dx_rows_multi(const float *dout, const int32_t *rowptr_t, const int32_t *col_t, int64_t n_src, int64_t n_dst, int h,
+                                int add_self, const float *const *residuals, int num_residuals, float *dx, void *stream) {
+    PHC_REQUIRE(n_src >= 0 && n_dst >= 0 && h >= 4 && h % 4 == 0, PHC_ERR_INVALID_ARG, "phc_aggregate_dx_rows_multi: bad sizes (h %% 4 == 0)");
+    PHC_REQUIRE(num_residuals >= 0 && num_residuals <= 8 && (num_residuals == 0 || residuals), PHC_ERR_UNSUPPORTED,
+                "phc_aggregate_dx_rows_multi: %d residual tensors (0..8)", num_residuals);
+    if (num_residuals <= 1) return phc_aggregate_dx_rows(dout, rowptr_t, col_t, n_src, n_dst, h, add_self, num_residuals ? residuals[0] : nullptr, dx, stream);
+    if (n_src == 0) return PHC_OK;
+    PHC_REQUIRE(dout && rowptr_t && col_t && dx, PHC_ERR_INVALID_ARG, "phc_aggregate_dx_rows_multi: null pointer");
+    DxResiduals more = {};
+    more.n = num_residuals;
+    bool aligned = al16(dout) && al16(dx);
+    for (int q = 0; q < num_residuals; ++q) {
+        PHC_REQUIRE(residuals[q], PHC_ERR_INVALID_ARG, "phc_aggregate_dx_rows_multi: residual %d is null", q);
+        more.p[q] = residuals[q];
+        aligned = aligned && al16(residuals[q]);
+    }
+    PHC_REQUIRE(aligned, PHC_ERR_UNSUPPORTED, "phc_aggregate_dx_rows_multi: 16-byte aligned rows");
+    hipStream_t s = (hipStream_t)stream;
+    const int lpr = lpr_for(h >> 2);
+    const int rows_per_wg = 4 * (WAVE / lpr);
+    const unsigned rb = (unsigned)xcd_grid((n_src + rows_per_wg - 1) / rows_per_wg);
+    ProfScope prof(K_AGG_ENC_DX, s);
+#define PHC_DXM(LPRC, NR)                                                                                                            \
+    PHC_LAUNCH((aggregate_dx_rows_kernel<LPRC, NR>), dim3(rb), dim3(ENC_THREADS), 0, s, dout, rowptr_t, col_t, (long long)n_src, \
+               (long long)n_dst, h, add_self, dx, (const float *)nullptr, more)
+#define PHC_DXM_N(LPRC)            \
+    if (num_residuals <= 4)        \
+        PHC_DXM(LPRC, 4);          \
+    else                           \
+        PHC_DXM(LPRC, 8)
+    switch (lpr) {
+        case 8: PHC_DXM_N(8); break;
+        case 16: PHC_DXM_N(16); break;
+        case 32: PHC_DXM_N(32); break;
+        default: PHC_DXM_N(64); break;
+    }
+#undef PHC_DXM_N
+#undef PHC_DXM
+    return check_launch("aggregate_dx_rows_multi");
 }
 
 int phc_aggregate_dx_rows(const float *dout, const int32_t *rowptr_t, const int32_t *col_t, int64_t n_src, int64_t n_dst, int h,

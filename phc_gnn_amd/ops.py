@@ -865,6 +865,11 @@ class BNStatsRequest:
         return self.partial, self.counts, True
 
 
+# sc_type "first" models: the skips' gradient shares added inside the first layer's aggregation backward (DxSumHandoff) instead of
+# an n-way sum launch (PHC_SKIP_SUM_HANDOFF=0 restores the launch)
+SKIP_SUM_HANDOFF = __import__("os").environ.get("PHC_SKIP_SUM_HANDOFF", "1") != "0"
+
+
 class DxHandoff:
     """Gradient hand-over between two consumers of ONE tensor x (the soft-attention read-out: x feeds the gate's PHM layer and
     the gated sum).  The consumer whose backward runs first parks its dx here instead of returning it; the PHM layer's backward
@@ -874,9 +879,31 @@ class DxHandoff:
         self.tensor = None
         self.accepted = False      # set by the consumer that will add the parked gradient (its forward ran): nobody parks before
 
+    def park(self, t):
+        self.tensor = t
+
     def take(self):
         t, self.tensor = self.tensor, None
         return t
+
+
+class DxSumHandoff(DxHandoff):
+    """The same for a tensor with MANY parked shares: the encoded atoms of an ``sc_type = "first"`` model are the skip tensor of
+    every layer (models.py:230-234) and the first conv's input.  Each layer's fused MLP + norm node parks its share of the
+    gradient here instead of returning it; the FIRST layer's aggregation backward — the last to run — adds all of them inside
+    its dx kernel (``phc_aggregate_dx_rows_multi``): the n-way sum launch in front of the atom-table gradient disappears."""
+    MAX = 8
+
+    def __init__(self):
+        super().__init__()
+        self.tensors = []
+
+    def park(self, t):
+        self.tensors.append(t)
+
+    def take(self):
+        ts, self.tensors = self.tensors, []
+        return ts if ts else None
 
 
 def phm_linear(x: torch.Tensor, phm_rule: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None,
@@ -953,6 +980,7 @@ class _FanoutFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, n):
         ctx.n = n
+        ctx.set_materialize_grads(False)     # a consumer that parked its share elsewhere (DxSumHandoff) hands back None, not zeros
         return tuple(x.view_as(x) for _ in range(n))
 
     @staticmethod
@@ -2202,7 +2230,9 @@ class _AggregateEncFn(torch.autograd.Function):
         need_t = any(ctx.needs_input_grad[7:])
         # the skip connection's share of dx (DxHandoff, parked by the layer's fused MLP + norm node)
         extra = ctx.dx_handoff.take() if ctx.dx_handoff is not None else None
-        if extra is not None and (not need_x or tuple(extra.shape) != (ctx.x_rows, h)):
+        extras = extra if isinstance(extra, list) else ([extra] if extra is not None else [])    # DxSumHandoff parks several
+        extra = extras[0] if len(extras) == 1 else None
+        if extras and (not need_x or any(tuple(e.shape) != (ctx.x_rows, h) for e in extras)):
             raise L.PhcError("DxHandoff: a parked gradient needs a consumer that computes dx of the same shape")
         rowptr_t = col_t = perm_t = None
         dx = None
@@ -2218,7 +2248,14 @@ class _AggregateEncFn(torch.autograd.Function):
             L.check(lib.phc_aggregate_dx_rows(L.ptr(dout_), L.ptr(rowptr_t), L.ptr(col_t), st.num_src, st.num_dst, h,
                                               1 if ctx.add_self else 0, L.ptr(extra), L.ptr(dx), L.stream_ptr(dev)),
                     "phc_aggregate_dx_rows")
-            dx_done, extra = True, None
+            dx_done, extra, extras = True, None, []
+        elif need_x and len(extras) > 1 and len(extras) <= 8 and ctx.act == 0 and ctx.x_rows == st.num_src and h % 4 == 0 \
+                and dout_.data_ptr() % 16 == 0 and all(e.is_contiguous() and e.data_ptr() % 16 == 0 for e in extras):
+            arr = (_C.c_void_p * len(extras))(*[e.data_ptr() for e in extras])
+            L.check(lib.phc_aggregate_dx_rows_multi(L.ptr(dout_), L.ptr(rowptr_t), L.ptr(col_t), st.num_src, st.num_dst, h,
+                                                    1 if ctx.add_self else 0, arr, len(extras), L.ptr(dx), L.stream_ptr(dev)),
+                    "phc_aggregate_dx_rows_multi")
+            dx_done, extras = True, []
         flat = ws = None
         ws_bytes = 0
         deferred = need_t and ctx.defer_tables is not None and _DEFER.active and not torch.is_grad_enabled()
@@ -2240,8 +2277,8 @@ class _AggregateEncFn(torch.autograd.Function):
                                               st.num_dst, ts.F, ts.n, ts.k, ctx.act, 1 if ctx.add_self else 0,
                                               None if dx_done else L.ptr(dx), L.ptr(flat), L.ptr(ws), ws_bytes, L.stream_ptr(dev)),
                     "phc_aggregate_enc_bwd")
-        if extra is not None:
-            dx += extra
+        for e in extras:                                     # (shapes the row walker does not take: plain adds)
+            dx += e
         if L.PROF_ON:
             E, Ns, Nd = st.num_edges, st.num_src, st.num_dst
             if need_x:
@@ -2701,7 +2738,7 @@ class _MLPNormFn(torch.autograd.Function):
         dskip = dout if (ctx.has_skip and needs[1]) else None
         hd = meta.get("skip_handoff")
         if hd is not None and hd.accepted and dskip is not None:
-            hd.tensor = dout_                                 # the skip's share of dx: added inside the aggregation's dx kernel
+            hd.park(dout_)                                    # the skip's share of dx: added inside the aggregation's dx kernel
             dskip = None
         return (ds if needs[0] else None, dskip, None, None, *grads, *aff)
 
