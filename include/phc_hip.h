@@ -349,6 +349,19 @@ int phc_aggregate_enc_bwd(const float *dout, const float *x, const int64_t *bond
  * walk is latency-bound): dx[s] = sum over the out-edges of s of dout[dst] (+ dout[s] with add_self, s < n_dst) (+ residual[s]).
  * `residual` (may be NULL): another gradient of the same rows — the additive skip connection's share of d x (models.py:208-215) —
  * added on the way out instead of by a separate element-wise launch.  h % 4 == 0, 16-byte aligned rows. */
+/* ABI 5: the model-level norm folded into the NEXT layer's aggregation.  x = act(norm(y)) (+ skip) (models.py:208-215) is evaluated
+ * on the fly for every gathered row and for the row itself — statistics from the accumulator `acc` the producing GEMM filled (as
+ * phc_bn_fwd_from_partials' accumulator form: save_stat [6 h], running statistics updated) — then  out[d] = sum_e (x[src_e] +
+ * enc_e) (+ x[d])  as phc_aggregate_encp_fwd with an identity message function; x itself is written once to x_out [n_dst, h].
+ * Same node set on both sides (n_src == n_dst); rows >= *n_valid_dev are padding (x = 0).  Bit-identical to the two launches it
+ * replaces.  phc_aggregate_norm_supported: molecule-scale row counts (the one-row-per-lane-group walker), h <= 512, packed codes. */
+int phc_aggregate_norm_supported(int64_t n_dst, int h, int F, int sum_vocab);
+int phc_aggregate_norm_encp_fwd(const float *y, const uint64_t *acc, const float *const *weight, const float *const *bias,
+                                float *const *running_mean, float *const *running_var, int64_t *const *num_batches_tracked, int n_comp,
+                                float momentum, float eps, int norm_act, const int32_t *n_valid_dev, const float *skip, float *save_stat,
+                                float *x_out, const uint32_t *codes, const float *const *tables, const int32_t *vocab,
+                                const int32_t *rowptr, const int32_t *col, int64_t n_dst, int F, int n, int k, int add_self, float *out,
+                                void *stream);
 int phc_aggregate_dx_rows(const float *dout, const int32_t *rowptr_t, const int32_t *col_t, int64_t n_src, int64_t n_dst, int h,
                           int add_self, const float *residual, float *dx, void *stream);
 /* ABI 5: the same with up to 8 further gradients of the same rows added on the way out, in the order given (residuals: HOST array of

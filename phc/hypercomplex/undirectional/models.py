@@ -138,14 +138,22 @@ class PHMSkipConnectAdd(nn.Module):
         return sum(p.numel() for p in self.parameters() if p.requires_grad)
 
     def compute_hidden_layer_embedding(self, conv, norm, x, edge_index, edge_attr, dropout_mpnn: float,
-                                       size=None, edge_encoder=None, n_valid=None, skip_sum=None, first_layer=False) -> torch.Tensor:
+                                       size=None, edge_encoder=None, n_valid=None, skip_sum=None, first_layer=False,
+                                       defer_norm=False) -> torch.Tensor:
         """x = [input of the conv, skip tensor]   (ref :200-217).  With ``edge_encoder`` given,
         ``edge_attr`` holds the raw integer bond features and the embedding is evaluated
         inside the aggregation kernel."""
         dropout_active = self.training and dropout_mpnn > 0.0
         tr = getattr(conv, "transform", None)
-        if self.training and norm is not None and not dropout_active and self.mlp_mp and x[0].is_cuda and \
-                hasattr(tr, "propagate_encoded") and hasattr(getattr(tr, "transform", None), "linear2"):
+        # the layer in front may have parked its last element-wise pass (engine: PendingNorm on x[0]): only the fused branch below
+        # passes it on to the aggregation kernel, every other path evaluates it now
+        pending = getattr(x[0], "_phc_pending", None)
+        fused_branch = self.training and norm is not None and not dropout_active and self.mlp_mp and x[0].is_cuda and \
+            hasattr(tr, "propagate_encoded") and hasattr(getattr(tr, "transform", None), "linear2")
+        if pending is not None and not (fused_branch and edge_encoder is not None and type(tr).__name__ == "PHMGINEConv"):
+            _engine.materialize_pending(x[0])
+            pending = None
+        if fused_branch:
             # PHMGINEConv + model norm, training mode: aggregation, then the MLP and the norm as ONE autograd node whose
             # backward folds both batch-norm backwards into the dx GEMMs (engine: mlp_norm_fused); None = not applicable
             # the conv's input is also the layer's skip tensor (sc_type "last"): the skip's share of dx is handed to the
@@ -158,11 +166,17 @@ class PHMSkipConnectAdd(nn.Module):
                 agg_handoff = skip_sum if first_layer else None
                 handoff = skip_sum
             if edge_encoder is not None:
-                agg = tr.propagate_encoded(edge_index, x[0], edge_attr, edge_encoder, size, add_self=tr.add_self_loops,
-                                           dx_handoff=agg_handoff)
+                if pending is not None:
+                    agg = tr.propagate_encoded(edge_index, x[0], edge_attr, edge_encoder, size, add_self=tr.add_self_loops,
+                                               dx_handoff=agg_handoff, pending=pending)
+                    x[0]._phc_pending = None                 # evaluated (or materialised) by that call
+                else:
+                    agg = tr.propagate_encoded(edge_index, x[0], edge_attr, edge_encoder, size, add_self=tr.add_self_loops,
+                                               dx_handoff=agg_handoff)
             else:
                 agg = tr.propagate(edge_index, x=x[0], edge_attr=edge_attr, size=size, add_self=tr.add_self_loops)
-            fused = _engine.mlp_norm_fused(agg, x[1], n_valid, tr.transform, norm, self.activation_str, skip_handoff=handoff)
+            fused = _engine.mlp_norm_fused(agg, x[1], n_valid, tr.transform, norm, self.activation_str, skip_handoff=handoff,
+                                           defer_apply=defer_norm)
             if fused is not None:
                 return fused
             h = tr.transform(agg, n_valid=n_valid)
@@ -215,13 +229,17 @@ class PHMSkipConnectAdd(nn.Module):
                 h = self.compute_hidden_layer_embedding(conv=self.convs[i], norm=self.norms[i], x=[h, skip],
                                                         edge_index=edge_index, edge_attr=edge_attr,
                                                         dropout_mpnn=self.dropout_mpnn[i], size=size, edge_encoder=enc,
-                                                        n_valid=n_valid, skip_sum=skip_sum, first_layer=(i == 0))
+                                                        n_valid=n_valid, skip_sum=skip_sum, first_layer=(i == 0),
+                                                        # the layer's last element-wise pass rides in the NEXT layer's aggregation
+                                                        defer_norm=(i + 1 < L_ and getattr(self.bondencoders[i + 1], "engine_tables",
+                                                                                            None) is not None))
                 continue
             e = enc(edge_attr)
             e = e.reshape(e.size(0), self.mp_layers[i])
             h = self.compute_hidden_layer_embedding(conv=self.convs[i], norm=self.norms[i], x=[h, skip],
                                                     edge_index=edge_index, edge_attr=e,
                                                     dropout_mpnn=self.dropout_mpnn[i], size=size, n_valid=n_valid)
+        _engine.materialize_pending(h)                       # (never parked for the last layer; a guard for subclasses)
         num_graphs = getattr(data, "num_graphs", None)
         # The reference's scatter-based global_add_pool does not care about the order of `batch`; the binary-search
         # read-out does.  Only a batch object that SAYS its `batch` vector is non-decreasing (harness.to_device and the

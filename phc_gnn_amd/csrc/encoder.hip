@@ -325,6 +325,152 @@ __global__ __launch_bounds__(ENC_THREADS) void aggregate_encp_direct_fwd_kernel(
     }
 }
 
+// ---- the model-level norm folded into the NEXT layer's aggregation (round 4) -------------------------------------------------
+// models.py:208-215 ends a layer with  x = act(norm(y)) (+ skip);  the next layer starts with  s[d] = sum_e (x[src_e] + enc_e) + x[d]
+// (messagepassing.py:132-146).  With the norm's batch statistics in an accumulator (the producing GEMM's epilogue) the element-wise
+// pass between the two is not a launch of its own: this kernel derives scale / shift in its prologue (the arithmetic of
+// bn_apply_acc_kernel: replica totals summed in double, in replica order), applies  act(y * scale + shift) + skip  to every row
+// it gathers AND to its own row, which it also writes out once as x (later readers: the skip of an sc_type "last" model, the
+// gradient kernels through save_stat, nothing else).  One row per lane group as above; identity message function; rows >= *n_valid
+// are padding and read as 0, exactly as the stand-alone pass leaves them.  Bit-identical to the two launches it replaces.
+constexpr int AGN_MAX_H = 512;
+template <int LPR, int F>
+__global__ __launch_bounds__(ENC_THREADS) void aggregate_norm_direct_fwd_kernel(
+    const float *__restrict__ y, const float *__restrict__ skip, BnParams p, const int *__restrict__ n_valid, float momentum, float eps,
+    const unsigned long long *__restrict__ acc, int norm_act, float *__restrict__ stat, float *__restrict__ xout,
+    const unsigned *__restrict__ codes, const float *const *__restrict__ tables, EncMeta m, const int *__restrict__ rowptr,
+    const int *__restrict__ col, long long n_dst, int n, int k, int add_self, float *__restrict__ out) {
+    __shared__ __attribute__((aligned(16))) float s_scale[AGN_MAX_H], s_shift[AGN_MAX_H];
+    const int h = n * k, h4 = h >> 2;
+    constexpr int G = WAVE / LPR;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int grp = lane / LPR, li = lane - grp * LPR;
+    const long long count = n_valid ? min((long long)*n_valid, n_dst) : n_dst;
+    const long long d0 = (((long long)xcd_contiguous_block(blockIdx.x, gridDim.x) * ENC_THREADS + tid) >> 6) * G;
+    // this lane group's row pointers go in flight before the totals prologue (clamped: a workgroup past the rows still helps nobody,
+    // but it must reach the barrier)
+    const long long d = d0 + grp;
+    const bool valid = d < n_dst;
+    const long long dc = valid ? d : 0;
+    const int e_begin_raw = rowptr[dc], e_end_raw = rowptr[dc + 1];
+    // ---- prologue: scale / shift of every column (one column per thread and round) ----
+    const bool owner = blockIdx.x == 0;
+    for (int c = tid; c < h; c += ENC_THREADS) {
+        double S = 0.0, Q = 0.0;
+#pragma unroll
+        for (int rp = 0; rp < STAT_ACC_REP; ++rp) {
+            S += stat_acc_part(acc, h, rp, 0, c);
+            Q += stat_acc_part(acc, h, rp, 1, c);
+        }
+        const int comp = c / p.k, kk = c - comp * p.k;
+        float w = 1.f, bq = 0.f, rm_old = 0.f, rv_old = 1.f;
+        for (int q = 0; q < p.n_comp; ++q)                     // uniform walk of the by-value pointer tables
+            if (q == comp) {
+                if (p.has_weight) w = p.weight[q][kk];
+                if (p.has_bias) bq = p.bias[q][kk];
+                if (p.has_running && owner) { rm_old = p.running_mean[q][kk]; rv_old = p.running_var[q][kk]; }
+            }
+        const double cntd = (double)max(count, 1LL);
+        const double meand = S / cntd;
+        const double vard = fmax(Q / cntd - meand * meand, 0.0);
+        const float mean = (float)meand, var = (float)vard;
+        const float invstd = 1.f / sqrtf(var + eps);
+        s_scale[c] = invstd * w;
+        s_shift[c] = bq - mean * invstd * w;
+        if (owner) {
+            stat[c] = mean;
+            stat[h + c] = invstd;
+            stat[2 * h + c] = invstd * w;
+            stat[3 * h + c] = bq - mean * invstd * w;
+            stat[4 * h + c] = w;
+            stat[5 * h + c] = bq;
+            if (p.has_running) {
+                const float unbiased = count > 1 ? (float)(vard * cntd / (cntd - 1.0)) : var;
+                for (int q = 0; q < p.n_comp; ++q)
+                    if (q == comp) {
+                        p.running_mean[q][kk] = (1.f - momentum) * rm_old + momentum * mean;
+                        p.running_var[q][kk] = (1.f - momentum) * rv_old + momentum * unbiased;
+                    }
+            }
+        }
+    }
+    if (owner && p.has_nbt && tid < p.n_comp)
+        for (int q = 0; q < p.n_comp; ++q)
+            if (q == tid) *p.num_batches_tracked[q] += 1;
+    __syncthreads();
+    if (d0 >= n_dst) return;                                 // wave-uniform
+    const bool relu = norm_act == PHC_ACT_RELU;
+    // one normalised row slice: act(y * scale + shift) (+ skip), 0 for a padding row
+    auto xrow = [&](long long r, int c4, const float4 sc, const float4 sh) {
+        const float4 v = reinterpret_cast<const float4 *>(y + (size_t)r * h)[c4];
+        const float4 rr = reinterpret_cast<const float4 *>(skip ? skip + (size_t)r * h : y)[c4];
+        float4 o;
+        if (relu) {
+            o.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f); o.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
+            o.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f); o.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
+        } else {
+            o.x = act_fwd_rt(norm_act, fmaf(v.x, sc.x, sh.x)); o.y = act_fwd_rt(norm_act, fmaf(v.y, sc.y, sh.y));
+            o.z = act_fwd_rt(norm_act, fmaf(v.z, sc.z, sh.z)); o.w = act_fwd_rt(norm_act, fmaf(v.w, sc.w, sh.w));
+        }
+        if (skip) { o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w; }
+        if (r >= count) o = make_float4(0.f, 0.f, 0.f, 0.f);
+        return o;
+    };
+    auto row = [&](long long dd, int e0, int e1, int first, int step, bool coop) {
+        for (int c4 = li; c4 < h4; c4 += LPR) {
+            const int c = (c4 * 4) / k, kk = c4 * 4 - c * k;
+            const float *tp[F];
+#pragma unroll
+            for (int f = 0; f < F; ++f) tp[f] = tables[c * F + f] + kk - (size_t)m.off[f] * k;
+            const float4 sc = *reinterpret_cast<const float4 *>(s_scale + 4 * c4), sh = *reinterpret_cast<const float4 *>(s_shift + 4 * c4);
+            const float4 selfv = xrow(dd, c4, sc, sh);
+            float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
+            auto message = [&](int s, unsigned code) {
+                float4 v = xrow(s, c4, sc, sh);
+#pragma unroll
+                for (int f = 0; f < F; ++f) acc4(v, *reinterpret_cast<const float4 *>(tp[f] + (size_t)((code >> (8 * f)) & 255u) * k));
+                return v;
+            };
+            int e = e0 + first;
+            if (e0 < e1) {
+                const int i0 = min(e, e1 - 1), i1 = min(e + step, e1 - 1);
+                const int s0 = col[i0], s1 = col[i1];
+                const unsigned k0 = codes[i0], k1 = codes[i1];
+                const float4 v0 = message(s0, k0), v1 = message(s1, k1);
+                if (e < e1) acc4(acc0, v0);
+                if (e + step < e1) acc4(acc1, v1);
+                e += 2 * step;
+            }
+            for (; e < e1; e += step) acc4(acc0, message(col[e], codes[e]));
+            float4 a4 = make_float4(acc0.x + acc1.x, acc0.y + acc1.y, acc0.z + acc1.z, acc0.w + acc1.w);
+            if (coop) {
+#pragma unroll
+                for (int off = LPR; off < WAVE; off <<= 1) {
+                    a4.x += __shfl_xor(a4.x, off, WAVE); a4.y += __shfl_xor(a4.y, off, WAVE);
+                    a4.z += __shfl_xor(a4.z, off, WAVE); a4.w += __shfl_xor(a4.w, off, WAVE);
+                }
+            }
+            if (!coop || grp == 0) {
+                reinterpret_cast<float4 *>(xout + (size_t)dd * h)[c4] = selfv;        // x itself, once
+                if (add_self) acc4(a4, selfv);
+                reinterpret_cast<float4 *>(out + (size_t)dd * h)[c4] = a4;
+            }
+        }
+    };
+    const int e_begin = valid ? e_begin_raw : 0, e_end = valid ? e_end_raw : 0;
+    const bool heavy = G > 1 && e_end - e_begin > AGG_HEAVY;
+    if (valid && !heavy) row(d, e_begin, e_end, 0, 1, false);
+    if (G > 1) {
+        const unsigned long long hb = __ballot(heavy);
+        if (hb) {
+            for (int g = 0; g < G; ++g) {
+                const int eb = __shfl(e_begin, g * LPR, WAVE), ee = __shfl(e_end, g * LPR, WAVE);
+                if ((hb >> (g * LPR)) & 1ull) row(d0 + g, eb, ee, grp, G, true);
+            }
+        }
+    }
+}
+
 // dx of the same aggregation for an identity message function on a molecule batch (dx[s] = sum of dout over the out-edges
 // of s, + dout[s] for the self loop): one source row per lane group as above, no tables, no x.
 // NRES > 1: up to NRES further gradients of the same rows (the shares of a skip tensor that feeds every layer, sc_type "first":
@@ -1646,6 +1792,63 @@ int phc_aggregate_encp_fwd(const float *x, const uint32_t *codes, const float *c
 #undef PHC_AP_F
 #undef PHC_AP_LAUNCH
     return check_launch("aggregate_encp_fwd");
+}
+
+static inline long long encp_direct_max() {
+    static const long long v = getenv("PHC_ENCP_DIRECT_MAX") ? atoll(getenv("PHC_ENCP_DIRECT_MAX")) : 32768;
+    return v;
+}
+int phc_aggregate_norm_supported(int64_t n_dst, int h, int F, int R) {
+    return (n_dst >= 1 && n_dst <= encp_direct_max() && h >= 4 && h % 4 == 0 && h <= AGN_MAX_H && F >= 1 && F <= 4 && R <= 256) ? 1 : 0;
+}
+
+int phc_aggregate_norm_encp_fwd(const float *y, const uint64_t *acc, const float *const *weight, const float *const *bias,
+                                float *const *running_mean, float *const *running_var, int64_t *const *num_batches_tracked, int n_comp,
+                                float momentum, float eps, int norm_act, const int32_t *n_valid_dev, const float *skip, float *save_stat,
+                                float *x_out, const uint32_t *codes, const float *const *tables, const int32_t *vocab,
+                                const int32_t *rowptr, const int32_t *col, int64_t n_dst, int F, int n, int k, int add_self, float *out,
+                                void *stream) {
+    EncMeta m;
+    int rc = make_meta("phc_aggregate_norm_encp_fwd", F, vocab, &m);
+    if (rc) return rc;
+    const int h = n * k;
+    PHC_REQUIRE(phc_aggregate_norm_supported(n_dst, h, F, m.R) && n * F <= PHC_MAX_COMPONENTS * 4 && k % 4 == 0, PHC_ERR_UNSUPPORTED,
+                "phc_aggregate_norm_encp_fwd: %lld rows, h = %d, F = %d, sum(vocab) = %d outside the fused form's range", (long long)n_dst,
+                h, F, m.R);
+    PHC_REQUIRE(norm_act >= PHC_ACT_IDENTITY && norm_act <= PHC_ACT_SELU, PHC_ERR_INVALID_ARG, "phc_aggregate_norm_encp_fwd: unknown activation %d",
+                norm_act);
+    PHC_REQUIRE(y && acc && save_stat && x_out && codes && tables && rowptr && col && out, PHC_ERR_INVALID_ARG,
+                "phc_aggregate_norm_encp_fwd: null pointer");
+    PHC_REQUIRE(al16(y) && al16(x_out) && al16(out) && (!skip || al16(skip)) && (reinterpret_cast<uintptr_t>(acc) & 7) == 0, PHC_ERR_UNSUPPORTED,
+                "phc_aggregate_norm_encp_fwd: 16-byte aligned rows / 8-byte aligned accumulator");
+    BnParams p;
+    rc = fill_params("phc_aggregate_norm_encp_fwd", &p, weight, bias, running_mean, running_var, num_batches_tracked, n_comp, h);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int lpr = lpr_for(h >> 2);
+    const int rows_per_wg = 4 * (WAVE / lpr);
+    const long long dblocks = xcd_grid((n_dst + rows_per_wg - 1) / rows_per_wg);
+    const unsigned long long *acc64 = reinterpret_cast<const unsigned long long *>(acc);
+    ProfScope prof(K_AGG_ENC_FWD, s);
+#define PHC_AGN_LAUNCH(LPRC, FC)                                                                                                      \
+    PHC_LAUNCH((aggregate_norm_direct_fwd_kernel<LPRC, FC>), dim3((unsigned)dblocks), dim3(ENC_THREADS), 0, s, y, skip, p, n_valid_dev,  \
+               momentum, eps, acc64, norm_act, save_stat, x_out, codes, tables, m, rowptr, col, (long long)n_dst, n, k, add_self, out)
+#define PHC_AGN_F(LPRC)                                 \
+    switch (F) {                                        \
+        case 1: PHC_AGN_LAUNCH(LPRC, 1); break;         \
+        case 2: PHC_AGN_LAUNCH(LPRC, 2); break;         \
+        case 3: PHC_AGN_LAUNCH(LPRC, 3); break;         \
+        default: PHC_AGN_LAUNCH(LPRC, 4); break;        \
+    }
+    switch (lpr) {
+        case 8: PHC_AGN_F(8); break;
+        case 16: PHC_AGN_F(16); break;
+        case 32: PHC_AGN_F(32); break;
+        default: PHC_AGN_F(64); break;
+    }
+#undef PHC_AGN_F
+#undef PHC_AGN_LAUNCH
+    return check_launch("aggregate_norm_encp_fwd");
 }
 
 int phc_aggregate_dx_rows_multi(const float *dout, const int32_t *rowptr_t, const int32_t *col_t, int64_t n_src, int64_t n_dst, int h,

@@ -199,6 +199,9 @@ SIGNATURES = {
     "phc_sum_n": (_I, [_P, _I, _L, _P, _P]),
     "phc_copy2d_batched": (_I, [_P, _I, _L, _P, _P, _P]),
     "phc_aggregate_dx_rows": (_I, [_P, _P, _P, _L, _L, _I, _I, _P, _P, _P]),
+    "phc_aggregate_norm_supported": (_I, [_L, _I, _I, _I]),
+    "phc_aggregate_norm_encp_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, C.c_float, C.c_float, _I, _P, _P, _P, _P, _P, _P, _P, _P, _P, _L,
+                                         _I, _I, _I, _I, _P, _P]),
     "phc_aggregate_dx_rows_multi": (_I, [_P, _P, _P, _L, _L, _I, _I, _P, _I, _P, _P]),
     "phc_vec_sums": (_I, [_P, _P, _P, _I, _P]),
     "phc_small_linear_max_weights": (_I, []),

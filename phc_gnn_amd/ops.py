@@ -2177,12 +2177,19 @@ def encode(idx: torch.Tensor, ts: TableSet, tables) -> torch.Tensor:
 
 class _AggregateEncFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, bond_idx, st: EdgeStructure, act: int, add_self: bool, ts: TableSet, dx_handoff, *tables):
+    def forward(ctx, x, bond_idx, st: EdgeStructure, act: int, add_self: bool, ts: TableSet, dx_handoff, pending, *tables):
         lib = L.load()
         ctx.dx_handoff = dx_handoff
         if dx_handoff is not None:
             dx_handoff.accepted = True
         dev = L.require_device(x, bond_idx)
+        # `pending`: x = act(norm(y)) (+ skip) has not been evaluated yet (PendingNorm): this launch does it on the fly for every row
+        # it gathers and writes x itself once — or, outside the fused kernel's range, the stand-alone pass runs right here
+        fuse_norm = pending is not None and not pending.done and act == 0 and ts.F <= 4 and ts.R <= 256 and x.is_contiguous() and \
+            x.shape[0] == st.num_src == st.num_dst and x.shape[0] * x.shape[1] <= NORM_INTO_AGGREGATE_MAX_WORK and \
+            bool(lib.phc_aggregate_norm_supported(st.num_dst, x.shape[1], ts.F, ts.R))
+        if pending is not None and not pending.done and not fuse_norm:
+            pending.materialize()
         x_ = L.f32c(x)
         bond_ = _idx64(bond_idx)
         h = x_.shape[1]
@@ -2195,7 +2202,11 @@ class _AggregateEncFn(torch.autograd.Function):
         rowptr, col, perm = st.csr
         out = torch.empty((st.num_dst, h), dtype=torch.float32, device=dev)
         ctx.codes = None
-        if ts.F <= 4 and ts.R <= 256:
+        if fuse_norm:
+            codes = st.packed_codes(bond_, ts.vocab_c, ts.F)
+            ctx.codes = codes
+            pending.run_fused(x_, codes, ts, rowptr, col, st.num_dst, add_self, out)
+        elif ts.F <= 4 and ts.R <= 256:
             codes = st.packed_codes(bond_, ts.vocab_c, ts.F)        # 4 bytes per edge, in sorted order, built once per batch
             ctx.codes = codes
             L.check(lib.phc_aggregate_encp_fwd(L.ptr(x_), L.ptr(codes), L.ptr(ts.ptrs), ts.vocab_c, L.ptr(rowptr), L.ptr(col),
@@ -2227,7 +2238,7 @@ class _AggregateEncFn(torch.autograd.Function):
         dev = dout_.device
         h = dout_.shape[1]
         need_x = ctx.needs_input_grad[0]
-        need_t = any(ctx.needs_input_grad[7:])
+        need_t = any(ctx.needs_input_grad[8:])
         # the skip connection's share of dx (DxHandoff, parked by the layer's fused MLP + norm node)
         extra = ctx.dx_handoff.take() if ctx.dx_handoff is not None else None
         extras = extra if isinstance(extra, list) else ([extra] if extra is not None else [])    # DxSumHandoff parks several
@@ -2260,7 +2271,7 @@ class _AggregateEncFn(torch.autograd.Function):
         ws_bytes = 0
         deferred = need_t and ctx.defer_tables is not None and _DEFER.active and not torch.is_grad_enabled()
         if deferred:
-            params = [t if ng else None for t, ng in zip(ctx.defer_tables, ctx.needs_input_grad[7:])]
+            params = [t if ng else None for t, ng in zip(ctx.defer_tables, ctx.needs_input_grad[8:])]
             with _DEFER.lock:
                 _DEFER.table_jobs.append(dict(
                     key=(bond_.data_ptr(), st._src.data_ptr(), st._dst.data_ptr(), st.num_edges, ts.F, ts.n, ts.k, tuple(ts.vocab),
@@ -2287,12 +2298,12 @@ class _AggregateEncFn(torch.autograd.Function):
             if need_t and not deferred:
                 L.account("table_grad", 1.0 * E * ts.F * h, Nd * 4.0 * h + E * (4.0 + 8.0 * ts.F) + 4.0 * (Nd + 1))
         grads = ts.grad_views(flat) if (need_t and not deferred) else [None] * ts.num_tables
-        return (dx, None, None, None, None, None, None, *grads)
+        return (dx, None, None, None, None, None, None, None, *grads)
 
 
 def aggregate_sum_encoded(x: torch.Tensor, edge_index, bond_idx: torch.Tensor, ts: TableSet, tables,
                           msg_encoder: str = "identity", add_self_loops: bool = False,
-                          num_dst: Optional[int] = None, dx_handoff=None) -> torch.Tensor:
+                          num_dst: Optional[int] = None, dx_handoff=None, pending=None) -> torch.Tensor:
     """aggregate_sum with edge_attr[e] = Σ_f tables[c][f][bond_idx[e, f]] looked up inside the
     kernel (the [E, h] bond embedding is never written)."""
     st = edge_index if isinstance(edge_index, EdgeStructure) else edge_structure(edge_index, x.shape[0], num_dst)
@@ -2305,9 +2316,11 @@ def aggregate_sum_encoded(x: torch.Tensor, edge_index, bond_idx: torch.Tensor, t
                codes_for=(bond_idx, ts.vocab_c, ts.F) if packed else None)
     flat_tables = [t for comp in tables for t in comp]
     if not ts.fusable_into_aggregate:
+        if pending is not None:
+            pending.materialize()
         ea = _EncodeFn.apply(bond_idx, ts, *flat_tables)
         return _AggregateFn.apply(x, ea, st, _act_id(msg_encoder), bool(add_self_loops))
-    return _AggregateEncFn.apply(x, bond_idx, st, _act_id(msg_encoder), bool(add_self_loops), ts, dx_handoff, *flat_tables)
+    return _AggregateEncFn.apply(x, bond_idx, st, _act_id(msg_encoder), bool(add_self_loops), ts, dx_handoff, pending, *flat_tables)
 
 
 # ---------------------------------------------------------------------------
@@ -2628,6 +2641,66 @@ def _zero_acc(dev, h: int):
     return torch.zeros(lib.phc_stat_acc_words(h), dtype=torch.int64, device=dev)
 
 
+# the model-level norm's element-wise pass folded into the next layer's aggregation (phc_aggregate_norm_encp_fwd); off: the pass
+# runs as its own launch where it always did
+NORM_INTO_AGGREGATE = __import__("os").environ.get("PHC_NORM_INTO_AGGREGATE", "1") != "0"
+# ... up to this many row elements (rows x width): the fused kernel gathers two rows per edge (y and the skip) and transforms every one
+# of them; at 12.9 k x 128 that is cheaper than the launch it saves (molhiv_b512 0.606 -> 0.588 ms), at 23.6 k x 256 it is not
+# (zinc_b1024 1.973 -> 1.993 ms: alternating A/B on one box)
+NORM_INTO_AGGREGATE_MAX_WORK = int(__import__("os").environ.get("PHC_NORM_INTO_AGGREGATE_MAX_WORK", "3000000"))
+
+
+class PendingNorm:
+    """x = act(norm(y2)) (+ skip) that has NOT been evaluated yet: the fused MLP + norm node allocated ``out`` (= x) and ``save_stat``
+    and stopped in front of its last launch.  The consumer is the next layer's encoded sum aggregation (``run_fused``: one launch
+    does both and writes x on the way); anybody else calls ``materialize`` first — the stand-alone pass, identical results."""
+
+    def __init__(self, y2, acc2, outer, aff_o, act_o, skip, n_valid, out, save_o):
+        self.y2, self.acc2, self.outer, self.aff_o, self.act_o, self.skip, self.n_valid = y2, acc2, outer, aff_o, act_o, skip, n_valid
+        self.out, self.save_o = out, save_o
+        self.done = False
+
+    def _norm_args(self):
+        outer, aff_o = self.outer, self.aff_o
+        no = outer["n_comp"]
+        return (_ptr_array(aff_o[:no]) if aff_o else None, _ptr_array(aff_o[no:]) if aff_o else None, _ptr_array(outer["running_mean"]),
+                _ptr_array(outer["running_var"]), _ptr_array(outer["nbt"]), no)
+
+    def materialize(self):
+        if self.done:
+            return
+        lib = L.load()
+        N, h = self.y2.shape
+        w, b, rm, rv, nbt, no = self._norm_args()
+        L.check(lib.phc_bn_fwd_from_partials(
+            L.ptr(self.y2), L.ptr(self.acc2), None, 0, w, b, rm, rv, nbt, no, L.ptr(self.n_valid), N, h,
+            float(self.outer["momentum"]), float(self.outer["eps"]), self.act_o, L.ptr(self.skip), L.ptr(self.out), L.ptr(self.save_o), 0.0,
+            0, 0, None, L.stream_ptr(self.y2.device)), "phc_bn_fwd_from_partials")
+        if L.PROF_ON:
+            L.account("bn_apply", 2.0 * N * h, 4.0 * N * h * (3 if self.skip is not None else 2))
+        self.done = True
+
+    def run_fused(self, x_, codes, ts, rowptr, col, n_dst, add_self, agg_out):
+        lib = L.load()
+        assert x_.data_ptr() == self.out.data_ptr()
+        w, b, rm, rv, nbt, no = self._norm_args()
+        L.check(lib.phc_aggregate_norm_encp_fwd(
+            L.ptr(self.y2), L.ptr(self.acc2), w, b, rm, rv, nbt, no, float(self.outer["momentum"]), float(self.outer["eps"]), self.act_o,
+            L.ptr(self.n_valid), L.ptr(self.skip), L.ptr(self.save_o), L.ptr(self.out), L.ptr(codes), L.ptr(ts.ptrs), ts.vocab_c,
+            L.ptr(rowptr), L.ptr(col), n_dst, ts.F, ts.n, ts.k, 1 if add_self else 0, L.ptr(agg_out), L.stream_ptr(self.y2.device)),
+            "phc_aggregate_norm_encp_fwd")
+        self.done = True
+
+
+def materialize_pending(t: torch.Tensor) -> torch.Tensor:
+    """Run the parked norm pass of ``t`` (if it has one) before a consumer that is not the fused aggregation reads it."""
+    pend = getattr(t, "_phc_pending", None)
+    if pend is not None:
+        pend.materialize()
+        t._phc_pending = None
+    return t
+
+
 class _MLPNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, s, skip, n_valid, meta, A1, W1, b1, A2, W2, b2, *affine):
@@ -2653,15 +2726,14 @@ class _MLPNormFn(torch.autograd.Function):
             _ptr_array(inner["running_mean"]), _ptr_array(inner["running_var"]), _ptr_array(inner["nbt"]), ni,
             float(inner["momentum"]), float(inner["eps"]), L.ptr(save_i), act_i, L.ptr(n_valid), L.ptr(pre2[0]), L.ptr(pre2[2]),
             L.ptr(b2), N, h, h, L.ptr(y2), L.ptr(acc2), None, None, sp), "phc_gemm_prebuilt_xf_acc")
-        L.check(lib.phc_bn_fwd_from_partials(
-            L.ptr(y2), L.ptr(acc2), None, 0, _ptr_array(aff_o[:no]) if aff_o else None, _ptr_array(aff_o[no:]) if aff_o else None,
-            _ptr_array(outer["running_mean"]), _ptr_array(outer["running_var"]), _ptr_array(outer["nbt"]), no, L.ptr(n_valid), N, h,
-            float(outer["momentum"]), float(outer["eps"]), act_o, L.ptr(skip), L.ptr(out), L.ptr(save_o), 0.0, 0, 0, None, sp),
-            "phc_bn_fwd_from_partials")
+        pend = PendingNorm(y2, acc2, outer, tuple(aff_o), act_o, skip, n_valid, out, save_o)
+        if meta.get("defer_apply"):
+            meta["pending"] = pend                           # the caller hands it to the next layer's aggregation (or materialises it)
+        else:
+            pend.materialize()
         if L.PROF_ON:
             L.account("phm_gemm_fwd", 2.0 * N * h * h, 4.0 * (2 * N * h + h * h + h))
             L.account("phm_gemm_fwd", 2.0 * N * h * h, 4.0 * (2 * N * h + h * h + h))
-            L.account("bn_apply", 2.0 * N * h, 4.0 * N * h * (3 if skip is not None else 2))
         ctx.save_for_backward(s, z1, y2, save_i, save_o, A1, W1, A2, W2)
         ctx.meta, ctx.n_valid = meta, n_valid
         ctx.params = ((A1, W1, b1), (A2, W2, b2))
@@ -2754,7 +2826,7 @@ def _norm_meta(nm):
                 weights=[m.weight for m in mods] if nm.affine else [], biases=[m.bias for m in mods] if nm.affine else [])
 
 
-def mlp_norm_fused(s, skip, n_valid, mlp, outer_norm, activation: str, skip_handoff=None):
+def mlp_norm_fused(s, skip, n_valid, mlp, outer_norm, activation: str, skip_handoff=None, defer_apply: bool = False):
     """``act(outer_norm(mlp(s))) + skip`` for a PHMMLP with an inner naive batch-norm, as one autograd node (training mode),
     or ``None`` when the preconditions do not hold: both linears square of width 128 or 256 with prebuilt k4 operands (inside
     ``prebuilt_H``), both norms naive batch-norms with running statistics, fusable activations, 16-byte aligned dense rows."""
@@ -2780,9 +2852,14 @@ def mlp_norm_fused(s, skip, n_valid, mlp, outer_norm, activation: str, skip_hand
         return None
     if any(b is not None and not b.is_contiguous() for b in (l1.b, l2.b)):
         return None
-    meta = dict(pre1=pre1, pre2=pre2, inner=inner, outer=outer, act_inner=act_i, act_outer=act_o, skip_handoff=skip_handoff)
+    meta = dict(pre1=pre1, pre2=pre2, inner=inner, outer=outer, act_inner=act_i, act_outer=act_o, skip_handoff=skip_handoff,
+                defer_apply=bool(defer_apply and NORM_INTO_AGGREGATE))
     affine = inner["weights"] + inner["biases"] + outer["weights"] + outer["biases"]
-    return _MLPNormFn.apply(s, skip, n_valid, meta, l1.phm_rule, l1.W, l1.b, l2.phm_rule, l2.W, l2.b, *affine)
+    out = _MLPNormFn.apply(s, skip, n_valid, meta, l1.phm_rule, l1.W, l1.b, l2.phm_rule, l2.W, l2.b, *affine)
+    pend = meta.pop("pending", None)
+    if pend is not None:
+        out._phc_pending = pend                              # (the model loop passes it on or materialises it: materialize_pending)
+    return out
 
 
 # ---------------------------------------------------------------------------
