@@ -81,11 +81,48 @@ def phm_linear_backward(x: Tensor, A: Tensor, W: Tensor, dy: Tensor):
 # ----------------------------------------------------------------------------
 # activations (phc/quaternion/activations.py:134-147)
 # ----------------------------------------------------------------------------
+# ---- ReLU gates as data (tests only) -------------------------------------------------------------------------------------
+# With ReLU a handful of pre-activations sit within an ulp of the kink; which side they fall on depends on the fp32 summation
+# order of whoever evaluates them, and one flipped gate moves whole gradient tensors by 1e-3.  To compare an implementation's
+# gradients TIGHTLY nonetheless, the oracle can (a) record the gates of its own run in call order and (b) be run with gates
+# imposed from outside: relu(x) := x * gate, gate a constant 0/1 tensor — the exact gradient of the function "with these gates".
+_GATES = {"impose": None, "record": None, "pre": None}
+
+
+class relu_gates:
+    """``with relu_gates(impose=[g0, g1, ...])``: the i-th relu call of the block multiplies by g_i instead of testing the sign.
+    ``with relu_gates(record=True) as r``: r.gates / r.pre hold every relu call's (x > 0) and its input, in call order."""
+
+    def __init__(self, impose=None, record=False):
+        self.impose, self.want_record = (list(impose) if impose is not None else None), record
+        self.gates, self.pre = [], []
+
+    def __enter__(self):
+        _GATES["impose"] = list(self.impose) if self.impose is not None else None
+        _GATES["record"] = self.gates if self.want_record else None
+        _GATES["pre"] = self.pre if self.want_record else None
+        return self
+
+    def __exit__(self, *exc):
+        left = _GATES["impose"]
+        _GATES["impose"] = _GATES["record"] = _GATES["pre"] = None
+        if exc[0] is None and left:
+            raise RuntimeError(f"relu_gates: {len(left)} imposed gates were not consumed")
+
+
 def activation(name: str, x: Tensor) -> Tensor:
     name = name.lower()
     if name == "identity":
         return x
     if name == "relu":
+        if _GATES["record"] is not None:
+            _GATES["record"].append((x > 0).detach())
+            _GATES["pre"].append(x.detach())
+        if _GATES["impose"] is not None:
+            g = _GATES["impose"].pop(0)
+            if tuple(g.shape) != tuple(x.shape):
+                raise RuntimeError(f"relu_gates: gate {tuple(g.shape)} for an input {tuple(x.shape)}")
+            return x * g.to(x.dtype)
         return F.relu(x)
     if name == "lrelu":
         return F.leaky_relu(x)

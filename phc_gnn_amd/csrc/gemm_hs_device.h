@@ -67,7 +67,9 @@ struct GemmHsArgs {
     const float *residual;     // [M, Nout] or null
     float *y;                  // [M, Nout]
     long long M;
-    int Nout;                  // = 16 * TPW * WAVES * panels
+    int K;                     // contraction depth = floats per row of x (<= the kernel's K template: the published 180 / 200 widths run
+                               // on the 192 / 208 instantiations, their last k-group and column tiles partly empty)
+    int Nout;                  // columns of the operand and of y (<= 16 * TPW * WAVES * panels)
     int panels;
     int groups;                // workgroups per panel (gridDim.x = panels * groups)
     const int *n_valid;        // device scalar or null (ST / XF / BW)
@@ -142,7 +144,8 @@ __device__ __forceinline__ void hs_publish(unsigned long long *acc, int Nout, in
             mine = c == 8 * t + 2 * q ? v0[t][q] : mine;
             mine = c == 8 * t + 2 * q + 1 ? v1[t][q] : mine;
         }
-    if (c < 8 * TPW) stat_acc_add(acc, Nout, rep, c & 1, col0 + 16 * (c >> 3) + 4 * kq + ((c >> 1) & 3), mine);
+    if (c < 8 * TPW && col0 + 16 * (c >> 3) + 4 * kq + ((c >> 1) & 3) < Nout)
+        stat_acc_add(acc, Nout, rep, c & 1, col0 + 16 * (c >> 3) + 4 * kq + ((c >> 1) & 3), mine);
 }
 
 constexpr int HS_ISTRIDE = 66;                                    // float4 slots per DMA instruction (64 + 2 pad)
@@ -159,7 +162,11 @@ constexpr size_t hs_lds_bytes() {
 
 template <int K, int TPW, int WAVES, int RB, int R, int FLAGS>
 __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfAcc xa) {
-    static_assert(K == 128 || K == 256, "K = 128 or 256 (one DMA instruction = 1 KiB = 256 / K rows)");
+    static_assert(K == 128 || (K > 128 && K <= 256 && K % 16 == 0),
+                  "K = 128 (two rows per 1-KiB DMA instruction) or a multiple of 16 in (128, 256] (one row per instruction)");
+    // KR = the rows' REAL width a.K <= K (a multiple of 4; == K for 128 / 256).  Chunks of a row past KR are never fetched (their
+    // lanes re-fetch chunk 0) and meet operand rows that read as zero; tiles / columns past a.Nout are loaded as zero and never stored.
+    const int KR = a.K;
     constexpr bool ST = (FLAGS & HS_ST) != 0, XF = (FLAGS & HS_XF) != 0, BW = (FLAGS & HS_BW) != 0, BA = (FLAGS & HS_BA) != 0;
     static_assert(!(BA && XF), "one operand transform per launch");
     constexpr int G = K / 16, RS = 16 * RB, RPI = 256 / K, INSTR = RS / RPI, IPW = INSTR / WAVES;
@@ -195,15 +202,17 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
     // ---- DMA of one step: instruction ii = wave + WAVES * u covers rows ii * RPI .. of the step ----
     const int dsub = RPI == 1 ? 0 : (lane >> 5);                  // row of the pair (K = 128)
     const int dchunk = (RPI == 1 ? lane : (lane & 31)) ^ dsub;    // the 16-byte chunk of its row this lane fetches
+    const bool dlive = 4 * dchunk < KR;                           // (always true at K = 128 / 256)
+    const int dfetch = dlive ? dchunk : 0;                        // a lane past the row's end re-fetches chunk 0: finite values x zero operand
     auto issue_step = [&](long long step_local, int slot) {
         const long long step = group + min(step_local, my_steps - 1) * a.groups;       // clamped: the tail re-loads valid rows
 #pragma unroll
         for (int u = 0; u < IPW; ++u) {
             const int ii = wave + WAVES * u;
             const long long row = min(step * RS + ii * RPI + dsub, a.M - 1);
-            hs_dma16(a.x + (size_t)row * K + 4 * dchunk, ring_lds + 16u * (unsigned)(slot * SLOT_F4 + ii * ISTRIDE));
+            hs_dma16(a.x + (size_t)row * KR + 4 * dfetch, ring_lds + 16u * (unsigned)(slot * SLOT_F4 + ii * ISTRIDE));
             if constexpr (BA)
-                hs_dma16(a.ba_x + (size_t)row * K + 4 * dchunk, ring_lds + 16u * (unsigned)(slot * SLOT_F4 + IMG_F4 + ii * ISTRIDE));
+                hs_dma16(a.ba_x + (size_t)row * KR + 4 * dfetch, ring_lds + 16u * (unsigned)(slot * SLOT_F4 + IMG_F4 + ii * ISTRIDE));
         }
     };
     // BA / XF from an accumulator: the totals' words and the norm constants of column `tid` go in flight FIRST, as ASM loads with
@@ -221,14 +230,14 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
         for (int qty = 0; qty < 2; ++qty)
 #pragma unroll
             for (int rep = 0; rep < STAT_ACC_REP; ++rep) {
-                const unsigned long long *p = p0 + ((size_t)(rep * 2 + qty) * 2) * K;
+                const unsigned long long *p = p0 + ((size_t)(rep * 2 + qty) * 2) * KR;
                 ba_raw[qty][rep][0] = hs_ld64(p);
-                ba_raw[qty][rep][1] = hs_ld64(p + K);
+                ba_raw[qty][rep][1] = hs_ld64(p + KR);
             }
     };
     if constexpr (XF) {                                           // an operand norm whose statistics are still totals
-        static_assert(K <= THREADS && K % 64 == 0, "one column per thread in the XF prologue");
-        if (xa.acc && tid < K) {
+        static_assert(K <= THREADS, "one column per thread in the XF prologue");
+        if (xa.acc && tid < KR) {
             acc_loads(xa.acc);
             const int comp = tid / xa.p.k, kk = tid - comp * xa.p.k;
             // (always two loads — the counted wait below relies on it; without affine parameters they read accumulator words)
@@ -243,13 +252,13 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
         }
     }
     if constexpr (BA) {
-        static_assert(K <= THREADS && K % 64 == 0, "one column per thread in the BA prologue");
-        if (tid < K) {
+        static_assert(K <= THREADS, "one column per thread in the BA prologue");
+        if (tid < KR) {
             acc_loads(a.ba_acc);
             cst_raw[0] = hs_ld32(a.ba_stat + tid);
-            cst_raw[1] = hs_ld32(a.ba_stat + K + tid);
-            cst_raw[2] = hs_ld32(a.ba_stat + 4 * K + tid);
-            cst_raw[3] = hs_ld32(a.ba_stat + 5 * K + tid);
+            cst_raw[1] = hs_ld32(a.ba_stat + KR + tid);
+            cst_raw[2] = hs_ld32(a.ba_stat + 4 * KR + tid);
+            cst_raw[3] = hs_ld32(a.ba_stat + 5 * KR + tid);
         }
     }
     // what a wavefront issues between those loads and their first use: the ring's first fill (bias and operand slice follow
@@ -279,7 +288,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
             // statistics still in an accumulator: column `tid` -> scale / shift in LDS (K <= THREADS or strided), workgroup 0
             // also leaves save_stat and the running statistics behind (the merge launch this replaces)
             const bool owner = blockIdx.x == 0;
-            if (tid < K) {
+            if (tid < KR) {
                 const int col = tid;
                 acc_arrived();
                 const float xf_w = xa.p.has_weight ? xfw_raw : 1.f, xf_b = xa.p.has_bias ? xfb_raw : 0.f;
@@ -305,8 +314,8 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
                 xf_lds[K + col] = bq - mean * invstd * w;
                 if (owner) {
                     float *st = xa.stat_out;
-                    st[col] = mean; st[K + col] = invstd; st[2 * K + col] = invstd * w; st[3 * K + col] = bq - mean * invstd * w;
-                    st[4 * K + col] = w; st[5 * K + col] = bq;
+                    st[col] = mean; st[KR + col] = invstd; st[2 * KR + col] = invstd * w; st[3 * KR + col] = bq - mean * invstd * w;
+                    st[4 * KR + col] = w; st[5 * KR + col] = bq;
                     if (xa.p.has_running) {
                         const float unbiased = n_valid > 1 ? (float)(vard * cntd / (cntd - 1.0)) : var;
                         for (int q = 0; q < xa.p.n_comp; ++q)
@@ -323,16 +332,16 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
                     if (q == tid) *xa.p.num_batches_tracked[q] += 1;
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // (a raw barrier: no wait for the operand slice / ring fill)
             __builtin_amdgcn_s_barrier();
-            xsc = *reinterpret_cast<const f32x4_t *>(xf_lds + 4 * dchunk);
-            xsh = *reinterpret_cast<const f32x4_t *>(xf_lds + K + 4 * dchunk);
+            xsc = *reinterpret_cast<const f32x4_t *>(xf_lds + 4 * dfetch);
+            xsh = *reinterpret_cast<const f32x4_t *>(xf_lds + K + 4 * dfetch);
         } else {
-            xsc = *reinterpret_cast<const f32x4_t *>(a.xf_stat + 2 * (size_t)K + 4 * dchunk);
-            xsh = *reinterpret_cast<const f32x4_t *>(a.xf_stat + 3 * (size_t)K + 4 * dchunk);
+            xsc = *reinterpret_cast<const f32x4_t *>(a.xf_stat + 2 * (size_t)KR + 4 * dfetch);
+            xsh = *reinterpret_cast<const f32x4_t *>(a.xf_stat + 3 * (size_t)KR + 4 * dfetch);
         }
     }
     // ---- BA: per-column constants of the un-applied norm backward -> LDS (workgroup 0 also leaves dweight | dbias behind) ----
     if constexpr (BA) {
-        if (tid < K) {
+        if (tid < KR) {
             const int col = tid;
             acc_arrived();
             const float ba_cst[4] = {cst_raw[0], cst_raw[1], cst_raw[2], cst_raw[3]};
@@ -358,7 +367,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
             ba_lds[6 * K + col] = ba_cst[2] * ba_cst[1];
             if (blockIdx.x == 0 && a.ba_dwb) {
                 a.ba_dwb[col] = (float)tot[1];
-                a.ba_dwb[K + col] = (float)tot[0];
+                a.ba_dwb[KR + col] = (float)tot[0];
             }
         }
         // (a raw barrier: __syncthreads() would also wait for the operand slice and the ring's first fill)
@@ -377,8 +386,9 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
     for (int t = 0; t < TPW; ++t) {
         // unconditional load (a null bias reads operand words and selects zero): the number of prologue loads is a constant
         // of the kernel — the first step's counted wait relies on it (PRO_LOADS below)
-        const f32x4_t v = *reinterpret_cast<const f32x4_t *>((a.bias ? a.bias : a.hk4) + col0 + 16 * t + 4 * kq);
-        bias4[t] = a.bias ? v : zero4;
+        const bool cok = col0 + 16 * t + 4 * kq < Nout;           // (a column tile past the operand's width: bias and operand read as 0)
+        const f32x4_t v = *reinterpret_cast<const f32x4_t *>((a.bias ? a.bias : a.hk4) + (cok ? col0 + 16 * t + 4 * kq : 0));
+        bias4[t] = (a.bias && cok) ? v : zero4;
     }
     __builtin_amdgcn_sched_barrier(0);                            // (hipcc would otherwise issue these loads last)
     // ---- operand slice -> registers (once per launch), k-group major: the first step consumes it in this order ----
@@ -388,7 +398,11 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
 #pragma unroll
         for (int g = 0; g < G; ++g)
 #pragma unroll
-            for (int t = 0; t < TPW; ++t) hreg[t][g] = src[(size_t)(4 * g + kq) * Nout + col0 + c + 16 * t];
+            for (int t = 0; t < TPW; ++t) {
+                const bool ok = 4 * (4 * g + kq) < KR && col0 + c + 16 * t < Nout;     // always true at 128 / 256
+                const f32x4_t v = src[ok ? (size_t)(4 * g + kq) * Nout + col0 + c + 16 * t : 0];
+                hreg[t][g] = ok ? v : zero4;
+            }
     }
     // fragment base of this lane per row block (float4 slots): row = rb * 16 + c
     int fbase[RB];
@@ -404,7 +418,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
     if constexpr (BW) {
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
-            const int col = col0 + 16 * t + 4 * kq;
+            const int col = col0 + 16 * t + 4 * kq < Nout ? col0 + 16 * t + 4 * kq : 0;
             bw_mean[t] = *reinterpret_cast<const f32x4_t *>(a.bw_stat + col);
             bw_inv[t] = *reinterpret_cast<const f32x4_t *>(a.bw_stat + (size_t)Nout + col);
             bw_w[t] = *reinterpret_cast<const f32x4_t *>(a.bw_stat + 4 * (size_t)Nout + col);
@@ -452,7 +466,9 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
     // The FIRST wait of the launch additionally has the prologue's own loads behind DMA(0): bias, operand slice (and the BW
     // constants) were issued after the ring's first fill — a lower bound of what is certainly younger is what the count needs.
     constexpr int PRO_LOADS = TPW + TPW * G + (BW ? 4 * TPW : 0);
-    static_assert(VM_KEEP + PRO_LOADS <= 63, "vmcnt is a 6-bit counter");
+    // (vmcnt is a 6-bit counter: a count past 63 saturates — a stricter wait, the first step then also waits for a few of the
+    // prologue's own loads; the 192 x 3-tile configuration with BA | BW reaches 67)
+    constexpr int FIRST_WAIT = VM_KEEP + PRO_LOADS > 63 ? 63 : VM_KEEP + PRO_LOADS;
 
     // Operand transform of THIS wavefront's own pieces of step `sl_step` (local index), in place in ring slot `tslot`
     // (XF: act(x * scale + shift); BA: the norm backward, also written out).  It runs one step AHEAD of the MFMAs: the pieces
@@ -467,7 +483,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
                 const long long row = step * RS + ii * RPI + dsub;
                 f32x4_t *p = ring + (size_t)tslot * SLOT_F4 + ii * ISTRIDE + lane;
                 f32x4_t v = *p;
-                const bool live = row < n_valid;
+                const bool live = row < n_valid && dlive;
                 if (a.xf_act == PHC_ACT_RELU) {
 #pragma unroll
                     for (int q = 0; q < 4; ++q) v[q] = live ? fmaxf(fmaf(v[q], xsc[q], xsh[q]), 0.f) : 0.f;
@@ -479,10 +495,10 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
             }
         }
         if constexpr (BA) {
-            const f32x4_t ci = *reinterpret_cast<const f32x4_t *>(ba_lds + 4 * dchunk), cnm = *reinterpret_cast<const f32x4_t *>(ba_lds + K + 4 * dchunk);
-            const f32x4_t cw = *reinterpret_cast<const f32x4_t *>(ba_lds + 2 * K + 4 * dchunk), cb = *reinterpret_cast<const f32x4_t *>(ba_lds + 3 * K + 4 * dchunk);
-            const f32x4_t cngx = *reinterpret_cast<const f32x4_t *>(ba_lds + 4 * K + 4 * dchunk), cng = *reinterpret_cast<const f32x4_t *>(ba_lds + 5 * K + 4 * dchunk);
-            const f32x4_t c1 = *reinterpret_cast<const f32x4_t *>(ba_lds + 6 * K + 4 * dchunk);
+            const f32x4_t ci = *reinterpret_cast<const f32x4_t *>(ba_lds + 4 * dfetch), cnm = *reinterpret_cast<const f32x4_t *>(ba_lds + K + 4 * dfetch);
+            const f32x4_t cw = *reinterpret_cast<const f32x4_t *>(ba_lds + 2 * K + 4 * dfetch), cb = *reinterpret_cast<const f32x4_t *>(ba_lds + 3 * K + 4 * dfetch);
+            const f32x4_t cngx = *reinterpret_cast<const f32x4_t *>(ba_lds + 4 * K + 4 * dfetch), cng = *reinterpret_cast<const f32x4_t *>(ba_lds + 5 * K + 4 * dfetch);
+            const f32x4_t c1 = *reinterpret_cast<const f32x4_t *>(ba_lds + 6 * K + 4 * dfetch);
             // The activation switch stays OUTSIDE the element loops (one straight-line body per kind): as a per-element select
             // chain hipcc turned it into ~20 scalar branches per element, 0.3-0.4 us of a 16-row step.
             auto rows = [&](auto kind) {
@@ -494,7 +510,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
                     f32x4_t *p = ring + (size_t)tslot * SLOT_F4 + ii * ISTRIDE + lane;
                     const f32x4_t gv = *p, xv = p[IMG_F4];
                     f32x4_t o = zero4;
-                    if (row < n_valid) {
+                    if (row < n_valid && dlive) {
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             // dz = w invstd (g - mean g - x_hat mean(g x_hat)); x_hat and the pre-activation exactly as the separate
@@ -510,7 +526,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
                         }
                     }
                     *p = o;
-                    if (row < a.M) *reinterpret_cast<f32x4_t *>(a.ba_dz + (size_t)row * K + 4 * dchunk) = o;
+                    if (row < a.M && dlive) *reinterpret_cast<f32x4_t *>(a.ba_dz + (size_t)row * KR + 4 * dchunk) = o;
                 }
             };
             if (a.ba_act == PHC_ACT_RELU)
@@ -522,7 +538,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
         }
     };
     if constexpr (XF || BA) {
-        hs_wait_vm<VM_KEEP + PRO_LOADS>();                        // DMA(0)
+        hs_wait_vm<FIRST_WAIT>();                        // DMA(0)
         if (a.stamps) dbg_t[2] = __builtin_amdgcn_s_memrealtime();
         transform(0, 0);
     }
@@ -535,7 +551,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
         if constexpr (XF || BA)
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");    // the in-place writes of step i are done before the barrier releases readers
         else if constexpr (decltype(first)::value)
-            hs_wait_vm<VM_KEEP + PRO_LOADS>();                    // own DMA pieces of step 0 (the prologue's loads stay in flight)
+            hs_wait_vm<FIRST_WAIT>();                    // own DMA pieces of step 0 (the prologue's loads stay in flight)
         else
             hs_wait_vm<VM_KEEP>();                                // own DMA pieces of step i
         // after the barrier: every wavefront's pieces of step i are in place, the slot of step i - 1 is free
@@ -560,7 +576,8 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
             for (int rb = 0; rb < RB; ++rb) {
                 const long long rowc = min(step * RS + rb * 16 + c, a.M - 1);
 #pragma unroll
-                for (int t = 0; t < TPW; ++t) bwx[rb][t] = *reinterpret_cast<const f32x4_t *>(a.bw_x + (size_t)rowc * Nout + col0 + 16 * t + 4 * kq);
+                for (int t = 0; t < TPW; ++t)
+                    bwx[rb][t] = *reinterpret_cast<const f32x4_t *>(a.bw_x + (size_t)rowc * Nout + (col0 + 16 * t + 4 * kq < Nout ? col0 + 16 * t + 4 * kq : 0));
             }
         }
         const f32x4_t *sl = ring + (size_t)slot * SLOT_F4;
@@ -646,9 +663,11 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
                 float *yr = a.y + (size_t)row * Nout + col0 + 4 * kq;
 #pragma unroll
                 for (int t = 0; t < TPW; ++t) {
-                    f32x4_t v = acc[rb][t];
-                    if (a.residual) v += *reinterpret_cast<const f32x4_t *>(a.residual + (size_t)row * Nout + col0 + 4 * kq + 16 * t);
-                    *reinterpret_cast<f32x4_t *>(yr + 16 * t) = v;
+                    if (col0 + 4 * kq + 16 * t < Nout) {          // (a partial last tile: Nout % 4 == 0, so a lane's four columns stand or fall together)
+                        f32x4_t v = acc[rb][t];
+                        if (a.residual) v += *reinterpret_cast<const f32x4_t *>(a.residual + (size_t)row * Nout + col0 + 4 * kq + 16 * t);
+                        *reinterpret_cast<f32x4_t *>(yr + 16 * t) = v;
+                    }
                 }
             }
         }

@@ -1369,10 +1369,19 @@ static inline bool hs_enabled() {
 // sixteen-row steps on 256 CUs: 4 rounds for 3.1 rounds of work); with two workgroups per CU (launch_hs_cfg) the H-stationary
 // kernel wins there too: molhiv_b512 0.694 / 0.692 / 0.697 -> 0.680 / 0.688 / 0.676 ms, molhiv_b32 (1 152 rows) 0.457 -> 0.425 ms,
 // the softmax step 0.801 -> 0.796 ms (alternating runs on one box).  PHC_GEMM_HS_MIN_ROWS_128=<rows> restores a threshold.
+// ... and the reference's PUBLISHED widths (benchmarks/README.md:45-91, run_script_zinc_phm4.sh: hidden 200 = 4 x 50 = 5 x 40 and
+// 180 = 4 x 45): square 180- / 200-wide layers run on the 192 / 208 instantiations — one row per DMA instruction, the last
+// k-group and the last column tiles partly empty (operand read as zero there).  PHC_GEMM_HS_PUB=0 keeps them on the LDS-panel kernel.
+static inline bool hs_pub_width(int K, int Nout) {
+    static const bool off = getenv("PHC_GEMM_HS_PUB") && atoi(getenv("PHC_GEMM_HS_PUB")) == 0;
+    return !off && K == Nout && (K == 180 || K == 200);
+}
+static inline bool hs_widths_ok(int K, int Nout) {
+    return ((K == 128 || K == 256) && (Nout == 128 || Nout == 256)) || hs_pub_width(K, Nout);
+}
 static bool hs_shape_ok(const float *x, const float *Mk4, int64_t N, int K, int Nout) {
     static const long long min128 = getenv("PHC_GEMM_HS_MIN_ROWS_128") ? atoll(getenv("PHC_GEMM_HS_MIN_ROWS_128")) : 0;
-    return hs_enabled() && Mk4 && N >= 1 && (K == 128 || K == 256) && (Nout == 128 || Nout == 256) &&
-           (K == 256 || Nout == 256 || N >= min128) &&
+    return hs_enabled() && Mk4 && N >= 1 && hs_widths_ok(K, Nout) && (K != 128 || Nout != 128 || N >= min128) &&
            ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(Mk4)) & 15) == 0;
 }
 
@@ -1384,7 +1393,7 @@ static int launch_hs_cfg(GemmHsArgs a, const XfAcc &xa, hipStream_t s) {
     // with statistics 41.9 -> 46.9 us per launch (5.8 -> 2.9 steps per workgroup: the last round is half empty)
     constexpr int RB = 1, R = HS_RING;
     a.stamps = g_hs_stamps;
-    a.panels = a.Nout / (16 * TPW * WAVES);
+    a.panels = (a.Nout + 16 * TPW * WAVES - 1) / (16 * TPW * WAVES);
     const long long steps = (a.M + 16 * RB - 1) / (16 * RB);
     // workgroups per CU: one for the 8-wavefront configurations (two wavefronts per SIMD; a second workgroup made the zinc_b1024
     // step 2.10 -> 2.23 ms).  The 128 x 128 configuration (4 wavefronts, 64 operand registers, 33 KB of ring) leaves a SIMD with
@@ -1410,15 +1419,19 @@ static int launch_hs(const GemmHsArgs &a, int K, const XfAcc &xa, hipStream_t s)
     // the 16x16x4 MFMA's 40-cycle dependent latency off the issue path)
     // (Nout = 256 as two 128-column workgroups of 4 wavefronts, two per CU: zinc_b1024 2.11 -> 3.98 ms — the doubled ring of the
     // folded-norm variants leaves room for one workgroup per CU only)
+    // 180 x 180: 12 of 16 column tiles (8 wavefronts x 2), 12 k-groups; 200 x 200: 13 of 16 tiles, 13 k-groups
+    // (4 wavefronts x 3 tiles for 180: the folded-norm variants then need > 256 registers and hipcc parks arrays in scratch)
+    if (K == 180 && a.Nout == 180) return launch_hs_cfg<192, 2, 8, FLAGS>(a, xa, s);
+    if (K == 200 && a.Nout == 200) return launch_hs_cfg<208, 2, 8, FLAGS>(a, xa, s);
     if (K == 256 && a.Nout == 256) return launch_hs_cfg<256, 2, 8, FLAGS>(a, xa, s);
     if (K == 256 && a.Nout == 128) return launch_hs_cfg<256, 2, 4, FLAGS>(a, xa, s);
     if (K == 128 && a.Nout == 256) return launch_hs_cfg<128, 2, 8, FLAGS>(a, xa, s);
     return launch_hs_cfg<128, 2, 4, FLAGS>(a, xa, s);
 }
 
-static GemmHsArgs hs_args(const float *x, const float *Mk4, const float *b, const float *residual, float *y, int64_t N, int Nout) {
+static GemmHsArgs hs_args(const float *x, const float *Mk4, const float *b, const float *residual, float *y, int64_t N, int K, int Nout) {
     GemmHsArgs a = {};
-    a.x = x; a.hk4 = Mk4; a.bias = b; a.residual = residual; a.y = y; a.M = N; a.Nout = Nout;
+    a.x = x; a.hk4 = Mk4; a.bias = b; a.residual = residual; a.y = y; a.M = N; a.K = K; a.Nout = Nout;
     return a;
 }
 
@@ -1434,6 +1447,9 @@ constexpr int64_t GEMM_BIG_M = 64 * 1024;
 // ... and the contraction depth from which it does: the published 180-wide model (run_script_zinc_phm4.sh) runs 1.756 -> 1.622 ms per
 // step on the 32-column configuration, the 200-wide one 1.940 -> 1.972 ms (alternating runs, PHC_GEMM_WIDE_K_M = 16384 / 1000000)
 constexpr int GEMM_WIDE_K_MIN = 192;
+// ... the 128-column / 8-wave configuration: its [K x 129] panel + staging must fit the 150 KB of dynamic LDS (K <= 160; a 180-deep
+// contraction at >= 64 k rows used to be refused by the runtime: "invalid argument")
+static inline bool gemm_big_cfg(int64_t N, int K, int Nout) { return N >= 64 * 1024 && Nout > 64 && K <= 160; }
 static inline int64_t gemm_wide_k_m() {
     // measured (bench.py, one MI355X): zinc_b1024 (23.6 k rows, PHM-8 hidden 256) 2.75 -> 2.58 ms, molpcba_b1024 (27.2 k rows)
     // 3.42 -> 3.19 ms per training step with the 8-wave configuration instead of 2 x (32 columns, 4 waves) per CU
@@ -1981,7 +1997,7 @@ int phc_gemm_prebuilt(const float *x, const float *M, const float *Mk4, const fl
     if (hs_shape_ok(x, Mk4, N, K, Nout) && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(residual)) & 15) == 0) {
         hipStream_t hs = (hipStream_t)stream;
         ProfScope prof(is_dx ? K_PHM_GEMM_DX : K_PHM_GEMM_FWD, hs);
-        launch_hs<0>(hs_args(x, Mk4, b, residual, y, N, Nout), K, XfAcc{}, hs);
+        launch_hs<0>(hs_args(x, Mk4, b, residual, y, N, K, Nout), K, XfAcc{}, hs);
         return check_launch("phc_gemm_prebuilt(hs)");
     }
     PHC_REQUIRE(K <= GEMM_PREBUILT_MAX_K && K % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 &&
@@ -1999,7 +2015,7 @@ int phc_gemm_prebuilt(const float *x, const float *M, const float *Mk4, const fl
     static const int small_bn = getenv("PHC_GEMM_PRE_BN") ? atoi(getenv("PHC_GEMM_PRE_BN")) : 32;
     if (N >= gemm_wide_k_m() && Nout > 64 && K > GEMM_WIDE_K_MIN)
         launch_stream_cfg<0, -1, 64, 8>(x, nullptr, M, b, residual, y, N, K, Nout, 1, K, Nout, 1, s);
-    else if (N >= GEMM_BIG_M && Nout > 64)
+    else if (gemm_big_cfg(N, K, Nout))
         launch_stream_cfg<0, -1, 128, 8>(x, nullptr, M, b, residual, y, N, K, Nout, 1, K, Nout, 1, s);
     else if (small_bn == 32 && Nout > 32 && N <= 32 * 1024)
         launch_stream_cfg<0, -1, 32, 4>(x, nullptr, M, b, residual, y, N, K, Nout, 1, K, Nout, 3, s);
@@ -2025,7 +2041,7 @@ int phc_gemm_prebuilt_stats(const float *x, const float *M, const float *Mk4, co
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(K_PHM_GEMM_FWD, s);
     if (acc && hs_shape_ok(x, Mk4, N, K, Nout) && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(b)) & 15) == 0) {
-        GemmHsArgs a = hs_args(x, Mk4, b, nullptr, y, N, Nout);
+        GemmHsArgs a = hs_args(x, Mk4, b, nullptr, y, N, K, Nout);
         a.n_valid = n_valid_dev;
         a.stat_acc = reinterpret_cast<unsigned long long *>(stats_partial);
         launch_hs<HS_ST>(a, K, XfAcc{}, s);
@@ -2038,7 +2054,7 @@ int phc_gemm_prebuilt_stats(const float *x, const float *M, const float *Mk4, co
     else if (N >= gemm_wide_k_m() && Nout > 64 && K > GEMM_WIDE_K_MIN)
         launch_stream_cfg<0, -1, 64, 8, 1>(x, nullptr, M, b, nullptr, y, N, K, Nout, 1, K, Nout, 1, s, n_valid_dev, stats_partial,
                                            stats_counts, num_partials, nullptr, 0, nullptr, nullptr, 0, acc);
-    else if (N >= GEMM_BIG_M && Nout > 64)
+    else if (gemm_big_cfg(N, K, Nout))
         launch_stream_cfg<0, -1, 128, 8, 1>(x, nullptr, M, b, nullptr, y, N, K, Nout, 1, K, Nout, 1, s, n_valid_dev, stats_partial,
                                             stats_counts, num_partials, nullptr, 0, nullptr, nullptr, 0, acc);
     else if (small_bn == 32 && Nout > 32 && N <= 32 * 1024)
@@ -2097,7 +2113,7 @@ static int gemm_prebuilt_xf_impl(const float *x, const float *xf_stat, int xf_ac
     ProfScope prof(K_PHM_GEMM_FWD, s);
     if ((!stats_partial || acc) && hs_shape_ok(x, Mk4, N, K, Nout) &&
         ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(b) | reinterpret_cast<uintptr_t>(xf_stat)) & 15) == 0) {
-        GemmHsArgs a = hs_args(x, Mk4, b, nullptr, y, N, Nout);
+        GemmHsArgs a = hs_args(x, Mk4, b, nullptr, y, N, K, Nout);
         a.n_valid = n_valid_dev;
         a.xf_stat = xf_stat;
         a.xf_act = xf_act;
@@ -2109,7 +2125,7 @@ static int gemm_prebuilt_xf_impl(const float *x, const float *xf_stat, int xf_ac
         return check_launch("phc_gemm_prebuilt_xf(hs)");
     }
     static const int small_bn = getenv("PHC_GEMM_PRE_BN") ? atoi(getenv("PHC_GEMM_PRE_BN")) : 32;
-    const bool big = N >= GEMM_BIG_M && Nout > 64;
+    const bool big = gemm_big_cfg(N, K, Nout);
     const bool small = small_bn == 32 && Nout > 32 && N <= 32 * 1024;
 #define PHC_XF_LAUNCH(SV)                                                                                                      \
     if (N >= gemm_wide_k_m() && Nout > 64 && K > GEMM_WIDE_K_MIN)                                                                          \
@@ -2149,7 +2165,7 @@ int phc_gemm_prebuilt_bwsums(const float *dy, const float *M, const float *Mk4, 
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(K_PHM_GEMM_DX, s);
     if (acc && hs_shape_ok(dy, Mk4, N, K, Nout)) {
-        GemmHsArgs a = hs_args(dy, Mk4, nullptr, nullptr, dz, N, Nout);
+        GemmHsArgs a = hs_args(dy, Mk4, nullptr, nullptr, dz, N, K, Nout);
         a.n_valid = n_valid_dev;
         a.stat_acc = reinterpret_cast<unsigned long long *>(sums_partial);
         a.bw_x = bn_x;
@@ -2162,7 +2178,7 @@ int phc_gemm_prebuilt_bwsums(const float *dy, const float *M, const float *Mk4, 
     if (N >= gemm_wide_k_m() && Nout > 64 && K > GEMM_WIDE_K_MIN)
         launch_stream_cfg<0, -1, 64, 8, 4>(dy, nullptr, M, nullptr, nullptr, dz, N, K, Nout, 1, K, Nout, 1, s, n_valid_dev, sums_partial,
                                            nullptr, num_partials, nullptr, 0, bn_x, bn_stat, act, acc);
-    else if (N >= GEMM_BIG_M && Nout > 64)
+    else if (gemm_big_cfg(N, K, Nout))
         launch_stream_cfg<0, -1, 128, 8, 4>(dy, nullptr, M, nullptr, nullptr, dz, N, K, Nout, 1, K, Nout, 1, s, n_valid_dev, sums_partial,
                                             nullptr, num_partials, nullptr, 0, bn_x, bn_stat, act, acc);
     else if (small_bn == 32 && Nout > 32 && N <= 32 * 1024)
@@ -2189,13 +2205,13 @@ int phc_debug_hs_stamps(unsigned long long *dev_words) {
 }
 
 int phc_gemm_bwd_apply_supported(int K, int Nout) {
-    return (hs_enabled() && (K == 128 || K == 256) && (Nout == 128 || Nout == 256)) ? 1 : 0;
+    return (hs_enabled() && hs_widths_ok(K, Nout)) ? 1 : 0;
 }
 
 int phc_gemm_bwd_apply(const phc_gemm_ba_desc *d, void *stream) {
     PHC_REQUIRE(d, PHC_ERR_INVALID_ARG, "phc_gemm_bwd_apply: null descriptor");
     PHC_REQUIRE(d->N >= 1 && phc_gemm_bwd_apply_supported(d->K, d->Nout), PHC_ERR_UNSUPPORTED,
-                "phc_gemm_bwd_apply: N=%lld K=%d Nout=%d outside the fused form's range (K, Nout in {128, 256})", (long long)d->N, d->K, d->Nout);
+                "phc_gemm_bwd_apply: N=%lld K=%d Nout=%d outside the fused form's range (K, Nout in {128, 256}, 180 x 180, 200 x 200)", (long long)d->N, d->K, d->Nout);
     PHC_REQUIRE(d->dout && d->bn_x && d->bn_stat && d->sums_acc && d->dz && d->Mk4 && d->y, PHC_ERR_INVALID_ARG, "phc_gemm_bwd_apply: null pointer");
     PHC_REQUIRE(d->act >= PHC_ACT_IDENTITY && d->act <= PHC_ACT_SELU, PHC_ERR_INVALID_ARG, "phc_gemm_bwd_apply: unknown activation %d", d->act);
     PHC_REQUIRE(d->count == 0 || d->count >= d->N, PHC_ERR_INVALID_ARG, "phc_gemm_bwd_apply: count=%lld < N=%lld", (long long)d->count, (long long)d->N);
@@ -2208,7 +2224,7 @@ int phc_gemm_bwd_apply(const phc_gemm_ba_desc *d, void *stream) {
                     ((reinterpret_cast<uintptr_t>(d->sums_acc) | reinterpret_cast<uintptr_t>(d->bw_sums_acc)) & 7) == 0,
                 PHC_ERR_UNSUPPORTED, "phc_gemm_bwd_apply: 16-byte aligned rows / 8-byte aligned accumulators required");
     hipStream_t s = (hipStream_t)stream;
-    GemmHsArgs a = hs_args(d->dout, d->Mk4, nullptr, nullptr, d->y, d->N, d->Nout);
+    GemmHsArgs a = hs_args(d->dout, d->Mk4, nullptr, nullptr, d->y, d->N, d->K, d->Nout);
     a.n_valid = d->n_valid_dev;
     a.ba_x = d->bn_x;
     a.ba_stat = d->bn_stat;

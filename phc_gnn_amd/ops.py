@@ -2391,6 +2391,8 @@ class _BatchNormActFn(torch.autograd.Function):
                 L.account("bn_apply", 2.0 * N * h, 4.0 * N * h * (3 if residual is not None else 2))
             ctx.save_for_backward(x_, save_stat)
             ctx.meta = (n_comp, bool(training), act, bool(affine), residual is not None, n_valid)
+            if training:
+                _tap(x_, save_stat, n_valid, act)
             return out
         ws_bytes = lib.phc_bn_ws_bytes(N, h)
         ws = torch.empty(ws_bytes, dtype=torch.uint8, device=dev)
@@ -2404,6 +2406,8 @@ class _BatchNormActFn(torch.autograd.Function):
             L.account("bn_apply", 2.0 * N * h, 4.0 * N * h * (3 if residual is not None else 2))
         ctx.save_for_backward(x_, save_stat)
         ctx.meta = (n_comp, bool(training), act, bool(affine), residual is not None, n_valid)
+        if training:
+            _tap(x_, save_stat, n_valid, act)
         return out
 
     @staticmethod
@@ -2494,6 +2498,7 @@ class _BNActLinearFn(torch.autograd.Function):
         ctx.save_for_backward(x, save_stat, A2, W2)
         ctx.HT2, ctx.HT2k4, ctx.params2 = HT2, k4[1], (A2, W2, b2)
         ctx.meta = (n_comp, act, bool(affine), n_valid)
+        _tap(x, save_stat, n_valid, act)
         return y
 
     @staticmethod
@@ -2701,6 +2706,18 @@ def materialize_pending(t: torch.Tensor) -> torch.Tensor:
     return t
 
 
+# Test hook: a list here collects, in forward order, (norm input, save_stat, n_valid, activation id) of every act(norm(.)) site of
+# the fused nodes (the two sites of a PHMMLP + norm node, the two of the fused head).  tests/test_gpu_fullwidth.py rebuilds the
+# ReLU gates the backward kernels take (sign of fma((z - mean) * invstd, w, b)) from them and imposes them on the float64 oracle.
+# The list keeps the tensors alive — under hipGraph capture that also keeps their pool blocks from being reused.
+RELU_TAP: Optional[list] = None
+
+
+def _tap(z, save_stat, n_valid, act):
+    if RELU_TAP is not None:
+        RELU_TAP.append((z, save_stat, n_valid, act))
+
+
 class _MLPNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, s, skip, n_valid, meta, A1, W1, b1, A2, W2, b2, *affine):
@@ -2726,6 +2743,8 @@ class _MLPNormFn(torch.autograd.Function):
             _ptr_array(inner["running_mean"]), _ptr_array(inner["running_var"]), _ptr_array(inner["nbt"]), ni,
             float(inner["momentum"]), float(inner["eps"]), L.ptr(save_i), act_i, L.ptr(n_valid), L.ptr(pre2[0]), L.ptr(pre2[2]),
             L.ptr(b2), N, h, h, L.ptr(y2), L.ptr(acc2), None, None, sp), "phc_gemm_prebuilt_xf_acc")
+        _tap(z1, save_i, n_valid, act_i)
+        _tap(y2, save_o, n_valid, act_o)
         pend = PendingNorm(y2, acc2, outer, tuple(aff_o), act_o, skip, n_valid, out, save_o)
         if meta.get("defer_apply"):
             meta["pending"] = pend                           # the caller hands it to the next layer's aggregation (or materialises it)
@@ -2929,6 +2948,8 @@ class _DownstreamFn(torch.autograd.Function):
         d.H1k4, d.H2k4 = L.ptr(pre[0][2]), L.ptr(pre[1][2])                        # k4 forms (None: the 32-row kernels)
         d.H1Tk4, d.H2Tk4 = L.ptr(pre[0][3]), L.ptr(pre[1][3])
         L.check(lib.phc_downstream_fwd(_C.byref(d), L.stream_ptr(dev)), "phc_downstream_fwd")
+        _tap(z1, stat1, n_valid, act)
+        _tap(z2, stat2, n_valid, act)
         if L.PROF_ON:
             L.account("downstream_fwd", 2.0 * B * (d0 * d1 + d1 * d2 + d2 * d3 + d3 * T), 4.0 * (B * (d0 + d1 + d2 + d3 + T) + d0 * d1 + d1 * d2))
         ctx.save_for_backward(x_, z1, z2, z3, stat1, stat2, Wr)

@@ -102,8 +102,9 @@ def audit_ring(asm_text: str):
                 if w:
                     waits.append((n, int(w.group(1))))
         have = {v for _, v in waits}
-        allowed = {0, vm_keep + pro}
-        need = {vm_keep + pro}
+        first = min(vm_keep + pro, 63)                    # (vmcnt is a 6-bit counter: the source saturates the first step's count)
+        allowed = {0, first}
+        need = {first}
         if XF or BA:
             allowed |= {vm_mid, acc_younger}
             need |= {vm_mid}
@@ -116,7 +117,7 @@ def audit_ring(asm_text: str):
             problems.append(f"missing counted waits {sorted(need - have)}")
         if not (XF or BA):
             for n, v in waits:
-                if v not in (vm_keep, vm_keep + pro):
+                if v not in (vm_keep, first):
                     continue
                 for t in lines[n + 1:]:
                     if t.startswith("s_barrier"):

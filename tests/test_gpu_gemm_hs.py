@@ -45,7 +45,7 @@ def _problem(N, K, Nout, seed, scale=1.0):
     return x, M, b
 
 
-@pytest.mark.parametrize("K,Nout", [(128, 128), (256, 256), (128, 256), (256, 128)])
+@pytest.mark.parametrize("K,Nout", [(128, 128), (256, 256), (128, 256), (256, 128), (180, 180), (200, 200)])
 @pytest.mark.parametrize("N", ROWS)
 def test_hs_plain_bias_residual(N, K, Nout):
     from phc_gnn_amd import lib as L
@@ -70,7 +70,7 @@ def test_hs_plain_bias_residual(N, K, Nout):
     assert_close(y1, ref.float(), 2e-6)
 
 
-@pytest.mark.parametrize("K,Nout", [(128, 128), (256, 256), (128, 256)])
+@pytest.mark.parametrize("K,Nout", [(128, 128), (256, 256), (128, 256), (180, 180), (200, 200)])
 @pytest.mark.parametrize("N,valid", [(16, 16), (17, 9), (333, 333), (12874, 12001), (70001, 70001)])
 def test_hs_statistics_accumulator(N, valid, K, Nout):
     """Output statistics in accumulator form, incl. padding rows past n_valid and a column whose mean is 300 standard deviations."""
@@ -107,7 +107,7 @@ def test_hs_statistics_accumulator(N, valid, K, Nout):
 
 
 @pytest.mark.parametrize("act", ["relu", "swish", "identity"])
-@pytest.mark.parametrize("K,Nout", [(128, 128), (256, 256), (256, 128)])
+@pytest.mark.parametrize("K,Nout", [(128, 128), (256, 256), (256, 128), (180, 180), (200, 200)])
 @pytest.mark.parametrize("N,valid", [(17, 17), (333, 301), (12874, 12874)])
 def test_hs_operand_transform_from_save_stat(N, valid, K, Nout, act):
     from oracle import phc_oracle as O
@@ -138,7 +138,7 @@ def test_hs_operand_transform_from_save_stat(N, valid, K, Nout, act):
             assert_close((Q / valid - (S / valid) ** 2).float(), y64[:valid].var(0, unbiased=False).float(), 5e-5, "xf: variance of the output")
 
 
-@pytest.mark.parametrize("K,Nout,n_comp", [(128, 128, 4), (256, 256, 8), (256, 128, 4)])
+@pytest.mark.parametrize("K,Nout,n_comp", [(128, 128, 4), (256, 256, 8), (256, 128, 4), (180, 180, 4), (200, 200, 5)])
 @pytest.mark.parametrize("N,valid", [(333, 301), (12874, 12874)])
 def test_hs_operand_transform_from_an_accumulator(N, valid, K, Nout, n_comp):
     """linear1 (statistics into an accumulator) -> [norm -> relu -> linear2] with the norm's scale / shift derived in the second
@@ -192,7 +192,7 @@ def test_hs_operand_transform_from_an_accumulator(N, valid, K, Nout, n_comp):
 
 
 @pytest.mark.parametrize("act", ["relu", "swish"])
-@pytest.mark.parametrize("K,Nout", [(128, 128), (256, 256), (128, 256)])
+@pytest.mark.parametrize("K,Nout", [(128, 128), (256, 256), (128, 256), (180, 180), (200, 200)])
 @pytest.mark.parametrize("N,valid", [(17, 11), (333, 333), (12874, 12001)])
 def test_hs_backward_sums(N, valid, K, Nout, act):
     """dz = dy . H^T plus the norm backward's column sums (sum g, sum g x_hat), accumulator form."""
@@ -248,7 +248,7 @@ def test_k4_operands_from_the_batched_builder():
 
 
 @pytest.mark.parametrize("act,act_in", [("relu", "relu"), ("swish", "identity")])
-@pytest.mark.parametrize("K,Nout", [(128, 128), (256, 256), (256, 128)])
+@pytest.mark.parametrize("K,Nout", [(128, 128), (256, 256), (256, 128), (180, 180), (200, 200)])
 @pytest.mark.parametrize("N,valid", [(17, 11), (333, 333), (12874, 12001)])
 def test_hs_norm_backward_folded_into_the_dx_gemm(N, valid, K, Nout, act, act_in):
     """phc_bn_bwd_partial_acc -> phc_gemm_bwd_apply (with the second-stage sums): dz (the norm backward's dx), dwb, y = dz . M
@@ -321,7 +321,7 @@ def test_hs_norm_backward_folded_into_the_dx_gemm(N, valid, K, Nout, act, act_in
     assert torch.equal(dz_b, dz) and torch.equal(y_b, y)
 
 
-@pytest.mark.parametrize("wl", ["molhiv_b32", "molhiv_b512", "zinc_b1024"])
+@pytest.mark.parametrize("wl", ["molhiv_b32", "molhiv_b512", "zinc_b1024", "zinc_pub_phc4_4x180_nodrop", "zinc_pub_phc5_4x200_nodrop"])
 def test_fused_mlp_norm_node_equals_the_separate_nodes(wl):
     """One training step with the PHMMLP + model norm of every layer as ONE autograd node (ops.mlp_norm_fused: both norm
     backwards folded into the dx GEMMs) against the same step on the separate nodes: loss, every gradient, running statistics."""
