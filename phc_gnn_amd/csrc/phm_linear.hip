@@ -1387,11 +1387,12 @@ static bool hs_shape_ok(const float *x, const float *Mk4, int64_t N, int K, int 
 
 static unsigned long long *g_hs_stamps = nullptr;             // diagnostics (phc_debug_hs_stamps): per-wavefront phase clocks
 
-template <int K, int TPW, int WAVES, int FLAGS>
+template <int K, int TPW, int WAVES, int FLAGS, int RB = 1>
 static int launch_hs_cfg(GemmHsArgs a, const XfAcc &xa, hipStream_t s) {
     // 16-row steps (RB = 1).  32-row steps (RB = 2) were measured inside the replayed zinc_b1024 step: plain 28.3 -> 33.6 us,
-    // with statistics 41.9 -> 46.9 us per launch (5.8 -> 2.9 steps per workgroup: the last round is half empty)
-    constexpr int RB = 1, R = HS_RING;
+    // with statistics 41.9 -> 46.9 us per launch (5.8 -> 2.9 steps per workgroup: the last round is half empty); they are for
+    // launches with hundreds of steps per workgroup (config 5: launch_hs)
+    constexpr int R = HS_RING;
     a.stamps = g_hs_stamps;
     a.panels = (a.Nout + 16 * TPW * WAVES - 1) / (16 * TPW * WAVES);
     const long long steps = (a.M + 16 * RB - 1) / (16 * RB);
@@ -1426,6 +1427,11 @@ static int launch_hs(const GemmHsArgs &a, int K, const XfAcc &xa, hipStream_t s)
     if (K == 256 && a.Nout == 256) return launch_hs_cfg<256, 2, 8, FLAGS>(a, xa, s);
     if (K == 256 && a.Nout == 128) return launch_hs_cfg<256, 2, 4, FLAGS>(a, xa, s);
     if (K == 128 && a.Nout == 256) return launch_hs_cfg<128, 2, 8, FLAGS>(a, xa, s);
+    // 128 x 128 at config-5 scale (millions of rows: thousands of steps per workgroup): 32-row steps halve the per-row share of the
+    // step's fixed costs (DMA issue, counted wait, barrier) — measured worth nothing (10 M rows, two workgroups per CU: 2868 -> 2857 us,
+    // 114.3 -> 114.7 TFLOP/s; one per CU 3063 -> 2961): the launch is not bound by them.  Off; PHC_HS_RB2_MIN_ROWS=<rows> turns it on.
+    static const long long rb2_min = getenv("PHC_HS_RB2_MIN_ROWS") ? atoll(getenv("PHC_HS_RB2_MIN_ROWS")) : 0;
+    if (rb2_min > 0 && a.M >= rb2_min) return launch_hs_cfg<128, 2, 4, FLAGS, 2>(a, xa, s);
     return launch_hs_cfg<128, 2, 4, FLAGS>(a, xa, s);
 }
 
