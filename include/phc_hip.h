@@ -130,6 +130,21 @@ typedef struct phc_phm_H_job {
     int32_t gate_k;
 } phc_phm_H_job;
 int phc_phm_build_H_batched(const phc_phm_H_job *jobs, int num_jobs, void *stream);
+/* ABI 5: the same launch with the step's ATOM ENCODER riding in it as passenger workgroups (encoder.py:31-34:
+ * out[i, c k + kap] = sum_f T_{c,f}[idx[i, f]][kap], exactly phc_encode_fwd): both depend on the parameters and the batch only, and
+ * both are latency-bound — one launch instead of two at the head of a training step.  tables: DEVICE array of n * F table pointers
+ * ([c][f] -> [vocab_f, k] fp32), vocab: host array of F sizes, out [N, n k] 16-byte aligned; F <= 10, k % 4 == 0
+ * (phc_encode_front_supported); index validation as phc_encode_fwd (PHC_IDX_ERR_ATOM).  enc == NULL: phc_phm_build_H_batched. */
+typedef struct phc_encode_front {
+    const int64_t *idx_i64;
+    const float *const *tables;
+    const int32_t *vocab;
+    float *out;
+    int64_t N;
+    int32_t F, n, k;
+} phc_encode_front;
+int phc_encode_front_supported(int64_t N, int F, int n, int k);
+int phc_phm_build_H_batched_ex(const phc_phm_H_job *jobs, int num_jobs, const phc_encode_front *enc, void *stream);
 /* Parameter gradients of that gate map from dM^T = dg^T . x [kg, in] and dbg = sum dg [kg] (what a dense parameter-gradient job
  * with x and dg leaves behind): dH = dM . gate_w is re-evaluated where needed (never stored), dA / dW its contractions with W / A,
  * dWg = dM^T . H + dbg (x) phm_b, db = dbg . gate_w.  H [in, h] is the PHM layer's operand matrix (phc_phm_build_H*).  Outputs may be

@@ -913,7 +913,52 @@ __device__ __forceinline__ void gate_compose_block(const HJobDev &jb, int r) {
     }
 }
 
-__global__ __launch_bounds__(256) void phm_build_H_batched_kernel(HBatch b) {
+// The atom encoder of the step (encoder.py:31-34: out[i, c k + kap] = sum_f T_{c,f}[idx[i, f]][kap]) as PASSENGER workgroups of the
+// operand-build launch: both depend on nothing but the parameters and the batch, and both are latency-bound — side by side they
+// take what the longer one takes (one launch and ~8 us per step less than back to back).  One thread per (row, float4 column
+// group) and round; the F indices of a row are read by every thread of the row (one line, broadcast), an out-of-range index reads
+// row 0 and raises PHC_IDX_ERR_ATOM exactly as phc_encode_fwd does.
+constexpr int HB_ENC_MAX_F = 10;
+struct EncFront {
+    const long long *idx;            // [N, F]
+    const float *const *tables;      // device array of n * F table pointers ([c][f] -> [V_f, k])
+    float *out;                      // [N, n k]
+    long long N;
+    int F, n, k;
+    int vocab[HB_ENC_MAX_F];
+    unsigned blk0, blocks;           // its workgroups sit behind the operand jobs'
+    int *err;
+};
+__device__ __forceinline__ void encode_front_block(const EncFront &e, unsigned bx) {
+    const int h4 = (e.n * e.k) >> 2;
+    const long long total = e.N * h4;
+    for (long long t = (long long)bx * 256 + threadIdx.x; t < total; t += (long long)e.blocks * 256) {
+        const long long i = t / h4;
+        const int c4 = (int)(t - i * h4), col = c4 << 2;
+        const int c = col / e.k, kap = col - c * e.k;
+        long long iv[HB_ENC_MAX_F];
+#pragma unroll
+        for (int f = 0; f < HB_ENC_MAX_F; ++f) {
+            const int ff = min(f, e.F - 1);
+            iv[f] = checked_index(e.idx[i * e.F + ff], e.vocab[ff], e.err, PHC_IDX_ERR_ATOM);
+        }
+        float4 rows[HB_ENC_MAX_F];
+#pragma unroll
+        for (int f = 0; f < HB_ENC_MAX_F; ++f)
+            rows[f] = *reinterpret_cast<const float4 *>(e.tables[c * e.F + min(f, e.F - 1)] + iv[f] * e.k + kap);
+        float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int f = 0; f < HB_ENC_MAX_F; ++f)
+            if (f < e.F) { acc.x += rows[f].x; acc.y += rows[f].y; acc.z += rows[f].z; acc.w += rows[f].w; }
+        reinterpret_cast<float4 *>(e.out + (size_t)i * e.n * e.k)[c4] = acc;
+    }
+}
+
+__global__ __launch_bounds__(256) void phm_build_H_batched_kernel(HBatch b, EncFront enc) {
+    if (enc.blocks && blockIdx.x >= enc.blk0) {              // (block-uniform)
+        encode_front_block(enc, blockIdx.x - enc.blk0);
+        return;
+    }
     int job = 0;
     for (int q = 1; q < b.num; ++q)
         if (blockIdx.x >= b.j[q].blk0) job = q;
@@ -1913,9 +1958,35 @@ int phc_phm_linear_bwd(const float *x, const float *A, const float *W, const flo
 }
 
 // ---- prebuilt operand matrices --------------------------------------------------------------
+static int build_H_batched_impl(const phc_phm_H_job *jobs, int num_jobs, const phc_encode_front *enc, void *stream);
+
 int phc_phm_build_H_batched(const phc_phm_H_job *jobs, int num_jobs, void *stream) {
+    return build_H_batched_impl(jobs, num_jobs, nullptr, stream);
+}
+int phc_encode_front_supported(int64_t N, int F, int n, int k) {
+    return (N >= 1 && F >= 1 && F <= HB_ENC_MAX_F && n >= 1 && n <= PHC_MAX_COMPONENTS && k >= 4 && k % 4 == 0) ? 1 : 0;
+}
+int phc_phm_build_H_batched_ex(const phc_phm_H_job *jobs, int num_jobs, const phc_encode_front *enc, void *stream) {
+    return build_H_batched_impl(jobs, num_jobs, enc, stream);
+}
+
+static int build_H_batched_impl(const phc_phm_H_job *jobs, int num_jobs, const phc_encode_front *enc, void *stream) {
     PHC_REQUIRE(num_jobs >= 0 && (num_jobs == 0 || jobs), PHC_ERR_INVALID_ARG, "phc_phm_build_H_batched: bad job table");
     hipStream_t s = (hipStream_t)stream;
+    EncFront ef = {};
+    if (enc) {
+        PHC_REQUIRE(num_jobs >= 1 && phc_encode_front_supported(enc->N, enc->F, enc->n, enc->k) && enc->idx_i64 && enc->tables && enc->vocab &&
+                        enc->out && (reinterpret_cast<uintptr_t>(enc->out) & 15) == 0,
+                    PHC_ERR_INVALID_ARG, "phc_phm_build_H_batched_ex: encoder passenger N=%lld F=%d n=%d k=%d (F <= %d, k %% 4 == 0, aligned out)",
+                    (long long)enc->N, enc->F, enc->n, enc->k, HB_ENC_MAX_F);
+        ef.idx = reinterpret_cast<const long long *>(enc->idx_i64);
+        ef.tables = enc->tables; ef.out = enc->out; ef.N = enc->N; ef.F = enc->F; ef.n = enc->n; ef.k = enc->k;
+        for (int f = 0; f < enc->F; ++f) {
+            PHC_REQUIRE(enc->vocab[f] >= 1, PHC_ERR_INVALID_ARG, "phc_phm_build_H_batched_ex: vocab[%d] = %d", f, enc->vocab[f]);
+            ef.vocab[f] = enc->vocab[f];
+        }
+        ef.err = err_word();
+    }
     for (int c0 = 0; c0 < num_jobs; c0 += H_JOBS_PER_LAUNCH) {
         const int cn = num_jobs - c0 < H_JOBS_PER_LAUNCH ? num_jobs - c0 : H_JOBS_PER_LAUNCH;
         HBatch b;
@@ -1960,8 +2031,18 @@ int phc_phm_build_H_batched(const phc_phm_H_job *jobs, int num_jobs, void *strea
             b.j[k].blk0 = blocks;
             blocks += (unsigned)(((size_t)jb.n * jb.kin * jb.n * jb.kout + 255) / 256);
         }
+        EncFront e = {};
+        if (enc && c0 + cn >= num_jobs) {                        // the passenger rides in the last chunk's launch
+            e = ef;
+            const long long units = ef.N * ((ef.n * ef.k) >> 2);
+            long long eb = (units + 255) / 256;
+            if (eb > 8192) eb = 8192;
+            e.blk0 = blocks;
+            e.blocks = (unsigned)eb;
+            blocks += (unsigned)eb;
+        }
         ProfScope prof(K_PHM_BUILD_H, s);
-        PHC_LAUNCH(phm_build_H_batched_kernel, dim3(blocks), dim3(256), 0, s, b);
+        PHC_LAUNCH(phm_build_H_batched_kernel, dim3(blocks), dim3(256), 0, s, b, e);
         int rc = check_launch("phm_build_H_batched");
         if (rc) return rc;
     }

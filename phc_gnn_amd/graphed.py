@@ -30,7 +30,7 @@ import torch
 from . import synth
 from .graph import cached_structures_of, clear_structure_cache
 from .harness import StepConfig, advance_dropout_rng, apply_weight_regulariser, loss_fn, optimizer_step, park_weight_regulariser
-from .ops import deferred_param_grads, dense_weights, gate_specs, phm_pairs, prebuilt_H, stat_accumulators
+from .ops import atom_encode_spec, deferred_param_grads, dense_weights, gate_specs, phm_pairs, prebuilt_H, stat_accumulators
 
 
 def bucket_shape(batches: List[synth.GraphBatch], slack: float = 0.02, multiple: int = 128):
@@ -288,7 +288,8 @@ class GraphedTrainStep:
         """zero_grad, forward, loss, backward (+ pack the gradients into the flat all-reduce bucket)."""
         self.optimizer.zero_grad(set_to_none=True)
         advance_dropout_rng(self.model, bs.data)
-        with stat_accumulators(self.device), prebuilt_H(self._pairs, self._dense, self._gates), deferred_param_grads():
+        with stat_accumulators(self.device), prebuilt_H(self._pairs, self._dense, self._gates,
+                                                        encode=atom_encode_spec(self.model, bs.data)), deferred_param_grads():
             logits = self.model(bs.data)
             loss = loss_fn(logits, bs.data, self.cfg.regression)
             loss.backward(self._seed)

@@ -12,8 +12,8 @@ import torch
 import torch.nn.functional as F
 
 from . import synth
-from .ops import (deferred_param_grads, dense_weights, gate_specs, masked_bce_with_logits, masked_l1, phm_pairs, phm_weight_regularization_,
-                  prebuilt_H, stat_accumulators)
+from .ops import (atom_encode_spec, deferred_param_grads, dense_weights, gate_specs, masked_bce_with_logits, masked_l1, phm_pairs,
+                  phm_weight_regularization_, prebuilt_H, stat_accumulators)
 from .optim import ClipAdam
 
 # BASELINE.json configs -> PHMSkipConnectAdd arguments (SURVEY.md §8d "Model settings")
@@ -148,7 +148,9 @@ def train_step(model, data, optimizer: Optional[torch.optim.Optimizer], cfg: Ste
     advance_dropout_rng(model, data)
     # operand matrices of all PHM layers: one launch; dW/dA/db of all layers: three batched launches after the backward
     # (stat_accumulators: the batch-norm statistics of the step travel through zeroed accumulator slots, no merge launches)
-    with stat_accumulators(data.x.device), prebuilt_H(phm_pairs(model), dense_weights(model), gate_specs(model)), deferred_param_grads():
+    # (the atom encoder rides in the operand-build launch: atom_encode_spec)
+    with stat_accumulators(data.x.device), prebuilt_H(phm_pairs(model), dense_weights(model), gate_specs(model),
+                                                      encode=atom_encode_spec(model, data)), deferred_param_grads():
         logits = model(data)
         loss = loss_fn(logits, data, cfg.regression)
         loss.backward(backward_seed(loss))

@@ -69,6 +69,11 @@ class GemmBaDesc(C.Structure):
                 ("bw_x", _P), ("bw_stat", _P), ("bw_sums_acc", _P), ("count", _L)]
 
 
+class EncodeFront(C.Structure):
+    """phc_encode_front (include/phc_hip.h)."""
+    _fields_ = [("idx_i64", _P), ("tables", _P), ("vocab", _P), ("out", _P), ("N", _L), ("F", C.c_int32), ("n", C.c_int32), ("k", C.c_int32)]
+
+
 class TailExtras(C.Structure):
     """phc_tail_extras (include/phc_hip.h)."""
     _fields_ = [("gate_job", C.c_int32), ("gate_n", C.c_int32), ("gate_kin", C.c_int32), ("gate_kout", C.c_int32), ("gate_kg", C.c_int32),
@@ -101,6 +106,8 @@ SIGNATURES = {
     "phc_phm_linear_bwd_ws_bytes": (_S, [_L, _I, _I, _I]),
     "phc_phm_linear_bwd": (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _P, _P, _P, _P, _P, _S, _P]),
     "phc_phm_build_H_batched": (_I, [C.POINTER(HJob), _I, _P]),
+    "phc_encode_front_supported": (_I, [_L, _I, _I, _I]),
+    "phc_phm_build_H_batched_ex": (_I, [C.POINTER(HJob), _I, C.POINTER(EncodeFront), _P]),
     "phc_gemm_prebuilt": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _P, _I, _P]),
     "phc_gemm_stats_max_partials": (_I, []),
     "phc_stat_acc_words": (_S, [_I]),

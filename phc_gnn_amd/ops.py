@@ -460,6 +460,8 @@ def _flush_param_grads(jobs, return_grads: bool = False):
 # from them (phc_gemm_prebuilt) instead of re-assembling it from A and W in every workgroup.  The block must not
 # span an in-place update of the weights (one training step: forward + backward, optimizer step after it).
 class _Prebuilt:
+    encoded = None        # (idx data_ptr, idx shape, table-pointer array data_ptr, out): the atom encoding the build launch produced
+
     def __init__(self):
         self.table = {}
 
@@ -516,8 +518,23 @@ PREBUILT_MAX_WIDTH = 768
 FUSED_MAX_WIDTH = 256
 
 
+# the step's atom encoder as passenger workgroups of the operand-build launch (phc_phm_build_H_batched_ex)
+ENCODE_FRONT = __import__("os").environ.get("PHC_ENCODE_FRONT", "1") != "0"
+
+
+def atom_encode_spec(model, data):
+    """(idx, TableSet, tables) of ``model.atomencoder`` applied to ``data.x`` when that is the integer / sum encoder the engine
+    evaluates in one kernel, else None: what ``prebuilt_H(encode=...)`` needs to run the encoder inside the operand-build launch."""
+    enc = getattr(model, "atomencoder", None)
+    tables = getattr(enc, "engine_tables", None) if enc is not None else None
+    x = getattr(data, "x", None)
+    if tables is None or x is None or not x.is_cuda or x.dim() != 2:
+        return None
+    return x, tableset_for(enc, tables), tables
+
+
 @contextlib.contextmanager
-def prebuilt_H(pairs, dense=(), gates=()):
+def prebuilt_H(pairs, dense=(), gates=(), encode=None):
     if _PREBUILT.table or not (pairs or dense or gates):   # nested (outermost wins) or nothing to do
         yield
         return
@@ -598,10 +615,24 @@ def prebuilt_H(pairs, dense=(), gates=()):
                     off += 4 * sz
                     arr[len(gts) + i] = L.HJob(L.ptr(A), L.ptr(W), L.ptr(H), L.ptr(HT), n, kin, kout, 0, L.ptr(Hk4), L.ptr(HTk4))
                     _PREBUILT.table[(A.data_ptr(), W.data_ptr())] = (H, HT, A._version, W._version, Hk4, HTk4)
-                L.check(lib.phc_phm_build_H_batched(arr, len(arr), L.stream_ptr(dev)), "phc_phm_build_H_batched")
+                ef = None
+                if encode is not None and ENCODE_FRONT and encode[0].device == dev and len(arr) > 0:
+                    idx, ts, tables = encode
+                    ts = ts.vector_form(tables)
+                    idx_ = _idx64(idx)
+                    if idx_.shape[1] == ts.F and lib.phc_encode_front_supported(idx_.shape[0], ts.F, ts.n, ts.k):
+                        enc_out = torch.empty((idx_.shape[0], ts.n * ts.k), dtype=torch.float32, device=dev)
+                        ef = L.EncodeFront(L.ptr(idx_), L.ptr(ts.ptrs), _C.cast(ts.vocab_c, _C.c_void_p), L.ptr(enc_out), idx_.shape[0],
+                                           ts.F, ts.n, ts.k)
+                        _PREBUILT.encoded = (idx_.data_ptr(), tuple(idx_.shape), ts.ptrs.data_ptr(), enc_out, idx_)
+                L.check(lib.phc_phm_build_H_batched_ex(arr, len(arr), _C.byref(ef) if ef is not None else None, L.stream_ptr(dev)),
+                        "phc_phm_build_H_batched")
+                if ef is not None and L.PROF_ON:
+                    L.account("encode_fwd", 0.0, idx_.shape[0] * (8.0 * ts.F + 4.0 * ts.n * ts.k) + 4.0 * ts.R * ts.n * ts.k)
         yield
     finally:
         _PREBUILT.table = {}
+        _PREBUILT.encoded = None
         if outer_step:
             _FLAT_STEP.packed = None
 
@@ -2135,12 +2166,17 @@ class _EncodeFn(torch.autograd.Function):
         N = idx_.shape[0]
         if idx_.shape[1] != ts.F:
             raise L.PhcError(f"index tensor has {idx_.shape[1]} features, encoder has {ts.F}")
-        out = torch.empty((N, ts.n * ts.k), dtype=torch.float32, device=dev)
-        L.check(lib.phc_encode_fwd(L.ptr(idx_), L.ptr(ts.ptrs), ts.vocab_c, N, ts.F, ts.n, ts.k, L.ptr(out), L.stream_ptr(dev)),
-                "phc_encode_fwd")
+        pre = _PREBUILT.encoded
+        if pre is not None and pre[0] == idx_.data_ptr() and pre[1] == tuple(idx_.shape) and pre[2] == ts.ptrs.data_ptr():
+            out = pre[3]                                     # evaluated by the step's operand-build launch (prebuilt_H(encode=...))
+            _PREBUILT.encoded = None                         # (one consumer: a second call would alias the first one's output)
+        else:
+            out = torch.empty((N, ts.n * ts.k), dtype=torch.float32, device=dev)
+            L.check(lib.phc_encode_fwd(L.ptr(idx_), L.ptr(ts.ptrs), ts.vocab_c, N, ts.F, ts.n, ts.k, L.ptr(out), L.stream_ptr(dev)),
+                    "phc_encode_fwd")
+            if L.PROF_ON:
+                L.account("encode_fwd", 0.0, N * (8.0 * ts.F + 4.0 * ts.n * ts.k) + 4.0 * ts.R * ts.n * ts.k)
         L.maybe_check_indices(dev)
-        if L.PROF_ON:
-            L.account("encode_fwd", 0.0, N * (8.0 * ts.F + 4.0 * ts.n * ts.k) + 4.0 * ts.R * ts.n * ts.k)
         ctx.ts = ts
         ctx.save_for_backward(idx_)
         ctx.defer_tables = tuple(tables) if (_DEFER.active and N > 0 and all(t.is_leaf and t.grad_fn is None for t in tables)) else None

@@ -71,3 +71,27 @@ def test_skip_gradient_shares_meet_in_the_first_aggregation_backward(workload):
     for k in on[1]:
         ref = off[1][k]
         assert float((on[1][k] - ref).abs().max()) <= 2e-6 * max(float(ref.abs().max()), 1e-30), k
+
+
+@pytest.mark.parametrize("workload", ["molhiv_b32", "zinc_small_last", "zinc_pub_phc4_4x180_nodrop"])
+def test_atom_encoder_inside_the_operand_build_launch_is_bit_identical(workload):
+    """phc_phm_build_H_batched_ex: the atom encoder as passenger workgroups of the step's first launch (the same table rows added in
+    the same order as phc_encode_fwd) — k % 4 != 0 models (flat table images) included."""
+    from phc_gnn_amd import harness
+    if workload == "zinc_small_last":
+        harness.WORKLOADS.setdefault("zinc_small_last", dict(dataset="zinc", batch_size=48, phm_dim=4, hidden=64, layers=3, d_units=[64, 32],
+                                                             target_dim=1, sc_type="last", regression=True))
+    _same(_step(workload, dict(ENCODE_FRONT=True)), _step(workload, dict(ENCODE_FRONT=False)))
+
+
+def test_atom_encoder_passenger_reports_bad_indices():
+    """An atom feature outside its vocabulary is read as row 0 and raises at the next check point, as in the stand-alone launch."""
+    from phc_gnn_amd import harness, lib
+    model = harness.build_model("molhiv_b32", DEV, seed=3).train()
+    data = harness.to_device(harness.make_batch("molhiv_b32", seed=11), DEV)
+    data.x = data.x.clone()
+    data.x[5, 0] = 100000
+    harness.train_step(model, data, None, harness.StepConfig(optimizer=False))
+    torch.cuda.synchronize()
+    with pytest.raises(IndexError):
+        lib.check_indices(torch.device(DEV))
