@@ -641,13 +641,14 @@ int phc_bn_bwd_from_partials(const float *dy, const float *x, const float *save_
                              float *dwb_flat, void *ws, size_t ws_bytes, void *stream);
 
 /* The step's tail in one pass: every parameter gradient of a model — PHM / dense layers (jobs, as for
- * phc_phm_param_grads; <= 16, matrices below 256 columns), the bond tables of all message-passing layers
+ * phc_phm_param_grads; <= 16), the bond tables of all message-passing layers
  * (tjobs, as for phc_table_grads_batched; <= 8) and the atom-encoder tables (atom_*, as phc_encode_bwd; N_atoms
  * = 0: none) — in three launches.  The first runs the latency-bound table-slab workgroups and the MFMA-bound
  * dH-slab workgroups SIDE BY SIDE (the former dispatched first, into the slots the latter leave free), the
  * second all slab reductions, the third the PHM contraction.  Results are identical to the separate entry
- * points (same workgroup bodies, same fixed summation order).  PHC_ERR_UNSUPPORTED when a job needs the
- * 128 x 128 tile path: use the separate entry points then.
+ * points (same workgroup bodies, same fixed summation order).  Layers of 256 columns and more (round 4) ride in the
+ * first launch as register-resident 128 x 64 tiles when their operand form allows it (widths multiples of 4, a plain
+ * or relu-normalised operand); the rest of them take one more launch of 128 x 128 LDS tiles in front.
  * Bond tables: bond_n_dst > 0 selects the counted form of phc_table_grads_counted (bond_rowptr / bond_codes, act
  * must be identity; bond_i64 / edge_* may be NULL), bond_n_dst = 0 the per-edge form of phc_table_grads_batched.
  * bond_counts (optional, counted form only): the code_counts of phc_csr_build_pair_codes — the bond tables then take

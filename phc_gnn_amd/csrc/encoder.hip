@@ -1373,7 +1373,7 @@ __global__ __launch_bounds__(256, 2) void tail_partial_kernel(GradBatch gb, Tail
     const long long xf_count = j.xf_stat ? (j.xf_n_valid ? min((long long)*j.xf_n_valid, j.N) : j.N) : 0;
     int tile;
     long long split;
-    xcd_tile_split(local, (unsigned)j.tiles, (unsigned)j.splits, tile, split);
+    xcd_tile_split(blockIdx.x, local, (unsigned)j.tiles, (unsigned)j.splits, tile, split);
     if (j.t128 == 3 && dh3_np(j.out) == 2)
         dH_direct_body<2>(j.x, j.dy, j.slabs, j.N, j.in, j.out, j.tiles_j, j.rows_per_split, tile, split, smem, j.xf_stat, j.xf_act,
                           xf_count);
@@ -2220,7 +2220,6 @@ static int step_tail_impl(const phc_phm_grad_job *jobs, int num_jobs, const phc_
     GradLaunch gl;
     rc = prepare_grad_launch("phc_step_tail", jobs, num_jobs, wsf, &gl, tail_direct_form(num_tjobs, N_atoms));
     if (rc) return rc;
-    PHC_REQUIRE(gl.nb_partial128 == 0, PHC_ERR_UNSUPPORTED, "phc_step_tail: 128 x 128 tile jobs take phc_phm_param_grads");
     wsf += phm_floats;
     TailTables t;
     memset(&t, 0, sizeof(t));
@@ -2293,6 +2292,8 @@ static int step_tail_impl(const phc_phm_grad_job *jobs, int num_jobs, const phc_
     const unsigned nb1 = t.nb_atom + t.nb_bond + gl.nb_partial, nb2 = t.nr_phm + t.nr_bond + t.nr_atom;
     rc = launch_grad_direct("step_tail(direct)", gl, s);     // the 128-multiple layers: register-resident tiles, their own launch
     if (rc) return rc;
+    rc = launch_grad_partial128("step_tail(128 x 128 LDS tiles)", gl, s);   // wide layers outside the register-resident form (e.g. a
+    if (rc) return rc;                                       // smooth activation folded into the operand): their own launch too
     if (nb1 > 0) {
         ProfScope prof(K_PHM_DH_PARTIAL, s);
         GradBatch b64 = gl.batch;                            // this launch takes the 64 x 64 tile jobs only

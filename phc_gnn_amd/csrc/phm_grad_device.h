@@ -586,18 +586,29 @@ struct GradBatch {
     GradJobDev j[GRAD_JOBS_PER_LAUNCH];
 };
 
-// XCD-aware (tile, split) of the `local`-th workgroup of a job: workgroups go to the 8 XCDs round-robin by block id, and
-// the tiles of one split read the same x / dy rows.  Inside every run of 8 * tiles ids the pairs are permuted so that the
-// tiles of one split sit 8 ids apart — on one XCD, whose L2 serves the re-reads (a trailing partial run keeps the plain order).
-__device__ __forceinline__ void xcd_tile_split(unsigned local, unsigned tiles, unsigned splits, int &tile, long long &split) {
-    const unsigned run = 8u * tiles, chunk = local / run, rem = local - chunk * run;
-    if (PHC_XCD_MAP && tiles > 1 && chunk * 8u + 8u <= splits) {
-        tile = (int)(rem >> 3);
-        split = chunk * 8u + (rem & 7u);
-    } else {
-        tile = (int)(local % tiles);
-        split = local / tiles;
+// XCD-aware (tile, split) of the `local`-th workgroup of a job whose workgroup has the launch-wide id `gid`: workgroups go to the
+// 8 XCDs round-robin by block id, and the tiles of one split read the same x / dy rows.  The job's workgroups that land on one XCD
+// (ids congruent mod 8) take a CONTIGUOUS range of the split-major order L = split * tiles + tile, so a split's tiles run on one
+// XCD (two where a range boundary cuts it) and its rows come from memory once, from that XCD's L2 afterwards — whatever the
+// number of splits (the first form of this map needed whole runs of 8 splits: six splits of 256-wide layers at 23 k rows had
+// every tile of a split on a different XCD and fetched the rows eight times).  Which workgroup computes a (tile, split) never
+// changes what is computed: results are bit-identical with the map on or off.
+__device__ __forceinline__ void xcd_tile_split(unsigned gid, unsigned local, unsigned tiles, unsigned splits, int &tile, long long &split) {
+    const unsigned C = tiles * splits;
+    unsigned L = local;
+    if (PHC_XCD_MAP && tiles > 1 && C >= 16u) {
+        const unsigned base = gid - local, x = gid & 7u;
+        unsigned before = 0;
+#pragma unroll
+        for (unsigned xp = 0; xp < 8u; ++xp) {
+            const unsigned f = (xp - base) & 7u;                 // the job's first workgroup on XCD xp
+            const unsigned cnt = f < C ? (C - f + 7u) >> 3 : 0u;
+            before += xp < x ? cnt : 0u;
+        }
+        L = before + ((local - ((x - base) & 7u)) >> 3);
     }
+    tile = (int)(L % tiles);
+    split = L / tiles;
 }
 
 // ---- the explicit weight regulariser inside the step tail (regularization.py:15-23, train_hiv.py:181-196) ----
@@ -693,6 +704,7 @@ size_t grad_chunk_ws_floats(const phc_phm_grad_job *jobs, int num_jobs, int dire
 int prepare_grad_launch(const char *who, const phc_phm_grad_job *jobs, int num_jobs, float *ws_base, GradLaunch *out, int direct_form = 2);
 int launch_grad_rest(const char *who, const GradLaunch &gl, bool partial64_too, hipStream_t s);
 int launch_grad_contract(const char *who, const GradLaunch &gl, hipStream_t s);
+int launch_grad_partial128(const char *who, const GradLaunch &gl, hipStream_t s);    // the t128 == 1 jobs of a prepared batch, if any
 // the tail's last launch with the gate map's parameter gradients (gate != NULL, see GateGradHost) and the weight regulariser's
 // value (reg != NULL) riding in it as extra workgroups
 struct GateGradHost {

@@ -1105,7 +1105,7 @@ __global__ __launch_bounds__(256) void phm_grads_partial_kernel(GradBatch b) {
     const unsigned local = blockIdx.x - j.blk0_partial;
     int tile;
     long long split;
-    xcd_tile_split(local, (unsigned)j.tiles, (unsigned)j.splits, tile, split);
+    xcd_tile_split(blockIdx.x, local, (unsigned)j.tiles, (unsigned)j.splits, tile, split);
     __shared__ __attribute__((aligned(16))) float smem[2 * DH_RB * DH_STRIDE];      // 32 KB, either tile shape
     static_assert(2 * DH_RB * DH_STRIDE == 2 * DH_RB2 * DH_T2, "both tile shapes stage 32 KB");
     const long long xf_count = j.xf_stat ? (j.xf_n_valid ? min((long long)*j.xf_n_valid, j.N) : j.N) : 0;
@@ -1127,7 +1127,7 @@ __global__ __launch_bounds__(256) void phm_grads_direct_kernel(GradBatch b) {
     const unsigned local = blockIdx.x - j.blk0_partial;
     int tile;
     long long split;
-    xcd_tile_split(local, (unsigned)j.tiles, (unsigned)j.splits, tile, split);
+    xcd_tile_split(blockIdx.x, local, (unsigned)j.tiles, (unsigned)j.splits, tile, split);
     const long long xf_count = j.xf_stat ? (j.xf_n_valid ? min((long long)*j.xf_n_valid, j.N) : j.N) : 0;
     dH_direct_body<4>(j.x, j.dy, j.slabs, j.N, j.in, j.out, j.tiles_j, j.rows_per_split, tile, split, direct_smem, j.xf_stat, j.xf_act,
                    xf_count);
@@ -1767,6 +1767,16 @@ int launch_grad_direct(const char *who, const GradLaunch &gl, hipStream_t s, boo
     } else {
         PHC_LAUNCH(phm_grads_direct_kernel, dim3(gl.nb_direct), dim3(256), DH_DIRECT_LDS_BYTES, s, bs);
     }
+    return check_launch(who);
+}
+
+int launch_grad_partial128(const char *who, const GradLaunch &gl, hipStream_t s) {
+    if (gl.nb_partial128 == 0) return PHC_OK;
+    GradBatch bs = gl.batch;                                 // jobs of the other tile forms are masked out
+    for (int k = 0; k < bs.num; ++k)
+        if (bs.j[k].t128 != 1) bs.j[k].blk0_partial = 0xffffffffu;
+    ProfScope prof(K_PHM_DH_PARTIAL, s);
+    PHC_LAUNCH(phm_grads_partial_kernel<1>, dim3(gl.nb_partial128), dim3(256), 0, s, bs);
     return check_launch(who);
 }
 

@@ -104,6 +104,9 @@ def deferred_param_grads():
 
 # the explicit weight regulariser and the gate map's parameter gradients inside the step tail's last two launches
 TAIL_EXTRAS = __import__("os").environ.get("PHC_TAIL_EXTRAS", "1") != "0"
+# 256-wide layers inside the fused step tail (register-resident 128 x 64 tiles beside the table-gradient workgroups, regulariser and
+# gate-map gradients as passengers) instead of phc_phm_param_grads + separate table / regulariser / gate launches
+TAIL_WIDE = __import__("os").environ.get("PHC_TAIL_WIDE", "1") != "0"
 
 
 def request_weight_regulariser(Ws, coef: float, p: int, loss: Optional[torch.Tensor]) -> bool:
@@ -207,7 +210,7 @@ def _flush_step_tail(jobs, tjobs, ajobs, reg=None) -> bool:
         return False
     for jb in jobs:                                         # 128 x 128 tile jobs go through phc_phm_param_grads
         n, kin, kout = _job_dims(jb)
-        if jb["x"].shape[0] >= 65536 or (n * kin >= 256 and n * kout >= 256):
+        if jb["x"].shape[0] >= 65536 or (n * kin >= 256 and n * kout >= 256 and not TAIL_WIDE):
             return False
     keys = {tj["key"] for tj in tjobs}
     if len(keys) > 1 or len(tjobs) > 8:
