@@ -631,6 +631,49 @@ int phc_debug_hs_stamps(unsigned long long *dev_words);
  * phc_gemm_hs_set_enabled returns the previous setting. */
 int phc_gemm_hs_enabled(void);
 int phc_gemm_hs_set_enabled(int on);
+
+/* The layer's sum aggregation INSIDE its first GEMM (ABI 5, molecule batches).  One launch computes
+ *     s[d] = sum_{e: dst_e = d} (x[src_e] + sum_f table_{c,f}[code_f(e)]) (+ x[d])     messagepassing.py:132-146 (GINE, identity
+ *                                                                                      message function), encoder.py:31-34
+ *     y    = s . M + b  and the column statistics of y (accumulator form)             layers.py:198-219, 349-355; norm.py:30-35
+ * where x is either a tensor (norm_acc = NULL) or the layer in front's  act(batch_norm(x_in)) (+ skip)  that has not been applied
+ * yet (norm_acc = the accumulator its producing GEMM filled; models.py:208-215): the launch then derives scale / shift in its
+ * prologue, applies them to every row it gathers, writes x_out once and leaves save_stat / the running statistics behind — what
+ * phc_aggregate_norm_encp_fwd does.  The workgroup that owns a 16-row step of the GEMM builds the step's rows itself (row-per-lane-
+ * group walk, same edge order and additions as phc_aggregate_encp_fwd: s is bit-identical), writes s out once (the parameter-
+ * gradient GEMM reads it) and multiplies from LDS; y and the accumulator are what phc_gemm_prebuilt_stats produces from that s.
+ * Two launches (three with the stand-alone norm pass) become one.  h = Nout = 128, k % 4 == 0, F <= 4, sum(vocab) <= 256, codes as
+ * written by phc_csr_build_pair_codes / phc_pack_edge_codes, 16-byte aligned rows (phc_gemm_aggregate_supported); otherwise
+ * PHC_ERR_UNSUPPORTED and the caller runs the separate entry points. */
+typedef struct phc_gemm_ag_desc {
+    const float *x;                /* [N, h]: the gathered tensor, or (norm_acc != NULL) the pending norm's input            */
+    const uint32_t *codes;         /* [E] packed bond codes in destination-sorted order                                      */
+    const float *const *tables;    /* device array [n * F] of table pointers                                                 */
+    const int32_t *vocab;          /* host [F]                                                                               */
+    const int32_t *rowptr, *col;   /* destination-sorted view                                                                */
+    int64_t N;                     /* rows (= destinations = sources)                                                        */
+    int32_t F, n, k, add_self;
+    float *s_out;                  /* [N, h] out: the aggregate                                                              */
+    /* pending norm (all ignored when norm_acc == NULL) */
+    const uint64_t *norm_acc;
+    const float *const *weight, *const *bias;
+    float *const *running_mean, *const *running_var;
+    int64_t *const *num_batches_tracked;
+    int32_t n_comp, norm_act;
+    float momentum, eps;
+    const float *skip;             /* [N, h] or NULL                                                                         */
+    float *save_stat;              /* [6 h] out                                                                              */
+    float *x_out;                  /* [N, h] out: the normalised rows                                                        */
+    /* GEMM with the statistics epilogue */
+    const float *Mk4;              /* [h, Nout] operand, k4 form                                                             */
+    const float *b;                /* [Nout] or NULL                                                                         */
+    int32_t Nout;
+    float *y;                      /* [N, Nout] out                                                                          */
+    const int32_t *n_valid_dev;    /* device scalar or NULL: rows below it count for both norms' statistics                  */
+    uint64_t *stat_acc;            /* accumulator of width Nout (zeroed by the caller)                                       */
+} phc_gemm_ag_desc;
+int phc_gemm_aggregate_supported(int64_t N, int h, int Nout, int F, int vocab_rows);
+int phc_gemm_aggregate_stats(const phc_gemm_ag_desc *d, void *stream);
 int phc_gemm_bwd_apply(const phc_gemm_ba_desc *d, void *stream);
 /* The sums pass alone: adds sum g | sum g x_hat of (dy, x, save_stat) over the rows below *n_valid_dev into `acc` (width h,
  * zeroed by the caller; h % 4 == 0, h <= 8192, 16-byte aligned rows) — phc_bn_bwd's first launch without its second. */

@@ -50,7 +50,7 @@ class _SumConvBase(nn.Module):
         return _engine.aggregate_sum(x, edge_index, edge_attr, self.msg_encoder_str, add_self, num_dst)
 
     def propagate_encoded(self, edge_index: Adj, x: torch.Tensor, edge_idx: torch.Tensor, encoder, size: Size = None,
-                          add_self: bool = False, dx_handoff=None, pending=None) -> torch.Tensor:
+                          add_self: bool = False, dx_handoff=None, pending=None, lazy: bool = False) -> torch.Tensor:
         """Same as ``propagate`` with edge_attr = encoder(edge_idx), evaluated inside the
         aggregation kernel from LDS-staged embedding tables (no [E, h] tensor).  ``dx_handoff`` (engine: DxHandoff): another
         consumer of ``x`` may park its gradient there; this op's backward then adds it inside its own dx kernel."""
@@ -59,7 +59,7 @@ class _SumConvBase(nn.Module):
         # pending (engine: PendingNorm): x = act(norm(y)) (+ skip) of the layer in front has not been evaluated yet; the
         # aggregation kernel does it on the fly (or runs the stand-alone pass first where it cannot)
         return _engine.aggregate_sum_encoded(x, edge_index, edge_idx, _engine.tableset_for(encoder, tables), tables,
-                                             self.msg_encoder_str, add_self, num_dst, dx_handoff=dx_handoff, pending=pending)
+                                             self.msg_encoder_str, add_self, num_dst, dx_handoff=dx_handoff, pending=pending, lazy=lazy)
 
     def message(self, x_j: torch.Tensor, edge_attr: torch.Tensor) -> torch.Tensor:
         """Per-edge message (API parity; the engine fuses this into the aggregation)."""

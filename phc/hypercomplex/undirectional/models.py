@@ -166,10 +166,16 @@ class PHMSkipConnectAdd(nn.Module):
                 agg_handoff = skip_sum if first_layer else None
                 handoff = skip_sum
             if edge_encoder is not None:
+                # lazy: the aggregate goes straight into the fused node below, whose first GEMM may build the rows itself
+                # (engine: PendingAggregate; mlp_norm_fused launches the aggregation on its own when it does not apply)
+                lazy = type(tr).__name__ == "PHMGINEConv"
                 if pending is not None:
                     agg = tr.propagate_encoded(edge_index, x[0], edge_attr, edge_encoder, size, add_self=tr.add_self_loops,
-                                               dx_handoff=agg_handoff, pending=pending)
-                    x[0]._phc_pending = None                 # evaluated (or materialised) by that call
+                                               dx_handoff=agg_handoff, pending=pending, lazy=lazy)
+                    x[0]._phc_pending = None                 # evaluated (or materialised) by that call, or riding with the aggregate
+                elif lazy:
+                    agg = tr.propagate_encoded(edge_index, x[0], edge_attr, edge_encoder, size, add_self=tr.add_self_loops,
+                                               dx_handoff=agg_handoff, lazy=True)
                 else:
                     agg = tr.propagate_encoded(edge_index, x[0], edge_attr, edge_encoder, size, add_self=tr.add_self_loops,
                                                dx_handoff=agg_handoff)

@@ -34,7 +34,7 @@ static const char *const kKernelNames[K_NUM_KERNELS] = {
     "bn_stats_partial", "bn_finalize", "bn_apply", "bn_bwd_partial", "bn_bwd_finalize", "bn_bwd_apply",
     "pack_edge_codes", "aggregate_softmax_fwd", "aggregate_softmax_bwd",
     "bce_masked_fwd", "bce_masked_bwd", "gated_pool_fwd", "gated_pool_bwd", "clip_adam", "small_linear", "sum_n",
-    "downstream_fwd", "downstream_bwd",
+    "downstream_fwd", "downstream_bwd", "phm_gemm_ag_fwd",
 };
 
 // ---- profiler ------------------------------------------------------------------

@@ -306,23 +306,19 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
                 const double S = tq[0], Q = tq[1];
                 const int comp = col / xa.p.k, kk = col - comp * xa.p.k;
                 const float w = xf_w, bq = xf_b;
-                const double cntd = (double)max(n_valid, 1LL);
-                const double meand = S / cntd, vard = fmax(Q / cntd - meand * meand, 0.0);
-                const float mean = (float)meand, var = (float)vard;
-                const float invstd = 1.f / sqrtf(var + xa.eps);
-                xf_lds[col] = invstd * w;
-                xf_lds[K + col] = bq - mean * invstd * w;
+                const BnFromTotals bt = bn_from_totals(S, Q, n_valid, w, bq, xa.eps);
+                xf_lds[col] = bt.scale;
+                xf_lds[K + col] = bt.shift;
                 if (owner) {
                     float *st = xa.stat_out;
-                    st[col] = mean; st[KR + col] = invstd; st[2 * KR + col] = invstd * w; st[3 * KR + col] = bq - mean * invstd * w;
+                    st[col] = bt.mean; st[KR + col] = bt.invstd; st[2 * KR + col] = bt.scale; st[3 * KR + col] = bt.shift;
                     st[4 * KR + col] = w; st[5 * KR + col] = bq;
                     if (xa.p.has_running) {
-                        const float unbiased = n_valid > 1 ? (float)(vard * cntd / (cntd - 1.0)) : var;
                         for (int q = 0; q < xa.p.n_comp; ++q)
                             if (q == comp) {
                                 float *rm = xa.p.running_mean[q] + kk, *rv = xa.p.running_var[q] + kk;
-                                *rm = (1.f - xa.momentum) * *rm + xa.momentum * mean;
-                                *rv = (1.f - xa.momentum) * *rv + xa.momentum * unbiased;
+                                *rm = bn_running_update(*rm, xa.momentum, bt.mean);
+                                *rv = bn_running_update(*rv, xa.momentum, bt.unbiased);
                             }
                     }
                 }

@@ -477,26 +477,21 @@ __global__ __launch_bounds__(BN_THREADS) void bn_apply_acc_kernel(const float *_
             S += r_d[rp][ci];
             Q += r_d[STAT_ACC_REP + rp][ci];
         }
-        const double cntd = (double)max(count, 1LL);
-        const double meand = S / cntd;
-        const double vard = fmax(Q / cntd - meand * meand, 0.0);
-        const float mean = (float)meand, var = (float)vard;
-        const float invstd = 1.f / sqrtf(var + eps);
-        s_scale[ci] = invstd * w;
-        s_shift[ci] = bq - mean * invstd * w;
+        const BnFromTotals bt = bn_from_totals(S, Q, count, w, bq, eps);
+        s_scale[ci] = bt.scale;
+        s_shift[ci] = bt.shift;
         if (blockIdx.y == 0 && c_ok) {
-            stat[c] = mean;
-            stat[h + c] = invstd;
-            stat[2 * h + c] = invstd * w;
-            stat[3 * h + c] = bq - mean * invstd * w;
+            stat[c] = bt.mean;
+            stat[h + c] = bt.invstd;
+            stat[2 * h + c] = bt.scale;
+            stat[3 * h + c] = bt.shift;
             stat[4 * h + c] = w;
             stat[5 * h + c] = bq;
             if (p.has_running) {
-                const float unbiased = count > 1 ? (float)(vard * cntd / (cntd - 1.0)) : var;
                 for (int q = 0; q < p.n_comp; ++q)
                     if (q == comp) {
-                        p.running_mean[q][kk] = (1.f - momentum) * rm_old + momentum * mean;
-                        p.running_var[q][kk] = (1.f - momentum) * rv_old + momentum * unbiased;
+                        p.running_mean[q][kk] = bn_running_update(rm_old, momentum, bt.mean);
+                        p.running_var[q][kk] = bn_running_update(rv_old, momentum, bt.unbiased);
                     }
             }
         }

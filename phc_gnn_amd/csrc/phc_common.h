@@ -95,6 +95,7 @@ enum KernelId : int {
     K_SUM_N,
     K_DOWNSTREAM_FWD,
     K_DOWNSTREAM_BWD,
+    K_PHM_GEMM_AG,
     K_NUM_KERNELS
 };
 
@@ -223,6 +224,33 @@ __device__ __forceinline__ double stat_acc_total(const unsigned long long *__res
         lo += (long long)p[h];
     }
     return (double)hi * (1.0 / 4096.0) + (double)lo * (1.0 / 4611686018427387904.0);
+}
+
+// Norm constants from a column's accumulator totals (S = sum x, Q = sum x^2 over `count` rows; norm.py:30-35 forward, training mode).
+// ONE definition for every kernel that derives them in its prologue (bn_apply_acc_kernel, the normalising-operand GEMMs, the
+// aggregations that apply a pending norm): several tests and the step's A/B switches rely on those kernels producing the SAME bits,
+// and with -ffp-contract=fast the compiler is free to fuse  b - mean * invstd * w  or  (1 - m) * old + m * new  differently in
+// different kernels (seen: the running variance one ulp apart).  Contraction is off inside.
+struct BnFromTotals {
+    float mean, invstd, scale, shift, unbiased;
+};
+__device__ __forceinline__ BnFromTotals bn_from_totals(double S, double Q, long long count, float w, float b, float eps) {
+#pragma clang fp contract(off)
+    BnFromTotals r;
+    const double cntd = (double)(count > 1 ? count : 1);
+    const double meand = S / cntd;
+    const double vard = fmax(Q / cntd - meand * meand, 0.0);
+    const float var = (float)vard;
+    r.mean = (float)meand;
+    r.invstd = 1.f / sqrtf(var + eps);
+    r.scale = r.invstd * w;
+    r.shift = b - r.mean * r.invstd * w;
+    r.unbiased = count > 1 ? (float)(vard * cntd / (cntd - 1.0)) : var;
+    return r;
+}
+__device__ __forceinline__ float bn_running_update(float old, float momentum, float value) {
+#pragma clang fp contract(off)
+    return (1.f - momentum) * old + momentum * value;
 }
 
 // hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute: one bit per device ordinal and kernel instantiation

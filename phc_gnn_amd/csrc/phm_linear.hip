@@ -20,6 +20,7 @@
 #include "phc_common.h"
 #include "phm_grad_device.h"
 #include "gemm_hs_device.h"
+#include "gemm_hs_ag_device.h"
 #include <vector>
 
 namespace phc {
@@ -511,25 +512,21 @@ __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
             const bool owner = pbx == 0 && pby == 0;
             const int c = tid;
             if (c < K) {
-                const double cntd = (double)max(xf_count, 1LL);
-                const double meand = xa_S / cntd, vard = fmax(xa_Q / cntd - meand * meand, 0.0);
                 const float w = xa_w, bq = xa_b;
-                const float mean = (float)meand, var = (float)vard;
-                const float invstd = 1.f / sqrtf(var + xa.eps);
-                xf_lds[c] = invstd * w;
-                xf_lds[K + c] = bq - mean * invstd * w;
+                const BnFromTotals bt = bn_from_totals(xa_S, xa_Q, xf_count, w, bq, xa.eps);
+                xf_lds[c] = bt.scale;
+                xf_lds[K + c] = bt.shift;
                 if (owner) {
                     float *st = xa.stat_out;
-                    st[c] = mean; st[K + c] = invstd; st[2 * K + c] = invstd * w; st[3 * K + c] = bq - mean * invstd * w;
+                    st[c] = bt.mean; st[K + c] = bt.invstd; st[2 * K + c] = bt.scale; st[3 * K + c] = bt.shift;
                     st[4 * K + c] = w; st[5 * K + c] = bq;
                     if (xa.p.has_running) {
-                        const float unbiased = xf_count > 1 ? (float)(vard * cntd / (cntd - 1.0)) : var;
                         const int comp = c / xa.p.k, kk = c - comp * xa.p.k;
                         for (int q = 0; q < xa.p.n_comp; ++q)
                             if (q == comp) {
                                 float *rm = xa.p.running_mean[q] + kk, *rv = xa.p.running_var[q] + kk;
-                                *rm = (1.f - xa.momentum) * *rm + xa.momentum * mean;
-                                *rv = (1.f - xa.momentum) * *rv + xa.momentum * unbiased;
+                                *rm = bn_running_update(*rm, xa.momentum, bt.mean);
+                                *rv = bn_running_update(*rv, xa.momentum, bt.unbiased);
                             }
                     }
                 }
@@ -2289,6 +2286,84 @@ int phc_gemm_prebuilt_bwsums(const float *dy, const float *M, const float *Mk4, 
 
 // The norm backward's element-wise pass folded into the dx GEMM behind it (HS_BA), optionally with the sums epilogue of the
 // norm in front of that GEMM (HS_BW): see include/phc_hip.h.
+int phc_gemm_aggregate_supported(int64_t N, int h, int Nout, int F, int vocab_rows) {
+    static const bool off = getenv("PHC_GEMM_AGGREGATE") && atoi(getenv("PHC_GEMM_AGGREGATE")) == 0;
+    return (!off && hs_enabled() && N >= 1 && N <= (1 << 20) && h == 128 && Nout == 128 && F >= 1 && F <= HS_AG_MAX_F && vocab_rows >= 1 &&
+            vocab_rows <= HS_AG_MAX_ROWS) ? 1 : 0;
+}
+
+int phc_gemm_aggregate_stats(const phc_gemm_ag_desc *d, void *stream) {
+    PHC_REQUIRE(d, PHC_ERR_INVALID_ARG, "phc_gemm_aggregate_stats: null descriptor");
+    PHC_REQUIRE(d->n >= 1 && d->k >= 1 && d->vocab && d->F >= 1 && d->F <= HS_AG_MAX_F, PHC_ERR_INVALID_ARG,
+                "phc_gemm_aggregate_stats: bad shape (n %d, k %d, F %d)", d->n, d->k, d->F);
+    const int h = d->n * d->k;
+    HsAgArgs ag = {};
+    ag.F = d->F;
+    ag.off[0] = 0;
+    for (int f = 0; f < d->F; ++f) {
+        PHC_REQUIRE(d->vocab[f] >= 1, PHC_ERR_INVALID_ARG, "phc_gemm_aggregate_stats: vocab[%d] = %d", f, d->vocab[f]);
+        ag.off[f + 1] = ag.off[f] + d->vocab[f];
+    }
+    PHC_REQUIRE(phc_gemm_aggregate_supported(d->N, h, d->Nout, d->F, ag.off[d->F]) && d->k % 4 == 0 && d->n * d->F <= PHC_MAX_COMPONENTS * 4,
+                PHC_ERR_UNSUPPORTED, "phc_gemm_aggregate_stats: %lld rows, h = %d, Nout = %d, F = %d, sum(vocab) = %d outside the fused form's range",
+                (long long)d->N, h, d->Nout, d->F, ag.off[d->F]);
+    PHC_REQUIRE(d->x && d->codes && d->tables && d->rowptr && d->col && d->s_out && d->Mk4 && d->y && d->stat_acc, PHC_ERR_INVALID_ARG,
+                "phc_gemm_aggregate_stats: null pointer");
+    const bool normed = d->norm_acc != nullptr;
+    PHC_REQUIRE(!normed || (d->save_stat && d->x_out), PHC_ERR_INVALID_ARG, "phc_gemm_aggregate_stats: a pending norm needs save_stat and x_out");
+    PHC_REQUIRE(!normed || (d->norm_act >= PHC_ACT_IDENTITY && d->norm_act <= PHC_ACT_SELU), PHC_ERR_INVALID_ARG,
+                "phc_gemm_aggregate_stats: unknown activation %d", d->norm_act);
+    PHC_REQUIRE(((reinterpret_cast<uintptr_t>(d->x) | reinterpret_cast<uintptr_t>(d->s_out) | reinterpret_cast<uintptr_t>(d->Mk4) |
+                  reinterpret_cast<uintptr_t>(d->y) | reinterpret_cast<uintptr_t>(d->b) |
+                  (normed ? (reinterpret_cast<uintptr_t>(d->x_out) | reinterpret_cast<uintptr_t>(d->skip)) : 0)) & 15) == 0 &&
+                    ((reinterpret_cast<uintptr_t>(d->stat_acc) | reinterpret_cast<uintptr_t>(d->norm_acc)) & 7) == 0,
+                PHC_ERR_UNSUPPORTED, "phc_gemm_aggregate_stats: 16-byte aligned rows / 8-byte aligned accumulators");
+    if (normed) {
+        int rc = fill_params("phc_gemm_aggregate_stats", &ag.p, d->weight, d->bias, d->running_mean, d->running_var, d->num_batches_tracked,
+                             d->n_comp, h);
+        if (rc) return rc;
+        ag.acc = reinterpret_cast<const unsigned long long *>(d->norm_acc);
+        ag.skip = d->skip; ag.x_out = d->x_out; ag.stat = d->save_stat;
+        ag.momentum = d->momentum; ag.eps = d->eps; ag.norm_act = d->norm_act;
+    }
+    ag.y = d->x; ag.codes = d->codes; ag.tables = d->tables; ag.rowptr = d->rowptr; ag.col = d->col;
+    ag.s_out = d->s_out; ag.n = d->n; ag.k = d->k; ag.add_self = d->add_self ? 1 : 0;
+    GemmHsArgs a = hs_args(nullptr, d->Mk4, d->b, nullptr, d->y, d->N, h, d->Nout);
+    a.n_valid = d->n_valid_dev;
+    a.stat_acc = reinterpret_cast<unsigned long long *>(d->stat_acc);
+    a.panels = 1;
+    // workgroups: as many as the statistics-epilogue GEMM on the same rows takes (two per CU) — a workgroup's steps, and with them
+    // the partial sums it adds to the accumulator, are then the same sets of rows: the totals are bit-identical to that launch's
+    static const int per_cu_env = getenv("PHC_HS_AG_GROUPS_PER_CU") ? atoi(getenv("PHC_HS_AG_GROUPS_PER_CU")) : 0;
+    const long long steps = (d->N + 15) / 16;
+    long long groups = (long long)(per_cu_env > 0 ? per_cu_env : 2) * num_cu();
+    if (groups > steps) groups = steps;
+    a.groups = (int)groups;
+    hipStream_t s = (hipStream_t)stream;
+    const size_t tbl_bytes = (size_t)(128 + ag.off[d->F]) * 128 * sizeof(float);     // the operand (k4 form) + the bond tables in LDS
+    ProfScope prof(K_PHM_GEMM_AG, s);
+#define PHC_AG_LAUNCH1(FC, NC)                                                                                                     \
+    do {                                                                                                                           \
+        PHC_REQUIRE(ensure_dynamic_lds(&gemm_hs_ag_kernel<FC, NC>, (128 + HS_AG_MAX_ROWS) * 128 * sizeof(float)), PHC_ERR_LAUNCH,  \
+                    "phc_gemm_aggregate_stats: the device refused the dynamic LDS");                                              \
+        PHC_LAUNCH((gemm_hs_ag_kernel<FC, NC>), dim3((unsigned)groups), dim3(HS_AG_THREADS), tbl_bytes, s, a, ag);                \
+    } while (0)
+#define PHC_AG_LAUNCH(FC)             \
+    if (normed)                       \
+        PHC_AG_LAUNCH1(FC, true);     \
+    else                              \
+        PHC_AG_LAUNCH1(FC, false)
+    switch (d->F) {
+        case 1: PHC_AG_LAUNCH(1); break;
+        case 2: PHC_AG_LAUNCH(2); break;
+        case 3: PHC_AG_LAUNCH(3); break;
+        default: PHC_AG_LAUNCH(4); break;
+    }
+#undef PHC_AG_LAUNCH
+#undef PHC_AG_LAUNCH1
+    return check_launch("phc_gemm_aggregate_stats");
+}
+
 int phc_gemm_hs_enabled(void) { return hs_enabled() ? 1 : 0; }
 int phc_gemm_hs_set_enabled(int on) {
     const int prev = hs_enabled() ? 1 : 0;

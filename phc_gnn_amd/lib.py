@@ -69,6 +69,16 @@ class GemmBaDesc(C.Structure):
                 ("bw_x", _P), ("bw_stat", _P), ("bw_sums_acc", _P), ("count", _L)]
 
 
+class GemmAgDesc(C.Structure):
+    """phc_gemm_ag_desc (include/phc_hip.h)."""
+    _fields_ = [("x", _P), ("codes", _P), ("tables", _P), ("vocab", _P), ("rowptr", _P), ("col", _P), ("N", _L),
+                ("F", C.c_int32), ("n", C.c_int32), ("k", C.c_int32), ("add_self", C.c_int32), ("s_out", _P),
+                ("norm_acc", _P), ("weight", _P), ("bias", _P), ("running_mean", _P), ("running_var", _P), ("num_batches_tracked", _P),
+                ("n_comp", C.c_int32), ("norm_act", C.c_int32), ("momentum", C.c_float), ("eps", C.c_float),
+                ("skip", _P), ("save_stat", _P), ("x_out", _P),
+                ("Mk4", _P), ("b", _P), ("Nout", C.c_int32), ("y", _P), ("n_valid_dev", _P), ("stat_acc", _P)]
+
+
 class EncodeFront(C.Structure):
     """phc_encode_front (include/phc_hip.h)."""
     _fields_ = [("idx_i64", _P), ("tables", _P), ("vocab", _P), ("out", _P), ("N", _L), ("F", C.c_int32), ("n", C.c_int32), ("k", C.c_int32)]
@@ -127,6 +137,8 @@ SIGNATURES = {
     "phc_gemm_hs_enabled": (_I, []),
     "phc_gemm_hs_set_enabled": (_I, [_I]),
     "phc_gemm_bwd_apply": (_I, [C.POINTER(GemmBaDesc), _P]),
+    "phc_gemm_aggregate_supported": (_I, [_L, _I, _I, _I, _I]),
+    "phc_gemm_aggregate_stats": (_I, [C.POINTER(GemmAgDesc), _P]),
     "phc_bn_bwd_partial_acc": (_I, [_P, _P, _P, _P, _L, _I, _I, _P, _P]),
     "phc_bn_bwd_from_partials": (_I, [_P, _P, _P, _P, _I, _P, _L, _I, _I, _P, _P, _P, _S, _P]),
     "phc_phm_param_grads_ws_bytes": (_S, [C.POINTER(GradJob), _I]),

@@ -2216,7 +2216,7 @@ def encode(idx: torch.Tensor, ts: TableSet, tables) -> torch.Tensor:
 
 class _AggregateEncFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, bond_idx, st: EdgeStructure, act: int, add_self: bool, ts: TableSet, dx_handoff, pending, *tables):
+    def forward(ctx, x, bond_idx, st: EdgeStructure, act: int, add_self: bool, ts: TableSet, dx_handoff, pending, lazy_box, *tables):
         lib = L.load()
         ctx.dx_handoff = dx_handoff
         if dx_handoff is not None:
@@ -2241,7 +2241,17 @@ class _AggregateEncFn(torch.autograd.Function):
         rowptr, col, perm = st.csr
         out = torch.empty((st.num_dst, h), dtype=torch.float32, device=dev)
         ctx.codes = None
-        if fuse_norm:
+        # `lazy_box` (a dict): the caller feeds this aggregate straight into the fused MLP + norm node — when the shapes allow it
+        # nothing is launched here: the node's first GEMM builds the rows itself (phc_gemm_aggregate_stats) and writes `out` on the
+        # way; anybody else who reads `out` first calls PendingAggregate.materialize (the launch that would have run here)
+        lazy = lazy_box is not None and GEMM_AGGREGATE and act == 0 and x_.is_contiguous() and x_.shape[0] == st.num_src == st.num_dst and \
+            x_.shape[0] * h <= NORM_INTO_AGGREGATE_MAX_WORK and x_.data_ptr() % 16 == 0 and ts.k % 4 == 0 and \
+            (pending is None or pending.done or fuse_norm) and bool(lib.phc_gemm_aggregate_supported(st.num_dst, h, h, ts.F, ts.R))
+        if lazy:
+            codes = st.packed_codes(bond_, ts.vocab_c, ts.F)
+            ctx.codes = codes
+            lazy_box["pa"] = PendingAggregate(x_, codes, ts, st, add_self, out, pending if fuse_norm else None)
+        elif fuse_norm:
             codes = st.packed_codes(bond_, ts.vocab_c, ts.F)
             ctx.codes = codes
             pending.run_fused(x_, codes, ts, rowptr, col, st.num_dst, add_self, out)
@@ -2255,7 +2265,7 @@ class _AggregateEncFn(torch.autograd.Function):
             L.check(lib.phc_aggregate_enc_fwd(L.ptr(x_), L.ptr(bond_), L.ptr(ts.ptrs), ts.vocab_c, L.ptr(rowptr), L.ptr(col),
                                               L.ptr(perm), st.num_dst, ts.F, ts.n, ts.k, act, 1 if add_self else 0, L.ptr(out),
                                               L.stream_ptr(dev)), "phc_aggregate_enc_fwd")
-        if L.PROF_ON:
+        if L.PROF_ON and not lazy:
             E, N = st.num_edges, st.num_dst
             L.account("aggregate_enc_fwd", 2.0 * E * h,
                       E * (4.0 * h + 4 + 4 + 8.0 * ts.F) + N * 4.0 * h * (2 if add_self else 1) + 4.0 * (N + 1))
@@ -2277,7 +2287,7 @@ class _AggregateEncFn(torch.autograd.Function):
         dev = dout_.device
         h = dout_.shape[1]
         need_x = ctx.needs_input_grad[0]
-        need_t = any(ctx.needs_input_grad[8:])
+        need_t = any(ctx.needs_input_grad[9:])
         # the skip connection's share of dx (DxHandoff, parked by the layer's fused MLP + norm node)
         extra = ctx.dx_handoff.take() if ctx.dx_handoff is not None else None
         extras = extra if isinstance(extra, list) else ([extra] if extra is not None else [])    # DxSumHandoff parks several
@@ -2310,7 +2320,7 @@ class _AggregateEncFn(torch.autograd.Function):
         ws_bytes = 0
         deferred = need_t and ctx.defer_tables is not None and _DEFER.active and not torch.is_grad_enabled()
         if deferred:
-            params = [t if ng else None for t, ng in zip(ctx.defer_tables, ctx.needs_input_grad[8:])]
+            params = [t if ng else None for t, ng in zip(ctx.defer_tables, ctx.needs_input_grad[9:])]
             with _DEFER.lock:
                 _DEFER.table_jobs.append(dict(
                     key=(bond_.data_ptr(), st._src.data_ptr(), st._dst.data_ptr(), st.num_edges, ts.F, ts.n, ts.k, tuple(ts.vocab),
@@ -2337,14 +2347,15 @@ class _AggregateEncFn(torch.autograd.Function):
             if need_t and not deferred:
                 L.account("table_grad", 1.0 * E * ts.F * h, Nd * 4.0 * h + E * (4.0 + 8.0 * ts.F) + 4.0 * (Nd + 1))
         grads = ts.grad_views(flat) if (need_t and not deferred) else [None] * ts.num_tables
-        return (dx, None, None, None, None, None, None, None, *grads)
+        return (dx, None, None, None, None, None, None, None, None, *grads)
 
 
 def aggregate_sum_encoded(x: torch.Tensor, edge_index, bond_idx: torch.Tensor, ts: TableSet, tables,
                           msg_encoder: str = "identity", add_self_loops: bool = False,
-                          num_dst: Optional[int] = None, dx_handoff=None, pending=None) -> torch.Tensor:
+                          num_dst: Optional[int] = None, dx_handoff=None, pending=None, lazy: bool = False) -> torch.Tensor:
     """aggregate_sum with edge_attr[e] = Σ_f tables[c][f][bond_idx[e, f]] looked up inside the
-    kernel (the [E, h] bond embedding is never written)."""
+    kernel (the [E, h] bond embedding is never written).  ``lazy``: the result goes straight into ``mlp_norm_fused`` — the
+    launch may then be left to that node's first GEMM (``PendingAggregate`` on the returned tensor)."""
     st = edge_index if isinstance(edge_index, EdgeStructure) else edge_structure(edge_index, x.shape[0], num_dst)
     ts = ts.vector_form(tables)
     packed = ts.fusable_into_aggregate and ts.F <= 4 and ts.R <= 256
@@ -2359,7 +2370,11 @@ def aggregate_sum_encoded(x: torch.Tensor, edge_index, bond_idx: torch.Tensor, t
             pending.materialize()
         ea = _EncodeFn.apply(bond_idx, ts, *flat_tables)
         return _AggregateFn.apply(x, ea, st, _act_id(msg_encoder), bool(add_self_loops))
-    return _AggregateEncFn.apply(x, bond_idx, st, _act_id(msg_encoder), bool(add_self_loops), ts, dx_handoff, pending, *flat_tables)
+    box = {} if (lazy and torch.is_grad_enabled()) else None
+    res = _AggregateEncFn.apply(x, bond_idx, st, _act_id(msg_encoder), bool(add_self_loops), ts, dx_handoff, pending, box, *flat_tables)
+    if box and box.get("pa") is not None:
+        res._phc_pending_agg = box["pa"]
+    return res
 
 
 # ---------------------------------------------------------------------------
@@ -2694,6 +2709,86 @@ NORM_INTO_AGGREGATE = __import__("os").environ.get("PHC_NORM_INTO_AGGREGATE", "1
 NORM_INTO_AGGREGATE_MAX_WORK = int(__import__("os").environ.get("PHC_NORM_INTO_AGGREGATE_MAX_WORK", "3000000"))
 
 
+GEMM_AGGREGATE = __import__("os").environ.get("PHC_GEMM_AGGREGATE", "1") != "0"
+
+
+class PendingAggregate:
+    """s = sum aggregation of a layer input that has NOT been launched: ``out`` (= s) is allocated, the fused MLP + norm node's first
+    GEMM builds the rows itself and writes them on the way (``run_with_gemm``: phc_gemm_aggregate_stats, csrc/gemm_hs_ag_device.h).
+    ``materialize`` is the launch that would have run in the aggregation's forward — identical rows.  ``pending``: the layer
+    input's own un-applied norm (PendingNorm) rides along in either form."""
+
+    def __init__(self, x_, codes, ts, st, add_self, out, pending):
+        self.x_, self.codes, self.ts, self.st, self.add_self, self.out, self.pending = x_, codes, ts, st, add_self, out, pending
+        self.done = False
+
+    def _account(self):
+        if L.PROF_ON:
+            E, N, h, ts = self.st.num_edges, self.st.num_dst, self.out.shape[1], self.ts
+            L.account("aggregate_enc_fwd", 2.0 * E * h,
+                      E * (4.0 * h + 4 + 4 + 8.0 * ts.F) + N * 4.0 * h * (2 if self.add_self else 1) + 4.0 * (N + 1))
+
+    def materialize(self):
+        if self.done:
+            return
+        lib = L.load()
+        rowptr, col, _ = self.st.csr
+        ts = self.ts
+        if self.pending is not None and not self.pending.done:
+            self.pending.run_fused(self.x_, self.codes, ts, rowptr, col, self.st.num_dst, self.add_self, self.out)
+        else:
+            L.check(lib.phc_aggregate_encp_fwd(L.ptr(self.x_), L.ptr(self.codes), L.ptr(ts.ptrs), ts.vocab_c, L.ptr(rowptr), L.ptr(col),
+                                               self.st.num_dst, ts.F, ts.n, ts.k, 0, 1 if self.add_self else 0, L.ptr(self.out),
+                                               L.stream_ptr(self.out.device)), "phc_aggregate_encp_fwd")
+        self._account()
+        self.done = True
+
+    def run_with_gemm(self, Mk4, b, y, n_valid, acc) -> bool:
+        """The aggregate + ``y = s . M + b`` + the statistics of y in one launch; False = outside the fused form (nothing launched)."""
+        lib = L.load()
+        N, h = self.out.shape
+        ts = self.ts
+        if self.done or y.shape != (N, h) or not lib.phc_gemm_aggregate_supported(N, h, y.shape[1], ts.F, ts.R):
+            return False
+        rowptr, col, _ = self.st.csr
+        d = L.GemmAgDesc()
+        d.codes, d.tables, d.vocab = L.ptr(self.codes), L.ptr(ts.ptrs), _C.cast(ts.vocab_c, _C.c_void_p)
+        d.rowptr, d.col, d.N, d.F, d.n, d.k, d.add_self = L.ptr(rowptr), L.ptr(col), N, ts.F, ts.n, ts.k, 1 if self.add_self else 0
+        d.s_out = L.ptr(self.out)
+        keep = None
+        pn = self.pending if (self.pending is not None and not self.pending.done) else None
+        if pn is not None:
+            keep = pn._norm_args()
+            w, bb, rm, rv, nbt, no = keep
+            cast = lambda a: _C.cast(a, _C.c_void_p) if a is not None else None
+            d.x, d.norm_acc = L.ptr(pn.y2), L.ptr(pn.acc2)
+            d.weight, d.bias, d.running_mean, d.running_var, d.num_batches_tracked = cast(w), cast(bb), cast(rm), cast(rv), cast(nbt)
+            d.n_comp, d.norm_act, d.momentum, d.eps = no, pn.act_o, float(pn.outer["momentum"]), float(pn.outer["eps"])
+            d.skip, d.save_stat, d.x_out = L.ptr(pn.skip), L.ptr(pn.save_o), L.ptr(pn.out)
+            assert self.x_.data_ptr() == pn.out.data_ptr()
+        else:
+            d.x = L.ptr(self.x_)
+        d.Mk4, d.b, d.Nout, d.y, d.n_valid_dev, d.stat_acc = L.ptr(Mk4), L.ptr(b), y.shape[1], L.ptr(y), L.ptr(n_valid), L.ptr(acc)
+        L.check(lib.phc_gemm_aggregate_stats(_C.byref(d), L.stream_ptr(self.out.device)), "phc_gemm_aggregate_stats")
+        if pn is not None:
+            pn.done = True
+        if L.PROF_ON:
+            E = self.st.num_edges
+            L.account("phm_gemm_ag_fwd", 2.0 * N * h * h + 2.0 * E * h,
+                      4.0 * (2 * N * h + h * h + h) + E * (4.0 * h + 8 + 8.0 * ts.F) + N * 4.0 * h * (2 if self.add_self else 1))
+        self.done = True
+        return True
+
+
+def materialize_pending_aggregate(t: torch.Tensor) -> torch.Tensor:
+    """Launch the parked aggregation of ``t`` (if it has one) before a consumer other than the fused MLP + norm node reads it."""
+    pa = getattr(t, "_phc_pending_agg", None)
+    if pa is not None:
+        pa.materialize()
+        t._phc_pending_agg = None
+    return t
+
+
 class PendingNorm:
     """x = act(norm(y2)) (+ skip) that has NOT been evaluated yet: the fused MLP + norm node allocated ``out`` (= x) and ``save_stat``
     and stopped in front of its last launch.  The consumer is the next layer's encoded sum aggregation (``run_fused``: one launch
@@ -2775,8 +2870,13 @@ class _MLPNormFn(torch.autograd.Function):
         save_i = torch.empty(6 * h, dtype=torch.float32, device=dev)
         save_o = torch.empty(6 * h, dtype=torch.float32, device=dev)
         acc1, acc2 = _zero_acc(dev, h), _zero_acc(dev, h)
-        L.check(lib.phc_gemm_prebuilt_stats(L.ptr(s), L.ptr(pre1[0]), L.ptr(pre1[2]), L.ptr(b1), N, h, h, L.ptr(z1), L.ptr(n_valid),
-                                            L.ptr(acc1), None, None, sp), "phc_gemm_prebuilt_stats")
+        pa = meta.pop("pending_agg", None)
+        fused_agg = pa is not None and (b1 is None or b1.data_ptr() % 16 == 0) and pa.run_with_gemm(pre1[2], b1, z1, n_valid, acc1)
+        if not fused_agg:
+            if pa is not None:
+                pa.materialize()
+            L.check(lib.phc_gemm_prebuilt_stats(L.ptr(s), L.ptr(pre1[0]), L.ptr(pre1[2]), L.ptr(b1), N, h, h, L.ptr(z1), L.ptr(n_valid),
+                                                L.ptr(acc1), None, None, sp), "phc_gemm_prebuilt_stats")
         L.check(lib.phc_gemm_prebuilt_xf_acc(
             L.ptr(z1), L.ptr(acc1), _ptr_array(aff_i[:ni]) if aff_i else None, _ptr_array(aff_i[ni:]) if aff_i else None,
             _ptr_array(inner["running_mean"]), _ptr_array(inner["running_var"]), _ptr_array(inner["nbt"]), ni,
@@ -2790,7 +2890,8 @@ class _MLPNormFn(torch.autograd.Function):
         else:
             pend.materialize()
         if L.PROF_ON:
-            L.account("phm_gemm_fwd", 2.0 * N * h * h, 4.0 * (2 * N * h + h * h + h))
+            if not fused_agg:
+                L.account("phm_gemm_fwd", 2.0 * N * h * h, 4.0 * (2 * N * h + h * h + h))
             L.account("phm_gemm_fwd", 2.0 * N * h * h, 4.0 * (2 * N * h + h * h + h))
         ctx.save_for_backward(s, z1, y2, save_i, save_o, A1, W1, A2, W2)
         ctx.meta, ctx.n_valid = meta, n_valid
@@ -2885,6 +2986,18 @@ def _norm_meta(nm):
 
 
 def mlp_norm_fused(s, skip, n_valid, mlp, outer_norm, activation: str, skip_handoff=None, defer_apply: bool = False):
+    """``_mlp_norm_fused`` (below); an aggregation parked on ``s`` (PendingAggregate) is handed to the node's first GEMM, or launched
+    here when the node does not apply."""
+    pa = getattr(s, "_phc_pending_agg", None)
+    if pa is not None:
+        s._phc_pending_agg = None
+    out = _mlp_norm_fused(s, skip, n_valid, mlp, outer_norm, activation, skip_handoff, defer_apply, pa)
+    if out is None and pa is not None:
+        pa.materialize()
+    return out
+
+
+def _mlp_norm_fused(s, skip, n_valid, mlp, outer_norm, activation: str, skip_handoff=None, defer_apply: bool = False, pending_agg=None):
     """``act(outer_norm(mlp(s))) + skip`` for a PHMMLP with an inner naive batch-norm, as one autograd node (training mode),
     or ``None`` when the preconditions do not hold: both linears square of width 128 or 256 with prebuilt k4 operands (inside
     ``prebuilt_H``), both norms naive batch-norms with running statistics, fusable activations, 16-byte aligned dense rows."""
@@ -2911,7 +3024,7 @@ def mlp_norm_fused(s, skip, n_valid, mlp, outer_norm, activation: str, skip_hand
     if any(b is not None and not b.is_contiguous() for b in (l1.b, l2.b)):
         return None
     meta = dict(pre1=pre1, pre2=pre2, inner=inner, outer=outer, act_inner=act_i, act_outer=act_o, skip_handoff=skip_handoff,
-                defer_apply=bool(defer_apply and NORM_INTO_AGGREGATE))
+                defer_apply=bool(defer_apply and NORM_INTO_AGGREGATE), pending_agg=pending_agg)
     affine = inner["weights"] + inner["biases"] + outer["weights"] + outer["biases"]
     out = _MLPNormFn.apply(s, skip, n_valid, meta, l1.phm_rule, l1.W, l1.b, l2.phm_rule, l2.W, l2.b, *affine)
     pend = meta.pop("pending", None)

@@ -95,3 +95,119 @@ def test_atom_encoder_passenger_reports_bad_indices():
     torch.cuda.synchronize()
     with pytest.raises(IndexError):
         lib.check_indices(torch.device(DEV))
+
+
+# ---- the aggregation inside the layer's first GEMM (phc_gemm_aggregate_stats, csrc/gemm_hs_ag_device.h) ----------------------------
+def _random_graph(N, E, hubs, seed):
+    g = torch.Generator().manual_seed(seed)
+    src = torch.randint(0, N, (E,), generator=g)
+    dst = torch.randint(0, N, (E,), generator=g)
+    if hubs:                                                              # rows with > 16 in-edges (the two-pass walk), one of 300
+        dst[: E // 6] = N // 3
+        dst[E // 6: E // 6 + 40] = 5
+    dst[dst == N - 2] = 0                                                 # an isolated destination near the end
+    return torch.stack([src, dst])
+
+
+@pytest.mark.parametrize("N,E,hubs", [(1000, 2100, False), (12874, 27650, False), (333, 1500, True), (16, 40, False), (25000, 52000, True)])
+@pytest.mark.parametrize("F,normed,act,with_skip,add_self", [(3, False, "relu", False, True), (3, True, "relu", True, True),
+                                                             (1, True, "swish", False, True), (2, True, "relu", True, False),
+                                                             (4, False, "relu", False, False)])
+def test_aggregation_inside_the_first_gemm_equals_the_separate_launches(N, E, hubs, F, normed, act, with_skip, add_self):
+    """s, x, save_stat, running statistics, y and the statistics accumulator of ONE phc_gemm_aggregate_stats launch against
+    phc_aggregate_encp_fwd / phc_aggregate_norm_encp_fwd followed by phc_gemm_prebuilt_stats: bit for bit (same walk, same MFMA
+    order, same partial sums per workgroup)."""
+    import ctypes as C
+    from phc_gnn_amd import lib as L, ops
+    from phc_gnn_amd.graph import edge_structure
+    lib = L.load()
+    n, k, h = 4, 32, 128
+    vocab = [5, 6, 2, 3][:F]
+    if not lib.phc_gemm_aggregate_supported(N, h, h, F, sum(vocab)):
+        pytest.skip("outside the fused form")
+    g = torch.Generator().manual_seed(N + F)
+    ei = _random_graph(N, E, hubs, seed=N).to(DEV)
+    bond = torch.stack([torch.randint(0, v, (E,), generator=g) for v in vocab], 1).to(DEV)
+    tables = [[torch.randn(v, k, generator=g).to(DEV) for v in vocab] for _ in range(n)]
+    ts = ops.TableSet(tables).vector_form(tables)
+    st = edge_structure(ei, N, N)
+    st.prepare(for_backward=False, codes_for=(bond, ts.vocab_c, ts.F))
+    rowptr, col, _ = st.csr
+    codes = st.packed_codes(bond, ts.vocab_c, ts.F)
+    valid = N - 7 if N > 16 else N
+    nv = torch.tensor([valid], dtype=torch.int32, device=DEV)
+    sp = L.stream_ptr(torch.device(DEV))
+    M = (torch.randn(h, h, generator=g) / h ** 0.5).to(DEV)
+    M4 = M.view(h // 4, 4, h).permute(0, 2, 1).contiguous()
+    b = torch.randn(h, generator=g).to(DEV)
+    y_in = torch.randn(N, h, generator=g).to(DEV)
+    skip = torch.randn(N, h, generator=g).to(DEV) if with_skip else None
+    words = lib.phc_stat_acc_words(h)
+    arr = lambda tsr: (C.c_void_p * len(tsr))(*[t.data_ptr() for t in tsr])
+    w = [(0.5 + torch.rand(k, generator=g)).to(DEV) for _ in range(n)]
+    bb = [torch.randn(k, generator=g).to(DEV) for _ in range(n)]
+    norm_acc = torch.zeros(words, dtype=torch.int64, device=DEV)
+    if normed:                                                            # the statistics a producing GEMM would have left behind
+        L.check(lib.phc_gemm_prebuilt_stats(L.ptr(torch.randn(N, h, generator=g).to(DEV)), L.ptr(M), None, None, N, h, h, L.ptr(y_in), L.ptr(nv),
+                                            L.ptr(norm_acc), None, None, sp), "producer")
+    res = {}
+    for tag in ("separate", "fused"):
+        rm = [torch.zeros(k, device=DEV) for _ in range(n)]
+        rv = [torch.ones(k, device=DEV) for _ in range(n)]
+        nbt = [torch.zeros((), dtype=torch.int64, device=DEV) for _ in range(n)]
+        save = torch.zeros(6 * h, device=DEV)
+        x_out = torch.zeros(N, h, device=DEV)
+        s_out = torch.empty(N, h, device=DEV)
+        y = torch.empty(N, h, device=DEV)
+        acc = torch.zeros(words, dtype=torch.int64, device=DEV)
+        if tag == "separate":
+            if normed:
+                L.check(lib.phc_aggregate_norm_encp_fwd(L.ptr(y_in), L.ptr(norm_acc), arr(w), arr(bb), arr(rm), arr(rv), arr(nbt), n, 0.1, 1e-5,
+                                                        L.ACT_IDS[act], L.ptr(nv), L.ptr(skip), L.ptr(save), L.ptr(x_out), L.ptr(codes),
+                                                        L.ptr(ts.ptrs), ts.vocab_c, L.ptr(rowptr), L.ptr(col), N, F, n, k, int(add_self),
+                                                        L.ptr(s_out), sp), "aggregate_norm")
+            else:
+                L.check(lib.phc_aggregate_encp_fwd(L.ptr(y_in), L.ptr(codes), L.ptr(ts.ptrs), ts.vocab_c, L.ptr(rowptr), L.ptr(col), N, F, n, k, 0,
+                                                   int(add_self), L.ptr(s_out), sp), "aggregate")
+            L.check(lib.phc_gemm_prebuilt_stats(L.ptr(s_out), L.ptr(M), L.ptr(M4), L.ptr(b), N, h, h, L.ptr(y), L.ptr(nv), L.ptr(acc), None, None,
+                                                sp), "gemm stats")
+        else:
+            d = L.GemmAgDesc()
+            d.x, d.codes, d.tables, d.vocab = L.ptr(y_in), L.ptr(codes), L.ptr(ts.ptrs), C.cast(ts.vocab_c, C.c_void_p)
+            d.rowptr, d.col, d.N, d.F, d.n, d.k, d.add_self, d.s_out = L.ptr(rowptr), L.ptr(col), N, F, n, k, int(add_self), L.ptr(s_out)
+            keep = (arr(w), arr(bb), arr(rm), arr(rv), arr(nbt))
+            if normed:
+                d.norm_acc = L.ptr(norm_acc)
+                d.weight, d.bias, d.running_mean, d.running_var, d.num_batches_tracked = (C.cast(a_, C.c_void_p) for a_ in keep)
+                d.n_comp, d.norm_act, d.momentum, d.eps = n, L.ACT_IDS[act], 0.1, 1e-5
+                d.skip, d.save_stat, d.x_out = L.ptr(skip), L.ptr(save), L.ptr(x_out)
+            d.Mk4, d.b, d.Nout, d.y, d.n_valid_dev, d.stat_acc = L.ptr(M4), L.ptr(b), h, L.ptr(y), L.ptr(nv), L.ptr(acc)
+            L.check(lib.phc_gemm_aggregate_stats(C.byref(d), sp), "phc_gemm_aggregate_stats")
+        torch.cuda.synchronize()
+        res[tag] = dict(s=s_out, y=y, acc=acc, x=x_out, save=save, rm=torch.cat(rm), rv=torch.cat(rv), nbt=torch.stack(nbt))
+    for key in res["fused"]:
+        a_, b_ = res["fused"][key], res["separate"][key]
+        assert torch.equal(a_, b_), (key, float((a_.double() - b_.double()).abs().max()))
+
+
+@pytest.mark.parametrize("workload", ["molhiv_b32", "molhiv_b32_swish", "molhiv_b512", "zinc_small_last_128"])
+@pytest.mark.parametrize("graph", [False, True])
+def test_aggregation_inside_the_first_gemm_leaves_the_step_bit_identical(workload, graph):
+    """The whole training step (loss, every gradient, every buffer) with ops.GEMM_AGGREGATE on and off; the fused launch must really
+    have run (the launch profiler books it under its own name)."""
+    from phc_gnn_amd import harness, lib as L
+    if workload == "zinc_small_last_128":
+        harness.WORKLOADS.setdefault("zinc_small_last_128", dict(dataset="zinc", batch_size=48, phm_dim=4, hidden=128, layers=3, d_units=[64, 32],
+                                                                 target_dim=1, sc_type="last", regression=True))
+    on = _step(workload, dict(GEMM_AGGREGATE=True), graph)
+    off = _step(workload, dict(GEMM_AGGREGATE=False), graph)
+    _same(on, off)
+    if not graph:
+        L.prof_enable(True)
+        L.prof_reset()
+        try:
+            _step(workload, dict(GEMM_AGGREGATE=True), False)
+            names = {k for k, v in L.prof_read().items() if v["launches"] > 0}
+        finally:
+            L.prof_enable(False)
+        assert "phm_gemm_ag_fwd" in names, sorted(names)
