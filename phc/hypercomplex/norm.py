@@ -28,10 +28,38 @@ class NaivePHMNorm(nn.Module):
         self.bn = nn.ModuleList([nn.BatchNorm1d(self.num_features, eps, momentum, affine, track_running_stats)
                                  for _ in range(phm_dim)])
         self.reset_parameters()
+        self._lay_out_back_to_back()
 
     def reset_parameters(self):
         for module in self.bn:
             module.reset_parameters()
+
+    def _lay_out_back_to_back(self):
+        """Engine extension: the n components' weights (biases, running means, running variances) become views of ONE storage each,
+        component c at offset c * k.  Names, shapes, values and ``state_dict`` are the reference's; what changes is that the engine's
+        kernels find column ``c * k + j`` of a parameter at ``weight_0 + c * k + j`` — one load in their prologue instead of a pointer
+        hop per component table (``BnParams.flat``, csrc/phc_common.h).  Re-done whenever the module's tensors are moved
+        (``_apply``: .to / .cuda / .float); any other re-pointing of a parameter (a deep copy, ``load_state_dict(assign=True)``)
+        simply leaves the kernels on their pointer tables."""
+        k = self.num_features
+        for name in ("weight", "bias", "running_mean", "running_var"):
+            ts = [getattr(m, name, None) for m in self.bn]
+            if any(t is None for t in ts) or len(ts) < 2:
+                continue
+            t0 = ts[0]
+            if all(t.device == t0.device and t.dtype == t0.dtype and t.is_contiguous() and
+                   t.data_ptr() == t0.data_ptr() + c * k * t0.element_size() for c, t in enumerate(ts)):
+                continue
+            if any(t.device != t0.device or t.dtype != t0.dtype for t in ts):
+                continue
+            flat = torch.cat([t.detach().reshape(-1) for t in ts])
+            for c, t in enumerate(ts):
+                t.data = flat[c * k:(c + 1) * k]
+
+    def _apply(self, fn, *args, **kwargs):
+        out = super()._apply(fn, *args, **kwargs)
+        self._lay_out_back_to_back()
+        return out
 
     def forward(self, x: torch.Tensor) -> torch.Tensor:
         return self.forward_fused(x)

@@ -364,12 +364,12 @@ __global__ __launch_bounds__(ENC_THREADS) void aggregate_norm_direct_fwd_kernel(
         }
         const int comp = c / p.k, kk = c - comp * p.k;
         float w = 1.f, bq = 0.f, rm_old = 0.f, rv_old = 1.f;
-        for (int q = 0; q < p.n_comp; ++q)                     // uniform walk of the by-value pointer tables
-            if (q == comp) {
-                if (p.has_weight) w = p.weight[q][kk];
-                if (p.has_bias) bq = p.bias[q][kk];
-                if (p.has_running && owner) { rm_old = p.running_mean[q][kk]; rv_old = p.running_var[q][kk]; }
-            }
+        if (p.has_weight) w = *bn_col_ptr(p.weight, p.flat, comp, kk, c);
+        if (p.has_bias) bq = *bn_col_ptr(p.bias, p.flat, comp, kk, c);
+        if (p.has_running && owner) {
+            rm_old = *bn_col_ptr(p.running_mean, p.flat, comp, kk, c);
+            rv_old = *bn_col_ptr(p.running_var, p.flat, comp, kk, c);
+        }
         const BnFromTotals bt = bn_from_totals(S, Q, count, w, bq, eps);
         s_scale[c] = bt.scale;
         s_shift[c] = bt.shift;
@@ -381,11 +381,8 @@ __global__ __launch_bounds__(ENC_THREADS) void aggregate_norm_direct_fwd_kernel(
             stat[4 * h + c] = w;
             stat[5 * h + c] = bq;
             if (p.has_running) {
-                for (int q = 0; q < p.n_comp; ++q)
-                    if (q == comp) {
-                        p.running_mean[q][kk] = bn_running_update(rm_old, momentum, bt.mean);
-                        p.running_var[q][kk] = bn_running_update(rv_old, momentum, bt.unbiased);
-                    }
+                *bn_col_ptr(p.running_mean, p.flat, comp, kk, c) = bn_running_update(rm_old, momentum, bt.mean);
+                *bn_col_ptr(p.running_var, p.flat, comp, kk, c) = bn_running_update(rv_old, momentum, bt.unbiased);
             }
         }
     }

@@ -52,7 +52,7 @@ constexpr int HS_AG_THREADS = 512;
 #define PHC_AG_OCC __attribute__((amdgpu_waves_per_eu(4, 4)))
 #endif
 
-template <int F, bool NORMED>
+template <int F, bool NORMED, bool RELU, bool FLAT>
 __global__ __launch_bounds__(HS_AG_THREADS) PHC_AG_OCC void gemm_hs_ag_kernel(GemmHsArgs a, HsAgArgs ag) {
     constexpr int K = 128, G = K / 16, ISTRIDE = HS_ISTRIDE, INSTR = 8, H4 = K / 4, NOUT = 128;
     __shared__ f32x4_t image[INSTR * ISTRIDE];                   // one 16-row operand image (8 two-row "instructions", padded)
@@ -69,13 +69,110 @@ __global__ __launch_bounds__(HS_AG_THREADS) PHC_AG_OCC void gemm_hs_ag_kernel(Ge
     const int my_steps = group < num_steps ? (num_steps - group + a.groups - 1) / a.groups : 0;
     if (my_steps == 0) return;
     const int M = (int)a.M;
+    // diagnostics (phc_debug_hs_stamps; null in the product): 100 MHz ticks at entry | first barrier passed | loop done | end, and per
+    // phase summed over the steps: rows added up | image barrier | MFMAs + epilogue
+    unsigned long long tk[4] = {0, 0, 0, 0}, ph[3] = {0, 0, 0}, dbg[4] = {0, 0, 0, 0};
+    if (a.stamps) tk[0] = __builtin_amdgcn_s_memrealtime();
     const int count = a.n_valid ? min(*a.n_valid, M) : M;
     auto lds_barrier = [] {                                       // LDS traffic only: __syncthreads() would also wait for the s / x
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // stores of the step (vmcnt(0))
         __builtin_amdgcn_s_barrier();
     };
 
-    // ---- the operand matrix -> LDS by LDS-DMA: 64 instructions of 1 KiB, eight per wavefront, a straight copy of the k4 form ----
+    // ---- this half-wavefront's row of a step: image instruction `wave`, row 2 wave + dsub; its 16-byte chunk (odd rows XOR 1) ----
+    const int dsub = lane >> 5, li = lane & 31;
+    const int c4 = li ^ dsub;
+    auto row_of = [&](int sl) { return (group + sl * a.groups) * 16 + 2 * wave + dsub; };
+    const float4 *Y4 = reinterpret_cast<const float4 *>(ag.y) + c4;
+    const float4 *S4 = reinterpret_cast<const float4 *>(ag.skip ? ag.skip : ag.y) + c4;   // (a missing skip re-reads y and is not added)
+    const bool has_skip = ag.skip != nullptr;
+    // What a lane group needs of a step before it can add anything up: the row's edge range, the sources and codes of its first two
+    // edges, and (RAW) the rows themselves as they lie in memory.  All of it is fetched BEFORE the launch's first barrier for the
+    // first step, and down to the codes for the second: three dependent round trips that overlap the operand's DMA, the tables'
+    // staging and the pending norm's prologue instead of following them.
+    struct Raw {
+        float4 v, rr;
+    };
+    auto load_raw = [&](int r) {
+        Raw w;
+        w.v = Y4[(size_t)r * H4];
+        if constexpr (NORMED) w.rr = S4[(size_t)r * H4];
+        else w.rr = w.v;
+        return w;
+    };
+    constexpr int NPRE0 = NORMED ? 1 : 2;                         // steps whose pointers / sources / codes are fetched ahead
+    int d_[2] = {0, 0}, e0_[2] = {0, 0}, e1_[2] = {0, 0}, s0_[2] = {0, 0}, s1_[2] = {0, 0};
+    unsigned k0_[2] = {0, 0}, k1_[2] = {0, 0};
+#pragma unroll
+    for (int q = 0; q < NPRE0; ++q) {
+        d_[q] = row_of(min(q, my_steps - 1));
+        const int dc = d_[q] < M ? d_[q] : 0;
+        e0_[q] = ag.rowptr[dc];
+        e1_[q] = ag.rowptr[dc + 1];
+    }
+    // ---- bond tables: pointer hop now, rows below ----
+    const int tblR = ag.off[F];
+    const float *tsrc = nullptr;
+    int tcomp = 0, tkk = 0, tr = 0, tf = 0, toff = 0;
+    if (tid < tblR * H4) {                                       // (R <= 16 rows on molecule data: one float4 per thread; more rows: the loop below)
+        tr = tid >> 5;
+        const int q4 = tid & 31;
+        tcomp = (q4 * 4) / ag.k;
+        tkk = q4 * 4 - tcomp * ag.k;
+#pragma unroll
+        for (int t = 1; t < F; ++t) {                            // (constant indices into the by-value offset table: no scratch copy)
+            const bool past = tr >= ag.off[t];
+            tf = past ? t : tf;
+            toff = past ? ag.off[t] : toff;
+        }
+        tsrc = ag.tables[tcomp * F + tf];
+    }
+    // pending norm: column ncol = tid / 4, accumulator replica tid % 4 (STAT_ACC_REP == 4) — every wavefront takes 16 columns, so the
+    // accumulator's round trip and the double arithmetic are spread evenly instead of holding up the two wavefronts that would own
+    // all 128 columns (they reached the first barrier 2 us behind the others, scripts/dbg/ag_phases.py).  The loads go out BEHIND
+    // the sources / codes below: nothing on the row-pointer -> source -> row chain waits for them.
+    static_assert(STAT_ACC_REP == 4 && HS_AG_THREADS == 4 * K, "one (column, replica) pair per thread");
+    const int ncol = tid >> 2, nrep = tid & 3;
+    const int ncomp = NORMED ? ncol / ag.p.k : 0, nkk = NORMED ? ncol - ncomp * ag.p.k : 0;
+    const bool owner = blockIdx.x == 0;
+    double nS = 0.0, nQ = 0.0;
+    float nw = 1.f, nb = 0.f, rm_old = 0.f, rv_old = 1.f;
+    // ---- second round trip: sources and codes of the first two edges of both steps (pointer-selected: an empty row reads row pointers).
+    // With a norm pending only the first step's: at 128 registers per lane hipcc spilled the second step's as they arrived — a wait
+    // per load, in the middle of the chain (scripts/dbg/ag_phases.py: 2 us) ----
+    constexpr int NPRE = NORMED ? 1 : 2;
+#pragma unroll
+    for (int q = 0; q < NPRE; ++q) {
+        const bool valid = d_[q] < M;
+        e0_[q] = valid ? e0_[q] : 0;
+        e1_[q] = valid ? e1_[q] : 0;
+        const bool any = e0_[q] < e1_[q];
+        const int stride = e1_[q] - e0_[q] > 16 ? 2 : 1;         // (AGG_HEAVY of encoder.hip: two strided passes)
+        const int i0 = any ? min(e0_[q], e1_[q] - 1) : 0, i1 = any ? min(e0_[q] + stride, e1_[q] - 1) : 0;
+        const int *cp = any ? ag.col : ag.rowptr;
+        const unsigned *kp = any ? ag.codes : reinterpret_cast<const unsigned *>(ag.rowptr);
+        s0_[q] = cp[i0];
+        s1_[q] = cp[i1];
+        k0_[q] = kp[i0];
+        k1_[q] = kp[i1];
+    }
+    unsigned long long araw[4] = {0, 0, 0, 0};                   // this replica's words of (sum | sum of squares) x (hi | lo): converted below
+    if constexpr (NORMED) {
+        const unsigned long long *ap = ag.acc + (size_t)(nrep * 2) * 2 * K + ncol;      // (the layout of stat_acc_part, phc_common.h)
+        araw[0] = ap[0]; araw[1] = ap[K]; araw[2] = ap[2 * K]; araw[3] = ap[3 * K];
+        if (ag.p.has_weight) nw = FLAT ? ag.p.weight[0][ncol] : bn_pick(ag.p.weight, ncomp)[nkk];
+        if (ag.p.has_bias) nb = FLAT ? ag.p.bias[0][ncol] : bn_pick(ag.p.bias, ncomp)[nkk];
+        if (ag.p.has_running && owner) {
+            rm_old = FLAT ? ag.p.running_mean[0][ncol] : bn_pick(ag.p.running_mean, ncomp)[nkk];
+            rv_old = FLAT ? ag.p.running_var[0][ncol] : bn_pick(ag.p.running_var, ncomp)[nkk];
+        }
+    }
+    if (a.stamps) dbg[1] = __builtin_amdgcn_s_memrealtime();
+    float4 trow = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (tid < tblR * H4) trow = *reinterpret_cast<const float4 *>(tsrc + (size_t)(tr - toff) * ag.k + tkk);
+    // ---- the operand matrix -> LDS by LDS-DMA: 64 instructions of 1 KiB, eight per wavefront, a straight copy of the k4 form.
+    // Issued HERE: memory operations of a wavefront complete in order, so everything issued behind the DMA waits for it — the two
+    // dependent hops above would each have paid the 64 KB ----
     {
         const unsigned lds0 = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(hs_lds_void *)ag_dyn);
 #pragma unroll
@@ -84,67 +181,56 @@ __global__ __launch_bounds__(HS_AG_THREADS) PHC_AG_OCC void gemm_hs_ag_kernel(Ge
             hs_dma16(a.hk4 + (size_t)ii * 256 + 4 * lane, lds0 + 1024u * (unsigned)ii);
         }
     }
-    // ---- this half-wavefront's row of a step: image instruction `wave`, row 2 wave + dsub; its 16-byte chunk (odd rows XOR 1) ----
-    const int dsub = lane >> 5, li = lane & 31;
-    const int c4 = li ^ dsub;
-    auto row_of = [&](int sl) { return (group + sl * a.groups) * 16 + 2 * wave + dsub; };
-    // row pointers of the first two steps go in flight before anything else (clamped rows)
-    int d_[2], eb_[2], ee_[2];
-#pragma unroll
-    for (int q = 0; q < 2; ++q) {
-        d_[q] = row_of(min(q, my_steps - 1));
-        const int dc = d_[q] < M ? d_[q] : 0;
-        eb_[q] = ag.rowptr[dc];
-        ee_[q] = ag.rowptr[dc + 1];
-    }
-    // ---- bond tables -> LDS (one float4 per thread on molecule data; pointer hop + rows overlap the row-pointer chain) ----
+    // ---- third round trip: the first step's rows ----
+    const int self0 = ((NORMED || ag.add_self) && d_[0] < M) ? d_[0] : 0;
+    float4 w0v, w0r, w1v, w1r, wsv, wsr;                         // (plain float4 variables: a struct modified in the step loop stayed in scratch)
     {
-        const int R = ag.off[F];
-        for (int e = tid; e < R * H4; e += HS_AG_THREADS) {
-            const int r = e >> 5, q4 = e & 31;
-            const int comp = (q4 * 4) / ag.k, kk = q4 * 4 - comp * ag.k;
-            int f = 0;
-#pragma unroll
-            for (int t = 1; t < F; ++t) f = r >= ag.off[t] ? t : f;
-            reinterpret_cast<float4 *>(ag_tbl)[e] = *reinterpret_cast<const float4 *>(ag.tables[comp * F + f] + (size_t)(r - ag.off[f]) * ag.k + kk);
-        }
+        const Raw a0 = load_raw(e0_[0] < e1_[0] ? s0_[0] : 0), a1 = load_raw(e0_[0] < e1_[0] ? s1_[0] : 0), as = load_raw(self0);
+        w0v = a0.v; w0r = a0.rr; w1v = a1.v; w1r = a1.rr; wsv = as.v; wsr = as.rr;
     }
-    // ---- pending norm: scale / shift of every column (the arithmetic of aggregate_norm_direct_fwd_kernel's prologue) ----
-    if constexpr (NORMED) {
-        const bool owner = blockIdx.x == 0;
-        const int h = K;
-        for (int cc = tid; cc < h; cc += HS_AG_THREADS) {
-            double S = 0.0, Q = 0.0;
+    // ---- LDS: tables, scale / shift ----
+    if (tid < tblR * H4) reinterpret_cast<float4 *>(ag_tbl)[tid] = trow;
+    for (int e = tid + HS_AG_THREADS; e < tblR * H4; e += HS_AG_THREADS) {       // (table rows past the first 16)
+        const int r = e >> 5, q4 = e & 31;
+        const int comp = (q4 * 4) / ag.k, kk = q4 * 4 - comp * ag.k;
+        int f = 0, fo = 0;
 #pragma unroll
-            for (int rp = 0; rp < STAT_ACC_REP; ++rp) {
-                S += stat_acc_part(ag.acc, h, rp, 0, cc);
-                Q += stat_acc_part(ag.acc, h, rp, 1, cc);
-            }
-            const int comp = cc / ag.p.k, kk = cc - comp * ag.p.k;
-            float w = 1.f, bq = 0.f, rm_old = 0.f, rv_old = 1.f;
-            for (int q = 0; q < ag.p.n_comp; ++q)
-                if (q == comp) {
-                    if (ag.p.has_weight) w = ag.p.weight[q][kk];
-                    if (ag.p.has_bias) bq = ag.p.bias[q][kk];
-                    if (ag.p.has_running && owner) { rm_old = ag.p.running_mean[q][kk]; rv_old = ag.p.running_var[q][kk]; }
-                }
-            const BnFromTotals bt = bn_from_totals(S, Q, count, w, bq, ag.eps);
-            s_scale[cc] = bt.scale;
-            s_shift[cc] = bt.shift;
+        for (int t = 1; t < F; ++t) {
+            const bool past = r >= ag.off[t];
+            f = past ? t : f;
+            fo = past ? ag.off[t] : fo;
+        }
+        reinterpret_cast<float4 *>(ag_tbl)[e] = *reinterpret_cast<const float4 *>(ag.tables[comp * F + f] + (size_t)(r - fo) * ag.k + kk);
+    }
+    // the norm's constants: their double arithmetic runs while the rows travel.  The four replicas' parts meet in the first lane of
+    // the quad in replica order — ((p0 + p1) + p2) + p3, the order of the stand-alone kernels' loop: the same bits
+    __builtin_amdgcn_sched_barrier(0);                           // (nothing below may be scheduled in front of the row loads above: the
+                                                                 // conversion of the accumulator words would wait for them there)
+    if constexpr (NORMED) {
+        nS = (double)(long long)araw[0] * (1.0 / 4096.0) + (double)(long long)araw[1] * (1.0 / 4611686018427387904.0);
+        nQ = (double)(long long)araw[2] * (1.0 / 4096.0) + (double)(long long)araw[3] * (1.0 / 4611686018427387904.0);
+        const int qbase = lane & ~3;
+        double S = __shfl(nS, qbase, 64), Q = __shfl(nQ, qbase, 64);
+#pragma unroll
+        for (int r = 1; r < 4; ++r) {
+            S += __shfl(nS, qbase + r, 64);
+            Q += __shfl(nQ, qbase + r, 64);
+        }
+        if (nrep == 0) {
+            const BnFromTotals bt = bn_from_totals(S, Q, count, nw, nb, ag.eps);
+            s_scale[ncol] = bt.scale;
+            s_shift[ncol] = bt.shift;
             if (owner) {
                 float *stat = ag.stat;
-                stat[cc] = bt.mean;
-                stat[h + cc] = bt.invstd;
-                stat[2 * h + cc] = bt.scale;
-                stat[3 * h + cc] = bt.shift;
-                stat[4 * h + cc] = w;
-                stat[5 * h + cc] = bq;
+                stat[ncol] = bt.mean;
+                stat[K + ncol] = bt.invstd;
+                stat[2 * K + ncol] = bt.scale;
+                stat[3 * K + ncol] = bt.shift;
+                stat[4 * K + ncol] = nw;
+                stat[5 * K + ncol] = nb;
                 if (ag.p.has_running) {
-                    for (int q = 0; q < ag.p.n_comp; ++q)
-                        if (q == comp) {
-                            ag.p.running_mean[q][kk] = bn_running_update(rm_old, ag.momentum, bt.mean);
-                            ag.p.running_var[q][kk] = bn_running_update(rv_old, ag.momentum, bt.unbiased);
-                        }
+                    *(FLAT ? ag.p.running_mean[0] + ncol : bn_pick(ag.p.running_mean, ncomp) + nkk) = bn_running_update(rm_old, ag.momentum, bt.mean);
+                    *(FLAT ? ag.p.running_var[0] + ncol : bn_pick(ag.p.running_var, ncomp) + nkk) = bn_running_update(rv_old, ag.momentum, bt.unbiased);
                 }
             }
         }
@@ -152,22 +238,21 @@ __global__ __launch_bounds__(HS_AG_THREADS) PHC_AG_OCC void gemm_hs_ag_kernel(Ge
             for (int q = 0; q < ag.p.n_comp; ++q)
                 if (q == tid) *ag.p.num_batches_tracked[q] += 1;
     }
+    if (a.stamps) dbg[2] = __builtin_amdgcn_s_memrealtime();
     hs_wait_vm<0>();                                             // the operand's DMA (hipcc does not see it) has landed
+    if (a.stamps) dbg[3] = __builtin_amdgcn_s_memrealtime();
     lds_barrier();                                               // operand, tables (and scale / shift) are in LDS
-    const bool relu = ag.norm_act == PHC_ACT_RELU;
+    if (a.stamps) tk[1] = __builtin_amdgcn_s_memrealtime();
     const float4 *tb = reinterpret_cast<const float4 *>(ag_tbl) + c4;    // this lane's chunk of every table row
-    const float *skp = ag.skip ? ag.skip : ag.y;                 // (both loads unconditional: a missing skip re-reads y and is not added)
-    const bool has_skip = ag.skip != nullptr;
     // one row slice as the aggregation sees it: x, or act(y * scale + shift) (+ skip), 0 for a padding row of a normalised tensor
-    auto xrow = [&](int r) {
-        const float4 v = reinterpret_cast<const float4 *>(ag.y)[(size_t)r * H4 + c4];
+    auto xval = [&](const Raw &w, int r) {
         if constexpr (!NORMED) {
-            return v;
+            return w.v;
         } else {
-            const float4 rr = reinterpret_cast<const float4 *>(skp)[(size_t)r * H4 + c4];
+            const float4 v = w.v, rr = w.rr;
             const float4 sc = *reinterpret_cast<const float4 *>(s_scale + 4 * c4), sh = *reinterpret_cast<const float4 *>(s_shift + 4 * c4);
             float4 o;
-            if (relu) {
+            if constexpr (RELU) {                                // (one activation kind per instantiation: both bodies in one kernel cost registers)
                 o.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f); o.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
                 o.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f); o.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
             } else {
@@ -180,8 +265,8 @@ __global__ __launch_bounds__(HS_AG_THREADS) PHC_AG_OCC void gemm_hs_ag_kernel(Ge
             return o;
         }
     };
-    auto message = [&](int s, unsigned code) {
-        float4 v = xrow(s);
+    auto message = [&](const Raw &w, int s, unsigned code) {
+        float4 v = xval(w, s);
 #pragma unroll
         for (int f = 0; f < F; ++f) {
             const float4 t = tb[((code >> (8 * f)) & 255u) * H4];
@@ -189,32 +274,36 @@ __global__ __launch_bounds__(HS_AG_THREADS) PHC_AG_OCC void gemm_hs_ag_kernel(Ge
         }
         return v;
     };
-    // Build this wavefront's two rows of a step: LDS image + s (+ x) in memory.  The walk is the aggregation kernels' `row` body:
-    // edges e0 + first, + stride, ... of [e0, e1), the first two in one round trip, partial sums acc0 / acc1.  A row with more
-    // than 16 in-edges takes two passes (first = 0, 1; stride 2) whose results are added — what the two lane groups of a wavefront
-    // compute and exchange there.
-    auto fill = [&](int d, int eb_raw, int ee_raw) {
+    // Add up this wavefront's two rows of a step from the prefetched pieces: LDS image + s (+ x) in memory.  The walk is the
+    // aggregation kernels' `row` body: edges e0 + first, + stride, ... of [e0, e1), the first two in one round trip, partial sums
+    // acc0 / acc1.  A row with more than 16 in-edges takes two passes (first = 0, 1; stride 2) whose results are added — what the
+    // two lane groups of a wavefront compute and exchange there.
+    auto finish = [&](int d, int e0, int e1, int s0, int s1, unsigned k0, unsigned k1, const float4 r0v, const float4 r0r, const float4 r1v,
+                      const float4 r1r, const float4 rsv, const float4 rsr) {
         const bool valid = d < M;
-        const int e0 = valid ? eb_raw : 0, e1 = valid ? ee_raw : 0;
-        const bool heavy = e1 - e0 > 16;                         // (AGG_HEAVY of encoder.hip)
-        const int stride = heavy ? 2 : 1;
-        const float4 selfv = xrow((NORMED || ag.add_self) && valid ? d : 0);
+        const int stride = e1 - e0 > 16 ? 2 : 1;
+        const int selfr = ((NORMED || ag.add_self) && valid) ? d : 0;
+        const float4 selfv = xval(Raw{rsv, rsr}, selfr);
         float4 tot = make_float4(0.f, 0.f, 0.f, 0.f);
         for (int first = 0; first < stride; ++first) {
             float4 acc0 = make_float4(0.f, 0.f, 0.f, 0.f), acc1 = acc0;
-            int e = e0 + first;
-            if (e0 < e1) {                                       // the first two edges travel together (clamped indices)
-                const int i0 = min(e, e1 - 1), i1 = min(e + stride, e1 - 1);
-                const int s0 = ag.col[i0], s1 = ag.col[i1];
-                const unsigned k0 = ag.codes[i0], k1 = ag.codes[i1];
-                const float4 v0 = message(s0, k0), v1 = message(s1, k1);
+            int e = e0 + first, nth = 0;
+            if (first == 0 && e0 < e1) {                         // the prefetched pair: the first two edges travel together
+                const float4 v0 = message(Raw{r0v, r0r}, s0, k0), v1 = message(Raw{r1v, r1r}, s1, k1);
                 if (e < e1) { acc0.x += v0.x; acc0.y += v0.y; acc0.z += v0.z; acc0.w += v0.w; }
                 if (e + stride < e1) { acc1.x += v1.x; acc1.y += v1.y; acc1.z += v1.z; acc1.w += v1.w; }
                 e += 2 * stride;
+                nth = 2;
             }
-            for (; e < e1; e += stride) {
-                const float4 v = message(ag.col[e], ag.codes[e]);
-                acc0.x += v.x; acc0.y += v.y; acc0.z += v.z; acc0.w += v.w;
+            // the rest, one at a time; the SECOND edge of a pass goes to acc1 (second pass of a long row: same partial sums as the
+            // pair above would give)
+            for (; e < e1; e += stride, ++nth) {
+                const int t0 = ag.col[e];
+                const unsigned c0 = ag.codes[e];
+                const Raw q0 = load_raw(t0);
+                const float4 v = message(q0, t0, c0);
+                if (nth == 1) { acc1.x += v.x; acc1.y += v.y; acc1.z += v.z; acc1.w += v.w; }
+                else { acc0.x += v.x; acc0.y += v.y; acc0.z += v.z; acc0.w += v.w; }
             }
             const float4 a4 = make_float4(acc0.x + acc1.x, acc0.y + acc1.y, acc0.z + acc1.z, acc0.w + acc1.w);
             // (one pass: tot = a4.  two passes: a4(first 0) + a4(first 1), the shuffle-add of the shared walk)
@@ -236,19 +325,36 @@ __global__ __launch_bounds__(HS_AG_THREADS) PHC_AG_OCC void gemm_hs_ag_kernel(Ge
     const f32x4_t *hfrag = opnd + kq * NOUT + col0 + c;          // operand fragment of k-group g: hfrag[4 g * NOUT]
     f32x4_t st_p = zero4, st_s1 = zero4, st_s2 = zero4;
     float st_n = 0.f;
+    int cd = d_[0], ce0 = e0_[0], ce1 = e1_[0], cs0 = s0_[0], cs1 = s1_[0];
+    unsigned ck0 = k0_[0], ck1 = k1_[0];
     for (int i = 0; i < my_steps; ++i) {
         const int step = group + i * a.groups;
-        {
-            int d = i == 0 ? d_[0] : d_[1], eb = i == 0 ? eb_[0] : eb_[1], ee = i == 0 ? ee_[0] : ee_[1];
-            if (i >= 2) {                                        // (third and later steps of a workgroup: launches past 512 x 32 rows)
-                d = row_of(i);
-                const int dc = d < M ? d : 0;
-                eb = ag.rowptr[dc];
-                ee = ag.rowptr[dc + 1];
+        if (i > 0) {
+            // the rows of a later step: sources / codes of the second step were fetched with the first's, a third one's are not
+            cd = d_[1]; ce0 = e0_[1]; ce1 = e1_[1]; cs0 = s0_[1]; cs1 = s1_[1]; ck0 = k0_[1]; ck1 = k1_[1];
+            if (i >= NPRE) {                                     // (not fetched ahead: a norm pending, or launches past 512 x 32 rows)
+                cd = row_of(i);
+                const bool valid = cd < M;
+                const int dc = valid ? cd : 0;
+                ce0 = valid ? ag.rowptr[dc] : 0;
+                ce1 = valid ? ag.rowptr[dc + 1] : 0;
+                const bool any = ce0 < ce1;
+                const int stride = ce1 - ce0 > 16 ? 2 : 1;
+                const int i0 = any ? min(ce0, ce1 - 1) : 0, i1 = any ? min(ce0 + stride, ce1 - 1) : 0;
+                const int *cp = any ? ag.col : ag.rowptr;
+                const unsigned *kp = any ? ag.codes : reinterpret_cast<const unsigned *>(ag.rowptr);
+                cs0 = cp[i0]; cs1 = cp[i1]; ck0 = kp[i0]; ck1 = kp[i1];
             }
-            fill(d, eb, ee);
+            const int selfr = ((NORMED || ag.add_self) && cd < M) ? cd : 0;
+            const Raw a0 = load_raw(ce0 < ce1 ? cs0 : 0), a1 = load_raw(ce0 < ce1 ? cs1 : 0), as = load_raw(selfr);
+            w0v = a0.v; w0r = a0.rr; w1v = a1.v; w1r = a1.rr; wsv = as.v; wsr = as.rr;
         }
+        unsigned long long p0 = 0, p1 = 0, p2 = 0;
+        if (a.stamps) p0 = __builtin_amdgcn_s_memrealtime();
+        finish(cd, ce0, ce1, cs0, cs1, ck0, ck1, w0v, w0r, w1v, w1r, wsv, wsr);     // (ONE call site: the walk is a lot of code)
+        if (a.stamps) p1 = __builtin_amdgcn_s_memrealtime();
         lds_barrier();                                           // the step's image is complete
+        if (a.stamps) p2 = __builtin_amdgcn_s_memrealtime();
         f32x4_t acc = bias4;
         f32x4_t fr[2], hr[2];
         fr[0] = image[fbase];
@@ -275,7 +381,13 @@ __global__ __launch_bounds__(HS_AG_THREADS) PHC_AG_OCC void gemm_hs_ag_kernel(Ge
         }
         if (row < M) *reinterpret_cast<f32x4_t *>(a.y + (size_t)row * NOUT + col0 + 4 * kq) = acc;
         if (i + 1 < my_steps) lds_barrier();                     // every wavefront has read the image
+        if (a.stamps) {
+            asm volatile("s_nop 0" ::"v"(acc));
+            const unsigned long long p3 = __builtin_amdgcn_s_memrealtime();
+            ph[0] += p1 - p0; ph[1] += p2 - p1; ph[2] += p3 - p2;
+        }
     }
+    if (a.stamps) tk[2] = __builtin_amdgcn_s_memrealtime();
     // ---- statistics of the output columns (gemm_hs16_kernel's HS_ST finale) ----
     {
         double S[1][4], Q[1][4];
@@ -286,6 +398,15 @@ __global__ __launch_bounds__(HS_AG_THREADS) PHC_AG_OCC void gemm_hs_ag_kernel(Ge
             Q[0][q] = hs_sum16(n * p * p + 2.0 * p * s1 + s2);
         }
         hs_publish<1>(a.stat_acc, NOUT, (int)(group % STAT_ACC_REP), col0, kq, c, S, Q);
+    }
+    if (a.stamps) {
+        tk[3] = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) {
+            unsigned long long *o = a.stamps + ((size_t)blockIdx.x * 8 + wave) * 12;
+            o[0] = tk[0]; o[1] = tk[1]; o[2] = tk[2]; o[3] = tk[3];
+            o[4] = ph[0]; o[5] = ph[1]; o[6] = ph[2]; o[7] = (unsigned long long)my_steps;
+            o[8] = dbg[0]; o[9] = dbg[1]; o[10] = dbg[2]; o[11] = dbg[3];
+        }
     }
 }
 

@@ -241,12 +241,11 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
             acc_loads(xa.acc);
             const int comp = tid / xa.p.k, kk = tid - comp * xa.p.k;
             // (always two loads — the counted wait below relies on it; without affine parameters they read accumulator words)
+            // (components laid out back to back — phc/hypercomplex/norm.py keeps them so —: the first table's pointer + the column; the
+            // table walk costs a pointer round trip in front of the asm load, with a full drain of the ring's first fill)
             const float *pw = reinterpret_cast<const float *>(xa.acc), *pb = pw;
-            for (int q = 0; q < xa.p.n_comp; ++q)
-                if (q == comp) {
-                    if (xa.p.has_weight) pw = xa.p.weight[q] + kk;
-                    if (xa.p.has_bias) pb = xa.p.bias[q] + kk;
-                }
+            if (xa.p.has_weight) pw = bn_col_ptr(xa.p.weight, xa.p.flat, comp, kk, tid);
+            if (xa.p.has_bias) pb = bn_col_ptr(xa.p.bias, xa.p.flat, comp, kk, tid);
             xfw_raw = hs_ld32(pw);
             xfb_raw = hs_ld32(pb);
         }
@@ -314,12 +313,9 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
                     st[col] = bt.mean; st[KR + col] = bt.invstd; st[2 * KR + col] = bt.scale; st[3 * KR + col] = bt.shift;
                     st[4 * KR + col] = w; st[5 * KR + col] = bq;
                     if (xa.p.has_running) {
-                        for (int q = 0; q < xa.p.n_comp; ++q)
-                            if (q == comp) {
-                                float *rm = xa.p.running_mean[q] + kk, *rv = xa.p.running_var[q] + kk;
-                                *rm = bn_running_update(*rm, xa.momentum, bt.mean);
-                                *rv = bn_running_update(*rv, xa.momentum, bt.unbiased);
-                            }
+                        float *rm = bn_col_ptr(xa.p.running_mean, xa.p.flat, comp, kk, col), *rv = bn_col_ptr(xa.p.running_var, xa.p.flat, comp, kk, col);
+                        *rm = bn_running_update(*rm, xa.momentum, bt.mean);
+                        *rv = bn_running_update(*rv, xa.momentum, bt.unbiased);
                     }
                 }
             }

@@ -169,6 +169,8 @@ struct BnParams {
     int n_comp;
     int k;              // columns per component
     int has_weight, has_bias, has_running, has_nbt;
+    int flat;           // every table present lays its components out back to back (tbl[c] == tbl[0] + c * k): column `col` of a
+                        // table is then tbl[0][col] — one load, no pointer hop (phc/hypercomplex/norm.py keeps them that way)
 };
 inline int fill_params(const char *who, BnParams *p, const float *const *weight, const float *const *bias,
                        float *const *running_mean, float *const *running_var, int64_t *const *nbt, int n_comp, int h) {
@@ -188,6 +190,13 @@ inline int fill_params(const char *who, BnParams *p, const float *const *weight,
         p->num_batches_tracked[c] = nbt ? reinterpret_cast<long long *>(nbt[c]) : nullptr;
         PHC_REQUIRE((!weight || weight[c]) && (!bias || bias[c]) && (!p->has_running || (running_mean[c] && running_var[c])),
                     PHC_ERR_INVALID_ARG, "%s: null parameter pointer for component %d", who, c);
+    }
+    p->flat = 1;
+    for (int c = 1; c < n_comp; ++c) {
+        const size_t o = (size_t)c * p->k;
+        if ((weight && weight[c] != weight[0] + o) || (bias && bias[c] != bias[0] + o) ||
+            (p->has_running && (running_mean[c] != running_mean[0] + o || running_var[c] != running_var[0] + o)))
+            p->flat = 0;
     }
     return PHC_OK;
 }
@@ -224,6 +233,29 @@ __device__ __forceinline__ double stat_acc_total(const unsigned long long *__res
         lo += (long long)p[h];
     }
     return (double)hi * (1.0 / 4096.0) + (double)lo * (1.0 / 4611686018427387904.0);
+}
+
+// The pointer of component `comp` out of one of BnParams' by-value tables, by a select chain over CONSTANT indices.  As
+// `for (q < n_comp) if (q == comp) v = tbl[q][kk]` the table is indexed at run time: hipcc reads the pointer with a vector load from
+// the kernel-argument segment and waits for it (vmcnt(0)) before it can load the value — weight, bias, running mean and running
+// variance were four serial pairs of round trips in every kernel's prologue (3.3 us of the 6 us in front of the first barrier of
+// gemm_hs_ag_kernel, scripts/dbg/ag_phases.py).  With constant indices the pointers are scalar loads issued at kernel entry and the
+// values are independent loads that travel together.
+template <typename T>
+__device__ __forceinline__ T *bn_pick(T *const (&tbl)[BN_MAX_COMP], int comp) {
+    T *p = tbl[0];
+#pragma unroll
+    for (int q = 1; q < BN_MAX_COMP; ++q) p = comp == q ? tbl[q] : p;
+    return p;
+}
+
+// &table(comp)[kk] = the entry of column col = comp * k + kk: from the first table when the components are contiguous.  (hipcc
+// evaluates both sides of the select — the table walk's pointer load still stands in front of the value load; a run-time BRANCH
+// around the two loads is worse: every join costs an s_waitcnt vmcnt(0).  Kernels where that round trip is on the critical path take
+// the layout as a template parameter instead: gemm_hs_ag_kernel.)
+template <typename T>
+__device__ __forceinline__ T *bn_col_ptr(T *const (&tbl)[BN_MAX_COMP], int flat, int comp, int kk, int col) {
+    return flat ? tbl[0] + col : bn_pick(tbl, comp) + kk;
 }
 
 // Norm constants from a column's accumulator totals (S = sum x, Q = sum x^2 over `count` rows; norm.py:30-35 forward, training mode).

@@ -432,11 +432,8 @@ __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
             xa_S = stat_acc_total(xa.acc, K, 0, tid);
             xa_Q = stat_acc_total(xa.acc, K, 1, tid);
             const int comp = tid / xa.p.k, kk = tid - comp * xa.p.k;
-            for (int q = 0; q < xa.p.n_comp; ++q)
-                if (q == comp) {
-                    if (xa.p.has_weight) xa_w = xa.p.weight[q][kk];
-                    if (xa.p.has_bias) xa_b = xa.p.bias[q][kk];
-                }
+            if (xa.p.has_weight) xa_w = *bn_col_ptr(xa.p.weight, xa.p.flat, comp, kk, tid);
+            if (xa.p.has_bias) xa_b = *bn_col_ptr(xa.p.bias, xa.p.flat, comp, kk, tid);
         }
     }
 
@@ -522,12 +519,9 @@ __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
                     st[4 * K + c] = w; st[5 * K + c] = bq;
                     if (xa.p.has_running) {
                         const int comp = c / xa.p.k, kk = c - comp * xa.p.k;
-                        for (int q = 0; q < xa.p.n_comp; ++q)
-                            if (q == comp) {
-                                float *rm = xa.p.running_mean[q] + kk, *rv = xa.p.running_var[q] + kk;
-                                *rm = bn_running_update(*rm, xa.momentum, bt.mean);
-                                *rv = bn_running_update(*rv, xa.momentum, bt.unbiased);
-                            }
+                        float *rm = bn_col_ptr(xa.p.running_mean, xa.p.flat, comp, kk, c), *rv = bn_col_ptr(xa.p.running_var, xa.p.flat, comp, kk, c);
+                        *rm = bn_running_update(*rm, xa.momentum, bt.mean);
+                        *rv = bn_running_update(*rv, xa.momentum, bt.unbiased);
                     }
                 }
             }
@@ -2332,6 +2326,7 @@ int phc_gemm_aggregate_stats(const phc_gemm_ag_desc *d, void *stream) {
     a.n_valid = d->n_valid_dev;
     a.stat_acc = reinterpret_cast<unsigned long long *>(d->stat_acc);
     a.panels = 1;
+    a.stamps = g_hs_stamps;
     // workgroups: as many as the statistics-epilogue GEMM on the same rows takes (two per CU) — a workgroup's steps, and with them
     // the partial sums it adds to the accumulator, are then the same sets of rows: the totals are bit-identical to that launch's
     static const int per_cu_env = getenv("PHC_HS_AG_GROUPS_PER_CU") ? atoi(getenv("PHC_HS_AG_GROUPS_PER_CU")) : 0;
@@ -2342,17 +2337,24 @@ int phc_gemm_aggregate_stats(const phc_gemm_ag_desc *d, void *stream) {
     hipStream_t s = (hipStream_t)stream;
     const size_t tbl_bytes = (size_t)(128 + ag.off[d->F]) * 128 * sizeof(float);     // the operand (k4 form) + the bond tables in LDS
     ProfScope prof(K_PHM_GEMM_AG, s);
-#define PHC_AG_LAUNCH1(FC, NC)                                                                                                     \
+#define PHC_AG_LAUNCH1(FC, NC, RC, LC)                                                                                             \
     do {                                                                                                                           \
-        PHC_REQUIRE(ensure_dynamic_lds(&gemm_hs_ag_kernel<FC, NC>, (128 + HS_AG_MAX_ROWS) * 128 * sizeof(float)), PHC_ERR_LAUNCH,  \
+        PHC_REQUIRE(ensure_dynamic_lds(&gemm_hs_ag_kernel<FC, NC, RC, LC>, (128 + HS_AG_MAX_ROWS) * 128 * sizeof(float)), PHC_ERR_LAUNCH, \
                     "phc_gemm_aggregate_stats: the device refused the dynamic LDS");                                              \
-        PHC_LAUNCH((gemm_hs_ag_kernel<FC, NC>), dim3((unsigned)groups), dim3(HS_AG_THREADS), tbl_bytes, s, a, ag);                \
+        PHC_LAUNCH((gemm_hs_ag_kernel<FC, NC, RC, LC>), dim3((unsigned)groups), dim3(HS_AG_THREADS), tbl_bytes, s, a, ag);        \
     } while (0)
-#define PHC_AG_LAUNCH(FC)             \
-    if (normed)                       \
-        PHC_AG_LAUNCH1(FC, true);     \
-    else                              \
-        PHC_AG_LAUNCH1(FC, false)
+    // (the norm parameters' layout is a template parameter: a run-time branch around the loads costs a full drain at its join)
+#define PHC_AG_LAUNCH(FC)                                   \
+    if (normed && ag.norm_act == PHC_ACT_RELU && ag.p.flat) \
+        PHC_AG_LAUNCH1(FC, true, true, true);               \
+    else if (normed && ag.norm_act == PHC_ACT_RELU)         \
+        PHC_AG_LAUNCH1(FC, true, true, false);              \
+    else if (normed && ag.p.flat)                           \
+        PHC_AG_LAUNCH1(FC, true, false, true);              \
+    else if (normed)                                        \
+        PHC_AG_LAUNCH1(FC, true, false, false);             \
+    else                                                    \
+        PHC_AG_LAUNCH1(FC, false, true, true)
     switch (d->F) {
         case 1: PHC_AG_LAUNCH(1); break;
         case 2: PHC_AG_LAUNCH(2); break;
