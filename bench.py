@@ -57,7 +57,7 @@ import torch  # noqa: E402
 
 PEAK_HBM_GBS = 8000.0          # MI355X_MICROARCH.md: 8 TB/s HBM3E
 PEAK_FP32_MFMA_TFLOPS = 157.3  # MI355X_MICROARCH.md: dense fp32 matrix peak
-MFMA_KERNELS = ("phm_gemm_fwd", "phm_gemm_dx", "phm_dH_partial", "table_grad")
+MFMA_KERNELS = ("phm_gemm_fwd", "phm_gemm_dx", "phm_dH_partial", "table_grad", "phm_gemm_ag_fwd")
 # launch-profiler kernel name -> substrings of the rocprofv3 kernel names of that FAMILY in profiles/<PMC_FILE>
 # (a family = every instantiation the launch profiler books under one name; traffic = launch-weighted mean over them)
 PMC_NAMES = {"phm_gemm_fwd": ("gemm_hs16_kernel<128, 2, 4, 1, 4, 1>", "gemm_hs16_kernel<128, 2, 4, 1, 4, 3>",
@@ -65,6 +65,8 @@ PMC_NAMES = {"phm_gemm_fwd": ("gemm_hs16_kernel<128, 2, 4, 1, 4, 1>", "gemm_hs16
                               "gemm_hs16_kernel<256, 2, 8, 1, 4, 0>", "gemm_hs16_kernel<128, 2, 4, 1, 4, 0>"),
              "phm_gemm_dx": ("gemm_hs16_kernel<128, 2, 4, 1, 4, 8>", "gemm_hs16_kernel<128, 2, 4, 1, 4, 12>",
                              "gemm_hs16_kernel<256, 2, 8, 1, 4, 8>", "gemm_hs16_kernel<256, 2, 8, 1, 4, 12>"),
+             # the layer's aggregation inside its first GEMM (molecule batches, round 4): GEMM flops only are booked
+             "phm_gemm_ag_fwd": ("gemm_hs_ag_kernel",),
              "phm_dH_partial": ("tail_partial_kernel",), "aggregate_enc_fwd": ("aggregate_encp_direct_fwd_kernel", "aggregate_norm_fwd_kernel"),
              "aggregate_enc_dx": ("aggregate_dx_rows_kernel",), "aggregate_fwd": ("aggregate_fwd_kernel",),
              "bn_apply": ("bn_apply_acc_kernel",), "bn_bwd_apply": ("bn_bwd_apply_acc_kernel",), "bn_bwd_partial": ("bn_bwd_partial_kernel",),
@@ -621,7 +623,11 @@ def main():
                 out["traffic"] = pmc_traffic(kname, args.workload)
                 return out
             result["roofline_phm_gemm"] = frac_of("phm_gemm_fwd")
-            result["roofline_aggregate"] = frac_of("aggregate_enc_fwd") or frac_of("aggregate_fwd")
+            # (molecule batches: the forward aggregation rides inside the layer's first GEMM — `roofline_phm_gemm_aggregate` —
+            # and the row walker that is left is the backward one)
+            result["roofline_aggregate"] = frac_of("aggregate_enc_fwd") or frac_of("aggregate_fwd") or frac_of("aggregate_enc_dx")
+            if "phm_gemm_ag_fwd" in times:
+                result["roofline_phm_gemm_aggregate"] = frac_of("phm_gemm_ag_fwd")
             roof = frac_of(name)
             roof.update({"traffic_source": "profiles/" + PMC_FILE + " (rocprofv3 --pmc passes of this workload: FETCH_SIZE x2 + "
                          "WRITE_SIZE per launch, MI355X_MICROARCH.md HBM section, launch-weighted over the family's instantiations; "

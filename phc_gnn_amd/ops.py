@@ -2774,7 +2774,8 @@ class PendingAggregate:
             pn.done = True
         if L.PROF_ON:
             E = self.st.num_edges
-            L.account("phm_gemm_ag_fwd", 2.0 * N * h * h + 2.0 * E * h,
+            # (flops: the GEMM's only — the sums of the aggregation are not matrix work)
+            L.account("phm_gemm_ag_fwd", 2.0 * N * h * h,
                       4.0 * (2 * N * h + h * h + h) + E * (4.0 * h + 8 + 8.0 * ts.F) + N * 4.0 * h * (2 if self.add_self else 1))
         self.done = True
         return True
