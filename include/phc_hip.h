@@ -826,6 +826,37 @@ int phc_gated_pool_fwd(const float *x, const float *gate, const int32_t *seg_ptr
  * every workgroup finds its graph's rows with two cooperative searches, so no segment-pointer launch is needed. */
 int phc_gated_pool_fwd_sorted(const float *x, const float *gate, const int64_t *batch_sorted_i64, int64_t N,
                               int64_t num_graphs, int h, int n_comp, float *out, void *stream);
+/* The soft-attention read-out's forward as ONE launch (ABI 5, h = 128, k = kg = 32: phc_readout_fused_supported):
+ *     x    = act(batch_norm(x_in)) (+ skip)   the last layer's norm, un-applied (norm_acc != NULL; as phc_aggregate_norm_encp_fwd), or x
+ *     gate = x . M + c                        M [h, kg] row-major: the composed gate map (phc_phm_H_job.flags == 3), pooling.py:57-66
+ *     out[g, c k + j] = sum_{r: batch[r] = g} x[r, c k + j] sigmoid(gate[r, j])              (phc_gated_pool_fwd_sorted)
+ * A workgroup owns a graph (rows found in the sorted batch vector), builds 16-row tiles of x in LDS, multiplies them with the gate
+ * operand on the matrix cores and adds the gated rows up; x_out (norm_acc != NULL) and gate are written once for the backward
+ * kernels, which are unchanged.  Same function as phc_bn_fwd_from_partials + phc_gemm_prebuilt + phc_gated_pool_fwd_sorted up to
+ * the fp32 summation order of the gate's contraction and of the per-graph sums (x itself is bit-identical). */
+typedef struct phc_readout_desc {
+    const float *x;                /* [N, h] rows, or the pending norm's input                                  */
+    const int64_t *batch_sorted_i64;   /* [N] non-decreasing graph ids                                          */
+    int64_t N, num_graphs;
+    int32_t h, n_comp, kg;
+    const float *M, *c;            /* gate operand [h, kg] and bias [kg] (or NULL)                              */
+    float *gate;                   /* [N, kg] out (pre-sigmoid)                                                 */
+    float *out;                    /* [num_graphs, h] out                                                       */
+    const int32_t *n_valid_dev;    /* device scalar or NULL: rows at and beyond it are padding (x := 0)         */
+    /* pending norm (ignored when norm_acc == NULL) */
+    const uint64_t *norm_acc;
+    const float *const *weight, *const *bias;
+    float *const *running_mean, *const *running_var;
+    int64_t *const *num_batches_tracked;
+    int32_t norm_n_comp, norm_act;
+    float momentum, eps;
+    const float *skip;
+    float *save_stat, *x_out;
+} phc_readout_desc;
+int phc_readout_fused_supported(int64_t N, int64_t num_graphs, int h, int n_comp, int kg);
+int phc_readout_fused_fwd(const phc_readout_desc *d, void *stream);
+/* Diagnostics only: 8 x 8 bytes per graph; every phc_readout_fused_fwd launch then stamps its workgroups' phase clocks there. */
+int phc_debug_readout_stamps(unsigned long long *dev_words);
 int phc_gated_pool_bwd(const float *dout, const float *x, const float *gate, const int64_t *batch, int64_t N,
                        int64_t num_graphs, int h, int n_comp, float *dx, float *dgate, void *stream);
 

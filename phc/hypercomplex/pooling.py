@@ -64,8 +64,10 @@ class PHMSoftAttentionPooling(nn.Module):
                 and _engine.gate_composable(self.linear.W, aff.weight):
             # Linear(PHMLinear(x)) has nothing between its two maps: one GEMM with the composed [embed, embed / phm_dim] operand
             # (built by the step's operand launch), no [N, embed] intermediate — the same numbers up to fp32 round-off
-            gate = _engine.gate_linear(x, self.linear.phm_rule, self.linear.W, self.linear.b, aff.weight, aff.bias, dx_handoff=handoff)
+            gate = _engine.gate_linear(x, self.linear.phm_rule, self.linear.W, self.linear.b, aff.weight, aff.bias, dx_handoff=handoff,
+                                       lazy=bool(is_sorted))
         else:
+            _engine.materialize_pending(x)
             gate = self.real_trafo(self.linear(x, dx_handoff=handoff))         # pre-sigmoid [N, embed_dim / phm_dim]
         # sigmoid, broadcast over the components, multiply and per-graph sum in one engine pass
         return _engine.gated_segment_sum(x, gate, batch, self.phm_dim, num_graphs=num_graphs, is_sorted=is_sorted,

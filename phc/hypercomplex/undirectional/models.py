@@ -224,6 +224,8 @@ class PHMSkipConnectAdd(nn.Module):
         skip_sum = _engine.DxSumHandoff() if (uses is not None and atom.requires_grad and torch.is_grad_enabled()
                                               and L_ <= _engine.DxSumHandoff.MAX and _engine.SKIP_SUM_HANDOFF) else None
         h = uses[0] if uses is not None else atom
+        # (a sorted batch's soft-attention read-out applies the last layer's norm itself: engine PendingGate / phc_readout_fused_fwd)
+        readout_takes_norm = isinstance(self.pooling, PHMSoftAttentionPooling) and bool(getattr(data, "batch_is_sorted", False))
         for i in range(L_):
             if uses is not None:
                 skip = uses[1 + i]
@@ -237,15 +239,17 @@ class PHMSkipConnectAdd(nn.Module):
                                                         dropout_mpnn=self.dropout_mpnn[i], size=size, edge_encoder=enc,
                                                         n_valid=n_valid, skip_sum=skip_sum, first_layer=(i == 0),
                                                         # the layer's last element-wise pass rides in the NEXT layer's aggregation
-                                                        defer_norm=(i + 1 < L_ and getattr(self.bondencoders[i + 1], "engine_tables",
-                                                                                            None) is not None))
+                                                        # ... the last layer's in the soft-attention read-out's one launch
+                                                        defer_norm=(getattr(self.bondencoders[i + 1], "engine_tables", None) is not None
+                                                                    if i + 1 < L_ else readout_takes_norm))
                 continue
             e = enc(edge_attr)
             e = e.reshape(e.size(0), self.mp_layers[i])
             h = self.compute_hidden_layer_embedding(conv=self.convs[i], norm=self.norms[i], x=[h, skip],
                                                     edge_index=edge_index, edge_attr=e,
                                                     dropout_mpnn=self.dropout_mpnn[i], size=size, n_valid=n_valid)
-        _engine.materialize_pending(h)                       # (never parked for the last layer; a guard for subclasses)
+        if not readout_takes_norm:
+            _engine.materialize_pending(h)                   # (a guard for subclasses: only that read-out knows about a parked norm)
         num_graphs = getattr(data, "num_graphs", None)
         # The reference's scatter-based global_add_pool does not care about the order of `batch`; the binary-search
         # read-out does.  Only a batch object that SAYS its `batch` vector is non-decreasing (harness.to_device and the

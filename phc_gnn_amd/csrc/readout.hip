@@ -228,6 +228,263 @@ __global__ __launch_bounds__(GP_THREADS) void gated_pool_fwd_kernel(const float 
     }
 }
 
+// ---- the whole read-out forward as ONE launch (round 4) ---------------------------------------------------------------------------
+//   x    = act(norm(y)) (+ skip)            the last layer's un-applied norm (models.py:208-215), or x as it is
+//   gate = x . M + c                        the composed gate map Linear(PHMLinear(x)) (pooling.py:57-66), M [128, 32]
+//   out[g, c k + j] = sum_{r in graph g} x[r, c k + j] sigmoid(gate[r, j])
+// Separately: bn_apply_acc_kernel -> the gate GEMM -> gated_pool_fwd_kernel, three launches over the same 12.9 k x 128 rows (34 us of the
+// molecule step).  Here a workgroup owns a GRAPH (its rows found in the sorted batch vector by two cooperative searches in lockstep,
+// beside the norm's accumulator prologue): 16 rows at a time go into an LDS image in the MFMA fragment layout (gemm_hs_ag_device.h:
+// two rows per 1 KiB instruction, odd row XOR 1), two wavefronts multiply the image with the gate operand they hold in registers
+// (16 x 128 x 32 by v_mfma_f32_16x16x4_f32, swapped roles), sigmoid(gate) goes to LDS, and every thread adds its column's products.
+// x and gate are written out once (the backward kernels read them, unchanged).  h = 128, k = 32.
+constexpr int RF_THREADS = 512;
+struct ReadoutFusedArgs {
+    const float *y, *skip;
+    const unsigned long long *acc;
+    BnParams p;
+    float momentum, eps;
+    int norm_act;
+    float *stat, *x_out;
+    const int *n_valid;
+    const long long *batch;
+    int N, num_graphs;
+    const float *M, *c;
+    float *gate, *out;
+    unsigned long long *stamps;      // diagnostics (phc_debug_readout_stamps): 8 words per workgroup, null in the product
+};
+using rf_f32x4 = __attribute__((ext_vector_type(4))) float;
+// LDS traffic only: __syncthreads() also waits for every global load and store in flight (vmcnt(0)) — the next tile's rows, fetched
+// ahead on purpose, and the x / gate rows on their way out
+__device__ __forceinline__ void rf_lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+}
+
+template <bool NORMED, bool RELU, bool FLAT>
+__global__ __launch_bounds__(RF_THREADS) void readout_fused_fwd_kernel(ReadoutFusedArgs a) {
+    constexpr int K = 128, KG = 32, H4 = 32, ISTRIDE = 66, G = 8;
+    __shared__ rf_f32x4 image[8 * ISTRIDE];
+    __shared__ __attribute__((aligned(16))) float s_scale[K], s_shift[K];
+    __shared__ float sgate[16][KG + 1];
+    __shared__ float red[4][K];
+    __shared__ int slot[2];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, kq = lane >> 4;
+    const int g = (int)blockIdx.x;
+    const int N = a.N;
+    unsigned long long tk[6] = {0, 0, 0, 0, 0, 0};
+    if (a.stamps) tk[0] = __builtin_amdgcn_s_memrealtime();
+    // ---- first level of the search for this graph's rows: both keys probe the same positions, ONE load, in flight before everything
+    // else (memory operations complete in order: behind the accumulator words and the gate operand it came back 9 us after entry) ----
+    const int stride1 = max((N + RF_THREADS - 1) / RF_THREADS, 1);
+    const int i1 = tid * stride1;
+    const long long v1 = i1 < N ? a.batch[i1] : 0x7fffffffffffffffLL;
+    const int nvr = a.n_valid ? *a.n_valid : N;                  // (behind the probe: the first thing waited for is the probe)
+    // ---- pending norm: (column, replica) per thread, as gemm_hs_ag_kernel ----
+    const int ncol = tid >> 2, nrep = tid & 3;
+    const int ncomp = NORMED ? ncol / a.p.k : 0, nkk = NORMED ? ncol - ncomp * a.p.k : 0;
+    const bool owner = blockIdx.x == 0;
+    unsigned long long araw[4] = {0, 0, 0, 0};
+    float nw = 1.f, nb = 0.f, rm_old = 0.f, rv_old = 1.f;
+    if constexpr (NORMED) {
+        const unsigned long long *ap = a.acc + (size_t)(nrep * 2) * 2 * K + ncol;
+        araw[0] = ap[0]; araw[1] = ap[K]; araw[2] = ap[2 * K]; araw[3] = ap[3 * K];
+        if (a.p.has_weight) nw = FLAT ? a.p.weight[0][ncol] : bn_pick(a.p.weight, ncomp)[nkk];
+        if (a.p.has_bias) nb = FLAT ? a.p.bias[0][ncol] : bn_pick(a.p.bias, ncomp)[nkk];
+        if (a.p.has_running && owner) {
+            rm_old = FLAT ? a.p.running_mean[0][ncol] : bn_pick(a.p.running_mean, ncomp)[nkk];
+            rv_old = FLAT ? a.p.running_var[0][ncol] : bn_pick(a.p.running_var, ncomp)[nkk];
+        }
+    }
+    // ---- rows of graph g: lower bounds of g and g + 1 in the sorted batch vector, both searches in lockstep (RF_THREADS probes per
+    // level and key: two levels cover 262 144 rows) ----
+    int r0, r1;
+    {
+        int lo[2] = {0, 0}, hi[2] = {N, N};
+        const long long key[2] = {(long long)g, (long long)g + 1};
+        for (int level = 0;; ++level) {
+            int stride[2], first[2], pi[2];
+            bool ge[2];
+            long long pv[2];
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int len = hi[s] - lo[s];
+                stride[s] = max((len + RF_THREADS - 1) / RF_THREADS, 1);
+                pi[s] = lo[s] + tid * stride[s];
+            }
+            // both keys' probes in ONE round trip, unconditional (clamped): as `i < hi && batch[i] >= key` each load sits in a branch of
+            // its own with a full drain (vmcnt(0): the accumulator words too) at the join — two serial round trips per level
+            if (level == 0) {
+                pv[0] = pv[1] = v1;                              // (lo = 0, hi = N for both keys: the probe fetched at entry)
+            } else {
+                pv[0] = a.batch[min(pi[0], N - 1)];
+                pv[1] = a.batch[min(pi[1], N - 1)];
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) ge[s] = pi[s] < hi[s] && pv[s] >= key[s];
+            if (tid < 2) slot[tid] = RF_THREADS;
+            rf_lds_barrier();                                  // (not __syncthreads: that would drain the accumulator words' loads)
+#pragma unroll
+            for (int s = 0; s < 2; ++s)
+                if (ge[s]) atomicMin(&slot[s], tid);
+            rf_lds_barrier();
+            first[0] = slot[0];
+            first[1] = slot[1];
+            rf_lds_barrier();
+            bool done = true;
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const int len = hi[s] - lo[s];
+                if (len <= 0) continue;
+                const int probes = (len + stride[s] - 1) / stride[s];
+                if (stride[s] == 1) {
+                    const int ans = first[s] >= probes ? hi[s] : lo[s] + first[s];
+                    lo[s] = hi[s] = ans;
+                } else {
+                    const int nlo = first[s] == 0 ? lo[s] : lo[s] + (min(first[s], probes) - 1) * stride[s] + 1;
+                    const int nhi = first[s] >= probes ? hi[s] : lo[s] + first[s] * stride[s];
+                    lo[s] = nlo;
+                    hi[s] = nhi;
+                    done = done && nhi <= nlo;
+                }
+            }
+            if (done) break;
+        }
+        r0 = lo[0];
+        r1 = lo[1];
+    }
+    if (a.stamps) tk[1] = __builtin_amdgcn_s_memrealtime();
+    const int count = min(nvr, N);
+    // ---- the gate operand of this wavefront's 16-column tile (wavefronts 0, 1): k-group gq, step q -> row 16 gq + 4 kq + q of M ----
+    rf_f32x4 hreg[G];
+    if (wave < 2) {
+#pragma unroll
+        for (int gq = 0; gq < G; ++gq)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) hreg[gq][q] = a.M[(size_t)(16 * gq + 4 * kq + q) * KG + 16 * wave + c];
+    }
+    // ---- the norm's constants (arithmetic and order of the stand-alone kernels: bn_from_totals, replicas in order) ----
+    if constexpr (NORMED) {
+        const double pS = (double)(long long)araw[0] * (1.0 / 4096.0) + (double)(long long)araw[1] * (1.0 / 4611686018427387904.0);
+        const double pQ = (double)(long long)araw[2] * (1.0 / 4096.0) + (double)(long long)araw[3] * (1.0 / 4611686018427387904.0);
+        const int qbase = lane & ~3;
+        double S = __shfl(pS, qbase, 64), Q = __shfl(pQ, qbase, 64);
+#pragma unroll
+        for (int r = 1; r < 4; ++r) {
+            S += __shfl(pS, qbase + r, 64);
+            Q += __shfl(pQ, qbase + r, 64);
+        }
+        if (nrep == 0) {
+            const BnFromTotals bt = bn_from_totals(S, Q, count, nw, nb, a.eps);
+            s_scale[ncol] = bt.scale;
+            s_shift[ncol] = bt.shift;
+            if (owner) {
+                float *stat = a.stat;
+                stat[ncol] = bt.mean;
+                stat[K + ncol] = bt.invstd;
+                stat[2 * K + ncol] = bt.scale;
+                stat[3 * K + ncol] = bt.shift;
+                stat[4 * K + ncol] = nw;
+                stat[5 * K + ncol] = nb;
+                if (a.p.has_running) {
+                    *(FLAT ? a.p.running_mean[0] + ncol : bn_pick(a.p.running_mean, ncomp) + nkk) = bn_running_update(rm_old, a.momentum, bt.mean);
+                    *(FLAT ? a.p.running_var[0] + ncol : bn_pick(a.p.running_var, ncomp) + nkk) = bn_running_update(rv_old, a.momentum, bt.unbiased);
+                }
+            }
+        }
+        if (owner && a.p.has_nbt && tid < a.p.n_comp)
+            for (int q = 0; q < a.p.n_comp; ++q)
+                if (q == tid) *a.p.num_batches_tracked[q] += 1;
+        rf_lds_barrier();
+    }
+    if (a.stamps) tk[2] = __builtin_amdgcn_s_memrealtime();
+    const int dsub = lane >> 5, li = lane & 31, c4 = li ^ dsub;
+    const float4 *Y4 = reinterpret_cast<const float4 *>(a.y) + c4;
+    const float4 *S4 = reinterpret_cast<const float4 *>(a.skip ? a.skip : a.y) + c4;
+    const bool has_skip = a.skip != nullptr;
+    const int fbase = (c >> 1) * ISTRIDE + (c & 1) * H4 + (kq ^ (c & 1));
+    rf_f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
+    if (wave < 2 && a.c) bias4 = *reinterpret_cast<const rf_f32x4 *>(a.c + 16 * wave + 4 * kq);
+    const int pcol = tid & (K - 1), part = tid >> 7;           // the column this thread adds up, and its quarter of a tile's rows
+    float pacc = 0.f;
+    // the next tile's rows travel while this tile is multiplied and added up (a 200-atom molecule is 13 tiles: its workgroup is the
+    // launch's critical path)
+    float4 v_next = make_float4(0.f, 0.f, 0.f, 0.f), rr_next = v_next;
+    if (r0 < r1) {
+        const int rn = min(r0 + 2 * wave + dsub, r1 - 1);
+        v_next = Y4[(size_t)rn * H4];
+        if constexpr (NORMED) rr_next = S4[(size_t)rn * H4];
+    }
+    for (int rb = r0; rb < r1; rb += 16) {
+        // ---- this half-wavefront's row of the tile -> LDS image (and out to memory once) ----
+        const int r = rb + 2 * wave + dsub;
+        const bool valid = r < r1;
+        const int rc = valid ? r : r1 - 1;
+        const float4 v = v_next;
+        const float4 rr_cur = rr_next;
+        if (rb + 16 < r1) {
+            const int rn = min(rb + 16 + 2 * wave + dsub, r1 - 1);
+            v_next = Y4[(size_t)rn * H4];
+            if constexpr (NORMED) rr_next = S4[(size_t)rn * H4];
+        }
+        float4 o = v;
+        if constexpr (NORMED) {
+            const float4 rr = rr_cur;
+            const float4 sc = *reinterpret_cast<const float4 *>(s_scale + 4 * c4), sh = *reinterpret_cast<const float4 *>(s_shift + 4 * c4);
+            if constexpr (RELU) {
+                o.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f); o.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
+                o.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f); o.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
+            } else {
+                o.x = act_fwd_rt(a.norm_act, fmaf(v.x, sc.x, sh.x)); o.y = act_fwd_rt(a.norm_act, fmaf(v.y, sc.y, sh.y));
+                o.z = act_fwd_rt(a.norm_act, fmaf(v.z, sc.z, sh.z)); o.w = act_fwd_rt(a.norm_act, fmaf(v.w, sc.w, sh.w));
+            }
+            o.x = has_skip ? o.x + rr.x : o.x; o.y = has_skip ? o.y + rr.y : o.y;
+            o.z = has_skip ? o.z + rr.z : o.z; o.w = has_skip ? o.w + rr.w : o.w;
+            if (rc >= count) o = make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        if (!valid) o = make_float4(0.f, 0.f, 0.f, 0.f);
+        image[wave * ISTRIDE + lane] = rf_f32x4{o.x, o.y, o.z, o.w};
+        if constexpr (NORMED) {
+            if (valid) reinterpret_cast<float4 *>(a.x_out)[(size_t)r * H4 + c4] = o;
+        }
+        rf_lds_barrier();
+        // ---- gate tile: wavefront w < 2 owns columns 16 w .. 16 w + 15 ----
+        if (wave < 2) {
+            rf_f32x4 acc = bias4;
+#pragma unroll
+            for (int gq = 0; gq < G; ++gq) {
+                const rf_f32x4 fr = image[fbase + 4 * gq];
+#pragma unroll
+                for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(hreg[gq][q], fr[q], acc, 0, 0, 0);
+            }
+            const int row = rb + c;                              // lane (c, kq) holds gate[row][16 w + 4 kq .. + 3]
+            if (row < r1) *reinterpret_cast<rf_f32x4 *>(a.gate + (size_t)row * KG + 16 * wave + 4 * kq) = acc;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) sgate[c][16 * wave + 4 * kq + q] = 1.f / (1.f + expf(-acc[q]));
+        }
+        rf_lds_barrier();
+        // ---- this thread's column: rows part, part + 4, ... of the tile ----
+        const float *img = reinterpret_cast<const float *>(image);
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            const int rr_ = part + 4 * u;
+            const float xv = img[((rr_ >> 1) * ISTRIDE + 32 * (rr_ & 1) + ((pcol >> 2) ^ (rr_ & 1))) * 4 + (pcol & 3)];
+            pacc = rb + rr_ < r1 ? fmaf(xv, sgate[rr_][pcol & (KG - 1)], pacc) : pacc;
+        }
+        rf_lds_barrier();
+    }
+    if (a.stamps) tk[3] = __builtin_amdgcn_s_memrealtime();
+    red[part][pcol] = pacc;
+    __syncthreads();
+    if (part == 0) a.out[(size_t)g * K + pcol] = (red[0][pcol] + red[1][pcol]) + (red[2][pcol] + red[3][pcol]);
+    if (a.stamps && tid == 0) {
+        unsigned long long *o = a.stamps + (size_t)g * 8;
+        o[0] = tk[0]; o[1] = tk[1]; o[2] = tk[2]; o[3] = tk[3]; o[4] = __builtin_amdgcn_s_memrealtime(); o[5] = (unsigned long long)(r1 - r0);
+    }
+}
+
 // dx[r, c*k+j] = dout[g(r), c*k+j] * s_j ;  dgate[r, j] = s_j (1 - s_j) * sum_c dout[g(r), c*k+j] * x[r, c*k+j]
 // Row-parallel: thread -> (row, VEC gate columns), graph id from the int64 `batch` vector.
 template <int VEC>
@@ -522,6 +779,60 @@ int phc_gated_pool_fwd_sorted(const float *x, const float *gate, const int64_t *
                               int n_comp, float *out, void *stream) {
     PHC_REQUIRE(num_graphs == 0 || batch_sorted_i64, PHC_ERR_INVALID_ARG, "phc_gated_pool_fwd_sorted: null pointer");
     return gated_pool_fwd_impl(x, gate, nullptr, batch_sorted_i64, N, num_graphs, h, n_comp, out, stream);
+}
+
+static unsigned long long *g_readout_stamps = nullptr;
+int phc_debug_readout_stamps(unsigned long long *dev_words) {
+    g_readout_stamps = dev_words;
+    return PHC_OK;
+}
+
+int phc_readout_fused_supported(int64_t N, int64_t num_graphs, int h, int n_comp, int kg) {
+    static const bool off = getenv("PHC_READOUT_FUSED") && atoi(getenv("PHC_READOUT_FUSED")) == 0;
+    return (!off && N >= 1 && N <= (1 << 18) && num_graphs >= 1 && num_graphs <= (1 << 20) && h == 128 && n_comp >= 1 && h % n_comp == 0 &&
+            kg == 32 && h / n_comp == 32) ? 1 : 0;
+}
+
+int phc_readout_fused_fwd(const phc_readout_desc *d, void *stream) {
+    PHC_REQUIRE(d, PHC_ERR_INVALID_ARG, "phc_readout_fused_fwd: null descriptor");
+    PHC_REQUIRE(phc_readout_fused_supported(d->N, d->num_graphs, d->h, d->n_comp, d->kg), PHC_ERR_UNSUPPORTED,
+                "phc_readout_fused_fwd: %lld rows, %lld graphs, h = %d, %d components, gate width %d outside the fused form's range",
+                (long long)d->N, (long long)d->num_graphs, d->h, d->n_comp, d->kg);
+    PHC_REQUIRE(d->x && d->batch_sorted_i64 && d->M && d->gate && d->out, PHC_ERR_INVALID_ARG, "phc_readout_fused_fwd: null pointer");
+    const bool normed = d->norm_acc != nullptr;
+    PHC_REQUIRE(!normed || (d->save_stat && d->x_out), PHC_ERR_INVALID_ARG, "phc_readout_fused_fwd: a pending norm needs save_stat and x_out");
+    PHC_REQUIRE(!normed || (d->norm_act >= PHC_ACT_IDENTITY && d->norm_act <= PHC_ACT_SELU), PHC_ERR_INVALID_ARG,
+                "phc_readout_fused_fwd: unknown activation %d", d->norm_act);
+    PHC_REQUIRE(((reinterpret_cast<uintptr_t>(d->x) | reinterpret_cast<uintptr_t>(d->gate) | reinterpret_cast<uintptr_t>(d->c) |
+                  (normed ? (reinterpret_cast<uintptr_t>(d->x_out) | reinterpret_cast<uintptr_t>(d->skip)) : 0)) & 15) == 0 &&
+                    (reinterpret_cast<uintptr_t>(d->norm_acc) & 7) == 0,
+                PHC_ERR_UNSUPPORTED, "phc_readout_fused_fwd: 16-byte aligned rows / 8-byte aligned accumulator");
+    ReadoutFusedArgs a = {};
+    if (normed) {
+        int rc = fill_params("phc_readout_fused_fwd", &a.p, d->weight, d->bias, d->running_mean, d->running_var, d->num_batches_tracked,
+                             d->norm_n_comp, d->h);
+        if (rc) return rc;
+        a.acc = reinterpret_cast<const unsigned long long *>(d->norm_acc);
+        a.skip = d->skip; a.x_out = d->x_out; a.stat = d->save_stat;
+        a.momentum = d->momentum; a.eps = d->eps; a.norm_act = d->norm_act;
+    }
+    a.y = d->x; a.n_valid = d->n_valid_dev; a.batch = reinterpret_cast<const long long *>(d->batch_sorted_i64);
+    a.N = (int)d->N; a.num_graphs = (int)d->num_graphs; a.M = d->M; a.c = d->c; a.gate = d->gate; a.out = d->out;
+    a.stamps = g_readout_stamps;
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(K_GATED_POOL_FWD, s);
+    const dim3 grid((unsigned)d->num_graphs), block(RF_THREADS);
+    if (!normed)
+        PHC_LAUNCH((readout_fused_fwd_kernel<false, true, true>), grid, block, 0, s, a);
+    else if (a.norm_act == PHC_ACT_RELU && a.p.flat)
+        PHC_LAUNCH((readout_fused_fwd_kernel<true, true, true>), grid, block, 0, s, a);
+    else if (a.norm_act == PHC_ACT_RELU)
+        PHC_LAUNCH((readout_fused_fwd_kernel<true, true, false>), grid, block, 0, s, a);
+    else if (a.p.flat)
+        PHC_LAUNCH((readout_fused_fwd_kernel<true, false, true>), grid, block, 0, s, a);
+    else
+        PHC_LAUNCH((readout_fused_fwd_kernel<true, false, false>), grid, block, 0, s, a);
+    return check_launch("phc_readout_fused_fwd");
 }
 
 int phc_gated_pool_bwd(const float *dout, const float *x, const float *gate, const int64_t *batch, int64_t N, int64_t num_graphs,

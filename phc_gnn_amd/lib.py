@@ -79,6 +79,15 @@ class GemmAgDesc(C.Structure):
                 ("Mk4", _P), ("b", _P), ("Nout", C.c_int32), ("y", _P), ("n_valid_dev", _P), ("stat_acc", _P)]
 
 
+class ReadoutDesc(C.Structure):
+    """phc_readout_desc (include/phc_hip.h)."""
+    _fields_ = [("x", _P), ("batch_sorted_i64", _P), ("N", _L), ("num_graphs", _L), ("h", C.c_int32), ("n_comp", C.c_int32), ("kg", C.c_int32),
+                ("M", _P), ("c", _P), ("gate", _P), ("out", _P), ("n_valid_dev", _P),
+                ("norm_acc", _P), ("weight", _P), ("bias", _P), ("running_mean", _P), ("running_var", _P), ("num_batches_tracked", _P),
+                ("norm_n_comp", C.c_int32), ("norm_act", C.c_int32), ("momentum", C.c_float), ("eps", C.c_float),
+                ("skip", _P), ("save_stat", _P), ("x_out", _P)]
+
+
 class EncodeFront(C.Structure):
     """phc_encode_front (include/phc_hip.h)."""
     _fields_ = [("idx_i64", _P), ("tables", _P), ("vocab", _P), ("out", _P), ("N", _L), ("F", C.c_int32), ("n", C.c_int32), ("k", C.c_int32)]
@@ -138,6 +147,9 @@ SIGNATURES = {
     "phc_gemm_hs_set_enabled": (_I, [_I]),
     "phc_gemm_bwd_apply": (_I, [C.POINTER(GemmBaDesc), _P]),
     "phc_gemm_aggregate_supported": (_I, [_L, _I, _I, _I, _I]),
+    "phc_readout_fused_supported": (_I, [_L, _L, _I, _I, _I]),
+    "phc_readout_fused_fwd": (_I, [C.POINTER(ReadoutDesc), _P]),
+    "phc_debug_readout_stamps": (_I, [_P]),
     "phc_gemm_aggregate_stats": (_I, [C.POINTER(GemmAgDesc), _P]),
     "phc_bn_bwd_partial_acc": (_I, [_P, _P, _P, _P, _L, _I, _I, _P, _P]),
     "phc_bn_bwd_from_partials": (_I, [_P, _P, _P, _P, _I, _P, _L, _I, _I, _P, _P, _P, _S, _P]),

@@ -1684,16 +1684,22 @@ class _GatedSegmentSumFn(torch.autograd.Function):
     """out[g, c*k+j] = Σ_{r in graph g} x[r, c*k+j]·σ(gate[r, j]) over rows that are already grouped by graph."""
 
     @staticmethod
-    def forward(ctx, x, gate, st: SegmentStructure, n_comp: int, dx_handoff=None):
+    def forward(ctx, x, gate, st: SegmentStructure, n_comp: int, dx_handoff=None, pending_gate=None):
         lib = L.load()
         ctx.dx_handoff = dx_handoff
         dev = L.require_device(x, gate)
+        if pending_gate is not None and not (st.is_sorted and st._csr is None and not _POOL_SEGPTR):
+            pending_gate.materialize()
+            pending_gate = None
         x_, g_ = L.f32c(x), L.f32c(gate)
         N, h = x_.shape
         if h % n_comp or tuple(g_.shape) != (N, h // n_comp):
             raise L.PhcError(f"gate must be [{N}, {h // n_comp}] for x [{N}, {h}] with {n_comp} components")
         out = torch.empty((st.num_segments, h), dtype=torch.float32, device=dev)
-        if st.is_sorted and st._csr is None and not _POOL_SEGPTR:
+        pg = pending_gate
+        if pg is not None and pg.run_with_pool(st, n_comp, out):
+            pass
+        elif st.is_sorted and st._csr is None and not _POOL_SEGPTR:
             # collated batch: the workgroups find their rows in the sorted `batch` vector themselves (no pointer launch)
             L.check(lib.phc_gated_pool_fwd_sorted(L.ptr(x_), L.ptr(g_), L.ptr(st.batch), N, st.num_segments, h, n_comp,
                                                   L.ptr(out), L.stream_ptr(dev)), "phc_gated_pool_fwd_sorted")
@@ -1723,7 +1729,7 @@ class _GatedSegmentSumFn(torch.autograd.Function):
         if ctx.dx_handoff is not None and ctx.dx_handoff.accepted and dx is not None:
             ctx.dx_handoff.tensor = dx                      # added inside the gate layer's dx GEMM (DxHandoff)
             dx = None
-        return dx, dg, None, None, None
+        return dx, dg, None, None, None, None
 
 
 def gated_segment_sum(x: torch.Tensor, gate: torch.Tensor, batch, n_comp: int, num_graphs: Optional[int] = None,
@@ -1732,11 +1738,16 @@ def gated_segment_sum(x: torch.Tensor, gate: torch.Tensor, batch, n_comp: int, n
     [N, h/n_comp] broadcast over the n_comp components.  One kernel each way when ``batch`` is sorted (collated
     mini-batches are); an unsorted ``batch`` takes the sigmoid / multiply / segment-sum route."""
     st = batch if isinstance(batch, SegmentStructure) else segment_structure(batch, num_graphs, is_sorted)
+    pg = getattr(gate, "_phc_pending_gate", None)
+    if pg is not None:
+        gate._phc_pending_gate = None
     if not st.is_sorted:
+        if pg is not None:
+            pg.materialize()
         N, h = x.shape
         gated = (x.view(N, n_comp, h // n_comp) * torch.sigmoid(gate).unsqueeze(1)).reshape(N, h)
         return _SegmentSumFn.apply(gated, st)
-    return _GatedSegmentSumFn.apply(x, gate, st, n_comp, dx_handoff)
+    return _GatedSegmentSumFn.apply(x, gate, st, n_comp, dx_handoff, pg)
 
 
 # ---------------------------------------------------------------------------
@@ -1780,7 +1791,7 @@ def _gate_operands(A, W, b, Wg, bg):
 
 class _GateLinearFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, A, W, b, Wg, bg, dx_handoff=None):
+    def forward(ctx, x, A, W, b, Wg, bg, dx_handoff=None, lazy_box=None):
         lib = L.load()
         dev = L.require_device(x, A, W, b, Wg, bg)
         n, kin, kout = W.shape
@@ -1790,11 +1801,21 @@ class _GateLinearFn(torch.autograd.Function):
         N = x_.shape[0]
         M, MT, c = _gate_operands(A_, W_, b_, Wg_, bg_)
         gate = torch.empty((N, kg), dtype=torch.float32, device=dev)
-        if N:
-            L.check(lib.phc_gemm_prebuilt(L.ptr(x_), L.ptr(M), None, L.ptr(c), None, N, inw, kg, L.ptr(gate), 0, L.stream_ptr(dev)),
-                    "phc_gemm_prebuilt(gate)")
-            if L.PROF_ON:
-                L.account("phm_gemm_fwd", 2.0 * N * inw * kg, 4.0 * (N * (inw + kg) + inw * kg))
+        pend = lazy_box.get("pend") if lazy_box is not None else None      # the layer in front's un-applied norm (PendingNorm), if any
+        lazy = lazy_box is not None and lazy_box.get("lazy") and READOUT_FUSED and N > 0 and x_.data_ptr() % 16 == 0 and \
+            bool(lib.phc_readout_fused_supported(N, 1, inw, n, kg)) and (c is None or c.data_ptr() % 16 == 0)
+        if lazy:
+            # nothing is launched here: the gated sum that consumes this gate builds it itself (phc_readout_fused_fwd);
+            # anybody else calls PendingGate.materialize first
+            lazy_box["pg"] = PendingGate(x_, M, c, gate, pend if (pend is not None and not pend.done) else None)
+        else:
+            if pend is not None:
+                pend.materialize()
+            if N:
+                L.check(lib.phc_gemm_prebuilt(L.ptr(x_), L.ptr(M), None, L.ptr(c), None, N, inw, kg, L.ptr(gate), 0, L.stream_ptr(dev)),
+                        "phc_gemm_prebuilt(gate)")
+                if L.PROF_ON:
+                    L.account("phm_gemm_fwd", 2.0 * N * inw * kg, 4.0 * (N * (inw + kg) + inw * kg))
         ctx.dx_handoff = dx_handoff
         if dx_handoff is not None:
             dx_handoff.accepted = True
@@ -1834,7 +1855,7 @@ class _GateLinearFn(torch.autograd.Function):
         need = ctx.needs_input_grad
         nA, nW, nb, nWg, nbg = need[1], need[2], need[3] and b is not None, need[4], need[5] and bg is not None
         if not (nA or nW or nb or nWg or nbg) or N == 0:
-            return dx, None, None, None, None, None, None
+            return dx, None, None, None, None, None, None, None
         H = ctx.H
         results = {}
 
@@ -1865,17 +1886,84 @@ class _GateLinearFn(torch.autograd.Function):
                                            bg if nbg else None))
             with _DEFER.lock:
                 _DEFER.jobs.append(job)
-            return dx, None, None, None, None, None, None
+            return dx, None, None, None, None, None, None, None
         job["post"] = None
         (grads,) = _flush_param_grads([job], return_grads=True)
         post(grads)
         dA, dW, db, dWg, dbg = results["g"]
-        return dx, dA, dW, db, dWg, dbg, None
+        return dx, dA, dW, db, dWg, dbg, None, None
 
 
-def gate_linear(x: torch.Tensor, phm_rule, W, b, gate_weight, gate_bias, dx_handoff=None) -> torch.Tensor:
-    """Pre-sigmoid gate of the soft-attention read-out, ``Linear(PHMLinear(x))`` as one linear map (see above)."""
-    return _GateLinearFn.apply(x, phm_rule, W, b, gate_weight, gate_bias, dx_handoff)
+def gate_linear(x: torch.Tensor, phm_rule, W, b, gate_weight, gate_bias, dx_handoff=None, lazy: bool = False) -> torch.Tensor:
+    """Pre-sigmoid gate of the soft-attention read-out, ``Linear(PHMLinear(x))`` as one linear map (see above).  ``lazy``: the gate
+    goes straight into ``gated_segment_sum`` over a sorted batch — the launch may be left to that node (``PendingGate``)."""
+    pend = getattr(x, "_phc_pending", None)
+    want = bool(lazy and torch.is_grad_enabled())
+    box = dict(pend=pend, lazy=want) if (want or pend is not None) else None
+    gate = _GateLinearFn.apply(x, phm_rule, W, b, gate_weight, gate_bias, dx_handoff, box)
+    if box and box.get("pg") is not None:
+        gate._phc_pending_gate = box["pg"]
+        if box["pg"].pending is not None:
+            x._phc_pending = None                            # rides with the gate now
+    elif pend is not None:
+        x._phc_pending = None                                # (materialised inside the node)
+    return gate
+
+
+READOUT_FUSED = __import__("os").environ.get("PHC_READOUT_FUSED", "1") != "0"
+
+
+class PendingGate:
+    """gate = x . M + c of the soft-attention read-out that has NOT been launched (``gate`` is allocated): the gated per-graph sum
+    builds it itself (phc_readout_fused_fwd, csrc/readout.hip) together with the layer in front's un-applied norm (``pending``);
+    ``materialize`` = the launches that would have run (norm pass, gate GEMM)."""
+
+    def __init__(self, x_, M, c, gate, pending):
+        self.x_, self.M, self.c, self.gate, self.pending = x_, M, c, gate, pending
+        self.done = False
+
+    def materialize(self):
+        if self.done:
+            return
+        lib = L.load()
+        if self.pending is not None:
+            self.pending.materialize()
+        N, inw = self.x_.shape
+        kg = self.gate.shape[1]
+        L.check(lib.phc_gemm_prebuilt(L.ptr(self.x_), L.ptr(self.M), None, L.ptr(self.c), None, N, inw, kg, L.ptr(self.gate), 0,
+                                      L.stream_ptr(self.x_.device)), "phc_gemm_prebuilt(gate)")
+        if L.PROF_ON:
+            L.account("phm_gemm_fwd", 2.0 * N * inw * kg, 4.0 * (N * (inw + kg) + inw * kg))
+        self.done = True
+
+    def run_with_pool(self, st, n_comp, out) -> bool:
+        """Norm (if pending) + gate + gated per-graph sum in one launch; False = outside the fused form (nothing launched)."""
+        lib = L.load()
+        N, h = self.x_.shape
+        kg = self.gate.shape[1]
+        if self.done or not st.is_sorted or not lib.phc_readout_fused_supported(N, st.num_segments, h, n_comp, kg):
+            return False
+        d = L.ReadoutDesc()
+        d.batch_sorted_i64, d.N, d.num_graphs, d.h, d.n_comp, d.kg = L.ptr(st.batch), N, st.num_segments, h, n_comp, kg
+        d.M, d.c, d.gate, d.out = L.ptr(self.M), L.ptr(self.c), L.ptr(self.gate), L.ptr(out)
+        keep = None
+        pn = self.pending if (self.pending is not None and not self.pending.done) else None
+        if pn is not None:
+            keep = pn._norm_args()
+            w, bb, rm, rv, nbt, no = keep
+            cast = lambda a: _C.cast(a, _C.c_void_p) if a is not None else None
+            assert self.x_.data_ptr() == pn.out.data_ptr()
+            d.x, d.norm_acc, d.n_valid_dev = L.ptr(pn.y2), L.ptr(pn.acc2), L.ptr(pn.n_valid)
+            d.weight, d.bias, d.running_mean, d.running_var, d.num_batches_tracked = cast(w), cast(bb), cast(rm), cast(rv), cast(nbt)
+            d.norm_n_comp, d.norm_act, d.momentum, d.eps = no, pn.act_o, float(pn.outer["momentum"]), float(pn.outer["eps"])
+            d.skip, d.save_stat, d.x_out = L.ptr(pn.skip), L.ptr(pn.save_o), L.ptr(pn.out)
+        else:
+            d.x = L.ptr(self.x_)
+        L.check(lib.phc_readout_fused_fwd(_C.byref(d), L.stream_ptr(self.x_.device)), "phc_readout_fused_fwd")
+        if pn is not None:
+            pn.done = True
+        self.done = True
+        return True
 
 
 # Tensors known to hold exactly 1.0 for their whole life (harness.backward_seed, GraphedTrainStep's seed): a backward

@@ -211,3 +211,95 @@ def test_aggregation_inside_the_first_gemm_leaves_the_step_bit_identical(workloa
         finally:
             L.prof_enable(False)
         assert "phm_gemm_ag_fwd" in names, sorted(names)
+
+
+# ---- the read-out's forward as one launch (phc_readout_fused_fwd, csrc/readout.hip) ------------------------------------------------
+@pytest.mark.parametrize("B,sizes", [(7, "small"), (544, "molecules"), (40, "big")])
+@pytest.mark.parametrize("normed,act,with_skip", [(False, "relu", False), (True, "relu", True), (True, "swish", False)])
+def test_readout_in_one_launch_equals_the_three_launches(B, sizes, normed, act, with_skip):
+    """x (bit for bit), gate and the per-graph sums (fp32 summation order: 2e-6 of the largest entry) of ONE phc_readout_fused_fwd
+    launch against phc_bn_fwd_from_partials -> phc_gemm_prebuilt -> phc_gated_pool_fwd_sorted; empty graphs, graphs of 1 ... 300 rows,
+    padding rows behind *n_valid."""
+    import ctypes as C
+    from phc_gnn_amd import lib as L
+    lib = L.load()
+    n, k, h, kg = 4, 32, 128, 32
+    g = torch.Generator().manual_seed(B)
+    hi = dict(small=5, molecules=45, big=300)[sizes]
+    cnt = torch.randint(0, hi, (B,), generator=g)
+    cnt[B // 2] = 0                                                       # an empty graph in the middle
+    cnt[0] = max(int(cnt[0]), 1)
+    batch = torch.repeat_interleave(torch.arange(B), cnt).to(DEV)
+    N = int(batch.numel())
+    if not lib.phc_readout_fused_supported(N, B, h, n, kg):
+        pytest.skip("outside the fused form")
+    valid = max(N - 5, 1)
+    nv = torch.tensor([valid], dtype=torch.int32, device=DEV)
+    sp = L.stream_ptr(torch.device(DEV))
+    M = (torch.randn(h, kg, generator=g) / h ** 0.5).to(DEV)
+    c = torch.randn(kg, generator=g).to(DEV)
+    y_in = torch.randn(N, h, generator=g).to(DEV)
+    skip = torch.randn(N, h, generator=g).to(DEV) if with_skip else None
+    words = lib.phc_stat_acc_words(h)
+    arr = lambda tsr: (C.c_void_p * len(tsr))(*[t.data_ptr() for t in tsr])
+    split = lambda t: [t[cc * k:(cc + 1) * k] for cc in range(n)]
+    w, bb = split((0.5 + torch.rand(h, generator=g)).to(DEV)), split(torch.randn(h, generator=g).to(DEV))
+    norm_acc = torch.zeros(words, dtype=torch.int64, device=DEV)
+    if normed:
+        P = (torch.randn(h, h, generator=g) / h ** 0.5).to(DEV)
+        L.check(lib.phc_gemm_prebuilt_stats(L.ptr(torch.randn(N, h, generator=g).to(DEV)), L.ptr(P), None, None, N, h, h, L.ptr(y_in), L.ptr(nv),
+                                            L.ptr(norm_acc), None, None, sp), "producer")
+    res = {}
+    for tag in ("separate", "fused"):
+        rm, rv = split(torch.zeros(h, device=DEV)), split(torch.ones(h, device=DEV))
+        nbt = [torch.zeros((), dtype=torch.int64, device=DEV) for _ in range(n)]
+        save = torch.zeros(6 * h, device=DEV)
+        x_out = torch.zeros(N, h, device=DEV)
+        gate = torch.zeros(N, kg, device=DEV)
+        out = torch.full((B, h), 7.0, device=DEV)
+        keep = (arr(w), arr(bb), arr(rm), arr(rv), arr(nbt))
+        if tag == "separate":
+            x = y_in
+            if normed:
+                L.check(lib.phc_bn_fwd_from_partials(L.ptr(y_in), L.ptr(norm_acc), None, 0, keep[0], keep[1], keep[2], keep[3], keep[4], n, L.ptr(nv),
+                                                     N, h, 0.1, 1e-5, L.ACT_IDS[act], L.ptr(skip), L.ptr(x_out), L.ptr(save), 0.0, 0, 0, None, sp),
+                        "bn_fwd_from_partials")
+                x = x_out
+            L.check(lib.phc_gemm_prebuilt(L.ptr(x), L.ptr(M), None, L.ptr(c), None, N, h, kg, L.ptr(gate), 0, sp), "gate gemm")
+            L.check(lib.phc_gated_pool_fwd_sorted(L.ptr(x), L.ptr(gate), L.ptr(batch), N, B, h, n, L.ptr(out), sp), "gated_pool")
+        else:
+            d = L.ReadoutDesc()
+            d.x, d.batch_sorted_i64, d.N, d.num_graphs, d.h, d.n_comp, d.kg = L.ptr(y_in), L.ptr(batch), N, B, h, n, kg
+            d.M, d.c, d.gate, d.out, d.n_valid_dev = L.ptr(M), L.ptr(c), L.ptr(gate), L.ptr(out), L.ptr(nv)
+            if normed:
+                d.norm_acc = L.ptr(norm_acc)
+                d.weight, d.bias, d.running_mean, d.running_var, d.num_batches_tracked = (C.cast(a_, C.c_void_p) for a_ in keep)
+                d.norm_n_comp, d.norm_act, d.momentum, d.eps = n, L.ACT_IDS[act], 0.1, 1e-5
+                d.skip, d.save_stat, d.x_out = L.ptr(skip), L.ptr(save), L.ptr(x_out)
+            L.check(lib.phc_readout_fused_fwd(C.byref(d), sp), "phc_readout_fused_fwd")
+        torch.cuda.synchronize()
+        res[tag] = dict(x=x_out, save=save, rm=torch.cat(rm), rv=torch.cat(rv), nbt=torch.stack(nbt), gate=gate, out=out)
+    for key in ("x", "save", "rm", "rv", "nbt"):
+        assert torch.equal(res["fused"][key], res["separate"][key]), key
+    for key in ("gate", "out"):
+        a_, b_ = res["fused"][key].double(), res["separate"][key].double()
+        assert float((a_ - b_).abs().max()) <= 2e-6 * max(float(b_.abs().max()), 1e-30), (key, float((a_ - b_).abs().max()), float(b_.abs().max()))
+
+
+@pytest.mark.parametrize("workload", ["molhiv_b32_swish", "molhiv_b512_swish", "molhiv_b32"])
+@pytest.mark.parametrize("graph", [False, True])
+def test_readout_in_one_launch_leaves_the_step_unchanged(workload, graph):
+    """Loss and every gradient with ops.READOUT_FUSED on and off (a different fp32 summation order in the gate and in the per-graph
+    sums: 2e-5 of each tensor's largest entry on the smooth models; the ReLU model's loss only — a gate at the kink may flip)."""
+    on = _step(workload, dict(READOUT_FUSED=True), graph)
+    off = _step(workload, dict(READOUT_FUSED=False), graph)
+    assert abs(float(on[0]) - float(off[0])) <= 2e-6 * abs(float(off[0])), (float(on[0]), float(off[0]))
+    if "swish" in workload:
+        for k in off[1]:
+            ref = off[1][k]
+            if float(ref.abs().max()) < 1e-7:                         # a bias in front of a batch-norm: zero up to round-off noise
+                continue
+            assert float((on[1][k] - ref).abs().max()) <= 2e-5 * max(float(ref.abs().max()), 1e-30), k
+    for k in off[2]:
+        ref = off[2][k].double()
+        assert float((on[2][k].double() - ref).abs().max()) <= 1e-6 * max(float(ref.abs().max()), 1e-30), ("buffer", k)
