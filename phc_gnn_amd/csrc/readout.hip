@@ -332,6 +332,7 @@ __global__ __launch_bounds__(RF_THREADS) void readout_fused_fwd_kernel(ReadoutFu
             rf_lds_barrier();
             first[0] = slot[0];
             first[1] = slot[1];
+            if (a.stamps && level < 2) tk[4 + level] = __builtin_amdgcn_s_memrealtime();
             rf_lds_barrier();
             bool done = true;
 #pragma unroll
@@ -482,6 +483,7 @@ __global__ __launch_bounds__(RF_THREADS) void readout_fused_fwd_kernel(ReadoutFu
     if (a.stamps && tid == 0) {
         unsigned long long *o = a.stamps + (size_t)g * 8;
         o[0] = tk[0]; o[1] = tk[1]; o[2] = tk[2]; o[3] = tk[3]; o[4] = __builtin_amdgcn_s_memrealtime(); o[5] = (unsigned long long)(r1 - r0);
+        o[6] = tk[4]; o[7] = tk[5];
     }
 }
 

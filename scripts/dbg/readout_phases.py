@@ -32,6 +32,7 @@ t0 = w[:, 0].min()
 us = lambda c: (w[:, c] - w[:, 0]) * 0.01
 rows = w[:, 5]
 print(f"{wl}: {len(w)} graphs, rows per graph mean {rows.mean():.1f} max {int(rows.max())}")
+print(f"search: first level resolved {((w[:, 6] - w[:, 0]) * 0.01).median():.2f} us after entry, second {((w[:, 7] - w[:, 0]) * 0.01).median():.2f}")
 print(f"entry spread {((w[:, 0] - t0) * 0.01).max():.2f} us | rows found {us(1).median():.2f} | norm constants {us(2).median():.2f} | tiles done med {us(3).median():.2f} "
       f"max {us(3).max():.2f} | end med {us(4).median():.2f} max {us(4).max():.2f} | last end since first entry {((w[:, 4] - t0) * 0.01).max():.2f}")
 for lo, hi in ((0, 16), (17, 32), (33, 48), (49, 96), (97, 1000)):
