@@ -945,6 +945,62 @@ __device__ __forceinline__ void encode_front_block(const EncFront &e, unsigned b
     }
 }
 
+// A PHM job in 32 x 32 tiles (round 4; in, out, kout multiples of 4 and 16-byte aligned outputs): a thread computes four consecutive
+// columns of one row (the n terms' W values as ONE float4 each, the A values shared by the four columns), the tile meets in LDS and
+// all four forms leave as 16-byte stores in runs of 128-512 bytes.  One thread per element — the form this replaces and the fallback —
+// wrote H^T, the k4 form and its transpose as scattered 4-byte stores: 46 us for the twelve 256 x 256 operands of the ZINC model.
+// Same sums in the same order (ascending i).
+__device__ __forceinline__ void phm_build_tile(const HJobDev &jb, int tile) {
+    __shared__ float t_[32][33];
+    const int n = jb.n, kin = jb.kin, kout = jb.kout, in = n * kin, out = n * kout;
+    const int tj = (out + 31) / 32;
+    const int k0 = (tile / tj) * 32, j0 = (tile % tj) * 32;
+    const int tid = threadIdx.x;
+    {
+        const int kk = tid >> 3, jq = (tid & 7) * 4;
+        const int k = min(k0 + kk, in - 1), jc = min(j0 + jq, out - 4);
+        const int a = k / kin, kap = k - a * kin;
+        const int c = jc / kout, pi = jc - c * kout;           // (kout % 4 == 0: the four columns share the component)
+        float4 hs = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int i0 = 0; i0 < n; i0 += 4) {                     // four terms per round trip (clamped, selected; ascending i)
+            float av[4];
+            float4 wv[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const int i = min(i0 + q, n - 1);
+                av[q] = jb.A[(i * n + a) * n + c];
+                wv[q] = *reinterpret_cast<const float4 *>(jb.W + ((size_t)i * kin + kap) * kout + pi);
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (i0 + q < n) {
+                    hs.x = fmaf(av[q], wv[q].x, hs.x); hs.y = fmaf(av[q], wv[q].y, hs.y);
+                    hs.z = fmaf(av[q], wv[q].z, hs.z); hs.w = fmaf(av[q], wv[q].w, hs.w);
+                }
+        }
+        t_[kk][jq] = hs.x; t_[kk][jq + 1] = hs.y; t_[kk][jq + 2] = hs.z; t_[kk][jq + 3] = hs.w;
+    }
+    __syncthreads();
+    const int r = tid >> 3, q4 = (tid & 7) * 4;               // a row of the tile and a quad of its columns (or the transpose)
+    // H: row k0 + r, columns j0 + q4 .. + 3
+    if (k0 + r < in && j0 + q4 < out)
+        *reinterpret_cast<float4 *>(jb.H + (size_t)(k0 + r) * out + j0 + q4) = make_float4(t_[r][q4], t_[r][q4 + 1], t_[r][q4 + 2], t_[r][q4 + 3]);
+    // H^T: row j0 + r, columns k0 + q4 .. + 3
+    if (jb.HT && j0 + r < out && k0 + q4 < in)
+        *reinterpret_cast<float4 *>(jb.HT + (size_t)(j0 + r) * in + k0 + q4) = make_float4(t_[q4][r], t_[q4 + 1][r], t_[q4 + 2][r], t_[q4 + 3][r]);
+    // k4 form: float4 slot (k / 4) * out + jc = H[4 (k / 4) .. + 3][jc]: k-quad tid / 32, column tid % 32
+    {
+        const int kq_ = tid >> 5, jj = tid & 31;
+        if (jb.Hk4 && k0 + 4 * kq_ < in && j0 + jj < out)
+            *reinterpret_cast<float4 *>(jb.Hk4 + ((size_t)((k0 >> 2) + kq_) * out + j0 + jj) * 4) =
+                make_float4(t_[4 * kq_][jj], t_[4 * kq_ + 1][jj], t_[4 * kq_ + 2][jj], t_[4 * kq_ + 3][jj]);
+        // transpose's k4 form: float4 slot (jc / 4) * in + k = H[k][4 (jc / 4) .. + 3]: column quad tid / 32, row tid % 32
+        if (jb.HTk4 && j0 + 4 * kq_ < out && k0 + jj < in)
+            *reinterpret_cast<float4 *>(jb.HTk4 + ((size_t)((j0 >> 2) + kq_) * in + k0 + jj) * 4) =
+                make_float4(t_[jj][4 * kq_], t_[jj][4 * kq_ + 1], t_[jj][4 * kq_ + 2], t_[jj][4 * kq_ + 3]);
+    }
+}
+
 __global__ __launch_bounds__(256) void phm_build_H_batched_kernel(HBatch b, EncFront enc) {
     if (enc.blocks && blockIdx.x >= enc.blk0) {              // (block-uniform)
         encode_front_block(enc, blockIdx.x - enc.blk0);
@@ -958,6 +1014,10 @@ __global__ __launch_bounds__(256) void phm_build_H_batched_kernel(HBatch b, EncF
     const int in = n * kin, out = n * kout;
     if (jb.dense_t == 3) {                                    // (block-uniform)
         gate_compose_block(jb, (int)(blockIdx.x - jb.blk0));
+        return;
+    }
+    if (jb.dense_t == 4) {                                    // a PHM job in 32 x 32 tiles
+        phm_build_tile(jb, (int)(blockIdx.x - jb.blk0));
         return;
     }
     const int e = (blockIdx.x - jb.blk0) * 256 + threadIdx.x;
@@ -2030,7 +2090,16 @@ static int build_H_batched_impl(const phc_phm_H_job *jobs, int num_jobs, const p
             b.j[k].Hk4 = jb.Hk4; b.j[k].HTk4 = jb.HTk4;
             b.j[k].n = jb.n; b.j[k].kin = jb.kin; b.j[k].kout = jb.kout; b.j[k].dense_t = dense_t;
             b.j[k].blk0 = blocks;
-            blocks += (unsigned)(((size_t)jb.n * jb.kin * jb.n * jb.kout + 255) / 256);
+            static const bool no_tiles = getenv("PHC_BUILD_H_TILES") && atoi(getenv("PHC_BUILD_H_TILES")) == 0;
+            const bool tiled = !no_tiles && !dense_t && in_ % 4 == 0 && out_ % 4 == 0 && jb.kout % 4 == 0 && in_ >= 4 && out_ >= 4 &&
+                               ((reinterpret_cast<uintptr_t>(jb.H) | reinterpret_cast<uintptr_t>(jb.HT) | reinterpret_cast<uintptr_t>(jb.Hk4) |
+                                 reinterpret_cast<uintptr_t>(jb.HTk4) | reinterpret_cast<uintptr_t>(jb.W)) & 15) == 0;
+            if (tiled) {
+                b.j[k].dense_t = 4;
+                blocks += (unsigned)(((in_ + 31) / 32) * ((out_ + 31) / 32));
+            } else {
+                blocks += (unsigned)(((size_t)jb.n * jb.kin * jb.n * jb.kout + 255) / 256);
+            }
         }
         EncFront e = {};
         if (enc && c0 + cn >= num_jobs) {                        // the passenger rides in the last chunk's launch

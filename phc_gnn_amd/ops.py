@@ -2125,7 +2125,7 @@ class TableSet:
 
 
 FLAT_TABLES = __import__("os").environ.get("PHC_FLAT_TABLES", "1") != "0"      # A/B switch
-_FLAT_STEP = threading.local()           # .packed: ids of the images refreshed in the running step (prebuilt_H context)
+_FLAT_STEP = threading.local()           # .packed: SERIAL numbers of the images refreshed in the running step (prebuilt_H context)
 
 
 class FlatTableSet(TableSet):
@@ -2203,7 +2203,7 @@ class FlatTableSet(TableSet):
                     "phc_copy2d_batched(pack all tables)")
             packed = getattr(_FLAT_STEP, "packed", None)
             if packed is not None:
-                packed.update(id(f) for f in fs)
+                packed.update(f.serial for f in fs)
 
     def refresh(self, tables):              # (TableSet.current: the image has no tables of its own to follow)
         raise L.PhcError("FlatTableSet is derived from its parent TableSet")
@@ -2211,9 +2211,13 @@ class FlatTableSet(TableSet):
     def refresh_image(self) -> None:
         packed = getattr(_FLAT_STEP, "packed", None)
         if packed is not None:
-            if id(self) in packed:
+            # (serial numbers, not id(): an image that was marked at the step's start and is collected DURING the step — a dead
+            # model's, freed by the cyclic collector at any moment — leaves its id() to the next object Python creates; a new
+            # model's image that got it looked "already refreshed" and stayed at its initial zeros: an encoder that embeds
+            # everything as 0 for one step, the loss a few percent off, once in a few hundred test runs)
+            if self.serial in packed:
                 return                      # already refreshed in this training step (the tables change only at its end)
-            packed.add(id(self))
+            packed.add(self.serial)
         L.check(L.load().phc_copy2d_batched(L.ptr(self._pack_jobs), self.num_jobs, self.max_elems, None, L.ptr(self.image),
                                             L.stream_ptr(self.dev)), "phc_copy2d_batched(pack tables)")
 

@@ -303,3 +303,26 @@ def test_readout_in_one_launch_leaves_the_step_unchanged(workload, graph):
     for k in off[2]:
         ref = off[2][k].double()
         assert float((on[2][k].double() - ref).abs().max()) <= 1e-6 * max(float(ref.abs().max()), 1e-30), ("buffer", k)
+
+
+def test_flat_table_image_is_not_taken_for_refreshed_because_of_a_recycled_python_id():
+    """Regression (round 4): the per-step set of already-refreshed flat table images was keyed by id().  An image marked at the step's
+    start and garbage-collected during the step leaves its id() to the next Python object — a new model's image that inherited it was
+    skipped and embedded everything as zero for one step (seen as a loss 3-4 % off once in a few hundred runs of
+    tests/test_gpu_gemm_hs.py::test_fused_mlp_norm_node_equals_the_separate_nodes[zinc_pub_phc4_4x180_nodrop])."""
+    from phc_gnn_amd import ops
+    g = torch.Generator().manual_seed(3)
+    n, k, vocab = 4, 45, [5, 6, 2]
+    tables = [[torch.randn(v, k, generator=g).to(DEV) for v in vocab] for _ in range(n)]
+    fs = ops.TableSet(tables).vector_form(tables)
+    assert isinstance(fs, ops.FlatTableSet)
+    fs.image.zero_()
+    keep = getattr(ops._FLAT_STEP, "packed", None)
+    ops._FLAT_STEP.packed = {id(fs)}                                       # a dead object's id that this image happened to inherit
+    try:
+        fs.refresh_image()
+    finally:
+        ops._FLAT_STEP.packed = keep
+    torch.cuda.synchronize()
+    want = torch.cat([torch.cat([tables[c][f] for c in range(n)], 1) for f in range(len(vocab))], 0)
+    assert torch.equal(fs.image, want)
