@@ -355,8 +355,22 @@ def maybe_check_indices(dev: torch.device) -> None:
         check_indices(dev)
 
 
+_EMPTY_BUF: dict = {}
+
+
 def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
-    return None if t is None else t.data_ptr()
+    """Device address for the C ABI.  An EMPTY tensor (a batch without edges: no sources, no codes) has address 0, which the entry
+    points' argument checks would take for a missing argument: it is represented by a small zeroed buffer of its device instead —
+    the kernels never index it (their counts are zero), and a clamped read of element 0 would find zeros."""
+    if t is None:
+        return None
+    p = t.data_ptr()
+    if p == 0 and t.is_cuda:
+        buf = _EMPTY_BUF.get(t.device)
+        if buf is None:
+            buf = _EMPTY_BUF[t.device] = torch.zeros(256, dtype=torch.uint8, device=t.device)
+        return buf.data_ptr()
+    return p
 
 
 def stream_ptr(device: torch.device) -> int:

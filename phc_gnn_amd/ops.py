@@ -2336,7 +2336,8 @@ class _AggregateEncFn(torch.autograd.Function):
         # `lazy_box` (a dict): the caller feeds this aggregate straight into the fused MLP + norm node — when the shapes allow it
         # nothing is launched here: the node's first GEMM builds the rows itself (phc_gemm_aggregate_stats) and writes `out` on the
         # way; anybody else who reads `out` first calls PendingAggregate.materialize (the launch that would have run here)
-        lazy = lazy_box is not None and GEMM_AGGREGATE and act == 0 and x_.is_contiguous() and x_.shape[0] == st.num_src == st.num_dst and \
+        lazy = lazy_box is not None and GEMM_AGGREGATE and act == 0 and st.num_edges > 0 and x_.is_contiguous() and \
+            x_.shape[0] == st.num_src == st.num_dst and \
             x_.shape[0] * h <= NORM_INTO_AGGREGATE_MAX_WORK and x_.data_ptr() % 16 == 0 and ts.k % 4 == 0 and \
             (pending is None or pending.done or fuse_norm) and bool(lib.phc_gemm_aggregate_supported(st.num_dst, h, h, ts.F, ts.R))
         if lazy:

@@ -326,3 +326,49 @@ def test_flat_table_image_is_not_taken_for_refreshed_because_of_a_recycled_pytho
     torch.cuda.synchronize()
     want = torch.cat([torch.cat([tables[c][f] for c in range(n)], 1) for f in range(len(vocab))], 0)
     assert torch.equal(fs.image, want)
+
+
+@pytest.mark.parametrize("edges", [0, 3])
+def test_a_batch_with_no_or_hardly_any_edges_takes_the_same_step_on_every_path(edges):
+    """Edge case of the reference's own tests (empty inputs): a collated batch whose graphs have no bonds at all (or three in total).
+    The round-4 fusions step aside (or run on empty rows); loss and gradients equal the unfused step's."""
+    import dataclasses
+    from phc_gnn_amd import harness, ops
+    wl = "molhiv_b32_swish"
+    gb = harness.make_batch(wl, seed=4)
+    gb = dataclasses.replace(gb, edge_index=gb.edge_index[:, :edges].copy(), edge_attr=gb.edge_attr[:edges].copy())
+    cfg = harness.StepConfig(optimizer=False, weight_decay=1e-3)
+    res = []
+    for on in (True, False):
+        keep = {k: getattr(ops, k) for k in ("GEMM_AGGREGATE", "READOUT_FUSED", "NORM_INTO_AGGREGATE")}
+        try:
+            for k in keep:
+                setattr(ops, k, on)
+            model = harness.build_model(wl, DEV, seed=2).train()
+            loss = harness.train_step(model, harness.to_device(gb, DEV), None, cfg)
+            torch.cuda.synchronize()
+            res.append((float(loss.detach()), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}))
+        finally:
+            for k, v in keep.items():
+                setattr(ops, k, v)
+    (l1, g1), (l0, g0) = res
+    assert l1 == l1 and abs(l1 - l0) <= 2e-6 * abs(l0), (l1, l0)
+    for k in g0:
+        ref_ = g0[k]
+        if float(ref_.abs().max()) < 1e-7:
+            continue
+        assert float((g1[k] - ref_).abs().max()) <= 2e-5 * float(ref_.abs().max()), k
+    if edges == 0:
+        return                          # (the reference itself cannot run this batch: models.py:238-240 reshapes an empty tensor with -1)
+    # ... and it is the reference's step: the CPU oracle on the same state and batch (forward loss, no regulariser)
+    from oracle import phc_oracle as O
+    from tests.test_gpu_fullwidth import _oracle_kwargs
+    model = harness.build_model(wl, "cpu", seed=2).train()
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    kw = harness.model_kwargs(harness.WORKLOADS[wl])
+    x, ei, ea, bt, y = (torch.from_numpy(a_) for a_ in (gb.x, gb.edge_index, gb.edge_attr, gb.batch, gb.y))
+    logits = O.skip_connect_add_forward(sd, x, ei, ea, bt, training=True, num_graphs=gb.num_graphs, **_oracle_kwargs(kw, x, ea))
+    ref = float(O.bce_loss_masked(logits, y))
+    mdl = harness.build_model(wl, DEV, seed=2).train()
+    l_plain = float(harness.train_step(mdl, harness.to_device(gb, DEV), None, harness.StepConfig(optimizer=False, weight_decay=0.0)).detach())
+    assert abs(l_plain - ref) <= 1e-5 * abs(ref), (l_plain, ref)
