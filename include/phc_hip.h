@@ -826,7 +826,7 @@ int phc_gated_pool_fwd(const float *x, const float *gate, const int32_t *seg_ptr
  * every workgroup finds its graph's rows with two cooperative searches, so no segment-pointer launch is needed. */
 int phc_gated_pool_fwd_sorted(const float *x, const float *gate, const int64_t *batch_sorted_i64, int64_t N,
                               int64_t num_graphs, int h, int n_comp, float *out, void *stream);
-/* The soft-attention read-out's forward as ONE launch (ABI 5, h = 128, k = kg = 32: phc_readout_fused_supported):
+/* The soft-attention read-out's forward as ONE launch (ABI 5; h = 128 with k = kg = 32, h = 256 with k = kg = 32 or 64: phc_readout_fused_supported):
  *     x    = act(batch_norm(x_in)) (+ skip)   the last layer's norm, un-applied (norm_acc != NULL; as phc_aggregate_norm_encp_fwd), or x
  *     gate = x . M + c                        M [h, kg] row-major: the composed gate map (phc_phm_H_job.flags == 3), pooling.py:57-66
  *     out[g, c k + j] = sum_{r: batch[r] = g} x[r, c k + j] sigmoid(gate[r, j])              (phc_gated_pool_fwd_sorted)

@@ -261,18 +261,26 @@ __device__ __forceinline__ void rf_lds_barrier() {
     __builtin_amdgcn_s_barrier();
 }
 
-template <bool NORMED, bool RELU, bool FLAT>
+// K = 128: two rows per 1 KiB image "instruction" (half-wavefront per row, odd row XOR 1), one pass of the 8 wavefronts per tile;
+// K = 256: one row per instruction (a wavefront per row), two passes.  KG = gate width = columns per component (k): 32 or 64.
+template <int K, int KG, bool NORMED, bool RELU, bool FLAT>
 __global__ __launch_bounds__(RF_THREADS) void readout_fused_fwd_kernel(ReadoutFusedArgs a) {
-    constexpr int K = 128, KG = 32, H4 = 32, ISTRIDE = 66, G = 8;
-    __shared__ rf_f32x4 image[8 * ISTRIDE];
+    static_assert((K == 128 || K == 256) && (KG == 32 || KG == 64), "read-out widths");
+    constexpr int H4 = K / 4, ISTRIDE = 66, TILES = KG / 16;
+    // the contraction of a gate tile is split over KSPLIT wavefronts (128 rows of the operand each: 32 registers per lane; all 256 in
+    // one wavefront would be 64 and push the kernel past two workgroups per CU); the halves meet in LDS
+    constexpr int KSPLIT = K / 128, G = 8;
+    constexpr int RPI = 256 / K, PASSES = 2 / RPI;                  // rows per image instruction, gather passes per tile
+    constexpr int PARTS = RF_THREADS / K, PAIRS = 4 * K / RF_THREADS;   // row parts of the column sums; (column, replica) pairs per thread
+    __shared__ rf_f32x4 image[(16 / RPI) * ISTRIDE];
     __shared__ __attribute__((aligned(16))) float s_scale[K], s_shift[K];
     __shared__ float sgate[16][KG + 1];
-    __shared__ float red[4][K];
+    __shared__ rf_f32x4 khalf[KSPLIT == 2 ? TILES * 64 : 1];        // the second half's partial gate tile, one float4 per lane
+    __shared__ float red[PARTS][K];
     __shared__ int slot[2];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, kq = lane >> 4;
-    const int g = (int)blockIdx.x;
     const int N = a.N;
     unsigned long long tk[6] = {0, 0, 0, 0, 0, 0};
     if (a.stamps) tk[0] = __builtin_amdgcn_s_memrealtime();
@@ -283,21 +291,33 @@ __global__ __launch_bounds__(RF_THREADS) void readout_fused_fwd_kernel(ReadoutFu
     const long long v1 = i1 < N ? a.batch[i1] : 0x7fffffffffffffffLL;
     const int nvr = a.n_valid ? *a.n_valid : N;                  // (behind the probe: the first thing waited for is the probe)
     // ---- pending norm: (column, replica) per thread, as gemm_hs_ag_kernel ----
-    const int ncol = tid >> 2, nrep = tid & 3;
-    const int ncomp = NORMED ? ncol / a.p.k : 0, nkk = NORMED ? ncol - ncomp * a.p.k : 0;
+    const int nrep = tid & 3;
     const bool owner = blockIdx.x == 0;
-    unsigned long long araw[4] = {0, 0, 0, 0};
-    float nw = 1.f, nb = 0.f, rm_old = 0.f, rv_old = 1.f;
-    if constexpr (NORMED) {
-        const unsigned long long *ap = a.acc + (size_t)(nrep * 2) * 2 * K + ncol;
-        araw[0] = ap[0]; araw[1] = ap[K]; araw[2] = ap[2 * K]; araw[3] = ap[3 * K];
-        if (a.p.has_weight) nw = FLAT ? a.p.weight[0][ncol] : bn_pick(a.p.weight, ncomp)[nkk];
-        if (a.p.has_bias) nb = FLAT ? a.p.bias[0][ncol] : bn_pick(a.p.bias, ncomp)[nkk];
-        if (a.p.has_running && owner) {
-            rm_old = FLAT ? a.p.running_mean[0][ncol] : bn_pick(a.p.running_mean, ncomp)[nkk];
-            rv_old = FLAT ? a.p.running_var[0][ncol] : bn_pick(a.p.running_var, ncomp)[nkk];
+    int ncol[PAIRS], ncomp[PAIRS], nkk[PAIRS];
+    unsigned long long araw[PAIRS][4];
+    float nw[PAIRS], nb[PAIRS], rm_old[PAIRS], rv_old[PAIRS];
+#pragma unroll
+    for (int pp = 0; pp < PAIRS; ++pp) {
+        ncol[pp] = (tid + RF_THREADS * pp) >> 2;
+        ncomp[pp] = NORMED ? ncol[pp] / a.p.k : 0;
+        nkk[pp] = NORMED ? ncol[pp] - ncomp[pp] * a.p.k : 0;
+        araw[pp][0] = araw[pp][1] = araw[pp][2] = araw[pp][3] = 0;
+        nw[pp] = 1.f; nb[pp] = 0.f; rm_old[pp] = 0.f; rv_old[pp] = 1.f;
+        if constexpr (NORMED) {
+            const unsigned long long *ap = a.acc + (size_t)(nrep * 2) * 2 * K + ncol[pp];
+            araw[pp][0] = ap[0]; araw[pp][1] = ap[K]; araw[pp][2] = ap[2 * K]; araw[pp][3] = ap[3 * K];
+            if (a.p.has_weight) nw[pp] = FLAT ? a.p.weight[0][ncol[pp]] : bn_pick(a.p.weight, ncomp[pp])[nkk[pp]];
+            if (a.p.has_bias) nb[pp] = FLAT ? a.p.bias[0][ncol[pp]] : bn_pick(a.p.bias, ncomp[pp])[nkk[pp]];
+            if (a.p.has_running && owner) {
+                rm_old[pp] = FLAT ? a.p.running_mean[0][ncol[pp]] : bn_pick(a.p.running_mean, ncomp[pp])[nkk[pp]];
+                rv_old[pp] = FLAT ? a.p.running_var[0][ncol[pp]] : bn_pick(a.p.running_var, ncomp[pp])[nkk[pp]];
+            }
         }
     }
+    // A workgroup takes graphs blockIdx.x, + gridDim.x, ...: the launch has at most as many workgroups as are resident at once (two per
+    // CU), so nobody waits for a slot, and a workgroup's later graphs find the batch vector, the code and the TLB warm (the first
+    // dependent load of a workgroup costs 6 us, a later search level 2).
+    int g = (int)blockIdx.x;
     // ---- rows of graph g: lower bounds of g and g + 1 in the sorted batch vector, both searches in lockstep (RF_THREADS probes per
     // level and key: two levels cover 262 144 rows) ----
     int r0, r1;
@@ -357,41 +377,47 @@ __global__ __launch_bounds__(RF_THREADS) void readout_fused_fwd_kernel(ReadoutFu
         r1 = lo[1];
     }
     if (a.stamps) tk[1] = __builtin_amdgcn_s_memrealtime();
+    const int rows_first = r1 - r0;
     const int count = min(nvr, N);
-    // ---- the gate operand of this wavefront's 16-column tile (wavefronts 0, 1): k-group gq, step q -> row 16 gq + 4 kq + q of M ----
+    // ---- the gate operand of this wavefront's 16-column tile (the first KG / 16 wavefronts): k-group gq, step q -> row 16 gq + 4 kq + q of M ----
     rf_f32x4 hreg[G];
-    if (wave < 2) {
+    const int mtile = wave % TILES, mhalf = wave / TILES;         // (MFMA wavefronts: wave < TILES * KSPLIT)
+    if (wave < TILES * KSPLIT) {
 #pragma unroll
         for (int gq = 0; gq < G; ++gq)
 #pragma unroll
-            for (int q = 0; q < 4; ++q) hreg[gq][q] = a.M[(size_t)(16 * gq + 4 * kq + q) * KG + 16 * wave + c];
+            for (int q = 0; q < 4; ++q) hreg[gq][q] = a.M[(size_t)(128 * mhalf + 16 * gq + 4 * kq + q) * KG + 16 * mtile + c];
     }
     // ---- the norm's constants (arithmetic and order of the stand-alone kernels: bn_from_totals, replicas in order) ----
     if constexpr (NORMED) {
-        const double pS = (double)(long long)araw[0] * (1.0 / 4096.0) + (double)(long long)araw[1] * (1.0 / 4611686018427387904.0);
-        const double pQ = (double)(long long)araw[2] * (1.0 / 4096.0) + (double)(long long)araw[3] * (1.0 / 4611686018427387904.0);
-        const int qbase = lane & ~3;
-        double S = __shfl(pS, qbase, 64), Q = __shfl(pQ, qbase, 64);
 #pragma unroll
-        for (int r = 1; r < 4; ++r) {
-            S += __shfl(pS, qbase + r, 64);
-            Q += __shfl(pQ, qbase + r, 64);
-        }
-        if (nrep == 0) {
-            const BnFromTotals bt = bn_from_totals(S, Q, count, nw, nb, a.eps);
-            s_scale[ncol] = bt.scale;
-            s_shift[ncol] = bt.shift;
-            if (owner) {
-                float *stat = a.stat;
-                stat[ncol] = bt.mean;
-                stat[K + ncol] = bt.invstd;
-                stat[2 * K + ncol] = bt.scale;
-                stat[3 * K + ncol] = bt.shift;
-                stat[4 * K + ncol] = nw;
-                stat[5 * K + ncol] = nb;
-                if (a.p.has_running) {
-                    *(FLAT ? a.p.running_mean[0] + ncol : bn_pick(a.p.running_mean, ncomp) + nkk) = bn_running_update(rm_old, a.momentum, bt.mean);
-                    *(FLAT ? a.p.running_var[0] + ncol : bn_pick(a.p.running_var, ncomp) + nkk) = bn_running_update(rv_old, a.momentum, bt.unbiased);
+        for (int pp = 0; pp < PAIRS; ++pp) {
+            const double pS = (double)(long long)araw[pp][0] * (1.0 / 4096.0) + (double)(long long)araw[pp][1] * (1.0 / 4611686018427387904.0);
+            const double pQ = (double)(long long)araw[pp][2] * (1.0 / 4096.0) + (double)(long long)araw[pp][3] * (1.0 / 4611686018427387904.0);
+            const int qbase = lane & ~3;
+            double S = __shfl(pS, qbase, 64), Q = __shfl(pQ, qbase, 64);
+#pragma unroll
+            for (int r = 1; r < 4; ++r) {
+                S += __shfl(pS, qbase + r, 64);
+                Q += __shfl(pQ, qbase + r, 64);
+            }
+            if (nrep == 0) {
+                const int nc = ncol[pp];
+                const BnFromTotals bt = bn_from_totals(S, Q, count, nw[pp], nb[pp], a.eps);
+                s_scale[nc] = bt.scale;
+                s_shift[nc] = bt.shift;
+                if (owner) {
+                    float *stat = a.stat;
+                    stat[nc] = bt.mean;
+                    stat[K + nc] = bt.invstd;
+                    stat[2 * K + nc] = bt.scale;
+                    stat[3 * K + nc] = bt.shift;
+                    stat[4 * K + nc] = nw[pp];
+                    stat[5 * K + nc] = nb[pp];
+                    if (a.p.has_running) {
+                        *(FLAT ? a.p.running_mean[0] + nc : bn_pick(a.p.running_mean, ncomp[pp]) + nkk[pp]) = bn_running_update(rm_old[pp], a.momentum, bt.mean);
+                        *(FLAT ? a.p.running_var[0] + nc : bn_pick(a.p.running_var, ncomp[pp]) + nkk[pp]) = bn_running_update(rv_old[pp], a.momentum, bt.unbiased);
+                    }
                 }
             }
         }
@@ -401,88 +427,165 @@ __global__ __launch_bounds__(RF_THREADS) void readout_fused_fwd_kernel(ReadoutFu
         rf_lds_barrier();
     }
     if (a.stamps) tk[2] = __builtin_amdgcn_s_memrealtime();
-    const int dsub = lane >> 5, li = lane & 31, c4 = li ^ dsub;
+    // this thread's place in the image: K = 128: row 2 wave + dsub of the tile, chunk li ^ dsub; K = 256: rows wave and wave + 8, chunk lane
+    const int dsub = RPI == 2 ? lane >> 5 : 0, li = RPI == 2 ? lane & 31 : lane, c4 = li ^ dsub;
     const float4 *Y4 = reinterpret_cast<const float4 *>(a.y) + c4;
     const float4 *S4 = reinterpret_cast<const float4 *>(a.skip ? a.skip : a.y) + c4;
     const bool has_skip = a.skip != nullptr;
-    const int fbase = (c >> 1) * ISTRIDE + (c & 1) * H4 + (kq ^ (c & 1));
+    const int fbase = RPI == 2 ? (c >> 1) * ISTRIDE + (c & 1) * H4 + (kq ^ (c & 1)) : c * ISTRIDE + kq;
     rf_f32x4 bias4 = {0.f, 0.f, 0.f, 0.f};
-    if (wave < 2 && a.c) bias4 = *reinterpret_cast<const rf_f32x4 *>(a.c + 16 * wave + 4 * kq);
-    const int pcol = tid & (K - 1), part = tid >> 7;           // the column this thread adds up, and its quarter of a tile's rows
-    float pacc = 0.f;
-    // the next tile's rows travel while this tile is multiplied and added up (a 200-atom molecule is 13 tiles: its workgroup is the
-    // launch's critical path)
-    float4 v_next = make_float4(0.f, 0.f, 0.f, 0.f), rr_next = v_next;
-    if (r0 < r1) {
-        const int rn = min(r0 + 2 * wave + dsub, r1 - 1);
-        v_next = Y4[(size_t)rn * H4];
-        if constexpr (NORMED) rr_next = S4[(size_t)rn * H4];
-    }
-    for (int rb = r0; rb < r1; rb += 16) {
-        // ---- this half-wavefront's row of the tile -> LDS image (and out to memory once) ----
-        const int r = rb + 2 * wave + dsub;
-        const bool valid = r < r1;
-        const int rc = valid ? r : r1 - 1;
-        const float4 v = v_next;
-        const float4 rr_cur = rr_next;
-        if (rb + 16 < r1) {
-            const int rn = min(rb + 16 + 2 * wave + dsub, r1 - 1);
-            v_next = Y4[(size_t)rn * H4];
-            if constexpr (NORMED) rr_next = S4[(size_t)rn * H4];
-        }
-        float4 o = v;
-        if constexpr (NORMED) {
-            const float4 rr = rr_cur;
-            const float4 sc = *reinterpret_cast<const float4 *>(s_scale + 4 * c4), sh = *reinterpret_cast<const float4 *>(s_shift + 4 * c4);
-            if constexpr (RELU) {
-                o.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f); o.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
-                o.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f); o.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
-            } else {
-                o.x = act_fwd_rt(a.norm_act, fmaf(v.x, sc.x, sh.x)); o.y = act_fwd_rt(a.norm_act, fmaf(v.y, sc.y, sh.y));
-                o.z = act_fwd_rt(a.norm_act, fmaf(v.z, sc.z, sh.z)); o.w = act_fwd_rt(a.norm_act, fmaf(v.w, sc.w, sh.w));
+    if (wave < TILES && a.c) bias4 = *reinterpret_cast<const rf_f32x4 *>(a.c + 16 * wave + 4 * kq);      // (first halves only: mtile == wave)
+    const int pcol = tid & (K - 1), part = tid / K;            // the column this thread adds up, and its share of a tile's rows
+    for (;;) {
+        float pacc = 0.f;
+        auto tile_row = [&](int u) { return RPI == 2 ? 2 * wave + dsub : wave + 8 * u; };
+        // the next tile's rows travel while this tile is multiplied and added up (a 200-atom molecule is 13 tiles: its workgroup is the
+        // launch's critical path)
+        float4 v_next[PASSES], rr_next[PASSES];
+    #pragma unroll
+        for (int u = 0; u < PASSES; ++u) {
+            v_next[u] = make_float4(0.f, 0.f, 0.f, 0.f);
+            rr_next[u] = v_next[u];
+            if (r0 < r1) {
+                const int rn = min(r0 + tile_row(u), r1 - 1);
+                v_next[u] = Y4[(size_t)rn * H4];
+                if constexpr (NORMED) rr_next[u] = S4[(size_t)rn * H4];
             }
-            o.x = has_skip ? o.x + rr.x : o.x; o.y = has_skip ? o.y + rr.y : o.y;
-            o.z = has_skip ? o.z + rr.z : o.z; o.w = has_skip ? o.w + rr.w : o.w;
-            if (rc >= count) o = make_float4(0.f, 0.f, 0.f, 0.f);
         }
-        if (!valid) o = make_float4(0.f, 0.f, 0.f, 0.f);
-        image[wave * ISTRIDE + lane] = rf_f32x4{o.x, o.y, o.z, o.w};
-        if constexpr (NORMED) {
-            if (valid) reinterpret_cast<float4 *>(a.x_out)[(size_t)r * H4 + c4] = o;
-        }
-        rf_lds_barrier();
-        // ---- gate tile: wavefront w < 2 owns columns 16 w .. 16 w + 15 ----
-        if (wave < 2) {
+        for (int rb = r0; rb < r1; rb += 16) {
+            // ---- this (half-)wavefront's rows of the tile -> LDS image (and out to memory once) ----
+    #pragma unroll
+            for (int u = 0; u < PASSES; ++u) {
+                const int tr = tile_row(u);
+                const int r = rb + tr;
+                const bool valid = r < r1;
+                const int rc = valid ? r : r1 - 1;
+                const float4 v = v_next[u];
+                const float4 rr = rr_next[u];
+                if (rb + 16 < r1) {
+                    const int rn = min(rb + 16 + tr, r1 - 1);
+                    v_next[u] = Y4[(size_t)rn * H4];
+                    if constexpr (NORMED) rr_next[u] = S4[(size_t)rn * H4];
+                }
+                float4 o = v;
+                if constexpr (NORMED) {
+                    const float4 sc = *reinterpret_cast<const float4 *>(s_scale + 4 * c4), sh = *reinterpret_cast<const float4 *>(s_shift + 4 * c4);
+                    if constexpr (RELU) {
+                        o.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f); o.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
+                        o.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f); o.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
+                    } else {
+                        o.x = act_fwd_rt(a.norm_act, fmaf(v.x, sc.x, sh.x)); o.y = act_fwd_rt(a.norm_act, fmaf(v.y, sc.y, sh.y));
+                        o.z = act_fwd_rt(a.norm_act, fmaf(v.z, sc.z, sh.z)); o.w = act_fwd_rt(a.norm_act, fmaf(v.w, sc.w, sh.w));
+                    }
+                    o.x = has_skip ? o.x + rr.x : o.x; o.y = has_skip ? o.y + rr.y : o.y;
+                    o.z = has_skip ? o.z + rr.z : o.z; o.w = has_skip ? o.w + rr.w : o.w;
+                    if (rc >= count) o = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+                if (!valid) o = make_float4(0.f, 0.f, 0.f, 0.f);
+                image[(RPI == 2 ? wave : tr) * ISTRIDE + lane] = rf_f32x4{o.x, o.y, o.z, o.w};
+                if constexpr (NORMED) {
+                    if (valid) reinterpret_cast<float4 *>(a.x_out)[(size_t)r * H4 + c4] = o;
+                }
+            }
+            rf_lds_barrier();
+            // ---- gate tile: wavefront w < KG / 16 owns columns 16 w .. 16 w + 15 ----
             rf_f32x4 acc = bias4;
-#pragma unroll
-            for (int gq = 0; gq < G; ++gq) {
-                const rf_f32x4 fr = image[fbase + 4 * gq];
-#pragma unroll
-                for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(hreg[gq][q], fr[q], acc, 0, 0, 0);
+            if (wave < TILES * KSPLIT) {
+    #pragma unroll
+                for (int gq = 0; gq < G; ++gq) {
+                    const rf_f32x4 fr = image[fbase + 4 * (gq + G * mhalf)];
+    #pragma unroll
+                    for (int q = 0; q < 4; ++q) acc = __builtin_amdgcn_mfma_f32_16x16x4f32(hreg[gq][q], fr[q], acc, 0, 0, 0);
+                }
             }
-            const int row = rb + c;                              // lane (c, kq) holds gate[row][16 w + 4 kq .. + 3]
-            if (row < r1) *reinterpret_cast<rf_f32x4 *>(a.gate + (size_t)row * KG + 16 * wave + 4 * kq) = acc;
-#pragma unroll
-            for (int q = 0; q < 4; ++q) sgate[c][16 * wave + 4 * kq + q] = 1.f / (1.f + expf(-acc[q]));
+            if constexpr (KSPLIT == 2) {
+                if (wave >= TILES && wave < 2 * TILES) khalf[mtile * 64 + lane] = acc;          // (bias4 is zero in the second halves)
+                rf_lds_barrier();
+                if (wave < TILES) acc += khalf[mtile * 64 + lane];
+            }
+            if (wave < TILES) {
+                const int row = rb + c;                              // lane (c, kq) holds gate[row][16 w + 4 kq .. + 3]
+                if (row < r1) *reinterpret_cast<rf_f32x4 *>(a.gate + (size_t)row * KG + 16 * wave + 4 * kq) = acc;
+    #pragma unroll
+                for (int q = 0; q < 4; ++q) sgate[c][16 * wave + 4 * kq + q] = 1.f / (1.f + expf(-acc[q]));
+            }
+            rf_lds_barrier();
+            // ---- this thread's column: rows part, part + PARTS, ... of the tile ----
+            const float *img = reinterpret_cast<const float *>(image);
+    #pragma unroll
+            for (int u = 0; u < 16 / PARTS; ++u) {
+                const int rr_ = part + PARTS * u;
+                const int slot4 = RPI == 2 ? (rr_ >> 1) * ISTRIDE + 32 * (rr_ & 1) + ((pcol >> 2) ^ (rr_ & 1)) : rr_ * ISTRIDE + (pcol >> 2);
+                const float xv = img[slot4 * 4 + (pcol & 3)];
+                pacc = rb + rr_ < r1 ? fmaf(xv, sgate[rr_][pcol & (KG - 1)], pacc) : pacc;
+            }
+            rf_lds_barrier();
         }
-        rf_lds_barrier();
-        // ---- this thread's column: rows part, part + 4, ... of the tile ----
-        const float *img = reinterpret_cast<const float *>(image);
-#pragma unroll
-        for (int u = 0; u < 4; ++u) {
-            const int rr_ = part + 4 * u;
-            const float xv = img[((rr_ >> 1) * ISTRIDE + 32 * (rr_ & 1) + ((pcol >> 2) ^ (rr_ & 1))) * 4 + (pcol & 3)];
-            pacc = rb + rr_ < r1 ? fmaf(xv, sgate[rr_][pcol & (KG - 1)], pacc) : pacc;
+        if (a.stamps && tk[3] == 0) tk[3] = __builtin_amdgcn_s_memrealtime();
+        red[part][pcol] = pacc;
+        __syncthreads();
+        if (part == 0) {
+            float tot = red[0][pcol] + red[1][pcol];
+            if constexpr (PARTS == 4) tot += red[2][pcol] + red[3][pcol];
+            a.out[(size_t)g * K + pcol] = tot;
         }
-        rf_lds_barrier();
+
+        g += (int)gridDim.x;
+        if (g >= a.num_graphs) break;
+        rf_lds_barrier();                                        // (red / slot are reused)
+        // ---- the next graph's rows: the same search, every level from memory ----
+        {
+            int lo[2] = {0, 0}, hi[2] = {N, N};
+            const long long key[2] = {(long long)g, (long long)g + 1};
+            for (;;) {
+                int stride[2], first[2], pi[2];
+                bool ge[2];
+                long long pv[2];
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int len = hi[s] - lo[s];
+                    stride[s] = max((len + RF_THREADS - 1) / RF_THREADS, 1);
+                    pi[s] = lo[s] + tid * stride[s];
+                }
+                pv[0] = a.batch[min(pi[0], N - 1)];
+                pv[1] = a.batch[min(pi[1], N - 1)];
+#pragma unroll
+                for (int s = 0; s < 2; ++s) ge[s] = pi[s] < hi[s] && pv[s] >= key[s];
+                if (tid < 2) slot[tid] = RF_THREADS;
+                rf_lds_barrier();
+#pragma unroll
+                for (int s = 0; s < 2; ++s)
+                    if (ge[s]) atomicMin(&slot[s], tid);
+                rf_lds_barrier();
+                first[0] = slot[0];
+                first[1] = slot[1];
+                rf_lds_barrier();
+                bool done = true;
+#pragma unroll
+                for (int s = 0; s < 2; ++s) {
+                    const int len = hi[s] - lo[s];
+                    if (len <= 0) continue;
+                    const int probes = (len + stride[s] - 1) / stride[s];
+                    if (stride[s] == 1) {
+                        const int ans = first[s] >= probes ? hi[s] : lo[s] + first[s];
+                        lo[s] = hi[s] = ans;
+                    } else {
+                        const int nlo = first[s] == 0 ? lo[s] : lo[s] + (min(first[s], probes) - 1) * stride[s] + 1;
+                        const int nhi = first[s] >= probes ? hi[s] : lo[s] + first[s] * stride[s];
+                        lo[s] = nlo;
+                        hi[s] = nhi;
+                        done = done && nhi <= nlo;
+                    }
+                }
+                if (done) break;
+            }
+            r0 = lo[0];
+            r1 = lo[1];
+        }
     }
-    if (a.stamps) tk[3] = __builtin_amdgcn_s_memrealtime();
-    red[part][pcol] = pacc;
-    __syncthreads();
-    if (part == 0) a.out[(size_t)g * K + pcol] = (red[0][pcol] + red[1][pcol]) + (red[2][pcol] + red[3][pcol]);
     if (a.stamps && tid == 0) {
-        unsigned long long *o = a.stamps + (size_t)g * 8;
-        o[0] = tk[0]; o[1] = tk[1]; o[2] = tk[2]; o[3] = tk[3]; o[4] = __builtin_amdgcn_s_memrealtime(); o[5] = (unsigned long long)(r1 - r0);
+        unsigned long long *o = a.stamps + (size_t)blockIdx.x * 8;        // (the workgroup's FIRST graph)
+        o[0] = tk[0]; o[1] = tk[1]; o[2] = tk[2]; o[3] = tk[3]; o[4] = __builtin_amdgcn_s_memrealtime(); o[5] = (unsigned long long)rows_first;
         o[6] = tk[4]; o[7] = tk[5];
     }
 }
@@ -783,6 +886,15 @@ int phc_gated_pool_fwd_sorted(const float *x, const float *gate, const int64_t *
     return gated_pool_fwd_impl(x, gate, nullptr, batch_sorted_i64, N, num_graphs, h, n_comp, out, stream);
 }
 
+static int ro_num_cu() {
+    static int n = 0;
+    if (n == 0) {
+        int dev = 0;
+        hipDeviceProp_t pr;
+        n = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&pr, dev) == hipSuccess && pr.multiProcessorCount > 0) ? pr.multiProcessorCount : 256;
+    }
+    return n;
+}
 static unsigned long long *g_readout_stamps = nullptr;
 int phc_debug_readout_stamps(unsigned long long *dev_words) {
     g_readout_stamps = dev_words;
@@ -791,8 +903,8 @@ int phc_debug_readout_stamps(unsigned long long *dev_words) {
 
 int phc_readout_fused_supported(int64_t N, int64_t num_graphs, int h, int n_comp, int kg) {
     static const bool off = getenv("PHC_READOUT_FUSED") && atoi(getenv("PHC_READOUT_FUSED")) == 0;
-    return (!off && N >= 1 && N <= (1 << 18) && num_graphs >= 1 && num_graphs <= (1 << 20) && h == 128 && n_comp >= 1 && h % n_comp == 0 &&
-            kg == 32 && h / n_comp == 32) ? 1 : 0;
+    return (!off && N >= 1 && N <= (1 << 18) && num_graphs >= 1 && num_graphs <= (1 << 20) && (h == 128 || h == 256) && n_comp >= 1 &&
+            h % n_comp == 0 && ((h == 128 && kg == 32) || (h == 256 && (kg == 32 || kg == 64))) && h / n_comp == kg) ? 1 : 0;
 }
 
 int phc_readout_fused_fwd(const phc_readout_desc *d, void *stream) {
@@ -823,17 +935,28 @@ int phc_readout_fused_fwd(const phc_readout_desc *d, void *stream) {
     a.stamps = g_readout_stamps;
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(K_GATED_POOL_FWD, s);
-    const dim3 grid((unsigned)d->num_graphs), block(RF_THREADS);
-    if (!normed)
-        PHC_LAUNCH((readout_fused_fwd_kernel<false, true, true>), grid, block, 0, s, a);
-    else if (a.norm_act == PHC_ACT_RELU && a.p.flat)
-        PHC_LAUNCH((readout_fused_fwd_kernel<true, true, true>), grid, block, 0, s, a);
-    else if (a.norm_act == PHC_ACT_RELU)
-        PHC_LAUNCH((readout_fused_fwd_kernel<true, true, false>), grid, block, 0, s, a);
-    else if (a.p.flat)
-        PHC_LAUNCH((readout_fused_fwd_kernel<true, false, true>), grid, block, 0, s, a);
+    const long long slots = 2LL * ro_num_cu();                       // both instantiations fit two workgroups of 512 threads per CU
+    const dim3 grid((unsigned)(d->num_graphs < slots ? d->num_graphs : slots)), block(RF_THREADS);
+#define PHC_RF_LAUNCH(KC, GC)                                                                                  \
+    do {                                                                                                      \
+        if (!normed)                                                                                          \
+            PHC_LAUNCH((readout_fused_fwd_kernel<KC, GC, false, true, true>), grid, block, 0, s, a);          \
+        else if (a.norm_act == PHC_ACT_RELU && a.p.flat)                                                      \
+            PHC_LAUNCH((readout_fused_fwd_kernel<KC, GC, true, true, true>), grid, block, 0, s, a);           \
+        else if (a.norm_act == PHC_ACT_RELU)                                                                  \
+            PHC_LAUNCH((readout_fused_fwd_kernel<KC, GC, true, true, false>), grid, block, 0, s, a);          \
+        else if (a.p.flat)                                                                                    \
+            PHC_LAUNCH((readout_fused_fwd_kernel<KC, GC, true, false, true>), grid, block, 0, s, a);          \
+        else                                                                                                  \
+            PHC_LAUNCH((readout_fused_fwd_kernel<KC, GC, true, false, false>), grid, block, 0, s, a);         \
+    } while (0)
+    if (d->h == 128)
+        PHC_RF_LAUNCH(128, 32);
+    else if (d->kg == 32)
+        PHC_RF_LAUNCH(256, 32);
     else
-        PHC_LAUNCH((readout_fused_fwd_kernel<true, false, false>), grid, block, 0, s, a);
+        PHC_RF_LAUNCH(256, 64);
+#undef PHC_RF_LAUNCH
     return check_launch("phc_readout_fused_fwd");
 }
 

@@ -216,14 +216,15 @@ def test_aggregation_inside_the_first_gemm_leaves_the_step_bit_identical(workloa
 # ---- the read-out's forward as one launch (phc_readout_fused_fwd, csrc/readout.hip) ------------------------------------------------
 @pytest.mark.parametrize("B,sizes", [(7, "small"), (544, "molecules"), (40, "big")])
 @pytest.mark.parametrize("normed,act,with_skip", [(False, "relu", False), (True, "relu", True), (True, "swish", False)])
-def test_readout_in_one_launch_equals_the_three_launches(B, sizes, normed, act, with_skip):
+@pytest.mark.parametrize("n,k", [(4, 32), (8, 32), (4, 64)])             # h = 128 (configs[1]), 256 (configs[2] PHM-8, configs[3] PHM-4)
+def test_readout_in_one_launch_equals_the_three_launches(B, sizes, normed, act, with_skip, n, k):
     """x (bit for bit), gate and the per-graph sums (fp32 summation order: 2e-6 of the largest entry) of ONE phc_readout_fused_fwd
     launch against phc_bn_fwd_from_partials -> phc_gemm_prebuilt -> phc_gated_pool_fwd_sorted; empty graphs, graphs of 1 ... 300 rows,
     padding rows behind *n_valid."""
     import ctypes as C
     from phc_gnn_amd import lib as L
     lib = L.load()
-    n, k, h, kg = 4, 32, 128, 32
+    h, kg = n * k, k
     g = torch.Generator().manual_seed(B)
     hi = dict(small=5, molecules=45, big=300)[sizes]
     cnt = torch.randint(0, hi, (B,), generator=g)
@@ -286,11 +287,16 @@ def test_readout_in_one_launch_equals_the_three_launches(B, sizes, normed, act, 
         assert float((a_ - b_).abs().max()) <= 2e-6 * max(float(b_.abs().max()), 1e-30), (key, float((a_ - b_).abs().max()), float(b_.abs().max()))
 
 
-@pytest.mark.parametrize("workload", ["molhiv_b32_swish", "molhiv_b512_swish", "molhiv_b32"])
+@pytest.mark.parametrize("workload", ["molhiv_b32_swish", "molhiv_b512_swish", "molhiv_b32", "zinc_small_256_swish", "molpcba_small_256_swish"])
 @pytest.mark.parametrize("graph", [False, True])
 def test_readout_in_one_launch_leaves_the_step_unchanged(workload, graph):
     """Loss and every gradient with ops.READOUT_FUSED on and off (a different fp32 summation order in the gate and in the per-graph
     sums: 2e-5 of each tensor's largest entry on the smooth models; the ReLU model's loss only — a gate at the kink may flip)."""
+    from phc_gnn_amd import harness
+    harness.WORKLOADS.setdefault("zinc_small_256_swish", dict(dataset="zinc", batch_size=48, phm_dim=8, hidden=256, layers=2, d_units=[64, 32],
+                                                              target_dim=1, sc_type="last", regression=True, activation="swish"))
+    harness.WORKLOADS.setdefault("molpcba_small_256_swish", dict(dataset="molpcba", batch_size=40, phm_dim=4, hidden=256, layers=2, d_units=[64, 32],
+                                                                 target_dim=8, sc_type="first", nan_frac=0.5, activation="swish"))
     on = _step(workload, dict(READOUT_FUSED=True), graph)
     off = _step(workload, dict(READOUT_FUSED=False), graph)
     assert abs(float(on[0]) - float(off[0])) <= 2e-6 * abs(float(off[0])), (float(on[0]), float(off[0]))
