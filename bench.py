@@ -315,7 +315,7 @@ def bench_large_graph(args, world, rank, dev):
         ev0.record()
         for _ in range(3):
             recv, wk = _exchange_rows(agg.backend, agg.lane, x_own.detach(), plan.send_rows, plan.n_halo, plan.recv_splits,
-                                      plan.send_splits, plan.group)
+                                      plan.send_splits, plan.group, plan.max_pair_rows)
             _finish(agg.lane, wk)
         ev1.record(); torch.cuda.synchronize()
         ex_ms = ev0.elapsed_time(ev1) / 3

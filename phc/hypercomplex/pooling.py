@@ -7,6 +7,7 @@ import torch
 import torch.nn as nn
 
 from phc.hypercomplex.layers import PHMLinear, RealTransformer
+from phc.hypercomplex.utils import any_forward_hooks
 from phc_gnn_amd import ops as _engine
 
 
@@ -61,7 +62,7 @@ class PHMSoftAttentionPooling(nn.Module):
             else None
         aff = getattr(self.real_trafo, "affine", None)
         if _engine.GATE_COMPOSED and isinstance(aff, nn.Linear) and x.is_cuda and x.dim() == 2 \
-                and _engine.gate_composable(self.linear.W, aff.weight):
+                and _engine.gate_composable(self.linear.W, aff.weight) and not any_forward_hooks(self.linear, self.real_trafo):
             # Linear(PHMLinear(x)) has nothing between its two maps: one GEMM with the composed [embed, embed / phm_dim] operand
             # (built by the step's operand launch), no [N, embed] intermediate — the same numbers up to fp32 round-off
             gate = _engine.gate_linear(x, self.linear.phm_rule, self.linear.W, self.linear.b, aff.weight, aff.bias, dx_handoff=handoff,

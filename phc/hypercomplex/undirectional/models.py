@@ -16,7 +16,7 @@ from phc.hypercomplex.layers import PHMMLP, phm_dropout
 from phc.hypercomplex.norm import PHMNorm
 from phc.hypercomplex.pooling import PHMGlobalSumPooling, PHMSoftAttentionPooling
 from phc.hypercomplex.undirectional.messagepassing import PHMMessagePassing
-from phc.hypercomplex.utils import get_multiplication_matrices
+from phc.hypercomplex.utils import any_forward_hooks as _any_hooks, get_multiplication_matrices
 from phc.quaternion.activations import get_module_activation
 from phc_gnn_amd import ops as _engine
 
@@ -27,7 +27,14 @@ BOND_FEAT_DIMS = [5, 6, 2]
 
 
 class PHMSkipConnectAdd(nn.Module):
-    """Undirectional message-passing network with additive skip connections."""
+    """Undirectional message-passing network with additive skip connections.
+
+    Observability contract: on the engine's fast path a layer's last element-wise pass may be PARKED
+    (``ops.PendingNorm`` / ``PendingAggregate`` / ``PendingGate``) and evaluated inside the next launch, and sub-modules are driven
+    through fused entry points rather than ``__call__``.  That is invisible to callers of ``model(data)``.  Whoever wants to
+    LOOK between the layers registers forward hooks on ``convs[i]`` / ``norms[i]`` / ``pooling`` as with the reference — the
+    model then runs the reference's own sequence through every module's ``__call__`` (ref :200-217), and every hook sees
+    finished tensors."""
 
     def __init__(self, phm_dim: int = 4, learn_phm: bool = True, phm_rule=None,
                  atom_input_dims: Union[int, list] = ATOM_FEAT_DIMS, atom_encoded_dim: int = 196,
@@ -143,6 +150,21 @@ class PHMSkipConnectAdd(nn.Module):
         """x = [input of the conv, skip tensor]   (ref :200-217).  With ``edge_encoder`` given,
         ``edge_attr`` holds the raw integer bond features and the embedding is evaluated
         inside the aggregation kernel."""
+        if getattr(self, "_observable_now", False):
+            # somebody registered forward hooks: the reference's sequence (ref :200-217), every module through its __call__
+            _engine.materialize_pending(x[0])
+            if n_valid is not None:
+                raise NotImplementedError("forward hooks are not available on fixed-shape (padded / hipGraph-replayed) batches: "
+                                          "a replay does not run Python; remove the hooks or run the plain batch")
+            if edge_encoder is not None:
+                e = edge_encoder(edge_attr)
+                edge_attr = e.reshape(e.size(0), -1)
+            h = conv(x=x[0], edge_index=edge_index, edge_attr=edge_attr, size=size)
+            if norm is not None:
+                h = norm(h)
+            h = self.f_act(h)
+            h = phm_dropout(x=h, p=dropout_mpnn, phm_dim=self.phm_dim, training=self.training, same=self.same_dropout)
+            return h + x[1]
         dropout_active = self.training and dropout_mpnn > 0.0
         tr = getattr(conv, "transform", None)
         # the layer in front may have parked its last element-wise pass (engine: PendingNorm on x[0]): only the fused branch below
@@ -215,6 +237,9 @@ class PHMSkipConnectAdd(nn.Module):
         atom = self.atomencoder(x)
         atom = atom.reshape(atom.size(0), self.phm_dim * self.atom_encoded_dim)     # component-major [N, h]
         L_ = len(self.mp_layers)
+        # unfinished tensors never leave this method, and nobody inside can look at them unless hooked in: with hooks anywhere
+        # below, every layer takes the reference's module-by-module sequence (class docstring)
+        self._observable_now = observable = _any_hooks(self.convs, self.norms, self.pooling)
         # the encoded atoms feed the first conv and (sc_type "first") every layer's skip: one fan-out node, so that
         # their gradients are summed in one pass
         # ("last": the conv input IS the skip tensor — one tensor object, see compute_hidden_layer_embedding's hand-off)
@@ -225,7 +250,8 @@ class PHMSkipConnectAdd(nn.Module):
                                               and L_ <= _engine.DxSumHandoff.MAX and _engine.SKIP_SUM_HANDOFF) else None
         h = uses[0] if uses is not None else atom
         # (a sorted batch's soft-attention read-out applies the last layer's norm itself: engine PendingGate / phc_readout_fused_fwd)
-        readout_takes_norm = isinstance(self.pooling, PHMSoftAttentionPooling) and bool(getattr(data, "batch_is_sorted", False))
+        readout_takes_norm = isinstance(self.pooling, PHMSoftAttentionPooling) and bool(getattr(data, "batch_is_sorted", False)) \
+            and not observable
         for i in range(L_):
             if uses is not None:
                 skip = uses[1 + i]
@@ -240,8 +266,9 @@ class PHMSkipConnectAdd(nn.Module):
                                                         n_valid=n_valid, skip_sum=skip_sum, first_layer=(i == 0),
                                                         # the layer's last element-wise pass rides in the NEXT layer's aggregation
                                                         # ... the last layer's in the soft-attention read-out's one launch
-                                                        defer_norm=(getattr(self.bondencoders[i + 1], "engine_tables", None) is not None
-                                                                    if i + 1 < L_ else readout_takes_norm))
+                                                        defer_norm=not observable and (
+                                                            getattr(self.bondencoders[i + 1], "engine_tables", None) is not None
+                                                            if i + 1 < L_ else readout_takes_norm))
                 continue
             e = enc(edge_attr)
             e = e.reshape(e.size(0), self.mp_layers[i])

@@ -90,3 +90,17 @@ def phm_cat(tensors: list, phm_dim: int, dim=-1) -> torch.Tensor:
     out = torch.cat(split, dim=2).reshape(tensors[0].shape[0], -1)
     assert out.shape[1] == sum(t.shape[1] for t in tensors)
     return out
+
+
+def any_forward_hooks(*roots) -> bool:
+    """True if a forward (pre-)hook is registered on any of the modules or their sub-modules (or globally)."""
+    from torch.nn.modules import module as _m
+    if _m._global_forward_hooks or _m._global_forward_pre_hooks:
+        return True
+    for root in roots:
+        if root is None:
+            continue
+        for sub in root.modules():
+            if sub._forward_hooks or sub._forward_pre_hooks:
+                return True
+    return False

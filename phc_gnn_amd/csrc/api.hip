@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include <mutex>
+#include <unordered_map>
 #include <vector>
 
 #include "phc_common.h"
@@ -117,6 +118,28 @@ static void prof_drain_locked() {
         g_free.push_back(p);
     }
     g_slots.clear();
+}
+
+// (kernel address, device ordinal) -> largest dynamic-LDS size the attribute was set to (phc_common.h: ensure_dynamic_lds)
+static std::mutex g_lds_mu;
+static std::unordered_map<unsigned long long, size_t> g_lds_done;
+bool ensure_dynamic_lds_addr(const void *kernel, size_t bytes) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 256) {
+        (void)hipGetLastError();
+        return false;
+    }
+    // code addresses fit 56 bits: the device ordinal rides in the top byte of the key
+    const unsigned long long key = ((unsigned long long)(uintptr_t)kernel & 0x00ffffffffffffffull) | ((unsigned long long)dev << 56);
+    std::lock_guard<std::mutex> lk(g_lds_mu);
+    auto it = g_lds_done.find(key);
+    if (it != g_lds_done.end() && it->second >= bytes) return true;
+    if (hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    g_lds_done[key] = bytes;
+    return true;
 }
 
 }  // namespace phc

@@ -285,25 +285,14 @@ __device__ __forceinline__ float bn_running_update(float old, float momentum, fl
     return (1.f - momentum) * old + momentum * value;
 }
 
-// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE attribute: one bit per device ordinal and kernel instantiation
-// (the static lives in the template instantiation), set on first use on that device and checked.  false = the runtime refused
-// (the caller takes its fallback path or reports PHC_ERR_LAUNCH).
+// hipFuncAttributeMaxDynamicSharedMemorySize is a PER-DEVICE, PER-KERNEL attribute.  The cache is keyed by the kernel's ADDRESS and
+// the device ordinal (api.hip: a mutex-guarded set) — every instantiation of a kernel template has the same function-pointer TYPE,
+// so a static inside a template over that type would be shared by the whole family and only the first instantiation launched on a
+// device would get the attribute.  false = the runtime refused (the caller takes its fallback path or reports PHC_ERR_LAUNCH).
+bool ensure_dynamic_lds_addr(const void *kernel, size_t bytes);
 template <typename K>
 inline bool ensure_dynamic_lds(K kernel, size_t bytes) {
-    static unsigned long long done[4] = {0, 0, 0, 0};           // device ordinals 0..255
-    int dev = 0;
-    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 256) {
-        (void)hipGetLastError();
-        return false;
-    }
-    const unsigned long long bit = 1ull << (dev & 63);
-    if (__atomic_load_n(&done[dev >> 6], __ATOMIC_ACQUIRE) & bit) return true;
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes) != hipSuccess) {
-        (void)hipGetLastError();
-        return false;
-    }
-    __atomic_fetch_or(&done[dev >> 6], bit, __ATOMIC_RELEASE);
-    return true;
+    return ensure_dynamic_lds_addr(reinterpret_cast<const void *>(kernel), bytes);
 }
 
 inline int check_launch(const char *what) {

@@ -118,6 +118,10 @@ class HaloPlan:
     halo_edge_ids: torch.Tensor       # [E_halo]
     group: Optional[object] = None
     max_pair_rows: int = 0            # largest row count any PAIR of ranks exchanges (same value on every rank; 0 = unknown)
+    serial: int = -1                  # number of this plan, AGREED by every rank of the group (key of the exchange's start-up check)
+
+
+_next_plan_serial = 0
 
 
 def build_halo_plan(edge_index: torch.Tensor, num_nodes: int, group=None) -> HaloPlan:
@@ -147,15 +151,19 @@ def build_halo_plan(edge_index: torch.Tensor, num_nodes: int, group=None) -> Hal
         raise RuntimeError("halo plan: received a request for a row this rank does not own")
 
     # (host reads above: once per graph; the plan is reused by every layer and every step)
-    biggest = torch.tensor([max(need_l + asked_l + [0])], dtype=torch.int64, device=dev)
+    # ... and one plan number every rank agrees on (ranks may have built different numbers of plans in other groups before)
+    global _next_plan_serial
+    biggest = torch.tensor([max(need_l + asked_l + [0]), _next_plan_serial], dtype=torch.int64, device=dev)
     dist.all_reduce(biggest, op=dist.ReduceOp.MAX, group=group)         # every rank must cut its exchanges alike (_exchange_rows)
+    serial = int(biggest[1].item())
+    _next_plan_serial = serial + 1
     loc_ei = torch.stack([s[loc_pos] - lo, d[loc_pos]], 0)
     halo_src = torch.searchsorted(halo_ids, s[halo_pos])
     halo_ei = torch.stack([halo_src, d[halo_pos]], 0)
     return HaloPlan(rank=rank, world=world, lo=lo, hi=hi, n_own=hi - lo, n_halo=int(halo_ids.numel()),
                     halo_ids=halo_ids, recv_splits=need_l, send_rows=(req - lo).contiguous(), send_splits=asked_l,
                     loc_edge_index=loc_ei.contiguous(), loc_edge_ids=mine[loc_pos], halo_edge_index=halo_ei.contiguous(),
-                    halo_edge_ids=mine[halo_pos], group=group, max_pair_rows=int(biggest.item()))
+                    halo_edge_ids=mine[halo_pos], group=group, max_pair_rows=int(biggest[0].item()), serial=serial)
 
 
 class _CommLane:
@@ -322,12 +330,15 @@ def _chunk_bounds(n: int, chunks: int):
 
 
 # ---- start-up check of the exchange ------------------------------------------------------------------------------------
-# The first exchange of every (lane, split pattern, width) is preceded by ONE exchange of the same shape whose payload every
+# The first exchange of every (lane, plan, direction, width) is preceded by ONE exchange of the same shape whose payload every
 # receiver can predict: row j of the segment rank s sends to rank d holds (s * A + d * B + 97 j + column) mod 65521 — exact in
 # fp32.  It travels the very path the real rows take (same splits, same chunk cut, same backend), so a transport that delivers
 # wrong rows at this size — as one > 2 GiB RCCL all-to-all did — fails LOUDLY at start-up on every rank (the mismatch count is
 # all-reduced, so no rank is left waiting in a collective) instead of training on silently corrupted halo rows.
-# PHC_EXCHANGE_SELFCHECK=0 skips it.
+# The check is itself collective (an all-to-all and an all-reduce), so whether it runs must be decided IDENTICALLY on every rank:
+# its key is (HaloPlan.serial — agreed by an all-reduce when the plan is built —, direction, width, dtype, chunk size), never a
+# rank's own split lists (a rank whose send and receive splits coincide would take the backward exchange for already verified
+# while its peers run the check).  PHC_EXCHANGE_SELFCHECK=0 skips it.
 EXCHANGE_SELFCHECK = __import__("os").environ.get("PHC_EXCHANGE_SELFCHECK", "1") != "0"
 _PAT_A, _PAT_B, _PAT_M = 1315423911, 2654435761, 65521
 
@@ -366,16 +377,17 @@ def _verify_exchange(be, lane: "_CommLane", h: int, dtype, device, out_splits, i
 
 
 def _exchange_rows(be, lane: _CommLane, rows_src: torch.Tensor, gather_index: Optional[torch.Tensor], out_rows: int,
-                   out_splits, in_splits, group, max_pair_rows: int = 0, _check: bool = True):
+                   out_splits, in_splits, group, max_pair_rows: int = 0, _check: bool = True, check_key=None):
     """Start one all-to-all(v) of feature rows on the comm lane: (optionally) gather the rows to send with the engine's
     row-gather kernel, then the collective.  Returns (recv buffer, handle); ``_finish`` joins.
     ``max_pair_rows``: the plan's global pair maximum (HaloPlan.max_pair_rows) — decides, identically on every rank, into how
-    many row chunks the exchange is cut (0: this rank's own splits decide; only valid for a group of one)."""
+    many row chunks the exchange is cut (0: this rank's own splits decide; only valid for a group of one).
+    ``check_key``: (HaloPlan.serial, direction) — identical on every rank of the group; None = no start-up check."""
     h = rows_src.shape[1]
-    if _check and EXCHANGE_SELFCHECK and dist.is_initialized():
-        key = (tuple(out_splits), tuple(in_splits), h, rows_src.dtype, MAX_PAIR_BYTES)
+    if _check and EXCHANGE_SELFCHECK and check_key is not None and dist.is_initialized():
+        key = (tuple(check_key), h, rows_src.dtype, MAX_PAIR_BYTES)
         seen = lane.__dict__.setdefault("_verified", set())
-        if key not in seen:                                     # (same key on both sides of every pair: collective by construction)
+        if key not in seen:                                     # (every part of the key is the same on every rank)
             seen.add(key)
             _verify_exchange(be, lane, h, rows_src.dtype, rows_src.device, out_splits, in_splits, group, max_pair_rows)
     recv = torch.empty((out_rows, h), dtype=rows_src.dtype, device=rows_src.device)
@@ -433,7 +445,7 @@ class _ShardedAggregateFn(torch.autograd.Function):
         plan, be, lane = agg.plan, agg.backend, agg.lane
         x_own = x_own.contiguous()
         recv, work = _exchange_rows(be, lane, x_own, plan.send_rows, plan.n_halo, plan.recv_splits, plan.send_splits, plan.group,
-                                    plan.max_pair_rows)
+                                    plan.max_pair_rows, check_key=(plan.serial, "fwd"))
         out = be.aggregate_fwd(x_own, ea_loc, agg.st_loc, act, add_self)            # overlaps the exchange
         _finish(lane, work)
         if plan.halo_edge_index.shape[1] > 0:
@@ -481,7 +493,7 @@ class ShardedAggregate:
         """(out, recv) without autograd bookkeeping (the fused layer below keeps its own)."""
         plan, be = self.plan, self.backend
         recv, work = _exchange_rows(be, self.lane, x_own, plan.send_rows, plan.n_halo, plan.recv_splits, plan.send_splits, plan.group,
-                                    plan.max_pair_rows)
+                                    plan.max_pair_rows, check_key=(plan.serial, "fwd"))
         out = be.aggregate_fwd(x_own, ea_loc, self.st_loc, act, add_self)
         _finish(self.lane, work)
         if plan.halo_edge_index.shape[1] > 0:
@@ -499,7 +511,7 @@ class ShardedAggregate:
             d_halo = dout.new_zeros((plan.n_halo, h))
             dea_halo = dout.new_zeros((0, h)) if need_dea[1] else None
         back, work = _exchange_rows(be, self.lane, d_halo, None, int(plan.send_rows.numel()), plan.send_splits, plan.recv_splits,
-                                    plan.group, plan.max_pair_rows)
+                                    plan.group, plan.max_pair_rows, check_key=(plan.serial, "bwd"))
         d_own, dea_loc = be.aggregate_bwd(dout, x_own, ea_loc, self.st_loc, act, add_self, need_dea[0])
         extra = overlap() if overlap is not None else None
         _finish(self.lane, work)

@@ -331,6 +331,8 @@ def _register_error_word(dev: torch.device) -> None:
     check(load().phc_set_error_word(dev.index if dev.index is not None else torch.cuda.current_device(), word.data_ptr()),
           "phc_set_error_word")
     _ERR_WORDS[dev] = word
+    if dev not in _EMPTY_BUF and not torch.cuda.is_current_stream_capturing():
+        _make_empty_buf(dev)
 
 
 def check_indices(device: Optional[torch.device] = None) -> None:
@@ -368,9 +370,19 @@ def ptr(t: Optional[torch.Tensor]) -> Optional[int]:
     if p == 0 and t.is_cuda:
         buf = _EMPTY_BUF.get(t.device)
         if buf is None:
-            buf = _EMPTY_BUF[t.device] = torch.zeros(256, dtype=torch.uint8, device=t.device)
+            buf = _make_empty_buf(t.device)
         return buf.data_ptr()
     return p
+
+
+def _make_empty_buf(dev: torch.device) -> torch.Tensor:
+    """The device's stand-in for empty tensors (ptr): created on the device's first engine op (_register_error_word), never inside
+    a stream capture — there the buffer would land in the graph's private pool and its memset would only be recorded, not run."""
+    if torch.cuda.is_current_stream_capturing():
+        raise PhcError("an empty tensor reached the engine inside a hipGraph capture before any engine op had run on this device "
+                       "eagerly (run one eager warm-up step first: GraphedTrainStep does)")
+    buf = _EMPTY_BUF[dev] = torch.zeros(256, dtype=torch.uint8, device=dev)
+    return buf
 
 
 def stream_ptr(device: torch.device) -> int:

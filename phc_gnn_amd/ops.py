@@ -1697,7 +1697,10 @@ class _GatedSegmentSumFn(torch.autograd.Function):
             raise L.PhcError(f"gate must be [{N}, {h // n_comp}] for x [{N}, {h}] with {n_comp} components")
         out = torch.empty((st.num_segments, h), dtype=torch.float32, device=dev)
         pg = pending_gate
-        if pg is not None and pg.run_with_pool(st, n_comp, out):
+        if pg is not None and not pg.run_with_pool(st, n_comp, out):
+            pg.materialize()                     # outside the one-launch form after all: finish norm + gate before the pool reads them
+            pg = None
+        if pg is not None:
             pass
         elif st.is_sorted and st._csr is None and not _POOL_SEGPTR:
             # collated batch: the workgroups find their rows in the sorted `batch` vector themselves (no pointer launch)

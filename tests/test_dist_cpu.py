@@ -128,12 +128,17 @@ def _graph(N, E, world, kind, seed):
     """Edge list [2, E'] of the multi-rank tests.  kind "uniform": iid edges.  kind "holes" (what an 8-rank run meets on real
     partitions and a uniform toy graph never shows): the LAST rank's nodes have local in-edges only (a rank with no halo at
     all), ranks 0 and 1 exchange nothing in either direction (empty peer segments inside the all-to-all), and from 4 ranks up
-    rank 2's nodes have no in-edge whatsoever (empty local AND halo structures; it still serves rows to the others)."""
+    rank 2's nodes have no in-edge whatsoever (empty local AND halo structures; it still serves rows to the others).
+    kind "island": the last rank exchanges NOTHING in either direction — its send and receive splits coincide (all zero), the
+    case in which a rank-local key of the exchange's start-up check would take the backward exchange for already verified while
+    its peers run the (collective) check."""
     ei = torch.from_numpy(synth.random_edges(N, E, seed=seed))
     if kind == "uniform":
         return ei
     b = torch.tensor(partition_bounds(N, world)[1:])
     own_s, own_d = torch.bucketize(ei[0], b, right=True), torch.bucketize(ei[1], b, right=True)
+    if kind == "island":
+        return ei[:, ~((own_s != own_d) & ((own_s == world - 1) | (own_d == world - 1)))].contiguous()
     drop = (own_d == world - 1) & (own_s != world - 1)
     drop |= ((own_s == 0) & (own_d == 1)) | ((own_s == 1) & (own_d == 0))
     if world >= 4:
@@ -156,6 +161,8 @@ def _worker_sharded(rank, world, port, act, tmp, max_pair_bytes=None, kind="unif
         ea = torch.randn(E, h, generator=g)
         dy = torch.randn(N, h, generator=g)
         plan = build_halo_plan(ei, N)
+        if kind == "island" and rank == world - 1:
+            assert plan.recv_splits == plan.send_splits == [0] * world
         if kind == "holes":
             assert (plan.n_halo == 0) == (rank == world - 1 or (world >= 4 and rank == 2)), (rank, plan.n_halo)
             if rank in (0, 1):
@@ -191,6 +198,7 @@ def _worker_sharded(rank, world, port, act, tmp, max_pair_bytes=None, kind="unif
     (3, "relu", 700, "uniform"),            # odd world, three chunks per exchange
     (4, "identity", None, "holes"),
     (8, "relu", 300, "holes"),              # the driver's 8-rank shape: chunked, empty peer segments, ranks without halo / edges
+    (3, "relu", None, "island"),            # a rank whose send and receive splits coincide: the start-up check stays collective
 ])
 def test_sharded_aggregate_equals_single_process(tmp_path, world, act, max_pair_bytes, kind):
     """``max_pair_bytes``: every exchange is cut into row chunks (dist.MAX_PAIR_BYTES, the guard against > 1 GiB messages),
