@@ -51,8 +51,13 @@ WORKLOADS.update({
     # run_script_zinc_phm4.sh: PHC-4, embed 180, 4 x 180, head 180, 80
     "zinc_pub_phc4_4x180": dict(dataset="zinc", batch_size=1024, phm_dim=4, hidden=180, layers=4, d_units=[180, 80],
                                 target_dim=1, sc_type="last", regression=True, dropout_dn=[0.2, 0.1]),
+    # ogbg-molpcba published model (benchmarks/run_script_pcba_phm4.sh:3-10, README.md:58-66): PHC-4, 7 x 512, PHMConv
+    # (--mlp_mp False), head 768, 256 over 128 tasks, dropout 0.1 in every layer; the script's default batch of 512
+    "molpcba_pub_phc4_7x512": dict(dataset="molpcba", batch_size=512, phm_dim=4, hidden=512, layers=7, d_units=[768, 256],
+                                   target_dim=128, sc_type="first", mlp=False, nan_frac=0.6, dropout_mpnn=[0.1] * 7,
+                                   dropout_dn=[0.3, 0.2]),
 })
-for _k in ("molhiv_pub_phc4_2x200", "zinc_pub_phc5_4x200", "zinc_pub_phc4_4x180"):
+for _k in ("molhiv_pub_phc4_2x200", "zinc_pub_phc5_4x200", "zinc_pub_phc4_4x180", "molpcba_pub_phc4_7x512"):
     WORKLOADS[_k + "_nodrop"] = {k: v for k, v in WORKLOADS[_k].items() if not k.startswith("dropout")}
     WORKLOADS[_k + "_nodrop_swish"] = dict(WORKLOADS[_k + "_nodrop"], activation="swish")
 # smooth-activation twins (parity runs: without the ReLU kink every gradient tensor is comparable to ~1e-5)

@@ -599,6 +599,22 @@ def g12_published():
                                 sc_type="last", activation=act, **common, **zkw), regression=True, store_grad32=False)
 
 
+def g12_pcba_published():
+    """The reference's published ogbg-molpcba model (benchmarks/run_script_pcba_phm4.sh:3-10, README.md:58-66) with dropout 0:
+    PHC-4, embed 512, 7 x 512 with --mlp_mp False (PHMConv: ONE PHM layer per message-passing layer, messagepassing.py:55-74),
+    head 768, 256 over 128 tasks with ~60 % unlabeled entries; a 24-graph batch keeps the file small (the parameters dominate it).
+    ``g12_pcba_phc4_7x512_swish``: the smooth-activation twin."""
+    common = dict(norm_mp="naive-batch-norm", norm_dn="naive-batch-norm", pooling="softattention", real_trafo="linear",
+                  w_init="phm", c_init="standard", learn_phm=True)
+    pcba = [synth.molecule_batch(24, seed=42, dataset="molpcba", num_tasks=128, nan_frac=0.6)]
+    for act in ("relu", "swish"):
+        sfx = "" if act == "relu" else "_swish"
+        _fullwidth_fixture("g12_pcba_phc4_7x512" + sfx, pcba, 1240,
+                           dict(phm_dim=4, atom_encoded_dim=512, mp_layers=[512] * 7, dropout_mpnn=[0.0] * 7, mlp=False,
+                                msg_aggr="sum", downstream_layers=[768, 256], dropout_dn=[0.0, 0.0], target_dim=128,
+                                sc_type="first", activation=act, **common), store_grad32=False)
+
+
 def g11_regulariser():
     """phm_weight_regularization (regularization.py:15-23) value and gradients for p = 1, 2 on a stack of PHM layers, plus
     the regularised loop body of train() (train_hiv.py:173-201 with the script's defaults lr 1e-3, weightdecay 1e-3, p 2):
@@ -667,7 +683,7 @@ def g9_dropout():
 
 if __name__ == "__main__":
     makers = [g1_phm_linear, g2_g3_g4_kronecker_rules, g5_convs, g5b_softmax, g6_norm, g7_heads, g8_models,
-              g8_model_softmax, g9_dropout, g10_fullwidth, g10_fullwidth_swish256, g11_regulariser, g12_published, g8_yardsticks]
+              g8_model_softmax, g9_dropout, g10_fullwidth, g10_fullwidth_swish256, g11_regulariser, g12_published, g12_pcba_published, g8_yardsticks]
     wanted = sys.argv[1:]                       # e.g. `make_golden.py g8_model_softmax` rewrites only that fixture
     for make in makers:
         if not wanted or make.__name__ in wanted:

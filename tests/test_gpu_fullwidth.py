@@ -66,6 +66,10 @@ for _sfx, _act in (("", "relu"), ("_swish", "swish")):
     FULL["g12_zinc_phc4_4x180" + _sfx] = (dict(phm_dim=4, atom_input_dims=[28], bond_input_dims=[4], atom_encoded_dim=180,
                                                mp_layers=[180] * 4, dropout_mpnn=[0.0] * 4, mlp=True, downstream_layers=[180, 80],
                                                dropout_dn=[0.0, 0.0], target_dim=1, sc_type="last", activation=_act), True)
+    # the published ogbg-molpcba model (make_golden.py::g12_pcba_published; run_script_pcba_phm4.sh:3-10): 7 x 512, PHMConv (mlp False)
+    FULL["g12_pcba_phc4_7x512" + _sfx] = (dict(phm_dim=4, atom_encoded_dim=512, mp_layers=[512] * 7, dropout_mpnn=[0.0] * 7, mlp=False,
+                                               downstream_layers=[768, 256], dropout_dn=[0.0, 0.0], target_dim=128, sc_type="first",
+                                               activation=_act), False)
 
 
 def _model(name, z):
@@ -200,7 +204,7 @@ def _relu_fixture_check(name, z, model, named_grads, tap, what):
     kw = dict(COMMON, **FULL[name][0])
     L_ = len(kw["mp_layers"])
     gb_rows, B = int(z["x"].shape[0]), int(z["y"].shape[0])
-    gates = _engine_gates(tap.sites(2 * L_ + 2), gb_rows, B)
+    gates = _engine_gates(tap.sites((2 if kw.get("mlp", True) else 1) * L_ + 2), gb_rows, B)   # PHMConv: one act(norm) per layer
     sd = {k: v.clone() for k, v in sub(z, "sd::").items()}
     arrays = (z["x"], z["edge_index"], z["edge_attr"], z["batch"])
     _check_relu_with_gates(named_grads, sd, arrays, z["y"], FULL[name][1], _oracle_kwargs(kw, z["x"], z["edge_attr"]), gates, what)
@@ -410,6 +414,9 @@ FULL_SIZE.update({
     "zinc_pub_phc4_4x180_nodrop": dict(phm_dim=4, num_layers=4, num_atom_feats=1, num_bond_feats=1, num_dn_hidden=2, mlp=True,
                                        sc_type="last"),
 })
+# the published ogbg-molpcba model at the script's batch of 512 (run_script_pcba_phm4.sh:3-10): 7 x 512, PHMConv, 768-wide head
+FULL_SIZE["molpcba_pub_phc4_7x512_nodrop"] = dict(phm_dim=4, num_layers=7, num_atom_feats=9, num_bond_feats=3, num_dn_hidden=2,
+                                                  mlp=False, sc_type="first")
 # the same three with the smooth activation (no ReLU kink): every gradient tensor within 3e-5 of the float64 oracle
 FULL_SIZE.update({k + "_swish": dict(v, act="swish") for k, v in list(FULL_SIZE.items())})
 SMOOTH_GRAD_TOL = 3e-5
@@ -474,7 +481,7 @@ def test_full_size_config_against_the_oracle(workload, path):
         # ReLU: the gate-exact statements (see _check_relu_with_gates) at the configuration's full size, on the timed paths
         okw = dict(FULL_SIZE[workload])
         L_ = okw["num_layers"]
-        gates = _engine_gates(tap.sites(2 * L_ + 2), gb.num_nodes, gb.num_graphs)
+        gates = _engine_gates(tap.sites((2 if okw.get("mlp", True) else 1) * L_ + 2), gb.num_nodes, gb.num_graphs)
         params = dict(model.named_parameters())
         _check_relu_with_gates([(k, params[k].grad) for k in names], sd, args, y, regression, okw, gates, f"{workload} {path}")
         return

@@ -195,6 +195,9 @@ for _sfx, _act in (("", "relu"), ("_swish", "swish")):
                                                        mlp=True, sc_type="last", act=_act)
     FULLWIDTH_CFGS["g12_zinc_phc4_4x180" + _sfx] = dict(phm_dim=4, num_layers=4, num_atom_feats=1, num_bond_feats=1, num_dn_hidden=2,
                                                        mlp=True, sc_type="last", act=_act)
+    # the published ogbg-molpcba model (run_script_pcba_phm4.sh:3-10; make_golden.py::g12_pcba_published): 7 x 512, PHMConv
+    FULLWIDTH_CFGS["g12_pcba_phc4_7x512" + _sfx] = dict(phm_dim=4, num_layers=7, num_atom_feats=9, num_bond_feats=3, num_dn_hidden=2,
+                                                       mlp=False, sc_type="first", act=_act)
 L1_FIXTURES = ("g10_zinc_h256", "g12_zinc")
 
 

@@ -1,5 +1,5 @@
-"""Container-only: the reference's own training script (benchmarks/train_hiv.py) imports and sets itself up against THIS
-repo's ``phc`` package — the drop-in claim of SURVEY.md §8(b) checked on the script rather than on an API list.
+"""Container-only: the reference's own training scripts (benchmarks/train_hiv.py, train_zinc.py, train_pcba.py) import and set
+themselves up against THIS repo's ``phc`` package — the drop-in claim of SURVEY.md §8(b) checked on the script rather than on an API list.
 
 What runs: the script's module-level imports (train_hiv.py:1-40) with ``phc`` = this repo's package, its argument parser with
 its defaults (:43-160), the model construction exactly as main() does it (:564-579), the parameter-group split and the
@@ -27,8 +27,15 @@ def _module(name, **attrs):
     return m
 
 
-@pytest.fixture()
-def train_script(monkeypatch, tmp_path):
+SCRIPTS = ["train_hiv", "train_zinc", "train_pcba"]
+
+
+@pytest.fixture(params=SCRIPTS)
+def train_script(request, monkeypatch, tmp_path):
+    yield from _import_script(request.param, monkeypatch, tmp_path)
+
+
+def _import_script(script, monkeypatch, tmp_path):
     saved = dict(sys.modules)
     saved_path = list(sys.path)
 
@@ -43,6 +50,7 @@ def train_script(monkeypatch, tmp_path):
     tg = _module("torch_geometric")
     tg.data = _module("torch_geometric.data", DataLoader=_Dummy, Batch=_Dummy)
     tg.transforms = _module("torch_geometric.transforms", RemoveIsolatedNodes=_Dummy)
+    tg.datasets = _module("torch_geometric.datasets", ZINC=_Dummy)                       # train_zinc.py:16
     tg.utils = _module("torch_geometric.utils", degree=lambda *a, **k: None, remove_isolated_nodes=lambda *a, **k: None)
     ogb = _module("ogb")
     ogb.utils = _module("ogb.utils")
@@ -53,10 +61,11 @@ def train_script(monkeypatch, tmp_path):
     sys.path[:] = [root] + [p for p in sys.path if os.path.abspath(p or ".") not in (root, REF)] + [REF]     # phc = this repo's
     for k in [k for k in sys.modules if k == "benchmarks" or k.startswith("benchmarks.")]:
         del sys.modules[k]
-    monkeypatch.setattr(sys, "argv", ["train_hiv.py"])
+    monkeypatch.setattr(sys, "argv", [script + ".py"])
     monkeypatch.chdir(tmp_path)
     import importlib
-    T = importlib.import_module("benchmarks.train_hiv")
+    T = importlib.import_module("benchmarks." + script)
+    T._script_name = script
     import phc
     assert os.path.abspath(phc.__file__).startswith(root), phc.__file__
     yield T
@@ -70,10 +79,16 @@ def train_script(monkeypatch, tmp_path):
             del sys.modules[k]
 
 
-def test_train_hiv_sets_itself_up_on_this_package(train_script):
-    T = train_script
-    args = T.get_parser()
-    assert args.type == "undirectional-phm-sc-add" and args.aggr_msg == "softmax" and args.weightdecay == 0.001
+# what main() of each script passes that the parser does not hold (train_hiv.py:497-498,575; train_zinc.py:513-514,582;
+# train_pcba.py:499-500,575) and the parser defaults that identify the script
+_PER_SCRIPT = {
+    "train_hiv": dict(atom=[119, 4, 12, 12, 10, 6, 6, 2, 2], bond=[5, 6, 2], target_dim=1, sched_mode="max"),
+    "train_zinc": dict(atom=[28], bond=[4], target_dim=1, sched_mode="min"),
+    "train_pcba": dict(atom=[119, 4, 12, 12, 10, 6, 6, 2, 2], bond=[5, 6, 2], target_dim=128, sched_mode="max"),
+}
+
+
+def _build_as_main_does(T, args, spec, **override):
     str2bool = T.str2bool
     mp_layers = [int(i) for i in args.mp_units.split(",")]
     downstream_layers = [int(i) for i in args.d_units.split(",")]
@@ -81,16 +96,28 @@ def test_train_hiv_sets_itself_up_on_this_package(train_script):
     dn_dropout = [float(i) for i in args.dropout_dn.split(",")]
     aggr_kwargs = {"aggregators": ["mean", "min", "max", "std"], "scalers": ["identity", "amplification", "attenuation"], "deg": None,
                    "post_layers": 1, "msg_scalers": str2bool(args.msg_scale), "initial_beta": 1.0, "learn_beta": True}
-    # the call of main() (train_hiv.py:566-579), argument for argument
-    model = T.UPH_SC_ADD(phm_dim=args.phm_dim, learn_phm=str2bool(args.learn_phm), phm_rule=None,
-                         atom_input_dims=T.get_atom_feature_dims(), atom_encoded_dim=args.input_embed_dim,
-                         bond_input_dims=T.get_bond_feature_dims(), naive_encoder=not str2bool(args.full_encoder),
-                         mp_layers=mp_layers, dropout_mpnn=mp_dropout, w_init=args.w_init, c_init=args.c_init,
-                         same_dropout=str2bool(args.same_dropout), norm_mp=args.mp_norm, add_self_loops=True,
-                         msg_aggr=args.aggr_msg, node_aggr=args.aggr_node, mlp=str2bool(args.mlp_mp), pooling=args.pooling,
-                         activation=args.activation, real_trafo=args.real_trafo, downstream_layers=downstream_layers,
-                         target_dim=1, dropout_dn=dn_dropout, norm_dn=str(args.d_bn), msg_encoder=args.msg_encoder,
-                         sc_type=args.sc_type, **aggr_kwargs)
+    # the call of main() (train_hiv.py:566-579, train_zinc.py:570-583, train_pcba.py:565-579), argument for argument
+    kw = dict(phm_dim=args.phm_dim, learn_phm=str2bool(args.learn_phm), phm_rule=None,
+              atom_input_dims=spec["atom"], atom_encoded_dim=args.input_embed_dim,
+              bond_input_dims=spec["bond"], naive_encoder=not str2bool(args.full_encoder),
+              mp_layers=mp_layers, dropout_mpnn=mp_dropout, w_init=args.w_init, c_init=args.c_init,
+              same_dropout=str2bool(args.same_dropout), norm_mp=args.mp_norm, add_self_loops=True,
+              msg_aggr=args.aggr_msg, node_aggr=args.aggr_node, mlp=str2bool(args.mlp_mp), pooling=args.pooling,
+              activation=args.activation, real_trafo=args.real_trafo, downstream_layers=downstream_layers,
+              target_dim=spec["target_dim"], dropout_dn=dn_dropout, norm_dn=str(args.d_bn), msg_encoder=args.msg_encoder,
+              sc_type=args.sc_type, **aggr_kwargs)
+    kw.update(override)
+    return T.UPH_SC_ADD(**kw), mp_layers, downstream_layers
+
+
+def test_train_script_sets_itself_up_on_this_package(train_script):
+    T = train_script
+    spec = _PER_SCRIPT[T._script_name]
+    args = T.get_parser()
+    assert args.type == "undirectional-phm-sc-add"
+    if T._script_name == "train_hiv":
+        assert args.aggr_msg == "softmax" and args.weightdecay == 0.001
+    model, mp_layers, downstream_layers = _build_as_main_does(T, args, spec)
     assert hasattr(model, "phm_dim")                                     # what train() keys the regulariser on (:182)
     model.reset_parameters()                                             # do_run :261
     # parameter groups + the script's own coverage assert (:265-282)
@@ -101,13 +128,14 @@ def test_train_hiv_sets_itself_up_on_this_package(train_script):
     total = sum(p.numel() for p in model.parameters() if p.requires_grad)
     assert split == total == model.get_number_of_params_()
     optimizer = torch.optim.Adam(groups, weight_decay=0.0)
-    torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, factor=args.factor, patience=args.patience, mode="max", min_lr=1e-6)
+    torch.optim.lr_scheduler.ReduceLROnPlateau(optimizer, factor=args.factor, patience=args.patience, mode=spec["sched_mode"], min_lr=1e-6)
     # the explicit regulariser of train() (:181-196) finds every W / phm_rule by attribute name
     reg = args.lr * args.weightdecay * T.phm_weight_regularization(model, device="cpu", p=args.regularization)
     reg = reg + args.lr * 0.1 * T.multiplication_rule_regularization(model, p=1)
     reg.backward()
     n_w = sum(1 for m in model.modules() if hasattr(m, "W") and getattr(m, "W") is not None)
-    assert n_w == 2 * len(mp_layers) + 1 + len(downstream_layers) + 1    # 2 per GINE layer, pooling, downstream stack
+    per_layer = 2 if T.str2bool(args.mlp_mp) else 1                      # PHMGINEConv's MLP has two PHM layers, PHMConv one
+    assert n_w == per_layer * len(mp_layers) + 1 + len(downstream_layers) + 1    # + pooling + downstream stack
     assert all(m.W.grad is not None for m in model.modules() if hasattr(m, "W") and isinstance(getattr(m, "W"), torch.nn.Parameter))
     # whole-module pickling (:344, :369)
     buf = io.BytesIO()
@@ -117,3 +145,27 @@ def test_train_hiv_sets_itself_up_on_this_package(train_script):
     sd, sd2 = model.state_dict(), clone.state_dict()
     assert list(sd) == list(sd2) and all(torch.equal(sd[k], sd2[k]) for k in sd)
     assert repr(model).startswith("PHMSkipConnectAdd(")
+
+
+def test_train_pcba_published_command_line_constructs(monkeypatch, tmp_path):
+    """The published ogbg-molpcba model (benchmarks/run_script_pcba_phm4.sh:3-10, README.md:58-66): 7 x 512, PHMConv
+    (--mlp_mp False), --d_units 768,256, 128 tasks, dropout 0.1 / 0.3,0.2 — parsed by the script's own parser."""
+    gen = _import_script("train_pcba", monkeypatch, tmp_path)
+    T = next(gen)
+    try:
+        monkeypatch.setattr(sys, "argv", "train_pcba.py --input_embed_dim 512 --mp_units 512,512,512,512,512,512,512 "
+                            "--dropout_mpnn 0.1,0.1,0.1,0.1,0.1,0.1,0.1 --mp_norm naive-batch-norm --d_units 768,256 "
+                            "--aggr_msg sum --aggr_node sum --dropout_dn 0.3,0.2 --phm_dim 4 --learn_phm True --d_bn naive-batch-norm "
+                            "--type undirectional-phm-sc-add --w_init phm --c_init standard --full_encoder True --mlp_mp False "
+                            "--weightdecay 0.0001 --msg_encoder identity --grad_clipping 2.0".split())
+        args = T.get_parser()
+        model, mp_layers, dn = _build_as_main_does(T, args, _PER_SCRIPT["train_pcba"])
+        assert len(model.convs) == 7 and mp_layers == [512] * 7 and dn == [768, 256]
+        assert all(type(c.transform).__name__ == "PHMConv" for c in model.convs)
+        from phc_gnn_amd import harness
+        ours = harness.build_model("molpcba_pub_phc4_7x512", "cpu", seed=0)
+        assert [tuple(v.shape) for v in ours.state_dict().values()] == [tuple(v.shape) for v in model.state_dict().values()]
+        assert list(ours.state_dict()) == list(model.state_dict())
+    finally:
+        for _ in gen:
+            pass
