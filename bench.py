@@ -636,7 +636,9 @@ def main():
                                                         for k, v in sorted(times.items())}})
             result["roofline"] = roof
         if world == 1 and args.cpu_steps > 0:
-            result["cpu_baseline"] = cpu_baseline(args, args.workload, model, host_batches[0])
+            # (bounded: ~25 s of CPU work whatever the workload — the wide configurations take seconds per oracle step)
+            result["cpu_baseline"] = cpu_baseline(args, args.workload, model, host_batches[0], budget_s=25.0,
+                                                  warmup=3 if args.workload.startswith("molhiv") else 1)
             all_cores = os.cpu_count() or args.cpu_threads
             if all_cores != args.cpu_threads and all_cores <= args.cpu_all_cores_max:
                 # the secondary denominator, every core of the GPU host (count stated)

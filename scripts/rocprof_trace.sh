@@ -8,6 +8,6 @@ rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 bench.py
 tail -1 $OUT/bench.log | cut -c1-200
 T=$(find $OUT -name "*kernel_trace.csv" | head -1)
 python3 scripts/trace_one_step.py $T ${2:-1600} > $OUT/last_step.txt
-python3 scripts/summarize_rocprof.py $(find $OUT -name "*kernel_stats.csv" | head -1) 38 60 > $OUT/summary.txt
+python3 scripts/summarize_rocprof.py $T 25 60 > $OUT/summary.txt          # the last 25 replayed steps only
 find $OUT -name "*kernel_trace.csv" -size +20M -delete
 tail -3 $OUT/last_step.txt

@@ -11,7 +11,11 @@ for wl in molhiv_b512 zinc_b1024 molpcba_b1024; do
   python3 scripts/summarize_pmc.py $F $W gpurun_out/${R}_pmc_traffic.json $wl >> gpurun_out/${R}_pmc_traffic.txt 2>&1
   find gpurun_out/pmc_${R}_${wl}_FETCH_SIZE gpurun_out/pmc_${R}_${wl}_WRITE_SIZE -name "*.csv" -size +5M -delete
 done
-for wl in zinc_b1024 molpcba_b1024 molhiv_b512_softmax molhiv_b512_conv molhiv_b32 molhiv_pub_phc4_2x200 zinc_pub_phc5_4x200 zinc_pub_phc4_4x180; do
+# (the BASELINE configurations carry their CPU denominator: a bounded oracle sample at 6 threads, bench.py cpu_baseline)
+for wl in zinc_b1024 molpcba_b1024; do
+  python bench.py --workload $wl --cpu-steps 8 --cpu-all-cores-max 0 2>&1 | grep '^{"metric"' | tail -1 > gpurun_out/${R}_bench_$wl.json
+done
+for wl in molhiv_b512_softmax molhiv_b512_conv molhiv_b32 molhiv_pub_phc4_2x200 zinc_pub_phc5_4x200 zinc_pub_phc4_4x180 molpcba_pub_phc4_7x512; do
   python bench.py --workload $wl --cpu-steps 0 2>&1 | grep '^{"metric"' | tail -1 > gpurun_out/${R}_bench_$wl.json
 done
 # kernel stats of the wide configurations and of config-5 at its full size (one GPU)
@@ -20,7 +24,12 @@ for wl in zinc_b1024 molpcba_b1024 synth_10m50m; do
   rm -rf $OUT && mkdir -p $OUT
   if [ $wl = synth_10m50m ]; then ST=8; WU=2; else ST=50; WU=10; fi
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -- python3 bench.py --workload $wl --steps $ST --warmup $WU --cpu-steps 0 --min-time 0 --profile-steps 0 > $OUT/bench.log 2>&1
-  python3 scripts/summarize_rocprof.py $(ls -t $OUT/*/*kernel_stats.csv | head -1) $((ST + WU)) 60 > gpurun_out/${R}_bench_${wl}_kernel_stats_summary.txt
+  # per REPLAYED step: the kernel trace restricted to the last steps (set-up launches excluded); config 5 is eager: whole-run stats
+  if [ $wl = synth_10m50m ]; then
+    python3 scripts/summarize_rocprof.py $(ls -t $OUT/*/*kernel_stats.csv | head -1) $((ST + WU)) 60 > gpurun_out/${R}_bench_${wl}_kernel_stats_summary.txt
+  else
+    python3 scripts/summarize_rocprof.py $(ls -t $OUT/*/*kernel_trace.csv | head -1) 40 60 > gpurun_out/${R}_bench_${wl}_kernel_stats_summary.txt
+  fi
   find $OUT -name "*kernel_trace.csv" -delete; find $OUT -name "*.db" -delete
 done
 python bench.py --workload synth_10m50m --steps 10 --warmup 2 2>&1 | tail -1 > gpurun_out/${R}_bench_synth_10m50m_1gpu.json
