@@ -259,6 +259,16 @@ class EngineBackend:
             [m.num_batches_tracked for m in mods], norm._momentum(), norm.eps,       # momentum=None is refused, as on one device
             self._ops._act_id(act), residual)
 
+    def bn_eval(self, x, norm, act, residual=None):
+        """act(norm(x)) (+ residual) with the RUNNING statistics (norm.py:30-35, eval mode): rows are independent — no exchange."""
+        was = norm.training
+        norm.train(False)
+        try:
+            with torch.no_grad():
+                return norm.forward_fused(x, activation=act, residual=residual)
+        finally:
+            norm.train(was)
+
     def bn_bwd_sums(self, dy, x, save_stat, act):
         return self._ops.bn_bwd_sums(dy, x, save_stat, self._ops._act_id(act))
 
@@ -692,8 +702,7 @@ class ShardedPHMGINEConv(torch.nn.Module):
                 link: Optional[NormLink] = None) -> torch.Tensor:
         mlp = self.conv.transform
         if not self.training:
-            raise NotImplementedError("ShardedPHMGINEConv: training-mode statistics only (eval uses the running statistics of "
-                                      "the wrapped conv on any single rank)")
+            return self._forward_eval(x_own, ea_loc, ea_halo)
         affine = []
         if mlp.norm_flag:
             nb = mlp.norm.bn
@@ -703,6 +712,18 @@ class ShardedPHMGINEConv(torch.nn.Module):
                 affine = [m.weight for m in nb.bn] + [m.bias for m in nb.bn]
         l1, l2 = mlp.linear1, mlp.linear2
         return _ShardedGINEFn.apply(self, link, x_own, ea_loc, ea_halo, l1.phm_rule, l1.W, l1.b, l2.phm_rule, l2.W, l2.b, *affine)
+
+
+    def _forward_eval(self, x_own, ea_loc, ea_halo):
+        """Validation between epochs (train_hiv.py:204-230 on a shard): the halo exchange is the only collective — with the running
+        statistics every row of linear1 -> norm -> act -> linear2 is independent of the other ranks' rows.  Forward only."""
+        mlp, be = self.conv.transform, self.agg.backend
+        with torch.no_grad():
+            s, _ = self.agg.forward_raw(x_own.contiguous(), ea_loc, ea_halo, self.msg_encoder, self.conv.add_self_loops)
+            l1, l2 = mlp.linear1, mlp.linear2
+            z = be.linear_fwd(s, l1.phm_rule, l1.W, l1.b)
+            a = be.bn_eval(z, mlp.norm.bn, mlp.activation_str) if mlp.norm_flag else self.act_fn(z)
+            return be.linear_fwd(a, l2.phm_rule, l2.W, l2.b)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -780,8 +801,10 @@ class ShardedPHMNorm(torch.nn.Module):
 
     def forward(self, x_own: torch.Tensor, residual: Optional[torch.Tensor] = None, link: Optional[NormLink] = None) -> torch.Tensor:
         nb = self.norm.bn
-        if not self.training or not hasattr(nb, "bn") or not nb.track_running_stats:
-            raise NotImplementedError("ShardedPHMNorm: training-mode naive-batch-norm with running statistics only")
+        if not hasattr(nb, "bn") or not nb.track_running_stats:
+            raise NotImplementedError("ShardedPHMNorm: naive-batch-norm with running statistics only")
+        if not self.training:                                   # eval: running statistics, no exchange (forward only)
+            return self.backend.bn_eval(x_own.contiguous(), nb, self.activation, residual)
         affine = ([m.weight for m in nb.bn] + [m.bias for m in nb.bn]) if nb.affine else []
         return _ShardedNormActFn.apply(x_own, residual, self, link, *affine)
 

@@ -105,6 +105,14 @@ class OracleBackend:
         out = O.activation(act, zhat * w + b)
         return (out if residual is None else out + residual), torch.cat([mean, invstd, w, b])
 
+    def bn_eval(self, x, norm, act, residual=None):
+        """norm.py:30-35 in eval mode: the running statistics, one BatchNorm1d per component."""
+        mods = list(norm.bn)
+        out = O.batch_norm_naive(x, len(mods), [m.weight for m in mods], [m.bias for m in mods], [m.running_mean for m in mods],
+                                 [m.running_var for m in mods], False, norm.momentum, norm.eps)
+        out = O.activation(act, out)
+        return out if residual is None else out + residual
+
     def _g(self, dy, x, save, act):
         mean, invstd, w, b = save.view(4, -1)
         xhat = (x - mean) * invstd
@@ -450,6 +458,62 @@ def test_sharded_stack_with_model_level_norm_equals_single_process(tmp_path, wor
             assert torch.equal(a, b)
         for a, b in zip(shards[0]["grads"], other["grads"]):
             assert torch.equal(a, b)                                  # one summed gradient on every rank
+
+
+# ---- eval mode (validation between epochs): running statistics, the halo exchange is the only collective ------------------------
+def _worker_stack_eval(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        N, E, n, h, ei, x, ea, dy = _stack_problem(world, "uniform")
+        convs, norms = _make_stack(n, h, seed=31)
+        _set_running_stats(convs, norms)
+        plan = build_halo_plan(ei, N)
+        stack = ShardedGINEStack(convs, norms, plan, N, activation="relu", backend=OracleBackend()).eval()
+        before = [b.clone() for m in convs + norms for b in m.buffers()]
+        ea_loc, ea_halo = stack.agg.split_edge_attr(ea)
+        y = stack(x[plan.lo:plan.hi].clone(), ea_loc, ea_halo)
+        after = [b.clone() for m in convs + norms for b in m.buffers()]
+        assert all(torch.equal(a, b) for a, b in zip(before, after))     # eval leaves the running statistics alone
+        assert all(m.training is False for m in stack.modules())
+        torch.save(dict(y=y, lo=plan.lo, hi=plan.hi), os.path.join(tmp, f"e{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def _set_running_stats(convs, norms):
+    g = torch.Generator().manual_seed(77)
+    for m in convs + norms:
+        for name, b in m.named_buffers():
+            if name.endswith("running_mean"):
+                b.copy_(0.2 * torch.randn(b.shape, generator=g))
+            elif name.endswith("running_var"):
+                b.copy_(0.5 + torch.rand(b.shape, generator=g))
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_stack_eval_mode_uses_running_statistics(tmp_path, world):
+    """``ShardedGINEStack.eval()`` (validation between epochs) == the oracle's eval-mode stack on the whole graph
+    (norm.py:30-35 with the running statistics; models.py:208-215), buffers untouched."""
+    mp.spawn(_worker_stack_eval, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    N, E, n, h, ei, x, ea, dy = _stack_problem(world, "uniform")
+    convs, norms = _make_stack(n, h, seed=31)
+    _set_running_stats(convs, norms)
+    p = {}
+    for i, (c, nm) in enumerate(zip(convs, norms)):
+        p.update({f"c{i}." + k: v.detach().clone() for k, v in c.state_dict().items()})
+        p.update({f"n{i}." + k: v.detach().clone() for k, v in nm.state_dict().items()})
+    hcur = x
+    with torch.no_grad():
+        for i in range(2):
+            y = O.phm_gine_conv(hcur, ei, ea, p, f"c{i}.transform.", n, "relu", True, False, True, "relu", None)
+            hcur = O.activation("relu", O._norm_from_state(y, p, f"n{i}.", n, False)) + hcur
+    yy = torch.zeros(N, h)
+    for r in range(world):
+        d = torch.load(os.path.join(tmp_path, f"e{r}.pt"))
+        yy[d["lo"]:d["hi"]] = d["y"]
+    err = float((yy - hcur).abs().max()) / max(float(hcur.abs().max()), 1e-30)
+    assert err <= 1e-5, err
 
 
 # ---- the exchange's start-up check: a transport that delivers a wrong row fails loudly, on every rank -----------------------

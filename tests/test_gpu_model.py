@@ -631,6 +631,54 @@ def test_sharded_stack_norm_link_equals_unlinked_stack(rccl_single_rank):
         assert_close(res[0][k], res[1][k], 3e-5, k)
 
 
+def test_sharded_stack_eval_mode_equals_the_oracle(rccl_single_rank):
+    """``ShardedGINEStack.eval()`` on the engine backend (running statistics, the halo exchange the only collective: VERDICT r4 weak 10)
+    against the oracle's eval-mode stack (norm.py:30-35 eval, models.py:208-215) on the whole graph; buffers untouched."""
+    from oracle import phc_oracle as O
+    from phc.hypercomplex.norm import PHMNorm
+    from phc.hypercomplex.undirectional.messagepassing import PHMGINEConv
+    from phc_gnn_amd import synth
+    from phc_gnn_amd.dist import ShardedGINEStack
+    n, h, N, E, LAYERS = 4, 128, 5_003, 21_000, 2
+    ei_h = torch.from_numpy(synth.random_edges(N, E, seed=41))
+    g = torch.Generator().manual_seed(42)
+    x, ea = torch.randn(N, h, generator=g), torch.randn(E, h, generator=g)
+    torch.manual_seed(8)
+    np.random.seed(8)
+    convs = [PHMGINEConv(h, h, phm_dim=n, phm_rule=None, norm="naive-batch-norm", activation="relu", msg_encoder="relu") for _ in range(LAYERS)]
+    norms = [PHMNorm(num_features=h, phm_dim=n, type="naive-batch-norm") for _ in range(LAYERS)]
+    gw = torch.Generator().manual_seed(43)
+    with torch.no_grad():
+        for mod in convs + norms:
+            for name, p in mod.named_parameters():
+                if p.dim() == 1:
+                    p.copy_(0.5 + torch.rand(p.shape, generator=gw) if name.endswith("weight") else 0.1 * torch.randn(p.shape, generator=gw))
+            for name, b in mod.named_buffers():
+                if name.endswith("running_mean"):
+                    b.copy_(0.2 * torch.randn(b.shape, generator=gw))
+                elif name.endswith("running_var"):
+                    b.copy_(0.5 + torch.rand(b.shape, generator=gw))
+    p = {}
+    for i, (c, nm) in enumerate(zip(convs, norms)):
+        p.update({f"c{i}." + k: v.detach().clone() for k, v in c.state_dict().items()})
+        p.update({f"n{i}." + k: v.detach().clone() for k, v in nm.state_dict().items()})
+    hcur = x
+    with torch.no_grad():
+        for i in range(LAYERS):
+            y = O.phm_gine_conv(hcur, ei_h, ea, p, f"c{i}.transform.", n, "relu", True, False, True, "relu", None)
+            hcur = O.activation("relu", O._norm_from_state(y, p, f"n{i}.", n, False)) + hcur
+    for m in convs + norms:
+        m.to(DEV)
+    plan = _loopback_plan(ei_h.to(DEV), N)
+    stack = ShardedGINEStack(convs, norms, plan, N, activation="relu").eval()
+    before = [b.clone() for m in convs + norms for b in m.buffers()]
+    el, eh = stack.agg.split_edge_attr(ea.to(DEV))
+    out = stack(x.to(DEV), el, eh)
+    torch.cuda.synchronize()
+    assert all(torch.equal(a, b) for a, b in zip(before, [b for m in convs + norms for b in m.buffers()]))
+    assert_close(out.cpu(), hcur, 1e-5, "eval-mode sharded stack vs the oracle")
+
+
 def test_sharded_gine_layer_norm_folded_into_gemms_equals_separate_passes(rccl_single_rank):
     """The sharded layer's norm inside its GEMMs (statistics epilogue -> moments, normalising operand, norm backward in the dx
     GEMM on all-reduced integer sums) against the same layer with the four norm passes as launches of their own
