@@ -1,0 +1,391 @@
+// Aggregation INSIDE the first GEMM of a message-passing layer for the WIDE layers (round 5): hidden 256 (BASELINE configs[2], [3])
+// and the reference's published widths 180 / 200 on the 192 / 208 register geometry — what gemm_hs_ag_device.h does at hidden 128:
+//     s[d] = sum_{e: dst_e = d} (x[src_e] + enc_e) (+ x[d])        messagepassing.py:132-146 (PHMGINEConv.propagate, GINE sum)
+//     z    = s . H (+ b),  column statistics of z                   layers.py:198-219, 349-355 (PHMMLP.linear1 + its batch-norm's sums)
+// optionally with the model-level norm of the layer in FRONT still un-applied:  x := act(norm(y)) (+ skip)   (models.py:208-215).
+//
+// What differs from the 128-wide kernel, and why:
+//   * the operand matrix does not fit the LDS (256 x 256 x 4 B): it lives in the wavefronts' REGISTERS exactly as in
+//     gemm_hs16_kernel<K, 2, 8> (8 wavefronts x 2 column tiles, K / 16 float4 per tile and lane: 128 registers at K = 256), one
+//     workgroup per CU, 256 registers per lane;
+//   * a row is 720 B - 1 KiB: ONE WAVEFRONT gathers a row (lane = 16-byte chunk; lanes past the row's end idle), so everything about
+//     a row — its edge range, its sources, its packed codes — is wave-uniform and travels in SGPRs; a wavefront owns rows 2 w and
+//     2 w + 1 of every 16-row step;
+//   * a workgroup runs 3 - 7 steps (23.6 k rows / 256 CUs = 5.8): the gather of step i + 1 must hide under the MFMAs of step i
+//     (3.4 us of matrix work per step), not stand in front of its own.  Two LDS images alternate; per wavefront the dependent chain
+//     row pointers -> sources / codes -> rows is a rolling three-stage pipeline of ordinary loads whose every consumer runs at
+//     least half an MFMA phase after the issue:
+//         MFMAs of step i, k-groups 0 .. G/2-1        | rows of (A, i + 1) in flight
+//         finish row A of step i + 1 -> image, issue rows of (B, i + 1)
+//         MFMAs of step i, k-groups G/2 .. G-1        | rows of (B, i + 1) in flight
+//         finish row B of step i + 1 -> image;  row pointers of step i + 3 (issued an iteration ago) -> issue its sources / codes;
+//         issue row pointers of step i + 4
+//         epilogue of step i (y, statistics), s / x of row B out       <- stores LAST in the iteration: nothing younger is waited for
+//         issue rows of (A, i + 2) from the sources / codes issued an iteration ago
+//     Only ONE row's gathered pieces are live at a time (NE edges + self, twice that with a norm pending): that is what fits beside
+//     128 operand registers.
+// Same edge order, same additions as aggregate_encp_direct_fwd_kernel<64, 0, F> / aggregate_norm_direct_fwd_kernel<64, F> (pair
+// first: acc0 = m0 + m2 + m3 + ..., acc1 = m1, s = (acc0 + acc1) + self), same MFMA order, row ownership and statistics epilogue
+// as gemm_hs16_kernel<K, 2, 8, 1, R, HS_ST> with the same number of workgroups: s, x, save_stat, running statistics, z and the
+// integer statistics totals are bit-identical to the separate launches.
+#pragma once
+#include "gemm_hs_ag_device.h"
+
+namespace phc {
+
+constexpr int HS_AGW_THREADS = 512;
+
+template <int K, bool NORMED, bool RELU, int NE>
+__global__ __launch_bounds__(HS_AGW_THREADS) void gemm_hs_agw_kernel(GemmHsArgs a, HsAgArgs ag) {
+    static_assert(K > 128 && K <= 256 && K % 16 == 0, "one row per 1-KiB image instruction");
+    static_assert(NE >= 2 && NE <= 4, "edges of a row fetched ahead");
+    constexpr int G = K / 16, GH = G / 2, TPW = 2, ISTRIDE = HS_ISTRIDE, IMG_F4 = 16 * ISTRIDE;
+    __shared__ f32x4_t image[2][IMG_F4];                          // two 16-row operand images (one row per padded 1-KiB line)
+    __shared__ __attribute__((aligned(16))) float s_scale[K], s_shift[K], s_bias[K];   // (the bias lives in LDS: 8 registers fewer)
+    extern __shared__ __attribute__((aligned(16))) float agw_dyn[];   // [R][KR] bond tables: row = packed code byte, columns as in x
+    const int KR = a.K, H4 = KR >> 2, Nout = a.Nout;
+    const int F = ag.F;                                           // (a run-time bound, 1..4: one instantiation per geometry and norm form)
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, kq = lane >> 4;
+    const int col0 = wave * 16 * TPW;
+    const int group = (int)blockIdx.x;
+    const int M = (int)a.M;
+    const int num_steps = (M + 15) / 16;
+    const int my_steps = group < num_steps ? (num_steps - group + a.groups - 1) / a.groups : 0;
+    if (my_steps == 0) return;
+    const int count = a.n_valid ? min(*a.n_valid, M) : M;
+    const bool live = lane < H4;                                  // this lane's 16-byte chunk exists in a row
+    const int c4 = live ? lane : 0;
+    auto lds_barrier = [] {                                       // LDS traffic only: __syncthreads() would also wait for stores / prefetches
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+    };
+    const float4 *Y4 = reinterpret_cast<const float4 *>(ag.y) + c4;
+    const float4 *S4 = reinterpret_cast<const float4 *>(ag.skip ? ag.skip : ag.y) + c4;
+    const bool has_skip = ag.skip != nullptr;
+    const float4 zf4 = make_float4(0.f, 0.f, 0.f, 0.f);
+
+    // ---- per-step metadata of this wavefront's two rows (A = 2 w, B = 2 w + 1 of the step), as vector loads on a few lanes -------
+    auto rowA_of = [&](int sl) { return (group + sl * a.groups) * 16 + 2 * wave; };
+    // row pointers of rows A, A + 1, A + 2 (lanes 0..2; clamped to the table's last entry: a row past M is empty)
+    auto load_ptrs = [&](int sl) {
+        const int r = min(rowA_of(min(sl, my_steps - 1)) + min(lane, 2), M);
+        return ag.rowptr[r];
+    };
+    struct Meta {
+        int e0[2], e1[2];
+    };
+    auto ptrs_of = [&](int v) {
+        Meta m;
+        m.e0[0] = __builtin_amdgcn_readlane(v, 0);
+        m.e1[0] = m.e0[1] = __builtin_amdgcn_readlane(v, 1);
+        m.e1[1] = __builtin_amdgcn_readlane(v, 2);
+        return m;
+    };
+    // sources and codes of the first NE edges of both rows: lanes 0..NE-1 row A, lanes 8..8+NE-1 row B (an empty row reads row pointers)
+    auto load_edges = [&](const Meta &m, int &srcs, unsigned &cods) {
+        const int rsel = (lane >> 3) & 1, j = lane & 7;
+        const int e0 = rsel ? m.e0[1] : m.e0[0], e1 = rsel ? m.e1[1] : m.e1[0];
+        const bool any = e0 < e1;
+        const int idx = any ? min(e0 + min(j, NE - 1), e1 - 1) : 0;
+        srcs = (any ? ag.col : ag.rowptr)[idx];
+        cods = (any ? ag.codes : reinterpret_cast<const unsigned *>(ag.rowptr))[idx];
+    };
+
+    // ---- one row's gathered pieces ----
+    struct Raw {
+        float4 v[NE + 1], rr[NORMED ? NE + 1 : 1];               // edges 0..NE-1, then the row itself
+    };
+    auto load_row = [&](int r, float4 &v, float4 &rr) {
+        v = Y4[(size_t)r * H4];
+        if constexpr (NORMED) rr = S4[(size_t)r * H4];
+    };
+    auto issue_raw = [&](Raw &w, int d, int e0, int e1, int srcs, int which) {
+        const int deg = e1 - e0;
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+            w.v[j] = zf4;
+            if constexpr (NORMED) w.rr[j] = zf4;
+            if (deg > j) load_row(__builtin_amdgcn_readlane(srcs, 8 * which + j), w.v[j], w.rr[NORMED ? j : 0]);
+        }
+        w.v[NE] = zf4;
+        if constexpr (NORMED) w.rr[NE] = zf4;
+        if ((NORMED || ag.add_self) && d < M) load_row(d, w.v[NE], w.rr[NORMED ? NE : 0]);
+    };
+    const float4 *tb = reinterpret_cast<const float4 *>(agw_dyn) + c4;   // this lane's chunk of every table row
+    auto xval = [&](const float4 v, const float4 rr, int r) {
+        if constexpr (!NORMED) {
+            return v;
+        } else {
+            // (scale / shift of this lane's four columns are re-read from LDS at every use: 8 registers the K = 256 geometry lacks)
+            const float4 sc4 = *reinterpret_cast<const float4 *>(s_scale + 4 * c4), sh4 = *reinterpret_cast<const float4 *>(s_shift + 4 * c4);
+            float4 o;
+            if constexpr (RELU) {
+                o.x = fmaxf(fmaf(v.x, sc4.x, sh4.x), 0.f); o.y = fmaxf(fmaf(v.y, sc4.y, sh4.y), 0.f);
+                o.z = fmaxf(fmaf(v.z, sc4.z, sh4.z), 0.f); o.w = fmaxf(fmaf(v.w, sc4.w, sh4.w), 0.f);
+            } else {
+                o.x = act_fwd_rt(ag.norm_act, fmaf(v.x, sc4.x, sh4.x)); o.y = act_fwd_rt(ag.norm_act, fmaf(v.y, sc4.y, sh4.y));
+                o.z = act_fwd_rt(ag.norm_act, fmaf(v.z, sc4.z, sh4.z)); o.w = act_fwd_rt(ag.norm_act, fmaf(v.w, sc4.w, sh4.w));
+            }
+            o.x = has_skip ? o.x + rr.x : o.x; o.y = has_skip ? o.y + rr.y : o.y;
+            o.z = has_skip ? o.z + rr.z : o.z; o.w = has_skip ? o.w + rr.w : o.w;
+            if (r >= count) o = zf4;
+            return o;
+        }
+    };
+    auto message = [&](const float4 v0, const float4 rr, int s, unsigned code) {
+        float4 v = xval(v0, rr, s);
+#pragma unroll
+        for (int f = 0; f < HS_AG_MAX_F; ++f) {
+            if (f < F) {
+                const float4 t = tb[((code >> (8 * f)) & 255u) * H4];
+                v.x += t.x; v.y += t.y; v.z += t.z; v.w += t.w;
+            }
+        }
+        return v;
+    };
+    // add one row up from its pieces -> the image line of row `rs` (0..15) of buffer `buf`; returns s and x of the row for the stores
+    auto finish = [&](const Raw &w, int d, int e0, int e1, int srcs, unsigned cods, int which, int buf, int rs, float4 &tot, float4 &selfv) {
+        const bool valid = d < M;
+        const int deg = e1 - e0;
+        selfv = xval(w.v[NE], w.rr[NORMED ? NE : 0], valid ? d : 0);
+        float4 acc0 = zf4, acc1 = zf4;
+#pragma unroll
+        for (int j = 0; j < NE; ++j) {
+            if (deg > j) {
+                const float4 m = message(w.v[j], w.rr[NORMED ? j : 0], __builtin_amdgcn_readlane(srcs, 8 * which + j),
+                                         (unsigned)__builtin_amdgcn_readlane((int)cods, 8 * which + j));
+                if (j == 1) { acc1.x += m.x; acc1.y += m.y; acc1.z += m.z; acc1.w += m.w; }
+                else { acc0.x += m.x; acc0.y += m.y; acc0.z += m.z; acc0.w += m.w; }
+            }
+        }
+        for (int e = e0 + NE; e < e1; ++e) {                      // (past the window: one round trip each; rare on molecule graphs)
+            const int t0 = ag.col[e];
+            const unsigned c0 = ag.codes[e];
+            float4 v, rr = zf4;
+            load_row(t0, v, rr);
+            const float4 m = message(v, rr, t0, c0);
+            acc0.x += m.x; acc0.y += m.y; acc0.z += m.z; acc0.w += m.w;
+        }
+        tot = make_float4(acc0.x + acc1.x, acc0.y + acc1.y, acc0.z + acc1.z, acc0.w + acc1.w);
+        if (ag.add_self) { tot.x += selfv.x; tot.y += selfv.y; tot.z += selfv.z; tot.w += selfv.w; }
+        if (!valid || !live) tot = zf4;
+        image[buf][rs * ISTRIDE + lane] = f32x4_t{tot.x, tot.y, tot.z, tot.w};
+    };
+    auto store_row = [&](int d, const float4 tot, const float4 selfv) {
+        if (d < M && live) {
+            reinterpret_cast<float4 *>(ag.s_out)[(size_t)d * H4 + c4] = tot;
+            if constexpr (NORMED) reinterpret_cast<float4 *>(ag.x_out)[(size_t)d * H4 + c4] = selfv;
+        }
+    };
+
+    // ================= prologue =================
+    // the dependent chain of the first steps goes out first; everything else of the prologue travels behind it
+    int pv0 = load_ptrs(0), pv1 = load_ptrs(1), pv2 = load_ptrs(2), pv3 = load_ptrs(3);
+    // pending norm: (column, replica pair) per thread; the four replicas' parts meet in replica order ((p0 + p1) + p2) + p3 — the
+    // order of bn_apply_acc_kernel / aggregate_norm_direct_fwd_kernel: the same bits
+    const int ncol = tid >> 1, nhalf = tid & 1;
+    const bool ncol_ok = NORMED && ncol < KR;
+    const int ncomp = NORMED ? min(ncol, KR - 1) / ag.p.k : 0, nkk = NORMED ? min(ncol, KR - 1) - ncomp * ag.p.k : 0;
+    const bool owner = blockIdx.x == 0;
+    unsigned long long araw[2][4] = {{0, 0, 0, 0}, {0, 0, 0, 0}};    // [replica of this half][sum hi | sum lo | squares hi | squares lo]
+    float nw = 1.f, nb = 0.f, rm_old = 0.f, rv_old = 1.f;
+    Meta m0 = ptrs_of(pv0), m1 = ptrs_of(pv1), m2 = ptrs_of(pv2);
+    int srcs0, srcs1, srcs2;
+    unsigned cods0, cods1, cods2;
+    load_edges(m0, srcs0, cods0);
+    load_edges(m1, srcs1, cods1);
+    load_edges(m2, srcs2, cods2);
+    if constexpr (NORMED) {
+        if (ncol_ok) {
+#pragma unroll
+            for (int r2 = 0; r2 < 2; ++r2) {
+                const unsigned long long *ap = ag.acc + (size_t)((2 * nhalf + r2) * 2) * 2 * KR + ncol;   // (layout of stat_acc_part)
+                araw[r2][0] = ap[0]; araw[r2][1] = ap[KR]; araw[r2][2] = ap[2 * KR]; araw[r2][3] = ap[3 * KR];
+            }
+            if (nhalf == 0) {
+                if (ag.p.has_weight) nw = *bn_col_ptr(ag.p.weight, ag.p.flat, ncomp, nkk, ncol);
+                if (ag.p.has_bias) nb = *bn_col_ptr(ag.p.bias, ag.p.flat, ncomp, nkk, ncol);
+                if (ag.p.has_running && owner) {
+                    rm_old = *bn_col_ptr(ag.p.running_mean, ag.p.flat, ncomp, nkk, ncol);
+                    rv_old = *bn_col_ptr(ag.p.running_var, ag.p.flat, ncomp, nkk, ncol);
+                }
+            }
+        }
+    }
+    // bond tables -> LDS (R x H4 float4)
+    int tblR = ag.off[1];
+#pragma unroll
+    for (int t = 2; t <= HS_AG_MAX_F; ++t) tblR = t <= F ? ag.off[t] : tblR;
+    for (int e = tid; e < tblR * H4; e += HS_AGW_THREADS) {
+        const int r = e / H4, q4 = e - r * H4;
+        const int comp = (q4 * 4) / ag.k, kk = q4 * 4 - comp * ag.k;
+        int f = 0, fo = 0;
+#pragma unroll
+        for (int t = 1; t < HS_AG_MAX_F; ++t) {
+            const bool past = t < F && r >= ag.off[t];
+            f = past ? t : f;
+            fo = past ? ag.off[t] : fo;
+        }
+        reinterpret_cast<float4 *>(agw_dyn)[e] = *reinterpret_cast<const float4 *>(ag.tables[comp * F + f] + (size_t)(r - fo) * ag.k + kk);
+    }
+    if constexpr (NORMED) {
+        double pS[2], pQ[2];
+#pragma unroll
+        for (int r2 = 0; r2 < 2; ++r2) {
+            pS[r2] = (double)(long long)araw[r2][0] * (1.0 / 4096.0) + (double)(long long)araw[r2][1] * (1.0 / 4611686018427387904.0);
+            pQ[r2] = (double)(long long)araw[r2][2] * (1.0 / 4096.0) + (double)(long long)araw[r2][3] * (1.0 / 4611686018427387904.0);
+        }
+        // even lane: replicas 0, 1; odd lane: replicas 2, 3 -> ((p0 + p1) + p2) + p3 on the even lane
+        const double oS0 = __shfl(pS[0], lane | 1, 64), oS1 = __shfl(pS[1], lane | 1, 64);
+        const double oQ0 = __shfl(pQ[0], lane | 1, 64), oQ1 = __shfl(pQ[1], lane | 1, 64);
+        if (nhalf == 0 && ncol_ok) {
+            const double S = ((pS[0] + pS[1]) + oS0) + oS1, Q = ((pQ[0] + pQ[1]) + oQ0) + oQ1;
+            const BnFromTotals bt = bn_from_totals(S, Q, count, nw, nb, ag.eps);
+            s_scale[ncol] = bt.scale;
+            s_shift[ncol] = bt.shift;
+            if (owner) {
+                float *stat = ag.stat;
+                stat[ncol] = bt.mean;
+                stat[KR + ncol] = bt.invstd;
+                stat[2 * KR + ncol] = bt.scale;
+                stat[3 * KR + ncol] = bt.shift;
+                stat[4 * KR + ncol] = nw;
+                stat[5 * KR + ncol] = nb;
+                if (ag.p.has_running) {
+                    *bn_col_ptr(ag.p.running_mean, ag.p.flat, ncomp, nkk, ncol) = bn_running_update(rm_old, ag.momentum, bt.mean);
+                    *bn_col_ptr(ag.p.running_var, ag.p.flat, ncomp, nkk, ncol) = bn_running_update(rv_old, ag.momentum, bt.unbiased);
+                }
+            }
+        }
+        if (owner && ag.p.has_nbt && tid < ag.p.n_comp)
+            for (int q = 0; q < ag.p.n_comp; ++q)
+                if (q == tid) *ag.p.num_batches_tracked[q] += 1;
+    }
+    // rows of (A, 0) go in flight in front of the operand slice: the slice's 256 KB per workgroup arrive under the first finish
+    Raw raw;
+    int dA = rowA_of(0), dB = dA + 1;
+    issue_raw(raw, dA, m0.e0[0], m0.e1[0], srcs0, 0);
+    // ---- bias and operand slice -> registers (gemm_hs16_kernel's layout and order) ----
+    const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
+    if (tid < K) s_bias[tid] = (a.bias && tid < Nout) ? a.bias[tid] : 0.f;
+    f32x4_t hreg[TPW][G];
+    {
+        const f32x4_t *src = reinterpret_cast<const f32x4_t *>(a.hk4);
+#pragma unroll
+        for (int g = 0; g < G; ++g)
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                const bool ok = 4 * (4 * g + kq) < KR && col0 + c + 16 * t < Nout;
+                const f32x4_t v = src[ok ? (size_t)(4 * g + kq) * Nout + col0 + c + 16 * t : 0];
+                hreg[t][g] = ok ? v : zero4;
+            }
+    }
+    lds_barrier();                                                // tables (and scale / shift) are in LDS
+    float4 totA, selfA, totB, selfB;
+    finish(raw, dA, m0.e0[0], m0.e1[0], srcs0, cods0, 0, 0, 2 * wave, totA, selfA);
+    store_row(dA, totA, selfA);
+    issue_raw(raw, dB, m0.e0[1], m0.e1[1], srcs0, 1);
+    finish(raw, dB, m0.e0[1], m0.e1[1], srcs0, cods0, 1, 0, 2 * wave + 1, totB, selfB);
+    store_row(dB, totB, selfB);
+    // pipeline state at the top of iteration i: rows of (A, i + 1) in flight; (mn, srcs_n, cods_n) = step i + 1, arrived;
+    // (m2, srcs2, cods2) = step i + 2, sources / codes in flight; pv3 = row pointers of step i + 3 in flight
+    Meta mn = m1;
+    int srcs_n = srcs1;
+    unsigned cods_n = cods1;
+    if (my_steps > 1) issue_raw(raw, rowA_of(1), mn.e0[0], mn.e1[0], srcs_n, 0);
+
+    const int fbase = c * ISTRIDE + kq;                           // fragment base of this lane: row c, chunk 4 g + kq of k-group g
+    f32x4_t st_p[TPW], st_s1[TPW], st_s2[TPW];
+    float st_n = 0.f;
+#pragma unroll
+    for (int t = 0; t < TPW; ++t) st_p[t] = st_s1[t] = st_s2[t] = zero4;
+
+    // ================= steps =================
+    for (int i = 0; i < my_steps; ++i) {
+        const int step = group + i * a.groups;
+        const int buf = i & 1;
+        const bool more = i + 1 < my_steps;
+        lds_barrier();                                            // image[buf] complete; image[buf ^ 1] free (read by step i - 1)
+        const f32x4_t *sl = image[buf];
+        f32x4_t acc[TPW];
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) acc[t] = *reinterpret_cast<const f32x4_t *>(s_bias + col0 + 16 * t + 4 * kq);
+        f32x4_t fr[2];
+        fr[0] = sl[fbase];
+        auto mfma_range = [&](int g0, int g1) {
+#pragma unroll
+            for (int g = g0; g < g1; ++g) {
+                if (g + 1 < G) fr[(g + 1) & 1] = sl[fbase + 4 * (g + 1)];
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int q = 0; q < 4; ++q)
+#pragma unroll
+                    for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(hreg[t][g][q], fr[g & 1][q], acc[t], 0, 0, 0);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        mfma_range(0, GH);
+        const int nA = rowA_of(min(i + 1, my_steps - 1)), nB = nA + 1;
+        if (more) {
+            finish(raw, nA, mn.e0[0], mn.e1[0], srcs_n, cods_n, 0, buf ^ 1, 2 * wave, totA, selfA);
+            // (row A's stores go out here: they are OLDER than the loads of row B issued next, so whoever waits for those has
+            // given them half a phase — and s / x of row A need no registers across the second half)
+            store_row(nA, totA, selfA);
+            issue_raw(raw, nB, mn.e0[1], mn.e1[1], srcs_n, 1);
+        }
+        mfma_range(GH, G);
+        if (more) {
+            finish(raw, nB, mn.e0[1], mn.e1[1], srcs_n, cods_n, 1, buf ^ 1, 2 * wave + 1, totB, selfB);
+            // rotate: step i + 2's sources / codes (issued an iteration ago) become "next"; step i + 3's row pointers (ditto) are
+            // decoded and its sources / codes go out; step i + 4's row pointers go out
+            mn = m2; srcs_n = srcs2; cods_n = cods2;
+            m2 = ptrs_of(pv3);
+            load_edges(m2, srcs2, cods2);
+            pv3 = load_ptrs(i + 4);
+        }
+        // ---- epilogue of step i: lane (c, kq) holds z[row][col0 + 16 t + 4 kq .. +3] ----
+        const int row = step * 16 + c;
+        if (row < count) {
+            if (st_n == 0.f) {
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) st_p[t] = acc[t];
+            } else {
+#pragma unroll
+                for (int t = 0; t < TPW; ++t) {
+                    const f32x4_t dlt = acc[t] - st_p[t];
+                    st_s1[t] += dlt;
+                    st_s2[t] += dlt * dlt;
+                }
+            }
+            st_n += 1.f;
+        }
+        if (row < M) {
+            float *yr = a.y + (size_t)row * Nout + col0 + 4 * kq;
+#pragma unroll
+            for (int t = 0; t < TPW; ++t)
+                if (col0 + 4 * kq + 16 * t < Nout) *reinterpret_cast<f32x4_t *>(yr + 16 * t) = acc[t];
+        }
+        if (more) {
+            store_row(nB, totB, selfB);
+            // rows of (A, i + 2): behind the stores in program order, consumed half a phase into the next step
+            if (i + 2 < my_steps) issue_raw(raw, rowA_of(i + 2), mn.e0[0], mn.e1[0], srcs_n, 0);
+        }
+    }
+    // ---- statistics of the output columns (gemm_hs16_kernel's HS_ST finale) ----
+    {
+        double S[TPW][4], Q[TPW][4];
+#pragma unroll
+        for (int t = 0; t < TPW; ++t)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const double n = (double)st_n, p = (double)st_p[t][q], s1 = (double)st_s1[t][q], s2 = (double)st_s2[t][q];
+                S[t][q] = hs_sum16(n * p + s1);
+                Q[t][q] = hs_sum16(n * p * p + 2.0 * p * s1 + s2);
+            }
+        hs_publish<TPW>(a.stat_acc, Nout, (int)(group % STAT_ACC_REP), col0, kq, c, S, Q);
+    }
+}
+
+}  // namespace phc

@@ -2349,9 +2349,18 @@ int phc_gemm_prebuilt_bwsums(const float *dy, const float *M, const float *Mk4, 
 
 // The norm backward's element-wise pass folded into the dx GEMM behind it (HS_BA), optionally with the sums epilogue of the
 // norm in front of that GEMM (HS_BW): see include/phc_hip.h.
+namespace phc {
+bool gemm_agw_shape_ok(int h, int Nout);                                                        // gemm_agw.hip: 256, 180, 200 (square)
+int launch_gemm_agw(const GemmHsArgs &a, const HsAgArgs &ag, bool normed, hipStream_t s);
+}
+static inline bool agw_enabled() {
+    static const bool off = getenv("PHC_GEMM_AGGREGATE_WIDE") && atoi(getenv("PHC_GEMM_AGGREGATE_WIDE")) == 0;
+    return !off;
+}
 int phc_gemm_aggregate_supported(int64_t N, int h, int Nout, int F, int vocab_rows) {
     static const bool off = getenv("PHC_GEMM_AGGREGATE") && atoi(getenv("PHC_GEMM_AGGREGATE")) == 0;
-    return (!off && hs_enabled() && N >= 1 && N <= (1 << 20) && h == 128 && Nout == 128 && F >= 1 && F <= HS_AG_MAX_F && vocab_rows >= 1 &&
+    const bool shape = (h == 128 && Nout == 128) || (agw_enabled() && gemm_agw_shape_ok(h, Nout) && hs_widths_ok(h, Nout));
+    return (!off && hs_enabled() && N >= 1 && N <= (1 << 20) && shape && F >= 1 && F <= HS_AG_MAX_F && vocab_rows >= 1 &&
             vocab_rows <= HS_AG_MAX_ROWS) ? 1 : 0;
 }
 
@@ -2396,14 +2405,25 @@ int phc_gemm_aggregate_stats(const phc_gemm_ag_desc *d, void *stream) {
     a.stat_acc = reinterpret_cast<unsigned long long *>(d->stat_acc);
     a.panels = 1;
     a.stamps = g_hs_stamps;
+    hipStream_t s = (hipStream_t)stream;
+    const long long steps = (d->N + 15) / 16;
+    if (h != 128) {
+        // the wide layers (gemm_hs_agw_device.h): one workgroup per CU, as launch_hs_cfg<K, 2, 8> counts them
+        static const int wide_per_cu_env = getenv("PHC_HS_GROUPS_PER_CU") ? atoi(getenv("PHC_HS_GROUPS_PER_CU")) : 0;
+        long long groups = (long long)(wide_per_cu_env > 0 ? wide_per_cu_env : 1) * num_cu();
+        if (groups > steps) groups = steps;
+        a.groups = (int)groups;
+        ProfScope prof(K_PHM_GEMM_AG, s);
+        int rc = launch_gemm_agw(a, ag, normed, s);
+        if (rc) return rc;
+        return check_launch("phc_gemm_aggregate_stats");
+    }
     // workgroups: as many as the statistics-epilogue GEMM on the same rows takes (two per CU) — a workgroup's steps, and with them
     // the partial sums it adds to the accumulator, are then the same sets of rows: the totals are bit-identical to that launch's
     static const int per_cu_env = getenv("PHC_HS_AG_GROUPS_PER_CU") ? atoi(getenv("PHC_HS_AG_GROUPS_PER_CU")) : 0;
-    const long long steps = (d->N + 15) / 16;
     long long groups = (long long)(per_cu_env > 0 ? per_cu_env : 2) * num_cu();
     if (groups > steps) groups = steps;
     a.groups = (int)groups;
-    hipStream_t s = (hipStream_t)stream;
     const size_t tbl_bytes = (size_t)(128 + ag.off[d->F]) * 128 * sizeof(float);     // the operand (k4 form) + the bond tables in LDS
     ProfScope prof(K_PHM_GEMM_AG, s);
 #define PHC_AG_LAUNCH1(FC, NC, RC, LC)                                                                                             \

@@ -2319,9 +2319,21 @@ class _AggregateEncFn(torch.autograd.Function):
         dev = L.require_device(x, bond_idx)
         # `pending`: x = act(norm(y)) (+ skip) has not been evaluated yet (PendingNorm): this launch does it on the fly for every row
         # it gathers and writes x itself once — or, outside the fused kernel's range, the stand-alone pass runs right here
+        # `lazy_box` (a dict): the caller feeds this aggregate straight into the fused MLP + norm node — when the shapes allow it
+        # nothing is launched here: the node's first GEMM builds the rows itself (phc_gemm_aggregate_stats) and writes `out` on the
+        # way; anybody else who reads `out` first calls PendingAggregate.materialize (the launch that would have run here).
+        # Hidden 128: up to NORM_INTO_AGGREGATE_MAX_WORK row elements; the wide layers (256, 180, 200: gemm_hs_agw_device.h, where the
+        # gather hides under the MFMAs of the step in front) at any size the entry point takes.
+        hx = x.shape[1]
+        wide = hx != 128
+        lazy_shape = lazy_box is not None and GEMM_AGGREGATE and act == 0 and st.num_edges > 0 and x.is_contiguous() and \
+            x.dtype == torch.float32 and x.shape[0] == st.num_src == st.num_dst and x.data_ptr() % 16 == 0 and ts.k % 4 == 0 and \
+            (wide or x.shape[0] * hx <= NORM_INTO_AGGREGATE_MAX_WORK) and \
+            bool(lib.phc_gemm_aggregate_supported(st.num_dst, hx, hx, ts.F, ts.R))
         fuse_norm = pending is not None and not pending.done and act == 0 and ts.F <= 4 and ts.R <= 256 and x.is_contiguous() and \
-            x.shape[0] == st.num_src == st.num_dst and x.shape[0] * x.shape[1] <= NORM_INTO_AGGREGATE_MAX_WORK and \
-            bool(lib.phc_aggregate_norm_supported(st.num_dst, x.shape[1], ts.F, ts.R))
+            x.shape[0] == st.num_src == st.num_dst and \
+            (x.shape[0] * hx <= NORM_INTO_AGGREGATE_MAX_WORK or (wide and lazy_shape and GEMM_AGGREGATE_WIDE_NORM)) and \
+            bool(lib.phc_aggregate_norm_supported(st.num_dst, hx, ts.F, ts.R))
         if pending is not None and not pending.done and not fuse_norm:
             pending.materialize()
         x_ = L.f32c(x)
@@ -2336,13 +2348,7 @@ class _AggregateEncFn(torch.autograd.Function):
         rowptr, col, perm = st.csr
         out = torch.empty((st.num_dst, h), dtype=torch.float32, device=dev)
         ctx.codes = None
-        # `lazy_box` (a dict): the caller feeds this aggregate straight into the fused MLP + norm node — when the shapes allow it
-        # nothing is launched here: the node's first GEMM builds the rows itself (phc_gemm_aggregate_stats) and writes `out` on the
-        # way; anybody else who reads `out` first calls PendingAggregate.materialize (the launch that would have run here)
-        lazy = lazy_box is not None and GEMM_AGGREGATE and act == 0 and st.num_edges > 0 and x_.is_contiguous() and \
-            x_.shape[0] == st.num_src == st.num_dst and \
-            x_.shape[0] * h <= NORM_INTO_AGGREGATE_MAX_WORK and x_.data_ptr() % 16 == 0 and ts.k % 4 == 0 and \
-            (pending is None or pending.done or fuse_norm) and bool(lib.phc_gemm_aggregate_supported(st.num_dst, h, h, ts.F, ts.R))
+        lazy = lazy_shape and x_.data_ptr() == x.data_ptr() and (pending is None or pending.done or fuse_norm)
         if lazy:
             codes = st.packed_codes(bond_, ts.vocab_c, ts.F)
             ctx.codes = codes
@@ -2806,6 +2812,9 @@ NORM_INTO_AGGREGATE_MAX_WORK = int(__import__("os").environ.get("PHC_NORM_INTO_A
 
 
 GEMM_AGGREGATE = __import__("os").environ.get("PHC_GEMM_AGGREGATE", "1") != "0"
+# the wide layers' fused launch also applies a pending norm to every row it gathers (two loads per gathered row: y and the skip);
+# off: the norm's element-wise pass stays a launch of its own there and only the plain aggregation rides in the GEMM
+GEMM_AGGREGATE_WIDE_NORM = __import__("os").environ.get("PHC_GEMM_AGGREGATE_WIDE_NORM", "1") != "0"
 
 
 class PendingAggregate:

@@ -109,32 +109,28 @@ def _random_graph(N, E, hubs, seed):
     return torch.stack([src, dst])
 
 
-@pytest.mark.parametrize("N,E,hubs", [(1000, 2100, False), (12874, 27650, False), (333, 1500, True), (16, 40, False), (25000, 52000, True)])
-@pytest.mark.parametrize("F,normed,act,with_skip,add_self", [(3, False, "relu", False, True), (3, True, "relu", True, True),
-                                                             (1, True, "swish", False, True), (2, True, "relu", True, False),
-                                                             (4, False, "relu", False, False)])
-def test_aggregation_inside_the_first_gemm_equals_the_separate_launches(N, E, hubs, F, normed, act, with_skip, add_self):
-    """s, x, save_stat, running statistics, y and the statistics accumulator of ONE phc_gemm_aggregate_stats launch against
-    phc_aggregate_encp_fwd / phc_aggregate_norm_encp_fwd followed by phc_gemm_prebuilt_stats: bit for bit (same walk, same MFMA
-    order, same partial sums per workgroup)."""
+WIDTHS = [(4, 32), (8, 32), (4, 64), (4, 45), (5, 40)]                  # h = 128 | 256 (configs[2] PHM-8, configs[3] PHM-4) | 180, 200 (published)
+
+
+def _gemm_aggregate_case(N, E, hubs, F, normed, act, with_skip, add_self, n, k, valid, tags=("separate", "fused")):
+    """One phc_gemm_aggregate_stats launch and / or the launches it replaces on the same inputs; returns (results by tag, inputs)."""
     import ctypes as C
     from phc_gnn_amd import lib as L, ops
     from phc_gnn_amd.graph import edge_structure
     lib = L.load()
-    n, k, h = 4, 32, 128
+    h = n * k
     vocab = [5, 6, 2, 3][:F]
     if not lib.phc_gemm_aggregate_supported(N, h, h, F, sum(vocab)):
         pytest.skip("outside the fused form")
-    g = torch.Generator().manual_seed(N + F)
+    g = torch.Generator().manual_seed(N + F + h)
     ei = _random_graph(N, E, hubs, seed=N).to(DEV)
     bond = torch.stack([torch.randint(0, v, (E,), generator=g) for v in vocab], 1).to(DEV)
     tables = [[torch.randn(v, k, generator=g).to(DEV) for v in vocab] for _ in range(n)]
-    ts = ops.TableSet(tables).vector_form(tables)
+    ts = ops.TableSet(tables).vector_form(tables)                         # (k % 4 != 0: one flat image, n = 1, k = h)
     st = edge_structure(ei, N, N)
     st.prepare(for_backward=False, codes_for=(bond, ts.vocab_c, ts.F))
     rowptr, col, _ = st.csr
     codes = st.packed_codes(bond, ts.vocab_c, ts.F)
-    valid = N - 7 if N > 16 else N
     nv = torch.tensor([valid], dtype=torch.int32, device=DEV)
     sp = L.stream_ptr(torch.device(DEV))
     M = (torch.randn(h, h, generator=g) / h ** 0.5).to(DEV)
@@ -151,7 +147,7 @@ def test_aggregation_inside_the_first_gemm_equals_the_separate_launches(N, E, hu
         L.check(lib.phc_gemm_prebuilt_stats(L.ptr(torch.randn(N, h, generator=g).to(DEV)), L.ptr(M), None, None, N, h, h, L.ptr(y_in), L.ptr(nv),
                                             L.ptr(norm_acc), None, None, sp), "producer")
     res = {}
-    for tag in ("separate", "fused"):
+    for tag in tags:
         rm = [torch.zeros(k, device=DEV) for _ in range(n)]
         rv = [torch.ones(k, device=DEV) for _ in range(n)]
         nbt = [torch.zeros((), dtype=torch.int64, device=DEV) for _ in range(n)]
@@ -164,17 +160,17 @@ def test_aggregation_inside_the_first_gemm_equals_the_separate_launches(N, E, hu
             if normed:
                 L.check(lib.phc_aggregate_norm_encp_fwd(L.ptr(y_in), L.ptr(norm_acc), arr(w), arr(bb), arr(rm), arr(rv), arr(nbt), n, 0.1, 1e-5,
                                                         L.ACT_IDS[act], L.ptr(nv), L.ptr(skip), L.ptr(save), L.ptr(x_out), L.ptr(codes),
-                                                        L.ptr(ts.ptrs), ts.vocab_c, L.ptr(rowptr), L.ptr(col), N, F, n, k, int(add_self),
+                                                        L.ptr(ts.ptrs), ts.vocab_c, L.ptr(rowptr), L.ptr(col), N, F, ts.n, ts.k, int(add_self),
                                                         L.ptr(s_out), sp), "aggregate_norm")
             else:
-                L.check(lib.phc_aggregate_encp_fwd(L.ptr(y_in), L.ptr(codes), L.ptr(ts.ptrs), ts.vocab_c, L.ptr(rowptr), L.ptr(col), N, F, n, k, 0,
+                L.check(lib.phc_aggregate_encp_fwd(L.ptr(y_in), L.ptr(codes), L.ptr(ts.ptrs), ts.vocab_c, L.ptr(rowptr), L.ptr(col), N, F, ts.n, ts.k, 0,
                                                    int(add_self), L.ptr(s_out), sp), "aggregate")
             L.check(lib.phc_gemm_prebuilt_stats(L.ptr(s_out), L.ptr(M), L.ptr(M4), L.ptr(b), N, h, h, L.ptr(y), L.ptr(nv), L.ptr(acc), None, None,
                                                 sp), "gemm stats")
         else:
             d = L.GemmAgDesc()
             d.x, d.codes, d.tables, d.vocab = L.ptr(y_in), L.ptr(codes), L.ptr(ts.ptrs), C.cast(ts.vocab_c, C.c_void_p)
-            d.rowptr, d.col, d.N, d.F, d.n, d.k, d.add_self, d.s_out = L.ptr(rowptr), L.ptr(col), N, F, n, k, int(add_self), L.ptr(s_out)
+            d.rowptr, d.col, d.N, d.F, d.n, d.k, d.add_self, d.s_out = L.ptr(rowptr), L.ptr(col), N, F, ts.n, ts.k, int(add_self), L.ptr(s_out)
             keep = (arr(w), arr(bb), arr(rm), arr(rv), arr(nbt))
             if normed:
                 d.norm_acc = L.ptr(norm_acc)
@@ -185,20 +181,93 @@ def test_aggregation_inside_the_first_gemm_equals_the_separate_launches(N, E, hu
             L.check(lib.phc_gemm_aggregate_stats(C.byref(d), sp), "phc_gemm_aggregate_stats")
         torch.cuda.synchronize()
         res[tag] = dict(s=s_out, y=y, acc=acc, x=x_out, save=save, rm=torch.cat(rm), rv=torch.cat(rv), nbt=torch.stack(nbt))
+    return res, dict(ei=ei, bond=bond, tables=tables, M=M, b=b, y_in=y_in, skip=skip, w=w, bb=bb, h=h)
+
+
+@pytest.mark.parametrize("n,k", WIDTHS)
+@pytest.mark.parametrize("N,E,hubs", [(1000, 2100, False), (12874, 27650, False), (333, 1500, True), (16, 40, False), (25000, 52000, True)])
+@pytest.mark.parametrize("F,normed,act,with_skip,add_self", [(3, False, "relu", False, True), (3, True, "relu", True, True),
+                                                             (1, True, "swish", False, True), (2, True, "relu", True, False),
+                                                             (4, False, "relu", False, False)])
+def test_aggregation_inside_the_first_gemm_equals_the_separate_launches(N, E, hubs, F, normed, act, with_skip, add_self, n, k):
+    """s, x, save_stat, running statistics, y and the statistics accumulator of ONE phc_gemm_aggregate_stats launch against
+    phc_aggregate_encp_fwd / phc_aggregate_norm_encp_fwd followed by phc_gemm_prebuilt_stats: bit for bit (same walk, same MFMA
+    order, same partial sums per workgroup) — hidden 128 (gemm_hs_ag_device.h) and the wide layers 256 / 180 / 200
+    (gemm_hs_agw_device.h; round 5)."""
+    res, _ = _gemm_aggregate_case(N, E, hubs, F, normed, act, with_skip, add_self, n, k, valid=N - 7 if N > 16 else N)
     for key in res["fused"]:
         a_, b_ = res["fused"][key], res["separate"][key]
         assert torch.equal(a_, b_), (key, float((a_.double() - b_.double()).abs().max()))
 
 
-@pytest.mark.parametrize("workload", ["molhiv_b32", "molhiv_b32_swish", "molhiv_b512", "zinc_small_last_128"])
+@pytest.mark.parametrize("n,k", WIDTHS)
+@pytest.mark.parametrize("N,E,hubs", [(2000, 4300, False), (333, 1500, True)])
+@pytest.mark.parametrize("F,normed,act,with_skip,add_self", [(3, False, "relu", False, True), (3, True, "relu", True, True),
+                                                             (1, True, "swish", False, False)])
+def test_aggregation_inside_the_first_gemm_against_the_oracle(N, E, hubs, F, normed, act, with_skip, add_self, n, k):
+    """The fused launch DIRECTLY against the oracle (not only against the launches it replaces):
+    x = act(norm(y)) + skip (norm.py:30-35, models.py:208-215), edge embedding = sum of the integer encoder's table rows
+    (encoder.py), s = propagate_add(x, edge_index, e) (+ x) (messagepassing.py:132-146), z = s . H + b (layers.py:198-219), and the
+    batch statistics of z that the launch leaves in its accumulator — float64 on the host, 1e-5 of each tensor's largest entry."""
+    from oracle import phc_oracle as O
+    from phc_gnn_amd import lib as L, ops
+    res, inp = _gemm_aggregate_case(N, E, hubs, F, normed, act, with_skip, add_self, n, k, valid=N, tags=("fused",))
+    r = res["fused"]
+    h = inp["h"]
+    y_in, ei = inp["y_in"].double().cpu(), inp["ei"].cpu()
+    x = y_in
+    if normed:
+        w, bb = [t.double().cpu() for t in inp["w"]], [t.double().cpu() for t in inp["bb"]]
+        rm, rv = [torch.zeros(k, dtype=torch.float64) for _ in range(n)], [torch.ones(k, dtype=torch.float64) for _ in range(n)]
+        x = O.activation(act, O.batch_norm_naive(y_in, n, w, bb, rm, rv, True, 0.1, 1e-5))
+        if with_skip:
+            x = x + inp["skip"].double().cpu()
+        assert_rel(r["x"], x, 1e-5, "x")
+        assert_rel(r["rm"], torch.cat(rm), 1e-5, "running_mean")
+        assert_rel(r["rv"], torch.cat(rv), 1e-5, "running_var")
+    bond = inp["bond"].cpu()
+    ea = torch.cat([sum(inp["tables"][c][f].double().cpu()[bond[:, f]] for f in range(F)) for c in range(n)], 1)    # component-major [E, h]
+    s = O.propagate_add(x, ei, ea, "identity")
+    if add_self:
+        s = s + x
+    assert_rel(r["s"], s, 1e-5, "s")
+    z = s @ inp["M"].double().cpu() + inp["b"].double().cpu()
+    assert_rel(r["y"], z, 1e-5, "z")
+    mom = ops.stat_acc_read(r["acc"], h, N).double().cpu()                 # (sum | M2) of z as the next norm reads them
+    assert_rel(mom[:h], z.sum(0), 1e-5, "column sums of z")
+    assert_rel(mom[h:], ((z - z.mean(0)) ** 2).sum(0), 1e-4, "column M2 of z")
+
+
+def assert_rel(got, ref, tol, what):
+    got, ref = got.double().cpu(), ref.double().cpu()
+    err = float((got - ref).abs().max()) / max(float(ref.abs().max()), 1e-30)
+    assert err <= tol, (what, err)
+
+
+_AG_EXTRA = {
+    "zinc_small_last_128": dict(dataset="zinc", batch_size=48, phm_dim=4, hidden=128, layers=3, d_units=[64, 32], target_dim=1,
+                                sc_type="last", regression=True),
+    # the wide layers (gemm_hs_agw_device.h): configs[2]'s and configs[3]'s geometry, the published 180 / 200 widths (k = 45 / 40)
+    "zinc_small_last_256": dict(dataset="zinc", batch_size=96, phm_dim=8, hidden=256, layers=3, d_units=[64, 32], target_dim=1,
+                                sc_type="last", regression=True),
+    "molpcba_small_256": dict(dataset="molpcba", batch_size=40, phm_dim=4, hidden=256, layers=3, d_units=[64, 32], target_dim=8,
+                              sc_type="first", nan_frac=0.5),
+    "zinc_small_last_180_swish": dict(dataset="zinc", batch_size=64, phm_dim=4, hidden=180, layers=3, d_units=[60, 32], target_dim=1,
+                                      sc_type="last", regression=True, activation="swish"),
+    "zinc_small_last_200": dict(dataset="zinc", batch_size=64, phm_dim=5, hidden=200, layers=2, d_units=[60, 30], target_dim=1,
+                                sc_type="last", regression=True),
+}
+
+
+@pytest.mark.parametrize("workload", ["molhiv_b32", "molhiv_b32_swish", "molhiv_b512", "zinc_small_last_128", "zinc_small_last_256",
+                                      "molpcba_small_256", "zinc_small_last_180_swish", "zinc_small_last_200", "zinc_b1024"])
 @pytest.mark.parametrize("graph", [False, True])
 def test_aggregation_inside_the_first_gemm_leaves_the_step_bit_identical(workload, graph):
     """The whole training step (loss, every gradient, every buffer) with ops.GEMM_AGGREGATE on and off; the fused launch must really
     have run (the launch profiler books it under its own name)."""
     from phc_gnn_amd import harness, lib as L
-    if workload == "zinc_small_last_128":
-        harness.WORKLOADS.setdefault("zinc_small_last_128", dict(dataset="zinc", batch_size=48, phm_dim=4, hidden=128, layers=3, d_units=[64, 32],
-                                                                 target_dim=1, sc_type="last", regression=True))
+    if workload in _AG_EXTRA:
+        harness.WORKLOADS.setdefault(workload, _AG_EXTRA[workload])
     on = _step(workload, dict(GEMM_AGGREGATE=True), graph)
     off = _step(workload, dict(GEMM_AGGREGATE=False), graph)
     _same(on, off)
