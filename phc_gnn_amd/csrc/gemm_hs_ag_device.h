@@ -47,6 +47,11 @@ struct HsAgArgs {
     int n, k, add_self;
 };
 
+// the wide layers' form of the same launch (gemm_hs_agw_device.h, compiled in gemm_agw.hip): widths 256, 180, 200 (square)
+constexpr int HS_AGW_MAX_ROWS = 64;                               // bond-table rows it stages in LDS (64 KB at 256 columns)
+bool gemm_agw_shape_ok(int h, int Nout, int vocab_rows);
+int launch_gemm_agw(const GemmHsArgs &a, const HsAgArgs &ag, bool normed, hipStream_t s);
+
 constexpr int HS_AG_THREADS = 512;
 #ifndef PHC_AG_OCC
 #define PHC_AG_OCC __attribute__((amdgpu_waves_per_eu(4, 4)))

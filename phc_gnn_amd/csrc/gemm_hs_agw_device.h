@@ -11,19 +11,14 @@
 //   * a row is 720 B - 1 KiB: ONE WAVEFRONT gathers a row (lane = 16-byte chunk; lanes past the row's end idle), so everything about
 //     a row — its edge range, its sources, its packed codes — is wave-uniform and travels in SGPRs; a wavefront owns rows 2 w and
 //     2 w + 1 of every 16-row step;
-//   * a workgroup runs 3 - 7 steps (23.6 k rows / 256 CUs = 5.8): the gather of step i + 1 must hide under the MFMAs of step i
-//     (3.4 us of matrix work per step), not stand in front of its own.  Two LDS images alternate; per wavefront the dependent chain
-//     row pointers -> sources / codes -> rows is a rolling three-stage pipeline of ordinary loads whose every consumer runs at
-//     least half an MFMA phase after the issue:
-//         MFMAs of step i, k-groups 0 .. G/2-1        | rows of (A, i + 1) in flight
-//         finish row A of step i + 1 -> image, issue rows of (B, i + 1)
-//         MFMAs of step i, k-groups G/2 .. G-1        | rows of (B, i + 1) in flight
-//         finish row B of step i + 1 -> image;  row pointers of step i + 3 (issued an iteration ago) -> issue its sources / codes;
-//         issue row pointers of step i + 4
-//         epilogue of step i (y, statistics), s / x of row B out       <- stores LAST in the iteration: nothing younger is waited for
-//         issue rows of (A, i + 2) from the sources / codes issued an iteration ago
-//     Only ONE row's gathered pieces are live at a time (NE edges + self, twice that with a norm pending): that is what fits beside
-//     128 operand registers.
+//   * a workgroup runs 3 - 7 steps (23.6 k rows / 256 CUs = 5.8) and a gathered row takes 1 - 2 us to arrive under load: the
+//     gather of step i + 1 must be in flight under the MFMAs of step i.  Two LDS images alternate; per wavefront the dependent chain
+//     row pointers -> sources / codes -> rows is a rolling three-stage pipeline of ordinary loads (metadata of steps i + 2 .. i + 4
+//     in flight on a few lanes, decoded into SGPRs by v_readlane).  FULL (no norm pending: 20 registers of pieces per row): both
+//     rows' pieces of step i + 1 travel a whole step ahead.  With a norm pending every gathered row is two loads (y and the skip: 32
+//     registers per row at NE = 3) and only ONE row's pieces fit beside the 128 operand registers: row A travels under the second
+//     half of the previous step's MFMAs, row B under the first half of this step's.  (The last k-groups of the operand in LDS
+//     instead — 64 - 96 KB, 32 - 48 registers back — was measured: the fragment reads make the MFMA phase 3.8 instead of 2.0 us.)
 // Same edge order, same additions as aggregate_encp_direct_fwd_kernel<64, 0, F> / aggregate_norm_direct_fwd_kernel<64, F> (pair
 // first: acc0 = m0 + m2 + m3 + ..., acc1 = m1, s = (acc0 + acc1) + self), same MFMA order, row ownership and statistics epilogue
 // as gemm_hs16_kernel<K, 2, 8, 1, R, HS_ST> with the same number of workgroups: s, x, save_stat, running statistics, z and the
@@ -35,11 +30,11 @@ namespace phc {
 
 constexpr int HS_AGW_THREADS = 512;
 
-template <int K, bool NORMED, bool RELU, int NE>
+template <int K, bool NORMED, bool RELU, int NE, bool FULL>
 __global__ __launch_bounds__(HS_AGW_THREADS) void gemm_hs_agw_kernel(GemmHsArgs a, HsAgArgs ag) {
     static_assert(K > 128 && K <= 256 && K % 16 == 0, "one row per 1-KiB image instruction");
     static_assert(NE >= 2 && NE <= 4, "edges of a row fetched ahead");
-    constexpr int G = K / 16, GH = G / 2, TPW = 2, ISTRIDE = HS_ISTRIDE, IMG_F4 = 16 * ISTRIDE;
+    constexpr int G = K / 16, TPW = 2, ISTRIDE = HS_ISTRIDE, IMG_F4 = 16 * ISTRIDE;
     __shared__ f32x4_t image[2][IMG_F4];                          // two 16-row operand images (one row per padded 1-KiB line)
     __shared__ __attribute__((aligned(16))) float s_scale[K], s_shift[K], s_bias[K];   // (the bias lives in LDS: 8 registers fewer)
     extern __shared__ __attribute__((aligned(16))) float agw_dyn[];   // [R][KR] bond tables: row = packed code byte, columns as in x
@@ -52,8 +47,16 @@ __global__ __launch_bounds__(HS_AGW_THREADS) void gemm_hs_agw_kernel(GemmHsArgs 
     const int group = (int)blockIdx.x;
     const int M = (int)a.M;
     const int num_steps = (M + 15) / 16;
+    // (a contiguous range of steps per XCD instead of group + i * groups — neighbouring rows' gathers meeting in one L2 — measured:
+    // 50.36 vs 50.47 us per launch at 24 k rows x 256; the mapping stays the statistics GEMM's, whose totals this launch reproduces)
+    const int gfirst = group, gstride = a.groups;
     const int my_steps = group < num_steps ? (num_steps - group + a.groups - 1) / a.groups : 0;
     if (my_steps == 0) return;
+    // diagnostics (phc_debug_hs_stamps; null in the product): 100 MHz ticks at entry | loop start | loop done | end, and per phase
+    // summed over the steps: image barrier | MFMAs first half | finish row A | MFMAs second half | finish row B + metadata |
+    // epilogue + stores + next rows' issue   (scripts/dbg/agw_phases.py)
+    unsigned long long tk[4] = {0, 0, 0, 0}, ph[6] = {0, 0, 0, 0, 0, 0}, t_chain = 0;
+    if (a.stamps) tk[0] = __builtin_amdgcn_s_memrealtime();
     const int count = a.n_valid ? min(*a.n_valid, M) : M;
     const bool live = lane < H4;                                  // this lane's 16-byte chunk exists in a row
     const int c4 = live ? lane : 0;
@@ -67,7 +70,7 @@ __global__ __launch_bounds__(HS_AGW_THREADS) void gemm_hs_agw_kernel(GemmHsArgs 
     const float4 zf4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
     // ---- per-step metadata of this wavefront's two rows (A = 2 w, B = 2 w + 1 of the step), as vector loads on a few lanes -------
-    auto rowA_of = [&](int sl) { return (group + sl * a.groups) * 16 + 2 * wave; };
+    auto rowA_of = [&](int sl) { return (gfirst + sl * gstride) * 16 + 2 * wave; };
     // row pointers of rows A, A + 1, A + 2 (lanes 0..2; clamped to the table's last entry: a row past M is empty)
     auto load_ptrs = [&](int sl) {
         const int r = min(rowA_of(min(sl, my_steps - 1)) + min(lane, 2), M);
@@ -93,6 +96,7 @@ __global__ __launch_bounds__(HS_AGW_THREADS) void gemm_hs_agw_kernel(GemmHsArgs 
         cods = (any ? ag.codes : reinterpret_cast<const unsigned *>(ag.rowptr))[idx];
     };
 
+    float *agw_tbl = agw_dyn;
     // ---- one row's gathered pieces ----
     struct Raw {
         float4 v[NE + 1], rr[NORMED ? NE + 1 : 1];               // edges 0..NE-1, then the row itself
@@ -113,7 +117,7 @@ __global__ __launch_bounds__(HS_AGW_THREADS) void gemm_hs_agw_kernel(GemmHsArgs 
         if constexpr (NORMED) w.rr[NE] = zf4;
         if ((NORMED || ag.add_self) && d < M) load_row(d, w.v[NE], w.rr[NORMED ? NE : 0]);
     };
-    const float4 *tb = reinterpret_cast<const float4 *>(agw_dyn) + c4;   // this lane's chunk of every table row
+    const float4 *tb = reinterpret_cast<const float4 *>(agw_tbl) + c4;   // this lane's chunk of every table row
     auto xval = [&](const float4 v, const float4 rr, int r) {
         if constexpr (!NORMED) {
             return v;
@@ -146,10 +150,14 @@ __global__ __launch_bounds__(HS_AGW_THREADS) void gemm_hs_agw_kernel(GemmHsArgs 
         return v;
     };
     // add one row up from its pieces -> the image line of row `rs` (0..15) of buffer `buf`; returns s and x of the row for the stores
-    auto finish = [&](const Raw &w, int d, int e0, int e1, int srcs, unsigned cods, int which, int buf, int rs, float4 &tot, float4 &selfv) {
+    auto finish = [&](const Raw &w, int d, int e0, int e1, int srcs, unsigned cods, int which, int buf, int rs) {
         const bool valid = d < M;
         const int deg = e1 - e0;
-        selfv = xval(w.v[NE], w.rr[NORMED ? NE : 0], valid ? d : 0);
+        const float4 selfv = xval(w.v[NE], w.rr[NORMED ? NE : 0], valid ? d : 0);
+        // (x of the row goes out at once: older than every load issued from here on, and 8 registers fewer across the rotation)
+        if constexpr (NORMED) {
+            if (valid && live) reinterpret_cast<float4 *>(ag.x_out)[(size_t)d * H4 + c4] = selfv;
+        }
         float4 acc0 = zf4, acc1 = zf4;
 #pragma unroll
         for (int j = 0; j < NE; ++j) {
@@ -168,15 +176,16 @@ __global__ __launch_bounds__(HS_AGW_THREADS) void gemm_hs_agw_kernel(GemmHsArgs 
             const float4 m = message(v, rr, t0, c0);
             acc0.x += m.x; acc0.y += m.y; acc0.z += m.z; acc0.w += m.w;
         }
-        tot = make_float4(acc0.x + acc1.x, acc0.y + acc1.y, acc0.z + acc1.z, acc0.w + acc1.w);
+        float4 tot = make_float4(acc0.x + acc1.x, acc0.y + acc1.y, acc0.z + acc1.z, acc0.w + acc1.w);
         if (ag.add_self) { tot.x += selfv.x; tot.y += selfv.y; tot.z += selfv.z; tot.w += selfv.w; }
         if (!valid || !live) tot = zf4;
         image[buf][rs * ISTRIDE + lane] = f32x4_t{tot.x, tot.y, tot.z, tot.w};
     };
-    auto store_row = [&](int d, const float4 tot, const float4 selfv) {
+    // (s of the row is re-read from the image line it was written to: 8 registers fewer across the metadata rotation)
+    auto store_row = [&](int d, int buf, int rs) {
         if (d < M && live) {
-            reinterpret_cast<float4 *>(ag.s_out)[(size_t)d * H4 + c4] = tot;
-            if constexpr (NORMED) reinterpret_cast<float4 *>(ag.x_out)[(size_t)d * H4 + c4] = selfv;
+            const f32x4_t t4 = image[buf][rs * ISTRIDE + lane];
+            reinterpret_cast<float4 *>(ag.s_out)[(size_t)d * H4 + c4] = make_float4(t4[0], t4[1], t4[2], t4[3]);
         }
     };
 
@@ -214,6 +223,11 @@ __global__ __launch_bounds__(HS_AGW_THREADS) void gemm_hs_agw_kernel(GemmHsArgs 
             }
         }
     }
+    // the rows of step 0 go in flight in front of everything bulky (FULL: both of this wavefront's rows; otherwise row A)
+    Raw rawA, rawB;                                               // (rawB: FULL only — without it one set of pieces is live at a time)
+    int dA = rowA_of(0), dB = dA + 1;
+    issue_raw(rawA, dA, m0.e0[0], m0.e1[0], srcs0, 0);
+    if constexpr (FULL) issue_raw(rawB, dB, m0.e0[1], m0.e1[1], srcs0, 1);
     // bond tables -> LDS (R x H4 float4)
     int tblR = ag.off[1];
 #pragma unroll
@@ -228,7 +242,7 @@ __global__ __launch_bounds__(HS_AGW_THREADS) void gemm_hs_agw_kernel(GemmHsArgs 
             f = past ? t : f;
             fo = past ? ag.off[t] : fo;
         }
-        reinterpret_cast<float4 *>(agw_dyn)[e] = *reinterpret_cast<const float4 *>(ag.tables[comp * F + f] + (size_t)(r - fo) * ag.k + kk);
+        reinterpret_cast<float4 *>(agw_tbl)[e] = *reinterpret_cast<const float4 *>(ag.tables[comp * F + f] + (size_t)(r - fo) * ag.k + kk);
     }
     if constexpr (NORMED) {
         double pS[2], pQ[2];
@@ -263,13 +277,9 @@ __global__ __launch_bounds__(HS_AGW_THREADS) void gemm_hs_agw_kernel(GemmHsArgs 
             for (int q = 0; q < ag.p.n_comp; ++q)
                 if (q == tid) *ag.p.num_batches_tracked[q] += 1;
     }
-    // rows of (A, 0) go in flight in front of the operand slice: the slice's 256 KB per workgroup arrive under the first finish
-    Raw raw;
-    int dA = rowA_of(0), dB = dA + 1;
-    issue_raw(raw, dA, m0.e0[0], m0.e1[0], srcs0, 0);
-    // ---- bias and operand slice -> registers (gemm_hs16_kernel's layout and order) ----
     const f32x4_t zero4 = {0.f, 0.f, 0.f, 0.f};
     if (tid < K) s_bias[tid] = (a.bias && tid < Nout) ? a.bias[tid] : 0.f;
+    // ---- the operand -> registers (gemm_hs16_kernel's layout and order) ----
     f32x4_t hreg[TPW][G];
     {
         const f32x4_t *src = reinterpret_cast<const f32x4_t *>(a.hk4);
@@ -282,42 +292,64 @@ __global__ __launch_bounds__(HS_AGW_THREADS) void gemm_hs_agw_kernel(GemmHsArgs 
                 hreg[t][g] = ok ? v : zero4;
             }
     }
-    lds_barrier();                                                // tables (and scale / shift) are in LDS
-    float4 totA, selfA, totB, selfB;
-    finish(raw, dA, m0.e0[0], m0.e1[0], srcs0, cods0, 0, 0, 2 * wave, totA, selfA);
-    store_row(dA, totA, selfA);
-    issue_raw(raw, dB, m0.e0[1], m0.e1[1], srcs0, 1);
-    finish(raw, dB, m0.e0[1], m0.e1[1], srcs0, cods0, 1, 0, 2 * wave + 1, totB, selfB);
-    store_row(dB, totB, selfB);
-    // pipeline state at the top of iteration i: rows of (A, i + 1) in flight; (mn, srcs_n, cods_n) = step i + 1, arrived;
-    // (m2, srcs2, cods2) = step i + 2, sources / codes in flight; pv3 = row pointers of step i + 3 in flight
+    lds_barrier();                                                // tables, bias (and scale / shift) are in LDS
+    if (a.stamps) t_chain = __builtin_amdgcn_s_memrealtime();
+    finish(rawA, dA, m0.e0[0], m0.e1[0], srcs0, cods0, 0, 0, 2 * wave);
+    if constexpr (FULL) {
+        finish(rawB, dB, m0.e0[1], m0.e1[1], srcs0, cods0, 1, 0, 2 * wave + 1);
+    } else {
+        issue_raw(rawA, dB, m0.e0[1], m0.e1[1], srcs0, 1);
+        finish(rawA, dB, m0.e0[1], m0.e1[1], srcs0, cods0, 1, 0, 2 * wave + 1);
+    }
+    // pipeline state at the top of iteration i: rows of step i + 1 in flight (FULL: both, otherwise row A); (mn, srcs_n, cods_n) =
+    // step i + 1, arrived; (m2, srcs2, cods2) = step i + 2, sources / codes in flight; pv3 = row pointers of step i + 3 in flight
     Meta mn = m1;
     int srcs_n = srcs1;
     unsigned cods_n = cods1;
-    if (my_steps > 1) issue_raw(raw, rowA_of(1), mn.e0[0], mn.e1[0], srcs_n, 0);
+    if (my_steps > 1) {
+        issue_raw(rawA, rowA_of(1), mn.e0[0], mn.e1[0], srcs_n, 0);
+        if constexpr (FULL) issue_raw(rawB, rowA_of(1) + 1, mn.e0[1], mn.e1[1], srcs_n, 1);
+    }
+    store_row(dA, 0, 2 * wave);
+    store_row(dB, 0, 2 * wave + 1);
 
     const int fbase = c * ISTRIDE + kq;                           // fragment base of this lane: row c, chunk 4 g + kq of k-group g
     f32x4_t st_p[TPW], st_s1[TPW], st_s2[TPW];
     float st_n = 0.f;
 #pragma unroll
     for (int t = 0; t < TPW; ++t) st_p[t] = st_s1[t] = st_s2[t] = zero4;
-
+    // The operand slice must be COMPLETE in hipcc's own bookkeeping before the loop: a load it still counts as pending at the loop
+    // header is waited for with vmcnt(0) at its first use in EVERY iteration — in front of the MFMAs, where that drain also waits
+    // for the rows issued a moment ago (seen in the generated code and in the clocks: the gather latency stood in front of the
+    // matrix work instead of under it).  An empty asm that reads the registers places that wait here, once (gemm_hs16_kernel: settle).
+#pragma unroll
+    for (int t = 0; t < TPW; ++t)
+#pragma unroll
+        for (int g = 0; g < G; g += 4)
+            asm volatile("" ::"v"(hreg[t][g]), "v"(hreg[t][g + 1]), "v"(hreg[t][g + 2]), "v"(hreg[t][g + 3]));
+    if (a.stamps) tk[1] = __builtin_amdgcn_s_memrealtime();
     // ================= steps =================
     for (int i = 0; i < my_steps; ++i) {
-        const int step = group + i * a.groups;
+        const int step = gfirst + i * gstride;
         const int buf = i & 1;
         const bool more = i + 1 < my_steps;
+        unsigned long long p0 = 0, p1 = 0, p5 = 0;
+        if (a.stamps) p0 = __builtin_amdgcn_s_memrealtime();
         lds_barrier();                                            // image[buf] complete; image[buf ^ 1] free (read by step i - 1)
+        if (a.stamps) p1 = __builtin_amdgcn_s_memrealtime();
         const f32x4_t *sl = image[buf];
         f32x4_t acc[TPW];
 #pragma unroll
         for (int t = 0; t < TPW; ++t) acc[t] = *reinterpret_cast<const f32x4_t *>(s_bias + col0 + 16 * t + 4 * kq);
         f32x4_t fr[2];
-        fr[0] = sl[fbase];
-        auto mfma_range = [&](int g0, int g1) {
+        auto mfma_range = [&](auto g0c, auto g1c) {
+            constexpr int g0 = decltype(g0c)::value, g1 = decltype(g1c)::value;
+            unsigned long long q0 = 0;
+            if (a.stamps) q0 = __builtin_amdgcn_s_memrealtime();
+            fr[g0 & 1] = sl[fbase + 4 * g0];
 #pragma unroll
             for (int g = g0; g < g1; ++g) {
-                if (g + 1 < G) fr[(g + 1) & 1] = sl[fbase + 4 * (g + 1)];
+                if (g + 1 < g1) fr[(g + 1) & 1] = sl[fbase + 4 * (g + 1)];
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
                 for (int q = 0; q < 4; ++q)
@@ -325,27 +357,61 @@ __global__ __launch_bounds__(HS_AGW_THREADS) void gemm_hs_agw_kernel(GemmHsArgs 
                     for (int t = 0; t < TPW; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(hreg[t][g][q], fr[g & 1][q], acc[t], 0, 0, 0);
                 __builtin_amdgcn_sched_barrier(0);
             }
+            if (a.stamps) { asm volatile("s_nop 0" ::"v"(acc[0])); ph[1] += __builtin_amdgcn_s_memrealtime() - q0; }
         };
-        mfma_range(0, GH);
         const int nA = rowA_of(min(i + 1, my_steps - 1)), nB = nA + 1;
-        if (more) {
-            finish(raw, nA, mn.e0[0], mn.e1[0], srcs_n, cods_n, 0, buf ^ 1, 2 * wave, totA, selfA);
-            // (row A's stores go out here: they are OLDER than the loads of row B issued next, so whoever waits for those has
-            // given them half a phase — and s / x of row A need no registers across the second half)
-            store_row(nA, totA, selfA);
-            issue_raw(raw, nB, mn.e0[1], mn.e1[1], srcs_n, 1);
-        }
-        mfma_range(GH, G);
-        if (more) {
-            finish(raw, nB, mn.e0[1], mn.e1[1], srcs_n, cods_n, 1, buf ^ 1, 2 * wave + 1, totB, selfB);
-            // rotate: step i + 2's sources / codes (issued an iteration ago) become "next"; step i + 3's row pointers (ditto) are
-            // decoded and its sources / codes go out; step i + 4's row pointers go out
+        // rotate: step i + 2's sources / codes (issued an iteration ago) become "next"; step i + 3's row pointers (ditto) are decoded
+        // and its sources / codes go out; step i + 4's row pointers go out
+        auto rotate = [&]() {
             mn = m2; srcs_n = srcs2; cods_n = cods2;
             m2 = ptrs_of(pv3);
             load_edges(m2, srcs2, cods2);
             pv3 = load_ptrs(i + 4);
+        };
+        // the gather work of step i + 1.  FULL: both rows at once, then the rows of step i + 2 go out.  Otherwise in two halves around
+        // the MFMAs: (row A, issue row B) and (row B, rotate, issue row A of step i + 2).
+        auto gather_a = [&]() {
+            if (!more) return;
+            unsigned long long q0 = 0;
+            if (a.stamps) q0 = __builtin_amdgcn_s_memrealtime();
+            finish(rawA, nA, mn.e0[0], mn.e1[0], srcs_n, cods_n, 0, buf ^ 1, 2 * wave);
+            if constexpr (!FULL) issue_raw(rawA, nB, mn.e0[1], mn.e1[1], srcs_n, 1);
+            if (a.stamps) ph[2] += __builtin_amdgcn_s_memrealtime() - q0;
+        };
+        auto gather_b = [&]() {
+            if (!more) return;
+            unsigned long long q0 = 0;
+            if (a.stamps) q0 = __builtin_amdgcn_s_memrealtime();
+            if constexpr (FULL) finish(rawB, nB, mn.e0[1], mn.e1[1], srcs_n, cods_n, 1, buf ^ 1, 2 * wave + 1);
+            else finish(rawA, nB, mn.e0[1], mn.e1[1], srcs_n, cods_n, 1, buf ^ 1, 2 * wave + 1);
+            if (a.stamps) { ph[3] += __builtin_amdgcn_s_memrealtime() - q0; q0 = __builtin_amdgcn_s_memrealtime(); }
+            rotate();
+            if (i + 2 < my_steps) {
+                issue_raw(rawA, rowA_of(i + 2), mn.e0[0], mn.e1[0], srcs_n, 0);
+                if constexpr (FULL) issue_raw(rawB, rowA_of(i + 2) + 1, mn.e0[1], mn.e1[1], srcs_n, 1);
+            }
+            if (a.stamps) ph[4] += __builtin_amdgcn_s_memrealtime() - q0;
+        };
+        using I0 = std::integral_constant<int, 0>;
+        using IH = std::integral_constant<int, G / 2>;
+        using IG = std::integral_constant<int, G>;
+        // (Wavefronts w and w + 4 share a SIMD.  Running them in ANTI-PHASE — 4 - 7 gathering under the MFMAs of 0 - 3 and multiplying
+        // afterwards — was measured (scripts/dbg/agw_phases.py, 24 k rows x 180): the gather's VALU work takes 1.5 - 1.6 us beside a
+        // partner that issues MFMAs against 0.3 us beside an idle one, the MFMAs then run uncontended at 1.45 instead of 2.9 us, and
+        // the step takes what it took (28.7 vs 29.3 us per launch): per SIMD the two wavefronts' matrix and vector work ADD UP
+        // whatever the order.  What shortens the step is fewer vector instructions in the gather, not their placement.)
+        if constexpr (FULL) {
+            mfma_range(I0{}, IG{});
+            gather_a();
+            gather_b();
+        } else {
+            mfma_range(I0{}, IH{});
+            gather_a();
+            mfma_range(IH{}, IG{});
+            gather_b();
         }
-        // ---- epilogue of step i: lane (c, kq) holds z[row][col0 + 16 t + 4 kq .. +3] ----
+        if (a.stamps) p5 = __builtin_amdgcn_s_memrealtime();
+        // ---- epilogue of step i: lane (c, kq) holds z[row][col0 + 16 t + 4 kq .. +3]; stores LAST in the iteration ----
         const int row = step * 16 + c;
         if (row < count) {
             if (st_n == 0.f) {
@@ -368,11 +434,15 @@ __global__ __launch_bounds__(HS_AGW_THREADS) void gemm_hs_agw_kernel(GemmHsArgs 
                 if (col0 + 4 * kq + 16 * t < Nout) *reinterpret_cast<f32x4_t *>(yr + 16 * t) = acc[t];
         }
         if (more) {
-            store_row(nB, totB, selfB);
-            // rows of (A, i + 2): behind the stores in program order, consumed half a phase into the next step
-            if (i + 2 < my_steps) issue_raw(raw, rowA_of(i + 2), mn.e0[0], mn.e1[0], srcs_n, 0);
+            store_row(nA, buf ^ 1, 2 * wave);
+            store_row(nB, buf ^ 1, 2 * wave + 1);
+        }
+        if (a.stamps) {
+            const unsigned long long p6 = __builtin_amdgcn_s_memrealtime();
+            ph[0] += p1 - p0; ph[5] += p6 - p5;
         }
     }
+    if (a.stamps) tk[2] = __builtin_amdgcn_s_memrealtime();
     // ---- statistics of the output columns (gemm_hs16_kernel's HS_ST finale) ----
     {
         double S[TPW][4], Q[TPW][4];
@@ -385,6 +455,17 @@ __global__ __launch_bounds__(HS_AGW_THREADS) void gemm_hs_agw_kernel(GemmHsArgs 
                 Q[t][q] = hs_sum16(n * p * p + 2.0 * p * s1 + s2);
             }
         hs_publish<TPW>(a.stat_acc, Nout, (int)(group % STAT_ACC_REP), col0, kq, c, S, Q);
+    }
+    if (a.stamps) {
+        tk[3] = __builtin_amdgcn_s_memrealtime();
+        if (lane == 0) {
+            unsigned long long *o = a.stamps + ((size_t)blockIdx.x * 8 + wave) * 12;
+            o[0] = tk[0]; o[1] = tk[1]; o[2] = tk[2]; o[3] = tk[3];
+#pragma unroll
+            for (int q = 0; q < 6; ++q) o[4 + q] = ph[q];
+            o[10] = (unsigned long long)my_steps;
+            o[11] = t_chain;
+        }
     }
 }
 

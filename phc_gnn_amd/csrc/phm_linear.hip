@@ -2349,17 +2349,13 @@ int phc_gemm_prebuilt_bwsums(const float *dy, const float *M, const float *Mk4, 
 
 // The norm backward's element-wise pass folded into the dx GEMM behind it (HS_BA), optionally with the sums epilogue of the
 // norm in front of that GEMM (HS_BW): see include/phc_hip.h.
-namespace phc {
-bool gemm_agw_shape_ok(int h, int Nout);                                                        // gemm_agw.hip: 256, 180, 200 (square)
-int launch_gemm_agw(const GemmHsArgs &a, const HsAgArgs &ag, bool normed, hipStream_t s);
-}
 static inline bool agw_enabled() {
     static const bool off = getenv("PHC_GEMM_AGGREGATE_WIDE") && atoi(getenv("PHC_GEMM_AGGREGATE_WIDE")) == 0;
     return !off;
 }
 int phc_gemm_aggregate_supported(int64_t N, int h, int Nout, int F, int vocab_rows) {
     static const bool off = getenv("PHC_GEMM_AGGREGATE") && atoi(getenv("PHC_GEMM_AGGREGATE")) == 0;
-    const bool shape = (h == 128 && Nout == 128) || (agw_enabled() && gemm_agw_shape_ok(h, Nout) && hs_widths_ok(h, Nout));
+    const bool shape = (h == 128 && Nout == 128) || (agw_enabled() && gemm_agw_shape_ok(h, Nout, vocab_rows) && hs_widths_ok(h, Nout));
     return (!off && hs_enabled() && N >= 1 && N <= (1 << 20) && shape && F >= 1 && F <= HS_AG_MAX_F && vocab_rows >= 1 &&
             vocab_rows <= HS_AG_MAX_ROWS) ? 1 : 0;
 }
