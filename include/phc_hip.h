@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PHC_ABI_VERSION 5
+#define PHC_ABI_VERSION 6
 
 #define PHC_OK 0
 #define PHC_ERR_INVALID_ARG (-1)   /* null pointer, negative size, bad enum        */
@@ -619,6 +619,12 @@ typedef struct phc_gemm_ba_desc {
     int64_t count;                 /* rows sums_acc was taken over when that is MORE than this launch's rows: a row-sharded norm
                                       whose accumulators were all-reduced (integer sum: exact) divides by the total of all ranks;
                                       0 = the valid rows of this launch                                */
+    /* ABI 6: the norm's output went through phm_dropout before it was used (models.py:211-213: act -> dropout -> + skip): dout is
+     * multiplied by the forward's keep-and-scale mask inside the transform (arguments as for phc_bn_bwd; drop_p = 0: off).  Square
+     * layers of width 128 / 256 / 180 / 200. */
+    float drop_p;
+    int32_t drop_same_k, drop_site;
+    const uint64_t *rng_state;
 } phc_gemm_ba_desc;
 int phc_gemm_bwd_apply_supported(int K, int Nout);
 /* Diagnostics only: when set (device buffer, 12 x 8 bytes per wavefront of the largest launch), every H-stationary GEMM launch
@@ -679,6 +685,10 @@ int phc_gemm_bwd_apply(const phc_gemm_ba_desc *d, void *stream);
  * zeroed by the caller; h % 4 == 0, h <= 8192, 16-byte aligned rows) — phc_bn_bwd's first launch without its second. */
 int phc_bn_bwd_partial_acc(const float *dy, const float *x, const float *save_stat, const int32_t *n_valid_dev, int64_t N, int h,
                            int act, uint64_t *acc, void *stream);
+/* ABI 6: the same sums with the forward's dropout mask on dy (arguments as for phc_bn_bwd; drop_p = 0: exactly the call above). */
+int phc_bn_bwd_partial_acc_drop(const float *dy, const float *x, const float *save_stat, const int32_t *n_valid_dev, int64_t N, int h,
+                                int act, uint64_t *acc, float drop_p, int drop_same_k, int drop_site, const uint64_t *rng_state,
+                                void *stream);
 int phc_bn_bwd_from_partials(const float *dy, const float *x, const float *save_stat, const float *sums_partial,
                              int num_partials, const int32_t *n_valid_dev, int64_t N, int h, int act, float *dx,
                              float *dwb_flat, void *ws, size_t ws_bytes, void *stream);

@@ -170,8 +170,9 @@ class PHMSkipConnectAdd(nn.Module):
         # the layer in front may have parked its last element-wise pass (engine: PendingNorm on x[0]): only the fused branch below
         # passes it on to the aggregation kernel, every other path evaluates it now
         pending = getattr(x[0], "_phc_pending", None)
-        fused_branch = self.training and norm is not None and not dropout_active and self.mlp_mp and x[0].is_cuda and \
-            hasattr(tr, "propagate_encoded") and hasattr(getattr(tr, "transform", None), "linear2")
+        # (with dropout the mask rides in the fused node's norm passes: engine HS_DR, round 5; MLP_NORM_DROPOUT=0 restores the separate nodes)
+        fused_branch = self.training and norm is not None and (not dropout_active or _engine.MLP_NORM_DROPOUT) and self.mlp_mp and \
+            x[0].is_cuda and hasattr(tr, "propagate_encoded") and hasattr(getattr(tr, "transform", None), "linear2")
         if pending is not None and not (fused_branch and edge_encoder is not None and type(tr).__name__ == "PHMGINEConv"):
             _engine.materialize_pending(x[0])
             pending = None
@@ -203,8 +204,10 @@ class PHMSkipConnectAdd(nn.Module):
                                                dx_handoff=agg_handoff)
             else:
                 agg = tr.propagate(edge_index, x=x[0], edge_attr=edge_attr, size=size, add_self=tr.add_self_loops)
+            site = next((i for i, nm in enumerate(self.norms) if nm is norm), 0)
             fused = _engine.mlp_norm_fused(agg, x[1], n_valid, tr.transform, norm, self.activation_str, skip_handoff=handoff,
-                                           defer_apply=defer_norm)
+                                           defer_apply=defer_norm and not dropout_active,
+                                           dropout=(dropout_mpnn, self.same_dropout, site) if dropout_active else None)
             if fused is not None:
                 return fused
             h = tr.transform(agg, n_valid=n_valid)

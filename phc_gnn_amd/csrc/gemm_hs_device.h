@@ -38,8 +38,17 @@
 //               in LDS (norm.py:30-35 backward; the per-column means come from the sums accumulator of the pass in front),
 //               feeds it to the MFMAs and also writes it out (the parameter-gradient GEMM of the layer reads it later):
 //               the norm backward's element-wise pass and its launch disappear into the dx GEMM behind it.
+//        HS_DR  (with HS_BA) the norm's output went through phm_dropout (models.py:211-213: act -> dropout -> + skip): the upstream
+//               gradient is multiplied by the keep-and-scale mask first, regenerated from (seed, step, site, row, column) exactly as
+//               bn_bwd_apply_acc_kernel regenerates it (phc_common.h: drop_factors) — round 5: the reference's default and published
+//               settings all train with dropout, and without this flag their layers fell off the fused MLP + norm node.
 #pragma once
 #include <hip/hip_runtime.h>
+
+// Every lambda of the kernel below MUST be inlined: one that is not takes its captures through a closure object in memory, and a
+// captured by-value kernel argument struct then lives in scratch for the whole launch (seen when the dropout mask's Philox rounds
+// pushed `transform` past hipcc's inlining threshold: 432 - 720 bytes of private segment, 88 instead of 30 us per launch).
+#define PHC_HS_INLINE __attribute__((always_inline))
 
 #include <type_traits>
 
@@ -49,7 +58,7 @@ namespace phc {
 
 using f32x4_t = __attribute__((ext_vector_type(4))) float;
 
-constexpr int HS_ST = 1, HS_XF = 2, HS_BW = 4, HS_BA = 8;
+constexpr int HS_ST = 1, HS_XF = 2, HS_BW = 4, HS_BA = 8, HS_DR = 16;
 
 // XF operand whose batch statistics are still in an ACCUMULATOR: the launch derives scale / shift itself, in its prologue
 // (acc == NULL: xf_stat holds them, merged elsewhere).
@@ -86,6 +95,7 @@ struct GemmHsArgs {
     int ba_act;
     float *ba_dz;              // BA: [M, K] out
     float *ba_dwb;             // BA: [2 K] out or null: dweight = sum g x_hat | dbias = sum g   (written by workgroup 0)
+    BnDrop ba_drop;            // DR: the dropout behind the norm's activation (p, same, k, site, device {seed, step})
     unsigned long long *stamps;     // diagnostics only (null in the product): 12 words per wavefront, see the kernel's end
 };
 
@@ -168,7 +178,19 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
     // lanes re-fetch chunk 0) and meet operand rows that read as zero; tiles / columns past a.Nout are loaded as zero and never stored.
     const int KR = a.K;
     constexpr bool ST = (FLAGS & HS_ST) != 0, XF = (FLAGS & HS_XF) != 0, BW = (FLAGS & HS_BW) != 0, BA = (FLAGS & HS_BA) != 0;
+    constexpr bool DR = (FLAGS & HS_DR) != 0;
     static_assert(!(BA && XF), "one operand transform per launch");
+    static_assert(!DR || BA, "the dropout mask rides in the norm-backward transform");
+    // DR: seed and step of the mask — a uniform address out of the kernel arguments: scalar loads (lgkmcnt), issued in front of
+    // everything and invisible to the counted vmcnt waits below
+    unsigned long long dr_seed = 0, dr_step = 0;
+    float dr_p = 0.f;
+    int dr_same = 0, dr_k = 4, dr_site = 0;                       // (copies: a reference to a member of `a` would put all of `a` in scratch)
+    if constexpr (DR) {
+        dr_seed = a.ba_drop.state[0];
+        dr_step = a.ba_drop.state[1];
+        dr_p = a.ba_drop.p; dr_same = a.ba_drop.same; dr_k = a.ba_drop.k; dr_site = a.ba_drop.site;
+    }
     constexpr int G = K / 16, RS = 16 * RB, RPI = 256 / K, INSTR = RS / RPI, IPW = INSTR / WAVES;
     static_assert(INSTR % WAVES == 0 && IPW >= 1, "the DMA instructions of a step divide among the wavefronts");
     constexpr int ISTRIDE = HS_ISTRIDE;
@@ -204,7 +226,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
     const int dchunk = (RPI == 1 ? lane : (lane & 31)) ^ dsub;    // the 16-byte chunk of its row this lane fetches
     const bool dlive = 4 * dchunk < KR;                           // (always true at K = 128 / 256)
     const int dfetch = dlive ? dchunk : 0;                        // a lane past the row's end re-fetches chunk 0: finite values x zero operand
-    auto issue_step = [&](long long step_local, int slot) {
+    auto issue_step = [&](long long step_local, int slot) PHC_HS_INLINE {
         const long long step = group + min(step_local, my_steps - 1) * a.groups;       // clamped: the tail re-loads valid rows
 #pragma unroll
         for (int u = 0; u < IPW; ++u) {
@@ -224,7 +246,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
     // them to the counted wait: a register copy hipcc placed in between would read them before the data is there)
     unsigned long long ba_raw[(BA || XF) ? 2 : 1][(BA || XF) ? STAT_ACC_REP : 1][2];
     float cst_raw[4], xfw_raw, xfb_raw;
-    auto acc_loads = [&](const unsigned long long *acc) {
+    auto acc_loads = [&](const unsigned long long *acc) PHC_HS_INLINE {
         const unsigned long long *p0 = acc + tid;
 #pragma unroll
         for (int qty = 0; qty < 2; ++qty)
@@ -264,7 +286,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
     // the constants)
     constexpr int ACC_YOUNGER = (R - 1) * IPW * (BA ? 2 : 1);
     static_assert(ACC_YOUNGER <= 63, "vmcnt is a 6-bit counter");
-    auto acc_arrived = [&]() {                                    // counted wait + the registers tied behind it
+    auto acc_arrived = [&]() PHC_HS_INLINE {                                // counted wait + the registers tied behind it
         asm volatile("s_waitcnt vmcnt(%8)"
                      : "+v"(ba_raw[0][0][0]), "+v"(ba_raw[0][0][1]), "+v"(ba_raw[0][1][0]), "+v"(ba_raw[0][1][1]), "+v"(ba_raw[0][2][0]),
                        "+v"(ba_raw[0][2][1]), "+v"(ba_raw[0][3][0]), "+v"(ba_raw[0][3][1])
@@ -432,7 +454,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
     // also drain the DMA ring.  An empty asm that reads the registers makes hipcc place that wait where `settle` is called:
     // behind the FIRST step, which is peeled out of the loop and waits for each operand register where it first needs it —
     // so the slice's 256 KB per workgroup arrive under the first step's MFMAs instead of in front of them.
-    auto settle = [&]() {
+    auto settle = [&]() PHC_HS_INLINE {
 #pragma unroll
         for (int t = 0; t < TPW; ++t) {
 #pragma unroll
@@ -466,7 +488,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
     // (XF: act(x * scale + shift); BA: the norm backward, also written out).  It runs one step AHEAD of the MFMAs: the pieces
     // of step i + 1 are transformed in front of the MFMAs of step i, so that their LDS round trip and the barrier that
     // publishes them never sit between two steps' matrix work.
-    auto transform = [&](long long sl_step, int tslot) {
+    auto transform = [&](long long sl_step, int tslot) PHC_HS_INLINE {
         const long long step = group + sl_step * a.groups;
         if constexpr (XF) {
 #pragma unroll
@@ -493,16 +515,21 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
             const f32x4_t c1 = *reinterpret_cast<const f32x4_t *>(ba_lds + 6 * K + 4 * dfetch);
             // The activation switch stays OUTSIDE the element loops (one straight-line body per kind): as a per-element select
             // chain hipcc turned it into ~20 scalar branches per element, 0.3-0.4 us of a 16-row step.
-            auto rows = [&](auto kind) {
+            auto rows = [&](auto kind) PHC_HS_INLINE {
                 constexpr int KIND = decltype(kind)::value;           // 0 identity, 1 relu, 2 any other (runtime switch per element)
 #pragma unroll
                 for (int u = 0; u < IPW; ++u) {
                     const int ii = wave + WAVES * u;
                     const long long row = step * RS + ii * RPI + dsub;
                     f32x4_t *p = ring + (size_t)tslot * SLOT_F4 + ii * ISTRIDE + lane;
-                    const f32x4_t gv = *p, xv = p[IMG_F4];
+                    f32x4_t gv = *p;
+                    const f32x4_t xv = p[IMG_F4];
                     f32x4_t o = zero4;
                     if (row < n_valid && dlive) {
+                        if constexpr (DR) {                       // g := dout * mask (the forward's keep-and-scale factors)
+                            const float4 f = drop_factors_v(dr_p, dr_same, dr_k, dr_site, dr_seed, dr_step, row, 4 * dchunk, KR);
+                            gv[0] *= f.x; gv[1] *= f.y; gv[2] *= f.z; gv[3] *= f.w;
+                        }
 #pragma unroll
                         for (int q = 0; q < 4; ++q) {
                             // dz = w invstd (g - mean g - x_hat mean(g x_hat)); x_hat and the pre-activation exactly as the separate
@@ -536,7 +563,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
     }
     int slot = 0;
     unsigned long long ph[4] = {0, 0, 0, 0};                      // diagnostics: 100 MHz ticks in wait+barrier | issue+transform | MFMAs | epilogue
-    auto step_body = [&](long long i, auto first) {
+    auto step_body = [&](long long i, auto first) PHC_HS_INLINE {
         const long long step = group + i * a.groups;
         unsigned long long pt0 = 0, pt1 = 0, pt2 = 0, pt3 = 0;
         if (a.stamps) pt0 = __builtin_amdgcn_s_memrealtime();
@@ -623,7 +650,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
             }
             if constexpr (BW) {
                 if (row < n_valid) {
-                    auto sums = [&](auto kind) {                  // (the activation switch outside the element loops, as in `transform`)
+                    auto sums = [&](auto kind) PHC_HS_INLINE {               // (the activation switch outside the element loops, as in `transform`)
                         constexpr int KIND = decltype(kind)::value;
 #pragma unroll
                         for (int t = 0; t < TPW; ++t)

@@ -28,42 +28,7 @@ __device__ __forceinline__ float bn_b(const BnParams &p, int col) { return p.has
 template <int ACT>
 __device__ __forceinline__ float bn_act(float z) { return act_fwd<ACT>(z); }
 
-// ---- dropout fused behind the activation (models.py:211-213, downstream.py:108-111: act -> phm_dropout -> (+ skip)) ----
-// phm_dropout (layers.py:31-55): p = drop rate, kept entries scaled by 1 / (1 - p); same = one mask per (row, channel)
-// shared by the n hypercomplex components.  The mask is a pure function of (seed, step, site, row, channel): Philox4x32-10
-// with key = seed, counter = (element group, site, step), so the backward kernels regenerate it instead of reading a
-// stored mask, and a replayed hipGraph draws a fresh mask every step (step is a device counter, phc_rng_advance).
-struct BnDrop {
-    float p;                        // 0: off
-    int same, k, site;              // k = columns per component
-    const unsigned long long *state;   // device: {seed, step}
-};
-
-__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 key) {
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const unsigned hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
-        const unsigned hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
-        c = make_uint4(hi1 ^ c.y ^ key.x, lo1, hi0 ^ c.w ^ key.y, lo0);
-        key.x += 0x9E3779B9u;
-        key.y += 0xBB67AE85u;
-    }
-    return c;
-}
-
-// keep-and-scale factors of the 4 consecutive columns starting at col (col % 4 == 0, k % 4 == 0) of row r
-__device__ __forceinline__ float4 drop_factors(const BnDrop &d, unsigned long long seed, unsigned long long step, long long r, int col,
-                                               int h) {
-    const int chan = d.same ? col % d.k : col;                       // same: the mask ignores the component
-    const int width = d.same ? d.k : h;
-    const unsigned long long g = (unsigned long long)r * (unsigned long long)(width >> 2) + (unsigned long long)(chan >> 2);
-    const uint4 rnd = philox4x32_10(make_uint4((unsigned)g, (unsigned)(g >> 32), (unsigned)d.site, (unsigned)step),
-                                    make_uint2((unsigned)seed, (unsigned)(seed >> 32) ^ (unsigned)(step >> 32)));
-    const float inv = 1.f / (1.f - d.p);
-    const float u0 = rnd.x * 2.3283064365386963e-10f, u1 = rnd.y * 2.3283064365386963e-10f, u2 = rnd.z * 2.3283064365386963e-10f,
-                u3 = rnd.w * 2.3283064365386963e-10f;
-    return make_float4(u0 >= d.p ? inv : 0.f, u1 >= d.p ? inv : 0.f, u2 >= d.p ? inv : 0.f, u3 >= d.p ? inv : 0.f);
-}
+// (BnDrop, philox4x32_10, drop_factors, make_drop: phc_common.h — the H-stationary GEMM's norm-backward transform draws the same masks)
 
 // ---- pass 1 (forward): per-column shifted sums over a row range --------------------------------
 // thread -> (vector column c = tid % cols, row lane rl = tid / cols), VEC columns per thread;
@@ -904,19 +869,6 @@ static inline unsigned apply_grid(long long N, int h) {
     return (unsigned)blocks;
 }
 
-static int make_drop(const char *who, BnDrop *d, float p, int same_k, int site, const uint64_t *state, int h) {
-    d->p = 0.f; d->same = 0; d->k = h; d->site = site; d->state = nullptr;
-    if (p <= 0.f) return PHC_OK;
-    PHC_REQUIRE(p < 1.f && state, PHC_ERR_INVALID_ARG, "%s: dropout p=%g needs 0 <= p < 1 and an rng state", who, (double)p);
-    PHC_REQUIRE(h % 4 == 0 && (same_k == 0 || (same_k % 4 == 0 && h % same_k == 0)), PHC_ERR_UNSUPPORTED,
-                "%s: fused dropout needs h %% 4 == 0 (and k %% 4 == 0 for the shared mask)", who);
-    d->p = p;
-    d->same = same_k > 0;
-    d->k = same_k > 0 ? same_k : h;
-    d->state = reinterpret_cast<const unsigned long long *>(state);
-    return PHC_OK;
-}
-
 __global__ void rng_advance_kernel(unsigned long long *state) { state[1] += 1ull; }
 
 #define PHC_BN_ACT_SWITCH(act, MACRO)                 \
@@ -1109,6 +1061,12 @@ static int launch_bwd_apply_acc(const float *dy, const float *x, const float *sa
 
 int phc_bn_bwd_partial_acc(const float *dy, const float *x, const float *save_stat, const int32_t *n_valid_dev, int64_t N, int h,
                            int act, uint64_t *acc, void *stream) {
+    return phc_bn_bwd_partial_acc_drop(dy, x, save_stat, n_valid_dev, N, h, act, acc, 0.f, 0, 0, nullptr, stream);
+}
+
+int phc_bn_bwd_partial_acc_drop(const float *dy, const float *x, const float *save_stat, const int32_t *n_valid_dev, int64_t N, int h,
+                                int act, uint64_t *acc, float drop_p, int drop_same_k, int drop_site, const uint64_t *rng_state,
+                                void *stream) {
     PHC_REQUIRE(N >= 1 && h >= 4 && h % 4 == 0 && h <= 8192, PHC_ERR_INVALID_ARG, "phc_bn_bwd_partial_acc: N=%lld h=%d", (long long)N, h);
     PHC_REQUIRE(act >= PHC_ACT_IDENTITY && act <= PHC_ACT_SELU, PHC_ERR_INVALID_ARG, "phc_bn_bwd_partial_acc: unknown activation %d", act);
     PHC_REQUIRE(dy && x && save_stat && acc, PHC_ERR_INVALID_ARG, "phc_bn_bwd_partial_acc: null pointer");
@@ -1116,7 +1074,9 @@ int phc_bn_bwd_partial_acc(const float *dy, const float *x, const float *save_st
                 PHC_ERR_UNSUPPORTED, "phc_bn_bwd_partial_acc: 16-byte aligned rows, 8-byte aligned accumulator");
     hipStream_t s = (hipStream_t)stream;
     BnPlan plan = bn_plan(N);
-    BnDrop drop = {};
+    BnDrop drop;
+    int rc = make_drop("phc_bn_bwd_partial_acc", &drop, drop_p, drop_same_k, drop_site, rng_state, h);
+    if (rc) return rc;
     ProfScope prof(K_BN_BWD_PARTIAL, s);
 #define PHC_BN_BPA(ACTC)                                                                                                     \
     PHC_LAUNCH((bn_bwd_partial_kernel<ACTC, 4>), dim3(plan.num_partials), dim3(BN_THREADS), 0, s, dy, x, save_stat, n_valid_dev,     \

@@ -295,6 +295,62 @@ inline bool ensure_dynamic_lds(K kernel, size_t bytes) {
     return ensure_dynamic_lds_addr(reinterpret_cast<const void *>(kernel), bytes);
 }
 
+// ---- dropout fused behind the activation (models.py:211-213, downstream.py:108-111: act -> phm_dropout -> (+ skip)) ----
+// phm_dropout (layers.py:31-55): p = drop rate, kept entries scaled by 1 / (1 - p); same = one mask per (row, channel)
+// shared by the n hypercomplex components.  The mask is a pure function of (seed, step, site, row, channel): Philox4x32-10
+// with key = seed, counter = (element group, site, step), so the backward kernels regenerate it instead of reading a
+// stored mask, and a replayed hipGraph draws a fresh mask every step (step is a device counter, phc_rng_advance).
+struct BnDrop {
+    float p;                        // 0: off
+    int same, k, site;              // k = columns per component
+    const unsigned long long *state;   // device: {seed, step}
+};
+
+__device__ __forceinline__ uint4 philox4x32_10(uint4 c, uint2 key) {
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        const unsigned hi0 = __umulhi(0xD2511F53u, c.x), lo0 = 0xD2511F53u * c.x;
+        const unsigned hi1 = __umulhi(0xCD9E8D57u, c.z), lo1 = 0xCD9E8D57u * c.z;
+        c = make_uint4(hi1 ^ c.y ^ key.x, lo1, hi0 ^ c.w ^ key.y, lo0);
+        key.x += 0x9E3779B9u;
+        key.y += 0xBB67AE85u;
+    }
+    return c;
+}
+
+// keep-and-scale factors of the 4 consecutive columns starting at col (col % 4 == 0, k % 4 == 0) of row r — the mask's parameters by
+// VALUE: a kernel that passes a member of its by-value argument struct by reference makes hipcc copy the whole struct into scratch
+// (seen with GemmHsArgs::ba_drop: 432 - 720 bytes of private segment and an 88 instead of 30 us launch)
+__device__ __forceinline__ float4 drop_factors_v(float p, int same, int k, int site, unsigned long long seed, unsigned long long step,
+                                                 long long r, int col, int h) {
+    const int chan = same ? col % k : col;                           // same: the mask ignores the component
+    const int width = same ? k : h;
+    const unsigned long long g = (unsigned long long)r * (unsigned long long)(width >> 2) + (unsigned long long)(chan >> 2);
+    const uint4 rnd = philox4x32_10(make_uint4((unsigned)g, (unsigned)(g >> 32), (unsigned)site, (unsigned)step),
+                                    make_uint2((unsigned)seed, (unsigned)(seed >> 32) ^ (unsigned)(step >> 32)));
+    const float inv = 1.f / (1.f - p);
+    const float u0 = rnd.x * 2.3283064365386963e-10f, u1 = rnd.y * 2.3283064365386963e-10f, u2 = rnd.z * 2.3283064365386963e-10f,
+                u3 = rnd.w * 2.3283064365386963e-10f;
+    return make_float4(u0 >= p ? inv : 0.f, u1 >= p ? inv : 0.f, u2 >= p ? inv : 0.f, u3 >= p ? inv : 0.f);
+}
+__device__ __forceinline__ float4 drop_factors(const BnDrop &d, unsigned long long seed, unsigned long long step, long long r, int col,
+                                               int h) {
+    return drop_factors_v(d.p, d.same, d.k, d.site, seed, step, r, col, h);
+}
+
+inline int make_drop(const char *who, BnDrop *d, float p, int same_k, int site, const uint64_t *state, int h) {
+    d->p = 0.f; d->same = 0; d->k = h; d->site = site; d->state = nullptr;
+    if (p <= 0.f) return PHC_OK;
+    PHC_REQUIRE(p < 1.f && state, PHC_ERR_INVALID_ARG, "%s: dropout p=%g needs 0 <= p < 1 and an rng state", who, (double)p);
+    PHC_REQUIRE(h % 4 == 0 && (same_k == 0 || (same_k % 4 == 0 && h % same_k == 0)), PHC_ERR_UNSUPPORTED,
+                "%s: fused dropout needs h %% 4 == 0 (and k %% 4 == 0 for the shared mask)", who);
+    d->p = p;
+    d->same = same_k > 0;
+    d->k = same_k > 0 ? same_k : h;
+    d->state = reinterpret_cast<const unsigned long long *>(state);
+    return PHC_OK;
+}
+
 inline int check_launch(const char *what) {
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) {

@@ -1531,6 +1531,15 @@ static int launch_hs(const GemmHsArgs &a, int K, const XfAcc &xa, hipStream_t s)
     return launch_hs_cfg<128, 2, 4, FLAGS>(a, xa, s);
 }
 
+// the square configurations only (the dropout variants of the folded norm backward: fewer instantiations of a heavy kernel)
+template <int FLAGS>
+static int launch_hs_square(const GemmHsArgs &a, int K, hipStream_t s) {
+    if (K == 180) return launch_hs_cfg<192, 2, 8, FLAGS>(a, XfAcc{}, s);
+    if (K == 200) return launch_hs_cfg<208, 2, 8, FLAGS>(a, XfAcc{}, s);
+    if (K == 256) return launch_hs_cfg<256, 2, 8, FLAGS>(a, XfAcc{}, s);
+    return launch_hs_cfg<128, 2, 4, FLAGS>(a, XfAcc{}, s);
+}
+
 static GemmHsArgs hs_args(const float *x, const float *Mk4, const float *b, const float *residual, float *y, int64_t N, int K, int Nout) {
     GemmHsArgs a = {};
     a.x = x; a.hk4 = Mk4; a.bias = b; a.residual = residual; a.y = y; a.M = N; a.K = K; a.Nout = Nout;
@@ -2492,13 +2501,24 @@ int phc_gemm_bwd_apply(const phc_gemm_ba_desc *d, void *stream) {
     a.ba_dz = d->dz;
     a.ba_dwb = d->dwb;
     a.ba_count = d->count;
+    // ABI 6: dropout behind the norm's activation — the mask multiplies the upstream gradient inside the transform (HS_DR)
+    int rc = make_drop("phc_gemm_bwd_apply", &a.ba_drop, d->drop_p, d->drop_same_k, d->drop_site, d->rng_state, d->K);
+    if (rc) return rc;
+    const bool dr = a.ba_drop.p > 0.f;
+    PHC_REQUIRE(!dr || (d->K == d->Nout && (d->K == 128 || d->K == 256 || d->K == 180 || d->K == 200)), PHC_ERR_UNSUPPORTED,
+                "phc_gemm_bwd_apply: the dropout form serves square layers of width 128 / 256 / 180 / 200 (K = %d, Nout = %d)", d->K, d->Nout);
     ProfScope prof(K_PHM_GEMM_DX, s);
     if (bw) {
         a.stat_acc = reinterpret_cast<unsigned long long *>(d->bw_sums_acc);
         a.bw_x = d->bw_x;
         a.bw_stat = d->bw_stat;
         a.bw_act = d->bw_act;
-        launch_hs<HS_BA | HS_BW>(a, d->K, XfAcc{}, s);
+        if (dr)
+            launch_hs_square<HS_BA | HS_BW | HS_DR>(a, d->K, s);
+        else
+            launch_hs<HS_BA | HS_BW>(a, d->K, XfAcc{}, s);
+    } else if (dr) {
+        launch_hs_square<HS_BA | HS_DR>(a, d->K, s);
     } else {
         launch_hs<HS_BA>(a, d->K, XfAcc{}, s);
     }

@@ -15,7 +15,7 @@ import torch
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, "libphc_hip.so")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 ACT_IDS = {"identity": 0, "relu": 1, "lrelu": 2, "elu": 3, "swish": 4, "selu": 5}
 
 
@@ -66,7 +66,8 @@ class GemmBaDesc(C.Structure):
     """phc_gemm_ba_desc (include/phc_hip.h)."""
     _fields_ = [("dout", _P), ("bn_x", _P), ("bn_stat", _P), ("sums_acc", _P), ("n_valid_dev", _P), ("dz", _P), ("dwb", _P),
                 ("Mk4", _P), ("y", _P), ("N", _L), ("K", C.c_int32), ("Nout", C.c_int32), ("act", C.c_int32), ("bw_act", C.c_int32),
-                ("bw_x", _P), ("bw_stat", _P), ("bw_sums_acc", _P), ("count", _L)]
+                ("bw_x", _P), ("bw_stat", _P), ("bw_sums_acc", _P), ("count", _L),
+                ("drop_p", C.c_float), ("drop_same_k", C.c_int32), ("drop_site", C.c_int32), ("rng_state", _P)]
 
 
 class GemmAgDesc(C.Structure):
@@ -152,6 +153,7 @@ SIGNATURES = {
     "phc_debug_readout_stamps": (_I, [_P]),
     "phc_gemm_aggregate_stats": (_I, [C.POINTER(GemmAgDesc), _P]),
     "phc_bn_bwd_partial_acc": (_I, [_P, _P, _P, _P, _L, _I, _I, _P, _P]),
+    "phc_bn_bwd_partial_acc_drop": (_I, [_P, _P, _P, _P, _L, _I, _I, _P, C.c_float, _I, _I, _P, _P]),
     "phc_bn_bwd_from_partials": (_I, [_P, _P, _P, _P, _I, _P, _L, _I, _I, _P, _P, _P, _S, _P]),
     "phc_phm_param_grads_ws_bytes": (_S, [C.POINTER(GradJob), _I]),
     "phc_phm_param_grads": (_I, [C.POINTER(GradJob), _I, _P, _S, _P]),

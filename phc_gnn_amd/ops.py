@@ -2789,6 +2789,8 @@ MLP_NORM_FUSED = __import__("os").environ.get("PHC_MLP_NORM_FUSED", "1") != "0"
 # 128 and 12.9 k rows the two folded GEMMs cost what the GEMMs + element-wise launches they replace cost (0.7168 vs 0.7172 ms,
 # three alternating runs) with 8 launches per step fewer (65 -> 57), and at 32 graphs per batch the step is launch-bound: 0.492 ->
 # 0.462 ms.  On everywhere the kernels serve; PHC_MLP_NORM_FUSED_MIN_WORK sets a rows x width threshold for A/B runs.
+# ... also for layers that drop (the reference's default and published settings): the mask inside the node's norm passes
+MLP_NORM_DROPOUT = __import__("os").environ.get("PHC_MLP_NORM_DROPOUT", "1") != "0"
 MLP_NORM_FUSED_MIN_WORK = int(__import__("os").environ.get("PHC_MLP_NORM_FUSED_MIN_WORK", "0"))
 
 
@@ -2900,9 +2902,10 @@ class PendingNorm:
     and stopped in front of its last launch.  The consumer is the next layer's encoded sum aggregation (``run_fused``: one launch
     does both and writes x on the way); anybody else calls ``materialize`` first — the stand-alone pass, identical results."""
 
-    def __init__(self, y2, acc2, outer, aff_o, act_o, skip, n_valid, out, save_o):
+    def __init__(self, y2, acc2, outer, aff_o, act_o, skip, n_valid, out, save_o, drop=(0.0, 0, 0, None)):
         self.y2, self.acc2, self.outer, self.aff_o, self.act_o, self.skip, self.n_valid = y2, acc2, outer, aff_o, act_o, skip, n_valid
         self.out, self.save_o = out, save_o
+        self.drop = drop                                      # (p, same_k, site, rng state): phm_dropout behind the activation
         self.done = False
 
     def _norm_args(self):
@@ -2919,8 +2922,8 @@ class PendingNorm:
         w, b, rm, rv, nbt, no = self._norm_args()
         L.check(lib.phc_bn_fwd_from_partials(
             L.ptr(self.y2), L.ptr(self.acc2), None, 0, w, b, rm, rv, nbt, no, L.ptr(self.n_valid), N, h,
-            float(self.outer["momentum"]), float(self.outer["eps"]), self.act_o, L.ptr(self.skip), L.ptr(self.out), L.ptr(self.save_o), 0.0,
-            0, 0, None, L.stream_ptr(self.y2.device)), "phc_bn_fwd_from_partials")
+            float(self.outer["momentum"]), float(self.outer["eps"]), self.act_o, L.ptr(self.skip), L.ptr(self.out), L.ptr(self.save_o),
+            self.drop[0], self.drop[1], self.drop[2], L.ptr(self.drop[3]), L.stream_ptr(self.y2.device)), "phc_bn_fwd_from_partials")
         if L.PROF_ON:
             L.account("bn_apply", 2.0 * N * h, 4.0 * N * h * (3 if self.skip is not None else 2))
         self.done = True
@@ -2990,8 +2993,15 @@ class _MLPNormFn(torch.autograd.Function):
             L.ptr(b2), N, h, h, L.ptr(y2), L.ptr(acc2), None, None, sp), "phc_gemm_prebuilt_xf_acc")
         _tap(z1, save_i, n_valid, act_i)
         _tap(y2, save_o, n_valid, act_o)
-        pend = PendingNorm(y2, acc2, outer, tuple(aff_o), act_o, skip, n_valid, out, save_o)
-        if meta.get("defer_apply"):
+        # dropout behind the outer norm's activation (models.py:211-213): the mask rides in the norm's apply pass here and in the norm
+        # backward folded into the dx GEMM (HS_DR) — never deferred into another launch (those forms do not draw masks)
+        drop = (0.0, 0, 0, None)
+        dp = meta.get("dropout")
+        if dp is not None and dp[0] > 0.0:
+            drop = (float(dp[0]), (h // no) if dp[1] else 0, int(dp[2]), rng_state(dev))
+        ctx.drop = drop
+        pend = PendingNorm(y2, acc2, outer, tuple(aff_o), act_o, skip, n_valid, out, save_o, drop)
+        if meta.get("defer_apply") and drop[0] == 0.0:
             meta["pending"] = pend                           # the caller hands it to the next layer's aggregation (or materialises it)
         else:
             pend.materialize()
@@ -3025,13 +3035,19 @@ class _MLPNormFn(torch.autograd.Function):
         ds = torch.empty((N, h), dtype=torch.float32, device=dev)
         dwb_o = torch.empty(2 * h, dtype=torch.float32, device=dev)
         dwb_i = torch.empty(2 * h, dtype=torch.float32, device=dev)
-        L.check(lib.phc_bn_bwd_partial_acc(L.ptr(dout_), L.ptr(y2), L.ptr(save_o), L.ptr(n_valid), N, h, act_o, L.ptr(acc_o), sp),
-                "phc_bn_bwd_partial_acc")
+        drop = ctx.drop
+        if drop[0] > 0.0:
+            L.check(lib.phc_bn_bwd_partial_acc_drop(L.ptr(dout_), L.ptr(y2), L.ptr(save_o), L.ptr(n_valid), N, h, act_o, L.ptr(acc_o),
+                                                    drop[0], drop[1], drop[2], L.ptr(drop[3]), sp), "phc_bn_bwd_partial_acc_drop")
+        else:
+            L.check(lib.phc_bn_bwd_partial_acc(L.ptr(dout_), L.ptr(y2), L.ptr(save_o), L.ptr(n_valid), N, h, act_o, L.ptr(acc_o), sp),
+                    "phc_bn_bwd_partial_acc")
         d = L.GemmBaDesc()
         d.dout, d.bn_x, d.bn_stat, d.sums_acc, d.n_valid_dev = L.ptr(dout_), L.ptr(y2), L.ptr(save_o), L.ptr(acc_o), L.ptr(n_valid)
         d.dz, d.dwb, d.Mk4, d.y = L.ptr(dy2), L.ptr(dwb_o), L.ptr(pre2[3]), L.ptr(da)
         d.N, d.K, d.Nout, d.act = N, h, h, act_o
         d.bw_act, d.bw_x, d.bw_stat, d.bw_sums_acc = act_i, L.ptr(z1), L.ptr(save_i), L.ptr(acc_i)
+        d.drop_p, d.drop_same_k, d.drop_site, d.rng_state = drop[0], drop[1], drop[2], L.ptr(drop[3])
         L.check(lib.phc_gemm_bwd_apply(_C.byref(d), sp), "phc_gemm_bwd_apply(outer)")
         d2 = L.GemmBaDesc()
         d2.dout, d2.bn_x, d2.bn_stat, d2.sums_acc, d2.n_valid_dev = L.ptr(da), L.ptr(z1), L.ptr(save_i), L.ptr(acc_i), L.ptr(n_valid)
@@ -3091,19 +3107,20 @@ def _norm_meta(nm):
                 weights=[m.weight for m in mods] if nm.affine else [], biases=[m.bias for m in mods] if nm.affine else [])
 
 
-def mlp_norm_fused(s, skip, n_valid, mlp, outer_norm, activation: str, skip_handoff=None, defer_apply: bool = False):
+def mlp_norm_fused(s, skip, n_valid, mlp, outer_norm, activation: str, skip_handoff=None, defer_apply: bool = False, dropout=None):
     """``_mlp_norm_fused`` (below); an aggregation parked on ``s`` (PendingAggregate) is handed to the node's first GEMM, or launched
-    here when the node does not apply."""
+    here when the node does not apply.  ``dropout`` = (p, same, site): phm_dropout behind the outer norm's activation (round 5)."""
     pa = getattr(s, "_phc_pending_agg", None)
     if pa is not None:
         s._phc_pending_agg = None
-    out = _mlp_norm_fused(s, skip, n_valid, mlp, outer_norm, activation, skip_handoff, defer_apply, pa)
+    out = _mlp_norm_fused(s, skip, n_valid, mlp, outer_norm, activation, skip_handoff, defer_apply, pa, dropout)
     if out is None and pa is not None:
         pa.materialize()
     return out
 
 
-def _mlp_norm_fused(s, skip, n_valid, mlp, outer_norm, activation: str, skip_handoff=None, defer_apply: bool = False, pending_agg=None):
+def _mlp_norm_fused(s, skip, n_valid, mlp, outer_norm, activation: str, skip_handoff=None, defer_apply: bool = False, pending_agg=None,
+                    dropout=None):
     """``act(outer_norm(mlp(s))) + skip`` for a PHMMLP with an inner naive batch-norm, as one autograd node (training mode),
     or ``None`` when the preconditions do not hold: both linears square of width 128 or 256 with prebuilt k4 operands (inside
     ``prebuilt_H``), both norms naive batch-norms with running statistics, fusable activations, 16-byte aligned dense rows."""
@@ -3129,8 +3146,12 @@ def _mlp_norm_fused(s, skip, n_valid, mlp, outer_norm, activation: str, skip_han
         return None
     if any(b is not None and not b.is_contiguous() for b in (l1.b, l2.b)):
         return None
+    dropping = dropout is not None and dropout[0] > 0.0
+    if dropping and not (h in (128, 256, 180, 200) and h % 4 == 0 and (not dropout[1] or (h // outer["n_comp"]) % 4 == 0)):
+        return None                                          # (the mask's column groups; the HS_DR instantiations)
     meta = dict(pre1=pre1, pre2=pre2, inner=inner, outer=outer, act_inner=act_i, act_outer=act_o, skip_handoff=skip_handoff,
-                defer_apply=bool(defer_apply and NORM_INTO_AGGREGATE), pending_agg=pending_agg)
+                defer_apply=bool(defer_apply and NORM_INTO_AGGREGATE and not dropping), pending_agg=pending_agg,
+                dropout=dropout if dropping else None)
     affine = inner["weights"] + inner["biases"] + outer["weights"] + outer["biases"]
     out = _MLPNormFn.apply(s, skip, n_valid, meta, l1.phm_rule, l1.W, l1.b, l2.phm_rule, l2.W, l2.b, *affine)
     pend = meta.pop("pending", None)

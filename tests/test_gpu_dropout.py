@@ -103,3 +103,86 @@ def test_training_step_with_the_reference_default_dropout_under_graph_replay():
         a = model(step.data)
         b = model(step.data)
     assert torch.equal(a, b)
+
+
+# ---- dropout INSIDE the fused MLP + norm node (round 5: the mask in the norm's apply pass and in the norm backward folded into the dx
+# GEMM, HS_DR) against the separate nodes that layers with dropout used before: the masks are a function of (seed, step, site, row,
+# column) only, so both paths draw the SAME masks and the whole step must agree ---------------------------------------------------
+_DROP_WORKLOADS = {
+    "molhiv_small_drop": dict(dataset="molhiv", batch_size=48, phm_dim=4, hidden=128, layers=3, d_units=[64, 32], target_dim=1, sc_type="first",
+                              dropout_mpnn=[0.2, 0.1, 0.3], dropout_dn=[0.2, 0.1], activation="swish"),
+    "molhiv_small_drop_same": dict(dataset="molhiv", batch_size=48, phm_dim=4, hidden=128, layers=2, d_units=[64, 32], target_dim=1, sc_type="first",
+                                   dropout_mpnn=[0.25, 0.25], same_dropout=True, activation="swish"),
+    "zinc_small_256_drop": dict(dataset="zinc", batch_size=64, phm_dim=8, hidden=256, layers=2, d_units=[64, 32], target_dim=1, sc_type="last",
+                                regression=True, dropout_mpnn=[0.2, 0.2], activation="swish"),
+    "hiv_pub_200_drop": dict(dataset="molhiv", batch_size=64, phm_dim=4, hidden=200, layers=2, d_units=[128, 32], target_dim=1, sc_type="first",
+                             msg_aggr="softmax", dropout_mpnn=[0.2, 0.2], dropout_dn=[0.3, 0.1], activation="swish"),
+    "zinc_pub_180_drop_relu": dict(dataset="zinc", batch_size=64, phm_dim=4, hidden=180, layers=2, d_units=[180, 80], target_dim=1, sc_type="last",
+                                   regression=True, dropout_mpnn=[0.1, 0.1]),
+}
+
+
+def _drop_step(workload, fused, graph=False):
+    from phc_gnn_amd import graphed, harness, lib as L, ops
+    from phc_gnn_amd.optim import ClipAdam
+    harness.WORKLOADS.setdefault(workload, _DROP_WORKLOADS[workload])
+    keep = ops.MLP_NORM_DROPOUT
+    ops.MLP_NORM_DROPOUT = fused
+    try:
+        dev = torch.device(DEV)
+        model = harness.build_model(workload, DEV, seed=4).train()
+        if _DROP_WORKLOADS[workload].get("same_dropout"):
+            model.same_dropout = True
+        gb = harness.make_batch(workload, seed=9)
+        cfg = harness.StepConfig(regression=bool(_DROP_WORKLOADS[workload].get("regression")), optimizer=False, weight_decay=0.0)
+        ops.rng_seed(dev, 777)
+        if not graph:                                        # (the launch profiler's events cannot be recorded inside a capture)
+            L.prof_enable(True)
+            L.prof_reset()
+        try:
+            if graph:
+                n_max, e_max = graphed.bucket_shape([gb])
+                padded = graphed.padded_to_device(graphed.pad_batch(gb, n_max + 21, e_max + 33), DEV)
+                sd = {k: v.clone() for k, v in model.state_dict().items()}
+                step = graphed.GraphedTrainStep(model, ClipAdam(model.parameters(), lr=1e-3), cfg, padded, warmup=2)
+                model.load_state_dict(sd)
+                ops.rng_seed(dev, 777)
+                loss = step.step(padded)
+            else:
+                loss = harness.train_step(model, harness.to_device(gb, DEV), None, cfg)
+            torch.cuda.synchronize()
+            names = {k for k, v in L.prof_read().items() if v["launches"] > 0} if not graph else set()
+        finally:
+            if not graph:
+                L.prof_enable(False)
+        return loss.detach().clone(), {k: p.grad.clone() for k, p in model.named_parameters() if p.grad is not None}, names
+    finally:
+        ops.MLP_NORM_DROPOUT = keep
+
+
+@pytest.mark.parametrize("workload", list(_DROP_WORKLOADS))
+def test_dropout_inside_the_fused_mlp_norm_node_equals_the_separate_nodes(workload):
+    """Loss and every gradient of one training step (same seed: same masks) with the layers' dropout inside the fused node
+    (ops.MLP_NORM_DROPOUT) and on the separate norm nodes; widths 128 / 256 / 200 / 180, `same` masks, softmax aggregation, ReLU."""
+    on = _drop_step(workload, True)
+    off = _drop_step(workload, False)
+    assert abs(float(on[0]) - float(off[0])) <= 1e-5 * max(abs(float(off[0])), 1e-30), (float(on[0]), float(off[0]))
+    relu = _DROP_WORKLOADS[workload].get("activation", "relu") == "relu"
+    for k in off[1]:
+        ref = off[1][k]
+        if float(ref.abs().max()) < 1e-7:
+            continue
+        err = float((on[1][k] - ref).abs().max()) / max(float(ref.abs().max()), 1e-30)
+        assert err <= (2e-3 if relu else 3e-5), (k, err)          # (ReLU: a gate at the kink may fall on the other side in another summation order)
+    # the fused node really ran: the separate nodes' element-wise norm backward is gone from the layers (the head keeps its own)
+    assert "bn_bwd_apply" in off[2]
+
+
+def test_dropout_inside_the_fused_node_draws_a_new_mask_every_replay():
+    """hipGraph replay: the step counter is a device value — two replays from the same state give different losses, the same seed and
+    step the same loss (the fused node's three mask sites agree with each other, or the gradients above would not match)."""
+    a = _drop_step("molhiv_small_drop", True, graph=True)
+    b = _drop_step("molhiv_small_drop", True, graph=True)
+    assert float(a[0]) == float(b[0])
+    e = _drop_step("molhiv_small_drop", True, graph=False)       # the eager step from the same state, seed and step counter: the same masks
+    assert abs(float(a[0]) - float(e[0])) <= 1e-5 * abs(float(e[0]))
