@@ -2266,18 +2266,7 @@ static int step_tail_impl(const phc_phm_grad_job *jobs, int num_jobs, const phc_
         t.nr_atom = (unsigned)((ma.R * h + 63) / 64);
     }
     t.nr_phm = gl.nb_reduce;
-#ifdef PHC_EXP_TAIL_SKIP
-    {   // experiment build: leave one family of workgroups out of the first launch (results are wrong, timing only)
-        const char *skip = getenv("PHC_EXP_TAIL_SKIP");
-        if (skip && strstr(skip, "atom")) t.nb_atom = 0;
-        if (skip && strstr(skip, "bond")) t.nb_bond = 0;
-        if (skip && strstr(skip, "dh")) gl.nb_partial = 0;
-    }
-#endif
-    {
-        static const int knob = getenv("PHC_TAIL_DH_FIRST") ? atoi(getenv("PHC_TAIL_DH_FIRST")) : -1;
-        t.dh_first = knob > 0 ? 1 : 0;                       // measured within noise of the family order: off
-    }
+    t.dh_first = 0;                                          // (the long dH workgroups first: measured within noise of the family order; switch removed in round 5)
     if (getenv("PHC_DEBUG_PLANS"))
         fprintf(stderr, "[phc tail] atoms: %lld nodes direct=%d wgs=%u | bonds: %d jobs direct=%d wgs=%u | dH wgs=%u (own launch %u)\n",
                 (long long)N_atoms, t.atom_direct, t.nb_atom, num_tjobs, t.counts_b ? 1 : 0, t.nb_bond, gl.nb_partial, gl.nb_direct);

@@ -60,7 +60,7 @@ __global__ __launch_bounds__(HS_AGW_THREADS) void gemm_hs_agw_kernel(GemmHsArgs 
     const int count = a.n_valid ? min(*a.n_valid, M) : M;
     const bool live = lane < H4;                                  // this lane's 16-byte chunk exists in a row
     const int c4 = live ? lane : 0;
-    auto lds_barrier = [] {                                       // LDS traffic only: __syncthreads() would also wait for stores / prefetches
+    auto lds_barrier = []() PHC_HS_INLINE {                                       // LDS traffic only: __syncthreads() would also wait for stores / prefetches
         asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
         __builtin_amdgcn_s_barrier();
     };
@@ -70,16 +70,16 @@ __global__ __launch_bounds__(HS_AGW_THREADS) void gemm_hs_agw_kernel(GemmHsArgs 
     const float4 zf4 = make_float4(0.f, 0.f, 0.f, 0.f);
 
     // ---- per-step metadata of this wavefront's two rows (A = 2 w, B = 2 w + 1 of the step), as vector loads on a few lanes -------
-    auto rowA_of = [&](int sl) { return (gfirst + sl * gstride) * 16 + 2 * wave; };
+    auto rowA_of = [&](int sl) PHC_HS_INLINE { return (gfirst + sl * gstride) * 16 + 2 * wave; };
     // row pointers of rows A, A + 1, A + 2 (lanes 0..2; clamped to the table's last entry: a row past M is empty)
-    auto load_ptrs = [&](int sl) {
+    auto load_ptrs = [&](int sl) PHC_HS_INLINE {
         const int r = min(rowA_of(min(sl, my_steps - 1)) + min(lane, 2), M);
         return ag.rowptr[r];
     };
     struct Meta {
         int e0[2], e1[2];
     };
-    auto ptrs_of = [&](int v) {
+    auto ptrs_of = [&](int v) PHC_HS_INLINE {
         Meta m;
         m.e0[0] = __builtin_amdgcn_readlane(v, 0);
         m.e1[0] = m.e0[1] = __builtin_amdgcn_readlane(v, 1);
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(HS_AGW_THREADS) void gemm_hs_agw_kernel(GemmHsArgs 
         return m;
     };
     // sources and codes of the first NE edges of both rows: lanes 0..NE-1 row A, lanes 8..8+NE-1 row B (an empty row reads row pointers)
-    auto load_edges = [&](const Meta &m, int &srcs, unsigned &cods) {
+    auto load_edges = [&](const Meta &m, int &srcs, unsigned &cods) PHC_HS_INLINE {
         const int rsel = (lane >> 3) & 1, j = lane & 7;
         const int e0 = rsel ? m.e0[1] : m.e0[0], e1 = rsel ? m.e1[1] : m.e1[0];
         const bool any = e0 < e1;
@@ -101,11 +101,11 @@ __global__ __launch_bounds__(HS_AGW_THREADS) void gemm_hs_agw_kernel(GemmHsArgs 
     struct Raw {
         float4 v[NE + 1], rr[NORMED ? NE + 1 : 1];               // edges 0..NE-1, then the row itself
     };
-    auto load_row = [&](int r, float4 &v, float4 &rr) {
+    auto load_row = [&](int r, float4 &v, float4 &rr) PHC_HS_INLINE {
         v = Y4[(size_t)r * H4];
         if constexpr (NORMED) rr = S4[(size_t)r * H4];
     };
-    auto issue_raw = [&](Raw &w, int d, int e0, int e1, int srcs, int which) {
+    auto issue_raw = [&](Raw &w, int d, int e0, int e1, int srcs, int which) PHC_HS_INLINE {
         const int deg = e1 - e0;
 #pragma unroll
         for (int j = 0; j < NE; ++j) {
@@ -118,7 +118,7 @@ __global__ __launch_bounds__(HS_AGW_THREADS) void gemm_hs_agw_kernel(GemmHsArgs 
         if ((NORMED || ag.add_self) && d < M) load_row(d, w.v[NE], w.rr[NORMED ? NE : 0]);
     };
     const float4 *tb = reinterpret_cast<const float4 *>(agw_tbl) + c4;   // this lane's chunk of every table row
-    auto xval = [&](const float4 v, const float4 rr, int r) {
+    auto xval = [&](const float4 v, const float4 rr, int r) PHC_HS_INLINE {
         if constexpr (!NORMED) {
             return v;
         } else {
@@ -138,7 +138,7 @@ __global__ __launch_bounds__(HS_AGW_THREADS) void gemm_hs_agw_kernel(GemmHsArgs 
             return o;
         }
     };
-    auto message = [&](const float4 v0, const float4 rr, int s, unsigned code) {
+    auto message = [&](const float4 v0, const float4 rr, int s, unsigned code) PHC_HS_INLINE {
         float4 v = xval(v0, rr, s);
 #pragma unroll
         for (int f = 0; f < HS_AG_MAX_F; ++f) {
@@ -150,7 +150,7 @@ __global__ __launch_bounds__(HS_AGW_THREADS) void gemm_hs_agw_kernel(GemmHsArgs 
         return v;
     };
     // add one row up from its pieces -> the image line of row `rs` (0..15) of buffer `buf`; returns s and x of the row for the stores
-    auto finish = [&](const Raw &w, int d, int e0, int e1, int srcs, unsigned cods, int which, int buf, int rs) {
+    auto finish = [&](const Raw &w, int d, int e0, int e1, int srcs, unsigned cods, int which, int buf, int rs) PHC_HS_INLINE {
         const bool valid = d < M;
         const int deg = e1 - e0;
         const float4 selfv = xval(w.v[NE], w.rr[NORMED ? NE : 0], valid ? d : 0);
@@ -182,7 +182,7 @@ __global__ __launch_bounds__(HS_AGW_THREADS) void gemm_hs_agw_kernel(GemmHsArgs 
         image[buf][rs * ISTRIDE + lane] = f32x4_t{tot.x, tot.y, tot.z, tot.w};
     };
     // (s of the row is re-read from the image line it was written to: 8 registers fewer across the metadata rotation)
-    auto store_row = [&](int d, int buf, int rs) {
+    auto store_row = [&](int d, int buf, int rs) PHC_HS_INLINE {
         if (d < M && live) {
             const f32x4_t t4 = image[buf][rs * ISTRIDE + lane];
             reinterpret_cast<float4 *>(ag.s_out)[(size_t)d * H4 + c4] = make_float4(t4[0], t4[1], t4[2], t4[3]);
@@ -342,7 +342,7 @@ __global__ __launch_bounds__(HS_AGW_THREADS) void gemm_hs_agw_kernel(GemmHsArgs 
 #pragma unroll
         for (int t = 0; t < TPW; ++t) acc[t] = *reinterpret_cast<const f32x4_t *>(s_bias + col0 + 16 * t + 4 * kq);
         f32x4_t fr[2];
-        auto mfma_range = [&](auto g0c, auto g1c) {
+        auto mfma_range = [&](auto g0c, auto g1c) PHC_HS_INLINE {
             constexpr int g0 = decltype(g0c)::value, g1 = decltype(g1c)::value;
             unsigned long long q0 = 0;
             if (a.stamps) q0 = __builtin_amdgcn_s_memrealtime();
@@ -362,7 +362,7 @@ __global__ __launch_bounds__(HS_AGW_THREADS) void gemm_hs_agw_kernel(GemmHsArgs 
         const int nA = rowA_of(min(i + 1, my_steps - 1)), nB = nA + 1;
         // rotate: step i + 2's sources / codes (issued an iteration ago) become "next"; step i + 3's row pointers (ditto) are decoded
         // and its sources / codes go out; step i + 4's row pointers go out
-        auto rotate = [&]() {
+        auto rotate = [&]() PHC_HS_INLINE {
             mn = m2; srcs_n = srcs2; cods_n = cods2;
             m2 = ptrs_of(pv3);
             load_edges(m2, srcs2, cods2);
@@ -370,7 +370,7 @@ __global__ __launch_bounds__(HS_AGW_THREADS) void gemm_hs_agw_kernel(GemmHsArgs 
         };
         // the gather work of step i + 1.  FULL: both rows at once, then the rows of step i + 2 go out.  Otherwise in two halves around
         // the MFMAs: (row A, issue row B) and (row B, rotate, issue row A of step i + 2).
-        auto gather_a = [&]() {
+        auto gather_a = [&]() PHC_HS_INLINE {
             if (!more) return;
             unsigned long long q0 = 0;
             if (a.stamps) q0 = __builtin_amdgcn_s_memrealtime();
@@ -378,7 +378,7 @@ __global__ __launch_bounds__(HS_AGW_THREADS) void gemm_hs_agw_kernel(GemmHsArgs 
             if constexpr (!FULL) issue_raw(rawA, nB, mn.e0[1], mn.e1[1], srcs_n, 1);
             if (a.stamps) ph[2] += __builtin_amdgcn_s_memrealtime() - q0;
         };
-        auto gather_b = [&]() {
+        auto gather_b = [&]() PHC_HS_INLINE {
             if (!more) return;
             unsigned long long q0 = 0;
             if (a.stamps) q0 = __builtin_amdgcn_s_memrealtime();

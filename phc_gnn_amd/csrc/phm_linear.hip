@@ -1523,11 +1523,8 @@ static int launch_hs(const GemmHsArgs &a, int K, const XfAcc &xa, hipStream_t s)
     if (K == 256 && a.Nout == 256) return launch_hs_cfg<256, 2, 8, FLAGS>(a, xa, s);
     if (K == 256 && a.Nout == 128) return launch_hs_cfg<256, 2, 4, FLAGS>(a, xa, s);
     if (K == 128 && a.Nout == 256) return launch_hs_cfg<128, 2, 8, FLAGS>(a, xa, s);
-    // 128 x 128 at config-5 scale (millions of rows: thousands of steps per workgroup): 32-row steps halve the per-row share of the
-    // step's fixed costs (DMA issue, counted wait, barrier) — measured worth nothing (10 M rows, two workgroups per CU: 2868 -> 2857 us,
-    // 114.3 -> 114.7 TFLOP/s; one per CU 3063 -> 2961): the launch is not bound by them.  Off; PHC_HS_RB2_MIN_ROWS=<rows> turns it on.
-    static const long long rb2_min = getenv("PHC_HS_RB2_MIN_ROWS") ? atoll(getenv("PHC_HS_RB2_MIN_ROWS")) : 0;
-    if (rb2_min > 0 && a.M >= rb2_min) return launch_hs_cfg<128, 2, 4, FLAGS, 2>(a, xa, s);
+    // (128 x 128 with 32-row steps at config-5 scale was measured worth nothing — 10 M rows, two workgroups per CU: 2868 -> 2857 us —
+    // and its instantiations were removed in round 5; the kernel's RB parameter remains)
     return launch_hs_cfg<128, 2, 4, FLAGS>(a, xa, s);
 }
 
@@ -1574,19 +1571,15 @@ static int launch_gemm(const float *X, const float *A, const float *W, const flo
     if (M == 0) return PHC_OK;
     ProfScope prof(TRANS ? K_PHM_GEMM_DX : K_PHM_GEMM_FWD, s);
     const bool vec4 = (K % 4 == 0) && ((reinterpret_cast<uintptr_t>(X) & 15) == 0);
-    const bool stream = vec4 && K <= GEMM_STREAM_MAX_K && !getenv("PHC_GEMM_TILED");
+    const bool stream = vec4 && K <= GEMM_STREAM_MAX_K;
     const bool wide_k = K > 128;                       // the [K x 128] panel no longer fits next to 8 staging buffers
     const bool big = M >= GEMM_BIG_M && Nout > 64;
-    // molecule batches: 32-column panels give 4x the wavefronts of the 128-column config, each a quarter as long
-    // (measured on MI355X: no gain for y = x.H, slower for dx — kept as an opt-in experiment)
-    const bool small32 = M <= 24 * 1024 && Nout >= 64 && getenv("PHC_GEMM_32") != nullptr;
+    // (32-column panels for molecule batches: measured no gain for y = x.H, slower for dx — removed in round 5)
 #define PHC_GEMM_LAUNCH(NP)                                                                                              \
     if (stream && big && wide_k)                                                                                         \
         launch_stream_cfg<TRANS, NP, 64, 8>(X, A, W, bias, residual, out, M, K, Nout, n, kin, kout, 1, s);                \
     else if (stream && big)                                                                                              \
         launch_stream_cfg<TRANS, NP, 128, 8>(X, A, W, bias, residual, out, M, K, Nout, n, kin, kout, 1, s);               \
-    else if (stream && small32)                                                                                          \
-        launch_stream_cfg<TRANS, NP, 32, 4>(X, A, W, bias, residual, out, M, K, Nout, n, kin, kout, 3, s);                \
     else if (stream)                                                                                                     \
         launch_stream_cfg<TRANS, NP, 64, 4>(X, A, W, bias, residual, out, M, K, Nout, n, kin, kout, 2, s);                \
     else if (big)                                                                                                        \

@@ -17,8 +17,6 @@ import torch
 from . import lib as L
 
 _CACHE_SIZE = 16
-_NO_PAIR = bool(__import__('os').environ.get('PHC_NO_CSR_PAIR'))
-_NO_BUCKETED = bool(__import__('os').environ.get('PHC_NO_CSR_BUCKETED'))
 BUCKETED_MIN_ITEMS, BUCKETED_MIN_KEYS = 1 << 20, 1 << 16
 _cache: "OrderedDict[tuple, EdgeStructure]" = OrderedDict()
 
@@ -35,7 +33,7 @@ def _build_sorted(key: torch.Tensor, other: Optional[torch.Tensor], num_keys: in
         rowptr = torch.empty(num_keys + 1, dtype=torch.int32, device=dev)
         col = torch.empty(E, dtype=torch.int32, device=dev)
         perm = torch.empty(E, dtype=torch.int32, device=dev)
-    if E >= BUCKETED_MIN_ITEMS and num_keys >= BUCKETED_MIN_KEYS and num_keys <= 16384 * 4096 and not _NO_BUCKETED:
+    if E >= BUCKETED_MIN_ITEMS and num_keys >= BUCKETED_MIN_KEYS and num_keys <= 16384 * 4096:
         # large graphs: partition by key range first, then sort bucket by bucket in LDS (same result, ~2x faster at 10 M / 50 M;
         # rows longer than 2048 items — a hub of a power-law graph — are sorted by a workgroup-wide bitonic network in both paths)
         ws_bytes = lib.phc_csr_bucketed_ws_bytes(E, num_keys)
@@ -126,7 +124,7 @@ class EdgeStructure:
         features behind the packed codes) changed IN PLACE: the per-batch preprocessing of a fixed-shape step whose
         static buffers were reloaded (graphed.GraphedTrainStep captures this as its own small graph)."""
         pair_rebuilt = False
-        if self._csr is not None and self._csc is not None and self.num_edges > 0 and not _NO_PAIR and \
+        if self._csr is not None and self._csc is not None and self.num_edges > 0 and \
                 0 < max(self.num_src, self.num_dst) <= self.PAIR_MAX_ROWS:
             self._build_pair(reuse=True)
             pair_rebuilt = True
@@ -207,7 +205,7 @@ class EdgeStructure:
         """Build what a forward (and, with ``for_backward``, its backward) will walk.  A differentiable forward wants
         the source-sorted view later: both views are then built side by side (5 launches instead of 22).  ``codes_for
         = (int64 bond tensor, vocab_c, F)``: the caller will ask for ``packed_codes`` of it next — they ride along."""
-        if (for_backward and self._csr is None and self._csc is None and self.num_edges > 0 and not _NO_PAIR
+        if (for_backward and self._csr is None and self._csc is None and self.num_edges > 0
                 and 0 < max(self.num_src, self.num_dst) <= self.PAIR_MAX_ROWS):
             self._build_pair(codes_for=codes_for)
         return self

@@ -1677,7 +1677,6 @@ def global_add_pool(x: torch.Tensor, batch, num_graphs: Optional[int] = None, is
     return _SegmentSumFn.apply(x, st)
 
 
-_POOL_SEGPTR = bool(__import__("os").environ.get("PHC_POOL_SEGPTR"))      # A/B switch: segment pointers from their own launch
 
 
 class _GatedSegmentSumFn(torch.autograd.Function):
@@ -1688,7 +1687,7 @@ class _GatedSegmentSumFn(torch.autograd.Function):
         lib = L.load()
         ctx.dx_handoff = dx_handoff
         dev = L.require_device(x, gate)
-        if pending_gate is not None and not (st.is_sorted and st._csr is None and not _POOL_SEGPTR):
+        if pending_gate is not None and not (st.is_sorted and st._csr is None):
             pending_gate.materialize()
             pending_gate = None
         x_, g_ = L.f32c(x), L.f32c(gate)
@@ -1702,7 +1701,7 @@ class _GatedSegmentSumFn(torch.autograd.Function):
             pg = None
         if pg is not None:
             pass
-        elif st.is_sorted and st._csr is None and not _POOL_SEGPTR:
+        elif st.is_sorted and st._csr is None:
             # collated batch: the workgroups find their rows in the sorted `batch` vector themselves (no pointer launch)
             L.check(lib.phc_gated_pool_fwd_sorted(L.ptr(x_), L.ptr(g_), L.ptr(st.batch), N, st.num_segments, h, n_comp,
                                                   L.ptr(out), L.stream_ptr(dev)), "phc_gated_pool_fwd_sorted")
