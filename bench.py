@@ -66,14 +66,14 @@ PMC_NAMES = {"phm_gemm_fwd": ("gemm_hs16_kernel<128, 2, 4, 1, 4, 1>", "gemm_hs16
              "phm_gemm_dx": ("gemm_hs16_kernel<128, 2, 4, 1, 4, 8>", "gemm_hs16_kernel<128, 2, 4, 1, 4, 12>",
                              "gemm_hs16_kernel<256, 2, 8, 1, 4, 8>", "gemm_hs16_kernel<256, 2, 8, 1, 4, 12>"),
              # the layer's aggregation inside its first GEMM (molecule batches, round 4): GEMM flops only are booked
-             "phm_gemm_ag_fwd": ("gemm_hs_ag_kernel",),
+             "phm_gemm_ag_fwd": ("gemm_hs_ag_kernel", "gemm_hs_agw_kernel"),          # (round 5: the wide layers' form)
              "phm_dH_partial": ("tail_partial_kernel",), "aggregate_enc_fwd": ("aggregate_encp_direct_fwd_kernel", "aggregate_norm_fwd_kernel"),
              "aggregate_enc_dx": ("aggregate_dx_rows_kernel",), "aggregate_fwd": ("aggregate_fwd_kernel",),
              "bn_apply": ("bn_apply_acc_kernel",), "bn_bwd_apply": ("bn_bwd_apply_acc_kernel",), "bn_bwd_partial": ("bn_bwd_partial_kernel",),
              "bn_stats_partial": ("bn_stats_partial_kernel",), "table_grad": ("table_grad_mfma_kernel<1",)}
 
 
-PMC_FILE = "r04_pmc_traffic.json"
+PMC_FILE = "r05_pmc_traffic.json"
 # below this footprint a row walker's rows are served by the L2s / the 256 MiB Infinity Cache, not by HBM
 # (MI355X_MICROARCH.md: 38 MB table of random rows 8.6 TB/s, 151 MB 7.4-7.9 TB/s, HBM sweep 6.0-6.1 TB/s)
 INFINITY_CACHE_BYTES = 256 * 1024 * 1024

@@ -104,7 +104,7 @@ us = lambda t: t * 0.01
 names = ["image barrier", "MFMAs", "row A", "row B", "rotate + issue", "epilogue + stores"]
 widx = torch.arange(stamps.numel() // 12).view(-1)[(stamps.cpu().view(-1, 12)[:, 0] != 0)] % 8          # wavefront index in its workgroup
 for ns in sorted(set(steps.tolist())):
-    for grp, gname in ((widx < 4, "waves 0-3 (MFMA first)"), (widx >= 4, "waves 4-7 (gather first)")):
+    for grp, gname in ((widx < 4, "wavefronts 0-3"), (widx >= 4, "wavefronts 4-7 (their SIMD partners)")):
         sel = wv[(steps == ns) & grp]
         if len(sel) == 0:
             continue
