@@ -356,6 +356,84 @@ def test_readout_in_one_launch_equals_the_three_launches(B, sizes, normed, act, 
         assert float((a_ - b_).abs().max()) <= 2e-6 * max(float(b_.abs().max()), 1e-30), (key, float((a_ - b_).abs().max()), float(b_.abs().max()))
 
 
+@pytest.mark.parametrize("B,sizes", [(7, "small"), (300, "molecules"), (40, "big")])
+@pytest.mark.parametrize("normed,act,with_skip", [(False, "relu", False), (True, "relu", True), (True, "swish", False)])
+@pytest.mark.parametrize("n,k", [(4, 32), (8, 32), (4, 64)])
+def test_readout_in_one_launch_against_the_oracle(B, sizes, normed, act, with_skip, n, k):
+    """phc_readout_fused_fwd DIRECTLY against the oracle: x = act(norm(y)) + skip (norm.py:30-35,
+    models.py:208-215), out = soft_attention_pool(x, batch; PHMLinear h -> h, Linear h -> k) (pooling.py:57-66, layers.py:399-414) —
+    the launch takes the composed gate operand M = H . Wg^T and bias c = b . Wg^T + bg, built here in float64 from the layer's own
+    parameters; float64 oracle on the host, 1e-5 of each tensor's largest entry."""
+    import ctypes as C
+    from oracle import phc_oracle as O
+    from phc_gnn_amd import lib as L
+    lib = L.load()
+    h, kg = n * k, k
+    g = torch.Generator().manual_seed(B + h)
+    hi = dict(small=5, molecules=45, big=300)[sizes]
+    cnt = torch.randint(0, hi, (B,), generator=g)
+    cnt[B // 2] = 0
+    cnt[0] = max(int(cnt[0]), 1)
+    batch_h = torch.repeat_interleave(torch.arange(B), cnt)
+    N = int(batch_h.numel())
+    if not lib.phc_readout_fused_supported(N, B, h, n, kg):
+        pytest.skip("outside the fused form")
+    batch = batch_h.to(DEV)
+    nv = torch.tensor([N], dtype=torch.int32, device=DEV)
+    sp = L.stream_ptr(torch.device(DEV))
+    # the gate's two maps: PHMLinear(h -> h) with rule A [n, n, n], weights W [n, k, k], bias b [h]; Linear(h -> kg)
+    A = torch.randn(n, n, n, generator=g, dtype=torch.float64) * 0.5
+    W = torch.randn(n, k, k, generator=g, dtype=torch.float64) / k ** 0.5
+    b = torch.randn(h, generator=g, dtype=torch.float64) * 0.1
+    lin_w = torch.randn(kg, h, generator=g, dtype=torch.float64) / h ** 0.5
+    lin_b = torch.randn(kg, generator=g, dtype=torch.float64) * 0.1
+    H = O.kron_sum_H(A, W)                                                # [h, h]: y = x . H + b
+    M = (H @ lin_w.t()).float().to(DEV).contiguous()
+    c = (b @ lin_w.t() + lin_b).float().to(DEV)
+    y_in = torch.randn(N, h, generator=g).to(DEV)
+    skip = torch.randn(N, h, generator=g).to(DEV) if with_skip else None
+    words = lib.phc_stat_acc_words(h)
+    arr = lambda tsr: (C.c_void_p * len(tsr))(*[t.data_ptr() for t in tsr])
+    split = lambda t: [t[cc * k:(cc + 1) * k] for cc in range(n)]
+    w_h, b_h = 0.5 + torch.rand(h, generator=g), torch.randn(h, generator=g)
+    w, bb = split(w_h.to(DEV)), split(b_h.to(DEV))
+    norm_acc = torch.zeros(words, dtype=torch.int64, device=DEV)
+    if normed:
+        P = (torch.randn(h, h, generator=g) / h ** 0.5).to(DEV)
+        L.check(lib.phc_gemm_prebuilt_stats(L.ptr(torch.randn(N, h, generator=g).to(DEV)), L.ptr(P), None, None, N, h, h, L.ptr(y_in), L.ptr(nv),
+                                            L.ptr(norm_acc), None, None, sp), "producer")
+    rm, rv = split(torch.zeros(h, device=DEV)), split(torch.ones(h, device=DEV))
+    nbt = [torch.zeros((), dtype=torch.int64, device=DEV) for _ in range(n)]
+    save = torch.zeros(6 * h, device=DEV)
+    x_out = torch.zeros(N, h, device=DEV)
+    gate = torch.zeros(N, kg, device=DEV)
+    out = torch.full((B, h), 7.0, device=DEV)
+    keep = (arr(w), arr(bb), arr(rm), arr(rv), arr(nbt))
+    d = L.ReadoutDesc()
+    d.x, d.batch_sorted_i64, d.N, d.num_graphs, d.h, d.n_comp, d.kg = L.ptr(y_in), L.ptr(batch), N, B, h, n, kg
+    d.M, d.c, d.gate, d.out, d.n_valid_dev = L.ptr(M), L.ptr(c), L.ptr(gate), L.ptr(out), L.ptr(nv)
+    if normed:
+        d.norm_acc = L.ptr(norm_acc)
+        d.weight, d.bias, d.running_mean, d.running_var, d.num_batches_tracked = (C.cast(a_, C.c_void_p) for a_ in keep)
+        d.norm_n_comp, d.norm_act, d.momentum, d.eps = n, L.ACT_IDS[act], 0.1, 1e-5
+        d.skip, d.save_stat, d.x_out = L.ptr(skip), L.ptr(save), L.ptr(x_out)
+    L.check(lib.phc_readout_fused_fwd(C.byref(d), sp), "phc_readout_fused_fwd")
+    torch.cuda.synchronize()
+    x = y_in.double().cpu()
+    if normed:
+        rmh, rvh = [torch.zeros(k, dtype=torch.float64) for _ in range(n)], [torch.ones(k, dtype=torch.float64) for _ in range(n)]
+        x = O.activation(act, O.batch_norm_naive(x, n, split(w_h.double()), split(b_h.double()), rmh, rvh, True, 0.1, 1e-5))
+        if with_skip:
+            x = x + skip.double().cpu()
+        assert_rel(x_out, x, 1e-5, "x")
+        assert_rel(torch.cat(rm), torch.cat(rmh), 1e-5, "running_mean")
+        assert_rel(torch.cat(rv), torch.cat(rvh), 1e-5, "running_var")
+    ref = O.soft_attention_pool(x, batch_h, A, W, b, lin_w, lin_b, n, num_graphs=B)
+    pre = O.phm_linear(x, A, W, b) @ lin_w.t() + lin_b                    # the pre-sigmoid gate the launch leaves behind
+    assert_rel(gate, pre, 1e-5, "gate (pre-sigmoid)")
+    assert_rel(out, ref, 1e-5, "per-graph sums")
+
+
 @pytest.mark.parametrize("workload", ["molhiv_b32_swish", "molhiv_b512_swish", "molhiv_b32", "zinc_small_256_swish", "molpcba_small_256_swish"])
 @pytest.mark.parametrize("graph", [False, True])
 def test_readout_in_one_launch_leaves_the_step_unchanged(workload, graph):
