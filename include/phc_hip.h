@@ -277,6 +277,20 @@ int phc_aggregate_softmax_bwd_self(const float *dout, const float *out, const fl
                                    const int32_t *perm_t, int64_t n_src, int h, int act, int64_t self_n_dst, float *dx,
                                    float *dea, float *dbeta_partial, void *stream);
 
+/* ABI 6: the model-level norm of the layer in FRONT folded into the softmax aggregation (what phc_aggregate_norm_encp_fwd does
+ * for the sum): x = act(batch_norm(y)) (+ skip) (models.py:208-215) is evaluated on the fly for every gathered row and for the row
+ * itself from the statistics accumulator the producing GEMM filled, written once as x_out, save_stat / running statistics left
+ * behind by the first workgroup; then messagepassing.py:211-214 / 297-300 as phc_aggregate_softmax_enc_fwd (identity message
+ * function).  Bit-identical to phc_bn_fwd_from_partials followed by phc_aggregate_softmax_enc_fwd.  h % 4 == 0, h <= 512. */
+int phc_aggregate_softmax_norm_supported(int64_t N, int h, int F, int vocab_rows);
+int phc_aggregate_softmax_norm_enc_fwd(const float *y, const uint64_t *norm_acc, const float *const *weight, const float *const *bias,
+                                       float *const *running_mean, float *const *running_var, int64_t *const *num_batches_tracked,
+                                       int n_comp, float momentum, float eps, int norm_act, const int32_t *n_valid_dev,
+                                       const float *skip, float *save_stat, float *x_out, const uint32_t *codes_sorted,
+                                       const float *const *tables, const int32_t *vocab, int F, int n, int k, const int32_t *rowptr,
+                                       const int32_t *col, const float *beta_dev, int64_t n_dst, float *out, float *out_self,
+                                       float *lse, void *stream);
+
 /* The softmax aggregation with the bond embedding read in place (N1 on the N2 operators): instead of an [E, h] edge
  * tensor the kernels take the packed table rows of every edge (phc_pack_edge_codes) and the n*F table pointers, as
  * phc_aggregate_encp_fwd does for the sum.  Forward: codes_sorted in destination-sorted order (perm = the CSR's perm).

@@ -173,7 +173,8 @@ class PHMSkipConnectAdd(nn.Module):
         # (with dropout the mask rides in the fused node's norm passes: engine HS_DR, round 5; MLP_NORM_DROPOUT=0 restores the separate nodes)
         fused_branch = self.training and norm is not None and (not dropout_active or _engine.MLP_NORM_DROPOUT) and self.mlp_mp and \
             x[0].is_cuda and hasattr(tr, "propagate_encoded") and hasattr(getattr(tr, "transform", None), "linear2")
-        if pending is not None and not (fused_branch and edge_encoder is not None and type(tr).__name__ == "PHMGINEConv"):
+        if pending is not None and not (fused_branch and edge_encoder is not None and
+                                        type(tr).__name__ in ("PHMGINEConv", "PHMGINEConvSoftmax")):
             _engine.materialize_pending(x[0])
             pending = None
         if fused_branch:

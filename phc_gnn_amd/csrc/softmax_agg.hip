@@ -183,6 +183,153 @@ __global__ __launch_bounds__(SM_THREADS) void softmax_agg_fwd_kernel(const float
     }
 }
 
+// ---- the model-level norm folded into the NEXT layer's softmax aggregation (round 5) ------------------------------------------------
+// models.py:208-215 ends a layer with  x = act(norm(y)) (+ skip);  with the reference's default aggregation the next layer starts with
+// the softmax walk above over x.  As in aggregate_norm_direct_fwd_kernel (encoder.hip) the element-wise pass between the two is not a
+// launch of its own: the prologue derives scale / shift from the statistics accumulator the producing GEMM filled (the arithmetic of
+// bn_apply_acc_kernel: replica totals in double, in replica order), every gathered row and the row itself are normalised on the
+// fly, x is written once by the row's owner, block 0 leaves save_stat and the running statistics behind.  Identity message function,
+// packed bond codes; rows >= *n_valid are padding and read as 0.  Bit-identical to phc_bn_fwd_from_partials + the walk above.
+constexpr int SMN_MAX_H = 512;
+template <int LPR>
+__global__ __launch_bounds__(SM_THREADS) void softmax_agg_norm_fwd_kernel(
+    const float *__restrict__ y, const float *__restrict__ skip, BnParams p, const int *__restrict__ n_valid, float momentum, float eps,
+    const unsigned long long *__restrict__ acc, int norm_act, float *__restrict__ stat, float *__restrict__ xout,
+    const int *__restrict__ rowptr, const int *__restrict__ col, const float *__restrict__ beta_p, long long n_dst, int h,
+    float *__restrict__ out, float *__restrict__ lse, float *__restrict__ out_self, SmEnc enc) {
+    __shared__ __attribute__((aligned(16))) float s_scale[SMN_MAX_H], s_shift[SMN_MAX_H];
+    constexpr int G = WAVE / LPR;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int grp = lane / LPR, li = lane - grp * LPR;
+    const long long wave_id = ((long long)xcd_contiguous_block(blockIdx.x, gridDim.x) * SM_THREADS + tid) >> 6;
+    const long long n_waves = ((long long)gridDim.x * SM_THREADS) >> 6;
+    const int h4 = h >> 2;
+    const float beta = *beta_p;
+    const long long count = n_valid ? min((long long)*n_valid, n_dst) : n_dst;
+    const bool owner = blockIdx.x == 0;
+    for (int c = tid; c < h; c += SM_THREADS) {
+        double S = 0.0, Q = 0.0;
+#pragma unroll
+        for (int rp = 0; rp < STAT_ACC_REP; ++rp) {
+            S += stat_acc_part(acc, h, rp, 0, c);
+            Q += stat_acc_part(acc, h, rp, 1, c);
+        }
+        const int comp = c / p.k, kk = c - comp * p.k;
+        float w = 1.f, bq = 0.f, rm_old = 0.f, rv_old = 1.f;
+        if (p.has_weight) w = *bn_col_ptr(p.weight, p.flat, comp, kk, c);
+        if (p.has_bias) bq = *bn_col_ptr(p.bias, p.flat, comp, kk, c);
+        if (p.has_running && owner) {
+            rm_old = *bn_col_ptr(p.running_mean, p.flat, comp, kk, c);
+            rv_old = *bn_col_ptr(p.running_var, p.flat, comp, kk, c);
+        }
+        const BnFromTotals bt = bn_from_totals(S, Q, count, w, bq, eps);
+        s_scale[c] = bt.scale;
+        s_shift[c] = bt.shift;
+        if (owner) {
+            stat[c] = bt.mean;
+            stat[h + c] = bt.invstd;
+            stat[2 * h + c] = bt.scale;
+            stat[3 * h + c] = bt.shift;
+            stat[4 * h + c] = w;
+            stat[5 * h + c] = bq;
+            if (p.has_running) {
+                *bn_col_ptr(p.running_mean, p.flat, comp, kk, c) = bn_running_update(rm_old, momentum, bt.mean);
+                *bn_col_ptr(p.running_var, p.flat, comp, kk, c) = bn_running_update(rv_old, momentum, bt.unbiased);
+            }
+        }
+    }
+    if (owner && p.has_nbt && tid < p.n_comp)
+        for (int q = 0; q < p.n_comp; ++q)
+            if (q == tid) *p.num_batches_tracked[q] += 1;
+    __syncthreads();
+    const bool relu = norm_act == PHC_ACT_RELU;
+    auto xrow = [&](long long r, int c4, const float4 sc, const float4 sh) {
+        const float4 v = reinterpret_cast<const float4 *>(y + (size_t)r * h)[c4];
+        const float4 rr = reinterpret_cast<const float4 *>(skip ? skip + (size_t)r * h : y)[c4];
+        float4 o;
+        if (relu) {
+            o.x = fmaxf(fmaf(v.x, sc.x, sh.x), 0.f); o.y = fmaxf(fmaf(v.y, sc.y, sh.y), 0.f);
+            o.z = fmaxf(fmaf(v.z, sc.z, sh.z), 0.f); o.w = fmaxf(fmaf(v.w, sc.w, sh.w), 0.f);
+        } else {
+            o.x = act_fwd_rt(norm_act, fmaf(v.x, sc.x, sh.x)); o.y = act_fwd_rt(norm_act, fmaf(v.y, sc.y, sh.y));
+            o.z = act_fwd_rt(norm_act, fmaf(v.z, sc.z, sh.z)); o.w = act_fwd_rt(norm_act, fmaf(v.w, sc.w, sh.w));
+        }
+        if (skip) { o.x += rr.x; o.y += rr.y; o.z += rr.z; o.w += rr.w; }
+        if (r >= count) o = make_float4(0.f, 0.f, 0.f, 0.f);
+        return o;
+    };
+    auto row = [&](long long d, int e0, int e1, int first, int step, bool coop) {
+        for (int c4 = li; c4 < h4; c4 += LPR) {
+            const float4 sc = *reinterpret_cast<const float4 *>(s_scale + 4 * c4), sh = *reinterpret_cast<const float4 *>(s_shift + 4 * c4);
+            const float4 xd = xrow(d, c4, sc, sh);
+            float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, s[4] = {0.f, 0.f, 0.f, 0.f}, w[4] = {0.f, 0.f, 0.f, 0.f};
+            const float *tp[4] = {nullptr, nullptr, nullptr, nullptr};
+            sm_table_ptrs(enc, c4, tp);
+            auto message = [&](int e) {
+                float4 v = xrow(col[e], c4, sc, sh);
+                const float4 a = sm_enc_rows(enc, tp, enc.codes[e]);
+                v.x += a.x; v.y += a.y; v.z += a.z; v.w += a.w;
+                return v;
+            };
+            auto update = [&](const float4 &m) {
+                sm_update(mx[0], s[0], w[0], m.x, beta);
+                sm_update(mx[1], s[1], w[1], m.y, beta);
+                sm_update(mx[2], s[2], w[2], m.z, beta);
+                sm_update(mx[3], s[3], w[3], m.w, beta);
+            };
+            int e = e0 + first;
+            if (e0 < e1) {
+                const float4 m0 = message(min(e, e1 - 1)), m1 = message(min(e + step, e1 - 1));
+                if (e < e1) update(m0);
+                if (e + step < e1) update(m1);
+                e += 2 * step;
+            }
+            for (; e < e1; e += step) update(message(e));
+            if (coop) {
+#pragma unroll
+                for (int off = LPR; off < WAVE; off <<= 1) {
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float m2 = __shfl_xor(mx[q], off, WAVE), s2 = __shfl_xor(s[q], off, WAVE), w2 = __shfl_xor(w[q], off, WAVE);
+                        sm_merge(mx[q], s[q], w[q], m2, s2, w2);
+                    }
+                }
+            }
+            if (!coop || grp == 0) {
+                float4 o, l;
+                float *op = &o.x, *lp = &l.x;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float z = s[q] + SM_EPS;
+                    op[q] = (e1 > e0) ? w[q] / z : 0.f;
+                    lp[q] = (e1 > e0) ? mx[q] + __logf(z) : 0.f;
+                }
+                reinterpret_cast<float4 *>(xout + (size_t)d * h)[c4] = xd;                  // x itself, once
+                reinterpret_cast<float4 *>(out + (size_t)d * h)[c4] = o;
+                reinterpret_cast<float4 *>(lse + (size_t)d * h)[c4] = l;
+                if (out_self)
+                    reinterpret_cast<float4 *>(out_self + (size_t)d * h)[c4] = make_float4(o.x + xd.x, o.y + xd.y, o.z + xd.z, o.w + xd.w);
+            }
+        }
+    };
+    for (long long d0 = wave_id * G; d0 < n_dst; d0 += n_waves * G) {           // wave-uniform bounds
+        const long long d = d0 + grp;
+        const bool valid = d < n_dst;
+        const int e_begin = valid ? rowptr[d] : 0, e_end = valid ? rowptr[d + 1] : 0;
+        const bool heavy = G > 1 && e_end - e_begin > SM_HEAVY;
+        if (valid && !heavy) row(d, e_begin, e_end, 0, 1, false);
+        if (G > 1) {
+            const unsigned long long hb = __ballot(heavy);
+            if (hb) {
+                for (int g = 0; g < G; ++g) {
+                    const int eb = __shfl(e_begin, g * LPR, WAVE), ee = __shfl(e_end, g * LPR, WAVE);
+                    if ((hb >> (g * LPR)) & 1ull) row(d0 + g, eb, ee, grp, G, true);
+                }
+            }
+        }
+    }
+}
+
 // source-sorted walk; dbeta partial sums per workgroup (fixed order => reproducible).  dbeta_partial has n_partials slots
 // (phc_softmax_bwd_num_partials: the one-row-per-wavefront bound); the grid may be smaller and zeroes the rest.
 template <int LPR, int ACT>
@@ -338,6 +485,49 @@ static int sm_make_enc(const char *who, const uint32_t *codes, const float *cons
     }
     PHC_REQUIRE(off <= 256, PHC_ERR_UNSUPPORTED, "%s: packed codes need sum(vocab) <= 256", who);
     return PHC_OK;
+}
+
+int phc_aggregate_softmax_norm_supported(int64_t N, int h, int F, int vocab_rows) {
+    return (N >= 1 && h >= 4 && h % 4 == 0 && h <= SMN_MAX_H && F >= 1 && F <= 4 && vocab_rows >= 1 && vocab_rows <= 256) ? 1 : 0;
+}
+
+int phc_aggregate_softmax_norm_enc_fwd(const float *y, const uint64_t *norm_acc, const float *const *weight, const float *const *bias,
+                                       float *const *running_mean, float *const *running_var, int64_t *const *num_batches_tracked,
+                                       int n_comp, float momentum, float eps, int norm_act, const int32_t *n_valid_dev, const float *skip,
+                                       float *save_stat, float *x_out, const uint32_t *codes_sorted, const float *const *tables,
+                                       const int32_t *vocab, int F, int n, int k, const int32_t *rowptr, const int32_t *col,
+                                       const float *beta_dev, int64_t n_dst, float *out, float *out_self, float *lse, void *stream) {
+    const int h = n * k;
+    SmEnc enc;
+    int rc = sm_make_enc("phc_aggregate_softmax_norm_enc_fwd", codes_sorted, tables, vocab, F, n, k, h, &enc);
+    if (rc) return rc;
+    PHC_REQUIRE(phc_aggregate_softmax_norm_supported(n_dst, h, F, enc.off[F - 1] + vocab[F - 1]), PHC_ERR_UNSUPPORTED,
+                "phc_aggregate_softmax_norm_enc_fwd: %lld rows, h = %d, F = %d outside the fused form's range", (long long)n_dst, h, F);
+    PHC_REQUIRE(y && norm_acc && save_stat && x_out && rowptr && col && beta_dev && out && lse && codes_sorted, PHC_ERR_INVALID_ARG,
+                "phc_aggregate_softmax_norm_enc_fwd: null pointer");
+    PHC_REQUIRE(norm_act >= PHC_ACT_IDENTITY && norm_act <= PHC_ACT_SELU, PHC_ERR_INVALID_ARG,
+                "phc_aggregate_softmax_norm_enc_fwd: unknown activation %d", norm_act);
+    PHC_REQUIRE(sm_al16(y) && sm_al16(x_out) && sm_al16(out) && sm_al16(lse) && (!skip || sm_al16(skip)) && (!out_self || sm_al16(out_self)) &&
+                    (reinterpret_cast<uintptr_t>(norm_acc) & 7) == 0,
+                PHC_ERR_UNSUPPORTED, "phc_aggregate_softmax_norm_enc_fwd: 16-byte aligned rows, 8-byte aligned accumulator");
+    BnParams p;
+    rc = fill_params("phc_aggregate_softmax_norm_enc_fwd", &p, weight, bias, running_mean, running_var, num_batches_tracked, n_comp, h);
+    if (rc) return rc;
+    hipStream_t s = (hipStream_t)stream;
+    const int lpr = sm_lpr(h >> 2);
+    const unsigned long long *acc = reinterpret_cast<const unsigned long long *>(norm_acc);
+    ProfScope prof(K_SOFTMAX_FWD, s);
+#define PHC_SMN(LPRC)                                                                                                                 \
+    PHC_LAUNCH((softmax_agg_norm_fwd_kernel<LPRC>), dim3(sm_grid(n_dst, 64 / lpr)), dim3(SM_THREADS), 0, s, y, skip, p, n_valid_dev, momentum, \
+               eps, acc, norm_act, save_stat, x_out, rowptr, col, beta_dev, (long long)n_dst, h, out, lse, out_self, enc)
+    switch (lpr) {
+        case 8: PHC_SMN(8); break;
+        case 16: PHC_SMN(16); break;
+        case 32: PHC_SMN(32); break;
+        default: PHC_SMN(64); break;
+    }
+#undef PHC_SMN
+    return check_launch("aggregate_softmax_norm_enc_fwd");
 }
 
 static int sm_fwd_impl(const float *x, const float *ea, const int32_t *rowptr, const int32_t *col, const int32_t *perm,

@@ -1544,9 +1544,16 @@ class _AggregateSoftmaxEncFn(torch.autograd.Function):
     """Softmax aggregation with the bond encoder read in place (packed codes + tables, no [E, h] forward tensor)."""
 
     @staticmethod
-    def forward(ctx, x, bond_idx, beta, st: EdgeStructure, act: int, add_self: bool, ts: "TableSet", *tables):
+    def forward(ctx, x, bond_idx, beta, st: EdgeStructure, act: int, add_self: bool, ts: "TableSet", pending, *tables):
         lib = L.load()
         dev = L.require_device(x, bond_idx, beta)
+        # `pending`: x = act(norm(y)) (+ skip) has not been evaluated yet (PendingNorm): the walk does it on the fly for every row it
+        # gathers and writes x itself once (phc_aggregate_softmax_norm_enc_fwd, round 5) — or the stand-alone pass runs right here
+        fuse_norm = pending is not None and not pending.done and NORM_INTO_AGGREGATE and act == 0 and x.is_contiguous() and \
+            x.shape[0] == st.num_src == st.num_dst and st.num_edges > 0 and x.shape[0] * x.shape[1] <= NORM_INTO_AGGREGATE_MAX_WORK and \
+            bool(lib.phc_aggregate_softmax_norm_supported(st.num_dst, x.shape[1], ts.F, ts.R))
+        if pending is not None and not pending.done and not fuse_norm:
+            pending.materialize()
         x_ = L.f32c(x)
         bond_ = _idx64(bond_idx)
         beta_ = L.f32c(beta.reshape(1))
@@ -1562,9 +1569,20 @@ class _AggregateSoftmaxEncFn(torch.autograd.Function):
         out = torch.empty((st.num_dst, h), dtype=torch.float32, device=dev)
         lse = torch.empty((st.num_dst, h), dtype=torch.float32, device=dev)
         out_self = torch.empty_like(out) if add_self else None
-        L.check(lib.phc_aggregate_softmax_enc_fwd(L.ptr(x_), L.ptr(codes), L.ptr(ts.ptrs), ts.vocab_c, ts.F, ts.n, ts.k,
-                                                  L.ptr(rowptr), L.ptr(col), L.ptr(beta_), st.num_dst, act, L.ptr(out),
-                                                  L.ptr(out_self), L.ptr(lse), L.stream_ptr(dev)), "phc_aggregate_softmax_enc_fwd")
+        if fuse_norm:
+            pn = pending
+            assert x_.data_ptr() == pn.out.data_ptr()
+            w, bb, rm, rv, nbt, no = pn._norm_args()
+            L.check(lib.phc_aggregate_softmax_norm_enc_fwd(
+                L.ptr(pn.y2), L.ptr(pn.acc2), w, bb, rm, rv, nbt, no, float(pn.outer["momentum"]), float(pn.outer["eps"]), pn.act_o,
+                L.ptr(pn.n_valid), L.ptr(pn.skip), L.ptr(pn.save_o), L.ptr(pn.out), L.ptr(codes), L.ptr(ts.ptrs), ts.vocab_c, ts.F, ts.n,
+                ts.k, L.ptr(rowptr), L.ptr(col), L.ptr(beta_), st.num_dst, L.ptr(out), L.ptr(out_self), L.ptr(lse), L.stream_ptr(dev)),
+                "phc_aggregate_softmax_norm_enc_fwd")
+            pn.done = True
+        else:
+            L.check(lib.phc_aggregate_softmax_enc_fwd(L.ptr(x_), L.ptr(codes), L.ptr(ts.ptrs), ts.vocab_c, ts.F, ts.n, ts.k,
+                                                      L.ptr(rowptr), L.ptr(col), L.ptr(beta_), st.num_dst, act, L.ptr(out),
+                                                      L.ptr(out_self), L.ptr(lse), L.stream_ptr(dev)), "phc_aggregate_softmax_enc_fwd")
         if L.PROF_ON:
             E, N = st.num_edges, st.num_dst
             L.account("aggregate_softmax_fwd", 8.0 * E * h, E * (4.0 * h + 12) + N * 8.0 * h)
@@ -1586,7 +1604,7 @@ class _AggregateSoftmaxEncFn(torch.autograd.Function):
         h = dout_.shape[1]
         rowptr_t, col_t, perm_t = st.csc
         codes_o = st.packed_codes_src(bond_, ts.vocab_c, ts.F)
-        need_t = any(ctx.needs_input_grad[7:])
+        need_t = any(ctx.needs_input_grad[8:])
         dx = torch.empty((st.num_src, h), dtype=torch.float32, device=dev)
         dea = torch.empty((st.num_edges, h), dtype=torch.float32, device=dev) if need_t else None
         nparts = lib.phc_softmax_bwd_num_partials(st.num_src)
@@ -1609,7 +1627,7 @@ class _AggregateSoftmaxEncFn(torch.autograd.Function):
         tgrads = [None] * ts.num_tables
         if need_t:
             if ctx.defer_tables is not None and _DEFER.active and not torch.is_grad_enabled():
-                params = [t if ng else None for t, ng in zip(ctx.defer_tables, ctx.needs_input_grad[7:])]
+                params = [t if ng else None for t, ng in zip(ctx.defer_tables, ctx.needs_input_grad[8:])]
                 with _DEFER.lock:                            # d enc = dea: an encoder job over the edge rows
                     _DEFER.atom_jobs.append(dict(dout=dea, idx=bond_, ts=ts, params=params))
             else:
@@ -1619,18 +1637,19 @@ class _AggregateSoftmaxEncFn(torch.autograd.Function):
                 L.check(lib.phc_encode_bwd(L.ptr(dea), L.ptr(bond_), st.num_edges, ts.F, ts.vocab_c, ts.n, ts.k, L.ptr(flat),
                                            L.ptr(ws), ws_bytes, L.stream_ptr(dev)), "phc_encode_bwd")
                 tgrads = list(ts.grad_views(flat))
-        return ((dx if ctx.needs_input_grad[0] else None), None, dbeta, None, None, None, None, *tgrads)
+        return ((dx if ctx.needs_input_grad[0] else None), None, dbeta, None, None, None, None, None, *tgrads)
 
 
 def aggregate_softmax_encoded(x: torch.Tensor, edge_index, bond_idx: torch.Tensor, ts: "TableSet", tables, beta: torch.Tensor,
-                              msg_encoder: str = "identity", add_self: bool = False, num_dst: Optional[int] = None) -> torch.Tensor:
+                              msg_encoder: str = "identity", add_self: bool = False, num_dst: Optional[int] = None,
+                              pending=None) -> torch.Tensor:
     """aggregate_softmax with ``edge_attr = bond encoder(bond_idx)`` evaluated inside the kernels (needs
     ``ts.fusable_into_aggregate`` and F <= 4, sum(vocab) <= 256: the packed-code limits)."""
     st = edge_index if isinstance(edge_index, EdgeStructure) else edge_structure(edge_index, x.shape[0], num_dst)
     ts = ts.vector_form(tables)
     bond_idx = _idx64(bond_idx)
     st.prepare(for_backward=torch.is_grad_enabled() and x.requires_grad, codes_for=(bond_idx, ts.vocab_c, ts.F))
-    return _AggregateSoftmaxEncFn.apply(x, bond_idx, beta, st, _act_id(msg_encoder), add_self, ts,
+    return _AggregateSoftmaxEncFn.apply(x, bond_idx, beta, st, _act_id(msg_encoder), add_self, ts, pending,
                                         *[t for comp in tables for t in comp])
 
 

@@ -46,13 +46,18 @@ def _same(a, b):
         assert torch.equal(a[2][k], b[2][k]), ("buffer", k)
 
 
-@pytest.mark.parametrize("workload", ["molhiv_b32", "molhiv_b32_swish", "zinc_small_last"])
+@pytest.mark.parametrize("workload", ["molhiv_b32", "molhiv_b32_swish", "zinc_small_last", "molhiv_b32_softmax", "molhiv_small_200_softmax_swish"])
 @pytest.mark.parametrize("graph", [False, True])
 def test_norm_folded_into_the_next_aggregation_is_bit_identical(workload, graph):
     from phc_gnn_amd import harness
     if workload == "zinc_small_last":                                     # sc_type "last": the skip IS the parked tensor
         harness.WORKLOADS.setdefault("zinc_small_last", dict(dataset="zinc", batch_size=48, phm_dim=4, hidden=64, layers=3, d_units=[64, 32],
                                                              target_dim=1, sc_type="last", regression=True))
+    # round 5: the same fold inside the SOFTMAX aggregation (phc_aggregate_softmax_norm_enc_fwd; messagepassing.py:211-214, 297-300)
+    harness.WORKLOADS.setdefault("molhiv_b32_softmax", dict(harness.WORKLOADS["molhiv_b32"], msg_aggr="softmax"))
+    harness.WORKLOADS.setdefault("molhiv_small_200_softmax_swish", dict(dataset="molhiv", batch_size=40, phm_dim=4, hidden=200, layers=3,
+                                                                        d_units=[128, 32], target_dim=1, sc_type="first", msg_aggr="softmax",
+                                                                        activation="swish"))
     on = _step(workload, dict(NORM_INTO_AGGREGATE=True), graph)
     off = _step(workload, dict(NORM_INTO_AGGREGATE=False), graph)
     _same(on, off)
@@ -580,3 +585,70 @@ def test_forward_hooks_see_finished_activations(workload):
     model.load_state_dict(sd)
     again = model(data).detach()
     assert torch.equal(again, fast)
+
+
+@pytest.mark.parametrize("n,k", [(4, 32), (4, 50), (8, 32)])
+@pytest.mark.parametrize("N,E,hubs", [(1000, 2100, False), (333, 1500, True), (12874, 27650, False)])
+@pytest.mark.parametrize("F,act,with_skip,add_self", [(3, "relu", True, True), (1, "swish", False, True), (2, "relu", True, False)])
+def test_norm_folded_into_the_softmax_aggregation_equals_the_two_launches(N, E, hubs, F, act, with_skip, add_self, n, k):
+    """phc_aggregate_softmax_norm_enc_fwd against phc_bn_fwd_from_partials followed by phc_aggregate_softmax_enc_fwd: x, save_stat,
+    running statistics, the aggregate, its self-loop form and the log-sum-exp bit for bit (same walk, same online softmax order)."""
+    import ctypes as C
+    from phc_gnn_amd import lib as L, ops
+    from phc_gnn_amd.graph import edge_structure
+    lib = L.load()
+    h = n * k
+    vocab = [5, 6, 2, 3][:F]
+    g = torch.Generator().manual_seed(N + F + h)
+    ei = _random_graph(N, E, hubs, seed=N).to(DEV)
+    bond = torch.stack([torch.randint(0, v, (E,), generator=g) for v in vocab], 1).to(DEV)
+    tables = [[torch.randn(v, k, generator=g).to(DEV) for v in vocab] for _ in range(n)]
+    ts = ops.TableSet(tables).vector_form(tables)
+    if not lib.phc_aggregate_softmax_norm_supported(N, h, F, sum(vocab)):
+        pytest.skip("outside the fused form")
+    st = edge_structure(ei, N, N)
+    st.prepare(for_backward=False, codes_for=(bond, ts.vocab_c, ts.F))
+    rowptr, col, _ = st.csr
+    codes = st.packed_codes(bond, ts.vocab_c, ts.F)
+    valid = N - 7
+    nv = torch.tensor([valid], dtype=torch.int32, device=DEV)
+    sp = L.stream_ptr(torch.device(DEV))
+    beta = torch.tensor([1.3], device=DEV)
+    P = (torch.randn(h, h, generator=g) / h ** 0.5).to(DEV)
+    y_in = torch.empty(N, h, device=DEV)
+    skip = torch.randn(N, h, generator=g).to(DEV) if with_skip else None
+    words = lib.phc_stat_acc_words(h)
+    arr = lambda tsr: (C.c_void_p * len(tsr))(*[t.data_ptr() for t in tsr])
+    w = [(0.5 + torch.rand(k, generator=g)).to(DEV) for _ in range(n)]
+    bb = [torch.randn(k, generator=g).to(DEV) for _ in range(n)]
+    norm_acc = torch.zeros(words, dtype=torch.int64, device=DEV)
+    L.check(lib.phc_gemm_prebuilt_stats(L.ptr(torch.randn(N, h, generator=g).to(DEV)), L.ptr(P), None, None, N, h, h, L.ptr(y_in), L.ptr(nv),
+                                        L.ptr(norm_acc), None, None, sp), "producer")
+    res = {}
+    for tag in ("separate", "fused"):
+        rm = [torch.zeros(k, device=DEV) for _ in range(n)]
+        rv = [torch.ones(k, device=DEV) for _ in range(n)]
+        nbt = [torch.zeros((), dtype=torch.int64, device=DEV) for _ in range(n)]
+        save = torch.zeros(6 * h, device=DEV)
+        x_out = torch.zeros(N, h, device=DEV)
+        out, lse = torch.empty(N, h, device=DEV), torch.empty(N, h, device=DEV)
+        out_self = torch.empty(N, h, device=DEV) if add_self else None
+        keep = (arr(w), arr(bb), arr(rm), arr(rv), arr(nbt))
+        if tag == "separate":
+            L.check(lib.phc_bn_fwd_from_partials(L.ptr(y_in), L.ptr(norm_acc), None, 0, keep[0], keep[1], keep[2], keep[3], keep[4], n, L.ptr(nv),
+                                                 N, h, 0.1, 1e-5, L.ACT_IDS[act], L.ptr(skip), L.ptr(x_out), L.ptr(save), 0.0, 0, 0, None, sp),
+                    "bn_fwd_from_partials")
+            L.check(lib.phc_aggregate_softmax_enc_fwd(L.ptr(x_out), L.ptr(codes), L.ptr(ts.ptrs), ts.vocab_c, ts.F, ts.n, ts.k, L.ptr(rowptr),
+                                                      L.ptr(col), L.ptr(beta), N, 0, L.ptr(out), L.ptr(out_self), L.ptr(lse), sp), "softmax")
+        else:
+            L.check(lib.phc_aggregate_softmax_norm_enc_fwd(L.ptr(y_in), L.ptr(norm_acc), keep[0], keep[1], keep[2], keep[3], keep[4], n, 0.1, 1e-5,
+                                                           L.ACT_IDS[act], L.ptr(nv), L.ptr(skip), L.ptr(save), L.ptr(x_out), L.ptr(codes),
+                                                           L.ptr(ts.ptrs), ts.vocab_c, ts.F, ts.n, ts.k, L.ptr(rowptr), L.ptr(col), L.ptr(beta), N,
+                                                           L.ptr(out), L.ptr(out_self), L.ptr(lse), sp), "softmax norm")
+        torch.cuda.synchronize()
+        res[tag] = dict(x=x_out, save=save, rm=torch.cat(rm), rv=torch.cat(rv), nbt=torch.stack(nbt), out=out, lse=lse)
+        if add_self:
+            res[tag]["out_self"] = out_self
+    for key in res["fused"]:
+        a_, b_ = res["fused"][key], res["separate"][key]
+        assert torch.equal(a_, b_), (key, float((a_.double() - b_.double()).abs().max()))
