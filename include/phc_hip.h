@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PHC_ABI_VERSION 6
+#define PHC_ABI_VERSION 7
 
 #define PHC_OK 0
 #define PHC_ERR_INVALID_ARG (-1)   /* null pointer, negative size, bad enum        */
@@ -836,6 +836,52 @@ int phc_downstream_supported_k4(int64_t B, int d0, int d1, int d2, int d3, int T
 size_t phc_downstream_partial_floats(int64_t B);
 int phc_downstream_fwd(const phc_downstream_desc *desc, void *stream);
 int phc_downstream_bwd(const phc_downstream_desc *desc, void *stream);
+
+/* ABI 7: the head at widths beyond phc_downstream_* (d1 = 768, d3 = n * 128 targets, T = 128: BASELINE configs[3]'s molpcba head
+ * 256 -> 768 -> 256 -> 512 -> 128, downstream.py:90-120 + layers.py:399-414) as ONE launch per direction (csrc/head_chain.hip).
+ * A launch is a CHAIN of up to PHC_HEAD_MAX_STAGES stages over the B rows:
+ *     y_s = in_s . M_s^T + bias_s            M_s [N_s][K_s] row-major (out column major: M_s[c][k] multiplies in_s[:, k])
+ *     post 0:  out_s = y_s ;                                                   in_{s+1} = y_s
+ *     post 1:  out_s = y_s (the pre-norm z), stat = save_stat (phc_bn_fwd's layout), running statistics updated ;
+ *              in_{s+1} = act(batch_norm_train(y_s)) over all rows < *n_valid_dev  (norm.py:30-35; stages 0 and 1 only)
+ *     post 2:  g = y_s * act'(x_hat w + b), x_hat from (z, stat) of the forward ; out_s = in_{s+1} = batch_norm_backward(g) ;
+ *              dwb = dweight | dbias of the norm  (what autograd derives from norm.py:30-35)
+ * Forward chain of the head:  M = (H1^T, H2^T, H3^T, Wr), post = (1, 1, 0, 0), in = x, out = (z1, z2, z3, logits).
+ * Backward chain:             M = (Wr^T, H3, H2, H1),     post = (0, 2, 2, 0), in = dlogits, out = (dz3, dz2, dz1, dx);
+ * the parameter gradients of the four layers are jobs of phc_step_tail / phc_phm_param_grads with (x, dz1), ((z1, stat1), dz2),
+ * ((z2, stat2), dz3), (z3, dlogits) as before.  Every M is a matrix phc_phm_build_H_batched already holds (H, H^T, the dense weight
+ * and its transpose), read in place.
+ * K_s, N_s multiples of 16, K_s <= 1024, K_{s+1} = N_s; the grid is (B / 16 row blocks) x (CB column blocks) and all of it must be
+ * resident at once (phc_head_chain_supported asks the device; 1024 valid rows at these widths on a 256-CU device).
+ * work: phc_head_chain_work_floats floats, sync: 4 uint32 — both ZERO before the first use and never touched by the caller afterwards,
+ * one pair per direction, per stream and per shape (same protocol as phc_downstream_*: generation-tagged 8-byte granules).
+ * Same function as the per-layer entry points up to the fp32 summation order; bit-reproducible from launch to launch. */
+#define PHC_HEAD_MAX_STAGES 4
+typedef struct phc_head_stage {
+    const float *M;                /* [N][K] */
+    const float *bias;             /* [N] or NULL */
+    int32_t K, N, post;
+    float *out;                    /* [B][N] */
+    const float *z;                /* post 2: the forward's pre-norm output [B][N] */
+    float *stat;                   /* post 1: save_stat out [6 N]; post 2: save_stat in */
+    float *dwb;                    /* post 2: [2 N] out, may be NULL */
+    phc_downstream_norm norm;      /* post 1 */
+} phc_head_stage;
+typedef struct phc_head_chain_desc {
+    int64_t B;
+    int32_t n_stages, act;
+    const int32_t *n_valid_dev;    /* device scalar or NULL: rows at and beyond it are padding graphs */
+    int64_t valid_rows_max;        /* an upper bound of *n_valid_dev the caller guarantees (0: B).  Row blocks at and beyond
+                                    * *n_valid_dev exit at once (their output rows are zero) and need not be resident with the others:
+                                    * a fixed-shape batch of 1024 graphs + 32 padding graphs runs on a 256-CU device. */
+    const float *in;               /* [B][stage[0].K] */
+    phc_head_stage stage[PHC_HEAD_MAX_STAGES];
+    float *work;
+    uint32_t *sync;
+} phc_head_chain_desc;
+int phc_head_chain_supported(int64_t B, int64_t valid_rows_max, int n_stages, const int32_t *K, const int32_t *N);
+size_t phc_head_chain_work_floats(int64_t B, int n_stages, const int32_t *N);
+int phc_head_chain(const phc_head_chain_desc *desc, void *stream);
 
 /* Gated per-graph sum of PHMSoftAttentionPooling (phc/hypercomplex/pooling.py:57-66):
  *   out[g, c*k + j] = sum_{r : batch[r] = g} x[r, c*k + j] * sigmoid(gate[r, j]),   k = h / n_comp

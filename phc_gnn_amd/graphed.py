@@ -155,6 +155,7 @@ class GraphedTrainStep:
         dev = example["x"].device
         B = int(example["num_graphs"])
         n_valid_graphs = torch.tensor(B, dtype=torch.int32, device=dev)
+        n_valid_graphs._phc_max_valid = B           # (host-side bound for kernels whose grid depends on it: ops.downstream_head)
         self.sets: List[_BatchSet] = []
         for _ in range(2 if (self.pipeline or self.double_buffer) else 1):
             bs = _BatchSet()

@@ -15,7 +15,7 @@ import torch
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, "libphc_hip.so")
 
-ABI_VERSION = 6
+ABI_VERSION = 7
 ACT_IDS = {"identity": 0, "relu": 1, "lrelu": 2, "elu": 3, "swish": 4, "selu": 5}
 
 
@@ -60,6 +60,18 @@ class DownstreamDesc(C.Structure):
                 ("dx", _P), ("dz1", _P), ("dz2", _P), ("dz3", _P), ("dwb1", _P), ("dwb2", _P), ("dWr", _P),
                 ("partial", _P), ("sync", _P),
                 ("H1k4", _P), ("H2k4", _P), ("H1Tk4", _P), ("H2Tk4", _P)]
+
+
+class HeadStage(C.Structure):
+    """phc_head_stage (include/phc_hip.h)."""
+    _fields_ = [("M", _P), ("bias", _P), ("K", C.c_int32), ("N", C.c_int32), ("post", C.c_int32), ("out", _P), ("z", _P), ("stat", _P),
+                ("dwb", _P), ("norm", DownstreamNorm)]
+
+
+class HeadChainDesc(C.Structure):
+    """phc_head_chain_desc (include/phc_hip.h)."""
+    _fields_ = [("B", _L), ("n_stages", C.c_int32), ("act", C.c_int32), ("n_valid_dev", _P), ("valid_rows_max", _L), ("in_", _P), ("stage", HeadStage * 4),
+                ("work", _P), ("sync", _P)]
 
 
 class GemmBaDesc(C.Structure):
@@ -166,6 +178,9 @@ SIGNATURES = {
     "phc_downstream_partial_floats": (_S, [_L]),
     "phc_downstream_fwd": (_I, [C.POINTER(DownstreamDesc), _P]),
     "phc_downstream_bwd": (_I, [C.POINTER(DownstreamDesc), _P]),
+    "phc_head_chain_supported": (_I, [_L, _L, _I, C.POINTER(C.c_int32), C.POINTER(C.c_int32)]),
+    "phc_head_chain_work_floats": (_S, [_L, _I, C.POINTER(C.c_int32)]),
+    "phc_head_chain": (_I, [C.POINTER(HeadChainDesc), _P]),
     "phc_pack_grads": (_I, [_P, _P, _I, _P, _I, _P, _P, C.c_float, _P]),
     "phc_phm_weight_reg_max_jobs": (_I, []),
     "phc_phm_weight_reg_max_blocks": (_I, []),

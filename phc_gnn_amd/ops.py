@@ -3329,6 +3329,158 @@ class _DownstreamFn(torch.autograd.Function):
         return (dx, None, None, *flat, dWr[:T * d3].view(T, d3), dWr[T * d3:], *aff)
 
 
+HEAD_CHAIN = __import__("os").environ.get("PHC_HEAD_CHAIN", "1") != "0"
+_HC_BUFFERS: dict = {}
+
+
+def _hc_buffers(dev, which: str, B: int, widths: tuple):
+    """(sync words, work buffer) of a head-chain launch, per device, stream, direction and shape: zero before the first use and
+    owned by the kernels from then on (generation-tagged granules, as ``_dn_buffers``)."""
+    lib = L.load()
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream, which, B, widths)
+    ent = _HC_BUFFERS.get(key)
+    if ent is None:
+        arr = (_C.c_int32 * len(widths))(*widths)
+        need = lib.phc_head_chain_work_floats(B, len(widths), arr)
+        ent = (torch.zeros(4, dtype=torch.int32, device=dev), torch.zeros(max(need, 4), dtype=torch.float32, device=dev))
+        _HC_BUFFERS[key] = ent
+    return ent
+
+
+def _hc_stage(d, i, M, bias, K, N, post, out, z=None, stat=None, dwb=None, norm=None):
+    st = d.stage[i]
+    st.M, st.bias, st.K, st.N, st.post, st.out = L.ptr(M), L.ptr(bias), K, N, post, L.ptr(out)
+    st.z, st.stat, st.dwb = L.ptr(z), L.ptr(stat), L.ptr(dwb)
+    if norm is not None:
+        st.norm = norm
+
+
+class _HeadChainFn(torch.autograd.Function):
+    """logits = RealTransformer(PHMDownstreamNet(x)) for two hidden layers, training mode (downstream.py:90-120,
+    layers.py:399-414) at widths beyond ``_DownstreamFn`` (molpcba: 256 -> 768 -> 256 -> 512 -> 128): ONE ``phc_head_chain`` launch
+    forward — stages (H1^T, H2^T, H3^T, Wr) with norm + activation behind the first two — and ONE backward — stages
+    (Wr^T, H3, H2, H1) with the norms' backward behind the second and third.  The four layers' parameter gradients leave as jobs of
+    the deferred / batched gradient machinery: (x, dz1), ((z1, stat1), dz2), ((z2, stat2), dz3) and the dense (z3, dlogits)."""
+
+    @staticmethod
+    def forward(ctx, x, n_valid, meta, A1, W1, b1, A2, W2, b2, A3, W3, b3, Wr, br, *affine):
+        lib = L.load()
+        dev = L.require_device(x, Wr)
+        act, norms, pre = meta["act"], meta["norms"], meta["pre"]
+        x_ = L.f32c(x)
+        B, d0 = x_.shape
+        d1, d2, d3 = W1.shape[0] * W1.shape[2], W2.shape[0] * W2.shape[2], W3.shape[0] * W3.shape[2]
+        T = Wr.shape[0]
+        z1 = torch.empty((B, d1), dtype=torch.float32, device=dev)
+        z2 = torch.empty((B, d2), dtype=torch.float32, device=dev)
+        z3 = torch.empty((B, d3), dtype=torch.float32, device=dev)
+        logits = torch.empty((B, T), dtype=torch.float32, device=dev)
+        stat1 = torch.empty(6 * d1, dtype=torch.float32, device=dev)
+        stat2 = torch.empty(6 * d2, dtype=torch.float32, device=dev)
+        sync, work = _hc_buffers(dev, "fwd", B, (d1, d2, d3, T))
+        keep = []
+        d = L.HeadChainDesc()
+        d.B, d.n_stages, d.act, d.n_valid_dev, d.in_ = B, 4, act, L.ptr(n_valid), L.ptr(x_)
+        d.valid_rows_max = meta["valid_max"]
+        _hc_stage(d, 0, pre[0][1], b1, d0, d1, 1, z1, stat=stat1,
+                  norm=_dn_norm(norms[0]["tensors"], norms[0]["n_comp"], norms[0]["momentum"], norms[0]["eps"], keep))
+        _hc_stage(d, 1, pre[1][1], b2, d1, d2, 1, z2, stat=stat2,
+                  norm=_dn_norm(norms[1]["tensors"], norms[1]["n_comp"], norms[1]["momentum"], norms[1]["eps"], keep))
+        _hc_stage(d, 2, pre[2][1], b3, d2, d3, 0, z3)
+        _hc_stage(d, 3, Wr, br, d3, T, 0, logits)
+        d.work, d.sync = L.ptr(work), L.ptr(sync)
+        L.check(lib.phc_head_chain(_C.byref(d), L.stream_ptr(dev)), "phc_head_chain(forward)")
+        _tap(z1, stat1, n_valid, act)
+        _tap(z2, stat2, n_valid, act)
+        if L.PROF_ON:
+            L.account("head_chain_fwd", 2.0 * B * (d0 * d1 + d1 * d2 + d2 * d3 + d3 * T),
+                      4.0 * (B * (d0 + d1 + d2 + d3 + T) + d0 * d1 + d1 * d2 + d2 * d3 + d3 * T))
+        ctx.save_for_backward(x_, z1, z2, z3, stat1, stat2, Wr)
+        ctx.meta = meta
+        ctx.n_valid = n_valid
+        ctx.phm = ((A1, W1, b1), (A2, W2, b2), (A3, W3, b3))
+        ctx.br = br
+        ctx.n_affine = len(affine)
+        return logits
+
+    @staticmethod
+    def backward(ctx, dlogits):
+        lib = L.load()
+        x_, z1, z2, z3, stat1, stat2, Wr = ctx.saved_tensors
+        meta, n_valid = ctx.meta, ctx.n_valid
+        act, norms, pre, WrT = meta["act"], meta["norms"], meta["pre"], meta["WrT"]
+        dev = x_.device
+        B, d0 = x_.shape
+        d1, d2, d3, T = z1.shape[1], z2.shape[1], z3.shape[1], Wr.shape[0]
+        dl = L.f32c(dlogits)
+        need_x = ctx.needs_input_grad[0]
+        dx = torch.empty_like(x_) if need_x else None
+        dz1, dz2, dz3 = torch.empty_like(z1), torch.empty_like(z2), torch.empty_like(z3)
+        dwb1 = torch.empty(2 * d1, dtype=torch.float32, device=dev)
+        dwb2 = torch.empty(2 * d2, dtype=torch.float32, device=dev)
+        widths = (d3, d2, d1, d0) if need_x else (d3, d2, d1)
+        sync, work = _hc_buffers(dev, "bwd", B, widths)
+        d = L.HeadChainDesc()
+        d.B, d.n_stages, d.act, d.n_valid_dev, d.in_ = B, len(widths), act, L.ptr(n_valid), L.ptr(dl)
+        d.valid_rows_max = meta["valid_max"]
+        _hc_stage(d, 0, WrT, None, T, d3, 0, dz3)                                  # dz3 = dlogits . Wr
+        _hc_stage(d, 1, pre[2][0], None, d3, d2, 2, dz2, z=z2, stat=stat2, dwb=dwb2)      # da2 = dz3 . H3^T, norm 2 backwards
+        _hc_stage(d, 2, pre[1][0], None, d2, d1, 2, dz1, z=z1, stat=stat1, dwb=dwb1)      # da1 = dz2 . H2^T, norm 1 backwards
+        if need_x:
+            _hc_stage(d, 3, pre[0][0], None, d1, d0, 0, dx)                         # dx = dz1 . H1^T
+        d.work, d.sync = L.ptr(work), L.ptr(sync)
+        L.check(lib.phc_head_chain(_C.byref(d), L.stream_ptr(dev)), "phc_head_chain(backward)")
+        if L.PROF_ON:
+            L.account("head_chain_bwd", 2.0 * B * (d0 * d1 + d1 * d2 + d2 * d3 + d3 * T),
+                      4.0 * (B * (d0 + 2 * d1 + 2 * d2 + d3 + T) + d0 * d1 + d1 * d2 + d2 * d3 + d3 * T))
+        needs = ctx.needs_input_grad
+        xs = ((x_, None), (z1, (stat1, n_valid, act)), (z2, (stat2, n_valid, act)))
+        dys = (dz1, dz2, dz3)
+        jobs, grads = [], []
+        for i, (A, W, b) in enumerate(ctx.phm):
+            nA, nW, nb = needs[3 + 3 * i], needs[4 + 3 * i], needs[5 + 3 * i] and b is not None
+            if not (nA or nW or nb):
+                grads.append((None, None, None))
+                continue
+            job = dict(x=xs[i][0], dy=dys[i], A=A, W=W, need=(nA, nW, nb), params=(A if nA else None, W if nW else None, b if nb else None))
+            if xs[i][1] is not None:
+                job["xf"] = xs[i][1]
+            jobs.append((i, job))
+            grads.append(None)
+        br = ctx.br
+        nWr, nbr = needs[12], needs[13] and br is not None
+        if nWr or nbr:                                        # the dense head in PHM form: n = 1, W = Wr^T, dW written as [T, d3]
+            jobs.append((3, dict(x=z3, dy=dl, A=_one(dev), W=Wr, need=(False, nWr, nbr),
+                                 params=(None, Wr if nWr else None, br if nbr else None), dense=True)))
+        grads.append((None, None, None))
+        if jobs:
+            deferred = _DEFER.active and not torch.is_grad_enabled() and \
+                all(p is None or p.is_leaf for _, jb in jobs for p in jb["params"])
+            if deferred:
+                with _DEFER.lock:
+                    _DEFER.jobs.extend(jb for _, jb in jobs)
+                for i, _ in jobs:
+                    grads[i] = (None, None, None)
+            else:
+                for _, jb in jobs:
+                    jb["params"] = (None, None, None)
+                outs = _flush_param_grads([jb for _, jb in jobs], return_grads=True)
+                for (i, _), o in zip(jobs, outs):
+                    grads[i] = o
+        flat = []
+        for gA, gW, gb in grads[:3]:
+            flat.extend([gA, gW, gb])
+        aff = []
+        if ctx.n_affine:
+            for dwb, nm, width in ((dwb1, norms[0], d1), (dwb2, norms[1], d2)):
+                if not nm["affine"]:
+                    continue
+                n, k = nm["n_comp"], width // nm["n_comp"]
+                aff.extend([dwb[c * k:(c + 1) * k] for c in range(n)])
+                aff.extend([dwb[width + c * k:width + (c + 1) * k] for c in range(n)])
+        return (dx, None, None, *flat, grads[3][1], grads[3][2], *aff)
+
+
 def downstream_head(x, n_valid, affine_layers, norm_modules, real_affine, activation: str):
     """The fused head, or ``None`` when its preconditions do not hold (the caller then runs layer by layer): three PHM
     layers with prebuilt operand matrices (inside ``prebuilt_H``), two naive batch-norms with running statistics, a dense
@@ -3349,8 +3501,25 @@ def downstream_head(x, n_valid, affine_layers, norm_modules, real_affine, activa
     has_k4 = all(pre[i][2] is not None and pre[i][3] is not None for i in (0, 1))
     supported = lib.phc_downstream_supported_k4 if has_k4 else lib.phc_downstream_supported
     if x.shape[1] != d0 or W2.shape[0] * W2.shape[1] != d1 or W3.shape[0] * W3.shape[1] != d2 or Wr.shape[1] != d3 or \
-            not supported(x.shape[0], d0, d1, d2, d3, T) or x.dtype != torch.float32 or not Wr.is_contiguous():
+            x.dtype != torch.float32 or not Wr.is_contiguous():
         return None
+    chain = False
+    WrT, valid_max = None, x.shape[0]
+    if not supported(x.shape[0], d0, d1, d2, d3, T):
+        # beyond the 16-row kernels (molpcba: 768-wide hidden layer, 128 targets): the 2-D chain kernel, when its shapes and the
+        # device allow it and the dense head's transpose is among the step's prebuilt operands
+        dense = _prebuilt_for(None, Wr) if HEAD_CHAIN else None
+        if dense is None or real_affine.bias is None:
+            return None
+        # (a fixed-shape batch says how many of its graphs can be real: the rows behind them are padding in every replay)
+        valid_max = min(int(getattr(n_valid, "_phc_max_valid", x.shape[0])), x.shape[0]) if n_valid is not None else x.shape[0]
+        Ks, Ns = (_C.c_int32 * 4)(d0, d1, d2, d3), (_C.c_int32 * 4)(d1, d2, d3, T)
+        if not lib.phc_head_chain_supported(x.shape[0], valid_max, 4, Ks, Ns):
+            return None
+        Kb, Nb = (_C.c_int32 * 4)(T, d3, d2, d1), (_C.c_int32 * 4)(d3, d2, d1, d0)
+        if not lib.phc_head_chain_supported(x.shape[0], valid_max, 4, Kb, Nb):
+            return None
+        chain, WrT = True, dense[0]
     norms, affine = [], []
     for nm in norm_modules:
         mods = list(nm.bn)
@@ -3363,8 +3532,10 @@ def downstream_head(x, n_valid, affine_layers, norm_modules, real_affine, activa
                           affine=bool(nm.affine)))
         if nm.affine:
             affine.extend(w + b)
-    meta = dict(act=_act_id(activation), norms=norms, pre=pre)
+    meta = dict(act=_act_id(activation), norms=norms, pre=pre, WrT=WrT, valid_max=valid_max)
     l1, l2, l3 = affine_layers
+    if chain:
+        return _HeadChainFn.apply(x, n_valid, meta, l1.phm_rule, l1.W, l1.b, l2.phm_rule, l2.W, l2.b, l3.phm_rule, l3.W, l3.b, Wr, br, *affine)
     return _DownstreamFn.apply(x, n_valid, meta, l1.phm_rule, l1.W, l1.b, l2.phm_rule, l2.W, l2.b, l3.phm_rule, l3.W, l3.b, Wr, br, *affine)
 
 
