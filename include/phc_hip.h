@@ -825,7 +825,7 @@ typedef struct phc_downstream_desc {
     float *partial;
     uint32_t *sync;
     /* ABI 5 (may all be NULL): the k4 forms of H1, H2 and of their transposes (phc_phm_H_job.Hk4 / HTk4).  With them the call runs
-     * on the 16-row kernels (csrc/downstream.hip, v2): 16 rows per workgroup (32 above 1024 rows), the three wide GEMMs on
+     * on the 16-row kernels (csrc/downstream.hip, v2): 16 rows per workgroup (32 above 1280 rows), the three wide GEMMs on
      * v_mfma_f32_16x16x4_f32 with the operand loaded straight into registers — no LDS staging pass in front of the first MFMA —
      * and d0, d1, d2 any multiple of 4 in [16, 256] (the 256-wide heads of configs[2], the reference's 180 -> 180 -> 80 head),
      * B <= 2048 (phc_downstream_supported_k4).  Same results up to the fp32 summation order; same partial / sync protocol. */

@@ -58,7 +58,7 @@ def _run_fused(dn, x, dy, n_valid=None):
     (4, 32, (128, 128), 3, "relu", 1025),
     # the 16-row kernels' wider range (round 4): configs[2]'s head (ZINC PHM-8, d_units 256,128), a 256-wide PHM-4 head, the
     # reference's own ZINC head (run_script_zinc_phm4.sh: 180 -> 180 -> 80: partial k-groups and column tiles), a 200-wide PHM-5
-    # head, 32-row workgroups above 1024 rows, one partial workgroup, fewer rows than one MFMA block
+    # head, 32-row workgroups above 1280 rows, one partial workgroup, fewer rows than one MFMA block
     (8, 256, (256, 128), 1, "relu", 1024), (4, 256, (256, 128), 2, "swish", 777), (4, 180, (180, 80), 1, "relu", 1000),
     (5, 200, (200, 100), 4, "relu", 513), (4, 128, (128, 32), 1, "relu", 1500), (4, 128, (256, 16), 1, "elu", 2048),
     (4, 128, (128, 32), 1, "relu", 3), (4, 16, (16, 16), 1, "relu", 70)])
