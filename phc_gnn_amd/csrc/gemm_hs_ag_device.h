@@ -318,8 +318,17 @@ __global__ __launch_bounds__(HS_AG_THREADS) PHC_AG_OCC void gemm_hs_ag_kernel(Ge
         if (!valid) tot = make_float4(0.f, 0.f, 0.f, 0.f);
         image[wave * ISTRIDE + lane] = f32x4_t{tot.x, tot.y, tot.z, tot.w};
         if (valid) {
-            reinterpret_cast<float4 *>(ag.s_out)[(size_t)d * H4 + c4] = tot;
-            if constexpr (NORMED) reinterpret_cast<float4 *>(ag.x_out)[(size_t)d * H4 + c4] = selfv;
+            // buffer stores: base in scalar registers, the lane's part a 32-bit offset (M <= 2^20 rows of 512 bytes).  As pointer
+            // arithmetic hipcc kept `s_out + lane chunk` and `x_out + lane chunk` as two 64-bit register pairs through the loop,
+            // spilled the second one (128 registers per lane: two workgroups per CU) and reloaded it in front of every row's store
+            // behind `s_waitcnt vmcnt(0)` — which also drained the row gathers issued ahead.
+            using u32x4 = __attribute__((ext_vector_type(4))) unsigned;
+            const int off = d * (H4 * 16) + c4 * 16;
+            __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(tot.x), __float_as_uint(tot.y), __float_as_uint(tot.z), __float_as_uint(tot.w)},
+                                                   __builtin_amdgcn_make_buffer_rsrc((void *)ag.s_out, 0, 0x7ffffff0, 0x00020000), off, 0, 0);
+            if constexpr (NORMED)
+                __builtin_amdgcn_raw_buffer_store_b128(u32x4{__float_as_uint(selfv.x), __float_as_uint(selfv.y), __float_as_uint(selfv.z), __float_as_uint(selfv.w)},
+                                                       __builtin_amdgcn_make_buffer_rsrc((void *)ag.x_out, 0, 0x7ffffff0, 0x00020000), off, 0, 0);
         }
     };
 

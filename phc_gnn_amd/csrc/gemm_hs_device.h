@@ -59,6 +59,7 @@ namespace phc {
 using f32x4_t = __attribute__((ext_vector_type(4))) float;
 
 constexpr int HS_ST = 1, HS_XF = 2, HS_BW = 4, HS_BA = 8, HS_DR = 16;
+constexpr int HS_BW_COLS = 256;                      // widest output the BW variants serve (their norm constants' LDS copy: [4][HS_BW_COLS])
 
 // XF operand whose batch statistics are still in an ACCUMULATOR: the launch derives scale / shift itself, in its prologue
 // (acc == NULL: xf_stat holds them, merged elsewhere).
@@ -167,7 +168,7 @@ constexpr size_t hs_slot_bytes() {                                // one operand
 template <int K, int RB, int R, int FLAGS>
 constexpr size_t hs_lds_bytes() {
     return (size_t)R * hs_slot_bytes<K, RB>() * ((FLAGS & HS_BA) ? 2 : 1) + ((FLAGS & HS_XF) ? 2 * (size_t)K * sizeof(float) : 0) +
-           ((FLAGS & HS_BA) ? 7 * (size_t)K * sizeof(float) : 0);
+           ((FLAGS & HS_BA) ? 7 * (size_t)K * sizeof(float) : 0) + (((FLAGS & HS_BW) && K == 256) ? 4 * (size_t)HS_BW_COLS * sizeof(float) : 0);
 }
 
 template <int K, int TPW, int WAVES, int RB, int R, int FLAGS>
@@ -179,6 +180,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
     const int KR = a.K;
     constexpr bool ST = (FLAGS & HS_ST) != 0, XF = (FLAGS & HS_XF) != 0, BW = (FLAGS & HS_BW) != 0, BA = (FLAGS & HS_BA) != 0;
     constexpr bool DR = (FLAGS & HS_DR) != 0;
+    constexpr bool BW_LDS = BW && K == 256;                      // the norm constants of the output columns parked in LDS behind the first step
     static_assert(!(BA && XF), "one operand transform per launch");
     static_assert(!DR || BA, "the dropout mask rides in the norm-backward transform");
     // DR: seed and step of the mask — a uniform address out of the kernel arguments: scalar loads (lgkmcnt), issued in front of
@@ -202,6 +204,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
     f32x4_t *ring = reinterpret_cast<f32x4_t *>(smem);            // [R][SLOT_F4]
     float *xf_lds = smem + (size_t)R * SLOT_F4 * 4;               // XF from an accumulator: scale[K] | shift[K]
     float *ba_lds = xf_lds;                                       // BA: invstd | mean | w | b | -mean(g x_hat) | -mean g | w invstd   [7][K]
+    float *bw_lds = xf_lds + (XF ? 2 * K : 0) + (BA ? 7 * K : 0);   // BW: mean | invstd | w | b of the OUTPUT columns   [4][HS_BW_COLS]
     const unsigned ring_lds = __builtin_amdgcn_readfirstlane((unsigned)(unsigned long long)(hs_lds_void *)smem);   // LDS byte address
 
     unsigned long long st_t[3] = {0, 0, 0}, st_r[3] = {0, 0, 0}, dbg_t[3] = {0, 0, 0};
@@ -599,6 +602,21 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
                     bwx[rb][t] = *reinterpret_cast<const f32x4_t *>(a.bw_x + (size_t)rowc * Nout + (col0 + 16 * t + 4 * kq < Nout ? col0 + 16 * t + 4 * kq : 0));
             }
         }
+        f32x4_t cw_mean[BW ? TPW : 1], cw_inv[BW ? TPW : 1], cw_w[BW ? TPW : 1], cw_b[BW ? TPW : 1];
+        if constexpr (BW) {
+#pragma unroll
+            for (int t = 0; t < TPW; ++t) {
+                if constexpr (decltype(first)::value || !BW_LDS) {
+                    cw_mean[t] = bw_mean[t]; cw_inv[t] = bw_inv[t]; cw_w[t] = bw_w[t]; cw_b[t] = bw_b[t];
+                } else {
+                    const int lc = min(col0 + 16 * t + 4 * kq, HS_BW_COLS - 4);
+                    cw_mean[t] = *reinterpret_cast<const f32x4_t *>(bw_lds + lc);
+                    cw_inv[t] = *reinterpret_cast<const f32x4_t *>(bw_lds + HS_BW_COLS + lc);
+                    cw_w[t] = *reinterpret_cast<const f32x4_t *>(bw_lds + 2 * HS_BW_COLS + lc);
+                    cw_b[t] = *reinterpret_cast<const f32x4_t *>(bw_lds + 3 * HS_BW_COLS + lc);
+                }
+            }
+        }
         const f32x4_t *sl = ring + (size_t)slot * SLOT_F4;
         f32x4_t acc[RB][TPW];
 #pragma unroll
@@ -656,8 +674,8 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
                         for (int t = 0; t < TPW; ++t)
 #pragma unroll
                             for (int q = 0; q < 4; ++q) {
-                                const float xh = (bwx[rb][t][q] - bw_mean[t][q]) * bw_inv[t][q];
-                                const float z = fmaf(xh, bw_w[t][q], bw_b[t][q]);
+                                const float xh = (bwx[rb][t][q] - cw_mean[t][q]) * cw_inv[t][q];
+                                const float z = fmaf(xh, cw_w[t][q], cw_b[t][q]);
                                 const float v = acc[rb][t][q];
                                 float gq;
                                 if constexpr (KIND == 1)
@@ -703,6 +721,22 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
     };
     step_body(0, std::true_type{});
     settle();
+    // BW: from here on the norm constants of this lane's columns live in LDS (every lane parks its own copy; the 16 row lanes of a
+    // column quad write the same words) and are re-read where a step's epilogue needs them.  Held in registers through the loop they
+    // were 32 of 256 + 12 more: the <256, 2, 8, ..., BA | BW> instantiations reloaded three spilled values from scratch several times
+    // per step — ordinary vector-memory loads in the middle of the ring's counted waits (zinc_b1024 1.845 -> 1.824 ms, molpcba_b1024
+    // 2.076 -> 2.064 without them).  K = 256 only: the narrower instantiations have the registers (and at K = 128 the extra LDS
+    // reads cost what they save: 0.5755 vs 0.5783 ms).
+    if constexpr (BW_LDS) {
+#pragma unroll
+        for (int t = 0; t < TPW; ++t) {
+            const int lc = min(col0 + 16 * t + 4 * kq, HS_BW_COLS - 4);
+            *reinterpret_cast<f32x4_t *>(bw_lds + lc) = bw_mean[t];
+            *reinterpret_cast<f32x4_t *>(bw_lds + HS_BW_COLS + lc) = bw_inv[t];
+            *reinterpret_cast<f32x4_t *>(bw_lds + 2 * HS_BW_COLS + lc) = bw_w[t];
+            *reinterpret_cast<f32x4_t *>(bw_lds + 3 * HS_BW_COLS + lc) = bw_b[t];
+        }
+    }
     for (long long i = 1; i < my_steps; ++i) step_body(i, std::false_type{});
     hs_wait_vm<0>();                                              // the clamped tail DMAs must not outlive the workgroup's LDS
 
