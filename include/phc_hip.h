@@ -830,9 +830,20 @@ typedef struct phc_downstream_desc {
      * and d0, d1, d2 any multiple of 4 in [16, 256] (the 256-wide heads of configs[2], the reference's 180 -> 180 -> 80 head),
      * B <= 2048 (phc_downstream_supported_k4).  Same results up to the fp32 summation order; same partial / sync protocol. */
     const float *H1k4, *H2k4, *H1Tk4, *H2Tk4;
+    /* ABI 7 (16-row kernels only; all zero / NULL: no dropout): phm_dropout behind the two activations (downstream.py:104-107,
+     * layers.py:31-55), the masks of phc_bn_fwd's fused dropout — a pure function of (seed, step, site, row, column group), so the
+     * backward launch re-derives them.  drop_same_k*: 0 = one mask value per element, else the component width (the mask is shared
+     * by the components); rng_state: device {seed, step}.  a1 [B, d1], a2 [B, d2]: the dropped activations, written by the forward
+     * when not NULL — with dropout the parameter-gradient jobs of layers 2 and 3 take them as x (the operand transform from
+     * (z, stat) knows no mask). */
+    float drop_p1, drop_p2;
+    int32_t drop_same_k1, drop_same_k2, drop_site1, drop_site2;
+    const uint64_t *rng_state;
+    float *a1, *a2;
 } phc_downstream_desc;
 int phc_downstream_supported(int64_t B, int d0, int d1, int d2, int d3, int T);
 int phc_downstream_supported_k4(int64_t B, int d0, int d1, int d2, int d3, int T);
+int phc_downstream_dropout_supported(int64_t B, int d0, int d1, int d2, int d3, int T);   /* ABI 7: the drop_* fields are served */
 size_t phc_downstream_partial_floats(int64_t B);
 int phc_downstream_fwd(const phc_downstream_desc *desc, void *stream);
 int phc_downstream_bwd(const phc_downstream_desc *desc, void *stream);

@@ -58,11 +58,13 @@ class PHMDownstreamNet(nn.Module):
     def forward(self, x: torch.Tensor, verbose=False, n_valid=None, **kwargs) -> torch.Tensor:
         last = len(self.affine) - 1
         engine = self.norm_flag and self.training and x.is_cuda and x.dim() == 2
-        if engine and last == 2 and self.real_trafo_type == "linear" and not any(p > 0.0 for p in self.dropout) and \
-                all(hasattr(nm.bn, "bn") for nm in self.norm) and not verbose:
-            # the whole head (three PHM layers, two norms, the dense map to the targets) in ONE engine launch each way
+        if engine and last == 2 and self.real_trafo_type == "linear" and all(hasattr(nm.bn, "bn") for nm in self.norm) and not verbose:
+            # the whole head (three PHM layers, two norms, the dense map to the targets) in ONE engine launch each way; with
+            # dropout (:104-107) the masks of the stand-alone fused passes (sites 64 + i) are drawn inside it
             y = _engine.downstream_head(x, n_valid, list(self.affine), [nm.bn for nm in self.norm], self.real_trafo.affine,
-                                        self.activation_str)
+                                        self.activation_str,
+                                        dropout=((self.dropout[0], self.dropout[1]), self.same_dropout, (64, 65))
+                                        if any(p > 0.0 for p in self.dropout[:2]) else None)
             if y is not None:
                 return y
         i = 0

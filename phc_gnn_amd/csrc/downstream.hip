@@ -60,6 +60,13 @@ struct DnArgs {
     float *z1, *z2, *z3, *logits, *stat1, *stat2;             // forward outputs (z*, stat* are what the backward reads)
     const float *dlogits;
     float *dx, *dz1, *dz2, *dz3, *dwb1, *dwb2, *dWr, *dbr;    // backward outputs
+    // v2 only: phm_dropout behind the two activations (downstream.py:104-107; layers.py:31-55) — keep-and-scale factors of
+    // drop_factors_v(p, same, k, site, seed, step, row, column, width); a1 / a2: the dropped activations [B, d1] / [B, d2] the
+    // forward leaves for the parameter-gradient jobs of layers 2 and 3 (without dropout those re-derive them from z and save_stat)
+    float drop_p1, drop_p2;
+    int drop_same1, drop_same2, drop_k1, drop_k2, drop_site1, drop_site2;
+    const unsigned long long *rng;                            // device {seed, step}; NULL: no dropout
+    float *a1, *a2;
     unsigned long long *partial;                              // [2][G][DN_PSTRIDE] {value, tag} granules
     unsigned *sync;                                           // generation word
     int *err;                                                 // device error word (phc_set_error_word) or NULL
@@ -984,7 +991,8 @@ __device__ __forceinline__ void d2_fwd_norm(const DnArgs &a, const DnNorm &bn, c
 // Aout = act(Z * scale + shift) on the slab (rows >= n_valid: 0; columns N .. r16(N): 0)
 template <int RB>
 __device__ __forceinline__ void d2_apply_norm_act(const float *Z, int ldz, float *Aout, int lda, int N, const float *sc, int act, int rb,
-                                                  int nvalid) {
+                                                  int nvalid, float drop_p = 0.f, int drop_same = 0, int drop_k = 4, int drop_site = 0,
+                                                  unsigned long long seed = 0, unsigned long long step = 0) {
     const int n4 = r16(N) >> 2;
     const bool relu = act == PHC_ACT_RELU;
     for (int e = threadIdx.x; e < 16 * RB * n4; e += D2_THREADS) {
@@ -999,6 +1007,10 @@ __device__ __forceinline__ void d2_apply_norm_act(const float *Z, int ldz, float
             } else {
                 o.x = act_fwd_rt(act, fmaf(z.x, s4.x, h4.x)); o.y = act_fwd_rt(act, fmaf(z.y, s4.y, h4.y));
                 o.z = act_fwd_rt(act, fmaf(z.z, s4.z, h4.z)); o.w = act_fwd_rt(act, fmaf(z.w, s4.w, h4.w));
+            }
+            if (drop_p > 0.f) {                                  // (uniform)
+                const float4 f = drop_factors_v(drop_p, drop_same, drop_k, drop_site, seed, step, rb + row, c, N);
+                o.x *= f.x; o.y *= f.y; o.z *= f.z; o.w *= f.w;
             }
         }
         *reinterpret_cast<float4 *>(Aout + row * lda + c) = o;
@@ -1039,6 +1051,7 @@ __global__ __launch_bounds__(D2_THREADS) void downstream2_fwd_kernel(DnArgs a) {
     float *Hs3 = sm + L.off_small, *wr = Hs3 + r4(d2 * d3), *z3s = wr + r4(T * d3 + T), *bs = z3s + r4(R * d3);     // bs: b1 | b2 | b3
     const unsigned tag = __hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
     const int nvalid = a.n_valid ? min(*a.n_valid, a.B) : a.B;
+    const unsigned long long rng_seed = a.rng ? a.rng[0] : 0ull, rng_step = a.rng ? a.rng[1] : 0ull;    // (uniform: scalar loads)
 
     // ---- everything this launch reads from memory goes in flight now: the first GEMM's operand slice into registers, the
     // x slab and the small operands into LDS ----
@@ -1100,7 +1113,8 @@ __global__ __launch_bounds__(D2_THREADS) void downstream2_fwd_kernel(DnArgs a) {
     // element-wise pass
     d2_load_operand(a.H2k4, d1, d2, p2, lane, h);
     DN_STAMP(5);
-    d2_apply_norm_act<RB>(bufB, L.ld1, bufA, L.ld1, d1, sc, a.act, rb, nvalid);
+    d2_apply_norm_act<RB>(bufB, L.ld1, bufA, L.ld1, d1, sc, a.act, rb, nvalid, a.drop_p1, a.drop_same1, a.drop_k1, a.drop_site1, rng_seed, rng_step);
+    if (a.a1) d2_store_rows<RB>(bufA, L.ld1, a.B, rb, d1, a.a1);
     // layer 2
     DN_STAMP(6);
     d2_gemm<RB>(bufA, L.ld1, h, p2, d2, bs + D2_MAXW, red, bufB, L.ld2);
@@ -1108,7 +1122,8 @@ __global__ __launch_bounds__(D2_THREADS) void downstream2_fwd_kernel(DnArgs a) {
     d2_store_rows<RB>(bufB, L.ld2, a.B, rb, d2, a.z2);
     d2_fwd_norm<RB>(a, a.bn2, bufB, L.ld2, d2, nvalid, a.partial + (size_t)a.G * D2_PSTRIDE, tag, sc, red, w2, bb2, rm2, rv2, k2, 8);
     DN_STAMP(10);
-    d2_apply_norm_act<RB>(bufB, L.ld2, bufA, L.ld2, d2, sc, a.act, rb, nvalid);
+    d2_apply_norm_act<RB>(bufB, L.ld2, bufA, L.ld2, d2, sc, a.act, rb, nvalid, a.drop_p2, a.drop_same2, a.drop_k2, a.drop_site2, rng_seed, rng_step);
+    if (a.a2) d2_store_rows<RB>(bufA, L.ld2, a.B, rb, d2, a.a2);
     // layer 3 (d2 -> d3 = n * target, a handful of columns) and the real head (d3 -> T): plain FMAs
     // (eight lanes per output element, each a strided eighth of the contraction, fixed-order butterfly: one thread per element
     // walked d2 dependent LDS reads — 1.6 us for 64 outputs)
@@ -1251,7 +1266,8 @@ __device__ __forceinline__ void d2_merge_extras(const unsigned long long *part, 
 // g = da * act'(x_hat w + b), x_hat = (z - mean) invstd for the slab: DA (LDS) and Z (LDS) -> Gout, XHout (may alias DA / Z)
 template <int RB>
 __device__ __forceinline__ void d2_gate_rows(const float *DA, const float *Z, int ld, int N, const float *st, int act, int rb, int nvalid,
-                                             float *Gout, float *XHout) {
+                                             float *Gout, float *XHout, float drop_p = 0.f, int drop_same = 0, int drop_k = 4,
+                                             int drop_site = 0, unsigned long long seed = 0, unsigned long long step = 0) {
     const bool relu = act == PHC_ACT_RELU;
     const int Np = r16(N);
     for (int e = threadIdx.x; e < 16 * RB * Np; e += D2_THREADS) {
@@ -1263,6 +1279,11 @@ __device__ __forceinline__ void d2_gate_rows(const float *DA, const float *Z, in
             const float da = DA[row * ld + c];
             gv = relu ? (pre > 0.f ? da : 0.f) : da * act_grad_rt(act, pre);
             if (rb + row >= nvalid) gv = 0.f;
+            if (drop_p > 0.f) {                                  // the forward's mask on the upstream gradient (uniform branch)
+                const float4 f = drop_factors_v(drop_p, drop_same, drop_k, drop_site, seed, step, rb + row, c & ~3, N);
+                const int q = c & 3;
+                gv *= q == 0 ? f.x : (q == 1 ? f.y : (q == 2 ? f.z : f.w));
+            }
         }
         Gout[row * ld + c] = gv;
         XHout[row * ld + c] = xh;
@@ -1283,6 +1304,7 @@ __global__ __launch_bounds__(D2_THREADS) void downstream2_bwd_kernel(DnArgs a) {
           *st1 = dz3s + r4(R * d3), *st2 = st1 + 4 * D2_MAXW, *bufC = st2 + 4 * D2_MAXW;        // st*: mean | invstd | w | b
     const unsigned tag = __hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
     const int nvalid = a.n_valid ? min(*a.n_valid, a.B) : a.B;
+    const unsigned long long rng_seed = a.rng ? a.rng[0] : 0ull, rng_step = a.rng ? a.rng[1] : 0ull;    // (uniform: scalar loads)
     (void)ldm;
 
     // ---- everything in flight: the first GEMM's operand (H2^T) into registers, the slabs of z2 / z1 and the small operands into LDS ----
@@ -1339,7 +1361,7 @@ __global__ __launch_bounds__(D2_THREADS) void downstream2_bwd_kernel(DnArgs a) {
     }
     d2_lds_barrier();
     DN_STAMP(18);
-    d2_gate_rows<RB>(bufA, bufB, L.ld2, d2, st2, a.act, rb, nvalid, bufA, bufB);
+    d2_gate_rows<RB>(bufA, bufB, L.ld2, d2, st2, a.act, rb, nvalid, bufA, bufB, a.drop_p2, a.drop_same2, a.drop_k2, a.drop_site2, rng_seed, rng_step);
     DN_STAMP(19);
     float sg2 = 0.f, sgx2 = 0.f, sg1 = 0.f, sgx1 = 0.f;
     d2_bwd_norm<RB>(a, bufA, bufB, L.ld2, d2, nvalid, rb, part1, tag, st2, sc, red, sg2, sgx2, 20);
@@ -1349,7 +1371,8 @@ __global__ __launch_bounds__(D2_THREADS) void downstream2_bwd_kernel(DnArgs a) {
     d2_gemm<RB>(bufA, L.ld2, h, pa, d1, nullptr, red, bufB, L.ld1);
     DN_STAMP(23);
     if (a.dx) d2_load_operand(a.H1Tk4, d1, d0, pb, lane, h);
-    d2_gate_rows<RB>(bufB, bufC, L.ld1, d1, st1, a.act, rb, nvalid, bufA, bufB);       // g1 -> bufA, x_hat1 -> bufB
+    d2_gate_rows<RB>(bufB, bufC, L.ld1, d1, st1, a.act, rb, nvalid, bufA, bufB, a.drop_p1, a.drop_same1, a.drop_k1, a.drop_site1, rng_seed,
+                     rng_step);                                                          // g1 -> bufA, x_hat1 -> bufB
     DN_STAMP(24);
     d2_bwd_norm<RB>(a, bufA, bufB, L.ld1, d1, nvalid, rb, part2, tag, st1, sc, red, sg1, sgx1, 25);
     DN_STAMP(27);
@@ -1520,6 +1543,24 @@ static int dn_common(const char *who, const phc_downstream_desc *d, DnArgs *a, b
     a->B = (int)d->B; a->d0 = d->d0; a->d1 = d->d1; a->d2 = d->d2; a->d3 = d->d3; a->T = d->T; a->act = d->act;
     a->G = *v2 ? (a->B + 16 * dn2_rb(a->B) - 1) / (16 * dn2_rb(a->B)) : (a->B + DN_ROWS - 1) / DN_ROWS;
     a->H1k4 = d->H1k4; a->H2k4 = d->H2k4; a->H1Tk4 = d->H1Tk4; a->H2Tk4 = d->H2Tk4;
+    {
+        const bool dropping = d->drop_p1 > 0.f || d->drop_p2 > 0.f;
+        PHC_REQUIRE(!dropping || *v2, PHC_ERR_UNSUPPORTED, "%s: dropout inside the fused head needs the 16-row kernels (k4 operands, their shapes)", who);
+        PHC_REQUIRE(!dropping || (d->rng_state && d->drop_p1 < 1.f && d->drop_p2 < 1.f && d->drop_p1 >= 0.f && d->drop_p2 >= 0.f),
+                    PHC_ERR_INVALID_ARG, "%s: dropout p = %g / %g needs 0 <= p < 1 and an rng state", who, (double)d->drop_p1, (double)d->drop_p2);
+        PHC_REQUIRE(!dropping || ((d->drop_same_k1 == 0 || (d->drop_same_k1 % 4 == 0 && d->d1 % d->drop_same_k1 == 0)) &&
+                                  (d->drop_same_k2 == 0 || (d->drop_same_k2 % 4 == 0 && d->d2 % d->drop_same_k2 == 0))),
+                    PHC_ERR_UNSUPPORTED, "%s: a shared dropout mask needs component widths that are multiples of 4", who);
+        a->drop_p1 = d->drop_p1; a->drop_p2 = d->drop_p2;
+        a->drop_same1 = d->drop_same_k1 > 0; a->drop_same2 = d->drop_same_k2 > 0;
+        a->drop_k1 = d->drop_same_k1 > 0 ? d->drop_same_k1 : d->d1;
+        a->drop_k2 = d->drop_same_k2 > 0 ? d->drop_same_k2 : d->d2;
+        a->drop_site1 = d->drop_site1; a->drop_site2 = d->drop_site2;
+        a->rng = dropping ? reinterpret_cast<const unsigned long long *>(d->rng_state) : nullptr;
+        a->a1 = *v2 ? d->a1 : nullptr; a->a2 = *v2 ? d->a2 : nullptr;
+        PHC_REQUIRE(((reinterpret_cast<uintptr_t>(d->a1) | reinterpret_cast<uintptr_t>(d->a2)) & 15) == 0, PHC_ERR_UNSUPPORTED,
+                    "%s: 16-byte aligned a1 / a2 required", who);
+    }
     a->n_valid = d->n_valid_dev;
     a->partial = reinterpret_cast<unsigned long long *>(d->partial);
     a->sync = reinterpret_cast<unsigned *>(d->sync);
@@ -1551,6 +1592,12 @@ int phc_downstream_supported_k4(int64_t B, int d0, int d1, int d2, int d3, int T
     const int Bc = (int)(B > (1LL << 20) ? 1 << 20 : B);
     if (dn2_shape_ok(Bc, d0, d1, d2, d3, T) && dn2_device_ok(Bc, d0, d1, d2, d3, T)) return 1;
     return phc_downstream_supported(B, d0, d1, d2, d3, T);
+}
+
+/* dropout inside the fused head (phc_downstream_desc.drop_*): served by the 16-row kernels only */
+int phc_downstream_dropout_supported(int64_t B, int d0, int d1, int d2, int d3, int T) {
+    const int Bc = (int)(B > (1LL << 20) ? 1 << 20 : B);
+    return (d1 % 4 == 0 && d2 % 4 == 0 && dn2_shape_ok(Bc, d0, d1, d2, d3, T) && dn2_device_ok(Bc, d0, d1, d2, d3, T)) ? 1 : 0;
 }
 
 size_t phc_downstream_partial_floats(int64_t B) {

@@ -59,7 +59,9 @@ class DownstreamDesc(C.Structure):
                 ("dlogits", _P),
                 ("dx", _P), ("dz1", _P), ("dz2", _P), ("dz3", _P), ("dwb1", _P), ("dwb2", _P), ("dWr", _P),
                 ("partial", _P), ("sync", _P),
-                ("H1k4", _P), ("H2k4", _P), ("H1Tk4", _P), ("H2Tk4", _P)]
+                ("H1k4", _P), ("H2k4", _P), ("H1Tk4", _P), ("H2Tk4", _P),
+                ("drop_p1", C.c_float), ("drop_p2", C.c_float), ("drop_same_k1", C.c_int32), ("drop_same_k2", C.c_int32),
+                ("drop_site1", C.c_int32), ("drop_site2", C.c_int32), ("rng_state", _P), ("a1", _P), ("a2", _P)]
 
 
 class HeadStage(C.Structure):
@@ -175,6 +177,7 @@ SIGNATURES = {
     "phc_bn_bwd_apply": (_I, [_P, _P, _P, _P, _L, _L, _I, _I, _P, _P, _S, _P]),
     "phc_downstream_supported": (_I, [_L, _I, _I, _I, _I, _I]),
     "phc_downstream_supported_k4": (_I, [_L, _I, _I, _I, _I, _I]),
+    "phc_downstream_dropout_supported": (_I, [_L, _I, _I, _I, _I, _I]),
     "phc_downstream_partial_floats": (_S, [_L]),
     "phc_downstream_fwd": (_I, [C.POINTER(DownstreamDesc), _P]),
     "phc_downstream_bwd": (_I, [C.POINTER(DownstreamDesc), _P]),

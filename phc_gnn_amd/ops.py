@@ -200,6 +200,14 @@ def _flush_encoder_grads(ajobs) -> None:
             _assign_grads(aj["params"], aj["ts"].grad_views(flat[i * per:(i + 1) * per]))
 
 
+# Order of the dH family's jobs inside the step tail, by rows (stable): "desc" = the node-level jobs first, the head's few-row jobs
+# last.  Workgroups start in job order and the launch holds more of them than the device has slots: the late starters should be
+# the short ones.  The fused head appends its three jobs in forward order, the per-layer path in backward order — with dropout
+# inside the fused head (this round) zinc_pub_phc4_4x180's tail went 270 -> 321 us until the order was fixed; "desc" against the
+# order of arrival: 1.479 -> 1.426 ms there, molpcba_b1024 2.071 -> 2.064, molhiv_b512 0.577 -> 0.567, the others unchanged.
+TAIL_JOB_ORDER = __import__("os").environ.get("PHC_TAIL_JOB_ORDER", "desc")   # "none", "asc", "desc"
+
+
 def _flush_step_tail(jobs, tjobs, ajobs, reg=None) -> bool:
     """Everything in one phc_step_tail call when the shapes allow it; False: the caller runs the separate flushes (``reg``, a
     parked weight regulariser, is then still the caller's to launch)."""
@@ -224,6 +232,8 @@ def _flush_step_tail(jobs, tjobs, ajobs, reg=None) -> bool:
             (ajobs and ajobs[0]["dout"].device != dev):
         return False
     lib = L.load()
+    if TAIL_JOB_ORDER in ("asc", "desc"):
+        jobs.sort(key=lambda jb: jb["x"].shape[0], reverse=(TAIL_JOB_ORDER == "desc"))
     with torch.cuda.device(dev):
         # PHM / dense jobs
         total = 0
@@ -3210,6 +3220,13 @@ def _dn_norm(norm_tensors, n_comp, momentum, eps, keep):
     return L.DownstreamNorm(cast(arrs[0]), cast(arrs[1]), cast(arrs[2]), cast(arrs[3]), cast(arrs[4]), n_comp, float(momentum), float(eps))
 
 
+def _dn_set_drop(d, drop):
+    (p1, k1, s1), (p2, k2, s2), state = drop
+    d.drop_p1, d.drop_same_k1, d.drop_site1 = float(p1), int(k1), int(s1)
+    d.drop_p2, d.drop_same_k2, d.drop_site2 = float(p2), int(k2), int(s2)
+    d.rng_state = L.ptr(state)
+
+
 class _DownstreamFn(torch.autograd.Function):
     """logits = RealTransformer(PHMDownstreamNet(x)) for two hidden layers, training mode (downstream.py:90-120,
     layers.py:399-414): ONE engine launch forward, ONE backward (``phc_downstream_fwd`` / ``_bwd``).  The PHM layers'
@@ -3244,9 +3261,17 @@ class _DownstreamFn(torch.autograd.Function):
         d.partial, d.sync = L.ptr(partial), L.ptr(sync)
         d.H1k4, d.H2k4 = L.ptr(pre[0][2]), L.ptr(pre[1][2])                        # k4 forms (None: the 32-row kernels)
         d.H1Tk4, d.H2Tk4 = L.ptr(pre[0][3]), L.ptr(pre[1][3])
+        drop = meta.get("drop")                              # ((p1, same_k1, site1), (p2, same_k2, site2), rng state) or None
+        a1 = a2 = None
+        if drop is not None:
+            a1 = torch.empty((B, d1), dtype=torch.float32, device=dev)
+            a2 = torch.empty((B, d2), dtype=torch.float32, device=dev)
+            _dn_set_drop(d, drop)
+            d.a1, d.a2 = L.ptr(a1), L.ptr(a2)
         L.check(lib.phc_downstream_fwd(_C.byref(d), L.stream_ptr(dev)), "phc_downstream_fwd")
-        _tap(z1, stat1, n_valid, act)
-        _tap(z2, stat2, n_valid, act)
+        if drop is None:
+            _tap(z1, stat1, n_valid, act)
+            _tap(z2, stat2, n_valid, act)
         if L.PROF_ON:
             L.account("downstream_fwd", 2.0 * B * (d0 * d1 + d1 * d2 + d2 * d3 + d3 * T), 4.0 * (B * (d0 + d1 + d2 + d3 + T) + d0 * d1 + d1 * d2))
         ctx.save_for_backward(x_, z1, z2, z3, stat1, stat2, Wr)
@@ -3254,6 +3279,7 @@ class _DownstreamFn(torch.autograd.Function):
         ctx.n_valid = n_valid
         ctx.phm = ((A1, W1, b1), (A2, W2, b2), (A3, W3, b3))
         ctx.n_affine = len(affine)
+        ctx.dropped = (a1, a2)
         return logits
 
     @staticmethod
@@ -3273,6 +3299,7 @@ class _DownstreamFn(torch.autograd.Function):
         dwb2 = torch.empty(2 * d2, dtype=torch.float32, device=dev)
         dWr = torch.empty(T * d3 + T, dtype=torch.float32, device=dev)
         sync, partial = _dn_buffers(dev, "bwd", B)
+        a1, a2 = ctx.dropped
         d = L.DownstreamDesc()
         d.B, d.d0, d.d1, d.d2, d.d3, d.T, d.act = B, d0, d1, d2, d3, T, act
         d.n_valid_dev = L.ptr(n_valid)
@@ -3283,12 +3310,15 @@ class _DownstreamFn(torch.autograd.Function):
         d.partial, d.sync = L.ptr(partial), L.ptr(sync)
         d.H1k4, d.H2k4 = L.ptr(pre[0][2]), L.ptr(pre[1][2])
         d.H1Tk4, d.H2Tk4 = L.ptr(pre[0][3]), L.ptr(pre[1][3])
+        if meta.get("drop") is not None:
+            _dn_set_drop(d, meta["drop"])                    # the forward's masks, re-derived from (seed, step, site, row, column)
         L.check(lib.phc_downstream_bwd(_C.byref(d), L.stream_ptr(dev)), "phc_downstream_bwd")
         if L.PROF_ON:
             L.account("downstream_bwd", 2.0 * B * (d0 * d1 + d1 * d2 + 2 * d2 * d3 + 2 * d3 * T), 4.0 * (B * (d0 + 2 * d1 + 2 * d2 + 2 * d3 + T) + d0 * d1 + d1 * d2))
         # the three PHM layers' parameter gradients: jobs for the batched gradient launches
         needs = ctx.needs_input_grad
-        xs = ((x_, None), (z1, (stat1, n_valid, act)), (z2, (stat2, n_valid, act)))
+        # (with dropout the layers' inputs are the dropped activations the forward wrote: the operand transform knows no mask)
+        xs = ((x_, None), (z1, (stat1, n_valid, act)), (z2, (stat2, n_valid, act))) if a1 is None else ((x_, None), (a1, None), (a2, None))
         dys = (dz1, dz2, dz3)
         jobs, grads = [], []
         for i, (A, W, b) in enumerate(ctx.phm):
@@ -3481,7 +3511,10 @@ class _HeadChainFn(torch.autograd.Function):
         return (dx, None, None, *flat, grads[3][1], grads[3][2], *aff)
 
 
-def downstream_head(x, n_valid, affine_layers, norm_modules, real_affine, activation: str):
+HEAD_DROPOUT = __import__("os").environ.get("PHC_HEAD_DROPOUT", "1") != "0"
+
+
+def downstream_head(x, n_valid, affine_layers, norm_modules, real_affine, activation: str, dropout=None):
     """The fused head, or ``None`` when its preconditions do not hold (the caller then runs layer by layer): three PHM
     layers with prebuilt operand matrices (inside ``prebuilt_H``), two naive batch-norms with running statistics, a dense
     nn.Linear head, widths the kernel supports (``phc_downstream_supported``)."""
@@ -3505,6 +3538,17 @@ def downstream_head(x, n_valid, affine_layers, norm_modules, real_affine, activa
         return None
     chain = False
     WrT, valid_max = None, x.shape[0]
+    drop = None
+    if dropout is not None and any(p > 0.0 for p in dropout[0]):
+        # phm_dropout behind the two activations (``dropout`` = ((p1, p2), same, (site1, site2))): the 16-row kernels draw the masks
+        # of the stand-alone fused passes; widths and component widths multiples of 4
+        (p1, p2), same, (s1, s2) = dropout
+        n1, n2 = len(list(norm_modules[0].bn)), len(list(norm_modules[1].bn))
+        k1, k2 = (d1 // n1 if same else 0), (d2 // n2 if same else 0)
+        if not (HEAD_DROPOUT and has_k4 and lib.phc_downstream_supported_k4(x.shape[0], d0, d1, d2, d3, T) and d1 % 4 == 0 and d2 % 4 == 0
+                and k1 % 4 == 0 and k2 % 4 == 0 and lib.phc_downstream_dropout_supported(x.shape[0], d0, d1, d2, d3, T)):
+            return None
+        drop = ((float(p1), k1, int(s1)), (float(p2), k2, int(s2)), rng_state(x.device))
     if not supported(x.shape[0], d0, d1, d2, d3, T):
         # beyond the 16-row kernels (molpcba: 768-wide hidden layer, 128 targets): the 2-D chain kernel, when its shapes and the
         # device allow it and the dense head's transpose is among the step's prebuilt operands
@@ -3532,7 +3576,9 @@ def downstream_head(x, n_valid, affine_layers, norm_modules, real_affine, activa
                           affine=bool(nm.affine)))
         if nm.affine:
             affine.extend(w + b)
-    meta = dict(act=_act_id(activation), norms=norms, pre=pre, WrT=WrT, valid_max=valid_max)
+    if drop is not None and chain:
+        return None
+    meta = dict(act=_act_id(activation), norms=norms, pre=pre, WrT=WrT, valid_max=valid_max, drop=drop)
     l1, l2, l3 = affine_layers
     if chain:
         return _HeadChainFn.apply(x, n_valid, meta, l1.phm_rule, l1.W, l1.b, l2.phm_rule, l2.W, l2.b, l3.phm_rule, l3.W, l3.b, Wr, br, *affine)

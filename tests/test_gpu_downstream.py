@@ -126,3 +126,49 @@ def test_fused_head_padding_rows_are_inert_and_launches_repeat(n, d_in, hidden, 
     for y2, dx2, g2 in outs[1:]:
         assert torch.equal(y2, y) and torch.equal(dx2, dx)
         assert all(torch.equal(g2[k], grads[k]) for k in grads)
+
+
+@pytest.mark.parametrize("n,d_in,hidden,act,B,p,same", [
+    (4, 200, (128, 32), "relu", 544, (0.3, 0.1), False),       # the published ogbg-molhiv head (benchmarks/README.md: d_units 128, 32; dropout_dn 0.3, 0.1)
+    (4, 180, (180, 80), "swish", 1056, (0.2, 0.1), False),     # run_script_zinc_phm4.sh's head at the graph-replay batch
+    (4, 128, (128, 32), "swish", 100, (0.5, 0.25), True),      # masks shared by the components
+    (8, 256, (256, 128), "relu", 1056, (0.2, 0.1), True),
+    (4, 128, (128, 32), "swish", 1500, (0.0, 0.4), False),     # 32-row workgroups, dropout behind the second activation only
+])
+def test_fused_head_with_dropout_matches_the_per_layer_path(n, d_in, hidden, act, B, p, same):
+    """phm_dropout behind the head's activations (downstream.py:104-107) inside the one-launch head: the masks are the stand-alone fused
+    passes' (a function of seed, step, site, row and column group), so the same seed gives the same function — logits, dx and every
+    parameter gradient against the layer-by-layer path with its `phc_bn_fwd` dropout."""
+    from phc_gnn_amd import lib, ops
+    if not lib.load().phc_downstream_dropout_supported(B, d_in, hidden[0], hidden[1], n * 1, 1):
+        pytest.skip("shape outside the 16-row fused head")
+    g = torch.Generator().manual_seed(38)
+    x, dy = torch.randn(B, d_in, generator=g), torch.randn(B, 1, generator=g)
+    res = []
+    for fused in (True, False):
+        dn = _make(n, d_in, hidden, 1, act, seed=37)
+        dn.dropout, dn.same_dropout = list(p), same
+        dn.to(DEV)
+        keep = ops.HEAD_DROPOUT
+        ops.HEAD_DROPOUT = fused
+        try:
+            ops.rng_seed(torch.device(DEV), 1234)
+            xd = x.to(DEV).requires_grad_()
+            with ops.prebuilt_H(ops.phm_pairs(dn), ops.dense_weights(dn)):
+                y = dn(xd)
+                assert (type(y.grad_fn).__name__ == "_DownstreamFnBackward") == fused, type(y.grad_fn).__name__
+                y.backward(dy.to(DEV))
+        finally:
+            ops.HEAD_DROPOUT = keep
+        res.append((y.detach(), xd.grad, {k: q.grad for k, q in dn.named_parameters() if q.grad is not None},
+                    {k: b.clone() for k, b in dn.named_buffers() if b.is_floating_point()}))
+    tol = 3e-5 if act != "relu" else 2e-4
+    assert_close(res[0][0], res[1][0], tol, "logits")
+    assert_close(res[0][1], res[1][1], tol, "dx")
+    # the masks really dropped something: a p-fraction of the second layer's input is zero on both paths alike
+    assert float((res[0][1] == 0).float().mean()) < 0.5
+    for k in res[1][2]:
+        if k not in ("affine.0.b", "affine.1.b"):
+            assert_close(res[0][2][k], res[1][2][k], tol, "grad " + k)
+    for k in res[1][3]:
+        assert_close(res[0][3][k], res[1][3][k], tol, k)
