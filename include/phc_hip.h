@@ -877,6 +877,13 @@ typedef struct phc_head_stage {
     float *stat;                   /* post 1: save_stat out [6 N]; post 2: save_stat in */
     float *dwb;                    /* post 2: [2 N] out, may be NULL */
     phc_downstream_norm norm;      /* post 1 */
+    /* phm_dropout behind the activation of a post 1 stage and, with the same values, in the post 2 stage of the backward chain that
+     * undoes it (drop_p = 0: none; drop_same_k: 0 or the component width of a mask shared by the components; the masks of
+     * phc_bn_fwd's fused dropout — phc_head_chain_desc.rng_state).  a_out (post 1, may be NULL): the (dropped) activation [B][N],
+     * the x of the next layer's parameter-gradient job when a mask is on. */
+    float drop_p;
+    int32_t drop_same_k, drop_site;
+    float *a_out;
 } phc_head_stage;
 typedef struct phc_head_chain_desc {
     int64_t B;
@@ -889,6 +896,7 @@ typedef struct phc_head_chain_desc {
     phc_head_stage stage[PHC_HEAD_MAX_STAGES];
     float *work;
     uint32_t *sync;
+    const uint64_t *rng_state;     /* device {seed, step}; needed when a stage has drop_p > 0 */
 } phc_head_chain_desc;
 int phc_head_chain_supported(int64_t B, int64_t valid_rows_max, int n_stages, const int32_t *K, const int32_t *N);
 size_t phc_head_chain_work_floats(int64_t B, int n_stages, const int32_t *N);

@@ -53,6 +53,9 @@ struct HcNorm {
 struct HcStage {
     const float *M, *bias, *z;
     float *out, *stat, *dwb;
+    float *a_out;                                    // post 1: the (dropped) activation [B][N] for the parameter-gradient job of the next layer, or null
+    float drop_p;                                    // post 1 / 2: phm_dropout behind the activation (0: none); mask = drop_factors_v(...)
+    int drop_same, drop_k, drop_site;
     int K, N, post;
     // filled by the host from (K, N, CB): the column block, its GEMM plan (hc_plan) and the stage's records in the work buffer (granules)
     int Nc, tiles, kg, ksplit, U;
@@ -66,6 +69,7 @@ struct HcArgs {
     HcNorm bn[2];                                    // the norms of stages 0 and 1 (post 1)
     unsigned long long *work;
     unsigned *sync;                                  // [0] generation, [1] arrivals of the running launch
+    const unsigned long long *rng;                   // device {seed, step} of the dropout masks, or null
     int *err;
     int lda, ldn, off_o, off_z, off_red, off_sc, off_st, off_bias;      // LDS carve-up (hc_lds), floats
 };
@@ -404,6 +408,7 @@ __global__ __launch_bounds__(HC_THREADS) void head_chain_kernel(HcArgs a) {
     const unsigned tag = __hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
     const int nvalid = a.n_valid ? min(*a.n_valid, a.B) : a.B;
     const int nv = hc_rows_counted(nvalid, rbi);
+    const unsigned long long rng_seed = a.rng ? a.rng[0] : 0ull, rng_step = a.rng ? a.rng[1] : 0ull;      // (uniform: scalar loads)
     const int RBv = max((nvalid + 15) >> 4, 1);      // row blocks with valid rows: they deal the norms' columns among themselves
     if (blockIdx.x == 0 && tid == 0 && nvalid > a.valid_max && a.err) atomicOr(a.err, PHC_ERR_RENDEZVOUS);      // (the caller's bound does not hold)
 
@@ -418,7 +423,10 @@ __global__ __launch_bounds__(HC_THREADS) void head_chain_kernel(HcArgs a) {
                 const int N = st.N, Nc = st.Nc, c0 = cb * Nc, w4 = Nc >> 2;
                 for (int e = tid; e < 16 * w4; e += HC_THREADS) {
                     const int row = e / w4, c4 = e - row * w4;
-                    if (r0 + row < a.B) *reinterpret_cast<float4 *>(st.out + (size_t)(r0 + row) * N + c0 + 4 * c4) = make_float4(0.f, 0.f, 0.f, 0.f);
+                    if (r0 + row < a.B) {
+                        *reinterpret_cast<float4 *>(st.out + (size_t)(r0 + row) * N + c0 + 4 * c4) = make_float4(0.f, 0.f, 0.f, 0.f);
+                        if (st.a_out) *reinterpret_cast<float4 *>(st.a_out + (size_t)(r0 + row) * N + c0 + 4 * c4) = make_float4(0.f, 0.f, 0.f, 0.f);
+                    }
                 }
             }
         }
@@ -497,6 +505,12 @@ __global__ __launch_bounds__(HC_THREADS) void head_chain_kernel(HcArgs a) {
                         const float da = tileO[row * ldn + c];
                         float gv = relu ? (pre > 0.f ? da : 0.f) : da * act_grad_rt(a.act, pre);
                         if (r0 + row >= nvalid) gv = 0.f;
+                        if (st.drop_p > 0.f) {                       // the forward's mask on the upstream gradient (uniform branch)
+                            const float4 f = drop_factors_v(st.drop_p, st.drop_same, st.drop_k, st.drop_site, rng_seed, rng_step, r0 + row,
+                                                            (c0 + c) & ~3, N);
+                            const int q = c & 3;
+                            gv *= q == 0 ? f.x : (q == 1 ? f.y : (q == 2 ? f.z : f.w));
+                        }
                         tileO[row * ldn + c] = gv;
                         tileZ[row * ldn + c] = xh;
                     }
@@ -635,6 +649,11 @@ __global__ __launch_bounds__(HC_THREADS) void head_chain_kernel(HcArgs a) {
                                 o.x = act_fwd_rt(a.act, fmaf(z.x, s4.x, h4.x)); o.y = act_fwd_rt(a.act, fmaf(z.y, s4.y, h4.y));
                                 o.z = act_fwd_rt(a.act, fmaf(z.z, s4.z, h4.z)); o.w = act_fwd_rt(a.act, fmaf(z.w, s4.w, h4.w));
                             }
+                            if (st.drop_p > 0.f) {                   // (uniform)
+                                const float4 f = drop_factors_v(st.drop_p, st.drop_same, st.drop_k, st.drop_site, rng_seed, rng_step, r0 + row,
+                                                                c0 + c, N);
+                                o.x *= f.x; o.y *= f.y; o.z *= f.z; o.w *= f.w;
+                            }
                         }
                         *reinterpret_cast<float4 *>(tileO + row * ldn + c) = o;
                     }
@@ -651,6 +670,7 @@ __global__ __launch_bounds__(HC_THREADS) void head_chain_kernel(HcArgs a) {
                 HC_STAMP(8 * s + 6);
                 if (!last) hc_publish(tileO, ldn, Nc, a.work + st.xch_off + (size_t)r0 * N, N, c0, tag);
                 if (BWD) hc_store_tile(tileO, ldn, a.B, r0, N, c0, Nc, st.out);
+                if (!BWD && st.a_out) hc_store_tile(tileO, ldn, a.B, r0, N, c0, Nc, st.a_out);
                 hc_barrier();
             }
         }
@@ -809,7 +829,7 @@ int phc_head_chain(const phc_head_chain_desc *d, void *stream) {
     a.sync = d->sync;
     a.err = err_word();
     uintptr_t align = reinterpret_cast<uintptr_t>(d->in) | reinterpret_cast<uintptr_t>(d->work);
-    bool bwd = false, fwd = false;
+    bool bwd = false, fwd = false, dropping = false;
     int posts[HC_MAX_STAGES] = {0, 0, 0, 0};
     for (int s = 0; s < d->n_stages; ++s) {
         const phc_head_stage &q = d->stage[s];
@@ -820,6 +840,19 @@ int phc_head_chain(const phc_head_chain_desc *d, void *stream) {
         PHC_REQUIRE(q.post != 2 || (q.z && q.stat), PHC_ERR_INVALID_ARG, "phc_head_chain: stage %d: the forward's z / save_stat missing", s);
         a.st[s].M = q.M; a.st[s].bias = q.bias; a.st[s].z = q.z; a.st[s].out = q.out; a.st[s].stat = q.stat; a.st[s].dwb = q.dwb;
         a.st[s].K = q.K; a.st[s].N = q.N; a.st[s].post = q.post;
+        a.st[s].a_out = q.post == 1 ? q.a_out : nullptr;
+        a.st[s].drop_p = 0.f; a.st[s].drop_same = 0; a.st[s].drop_k = q.N; a.st[s].drop_site = q.drop_site;
+        if (q.post != 0 && q.drop_p > 0.f) {
+            PHC_REQUIRE(q.drop_p < 1.f && d->rng_state, PHC_ERR_INVALID_ARG, "phc_head_chain: stage %d: dropout p = %g needs p < 1 and an rng state", s,
+                        (double)q.drop_p);
+            PHC_REQUIRE(q.drop_same_k == 0 || (q.drop_same_k % 4 == 0 && q.N % q.drop_same_k == 0), PHC_ERR_UNSUPPORTED,
+                        "phc_head_chain: stage %d: a shared dropout mask needs a component width that is a multiple of 4", s);
+            a.st[s].drop_p = q.drop_p;
+            a.st[s].drop_same = q.drop_same_k > 0;
+            a.st[s].drop_k = q.drop_same_k > 0 ? q.drop_same_k : q.N;
+            dropping = true;
+        }
+        align |= reinterpret_cast<uintptr_t>(a.st[s].a_out);
         const HcPlan pl = hc_plan(q.K, q.N / sh.CB);
         a.st[s].Nc = q.N / sh.CB; a.st[s].tiles = pl.tiles; a.st[s].kg = pl.kg; a.st[s].ksplit = pl.ksplit; a.st[s].U = pl.U;
         posts[s] = q.post;
@@ -842,6 +875,7 @@ int phc_head_chain(const phc_head_chain_desc *d, void *stream) {
         a.lda = l.lda; a.ldn = l.ldn; a.off_o = l.off_o; a.off_z = l.off_z; a.off_red = l.off_red; a.off_sc = l.off_sc; a.off_st = l.off_st;
         a.off_bias = l.off_bias;
     }
+    a.rng = dropping ? reinterpret_cast<const unsigned long long *>(d->rng_state) : nullptr;
     PHC_REQUIRE(!(fwd && bwd), PHC_ERR_INVALID_ARG, "phc_head_chain: a chain is forward (post 0 / 1) or backward (post 0 / 2)");
     PHC_REQUIRE((align & 15) == 0, PHC_ERR_UNSUPPORTED, "phc_head_chain: 16-byte aligned rows required");
     hipStream_t s = static_cast<hipStream_t>(stream);

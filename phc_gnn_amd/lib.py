@@ -67,13 +67,14 @@ class DownstreamDesc(C.Structure):
 class HeadStage(C.Structure):
     """phc_head_stage (include/phc_hip.h)."""
     _fields_ = [("M", _P), ("bias", _P), ("K", C.c_int32), ("N", C.c_int32), ("post", C.c_int32), ("out", _P), ("z", _P), ("stat", _P),
-                ("dwb", _P), ("norm", DownstreamNorm)]
+                ("dwb", _P), ("norm", DownstreamNorm), ("drop_p", C.c_float), ("drop_same_k", C.c_int32), ("drop_site", C.c_int32),
+                ("a_out", _P)]
 
 
 class HeadChainDesc(C.Structure):
     """phc_head_chain_desc (include/phc_hip.h)."""
     _fields_ = [("B", _L), ("n_stages", C.c_int32), ("act", C.c_int32), ("n_valid_dev", _P), ("valid_rows_max", _L), ("in_", _P), ("stage", HeadStage * 4),
-                ("work", _P), ("sync", _P)]
+                ("work", _P), ("sync", _P), ("rng_state", _P)]
 
 
 class GemmBaDesc(C.Structure):

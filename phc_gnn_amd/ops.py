@@ -3377,12 +3377,15 @@ def _hc_buffers(dev, which: str, B: int, widths: tuple):
     return ent
 
 
-def _hc_stage(d, i, M, bias, K, N, post, out, z=None, stat=None, dwb=None, norm=None):
+def _hc_stage(d, i, M, bias, K, N, post, out, z=None, stat=None, dwb=None, norm=None, drop=None, a_out=None):
     st = d.stage[i]
     st.M, st.bias, st.K, st.N, st.post, st.out = L.ptr(M), L.ptr(bias), K, N, post, L.ptr(out)
     st.z, st.stat, st.dwb = L.ptr(z), L.ptr(stat), L.ptr(dwb)
     if norm is not None:
         st.norm = norm
+    if drop is not None:                                   # (p, same_k, site)
+        st.drop_p, st.drop_same_k, st.drop_site = float(drop[0]), int(drop[1]), int(drop[2])
+    st.a_out = L.ptr(a_out)
 
 
 class _HeadChainFn(torch.autograd.Function):
@@ -3412,16 +3415,25 @@ class _HeadChainFn(torch.autograd.Function):
         d = L.HeadChainDesc()
         d.B, d.n_stages, d.act, d.n_valid_dev, d.in_ = B, 4, act, L.ptr(n_valid), L.ptr(x_)
         d.valid_rows_max = meta["valid_max"]
+        drop = meta.get("drop")                              # ((p1, same_k1, site1), (p2, same_k2, site2), rng state) or None
+        a1 = a2 = None
+        if drop is not None:
+            a1 = torch.empty((B, d1), dtype=torch.float32, device=dev)
+            a2 = torch.empty((B, d2), dtype=torch.float32, device=dev)
+            d.rng_state = L.ptr(drop[2])
         _hc_stage(d, 0, pre[0][1], b1, d0, d1, 1, z1, stat=stat1,
-                  norm=_dn_norm(norms[0]["tensors"], norms[0]["n_comp"], norms[0]["momentum"], norms[0]["eps"], keep))
+                  norm=_dn_norm(norms[0]["tensors"], norms[0]["n_comp"], norms[0]["momentum"], norms[0]["eps"], keep),
+                  drop=drop[0] if drop else None, a_out=a1)
         _hc_stage(d, 1, pre[1][1], b2, d1, d2, 1, z2, stat=stat2,
-                  norm=_dn_norm(norms[1]["tensors"], norms[1]["n_comp"], norms[1]["momentum"], norms[1]["eps"], keep))
+                  norm=_dn_norm(norms[1]["tensors"], norms[1]["n_comp"], norms[1]["momentum"], norms[1]["eps"], keep),
+                  drop=drop[1] if drop else None, a_out=a2)
         _hc_stage(d, 2, pre[2][1], b3, d2, d3, 0, z3)
         _hc_stage(d, 3, Wr, br, d3, T, 0, logits)
         d.work, d.sync = L.ptr(work), L.ptr(sync)
         L.check(lib.phc_head_chain(_C.byref(d), L.stream_ptr(dev)), "phc_head_chain(forward)")
-        _tap(z1, stat1, n_valid, act)
-        _tap(z2, stat2, n_valid, act)
+        if drop is None:
+            _tap(z1, stat1, n_valid, act)
+            _tap(z2, stat2, n_valid, act)
         if L.PROF_ON:
             L.account("head_chain_fwd", 2.0 * B * (d0 * d1 + d1 * d2 + d2 * d3 + d3 * T),
                       4.0 * (B * (d0 + d1 + d2 + d3 + T) + d0 * d1 + d1 * d2 + d2 * d3 + d3 * T))
@@ -3431,6 +3443,7 @@ class _HeadChainFn(torch.autograd.Function):
         ctx.phm = ((A1, W1, b1), (A2, W2, b2), (A3, W3, b3))
         ctx.br = br
         ctx.n_affine = len(affine)
+        ctx.dropped = (a1, a2)
         return logits
 
     @staticmethod
@@ -3454,8 +3467,12 @@ class _HeadChainFn(torch.autograd.Function):
         d.B, d.n_stages, d.act, d.n_valid_dev, d.in_ = B, len(widths), act, L.ptr(n_valid), L.ptr(dl)
         d.valid_rows_max = meta["valid_max"]
         _hc_stage(d, 0, WrT, None, T, d3, 0, dz3)                                  # dz3 = dlogits . Wr
-        _hc_stage(d, 1, pre[2][0], None, d3, d2, 2, dz2, z=z2, stat=stat2, dwb=dwb2)      # da2 = dz3 . H3^T, norm 2 backwards
-        _hc_stage(d, 2, pre[1][0], None, d2, d1, 2, dz1, z=z1, stat=stat1, dwb=dwb1)      # da1 = dz2 . H2^T, norm 1 backwards
+        drop = meta.get("drop")
+        a1, a2 = ctx.dropped
+        if drop is not None:
+            d.rng_state = L.ptr(drop[2])                     # the forward's masks, re-derived from (seed, step, site, row, column)
+        _hc_stage(d, 1, pre[2][0], None, d3, d2, 2, dz2, z=z2, stat=stat2, dwb=dwb2, drop=drop[1] if drop else None)      # da2 = dz3 . H3^T, norm 2 backwards
+        _hc_stage(d, 2, pre[1][0], None, d2, d1, 2, dz1, z=z1, stat=stat1, dwb=dwb1, drop=drop[0] if drop else None)      # da1 = dz2 . H2^T, norm 1 backwards
         if need_x:
             _hc_stage(d, 3, pre[0][0], None, d1, d0, 0, dx)                         # dx = dz1 . H1^T
         d.work, d.sync = L.ptr(work), L.ptr(sync)
@@ -3464,7 +3481,7 @@ class _HeadChainFn(torch.autograd.Function):
             L.account("head_chain_bwd", 2.0 * B * (d0 * d1 + d1 * d2 + d2 * d3 + d3 * T),
                       4.0 * (B * (d0 + 2 * d1 + 2 * d2 + d3 + T) + d0 * d1 + d1 * d2 + d2 * d3 + d3 * T))
         needs = ctx.needs_input_grad
-        xs = ((x_, None), (z1, (stat1, n_valid, act)), (z2, (stat2, n_valid, act)))
+        xs = ((x_, None), (z1, (stat1, n_valid, act)), (z2, (stat2, n_valid, act))) if a1 is None else ((x_, None), (a1, None), (a2, None))
         dys = (dz1, dz2, dz3)
         jobs, grads = [], []
         for i, (A, W, b) in enumerate(ctx.phm):
@@ -3545,8 +3562,10 @@ def downstream_head(x, n_valid, affine_layers, norm_modules, real_affine, activa
         (p1, p2), same, (s1, s2) = dropout
         n1, n2 = len(list(norm_modules[0].bn)), len(list(norm_modules[1].bn))
         k1, k2 = (d1 // n1 if same else 0), (d2 // n2 if same else 0)
-        if not (HEAD_DROPOUT and has_k4 and lib.phc_downstream_supported_k4(x.shape[0], d0, d1, d2, d3, T) and d1 % 4 == 0 and d2 % 4 == 0
-                and k1 % 4 == 0 and k2 % 4 == 0 and lib.phc_downstream_dropout_supported(x.shape[0], d0, d1, d2, d3, T)):
+        if not (HEAD_DROPOUT and d1 % 4 == 0 and d2 % 4 == 0 and k1 % 4 == 0 and k2 % 4 == 0):
+            return None
+        # (served by the 16-row kernels or by the chain kernel; the 32-row kernels know no mask)
+        if supported(x.shape[0], d0, d1, d2, d3, T) and not (has_k4 and lib.phc_downstream_dropout_supported(x.shape[0], d0, d1, d2, d3, T)):
             return None
         drop = ((float(p1), k1, int(s1)), (float(p2), k2, int(s2)), rng_state(x.device))
     if not supported(x.shape[0], d0, d1, d2, d3, T):
@@ -3576,8 +3595,6 @@ def downstream_head(x, n_valid, affine_layers, norm_modules, real_affine, activa
                           affine=bool(nm.affine)))
         if nm.affine:
             affine.extend(w + b)
-    if drop is not None and chain:
-        return None
     meta = dict(act=_act_id(activation), norms=norms, pre=pre, WrT=WrT, valid_max=valid_max, drop=drop)
     l1, l2, l3 = affine_layers
     if chain:

@@ -139,3 +139,40 @@ def test_head_chain_switch_falls_back_to_the_per_layer_path():
     for k in res[1][2]:
         if k not in ("affine.0.b", "affine.1.b"):
             assert_close(res[0][2][k], res[1][2][k], 2e-5, "grad " + k)
+
+
+@pytest.mark.parametrize("n,d_in,hidden,target,act,B,p,same", [
+    (4, 512, (768, 256), 128, "relu", 544, (0.3, 0.2), False),     # the published ogbg-molpcba head with its dropout, graph-replay batch
+    (4, 256, (768, 256), 128, "swish", 300, (0.25, 0.5), True),    # masks shared by the components
+])
+def test_head_chain_with_dropout_matches_the_per_layer_path(n, d_in, hidden, target, act, B, p, same):
+    """phm_dropout behind the head's activations (downstream.py:104-107) inside the chain launches: the masks are the stand-alone fused
+    passes' (seed, step, site, row, column group), so the same seed gives the same function on both paths."""
+    from phc_gnn_amd import ops
+    if not _supported(B, d_in, hidden, n, target):
+        pytest.skip("shape outside the chain kernel on this device")
+    g = torch.Generator().manual_seed(48)
+    x, dy = torch.randn(B, d_in, generator=g), torch.randn(B, target, generator=g)
+    res = []
+    for on in (True, False):
+        dn = _make(n, d_in, hidden, target, act, seed=47)
+        dn.dropout, dn.same_dropout = list(p), same
+        dn.to(DEV)
+        keep = ops.HEAD_CHAIN
+        ops.HEAD_CHAIN = on
+        try:
+            ops.rng_seed(torch.device(DEV), 4321)
+            xd = x.to(DEV).requires_grad_()
+            with ops.prebuilt_H(ops.phm_pairs(dn), ops.dense_weights(dn)):
+                y = dn(xd)
+                assert (type(y.grad_fn).__name__ == "_HeadChainFnBackward") == on, type(y.grad_fn).__name__
+                y.backward(dy.to(DEV))
+        finally:
+            ops.HEAD_CHAIN = keep
+        res.append((y.detach(), xd.grad, {k: q.grad for k, q in dn.named_parameters() if q.grad is not None}))
+    tol = 3e-5 if act != "relu" else 2e-4
+    assert_close(res[0][0], res[1][0], tol, "logits")
+    assert_close(res[0][1], res[1][1], tol, "dx")
+    for k in res[1][2]:
+        if k not in ("affine.0.b", "affine.1.b"):
+            assert_close(res[0][2][k], res[1][2][k], tol, "grad " + k)
