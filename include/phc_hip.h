@@ -494,6 +494,11 @@ int phc_stat_acc_read(const uint64_t *acc, int h, int64_t count, float *out, voi
 int phc_gemm_prebuilt_stats(const float *x, const float *M, const float *Mk4, const float *b, int64_t N, int K, int Nout, float *y,
                             const int32_t *n_valid_dev, float *stats_partial, float *stats_counts, int *num_partials,
                             void *stream);
+/* ABI 7: the same with a residual added to the stored rows AND counted in the statistics — y = x . M + b + residual,
+ * PHMConv's `transform(agg) + x` (messagepassing.py:62-65) in front of the model's norm (models.py:208-215). */
+int phc_gemm_prebuilt_stats_res(const float *x, const float *M, const float *Mk4, const float *b, const float *residual, int64_t N,
+                                int K, int Nout, float *y, const int32_t *n_valid_dev, float *stats_partial, float *stats_counts,
+                                int *num_partials, void *stream);
 int phc_bn_fwd_from_partials(const float *x, const float *stats_partial, const float *stats_counts, int num_partials,
                              const float *const *weight, const float *const *bias, float *const *running_mean,
                              float *const *running_var, int64_t *const *num_batches_tracked, int n_comp,

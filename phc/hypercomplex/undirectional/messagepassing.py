@@ -106,14 +106,17 @@ class PHMConv(_SumConvBase):
         return self.transform(agg)
 
     def forward_encoded(self, x: torch.Tensor, edge_index: Adj, edge_idx: torch.Tensor, encoder, size: Size = None,
-                        n_valid=None):
-        """forward() with edge_attr given as integer bond features + their PHMEncoder."""
+                        n_valid=None, bn_stats: bool = False):
+        """forward() with edge_attr given as integer bond features + their PHMEncoder.  ``bn_stats`` (engine): the model's norm
+        follows (models.py:208-215) — the transform's GEMM also emits the batch-norm statistics of its output, so that norm is one
+        apply pass."""
+        stats = _engine.BNStatsRequest(n_valid, consumer="apply") if (bn_stats and x.is_cuda and x.dim() == 2) else None
         if self.same_dim:
             agg = self.propagate_encoded(edge_index, x, edge_idx, encoder, size, add_self=False)
             lin = self.transform
-            return _engine.phm_linear(agg, lin.phm_rule, lin.W, lin.b, x if self.add_self_loops else None)
+            return _engine.phm_linear(agg, lin.phm_rule, lin.W, lin.b, x if self.add_self_loops else None, bn_stats=stats)
         agg = self.propagate_encoded(edge_index, x, edge_idx, encoder, size, add_self=self.add_self_loops)
-        return self.transform(agg)
+        return self.transform(agg, bn_stats=stats) if stats is not None else self.transform(agg)
 
     def __repr__(self):
         return "{}(in_features={}, out_features={}, phm_dim={}, phm_rule={}, learn_phm={}, bias={}, " \
@@ -300,8 +303,10 @@ class PHMMessagePassing(nn.Module):
         return self.transform(x, edge_index, edge_attr, size)
 
     def forward_encoded(self, x: torch.Tensor, edge_index: Adj, edge_idx: torch.Tensor, encoder, size: Size = None,
-                        n_valid=None):
+                        n_valid=None, bn_stats: bool = False):
         """Engine extension: like forward(), but takes the raw integer edge features and the
         PHMEncoder that embeds them, so the embedding is fused into the aggregation.  ``n_valid``
         marks the padding rows of a fixed-shape batch (device int32 scalar)."""
+        if bn_stats and isinstance(self.transform, PHMConv):
+            return self.transform.forward_encoded(x, edge_index, edge_idx, encoder, size, n_valid=n_valid, bn_stats=True)
         return self.transform.forward_encoded(x, edge_index, edge_idx, encoder, size, n_valid=n_valid)

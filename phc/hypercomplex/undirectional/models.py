@@ -213,7 +213,9 @@ class PHMSkipConnectAdd(nn.Module):
                 return fused
             h = tr.transform(agg, n_valid=n_valid)
         elif edge_encoder is not None:
-            h = conv.forward_encoded(x[0], edge_index, edge_attr, edge_encoder, size, n_valid=n_valid)
+            # (PHMConv: the transform's GEMM emits the statistics of the norm that follows, unless hooks want the reference's sequence)
+            h = conv.forward_encoded(x[0], edge_index, edge_attr, edge_encoder, size, n_valid=n_valid,
+                                     bn_stats=norm is not None and self.training and not getattr(self, "_observable_now", False))
         elif n_valid is not None and self.mlp_mp:
             h = conv.transform(x[0], edge_index, edge_attr, size, n_valid=n_valid)
         else:

@@ -651,6 +651,14 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
         for (int rb = 0; rb < RB; ++rb) {
             const long long row = step * RS + rb * 16 + c;
             if constexpr (ST) {
+                // statistics of what is STORED: with a residual (PHMConv's self loop behind the transform, messagepassing.py:62-65)
+                // it joins the accumulators in front of them
+                if (a.residual && row < a.M) {
+#pragma unroll
+                    for (int t = 0; t < TPW; ++t)
+                        if (col0 + 4 * kq + 16 * t < Nout)
+                            acc[rb][t] += *reinterpret_cast<const f32x4_t *>(a.residual + (size_t)row * Nout + col0 + 4 * kq + 16 * t);
+                }
                 if (row < n_valid) {
                     if (st_n == 0.f) {
 #pragma unroll
@@ -702,7 +710,8 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
                 for (int t = 0; t < TPW; ++t) {
                     if (col0 + 4 * kq + 16 * t < Nout) {          // (a partial last tile: Nout % 4 == 0, so a lane's four columns stand or fall together)
                         f32x4_t v = acc[rb][t];
-                        if (a.residual) v += *reinterpret_cast<const f32x4_t *>(a.residual + (size_t)row * Nout + col0 + 4 * kq + 16 * t);
+                        if constexpr (!ST)
+                            if (a.residual) v += *reinterpret_cast<const f32x4_t *>(a.residual + (size_t)row * Nout + col0 + 4 * kq + 16 * t);
                         *reinterpret_cast<f32x4_t *>(yr + 16 * t) = v;
                     }
                 }

@@ -614,6 +614,22 @@ __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
         ST_STAMP(6);
         const long long row_base = slab * 32;
         if constexpr (ST) {
+            // statistics of what is STORED: a residual (PHMConv's self loop behind the transform) joins the accumulators in front
+            // of them, in the MFMA layout (register reg = row (reg & 3) + 8 (reg >> 2) + 4 hh, lane = column r: 128-byte runs per row)
+            if (residual) {
+#pragma unroll
+                for (int ct = 0; ct < CT; ++ct) {
+                    const int col = j0 + ct * 32 + r;
+                    float rv[16];
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) {
+                        const long long grow = min(row_base + (reg & 3) + 8 * (reg >> 2) + 4 * hh, M - 1);
+                        rv[reg] = residual[(size_t)grow * Nout + min(col, Nout - 1)];
+                    }
+#pragma unroll
+                    for (int reg = 0; reg < 16; ++reg) acc[ct][reg] += rv[reg];
+                }
+            }
             // rows of this slab that count: [row_base, min(row_base + 32, st_count))
             const int nv = (int)max(0LL, min(32LL, st_count - row_base));
             if (nv > 0) {                                                    // wave-uniform
@@ -668,7 +684,7 @@ __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
                     float4 v = *reinterpret_cast<const float4 *>(stage + row * 36 + c4 * 4);
                     if (grow < M && col < Nout) {
                         v.x += bias4[ct].x; v.y += bias4[ct].y; v.z += bias4[ct].z; v.w += bias4[ct].w;
-                        if (residual) {
+                        if (!ST && residual) {
                             const float4 r4 = *reinterpret_cast<const float4 *>(residual + (size_t)grow * Nout + col);
                             v.x += r4.x; v.y += r4.y; v.z += r4.z; v.w += r4.w;
                         }
@@ -712,7 +728,7 @@ __global__ __launch_bounds__(64 * WAVES) void phm_stream_kernel(
                     if (grow < M && col < Nout) {
                         float v = acc[ct][reg];
                         if (bias) v += bias[col];
-                        if (residual) v += residual[(size_t)grow * Nout + col];
+                        if (!ST && residual) v += residual[(size_t)grow * Nout + col];
                         out[(size_t)grow * Nout + col] = v;
                     }
                 }
@@ -2189,7 +2205,15 @@ int phc_stat_acc_replicas(void) { return STAT_ACC_REP; }
 
 int phc_gemm_prebuilt_stats(const float *x, const float *M, const float *Mk4, const float *b, int64_t N, int K, int Nout, float *y,
                             const int32_t *n_valid_dev, float *stats_partial, float *stats_counts, int *num_partials, void *stream) {
+    return phc_gemm_prebuilt_stats_res(x, M, Mk4, b, nullptr, N, K, Nout, y, n_valid_dev, stats_partial, stats_counts, num_partials, stream);
+}
+
+int phc_gemm_prebuilt_stats_res(const float *x, const float *M, const float *Mk4, const float *b, const float *residual, int64_t N, int K,
+                                int Nout, float *y, const int32_t *n_valid_dev, float *stats_partial, float *stats_counts,
+                                int *num_partials, void *stream) {
     PHC_REQUIRE(N >= 1 && K >= 1 && Nout >= 1, PHC_ERR_INVALID_ARG, "phc_gemm_prebuilt_stats: bad shape");
+    PHC_REQUIRE(!residual || ((reinterpret_cast<uintptr_t>(residual) & 15) == 0 && Nout % 4 == 0), PHC_ERR_UNSUPPORTED,
+                "phc_gemm_prebuilt_stats_res: 16-byte aligned residual rows required");
     const int acc = stats_counts ? 0 : 1;                    // accumulator form: stats_partial is a statistics accumulator
     PHC_REQUIRE(x && M && y && stats_partial && (acc || num_partials), PHC_ERR_INVALID_ARG, "phc_gemm_prebuilt_stats: null pointer");
     PHC_REQUIRE(!acc || (reinterpret_cast<uintptr_t>(stats_partial) & 7) == 0, PHC_ERR_INVALID_ARG,
@@ -2200,7 +2224,7 @@ int phc_gemm_prebuilt_stats(const float *x, const float *M, const float *Mk4, co
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(K_PHM_GEMM_FWD, s);
     if (acc && hs_shape_ok(x, Mk4, N, K, Nout) && ((reinterpret_cast<uintptr_t>(y) | reinterpret_cast<uintptr_t>(b)) & 15) == 0) {
-        GemmHsArgs a = hs_args(x, Mk4, b, nullptr, y, N, K, Nout);
+        GemmHsArgs a = hs_args(x, Mk4, b, residual, y, N, K, Nout);
         a.n_valid = n_valid_dev;
         a.stat_acc = reinterpret_cast<unsigned long long *>(stats_partial);
         launch_hs<HS_ST>(a, K, XfAcc{}, s);
@@ -2208,19 +2232,19 @@ int phc_gemm_prebuilt_stats(const float *x, const float *M, const float *Mk4, co
     }
     static const int small_bn = getenv("PHC_GEMM_PRE_BN") ? atoi(getenv("PHC_GEMM_PRE_BN")) : 32;
     if (K > GEMM_STREAM_MAX_K)                               // deep contraction: 32-column panels, one workgroup per CU
-        launch_stream_cfg<0, -1, 32, 4, 1>(x, nullptr, M, b, nullptr, y, N, K, Nout, 1, K, Nout, 1, s, n_valid_dev, stats_partial,
+        launch_stream_cfg<0, -1, 32, 4, 1>(x, nullptr, M, b, residual, y, N, K, Nout, 1, K, Nout, 1, s, n_valid_dev, stats_partial,
                                            stats_counts, num_partials, nullptr, 0, nullptr, nullptr, 0, acc);
     else if (N >= gemm_wide_k_m() && Nout > 64 && K > GEMM_WIDE_K_MIN)
-        launch_stream_cfg<0, -1, 64, 8, 1>(x, nullptr, M, b, nullptr, y, N, K, Nout, 1, K, Nout, 1, s, n_valid_dev, stats_partial,
+        launch_stream_cfg<0, -1, 64, 8, 1>(x, nullptr, M, b, residual, y, N, K, Nout, 1, K, Nout, 1, s, n_valid_dev, stats_partial,
                                            stats_counts, num_partials, nullptr, 0, nullptr, nullptr, 0, acc);
     else if (gemm_big_cfg(N, K, Nout))
-        launch_stream_cfg<0, -1, 128, 8, 1>(x, nullptr, M, b, nullptr, y, N, K, Nout, 1, K, Nout, 1, s, n_valid_dev, stats_partial,
+        launch_stream_cfg<0, -1, 128, 8, 1>(x, nullptr, M, b, residual, y, N, K, Nout, 1, K, Nout, 1, s, n_valid_dev, stats_partial,
                                             stats_counts, num_partials, nullptr, 0, nullptr, nullptr, 0, acc);
     else if (small_bn == 32 && Nout > 32 && N <= 32 * 1024)
-        launch_stream_cfg<0, -1, 32, 4, 1>(x, nullptr, M, b, nullptr, y, N, K, Nout, 1, K, Nout, 3, s, n_valid_dev, stats_partial,
+        launch_stream_cfg<0, -1, 32, 4, 1>(x, nullptr, M, b, residual, y, N, K, Nout, 1, K, Nout, 3, s, n_valid_dev, stats_partial,
                                            stats_counts, num_partials, nullptr, 0, nullptr, nullptr, 0, acc);
     else
-        launch_stream_cfg<0, -1, 64, 4, 1>(x, nullptr, M, b, nullptr, y, N, K, Nout, 1, K, Nout, 2, s, n_valid_dev, stats_partial,
+        launch_stream_cfg<0, -1, 64, 4, 1>(x, nullptr, M, b, residual, y, N, K, Nout, 1, K, Nout, 2, s, n_valid_dev, stats_partial,
                                            stats_counts, num_partials, nullptr, 0, nullptr, nullptr, 0, acc);
     return check_launch("phc_gemm_prebuilt_stats");
 }

@@ -148,6 +148,7 @@ SIGNATURES = {
     "phc_stat_acc_words": (_S, [_I]),
     "phc_stat_acc_replicas": (_I, []),
     "phc_gemm_prebuilt_stats": (_I, [_P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _P, C.POINTER(_I), _P]),
+    "phc_gemm_prebuilt_stats_res": (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _P, _P, _P, _P, C.POINTER(_I), _P]),
     "phc_bn_fwd_from_partials": (_I, [_P, _P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _L, _I, C.c_float, C.c_float, _I, _P, _P, _P,
                                       C.c_float, _I, _I, _P, _P]),
     "phc_bn_finalize_from_partials": (_I, [_P, _P, _I, _P, _P, _P, _P, _P, _I, _P, _L, _I, C.c_float, C.c_float, _P, _P]),

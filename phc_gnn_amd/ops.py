@@ -660,6 +660,11 @@ def _prebuilt_for(A, W):
 # ---------------------------------------------------------------------------
 # PHM linear
 # ---------------------------------------------------------------------------
+# PHMConv (mlp = False): the statistics of `transform(agg) + x` out of the transform's GEMM (phc_gemm_prebuilt_stats_res) instead of a
+# statistics pass + a finalize launch in front of the norm's apply pass
+STATS_WITH_RESIDUAL = __import__("os").environ.get("PHC_STATS_WITH_RESIDUAL", "1") != "0"
+
+
 class _PHMLinearFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, A, W, b, residual, bn_stats=None, dx_handoff=None):
@@ -680,12 +685,14 @@ class _PHMLinearFn(torch.autograd.Function):
         y = torch.empty((N, n * kout), dtype=torch.float32, device=dev)
         pre = _prebuilt_for(A_, W_) if (_PREBUILT.table and x2.data_ptr() % 16 == 0) else None
         ctx.HT = ctx.HTk4 = None
-        if pre is not None and bn_stats is not None and res2 is None and N > 0 and x.dim() == 2:
+        if pre is not None and bn_stats is not None and N > 0 and x.dim() == 2 and \
+                (res2 is None or (STATS_WITH_RESIDUAL and res2.data_ptr() % 16 == 0 and (n * kout) % 4 == 0)):
+            # (with a residual — PHMConv's self loop behind the transform — the statistics are those of the stored sum)
             sp, sc, want_num = bn_stats.allocate(dev, n * kout, lib.phc_gemm_stats_max_partials())
             num = _C.c_int(0)
-            L.check(lib.phc_gemm_prebuilt_stats(L.ptr(x2), L.ptr(pre[0]), L.ptr(pre[2]), L.ptr(b_), N, n * kin, n * kout, L.ptr(y),
-                                                L.ptr(bn_stats.n_valid), L.ptr(sp), L.ptr(sc),
-                                                _C.byref(num) if want_num else None, L.stream_ptr(dev)), "phc_gemm_prebuilt_stats")
+            L.check(lib.phc_gemm_prebuilt_stats_res(L.ptr(x2), L.ptr(pre[0]), L.ptr(pre[2]), L.ptr(b_), L.ptr(res2), N, n * kin, n * kout,
+                                                    L.ptr(y), L.ptr(bn_stats.n_valid), L.ptr(sp), L.ptr(sc),
+                                                    _C.byref(num) if want_num else None, L.stream_ptr(dev)), "phc_gemm_prebuilt_stats")
             bn_stats.num = num.value
             ctx.HT, ctx.HTk4 = pre[1], pre[3]
         elif pre is not None:
