@@ -112,9 +112,14 @@ class PHMConv(_SumConvBase):
         apply pass."""
         stats = _engine.BNStatsRequest(n_valid, consumer="apply") if (bn_stats and x.is_cuda and x.dim() == 2) else None
         if self.same_dim:
-            agg = self.propagate_encoded(edge_index, x, edge_idx, encoder, size, add_self=False)
+            # x is read twice — by the aggregation and as the self loop behind the transform; the self loop's share of dx (= dy of the
+            # transform) is parked and added inside the aggregation's backward walk instead of by an add launch
+            share = _engine.DxHandoff() if (_engine.RESIDUAL_HANDOFF and self.add_self_loops and x.is_cuda and x.requires_grad
+                                            and torch.is_grad_enabled()) else None
+            agg = self.propagate_encoded(edge_index, x, edge_idx, encoder, size, add_self=False, dx_handoff=share)
             lin = self.transform
-            return _engine.phm_linear(agg, lin.phm_rule, lin.W, lin.b, x if self.add_self_loops else None, bn_stats=stats)
+            return _engine.phm_linear(agg, lin.phm_rule, lin.W, lin.b, x if self.add_self_loops else None, bn_stats=stats,
+                                      res_handoff=share)
         agg = self.propagate_encoded(edge_index, x, edge_idx, encoder, size, add_self=self.add_self_loops)
         return self.transform(agg, bn_stats=stats) if stats is not None else self.transform(agg)
 

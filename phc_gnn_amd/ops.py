@@ -663,15 +663,20 @@ def _prebuilt_for(A, W):
 # PHMConv (mlp = False): the statistics of `transform(agg) + x` out of the transform's GEMM (phc_gemm_prebuilt_stats_res) instead of a
 # statistics pass + a finalize launch in front of the norm's apply pass
 STATS_WITH_RESIDUAL = __import__("os").environ.get("PHC_STATS_WITH_RESIDUAL", "1") != "0"
+# ... and the self loop's share of dx parked for the aggregation's backward walk (PHC_RESIDUAL_HANDOFF=0: autograd adds the two)
+RESIDUAL_HANDOFF = __import__("os").environ.get("PHC_RESIDUAL_HANDOFF", "1") != "0"
 
 
 class _PHMLinearFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, A, W, b, residual, bn_stats=None, dx_handoff=None):
+    def forward(ctx, x, A, W, b, residual, bn_stats=None, dx_handoff=None, res_handoff=None):
         lib = L.load()
         ctx.dx_handoff = dx_handoff
         if dx_handoff is not None:
             dx_handoff.accepted = True
+        # the residual's gradient (= dy) parked for another consumer of the residual tensor whose backward runs later and adds it
+        # inside its own kernel (PHMConv: the self loop's share of dx goes into the aggregation's backward walk, no add launch)
+        ctx.res_handoff = res_handoff if (res_handoff is not None and res_handoff.accepted and residual is not None) else None
         dev = L.require_device(x, A, W, b, residual)
         n, kin, kout = W.shape
         if tuple(A.shape) != (n, n, n):
@@ -750,8 +755,7 @@ class _PHMLinearFn(torch.autograd.Function):
             with _DEFER.lock:
                 _DEFER.jobs.append(dict(x=x2, dy=dy2, A=A, W=W, need=(need_A, need_W, need_b),
                                         params=(pA if need_A else None, pW if need_W else None, pb if need_b else None)))
-            return (dx.reshape(ctx.x_shape) if need_x else None, None, None, None,
-                    dy.reshape(ctx.res_shape) if (need_res and ctx.has_res) else None, None, None)
+            return (dx.reshape(ctx.x_shape) if need_x else None, None, None, None, _res_grad(ctx, dy, dy2, need_res), None, None, None)
         dW = torch.empty_like(W) if need_param else None
         dA = torch.empty_like(A) if need_A else None
         db = torch.empty(n * kout, dtype=torch.float32, device=dev) if need_b else None
@@ -769,8 +773,18 @@ class _PHMLinearFn(torch.autograd.Function):
                 L.account("phm_dH_partial", gemm, io + 4.0 * n * kin * n * kout)
         if extra is not None:
             dx += extra
-        return (dx.reshape(ctx.x_shape) if need_x else None, dA, dW if need_W else None, db,
-                dy.reshape(ctx.res_shape) if (need_res and ctx.has_res) else None, None, None)
+        return (dx.reshape(ctx.x_shape) if need_x else None, dA, dW if need_W else None, db, _res_grad(ctx, dy, dy2, need_res), None, None, None)
+
+
+def _res_grad(ctx, dy, dy2, need_res):
+    """The residual input's gradient of ``_PHMLinearFn``: dy itself — returned, or parked in the hand-off (then autograd gets None
+    for this input and the consumer behind the hand-off adds the share)."""
+    if not (need_res and ctx.has_res):
+        return None
+    if ctx.res_handoff is not None and dy2.dim() == 2 and tuple(dy2.shape) == tuple(ctx.res_shape):
+        ctx.res_handoff.park(dy2)
+        return None
+    return dy.reshape(ctx.res_shape)
 
 
 def phm_linear_dx_raw(dy: torch.Tensor, A: torch.Tensor, W: torch.Tensor) -> torch.Tensor:
@@ -959,9 +973,9 @@ class DxSumHandoff(DxHandoff):
 
 def phm_linear(x: torch.Tensor, phm_rule: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None,
                residual: Optional[torch.Tensor] = None, bn_stats: Optional[BNStatsRequest] = None,
-               dx_handoff: Optional[DxHandoff] = None) -> torch.Tensor:
+               dx_handoff: Optional[DxHandoff] = None, res_handoff: Optional[DxHandoff] = None) -> torch.Tensor:
     """y = x · (Σ_i phm_rule[i] ⊗ W[i]) + bias (+ residual)."""
-    y = _PHMLinearFn.apply(x, phm_rule, W, bias, residual, bn_stats, dx_handoff)
+    y = _PHMLinearFn.apply(x, phm_rule, W, bias, residual, bn_stats, dx_handoff, res_handoff)
     if bn_stats is not None and bn_stats.partial is not None:
         y._phc_bn = bn_stats                 # consumed by batch_norm_act if it is handed this very tensor
     return y
