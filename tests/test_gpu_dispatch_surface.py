@@ -19,6 +19,9 @@ DEV = "cuda:0"
 REPEATS = 30
 
 EXTRA_WORKLOADS = {
+    # PHMConv layers (mlp = False; SURVEY 8d's second variant): the statistics-with-residual GEMM and the self loop's gradient hand-off
+    "molhiv_b32_conv": dict(dataset="molhiv", batch_size=32, phm_dim=4, hidden=128, layers=4, d_units=[128, 32], target_dim=1,
+                            sc_type="first", mlp=False),
     # a small 256-wide PHM-8 model (configs[2]'s kernels: K = 256 GEMM family, k = 32 components, sc_type "last", L1 loss)
     "zinc_small_256": dict(dataset="zinc", batch_size=48, phm_dim=8, hidden=256, layers=3, d_units=[256, 128], target_dim=1,
                            sc_type="last", regression=True),
@@ -99,12 +102,14 @@ def test_repeated_steps_are_bit_equal_under_allocator_pollution(workload, mode):
 # every module-level fusion switch of ops.py (name -> the value that is NOT the default); the default step is the "none" case
 TOGGLES = ["none", "GEMM_AGGREGATE", "READOUT_FUSED", "NORM_INTO_AGGREGATE", "MLP_NORM_FUSED", "SKIP_SUM_HANDOFF", "ENCODE_FRONT",
            "STEP_TAIL_MERGED", "GATE_COMPOSED", "TAIL_EXTRAS", "TAIL_WIDE", "TABLE_GRADS_COUNTED", "STAT_ACC", "FLAT_TABLES",
-           "BN_BWD_SUMS_IN_GEMM", "DOWNSTREAM_FUSED"]
+           "BN_BWD_SUMS_IN_GEMM", "DOWNSTREAM_FUSED", "STATS_WITH_RESIDUAL", "RESIDUAL_HANDOFF", "HEAD_CHAIN", "HEAD_DROPOUT"]
 ORACLE_KW = {
     "molhiv_b32_swish": dict(phm_dim=4, num_layers=4, num_atom_feats=9, num_bond_feats=3, num_dn_hidden=2, mlp=True, sc_type="first",
                              act="swish"),
     "zinc_small_256_swish": dict(phm_dim=8, num_layers=3, num_atom_feats=1, num_bond_feats=1, num_dn_hidden=2, mlp=True, sc_type="last",
                                  act="swish"),
+    "molhiv_b32_conv_swish": dict(phm_dim=4, num_layers=4, num_atom_feats=9, num_bond_feats=3, num_dn_hidden=2, mlp=False, sc_type="first",
+                                  act="swish"),
 }
 _ORACLE: dict = {}
 
