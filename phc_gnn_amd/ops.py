@@ -200,12 +200,13 @@ def _flush_encoder_grads(ajobs) -> None:
             _assign_grads(aj["params"], aj["ts"].grad_views(flat[i * per:(i + 1) * per]))
 
 
-# Order of the dH family's jobs inside the step tail, by rows (stable): "desc" = the node-level jobs first, the head's few-row jobs
-# last.  Workgroups start in job order and the launch holds more of them than the device has slots: the late starters should be
-# the short ones.  The fused head appends its three jobs in forward order, the per-layer path in backward order — with dropout
-# inside the fused head (this round) zinc_pub_phc4_4x180's tail went 270 -> 321 us until the order was fixed; "desc" against the
-# order of arrival: 1.479 -> 1.426 ms there, molpcba_b1024 2.071 -> 2.064, molhiv_b512 0.577 -> 0.567, the others unchanged.
-TAIL_JOB_ORDER = __import__("os").environ.get("PHC_TAIL_JOB_ORDER", "desc")   # "none", "asc", "desc"
+# Order of the dH family's jobs inside the step tail.  Workgroups start in job order, two per CU, and a node-level job's workgroup
+# runs six times longer than one of the head's 1 056-row jobs.  The one-launch heads queue their jobs (in forward order) when THEIR
+# backward runs, i.e. first in the list: measured, those belong at the END ("head_last": zinc_pub_phc4_4x180 1.479 -> 1.426 ms once
+# its head was fused, molpcba_b1024 2.071 -> 2.064, molhiv_b512 0.577 -> 0.567, zinc_b1024 and the 2 x 200 model unchanged).  A
+# plain sort by rows ("desc") does the same for them but also moves the per-layer head's LDS-tiled jobs of zinc_pub_phc5_4x200 (130
+# columns: not register-resident) behind everything: 1.575 -> 1.606 ms; "asc" equals the order of arrival everywhere.  Empirical.
+TAIL_JOB_ORDER = __import__("os").environ.get("PHC_TAIL_JOB_ORDER", "head_last")   # "none", "head_last", "asc", "desc"
 
 
 def _flush_step_tail(jobs, tjobs, ajobs, reg=None) -> bool:
@@ -234,6 +235,8 @@ def _flush_step_tail(jobs, tjobs, ajobs, reg=None) -> bool:
     lib = L.load()
     if TAIL_JOB_ORDER in ("asc", "desc"):
         jobs.sort(key=lambda jb: jb["x"].shape[0], reverse=(TAIL_JOB_ORDER == "desc"))
+    elif TAIL_JOB_ORDER == "head_last":
+        jobs.sort(key=lambda jb: 1 if jb.get("late") else 0)          # (stable: everything else keeps its order of arrival)
     with torch.cuda.device(dev):
         # PHM / dense jobs
         total = 0
@@ -3347,7 +3350,8 @@ class _DownstreamFn(torch.autograd.Function):
             if not (nA or nW or nb):
                 grads.append((None, None, None))
                 continue
-            job = dict(x=xs[i][0], dy=dys[i], A=A, W=W, need=(nA, nW, nb), params=(A if nA else None, W if nW else None, b if nb else None))
+            job = dict(x=xs[i][0], dy=dys[i], A=A, W=W, need=(nA, nW, nb), params=(A if nA else None, W if nW else None, b if nb else None),
+                       late=True)
             if xs[i][1] is not None:
                 job["xf"] = xs[i][1]
             jobs.append((i, job))
@@ -3510,7 +3514,8 @@ class _HeadChainFn(torch.autograd.Function):
             if not (nA or nW or nb):
                 grads.append((None, None, None))
                 continue
-            job = dict(x=xs[i][0], dy=dys[i], A=A, W=W, need=(nA, nW, nb), params=(A if nA else None, W if nW else None, b if nb else None))
+            job = dict(x=xs[i][0], dy=dys[i], A=A, W=W, need=(nA, nW, nb), params=(A if nA else None, W if nW else None, b if nb else None),
+                       late=True)
             if xs[i][1] is not None:
                 job["xf"] = xs[i][1]
             jobs.append((i, job))
@@ -3519,7 +3524,7 @@ class _HeadChainFn(torch.autograd.Function):
         nWr, nbr = needs[12], needs[13] and br is not None
         if nWr or nbr:                                        # the dense head in PHM form: n = 1, W = Wr^T, dW written as [T, d3]
             jobs.append((3, dict(x=z3, dy=dl, A=_one(dev), W=Wr, need=(False, nWr, nbr),
-                                 params=(None, Wr if nWr else None, br if nbr else None), dense=True)))
+                                 params=(None, Wr if nWr else None, br if nbr else None), dense=True, late=True)))
         grads.append((None, None, None))
         if jobs:
             deferred = _DEFER.active and not torch.is_grad_enabled() and \
