@@ -2266,7 +2266,8 @@ static int step_tail_impl(const phc_phm_grad_job *jobs, int num_jobs, const phc_
         t.nr_atom = (unsigned)((ma.R * h + 63) / 64);
     }
     t.nr_phm = gl.nb_reduce;
-    t.dh_first = 0;                                          // (the long dH workgroups first: measured within noise of the family order; switch removed in round 5)
+    t.dh_first = 0;                                          // (the long dH workgroups first: round 4 within noise at molecule scale; re-measured late in round 5:
+                                                             //  zinc_b1024 1.836 -> 1.866 ms, molpcba_b1024 2.073 -> 2.063, 4 x 180 1.425 -> 1.418, 2 x 200 0.845 -> 0.838 — no rule)
     if (getenv("PHC_DEBUG_PLANS"))
         fprintf(stderr, "[phc tail] atoms: %lld nodes direct=%d wgs=%u | bonds: %d jobs direct=%d wgs=%u | dH wgs=%u (own launch %u)\n",
                 (long long)N_atoms, t.atom_direct, t.nb_atom, num_tjobs, t.counts_b ? 1 : 0, t.nb_bond, gl.nb_partial, gl.nb_direct);
