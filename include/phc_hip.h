@@ -953,6 +953,13 @@ int phc_readout_fused_fwd(const phc_readout_desc *d, void *stream);
 int phc_debug_readout_stamps(unsigned long long *dev_words);
 int phc_gated_pool_bwd(const float *dout, const float *x, const float *gate, const int64_t *batch, int64_t N,
                        int64_t num_graphs, int h, int n_comp, float *dx, float *dgate, void *stream);
+/* ABI 7: the same with the gate layer's backward-data map folded in — gate = x . M + c (ops.gate_linear's composed operand,
+ * pooling.py:57-66), MT = M^T [k, h] row-major:  dx[r, :] = dout[g(r), :] * sigmoid(gate[r, :]) (per component) + dgate[r, :] . MT.
+ * One launch instead of phc_gated_pool_bwd + a K = k GEMM with the pooled share as residual.  k = h / n_comp = 32 (64 with
+ * PHC_POOL_BWD_GATE=2: slower than the two launches there), n_comp <= 8 (phc_gated_pool_bwd_gate_supported); dx, dgate both required. */
+int phc_gated_pool_bwd_gate_supported(int h, int n_comp);
+int phc_gated_pool_bwd_gate(const float *dout, const float *x, const float *gate, const int64_t *batch, int64_t N, int64_t num_graphs,
+                            int h, int n_comp, const float *MT, float *dx, float *dgate, void *stream);
 
 /* Many small strided 2-D copies in one launch: dst[r * dst_stride + c] = src[r * src_stride + c], r < rows, c < cols, with
  * src = (job.src ? job.src : src_base) + job.src_off and dst likewise (element offsets).  `jobs_dev` is a DEVICE array, built once

@@ -638,6 +638,69 @@ __global__ __launch_bounds__(256) void gated_pool_bwd_kernel(const float *__rest
     }
 }
 
+// The same with the gate layer's backward-data map folded in (pooling.py:57-66 computes gate = x . M + c with M the composed
+// [h, k] operand of ops.gate_linear): the row's dgate values never leave the row's lane group before
+//     dx[r, :] = dout[g(r), :] * s  +  dgate[r, :] . M^T                       (M^T [k, h] row-major, staged in LDS)
+// is complete — one launch instead of this one and a K = k GEMM with the pooled share as its residual operand.
+// KV = k / 4 lanes per row (8 or 16, adjacent and aligned): every lane owns 4 gate columns and the 4 n_comp columns of x they gate;
+// the lane group all-gathers its dgate values by shuffles, each lane adds the k-term dot products of ITS columns.
+template <int KV>
+__global__ __launch_bounds__(256) void gated_pool_bwd_gate_kernel(const float *__restrict__ dout, const float *__restrict__ x,
+                                                                const float *__restrict__ gate, const long long *__restrict__ batch,
+                                                                long long N, int h, int n_comp, const float *__restrict__ MT,
+                                                                float *__restrict__ dx, float *__restrict__ dgate) {
+    extern __shared__ __attribute__((aligned(16))) float4 mt4[];          // [k][h / 4]
+    constexpr int k = 4 * KV, RPB = 256 / KV;
+    const int h4 = h >> 2, tid = threadIdx.x;
+    for (int e = tid; e < k * h4; e += 256) mt4[e] = reinterpret_cast<const float4 *>(MT)[e];
+    __syncthreads();
+    const int jq = tid % KV, j = 4 * jq, lane = tid & 63, lbase = lane - (lane % KV);
+    for (long long r0 = (long long)blockIdx.x * RPB; r0 < N; r0 += (long long)gridDim.x * RPB) {       // (uniform bound: every lane shuffles)
+        const long long r = r0 + tid / KV;
+        const bool live = r < N;
+        const long long rc = live ? r : N - 1;
+        const long long g = batch[rc];
+        const float4 gv = *reinterpret_cast<const float4 *>(gate + (size_t)rc * k + j);
+        const float s0 = 1.f / (1.f + expf(-gv.x)), s1 = 1.f / (1.f + expf(-gv.y)), s2 = 1.f / (1.f + expf(-gv.z)), s3 = 1.f / (1.f + expf(-gv.w));
+        float4 acc[8];
+        float dg0 = 0.f, dg1 = 0.f, dg2 = 0.f, dg3 = 0.f;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            if (c < n_comp) {
+                const int col = c * k + j;
+                const float4 d = *reinterpret_cast<const float4 *>(dout + (size_t)g * h + col);
+                const float4 xv = *reinterpret_cast<const float4 *>(x + (size_t)rc * h + col);
+                dg0 = fmaf(d.x, xv.x, dg0); dg1 = fmaf(d.y, xv.y, dg1); dg2 = fmaf(d.z, xv.z, dg2); dg3 = fmaf(d.w, xv.w, dg3);
+                acc[c] = make_float4(d.x * s0, d.y * s1, d.z * s2, d.w * s3);
+            }
+        }
+        const float4 dgs = make_float4(dg0 * s0 * (1.f - s0), dg1 * s1 * (1.f - s1), dg2 * s2 * (1.f - s2), dg3 * s3 * (1.f - s3));
+        if (live) *reinterpret_cast<float4 *>(dgate + (size_t)r * k + j) = dgs;
+#pragma unroll
+        for (int t = 0; t < KV; ++t) {
+            const float u0 = __shfl(dgs.x, lbase + t, 64), u1 = __shfl(dgs.y, lbase + t, 64), u2 = __shfl(dgs.z, lbase + t, 64),
+                        u3 = __shfl(dgs.w, lbase + t, 64);
+            const float4 *mrow = mt4 + (size_t)(4 * t) * h4 + jq;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                if (c < n_comp) {
+                    const int o = c * KV;                    // (c k + j) / 4 = c KV + jq
+                    const float4 m0 = mrow[o], m1 = mrow[h4 + o], m2 = mrow[2 * h4 + o], m3 = mrow[3 * h4 + o];
+                    acc[c].x += u0 * m0.x + u1 * m1.x + u2 * m2.x + u3 * m3.x;
+                    acc[c].y += u0 * m0.y + u1 * m1.y + u2 * m2.y + u3 * m3.y;
+                    acc[c].z += u0 * m0.z + u1 * m1.z + u2 * m2.z + u3 * m3.z;
+                    acc[c].w += u0 * m0.w + u1 * m1.w + u2 * m2.w + u3 * m3.w;
+                }
+            }
+        }
+        if (live) {
+#pragma unroll
+            for (int c = 0; c < 8; ++c)
+                if (c < n_comp) *reinterpret_cast<float4 *>(dx + (size_t)r * h + c * k + j) = acc[c];
+        }
+    }
+}
+
 // ---- tiny dense head ------------------------------------------------------------------------------
 // y[r, o] = b[o] + sum_i x[r, i] w[o, i] for the last map of the read-out (RealTransformer 'linear' on
 // n*target -> target columns, layers.py:399-414: 4 -> 1 for ogbg-molhiv): a BLAS call plus its two backward GEMMs,
@@ -980,6 +1043,44 @@ int phc_gated_pool_bwd(const float *dout, const float *x, const float *gate, con
         PHC_LAUNCH((gated_pool_bwd_kernel<1>), dim3((unsigned)blocks), dim3(256), 0, s, dout, x, gate,
                    reinterpret_cast<const long long *>(batch), (long long)N, h, k, n_comp, dx, dgate);
     return check_launch("gated_pool_bwd");
+}
+
+int phc_gated_pool_bwd_gate_supported(int h, int n_comp) {
+    static const bool off = getenv("PHC_POOL_BWD_GATE") && atoi(getenv("PHC_POOL_BWD_GATE")) == 0;
+    if (off || n_comp < 1 || n_comp > 8 || h < 1 || h % n_comp) return 0;
+    const int k = h / n_comp;
+    // (k = 64 — configs[3] — is served by the kernel but measured 6 us per step slower than the two launches: 256 LDS reads per lane
+    // behind a 64 KB operand; PHC_POOL_BWD_GATE=2 turns it on)
+    static const bool k64 = getenv("PHC_POOL_BWD_GATE") && atoi(getenv("PHC_POOL_BWD_GATE")) == 2;
+    return ((k == 32 || (k == 64 && k64)) && (size_t)k * h * sizeof(float) <= 96 * 1024) ? 1 : 0;
+}
+
+int phc_gated_pool_bwd_gate(const float *dout, const float *x, const float *gate, const int64_t *batch, int64_t N, int64_t num_graphs,
+                            int h, int n_comp, const float *MT, float *dx, float *dgate, void *stream) {
+    PHC_REQUIRE(N >= 0 && num_graphs >= 0 && phc_gated_pool_bwd_gate_supported(h, n_comp), PHC_ERR_UNSUPPORTED,
+                "phc_gated_pool_bwd_gate: h = %d with %d components (k = 32 or 64, at most 8 components)", h, n_comp);
+    if (N == 0) return PHC_OK;
+    PHC_REQUIRE(dout && x && gate && batch && MT && dx && dgate, PHC_ERR_INVALID_ARG, "phc_gated_pool_bwd_gate: null pointer");
+    PHC_REQUIRE(((reinterpret_cast<uintptr_t>(dout) | reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(gate) |
+                  reinterpret_cast<uintptr_t>(MT) | reinterpret_cast<uintptr_t>(dx) | reinterpret_cast<uintptr_t>(dgate)) & 15) == 0,
+                PHC_ERR_UNSUPPORTED, "phc_gated_pool_bwd_gate: 16-byte aligned rows required");
+    hipStream_t s = (hipStream_t)stream;
+    const int k = h / n_comp, KV = k / 4;
+    const size_t lds = sizeof(float) * (size_t)k * h;
+    long long blocks = (N * KV + 255) / 256;
+    const long long cap = 2LL * ro_num_cu();
+    if (blocks > cap) blocks = cap;
+    ProfScope prof(K_GATED_POOL_BWD, s);
+    if (KV == 8) {
+        PHC_REQUIRE(ensure_dynamic_lds(&gated_pool_bwd_gate_kernel<8>, 96 * 1024), PHC_ERR_LAUNCH, "phc_gated_pool_bwd_gate: dynamic LDS refused");
+        PHC_LAUNCH((gated_pool_bwd_gate_kernel<8>), dim3((unsigned)blocks), dim3(256), lds, s, dout, x, gate,
+                   reinterpret_cast<const long long *>(batch), (long long)N, h, n_comp, MT, dx, dgate);
+    } else {
+        PHC_REQUIRE(ensure_dynamic_lds(&gated_pool_bwd_gate_kernel<16>, 96 * 1024), PHC_ERR_LAUNCH, "phc_gated_pool_bwd_gate: dynamic LDS refused");
+        PHC_LAUNCH((gated_pool_bwd_gate_kernel<16>), dim3((unsigned)blocks), dim3(256), lds, s, dout, x, gate,
+                   reinterpret_cast<const long long *>(batch), (long long)N, h, n_comp, MT, dx, dgate);
+    }
+    return check_launch("gated_pool_bwd_gate");
 }
 
 // ---- batched strided 2-D copies (phc_copy2d_batched): the flat [R, h] image of an encoder's [V_f, k] tables and back ----

@@ -252,6 +252,8 @@ SIGNATURES = {
     "phc_gated_pool_fwd": (_I, [_P, _P, _P, _L, _I, _I, _P, _P]),
     "phc_gated_pool_fwd_sorted": (_I, [_P, _P, _P, _L, _L, _I, _I, _P, _P]),
     "phc_gated_pool_bwd": (_I, [_P, _P, _P, _P, _L, _L, _I, _I, _P, _P, _P]),
+    "phc_gated_pool_bwd_gate_supported": (_I, [_I, _I]),
+    "phc_gated_pool_bwd_gate": (_I, [_P, _P, _P, _P, _L, _L, _I, _I, _P, _P, _P, _P]),
     "phc_sum_n": (_I, [_P, _I, _L, _P, _P]),
     "phc_copy2d_batched": (_I, [_P, _I, _L, _P, _P, _P]),
     "phc_aggregate_dx_rows": (_I, [_P, _P, _P, _L, _L, _I, _I, _P, _P, _P]),

@@ -1732,6 +1732,10 @@ def global_add_pool(x: torch.Tensor, batch, num_graphs: Optional[int] = None, is
 
 
 
+# the gate layer's backward-data map inside the gated sum's backward launch (phc_gated_pool_bwd_gate; k = 32 / 64, composed gate)
+POOL_BWD_GATE = __import__("os").environ.get("PHC_POOL_BWD_GATE", "1") != "0"
+
+
 class _GatedSegmentSumFn(torch.autograd.Function):
     """out[g, c*k+j] = Σ_{r in graph g} x[r, c*k+j]·σ(gate[r, j]) over rows that are already grouped by graph."""
 
@@ -1777,6 +1781,17 @@ class _GatedSegmentSumFn(torch.autograd.Function):
         N, h = x_.shape
         dx = torch.empty_like(x_) if ctx.needs_input_grad[0] else None
         dg = torch.empty_like(g_) if ctx.needs_input_grad[1] else None
+        ho = ctx.dx_handoff
+        MT = getattr(ho, "gate_MT", None) if (ho is not None and ho.accepted) else None
+        if POOL_BWD_GATE and MT is not None and dx is not None and dg is not None and N > 0 and tuple(MT.shape) == (g_.shape[1], h) \
+                and MT.is_contiguous() and lib.phc_gated_pool_bwd_gate_supported(h, n_comp) and dout_.data_ptr() % 16 == 0:
+            # the gate layer's dx = dg . M^T rides in this launch: dx is x's whole gradient from the read-out
+            L.check(lib.phc_gated_pool_bwd_gate(L.ptr(dout_), L.ptr(x_), L.ptr(g_), L.ptr(batch), N, G, h, n_comp, L.ptr(MT), L.ptr(dx),
+                                                L.ptr(dg), L.stream_ptr(dev)), "phc_gated_pool_bwd_gate")
+            if L.PROF_ON:
+                L.account("gated_pool_bwd", 4.0 * N * h + 2.0 * N * h * g_.shape[1], 4.0 * (N * (2 * h + 2 * h // n_comp) + G * h))
+            ho.tensor, ho.complete = dx, True
+            return None, dg, None, None, None, None
         L.check(lib.phc_gated_pool_bwd(L.ptr(dout_), L.ptr(x_), L.ptr(g_), L.ptr(batch), N, G, h, n_comp, L.ptr(dx), L.ptr(dg),
                                        L.stream_ptr(dev)), "phc_gated_pool_bwd")
         if L.PROF_ON:
@@ -1874,6 +1889,8 @@ class _GateLinearFn(torch.autograd.Function):
         ctx.dx_handoff = dx_handoff
         if dx_handoff is not None:
             dx_handoff.accepted = True
+            dx_handoff.gate_MT = MT                          # the gated sum's backward may apply this map itself (POOL_BWD_GATE)
+            dx_handoff.complete = False
         pre = _prebuilt_for(A_, W_) if _PREBUILT.table else None
         ctx.H = pre[0] if pre is not None else None          # the PHM layer's own operand matrix, for dWg = dM^T . H
         ctx.MT = MT
@@ -1896,7 +1913,13 @@ class _GateLinearFn(torch.autograd.Function):
         sp = L.stream_ptr(dev)
         dx = None
         extra = ctx.dx_handoff.take() if ctx.dx_handoff is not None else None
-        if ctx.needs_input_grad[0]:
+        if extra is not None and getattr(ctx.dx_handoff, "complete", False):
+            # the gated sum's backward launch already added dg . M^T to its share (phc_gated_pool_bwd_gate): nothing to launch here
+            ctx.dx_handoff.complete = False
+            if not ctx.needs_input_grad[0]:
+                raise L.PhcError("gate_linear: a complete dx without a consumer")
+            dx = extra
+        elif ctx.needs_input_grad[0]:
             dx = torch.empty((N, inw), dtype=torch.float32, device=dev)
             if N:
                 L.check(lib.phc_gemm_prebuilt(L.ptr(dg_), L.ptr(ctx.MT), None, None, L.ptr(L.f32c(extra)) if extra is not None else None, N, kg,
