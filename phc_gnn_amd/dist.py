@@ -543,12 +543,35 @@ class NormLink:
     the norm skips its pass over y).  Backward: the norm takes its column sums, all-reduces them and PARKS (dout, y, save_stat,
     sums, activation) instead of applying them; the conv's backward runs the element-wise part inside its first dx GEMM
     (``phc_gemm_bwd_apply``).  The conv's output must feed that norm and nothing else."""
-    __slots__ = ("fused", "moments", "parked")
+    __slots__ = ("fused", "moments", "parked", "dea_sink")
 
     def __init__(self):
         self.fused = False
         self.moments = None
         self.parked = None
+        self.dea_sink = None
+
+
+class EdgeGradSink:
+    """The gradient of ONE edge-attribute tensor read by all L layers of a ``ShardedGINEStack`` through identity message functions:
+        d ea[e] = sum_l dagg_l[dst(e)] = (sum_l dagg_l)[dst(e)]
+    (messagepassing.py:132-146: the message is x_j + edge_attr; dagg_l = the gradient of layer l's aggregate, [n_own, h]).  Every
+    layer's backward adds its dagg here and skips its own [E, h] gradient; the LAST layer to run gathers the sum once.  Autograd
+    would otherwise write L tensors of E x h and add them up pairwise — at config 5 (E = 50 M, h = 128: 25.6 GB each) that was
+    48 ms of element-wise adds and 3 x 5 ms of edge-gradient writes in a 255 ms four-layer step."""
+
+    def __init__(self, n_layers: int):
+        self.remaining = int(n_layers)
+        self.total = None
+
+    def add(self, dagg: torch.Tensor) -> bool:
+        """True when this was the last layer: ``self.total`` is complete."""
+        if self.total is None:
+            self.total = dagg                                   # (a temporary of the calling backward: nobody else writes it)
+        else:
+            self.total.add_(dagg)
+        self.remaining -= 1
+        return self.remaining == 0
 
 
 class _ShardedGINEFn(torch.autograd.Function):
@@ -601,6 +624,12 @@ class _ShardedGINEFn(torch.autograd.Function):
                 a = layer.act_fn(z)
             y = be.linear_fwd_pre(a, pre[1], b2) if pre is not None else be.linear_fwd(a, A2, W2, b2)
         ctx.layer = layer
+        sink = link.dea_sink if link is not None else None
+        # (grad mode is off inside Function.forward: the stack made the sink only where gradients are wanted)
+        ctx.dea_sink = sink if (sink is not None and act_msg == "identity"
+                                and ((ea_loc is not None and ctx.needs_input_grad[3]) or (ea_halo is not None and ctx.needs_input_grad[4]))) else None
+        if sink is not None and ctx.dea_sink is None:
+            sink.remaining -= 1                                 # (this layer returns its own edge gradients, if any)
         ctx.link = link if (link is not None and fused) else None
         if link is not None:
             link.fused = fused
@@ -653,6 +682,10 @@ class _ShardedGINEFn(torch.autograd.Function):
         if not ctx.fused:
             ds = be.linear_dx_pre(dz, pre[0]) if pre is not None else be.linear_dx(dz, A1, W1)
         need_dea = (ctx.needs_input_grad[3] and ea_loc is not None, ctx.needs_input_grad[4] and ea_halo is not None)
+        sink = ctx.dea_sink
+        want_dea = need_dea
+        if sink is not None:
+            need_dea = (False, False)                                         # the stack's layers share ONE edge gradient (EdgeGradSink)
 
         def param_grads():                                                    # queued while the halo gradients travel
             g2 = (be.linear_param_grads_xf(z, save_stat, act, dy, A2, W2, ctx.has_bias[1]) if ctx.fused
@@ -662,6 +695,15 @@ class _ShardedGINEFn(torch.autograd.Function):
 
         d_own, dea_loc, dea_halo, (g1, g2) = agg.backward_raw(ds, x_own, recv, ea_loc, ea_halo, act_msg,
                                                               layer.conv.add_self_loops, need_dea, overlap=param_grads)
+        if sink is not None and sink.add(ds):
+            # the last layer of the stack to run: d ea[e] = (sum of the layers' aggregate gradients)[dst(e)], one gather per edge set
+            if want_dea[0]:
+                dea_loc = be.gather_rows(sink.total, plan.loc_edge_index[1])
+            if want_dea[1] and plan.halo_edge_index.shape[1] > 0:
+                dea_halo = be.gather_rows(sink.total, plan.halo_edge_index[1])
+            elif want_dea[1]:
+                dea_halo = ds.new_zeros((0, ds.shape[1]))
+            sink.total = None
         aff = []
         if ctx.n_affine:
             n = ctx.n_affine // 2
@@ -809,6 +851,9 @@ class ShardedPHMNorm(torch.nn.Module):
         return _ShardedNormActFn.apply(x_own, residual, self, link, *affine)
 
 
+EDGE_GRAD_SINK = __import__("os").environ.get("PHC_EDGE_GRAD_SINK", "1") != "0"
+
+
 class ShardedGINEStack(torch.nn.Module):
     """L message-passing layers of PHMSkipConnectAdd on one sharded graph: x <- act(norm(conv(x, edges))) + skip per layer
     (models.py:200-217 with sc_type "last"), every conv a ShardedPHMGINEConv and every norm a ShardedPHMNorm over ONE halo plan
@@ -823,7 +868,10 @@ class ShardedGINEStack(torch.nn.Module):
 
     def forward(self, x_own, ea_loc, ea_halo):
         h = x_own
+        # one edge-attribute tensor feeds every layer: its gradient is gathered once from the sum of the layers' aggregate gradients
+        sink = EdgeGradSink(len(self.layers)) if (EDGE_GRAD_SINK and torch.is_grad_enabled() and len(self.layers) > 1) else None
         for layer, norm in zip(self.layers, self.norms):
             link = NormLink()                   # (does nothing unless the engine's folded norm forms serve the layer)
+            link.dea_sink = sink
             h = norm(layer(h, ea_loc, ea_halo, link=link), residual=h, link=link)
         return h

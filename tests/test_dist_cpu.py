@@ -404,12 +404,20 @@ def _worker_stack(rank, world, port, tmp, kind="uniform", max_pair_bytes=None):
         stack = ShardedGINEStack(convs, norms, plan, N, activation="relu", backend=OracleBackend()).train()
         x_own = x[plan.lo:plan.hi].clone().requires_grad_()
         ea_loc, ea_halo = stack.agg.split_edge_attr(ea)
+        # ONE edge-attribute tensor feeds both layers and wants its gradient: the stack gathers it once from the sum of the layers'
+        # aggregate gradients (dist.EdgeGradSink)
+        ea_loc = ea_loc.clone().requires_grad_()
+        ea_halo = ea_halo.clone().requires_grad_()
         y = stack(x_own, ea_loc, ea_halo)
         y.backward(dy[plan.lo:plan.hi])
         params = [p for m in convs + norms for p in m.parameters()]
         FlatGradSync(params, average=False)()
+        zero = torch.zeros(0, h)
         torch.save(dict(y=y.detach(), gx=x_own.grad, lo=plan.lo, hi=plan.hi, grads=[p.grad.clone() for p in params],
-                        buffers=[b.clone() for m in convs + norms for b in m.buffers()]), os.path.join(tmp, f"s{rank}.pt"))
+                        buffers=[b.clone() for m in convs + norms for b in m.buffers()],
+                        dea_loc=ea_loc.grad if ea_loc.grad is not None else zero, loc_ids=plan.loc_edge_ids.clone(),
+                        dea_halo=ea_halo.grad if ea_halo.grad is not None else zero, halo_ids=plan.halo_edge_ids.clone()),
+                   os.path.join(tmp, f"s{rank}.pt"))
     finally:
         dist.destroy_process_group()
 
@@ -433,22 +441,31 @@ def test_sharded_stack_with_model_level_norm_equals_single_process(tmp_path, wor
     for k in names:
         p[k].requires_grad_()
     xr = x.clone().requires_grad_()
+    ear = ea.clone().requires_grad_()
     hcur = xr
     for i in range(2):
-        y = O.phm_gine_conv(hcur, ei, ea, p, f"c{i}.transform.", n, "relu", True, True, True, "relu", None)
+        y = O.phm_gine_conv(hcur, ei, ear, p, f"c{i}.transform.", n, "relu", True, True, True, "relu", None)
         hcur = O.activation("relu", O._norm_from_state(y, p, f"n{i}.", n, True)) + hcur
-    grads = torch.autograd.grad(hcur, [xr] + [p[k] for k in order], dy, allow_unused=True)
+    grads = torch.autograd.grad(hcur, [xr, ear] + [p[k] for k in order], dy, allow_unused=True)
+    dea_ref, grads = grads[1], (grads[0],) + tuple(grads[2:])
     shards = [torch.load(os.path.join(tmp_path, f"s{r}.pt")) for r in range(world)]
-    yy, gx = torch.zeros(N, h), torch.zeros(N, h)
+    yy, gx, dea = torch.zeros(N, h), torch.zeros(N, h), torch.zeros(ei.shape[1], h)
+    seen = torch.zeros(ei.shape[1], dtype=torch.int64)
     for d in shards:
         yy[d["lo"]:d["hi"]] = d["y"]
         gx[d["lo"]:d["hi"]] = d["gx"]
+        for ids, g in ((d["loc_ids"], d["dea_loc"]), (d["halo_ids"], d["dea_halo"])):
+            if ids.numel():
+                dea[ids] = g
+                seen[ids] += 1
+    assert bool((seen == 1).all())                                    # every edge belongs to exactly one rank's local or halo set
 
     def close(a, b, what, tol=3e-5):
         err = float((a - b).abs().max()) / max(float(b.abs().max()), 1e-30)
         assert err <= tol, (what, err)
     close(yy, hcur.detach(), "y")
     close(gx, grads[0], "dx")
+    close(dea, dea_ref, "d edge_attr (one gather from the sum of both layers' aggregate gradients)")
     for k, got, ref in zip(order, shards[0]["grads"], grads[1:]):
         if ref is None or k.endswith("linear1.b") or k.endswith("linear2.b"):     # biases in front of a norm: zero up to round-off
             continue
