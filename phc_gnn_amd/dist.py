@@ -214,8 +214,17 @@ class EngineBackend:
     def aggregate_fwd(self, x, ea, st, act, add_self, accumulate_into=None):
         return self._ops.aggregate_fwd_raw(x, ea, st, act, add_self, accumulate_into)
 
-    def aggregate_bwd(self, dout, x, ea, st, act, add_self, need_dea):
-        return self._ops.aggregate_bwd_raw(dout, x, ea, st, act, add_self, need_dea)
+    def aggregate_bwd(self, dout, x, ea, st, act, add_self, need_dea, extra=None):
+        """(dx, dea | None); ``extra``: another consumer's share of the gradient of x, added to dx (inside the walk where the
+        row walker serves the call: identity messages, no edge gradient)."""
+        if extra is not None and not need_dea and act == "identity":
+            dx = self._ops.aggregate_dx_rows_raw(dout, st, add_self, extra)
+            if dx is not None:
+                return dx, None
+        dx, dea = self._ops.aggregate_bwd_raw(dout, x, ea, st, act, add_self, need_dea)
+        if extra is not None:
+            dx += extra
+        return dx, dea
 
     def gather_rows(self, x, rows):
         return self._ops.gather_rows(x, rows)                   # phc_gather_rows_i64
@@ -510,9 +519,9 @@ class ShardedAggregate:
             out = be.aggregate_fwd(recv, ea_halo, self.st_halo, act, False, accumulate_into=out)
         return out, recv
 
-    def backward_raw(self, dout, x_own, recv, ea_loc, ea_halo, act: str, add_self: bool, need_dea=(False, False), overlap=None):
+    def backward_raw(self, dout, x_own, recv, ea_loc, ea_halo, act: str, add_self: bool, need_dea=(False, False), overlap=None, extra=None):
         """(d_own, dea_loc, dea_halo); ``overlap``: a callable queued on the compute stream while the gradient rows of
-        the halo sources travel back (the layer's parameter-gradient GEMMs)."""
+        the halo sources travel back (the layer's parameter-gradient GEMMs); ``extra``: another consumer's share of d x_own."""
         plan, be = self.plan, self.backend
         h = dout.shape[1]
         if plan.n_halo > 0 and plan.halo_edge_index.shape[1] > 0:          # gradient of the halo rows first: it has to travel
@@ -522,7 +531,8 @@ class ShardedAggregate:
             dea_halo = dout.new_zeros((0, h)) if need_dea[1] else None
         back, work = _exchange_rows(be, self.lane, d_halo, None, int(plan.send_rows.numel()), plan.send_splits, plan.recv_splits,
                                     plan.group, plan.max_pair_rows, check_key=(plan.serial, "bwd"))
-        d_own, dea_loc = be.aggregate_bwd(dout, x_own, ea_loc, self.st_loc, act, add_self, need_dea[0])
+        d_own, dea_loc = be.aggregate_bwd(dout, x_own, ea_loc, self.st_loc, act, add_self, need_dea[0], extra=extra) if extra is not None \
+            else be.aggregate_bwd(dout, x_own, ea_loc, self.st_loc, act, add_self, need_dea[0])
         extra = overlap() if overlap is not None else None
         _finish(self.lane, work)
         if self.seg_back is not None:
@@ -543,13 +553,15 @@ class NormLink:
     the norm skips its pass over y).  Backward: the norm takes its column sums, all-reduces them and PARKS (dout, y, save_stat,
     sums, activation) instead of applying them; the conv's backward runs the element-wise part inside its first dx GEMM
     (``phc_gemm_bwd_apply``).  The conv's output must feed that norm and nothing else."""
-    __slots__ = ("fused", "moments", "parked", "dea_sink")
+    __slots__ = ("fused", "moments", "parked", "dea_sink", "take_res", "res_share")
 
     def __init__(self):
         self.fused = False
         self.moments = None
         self.parked = None
         self.dea_sink = None
+        self.take_res = False        # the norm's residual IS the conv's input (ShardedGINEStack): its gradient share (= the norm's dout)
+        self.res_share = None        # is parked here and added inside the conv's aggregation backward instead of by autograd
 
 
 class EdgeGradSink:
@@ -631,8 +643,11 @@ class _ShardedGINEFn(torch.autograd.Function):
         if sink is not None and ctx.dea_sink is None:
             sink.remaining -= 1                                 # (this layer returns its own edge gradients, if any)
         ctx.link = link if (link is not None and fused) else None
+        ctx.res_link = link if (link is not None and link.take_res and ctx.needs_input_grad[2]) else None
         if link is not None:
             link.fused = fused
+            if ctx.res_link is None:
+                link.take_res = False                           # (nobody will add a parked share: the norm returns it to autograd)
         ctx.has_ea = (ea_loc is not None, ea_halo is not None)
         ctx.has_bias = (b1 is not None, b2 is not None)
         ctx.n_affine = len(affine)
@@ -693,8 +708,11 @@ class _ShardedGINEFn(torch.autograd.Function):
             g1 = be.linear_param_grads(s, dz, A1, W1, ctx.has_bias[0])
             return g1, g2
 
+        share = None
+        if ctx.res_link is not None:
+            share, ctx.res_link.res_share = ctx.res_link.res_share, None     # the skip's share of d x_own, parked by the norm behind this conv
         d_own, dea_loc, dea_halo, (g1, g2) = agg.backward_raw(ds, x_own, recv, ea_loc, ea_halo, act_msg,
-                                                              layer.conv.add_self_loops, need_dea, overlap=param_grads)
+                                                              layer.conv.add_self_loops, need_dea, overlap=param_grads, extra=share)
         if sink is not None and sink.add(ds):
             # the last layer of the stack to run: d ea[e] = (sum of the layers' aggregate gradients)[dst(e)], one gather per edge set
             if want_dea[0]:
@@ -790,6 +808,7 @@ class _ShardedNormActFn(torch.autograd.Function):
                                                 mod.activation, residual)
         ctx.mod = mod
         ctx.link = link if linked else None
+        ctx.res_link = link if (link is not None and link.take_res and residual is not None) else None
         ctx.has_res = residual is not None
         ctx.n_affine = len(affine)
         ctx.save_for_backward(x, save_stat)
@@ -823,7 +842,11 @@ class _ShardedNormActFn(torch.autograd.Function):
             h = x.shape[1]
             k = h // n
             aff = [dwb[c * k:(c + 1) * k] for c in range(n)] + [dwb[h + c * k:h + (c + 1) * k] for c in range(n)]
-        return (dx, dout if ctx.has_res else None, None, None, *aff)
+        dres = dout if ctx.has_res else None
+        if ctx.res_link is not None and ctx.needs_input_grad[1]:
+            ctx.res_link.res_share = dout                                     # added inside the conv's aggregation backward (NormLink)
+            dres = None
+        return (dx, dres, None, None, *aff)
 
 
 class ShardedPHMNorm(torch.nn.Module):
@@ -852,6 +875,7 @@ class ShardedPHMNorm(torch.nn.Module):
 
 
 EDGE_GRAD_SINK = __import__("os").environ.get("PHC_EDGE_GRAD_SINK", "1") != "0"
+RESIDUAL_SHARE = __import__("os").environ.get("PHC_STACK_RESIDUAL_SHARE", "1") != "0"
 
 
 class ShardedGINEStack(torch.nn.Module):
@@ -873,5 +897,6 @@ class ShardedGINEStack(torch.nn.Module):
         for layer, norm in zip(self.layers, self.norms):
             link = NormLink()                   # (does nothing unless the engine's folded norm forms serve the layer)
             link.dea_sink = sink
+            link.take_res = RESIDUAL_SHARE and torch.is_grad_enabled()     # the norm's residual below is this conv's input
             h = norm(layer(h, ea_loc, ea_halo, link=link), residual=h, link=link)
         return h

@@ -1283,6 +1283,27 @@ def aggregate_bwd_raw(dout: torch.Tensor, x: Optional[torch.Tensor], ea: Optiona
     return dx, dea
 
 
+def aggregate_dx_rows_raw(dout: torch.Tensor, st: EdgeStructure, add_self: bool, extra: Optional[torch.Tensor] = None):
+    """dx [num_src, h] of an identity-message aggregation by the row walker (no autograd bookkeeping):
+    dx[s] = sum over out-edges of dout[dst(e)] (+ dout[s] with the self loop) (+ extra[s], another consumer's share of the same
+    tensor's gradient — added on the way out, no add launch).  None when the shapes are outside the walker's range."""
+    lib = L.load()
+    dev = L.require_device(dout, extra)
+    dout_ = L.f32c(dout)
+    h = dout_.shape[1]
+    if h % 4 or dout_.data_ptr() % 16 or st.num_src != st.num_dst or (extra is not None and (extra.data_ptr() % 16 or not extra.is_contiguous()
+                                                                                          or tuple(extra.shape) != (st.num_src, h))):
+        return None
+    rowptr_t, col_t, _ = st.csc
+    dx = torch.empty((st.num_src, h), dtype=torch.float32, device=dev)
+    L.check(lib.phc_aggregate_dx_rows(L.ptr(dout_), L.ptr(rowptr_t), L.ptr(col_t), st.num_src, st.num_dst, h, 1 if add_self else 0,
+                                      L.ptr(extra), L.ptr(dx), L.stream_ptr(dev)), "phc_aggregate_dx_rows")
+    if L.PROF_ON:
+        E, Ns = st.num_edges, st.num_src
+        L.account("aggregate_enc_dx", 1.0 * E * h, E * (4.0 * h + 4) + Ns * 4.0 * h * (2 if add_self else 1) + 4.0 * (Ns + 1))
+    return dx
+
+
 def gather_rows(x: torch.Tensor, rows_i64: torch.Tensor) -> torch.Tensor:
     """out[r] = x[rows[r]] (engine kernel; staging of the halo exchange's send buffer)."""
     lib = L.load()

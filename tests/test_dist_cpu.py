@@ -45,13 +45,15 @@ class OracleBackend:
         out = out + x[:st.num_dst] if add_self else out
         return out if accumulate_into is None else accumulate_into + out
 
-    def aggregate_bwd(self, dout, x, ea, st, act, add_self, need_dea):
+    def aggregate_bwd(self, dout, x, ea, st, act, add_self, need_dea, extra=None):
         with torch.enable_grad():
             xr = x.detach().clone().requires_grad_()
             er = ea.detach().clone().requires_grad_() if ea is not None else None
             out = self.aggregate_fwd(xr, er, st, act, add_self)
             grads = torch.autograd.grad(out, [xr] + ([er] if er is not None else []), dout, allow_unused=True)
         dx = grads[0] if grads[0] is not None else torch.zeros_like(x)
+        if extra is not None:                                     # another consumer's share of d x (the stack's skip: dist.NormLink)
+            dx = dx + extra
         return dx, (grads[1] if (need_dea and er is not None) else None)
 
     def gather_rows(self, x, rows):
