@@ -1365,16 +1365,38 @@ __global__ __launch_bounds__(256, 2) void tail_partial_kernel(GradBatch gb, Tail
     const long long xf_count = j.xf_stat ? (j.xf_n_valid ? min((long long)*j.xf_n_valid, j.N) : j.N) : 0;
     int tile;
     long long split;
-    xcd_tile_split(blockIdx.x, local, (unsigned)j.tiles, (unsigned)j.splits, tile, split);
-    if (j.t128 == 3 && dh3_np(j.out) == 2)
-        dH_direct_body<2>(j.x, j.dy, j.slabs, j.N, j.in, j.out, j.tiles_j, j.rows_per_split, tile, split, smem, j.xf_stat, j.xf_act,
-                          xf_count);
-    else if (j.t128 == 3)                                    // out an odd multiple of 32: 128 x 32 tiles
-        dH_direct_body<1>(j.x, j.dy, j.slabs, j.N, j.in, j.out, j.tiles_j, j.rows_per_split, tile, split, smem, j.xf_stat, j.xf_act,
-                          xf_count);
-    else
+    // Even shares (GradJobDev.pair > 1, form 3): the job's rows are cut into splits - 1 full splits and a shorter last one, and the
+    // last splits of `pair` tiles are ONE workgroup's work, one after the other — every workgroup of the family then has (about)
+    // rows_per_split rows whatever N / rows_per_split leaves over, instead of the family's split count being rounded to what fits the
+    // slots (88 tiles x 5 splits = 440 of 512 at hidden 256).  Which workgroup computes a (tile, split) never changes what is computed.
+    int tasks = 1, tile_step = 0;
+    if (j.t128 == 3 && j.pair > 1) {
+        const unsigned full = (unsigned)j.tiles * (unsigned)(j.splits - 1);
+        if (local < full) {
+            xcd_tile_split(blockIdx.x, local, (unsigned)j.tiles, (unsigned)(j.splits - 1), tile, split);
+        } else {
+            tile = (int)(local - full) * j.pair;
+            split = j.splits - 1;
+            tasks = min(j.pair, j.tiles - tile);
+            tile_step = 1;
+        }
+    } else {
+        xcd_tile_split(blockIdx.x, local, (unsigned)j.tiles, (unsigned)j.splits, tile, split);
+    }
+    if (j.t128 == 3) {
+        for (int q = 0; q < tasks; ++q, tile += tile_step) {
+            if (q) __syncthreads();                          // (the staging area of the task in front)
+            if (dh3_np(j.out) == 2)
+                dH_direct_body<2>(j.x, j.dy, j.slabs, j.N, j.in, j.out, j.tiles_j, j.rows_per_split, tile, split, smem, j.xf_stat, j.xf_act,
+                                  xf_count);
+            else                                             // out an odd multiple of 32: 128 x 32 tiles
+                dH_direct_body<1>(j.x, j.dy, j.slabs, j.N, j.in, j.out, j.tiles_j, j.rows_per_split, tile, split, smem, j.xf_stat, j.xf_act,
+                                  xf_count);
+        }
+    } else {
         dH_partial_body(j.x, j.dy, j.slabs, j.N, j.in, j.out, j.tiles_j, j.rows_per_split, j.vec4, tile, split, smem, j.xf_stat, j.xf_act,
                         xf_count);
+    }
 }
 
 __global__ __launch_bounds__(256) void tail_reduce_kernel(GradBatch gb, TailTables t, TailReg reg) {

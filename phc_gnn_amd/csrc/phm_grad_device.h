@@ -452,7 +452,9 @@ __device__ __forceinline__ void dH_direct_body(const float *__restrict__ X, cons
     using DVT = typename DhVec<NP>::T;
     const long long r_begin = split * rows_per_split;
     const long long r_end = min(N, r_begin + rows_per_split);
-    const long long rq = rows_per_split >> 2;           // rows_per_split % 8 == 0: every quarter starts on an even row
+    // the rows of THIS split in four wavefront quarters of whole 16-row iterations (a full split: rows_per_split / 4, as ever; the
+    // shorter last split of a job is dealt evenly too — its workgroup may go on to the last split of another tile: GradJobDev.pair)
+    const long long rq = ((max(r_end - r_begin, 0LL) + 63) >> 6) << 4;
     const long long w_begin = min(r_begin + wave * rq, r_end), w_end = min(w_begin + rq, r_end);
     const size_t slab_elems = (size_t)in * out + out;
     float *slab = slabs + (size_t)split * slab_elems;
@@ -579,6 +581,7 @@ struct GradJobDev {
     const int *xf_n_valid;
     int xf_act;
     unsigned blk0_partial, blk0_reduce, blk0_contract;      // first workgroup of this job in each launch
+    int pair;                                                // form 3, > 1: the last (shorter) splits of `pair` tiles share ONE workgroup
     const float *reg_add;                                    // != NULL: added to dW as it is written (the weight regulariser's gradient)
 };
 struct GradBatch {

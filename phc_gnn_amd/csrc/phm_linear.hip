@@ -1675,7 +1675,7 @@ static DhPlan dh_plan_direct(int64_t N, int in, int out) {
 }
 
 struct GradPlan {
-    int tiles_i, tiles_j, splits, t128;
+    int tiles_i, tiles_j, splits, t128, pair;
     int64_t rows_per_split;
     size_t slab_elems;
 };
@@ -1702,6 +1702,7 @@ static void grad_plans(const phc_phm_grad_job *jobs, int num, GradPlan *plans, i
     for (int k = 0; k < num; ++k) {
         const int in = jobs[k].n * jobs[k].kin, out = jobs[k].n * jobs[k].kout;
         plans[k].t128 = dh_use_direct(jobs[k]) ? direct_form : (dh_use_128(jobs[k].N, in, out) ? 1 : 0);
+        plans[k].pair = 1;
         const int T = plans[k].t128 ? DH_T2 : DH_T;
         plans[k].tiles_i = (in + T - 1) / T;
         plans[k].tiles_j = plans[k].t128 == 3 ? (out + 32 * dh3_np(out) - 1) / (32 * dh3_np(out)) : (out + T - 1) / T;
@@ -1718,27 +1719,44 @@ static void grad_plans(const phc_phm_grad_job *jobs, int num, GradPlan *plans, i
         static const int64_t dtarget3 = getenv("PHC_DH_DIRECT64_TARGET") ? atoll(getenv("PHC_DH_DIRECT64_TARGET")) : 512;
         const int64_t dtarget = direct_form == 3 ? dtarget3 : dtarget2;       // form 3: two workgroups per CU
         // multiples of 64 rows: each of the four wavefronts then runs whole 16-row iterations of the unmasked loop
+        // form 3 (the step tail), even shares: a job's shorter last split is `pair` tiles' worth of ONE workgroup when that many of them
+        // fit in rows_per_split rows (tail kernel, GradJobDev.pair) — the workgroup count is then (nearly) continuous in rows_per_split
+        // and the family fills its slots instead of stopping at the last whole split count that fits (PHC_DH_PAIR=0: whole counts)
+        static const bool pairing = !(getenv("PHC_DH_PAIR") && atoi(getenv("PHC_DH_PAIR")) == 0);
+        auto pair_of = [&](int k, int64_t rps) -> int {
+            if (direct_form != 3 || !pairing) return 1;
+            const int64_t rem = jobs[k].N % rps;
+            if (rem == 0 || jobs[k].N < rps) return 1;
+            const int64_t m = rps / ((rem + 63) / 64 * 64);
+            return (int)(m < 1 ? 1 : (m > 8 ? 8 : m));
+        };
+        auto wgs_of = [&](int k, int64_t rps) -> int64_t {
+            const int64_t tiles = (int64_t)plans[k].tiles_i * plans[k].tiles_j, splits = (jobs[k].N + rps - 1) / rps;
+            const int m = pair_of(k, rps);
+            return m > 1 ? tiles * (splits - 1) + (tiles + m - 1) / m : tiles * splits;
+        };
         int64_t rps = (direct_rows / dtarget + 63) / 64 * 64;
         if (rps < 64) rps = 64;
         for (;; rps += 64) {
             int64_t wgs = 0;
             for (int k = 0; k < num; ++k)
-                if (plans[k].t128 >= 2) wgs += (int64_t)plans[k].tiles_i * plans[k].tiles_j * ((jobs[k].N + rps - 1) / rps);
+                if (plans[k].t128 >= 2) wgs += wgs_of(k, rps);
             if (wgs <= dtarget || rps >= direct_rows) break;
         }
         for (int k = 0; k < num; ++k)
             if (plans[k].t128 >= 2) {
                 plans[k].rows_per_split = rps;
                 plans[k].splits = (int)((jobs[k].N + rps - 1) / rps);
+                plans[k].pair = pair_of(k, rps);
             }
     }
     static const int64_t target = getenv("PHC_GRAD_TARGET") ? atoll(getenv("PHC_GRAD_TARGET")) : 1024;    // tuning knob
     static const bool dbg = getenv("PHC_DEBUG_PLANS") != nullptr;
     if (dbg)
         for (int k = 0; k < num; ++k)
-            fprintf(stderr, "[phc plan] job %d: N=%lld in=%d out=%d form=%d xf=%d splits=%d rows_per_split=%lld\n", k, (long long)jobs[k].N,
+            fprintf(stderr, "[phc plan] job %d: N=%lld in=%d out=%d form=%d xf=%d splits=%d rows_per_split=%lld pair=%d\n", k, (long long)jobs[k].N,
                     jobs[k].n * jobs[k].kin, jobs[k].n * jobs[k].kout, plans[k].t128, jobs[k].xf_stat ? jobs[k].xf_act : -1,
-                    plans[k].t128 >= 2 ? plans[k].splits : -1, plans[k].t128 >= 2 ? (long long)plans[k].rows_per_split : -1LL);
+                    plans[k].t128 >= 2 ? plans[k].splits : -1, plans[k].t128 >= 2 ? (long long)plans[k].rows_per_split : -1LL, plans[k].pair);
     for (int k = 0; k < num; ++k) {
         if (plans[k].t128 >= 2) continue;
         const int64_t max_splits = (jobs[k].N + DH_RB - 1) / DH_RB;
@@ -1811,7 +1829,9 @@ int prepare_grad_launch(const char *who, const phc_phm_grad_job *jobs, int cn, f
         d.blk0_partial = nb_mine;
         d.blk0_reduce = nb_reduce;
         d.blk0_contract = nb_contract;
-        nb_mine += (unsigned)d.tiles * (unsigned)d.splits;
+        d.pair = d.t128 == 3 ? plans[k].pair : 1;
+        nb_mine += d.pair > 1 ? (unsigned)d.tiles * (unsigned)(d.splits - 1) + (unsigned)((d.tiles + d.pair - 1) / d.pair)
+                              : (unsigned)d.tiles * (unsigned)d.splits;
         nb_reduce += (unsigned)((plans[k].slab_elems + 63) / 64);
         nb_contract += (unsigned)(d.dA_blocks + (jb.n * jb.kin * jb.kout + 255) / 256);
     }

@@ -652,3 +652,33 @@ def test_norm_folded_into_the_softmax_aggregation_equals_the_two_launches(N, E, 
     for key in res["fused"]:
         a_, b_ = res["fused"][key], res["separate"][key]
         assert torch.equal(a_, b_), (key, float((a_.double() - b_.double()).abs().max()))
+
+
+# ---- round 5: even shares in the step tail's dH family (GradJobDev.pair: the last splits of several tiles in one workgroup) ----
+@pytest.mark.parametrize("workload", ["molhiv_b512", "molpcba_b1024"])
+def test_paired_last_splits_of_the_tail_match_whole_split_counts(workload, tmp_path):
+    """The planner's switch is read once per process: two child processes run the same eager step (scripts/dbg/tail_pair_step.py) with
+    PHC_DH_PAIR=1 (the default; its plan must really pair: `pair=` > 1 in the plan dump) and 0.  Same loss bit for bit (the forward does
+    not involve the tail); every gradient within summation-order round-off (the paired plan cuts the rows into other splits)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    res = {}
+    for pair in ("1", "0"):
+        out = str(tmp_path / f"step_{pair}.pt")
+        env = dict(os.environ, PHC_DH_PAIR=pair, PHC_DEBUG_PLANS="1")
+        p = subprocess.run([sys.executable, os.path.join(root, "scripts", "dbg", "tail_pair_step.py"), workload, out], env=env, cwd=root,
+                           capture_output=True, text=True, timeout=600)
+        assert p.returncode == 0, p.stderr[-2000:]
+        pairs = [int(l.rsplit("pair=", 1)[1]) for l in p.stderr.splitlines() if "[phc plan]" in l and "form=3" in l]
+        assert pairs, "no plan dump"
+        assert (max(pairs) > 1) == (pair == "1"), (pair, sorted(set(pairs)))
+        res[pair] = torch.load(out)
+    a, b = res["1"], res["0"]
+    assert torch.equal(a["loss"], b["loss"])
+    assert a["grads"].keys() == b["grads"].keys()
+    for k in a["grads"]:
+        ref = float(b["grads"][k].abs().max())
+        err = float((a["grads"][k] - b["grads"][k]).abs().max())
+        assert err <= 1e-5 * ref + 1e-7, (k, err, ref)
