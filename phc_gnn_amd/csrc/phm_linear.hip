@@ -1725,8 +1725,8 @@ static void grad_plans(const phc_phm_grad_job *jobs, int num, GradPlan *plans, i
         static const bool pairing = !(getenv("PHC_DH_PAIR") && atoi(getenv("PHC_DH_PAIR")) == 0);
         auto pair_of = [&](int k, int64_t rps) -> int {
             if (direct_form != 3 || !pairing) return 1;
-            const int64_t rem = jobs[k].N % rps;
-            if (rem == 0 || jobs[k].N < rps) return 1;
+            const int64_t rem = jobs[k].N < rps ? jobs[k].N : jobs[k].N % rps;      // (a job of fewer rows than one split: its only split)
+            if (rem == 0) return 1;
             const int64_t m = rps / ((rem + 63) / 64 * 64);
             return (int)(m < 1 ? 1 : (m > 8 ? 8 : m));
         };
