@@ -33,11 +33,22 @@ from .harness import StepConfig, advance_dropout_rng, apply_weight_regulariser, 
 from .ops import atom_encode_spec, deferred_param_grads, dense_weights, gate_specs, phm_pairs, prebuilt_H, stat_accumulators
 
 
+# rows of one full round of the row-blocked GEMM launches: 16-row steps x one workgroup per CU of a 256-CU part (the 256-wide layers;
+# the 128-wide ones run two workgroups per CU: 8 192 rows, a multiple).  A padded node count just ABOVE a whole number of rounds costs
+# every such launch a nearly empty extra round (24 832 rows = 6.06 rounds: seven passes of the step loop where 24 576 take six).
+ROUND_ROWS = int(__import__("os").environ.get("PHC_BUCKET_ROUND_ROWS", "4096"))
+
+
 def bucket_shape(batches: List[synth.GraphBatch], slack: float = 0.02, multiple: int = 128):
-    """(N_max, E_max) covering every batch with a little slack, plus room for padding nodes."""
+    """(N_max, E_max) covering every batch with a little slack, plus room for padding nodes.  Inside the slack window a node count that
+    is a whole number of GEMM rounds (ROUND_ROWS) is preferred: the padding is there to be cheap."""
     n = max(b.num_nodes for b in batches)
     e = max(b.num_edges for b in batches)
     n_max = int(np.ceil(n * (1 + slack) / multiple) * multiple) + multiple
+    if ROUND_ROWS > 0:
+        whole = n_max // ROUND_ROWS * ROUND_ROWS
+        if whole >= n + multiple:                             # (still at least `multiple` padding nodes: the padding graphs live there)
+            n_max = whole
     e_max = int(np.ceil(e * (1 + slack) / multiple) * multiple)
     return n_max, e_max
 

@@ -171,3 +171,15 @@ def test_synthetic_batches_are_seeded_and_shaped():
     assert (a.edge_index[0, 0::2] == a.edge_index[1, 1::2]).all()      # each bond = two directed edges
     assert 20 < a.num_nodes / 64 < 31 and 1.0 < a.num_edges / 2 / a.num_nodes < 1.2
     assert (a.x.max(0) < np.array(synth.OGB_ATOM_DIMS)).all()
+
+
+def test_bucket_shape_prefers_whole_gemm_rounds_inside_its_slack():
+    """graphed.bucket_shape: every batch fits with at least 128 padding nodes; when a whole number of 4 096-row GEMM rounds lies inside
+    the slack window it is taken (24 200 nodes: 24 576 instead of 24 832), otherwise the window's upper end stays."""
+    from types import SimpleNamespace as NS
+    from phc_gnn_amd import graphed
+    for n, want in ((24200, 24576), (24460, 25088), (13100, 13568), (27400, 28160), (500, 640)):
+        n_max, e_max = graphed.bucket_shape([NS(num_nodes=n, num_edges=2 * n), NS(num_nodes=n - 50, num_edges=2 * n + 10)])
+        assert n_max == want, (n, n_max)
+        assert n_max >= n + 128 and n_max % 128 == 0
+        assert e_max >= 2 * n + 10 and e_max % 128 == 0
