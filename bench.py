@@ -121,9 +121,13 @@ def parse_args():
     ap.add_argument("--workload", default="molhiv_b512")
     ap.add_argument("--num-batches", type=int, default=8, help="distinct resident batches cycled through")
     ap.add_argument("--fwd-bwd-only", action="store_true", help="leave grad clipping + Adam out of the step")
-    ap.add_argument("--mode", choices=["graph", "eager"], default="graph",
+    ap.add_argument("--mode", choices=["graph", "eager", "refloop"], default="graph",
                     help="graph: whole step captured once into a hipGraph over bucket-padded batches, replayed per "
-                         "batch (phc_gnn_amd/graphed.py); eager: one launch per kernel from Python")
+                         "batch (phc_gnn_amd/graphed.py); eager: harness.train_step, one launch per kernel from Python; "
+                         "refloop: the loop body of the reference's train() (benchmarks/train_hiv.py:175-202) as it stands "
+                         "— boolean-mask BCE, phm_weight_regularization, loss.backward(), clip_grad_norm_, "
+                         "torch.optim.Adam.step(), loss.item() every step — on the mirror model, nothing of harness.py "
+                         "(what a user who only swaps the package gets; molhiv workloads)")
     ap.add_argument("--optimizer", choices=["engine", "torch"], default="engine",
                     help="engine: phc_gnn_amd.optim.ClipAdam (clip + Adam in two launches); torch: clip_grad_norm_ + "
                          "torch.optim.Adam(fused, capturable)")
@@ -491,9 +495,39 @@ def main():
         padded = [graphed.padded_to_device(graphed.pad_batch(gb, n_max, e_max), dev) for gb in host_batches]
         graph_step = graphed.GraphedTrainStep(model, opt, cfg, padded[0], grad_sync=grad_sync)
 
+    if args.mode == "refloop":
+        if w.get("regression") or world > 1:
+            raise SystemExit("--mode refloop reproduces benchmarks/train_hiv.py's loop body: BCE workloads, one rank")
+        import torch.nn.functional as F
+        from phc.hypercomplex.regularization import phm_weight_regularization
+        opt = torch.optim.Adam(model.parameters(), weight_decay=0.0)             # train_hiv.py:285
+        kwargs = {"weight_decay": args.weight_decay, "lr": 1e-3, "p": 2, "grad_clipping": 0.0 if args.fwd_bwd_only else 2.0}
+        ref_state = {"total_loss": 0.0}
+
+    def ref_loop_body(data):
+        """benchmarks/train_hiv.py:174-202, statement for statement (``data`` already on the device)."""
+        mask = ~torch.isnan(data.y)
+        opt.zero_grad()
+        logits = model(data)
+        y = data.y.to(torch.float)
+        loss = F.binary_cross_entropy_with_logits(input=logits[mask], target=y[mask])
+        reg_loss = torch.tensor(0.0, device=dev)
+        if kwargs["weight_decay"] > 0.0:
+            reg_loss += kwargs["lr"] * kwargs["weight_decay"] * phm_weight_regularization(model, device=dev, p=kwargs["p"])
+        loss += reg_loss.squeeze()
+        loss.backward()
+        if kwargs["grad_clipping"] > 0.0:
+            torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm=kwargs["grad_clipping"], norm_type=2)
+        if not args.fwd_bwd_only:
+            opt.step()
+        ref_state["total_loss"] += loss.item() * data.num_graphs
+
     def run(n, offset=0, eager=False):
         for i in range(n):
             j = (offset + i) % len(host_batches)
+            if args.mode == "refloop":
+                ref_loop_body(batches[j])
+                continue
             if graph_step is not None and not eager:
                 # D2D copy into the static buffers + one graph launch (PHC_GRAPH_PIPELINE=1: the batch's preprocessing graph
                 # was queued on a second stream by the previous call; this call launches the step graph and queues the next)
@@ -581,7 +615,10 @@ def main():
                               f"({n_max} nodes, {e_max} edges); per-step D2D batch copy + CSR/CSC build "
                               + ("replayed one batch ahead on a second stream" if graph_step.pipeline else "inside the step graph"))
                              if graph_step is not None
-                             else "eager (one launch per kernel)",
+                             else ("the reference's own loop body (benchmarks/train_hiv.py:174-202 verbatim: boolean-mask BCE, "
+                                   "phm_weight_regularization, loss.backward(), clip_grad_norm_, torch.optim.Adam, loss.item() "
+                                   "every step) on the mirror model" if args.mode == "refloop"
+                                   else "eager (harness.train_step: one launch per kernel from Python)"),
                    "graph_packet_capture": (os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") == "1")
                                            + 0 if graph_step is not None else None,
                    "static_input_sets": len(graph_step.sets) if graph_step is not None else None,

@@ -36,7 +36,7 @@
 extern "C" {
 #endif
 
-#define PHC_ABI_VERSION 7
+#define PHC_ABI_VERSION 8
 
 #define PHC_OK 0
 #define PHC_ERR_INVALID_ARG (-1)   /* null pointer, negative size, bad enum        */
@@ -1026,6 +1026,20 @@ int phc_clip_adam_step(const uint64_t *table_dev, const float *const *grads, int
                        int num_chunks, int chunk_base, int total_chunks, int phases, float max_norm, float lr, float beta1,
                        float beta2, float eps, float *step_dev, float *scal_dev, float *partial_dev,
                        int write_back_clipped, void *stream);
+
+/* The same pair as ONE launch (ABI 8): the sums of squares travel between the workgroups inside the launch (tagged write-through
+ * granules, as the fused prediction head's batch statistics do), so the launch needs every chunk's workgroup co-resident:
+ * phc_clip_adam_fused_supported() answers for the current device (1 = the model's chunk count fits; a CU mask in the environment
+ * disqualifies), PHC_ERR_UNSUPPORTED otherwise — callers then use phc_clip_adam_step.  `ws`: phc_clip_adam_fused_ws_bytes(total_chunks)
+ * bytes, 8-byte aligned, ZERO before the first use and owned by this optimizer (it holds the launch generation).  Results are
+ * bit-identical to phc_clip_adam_step(phases = 5): same per-chunk reduction tree, same order of the chunk sums.  A rendezvous that
+ * never completes raises PHC_ERR_RENDEZVOUS in the device error word and leaves NaN parameters, never a hang.
+ * Replaces in the step: clip_grad_norm_ + Adam.step() (benchmarks/train_hiv.py:198-201). */
+size_t phc_clip_adam_fused_ws_bytes(int total_chunks);
+int phc_clip_adam_fused_supported(int num_tensors, int total_chunks);
+int phc_clip_adam_fused(const uint64_t *table_dev, const float *const *grads, int num_tensors, const int32_t *chunks_dev, int total_chunks,
+                        float max_norm, float lr, float beta1, float beta2, float eps, float *step_dev, float *scal_dev, void *ws,
+                        size_t ws_bytes, int write_back_clipped, void *stream);
 
 /* Data-parallel gradient bucket (ABI 4): every gradient tensor of the model -> ONE flat fp32 buffer in ONE launch, scaled by
  * `scale` (1 / world: the mean of the replicas' gradients folded in in front of the SUM all-reduce).  Tables as phc_clip_adam_step

@@ -7,6 +7,8 @@
 // (3) the Adam update with the clip coefficient applied on the fly.  Same arithmetic as torch's fused Adam:
 //   m = m + (g - m)(1 - b1);  v = b2 v + (1 - b2) g g;  p -= lr / (1 - b1^t) * m / (sqrt(v) / sqrt(1 - b2^t) + eps)
 // with g = clip_coef * grad, clip_coef = min(1, max_norm / (||grads||_2 + 1e-6)).
+#include <stdlib.h>
+
 #include "phc_common.h"
 
 namespace phc {
@@ -118,6 +120,117 @@ __global__ __launch_bounds__(256) void opt_adam_kernel(OptGrads grads, const uns
         const long long e = min((long long)off + threadIdx.x + 256 * q, end - 1);
         g_[q] = g[e]; m_[q] = m[e]; v_[q] = v[e]; p_[q] = p[e];
     }
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const long long e = (long long)off + threadIdx.x + 256 * q;
+        if (e < end) {
+            const float gv = g_[q] * coef;
+            float mv = m_[q], vv = v_[q];
+            mv = mv + (gv - mv) * (1.f - beta1);             // lerp, as torch's fused kernel
+            vv = beta2 * vv + (1.f - beta2) * gv * gv;
+            const float denom = sqrtf(vv) / bc2_sqrt + eps;
+            p[e] = p_[q] - step_size * (mv / denom);
+            m[e] = mv;
+            v[e] = vv;
+            if (write_back) const_cast<float *>(g)[e] = gv;  // clip_grad_norm_ scales the gradients in place
+        }
+    }
+}
+
+
+// ---- clip + Adam in ONE launch (round 6) ------------------------------------------------------------------------------
+// The two launches above are one dependent pair: every workgroup of the update needs ALL per-chunk sums of squares.  Inside
+// a replayed step the pair costs ~20 us for ~3 us of work (scripts/dbg/r06_ablate.sh), so the hand-over moves inside the
+// launch: a workgroup loads its chunk (gradient, both moments, parameter: all four round trips in flight together), reduces
+// its sum of squares with the SAME fixed tree as opt_sumsq_kernel, publishes it as a {value, tag} granule (write-through
+// store, csrc/downstream.hip) and collects every chunk's granule, repeating the loads until each tag equals this launch's.
+// The total norm is then summed in the same fixed order as opt_adam_kernel sums `partial` — the update is bit-identical to
+// the two launches'.  All workgroups must be co-resident (they wait for each other): the host launches this form only when
+// the chunk count fits the device's real capacity for this kernel, and the poll loop is bounded (OPT_SPIN_MAX ->
+// PHC_ERR_RENDEZVOUS in the device error word, a NaN coefficient) so that an unforeseen stall ends the launch.
+// The per-tensor step counter is read by every workgroup BEFORE it publishes (so before anybody can be past the collect) and
+// written back by the tensor's first chunk AFTER the collect: no workgroup can see the incremented value.
+constexpr int OPT_SPIN_MAX = 1 << 21;
+
+__global__ __launch_bounds__(256) void opt_clip_adam_fused_kernel(OptGrads grads, const unsigned long long *__restrict__ table,
+                                                                const int *__restrict__ chunks, float *__restrict__ scal,
+                                                                float *__restrict__ steps, unsigned long long *__restrict__ gran,
+                                                                unsigned *__restrict__ gen, int *__restrict__ err, int total_chunks,
+                                                                float max_norm, float lr, float beta1, float beta2, float eps,
+                                                                int write_back) {
+    __shared__ float red[256];
+    __shared__ float s_coef;
+    const unsigned tag = __hip_atomic_load(gen, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    const int t = chunks[2 * blockIdx.x], off = chunks[2 * blockIdx.x + 1];
+    const float *g = grads.g[t];
+    float *p = reinterpret_cast<float *>(table[4 * t]);
+    float *m = reinterpret_cast<float *>(table[4 * t + 1]);
+    float *v = reinterpret_cast<float *>(table[4 * t + 2]);
+    const long long numel = (long long)table[4 * t + 3];
+    const float tstep = steps[t] + (g ? 1.f : 0.f);           // (in flight in front of the chunk's loads: it has landed before the publish)
+    const long long end = min((long long)off + OPT_CHUNK, numel);
+    constexpr int PER = OPT_CHUNK / 256;
+    float g_[PER], m_[PER], v_[PER], p_[PER];
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {                          // all 4 * PER loads in flight together (clamped addresses)
+        const long long e = min((long long)off + threadIdx.x + 256 * q, end - 1);
+        g_[q] = g ? g[e] : 0.f;
+        m_[q] = m[e]; v_[q] = v[e]; p_[q] = p[e];
+    }
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const float gv = (long long)off + threadIdx.x + 256 * q < end ? g_[q] : 0.f;
+        s = fmaf(gv, gv, s);
+    }
+    red[threadIdx.x] = s;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {                  // fixed tree (opt_sumsq_kernel's)
+        if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        __hip_atomic_store(gran + blockIdx.x, ((unsigned long long)tag << 32) | (unsigned long long)__float_as_uint(red[0]),
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __syncthreads();                                         // (red[] is reused below)
+    // ---- collect: chunk c by thread c % 256, in opt_adam_kernel's order ----
+    float sacc = 0.f;
+    bool dead = false;
+    for (int c = threadIdx.x; c < total_chunks; c += 256) {
+        unsigned long long q;
+        int spins = 0;
+        do {
+            q = __hip_atomic_load(gran + c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if ((unsigned)(q >> 32) == tag) break;
+            __builtin_amdgcn_s_sleep(1);
+        } while (++spins <= OPT_SPIN_MAX);
+        if ((unsigned)(q >> 32) != tag) dead = true;
+        sacc += __uint_as_float((unsigned)q);
+    }
+    if (dead) {
+        if (err) atomicOr(err, PHC_ERR_RENDEZVOUS);
+        sacc = __int_as_float(0x7fc00000);                   // a timed-out exchange must not look like a result
+    }
+    red[threadIdx.x] = sacc;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if (threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float norm = sqrtf(red[0]);
+        s_coef = max_norm > 0.f ? fminf(1.f, max_norm / (norm + 1e-6f)) : 1.f;
+        if (blockIdx.x == 0) {
+            if (scal) { scal[0] = norm; scal[1] = s_coef; }
+            // (every other workgroup has published, i.e. has read the generation word: the bump cannot reach one of this launch)
+            __hip_atomic_fetch_add(gen, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        if (g && off == 0) steps[t] = tstep;                 // torch.optim.Adam counts steps per parameter tensor
+    }
+    __syncthreads();
+    if (!g) return;                                          // parameter without a gradient this step: untouched
+    const float coef = s_coef, bc1 = 1.f - powf(beta1, tstep), bc2_sqrt = sqrtf(1.f - powf(beta2, tstep));
+    const float step_size = lr / bc1;
 #pragma unroll
     for (int q = 0; q < PER; ++q) {
         const long long e = (long long)off + threadIdx.x + 256 * q;
@@ -277,6 +390,55 @@ int phc_clip_adam_step(const uint64_t *table_dev, const float *const *grads, int
                    chunks_dev, chunk_base == 0 ? scal_dev : nullptr, step_dev, partial_dev, total_chunks, max_norm, lr, beta1, beta2,
                    eps, write_back_clipped);
     return check_launch("clip_adam_step");
+}
+
+// resident capacity of the one-launch form on the current device (its workgroups wait for each other)
+static int opt_fused_capacity() {
+    static int cap[64];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (cap[dev] == 0) {
+        int per_cu = 0;
+        hipDeviceProp_t prop;
+        if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, opt_clip_adam_fused_kernel, 256, 0) != hipSuccess ||
+            hipGetDeviceProperties(&prop, dev) != hipSuccess || getenv("HSA_CU_MASK") || getenv("ROC_GLOBAL_CU_MASK"))
+            cap[dev] = -1;
+        else
+            // (a margin: MI355X_MICROARCH.md, the occupancy API can be one block per CU high; two per CU is all this launch asks for)
+            cap[dev] = (per_cu > 2 ? 2 : (per_cu > 1 ? per_cu - 1 : 0)) * prop.multiProcessorCount;
+        if (cap[dev] == 0) cap[dev] = -1;
+    }
+    return cap[dev] > 0 ? cap[dev] : 0;
+}
+
+size_t phc_clip_adam_fused_ws_bytes(int total_chunks) {
+    return total_chunks < 1 ? 0 : sizeof(unsigned long long) * (size_t)total_chunks + 16;
+}
+
+int phc_clip_adam_fused_supported(int num_tensors, int total_chunks) {
+    return num_tensors >= 1 && num_tensors <= OPT_MAX_TENSORS && total_chunks >= 1 && total_chunks <= opt_fused_capacity();
+}
+
+int phc_clip_adam_fused(const uint64_t *table_dev, const float *const *grads, int num_tensors, const int32_t *chunks_dev, int total_chunks,
+                        float max_norm, float lr, float beta1, float beta2, float eps, float *step_dev, float *scal_dev, void *ws,
+                        size_t ws_bytes, int write_back_clipped, void *stream) {
+    PHC_REQUIRE(phc_clip_adam_fused_supported(num_tensors, total_chunks), PHC_ERR_UNSUPPORTED,
+                "phc_clip_adam_fused: %d tensors / %d chunks do not fit one co-resident launch (capacity %d chunks)", num_tensors,
+                total_chunks, opt_fused_capacity());
+    PHC_REQUIRE(table_dev && grads && chunks_dev && step_dev && scal_dev, PHC_ERR_INVALID_ARG, "phc_clip_adam_fused: null pointer");
+    PHC_REQUIRE(ws && ws_bytes >= phc_clip_adam_fused_ws_bytes(total_chunks) && (reinterpret_cast<uintptr_t>(ws) & 7) == 0, PHC_ERR_WORKSPACE,
+                "phc_clip_adam_fused: workspace missing (phc_clip_adam_fused_ws_bytes, zero before the first use)");
+    PHC_REQUIRE(lr > 0.f && beta1 >= 0.f && beta1 < 1.f && beta2 >= 0.f && beta2 < 1.f && eps > 0.f, PHC_ERR_INVALID_ARG,
+                "phc_clip_adam_fused: bad hyper-parameters");
+    hipStream_t s = (hipStream_t)stream;
+    OptGrads g;
+    for (int t = 0; t < OPT_MAX_TENSORS; ++t) g.g[t] = t < num_tensors ? grads[t] : nullptr;
+    unsigned long long *gran = static_cast<unsigned long long *>(ws);
+    unsigned *gen = reinterpret_cast<unsigned *>(gran + total_chunks);
+    ProfScope prof(K_CLIP_ADAM, s);
+    PHC_LAUNCH(opt_clip_adam_fused_kernel, dim3(total_chunks), dim3(256), 0, s, g, reinterpret_cast<const unsigned long long *>(table_dev),
+               chunks_dev, scal_dev, step_dev, gran, gen, err_word(), total_chunks, max_norm, lr, beta1, beta2, eps, write_back_clipped);
+    return check_launch("clip_adam_fused");
 }
 
 int phc_pack_grads(const uint64_t *table_dev, const float *const *grads, int num_tensors, const int32_t *chunks_dev, int num_chunks,

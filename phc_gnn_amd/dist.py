@@ -573,17 +573,36 @@ class EdgeGradSink:
     48 ms of element-wise adds and 3 x 5 ms of edge-gradient writes in a 255 ms four-layer step."""
 
     def __init__(self, n_layers: int):
-        self.remaining = int(n_layers)
+        self.n_layers = int(n_layers)
+        self.joined = 0              # layers of this forward that hand their edge gradient to the sink
+        self.adds = 0                # ... of which this many have run their backward since the last flush
         self.total = None
 
-    def add(self, dagg: torch.Tensor) -> bool:
-        """True when this was the last layer: ``self.total`` is complete."""
+    def join(self) -> bool:
+        """Called from a layer's forward.  True for the FIRST layer (forward order) that joins: it is the flusher.  Every layer's
+        backward needs the gradient of its own output, which comes out of the backward of the layer behind it, so the first
+        participant of the forward is the last one to run in ANY backward through the stack — a full one, a second one over a retained
+        graph, or one rooted at an intermediate layer's output (then the sum holds the layers in front of that root, which is that
+        root's edge gradient).  A count of expected calls would be wrong in the last two cases."""
+        self.joined += 1
+        return self.joined == 1
+
+    def add(self, dagg: torch.Tensor, flush: bool) -> bool:
+        """``flush``: this is the flusher's backward — ``self.total`` is complete; the caller gathers from it and calls ``take``."""
+        if self.adds >= self.joined:
+            raise RuntimeError("EdgeGradSink: more layer backwards than participating layers since the last flush "
+                               "(a backward pass through the stack was abandoned half-way?)")
         if self.total is None:
-            self.total = dagg                                   # (a temporary of the calling backward: nobody else writes it)
+            self.total = dagg                                   # (a fresh temporary of the calling backward: nobody else writes it)
         else:
             self.total.add_(dagg)
-        self.remaining -= 1
-        return self.remaining == 0
+        self.adds += 1
+        return flush
+
+    def take(self) -> torch.Tensor:
+        """The finished sum; the sink is empty again (the next backward over a retained graph starts from nothing)."""
+        t, self.total, self.adds = self.total, None, 0
+        return t
 
 
 class _ShardedGINEFn(torch.autograd.Function):
@@ -640,8 +659,8 @@ class _ShardedGINEFn(torch.autograd.Function):
         # (grad mode is off inside Function.forward: the stack made the sink only where gradients are wanted)
         ctx.dea_sink = sink if (sink is not None and act_msg == "identity"
                                 and ((ea_loc is not None and ctx.needs_input_grad[3]) or (ea_halo is not None and ctx.needs_input_grad[4]))) else None
-        if sink is not None and ctx.dea_sink is None:
-            sink.remaining -= 1                                 # (this layer returns its own edge gradients, if any)
+        # (a layer that does not join returns its own edge gradients, if any)
+        ctx.sink_flush = ctx.dea_sink.join() if ctx.dea_sink is not None else False
         ctx.link = link if (link is not None and fused) else None
         ctx.res_link = link if (link is not None and link.take_res and ctx.needs_input_grad[2]) else None
         if link is not None:
@@ -713,15 +732,16 @@ class _ShardedGINEFn(torch.autograd.Function):
             share, ctx.res_link.res_share = ctx.res_link.res_share, None     # the skip's share of d x_own, parked by the norm behind this conv
         d_own, dea_loc, dea_halo, (g1, g2) = agg.backward_raw(ds, x_own, recv, ea_loc, ea_halo, act_msg,
                                                               layer.conv.add_self_loops, need_dea, overlap=param_grads, extra=share)
-        if sink is not None and sink.add(ds):
+        if sink is not None and sink.add(ds, ctx.sink_flush):
             # the last layer of the stack to run: d ea[e] = (sum of the layers' aggregate gradients)[dst(e)], one gather per edge set
+            total = sink.take()
             if want_dea[0]:
-                dea_loc = be.gather_rows(sink.total, plan.loc_edge_index[1])
+                dea_loc = be.gather_rows(total, plan.loc_edge_index[1])
             if want_dea[1] and plan.halo_edge_index.shape[1] > 0:
-                dea_halo = be.gather_rows(sink.total, plan.halo_edge_index[1])
+                dea_halo = be.gather_rows(total, plan.halo_edge_index[1])
             elif want_dea[1]:
                 dea_halo = ds.new_zeros((0, ds.shape[1]))
-            sink.total = None
+            del total
         aff = []
         if ctx.n_affine:
             n = ctx.n_affine // 2

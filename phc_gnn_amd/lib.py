@@ -15,7 +15,7 @@ import torch
 _PKG_DIR = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_PKG_DIR, "libphc_hip.so")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 ACT_IDS = {"identity": 0, "relu": 1, "lrelu": 2, "elu": 3, "swish": 4, "selu": 5}
 
 
@@ -269,6 +269,9 @@ SIGNATURES = {
     "phc_clip_adam_chunk": (_I, []),
     "phc_clip_adam_step": (_I, [_P, _P, _I, _P, _I, _I, _I, _I, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P, _P,
                                 _I, _P]),
+    "phc_clip_adam_fused_ws_bytes": (C.c_size_t, [_I]),
+    "phc_clip_adam_fused_supported": (_I, [_I, _I]),
+    "phc_clip_adam_fused": (_I, [_P, _P, _I, _P, _I, C.c_float, C.c_float, C.c_float, C.c_float, C.c_float, _P, _P, _P, C.c_size_t, _I, _P]),
     "phc_prof_enable": (_I, [_I]),
     "phc_prof_reset": (_I, []),
     "phc_prof_num_kernels": (_I, []),

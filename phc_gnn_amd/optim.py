@@ -15,6 +15,10 @@ import torch
 from . import lib as L
 
 
+# clip + Adam as ONE launch whose workgroups exchange the sums of squares inside it (csrc/optim.hip, round 6); 0 = the two launches
+FUSED_STEP = __import__("os").environ.get("PHC_CLIP_ADAM_FUSED", "1") != "0"
+
+
 class ClipAdam:
     """Drop-in for the (clip_grad_norm_, Adam) pair of the training loop.  API: ``zero_grad(set_to_none=True)``,
     ``step(max_norm=None)`` (returns the device scalar of the total gradient norm), ``state_dict`` /
@@ -59,6 +63,10 @@ class ClipAdam:
             chunk_base += len(chunks)
         self.total_chunks = chunk_base
         self.partial = torch.empty(self.total_chunks, dtype=torch.float32, device=dev)
+        # the one-launch form (phc_clip_adam_fused): one parameter group whose chunks fit a co-resident launch
+        self._fused_ws = None
+        if FUSED_STEP and len(self.groups) == 1 and lib.phc_clip_adam_fused_supported(len(self.params), self.total_chunks):
+            self._fused_ws = torch.zeros(lib.phc_clip_adam_fused_ws_bytes(self.total_chunks), dtype=torch.uint8, device=dev)
         self._ptrs = [p.data_ptr() for p in self.params]
 
     # -- torch.optim-like surface ------------------------------------------------------------------
@@ -108,7 +116,13 @@ class ClipAdam:
                                            self.betas[1], self.eps, L.ptr(grp["steps"]), L.ptr(self.scalars),
                                            L.ptr(self.partial), 1 if self.write_back_clipped else 0, stream),
                     "phc_clip_adam_step")
-        if single:
+        if single and self._fused_ws is not None:
+            grp, arr = calls[0]
+            L.check(lib.phc_clip_adam_fused(L.ptr(grp["table"]), arr, len(grp["idx"]), L.ptr(grp["chunks"]), self.total_chunks, mn, self.lr,
+                                            self.betas[0], self.betas[1], self.eps, L.ptr(grp["steps"]), L.ptr(self.scalars),
+                                            L.ptr(self._fused_ws), self._fused_ws.numel(), 1 if self.write_back_clipped else 0, stream),
+                    "phc_clip_adam_fused")
+        elif single:
             call(calls[0][0], calls[0][1], 5)               # sums of squares, then the update (which derives the norm itself)
         else:
             for grp, arr in calls:

@@ -574,3 +574,46 @@ def test_exchange_self_check_catches_a_corrupted_row_on_every_rank(tmp_path):
     msgs = [open(os.path.join(tmp_path, f"c{r}.txt")).read() for r in range(world)]
     assert all("halo exchange self check failed" in m for m in msgs), msgs
     assert "rank 1 received 1 wrong rows" in msgs[1] and "rank 0 received 0 wrong rows" in msgs[0], msgs
+
+
+def _worker_stack_reentrant(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        N, E, n, h, ei, x, ea, dy = _stack_problem(world, "uniform")
+        convs, norms = _make_stack(n, h, seed=31)
+        plan = build_halo_plan(ei, N)
+        stack = ShardedGINEStack(convs, norms, plan, N, activation="relu", backend=OracleBackend()).train()
+        x_own = x[plan.lo:plan.hi].clone().requires_grad_()
+        ea_loc, ea_halo = stack.agg.split_edge_attr(ea)
+        ea_loc = ea_loc.clone().requires_grad_()
+        ea_halo = ea_halo.clone().requires_grad_()
+        y = stack(x_own, ea_loc, ea_halo)
+        dyo = dy[plan.lo:plan.hi]
+        # (1) the edge gradient ALONE (autograd.grad, graph retained), (2) a full backward over the retained graph, (3) a second
+        # full backward: .grad accumulates — every one of them must see the whole edge gradient
+        only = torch.autograd.grad(y, [ea_loc, ea_halo], dyo, retain_graph=True, allow_unused=True)
+        y.backward(dyo, retain_graph=True)
+        first = [t.grad.clone() if t.grad is not None else None for t in (ea_loc, ea_halo, x_own)]
+        y.backward(dyo)
+        second = [t.grad.clone() if t.grad is not None else None for t in (ea_loc, ea_halo, x_own)]
+        torch.save(dict(only=only, first=first, second=second), os.path.join(tmp, f"re{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+def test_edge_grad_sink_is_reentrant(tmp_path):
+    """ADVICE r5 (dist.EdgeGradSink): a second backward over a retained graph, and a backward that asks for the edge gradient alone,
+    get the same edge-attribute gradient as the first full backward (the sink used to count down once and then return nothing)."""
+    world = 2
+    mp.spawn(_worker_stack_reentrant, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    for r in range(world):
+        d = torch.load(os.path.join(tmp_path, f"re{r}.pt"))
+        for i in range(2):                                   # local / halo edge sets
+            if d["first"][i] is None:
+                assert d["only"][i] is None and d["second"][i] is None
+                continue
+            assert float(d["first"][i].abs().max()) > 0
+            torch.testing.assert_close(d["only"][i], d["first"][i], rtol=1e-6, atol=1e-6)
+            torch.testing.assert_close(d["second"][i], 2 * d["first"][i], rtol=1e-6, atol=1e-6)
+        torch.testing.assert_close(d["second"][2], 2 * d["first"][2], rtol=1e-6, atol=1e-6)

@@ -28,7 +28,7 @@ def test_library_exports_every_declared_symbol():
     for name in declared:
         assert hasattr(handle, name), f"libphc_hip.so does not export {name}"
         assert name in lib.SIGNATURES, f"{name} has no ctypes signature"
-    assert handle.phc_version() == lib.ABI_VERSION == 7
+    assert handle.phc_version() == lib.ABI_VERSION == 8
     assert handle.phc_error_string(-3).decode().startswith("workspace")
 
 
