@@ -845,10 +845,21 @@ typedef struct phc_downstream_desc {
     int32_t drop_same_k1, drop_same_k2, drop_site1, drop_site2;
     const uint64_t *rng_state;
     float *a1, *a2;
+    /* ABI 8 (16-row kernels, forward only; loss_y NULL: off): the training loss of the logits inside the forward launch —
+     * mean over the entries whose label is not NaN of BCE-with-logits (loss_kind 0: benchmarks/train_hiv.py:174-178,
+     * mask = ~isnan(y); criterion(logits[mask], y[mask])) or of |logit - y| (loss_kind 1: train_zinc.py's L1Loss) — as
+     * phc_bce_masked_fwd_unit / phc_l1_masked_fwd_unit compute it in a launch of their own: loss_out [3] = loss | sum | labeled
+     * count, loss_dlogits [B, T] = d loss / d logits for an upstream gradient of 1.  loss_y [B, T]; B T <= 4096
+     * (phc_downstream_loss_supported); loss_granules: B T 8-byte words, ZERO before the first use, owned like `partial`. */
+    const float *loss_y;
+    int32_t loss_kind;
+    float *loss_out, *loss_dlogits;
+    uint64_t *loss_granules;
 } phc_downstream_desc;
 int phc_downstream_supported(int64_t B, int d0, int d1, int d2, int d3, int T);
 int phc_downstream_supported_k4(int64_t B, int d0, int d1, int d2, int d3, int T);
 int phc_downstream_dropout_supported(int64_t B, int d0, int d1, int d2, int d3, int T);   /* ABI 7: the drop_* fields are served */
+int phc_downstream_loss_supported(int64_t B, int d0, int d1, int d2, int d3, int T);      /* ABI 8: the loss_* fields are served */
 size_t phc_downstream_partial_floats(int64_t B);
 int phc_downstream_fwd(const phc_downstream_desc *desc, void *stream);
 int phc_downstream_bwd(const phc_downstream_desc *desc, void *stream);

@@ -70,6 +70,13 @@ struct DnArgs {
     unsigned long long *partial;                              // [2][G][DN_PSTRIDE] {value, tag} granules
     unsigned *sync;                                           // generation word
     int *err;                                                 // device error word (phc_set_error_word) or NULL
+    // v2 forward only (round 6): the NaN-masked mean loss of the logits inside the launch — every workgroup also publishes its
+    // logits as {value, tag} granules, workgroup 0 collects them at its end, writes loss | sum | count and d loss / d logits for
+    // an upstream gradient of 1 (what bce_masked_fwd_unit_kernel did in a launch of its own: 16 us inside a replayed step)
+    const float *loss_y;                                      // [B, T] labels, NaN = unlabeled; NULL: off
+    unsigned long long *loss_gran;                            // [B T] granules
+    float *loss_out, *loss_dz;                                // [3], [B, T]
+    int loss_kind;                                            // 0 BCE with logits, 1 L1
 };
 
 // A rendezvous that never completes (a producer workgroup that is not resident: CU mask, another stream owning the CUs, a
@@ -77,6 +84,7 @@ struct DnArgs {
 // rounds, raises PHC_ERR_RENDEZVOUS in the device error word and lets the launch run to its end (its outputs are then
 // garbage; the host raises at its next check point).  2^21 rounds of >= 1 us each: seconds, never reached by a live exchange.
 constexpr int DN_SPIN_MAX = 1 << 21;
+constexpr int DN_LOSS_MAX = 4096;                            // logits whose loss the forward launch can take (DnArgs.loss_y)
 
 #ifdef PHC_DN_TIMING
 // experiment build only: workgroup 0 / G-1 stamp the phases of the forward launch (100 MHz wall clock)
@@ -1040,6 +1048,79 @@ __host__ __device__ inline D2Lds d2_lds(int RB, int d0, int d1, int d2, int d3, 
     return l;
 }
 
+// The loss at the end of workgroup 0 (DnArgs.loss_y): entry e by thread e % 512; per-thread sums in entry order, the 64 lanes
+// of a wavefront by a fixed butterfly, the 8 wavefronts in order — one fixed summation tree whatever the grid.
+__device__ __forceinline__ float d2_bce_entry(float z, float y) { return fmaxf(z, 0.f) - z * y + log1pf(expf(-fabsf(z))); }
+template <int KIND>
+__device__ __forceinline__ void d2_loss_tail(const DnArgs &a, unsigned tag, float *scratch) {
+    const int tid = threadIdx.x, total = a.B * a.T;
+    constexpr int PER = 8;                                    // total <= 4096 = 8 x 512 (host-checked)
+    float zv[PER], yv[PER];
+    bool dead = false;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int e = tid + D2_THREADS * q;
+        zv[q] = 0.f;
+        yv[q] = __int_as_float(0x7fc00000);
+        if (e < total) {
+            unsigned long long w;
+            int spins = 0;
+            do {
+                w = get_granule(a.loss_gran + e);
+                if ((unsigned)(w >> 32) == tag) break;
+                __builtin_amdgcn_s_sleep(1);
+            } while (++spins <= DN_SPIN_MAX);
+            dead = dead || (unsigned)(w >> 32) != tag;
+            zv[q] = __uint_as_float((unsigned)w);
+            yv[q] = a.loss_y[e];
+        }
+    }
+    float s = 0.f, c = 0.f;
+#pragma unroll
+    for (int q = 0; q < PER; ++q)
+        if (yv[q] == yv[q]) {                                 // labeled (not NaN)
+            s += KIND == 0 ? d2_bce_entry(zv[q], yv[q]) : fabsf(zv[q] - yv[q]);
+            c += 1.f;
+        }
+    if (dead) {
+        if (a.err) atomicOr(a.err, PHC_ERR_RENDEZVOUS);
+        s = __int_as_float(0x7fc00000);
+    }
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+        s += __shfl_xor(s, off, 64);
+        c += __shfl_xor(c, off, 64);
+    }
+    d2_lds_barrier();                                         // (scratch: whoever used it last is done)
+    if ((tid & 63) == 0) { scratch[tid >> 6] = s; scratch[8 + (tid >> 6)] = c; }
+    d2_lds_barrier();
+    s = c = 0.f;
+#pragma unroll
+    for (int w = 0; w < D2_WAVES; ++w) { s += scratch[w]; c += scratch[8 + w]; }
+    if (tid == 0) {
+        a.loss_out[0] = s / c;                                // no labeled entry: NaN, like the mean of an empty selection
+        a.loss_out[1] = s;
+        a.loss_out[2] = c;
+    }
+    const float scale = 1.f / c;
+#pragma unroll
+    for (int q = 0; q < PER; ++q) {
+        const int e = tid + D2_THREADS * q;
+        if (e < total) {
+            float gq = 0.f;
+            if (yv[q] == yv[q]) {
+                if (KIND == 0) {
+                    gq = (1.f / (1.f + expf(-zv[q])) - yv[q]) * scale;
+                } else {
+                    const float d = zv[q] - yv[q];
+                    gq = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * scale;      // torch's sign(0) = 0
+                }
+            }
+            a.loss_dz[e] = gq;
+        }
+    }
+}
+
 template <int RB>
 __global__ __launch_bounds__(D2_THREADS) void downstream2_fwd_kernel(DnArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
@@ -1146,12 +1227,22 @@ __global__ __launch_bounds__(D2_THREADS) void downstream2_fwd_kernel(DnArgs a) {
         const int row = e / T, t = e - row * T;
         float v = wr[T * d3 + t];
         for (int j = 0; j < d3; ++j) v = fmaf(z3s[row * d3 + j], wr[t * d3 + j], v);
-        if (rb + row < a.B) a.logits[(size_t)(rb + row) * T + t] = v;
+        if (rb + row < a.B) {
+            a.logits[(size_t)(rb + row) * T + t] = v;
+            if (a.loss_y) put_granule(a.loss_gran + (size_t)(rb + row) * T + t, v, tag);
+        }
     }
     DN_STAMP(11);
     if (g == 0) {                                                // what the norms leave behind, off every other workgroup's path
         d2_write_norm_state(a.bn1, k1, a.stat1, d1);
         d2_write_norm_state(a.bn2, k2, a.stat2, d2);
+        if (a.loss_y) {
+            if (a.loss_kind == 0)
+                d2_loss_tail<0>(a, tag, red);
+            else
+                d2_loss_tail<1>(a, tag, red);
+        }
+        // (the bump comes behind the collect: every workgroup has published its logits, i.e. has read the generation word)
         if (tid == 0) __hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
 }
@@ -1600,6 +1691,12 @@ int phc_downstream_dropout_supported(int64_t B, int d0, int d1, int d2, int d3, 
     return (d1 % 4 == 0 && d2 % 4 == 0 && dn2_shape_ok(Bc, d0, d1, d2, d3, T) && dn2_device_ok(Bc, d0, d1, d2, d3, T)) ? 1 : 0;
 }
 
+/* ABI 8: phc_downstream_desc.loss_* are served (the 16-row kernels' range and at most 4096 logits) */
+int phc_downstream_loss_supported(int64_t B, int d0, int d1, int d2, int d3, int T) {
+    const int Bc = (int)(B > (1LL << 20) ? 1 << 20 : B);
+    return ((long long)B * T <= DN_LOSS_MAX && dn2_shape_ok(Bc, d0, d1, d2, d3, T) && dn2_device_ok(Bc, d0, d1, d2, d3, T)) ? 1 : 0;
+}
+
 size_t phc_downstream_partial_floats(int64_t B) {
     if (B < 1) return 0;
     const size_t v1 = 2 * 2 * (size_t)((B + DN_ROWS - 1) / DN_ROWS) * DN_PSTRIDE;      // 8-byte {value, tag} granules
@@ -1618,6 +1715,15 @@ int phc_downstream_fwd(const phc_downstream_desc *d, void *stream) {
     if (rc) return rc;
     a.x = d->x; a.H1 = d->H1; a.b1 = d->b1; a.H2 = d->H2; a.b2 = d->b2; a.H3 = d->H3; a.b3 = d->b3; a.logits = d->logits;
     PHC_REQUIRE(a.x && a.H1 && a.H2 && a.H3 && a.logits, PHC_ERR_INVALID_ARG, "phc_downstream_fwd: null pointer");
+    if (d->loss_y) {
+        PHC_REQUIRE(v2 && (long long)d->B * d->T <= DN_LOSS_MAX, PHC_ERR_UNSUPPORTED,
+                    "phc_downstream_fwd: the loss inside the launch needs the 16-row kernels and B T <= %d (phc_downstream_loss_supported)", DN_LOSS_MAX);
+        PHC_REQUIRE(d->loss_out && d->loss_dlogits && d->loss_granules && (d->loss_kind == 0 || d->loss_kind == 1) &&
+                        (reinterpret_cast<uintptr_t>(d->loss_granules) & 7) == 0,
+                    PHC_ERR_INVALID_ARG, "phc_downstream_fwd: loss_out / loss_dlogits / loss_granules / loss_kind");
+        a.loss_y = d->loss_y; a.loss_out = d->loss_out; a.loss_dz = d->loss_dlogits; a.loss_kind = d->loss_kind;
+        a.loss_gran = reinterpret_cast<unsigned long long *>(d->loss_granules);
+    }
     PHC_REQUIRE(((reinterpret_cast<uintptr_t>(a.x) | reinterpret_cast<uintptr_t>(a.H1) | reinterpret_cast<uintptr_t>(a.H2) |
                   reinterpret_cast<uintptr_t>(a.z1) | reinterpret_cast<uintptr_t>(a.z2)) & 15) == 0,
                 PHC_ERR_UNSUPPORTED, "phc_downstream_fwd: 16-byte aligned rows required");

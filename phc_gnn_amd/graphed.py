@@ -30,7 +30,7 @@ import torch
 from . import synth
 from .graph import cached_structures_of, clear_structure_cache
 from .harness import StepConfig, advance_dropout_rng, apply_weight_regulariser, loss_fn, optimizer_step, park_weight_regulariser
-from .ops import atom_encode_spec, deferred_param_grads, dense_weights, gate_specs, phm_pairs, prebuilt_H, stat_accumulators
+from .ops import atom_encode_spec, deferred_param_grads, dense_weights, expect_loss, gate_specs, phm_pairs, prebuilt_H, stat_accumulators
 
 
 # rows of one full round of the row-blocked GEMM launches: 16-row steps x one workgroup per CU of a 256-CU part (the 256-wide layers;
@@ -302,7 +302,8 @@ class GraphedTrainStep:
         advance_dropout_rng(self.model, bs.data)
         with stat_accumulators(self.device), prebuilt_H(self._pairs, self._dense, self._gates,
                                                         encode=atom_encode_spec(self.model, bs.data)), deferred_param_grads():
-            logits = self.model(bs.data)
+            with expect_loss(bs.data.y, "l1" if self.cfg.regression else "bce"):
+                logits = self.model(bs.data)
             loss = loss_fn(logits, bs.data, self.cfg.regression)
             loss.backward(self._seed)
             parked = park_weight_regulariser(self.model, loss, self.cfg)

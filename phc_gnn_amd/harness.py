@@ -12,8 +12,8 @@ import torch
 import torch.nn.functional as F
 
 from . import synth
-from .ops import (atom_encode_spec, deferred_param_grads, dense_weights, gate_specs, masked_bce_with_logits, masked_l1, phm_pairs,
-                  phm_weight_regularization_, prebuilt_H, stat_accumulators)
+from .ops import (atom_encode_spec, deferred_param_grads, dense_weights, expect_loss, gate_specs, masked_bce_with_logits, masked_l1,
+                  phm_pairs, phm_weight_regularization_, prebuilt_H, stat_accumulators)
 from .optim import ClipAdam
 
 # BASELINE.json configs -> PHMSkipConnectAdd arguments (SURVEY.md §8d "Model settings")
@@ -156,7 +156,8 @@ def train_step(model, data, optimizer: Optional[torch.optim.Optimizer], cfg: Ste
     # (the atom encoder rides in the operand-build launch: atom_encode_spec)
     with stat_accumulators(data.x.device), prebuilt_H(phm_pairs(model), dense_weights(model), gate_specs(model),
                                                       encode=atom_encode_spec(model, data)), deferred_param_grads():
-        logits = model(data)
+        with expect_loss(getattr(data, "y", None), "l1" if cfg.regression else "bce"):     # (a head that can leaves the loss behind)
+            logits = model(data)
         loss = loss_fn(logits, data, cfg.regression)
         loss.backward(backward_seed(loss))
         parked = park_weight_regulariser(model, loss, cfg)       # rides in the step tail's launches when it can

@@ -2138,16 +2138,76 @@ class _MaskedL1Fn(torch.autograd.Function):
         return _masked_loss_backward(ctx, dloss)
 
 
+# The training loss inside the prediction head's forward launch (phc_downstream_desc.loss_*, ABI 8): a step that knows its labels
+# before the model runs says so with ``expect_loss``; a head whose shapes allow it (the 16-row kernels, at most 4096 logits) then
+# leaves the loss and d loss / d logits behind, and ``masked_bce_with_logits`` / ``masked_l1`` on those logits and labels launch nothing.
+HEAD_LOSS = __import__("os").environ.get("PHC_HEAD_LOSS", "1") != "0"
+_LOSS_HINT = threading.local()
+_LOSS_KINDS = {"bce": 0, "l1": 1}
+
+
+@contextlib.contextmanager
+def expect_loss(y: Optional[torch.Tensor], kind: str):
+    """``y``: the labels the step will hand to ``masked_bce_with_logits`` (kind "bce") / ``masked_l1`` ("l1") with the model's output."""
+    prev = getattr(_LOSS_HINT, "spec", None)
+    ok = HEAD_LOSS and y is not None and y.is_cuda and y.dtype == torch.float32 and y.is_contiguous() and y.dim() == 2
+    _LOSS_HINT.spec = (y, _LOSS_KINDS[kind]) if ok else None
+    try:
+        yield
+    finally:
+        _LOSS_HINT.spec = prev
+
+
+_DN_LOSS_GRANULES: dict = {}
+
+
+def _dn_loss_granules(dev, B: int, total: int) -> torch.Tensor:
+    """The logits' hand-over words of the head's in-launch loss, per device, stream and row count (zero before the first use, owned by
+    the kernels from then on: generation-tagged granules, as ``_dn_buffers``' partial buffer whose generation they share)."""
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream, B, total)
+    buf = _DN_LOSS_GRANULES.get(key)
+    if buf is None:
+        buf = _DN_LOSS_GRANULES[key] = torch.zeros(total, dtype=torch.int64, device=dev)
+    return buf
+
+
+class _HeadLossFn(torch.autograd.Function):
+    """The masked mean loss the head's forward launch already computed: (loss | sum | count, d loss / d logits for an upstream 1)."""
+
+    @staticmethod
+    def forward(ctx, logits, out3, dz_unit):
+        ctx.save_for_backward(dz_unit)
+        ctx.shape = logits.shape
+        return out3[0]
+
+    @staticmethod
+    def backward(ctx, dloss):
+        (dz_unit,) = ctx.saved_tensors
+        if dloss.numel() == 1 and (dloss.data_ptr(), dloss.device) in _UNIT_SEEDS:
+            return dz_unit.reshape(ctx.shape), None, None        # upstream gradient is the resident 1: nothing to launch
+        return (dz_unit * dloss).reshape(ctx.shape), None, None
+
+
+def _head_loss(logits: torch.Tensor, y: torch.Tensor, kind: int):
+    res = getattr(logits, "_phc_loss", None)
+    if res is None or res[3] != kind or res[2].data_ptr() != y.data_ptr() or tuple(res[2].shape) != tuple(y.shape) or \
+            res[2]._version != res[4] or tuple(logits.shape) != tuple(y.shape):
+        return None
+    return _HeadLossFn.apply(logits, res[0], res[1])
+
+
 def masked_l1(pred: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     """mean |pred - y| over the entries whose target is not NaN (benchmarks/train_zinc.py: torch.nn.L1Loss; the padding graphs
     of a fixed-shape batch carry NaN targets) — one kernel each way instead of a dozen element-wise launches."""
-    return _MaskedL1Fn.apply(pred, y)
+    done = _head_loss(pred, y, 1)
+    return done if done is not None else _MaskedL1Fn.apply(pred, y)
 
 
 def masked_bce_with_logits(logits: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
     """mean BCE-with-logits over the labeled entries, NaN in ``y`` = unlabeled (benchmarks/train_hiv.py:174-178:
     ``mask = ~isnan(y); criterion(logits[mask], y[mask])``) — one kernel each way, no host synchronisation."""
-    return _MaskedBCEFn.apply(logits, y)
+    done = _head_loss(logits, y, 0)
+    return done if done is not None else _MaskedBCEFn.apply(logits, y)
 
 
 # ---------------------------------------------------------------------------
@@ -3336,6 +3396,14 @@ class _DownstreamFn(torch.autograd.Function):
             a2 = torch.empty((B, d2), dtype=torch.float32, device=dev)
             _dn_set_drop(d, drop)
             d.a1, d.a2 = L.ptr(a1), L.ptr(a2)
+        loss = meta.get("loss")                              # (labels, kind) when the step said which loss follows (expect_loss)
+        if loss is not None:
+            y_, kind = loss
+            out3 = torch.empty(3, dtype=torch.float32, device=dev)
+            dz_unit = torch.empty((B, T), dtype=torch.float32, device=dev)
+            d.loss_y, d.loss_kind, d.loss_out, d.loss_dlogits = L.ptr(y_), kind, L.ptr(out3), L.ptr(dz_unit)
+            d.loss_granules = L.ptr(_dn_loss_granules(dev, B, B * T))
+            meta["loss_result"] = (out3, dz_unit, y_, kind, y_._version)
         L.check(lib.phc_downstream_fwd(_C.byref(d), L.stream_ptr(dev)), "phc_downstream_fwd")
         if drop is None:
             _tap(z1, stat1, n_valid, act)
@@ -3669,7 +3737,14 @@ def downstream_head(x, n_valid, affine_layers, norm_modules, real_affine, activa
     l1, l2, l3 = affine_layers
     if chain:
         return _HeadChainFn.apply(x, n_valid, meta, l1.phm_rule, l1.W, l1.b, l2.phm_rule, l2.W, l2.b, l3.phm_rule, l3.W, l3.b, Wr, br, *affine)
-    return _DownstreamFn.apply(x, n_valid, meta, l1.phm_rule, l1.W, l1.b, l2.phm_rule, l2.W, l2.b, l3.phm_rule, l3.W, l3.b, Wr, br, *affine)
+    hint = getattr(_LOSS_HINT, "spec", None)
+    if hint is not None and has_k4 and torch.is_grad_enabled() and tuple(hint[0].shape) == (x.shape[0], T) and hint[0].device == x.device \
+            and lib.phc_downstream_loss_supported(x.shape[0], d0, d1, d2, d3, T):
+        meta["loss"] = hint
+    out = _DownstreamFn.apply(x, n_valid, meta, l1.phm_rule, l1.W, l1.b, l2.phm_rule, l2.W, l2.b, l3.phm_rule, l3.W, l3.b, Wr, br, *affine)
+    if meta.get("loss_result") is not None:
+        out._phc_loss = meta.pop("loss_result")              # what masked_bce_with_logits / masked_l1 on these logits return
+    return out
 
 
 

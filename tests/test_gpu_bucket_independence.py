@@ -1,0 +1,37 @@
+"""A batch's loss and gradients must not depend on the bucket it is padded to: real batches land in whatever
+bucket the loader's slack leaves them (benchmarks/train_hiv.py:171-173: RemoveIsolatedNodes + a shuffled loader), and padding rows /
+edges / graphs are inert.  Same batch, two bucket shapes -> bit-identical loss and parameter gradients."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+DEV = torch.device("cuda:0") if torch.cuda.is_available() else None
+
+
+def _grads(workload, gb, n_max, e_max, seed=2):
+    from phc_gnn_amd import graphed, harness, lib
+    model = harness.build_model(workload, DEV, seed=seed).train()
+    w = harness.WORKLOADS[workload]
+    cfg = harness.StepConfig(regression=bool(w.get("regression")), optimizer=False, weight_decay=1e-3)
+    padded = graphed.padded_to_device(graphed.pad_batch(gb, n_max, e_max), DEV)
+    from phc_gnn_amd.optim import ClipAdam
+    step = graphed.GraphedTrainStep(model, ClipAdam(model.parameters(), lr=1e-3), cfg, padded, warmup=2)
+    with step.on_stream():
+        step.step(padded)
+        loss = step.step(padded).clone()
+    torch.cuda.synchronize()
+    lib.check_indices(DEV)
+    return float(loss), {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+
+
+@pytest.mark.parametrize("workload,extra_n,extra_e", [("molhiv_b512", 4096 + 128, 2048), ("molhiv_b512", 256, 128), ("zinc_b1024", 4096, 4096),
+                                                      ("molhiv_b512_softmax", 1024, 512), ("molhiv_b512_conv", 1024, 512)])
+def test_same_batch_in_two_buckets(workload, extra_n, extra_e):
+    from phc_gnn_amd import graphed, harness
+    gb = harness.make_batch(workload, seed=21)
+    n_max, e_max = graphed.bucket_shape([gb])
+    la, ga = _grads(workload, gb, n_max, e_max)
+    lb, gb_ = _grads(workload, gb, n_max + extra_n, e_max + extra_e)
+    differ = [k for k in ga if not torch.equal(ga[k], gb_[k])]
+    worst = max((float((ga[k] - gb_[k]).abs().max()) / max(float(ga[k].abs().max()), 1e-30) for k in differ), default=0.0)
+    assert la == lb and not differ, (la, lb, len(differ), len(ga), worst, differ[:12])
