@@ -657,6 +657,34 @@ int phc_debug_hs_stamps(unsigned long long *dev_words);
 int phc_gemm_hs_enabled(void);
 int phc_gemm_hs_set_enabled(int on);
 
+/* ABI 8: the backward of  act(norm_o(PHMMLP(s)))  at hidden 128 as ONE launch (csrc/mlp_fused.hip) instead of
+ * phc_bn_bwd_partial_acc + phc_gemm_bwd_apply (outer, with the inner norm's sums) + phc_gemm_bwd_apply (inner) — autograd of
+ * phc/hypercomplex/layers.py:349-355 behind undirectional/models.py:208-215 (norm.py:30-35).  A workgroup keeps its <= 32 rows in
+ * LDS for the whole chain; the two grid-wide dependencies (a norm backward needs its column sums over all rows) are barriers
+ * inside the launch, crossed only by the integer accumulators.  Outputs as the three launches': dy2 = the outer norm's dx (the dy of
+ * linear2's parameter-gradient job), dz1 = the inner norm's dx (linear1's), ds = d loss / d s, dwb_* = dweight | dbias of the norms;
+ * `da` never reaches memory.  Same results up to the fp32 summation order of the column sums; bit-reproducible.
+ * acc_o / acc_i: phc_stat_acc_words(128) zeroed words each; barrier: phc_mlp_norm_bwd_fused_barrier_words() uint32, ZERO before the
+ * first use, owned by the kernel (one buffer per stream).  phc_mlp_norm_bwd_fused_supported(N, h): h = 128 and ceil(N / 32) workgroups co-resident on this device. */
+typedef struct phc_mlp_norm_bwd_desc {
+    const float *dout;             /* [N, h] upstream gradient of act(norm_o(y2)) (+ skip)             */
+    const float *y2, *z1;          /* [N, h] the outer / inner norm's input                            */
+    const float *save_o, *save_i;  /* [6 h] their save_stat                                            */
+    const float *H2Tk4, *H1Tk4;    /* k4 forms of linear2's / linear1's H^T                            */
+    float *dy2, *dz1, *ds;         /* [N, h] out                                                       */
+    float *dwb_o, *dwb_i;          /* [2 h] out or NULL                                                */
+    uint64_t *acc_o, *acc_i;
+    const int32_t *n_valid_dev;    /* device scalar or NULL                                            */
+    int64_t N;
+    int32_t h, act_o, act_i;
+    uint32_t *barrier;
+} phc_mlp_norm_bwd_desc;
+int phc_mlp_norm_bwd_fused_supported(int64_t N, int h);
+size_t phc_mlp_norm_bwd_fused_barrier_words(void);        /* uint32 words of `barrier` */
+int phc_mlp_norm_bwd_fused(const phc_mlp_norm_bwd_desc *desc, void *stream);
+/* Diagnostics only: when set (16 device words), workgroups 0 and G - 1 of every launch stamp their phase clocks there; NULL: off. */
+int phc_debug_mlp_bwd_stamps(unsigned long long *dev_words);
+
 /* The layer's sum aggregation INSIDE its first GEMM (ABI 5, molecule batches).  One launch computes
  *     s[d] = sum_{e: dst_e = d} (x[src_e] + sum_f table_{c,f}[code_f(e)]) (+ x[d])     messagepassing.py:132-146 (GINE, identity
  *                                                                                      message function), encoder.py:31-34

@@ -22,7 +22,7 @@ OBJ_DIR = os.path.join(PKG_DIR, "build")
 LIB_PATH = os.path.join(PKG_DIR, "libphc_hip.so")
 ARCH = "gfx950"
 
-SOURCES = ["api.hip", "phm_linear.hip", "gemm_agw.hip", "aggregate.hip", "csr.hip", "encoder.hip", "norm.hip", "softmax_agg.hip", "readout.hip", "optim.hip", "downstream.hip", "head_chain.hip"]
+SOURCES = ["api.hip", "phm_linear.hip", "gemm_agw.hip", "aggregate.hip", "csr.hip", "encoder.hip", "norm.hip", "softmax_agg.hip", "readout.hip", "optim.hip", "downstream.hip", "head_chain.hip", "mlp_fused.hip"]
 COMMON_FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", f"-I{INCLUDE}", f"-I{CSRC}",
                 "-Wall", "-Wno-unused-function", "-Wno-unused-result", "-Wno-unused-value", "-fno-gpu-rdc"]
 

@@ -65,6 +65,13 @@ class DownstreamDesc(C.Structure):
                 ("loss_y", _P), ("loss_kind", C.c_int32), ("loss_out", _P), ("loss_dlogits", _P), ("loss_granules", _P)]
 
 
+class MlpNormBwdDesc(C.Structure):
+    """phc_mlp_norm_bwd_desc (include/phc_hip.h)."""
+    _fields_ = [("dout", _P), ("y2", _P), ("z1", _P), ("save_o", _P), ("save_i", _P), ("H2Tk4", _P), ("H1Tk4", _P),
+                ("dy2", _P), ("dz1", _P), ("ds", _P), ("dwb_o", _P), ("dwb_i", _P), ("acc_o", _P), ("acc_i", _P),
+                ("n_valid_dev", _P), ("N", _L), ("h", C.c_int32), ("act_o", C.c_int32), ("act_i", C.c_int32), ("barrier", _P)]
+
+
 class HeadStage(C.Structure):
     """phc_head_stage (include/phc_hip.h)."""
     _fields_ = [("M", _P), ("bias", _P), ("K", C.c_int32), ("N", C.c_int32), ("post", C.c_int32), ("out", _P), ("z", _P), ("stat", _P),
@@ -178,6 +185,10 @@ SIGNATURES = {
     "phc_bn_fwd_from_moments": (_I, [_P, _L, _P, _P, _I, _L, _P, _P, _P, _P, _P, _I, _I, C.c_float, C.c_float, _I, _P, _P, _P, _P]),
     "phc_bn_bwd_sums": (_I, [_P, _P, _P, _L, _I, _I, _P, _P, _S, _P]),
     "phc_bn_bwd_apply": (_I, [_P, _P, _P, _P, _L, _L, _I, _I, _P, _P, _S, _P]),
+    "phc_mlp_norm_bwd_fused_supported": (_I, [_L, _I]),
+    "phc_mlp_norm_bwd_fused": (_I, [C.POINTER(MlpNormBwdDesc), _P]),
+    "phc_mlp_norm_bwd_fused_barrier_words": (_S, []),
+    "phc_debug_mlp_bwd_stamps": (_I, [_P]),
     "phc_downstream_supported": (_I, [_L, _I, _I, _I, _I, _I]),
     "phc_downstream_supported_k4": (_I, [_L, _I, _I, _I, _I, _I]),
     "phc_downstream_dropout_supported": (_I, [_L, _I, _I, _I, _I, _I]),

@@ -3117,6 +3117,20 @@ def _tap(z, save_stat, n_valid, act):
         RELU_TAP.append((z, save_stat, n_valid, act))
 
 
+# the MLP + norm node's backward as ONE launch at hidden 128 (csrc/mlp_fused.hip, round 6); 0 = the three launches
+MLP_BWD_FUSED = __import__("os").environ.get("PHC_MLP_BWD_FUSED", "1") != "0"
+_GRID_BARRIERS: dict = {}
+
+
+def _grid_barrier_words(dev) -> torch.Tensor:
+    """{arrivals, generation} of the in-launch grid barriers, per device and stream: zero before the first use, owned by the kernels."""
+    key = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    w = _GRID_BARRIERS.get(key)
+    if w is None:
+        w = _GRID_BARRIERS[key] = torch.zeros(L.load().phc_mlp_norm_bwd_fused_barrier_words(), dtype=torch.int32, device=dev)
+    return w
+
+
 class _MLPNormFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, s, skip, n_valid, meta, A1, W1, b1, A2, W2, b2, *affine):
@@ -3192,6 +3206,20 @@ class _MLPNormFn(torch.autograd.Function):
         dwb_o = torch.empty(2 * h, dtype=torch.float32, device=dev)
         dwb_i = torch.empty(2 * h, dtype=torch.float32, device=dev)
         drop = ctx.drop
+        if MLP_BWD_FUSED and drop[0] == 0.0 and pre2[3] is not None and pre1[3] is not None and dout_.data_ptr() % 16 == 0 and \
+                lib.phc_mlp_norm_bwd_fused_supported(N, h):
+            # the whole chain in ONE launch (csrc/mlp_fused.hip): rows stay in LDS, the two grid-wide dependencies are barriers inside it
+            fd = L.MlpNormBwdDesc()
+            fd.dout, fd.y2, fd.z1, fd.save_o, fd.save_i = L.ptr(dout_), L.ptr(y2), L.ptr(z1), L.ptr(save_o), L.ptr(save_i)
+            fd.H2Tk4, fd.H1Tk4 = L.ptr(pre2[3]), L.ptr(pre1[3])
+            fd.dy2, fd.dz1, fd.ds, fd.dwb_o, fd.dwb_i = L.ptr(dy2), L.ptr(dz1), L.ptr(ds), L.ptr(dwb_o), L.ptr(dwb_i)
+            fd.acc_o, fd.acc_i, fd.n_valid_dev = L.ptr(acc_o), L.ptr(acc_i), L.ptr(n_valid)
+            fd.N, fd.h, fd.act_o, fd.act_i = N, h, act_o, act_i
+            fd.barrier = L.ptr(_grid_barrier_words(dev))
+            L.check(lib.phc_mlp_norm_bwd_fused(_C.byref(fd), sp), "phc_mlp_norm_bwd_fused")
+            if L.PROF_ON:                                    # (both dx GEMMs of the node: booked as one launch of the family)
+                L.account("phm_gemm_dx", 4.0 * N * h * h, 4.0 * (6 * N * h + 2 * h * h))
+            return _MLPNormFn._finish_backward(ctx, dout, dout_, s, z1, y2, save_i, dy2, dz1, ds, dwb_o, dwb_i, N, h)
         if drop[0] > 0.0:
             L.check(lib.phc_bn_bwd_partial_acc_drop(L.ptr(dout_), L.ptr(y2), L.ptr(save_o), L.ptr(n_valid), N, h, act_o, L.ptr(acc_o),
                                                     drop[0], drop[1], drop[2], L.ptr(drop[3]), sp), "phc_bn_bwd_partial_acc_drop")
@@ -3215,6 +3243,14 @@ class _MLPNormFn(torch.autograd.Function):
             L.account("bn_bwd_partial", 6.0 * N * h, 8.0 * N * h)
             L.account("phm_gemm_dx", 2.0 * N * h * h, 4.0 * (4 * N * h + h * h))
             L.account("phm_gemm_dx", 2.0 * N * h * h, 4.0 * (4 * N * h + h * h))
+        return _MLPNormFn._finish_backward(ctx, dout, dout_, s, z1, y2, save_i, dy2, dz1, ds, dwb_o, dwb_i, N, h)
+
+    @staticmethod
+    def _finish_backward(ctx, dout, dout_, s, z1, y2, save_i, dy2, dz1, ds, dwb_o, dwb_i, N, h):
+        meta, n_valid = ctx.meta, ctx.n_valid
+        inner, outer = meta["inner"], meta["outer"]
+        act_i = meta["act_inner"]
+        needs = ctx.needs_input_grad
         # parameter gradients: (z1 through the inner norm, dy2) for linear2, (s, dz1) for linear1
         (pA1, pW1, pb1), (pA2, pW2, pb2) = ctx.params
         grads = [None] * 6
