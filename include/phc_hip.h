@@ -561,6 +561,15 @@ int phc_csr_build_pair_codes_resident(const int64_t *edge_src_i64, const int64_t
                                       int64_t n_dst, int32_t *rowptr, int32_t *col, int32_t *perm, int32_t *rowptr_t, int32_t *col_t,
                                       int32_t *perm_t, const int64_t *bond_i64, const int32_t *vocab, int F, uint32_t *codes,
                                       float *code_counts, void *ws_zeroed_once, size_t ws_bytes, void *stream);
+/* ABI 8: ... and the first four in-edges of every destination row side by side, ell [n_dst][8] int32 (slots 0-3: source, 4-7: packed
+ * code), and the first four out-edges of every source row, ell_t [n_src][4] (destination); either may be NULL; slots past a row's
+ * degree name the row itself (code 0).  A kernel that owns a row reads its edges in the same round trip as its row pointers
+ * (phc_mlp_norm_fwd_fused's aggregation).  Rows with more than four edges: the rest through rowptr / col / codes as before. */
+int phc_csr_build_pair_codes_resident_ell(const int64_t *edge_src_i64, const int64_t *edge_dst_i64, int64_t E, int64_t n_src,
+                                          int64_t n_dst, int32_t *rowptr, int32_t *col, int32_t *perm, int32_t *rowptr_t, int32_t *col_t,
+                                          int32_t *perm_t, const int64_t *bond_i64, const int32_t *vocab, int F, uint32_t *codes,
+                                          float *code_counts, int32_t *ell, int32_t *ell_t, void *ws_zeroed_once, size_t ws_bytes,
+                                          void *stream);
 
 /* Per-batch preprocessing on the device: drop the nodes no edge touches and re-index,
  * i.e. the reference's CustomRemoveIsolatedNodes / PyG RemoveIsolatedNodes applied to every collated
@@ -682,8 +691,61 @@ typedef struct phc_mlp_norm_bwd_desc {
 int phc_mlp_norm_bwd_fused_supported(int64_t N, int h);
 size_t phc_mlp_norm_bwd_fused_barrier_words(void);        /* uint32 words of `barrier` */
 int phc_mlp_norm_bwd_fused(const phc_mlp_norm_bwd_desc *desc, void *stream);
-/* Diagnostics only: when set (16 device words), workgroups 0 and G - 1 of every launch stamp their phase clocks there; NULL: off. */
+/* Diagnostics only: when set (32 device words), workgroups 0 and G - 1 of every launch stamp their phase clocks there; NULL: off. */
 int phc_debug_mlp_bwd_stamps(unsigned long long *dev_words);
+
+/* ABI 8: the forward of the same node behind the aggregation as ONE launch (csrc/mlp_fused.hip) instead of
+ * phc_gemm_prebuilt_stats + phc_gemm_prebuilt_xf_acc:  z1 = s . H1 + b1;  a = act(batch_norm_train(z1));  y2 = a . H2 + b2
+ * (phc/hypercomplex/layers.py:349-355, norm.py:30-35), the statistics (sum | sum of squares over the valid rows) of y2 left in acc2
+ * for whoever applies the model-level norm.  z1's rows stay in registers across the launch's one grid-wide dependency, `a` never
+ * reaches memory; z1 and y2 are bit-identical to the two launches' for the same operands.  The norm's tables as in phc_bn_fwd;
+ * save_stat [6 h] (phc_bn_fwd's layout) and the running statistics are written by the launch.  acc1 / acc2: phc_stat_acc_words(128)
+ * zeroed words each; barrier: as phc_mlp_norm_bwd_fused (the two may share one buffer per stream). */
+typedef struct phc_mlp_norm_fwd_desc {
+    const float *s;                /* [N, h] the layer's aggregated input                              */
+    const float *H1k4, *b1, *H2k4, *b2;   /* k4 operands of linear1 / linear2; biases [h] or NULL     */
+    float *z1, *y2;                /* [N, h] out                                                       */
+    uint64_t *acc1, *acc2;
+    const float *const *weight, *const *bias;            /* the inner norm: host arrays of n_comp device pointers (NULL: no affine) */
+    float *const *running_mean, *const *running_var;
+    int64_t *const *num_batches_tracked;
+    int32_t n_comp;
+    float momentum, eps;
+    float *save_stat;              /* [6 h] out                                                        */
+    int32_t act;                   /* the MLP's activation                                             */
+    const int32_t *n_valid_dev;
+    int64_t N;
+    int32_t h;
+    uint32_t *barrier;
+    /* The layer's sum aggregation inside the same launch (codes != NULL; `s` is then ignored): the rows of
+     *     s[d] = sum_{e: dst_e = d} (x[src_e] + sum_f table_{c,f}[code_f(e)]) (+ x[d])     messagepassing.py:132-146, encoder.py:31-34
+     * are built by the workgroup that owns them (one row per 32-lane group, edge order and additions of phc_aggregate_encp_fwd: s is
+     * bit-identical) and written to s_out once (the parameter-gradient GEMM reads it); fields as in phc_gemm_ag_desc.  With norm_acc
+     * != NULL x is the un-applied  act(batch_norm(x)) (+ skip)  of the layer in front (models.py:208-215): scale / shift from its
+     * accumulator in the prologue, every gathered row normalised on the fly, x_out written once, save_stat_o and the running
+     * statistics left behind — what phc_aggregate_norm_encp_fwd does.  phc_mlp_norm_fwd_fused_agg_supported: k % 4 == 0, F <= 4,
+     * sum(vocab) <= 32. */
+    const float *x;
+    const uint32_t *codes;
+    const float *const *tables;
+    const int32_t *vocab;          /* host [F] */
+    const int32_t *rowptr, *col;
+    const int32_t *ell;            /* [N][8] from phc_csr_build_pair_codes_resident_ell (required with codes)               */
+    const float *const *tables_host;   /* HOST array [n F] of the same table pointers (n F <= 16; required with codes)      */
+    int32_t F, n, add_self;
+    float *s_out;
+    const uint64_t *norm_acc;
+    const float *const *weight_o, *const *bias_o;
+    float *const *running_mean_o, *const *running_var_o;
+    int64_t *const *num_batches_tracked_o;
+    int32_t n_comp_o, norm_act;
+    float momentum_o, eps_o;
+    const float *skip;
+    float *save_stat_o, *x_out;
+} phc_mlp_norm_fwd_desc;
+int phc_mlp_norm_fwd_fused_supported(int64_t N, int h);
+int phc_mlp_norm_fwd_fused_agg_supported(int64_t N, int h, int n, int F, int vocab_rows);
+int phc_mlp_norm_fwd_fused(const phc_mlp_norm_fwd_desc *desc, void *stream);
 
 /* The layer's sum aggregation INSIDE its first GEMM (ABI 5, molecule batches).  One launch computes
  *     s[d] = sum_{e: dst_e = d} (x[src_e] + sum_f table_{c,f}[code_f(e)]) (+ x[d])     messagepassing.py:132-146 (GINE, identity

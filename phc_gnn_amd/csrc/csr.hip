@@ -387,6 +387,11 @@ struct CsrPair {
     float *counts;
     int CR, R;
     int resident;                      // the counter arrays of the workspace are zero on entry and are left zero (no zero launch)
+    // optional (round 6): the first four in-edges of every destination row side by side — ell[row][0..3] = source, ell[row][4..7] =
+    // packed code, slots past the row's degree name the row itself (a row its reader loads anyway) with code 0 — and the first four
+    // out-edges of every source row, ell_t[row][0..3] = destination.  A reader that owns a row gets its edges in the SAME round trip as
+    // the row pointers instead of one later (the aggregating fused forward / backward, csrc/mlp_fused.hip).
+    int *ell, *ell_t;
 };
 
 __global__ void csr_pair_zero_kernel(CsrPair p) {
@@ -486,14 +491,29 @@ __global__ __launch_bounds__(256) void csr_pair_canon_kernel(CsrPair p) {
             int rank = 0;
             for (int j = 0; j < deg; ++j) rank += (sd.tmp_perm[b + j] < v) ? 1 : 0;
             sd.perm[b + rank] = v;
-            sd.col[b + rank] = (int)safe_index(sd.other[v], num_other);
+            const int oth = (int)safe_index(sd.other[v], num_other);
+            sd.col[b + rank] = oth;
+            unsigned c = 0;
             if (blockIdx.y == 0 && p.codes) {
-                unsigned c = 0;
                 for (int f = 0; f < p.F; ++f)
                     c |= (unsigned)(p.off[f] + (int)checked_index(p.bond[(long long)v * p.F + f], p.vocab[f], p.err, PHC_IDX_ERR_BOND))
                          << (8 * f);
                 p.codes[b + rank] = c;
             }
+            if (rank < 4) {
+                if (blockIdx.y == 0 && p.ell) {
+                    p.ell[k * 8 + rank] = oth;
+                    p.ell[k * 8 + 4 + rank] = (int)c;
+                }
+                if (blockIdx.y == 1 && p.ell_t) p.ell_t[k * 4 + rank] = oth;
+            }
+        }
+        if (li < 4 && li >= deg) {                           // slots past the degree: the row itself
+            if (blockIdx.y == 0 && p.ell) {
+                p.ell[k * 8 + li] = (int)k;
+                p.ell[k * 8 + 4 + li] = 0;
+            }
+            if (blockIdx.y == 1 && p.ell_t) p.ell_t[k * 4 + li] = (int)k;
         }
         if (blockIdx.y == 0 && p.counts) {
             // the 8 lanes of the row's group share the table rows; each walks the row's edges for its own rows (read from the
@@ -742,7 +762,7 @@ int phc_csr_build_pair(const int64_t *edge_src_i64, const int64_t *edge_dst_i64,
 static int csr_build_pair_impl(const int64_t *edge_src_i64, const int64_t *edge_dst_i64, int64_t E, int64_t n_src, int64_t n_dst,
                                int32_t *rowptr, int32_t *col, int32_t *perm, int32_t *rowptr_t, int32_t *col_t, int32_t *perm_t,
                                const int64_t *bond_i64, const int32_t *vocab, int F, uint32_t *codes, float *code_counts, void *ws,
-                               size_t ws_bytes, void *stream, int resident);
+                               size_t ws_bytes, void *stream, int resident, int32_t *ell = nullptr, int32_t *ell_t = nullptr);
 
 int phc_csr_build_pair_codes(const int64_t *edge_src_i64, const int64_t *edge_dst_i64, int64_t E, int64_t n_src, int64_t n_dst,
                              int32_t *rowptr, int32_t *col, int32_t *perm, int32_t *rowptr_t, int32_t *col_t, int32_t *perm_t,
@@ -760,10 +780,23 @@ int phc_csr_build_pair_codes_resident(const int64_t *edge_src_i64, const int64_t
                                codes, code_counts, ws_zeroed_once, ws_bytes, stream, 1);
 }
 
+/* ABI 8: the same build that also leaves the first four in-edges (sources | codes) of every destination row in ell [n_dst][8] and the
+ * first four out-edges (destinations) of every source row in ell_t [n_src][4] (either may be NULL); slots past a row's degree name the
+ * row itself.  Readers: phc_mlp_norm_fwd_fused / phc_mlp_norm_bwd_fused (a row's edges in the round trip of its row pointers). */
+int phc_csr_build_pair_codes_resident_ell(const int64_t *edge_src_i64, const int64_t *edge_dst_i64, int64_t E, int64_t n_src,
+                                          int64_t n_dst, int32_t *rowptr, int32_t *col, int32_t *perm, int32_t *rowptr_t, int32_t *col_t,
+                                          int32_t *perm_t, const int64_t *bond_i64, const int32_t *vocab, int F, uint32_t *codes,
+                                          float *code_counts, int32_t *ell, int32_t *ell_t, void *ws_zeroed_once, size_t ws_bytes,
+                                          void *stream) {
+    PHC_REQUIRE(!ell || codes, PHC_ERR_INVALID_ARG, "phc_csr_build_pair_codes_resident_ell: ell carries the packed codes: codes must be built too");
+    return csr_build_pair_impl(edge_src_i64, edge_dst_i64, E, n_src, n_dst, rowptr, col, perm, rowptr_t, col_t, perm_t, bond_i64, vocab, F,
+                               codes, code_counts, ws_zeroed_once, ws_bytes, stream, 1, ell, ell_t);
+}
+
 static int csr_build_pair_impl(const int64_t *edge_src_i64, const int64_t *edge_dst_i64, int64_t E, int64_t n_src, int64_t n_dst,
                                int32_t *rowptr, int32_t *col, int32_t *perm, int32_t *rowptr_t, int32_t *col_t, int32_t *perm_t,
                                const int64_t *bond_i64, const int32_t *vocab, int F, uint32_t *codes, float *code_counts, void *ws,
-                               size_t ws_bytes, void *stream, int resident) {
+                               size_t ws_bytes, void *stream, int resident, int32_t *ell, int32_t *ell_t) {
     int code_off[4] = {0, 0, 0, 0};
     int code_rows = 0;
     if (codes) {
@@ -812,6 +845,8 @@ static int csr_build_pair_impl(const int64_t *edge_src_i64, const int64_t *edge_
     }
     p.err = err_word();
     p.resident = resident;
+    p.ell = ell;
+    p.ell_t = ell_t;
     const long long nmax = (n_src > n_dst ? n_src : n_dst) + 1;
     const unsigned ngrid = (unsigned)((nmax + 255) / 256);
     const unsigned egrid = (unsigned)((E + 255) / 256 > 4096 ? 4096 : (E + 255) / 256);

@@ -26,6 +26,8 @@
 // accumulators: bit-reproducible, and within fp32 round-off of the separate launches' sums.
 #include <stdlib.h>
 
+#include <type_traits>
+
 #include "phc_common.h"
 
 namespace phc {
@@ -126,46 +128,27 @@ __device__ __forceinline__ void mf_gemm_tile(const float *tile, const f32x4_t (&
     }
 }
 
-// g = up act'(x_hat w + b), x_hat = (x - mean) invstd for this thread's two float4 of every tile; column sums of g and g x_hat over
-// the workgroup's valid rows -> the accumulator.  UP / X: LDS tiles (in place: UP := g, X := x_hat); cst: mean | invstd | w | b [4][128]
-template <int MAXS>
-__device__ __forceinline__ void mf_gate_and_sums(float *UP, float *X, int tile_stride, const float *cst, int act, int steps, long long step0,
-                                                 long long gstride, long long n_valid, float *red, unsigned long long *acc, int rep) {
-    const int tid = threadIdx.x, c4 = tid & 31, rg = tid >> 5, lane = tid & 63, wave = tid >> 6;
-    const f32x4_t mean = *reinterpret_cast<const f32x4_t *>(cst + 4 * c4), inv = *reinterpret_cast<const f32x4_t *>(cst + MF_H + 4 * c4);
-    const f32x4_t w = *reinterpret_cast<const f32x4_t *>(cst + 2 * MF_H + 4 * c4), b = *reinterpret_cast<const f32x4_t *>(cst + 3 * MF_H + 4 * c4);
-    f32x4_t sg = {0.f, 0.f, 0.f, 0.f}, sgx = {0.f, 0.f, 0.f, 0.f};
-    const bool relu = act == PHC_ACT_RELU;
+// the same with the accumulators starting from the bias (gemm_hs16_kernel's order: y = b, then the k-groups in ascending order)
+__device__ __forceinline__ void mf_gemm_tile_bias(const float *tile, const f32x4_t (&hreg)[2][8], int c, int kq, const f32x4_t (&bias)[2],
+                                                  f32x4_t (&acc)[2]) {
+    acc[0] = bias[0];
+    acc[1] = bias[1];
+    f32x4_t fr[2];
+    fr[0] = *reinterpret_cast<const f32x4_t *>(tile + c * MF_LD + 4 * kq);
 #pragma unroll
-    for (int s = 0; s < MAXS; ++s) {
-        if (s < steps) {
+    for (int g = 0; g < 8; ++g) {
+        if (g + 1 < 8) fr[(g + 1) & 1] = *reinterpret_cast<const f32x4_t *>(tile + c * MF_LD + 16 * (g + 1) + 4 * kq);
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int r = rg + 8 * u;
-                const long long row = (step0 + s * gstride) * 16 + r;
-                float *pu = UP + s * tile_stride + r * MF_LD + 4 * c4, *px = X + s * tile_stride + r * MF_LD + 4 * c4;
-                const f32x4_t up = *reinterpret_cast<const f32x4_t *>(pu), xv = *reinterpret_cast<const f32x4_t *>(px);
-                f32x4_t gq, xh;
+        for (int q = 0; q < 4; ++q)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
-                    xh[q] = (xv[q] - mean[q]) * inv[q];
-                    const float pre = fmaf(xh[q], w[q], b[q]);
-                    float gv = up[q];
-                    if (relu)
-                        gv = pre > 0.f ? gv : 0.f;
-                    else
-                        gv *= act_grad_rt(act, pre);
-                    gq[q] = row < n_valid ? gv : 0.f;
-                    xh[q] = row < n_valid ? xh[q] : 0.f;     // (a padding row may hold anything: 0 x NaN must not reach the sums)
-                    sg[q] += gq[q];
-                    sgx[q] = fmaf(gq[q], xh[q], sgx[q]);
-                }
-                *reinterpret_cast<f32x4_t *>(pu) = gq;
-                *reinterpret_cast<f32x4_t *>(px) = xh;
-            }
-        }
+            for (int t = 0; t < 2; ++t) acc[t] = __builtin_amdgcn_mfma_f32_16x16x4f32(hreg[t][g][q], fr[g & 1][q], acc[t], 0, 0, 0);
     }
-    // the wavefront's two row groups (lanes l, l + 32), then the four wavefronts in order
+}
+
+// a thread's column sums (its rows, four columns) -> the accumulator: the wavefront's two row groups (lanes l, l + 32), then the four
+// wavefronts in order through LDS, then one integer add per column and quantity
+__device__ __forceinline__ void mf_publish_sums(f32x4_t sg, f32x4_t sgx, float *red, unsigned long long *acc, int rep) {
+    const int tid = threadIdx.x, c4 = tid & 31, lane = tid & 63, wave = tid >> 6;
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         sg[q] += __shfl_xor(sg[q], 32, 64);
@@ -186,6 +169,58 @@ __device__ __forceinline__ void mf_gate_and_sums(float *UP, float *X, int tile_s
         stat_acc_add(acc, MF_H, rep, 0, tid, (double)a);
         stat_acc_add(acc, MF_H, rep, 1, tid, (double)bq);
     }
+}
+
+// g = up act'(x_hat w + b), x_hat = (x - mean) invstd for this thread's two float4 of every tile; column sums of g and g x_hat over
+// the workgroup's valid rows -> the accumulator.  UP / X: LDS tiles (in place: UP := g, X := x_hat); cst: mean | invstd | w | b [4][128]
+// (the activation switch stays OUTSIDE the element loops — one straight-line body per kind, RELU a template parameter: as a
+// per-element select the run-time switch over six activations was expanded at every element, 160 times in the aggregating forward:
+// 20 000 lines of ISA, more than the instruction cache holds, 5 us of arithmetic for two rows)
+template <int MAXS, bool RELU>
+__device__ __forceinline__ void mf_gate_and_sums_k(float *UP, float *X, int tile_stride, const float *cst, int act, int steps, long long step0,
+                                                   long long gstride, long long n_valid, float *red, unsigned long long *acc, int rep) {
+    const int tid = threadIdx.x, c4 = tid & 31, rg = tid >> 5, lane = tid & 63, wave = tid >> 6;
+    const f32x4_t mean = *reinterpret_cast<const f32x4_t *>(cst + 4 * c4), inv = *reinterpret_cast<const f32x4_t *>(cst + MF_H + 4 * c4);
+    const f32x4_t w = *reinterpret_cast<const f32x4_t *>(cst + 2 * MF_H + 4 * c4), b = *reinterpret_cast<const f32x4_t *>(cst + 3 * MF_H + 4 * c4);
+    f32x4_t sg = {0.f, 0.f, 0.f, 0.f}, sgx = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) {
+        if (s < steps) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int r = rg + 8 * u;
+                const long long row = (step0 + s * gstride) * 16 + r;
+                float *pu = UP + s * tile_stride + r * MF_LD + 4 * c4, *px = X + s * tile_stride + r * MF_LD + 4 * c4;
+                const f32x4_t up = *reinterpret_cast<const f32x4_t *>(pu), xv = *reinterpret_cast<const f32x4_t *>(px);
+                f32x4_t gq, xh;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    xh[q] = (xv[q] - mean[q]) * inv[q];
+                    const float pre = fmaf(xh[q], w[q], b[q]);
+                    float gv = up[q];
+                    if constexpr (RELU)
+                        gv = pre > 0.f ? gv : 0.f;
+                    else
+                        gv *= act_grad_rt(act, pre);
+                    gq[q] = row < n_valid ? gv : 0.f;
+                    xh[q] = row < n_valid ? xh[q] : 0.f;     // (a padding row may hold anything: 0 x NaN must not reach the sums)
+                    sg[q] += gq[q];
+                    sgx[q] = fmaf(gq[q], xh[q], sgx[q]);
+                }
+                *reinterpret_cast<f32x4_t *>(pu) = gq;
+                *reinterpret_cast<f32x4_t *>(px) = xh;
+            }
+        }
+    }
+    mf_publish_sums(sg, sgx, red, acc, rep);
+}
+template <int MAXS>
+__device__ __forceinline__ void mf_gate_and_sums(float *UP, float *X, int tile_stride, const float *cst, int act, int steps, long long step0,
+                                                 long long gstride, long long n_valid, float *red, unsigned long long *acc, int rep) {
+    if (act == PHC_ACT_RELU)
+        mf_gate_and_sums_k<MAXS, true>(UP, X, tile_stride, cst, act, steps, step0, gstride, n_valid, red, acc, rep);
+    else
+        mf_gate_and_sums_k<MAXS, false>(UP, X, tile_stride, cst, act, steps, step0, gstride, n_valid, red, acc, rep);
 }
 
 // the accumulator's totals of column `col` (agent-scope loads: the words were written by other CUs' atomics inside this launch)
@@ -234,11 +269,11 @@ __device__ __forceinline__ void mf_norm_bwd(float *G, const float *XH, int tile_
 #define MF_STAMP(i)                                                                                        \
     do {                                                                                                   \
         if (a.stamps && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))              \
-            a.stamps[(blockIdx.x == 0 ? 0 : 8) + (i)] = __builtin_amdgcn_s_memrealtime();                  \
+            a.stamps[(blockIdx.x == 0 ? 0 : 16) + (i)] = __builtin_amdgcn_s_memrealtime();                 \
     } while (0)
 
 template <int MAXS>
-__global__ __launch_bounds__(MF_THREADS) void mlp_bwd_fused_kernel(MlpBwdArgs a) {
+__global__ __launch_bounds__(MF_THREADS, 2) void mlp_bwd_fused_kernel(MlpBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int TS = 3 * MF_TILE;                          // per step: [G | X | Z] tiles
     float *tG = sm, *tX = sm + MF_TILE, *tZ = sm + 2 * MF_TILE;
@@ -276,20 +311,50 @@ __global__ __launch_bounds__(MF_THREADS) void mlp_bwd_fused_kernel(MlpBwdArgs a)
             cst_i[q * MF_H + tid] = a.save_i[slot * MF_H + tid];
         }
     }
+    // the outer norm's constants of this thread's four columns straight into registers: the first gate pass runs on the loaded rows
+    // BEFORE they go to LDS (one LDS round trip less in front of the first barrier)
+    const f32x4_t o_mean = *reinterpret_cast<const f32x4_t *>(a.save_o + 4 * c4), o_inv = *reinterpret_cast<const f32x4_t *>(a.save_o + MF_H + 4 * c4);
+    const f32x4_t o_w = *reinterpret_cast<const f32x4_t *>(a.save_o + 4 * MF_H + 4 * c4), o_b = *reinterpret_cast<const f32x4_t *>(a.save_o + 5 * MF_H + 4 * c4);
     mf_load_operand(a.H2Tk4, col0, c, kq, hreg);             // (behind the rows: the first barrier does not need them)
     mf_load_operand(a.H1Tk4, col0, c, kq, hreg1);
+    {
+        f32x4_t sg = {0.f, 0.f, 0.f, 0.f}, sgx = {0.f, 0.f, 0.f, 0.f};
+        auto gate0 = [&](auto relu_c) __attribute__((always_inline)) {
+            constexpr bool RELU = decltype(relu_c)::value;
 #pragma unroll
-    for (int s = 0; s < MAXS; ++s)
+        for (int s = 0; s < MAXS; ++s)
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int r = rg + 8 * u;
-            *reinterpret_cast<f32x4_t *>(tG + s * TS + r * MF_LD + 4 * c4) = ld[s][u][0];
-            *reinterpret_cast<f32x4_t *>(tX + s * TS + r * MF_LD + 4 * c4) = ld[s][u][1];
-            *reinterpret_cast<f32x4_t *>(tZ + s * TS + r * MF_LD + 4 * c4) = ld[s][u][2];
-        }
-    mf_lds_barrier();
-    MF_STAMP(1);
-    mf_gate_and_sums<MAXS>(tG, tX, TS, cst_o, a.act_o, steps, g, G, n_valid, red, a.acc_o, rep);
+            for (int u = 0; u < 2; ++u) {
+                const int r = rg + 8 * u;
+                const long long row = (g + (long long)s * G) * 16 + r;
+                const bool live = s < steps && row < n_valid;
+                f32x4_t gq, xh;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    xh[q] = (ld[s][u][1][q] - o_mean[q]) * o_inv[q];
+                    const float pre = fmaf(xh[q], o_w[q], o_b[q]);
+                    float gv = ld[s][u][0][q];
+                    if constexpr (RELU)
+                        gv = pre > 0.f ? gv : 0.f;
+                    else
+                        gv *= act_grad_rt(a.act_o, pre);
+                    gq[q] = live ? gv : 0.f;
+                    xh[q] = live ? xh[q] : 0.f;              // (a padding row may hold anything: 0 x NaN must not reach the sums)
+                    sg[q] += gq[q];
+                    sgx[q] = fmaf(gq[q], xh[q], sgx[q]);
+                }
+                *reinterpret_cast<f32x4_t *>(tG + s * TS + r * MF_LD + 4 * c4) = gq;
+                *reinterpret_cast<f32x4_t *>(tX + s * TS + r * MF_LD + 4 * c4) = xh;
+                *reinterpret_cast<f32x4_t *>(tZ + s * TS + r * MF_LD + 4 * c4) = ld[s][u][2];
+            }
+        };
+        if (a.act_o == PHC_ACT_RELU)
+            gate0(std::true_type{});
+        else
+            gate0(std::false_type{});
+        MF_STAMP(1);
+        mf_publish_sums(sg, sgx, red, a.acc_o, rep);
+    }
     MF_STAMP(2);
     mf_grid_barrier(a.bar, gen, a.err);
     MF_STAMP(3);
@@ -351,6 +416,446 @@ __global__ __launch_bounds__(MF_THREADS) void mlp_bwd_fused_kernel(MlpBwdArgs a)
     MF_STAMP(7);
 }
 
+// =====================================================================================================================
+// The FORWARD of the same node behind the aggregation:  z1 = s . H1 + b1;  a = act(norm_i(z1));  y2 = a . H2 + b2, with the
+// statistics of y2 left in an accumulator for whoever applies the model-level norm (ops.PendingNorm) — layers.py:349-355 in
+// training mode (norm.py:30-35: batch statistics over the valid rows, running statistics updated).  Two launches so far
+// (gemm_hs16<.., ST> or the aggregation-carrying gemm_hs_ag_kernel, then gemm_hs16<.., XF | ST>: 21.6 + 16.4 us at molhiv_b512);
+// here one: the rows of z1 stay in the wavefronts' REGISTERS across the one grid-wide dependency (the norm's statistics over all
+// rows), only the accumulator crosses the barrier, and the activations `a` never reach memory.
+//     P0   rows of s -> LDS;  z1 = s . H1 + b1 -> memory (the backward reads it) and registers;  column sum | sum of squares of
+//          z1 over the valid rows (double, per wavefront: it owns its 32 columns for every row) -> acc1          | barrier
+//     P1   scale / shift from the totals (bn_from_totals: one definition for every kernel); workgroup 0 leaves save_stat and the
+//          running statistics behind;  a = act(z1 scale + shift) -> LDS (rows >= *n_valid: 0);  y2 = a . H2 + b2 -> memory;
+//          statistics of y2 -> acc2
+// MFMA order, bias handling and the statistics' pivot-free double sums: z1 and y2 are bit-identical to gemm_hs16_kernel's for the
+// same operands; the totals agree to double round-off.
+struct MlpFwdArgs {
+    const float *s;                              // [N, 128]
+    const float *H1k4, *b1, *H2k4, *b2;          // k4 operands; biases [128] or NULL
+    float *z1, *y2;                              // [N, 128] out
+    unsigned long long *acc1, *acc2;             // zeroed accumulators of width 128 (acc1: this launch's own exchange)
+    BnParams p;                                  // the inner norm's parameter tables
+    float momentum, eps;
+    float *save_i;                               // [6 x 128] out (workgroup 0)
+    int act_i;
+    const int *n_valid;
+    long long N;
+    unsigned *bar;
+    int *err;
+    unsigned long long *stamps;
+    // ---- AGG: the layer's sum aggregation builds the rows of s inside the launch (messagepassing.py:132-146, identity message
+    // function; encoder.py:31-34): s[d] = sum_{e: dst_e = d} (x[src_e] + sum_f table_f[code_f(e)]) (+ x[d]), x either a tensor or the
+    // un-applied  act(norm_o(y)) (+ skip)  of the layer in front (nacc != NULL; models.py:208-215) — what aggregate_encp_direct_fwd /
+    // aggregate_norm_direct_fwd (encoder.hip) compute in a launch of their own, same edge order and additions: s is bit-identical ----
+    const float *x;                              // [N, 128] gathered tensor, or the pending norm's input y
+    const unsigned *codes;                       // [E] packed bond codes, destination-sorted
+    const float *const *tables;                  // device [n F] table pointers
+    const float *tp[16];                         // ... the same pointers by value (n F <= 16): no pointer hop in front of the table rows
+    const int *rowptr, *col;
+    const int *ell;                              // [N][8]: the first four in-edges of every row (sources | codes), csr.hip
+    int F, R, off[5], n_cmp, k, add_self;
+    float *s_out;                                // [N, 128] out
+    const unsigned long long *nacc;              // pending norm: the accumulator its producing GEMM filled; NULL: x is a tensor
+    BnParams po;
+    float mom_o, eps_o;
+    int act_o;
+    const float *skip;                           // [N, 128] or NULL
+    float *stat_o, *x_out;                       // [6 x 128], [N, 128] out
+};
+constexpr int MF_AGG_MAX_R = 32;                 // bond-table rows staged in LDS
+
+// sum over the 16 lanes that share kq (xor offsets 1, 2, 4, 8 stay inside the group)
+__device__ __forceinline__ double mf_sum16(double v) {
+#pragma unroll
+    for (int off = 1; off < 16; off <<= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// column sums / sums of squares (double) of this wavefront's 32 columns over the workgroup's valid rows -> accumulator.  A lane holds
+// one row (c) of 8 columns per step; the 16 rows meet through LDS (wred: [16 rows][64 (column, quantity)] doubles of this wavefront):
+// as 4 x 16 dependent cross-lane shuffles of doubles the reduction took 3.2 us of the launch (scripts/dbg/mlp_fwd_phases.py).
+// Lane L then owns (column L / 2, quantity L % 2) and adds its 16 rows in row order: one fixed tree.
+template <int MAXS>
+__device__ __forceinline__ void mf_column_stats(const f32x4_t (&v)[MAXS][2], int steps, long long step0, long long gstride, long long n_valid,
+                                                int c, int kq, int col0, double *wred, unsigned long long *acc, int rep) {
+    double S[2][4], Q[2][4];
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) S[t][q] = Q[t][q] = 0.0;
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) {
+        const long long row = (step0 + s * gstride) * 16 + c;
+        if (s < steps && row < n_valid) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const double d = (double)v[s][t][q];
+                    S[t][q] += d;
+                    Q[t][q] = fma(d, d, Q[t][q]);
+                }
+        }
+    }
+    // wred[c][2 * lc + qty], lc = 16 t + 4 kq + q the wavefront's local column; row stride 66 doubles (the 16 lanes of a kq group
+    // write 16 different rows: 66 x 8 bytes apart = 2 banks off per row)
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int lc = 16 * t + 4 * kq + q;
+            wred[c * 66 + 2 * lc] = S[t][q];
+            wred[c * 66 + 2 * lc + 1] = Q[t][q];
+        }
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");        // (the wavefront's own LDS writes: no workgroup barrier needed)
+    const int lane = 16 * kq + c;
+    double mine = 0.0;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) mine += wred[r * 66 + lane];
+    stat_acc_add(acc, MF_H, rep, lane & 1, col0 + (lane >> 1), mine);
+}
+
+template <int MAXS, bool AGG>
+__global__ __launch_bounds__(MF_THREADS, 2) void mlp_fwd_fused_kernel(MlpFwdArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float *tS = sm;                                          // [MAXS] tiles: s, then a
+    float *ss = sm + (size_t)MAXS * MF_TILE;                 // scale | shift [2][128]
+    double *wred = reinterpret_cast<double *>(ss + 2 * MF_H) + (size_t)(threadIdx.x >> 6) * (16 * 66);   // per wavefront [16][66] doubles
+    float *ss_o = reinterpret_cast<float *>(reinterpret_cast<double *>(ss + 2 * MF_H) + (size_t)MF_WAVES * 16 * 66);   // AGG: the pending norm's scale | shift
+    float *tbl = ss_o + 2 * MF_H;                            // AGG: bond tables [R][128]
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int c = lane & 15, kq = lane >> 4, col0 = 32 * wave;
+    const int c4 = tid & 31, rg = tid >> 5;
+    // workgroup -> rows: MAXS consecutive 16-row steps, and the workgroups of one XCD (block ids congruent mod 8) a CONTIGUOUS range of
+    // them (phc_common.h: xcd_contiguous_block; the grid is a multiple of 8) — a molecule's atoms are consecutive rows and its bonds
+    // stay inside it, so the rows the aggregation gathers come from that XCD's L2 (round-robin steps made every XCD touch every row:
+    // the gather rounds ran at Infinity-Cache bandwidth, 19 us in front of the first GEMM)
+    const long long N = a.N, g = blockIdx.x;
+    const long long lb = xcd_contiguous_block(blockIdx.x, gridDim.x), G = 1;
+    const long long num_steps = (N + 15) / 16;
+    const long long gs = lb * MAXS;                          // first step of this workgroup
+    const int steps = (int)max(0LL, min((long long)MAXS, num_steps - gs));
+    unsigned gen = 0;
+    if (tid == 0) gen = __hip_atomic_load(a.bar + (MF_SUB + 1 + g % MF_SUB) * MF_BSTRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const long long n_valid = a.n_valid ? min((long long)*a.n_valid, N) : N;
+    const int rep = (int)(g % STAT_ACC_REP);
+    const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+    MF_STAMP(0);
+    // ---- P0 ----
+    f32x4_t ld[MAXS][2];
+    BnFromTotals bt_o = {};
+    float ow = 1.f, ob = 0.f;
+    if constexpr (!AGG) {
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const long long row = min((gs + (long long)min(s, max(steps - 1, 0)) * G) * 16 + rg + 8 * u, N - 1);
+                ld[s][u] = *reinterpret_cast<const f32x4_t *>(a.s + (size_t)row * MF_H + 4 * c4);
+            }
+    } else {
+        // One row per 32-lane group (this thread: columns 4 c4 .. + 3 of rows rg, rg + 8 of every step).  Dependent chain:
+        // row pointers -> sources | codes of the first four edges -> rows (two rounds of two edges, all four rows of the thread in
+        // flight together); meanwhile the bond tables go to LDS and the pending norm's scale / shift are derived from its totals.
+        const bool normed = a.nacc != nullptr;
+        const long long count = n_valid;
+        long long dj[MAXS * 2];
+        int eb[MAXS * 2], deg[MAXS * 2];
+        int src[MAXS * 2][4];
+        unsigned code[MAXS * 2][4];
+        // round trip 1: row pointers AND the row's first four edges (ell: csr.hip writes them side by side per row)
+#pragma unroll
+        for (int j = 0; j < MAXS * 2; ++j) {
+            const int sI = j >> 1, u = j & 1;
+            const long long d = (gs + (long long)sI * G) * 16 + rg + 8 * u;
+            const bool ok = sI < steps && d < N;
+            dj[j] = ok ? d : -1;
+            const long long dc = ok ? d : 0;
+            eb[j] = a.rowptr[dc];
+            deg[j] = ok ? a.rowptr[dc + 1] - eb[j] : 0;
+            const int4 es = *reinterpret_cast<const int4 *>(a.ell + dc * 8), ec = *reinterpret_cast<const int4 *>(a.ell + dc * 8 + 4);
+            src[j][0] = es.x; src[j][1] = es.y; src[j][2] = es.z; src[j][3] = es.w;
+            code[j][0] = (unsigned)ec.x; code[j][1] = (unsigned)ec.y; code[j][2] = (unsigned)ec.z; code[j][3] = (unsigned)ec.w;
+        }
+        // bond tables -> LDS: row r of feature f(r), component cc = column / k.  All of a thread's entries travel together (clamped,
+        // unrolled; pointers out of the kernel arguments by constant index: as a run-time loop with a pointer hop per entry the staging
+        // alone was four dependent round trips, 16 us in front of the gather)
+        {
+            f32x4_t tv[MF_AGG_MAX_R * 32 / MF_THREADS];
+#pragma unroll
+            for (int it = 0; it < MF_AGG_MAX_R * 32 / MF_THREADS; ++it) {
+                const int e = min(tid + it * MF_THREADS, a.R * 32 - 1);
+                const int r = e >> 5, q = e & 31, cc = (4 * q) / a.k, kk = 4 * q - cc * a.k;
+                int f = 0, o = 0;
+#pragma unroll
+                for (int u = 1; u < 4; ++u) {
+                    const bool past = u < a.F && r >= a.off[u];
+                    f = past ? u : f;
+                    o = past ? a.off[u] : o;
+                }
+                const int ti = cc * a.F + f;
+                const float *base = a.tp[0];
+#pragma unroll
+                for (int u = 1; u < 16; ++u) base = ti == u ? a.tp[u] : base;
+                tv[it] = *reinterpret_cast<const f32x4_t *>(base + (size_t)(r - o) * a.k + kk);
+            }
+#pragma unroll
+            for (int it = 0; it < MF_AGG_MAX_R * 32 / MF_THREADS; ++it) {
+                const int e = tid + it * MF_THREADS;
+                if (e < a.R * 32) *reinterpret_cast<f32x4_t *>(tbl + (e >> 5) * MF_H + 4 * (e & 31)) = tv[it];
+            }
+        }
+        if (normed && tid < MF_H) {
+            double S = 0.0, Q = 0.0;
+#pragma unroll
+            for (int rp = 0; rp < STAT_ACC_REP; ++rp) {      // (the totals of the launch in front: plain loads across a kernel boundary)
+                S += stat_acc_part(a.nacc, MF_H, rp, 0, tid);
+                Q += stat_acc_part(a.nacc, MF_H, rp, 1, tid);
+            }
+            const int comp = tid / a.po.k, kk = tid - comp * a.po.k;
+            if (a.po.has_weight) ow = *bn_col_ptr(a.po.weight, a.po.flat, comp, kk, tid);
+            if (a.po.has_bias) ob = *bn_col_ptr(a.po.bias, a.po.flat, comp, kk, tid);
+            bt_o = bn_from_totals(S, Q, count, ow, ob, a.eps_o);
+            ss_o[tid] = bt_o.scale;
+            ss_o[MF_H + tid] = bt_o.shift;
+        }
+        MF_STAMP(8);
+        mf_lds_barrier();                                    // tables and scale / shift are in LDS
+        MF_STAMP(9);
+        const f32x4_t sc = normed ? *reinterpret_cast<const f32x4_t *>(ss_o + 4 * c4) : zero;
+        const f32x4_t sh = normed ? *reinterpret_cast<const f32x4_t *>(ss_o + MF_H + 4 * c4) : zero;
+        const float *skp = a.skip ? a.skip : a.x;            // (without a skip the second load re-reads y: the loads stay unconditional)
+        // one normalised row slice: act(y scale + shift) (+ skip), 0 for a padding row; the plain tensor otherwise
+        // KIND 0: a plain tensor; 1: relu(norm) (+ skip); 2: any other activation
+        auto xrow = [&](auto kind_c, long long r, const f32x4_t yv, const f32x4_t kv) __attribute__((always_inline)) {
+            constexpr int KIND = decltype(kind_c)::value;
+            if constexpr (KIND == 0) {
+                return yv;
+            } else {
+                f32x4_t o;
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const float pre = fmaf(yv[q], sc[q], sh[q]);
+                    o[q] = KIND == 1 ? fmaxf(pre, 0.f) : act_fwd_rt(a.act_o, pre);
+                    if (a.skip) o[q] += kv[q];
+                    if (r >= count) o[q] = 0.f;
+                }
+                return o;
+            }
+        };
+        auto add_tables = [&](f32x4_t &v, unsigned cd) __attribute__((always_inline)) {
+#pragma unroll
+            for (int f = 0; f < 4; ++f)
+                if (f < a.F) v += *reinterpret_cast<const f32x4_t *>(tbl + ((cd >> (8 * f)) & 255u) * MF_H + 4 * c4);
+        };
+        // round trips 2 and 3: the row itself and its first four sources (slots past the degree name the row itself: lines it loads
+        // anyway), one STEP's two rows at a time — all four rows in flight are 160 registers beside the sources and codes: 13 spilled
+        // values whose scratch traffic sat in the middle of the gather (9 us between issuing the loads and the sums).  Additions in the
+        // row walker's order (acc0: edges 0, 2, 3, ...; acc1: edge 1)
+        f32x4_t self_keep[MAXS * 2];
+        auto gather = [&](auto kind_c) __attribute__((always_inline)) {
+#pragma unroll
+        for (int sI = 0; sI < MAXS; ++sI) {
+            f32x4_t ys[2], ks[2], ye[2][4], ke[2][4];
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int j = 2 * sI + u;
+                const long long dc = dj[j] >= 0 ? dj[j] : 0;
+                ys[u] = *reinterpret_cast<const f32x4_t *>(a.x + (size_t)dc * MF_H + 4 * c4);
+                ks[u] = *reinterpret_cast<const f32x4_t *>(skp + (size_t)dc * MF_H + 4 * c4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    ye[u][i] = *reinterpret_cast<const f32x4_t *>(a.x + (size_t)src[j][i] * MF_H + 4 * c4);
+                    ke[u][i] = *reinterpret_cast<const f32x4_t *>(skp + (size_t)src[j][i] * MF_H + 4 * c4);
+                }
+            }
+            if (sI == 0) MF_STAMP(10);
+            if (a.stamps) {                                  // diagnostics: the loads' arrival apart from the arithmetic behind it
+                asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                if (sI == 0) MF_STAMP(12); else MF_STAMP(14);
+            }
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int j = 2 * sI + u;
+                const f32x4_t selfv = xrow(kind_c, dj[j] >= 0 ? dj[j] : 0, ys[u], ks[u]);
+                f32x4_t v[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    v[i] = xrow(kind_c, src[j][i], ye[u][i], ke[u][i]);
+                    add_tables(v[i], code[j][i]);
+                }
+                f32x4_t acc0 = deg[j] > 0 ? v[0] : zero;
+                const f32x4_t acc1 = deg[j] > 1 ? v[1] : zero;
+                if (deg[j] > 2) acc0 += v[2];
+                if (deg[j] > 3) acc0 += v[3];
+                for (int e = eb[j] + 4; e < eb[j] + deg[j]; ++e) {   // a row with more than four in-edges: one at a time (rare on molecules)
+                    const int sJ = a.col[e];
+                    const unsigned cd = a.codes[e];
+                    f32x4_t vv = xrow(kind_c, sJ, *reinterpret_cast<const f32x4_t *>(a.x + (size_t)sJ * MF_H + 4 * c4),
+                                      *reinterpret_cast<const f32x4_t *>(skp + (size_t)sJ * MF_H + 4 * c4));
+                    add_tables(vv, cd);
+                    acc0 += vv;
+                }
+                f32x4_t a4 = acc0 + acc1;
+                if (a.add_self) a4 += selfv;
+                if (dj[j] < 0) a4 = zero;
+                ld[sI][u] = a4;
+                self_keep[j] = selfv;
+            }
+            if (sI == 0) MF_STAMP(13);
+        }
+        MF_STAMP(15);
+        };
+        if (!normed)
+            gather(std::integral_constant<int, 0>{});
+        else if (a.act_o == PHC_ACT_RELU)
+            gather(std::integral_constant<int, 1>{});
+        else
+            gather(std::integral_constant<int, 2>{});
+        // every store BEHIND every load: hipcc cannot prove x_out / s_out distinct from x / skip and drains the stores (a full
+        // s_waitcnt vmcnt(0): two microseconds of store completion) in front of every later load — per row that was 9 us of the gather
+#pragma unroll
+        for (int j = 0; j < MAXS * 2; ++j)
+            if (dj[j] >= 0) {
+                if (normed) *reinterpret_cast<f32x4_t *>(a.x_out + (size_t)dj[j] * MF_H + 4 * c4) = self_keep[j];   // x itself, once
+                *reinterpret_cast<f32x4_t *>(a.s_out + (size_t)dj[j] * MF_H + 4 * c4) = ld[j >> 1][j & 1];
+            }
+        MF_STAMP(11);
+    }
+    // the norm's affine parameters of column tid (unconditional loads; without a table the running mean's address is read)
+    float nw = 1.f, nb = 0.f;
+    if (tid < MF_H) {
+        const int comp = tid / a.p.k, kk = tid - comp * a.p.k;
+        if (a.p.has_weight) nw = *bn_col_ptr(a.p.weight, a.p.flat, comp, kk, tid);
+        if (a.p.has_bias) nb = *bn_col_ptr(a.p.bias, a.p.flat, comp, kk, tid);
+    }
+    f32x4_t bias1[2], bias2[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+        bias1[t] = a.b1 ? *reinterpret_cast<const f32x4_t *>(a.b1 + col0 + 16 * t + 4 * kq) : zero;
+        bias2[t] = a.b2 ? *reinterpret_cast<const f32x4_t *>(a.b2 + col0 + 16 * t + 4 * kq) : zero;
+    }
+    // (AGG: the operand slices go in flight behind the gather — its rounds need the registers)
+    f32x4_t hreg[2][8], hreg2[2][8];
+    mf_load_operand(a.H1k4, col0, c, kq, hreg);
+    mf_load_operand(a.H2k4, col0, c, kq, hreg2);
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s)
+#pragma unroll
+        for (int u = 0; u < 2; ++u) *reinterpret_cast<f32x4_t *>(tS + s * MF_TILE + (rg + 8 * u) * MF_LD + 4 * c4) = ld[s][u];
+    mf_lds_barrier();
+    MF_STAMP(1);
+    f32x4_t z[MAXS][2];
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) {
+        z[s][0] = z[s][1] = zero;
+        if (s < steps) {
+            mf_gemm_tile_bias(tS + s * MF_TILE, hreg, c, kq, bias1, z[s]);
+            const long long row = (gs + (long long)s * G) * 16 + c;
+            if (row < N) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) *reinterpret_cast<f32x4_t *>(a.z1 + (size_t)row * MF_H + col0 + 16 * t + 4 * kq) = z[s][t];
+            }
+        }
+    }
+    MF_STAMP(2);
+    mf_column_stats<MAXS>(z, steps, gs, G, n_valid, c, kq, col0, wred, a.acc1, rep);
+    MF_STAMP(3);
+    mf_grid_barrier(a.bar, gen, a.err);
+    MF_STAMP(4);
+    // ---- P1 ----
+    BnFromTotals bt = {};
+    if (tid < MF_H) {
+        double S, Q;
+        mf_totals(a.acc1, tid, S, Q);
+        bt = bn_from_totals(S, Q, n_valid, nw, nb, a.eps);
+        ss[tid] = bt.scale;
+        ss[MF_H + tid] = bt.shift;
+    }
+    mf_lds_barrier();
+    {
+        auto xf = [&](auto relu_c) __attribute__((always_inline)) {
+        constexpr bool RELU = decltype(relu_c)::value;
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            const f32x4_t sc = *reinterpret_cast<const f32x4_t *>(ss + col0 + 16 * t + 4 * kq);
+            const f32x4_t sh = *reinterpret_cast<const f32x4_t *>(ss + MF_H + col0 + 16 * t + 4 * kq);
+#pragma unroll
+            for (int s = 0; s < MAXS; ++s) {
+                if (s < steps) {
+                    const long long row = (gs + (long long)s * G) * 16 + c;
+                    f32x4_t v;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float pre = fmaf(z[s][t][q], sc[q], sh[q]);
+                        v[q] = row < n_valid ? (RELU ? fmaxf(pre, 0.f) : act_fwd_rt(a.act_i, pre)) : 0.f;
+                    }
+                    *reinterpret_cast<f32x4_t *>(tS + s * MF_TILE + c * MF_LD + col0 + 16 * t + 4 * kq) = v;
+                }
+            }
+        }
+        };
+        if (a.act_i == PHC_ACT_RELU)
+            xf(std::true_type{});
+        else
+            xf(std::false_type{});
+    }
+    mf_lds_barrier();
+    MF_STAMP(5);
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) {
+        z[s][0] = z[s][1] = zero;
+        if (s < steps) {
+            mf_gemm_tile_bias(tS + s * MF_TILE, hreg2, c, kq, bias2, z[s]);
+            const long long row = (gs + (long long)s * G) * 16 + c;
+            if (row < N) {
+#pragma unroll
+                for (int t = 0; t < 2; ++t) *reinterpret_cast<f32x4_t *>(a.y2 + (size_t)row * MF_H + col0 + 16 * t + 4 * kq) = z[s][t];
+            }
+        }
+    }
+    MF_STAMP(6);
+    mf_column_stats<MAXS>(z, steps, gs, G, n_valid, c, kq, col0, wred, a.acc2, rep);
+    MF_STAMP(7);
+    // what the norm leaves behind (save_stat, the running statistics' read-modify-write): by the LAST workgroup — the one with the
+    // fewest rows — behind everything else it does; on workgroup 0's path in front of the second GEMM this was 4.4 us of the launch
+    if (lb == (long long)gridDim.x - 1) {
+        if (tid < MF_H) {
+            float *st = a.save_i;
+            st[tid] = bt.mean; st[MF_H + tid] = bt.invstd; st[2 * MF_H + tid] = bt.scale; st[3 * MF_H + tid] = bt.shift;
+            st[4 * MF_H + tid] = nw; st[5 * MF_H + tid] = nb;
+            if (a.p.has_running) {
+                const int comp = tid / a.p.k, kk = tid - comp * a.p.k;
+                float *rm = bn_col_ptr(a.p.running_mean, a.p.flat, comp, kk, tid), *rv = bn_col_ptr(a.p.running_var, a.p.flat, comp, kk, tid);
+                *rm = bn_running_update(*rm, a.momentum, bt.mean);
+                *rv = bn_running_update(*rv, a.momentum, bt.unbiased);
+            }
+        }
+        if (a.p.has_nbt && tid < a.p.n_comp)
+            for (int q = 0; q < a.p.n_comp; ++q)
+                if (q == tid) *a.p.num_batches_tracked[q] += 1;
+        if constexpr (AGG) {
+            if (a.nacc) {                                    // ... and the pending norm of the layer in front
+                if (tid < MF_H) {
+                    float *st = a.stat_o;
+                    st[tid] = bt_o.mean; st[MF_H + tid] = bt_o.invstd; st[2 * MF_H + tid] = bt_o.scale; st[3 * MF_H + tid] = bt_o.shift;
+                    st[4 * MF_H + tid] = ow; st[5 * MF_H + tid] = ob;
+                    if (a.po.has_running) {
+                        const int comp = tid / a.po.k, kk = tid - comp * a.po.k;
+                        float *rm = bn_col_ptr(a.po.running_mean, a.po.flat, comp, kk, tid), *rv = bn_col_ptr(a.po.running_var, a.po.flat, comp, kk, tid);
+                        *rm = bn_running_update(*rm, a.mom_o, bt_o.mean);
+                        *rv = bn_running_update(*rv, a.mom_o, bt_o.unbiased);
+                    }
+                }
+                if (a.po.has_nbt && tid < a.po.n_comp)
+                    for (int q = 0; q < a.po.n_comp; ++q)
+                        if (q == tid) *a.po.num_batches_tracked[q] += 1;
+            }
+        }
+    }
+}
+
 // ---- host ----------------------------------------------------------------------------------------------------
 constexpr int MF_MAXS = 2;
 
@@ -380,9 +885,36 @@ using namespace phc;
 
 static unsigned long long *g_mf_stamps = nullptr;
 
+static size_t mf_fwd_lds_bytes(bool agg = false) {
+    return sizeof(float) * ((size_t)MF_MAXS * MF_TILE + 2 * MF_H) + sizeof(double) * (size_t)MF_WAVES * 16 * 66 +
+           (agg ? sizeof(float) * (size_t)(2 * MF_H + MF_AGG_MAX_R * MF_H) : 0);
+}
+template <typename K>
+static int mf_capacity_of(K kernel, int *cache, size_t lds, const char *switch_env) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
+    if (cache[dev] == 0) {
+        int per_cu = 0;
+        hipDeviceProp_t prop;
+        const bool off = getenv(switch_env) && atoi(getenv(switch_env)) == 0;
+        if (off || !ensure_dynamic_lds(kernel, lds) || hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, MF_THREADS, lds) != hipSuccess ||
+            hipGetDeviceProperties(&prop, dev) != hipSuccess || getenv("HSA_CU_MASK") || getenv("ROC_GLOBAL_CU_MASK"))
+            cache[dev] = -1;
+        else
+            cache[dev] = (per_cu > 2 ? 2 : per_cu) * prop.multiProcessorCount;
+        if (cache[dev] == 0) cache[dev] = -1;
+    }
+    return cache[dev] > 0 ? cache[dev] : 0;
+}
+static int mf_fwd_capacity(bool agg) {
+    static int cap[2][64];
+    return agg ? mf_capacity_of(&mlp_fwd_fused_kernel<MF_MAXS, true>, cap[1], mf_fwd_lds_bytes(true), "PHC_MLP_FWD_FUSED")
+               : mf_capacity_of(&mlp_fwd_fused_kernel<MF_MAXS, false>, cap[0], mf_fwd_lds_bytes(false), "PHC_MLP_FWD_FUSED");
+}
+
 extern "C" {
 
-/* diagnostics only: 16 device words that workgroups 0 and G - 1 of every phc_mlp_norm_bwd_fused launch stamp (100 MHz clock) */
+/* diagnostics only: 32 device words that workgroups 0 and G - 1 of every phc_mlp_norm_bwd_fused launch stamp (100 MHz clock) */
 int phc_debug_mlp_bwd_stamps(unsigned long long *dev_words) {
     g_mf_stamps = dev_words;
     return PHC_OK;
@@ -423,6 +955,88 @@ int phc_mlp_norm_bwd_fused(const phc_mlp_norm_bwd_desc *d, void *stream) {
     ProfScope prof(K_PHM_GEMM_DX, s);
     PHC_LAUNCH(mlp_bwd_fused_kernel<MF_MAXS>, dim3((unsigned)groups), dim3(MF_THREADS), lds, s, a);
     return check_launch("mlp_norm_bwd_fused");
+}
+
+static long long mf_fwd_groups(long long N) {
+    const long long steps = (N + 15) / 16;
+    return xcd_grid((steps + MF_MAXS - 1) / MF_MAXS);        // (a multiple of 8: xcd_contiguous_block)
+}
+int phc_mlp_norm_fwd_fused_supported(int64_t N, int h) {
+    if (h != MF_H || N < 1) return 0;
+    return mf_fwd_groups(N) <= mf_fwd_capacity(false) ? 1 : 0;
+}
+/* ... with the layer's aggregation inside the launch (phc_mlp_norm_fwd_desc.codes != NULL): F bond features, vocab_rows = sum(vocab) */
+int phc_mlp_norm_fwd_fused_agg_supported(int64_t N, int h, int n, int F, int vocab_rows) {
+    if (h != MF_H || N < 1 || N >= (1LL << 31) || n < 1 || h % n || (h / n) % 4 || F < 1 || F > 4 || vocab_rows < 1 || vocab_rows > MF_AGG_MAX_R) return 0;
+    return mf_fwd_groups(N) <= mf_fwd_capacity(true) ? 1 : 0;
+}
+
+int phc_mlp_norm_fwd_fused(const phc_mlp_norm_fwd_desc *d, void *stream) {
+    PHC_REQUIRE(d, PHC_ERR_INVALID_ARG, "phc_mlp_norm_fwd_fused: null descriptor");
+    const bool agg = d->codes != nullptr;
+    MlpFwdArgs a = {};
+    if (agg) {
+        PHC_REQUIRE(d->vocab && d->F >= 1 && d->F <= 4 && d->n >= 1, PHC_ERR_INVALID_ARG, "phc_mlp_norm_fwd_fused: aggregation needs vocab, 1 <= F <= 4");
+        a.F = d->F;
+        a.off[0] = 0;
+        for (int f = 0; f < d->F; ++f) {
+            PHC_REQUIRE(d->vocab[f] >= 1, PHC_ERR_INVALID_ARG, "phc_mlp_norm_fwd_fused: vocab[%d] = %d", f, d->vocab[f]);
+            a.off[f + 1] = a.off[f] + d->vocab[f];
+        }
+        a.R = a.off[d->F];
+        PHC_REQUIRE(phc_mlp_norm_fwd_fused_agg_supported(d->N, d->h, d->n, d->F, a.R), PHC_ERR_UNSUPPORTED,
+                    "phc_mlp_norm_fwd_fused: N=%lld h=%d n=%d F=%d sum(vocab)=%d outside the aggregating form's range", (long long)d->N, d->h, d->n,
+                    d->F, a.R);
+        PHC_REQUIRE(d->x && d->tables && d->rowptr && d->col && d->s_out, PHC_ERR_INVALID_ARG, "phc_mlp_norm_fwd_fused: null aggregation pointer");
+        const bool normed = d->norm_acc != nullptr;
+        PHC_REQUIRE(!normed || (d->save_stat_o && d->x_out && d->norm_act >= PHC_ACT_IDENTITY && d->norm_act <= PHC_ACT_SELU), PHC_ERR_INVALID_ARG,
+                    "phc_mlp_norm_fwd_fused: a pending norm needs save_stat_o, x_out and an activation");
+        PHC_REQUIRE(((reinterpret_cast<uintptr_t>(d->x) | reinterpret_cast<uintptr_t>(d->s_out) |
+                      (normed ? (reinterpret_cast<uintptr_t>(d->x_out) | reinterpret_cast<uintptr_t>(d->skip)) : 0)) & 15) == 0 &&
+                        (reinterpret_cast<uintptr_t>(d->norm_acc) & 7) == 0,
+                    PHC_ERR_UNSUPPORTED, "phc_mlp_norm_fwd_fused: 16-byte aligned rows / 8-byte aligned accumulator required");
+        if (normed) {
+            int rc = fill_params("phc_mlp_norm_fwd_fused(outer)", &a.po, d->weight_o, d->bias_o, d->running_mean_o, d->running_var_o,
+                                 d->num_batches_tracked_o, d->n_comp_o, d->h);
+            if (rc) return rc;
+            a.nacc = reinterpret_cast<const unsigned long long *>(d->norm_acc);
+            a.mom_o = d->momentum_o; a.eps_o = d->eps_o; a.act_o = d->norm_act; a.skip = d->skip; a.stat_o = d->save_stat_o; a.x_out = d->x_out;
+        }
+        PHC_REQUIRE(d->ell && (reinterpret_cast<uintptr_t>(d->ell) & 15) == 0, PHC_ERR_INVALID_ARG,
+                    "phc_mlp_norm_fwd_fused: the aggregation needs the row-major edge slots (ell, phc_csr_build_pair_codes_resident_ell)");
+        a.ell = d->ell;
+        PHC_REQUIRE(d->tables_host && d->n * d->F <= 16, PHC_ERR_INVALID_ARG,
+                    "phc_mlp_norm_fwd_fused: the aggregation takes the table pointers by value (tables_host, n F <= 16)");
+        for (int i = 0; i < 16; ++i) a.tp[i] = i < d->n * d->F ? d->tables_host[i] : d->tables_host[0];
+        a.x = d->x; a.codes = d->codes; a.tables = d->tables; a.rowptr = d->rowptr; a.col = d->col; a.n_cmp = d->n; a.k = d->h / d->n;
+        a.add_self = d->add_self ? 1 : 0; a.s_out = d->s_out;
+    } else {
+        PHC_REQUIRE(phc_mlp_norm_fwd_fused_supported(d->N, d->h), PHC_ERR_UNSUPPORTED,
+                    "phc_mlp_norm_fwd_fused: N=%lld h=%d outside the one-launch form's range (h = 128, ceil(N / 32) co-resident workgroups)",
+                    (long long)d->N, d->h);
+        PHC_REQUIRE(d->s && (reinterpret_cast<uintptr_t>(d->s) & 15) == 0, PHC_ERR_INVALID_ARG, "phc_mlp_norm_fwd_fused: s");
+    }
+    PHC_REQUIRE(d->H1k4 && d->H2k4 && d->z1 && d->y2 && d->acc1 && d->acc2 && d->save_stat && d->barrier, PHC_ERR_INVALID_ARG,
+                "phc_mlp_norm_fwd_fused: null pointer");
+    PHC_REQUIRE(d->act >= PHC_ACT_IDENTITY && d->act <= PHC_ACT_SELU, PHC_ERR_INVALID_ARG, "phc_mlp_norm_fwd_fused: unknown activation %d", d->act);
+    PHC_REQUIRE(((reinterpret_cast<uintptr_t>(d->H1k4) | reinterpret_cast<uintptr_t>(d->H2k4) | reinterpret_cast<uintptr_t>(d->z1) |
+                  reinterpret_cast<uintptr_t>(d->y2) | reinterpret_cast<uintptr_t>(d->b1) | reinterpret_cast<uintptr_t>(d->b2)) & 15) == 0 &&
+                    ((reinterpret_cast<uintptr_t>(d->acc1) | reinterpret_cast<uintptr_t>(d->acc2)) & 7) == 0,
+                PHC_ERR_UNSUPPORTED, "phc_mlp_norm_fwd_fused: 16-byte aligned rows / biases, 8-byte aligned accumulators required");
+    int rc = fill_params("phc_mlp_norm_fwd_fused", &a.p, d->weight, d->bias, d->running_mean, d->running_var, d->num_batches_tracked, d->n_comp, d->h);
+    if (rc) return rc;
+    a.s = d->s; a.H1k4 = d->H1k4; a.b1 = d->b1; a.H2k4 = d->H2k4; a.b2 = d->b2; a.z1 = d->z1; a.y2 = d->y2;
+    a.acc1 = reinterpret_cast<unsigned long long *>(d->acc1); a.acc2 = reinterpret_cast<unsigned long long *>(d->acc2);
+    a.momentum = d->momentum; a.eps = d->eps; a.save_i = d->save_stat; a.act_i = d->act; a.n_valid = d->n_valid_dev; a.N = d->N;
+    a.bar = d->barrier; a.err = err_word(); a.stamps = g_mf_stamps;
+    const long long groups = mf_fwd_groups(d->N);
+    hipStream_t s = (hipStream_t)stream;
+    ProfScope prof(agg ? K_PHM_GEMM_AG : K_PHM_GEMM_FWD, s);
+    if (agg)
+        PHC_LAUNCH((mlp_fwd_fused_kernel<MF_MAXS, true>), dim3((unsigned)groups), dim3(MF_THREADS), mf_fwd_lds_bytes(true), s, a);
+    else
+        PHC_LAUNCH((mlp_fwd_fused_kernel<MF_MAXS, false>), dim3((unsigned)groups), dim3(MF_THREADS), mf_fwd_lds_bytes(false), s, a);
+    return check_launch("mlp_norm_fwd_fused");
 }
 
 }  // extern "C"

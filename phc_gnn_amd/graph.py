@@ -78,6 +78,7 @@ class EdgeStructure:
         self._codes_orig_args = None
         self._codes_src: dict = {}
         self._codes_src_args = None
+        self._ell = self._ell_t = None    # first four in- / out-edges per row (pair build with codes)
 
     def packed_codes(self, bond_idx: torch.Tensor, vocab_c, F: int) -> torch.Tensor:
         """uint32 per edge in destination-sorted order: the F table rows of the edge's integer features, one
@@ -133,6 +134,8 @@ class EdgeStructure:
                 _build_sorted(self._dst, self._src, self.num_dst, out=self._csr, num_other=self.num_src)
             if self._csc is not None:
                 _build_sorted(self._src, self._dst, self.num_src, out=self._csc, num_other=self.num_dst)
+        if not pair_rebuilt:
+            self._ell = self._ell_t = None                            # (only the pair build writes them)
         if not (pair_rebuilt and self._codes_args is not None):      # the pair launches repacked the sorted codes already
             self._code_counts = None                                  # (and the counts that go with them; stale otherwise)
             for codes in self._codes.values():
@@ -177,6 +180,7 @@ class EdgeStructure:
         self._pair_ws = ws
         codes = bond = vocab_c = counts = None
         F = 0
+        ell, ell_t = (getattr(self, "_ell", None), getattr(self, "_ell_t", None)) if reuse else (None, None)
         if reuse and self._codes and self._codes_args is not None:
             bond, vocab_c, F = self._codes_args
             codes = next(iter(self._codes.values()))
@@ -188,11 +192,18 @@ class EdgeStructure:
             rows = sum(int(v) for v in list(vocab_c)[:F])
             if rows <= 32:                                   # per-destination table-row counts (phc_step_tail's bond operand)
                 counts = torch.empty((self.num_dst, 16 if rows <= 16 else 32), dtype=torch.float32, device=dev)
-        L.check(lib.phc_csr_build_pair_codes_resident(L.ptr(self._src), L.ptr(self._dst), E, self.num_src, self.num_dst, L.ptr(csr[0]),
-                                             L.ptr(csr[1]), L.ptr(csr[2]), L.ptr(csc[0]), L.ptr(csc[1]), L.ptr(csc[2]),
-                                             L.ptr(bond), vocab_c, F, L.ptr(codes), L.ptr(counts), L.ptr(ws), ws_bytes,
-                                             L.stream_ptr(dev)),
-                "phc_csr_build_pair_codes_resident")
+            # the first four in- / out-edges of every row side by side (the aggregating fused launches read a row's edges in the round
+            # trip of its row pointers: csrc/mlp_fused.hip)
+            ell = torch.empty((self.num_dst, 8), dtype=torch.int32, device=dev)
+            ell_t = torch.empty((self.num_src, 4), dtype=torch.int32, device=dev)
+        if codes is None:
+            ell = None                                       # (ell carries the packed codes)
+        L.check(lib.phc_csr_build_pair_codes_resident_ell(L.ptr(self._src), L.ptr(self._dst), E, self.num_src, self.num_dst, L.ptr(csr[0]),
+                                                 L.ptr(csr[1]), L.ptr(csr[2]), L.ptr(csc[0]), L.ptr(csc[1]), L.ptr(csc[2]),
+                                                 L.ptr(bond), vocab_c, F, L.ptr(codes), L.ptr(counts), L.ptr(ell), L.ptr(ell_t), L.ptr(ws),
+                                                 ws_bytes, L.stream_ptr(dev)),
+                "phc_csr_build_pair_codes_resident_ell")
+        self._ell, self._ell_t = ell, ell_t
         self._code_counts = (codes, counts) if counts is not None else None
         L.maybe_check_indices(dev)
         self._csr, self._csc = csr, csc

@@ -72,6 +72,18 @@ class MlpNormBwdDesc(C.Structure):
                 ("n_valid_dev", _P), ("N", _L), ("h", C.c_int32), ("act_o", C.c_int32), ("act_i", C.c_int32), ("barrier", _P)]
 
 
+class MlpNormFwdDesc(C.Structure):
+    """phc_mlp_norm_fwd_desc (include/phc_hip.h)."""
+    _fields_ = [("s", _P), ("H1k4", _P), ("b1", _P), ("H2k4", _P), ("b2", _P), ("z1", _P), ("y2", _P), ("acc1", _P), ("acc2", _P),
+                ("weight", _P), ("bias", _P), ("running_mean", _P), ("running_var", _P), ("num_batches_tracked", _P),
+                ("n_comp", C.c_int32), ("momentum", C.c_float), ("eps", C.c_float), ("save_stat", _P), ("act", C.c_int32),
+                ("n_valid_dev", _P), ("N", _L), ("h", C.c_int32), ("barrier", _P),
+                ("x", _P), ("codes", _P), ("tables", _P), ("vocab", _P), ("rowptr", _P), ("col", _P), ("ell", _P), ("tables_host", _P), ("F", C.c_int32), ("n", C.c_int32),
+                ("add_self", C.c_int32), ("s_out", _P), ("norm_acc", _P), ("weight_o", _P), ("bias_o", _P), ("running_mean_o", _P),
+                ("running_var_o", _P), ("num_batches_tracked_o", _P), ("n_comp_o", C.c_int32), ("norm_act", C.c_int32),
+                ("momentum_o", C.c_float), ("eps_o", C.c_float), ("skip", _P), ("save_stat_o", _P), ("x_out", _P)]
+
+
 class HeadStage(C.Structure):
     """phc_head_stage (include/phc_hip.h)."""
     _fields_ = [("M", _P), ("bias", _P), ("K", C.c_int32), ("N", C.c_int32), ("post", C.c_int32), ("out", _P), ("z", _P), ("stat", _P),
@@ -185,6 +197,9 @@ SIGNATURES = {
     "phc_bn_fwd_from_moments": (_I, [_P, _L, _P, _P, _I, _L, _P, _P, _P, _P, _P, _I, _I, C.c_float, C.c_float, _I, _P, _P, _P, _P]),
     "phc_bn_bwd_sums": (_I, [_P, _P, _P, _L, _I, _I, _P, _P, _S, _P]),
     "phc_bn_bwd_apply": (_I, [_P, _P, _P, _P, _L, _L, _I, _I, _P, _P, _S, _P]),
+    "phc_mlp_norm_fwd_fused_supported": (_I, [_L, _I]),
+    "phc_mlp_norm_fwd_fused_agg_supported": (_I, [_L, _I, _I, _I, _I]),
+    "phc_mlp_norm_fwd_fused": (_I, [C.POINTER(MlpNormFwdDesc), _P]),
     "phc_mlp_norm_bwd_fused_supported": (_I, [_L, _I]),
     "phc_mlp_norm_bwd_fused": (_I, [C.POINTER(MlpNormBwdDesc), _P]),
     "phc_mlp_norm_bwd_fused_barrier_words": (_S, []),
@@ -212,6 +227,7 @@ SIGNATURES = {
     "phc_csr_build_pair": (_I, [_P, _P, _L, _L, _L, _P, _P, _P, _P, _P, _P, _P, _S, _P]),
     "phc_csr_build_pair_codes": (_I, [_P, _P, _L, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _S, _P]),
     "phc_csr_build_pair_codes_resident": (_I, [_P, _P, _L, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _S, _P]),
+    "phc_csr_build_pair_codes_resident_ell": (_I, [_P, _P, _L, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _S, _P]),
     "phc_remove_isolated_ws_bytes": (_S, [_L]),
     "phc_remove_isolated_nodes": (_I, [_P, _P, _L, _L, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _S, _P]),
     "phc_segment_ptr_sorted": (_I, [_P, _L, _L, _P, _P]),

@@ -3119,6 +3119,10 @@ def _tap(z, save_stat, n_valid, act):
 
 # the MLP + norm node's backward as ONE launch at hidden 128 (csrc/mlp_fused.hip, round 6); 0 = the three launches
 MLP_BWD_FUSED = __import__("os").environ.get("PHC_MLP_BWD_FUSED", "1") != "0"
+# ... and its forward behind the aggregation (both GEMMs + the inner norm); 0 = the two launches (the first carrying the aggregation)
+MLP_FWD_FUSED = __import__("os").environ.get("PHC_MLP_FWD_FUSED", "1") != "0"
+# ... with the layer's aggregation (and the un-applied norm of the layer in front) building the rows inside that launch; 0 = its own launch
+MLP_FWD_FUSED_AGG = __import__("os").environ.get("PHC_MLP_FWD_FUSED_AGG", "1") != "0"
 _GRID_BARRIERS: dict = {}
 
 
@@ -3150,6 +3154,62 @@ class _MLPNormFn(torch.autograd.Function):
         save_o = torch.empty(6 * h, dtype=torch.float32, device=dev)
         acc1, acc2 = _zero_acc(dev, h), _zero_acc(dev, h)
         pa = meta.pop("pending_agg", None)
+        if MLP_FWD_FUSED and h == 128 and pre1[2] is not None and pre2[2] is not None and s.data_ptr() % 16 == 0 and \
+                all(t is None or t.data_ptr() % 16 == 0 for t in (b1, b2)) and lib.phc_mlp_norm_fwd_fused_supported(N, h):
+            # both GEMMs and the inner norm in ONE launch (csrc/mlp_fused.hip): z1's rows stay in registers across the one grid-wide
+            # dependency; the aggregation runs as its own (row-walker) launch in front
+            fd = L.MlpNormFwdDesc()
+            keep_o = None
+            if pa is not None and not pa.done and MLP_FWD_FUSED_AGG and tuple(pa.out.shape) == (N, h) and \
+                    getattr(pa.st, "_ell", None) is not None and len(pa.ts.key) <= 16 and \
+                    lib.phc_mlp_norm_fwd_fused_agg_supported(N, h, pa.ts.n, pa.ts.F, pa.ts.R):
+                # ... and the layer's aggregation builds the rows of s inside it (with the un-applied norm of the layer in front)
+                ts_, (rowptr_, col_, _) = pa.ts, pa.st.csr
+                fd.codes, fd.tables, fd.vocab = L.ptr(pa.codes), L.ptr(ts_.ptrs), _C.cast(ts_.vocab_c, _C.c_void_p)
+                fd.rowptr, fd.col, fd.F, fd.n, fd.add_self, fd.s_out = L.ptr(rowptr_), L.ptr(col_), ts_.F, ts_.n, 1 if pa.add_self else 0, L.ptr(pa.out)
+                fd.ell = L.ptr(pa.st._ell)
+                tabs_host = (_C.c_void_p * len(ts_.key))(*ts_.key)          # the table pointers by value (no pointer hop in the kernel)
+                fd.tables_host = _C.cast(tabs_host, _C.c_void_p)
+                pn = pa.pending if (pa.pending is not None and not pa.pending.done) else None
+                if pn is not None:
+                    keep_o = pn._norm_args()
+                    w_o, b_o, rm_o, rv_o, nbt_o, no_ = keep_o
+                    cast_o = lambda arr: _C.cast(arr, _C.c_void_p) if arr is not None else None
+                    fd.x, fd.norm_acc = L.ptr(pn.y2), L.ptr(pn.acc2)
+                    fd.weight_o, fd.bias_o, fd.running_mean_o, fd.running_var_o, fd.num_batches_tracked_o = \
+                        cast_o(w_o), cast_o(b_o), cast_o(rm_o), cast_o(rv_o), cast_o(nbt_o)
+                    fd.n_comp_o, fd.norm_act, fd.momentum_o, fd.eps_o = no_, pn.act_o, float(pn.outer["momentum"]), float(pn.outer["eps"])
+                    fd.skip, fd.save_stat_o, fd.x_out = L.ptr(pn.skip), L.ptr(pn.save_o), L.ptr(pn.out)
+                    assert pa.x_.data_ptr() == pn.out.data_ptr()
+                else:
+                    fd.x = L.ptr(pa.x_)
+                    pn = False
+            else:
+                pn = None
+                if pa is not None:
+                    pa.materialize()
+            fd.s, fd.H1k4, fd.b1, fd.H2k4, fd.b2 = L.ptr(s), L.ptr(pre1[2]), L.ptr(b1), L.ptr(pre2[2]), L.ptr(b2)
+            fd.z1, fd.y2, fd.acc1, fd.acc2 = L.ptr(z1), L.ptr(y2), L.ptr(acc1), L.ptr(acc2)
+            keep = (_ptr_array(aff_i[:ni]) if aff_i else None, _ptr_array(aff_i[ni:]) if aff_i else None,
+                    _ptr_array(inner["running_mean"]), _ptr_array(inner["running_var"]), _ptr_array(inner["nbt"]))
+            cast = lambda arr: _C.cast(arr, _C.c_void_p) if arr is not None else None
+            fd.weight, fd.bias, fd.running_mean, fd.running_var, fd.num_batches_tracked = (cast(k_) for k_ in keep)
+            fd.n_comp, fd.momentum, fd.eps, fd.save_stat, fd.act = ni, float(inner["momentum"]), float(inner["eps"]), L.ptr(save_i), act_i
+            fd.n_valid_dev, fd.N, fd.h, fd.barrier = L.ptr(n_valid), N, h, L.ptr(_grid_barrier_words(dev))
+            L.check(lib.phc_mlp_norm_fwd_fused(_C.byref(fd), sp), "phc_mlp_norm_fwd_fused")
+            if pn is not None:                               # the aggregation (and its pending norm) ran inside the launch
+                if pn is not False:
+                    pn.done = True
+                pa.done = True
+                if L.PROF_ON:
+                    E_ = pa.st.num_edges
+                    L.account("phm_gemm_ag_fwd", 4.0 * N * h * h,
+                              4.0 * (3 * N * h + 2 * h * h + 2 * h) + E_ * (4.0 * h + 8 + 8.0 * pa.ts.F) + N * 4.0 * h * (2 if pa.add_self else 1))
+                fused_agg = "mlp+agg"
+            else:
+                fused_agg = "mlp"                            # (accounting: ONE launch of the family with both GEMMs' work)
+            return _MLPNormFn._finish_forward(ctx, s, skip, n_valid, meta, z1, y2, out, save_i, save_o, acc2, outer, aff_i, aff_o, act_i, act_o,
+                                              A1, W1, b1, A2, W2, b2, fused_agg, N, h, dev, no)
         fused_agg = pa is not None and (b1 is None or b1.data_ptr() % 16 == 0) and pa.run_with_gemm(pre1[2], b1, z1, n_valid, acc1)
         if not fused_agg:
             if pa is not None:
@@ -3161,6 +3221,12 @@ class _MLPNormFn(torch.autograd.Function):
             _ptr_array(inner["running_mean"]), _ptr_array(inner["running_var"]), _ptr_array(inner["nbt"]), ni,
             float(inner["momentum"]), float(inner["eps"]), L.ptr(save_i), act_i, L.ptr(n_valid), L.ptr(pre2[0]), L.ptr(pre2[2]),
             L.ptr(b2), N, h, h, L.ptr(y2), L.ptr(acc2), None, None, sp), "phc_gemm_prebuilt_xf_acc")
+        return _MLPNormFn._finish_forward(ctx, s, skip, n_valid, meta, z1, y2, out, save_i, save_o, acc2, outer, aff_i, aff_o, act_i, act_o,
+                                          A1, W1, b1, A2, W2, b2, fused_agg, N, h, dev, no)
+
+    @staticmethod
+    def _finish_forward(ctx, s, skip, n_valid, meta, z1, y2, out, save_i, save_o, acc2, outer, aff_i, aff_o, act_i, act_o,
+                        A1, W1, b1, A2, W2, b2, fused_agg, N, h, dev, no):
         _tap(z1, save_i, n_valid, act_i)
         _tap(y2, save_o, n_valid, act_o)
         # dropout behind the outer norm's activation (models.py:211-213): the mask rides in the norm's apply pass here and in the norm
@@ -3176,9 +3242,14 @@ class _MLPNormFn(torch.autograd.Function):
         else:
             pend.materialize()
         if L.PROF_ON:
-            if not fused_agg:
+            if fused_agg == "mlp":
+                L.account("phm_gemm_fwd", 4.0 * N * h * h, 4.0 * (3 * N * h + 2 * h * h + 2 * h))
+            elif fused_agg == "mlp+agg":
+                pass                                         # (booked where it was launched)
+            else:
+                if not fused_agg:
+                    L.account("phm_gemm_fwd", 2.0 * N * h * h, 4.0 * (2 * N * h + h * h + h))
                 L.account("phm_gemm_fwd", 2.0 * N * h * h, 4.0 * (2 * N * h + h * h + h))
-            L.account("phm_gemm_fwd", 2.0 * N * h * h, 4.0 * (2 * N * h + h * h + h))
         ctx.save_for_backward(s, z1, y2, save_i, save_o, A1, W1, A2, W2)
         ctx.meta, ctx.n_valid = meta, n_valid
         ctx.params = ((A1, W1, b1), (A2, W2, b2))

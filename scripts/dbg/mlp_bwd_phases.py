@@ -24,7 +24,7 @@ dy2, dz1, ds, da = (torch.empty(N, h, device=dev) for _ in range(4))
 dwb_o, dwb_i = torch.empty(2 * h, device=dev), torch.empty(2 * h, device=dev)
 words = lib.phc_stat_acc_words(h)
 bar = torch.zeros(lib.phc_mlp_norm_bwd_fused_barrier_words(), dtype=torch.int32, device=dev)
-stamps = torch.zeros(16, dtype=torch.int64, device=dev)
+stamps = torch.zeros(32, dtype=torch.int64, device=dev)
 act = 1
 
 def fused(acc_o, acc_i):
@@ -90,7 +90,7 @@ for i in range(10):
     rows.append(stamps.clone().cpu())
 lib.phc_debug_mlp_bwd_stamps(None)
 names = ["rows in LDS", "sums_o issued", "barrier 1", "P1 done (dz_o, MFMA, da)", "sums_i issued", "barrier 2", "end"]
-for which, off in (("wg0", 0), ("wgLast", 8)):
+for which, off in (("wg0", 0), ("wgLast", 16)):
     med = []
     for j in range(1, 8):
         v = sorted(float(r[off + j] - r[off + j - 1]) / 100.0 for r in rows)

@@ -34,7 +34,7 @@ def from_trace(path, steps, top):
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     names = [r["Kernel_Name"] for r in rows]
-    marker = next((n for n in set(names) if "opt_adam_kernel" in n), None)
+    marker = next((n for n in set(names) if ("opt_adam_kernel" in n or "opt_clip_adam_fused_kernel" in n)), None)
     if marker is None:
         cnt = defaultdict(int)
         for n in names:
