@@ -321,7 +321,7 @@ def test_hs_norm_backward_folded_into_the_dx_gemm(N, valid, K, Nout, act, act_in
     assert torch.equal(dz_b, dz) and torch.equal(y_b, y)
 
 
-@pytest.mark.parametrize("wl", ["molhiv_b32", "molhiv_b512", "zinc_b1024", "zinc_pub_phc4_4x180_nodrop", "zinc_pub_phc5_4x200_nodrop"])
+@pytest.mark.parametrize("wl", ["molhiv_b32", "molhiv_b512", "molhiv_b512_swish", "zinc_b1024", "zinc_pub_phc4_4x180_nodrop", "zinc_pub_phc5_4x200_nodrop"])
 def test_fused_mlp_norm_node_equals_the_separate_nodes(wl):
     """One training step with the PHMMLP + model norm of every layer as ONE autograd node (ops.mlp_norm_fused: both norm
     backwards folded into the dx GEMMs) against the same step on the separate nodes: loss, every gradient, running statistics."""
@@ -348,7 +348,11 @@ def test_fused_mlp_norm_node_equals_the_separate_nodes(wl):
     assert g1.keys() == g0.keys() and len(g1) > 50
     keep = [k for k in g0 if not (k.endswith(".b") and k not in ("pooling.linear.b", "downstream.affine.2.b")) and float(g0[k].abs().max()) > 0]
     worst, worst_key = max((relerr(g1[k], g0[k]), k) for k in keep)
-    # fp32 noise through the batch-norms and ReLU kinks (cf. tests/test_gpu_stat_accumulators.py): a wrong formula shows as 1e-1
-    assert worst < 1e-3, (worst, worst_key)
+    # fp32 noise through the batch-norms and ReLU kinks (cf. tests/test_gpu_stat_accumulators.py): a wrong formula shows as 1e-1.
+    # At hidden 128 the fused node runs on the one-launch kernels (csrc/mlp_fused.hip, round 6), whose statistics are summed in double:
+    # against the separate nodes' fp32 partials a few more elements sit on the other side of a ReLU kink (1e-2 on a norm bias's
+    # gradient, seen); the smooth twin shows the formulas agree to round-off.
+    bound = 3e-5 if "swish" in wl else (2e-2 if harness.WORKLOADS[wl]["hidden"] == 128 else 1e-3)
+    assert worst < bound, (worst, worst_key)
     for k in s0:
         assert_close(s1[k], s0[k], 1e-5, k)
