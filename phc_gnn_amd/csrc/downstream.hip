@@ -1541,9 +1541,9 @@ static inline bool dn2_enabled() {
     static const bool off = getenv("PHC_DOWNSTREAM_V2") && atoi(getenv("PHC_DOWNSTREAM_V2")) == 0;
     return !off;
 }
-// rows per workgroup: 16 (RB = 1) up to 1280 rows, 32 above (at most D2_MAX_WG workgroups).  PHC_DN2_RB=2 / =1 force 32- / 16-row workgroups.
+// rows per workgroup: 16 (RB = 1) up to 1280 rows, 32 above (at most D2_MAX_WG workgroups).
 static inline int dn2_rb(int B) {
-    static const int forced = getenv("PHC_DN2_RB") ? atoi(getenv("PHC_DN2_RB")) : 0;
+    constexpr int forced = 0;
     if (forced == 1 && (B + 15) / 16 <= D2_MAX_WG) return 1;
     // (1280, not 1024: the graph-replay batch of configs[2] is 1024 + 32 padding graphs — on 33 workgroups of 32 rows its head took
     // 65 + 63 us of the step, on 66 of 16 rows zinc_b1024 is 1.870 -> 1.848 ms)

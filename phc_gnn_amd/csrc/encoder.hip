@@ -1446,7 +1446,7 @@ struct TgPlan {
 // register-resident atom form: tiles = (M groups of 96 table rows) x (64-column tiles), one workgroup per (tile, split), about 256
 // workgroups, every split the same number of nodes (a multiple of 8: four wavefront quarters starting on even nodes)
 static bool tg_direct_shape_ok(long long n_items, int h) {
-    static const bool off = getenv("PHC_TG_NO_DIRECT") != nullptr;
+    constexpr bool off = false;
     return !off && h % 64 == 0 && n_items >= 8;
 }
 static TgPlan tg_plan_direct(long long n_items, int R, int h) {
@@ -1454,7 +1454,7 @@ static TgPlan tg_plan_direct(long long n_items, int R, int h) {
     p.tiles_i = (R + 32 * TD_MB - 1) / (32 * TD_MB);
     p.tiles_j = h / 64;
     const long long tiles = (long long)p.tiles_i * p.tiles_j;
-    static const long long target = getenv("PHC_TG_DIRECT_TARGET") ? atoll(getenv("PHC_TG_DIRECT_TARGET")) : 256;
+    constexpr long long target = 256;
     long long ips = ((n_items * tiles + target - 1) / target + 7) / 8 * 8;
     if (ips < 8) ips = 8;
     const size_t cap_slabs = ((size_t)16 << 20) / (sizeof(float) * (size_t)R * h);       // <= 16 MB of slabs
@@ -1472,7 +1472,7 @@ static TgPlan tg_plan_direct_bond(long long n_items, int R, int h, int jobs) {
     p.tiles_i = (jobs + TD_JG - 1) / TD_JG;                  // layer groups
     p.tiles_j = h / 64;
     const long long tiles = (long long)p.tiles_i * p.tiles_j;
-    static const long long target = getenv("PHC_TG_DIRECT_TARGET") ? atoll(getenv("PHC_TG_DIRECT_TARGET")) : 256;
+    constexpr long long target = 256;
     long long ips = ((n_items * tiles + target - 1) / target + 7) / 8 * 8;
     if (ips < 8) ips = 8;
     p.items_per_split = ips;
@@ -1489,7 +1489,7 @@ static TgPlan tg_plan(long long n_items, int R, int h, int jobs = 1) {
     const int tiles = p.tiles_i * p.tiles_j;
     // workgroups of the whole launch: ~2-4 per CU for molecule batches; for large inputs one workgroup per ~8k items
     // (a fixed 512 left each workgroup with thousands of dependent gather -> MFMA rounds: 19 ms for 10 M atoms)
-    static const long long knob = getenv("PHC_TG_TARGET") ? atoll(getenv("PHC_TG_TARGET")) : 0;      // tuning knob
+    constexpr long long knob = 0;
     long long target = knob > 0 ? knob : (jobs > 1 ? 1024 : 512);
     const long long by_items = (n_items / 8192) * tiles * jobs;
     if (by_items > target) target = by_items;
@@ -1770,7 +1770,7 @@ int phc_aggregate_encp_fwd(const float *x, const uint32_t *codes, const float *c
     const int rows_per_wg = 4 * (WAVE / lpr);                 // direct form: one row per lane group
     const long long dblocks = xcd_grid((n_dst + rows_per_wg - 1) / rows_per_wg);      // a multiple of 8: one contiguous row range per XCD
     // molecule batches: one wavefront per row, tables read from L2 (no LDS staging); large graphs amortise the staging
-    static const long long direct_max = getenv("PHC_ENCP_DIRECT_MAX") ? atoll(getenv("PHC_ENCP_DIRECT_MAX")) : 32768;
+    constexpr long long direct_max = 32768;
     const bool direct = n_dst <= direct_max;
     ProfScope prof(K_AGG_ENC_FWD, s);
 #define PHC_AP_LAUNCH(LPRC, ACTC, FC)                                                                                     \
@@ -1809,7 +1809,7 @@ int phc_aggregate_encp_fwd(const float *x, const uint32_t *codes, const float *c
 }
 
 static inline long long encp_direct_max() {
-    static const long long v = getenv("PHC_ENCP_DIRECT_MAX") ? atoll(getenv("PHC_ENCP_DIRECT_MAX")) : 32768;
+    constexpr long long v = 32768;
     return v;
 }
 int phc_aggregate_norm_supported(int64_t n_dst, int h, int F, int R) {
@@ -1959,7 +1959,7 @@ int phc_aggregate_enc_bwd(const float *dout, const float *x, const int64_t *bond
         blocks = xcd_grid(blocks);
         const int lpr = lpr_for(h >> 2);
         ProfScope prof(K_AGG_ENC_DX, s);
-        static const long long rows_max = getenv("PHC_ENCP_DIRECT_MAX") ? atoll(getenv("PHC_ENCP_DIRECT_MAX")) : 32768;
+        constexpr long long rows_max = 32768;
         if (act == PHC_ACT_IDENTITY && n_src <= rows_max) {                   // molecule batches: one source row per lane group
             const int rows_per_wg = 4 * (WAVE / lpr);
             const unsigned rb = (unsigned)xcd_grid((n_src + rows_per_wg - 1) / rows_per_wg);
@@ -2122,7 +2122,7 @@ int phc_table_grads_counted(const phc_table_grad_job *jobs, int num_jobs, const 
 // wavefronts per SIMD: the latency-bound table gathers run beside the MFMA-bound dH wavefronts); without them the 128 x 128
 // tiles in their own launch.
 static int tail_direct_form(int num_tjobs, int64_t N_atoms) {
-    static const int forced = getenv("PHC_TAIL_DIRECT_FORM") ? atoi(getenv("PHC_TAIL_DIRECT_FORM")) : 0;
+    constexpr int forced = 0;
     if (forced == 2 || forced == 3) return forced;
     return (num_tjobs > 0 || N_atoms > 0) ? 3 : 2;
 }

@@ -732,7 +732,7 @@ static int hc_capacity(size_t lds_bytes) {
 static HcShape hc_shape(long long B, long long valid_max, int n_stages, const int *K, const int *N, bool device) {
     HcShape r = {};
     static const bool off = getenv("PHC_HEAD_CHAIN") && atoi(getenv("PHC_HEAD_CHAIN")) == 0;
-    static const int forced_cb = getenv("PHC_HEAD_CHAIN_CB") ? atoi(getenv("PHC_HEAD_CHAIN_CB")) : 0;
+    constexpr int forced_cb = 0;
     if (off || B < 1 || B > (1 << 20) || n_stages < 1 || n_stages > HC_MAX_STAGES) return r;
     for (int s = 0; s < n_stages; ++s) {
         if (K[s] < 16 || K[s] > HC_MAX_K || K[s] % 16 || N[s] < 16 || N[s] % 16) return r;

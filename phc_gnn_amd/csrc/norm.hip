@@ -1000,9 +1000,7 @@ int phc_bn_fwd_from_partials(const float *x, const float *stats_partial, const f
 #undef PHC_BN_FWDA
         return check_launch("bn_apply_acc");
     }
-    const char *env_merged = getenv("PHC_BN_APPLY_MERGED");               // A/B switch (read per call: cheap next to a launch)
-    const bool no_merged = env_merged && atoi(env_merged) == 0;
-    if (vec4 && !no_merged) {
+    if (vec4) {
         // one launch: the merge of the partials rides in the prologue of the normalisation
         long long groups = (N + 127) / 128;                      // >= 128 rows per workgroup
         const long long cap = (8LL * 256) / bn_col_blocks(h);    // ~8 workgroups per CU at most
@@ -1137,7 +1135,7 @@ int phc_bn_bwd(const float *dy, const float *x, const float *save_stat, const in
         if (rc) return rc;
     }
     if (!dx) return PHC_OK;
-    if (acc_mode && vec4 && !getenv("PHC_BN_BWD_APPLY_FLAT")) return launch_bwd_apply_acc(dy, x, save_stat, n_valid_dev, N, h, act, acc, dx, dwb_flat, training, drop, s);
+    if (acc_mode && vec4) return launch_bwd_apply_acc(dy, x, save_stat, n_valid_dev, N, h, act, acc, dx, dwb_flat, training, drop, s);
     const size_t lds = sizeof(float) * 6 * (size_t)h;
     ProfScope prof(K_BN_BWD_APPLY, s);
 #define PHC_BN_BA(ACTC)                                                                                                      \
@@ -1178,7 +1176,7 @@ int phc_bn_bwd_from_partials(const float *dy, const float *x, const float *save_
         if (rc) return rc;
     }
     if (!dx) return PHC_OK;
-    if (acc_mode && vec4 && !getenv("PHC_BN_BWD_APPLY_FLAT"))
+    if (acc_mode && vec4)
         return launch_bwd_apply_acc(dy, x, save_stat, n_valid_dev, N, h, act, acc, dx, dwb_flat, 1, BnDrop{0.f, 0, h, 0, nullptr}, s);
     const size_t lds = sizeof(float) * 6 * (size_t)h;
     ProfScope prof(K_BN_BWD_APPLY, s);

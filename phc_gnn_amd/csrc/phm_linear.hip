@@ -1441,7 +1441,7 @@ static int launch_stream_cfg(const float *X, const float *A, const float *W, con
     if ((STATS & 5) && gy > GEMM_STATS_MAX_PARTIALS) gy = GEMM_STATS_MAX_PARTIALS;      // one statistics partial per workgroup row
     {
         // experiment: fewer, longer workgroup rows for the statistics-emitting launches (fewer partials to merge downstream)
-        static const int cap = getenv("PHC_GEMM_STATS_GY") ? atoi(getenv("PHC_GEMM_STATS_GY")) : 0;
+        constexpr int cap = 0;
         if ((STATS & 1) && cap > 0 && gy > cap) gy = cap;
     }
     if (gy < 1) gy = 1;
@@ -1480,7 +1480,7 @@ static inline bool hs_enabled() {
 // at K = Nout = 128 with ONE workgroup per CU the 32-column staged kernel was 0.2-0.4 us per launch ahead at 12.9 k rows (805
 // sixteen-row steps on 256 CUs: 4 rounds for 3.1 rounds of work); with two workgroups per CU (launch_hs_cfg) the H-stationary
 // kernel wins there too: molhiv_b512 0.694 / 0.692 / 0.697 -> 0.680 / 0.688 / 0.676 ms, molhiv_b32 (1 152 rows) 0.457 -> 0.425 ms,
-// the softmax step 0.801 -> 0.796 ms (alternating runs on one box).  PHC_GEMM_HS_MIN_ROWS_128=<rows> restores a threshold.
+// the softmax step 0.801 -> 0.796 ms (alternating runs on one box).  (The threshold knob went with round 6: 0 rows.)
 // ... and the reference's PUBLISHED widths (benchmarks/README.md:45-91, run_script_zinc_phm4.sh: hidden 200 = 4 x 50 = 5 x 40 and
 // 180 = 4 x 45): square 180- / 200-wide layers run on the 192 / 208 instantiations — one row per DMA instruction, the last
 // k-group and the last column tiles partly empty (operand read as zero there).  PHC_GEMM_HS_PUB=0 keeps them on the LDS-panel kernel.
@@ -1492,7 +1492,7 @@ static inline bool hs_widths_ok(int K, int Nout) {
     return ((K == 128 || K == 256) && (Nout == 128 || Nout == 256)) || hs_pub_width(K, Nout);
 }
 static bool hs_shape_ok(const float *x, const float *Mk4, int64_t N, int K, int Nout) {
-    static const long long min128 = getenv("PHC_GEMM_HS_MIN_ROWS_128") ? atoll(getenv("PHC_GEMM_HS_MIN_ROWS_128")) : 0;
+    constexpr long long min128 = 0;
     return hs_enabled() && Mk4 && N >= 1 && hs_widths_ok(K, Nout) && (K != 128 || Nout != 128 || N >= min128) &&
            ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(Mk4)) & 15) == 0;
 }
@@ -1513,7 +1513,7 @@ static int launch_hs_cfg(GemmHsArgs a, const XfAcc &xa, hipStream_t s) {
     // one wavefront: two workgroups per CU are worth 3-4 % at scale (10 M rows: 3.07 -> 2.95 ms, scripts/dbg/gemm_hs_vs_panel.py)
     // and 2 % of the molhiv_b512 step, whose folded-norm dx GEMMs then run 1.7 instead of 3.4 steps per workgroup
     // (0.706 / 0.711 / 0.714 -> 0.695 / 0.692 / 0.698 ms, alternating runs on one box with PHC_HS_GROUPS_PER_CU = 1 / 2)
-    static const int per_cu_env = getenv("PHC_HS_GROUPS_PER_CU") ? atoi(getenv("PHC_HS_GROUPS_PER_CU")) : 0;
+    constexpr int per_cu_env = 0;
     const int per_cu = per_cu_env > 0 ? per_cu_env : (WAVES == 4 && K == 128 ? 2 : 1);
     long long groups = (long long)per_cu * num_cu() / a.panels;
     if (groups > steps) groups = steps;
@@ -1567,7 +1567,7 @@ constexpr int GEMM_PREBUILT_MAX_K = 768;
 // rows at which the 128-column / 8-wave streaming configuration takes over from the 64-column / 4-wave one
 constexpr int64_t GEMM_BIG_M = 64 * 1024;
 // K > 128 (hidden 256): rows from which the 64-column / 8-wave configuration (one panel per CU shared by 8 wavefronts, x
-// read 4x) takes over from the 32-column / 4-wave one (two workgroups per CU, x read 8x).  PHC_GEMM_WIDE_K_M overrides.
+// read 4x) takes over from the 32-column / 4-wave one (two workgroups per CU, x read 8x).
 // ... and the contraction depth from which it does: the published 180-wide model (run_script_zinc_phm4.sh) runs 1.756 -> 1.622 ms per
 // step on the 32-column configuration, the 200-wide one 1.940 -> 1.972 ms (alternating runs, PHC_GEMM_WIDE_K_M = 16384 / 1000000)
 constexpr int GEMM_WIDE_K_MIN = 192;
@@ -1577,7 +1577,7 @@ static inline bool gemm_big_cfg(int64_t N, int K, int Nout) { return N >= 64 * 1
 static inline int64_t gemm_wide_k_m() {
     // measured (bench.py, one MI355X): zinc_b1024 (23.6 k rows, PHM-8 hidden 256) 2.75 -> 2.58 ms, molpcba_b1024 (27.2 k rows)
     // 3.42 -> 3.19 ms per training step with the 8-wave configuration instead of 2 x (32 columns, 4 waves) per CU
-    static const int64_t v = getenv("PHC_GEMM_WIDE_K_M") ? atoll(getenv("PHC_GEMM_WIDE_K_M")) : 16 * 1024;
+    constexpr int64_t v = 16 * 1024;
     return v;
 }
 
@@ -1617,7 +1617,7 @@ static int launch_gemm(const float *X, const float *A, const float *W, const flo
 // splits a single big tile needs cost nothing next to the operand stream (>= 64k rows): otherwise the slab
 // traffic of those splits outweighs the halved operand reads (measured at 128 x 128, N = 13.8k)
 static inline bool dh_use_128(int64_t N, int in, int out) {
-    static const bool no128 = getenv("PHC_DH_NO_128") != nullptr;
+    constexpr bool no128 = false;
     if (no128 || in < DH_T2 || out < DH_T2 || in % 4 || out % 4) return false;
     return (in >= 2 * DH_T2 && out >= 2 * DH_T2) || N >= 64 * 1024;
 }
@@ -1636,7 +1636,7 @@ static DhPlan dh_plan(int64_t N, int in, int out) {
     p.tiles_i = (in + T - 1) / T;
     p.tiles_j = (out + T - 1) / T;
     const int tiles = p.tiles_i * p.tiles_j;
-    static const int target_blocks = getenv("PHC_DH_BLOCKS") ? atoi(getenv("PHC_DH_BLOCKS")) : 512;
+    constexpr int target_blocks = 512;
     int64_t splits = (target_blocks + tiles - 1) / tiles;       // ~2 workgroups per CU (fixed: plan must not depend on the device)
     const int64_t max_splits = (N + DH_RB - 1) / DH_RB;
     if (splits > max_splits) splits = max_splits;
@@ -1654,7 +1654,7 @@ static DhPlan dh_plan(int64_t N, int in, int out) {
 // register-resident form of ONE layer (phc_phm_linear_bwd): splits = workgroups / tiles with every workgroup the same number
 // of rows (a multiple of 64), at most 256 workgroups (one round of one workgroup per CU on a 256-CU part; shape-only: fixed order)
 static bool dh_direct_shape_ok(int64_t N, int in, int out) {
-    static const bool off = getenv("PHC_DH_NO_DIRECT") != nullptr;
+    constexpr bool off = false;
     if ((int64_t)(in > out ? in : out) * 4 * (N / 256 + 128) >= ((int64_t)1 << 31)) return false;       // 32-bit offsets per wavefront
     return !off && in % 4 == 0 && out % 4 == 0 && in >= 96 && out >= 32 && N >= 8;             // partial edge tiles: dH_direct_body
 }
@@ -1664,7 +1664,7 @@ static DhPlan dh_plan_direct(int64_t N, int in, int out) {
     p.tiles_i = (in + DH_D - 1) / DH_D;
     p.tiles_j = (out + DH_D - 1) / DH_D;
     const int64_t tiles = (int64_t)p.tiles_i * p.tiles_j;
-    static const int64_t dtarget = getenv("PHC_DH_DIRECT_TARGET") ? atoll(getenv("PHC_DH_DIRECT_TARGET")) : 256;
+    constexpr int64_t dtarget = 256;
     int64_t rps = (tiles * N / dtarget + 63) / 64 * 64;
     if (rps < 64) rps = 64;
     while (tiles * ((N + rps - 1) / rps) > dtarget && rps < N) rps += 64;
@@ -1683,7 +1683,7 @@ struct GradPlan {
 // register-resident tile form (dH_direct_body): float4-addressable operands; widths that are not multiples of the tile end in a
 // partial tile (form 2: 128 x 128 tiles; form 3: 128 x 64, or 128 x 32 when out is an odd multiple of 32 — dh3_np)
 static inline bool dh_use_direct(const phc_phm_grad_job &jb) {
-    static const bool off = getenv("PHC_DH_NO_DIRECT") != nullptr;
+    constexpr bool off = false;
     const int in = jb.n * jb.kin, out = jb.n * jb.kout;
     if ((int64_t)(in > out ? in : out) * 4 * (jb.N / 256 + 128) >= ((int64_t)1 << 31)) return false;    // 32-bit offsets per wavefront
     return !off && in % 4 == 0 && out % 4 == 0 && in >= 96 && out >= 32 && jb.N >= 8 && (reinterpret_cast<uintptr_t>(jb.x) & 15) == 0 &&
@@ -1715,8 +1715,8 @@ static void grad_plans(const phc_phm_grad_job *jobs, int num, GradPlan *plans, i
     if (direct_rows > 0) {
         // register-resident jobs: one workgroup per CU of a 256-CU part in ONE round (a workgroup owns its CU: 512 registers per
         // lane), every workgroup the same number of rows: the smallest multiple of 8 whose workgroup count fits the target
-        static const int64_t dtarget2 = getenv("PHC_DH_DIRECT_TARGET") ? atoll(getenv("PHC_DH_DIRECT_TARGET")) : 256;
-        static const int64_t dtarget3 = getenv("PHC_DH_DIRECT64_TARGET") ? atoll(getenv("PHC_DH_DIRECT64_TARGET")) : 512;
+        constexpr int64_t dtarget2 = 256;
+        constexpr int64_t dtarget3 = 512;
         const int64_t dtarget = direct_form == 3 ? dtarget3 : dtarget2;       // form 3: two workgroups per CU
         // multiples of 64 rows: each of the four wavefronts then runs whole 16-row iterations of the unmasked loop
         // form 3 (the step tail), even shares: a job's shorter last split is `pair` tiles' worth of ONE workgroup when that many of them
@@ -1750,7 +1750,7 @@ static void grad_plans(const phc_phm_grad_job *jobs, int num, GradPlan *plans, i
                 plans[k].pair = pair_of(k, rps);
             }
     }
-    static const int64_t target = getenv("PHC_GRAD_TARGET") ? atoll(getenv("PHC_GRAD_TARGET")) : 1024;    // tuning knob
+    constexpr int64_t target = 1024;
     static const bool dbg = getenv("PHC_DEBUG_PLANS") != nullptr;
     if (dbg)
         for (int k = 0; k < num; ++k)
@@ -2128,7 +2128,7 @@ static int build_H_batched_impl(const phc_phm_H_job *jobs, int num_jobs, const p
             b.j[k].Hk4 = jb.Hk4; b.j[k].HTk4 = jb.HTk4;
             b.j[k].n = jb.n; b.j[k].kin = jb.kin; b.j[k].kout = jb.kout; b.j[k].dense_t = dense_t;
             b.j[k].blk0 = blocks;
-            static const bool no_tiles = getenv("PHC_BUILD_H_TILES") && atoi(getenv("PHC_BUILD_H_TILES")) == 0;
+            constexpr bool no_tiles = false;
             const bool tiled = !no_tiles && !dense_t && in_ % 4 == 0 && out_ % 4 == 0 && jb.kout % 4 == 0 && in_ >= 4 && out_ >= 4 &&
                                ((reinterpret_cast<uintptr_t>(jb.H) | reinterpret_cast<uintptr_t>(jb.HT) | reinterpret_cast<uintptr_t>(jb.Hk4) |
                                  reinterpret_cast<uintptr_t>(jb.HTk4) | reinterpret_cast<uintptr_t>(jb.W)) & 15) == 0;
@@ -2206,8 +2206,8 @@ int phc_gemm_prebuilt(const float *x, const float *M, const float *Mk4, const fl
     }
     // Few rows (molecule batches: about one 32-row slab per wavefront): 32-column panels give twice the wavefronts,
     // each half as long — measured 0.8 us per launch faster than 64-column panels at N = 13.8k; above that the extra
-    // re-reads of x cost more than the occupancy gains.  PHC_GEMM_PRE_BN=64 forces the wider panel.
-    static const int small_bn = getenv("PHC_GEMM_PRE_BN") ? atoi(getenv("PHC_GEMM_PRE_BN")) : 32;
+    // re-reads of x cost more than the occupancy gains.
+    constexpr int small_bn = 32;
     if (N >= gemm_wide_k_m() && Nout > 64 && K > GEMM_WIDE_K_MIN)
         launch_stream_cfg<0, -1, 64, 8>(x, nullptr, M, b, residual, y, N, K, Nout, 1, K, Nout, 1, s);
     else if (gemm_big_cfg(N, K, Nout))
@@ -2250,7 +2250,7 @@ int phc_gemm_prebuilt_stats_res(const float *x, const float *M, const float *Mk4
         launch_hs<HS_ST>(a, K, XfAcc{}, s);
         return check_launch("phc_gemm_prebuilt_stats(hs)");
     }
-    static const int small_bn = getenv("PHC_GEMM_PRE_BN") ? atoi(getenv("PHC_GEMM_PRE_BN")) : 32;
+    constexpr int small_bn = 32;
     if (K > GEMM_STREAM_MAX_K)                               // deep contraction: 32-column panels, one workgroup per CU
         launch_stream_cfg<0, -1, 32, 4, 1>(x, nullptr, M, b, residual, y, N, K, Nout, 1, K, Nout, 1, s, n_valid_dev, stats_partial,
                                            stats_counts, num_partials, nullptr, 0, nullptr, nullptr, 0, acc);
@@ -2327,7 +2327,7 @@ static int gemm_prebuilt_xf_impl(const float *x, const float *xf_stat, int xf_ac
             launch_hs<HS_XF>(a, K, xa, s);
         return check_launch("phc_gemm_prebuilt_xf(hs)");
     }
-    static const int small_bn = getenv("PHC_GEMM_PRE_BN") ? atoi(getenv("PHC_GEMM_PRE_BN")) : 32;
+    constexpr int small_bn = 32;
     const bool big = gemm_big_cfg(N, K, Nout);
     const bool small = small_bn == 32 && Nout > 32 && N <= 32 * 1024;
 #define PHC_XF_LAUNCH(SV)                                                                                                      \
@@ -2377,7 +2377,7 @@ int phc_gemm_prebuilt_bwsums(const float *dy, const float *M, const float *Mk4, 
         launch_hs<HS_BW>(a, K, XfAcc{}, s);
         return check_launch("phc_gemm_prebuilt_bwsums(hs)");
     }
-    static const int small_bn = getenv("PHC_GEMM_PRE_BN") ? atoi(getenv("PHC_GEMM_PRE_BN")) : 32;
+    constexpr int small_bn = 32;
     if (N >= gemm_wide_k_m() && Nout > 64 && K > GEMM_WIDE_K_MIN)
         launch_stream_cfg<0, -1, 64, 8, 4>(dy, nullptr, M, nullptr, nullptr, dz, N, K, Nout, 1, K, Nout, 1, s, n_valid_dev, sums_partial,
                                            nullptr, num_partials, nullptr, 0, bn_x, bn_stat, act, acc);
@@ -2451,7 +2451,7 @@ int phc_gemm_aggregate_stats(const phc_gemm_ag_desc *d, void *stream) {
     const long long steps = (d->N + 15) / 16;
     if (h != 128) {
         // the wide layers (gemm_hs_agw_device.h): one workgroup per CU, as launch_hs_cfg<K, 2, 8> counts them
-        static const int wide_per_cu_env = getenv("PHC_HS_GROUPS_PER_CU") ? atoi(getenv("PHC_HS_GROUPS_PER_CU")) : 0;
+        constexpr int wide_per_cu_env = 0;
         long long groups = (long long)(wide_per_cu_env > 0 ? wide_per_cu_env : 1) * num_cu();
         if (groups > steps) groups = steps;
         a.groups = (int)groups;
@@ -2462,7 +2462,7 @@ int phc_gemm_aggregate_stats(const phc_gemm_ag_desc *d, void *stream) {
     }
     // workgroups: as many as the statistics-epilogue GEMM on the same rows takes (two per CU) — a workgroup's steps, and with them
     // the partial sums it adds to the accumulator, are then the same sets of rows: the totals are bit-identical to that launch's
-    static const int per_cu_env = getenv("PHC_HS_AG_GROUPS_PER_CU") ? atoi(getenv("PHC_HS_AG_GROUPS_PER_CU")) : 0;
+    constexpr int per_cu_env = 0;
     long long groups = (long long)(per_cu_env > 0 ? per_cu_env : 2) * num_cu();
     if (groups > steps) groups = steps;
     a.groups = (int)groups;

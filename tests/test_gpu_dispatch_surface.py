@@ -102,7 +102,8 @@ def test_repeated_steps_are_bit_equal_under_allocator_pollution(workload, mode):
 # every module-level fusion switch of ops.py (name -> the value that is NOT the default); the default step is the "none" case
 TOGGLES = ["none", "GEMM_AGGREGATE", "READOUT_FUSED", "NORM_INTO_AGGREGATE", "MLP_NORM_FUSED", "SKIP_SUM_HANDOFF", "ENCODE_FRONT",
            "STEP_TAIL_MERGED", "GATE_COMPOSED", "TAIL_EXTRAS", "TAIL_WIDE", "TABLE_GRADS_COUNTED", "STAT_ACC", "FLAT_TABLES",
-           "BN_BWD_SUMS_IN_GEMM", "DOWNSTREAM_FUSED", "STATS_WITH_RESIDUAL", "RESIDUAL_HANDOFF", "HEAD_CHAIN", "HEAD_DROPOUT", "POOL_BWD_GATE"]
+           "BN_BWD_SUMS_IN_GEMM", "DOWNSTREAM_FUSED", "STATS_WITH_RESIDUAL", "RESIDUAL_HANDOFF", "HEAD_CHAIN", "HEAD_DROPOUT", "POOL_BWD_GATE",
+           "MLP_BWD_FUSED", "MLP_FWD_FUSED", "MLP_FWD_FUSED_AGG", "HEAD_LOSS"]
 ORACLE_KW = {
     "molhiv_b32_swish": dict(phm_dim=4, num_layers=4, num_atom_feats=9, num_bond_feats=3, num_dn_hidden=2, mlp=True, sc_type="first",
                              act="swish"),
@@ -135,16 +136,13 @@ def _oracle(workload, sd, gb, regression):
     return _ORACLE[workload]
 
 
-@pytest.mark.parametrize("workload", list(ORACLE_KW))
-@pytest.mark.parametrize("toggle", TOGGLES)
-def test_every_single_toggle_flip_holds_the_oracle(workload, toggle):
-    """The step without the explicit regulariser (the oracle call is the model's loss alone), smooth activation: logits and loss
-    within 1e-5 of the float32 oracle, every gradient tensor within 3e-5 of the float64 oracle — with ONE switch off its default."""
+def check_step_against_oracle(workload, toggle="none", tag=None):
+    """One small step (smooth activation, no explicit regulariser) held to the oracle: logits and loss within 1e-5 of the float32
+    oracle, every gradient tensor within 3e-5 of the float64 oracle — with ``ops.<toggle>`` off its default (or none)."""
     from phc_gnn_amd import harness, ops
     w = _workload(workload[:-6])
     regression = bool(w.get("regression"))
-    if toggle != "none" and not hasattr(ops, toggle):
-        pytest.skip(f"ops.{toggle} no longer exists")
+    tag = tag or f"{toggle} flipped"
     keep = getattr(ops, toggle) if toggle != "none" else None
     try:
         if toggle != "none":
@@ -166,8 +164,8 @@ def test_every_single_toggle_flip_holds_the_oracle(workload, toggle):
         if toggle != "none":
             setattr(ops, toggle, keep)
     lt32, lo32, g64 = _oracle(workload, sd, gb, regression)
-    assert_close(logits_box["l"][:gb.num_graphs], lt32, TOL, f"{workload} [{toggle} flipped]: logits")
-    assert_close(loss, lo32, TOL, f"{workload} [{toggle} flipped]: loss")
+    assert_close(logits_box["l"][:gb.num_graphs], lt32, TOL, f"{workload} [{tag}]: logits")
+    assert_close(loss, lo32, TOL, f"{workload} [{tag}]: loss")
     bad = []
     for k, prm in model.named_parameters():
         r = g64.get(k)
@@ -177,4 +175,38 @@ def test_every_single_toggle_flip_holds_the_oracle(workload, toggle):
         e = relerr(prm.grad, r)
         if e > 3e-5:
             bad.append((e, k))
-    assert not bad, f"{workload} [{toggle} flipped]: " + "; ".join(f"{k}: {e:.2e}" for e, k in sorted(bad, reverse=True)[:6])
+    assert not bad, f"{workload} [{tag}]: " + "; ".join(f"{k}: {e:.2e}" for e, k in sorted(bad, reverse=True)[:6])
+
+
+@pytest.mark.parametrize("workload", list(ORACLE_KW))
+@pytest.mark.parametrize("toggle", TOGGLES)
+def test_every_single_toggle_flip_holds_the_oracle(workload, toggle):
+    """The step without the explicit regulariser (the oracle call is the model's loss alone), smooth activation: logits and loss
+    within 1e-5 of the float32 oracle, every gradient tensor within 3e-5 of the float64 oracle — with ONE switch off its default."""
+    from phc_gnn_amd import ops
+    if toggle != "none" and not hasattr(ops, toggle):
+        pytest.skip(f"ops.{toggle} no longer exists")
+    check_step_against_oracle(workload, toggle)
+
+
+# The switches the LIBRARY reads from the environment (``static const`` reads inside csrc/: a value is fixed for the life of a process).
+# What is left of them after round 6's pruning are product switches — which kernel family serves a call — and each is held to the
+# oracle on its non-default side in a FRESH child process (never a re-exec of a process that has touched the GPU).
+ENV_FLIPS = [("PHC_GEMM_NO_HS", "1"), ("PHC_GEMM_HS_PUB", "0"), ("PHC_GEMM_AGGREGATE", "0"), ("PHC_GEMM_AGGREGATE_WIDE", "0"),
+             ("PHC_DOWNSTREAM_V2", "0"), ("PHC_HEAD_CHAIN", "0"), ("PHC_READOUT_FUSED", "0"), ("PHC_POOL_BWD_GATE", "0"), ("PHC_DH_PAIR", "0"),
+             ("PHC_MLP_BWD_FUSED", "0"), ("PHC_MLP_FWD_FUSED", "0"), ("PHC_CLIP_ADAM_FUSED", "0")]
+
+
+@pytest.mark.parametrize("name,value", ENV_FLIPS)
+def test_every_library_switch_holds_the_oracle_in_a_fresh_process(name, value):
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, **{name: value})
+    env["PYTHONPATH"] = root + os.pathsep + env.get("PYTHONPATH", "")
+    workloads = ["molhiv_b32_swish", "zinc_small_256_swish"] if name in ("PHC_GEMM_NO_HS", "PHC_GEMM_AGGREGATE_WIDE", "PHC_DH_PAIR", "PHC_GEMM_HS_PUB") \
+        else ["molhiv_b32_swish"]
+    r = subprocess.run([sys.executable, "-m", "tests.helpers.flip_child", f"{name}={value}"] + workloads, cwd=root, env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "FLIP-OK" in r.stdout, (name, value, r.stdout[-2000:], r.stderr[-2000:])
