@@ -15,9 +15,14 @@ def multiplication_rule_regularization(model, p: int = 1, device=None):
 
 
 def phm_weight_regularization(model, p: int = 2, device=None):
+    weights = [module.W for _, module in model.named_modules() if getattr(module, "W", None) is not None]
+    if weights and all(w.is_cuda for w in weights):
+        # ROCm weights: the same value (and its gradient) from one engine launch instead of three small launches per layer each way
+        from phc_gnn_amd import ops as _engine
+        reg = _engine.weight_regularization(weights, p)
+        if reg is not None:
+            return reg
     reg = 0.0
-    for _, module in model.named_modules():
-        weight = getattr(module, "W", None)
-        if weight is not None:
-            reg = reg + weight.norm(p=p, dim=0).mean()
+    for weight in weights:
+        reg = reg + weight.norm(p=p, dim=0).mean()
     return reg

@@ -234,6 +234,15 @@ class PHMSkipConnectAdd(nn.Module):
         return h + x[1]
 
     def forward(self, data, size=None) -> torch.Tensor:
+        # Called outside the step's contexts (the reference's own loop body: model(data); loss.backward()): a training-mode forward on
+        # a ROCm device opens them itself and closes them behind its backward (engine: auto_step_forward) — one operand-build launch,
+        # statistics through accumulators, the batched step tail.
+        if _engine.AUTO_STEP and self.training and torch.is_grad_enabled() and getattr(data.x, "is_cuda", False) and \
+                (not _engine.step_context_active() or _engine.auto_step_open()):      # (an auto-opened block whose backward never came is replaced)
+            return _engine.auto_step_forward(self, data, lambda: self._forward(data, size))
+        return self._forward(data, size)
+
+    def _forward(self, data, size=None) -> torch.Tensor:
         x, edge_index, edge_attr, batch = data.x, data.edge_index, data.edge_attr, data.batch
         if isinstance(self.bond_input_dims, list):
             edge_attr = edge_attr.to(torch.long)
