@@ -65,6 +65,9 @@ constexpr size_t mf_lds_floats() {
 // arrival of a group arrives at the top counter, and the last of those moves every group's generation word (each on its own
 // 128-byte line: a group's workgroups poll their own line).  Words (uint32, stride MF_BSTRIDE): [0, MF_SUB) group counters,
 // [MF_SUB] top counter, [MF_SUB + 1 + k] generation of group k.
+// (Tried: monotonic group counters that every workgroup polls directly — arrive, then see: two round trips instead of four.  With
+// 416 workgroups sweeping all 16 counter lines per poll the arrivals themselves slowed down: 5 - 8 us per barrier instead of 2.5 - 4,
+// molhiv_b512 0.51 -> 0.55 ms.  The pollers stay on lines nobody adds to.)
 constexpr int MF_SUB = 16, MF_BSTRIDE = 32, MF_BAR_WORDS = (2 * MF_SUB + 1) * MF_BSTRIDE;
 __device__ __forceinline__ void mf_grid_barrier(unsigned *bar, unsigned &gen, int *err) {
     __syncthreads();                                         // (s_waitcnt vmcnt(0): this workgroup's atomics have been performed)
@@ -578,6 +581,26 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mlp_fwd_fused_kernel(MlpFwdArgs
             src[j][0] = es.x; src[j][1] = es.y; src[j][2] = es.z; src[j][3] = es.w;
             code[j][0] = (unsigned)ec.x; code[j][1] = (unsigned)ec.y; code[j][2] = (unsigned)ec.z; code[j][3] = (unsigned)ec.w;
         }
+        const float *skp = a.skip ? a.skip : a.x;            // (without a skip the second load re-reads y: the loads stay unconditional)
+        // the raw rows of one step's two rows: the row itself and its first four sources
+        auto issue_rows = [&](int sI, f32x4_t (&ys)[2], f32x4_t (&ks)[2], f32x4_t (&ye)[2][4], f32x4_t (&ke)[2][4]) __attribute__((always_inline)) {
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const int j = 2 * sI + u;
+                const long long dc = dj[j] >= 0 ? dj[j] : 0;
+                ys[u] = *reinterpret_cast<const f32x4_t *>(a.x + (size_t)dc * MF_H + 4 * c4);
+                ks[u] = *reinterpret_cast<const f32x4_t *>(skp + (size_t)dc * MF_H + 4 * c4);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    ye[u][i] = *reinterpret_cast<const f32x4_t *>(a.x + (size_t)src[j][i] * MF_H + 4 * c4);
+                    ke[u][i] = *reinterpret_cast<const f32x4_t *>(skp + (size_t)src[j][i] * MF_H + 4 * c4);
+                }
+            }
+        };
+        // the first step's rows go in flight as soon as the edge slots are there: they travel under the table staging, the pending
+        // norm's totals and the barrier below
+        f32x4_t ys0[2], ks0[2], ye0[2][4], ke0[2][4];
+        issue_rows(0, ys0, ks0, ye0, ke0);
         // bond tables -> LDS: row r of feature f(r), component cc = column / k.  All of a thread's entries travel together (clamped,
         // unrolled; pointers out of the kernel arguments by constant index: as a run-time loop with a pointer hop per entry the staging
         // alone was four dependent round trips, 16 us in front of the gather)
@@ -625,7 +648,6 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mlp_fwd_fused_kernel(MlpFwdArgs
         MF_STAMP(9);
         const f32x4_t sc = normed ? *reinterpret_cast<const f32x4_t *>(ss_o + 4 * c4) : zero;
         const f32x4_t sh = normed ? *reinterpret_cast<const f32x4_t *>(ss_o + MF_H + 4 * c4) : zero;
-        const float *skp = a.skip ? a.skip : a.x;            // (without a skip the second load re-reads y: the loads stay unconditional)
         // one normalised row slice: act(y scale + shift) (+ skip), 0 for a padding row; the plain tensor otherwise
         // KIND 0: a plain tensor; 1: relu(norm) (+ skip); 2: any other activation
         auto xrow = [&](auto kind_c, long long r, const f32x4_t yv, const f32x4_t kv) __attribute__((always_inline)) {
@@ -658,17 +680,15 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mlp_fwd_fused_kernel(MlpFwdArgs
 #pragma unroll
         for (int sI = 0; sI < MAXS; ++sI) {
             f32x4_t ys[2], ks[2], ye[2][4], ke[2][4];
+            if (sI == 0) {
 #pragma unroll
-            for (int u = 0; u < 2; ++u) {
-                const int j = 2 * sI + u;
-                const long long dc = dj[j] >= 0 ? dj[j] : 0;
-                ys[u] = *reinterpret_cast<const f32x4_t *>(a.x + (size_t)dc * MF_H + 4 * c4);
-                ks[u] = *reinterpret_cast<const f32x4_t *>(skp + (size_t)dc * MF_H + 4 * c4);
+                for (int u = 0; u < 2; ++u) {
+                    ys[u] = ys0[u]; ks[u] = ks0[u];
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    ye[u][i] = *reinterpret_cast<const f32x4_t *>(a.x + (size_t)src[j][i] * MF_H + 4 * c4);
-                    ke[u][i] = *reinterpret_cast<const f32x4_t *>(skp + (size_t)src[j][i] * MF_H + 4 * c4);
+                    for (int i = 0; i < 4; ++i) { ye[u][i] = ye0[u][i]; ke[u][i] = ke0[u][i]; }
                 }
+            } else {
+                issue_rows(sI, ys, ks, ye, ke);
             }
             if (sI == 0) MF_STAMP(10);
             if (a.stamps) {                                  // diagnostics: the loads' arrival apart from the arithmetic behind it
