@@ -220,8 +220,22 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
     const long long my_steps = group < num_steps ? (num_steps - group + a.groups - 1) / a.groups : 0;
     if (my_steps == 0) return;                                    // whole workgroup: uniform
     long long n_valid = a.M;
+    // XF / BA launches: steps that hold padding rows ONLY (every row >= *n_valid: the tail of a fixed-shape batch) take no loads and no
+    // matrix work.  Their operand rows read as zero by definition, so their output rows are the bias (0 for a dx GEMM) and dz = 0 —
+    // written directly, bit-identical to computing them.  Whether a bucket's padded row count is a whole number of rounds of this
+    // launch's step loop then no longer decides whether the launch pays a nearly empty extra pass (24 832 rows at 16 rows x 256
+    // workgroups: seven passes against six).  The workgroup's FIRST step is always computed (the peeled step carries the prologue's
+    // waits); padding rows stay out of every statistic and carry zero gradient either way.
+    long long my_live = my_steps;
     if constexpr (ST || XF || BW || BA) {
         if (a.n_valid) n_valid = min((long long)*a.n_valid, a.M);
+    }
+    if constexpr (XF || BA) {
+        if (a.n_valid && !a.residual) {
+            const long long live_steps = (n_valid + RS - 1) / RS;
+            const long long lv = group < live_steps ? (live_steps - group + a.groups - 1) / a.groups : 0;
+            my_live = max(1LL, min(my_steps, lv));
+        }
     }
 
     // ---- DMA of one step: instruction ii = wave + WAVES * u covers rows ii * RPI .. of the step ----
@@ -585,7 +599,7 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
             issue_step(i + R - 1, nslot);
         }
         if constexpr (XF || BA) {
-            if (i + 1 < my_steps) {
+            if (i + 1 < my_live) {
                 hs_wait_vm<VM_KEEP_MID>();                        // DMA(i + 1): the younger steps stay in flight behind it
                 transform(i + 1, slot + 1 == R ? 0 : slot + 1);
             }
@@ -746,8 +760,28 @@ __global__ __launch_bounds__(64 * WAVES) void gemm_hs16_kernel(GemmHsArgs a, XfA
             *reinterpret_cast<f32x4_t *>(bw_lds + 3 * HS_BW_COLS + lc) = bw_b[t];
         }
     }
-    for (long long i = 1; i < my_steps; ++i) step_body(i, std::false_type{});
+    for (long long i = 1; i < my_live; ++i) step_body(i, std::false_type{});
     hs_wait_vm<0>();                                              // the clamped tail DMAs must not outlive the workgroup's LDS
+    // padding-only steps (XF / BA): y = bias, the norm backward's dz = 0
+    for (long long i = my_live; i < my_steps; ++i) {
+        const long long step = group + i * a.groups;
+#pragma unroll
+        for (int rb = 0; rb < RB; ++rb) {
+            const long long row = step * RS + rb * 16 + c;
+            if (row < a.M) {
+#pragma unroll
+                for (int t = 0; t < TPW; ++t)
+                    if (col0 + 4 * kq + 16 * t < Nout) *reinterpret_cast<f32x4_t *>(a.y + (size_t)row * Nout + col0 + 4 * kq + 16 * t) = bias4[t];
+            }
+        }
+        if constexpr (BA) {
+            const int k4 = KR >> 2;
+            for (int e = tid; e < RS * k4; e += THREADS) {
+                const long long row = step * RS + e / k4;
+                if (row < a.M) *reinterpret_cast<f32x4_t *>(a.ba_dz + (size_t)row * KR + 4 * (e % k4)) = zero4;
+            }
+        }
+    }
 
     // ---- statistics: the 16 row lanes of a column group meet (fixed order), then two atomic instructions per wavefront ----
     if constexpr (ST) {
