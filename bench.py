@@ -62,18 +62,22 @@ MFMA_KERNELS = ("phm_gemm_fwd", "phm_gemm_dx", "phm_dH_partial", "table_grad", "
 # (a family = every instantiation the launch profiler books under one name; traffic = launch-weighted mean over them)
 PMC_NAMES = {"phm_gemm_fwd": ("gemm_hs16_kernel<128, 2, 4, 1, 4, 1>", "gemm_hs16_kernel<128, 2, 4, 1, 4, 3>",
                               "gemm_hs16_kernel<256, 2, 8, 1, 4, 1>", "gemm_hs16_kernel<256, 2, 8, 1, 4, 3>",
-                              "gemm_hs16_kernel<256, 2, 8, 1, 4, 0>", "gemm_hs16_kernel<128, 2, 4, 1, 4, 0>"),
+                              "gemm_hs16_kernel<256, 2, 8, 1, 4, 0>", "gemm_hs16_kernel<128, 2, 4, 1, 4, 0>", "mlp_fwd_fused_kernel<2, false>"),
+             # (round 6, hidden 128: both dx GEMMs of a layer and both norm backwards are ONE launch, mlp_bwd_fused_kernel; its flops
+             # are booked as the two GEMMs')
              "phm_gemm_dx": ("gemm_hs16_kernel<128, 2, 4, 1, 4, 8>", "gemm_hs16_kernel<128, 2, 4, 1, 4, 12>",
-                             "gemm_hs16_kernel<256, 2, 8, 1, 4, 8>", "gemm_hs16_kernel<256, 2, 8, 1, 4, 12>"),
+                             "gemm_hs16_kernel<256, 2, 8, 1, 4, 8>", "gemm_hs16_kernel<256, 2, 8, 1, 4, 12>", "mlp_bwd_fused_kernel"),
              # the layer's aggregation inside its first GEMM (molecule batches, round 4): GEMM flops only are booked
-             "phm_gemm_ag_fwd": ("gemm_hs_ag_kernel", "gemm_hs_agw_kernel"),          # (round 5: the wide layers' form)
+             # (round 6, hidden 128: aggregation + both GEMMs + the inner norm in ONE launch, mlp_fwd_fused_kernel<2, true>)
+             "phm_gemm_ag_fwd": ("gemm_hs_ag_kernel", "gemm_hs_agw_kernel", "mlp_fwd_fused_kernel<2, true>"),
              "phm_dH_partial": ("tail_partial_kernel",), "aggregate_enc_fwd": ("aggregate_encp_direct_fwd_kernel", "aggregate_norm_fwd_kernel"),
-             "aggregate_enc_dx": ("aggregate_dx_rows_kernel",), "aggregate_fwd": ("aggregate_fwd_kernel",),
+             "aggregate_enc_dx": ("aggregate_dx_rows_kernel",), "aggregate_fwd": ("aggregate_fwd_kernel",), "aggregate_bwd": ("aggregate_bwd_kernel",),
              "bn_apply": ("bn_apply_acc_kernel",), "bn_bwd_apply": ("bn_bwd_apply_acc_kernel",), "bn_bwd_partial": ("bn_bwd_partial_kernel",),
              "bn_stats_partial": ("bn_stats_partial_kernel",), "table_grad": ("table_grad_mfma_kernel<1",)}
 
 
-PMC_FILE = "r05_pmc_traffic.json"
+PMC_FILE = "r06_pmc_traffic.json"
+PMC_MFMA_FILE = "r06_pmc_mfma.json"
 # below this footprint a row walker's rows are served by the L2s / the 256 MiB Infinity Cache, not by HBM
 # (MI355X_MICROARCH.md: 38 MB table of random rows 8.6 TB/s, 151 MB 7.4-7.9 TB/s, HBM sweep 6.0-6.1 TB/s)
 INFINITY_CACHE_BYTES = 256 * 1024 * 1024
@@ -100,6 +104,28 @@ def pmc_traffic(kernel: str, workload: str = "molhiv_b512"):
             tot += rec.get("hbm_bytes_per_launch", 0.0) * rec.get("launches", 1)
             n += rec.get("launches", 1)
     return round(tot / n) if n else None
+
+
+def pmc_mfma(kernel: str, workload: str = "molhiv_b512"):
+    """MFMA-pipe utilisation of the kernel family `kernel` in `workload` from the committed rocprofv3 counter passes
+    (scripts/rocprof_pmc_mfma.sh: SQ_VALU_MFMA_BUSY_CYCLES / (4 x SQ_BUSY_CU_CYCLES), launch-weighted over the family's instantiations:
+    the share of the cycles a CU has wavefronts of the launch during which a SIMD's matrix pipe is busy), or None."""
+    path = os.path.join(ROOT, "profiles", PMC_MFMA_FILE)
+    pats = PMC_NAMES.get(kernel)
+    if pats is None or not os.path.exists(path):
+        return None
+    try:
+        table = json.load(open(path)).get(workload)
+    except Exception:
+        return None
+    if not table:
+        return None
+    tot = n = 0.0
+    for name, rec in table.items():
+        if any(p in name for p in pats) and rec.get("mfma_busy") is not None:
+            tot += rec["mfma_busy"] * rec.get("launches", 1)
+            n += rec.get("launches", 1)
+    return round(tot / n, 4) if n else None
 
 
 def _flush_c_stdio():
@@ -396,7 +422,9 @@ def bench_large_graph(args, world, rank, dev):
         else:
             ach = work[name]["bytes"] / (t_ms * 1e-3) / 1e9
             roof = {"bound": "hbm", "achieved": round(ach, 1), "peak": PEAK_HBM_GBS, "unit": "GB/s", "frac": round(ach / PEAK_HBM_GBS, 4)}
-        roof.update({"traffic": None, "kernel": name, "launches": n_launch, "avg_launch_us": round(1e3 * t_ms / max(n_launch, 1), 1)})
+        roof.update({"traffic": pmc_traffic(name, args.workload), "kernel": name, "launches": n_launch,
+                     "avg_launch_us": round(1e3 * t_ms / max(n_launch, 1), 1),
+                     "traffic_source": "profiles/" + PMC_FILE + " (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE per launch of this workload)"})
         agg_b = sum(work[k]["bytes"] for k in ("aggregate_fwd", "aggregate_bwd") if k in work)
         agg_t = sum(times[k]["total_ms"] for k in ("aggregate_fwd", "aggregate_bwd") if k in times)
         result = {"metric": "edges/sec (fwd+bwd) of one PHMGINEConv PHM-4 layer on a synthetic 10M-node/50M-edge graph",
@@ -658,6 +686,9 @@ def main():
                         out["peak_note"] = ("footprint below the 256 MiB Infinity Cache: priced against the guide's random-row rate "
                                             "out of it (8.6 TB/s), not against HBM (8 TB/s)")
                 out["traffic"] = pmc_traffic(kname, args.workload)
+                if kname in MFMA_KERNELS:
+                    # counter-based: SQ_VALU_MFMA_BUSY_CYCLES / (4 SIMDs x SQ_BUSY_CU_CYCLES) from profiles/<PMC_MFMA_FILE>
+                    out["mfma_busy"] = pmc_mfma(kname, args.workload)
                 return out
             result["roofline_phm_gemm"] = frac_of("phm_gemm_fwd")
             # (molecule batches: the forward aggregation rides inside the layer's first GEMM — `roofline_phm_gemm_aggregate` —

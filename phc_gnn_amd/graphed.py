@@ -47,7 +47,9 @@ def bucket_shape(batches: List[synth.GraphBatch], slack: float = 0.02, multiple:
     n_max = int(np.ceil(n * (1 + slack) / multiple) * multiple) + multiple
     if ROUND_ROWS > 0:
         whole = n_max // ROUND_ROWS * ROUND_ROWS
-        if whole >= n + multiple:                             # (still at least `multiple` padding nodes: the padding graphs live there)
+        # (only while half of the relative slack and `multiple` padding nodes remain — ADVICE r5: a caller that sizes the bucket from
+        # a SAMPLE of its batches relies on the slack; the padding graphs live in the padding nodes)
+        if whole >= int(np.ceil(n * (1 + slack / 2))) + multiple:
             n_max = whole
     e_max = int(np.ceil(e * (1 + slack) / multiple) * multiple)
     return n_max, e_max

@@ -7,6 +7,6 @@ WL=${2:-molhiv_b512}
 for c in FETCH_SIZE WRITE_SIZE; do
   OUT=$GRAFT_REPO_ROOT/gpurun_out/pmc_$1_${WL}_$c
   rm -rf $OUT && mkdir -p $OUT
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT -- python3 bench.py --workload $WL --steps 10 --warmup 3 --cpu-steps 0 --mode eager --profile-steps 0 --min-time 0 > $OUT/bench.log 2>&1
+  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT -- python3 bench.py --workload $WL --steps ${PHC_PMC_STEPS:-10} --warmup ${PHC_PMC_WARMUP:-3} --cpu-steps 0 --mode eager --profile-steps 0 --min-time 0 > $OUT/bench.log 2>&1
   ls $OUT/*/ | head
 done

@@ -1,6 +1,6 @@
 """Compact per-step summary of a rocprofv3 --kernel-trace --stats run.
 
-    summarize_rocprof.py <kernel_stats.csv | kernel_trace.csv> [steps] [top]
+    summarize_rocprof.py <kernel_stats.csv | kernel_trace.csv> [steps] [top] [marker substring]
 
 Given the kernel TRACE, the table is restricted to the REPLAY WINDOW: the last `steps` whole training steps of the run, a step
 being the span from one launch of the step's last kernel (the marker, `opt_adam_kernel` when present, otherwise the most frequent
@@ -30,11 +30,14 @@ def table(rows_by_name, steps, top, header):
         print(f"{short(name):60s} {c / steps:10.1f} {t / c / 1e3:9.2f} {t / steps / 1e3:9.1f} {100 * t / tot:6.2f}")
 
 
-def from_trace(path, steps, top):
+def from_trace(path, steps, top, marker_sub=None):
     rows = list(csv.DictReader(open(path)))
     rows.sort(key=lambda r: int(r["Start_Timestamp"]))
     names = [r["Kernel_Name"] for r in rows]
-    marker = next((n for n in set(names) if ("opt_adam_kernel" in n or "opt_clip_adam_fused_kernel" in n)), None)
+    if marker_sub:
+        marker = next((n for n in set(names) if marker_sub in n), None)
+    else:
+        marker = next((n for n in set(names) if ("opt_adam_kernel" in n or "opt_clip_adam_fused_kernel" in n)), None)
     if marker is None:
         cnt = defaultdict(int)
         for n in names:
@@ -67,4 +70,7 @@ if __name__ == "__main__":
     steps = float(sys.argv[2]) if len(sys.argv) > 2 else 1.0
     top = int(sys.argv[3]) if len(sys.argv) > 3 else 30
     head = open(path).readline()
-    (from_trace if "Start_Timestamp" in head else from_stats)(path, steps, top)
+    if "Start_Timestamp" in head:
+        from_trace(path, steps, top, sys.argv[4] if len(sys.argv) > 4 else None)     # [4]: substring of the step's marker kernel
+    else:
+        from_stats(path, steps, top)
