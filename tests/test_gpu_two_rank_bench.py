@@ -6,6 +6,12 @@ import json
 import os
 import socket
 import subprocess
+
+# Two PROCESSES share one GPU here (a test-only stand-in for two ranks): the launches whose workgroups wait for each other inside the
+# launch (the one-launch MLP / optimizer kernels of round 6) assume their grid is co-resident, which two processes interleaving on one
+# device cannot promise — each could hold part of the CUs and wait for the rest (the poll is bounded: the run would end with
+# PHC_ERR_RENDEZVOUS, not hang).  A rank that owns its GPU, as bench.py --gpus N launches them, is not in that position.
+SHARED_GPU_ENV = {"PHC_MLP_BWD_FUSED": "0", "PHC_MLP_FWD_FUSED": "0", "PHC_CLIP_ADAM_FUSED": "0"}
 import sys
 
 import pytest
@@ -23,7 +29,7 @@ def _free_port():
 def _two_ranks(args):
     port = str(_free_port())
     child = os.path.join(HERE, "helpers", "two_rank_bench_child.py")
-    procs = [subprocess.Popen([sys.executable, child, str(r), "2", port] + args, stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+    procs = [subprocess.Popen([sys.executable, child, str(r), "2", port] + args, env=dict(__import__("os").environ, **SHARED_GPU_ENV), stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
                               text=True) for r in range(2)]
     outs = []
     for p in procs:
