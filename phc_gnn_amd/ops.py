@@ -62,21 +62,20 @@ class _Deferred:
 _DEFER = _Deferred()
 
 
-@contextlib.contextmanager
-def deferred_param_grads():
-    """Wrap forward + ``loss.backward()`` of a training step; parameter gradients of the PHM layers are complete
-    when the block exits."""
-    if _DEFER.active:                       # nested: the outermost block flushes
-        yield
-        return
-    _DEFER.active = True
+class _AutoStep:                           # (process-wide, like the contexts it opens: the backward's hooks run on autograd's device thread)
+    stack = None                           # the ExitStack of a step block a model forward opened by itself (auto_step_forward)
+    in_forward = False
+
+
+_AUTO = _AutoStep()
+
+
+def _deferred_reset() -> None:
     _DEFER.jobs, _DEFER.table_jobs, _DEFER.atom_jobs, _DEFER.beta_jobs, _DEFER.reg = [], [], [], [], None
-    try:
-        yield
-    except BaseException:
-        _DEFER.active = False
-        _DEFER.jobs, _DEFER.table_jobs, _DEFER.atom_jobs, _DEFER.beta_jobs, _DEFER.reg = [], [], [], [], None
-        raise
+
+
+def _deferred_flush() -> None:
+    """Everything filed since the block opened -> the batched launches; the block is closed afterwards."""
     _DEFER.active = False
     jobs, _DEFER.jobs = _DEFER.jobs, []
     tjobs, _DEFER.table_jobs = _DEFER.table_jobs, []
@@ -100,6 +99,26 @@ def deferred_param_grads():
         _flush_param_grads(jobs)
     if reg is not None:                                      # the regulariser could not ride in a step tail: its own launch
         _weight_reg_launch(reg["Ws"], reg["coef"], reg["p"], reg["loss"])
+
+
+@contextlib.contextmanager
+def deferred_param_grads():
+    """Wrap forward + ``loss.backward()`` of a training step; parameter gradients of the PHM layers are complete
+    when the block exits."""
+    if _AUTO.stack is not None and not _AUTO.in_forward:
+        close_auto_step(flush=False)                         # (a block a forward opened by itself whose backward never came)
+    if _DEFER.active:                       # nested: the outermost block flushes
+        yield
+        return
+    _DEFER.active = True
+    _deferred_reset()
+    try:
+        yield
+    except BaseException:
+        _DEFER.active = False
+        _deferred_reset()
+        raise
+    _deferred_flush()
 
 
 # the explicit weight regulariser and the gate map's parameter gradients inside the step tail's last two launches
@@ -551,6 +570,8 @@ def atom_encode_spec(model, data):
 
 @contextlib.contextmanager
 def prebuilt_H(pairs, dense=(), gates=(), encode=None):
+    if _AUTO.stack is not None and not _AUTO.in_forward:
+        close_auto_step(flush=False)                       # (a block a forward opened by itself whose backward never came)
     if _PREBUILT.table or not (pairs or dense or gates):   # nested (outermost wins) or nothing to do
         yield
         return
@@ -3881,11 +3902,7 @@ def downstream_head(x, n_valid, affine_layers, norm_modules, real_affine, activa
 AUTO_STEP = __import__("os").environ.get("PHC_AUTO_STEP", "1") != "0"
 
 
-class _AutoStep:                           # (process-wide, like the contexts it opens: the backward's hooks run on autograd's device thread)
-    stack = None
-
-
-_AUTO = _AutoStep()
+# (_AUTO: defined beside _DEFER)
 
 
 def step_context_active() -> bool:
@@ -3898,12 +3915,15 @@ def auto_step_open() -> bool:
 
 def close_auto_step(flush: bool = False) -> None:
     """Close a step block a forward opened by itself (no-op when none is open).  ``flush`` False: drop whatever was deferred."""
-    stack = getattr(_AUTO, "stack", None)
+    stack = _AUTO.stack
     if stack is None:
         return
     _AUTO.stack = None
-    if not flush:
-        _DEFER.jobs, _DEFER.table_jobs, _DEFER.atom_jobs, _DEFER.beta_jobs, _DEFER.reg = [], [], [], [], None
+    if flush and _DEFER.active:
+        _deferred_flush()
+    else:
+        _DEFER.active = False
+        _deferred_reset()
     stack.close()
 
 
@@ -3919,7 +3939,10 @@ def _accumulate_nodes(model):
 
 
 def auto_step_forward(model, data, run):
-    """``run()`` = the model's forward.  Opens the step's contexts around it and arranges for them to close behind the backward."""
+    """``run()`` = the model's forward.  Opens the step's contexts around it and arranges for them to close behind the backward.
+    Parameter-gradient deferral is live only INSIDE the forward (the layers note that their gradients may be deferred) and between
+    the start and the end of the backward pass that reaches the output: code that runs between the two — or a backward that never
+    comes — sees no open deferral block."""
     close_auto_step(flush=False)                             # a block whose backward never came
     dev = data.x.device
     specs = model.__dict__.get("_phc_auto_specs")
@@ -3927,15 +3950,21 @@ def auto_step_forward(model, data, run):
     if specs is None or specs[0] != key:
         specs = model.__dict__["_phc_auto_specs"] = (key, phm_pairs(model), dense_weights(model), gate_specs(model))
     stack = contextlib.ExitStack()
+    _AUTO.in_forward = True
     try:
         stack.enter_context(stat_accumulators(dev))
         stack.enter_context(prebuilt_H(specs[1], specs[2], specs[3], encode=atom_encode_spec(model, data)))
-        stack.enter_context(deferred_param_grads())
+        _DEFER.active = True
+        _deferred_reset()
         out = run()
     except BaseException:
-        _DEFER.jobs, _DEFER.table_jobs, _DEFER.atom_jobs, _DEFER.beta_jobs, _DEFER.reg = [], [], [], [], None
+        _DEFER.active = False
+        _deferred_reset()
         stack.close()
         raise
+    finally:
+        _AUTO.in_forward = False
+    _DEFER.active = False
     if not (torch.is_tensor(out) and out.requires_grad):
         stack.close()
         return out
@@ -3943,15 +3972,15 @@ def auto_step_forward(model, data, run):
     nodes = _accumulate_nodes(model)
 
     def at_backward_start(grad):
-        if getattr(_AUTO, "stack", None) is not stack:
+        if _AUTO.stack is not stack:
             return grad                                      # (closed meanwhile: a second backward over a retained graph runs per layer)
         try:
             accumulating = all(torch._C._will_engine_execute_node(nd) for nd in nodes)
         except Exception:
             accumulating = False
-        if not accumulating:
-            _DEFER.active = False                            # torch.autograd.grad / inputs=...: every layer returns its own gradients
-        torch.autograd.Variable._execution_engine.queue_callback(lambda: close_auto_step(flush=True) if getattr(_AUTO, "stack", None) is stack else None)
+        # torch.autograd.grad / inputs=...: no AccumulateGrad runs — every layer returns its own gradients (no deferral)
+        _DEFER.active = accumulating
+        torch.autograd.Variable._execution_engine.queue_callback(lambda: close_auto_step(flush=True) if _AUTO.stack is stack else None)
         return grad
     out.register_hook(at_backward_start)
     return out

@@ -27,7 +27,8 @@ def test_plain_backward_takes_the_batched_tail_and_matches_the_harness_step():
     from phc_gnn_amd import harness, ops
     model, data = _fresh()
     loss = _ref_loop_loss(model, data)
-    assert ops._DEFER.active and ops._PREBUILT.table           # the forward opened the step's block by itself
+    assert ops.auto_step_open() and ops._PREBUILT.table        # the forward opened the step's block by itself
+    assert not ops._DEFER.active                               # ... and nothing is deferred outside the forward and the backward pass
     loss.backward()
     assert not ops.step_context_active() and getattr(ops._AUTO, "stack", None) is None      # ... and the backward closed it
     got = {k: p.grad.clone() for k, p in model.named_parameters()}
