@@ -687,8 +687,20 @@ typedef struct phc_mlp_norm_bwd_desc {
     int64_t N;
     int32_t h, act_o, act_i;
     uint32_t *barrier;
+    /* agg_src != NULL: `dout` does not exist yet — it is the dx of the sum aggregation of the layer ABOVE (autograd of
+     * undirectional/messagepassing.py:132-146, identity message function; what phc_aggregate_dx_rows computes in a launch of its own):
+     *     dout[r] = sum over the out-edges (r -> d) of agg_src[d]  (+ agg_src[r] when agg_add_self)  (+ agg_residual[r]),
+     * agg_src = that layer's ds.  The launch builds the rows itself (same edge order and additions as phc_aggregate_dx_rows: identical
+     * rows for out-degrees <= 16) and writes them to dx_out once; `dout` is ignored.  agg_rowptr_t / agg_col_t: the source-sorted
+     * view; agg_ell_t [N][4]: phc_csr_build_pair_codes_resident_ell.  n_src = n_dst = N. */
+    const float *agg_src;          /* [N, h] or NULL                                                   */
+    const float *agg_residual;     /* [N, h] or NULL                                                   */
+    const int32_t *agg_rowptr_t, *agg_col_t, *agg_ell_t;
+    float *dx_out;                 /* [N, h] out                                                       */
+    int32_t agg_add_self;
 } phc_mlp_norm_bwd_desc;
 int phc_mlp_norm_bwd_fused_supported(int64_t N, int h);
+int phc_mlp_norm_bwd_fused_agg_supported(int64_t N, int h);
 size_t phc_mlp_norm_bwd_fused_barrier_words(void);        /* uint32 words of `barrier` */
 int phc_mlp_norm_bwd_fused(const phc_mlp_norm_bwd_desc *desc, void *stream);
 /* Diagnostics only: when set (32 device words), workgroups 0 and G - 1 of every launch stamp their phase clocks there; NULL: off. */

@@ -50,16 +50,18 @@ class _SumConvBase(nn.Module):
         return _engine.aggregate_sum(x, edge_index, edge_attr, self.msg_encoder_str, add_self, num_dst)
 
     def propagate_encoded(self, edge_index: Adj, x: torch.Tensor, edge_idx: torch.Tensor, encoder, size: Size = None,
-                          add_self: bool = False, dx_handoff=None, pending=None, lazy: bool = False) -> torch.Tensor:
+                          add_self: bool = False, dx_handoff=None, pending=None, lazy: bool = False, dx_link=None) -> torch.Tensor:
         """Same as ``propagate`` with edge_attr = encoder(edge_idx), evaluated inside the
         aggregation kernel from LDS-staged embedding tables (no [E, h] tensor).  ``dx_handoff`` (engine: DxHandoff): another
-        consumer of ``x`` may park its gradient there; this op's backward then adds it inside its own dx kernel."""
+        consumer of ``x`` may park its gradient there; this op's backward then adds it inside its own dx kernel.  ``dx_link``
+        (engine: DxLink): this op is x's only autograd consumer and x's producer may build this op's dx inside its own backward launch."""
         tables = encoder.engine_tables
         num_dst = size[1] if size is not None and size[1] is not None else None
         # pending (engine: PendingNorm): x = act(norm(y)) (+ skip) of the layer in front has not been evaluated yet; the
         # aggregation kernel does it on the fly (or runs the stand-alone pass first where it cannot)
         return _engine.aggregate_sum_encoded(x, edge_index, edge_idx, _engine.tableset_for(encoder, tables), tables,
-                                             self.msg_encoder_str, add_self, num_dst, dx_handoff=dx_handoff, pending=pending, lazy=lazy)
+                                             self.msg_encoder_str, add_self, num_dst, dx_handoff=dx_handoff, pending=pending, lazy=lazy,
+                                             dx_link=dx_link)
 
     def message(self, x_j: torch.Tensor, edge_attr: torch.Tensor) -> torch.Tensor:
         """Per-edge message (API parity; the engine fuses this into the aggregation)."""
@@ -198,7 +200,7 @@ class _SoftmaxMixin:
         out = _engine.aggregate_softmax(x, edge_index, edge_attr, self.beta, self.msg_encoder_str, num_dst, add_self=fused_self)
         return out + x if (add_self and not fused_self) else out
 
-    def propagate_encoded(self, edge_index, x, edge_idx, encoder, size=None, add_self=False, dx_handoff=None, pending=None, lazy=False):
+    def propagate_encoded(self, edge_index, x, edge_idx, encoder, size=None, add_self=False, dx_handoff=None, pending=None, lazy=False, dx_link=None):
         # (dx_handoff is never accepted here: the softmax backward has no residual input, so nobody parks a gradient in it;
         # `pending`: the un-applied norm of the layer in front rides in the walk — engine PendingNorm; `lazy` has no softmax form)
         """Softmax aggregation with edge_attr = encoder(edge_idx): the kernels add the F table rows of every edge

@@ -193,13 +193,18 @@ class PHMSkipConnectAdd(nn.Module):
                 # lazy: the aggregate goes straight into the fused node below, whose first GEMM may build the rows itself
                 # (engine: PendingAggregate; mlp_norm_fused launches the aggregation on its own when it does not apply)
                 lazy = type(tr).__name__ == "PHMGINEConv"
+                # the aggregation is x[0]'s ONLY autograd consumer (the skip's share travels through a hand-off, or the skip is another
+                # tensor): its dx may be built inside the backward launch of the fused node that produced x[0] (engine: DxLink)
+                single = (handoff is not None and agg_handoff is handoff and x[0] is x[1]) or \
+                    (skip_sum is not None and x[0] is not x[1] and not first_layer)
+                dx_link = getattr(x[0], "_phc_dx_link", None) if (single and lazy) else None
                 if pending is not None:
                     agg = tr.propagate_encoded(edge_index, x[0], edge_attr, edge_encoder, size, add_self=tr.add_self_loops,
-                                               dx_handoff=agg_handoff, pending=pending, lazy=lazy)
+                                               dx_handoff=agg_handoff, pending=pending, lazy=lazy, dx_link=dx_link)
                     x[0]._phc_pending = None                 # evaluated (or materialised) by that call, or riding with the aggregate
                 elif lazy:
                     agg = tr.propagate_encoded(edge_index, x[0], edge_attr, edge_encoder, size, add_self=tr.add_self_loops,
-                                               dx_handoff=agg_handoff, lazy=True)
+                                               dx_handoff=agg_handoff, lazy=True, dx_link=dx_link)
                 else:
                     agg = tr.propagate_encoded(edge_index, x[0], edge_attr, edge_encoder, size, add_self=tr.add_self_loops,
                                                dx_handoff=agg_handoff)

@@ -53,6 +53,16 @@ struct MlpBwdArgs {
     unsigned *bar;                               // barrier words (mf_grid_barrier): zero before the first use, owned by the kernel
     int *err;
     unsigned long long *stamps;                  // diagnostics only (NULL in the product): 8 wall-clock stamps of workgroups 0 and G - 1
+    // ---- AGGT: `dout` is not there yet — it is the dx of the sum aggregation of the layer ABOVE (messagepassing.py:132-146 backward,
+    // identity message function): dout[r] = sum over the out-edges (r -> d) of gsrc[d] (+ gsrc[r] for the self term) (+ residual[r]),
+    // gsrc = that layer's ds.  The rows are built in P0 by aggregate_dx_rows_kernel's own additions (encoder.hip: same edge order,
+    // same association) and written to dx_out once (the skip's share of the layer below / the encoder's gradient read them) ----
+    const float *gsrc;                           // [N, 128]
+    const float *residual;                       // [N, 128] or NULL
+    const int *rowptr_t, *col_t;                 // source-sorted view (CSC of the destination-sorted one)
+    const int *ell_t;                            // [N][4]: the first four out-edges of every row (destinations), csr.hip
+    float *dx_out;                               // [N, 128] out
+    int add_self;
 };
 
 template <int MAXS>
@@ -275,7 +285,7 @@ __device__ __forceinline__ void mf_norm_bwd(float *G, const float *XH, int tile_
             a.stamps[(blockIdx.x == 0 ? 0 : 16) + (i)] = __builtin_amdgcn_s_memrealtime();                 \
     } while (0)
 
-template <int MAXS>
+template <int MAXS, bool AGGT>
 __global__ __launch_bounds__(MF_THREADS, 2) void mlp_bwd_fused_kernel(MlpBwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     constexpr int TS = 3 * MF_TILE;                          // per step: [G | X | Z] tiles
@@ -284,9 +294,15 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mlp_bwd_fused_kernel(MlpBwdArgs
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int c = lane & 15, kq = lane >> 4, col0 = 32 * wave;
     const int c4 = tid & 31, rg = tid >> 5;
-    const long long N = a.N, G = gridDim.x, g = blockIdx.x;
+    // workgroup -> steps.  Plain: round-robin (g, g + G).  AGGT: MAXS consecutive steps, the workgroups of one XCD a contiguous range of
+    // them (xcd_contiguous_block; the grid is a multiple of 8) — the forward kernel's map: a molecule's bonds stay inside it, so the
+    // rows of the layer above that the gather reads were written through this XCD's L2
+    const long long N = a.N, g = blockIdx.x;
+    const long long G = AGGT ? 1 : (long long)gridDim.x;     // step stride
     const long long num_steps = (N + 15) / 16;
-    const int steps = (int)min((long long)MAXS, g < num_steps ? (num_steps - g + G - 1) / G : 0LL);
+    const long long g0 = AGGT ? (long long)xcd_contiguous_block(blockIdx.x, gridDim.x) * MAXS : g;      // first step
+    const int steps = AGGT ? (int)max(0LL, min((long long)MAXS, num_steps - g0))
+                           : (int)min((long long)MAXS, g < num_steps ? (num_steps - g + G - 1) / G : 0LL);
     unsigned gen = 0;
     if (tid == 0) gen = __hip_atomic_load(a.bar + (MF_SUB + 1 + g % MF_SUB) * MF_BSTRIDE, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     const long long n_valid = a.n_valid ? min((long long)*a.n_valid, N) : N;
@@ -297,27 +313,98 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mlp_bwd_fused_kernel(MlpBwdArgs
     // both operand slices live in registers for the whole launch (2 x 64): nothing is loaded between the barriers
     f32x4_t hreg[2][8], hreg1[2][8];
     f32x4_t ld[MAXS][2][3];
+    // the norms' constants: column tid's for the LDS tables (stored behind the rows), and the outer norm's of this thread's four
+    // columns straight into registers — the first gate pass runs on the loaded rows BEFORE they go to LDS (one LDS round trip less in
+    // front of the first barrier).  AGGT: issued between the gather's two round trips (behind the gather they were a third)
+    float cso[4], csi[4];
+    f32x4_t o_mean, o_inv, o_w, o_b;
+    auto load_consts = [&]() __attribute__((always_inline)) {
+        if (tid < MF_H) {
 #pragma unroll
-    for (int s = 0; s < MAXS; ++s)
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const long long row = min((g + (long long)min(s, max(steps - 1, 0)) * G) * 16 + rg + 8 * u, N - 1);
-            ld[s][u][0] = *reinterpret_cast<const f32x4_t *>(a.dout + (size_t)row * MF_H + 4 * c4);
-            ld[s][u][1] = *reinterpret_cast<const f32x4_t *>(a.y2 + (size_t)row * MF_H + 4 * c4);
-            ld[s][u][2] = *reinterpret_cast<const f32x4_t *>(a.z1 + (size_t)row * MF_H + 4 * c4);
+            for (int q = 0; q < 4; ++q) {
+                const int slot = q < 2 ? q : q + 2;          // mean, invstd, w, b = save_stat slots 0, 1, 4, 5
+                cso[q] = a.save_o[slot * MF_H + tid];
+                csi[q] = a.save_i[slot * MF_H + tid];
+            }
         }
+        o_mean = *reinterpret_cast<const f32x4_t *>(a.save_o + 4 * c4);
+        o_inv = *reinterpret_cast<const f32x4_t *>(a.save_o + MF_H + 4 * c4);
+        o_w = *reinterpret_cast<const f32x4_t *>(a.save_o + 4 * MF_H + 4 * c4);
+        o_b = *reinterpret_cast<const f32x4_t *>(a.save_o + 5 * MF_H + 4 * c4);
+    };
+    if constexpr (!AGGT) {
+#pragma unroll
+        for (int s = 0; s < MAXS; ++s)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) {
+                const long long row = min((g0 + (long long)min(s, max(steps - 1, 0)) * G) * 16 + rg + 8 * u, N - 1);
+                ld[s][u][0] = *reinterpret_cast<const f32x4_t *>(a.dout + (size_t)row * MF_H + 4 * c4);
+                ld[s][u][1] = *reinterpret_cast<const f32x4_t *>(a.y2 + (size_t)row * MF_H + 4 * c4);
+                ld[s][u][2] = *reinterpret_cast<const f32x4_t *>(a.z1 + (size_t)row * MF_H + 4 * c4);
+            }
+        load_consts();
+    } else {
+        // One row per 32-lane group (this thread: columns 4 c4 .. + 3 of rows rg, rg + 8 of every step).  Round trip 1: row pointers
+        // and the row's first four out-edges (ell_t: side by side per row) — with the rows of y2 and z1 behind them; round trip 2:
+        // the row of gsrc itself, the residual's and the four destinations' (slots past the degree name the row itself: a line it
+        // loads anyway), all four rows of the thread in flight together (the operand slices wait until the gather is through).
+        const f32x4_t zero = {0.f, 0.f, 0.f, 0.f};
+        long long dj[MAXS * 2];
+        int eb[MAXS * 2], deg[MAXS * 2], dst[MAXS * 2][4];
+#pragma unroll
+        for (int j = 0; j < MAXS * 2; ++j) {
+            const int sI = j >> 1, u = j & 1;
+            const long long d = (g0 + sI) * 16 + rg + 8 * u;
+            const bool ok = sI < steps && d < N;
+            dj[j] = ok ? d : -1;
+            const long long dc = ok ? d : 0;
+            eb[j] = a.rowptr_t[dc];
+            deg[j] = ok ? a.rowptr_t[dc + 1] - eb[j] : 0;
+            const int4 ed = *reinterpret_cast<const int4 *>(a.ell_t + dc * 4);
+            dst[j][0] = ed.x; dst[j][1] = ed.y; dst[j][2] = ed.z; dst[j][3] = ed.w;
+        }
+#pragma unroll
+        for (int j = 0; j < MAXS * 2; ++j) {
+            const long long dc = dj[j] >= 0 ? dj[j] : 0;
+            ld[j >> 1][j & 1][1] = *reinterpret_cast<const f32x4_t *>(a.y2 + (size_t)dc * MF_H + 4 * c4);
+            ld[j >> 1][j & 1][2] = *reinterpret_cast<const f32x4_t *>(a.z1 + (size_t)dc * MF_H + 4 * c4);
+        }
+        load_consts();
+        const float *res = a.residual ? a.residual : a.gsrc;  // (without a residual the load re-reads the row itself: unconditional)
+        f32x4_t sv[MAXS * 2], rv[MAXS * 2], gv[MAXS * 2][4];
+#pragma unroll
+        for (int j = 0; j < MAXS * 2; ++j) {
+            const long long dc = dj[j] >= 0 ? dj[j] : 0;
+            sv[j] = *reinterpret_cast<const f32x4_t *>(a.gsrc + (size_t)dc * MF_H + 4 * c4);
+            rv[j] = *reinterpret_cast<const f32x4_t *>(res + (size_t)dc * MF_H + 4 * c4);
+#pragma unroll
+            for (int i = 0; i < 4; ++i) gv[j][i] = *reinterpret_cast<const f32x4_t *>(a.gsrc + (size_t)dst[j][i] * MF_H + 4 * c4);
+        }
+        // aggregate_dx_rows_kernel's additions: acc = 0 + (g0 + g1); + g2; + g3; ...; + self; + residual
+#pragma unroll
+        for (int j = 0; j < MAXS * 2; ++j) {
+            f32x4_t acc = zero;
+            if (deg[j] > 0) acc += gv[j][0] + (deg[j] > 1 ? gv[j][1] : zero);
+            if (deg[j] > 2) acc += gv[j][2];
+            if (deg[j] > 3) acc += gv[j][3];
+            for (int e = eb[j] + 4; e < eb[j] + deg[j]; ++e)     // a row with more than four out-edges: one at a time (rare on molecules)
+                acc += *reinterpret_cast<const f32x4_t *>(a.gsrc + (size_t)a.col_t[e] * MF_H + 4 * c4);
+            if (a.add_self) acc += sv[j];
+            if (a.residual) acc += rv[j];
+            ld[j >> 1][j & 1][0] = dj[j] >= 0 ? acc : zero;
+        }
+        // (every store behind every load: hipcc cannot prove dx_out distinct from the inputs)
+#pragma unroll
+        for (int j = 0; j < MAXS * 2; ++j)
+            if (dj[j] >= 0) *reinterpret_cast<f32x4_t *>(a.dx_out + (size_t)dj[j] * MF_H + 4 * c4) = ld[j >> 1][j & 1][0];
+    }
     if (tid < MF_H) {
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
-            const int slot = q < 2 ? q : q + 2;              // mean, invstd, w, b = save_stat slots 0, 1, 4, 5
-            cst_o[q * MF_H + tid] = a.save_o[slot * MF_H + tid];
-            cst_i[q * MF_H + tid] = a.save_i[slot * MF_H + tid];
+            cst_o[q * MF_H + tid] = cso[q];
+            cst_i[q * MF_H + tid] = csi[q];
         }
     }
-    // the outer norm's constants of this thread's four columns straight into registers: the first gate pass runs on the loaded rows
-    // BEFORE they go to LDS (one LDS round trip less in front of the first barrier)
-    const f32x4_t o_mean = *reinterpret_cast<const f32x4_t *>(a.save_o + 4 * c4), o_inv = *reinterpret_cast<const f32x4_t *>(a.save_o + MF_H + 4 * c4);
-    const f32x4_t o_w = *reinterpret_cast<const f32x4_t *>(a.save_o + 4 * MF_H + 4 * c4), o_b = *reinterpret_cast<const f32x4_t *>(a.save_o + 5 * MF_H + 4 * c4);
     mf_load_operand(a.H2Tk4, col0, c, kq, hreg);             // (behind the rows: the first barrier does not need them)
     mf_load_operand(a.H1Tk4, col0, c, kq, hreg1);
     {
@@ -329,7 +416,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mlp_bwd_fused_kernel(MlpBwdArgs
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
                 const int r = rg + 8 * u;
-                const long long row = (g + (long long)s * G) * 16 + r;
+                const long long row = (g0 + (long long)s * G) * 16 + r;
                 const bool live = s < steps && row < n_valid;
                 f32x4_t gq, xh;
 #pragma unroll
@@ -372,7 +459,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mlp_bwd_fused_kernel(MlpBwdArgs
         if (g == 0 && a.dwb_o) { a.dwb_o[tid] = (float)t1; a.dwb_o[MF_H + tid] = (float)t0; }
     }
     mf_lds_barrier();
-    mf_norm_bwd<MAXS>(tG, tX, TS, cst_o, mm, steps, g, G, n_valid, N, a.dy2);
+    mf_norm_bwd<MAXS>(tG, tX, TS, cst_o, mm, steps, g0, G, n_valid, N, a.dy2);
     mf_lds_barrier();
     {
         f32x4_t acc[MAXS][2];
@@ -389,7 +476,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mlp_bwd_fused_kernel(MlpBwdArgs
     }
     mf_lds_barrier();
     MF_STAMP(4);
-    mf_gate_and_sums<MAXS>(tX, tZ, TS, cst_i, a.act_i, steps, g, G, n_valid, red, a.acc_i, rep);
+    mf_gate_and_sums<MAXS>(tX, tZ, TS, cst_i, a.act_i, steps, g0, G, n_valid, red, a.acc_i, rep);
     MF_STAMP(5);
     mf_grid_barrier(a.bar, gen, a.err);
     MF_STAMP(6);
@@ -403,14 +490,14 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mlp_bwd_fused_kernel(MlpBwdArgs
         if (g == 0 && a.dwb_i) { a.dwb_i[tid] = (float)t1; a.dwb_i[MF_H + tid] = (float)t0; }
     }
     mf_lds_barrier();
-    mf_norm_bwd<MAXS>(tX, tZ, TS, cst_i, mm, steps, g, G, n_valid, N, a.dz1);
+    mf_norm_bwd<MAXS>(tX, tZ, TS, cst_i, mm, steps, g0, G, n_valid, N, a.dz1);
     mf_lds_barrier();
 #pragma unroll
     for (int s = 0; s < MAXS; ++s)
         if (s < steps) {
             f32x4_t acc[2];
             mf_gemm_tile(tX + s * TS, hreg1, c, kq, acc);
-            const long long row = (g + (long long)s * G) * 16 + c;
+            const long long row = (g0 + (long long)s * G) * 16 + c;
             if (row < N) {
 #pragma unroll
                 for (int t = 0; t < 2; ++t) *reinterpret_cast<f32x4_t *>(a.ds + (size_t)row * MF_H + col0 + 16 * t + 4 * kq) = acc[t];
@@ -597,48 +684,61 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mlp_fwd_fused_kernel(MlpFwdArgs
                 }
             }
         };
-        // the first step's rows go in flight as soon as the edge slots are there: they travel under the table staging, the pending
-        // norm's totals and the barrier below
-        f32x4_t ys0[2], ks0[2], ye0[2][4], ke0[2][4];
-        issue_rows(0, ys0, ks0, ye0, ke0);
-        // bond tables -> LDS: row r of feature f(r), component cc = column / k.  All of a thread's entries travel together (clamped,
-        // unrolled; pointers out of the kernel arguments by constant index: as a run-time loop with a pointer hop per entry the staging
-        // alone was four dependent round trips, 16 us in front of the gather)
-        {
-            f32x4_t tv[MF_AGG_MAX_R * 32 / MF_THREADS];
+        // Everything else the prologue reads goes in flight in the SAME round trip as the row pointers and edge slots — the bond
+        // table entries (addresses out of the kernel arguments), the pending norm's totals and affine parameters — BEFORE the first
+        // use of an edge slot makes the wavefront wait: behind issue_rows they were a second round trip in front of the LDS barrier
+        // (prologue 5.4 us, scripts/dbg/mlp_fwd_agg_phases.py).  bond tables -> LDS: row r of feature f(r), component cc = column / k.
+        // All of a thread's entries travel together (clamped, unrolled; pointers out of the kernel arguments by constant index: as a
+        // run-time loop with a pointer hop per entry the staging alone was four dependent round trips, 16 us in front of the gather)
+        f32x4_t tv[MF_AGG_MAX_R * 32 / MF_THREADS];
 #pragma unroll
-            for (int it = 0; it < MF_AGG_MAX_R * 32 / MF_THREADS; ++it) {
-                const int e = min(tid + it * MF_THREADS, a.R * 32 - 1);
-                const int r = e >> 5, q = e & 31, cc = (4 * q) / a.k, kk = 4 * q - cc * a.k;
-                int f = 0, o = 0;
+        for (int it = 0; it < MF_AGG_MAX_R * 32 / MF_THREADS; ++it) {
+            const int e = min(tid + it * MF_THREADS, a.R * 32 - 1);
+            const int r = e >> 5, q = e & 31, cc = (4 * q) / a.k, kk = 4 * q - cc * a.k;
+            int f = 0, o = 0;
 #pragma unroll
-                for (int u = 1; u < 4; ++u) {
-                    const bool past = u < a.F && r >= a.off[u];
-                    f = past ? u : f;
-                    o = past ? a.off[u] : o;
-                }
-                const int ti = cc * a.F + f;
-                const float *base = a.tp[0];
-#pragma unroll
-                for (int u = 1; u < 16; ++u) base = ti == u ? a.tp[u] : base;
-                tv[it] = *reinterpret_cast<const f32x4_t *>(base + (size_t)(r - o) * a.k + kk);
+            for (int u = 1; u < 4; ++u) {
+                const bool past = u < a.F && r >= a.off[u];
+                f = past ? u : f;
+                o = past ? a.off[u] : o;
             }
+            const int ti = cc * a.F + f;
+            const float *base = a.tp[0];
 #pragma unroll
-            for (int it = 0; it < MF_AGG_MAX_R * 32 / MF_THREADS; ++it) {
-                const int e = tid + it * MF_THREADS;
-                if (e < a.R * 32) *reinterpret_cast<f32x4_t *>(tbl + (e >> 5) * MF_H + 4 * (e & 31)) = tv[it];
-            }
+            for (int u = 1; u < 16; ++u) base = ti == u ? a.tp[u] : base;
+            tv[it] = *reinterpret_cast<const f32x4_t *>(base + (size_t)(r - o) * a.k + kk);
         }
-        if (normed && tid < MF_H) {
-            double S = 0.0, Q = 0.0;
+        unsigned long long tw[STAT_ACC_REP][2][2];           // (the totals of the launch in front: plain loads across a kernel boundary)
+        const bool norm_lane = normed && tid < MF_H;         // wave-uniform (wavefronts 0 and 1)
+        if (norm_lane) {
 #pragma unroll
-            for (int rp = 0; rp < STAT_ACC_REP; ++rp) {      // (the totals of the launch in front: plain loads across a kernel boundary)
-                S += stat_acc_part(a.nacc, MF_H, rp, 0, tid);
-                Q += stat_acc_part(a.nacc, MF_H, rp, 1, tid);
-            }
+            for (int rp = 0; rp < STAT_ACC_REP; ++rp)
+#pragma unroll
+                for (int qty = 0; qty < 2; ++qty) {
+                    const unsigned long long *pw = a.nacc + ((size_t)(rp * 2 + qty) * 2) * MF_H + tid;
+                    tw[rp][qty][0] = pw[0];
+                    tw[rp][qty][1] = pw[MF_H];
+                }
             const int comp = tid / a.po.k, kk = tid - comp * a.po.k;
             if (a.po.has_weight) ow = *bn_col_ptr(a.po.weight, a.po.flat, comp, kk, tid);
             if (a.po.has_bias) ob = *bn_col_ptr(a.po.bias, a.po.flat, comp, kk, tid);
+        }
+        // the first step's rows go in flight as soon as the edge slots are there: they travel under the table staging, the pending
+        // norm's arithmetic and the barrier below
+        f32x4_t ys0[2], ks0[2], ye0[2][4], ke0[2][4];
+        issue_rows(0, ys0, ks0, ye0, ke0);
+#pragma unroll
+        for (int it = 0; it < MF_AGG_MAX_R * 32 / MF_THREADS; ++it) {
+            const int e = tid + it * MF_THREADS;
+            if (e < a.R * 32) *reinterpret_cast<f32x4_t *>(tbl + (e >> 5) * MF_H + 4 * (e & 31)) = tv[it];
+        }
+        if (norm_lane) {
+            double S = 0.0, Q = 0.0;
+#pragma unroll
+            for (int rp = 0; rp < STAT_ACC_REP; ++rp) {      // (stat_acc_part's arithmetic, in its order)
+                S += (double)(long long)tw[rp][0][0] * (1.0 / 4096.0) + (double)(long long)tw[rp][0][1] * (1.0 / 4611686018427387904.0);
+                Q += (double)(long long)tw[rp][1][0] * (1.0 / 4096.0) + (double)(long long)tw[rp][1][1] * (1.0 / 4611686018427387904.0);
+            }
             bt_o = bn_from_totals(S, Q, count, ow, ob, a.eps_o);
             ss_o[tid] = bt_o.scale;
             ss_o[MF_H + tid] = bt_o.shift;
@@ -888,8 +988,8 @@ static int mf_capacity() {
         int per_cu = 0;
         hipDeviceProp_t prop;
         static const bool off = getenv("PHC_MLP_BWD_FUSED") && atoi(getenv("PHC_MLP_BWD_FUSED")) == 0;
-        if (off || !ensure_dynamic_lds(&mlp_bwd_fused_kernel<MF_MAXS>, lds) ||
-            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mlp_bwd_fused_kernel<MF_MAXS>, MF_THREADS, lds) != hipSuccess ||
+        if (off || !ensure_dynamic_lds(&mlp_bwd_fused_kernel<MF_MAXS, false>, lds) || !ensure_dynamic_lds(&mlp_bwd_fused_kernel<MF_MAXS, true>, lds) ||
+            hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mlp_bwd_fused_kernel<MF_MAXS, true>, MF_THREADS, lds) != hipSuccess ||
             hipGetDeviceProperties(&prop, dev) != hipSuccess || getenv("HSA_CU_MASK") || getenv("ROC_GLOBAL_CU_MASK"))
             cap[dev] = -1;
         else
@@ -947,12 +1047,20 @@ int phc_mlp_norm_bwd_fused_supported(int64_t N, int h) {
     return groups <= mf_capacity() ? 1 : 0;
 }
 
+/* ... with the dx of the layer above's sum aggregation building the rows of dout inside the launch (desc.agg_src != NULL) */
+int phc_mlp_norm_bwd_fused_agg_supported(int64_t N, int h) {
+    if (h != MF_H || N < 1 || N >= (1LL << 31)) return 0;
+    const long long steps = (N + 15) / 16;
+    return xcd_grid((steps + MF_MAXS - 1) / MF_MAXS) <= mf_capacity() ? 1 : 0;
+}
+
 int phc_mlp_norm_bwd_fused(const phc_mlp_norm_bwd_desc *d, void *stream) {
     PHC_REQUIRE(d, PHC_ERR_INVALID_ARG, "phc_mlp_norm_bwd_fused: null descriptor");
-    PHC_REQUIRE(phc_mlp_norm_bwd_fused_supported(d->N, d->h), PHC_ERR_UNSUPPORTED,
+    const bool agg = d->agg_src != nullptr;
+    PHC_REQUIRE(agg ? phc_mlp_norm_bwd_fused_agg_supported(d->N, d->h) : phc_mlp_norm_bwd_fused_supported(d->N, d->h), PHC_ERR_UNSUPPORTED,
                 "phc_mlp_norm_bwd_fused: N=%lld h=%d outside the one-launch form's range (h = 128, ceil(N / 32) co-resident workgroups)",
                 (long long)d->N, d->h);
-    PHC_REQUIRE(d->dout && d->y2 && d->z1 && d->save_o && d->save_i && d->H2Tk4 && d->H1Tk4 && d->dy2 && d->dz1 && d->ds && d->acc_o &&
+    PHC_REQUIRE((agg || d->dout) && d->y2 && d->z1 && d->save_o && d->save_i && d->H2Tk4 && d->H1Tk4 && d->dy2 && d->dz1 && d->ds && d->acc_o &&
                     d->acc_i && d->barrier,
                 PHC_ERR_INVALID_ARG, "phc_mlp_norm_bwd_fused: null pointer");
     PHC_REQUIRE(d->act_o >= PHC_ACT_IDENTITY && d->act_o <= PHC_ACT_SELU && d->act_i >= PHC_ACT_IDENTITY && d->act_i <= PHC_ACT_SELU,
@@ -962,18 +1070,32 @@ int phc_mlp_norm_bwd_fused(const phc_mlp_norm_bwd_desc *d, void *stream) {
                   reinterpret_cast<uintptr_t>(d->dz1) | reinterpret_cast<uintptr_t>(d->ds)) & 15) == 0 &&
                     ((reinterpret_cast<uintptr_t>(d->acc_o) | reinterpret_cast<uintptr_t>(d->acc_i)) & 7) == 0,
                 PHC_ERR_UNSUPPORTED, "phc_mlp_norm_bwd_fused: 16-byte aligned rows / 8-byte aligned accumulators required");
-    MlpBwdArgs a;
+    MlpBwdArgs a = {};
     a.dout = d->dout; a.y2 = d->y2; a.z1 = d->z1; a.save_o = d->save_o; a.save_i = d->save_i; a.H2Tk4 = d->H2Tk4; a.H1Tk4 = d->H1Tk4;
     a.dy2 = d->dy2; a.dz1 = d->dz1; a.ds = d->ds; a.dwb_o = d->dwb_o; a.dwb_i = d->dwb_i;
     a.acc_o = reinterpret_cast<unsigned long long *>(d->acc_o); a.acc_i = reinterpret_cast<unsigned long long *>(d->acc_i);
     a.n_valid = d->n_valid_dev; a.N = d->N; a.act_o = d->act_o; a.act_i = d->act_i;
     a.bar = d->barrier; a.err = err_word();
     a.stamps = g_mf_stamps;
-    const long long steps = (d->N + 15) / 16, groups = (steps + MF_MAXS - 1) / MF_MAXS;
+    const long long steps = (d->N + 15) / 16;
+    long long groups = (steps + MF_MAXS - 1) / MF_MAXS;
+    if (agg) {
+        PHC_REQUIRE(d->agg_rowptr_t && d->agg_col_t && d->agg_ell_t && d->dx_out, PHC_ERR_INVALID_ARG,
+                    "phc_mlp_norm_bwd_fused: the aggregation's dx needs rowptr_t, col_t, ell_t (phc_csr_build_pair_codes_resident_ell) and dx_out");
+        PHC_REQUIRE(((reinterpret_cast<uintptr_t>(d->agg_src) | reinterpret_cast<uintptr_t>(d->agg_residual) | reinterpret_cast<uintptr_t>(d->dx_out) |
+                      reinterpret_cast<uintptr_t>(d->agg_ell_t)) & 15) == 0,
+                    PHC_ERR_UNSUPPORTED, "phc_mlp_norm_bwd_fused: 16-byte aligned agg_src / agg_residual / dx_out / ell_t required");
+        a.gsrc = d->agg_src; a.residual = d->agg_residual; a.rowptr_t = d->agg_rowptr_t; a.col_t = d->agg_col_t; a.ell_t = d->agg_ell_t;
+        a.dx_out = d->dx_out; a.add_self = d->agg_add_self ? 1 : 0;
+        groups = xcd_grid(groups);                           // (a multiple of 8: xcd_contiguous_block)
+    }
     const size_t lds = sizeof(float) * mf_lds_floats<MF_MAXS>();
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(K_PHM_GEMM_DX, s);
-    PHC_LAUNCH(mlp_bwd_fused_kernel<MF_MAXS>, dim3((unsigned)groups), dim3(MF_THREADS), lds, s, a);
+    if (agg)
+        PHC_LAUNCH((mlp_bwd_fused_kernel<MF_MAXS, true>), dim3((unsigned)groups), dim3(MF_THREADS), lds, s, a);
+    else
+        PHC_LAUNCH((mlp_bwd_fused_kernel<MF_MAXS, false>), dim3((unsigned)groups), dim3(MF_THREADS), lds, s, a);
     return check_launch("mlp_norm_bwd_fused");
 }
 

@@ -69,7 +69,9 @@ class MlpNormBwdDesc(C.Structure):
     """phc_mlp_norm_bwd_desc (include/phc_hip.h)."""
     _fields_ = [("dout", _P), ("y2", _P), ("z1", _P), ("save_o", _P), ("save_i", _P), ("H2Tk4", _P), ("H1Tk4", _P),
                 ("dy2", _P), ("dz1", _P), ("ds", _P), ("dwb_o", _P), ("dwb_i", _P), ("acc_o", _P), ("acc_i", _P),
-                ("n_valid_dev", _P), ("N", _L), ("h", C.c_int32), ("act_o", C.c_int32), ("act_i", C.c_int32), ("barrier", _P)]
+                ("n_valid_dev", _P), ("N", _L), ("h", C.c_int32), ("act_o", C.c_int32), ("act_i", C.c_int32), ("barrier", _P),
+                ("agg_src", _P), ("agg_residual", _P), ("agg_rowptr_t", _P), ("agg_col_t", _P), ("agg_ell_t", _P), ("dx_out", _P),
+                ("agg_add_self", C.c_int32)]
 
 
 class MlpNormFwdDesc(C.Structure):
@@ -201,6 +203,7 @@ SIGNATURES = {
     "phc_mlp_norm_fwd_fused_agg_supported": (_I, [_L, _I, _I, _I, _I]),
     "phc_mlp_norm_fwd_fused": (_I, [C.POINTER(MlpNormFwdDesc), _P]),
     "phc_mlp_norm_bwd_fused_supported": (_I, [_L, _I]),
+    "phc_mlp_norm_bwd_fused_agg_supported": (_I, [_L, _I]),
     "phc_mlp_norm_bwd_fused": (_I, [C.POINTER(MlpNormBwdDesc), _P]),
     "phc_mlp_norm_bwd_fused_barrier_words": (_S, []),
     "phc_debug_mlp_bwd_stamps": (_I, [_P]),

@@ -995,6 +995,44 @@ class DxSumHandoff(DxHandoff):
         return ts if ts else None
 
 
+# the dx of a layer's sum aggregation built inside the backward launch of the fused MLP + norm node BELOW it (round 6,
+# phc_mlp_norm_bwd_desc.agg_src): three aggregate_dx_rows launches less per molhiv step; 0 = the launch of its own
+MLP_BWD_FUSED_AGG = __import__("os").environ.get("PHC_MLP_BWD_FUSED_AGG", "1") != "0"
+
+
+class PendingDx:
+    """dx of a sum aggregation (identity message function) that has NOT been launched: ``dx`` is allocated and was returned to
+    autograd as the gradient of the aggregation's input, its rows are still to be written.  The one consumer — the backward of the
+    fused MLP + norm node that produced that input (``DxLink``) — builds them inside its own launch (``phc_mlp_norm_bwd_fused`` with
+    ``agg_src``), or calls ``materialize`` first: the launch that would have run in the aggregation's backward, identical rows."""
+
+    def __init__(self, gsrc, residual, st, add_self, dx):
+        self.gsrc, self.residual, self.st, self.add_self, self.dx = gsrc, residual, st, add_self, dx
+
+    def materialize(self):
+        lib = L.load()
+        st = self.st
+        rowptr_t, col_t, _ = st.csc
+        h = self.dx.shape[1]
+        L.check(lib.phc_aggregate_dx_rows(L.ptr(self.gsrc), L.ptr(rowptr_t), L.ptr(col_t), st.num_src, st.num_dst, h,
+                                          1 if self.add_self else 0, L.ptr(self.residual), L.ptr(self.dx), L.stream_ptr(self.dx.device)),
+                "phc_aggregate_dx_rows")
+
+
+class DxLink:
+    """Backward-side mirror of ``PendingAggregate``: joins the fused MLP + norm node of layer l - 1 (the producer of x) with the sum
+    aggregation of layer l (x's ONLY autograd consumer: the model loop hands the link over only then — the skip's share travels
+    through a DxHandoff / DxSumHandoff).  ``ready``: the node's backward can take the one-launch form with the aggregation inside."""
+
+    def __init__(self):
+        self.ready = False
+        self.pending: Optional[PendingDx] = None
+
+    def take(self):
+        p, self.pending = self.pending, None
+        return p
+
+
 def phm_linear(x: torch.Tensor, phm_rule: torch.Tensor, W: torch.Tensor, bias: Optional[torch.Tensor] = None,
                residual: Optional[torch.Tensor] = None, bn_stats: Optional[BNStatsRequest] = None,
                dx_handoff: Optional[DxHandoff] = None, res_handoff: Optional[DxHandoff] = None) -> torch.Tensor:
@@ -2488,9 +2526,10 @@ def encode(idx: torch.Tensor, ts: TableSet, tables) -> torch.Tensor:
 
 class _AggregateEncFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, bond_idx, st: EdgeStructure, act: int, add_self: bool, ts: TableSet, dx_handoff, pending, lazy_box, *tables):
+    def forward(ctx, x, bond_idx, st: EdgeStructure, act: int, add_self: bool, ts: TableSet, dx_handoff, pending, lazy_box, dx_link, *tables):
         lib = L.load()
         ctx.dx_handoff = dx_handoff
+        ctx.dx_link = dx_link
         if dx_handoff is not None:
             dx_handoff.accepted = True
         dev = L.require_device(x, bond_idx)
@@ -2566,7 +2605,7 @@ class _AggregateEncFn(torch.autograd.Function):
         dev = dout_.device
         h = dout_.shape[1]
         need_x = ctx.needs_input_grad[0]
-        need_t = any(ctx.needs_input_grad[9:])
+        need_t = any(ctx.needs_input_grad[10:])
         # the skip connection's share of dx (DxHandoff, parked by the layer's fused MLP + norm node)
         extra = ctx.dx_handoff.take() if ctx.dx_handoff is not None else None
         extras = extra if isinstance(extra, list) else ([extra] if extra is not None else [])    # DxSumHandoff parks several
@@ -2581,7 +2620,15 @@ class _AggregateEncFn(torch.autograd.Function):
             if ctx.x_rows > st.num_src:
                 dx[st.num_src:].zero_()
         dx_done = False
-        if need_x and extra is not None and ctx.act == 0 and ctx.x_rows == st.num_src and h % 4 == 0 and extra.data_ptr() % 16 == 0 \
+        link = ctx.dx_link
+        if need_x and link is not None and link.ready and MLP_BWD_FUSED_AGG and ctx.act == 0 and len(extras) <= 1 and \
+                ctx.x_rows == st.num_src == st.num_dst and h == 128 and getattr(st, "_ell_t", None) is not None and \
+                dout_.data_ptr() % 16 == 0 and (extra is None or (extra.is_contiguous() and extra.data_ptr() % 16 == 0)) and \
+                not torch.is_grad_enabled():
+            # nothing is launched here: the backward of the node that produced x builds these rows inside its own launch (PendingDx)
+            link.pending = PendingDx(dout_, extra, st, ctx.add_self, dx)
+            dx_done, extra, extras = True, None, []
+        elif need_x and extra is not None and ctx.act == 0 and ctx.x_rows == st.num_src and h % 4 == 0 and extra.data_ptr() % 16 == 0 \
                 and dout_.data_ptr() % 16 == 0:
             # identity message function: dx by the row walker, the parked gradient added on the way out (no add launch)
             L.check(lib.phc_aggregate_dx_rows(L.ptr(dout_), L.ptr(rowptr_t), L.ptr(col_t), st.num_src, st.num_dst, h,
@@ -2599,7 +2646,7 @@ class _AggregateEncFn(torch.autograd.Function):
         ws_bytes = 0
         deferred = need_t and ctx.defer_tables is not None and _DEFER.active and not torch.is_grad_enabled()
         if deferred:
-            params = [t if ng else None for t, ng in zip(ctx.defer_tables, ctx.needs_input_grad[9:])]
+            params = [t if ng else None for t, ng in zip(ctx.defer_tables, ctx.needs_input_grad[10:])]
             with _DEFER.lock:
                 _DEFER.table_jobs.append(dict(
                     key=(bond_.data_ptr(), st._src.data_ptr(), st._dst.data_ptr(), st.num_edges, ts.F, ts.n, ts.k, tuple(ts.vocab),
@@ -2620,18 +2667,18 @@ class _AggregateEncFn(torch.autograd.Function):
             dx += e
         if L.PROF_ON:
             E, Ns, Nd = st.num_edges, st.num_src, st.num_dst
-            if need_x:
+            if need_x and not (link is not None and link.pending is not None):
                 L.account("aggregate_enc_dx", 1.0 * E * h, E * (4.0 * h + 4) + Ns * 4.0 * h * (2 if ctx.add_self else 1)
                           + 4.0 * (Ns + 1))
             if need_t and not deferred:
                 L.account("table_grad", 1.0 * E * ts.F * h, Nd * 4.0 * h + E * (4.0 + 8.0 * ts.F) + 4.0 * (Nd + 1))
         grads = ts.grad_views(flat) if (need_t and not deferred) else [None] * ts.num_tables
-        return (dx, None, None, None, None, None, None, None, None, *grads)
+        return (dx, None, None, None, None, None, None, None, None, None, *grads)
 
 
 def aggregate_sum_encoded(x: torch.Tensor, edge_index, bond_idx: torch.Tensor, ts: TableSet, tables,
                           msg_encoder: str = "identity", add_self_loops: bool = False,
-                          num_dst: Optional[int] = None, dx_handoff=None, pending=None, lazy: bool = False) -> torch.Tensor:
+                          num_dst: Optional[int] = None, dx_handoff=None, pending=None, lazy: bool = False, dx_link=None) -> torch.Tensor:
     """aggregate_sum with edge_attr[e] = Σ_f tables[c][f][bond_idx[e, f]] looked up inside the
     kernel (the [E, h] bond embedding is never written).  ``lazy``: the result goes straight into ``mlp_norm_fused`` — the
     launch may then be left to that node's first GEMM (``PendingAggregate`` on the returned tensor)."""
@@ -2650,7 +2697,7 @@ def aggregate_sum_encoded(x: torch.Tensor, edge_index, bond_idx: torch.Tensor, t
         ea = _EncodeFn.apply(bond_idx, ts, *flat_tables)
         return _AggregateFn.apply(x, ea, st, _act_id(msg_encoder), bool(add_self_loops))
     box = {} if (lazy and torch.is_grad_enabled()) else None
-    res = _AggregateEncFn.apply(x, bond_idx, st, _act_id(msg_encoder), bool(add_self_loops), ts, dx_handoff, pending, box, *flat_tables)
+    res = _AggregateEncFn.apply(x, bond_idx, st, _act_id(msg_encoder), bool(add_self_loops), ts, dx_handoff, pending, box, dx_link, *flat_tables)
     if box and box.get("pa") is not None:
         res._phc_pending_agg = box["pa"]
     return res
@@ -3283,6 +3330,11 @@ class _MLPNormFn(torch.autograd.Function):
                 if not fused_agg:
                     L.account("phm_gemm_fwd", 2.0 * N * h * h, 4.0 * (2 * N * h + h * h + h))
                 L.account("phm_gemm_fwd", 2.0 * N * h * h, 4.0 * (2 * N * h + h * h + h))
+        # the aggregation that consumes `out` may leave its dx to this node's backward (DxLink: the caller attaches it to `out`)
+        link = meta.get("dx_link")
+        if link is not None:
+            link.ready = bool(MLP_BWD_FUSED and MLP_BWD_FUSED_AGG and drop[0] == 0.0 and h == 128 and meta["pre2"][3] is not None and
+                              meta["pre1"][3] is not None and _supported("phc_mlp_norm_bwd_fused_agg_supported", N, h))
         ctx.save_for_backward(s, z1, y2, save_i, save_o, A1, W1, A2, W2)
         ctx.meta, ctx.n_valid = meta, n_valid
         ctx.params = ((A1, W1, b1), (A2, W2, b2))
@@ -3302,6 +3354,12 @@ class _MLPNormFn(torch.autograd.Function):
         sp = L.stream_ptr(dev)
         dout_ = L.f32c(dout)
         needs = ctx.needs_input_grad
+        # the gradient may be the un-launched dx of the aggregation above (PendingDx): built inside the one-launch form below, or by
+        # the launch of its own right here
+        link = meta.get("dx_link")
+        pd = link.take() if link is not None else None
+        if pd is not None and (dout_.data_ptr() != pd.dx.data_ptr() or tuple(dout_.shape) != tuple(pd.dx.shape)):
+            raise L.PhcError("DxLink: the parked aggregation gradient is not the gradient this node received")
         acc_o, acc_i = _zero_acc(dev, h), _zero_acc(dev, h)
         dy2 = torch.empty((N, h), dtype=torch.float32, device=dev)       # d loss / d y2 (the outer norm's dx)
         da = torch.empty((N, h), dtype=torch.float32, device=dev)        # d loss / d act(norm_i(z1))
@@ -3320,10 +3378,22 @@ class _MLPNormFn(torch.autograd.Function):
             fd.acc_o, fd.acc_i, fd.n_valid_dev = L.ptr(acc_o), L.ptr(acc_i), L.ptr(n_valid)
             fd.N, fd.h, fd.act_o, fd.act_i = N, h, act_o, act_i
             fd.barrier = L.ptr(_grid_barrier_words(dev))
+            if pd is not None and _supported("phc_mlp_norm_bwd_fused_agg_supported", N, h):
+                rowptr_t_, col_t_, _ = pd.st.csc
+                fd.agg_src, fd.agg_residual, fd.dx_out = L.ptr(pd.gsrc), L.ptr(pd.residual), L.ptr(pd.dx)
+                fd.agg_rowptr_t, fd.agg_col_t, fd.agg_ell_t = L.ptr(rowptr_t_), L.ptr(col_t_), L.ptr(pd.st._ell_t)
+                fd.agg_add_self = 1 if pd.add_self else 0
+                fd.dout = None
+                pd_fused, pd = pd, None
+            elif pd is not None:
+                pd.materialize()
+                pd = None
             L.check(lib.phc_mlp_norm_bwd_fused(_C.byref(fd), sp), "phc_mlp_norm_bwd_fused")
             if L.PROF_ON:                                    # (both dx GEMMs of the node: booked as one launch of the family)
                 L.account("phm_gemm_dx", 4.0 * N * h * h, 4.0 * (6 * N * h + 2 * h * h))
             return _MLPNormFn._finish_backward(ctx, dout, dout_, s, z1, y2, save_i, dy2, dz1, ds, dwb_o, dwb_i, N, h)
+        if pd is not None:
+            pd.materialize()
         if drop[0] > 0.0:
             L.check(lib.phc_bn_bwd_partial_acc_drop(L.ptr(dout_), L.ptr(y2), L.ptr(save_o), L.ptr(n_valid), N, h, act_o, L.ptr(acc_o),
                                                     drop[0], drop[1], drop[2], L.ptr(drop[3]), sp), "phc_bn_bwd_partial_acc_drop")
@@ -3445,11 +3515,14 @@ def _mlp_norm_fused(s, skip, n_valid, mlp, outer_norm, activation: str, skip_han
     dropping = dropout is not None and dropout[0] > 0.0
     if dropping and not (h in (128, 256, 180, 200) and h % 4 == 0 and (not dropout[1] or (h // outer["n_comp"]) % 4 == 0)):
         return None                                          # (the mask's column groups; the HS_DR instantiations)
+    link = DxLink() if MLP_BWD_FUSED_AGG else None
     meta = dict(pre1=pre1, pre2=pre2, inner=inner, outer=outer, act_inner=act_i, act_outer=act_o, skip_handoff=skip_handoff,
                 defer_apply=bool(defer_apply and NORM_INTO_AGGREGATE and not dropping), pending_agg=pending_agg,
-                dropout=dropout if dropping else None)
+                dropout=dropout if dropping else None, dx_link=link)
     affine = inner["weights"] + inner["biases"] + outer["weights"] + outer["biases"]
     out = _MLPNormFn.apply(s, skip, n_valid, meta, l1.phm_rule, l1.W, l1.b, l2.phm_rule, l2.W, l2.b, *affine)
+    if link is not None and link.ready:
+        out._phc_dx_link = link                              # (the model loop hands it to out's consumer when there is exactly one)
     pend = meta.pop("pending", None)
     if pend is not None:
         out._phc_pending = pend                              # (the model loop passes it on or materialises it: materialize_pending)
