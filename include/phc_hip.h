@@ -705,6 +705,7 @@ size_t phc_mlp_norm_bwd_fused_barrier_words(void);        /* uint32 words of `ba
 int phc_mlp_norm_bwd_fused(const phc_mlp_norm_bwd_desc *desc, void *stream);
 /* Diagnostics only: when set (32 device words), workgroups 0 and G - 1 of every launch stamp their phase clocks there; NULL: off. */
 int phc_debug_mlp_bwd_stamps(unsigned long long *dev_words);
+int phc_debug_mlp_all_stamps(unsigned long long *dev_words);   /* ... 8 words per workgroup: phases 0 .. 7 of every workgroup */
 
 /* ABI 8: the forward of the same node behind the aggregation as ONE launch (csrc/mlp_fused.hip) instead of
  * phc_gemm_prebuilt_stats + phc_gemm_prebuilt_xf_acc:  z1 = s . H1 + b1;  a = act(batch_norm_train(z1));  y2 = a . H2 + b2

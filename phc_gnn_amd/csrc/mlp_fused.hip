@@ -53,6 +53,7 @@ struct MlpBwdArgs {
     unsigned *bar;                               // barrier words (mf_grid_barrier): zero before the first use, owned by the kernel
     int *err;
     unsigned long long *stamps;                  // diagnostics only (NULL in the product): 8 wall-clock stamps of workgroups 0 and G - 1
+    unsigned long long *stamps_all;              // diagnostics only: 8 stamps of EVERY workgroup ([8 g + k])
     // ---- AGGT: `dout` is not there yet — it is the dx of the sum aggregation of the layer ABOVE (messagepassing.py:132-146 backward,
     // identity message function): dout[r] = sum over the out-edges (r -> d) of gsrc[d] (+ gsrc[r] for the self term) (+ residual[r]),
     // gsrc = that layer's ds.  The rows are built in P0 by aggregate_dx_rows_kernel's own additions (encoder.hip: same edge order,
@@ -283,6 +284,8 @@ __device__ __forceinline__ void mf_norm_bwd(float *G, const float *XH, int tile_
     do {                                                                                                   \
         if (a.stamps && threadIdx.x == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x - 1))              \
             a.stamps[(blockIdx.x == 0 ? 0 : 16) + (i)] = __builtin_amdgcn_s_memrealtime();                 \
+        if ((i) < 8 && a.stamps_all && threadIdx.x == 0)                                                   \
+            a.stamps_all[8 * blockIdx.x + (i)] = __builtin_amdgcn_s_memrealtime();                         \
     } while (0)
 
 template <int MAXS, bool AGGT>
@@ -533,7 +536,7 @@ struct MlpFwdArgs {
     long long N;
     unsigned *bar;
     int *err;
-    unsigned long long *stamps;
+    unsigned long long *stamps, *stamps_all;
     // ---- AGG: the layer's sum aggregation builds the rows of s inside the launch (messagepassing.py:132-146, identity message
     // function; encoder.py:31-34): s[d] = sum_{e: dst_e = d} (x[src_e] + sum_f table_f[code_f(e)]) (+ x[d]), x either a tensor or the
     // un-applied  act(norm_o(y)) (+ skip)  of the layer in front (nacc != NULL; models.py:208-215) — what aggregate_encp_direct_fwd /
@@ -1003,7 +1006,7 @@ static int mf_capacity() {
 
 using namespace phc;
 
-static unsigned long long *g_mf_stamps = nullptr;
+static unsigned long long *g_mf_stamps = nullptr, *g_mf_stamps_all = nullptr;
 
 static size_t mf_fwd_lds_bytes(bool agg = false) {
     return sizeof(float) * ((size_t)MF_MAXS * MF_TILE + 2 * MF_H) + sizeof(double) * (size_t)MF_WAVES * 16 * 66 +
@@ -1037,6 +1040,11 @@ extern "C" {
 /* diagnostics only: 32 device words that workgroups 0 and G - 1 of every phc_mlp_norm_bwd_fused launch stamp (100 MHz clock) */
 int phc_debug_mlp_bwd_stamps(unsigned long long *dev_words) {
     g_mf_stamps = dev_words;
+    return PHC_OK;
+}
+/* diagnostics only: 8 words per workgroup of every one-launch MLP kernel (phases 0 .. 7 of EVERY workgroup) */
+int phc_debug_mlp_all_stamps(unsigned long long *dev_words) {
+    g_mf_stamps_all = dev_words;
     return PHC_OK;
 }
 size_t phc_mlp_norm_bwd_fused_barrier_words(void) { return MF_BAR_WORDS; }
@@ -1076,7 +1084,7 @@ int phc_mlp_norm_bwd_fused(const phc_mlp_norm_bwd_desc *d, void *stream) {
     a.acc_o = reinterpret_cast<unsigned long long *>(d->acc_o); a.acc_i = reinterpret_cast<unsigned long long *>(d->acc_i);
     a.n_valid = d->n_valid_dev; a.N = d->N; a.act_o = d->act_o; a.act_i = d->act_i;
     a.bar = d->barrier; a.err = err_word();
-    a.stamps = g_mf_stamps;
+    a.stamps = g_mf_stamps; a.stamps_all = g_mf_stamps_all;
     const long long steps = (d->N + 15) / 16;
     long long groups = (steps + MF_MAXS - 1) / MF_MAXS;
     if (agg) {
@@ -1170,7 +1178,7 @@ int phc_mlp_norm_fwd_fused(const phc_mlp_norm_fwd_desc *d, void *stream) {
     a.s = d->s; a.H1k4 = d->H1k4; a.b1 = d->b1; a.H2k4 = d->H2k4; a.b2 = d->b2; a.z1 = d->z1; a.y2 = d->y2;
     a.acc1 = reinterpret_cast<unsigned long long *>(d->acc1); a.acc2 = reinterpret_cast<unsigned long long *>(d->acc2);
     a.momentum = d->momentum; a.eps = d->eps; a.save_i = d->save_stat; a.act_i = d->act; a.n_valid = d->n_valid_dev; a.N = d->N;
-    a.bar = d->barrier; a.err = err_word(); a.stamps = g_mf_stamps;
+    a.bar = d->barrier; a.err = err_word(); a.stamps = g_mf_stamps; a.stamps_all = g_mf_stamps_all;
     const long long groups = mf_fwd_groups(d->N);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(agg ? K_PHM_GEMM_AG : K_PHM_GEMM_FWD, s);

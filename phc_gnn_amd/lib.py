@@ -207,6 +207,7 @@ SIGNATURES = {
     "phc_mlp_norm_bwd_fused": (_I, [C.POINTER(MlpNormBwdDesc), _P]),
     "phc_mlp_norm_bwd_fused_barrier_words": (_S, []),
     "phc_debug_mlp_bwd_stamps": (_I, [_P]),
+    "phc_debug_mlp_all_stamps": (_I, [_P]),
     "phc_downstream_supported": (_I, [_L, _I, _I, _I, _I, _I]),
     "phc_downstream_supported_k4": (_I, [_L, _I, _I, _I, _I, _I]),
     "phc_downstream_dropout_supported": (_I, [_L, _I, _I, _I, _I, _I]),
