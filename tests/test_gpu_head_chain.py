@@ -22,12 +22,13 @@ def _supported(B, d_in, hidden, n, target, valid_max=0):
     return bool(L.phc_head_chain_supported(B, valid_max, 4, Ks, Ns)) and bool(L.phc_head_chain_supported(B, valid_max, 4, Kb, Nb))
 
 
-def _run_chain(dn, x, dy, n_valid=None):
+def _run_chain(dn, x, dy, n_valid=None, chain=True):
     from phc_gnn_amd import ops
     xd = x.to(DEV).requires_grad_()
     with ops.prebuilt_H(ops.phm_pairs(dn), ops.dense_weights(dn)):
         y = dn(xd, n_valid=n_valid)
-        assert type(y.grad_fn).__name__ == "_HeadChainFnBackward", type(y.grad_fn).__name__       # the chain launch really ran
+        # the chain launch really ran (chain=False: a shape outside it must take the per-layer path, not the chain)
+        assert (type(y.grad_fn).__name__ == "_HeadChainFnBackward") == chain, type(y.grad_fn).__name__
         y.backward(dy.to(DEV))
     return y.detach(), xd.grad
 
@@ -37,7 +38,9 @@ CASES = [
     (4, 512, (768, 256), 128, "relu", 512),           # the published molpcba model (benchmarks/README.md: 7 x 512, d_units 768, 256)
     (4, 256, (768, 256), 128, "swish", 300),          # a partial last row block
     (4, 256, (768, 256), 128, "relu", 5),             # fewer rows than one MFMA block
-    (8, 256, (512, 128), 16, "lrelu", 777),           # PHM-8, other widths: d3 = 128, T = 16
+    (8, 256, (512, 128), 16, "lrelu", 777),           # PHM-8, T = 16: a 16-column last stage leaves ONE column block of 512 columns —
+                                                      # outside the chain kernel (HC_MAX_NC): the per-layer path must serve it
+    (8, 256, (256, 128), 64, "lrelu", 777),           # PHM-8 inside the chain kernel: d3 = 512, T = 64 (four column blocks)
     (4, 128, (256, 64), 32, "elu", 130),              # d3 = 128, T = 32
     (2, 128, (768, 256), 128, "relu", 64),            # few row blocks: eight column blocks, 24 owned columns per workgroup
 ]
@@ -45,14 +48,14 @@ CASES = [
 
 @pytest.mark.parametrize("n,d_in,hidden,target,act,B", CASES)
 def test_head_chain_matches_oracle(n, d_in, hidden, target, act, B):
-    if not _supported(B, d_in, hidden, n, target):
-        pytest.skip("shape outside the chain kernel on this device")
+    chain = _supported(B, d_in, hidden, n, target)
+    assert chain == ((n, target) != (8, 16)), "the chain kernel's range changed: update CASES"
     dn = _make(n, d_in, hidden, target, act, seed=7)
     g = torch.Generator().manual_seed(8)
     x, dy = torch.randn(B, d_in, generator=g), torch.randn(B, target, generator=g)
     ref_y, ref_dx, ref_g, ref_state = _oracle(dn, x, dy, n, act)
     dn.to(DEV)
-    y, dx = _run_chain(dn, x, dy)
+    y, dx = _run_chain(dn, x, dy, chain=chain)
     tol = 3e-5
     assert_close(y, ref_y, tol, "logits")
     assert_close(dx, ref_dx, tol, "dx")

@@ -70,8 +70,10 @@ def test_skip_gradient_shares_meet_in_the_first_aggregation_backward(workload):
     if workload == "molpcba_small":                                       # five layers: the eight-slot instantiation
         harness.WORKLOADS.setdefault("molpcba_small", dict(dataset="molpcba", batch_size=24, phm_dim=4, hidden=64, layers=5, d_units=[64, 32],
                                                            target_dim=8, sc_type="first", nan_frac=0.5))
-    on = _step(workload, dict(SKIP_SUM_HANDOFF=True))
-    off = _step(workload, dict(SKIP_SUM_HANDOFF=False))
+    # (round 6: the aggregation's dx inside the backward launch exists only with the hand-off — it regroups the norms' column sums;
+    # off in both runs, so that the two differ by the hand-off alone)
+    on = _step(workload, dict(SKIP_SUM_HANDOFF=True, MLP_BWD_FUSED_AGG=False))
+    off = _step(workload, dict(SKIP_SUM_HANDOFF=False, MLP_BWD_FUSED_AGG=False))
     assert torch.allclose(on[0], off[0], rtol=0, atol=0)
     for k in on[1]:
         ref = off[1][k]
