@@ -22,6 +22,8 @@ default backend has no CPU path.
 """
 from __future__ import annotations
 
+import os
+import warnings
 from dataclasses import dataclass
 from typing import List, Optional, Sequence
 
@@ -564,6 +566,24 @@ class NormLink:
         self.res_share = None        # is parked here and added inside the conv's aggregation backward instead of by autograd
 
 
+_EVAL_GRAD_WARNED: set = set()
+
+
+def _refuse_eval_grad(who: str, *tensors) -> None:
+    """The eval-mode forwards of the sharded modules are forward-only (they run under ``no_grad``).  A caller with gradients enabled
+    whose inputs require grad gets a DETACHED result: say so, once per module kind.  Not an error — a validation loop
+    that forgot ``torch.no_grad()`` feeds tensors derived from the parameters and wants exactly this forward; set
+    ``PHC_EVAL_GRAD_STRICT=1`` to make it one (saliency / frozen-norm fine-tuning must use training mode)."""
+    if torch.is_grad_enabled() and any(t is not None and torch.is_tensor(t) and t.requires_grad for t in tensors):
+        msg = (f"{who}: eval mode is forward-only on the sharded path — an input requires grad and the result is detached; "
+               "call it under torch.no_grad(), or in training mode if the gradient is wanted")
+        if os.environ.get("PHC_EVAL_GRAD_STRICT", "0") == "1":
+            raise NotImplementedError(msg)
+        if who not in _EVAL_GRAD_WARNED:
+            _EVAL_GRAD_WARNED.add(who)
+            warnings.warn(msg, RuntimeWarning, stacklevel=3)
+
+
 class EdgeGradSink:
     """The gradient of ONE edge-attribute tensor read by all L layers of a ``ShardedGINEStack`` through identity message functions:
         d ea[e] = sum_l dagg_l[dst(e)] = (sum_l dagg_l)[dst(e)]
@@ -798,6 +818,7 @@ class ShardedPHMGINEConv(torch.nn.Module):
         """Validation between epochs (train_hiv.py:204-230 on a shard): the halo exchange is the only collective — with the running
         statistics every row of linear1 -> norm -> act -> linear2 is independent of the other ranks' rows.  Forward only."""
         mlp, be = self.conv.transform, self.agg.backend
+        _refuse_eval_grad("ShardedPHMGINEConv", x_own, ea_loc, ea_halo)
         with torch.no_grad():
             s, _ = self.agg.forward_raw(x_own.contiguous(), ea_loc, ea_halo, self.msg_encoder, self.conv.add_self_loops)
             l1, l2 = mlp.linear1, mlp.linear2
@@ -889,6 +910,7 @@ class ShardedPHMNorm(torch.nn.Module):
         if not hasattr(nb, "bn") or not nb.track_running_stats:
             raise NotImplementedError("ShardedPHMNorm: naive-batch-norm with running statistics only")
         if not self.training:                                   # eval: running statistics, no exchange (forward only)
+            _refuse_eval_grad("ShardedPHMNorm", x_own, residual)
             return self.backend.bn_eval(x_own.contiguous(), nb, self.activation, residual)
         affine = ([m.weight for m in nb.bn] + [m.bias for m in nb.bn]) if nb.affine else []
         return _ShardedNormActFn.apply(x_own, residual, self, link, *affine)

@@ -490,11 +490,22 @@ def _worker_stack_eval(rank, world, port, tmp):
         plan = build_halo_plan(ei, N)
         stack = ShardedGINEStack(convs, norms, plan, N, activation="relu", backend=OracleBackend()).eval()
         before = [b.clone() for m in convs + norms for b in m.buffers()]
-        ea_loc, ea_halo = stack.agg.split_edge_attr(ea)
-        y = stack(x[plan.lo:plan.hi].clone(), ea_loc, ea_halo)
+        ea_loc, ea_halo = stack.agg.split_edge_attr(ea.detach())
+        y = stack(x[plan.lo:plan.hi].detach().clone(), ea_loc, ea_halo)
         after = [b.clone() for m in convs + norms for b in m.buffers()]
         assert all(torch.equal(a, b) for a, b in zip(before, after))     # eval leaves the running statistics alone
         assert all(m.training is False for m in stack.modules())
+        # forward only: with PHC_EVAL_GRAD_STRICT=1 an input that requires grad is refused instead of answered with a detached tensor
+        # (by default a warning) — before any collective of the call, so every rank raises alike
+        os.environ["PHC_EVAL_GRAD_STRICT"] = "1"
+        try:
+            stack(x[plan.lo:plan.hi].detach().clone().requires_grad_(), ea_loc, ea_halo)
+            raised = False
+        except NotImplementedError:
+            raised = True
+        finally:
+            os.environ.pop("PHC_EVAL_GRAD_STRICT")
+        assert raised
         torch.save(dict(y=y, lo=plan.lo, hi=plan.hi), os.path.join(tmp, f"e{rank}.pt"))
     finally:
         dist.destroy_process_group()
