@@ -958,11 +958,21 @@ typedef struct phc_downstream_desc {
     int32_t loss_kind;
     float *loss_out, *loss_dlogits;
     uint64_t *loss_granules;
+    /* ABI 8 (with loss_y; phc_downstream_fused_bwd_supported): fused_bwd != 0 makes phc_downstream_fwd run the BACKWARD too, in the same
+     * launch, for an upstream gradient d loss = 1 (autograd of downstream.py:90-120 + layers.py:399-414 behind the masked mean loss:
+     * what phc_downstream_bwd computes from loss_dlogits): the backward's fields above (H1T, H2T, H3T, H1Tk4, H2Tk4, dx, dz1, dz2, dz3,
+     * dwb1, dwb2, dWr) are read / written as phc_downstream_bwd does, `dlogits` is not read.  partial_bwd / sync_bwd: the buffers the
+     * caller would hand to phc_downstream_bwd as partial / sync (distinct from the forward's).  Bit-identical to the two launches.
+     * A caller whose upstream gradient turns out not to be 1 calls phc_downstream_bwd afterwards: it overwrites the outputs. */
+    int32_t fused_bwd;
+    float *partial_bwd;
+    uint32_t *sync_bwd;
 } phc_downstream_desc;
 int phc_downstream_supported(int64_t B, int d0, int d1, int d2, int d3, int T);
 int phc_downstream_supported_k4(int64_t B, int d0, int d1, int d2, int d3, int T);
 int phc_downstream_dropout_supported(int64_t B, int d0, int d1, int d2, int d3, int T);   /* ABI 7: the drop_* fields are served */
 int phc_downstream_loss_supported(int64_t B, int d0, int d1, int d2, int d3, int T);      /* ABI 8: the loss_* fields are served */
+int phc_downstream_fused_bwd_supported(int64_t B, int d0, int d1, int d2, int d3, int T); /* ABI 8: fused_bwd is served */
 size_t phc_downstream_partial_floats(int64_t B);
 int phc_downstream_fwd(const phc_downstream_desc *desc, void *stream);
 int phc_downstream_bwd(const phc_downstream_desc *desc, void *stream);

@@ -76,7 +76,9 @@ struct DnArgs {
     const float *loss_y;                                      // [B, T] labels, NaN = unlabeled; NULL: off
     unsigned long long *loss_gran;                            // [B T] granules
     float *loss_out, *loss_dz;                                // [3], [B, T]
-    int loss_kind;                                            // 0 BCE with logits, 1 L1
+    int loss_kind;                                            // 0 BCE with logits, 1 L1    // forward + backward in ONE launch (downstream2_fb_kernel): the backward part's own exchange buffers and generation word
+    unsigned long long *partial_b;
+    unsigned *sync_b;
 };
 
 // A rendezvous that never completes (a producer workgroup that is not resident: CU mask, another stream owning the CUs, a
@@ -664,6 +666,7 @@ constexpr int D2_EXTRA = DN_MAXT * DN_MAXD3 + DN_MAXT;
 constexpr int D2_PSTRIDE = 2 * D2_MAXW + D2_EXTRA;     // granules per workgroup per exchange
 constexpr int D2_MAX_WG = 128;
 constexpr int D2_MERGE = 16;                           // granule pairs in flight per thread while collecting
+constexpr int D2_FB_STASH = 15 * D2_MAXW;              // floats behind the carve-up: the norms' statistics across the one-launch forward + backward
 
 __host__ __device__ __forceinline__ int r16(int v) { return (v + 15) & ~15; }
 
@@ -1121,16 +1124,22 @@ __device__ __forceinline__ void d2_loss_tail(const DnArgs &a, unsigned tag, floa
     }
 }
 
-template <int RB>
-__global__ __launch_bounds__(D2_THREADS) void downstream2_fwd_kernel(DnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
+// The forward of a 16 RB-row workgroup up to its logits (everything but workgroup 0's leftovers: d2_fwd_tail).  k1 / k2: the norms'
+// statistics of column tid (identical on every workgroup: fixed merge order); my_logit: logits entry tid of this workgroup's rows
+// (R T <= 256 entries: one per thread) — what the one-launch forward + backward (downstream2_fb_kernel) carries over.
+// COUNT (the one-launch forward + backward): this thread's share of the labeled entries of loss_y (entry e by thread e % 512) comes
+// back in `labeled` — the labels travel with the launch's first loads and are counted behind the staging barrier, where they have
+// landed anyway (counted in front of the body they held the operand loads back for a whole first-touch round trip; kept as eight
+// raw values across the body they cost eight registers of a kernel that has none to spare).
+template <int RB, bool COUNT = false>
+__device__ __forceinline__ void d2_fwd_body(const DnArgs &a, float *sm, unsigned tag, D2Keep &k1, D2Keep &k2, float &my_logit,
+                                            float *labeled = nullptr) {
     constexpr int R = 16 * RB;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = blockIdx.x, rb = g * R;
     const int d0 = a.d0, d1 = a.d1, d2 = a.d2, d3 = a.d3, T = a.T;
     const D2Lds L = d2_lds(RB, d0, d1, d2, d3, T);
     float *bufA = sm + L.off_a, *bufB = sm + L.off_b, *red = sm + L.off_red, *sc = sm + L.off_sc;
     float *Hs3 = sm + L.off_small, *wr = Hs3 + r4(d2 * d3), *z3s = wr + r4(T * d3 + T), *bs = z3s + r4(R * d3);     // bs: b1 | b2 | b3
-    const unsigned tag = __hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
     const int nvalid = a.n_valid ? min(*a.n_valid, a.B) : a.B;
     const unsigned long long rng_seed = a.rng ? a.rng[0] : 0ull, rng_step = a.rng ? a.rng[1] : 0ull;    // (uniform: scalar loads)
 
@@ -1140,6 +1149,11 @@ __global__ __launch_bounds__(D2_THREADS) void downstream2_fwd_kernel(DnArgs a) {
     const D2Plan p1 = d2_plan(d0, d1, wave), p2 = d2_plan(d1, d2, wave);
     D2Regs h;
     d2_load_operand(a.H1k4, d0, d1, p1, lane, h);
+    float yv[COUNT ? 8 : 1];                                 // B T <= 4096 = 8 x 512 (host-checked)
+    if constexpr (COUNT) {
+#pragma unroll
+        for (int q = 0; q < 8; ++q) yv[q] = a.loss_y[min(tid + D2_THREADS * q, a.B * T - 1)];
+    }
     DN_STAMP(12);
     // the norms' per-component parameter pointers -> LDS (uniform kernarg reads), each column thread fetches its own four values
     // behind the staging barrier: they arrive under the first GEMM (as run-time loops over the components with the loads inside,
@@ -1166,6 +1180,12 @@ __global__ __launch_bounds__(D2_THREADS) void downstream2_fwd_kernel(DnArgs a) {
     if (tid < d3) bs[2 * D2_MAXW + tid] = a.b3 ? a.b3[tid] : 0.f;
     __syncthreads();
     DN_STAMP(1);
+    if constexpr (COUNT) {
+        float c = 0.f;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) c += (tid + D2_THREADS * q < a.B * T && yv[q] == yv[q]) ? 1.f : 0.f;
+        *labeled = c;
+    }
     float w1 = 1.f, bb1 = 0.f, rm1 = 0.f, rv1 = 1.f, w2 = 1.f, bb2 = 0.f, rm2 = 0.f, rv2 = 1.f;
     {
         const int c1 = min(tid, d1 - 1), c2 = min(tid, d2 - 1);
@@ -1187,7 +1207,6 @@ __global__ __launch_bounds__(D2_THREADS) void downstream2_fwd_kernel(DnArgs a) {
     d2_gemm<RB>(bufA, L.ldx, h, p1, d1, bs, red, bufB, L.ld1);
     DN_STAMP(2);
     d2_store_rows<RB>(bufB, L.ld1, a.B, rb, d1, a.z1);
-    D2Keep k1 = {}, k2 = {};
     d2_fwd_norm<RB>(a, a.bn1, bufB, L.ld1, d1, nvalid, a.partial, tag, sc, red, w1, bb1, rm1, rv1, k1, 3);
     // the second GEMM's operand: issued BEHIND the exchange (its lines would compete with the granule sweep for the CU's few
     // outstanding misses: the collect took 6.5 us with the operand in flight beside it, 2.6 us without), it arrives under the
@@ -1227,25 +1246,42 @@ __global__ __launch_bounds__(D2_THREADS) void downstream2_fwd_kernel(DnArgs a) {
         const int row = e / T, t = e - row * T;
         float v = wr[T * d3 + t];
         for (int j = 0; j < d3; ++j) v = fmaf(z3s[row * d3 + j], wr[t * d3 + j], v);
+        if (e == tid) my_logit = v;
         if (rb + row < a.B) {
             a.logits[(size_t)(rb + row) * T + t] = v;
             if (a.loss_y) put_granule(a.loss_gran + (size_t)(rb + row) * T + t, v, tag);
         }
     }
     DN_STAMP(11);
-    if (g == 0) {                                                // what the norms leave behind, off every other workgroup's path
-        d2_write_norm_state(a.bn1, k1, a.stat1, d1);
-        d2_write_norm_state(a.bn2, k2, a.stat2, d2);
-        if (a.loss_y) {
-            if (a.loss_kind == 0)
-                d2_loss_tail<0>(a, tag, red);
-            else
-                d2_loss_tail<1>(a, tag, red);
-        }
-        // (the bump comes behind the collect: every workgroup has published its logits, i.e. has read the generation word)
-        if (tid == 0) __hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
 }
+
+// workgroup 0's leftovers of the forward: what the norms leave behind, the loss, the generation bump — off every other workgroup's path
+template <int RB>
+__device__ __forceinline__ void d2_fwd_tail(const DnArgs &a, float *sm, unsigned tag, const D2Keep &k1, const D2Keep &k2) {
+    const D2Lds L = d2_lds(RB, a.d0, a.d1, a.d2, a.d3, a.T);
+    float *red = sm + L.off_red;
+    d2_write_norm_state(a.bn1, k1, a.stat1, a.d1);
+    d2_write_norm_state(a.bn2, k2, a.stat2, a.d2);
+    if (a.loss_y) {
+        if (a.loss_kind == 0)
+            d2_loss_tail<0>(a, tag, red);
+        else
+            d2_loss_tail<1>(a, tag, red);
+    }
+    // (the bump comes behind the collect: every workgroup has published its logits, i.e. has read the generation word)
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int RB>
+__global__ __launch_bounds__(D2_THREADS) void downstream2_fwd_kernel(DnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const unsigned tag = __hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    D2Keep k1 = {}, k2 = {};
+    float my_logit = 0.f;
+    d2_fwd_body<RB>(a, sm, tag, k1, k2, my_logit);
+    if (blockIdx.x == 0) d2_fwd_tail<RB>(a, sm, tag, k1, k2);
+}
+
 
 // backward norm (as bwd_norm): Gm = g, XH = x_hat, both [16 RB][ld] in LDS; Gm := dz in place.  keep_sg / keep_sgx: the column
 // totals (workgroup 0 writes dweight | dbias from them at the end of the launch); scratch: 2 x 512 floats of LDS
@@ -1382,9 +1418,13 @@ __device__ __forceinline__ void d2_gate_rows(const float *DA, const float *Z, in
     d2_lds_barrier();
 }
 
-template <int RB>
-__global__ __launch_bounds__(D2_THREADS) void downstream2_bwd_kernel(DnArgs a) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
+// The backward of a 16 RB-row workgroup (everything but workgroup 0's leftovers: d2_bwd_tail).  FUSED: the part behind the forward
+// in ONE launch (downstream2_fb_kernel) — d loss / d logits of the workgroup's rows is the caller's (entry tid: my_dlogit), the
+// norms' mean | invstd | w | b were put in place by the caller (d2_bwd_stats: workgroup 0 has not written save_stat yet), z1 / z2 / z3
+// are re-read from memory (this workgroup's own stores, complete behind the caller's barrier).
+template <int RB, bool FUSED>
+__device__ __forceinline__ void d2_bwd_body(const DnArgs &a, unsigned long long *partial, float *sm, unsigned tag, float my_dlogit,
+                                            float &sg1, float &sgx1, float &sg2, float &sgx2) {
     constexpr int R = 16 * RB;
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6), g = blockIdx.x, rb = g * R;
     const int d0 = a.d0, d1 = a.d1, d2 = a.d2, d3 = a.d3, T = a.T;
@@ -1393,7 +1433,6 @@ __global__ __launch_bounds__(D2_THREADS) void downstream2_bwd_kernel(DnArgs a) {
     float *bufA = sm + L.off_a, *bufB = sm + L.off_b, *red = sm + L.off_red, *sc = sm + L.off_sc;
     float *Hs3T = sm + L.off_small, *wr = Hs3T + r4(d3 * d2), *dls = wr + r4(T * d3), *z3s = dls + r4(R * T), *dz3s = z3s + r4(R * d3),
           *st1 = dz3s + r4(R * d3), *st2 = st1 + 4 * D2_MAXW, *bufC = st2 + 4 * D2_MAXW;        // st*: mean | invstd | w | b
-    const unsigned tag = __hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
     const int nvalid = a.n_valid ? min(*a.n_valid, a.B) : a.B;
     const unsigned long long rng_seed = a.rng ? a.rng[0] : 0ull, rng_step = a.rng ? a.rng[1] : 0ull;    // (uniform: scalar loads)
     (void)ldm;
@@ -1407,13 +1446,19 @@ __global__ __launch_bounds__(D2_THREADS) void downstream2_bwd_kernel(DnArgs a) {
     d2_rows_to_lds<RB>(a.z1, a.B, rb, d1, bufC, L.ld1);          // bufC: z1 slab (kept until its turn)
     for (int e = tid; e < d3 * d2; e += D2_THREADS) Hs3T[e] = a.H3T[e];
     for (int e = tid; e < T * d3; e += D2_THREADS) wr[e] = a.Wr[e];
-    for (int e = tid; e < R * T; e += D2_THREADS) dls[e] = rb * T + e < a.B * T ? a.dlogits[(size_t)rb * T + e] : 0.f;
+    if constexpr (FUSED) {
+        if (tid < R * T) dls[tid] = rb * T + tid < a.B * T ? my_dlogit : 0.f;        // (R T <= 256: one entry per thread)
+    } else {
+        for (int e = tid; e < R * T; e += D2_THREADS) dls[e] = rb * T + e < a.B * T ? a.dlogits[(size_t)rb * T + e] : 0.f;
+    }
     for (int e = tid; e < R * d3; e += D2_THREADS) z3s[e] = rb * d3 + e < a.B * d3 ? a.z3[(size_t)rb * d3 + e] : 0.f;
+    if constexpr (!FUSED) {                                  // (FUSED: the caller wrote st1 / st2 out of the forward's registers: d2_bwd_stats)
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {                            // mean, invstd, w, b of both norms (save_stat slots 0, 1, 4, 5)
-        const int slot = q < 2 ? q : q + 2;
-        if (tid < d1) st1[q * D2_MAXW + tid] = a.stat1[slot * d1 + tid];
-        if (tid < d2) st2[q * D2_MAXW + tid] = a.stat2[slot * d2 + tid];
+        for (int q = 0; q < 4; ++q) {                        // mean, invstd, w, b of both norms (save_stat slots 0, 1, 4, 5)
+            const int slot = q < 2 ? q : q + 2;
+            if (tid < d1) st1[q * D2_MAXW + tid] = a.stat1[slot * d1 + tid];
+            if (tid < d2) st2[q * D2_MAXW + tid] = a.stat2[slot * d2 + tid];
+        }
     }
     __syncthreads();
     DN_STAMP(17);
@@ -1426,7 +1471,7 @@ __global__ __launch_bounds__(D2_THREADS) void downstream2_bwd_kernel(DnArgs a) {
         dz3s[row * d3 + j] = v;
         if (rb + row < a.B) a.dz3[(size_t)(rb + row) * d3 + j] = v;
     }
-    unsigned long long *part1 = a.partial, *part2 = a.partial + (size_t)a.G * D2_PSTRIDE;
+    unsigned long long *part1 = partial, *part2 = partial + (size_t)a.G * D2_PSTRIDE;      // (the caller's: a.partial, or the one-launch form's a.partial_b)
     for (int e = tid; e < T * d3 + T; e += D2_THREADS) {
         float s = 0.f;
         if (e < T * d3) {
@@ -1454,7 +1499,6 @@ __global__ __launch_bounds__(D2_THREADS) void downstream2_bwd_kernel(DnArgs a) {
     DN_STAMP(18);
     d2_gate_rows<RB>(bufA, bufB, L.ld2, d2, st2, a.act, rb, nvalid, bufA, bufB, a.drop_p2, a.drop_same2, a.drop_k2, a.drop_site2, rng_seed, rng_step);
     DN_STAMP(19);
-    float sg2 = 0.f, sgx2 = 0.f, sg1 = 0.f, sgx1 = 0.f;
     d2_bwd_norm<RB>(a, bufA, bufB, L.ld2, d2, nvalid, rb, part1, tag, st2, sc, red, sg2, sgx2, 20);
     DN_STAMP(22);
     d2_store_rows<RB>(bufA, L.ld2, a.B, rb, d2, a.dz2);
@@ -1475,13 +1519,110 @@ __global__ __launch_bounds__(D2_THREADS) void downstream2_bwd_kernel(DnArgs a) {
         d2_store_rows<RB>(bufB, L.ldx, a.B, rb, d0, a.dx);
     }
     DN_STAMP(29);
-    if (g == 0) {                                                // workgroup 0's leftovers, off every other workgroup's path
-        if (a.dwb2 && tid < d2) { a.dwb2[tid] = sgx2; a.dwb2[d2 + tid] = sg2; }
-        if (a.dwb1 && tid < d1) { a.dwb1[tid] = sgx1; a.dwb1[d1 + tid] = sg1; }
-        if (a.dWr) d2_merge_extras(part1, a.G, tag, T * d3 + T, a.dWr, a.err);
-    }
-    if (g == 0 && tid == 0) __hip_atomic_fetch_add(a.sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+
+// where d2_bwd_body keeps the norms' mean | invstd | w | b rows (st1; st2 = st1 + 4 D2_MAXW): the one-launch form fills them itself
+template <int RB>
+__device__ __forceinline__ float *d2_bwd_stats(const DnArgs &a, float *sm) {
+    constexpr int R = 16 * RB;
+    const D2Lds L = d2_lds(RB, a.d0, a.d1, a.d2, a.d3, a.T);
+    return sm + L.off_small + r4(a.d3 * a.d2) + r4(a.T * a.d3) + r4(R * a.T) + 2 * r4(R * a.d3);
+}
+
+// workgroup 0's leftovers of the backward (the norms' affine gradients, the dense head's, the generation bump), off every other
+// workgroup's path
+__device__ __forceinline__ void d2_bwd_tail(const DnArgs &a, const unsigned long long *partial, unsigned *sync, unsigned tag, float sg1, float sgx1,
+                                            float sg2, float sgx2) {
+    const int tid = threadIdx.x;
+    if (a.dwb2 && tid < a.d2) { a.dwb2[tid] = sgx2; a.dwb2[a.d2 + tid] = sg2; }
+    if (a.dwb1 && tid < a.d1) { a.dwb1[tid] = sgx1; a.dwb1[a.d1 + tid] = sg1; }
+    if (a.dWr) d2_merge_extras(partial, a.G, tag, a.T * a.d3 + a.T, a.dWr, a.err);
+    if (tid == 0) __hip_atomic_fetch_add(sync, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <int RB>
+__global__ __launch_bounds__(D2_THREADS) void downstream2_bwd_kernel(DnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    const unsigned tag = __hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    float sg1 = 0.f, sgx1 = 0.f, sg2 = 0.f, sgx2 = 0.f;
+    d2_bwd_body<RB, false>(a, a.partial, sm, tag, 0.f, sg1, sgx1, sg2, sgx2);
+    if (blockIdx.x == 0) d2_bwd_tail(a, a.partial, a.sync, tag, sg1, sgx1, sg2, sgx2);
+}
+
+// Forward AND backward of the head in ONE launch (round 6): a training step whose loss is taken inside the forward launch
+// (DnArgs.loss_y) knows d loss / d logits of its rows as soon as it knows the labeled count — every workgroup counts the labels
+// itself (<= 4096 entries, read at kernel entry) — so, for an upstream gradient of 1, the backward can start where the forward
+// ends: no launch boundary (its 8 us floor, the 6 us first dependent load of the backward's workgroups), the operands' lines warm.
+// The two parts keep their own exchange buffers and generation words (partial / sync, partial_b / sync_b): the protocols are the
+// separate launches'.  The parts' leftovers come behind the backward part (on two workgroups).  Same arithmetic as the two launches:
+// bit-identical outputs.
+template <int RB>
+__global__ __launch_bounds__(D2_THREADS) void downstream2_fb_kernel(DnArgs a) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    constexpr int R = 16 * RB;
+    const int tid = threadIdx.x, rb = blockIdx.x * R;
+    const unsigned tag_f = __hip_atomic_load(a.sync, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    const unsigned tag_b = __hip_atomic_load(a.sync_b, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1u;
+    const int total = a.B * a.T;
+    const int mine = rb * a.T + tid;                          // (entry tid of this workgroup's rows: tid < R T)
+    const float my_y = a.loss_y[min(mine, total - 1)];
+    D2Keep k1 = {}, k2 = {};
+    float my_logit = 0.f, c = 0.f;
+    d2_fwd_body<RB, true>(a, sm, tag_f, k1, k2, my_logit, &c);
+    // the labeled count (an integer in a float: the same number whatever the order) and this thread's d loss / d logit, as
+    // d2_loss_tail writes it for an upstream gradient of 1
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) c += __shfl_xor(c, off, 64);
+    const D2Lds L = d2_lds(RB, a.d0, a.d1, a.d2, a.d3, a.T);
+    float *scratch = sm + L.off_red;
+    float *stash = sm + L.total;                              // [14][256] behind both parts' carve-ups: the norms' statistics of column tid
+    __syncthreads();                                          // the forward part's LDS is dead, its stores (z1, z2, z3: re-read below) complete
+    if ((tid & 63) == 0) scratch[tid >> 6] = c;
+    if (tid < D2_MAXW) {                                      // (workgroup 0's forward leftovers come behind the backward part: 14 registers less across it)
+        stash[0 * D2_MAXW + tid] = k1.mean; stash[1 * D2_MAXW + tid] = k1.invstd; stash[2 * D2_MAXW + tid] = k1.w; stash[3 * D2_MAXW + tid] = k1.b;
+        stash[4 * D2_MAXW + tid] = k1.unbiased; stash[5 * D2_MAXW + tid] = k1.rm_old; stash[6 * D2_MAXW + tid] = k1.rv_old;
+        stash[7 * D2_MAXW + tid] = k2.mean; stash[8 * D2_MAXW + tid] = k2.invstd; stash[9 * D2_MAXW + tid] = k2.w; stash[10 * D2_MAXW + tid] = k2.b;
+        stash[11 * D2_MAXW + tid] = k2.unbiased; stash[12 * D2_MAXW + tid] = k2.rm_old; stash[13 * D2_MAXW + tid] = k2.rv_old;
+        stash[14 * D2_MAXW + tid] = __int_as_float(k1.valid | (k2.valid << 1));
+        // ... and the backward part's mean | invstd | w | b rows of both norms, where d2_bwd_body reads them
+        float *st1 = d2_bwd_stats<RB>(a, sm), *st2 = st1 + 4 * D2_MAXW;
+        if (tid < a.d1) { st1[tid] = k1.mean; st1[D2_MAXW + tid] = k1.invstd; st1[2 * D2_MAXW + tid] = k1.w; st1[3 * D2_MAXW + tid] = k1.b; }
+        if (tid < a.d2) { st2[tid] = k2.mean; st2[D2_MAXW + tid] = k2.invstd; st2[2 * D2_MAXW + tid] = k2.w; st2[3 * D2_MAXW + tid] = k2.b; }
+    }
+    d2_lds_barrier();
+    c = 0.f;
+#pragma unroll
+    for (int w = 0; w < D2_WAVES; ++w) c += scratch[w];
+    d2_lds_barrier();
+    float my_dlogit = 0.f;
+    if (mine < total && my_y == my_y) {
+        const float scale = 1.f / c;
+        if (a.loss_kind == 0) {
+            my_dlogit = (1.f / (1.f + expf(-my_logit)) - my_y) * scale;
+        } else {
+            const float d = my_logit - my_y;
+            my_dlogit = (d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f)) * scale;
+        }
+    }
+    float sg1 = 0.f, sgx1 = 0.f, sg2 = 0.f, sgx2 = 0.f;
+    d2_bwd_body<RB, true>(a, a.partial_b, sm, tag_b, my_dlogit, sg1, sgx1, sg2, sgx2);
+    // the two parts' leftovers on two different workgroups: the forward's (the norms' state, the loss: a collect of all logits) on the
+    // LAST one — fewest rows, first through its backward part —, the backward's on workgroup 0; on one workgroup they were one behind
+    // the other at the end of the launch's longest path
+    if (blockIdx.x == gridDim.x - 1) {
+        if (tid < D2_MAXW) {
+            k1.mean = stash[0 * D2_MAXW + tid]; k1.invstd = stash[1 * D2_MAXW + tid]; k1.w = stash[2 * D2_MAXW + tid]; k1.b = stash[3 * D2_MAXW + tid];
+            k1.unbiased = stash[4 * D2_MAXW + tid]; k1.rm_old = stash[5 * D2_MAXW + tid]; k1.rv_old = stash[6 * D2_MAXW + tid];
+            k2.mean = stash[7 * D2_MAXW + tid]; k2.invstd = stash[8 * D2_MAXW + tid]; k2.w = stash[9 * D2_MAXW + tid]; k2.b = stash[10 * D2_MAXW + tid];
+            k2.unbiased = stash[11 * D2_MAXW + tid]; k2.rm_old = stash[12 * D2_MAXW + tid]; k2.rv_old = stash[13 * D2_MAXW + tid];
+            const int v = __float_as_int(stash[14 * D2_MAXW + tid]);
+            k1.valid = v & 1; k2.valid = (v >> 1) & 1;
+        }
+        d2_fwd_tail<RB>(a, sm, tag_f, k1, k2);
+    }
+    if (blockIdx.x == 0) d2_bwd_tail(a, a.partial_b, a.sync_b, tag_b, sg1, sgx1, sg2, sgx2);
+}
+
 
 
 static size_t dn_lds_floats(int d0, int d1, int d2, int d3, int T, bool bwd) {
@@ -1563,7 +1704,7 @@ static int dn2_capacity_of(K kernel, int slot, size_t lds_bytes) {
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 0;
     struct Slot { size_t lds; int cap; };
-    static Slot cache[64][4] = {};
+    static Slot cache[64][6] = {};
     Slot &sl = cache[dev][slot];
     if (sl.lds == lds_bytes && sl.cap > 0) return sl.cap;
     if (!ensure_dynamic_lds(kernel, 150 * 1024)) return 0;
@@ -1584,6 +1725,16 @@ static bool dn2_device_ok(int B, int d0, int d1, int d2, int d3, int T) {
     if (RB == 1)
         return dn2_capacity_of(&downstream2_fwd_kernel<1>, 0, lds) >= G && dn2_capacity_of(&downstream2_bwd_kernel<1>, 1, lds) >= G;
     return dn2_capacity_of(&downstream2_fwd_kernel<2>, 2, lds) >= G && dn2_capacity_of(&downstream2_bwd_kernel<2>, 3, lds) >= G;
+}
+
+// ... and of the one-launch forward + backward
+static bool dn2_fb_device_ok(int B, int d0, int d1, int d2, int d3, int T) {
+    static const bool off = getenv("PHC_HEAD_FUSED_BWD") && atoi(getenv("PHC_HEAD_FUSED_BWD")) == 0;
+    if (off) return false;
+    const int RB = dn2_rb(B), G = (B + 16 * RB - 1) / (16 * RB);
+    const size_t lds = sizeof(float) * ((size_t)d2_lds(RB, d0, d1, d2, d3, T).total + D2_FB_STASH);
+    if (lds > 150 * 1024) return false;
+    return RB == 1 ? dn2_capacity_of(&downstream2_fb_kernel<1>, 4, lds) >= G : dn2_capacity_of(&downstream2_fb_kernel<2>, 5, lds) >= G;
 }
 
 // all G workgroups of BOTH launches must be able to be resident at once on this device
@@ -1697,6 +1848,12 @@ int phc_downstream_loss_supported(int64_t B, int d0, int d1, int d2, int d3, int
     return ((long long)B * T <= DN_LOSS_MAX && dn2_shape_ok(Bc, d0, d1, d2, d3, T) && dn2_device_ok(Bc, d0, d1, d2, d3, T)) ? 1 : 0;
 }
 
+/* ABI 8: phc_downstream_desc.fused_bwd is served: forward (with the loss) AND backward for an upstream gradient of 1 in ONE launch */
+int phc_downstream_fused_bwd_supported(int64_t B, int d0, int d1, int d2, int d3, int T) {
+    const int Bc = (int)(B > (1LL << 20) ? 1 << 20 : B);
+    return (phc_downstream_loss_supported(B, d0, d1, d2, d3, T) && 16 * dn2_rb(Bc) * T <= 256 && dn2_fb_device_ok(Bc, d0, d1, d2, d3, T)) ? 1 : 0;
+}
+
 size_t phc_downstream_partial_floats(int64_t B) {
     if (B < 1) return 0;
     const size_t v1 = 2 * 2 * (size_t)((B + DN_ROWS - 1) / DN_ROWS) * DN_PSTRIDE;      // 8-byte {value, tag} granules
@@ -1728,6 +1885,31 @@ int phc_downstream_fwd(const phc_downstream_desc *d, void *stream) {
                   reinterpret_cast<uintptr_t>(a.z1) | reinterpret_cast<uintptr_t>(a.z2)) & 15) == 0,
                 PHC_ERR_UNSUPPORTED, "phc_downstream_fwd: 16-byte aligned rows required");
     hipStream_t s = (hipStream_t)stream;
+    if (d->fused_bwd) {
+        // forward + backward in ONE launch: the backward's operands and outputs as phc_downstream_bwd takes them (dlogits is not read:
+        // the launch derives it from its own logits and the labels), its own exchange buffers
+        PHC_REQUIRE(d->loss_y && phc_downstream_fused_bwd_supported(d->B, d->d0, d->d1, d->d2, d->d3, d->T), PHC_ERR_UNSUPPORTED,
+                    "phc_downstream_fwd: fused_bwd needs the loss inside the launch and phc_downstream_fused_bwd_supported");
+        a.H1T = d->H1T; a.H2T = d->H2T; a.H3T = d->H3T;
+        a.dx = d->dx; a.dz1 = d->dz1; a.dz2 = d->dz2; a.dz3 = d->dz3; a.dwb1 = d->dwb1; a.dwb2 = d->dwb2; a.dWr = d->dWr;
+        a.dbr = d->dWr ? d->dWr + d->T * d->d3 : nullptr;
+        a.partial_b = reinterpret_cast<unsigned long long *>(d->partial_bwd);
+        a.sync_b = reinterpret_cast<unsigned *>(d->sync_bwd);
+        PHC_REQUIRE(a.H1T && a.H2T && a.H3T && a.dz1 && a.dz2 && a.dz3 && a.dWr && a.partial_b && a.sync_b && a.partial_b != a.partial &&
+                        a.sync_b != a.sync,
+                    PHC_ERR_INVALID_ARG, "phc_downstream_fwd: fused_bwd: null backward pointer, or the backward's partial / sync are the forward's");
+        PHC_REQUIRE(((reinterpret_cast<uintptr_t>(a.H1T) | reinterpret_cast<uintptr_t>(a.H2T) | reinterpret_cast<uintptr_t>(a.dz1) |
+                      reinterpret_cast<uintptr_t>(a.dz2) | reinterpret_cast<uintptr_t>(a.dx)) & 15) == 0,
+                    PHC_ERR_UNSUPPORTED, "phc_downstream_fwd: fused_bwd: 16-byte aligned rows required");
+        ProfScope prof(K_DOWNSTREAM_FWD, s);
+        const int RB = dn2_rb(a.B);
+        const size_t lds2 = sizeof(float) * ((size_t)d2_lds(RB, a.d0, a.d1, a.d2, a.d3, a.T).total + D2_FB_STASH);
+        if (RB == 1)
+            PHC_LAUNCH(downstream2_fb_kernel<1>, dim3(a.G), dim3(D2_THREADS), lds2, s, a);
+        else
+            PHC_LAUNCH(downstream2_fb_kernel<2>, dim3(a.G), dim3(D2_THREADS), lds2, s, a);
+        return check_launch("downstream2_fb");
+    }
     // (hipFuncAttributeMaxDynamicSharedMemorySize was set, per device and checked, by the capacity queries of dn_common)
     ProfScope prof(K_DOWNSTREAM_FWD, s);
     if (v2) {

@@ -62,7 +62,8 @@ class DownstreamDesc(C.Structure):
                 ("H1k4", _P), ("H2k4", _P), ("H1Tk4", _P), ("H2Tk4", _P),
                 ("drop_p1", C.c_float), ("drop_p2", C.c_float), ("drop_same_k1", C.c_int32), ("drop_same_k2", C.c_int32),
                 ("drop_site1", C.c_int32), ("drop_site2", C.c_int32), ("rng_state", _P), ("a1", _P), ("a2", _P),
-                ("loss_y", _P), ("loss_kind", C.c_int32), ("loss_out", _P), ("loss_dlogits", _P), ("loss_granules", _P)]
+                ("loss_y", _P), ("loss_kind", C.c_int32), ("loss_out", _P), ("loss_dlogits", _P), ("loss_granules", _P),
+                ("fused_bwd", C.c_int32), ("partial_bwd", _P), ("sync_bwd", _P)]
 
 
 class MlpNormBwdDesc(C.Structure):
@@ -212,6 +213,7 @@ SIGNATURES = {
     "phc_downstream_supported_k4": (_I, [_L, _I, _I, _I, _I, _I]),
     "phc_downstream_dropout_supported": (_I, [_L, _I, _I, _I, _I, _I]),
     "phc_downstream_loss_supported": (_I, [_L, _I, _I, _I, _I, _I]),
+    "phc_downstream_fused_bwd_supported": (_I, [_L, _I, _I, _I, _I, _I]),
     "phc_downstream_partial_floats": (_S, [_L]),
     "phc_downstream_fwd": (_I, [C.POINTER(DownstreamDesc), _P]),
     "phc_downstream_bwd": (_I, [C.POINTER(DownstreamDesc), _P]),

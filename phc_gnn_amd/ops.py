@@ -2201,6 +2201,8 @@ class _MaskedL1Fn(torch.autograd.Function):
 # before the model runs says so with ``expect_loss``; a head whose shapes allow it (the 16-row kernels, at most 4096 logits) then
 # leaves the loss and d loss / d logits behind, and ``masked_bce_with_logits`` / ``masked_l1`` on those logits and labels launch nothing.
 HEAD_LOSS = __import__("os").environ.get("PHC_HEAD_LOSS", "1") != "0"
+# ... and the head's BACKWARD in that same launch (phc_downstream_desc.fused_bwd; csrc/downstream.hip downstream2_fb_kernel); 0 = its own launch
+HEAD_FUSED_BWD = __import__("os").environ.get("PHC_HEAD_FUSED_BWD", "1") != "0"
 _LOSS_HINT = threading.local()
 _LOSS_KINDS = {"bce": 0, "l1": 1}
 
@@ -3617,6 +3619,22 @@ class _DownstreamFn(torch.autograd.Function):
             d.loss_y, d.loss_kind, d.loss_out, d.loss_dlogits = L.ptr(y_), kind, L.ptr(out3), L.ptr(dz_unit)
             d.loss_granules = L.ptr(_dn_loss_granules(dev, B, B * T))
             meta["loss_result"] = (out3, dz_unit, y_, kind, y_._version)
+        ctx.fused_bwd = None
+        if loss is not None and HEAD_FUSED_BWD and any(ctx.needs_input_grad) and pre[0][1] is not None and pre[1][1] is not None and \
+                pre[2][1] is not None and _supported("phc_downstream_fused_bwd_supported", B, d0, d1, d2, d3, T):
+            # ... and the BACKWARD in the same launch, for an upstream gradient of 1 (the step's loss.backward(): ops.register_unit_seed):
+            # d loss / d logits of a workgroup's rows needs the labeled count only, which every workgroup counts itself.  The backward
+            # node hands these results out when the gradient it receives IS dz_unit, and launches phc_downstream_bwd otherwise.
+            need_x = ctx.needs_input_grad[0]
+            fb = dict(dx=torch.empty_like(x_) if need_x else None, dz1=torch.empty_like(z1), dz2=torch.empty_like(z2), dz3=torch.empty_like(z3),
+                      dwb1=torch.empty(2 * d1, dtype=torch.float32, device=dev), dwb2=torch.empty(2 * d2, dtype=torch.float32, device=dev),
+                      dWr=torch.empty(T * d3 + T, dtype=torch.float32, device=dev), token=dz_unit)
+            sync_b, partial_b = _dn_buffers(dev, "bwd", B)
+            d.H1T, d.H2T, d.H3T = L.ptr(pre[0][1]), L.ptr(pre[1][1]), L.ptr(pre[2][1])
+            d.dx, d.dz1, d.dz2, d.dz3 = L.ptr(fb["dx"]), L.ptr(fb["dz1"]), L.ptr(fb["dz2"]), L.ptr(fb["dz3"])
+            d.dwb1, d.dwb2, d.dWr = L.ptr(fb["dwb1"]), L.ptr(fb["dwb2"]), L.ptr(fb["dWr"])
+            d.fused_bwd, d.partial_bwd, d.sync_bwd = 1, L.ptr(partial_b), L.ptr(sync_b)
+            ctx.fused_bwd = fb
         L.check(lib.phc_downstream_fwd(_C.byref(d), L.stream_ptr(dev)), "phc_downstream_fwd")
         if drop is None:
             _tap(z1, stat1, n_valid, act)
@@ -3642,13 +3660,19 @@ class _DownstreamFn(torch.autograd.Function):
         d1, d2, d3, T = z1.shape[1], z2.shape[1], z3.shape[1], Wr.shape[0]
         dl = L.f32c(dlogits)
         need_x = ctx.needs_input_grad[0]
+        a1, a2 = ctx.dropped
+        fb = ctx.fused_bwd
+        if fb is not None and dl.data_ptr() == fb["token"].data_ptr() and tuple(dl.shape) == tuple(fb["token"].shape):
+            # the forward launch ran this backward already (upstream gradient 1: the gradient received IS its d loss / d logits)
+            dx, dz1, dz2, dz3, dwb1, dwb2, dWr = fb["dx"], fb["dz1"], fb["dz2"], fb["dz3"], fb["dwb1"], fb["dwb2"], fb["dWr"]
+            return _DownstreamFn._finish_backward(ctx, x_, z1, z2, stat1, stat2, n_valid, act, norms, a1, a2, dx, dz1, dz2, dz3, dwb1, dwb2, dWr,
+                                                  d1, d2, d3, T)
         dx = torch.empty_like(x_) if need_x else None
         dz1, dz2, dz3 = torch.empty_like(z1), torch.empty_like(z2), torch.empty_like(z3)
         dwb1 = torch.empty(2 * d1, dtype=torch.float32, device=dev)
         dwb2 = torch.empty(2 * d2, dtype=torch.float32, device=dev)
         dWr = torch.empty(T * d3 + T, dtype=torch.float32, device=dev)
         sync, partial = _dn_buffers(dev, "bwd", B)
-        a1, a2 = ctx.dropped
         d = L.DownstreamDesc()
         d.B, d.d0, d.d1, d.d2, d.d3, d.T, d.act = B, d0, d1, d2, d3, T, act
         d.n_valid_dev = L.ptr(n_valid)
@@ -3664,6 +3688,11 @@ class _DownstreamFn(torch.autograd.Function):
         L.check(lib.phc_downstream_bwd(_C.byref(d), L.stream_ptr(dev)), "phc_downstream_bwd")
         if L.PROF_ON:
             L.account("downstream_bwd", 2.0 * B * (d0 * d1 + d1 * d2 + 2 * d2 * d3 + 2 * d3 * T), 4.0 * (B * (d0 + 2 * d1 + 2 * d2 + 2 * d3 + T) + d0 * d1 + d1 * d2))
+        return _DownstreamFn._finish_backward(ctx, x_, z1, z2, stat1, stat2, n_valid, act, norms, a1, a2, dx, dz1, dz2, dz3, dwb1, dwb2, dWr,
+                                              d1, d2, d3, T)
+
+    @staticmethod
+    def _finish_backward(ctx, x_, z1, z2, stat1, stat2, n_valid, act, norms, a1, a2, dx, dz1, dz2, dz3, dwb1, dwb2, dWr, d1, d2, d3, T):
         # the three PHM layers' parameter gradients: jobs for the batched gradient launches
         needs = ctx.needs_input_grad
         # (with dropout the layers' inputs are the dropped activations the forward wrote: the operand transform knows no mask)
@@ -4000,10 +4029,12 @@ def close_auto_step(flush: bool = False) -> None:
     stack.close()
 
 
-def _accumulate_nodes(model):
-    """The AccumulateGrad nodes of the model's leaf parameters (cached on the model; they live as long as the parameters)."""
+def _accumulate_nodes(model, all_params=None):
+    """The AccumulateGrad nodes of the model's leaf parameters (cached on the model; they live as long as the parameters).
+    ``all_params``: the caller's ``list(model.parameters())`` of this step (one module-tree walk per step instead of two: the walk is
+    0.3 ms of host time at 205 parameter tensors, scripts/dbg/refloop_profile.py)."""
     cache = model.__dict__.get("_phc_acc_nodes")
-    params = [p for p in model.parameters() if p.requires_grad]
+    params = [p for p in (model.parameters() if all_params is None else all_params) if p.requires_grad]
     if cache is None or cache[0] != tuple(id(p) for p in params):
         with torch.enable_grad():
             nodes = [p.view_as(p).grad_fn.next_functions[0][0] for p in params]
@@ -4019,7 +4050,8 @@ def auto_step_forward(model, data, run):
     close_auto_step(flush=False)                             # a block whose backward never came
     dev = data.x.device
     specs = model.__dict__.get("_phc_auto_specs")
-    key = tuple(id(p) for p in model.parameters())
+    all_params = list(model.parameters())
+    key = tuple(id(p) for p in all_params)
     if specs is None or specs[0] != key:
         specs = model.__dict__["_phc_auto_specs"] = (key, phm_pairs(model), dense_weights(model), gate_specs(model))
     stack = contextlib.ExitStack()
@@ -4042,7 +4074,7 @@ def auto_step_forward(model, data, run):
         stack.close()
         return out
     _AUTO.stack = stack
-    nodes = _accumulate_nodes(model)
+    nodes = _accumulate_nodes(model, all_params)
 
     def at_backward_start(grad):
         if _AUTO.stack is not stack:

@@ -103,7 +103,7 @@ def test_repeated_steps_are_bit_equal_under_allocator_pollution(workload, mode):
 TOGGLES = ["none", "GEMM_AGGREGATE", "READOUT_FUSED", "NORM_INTO_AGGREGATE", "MLP_NORM_FUSED", "SKIP_SUM_HANDOFF", "ENCODE_FRONT",
            "STEP_TAIL_MERGED", "GATE_COMPOSED", "TAIL_EXTRAS", "TAIL_WIDE", "TABLE_GRADS_COUNTED", "STAT_ACC", "FLAT_TABLES",
            "BN_BWD_SUMS_IN_GEMM", "DOWNSTREAM_FUSED", "STATS_WITH_RESIDUAL", "RESIDUAL_HANDOFF", "HEAD_CHAIN", "HEAD_DROPOUT", "POOL_BWD_GATE",
-           "MLP_BWD_FUSED", "MLP_FWD_FUSED", "MLP_FWD_FUSED_AGG", "HEAD_LOSS", "MLP_BWD_FUSED_AGG"]
+           "MLP_BWD_FUSED", "MLP_FWD_FUSED", "MLP_FWD_FUSED_AGG", "HEAD_LOSS", "MLP_BWD_FUSED_AGG", "HEAD_FUSED_BWD"]
 ORACLE_KW = {
     "molhiv_b32_swish": dict(phm_dim=4, num_layers=4, num_atom_feats=9, num_bond_feats=3, num_dn_hidden=2, mlp=True, sc_type="first",
                              act="swish"),
@@ -194,7 +194,7 @@ def test_every_single_toggle_flip_holds_the_oracle(workload, toggle):
 # oracle on its non-default side in a FRESH child process (never a re-exec of a process that has touched the GPU).
 ENV_FLIPS = [("PHC_GEMM_NO_HS", "1"), ("PHC_GEMM_HS_PUB", "0"), ("PHC_GEMM_AGGREGATE", "0"), ("PHC_GEMM_AGGREGATE_WIDE", "0"),
              ("PHC_DOWNSTREAM_V2", "0"), ("PHC_HEAD_CHAIN", "0"), ("PHC_READOUT_FUSED", "0"), ("PHC_POOL_BWD_GATE", "0"), ("PHC_DH_PAIR", "0"),
-             ("PHC_MLP_BWD_FUSED", "0"), ("PHC_MLP_FWD_FUSED", "0"), ("PHC_CLIP_ADAM_FUSED", "0")]
+             ("PHC_MLP_BWD_FUSED", "0"), ("PHC_MLP_FWD_FUSED", "0"), ("PHC_CLIP_ADAM_FUSED", "0"), ("PHC_HEAD_FUSED_BWD", "0")]
 
 
 @pytest.mark.parametrize("name,value", ENV_FLIPS)

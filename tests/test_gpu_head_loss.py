@@ -95,3 +95,69 @@ def test_loss_hint_is_ignored_when_the_labels_differ(monkeypatch):
         c = ops._MaskedBCEFn.apply(logits.detach(), data.y)
     assert abs(float(a) - float(c)) <= 2e-6 * abs(float(c))
     assert abs(float(a) - float(b)) > 1e-3
+
+
+# ---- forward AND backward of the head in ONE launch (phc_downstream_desc.fused_bwd, ops.HEAD_FUSED_BWD) -------------------------------
+def _count_head_launches(monkeypatch):
+    from phc_gnn_amd import lib
+    h = lib.load()
+    seen = {"fwd": 0, "fwd_fused": 0, "bwd": 0}
+    real_f, real_b = h.phc_downstream_fwd, h.phc_downstream_bwd
+
+    def fwd(desc, stream):
+        d = desc._obj if hasattr(desc, "_obj") else desc.contents
+        seen["fwd_fused" if d.fused_bwd else "fwd"] += 1
+        return real_f(desc, stream)
+
+    def bwd(desc, stream):
+        seen["bwd"] += 1
+        return real_b(desc, stream)
+    monkeypatch.setattr(h, "phc_downstream_fwd", fwd)
+    monkeypatch.setattr(h, "phc_downstream_bwd", bwd)
+    return seen
+
+
+@pytest.mark.parametrize("workload", ["molhiv_b32", "molhiv_b512", "zinc_b1024", "molhiv_pub_phc4_2x200_nodrop", "molhiv_pub_phc4_2x200"])
+@pytest.mark.parametrize("graph", [False, True])
+def test_head_backward_inside_the_forward_launch_is_bit_identical(workload, graph, monkeypatch):
+    """BCE and L1 heads, 16- and 32-row workgroups, dropout behind the head's activations: the one launch == the two launches."""
+    from phc_gnn_amd import ops
+    seen = _count_head_launches(monkeypatch)
+    monkeypatch.setattr(ops, "HEAD_FUSED_BWD", True)
+    ops.rng_seed(DEV, 77)                                     # (the dropout workload: the same masks in both runs)
+    la, ga, _, _, _ = _step(workload, True, monkeypatch, graph=graph)
+    assert seen["fwd_fused"] >= 1 and seen["bwd"] == 0 and seen["fwd"] == 0, seen
+    for k in seen:
+        seen[k] = 0
+    monkeypatch.setattr(ops, "HEAD_FUSED_BWD", False)
+    ops.rng_seed(DEV, 77)
+    lb, gb_, _, _, _ = _step(workload, True, monkeypatch, graph=graph)
+    assert seen["fwd_fused"] == 0 and seen["bwd"] >= 1, seen
+    assert la == lb
+    for k in gb_:
+        assert torch.equal(ga[k], gb_[k]), (k, float((ga[k] - gb_[k]).abs().max()))
+
+
+def test_head_backward_falls_back_when_the_upstream_gradient_is_not_one(monkeypatch):
+    """(2 loss).backward(): the gradient the head's node receives is not the forward launch's d loss / d logits — it launches
+    phc_downstream_bwd with what it received, and the results are those of the two-launch path."""
+    from phc_gnn_amd import harness, ops
+    seen = _count_head_launches(monkeypatch)
+
+    def run(fused):
+        monkeypatch.setattr(ops, "HEAD_FUSED_BWD", fused)
+        model = harness.build_model("molhiv_b32", DEV, seed=4).train()
+        data = harness.to_device(harness.make_batch("molhiv_b32", seed=5), DEV)
+        with ops.stat_accumulators(DEV), ops.prebuilt_H(ops.phm_pairs(model), ops.dense_weights(model), ops.gate_specs(model)):
+            with ops.expect_loss(data.y, "bce"):
+                logits = model(data)
+            loss = ops.masked_bce_with_logits(logits, data.y)
+            (2.0 * loss).backward()
+        torch.cuda.synchronize()
+        return float(loss), {k: p.grad.detach().clone() for k, p in model.named_parameters()}
+    la, ga = run(True)
+    assert seen["fwd_fused"] == 1 and seen["bwd"] == 1, seen
+    lb, gb_ = run(False)
+    assert la == lb
+    for k in gb_:
+        assert torch.equal(ga[k], gb_[k]), k
