@@ -1154,6 +1154,16 @@ __device__ __forceinline__ void d2_fwd_body(const DnArgs &a, float *sm, unsigned
 #pragma unroll
         for (int q = 0; q < 8; ++q) yv[q] = a.loss_y[min(tid + D2_THREADS * q, a.B * T - 1)];
     }
+    // First touches: a workgroup's first access to a buffer costs a page walk on top of the round trip (the first exchange of a launch
+    // took 6.4 - 7.7 us against 2.3 - 3.5 for the later ones, scripts/dbg/dn_fb_time.py).  The exchange records this workgroup will
+    // sweep are touched NOW, under the staging loads; the values are dropped behind the staging barrier.
+    unsigned long long warm[COUNT ? 4 : 2];
+    warm[0] = get_granule(a.partial + (size_t)g * D2_PSTRIDE);
+    warm[1] = get_granule(a.partial + ((size_t)a.G + g) * D2_PSTRIDE);
+    if constexpr (COUNT) {
+        warm[2] = get_granule(a.partial_b + (size_t)g * D2_PSTRIDE);
+        warm[3] = get_granule(a.partial_b + ((size_t)a.G + g) * D2_PSTRIDE);
+    }
     DN_STAMP(12);
     // the norms' per-component parameter pointers -> LDS (uniform kernarg reads), each column thread fetches its own four values
     // behind the staging barrier: they arrive under the first GEMM (as run-time loops over the components with the loads inside,
@@ -1180,6 +1190,8 @@ __device__ __forceinline__ void d2_fwd_body(const DnArgs &a, float *sm, unsigned
     if (tid < d3) bs[2 * D2_MAXW + tid] = a.b3 ? a.b3[tid] : 0.f;
     __syncthreads();
     DN_STAMP(1);
+#pragma unroll
+    for (int q = 0; q < (COUNT ? 4 : 2); ++q) asm volatile("" ::"v"(warm[q]));
     if constexpr (COUNT) {
         float c = 0.f;
 #pragma unroll
