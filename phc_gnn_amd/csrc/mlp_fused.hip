@@ -875,11 +875,6 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mlp_fwd_fused_kernel(MlpFwdArgs
         z[s][0] = z[s][1] = zero;
         if (s < steps) {
             mf_gemm_tile_bias(tS + s * MF_TILE, hreg, c, kq, bias1, z[s]);
-            const long long row = (gs + (long long)s * G) * 16 + c;
-            if (row < N) {
-#pragma unroll
-                for (int t = 0; t < 2; ++t) *reinterpret_cast<f32x4_t *>(a.z1 + (size_t)row * MF_H + col0 + 16 * t + 4 * kq) = z[s][t];
-            }
         }
     }
     MF_STAMP(2);
@@ -887,6 +882,16 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mlp_fwd_fused_kernel(MlpFwdArgs
     MF_STAMP(3);
     mf_grid_barrier(a.bar, gen, a.err);
     MF_STAMP(4);
+    // z1 goes to memory BEHIND the barrier (the backward reads it; the rows stay in registers across the barrier anyway): in front of
+    // it the arrival waited for these stores to complete (the barrier's wait covers everything the workgroup has in flight)
+#pragma unroll
+    for (int s = 0; s < MAXS; ++s) {
+        const long long row = (gs + (long long)s * G) * 16 + c;
+        if (s < steps && row < N) {
+#pragma unroll
+            for (int t = 0; t < 2; ++t) *reinterpret_cast<f32x4_t *>(a.z1 + (size_t)row * MF_H + col0 + 16 * t + 4 * kq) = z[s][t];
+        }
+    }
     // ---- P1 ----
     BnFromTotals bt = {};
     if (tid < MF_H) {
