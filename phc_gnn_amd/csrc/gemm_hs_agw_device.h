@@ -58,6 +58,13 @@ __global__ __launch_bounds__(HS_AGW_THREADS) void gemm_hs_agw_kernel(GemmHsArgs 
     unsigned long long tk[4] = {0, 0, 0, 0}, ph[6] = {0, 0, 0, 0, 0, 0}, t_chain = 0;
     if (a.stamps) tk[0] = __builtin_amdgcn_s_memrealtime();
     const int count = a.n_valid ? min(*a.n_valid, M) : M;
+    // Steps that hold padding rows ONLY (every row >= *n_valid: the tail of a fixed-shape batch; the LAST steps of a workgroup) take no
+    // gather and no matrix work (gemm_hs16_kernel's XF / BA launches do the same): their rows are written as s = 0, x = 0, z = bias —
+    // finite values nobody weighs (every consumer masks rows >= *n_valid or multiplies them with a zero gradient).  Whether a
+    // bucket's padded row count is a whole number of rounds of this launch then no longer decides whether it pays a nearly empty
+    // extra pass (24 832 rows: seven passes against six).  The workgroup's first step is always computed.
+    const int live_steps = (count + 15) / 16;
+    const int my_live = max(1, min(my_steps, group < live_steps ? (live_steps - group + a.groups - 1) / a.groups : 0));
     const bool live = lane < H4;                                  // this lane's 16-byte chunk exists in a row
     const int c4 = live ? lane : 0;
     auto lds_barrier = []() PHC_HS_INLINE {                                       // LDS traffic only: __syncthreads() would also wait for stores / prefetches
@@ -306,7 +313,7 @@ __global__ __launch_bounds__(HS_AGW_THREADS) void gemm_hs_agw_kernel(GemmHsArgs 
     Meta mn = m1;
     int srcs_n = srcs1;
     unsigned cods_n = cods1;
-    if (my_steps > 1) {
+    if (my_live > 1) {
         issue_raw(rawA, rowA_of(1), mn.e0[0], mn.e1[0], srcs_n, 0);
         if constexpr (FULL) issue_raw(rawB, rowA_of(1) + 1, mn.e0[1], mn.e1[1], srcs_n, 1);
     }
@@ -329,10 +336,10 @@ __global__ __launch_bounds__(HS_AGW_THREADS) void gemm_hs_agw_kernel(GemmHsArgs 
             asm volatile("" ::"v"(hreg[t][g]), "v"(hreg[t][g + 1]), "v"(hreg[t][g + 2]), "v"(hreg[t][g + 3]));
     if (a.stamps) tk[1] = __builtin_amdgcn_s_memrealtime();
     // ================= steps =================
-    for (int i = 0; i < my_steps; ++i) {
+    for (int i = 0; i < my_live; ++i) {
         const int step = gfirst + i * gstride;
         const int buf = i & 1;
-        const bool more = i + 1 < my_steps;
+        const bool more = i + 1 < my_live;
         unsigned long long p0 = 0, p1 = 0, p5 = 0;
         if (a.stamps) p0 = __builtin_amdgcn_s_memrealtime();
         lds_barrier();                                            // image[buf] complete; image[buf ^ 1] free (read by step i - 1)
@@ -386,7 +393,7 @@ __global__ __launch_bounds__(HS_AGW_THREADS) void gemm_hs_agw_kernel(GemmHsArgs 
             else finish(rawA, nB, mn.e0[1], mn.e1[1], srcs_n, cods_n, 1, buf ^ 1, 2 * wave + 1);
             if (a.stamps) { ph[3] += __builtin_amdgcn_s_memrealtime() - q0; q0 = __builtin_amdgcn_s_memrealtime(); }
             rotate();
-            if (i + 2 < my_steps) {
+            if (i + 2 < my_live) {
                 issue_raw(rawA, rowA_of(i + 2), mn.e0[0], mn.e1[0], srcs_n, 0);
                 if constexpr (FULL) issue_raw(rawB, rowA_of(i + 2) + 1, mn.e0[1], mn.e1[1], srcs_n, 1);
             }
@@ -440,6 +447,25 @@ __global__ __launch_bounds__(HS_AGW_THREADS) void gemm_hs_agw_kernel(GemmHsArgs 
         if (a.stamps) {
             const unsigned long long p6 = __builtin_amdgcn_s_memrealtime();
             ph[0] += p1 - p0; ph[5] += p6 - p5;
+        }
+    }
+    // padding-only steps: s = 0 (x = 0), z = bias
+    for (int i = my_live; i < my_steps; ++i) {
+        const int step = gfirst + i * gstride;
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int d = step * 16 + 2 * wave + u;
+            if (d < M && live) {
+                reinterpret_cast<float4 *>(ag.s_out)[(size_t)d * H4 + c4] = zf4;
+                if constexpr (NORMED) reinterpret_cast<float4 *>(ag.x_out)[(size_t)d * H4 + c4] = zf4;
+            }
+        }
+        const int row = step * 16 + c;
+        if (row < M) {
+            float *yr = a.y + (size_t)row * Nout + col0 + 4 * kq;
+#pragma unroll
+            for (int t = 0; t < TPW; ++t)
+                if (col0 + 4 * kq + 16 * t < Nout) *reinterpret_cast<f32x4_t *>(yr + 16 * t) = *reinterpret_cast<const f32x4_t *>(s_bias + col0 + 16 * t + 4 * kq);
         }
     }
     if (a.stamps) tk[2] = __builtin_amdgcn_s_memrealtime();
