@@ -755,6 +755,13 @@ typedef struct phc_mlp_norm_fwd_desc {
     float momentum_o, eps_o;
     const float *skip;
     float *save_stat_o, *x_out;
+    /* softmax_beta != NULL (with codes): the layer's SOFTMAX aggregation instead of the sum (PHMGINEConvSoftmax.aggregate,
+     * messagepassing.py:211-214, 297-300: out = sum_e softmax_e(beta m_e) m_e per destination and column) — what
+     * phc_aggregate_softmax_enc_fwd / phc_aggregate_softmax_norm_enc_fwd compute in a launch of their own, same online softmax in the
+     * same edge order: agg_out [N, h] (the plain aggregate) and lse [N, h] (max + log(sum + 1e-12)) are written for
+     * phc_aggregate_softmax_enc_bwd, s_out = agg_out (+ x when add_self) feeds the first GEMM; bit-identical for in-degrees <= 16. */
+    const float *softmax_beta;     /* device scalar */
+    float *agg_out, *lse;
 } phc_mlp_norm_fwd_desc;
 int phc_mlp_norm_fwd_fused_supported(int64_t N, int h);
 int phc_mlp_norm_fwd_fused_agg_supported(int64_t N, int h, int n, int F, int vocab_rows);

@@ -12,6 +12,16 @@ from phc_gnn_amd import ops as _engine
 from phc.quaternion.activations import get_module_activation
 
 
+def _any_local_hooks(*roots) -> bool:
+    """A forward (pre-)hook registered on one of these modules or their sub-modules (global hooks do not count: they would take
+    every model off its fused head)."""
+    for root in roots:
+        for sub in root.modules():
+            if sub._forward_hooks or sub._forward_pre_hooks:
+                return True
+    return False
+
+
 class PHMDownstreamNet(nn.Module):
     def __init__(self, in_features: int, phm_dim: int, phm_rule, hidden_layers: list, out_features: int,
                  activation: str, bias: bool, norm: str, w_init: str, c_init: str, dropout: Union[float, list],
@@ -58,7 +68,9 @@ class PHMDownstreamNet(nn.Module):
     def forward(self, x: torch.Tensor, verbose=False, n_valid=None, **kwargs) -> torch.Tensor:
         last = len(self.affine) - 1
         engine = self.norm_flag and self.training and x.is_cuda and x.dim() == 2
-        if engine and last == 2 and self.real_trafo_type == "linear" and all(hasattr(nm.bn, "bn") for nm in self.norm) and not verbose:
+        # (forward hooks on the head's layers: the one-launch head never calls them — the per-layer sequence below does)
+        if engine and last == 2 and self.real_trafo_type == "linear" and all(hasattr(nm.bn, "bn") for nm in self.norm) and not verbose \
+                and not _any_local_hooks(self.affine, self.real_trafo):
             # the whole head (three PHM layers, two norms, the dense map to the targets) in ONE engine launch each way; with
             # dropout (:104-107) the masks of the stand-alone fused passes (sites 64 + i) are drawn inside it
             y = _engine.downstream_head(x, n_valid, list(self.affine), [nm.bn for nm in self.norm], self.real_trafo.affine,

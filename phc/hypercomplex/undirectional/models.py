@@ -192,7 +192,7 @@ class PHMSkipConnectAdd(nn.Module):
             if edge_encoder is not None:
                 # lazy: the aggregate goes straight into the fused node below, whose first GEMM may build the rows itself
                 # (engine: PendingAggregate; mlp_norm_fused launches the aggregation on its own when it does not apply)
-                lazy = type(tr).__name__ == "PHMGINEConv"
+                lazy = type(tr).__name__ in ("PHMGINEConv", "PHMGINEConvSoftmax")
                 # the aggregation is x[0]'s ONLY autograd consumer (the skip's share travels through a hand-off, or the skip is another
                 # tensor): its dx may be built inside the backward launch of the fused node that produced x[0] (engine: DxLink)
                 single = (handoff is not None and agg_handoff is handoff and x[0] is x[1]) or \

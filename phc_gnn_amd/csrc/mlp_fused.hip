@@ -555,6 +555,12 @@ struct MlpFwdArgs {
     int act_o;
     const float *skip;                           // [N, 128] or NULL
     float *stat_o, *x_out;                       // [6 x 128], [N, 128] out
+    // ---- AGG == 2: the SOFTMAX aggregation instead of the sum (messagepassing.py:211-214, 297-300; softmax_agg.hip's walk): per
+    // destination and column  out = sum_e softmax_e(beta m_e) m_e,  m_e = x[src_e] + (t0 + t1 + ...) — the online softmax of
+    // softmax_agg_norm_fwd_kernel in its edge order, the table rows added in ITS association: out, lse and s = out (+ x) are
+    // bit-identical to that launch's for in-degrees <= 16 ----
+    const float *beta;                           // device scalar
+    float *agg_out, *lse;                        // [N, 128] out: the plain aggregate and max + log(sum + eps) (the backward walk reads them)
 };
 constexpr int MF_AGG_MAX_R = 32;                 // bond-table rows staged in LDS
 
@@ -609,7 +615,7 @@ __device__ __forceinline__ void mf_column_stats(const f32x4_t (&v)[MAXS][2], int
     stat_acc_add(acc, MF_H, rep, lane & 1, col0 + (lane >> 1), mine);
 }
 
-template <int MAXS, bool AGG>
+template <int MAXS, int AGG>                     // AGG: 0 rows of s from memory, 1 sum aggregation, 2 softmax aggregation
 __global__ __launch_bounds__(MF_THREADS, 2) void mlp_fwd_fused_kernel(MlpFwdArgs a) {
     extern __shared__ __attribute__((aligned(16))) float sm[];
     float *tS = sm;                                          // [MAXS] tiles: s, then a
@@ -639,7 +645,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mlp_fwd_fused_kernel(MlpFwdArgs
     f32x4_t ld[MAXS][2];
     BnFromTotals bt_o = {};
     float ow = 1.f, ob = 0.f;
-    if constexpr (!AGG) {
+    if constexpr (AGG == 0) {
 #pragma unroll
         for (int s = 0; s < MAXS; ++s)
 #pragma unroll
@@ -769,6 +775,17 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mlp_fwd_fused_kernel(MlpFwdArgs
                 return o;
             }
         };
+        // softmax_agg.hip's sm_enc_rows: the edge's table rows summed FIRST (t0 + t1 + ...), then added to the row
+        auto table_sum = [&](unsigned cd) __attribute__((always_inline)) {
+            f32x4_t t = *reinterpret_cast<const f32x4_t *>(tbl + (cd & 255u) * MF_H + 4 * c4);
+#pragma unroll
+            for (int f = 1; f < 4; ++f)
+                if (f < a.F) t += *reinterpret_cast<const f32x4_t *>(tbl + ((cd >> (8 * f)) & 255u) * MF_H + 4 * c4);
+            return t;
+        };
+        const float beta = AGG == 2 ? *a.beta : 0.f;
+        float *keep2 = reinterpret_cast<float *>(reinterpret_cast<double *>(ss + 2 * MF_H));   // AGG == 2: [2][16 MAXS][MF_LD] over the statistics' scratch
+        static_assert((size_t)2 * 16 * MAXS * MF_LD * sizeof(float) <= sizeof(double) * (size_t)MF_WAVES * 16 * 66, "aggregate + lse rows fit the scratch");
         auto add_tables = [&](f32x4_t &v, unsigned cd) __attribute__((always_inline)) {
 #pragma unroll
             for (int f = 0; f < 4; ++f)
@@ -802,25 +819,57 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mlp_fwd_fused_kernel(MlpFwdArgs
             for (int u = 0; u < 2; ++u) {
                 const int j = 2 * sI + u;
                 const f32x4_t selfv = xrow(kind_c, dj[j] >= 0 ? dj[j] : 0, ys[u], ks[u]);
-                f32x4_t v[4];
+                f32x4_t a4;
+                if constexpr (AGG == 2) {
+                    // the online softmax of softmax_agg_norm_fwd_kernel: edges in order, one (max, sum, weighted sum) per column
+                    float mx[4] = {-INFINITY, -INFINITY, -INFINITY, -INFINITY}, sN[4] = {0.f, 0.f, 0.f, 0.f}, wN[4] = {0.f, 0.f, 0.f, 0.f};
+                    auto update = [&](const f32x4_t xv, unsigned cd) __attribute__((always_inline)) {
+                        const f32x4_t m = xv + table_sum(cd);
 #pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    v[i] = xrow(kind_c, src[j][i], ye[u][i], ke[u][i]);
-                    add_tables(v[i], code[j][i]);
+                        for (int q = 0; q < 4; ++q) sm_update(mx[q], sN[q], wN[q], m[q], beta);
+                    };
+#pragma unroll
+                    for (int i = 0; i < 4; ++i)
+                        if (deg[j] > i) update(xrow(kind_c, src[j][i], ye[u][i], ke[u][i]), code[j][i]);
+                    for (int e = eb[j] + 4; e < eb[j] + deg[j]; ++e) {   // more than four in-edges: one at a time (rare on molecules)
+                        const int sJ = a.col[e];
+                        update(xrow(kind_c, sJ, *reinterpret_cast<const f32x4_t *>(a.x + (size_t)sJ * MF_H + 4 * c4),
+                                    *reinterpret_cast<const f32x4_t *>(skp + (size_t)sJ * MF_H + 4 * c4)), a.codes[e]);
+                    }
+                    f32x4_t o, l;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const float z = sN[q] + SM_EPS;
+                        o[q] = deg[j] > 0 ? wN[q] / z : 0.f;
+                        l[q] = deg[j] > 0 ? mx[q] + __logf(z) : 0.f;
+                    }
+                    // (the aggregate and its log-sum-exp wait in LDS — the statistics' scratch, idle until the first GEMM is through — for
+                    // the stores behind the gather: in registers they were 32 more across the second step's loads)
+                    const int Lr = 16 * sI + rg + 8 * u;
+                    *reinterpret_cast<f32x4_t *>(keep2 + Lr * MF_LD + 4 * c4) = o;
+                    *reinterpret_cast<f32x4_t *>(keep2 + (16 * MAXS + Lr) * MF_LD + 4 * c4) = l;
+                    a4 = o;
+                } else {
+                    f32x4_t v[4];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        v[i] = xrow(kind_c, src[j][i], ye[u][i], ke[u][i]);
+                        add_tables(v[i], code[j][i]);
+                    }
+                    f32x4_t acc0 = deg[j] > 0 ? v[0] : zero;
+                    const f32x4_t acc1 = deg[j] > 1 ? v[1] : zero;
+                    if (deg[j] > 2) acc0 += v[2];
+                    if (deg[j] > 3) acc0 += v[3];
+                    for (int e = eb[j] + 4; e < eb[j] + deg[j]; ++e) {   // a row with more than four in-edges: one at a time (rare on molecules)
+                        const int sJ = a.col[e];
+                        const unsigned cd = a.codes[e];
+                        f32x4_t vv = xrow(kind_c, sJ, *reinterpret_cast<const f32x4_t *>(a.x + (size_t)sJ * MF_H + 4 * c4),
+                                          *reinterpret_cast<const f32x4_t *>(skp + (size_t)sJ * MF_H + 4 * c4));
+                        add_tables(vv, cd);
+                        acc0 += vv;
+                    }
+                    a4 = acc0 + acc1;
                 }
-                f32x4_t acc0 = deg[j] > 0 ? v[0] : zero;
-                const f32x4_t acc1 = deg[j] > 1 ? v[1] : zero;
-                if (deg[j] > 2) acc0 += v[2];
-                if (deg[j] > 3) acc0 += v[3];
-                for (int e = eb[j] + 4; e < eb[j] + deg[j]; ++e) {   // a row with more than four in-edges: one at a time (rare on molecules)
-                    const int sJ = a.col[e];
-                    const unsigned cd = a.codes[e];
-                    f32x4_t vv = xrow(kind_c, sJ, *reinterpret_cast<const f32x4_t *>(a.x + (size_t)sJ * MF_H + 4 * c4),
-                                      *reinterpret_cast<const f32x4_t *>(skp + (size_t)sJ * MF_H + 4 * c4));
-                    add_tables(vv, cd);
-                    acc0 += vv;
-                }
-                f32x4_t a4 = acc0 + acc1;
                 if (a.add_self) a4 += selfv;
                 if (dj[j] < 0) a4 = zero;
                 ld[sI][u] = a4;
@@ -843,6 +892,12 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mlp_fwd_fused_kernel(MlpFwdArgs
             if (dj[j] >= 0) {
                 if (normed) *reinterpret_cast<f32x4_t *>(a.x_out + (size_t)dj[j] * MF_H + 4 * c4) = self_keep[j];   // x itself, once
                 *reinterpret_cast<f32x4_t *>(a.s_out + (size_t)dj[j] * MF_H + 4 * c4) = ld[j >> 1][j & 1];
+                if constexpr (AGG == 2) {
+                    const int Lr = 16 * (j >> 1) + rg + 8 * (j & 1);
+                    *reinterpret_cast<f32x4_t *>(a.agg_out + (size_t)dj[j] * MF_H + 4 * c4) = *reinterpret_cast<const f32x4_t *>(keep2 + Lr * MF_LD + 4 * c4);
+                    *reinterpret_cast<f32x4_t *>(a.lse + (size_t)dj[j] * MF_H + 4 * c4) =
+                        *reinterpret_cast<const f32x4_t *>(keep2 + (16 * MAXS + Lr) * MF_LD + 4 * c4);
+                }
             }
         MF_STAMP(11);
     }
@@ -963,7 +1018,7 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mlp_fwd_fused_kernel(MlpFwdArgs
         if (a.p.has_nbt && tid < a.p.n_comp)
             for (int q = 0; q < a.p.n_comp; ++q)
                 if (q == tid) *a.p.num_batches_tracked[q] += 1;
-        if constexpr (AGG) {
+        if constexpr (AGG != 0) {
             if (a.nacc) {                                    // ... and the pending norm of the layer in front
                 if (tid < MF_H) {
                     float *st = a.stat_o;
@@ -1035,9 +1090,12 @@ static int mf_capacity_of(K kernel, int *cache, size_t lds, const char *switch_e
     return cache[dev] > 0 ? cache[dev] : 0;
 }
 static int mf_fwd_capacity(bool agg) {
-    static int cap[2][64];
-    return agg ? mf_capacity_of(&mlp_fwd_fused_kernel<MF_MAXS, true>, cap[1], mf_fwd_lds_bytes(true), "PHC_MLP_FWD_FUSED")
-               : mf_capacity_of(&mlp_fwd_fused_kernel<MF_MAXS, false>, cap[0], mf_fwd_lds_bytes(false), "PHC_MLP_FWD_FUSED");
+    static int cap[3][64];
+    if (!agg) return mf_capacity_of(&mlp_fwd_fused_kernel<MF_MAXS, 0>, cap[0], mf_fwd_lds_bytes(false), "PHC_MLP_FWD_FUSED");
+    // (the sum and the softmax form: the smaller of the two answers serves both)
+    const int c1 = mf_capacity_of(&mlp_fwd_fused_kernel<MF_MAXS, 1>, cap[1], mf_fwd_lds_bytes(true), "PHC_MLP_FWD_FUSED");
+    const int c2 = mf_capacity_of(&mlp_fwd_fused_kernel<MF_MAXS, 2>, cap[2], mf_fwd_lds_bytes(true), "PHC_MLP_FWD_FUSED");
+    return c1 < c2 ? c1 : c2;
 }
 
 extern "C" {
@@ -1187,10 +1245,17 @@ int phc_mlp_norm_fwd_fused(const phc_mlp_norm_fwd_desc *d, void *stream) {
     const long long groups = mf_fwd_groups(d->N);
     hipStream_t s = (hipStream_t)stream;
     ProfScope prof(agg ? K_PHM_GEMM_AG : K_PHM_GEMM_FWD, s);
-    if (agg)
-        PHC_LAUNCH((mlp_fwd_fused_kernel<MF_MAXS, true>), dim3((unsigned)groups), dim3(MF_THREADS), mf_fwd_lds_bytes(true), s, a);
-    else
-        PHC_LAUNCH((mlp_fwd_fused_kernel<MF_MAXS, false>), dim3((unsigned)groups), dim3(MF_THREADS), mf_fwd_lds_bytes(false), s, a);
+    if (agg && d->softmax_beta) {
+        PHC_REQUIRE(d->agg_out && d->lse && ((reinterpret_cast<uintptr_t>(d->agg_out) | reinterpret_cast<uintptr_t>(d->lse)) & 15) == 0,
+                    PHC_ERR_INVALID_ARG, "phc_mlp_norm_fwd_fused: the softmax aggregation needs agg_out and lse (16-byte aligned)");
+        a.beta = d->softmax_beta; a.agg_out = d->agg_out; a.lse = d->lse;
+        PHC_LAUNCH((mlp_fwd_fused_kernel<MF_MAXS, 2>), dim3((unsigned)groups), dim3(MF_THREADS), mf_fwd_lds_bytes(true), s, a);
+    } else if (agg) {
+        PHC_LAUNCH((mlp_fwd_fused_kernel<MF_MAXS, 1>), dim3((unsigned)groups), dim3(MF_THREADS), mf_fwd_lds_bytes(true), s, a);
+    } else {
+        PHC_REQUIRE(!d->softmax_beta, PHC_ERR_INVALID_ARG, "phc_mlp_norm_fwd_fused: softmax_beta without an aggregation (codes)");
+        PHC_LAUNCH((mlp_fwd_fused_kernel<MF_MAXS, 0>), dim3((unsigned)groups), dim3(MF_THREADS), mf_fwd_lds_bytes(false), s, a);
+    }
     return check_launch("mlp_norm_fwd_fused");
 }
 

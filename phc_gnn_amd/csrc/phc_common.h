@@ -258,6 +258,22 @@ __device__ __forceinline__ T *bn_col_ptr(T *const (&tbl)[BN_MAX_COMP], int flat,
     return flat ? tbl[0] + col : bn_pick(tbl, comp) + kk;
 }
 
+// ---- online softmax of the softmax neighbour aggregation (softmax_agg.hip; mlp_fused.hip's aggregating forward) ----
+// torch-scatter 2.0.5's scatter_softmax: max-shifted, eps = 1e-12 added to the segment sum (messagepassing.py:211-214, 297-300).
+// One column's running (max, sum, weighted sum) takes the next message m of its segment, in edge order.
+constexpr float SM_EPS = 1e-12f;
+__device__ __forceinline__ void sm_update(float &mx, float &s, float &w, float m, float beta) {
+    // Both cases of the recurrence — a new maximum (rescale the sums by r = exp(mx - sc), add 1 | m) and an ordinary message (add
+    // p = exp(sc - mx) | p m) — take ONE exponential, of -|sc - mx| (mx = -inf on the first edge: 0).  Written without a branch: the
+    // lanes of a wavefront disagree about the case, and as two branches each lane paid both exponentials.
+    const float sc = beta * m;
+    const bool gt = sc > mx;
+    const float e = __expf(-fabsf(sc - mx));
+    s = gt ? fmaf(s, e, 1.f) : s + e;
+    w = gt ? fmaf(w, e, m) : fmaf(e, m, w);
+    mx = gt ? sc : mx;
+}
+
 // Norm constants from a column's accumulator totals (S = sum x, Q = sum x^2 over `count` rows; norm.py:30-35 forward, training mode).
 // ONE definition for every kernel that derives them in its prologue (bn_apply_acc_kernel, the normalising-operand GEMMs, the
 // aggregations that apply a pending norm): several tests and the step's A/B switches rely on those kernels producing the SAME bits,

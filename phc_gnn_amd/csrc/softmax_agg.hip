@@ -15,7 +15,7 @@
 namespace phc {
 
 constexpr int SM_THREADS = 256;
-constexpr float SM_EPS = 1e-12f;
+// (SM_EPS, sm_update: phc_common.h — the aggregating one-launch MLP forward of mlp_fused.hip runs the same online softmax)
 
 // Bond embedding read in place (SURVEY §8f N1 on the softmax operators): instead of an [E, h] edge tensor the kernels
 // take the packed table rows of every edge (phc_pack_edge_codes: byte f = off_f + value) and the n*F table pointers,
@@ -58,20 +58,6 @@ __device__ __forceinline__ void sm_table_ptrs(const SmEnc &enc, int c4, const fl
 struct Sm4 {            // online softmax state for 4 columns
     float4 mx, s, w;
 };
-
-__device__ __forceinline__ void sm_update(float &mx, float &s, float &w, float m, float beta) {
-    const float sc = beta * m;
-    if (sc > mx) {
-        const float r = __expf(mx - sc);      // mx = -inf on the first edge: r = 0
-        s = s * r + 1.f;
-        w = w * r + m;
-        mx = sc;
-    } else {
-        const float p = __expf(sc - mx);
-        s += p;
-        w = fmaf(p, m, w);
-    }
-}
 
 __device__ __forceinline__ void sm_merge(float &mx, float &s, float &w, float mx2, float s2, float w2) {
     const float M = fmaxf(mx, mx2);

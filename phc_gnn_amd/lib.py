@@ -84,7 +84,8 @@ class MlpNormFwdDesc(C.Structure):
                 ("x", _P), ("codes", _P), ("tables", _P), ("vocab", _P), ("rowptr", _P), ("col", _P), ("ell", _P), ("tables_host", _P), ("F", C.c_int32), ("n", C.c_int32),
                 ("add_self", C.c_int32), ("s_out", _P), ("norm_acc", _P), ("weight_o", _P), ("bias_o", _P), ("running_mean_o", _P),
                 ("running_var_o", _P), ("num_batches_tracked_o", _P), ("n_comp_o", C.c_int32), ("norm_act", C.c_int32),
-                ("momentum_o", C.c_float), ("eps_o", C.c_float), ("skip", _P), ("save_stat_o", _P), ("x_out", _P)]
+                ("momentum_o", C.c_float), ("eps_o", C.c_float), ("skip", _P), ("save_stat_o", _P), ("x_out", _P),
+                ("softmax_beta", _P), ("agg_out", _P), ("lse", _P)]
 
 
 class HeadStage(C.Structure):

@@ -1658,7 +1658,7 @@ class _AggregateSoftmaxEncFn(torch.autograd.Function):
     """Softmax aggregation with the bond encoder read in place (packed codes + tables, no [E, h] forward tensor)."""
 
     @staticmethod
-    def forward(ctx, x, bond_idx, beta, st: EdgeStructure, act: int, add_self: bool, ts: "TableSet", pending, *tables):
+    def forward(ctx, x, bond_idx, beta, st: EdgeStructure, act: int, add_self: bool, ts: "TableSet", pending, lazy_box, *tables):
         lib = L.load()
         dev = L.require_device(x, bond_idx, beta)
         # `pending`: x = act(norm(y)) (+ skip) has not been evaluated yet (PendingNorm): the walk does it on the fly for every row it
@@ -1683,7 +1683,17 @@ class _AggregateSoftmaxEncFn(torch.autograd.Function):
         out = torch.empty((st.num_dst, h), dtype=torch.float32, device=dev)
         lse = torch.empty((st.num_dst, h), dtype=torch.float32, device=dev)
         out_self = torch.empty_like(out) if add_self else None
-        if fuse_norm:
+        # `lazy_box` (a dict): the caller feeds this aggregate straight into the fused MLP + norm node — at hidden 128 nothing is
+        # launched here: that node's one-launch forward walks the rows itself (mlp_fused.hip, AGG = 2) and writes out / lse /
+        # out_self on the way; anybody else who reads them first calls PendingSoftmaxAggregate.materialize (the launch below)
+        lazy = lazy_box is not None and MLP_FWD_FUSED and MLP_FWD_FUSED_AGG and SOFTMAX_INTO_MLP and act == 0 and h == 128 and \
+            st.num_edges > 0 and x_.shape[0] == st.num_src == st.num_dst and x_.data_ptr() == x.data_ptr() and x_.data_ptr() % 16 == 0 and \
+            getattr(st, "_ell", None) is not None and len(ts.key) <= 16 and (pending is None or pending.done or fuse_norm) and \
+            _supported("phc_mlp_norm_fwd_fused_agg_supported", st.num_dst, h, ts.n, ts.F, ts.R)
+        if lazy:
+            lazy_box["pa"] = PendingSoftmaxAggregate(x_, codes, ts, st, bool(add_self), out_self if add_self else out,
+                                                     pending if fuse_norm else None, beta_, out, lse, act)
+        elif fuse_norm:
             pn = pending
             assert x_.data_ptr() == pn.out.data_ptr()
             w, bb, rm, rv, nbt, no = pn._norm_args()
@@ -1697,7 +1707,7 @@ class _AggregateSoftmaxEncFn(torch.autograd.Function):
             L.check(lib.phc_aggregate_softmax_enc_fwd(L.ptr(x_), L.ptr(codes), L.ptr(ts.ptrs), ts.vocab_c, ts.F, ts.n, ts.k,
                                                       L.ptr(rowptr), L.ptr(col), L.ptr(beta_), st.num_dst, act, L.ptr(out),
                                                       L.ptr(out_self), L.ptr(lse), L.stream_ptr(dev)), "phc_aggregate_softmax_enc_fwd")
-        if L.PROF_ON:
+        if L.PROF_ON and not lazy:
             E, N = st.num_edges, st.num_dst
             L.account("aggregate_softmax_fwd", 8.0 * E * h, E * (4.0 * h + 12) + N * 8.0 * h)
         ctx.st, ctx.act, ctx.add_self, ctx.ts = st, act, bool(add_self), ts
@@ -1718,7 +1728,7 @@ class _AggregateSoftmaxEncFn(torch.autograd.Function):
         h = dout_.shape[1]
         rowptr_t, col_t, perm_t = st.csc
         codes_o = st.packed_codes_src(bond_, ts.vocab_c, ts.F)
-        need_t = any(ctx.needs_input_grad[8:])
+        need_t = any(ctx.needs_input_grad[9:])
         dx = torch.empty((st.num_src, h), dtype=torch.float32, device=dev)
         dea = torch.empty((st.num_edges, h), dtype=torch.float32, device=dev) if need_t else None
         nparts = lib.phc_softmax_bwd_num_partials(st.num_src)
@@ -1741,7 +1751,7 @@ class _AggregateSoftmaxEncFn(torch.autograd.Function):
         tgrads = [None] * ts.num_tables
         if need_t:
             if ctx.defer_tables is not None and _DEFER.active and not torch.is_grad_enabled():
-                params = [t if ng else None for t, ng in zip(ctx.defer_tables, ctx.needs_input_grad[8:])]
+                params = [t if ng else None for t, ng in zip(ctx.defer_tables, ctx.needs_input_grad[9:])]
                 with _DEFER.lock:                            # d enc = dea: an encoder job over the edge rows
                     _DEFER.atom_jobs.append(dict(dout=dea, idx=bond_, ts=ts, params=params))
             else:
@@ -1751,20 +1761,24 @@ class _AggregateSoftmaxEncFn(torch.autograd.Function):
                 L.check(lib.phc_encode_bwd(L.ptr(dea), L.ptr(bond_), st.num_edges, ts.F, ts.vocab_c, ts.n, ts.k, L.ptr(flat),
                                            L.ptr(ws), ws_bytes, L.stream_ptr(dev)), "phc_encode_bwd")
                 tgrads = list(ts.grad_views(flat))
-        return ((dx if ctx.needs_input_grad[0] else None), None, dbeta, None, None, None, None, None, *tgrads)
+        return ((dx if ctx.needs_input_grad[0] else None), None, dbeta, None, None, None, None, None, None, *tgrads)
 
 
 def aggregate_softmax_encoded(x: torch.Tensor, edge_index, bond_idx: torch.Tensor, ts: "TableSet", tables, beta: torch.Tensor,
                               msg_encoder: str = "identity", add_self: bool = False, num_dst: Optional[int] = None,
-                              pending=None) -> torch.Tensor:
+                              pending=None, lazy: bool = False) -> torch.Tensor:
     """aggregate_softmax with ``edge_attr = bond encoder(bond_idx)`` evaluated inside the kernels (needs
     ``ts.fusable_into_aggregate`` and F <= 4, sum(vocab) <= 256: the packed-code limits)."""
     st = edge_index if isinstance(edge_index, EdgeStructure) else edge_structure(edge_index, x.shape[0], num_dst)
     ts = ts.vector_form(tables)
     bond_idx = _idx64(bond_idx)
     st.prepare(for_backward=torch.is_grad_enabled() and x.requires_grad, codes_for=(bond_idx, ts.vocab_c, ts.F))
-    return _AggregateSoftmaxEncFn.apply(x, bond_idx, beta, st, _act_id(msg_encoder), add_self, ts, pending,
-                                        *[t for comp in tables for t in comp])
+    box = {} if (lazy and torch.is_grad_enabled()) else None
+    res = _AggregateSoftmaxEncFn.apply(x, bond_idx, beta, st, _act_id(msg_encoder), add_self, ts, pending, box,
+                                       *[t for comp in tables for t in comp])
+    if box and box.get("pa") is not None:
+        res._phc_pending_agg = box["pa"]
+    return res
 
 
 # ---------------------------------------------------------------------------
@@ -3114,6 +3128,54 @@ class PendingAggregate:
         return True
 
 
+# the softmax aggregation's walk inside the one-launch MLP forward at hidden 128 (mlp_fused.hip AGG = 2); 0 = its own launch
+SOFTMAX_INTO_MLP = __import__("os").environ.get("PHC_SOFTMAX_INTO_MLP", "1") != "0"
+
+
+class PendingSoftmaxAggregate(PendingAggregate):
+    """The SOFTMAX aggregation of a layer input that has NOT been launched (messagepassing.py:211-214, 297-300): ``agg`` (the plain
+    aggregate), ``lse`` and ``out`` (= agg, + x with the layer's self loop) are allocated — the backward walk reads the first two —,
+    the fused MLP + norm node's one-launch forward walks the rows itself and writes all three on the way.  ``materialize`` is the launch
+    that would have run in the aggregation's forward: identical rows."""
+    softmax = True
+
+    def __init__(self, x_, codes, ts, st, add_self, out, pending, beta, agg, lse, act):
+        super().__init__(x_, codes, ts, st, add_self, out, pending)
+        self.beta, self.agg, self.lse, self.act = beta, agg, lse, act
+
+    def _account(self):
+        if L.PROF_ON:
+            E, N, h = self.st.num_edges, self.st.num_dst, self.out.shape[1]
+            L.account("aggregate_softmax_fwd", 8.0 * E * h, E * (4.0 * h + 12) + N * 8.0 * h)
+
+    def materialize(self):
+        if self.done:
+            return
+        lib = L.load()
+        rowptr, col, _ = self.st.csr
+        ts, st = self.ts, self.st
+        out_self = self.out if self.add_self else None
+        dev = self.out.device
+        pn = self.pending if (self.pending is not None and not self.pending.done) else None
+        if pn is not None:
+            w, bb, rm, rv, nbt, no = pn._norm_args()
+            L.check(lib.phc_aggregate_softmax_norm_enc_fwd(
+                L.ptr(pn.y2), L.ptr(pn.acc2), w, bb, rm, rv, nbt, no, float(pn.outer["momentum"]), float(pn.outer["eps"]), pn.act_o,
+                L.ptr(pn.n_valid), L.ptr(pn.skip), L.ptr(pn.save_o), L.ptr(pn.out), L.ptr(self.codes), L.ptr(ts.ptrs), ts.vocab_c, ts.F, ts.n,
+                ts.k, L.ptr(rowptr), L.ptr(col), L.ptr(self.beta), st.num_dst, L.ptr(self.agg), L.ptr(out_self), L.ptr(self.lse),
+                L.stream_ptr(dev)), "phc_aggregate_softmax_norm_enc_fwd")
+            pn.done = True
+        else:
+            L.check(lib.phc_aggregate_softmax_enc_fwd(L.ptr(self.x_), L.ptr(self.codes), L.ptr(ts.ptrs), ts.vocab_c, ts.F, ts.n, ts.k,
+                                                      L.ptr(rowptr), L.ptr(col), L.ptr(self.beta), st.num_dst, self.act, L.ptr(self.agg),
+                                                      L.ptr(out_self), L.ptr(self.lse), L.stream_ptr(dev)), "phc_aggregate_softmax_enc_fwd")
+        self._account()
+        self.done = True
+
+    def run_with_gemm(self, Mk4, b, y, n_valid, acc) -> bool:
+        return False                                          # (the aggregation-inside-the-GEMM launches are the sum's)
+
+
 def materialize_pending_aggregate(t: torch.Tensor) -> torch.Tensor:
     """Launch the parked aggregation of ``t`` (if it has one) before a consumer other than the fused MLP + norm node reads it."""
     pa = getattr(t, "_phc_pending_agg", None)
@@ -3250,6 +3312,8 @@ class _MLPNormFn(torch.autograd.Function):
                 fd.codes, fd.tables, fd.vocab = L.ptr(pa.codes), L.ptr(ts_.ptrs), _C.cast(ts_.vocab_c, _C.c_void_p)
                 fd.rowptr, fd.col, fd.F, fd.n, fd.add_self, fd.s_out = L.ptr(rowptr_), L.ptr(col_), ts_.F, ts_.n, 1 if pa.add_self else 0, L.ptr(pa.out)
                 fd.ell = L.ptr(pa.st._ell)
+                if getattr(pa, "softmax", False):             # the softmax walk instead of the sum (PendingSoftmaxAggregate)
+                    fd.softmax_beta, fd.agg_out, fd.lse = L.ptr(pa.beta), L.ptr(pa.agg), L.ptr(pa.lse)
                 tabs_host = (_C.c_void_p * len(ts_.key))(*ts_.key)          # the table pointers by value (no pointer hop in the kernel)
                 fd.tables_host = _C.cast(tabs_host, _C.c_void_p)
                 pn = pa.pending if (pa.pending is not None and not pa.pending.done) else None

@@ -103,7 +103,7 @@ def test_repeated_steps_are_bit_equal_under_allocator_pollution(workload, mode):
 TOGGLES = ["none", "GEMM_AGGREGATE", "READOUT_FUSED", "NORM_INTO_AGGREGATE", "MLP_NORM_FUSED", "SKIP_SUM_HANDOFF", "ENCODE_FRONT",
            "STEP_TAIL_MERGED", "GATE_COMPOSED", "TAIL_EXTRAS", "TAIL_WIDE", "TABLE_GRADS_COUNTED", "STAT_ACC", "FLAT_TABLES",
            "BN_BWD_SUMS_IN_GEMM", "DOWNSTREAM_FUSED", "STATS_WITH_RESIDUAL", "RESIDUAL_HANDOFF", "HEAD_CHAIN", "HEAD_DROPOUT", "POOL_BWD_GATE",
-           "MLP_BWD_FUSED", "MLP_FWD_FUSED", "MLP_FWD_FUSED_AGG", "HEAD_LOSS", "MLP_BWD_FUSED_AGG", "HEAD_FUSED_BWD"]
+           "MLP_BWD_FUSED", "MLP_FWD_FUSED", "MLP_FWD_FUSED_AGG", "HEAD_LOSS", "MLP_BWD_FUSED_AGG", "HEAD_FUSED_BWD", "SOFTMAX_INTO_MLP"]
 ORACLE_KW = {
     "molhiv_b32_swish": dict(phm_dim=4, num_layers=4, num_atom_feats=9, num_bond_feats=3, num_dn_hidden=2, mlp=True, sc_type="first",
                              act="swish"),

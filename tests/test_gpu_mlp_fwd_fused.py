@@ -70,6 +70,39 @@ def test_aggregation_inside_the_fused_forward_is_bit_identical_to_its_own_launch
         assert torch.equal(ga[k], gb_[k]), k
 
 
+@pytest.mark.parametrize("workload", ["molhiv_b32_softmax", "molhiv_b512_softmax", "molhiv_b32_softmax_swish"])
+@pytest.mark.parametrize("graph", [False, True])
+def test_softmax_aggregation_inside_the_fused_forward_is_bit_identical_to_its_own_launch(workload, graph, monkeypatch):
+    """The reference's default molhiv aggregation (messagepassing.py:211-214, 297-300) as the gather stage of the one-launch forward
+    (mlp_fused.hip AGG = 2): the same online softmax in the same edge order, the same table-row sums — the whole step equals the step
+    with phc_aggregate_softmax_norm_enc_fwd as its own launch bit for bit (loss, every gradient, the running statistics)."""
+    from phc_gnn_amd import harness, lib, ops
+    base = "molhiv_b512" if "b512" in workload else "molhiv_b32"
+    extra = dict(msg_aggr="softmax", **({"activation": "swish"} if workload.endswith("swish") else {}))
+    monkeypatch.setitem(harness.WORKLOADS, workload, dict(harness.WORKLOADS[base], **extra))
+    h = lib.load()
+    real = h.phc_mlp_norm_fwd_fused
+    seen = {"softmax": 0, "other": 0}
+
+    def wrapped(desc, stream):
+        d = desc._obj if hasattr(desc, "_obj") else desc.contents
+        seen["softmax" if d.softmax_beta else "other"] += 1
+        return real(desc, stream)
+    monkeypatch.setattr(h, "phc_mlp_norm_fwd_fused", wrapped)
+    monkeypatch.setattr(ops, "SOFTMAX_INTO_MLP", True)
+    la, ga, ba = _step(workload, True, monkeypatch, graph)
+    assert seen["softmax"] >= 4 and seen["other"] == 0, seen  # every layer's walk ran inside its MLP launch
+    seen["softmax"] = 0
+    monkeypatch.setattr(ops, "SOFTMAX_INTO_MLP", False)
+    lb, gb_, bb = _step(workload, True, monkeypatch, graph)
+    assert seen["softmax"] == 0 and seen["other"] >= 4, seen
+    assert la == lb
+    for k in bb:
+        assert torch.equal(ba[k], bb[k]), k
+    for k in gb_:
+        assert torch.equal(ga[k], gb_[k]), (k, float((ga[k] - gb_[k]).abs().max()))
+
+
 def test_fused_forward_op_level():
     """z1, y2, save_stat and the accumulator totals of y2 against the two launches on the same operands (z1, y2 bit for bit)."""
     from phc_gnn_amd import lib as L, ops

@@ -589,6 +589,26 @@ def test_forward_hooks_see_finished_activations(workload):
     assert torch.equal(again, fast)
 
 
+def test_forward_hook_on_a_head_layer_fires():
+    """the one-launch head never calls its layers — with a forward hook on one of them the head takes the per-layer
+    sequence (PHMLinear.__call__), the hook sees that layer's output, and the logits stay the fast path's."""
+    from phc_gnn_amd import harness
+    model = harness.build_model("molhiv_b32_swish", DEV, seed=5).train()
+    data = harness.to_device(harness.make_batch("molhiv_b32_swish", seed=2), DEV)
+    sd = {k: v.clone() for k, v in model.state_dict().items()}
+    fast = model(data).detach().clone()
+    model.load_state_dict(sd)
+    seen = []
+    hk = model.downstream.affine[1].register_forward_hook(lambda m, a, out: seen.append(out.detach().clone()))
+    try:
+        hooked = model(data).detach().clone()
+    finally:
+        hk.remove()
+    torch.cuda.synchronize()
+    assert len(seen) == 1 and torch.isfinite(seen[0]).all() and seen[0].shape[0] == fast.shape[0]
+    assert float((hooked - fast).abs().max()) <= 1e-5 * max(float(fast.abs().max()), 1e-30)
+
+
 @pytest.mark.parametrize("n,k", [(4, 32), (4, 50), (8, 32)])
 @pytest.mark.parametrize("N,E,hubs", [(1000, 2100, False), (333, 1500, True), (12874, 27650, False)])
 @pytest.mark.parametrize("F,act,with_skip,add_self", [(3, "relu", True, True), (1, "swish", False, True), (2, "relu", True, False)])
