@@ -87,8 +87,9 @@ class PHMDownstreamNet(nn.Module):
             nxt = self.affine[i + 1]
             nxt_stats = _engine.BNStatsRequest(n_valid) if (engine and i + 1 != last) else None
             no_dropout = not (self.training and self.dropout[i] > 0.0)
-            if engine and no_dropout:
-                # norm -> activation -> next layer inside the next GEMM's operand staging (no normalised tensor)
+            if engine and no_dropout and not _any_local_hooks(nxt):
+                # norm -> activation -> next layer inside the next GEMM's operand staging (no normalised tensor; never with a forward
+                # hook on that layer: the fused form does not call it)
                 y = self.norm[i].forward_fused_linear(x, self.activation_str, n_valid, nxt, nxt_stats)
                 if y is not None:
                     x = y
