@@ -62,14 +62,14 @@ MFMA_KERNELS = ("phm_gemm_fwd", "phm_gemm_dx", "phm_dH_partial", "table_grad", "
 # (a family = every instantiation the launch profiler books under one name; traffic = launch-weighted mean over them)
 PMC_NAMES = {"phm_gemm_fwd": ("gemm_hs16_kernel<128, 2, 4, 1, 4, 1>", "gemm_hs16_kernel<128, 2, 4, 1, 4, 3>",
                               "gemm_hs16_kernel<256, 2, 8, 1, 4, 1>", "gemm_hs16_kernel<256, 2, 8, 1, 4, 3>",
-                              "gemm_hs16_kernel<256, 2, 8, 1, 4, 0>", "gemm_hs16_kernel<128, 2, 4, 1, 4, 0>", "mlp_fwd_fused_kernel<2, false>"),
+                              "gemm_hs16_kernel<256, 2, 8, 1, 4, 0>", "gemm_hs16_kernel<128, 2, 4, 1, 4, 0>", "mlp_fwd_fused_kernel<2, 0>"),
              # (round 6, hidden 128: both dx GEMMs of a layer and both norm backwards are ONE launch, mlp_bwd_fused_kernel; its flops
              # are booked as the two GEMMs')
              "phm_gemm_dx": ("gemm_hs16_kernel<128, 2, 4, 1, 4, 8>", "gemm_hs16_kernel<128, 2, 4, 1, 4, 12>",
                              "gemm_hs16_kernel<256, 2, 8, 1, 4, 8>", "gemm_hs16_kernel<256, 2, 8, 1, 4, 12>", "mlp_bwd_fused_kernel"),
              # the layer's aggregation inside its first GEMM (molecule batches, round 4): GEMM flops only are booked
-             # (round 6, hidden 128: aggregation + both GEMMs + the inner norm in ONE launch, mlp_fwd_fused_kernel<2, true>)
-             "phm_gemm_ag_fwd": ("gemm_hs_ag_kernel", "gemm_hs_agw_kernel", "mlp_fwd_fused_kernel<2, true>"),
+             # (round 6, hidden 128: aggregation — <2, 1> sum, <2, 2> softmax — + both GEMMs + the inner norm in ONE launch)
+             "phm_gemm_ag_fwd": ("gemm_hs_ag_kernel", "gemm_hs_agw_kernel", "mlp_fwd_fused_kernel<2, 1>", "mlp_fwd_fused_kernel<2, 2>"),
              "phm_dH_partial": ("tail_partial_kernel",), "aggregate_enc_fwd": ("aggregate_encp_direct_fwd_kernel", "aggregate_norm_fwd_kernel"),
              "aggregate_enc_dx": ("aggregate_dx_rows_kernel",), "aggregate_fwd": ("aggregate_fwd_kernel",), "aggregate_bwd": ("aggregate_bwd_kernel",),
              "bn_apply": ("bn_apply_acc_kernel",), "bn_bwd_apply": ("bn_bwd_apply_acc_kernel",), "bn_bwd_partial": ("bn_bwd_partial_kernel",),
