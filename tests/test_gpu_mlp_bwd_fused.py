@@ -191,3 +191,60 @@ def test_aggregation_dx_rows_are_the_row_walkers(residual, add_self):
     for a, b in zip(outs + dwb, outs0 + dwb0):
         ref = float(b.abs().max())
         assert float((a - b).abs().max()) <= 2e-6 * max(ref, 1.0), float((a - b).abs().max())
+
+
+def test_parked_aggregation_dx_is_launched_when_the_consumer_cannot_fuse(monkeypatch):
+    """The safety net: the aggregation parked its dx (the link said the node below would build it), but at backward time that node's
+    one-launch form is not available — it must launch the stand-alone kernel itself (PendingDx.materialize), same results."""
+    from phc_gnn_amd import ops
+    la, ga = _step_agg("molhiv_b32", True, monkeypatch, False)[:2]
+    real = ops._supported
+    state = {"calls": 0, "materialized": 0}
+
+    def supported(name, *args):
+        if name == "phc_mlp_norm_bwd_fused_agg_supported":
+            state["calls"] += 1
+            return state["calls"] <= 4                       # the four forward-time queries (link.ready) say yes, the backward's say no
+        return real(name, *args)
+    real_mat = ops.PendingDx.materialize
+
+    def mat(self):
+        state["materialized"] += 1
+        return real_mat(self)
+    monkeypatch.setattr(ops, "_supported", supported)
+    monkeypatch.setattr(ops.PendingDx, "materialize", mat)
+    lb, gb_ = _step_agg("molhiv_b32", True, monkeypatch, False)[:2]
+    assert state["materialized"] == 3, state
+    assert la == lb
+    for k in gb_:
+        ref = float(gb_[k].abs().max())
+        if ref >= 1e-7:
+            assert float((ga[k] - gb_[k]).abs().max()) <= 1e-5 * ref, k
+
+
+def test_aggregation_dx_inside_the_backward_under_autograd_grad(monkeypatch):
+    """torch.autograd.grad (no AccumulateGrad nodes, no deferral): the link between the nodes works the same."""
+    from phc_gnn_amd import harness, ops
+    seen = _count_agg_launches(monkeypatch)
+
+    def run(agg):
+        monkeypatch.setattr(ops, "MLP_BWD_FUSED_AGG", agg)
+        model = harness.build_model("molhiv_b32_swish", DEV, seed=9).train()
+        data = harness.to_device(harness.make_batch("molhiv_b32_swish", seed=4), DEV)
+        params = [p for p in model.parameters() if p.requires_grad]
+        with ops.stat_accumulators(DEV), ops.prebuilt_H(ops.phm_pairs(model), ops.dense_weights(model), ops.gate_specs(model)):
+            loss = model(data).square().mean()
+            grads = torch.autograd.grad(loss, params, allow_unused=True)
+        torch.cuda.synchronize()
+        return float(loss.detach()), grads
+    la, ga = run(True)
+    assert seen["agg"] == 3, seen
+    lb, gb_ = run(False)
+    assert la == lb
+    for a, b in zip(ga, gb_):
+        if b is None:
+            assert a is None
+            continue
+        ref = float(b.abs().max())
+        if ref >= 1e-7:
+            assert float((a - b).abs().max()) <= 1e-5 * ref
