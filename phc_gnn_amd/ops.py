@@ -1690,26 +1690,15 @@ class _AggregateSoftmaxEncFn(torch.autograd.Function):
             st.num_edges > 0 and x_.shape[0] == st.num_src == st.num_dst and x_.data_ptr() == x.data_ptr() and x_.data_ptr() % 16 == 0 and \
             getattr(st, "_ell", None) is not None and len(ts.key) <= 16 and (pending is None or pending.done or fuse_norm) and \
             _supported("phc_mlp_norm_fwd_fused_agg_supported", st.num_dst, h, ts.n, ts.F, ts.R)
+        # (one description of the launch — PendingSoftmaxAggregate.materialize —, run now or left to the consumer)
+        pa = PendingSoftmaxAggregate(x_, codes, ts, st, bool(add_self), out_self if add_self else out, pending if fuse_norm else None,
+                                     beta_, out, lse, act)
+        if fuse_norm:
+            assert x_.data_ptr() == pending.out.data_ptr()
         if lazy:
-            lazy_box["pa"] = PendingSoftmaxAggregate(x_, codes, ts, st, bool(add_self), out_self if add_self else out,
-                                                     pending if fuse_norm else None, beta_, out, lse, act)
-        elif fuse_norm:
-            pn = pending
-            assert x_.data_ptr() == pn.out.data_ptr()
-            w, bb, rm, rv, nbt, no = pn._norm_args()
-            L.check(lib.phc_aggregate_softmax_norm_enc_fwd(
-                L.ptr(pn.y2), L.ptr(pn.acc2), w, bb, rm, rv, nbt, no, float(pn.outer["momentum"]), float(pn.outer["eps"]), pn.act_o,
-                L.ptr(pn.n_valid), L.ptr(pn.skip), L.ptr(pn.save_o), L.ptr(pn.out), L.ptr(codes), L.ptr(ts.ptrs), ts.vocab_c, ts.F, ts.n,
-                ts.k, L.ptr(rowptr), L.ptr(col), L.ptr(beta_), st.num_dst, L.ptr(out), L.ptr(out_self), L.ptr(lse), L.stream_ptr(dev)),
-                "phc_aggregate_softmax_norm_enc_fwd")
-            pn.done = True
+            lazy_box["pa"] = pa
         else:
-            L.check(lib.phc_aggregate_softmax_enc_fwd(L.ptr(x_), L.ptr(codes), L.ptr(ts.ptrs), ts.vocab_c, ts.F, ts.n, ts.k,
-                                                      L.ptr(rowptr), L.ptr(col), L.ptr(beta_), st.num_dst, act, L.ptr(out),
-                                                      L.ptr(out_self), L.ptr(lse), L.stream_ptr(dev)), "phc_aggregate_softmax_enc_fwd")
-        if L.PROF_ON and not lazy:
-            E, N = st.num_edges, st.num_dst
-            L.account("aggregate_softmax_fwd", 8.0 * E * h, E * (4.0 * h + 12) + N * 8.0 * h)
+            pa.materialize()
         ctx.st, ctx.act, ctx.add_self, ctx.ts = st, act, bool(add_self), ts
         ctx.beta_param = beta if (_DEFER.active and beta.is_leaf and beta.grad_fn is None and beta.requires_grad) else None
         ctx.defer_tables = tuple(tables) if (_DEFER.active and st.num_edges > 0 and
