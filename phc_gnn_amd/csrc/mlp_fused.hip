@@ -16,6 +16,9 @@
 //          da = dz_o . H2^T (v_mfma_f32_16x16x4_f32, operand in registers as in gemm_hs_device.h);
 //          g_i = da act_i'(x_hat_i w + b), x_hat_i;  column sums -> acc_i                                       | barrier 2
 //     P2   dz_i -> memory (linear1's dH job);  ds = dz_i . H1^T -> memory
+// AGGT (second half of round 6): `dout` itself is built in P0 — it is the dx of the sum aggregation of the layer ABOVE (autograd of
+// messagepassing.py:132-146, identity message function): row pointers + the row's first four out-edges in one round trip, the rows of
+// that layer's ds in the next, aggregate_dx_rows_kernel's own additions; the rows are written once (the skip's share reads them).
 // Rows >= *n_valid are padding rows of a fixed-shape batch: zero gradient everywhere, as in the separate launches.
 // All workgroups must be co-resident (they wait for each other): the host launches this form only when ceil(steps / MAXS)
 // workgroups fit the device's real capacity for the kernel, and the barrier's poll is bounded (PHC_ERR_RENDEZVOUS in the device
@@ -516,7 +519,9 @@ __global__ __launch_bounds__(MF_THREADS, 2) void mlp_bwd_fused_kernel(MlpBwdArgs
 // (gemm_hs16<.., ST> or the aggregation-carrying gemm_hs_ag_kernel, then gemm_hs16<.., XF | ST>: 21.6 + 16.4 us at molhiv_b512);
 // here one: the rows of z1 stay in the wavefronts' REGISTERS across the one grid-wide dependency (the norm's statistics over all
 // rows), only the accumulator crosses the barrier, and the activations `a` never reach memory.
-//     P0   rows of s -> LDS;  z1 = s . H1 + b1 -> memory (the backward reads it) and registers;  column sum | sum of squares of
+//     (AGG = 1 / 2: P0 builds the rows of s itself — the layer's sum / softmax aggregation over x or over the un-applied
+//      act(norm(y)) (+ skip) of the layer in front: MlpFwdArgs)
+//     P0   rows of s -> LDS;  z1 = s . H1 + b1 -> registers (memory behind the barrier: the backward reads it);  column sum | sum of squares of
 //          z1 over the valid rows (double, per wavefront: it owns its 32 columns for every row) -> acc1          | barrier
 //     P1   scale / shift from the totals (bn_from_totals: one definition for every kernel); workgroup 0 leaves save_stat and the
 //          running statistics behind;  a = act(z1 scale + shift) -> LDS (rows >= *n_valid: 0);  y2 = a . H2 + b2 -> memory;
