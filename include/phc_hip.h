@@ -570,6 +570,13 @@ int phc_csr_build_pair_codes_resident_ell(const int64_t *edge_src_i64, const int
                                           int32_t *perm_t, const int64_t *bond_i64, const int32_t *vocab, int F, uint32_t *codes,
                                           float *code_counts, int32_t *ell, int32_t *ell_t, void *ws_zeroed_once, size_t ws_bytes,
                                           void *stream);
+/* ... and the packed codes in SOURCE-sorted order too (codes_src [E] or NULL): what phc_pack_edge_codes(perm_t) computes in a launch of
+ * its own for phc_aggregate_softmax_enc_bwd's walk. */
+int phc_csr_build_pair_codes_resident_ell_src(const int64_t *edge_src_i64, const int64_t *edge_dst_i64, int64_t E, int64_t n_src,
+                                              int64_t n_dst, int32_t *rowptr, int32_t *col, int32_t *perm, int32_t *rowptr_t, int32_t *col_t,
+                                              int32_t *perm_t, const int64_t *bond_i64, const int32_t *vocab, int F, uint32_t *codes,
+                                              float *code_counts, int32_t *ell, int32_t *ell_t, uint32_t *codes_src, void *ws_zeroed_once,
+                                              size_t ws_bytes, void *stream);
 
 /* Per-batch preprocessing on the device: drop the nodes no edge touches and re-index,
  * i.e. the reference's CustomRemoveIsolatedNodes / PyG RemoveIsolatedNodes applied to every collated

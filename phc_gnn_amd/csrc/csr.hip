@@ -392,6 +392,7 @@ struct CsrPair {
     // out-edges of every source row, ell_t[row][0..3] = destination.  A reader that owns a row gets its edges in the SAME round trip as
     // the row pointers instead of one later (the aggregating fused forward / backward, csrc/mlp_fused.hip).
     int *ell, *ell_t;
+    unsigned *codes_t;                 // optional: the packed codes in the order of side 1 (source-sorted: the softmax backward's walk)
 };
 
 __global__ void csr_pair_zero_kernel(CsrPair p) {
@@ -499,6 +500,11 @@ __global__ __launch_bounds__(256) void csr_pair_canon_kernel(CsrPair p) {
                     c |= (unsigned)(p.off[f] + (int)checked_index(p.bond[(long long)v * p.F + f], p.vocab[f], p.err, PHC_IDX_ERR_BOND))
                          << (8 * f);
                 p.codes[b + rank] = c;
+            }
+            if (blockIdx.y == 1 && p.codes_t) {              // (side 0 reports a bad index; here it reads as 0 like everywhere else)
+                for (int f = 0; f < p.F; ++f)
+                    c |= (unsigned)(p.off[f] + (int)safe_index(p.bond[(long long)v * p.F + f], p.vocab[f])) << (8 * f);
+                p.codes_t[b + rank] = c;
             }
             if (rank < 4) {
                 if (blockIdx.y == 0 && p.ell) {
@@ -762,7 +768,8 @@ int phc_csr_build_pair(const int64_t *edge_src_i64, const int64_t *edge_dst_i64,
 static int csr_build_pair_impl(const int64_t *edge_src_i64, const int64_t *edge_dst_i64, int64_t E, int64_t n_src, int64_t n_dst,
                                int32_t *rowptr, int32_t *col, int32_t *perm, int32_t *rowptr_t, int32_t *col_t, int32_t *perm_t,
                                const int64_t *bond_i64, const int32_t *vocab, int F, uint32_t *codes, float *code_counts, void *ws,
-                               size_t ws_bytes, void *stream, int resident, int32_t *ell = nullptr, int32_t *ell_t = nullptr);
+                               size_t ws_bytes, void *stream, int resident, int32_t *ell = nullptr, int32_t *ell_t = nullptr,
+                               uint32_t *codes_src = nullptr);
 
 int phc_csr_build_pair_codes(const int64_t *edge_src_i64, const int64_t *edge_dst_i64, int64_t E, int64_t n_src, int64_t n_dst,
                              int32_t *rowptr, int32_t *col, int32_t *perm, int32_t *rowptr_t, int32_t *col_t, int32_t *perm_t,
@@ -793,10 +800,22 @@ int phc_csr_build_pair_codes_resident_ell(const int64_t *edge_src_i64, const int
                                codes, code_counts, ws_zeroed_once, ws_bytes, stream, 1, ell, ell_t);
 }
 
+/* ... and the packed codes in SOURCE-sorted order as well (codes_src [E], may be NULL): what phc_pack_edge_codes(perm_t) computes in a
+ * launch of its own for the softmax aggregation's backward walk */
+int phc_csr_build_pair_codes_resident_ell_src(const int64_t *edge_src_i64, const int64_t *edge_dst_i64, int64_t E, int64_t n_src,
+                                              int64_t n_dst, int32_t *rowptr, int32_t *col, int32_t *perm, int32_t *rowptr_t, int32_t *col_t,
+                                              int32_t *perm_t, const int64_t *bond_i64, const int32_t *vocab, int F, uint32_t *codes,
+                                              float *code_counts, int32_t *ell, int32_t *ell_t, uint32_t *codes_src, void *ws_zeroed_once,
+                                              size_t ws_bytes, void *stream) {
+    PHC_REQUIRE((!ell && !codes_src) || codes, PHC_ERR_INVALID_ARG, "phc_csr_build_pair_codes_resident_ell_src: ell / codes_src need codes");
+    return csr_build_pair_impl(edge_src_i64, edge_dst_i64, E, n_src, n_dst, rowptr, col, perm, rowptr_t, col_t, perm_t, bond_i64, vocab, F,
+                               codes, code_counts, ws_zeroed_once, ws_bytes, stream, 1, ell, ell_t, codes_src);
+}
+
 static int csr_build_pair_impl(const int64_t *edge_src_i64, const int64_t *edge_dst_i64, int64_t E, int64_t n_src, int64_t n_dst,
                                int32_t *rowptr, int32_t *col, int32_t *perm, int32_t *rowptr_t, int32_t *col_t, int32_t *perm_t,
                                const int64_t *bond_i64, const int32_t *vocab, int F, uint32_t *codes, float *code_counts, void *ws,
-                               size_t ws_bytes, void *stream, int resident, int32_t *ell, int32_t *ell_t) {
+                               size_t ws_bytes, void *stream, int resident, int32_t *ell, int32_t *ell_t, uint32_t *codes_src) {
     int code_off[4] = {0, 0, 0, 0};
     int code_rows = 0;
     if (codes) {
@@ -847,6 +866,7 @@ static int csr_build_pair_impl(const int64_t *edge_src_i64, const int64_t *edge_
     p.resident = resident;
     p.ell = ell;
     p.ell_t = ell_t;
+    p.codes_t = codes ? codes_src : nullptr;
     const long long nmax = (n_src > n_dst ? n_src : n_dst) + 1;
     const unsigned ngrid = (unsigned)((nmax + 255) / 256);
     const unsigned egrid = (unsigned)((E + 255) / 256 > 4096 ? 4096 : (E + 255) / 256);

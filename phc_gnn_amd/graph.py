@@ -142,12 +142,13 @@ class EdgeStructure:
                 self._pack_codes(*self._codes_args, codes)
         for codes in self._codes_orig.values():
             self._pack_codes(*self._codes_orig_args, codes, sorted_order=False)
-        for codes in self._codes_src.values():
-            self._pack_codes(*self._codes_src_args, codes, by_source=True)
+        if not (pair_rebuilt and getattr(self, "_pair_packed_src", False)):      # (... and the source-sorted codes, when it carries them)
+            for codes in self._codes_src.values():
+                self._pack_codes(*self._codes_src_args, codes, by_source=True)
 
     PAIR_MAX_ROWS = 32767
 
-    def _build_pair(self, reuse: bool = False, codes_for=None) -> None:
+    def _build_pair(self, reuse: bool = False, codes_for=None, codes_src: bool = False) -> None:
         """Both views side by side (phc_csr_build_pair: 5 launches instead of 22); ``codes_for = (bond_idx, vocab_c, F)``:
         the packed edge codes of that bond tensor come out of the same launches."""
         lib = L.load()
@@ -198,11 +199,24 @@ class EdgeStructure:
             ell_t = torch.empty((self.num_src, 4), dtype=torch.int32, device=dev)
         if codes is None:
             ell = None                                       # (ell carries the packed codes)
-        L.check(lib.phc_csr_build_pair_codes_resident_ell(L.ptr(self._src), L.ptr(self._dst), E, self.num_src, self.num_dst, L.ptr(csr[0]),
-                                                 L.ptr(csr[1]), L.ptr(csr[2]), L.ptr(csc[0]), L.ptr(csc[1]), L.ptr(csc[2]),
-                                                 L.ptr(bond), vocab_c, F, L.ptr(codes), L.ptr(counts), L.ptr(ell), L.ptr(ell_t), L.ptr(ws),
-                                                 ws_bytes, L.stream_ptr(dev)),
-                "phc_csr_build_pair_codes_resident_ell")
+        # the same codes in SOURCE-sorted order (the softmax aggregation's backward walk: packed_codes_src) out of the same launches
+        csrc = None
+        if codes is not None:
+            if reuse:
+                if self._codes_src and self._codes_src_args is not None and self._codes_src_args[0] is bond and \
+                        tuple(self._codes_src_args[1]) == tuple(vocab_c):
+                    csrc = next(iter(self._codes_src.values()))
+            elif codes_src:
+                csrc = torch.empty(E, dtype=torch.int32, device=dev)
+        L.check(lib.phc_csr_build_pair_codes_resident_ell_src(L.ptr(self._src), L.ptr(self._dst), E, self.num_src, self.num_dst, L.ptr(csr[0]),
+                                                     L.ptr(csr[1]), L.ptr(csr[2]), L.ptr(csc[0]), L.ptr(csc[1]), L.ptr(csc[2]),
+                                                     L.ptr(bond), vocab_c, F, L.ptr(codes), L.ptr(counts), L.ptr(ell), L.ptr(ell_t),
+                                                     L.ptr(csrc), L.ptr(ws), ws_bytes, L.stream_ptr(dev)),
+                "phc_csr_build_pair_codes_resident_ell_src")
+        self._pair_packed_src = csrc is not None
+        if csrc is not None and not reuse:
+            self._codes_src = {(bond.data_ptr(), bond._version, tuple(vocab_c)): csrc}
+            self._codes_src_args = (bond, vocab_c, F)
         self._ell, self._ell_t = ell, ell_t
         self._code_counts = (codes, counts) if counts is not None else None
         L.maybe_check_indices(dev)
@@ -212,13 +226,14 @@ class EdgeStructure:
             self._codes_args = (bond, vocab_c, F)
         self._pair_packed = codes is not None
 
-    def prepare(self, for_backward: bool, codes_for=None) -> "EdgeStructure":
+    def prepare(self, for_backward: bool, codes_for=None, codes_src: bool = False) -> "EdgeStructure":
         """Build what a forward (and, with ``for_backward``, its backward) will walk.  A differentiable forward wants
         the source-sorted view later: both views are then built side by side (5 launches instead of 22).  ``codes_for
-        = (int64 bond tensor, vocab_c, F)``: the caller will ask for ``packed_codes`` of it next — they ride along."""
+        = (int64 bond tensor, vocab_c, F)``: the caller will ask for ``packed_codes`` of it next — they ride along (``codes_src``: and for
+        ``packed_codes_src`` in its backward)."""
         if (for_backward and self._csr is None and self._csc is None and self.num_edges > 0
                 and 0 < max(self.num_src, self.num_dst) <= self.PAIR_MAX_ROWS):
-            self._build_pair(codes_for=codes_for)
+            self._build_pair(codes_for=codes_for, codes_src=codes_src)
         return self
 
     @property

@@ -235,6 +235,7 @@ SIGNATURES = {
     "phc_csr_build_pair_codes": (_I, [_P, _P, _L, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _S, _P]),
     "phc_csr_build_pair_codes_resident": (_I, [_P, _P, _L, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _S, _P]),
     "phc_csr_build_pair_codes_resident_ell": (_I, [_P, _P, _L, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _S, _P]),
+    "phc_csr_build_pair_codes_resident_ell_src": (_I, [_P, _P, _L, _L, _L, _P, _P, _P, _P, _P, _P, _P, _P, _I, _P, _P, _P, _P, _P, _P, _S, _P]),
     "phc_remove_isolated_ws_bytes": (_S, [_L]),
     "phc_remove_isolated_nodes": (_I, [_P, _P, _L, _L, _P, _I, _P, _P, _P, _P, _P, _P, _P, _P, _S, _P]),
     "phc_segment_ptr_sorted": (_I, [_P, _L, _L, _P, _P]),

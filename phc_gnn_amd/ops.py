@@ -1761,7 +1761,7 @@ def aggregate_softmax_encoded(x: torch.Tensor, edge_index, bond_idx: torch.Tenso
     st = edge_index if isinstance(edge_index, EdgeStructure) else edge_structure(edge_index, x.shape[0], num_dst)
     ts = ts.vector_form(tables)
     bond_idx = _idx64(bond_idx)
-    st.prepare(for_backward=torch.is_grad_enabled() and x.requires_grad, codes_for=(bond_idx, ts.vocab_c, ts.F))
+    st.prepare(for_backward=torch.is_grad_enabled() and x.requires_grad, codes_for=(bond_idx, ts.vocab_c, ts.F), codes_src=True)
     box = {} if (lazy and torch.is_grad_enabled()) else None
     res = _AggregateSoftmaxEncFn.apply(x, bond_idx, beta, st, _act_id(msg_encoder), add_self, ts, pending, box,
                                        *[t for comp in tables for t in comp])

@@ -968,6 +968,27 @@ def test_csr_pair_build_equals_two_single_builds(kind):
             assert torch.equal(x, y)
 
 
+def test_csr_pair_build_source_sorted_codes_equal_the_pack_launch():
+    """The packed bond codes in SOURCE-sorted order out of the pair build (phc_csr_build_pair_codes_resident_ell_src) == phc_pack_edge_codes
+    through perm_t in a launch of its own; refreshed by an in-place rebuild."""
+    import ctypes as C
+    from phc_gnn_amd import synth
+    from phc_gnn_amd.graph import EdgeStructure
+    b = synth.molecule_batch(64, seed=9)
+    t = torch.from_numpy(np.ascontiguousarray(b.edge_index)).to(DEV)
+    bond = torch.from_numpy(np.ascontiguousarray(b.edge_attr)).to(DEV)
+    vocab = (C.c_int32 * 3)(5, 6, 2)
+    a = EdgeStructure(t, b.num_nodes).prepare(for_backward=True, codes_for=(bond, vocab, 3), codes_src=True)
+    assert a._pair_packed_src
+    got = a.packed_codes_src(bond, vocab, 3)
+    ref = torch.empty_like(got)
+    a._pack_codes(bond, vocab, 3, ref, by_source=True)
+    assert torch.equal(got, ref)
+    got.fill_(-1)
+    a.rebuild()
+    assert torch.equal(a.packed_codes_src(bond, vocab, 3), ref)
+
+
 def test_phm_linear_backward_large_n_uses_the_wide_tile(ops):
     """N >= 64k rows: dH = x^T.dy runs on 128 x 128 tiles (per-layer path); results vs the oracle."""
     from oracle import phc_oracle as O
