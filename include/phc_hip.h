@@ -306,6 +306,13 @@ int phc_aggregate_softmax_enc_bwd(const float *dout, const float *out, const flo
                                   int n, int k, const float *beta_dev, const int32_t *rowptr_t, const int32_t *col_t,
                                   const int32_t *perm_t, int64_t n_src, int act, int64_t self_n_dst, float *dx,
                                   float *dea, float *dbeta_partial, void *stream);
+/* ... with up to 8 further gradients of the same rows (residuals: HOST array of device pointers [n_src, n k]) added on the way out in
+ * slot order: the skip connections' shares of dx (models.py:230-234) — the n-way sum launch behind the walk disappears. */
+int phc_aggregate_softmax_enc_bwd_res(const float *dout, const float *out, const float *lse, const float *x, const uint32_t *codes_src,
+                                      const float *const *tables, const int32_t *vocab, int F, int n, int k, const float *beta_dev,
+                                      const int32_t *rowptr_t, const int32_t *col_t, const int32_t *perm_t, int64_t n_src, int act,
+                                      int64_t self_n_dst, const float *const *residuals, int num_residuals, float *dx, float *dea,
+                                      float *dbeta_partial, void *stream);
 
 /* out[r, :] = src[idx[r], :]   (row gather; backward of a segment sum, e.g.
  * global_add_pool's gradient dx[i] = dout[batch[i]], pooling.py:14) */

@@ -201,7 +201,7 @@ class _SoftmaxMixin:
         return out + x if (add_self and not fused_self) else out
 
     def propagate_encoded(self, edge_index, x, edge_idx, encoder, size=None, add_self=False, dx_handoff=None, pending=None, lazy=False, dx_link=None):
-        # (dx_handoff is never accepted here: the softmax backward has no residual input, so nobody parks a gradient in it;
+        # (dx_handoff: the skips' shares of dx are added inside the softmax backward walk — engine phc_aggregate_softmax_enc_bwd_res;
         # `pending`: the un-applied norm of the layer in front rides in the walk — engine PendingNorm; `lazy`: the walk may be left to
         # the fused MLP + norm node's one-launch forward — engine PendingSoftmaxAggregate)
         """Softmax aggregation with edge_attr = encoder(edge_idx): the kernels add the F table rows of every edge
@@ -211,7 +211,8 @@ class _SoftmaxMixin:
         num_dst = size[1] if size is not None and size[1] is not None else None
         if ts.F <= 4 and ts.R <= 256 and ts.k % 4 == 0 and (num_dst is None or num_dst == x.size(0) or not add_self):
             return _engine.aggregate_softmax_encoded(x, edge_index, edge_idx, ts, tables, self.beta, self.msg_encoder_str,
-                                                     add_self=add_self, num_dst=num_dst, pending=pending, lazy=lazy)
+                                                     add_self=add_self, num_dst=num_dst, pending=pending, lazy=lazy,
+                                                     dx_handoff=dx_handoff)
         _engine.materialize_pending(x)
         ea = encoder(edge_idx)                               # wider vocabularies: embed the bonds and take the tensor path
         return self.propagate(edge_index, x=x, edge_attr=ea.reshape(ea.size(0), -1), size=size, add_self=add_self)

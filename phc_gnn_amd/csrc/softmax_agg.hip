@@ -20,6 +20,10 @@ constexpr int SM_THREADS = 256;
 // Bond embedding read in place (SURVEY §8f N1 on the softmax operators): instead of an [E, h] edge tensor the kernels
 // take the packed table rows of every edge (phc_pack_edge_codes: byte f = off_f + value) and the n*F table pointers,
 // and add the F table rows to x[src] themselves (rows come from L2: a bond encoder has 13 rows).
+struct SmResiduals {                         // further gradients of the rows a backward walk writes (softmax_agg_bwd_kernel)
+    const float *p[8];
+    int n;
+};
 struct SmEnc {
     const unsigned *codes;                   // NULL: use the edge tensor
     const float *const *tables;              // [n * F] device pointers, table (c, f) is [V_f, k]
@@ -323,7 +327,9 @@ __global__ __launch_bounds__(SM_THREADS) void softmax_agg_bwd_kernel(
     const float *__restrict__ dout, const float *__restrict__ out, const float *__restrict__ lse, const float *__restrict__ x,
     const float *__restrict__ ea, const float *__restrict__ beta_p, const int *__restrict__ rowptr_t, const int *__restrict__ col_t,
     const int *__restrict__ perm_t, long long n_src, int h, float *__restrict__ dx, float *__restrict__ dea,
-    float *__restrict__ dbeta_partial, int n_partials, long long self_n_dst, SmEnc enc) {
+    float *__restrict__ dbeta_partial, int n_partials, long long self_n_dst, SmEnc enc, SmResiduals res) {
+    // res: up to 8 further gradients of the SAME rows (the skip connections' shares of dx, ops.DxHandoff / DxSumHandoff) added on the
+    // way out in slot order — the n-way sum launch in front of the atom-table gradient disappears (as aggregate_dx_rows_kernel<.., NRES>)
     __shared__ float red[SM_THREADS];
     constexpr int G = WAVE / LPR;
     const int lane = threadIdx.x & 63;
@@ -338,6 +344,11 @@ __global__ __launch_bounds__(SM_THREADS) void softmax_agg_bwd_kernel(
             const float4 xs = reinterpret_cast<const float4 *>(x + (size_t)sidx * h)[c4];
             float4 gs = make_float4(0.f, 0.f, 0.f, 0.f);    // the self loop's gradient: dx[s] += dout[s]
             if (sidx < self_n_dst) gs = reinterpret_cast<const float4 *>(dout + (size_t)sidx * h)[c4];
+            float4 rv[8];
+            if (res.n > 0) {                                 // (uniform; unconditional loads: an unused slot re-reads x's row)
+#pragma unroll
+                for (int q = 0; q < 8; ++q) rv[q] = reinterpret_cast<const float4 *>((q < res.n ? res.p[q] : x) + (size_t)sidx * h)[c4];
+            }
             float acc[4] = {0.f, 0.f, 0.f, 0.f};
             const float *tp[4] = {nullptr, nullptr, nullptr, nullptr};
             if (enc.codes) sm_table_ptrs(enc, c4, tp);
@@ -388,8 +399,15 @@ __global__ __launch_bounds__(SM_THREADS) void softmax_agg_bwd_kernel(
 #pragma unroll
                     for (int q = 0; q < 4; ++q) acc[q] += __shfl_xor(acc[q], off, WAVE);
             }
-            if (!coop || grp == 0)
-                reinterpret_cast<float4 *>(dx + (size_t)sidx * h)[c4] = make_float4(acc[0] + gs.x, acc[1] + gs.y, acc[2] + gs.z, acc[3] + gs.w);
+            if (!coop || grp == 0) {
+                float4 o4 = make_float4(acc[0] + gs.x, acc[1] + gs.y, acc[2] + gs.z, acc[3] + gs.w);
+                if (res.n > 0) {
+#pragma unroll
+                    for (int q = 0; q < 8; ++q)
+                        if (q < res.n) { o4.x += rv[q].x; o4.y += rv[q].y; o4.z += rv[q].z; o4.w += rv[q].w; }     // fixed order: slot 0, 1, ...
+                }
+                reinterpret_cast<float4 *>(dx + (size_t)sidx * h)[c4] = o4;
+            }
         }
     };
     for (long long s0 = wave_id * G; s0 < n_src; s0 += n_waves * G) {           // wave-uniform bounds
@@ -577,7 +595,8 @@ int phc_aggregate_softmax_bwd(const float *dout, const float *out, const float *
 
 static int sm_bwd_impl(const float *dout, const float *out, const float *lse, const float *x, const float *ea, const float *beta_dev,
                        const int32_t *rowptr_t, const int32_t *col_t, const int32_t *perm_t, int64_t n_src, int h, int act,
-                       int64_t self_n_dst, float *dx, float *dea, float *dbeta_partial, SmEnc enc, void *stream);
+                       int64_t self_n_dst, float *dx, float *dea, float *dbeta_partial, SmEnc enc, void *stream,
+                       const float *const *residuals = nullptr, int num_residuals = 0);
 
 int phc_aggregate_softmax_bwd_self(const float *dout, const float *out, const float *lse, const float *x, const float *ea,
                                    const float *beta_dev, const int32_t *rowptr_t, const int32_t *col_t, const int32_t *perm_t,
@@ -601,9 +620,32 @@ int phc_aggregate_softmax_enc_bwd(const float *dout, const float *out, const flo
                        dbeta_partial, enc, stream);
 }
 
+/* ... with up to 8 further gradients of the same rows added on the way out (the skip connections' shares of dx: models.py:230-234 with
+ * sc_type "first", the skip tensor itself with "last") — what an n-way sum launch did behind this one */
+int phc_aggregate_softmax_enc_bwd_res(const float *dout, const float *out, const float *lse, const float *x, const uint32_t *codes_src,
+                                      const float *const *tables, const int32_t *vocab, int F, int n, int k, const float *beta_dev,
+                                      const int32_t *rowptr_t, const int32_t *col_t, const int32_t *perm_t, int64_t n_src, int act,
+                                      int64_t self_n_dst, const float *const *residuals, int num_residuals, float *dx, float *dea,
+                                      float *dbeta_partial, void *stream) {
+    SmEnc enc;
+    int rc = sm_make_enc("phc_aggregate_softmax_enc_bwd_res", codes_src, tables, vocab, F, n, k, n * k, &enc);
+    if (rc) return rc;
+    return sm_bwd_impl(dout, out, lse, x, nullptr, beta_dev, rowptr_t, col_t, perm_t, n_src, n * k, act, self_n_dst, dx, dea,
+                       dbeta_partial, enc, stream, residuals, num_residuals);
+}
+
 static int sm_bwd_impl(const float *dout, const float *out, const float *lse, const float *x, const float *ea, const float *beta_dev,
                        const int32_t *rowptr_t, const int32_t *col_t, const int32_t *perm_t, int64_t n_src, int h, int act,
-                       int64_t self_n_dst, float *dx, float *dea, float *dbeta_partial, SmEnc enc, void *stream) {
+                       int64_t self_n_dst, float *dx, float *dea, float *dbeta_partial, SmEnc enc, void *stream,
+                       const float *const *residuals, int num_residuals) {
+    SmResiduals res = {};
+    PHC_REQUIRE(num_residuals >= 0 && num_residuals <= 8 && (num_residuals == 0 || residuals), PHC_ERR_INVALID_ARG,
+                "phc_aggregate_softmax_bwd: %d residual tensors (0..8)", num_residuals);
+    for (int q = 0; q < num_residuals; ++q) {
+        PHC_REQUIRE(residuals[q] && sm_al16(residuals[q]), PHC_ERR_INVALID_ARG, "phc_aggregate_softmax_bwd: residual %d is null / not 16-byte aligned", q);
+        res.p[q] = residuals[q];
+    }
+    res.n = num_residuals;
     PHC_REQUIRE(self_n_dst >= 0, PHC_ERR_INVALID_ARG, "phc_aggregate_softmax_bwd_self: bad self_n_dst");
     PHC_REQUIRE(n_src >= 0 && h >= 1, PHC_ERR_INVALID_ARG, "phc_aggregate_softmax_bwd: bad sizes");
     PHC_REQUIRE(act >= PHC_ACT_IDENTITY && act <= PHC_ACT_SELU, PHC_ERR_INVALID_ARG, "phc_aggregate_softmax_bwd: unknown activation %d", act);
@@ -617,10 +659,10 @@ static int sm_bwd_impl(const float *dout, const float *out, const float *lse, co
     ProfScope prof(K_SOFTMAX_BWD, s);
 #define PHC_SM_BWD(ACTC)                                                                                                 \
     switch (lpr) {                                                                                                       \
-        case 8: PHC_LAUNCH((softmax_agg_bwd_kernel<8, ACTC>), dim3(sm_grid(n_src, 64 / lpr)), dim3(SM_THREADS), 0, s, dout, out, lse, x, ea, beta_dev, rowptr_t, col_t, perm_t, (long long)n_src, h, dx, dea, dbeta_partial, (int)sm_grid(n_src), (long long)self_n_dst, enc); break;   \
-        case 16: PHC_LAUNCH((softmax_agg_bwd_kernel<16, ACTC>), dim3(sm_grid(n_src, 64 / lpr)), dim3(SM_THREADS), 0, s, dout, out, lse, x, ea, beta_dev, rowptr_t, col_t, perm_t, (long long)n_src, h, dx, dea, dbeta_partial, (int)sm_grid(n_src), (long long)self_n_dst, enc); break; \
-        case 32: PHC_LAUNCH((softmax_agg_bwd_kernel<32, ACTC>), dim3(sm_grid(n_src, 64 / lpr)), dim3(SM_THREADS), 0, s, dout, out, lse, x, ea, beta_dev, rowptr_t, col_t, perm_t, (long long)n_src, h, dx, dea, dbeta_partial, (int)sm_grid(n_src), (long long)self_n_dst, enc); break; \
-        default: PHC_LAUNCH((softmax_agg_bwd_kernel<64, ACTC>), dim3(sm_grid(n_src, 64 / lpr)), dim3(SM_THREADS), 0, s, dout, out, lse, x, ea, beta_dev, rowptr_t, col_t, perm_t, (long long)n_src, h, dx, dea, dbeta_partial, (int)sm_grid(n_src), (long long)self_n_dst, enc); break; \
+        case 8: PHC_LAUNCH((softmax_agg_bwd_kernel<8, ACTC>), dim3(sm_grid(n_src, 64 / lpr)), dim3(SM_THREADS), 0, s, dout, out, lse, x, ea, beta_dev, rowptr_t, col_t, perm_t, (long long)n_src, h, dx, dea, dbeta_partial, (int)sm_grid(n_src), (long long)self_n_dst, enc, res); break;   \
+        case 16: PHC_LAUNCH((softmax_agg_bwd_kernel<16, ACTC>), dim3(sm_grid(n_src, 64 / lpr)), dim3(SM_THREADS), 0, s, dout, out, lse, x, ea, beta_dev, rowptr_t, col_t, perm_t, (long long)n_src, h, dx, dea, dbeta_partial, (int)sm_grid(n_src), (long long)self_n_dst, enc, res); break; \
+        case 32: PHC_LAUNCH((softmax_agg_bwd_kernel<32, ACTC>), dim3(sm_grid(n_src, 64 / lpr)), dim3(SM_THREADS), 0, s, dout, out, lse, x, ea, beta_dev, rowptr_t, col_t, perm_t, (long long)n_src, h, dx, dea, dbeta_partial, (int)sm_grid(n_src), (long long)self_n_dst, enc, res); break; \
+        default: PHC_LAUNCH((softmax_agg_bwd_kernel<64, ACTC>), dim3(sm_grid(n_src, 64 / lpr)), dim3(SM_THREADS), 0, s, dout, out, lse, x, ea, beta_dev, rowptr_t, col_t, perm_t, (long long)n_src, h, dx, dea, dbeta_partial, (int)sm_grid(n_src), (long long)self_n_dst, enc, res); break; \
     }
     PHC_SM_ACT(act, PHC_SM_BWD)
 #undef PHC_SM_BWD

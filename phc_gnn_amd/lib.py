@@ -252,6 +252,7 @@ SIGNATURES = {
     "phc_aggregate_softmax_norm_enc_fwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, C.c_float, C.c_float, _I, _P, _P, _P, _P, _P, _P, _P, _I, _I, _I,
                                                 _P, _P, _P, _L, _P, _P, _P, _P]),
     "phc_aggregate_softmax_enc_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _L, _I, _L, _P, _P, _P, _P]),
+    "phc_aggregate_softmax_enc_bwd_res": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _P, _P, _P, _P, _L, _I, _L, _P, _I, _P, _P, _P, _P]),
     "phc_encode_fwd": (_I, [_P, _P, _P, _L, _I, _I, _I, _P, _P]),
     "phc_encode_bwd_ws_bytes": (_S, [_L, _I, _P, _I, _I]),
     "phc_encode_bwd": (_I, [_P, _P, _L, _I, _P, _I, _I, _P, _P, _S, _P]),

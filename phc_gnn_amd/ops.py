@@ -1658,9 +1658,14 @@ class _AggregateSoftmaxEncFn(torch.autograd.Function):
     """Softmax aggregation with the bond encoder read in place (packed codes + tables, no [E, h] forward tensor)."""
 
     @staticmethod
-    def forward(ctx, x, bond_idx, beta, st: EdgeStructure, act: int, add_self: bool, ts: "TableSet", pending, lazy_box, *tables):
+    def forward(ctx, x, bond_idx, beta, st: EdgeStructure, act: int, add_self: bool, ts: "TableSet", pending, lazy_box, dx_handoff, *tables):
         lib = L.load()
         dev = L.require_device(x, bond_idx, beta)
+        # the skip connections' shares of dx (DxHandoff / DxSumHandoff) are added inside this op's backward walk
+        # (phc_aggregate_softmax_enc_bwd_res) when x's rows are the walk's source rows
+        ctx.dx_handoff = dx_handoff if (dx_handoff is not None and x.shape[0] == st.num_src and x.shape[1] % 4 == 0) else None
+        if ctx.dx_handoff is not None:
+            ctx.dx_handoff.accepted = True
         # `pending`: x = act(norm(y)) (+ skip) has not been evaluated yet (PendingNorm): the walk does it on the fly for every row it
         # gathers and writes x itself once (phc_aggregate_softmax_norm_enc_fwd, round 5) — or the stand-alone pass runs right here
         fuse_norm = pending is not None and not pending.done and NORM_INTO_AGGREGATE and act == 0 and x.is_contiguous() and \
@@ -1717,16 +1722,26 @@ class _AggregateSoftmaxEncFn(torch.autograd.Function):
         h = dout_.shape[1]
         rowptr_t, col_t, perm_t = st.csc
         codes_o = st.packed_codes_src(bond_, ts.vocab_c, ts.F)
-        need_t = any(ctx.needs_input_grad[9:])
+        need_t = any(ctx.needs_input_grad[10:])
         dx = torch.empty((st.num_src, h), dtype=torch.float32, device=dev)
         dea = torch.empty((st.num_edges, h), dtype=torch.float32, device=dev) if need_t else None
         nparts = lib.phc_softmax_bwd_num_partials(st.num_src)
         parts = torch.empty(nparts, dtype=torch.float32, device=dev)
-        L.check(lib.phc_aggregate_softmax_enc_bwd(L.ptr(dout_), L.ptr(out), L.ptr(lse), L.ptr(x_), L.ptr(codes_o), L.ptr(ts.ptrs),
-                                                  ts.vocab_c, ts.F, ts.n, ts.k, L.ptr(beta_), L.ptr(rowptr_t), L.ptr(col_t),
-                                                  L.ptr(perm_t), st.num_src, ctx.act,
-                                                  min(st.num_dst, st.num_src) if ctx.add_self else 0, L.ptr(dx), L.ptr(dea),
-                                                  L.ptr(parts), L.stream_ptr(dev)), "phc_aggregate_softmax_enc_bwd")
+        extra = ctx.dx_handoff.take() if ctx.dx_handoff is not None else None
+        extras = extra if isinstance(extra, list) else ([extra] if extra is not None else [])
+        if extras and (not ctx.needs_input_grad[0] or any(tuple(e.shape) != (st.num_src, h) for e in extras)):
+            raise L.PhcError("DxHandoff: a parked gradient needs a consumer that computes dx of the same shape")
+        in_walk = [e for e in extras if e.is_contiguous() and e.dtype == torch.float32 and e.data_ptr() % 16 == 0][:8] if len(extras) <= 8 else []
+        rest = [e for e in extras if not any(e is w for w in in_walk)]
+        arr = (_C.c_void_p * max(len(in_walk), 1))(*[e.data_ptr() for e in in_walk])
+        L.check(lib.phc_aggregate_softmax_enc_bwd_res(L.ptr(dout_), L.ptr(out), L.ptr(lse), L.ptr(x_), L.ptr(codes_o), L.ptr(ts.ptrs),
+                                                      ts.vocab_c, ts.F, ts.n, ts.k, L.ptr(beta_), L.ptr(rowptr_t), L.ptr(col_t),
+                                                      L.ptr(perm_t), st.num_src, ctx.act,
+                                                      min(st.num_dst, st.num_src) if ctx.add_self else 0, arr if in_walk else None,
+                                                      len(in_walk), L.ptr(dx), L.ptr(dea), L.ptr(parts), L.stream_ptr(dev)),
+                "phc_aggregate_softmax_enc_bwd_res")
+        for e in rest:                                       # (shapes / layouts the walk does not take: plain adds)
+            dx += e
         if L.PROF_ON:
             E, N = st.num_edges, st.num_src
             L.account("aggregate_softmax_bwd", 12.0 * E * h, E * (4.0 * h * (4 if need_t else 3) + 12) + N * 8.0 * h)
@@ -1740,7 +1755,7 @@ class _AggregateSoftmaxEncFn(torch.autograd.Function):
         tgrads = [None] * ts.num_tables
         if need_t:
             if ctx.defer_tables is not None and _DEFER.active and not torch.is_grad_enabled():
-                params = [t if ng else None for t, ng in zip(ctx.defer_tables, ctx.needs_input_grad[9:])]
+                params = [t if ng else None for t, ng in zip(ctx.defer_tables, ctx.needs_input_grad[10:])]
                 with _DEFER.lock:                            # d enc = dea: an encoder job over the edge rows
                     _DEFER.atom_jobs.append(dict(dout=dea, idx=bond_, ts=ts, params=params))
             else:
@@ -1750,12 +1765,12 @@ class _AggregateSoftmaxEncFn(torch.autograd.Function):
                 L.check(lib.phc_encode_bwd(L.ptr(dea), L.ptr(bond_), st.num_edges, ts.F, ts.vocab_c, ts.n, ts.k, L.ptr(flat),
                                            L.ptr(ws), ws_bytes, L.stream_ptr(dev)), "phc_encode_bwd")
                 tgrads = list(ts.grad_views(flat))
-        return ((dx if ctx.needs_input_grad[0] else None), None, dbeta, None, None, None, None, None, None, *tgrads)
+        return ((dx if ctx.needs_input_grad[0] else None), None, dbeta, None, None, None, None, None, None, None, *tgrads)
 
 
 def aggregate_softmax_encoded(x: torch.Tensor, edge_index, bond_idx: torch.Tensor, ts: "TableSet", tables, beta: torch.Tensor,
                               msg_encoder: str = "identity", add_self: bool = False, num_dst: Optional[int] = None,
-                              pending=None, lazy: bool = False) -> torch.Tensor:
+                              pending=None, lazy: bool = False, dx_handoff=None) -> torch.Tensor:
     """aggregate_softmax with ``edge_attr = bond encoder(bond_idx)`` evaluated inside the kernels (needs
     ``ts.fusable_into_aggregate`` and F <= 4, sum(vocab) <= 256: the packed-code limits)."""
     st = edge_index if isinstance(edge_index, EdgeStructure) else edge_structure(edge_index, x.shape[0], num_dst)
@@ -1763,7 +1778,7 @@ def aggregate_softmax_encoded(x: torch.Tensor, edge_index, bond_idx: torch.Tenso
     bond_idx = _idx64(bond_idx)
     st.prepare(for_backward=torch.is_grad_enabled() and x.requires_grad, codes_for=(bond_idx, ts.vocab_c, ts.F), codes_src=True)
     box = {} if (lazy and torch.is_grad_enabled()) else None
-    res = _AggregateSoftmaxEncFn.apply(x, bond_idx, beta, st, _act_id(msg_encoder), add_self, ts, pending, box,
+    res = _AggregateSoftmaxEncFn.apply(x, bond_idx, beta, st, _act_id(msg_encoder), add_self, ts, pending, box, dx_handoff,
                                        *[t for comp in tables for t in comp])
     if box and box.get("pa") is not None:
         res._phc_pending_agg = box["pa"]

@@ -63,10 +63,15 @@ def test_norm_folded_into_the_next_aggregation_is_bit_identical(workload, graph)
     _same(on, off)
 
 
-@pytest.mark.parametrize("workload", ["molhiv_b32", "molpcba_small"])
+@pytest.mark.parametrize("workload", ["molhiv_b32", "molpcba_small", "molhiv_b32_softmax", "molhiv_small_200_softmax_swish"])
 def test_skip_gradient_shares_meet_in_the_first_aggregation_backward(workload):
-    """Same sums in a different order (slot order inside the dx kernel instead of the n-way sum kernel's): 1e-6 of the largest entry."""
+    """Same sums in a different order (slot order inside the dx kernel instead of the n-way sum kernel's): 1e-6 of the largest entry.
+    Softmax aggregation: the shares ride in phc_aggregate_softmax_enc_bwd_res's walk."""
     from phc_gnn_amd import harness
+    harness.WORKLOADS.setdefault("molhiv_b32_softmax", dict(harness.WORKLOADS["molhiv_b32"], msg_aggr="softmax"))
+    harness.WORKLOADS.setdefault("molhiv_small_200_softmax_swish", dict(dataset="molhiv", batch_size=40, phm_dim=4, hidden=200, layers=3,
+                                                                        d_units=[128, 32], target_dim=1, sc_type="first", msg_aggr="softmax",
+                                                                        activation="swish"))
     if workload == "molpcba_small":                                       # five layers: the eight-slot instantiation
         harness.WORKLOADS.setdefault("molpcba_small", dict(dataset="molpcba", batch_size=24, phm_dim=4, hidden=64, layers=5, d_units=[64, 32],
                                                            target_dim=8, sc_type="first", nan_frac=0.5))
