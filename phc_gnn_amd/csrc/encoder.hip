@@ -1311,9 +1311,33 @@ struct TailTables {
     unsigned nr_phm, nr_bond, nr_atom;                       // ... of the reduce launch
 };
 
+#ifdef PHC_TAIL_STAMPS
+// experiment build only (scripts/dbg/tail_wg_timeline.py): entry / exit wall clock (100 MHz), family and hardware id of EVERY workgroup
+static __device__ unsigned long long g_tail_ts[4096 * 4];
+struct TailStamp {
+    unsigned long long t0;
+    __device__ TailStamp() : t0(__builtin_amdgcn_s_memrealtime()) {}
+    __device__ void done(unsigned family) const {
+        __syncthreads();
+        if (threadIdx.x == 0 && blockIdx.x < 4096) {
+            unsigned long long *o = g_tail_ts + 4 * (size_t)blockIdx.x;
+            o[0] = t0; o[1] = __builtin_amdgcn_s_memrealtime(); o[2] = family;
+            o[3] = ((unsigned long long)__builtin_amdgcn_s_getreg((20 << 11) | (0 << 6) | 31) << 32) |     // XCC_ID
+                   __builtin_amdgcn_s_getreg((4 << 11) | (0 << 6) | 31);                                     // HW_ID
+        }
+    }
+};
+#define TAIL_DONE(f) stamp_.done(f)
+#else
+#define TAIL_DONE(f) do { } while (0)
+#endif
+
 template <int ACT>
 __global__ __launch_bounds__(256, 2) void tail_partial_kernel(GradBatch gb, TailTables t) {
     __shared__ __attribute__((aligned(16))) float smem[2 * TG_IB * TG_T];
+#ifdef PHC_TAIL_STAMPS
+    const TailStamp stamp_;
+#endif
     static_assert(2 * TG_IB * TG_T == 2 * DH_RB * DH_STRIDE, "table and dH workgroups stage the same 32 KB");
     // Dispatch order: workgroups start in block order, two per CU: table families, then the dH family.  The long dH workgroups
     // first (t.dh_first, PHC_TAIL_DH_FIRST=1) measured within noise of it; interleaving the families in proportion cost 15 us.
@@ -1326,10 +1350,12 @@ __global__ __launch_bounds__(256, 2) void tail_partial_kernel(GradBatch gb, Tail
         const int tile = bx % t.tiles_a;
         if (t.atom_direct) {
             atom_direct_body(t.atom_dout, t.atom_idx, t.ma, t.N_a, t.ips_a, t.h, t.tiles_j_a, t.atom_slabs, tile, bx / t.tiles_a, smem);
+            TAIL_DONE(0);
             return;
         }
         table_grad_rows_body<0>(t.atom_dout, t.atom_idx, nullptr, nullptr, 0, t.ma, t.N_a, t.ips_a, t.h, t.tiles_j_a, t.vec4_a, t.atom_slabs,
                                 tile, bx / t.tiles_a, smem);
+        TAIL_DONE(0);
         return;
     }
     bx -= t.nb_atom;
@@ -1341,6 +1367,7 @@ __global__ __launch_bounds__(256, 2) void tail_partial_kernel(GradBatch gb, Tail
         const int job0 = jg * TD_JG;
         bond_direct_body(t.bond, job0, min(TD_JG, t.jobs_b - job0), t.counts_b, t.cr_b, t.mb.R, t.E, t.ips_b, t.h, local % t.tiles_b,
                          local / t.tiles_b, smem);
+        TAIL_DONE(1);
         return;
     }
     if (bx < t.nb_bond) {
@@ -1354,6 +1381,7 @@ __global__ __launch_bounds__(256, 2) void tail_partial_kernel(GradBatch gb, Tail
         else
             table_grad_body<1, ACT>(jb.dout, t.bond_idx, t.mb, t.E, t.ips_b, t.h, t.tiles_j_b, t.src, t.dst, jb.x, jb.tables, t.n, t.k,
                                     t.vec4_b, jb.slabs, local % t.tiles_b, local / t.tiles_b, smem);
+        TAIL_DONE(1);
         return;
     }
     bx -= t.nb_bond;
@@ -1397,6 +1425,7 @@ __global__ __launch_bounds__(256, 2) void tail_partial_kernel(GradBatch gb, Tail
         dH_partial_body(j.x, j.dy, j.slabs, j.N, j.in, j.out, j.tiles_j, j.rows_per_split, j.vec4, tile, split, smem, j.xf_stat, j.xf_act,
                         xf_count);
     }
+    TAIL_DONE(2u + 16u * (unsigned)k + 4096u * (unsigned)tasks + 65536u * (unsigned)split);
 }
 
 __global__ __launch_bounds__(256) void tail_reduce_kernel(GradBatch gb, TailTables t, TailReg reg) {
@@ -1449,12 +1478,12 @@ static bool tg_direct_shape_ok(long long n_items, int h) {
     constexpr bool off = false;
     return !off && h % 64 == 0 && n_items >= 8;
 }
-static TgPlan tg_plan_direct(long long n_items, int R, int h) {
+constexpr long long TG_DIRECT_TARGET = 256;              // workgroups of a register-resident table family on its own
+static TgPlan tg_plan_direct(long long n_items, int R, int h, long long target = TG_DIRECT_TARGET) {
     TgPlan p;
     p.tiles_i = (R + 32 * TD_MB - 1) / (32 * TD_MB);
     p.tiles_j = h / 64;
     const long long tiles = (long long)p.tiles_i * p.tiles_j;
-    constexpr long long target = 256;
     long long ips = ((n_items * tiles + target - 1) / target + 7) / 8 * 8;
     if (ips < 8) ips = 8;
     const size_t cap_slabs = ((size_t)16 << 20) / (sizeof(float) * (size_t)R * h);       // <= 16 MB of slabs
@@ -1467,12 +1496,11 @@ static TgPlan tg_plan_direct(long long n_items, int R, int h) {
 }
 
 // register-resident bond form: tiles = (layer groups of TD_JG) x (64-column tiles); slab_floats is PER JOB
-static TgPlan tg_plan_direct_bond(long long n_items, int R, int h, int jobs) {
+static TgPlan tg_plan_direct_bond(long long n_items, int R, int h, int jobs, long long target = TG_DIRECT_TARGET) {
     TgPlan p;
     p.tiles_i = (jobs + TD_JG - 1) / TD_JG;                  // layer groups
     p.tiles_j = h / 64;
     const long long tiles = (long long)p.tiles_i * p.tiles_j;
-    constexpr long long target = 256;
     long long ips = ((n_items * tiles + target - 1) / target + 7) / 8 * 8;
     if (ips < 8) ips = 8;
     p.items_per_split = ips;
@@ -1553,6 +1581,13 @@ static int launch_table_grad(const float *dout, const long long *idx, const EncM
 using namespace phc;
 
 extern "C" {
+
+#ifdef PHC_TAIL_STAMPS
+int phc_debug_tail_stamps(unsigned long long *out) {
+    return hipMemcpyFromSymbol(out, HIP_SYMBOL(g_tail_ts), sizeof(unsigned long long) * 4096 * 4) == hipSuccess ? 0 : -1;
+}
+#endif
+
 
 int phc_encode_fwd(const int64_t *idx_i64, const float *const *tables, const int32_t *vocab, int64_t N, int F, int n, int k,
                    float *out, void *stream) {
@@ -2205,6 +2240,40 @@ int phc_step_tail_ex(const phc_phm_grad_job *jobs, int num_jobs, const phc_table
                           ws_bytes, extras, stream);
 }
 
+// The launch's 512 workgroup slots (two per CU) among its three families.  The table families' workgroups are latency-bound AND use the
+// matrix pipes (one-hot operands); with 256 workgroups each they fill every slot for the first 20 us of the molecule step's tail and the
+// dH family starts behind them (scripts/dbg/tail_wg_timeline.py: 252 + 244 table workgroups of 19 us, then 465 dH workgroups of 38 us —
+// 64 us for 27 000 workgroup-us of work, 53 us if the slots were full throughout).  Where the tables are a quarter or more of the
+// launch's work, every family gets slots in proportion to its work and all of them run from start to end: fewer, longer table
+// workgroups (fewer slabs to reduce), the dH family planned for the slots that are left.  Measured (round 6, alternating runs on one
+// box): molhiv_b512 0.4986 -> 0.4842 ms and 0.4951 -> 0.4869; at hidden 256 the tables are a sixth of the work and the same rule costs
+// 15 - 40 us (their matrix work slows the co-resident dH workgroups for the whole launch instead of for its first 60 us): unchanged
+// there.  Work estimates in workgroup-us from the same clocks: table tile rows 0.085 (atoms) / 0.03 per layer (bonds: 0.04 on their own, less beside the dH family), dH tile rows 0.075.
+struct TailShares {
+    long long target_a, target_b;
+    int slots_dh;
+};
+static TailShares tail_shares(const phc_phm_grad_job *jobs, int num_jobs, int bond_jobs, int64_t bond_n_dst, int64_t N_atoms, int R_a, int h,
+                              bool eligible) {
+    TailShares sh = {TG_DIRECT_TARGET, TG_DIRECT_TARGET, 512};
+    if (!eligible || N_atoms <= 0) return sh;
+    const double w_a = 0.085 * (double)N_atoms * ((R_a + 32 * TD_MB - 1) / (32 * TD_MB)) * (h / 64);
+    const double w_b = 0.03 * (double)bond_n_dst * (h / 64) * bond_jobs;
+    double w_d = 0.0;
+    for (int q = 0; q < num_jobs; ++q) {
+        const int in = jobs[q].n * jobs[q].kin, out = jobs[q].n * jobs[q].kout;
+        if (in % 4 == 0 && out % 4 == 0 && in >= 96 && out >= 32) w_d += 0.075 * (double)jobs[q].N * ((in + 127) / 128) * ((out + 63) / 64);
+    }
+    const double W = w_a + w_b + w_d;
+    if (w_d <= 0.0 || (w_a + w_b) < 0.25 * W) return sh;
+    auto share = [&](double w) { long long v = (long long)(0.85 * 512.0 * w / W / 8.0 + 0.5) * 8; return v < 32 ? 32LL : (v > 256 ? 256LL : v); };
+    sh.target_a = share(w_a);
+    sh.target_b = bond_jobs > 0 ? share(w_b) : 0;
+    sh.slots_dh = (int)(512 - sh.target_a - sh.target_b);
+    if (sh.slots_dh < 192) return TailShares{TG_DIRECT_TARGET, TG_DIRECT_TARGET, 512};      // (tables over three fifths of the work: as before)
+    return sh;
+}
+
 static int step_tail_impl(const phc_phm_grad_job *jobs, int num_jobs, const phc_table_grad_job *tjobs, int num_tjobs, const int64_t *bond_i64,
                           const int32_t *vocab_b, const int64_t *edge_src_i64, const int64_t *edge_dst_i64, int64_t E, int F_b, int act,
                           const int32_t *bond_rowptr, const uint32_t *bond_codes, const float *bond_counts, int64_t bond_n_dst,
@@ -2231,8 +2300,14 @@ static int step_tail_impl(const phc_phm_grad_job *jobs, int num_jobs, const phc_
     hipStream_t s = (hipStream_t)stream;
     const int h = n * k;
     float *wsf = static_cast<float *>(ws);
+    // which table families take their register-resident forms (decided before the split plans: the families share the launch's slots)
+    bool bond_direct = counted && bond_counts && mb.R <= 32 && tg_direct_shape_ok(bond_n_dst, h);
+    for (int q = 0; q < num_tjobs && bond_direct; ++q) bond_direct = tjobs[q].dout && (reinterpret_cast<uintptr_t>(tjobs[q].dout) & 7) == 0;
+    const bool atom_direct = N_atoms > 0 && tg_direct_shape_ok(N_atoms, h) && (reinterpret_cast<uintptr_t>(atom_dout) & 7) == 0;
+    const TailShares shares = tail_shares(jobs, num_jobs, bond_direct ? num_tjobs : 0, bond_n_dst, atom_direct ? N_atoms : 0, atom_direct ? ma.R : 0, h,
+                                          atom_direct && (num_tjobs == 0 || bond_direct));
     GradLaunch gl;
-    rc = prepare_grad_launch("phc_step_tail", jobs, num_jobs, wsf, &gl, tail_direct_form(num_tjobs, N_atoms));
+    rc = prepare_grad_launch("phc_step_tail", jobs, num_jobs, wsf, &gl, tail_direct_form(num_tjobs, N_atoms), shares.slots_dh);
     if (rc) return rc;
     wsf += phm_floats;
     TailTables t;
@@ -2247,10 +2322,8 @@ static int step_tail_impl(const phc_phm_grad_job *jobs, int num_jobs, const phc_
         t.rowptr_b = counted ? bond_rowptr : nullptr;
         t.codes_b = counted ? bond_codes : nullptr;
         t.n_edges_b = E;
-        bool bond_direct = counted && bond_counts && mb.R <= 32 && tg_direct_shape_ok(bond_n_dst, h);
-        for (int q = 0; q < num_tjobs && bond_direct; ++q) bond_direct = tjobs[q].dout && (reinterpret_cast<uintptr_t>(tjobs[q].dout) & 7) == 0;
         if (bond_direct) {                                   // register-resident form: its own split plan, the same slab stride
-            const TgPlan d = tg_plan_direct_bond(bond_n_dst, mb.R, h, num_tjobs);
+            const TgPlan d = tg_plan_direct_bond(bond_n_dst, mb.R, h, num_tjobs, shares.target_b);
             pb.items_per_split = d.items_per_split; pb.tiles_i = d.tiles_i; pb.tiles_j = d.tiles_j; pb.num_slabs = d.num_slabs;
             t.counts_b = bond_counts;
             t.cr_b = mb.R <= 16 ? 16 : 32;
@@ -2280,8 +2353,8 @@ static int step_tail_impl(const phc_phm_grad_job *jobs, int num_jobs, const phc_
         t.atom_dout = atom_dout;
         t.atom_idx = reinterpret_cast<const long long *>(atom_idx_i64);
         t.atom_slabs = wsf; t.atom_flat = atom_dtables_flat;
-        t.atom_direct = tg_direct_shape_ok(N_atoms, h) && (reinterpret_cast<uintptr_t>(atom_dout) & 7) == 0;
-        if (t.atom_direct) pa = tg_plan_direct(N_atoms, ma.R, h);
+        t.atom_direct = atom_direct;
+        if (t.atom_direct) pa = tg_plan_direct(N_atoms, ma.R, h, shares.target_a);
         t.N_a = N_atoms; t.ips_a = pa.items_per_split; t.tiles_j_a = pa.tiles_j; t.tiles_a = pa.tiles_i * pa.tiles_j; t.slabs_a = pa.num_slabs;
         t.vec4_a = (k % 4 == 0) && al16(atom_dout);
         t.nb_atom = (unsigned)t.tiles_a * (unsigned)t.slabs_a;

@@ -196,7 +196,7 @@ __device__ __forceinline__ void mf_publish_sums(f32x4_t sg, f32x4_t sgx, float *
 template <int MAXS, bool RELU>
 __device__ __forceinline__ void mf_gate_and_sums_k(float *UP, float *X, int tile_stride, const float *cst, int act, int steps, long long step0,
                                                    long long gstride, long long n_valid, float *red, unsigned long long *acc, int rep) {
-    const int tid = threadIdx.x, c4 = tid & 31, rg = tid >> 5, lane = tid & 63, wave = tid >> 6;
+    const int tid = threadIdx.x, c4 = tid & 31, rg = tid >> 5;
     const f32x4_t mean = *reinterpret_cast<const f32x4_t *>(cst + 4 * c4), inv = *reinterpret_cast<const f32x4_t *>(cst + MF_H + 4 * c4);
     const f32x4_t w = *reinterpret_cast<const f32x4_t *>(cst + 2 * MF_H + 4 * c4), b = *reinterpret_cast<const f32x4_t *>(cst + 3 * MF_H + 4 * c4);
     f32x4_t sg = {0.f, 0.f, 0.f, 0.f}, sgx = {0.f, 0.f, 0.f, 0.f};

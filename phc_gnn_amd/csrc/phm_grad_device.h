@@ -704,7 +704,8 @@ struct GradLaunch {
     unsigned nb_partial, nb_partial128, nb_direct, nb_reduce, nb_contract;
 };
 size_t grad_chunk_ws_floats(const phc_phm_grad_job *jobs, int num_jobs, int direct_form = 2);
-int prepare_grad_launch(const char *who, const phc_phm_grad_job *jobs, int num_jobs, float *ws_base, GradLaunch *out, int direct_form = 2);
+int prepare_grad_launch(const char *who, const phc_phm_grad_job *jobs, int num_jobs, float *ws_base, GradLaunch *out, int direct_form = 2,
+                        int slots3 = 512);
 int launch_grad_rest(const char *who, const GradLaunch &gl, bool partial64_too, hipStream_t s);
 int launch_grad_contract(const char *who, const GradLaunch &gl, hipStream_t s);
 int launch_grad_partial128(const char *who, const GradLaunch &gl, hipStream_t s);    // the t128 == 1 jobs of a prepared batch, if any

@@ -1697,7 +1697,8 @@ static inline bool dh_use_direct(const phc_phm_grad_job &jb) {
 // direct_form: 2 = 128 x 128 tiles per wavefront in their own launch (512 registers, one wavefront per SIMD); 3 = 128 x 64 tiles
 // (256 registers, two per SIMD) for a launch SHARED with other workgroup families (phc_step_tail: the table-gradient workgroups
 // are latency-bound gathers and run in the slots beside the MFMA-bound dH wavefronts)
-static void grad_plans(const phc_phm_grad_job *jobs, int num, GradPlan *plans, int direct_form = 2) {
+// slots3: the workgroup slots the form-3 family may take (512 = two per CU; the step tail leaves some to its table families)
+static void grad_plans(const phc_phm_grad_job *jobs, int num, GradPlan *plans, int direct_form = 2, int64_t slots3 = 512) {
     int64_t total = 0, direct_rows = 0;
     for (int k = 0; k < num; ++k) {
         const int in = jobs[k].n * jobs[k].kin, out = jobs[k].n * jobs[k].kout;
@@ -1716,7 +1717,7 @@ static void grad_plans(const phc_phm_grad_job *jobs, int num, GradPlan *plans, i
         // register-resident jobs: one workgroup per CU of a 256-CU part in ONE round (a workgroup owns its CU: 512 registers per
         // lane), every workgroup the same number of rows: the smallest multiple of 8 whose workgroup count fits the target
         constexpr int64_t dtarget2 = 256;
-        constexpr int64_t dtarget3 = 512;
+        const int64_t dtarget3 = slots3;
         const int64_t dtarget = direct_form == 3 ? dtarget3 : dtarget2;       // form 3: two workgroups per CU
         // multiples of 64 rows: each of the four wavefronts then runs whole 16-row iterations of the unmasked loop
         // form 3 (the step tail), even shares: a job's shorter last split is `pair` tiles' worth of ONE workgroup when that many of them
@@ -1790,11 +1791,12 @@ size_t grad_chunk_ws_floats(const phc_phm_grad_job *jobs, int num_jobs, int dire
     return off;
 }
 
-int prepare_grad_launch(const char *who, const phc_phm_grad_job *jobs, int cn, float *ws_base, GradLaunch *out, int direct_form) {
+int prepare_grad_launch(const char *who, const phc_phm_grad_job *jobs, int cn, float *ws_base, GradLaunch *out, int direct_form, int slots3) {
     PHC_REQUIRE(cn >= 1 && cn <= GRAD_JOBS_PER_LAUNCH, PHC_ERR_INVALID_ARG, "%s: %d jobs in one launch (1..%d)", who, cn,
                 GRAD_JOBS_PER_LAUNCH);
+    PHC_REQUIRE(slots3 >= 64 && slots3 <= 512, PHC_ERR_INVALID_ARG, "%s: %d workgroup slots for the parameter-gradient family", who, slots3);
     GradPlan plans[GRAD_JOBS_PER_LAUNCH];
-    grad_plans(jobs, cn, plans, direct_form);
+    grad_plans(jobs, cn, plans, direct_form, slots3);    // (fewer slots: longer splits, fewer slabs — grad_chunk_ws_floats' 512-slot size holds)
     GradBatch &b = out->batch;
     b.num = cn;
     unsigned nb_partial = 0, nb_partial128 = 0, nb_direct = 0, nb_reduce = 0, nb_contract = 0;
