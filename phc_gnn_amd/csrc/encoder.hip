@@ -2262,7 +2262,7 @@ static TailShares tail_shares(const phc_phm_grad_job *jobs, int num_jobs, int bo
     double w_d = 0.0;
     for (int q = 0; q < num_jobs; ++q) {
         const int in = jobs[q].n * jobs[q].kin, out = jobs[q].n * jobs[q].kout;
-        if (in % 4 == 0 && out % 4 == 0 && in >= 96 && out >= 32) w_d += 0.075 * (double)jobs[q].N * ((in + 127) / 128) * ((out + 63) / 64);
+        if (in % 4 == 0 && in >= 96 && out >= 32) w_d += 0.075 * (double)jobs[q].N * ((in + 127) / 128) * ((out + 63) / 64);
     }
     const double W = w_a + w_b + w_d;
     if (w_d <= 0.0 || (w_a + w_b) < 0.25 * W) return sh;

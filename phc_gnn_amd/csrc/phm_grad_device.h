@@ -297,8 +297,9 @@ __device__ __forceinline__ void dH_partial_body128(const float *__restrict__ X, 
 // ------------------------------------------------------------------------------------------
 constexpr int DH_D = 128;                               // tile edge of the register-resident form
 // columns per lane of the 256-register form (t128 == 3) for an output width: 128 x 64 tiles, or 128 x 32 ones when out is an
-// odd multiple of 32; any other width (a multiple of 4) takes 128 x 64 tiles with a partial last one
-__host__ __device__ inline int dh3_np(int out) { return out % 64 == 0 ? 2 : (out % 32 == 0 ? 1 : 2); }
+// odd multiple of 32; any other EVEN width takes 128 x 64 tiles with a partial last one (two columns of dy per lane: 8-byte loads), an
+// ODD width 128 x 32 tiles (one column per lane)
+__host__ __device__ inline int dh3_np(int out) { return out % 64 == 0 ? 2 : ((out % 32 == 0 || out % 2 != 0) ? 1 : 2); }
 #ifndef PHC_DH_PF
 #define PHC_DH_PF 4
 #endif

@@ -1682,11 +1682,14 @@ struct GradPlan {
 
 // register-resident tile form (dH_direct_body): float4-addressable operands; widths that are not multiples of the tile end in a
 // partial tile (form 2: 128 x 128 tiles; form 3: 128 x 64, or 128 x 32 when out is an odd multiple of 32 — dh3_np)
-static inline bool dh_use_direct(const phc_phm_grad_job &jb) {
+// (form 3 reads dy two columns per lane, or one when the width is odd: any width — the 200 -> 50 gate map of the published 2 x 200
+// model, which as 848 LDS-tile workgroups held the tail's slots for 20 us of its 130 (scripts/dbg/tail_wg_timeline.py), the 180 -> 45
+// one of the 4 x 180 model; form 2 reads four per lane)
+static inline bool dh_use_direct(const phc_phm_grad_job &jb, int form = 2) {
     constexpr bool off = false;
     const int in = jb.n * jb.kin, out = jb.n * jb.kout;
     if ((int64_t)(in > out ? in : out) * 4 * (jb.N / 256 + 128) >= ((int64_t)1 << 31)) return false;    // 32-bit offsets per wavefront
-    return !off && in % 4 == 0 && out % 4 == 0 && in >= 96 && out >= 32 && jb.N >= 8 && (reinterpret_cast<uintptr_t>(jb.x) & 15) == 0 &&
+    return !off && in % 4 == 0 && (form == 3 || out % 4 == 0) && in >= 96 && out >= 32 && jb.N >= 8 && (reinterpret_cast<uintptr_t>(jb.x) & 15) == 0 &&
            (reinterpret_cast<uintptr_t>(jb.dy) & 15) == 0 &&
            (!jb.xf_stat || ((reinterpret_cast<uintptr_t>(jb.xf_stat) & 15) == 0 &&
                             (jb.xf_act == PHC_ACT_IDENTITY || jb.xf_act == PHC_ACT_RELU)));
@@ -1702,7 +1705,7 @@ static void grad_plans(const phc_phm_grad_job *jobs, int num, GradPlan *plans, i
     int64_t total = 0, direct_rows = 0;
     for (int k = 0; k < num; ++k) {
         const int in = jobs[k].n * jobs[k].kin, out = jobs[k].n * jobs[k].kout;
-        plans[k].t128 = dh_use_direct(jobs[k]) ? direct_form : (dh_use_128(jobs[k].N, in, out) ? 1 : 0);
+        plans[k].t128 = dh_use_direct(jobs[k], direct_form) ? direct_form : (dh_use_128(jobs[k].N, in, out) ? 1 : 0);
         plans[k].pair = 1;
         const int T = plans[k].t128 ? DH_T2 : DH_T;
         plans[k].tiles_i = (in + T - 1) / T;
