@@ -17,3 +17,10 @@ done
 python bench.py --workload synth_10m50m --steps 10 --warmup 2 2>&1 | tail -1 > gpurun_out/r06_bench_synth_10m50m_1gpu.json
 python bench.py --workload synth_10m50m --layers 4 --steps 5 --warmup 2 2>&1 | tail -1 > gpurun_out/r06_bench_synth_10m50m_4layers_1gpu.json
 cut -c1-200 gpurun_out/r06_bench_default.json
+# every workgroup of the step tail's first launch against one clock (the -DPHC_TAIL_STAMPS variant: python -m phc_gnn_amd.build --variant tailstamps -DPHC_TAIL_STAMPS)
+if [ -f scripts/exp/variants/libphc_hip_tailstamps.so ]; then
+  for wl in molhiv_b512 molhiv_pub_phc4_2x200 zinc_b1024; do
+    PHC_DEBUG_PLANS=1 PHC_LIB_PATH=$GRAFT_REPO_ROOT/scripts/exp/variants/libphc_hip_tailstamps.so python scripts/dbg/tail_wg_timeline.py $wl 2>&1 | grep -v "amdgpu.ids" | awk '!seen[$0]++'
+    echo
+  done > gpurun_out/r06_tail_wg_timeline.txt
+fi
