@@ -914,7 +914,10 @@ __device__ __forceinline__ void atom_direct_body(const float *__restrict__ dout,
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[q][p2][i] = 0.f;
     const long long last = max(t_end - 1, 0LL);
-    const unsigned goff = (unsigned)(j0 + 2 * r) * 4u;
+    // (h need not be a multiple of 64 — the published 180 / 200-wide models: a lane whose two columns lie past the row reads the
+    // tile's first columns instead, in bounds, and stores nothing; h is even, a pair never straddles the end)
+    const bool clive = j0 + 2 * r < h;
+    const unsigned goff = (unsigned)(clive ? j0 + 2 * r : j0) * 4u;
     f32x2 ga[TD_PFA], gb[TD_PFA];
     int ia[TD_PFA][TD_MB], ib[TD_PFA][TD_MB];
     auto load = [&](f32x2 (&G)[TD_PFA], int (&I)[TD_PFA][TD_MB], long long row0) {
@@ -977,7 +980,7 @@ __device__ __forceinline__ void atom_direct_body(const float *__restrict__ dout,
         for (int e = 0; e < 4; ++e) {
             const f32x2 v = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
             const int row = r0 + 32 * q + e + 8 * wave + 4 * hh;            // reg = 4 wave + e
-            if (row < m.R) *reinterpret_cast<f32x2 *>(slab + (size_t)row * h + j0 + 2 * r) = v;
+            if (row < m.R && clive) *reinterpret_cast<f32x2 *>(slab + (size_t)row * h + j0 + 2 * r) = v;
         }
     }
 }
@@ -1108,7 +1111,10 @@ __device__ __forceinline__ void bond_direct_body(const TgBatch &jobs, int job0, 
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[u][p2][i] = 0.f;
     const long long last = max(t_end - 1, 0LL);
-    const unsigned goff = (unsigned)(j0 + 2 * r) * 4u;
+    // (h need not be a multiple of 64 — the published 180 / 200-wide models: a lane whose two columns lie past the row reads the
+    // tile's first columns instead, in bounds, and stores nothing; h is even, a pair never straddles the end)
+    const bool clive = j0 + 2 * r < h;
+    const unsigned goff = (unsigned)(clive ? j0 + 2 * r : j0) * 4u;
     const bool ccol = r < CR;
     const int cr = ccol ? r : 0;
     float ca[TD_PFB], cb[TD_PFB];
@@ -1168,7 +1174,7 @@ __device__ __forceinline__ void bond_direct_body(const TgBatch &jobs, int job0, 
             for (int e = 0; e < 4; ++e) {
                 const f32x2 v = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
                 const int row = e + 8 * wave + 4 * hh;
-                if (row < R) *reinterpret_cast<f32x2 *>(slab + (size_t)row * h + j0 + 2 * r) = v;
+                if (row < R && clive) *reinterpret_cast<f32x2 *>(slab + (size_t)row * h + j0 + 2 * r) = v;
             }
         }
     }
@@ -1204,7 +1210,10 @@ __device__ __forceinline__ void enc_direct_body(const TgBatch &jobs, int job0, i
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[u][p2][i] = 0.f;
     const long long last = max(t_end - 1, 0LL);
-    const unsigned goff = (unsigned)(j0 + 2 * r) * 4u;
+    // (h need not be a multiple of 64 — the published 180 / 200-wide models: a lane whose two columns lie past the row reads the
+    // tile's first columns instead, in bounds, and stores nothing; h is even, a pair never straddles the end)
+    const bool clive = j0 + 2 * r < h;
+    const unsigned goff = (unsigned)(clive ? j0 + 2 * r : j0) * 4u;
     int ia[TD_PFB], ib[TD_PFB];
     f32x2 ga[TD_PFB][TD_JG], gb[TD_PFB][TD_JG];
     auto load = [&](int (&I)[TD_PFB], f32x2 (&G)[TD_PFB][TD_JG], long long row0) {
@@ -1262,7 +1271,7 @@ __device__ __forceinline__ void enc_direct_body(const TgBatch &jobs, int job0, i
             for (int e = 0; e < 4; ++e) {
                 const f32x2 v = ((part[0][e] + part[1][e]) + part[2][e]) + part[3][e];
                 const int row = e + 8 * wave + 4 * hh;
-                if (row < R) *reinterpret_cast<f32x2 *>(slab + (size_t)row * h + j0 + 2 * r) = v;
+                if (row < R && clive) *reinterpret_cast<f32x2 *>(slab + (size_t)row * h + j0 + 2 * r) = v;
             }
         }
     }
@@ -1476,13 +1485,13 @@ struct TgPlan {
 // workgroups, every split the same number of nodes (a multiple of 8: four wavefront quarters starting on even nodes)
 static bool tg_direct_shape_ok(long long n_items, int h) {
     constexpr bool off = false;
-    return !off && h % 64 == 0 && n_items >= 8;
+    return !off && h % 2 == 0 && h >= 32 && n_items >= 8;  // (64-column tiles, the last one partial; rows of dout 8-byte aligned)
 }
 constexpr long long TG_DIRECT_TARGET = 256;              // workgroups of a register-resident table family on its own
 static TgPlan tg_plan_direct(long long n_items, int R, int h, long long target = TG_DIRECT_TARGET) {
     TgPlan p;
     p.tiles_i = (R + 32 * TD_MB - 1) / (32 * TD_MB);
-    p.tiles_j = h / 64;
+    p.tiles_j = (h + 63) / 64;
     const long long tiles = (long long)p.tiles_i * p.tiles_j;
     long long ips = ((n_items * tiles + target - 1) / target + 7) / 8 * 8;
     if (ips < 8) ips = 8;
@@ -1499,7 +1508,7 @@ static TgPlan tg_plan_direct(long long n_items, int R, int h, long long target =
 static TgPlan tg_plan_direct_bond(long long n_items, int R, int h, int jobs, long long target = TG_DIRECT_TARGET) {
     TgPlan p;
     p.tiles_i = (jobs + TD_JG - 1) / TD_JG;                  // layer groups
-    p.tiles_j = h / 64;
+    p.tiles_j = (h + 63) / 64;
     const long long tiles = (long long)p.tiles_i * p.tiles_j;
     long long ips = ((n_items * tiles + target - 1) / target + 7) / 8 * 8;
     if (ips < 8) ips = 8;
@@ -2257,8 +2266,8 @@ static TailShares tail_shares(const phc_phm_grad_job *jobs, int num_jobs, int bo
                               bool eligible) {
     TailShares sh = {TG_DIRECT_TARGET, TG_DIRECT_TARGET, 512};
     if (!eligible || N_atoms <= 0) return sh;
-    const double w_a = 0.085 * (double)N_atoms * ((R_a + 32 * TD_MB - 1) / (32 * TD_MB)) * (h / 64);
-    const double w_b = 0.03 * (double)bond_n_dst * (h / 64) * bond_jobs;
+    const double w_a = 0.085 * (double)N_atoms * ((R_a + 32 * TD_MB - 1) / (32 * TD_MB)) * ((h + 63) / 64);
+    const double w_b = 0.03 * (double)bond_n_dst * ((h + 63) / 64) * bond_jobs;
     double w_d = 0.0;
     for (int q = 0; q < num_jobs; ++q) {
         const int in = jobs[q].n * jobs[q].kin, out = jobs[q].n * jobs[q].kout;
