@@ -839,17 +839,19 @@ int phc_bn_bwd_from_partials(const float *dy, const float *x, const float *save_
 /* The step's tail in one pass: every parameter gradient of a model — PHM / dense layers (jobs, as for
  * phc_phm_param_grads; <= 16), the bond tables of all message-passing layers
  * (tjobs, as for phc_table_grads_batched; <= 8) and the atom-encoder tables (atom_*, as phc_encode_bwd; N_atoms
- * = 0: none) — in three launches.  The first runs the latency-bound table-slab workgroups and the MFMA-bound
- * dH-slab workgroups SIDE BY SIDE (the former dispatched first, into the slots the latter leave free), the
- * second all slab reductions, the third the PHM contraction.  Results are identical to the separate entry
+ * = 0: none) — in three launches.  The first runs the table-slab workgroups and the MFMA-bound dH-slab workgroups
+ * in ONE grid of 512 resident slots: the table families in front where they are a small part of the launch's work,
+ * every family on its share of the slots from the start where the tables are a quarter of it or more (hidden 128;
+ * round 6); the second all slab reductions, the third the PHM contraction.  Results are identical to the separate entry
  * points (same workgroup bodies, same fixed summation order).  Layers of 256 columns and more (round 4) ride in the
- * first launch as register-resident 128 x 64 tiles when their operand form allows it (widths multiples of 4, a plain
- * or relu-normalised operand); the rest of them take one more launch of 128 x 128 LDS tiles in front.
+ * first launch as register-resident 128 x 64 tiles (128 x 32 for an odd output width) when their operand form allows
+ * it (input width a multiple of 4, output width >= 32, a plain or relu-normalised operand); the rest of them take one
+ * more launch of 128 x 128 LDS tiles in front.
  * Bond tables: bond_n_dst > 0 selects the counted form of phc_table_grads_counted (bond_rowptr / bond_codes, act
  * must be identity; bond_i64 / edge_* may be NULL), bond_n_dst = 0 the per-edge form of phc_table_grads_batched.
  * bond_counts (optional, counted form only): the code_counts of phc_csr_build_pair_codes — the bond tables then take
  * the register-resident form (dT = counts^T . dout straight from global memory, all layers of a group sharing the
- * counts operand); the atom tables take theirs whenever h % 64 == 0. */
+ * counts operand); the atom tables take theirs whenever h is even and >= 32 (64-column tiles, the last one partial). */
 size_t phc_step_tail_ws_bytes(const phc_phm_grad_job *jobs, int num_jobs, int num_tjobs, int64_t E, int64_t bond_n_dst,
                               int F_b, const int32_t *vocab_b, int64_t N_atoms, int F_a, const int32_t *vocab_a, int n,
                               int k);
