@@ -2265,6 +2265,14 @@ struct TailShares {
 static TailShares tail_shares(const phc_phm_grad_job *jobs, int num_jobs, int bond_jobs, int64_t bond_n_dst, int64_t N_atoms, int R_a, int h,
                               bool eligible) {
     TailShares sh = {TG_DIRECT_TARGET, TG_DIRECT_TARGET, 512};
+#ifdef PHC_TAIL_KNOBS
+    // experiment build only: PHC_TAIL_SHARES="atoms,bonds,dH" overrides the rule (scripts/dbg/tail_shares_trace.sh)
+    if (const char *e = getenv("PHC_TAIL_SHARES")) {
+        long long a = 0, b = 0;
+        int d = 0;
+        if (sscanf(e, "%lld,%lld,%d", &a, &b, &d) == 3 && eligible) return TailShares{a, b, d};
+    }
+#endif
     if (!eligible || N_atoms <= 0) return sh;
     const double w_a = 0.085 * (double)N_atoms * ((R_a + 32 * TD_MB - 1) / (32 * TD_MB)) * ((h + 63) / 64);
     const double w_b = 0.03 * (double)bond_n_dst * ((h + 63) / 64) * bond_jobs;
