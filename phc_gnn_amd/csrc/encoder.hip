@@ -2252,8 +2252,8 @@ int phc_step_tail_ex(const phc_phm_grad_job *jobs, int num_jobs, const phc_table
 // The launch's 512 workgroup slots (two per CU) among its three families.  The table families' workgroups are latency-bound AND use the
 // matrix pipes (one-hot operands); with 256 workgroups each they fill every slot for the first 20 us of the molecule step's tail and the
 // dH family starts behind them (scripts/dbg/tail_wg_timeline.py: 252 + 244 table workgroups of 19 us, then 465 dH workgroups of 38 us —
-// 64 us for 27 000 workgroup-us of work, 53 us if the slots were full throughout).  Where the tables are a quarter or more of the
-// launch's work, every family gets slots in proportion to its work and all of them run from start to end: fewer, longer table
+// 64 us for 27 000 workgroup-us of work, 53 us if the slots were full throughout).  Where the tables are a fifth or more of the
+// launch's work (a fifth: see the threshold below), every family gets slots in proportion to its work and all of them run from start to end: fewer, longer table
 // workgroups (fewer slabs to reduce), the dH family planned for the slots that are left.  Measured (round 6, alternating runs on one
 // box): molhiv_b512 0.4986 -> 0.4842 ms and 0.4951 -> 0.4869; at hidden 256 the tables are a sixth of the work and the same rule costs
 // 15 - 40 us (their matrix work slows the co-resident dH workgroups for the whole launch instead of for its first 60 us): unchanged
@@ -2282,7 +2282,7 @@ static TailShares tail_shares(const phc_phm_grad_job *jobs, int num_jobs, int bo
         if (in % 4 == 0 && in >= 96 && out >= 32) w_d += 0.075 * (double)jobs[q].N * ((in + 127) / 128) * ((out + 63) / 64);
     }
     const double W = w_a + w_b + w_d;
-    if (w_d <= 0.0 || (w_a + w_b) < 0.25 * W) return sh;
+    if (w_d <= 0.0 || (w_a + w_b) < 0.20 * W) return sh;  // (softmax layers at hidden 128 — atom tables only, 21 % — gain 15 - 20 us; 2 x 200's 18 % nothing)
     auto share = [&](double w) { long long v = (long long)(0.85 * 512.0 * w / W / 8.0 + 0.5) * 8; return v < 32 ? 32LL : (v > 256 ? 256LL : v); };
     sh.target_a = share(w_a);
     sh.target_b = bond_jobs > 0 ? share(w_b) : 0;
