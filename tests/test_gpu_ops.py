@@ -1145,12 +1145,17 @@ def test_bn_act_linear_without_materialising_the_normalised_activation(ops, n, k
         assert_close(u, v, 3e-5, name)
 
 
-@pytest.mark.parametrize("N,k,vocab_b,n_layers", [(777, 16, [12, 9, 7], 5), (1203, 32, [5, 6, 2], 2), (64, 16, [3], 1)])
+@pytest.mark.parametrize("N,k,vocab_b,n_layers", [(777, 16, [12, 9, 7], 5), (1203, 32, [5, 6, 2], 2), (64, 16, [3], 1),
+                                                  # round 6: widths that are no multiple of 64 (the published 180 / 200-wide models: 64-column
+                                                  # tiles with a partial last one), a width below one tile
+                                                  (501, 45, [5, 6, 2], 2), (333, 50, [12, 9, 7], 5), (200, 10, [3], 1)])
 def test_step_tail_register_resident_table_gradients(ops, N, k, vocab_b, n_layers):
     """phc_step_tail with the encoder tables in their register-resident forms (atom_direct_body / bond_direct_body): widths of 64
     and 128 columns, 28 bond-table rows (32-column count operand) and 13 (16 columns), five layers (a full group of four and a
     short one), 180 atom-table rows (two M groups), node counts that are no multiple of anything — against the immediate
-    per-layer gradients (LDS tiles)."""
+    per-layer gradients (LDS tiles).  The PHM jobs beside them: h -> h, and two dense maps of an even and an odd output width
+    (h -> 50, h -> 45: the register-resident dH tiles with two columns / one column of dy per lane, the gate maps of the published
+    models) where the input width allows the form."""
     from phc_gnn_amd import synth
     g = torch.Generator().manual_seed(N)
     n = 4
@@ -1168,16 +1173,22 @@ def test_step_tail_register_resident_table_gradients(ops, N, k, vocab_b, n_layer
     A = torch.randn(n, n, n, generator=g).to(DEV).requires_grad_()
     W = (torch.randn(n, k, k, generator=g) * 0.2).to(DEV).requires_grad_()
     dy_lin = torch.randn(N, h, generator=g).to(DEV)
+    one = torch.ones(1, 1, 1, device=DEV)
+    dense = [((torch.randn(1, h, o, generator=g) * 0.1).to(DEV).requires_grad_(), torch.randn(o, generator=g).to(DEV).requires_grad_(),
+              torch.randn(N, o, generator=g).to(DEV)) for o in (50, 45)]
     owners = [torch.nn.Module() for _ in range(n_layers + 1)]
 
     def run(deferred):
-        every = [t for comp in tabs_a for t in comp] + [t for tabs, _ in layers for comp in tabs for t in comp] + [A, W]
+        every = [t for comp in tabs_a for t in comp] + [t for tabs, _ in layers for comp in tabs for t in comp] + [A, W] + \
+                [t for Wd, bd, _ in dense for t in (Wd, bd)]
         for t in every:
             t.grad = None
         ctx = ops.deferred_param_grads() if deferred else __import__("contextlib").nullcontext()
         with ctx:
             x0 = ops.encode(idx_a, ops.tableset_for(owners[-1], tabs_a), tabs_a)
             total = (ops.phm_linear(x0, A, W, None) * dy_lin).sum()                # a PHM job: the tail has something to batch
+            for Wd, bd, dyd in dense:
+                total = total + (ops.phm_linear(x0, one, Wd, bd) * dyd).sum()
             x = x0
             for (tabs, dy), owner in zip(layers, owners):
                 out = ops.aggregate_sum_encoded(x, ei, bond, ops.tableset_for(owner, tabs), tabs, "identity", True)
